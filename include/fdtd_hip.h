@@ -1,0 +1,152 @@
+/* fdtd_hip.h — C ABI of libfdtd_hip.so, the MI355X (gfx950) FDTD time-stepper.
+ *
+ * This is the drop-in boundary of the hot path.  The reference
+ * (flexcompute/tidy3d) has NO native interface for this path: its solver is a closed cloud
+ * service reached through  tidy3d/web/api/webapi.py:49 run() -> :159 upload() -> :266 start()
+ * -> :337 monitor() -> :631 load().  The functions below are what a local replacement of that
+ * upload/start/monitor/load sequence binds through ctypes:
+ *
+ *   upload  (webapi.py:159, hdf5 of the Simulation)      -> fdtd_create + fdtd_set_* / fdtd_add_*
+ *   start + monitor (webapi.py:266,:337; progress =
+ *        (perc_done, field_decay), task_core.py:537)     -> fdtd_run + FdtdProgressFn
+ *   load    (webapi.py:631, hdf5 of the monitor data)    -> fdtd_get_monitor / fdtd_get_field
+ *   task status "diverged" (webapi.py:370)               -> FdtdStats.diverged
+ *
+ * Conventions
+ *  - plain C; every function returns 0 on success, <0 on error; the message is available from
+ *    fdtd_last_error() (thread-local for create, per-handle otherwise).
+ *  - the caller owns every host buffer before and after a call (the library copies in/out
+ *    synchronously); the library owns all device memory, streams and RCCL communicators.
+ *  - one handle = one solve on one GPU (one z-slab of the domain in a multi-GPU run); calls on
+ *    a handle are not re-entrant and must come from one host thread.
+ *  - field arrays are [nz][ny][nx] C-ordered, x fastest, fp32 (ref monitor.py:35-36: 4 B real /
+ *    8 B complex).  Yee staggering as in ref components/grid/grid.py:465-491.
+ *  - component ids: 0..5 = Ex,Ey,Ez,Hx,Hy,Hz.
+ */
+#ifndef FDTD_HIP_H
+#define FDTD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct FdtdSolver FdtdSolver;
+
+enum { FDTD_BC_PEC = 0, FDTD_BC_PMC = 1, FDTD_BC_PERIODIC = 2, FDTD_BC_NEIGHBOR = 3 };
+enum { FDTD_MON_TIME = 0, FDTD_MON_DFT = 1 };
+/* kernel variants of the two main update kernels (A/B-tested by bench.py --variant) */
+enum { FDTD_VARIANT_AUTO = 0, FDTD_VARIANT_SIMPLE = 1, FDTD_VARIANT_ZMARCH = 2, FDTD_VARIANT_LDS = 3 };
+enum { FDTD_FLAG_TIME_KERNELS = 1 };   /* bracket every main-kernel launch with hipEvents */
+
+typedef struct FdtdConfig {
+  int32_t nx, ny, nz;      /* cells of THIS rank's slab (PML cells included)                    */
+  int32_t bc[6];           /* xmin,xmax,ymin,ymax,zmin,zmax: FDTD_BC_*; NEIGHBOR only on z faces */
+  int32_t device;          /* HIP device ordinal                                                */
+  int32_t variant;         /* FDTD_VARIANT_*                                                    */
+  int32_t flags;           /* FDTD_FLAG_*                                                       */
+  int32_t z_chunk;         /* planes marched per workgroup (0 = default)                        */
+  float   ch;              /* dt / mu0: H-update coefficient                                    */
+  int32_t reserved[6];
+} FdtdConfig;
+
+typedef struct FdtdStats {
+  int64_t steps_done;
+  int32_t diverged;          /* NaN/Inf seen in the field-energy reduction                       */
+  int32_t stopped_early;     /* shutoff reached                                                  */
+  double  field_decay;       /* last  sum|E|^2 / max sum|E|^2                                    */
+  double  run_ms;            /* hipEvent time of the last fdtd_run (whole step loop)             */
+  double  h_kernel_ms;       /* with FDTD_FLAG_TIME_KERNELS: summed durations of the main H ...  */
+  double  e_kernel_ms;       /* ... and E update kernels in the last fdtd_run                    */
+  int64_t h_kernel_launches;
+  int64_t e_kernel_launches;
+  int64_t device_bytes;      /* device memory held by the handle                                 */
+} FdtdStats;
+
+/* progress callback: (step, time [s], field_decay) -> non-zero aborts the run (Ctrl-C path).
+ * Mirrors the (perc_done, field_decay) pair the cloud reports (ref web/core/task_core.py:537). */
+typedef int (*FdtdProgressFn)(int64_t step, double time, double field_decay, void* user);
+
+const char* fdtd_last_error(const FdtdSolver* h);   /* h may be NULL: error of the last create */
+int  fdtd_device_count(void);
+
+int  fdtd_create(const FdtdConfig* cfg, FdtdSolver** out);
+void fdtd_destroy(FdtdSolver* h);
+
+/* 1/primal and 1/dual step vectors of one axis (length = n cells of that axis of this slab;
+ * ref grid.py:393-417).  axis 0,1,2 = x,y,z. */
+int fdtd_set_steps(FdtdSolver* h, int axis, const float* inv_primal, const float* inv_dual, int n);
+
+/* material table (index 0 = PEC: ca = cb = 0) and, optionally, the staircased material index
+ * volumes mat[3][nz][ny][nx] (uint8, one per E component, ref simulation.py:1135-1241).
+ * Without fdtd_set_material every cell uses entry 1. */
+int fdtd_set_media(FdtdSolver* h, const float* ca, const float* cb, int n_media);
+int fdtd_set_material(FdtdSolver* h, const uint8_t* mat, size_t bytes);
+
+/* CPML tables of one axis, each of length n (identity outside the slabs); [i_lo_e, ...) ranges
+ * are derived from n_lo/n_hi (ref boundary.py:195-254; formulas in tidy3d_amd/coeffs.py).
+ * z_offset: global z index of this slab's plane 0 is only needed by the host to slice the
+ * tables, the library sees slab-local tables. */
+int fdtd_set_pml(FdtdSolver* h, int axis, int n_lo, int n_hi,
+                 const float* kinv_e, const float* b_e, const float* c_e,
+                 const float* kinv_h, const float* b_h, const float* c_h, int n);
+
+/* pole-residue ADE group: the cells (linear index k*ny*nx + j*nx + i within the slab) of E
+ * component `comp` filled with one dispersive medium; kap/bet are n_poles complex pairs
+ * (re,im interleaved), cc the memory-term coefficient (ref medium.py:2900-2913). */
+int fdtd_add_ade(FdtdSolver* h, int comp, int64_t n_cells, const uint32_t* cell_index,
+                 int n_poles, const float* kap, const float* bet, float cc);
+
+/* current source: F[comp[p]][index[p]] += w_re[p]*Re(wave[n]) - w_im[p]*Im(wave[n]);
+ * E components use wave_e (sampled at t_n + dt/2), H components wave_h (t_n);
+ * waves are n_steps complex values (re,im interleaved)  (ref source.py:174-193, :543-632). */
+int fdtd_add_point_source(FdtdSolver* h, int64_t n_points, const int32_t* comp,
+                          const uint32_t* cell_index, const float* w_re, const float* w_im,
+                          int64_t n_steps, const float* wave_e, const float* wave_h);
+
+/* total-field/scattered-field source driven by a 1-D auxiliary grid (ref source.py:1204-1257);
+ * semantics documented at tidy3d_amd/spec.py TfsfSpec.  aux indices refer to e1 (h_corr) and
+ * h1 (e_corr). */
+int fdtd_add_tfsf(FdtdSolver* h, int n_aux, const float* ip1, const float* id1,
+                  float ch1, float ce1, float mur0, float mur1, int src_cell,
+                  int64_t n_steps, const float* wave,
+                  int64_t n_e, const int32_t* e_comp, const uint32_t* e_index, const float* e_w,
+                  const int32_t* e_aux,
+                  int64_t n_h, const int32_t* h_comp, const uint32_t* h_index, const float* h_w,
+                  const int32_t* h_aux);
+
+/* monitor over the Yee index box [lo, hi) of this slab.  steps: sorted time-step indices on
+ * which it records.  DFT monitors: nf frequencies and phase tables [n_rec][nf] complex
+ * (re,im interleaved) for E (t_n) and H (t_n + dt/2) samples (ref monitor.py:363-403,
+ * time.py:95-105).  Returns the monitor id (>= 0) or <0. */
+int fdtd_add_monitor(FdtdSolver* h, int kind, int n_comps, const int32_t* comps,
+                     const int32_t lo[3], const int32_t hi[3],
+                     int64_t n_rec, const int64_t* steps,
+                     int nf, const float* phase_e, const float* phase_h);
+/* time: float [n_rec][n_comps][bz][by][bx];  dft: complex64 [nf][n_comps][bz][by][bx] */
+int fdtd_get_monitor(FdtdSolver* h, int monitor_id, void* host, size_t bytes);
+
+int fdtd_set_field(FdtdSolver* h, int comp, const float* host, size_t bytes);
+int fdtd_get_field(FdtdSolver* h, int comp, float* host, size_t bytes);
+
+/* field-decay / shutoff: evaluate sum|E|^2 every `every` steps; stop when it falls below
+ * shutoff * max after step `ref_step` (ref simulation.py:2089-2096). every = 0 disables. */
+int fdtd_set_shutoff(FdtdSolver* h, int every, double shutoff, int64_t ref_step);
+
+/* z-slab decomposition over RCCL (one process per GPU).  Rank 0 creates the id, the host
+ * broadcasts it (torch.distributed), every rank calls fdtd_comm_init.  Faces with
+ * FDTD_BC_NEIGHBOR exchange ghost planes with rank-1 / rank+1 (periodic z wraps). */
+int fdtd_comm_unique_id(char id[128]);
+int fdtd_comm_init(FdtdSolver* h, const char id[128], int rank, int n_ranks);
+
+/* advance n_steps time steps starting at the handle's current step counter. */
+int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user);
+int fdtd_get_stats(FdtdSolver* h, FdtdStats* out);
+int fdtd_reset(FdtdSolver* h);      /* zero fields, auxiliaries, monitors and the step counter */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDTD_HIP_H */

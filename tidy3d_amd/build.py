@@ -1,0 +1,38 @@
+"""Build libfdtd_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build()."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libfdtd_hip.so")
+SOURCES = [os.path.join(CSRC, "fdtd_capi.hip")]
+DEPS = SOURCES + [os.path.join(CSRC, "fdtd_kernels.hpp"),
+                  os.path.join(HERE, "..", "include", "fdtd_hip.h")]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not needs_build():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value", "-I/opt/rocm/include",
+           *SOURCES, "-o", LIB, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,934 @@
+// libfdtd_hip.so — host side of the C ABI declared in include/fdtd_hip.h.
+// Owns device memory, HIP streams/events and the RCCL communicator of one z-slab solver.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fdtd_hip.h"
+#include "fdtd_kernels.hpp"
+
+using namespace fdtd;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct PmlAxisDev {
+  int n_lo = 0, n_hi = 0, n = 0;
+  float *kinv_e = nullptr, *b_e = nullptr, *c_e = nullptr, *kinv_h = nullptr, *b_h = nullptr, *c_h = nullptr;
+  // psi arrays: [side E/H][comp slot 0/1]
+  float* psi_e[2] = {nullptr, nullptr};
+  float* psi_h[2] = {nullptr, nullptr};
+  int ns_e = 0, ns_h = 0;          // slab extents along the axis (lo + hi entries)
+};
+
+struct AdeGroup {
+  int comp;
+  long long n;
+  uint32_t* cell;
+  float* e_old;
+  float2* q;
+  AdeP p;
+};
+
+struct PointSrc {
+  long long n_e = 0, n_h = 0;      // points split by E / H components
+  int32_t *comp_e = nullptr, *comp_h = nullptr;
+  uint32_t *cell_e = nullptr, *cell_h = nullptr;
+  float *wre_e = nullptr, *wim_e = nullptr, *wre_h = nullptr, *wim_h = nullptr;
+  float2 *wave_e = nullptr, *wave_h = nullptr;
+  long long n_steps = 0;
+};
+
+struct Tfsf {
+  int n_aux = 0, src_cell = 0;
+  float ch1 = 0, ce1 = 0, mur0 = 0, mur1 = 0;
+  float *ip1 = nullptr, *id1 = nullptr, *e1 = nullptr, *h1 = nullptr, *wave = nullptr;
+  long long n_steps = 0;
+  long long n_e = 0, n_h = 0;
+  int32_t *e_comp = nullptr, *h_comp = nullptr, *e_aux = nullptr, *h_aux = nullptr;
+  uint32_t *e_cell = nullptr, *h_cell = nullptr;
+  float *e_w = nullptr, *h_w = nullptr;
+};
+
+struct Monitor {
+  int kind = 0;
+  std::vector<int> comps;
+  BoxP box{};
+  std::vector<long long> steps;
+  size_t next = 0;                 // next entry of `steps` to record
+  int nf = 0;
+  float2 *phase_e = nullptr, *phase_h = nullptr;   // [n_rec][nf]
+  void* data = nullptr;
+  size_t data_bytes = 0;
+  long long cells = 0;
+};
+
+}  // namespace
+
+struct FdtdSolver {
+  FdtdConfig cfg{};
+  GridP g{};
+  std::string err;
+  std::vector<DevBuf> bufs;          // everything hipMalloc'ed (freed in destroy)
+  float* fbase[6] = {};              // allocation base (ghost plane -1)
+  FieldP f{};                        // interior plane 0
+  size_t field_bytes = 0;
+  float *ip[3] = {}, *idl[3] = {};
+  uint8_t* mat[3] = {};
+  float2* lut = nullptr;
+  int n_media = 0;
+  float ca1 = 1.f, cb1 = 0.f;
+  std::vector<float> cb_host;
+  PmlAxisDev pml[3];
+  std::vector<AdeGroup> ade;
+  std::vector<PointSrc> psrc;
+  std::vector<Tfsf> tfsf;
+  std::vector<Monitor> mons;
+  hipStream_t stream = nullptr, comm_stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> kev;       // per-launch timing events (FDTD_FLAG_TIME_KERNELS)
+  std::vector<int> kev_kind;
+  double* energy_dev = nullptr;
+  int decay_every = 0;
+  double shutoff = 0.0;
+  long long decay_ref = 0;
+  double energy_max = 0.0;
+  long long step = 0;
+  FdtdStats stats{};
+  int zchunk = 32;
+  int rows = 4;
+  // RCCL
+  ncclComm_t comm = nullptr;
+  int rank = 0, n_ranks = 1;
+  hipEvent_t ev_h_int = nullptr, ev_h_bnd = nullptr, ev_e_int = nullptr, ev_e_bnd = nullptr;
+};
+
+namespace {
+
+int fail(FdtdSolver* h, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf; else g_create_error = buf;
+  return -1;
+}
+
+#define HIPCHK(h, call)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(h, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+#define NCCLCHK(h, call)                                                                  \
+  do {                                                                                    \
+    ncclResult_t r_ = (call);                                                             \
+    if (r_ != ncclSuccess)                                                                \
+      return fail(h, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__, __LINE__); \
+  } while (0)
+
+template <typename T>
+int dev_alloc(FdtdSolver* h, T** out, size_t count, bool zero_fill = true) {
+  void* p = nullptr;
+  size_t bytes = count * sizeof(T);
+  if (bytes == 0) bytes = sizeof(T);
+  HIPCHK(h, hipMalloc(&p, bytes));
+  if (zero_fill) HIPCHK(h, hipMemset(p, 0, bytes));
+  h->bufs.push_back({p, bytes});
+  h->stats.device_bytes += (int64_t)bytes;
+  *out = reinterpret_cast<T*>(p);
+  return 0;
+}
+
+template <typename T>
+int dev_upload(FdtdSolver* h, T** out, const T* host, size_t count) {
+  if (dev_alloc(h, out, count, false)) return -1;
+  if (count) HIPCHK(h, hipMemcpy(*out, host, count * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+inline unsigned nblk(long long n, int b = 256) { return (unsigned)((n + b - 1) / b); }
+
+long long plane_cells(const FdtdSolver* h) { return (long long)h->cfg.nx * h->cfg.ny; }
+long long n_cells(const FdtdSolver* h) { return plane_cells(h) * h->cfg.nz; }
+
+float* field_ptr(FdtdSolver* h, int comp) {
+  switch (comp) {
+    case 0: return h->f.ex; case 1: return h->f.ey; case 2: return h->f.ez;
+    case 3: return h->f.hx; case 4: return h->f.hy; default: return h->f.hz;
+  }
+}
+
+StepP step_params(const FdtdSolver* h) {
+  StepP s;
+  s.ipx = h->ip[0]; s.ipy = h->ip[1]; s.ipz = h->ip[2];
+  s.idx = h->idl[0]; s.idy = h->idl[1]; s.idz = h->idl[2];
+  return s;
+}
+
+MatP mat_params(const FdtdSolver* h) {
+  MatP m;
+  m.mx = h->mat[0]; m.my = h->mat[1]; m.mz = h->mat[2];
+  m.lut = h->lut; m.n_media = h->n_media; m.ca1 = h->ca1; m.cb1 = h->cb1;
+  return m;
+}
+
+// ---- timing of the main kernels -----------------------------------------------------------
+void time_begin(FdtdSolver* h, int kind, hipStream_t st) {
+  if (!(h->cfg.flags & FDTD_FLAG_TIME_KERNELS)) return;
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  hipEventRecord(a, st);
+  h->kev.push_back(a);
+  h->kev.push_back(b);
+  h->kev_kind.push_back(kind);
+}
+void time_end(FdtdSolver* h, hipStream_t st) {
+  if (!(h->cfg.flags & FDTD_FLAG_TIME_KERNELS)) return;
+  hipEventRecord(h->kev.back(), st);
+}
+
+// ---- launches -------------------------------------------------------------------------------
+void launch_h_main(FdtdSolver* h, int kbeg, int kend, hipStream_t st) {
+  if (kend <= kbeg) return;
+  const GridP& g = h->g;
+  const bool vec = (g.nx % 4 == 0) && h->cfg.variant != FDTD_VARIANT_SIMPLE;
+  const int V = vec ? 4 : 1;
+  const int zc = (h->cfg.variant == FDTD_VARIANT_SIMPLE) ? 1 : h->zchunk;
+  dim3 block(64, h->rows, 1);
+  dim3 grid((g.nx + 64 * V - 1) / (64 * V), (g.ny + h->rows - 1) / h->rows, (kend - kbeg + zc - 1) / zc);
+  time_begin(h, 0, st);
+  if (vec)
+    hipLaunchKernelGGL((h_update_kernel<4>), grid, block, 0, st, g, h->f, step_params(h), kbeg, kend, zc);
+  else
+    hipLaunchKernelGGL((h_update_kernel<1>), grid, block, 0, st, g, h->f, step_params(h), kbeg, kend, zc);
+  time_end(h, st);
+}
+
+void launch_e_main(FdtdSolver* h, int kbeg, int kend, hipStream_t st) {
+  if (kend <= kbeg) return;
+  const GridP& g = h->g;
+  const bool vec = (g.nx % 4 == 0) && h->cfg.variant != FDTD_VARIANT_SIMPLE;
+  const int V = vec ? 4 : 1;
+  const int zc = (h->cfg.variant == FDTD_VARIANT_SIMPLE) ? 1 : h->zchunk;
+  const bool has_mat = h->mat[0] != nullptr;
+  dim3 block(64, h->rows, 1);
+  dim3 grid((g.nx + 64 * V - 1) / (64 * V), (g.ny + h->rows - 1) / h->rows, (kend - kbeg + zc - 1) / zc);
+  MatP m = mat_params(h);
+  StepP s = step_params(h);
+  time_begin(h, 1, st);
+  if (vec && has_mat)
+    hipLaunchKernelGGL((e_update_kernel<4, true>), grid, block, 0, st, g, h->f, s, m, kbeg, kend, zc);
+  else if (vec)
+    hipLaunchKernelGGL((e_update_kernel<4, false>), grid, block, 0, st, g, h->f, s, m, kbeg, kend, zc);
+  else if (has_mat)
+    hipLaunchKernelGGL((e_update_kernel<1, true>), grid, block, 0, st, g, h->f, s, m, kbeg, kend, zc);
+  else
+    hipLaunchKernelGGL((e_update_kernel<1, false>), grid, block, 0, st, g, h->f, s, m, kbeg, kend, zc);
+  time_end(h, st);
+}
+
+// slabs of one axis: E-side ranges [0,n_lo) and [N-n_hi+1,N); H-side [0,n_lo) and [N-n_hi,N)
+void launch_pml(FdtdSolver* h, bool e_side, int kbeg, int kend, hipStream_t st) {
+  const GridP& g = h->g;
+  const int N[3] = {g.nx, g.ny, g.nz};
+  for (int a = 0; a < 3; ++a) {
+    PmlAxisDev& P = h->pml[a];
+    if (P.n_lo + P.n_hi == 0) continue;
+    const int c1 = (a + 1) % 3, c2 = (a + 2) % 3;
+    for (int side = 0; side < 2; ++side) {
+      int s_lo, s_n, base;
+      if (side == 0) { s_lo = 0; s_n = P.n_lo; base = 0; }
+      else if (e_side) { s_lo = N[a] - P.n_hi + 1; s_n = P.n_hi - 1; base = P.n_lo; }
+      else { s_lo = N[a] - P.n_hi; s_n = P.n_hi; base = P.n_lo; }
+      if (s_n <= 0) continue;
+      SlabP sl;
+      sl.a = a; sl.s_lo = s_lo; sl.s_n = s_n; sl.psi_base = base;
+      sl.psi_ns = e_side ? P.ns_e : P.ns_h;
+      sl.kbeg = kbeg; sl.kend = kend; sl.kpsi0 = 0;
+      if (a == 2) {          // intersect the slab with the launch z-range
+        int lo = s_lo > kbeg ? s_lo : kbeg;
+        int hi = (s_lo + s_n) < kend ? (s_lo + s_n) : kend;
+        if (hi <= lo) continue;
+        sl.kbeg = lo; sl.kend = hi;
+      }
+      const long long bx = (a == 0) ? s_n : g.nx, by = (a == 1) ? s_n : g.ny;
+      const long long total = bx * by * (sl.kend - sl.kbeg);
+      if (total <= 0) continue;
+      if (e_side)
+        hipLaunchKernelGGL(pml_e_kernel, dim3(nblk(total)), dim3(256), 0, st, g, sl, field_ptr(h, c1),
+                           field_ptr(h, c2), (const float*)field_ptr(h, 3 + c1), (const float*)field_ptr(h, 3 + c2),
+                           P.psi_e[0], P.psi_e[1], (const float*)P.kinv_e, (const float*)P.b_e,
+                           (const float*)P.c_e, (const float*)h->idl[a], (const uint8_t*)h->mat[c1],
+                           (const uint8_t*)h->mat[c2], (const float2*)h->lut, h->cb1);
+      else
+        hipLaunchKernelGGL(pml_h_kernel, dim3(nblk(total)), dim3(256), 0, st, g, sl, field_ptr(h, 3 + c1),
+                           field_ptr(h, 3 + c2), (const float*)field_ptr(h, c1), (const float*)field_ptr(h, c2),
+                           P.psi_h[0], P.psi_h[1], (const float*)P.kinv_h, (const float*)P.b_h,
+                           (const float*)P.c_h, (const float*)h->ip[a]);
+    }
+  }
+}
+
+void launch_sources(FdtdSolver* h, bool e_side, long long n, int kbeg, int kend, hipStream_t st) {
+  const long long zlo = (long long)kbeg * h->g.sxy, zhi = (long long)kend * h->g.sxy;
+  const int off = e_side ? 0 : 3;
+  float *f0 = field_ptr(h, off), *f1 = field_ptr(h, off + 1), *f2 = field_ptr(h, off + 2);
+  for (Tfsf& t : h->tfsf) {
+    if (n >= t.n_steps) continue;
+    if (e_side) {
+      if (t.n_e)
+        hipLaunchKernelGGL(tfsf_corr_kernel, dim3(nblk(t.n_e)), dim3(256), 0, st, f0, f1, f2,
+                           (const int32_t*)t.e_comp, (const uint32_t*)t.e_cell, (const float*)t.e_w,
+                           (const int32_t*)t.e_aux, (const float*)t.h1, t.n_e, zlo, zhi);
+    } else {
+      if (t.n_h)
+        hipLaunchKernelGGL(tfsf_corr_kernel, dim3(nblk(t.n_h)), dim3(256), 0, st, f0, f1, f2,
+                           (const int32_t*)t.h_comp, (const uint32_t*)t.h_cell, (const float*)t.h_w,
+                           (const int32_t*)t.h_aux, (const float*)t.e1, t.n_h, zlo, zhi);
+    }
+  }
+  for (PointSrc& s : h->psrc) {
+    if (n >= s.n_steps) continue;
+    if (e_side && s.n_e)
+      hipLaunchKernelGGL(point_source_kernel, dim3(nblk(s.n_e)), dim3(256), 0, st, f0, f1, f2,
+                         (const int32_t*)s.comp_e, (const uint32_t*)s.cell_e, (const float*)s.wre_e,
+                         (const float*)s.wim_e, (const float2*)s.wave_e, n, s.n_e, zlo, zhi);
+    if (!e_side && s.n_h)
+      hipLaunchKernelGGL(point_source_kernel, dim3(nblk(s.n_h)), dim3(256), 0, st, f0, f1, f2,
+                         (const int32_t*)s.comp_h, (const uint32_t*)s.cell_h, (const float*)s.wre_h,
+                         (const float*)s.wim_h, (const float2*)s.wave_h, n, s.n_h, zlo, zhi);
+  }
+}
+
+// the 1-D incident grids advance once per phase on the main stream (not z-range dependent)
+void advance_tfsf_aux(FdtdSolver* h, bool e_side, long long n, hipStream_t st) {
+  for (Tfsf& t : h->tfsf) {
+    if (n >= t.n_steps) continue;
+    if (e_side)
+      hipLaunchKernelGGL(tfsf_aux_e_kernel, dim3(1), dim3(256), 0, st, t.e1, (const float*)t.h1,
+                         (const float*)t.id1, t.ce1, t.mur0, t.mur1, t.n_aux, t.src_cell,
+                         (const float*)t.wave, n);
+    else
+      hipLaunchKernelGGL(tfsf_aux_h_kernel, dim3(nblk(t.n_aux)), dim3(256), 0, st, t.h1, (const float*)t.e1,
+                         (const float*)t.ip1, t.ch1, t.n_aux);
+  }
+}
+
+void launch_ade(FdtdSolver* h, int kbeg, int kend, hipStream_t st) {
+  const long long zlo = (long long)kbeg * h->g.sxy, zhi = (long long)kend * h->g.sxy;
+  for (AdeGroup& a : h->ade)
+    hipLaunchKernelGGL(ade_kernel, dim3(nblk(a.n)), dim3(256), 0, st, field_ptr(h, a.comp),
+                       (const uint32_t*)a.cell, a.e_old, a.q, a.n, zlo, zhi, a.p);
+}
+
+// z boundary conditions of a single slab (no neighbour): fill ghost planes
+void fill_ghost_h(FdtdSolver* h, hipStream_t st) {
+  const long long pc = plane_cells(h);
+  const int bc0 = h->cfg.bc[4];
+  if (bc0 == FDTD_BC_PERIODIC) {
+    hipMemcpyAsync(h->f.hx - pc, h->f.hx + (long long)(h->g.nz - 1) * pc, pc * 4, hipMemcpyDeviceToDevice, st);
+    hipMemcpyAsync(h->f.hy - pc, h->f.hy + (long long)(h->g.nz - 1) * pc, pc * 4, hipMemcpyDeviceToDevice, st);
+  } else if (bc0 == FDTD_BC_PMC) {
+    hipLaunchKernelGGL(negate_copy_kernel, dim3(nblk(pc)), dim3(256), 0, st, h->f.hx - pc, (const float*)h->f.hx, pc);
+    hipLaunchKernelGGL(negate_copy_kernel, dim3(nblk(pc)), dim3(256), 0, st, h->f.hy - pc, (const float*)h->f.hy, pc);
+  }
+}
+void fill_ghost_e(FdtdSolver* h, hipStream_t st) {
+  const long long pc = plane_cells(h);
+  if (h->cfg.bc[5] == FDTD_BC_PERIODIC) {
+    hipMemcpyAsync(h->f.ex + (long long)h->g.nz * pc, h->f.ex, pc * 4, hipMemcpyDeviceToDevice, st);
+    hipMemcpyAsync(h->f.ey + (long long)h->g.nz * pc, h->f.ey, pc * 4, hipMemcpyDeviceToDevice, st);
+  }
+}
+
+// ---- halo exchange over RCCL ----------------------------------------------------------------
+// H phase: my top Hx,Hy plane -> upper neighbour's ghost(-1); E phase: my bottom Ex,Ey plane
+// -> lower neighbour's ghost(nz).  Periodic z wraps rank n-1 <-> 0.
+int exchange(FdtdSolver* h, bool e_side, hipStream_t st) {
+  const long long pc = plane_cells(h);
+  const int nz = h->g.nz;
+  const bool has_lo = h->cfg.bc[4] == FDTD_BC_NEIGHBOR, has_hi = h->cfg.bc[5] == FDTD_BC_NEIGHBOR;
+  const int lo = (h->rank - 1 + h->n_ranks) % h->n_ranks, hi = (h->rank + 1) % h->n_ranks;
+  NCCLCHK(h, ncclGroupStart());
+  if (!e_side) {
+    if (has_hi) {
+      NCCLCHK(h, ncclSend(h->f.hx + (long long)(nz - 1) * pc, pc, ncclFloat, hi, h->comm, st));
+      NCCLCHK(h, ncclSend(h->f.hy + (long long)(nz - 1) * pc, pc, ncclFloat, hi, h->comm, st));
+    }
+    if (has_lo) {
+      NCCLCHK(h, ncclRecv(h->f.hx - pc, pc, ncclFloat, lo, h->comm, st));
+      NCCLCHK(h, ncclRecv(h->f.hy - pc, pc, ncclFloat, lo, h->comm, st));
+    }
+  } else {
+    if (has_lo) {
+      NCCLCHK(h, ncclSend(h->f.ex, pc, ncclFloat, lo, h->comm, st));
+      NCCLCHK(h, ncclSend(h->f.ey, pc, ncclFloat, lo, h->comm, st));
+    }
+    if (has_hi) {
+      NCCLCHK(h, ncclRecv(h->f.ex + (long long)nz * pc, pc, ncclFloat, hi, h->comm, st));
+      NCCLCHK(h, ncclRecv(h->f.ey + (long long)nz * pc, pc, ncclFloat, hi, h->comm, st));
+    }
+  }
+  NCCLCHK(h, ncclGroupEnd());
+  return 0;
+}
+
+// ---- monitors ---------------------------------------------------------------------------------
+void record_monitors(FdtdSolver* h, long long n, bool post, hipStream_t st) {
+  for (Monitor& m : h->mons) {
+    if (m.next >= m.steps.size() || m.steps[m.next] != n) continue;
+    const long long rec = (long long)m.next;
+    const int nc = (int)m.comps.size();
+    for (int ic = 0; ic < nc; ++ic) {
+      const int c = m.comps[ic];
+      const float* F = field_ptr(h, c);
+      if (m.kind == FDTD_MON_TIME) {
+        float* out = reinterpret_cast<float*>(m.data) + (rec * nc + ic) * m.cells;
+        if (c < 3) {
+          if (!post)
+            hipLaunchKernelGGL(time_record_kernel, dim3(nblk(m.cells)), dim3(256), 0, st, F, h->g, m.box, out, 1.0f, 0);
+        } else {
+          hipLaunchKernelGGL(time_record_kernel, dim3(nblk(m.cells)), dim3(256), 0, st, F, h->g, m.box, out, 0.5f, 1);
+        }
+      } else {
+        float2* acc = reinterpret_cast<float2*>(m.data) + (long long)ic * m.cells;
+        const long long fstride = (long long)nc * m.cells;
+        if (c < 3 && !post)
+          hipLaunchKernelGGL(dft_record_kernel, dim3(nblk(m.cells)), dim3(256), 0, st, F, h->g, m.box, acc, fstride,
+                             (const float2*)(m.phase_e + rec * m.nf), m.nf);
+        else if (c >= 3 && post)
+          hipLaunchKernelGGL(dft_record_kernel, dim3(nblk(m.cells)), dim3(256), 0, st, F, h->g, m.box, acc, fstride,
+                             (const float2*)(m.phase_h + rec * m.nf), m.nf);
+      }
+    }
+    if (post) m.next++;
+  }
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+const char* fdtd_last_error(const FdtdSolver* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int fdtd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int fdtd_create(const FdtdConfig* cfg, FdtdSolver** out) {
+  if (!cfg || !out) return fail(nullptr, "fdtd_create: null argument");
+  if (cfg->nx < 1 || cfg->ny < 1 || cfg->nz < 1) return fail(nullptr, "fdtd_create: bad grid %d x %d x %d", cfg->nx, cfg->ny, cfg->nz);
+  if ((long long)cfg->nx * cfg->ny * (cfg->nz + 2) >= (1LL << 32))
+    return fail(nullptr, "fdtd_create: slab of %d x %d x %d cells exceeds the 2^32 cell index range", cfg->nx, cfg->ny, cfg->nz);
+  for (int a = 0; a < 3; ++a) {
+    const bool p0 = cfg->bc[2 * a] == FDTD_BC_PERIODIC, p1 = cfg->bc[2 * a + 1] == FDTD_BC_PERIODIC;
+    if (p0 != p1 && a < 2) return fail(nullptr, "fdtd_create: periodic boundary must be set on both faces of axis %d", a);
+    if (cfg->bc[2 * a + 1] == FDTD_BC_PMC) return fail(nullptr, "fdtd_create: PMC is supported on min faces only");
+    if (a < 2 && (cfg->bc[2 * a] == FDTD_BC_NEIGHBOR || cfg->bc[2 * a + 1] == FDTD_BC_NEIGHBOR))
+      return fail(nullptr, "fdtd_create: neighbour faces exist only along z");
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, "fdtd_create: no HIP device available");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, "fdtd_create: device %d out of range (%d devices)", cfg->device, ndev);
+  FdtdSolver* h = new FdtdSolver();
+  h->cfg = *cfg;
+  if (hipSetDevice(cfg->device) != hipSuccess) { delete h; return fail(nullptr, "hipSetDevice(%d) failed", cfg->device); }
+  GridP& g = h->g;
+  g.nx = cfg->nx; g.ny = cfg->ny; g.nz = cfg->nz;
+  g.sxy = (long long)cfg->nx * cfg->ny;
+  g.bcx0 = cfg->bc[0]; g.bcx1 = cfg->bc[1]; g.bcy0 = cfg->bc[2]; g.bcy1 = cfg->bc[3];
+  g.pec_z0 = cfg->bc[4] == FDTD_BC_PEC;
+  g.ch = cfg->ch;
+  h->zchunk = cfg->z_chunk > 0 ? cfg->z_chunk : 32;
+  h->rows = 4;
+  int rc = 0;
+  const size_t fcount = (size_t)g.sxy * (g.nz + 2);
+  h->field_bytes = fcount * sizeof(float);
+  for (int c = 0; c < 6 && !rc; ++c) rc = dev_alloc(h, &h->fbase[c], fcount);
+  if (!rc) {
+    h->f.ex = h->fbase[0] + g.sxy; h->f.ey = h->fbase[1] + g.sxy; h->f.ez = h->fbase[2] + g.sxy;
+    h->f.hx = h->fbase[3] + g.sxy; h->f.hy = h->fbase[4] + g.sxy; h->f.hz = h->fbase[5] + g.sxy;
+    rc = dev_alloc(h, &h->energy_dev, 1);
+  }
+  if (!rc) {
+    // default: unit steps, vacuum
+    const int N[3] = {g.nx, g.ny, g.nz};
+    for (int a = 0; a < 3 && !rc; ++a) {
+      std::vector<float> ones(N[a], 1.0f);
+      rc = dev_upload(h, &h->ip[a], (const float*)ones.data(), ones.size());
+      if (!rc) rc = dev_upload(h, &h->idl[a], (const float*)ones.data(), ones.size());
+    }
+  }
+  if (!rc && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) rc = fail(nullptr, "hipStreamCreate failed");
+  if (!rc && hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(nullptr, "hipStreamCreate failed");
+  if (!rc) {
+    hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
+    hipEventCreateWithFlags(&h->ev_h_int, hipEventDisableTiming);
+    hipEventCreateWithFlags(&h->ev_h_bnd, hipEventDisableTiming);
+    hipEventCreateWithFlags(&h->ev_e_int, hipEventDisableTiming);
+    hipEventCreateWithFlags(&h->ev_e_bnd, hipEventDisableTiming);
+  }
+  if (rc) {
+    g_create_error = h->err.empty() ? g_create_error : h->err;
+    fdtd_destroy(h);
+    return -1;
+  }
+  *out = h;
+  return 0;
+}
+
+void fdtd_destroy(FdtdSolver* h) {
+  if (!h) return;
+  hipSetDevice(h->cfg.device);
+  hipDeviceSynchronize();
+  if (h->comm) ncclCommDestroy(h->comm);
+  for (DevBuf& b : h->bufs) hipFree(b.p);
+  for (hipEvent_t e : h->kev) hipEventDestroy(e);
+  if (h->ev0) hipEventDestroy(h->ev0);
+  if (h->ev1) hipEventDestroy(h->ev1);
+  if (h->ev_h_int) hipEventDestroy(h->ev_h_int);
+  if (h->ev_h_bnd) hipEventDestroy(h->ev_h_bnd);
+  if (h->ev_e_int) hipEventDestroy(h->ev_e_int);
+  if (h->ev_e_bnd) hipEventDestroy(h->ev_e_bnd);
+  if (h->stream) hipStreamDestroy(h->stream);
+  if (h->comm_stream) hipStreamDestroy(h->comm_stream);
+  delete h;
+}
+
+int fdtd_set_steps(FdtdSolver* h, int axis, const float* inv_primal, const float* inv_dual, int n) {
+  if (!h) return -1;
+  const int N[3] = {h->g.nx, h->g.ny, h->g.nz};
+  if (axis < 0 || axis > 2 || n != N[axis]) return fail(h, "fdtd_set_steps: axis %d expects %d entries, got %d", axis, axis >= 0 && axis < 3 ? N[axis] : -1, n);
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipMemcpy(h->ip[axis], inv_primal, (size_t)n * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->idl[axis], inv_dual, (size_t)n * 4, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int fdtd_set_media(FdtdSolver* h, const float* ca, const float* cb, int n_media) {
+  if (!h) return -1;
+  if (n_media < 2 || n_media > 256) return fail(h, "fdtd_set_media: n_media must be in [2, 256], got %d", n_media);
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  std::vector<float2> lut(n_media);
+  for (int i = 0; i < n_media; ++i) { lut[i].x = ca[i]; lut[i].y = cb[i]; }
+  if (dev_upload(h, &h->lut, (const float2*)lut.data(), lut.size())) return -1;
+  h->n_media = n_media;
+  h->ca1 = ca[1];
+  h->cb1 = cb[1];
+  h->cb_host.assign(cb, cb + n_media);
+  return 0;
+}
+
+int fdtd_set_material(FdtdSolver* h, const uint8_t* mat, size_t bytes) {
+  if (!h) return -1;
+  const size_t nc = (size_t)n_cells(h);
+  if (bytes != 3 * nc) return fail(h, "fdtd_set_material: expected %zu bytes, got %zu", 3 * nc, bytes);
+  if (h->n_media == 0) return fail(h, "fdtd_set_material: call fdtd_set_media first");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  const size_t fcount = (size_t)h->g.sxy * (h->g.nz + 2);
+  for (int c = 0; c < 3; ++c) {
+    uint8_t* base = nullptr;
+    if (dev_alloc(h, &base, fcount, false)) return -1;
+    HIPCHK(h, hipMemset(base, 1, fcount));
+    h->mat[c] = base + h->g.sxy;
+    HIPCHK(h, hipMemcpy(h->mat[c], mat + c * nc, nc, hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+int fdtd_set_pml(FdtdSolver* h, int axis, int n_lo, int n_hi, const float* kinv_e, const float* b_e,
+                 const float* c_e, const float* kinv_h, const float* b_h, const float* c_h, int n) {
+  if (!h) return -1;
+  const int N[3] = {h->g.nx, h->g.ny, h->g.nz};
+  if (axis < 0 || axis > 2 || n != N[axis]) return fail(h, "fdtd_set_pml: bad axis/length");
+  if (n_lo < 0 || n_hi < 0 || n_lo + n_hi > n) return fail(h, "fdtd_set_pml: %d + %d layers exceed %d cells", n_lo, n_hi, n);
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  PmlAxisDev& P = h->pml[axis];
+  P.n_lo = n_lo; P.n_hi = n_hi; P.n = n;
+  if (dev_upload(h, &P.kinv_e, kinv_e, (size_t)n) || dev_upload(h, &P.b_e, b_e, (size_t)n) ||
+      dev_upload(h, &P.c_e, c_e, (size_t)n) || dev_upload(h, &P.kinv_h, kinv_h, (size_t)n) ||
+      dev_upload(h, &P.b_h, b_h, (size_t)n) || dev_upload(h, &P.c_h, c_h, (size_t)n))
+    return -1;
+  P.ns_e = n_lo + (n_hi > 0 ? n_hi - 1 : 0);
+  P.ns_h = n_lo + n_hi;
+  const size_t other = (size_t)n_cells(h) / (size_t)n;
+  for (int s = 0; s < 2; ++s) {
+    if (P.ns_e > 0 && dev_alloc(h, &P.psi_e[s], other * P.ns_e)) return -1;
+    if (P.ns_h > 0 && dev_alloc(h, &P.psi_h[s], other * P.ns_h)) return -1;
+  }
+  return 0;
+}
+
+int fdtd_add_ade(FdtdSolver* h, int comp, int64_t n, const uint32_t* cell_index, int n_poles, const float* kap,
+                 const float* bet, float cc) {
+  if (!h) return -1;
+  if (comp < 0 || comp > 2) return fail(h, "fdtd_add_ade: comp must be 0..2");
+  if (n_poles < 1 || n_poles > kMaxPoles) return fail(h, "fdtd_add_ade: n_poles must be in [1, %d]", kMaxPoles);
+  if (n <= 0) return 0;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  AdeGroup a{};
+  a.comp = comp; a.n = n;
+  if (dev_upload(h, &a.cell, cell_index, (size_t)n) || dev_alloc(h, &a.e_old, (size_t)n) ||
+      dev_alloc(h, &a.q, (size_t)n * n_poles))
+    return -1;
+  a.p.n_poles = n_poles; a.p.cc = cc;
+  for (int k = 0; k < n_poles; ++k) {
+    a.p.kap[k].x = kap[2 * k]; a.p.kap[k].y = kap[2 * k + 1];
+    a.p.bet[k].x = bet[2 * k]; a.p.bet[k].y = bet[2 * k + 1];
+  }
+  h->ade.push_back(a);
+  return 0;
+}
+
+int fdtd_add_point_source(FdtdSolver* h, int64_t n, const int32_t* comp, const uint32_t* cell, const float* w_re,
+                          const float* w_im, int64_t n_steps, const float* wave_e, const float* wave_h) {
+  if (!h) return -1;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  std::vector<int32_t> ce, chh;
+  std::vector<uint32_t> le, lh;
+  std::vector<float> re_e, im_e, re_h, im_h;
+  const uint64_t ncell = (uint64_t)n_cells(h);
+  for (int64_t i = 0; i < n; ++i) {
+    if (comp[i] < 0 || comp[i] > 5) return fail(h, "fdtd_add_point_source: bad component %d", comp[i]);
+    if (cell[i] >= ncell) return fail(h, "fdtd_add_point_source: cell index out of range");
+    if (comp[i] < 3) { ce.push_back(comp[i]); le.push_back(cell[i]); re_e.push_back(w_re[i]); im_e.push_back(w_im[i]); }
+    else { chh.push_back(comp[i]); lh.push_back(cell[i]); re_h.push_back(w_re[i]); im_h.push_back(w_im[i]); }
+  }
+  PointSrc s{};
+  s.n_e = (long long)ce.size(); s.n_h = (long long)chh.size(); s.n_steps = n_steps;
+  if (s.n_e) {
+    if (dev_upload(h, &s.comp_e, (const int32_t*)ce.data(), ce.size()) || dev_upload(h, &s.cell_e, (const uint32_t*)le.data(), le.size()) ||
+        dev_upload(h, &s.wre_e, (const float*)re_e.data(), re_e.size()) || dev_upload(h, &s.wim_e, (const float*)im_e.data(), im_e.size()) ||
+        dev_upload(h, &s.wave_e, reinterpret_cast<const float2*>(wave_e), (size_t)n_steps))
+      return -1;
+  }
+  if (s.n_h) {
+    if (dev_upload(h, &s.comp_h, (const int32_t*)chh.data(), chh.size()) || dev_upload(h, &s.cell_h, (const uint32_t*)lh.data(), lh.size()) ||
+        dev_upload(h, &s.wre_h, (const float*)re_h.data(), re_h.size()) || dev_upload(h, &s.wim_h, (const float*)im_h.data(), im_h.size()) ||
+        dev_upload(h, &s.wave_h, reinterpret_cast<const float2*>(wave_h), (size_t)n_steps))
+      return -1;
+  }
+  h->psrc.push_back(s);
+  return 0;
+}
+
+int fdtd_add_tfsf(FdtdSolver* h, int n_aux, const float* ip1, const float* id1, float ch1, float ce1, float mur0,
+                  float mur1, int src_cell, int64_t n_steps, const float* wave, int64_t n_e, const int32_t* e_comp,
+                  const uint32_t* e_index, const float* e_w, const int32_t* e_aux, int64_t n_h,
+                  const int32_t* h_comp, const uint32_t* h_index, const float* h_w, const int32_t* h_aux) {
+  if (!h) return -1;
+  if (n_aux < 4 || src_cell < 1 || src_cell >= n_aux) return fail(h, "fdtd_add_tfsf: bad auxiliary grid");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  Tfsf t{};
+  t.n_aux = n_aux; t.src_cell = src_cell; t.ch1 = ch1; t.ce1 = ce1; t.mur0 = mur0; t.mur1 = mur1;
+  t.n_steps = n_steps; t.n_e = n_e; t.n_h = n_h;
+  if (dev_upload(h, &t.ip1, ip1, (size_t)n_aux) || dev_upload(h, &t.id1, id1, (size_t)n_aux + 1) ||
+      dev_alloc(h, &t.e1, (size_t)n_aux + 1) || dev_alloc(h, &t.h1, (size_t)n_aux) ||
+      dev_upload(h, &t.wave, wave, (size_t)n_steps))
+    return -1;
+  if (n_e && (dev_upload(h, &t.e_comp, e_comp, (size_t)n_e) || dev_upload(h, &t.e_cell, e_index, (size_t)n_e) ||
+              dev_upload(h, &t.e_w, e_w, (size_t)n_e) || dev_upload(h, &t.e_aux, e_aux, (size_t)n_e)))
+    return -1;
+  if (n_h && (dev_upload(h, &t.h_comp, h_comp, (size_t)n_h) || dev_upload(h, &t.h_cell, h_index, (size_t)n_h) ||
+              dev_upload(h, &t.h_w, h_w, (size_t)n_h) || dev_upload(h, &t.h_aux, h_aux, (size_t)n_h)))
+    return -1;
+  h->tfsf.push_back(t);
+  return 0;
+}
+
+int fdtd_add_monitor(FdtdSolver* h, int kind, int n_comps, const int32_t* comps, const int32_t lo[3],
+                     const int32_t hi[3], int64_t n_rec, const int64_t* steps, int nf, const float* phase_e,
+                     const float* phase_h) {
+  if (!h) return -1;
+  if (kind != FDTD_MON_TIME && kind != FDTD_MON_DFT) return fail(h, "fdtd_add_monitor: bad kind %d", kind);
+  const int N[3] = {h->g.nx, h->g.ny, h->g.nz};
+  for (int a = 0; a < 3; ++a)
+    if (lo[a] < 0 || hi[a] > N[a] || hi[a] <= lo[a]) return fail(h, "fdtd_add_monitor: box [%d,%d) outside axis %d of %d cells", lo[a], hi[a], a, N[a]);
+  if (n_comps < 1 || n_comps > 6) return fail(h, "fdtd_add_monitor: n_comps must be 1..6");
+  if (kind == FDTD_MON_DFT && nf < 1) return fail(h, "fdtd_add_monitor: a DFT monitor needs frequencies");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  Monitor m;
+  m.kind = kind;
+  m.comps.assign(comps, comps + n_comps);
+  for (int c : m.comps) if (c < 0 || c > 5) return fail(h, "fdtd_add_monitor: bad component %d", c);
+  m.box.lo0 = lo[0]; m.box.lo1 = lo[1]; m.box.lo2 = lo[2];
+  m.box.nx = hi[0] - lo[0]; m.box.ny = hi[1] - lo[1]; m.box.nz = hi[2] - lo[2];
+  m.cells = (long long)m.box.nx * m.box.ny * m.box.nz;
+  m.steps.assign(steps, steps + n_rec);
+  for (size_t i = 1; i < m.steps.size(); ++i)
+    if (m.steps[i] <= m.steps[i - 1]) return fail(h, "fdtd_add_monitor: steps must be strictly increasing");
+  m.nf = nf;
+  if (kind == FDTD_MON_TIME) {
+    m.data_bytes = (size_t)n_rec * n_comps * m.cells * sizeof(float);
+    float* d = nullptr;
+    if (dev_alloc(h, &d, (size_t)n_rec * n_comps * m.cells)) return -1;
+    m.data = d;
+  } else {
+    m.data_bytes = (size_t)nf * n_comps * m.cells * sizeof(float2);
+    float2* d = nullptr;
+    if (dev_alloc(h, &d, (size_t)nf * n_comps * m.cells)) return -1;
+    m.data = d;
+    if (dev_upload(h, &m.phase_e, reinterpret_cast<const float2*>(phase_e), (size_t)n_rec * nf) ||
+        dev_upload(h, &m.phase_h, reinterpret_cast<const float2*>(phase_h), (size_t)n_rec * nf))
+      return -1;
+  }
+  h->mons.push_back(m);
+  return (int)h->mons.size() - 1;
+}
+
+int fdtd_get_monitor(FdtdSolver* h, int id, void* host, size_t bytes) {
+  if (!h) return -1;
+  if (id < 0 || id >= (int)h->mons.size()) return fail(h, "fdtd_get_monitor: bad id %d", id);
+  Monitor& m = h->mons[id];
+  if (bytes != m.data_bytes) return fail(h, "fdtd_get_monitor: expected %zu bytes, got %zu", m.data_bytes, bytes);
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(host, m.data, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int fdtd_set_field(FdtdSolver* h, int comp, const float* host, size_t bytes) {
+  if (!h) return -1;
+  if (comp < 0 || comp > 5) return fail(h, "fdtd_set_field: bad component");
+  if (bytes != (size_t)n_cells(h) * 4) return fail(h, "fdtd_set_field: expected %zu bytes", (size_t)n_cells(h) * 4);
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipMemcpy(field_ptr(h, comp), host, bytes, hipMemcpyHostToDevice));
+  // keep single-slab ghost planes consistent with the new interior
+  if (h->n_ranks == 1) { fill_ghost_h(h, h->stream); fill_ghost_e(h, h->stream); HIPCHK(h, hipStreamSynchronize(h->stream)); }
+  return 0;
+}
+
+int fdtd_get_field(FdtdSolver* h, int comp, float* host, size_t bytes) {
+  if (!h) return -1;
+  if (comp < 0 || comp > 5) return fail(h, "fdtd_get_field: bad component");
+  if (bytes != (size_t)n_cells(h) * 4) return fail(h, "fdtd_get_field: expected %zu bytes", (size_t)n_cells(h) * 4);
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(host, field_ptr(h, comp), bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int fdtd_set_shutoff(FdtdSolver* h, int every, double shutoff, int64_t ref_step) {
+  if (!h) return -1;
+  h->decay_every = every; h->shutoff = shutoff; h->decay_ref = ref_step;
+  return 0;
+}
+
+int fdtd_comm_unique_id(char id[128]) {
+  ncclUniqueId u;
+  if (ncclGetUniqueId(&u) != ncclSuccess) return fail(nullptr, "ncclGetUniqueId failed");
+  std::memcpy(id, &u, 128);
+  return 0;
+}
+
+int fdtd_comm_init(FdtdSolver* h, const char id[128], int rank, int n_ranks) {
+  if (!h) return -1;
+  if (rank < 0 || rank >= n_ranks) return fail(h, "fdtd_comm_init: bad rank %d of %d", rank, n_ranks);
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  ncclUniqueId u;
+  std::memcpy(&u, id, 128);
+  NCCLCHK(h, ncclCommInitRank(&h->comm, n_ranks, u, rank));
+  h->rank = rank; h->n_ranks = n_ranks;
+  return 0;
+}
+
+int fdtd_reset(FdtdSolver* h) {
+  if (!h) return -1;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (int c = 0; c < 6; ++c) HIPCHK(h, hipMemset(h->fbase[c], 0, h->field_bytes));
+  const size_t nc = (size_t)n_cells(h);
+  for (int a = 0; a < 3; ++a) {
+    PmlAxisDev& P = h->pml[a];
+    if (P.n == 0) continue;
+    const size_t other = nc / (size_t)P.n;
+    for (int s = 0; s < 2; ++s) {
+      if (P.psi_e[s]) HIPCHK(h, hipMemset(P.psi_e[s], 0, other * P.ns_e * 4));
+      if (P.psi_h[s]) HIPCHK(h, hipMemset(P.psi_h[s], 0, other * P.ns_h * 4));
+    }
+  }
+  for (AdeGroup& a : h->ade) {
+    HIPCHK(h, hipMemset(a.e_old, 0, (size_t)a.n * 4));
+    HIPCHK(h, hipMemset(a.q, 0, (size_t)a.n * a.p.n_poles * 8));
+  }
+  for (Tfsf& t : h->tfsf) {
+    HIPCHK(h, hipMemset(t.e1, 0, ((size_t)t.n_aux + 1) * 4));
+    HIPCHK(h, hipMemset(t.h1, 0, (size_t)t.n_aux * 4));
+  }
+  for (Monitor& m : h->mons) { HIPCHK(h, hipMemset(m.data, 0, m.data_bytes)); m.next = 0; }
+  h->step = 0; h->energy_max = 0.0;
+  h->stats.steps_done = 0; h->stats.diverged = 0; h->stats.stopped_early = 0; h->stats.field_decay = 1.0;
+  return 0;
+}
+
+int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user) {
+  if (!h) return -1;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  const bool multi = h->n_ranks > 1 && h->comm != nullptr;
+  const bool nb_lo = h->cfg.bc[4] == FDTD_BC_NEIGHBOR, nb_hi = h->cfg.bc[5] == FDTD_BC_NEIGHBOR;
+  if ((nb_lo || nb_hi) && !multi) return fail(h, "fdtd_run: neighbour faces need fdtd_comm_init");
+  const int nz = h->g.nz;
+  hipStream_t st = h->stream, cs = h->comm_stream;
+  for (hipEvent_t e : h->kev) hipEventDestroy(e);
+  h->kev.clear(); h->kev_kind.clear();
+  h->stats.stopped_early = 0;
+  HIPCHK(h, hipEventRecord(h->ev0, st));
+  int64_t done = 0;
+  for (; done < n_steps; ++done) {
+    const long long n = h->step;
+    record_monitors(h, n, false, st);
+    // ---------------- H phase ----------------
+    if (multi && nb_hi && nz > 1) {
+      // boundary plane first on the comm stream, interior on the main stream
+      HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
+      launch_h_main(h, nz - 1, nz, cs);
+      launch_pml(h, false, nz - 1, nz, cs);
+      launch_sources(h, false, n, nz - 1, nz, cs);
+      HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
+      HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
+      launch_h_main(h, 0, nz - 1, st);
+      launch_pml(h, false, 0, nz - 1, st);
+      launch_sources(h, false, n, 0, nz - 1, st);
+      advance_tfsf_aux(h, false, n, st);
+      HIPCHK(h, hipEventRecord(h->ev_h_int, st));
+      if (exchange(h, false, cs)) return -1;
+      HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
+    } else {
+      if (multi) HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
+      launch_h_main(h, 0, nz, st);
+      launch_pml(h, false, 0, nz, st);
+      launch_sources(h, false, n, 0, nz, st);
+      advance_tfsf_aux(h, false, n, st);
+      if (multi) {
+        HIPCHK(h, hipEventRecord(h->ev_h_int, st));
+        HIPCHK(h, hipStreamWaitEvent(cs, h->ev_h_int, 0));
+        if (exchange(h, false, cs)) return -1;
+        HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
+      } else {
+        fill_ghost_h(h, st);
+      }
+    }
+    if (!h->mons.empty()) {
+      if (multi) HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
+      record_monitors(h, n, true, st);
+    }
+    // ---------------- E phase ----------------
+    if (multi && nb_lo && nz > 1) {
+      HIPCHK(h, hipStreamWaitEvent(cs, h->ev_h_int, 0));     // plane 0 needs H[0] from the main stream
+      launch_e_main(h, 0, 1, cs);                             // ... and ghost(-1) just received on cs
+      launch_pml(h, true, 0, 1, cs);
+      launch_sources(h, true, n, 0, 1, cs);
+      launch_ade(h, 0, 1, cs);
+      HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
+      HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));     // top H plane was computed on cs
+      launch_e_main(h, 1, nz, st);
+      launch_pml(h, true, 1, nz, st);
+      launch_sources(h, true, n, 1, nz, st);
+      launch_ade(h, 1, nz, st);
+      advance_tfsf_aux(h, true, n, st);
+      HIPCHK(h, hipEventRecord(h->ev_e_int, st));
+      if (exchange(h, true, cs)) return -1;
+      HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
+    } else {
+      if (multi) HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
+      launch_e_main(h, 0, nz, st);
+      launch_pml(h, true, 0, nz, st);
+      launch_sources(h, true, n, 0, nz, st);
+      launch_ade(h, 0, nz, st);
+      advance_tfsf_aux(h, true, n, st);
+      if (multi) {
+        HIPCHK(h, hipEventRecord(h->ev_e_int, st));
+        HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
+        if (exchange(h, true, cs)) return -1;
+        HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
+      } else {
+        fill_ghost_e(h, st);
+      }
+    }
+    h->step = n + 1;
+    // ---------------- field decay / divergence ----------------
+    if (h->decay_every > 0 && (h->step % h->decay_every) == 0) {
+      if (multi) HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
+      HIPCHK(h, hipMemsetAsync(h->energy_dev, 0, sizeof(double), st));
+      const long long nc = n_cells(h);
+      unsigned blocks = nblk(nc);
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(energy_kernel, dim3(blocks), dim3(256), 0, st, (const float*)h->f.ex, (const float*)h->f.ey,
+                         (const float*)h->f.ez, nc, h->energy_dev);
+      double en = 0.0;
+      HIPCHK(h, hipMemcpyAsync(&en, h->energy_dev, sizeof(double), hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipStreamSynchronize(st));
+      if (multi) {
+        // sum over ranks (1 double every decay_every steps; off the critical path)
+        double* tmp = h->energy_dev;
+        HIPCHK(h, hipMemcpyAsync(tmp, &en, sizeof(double), hipMemcpyHostToDevice, st));
+        NCCLCHK(h, ncclAllReduce(tmp, tmp, 1, ncclDouble, ncclSum, h->comm, st));
+        HIPCHK(h, hipMemcpyAsync(&en, tmp, sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+      }
+      if (!std::isfinite(en)) {
+        h->stats.diverged = 1;
+        ++done;
+        break;
+      }
+      if (en > h->energy_max) h->energy_max = en;
+      h->stats.field_decay = h->energy_max > 0 ? en / h->energy_max : 1.0;
+      if (progress && progress(h->step, 0.0, h->stats.field_decay, user)) { ++done; break; }
+      if (h->shutoff > 0 && h->step > h->decay_ref && h->stats.field_decay < h->shutoff) {
+        h->stats.stopped_early = 1;
+        ++done;
+        break;
+      }
+    }
+  }
+  if (multi) {
+    HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
+    HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
+  }
+  HIPCHK(h, hipEventRecord(h->ev1, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  HIPCHK(h, hipStreamSynchronize(cs));
+  HIPCHK(h, hipGetLastError());
+  float ms = 0.f;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  h->stats.run_ms = ms;
+  h->stats.steps_done = h->step;
+  h->stats.h_kernel_ms = h->stats.e_kernel_ms = 0.0;
+  h->stats.h_kernel_launches = h->stats.e_kernel_launches = 0;
+  for (size_t i = 0; i < h->kev_kind.size(); ++i) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, h->kev[2 * i], h->kev[2 * i + 1]) != hipSuccess) continue;
+    if (h->kev_kind[i] == 0) { h->stats.h_kernel_ms += t; h->stats.h_kernel_launches++; }
+    else { h->stats.e_kernel_ms += t; h->stats.e_kernel_launches++; }
+  }
+  return 0;
+}
+
+int fdtd_get_stats(FdtdSolver* h, FdtdStats* out) {
+  if (!h || !out) return -1;
+  *out = h->stats;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,555 @@
+// Hand-written CDNA4 (gfx950) kernels of the FDTD hot path.  HIP only — no CUDA shims, no
+// dual paths.  SURVEY.md section 8(a) rows K1-K7; the reference contains no counterpart (its
+// solver is a closed service), conventions are pinned as cited in tidy3d_amd/coeffs.py.
+//
+// Memory layout: every field is [nz+2][ny][nx] fp32, x fastest, with one ghost xy-plane below
+// (k = -1) and above (k = nz) the slab; kernels receive pointers to interior plane k = 0.  The
+// ghost planes carry the z boundary condition (zeros for PEC, wrapped copy for periodic,
+// negated copy for PMC) or the neighbouring rank's plane in a z-slab decomposition, so the hot
+// kernels have no z special case.  A wavefront (64 lanes) always covers 64*V consecutive x
+// cells of ONE row: global loads are fully coalesced 256 B / 1 KiB segments, x+-1 neighbours
+// come from the adjacent lane by __shfl, z+-1 neighbours from registers carried along the
+// z-march, y+-1 neighbours from the row loaded by the neighbouring wave (L1/L2 hit).
+//
+// Roofline: HBM-bound stencil; algorithmic traffic 36 B/cell per pass (3 reads of the curl
+// source + 3 reads and 3 writes of the updated field), no MFMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fdtd {
+
+enum { BC_PEC = 0, BC_PMC = 1, BC_PERIODIC = 2, BC_NEIGHBOR = 3 };
+
+struct GridP {
+  int nx, ny, nz;
+  long long sxy;                 // nx * ny
+  int bcx0, bcx1, bcy0, bcy1;    // boundary codes of the x / y faces
+  int pec_z0;                    // tangential E on local plane k == 0 is a PEC wall
+  float ch;                      // dt / mu0
+};
+
+struct FieldP {
+  float* ex; float* ey; float* ez;
+  float* hx; float* hy; float* hz;
+};
+
+struct StepP {
+  const float* ipx; const float* ipy; const float* ipz;   // 1 / primal steps
+  const float* idx; const float* idy; const float* idz;   // 1 / dual steps
+};
+
+struct MatP {
+  const uint8_t* mx; const uint8_t* my; const uint8_t* mz;  // material index per E component
+  const float2* lut;                                        // (ca, cb) per medium
+  int n_media;
+  float ca1, cb1;                                           // uniform medium (entry 1)
+};
+
+// ---- small vector helpers -------------------------------------------------------------------
+template <int V>
+__device__ __forceinline__ void ldv(float (&r)[V], const float* __restrict__ p) {
+  if constexpr (V == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < V; ++e) r[e] = p[e];
+  }
+}
+
+template <int V>
+__device__ __forceinline__ void stv(float* __restrict__ p, const float (&r)[V]) {
+  if constexpr (V == 4) {
+    float4 t; t.x = r[0]; t.y = r[1]; t.z = r[2]; t.w = r[3];
+    *reinterpret_cast<float4*>(p) = t;
+  } else {
+#pragma unroll
+    for (int e = 0; e < V; ++e) p[e] = r[e];
+  }
+}
+
+template <int V>
+__device__ __forceinline__ void ldm(int (&m)[V], const uint8_t* __restrict__ p) {
+  if constexpr (V == 4) {
+    const uint32_t t = *reinterpret_cast<const uint32_t*>(p);
+    m[0] = t & 255u; m[1] = (t >> 8) & 255u; m[2] = (t >> 16) & 255u; m[3] = t >> 24;
+  } else {
+#pragma unroll
+    for (int e = 0; e < V; ++e) m[e] = p[e];
+  }
+}
+
+template <int V>
+__device__ __forceinline__ void zero(float (&r)[V]) {
+#pragma unroll
+  for (int e = 0; e < V; ++e) r[e] = 0.f;
+}
+
+// =============================================================================================
+// K1  H-update:  H -= ch * curl_primal(E)      (one workgroup = ROWS rows x 64*V cells, marched
+//                                               over `zchunk` planes with E_x,E_y carried in
+//                                               registers between planes)
+// =============================================================================================
+template <int V>
+__global__ __launch_bounds__(256) void h_update_kernel(GridP g, FieldP f, StepP s, int kbeg, int kend,
+                                                        int zchunk) {
+  const int tx = threadIdx.x;
+  const int i0 = (blockIdx.x * 64 + tx) * V;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (j >= g.ny) return;                       // whole wavefront (one row) leaves together
+  const int k0 = kbeg + blockIdx.z * zchunk;
+  const int k1 = min(k0 + zchunk, kend);
+  const bool act = i0 < g.nx;
+  const bool last_x = (i0 + V >= g.nx);
+  const bool per_x = g.bcx1 == BC_PERIODIC;
+  const bool use_jp = (j + 1 < g.ny) || (g.bcy1 == BC_PERIODIC);
+  const long long row = (long long)j * g.nx + i0;
+  const long long rowp = (j + 1 < g.ny) ? row + g.nx : (long long)i0;    // periodic wrap -> row 0
+  const float ch = g.ch;
+
+  float ipx[V];
+  zero<V>(ipx);
+  if (act) ldv<V>(ipx, s.ipx + i0);
+  const float ipy = s.ipy[j];
+
+  float exk[V], eyk[V];
+  zero<V>(exk); zero<V>(eyk);
+  if (act) {
+    ldv<V>(exk, f.ex + (long long)k0 * g.sxy + row);
+    ldv<V>(eyk, f.ey + (long long)k0 * g.sxy + row);
+  }
+  for (int k = k0; k < k1; ++k) {
+    const long long p = (long long)k * g.sxy + row;
+    const long long pj = (long long)k * g.sxy + rowp;
+    const float ipz = s.ipz[k];
+    float exn[V], eyn[V], ezk[V], exj[V], ezj[V], hx[V], hy[V], hz[V];
+    zero<V>(exn); zero<V>(eyn); zero<V>(ezk); zero<V>(exj); zero<V>(ezj);
+    if (act) {
+      ldv<V>(exn, f.ex + p + g.sxy);
+      ldv<V>(eyn, f.ey + p + g.sxy);
+      ldv<V>(ezk, f.ez + p);
+      if (use_jp) {
+        ldv<V>(exj, f.ex + pj);
+        ldv<V>(ezj, f.ez + pj);
+      }
+      ldv<V>(hx, f.hx + p);
+      ldv<V>(hy, f.hy + p);
+      ldv<V>(hz, f.hz + p);
+    }
+    // x+1 neighbour of the last element: lane+1's first element
+    float eyx = __shfl_down(eyk[0], 1);
+    float ezx = __shfl_down(ezk[0], 1);
+    if (act && (tx == 63 || last_x)) {
+      if (!last_x) { eyx = f.ey[p + V]; ezx = f.ez[p + V]; }
+      else if (per_x) { eyx = f.ey[p - i0]; ezx = f.ez[p - i0]; }
+      else { eyx = 0.f; ezx = 0.f; }
+    }
+    if (act) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float ey_ip = (e + 1 < V) ? eyk[(e + 1) % V] : eyx;
+        const float ez_ip = (e + 1 < V) ? ezk[(e + 1) % V] : ezx;
+        hx[e] -= ch * ((ezj[e] - ezk[e]) * ipy - (eyn[e] - eyk[e]) * ipz);
+        hy[e] -= ch * ((exn[e] - exk[e]) * ipz - (ez_ip - ezk[e]) * ipx[e]);
+        hz[e] -= ch * ((ey_ip - eyk[e]) * ipx[e] - (exj[e] - exk[e]) * ipy);
+      }
+      stv<V>(f.hx + p, hx);
+      stv<V>(f.hy + p, hy);
+      stv<V>(f.hz + p, hz);
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) { exk[e] = exn[e]; eyk[e] = eyn[e]; }
+  }
+}
+
+// =============================================================================================
+// K2  E-update:  E = Ca E + Cb * curl_dual(H), PEC walls on the min faces, optional uint8
+//                material index -> (Ca, Cb) look-up table staged in LDS.
+// =============================================================================================
+template <int V, bool MAT>
+__global__ __launch_bounds__(256) void e_update_kernel(GridP g, FieldP f, StepP s, MatP m, int kbeg,
+                                                        int kend, int zchunk) {
+  __shared__ float2 lut_s[256];
+  if constexpr (MAT) {
+    const int t = threadIdx.y * blockDim.x + threadIdx.x;
+    if (t < m.n_media) lut_s[t] = m.lut[t];
+    __syncthreads();
+  }
+  const int tx = threadIdx.x;
+  const int i0 = (blockIdx.x * 64 + tx) * V;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (j >= g.ny) return;
+  const int k0 = kbeg + blockIdx.z * zchunk;
+  const int k1 = min(k0 + zchunk, kend);
+  const bool act = i0 < g.nx;
+  const long long row = (long long)j * g.nx + i0;
+  // row j-1 and how to use it
+  const int bcy = g.bcy0, bcx = g.bcx0;
+  const long long rowm = (j > 0) ? row - g.nx : row + (long long)(g.ny - 1) * g.nx;  // periodic wrap
+  const int ymode = (j > 0) ? 0 : (bcy == BC_PERIODIC ? 0 : (bcy == BC_PMC ? 1 : 2));  // 0 load,1 negate,2 zero
+  const bool first_x = (i0 == 0);
+  const bool wall_y = (j == 0) && (bcy == BC_PEC);
+  const bool wall_x0 = first_x && (bcx == BC_PEC);
+
+  float idx[V];
+  zero<V>(idx);
+  if (act) ldv<V>(idx, s.idx + i0);
+  const float idy = s.idy[j];
+
+  float hxm[V], hym[V];
+  zero<V>(hxm); zero<V>(hym);
+  if (act) {
+    ldv<V>(hxm, f.hx + (long long)(k0 - 1) * g.sxy + row);
+    ldv<V>(hym, f.hy + (long long)(k0 - 1) * g.sxy + row);
+  }
+  for (int k = k0; k < k1; ++k) {
+    const long long p = (long long)k * g.sxy + row;
+    const long long pj = (long long)k * g.sxy + rowm;
+    const float idz = s.idz[k];
+    float hxk[V], hyk[V], hzk[V], hxj[V], hzj[V], ex[V], ey[V], ez[V];
+    zero<V>(hxk); zero<V>(hyk); zero<V>(hzk); zero<V>(hxj); zero<V>(hzj);
+    if (act) {
+      ldv<V>(hxk, f.hx + p);
+      ldv<V>(hyk, f.hy + p);
+      ldv<V>(hzk, f.hz + p);
+      if (ymode == 0) {
+        ldv<V>(hxj, f.hx + pj);
+        ldv<V>(hzj, f.hz + pj);
+      } else if (ymode == 1) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) { hxj[e] = -hxk[e]; hzj[e] = -hzk[e]; }
+      }
+      ldv<V>(ex, f.ex + p);
+      ldv<V>(ey, f.ey + p);
+      ldv<V>(ez, f.ez + p);
+    }
+    // x-1 neighbour of the first element: lane-1's last element
+    float hyx = __shfl_up(hyk[V - 1], 1);
+    float hzx = __shfl_up(hzk[V - 1], 1);
+    if (act && (tx == 0 || first_x)) {
+      if (!first_x) { hyx = f.hy[p - 1]; hzx = f.hz[p - 1]; }
+      else if (bcx == BC_PERIODIC) { hyx = f.hy[p + g.nx - 1]; hzx = f.hz[p + g.nx - 1]; }
+      else if (bcx == BC_PMC) { hyx = -hyk[0]; hzx = -hzk[0]; }
+      else { hyx = 0.f; hzx = 0.f; }
+    }
+    if (act) {
+      float cax[V], cbx[V], cay[V], cby[V], caz[V], cbz[V];
+      if constexpr (MAT) {
+        int mi[V];
+        ldm<V>(mi, m.mx + p);
+#pragma unroll
+        for (int e = 0; e < V; ++e) { const float2 c = lut_s[mi[e]]; cax[e] = c.x; cbx[e] = c.y; }
+        ldm<V>(mi, m.my + p);
+#pragma unroll
+        for (int e = 0; e < V; ++e) { const float2 c = lut_s[mi[e]]; cay[e] = c.x; cby[e] = c.y; }
+        ldm<V>(mi, m.mz + p);
+#pragma unroll
+        for (int e = 0; e < V; ++e) { const float2 c = lut_s[mi[e]]; caz[e] = c.x; cbz[e] = c.y; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          cax[e] = cay[e] = caz[e] = m.ca1;
+          cbx[e] = cby[e] = cbz[e] = m.cb1;
+        }
+      }
+      const bool wall_z = (k == 0) && g.pec_z0;
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float hy_im = (e > 0) ? hyk[(e + V - 1) % V] : hyx;
+        const float hz_im = (e > 0) ? hzk[(e + V - 1) % V] : hzx;
+        float nex = cax[e] * ex[e] + cbx[e] * ((hzk[e] - hzj[e]) * idy - (hyk[e] - hym[e]) * idz);
+        float ney = cay[e] * ey[e] + cby[e] * ((hxk[e] - hxm[e]) * idz - (hzk[e] - hz_im) * idx[e]);
+        float nez = caz[e] * ez[e] + cbz[e] * ((hyk[e] - hy_im) * idx[e] - (hxk[e] - hxj[e]) * idy);
+        const bool wx = wall_x0 && (e == 0);
+        if (wall_y || wall_z) nex = 0.f;
+        if (wx || wall_z) ney = 0.f;
+        if (wx || wall_y) nez = 0.f;
+        ex[e] = nex; ey[e] = ney; ez[e] = nez;
+      }
+      stv<V>(f.ex + p, ex);
+      stv<V>(f.ey + p, ey);
+      stv<V>(f.ez + p, ez);
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) { hxm[e] = hxk[e]; hym[e] = hyk[e]; }
+  }
+}
+
+// =============================================================================================
+// K3  CPML slab corrections (post-correction form: the main kernels use the plain derivative
+//     everywhere; inside a slab the difference  (1/kappa - 1) d + psi  is added afterwards,
+//     which is exact because both updates are linear in the curl).
+// =============================================================================================
+struct SlabP {
+  int a;              // PML axis
+  int s_lo, s_n;      // slab index range [s_lo, s_lo + s_n) along a
+  int psi_base;       // slab-local index of s_lo inside the psi array
+  int psi_ns;         // extent of the psi array along a (n_lo + n_hi entries)
+  int kbeg, kend;     // z-range processed by this launch (already intersected for a == 2)
+  int kpsi0;          // local k that maps to psi index 0 along z (0 unless a == 2: then unused)
+};
+
+__device__ __forceinline__ long long psi_index(const GridP& g, const SlabP& sl, int i, int j, int k, int si) {
+  if (sl.a == 0) return ((long long)k * g.ny + j) * sl.psi_ns + si;
+  if (sl.a == 1) return ((long long)k * sl.psi_ns + si) * g.nx + i;
+  return ((long long)si * g.ny + j) * g.nx + i;
+}
+
+// E-side:  E_{a+1} -= Cb * ((kinv-1) d(H_{a+2})/da + psi1),  E_{a+2} += Cb * ((kinv-1) d(H_{a+1})/da + psi2)
+__global__ __launch_bounds__(256) void pml_e_kernel(GridP g, SlabP sl, float* e1, float* e2, const float* h1,
+                                                     const float* h2, float* psi1, float* psi2,
+                                                     const float* kinv, const float* bb, const float* cc,
+                                                     const float* idl, const uint8_t* m1, const uint8_t* m2,
+                                                     const float2* lut, float cb_uniform) {
+  const int bx = (sl.a == 0) ? sl.s_n : g.nx;
+  const int by = (sl.a == 1) ? sl.s_n : g.ny;
+  const int bz = sl.kend - sl.kbeg;
+  const long long total = (long long)bx * by * bz;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int lx = (int)(t % bx);
+  const int ly = (int)((t / bx) % by);
+  const int lz = (int)(t / ((long long)bx * by));
+  const int i = (sl.a == 0) ? sl.s_lo + lx : lx;
+  const int j = (sl.a == 1) ? sl.s_lo + ly : ly;
+  const int k = sl.kbeg + lz;
+  const int ia = (sl.a == 0) ? i : (sl.a == 1 ? j : k);
+  const int c1 = (sl.a + 1) % 3, c2 = (sl.a + 2) % 3;
+  const int idx3[3] = {i, j, k};
+  const int bc0[3] = {g.bcx0, g.bcy0, g.pec_z0 ? BC_PEC : BC_NEIGHBOR};
+  const long long stride = (sl.a == 0) ? 1 : (sl.a == 1 ? (long long)g.nx : g.sxy);
+  const long long p = (long long)k * g.sxy + (long long)j * g.nx + i;
+  float d1, d2;   // d/da of H_{a+1}, H_{a+2}
+  if (ia == 0 && sl.a != 2) {
+    if (bc0[sl.a] == BC_PEC) return;                  // both components are wall-tangential: stay 0
+    if (bc0[sl.a] == BC_PMC) { d1 = 2.f * h1[p] * idl[ia]; d2 = 2.f * h2[p] * idl[ia]; }
+    else { const long long w = (long long)((sl.a == 0 ? g.nx : g.ny) - 1) * stride;
+           d1 = (h1[p] - h1[p + w]) * idl[ia]; d2 = (h2[p] - h2[p + w]) * idl[ia]; }
+  } else {
+    if (ia == 0 && g.pec_z0) return;                  // z wall (ghost plane otherwise)
+    d1 = (h1[p] - h1[p - stride]) * idl[ia];
+    d2 = (h2[p] - h2[p - stride]) * idl[ia];
+  }
+  const int si = sl.psi_base + (ia - sl.s_lo);
+  const long long q = psi_index(g, sl, i, j, k, si);
+  const float kv = kinv[ia] - 1.f, b = bb[ia], c = cc[ia];
+  const float p1 = b * psi1[q] + c * d2;     // psi of E_{a+1} follows d(H_{a+2})/da
+  const float p2 = b * psi2[q] + c * d1;     // psi of E_{a+2} follows d(H_{a+1})/da
+  psi1[q] = p1;
+  psi2[q] = p2;
+  const float cb1 = m1 ? lut[m1[p]].y : cb_uniform;
+  const float cb2 = m2 ? lut[m2[p]].y : cb_uniform;
+  // PEC walls of the other transverse axis
+  const bool w1 = (idx3[c2] == 0) && (bc0[c2] == BC_PEC);   // E_{c1} is tangential to the c2-wall
+  const bool w2 = (idx3[c1] == 0) && (bc0[c1] == BC_PEC);
+  if (!w1) e1[p] -= cb1 * (kv * d2 + p1);
+  if (!w2) e2[p] += cb2 * (kv * d1 + p2);
+}
+
+// H-side:  H_{a+1} += ch * ((kinv-1) d(E_{a+2})/da + psi1),  H_{a+2} -= ch * ((kinv-1) d(E_{a+1})/da + psi2)
+__global__ __launch_bounds__(256) void pml_h_kernel(GridP g, SlabP sl, float* h1, float* h2, const float* e1,
+                                                     const float* e2, float* psi1, float* psi2,
+                                                     const float* kinv, const float* bb, const float* cc,
+                                                     const float* ipl) {
+  const int bx = (sl.a == 0) ? sl.s_n : g.nx;
+  const int by = (sl.a == 1) ? sl.s_n : g.ny;
+  const int bz = sl.kend - sl.kbeg;
+  const long long total = (long long)bx * by * bz;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int lx = (int)(t % bx);
+  const int ly = (int)((t / bx) % by);
+  const int lz = (int)(t / ((long long)bx * by));
+  const int i = (sl.a == 0) ? sl.s_lo + lx : lx;
+  const int j = (sl.a == 1) ? sl.s_lo + ly : ly;
+  const int k = sl.kbeg + lz;
+  const int ia = (sl.a == 0) ? i : (sl.a == 1 ? j : k);
+  const int na = (sl.a == 0) ? g.nx : (sl.a == 1 ? g.ny : g.nz);
+  const int bc1 = (sl.a == 0) ? g.bcx1 : (sl.a == 1 ? g.bcy1 : BC_NEIGHBOR);
+  const long long stride = (sl.a == 0) ? 1 : (sl.a == 1 ? (long long)g.nx : g.sxy);
+  const long long p = (long long)k * g.sxy + (long long)j * g.nx + i;
+  float n1, n2;   // E_{a+1}, E_{a+2} at ia + 1
+  if (ia == na - 1 && sl.a != 2) {
+    if (bc1 == BC_PERIODIC) { n1 = e1[p - (long long)(na - 1) * stride]; n2 = e2[p - (long long)(na - 1) * stride]; }
+    else { n1 = 0.f; n2 = 0.f; }
+  } else {
+    n1 = e1[p + stride];      // for a == 2 the ghost plane holds the boundary value
+    n2 = e2[p + stride];
+  }
+  const float d1 = (n1 - e1[p]) * ipl[ia];
+  const float d2 = (n2 - e2[p]) * ipl[ia];
+  const int si = sl.psi_base + (ia - sl.s_lo);
+  const long long q = psi_index(g, sl, i, j, k, si);
+  const float kv = kinv[ia] - 1.f, b = bb[ia], c = cc[ia];
+  const float p1 = b * psi1[q] + c * d2;
+  const float p2 = b * psi2[q] + c * d1;
+  psi1[q] = p1;
+  psi2[q] = p2;
+  h1[p] += g.ch * (kv * d2 + p1);
+  h2[p] -= g.ch * (kv * d1 + p2);
+}
+
+// =============================================================================================
+// K4  ADE (pole-residue) post-update on the compact list of dispersive cells of one component
+//     and one medium:  E <- E* - cc * S(Q),  Q <- kap Q + bet (E_new + E_old)
+// =============================================================================================
+constexpr int kMaxPoles = 8;
+struct AdeP {
+  int n_poles;
+  float cc;
+  float2 kap[kMaxPoles];
+  float2 bet[kMaxPoles];
+};
+
+__global__ __launch_bounds__(256) void ade_kernel(float* e, const uint32_t* cell, float* e_old, float2* q,
+                                                   long long n, long long zlo, long long zhi, AdeP a) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const long long p = cell[t];
+  if (p < zlo || p >= zhi) return;        // z-range filter (multi-stream boundary planes)
+  const float es = e[p];
+  const float eo = e_old[t];
+  float S = 0.f;
+  float2 qq[kMaxPoles];
+#pragma unroll
+  for (int k = 0; k < kMaxPoles; ++k) {
+    if (k < a.n_poles) {
+      qq[k] = q[(long long)k * n + t];
+      // 2 Re[(kap - 1) Q]
+      S += 2.f * ((a.kap[k].x - 1.f) * qq[k].x - a.kap[k].y * qq[k].y);
+    }
+  }
+  const float en = es - a.cc * S;
+  e[p] = en;
+  e_old[t] = en;
+  const float se = en + eo;
+#pragma unroll
+  for (int k = 0; k < kMaxPoles; ++k) {
+    if (k < a.n_poles) {
+      float2 r;
+      r.x = a.kap[k].x * qq[k].x - a.kap[k].y * qq[k].y + a.bet[k].x * se;
+      r.y = a.kap[k].x * qq[k].y + a.kap[k].y * qq[k].x + a.bet[k].y * se;
+      q[(long long)k * n + t] = r;
+    }
+  }
+}
+
+// =============================================================================================
+// K5  sources
+// =============================================================================================
+// F[comp][cell] += w_re * Re(wave[n]) - w_im * Im(wave[n])
+__global__ __launch_bounds__(256) void point_source_kernel(float* f0, float* f1, float* f2, const int32_t* comp,
+                                                            const uint32_t* cell, const float* w_re,
+                                                            const float* w_im, const float2* wave, long long step,
+                                                            long long n, long long zlo, long long zhi) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const long long p = cell[t];
+  if (p < zlo || p >= zhi) return;
+  const float2 a = wave[step];
+  const int c = comp[t] % 3;
+  float* f = (c == 0) ? f0 : (c == 1 ? f1 : f2);
+  f[p] += w_re[t] * a.x - w_im[t] * a.y;
+}
+
+// TFSF surface correction:  F[comp][cell] += w * aux[aux_index]
+__global__ __launch_bounds__(256) void tfsf_corr_kernel(float* f0, float* f1, float* f2, const int32_t* comp,
+                                                         const uint32_t* cell, const float* w, const int32_t* ai,
+                                                         const float* aux, long long n, long long zlo, long long zhi) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const long long p = cell[t];
+  if (p < zlo || p >= zhi) return;
+  const int c = comp[t] % 3;
+  float* f = (c == 0) ? f0 : (c == 1 ? f1 : f2);
+  f[p] += w[t] * aux[ai[t]];
+}
+
+// 1-D auxiliary grid of the incident plane wave
+__global__ void tfsf_aux_h_kernel(float* h1, const float* e1, const float* ip1, float ch1, int n_aux) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_aux; i += gridDim.x * blockDim.x)
+    h1[i] -= ch1 * (e1[i + 1] - e1[i]) * ip1[i];
+}
+
+// single workgroup: interior update, first-order Mur at both ends, soft source
+__global__ void tfsf_aux_e_kernel(float* e1, const float* h1, const float* id1, float ce1, float mur0, float mur1,
+                                  int n_aux, int src_cell, const float* wave, long long step) {
+  __shared__ float old_s[4];
+  if (threadIdx.x == 0) {
+    old_s[0] = e1[0]; old_s[1] = e1[1]; old_s[2] = e1[n_aux]; old_s[3] = e1[n_aux - 1];
+  }
+  __syncthreads();
+  for (int i = 1 + threadIdx.x; i < n_aux; i += blockDim.x)
+    e1[i] -= ce1 * (h1[i] - h1[i - 1]) * id1[i];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    e1[0] = old_s[1] + mur0 * (e1[1] - old_s[0]);
+    e1[n_aux] = old_s[3] + mur1 * (e1[n_aux - 1] - old_s[2]);
+    e1[src_cell] += wave[step];
+  }
+}
+
+// =============================================================================================
+// K6  monitors
+// =============================================================================================
+struct BoxP { int lo0, lo1, lo2; int nx, ny, nz; };   // box origin (i,j,k) and extents
+
+// out[cell] (=|+=) scale * F[box cell]
+__global__ __launch_bounds__(256) void time_record_kernel(const float* f, GridP g, BoxP b, float* out, float scale,
+                                                           int accumulate) {
+  const long long total = (long long)b.nx * b.ny * b.nz;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int lx = (int)(t % b.nx), ly = (int)((t / b.nx) % b.ny), lz = (int)(t / ((long long)b.nx * b.ny));
+  const float v = scale * f[(long long)(b.lo2 + lz) * g.sxy + (long long)(b.lo1 + ly) * g.nx + b.lo0 + lx];
+  out[t] = accumulate ? out[t] + v : v;
+}
+
+// acc[f][cell] += F[box cell] * phase[f]     (acc stride between frequencies = fstride)
+__global__ __launch_bounds__(256) void dft_record_kernel(const float* f, GridP g, BoxP b, float2* acc,
+                                                          long long fstride, const float2* phase, int nf) {
+  const long long total = (long long)b.nx * b.ny * b.nz;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int lx = (int)(t % b.nx), ly = (int)((t / b.nx) % b.ny), lz = (int)(t / ((long long)b.nx * b.ny));
+  const float v = f[(long long)(b.lo2 + lz) * g.sxy + (long long)(b.lo1 + ly) * g.nx + b.lo0 + lx];
+  for (int q = 0; q < nf; ++q) {
+    const float2 ph = phase[q];
+    float2 a = acc[(long long)q * fstride + t];
+    a.x += v * ph.x;
+    a.y += v * ph.y;
+    acc[(long long)q * fstride + t] = a;
+  }
+}
+
+// =============================================================================================
+// K7  field-energy reduction  sum |E|^2  (shutoff / divergence detection)
+// =============================================================================================
+__global__ __launch_bounds__(256) void energy_kernel(const float* ex, const float* ey, const float* ez, long long n,
+                                                      double* out) {
+  __shared__ double part[4];
+  double acc = 0.0;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+       t += (long long)gridDim.x * blockDim.x) {
+    const float a = ex[t], b = ey[t], c = ez[t];
+    acc += (double)(a * a + b * b + c * c);
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) part[wv] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sblk = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sblk += part[w];
+    atomicAdd(out, sblk);
+  }
+}
+
+// ghost-plane helpers (single-GPU z boundary conditions)
+__global__ __launch_bounds__(256) void negate_copy_kernel(float* dst, const float* src, long long n) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) dst[t] = -src[t];
+}
+
+}  // namespace fdtd

@@ -1,0 +1,294 @@
+"""HipEngine: drives libfdtd_hip.so for one SolverSpec (or one z-slab of it).
+
+Python here is plumbing only: it casts the fp64 coefficient tables of
+``tidy3d_amd.coeffs`` to fp32, slices them to this rank's z-slab, hands them to
+the C ABI (include/fdtd_hip.h) and reads monitor buffers back.  All time stepping
+happens inside ``fdtd_run`` on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import lib as L
+from .coeffs import h_coeff, inv_steps, material_table, pml_axis
+from .exceptions import SolverLibraryError
+from .spec import BC_PERIODIC, MonitorSpec, SolverSpec
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _cplx_f32(a) -> np.ndarray:
+    """complex array -> float32 array with (re, im) interleaved on the last axis."""
+    a = np.asarray(a, dtype=np.complex128)
+    out = np.empty(a.shape + (2,), dtype=np.float32)
+    out[..., 0] = a.real
+    out[..., 1] = a.imag
+    return np.ascontiguousarray(out)
+
+
+def split_slabs(nz: int, n_ranks: int) -> List[Tuple[int, int]]:
+    """Contiguous z-slabs, as equal as possible."""
+    base, rem = divmod(nz, n_ranks)
+    out, z = [], 0
+    for r in range(n_ranks):
+        n = base + (1 if r < rem else 0)
+        out.append((z, z + n))
+        z += n
+    return out
+
+
+def _local_pml_counts(tables: List[np.ndarray]) -> Tuple[int, int]:
+    """Leading/trailing run of planes whose CPML tables differ from identity (see engine notes):
+    the library's slab ranges only need to be supersets of the true PML planes."""
+    kinv_e, b_e, c_e, kinv_h, b_h, c_h = tables
+    mask = (kinv_e != 1) | (b_e != 0) | (c_e != 0) | (kinv_h != 1) | (b_h != 0) | (c_h != 0)
+    n = len(mask)
+    if not mask.any():
+        return 0, 0
+    lead = int(np.argmin(mask)) if not mask.all() else n
+    if lead == n:
+        return n, 0
+    trail = int(np.argmin(mask[::-1]))
+    return lead, trail
+
+
+class HipEngine:
+    def __init__(self, spec: SolverSpec, lib: Optional[L.FdtdLib] = None, device: int = 0,
+                 variant: int = L.VARIANT_AUTO, flags: int = 0, z_chunk: int = 0,
+                 slab: Optional[Tuple[int, int]] = None, rank: int = 0, n_ranks: int = 1):
+        self.lib = lib or L.load_library()
+        self.spec = spec
+        self.rank, self.n_ranks = rank, n_ranks
+        nx, ny, nz = spec.shape
+        self.z0, self.z1 = slab if slab is not None else (0, nz)
+        self.nzl = self.z1 - self.z0
+        if self.nzl < 1:
+            raise SolverLibraryError("empty z-slab")
+        self.handle = C.c_void_p()
+        self._keep = []          # host arrays that must outlive a call
+        d = self.lib.dll
+
+        cfg = L.FdtdConfig()
+        cfg.nx, cfg.ny, cfg.nz = nx, ny, self.nzl
+        bc = [spec.bc[0][0], spec.bc[0][1], spec.bc[1][0], spec.bc[1][1], spec.bc[2][0], spec.bc[2][1]]
+        per_z = spec.bc[2][0] == BC_PERIODIC
+        if n_ranks > 1:
+            if self.z0 > 0 or per_z:
+                bc[4] = L.BC_NEIGHBOR
+            if self.z1 < nz or per_z:
+                bc[5] = L.BC_NEIGHBOR
+        for i, b in enumerate(bc):
+            cfg.bc[i] = int(b)
+        cfg.device, cfg.variant, cfg.flags, cfg.z_chunk = device, variant, flags, z_chunk
+        cfg.ch = float(h_coeff(spec.dt))
+        st = d.fdtd_create(C.byref(cfg), C.byref(self.handle))
+        if st < 0:
+            raise SolverLibraryError(f"fdtd_create failed: {self.lib.error(None)}")
+        try:
+            self._setup(spec)
+        except Exception:
+            self.close()
+            raise
+
+    # ------------------------------------------------------------------ setup
+    def _chk(self, st, what):
+        return self.lib.check(st, self.handle, what)
+
+    def _setup(self, spec: SolverSpec):
+        d, h = self.lib.dll, self.handle
+        nx, ny, nz = spec.shape
+        z0, z1, nzl = self.z0, self.z1, self.nzl
+        sxy = nx * ny
+        ip, idl = inv_steps(spec)
+        for a in range(3):
+            p, q = _f32(ip[a]), _f32(idl[a])
+            if a == 2:
+                p, q = _f32(p[z0:z1]), _f32(q[z0:z1])
+            self._chk(d.fdtd_set_steps(h, a, _ptr(p), _ptr(q), len(p)), "fdtd_set_steps")
+        self.mt = mt = material_table(spec.media, spec.dt)
+        ca, cb = _f32(mt.ca), _f32(mt.cb)
+        self._chk(d.fdtd_set_media(h, _ptr(ca), _ptr(cb), len(ca)), "fdtd_set_media")
+        if spec.mat_idx is not None:
+            m = np.ascontiguousarray(spec.mat_idx[:, z0:z1], dtype=np.uint8)
+            self._chk(d.fdtd_set_material(h, _ptr(m), m.nbytes), "fdtd_set_material")
+        # CPML
+        for a in range(3):
+            P = pml_axis(spec, a)
+            if P.n_lo + P.n_hi == 0:
+                continue
+            tabs = [P.kinv_e, P.b_e, P.c_e, P.kinv_h, P.b_h, P.c_h]
+            n_lo, n_hi = P.n_lo, P.n_hi
+            if a == 2:
+                tabs = [t[z0:z1] for t in tabs]
+                n_lo, n_hi = _local_pml_counts(tabs)
+                if n_lo + n_hi == 0:
+                    continue
+            t32 = [_f32(t) for t in tabs]
+            self._chk(d.fdtd_set_pml(h, a, n_lo, n_hi, *[_ptr(t) for t in t32], len(t32[0])),
+                      "fdtd_set_pml")
+        # ADE groups
+        for c in range(3):
+            for m in range(mt.n_media):
+                if not mt.is_dispersive(m):
+                    continue
+                if spec.mat_idx is not None:
+                    flat = spec.mat_idx[c, z0:z1].reshape(-1)
+                    idx = np.nonzero(flat == m)[0].astype(np.uint32)
+                elif m == 1:
+                    idx = np.arange(sxy * nzl, dtype=np.uint32)
+                else:
+                    continue
+                if idx.size == 0:
+                    continue
+                kap, bet = _cplx_f32(mt.kap[m]), _cplx_f32(mt.bet[m])
+                self._chk(d.fdtd_add_ade(h, c, idx.size, _ptr(idx), len(mt.kap[m]), _ptr(kap),
+                                         _ptr(bet), float(mt.cc[m])), "fdtd_add_ade")
+        # sources
+        for s in spec.sources:
+            k = s.ijk[:, 2]
+            keep = (k >= z0) & (k < z1)
+            if not keep.any():
+                continue
+            ijk = s.ijk[keep]
+            cell = ((ijk[:, 2] - z0).astype(np.int64) * sxy + ijk[:, 1].astype(np.int64) * nx
+                    + ijk[:, 0]).astype(np.uint32)
+            comp = np.ascontiguousarray(s.comp[keep], dtype=np.int32)
+            wre, wim = _f32(s.w_re[keep]), _f32(s.w_im[keep])
+            we, wh = _cplx_f32(s.wave_e), _cplx_f32(s.wave_h)
+            self._chk(d.fdtd_add_point_source(h, len(cell), _ptr(comp), _ptr(cell), _ptr(wre),
+                                              _ptr(wim), len(s.wave_e), _ptr(we), _ptr(wh)),
+                      "fdtd_add_point_source")
+        for t in spec.tfsf:
+            def loc(ijk, *arrs):
+                k = ijk[:, 2]
+                keep = (k >= z0) & (k < z1)
+                ij = ijk[keep]
+                cell = ((ij[:, 2] - z0).astype(np.int64) * sxy + ij[:, 1].astype(np.int64) * nx
+                        + ij[:, 0]).astype(np.uint32)
+                return [cell] + [np.ascontiguousarray(a[keep]) for a in arrs]
+            ecell, ecomp, ew, eaux = loc(t.e_corr_ijk, t.e_corr_comp.astype(np.int32),
+                                         t.e_corr_w.astype(np.float32), t.e_corr_aux.astype(np.int32))
+            hcell, hcomp, hw, haux = loc(t.h_corr_ijk, t.h_corr_comp.astype(np.int32),
+                                         t.h_corr_w.astype(np.float32), t.h_corr_aux.astype(np.int32))
+            ip1, id1, wave = _f32(t.ip1), _f32(t.id1), _f32(t.wave)
+            self._chk(d.fdtd_add_tfsf(h, t.n_aux, _ptr(ip1), _ptr(id1), float(t.ch1), float(t.ce1),
+                                      float(t.mur0), float(t.mur1), int(t.src_cell), len(wave),
+                                      _ptr(wave), len(ecell), _ptr(ecomp), _ptr(ecell), _ptr(ew),
+                                      _ptr(eaux), len(hcell), _ptr(hcomp), _ptr(hcell), _ptr(hw),
+                                      _ptr(haux)), "fdtd_add_tfsf")
+        # monitors (intersected with the slab)
+        self.mon_ids: List[Tuple[MonitorSpec, int, Tuple[int, int]]] = []
+        for m in spec.monitors:
+            lo2, hi2 = max(m.lo[2], z0), min(m.hi[2], z1)
+            if hi2 <= lo2:
+                self.mon_ids.append((m, -1, (0, 0)))
+                continue
+            comps = np.asarray(m.comps, dtype=np.int32)
+            lo = np.asarray([m.lo[0], m.lo[1], lo2 - z0], dtype=np.int32)
+            hi = np.asarray([m.hi[0], m.hi[1], hi2 - z0], dtype=np.int32)
+            steps = np.ascontiguousarray(m.steps, dtype=np.int64)
+            if m.kind == "dft":
+                pe, ph = _cplx_f32(m.phase_e), _cplx_f32(m.phase_h)
+                mid = d.fdtd_add_monitor(h, L.MON_DFT, len(comps), _ptr(comps), _ptr(lo), _ptr(hi),
+                                         len(steps), _ptr(steps), len(m.freqs), _ptr(pe), _ptr(ph))
+            else:
+                mid = d.fdtd_add_monitor(h, L.MON_TIME, len(comps), _ptr(comps), _ptr(lo), _ptr(hi),
+                                         len(steps), _ptr(steps), 0, None, None)
+            self._chk(mid, "fdtd_add_monitor")
+            self.mon_ids.append((m, mid, (lo2, hi2)))
+        self._chk(d.fdtd_set_shutoff(h, int(spec.decay_every), float(spec.shutoff),
+                                     int(spec.decay_ref_step)), "fdtd_set_shutoff")
+
+    # ------------------------------------------------------------------ multi-GPU
+    def unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        self.lib.check(self.lib.dll.fdtd_comm_unique_id(buf), None, "fdtd_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, uid: bytes):
+        buf = C.create_string_buffer(uid, 128)
+        self._chk(self.lib.dll.fdtd_comm_init(self.handle, buf, self.rank, self.n_ranks),
+                  "fdtd_comm_init")
+
+    # ------------------------------------------------------------------ run / IO
+    def run(self, n_steps: Optional[int] = None,
+            progress: Optional[Callable[[int, float, float], bool]] = None) -> L.FdtdStats:
+        n_steps = self.spec.n_steps if n_steps is None else n_steps
+        dt = self.spec.dt
+
+        def _cb(step, _t, decay, _user):
+            try:
+                return 1 if (progress and progress(int(step), step * dt, float(decay))) else 0
+            except KeyboardInterrupt:
+                return 1
+        cb = L.PROGRESS_FN(_cb) if progress else C.cast(None, L.PROGRESS_FN)
+        self._chk(self.lib.dll.fdtd_run(self.handle, int(n_steps), cb, None), "fdtd_run")
+        return self.stats()
+
+    def stats(self) -> L.FdtdStats:
+        st = L.FdtdStats()
+        self._chk(self.lib.dll.fdtd_get_stats(self.handle, C.byref(st)), "fdtd_get_stats")
+        return st
+
+    def reset(self):
+        self._chk(self.lib.dll.fdtd_reset(self.handle), "fdtd_reset")
+
+    def get_field(self, comp: int) -> np.ndarray:
+        nx, ny, _ = self.spec.shape
+        out = np.empty((self.nzl, ny, nx), dtype=np.float32)
+        self._chk(self.lib.dll.fdtd_get_field(self.handle, comp, _ptr(out), out.nbytes),
+                  "fdtd_get_field")
+        return out
+
+    def set_field(self, comp: int, arr: np.ndarray):
+        a = _f32(arr)
+        self._chk(self.lib.dll.fdtd_set_field(self.handle, comp, _ptr(a), a.nbytes),
+                  "fdtd_set_field")
+
+    def monitor_data(self) -> Dict[str, Tuple[np.ndarray, Tuple[int, int]]]:
+        """name -> (array over the slab-local part of the box, (z_lo, z_hi) global plane range).
+        time: float32 [n_rec, n_comps, bz, by, bx]; dft: complex64 [nf, n_comps, bz, by, bx]."""
+        out = {}
+        for m, mid, (lo2, hi2) in self.mon_ids:
+            if mid < 0:
+                continue
+            bz, by, bx = hi2 - lo2, m.hi[1] - m.lo[1], m.hi[0] - m.lo[0]
+            if m.kind == "dft":
+                arr = np.empty((len(m.freqs), len(m.comps), bz, by, bx), dtype=np.complex64)
+            else:
+                arr = np.empty((len(m.steps), len(m.comps), bz, by, bx), dtype=np.float32)
+            self._chk(self.lib.dll.fdtd_get_monitor(self.handle, mid, _ptr(arr), arr.nbytes),
+                      "fdtd_get_monitor")
+            out[m.name] = (arr, (lo2, hi2))
+        return out
+
+    def results(self) -> Dict[str, np.ndarray]:
+        """Single-slab convenience: name -> full array (same layout as the oracle's results())."""
+        return {k: v[0] for k, v in self.monitor_data().items()}
+
+    def close(self):
+        if getattr(self, "handle", None) and self.handle.value:
+            self.lib.dll.fdtd_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False

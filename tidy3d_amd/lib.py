@@ -1,0 +1,113 @@
+"""ctypes binding of libfdtd_hip.so (C ABI: include/fdtd_hip.h).
+
+The library is the product: there is no CPU fallback.  ``load_library()`` raises
+``SolverLibraryError`` when the shared object is missing or cannot be loaded, and
+``FdtdLib.check`` turns every negative status into an exception carrying
+``fdtd_last_error``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+from .exceptions import SolverLibraryError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libfdtd_hip.so")
+
+# every symbol include/fdtd_hip.h declares (tests check the library exports all of them)
+SYMBOLS = (
+    "fdtd_last_error", "fdtd_device_count", "fdtd_create", "fdtd_destroy", "fdtd_set_steps",
+    "fdtd_set_media", "fdtd_set_material", "fdtd_set_pml", "fdtd_add_ade",
+    "fdtd_add_point_source", "fdtd_add_tfsf", "fdtd_add_monitor", "fdtd_get_monitor",
+    "fdtd_set_field", "fdtd_get_field", "fdtd_set_shutoff", "fdtd_comm_unique_id",
+    "fdtd_comm_init", "fdtd_run", "fdtd_get_stats", "fdtd_reset",
+)
+
+BC_PEC, BC_PMC, BC_PERIODIC, BC_NEIGHBOR = 0, 1, 2, 3
+MON_TIME, MON_DFT = 0, 1
+VARIANT_AUTO, VARIANT_SIMPLE, VARIANT_ZMARCH, VARIANT_LDS = 0, 1, 2, 3
+FLAG_TIME_KERNELS = 1
+
+
+class FdtdConfig(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
+                ("bc", C.c_int32 * 6), ("device", C.c_int32), ("variant", C.c_int32),
+                ("flags", C.c_int32), ("z_chunk", C.c_int32), ("ch", C.c_float),
+                ("reserved", C.c_int32 * 6)]
+
+
+class FdtdStats(C.Structure):
+    _fields_ = [("steps_done", C.c_int64), ("diverged", C.c_int32), ("stopped_early", C.c_int32),
+                ("field_decay", C.c_double), ("run_ms", C.c_double), ("h_kernel_ms", C.c_double),
+                ("e_kernel_ms", C.c_double), ("h_kernel_launches", C.c_int64),
+                ("e_kernel_launches", C.c_int64), ("device_bytes", C.c_int64)]
+
+
+PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_int64, C.c_double, C.c_double, C.c_void_p)
+
+
+class FdtdLib:
+    def __init__(self, path: str):
+        self.path = path
+        try:
+            self.dll = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError as e:
+            raise SolverLibraryError(f"cannot load the HIP solver library '{path}': {e}") from e
+        missing = [s for s in SYMBOLS if not hasattr(self.dll, s)]
+        if missing:
+            raise SolverLibraryError(f"'{path}' does not export: {', '.join(missing)}")
+        d = self.dll
+        vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+        d.fdtd_last_error.restype = C.c_char_p
+        d.fdtd_last_error.argtypes = [vp]
+        d.fdtd_device_count.restype = C.c_int
+        d.fdtd_create.argtypes = [C.POINTER(FdtdConfig), C.POINTER(vp)]
+        d.fdtd_destroy.argtypes = [vp]
+        d.fdtd_destroy.restype = None
+        d.fdtd_set_steps.argtypes = [vp, C.c_int, vp, vp, C.c_int]
+        d.fdtd_set_media.argtypes = [vp, vp, vp, C.c_int]
+        d.fdtd_set_material.argtypes = [vp, vp, C.c_size_t]
+        d.fdtd_set_pml.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int]
+        d.fdtd_add_ade.argtypes = [vp, C.c_int, i64, vp, C.c_int, vp, vp, f32]
+        d.fdtd_add_point_source.argtypes = [vp, i64, vp, vp, vp, vp, i64, vp, vp]
+        d.fdtd_add_tfsf.argtypes = [vp, C.c_int, vp, vp, f32, f32, f32, f32, C.c_int, i64, vp,
+                                    i64, vp, vp, vp, vp, i64, vp, vp, vp, vp]
+        d.fdtd_add_monitor.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, i64, vp, C.c_int, vp, vp]
+        d.fdtd_get_monitor.argtypes = [vp, C.c_int, vp, C.c_size_t]
+        d.fdtd_set_field.argtypes = [vp, C.c_int, vp, C.c_size_t]
+        d.fdtd_get_field.argtypes = [vp, C.c_int, vp, C.c_size_t]
+        d.fdtd_set_shutoff.argtypes = [vp, C.c_int, C.c_double, i64]
+        d.fdtd_comm_unique_id.argtypes = [vp]
+        d.fdtd_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+        d.fdtd_run.argtypes = [vp, i64, PROGRESS_FN, vp]
+        d.fdtd_get_stats.argtypes = [vp, C.POINTER(FdtdStats)]
+        d.fdtd_reset.argtypes = [vp]
+
+    def error(self, handle) -> str:
+        msg = self.dll.fdtd_last_error(handle)
+        return msg.decode("utf-8", "replace") if msg else ""
+
+    def check(self, status: int, handle=None, what: str = ""):
+        if status < 0:
+            raise SolverLibraryError(f"{what or 'libfdtd_hip'} failed: {self.error(handle)}")
+        return status
+
+
+_cached: Optional[FdtdLib] = None
+
+
+def load_library(path: Optional[str] = None) -> FdtdLib:
+    """Load the HIP library (in-tree build).  Fails loudly — never substitutes a CPU path."""
+    global _cached
+    if path is None:
+        if _cached is not None:
+            return _cached
+        if not os.path.exists(DEFAULT_LIB):
+            raise SolverLibraryError(
+                f"{DEFAULT_LIB} not found: build it with `python -m tidy3d_amd.build` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback.")
+        _cached = FdtdLib(DEFAULT_LIB)
+        return _cached
+    return FdtdLib(path)

@@ -1,0 +1,1145 @@
+"""tidy3d-free mirror of the part of the ``tidy3d.components`` schema that the
+FDTD hot path consumes.
+
+Why this exists: the solver must accept a ``tidy3d.Simulation``; the real
+package is not importable on the GPU box (h5py/xarray/shapely/autograd are
+absent), so the boundary is defined on tidy3d's *JSON/dict form* — the output
+of ``Simulation.dict()`` / ``.json()`` (fixture: reference
+tests/sims/simulation_sample.json).  ``parse(obj)`` turns such a dict into the
+light classes below; ``tidy3d_amd.adapter`` feeds real tidy3d objects through
+the same path.  Class names, field names, defaults and semantics follow the
+reference (cited per class) so that scripts and tests read like tidy3d's own::
+
+    import tidy3d_amd.schema as td
+    sim = td.Simulation(size=(4, 3, 2), grid_spec=td.GridSpec.uniform(dl=0.05), ...)
+
+Only arithmetic needed by the solver is implemented (grid, dt, pole-residue
+conversion, source waveforms, monitor index spans).  Plotting, validation
+beyond what protects the solver, file IO and the cloud client are out of
+scope.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .constants import (C_0, EPSILON_0, DFT_CUTOFF, END_TIME_FACTOR_GAUSSIAN, fp_eps, inf,
+                        LARGE_NUMBER)
+from .exceptions import SetupError, Tidy3dNotImplementedError, ValidationError
+
+_REGISTRY: Dict[str, type] = {}
+
+
+def _register(cls):
+    _REGISTRY[cls.__name__] = cls
+    return cls
+
+
+def _tup(x):
+    if x is None:
+        return None
+    return tuple(_tup(v) if isinstance(v, (list, tuple)) else v for v in x)
+
+
+def _to_float(v):
+    """tidy3d serialises +-inf as the strings "Infinity" / "-Infinity"."""
+    if isinstance(v, str):
+        return float(v.replace("Infinity", "inf"))
+    return v
+
+
+def _clean(v):
+    if isinstance(v, dict):
+        return parse(v)
+    if isinstance(v, (list, tuple)):
+        return tuple(_clean(x) for x in v)
+    if isinstance(v, str) and v in ("Infinity", "-Infinity", "NaN"):
+        return _to_float(v)
+    return v
+
+
+@dataclass
+class Unsupported:
+    """Placeholder for a schema type the solver does not implement.  Parsing never
+    fails on it; the solver raises ``Tidy3dNotImplementedError`` naming the feature
+    only if the object is actually used (SURVEY.md section 8(b) "Errors")."""
+
+    type: str = ""
+    raw: dict = field(default_factory=dict)
+
+    def fail(self):
+        raise Tidy3dNotImplementedError(
+            f"'{self.type}' is not supported by the MI355X local FDTD solver.")
+
+
+def parse(obj: Any):
+    """dict (tidy3d ``.dict()`` / JSON form, discriminated by ``"type"``) -> mirror object."""
+    if isinstance(obj, (list, tuple)):
+        return tuple(parse(o) for o in obj)
+    if not isinstance(obj, dict):
+        return _to_float(obj) if isinstance(obj, str) and "Infinity" in obj else obj
+    tname = obj.get("type")
+    cls = _REGISTRY.get(tname)
+    if cls is None:
+        return Unsupported(type=str(tname), raw=obj)
+    names = {f.name for f in dataclasses.fields(cls)}
+    kwargs = {}
+    for k, v in obj.items():
+        if k in ("type", "attrs") or k not in names:
+            continue
+        kwargs[k] = _clean(v)
+    return cls(**kwargs)
+
+
+class _Model:
+    """Common helpers (subset of ref components/base.py Tidy3dBaseModel)."""
+
+    @property
+    def type(self) -> str:
+        return self.__class__.__name__
+
+    def copy(self, **update):
+        return dataclasses.replace(self, **update)
+
+    updated_copy = copy
+
+    def dict(self) -> dict:
+        def conv(v):
+            if isinstance(v, _Model):
+                return v.dict()
+            if isinstance(v, (list, tuple)):
+                return [conv(x) for x in v]
+            if isinstance(v, complex):
+                return {"real": v.real, "imag": v.imag}
+            if isinstance(v, np.ndarray):
+                return v.tolist()
+            return v
+        out = {"type": self.type}
+        for f in dataclasses.fields(self):
+            out[f.name] = conv(getattr(self, f.name))
+        return out
+
+
+def _complex(v) -> complex:
+    """tidy3d ComplexNumber JSON form {"real":..,"imag":..} or (re, im) or python complex."""
+    if isinstance(v, dict):
+        return complex(v["real"], v["imag"])
+    if isinstance(v, Unsupported):
+        return complex(v.raw.get("real", 0.0), v.raw.get("imag", 0.0))
+    if isinstance(v, (tuple, list)) and len(v) == 2:
+        return complex(v[0], v[1])
+    return complex(v)
+
+
+# --------------------------------------------------------------------------------------
+# geometry  (ref components/geometry/base.py, primitives.py)
+# --------------------------------------------------------------------------------------
+
+@_register
+@dataclass
+class Box(_Model):
+    """Rectangular prism (ref geometry/base.py:1799; ``inside`` :2043-2067 inclusive <=)."""
+
+    center: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    size: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+
+    def __post_init__(self):
+        self.center = tuple(float(_to_float(c)) for c in self.center)
+        self.size = tuple(float(_to_float(s)) for s in self.size)
+
+    @property
+    def bounds(self):
+        c, s = np.array(self.center), np.array(self.size)
+        with np.errstate(invalid="ignore"):
+            lo = np.where(np.isinf(s), -inf, c - s / 2)
+            hi = np.where(np.isinf(s), inf, c + s / 2)
+        return tuple(lo), tuple(hi)
+
+    def inside(self, x, y, z):
+        x0, y0, z0 = self.center
+        lx, ly, lz = self.size
+        return ((np.abs(x - x0) <= lx / 2) & (np.abs(y - y0) <= ly / 2)
+                & (np.abs(z - z0) <= lz / 2))
+
+    @classmethod
+    def from_bounds(cls, rmin, rmax, **kw):
+        rmin, rmax = np.array(rmin, float), np.array(rmax, float)
+        return cls(center=tuple((rmin + rmax) / 2), size=tuple(rmax - rmin), **kw)
+
+    @property
+    def zero_dims(self) -> List[int]:
+        return [d for d, s in enumerate(self.size) if s == 0]
+
+    def surfaces(self):
+        """Six faces ordered x-,x+,y-,y+,z-,z+ (ref geometry/base.py:1836-1900)."""
+        (x0, y0, z0), (lx, ly, lz) = self.center, self.size
+        c = [(x0 - lx / 2, y0, z0), (x0 + lx / 2, y0, z0), (x0, y0 - ly / 2, z0),
+             (x0, y0 + ly / 2, z0), (x0, y0, z0 - lz / 2), (x0, y0, z0 + lz / 2)]
+        s = [(0, ly, lz)] * 2 + [(lx, 0, lz)] * 2 + [(lx, ly, 0)] * 2
+        names = ["x-", "x+", "y-", "y+", "z-", "z+"]
+        return [(n, Box(center=ci, size=si)) for n, ci, si in zip(names, c, s)]
+
+
+@_register
+@dataclass
+class Sphere(_Model):
+    """ref geometry/primitives.py:36; ``inside`` :44-68 (dist^2 <= r^2)."""
+
+    radius: float = 1.0
+    center: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+
+    @property
+    def bounds(self):
+        c = np.array(self.center, float)
+        return tuple(c - self.radius), tuple(c + self.radius)
+
+    def inside(self, x, y, z):
+        x0, y0, z0 = self.center
+        return ((x - x0) ** 2 + (y - y0) ** 2 + (z - z0) ** 2) <= self.radius ** 2
+
+
+@_register
+@dataclass
+class Cylinder(_Model):
+    """ref geometry/primitives.py:179; straight side walls only (sidewall_angle == 0)."""
+
+    radius: float = 1.0
+    length: float = 1.0
+    axis: int = 2
+    center: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    sidewall_angle: float = 0.0
+    reference_plane: str = "middle"
+
+    def __post_init__(self):
+        self.length = float(_to_float(self.length))
+        if self.sidewall_angle != 0.0:
+            raise Tidy3dNotImplementedError("Cylinder.sidewall_angle != 0 is not supported.")
+
+    @property
+    def bounds(self):
+        c = np.array(self.center, float)
+        h = np.full(3, self.radius)
+        h[self.axis] = self.length / 2
+        return tuple(c - h), tuple(c + h)
+
+    def inside(self, x, y, z):
+        p = [x, y, z]
+        c = list(self.center)
+        za = p.pop(self.axis)
+        z0 = c.pop(self.axis)
+        r2 = (p[0] - c[0]) ** 2 + (p[1] - c[1]) ** 2
+        return (r2 <= self.radius ** 2) & (np.abs(za - z0) <= self.length / 2)
+
+
+# --------------------------------------------------------------------------------------
+# media  (ref components/medium.py)
+# --------------------------------------------------------------------------------------
+
+class _AbstractMedium(_Model):
+    is_pec = False
+
+    def pole_residue(self) -> Tuple[float, float, Tuple[Tuple[complex, complex], ...]]:
+        """(eps_inf, conductivity, ((a_k, c_k), ...)) with
+        eps(w) = eps_inf + i sigma/(w eps0) - sum_k [c_k/(jw + a_k) + c_k*/(jw + a_k*)]
+        (ref medium.py:2900-2913; e^{-iwt} convention, ref medium.py:1016-1038)."""
+        raise NotImplementedError
+
+    def eps_model(self, frequency):
+        eps_inf, sigma, poles = self.pole_residue()
+        w = 2 * np.pi * np.asarray(frequency, dtype=float)
+        eps = eps_inf + 0j * w
+        if sigma:
+            eps = eps + 1j * sigma / (w * EPSILON_0)
+        for a, c in poles:
+            eps = eps - c / (1j * w + a) - np.conj(c) / (1j * w + np.conj(a))
+        return eps
+
+    @property
+    def n_cfl(self) -> float:
+        """ref medium.py:1591 (sqrt(eps)), :2744 (sqrt(eps_inf)), :1482 (PEC -> 1)."""
+        eps_inf = self.pole_residue()[0]
+        return float(np.real(np.sqrt(complex(eps_inf))))
+
+
+@_register
+@dataclass
+class Medium(_AbstractMedium):
+    """Dispersionless medium (ref medium.py:1499)."""
+
+    permittivity: float = 1.0
+    conductivity: float = 0.0
+    name: Optional[str] = None
+    frequency_range: Optional[Tuple[float, float]] = None
+
+    def __post_init__(self):
+        if self.permittivity < 1.0:
+            raise ValidationError("Medium.permittivity must be >= 1.")
+
+    def pole_residue(self):
+        return float(self.permittivity), float(self.conductivity), ()
+
+    @classmethod
+    def from_nk(cls, n: float, k: float, freq: float, **kw):
+        """ref medium.py:63-83 test + AbstractMedium.nk_to_eps_sigma."""
+        eps_c = (n + 1j * k) ** 2
+        sigma = 2 * np.pi * freq * eps_c.imag * EPSILON_0
+        return cls(permittivity=eps_c.real, conductivity=sigma, **kw)
+
+
+@_register
+@dataclass
+class PECMedium(_AbstractMedium):
+    """Perfect electric conductor (ref medium.py:1454)."""
+
+    name: Optional[str] = None
+    is_pec = True
+
+    def pole_residue(self):
+        return 1.0, 0.0, ()
+
+    @property
+    def n_cfl(self):
+        return 1.0
+
+    def eps_model(self, frequency):
+        return -1e8 + 0j * np.asarray(frequency, float)   # pec_val, ref constants.py:64
+
+
+PEC = PECMedium(name="PEC")
+
+
+@_register
+@dataclass
+class PoleResidue(_AbstractMedium):
+    """ref medium.py:2843; eps(w) formula :2900-2913."""
+
+    eps_inf: float = 1.0
+    poles: Tuple[Tuple[complex, complex], ...] = ()
+    name: Optional[str] = None
+    frequency_range: Optional[Tuple[float, float]] = None
+
+    def __post_init__(self):
+        self.poles = tuple((_complex(a), _complex(c)) for a, c in self.poles)
+
+    def pole_residue(self):
+        return float(self.eps_inf), 0.0, self.poles
+
+
+@_register
+@dataclass
+class Lorentz(_AbstractMedium):
+    """eps = eps_inf + sum de f^2/(f^2 - 2j f delta - f_^2) (ref medium.py:3943; poles :4021-4047)."""
+
+    eps_inf: float = 1.0
+    coeffs: Tuple[Tuple[float, float, float], ...] = ()
+    name: Optional[str] = None
+    frequency_range: Optional[Tuple[float, float]] = None
+
+    def pole_residue(self):
+        poles = []
+        for de, f, delta in self.coeffs:
+            w = 2 * np.pi * f
+            d = 2 * np.pi * delta
+            if d * d > w * w:                       # over-damped: two real poles
+                r = np.sqrt(d * d - w * w) + 0j
+                c0 = de * w ** 2 / 4 / r
+                poles.append((-d + r, c0))
+                poles.append((-d - r, -c0))
+            else:
+                r = np.sqrt(w * w - d * d)
+                poles.append((complex(-d, -r), 1j * de * w ** 2 / 2 / r))
+        return float(self.eps_inf), 0.0, tuple(poles)
+
+
+@_register
+@dataclass
+class Drude(_AbstractMedium):
+    """eps = eps_inf - sum f^2/(f_^2 + j f_ delta) (ref medium.py:4327; poles :4384-4409)."""
+
+    eps_inf: float = 1.0
+    coeffs: Tuple[Tuple[float, float], ...] = ()
+    name: Optional[str] = None
+    frequency_range: Optional[Tuple[float, float]] = None
+
+    def pole_residue(self):
+        poles = []
+        for f, delta in self.coeffs:
+            w = 2 * np.pi * f
+            d = 2 * np.pi * delta
+            c0 = (w ** 2) / 2 / d + 0j
+            poles.append((0j, c0))
+            poles.append((-d + 0j, -c0))
+        return float(self.eps_inf), 0.0, tuple(poles)
+
+
+@_register
+@dataclass
+class Sellmeier(_AbstractMedium):
+    """n^2 = 1 + sum B l^2/(l^2 - C) (ref medium.py:3584; poles :3677-3686)."""
+
+    coeffs: Tuple[Tuple[float, float], ...] = ()
+    name: Optional[str] = None
+    frequency_range: Optional[Tuple[float, float]] = None
+
+    def pole_residue(self):
+        poles = []
+        for B, C in self.coeffs:
+            beta = 2 * np.pi * C_0 / np.sqrt(C)
+            alpha = -0.5 * beta * B
+            poles.append((1j * beta, 1j * alpha))
+        return 1.0, 0.0, tuple(poles)
+
+
+@_register
+@dataclass
+class Debye(_AbstractMedium):
+    """eps = eps_inf + sum de/(1 - j f tau) (ref medium.py:4579; poles :4652-4666)."""
+
+    eps_inf: float = 1.0
+    coeffs: Tuple[Tuple[float, float], ...] = ()
+    name: Optional[str] = None
+    frequency_range: Optional[Tuple[float, float]] = None
+
+    def pole_residue(self):
+        poles = []
+        for de, tau in self.coeffs:
+            a = -2 * np.pi / tau + 0j
+            poles.append((a, -0.5 * de * a))
+        return float(self.eps_inf), 0.0, tuple(poles)
+
+
+@_register
+@dataclass
+class Structure(_Model):
+    """geometry + medium (ref components/structure.py:147)."""
+
+    geometry: Any = None
+    medium: Any = None
+    name: Optional[str] = None
+
+
+# --------------------------------------------------------------------------------------
+# grid specification  (ref components/grid/grid_spec.py)
+# --------------------------------------------------------------------------------------
+
+@_register
+@dataclass
+class UniformGrid(_Model):
+    """ref grid_spec.py:212; coords :237-269 (N = ceil(size/dl), dl snapped to tile size)."""
+
+    dl: float = 0.1
+
+    def make_coords_initial(self, center: float, size: float) -> np.ndarray:
+        num_cells = max(int(np.ceil(size / self.dl)), 1)
+        dl_snapped = size / num_cells if size > 0 else self.dl
+        return center - size / 2 + np.arange(num_cells + 1) * dl_snapped
+
+
+@_register
+@dataclass
+class CustomGrid(_Model):
+    """ref grid_spec.py:316; coords :350-385 + _postprocess_unaligned_grid :137-210."""
+
+    dl: Tuple[float, ...] = ()
+    custom_offset: Optional[float] = None
+
+    def make_coords_initial(self, center: float, size: float) -> np.ndarray:
+        b = np.append(0.0, np.cumsum(np.array(self.dl, float)))
+        if self.custom_offset is None:
+            b = b + (center - b[-1] / 2)
+        else:
+            b = b + self.custom_offset
+        relax = self.custom_offset is not None
+        bmin = np.nextafter(np.float32(center - size / 2), np.float32(-inf), dtype=np.float32)
+        bmax = np.nextafter(np.float32(center + size / 2), np.float32(inf), dtype=np.float32)
+        if bmax < b[0] or bmin > b[-1]:
+            raise SetupError("Simulation domain does not overlap with the provided grid.")
+        if size == 0:
+            ind = min(int(np.searchsorted(b, center, side="right")), len(b) - 1)
+            return b[ind - 1: ind + 1]
+        b = b[b <= bmax]
+        b = b[b >= bmin]
+        dl_min, dl_max = b[1] - b[0], b[-1] - b[-2]
+        while b[0] - dl_min >= bmin:
+            b = np.insert(b, 0, b[0] - dl_min)
+        while b[-1] + dl_max <= bmax:
+            b = np.append(b, b[-1] + dl_max)
+        if relax:
+            if np.isclose(b[0] - dl_min, bmin):
+                b = np.insert(b, 0, b[0] - dl_min)
+            if np.isclose(b[-1] + dl_max, bmax):
+                b = np.append(b, b[-1] + dl_max)
+        return b
+
+
+@_register
+@dataclass
+class CustomGridBoundaries(_Model):
+    """ref grid_spec.py:272: explicit boundary coordinates."""
+
+    coords: Tuple[float, ...] = ()
+
+    def make_coords_initial(self, center: float, size: float) -> np.ndarray:
+        b = np.array(self.coords, float)
+        return CustomGrid(dl=tuple(np.diff(b)), custom_offset=float(b[0])).make_coords_initial(
+            center, size)
+
+
+@_register
+@dataclass
+class GridSpec(_Model):
+    """ref grid_spec.py:520; ``make_grid`` :670; ``uniform`` classmethod :745."""
+
+    grid_x: Any = None
+    grid_y: Any = None
+    grid_z: Any = None
+    wavelength: Optional[float] = None
+
+    @classmethod
+    def uniform(cls, dl: float) -> "GridSpec":
+        return cls(grid_x=UniformGrid(dl=dl), grid_y=UniformGrid(dl=dl), grid_z=UniformGrid(dl=dl))
+
+    @property
+    def grids_1d(self):
+        return [self.grid_x, self.grid_y, self.grid_z]
+
+
+# --------------------------------------------------------------------------------------
+# boundaries  (ref components/boundary.py)
+# --------------------------------------------------------------------------------------
+
+@_register
+@dataclass
+class PMLParams(_Model):
+    """ref boundary.py:195-227; defaults = DefaultPMLParameters :233-243. sigma/alpha in
+    units of 2*EPSILON_0/dt (ref constants.py:120)."""
+
+    sigma_order: int = 3
+    sigma_min: float = 0.0
+    sigma_max: float = 1.5
+    kappa_order: int = 3
+    kappa_min: float = 1.0
+    kappa_max: float = 3.0
+    alpha_order: int = 1
+    alpha_min: float = 0.0
+    alpha_max: float = 0.0
+
+
+DefaultPMLParameters = PMLParams()
+DefaultStablePMLParameters = PMLParams(sigma_order=3, sigma_min=0.0, sigma_max=1.0,
+                                       kappa_order=3, kappa_min=1.0, kappa_max=5.0,
+                                       alpha_order=1, alpha_min=0.0, alpha_max=0.9)
+
+
+@_register
+@dataclass
+class PML(_Model):
+    """ref boundary.py:275 (12 layers :379)."""
+
+    num_layers: int = 12
+    parameters: PMLParams = field(default_factory=PMLParams)
+    name: Optional[str] = None
+
+
+@_register
+@dataclass
+class StablePML(_Model):
+    """ref boundary.py:392 (40 layers, DefaultStablePMLParameters :244)."""
+
+    num_layers: int = 40
+    parameters: PMLParams = field(default_factory=lambda: dataclasses.replace(
+        DefaultStablePMLParameters))
+    name: Optional[str] = None
+
+
+@_register
+@dataclass
+class PECBoundary(_Model):
+    """ref boundary.py:40."""
+    name: Optional[str] = None
+
+
+@_register
+@dataclass
+class PMCBoundary(_Model):
+    """ref boundary.py:45."""
+    name: Optional[str] = None
+
+
+@_register
+@dataclass
+class Periodic(_Model):
+    """ref boundary.py:27."""
+    name: Optional[str] = None
+
+
+@_register
+@dataclass
+class Boundary(_Model):
+    """Pair of edges along one axis (ref boundary.py:492); default PML both (:520-531)."""
+
+    plus: Any = field(default_factory=PML)
+    minus: Any = field(default_factory=PML)
+
+    def __post_init__(self):
+        per = [isinstance(e, Periodic) for e in (self.plus, self.minus)]
+        if any(per) and not all(per):
+            raise SetupError("Periodic boundaries must be applied on both sides of an axis "
+                             "(ref boundary.py:536-560).")
+
+    @classmethod
+    def pml(cls, num_layers: int = 12, parameters: PMLParams = None):
+        p = parameters or PMLParams()
+        return cls(plus=PML(num_layers=num_layers, parameters=p),
+                   minus=PML(num_layers=num_layers, parameters=p))
+
+    @classmethod
+    def stable_pml(cls, num_layers: int = 40, parameters: PMLParams = None):
+        p = parameters or dataclasses.replace(DefaultStablePMLParameters)
+        return cls(plus=StablePML(num_layers=num_layers, parameters=p),
+                   minus=StablePML(num_layers=num_layers, parameters=p))
+
+    @classmethod
+    def pec(cls):
+        return cls(plus=PECBoundary(), minus=PECBoundary())
+
+    @classmethod
+    def pmc(cls):
+        return cls(plus=PMCBoundary(), minus=PMCBoundary())
+
+    @classmethod
+    def periodic(cls):
+        return cls(plus=Periodic(), minus=Periodic())
+
+
+@_register
+@dataclass
+class BoundarySpec(_Model):
+    """ref boundary.py:732."""
+
+    x: Boundary = field(default_factory=Boundary)
+    y: Boundary = field(default_factory=Boundary)
+    z: Boundary = field(default_factory=Boundary)
+
+    @classmethod
+    def all_sides(cls, boundary):
+        mk = lambda: Boundary(plus=dataclasses.replace(boundary), minus=dataclasses.replace(boundary))
+        return cls(x=mk(), y=mk(), z=mk())
+
+    @classmethod
+    def pml(cls, x: bool = False, y: bool = False, z: bool = False):
+        """PML along the flagged axes, periodic elsewhere (ref boundary.py:803-831)."""
+        mk = lambda f: Boundary.pml() if f else Boundary.periodic()
+        return cls(x=mk(x), y=mk(y), z=mk(z))
+
+    @classmethod
+    def pec(cls, x: bool = False, y: bool = False, z: bool = False):
+        mk = lambda f: Boundary.pec() if f else Boundary.periodic()
+        return cls(x=mk(x), y=mk(y), z=mk(z))
+
+    @property
+    def to_list(self):
+        return [(self.x.minus, self.x.plus), (self.y.minus, self.y.plus),
+                (self.z.minus, self.z.plus)]
+
+
+# --------------------------------------------------------------------------------------
+# source time dependence  (ref components/source.py:60-260, components/time.py)
+# --------------------------------------------------------------------------------------
+
+class _SourceTime(_Model):
+
+    @property
+    def twidth(self) -> float:
+        return 1.0 / (2 * np.pi * self.fwidth)
+
+    def frequency_range(self, num_fwidth: float = 4.0):
+        """ref source.py:133-153."""
+        w = num_fwidth * self.fwidth
+        return (max(0.0, self.freq0 - w), self.freq0 + w)
+
+    def spectrum(self, times, freqs, dt):
+        """dt/sqrt(2 pi) * sum_n Re[amp(t_n)] e^{+i 2 pi f t_n}, times cut where the relative
+        amplitude is below DFT_CUTOFF (ref time.py:46-105)."""
+        times = np.asarray(times, float)
+        freqs = np.atleast_1d(np.asarray(freqs, float))
+        amps = np.real(self.amp_time(times))
+        if np.all(amps == 0.0):
+            return np.zeros(len(freqs), complex)
+        rel = np.where(np.abs(amps) / np.amax(np.abs(amps)) > DFT_CUTOFF)[0]
+        lo, hi = rel[0], rel[-1] + 1
+        amps, tcut = amps[lo:hi], times[lo:hi]
+        if tcut.size == 0:
+            return np.zeros(len(freqs), complex)
+        # blocked exact evaluation of the DTFT sum (the reference uses a running product)
+        out = np.zeros(len(freqs), complex)
+        for s in range(0, tcut.size, 8192):
+            ph = np.exp(2j * np.pi * freqs[:, None] * tcut[None, s:s + 8192])
+            out += ph @ amps[s:s + 8192]
+        return dt * out / np.sqrt(2 * np.pi)
+
+
+@_register
+@dataclass
+class GaussianPulse(_SourceTime):
+    """ref source.py:155; ``amp_time`` :174-193; ``end_time`` :195-202."""
+
+    freq0: float = 1.0
+    fwidth: float = 1.0
+    offset: float = 5.0
+    amplitude: float = 1.0
+    phase: float = 0.0
+    remove_dc_component: bool = True
+
+    def __post_init__(self):
+        if self.offset < 2.5:
+            raise ValidationError("GaussianPulse.offset must be >= 2.5 (ref source.py:127).")
+
+    def amp_time(self, time):
+        time = np.asarray(time, float)
+        omega0 = 2 * np.pi * self.freq0
+        ts = time - self.offset * self.twidth
+        amp = (np.exp(1j * self.phase) * np.exp(-1j * omega0 * time)
+               * np.exp(-(ts ** 2) / 2 / self.twidth ** 2) * self.amplitude)
+        if self.remove_dc_component:
+            return amp * (1j + ts / self.twidth ** 2 / omega0)
+        return amp * 1j
+
+    def end_time(self):
+        return self.offset * self.twidth + END_TIME_FACTOR_GAUSSIAN * self.twidth
+
+    @property
+    def amp_complex(self):
+        return self.amplitude * np.exp(1j * self.phase)
+
+
+@_register
+@dataclass
+class ContinuousWave(_SourceTime):
+    """ref source.py:226; ``amp_time`` :239-252."""
+
+    freq0: float = 1.0
+    fwidth: float = 1.0
+    offset: float = 5.0
+    amplitude: float = 1.0
+    phase: float = 0.0
+
+    def amp_time(self, time):
+        time = np.asarray(time, float)
+        omega0 = 2 * np.pi * self.freq0
+        ts = time - self.offset * self.twidth
+        return (np.exp(1j * self.phase) * np.exp(-1j * omega0 * time)
+                / (1 + np.exp(-ts / self.twidth)) * self.amplitude)
+
+    def end_time(self):
+        return None
+
+    @property
+    def amp_complex(self):
+        return self.amplitude * np.exp(1j * self.phase)
+
+
+# --------------------------------------------------------------------------------------
+# sources  (ref components/source.py)
+# --------------------------------------------------------------------------------------
+
+class _Source(_Model):
+
+    @property
+    def geometry(self) -> Box:
+        return Box(center=self.center, size=self.size)
+
+
+@_register
+@dataclass
+class UniformCurrentSource(_Source):
+    """ref source.py:585."""
+
+    source_time: Any = None
+    polarization: str = "Ez"
+    center: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    size: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    interpolate: bool = True
+    confine_to_bounds: bool = False
+    name: Optional[str] = None
+
+
+@_register
+@dataclass
+class PointDipole(_Source):
+    """ref source.py:600 (size fixed to (0,0,0) :624)."""
+
+    source_time: Any = None
+    polarization: str = "Ez"
+    center: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    size: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    interpolate: bool = True
+    confine_to_bounds: bool = False
+    name: Optional[str] = None
+
+    def __post_init__(self):
+        if tuple(self.size) != (0, 0, 0):
+            raise ValidationError("PointDipole.size must be (0, 0, 0).")
+
+
+@_register
+@dataclass
+class PlaneWave(_Source):
+    """ref source.py:1090; polarisation vector :966-990 (pol_angle = 0 -> E along the first
+    tangential axis ... for z injection: Ex)."""
+
+    source_time: Any = None
+    center: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    size: Tuple[float, float, float] = (inf, inf, 0.0)
+    direction: str = "+"
+    angle_theta: float = 0.0
+    angle_phi: float = 0.0
+    pol_angle: float = 0.0
+    num_freqs: int = 1
+    name: Optional[str] = None
+
+    @property
+    def injection_axis(self) -> int:
+        zd = [d for d, s in enumerate(self.size) if s == 0]
+        if len(zd) != 1:
+            raise SetupError("PlaneWave must have exactly one zero-size dimension.")
+        return zd[0]
+
+
+@_register
+@dataclass
+class TFSF(_Source):
+    """Total-field/scattered-field box source (ref source.py:1204-1257): plane wave
+    of 1 W/um^2 along ``injection_axis`` inside the box, nothing outside."""
+
+    source_time: Any = None
+    center: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    size: Tuple[float, float, float] = (1.0, 1.0, 1.0)
+    injection_axis: int = 2
+    direction: str = "+"
+    angle_theta: float = 0.0
+    angle_phi: float = 0.0
+    pol_angle: float = 0.0
+    num_freqs: int = 1
+    name: Optional[str] = None
+
+
+@_register
+@dataclass
+class ModeSpec(_Model):
+    """ref components/mode.py:18-209."""
+
+    num_modes: int = 1
+    target_neff: Optional[float] = None
+    num_pml: Tuple[int, int] = (0, 0)
+    filter_pol: Optional[str] = None
+    angle_theta: float = 0.0
+    angle_phi: float = 0.0
+    precision: str = "single"
+    bend_radius: Optional[float] = None
+    bend_axis: Optional[int] = None
+    track_freq: Optional[str] = "central"
+    group_index_step: Any = False
+
+
+@_register
+@dataclass
+class ModeSource(_Source):
+    """ref source.py:993-1085: injects mode ``mode_index`` carrying 1 W at freq0."""
+
+    source_time: Any = None
+    center: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    size: Tuple[float, float, float] = (inf, inf, 0.0)
+    direction: str = "+"
+    mode_spec: ModeSpec = field(default_factory=ModeSpec)
+    mode_index: int = 0
+    num_freqs: int = 1
+    name: Optional[str] = None
+
+    @property
+    def injection_axis(self) -> int:
+        zd = [d for d, s in enumerate(self.size) if s == 0]
+        if len(zd) != 1:
+            raise SetupError("ModeSource must be planar.")
+        return zd[0]
+
+
+# --------------------------------------------------------------------------------------
+# monitors  (ref components/monitor.py)
+# --------------------------------------------------------------------------------------
+
+@_register
+@dataclass
+class ApodizationSpec(_Model):
+    """ref components/apodization.py:8-102 (Gaussian ramps :87-94)."""
+
+    start: Optional[float] = None
+    end: Optional[float] = None
+    width: Optional[float] = None
+
+    def window(self, times) -> np.ndarray:
+        times = np.asarray(times, float)
+        amp = np.ones_like(times)
+        if self.start is not None:
+            m = times < self.start
+            amp[m] *= np.exp(-0.5 * ((times[m] - self.start) / self.width) ** 2)
+        if self.end is not None:
+            m = times > self.end
+            amp[m] *= np.exp(-0.5 * ((times[m] - self.end) / self.width) ** 2)
+        return amp
+
+
+class _Monitor(_Model):
+
+    @property
+    def geometry(self) -> Box:
+        return Box(center=self.center, size=self.size)
+
+
+_ALL_FIELDS = ("Ex", "Ey", "Ez", "Hx", "Hy", "Hz")
+
+
+class _TimeMonitorMixin:
+
+    def time_inds(self, tmesh) -> Tuple[int, int]:
+        """ref monitor.py:187-214."""
+        tmesh = np.asarray(tmesh)
+        beg, end = 0, 0
+        if tmesh.size == 0:
+            return beg, end
+        t_stop = self.stop
+        if t_stop is None:
+            end = int(tmesh.size)
+            t_stop = tmesh[-1]
+        else:
+            tend = np.nonzero(tmesh <= t_stop)[0]
+            if tend.size > 0:
+                end = int(tend[-1] + 1)
+        dt = 1e-20 if tmesh.size < 2 else tmesh[1] - tmesh[0]
+        if np.abs(self.start - t_stop) < dt and self.start <= tmesh[-1]:
+            beg = max(end - 1, 0)
+        else:
+            tbeg = np.nonzero(tmesh[:end] >= self.start)[0]
+            beg = int(tbeg[0]) if tbeg.size > 0 else end
+        return beg, end
+
+    def num_steps(self, tmesh) -> int:
+        """ref monitor.py:216-220."""
+        b, e = self.time_inds(tmesh)
+        return int((e - b) / self.interval)
+
+
+@_register
+@dataclass
+class FieldMonitor(_Monitor):
+    """Frequency-domain field monitor (ref monitor.py:363)."""
+
+    center: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    size: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    name: str = "field"
+    freqs: Tuple[float, ...] = ()
+    fields: Tuple[str, ...] = _ALL_FIELDS
+    interval_space: Tuple[int, int, int] = (1, 1, 1)
+    colocate: bool = True
+    apodization: ApodizationSpec = field(default_factory=ApodizationSpec)
+
+    def frequency_range(self):
+        return (min(self.freqs), max(self.freqs))
+
+
+@_register
+@dataclass
+class FieldTimeMonitor(_Monitor, _TimeMonitorMixin):
+    """Time-domain field monitor (ref monitor.py:403)."""
+
+    center: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    size: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    name: str = "field_time"
+    start: float = 0.0
+    stop: Optional[float] = None
+    interval: Optional[int] = None
+    fields: Tuple[str, ...] = _ALL_FIELDS
+    interval_space: Tuple[int, int, int] = (1, 1, 1)
+    colocate: bool = True
+
+    def __post_init__(self):
+        if self.interval is None:      # ref monitor.py:151-170: None -> 1 (with a warning)
+            self.interval = 1
+
+
+@_register
+@dataclass
+class FluxMonitor(_Monitor):
+    """Frequency-domain power flux through a plane or out of a box (ref monitor.py:569)."""
+
+    center: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    size: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    name: str = "flux"
+    freqs: Tuple[float, ...] = ()
+    normal_dir: Optional[str] = None
+    exclude_surfaces: Optional[Tuple[str, ...]] = None
+    interval_space: Tuple[int, int, int] = (1, 1, 1)
+    colocate: bool = True
+    apodization: ApodizationSpec = field(default_factory=ApodizationSpec)
+
+    def __post_init__(self):
+        nz = sum(1 for s in self.size if s == 0)
+        if nz == 1 and self.normal_dir is None:
+            self.normal_dir = "+"      # ref monitor.py:237-247 (planar default)
+
+    def frequency_range(self):
+        return (min(self.freqs), max(self.freqs))
+
+
+@_register
+@dataclass
+class FluxTimeMonitor(_Monitor, _TimeMonitorMixin):
+    """Time-domain power flux (ref monitor.py:602)."""
+
+    center: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    size: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    name: str = "flux_time"
+    start: float = 0.0
+    stop: Optional[float] = None
+    interval: Optional[int] = None
+    normal_dir: Optional[str] = None
+    exclude_surfaces: Optional[Tuple[str, ...]] = None
+    interval_space: Tuple[int, int, int] = (1, 1, 1)
+    colocate: bool = True
+
+    def __post_init__(self):
+        if self.interval is None:
+            self.interval = 1
+        nz = sum(1 for s in self.size if s == 0)
+        if nz == 1 and self.normal_dir is None:
+            self.normal_dir = "+"
+
+
+@_register
+@dataclass
+class ModeMonitor(_Monitor):
+    """Modal decomposition on a plane (ref monitor.py:631)."""
+
+    center: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    size: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    name: str = "mode"
+    freqs: Tuple[float, ...] = ()
+    mode_spec: ModeSpec = field(default_factory=ModeSpec)
+    interval_space: Tuple[int, int, int] = (1, 1, 1)
+    colocate: bool = False
+    store_fields_direction: Optional[str] = None
+    apodization: ApodizationSpec = field(default_factory=ApodizationSpec)
+
+    def frequency_range(self):
+        return (min(self.freqs), max(self.freqs))
+
+
+@_register
+@dataclass
+class RunTimeSpec(_Model):
+    """ref components/run_time_spec.py; evaluated in Simulation._run_time (simulation.py:3677)."""
+
+    quality_factor: float = 1.0
+    source_factor: float = 3.0
+
+
+@_register
+@dataclass
+class Staircasing(_Model):
+    """ref components/subpixel_spec.py (selection only; courant_ratio == 1)."""
+    courant_ratio = 1.0
+
+
+@_register
+@dataclass
+class SubpixelSpec(_Model):
+    """ref components/subpixel_spec.py:117.  This solver staircases every interface (the
+    averaging algorithms are server-side and absent from the reference);
+    the spec is honoured only through ``courant_ratio`` (:148)."""
+
+    dielectric: Any = None
+    metal: Any = None
+    pec: Any = None
+
+    def courant_ratio(self, contain_pec_structures: bool) -> float:
+        if contain_pec_structures and self.pec is not None:
+            raw = getattr(self.pec, "raw", None)
+            if isinstance(raw, dict) and raw.get("type") == "PECConformal":
+                # PECConformal.courant_ratio = 1 - timestep_reduction (default 0.3)
+                return 1.0 - float(raw.get("timestep_reduction", 0.3))
+            return float(getattr(self.pec, "courant_ratio", 1.0))
+        return 1.0
+
+
+# --------------------------------------------------------------------------------------
+# Simulation
+# --------------------------------------------------------------------------------------
+
+@_register
+@dataclass
+class Simulation(_Model):
+    """The problem statement (ref components/simulation.py:1580; fields: base_sim/simulation.py
+    :28-99, simulation.py:1683-2199).  Derived discretisation quantities live in
+    ``tidy3d_amd.discretize`` (grid, dt, tmesh, nyquist_step, monitor index spans)."""
+
+    size: Tuple[float, float, float] = (1.0, 1.0, 1.0)
+    center: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    run_time: Any = 1e-12
+    medium: Any = field(default_factory=Medium)
+    structures: Tuple[Structure, ...] = ()
+    symmetry: Tuple[int, int, int] = (0, 0, 0)
+    sources: Tuple[Any, ...] = ()
+    boundary_spec: BoundarySpec = field(default_factory=BoundarySpec)
+    monitors: Tuple[Any, ...] = ()
+    grid_spec: GridSpec = field(default_factory=GridSpec)
+    courant: float = 0.99
+    normalize_index: Optional[int] = 0
+    shutoff: float = 1e-5
+    subpixel: Any = True
+
+    def __post_init__(self):
+        self.size = tuple(float(s) for s in self.size)
+        self.center = tuple(float(c) for c in self.center)
+        self.structures = tuple(self.structures)
+        self.sources = tuple(self.sources)
+        self.monitors = tuple(self.monitors)
+        names = [m.name for m in self.monitors if not isinstance(m, Unsupported)]
+        if len(set(names)) != len(names):
+            raise SetupError("Monitor names must be unique (ref base_sim/simulation.py:122).")
+        if not (0 < self.courant <= 1):
+            raise ValidationError("courant must be in (0, 1].")
+
+    @classmethod
+    def from_dict(cls, d: dict) -> "Simulation":
+        sim = parse(d)
+        if not isinstance(sim, Simulation):
+            raise SetupError("dict does not describe a tidy3d Simulation")
+        return sim
+
+    @classmethod
+    def from_file(cls, fname: str) -> "Simulation":
+        import json
+        with open(fname) as f:
+            return cls.from_dict(json.load(f))
+
+    @property
+    def geometry(self) -> Box:
+        return Box(center=self.center, size=self.size)
+
+    @property
+    def mediums(self):
+        """Distinct media, background first (ref scene.py:192)."""
+        out = [self.medium]
+        for s in self.structures:
+            if not any(s.medium is m or s.medium == m for m in out):
+                out.append(s.medium)
+        return out
+
+    def validate_pre_upload(self, source_required: bool = True):
+        """ref simulation.py:3341-3361: a run needs at least one source."""
+        if source_required and len(self.sources) == 0:
+            raise SetupError("No sources in simulation.")

@@ -1,0 +1,40 @@
+"""Source discretisation: tidy3d source objects -> SolverSpec source lists, plus the
+frequency-domain normalisation spectrum of each source (ref sim_data.py:931-953)."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import schema as td
+from .discretize import current_source
+from .exceptions import Tidy3dNotImplementedError
+
+
+def _spectrum_fn(src, tmesh, dt):
+    """Normalisation spectrum: the DTFT (ref time.py:46-105) of the samples that are actually
+    injected.  Currents enter the E-update at t_n + dt/2, so the time axis is shifted by dt/2;
+    monitor DFTs use the true sample times as well, hence no spurious frequency-dependent phase
+    between fields and source (CHANGELOG:1292)."""
+    st = src.source_time
+
+    def fn(freqs):
+        return st.spectrum(tmesh + dt / 2, np.asarray(freqs, float), dt)
+    return fn
+
+
+def build_sources(disc, mt) -> None:
+    sim, spec, tmesh = disc.sim, disc.spec, disc.tmesh
+    disc.source_norm = []
+    for src in sim.sources:
+        if isinstance(src, td.Unsupported):
+            src.fail()
+        if isinstance(src, (td.PointDipole, td.UniformCurrentSource)):
+            spec.sources.append(current_source(spec, mt, src, tmesh))
+            disc.source_norm.append(_spectrum_fn(src, tmesh, spec.dt))
+        elif isinstance(src, (td.PlaneWave, td.TFSF)):
+            from .planewave import build_planewave
+            disc.source_norm.append(build_planewave(disc, mt, src))
+        elif isinstance(src, td.ModeSource):
+            from .modesource import build_mode_source
+            disc.source_norm.append(build_mode_source(disc, mt, src))
+        else:
+            raise Tidy3dNotImplementedError(f"source type '{src.type}' is not supported")

@@ -1,0 +1,198 @@
+"""SolverSpec: the tidy3d-free, plain-array statement of one FDTD run.
+
+This is the stratum between the schema (``tidy3d_amd.schema`` / a real
+``tidy3d.Simulation``) and the two consumers that must agree bit-for-bit on
+*what* is being solved: the HIP engine (``tidy3d_amd.engine`` ->
+``libfdtd_hip.so``) and the fp64 NumPy oracle (``oracle/fdtd_numpy.py``).
+Everything here is numpy arrays and POD scalars (SURVEY.md section 7 "Design stance").
+
+Array layout convention (identical on host, in the oracle and in HBM):
+fields are ``[nz][ny][nx]`` C-ordered, i.e. **x is the fastest index**; an
+xy-plane of one component is one contiguous block (what a z-slab halo
+exchange sends).  Yee staggering follows reference grid/grid.py:465-491:
+``Ex[k,j,i]`` sits at (xc[i], yb[j], zb[k]), ``Hx[k,j,i]`` at (xb[i], yc[j], zc[k]),
+with ``b`` = cell boundaries and ``c`` = cell centres.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+COMPONENTS = ("Ex", "Ey", "Ez", "Hx", "Hy", "Hz")
+COMP_ID = {c: i for i, c in enumerate(COMPONENTS)}
+
+BC_PEC = 0        # tangential E = 0 on the wall (also what backs every PML)
+BC_PMC = 1        # tangential H = 0 on the wall (supported on the min side only)
+BC_PERIODIC = 2
+
+
+@dataclass
+class MediumCoeffs:
+    """One entry of the material table; index 0 is always PEC."""
+
+    eps_inf: float = 1.0
+    sigma: float = 0.0                                   # S/um
+    poles: Tuple[Tuple[complex, complex], ...] = ()      # (a_k, c_k) rad/s, ref medium.py:2900
+    pec: bool = False
+    name: str = ""
+
+
+@dataclass
+class PmlFace:
+    """CPML profile of one face (ref boundary.py:195-254; units of sigma/alpha: 2 eps0/dt)."""
+
+    num_layers: int = 0
+    sigma_order: int = 3
+    sigma_min: float = 0.0
+    sigma_max: float = 1.5
+    kappa_order: int = 3
+    kappa_min: float = 1.0
+    kappa_max: float = 3.0
+    alpha_order: int = 1
+    alpha_min: float = 0.0
+    alpha_max: float = 0.0
+
+
+@dataclass
+class PointSourceSet:
+    """A current source as a list of Yee points with complex weights and one complex
+    waveform:  F[idx] += Re( (w_re + i w_im) * wave[n] ).
+
+    E components (electric current J) are added during the E-update with the waveform
+    sampled at t_{n+1/2}; H components (magnetic current M) during the H-update with the
+    waveform sampled at t_n.  The weights already contain the update coefficient of the
+    cell (-Cb / cell measure for J, -(dt/mu0) / cell measure for M)."""
+
+    comp: np.ndarray            # int32 [n]   component id 0..5
+    ijk: np.ndarray             # int32 [n,3] (i, j, k) global Yee indices
+    w_re: np.ndarray            # float64 [n]
+    w_im: np.ndarray            # float64 [n]
+    wave_e: np.ndarray          # complex128 [n_steps]  amp(t_n + dt/2)
+    wave_h: np.ndarray          # complex128 [n_steps]  amp(t_n)
+    name: str = ""
+
+
+@dataclass
+class TfsfSpec:
+    """Axis-aligned total-field/scattered-field source, reduced to plain lists.
+
+    A 1-D auxiliary Yee grid along the propagation axis carries the incident plane wave
+    (``e1`` on the n_aux+1 cell boundaries, ``h1`` on the n_aux centres; same steps and dt
+    as the 3-D grid, so its numerical dispersion matches the 3-D grid's exactly for
+    axis-aligned propagation).  Per step:
+
+      H-phase:  H[comp][ijk] += h_corr_w * e1[h_corr_aux]       (e1 at t_n)
+                h1 -= ch1 * (e1[1:] - e1[:-1]) * ip1
+      E-phase:  E[comp][ijk] += e_corr_w * h1[e_corr_aux]       (h1 at t_n + dt/2)
+                e1[1:-1] -= ce1 * (h1[1:] - h1[:-1]) * id1[1:-1]; Mur ABC at both ends;
+                e1[src_cell] += wave[n]
+
+    The correction lists (built on the host by ``tidy3d_amd.discretize``) hold every 3-D
+    node whose curl stencil straddles the TFSF surface, with the signed update coefficient
+    of that node folded into the weight."""
+
+    n_aux: int
+    ip1: np.ndarray             # float64 [n_aux]    1 / primal step
+    id1: np.ndarray             # float64 [n_aux+1]  1 / dual step (entries 1..n_aux-1 used)
+    ch1: float                  # h_sign * dt / mu0
+    ce1: float                  # h_sign * dt / (eps0 * eps_bg)
+    mur0: float
+    mur1: float
+    src_cell: int
+    wave: np.ndarray            # float64 [n_steps]
+    e_corr_comp: np.ndarray     # int32 [ne]
+    e_corr_ijk: np.ndarray      # int32 [ne, 3]
+    e_corr_w: np.ndarray        # float64 [ne]
+    e_corr_aux: np.ndarray      # int32 [ne]
+    h_corr_comp: np.ndarray     # int32 [nh]  (3..5)
+    h_corr_ijk: np.ndarray      # int32 [nh, 3]
+    h_corr_w: np.ndarray        # float64 [nh]
+    h_corr_aux: np.ndarray      # int32 [nh]
+    name: str = ""
+
+
+@dataclass
+class MonitorSpec:
+    """A recorder over a raw Yee index box [lo, hi) (same box for every component).
+
+    kind "time": every recorded step stores the raw component values (H averaged to t_n).
+    kind "dft" : running DFT  acc[f] += field * phase[n, f];  E uses phase_e (time t_n),
+                 H uses phase_h (time t_n + dt/2).  ``steps`` lists the time-step indices
+                 on which the monitor records."""
+
+    kind: str
+    comps: Tuple[int, ...]
+    lo: Tuple[int, int, int]
+    hi: Tuple[int, int, int]
+    steps: np.ndarray                                   # int64 [n_rec]
+    freqs: Optional[np.ndarray] = None                  # float64 [nf]          (dft)
+    phase_e: Optional[np.ndarray] = None                # complex128 [n_rec,nf] (dft)
+    phase_h: Optional[np.ndarray] = None                # complex128 [n_rec,nf] (dft)
+    name: str = ""
+
+    @property
+    def shape(self) -> Tuple[int, int, int]:
+        """(bz, by, bx) extents of the recorded box."""
+        return (self.hi[2] - self.lo[2], self.hi[1] - self.lo[1], self.hi[0] - self.lo[0])
+
+
+@dataclass
+class SolverSpec:
+    shape: Tuple[int, int, int]                         # (nx, ny, nz) cells incl. PML cells
+    boundaries: Tuple[np.ndarray, np.ndarray, np.ndarray]   # cell boundaries, N+1 each
+    dt: float
+    n_steps: int
+    bc: Tuple[Tuple[int, int], ...] = ((0, 0), (0, 0), (0, 0))   # [axis][minus, plus]
+    pml: Tuple[Tuple[PmlFace, PmlFace], ...] = None
+    media: List[MediumCoeffs] = field(default_factory=list)      # [0] = PEC, [1] = background
+    mat_idx: Optional[np.ndarray] = None                # uint8 [3, nz, ny, nx]; None = all [1]
+    sources: List[PointSourceSet] = field(default_factory=list)
+    tfsf: List[TfsfSpec] = field(default_factory=list)
+    monitors: List[MonitorSpec] = field(default_factory=list)
+    shutoff: float = 0.0                                # 0 disables the early stop
+    decay_every: int = 0                                # 0 = never evaluate field decay
+    decay_ref_step: int = 0                             # steps before this never shut off
+
+    def __post_init__(self):
+        if self.pml is None:
+            self.pml = tuple((PmlFace(), PmlFace()) for _ in range(3))
+        if not self.media:
+            self.media = [MediumCoeffs(pec=True, name="PEC"), MediumCoeffs(name="vacuum")]
+
+    # ---- derived 1-D geometry ------------------------------------------------------
+    @property
+    def n_cells(self) -> int:
+        nx, ny, nz = self.shape
+        return nx * ny * nz
+
+    def primal_steps(self, axis: int) -> np.ndarray:
+        """d[i] = b[i+1] - b[i]   (ref grid.py:393-401)."""
+        return np.diff(np.asarray(self.boundaries[axis], dtype=np.float64))
+
+    def dual_steps(self, axis: int) -> np.ndarray:
+        """dd[i] = (d[i] + d[i-1]) / 2; d[-1] wraps for periodic axes and mirrors (= d[0])
+        otherwise (ref grid.py:404-417 uses the periodic roll; the mirror value is only ever
+        used by the PMC rule since PEC zeroes the wall component)."""
+        d = self.primal_steps(axis)
+        prev = np.roll(d, 1)
+        if self.bc[axis][0] != BC_PERIODIC:
+            prev[0] = d[0]
+        return 0.5 * (d + prev)
+
+    def centers(self, axis: int) -> np.ndarray:
+        b = np.asarray(self.boundaries[axis], dtype=np.float64)
+        return 0.5 * (b[1:] + b[:-1])
+
+    def yee_coords(self, comp: int):
+        """(x, y, z) 1-D coordinate arrays (length N each) of component ``comp``
+        (ref grid.py:465-491)."""
+        is_h = comp >= 3
+        a = comp % 3
+        out = []
+        for ax in range(3):
+            b = np.asarray(self.boundaries[ax], dtype=np.float64)
+            on_center = (ax == a) != is_h      # E: centre along own axis; H: centre along others
+            out.append(0.5 * (b[1:] + b[:-1]) if on_center else b[:-1])
+        return tuple(out)
