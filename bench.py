@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""Benchmark of the FDTD hot path on MI355X: Mcells/s on a 512^3 Yee grid + HBM roofline.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line from
+rank 0.  For N > 1 the driver launches one process per GPU with torch.distributed.run; the
+512^3 grid is split into N z-slabs (strong scaling) with RCCL ghost-plane exchange.
+
+Workload (BASELINE.json metric; SURVEY.md section 8(d) variant V0): 512 x 512 x 512 cells, uniform
+dl = 0.05 um, vacuum, PEC walls, one Ez point dipole (GaussianPulse 200 THz), fields initialised
+to uniform random +-1e-3 (rng seed 0), fp32, curl-stencil only.  A "step" = one full time step
+(H pass + E pass) of all 6 components of every cell.  Inputs are resident in HBM before the
+timed region.
+
+Extra objects on the JSON line:
+  roofline     — dominant kernel (the E- or H-update, whichever is slower): algorithmic bytes per
+                 launch (36 B/cell x cells of the launch) / its average
+                 launch duration measured with hipEvents on the launch stream inside the library
+                 (FDTD_FLAG_TIME_KERNELS), against the 8 TB/s HBM peak.
+  cpu_baseline — the fp64->fp32 NumPy curl loop of oracle/fdtd_numpy.py (kind "port": the
+                 reference has no solver to time), on a bounded sample (smaller grid, few
+                 steps), rank 0 at N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12            # B/s, MI355X spec (MI355X_MICROARCH.md)
+BYTES_PER_CELL_PASS = 36     # 3 reads curl source + 3 reads + 3 writes updated field, fp32
+
+
+def build_spec(n: int, n_steps: int, workload: str):
+    import tidy3d_amd.schema as td
+    from tidy3d_amd.discretize import discretize
+
+    dl = 0.05
+    size = (n * dl,) * 3
+    pulse = td.GaussianPulse(freq0=2e14, fwidth=2e13)
+    structures = []
+    bspec = td.BoundarySpec.all_sides(td.PECBoundary())
+    if workload in ("v1", "v2", "v3"):
+        structures.append(td.Structure(geometry=td.Sphere(center=(0, 0, 0), radius=100 * dl * n / 512),
+                                       medium=td.Medium(permittivity=4.0)))
+    if workload == "v3":
+        structures[0] = td.Structure(geometry=structures[0].geometry,
+                                     medium=td.Lorentz(eps_inf=2.0, coeffs=[(2.0, 4e14, 2e13)]))
+    if workload in ("v2", "v3"):
+        size = ((n - 24) * dl,) * 3
+        bspec = td.BoundarySpec.all_sides(td.PML(num_layers=12))
+    sim = td.Simulation(size=size, grid_spec=td.GridSpec.uniform(dl=dl), run_time=1e-12,
+                        structures=structures,
+                        sources=[td.PointDipole(center=(0, 0, 0), source_time=pulse, polarization="Ez")],
+                        monitors=[], boundary_spec=bspec, shutoff=0)
+    disc = discretize(sim, n_steps=n_steps)
+    disc.spec.decay_every = 0
+    assert disc.spec.shape == (n, n, n), disc.spec.shape
+    return disc.spec
+
+
+def cpu_baseline(n: int = 160, steps: int = 6):
+    """Naive NumPy curl loop (oracle, fp32 arrays) on a bounded sample of the same workload."""
+    from oracle.fdtd_numpy import OracleFdtd
+    spec = build_spec(n, steps + 2, "v0")
+    o = OracleFdtd(spec, dtype=np.float32)
+    rng = np.random.default_rng(0)
+    for a in o.E + o.H:
+        a[...] = rng.uniform(-1e-3, 1e-3, a.shape).astype(np.float32)
+    o.step()
+    o.step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        o.step()
+    dt = time.perf_counter() - t0
+    return {"value": n ** 3 * steps / dt / 1e6, "unit": "Mcells/s", "cores": 1, "kind": "port",
+            "sample": f"{n}^3 vacuum PEC grid, {steps} steps, NumPy sliced curl loop fp32 "
+                      f"(single thread; host has {os.cpu_count()} cores)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n", type=int, default=512, help="cells per axis")
+    ap.add_argument("--workload", default="v0", choices=["v0", "v1", "v2", "v3"])
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--zchunk", type=int, default=0)
+    ap.add_argument("--rows", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--sweep", action="store_true", help="A/B kernel launch parameters (N=1)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from tidy3d_amd import lib as L
+    from tidy3d_amd.engine import HipEngine, split_slabs
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    n, K, W = args.n, args.steps, args.warmup
+    spec = build_spec(n, K + W + 64, args.workload)
+    slabs = split_slabs(n, world)
+    eng = HipEngine(spec, device=local_rank, variant=args.variant, z_chunk=args.zchunk,
+                    slab=slabs[rank], rank=rank, n_ranks=world)
+    if args.rows:
+        eng.set_option(L.OPT_ROWS, args.rows)
+    if world > 1:
+        uid = [eng.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        eng.comm_init(uid[0])
+    # synthetic initial data (uniform random +-1e-3, rng seed 0 -> same global field at any N)
+    z0, z1 = slabs[rank]
+    for c in range(6):
+        # generate only this slab's planes, reproducibly: one generator per (component, plane)
+        arr = np.empty((z1 - z0, n, n), dtype=np.float32)
+        for k in range(z0, z1):
+            arr[k - z0] = np.random.default_rng(c * 100003 + k).uniform(-1e-3, 1e-3, (n, n)).astype(np.float32)
+        eng.set_field(c, arr)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def timed(k):
+        sync()
+        t0 = time.perf_counter()
+        eng.run(k)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        return time.perf_counter() - t0
+
+    eng.run(W)
+    elapsed = timed(K)
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    cells = n ** 3
+    value = cells * K / elapsed / 1e6
+
+    # roofline of the dominant kernel: separate short run with per-launch hipEvents
+    eng.set_option(L.OPT_FLAGS, L.FLAG_TIME_KERNELS)
+    kr = min(K, 20)
+    eng.run(kr)
+    st = eng.stats()
+    eng.set_option(L.OPT_FLAGS, 0)
+    local_cells = (z1 - z0) * n * n
+    h_ms = st.h_kernel_ms / max(1, st.h_kernel_launches)
+    e_ms = st.e_kernel_ms / max(1, st.e_kernel_launches)
+    # when boundary planes are launched separately, normalise to the per-step duration
+    h_step = st.h_kernel_ms / kr
+    e_step = st.e_kernel_ms / kr
+    dom, dom_ms = ("e_update_kernel", e_step) if e_step >= h_step else ("h_update_kernel", h_step)
+    achieved = BYTES_PER_CELL_PASS * local_cells / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
+
+    out = {
+        "metric": "Mcells/s on 512^3 Yee grid", "value": value, "unit": "Mcells/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: vacuum {n}^3 Yee cells, PEC walls, Ez point dipole "
+                               "(GaussianPulse 200 THz), random +-1e-3 initial fields, curl stencil only"
+                   if args.workload == "v0" else f"{args.workload} {n}^3",
+                   "grid": [n, n, n], "parallelism": f"z-slab x{world}",
+                   "bytes_per_cell_step": 2 * BYTES_PER_CELL_PASS,
+                   "roofline_mcells_per_gpu": HBM_PEAK / (2 * BYTES_PER_CELL_PASS) / 1e6},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                     "avg_launch_ms": {"h_update_kernel": h_ms, "e_update_kernel": e_ms},
+                     "per_step_ms": {"h_update_kernel": h_step, "e_update_kernel": e_step},
+                     "algorithmic_bytes_per_launch": BYTES_PER_CELL_PASS * local_cells,
+                     "whole_step_frac": (2 * BYTES_PER_CELL_PASS * cells * K / elapsed) / (HBM_PEAK * world)},
+    }
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            out["roofline"]["traffic"] = json.load(open(pmc)).get(dom)
+        except Exception:
+            pass
+
+    if args.sweep and world == 1:
+        res = []
+        for rows in (1, 2, 4, 8):
+            for zc in (1, 4, 8, 16, 32, 64, 128):
+                eng.set_option(L.OPT_ROWS, rows)
+                eng.set_option(L.OPT_ZCHUNK, zc)
+                eng.run(3)
+                t = timed(20)
+                res.append({"rows": rows, "zchunk": zc, "mcells": cells * 20 / t / 1e6})
+                print(json.dumps(res[-1]), file=sys.stderr, flush=True)
+        out["sweep"] = res
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline()
+    eng.close()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,125 @@
+"""Shared parity cases: small simulations exercising every kernel of the hot path.  Used by the
+CPU emulator tests (kernel logic) and by the GPU tests (the real thing), both against the oracle."""
+import numpy as np
+
+import tidy3d_amd.schema as td
+from tidy3d_amd.discretize import discretize
+
+DL = 0.05
+PULSE = td.GaussianPulse(freq0=3e14, fwidth=1.5e14)
+
+
+def _sim(N, bspec, structures=(), sources=None, monitors=None, dl=DL, grid_spec=None):
+    size = tuple(n * dl for n in N)
+    if sources is None:
+        sources = [td.PointDipole(center=(0.03, -0.07, 0.01), source_time=PULSE, polarization="Ez"),
+                   td.PointDipole(center=(-0.1, 0.07, 0.06), source_time=PULSE, polarization="Hx")]
+    if monitors is None:
+        monitors = [td.FieldTimeMonitor(center=(-0.1, 0.1, -0.05), size=(0.3, 0.2, 0.1), name="t",
+                                        colocate=False, interval=7),
+                    td.FieldMonitor(center=(0, 0, 0), size=(0.4, 0.3, 0), freqs=[2.5e14, 3e14],
+                                    name="f")]
+    return td.Simulation(size=size, grid_spec=grid_spec or td.GridSpec.uniform(dl=dl), run_time=1e-12,
+                         structures=list(structures), sources=sources, monitors=monitors,
+                         boundary_spec=bspec, shutoff=0)
+
+
+def pec_box(N=(20, 16, 12)):
+    return _sim(N, td.BoundarySpec.all_sides(td.PECBoundary()))
+
+
+def pec_box_vec(N=(24, 16, 12)):
+    """nx % 4 == 0 after discretisation -> float4 path of the main kernels."""
+    return _sim(N, td.BoundarySpec.all_sides(td.PECBoundary()))
+
+
+def periodic_box(N=(16, 12, 10)):
+    return _sim(N, td.BoundarySpec(x=td.Boundary.periodic(), y=td.Boundary.periodic(),
+                                   z=td.Boundary.periodic()))
+
+
+def pml_box(N=(16, 12, 10)):
+    return _sim(N, td.BoundarySpec(x=td.Boundary.pml(num_layers=4), y=td.Boundary.pml(num_layers=5),
+                                   z=td.Boundary.pml(num_layers=3)))
+
+
+def stable_pml_box(N=(12, 10, 8)):
+    return _sim(N, td.BoundarySpec(x=td.Boundary.stable_pml(num_layers=6),
+                                   y=td.Boundary.stable_pml(num_layers=5),
+                                   z=td.Boundary.stable_pml(num_layers=4)))
+
+
+def media_mix(N=(13, 11, 9)):
+    """PML + periodic + PMC/PEC walls, Lorentz sphere (ADE), lossy box, PEC box."""
+    structures = [
+        td.Structure(geometry=td.Sphere(center=(0.05, 0, 0), radius=0.2),
+                     medium=td.Lorentz(eps_inf=2.0, coeffs=[(1.5, 4e14, 3e13)])),
+        td.Structure(geometry=td.Box(center=(-0.2, 0, 0), size=(0.15, 0.3, 0.2)),
+                     medium=td.Medium(permittivity=3.0, conductivity=0.02)),
+        td.Structure(geometry=td.Box(center=(0.2, 0.1, 0), size=(0.1, 0.1, 0.1)), medium=td.PEC)]
+    bspec = td.BoundarySpec(x=td.Boundary.pml(num_layers=4), y=td.Boundary.periodic(),
+                            z=td.Boundary(minus=td.PMCBoundary(), plus=td.PECBoundary()))
+    return _sim(N, bspec, structures)
+
+
+def drude_in_pml(N=(16, 12, 12)):
+    """Drude (two real poles) slab running through the x/y PML, plus an over-damped Lorentz box
+    and a Debye box: exercises multi-pole ADE groups inside CPML slabs."""
+    structures = [
+        td.Structure(geometry=td.Box(center=(0, 0, -0.15), size=(td.inf, td.inf, 0.2)),
+                     medium=td.Drude(eps_inf=1.5, coeffs=[(1.2e15, 8e13)])),
+        td.Structure(geometry=td.Box(center=(0.1, 0, 0.15), size=(0.2, 0.2, 0.15)),
+                     medium=td.Lorentz(eps_inf=1.2, coeffs=[(0.8, 2e14, 5e14)])),
+        td.Structure(geometry=td.Cylinder(center=(-0.2, 0, 0.1), radius=0.1, length=0.2, axis=1),
+                     medium=td.Debye(eps_inf=2.0, coeffs=[(1.0, 2e-15)]))]
+    return _sim(N, td.BoundarySpec.all_sides(td.PML(num_layers=4)), structures)
+
+
+def nonuniform_grid(N=(16, 12, 10)):
+    """CustomGrid with graded steps along x and z."""
+    dlx = tuple(0.03 + 0.02 * np.abs(np.linspace(-1, 1, 20)))
+    dlz = tuple(0.04 + 0.015 * np.linspace(0, 1, 12))
+    gs = td.GridSpec(grid_x=td.CustomGrid(dl=dlx), grid_y=td.UniformGrid(dl=DL),
+                     grid_z=td.CustomGrid(dl=dlz))
+    size = (float(np.sum(dlx)), 12 * DL, float(np.sum(dlz)))
+    sim = _sim((1, 1, 1), td.BoundarySpec(x=td.Boundary.pml(num_layers=3), y=td.Boundary.pec(),
+                                          z=td.Boundary.pml(num_layers=3)), grid_spec=gs)
+    return sim.copy(size=size)
+
+
+CASES = {
+    "pec_box": pec_box, "pec_box_vec": pec_box_vec, "periodic_box": periodic_box,
+    "pml_box": pml_box, "stable_pml_box": stable_pml_box, "media_mix": media_mix,
+    "drude_in_pml": drude_in_pml, "nonuniform_grid": nonuniform_grid,
+}
+
+
+def rel_err(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300))
+
+
+def run_case(name, lib, n_steps=60, scale=1, **engine_kw):
+    """Run case ``name`` through the C ABI library ``lib`` and through the oracle; return the
+    worst rel-L2 error over all monitors and over the final (E, H) state (field errors are
+    normalised by the norm of the whole E resp. H triple so that symmetry-suppressed components
+    do not inflate the figure)."""
+    from oracle.fdtd_numpy import OracleFdtd
+    from tidy3d_amd.engine import HipEngine
+    fn = CASES[name]
+    sim = fn() if scale == 1 else fn(tuple(int(n * scale) for n in fn.__defaults__[0]))
+    disc = discretize(sim, n_steps=n_steps)
+    o = OracleFdtd(disc.spec)
+    ref = o.run()
+    with HipEngine(disc.spec, lib=lib, **engine_kw) as e:
+        e.run()
+        got = e.results()
+        fields = [e.get_field(c) for c in range(6)]
+    worst = 0.0
+    for k in ref:
+        worst = max(worst, rel_err(got[k], ref[k]))
+    en = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in o.E))
+    hn = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in o.H))
+    for c in range(3):
+        worst = max(worst, float(np.linalg.norm(fields[c] - o.E[c]) / en))
+        worst = max(worst, float(np.linalg.norm(fields[3 + c] - o.H[c]) / hn))
+    return worst, disc

@@ -925,6 +925,18 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   return 0;
 }
 
+int fdtd_set_option(FdtdSolver* h, int key, int value) {
+  if (!h) return -1;
+  switch (key) {
+    case FDTD_OPT_FLAGS: h->cfg.flags = value; return 0;
+    case FDTD_OPT_VARIANT: h->cfg.variant = value; return 0;
+    case FDTD_OPT_ZCHUNK: if (value < 1) break; h->zchunk = value; return 0;
+    case FDTD_OPT_ROWS: if (value < 1 || value > 16) break; h->rows = value; return 0;
+    default: break;
+  }
+  return fail(h, "fdtd_set_option: bad key/value %d/%d", key, value);
+}
+
 int fdtd_get_stats(FdtdSolver* h, FdtdStats* out) {
   if (!h || !out) return -1;
   *out = h->stats;

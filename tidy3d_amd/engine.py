@@ -239,6 +239,9 @@ class HipEngine:
         self._chk(self.lib.dll.fdtd_get_stats(self.handle, C.byref(st)), "fdtd_get_stats")
         return st
 
+    def set_option(self, key: int, value: int):
+        self._chk(self.lib.dll.fdtd_set_option(self.handle, key, value), "fdtd_set_option")
+
     def reset(self):
         self._chk(self.lib.dll.fdtd_reset(self.handle), "fdtd_reset")
 

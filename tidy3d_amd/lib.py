@@ -22,13 +22,14 @@ SYMBOLS = (
     "fdtd_set_media", "fdtd_set_material", "fdtd_set_pml", "fdtd_add_ade",
     "fdtd_add_point_source", "fdtd_add_tfsf", "fdtd_add_monitor", "fdtd_get_monitor",
     "fdtd_set_field", "fdtd_get_field", "fdtd_set_shutoff", "fdtd_comm_unique_id",
-    "fdtd_comm_init", "fdtd_run", "fdtd_get_stats", "fdtd_reset",
+    "fdtd_comm_init", "fdtd_run", "fdtd_get_stats", "fdtd_reset", "fdtd_set_option",
 )
 
 BC_PEC, BC_PMC, BC_PERIODIC, BC_NEIGHBOR = 0, 1, 2, 3
 MON_TIME, MON_DFT = 0, 1
 VARIANT_AUTO, VARIANT_SIMPLE, VARIANT_ZMARCH, VARIANT_LDS = 0, 1, 2, 3
 FLAG_TIME_KERNELS = 1
+OPT_FLAGS, OPT_VARIANT, OPT_ZCHUNK, OPT_ROWS = 0, 1, 2, 3
 
 
 class FdtdConfig(C.Structure):
@@ -84,6 +85,7 @@ class FdtdLib:
         d.fdtd_run.argtypes = [vp, i64, PROGRESS_FN, vp]
         d.fdtd_get_stats.argtypes = [vp, C.POINTER(FdtdStats)]
         d.fdtd_reset.argtypes = [vp]
+        d.fdtd_set_option.argtypes = [vp, C.c_int, C.c_int]
 
     def error(self, handle) -> str:
         msg = self.dll.fdtd_last_error(handle)
