@@ -1,0 +1,160 @@
+"""GPU parity tests proper (run with -m gpu on a real MI355X): the product library
+libfdtd_hip.so, called through its C ABI, against the fp64 oracle on seeded small cases, and —
+at BASELINE.json's full 512^3 size — through size-independent bit-exact properties
+(translation invariance under periodic boundaries, linearity under power-of-two scaling,
+independence of the launch geometry).
+
+Tolerance: fp32 GPU vs fp64 oracle, rel-L2 <= 2e-5 over 60..100 steps (north_star: "stated fp32
+tolerance"; SURVEY.md section 7 step 3 asks <= 1e-5 over 200 steps on the vacuum case, checked in
+test_vacuum_200_steps)."""
+import numpy as np
+import pytest
+
+from cases import CASES, DL, PULSE, rel_err, run_case
+
+import tidy3d_amd.schema as td
+from tidy3d_amd import lib as L
+from tidy3d_amd.constants import C_0
+from tidy3d_amd.discretize import discretize
+from tidy3d_amd.engine import HipEngine
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def test_library_is_native_and_sees_a_gpu(hip_lib):
+    assert hip_lib.path.endswith("libfdtd_hip.so")
+    assert hip_lib.dll.fdtd_device_count() >= 1
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_gpu_matches_oracle_small(name, hip_lib):
+    worst, disc = run_case(name, hip_lib, n_steps=60)
+    assert worst < TOL, (name, disc.spec.shape, worst)
+
+
+@pytest.mark.parametrize("name", ["pec_box_vec", "media_mix", "drude_in_pml", "pml_box"])
+def test_gpu_matches_oracle_medium(name, hip_lib):
+    """~3x larger grids (several workgroups per axis, several z-chunks), 100 steps."""
+    worst, disc = run_case(name, hip_lib, n_steps=100, scale=3, z_chunk=8)
+    assert worst < TOL, (name, disc.spec.shape, worst)
+
+
+def test_vacuum_200_steps(hip_lib):
+    """<= 1e-5 rel-L2 over 200 steps, vacuum + PEC + dipole."""
+    sim = td.Simulation(size=(64 * DL,) * 3, grid_spec=td.GridSpec.uniform(dl=DL), run_time=1e-12,
+                        sources=[td.PointDipole(center=(0.1, 0, 0), source_time=PULSE, polarization="Ez")],
+                        monitors=[td.FieldTimeMonitor(center=(0, 0, 0), size=(1.0, 1.0, 0), name="t",
+                                                      interval=20, colocate=False)],
+                        boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary()), shutoff=0)
+    disc = discretize(sim, n_steps=200)
+    from oracle.fdtd_numpy import OracleFdtd
+    ref = OracleFdtd(disc.spec).run()["t"]
+    with HipEngine(disc.spec, lib=hip_lib) as e:
+        e.run()
+        got = e.results()["t"]
+    assert rel_err(got, ref) < 1e-5
+
+
+def _periodic_spec(n, src_cell, n_steps, amplitude=1.0):
+    dl = DL
+    c = tuple((s + 0.5) * dl - n * dl / 2 for s in src_cell)
+    pulse = td.GaussianPulse(freq0=2e14, fwidth=1e14, amplitude=amplitude)
+    sim = td.Simulation(size=(n * dl,) * 3, grid_spec=td.GridSpec.uniform(dl=dl), run_time=1e-12,
+                        sources=[td.PointDipole(center=c, source_time=pulse, polarization="Ez",
+                                                interpolate=False)],
+                        monitors=[], shutoff=0,
+                        boundary_spec=td.BoundarySpec(x=td.Boundary.periodic(), y=td.Boundary.periodic(),
+                                                      z=td.Boundary.periodic()))
+    d = discretize(sim, n_steps=n_steps)
+    assert d.spec.shape == (n, n, n)
+    return d.spec
+
+
+def _final_fields(spec, lib, **kw):
+    with HipEngine(spec, lib=lib, **kw) as e:
+        e.run()
+        return [e.get_field(c) for c in range(6)]
+
+
+def test_translation_invariance_512_bit_exact(hip_lib):
+    """512^3 periodic: moving the source by (67, 5, 37) cells moves every field by exactly the same
+    shift, bit for bit — any indexing slip at wavefront, workgroup, z-chunk or ghost-plane edges
+    would break this."""
+    n, steps, shift = 512, 24, (67, 5, 37)
+    a = _final_fields(_periodic_spec(n, (100, 200, 300), steps), hip_lib)
+    p2 = tuple((p + s) % n for p, s in zip((100, 200, 300), shift))
+    b = _final_fields(_periodic_spec(n, p2, steps), hip_lib)
+    assert max(np.abs(x).max() for x in a) > 0
+    for fa, fb in zip(a, b):
+        assert np.array_equal(np.roll(fa, (shift[2], shift[1], shift[0]), axis=(0, 1, 2)), fb)
+
+
+def test_linearity_power_of_two_512_bit_exact(hip_lib):
+    """512^3: scaling the source by 4 scales every field by exactly 4 (fp32 exponent shift)."""
+    n, steps = 512, 16
+    a = _final_fields(_periodic_spec(n, (256, 256, 256), steps, amplitude=1.0), hip_lib)
+    b = _final_fields(_periodic_spec(n, (256, 256, 256), steps, amplitude=4.0), hip_lib)
+    for fa, fb in zip(a, b):
+        assert np.array_equal(4.0 * fa, fb)
+
+
+@pytest.mark.parametrize("zchunk,rows", [(1, 1), (7, 2), (64, 8), (512, 4)])
+def test_launch_geometry_bit_identical(hip_lib, zchunk, rows):
+    from cases import media_mix
+    sim = media_mix((52, 44, 36))
+    disc = discretize(sim, n_steps=40)
+    outs = []
+    for zc, r in ((32, 4), (zchunk, rows)):
+        with HipEngine(disc.spec, lib=hip_lib, z_chunk=zc) as e:
+            e.set_option(L.OPT_ROWS, r)
+            e.run()
+            outs.append([e.get_field(c) for c in range(6)])
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
+
+
+def test_config2_vacuum_200_cube_cavity_resonances(hip_lib):
+    """BASELINE config[1]: vacuum 200^3 Yee cells, PointDipole + PEC walls + FieldTimeMonitor,
+    curl stencil only.  The spectrum of the probe must peak at the eigenfrequencies of the
+    *discrete* PEC cavity,  sin^2(w dt/2)/(c dt)^2 = sum_i sin^2(k_i d/2)/d^2, k_i = m_i pi/L."""
+    n, dl = 200, 0.05
+    pulse = td.GaussianPulse(freq0=3.5e13, fwidth=1.2e13)
+    sim = td.Simulation(size=(n * dl,) * 3, grid_spec=td.GridSpec.uniform(dl=dl), run_time=1e-12,
+                        sources=[td.PointDipole(center=(1.3, -0.7, 2.1), source_time=pulse, polarization="Ez")],
+                        monitors=[td.FieldTimeMonitor(center=(-2.1, 1.2, -0.6), size=(0, 0, 0), name="t",
+                                                      fields=["Ez"], colocate=False)],
+                        boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary()), shutoff=0)
+    steps = 12000
+    disc = discretize(sim, n_steps=steps)
+    with HipEngine(disc.spec, lib=hip_lib) as e:
+        st = e.run()
+        raw = e.results()["t"]
+    assert not st.diverged
+    sig = raw[:, 0].reshape(steps, -1)[:, 0].astype(np.float64)
+    dt = disc.spec.dt
+    pad = 8 * steps
+    spec_ = np.abs(np.fft.rfft(sig * np.hanning(steps), pad))
+    f = np.fft.rfftfreq(pad, dt)
+    Lc = n * dl
+    modes = []
+    for m in range(0, 4):
+        for q in range(0, 4):
+            for p in range(0, 4):
+                if (m > 0) + (q > 0) + (p > 0) < 2:
+                    continue
+                k = np.pi * np.array([m, q, p]) / Lc
+                s = np.sum(np.sin(k * dl / 2) ** 2 / dl ** 2)
+                modes.append(2 / dt * np.arcsin(C_0 * dt * np.sqrt(s)) / 2 / np.pi)
+    modes = np.array(sorted(set(np.round(modes, 3))))
+    from scipy.signal import find_peaks
+    pk, _ = find_peaks(spec_, height=spec_.max() * 0.05)
+    assert len(pk) >= 3
+    res = 1.0 / (steps * dt)
+    for x in f[pk]:
+        assert np.min(np.abs(modes - x)) < 1.5 * res, (x, modes[:8])
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    g.smoke()
