@@ -5,15 +5,15 @@ set -x
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 rocm-smi --showproductname 2>&1 | head -5 > gpurun_out/device.txt
-(timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -40) > gpurun_out/pytest_gpu.log
+(timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -40) > gpurun_out/pytest_gpu.log
 (timeout 600 python bench.py --steps 100 --warmup 10 ${BENCH_EXTRA:-} ) > gpurun_out/bench.json 2> gpurun_out/bench.err
 cat gpurun_out/bench.json
 if [ -n "$DO_SWEEP" ]; then
-  (timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu --sweep) > gpurun_out/bench_sweep.json 2> gpurun_out/bench_sweep.err
+  (timeout 900 python scripts/probe_geometry.py 512) > gpurun_out/probe_geometry.jsonl 2>&1
 fi
 if [ -n "$DO_PROF" ]; then
   cd /tmp
-  timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof.err
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof.err
   cd $GRAFT_REPO_ROOT
   find gpurun_out/prof -name '*stats*' | head; 
   find gpurun_out/prof -name '*kernel_trace*' -size +20M -delete

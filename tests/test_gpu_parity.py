@@ -57,8 +57,10 @@ def test_vacuum_200_steps(hip_lib):
 
 
 def _periodic_spec(n, src_cell, n_steps, amplitude=1.0):
-    dl = DL
-    c = tuple((s + 0.5) * dl - n * dl / 2 for s in src_cell)
+    dl = 0.0625      # power of two: every boundary / step is exact, so the grid is bitwise uniform
+    # 0.1 dl off the Ez node (x, y on boundaries, z on a centre): the nearest node is unambiguous
+    c = ((src_cell[0] + 0.1) * dl - n * dl / 2, (src_cell[1] + 0.1) * dl - n * dl / 2,
+         (src_cell[2] + 0.6) * dl - n * dl / 2)
     pulse = td.GaussianPulse(freq0=2e14, fwidth=1e14, amplitude=amplitude)
     sim = td.Simulation(size=(n * dl,) * 3, grid_spec=td.GridSpec.uniform(dl=dl), run_time=1e-12,
                         sources=[td.PointDipole(center=c, source_time=pulse, polarization="Ez",

@@ -460,7 +460,10 @@ int fdtd_create(const FdtdConfig* cfg, FdtdSolver** out) {
   g.bcx0 = cfg->bc[0]; g.bcx1 = cfg->bc[1]; g.bcy0 = cfg->bc[2]; g.bcy1 = cfg->bc[3];
   g.pec_z0 = cfg->bc[4] == FDTD_BC_PEC;
   g.ch = cfg->ch;
-  h->zchunk = cfg->z_chunk > 0 ? cfg->z_chunk : 32;
+  // measured on MI355X, 512^3 (profiles/r01a_probe_geometry_512.jsonl): short z-marches win —
+  // the 256 MiB Infinity Cache already serves the k+1 plane re-read, and more, smaller
+  // workgroups balance the 256 CUs better than long marches.
+  h->zchunk = cfg->z_chunk > 0 ? cfg->z_chunk : 2;
   h->rows = 4;
   int rc = 0;
   const size_t fcount = (size_t)g.sxy * (g.nz + 2);
@@ -931,7 +934,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_FLAGS: h->cfg.flags = value; return 0;
     case FDTD_OPT_VARIANT: h->cfg.variant = value; return 0;
     case FDTD_OPT_ZCHUNK: if (value < 1) break; h->zchunk = value; return 0;
-    case FDTD_OPT_ROWS: if (value < 1 || value > 16) break; h->rows = value; return 0;
+    case FDTD_OPT_ROWS: if (value < 1 || value > 8) break; h->rows = value; return 0;
     default: break;
   }
   return fail(h, "fdtd_set_option: bad key/value %d/%d", key, value);

@@ -92,7 +92,7 @@ __device__ __forceinline__ void zero(float (&r)[V]) {
 //                                               registers between planes)
 // =============================================================================================
 template <int V>
-__global__ __launch_bounds__(256) void h_update_kernel(GridP g, FieldP f, StepP s, int kbeg, int kend,
+__global__ __launch_bounds__(512) void h_update_kernel(GridP g, FieldP f, StepP s, int kbeg, int kend,
                                                         int zchunk) {
   const int tx = threadIdx.x;
   const int i0 = (blockIdx.x * 64 + tx) * V;
@@ -168,12 +168,12 @@ __global__ __launch_bounds__(256) void h_update_kernel(GridP g, FieldP f, StepP 
 //                material index -> (Ca, Cb) look-up table staged in LDS.
 // =============================================================================================
 template <int V, bool MAT>
-__global__ __launch_bounds__(256) void e_update_kernel(GridP g, FieldP f, StepP s, MatP m, int kbeg,
+__global__ __launch_bounds__(512) void e_update_kernel(GridP g, FieldP f, StepP s, MatP m, int kbeg,
                                                         int kend, int zchunk) {
   __shared__ float2 lut_s[256];
   if constexpr (MAT) {
-    const int t = threadIdx.y * blockDim.x + threadIdx.x;
-    if (t < m.n_media) lut_s[t] = m.lut[t];
+    for (int t = threadIdx.y * blockDim.x + threadIdx.x; t < m.n_media; t += blockDim.x * blockDim.y)
+      lut_s[t] = m.lut[t];
     __syncthreads();
   }
   const int tx = threadIdx.x;
