@@ -2,7 +2,7 @@
 
 Not part of the product: only ``tests/``, ``__graft_entry__.smoke()`` and the
 ``cpu_baseline`` leg of ``bench.py`` may import this module.  The product path
-(``tidy3d_amd.run`` -> ``libfdtd_hip.so``) never falls back to it.
+(``tidy3d_amd.web.run`` -> ``libfdtd_hip.so``) never falls back to it.
 
 PARITY STATUS: **the FDTD field values are "parity unpinned" against the
 reference** — flexcompute/tidy3d contains no time-stepper at all (SURVEY.md

@@ -1,0 +1,126 @@
+"""run(): the drop-in boundary end to end on CPU (HIP sources under the emulator): structure of
+the returned SimulationData follows the reference's fake backend run_emulated
+(ref tests/utils.py:862-1035) — coordinates, dims, dtypes — and the reference's error behaviour."""
+import numpy as np
+import pytest
+
+import tidy3d_amd
+import tidy3d_amd.schema as td
+from tidy3d_amd import discretize as D
+from tidy3d_amd.exceptions import SetupError, SolverLibraryError, Tidy3dNotImplementedError
+from tidy3d_amd.web import run
+
+DL = 0.05
+PULSE = td.GaussianPulse(freq0=3e14, fwidth=1e14)
+
+
+def _sim(**kw):
+    base = dict(size=(16 * DL, 12 * DL, 10 * DL), grid_spec=td.GridSpec.uniform(dl=DL), run_time=4e-14,
+                sources=[td.PointDipole(center=(0, 0, 0), source_time=PULSE, polarization="Ez")],
+                monitors=[td.FieldMonitor(center=(0, 0, 0.1), size=(0.4, 0.3, 0), freqs=[2.5e14, 3e14], name="f"),
+                          td.FieldMonitor(center=(0, 0, 0), size=(0.3, 0.2, 0.2), freqs=[3e14], name="fnc",
+                                          colocate=False, fields=["Ex", "Hz"]),
+                          td.FieldTimeMonitor(center=(0.1, 0, 0), size=(0, 0.2, 0.2), name="t", interval=4),
+                          td.FluxMonitor(center=(0, 0, 0.1), size=(0.4, 0.3, 0), freqs=[2.5e14, 3e14], name="fl"),
+                          td.FluxTimeMonitor(center=(0, 0, 0.1), size=(0.4, 0.3, 0), name="flt", interval=8)],
+                boundary_spec=td.BoundarySpec.all_sides(td.PML(num_layers=4)))
+    base.update(kw)
+    return td.Simulation(**base)
+
+
+@pytest.fixture(scope="module")
+def result(emu_lib):
+    sim = _sim()
+    return sim, run(sim, task_name="unit", verbose=False, lib=emu_lib)
+
+
+def test_data_follow_monitor_order_and_names(result):
+    sim, sd = result
+    assert [d.monitor.name for d in sd.data] == [m.name for m in sim.monitors]
+    assert sd["f"] is sd.data[0] and not sd.diverged
+
+
+def test_coordinates_match_run_emulated_rules(result):
+    """colocated -> sub-grid boundaries[:-1]; zero-size dim -> [center]; non-colocated -> the
+    component's own Yee coordinates (ref tests/utils.py:862-877)."""
+    sim, sd = result
+    b = D.make_boundaries(sim)
+    mon = sim.monitors[0]
+    span = D.discretize_inds_monitor(b, mon)
+    ex = sd["f"].Ex
+    assert ex.dims == ("x", "y", "z", "f")
+    np.testing.assert_allclose(ex.coords["x"], b[0][span[0, 0]:span[0, 1]])
+    np.testing.assert_allclose(ex.coords["y"], b[1][span[1, 0]:span[1, 1]])
+    np.testing.assert_allclose(ex.coords["z"], [0.1])
+    np.testing.assert_allclose(ex.coords["f"], mon.freqs)
+    assert ex.dtype == np.complex64 and ex.shape == sd["f"].Hy.shape
+    # non-colocated: Ex lives at x centres, Hz at x/y centres and z boundaries
+    mnc = sim.monitors[1]
+    s2 = D.discretize_inds_monitor(b, mnc)
+    xc = 0.5 * (b[0][1:] + b[0][:-1])
+    np.testing.assert_allclose(sd["fnc"].Ex.coords["x"], xc[s2[0, 0]:s2[0, 1]])
+    np.testing.assert_allclose(sd["fnc"].Ex.coords["y"], b[1][s2[1, 0]:s2[1, 1]])
+    assert set(sd["fnc"].field_components) == {"Ex", "Hz"}
+    # time monitor: tmesh[beg:end:interval], float32
+    tm = sd["t"].Ez
+    disc_t = D.make_tmesh(D.run_time(sim), D.compute_dt(sim, b))
+    beg, end = sim.monitors[2].time_inds(disc_t)
+    np.testing.assert_allclose(tm.coords["t"], disc_t[beg:end:4])
+    assert tm.dtype == np.float32 and tm.dims == ("x", "y", "z", "t")
+    assert sd["f"].grid_expanded["x"][0] == b[0][span[0, 0]]
+
+
+def test_flux_monitor_equals_field_monitor_flux(result):
+    _, sd = result
+    np.testing.assert_allclose(sd["fl"].flux.values, sd["f"].flux.values, rtol=2e-4)
+    assert sd["fl"].flux.dtype == np.float32 and sd["fl"].flux.dims == ("f",)
+    assert sd["flt"].flux.dims == ("t",) and np.all(np.isfinite(sd["flt"].flux.values))
+
+
+def test_log_format_and_final_decay(result):
+    """ref tests/test_data/test_sim_data.py:69,201-204."""
+    _, sd = result
+    lines = [ln for ln in sd.log.split("\n") if "field decay" in ln]
+    assert lines and lines[0].startswith("- Time step")
+    assert 0 <= sd.final_decay_value <= 1.0
+    assert "Solver time" in sd.log
+
+
+def test_normalisation_removes_pulse_shape_but_keeps_amplitude_and_phase(emu_lib):
+    """ref sim_data.py:943-951: amplitude and phase of the source stay in the data."""
+    mon = [td.FieldMonitor(center=(0.1, 0, 0), size=(0, 0, 0), freqs=[3e14], name="p", fields=["Ez"])]
+    a = run(_sim(monitors=mon), verbose=False, lib=emu_lib)["p"].Ez.values
+    src = td.PointDipole(center=(0, 0, 0), polarization="Ez",
+                         source_time=td.GaussianPulse(freq0=3e14, fwidth=1e14, amplitude=2.0, phase=0.5))
+    b = run(_sim(monitors=mon, sources=[src]), verbose=False, lib=emu_lib)["p"].Ez.values
+    np.testing.assert_allclose(b, a * 2.0 * np.exp(1j * 0.5), rtol=2e-4)
+    c = run(_sim(monitors=mon, normalize_index=None), verbose=False, lib=emu_lib)["p"].Ez.values
+    assert abs(c.ravel()[0]) != pytest.approx(abs(a.ravel()[0]), rel=1e-2)
+
+
+def test_errors_follow_the_reference(emu_lib):
+    with pytest.raises(SetupError):                      # ref simulation.py:3360
+        run(_sim(sources=[]), verbose=False, lib=emu_lib)
+    bad = _sim(boundary_spec=td.BoundarySpec(x=td.Boundary(plus=td.Unsupported(type="BlochBoundary"),
+                                                             minus=td.Unsupported(type="BlochBoundary"))))
+    with pytest.raises(Tidy3dNotImplementedError, match="BlochBoundary"):
+        run(bad, verbose=False, lib=emu_lib)
+    with pytest.raises(SetupError):
+        td.Simulation(size=(1, 1, 1), monitors=[td.FieldMonitor(name="a", freqs=[1e14]),
+                                                td.FieldMonitor(name="a", freqs=[1e14])])
+
+
+def test_accepts_json_dict_and_ignores_cloud_kwargs(emu_lib, tmp_path):
+    sim = _sim(monitors=[td.FluxMonitor(center=(0, 0, 0.1), size=(0.4, 0.3, 0), freqs=[3e14], name="fl")])
+    d = sim.dict()
+    out = tmp_path / "data.npz"
+    sd = tidy3d_amd.run(d, task_name="t", folder_name="x", path=str(out), callback_url=None, verbose=False,
+                        solver_version="ignored", worker_group=None, lib=emu_lib)
+    assert out.exists() and "fl/flux" in np.load(out).files
+    assert sd["fl"].flux.shape == (1,)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from tidy3d_amd.lib import load_library
+    with pytest.raises(SolverLibraryError):
+        load_library(str(tmp_path / "nope.so"))

@@ -7,6 +7,6 @@ __version__ = "0.1.0"
 
 
 def run(simulation, task_name=None, folder_name="default", path=None, **kwargs):
-    """Drop-in for ``tidy3d.web.run`` (ref web/api/webapi.py:49) — see tidy3d_amd.run.run."""
-    from .run import run as _run
+    """Drop-in for ``tidy3d.web.run`` (ref web/api/webapi.py:49) — see tidy3d_amd.web.run."""
+    from .web import run as _run
     return _run(simulation, task_name=task_name, folder_name=folder_name, path=path, **kwargs)

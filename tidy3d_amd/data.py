@@ -1,0 +1,397 @@
+"""Output side of the drop-in boundary: raw monitor buffers -> monitor data containers.
+
+Mirror of the part of ``tidy3d.components.data`` a solver must produce
+(SURVEY.md section 8(a) A12-A13): ``SimulationData`` holding one ``FieldData`` /
+``FieldTimeData`` / ``FluxData`` / ``FluxTimeData`` per monitor, on exactly the
+coordinates the reference's fake backend ``run_emulated`` uses
+(ref tests/utils.py:862-1035), normalised by the source spectrum
+(ref sim_data.py:931-953, monitor_data.py:972-979, :1955-1960), complex64/float32
+(ref monitor.py:35-36).  ``DataArray`` is a small numpy-backed stand-in for the
+xarray subclass (ref data_array.py:65) with the same ``dims``/``coords``/``values``/
+``sel``/``isel`` surface; ``tidy3d_amd.adapter.to_tidy3d`` converts to the real
+classes when tidy3d is importable.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import schema as td
+from .discretize import Discretization, FieldPlan, MonitorPlan
+from .exceptions import DataError
+from .spec import COMP_ID, SolverSpec
+
+
+class DataArray:
+    """Minimal labelled array: ``values`` + ordered ``coords`` (ref data_array.py:65-140)."""
+
+    def __init__(self, values, coords: Dict[str, Sequence], dims: Optional[Tuple[str, ...]] = None):
+        self.dims = tuple(dims) if dims is not None else tuple(coords.keys())
+        self.coords = {d: np.asarray(coords[d]) for d in self.dims}
+        self.values = np.asarray(values)
+        if self.values.shape != tuple(len(self.coords[d]) for d in self.dims):
+            raise DataError(f"DataArray shape {self.values.shape} does not match coords "
+                            f"{[len(self.coords[d]) for d in self.dims]}")
+
+    # numpy interop
+    def __array__(self, dtype=None, copy=None):
+        return self.values if dtype is None else self.values.astype(dtype)
+
+    @property
+    def shape(self):
+        return self.values.shape
+
+    @property
+    def dtype(self):
+        return self.values.dtype
+
+    @property
+    def real(self):
+        return DataArray(self.values.real, self.coords, self.dims)
+
+    @property
+    def imag(self):
+        return DataArray(self.values.imag, self.coords, self.dims)
+
+    @property
+    def abs(self):
+        return DataArray(np.abs(self.values), self.coords, self.dims)
+
+    def conj(self):
+        return DataArray(np.conj(self.values), self.coords, self.dims)
+
+    def _binary(self, other, op):
+        o = other.values if isinstance(other, DataArray) else other
+        return DataArray(op(self.values, o), self.coords, self.dims)
+
+    def __mul__(self, o): return self._binary(o, np.multiply)
+    __rmul__ = __mul__
+    def __add__(self, o): return self._binary(o, np.add)
+    def __sub__(self, o): return self._binary(o, np.subtract)
+    def __truediv__(self, o): return self._binary(o, np.divide)
+
+    def isel(self, **indexers):
+        vals, coords, dims = self.values, dict(self.coords), list(self.dims)
+        for d, idx in indexers.items():
+            ax = dims.index(d)
+            vals = np.take(vals, idx, axis=ax)
+            if np.ndim(idx) == 0:
+                dims.pop(ax)
+                coords.pop(d)
+            else:
+                coords[d] = coords[d][idx]
+        return DataArray(vals, coords, tuple(dims))
+
+    def sel(self, method: Optional[str] = None, **indexers):
+        out = self
+        for d, v in indexers.items():
+            c = out.coords[d]
+            if np.ndim(v) == 0:
+                i = int(np.argmin(np.abs(c - v)))
+                if method != "nearest" and not np.isclose(c[i], v, rtol=1e-9, atol=0):
+                    raise KeyError(f"{v} not found along '{d}' (use method='nearest')")
+                out = out.isel(**{d: i})
+            else:
+                ii = [int(np.argmin(np.abs(c - x))) for x in v]
+                out = out.isel(**{d: ii})
+        return out
+
+    def interp(self, **points):
+        """Linear interpolation along the given dims (edge values held outside)."""
+        out = self
+        for d, v in points.items():
+            ax = out.dims.index(d)
+            tgt = np.atleast_1d(np.asarray(v, float))
+            vals = interp_axis(out.values, out.coords[d], tgt, ax)
+            coords = dict(out.coords)
+            coords[d] = tgt
+            out = DataArray(vals, coords, out.dims)
+            if np.ndim(v) == 0:
+                out = out.isel(**{d: 0})
+        return out
+
+    def squeeze(self):
+        keep = [d for d in self.dims if len(self.coords[d]) != 1]
+        return DataArray(self.values.reshape([len(self.coords[d]) for d in keep]),
+                         {d: self.coords[d] for d in keep}, tuple(keep))
+
+    def __repr__(self):
+        return f"DataArray(dims={self.dims}, shape={self.shape}, dtype={self.dtype})"
+
+
+def interp_axis(arr: np.ndarray, src: np.ndarray, dst: np.ndarray, axis: int) -> np.ndarray:
+    """Linear interpolation of ``arr`` from coordinates ``src`` to ``dst`` along ``axis``; values
+    are held constant beyond the ends (the raw boxes are clipped at the domain walls)."""
+    src = np.asarray(src, float)
+    dst = np.asarray(dst, float)
+    if len(src) == len(dst) and np.array_equal(src, dst):
+        return arr
+    if len(src) == 1:
+        return np.repeat(arr, len(dst), axis=axis)
+    j = np.clip(np.searchsorted(src, dst, side="right") - 1, 0, len(src) - 2)
+    w = np.clip((dst - src[j]) / (src[j + 1] - src[j]), 0.0, 1.0)
+    a0 = np.take(arr, j, axis=axis)
+    a1 = np.take(arr, j + 1, axis=axis)
+    shp = [1] * arr.ndim
+    shp[axis] = -1
+    w = w.reshape(shp)
+    return a0 * (1 - w) + a1 * w
+
+
+# ----------------------------------------------------------------------------------------------
+# monitor data containers
+# ----------------------------------------------------------------------------------------------
+
+@dataclass
+class _FieldLike:
+    monitor: object
+    Ex: Optional[DataArray] = None
+    Ey: Optional[DataArray] = None
+    Ez: Optional[DataArray] = None
+    Hx: Optional[DataArray] = None
+    Hy: Optional[DataArray] = None
+    Hz: Optional[DataArray] = None
+    symmetry: Tuple[int, int, int] = (0, 0, 0)
+    symmetry_center: Optional[Tuple[float, float, float]] = None
+    grid_expanded: Optional[Dict[str, np.ndarray]] = None      # boundaries x, y, z of the sub-grid
+
+    @property
+    def field_components(self) -> Dict[str, DataArray]:
+        return {k: getattr(self, k) for k in ("Ex", "Ey", "Ez", "Hx", "Hy", "Hz")
+                if getattr(self, k) is not None}
+
+    def __getitem__(self, name):
+        return self.field_components[name]
+
+
+@dataclass
+class FieldData(_FieldLike):
+    """ref monitor_data.py:927 — dims (x, y, z, f), complex64."""
+
+    def normalize(self, spectrum_fn: Callable) -> "FieldData":
+        """Divide by the source spectrum (ref monitor_data.py:972-979)."""
+        out = FieldData(monitor=self.monitor, symmetry=self.symmetry,
+                        symmetry_center=self.symmetry_center, grid_expanded=self.grid_expanded)
+        for k, v in self.field_components.items():
+            s = np.asarray(spectrum_fn(v.coords["f"]))
+            setattr(out, k, DataArray((v.values / s[None, None, None, :]).astype(np.complex64),
+                                      v.coords, v.dims))
+        return out
+
+    @property
+    def flux(self) -> DataArray:
+        """Power through a planar monitor (ref monitor_data.py:582-618), FluxDataArray(f)."""
+        axis = [a for a in range(3) if self.monitor.size[a] == 0]
+        if len(axis) != 1:
+            raise DataError("flux needs a planar monitor")
+        return plane_flux(self, axis[0], self.monitor)
+
+
+@dataclass
+class FieldTimeData(_FieldLike):
+    """ref monitor_data.py:1119 — dims (x, y, z, t), float32."""
+
+
+@dataclass
+class FluxData:
+    """ref monitor_data.py:1898 — flux(f) float32."""
+    monitor: object
+    flux: DataArray = None
+
+    def normalize(self, spectrum_fn: Callable) -> "FluxData":
+        """Divide by |spectrum|^2 (ref monitor_data.py:1955-1960)."""
+        s = np.abs(np.asarray(spectrum_fn(self.flux.coords["f"]))) ** 2
+        return FluxData(monitor=self.monitor,
+                        flux=DataArray((self.flux.values / s).astype(np.float32), self.flux.coords))
+
+
+@dataclass
+class FluxTimeData:
+    """ref monitor_data.py:1992 — flux(t) float32."""
+    monitor: object
+    flux: DataArray = None
+
+
+@dataclass
+class SimulationData:
+    """ref sim_data.py:826: simulation + tuple of monitor data + solver log + diverged flag."""
+
+    simulation: object
+    data: Tuple[object, ...] = ()
+    log: Optional[str] = None
+    diverged: bool = False
+
+    def __post_init__(self):
+        names = [d.monitor.name for d in self.data]
+        sim_names = [m.name for m in self.simulation.monitors]
+        for n in names:          # ref base_sim/data/sim_data.py:54-84
+            if n not in sim_names:
+                raise DataError(f"Data with monitor name '{n}' supplied but not found in the "
+                                "original Simulation.")
+        if len(set(names)) != len(names):
+            raise DataError("monitor data names must be unique")
+
+    @property
+    def monitor_data(self) -> Dict[str, object]:
+        return {d.monitor.name: d for d in self.data}
+
+    def __getitem__(self, monitor_name: str):
+        try:
+            return self.monitor_data[monitor_name]
+        except KeyError:
+            raise DataError(f"monitor '{monitor_name}' not found in the simulation data") from None
+
+    @property
+    def final_decay_value(self) -> float:
+        """ref sim_data.py:916-929."""
+        if self.log is None:
+            raise DataError("No log string in the SimulationData object, can't find final decay value.")
+        lines = [ln for ln in self.log.split("\n") if "field decay" in ln]
+        return float(lines[-1].split("field decay: ")[-1]) if lines else 1.0
+
+
+# ----------------------------------------------------------------------------------------------
+# post-processing
+# ----------------------------------------------------------------------------------------------
+
+def _colocate_box(raw: np.ndarray, spec: SolverSpec, fp: FieldPlan, ic: int, fname: str) -> np.ndarray:
+    """raw [n_lead, n_comps, bz, by, bx] -> [n_lead, nz_t, ny_t, nx_t] on the target coordinates of
+    field ``fname`` (separable linear interpolation from the component's Yee coordinates; this is
+    both the colocation to the primal nodes, ref dataset.py:83-147 / CHANGELOG:467-470, and the
+    snapping of zero-size dimensions to the exact plane position, ref simulation.py:1019-1026)."""
+    comp = COMP_ID[fname]
+    yee = spec.yee_coords(comp)
+    arr = raw[:, ic]
+    for a in range(3):
+        lo = fp.lo[a]
+        n = arr.shape[3 - a]
+        src = yee[a][lo:lo + n]
+        arr = interp_axis(arr, src, fp.target[fname][a], axis=3 - a)
+    return arr
+
+
+def _grid_expanded(spec: SolverSpec, fp: FieldPlan) -> Dict[str, np.ndarray]:
+    out = {}
+    for a, d in enumerate("xyz"):
+        b = spec.boundaries[a]
+        lo, hi = max(int(fp.span[a, 0]), 0), min(int(fp.span[a, 1]), len(b) - 1)
+        out[d] = np.asarray(b[lo:hi + 1])
+    return out
+
+
+def _diff_area(plan_box: td.Box, coords1: np.ndarray, coords2: np.ndarray, axis: int,
+               gb1: np.ndarray, gb2: np.ndarray) -> np.ndarray:
+    """Integration weights for values colocated to the grid boundaries gb1 x gb2, truncated to
+    the monitor bounds (ref monitor_data.py:426-463)."""
+    (lo, hi) = plan_box.bounds
+    t = [a for a in range(3) if a != axis]
+
+    def sizes(gb, mlo, mhi):
+        if gb.size <= 1:
+            return np.array([1.0])
+        c = 0.5 * (gb[1:] + gb[:-1])
+        c = np.concatenate(([gb[0]], c, [gb[-1]]))
+        c = np.clip(c, mlo, mhi)
+        return c[1:] - c[:-1]
+    s1 = sizes(gb1, lo[t[0]], hi[t[0]])
+    s2 = sizes(gb2, lo[t[1]], hi[t[1]])
+    return np.outer(s1, s2)
+
+
+def plane_flux(fd: _FieldLike, axis: int, mon, sign: float = 1.0, box: Optional[td.Box] = None,
+               lead: str = "f") -> DataArray:
+    """0.5 Re(E x H*) . n integrated over the plane (ref monitor_data.py:582-618); for real
+    time-domain fields the factor 0.5 and the conjugate drop out (ref monitor_data.py:1158)."""
+    t = [a for a in range(3) if a != axis]
+    d1, d2 = "xyz"[t[0]], "xyz"[t[1]]
+    e1, e2 = fd["E" + d1], fd["E" + d2]
+    h1, h2 = fd["H" + d1], fd["H" + d2]
+    # (x, y, z, lead) -> drop the normal axis
+    def sq(v):
+        return np.take(v.values, 0, axis=axis)
+    if lead == "f":
+        s = 0.5 * np.real(sq(e1) * np.conj(sq(h2)) - sq(e2) * np.conj(sq(h1)))
+    else:
+        s = sq(e1) * sq(h2) - sq(e2) * sq(h1)
+    if axis == 1:       # (x, z) ordering is left-handed w.r.t. +y  (ref monitor_data.py:491-493)
+        s = -s
+    # colocated data sit on the sub-grid boundaries with the last one dropped
+    # (= colocation_boundaries, ref monitor_data.py:372-395), which is what _diff_area expects
+    gb1, gb2 = np.asarray(e1.coords[d1]), np.asarray(e1.coords[d2])
+    w = _diff_area(box or mon.geometry, None, None, axis, gb1, gb2)
+    flux = sign * np.tensordot(w, s, axes=([0, 1], [0, 1]))
+    return DataArray(flux.astype(np.float32), {lead: e1.coords[lead]})
+
+
+def _field_container(cls, mon, spec: SolverSpec, fp: FieldPlan, raw: np.ndarray, lead: str,
+                     lead_coords: np.ndarray, sim_center, dtype):
+    kw = {}
+    for ic, fname in enumerate(fp.fields):
+        arr = _colocate_box(raw, spec, fp, ic, fname)           # [lead, z, y, x]
+        arr = np.transpose(arr, (3, 2, 1, 0)).astype(dtype)      # (x, y, z, lead)
+        tx, ty, tz = fp.target[fname]
+        kw[fname] = DataArray(arr, {"x": tx, "y": ty, "z": tz, lead: lead_coords})
+    return cls(monitor=mon, symmetry=(0, 0, 0), symmetry_center=tuple(sim_center),
+               grid_expanded=_grid_expanded(spec, fp), **kw)
+
+
+def source_spectrum_fn(disc: Discretization, index: Optional[int]) -> Callable:
+    """ref sim_data.py:931-953: spectrum / amplitude / exp(i phase) of source ``index``."""
+    sim = disc.sim
+    if index is None or len(sim.sources) == 0:
+        return lambda f: np.ones(len(np.atleast_1d(f)), complex)
+    st = sim.sources[index].source_time
+    base = disc.source_norm[index]
+
+    def fn(freqs):
+        return base(freqs) / st.amplitude / np.exp(1j * st.phase)
+    return fn
+
+
+def assemble(disc: Discretization, raw: Dict[str, np.ndarray], log: str = "", diverged: bool = False,
+             n_steps_run: Optional[int] = None) -> SimulationData:
+    """Raw monitor buffers (name -> array as returned by the engine / oracle) -> SimulationData."""
+    sim, spec = disc.sim, disc.spec
+    norm = source_spectrum_fn(disc, sim.normalize_index)
+    out = []
+    for plan in disc.plans:
+        mon = plan.monitor
+        if plan.kind == "field":
+            fp = plan.fields[0]
+            fd = _field_container(FieldData, mon, spec, fp, raw[fp.spec_name], "f",
+                                  np.asarray(mon.freqs, float), sim.center, np.complex64)
+            out.append(fd.normalize(norm))
+        elif plan.kind == "field_time":
+            fp = plan.fields[0]
+            t = disc.tmesh[plan.steps]
+            out.append(_field_container(FieldTimeData, mon, spec, fp, raw[fp.spec_name], "t", t,
+                                        sim.center, np.float32))
+        elif plan.kind in ("flux", "flux_time"):
+            is_time = plan.kind == "flux_time"
+            lead = "t" if is_time else "f"
+            lead_coords = disc.tmesh[plan.steps] if is_time else np.asarray(mon.freqs, float)
+            total = None
+            from .discretize import flux_surfaces
+            for fp, (sname, box, axis, sign) in zip(plan.fields, flux_surfaces(mon)):
+                class _M:
+                    pass
+                m = _M()
+                m.size, m.center, m.geometry = box.size, box.center, box
+                fd = _field_container(FieldTimeData if is_time else FieldData, m, spec, fp,
+                                      raw[fp.spec_name], lead, lead_coords, sim.center,
+                                      np.float64 if is_time else np.complex128)
+                fl = plane_flux(fd, axis, m, sign=sign, box=box, lead=lead)
+                total = fl if total is None else DataArray(total.values + fl.values, fl.coords)
+            if is_time:
+                out.append(FluxTimeData(monitor=mon, flux=DataArray(total.values.astype(np.float32),
+                                                                   total.coords)))
+            else:
+                out.append(FluxData(monitor=mon, flux=total).normalize(norm))
+        elif plan.kind == "mode":
+            from .modesource import mode_monitor_data
+            out.append(mode_monitor_data(disc, plan, raw, norm))
+        else:
+            raise DataError(f"unknown monitor plan kind '{plan.kind}'")
+    return SimulationData(simulation=sim, data=tuple(out), log=log, diverged=diverged)

@@ -1,0 +1,135 @@
+"""``run()``: local, MI355X-native drop-in for ``tidy3d.web.run``.
+
+Mirrors the signature and behaviour of reference web/api/webapi.py:49-155 (via
+web/api/autograd/autograd.py:86): takes the Simulation positionally, tolerates and ignores the
+cloud-only keyword arguments, validates (``validate_pre_upload``, simulation.py:3341), runs the
+solve — here on the local GPU through ``libfdtd_hip.so`` instead of upload/start/monitor/
+download — and returns a ``SimulationData``; the post-run warnings of
+``Tidy3dStubData.postprocess`` (web/api/tidy3d_stub.py:219-233) are replicated.  The test-suite
+seam of the reference is ``monkeypatch.setattr(td.web, "run", run_emulated)``
+(tests/utils.py:880, tests/test_plugins/test_adjoint.py:95); this function plugs into the same
+seam.
+"""
+from __future__ import annotations
+
+import json
+import logging
+import time
+from typing import Optional
+
+import numpy as np
+
+from . import schema as td
+from .data import SimulationData, assemble
+from .discretize import discretize
+from .exceptions import SetupError
+
+log = logging.getLogger("tidy3d_amd")
+
+
+def _as_mirror(simulation):
+    """Accept a mirror Simulation, a real tidy3d.Simulation (anything with .json()/.dict()), a
+    dict in tidy3d's JSON form, or a path to a .json file."""
+    if isinstance(simulation, td.Simulation):
+        return simulation, False
+    if isinstance(simulation, str):
+        return td.Simulation.from_file(simulation), False
+    if isinstance(simulation, dict):
+        return td.Simulation.from_dict(simulation), False
+    if hasattr(simulation, "json") and callable(simulation.json):
+        return td.Simulation.from_dict(json.loads(simulation.json())), True
+    raise SetupError(f"cannot interpret {type(simulation)!r} as a tidy3d Simulation")
+
+
+def _log_line(step: int, n_steps: int, t: float, decay: float) -> str:
+    """Format pinned by ref tests/test_data/test_sim_data.py:69,201-204."""
+    perc = int(100 * step / max(n_steps, 1))
+    mant = f"{decay:.3e}"
+    return f"- Time step {step:6d} / time {t:.2e}s ({perc:3d} % done), field decay: {mant}"
+
+
+def run(simulation, task_name: Optional[str] = None, folder_name: str = "default",
+        path: Optional[str] = None, callback_url: Optional[str] = None, verbose: bool = True,
+        progress_callback_upload=None, progress_callback_download=None,
+        solver_version: Optional[str] = None, worker_group: Optional[str] = None,
+        simulation_type: str = "tidy3d", parent_tasks=None, local_gradient: bool = False,
+        *, device: int = 0, n_steps: Optional[int] = None, lib=None,
+        return_tidy3d: Optional[bool] = None) -> SimulationData:
+    """Solve ``simulation`` on the local MI355X and return its ``SimulationData``.
+
+    Cloud-only arguments (``folder_name``, ``callback_url``, ``progress_callback_*``,
+    ``solver_version``, ``worker_group``, ``parent_tasks``, ``local_gradient``) are accepted and
+    ignored.  ``path``: when given, the data is written there (tidy3d hdf5 when the real tidy3d
+    package is available, otherwise ``.npz``).  Extra keyword-only arguments select the GPU
+    (``device``), override the number of time steps (``n_steps``, tests/benchmarks) or pass an
+    explicitly loaded library (``lib``, tests)."""
+    from .engine import HipEngine
+
+    sim, was_tidy3d = _as_mirror(simulation)
+    sim.validate_pre_upload(source_required=True)
+    t_setup = time.perf_counter()
+    disc = discretize(sim, n_steps=n_steps)
+    spec = disc.spec
+    lines = [f"Simulation domain Nx, Ny, Nz: {list(spec.shape)}",
+             f"Applied symmetries: {tuple(sim.symmetry)}",
+             f"Number of computational grid points: {spec.n_cells:.4e}.",
+             f"Number of time steps: {spec.n_steps:.4e}",
+             f"Time step size (dt): {spec.dt:.4e}s", "",
+             "Running solver for %d time steps..." % spec.n_steps]
+
+    def progress(step, t, decay):
+        ln = _log_line(step, spec.n_steps, t, decay)
+        lines.append(ln)
+        if verbose:
+            print(ln, flush=True)
+        return False
+
+    with HipEngine(spec, lib=lib, device=device) as eng:
+        setup_s = time.perf_counter() - t_setup
+        t0 = time.perf_counter()
+        stats = eng.run(progress=progress if spec.decay_every else None)
+        solve_s = time.perf_counter() - t0
+        raw = eng.results()
+        steps_done = int(stats.steps_done)
+        diverged = bool(stats.diverged)
+        if stats.stopped_early:
+            lines.append(f"Field decay smaller than shutoff factor, exiting solver "
+                         f"(time step {steps_done}).")
+        if diverged:
+            lines.append("WARNING: field divergence detected, exiting solver.")
+    lines += ["", f"Setup time (s):  {setup_s:.4f}", f"Solver time (s): {solve_s:.4f}",
+              f"Time-stepping speed (cells/s): {spec.n_cells * steps_done / max(solve_s, 1e-9):.2e}"]
+    sim_data = assemble(disc, raw, log="\n".join(lines), diverged=diverged, n_steps_run=steps_done)
+
+    # post-run warnings, ref web/api/tidy3d_stub.py:219-233
+    if diverged:
+        log.warning("The simulation has diverged! For more information, check 'SimulationData.log'.")
+    elif sim.shutoff != 0 and spec.decay_every and sim_data.final_decay_value > sim.shutoff:
+        log.warning(f"Simulation final field decay value of {sim_data.final_decay_value} is greater "
+                    f"than the simulation shutoff threshold of {sim.shutoff}. Consider running the "
+                    "simulation again with a larger 'run_time' duration for more accurate results.")
+
+    want_td = was_tidy3d if return_tidy3d is None else return_tidy3d
+    if want_td:
+        from .adapter import to_tidy3d
+        out = to_tidy3d(sim_data, simulation if was_tidy3d else None)
+        if path:
+            out.to_file(path)
+        return out
+    if path:
+        save_npz(sim_data, path)
+    return sim_data
+
+
+def save_npz(sim_data: SimulationData, path: str) -> None:
+    """Plain .npz dump of every DataArray (values + coords) plus the log; the tidy3d hdf5
+    container needs h5py and is written through the real package (adapter.to_tidy3d)."""
+    blobs = {"log": np.array(sim_data.log or ""), "diverged": np.array(sim_data.diverged)}
+    for d in sim_data.data:
+        name = d.monitor.name
+        arrays = getattr(d, "field_components", None) or {"flux": d.flux}
+        for k, v in arrays.items():
+            blobs[f"{name}/{k}"] = v.values
+            for dim, c in v.coords.items():
+                blobs[f"{name}/{k}/{dim}"] = c
+    np.savez(path if path.endswith(".npz") else path + ".npz", **blobs)
