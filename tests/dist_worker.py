@@ -1,0 +1,75 @@
+"""Worker of the world_size-2 gloo test: runs the library's multi-rank path on CPU.  The HIP
+sources run under the emulator; its RCCL shim hands every grouped Send/Recv to the callback
+below, which performs them with torch.distributed (gloo)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+
+
+class P2POp(C.Structure):
+    _fields_ = [("kind", C.c_int), ("peer", C.c_int), ("buf", C.c_void_p), ("bytes", C.c_size_t)]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(P2POp), C.c_int, C.c_void_p)
+
+
+def _exchange(ops, n, _user):
+    reqs, keep = [], []
+    for i in range(n):
+        op = ops[i]
+        if op.kind in (0, 1):
+            arr = np.ctypeslib.as_array(C.cast(op.buf, C.POINTER(C.c_float)), shape=(op.bytes // 4,))
+            t = torch.from_numpy(arr)
+            keep.append(t)
+            reqs.append(dist.isend(t, op.peer) if op.kind == 1 else dist.irecv(t, op.peer))
+        else:
+            ct, dt = (C.c_float, 4) if op.kind == 2 else (C.c_double, 8)
+            arr = np.ctypeslib.as_array(C.cast(op.buf, C.POINTER(ct)), shape=(op.bytes // dt,))
+            t = torch.from_numpy(arr)
+            dist.all_reduce(t)
+    for r in reqs:
+        r.wait()
+    return 0
+
+
+def main():
+    case, n_steps, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    import build_emu
+    from tidy3d_amd.lib import load_library
+    from tidy3d_amd import dist as tdist
+    from tidy3d_amd.discretize import discretize
+    import cases
+    lib = load_library(build_emu.build())
+    cb = EXCHANGE_FN(_exchange)
+    lib.dll.hipemu_set_exchange(cb, None)
+    sim = cases.CASES[case]() if case in cases.CASES else getattr(cases, case)()
+    disc = discretize(sim, n_steps=n_steps)
+    disc.spec.decay_every = 10          # exercise the scalar all-reduce too
+    eng = tdist.make_engine(disc.spec, lib=lib, device=0)   # the emulator exposes one device
+    st = eng.run()
+    raw = tdist.gather_results(eng)
+    fields = [eng.get_field(c) for c in range(6)]
+    allf = [None] * world if rank == 0 else None
+    dist.gather_object((eng.z0, fields), allf, dst=0)
+    eng.close()
+    if rank == 0:
+        allf.sort(key=lambda p: p[0])
+        full = {f"field{c}": np.concatenate([p[1][c] for p in allf], axis=0) for c in range(6)}
+        np.savez(out, decay=st.field_decay, **{f"mon_{k}": v for k, v in raw.items()}, **full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -718,7 +718,13 @@ int fdtd_set_field(FdtdSolver* h, int comp, const float* host, size_t bytes) {
   HIPCHK(h, hipSetDevice(h->cfg.device));
   HIPCHK(h, hipMemcpy(field_ptr(h, comp), host, bytes, hipMemcpyHostToDevice));
   // keep single-slab ghost planes consistent with the new interior
-  if (h->n_ranks == 1) { fill_ghost_h(h, h->stream); fill_ghost_e(h, h->stream); HIPCHK(h, hipStreamSynchronize(h->stream)); }
+  if (h->comm == nullptr) { fill_ghost_h(h, h->stream); fill_ghost_e(h, h->stream); HIPCHK(h, hipStreamSynchronize(h->stream)); }
+  else if (comp == 0 || comp == 1 || comp == 3 || comp == 4) {
+    // with a communicator the ghost planes come from the neighbour: do one exchange now
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (exchange(h, comp < 3, h->comm_stream)) return -1;
+    HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+  }
   return 0;
 }
 
@@ -788,7 +794,7 @@ int fdtd_reset(FdtdSolver* h) {
 int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user) {
   if (!h) return -1;
   HIPCHK(h, hipSetDevice(h->cfg.device));
-  const bool multi = h->n_ranks > 1 && h->comm != nullptr;
+  const bool multi = h->comm != nullptr;     // also true for a 1-rank communicator (self exchange)
   const bool nb_lo = h->cfg.bc[4] == FDTD_BC_NEIGHBOR, nb_hi = h->cfg.bc[5] == FDTD_BC_NEIGHBOR;
   if ((nb_lo || nb_hi) && !multi) return fail(h, "fdtd_run: neighbour faces need fdtd_comm_init");
   const int nz = h->g.nz;
@@ -797,78 +803,74 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   h->kev.clear(); h->kev_kind.clear();
   h->stats.stopped_early = 0;
   HIPCHK(h, hipEventRecord(h->ev0, st));
+  if (multi && (nb_lo || nb_hi) && nz < 2) return fail(h, "fdtd_run: a z-slab needs at least 2 planes");
+  // Two-stream schedule of one step (st = main stream, cs = comm stream):
+  //   cs: [H top plane] -> send/recv H -> [E bottom plane] -> send/recv E      (boundary planes first)
+  //   st: [H interior ] ----------------> [E interior    ]
+  // Cross-stream edges (RAW and WAR), one event each:
+  //   ev_e_int : E interior of step n-1 done     -> cs may update/ship H top plane (reads E[nz-1])
+  //   ev_e_bnd : E plane 0 of step n-1 done (cs) -> st may run H interior (reads E[0]) and monitors
+  //   ev_h_int : H interior done                 -> cs may update E plane 0 (reads H[0])
+  //   ev_h_bnd : H top plane done (cs)           -> st may run E interior (reads H[nz-1])
+  // Ghost planes are only touched on cs, in stream order.  No host synchronisation in the loop.
   int64_t done = 0;
   for (; done < n_steps; ++done) {
     const long long n = h->step;
-    record_monitors(h, n, false, st);
-    // ---------------- H phase ----------------
-    if (multi && nb_hi && nz > 1) {
-      // boundary plane first on the comm stream, interior on the main stream
-      HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
-      launch_h_main(h, nz - 1, nz, cs);
-      launch_pml(h, false, nz - 1, nz, cs);
-      launch_sources(h, false, n, nz - 1, nz, cs);
-      HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
+    bool rec = false;
+    for (Monitor& m : h->mons) rec = rec || (m.next < m.steps.size() && m.steps[m.next] == n);
+    if (rec && multi) {
       HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
-      launch_h_main(h, 0, nz - 1, st);
-      launch_pml(h, false, 0, nz - 1, st);
-      launch_sources(h, false, n, 0, nz - 1, st);
-      advance_tfsf_aux(h, false, n, st);
-      HIPCHK(h, hipEventRecord(h->ev_h_int, st));
-      if (exchange(h, false, cs)) return -1;
-      HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
-    } else {
-      if (multi) HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
-      launch_h_main(h, 0, nz, st);
-      launch_pml(h, false, 0, nz, st);
-      launch_sources(h, false, n, 0, nz, st);
-      advance_tfsf_aux(h, false, n, st);
-      if (multi) {
-        HIPCHK(h, hipEventRecord(h->ev_h_int, st));
-        HIPCHK(h, hipStreamWaitEvent(cs, h->ev_h_int, 0));
-        if (exchange(h, false, cs)) return -1;
-        HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
-      } else {
-        fill_ghost_h(h, st);
-      }
+      HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
     }
-    if (!h->mons.empty()) {
+    if (rec) record_monitors(h, n, false, st);
+    // ---------------- H phase ----------------
+    const int h_top = (multi && nb_hi) ? nz - 1 : nz;      // planes [0, h_top) on st, [h_top, nz) on cs
+    if (multi && nb_hi) {
+      HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
+      launch_h_main(h, h_top, nz, cs);
+      launch_pml(h, false, h_top, nz, cs);
+      launch_sources(h, false, n, h_top, nz, cs);
+      HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
+    }
+    if (multi) HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
+    launch_h_main(h, 0, h_top, st);
+    launch_pml(h, false, 0, h_top, st);
+    launch_sources(h, false, n, 0, h_top, st);
+    advance_tfsf_aux(h, false, n, st);
+    if (multi) {
+      HIPCHK(h, hipEventRecord(h->ev_h_int, st));
+      if (!nb_hi) HIPCHK(h, hipStreamWaitEvent(cs, h->ev_h_int, 0));
+      HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));     // WAR: ghost(-1) was read by the last E pass
+      if (exchange(h, false, cs)) return -1;
+    }
+    if (!multi || !nb_lo) fill_ghost_h(h, st);   // physical z-min face of this slab (PMC / periodic)
+    if (rec) {
       if (multi) HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
       record_monitors(h, n, true, st);
     }
     // ---------------- E phase ----------------
-    if (multi && nb_lo && nz > 1) {
-      HIPCHK(h, hipStreamWaitEvent(cs, h->ev_h_int, 0));     // plane 0 needs H[0] from the main stream
-      launch_e_main(h, 0, 1, cs);                             // ... and ghost(-1) just received on cs
-      launch_pml(h, true, 0, 1, cs);
-      launch_sources(h, true, n, 0, 1, cs);
-      launch_ade(h, 0, 1, cs);
+    const int e_bot = (multi && nb_lo) ? 1 : 0;            // planes [0, e_bot) on cs, [e_bot, nz) on st
+    if (multi && nb_lo) {
+      HIPCHK(h, hipStreamWaitEvent(cs, h->ev_h_int, 0));
+      launch_e_main(h, 0, e_bot, cs);
+      launch_pml(h, true, 0, e_bot, cs);
+      launch_sources(h, true, n, 0, e_bot, cs);
+      launch_ade(h, 0, e_bot, cs);
       HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
-      HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));     // top H plane was computed on cs
-      launch_e_main(h, 1, nz, st);
-      launch_pml(h, true, 1, nz, st);
-      launch_sources(h, true, n, 1, nz, st);
-      launch_ade(h, 1, nz, st);
-      advance_tfsf_aux(h, true, n, st);
-      HIPCHK(h, hipEventRecord(h->ev_e_int, st));
-      if (exchange(h, true, cs)) return -1;
-      HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
-    } else {
-      if (multi) HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
-      launch_e_main(h, 0, nz, st);
-      launch_pml(h, true, 0, nz, st);
-      launch_sources(h, true, n, 0, nz, st);
-      launch_ade(h, 0, nz, st);
-      advance_tfsf_aux(h, true, n, st);
-      if (multi) {
-        HIPCHK(h, hipEventRecord(h->ev_e_int, st));
-        HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
-        if (exchange(h, true, cs)) return -1;
-        HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
-      } else {
-        fill_ghost_e(h, st);
-      }
     }
+    if (multi && nb_hi) HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
+    launch_e_main(h, e_bot, nz, st);
+    launch_pml(h, true, e_bot, nz, st);
+    launch_sources(h, true, n, e_bot, nz, st);
+    launch_ade(h, e_bot, nz, st);
+    advance_tfsf_aux(h, true, n, st);
+    if (multi) {
+      HIPCHK(h, hipEventRecord(h->ev_e_int, st));
+      if (!nb_lo) HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
+      HIPCHK(h, hipStreamWaitEvent(cs, h->ev_h_int, 0));     // WAR: ghost(nz) was read by this H pass
+      if (exchange(h, true, cs)) return -1;
+    }
+    if (!multi || !nb_hi) fill_ghost_e(h, st);   // physical z-max face of this slab (periodic)
     h->step = n + 1;
     // ---------------- field decay / divergence ----------------
     if (h->decay_every > 0 && (h->step % h->decay_every) == 0) {

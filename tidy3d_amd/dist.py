@@ -1,0 +1,89 @@
+"""Multi-GPU plumbing: one process per GPU (torchrun), z-slab decomposition, RCCL halo exchange.
+
+``torch.distributed`` is used for *plumbing only*: broadcasting the RCCL unique id that the C
+library's communicator is created from, barriers, and gathering monitor buffers to rank 0 after
+the run.  The per-step ghost-plane exchange (ncclSend/ncclRecv over xGMI, overlapped with the
+interior update on a second HIP stream) lives entirely inside ``libfdtd_hip.so``
+(csrc/fdtd_capi.hip, ``exchange``); there is no data-path collective besides that
+nearest-neighbour exchange and one scalar all-reduce per field-decay evaluation
+(SURVEY.md section 8(e)).
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from .engine import HipEngine, split_slabs
+from .spec import SolverSpec
+
+
+def env_ranks() -> Tuple[int, int, int]:
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def make_engine(spec: SolverSpec, lib=None, device: Optional[int] = None, **kw) -> HipEngine:
+    """This rank's slab engine with its RCCL communicator initialised (needs an initialised
+    torch.distributed process group when WORLD_SIZE > 1)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return HipEngine(spec, lib=lib, device=device or 0, **kw)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    nz = spec.shape[2]
+    if nz < 2 * world:
+        raise ValueError(f"{nz} planes cannot be split into {world} slabs of >= 2 planes")
+    slabs = split_slabs(nz, world)
+    if device is None:
+        device = env_ranks()[2]
+    eng = HipEngine(spec, lib=lib, device=device, slab=slabs[rank], rank=rank, n_ranks=world, **kw)
+    uid = [eng.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    eng.comm_init(uid[0])
+    return eng
+
+
+def gather_results(eng: HipEngine) -> Optional[Dict[str, np.ndarray]]:
+    """Collect every monitor's slab-local part on rank 0 and stitch along z.  Returns the
+    full-box arrays (same layout as HipEngine.results()) on rank 0, None elsewhere."""
+    import torch.distributed as dist
+    local = eng.monitor_data()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return {k: v[0] for k, v in local.items()}
+    rank, world = dist.get_rank(), dist.get_world_size()
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(local, gathered, dst=0)
+    if rank != 0:
+        return None
+    out = {}
+    for m in eng.spec.monitors:
+        parts = [(g[m.name][1], g[m.name][0]) for g in gathered if m.name in g]
+        if not parts:
+            continue
+        parts.sort(key=lambda p: p[0][0])
+        out[m.name] = np.concatenate([p[1] for p in parts], axis=2)
+        assert out[m.name].shape[2] == m.hi[2] - m.lo[2], (m.name, out[m.name].shape)
+    return out
+
+
+def run(simulation, verbose: bool = True, n_steps: Optional[int] = None, lib=None, **kw):
+    """Distributed counterpart of ``tidy3d_amd.web.run``: every rank calls it with the same
+    Simulation; rank 0 returns the SimulationData, the others None."""
+    import torch.distributed as dist
+    from .data import assemble
+    from .discretize import discretize
+    from .web import _as_mirror
+    sim, _ = _as_mirror(simulation)
+    sim.validate_pre_upload(source_required=True)
+    disc = discretize(sim, n_steps=n_steps)
+    eng = make_engine(disc.spec, lib=lib, **kw)
+    try:
+        stats = eng.run()
+        raw = gather_results(eng)
+    finally:
+        eng.close()
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if rank != 0:
+        return None
+    return assemble(disc, raw, log=f"distributed run over {eng.n_ranks} z-slabs", diverged=bool(stats.diverged))

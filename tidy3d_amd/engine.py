@@ -64,7 +64,8 @@ def _local_pml_counts(tables: List[np.ndarray]) -> Tuple[int, int]:
 class HipEngine:
     def __init__(self, spec: SolverSpec, lib: Optional[L.FdtdLib] = None, device: int = 0,
                  variant: int = L.VARIANT_AUTO, flags: int = 0, z_chunk: int = 0,
-                 slab: Optional[Tuple[int, int]] = None, rank: int = 0, n_ranks: int = 1):
+                 slab: Optional[Tuple[int, int]] = None, rank: int = 0, n_ranks: int = 1,
+                 force_comm: bool = False):
         self.lib = lib or L.load_library()
         self.spec = spec
         self.rank, self.n_ranks = rank, n_ranks
@@ -81,7 +82,7 @@ class HipEngine:
         cfg.nx, cfg.ny, cfg.nz = nx, ny, self.nzl
         bc = [spec.bc[0][0], spec.bc[0][1], spec.bc[1][0], spec.bc[1][1], spec.bc[2][0], spec.bc[2][1]]
         per_z = spec.bc[2][0] == BC_PERIODIC
-        if n_ranks > 1:
+        if n_ranks > 1 or force_comm:    # force_comm: 1-rank RCCL self exchange (periodic z), a test aid
             if self.z0 > 0 or per_z:
                 bc[4] = L.BC_NEIGHBOR
             if self.z1 < nz or per_z:
