@@ -1,11 +1,11 @@
 #!/bin/bash
-# One GPU-box visit: parity tests, bench (+launch-geometry sweep), rocprofv3 kernel trace.
+# One GPU-box visit: parity tests, bench, rocprofv3 kernel trace and (separate passes) PMC counters.
 # Everything the judge should see is copied from gpurun_out/ into profiles/ afterwards.
 set -x
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-rocm-smi --showproductname 2>&1 | head -5 > gpurun_out/device.txt
-(timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -40) > gpurun_out/pytest_gpu.log
+R=$GRAFT_REPO_ROOT
+(timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -40) > gpurun_out/pytest_gpu.log
 (timeout 600 python bench.py --steps 100 --warmup 10 ${BENCH_EXTRA:-} ) > gpurun_out/bench.json 2> gpurun_out/bench.err
 cat gpurun_out/bench.json
 if [ -n "$DO_SWEEP" ]; then
@@ -13,9 +13,13 @@ if [ -n "$DO_SWEEP" ]; then
 fi
 if [ -n "$DO_PROF" ]; then
   cd /tmp
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof.err
-  cd $GRAFT_REPO_ROOT
-  find gpurun_out/prof -name '*stats*' | head; 
-  find gpurun_out/prof -name '*kernel_trace*' -size +20M -delete
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o trace -- python $R/bench.py --steps 20 --warmup 3 --no-cpu > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc_$C -o pmc -- python $R/bench.py --steps 6 --warmup 2 --no-cpu > $R/gpurun_out/pmc_$C.json 2> $R/gpurun_out/pmc_$C.err
+  done
+  cd $R
+  find gpurun_out -name '*kernel_trace*' -size +8M -delete
+  python scripts/summarize_pmc.py gpurun_out > gpurun_out/pmc_summary.json 2> gpurun_out/pmc_summary.err
+  cat gpurun_out/pmc_summary.json
 fi
 tail -5 gpurun_out/pytest_gpu.log
