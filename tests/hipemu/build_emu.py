@@ -23,7 +23,7 @@ def build(force: bool = False) -> str:
     cxx = "/opt/rocm/lib/llvm/bin/clang++"
     if not os.path.exists(cxx):
         cxx = shutil.which("clang++") or shutil.which("g++")
-    cmd = [cxx, "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-I" + HERE,
+    cmd = [cxx, "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-I" + HERE,
            "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-pass-failed",
            "-x", "c++", os.path.join(CSRC, "fdtd_capi.hip"), os.path.join(HERE, "hip_emu.cpp"),
            "-o", LIB]

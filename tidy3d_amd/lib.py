@@ -53,7 +53,7 @@ class FdtdLib:
     def __init__(self, path: str):
         self.path = path
         try:
-            self.dll = C.CDLL(path, mode=C.RTLD_GLOBAL)
+            self.dll = C.CDLL(path)      # RTLD_LOCAL: never interpose another library's symbols
         except OSError as e:
             raise SolverLibraryError(f"cannot load the HIP solver library '{path}': {e}") from e
         missing = [s for s in SYMBOLS if not hasattr(self.dll, s)]
