@@ -164,11 +164,20 @@ def main():
     local_cells = (z1 - z0) * n * n
     h_ms = st.h_kernel_ms / max(1, st.h_kernel_launches)
     e_ms = st.e_kernel_ms / max(1, st.e_kernel_launches)
+    f_ms = st.fused_kernel_ms / max(1, st.fused_kernel_launches)
     # when boundary planes are launched separately, normalise to the per-step duration
     h_step = st.h_kernel_ms / kr
     e_step = st.e_kernel_ms / kr
-    dom, dom_ms = ("e_update_kernel", e_step) if e_step >= h_step else ("h_update_kernel", h_step)
-    achieved = BYTES_PER_CELL_PASS * local_cells / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
+    f_step = st.fused_kernel_ms / kr
+    if st.fused_kernel_launches:
+        # one launch advances E and H: algorithmic bytes of the launch = both passes (72 B/cell,
+        # the SURVEY.md section 8(d) figure); its real minimum traffic is 48 B/cell
+        dom, dom_ms, dom_bytes = "fused_step_kernel", f_step, 2 * BYTES_PER_CELL_PASS * local_cells
+    elif e_step >= h_step:
+        dom, dom_ms, dom_bytes = "e_update_kernel", e_step, BYTES_PER_CELL_PASS * local_cells
+    else:
+        dom, dom_ms, dom_bytes = "h_update_kernel", h_step, BYTES_PER_CELL_PASS * local_cells
+    achieved = dom_bytes / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
 
     out = {
         "metric": "Mcells/s on 512^3 Yee grid", "value": value, "unit": "Mcells/s",
@@ -183,9 +192,14 @@ def main():
                    "roofline_mcells_per_gpu": HBM_PEAK / (2 * BYTES_PER_CELL_PASS) / 1e6},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
-                     "avg_launch_ms": {"h_update_kernel": h_ms, "e_update_kernel": e_ms},
-                     "per_step_ms": {"h_update_kernel": h_step, "e_update_kernel": e_step},
-                     "algorithmic_bytes_per_launch": BYTES_PER_CELL_PASS * local_cells,
+                     "avg_launch_ms": {"h_update_kernel": h_ms, "e_update_kernel": e_ms,
+                                       "fused_step_kernel": f_ms},
+                     "per_step_ms": {"h_update_kernel": h_step, "e_update_kernel": e_step,
+                                     "fused_step_kernel": f_step},
+                     "algorithmic_bytes_per_launch": dom_bytes,
+                     "note": ("fused sweep: frac uses the 72 B/cell-step two-pass figure of SURVEY.md 8(d); "
+                              "its own minimum traffic is 48 B/cell-step, i.e. frac_vs_48B = %.3f"
+                              % (achieved * 48.0 / 72.0 / HBM_PEAK)) if dom == "fused_step_kernel" else "",
                      "whole_step_frac": (2 * BYTES_PER_CELL_PASS * cells * K / elapsed) / (HBM_PEAK * world)},
     }
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -38,7 +38,8 @@ typedef struct FdtdSolver FdtdSolver;
 enum { FDTD_BC_PEC = 0, FDTD_BC_PMC = 1, FDTD_BC_PERIODIC = 2, FDTD_BC_NEIGHBOR = 3 };
 enum { FDTD_MON_TIME = 0, FDTD_MON_DFT = 1 };
 /* kernel variants of the two main update kernels (A/B-tested by bench.py --variant) */
-enum { FDTD_VARIANT_AUTO = 0, FDTD_VARIANT_SIMPLE = 1, FDTD_VARIANT_ZMARCH = 2, FDTD_VARIANT_LDS = 3 };
+/* AUTO = FUSED on one GPU (single-sweep E+H update, 48 B/cell-step), two-pass ZMARCH otherwise */
+enum { FDTD_VARIANT_AUTO = 0, FDTD_VARIANT_SIMPLE = 1, FDTD_VARIANT_ZMARCH = 2, FDTD_VARIANT_FUSED = 3 };
 enum { FDTD_FLAG_TIME_KERNELS = 1 };   /* bracket every main-kernel launch with hipEvents */
 
 typedef struct FdtdConfig {
@@ -63,6 +64,8 @@ typedef struct FdtdStats {
   int64_t h_kernel_launches;
   int64_t e_kernel_launches;
   int64_t device_bytes;      /* device memory held by the handle                                 */
+  double  fused_kernel_ms;   /* ... and of the fused E+H sweep                                   */
+  int64_t fused_kernel_launches;
 } FdtdStats;
 
 /* progress callback: (step, time [s], field_decay) -> non-zero aborts the run (Ctrl-C path).
@@ -76,7 +79,9 @@ int  fdtd_create(const FdtdConfig* cfg, FdtdSolver** out);
 void fdtd_destroy(FdtdSolver* h);
 
 /* 1/primal and 1/dual step vectors of one axis (length = n cells of that axis of this slab;
- * ref grid.py:393-417).  axis 0,1,2 = x,y,z. */
+ * ref grid.py:393-417).  axis 0,1,2 = x,y,z.  For z, n may also be nz + 2: then entry 0 and
+ * n-1 are the values of the planes just below / above the slab (needed by the fused sweep on a
+ * z-slab of a non-uniform grid); with n == nz they are derived from the boundary condition. */
 int fdtd_set_steps(FdtdSolver* h, int axis, const float* inv_primal, const float* inv_dual, int n);
 
 /* material table (index 0 = PEC: ca = cb = 0) and, optionally, the staircased material index
@@ -145,7 +150,7 @@ int fdtd_comm_init(FdtdSolver* h, const char id[128], int rank, int n_ranks);
 int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user);
 int fdtd_get_stats(FdtdSolver* h, FdtdStats* out);
 /* tuning knobs that may change between runs of one handle (bench A/B without re-upload) */
-enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_ROWS = 3 };
+enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_ROWS = 3, FDTD_OPT_XCD_REMAP = 4 };
 int fdtd_set_option(FdtdSolver* h, int key, int value);
 int fdtd_reset(FdtdSolver* h);      /* zero fields, auxiliaries, monitors and the step counter */
 

@@ -1,0 +1,70 @@
+"""The fused single-sweep E+H kernel against the two-pass kernels (same library, same inputs):
+tile edges in x (two 256-cell tiles -> the x-halo column), y (halo wave) and z (chunk prologue),
+every boundary type, materials, ADE and CPML corrections around it."""
+import numpy as np
+import pytest
+
+import tidy3d_amd.schema as td
+from tidy3d_amd import lib as L
+from tidy3d_amd.discretize import discretize
+from tidy3d_amd.engine import HipEngine
+
+DL = 0.05
+PULSE = td.GaussianPulse(freq0=3e14, fwidth=1.5e14)
+
+
+def _sim(N, bspec, structures=()):
+    size = tuple(n * DL for n in N)
+    c = (0.3 * size[0], 0.1, 0.05)
+    return td.Simulation(size=size, grid_spec=td.GridSpec.uniform(dl=DL), run_time=1e-12,
+                         structures=list(structures),
+                         sources=[td.PointDipole(center=c, source_time=PULSE, polarization="Ez"),
+                                  td.PointDipole(center=(-0.2 * size[0], -0.1, 0), source_time=PULSE, polarization="Hy"),
+                                  td.PointDipole(center=(0.01, 0.02, -0.1), source_time=PULSE, polarization="Ex")],
+                         monitors=[td.FieldMonitor(center=(0, 0, 0), size=(td.inf, td.inf, 0), freqs=[3e14], name="f"),
+                                   td.FieldTimeMonitor(center=(0, 0, 0), size=(0.2, 0.2, 0.2), name="t", interval=3,
+                                                       colocate=False)],
+                         boundary_spec=bspec, shutoff=0)
+
+
+PER = td.BoundarySpec(x=td.Boundary.periodic(), y=td.Boundary.periodic(), z=td.Boundary.periodic())
+PEC = td.BoundarySpec.all_sides(td.PECBoundary())
+PMC = td.BoundarySpec(x=td.Boundary(minus=td.PMCBoundary(), plus=td.PECBoundary()),
+                      y=td.Boundary(minus=td.PMCBoundary(), plus=td.PECBoundary()),
+                      z=td.Boundary(minus=td.PMCBoundary(), plus=td.PECBoundary()))
+PML = td.BoundarySpec(x=td.Boundary.pml(num_layers=4), y=td.Boundary.pml(num_layers=3), z=td.Boundary.pml(num_layers=3))
+MEDIA = [td.Structure(geometry=td.Sphere(center=(0.05, 0, 0), radius=0.2),
+                      medium=td.Lorentz(eps_inf=2.0, coeffs=[(1.5, 4e14, 3e13)])),
+         td.Structure(geometry=td.Box(center=(-0.3, 0, 0), size=(0.25, 0.3, 0.2)),
+                      medium=td.Medium(permittivity=3.0, conductivity=0.02)),
+         td.Structure(geometry=td.Box(center=(0.3, 0.1, 0), size=(0.1, 0.1, 0.1)), medium=td.PEC)]
+
+CONFIGS = {
+    "periodic_two_x_tiles": ((264, 10, 9), PER, ()),
+    "pec_two_x_tiles": ((260, 9, 8), PEC, ()),
+    "pmc_min_faces": ((16, 10, 9), PMC, ()),
+    "pml_media": ((32, 14, 10), PML, MEDIA),
+    "periodic_media": ((32, 12, 10), PER, MEDIA),
+}
+
+
+def _run(spec, lib, variant, rows, zc):
+    with HipEngine(spec, lib=lib, variant=variant, z_chunk=zc) as e:
+        e.set_option(L.OPT_ROWS, rows)
+        e.run()
+        return [e.get_field(c) for c in range(6)], e.results()
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+@pytest.mark.parametrize("rows,zc", [(4, 16), (3, 2), (1, 1), (7, 5)])
+def test_fused_equals_two_pass(name, rows, zc, emu_lib):
+    N, bspec, structures = CONFIGS[name]
+    disc = discretize(_sim(N, bspec, structures), n_steps=24)
+    assert disc.spec.shape[0] % 4 == 0
+    ref_f, ref_m = _run(disc.spec, emu_lib, L.VARIANT_ZMARCH, 4, 2)
+    got_f, got_m = _run(disc.spec, emu_lib, L.VARIANT_FUSED, rows, zc)
+    scale = max(np.abs(x).max() for x in ref_f[:3]), max(np.abs(x).max() for x in ref_f[3:])
+    for c in range(6):
+        np.testing.assert_allclose(got_f[c], ref_f[c], rtol=0, atol=2e-6 * scale[c // 3])
+    for k in ref_m:
+        np.testing.assert_allclose(got_m[k], ref_m[k], rtol=0, atol=2e-6 * np.abs(ref_m[k]).max())

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/fdtd_hip.h"
@@ -83,7 +84,10 @@ struct FdtdSolver {
   std::string err;
   std::vector<DevBuf> bufs;          // everything hipMalloc'ed (freed in destroy)
   float* fbase[6] = {};              // allocation base (ghost plane -1)
-  FieldP f{};                        // interior plane 0
+  FieldP f{};                        // interior plane 0 of the CURRENT field set
+  float* fbase2[6] = {};             // second set for the fused (ping-pong) sweep, lazily allocated
+  FieldP f2{};
+  float* step_base[2] = {};          // 1/primal_z, 1/dual_z with one ghost entry on each side
   size_t field_bytes = 0;
   float *ip[3] = {}, *idl[3] = {};
   uint8_t* mat[3] = {};
@@ -107,7 +111,10 @@ struct FdtdSolver {
   double energy_max = 0.0;
   long long step = 0;
   FdtdStats stats{};
-  int zchunk = 32;
+  int zchunk = 2;
+  int zchunk_f = 16;                 // planes marched per workgroup by the fused sweep
+  int rows_f = 7;                    // rows per workgroup of the fused sweep (+1 halo wave = 512 threads)
+  int xcd_remap = 1;
   int rows = 4;
   // RCCL
   ncclComm_t comm = nullptr;
@@ -210,8 +217,9 @@ void launch_h_main(FdtdSolver* h, int kbeg, int kend, hipStream_t st) {
   const bool vec = (g.nx % 4 == 0) && h->cfg.variant != FDTD_VARIANT_SIMPLE;
   const int V = vec ? 4 : 1;
   const int zc = (h->cfg.variant == FDTD_VARIANT_SIMPLE) ? 1 : h->zchunk;
-  dim3 block(64, h->rows, 1);
-  dim3 grid((g.nx + 64 * V - 1) / (64 * V), (g.ny + h->rows - 1) / h->rows, (kend - kbeg + zc - 1) / zc);
+  const int rows = h->rows;                             // <= 8: __launch_bounds__(512)
+  dim3 block(64, rows, 1);
+  dim3 grid((g.nx + 64 * V - 1) / (64 * V), (g.ny + rows - 1) / rows, (kend - kbeg + zc - 1) / zc);
   time_begin(h, 0, st);
   if (vec)
     hipLaunchKernelGGL((h_update_kernel<4>), grid, block, 0, st, g, h->f, step_params(h), kbeg, kend, zc);
@@ -227,8 +235,9 @@ void launch_e_main(FdtdSolver* h, int kbeg, int kend, hipStream_t st) {
   const int V = vec ? 4 : 1;
   const int zc = (h->cfg.variant == FDTD_VARIANT_SIMPLE) ? 1 : h->zchunk;
   const bool has_mat = h->mat[0] != nullptr;
-  dim3 block(64, h->rows, 1);
-  dim3 grid((g.nx + 64 * V - 1) / (64 * V), (g.ny + h->rows - 1) / h->rows, (kend - kbeg + zc - 1) / zc);
+  const int rows = h->rows;                             // <= 8: __launch_bounds__(512)
+  dim3 block(64, rows, 1);
+  dim3 grid((g.nx + 64 * V - 1) / (64 * V), (g.ny + rows - 1) / rows, (kend - kbeg + zc - 1) / zc);
   MatP m = mat_params(h);
   StepP s = step_params(h);
   time_begin(h, 1, st);
@@ -241,6 +250,50 @@ void launch_e_main(FdtdSolver* h, int kbeg, int kend, hipStream_t st) {
   else
     hipLaunchKernelGGL((e_update_kernel<1, false>), grid, block, 0, st, g, h->f, s, m, kbeg, kend, zc);
   time_end(h, st);
+}
+
+// fused E+H sweep: reads the current set, writes the other one, then swaps them
+int launch_fused(FdtdSolver* h, hipStream_t st) {
+  const GridP& g = h->g;
+  if (!h->fbase2[0]) {
+    const size_t fcount = (size_t)g.sxy * (g.nz + 2);
+    for (int c = 0; c < 6; ++c)
+      if (dev_alloc(h, &h->fbase2[c], fcount)) return -1;
+    h->f2.ex = h->fbase2[0] + g.sxy; h->f2.ey = h->fbase2[1] + g.sxy; h->f2.ez = h->fbase2[2] + g.sxy;
+    h->f2.hx = h->fbase2[3] + g.sxy; h->f2.hy = h->fbase2[4] + g.sxy; h->f2.hz = h->fbase2[5] + g.sxy;
+  }
+  const int R = h->rows_f;
+  const int zc = h->zchunk_f;
+  dim3 block(64, R + 1, 1);
+  const int nbx = (g.nx + 255) / 256, nby = (g.ny + R - 1) / R, nbz = (g.nz + zc - 1) / zc;
+  const int total = nbx * nby * nbz;
+  const int remap = h->xcd_remap ? 1 : 0;
+  dim3 grid(remap ? ((total + 7) / 8) * 8 : total, 1, 1);
+  const size_t shmem = (size_t)2 * 2 * (R + 1) * 64 * sizeof(float4);
+  const int pmc = h->cfg.bc[4] == FDTD_BC_PMC;
+  MatP m = mat_params(h);
+  StepP s = step_params(h);
+  time_begin(h, 2, st);
+  if (h->mat[0])
+    hipLaunchKernelGGL((fused_step_kernel<true>), grid, block, shmem, st, g, h->f, h->f2, s, m, 0, g.nz, zc, pmc, nbx, nby, nbz, remap);
+  else
+    hipLaunchKernelGGL((fused_step_kernel<false>), grid, block, shmem, st, g, h->f, h->f2, s, m, 0, g.nz, zc, pmc, nbx, nby, nbz, remap);
+  time_end(h, st);
+  std::swap(h->f, h->f2);
+  for (int c = 0; c < 6; ++c) std::swap(h->fbase[c], h->fbase2[c]);
+  return 0;
+}
+
+// periodic z, fused sweep: the prologue recomputes H^{n+1/2}[-1] from ghost copies of E (all three
+// components) and H_x, H_y of plane nz-1; the top plane needs E_x, E_y of plane 0
+void fill_ghost_fused(FdtdSolver* h, hipStream_t st) {
+  if (h->cfg.bc[4] != FDTD_BC_PERIODIC) return;
+  const long long pc = plane_cells(h);
+  const long long top = (long long)(h->g.nz - 1) * pc;
+  float* lo[5] = {h->f.ex, h->f.ey, h->f.ez, h->f.hx, h->f.hy};
+  for (float* p : lo) hipMemcpyAsync(p - pc, p + top, pc * 4, hipMemcpyDeviceToDevice, st);
+  hipMemcpyAsync(h->f.ex + (long long)h->g.nz * pc, h->f.ex, pc * 4, hipMemcpyDeviceToDevice, st);
+  hipMemcpyAsync(h->f.ey + (long long)h->g.nz * pc, h->f.ey, pc * 4, hipMemcpyDeviceToDevice, st);
 }
 
 // slabs of one axis: E-side ranges [0,n_lo) and [N-n_hi+1,N); H-side [0,n_lo) and [N-n_hi,N)
@@ -464,6 +517,7 @@ int fdtd_create(const FdtdConfig* cfg, FdtdSolver** out) {
   // the 256 MiB Infinity Cache already serves the k+1 plane re-read, and more, smaller
   // workgroups balance the 256 CUs better than long marches.
   h->zchunk = cfg->z_chunk > 0 ? cfg->z_chunk : 2;
+  h->zchunk_f = cfg->z_chunk > 0 ? cfg->z_chunk : 16;
   h->rows = 4;
   int rc = 0;
   const size_t fcount = (size_t)g.sxy * (g.nz + 2);
@@ -478,9 +532,14 @@ int fdtd_create(const FdtdConfig* cfg, FdtdSolver** out) {
     // default: unit steps, vacuum
     const int N[3] = {g.nx, g.ny, g.nz};
     for (int a = 0; a < 3 && !rc; ++a) {
-      std::vector<float> ones(N[a], 1.0f);
+      // the z vectors carry one ghost entry below and above (indices -1 and nz)
+      std::vector<float> ones(N[a] + (a == 2 ? 2 : 0), 1.0f);
       rc = dev_upload(h, &h->ip[a], (const float*)ones.data(), ones.size());
       if (!rc) rc = dev_upload(h, &h->idl[a], (const float*)ones.data(), ones.size());
+      if (!rc && a == 2) {
+        h->step_base[0] = h->ip[2]; h->step_base[1] = h->idl[2];
+        h->ip[2] += 1; h->idl[2] += 1;
+      }
     }
   }
   if (!rc && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) rc = fail(nullptr, "hipStreamCreate failed");
@@ -522,10 +581,25 @@ void fdtd_destroy(FdtdSolver* h) {
 int fdtd_set_steps(FdtdSolver* h, int axis, const float* inv_primal, const float* inv_dual, int n) {
   if (!h) return -1;
   const int N[3] = {h->g.nx, h->g.ny, h->g.nz};
-  if (axis < 0 || axis > 2 || n != N[axis]) return fail(h, "fdtd_set_steps: axis %d expects %d entries, got %d", axis, axis >= 0 && axis < 3 ? N[axis] : -1, n);
+  if (axis < 0 || axis > 2) return fail(h, "fdtd_set_steps: bad axis %d", axis);
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  if (axis == 2 && n == N[2] + 2) {        // ghost entries supplied (z-slab of a non-uniform grid)
+    HIPCHK(h, hipMemcpy(h->step_base[0], inv_primal, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->step_base[1], inv_dual, (size_t)n * 4, hipMemcpyHostToDevice));
+    return 0;
+  }
+  if (n != N[axis]) return fail(h, "fdtd_set_steps: axis %d expects %d entries, got %d", axis, N[axis], n);
   HIPCHK(h, hipMemcpy(h->ip[axis], inv_primal, (size_t)n * 4, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(h->idl[axis], inv_dual, (size_t)n * 4, hipMemcpyHostToDevice));
+  if (axis == 2) {                         // ghost entries: wrap for periodic z, replicate otherwise
+    const bool per = h->cfg.bc[4] == FDTD_BC_PERIODIC;
+    const float lo[2] = {per ? inv_primal[n - 1] : inv_primal[0], per ? inv_dual[n - 1] : inv_dual[0]};
+    const float hi[2] = {per ? inv_primal[0] : inv_primal[n - 1], per ? inv_dual[0] : inv_dual[n - 1]};
+    for (int q = 0; q < 2; ++q) {
+      HIPCHK(h, hipMemcpy(h->step_base[q], &lo[q], 4, hipMemcpyHostToDevice));
+      HIPCHK(h, hipMemcpy(h->step_base[q] + n + 1, &hi[q], 4, hipMemcpyHostToDevice));
+    }
+  }
   return 0;
 }
 
@@ -718,7 +792,7 @@ int fdtd_set_field(FdtdSolver* h, int comp, const float* host, size_t bytes) {
   HIPCHK(h, hipSetDevice(h->cfg.device));
   HIPCHK(h, hipMemcpy(field_ptr(h, comp), host, bytes, hipMemcpyHostToDevice));
   // keep single-slab ghost planes consistent with the new interior
-  if (h->comm == nullptr) { fill_ghost_h(h, h->stream); fill_ghost_e(h, h->stream); HIPCHK(h, hipStreamSynchronize(h->stream)); }
+  if (h->comm == nullptr) { fill_ghost_h(h, h->stream); fill_ghost_e(h, h->stream); fill_ghost_fused(h, h->stream); HIPCHK(h, hipStreamSynchronize(h->stream)); }
   else if (comp == 0 || comp == 1 || comp == 3 || comp == 4) {
     // with a communicator the ghost planes come from the neighbour: do one exchange now
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -767,6 +841,7 @@ int fdtd_reset(FdtdSolver* h) {
   HIPCHK(h, hipSetDevice(h->cfg.device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   for (int c = 0; c < 6; ++c) HIPCHK(h, hipMemset(h->fbase[c], 0, h->field_bytes));
+  for (int c = 0; c < 6; ++c) if (h->fbase2[c]) HIPCHK(h, hipMemset(h->fbase2[c], 0, h->field_bytes));
   const size_t nc = (size_t)n_cells(h);
   for (int a = 0; a < 3; ++a) {
     PmlAxisDev& P = h->pml[a];
@@ -804,6 +879,10 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   h->stats.stopped_early = 0;
   HIPCHK(h, hipEventRecord(h->ev0, st));
   if (multi && (nb_lo || nb_hi) && nz < 2) return fail(h, "fdtd_run: a z-slab needs at least 2 planes");
+  // the fused sweep is the default single-GPU path whenever rows are float4-aligned
+  const bool fused = !multi && (h->g.nx % 4 == 0) &&
+                     (h->cfg.variant == FDTD_VARIANT_FUSED || h->cfg.variant == FDTD_VARIANT_AUTO) &&
+                     h->rows_f <= 15;
   // Two-stream schedule of one step (st = main stream, cs = comm stream):
   //   cs: [H top plane] -> send/recv H -> [E bottom plane] -> send/recv E      (boundary planes first)
   //   st: [H interior ] ----------------> [E interior    ]
@@ -823,6 +902,20 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
     }
     if (rec) record_monitors(h, n, false, st);
+    if (fused) {
+      // H-side corrections are additive: pre-apply them to H^{n-1/2}; E-side ones follow the sweep
+      launch_pml(h, false, 0, nz, st);
+      launch_sources(h, false, n, 0, nz, st);
+      advance_tfsf_aux(h, false, n, st);
+      if (launch_fused(h, st)) return -1;
+      if (rec) record_monitors(h, n, true, st);
+      launch_pml(h, true, 0, nz, st);
+      launch_sources(h, true, n, 0, nz, st);
+      launch_ade(h, 0, nz, st);
+      advance_tfsf_aux(h, true, n, st);
+      fill_ghost_fused(h, st);
+      h->step = n + 1;
+    } else {
     // ---------------- H phase ----------------
     const int h_top = (multi && nb_hi) ? nz - 1 : nz;      // planes [0, h_top) on st, [h_top, nz) on cs
     if (multi && nb_hi) {
@@ -872,6 +965,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     }
     if (!multi || !nb_hi) fill_ghost_e(h, st);   // physical z-max face of this slab (periodic)
     h->step = n + 1;
+    }
     // ---------------- field decay / divergence ----------------
     if (h->decay_every > 0 && (h->step % h->decay_every) == 0) {
       if (multi) HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
@@ -919,13 +1013,14 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->stats.run_ms = ms;
   h->stats.steps_done = h->step;
-  h->stats.h_kernel_ms = h->stats.e_kernel_ms = 0.0;
-  h->stats.h_kernel_launches = h->stats.e_kernel_launches = 0;
+  h->stats.h_kernel_ms = h->stats.e_kernel_ms = h->stats.fused_kernel_ms = 0.0;
+  h->stats.h_kernel_launches = h->stats.e_kernel_launches = h->stats.fused_kernel_launches = 0;
   for (size_t i = 0; i < h->kev_kind.size(); ++i) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, h->kev[2 * i], h->kev[2 * i + 1]) != hipSuccess) continue;
     if (h->kev_kind[i] == 0) { h->stats.h_kernel_ms += t; h->stats.h_kernel_launches++; }
-    else { h->stats.e_kernel_ms += t; h->stats.e_kernel_launches++; }
+    else if (h->kev_kind[i] == 1) { h->stats.e_kernel_ms += t; h->stats.e_kernel_launches++; }
+    else { h->stats.fused_kernel_ms += t; h->stats.fused_kernel_launches++; }
   }
   return 0;
 }
@@ -935,8 +1030,9 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
   switch (key) {
     case FDTD_OPT_FLAGS: h->cfg.flags = value; return 0;
     case FDTD_OPT_VARIANT: h->cfg.variant = value; return 0;
-    case FDTD_OPT_ZCHUNK: if (value < 1) break; h->zchunk = value; return 0;
-    case FDTD_OPT_ROWS: if (value < 1 || value > 8) break; h->rows = value; return 0;
+    case FDTD_OPT_ZCHUNK: if (value < 1) break; h->zchunk = value; h->zchunk_f = value; return 0;
+    case FDTD_OPT_ROWS: if (value < 1 || value > 15) break; h->rows = value > 8 ? 8 : value; h->rows_f = value; return 0;
+    case FDTD_OPT_XCD_REMAP: h->xcd_remap = value != 0; return 0;
     default: break;
   }
   return fail(h, "fdtd_set_option: bad key/value %d/%d", key, value);

@@ -277,6 +277,251 @@ __global__ __launch_bounds__(512) void e_update_kernel(GridP g, FieldP f, StepP 
 }
 
 // =============================================================================================
+// K1+K2 fused: one sweep advances H by curl E AND E by curl of the *new* H, reading set `a`
+// (E^n, H^{n-1/2}) and writing set `b` (E^{n+1}, H^{n+1/2})  — 6 reads + 6 writes = 48 B per
+// cell-step of HBM traffic instead of 72 B for the two-pass form.  Ping-pong buffers make the
+// sweep race-free; every additive correction (CPML, sources, ADE) commutes with it: H-side
+// corrections are pre-applied to H^{n-1/2} in `a`, E-side ones post-applied to E^{n+1} in `b`.
+//
+// Workgroup = (64 lanes x 4 cells) x (R rows + 1 halo row below); marches `zchunk` planes.
+//   * H^{n+1/2}[k] is computed in registers by every wave (the halo wave recomputes row j0-1);
+//   * E^{n+1}[k] needs H^{n+1/2} at x-1 (lane-1 via __shfl_up; the lane at the tile edge
+//     recomputes the x-halo column itself), at y-1 (previous wave via a double-buffered LDS
+//     slot, one barrier per plane) and at z-1 (registers carried from the previous plane; the
+//     first plane of a chunk recomputes H^{n+1/2}[k0-1] in a prologue).
+// =============================================================================================
+template <bool MAT>
+__global__ __launch_bounds__(1024) void fused_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
+                                                          int kbeg, int kend, int zchunk, int pmc_z0,
+                                                          int nbx, int nby, int nbz, int xcd_remap) {
+  constexpr int V = 4;
+  // 1-D launch; logical tile (bx, by, bz) with by fastest.  XCD-aware remap: hardware block L runs
+  // on XCD L % 8 (observed dispatch order, used for speed only), so XCD x is handed the contiguous
+  // range of logical tiles [x * per, (x+1) * per): y-neighbouring tiles — which share their halo
+  // row — are resident on the same XCD at about the same time and meet in its L2.
+  const int total = nbx * nby * nbz;
+  int t = blockIdx.x;
+  if (xcd_remap) {
+    const int per = (total + 7) >> 3;
+    t = (t & 7) * per + (t >> 3);
+    if (t >= total) return;              // whole workgroup leaves before any barrier
+  }
+  const int tile_y = t % nby;
+  const int tile_x = (t / nby) % nbx;
+  const int tile_z = t / (nby * nbx);
+  __shared__ float2 lut_s[256];
+  HIP_DYNAMIC_SHARED(float4, xch)      // [2 buffers][2 comps][blockDim.y][64]
+  if constexpr (MAT) {
+    for (int t = threadIdx.y * blockDim.x + threadIdx.x; t < m.n_media; t += blockDim.x * blockDim.y)
+      lut_s[t] = m.lut[t];
+    __syncthreads();
+  }
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int R = blockDim.y - 1;
+  const int i0 = (tile_x * 64 + tx) * V;
+  const bool halo = (ty == 0);
+  const bool per_x = g.bcx0 == BC_PERIODIC, per_y = g.bcy0 == BC_PERIODIC;
+  int j = tile_y * R + ty - 1;
+  bool row_ok = (j >= 0) && (j < g.ny);
+  if (j < 0 && per_y) { j = g.ny - 1; row_ok = true; }
+  const bool act = row_ok && (i0 < g.nx);
+  const int k0 = kbeg + tile_z * zchunk;
+  const int k1 = min(k0 + zchunk, kend);
+  const float ch = g.ch;
+  const bool last_x = (i0 + V >= g.nx);
+  const bool first_x = (i0 == 0);
+  const bool use_jp = (j + 1 < g.ny) || (g.bcy1 == BC_PERIODIC);
+  const long long row = (long long)j * g.nx + i0;
+  const long long rowp = (j + 1 < g.ny) ? row + g.nx : (long long)i0;
+  // x-halo column handled by the first lane of the tile (or the wrapped column for periodic x)
+  const bool xh = act && (tx == 0) && (!first_x || per_x);
+  const int im = first_x ? g.nx - 1 : i0 - 1;
+  const long long rowm_x = (long long)j * g.nx + im;
+  const long long rowpm_x = (j + 1 < g.ny) ? rowm_x + g.nx : (long long)im;
+  const bool wall_y = (j == 0) && (g.bcy0 == BC_PEC);
+  const bool wall_x0 = first_x && (g.bcx0 == BC_PEC);
+
+  float ipx[V], idx[V];
+  zero<V>(ipx); zero<V>(idx);
+  float ipy = 0.f, idy = 0.f, ipx_m = 0.f;
+  if (act) {
+    ldv<V>(ipx, s.ipx + i0);
+    ldv<V>(idx, s.idx + i0);
+    ipy = s.ipy[j];
+    idy = s.idy[j];
+    ipx_m = s.ipx[im];
+  }
+  float exk[V], eyk[V], hxm[V], hym[V];
+  zero<V>(exk); zero<V>(eyk); zero<V>(hxm); zero<V>(hym);
+  float exk_m = 0.f;
+  if (act) {
+    ldv<V>(exk, a.ex + (long long)k0 * g.sxy + row);
+    ldv<V>(eyk, a.ey + (long long)k0 * g.sxy + row);
+  }
+  if (xh) exk_m = a.ex[(long long)k0 * g.sxy + rowm_x];
+  // ---- prologue: H^{n+1/2}[k0-1] (x, y components) of the own cells --------------------------
+  {
+    const bool skip = (pmc_z0 && k0 == 0);
+    const long long p = (long long)(k0 - 1) * g.sxy + row;
+    float ezm[V], ezj[V], exm[V], eym[V], ho[V];
+    zero<V>(ezm); zero<V>(ezj); zero<V>(exm); zero<V>(eym);
+    if (act && !skip) {
+      ldv<V>(ezm, a.ez + p);
+      ldv<V>(exm, a.ex + p);
+      ldv<V>(eym, a.ey + p);
+      if (use_jp) ldv<V>(ezj, a.ez + (long long)(k0 - 1) * g.sxy + rowp);
+    }
+    float ezx = __shfl_down(ezm[0], 1);
+    if (act && !skip) {
+      if (tx == 63 || last_x) {
+        if (!last_x) ezx = a.ez[p + V];
+        else if (g.bcx1 == BC_PERIODIC) ezx = a.ez[p - i0];
+        else ezx = 0.f;
+      }
+      const float ipz = s.ipz[k0 - 1];
+      ldv<V>(ho, a.hx + p);
+#pragma unroll
+      for (int e = 0; e < V; ++e) hxm[e] = ho[e] - ch * ((ezj[e] - ezm[e]) * ipy - (eyk[e] - eym[e]) * ipz);
+      ldv<V>(ho, a.hy + p);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float ez_ip = (e + 1 < V) ? ezm[(e + 1) % V] : ezx;
+        hym[e] = ho[e] - ch * ((exk[e] - exm[e]) * ipz - (ez_ip - ezm[e]) * ipx[e]);
+      }
+    }
+  }
+  int cur = 0;
+  const int slot = (int)blockDim.y * 64;           // float4 entries per component per buffer
+  for (int k = k0; k < k1; ++k) {
+    const long long p = (long long)k * g.sxy + row;
+    const long long pj = (long long)k * g.sxy + rowp;
+    float exn[V], eyn[V], ezk[V], exj[V], ezj[V], hxn[V], hyn[V], hzn[V];
+    zero<V>(exn); zero<V>(eyn); zero<V>(ezk); zero<V>(exj); zero<V>(ezj);
+    zero<V>(hxn); zero<V>(hyn); zero<V>(hzn);
+    float ipz = 0.f, idz = 0.f;
+    if (act) {
+      ipz = s.ipz[k];
+      idz = s.idz[k];
+      ldv<V>(exn, a.ex + p + g.sxy);
+      ldv<V>(eyn, a.ey + p + g.sxy);
+      ldv<V>(ezk, a.ez + p);
+      if (use_jp) {
+        ldv<V>(exj, a.ex + pj);
+        ldv<V>(ezj, a.ez + pj);
+      }
+      ldv<V>(hxn, a.hx + p);
+      ldv<V>(hyn, a.hy + p);
+      ldv<V>(hzn, a.hz + p);
+    }
+    float eyx = __shfl_down(eyk[0], 1);
+    float ezx = __shfl_down(ezk[0], 1);
+    if (act && (tx == 63 || last_x)) {
+      if (!last_x) { eyx = a.ey[p + V]; ezx = a.ez[p + V]; }
+      else if (g.bcx1 == BC_PERIODIC) { eyx = a.ey[p - i0]; ezx = a.ez[p - i0]; }
+      else { eyx = 0.f; ezx = 0.f; }
+    }
+    if (act) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float ey_ip = (e + 1 < V) ? eyk[(e + 1) % V] : eyx;
+        const float ez_ip = (e + 1 < V) ? ezk[(e + 1) % V] : ezx;
+        hxn[e] -= ch * ((ezj[e] - ezk[e]) * ipy - (eyn[e] - eyk[e]) * ipz);
+        hyn[e] -= ch * ((exn[e] - exk[e]) * ipz - (ez_ip - ezk[e]) * ipx[e]);
+        hzn[e] -= ch * ((ey_ip - eyk[e]) * ipx[e] - (exj[e] - exk[e]) * ipy);
+      }
+    }
+    // x-halo column: H^{n+1/2}_{y,z} at i0-1 recomputed by the tile's first lane
+    float hy_m = 0.f, hz_m = 0.f, exn_m = 0.f;
+    if (xh) {
+      const long long pm = (long long)k * g.sxy + rowm_x;
+      exn_m = a.ex[pm + g.sxy];
+      const float ez_mm = a.ez[pm], ey_mm = a.ey[pm];
+      const float ex_jm = use_jp ? a.ex[(long long)k * g.sxy + rowpm_x] : 0.f;
+      hy_m = a.hy[pm] - ch * ((exn_m - exk_m) * ipz - (ezk[0] - ez_mm) * ipx_m);
+      hz_m = a.hz[pm] - ch * ((eyk[0] - ey_mm) * ipx_m - (ex_jm - exk_m) * ipy);
+    }
+    // publish H^{n+1/2}_{x,z} of this row for the row above
+    {
+      float4 t;
+      t.x = hxn[0]; t.y = hxn[1]; t.z = hxn[2]; t.w = hxn[3];
+      xch[(cur * 2 + 0) * slot + ty * 64 + tx] = t;
+      t.x = hzn[0]; t.y = hzn[1]; t.z = hzn[2]; t.w = hzn[3];
+      xch[(cur * 2 + 1) * slot + ty * 64 + tx] = t;
+    }
+    __syncthreads();
+    float hyx = __shfl_up(hyn[V - 1], 1);
+    float hzx = __shfl_up(hzn[V - 1], 1);
+    if (pmc_z0 && k == 0) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) { hxm[e] = -hxn[e]; hym[e] = -hyn[e]; }
+    }
+    if (act && !halo) {
+      if (tx == 0 || first_x) {
+        if (xh) { hyx = hy_m; hzx = hz_m; }
+        else if (g.bcx0 == BC_PMC) { hyx = -hyn[0]; hzx = -hzn[0]; }
+        else { hyx = 0.f; hzx = 0.f; }
+      }
+      float hxj[V], hzj[V];
+      if (j > 0 || per_y) {
+        const float4 t0 = xch[(cur * 2 + 0) * slot + (ty - 1) * 64 + tx];
+        const float4 t1 = xch[(cur * 2 + 1) * slot + (ty - 1) * 64 + tx];
+        hxj[0] = t0.x; hxj[1] = t0.y; hxj[2] = t0.z; hxj[3] = t0.w;
+        hzj[0] = t1.x; hzj[1] = t1.y; hzj[2] = t1.z; hzj[3] = t1.w;
+      } else if (g.bcy0 == BC_PMC) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) { hxj[e] = -hxn[e]; hzj[e] = -hzn[e]; }
+      } else {
+        zero<V>(hxj); zero<V>(hzj);
+      }
+      float cax[V], cbx[V], cay[V], cby[V], caz[V], cbz[V];
+      if constexpr (MAT) {
+        int mi[V];
+        ldm<V>(mi, m.mx + p);
+#pragma unroll
+        for (int e = 0; e < V; ++e) { const float2 c = lut_s[mi[e]]; cax[e] = c.x; cbx[e] = c.y; }
+        ldm<V>(mi, m.my + p);
+#pragma unroll
+        for (int e = 0; e < V; ++e) { const float2 c = lut_s[mi[e]]; cay[e] = c.x; cby[e] = c.y; }
+        ldm<V>(mi, m.mz + p);
+#pragma unroll
+        for (int e = 0; e < V; ++e) { const float2 c = lut_s[mi[e]]; caz[e] = c.x; cbz[e] = c.y; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          cax[e] = cay[e] = caz[e] = m.ca1;
+          cbx[e] = cby[e] = cbz[e] = m.cb1;
+        }
+      }
+      const bool wall_z = (k == 0) && g.pec_z0;
+      float ex[V], ey[V], ez[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float hy_im = (e > 0) ? hyn[(e + V - 1) % V] : hyx;
+        const float hz_im = (e > 0) ? hzn[(e + V - 1) % V] : hzx;
+        float nex = cax[e] * exk[e] + cbx[e] * ((hzn[e] - hzj[e]) * idy - (hyn[e] - hym[e]) * idz);
+        float ney = cay[e] * eyk[e] + cby[e] * ((hxn[e] - hxm[e]) * idz - (hzn[e] - hz_im) * idx[e]);
+        float nez = caz[e] * ezk[e] + cbz[e] * ((hyn[e] - hy_im) * idx[e] - (hxn[e] - hxj[e]) * idy);
+        const bool wx = wall_x0 && (e == 0);
+        if (wall_y || wall_z) nex = 0.f;
+        if (wx || wall_z) ney = 0.f;
+        if (wx || wall_y) nez = 0.f;
+        ex[e] = nex; ey[e] = ney; ez[e] = nez;
+      }
+      stv<V>(b.hx + p, hxn);
+      stv<V>(b.hy + p, hyn);
+      stv<V>(b.hz + p, hzn);
+      stv<V>(b.ex + p, ex);
+      stv<V>(b.ey + p, ey);
+      stv<V>(b.ez + p, ez);
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) { hxm[e] = hxn[e]; hym[e] = hyn[e]; exk[e] = exn[e]; eyk[e] = eyn[e]; }
+    exk_m = exn_m;
+    cur ^= 1;
+  }
+}
+
+// =============================================================================================
 // K3  CPML slab corrections (post-correction form: the main kernels use the plain derivative
 //     everywhere; inside a slab the difference  (1/kappa - 1) d + psi  is added afterwards,
 //     which is exact because both updates are linear in the curl).

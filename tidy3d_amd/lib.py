@@ -27,9 +27,9 @@ SYMBOLS = (
 
 BC_PEC, BC_PMC, BC_PERIODIC, BC_NEIGHBOR = 0, 1, 2, 3
 MON_TIME, MON_DFT = 0, 1
-VARIANT_AUTO, VARIANT_SIMPLE, VARIANT_ZMARCH, VARIANT_LDS = 0, 1, 2, 3
+VARIANT_AUTO, VARIANT_SIMPLE, VARIANT_ZMARCH, VARIANT_FUSED = 0, 1, 2, 3
 FLAG_TIME_KERNELS = 1
-OPT_FLAGS, OPT_VARIANT, OPT_ZCHUNK, OPT_ROWS = 0, 1, 2, 3
+OPT_FLAGS, OPT_VARIANT, OPT_ZCHUNK, OPT_ROWS, OPT_XCD_REMAP = 0, 1, 2, 3, 4
 
 
 class FdtdConfig(C.Structure):
@@ -43,7 +43,8 @@ class FdtdStats(C.Structure):
     _fields_ = [("steps_done", C.c_int64), ("diverged", C.c_int32), ("stopped_early", C.c_int32),
                 ("field_decay", C.c_double), ("run_ms", C.c_double), ("h_kernel_ms", C.c_double),
                 ("e_kernel_ms", C.c_double), ("h_kernel_launches", C.c_int64),
-                ("e_kernel_launches", C.c_int64), ("device_bytes", C.c_int64)]
+                ("e_kernel_launches", C.c_int64), ("device_bytes", C.c_int64),
+                ("fused_kernel_ms", C.c_double), ("fused_kernel_launches", C.c_int64)]
 
 
 PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_int64, C.c_double, C.c_double, C.c_void_p)
