@@ -13,7 +13,8 @@ CSRC = os.path.join(ROOT, "tidy3d_amd", "csrc")
 LIB = os.path.join(HERE, "libfdtd_emu.so")
 DEPS = [os.path.join(CSRC, "fdtd_capi.hip"), os.path.join(CSRC, "fdtd_kernels.hpp"),
         os.path.join(ROOT, "include", "fdtd_hip.h"), os.path.join(HERE, "hip_emu.cpp"),
-        os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "rccl", "rccl.h")]
+        os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "rccl", "rccl.h"),
+        os.path.abspath(__file__)]
 
 
 def build(force: bool = False) -> str:
@@ -23,7 +24,7 @@ def build(force: bool = False) -> str:
     cxx = "/opt/rocm/lib/llvm/bin/clang++"
     if not os.path.exists(cxx):
         cxx = shutil.which("clang++") or shutil.which("g++")
-    cmd = [cxx, "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-I" + HERE,
+    cmd = [cxx, "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-ffp-contract=off", "-mfma", "-I" + HERE,
            "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-pass-failed",
            "-x", "c++", os.path.join(CSRC, "fdtd_capi.hip"), os.path.join(HERE, "hip_emu.cpp"),
            "-o", LIB]

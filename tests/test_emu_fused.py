@@ -63,8 +63,8 @@ def test_fused_equals_two_pass(name, rows, zc, emu_lib):
     assert disc.spec.shape[0] % 4 == 0
     ref_f, ref_m = _run(disc.spec, emu_lib, L.VARIANT_ZMARCH, 4, 2)
     got_f, got_m = _run(disc.spec, emu_lib, L.VARIANT_FUSED, rows, zc)
-    scale = max(np.abs(x).max() for x in ref_f[:3]), max(np.abs(x).max() for x in ref_f[3:])
+    # explicit fma's + -ffp-contract=off + identical summation order: bit-for-bit agreement
     for c in range(6):
-        np.testing.assert_allclose(got_f[c], ref_f[c], rtol=0, atol=2e-6 * scale[c // 3])
+        assert np.array_equal(got_f[c], ref_f[c]), c
     for k in ref_m:
-        np.testing.assert_allclose(got_m[k], ref_m[k], rtol=0, atol=2e-6 * np.abs(ref_m[k]).max())
+        assert np.array_equal(got_m[k], ref_m[k]), k

@@ -183,3 +183,21 @@ def test_rccl_self_exchange_matches_ghost_copy(hip_lib):
         assert np.array_equal(a, b)
     for k in ref_m:
         assert np.array_equal(ref_m[k], got_m[k])
+
+
+@pytest.mark.parametrize("rows,zc", [(7, 16), (3, 5), (15, 64)])
+def test_fused_sweep_equals_two_pass_bit_for_bit(hip_lib, rows, zc):
+    """The fused single-sweep kernel and the two-pass kernels perform the same IEEE operations
+    per cell (the library is built with -ffp-contract=off), whatever the tiling."""
+    from cases import media_mix, periodic_box
+    for sim in (media_mix((52, 44, 36)), periodic_box((264, 40, 36))):
+        disc = discretize(sim, n_steps=30)
+        assert disc.spec.shape[0] % 4 == 0
+        outs = []
+        for variant, r, z in ((L.VARIANT_ZMARCH, 4, 2), (L.VARIANT_FUSED, rows, zc)):
+            with HipEngine(disc.spec, lib=hip_lib, variant=variant, z_chunk=z) as e:
+                e.set_option(L.OPT_ROWS, r)
+                e.run()
+                outs.append([e.get_field(c) for c in range(6)] + list(e.results().values()))
+        for x, y in zip(*outs):
+            assert np.array_equal(x, y)

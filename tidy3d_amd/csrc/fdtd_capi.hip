@@ -920,15 +920,15 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     const int h_top = (multi && nb_hi) ? nz - 1 : nz;      // planes [0, h_top) on st, [h_top, nz) on cs
     if (multi && nb_hi) {
       HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
+      launch_pml(h, false, h_top, nz, cs);           // H-side corrections first (they only read E^n):
+      launch_sources(h, false, n, h_top, nz, cs);    // same summation order as the fused sweep
       launch_h_main(h, h_top, nz, cs);
-      launch_pml(h, false, h_top, nz, cs);
-      launch_sources(h, false, n, h_top, nz, cs);
       HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
     }
     if (multi) HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
-    launch_h_main(h, 0, h_top, st);
     launch_pml(h, false, 0, h_top, st);
     launch_sources(h, false, n, 0, h_top, st);
+    launch_h_main(h, 0, h_top, st);
     advance_tfsf_aux(h, false, n, st);
     if (multi) {
       HIPCHK(h, hipEventRecord(h->ev_h_int, st));

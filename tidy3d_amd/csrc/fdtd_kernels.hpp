@@ -80,6 +80,19 @@ __device__ __forceinline__ void ldm(int (&m)[V], const uint8_t* __restrict__ p) 
   }
 }
 
+// The two update formulas, written once with explicit fused multiply-adds.  The library is built
+// with -ffp-contract=off, so these are the ONLY fma's: every code path (vector body, tile-edge
+// scalar column, chunk prologue, two-pass and fused kernels) rounds identically and results do
+// not depend on the launch geometry or on the kernel variant.
+//   H_new = h - ch * (a * wa - b * wb)
+__device__ __forceinline__ float upd_h(float h, float ch, float a, float wa, float b, float wb) {
+  return fmaf(-ch, fmaf(-b, wb, a * wa), h);
+}
+//   E_new = ca * e + cb * (a * wa - b * wb)
+__device__ __forceinline__ float upd_e(float e, float ca, float cb, float a, float wa, float b, float wb) {
+  return fmaf(cb, fmaf(-b, wb, a * wa), ca * e);
+}
+
 template <int V>
 __device__ __forceinline__ void zero(float (&r)[V]) {
 #pragma unroll
@@ -150,9 +163,9 @@ __global__ __launch_bounds__(512) void h_update_kernel(GridP g, FieldP f, StepP 
       for (int e = 0; e < V; ++e) {
         const float ey_ip = (e + 1 < V) ? eyk[(e + 1) % V] : eyx;
         const float ez_ip = (e + 1 < V) ? ezk[(e + 1) % V] : ezx;
-        hx[e] -= ch * ((ezj[e] - ezk[e]) * ipy - (eyn[e] - eyk[e]) * ipz);
-        hy[e] -= ch * ((exn[e] - exk[e]) * ipz - (ez_ip - ezk[e]) * ipx[e]);
-        hz[e] -= ch * ((ey_ip - eyk[e]) * ipx[e] - (exj[e] - exk[e]) * ipy);
+        hx[e] = upd_h(hx[e], ch, ezj[e] - ezk[e], ipy, eyn[e] - eyk[e], ipz);
+        hy[e] = upd_h(hy[e], ch, exn[e] - exk[e], ipz, ez_ip - ezk[e], ipx[e]);
+        hz[e] = upd_h(hz[e], ch, ey_ip - eyk[e], ipx[e], exj[e] - exk[e], ipy);
       }
       stv<V>(f.hx + p, hx);
       stv<V>(f.hy + p, hy);
@@ -258,9 +271,9 @@ __global__ __launch_bounds__(512) void e_update_kernel(GridP g, FieldP f, StepP 
       for (int e = 0; e < V; ++e) {
         const float hy_im = (e > 0) ? hyk[(e + V - 1) % V] : hyx;
         const float hz_im = (e > 0) ? hzk[(e + V - 1) % V] : hzx;
-        float nex = cax[e] * ex[e] + cbx[e] * ((hzk[e] - hzj[e]) * idy - (hyk[e] - hym[e]) * idz);
-        float ney = cay[e] * ey[e] + cby[e] * ((hxk[e] - hxm[e]) * idz - (hzk[e] - hz_im) * idx[e]);
-        float nez = caz[e] * ez[e] + cbz[e] * ((hyk[e] - hy_im) * idx[e] - (hxk[e] - hxj[e]) * idy);
+        float nex = upd_e(ex[e], cax[e], cbx[e], hzk[e] - hzj[e], idy, hyk[e] - hym[e], idz);
+        float ney = upd_e(ey[e], cay[e], cby[e], hxk[e] - hxm[e], idz, hzk[e] - hz_im, idx[e]);
+        float nez = upd_e(ez[e], caz[e], cbz[e], hyk[e] - hy_im, idx[e], hxk[e] - hxj[e], idy);
         const bool wx = wall_x0 && (e == 0);
         if (wall_y || wall_z) nex = 0.f;
         if (wx || wall_z) ney = 0.f;
@@ -381,12 +394,12 @@ __global__ __launch_bounds__(1024) void fused_step_kernel(GridP g, FieldP a, Fie
       const float ipz = s.ipz[k0 - 1];
       ldv<V>(ho, a.hx + p);
 #pragma unroll
-      for (int e = 0; e < V; ++e) hxm[e] = ho[e] - ch * ((ezj[e] - ezm[e]) * ipy - (eyk[e] - eym[e]) * ipz);
+      for (int e = 0; e < V; ++e) hxm[e] = upd_h(ho[e], ch, ezj[e] - ezm[e], ipy, eyk[e] - eym[e], ipz);
       ldv<V>(ho, a.hy + p);
 #pragma unroll
       for (int e = 0; e < V; ++e) {
         const float ez_ip = (e + 1 < V) ? ezm[(e + 1) % V] : ezx;
-        hym[e] = ho[e] - ch * ((exk[e] - exm[e]) * ipz - (ez_ip - ezm[e]) * ipx[e]);
+        hym[e] = upd_h(ho[e], ch, exk[e] - exm[e], ipz, ez_ip - ezm[e], ipx[e]);
       }
     }
   }
@@ -425,9 +438,9 @@ __global__ __launch_bounds__(1024) void fused_step_kernel(GridP g, FieldP a, Fie
       for (int e = 0; e < V; ++e) {
         const float ey_ip = (e + 1 < V) ? eyk[(e + 1) % V] : eyx;
         const float ez_ip = (e + 1 < V) ? ezk[(e + 1) % V] : ezx;
-        hxn[e] -= ch * ((ezj[e] - ezk[e]) * ipy - (eyn[e] - eyk[e]) * ipz);
-        hyn[e] -= ch * ((exn[e] - exk[e]) * ipz - (ez_ip - ezk[e]) * ipx[e]);
-        hzn[e] -= ch * ((ey_ip - eyk[e]) * ipx[e] - (exj[e] - exk[e]) * ipy);
+        hxn[e] = upd_h(hxn[e], ch, ezj[e] - ezk[e], ipy, eyn[e] - eyk[e], ipz);
+        hyn[e] = upd_h(hyn[e], ch, exn[e] - exk[e], ipz, ez_ip - ezk[e], ipx[e]);
+        hzn[e] = upd_h(hzn[e], ch, ey_ip - eyk[e], ipx[e], exj[e] - exk[e], ipy);
       }
     }
     // x-halo column: H^{n+1/2}_{y,z} at i0-1 recomputed by the tile's first lane
@@ -437,8 +450,8 @@ __global__ __launch_bounds__(1024) void fused_step_kernel(GridP g, FieldP a, Fie
       exn_m = a.ex[pm + g.sxy];
       const float ez_mm = a.ez[pm], ey_mm = a.ey[pm];
       const float ex_jm = use_jp ? a.ex[(long long)k * g.sxy + rowpm_x] : 0.f;
-      hy_m = a.hy[pm] - ch * ((exn_m - exk_m) * ipz - (ezk[0] - ez_mm) * ipx_m);
-      hz_m = a.hz[pm] - ch * ((eyk[0] - ey_mm) * ipx_m - (ex_jm - exk_m) * ipy);
+      hy_m = upd_h(a.hy[pm], ch, exn_m - exk_m, ipz, ezk[0] - ez_mm, ipx_m);
+      hz_m = upd_h(a.hz[pm], ch, eyk[0] - ey_mm, ipx_m, ex_jm - exk_m, ipy);
     }
     // publish H^{n+1/2}_{x,z} of this row for the row above
     {
@@ -498,9 +511,9 @@ __global__ __launch_bounds__(1024) void fused_step_kernel(GridP g, FieldP a, Fie
       for (int e = 0; e < V; ++e) {
         const float hy_im = (e > 0) ? hyn[(e + V - 1) % V] : hyx;
         const float hz_im = (e > 0) ? hzn[(e + V - 1) % V] : hzx;
-        float nex = cax[e] * exk[e] + cbx[e] * ((hzn[e] - hzj[e]) * idy - (hyn[e] - hym[e]) * idz);
-        float ney = cay[e] * eyk[e] + cby[e] * ((hxn[e] - hxm[e]) * idz - (hzn[e] - hz_im) * idx[e]);
-        float nez = caz[e] * ezk[e] + cbz[e] * ((hyn[e] - hy_im) * idx[e] - (hxn[e] - hxj[e]) * idy);
+        float nex = upd_e(exk[e], cax[e], cbx[e], hzn[e] - hzj[e], idy, hyn[e] - hym[e], idz);
+        float ney = upd_e(eyk[e], cay[e], cby[e], hxn[e] - hxm[e], idz, hzn[e] - hz_im, idx[e]);
+        float nez = upd_e(ezk[e], caz[e], cbz[e], hyn[e] - hy_im, idx[e], hxn[e] - hxj[e], idy);
         const bool wx = wall_x0 && (e == 0);
         if (wall_y || wall_z) nex = 0.f;
         if (wx || wall_z) ney = 0.f;
