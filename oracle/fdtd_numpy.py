@@ -222,7 +222,8 @@ class OracleFdtd:
                         ijk = t.h_corr_ijk[m]
                         np.add.at(self.H[c], (ijk[:, 2], ijk[:, 1], ijk[:, 0]),
                                   vals[m].astype(self.dtype))
-            h1 -= t.ch1 * (e1[1:] - e1[:-1]) * t.ip1
+            h1 *= t.ah
+            h1 -= t.bh * (e1[1:] - e1[:-1])
 
     def _tfsf_e(self, n: int):
         for t, st in zip(self.spec.tfsf, self.tfsf_state):
@@ -235,11 +236,8 @@ class OracleFdtd:
                         ijk = t.e_corr_ijk[m]
                         np.add.at(self.E[c], (ijk[:, 2], ijk[:, 1], ijk[:, 0]),
                                   vals[m].astype(self.dtype))
-            # advance 1-D E: interior nodes, first-order Mur at both ends, soft source
-            eold0, eold1, eoldm1, eoldm2 = e1[0], e1[1], e1[-1], e1[-2]
-            e1[1:-1] -= t.ce1 * (h1[1:] - h1[:-1]) * t.id1[1:-1]
-            e1[0] = eold1 + t.mur0 * (e1[1] - eold0)
-            e1[-1] = eoldm2 + t.mur1 * (e1[-2] - eoldm1)
+            # advance 1-D E: interior nodes (lossy pads at both ends, PEC end nodes), soft source
+            e1[1:-1] = t.ae[1:-1] * e1[1:-1] - t.be[1:-1] * (h1[1:] - h1[:-1])
             e1[t.src_cell] += t.wave[n]
 
     # ------------------------------------------------------------------ monitors

@@ -87,7 +87,32 @@ def nonuniform_grid(N=(16, 12, 10)):
     return sim.copy(size=size)
 
 
+def tfsf_box(N=(20, 16, 16)):
+    """TFSF box around a dielectric sphere, PML everywhere (Mie set-up in miniature)."""
+    src = td.TFSF(center=(0, 0, 0), size=(0.5, 0.4, 0.4), source_time=PULSE, injection_axis=2,
+                  direction="+", pol_angle=0.4)
+    structures = [td.Structure(geometry=td.Sphere(center=(0, 0, 0), radius=0.12),
+                               medium=td.Medium(permittivity=4.0))]
+    mons = [td.FieldTimeMonitor(center=(0, 0, 0), size=(0.7, 0.6, 0.6), name="t", colocate=False, interval=7),
+            td.FluxMonitor(center=(0, 0, 0), size=(0.7, 0.6, 0.6), freqs=[2.5e14, 3e14], name="sca")]
+    return _sim(N, td.BoundarySpec.all_sides(td.PML(num_layers=4)), structures, sources=[src],
+                monitors=mons)
+
+
+def planewave_periodic(N=(8, 12, 20)):
+    """PlaneWave launched along -x through a periodic cross-section, PML along x."""
+    src = td.PlaneWave(center=(0.2, 0, 0), size=(0, td.inf, td.inf), source_time=PULSE, direction="-",
+                       pol_angle=np.pi / 2)
+    structures = [td.Structure(geometry=td.Box(center=(-0.1, 0, 0), size=(0.1, td.inf, td.inf)),
+                               medium=td.Lorentz(eps_inf=2.0, coeffs=[(1.5, 4e14, 3e13)]))]
+    mons = [td.FieldMonitor(center=(-0.3, 0, 0), size=(0, td.inf, td.inf), freqs=[2.5e14, 3e14], name="f"),
+            td.FluxMonitor(center=(0.3, 0, 0), size=(0, td.inf, td.inf), freqs=[3e14], name="back")]
+    bspec = td.BoundarySpec(x=td.Boundary.pml(num_layers=6), y=td.Boundary.periodic(), z=td.Boundary.periodic())
+    return _sim(N, bspec, structures, sources=[src], monitors=mons)
+
+
 CASES = {
+    "tfsf_box": tfsf_box, "planewave_periodic": planewave_periodic,
     "pec_box": pec_box, "pec_box_vec": pec_box_vec, "periodic_box": periodic_box,
     "pml_box": pml_box, "stable_pml_box": stable_pml_box, "media_mix": media_mix,
     "drude_in_pml": drude_in_pml, "nonuniform_grid": nonuniform_grid,

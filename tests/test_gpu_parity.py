@@ -201,3 +201,42 @@ def test_fused_sweep_equals_two_pass_bit_for_bit(hip_lib, rows, zc):
                 outs.append([e.get_field(c) for c in range(6)] + list(e.results().values()))
         for x, y in zip(*outs):
             assert np.array_equal(x, y)
+
+
+def test_config4_mie_sphere_512_cube(hip_lib):
+    """BASELINE config[3]: Mie scattering, dielectric sphere, PlaneWave TFSF + PML, 512^3 cells on
+    one MI355X; scattering cross-section from the flux through a box in the scattered-field region
+    (normalised to 1 W/um^2 incident) vs the Mie series.  dl = lambda0/32, sphere radius 56 cells:
+    staircasing + dispersion error budget 3 %."""
+    import time
+    from tidy3d_amd.analytic import mie_cross_sections
+    from tidy3d_amd.data import assemble
+    lam0 = 1.0
+    f0 = C_0 / lam0
+    dl = lam0 / 32
+    n = 512 - 24
+    r, eps = 56 * dl, 2.56
+    pulse = td.GaussianPulse(freq0=f0, fwidth=f0 / 6)
+    freqs = [0.85 * f0, 0.95 * f0, f0, 1.05 * f0, 1.15 * f0]
+    box = 2 * r + 40 * dl
+    sim = td.Simulation(
+        size=(n * dl,) * 3, grid_spec=td.GridSpec.uniform(dl=dl), run_time=70 / f0,
+        structures=[td.Structure(geometry=td.Sphere(radius=r), medium=td.Medium(permittivity=eps))],
+        sources=[td.TFSF(center=(0, 0, 0), size=(box,) * 3, source_time=pulse, injection_axis=2, direction="+")],
+        monitors=[td.FluxMonitor(center=(0, 0, 0), size=(box + 40 * dl,) * 3, freqs=freqs, name="sca")],
+        boundary_spec=td.BoundarySpec.all_sides(td.PML(num_layers=12)), shutoff=1e-5)
+    t0 = time.time()
+    disc = discretize(sim)
+    assert disc.spec.shape == (512, 512, 512)
+    t1 = time.time()
+    with HipEngine(disc.spec, lib=hip_lib) as e:
+        st = e.run()
+        raw = e.results()
+    t2 = time.time()
+    sd = assemble(disc, raw, log="")
+    _, ana = mie_cross_sections(r, eps, freqs)
+    got = sd["sca"].flux.values
+    print(f"\n[mie 512^3] setup {t1 - t0:.1f}s, solve {t2 - t1:.1f}s ({st.steps_done} steps, "
+          f"{512**3 * st.steps_done / (st.run_ms * 1e-3) / 1e6:.0f} Mcells/s), sigma_sca/analytic = {got / ana}")
+    assert not st.diverged
+    np.testing.assert_allclose(got, ana, rtol=0.03)

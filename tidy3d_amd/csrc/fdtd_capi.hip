@@ -54,8 +54,7 @@ struct PointSrc {
 
 struct Tfsf {
   int n_aux = 0, src_cell = 0;
-  float ch1 = 0, ce1 = 0, mur0 = 0, mur1 = 0;
-  float *ip1 = nullptr, *id1 = nullptr, *e1 = nullptr, *h1 = nullptr, *wave = nullptr;
+  float *ae = nullptr, *be = nullptr, *ah = nullptr, *bh = nullptr, *e1 = nullptr, *h1 = nullptr, *wave = nullptr;
   long long n_steps = 0;
   long long n_e = 0, n_h = 0;
   int32_t *e_comp = nullptr, *h_comp = nullptr, *e_aux = nullptr, *h_aux = nullptr;
@@ -374,12 +373,11 @@ void advance_tfsf_aux(FdtdSolver* h, bool e_side, long long n, hipStream_t st) {
   for (Tfsf& t : h->tfsf) {
     if (n >= t.n_steps) continue;
     if (e_side)
-      hipLaunchKernelGGL(tfsf_aux_e_kernel, dim3(1), dim3(256), 0, st, t.e1, (const float*)t.h1,
-                         (const float*)t.id1, t.ce1, t.mur0, t.mur1, t.n_aux, t.src_cell,
-                         (const float*)t.wave, n);
+      hipLaunchKernelGGL(tfsf_aux_e_kernel, dim3(1), dim3(1024), 0, st, t.e1, (const float*)t.h1,
+                         (const float*)t.ae, (const float*)t.be, t.n_aux, t.src_cell, (const float*)t.wave, n);
     else
       hipLaunchKernelGGL(tfsf_aux_h_kernel, dim3(nblk(t.n_aux)), dim3(256), 0, st, t.h1, (const float*)t.e1,
-                         (const float*)t.ip1, t.ch1, t.n_aux);
+                         (const float*)t.ah, (const float*)t.bh, t.n_aux);
   }
 }
 
@@ -710,17 +708,18 @@ int fdtd_add_point_source(FdtdSolver* h, int64_t n, const int32_t* comp, const u
   return 0;
 }
 
-int fdtd_add_tfsf(FdtdSolver* h, int n_aux, const float* ip1, const float* id1, float ch1, float ce1, float mur0,
-                  float mur1, int src_cell, int64_t n_steps, const float* wave, int64_t n_e, const int32_t* e_comp,
+int fdtd_add_tfsf(FdtdSolver* h, int n_aux, const float* ae, const float* be, const float* ah, const float* bh,
+                  int src_cell, int64_t n_steps, const float* wave, int64_t n_e, const int32_t* e_comp,
                   const uint32_t* e_index, const float* e_w, const int32_t* e_aux, int64_t n_h,
                   const int32_t* h_comp, const uint32_t* h_index, const float* h_w, const int32_t* h_aux) {
   if (!h) return -1;
   if (n_aux < 4 || src_cell < 1 || src_cell >= n_aux) return fail(h, "fdtd_add_tfsf: bad auxiliary grid");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   Tfsf t{};
-  t.n_aux = n_aux; t.src_cell = src_cell; t.ch1 = ch1; t.ce1 = ce1; t.mur0 = mur0; t.mur1 = mur1;
+  t.n_aux = n_aux; t.src_cell = src_cell;
   t.n_steps = n_steps; t.n_e = n_e; t.n_h = n_h;
-  if (dev_upload(h, &t.ip1, ip1, (size_t)n_aux) || dev_upload(h, &t.id1, id1, (size_t)n_aux + 1) ||
+  if (dev_upload(h, &t.ae, ae, (size_t)n_aux + 1) || dev_upload(h, &t.be, be, (size_t)n_aux + 1) ||
+      dev_upload(h, &t.ah, ah, (size_t)n_aux) || dev_upload(h, &t.bh, bh, (size_t)n_aux) ||
       dev_alloc(h, &t.e1, (size_t)n_aux + 1) || dev_alloc(h, &t.h1, (size_t)n_aux) ||
       dev_upload(h, &t.wave, wave, (size_t)n_steps))
     return -1;
@@ -907,6 +906,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       launch_pml(h, false, 0, nz, st);
       launch_sources(h, false, n, 0, nz, st);
       advance_tfsf_aux(h, false, n, st);
+      if (h->cfg.bc[4] == FDTD_BC_PERIODIC) fill_ghost_h(h, st);   // ghost(-1) must carry the pre-corrections too
       if (launch_fused(h, st)) return -1;
       if (rec) record_monitors(h, n, true, st);
       launch_pml(h, true, 0, nz, st);

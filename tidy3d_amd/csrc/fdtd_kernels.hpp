@@ -721,31 +721,22 @@ __global__ __launch_bounds__(256) void tfsf_corr_kernel(float* f0, float* f1, fl
   if (p < zlo || p >= zhi) return;
   const int c = comp[t] % 3;
   float* f = (c == 0) ? f0 : (c == 1 ? f1 : f2);
-  f[p] += w[t] * aux[ai[t]];
+  atomicAdd(f + p, w[t] * aux[ai[t]]);      // a node on a box edge may appear in two entries
 }
 
 // 1-D auxiliary grid of the incident plane wave
-__global__ void tfsf_aux_h_kernel(float* h1, const float* e1, const float* ip1, float ch1, int n_aux) {
+__global__ void tfsf_aux_h_kernel(float* h1, const float* e1, const float* ah, const float* bh, int n_aux) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_aux; i += gridDim.x * blockDim.x)
-    h1[i] -= ch1 * (e1[i + 1] - e1[i]) * ip1[i];
+    h1[i] = ah[i] * h1[i] - bh[i] * (e1[i + 1] - e1[i]);
 }
 
-// single workgroup: interior update, first-order Mur at both ends, soft source
-__global__ void tfsf_aux_e_kernel(float* e1, const float* h1, const float* id1, float ce1, float mur0, float mur1,
-                                  int n_aux, int src_cell, const float* wave, long long step) {
-  __shared__ float old_s[4];
-  if (threadIdx.x == 0) {
-    old_s[0] = e1[0]; old_s[1] = e1[1]; old_s[2] = e1[n_aux]; old_s[3] = e1[n_aux - 1];
-  }
-  __syncthreads();
+// single workgroup: interior update (the grid ends in matched lossy pads; end nodes stay 0), soft source
+__global__ void tfsf_aux_e_kernel(float* e1, const float* h1, const float* ae, const float* be, int n_aux,
+                                  int src_cell, const float* wave, long long step) {
   for (int i = 1 + threadIdx.x; i < n_aux; i += blockDim.x)
-    e1[i] -= ce1 * (h1[i] - h1[i - 1]) * id1[i];
+    e1[i] = ae[i] * e1[i] - be[i] * (h1[i] - h1[i - 1]);
   __syncthreads();
-  if (threadIdx.x == 0) {
-    e1[0] = old_s[1] + mur0 * (e1[1] - old_s[0]);
-    e1[n_aux] = old_s[3] + mur1 * (e1[n_aux - 1] - old_s[2]);
-    e1[src_cell] += wave[step];
-  }
+  if (threadIdx.x == 0) e1[src_cell] += wave[step];
 }
 
 // =============================================================================================

@@ -180,9 +180,9 @@ class HipEngine:
                                          t.e_corr_w.astype(np.float32), t.e_corr_aux.astype(np.int32))
             hcell, hcomp, hw, haux = loc(t.h_corr_ijk, t.h_corr_comp.astype(np.int32),
                                          t.h_corr_w.astype(np.float32), t.h_corr_aux.astype(np.int32))
-            ip1, id1, wave = _f32(t.ip1), _f32(t.id1), _f32(t.wave)
-            self._chk(d.fdtd_add_tfsf(h, t.n_aux, _ptr(ip1), _ptr(id1), float(t.ch1), float(t.ce1),
-                                      float(t.mur0), float(t.mur1), int(t.src_cell), len(wave),
+            ae, be, ah, bh, wave = _f32(t.ae), _f32(t.be), _f32(t.ah), _f32(t.bh), _f32(t.wave)
+            self._chk(d.fdtd_add_tfsf(h, t.n_aux, _ptr(ae), _ptr(be), _ptr(ah), _ptr(bh),
+                                      int(t.src_cell), len(wave),
                                       _ptr(wave), len(ecell), _ptr(ecomp), _ptr(ecell), _ptr(ew),
                                       _ptr(eaux), len(hcell), _ptr(hcomp), _ptr(hcell), _ptr(hw),
                                       _ptr(haux)), "fdtd_add_tfsf")

@@ -74,7 +74,7 @@ class FdtdLib:
         d.fdtd_set_pml.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int]
         d.fdtd_add_ade.argtypes = [vp, C.c_int, i64, vp, C.c_int, vp, vp, f32]
         d.fdtd_add_point_source.argtypes = [vp, i64, vp, vp, vp, vp, i64, vp, vp]
-        d.fdtd_add_tfsf.argtypes = [vp, C.c_int, vp, vp, f32, f32, f32, f32, C.c_int, i64, vp,
+        d.fdtd_add_tfsf.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, i64, vp,
                                     i64, vp, vp, vp, vp, i64, vp, vp, vp, vp]
         d.fdtd_add_monitor.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, i64, vp, C.c_int, vp, vp]
         d.fdtd_get_monitor.argtypes = [vp, C.c_int, vp, C.c_size_t]

@@ -1,0 +1,274 @@
+"""PlaneWave and TFSF sources -> TfsfSpec (1-D auxiliary incident grid + surface correction lists).
+
+ref components/source.py:1090 (PlaneWave), :1204-1257 (TFSF: the box is the total-field region,
+the plane wave carries 1 W/um^2 along the injection axis), :966-990 (polarisation vector:
+pol_angle = 0 puts E on the first tangential axis in x,y,z order).
+
+Formulation (total-field / scattered-field, Taflove & Hagness ch. 5) reduced to lists:
+a node of component F belongs to the total-field (TF) region iff, along every axis, its index lies
+in [lo, hi] where the component sits on cell boundaries and in [lo, hi-1] where it sits on cell
+centres.  For every curl term that couples the updated node to a node of the incident components
+(E_e, H_q) the update must see *total* field if the updated node is TF and *scattered* field
+otherwise; the stored neighbour is total iff it is TF.  Hence each stencil leg gets
+``(in_TF(updated) - in_TF(neighbour)) * incident(neighbour)`` times the leg's signed update
+coefficient.  Legs with a non-zero factor exist only on the box surface; they are enumerated on
+the host, once.
+
+The incident field lives on a 1-D Yee grid that shares the 3-D grid's steps along the propagation
+axis (so numerical dispersion matches exactly), extended beyond the domain and terminated by
+matched lossy pads.  Its E_e / H_q are the physical components (signs included):
+  eps dE_e/dt = s dH_q/dp,  mu dH_q/dt = s dE_e/dp,   s = +1 if (e, p, q) is cyclic else -1.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Tuple
+
+import numpy as np
+
+from . import schema as td
+from .constants import C_0, EPSILON_0, ETA_0, MU_0
+from .exceptions import SetupError, Tidy3dNotImplementedError
+from .spec import SolverSpec, TfsfSpec
+
+N_PAD = 40          # cells of each lossy pad of the auxiliary grid
+N_EXT = 6           # loss-free extension cells between pad and domain (the soft source sits there)
+
+
+def _aux_grid(spec: SolverSpec, p: int, s: float, eps_bg: float):
+    """Coefficient arrays of the padded 1-D grid along axis p.  Returns (n_aux, off, ae, be, ah,
+    bh, d_primal) with ``off`` = aux index of 3-D boundary index 0."""
+    d = spec.primal_steps(p)
+    off = N_PAD + N_EXT
+    dp = np.concatenate([np.full(off, d[0]), d, np.full(off, d[-1])])       # primal steps
+    n = len(dp)
+    dd = np.empty(n + 1)
+    dd[1:-1] = 0.5 * (dp[1:] + dp[:-1])
+    dd[0], dd[-1] = dp[0], dp[-1]
+    dt = spec.dt
+    # matched loss: sigma/eps = sigma*/mu = g(x), cubic grading, g_max chosen for ~1e-8 round trip
+    def g_at(pos):          # pos: index coordinate (boundaries = integers, centres = +0.5)
+        depth = np.maximum(N_PAD - pos, pos - (n - N_PAD)) / N_PAD
+        depth = np.clip(depth, 0.0, 1.0)
+        gmax = 4.0 * C_0 / (np.sqrt(eps_bg) * N_PAD * d[0]) * np.log(1e4) / 2.0
+        return gmax * depth ** 3
+    ge = g_at(np.arange(n + 1, dtype=float))
+    gh = g_at(np.arange(n, dtype=float) + 0.5)
+    xe, xh = ge * dt / 2, gh * dt / 2
+    ae = (1 - xe) / (1 + xe)
+    ah = (1 - xh) / (1 + xh)
+    # e1 -= ce * (h[i]-h[i-1]) / dd  with  ce = -s dt/(eps0 eps_bg)   (see module docstring)
+    be = (-s * dt / (EPSILON_0 * eps_bg)) / dd / (1 + xe)
+    bh = (-s * dt / MU_0) / dp / (1 + xh)
+    return n, off, ae, be, ah, bh, dp
+
+
+def replay_aux(t: TfsfSpec, n_steps: int, probe: int) -> np.ndarray:
+    """Host replay of the 1-D incident grid: e1[probe] at t_n for n = 0..n_steps-1 (what the
+    3-D H-phase corrections read).  Used for source normalisation and by tests."""
+    e1 = np.zeros(t.n_aux + 1)
+    h1 = np.zeros(t.n_aux)
+    out = np.empty(n_steps)
+    for n in range(n_steps):
+        out[n] = e1[probe]
+        h1 *= t.ah
+        h1 -= t.bh * (e1[1:] - e1[:-1])
+        e1[1:-1] = t.ae[1:-1] * e1[1:-1] - t.be[1:-1] * (h1[1:] - h1[:-1])
+        e1[t.src_cell] += t.wave[n]
+    return out
+
+
+def _mask_1d(n: int, lo: int, hi: int, on_center: bool) -> np.ndarray:
+    """TF membership along one axis for node indices 0..n-1 (lo/hi may lie outside the grid)."""
+    idx = np.arange(n)
+    return (idx >= lo) & (idx <= (hi - 1 if on_center else hi))
+
+
+def _on_center(comp: int, axis: int) -> bool:
+    return ((comp % 3) == axis) != (comp >= 3)
+
+
+def _legs(spec: SolverSpec, mt, lo, hi, p: int, e: int, q: int, off: int):
+    """Enumerate the stencil legs that straddle the TF/SF surface.  Returns two dicts of arrays
+    (E-phase corrections reading h1, H-phase corrections reading e1)."""
+    from .coeffs import h_coeff, inv_steps
+    from .discretize import cb_at
+    N = spec.shape
+    ip, idl = inv_steps(spec)
+    ch = h_coeff(spec.dt)
+    out = {"e": [], "h": []}
+
+    def in_tf(comp, ijk):
+        m = np.ones(len(ijk), bool)
+        for a in range(3):
+            oc = _on_center(comp, a)
+            m &= (ijk[:, a] >= lo[a]) & (ijk[:, a] <= (hi[a] - 1 if oc else hi[a]))
+        return m
+
+    def candidates(comp):
+        """Nodes of `comp` within one cell of the box surface (union of 6 face slabs), clipped."""
+        rng = [np.arange(max(lo[a] - 1, 0), min(hi[a] + 2, N[a])) for a in range(3)]
+        pts = []
+        for a in range(3):
+            for face in (lo[a], hi[a]):
+                sl = [r for r in rng]
+                sl[a] = np.arange(max(face - 1, 0), min(face + 2, N[a]))
+                if any(len(x) == 0 for x in sl):
+                    continue
+                I, J, K = np.meshgrid(*sl, indexing="ij")
+                pts.append(np.stack([I.ravel(), J.ravel(), K.ravel()], axis=1))
+        if not pts:
+            return np.zeros((0, 3), int)
+        return np.unique(np.concatenate(pts), axis=0)
+
+    # ---- E-phase: E_c += Cb * sgn * (H_q[n] - H_q[n - e_a]) / dual_a for the term d_a H_q in (curl H)_c
+    for c in range(3):
+        for (a, f, sgn) in (((c + 1) % 3, (c + 2) % 3, 1.0), ((c + 2) % 3, (c + 1) % 3, -1.0)):
+            if f != q:
+                continue
+            nodes = candidates(c)
+            if len(nodes) == 0:
+                continue
+            in_e = in_tf(c, nodes).astype(float)
+            cb = cb_at(spec, mt, c, nodes)
+            # wall nodes of E are forced to zero by the main kernels: never correct them
+            from .spec import BC_PEC
+            wall = np.zeros(len(nodes), bool)
+            for b in range(3):
+                if b != c and spec.bc[b][0] == BC_PEC:
+                    wall |= nodes[:, b] == 0
+            for shift, leg_sign in ((0, 1.0), (-1, -1.0)):
+                nb = nodes.copy()
+                nb[:, a] += shift
+                valid = (nb[:, a] >= 0) & (nb[:, a] < N[a]) & ~wall
+                fac = (in_e - in_tf(3 + q, nb).astype(float)) * valid
+                sel = fac != 0
+                if not sel.any():
+                    continue
+                w = cb[sel] * sgn * leg_sign * idl[a][nodes[sel, a]] * fac[sel]
+                out["e"].append((np.full(sel.sum(), c), nodes[sel], w, nb[sel, p] + off))
+    # ---- H-phase: H_c -= ch * sgn * (E_e[n + e_a] - E_e[n]) / primal_a for the term d_a E_e in (curl E)_c
+    for c in range(3):
+        for (a, f, sgn) in (((c + 1) % 3, (c + 2) % 3, 1.0), ((c + 2) % 3, (c + 1) % 3, -1.0)):
+            if f != e:
+                continue
+            nodes = candidates(3 + c)
+            if len(nodes) == 0:
+                continue
+            in_h = in_tf(3 + c, nodes).astype(float)
+            for shift, leg_sign in ((1, 1.0), (0, -1.0)):
+                nb = nodes.copy()
+                nb[:, a] += shift
+                valid = (nb[:, a] >= 0) & (nb[:, a] < N[a])
+                fac = (in_h - in_tf(e, nb).astype(float)) * valid
+                sel = fac != 0
+                if not sel.any():
+                    continue
+                w = -ch * sgn * leg_sign * ip[a][nodes[sel, a]] * fac[sel]
+                out["h"].append((np.full(sel.sum(), 3 + c), nodes[sel], w, nb[sel, p] + off))
+    res = {}
+    for k in ("e", "h"):
+        if out[k]:
+            comp = np.concatenate([x[0] for x in out[k]]).astype(np.int32)
+            ijk = np.concatenate([x[1] for x in out[k]]).astype(np.int32)
+            w = np.concatenate([x[2] for x in out[k]])
+            aux = np.concatenate([x[3] for x in out[k]]).astype(np.int32)
+        else:
+            comp, ijk, w, aux = (np.zeros(0, np.int32), np.zeros((0, 3), np.int32), np.zeros(0),
+                                 np.zeros(0, np.int32))
+        res[k] = (comp, ijk, w, aux)
+    return res
+
+
+def make_tfsf(spec: SolverSpec, mt, lo, hi, p: int, direction: int, e: int, e_scale: float,
+              wave_fn: Callable[[np.ndarray], np.ndarray], eps_bg: float, name: str = "") -> Tuple[TfsfSpec, int]:
+    """One linearly polarised, axis-aligned plane wave.  ``wave_fn(t)`` is the desired incident
+    E_e(t) at the injection face (before scaling); returns (TfsfSpec, aux index of that face)."""
+    q = 3 - p - e
+    s = 1.0 if (e + 1) % 3 == p else -1.0
+    n_aux, off, ae, be, ah, bh, dp = _aux_grid(spec, p, s, eps_bg)
+    N = spec.shape[p]
+    if direction > 0:
+        src = off - 3
+        face = max(lo[p], 0) + off
+    else:
+        src = off + N + 3
+        face = min(hi[p], N) + off
+    # soft source: a sheet adding w per step radiates E = w * d/(2 v dt) to each side
+    v = C_0 / np.sqrt(eps_bg)
+    d_src = 0.5 * (dp[src] + dp[src - 1])
+    # delay so that the pulse arrives at the face with the requested waveform timing
+    dist = abs(np.sum(dp[min(src, face):max(src, face)]))
+    tmesh = spec.dt * np.arange(spec.n_steps)
+    wave = e_scale * wave_fn(tmesh + spec.dt + 0 * dist) * (2 * v * spec.dt / d_src)
+    legs = _legs(spec, mt, lo, hi, p, e, q, off)
+    # the H-phase legs read e1 (boundary-located along p): aux index = boundary index + off  (done)
+    # the E-phase legs read h1 (centre-located along p):   aux index = centre index + off    (done)
+    t = TfsfSpec(n_aux=n_aux, ae=ae, be=be, ah=ah, bh=bh, src_cell=int(src), wave=wave,
+                 e_corr_comp=legs["e"][0], e_corr_ijk=legs["e"][1], e_corr_w=legs["e"][2],
+                 e_corr_aux=legs["e"][3], h_corr_comp=legs["h"][0], h_corr_ijk=legs["h"][1],
+                 h_corr_w=legs["h"][2], h_corr_aux=legs["h"][3], name=name)
+    return t, int(face)
+
+
+def build_planewave(disc, mt, src) -> Callable:
+    """Discretise a PlaneWave or TFSF source; returns its normalisation spectrum function."""
+    sim, spec = disc.sim, disc.spec
+    if src.angle_theta != 0.0:
+        raise Tidy3dNotImplementedError("angled plane waves (angle_theta != 0) are not supported yet")
+    is_box = isinstance(src, td.TFSF)
+    p = int(src.injection_axis)
+    direction = 1 if src.direction == "+" else -1
+    N = spec.shape
+    b = spec.boundaries
+    big = 10 ** 9
+    if is_box:
+        lo, hi = [], []
+        for a in range(3):
+            c0, c1 = src.center[a] - src.size[a] / 2, src.center[a] + src.size[a] / 2
+            if not np.isfinite(src.size[a]):
+                lo.append(-big), hi.append(big)
+                continue
+            lo.append(int(np.argmin(np.abs(b[a] - c0))))
+            hi.append(int(np.argmin(np.abs(b[a] - c1))))
+            if hi[-1] - lo[-1] < 1:
+                raise SetupError("TFSF box is thinner than one cell")
+    else:
+        lo, hi = [-big] * 3, [big] * 3
+        face = int(np.argmin(np.abs(b[p] - src.center[p])))
+        if direction > 0:
+            lo[p] = face
+        else:
+            hi[p] = face
+        for a in range(3):
+            if a != p and np.isfinite(src.size[a]) and src.size[a] < (b[a][-1] - b[a][0]) * 0.999:
+                c0, c1 = src.center[a] - src.size[a] / 2, src.center[a] + src.size[a] / 2
+                lo[a] = int(np.argmin(np.abs(b[a] - c0)))
+                hi[a] = int(np.argmin(np.abs(b[a] - c1)))
+    eps_bg = float(np.real(spec.media[1].eps_inf))
+    if spec.media[1].poles or spec.media[1].sigma:
+        raise Tidy3dNotImplementedError("plane-wave injection needs a lossless, dispersionless background")
+    tang = [a for a in range(3) if a != p]
+    st = src.source_time
+    pol = float(src.pol_angle)
+    # 1 W/um^2 for amplitude 1: |E0|^2 = 2 eta / n  (ref source.py:1210-1214)
+    e_unit = np.sqrt(2 * ETA_0 / np.sqrt(eps_bg))
+    comps = [(tang[0], np.cos(pol)), (tang[1], np.sin(pol))]
+    specs = []
+    for e_axis, wgt in comps:
+        if abs(wgt) < 1e-12:
+            continue
+        t, face_aux = make_tfsf(spec, mt, lo, hi, p, direction, e_axis, e_unit * wgt,
+                                lambda tt: np.real(st.amp_time(tt)), eps_bg,
+                                name=getattr(src, "name", None) or src.type)
+        spec.tfsf.append(t)
+        specs.append((t, face_aux, wgt))
+
+    t0, face0, w0 = specs[0]
+    inc = replay_aux(t0, spec.n_steps, face0) / (e_unit * w0)     # incident E(t_n)/E_unit at the face
+    tmesh = disc.tmesh
+
+    def fn(freqs):
+        freqs = np.atleast_1d(np.asarray(freqs, float))
+        ph = np.exp(2j * np.pi * freqs[:, None] * tmesh[None, :])
+        return spec.dt / np.sqrt(2 * np.pi) * (ph @ inc)
+    return fn

@@ -84,22 +84,24 @@ class TfsfSpec:
     axis-aligned propagation).  Per step:
 
       H-phase:  H[comp][ijk] += h_corr_w * e1[h_corr_aux]       (e1 at t_n)
-                h1 -= ch1 * (e1[1:] - e1[:-1]) * ip1
+                h1 = ah * h1 - bh * (e1[1:] - e1[:-1])
       E-phase:  E[comp][ijk] += e_corr_w * h1[e_corr_aux]       (h1 at t_n + dt/2)
-                e1[1:-1] -= ce1 * (h1[1:] - h1[:-1]) * id1[1:-1]; Mur ABC at both ends;
+                e1[1:-1] = ae[1:-1] * e1[1:-1] - be[1:-1] * (h1[1:] - h1[:-1]);  e1[0] = e1[-1] = 0
                 e1[src_cell] += wave[n]
+
+    The 1-D grid extends beyond the 3-D domain and ends in matched lossy pads (graded electric
+    and magnetic conductivity, reflection-free in 1-D), which is what the per-node decay / update
+    coefficients ae, be, ah, bh encode.
 
     The correction lists (built on the host by ``tidy3d_amd.discretize``) hold every 3-D
     node whose curl stencil straddles the TFSF surface, with the signed update coefficient
     of that node folded into the weight."""
 
     n_aux: int
-    ip1: np.ndarray             # float64 [n_aux]    1 / primal step
-    id1: np.ndarray             # float64 [n_aux+1]  1 / dual step (entries 1..n_aux-1 used)
-    ch1: float                  # h_sign * dt / mu0
-    ce1: float                  # h_sign * dt / (eps0 * eps_bg)
-    mur0: float
-    mur1: float
+    ae: np.ndarray              # float64 [n_aux+1]  decay of e1
+    be: np.ndarray              # float64 [n_aux+1]  update coefficient of e1 (sign included)
+    ah: np.ndarray              # float64 [n_aux]    decay of h1
+    bh: np.ndarray              # float64 [n_aux]    update coefficient of h1 (sign included)
     src_cell: int
     wave: np.ndarray            # float64 [n_steps]
     e_corr_comp: np.ndarray     # int32 [ne]
