@@ -140,8 +140,12 @@ def run_case(name, lib, n_steps=60, scale=1, **engine_kw):
         got = e.results()
         fields = [e.get_field(c) for c in range(6)]
     worst = 0.0
+    # monitors that (still) hold almost nothing — e.g. the flux plane behind a one-way source before
+    # any reflection arrives — are judged against the scale of the largest monitor of the run
+    scale = max(np.linalg.norm(v) / np.sqrt(v.size) for v in ref.values()) if ref else 1.0
     for k in ref:
-        worst = max(worst, rel_err(got[k], ref[k]))
+        den = max(np.linalg.norm(ref[k]), 0.5 * scale * np.sqrt(ref[k].size), 1e-300)
+        worst = max(worst, float(np.linalg.norm(np.asarray(got[k]) - ref[k]) / den))
     en = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in o.E))
     hn = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in o.H))
     for c in range(3):
