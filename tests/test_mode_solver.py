@@ -1,0 +1,128 @@
+"""The product-side eigenmode solver (tidy3d_amd/mode_solver.py) against the reference's CPU mode
+solver: committed golden values produced by ref plugins/mode/solver.py (tests/golden/
+make_golden.py) and, when /root/reference is present, a direct comparison on an asymmetric
+structure; then the one-way mode launch built on it."""
+import json
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+import tidy3d_amd.schema as td
+from tidy3d_amd.constants import C_0
+from tidy3d_amd.mode_solver import mode_flux, solve_modes
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "mode_golden.json")) as f:
+    GOLD = json.load(f)["cases"]
+
+
+def _strip(c):
+    dl, W, H, nc, ncl, Lx, Ly = c["dl"], c["W"], c["H"], c["n_core"], c["n_clad"], c["Lx"], c["Ly"]
+    nx, ny = int(round(Lx / dl)), int(round(Ly / dl))
+    xb = -Lx / 2 + dl * np.arange(nx + 1)
+    yb = -Ly / 2 + dl * np.arange(ny + 1)
+    xc, yc = (xb[1:] + xb[:-1]) / 2, (yb[1:] + yb[:-1]) / 2
+
+    def eps_at(x, y):
+        X, Y = np.meshgrid(x, y, indexing="ij")
+        core = (np.abs(X) <= W / 2) & (np.abs(Y) <= H / 2)
+        return np.where(core, nc ** 2, ncl ** 2).astype(complex)
+    return eps_at(xc, yb[:-1]), eps_at(xb[:-1], yc), eps_at(xb[:-1], yb[:-1]), xb, yb
+
+
+def test_baseline_config1_strip_matches_reference_golden():
+    """BASELINE config[0]: 450 x 220 nm Si/SiO2 strip at 1.55 um, staircased, PEC outer walls."""
+    c = GOLD[0]
+    assert c["num_pml"] == [0, 0]
+    eu, ev, ew, xb, yb = _strip(c)
+    r = solve_modes(eu, ev, ew, xb, yb, C_0 / c["wavelength"], num_modes=c["num_modes"])
+    ref = np.array([complex(*z) for z in c["n_complex"]])
+    np.testing.assert_allclose(r.n_complex, ref, rtol=1e-8)
+    ny = len(yb) - 1
+    ex = np.abs(r.Eu[:, ny // 2, 0])
+    np.testing.assert_allclose(ex / ex.max(), c["abs_Ex_row"], atol=1e-9)
+    hy = np.abs(r.Hv[:, ny // 2, 0])
+    np.testing.assert_allclose(hy / hy.max(), c["abs_Hy_row"], atol=1e-9)
+    ey = np.abs(r.Ev[:, ny // 2, 1])
+    np.testing.assert_allclose(ey / ey.max(), c["abs_Ey_row_m1"], atol=1e-7)
+    # unit power, forward
+    for m in range(2):
+        f = dict(Eu=r.Eu[:, :, m], Ev=r.Ev[:, :, m], Hu=r.Hu[:, :, m], Hv=r.Hv[:, :, m])
+        assert mode_flux(f, xb, yb) == pytest.approx(1.0, rel=1e-12)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/tidy3d"), reason="reference checkout not present")
+def test_against_reference_solver_directly_on_asymmetric_rib():
+    import sys
+    sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..")))
+    from oracle.tidy3d_ref_loader import load_mode_solver
+    _, solver = load_mode_solver()
+    rng = np.random.default_rng(3)
+    xb = np.concatenate(([0.0], np.cumsum(0.03 + 0.02 * rng.random(44)))) - 1.0
+    yb = np.concatenate(([0.0], np.cumsum(0.025 + 0.02 * rng.random(36)))) - 0.6
+    xc, yc = (xb[1:] + xb[:-1]) / 2, (yb[1:] + yb[:-1]) / 2
+
+    def eps_at(x, y):
+        X, Y = np.meshgrid(x, y, indexing="ij")
+        e = np.full(X.shape, 1.44 ** 2, complex)
+        e[(np.abs(X - 0.1) <= 0.3) & (Y >= -0.1) & (Y <= 0.15)] = 3.48 ** 2
+        e[(Y >= -0.2) & (Y < -0.1)] = 2.0 ** 2 + 0.05j          # lossy slab below
+        return e
+    exx, eyy, ezz = eps_at(xc, yb[:-1]), eps_at(xb[:-1], yc), eps_at(xb[:-1], yb[:-1])
+    z = np.zeros_like(exx)
+    ms = SimpleNamespace(num_modes=3, bend_radius=None, bend_axis=None, angle_theta=0.0, angle_phi=0.0,
+                         num_pml=(0, 0), target_neff=None, precision="double")
+    fields, n_ref, _ = solver.compute_modes(eps_cross=[exx, z, z, z, eyy, z, z, z, ezz], coords=[xb, yb],
+                                            freq=C_0 / 1.55, mode_spec=ms, symmetry=(0, 0), direction="+")
+    r = solve_modes(exx, eyy, ezz, xb, yb, C_0 / 1.55, num_modes=3)
+    np.testing.assert_allclose(r.n_complex, n_ref, rtol=1e-7)
+    for m in range(3):
+        # same mode up to one complex scale: normalised inner product of the full tangential vectors
+        # (the reference runs ARPACK with tol = fp_eps = 1.2e-7, so ~1e-6 is its own accuracy)
+        mine_e = np.concatenate([r.Eu[:, :, m].ravel(), r.Ev[:, :, m].ravel()])
+        ref_e = np.concatenate([fields[0, 0, :, :, 0, m].ravel(), fields[0, 1, :, :, 0, m].ravel()])
+        mine_h = np.concatenate([r.Hu[:, :, m].ravel(), r.Hv[:, :, m].ravel()])
+        ref_h = np.concatenate([fields[1, 0, :, :, 0, m].ravel(), fields[1, 1, :, :, 0, m].ravel()])
+        for mine, ref in ((mine_e, ref_e), (mine_h, ref_h)):
+            ov = abs(np.vdot(ref, mine)) / (np.linalg.norm(ref) * np.linalg.norm(mine))
+            assert ov > 1 - 1e-6, (m, ov)
+        # E/H ratio (impedance and relative phase) must agree as well
+        a = np.vdot(fields[0, 0, :, :, 0, m], r.Eu[:, :, m]) / np.vdot(fields[0, 0, :, :, 0, m], fields[0, 0, :, :, 0, m])
+        b = np.vdot(fields[1, 1, :, :, 0, m], r.Hv[:, :, m]) / np.vdot(fields[1, 1, :, :, 0, m], fields[1, 1, :, :, 0, m])
+        assert abs(a / b) == pytest.approx(1.0, rel=1e-6)
+
+
+def test_mode_source_launches_one_way_with_unit_power():
+    """Strip waveguide, ModeSource -> forward flux ~ 1 W (x the colocation factor cos(beta dl/2),
+    see tests/test_tfsf.py), backward flux below -50 dB."""
+    from tidy3d_amd.data import assemble
+    from tidy3d_amd.discretize import discretize
+    from oracle.fdtd_numpy import OracleFdtd
+    lam = 1.55
+    f0 = C_0 / lam
+    dl = 0.05
+    pulse = td.GaussianPulse(freq0=f0, fwidth=f0 / 10)
+    sim = td.Simulation(
+        size=(1.6, 1.2, 2.0), grid_spec=td.GridSpec.uniform(dl=dl), run_time=1.2e-13,
+        medium=td.Medium(permittivity=1.44 ** 2),
+        structures=[td.Structure(geometry=td.Box(center=(0, 0, 0), size=(0.45, 0.22, td.inf)),
+                                 medium=td.Medium(permittivity=3.48 ** 2))],
+        sources=[td.ModeSource(center=(0, 0, -0.5), size=(td.inf, td.inf, 0), source_time=pulse, direction="+",
+                               mode_spec=td.ModeSpec(num_modes=2), mode_index=0)],
+        monitors=[td.FluxMonitor(center=(0, 0, 0.4), size=(td.inf, td.inf, 0), freqs=[0.97 * f0, f0, 1.03 * f0], name="fwd"),
+                  td.FluxMonitor(center=(0, 0, -0.8), size=(td.inf, td.inf, 0), freqs=[f0], name="bwd")],
+        boundary_spec=td.BoundarySpec.all_sides(td.PML(num_layers=8)), shutoff=1e-5)
+    disc = discretize(sim)
+    plane = list(disc.mode_planes.values())[0]
+    neff = plane.result.n_complex[0].real
+    assert 2.3 < neff < 2.7
+    raw = OracleFdtd(disc.spec).run()
+    sd = assemble(disc, raw, log="")
+    # 1 W launched; the flux *measurement* interpolates E and H linearly to the monitor plane,
+    # each losing up to cos(beta dl / 2) (here beta dl = 0.5): expected within [cos^2, 1]
+    beta = 2 * np.pi * f0 / C_0 * neff
+    lo = np.cos(beta * dl / 2) ** 2
+    assert np.all(sd["fwd"].flux.values > lo - 5e-3) and np.all(sd["fwd"].flux.values < 1.005)
+    assert abs(sd["bwd"].flux.values[0]) < 1e-5

@@ -1,0 +1,153 @@
+"""Full-vectorial finite-difference eigenmode solver on the 2-D Yee cross-section.
+
+Purpose: the mode profile a ``ModeSource`` injects (ref source.py:993-1085) and the basis of
+``ModeMonitor`` decompositions.  When the real tidy3d package is importable its own CPU
+``ModeSolver`` stays the reference ("left untouched", north_star); this module is the product-side
+implementation for hosts without tidy3d (the GPU box) and is held to the reference's
+``EigSolver.compute_modes`` (ref plugins/mode/solver.py:33-269) by golden n_eff / field fixtures
+(tests/golden/mode_golden.json, tests/test_mode_solver.py) — it is an independent derivation, not
+a copy.
+
+Formulation (e^{-i w t}, fields ~ e^{+i beta w}, w = propagation axis, (u, v, w) right-handed,
+Ht = eta0 H):  eliminating E_w and H_w from the six curl equations on the Yee cell gives
+
+    beta E_u =  k0 Ht_v + (1/k0) Duf [ (1/eps_w) (Dub Ht_v - Dvb Ht_u) ]
+    beta E_v = -k0 Ht_u + (1/k0) Dvf [ (1/eps_w) (Dub Ht_v - Dvb Ht_u) ]
+    beta Ht_u = -k0 eps_v E_v - (1/k0) Dub (Duf E_v - Dvf E_u)
+    beta Ht_v =  k0 eps_u E_u - (1/k0) Dvb (Duf E_v - Dvf E_u)
+
+i.e. beta [E] = P [Ht], beta [Ht] = Q [E]  =>  (P Q) [E] = beta^2 [E], with forward differences
+(primal steps) acting on E and backward differences (dual steps) acting on Ht, exactly the
+staggering of ref plugins/mode/derivatives.py:9-76.  Node layout in the plane (ref
+grid/grid.py:465-491): E_u at (uc, vb), E_v at (ub, vc), E_w at (ub, vb), H_u at (ub, vc),
+H_v at (uc, vb), H_w at (uc, vc).  The outer edge is PEC (min edge: tangential E on the wall is
+zero; max edge: truncation), like the reference's default.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spl
+
+from .constants import C_0, ETA_0
+
+
+@dataclass
+class ModeResult:
+    n_complex: np.ndarray          # [M]
+    # fields[name] complex [Nu, Nv, M] on the component's own Yee nodes, e^{+i beta w} convention,
+    # physical H (A/um per V/um); normalised to unit power flux along +w
+    Eu: np.ndarray
+    Ev: np.ndarray
+    Ew: np.ndarray
+    Hu: np.ndarray
+    Hv: np.ndarray
+    Hw: np.ndarray
+
+
+def _diff_ops(nu: int, nv: int, du_p, dv_p, du_d, dv_d, pec_min=(True, True)):
+    """Sparse forward (on primal steps) and backward (on dual steps) difference operators for
+    fields flattened as index = iu * nv + iv."""
+    def fwd(n, d):
+        D = sp.diags([-np.ones(n), np.ones(n - 1)], [0, 1], shape=(n, n), format="csr")
+        return sp.diags(1.0 / d) @ D            # last row: (0 - f[n-1]) -> truncation = PEC
+    def bwd(n, d):
+        main = np.ones(n)
+        main[0] = 0.0     # row 0 lives on the PEC wall: it only feeds wall-tangential E (clamped to
+        #                   zero) and wall-normal H (zero on a PEC) -> ref derivatives.py:43-62
+        D = sp.diags([main, -np.ones(n - 1)], [0, -1], shape=(n, n), format="csr")
+        return sp.diags(1.0 / d) @ D
+    Iu, Iv = sp.identity(nu, format="csr"), sp.identity(nv, format="csr")
+    Duf = sp.kron(fwd(nu, du_p), Iv, format="csr")
+    Dvf = sp.kron(Iu, fwd(nv, dv_p), format="csr")
+    Dub = sp.kron(bwd(nu, du_d), Iv, format="csr")
+    Dvb = sp.kron(Iu, bwd(nv, dv_d), format="csr")
+    return Duf, Dvf, Dub, Dvb
+
+
+def solve_modes(eps_u: np.ndarray, eps_v: np.ndarray, eps_w: np.ndarray, ub: np.ndarray,
+                vb: np.ndarray, freq: float, num_modes: int = 1,
+                target_neff: Optional[float] = None) -> ModeResult:
+    """eps_* are [Nu, Nv] (complex allowed) sampled at E_u (uc, vb), E_v (ub, vc), E_w (ub, vb);
+    ub / vb the Nu+1 / Nv+1 cell boundaries."""
+    nu, nv = eps_u.shape
+    N = nu * nv
+    k0 = 2 * np.pi * freq / C_0
+    du_p, dv_p = np.diff(ub), np.diff(vb)
+    du_d = np.concatenate(([du_p[0]], 0.5 * (du_p[1:] + du_p[:-1])))
+    dv_d = np.concatenate(([dv_p[0]], 0.5 * (dv_p[1:] + dv_p[:-1])))
+    Duf, Dvf, Dub, Dvb = _diff_ops(nu, nv, du_p, dv_p, du_d, dv_d)
+    eu, ev, ew = (sp.diags(np.asarray(a).reshape(-1)) for a in (eps_u, eps_v, eps_w))
+    ewi = sp.diags(1.0 / np.asarray(eps_w).reshape(-1))
+    # PEC on the min edges: the tangential E that sits on a wall is clamped to zero
+    mask_u = np.ones((nu, nv)); mask_u[:, 0] = 0        # E_u at vb[0]
+    mask_v = np.ones((nu, nv)); mask_v[0, :] = 0        # E_v at ub[0]
+    mask_w = np.ones((nu, nv)); mask_w[0, :] = 0; mask_w[:, 0] = 0
+    Mu, Mv, Mw = (sp.diags(m.reshape(-1)) for m in (mask_u, mask_v, mask_w))
+    I = sp.identity(N, format="csr")
+    # E_w = (i/(k0 eps_w)) (Dub Ht_v - Dvb Ht_u)   -> rows of P
+    curl_h = sp.hstack([-Dvb, Dub], format="csr")                       # acts on [Ht_u; Ht_v]
+    Ew_op = Mw @ ewi @ curl_h                                           # (without the i/k0 factor)
+    P = sp.vstack([
+        Mu @ (sp.hstack([sp.csr_matrix((N, N)), k0 * I]) + (1 / k0) * Duf @ Ew_op),
+        Mv @ (sp.hstack([-k0 * I, sp.csr_matrix((N, N))]) + (1 / k0) * Dvf @ Ew_op),
+    ], format="csr")
+    curl_e = sp.hstack([-Dvf, Duf], format="csr")                       # Duf E_v - Dvf E_u on [E_u; E_v]
+    Q = sp.vstack([
+        sp.hstack([sp.csr_matrix((N, N)), -k0 * ev]) - (1 / k0) * Dub @ curl_e,
+        sp.hstack([k0 * eu, sp.csr_matrix((N, N))]) - (1 / k0) * Dvb @ curl_e,
+    ], format="csr")
+    A = (P @ Q).tocsc()
+    if target_neff is None:
+        target_neff = float(np.sqrt(np.max(np.real([eps_u.max(), eps_v.max(), eps_w.max()]))))
+    sigma = (target_neff * k0) ** 2
+    rng = np.random.default_rng(0)
+    v0 = rng.standard_normal(2 * N)
+    vals, vecs = spl.eigs(A, k=num_modes, sigma=sigma, v0=v0, tol=1e-10)
+    beta = np.sqrt(vals + 0j)
+    beta = np.where(beta.real < 0, -beta, beta)
+    order = np.argsort(-beta.real)
+    beta, vecs = beta[order], vecs[:, order]
+    out = {k: np.zeros((nu, nv, num_modes), complex) for k in ("Eu", "Ev", "Ew", "Hu", "Hv", "Hw")}
+    for m in range(num_modes):
+        E = vecs[:, m]
+        Ht = (Q @ E) / beta[m]
+        Eu_, Ev_ = E[:N], E[N:]
+        Htu, Htv = Ht[:N], Ht[N:]
+        Ew_ = (1j / k0) * (Ew_op @ Ht)
+        Htw = (-1j / k0) * (curl_e @ E)
+        f = dict(Eu=Eu_, Ev=Ev_, Ew=Ew_, Hu=Htu / ETA_0, Hv=Htv / ETA_0, Hw=Htw / ETA_0)
+        f = {k: v.reshape(nu, nv) for k, v in f.items()}
+        # gauge: the largest tangential E sample is real and positive (ref mode_solver.py:803-806)
+        big = f["Eu"] if np.abs(f["Eu"]).max() >= np.abs(f["Ev"]).max() else f["Ev"]
+        ph = np.exp(-1j * np.angle(big.reshape(-1)[np.argmax(np.abs(big))]))
+        # unit power along +w: 0.5 Re int (E_u H_v* - E_v H_u*) dA, fields colocated to cell centres
+        f = {k: v * ph for k, v in f.items()}
+        p = mode_flux(f, ub, vb)
+        s = 1.0 / np.sqrt(abs(p)) if p != 0 else 1.0
+        for k in out:
+            out[k][:, :, m] = f[k] * s
+    return ModeResult(n_complex=beta / k0, **out)
+
+
+def _to_centres(f: np.ndarray, on_b_u: bool, on_b_v: bool) -> np.ndarray:
+    """Average a node field to cell centres (values beyond the max edge are the PEC zero)."""
+    g = f
+    if on_b_u:
+        g = 0.5 * (g + np.concatenate([g[1:], np.zeros_like(g[:1])], axis=0))
+    if on_b_v:
+        g = 0.5 * (g + np.concatenate([g[:, 1:], np.zeros_like(g[:, :1])], axis=1))
+    return g
+
+
+def mode_flux(f: dict, ub: np.ndarray, vb: np.ndarray) -> float:
+    """0.5 Re int (E_u H_v* - E_v H_u*) du dv with all four fields brought to the cell centres."""
+    eu = _to_centres(f["Eu"], False, True)
+    ev = _to_centres(f["Ev"], True, False)
+    hu = _to_centres(f["Hu"], True, False)
+    hv = _to_centres(f["Hv"], False, True)
+    dA = np.outer(np.diff(ub), np.diff(vb))
+    return float(0.5 * np.real(np.sum((eu * np.conj(hv) - ev * np.conj(hu)) * dA)))

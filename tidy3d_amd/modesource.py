@@ -1,0 +1,168 @@
+"""ModeSource (ref source.py:993-1085) and ModeMonitor (ref monitor.py:631) on top of the
+cross-section eigenmode solver.
+
+Injection: the source plane splits space into a total-field half-space (downstream of the plane
+along ``direction``) and a scattered-field half-space; the incident field is the waveguide mode
+E_m(u,v) a(t), H_m(u,v) a(t) (profile computed at freq0, ref source.py:1003: 1 W at the central
+frequency).  The stencil legs across the plane (tidy3d_amd.planewave.surface_legs) become a
+PointSourceSet with complex weights  leg_coefficient x mode_field(node): E-phase legs carry the
+tangential H of the mode half a cell off the plane (phase e^{-i beta dz/2}) sampled at t_{n+1/2},
+H-phase legs the tangential E on the plane at t_n — a one-way launch.
+
+When the real tidy3d package is importable, ``mode_profile`` can be swapped for tidy3d's own
+``ModeSolver(simulation, plane=source, ...)`` (north_star: the CPU ModeSolver stays the reference);
+here the independent solver of tidy3d_amd.mode_solver is used and pinned to the reference's
+arithmetic by tests/golden/mode_golden.json.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, Tuple
+
+import numpy as np
+
+from . import schema as td
+from .constants import C_0
+from .discretize import discretize_inds
+from .exceptions import SetupError, Tidy3dNotImplementedError
+from .mode_solver import ModeResult, solve_modes
+from .planewave import surface_legs
+from .spec import PointSourceSet, SolverSpec
+
+
+@dataclass
+class ModePlane:
+    p: int                       # propagation axis
+    u: int
+    v: int
+    k0: int                      # boundary index of the plane along p
+    lo: Tuple[int, int]          # first cell of the window along (u, v)
+    hi: Tuple[int, int]
+    result: ModeResult
+
+
+def _eps_plane(spec: SolverSpec, comp_axis: int, p: int, k: int, lo, hi, u: int, v: int, freq: float):
+    """eps(freq) at the Yee nodes of E_{comp_axis} on plane index k (p axis), window [lo, hi)."""
+    eps_tab = []
+    for med in spec.media:
+        if med.pec:
+            eps_tab.append(-1e8 + 0j)           # pec_val, ref constants.py:64
+            continue
+        w = 2 * np.pi * freq
+        e = med.eps_inf + 0j
+        if med.sigma:
+            from .constants import EPSILON_0
+            e += 1j * med.sigma / (w * EPSILON_0)
+        for a, c in med.poles:
+            e -= c / (1j * w + a) + np.conj(c) / (1j * w + np.conj(a))
+        eps_tab.append(e)
+    eps_tab = np.array(eps_tab)
+    nu, nv = hi[0] - lo[0], hi[1] - lo[1]
+    if spec.mat_idx is None:
+        return np.full((nu, nv), eps_tab[1])
+    k = int(np.clip(k, 0, spec.shape[p] - 1))
+    sl = [None, None, None]
+    sl[p] = k
+    sl[u] = slice(lo[0], hi[0])
+    sl[v] = slice(lo[1], hi[1])
+    m = spec.mat_idx[comp_axis][sl[2], sl[1], sl[0]]      # array axes are (z, y, x) minus the fixed one
+    # bring to (u, v) order
+    rem = [a for a in (2, 1, 0) if a != p]                 # physical axes of m's dims, in order
+    if rem == [v, u]:
+        m = m.T
+    return eps_tab[m]
+
+
+def mode_profile(spec: SolverSpec, box: td.Box, mode_spec, freq: float) -> ModePlane:
+    """Solve the cross-section eigenproblem on the plane of ``box`` (one zero-size dimension)."""
+    zd = [a for a in range(3) if box.size[a] == 0]
+    if len(zd) != 1:
+        raise SetupError("a mode plane needs exactly one zero-size dimension")
+    p = zd[0]
+    u, v = (p + 1) % 3, (p + 2) % 3
+    if getattr(mode_spec, "angle_theta", 0.0) or getattr(mode_spec, "bend_radius", None):
+        raise Tidy3dNotImplementedError("angled / bent mode planes are not supported")
+    if any(getattr(mode_spec, "num_pml", (0, 0))):
+        raise Tidy3dNotImplementedError("ModeSpec.num_pml is not supported (PEC-terminated mode plane)")
+    b = spec.boundaries
+    k0 = int(np.argmin(np.abs(b[p] - box.center[p])))
+    k0 = int(np.clip(k0, 1, spec.shape[p] - 1))
+    span = discretize_inds(list(b), box)
+    lo = (max(span[u][0], 0), max(span[v][0], 0))
+    hi = (min(span[u][1], spec.shape[u]), min(span[v][1], spec.shape[v]))
+    eps_u = _eps_plane(spec, u, p, k0, lo, hi, u, v, freq)
+    eps_v = _eps_plane(spec, v, p, k0, lo, hi, u, v, freq)
+    eps_w = _eps_plane(spec, p, p, k0, lo, hi, u, v, freq)
+    ub = b[u][lo[0]:hi[0] + 1]
+    vb = b[v][lo[1]:hi[1] + 1]
+    res = solve_modes(eps_u, eps_v, eps_w, ub, vb, freq, num_modes=int(mode_spec.num_modes),
+                      target_neff=mode_spec.target_neff)
+    return ModePlane(p=p, u=u, v=v, k0=k0, lo=lo, hi=hi, result=res)
+
+
+def build_mode_source(disc, mt, src) -> Callable:
+    sim, spec, tmesh = disc.sim, disc.spec, disc.tmesh
+    st = src.source_time
+    if int(getattr(src, "num_freqs", 1)) != 1:
+        raise Tidy3dNotImplementedError("ModeSource.num_freqs > 1 (broadband profile) is not supported")
+    plane = mode_profile(spec, src.geometry, src.mode_spec, st.freq0)
+    p, u, v, k0 = plane.p, plane.u, plane.v, plane.k0
+    r = plane.result
+    mi = int(src.mode_index)
+    if mi >= len(r.n_complex):
+        raise SetupError("mode_index exceeds mode_spec.num_modes")
+    direction = 1 if src.direction == "+" else -1
+    beta = 2 * np.pi * st.freq0 / C_0 * r.n_complex[mi]
+    big = 10 ** 9
+    lo, hi = [-big] * 3, [big] * 3
+    if direction > 0:
+        lo[p] = k0
+    else:
+        hi[p] = k0
+    legs = surface_legs(spec, mt, lo, hi, (u, v), (u, v))
+    d = spec.primal_steps(p)
+    # backward-travelling mode: tangential H flips sign
+    fields = {u: r.Eu[:, :, mi], v: r.Ev[:, :, mi], 3 + u: direction * r.Hu[:, :, mi],
+              3 + v: direction * r.Hv[:, :, mi]}
+
+    def sample(nb_comp, nb_ijk):
+        iu = nb_ijk[:, u] - plane.lo[0]
+        iv = nb_ijk[:, v] - plane.lo[1]
+        ok = (iu >= 0) & (iu < plane.hi[0] - plane.lo[0]) & (iv >= 0) & (iv < plane.hi[1] - plane.lo[1])
+        out = np.zeros(len(nb_ijk), complex)
+        for c, arr in fields.items():
+            m = ok & (nb_comp == c)
+            out[m] = arr[iu[m], iv[m]]
+        return out
+
+    comps, ijks, ws = [], [], []
+    for key in ("e", "h"):
+        comp, ijk, w, nbc, nbi = legs[key]
+        val = sample(nbc, nbi)
+        if key == "e":
+            # incident H sits on the cell centre next to the plane: half a cell of propagation phase
+            kc = nbi[:, p]
+            dist = 0.5 * d[np.clip(kc, 0, len(d) - 1)]
+            val = val * np.exp(-1j * beta * dist)
+        keep = val != 0
+        comps.append(comp[keep])
+        ijks.append(ijk[keep])
+        ws.append(w[keep] * val[keep])
+    comp = np.concatenate(comps).astype(np.int32)
+    ijk = np.concatenate(ijks).astype(np.int32)
+    w = np.concatenate(ws)
+    dt = spec.dt
+    spec.sources.append(PointSourceSet(
+        comp=comp, ijk=ijk, w_re=w.real.copy(), w_im=w.imag.copy(),
+        wave_e=np.asarray(st.amp_time(tmesh + dt / 2), complex),
+        wave_h=np.asarray(st.amp_time(tmesh), complex), name=getattr(src, "name", None) or "ModeSource"))
+    disc.mode_planes = getattr(disc, "mode_planes", {})
+    disc.mode_planes[id(src)] = plane
+
+    def fn(freqs):
+        return st.spectrum(tmesh, np.asarray(freqs, float), dt)
+    return fn
+
+
+def mode_monitor_data(disc, plan, raw, norm):
+    raise Tidy3dNotImplementedError("ModeMonitor decomposition is not implemented yet (SURVEY.md 8(f) rank 2)")

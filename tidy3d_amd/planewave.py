@@ -87,9 +87,11 @@ def _on_center(comp: int, axis: int) -> bool:
     return ((comp % 3) == axis) != (comp >= 3)
 
 
-def _legs(spec: SolverSpec, mt, lo, hi, p: int, e: int, q: int, off: int):
-    """Enumerate the stencil legs that straddle the TF/SF surface.  Returns two dicts of arrays
-    (E-phase corrections reading h1, H-phase corrections reading e1)."""
+def surface_legs(spec: SolverSpec, mt, lo, hi, inc_e, inc_h):
+    """Enumerate the stencil legs that straddle the TF/SF surface of the region [lo, hi] for an
+    incident field whose non-zero components are ``inc_e`` (E axes) and ``inc_h`` (H axes).
+    Returns {"e": (comp, ijk, w, nb_comp, nb_ijk), "h": (...)}: E-phase legs add
+    w * H_inc[nb_comp](nb_ijk) to E[comp](ijk); H-phase legs add w * E_inc[nb_comp](nb_ijk)."""
     from .coeffs import h_coeff, inv_steps
     from .discretize import cb_at
     N = spec.shape
@@ -123,7 +125,7 @@ def _legs(spec: SolverSpec, mt, lo, hi, p: int, e: int, q: int, off: int):
     # ---- E-phase: E_c += Cb * sgn * (H_q[n] - H_q[n - e_a]) / dual_a for the term d_a H_q in (curl H)_c
     for c in range(3):
         for (a, f, sgn) in (((c + 1) % 3, (c + 2) % 3, 1.0), ((c + 2) % 3, (c + 1) % 3, -1.0)):
-            if f != q:
+            if f not in inc_h:
                 continue
             nodes = candidates(c)
             if len(nodes) == 0:
@@ -140,16 +142,16 @@ def _legs(spec: SolverSpec, mt, lo, hi, p: int, e: int, q: int, off: int):
                 nb = nodes.copy()
                 nb[:, a] += shift
                 valid = (nb[:, a] >= 0) & (nb[:, a] < N[a]) & ~wall
-                fac = (in_e - in_tf(3 + q, nb).astype(float)) * valid
+                fac = (in_e - in_tf(3 + f, nb).astype(float)) * valid
                 sel = fac != 0
                 if not sel.any():
                     continue
                 w = cb[sel] * sgn * leg_sign * idl[a][nodes[sel, a]] * fac[sel]
-                out["e"].append((np.full(sel.sum(), c), nodes[sel], w, nb[sel, p] + off))
+                out["e"].append((np.full(sel.sum(), c), nodes[sel], w, np.full(sel.sum(), 3 + f), nb[sel]))
     # ---- H-phase: H_c -= ch * sgn * (E_e[n + e_a] - E_e[n]) / primal_a for the term d_a E_e in (curl E)_c
     for c in range(3):
         for (a, f, sgn) in (((c + 1) % 3, (c + 2) % 3, 1.0), ((c + 2) % 3, (c + 1) % 3, -1.0)):
-            if f != e:
+            if f not in inc_e:
                 continue
             nodes = candidates(3 + c)
             if len(nodes) == 0:
@@ -159,24 +161,31 @@ def _legs(spec: SolverSpec, mt, lo, hi, p: int, e: int, q: int, off: int):
                 nb = nodes.copy()
                 nb[:, a] += shift
                 valid = (nb[:, a] >= 0) & (nb[:, a] < N[a])
-                fac = (in_h - in_tf(e, nb).astype(float)) * valid
+                fac = (in_h - in_tf(f, nb).astype(float)) * valid
                 sel = fac != 0
                 if not sel.any():
                     continue
                 w = -ch * sgn * leg_sign * ip[a][nodes[sel, a]] * fac[sel]
-                out["h"].append((np.full(sel.sum(), 3 + c), nodes[sel], w, nb[sel, p] + off))
+                out["h"].append((np.full(sel.sum(), 3 + c), nodes[sel], w, np.full(sel.sum(), f), nb[sel]))
     res = {}
     for k in ("e", "h"):
         if out[k]:
             comp = np.concatenate([x[0] for x in out[k]]).astype(np.int32)
             ijk = np.concatenate([x[1] for x in out[k]]).astype(np.int32)
             w = np.concatenate([x[2] for x in out[k]])
-            aux = np.concatenate([x[3] for x in out[k]]).astype(np.int32)
+            nbc = np.concatenate([x[3] for x in out[k]]).astype(np.int32)
+            nbi = np.concatenate([x[4] for x in out[k]]).astype(np.int32)
         else:
-            comp, ijk, w, aux = (np.zeros(0, np.int32), np.zeros((0, 3), np.int32), np.zeros(0),
-                                 np.zeros(0, np.int32))
-        res[k] = (comp, ijk, w, aux)
+            comp, ijk, w, nbc, nbi = (np.zeros(0, np.int32), np.zeros((0, 3), np.int32), np.zeros(0),
+                                      np.zeros(0, np.int32), np.zeros((0, 3), np.int32))
+        res[k] = (comp, ijk, w, nbc, nbi)
     return res
+
+
+def _legs(spec: SolverSpec, mt, lo, hi, p: int, e: int, q: int, off: int):
+    """Plane-wave specialisation: incident components (E_e, H_q) read from the 1-D grid along p."""
+    legs = surface_legs(spec, mt, lo, hi, (e,), (q,))
+    return {k: (v[0], v[1], v[2], (v[4][:, p] + off).astype(np.int32)) for k, v in legs.items()}
 
 
 def make_tfsf(spec: SolverSpec, mt, lo, hi, p: int, direction: int, e: int, e_scale: float,
