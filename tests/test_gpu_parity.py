@@ -241,3 +241,56 @@ def test_config4_mie_sphere_512_cube(hip_lib):
           f"{512**3 * st.steps_done / (st.run_ms * 1e-3) / 1e6:.0f} Mcells/s), sigma_sca/analytic = {got / ana}")
     assert not st.diverged
     np.testing.assert_allclose(got, ana, rtol=0.04)
+
+
+def test_config3_si_strip_waveguide_mode_launch(hip_lib):
+    """BASELINE config[2]: Si strip waveguide, 400 x 200 x 800 cells (+12 PML cells per face =
+    424 x 224 x 824), ModeSource + PML + FluxMonitor on one MI355X.  The launched field is compared
+    with the CPU eigenmode (same solver that is pinned to the reference's compute_modes): modal
+    purity |a+|^2 / flux, backward power, and n_eff from the phase advance between two planes."""
+    import time
+    from tidy3d_amd.data import assemble
+    lam = 1.55
+    f0 = C_0 / lam
+    dl = 0.01
+    pulse = td.GaussianPulse(freq0=f0, fwidth=f0 / 10)
+    plane = (td.inf, td.inf, 0)
+    sim = td.Simulation(
+        size=(4.0, 2.0, 8.0), grid_spec=td.GridSpec.uniform(dl=dl), run_time=2.6e-13,
+        medium=td.Medium(permittivity=1.44 ** 2),
+        structures=[td.Structure(geometry=td.Box(center=(0, 0, 0), size=(0.45, 0.22, td.inf)),
+                                 medium=td.Medium(permittivity=3.48 ** 2))],
+        sources=[td.ModeSource(center=(0, 0, -3.5), size=plane, source_time=pulse, direction="+",
+                               mode_spec=td.ModeSpec(num_modes=1), mode_index=0)],
+        monitors=[td.FluxMonitor(center=(0, 0, 3.0), size=plane, freqs=[f0], name="fwd"),
+                  td.FluxMonitor(center=(0, 0, -3.8), size=plane, freqs=[f0], name="bwd"),
+                  td.ModeMonitor(center=(0, 0, 3.0), size=plane, freqs=[f0], mode_spec=td.ModeSpec(num_modes=1), name="mm"),
+                  td.FieldMonitor(center=(0, 0, 1.0), size=(0, 0, 0), freqs=[f0], name="p1", fields=["Ex"]),
+                  td.FieldMonitor(center=(0, 0, 2.0), size=(0, 0, 0), freqs=[f0], name="p2", fields=["Ex"])],
+        boundary_spec=td.BoundarySpec.all_sides(td.PML(num_layers=12)), shutoff=1e-5)
+    t0 = time.time()
+    disc = discretize(sim)
+    assert disc.spec.shape == (424, 224, 824)
+    t1 = time.time()
+    with HipEngine(disc.spec, lib=hip_lib) as e:
+        st = e.run()
+        raw = e.results()
+    t2 = time.time()
+    sd = assemble(disc, raw, log="")
+    neff = list(disc.mode_planes.values())[0].result.n_complex[0].real
+    fwd, bwd = float(sd["fwd"].flux.values[0]), float(sd["bwd"].flux.values[0])
+    a = sd["mm"].amps.values
+    purity = abs(a[0, 0, 0]) ** 2 / fwd
+    dphi = np.angle(sd["p2"].Ex.values.ravel()[0] / sd["p1"].Ex.values.ravel()[0])
+    beta = 2 * np.pi * f0 / C_0 * neff
+    dphi_ref = np.angle(np.exp(1j * beta * 1.0))
+    print(f"\n[config3] setup {t1 - t0:.1f}s solve {t2 - t1:.1f}s ({st.steps_done} steps, "
+          f"{disc.spec.n_cells * st.steps_done / (st.run_ms * 1e-3) / 1e6:.0f} Mcells/s) neff={neff:.6f} "
+          f"fwd={fwd:.6f} bwd={bwd:.3e} purity={purity:.7f} |a-|^2={abs(a[1, 0, 0])**2:.3e} "
+          f"dphi={dphi:.5f} vs {dphi_ref:.5f}")
+    assert not st.diverged
+    assert 0.985 < fwd < 1.002                 # 1 W launched (x colocation factor of the flux measurement)
+    assert abs(bwd) < 1e-5                     # one-way launch: backward power below -50 dB
+    # the propagating FDTD field vs the (continuous-z) eigenmode: 1 - purity ~ (beta dl)^2 / 12 ~ 5e-4
+    assert abs(1 - purity) < 1e-3
+    assert abs(np.angle(np.exp(1j * (dphi - dphi_ref)))) < 0.02      # beta of the FDTD mode vs the eigenvalue

@@ -164,5 +164,81 @@ def build_mode_source(disc, mt, src) -> Callable:
     return fn
 
 
+def _interp_nodes(arr: np.ndarray, src_u, src_v, dst_u, dst_v) -> np.ndarray:
+    from .data import interp_axis
+    return interp_axis(interp_axis(arr, src_u, dst_u, 0), src_v, dst_v, 1)
+
+
+def colocated_mode(plane: ModePlane, spec: SolverSpec, mi: int, direction: int, dst_u, dst_v) -> Dict[str, np.ndarray]:
+    """Tangential mode fields interpolated from their Yee nodes to the nodes (dst_u, dst_v) — the
+    same linear colocation the monitor data undergo (ref dataset.py:83-147)."""
+    r = plane.result
+    b = spec.boundaries
+    ub = b[plane.u][plane.lo[0]:plane.hi[0] + 1]
+    vb = b[plane.v][plane.lo[1]:plane.hi[1] + 1]
+    uc, vc = 0.5 * (ub[1:] + ub[:-1]), 0.5 * (vb[1:] + vb[:-1])
+    return {
+        "Eu": _interp_nodes(r.Eu[:, :, mi], uc, vb[:-1], dst_u, dst_v),
+        "Ev": _interp_nodes(r.Ev[:, :, mi], ub[:-1], vc, dst_u, dst_v),
+        "Hu": direction * _interp_nodes(r.Hu[:, :, mi], ub[:-1], vc, dst_u, dst_v),
+        "Hv": direction * _interp_nodes(r.Hv[:, :, mi], uc, vb[:-1], dst_u, dst_v),
+    }
+
+
+def overlap(a: Dict[str, np.ndarray], b: Dict[str, np.ndarray], w: np.ndarray) -> complex:
+    """(a, b) = 1/4 int (E_a* x H_b + H_a* x E_b) . n dA   (ref monitor_data.py:640-697), n = +w."""
+    e1h2 = np.conj(a["Eu"]) * b["Hv"] - np.conj(a["Ev"]) * b["Hu"]
+    h1e2 = np.conj(a["Hu"]) * b["Ev"] - np.conj(a["Hv"]) * b["Eu"]
+    return complex(0.25 * np.sum((e1h2 - h1e2) * w))
+
+
+@dataclass
+class ModeData:
+    """Mirror of tidy3d ModeData (ref monitor_data.py:1223): complex amplitudes of the forward (+)
+    and backward (-) modes, ``amps`` dims (direction, f, mode_index); ``n_complex`` (f, mode_index).
+    Modes are normalised to unit directed flux, amps = (mode, field)/(mode, mode) (CHANGELOG:534-538)."""
+    monitor: object
+    amps: object = None
+    n_complex: object = None
+
+
 def mode_monitor_data(disc, plan, raw, norm):
-    raise Tidy3dNotImplementedError("ModeMonitor decomposition is not implemented yet (SURVEY.md 8(f) rank 2)")
+    from .data import DataArray, FieldData, _diff_area, _field_container
+    mon = plan.monitor
+    spec = disc.spec
+    fp = plan.fields[0]
+    freqs = np.asarray(mon.freqs, float)
+    fd = _field_container(FieldData, mon, spec, fp, raw[fp.spec_name], "f", freqs, disc.sim.center,
+                          np.complex128).normalize(norm)
+    zd = [a for a in range(3) if mon.size[a] == 0]
+    p = zd[0]
+    u, v = (p + 1) % 3, (p + 2) % 3
+    names = "xyz"
+    gu = np.asarray(fd["E" + names[u]].coords[names[u]])
+    gv = np.asarray(fd["E" + names[u]].coords[names[v]])
+
+    def plane_vals(comp):
+        arr = fd[comp].values                     # (x, y, z, f)
+        arr = np.take(arr, 0, axis=p)             # drop the normal axis -> remaining spatial dims in x,y,z order
+        rem = [a for a in range(3) if a != p]
+        if rem != [u, v]:
+            arr = np.swapaxes(arr, 0, 1)
+        return arr                                # (u, v, f)
+    F = {"Eu": plane_vals("E" + names[u]), "Ev": plane_vals("E" + names[v]),
+         "Hu": plane_vals("H" + names[u]), "Hv": plane_vals("H" + names[v])}
+    w = _diff_area(mon.geometry, None, None, p, gu, gv)
+    nm = int(mon.mode_spec.num_modes)
+    amps = np.zeros((2, len(freqs), nm), complex)
+    neff = np.zeros((len(freqs), nm), complex)
+    for i, f in enumerate(freqs):
+        plane = mode_profile(spec, mon.geometry, mon.mode_spec, float(f))
+        neff[i] = plane.result.n_complex
+        Ff = {k: a[:, :, i] for k, a in F.items()}
+        for m in range(nm):
+            for d_i, direction in enumerate((1, -1)):
+                M = colocated_mode(plane, spec, m, direction, gu, gv)
+                amps[d_i, i, m] = overlap(M, Ff, w) / overlap(M, M, w)
+    return ModeData(monitor=mon,
+                    amps=DataArray(amps.astype(np.complex64), {"direction": np.array(["+", "-"]), "f": freqs,
+                                                               "mode_index": np.arange(nm)}),
+                    n_complex=DataArray(neff, {"f": freqs, "mode_index": np.arange(nm)}))
