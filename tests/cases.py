@@ -111,8 +111,36 @@ def planewave_periodic(N=(8, 12, 20)):
     return _sim(N, bspec, structures, sources=[src], monitors=mons)
 
 
+def gold_johnson_christy():
+    """Au (Johnson & Christy 1972 fit, 5 pole pairs) exactly as the reference's material library
+    serialises it (ref material_library.py:506), read from the committed golden fixture."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "schema_golden.json")) as f:
+        rec = json.load(f)["media"][-1]
+    return td.parse(rec["json"])
+
+
+def au_array(N=(12, 12, 24), dl=0.01):
+    """BASELINE config[4] in miniature: periodic array of Au nano-discs (5-pole dispersive ADE) on a
+    dielectric slab, plane wave from above, PML along z."""
+    pulse = td.GaussianPulse(freq0=5e14, fwidth=1e14)
+    size = tuple(n * dl for n in N)
+    structures = [td.Structure(geometry=td.Box(center=(0, 0, -size[2] / 4), size=(td.inf, td.inf, size[2] / 2)),
+                               medium=td.Medium(permittivity=2.1)),
+                  td.Structure(geometry=td.Cylinder(center=(0, 0, 0.02), radius=0.035, length=0.03, axis=2),
+                               medium=gold_johnson_christy())]
+    src = td.PlaneWave(center=(0, 0, size[2] / 2 - 0.03), size=(td.inf, td.inf, 0), source_time=pulse, direction="-")
+    mons = [td.FluxMonitor(center=(0, 0, size[2] / 2 - 0.015), size=(td.inf, td.inf, 0), freqs=[4.5e14, 5.5e14], name="R"),
+            td.FluxMonitor(center=(0, 0, -size[2] / 2 + 0.03), size=(td.inf, td.inf, 0), freqs=[4.5e14, 5.5e14], name="T"),
+            td.FieldTimeMonitor(center=(0, 0, 0.02), size=(0.05, 0.05, 0), name="t", interval=9, colocate=False)]
+    bspec = td.BoundarySpec(x=td.Boundary.periodic(), y=td.Boundary.periodic(), z=td.Boundary.pml(num_layers=6))
+    return td.Simulation(size=size, grid_spec=td.GridSpec.uniform(dl=dl), run_time=1e-12, structures=structures,
+                         sources=[src], monitors=mons, boundary_spec=bspec, shutoff=0)
+
+
 CASES = {
-    "tfsf_box": tfsf_box, "planewave_periodic": planewave_periodic,
+    "tfsf_box": tfsf_box, "planewave_periodic": planewave_periodic, "au_array": au_array,
     "pec_box": pec_box, "pec_box_vec": pec_box_vec, "periodic_box": periodic_box,
     "pml_box": pml_box, "stable_pml_box": stable_pml_box, "media_mix": media_mix,
     "drude_in_pml": drude_in_pml, "nonuniform_grid": nonuniform_grid,

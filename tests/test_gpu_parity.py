@@ -294,3 +294,57 @@ def test_config3_si_strip_waveguide_mode_launch(hip_lib):
     # the propagating FDTD field vs the (continuous-z) eigenmode: 1 - purity ~ (beta dl)^2 / 12 ~ 5e-4
     assert abs(1 - purity) < 1e-3
     assert abs(np.angle(np.exp(1j * (dphi - dphi_ref)))) < 0.02      # beta of the FDTD mode vs the eigenvalue
+
+
+def test_config5_au_nanoparticle_array_1024x1024x256(hip_lib):
+    """BASELINE config[4] on ONE MI355X (the 8-GPU z-slab run of the same grid is the driver's):
+    dispersive Au (Johnson & Christy, 5 pole pairs -> ADE) nano-disc array, 1024 x 1024 x 256 cells,
+    periodic in x/y, CPML in z, plane wave.  Checks stability of the 5-pole ADE over the whole run,
+    energy balance R + T + A = 1 with 0 < A, and the 16-fold translation symmetry of the array."""
+    import time
+    from cases import gold_johnson_christy
+    from tidy3d_amd.data import assemble
+    dl = 0.005
+    nxy, nz = 1024, 256 - 24
+    pitch = 64 * dl
+    au = gold_johnson_christy()
+    f0 = 5e14
+    pulse = td.GaussianPulse(freq0=f0, fwidth=1e14)
+    L, Lz = nxy * dl, nz * dl
+    discs = [td.Structure(geometry=td.Cylinder(center=(-L / 2 + (i + 0.5) * pitch, -L / 2 + (j + 0.5) * pitch, 0.0),
+                                               radius=0.08, length=0.04, axis=2), medium=au)
+             for i in range(16) for j in range(16)]
+    slab = td.Structure(geometry=td.Box(center=(0, 0, -Lz / 4 - 0.02), size=(td.inf, td.inf, Lz / 2)),
+                        medium=td.Medium(permittivity=2.1))
+    plane = (td.inf, td.inf, 0)
+    sim = td.Simulation(
+        size=(L, L, Lz), grid_spec=td.GridSpec.uniform(dl=dl), run_time=6e-14,
+        structures=[slab] + discs,
+        sources=[td.PlaneWave(center=(0, 0, Lz / 2 - 0.1), size=plane, source_time=pulse, direction="-")],
+        monitors=[td.FluxMonitor(center=(0, 0, Lz / 2 - 0.05), size=plane, freqs=[f0], name="R"),
+                  td.FluxMonitor(center=(0, 0, -Lz / 2 + 0.1), size=plane, freqs=[f0], name="T"),
+                  td.FieldMonitor(center=(0, 0, 0.03), size=(td.inf, 0, 0), freqs=[f0], name="line", fields=["Ex"],
+                                  colocate=False)],
+        boundary_spec=td.BoundarySpec(x=td.Boundary.periodic(), y=td.Boundary.periodic(), z=td.Boundary.pml()),
+        shutoff=1e-4)
+    t0 = time.time()
+    disc = discretize(sim)
+    assert disc.spec.shape == (1024, 1024, 256)
+    t1 = time.time()
+    with HipEngine(disc.spec, lib=hip_lib) as e:
+        st = e.run()
+        raw = e.results()
+    t2 = time.time()
+    sd = assemble(disc, raw, log="")
+    area = L * L
+    R = float(sd["R"].flux.values[0]) / area           # above the one-way source: only the reflected (+z) wave
+    T = -float(sd["T"].flux.values[0]) / area          # transmitted wave travels -z
+    A = 1 - R - T
+    line = sd["line"].Ex.values[:, 0, 0, 0]
+    print(f"\n[config5] setup {t1 - t0:.1f}s solve {t2 - t1:.1f}s ({st.steps_done} steps, "
+          f"{disc.spec.n_cells * st.steps_done / (st.run_ms * 1e-3) / 1e6:.0f} Mcells/s) R={R:.4f} T={T:.4f} A={A:.4f}")
+    assert not st.diverged
+    assert 0.0 < R < 1.0 and 0.0 < T < 1.0 and 0.005 < A < 0.9
+    # 16 periods along x: the line scan repeats every 64 cells
+    per = line[:1024].reshape(16, 64)
+    assert np.max(np.abs(per - per[0])) < 2e-3 * np.max(np.abs(per))
