@@ -38,6 +38,11 @@ def periodic_box(N=(16, 12, 10)):
                                    z=td.Boundary.periodic()))
 
 
+def periodic_box_tall(N=(16, 12, 16)):
+    """Periodic in z with enough planes for two fused z-slabs (lo == hi neighbour pairing)."""
+    return periodic_box(N)
+
+
 def pml_box(N=(16, 12, 10)):
     return _sim(N, td.BoundarySpec(x=td.Boundary.pml(num_layers=4), y=td.Boundary.pml(num_layers=5),
                                    z=td.Boundary.pml(num_layers=3)))
@@ -142,6 +147,7 @@ def au_array(N=(12, 12, 24), dl=0.01):
 CASES = {
     "tfsf_box": tfsf_box, "planewave_periodic": planewave_periodic, "au_array": au_array,
     "pec_box": pec_box, "pec_box_vec": pec_box_vec, "periodic_box": periodic_box,
+    "periodic_box_tall": periodic_box_tall,
     "pml_box": pml_box, "stable_pml_box": stable_pml_box, "media_mix": media_mix,
     "drude_in_pml": drude_in_pml, "nonuniform_grid": nonuniform_grid,
 }

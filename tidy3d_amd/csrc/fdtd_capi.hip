@@ -9,6 +9,7 @@
 #include <cstring>
 #include <string>
 #include <utility>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/fdtd_hip.h"
@@ -114,6 +115,7 @@ struct FdtdSolver {
   int zchunk_f = 16;                 // planes marched per workgroup by the fused sweep
   int rows_f = 7;                    // rows per workgroup of the fused sweep (+1 halo wave = 512 threads)
   int xcd_remap = 1;
+  int fused_multi_mode = 0;          // ghost planes currently follow the fused z-slab protocol
   int rows = 4;
   // RCCL
   ncclComm_t comm = nullptr;
@@ -251,20 +253,26 @@ void launch_e_main(FdtdSolver* h, int kbeg, int kend, hipStream_t st) {
   time_end(h, st);
 }
 
-// fused E+H sweep: reads the current set, writes the other one, then swaps them
-int launch_fused(FdtdSolver* h, hipStream_t st) {
+// fused E+H sweep over the planes [kbeg, kend): reads the current set, writes the other one
+int ensure_second_set(FdtdSolver* h) {
   const GridP& g = h->g;
-  if (!h->fbase2[0]) {
-    const size_t fcount = (size_t)g.sxy * (g.nz + 2);
-    for (int c = 0; c < 6; ++c)
-      if (dev_alloc(h, &h->fbase2[c], fcount)) return -1;
-    h->f2.ex = h->fbase2[0] + g.sxy; h->f2.ey = h->fbase2[1] + g.sxy; h->f2.ez = h->fbase2[2] + g.sxy;
-    h->f2.hx = h->fbase2[3] + g.sxy; h->f2.hy = h->fbase2[4] + g.sxy; h->f2.hz = h->fbase2[5] + g.sxy;
-  }
+  if (h->fbase2[0]) return 0;
+  const size_t fcount = (size_t)g.sxy * (g.nz + 2);
+  for (int c = 0; c < 6; ++c)
+    if (dev_alloc(h, &h->fbase2[c], fcount)) return -1;
+  h->f2.ex = h->fbase2[0] + g.sxy; h->f2.ey = h->fbase2[1] + g.sxy; h->f2.ez = h->fbase2[2] + g.sxy;
+  h->f2.hx = h->fbase2[3] + g.sxy; h->f2.hy = h->fbase2[4] + g.sxy; h->f2.hz = h->fbase2[5] + g.sxy;
+  return 0;
+}
+
+int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st) {
+  if (kend <= kbeg) return 0;
+  const GridP& g = h->g;
+  if (ensure_second_set(h)) return -1;
   const int R = h->rows_f;
   const int zc = h->zchunk_f;
   dim3 block(64, R + 1, 1);
-  const int nbx = (g.nx + 255) / 256, nby = (g.ny + R - 1) / R, nbz = (g.nz + zc - 1) / zc;
+  const int nbx = (g.nx + 255) / 256, nby = (g.ny + R - 1) / R, nbz = (kend - kbeg + zc - 1) / zc;
   const int total = nbx * nby * nbz;
   const int remap = h->xcd_remap ? 1 : 0;
   dim3 grid(remap ? ((total + 7) / 8) * 8 : total, 1, 1);
@@ -274,12 +282,21 @@ int launch_fused(FdtdSolver* h, hipStream_t st) {
   StepP s = step_params(h);
   time_begin(h, 2, st);
   if (h->mat[0])
-    hipLaunchKernelGGL((fused_step_kernel<true>), grid, block, shmem, st, g, h->f, h->f2, s, m, 0, g.nz, zc, pmc, nbx, nby, nbz, remap);
+    hipLaunchKernelGGL((fused_step_kernel<true>), grid, block, shmem, st, g, h->f, h->f2, s, m, kbeg, kend, zc, pmc, nbx, nby, nbz, remap);
   else
-    hipLaunchKernelGGL((fused_step_kernel<false>), grid, block, shmem, st, g, h->f, h->f2, s, m, 0, g.nz, zc, pmc, nbx, nby, nbz, remap);
+    hipLaunchKernelGGL((fused_step_kernel<false>), grid, block, shmem, st, g, h->f, h->f2, s, m, kbeg, kend, zc, pmc, nbx, nby, nbz, remap);
   time_end(h, st);
+  return 0;
+}
+
+void swap_sets(FdtdSolver* h) {
   std::swap(h->f, h->f2);
   for (int c = 0; c < 6; ++c) std::swap(h->fbase[c], h->fbase2[c]);
+}
+
+int launch_fused(FdtdSolver* h, hipStream_t st) {
+  if (launch_fused_range(h, 0, h->g.nz, st)) return -1;
+  swap_sets(h);
   return 0;
 }
 
@@ -435,6 +452,54 @@ int exchange(FdtdSolver* h, bool e_side, hipStream_t st) {
       NCCLCHK(h, ncclRecv(h->f.ex + (long long)nz * pc, pc, ncclFloat, hi, h->comm, st));
       NCCLCHK(h, ncclRecv(h->f.ey + (long long)nz * pc, pc, ncclFloat, hi, h->comm, st));
     }
+  }
+  NCCLCHK(h, ncclGroupEnd());
+  return 0;
+}
+
+// Fused sweep on z-slabs: the chunk prologue recomputes H^{n+1/2}[-1] from E^n[-1] (all three
+// components) and the corrected H^{n-1/2}_{x,y}[-1]; the top plane needs E^n_{x,y}[nz].
+//   exchange_fused_h : corrected H_x,H_y of my top plane  -> upper neighbour's ghost(-1)
+//   exchange_fused_e : E_x,E_y,E_z of my top plane -> upper ghost(-1); E_x,E_y of my bottom plane
+//                      -> lower neighbour's ghost(nz)
+int exchange_fused_h(FdtdSolver* h, hipStream_t st) {
+  const long long pc = plane_cells(h);
+  const int nz = h->g.nz;
+  const bool has_lo = h->cfg.bc[4] == FDTD_BC_NEIGHBOR, has_hi = h->cfg.bc[5] == FDTD_BC_NEIGHBOR;
+  const int lo = (h->rank - 1 + h->n_ranks) % h->n_ranks, hi = (h->rank + 1) % h->n_ranks;
+  NCCLCHK(h, ncclGroupStart());
+  if (has_hi) {
+    NCCLCHK(h, ncclSend(h->f.hx + (long long)(nz - 1) * pc, pc, ncclFloat, hi, h->comm, st));
+    NCCLCHK(h, ncclSend(h->f.hy + (long long)(nz - 1) * pc, pc, ncclFloat, hi, h->comm, st));
+  }
+  if (has_lo) {
+    NCCLCHK(h, ncclRecv(h->f.hx - pc, pc, ncclFloat, lo, h->comm, st));
+    NCCLCHK(h, ncclRecv(h->f.hy - pc, pc, ncclFloat, lo, h->comm, st));
+  }
+  NCCLCHK(h, ncclGroupEnd());
+  return 0;
+}
+
+int exchange_fused_e(FdtdSolver* h, hipStream_t st) {
+  const long long pc = plane_cells(h);
+  const int nz = h->g.nz;
+  const bool has_lo = h->cfg.bc[4] == FDTD_BC_NEIGHBOR, has_hi = h->cfg.bc[5] == FDTD_BC_NEIGHBOR;
+  const int lo = (h->rank - 1 + h->n_ranks) % h->n_ranks, hi = (h->rank + 1) % h->n_ranks;
+  float* e3[3] = {h->f.ex, h->f.ey, h->f.ez};
+  // RCCL pairs the k-th send to a peer with the k-th receive from it: when lo == hi (one or two
+  // ranks, periodic z) the posting order below must mirror the peer's: [to-hi sends][to-lo sends]
+  // on the sending side <-> [from-lo receives][from-hi receives] on the receiving side.
+  NCCLCHK(h, ncclGroupStart());
+  if (has_hi)
+    for (float* p : e3) NCCLCHK(h, ncclSend(p + (long long)(nz - 1) * pc, pc, ncclFloat, hi, h->comm, st));
+  if (has_lo) {
+    NCCLCHK(h, ncclSend(h->f.ex, pc, ncclFloat, lo, h->comm, st));
+    NCCLCHK(h, ncclSend(h->f.ey, pc, ncclFloat, lo, h->comm, st));
+    for (float* p : e3) NCCLCHK(h, ncclRecv(p - pc, pc, ncclFloat, lo, h->comm, st));
+  }
+  if (has_hi) {
+    NCCLCHK(h, ncclRecv(h->f.ex + (long long)nz * pc, pc, ncclFloat, hi, h->comm, st));
+    NCCLCHK(h, ncclRecv(h->f.ey + (long long)nz * pc, pc, ncclFloat, hi, h->comm, st));
   }
   NCCLCHK(h, ncclGroupEnd());
   return 0;
@@ -793,6 +858,7 @@ int fdtd_set_field(FdtdSolver* h, int comp, const float* host, size_t bytes) {
   // keep single-slab ghost planes consistent with the new interior
   if (h->comm == nullptr) { fill_ghost_h(h, h->stream); fill_ghost_e(h, h->stream); fill_ghost_fused(h, h->stream); HIPCHK(h, hipStreamSynchronize(h->stream)); }
   else if (comp == 0 || comp == 1 || comp == 3 || comp == 4) {
+    h->fused_multi_mode = 0;      // the next fdtd_run re-establishes the fused ghost protocol if it uses it
     // with a communicator the ghost planes come from the neighbour: do one exchange now
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (exchange(h, comp < 3, h->comm_stream)) return -1;
@@ -879,9 +945,23 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   HIPCHK(h, hipEventRecord(h->ev0, st));
   if (multi && (nb_lo || nb_hi) && nz < 2) return fail(h, "fdtd_run: a z-slab needs at least 2 planes");
   // the fused sweep is the default single-GPU path whenever rows are float4-aligned
-  const bool fused = !multi && (h->g.nx % 4 == 0) &&
-                     (h->cfg.variant == FDTD_VARIANT_FUSED || h->cfg.variant == FDTD_VARIANT_AUTO) &&
-                     h->rows_f <= 15;
+  const bool fused_ok = (h->g.nx % 4 == 0) && h->rows_f <= 15 &&
+                        (h->cfg.variant == FDTD_VARIANT_FUSED || h->cfg.variant == FDTD_VARIANT_AUTO);
+  const bool fused = !multi && fused_ok;
+  // with a communicator every rank must take the same path: the fused z-slab schedule runs only on
+  // explicit request (the host decides for all ranks, tidy3d_amd/engine.py), AUTO = two-pass
+  if (multi && h->cfg.variant == FDTD_VARIANT_FUSED && !(fused_ok && nz >= 4))
+    return fail(h, "fdtd_run: the fused z-slab schedule needs nx %% 4 == 0 and >= 4 planes per slab");
+  const bool fused_multi = multi && h->cfg.variant == FDTD_VARIANT_FUSED;
+  if (fused_multi != (h->fused_multi_mode != 0)) {
+    // ghost planes were prepared for the other scheme (fdtd_set_field): refresh them
+    h->fused_multi_mode = fused_multi ? 1 : 0;
+    if (fused_multi) {
+      HIPCHK(h, hipStreamSynchronize(st));
+      if (exchange_fused_e(h, cs)) return -1;
+      HIPCHK(h, hipStreamSynchronize(cs));
+    }
+  }
   // Two-stream schedule of one step (st = main stream, cs = comm stream):
   //   cs: [H top plane] -> send/recv H -> [E bottom plane] -> send/recv E      (boundary planes first)
   //   st: [H interior ] ----------------> [E interior    ]
@@ -901,7 +981,34 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
     }
     if (rec) record_monitors(h, n, false, st);
-    if (fused) {
+    if (fused_multi) {
+      // Two streams, no host sync.  cs: [E exchange of step n-1] -> H exchange -> bottom + top chunks;
+      // st: H pre-corrections -> interior chunks -> (join) -> E post-corrections.
+      const int zb = std::max(1, std::min(h->zchunk_f, nz / 4));
+      launch_pml(h, false, 0, nz, st);
+      launch_sources(h, false, n, 0, nz, st);
+      advance_tfsf_aux(h, false, n, st);
+      HIPCHK(h, hipEventRecord(h->ev_h_int, st));                 // pre-corrections done
+      HIPCHK(h, hipStreamWaitEvent(cs, h->ev_h_int, 0));
+      if (exchange_fused_h(h, cs)) return -1;                     // (in order after the last E exchange)
+      if (ensure_second_set(h)) return -1;
+      if (launch_fused_range(h, 0, zb, cs)) return -1;            // needs ghost(-1): E (last exchange), H (just now)
+      if (launch_fused_range(h, nz - zb, nz, cs)) return -1;      // needs ghost(nz) E (last exchange)
+      HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
+      if (launch_fused_range(h, zb, nz - zb, st)) return -1;      // interior: no ghost planes involved
+      HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
+      swap_sets(h);
+      if (rec) record_monitors(h, n, true, st);
+      launch_pml(h, true, 0, nz, st);
+      launch_sources(h, true, n, 0, nz, st);
+      launch_ade(h, 0, nz, st);
+      advance_tfsf_aux(h, true, n, st);
+      HIPCHK(h, hipEventRecord(h->ev_e_int, st));                 // E^{n+1} final
+      HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
+      if (exchange_fused_e(h, cs)) return -1;                     // overlaps the next step's pre-corrections + interior
+      HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
+      h->step = n + 1;
+    } else if (fused) {
       // H-side corrections are additive: pre-apply them to H^{n-1/2}; E-side ones follow the sweep
       launch_pml(h, false, 0, nz, st);
       launch_sources(h, false, n, 0, nz, st);

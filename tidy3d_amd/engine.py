@@ -89,6 +89,12 @@ class HipEngine:
                 bc[5] = L.BC_NEIGHBOR
         for i, b in enumerate(bc):
             cfg.bc[i] = int(b)
+        if (n_ranks > 1 or force_comm) and variant in (L.VARIANT_AUTO, L.VARIANT_FUSED):
+            # every rank takes the same decision (split_slabs is deterministic): fused z-slab schedule
+            # iff float4-aligned rows, >= 4 planes in every slab and no slab cut inside the z-PML
+            ok = (nx % 4 == 0 and min(b - a for a, b in split_slabs(nz, n_ranks)) >= 4
+                  and self._fused_slabs_ok(spec, n_ranks))
+            variant = L.VARIANT_FUSED if ok else L.VARIANT_ZMARCH
         cfg.device, cfg.variant, cfg.flags, cfg.z_chunk = device, variant, flags, z_chunk
         cfg.ch = float(h_coeff(spec.dt))
         st = d.fdtd_create(C.byref(cfg), C.byref(self.handle))
@@ -99,6 +105,18 @@ class HipEngine:
         except Exception:
             self.close()
             raise
+
+    @staticmethod
+    def _fused_slabs_ok(spec: SolverSpec, n_ranks: int) -> bool:
+        """The fused sweep keeps H^{n+1/2} of the plane below a slab in registers only, so the E-side
+        CPML correction of a slab's first plane (which differentiates H along z) cannot be formed
+        for it: z-slab cuts must fall outside the z-PML.  Otherwise the two-pass kernels are used."""
+        nz = spec.shape[2]
+        n_lo, n_hi = spec.pml[2][0].num_layers, spec.pml[2][1].num_layers
+        cuts = [z0 for z0, _ in split_slabs(nz, n_ranks)][1:]
+        if spec.bc[2][0] == BC_PERIODIC and n_ranks >= 1:
+            cuts = cuts + [0]
+        return all(n_lo <= z <= nz - n_hi for z in cuts) or (n_lo == 0 and n_hi == 0)
 
     # ------------------------------------------------------------------ setup
     def _chk(self, st, what):
