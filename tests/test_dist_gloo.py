@@ -32,7 +32,7 @@ def test_split_slabs():
 @pytest.mark.parametrize("world,case", [(2, "media_mix"), (2, "pml_box"), (3, "periodic_box"), (2, "drude_in_pml"),
                                         (2, "periodic_box_tall"), (4, "periodic_box_tall"), (2, "planewave_periodic")])
 def test_two_rank_run_matches_single_slab(world, case, emu_lib, tmp_path):
-    n_steps = 30
+    n_steps = 60 if case == "planewave_periodic" else 30     # let the injected wave reach the monitors
     out = str(tmp_path / "dist.npz")
     _launch(world, case, n_steps, out, 29511 + world + len(case))
     got = np.load(out)
