@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--n", type=int, default=512, help="cells per axis")
+    ap.add_argument("--size", "--n", dest="n", type=int, default=512, help="cells per axis")
     ap.add_argument("--workload", default="v0", choices=["v0", "v1", "v2", "v3"])
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--zchunk", type=int, default=0)
@@ -106,6 +106,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("BENCH_SINGLE_DEVICE"):      # debugging aid: several ranks on one GPU
+        local_rank = 0
     if world > 1:
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))

@@ -90,7 +90,7 @@ struct FdtdSolver {
   float* step_base[2] = {};          // 1/primal_z, 1/dual_z with one ghost entry on each side
   size_t field_bytes = 0;
   float *ip[3] = {}, *idl[3] = {};
-  uint8_t* mat[3] = {};
+  uint32_t* mat4 = nullptr;          // packed material words (interior plane 0), nullptr = uniform
   float2* lut = nullptr;
   int n_media = 0;
   float ca1 = 1.f, cb1 = 0.f;
@@ -190,7 +190,7 @@ StepP step_params(const FdtdSolver* h) {
 
 MatP mat_params(const FdtdSolver* h) {
   MatP m;
-  m.mx = h->mat[0]; m.my = h->mat[1]; m.mz = h->mat[2];
+  m.m4 = h->mat4;
   m.lut = h->lut; m.n_media = h->n_media; m.ca1 = h->ca1; m.cb1 = h->cb1;
   return m;
 }
@@ -235,7 +235,7 @@ void launch_e_main(FdtdSolver* h, int kbeg, int kend, hipStream_t st) {
   const bool vec = (g.nx % 4 == 0) && h->cfg.variant != FDTD_VARIANT_SIMPLE;
   const int V = vec ? 4 : 1;
   const int zc = (h->cfg.variant == FDTD_VARIANT_SIMPLE) ? 1 : h->zchunk;
-  const bool has_mat = h->mat[0] != nullptr;
+  const bool has_mat = h->mat4 != nullptr;
   const int rows = h->rows;                             // <= 8: __launch_bounds__(512)
   dim3 block(64, rows, 1);
   dim3 grid((g.nx + 64 * V - 1) / (64 * V), (g.ny + rows - 1) / rows, (kend - kbeg + zc - 1) / zc);
@@ -281,7 +281,7 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st) {
   MatP m = mat_params(h);
   StepP s = step_params(h);
   time_begin(h, 2, st);
-  if (h->mat[0])
+  if (h->mat4)
     hipLaunchKernelGGL((fused_step_kernel<true>), grid, block, shmem, st, g, h->f, h->f2, s, m, kbeg, kend, zc, pmc, nbx, nby, nbz, remap);
   else
     hipLaunchKernelGGL((fused_step_kernel<false>), grid, block, shmem, st, g, h->f, h->f2, s, m, kbeg, kend, zc, pmc, nbx, nby, nbz, remap);
@@ -343,8 +343,8 @@ void launch_pml(FdtdSolver* h, bool e_side, int kbeg, int kend, hipStream_t st) 
         hipLaunchKernelGGL(pml_e_kernel, dim3(nblk(total)), dim3(256), 0, st, g, sl, field_ptr(h, c1),
                            field_ptr(h, c2), (const float*)field_ptr(h, 3 + c1), (const float*)field_ptr(h, 3 + c2),
                            P.psi_e[0], P.psi_e[1], (const float*)P.kinv_e, (const float*)P.b_e,
-                           (const float*)P.c_e, (const float*)h->idl[a], (const uint8_t*)h->mat[c1],
-                           (const uint8_t*)h->mat[c2], (const float2*)h->lut, h->cb1);
+                           (const float*)P.c_e, (const float*)h->idl[a], (const uint32_t*)h->mat4,
+                           (const float2*)h->lut, h->cb1);
       else
         hipLaunchKernelGGL(pml_h_kernel, dim3(nblk(total)), dim3(256), 0, st, g, sl, field_ptr(h, 3 + c1),
                            field_ptr(h, 3 + c2), (const float*)field_ptr(h, c1), (const float*)field_ptr(h, c2),
@@ -687,13 +687,13 @@ int fdtd_set_material(FdtdSolver* h, const uint8_t* mat, size_t bytes) {
   if (h->n_media == 0) return fail(h, "fdtd_set_material: call fdtd_set_media first");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   const size_t fcount = (size_t)h->g.sxy * (h->g.nz + 2);
-  for (int c = 0; c < 3; ++c) {
-    uint8_t* base = nullptr;
-    if (dev_alloc(h, &base, fcount, false)) return -1;
-    HIPCHK(h, hipMemset(base, 1, fcount));
-    h->mat[c] = base + h->g.sxy;
-    HIPCHK(h, hipMemcpy(h->mat[c], mat + c * nc, nc, hipMemcpyHostToDevice));
-  }
+  std::vector<uint32_t> packed(fcount, 0x00010101u);          // ghost planes: background medium
+  uint32_t* dst = packed.data() + h->g.sxy;
+  for (size_t i = 0; i < nc; ++i)
+    dst[i] = (uint32_t)mat[i] | ((uint32_t)mat[nc + i] << 8) | ((uint32_t)mat[2 * nc + i] << 16);
+  uint32_t* base = nullptr;
+  if (dev_upload(h, &base, (const uint32_t*)packed.data(), fcount)) return -1;
+  h->mat4 = base + h->g.sxy;
   return 0;
 }
 

@@ -40,7 +40,7 @@ struct StepP {
 };
 
 struct MatP {
-  const uint8_t* mx; const uint8_t* my; const uint8_t* mz;  // material index per E component
+  const uint32_t* m4;             // packed material indices, one word per cell: byte c = index of E_c
   const float2* lut;                                        // (ca, cb) per medium
   int n_media;
   float ca1, cb1;                                           // uniform medium (entry 1)
@@ -69,11 +69,13 @@ __device__ __forceinline__ void stv(float* __restrict__ p, const float (&r)[V]) 
   }
 }
 
+// packed material words of V consecutive cells: ONE 16-byte load per thread (V = 4) instead of
+// three 4-byte ones
 template <int V>
-__device__ __forceinline__ void ldm(int (&m)[V], const uint8_t* __restrict__ p) {
+__device__ __forceinline__ void ldm(uint32_t (&m)[V], const uint32_t* __restrict__ p) {
   if constexpr (V == 4) {
-    const uint32_t t = *reinterpret_cast<const uint32_t*>(p);
-    m[0] = t & 255u; m[1] = (t >> 8) & 255u; m[2] = (t >> 16) & 255u; m[3] = t >> 24;
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    m[0] = t.x; m[1] = t.y; m[2] = t.z; m[3] = t.w;
   } else {
 #pragma unroll
     for (int e = 0; e < V; ++e) m[e] = p[e];
@@ -249,16 +251,15 @@ __global__ __launch_bounds__(512) void e_update_kernel(GridP g, FieldP f, StepP 
     if (act) {
       float cax[V], cbx[V], cay[V], cby[V], caz[V], cbz[V];
       if constexpr (MAT) {
-        int mi[V];
-        ldm<V>(mi, m.mx + p);
+        uint32_t mw[V];
+        ldm<V>(mw, m.m4 + p);
 #pragma unroll
-        for (int e = 0; e < V; ++e) { const float2 c = lut_s[mi[e]]; cax[e] = c.x; cbx[e] = c.y; }
-        ldm<V>(mi, m.my + p);
-#pragma unroll
-        for (int e = 0; e < V; ++e) { const float2 c = lut_s[mi[e]]; cay[e] = c.x; cby[e] = c.y; }
-        ldm<V>(mi, m.mz + p);
-#pragma unroll
-        for (int e = 0; e < V; ++e) { const float2 c = lut_s[mi[e]]; caz[e] = c.x; cbz[e] = c.y; }
+        for (int e = 0; e < V; ++e) {
+          const float2 c0 = lut_s[mw[e] & 255u];
+          const float2 c1 = lut_s[(mw[e] >> 8) & 255u];
+          const float2 c2 = lut_s[(mw[e] >> 16) & 255u];
+          cax[e] = c0.x; cbx[e] = c0.y; cay[e] = c1.x; cby[e] = c1.y; caz[e] = c2.x; cbz[e] = c2.y;
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < V; ++e) {
@@ -488,16 +489,15 @@ __global__ __launch_bounds__(1024) void fused_step_kernel(GridP g, FieldP a, Fie
       }
       float cax[V], cbx[V], cay[V], cby[V], caz[V], cbz[V];
       if constexpr (MAT) {
-        int mi[V];
-        ldm<V>(mi, m.mx + p);
+        uint32_t mw[V];
+        ldm<V>(mw, m.m4 + p);
 #pragma unroll
-        for (int e = 0; e < V; ++e) { const float2 c = lut_s[mi[e]]; cax[e] = c.x; cbx[e] = c.y; }
-        ldm<V>(mi, m.my + p);
-#pragma unroll
-        for (int e = 0; e < V; ++e) { const float2 c = lut_s[mi[e]]; cay[e] = c.x; cby[e] = c.y; }
-        ldm<V>(mi, m.mz + p);
-#pragma unroll
-        for (int e = 0; e < V; ++e) { const float2 c = lut_s[mi[e]]; caz[e] = c.x; cbz[e] = c.y; }
+        for (int e = 0; e < V; ++e) {
+          const float2 c0 = lut_s[mw[e] & 255u];
+          const float2 c1 = lut_s[(mw[e] >> 8) & 255u];
+          const float2 c2 = lut_s[(mw[e] >> 16) & 255u];
+          cax[e] = c0.x; cbx[e] = c0.y; cay[e] = c1.x; cby[e] = c1.y; caz[e] = c2.x; cbz[e] = c2.y;
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < V; ++e) {
@@ -558,7 +558,7 @@ __device__ __forceinline__ long long psi_index(const GridP& g, const SlabP& sl, 
 __global__ __launch_bounds__(256) void pml_e_kernel(GridP g, SlabP sl, float* e1, float* e2, const float* h1,
                                                      const float* h2, float* psi1, float* psi2,
                                                      const float* kinv, const float* bb, const float* cc,
-                                                     const float* idl, const uint8_t* m1, const uint8_t* m2,
+                                                     const float* idl, const uint32_t* m4,
                                                      const float2* lut, float cb_uniform) {
   const int bx = (sl.a == 0) ? sl.s_n : g.nx;
   const int by = (sl.a == 1) ? sl.s_n : g.ny;
@@ -596,8 +596,9 @@ __global__ __launch_bounds__(256) void pml_e_kernel(GridP g, SlabP sl, float* e1
   const float p2 = b * psi2[q] + c * d1;     // psi of E_{a+2} follows d(H_{a+1})/da
   psi1[q] = p1;
   psi2[q] = p2;
-  const float cb1 = m1 ? lut[m1[p]].y : cb_uniform;
-  const float cb2 = m2 ? lut[m2[p]].y : cb_uniform;
+  const uint32_t mw = m4 ? m4[p] : 0u;
+  const float cb1 = m4 ? lut[(mw >> (8 * c1)) & 255u].y : cb_uniform;
+  const float cb2 = m4 ? lut[(mw >> (8 * c2)) & 255u].y : cb_uniform;
   // PEC walls of the other transverse axis
   const bool w1 = (idx3[c2] == 0) && (bc0[c2] == BC_PEC);   // E_{c1} is tangential to the c2-wall
   const bool w2 = (idx3[c1] == 0) && (bc0[c1] == BC_PEC);
