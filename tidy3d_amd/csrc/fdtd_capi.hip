@@ -113,8 +113,10 @@ struct FdtdSolver {
   FdtdStats stats{};
   int zchunk = 2;
   int zchunk_f = 16;                 // planes marched per workgroup by the fused sweep
-  int rows_f = 7;                    // rows per workgroup of the fused sweep (+1 halo wave = 512 threads)
+  int rows_f = 3;                    // rows per workgroup of the fused sweep (+1 halo wave = 256 threads:
+                                     // ~150 VGPRs without spills, 3 workgroups per CU; measured best, profiles/r01g)
   int xcd_remap = 1;
+  int fused_lb = 0;                  // 0 = by workgroup size, else forced __launch_bounds__ variant
   int fused_multi_mode = 0;          // ghost planes currently follow the fused z-slab protocol
   int rows = 4;
   // RCCL
@@ -280,11 +282,20 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st) {
   const int pmc = h->cfg.bc[4] == FDTD_BC_PMC;
   MatP m = mat_params(h);
   StepP s = step_params(h);
+  // register budget follows the workgroup size: __launch_bounds__ of 256 / 512 / 1024 threads
+  const int threads = 64 * (R + 1);
+  int lb = h->fused_lb ? h->fused_lb : (threads <= 256 ? 256 : (threads <= 512 ? 512 : 1024));
+  if (lb < threads) lb = threads <= 512 ? 512 : 1024;
   time_begin(h, 2, st);
-  if (h->mat4)
-    hipLaunchKernelGGL((fused_step_kernel<true>), grid, block, shmem, st, g, h->f, h->f2, s, m, kbeg, kend, zc, pmc, nbx, nby, nbz, remap);
-  else
-    hipLaunchKernelGGL((fused_step_kernel<false>), grid, block, shmem, st, g, h->f, h->f2, s, m, kbeg, kend, zc, pmc, nbx, nby, nbz, remap);
+#define FDTD_LAUNCH_FUSED(MATV, LBV)                                                                  \
+  hipLaunchKernelGGL((fused_step_kernel<MATV, LBV>), grid, block, shmem, st, g, h->f, h->f2, s, m, kbeg, \
+                     kend, zc, pmc, nbx, nby, nbz, remap)
+  if (h->mat4) {
+    if (lb == 256) FDTD_LAUNCH_FUSED(true, 256); else if (lb == 512) FDTD_LAUNCH_FUSED(true, 512); else FDTD_LAUNCH_FUSED(true, 1024);
+  } else {
+    if (lb == 256) FDTD_LAUNCH_FUSED(false, 256); else if (lb == 512) FDTD_LAUNCH_FUSED(false, 512); else FDTD_LAUNCH_FUSED(false, 1024);
+  }
+#undef FDTD_LAUNCH_FUSED
   time_end(h, st);
   return 0;
 }
@@ -1140,6 +1151,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_ZCHUNK: if (value < 1) break; h->zchunk = value; h->zchunk_f = value; return 0;
     case FDTD_OPT_ROWS: if (value < 1 || value > 15) break; h->rows = value > 8 ? 8 : value; h->rows_f = value; return 0;
     case FDTD_OPT_XCD_REMAP: h->xcd_remap = value != 0; return 0;
+    case FDTD_OPT_FUSED_LB: if (value != 0 && value != 256 && value != 512 && value != 1024) break; h->fused_lb = value; return 0;
     default: break;
   }
   return fail(h, "fdtd_set_option: bad key/value %d/%d", key, value);

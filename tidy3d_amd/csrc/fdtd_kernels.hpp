@@ -304,8 +304,8 @@ __global__ __launch_bounds__(512) void e_update_kernel(GridP g, FieldP f, StepP 
 //     slot, one barrier per plane) and at z-1 (registers carried from the previous plane; the
 //     first plane of a chunk recomputes H^{n+1/2}[k0-1] in a prologue).
 // =============================================================================================
-template <bool MAT>
-__global__ __launch_bounds__(1024) void fused_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
+template <bool MAT, int LB>
+__global__ __launch_bounds__(LB) void fused_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
                                                           int kbeg, int kend, int zchunk, int pmc_z0,
                                                           int nbx, int nby, int nbz, int xcd_remap) {
   constexpr int V = 4;
