@@ -350,7 +350,19 @@ void launch_pml(FdtdSolver* h, bool e_side, int kbeg, int kend, hipStream_t st) 
       const long long bx = (a == 0) ? s_n : g.nx, by = (a == 1) ? s_n : g.ny;
       const long long total = bx * by * (sl.kend - sl.kbeg);
       if (total <= 0) continue;
-      if (e_side)
+      const bool vec4 = (a != 0) && (g.nx % 4 == 0);      // y / z slabs: float4 along x
+      if (vec4 && e_side)
+        hipLaunchKernelGGL(pml_e4_kernel, dim3(nblk(total / 4)), dim3(256), 0, st, g, sl, field_ptr(h, c1),
+                           field_ptr(h, c2), (const float*)field_ptr(h, 3 + c1), (const float*)field_ptr(h, 3 + c2),
+                           P.psi_e[0], P.psi_e[1], (const float*)P.kinv_e, (const float*)P.b_e,
+                           (const float*)P.c_e, (const float*)h->idl[a], (const uint32_t*)h->mat4,
+                           (const float2*)h->lut, h->cb1);
+      else if (vec4)
+        hipLaunchKernelGGL(pml_h4_kernel, dim3(nblk(total / 4)), dim3(256), 0, st, g, sl, field_ptr(h, 3 + c1),
+                           field_ptr(h, 3 + c2), (const float*)field_ptr(h, c1), (const float*)field_ptr(h, c2),
+                           P.psi_h[0], P.psi_h[1], (const float*)P.kinv_h, (const float*)P.b_h,
+                           (const float*)P.c_h, (const float*)h->ip[a]);
+      else if (e_side)
         hipLaunchKernelGGL(pml_e_kernel, dim3(nblk(total)), dim3(256), 0, st, g, sl, field_ptr(h, c1),
                            field_ptr(h, c2), (const float*)field_ptr(h, 3 + c1), (const float*)field_ptr(h, 3 + c2),
                            P.psi_e[0], P.psi_e[1], (const float*)P.kinv_e, (const float*)P.b_e,

@@ -649,6 +649,135 @@ __global__ __launch_bounds__(256) void pml_h_kernel(GridP g, SlabP sl, float* h1
   h2[p] -= g.ch * (kv * d1 + p2);
 }
 
+// float4 versions for the y and z slabs (rows are contiguous along x): one thread = 4 cells, same
+// per-element arithmetic as the scalar kernels above.
+__global__ __launch_bounds__(256) void pml_e4_kernel(GridP g, SlabP sl, float* e1, float* e2, const float* h1,
+                                                      const float* h2, float* psi1, float* psi2,
+                                                      const float* kinv, const float* bb, const float* cc,
+                                                      const float* idl, const uint32_t* m4,
+                                                      const float2* lut, float cb_uniform) {
+  constexpr int V = 4;
+  const int bx = g.nx / V;
+  const int by = (sl.a == 1) ? sl.s_n : g.ny;
+  const int bz = sl.kend - sl.kbeg;
+  const long long total = (long long)bx * by * bz;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int i0 = (int)(t % bx) * V;
+  const int ly = (int)((t / bx) % by);
+  const int lz = (int)(t / ((long long)bx * by));
+  const int j = (sl.a == 1) ? sl.s_lo + ly : ly;
+  const int k = sl.kbeg + lz;
+  const int ia = (sl.a == 1) ? j : k;
+  const int c1 = (sl.a + 1) % 3, c2 = (sl.a + 2) % 3;
+  const int bcz0 = g.pec_z0 ? BC_PEC : BC_NEIGHBOR;
+  const long long stride = (sl.a == 1) ? (long long)g.nx : g.sxy;
+  const long long p = (long long)k * g.sxy + (long long)j * g.nx + i0;
+  float a1[V], a2[V], b1[V], b2[V];
+  ldv<V>(a1, h1 + p);
+  ldv<V>(a2, h2 + p);
+  float s1 = 1.f;          // derivative = (a - s * b) * idl  with b the lower neighbour
+  if (ia == 0 && sl.a == 1) {
+    if (g.bcy0 == BC_PEC) return;
+    if (g.bcy0 == BC_PMC) { for (int e = 0; e < V; ++e) { b1[e] = a1[e]; b2[e] = a2[e]; } s1 = -1.f; }
+    else { ldv<V>(b1, h1 + p + (long long)(g.ny - 1) * stride); ldv<V>(b2, h2 + p + (long long)(g.ny - 1) * stride); }
+  } else {
+    if (ia == 0 && g.pec_z0) return;
+    ldv<V>(b1, h1 + p - stride);
+    ldv<V>(b2, h2 + p - stride);
+  }
+  const int si = sl.psi_base + (ia - sl.s_lo);
+  const long long q = psi_index(g, sl, i0, j, k, si);
+  const float kv = kinv[ia] - 1.f, b = bb[ia], c = cc[ia], w = idl[ia];
+  float q1[V], q2[V], x1[V], x2[V];
+  ldv<V>(q1, psi1 + q);
+  ldv<V>(q2, psi2 + q);
+  ldv<V>(x1, e1 + p);
+  ldv<V>(x2, e2 + p);
+  uint32_t mw[V] = {0u, 0u, 0u, 0u};
+  if (m4) ldm<V>(mw, m4 + p);
+  // E_{c1} is tangential to the c2-wall, E_{c2} to the c1-wall; along x only element i == 0 can sit on it
+  const int jk[3] = {0, j, k};
+  const int bc0[3] = {g.bcx0, g.bcy0, bcz0};
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    const float d1 = (s1 > 0.f) ? (a1[e] - b1[e]) * w : 2.f * a1[e] * w;
+    const float d2 = (s1 > 0.f) ? (a2[e] - b2[e]) * w : 2.f * a2[e] * w;
+    const float p1 = b * q1[e] + c * d2;
+    const float p2 = b * q2[e] + c * d1;
+    q1[e] = p1;
+    q2[e] = p2;
+    const float cb1 = m4 ? lut[(mw[e] >> (8 * c1)) & 255u].y : cb_uniform;
+    const float cb2 = m4 ? lut[(mw[e] >> (8 * c2)) & 255u].y : cb_uniform;
+    const int i3c2 = (c2 == 0) ? i0 + e : jk[c2];
+    const int i3c1 = (c1 == 0) ? i0 + e : jk[c1];
+    const bool w1 = (i3c2 == 0) && (bc0[c2] == BC_PEC);
+    const bool w2 = (i3c1 == 0) && (bc0[c1] == BC_PEC);
+    if (!w1) x1[e] -= cb1 * (kv * d2 + p1);
+    if (!w2) x2[e] += cb2 * (kv * d1 + p2);
+  }
+  stv<V>(psi1 + q, q1);
+  stv<V>(psi2 + q, q2);
+  stv<V>(e1 + p, x1);
+  stv<V>(e2 + p, x2);
+}
+
+__global__ __launch_bounds__(256) void pml_h4_kernel(GridP g, SlabP sl, float* h1, float* h2, const float* e1,
+                                                      const float* e2, float* psi1, float* psi2,
+                                                      const float* kinv, const float* bb, const float* cc,
+                                                      const float* ipl) {
+  constexpr int V = 4;
+  const int bx = g.nx / V;
+  const int by = (sl.a == 1) ? sl.s_n : g.ny;
+  const int bz = sl.kend - sl.kbeg;
+  const long long total = (long long)bx * by * bz;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int i0 = (int)(t % bx) * V;
+  const int ly = (int)((t / bx) % by);
+  const int lz = (int)(t / ((long long)bx * by));
+  const int j = (sl.a == 1) ? sl.s_lo + ly : ly;
+  const int k = sl.kbeg + lz;
+  const int ia = (sl.a == 1) ? j : k;
+  const long long stride = (sl.a == 1) ? (long long)g.nx : g.sxy;
+  const long long p = (long long)k * g.sxy + (long long)j * g.nx + i0;
+  float n1[V], n2[V], c1v[V], c2v[V];
+  if (ia == g.ny - 1 && sl.a == 1) {
+    if (g.bcy1 == BC_PERIODIC) {
+      ldv<V>(n1, e1 + p - (long long)(g.ny - 1) * stride);
+      ldv<V>(n2, e2 + p - (long long)(g.ny - 1) * stride);
+    } else { zero<V>(n1); zero<V>(n2); }
+  } else {
+    ldv<V>(n1, e1 + p + stride);
+    ldv<V>(n2, e2 + p + stride);
+  }
+  ldv<V>(c1v, e1 + p);
+  ldv<V>(c2v, e2 + p);
+  const int si = sl.psi_base + (ia - sl.s_lo);
+  const long long q = psi_index(g, sl, i0, j, k, si);
+  const float kv = kinv[ia] - 1.f, b = bb[ia], c = cc[ia], w = ipl[ia];
+  float q1[V], q2[V], x1[V], x2[V];
+  ldv<V>(q1, psi1 + q);
+  ldv<V>(q2, psi2 + q);
+  ldv<V>(x1, h1 + p);
+  ldv<V>(x2, h2 + p);
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    const float d1 = (n1[e] - c1v[e]) * w;
+    const float d2 = (n2[e] - c2v[e]) * w;
+    const float p1 = b * q1[e] + c * d2;
+    const float p2 = b * q2[e] + c * d1;
+    q1[e] = p1;
+    q2[e] = p2;
+    x1[e] += g.ch * (kv * d2 + p1);
+    x2[e] -= g.ch * (kv * d1 + p2);
+  }
+  stv<V>(psi1 + q, q1);
+  stv<V>(psi2 + q, q2);
+  stv<V>(h1 + p, x1);
+  stv<V>(h2 + p, x2);
+}
+
 // =============================================================================================
 // K4  ADE (pole-residue) post-update on the compact list of dispersive cells of one component
 //     and one medium:  E <- E* - cc * S(Q),  Q <- kap Q + bet (E_new + E_old)
