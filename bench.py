@@ -65,8 +65,9 @@ def build_spec(n: int, n_steps: int, workload: str):
     return disc.spec
 
 
-def cpu_baseline(n: int = 160, steps: int = 6):
-    """Naive NumPy curl loop (oracle, fp32 arrays) on a bounded sample of the same workload."""
+def cpu_baseline(n: int = 320, steps: int = 18):
+    """Naive NumPy curl loop (oracle, fp32 arrays) on a bounded sample of the same workload
+    (320^3 x 20 steps ~ 10 s of single-core work on the GPU box's host)."""
     from oracle.fdtd_numpy import OracleFdtd
     spec = build_spec(n, steps + 2, "v0")
     o = OracleFdtd(spec, dtype=np.float32)
