@@ -78,8 +78,13 @@ class HipEngine:
         self._keep = []          # host arrays that must outlive a call
         d = self.lib.dll
 
+        # Rows that are not a multiple of 4 cells are padded with PEC cells beyond the x-max wall —
+        # exactly the PEC truncation the wall stands for (every PML is PEC-backed) — so the float4 /
+        # fused kernels apply to any nx.  Periodic x cannot be padded (two-pass scalar kernels then).
+        self.pad_x = (-nx) % 4 if (spec.bc[0][1] != BC_PERIODIC and variant != L.VARIANT_SIMPLE) else 0
+        self.nxp = nx + self.pad_x
         cfg = L.FdtdConfig()
-        cfg.nx, cfg.ny, cfg.nz = nx, ny, self.nzl
+        cfg.nx, cfg.ny, cfg.nz = self.nxp, ny, self.nzl
         bc = [spec.bc[0][0], spec.bc[0][1], spec.bc[1][0], spec.bc[1][1], spec.bc[2][0], spec.bc[2][1]]
         per_z = spec.bc[2][0] == BC_PERIODIC
         if n_ranks > 1 or force_comm:    # force_comm: 1-rank RCCL self exchange (periodic z), a test aid
@@ -92,7 +97,7 @@ class HipEngine:
         if (n_ranks > 1 or force_comm) and variant in (L.VARIANT_AUTO, L.VARIANT_FUSED):
             # every rank takes the same decision (split_slabs is deterministic): fused z-slab schedule
             # iff float4-aligned rows, >= 4 planes in every slab and no slab cut inside the z-PML
-            ok = (nx % 4 == 0 and min(b - a for a, b in split_slabs(nz, n_ranks)) >= 4
+            ok = (self.nxp % 4 == 0 and min(b - a for a, b in split_slabs(nz, n_ranks)) >= 4
                   and self._fused_slabs_ok(spec, n_ranks))
             variant = L.VARIANT_FUSED if ok else L.VARIANT_ZMARCH
         cfg.device, cfg.variant, cfg.flags, cfg.z_chunk = device, variant, flags, z_chunk
@@ -124,20 +129,25 @@ class HipEngine:
 
     def _setup(self, spec: SolverSpec):
         d, h = self.lib.dll, self.handle
-        nx, ny, nz = spec.shape
+        nx0, ny, nz = spec.shape
+        pad = self.pad_x
+        nx = self.nxp                       # row length on the device
         z0, z1, nzl = self.z0, self.z1, self.nzl
         sxy = nx * ny
         ip, idl = inv_steps(spec)
         for a in range(3):
             p, q = _f32(ip[a]), _f32(idl[a])
+            if a == 0 and pad:
+                p, q = _f32(np.append(p, [p[-1]] * pad)), _f32(np.append(q, [q[-1]] * pad))
             if a == 2:
                 p, q = _f32(p[z0:z1]), _f32(q[z0:z1])
             self._chk(d.fdtd_set_steps(h, a, _ptr(p), _ptr(q), len(p)), "fdtd_set_steps")
         self.mt = mt = material_table(spec.media, spec.dt)
         ca, cb = _f32(mt.ca), _f32(mt.cb)
         self._chk(d.fdtd_set_media(h, _ptr(ca), _ptr(cb), len(ca)), "fdtd_set_media")
-        if spec.mat_idx is not None:
-            m = np.ascontiguousarray(spec.mat_idx[:, z0:z1], dtype=np.uint8)
+        if spec.mat_idx is not None or pad:
+            m = np.zeros((3, nzl, ny, nx), dtype=np.uint8)         # index 0 = PEC in the padding
+            m[..., :nx0] = spec.mat_idx[:, z0:z1] if spec.mat_idx is not None else 1
             self._chk(d.fdtd_set_material(h, _ptr(m), m.nbytes), "fdtd_set_material")
         # CPML
         for a in range(3):
@@ -146,6 +156,10 @@ class HipEngine:
                 continue
             tabs = [P.kinv_e, P.b_e, P.c_e, P.kinv_h, P.b_h, P.c_h]
             n_lo, n_hi = P.n_lo, P.n_hi
+            if a == 0 and pad:          # identity in the padding; the hi slab range grows to cover it
+                ident = [1.0, 0.0, 0.0, 1.0, 0.0, 0.0]
+                tabs = [np.append(t, [v] * pad) for t, v in zip(tabs, ident)]
+                n_hi = n_hi + pad if n_hi else 0
             if a == 2:
                 tabs = [t[z0:z1] for t in tabs]
                 n_lo, n_hi = _local_pml_counts(tabs)
@@ -160,10 +174,11 @@ class HipEngine:
                 if not mt.is_dispersive(m):
                     continue
                 if spec.mat_idx is not None:
-                    flat = spec.mat_idx[c, z0:z1].reshape(-1)
-                    idx = np.nonzero(flat == m)[0].astype(np.uint32)
+                    kk, jj, ii = np.nonzero(spec.mat_idx[c, z0:z1] == m)
+                    idx = (kk.astype(np.int64) * sxy + jj.astype(np.int64) * nx + ii).astype(np.uint32)
                 elif m == 1:
-                    idx = np.arange(sxy * nzl, dtype=np.uint32)
+                    kk, jj, ii = np.meshgrid(np.arange(nzl), np.arange(ny), np.arange(nx0), indexing="ij")
+                    idx = (kk.astype(np.int64) * sxy + jj * nx + ii).reshape(-1).astype(np.uint32)
                 else:
                     continue
                 if idx.size == 0:
@@ -266,13 +281,15 @@ class HipEngine:
 
     def get_field(self, comp: int) -> np.ndarray:
         nx, ny, _ = self.spec.shape
-        out = np.empty((self.nzl, ny, nx), dtype=np.float32)
+        out = np.empty((self.nzl, ny, self.nxp), dtype=np.float32)
         self._chk(self.lib.dll.fdtd_get_field(self.handle, comp, _ptr(out), out.nbytes),
                   "fdtd_get_field")
-        return out
+        return np.ascontiguousarray(out[..., :nx]) if self.pad_x else out
 
     def set_field(self, comp: int, arr: np.ndarray):
         a = _f32(arr)
+        if self.pad_x:
+            a = _f32(np.pad(a, ((0, 0), (0, 0), (0, self.pad_x))))
         self._chk(self.lib.dll.fdtd_set_field(self.handle, comp, _ptr(a), a.nbytes),
                   "fdtd_set_field")
 
