@@ -70,11 +70,17 @@ def _diff_ops(nu: int, nv: int, du_p, dv_p, du_d, dv_d, pec_min=(True, True)):
 
 def solve_modes(eps_u: np.ndarray, eps_v: np.ndarray, eps_w: np.ndarray, ub: np.ndarray,
                 vb: np.ndarray, freq: float, num_modes: int = 1,
-                target_neff: Optional[float] = None) -> ModeResult:
+                target_neff: Optional[float] = None, precision: str = "double") -> ModeResult:
     """eps_* are [Nu, Nv] (complex allowed) sampled at E_u (uc, vb), E_v (ub, vc), E_w (ub, vb);
     ub / vb the Nu+1 / Nv+1 cell boundaries."""
     nu, nv = eps_u.shape
     N = nu * nv
+    # lossless cross-sections give a real operator (half the LU cost); "single" follows
+    # ModeSpec.precision (ref mode.py:164, solver.py:247: the reference's default) and runs the
+    # factorisation and ARPACK in 32-bit
+    is_real = all(np.all(np.imag(a) == 0) for a in (eps_u, eps_v, eps_w))
+    if is_real:
+        eps_u, eps_v, eps_w = (np.real(a) for a in (eps_u, eps_v, eps_w))
     k0 = 2 * np.pi * freq / C_0
     du_p, dv_p = np.diff(ub), np.diff(vb)
     du_d = np.concatenate(([du_p[0]], 0.5 * (du_p[1:] + du_p[:-1])))
@@ -101,12 +107,17 @@ def solve_modes(eps_u: np.ndarray, eps_v: np.ndarray, eps_w: np.ndarray, ub: np.
         sp.hstack([k0 * eu, sp.csr_matrix((N, N))]) - (1 / k0) * Dvb @ curl_e,
     ], format="csr")
     A = (P @ Q).tocsc()
+    if precision == "single":
+        A = A.astype(np.float32 if is_real else np.complex64)
     if target_neff is None:
         target_neff = float(np.sqrt(np.max(np.real([eps_u.max(), eps_v.max(), eps_w.max()]))))
     sigma = (target_neff * k0) ** 2
     rng = np.random.default_rng(0)
-    v0 = rng.standard_normal(2 * N)
-    vals, vecs = spl.eigs(A, k=num_modes, sigma=sigma, v0=v0, tol=1e-10)
+    v0 = rng.standard_normal(2 * N).astype(A.dtype if not np.iscomplexobj(A) else np.float64)
+    vals, vecs = spl.eigs(A, k=num_modes, sigma=A.dtype.type(sigma) if precision == "single" else sigma,
+                          v0=v0.astype(A.dtype), tol=(1e-6 if precision == "single" else 1e-10))
+    vals = vals.astype(complex)
+    vecs = vecs.astype(complex)
     beta = np.sqrt(vals + 0j)
     beta = np.where(beta.real < 0, -beta, beta)
     order = np.argsort(-beta.real)

@@ -96,7 +96,8 @@ def mode_profile(spec: SolverSpec, box: td.Box, mode_spec, freq: float) -> ModeP
     ub = b[u][lo[0]:hi[0] + 1]
     vb = b[v][lo[1]:hi[1] + 1]
     res = solve_modes(eps_u, eps_v, eps_w, ub, vb, freq, num_modes=int(mode_spec.num_modes),
-                      target_neff=mode_spec.target_neff)
+                      target_neff=mode_spec.target_neff,
+                      precision=getattr(mode_spec, "precision", "single") or "single")
     return ModePlane(p=p, u=u, v=v, k0=k0, lo=lo, hi=hi, result=res)
 
 
