@@ -1111,12 +1111,13 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       HIPCHK(h, hipMemcpyAsync(&en, h->energy_dev, sizeof(double), hipMemcpyDeviceToHost, st));
       HIPCHK(h, hipStreamSynchronize(st));
       if (multi) {
-        // sum over ranks (1 double every decay_every steps; off the critical path)
+        // sum over ranks (1 double every decay_every steps).  Every RCCL call of this communicator
+        // is issued on the comm stream, in the same order on all ranks — never from two streams.
         double* tmp = h->energy_dev;
-        HIPCHK(h, hipMemcpyAsync(tmp, &en, sizeof(double), hipMemcpyHostToDevice, st));
-        NCCLCHK(h, ncclAllReduce(tmp, tmp, 1, ncclDouble, ncclSum, h->comm, st));
-        HIPCHK(h, hipMemcpyAsync(&en, tmp, sizeof(double), hipMemcpyDeviceToHost, st));
-        HIPCHK(h, hipStreamSynchronize(st));
+        HIPCHK(h, hipMemcpyAsync(tmp, &en, sizeof(double), hipMemcpyHostToDevice, cs));
+        NCCLCHK(h, ncclAllReduce(tmp, tmp, 1, ncclDouble, ncclSum, h->comm, cs));
+        HIPCHK(h, hipMemcpyAsync(&en, tmp, sizeof(double), hipMemcpyDeviceToHost, cs));
+        HIPCHK(h, hipStreamSynchronize(cs));
       }
       if (!std::isfinite(en)) {
         h->stats.diverged = 1;
