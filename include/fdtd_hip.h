@@ -75,7 +75,13 @@ typedef int (*FdtdProgressFn)(int64_t step, double time, double field_decay, voi
 const char* fdtd_last_error(const FdtdSolver* h);   /* h may be NULL: error of the last create */
 int  fdtd_device_count(void);
 
+/* One solve = one handle.  Stands in for SimulationTask.create + upload_simulation of the cloud
+ * path (ref web/api/webapi.py:219,237; web/core/task_core.py:121); the grid size is
+ * Simulation.grid.num_cells incl. the PML cells (ref simulation.py:4296, grid_spec.py:114-137),
+ * the face codes come from Simulation.boundary_spec (ref boundary.py:732; a PEC wall backs every
+ * PML, CHANGELOG.md:1290), ch = Simulation.dt / MU_0 (ref simulation.py:4194, constants.py:21). */
 int  fdtd_create(const FdtdConfig* cfg, FdtdSolver** out);
+/* ref web/api/webapi.py delete(): releases every device resource of the task */
 void fdtd_destroy(FdtdSolver* h);
 
 /* 1/primal and 1/dual step vectors of one axis (length = n cells of that axis of this slab;
@@ -86,14 +92,15 @@ int fdtd_set_steps(FdtdSolver* h, int axis, const float* inv_primal, const float
 
 /* material table (index 0 = PEC: ca = cb = 0) and, optionally, the staircased material index
  * volumes mat[3][nz][ny][nx] (uint8, one per E component, ref simulation.py:1135-1241).
- * Without fdtd_set_material every cell uses entry 1. */
+ * Without fdtd_set_material every cell uses entry 1.  (Ca, Cb) follow from Medium.permittivity /
+ * conductivity (ref medium.py:1499, :1016-1038) or the pole-residue form (ref medium.py:2739). */
 int fdtd_set_media(FdtdSolver* h, const float* ca, const float* cb, int n_media);
 int fdtd_set_material(FdtdSolver* h, const uint8_t* mat, size_t bytes);
 
-/* CPML tables of one axis, each of length n (identity outside the slabs); [i_lo_e, ...) ranges
- * are derived from n_lo/n_hi (ref boundary.py:195-254; formulas in tidy3d_amd/coeffs.py).
- * z_offset: global z index of this slab's plane 0 is only needed by the host to slice the
- * tables, the library sees slab-local tables. */
+/* CPML tables of one axis, each of length n (identity outside the slabs); the slab index ranges
+ * are derived from n_lo/n_hi = Simulation.num_pml_layers (ref simulation.py:1002) and the profile
+ * from PMLParams (ref boundary.py:195-254; sampling positions ref plugins/mode/derivatives.py:
+ * 174-197; formulas in tidy3d_amd/coeffs.py).  On a z-slab the host passes slab-local tables. */
 int fdtd_set_pml(FdtdSolver* h, int axis, int n_lo, int n_hi,
                  const float* kinv_e, const float* b_e, const float* c_e,
                  const float* kinv_h, const float* b_h, const float* c_h, int n);
@@ -133,6 +140,8 @@ int fdtd_add_monitor(FdtdSolver* h, int kind, int n_comps, const int32_t* comps,
 /* time: float [n_rec][n_comps][bz][by][bx];  dft: complex64 [nf][n_comps][bz][by][bx] */
 int fdtd_get_monitor(FdtdSolver* h, int monitor_id, void* host, size_t bytes);
 
+/* whole-volume field access [nz][ny][nx] (tests, benchmarks, checkpointing); the reference exposes
+ * fields only through monitors (ref monitor.py:363), so this has no cloud counterpart */
 int fdtd_set_field(FdtdSolver* h, int comp, const float* host, size_t bytes);
 int fdtd_get_field(FdtdSolver* h, int comp, float* host, size_t bytes);
 
@@ -146,8 +155,11 @@ int fdtd_set_shutoff(FdtdSolver* h, int every, double shutoff, int64_t ref_step)
 int fdtd_comm_unique_id(char id[128]);
 int fdtd_comm_init(FdtdSolver* h, const char id[128], int rank, int n_ranks);
 
-/* advance n_steps time steps starting at the handle's current step counter. */
+/* advance n_steps time steps starting at the handle's current step counter: start() + monitor()
+ * of the cloud path (ref web/api/webapi.py:266,:337); the step count is Simulation.num_time_steps
+ * (ref simulation.py:4226). */
 int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user);
+/* ref web/api/webapi.py:370 (task status incl. "diverged"), web/core/task_core.py:537 (run info) */
 int fdtd_get_stats(FdtdSolver* h, FdtdStats* out);
 /* tuning knobs that may change between runs of one handle (bench A/B without re-upload) */
 enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_ROWS = 3, FDTD_OPT_XCD_REMAP = 4,
