@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--zchunk", type=int, default=0)
     ap.add_argument("--rows", type=int, default=0)
+    ap.add_argument("--pml-fused", type=int, default=-1, help="axis mask of the CPML recursions folded into the fused sweep (0, 6, 7)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--sweep", action="store_true", help="A/B kernel launch parameters (N=1)")
     args = ap.parse_args()
@@ -122,6 +123,8 @@ def main():
                     slab=slabs[rank], rank=rank, n_ranks=world)
     if args.rows:
         eng.set_option(L.OPT_ROWS, args.rows)
+    if args.pml_fused >= 0:
+        eng.set_option(L.OPT_PML_FUSED, args.pml_fused)
     if world > 1:
         uid = [eng.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)

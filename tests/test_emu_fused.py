@@ -48,9 +48,11 @@ CONFIGS = {
 }
 
 
-def _run(spec, lib, variant, rows, zc):
+def _run(spec, lib, variant, rows, zc, pml_mask=None):
     with HipEngine(spec, lib=lib, variant=variant, z_chunk=zc) as e:
         e.set_option(L.OPT_ROWS, rows)
+        if pml_mask is not None:
+            e.set_option(L.OPT_PML_FUSED, pml_mask)
         e.run()
         return [e.get_field(c) for c in range(6)], e.results()
 
@@ -64,6 +66,21 @@ def test_fused_equals_two_pass(name, rows, zc, emu_lib):
     ref_f, ref_m = _run(disc.spec, emu_lib, L.VARIANT_ZMARCH, 4, 2)
     got_f, got_m = _run(disc.spec, emu_lib, L.VARIANT_FUSED, rows, zc)
     # explicit fma's + -ffp-contract=off + identical summation order: bit-for-bit agreement
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), c
+    for k in ref_m:
+        assert np.array_equal(got_m[k], ref_m[k]), k
+
+
+@pytest.mark.parametrize("mask", [0, 6, 7])
+@pytest.mark.parametrize("rows,zc", [(3, 16), (4, 3)])
+def test_fused_cpml_placement(mask, rows, zc, emu_lib):
+    """The CPML recursions as slab kernels (0), y/z inside the sweep (6), all inside (7): identical
+    arithmetic and summation order (H: x, y, z; E: y, z, x) -> bit-for-bit the two-pass result."""
+    N, bspec, structures = CONFIGS["pml_media"]
+    disc = discretize(_sim(N, bspec, structures), n_steps=24)
+    ref_f, ref_m = _run(disc.spec, emu_lib, L.VARIANT_ZMARCH, 4, 2)
+    got_f, got_m = _run(disc.spec, emu_lib, L.VARIANT_FUSED, rows, zc, mask)
     for c in range(6):
         assert np.array_equal(got_f[c], ref_f[c]), c
     for k in ref_m:

@@ -32,6 +32,8 @@ struct PmlAxisDev {
   // psi arrays: [side E/H][comp slot 0/1]
   float* psi_e[2] = {nullptr, nullptr};
   float* psi_h[2] = {nullptr, nullptr};
+  float* psi_h2[2] = {nullptr, nullptr};   // write set of the fused in-kernel CPML (ping-pong)
+  size_t psi_h_count = 0;
   int ns_e = 0, ns_h = 0;          // slab extents along the axis (lo + hi entries)
 };
 
@@ -117,6 +119,11 @@ struct FdtdSolver {
                                      // ~150 VGPRs without spills, 3 workgroups per CU; measured best, profiles/r01g)
   int xcd_remap = 1;
   int fused_lb = 0;                  // 0 = by workgroup size, else forced __launch_bounds__ variant
+  // axis mask of the CPML recursions folded into the fused sweep (single GPU): 0 = slab kernels,
+  // 6 = y and z, 7 = all.  Measured on 512^3 + 12-layer PML (profiles/r01h_pml_placement.txt): the
+  // extra live registers drop the sweep from 3 to 2 (mask 6) or 1 (mask 7) waves per SIMD, which
+  // costs more (+0.41 ms / +3.0 ms) than the slab kernels it removes (0.22 ms / 0.45 ms) -> default 0.
+  int pml_fused = 0;
   int fused_multi_mode = 0;          // ghost planes currently follow the fused z-slab protocol
   int rows = 4;
   // RCCL
@@ -267,7 +274,27 @@ int ensure_second_set(FdtdSolver* h) {
   return 0;
 }
 
-int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st) {
+PmlP pml_params(const FdtdSolver* h) {
+  PmlP pm{};
+  const int N[3] = {h->g.nx, h->g.ny, h->g.nz};
+  for (int a = 0; a < 3; ++a) {
+    const PmlAxisDev& P = h->pml[a];
+    PmlAxisP& A = pm.ax[a];
+    A.kinv_e = P.kinv_e; A.b_e = P.b_e; A.c_e = P.c_e;
+    A.kinv_h = P.kinv_h; A.b_h = P.b_h; A.c_h = P.c_h;
+    A.pe0 = P.psi_e[0]; A.pe1 = P.psi_e[1]; A.ph0 = P.psi_h[0]; A.ph1 = P.psi_h[1];
+    A.ph0n = P.psi_h2[0]; A.ph1n = P.psi_h2[1];
+    A.n_lo = P.n_lo; A.n_hi = P.n_hi; A.ns_e = P.ns_e; A.ns_h = P.ns_h; A.n = N[a];
+  }
+  return pm;
+}
+
+bool any_pml(const FdtdSolver* h) {
+  for (int a = 0; a < 3; ++a) if (h->pml[a].n_lo + h->pml[a].n_hi > 0) return true;
+  return false;
+}
+
+int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pml_inside = 0) {
   if (kend <= kbeg) return 0;
   const GridP& g = h->g;
   if (ensure_second_set(h)) return -1;
@@ -287,13 +314,20 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st) {
   int lb = h->fused_lb ? h->fused_lb : (threads <= 256 ? 256 : (threads <= 512 ? 512 : 1024));
   if (lb < threads) lb = threads <= 512 ? 512 : 1024;
   time_begin(h, 2, st);
-#define FDTD_LAUNCH_FUSED(MATV, LBV)                                                                  \
-  hipLaunchKernelGGL((fused_step_kernel<MATV, LBV>), grid, block, shmem, st, g, h->f, h->f2, s, m, kbeg, \
-                     kend, zc, pmc, nbx, nby, nbz, remap)
-  if (h->mat4) {
-    if (lb == 256) FDTD_LAUNCH_FUSED(true, 256); else if (lb == 512) FDTD_LAUNCH_FUSED(true, 512); else FDTD_LAUNCH_FUSED(true, 1024);
+  const PmlP pm = pml_params(h);
+#define FDTD_LAUNCH_FUSED(MATV, LBV, PMLV)                                                            \
+  hipLaunchKernelGGL((fused_step_kernel<MATV, LBV, PMLV>), grid, block, shmem, st, g, h->f, h->f2, s, m, kbeg, \
+                     kend, zc, pmc, nbx, nby, nbz, remap, pm)
+  if (pml_inside == 7) {    // CPML of all axes folded into the sweep (256- and 512-thread workgroups)
+    if (h->mat4) { if (lb == 256) FDTD_LAUNCH_FUSED(true, 256, 7); else FDTD_LAUNCH_FUSED(true, 512, 7); }
+    else { if (lb == 256) FDTD_LAUNCH_FUSED(false, 256, 7); else FDTD_LAUNCH_FUSED(false, 512, 7); }
+  } else if (pml_inside == 6) {   // y and z only (wave-uniform membership, float4 psi accesses)
+    if (h->mat4) { if (lb == 256) FDTD_LAUNCH_FUSED(true, 256, 6); else FDTD_LAUNCH_FUSED(true, 512, 6); }
+    else { if (lb == 256) FDTD_LAUNCH_FUSED(false, 256, 6); else FDTD_LAUNCH_FUSED(false, 512, 6); }
+  } else if (h->mat4) {
+    if (lb == 256) FDTD_LAUNCH_FUSED(true, 256, 0); else if (lb == 512) FDTD_LAUNCH_FUSED(true, 512, 0); else FDTD_LAUNCH_FUSED(true, 1024, 0);
   } else {
-    if (lb == 256) FDTD_LAUNCH_FUSED(false, 256); else if (lb == 512) FDTD_LAUNCH_FUSED(false, 512); else FDTD_LAUNCH_FUSED(false, 1024);
+    if (lb == 256) FDTD_LAUNCH_FUSED(false, 256, 0); else if (lb == 512) FDTD_LAUNCH_FUSED(false, 512, 0); else FDTD_LAUNCH_FUSED(false, 1024, 0);
   }
 #undef FDTD_LAUNCH_FUSED
   time_end(h, st);
@@ -305,8 +339,8 @@ void swap_sets(FdtdSolver* h) {
   for (int c = 0; c < 6; ++c) std::swap(h->fbase[c], h->fbase2[c]);
 }
 
-int launch_fused(FdtdSolver* h, hipStream_t st) {
-  if (launch_fused_range(h, 0, h->g.nz, st)) return -1;
+int launch_fused(FdtdSolver* h, hipStream_t st, int pml_inside) {
+  if (launch_fused_range(h, 0, h->g.nz, st, pml_inside)) return -1;
   swap_sets(h);
   return 0;
 }
@@ -324,12 +358,15 @@ void fill_ghost_fused(FdtdSolver* h, hipStream_t st) {
 }
 
 // slabs of one axis: E-side ranges [0,n_lo) and [N-n_hi+1,N); H-side [0,n_lo) and [N-n_hi,N)
-void launch_pml(FdtdSolver* h, bool e_side, int kbeg, int kend, hipStream_t st) {
+// Axis order: H side x, y, z; E side y, z, x — so that a sweep that folds only the y and z
+// recursions into the fused kernel (x stays a slab kernel before / after it) sums in the same order.
+void launch_pml(FdtdSolver* h, bool e_side, int kbeg, int kend, hipStream_t st, int axes = 7) {
   const GridP& g = h->g;
   const int N[3] = {g.nx, g.ny, g.nz};
-  for (int a = 0; a < 3; ++a) {
+  for (int ai = 0; ai < 3; ++ai) {
+    const int a = e_side ? (ai + 1) % 3 : ai;
     PmlAxisDev& P = h->pml[a];
-    if (P.n_lo + P.n_hi == 0) continue;
+    if (P.n_lo + P.n_hi == 0 || !((axes >> a) & 1)) continue;
     const int c1 = (a + 1) % 3, c2 = (a + 2) % 3;
     for (int side = 0; side < 2; ++side) {
       int s_lo, s_n, base;
@@ -739,6 +776,7 @@ int fdtd_set_pml(FdtdSolver* h, int axis, int n_lo, int n_hi, const float* kinv_
   for (int s = 0; s < 2; ++s) {
     if (P.ns_e > 0 && dev_alloc(h, &P.psi_e[s], other * P.ns_e)) return -1;
     if (P.ns_h > 0 && dev_alloc(h, &P.psi_h[s], other * P.ns_h)) return -1;
+    P.psi_h_count = other * P.ns_h;
   }
   return 0;
 }
@@ -1010,8 +1048,8 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       // boundary chunks: thin enough that [exchanges + boundary sweeps] on the comm stream take about as
       // long as the interior sweep on the main stream (at 8 x 64 planes: 2 x 8 planes vs 48 planes)
       const int zb = std::max(1, std::min(h->zchunk_f, nz / 8));
-      launch_pml(h, false, 0, nz, st);
       launch_sources(h, false, n, 0, nz, st);
+      launch_pml(h, false, 0, nz, st);
       advance_tfsf_aux(h, false, n, st);
       HIPCHK(h, hipEventRecord(h->ev_h_int, st));                 // pre-corrections done
       HIPCHK(h, hipStreamWaitEvent(cs, h->ev_h_int, 0));
@@ -1034,14 +1072,26 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
       h->step = n + 1;
     } else if (fused) {
-      // H-side corrections are additive: pre-apply them to H^{n-1/2}; E-side ones follow the sweep
-      launch_pml(h, false, 0, nz, st);
+      // H-side corrections are additive: pre-apply them to H^{n-1/2}; E-side ones follow the sweep.
+      // With pml_in the CPML recursions run inside the sweep (same arithmetic, no slab kernels).
+      int pml_in = 0;           // axes whose recursions run inside the sweep: none, {y, z} or all
+      if (h->pml_fused && any_pml(h) && 64 * (h->rows_f + 1) <= 512) pml_in = (h->pml_fused & 1) ? 7 : 6;
+      if (pml_in)
+        for (int a = 0; a < 3; ++a) {
+          if (!((pml_in >> a) & 1)) continue;
+          PmlAxisDev& P = h->pml[a];
+          for (int q = 0; q < 2; ++q)
+            if (P.psi_h[q] && !P.psi_h2[q] && dev_alloc(h, &P.psi_h2[q], P.psi_h_count)) return -1;
+        }
       launch_sources(h, false, n, 0, nz, st);
+      launch_pml(h, false, 0, nz, st, 7 & ~pml_in);
       advance_tfsf_aux(h, false, n, st);
       if (h->cfg.bc[4] == FDTD_BC_PERIODIC) fill_ghost_h(h, st);   // ghost(-1) must carry the pre-corrections too
-      if (launch_fused(h, st)) return -1;
+      if (launch_fused(h, st, pml_in)) return -1;
+      for (int a = 0; a < 3; ++a)
+        if ((pml_in >> a) & 1) { std::swap(h->pml[a].psi_h[0], h->pml[a].psi_h2[0]); std::swap(h->pml[a].psi_h[1], h->pml[a].psi_h2[1]); }
       if (rec) record_monitors(h, n, true, st);
-      launch_pml(h, true, 0, nz, st);
+      launch_pml(h, true, 0, nz, st, 7 & ~pml_in);
       launch_sources(h, true, n, 0, nz, st);
       launch_ade(h, 0, nz, st);
       advance_tfsf_aux(h, true, n, st);
@@ -1052,14 +1102,14 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     const int h_top = (multi && nb_hi) ? nz - 1 : nz;      // planes [0, h_top) on st, [h_top, nz) on cs
     if (multi && nb_hi) {
       HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
-      launch_pml(h, false, h_top, nz, cs);           // H-side corrections first (they only read E^n):
-      launch_sources(h, false, n, h_top, nz, cs);    // same summation order as the fused sweep
+      launch_sources(h, false, n, h_top, nz, cs);    // H-side corrections first (they only read E^n),
+      launch_pml(h, false, h_top, nz, cs);           // in the summation order of the fused sweep
       launch_h_main(h, h_top, nz, cs);
       HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
     }
     if (multi) HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
-    launch_pml(h, false, 0, h_top, st);
     launch_sources(h, false, n, 0, h_top, st);
+    launch_pml(h, false, 0, h_top, st);
     launch_h_main(h, 0, h_top, st);
     advance_tfsf_aux(h, false, n, st);
     if (multi) {
@@ -1166,6 +1216,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_ZCHUNK: if (value < 1) break; h->zchunk = value; h->zchunk_f = value; return 0;
     case FDTD_OPT_ROWS: if (value < 1 || value > 15) break; h->rows = value > 8 ? 8 : value; h->rows_f = value; return 0;
     case FDTD_OPT_XCD_REMAP: h->xcd_remap = value != 0; return 0;
+    case FDTD_OPT_PML_FUSED: h->pml_fused = value & 7; return 0;
     case FDTD_OPT_FUSED_LB: if (value != 0 && value != 256 && value != 512 && value != 1024) break; h->fused_lb = value; return 0;
     default: break;
   }

@@ -290,6 +290,75 @@ __global__ __launch_bounds__(512) void e_update_kernel(GridP g, FieldP f, StepP 
   }
 }
 
+// ---- CPML inside the fused sweep ------------------------------------------------------------
+// Same recursion and the same operation order as the slab kernels pml_h_kernel / pml_e_kernel
+// (K3 below), applied to registers: H-side corrections to H^{n-1/2} before upd_h, E-side ones to
+// E^{n+1} after upd_e, axes in the order x, y, z.  Halo rows / columns / prologue planes recompute
+// the corrected value from psi without storing it, so psi is updated exactly once per cell.
+struct PmlAxisP {
+  const float* kinv_e; const float* b_e; const float* c_e;
+  const float* kinv_h; const float* b_h; const float* c_h;
+  float* pe0; float* pe1;        // psi of E_{a+1}, E_{a+2}
+  const float* ph0; const float* ph1;   // psi of H_{a+1}, H_{a+2}: READ set  (halo rows, the x-halo
+  float* ph0n; float* ph1n;             // column and chunk prologues of OTHER workgroups re-read the old
+                                        // values, so the H-side psi is ping-ponged like the fields) / WRITE set
+  int n_lo, n_hi, ns_e, ns_h, n;
+};
+struct PmlP { PmlAxisP ax[3]; };
+
+__device__ __forceinline__ int pml_si_h(const PmlAxisP& A, int ia) {
+  if (ia < A.n_lo) return ia;
+  const int s0 = A.n - A.n_hi;
+  if (A.n_hi > 0 && ia >= s0) return A.n_lo + (ia - s0);
+  return -1;
+}
+__device__ __forceinline__ int pml_si_e(const PmlAxisP& A, int ia) {
+  if (ia < A.n_lo) return ia;
+  const int s0 = A.n - A.n_hi + 1;
+  if (A.n_hi > 1 && ia >= s0) return A.n_lo + (ia - s0);
+  return -1;
+}
+__device__ __forceinline__ long long pml_q(const GridP& g, int a, int ns, int i, int j, int k, int si) {
+  if (a == 0) return ((long long)k * g.ny + j) * ns + si;
+  if (a == 1) return ((long long)k * ns + si) * g.nx + i;
+  return ((long long)si * g.ny + j) * g.nx + i;
+}
+// one cell, one axis:  h1 += ch (kv d2 + p1),  h2 -= ch (kv d1 + p2)
+__device__ __forceinline__ void pml_h_cell(float& h1, float& h2, float d1, float d2, const PmlAxisP& A,
+                                           long long q, float kv, float b, float c, float ch, bool store) {
+  const float p1 = b * A.ph0[q] + c * d2;
+  const float p2 = b * A.ph1[q] + c * d1;
+  if (store) { A.ph0n[q] = p1; A.ph1n[q] = p2; }
+  h1 += ch * (kv * d2 + p1);
+  h2 -= ch * (kv * d1 + p2);
+}
+// same recursion on psi values already in registers (s1, s2 are replaced by their new values)
+__device__ __forceinline__ void pml_h_apply(float& h1, float& h2, float d1, float d2, float& s1, float& s2,
+                                            float kv, float b, float c, float ch) {
+  const float p1 = b * s1 + c * d2;
+  const float p2 = b * s2 + c * d1;
+  s1 = p1; s2 = p2;
+  h1 += ch * (kv * d2 + p1);
+  h2 -= ch * (kv * d1 + p2);
+}
+// four consecutive x cells of a row, axis y or z (uniform membership)
+__device__ __forceinline__ void pml_h_vec(float (&h1)[4], float (&h2)[4], const float (&d1)[4], const float (&d2)[4],
+                                          const PmlAxisP& A, long long q, float kv, float b, float c,
+                                          float ch, bool store) {
+  float q1[4], q2[4];
+  ldv<4>(q1, A.ph0 + q);
+  ldv<4>(q2, A.ph1 + q);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float p1 = b * q1[e] + c * d2[e];
+    const float p2 = b * q2[e] + c * d1[e];
+    q1[e] = p1; q2[e] = p2;
+    h1[e] += ch * (kv * d2[e] + p1);
+    h2[e] -= ch * (kv * d1[e] + p2);
+  }
+  if (store) { stv<4>(A.ph0n + q, q1); stv<4>(A.ph1n + q, q2); }
+}
+
 // =============================================================================================
 // K1+K2 fused: one sweep advances H by curl E AND E by curl of the *new* H, reading set `a`
 // (E^n, H^{n-1/2}) and writing set `b` (E^{n+1}, H^{n+1/2})  — 6 reads + 6 writes = 48 B per
@@ -304,10 +373,10 @@ __global__ __launch_bounds__(512) void e_update_kernel(GridP g, FieldP f, StepP 
 //     slot, one barrier per plane) and at z-1 (registers carried from the previous plane; the
 //     first plane of a chunk recomputes H^{n+1/2}[k0-1] in a prologue).
 // =============================================================================================
-template <bool MAT, int LB>
+template <bool MAT, int LB, int PML>   // PML: bit a set = CPML of axis a runs inside the sweep
 __global__ __launch_bounds__(LB) void fused_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
                                                           int kbeg, int kend, int zchunk, int pmc_z0,
-                                                          int nbx, int nby, int nbz, int xcd_remap) {
+                                                          int nbx, int nby, int nbz, int xcd_remap, PmlP pm) {
   constexpr int V = 4;
   // 1-D launch; logical tile (bx, by, bz) with by fastest.  XCD-aware remap: hardware block L runs
   // on XCD L % 8 (observed dispatch order, used for speed only), so XCD x is handed the contiguous
@@ -332,6 +401,7 @@ __global__ __launch_bounds__(LB) void fused_step_kernel(GridP g, FieldP a, Field
   }
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int R = blockDim.y - 1;
+  const PmlP& pmp = pm;
   const int i0 = (tile_x * 64 + tx) * V;
   const bool halo = (ty == 0);
   const bool per_x = g.bcx0 == BC_PERIODIC, per_y = g.bcy0 == BC_PERIODIC;
@@ -393,14 +463,87 @@ __global__ __launch_bounds__(LB) void fused_step_kernel(GridP g, FieldP a, Field
         else ezx = 0.f;
       }
       const float ipz = s.ipz[k0 - 1];
+      float hoy[V];
       ldv<V>(ho, a.hx + p);
+      ldv<V>(hoy, a.hy + p);
+      if constexpr (PML != 0) {
+        // corrected H^{n-1/2}_{x,y} of plane k0-1 (read-only psi; the plane's owner stores it)
+        const int kk = (k0 - 1 < 0) ? g.nz - 1 : k0 - 1;          // periodic z: ghost = top plane
+        if (k0 > 0 || !g.pec_z0) {
+          float dum[V];
+          // axis x: Hy += ch (kv dEz/dx + p1)        (all psi loads first, then the arithmetic)
+          if constexpr ((PML & 1) != 0) {
+            int si[V]; float s1[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+              si[e] = pml_si_h(pm.ax[0], i0 + e);
+              s1[e] = (si[e] >= 0) ? pm.ax[0].ph0[pml_q(g, 0, pm.ax[0].ns_h, i0 + e, j, kk, max(si[e], 0))] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < V; ++e)
+              if (si[e] >= 0) {
+                const float ez_ip = (e + 1 < V) ? ezm[(e + 1) % V] : ezx;
+                const float d2 = (ez_ip - ezm[e]) * ipx[e];
+                float hz_d = 0.f, s2 = 0.f;
+                pml_h_apply(hoy[e], hz_d, 0.f, d2, s1[e], s2, pm.ax[0].kinv_h[i0 + e] - 1.f, pm.ax[0].b_h[i0 + e],
+                            pm.ax[0].c_h[i0 + e], ch);
+              }
+          }
+          // axis y: Hx -= ch (kv dEz/dy + p2)
+          if constexpr ((PML & 2) != 0) {
+            const int si = pml_si_h(pm.ax[1], j);
+            if (si >= 0) {
+              float d1[V], d2[V];
+#pragma unroll
+              for (int e = 0; e < V; ++e) { d1[e] = (ezj[e] - ezm[e]) * ipy; d2[e] = 0.f; dum[e] = 0.f; }
+              pml_h_vec(dum, ho, d1, d2, pm.ax[1], pml_q(g, 1, pm.ax[1].ns_h, i0, j, kk, si),
+                        pm.ax[1].kinv_h[j] - 1.f, pm.ax[1].b_h[j], pm.ax[1].c_h[j], ch, false);
+            } }
+          // axis z: Hx += ch (kv dEy/dz + p1), Hy -= ch (kv dEx/dz + p2)   (only inside this slab)
+          if ((PML & 4) != 0 && k0 - 1 >= 0) {
+            const int si = pml_si_h(pm.ax[2], k0 - 1);
+            if (si >= 0) {
+              float d1[V], d2[V];
+#pragma unroll
+              for (int e = 0; e < V; ++e) { d1[e] = (exk[e] - exm[e]) * ipz; d2[e] = (eyk[e] - eym[e]) * ipz; }
+              pml_h_vec(ho, hoy, d1, d2, pm.ax[2], pml_q(g, 2, pm.ax[2].ns_h, i0, j, k0 - 1, si),
+                        pm.ax[2].kinv_h[k0 - 1] - 1.f, pm.ax[2].b_h[k0 - 1], pm.ax[2].c_h[k0 - 1], ch, false);
+            }
+          }
+        }
+      }
 #pragma unroll
       for (int e = 0; e < V; ++e) hxm[e] = upd_h(ho[e], ch, ezj[e] - ezm[e], ipy, eyk[e] - eym[e], ipz);
-      ldv<V>(ho, a.hy + p);
 #pragma unroll
       for (int e = 0; e < V; ++e) {
         const float ez_ip = (e + 1 < V) ? ezm[(e + 1) % V] : ezx;
-        hym[e] = upd_h(ho[e], ch, exk[e] - exm[e], ipz, ez_ip - ezm[e], ipx[e]);
+        hym[e] = upd_h(hoy[e], ch, exk[e] - exm[e], ipz, ez_ip - ezm[e], ipx[e]);
+      }
+    }
+  }
+  // CPML membership that does not change along the march (x: per cell, y: per row)
+  [[maybe_unused]] int sxh[V] = {-1, -1, -1, -1}, sxe[V] = {-1, -1, -1, -1};
+  [[maybe_unused]] bool xin_h = false, xin_e = false;
+  [[maybe_unused]] int syh = -1, sye = -1;
+  [[maybe_unused]] float hyc[3] = {0.f, 0.f, 0.f}, eyc[3] = {0.f, 0.f, 0.f};
+  if constexpr (PML != 0) {
+    if (act) {
+      if constexpr ((PML & 1) != 0) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          sxh[e] = pml_si_h(pm.ax[0], i0 + e);
+          sxe[e] = pml_si_e(pm.ax[0], i0 + e);
+          if (i0 + e == 0 && g.bcx0 == BC_PEC) sxe[e] = -1;       // E on the PEC wall stays clamped
+          xin_h = xin_h || sxh[e] >= 0;
+          xin_e = xin_e || sxe[e] >= 0;
+        }
+      }
+      if constexpr ((PML & 2) != 0) {
+        syh = pml_si_h(pm.ax[1], j);
+        sye = pml_si_e(pm.ax[1], j);
+        if (j == 0 && g.bcy0 == BC_PEC) sye = -1;
+        if (syh >= 0) { hyc[0] = pm.ax[1].kinv_h[j] - 1.f; hyc[1] = pm.ax[1].b_h[j]; hyc[2] = pm.ax[1].c_h[j]; }
+        if (sye >= 0) { eyc[0] = pm.ax[1].kinv_e[j] - 1.f; eyc[1] = pm.ax[1].b_e[j]; eyc[2] = pm.ax[1].c_e[j]; }
       }
     }
   }
@@ -427,12 +570,90 @@ __global__ __launch_bounds__(LB) void fused_step_kernel(GridP g, FieldP a, Field
       ldv<V>(hyn, a.hy + p);
       ldv<V>(hzn, a.hz + p);
     }
+    // H-side CPML state of this plane: issued with the field loads so that the latencies overlap
+    [[maybe_unused]] float hx1[V], hx2[V], hxk[V], hxb[V], hxc[V], hy1[V], hy2[V], hz1[V], hz2[V], hzc[3];
+    [[maybe_unused]] long long qxh = 0, qyh = 0, qzh = 0;
+    [[maybe_unused]] int szh = -1;
+    if constexpr (PML != 0) {
+      if (act) {
+        if constexpr ((PML & 1) != 0) {
+          if (xin_h) {
+            qxh = ((long long)k * g.ny + j) * pm.ax[0].ns_h;
+#pragma unroll
+            for (int e = 0; e < V; ++e)
+              if (sxh[e] >= 0) { hx1[e] = pm.ax[0].ph0[qxh + sxh[e]]; hx2[e] = pm.ax[0].ph1[qxh + sxh[e]]; }
+            ldv<V>(hxk, pm.ax[0].kinv_h + i0);
+            ldv<V>(hxb, pm.ax[0].b_h + i0);
+            ldv<V>(hxc, pm.ax[0].c_h + i0);
+          }
+        }
+        if constexpr ((PML & 2) != 0) {
+          if (syh >= 0) {
+            qyh = ((long long)k * pm.ax[1].ns_h + syh) * g.nx + i0;
+            ldv<V>(hy1, pm.ax[1].ph0 + qyh);
+            ldv<V>(hy2, pm.ax[1].ph1 + qyh);
+          }
+        }
+        if constexpr ((PML & 4) != 0) {
+          szh = pml_si_h(pm.ax[2], k);
+          if (szh >= 0) {
+            qzh = ((long long)szh * g.ny + j) * g.nx + i0;
+            ldv<V>(hz1, pm.ax[2].ph0 + qzh);
+            ldv<V>(hz2, pm.ax[2].ph1 + qzh);
+            hzc[0] = pm.ax[2].kinv_h[k] - 1.f; hzc[1] = pm.ax[2].b_h[k]; hzc[2] = pm.ax[2].c_h[k];
+          }
+        }
+      }
+    }
     float eyx = __shfl_down(eyk[0], 1);
     float ezx = __shfl_down(ezk[0], 1);
     if (act && (tx == 63 || last_x)) {
       if (!last_x) { eyx = a.ey[p + V]; ezx = a.ez[p + V]; }
       else if (g.bcx1 == BC_PERIODIC) { eyx = a.ey[p - i0]; ezx = a.ez[p - i0]; }
       else { eyx = 0.f; ezx = 0.f; }
+    }
+    if constexpr (PML != 0) {
+      if (act) {
+        const bool st_ok = !halo;            // the halo wave recomputes, the row's owner stores psi
+        // axis x: Hy += ch (kv dEz/dx + p1), Hz -= ch (kv dEy/dx + p2)
+        if constexpr ((PML & 1) != 0) {
+          if (xin_h) {
+#pragma unroll
+            for (int e = 0; e < V; ++e)
+              if (sxh[e] >= 0) {
+                const float ey_ip = (e + 1 < V) ? eyk[(e + 1) % V] : eyx;
+                const float ez_ip = (e + 1 < V) ? ezk[(e + 1) % V] : ezx;
+                pml_h_apply(hyn[e], hzn[e], (ey_ip - eyk[e]) * ipx[e], (ez_ip - ezk[e]) * ipx[e], hx1[e], hx2[e],
+                            hxk[e] - 1.f, hxb[e], hxc[e], ch);
+              }
+            if (st_ok) {
+#pragma unroll
+              for (int e = 0; e < V; ++e)
+                if (sxh[e] >= 0) { pm.ax[0].ph0n[qxh + sxh[e]] = hx1[e]; pm.ax[0].ph1n[qxh + sxh[e]] = hx2[e]; }
+            }
+          }
+        }
+        // axis y: Hz += ch (kv dEx/dy + p1), Hx -= ch (kv dEz/dy + p2)
+        if constexpr ((PML & 2) != 0) {
+          if (syh >= 0) {
+#pragma unroll
+            for (int e = 0; e < V; ++e)
+              pml_h_apply(hzn[e], hxn[e], (ezj[e] - ezk[e]) * ipy, (exj[e] - exk[e]) * ipy, hy1[e], hy2[e],
+                          hyc[0], hyc[1], hyc[2], ch);
+            if (st_ok) { stv<V>(pm.ax[1].ph0n + qyh, hy1); stv<V>(pm.ax[1].ph1n + qyh, hy2); }
+          }
+        }
+        // axis z: Hx += ch (kv dEy/dz + p1), Hy -= ch (kv dEx/dz + p2)
+        if constexpr ((PML & 4) != 0) {
+          if (szh >= 0) {
+#pragma unroll
+            for (int e = 0; e < V; ++e)
+              pml_h_apply(hxn[e], hyn[e], (exn[e] - exk[e]) * ipz, (eyn[e] - eyk[e]) * ipz, hz1[e], hz2[e],
+                          hzc[0], hzc[1], hzc[2], ch);
+            if (st_ok) { stv<V>(pm.ax[2].ph0n + qzh, hz1); stv<V>(pm.ax[2].ph1n + qzh, hz2); }
+          }
+        }
+      }
     }
     if (act) {
 #pragma unroll
@@ -444,6 +665,42 @@ __global__ __launch_bounds__(LB) void fused_step_kernel(GridP g, FieldP a, Field
         hzn[e] = upd_h(hzn[e], ch, ey_ip - eyk[e], ipx[e], exj[e] - exk[e], ipy);
       }
     }
+    // E-side CPML state: in flight across the LDS exchange and the barrier
+    [[maybe_unused]] float ex1[V], ex2[V], exk_[V], exb[V], exc[V], ey1[V], ey2[V], ez1[V], ez2[V], ezc[3];
+    [[maybe_unused]] long long qxe = 0, qye = 0, qze = 0;
+    [[maybe_unused]] int sze = -1;
+    if constexpr (PML != 0) {
+      if (act && !halo) {
+        if constexpr ((PML & 1) != 0) {
+          if (xin_e) {
+            qxe = ((long long)k * g.ny + j) * pmp.ax[0].ns_e;
+#pragma unroll
+            for (int e = 0; e < V; ++e)
+              if (sxe[e] >= 0) { ex1[e] = pmp.ax[0].pe0[qxe + sxe[e]]; ex2[e] = pmp.ax[0].pe1[qxe + sxe[e]]; }
+            ldv<V>(exk_, pmp.ax[0].kinv_e + i0);
+            ldv<V>(exb, pmp.ax[0].b_e + i0);
+            ldv<V>(exc, pmp.ax[0].c_e + i0);
+          }
+        }
+        if constexpr ((PML & 2) != 0) {
+          if (sye >= 0) {
+            qye = ((long long)k * pmp.ax[1].ns_e + sye) * g.nx + i0;
+            ldv<V>(ey1, pmp.ax[1].pe0 + qye);
+            ldv<V>(ey2, pmp.ax[1].pe1 + qye);
+          }
+        }
+        if constexpr ((PML & 4) != 0) {
+          sze = pml_si_e(pmp.ax[2], k);
+          if (k == 0 && g.pec_z0) sze = -1;
+          if (sze >= 0) {
+            qze = ((long long)sze * g.ny + j) * g.nx + i0;
+            ldv<V>(ez1, pmp.ax[2].pe0 + qze);
+            ldv<V>(ez2, pmp.ax[2].pe1 + qze);
+            ezc[0] = pmp.ax[2].kinv_e[k] - 1.f; ezc[1] = pmp.ax[2].b_e[k]; ezc[2] = pmp.ax[2].c_e[k];
+          }
+        }
+      }
+    }
     // x-halo column: H^{n+1/2}_{y,z} at i0-1 recomputed by the tile's first lane
     float hy_m = 0.f, hz_m = 0.f, exn_m = 0.f;
     if (xh) {
@@ -451,8 +708,30 @@ __global__ __launch_bounds__(LB) void fused_step_kernel(GridP g, FieldP a, Field
       exn_m = a.ex[pm + g.sxy];
       const float ez_mm = a.ez[pm], ey_mm = a.ey[pm];
       const float ex_jm = use_jp ? a.ex[(long long)k * g.sxy + rowpm_x] : 0.f;
-      hy_m = upd_h(a.hy[pm], ch, exn_m - exk_m, ipz, ezk[0] - ez_mm, ipx_m);
-      hz_m = upd_h(a.hz[pm], ch, eyk[0] - ey_mm, ipx_m, ex_jm - exk_m, ipy);
+      float hy_o = a.hy[pm], hz_o = a.hz[pm];
+      if constexpr (PML != 0) {
+        float dum = 0.f;
+        if constexpr ((PML & 1) != 0) {
+          const int si = pml_si_h(pmp.ax[0], im);      // axis x: Hy += .., Hz -= ..
+          if (si >= 0)
+            pml_h_cell(hy_o, hz_o, (eyk[0] - ey_mm) * ipx_m, (ezk[0] - ez_mm) * ipx_m, pmp.ax[0],
+                       pml_q(g, 0, pmp.ax[0].ns_h, im, j, k, si), pmp.ax[0].kinv_h[im] - 1.f, pmp.ax[0].b_h[im],
+                       pmp.ax[0].c_h[im], ch, false); }
+        if constexpr ((PML & 2) != 0) {
+          const int si = pml_si_h(pmp.ax[1], j);       // axis y: Hz += ch (kv dEx/dy + p1)
+          if (si >= 0)
+            pml_h_cell(hz_o, dum, 0.f, (ex_jm - exk_m) * ipy, pmp.ax[1],
+                       pml_q(g, 1, pmp.ax[1].ns_h, im, j, k, si), pmp.ax[1].kinv_h[j] - 1.f, pmp.ax[1].b_h[j],
+                       pmp.ax[1].c_h[j], ch, false); }
+        if constexpr ((PML & 4) != 0) {
+          const int si = pml_si_h(pmp.ax[2], k);       // axis z: Hy -= ch (kv dEx/dz + p2)
+          if (si >= 0)
+            pml_h_cell(dum, hy_o, (exn_m - exk_m) * ipz, 0.f, pmp.ax[2],
+                       pml_q(g, 2, pmp.ax[2].ns_h, im, j, k, si), pmp.ax[2].kinv_h[k] - 1.f, pmp.ax[2].b_h[k],
+                       pmp.ax[2].c_h[k], ch, false); }
+      }
+      hy_m = upd_h(hy_o, ch, exn_m - exk_m, ipz, ezk[0] - ez_mm, ipx_m);
+      hz_m = upd_h(hz_o, ch, eyk[0] - ey_mm, ipx_m, ex_jm - exk_m, ipy);
     }
     // publish H^{n+1/2}_{x,z} of this row for the row above
     {
@@ -519,6 +798,68 @@ __global__ __launch_bounds__(LB) void fused_step_kernel(GridP g, FieldP a, Field
         if (wx || wall_z) ney = 0.f;
         if (wx || wall_y) nez = 0.f;
         ex[e] = nex; ey[e] = ney; ez[e] = nez;
+      }
+      if constexpr (PML != 0) {
+        // E-side CPML, axes in the order y, z, x (= launch_pml's E-side order):
+        //   E_{a+1} -= cb (kv d2 + p1),  E_{a+2} += cb (kv d1 + p2),  d1 = d_a H_{a+1}, d2 = d_a H_{a+2}
+        // axis y: E_z -= cb (kv dHx/dy + p1),  E_x += cb (kv dHz/dy + p2)
+        if constexpr ((PML & 2) != 0) {
+          if (sye >= 0) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+              const float d1 = (hzn[e] - hzj[e]) * idy;
+              const float d2 = (hxn[e] - hxj[e]) * idy;
+              const float p1 = eyc[1] * ey1[e] + eyc[2] * d2;
+              const float p2 = eyc[1] * ey2[e] + eyc[2] * d1;
+              ey1[e] = p1; ey2[e] = p2;
+              const bool wx = wall_x0 && (e == 0);
+              if (!wx) ez[e] -= cbz[e] * (eyc[0] * d2 + p1);       // E_z is tangential to the x wall
+              if (!wall_z) ex[e] += cbx[e] * (eyc[0] * d1 + p2);   // E_x is tangential to the z wall
+            }
+            stv<V>(pmp.ax[1].pe0 + qye, ey1);
+            stv<V>(pmp.ax[1].pe1 + qye, ey2);
+          }
+        }
+        // axis z: E_x -= cb (kv dHy/dz + p1),  E_y += cb (kv dHx/dz + p2)
+        if constexpr ((PML & 4) != 0) {
+          if (sze >= 0) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+              const float d1 = (hxn[e] - hxm[e]) * idz;
+              const float d2 = (hyn[e] - hym[e]) * idz;
+              const float p1 = ezc[1] * ez1[e] + ezc[2] * d2;
+              const float p2 = ezc[1] * ez2[e] + ezc[2] * d1;
+              ez1[e] = p1; ez2[e] = p2;
+              const bool wx = wall_x0 && (e == 0);
+              if (!wall_y) ex[e] -= cbx[e] * (ezc[0] * d2 + p1);   // E_x is tangential to the y wall
+              if (!wx) ey[e] += cby[e] * (ezc[0] * d1 + p2);       // E_y is tangential to the x wall
+            }
+            stv<V>(pmp.ax[2].pe0 + qze, ez1);
+            stv<V>(pmp.ax[2].pe1 + qze, ez2);
+          }
+        }
+        // axis x: E_y -= cb (kv dHz/dx + p1),  E_z += cb (kv dHy/dx + p2)
+        if constexpr ((PML & 1) != 0) {
+          if (xin_e) {
+#pragma unroll
+            for (int e = 0; e < V; ++e)
+              if (sxe[e] >= 0) {
+                const float hy_im = (e > 0) ? hyn[(e + V - 1) % V] : hyx;
+                const float hz_im = (e > 0) ? hzn[(e + V - 1) % V] : hzx;
+                const float d1 = (hyn[e] - hy_im) * idx[e];
+                const float d2 = (hzn[e] - hz_im) * idx[e];
+                const float kv = exk_[e] - 1.f;
+                const float p1 = exb[e] * ex1[e] + exc[e] * d2;
+                const float p2 = exb[e] * ex2[e] + exc[e] * d1;
+                ex1[e] = p1; ex2[e] = p2;
+                if (!wall_z) ey[e] -= cby[e] * (kv * d2 + p1);     // E_y is tangential to the z wall
+                if (!wall_y) ez[e] += cbz[e] * (kv * d1 + p2);     // E_z is tangential to the y wall
+              }
+#pragma unroll
+            for (int e = 0; e < V; ++e)
+              if (sxe[e] >= 0) { pmp.ax[0].pe0[qxe + sxe[e]] = ex1[e]; pmp.ax[0].pe1[qxe + sxe[e]] = ex2[e]; }
+          }
+        }
       }
       stv<V>(b.hx + p, hxn);
       stv<V>(b.hy + p, hyn);
