@@ -37,6 +37,16 @@ HBM_PEAK = 8.0e12            # B/s, MI355X spec (MI355X_MICROARCH.md)
 BYTES_PER_CELL_PASS = 36     # 3 reads curl source + 3 reads + 3 writes updated field, fp32
 
 
+# SURVEY.md 8(d) throughput variants (each adds to the previous one)
+WORKLOADS = {
+    "v0": "vacuum, PEC walls, curl stencil only",
+    "v1": "v0 + dielectric sphere r=100 cells eps=4 (per-component material indices)",
+    "v2": "v1 + CPML 12 layers x 6 faces (inside the cell count)",
+    "v3": "v2 + one Lorentz pole in the sphere (ADE)",
+    "v4": "v3 + closed FluxMonitor box (300 cells), running DFT at 3 frequencies",
+}
+
+
 def build_spec(n: int, n_steps: int, workload: str):
     import tidy3d_amd.schema as td
     from tidy3d_amd.discretize import discretize
@@ -46,19 +56,23 @@ def build_spec(n: int, n_steps: int, workload: str):
     pulse = td.GaussianPulse(freq0=2e14, fwidth=2e13)
     structures = []
     bspec = td.BoundarySpec.all_sides(td.PECBoundary())
-    if workload in ("v1", "v2", "v3"):
+    if workload in ("v1", "v2", "v3", "v4"):
         structures.append(td.Structure(geometry=td.Sphere(center=(0, 0, 0), radius=100 * dl * n / 512),
                                        medium=td.Medium(permittivity=4.0)))
-    if workload == "v3":
+    if workload in ("v3", "v4"):
         structures[0] = td.Structure(geometry=structures[0].geometry,
                                      medium=td.Lorentz(eps_inf=2.0, coeffs=[(2.0, 4e14, 2e13)]))
-    if workload in ("v2", "v3"):
+    if workload in ("v2", "v3", "v4"):
         size = ((n - 24) * dl,) * 3
         bspec = td.BoundarySpec.all_sides(td.PML(num_layers=12))
+    monitors = []
+    if workload == "v4":      # closed flux box around the sphere, running DFT at 3 frequencies
+        monitors.append(td.FluxMonitor(center=(0, 0, 0), size=(300 * dl * n / 512,) * 3, name="flux",
+                                       freqs=[1.8e14, 2.0e14, 2.2e14]))
     sim = td.Simulation(size=size, grid_spec=td.GridSpec.uniform(dl=dl), run_time=1e-12,
                         structures=structures,
                         sources=[td.PointDipole(center=(0, 0, 0), source_time=pulse, polarization="Ez")],
-                        monitors=[], boundary_spec=bspec, shutoff=0)
+                        monitors=monitors, boundary_spec=bspec, shutoff=0)
     disc = discretize(sim, n_steps=n_steps)
     disc.spec.decay_every = 0
     assert disc.spec.shape == (n, n, n), disc.spec.shape
@@ -91,7 +105,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", "--n", dest="n", type=int, default=512, help="cells per axis")
-    ap.add_argument("--workload", default="v0", choices=["v0", "v1", "v2", "v3"])
+    ap.add_argument("--workload", default="v0", choices=["v0", "v1", "v2", "v3", "v4"])
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--zchunk", type=int, default=0)
     ap.add_argument("--rows", type=int, default=0)
@@ -190,9 +204,8 @@ def main():
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"{args.workload}: vacuum {n}^3 Yee cells, PEC walls, Ez point dipole "
-                               "(GaussianPulse 200 THz), random +-1e-3 initial fields, curl stencil only"
-                   if args.workload == "v0" else f"{args.workload} {n}^3",
+        "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]}; {n}^3 Yee cells, Ez point dipole "
+                               "(GaussianPulse 200 THz), random +-1e-3 initial fields",
                    "grid": [n, n, n], "parallelism": f"z-slab x{world}",
                    "bytes_per_cell_step": 2 * BYTES_PER_CELL_PASS,
                    "roofline_mcells_per_gpu": HBM_PEAK / (2 * BYTES_PER_CELL_PASS) / 1e6},

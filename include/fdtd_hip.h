@@ -163,7 +163,8 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
 int fdtd_get_stats(FdtdSolver* h, FdtdStats* out);
 /* tuning knobs that may change between runs of one handle (bench A/B without re-upload) */
 enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_ROWS = 3, FDTD_OPT_XCD_REMAP = 4,
-       FDTD_OPT_FUSED_LB = 5, FDTD_OPT_PML_FUSED = 6 /* axis bit mask: 0 (default), 6, 7 */ };
+       FDTD_OPT_FUSED_LB = 5, FDTD_OPT_PML_FUSED = 6 /* axis bit mask: 0 (default), 6, 7 */,
+       FDTD_OPT_BND_PLANES = 7 /* planes per boundary chunk of the fused z-slab schedule, 0 = auto */ };
 int fdtd_set_option(FdtdSolver* h, int key, int value);
 int fdtd_reset(FdtdSolver* h);      /* zero fields, auxiliaries, monitors and the step counter */
 

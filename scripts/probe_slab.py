@@ -1,0 +1,69 @@
+"""Per-rank timeline proxy for the N-GPU strong-scaling run: one 512 x 512 x (512/N) slab on ONE GPU,
+periodic in z, with the RCCL ghost exchange looped back to the same rank (HipEngine force_comm) —
+every kernel, event and Send/Recv of the multi-rank schedule runs, only the wire is missing.
+Prints one JSON line per (N, mode)."""
+import json
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import tidy3d_amd.schema as td
+from tidy3d_amd import lib as L
+from tidy3d_amd.discretize import discretize
+from tidy3d_amd.engine import HipEngine
+
+
+def spec_for(n, nz, steps):
+    dl = 0.05
+    pulse = td.GaussianPulse(freq0=2e14, fwidth=2e13)
+    b = td.BoundarySpec(x=td.Boundary(minus=td.PECBoundary(), plus=td.PECBoundary()),
+                        y=td.Boundary(minus=td.PECBoundary(), plus=td.PECBoundary()),
+                        z=td.Boundary.periodic())
+    sim = td.Simulation(size=(n * dl, n * dl, nz * dl), grid_spec=td.GridSpec.uniform(dl=dl), run_time=1e-12,
+                        sources=[td.PointDipole(center=(0, 0, 0), source_time=pulse, polarization="Ez")],
+                        monitors=[], boundary_spec=b, shutoff=0)
+    sp = discretize(sim, n_steps=steps).spec
+    sp.decay_every = 0
+    return sp
+
+
+def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--slabs", default="8,4,2")
+    ap.add_argument("--modes", default="single_fused,comm_fused,comm_two_pass")
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--zchunk", type=int, default=0)
+    ap.add_argument("--bnd", type=int, default=0)
+    args = ap.parse_args()
+    n = 512
+    steps, warm = args.steps, 30
+    all_modes = {"single_fused": dict(variant=L.VARIANT_FUSED),
+                 "comm_fused": dict(variant=L.VARIANT_FUSED, force_comm=True),
+                 "comm_two_pass": dict(variant=L.VARIANT_ZMARCH, force_comm=True)}
+    for ngpu in [int(x) for x in args.slabs.split(",")]:
+        nz = n // ngpu
+        sp = spec_for(n, nz, steps + warm + 8)
+        for mode in args.modes.split(","):
+            kw = dict(all_modes[mode], z_chunk=args.zchunk)
+            with HipEngine(sp, **kw) as e:
+                if kw.get("force_comm"):
+                    e.comm_init(e.unique_id())
+                if args.bnd:
+                    e.set_option(L.OPT_BND_PLANES, args.bnd)
+                rng = np.random.default_rng(0)
+                for c in range(6):
+                    e.set_field(c, rng.uniform(-1e-3, 1e-3, (nz, n, n)).astype(np.float32))
+                e.run(warm)
+                t0 = time.perf_counter()
+                e.run(steps)
+                dt = time.perf_counter() - t0
+                print(json.dumps({"slab_of": ngpu, "nz": nz, "mode": mode, "zchunk": args.zchunk, "bnd": args.bnd, "ms_per_step": dt / steps * 1e3,
+                                  "ideal_ms": 1.244 / ngpu,
+                                  "implied_speedup_vs_1gpu": 1.244 / (dt / steps * 1e3)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

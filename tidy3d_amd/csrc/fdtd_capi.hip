@@ -58,6 +58,7 @@ struct PointSrc {
 struct Tfsf {
   int n_aux = 0, src_cell = 0;
   float *ae = nullptr, *be = nullptr, *ah = nullptr, *bh = nullptr, *e1 = nullptr, *h1 = nullptr, *wave = nullptr;
+  float *e1c = nullptr, *h1c = nullptr;   // replica advanced on the comm stream (pipelined z-slab schedule)
   long long n_steps = 0;
   long long n_e = 0, n_h = 0;
   int32_t *e_comp = nullptr, *h_comp = nullptr, *e_aux = nullptr, *h_aux = nullptr;
@@ -124,7 +125,7 @@ struct FdtdSolver {
   // extra live registers drop the sweep from 3 to 2 (mask 6) or 1 (mask 7) waves per SIMD, which
   // costs more (+0.41 ms / +3.0 ms) than the slab kernels it removes (0.22 ms / 0.45 ms) -> default 0.
   int pml_fused = 0;
-  int fused_multi_mode = 0;          // ghost planes currently follow the fused z-slab protocol
+  int bnd_planes = 0;                // fused z-slab schedule: planes per boundary chunk (0 = heuristic)
   int rows = 4;
   // RCCL
   ncclComm_t comm = nullptr;
@@ -294,14 +295,16 @@ bool any_pml(const FdtdSolver* h) {
   return false;
 }
 
-int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pml_inside = 0) {
+int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pml_inside = 0, int k2beg = 0,
+                       int k2end = 0) {
   if (kend <= kbeg) return 0;
   const GridP& g = h->g;
   if (ensure_second_set(h)) return -1;
   const int R = h->rows_f;
   const int zc = h->zchunk_f;
   dim3 block(64, R + 1, 1);
-  const int nbx = (g.nx + 255) / 256, nby = (g.ny + R - 1) / R, nbz = (kend - kbeg + zc - 1) / zc;
+  const int nbx = (g.nx + 255) / 256, nby = (g.ny + R - 1) / R, nbz1 = (kend - kbeg + zc - 1) / zc;
+  const int nbz = nbz1 + (k2end > k2beg ? (k2end - k2beg + zc - 1) / zc : 0);
   const int total = nbx * nby * nbz;
   const int remap = h->xcd_remap ? 1 : 0;
   dim3 grid(remap ? ((total + 7) / 8) * 8 : total, 1, 1);
@@ -317,7 +320,7 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pm
   const PmlP pm = pml_params(h);
 #define FDTD_LAUNCH_FUSED(MATV, LBV, PMLV)                                                            \
   hipLaunchKernelGGL((fused_step_kernel<MATV, LBV, PMLV>), grid, block, shmem, st, g, h->f, h->f2, s, m, kbeg, \
-                     kend, zc, pmc, nbx, nby, nbz, remap, pm)
+                     kend, zc, pmc, nbx, nby, nbz, remap, pm, nbz1, k2beg, k2end)
   if (pml_inside == 7) {    // CPML of all axes folded into the sweep (256- and 512-thread workgroups)
     if (h->mat4) { if (lb == 256) FDTD_LAUNCH_FUSED(true, 256, 7); else FDTD_LAUNCH_FUSED(true, 512, 7); }
     else { if (lb == 256) FDTD_LAUNCH_FUSED(false, 256, 7); else FDTD_LAUNCH_FUSED(false, 512, 7); }
@@ -414,7 +417,8 @@ void launch_pml(FdtdSolver* h, bool e_side, int kbeg, int kend, hipStream_t st, 
   }
 }
 
-void launch_sources(FdtdSolver* h, bool e_side, long long n, int kbeg, int kend, hipStream_t st) {
+void launch_sources(FdtdSolver* h, bool e_side, long long n, int kbeg, int kend, hipStream_t st, bool replica = false) {
+  if (kend <= kbeg) return;
   const long long zlo = (long long)kbeg * h->g.sxy, zhi = (long long)kend * h->g.sxy;
   const int off = e_side ? 0 : 3;
   float *f0 = field_ptr(h, off), *f1 = field_ptr(h, off + 1), *f2 = field_ptr(h, off + 2);
@@ -424,12 +428,12 @@ void launch_sources(FdtdSolver* h, bool e_side, long long n, int kbeg, int kend,
       if (t.n_e)
         hipLaunchKernelGGL(tfsf_corr_kernel, dim3(nblk(t.n_e)), dim3(256), 0, st, f0, f1, f2,
                            (const int32_t*)t.e_comp, (const uint32_t*)t.e_cell, (const float*)t.e_w,
-                           (const int32_t*)t.e_aux, (const float*)t.h1, t.n_e, zlo, zhi);
+                           (const int32_t*)t.e_aux, (const float*)(replica ? t.h1c : t.h1), t.n_e, zlo, zhi);
     } else {
       if (t.n_h)
         hipLaunchKernelGGL(tfsf_corr_kernel, dim3(nblk(t.n_h)), dim3(256), 0, st, f0, f1, f2,
                            (const int32_t*)t.h_comp, (const uint32_t*)t.h_cell, (const float*)t.h_w,
-                           (const int32_t*)t.h_aux, (const float*)t.e1, t.n_h, zlo, zhi);
+                           (const int32_t*)t.h_aux, (const float*)(replica ? t.e1c : t.e1), t.n_h, zlo, zhi);
     }
   }
   for (PointSrc& s : h->psrc) {
@@ -446,19 +450,22 @@ void launch_sources(FdtdSolver* h, bool e_side, long long n, int kbeg, int kend,
 }
 
 // the 1-D incident grids advance once per phase on the main stream (not z-range dependent)
-void advance_tfsf_aux(FdtdSolver* h, bool e_side, long long n, hipStream_t st) {
+void advance_tfsf_aux(FdtdSolver* h, bool e_side, long long n, hipStream_t st, bool replica = false) {
   for (Tfsf& t : h->tfsf) {
     if (n >= t.n_steps) continue;
+    float* e1 = replica ? t.e1c : t.e1;
+    float* h1 = replica ? t.h1c : t.h1;
     if (e_side)
-      hipLaunchKernelGGL(tfsf_aux_e_kernel, dim3(1), dim3(1024), 0, st, t.e1, (const float*)t.h1,
+      hipLaunchKernelGGL(tfsf_aux_e_kernel, dim3(1), dim3(1024), 0, st, e1, (const float*)h1,
                          (const float*)t.ae, (const float*)t.be, t.n_aux, t.src_cell, (const float*)t.wave, n);
     else
-      hipLaunchKernelGGL(tfsf_aux_h_kernel, dim3(nblk(t.n_aux)), dim3(256), 0, st, t.h1, (const float*)t.e1,
+      hipLaunchKernelGGL(tfsf_aux_h_kernel, dim3(nblk(t.n_aux)), dim3(256), 0, st, h1, (const float*)e1,
                          (const float*)t.ah, (const float*)t.bh, t.n_aux);
   }
 }
 
 void launch_ade(FdtdSolver* h, int kbeg, int kend, hipStream_t st) {
+  if (kend <= kbeg) return;
   const long long zlo = (long long)kbeg * h->g.sxy, zhi = (long long)kend * h->g.sxy;
   for (AdeGroup& a : h->ade)
     hipLaunchKernelGGL(ade_kernel, dim3(nblk(a.n)), dim3(256), 0, st, field_ptr(h, a.comp),
@@ -556,6 +563,33 @@ int exchange_fused_e(FdtdSolver* h, hipStream_t st) {
     NCCLCHK(h, ncclSend(h->f.ex, pc, ncclFloat, lo, h->comm, st));
     NCCLCHK(h, ncclSend(h->f.ey, pc, ncclFloat, lo, h->comm, st));
     for (float* p : e3) NCCLCHK(h, ncclRecv(p - pc, pc, ncclFloat, lo, h->comm, st));
+  }
+  if (has_hi) {
+    NCCLCHK(h, ncclRecv(h->f.ex + (long long)nz * pc, pc, ncclFloat, hi, h->comm, st));
+    NCCLCHK(h, ncclRecv(h->f.ey + (long long)nz * pc, pc, ncclFloat, hi, h->comm, st));
+  }
+  NCCLCHK(h, ncclGroupEnd());
+  return 0;
+}
+
+// Pipelined z-slab schedule: ONE exchange per step carries everything the neighbours' boundary
+// chunks need for the next sweep — up: E_x,E_y,E_z and the pre-corrected H_x,H_y of my top plane
+// (-> upper ghost(-1)); down: E_x,E_y of my bottom plane (-> lower ghost(nz)).
+int exchange_fused_all(FdtdSolver* h, hipStream_t st) {
+  const long long pc = plane_cells(h);
+  const int nz = h->g.nz;
+  const bool has_lo = h->cfg.bc[4] == FDTD_BC_NEIGHBOR, has_hi = h->cfg.bc[5] == FDTD_BC_NEIGHBOR;
+  if (!has_lo && !has_hi) return 0;
+  const int lo = (h->rank - 1 + h->n_ranks) % h->n_ranks, hi = (h->rank + 1) % h->n_ranks;
+  float* up5[5] = {h->f.ex, h->f.ey, h->f.ez, h->f.hx, h->f.hy};
+  // posting order mirrors the peer's (see exchange_fused_e): [to-hi][to-lo] <-> [from-lo][from-hi]
+  NCCLCHK(h, ncclGroupStart());
+  if (has_hi)
+    for (float* p : up5) NCCLCHK(h, ncclSend(p + (long long)(nz - 1) * pc, pc, ncclFloat, hi, h->comm, st));
+  if (has_lo) {
+    NCCLCHK(h, ncclSend(h->f.ex, pc, ncclFloat, lo, h->comm, st));
+    NCCLCHK(h, ncclSend(h->f.ey, pc, ncclFloat, lo, h->comm, st));
+    for (float* p : up5) NCCLCHK(h, ncclRecv(p - pc, pc, ncclFloat, lo, h->comm, st));
   }
   if (has_hi) {
     NCCLCHK(h, ncclRecv(h->f.ex + (long long)nz * pc, pc, ncclFloat, hi, h->comm, st));
@@ -666,7 +700,15 @@ int fdtd_create(const FdtdConfig* cfg, FdtdSolver** out) {
     }
   }
   if (!rc && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) rc = fail(nullptr, "hipStreamCreate failed");
-  if (!rc && hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(nullptr, "hipStreamCreate failed");
+  // The comm stream carries the ghost exchanges and the boundary chunks.  High priority: its few
+  // workgroups are dispatched ahead of the interior sweep's, otherwise the RCCL Send/Recv kernel
+  // queues behind a full machine (measured: 138 us instead of 30 us, profiles/r01h_slab_timeline.txt).
+  if (!rc) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; }
+    if (hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, greatest) != hipSuccess)
+      rc = fail(nullptr, "hipStreamCreate failed");
+  }
   if (!rc) {
     hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
     hipEventCreateWithFlags(&h->ev_h_int, hipEventDisableTiming);
@@ -847,6 +889,7 @@ int fdtd_add_tfsf(FdtdSolver* h, int n_aux, const float* ae, const float* be, co
   if (dev_upload(h, &t.ae, ae, (size_t)n_aux + 1) || dev_upload(h, &t.be, be, (size_t)n_aux + 1) ||
       dev_upload(h, &t.ah, ah, (size_t)n_aux) || dev_upload(h, &t.bh, bh, (size_t)n_aux) ||
       dev_alloc(h, &t.e1, (size_t)n_aux + 1) || dev_alloc(h, &t.h1, (size_t)n_aux) ||
+      dev_alloc(h, &t.e1c, (size_t)n_aux + 1) || dev_alloc(h, &t.h1c, (size_t)n_aux) ||
       dev_upload(h, &t.wave, wave, (size_t)n_steps))
     return -1;
   if (n_e && (dev_upload(h, &t.e_comp, e_comp, (size_t)n_e) || dev_upload(h, &t.e_cell, e_index, (size_t)n_e) ||
@@ -919,7 +962,6 @@ int fdtd_set_field(FdtdSolver* h, int comp, const float* host, size_t bytes) {
   // keep single-slab ghost planes consistent with the new interior
   if (h->comm == nullptr) { fill_ghost_h(h, h->stream); fill_ghost_e(h, h->stream); fill_ghost_fused(h, h->stream); HIPCHK(h, hipStreamSynchronize(h->stream)); }
   else if (comp == 0 || comp == 1 || comp == 3 || comp == 4) {
-    h->fused_multi_mode = 0;      // the next fdtd_run re-establishes the fused ghost protocol if it uses it
     // with a communicator the ghost planes come from the neighbour: do one exchange now
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (exchange(h, comp < 3, h->comm_stream)) return -1;
@@ -1014,14 +1056,66 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   if (multi && h->cfg.variant == FDTD_VARIANT_FUSED && !(fused_ok && nz >= 4))
     return fail(h, "fdtd_run: the fused z-slab schedule needs nx %% 4 == 0 and >= 4 planes per slab");
   const bool fused_multi = multi && h->cfg.variant == FDTD_VARIANT_FUSED;
-  if (fused_multi != (h->fused_multi_mode != 0)) {
-    // ghost planes were prepared for the other scheme (fdtd_set_field): refresh them
-    h->fused_multi_mode = fused_multi ? 1 : 0;
-    if (fused_multi) {
-      HIPCHK(h, hipStreamSynchronize(st));
-      if (exchange_fused_e(h, cs)) return -1;
-      HIPCHK(h, hipStreamSynchronize(cs));
+  // ---- pipelined fused z-slab schedule (fused_multi) -------------------------------------------
+  // Per step, with  b_lo / b_hi  boundary planes next to a neighbour face:
+  //   cs: sweep [0,b_lo) + [nz-b_hi,nz)  -> E-side corrections and next step's H-side pre-corrections
+  //       of those planes -> ONE exchange (exchange_fused_all), which overlaps the interior sweep
+  //   st: sweep [b_lo, nz-b_hi)          -> the same corrections of the interior planes
+  // The next boundary sweep needs this exchange and the interior planes next to it (ev_e_int); the
+  // next interior sweep needs only the boundary planes next to it (ev_e_bnd, recorded BEFORE the
+  // exchange).  Invariant at the top of a step ("primed"): monitors pre-recorded, H-side
+  // pre-corrections applied on all planes, ghost planes in flight on cs.  Steps that record
+  // monitors, check the field decay or end the run use a joined tail on st instead and re-prime.
+  int b_lo = 0, b_hi = 0;
+  if (fused_multi) {
+    // boundary chunk = one z-chunk per neighbour face, a quarter slab at most (measured on the
+    // 512 x 512 x 64 proxy, profiles/r01h_slab_timeline.txt: 16 planes 0.181 ms, 8: 0.190, 4: 0.187)
+    int zb = h->bnd_planes > 0 ? h->bnd_planes : std::min(h->zchunk_f, nz / 4);
+    zb = std::max(1, std::min(zb, nz / 2));
+    b_lo = nb_lo ? zb : 0;
+    b_hi = nb_hi ? zb : 0;
+    // the z-CPML differentiates along z: its slabs must stay clear of the boundary chunks (whose
+    // corrections run on the other stream and before the ghost planes of the new step arrive)
+    const PmlAxisDev& pz = h->pml[2];
+    if (nb_hi && pz.n_lo > 0) b_hi = std::min(b_hi, nz - pz.n_lo - 1);
+    if (nb_lo && pz.n_hi > 0) b_lo = std::min(b_lo, nz - pz.n_hi - 1);
+    if ((nb_hi && b_hi < 1) || (nb_lo && b_lo < 1))
+      return fail(h, "fdtd_run: the fused z-slab schedule needs at least 2 planes between a slab cut and the z-PML");
+  }
+  bool primed = false;
+  auto e_post = [&](long long n, int k0, int k1, hipStream_t s, bool replica) {
+    launch_pml(h, true, k0, k1, s);
+    launch_sources(h, true, n, k0, k1, s, replica);
+    launch_ade(h, k0, k1, s);
+  };
+  auto h_pre = [&](long long n, int k0, int k1, hipStream_t s, bool replica) {
+    launch_sources(h, false, n, k0, k1, s, replica);
+    launch_pml(h, false, k0, k1, s);
+  };
+  auto rec_at = [&](long long n) {
+    for (Monitor& m : h->mons) if (m.next < m.steps.size() && m.steps[m.next] == n) return true;
+    return false;
+  };
+  // all planes on st: monitors of step n, H-side pre-corrections, then the exchange on cs
+  auto prime = [&](long long n) -> int {
+    if (rec_at(n)) record_monitors(h, n, false, st);
+    h_pre(n, 0, nz, st, false);
+    advance_tfsf_aux(h, false, n, st, false);
+    advance_tfsf_aux(h, false, n, st, true);
+    HIPCHK(h, hipEventRecord(h->ev_e_int, st));
+    HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
+    HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
+    if (exchange_fused_all(h, cs)) return -1;
+    primed = true;
+    return 0;
+  };
+  if (fused_multi) {
+    // the comm-stream replica of the 1-D incident grids starts from the main one
+    for (Tfsf& t : h->tfsf) {
+      HIPCHK(h, hipMemcpyAsync(t.e1c, t.e1, ((size_t)t.n_aux + 1) * 4, hipMemcpyDeviceToDevice, st));
+      HIPCHK(h, hipMemcpyAsync(t.h1c, t.h1, (size_t)t.n_aux * 4, hipMemcpyDeviceToDevice, st));
     }
+    if (ensure_second_set(h)) return -1;
   }
   // Two-stream schedule of one step (st = main stream, cs = comm stream):
   //   cs: [H top plane] -> send/recv H -> [E bottom plane] -> send/recv E      (boundary planes first)
@@ -1035,41 +1129,55 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   int64_t done = 0;
   for (; done < n_steps; ++done) {
     const long long n = h->step;
-    bool rec = false;
-    for (Monitor& m : h->mons) rec = rec || (m.next < m.steps.size() && m.steps[m.next] == n);
+    const bool rec = !fused_multi && rec_at(n);
     if (rec && multi) {
       HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
       HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
     }
     if (rec) record_monitors(h, n, false, st);
     if (fused_multi) {
-      // Two streams, no host sync.  cs: [E exchange of step n-1] -> H exchange -> bottom + top chunks;
-      // st: H pre-corrections -> interior chunks -> (join) -> E post-corrections.
-      // boundary chunks: thin enough that [exchanges + boundary sweeps] on the comm stream take about as
-      // long as the interior sweep on the main stream (at 8 x 64 planes: 2 x 8 planes vs 48 planes)
-      const int zb = std::max(1, std::min(h->zchunk_f, nz / 8));
-      launch_sources(h, false, n, 0, nz, st);
-      launch_pml(h, false, 0, nz, st);
-      advance_tfsf_aux(h, false, n, st);
-      HIPCHK(h, hipEventRecord(h->ev_h_int, st));                 // pre-corrections done
-      HIPCHK(h, hipStreamWaitEvent(cs, h->ev_h_int, 0));
-      if (exchange_fused_h(h, cs)) return -1;                     // (in order after the last E exchange)
-      if (ensure_second_set(h)) return -1;
-      if (launch_fused_range(h, 0, zb, cs)) return -1;            // needs ghost(-1): E (last exchange), H (just now)
-      if (launch_fused_range(h, nz - zb, nz, cs)) return -1;      // needs ghost(nz) E (last exchange)
-      HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
-      if (launch_fused_range(h, zb, nz - zb, st)) return -1;      // interior: no ghost planes involved
-      HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
-      swap_sets(h);
-      if (rec) record_monitors(h, n, true, st);
-      launch_pml(h, true, 0, nz, st);
-      launch_sources(h, true, n, 0, nz, st);
-      launch_ade(h, 0, nz, st);
-      advance_tfsf_aux(h, true, n, st);
-      HIPCHK(h, hipEventRecord(h->ev_e_int, st));                 // E^{n+1} final
+      if (!primed && prime(n)) return -1;
+      const bool decay_step = h->decay_every > 0 && ((n + 1) % h->decay_every) == 0;
+      const bool last = (done + 1 == n_steps) || decay_step;
+      // sweeps: boundary chunks (one launch) on cs, interior on st
       HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
-      if (exchange_fused_e(h, cs)) return -1;                     // overlaps the next step's pre-corrections + interior
-      HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
+      if (b_lo > 0 && b_hi > 0) { if (launch_fused_range(h, 0, b_lo, cs, 0, nz - b_hi, nz)) return -1; }
+      else if (b_lo > 0) { if (launch_fused_range(h, 0, b_lo, cs)) return -1; }
+      else if (b_hi > 0) { if (launch_fused_range(h, nz - b_hi, nz, cs)) return -1; }
+      HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
+      HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
+      if (launch_fused_range(h, b_lo, nz - b_hi, st)) return -1;
+      swap_sets(h);
+      const bool rec_post = rec_at(n);
+      if (rec_post || last || rec_at(n + 1)) {
+        // joined tail: everything after the sweeps on st
+        HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
+        if (rec_post) record_monitors(h, n, true, st);
+        e_post(n, 0, nz, st, false);
+        advance_tfsf_aux(h, true, n, st, false);
+        advance_tfsf_aux(h, true, n, st, true);
+        primed = false;
+        if (!last && prime(n + 1)) return -1;
+        if (last) {           // leave both streams joined; the next step (or run) primes again
+          HIPCHK(h, hipEventRecord(h->ev_e_int, st));
+          HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
+          HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
+        }
+      } else {
+        e_post(n, 0, b_lo, cs, true);
+        e_post(n, nz - b_hi, nz, cs, true);
+        advance_tfsf_aux(h, true, n, cs, true);
+        h_pre(n + 1, 0, b_lo, cs, true);
+        h_pre(n + 1, nz - b_hi, nz, cs, true);
+        advance_tfsf_aux(h, false, n + 1, cs, true);
+        HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
+        if (exchange_fused_all(h, cs)) return -1;
+        e_post(n, b_lo, nz - b_hi, st, false);
+        advance_tfsf_aux(h, true, n, st, false);
+        h_pre(n + 1, b_lo, nz - b_hi, st, false);
+        advance_tfsf_aux(h, false, n + 1, st, false);
+        HIPCHK(h, hipEventRecord(h->ev_e_int, st));
+      }
       h->step = n + 1;
     } else if (fused) {
       // H-side corrections are additive: pre-apply them to H^{n-1/2}; E-side ones follow the sweep.
@@ -1217,6 +1325,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_ROWS: if (value < 1 || value > 15) break; h->rows = value > 8 ? 8 : value; h->rows_f = value; return 0;
     case FDTD_OPT_XCD_REMAP: h->xcd_remap = value != 0; return 0;
     case FDTD_OPT_PML_FUSED: h->pml_fused = value & 7; return 0;
+    case FDTD_OPT_BND_PLANES: h->bnd_planes = value > 0 ? value : 0; return 0;
     case FDTD_OPT_FUSED_LB: if (value != 0 && value != 256 && value != 512 && value != 1024) break; h->fused_lb = value; return 0;
     default: break;
   }

@@ -376,7 +376,8 @@ __device__ __forceinline__ void pml_h_vec(float (&h1)[4], float (&h2)[4], const 
 template <bool MAT, int LB, int PML>   // PML: bit a set = CPML of axis a runs inside the sweep
 __global__ __launch_bounds__(LB) void fused_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
                                                           int kbeg, int kend, int zchunk, int pmc_z0,
-                                                          int nbx, int nby, int nbz, int xcd_remap, PmlP pm) {
+                                                          int nbx, int nby, int nbz, int xcd_remap, PmlP pm,
+                                                          int nbz1, int k2beg, int k2end) {
   constexpr int V = 4;
   // 1-D launch; logical tile (bx, by, bz) with by fastest.  XCD-aware remap: hardware block L runs
   // on XCD L % 8 (observed dispatch order, used for speed only), so XCD x is handed the contiguous
@@ -409,8 +410,11 @@ __global__ __launch_bounds__(LB) void fused_step_kernel(GridP g, FieldP a, Field
   bool row_ok = (j >= 0) && (j < g.ny);
   if (j < 0 && per_y) { j = g.ny - 1; row_ok = true; }
   const bool act = row_ok && (i0 < g.nx);
-  const int k0 = kbeg + tile_z * zchunk;
-  const int k1 = min(k0 + zchunk, kend);
+  // z tiles [0, nbz1) march through [kbeg, kend), tiles [nbz1, nbz) through a second plane range
+  // [k2beg, k2end): the bottom and top boundary chunks of a z-slab go out as ONE launch
+  const bool second = tile_z >= nbz1;
+  const int k0 = second ? k2beg + (tile_z - nbz1) * zchunk : kbeg + tile_z * zchunk;
+  const int k1 = min(k0 + zchunk, second ? k2end : kend);
   const float ch = g.ch;
   const bool last_x = (i0 + V >= g.nx);
   const bool first_x = (i0 == 0);

@@ -121,7 +121,11 @@ class HipEngine:
         cuts = [z0 for z0, _ in split_slabs(nz, n_ranks)][1:]
         if spec.bc[2][0] == BC_PERIODIC and n_ranks >= 1:
             cuts = cuts + [0]
-        return all(n_lo <= z <= nz - n_hi for z in cuts) or (n_lo == 0 and n_hi == 0)
+        # ... and leave two planes between a cut and the z-PML: the boundary chunk next to a cut
+        # is corrected on the comm stream before the neighbour's new planes arrive (fdtd_run)
+        lo = n_lo + 2 if n_lo else 0
+        hi = nz - n_hi - 2 if n_hi else nz
+        return all(lo <= z <= hi for z in cuts)
 
     # ------------------------------------------------------------------ setup
     def _chk(self, st, what):
