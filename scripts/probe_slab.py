@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--zchunk", type=int, default=0)
     ap.add_argument("--bnd", type=int, default=0)
+    ap.add_argument("--rows", type=int, default=0)
     args = ap.parse_args()
     n = 512
     steps, warm = args.steps, 30
@@ -53,6 +54,8 @@ def main():
                     e.comm_init(e.unique_id())
                 if args.bnd:
                     e.set_option(L.OPT_BND_PLANES, args.bnd)
+                if args.rows:
+                    e.set_option(L.OPT_ROWS, args.rows)
                 rng = np.random.default_rng(0)
                 for c in range(6):
                     e.set_field(c, rng.uniform(-1e-3, 1e-3, (nz, n, n)).astype(np.float32))
@@ -60,7 +63,7 @@ def main():
                 t0 = time.perf_counter()
                 e.run(steps)
                 dt = time.perf_counter() - t0
-                print(json.dumps({"slab_of": ngpu, "nz": nz, "mode": mode, "zchunk": args.zchunk, "bnd": args.bnd, "ms_per_step": dt / steps * 1e3,
+                print(json.dumps({"slab_of": ngpu, "nz": nz, "mode": mode, "zchunk": args.zchunk, "bnd": args.bnd, "rows": args.rows, "ms_per_step": dt / steps * 1e3,
                                   "ideal_ms": 1.244 / ngpu,
                                   "implied_speedup_vs_1gpu": 1.244 / (dt / steps * 1e3)}), flush=True)
 
