@@ -74,3 +74,37 @@ def test_real_tidy3d_simulation_passes_through_the_boundary(td_ref):
     # source waveform of the real object
     t = disc.tmesh[::50]
     np.testing.assert_allclose(mirror.sources[0].source_time.amp_time(t), sim.sources[0].source_time.amp_time(t), rtol=1e-12)
+
+
+def test_permittivity_monitor_matches_reference_epsilon(td_ref):
+    """PermittivityMonitor data == the reference's ``Simulation.epsilon`` recipe (ref
+    simulation.py:1105-1241) at the Ex / Ey / Ez Yee nodes of the monitor sub-grid (staircase:
+    ``subpixel=False``), complex dispersion and conductivity included."""
+    from tidy3d_amd.data import assemble
+    from tidy3d_amd.discretize import discretize
+    from tidy3d_amd.web import _as_mirror
+    td = td_ref
+    freqs = [2.0e14, 3.1e14]
+    mon = td.PermittivityMonitor(center=(0.1, 0.05, -0.1), size=(1.6, 0.9, 0.0), freqs=freqs, name="eps")
+    vol = td.PermittivityMonitor(center=(-0.5, 0.2, 0.0), size=(0.5, 0.6, 0.3), freqs=freqs[:1], name="eps3")
+    sim = _sim(td).updated_copy(monitors=[mon, vol], subpixel=False)
+    mirror, _ = _as_mirror(sim)
+    disc = discretize(mirror, n_steps=4)
+    data = assemble(disc, {})
+    for m_ref in (mon, vol):
+        got = data[m_ref.name]
+        for comp, key in (("eps_xx", "Ex"), ("eps_yy", "Ey"), ("eps_zz", "Ez")):
+            arr = got.field_components[comp]
+            for i_f, f in enumerate(m_ref.freqs):
+                # the loader stubs xarray, so Simulation.epsilon cannot return data here: evaluate
+                # its recipe (epsilon_on_grid, ref simulation.py:1196-1241) with the reference's own
+                # sub-grid, geometries and media instead
+                c = sim.discretize_monitor(m_ref)[key]
+                X, Y, Z = np.meshgrid(c.x, c.y, c.z, indexing="ij")
+                ref = np.full(X.shape, sim.medium.eps_model(f), dtype=complex)
+                for st in sim.structures:
+                    ref[st.geometry.inside(X, Y, Z)] = st.medium.eps_model(f)
+                np.testing.assert_allclose(arr.coords["x"], c.x, atol=1e-12)
+                np.testing.assert_allclose(arr.coords["y"], c.y, atol=1e-12)
+                np.testing.assert_allclose(arr.coords["z"], c.z, atol=1e-12)
+                np.testing.assert_allclose(arr.values[..., i_f], ref, rtol=1e-12)

@@ -74,6 +74,17 @@ def to_tidy3d(sim_data: SimulationData, td_simulation=None):
         elif isinstance(d, FluxTimeData):
             out.append(td.FluxTimeData(monitor=mon, flux=td.FluxTimeDataArray(
                 d.flux.values, coords={"t": d.flux.coords["t"]})))
+        elif type(d).__name__ == "PermittivityData":
+            comps = {k: td.ScalarFieldDataArray(v.values, coords={dim: v.coords[dim] for dim in v.dims})
+                     for k, v in d.field_components.items()}
+            out.append(td.PermittivityData(monitor=mon, symmetry=(0, 0, 0), symmetry_center=td_simulation.center,
+                                           grid_expanded=td_simulation.discretize_monitor(mon), **comps))
+        elif type(d).__name__ == "ModeData":
+            out.append(td.ModeData(
+                monitor=mon,
+                amps=td.ModeAmpsDataArray(d.amps.values, coords={dim: d.amps.coords[dim] for dim in d.amps.dims}),
+                n_complex=td.ModeIndexDataArray(d.n_complex.values,
+                                                coords={dim: d.n_complex.coords[dim] for dim in d.n_complex.dims})))
         else:
             raise Tidy3dNotImplementedError(f"no tidy3d conversion for {type(d).__name__}")
     return td.SimulationData(simulation=td_simulation, data=tuple(out), log=sim_data.log,

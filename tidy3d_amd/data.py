@@ -208,6 +208,20 @@ class FluxData:
 
 
 @dataclass
+class PermittivityData:
+    """ref monitor_data.py:1190-1222: eps_xx / eps_yy / eps_zz (x, y, z, f) at the Ex / Ey / Ez
+    Yee locations inside the monitor."""
+    monitor: object
+    eps_xx: DataArray = None
+    eps_yy: DataArray = None
+    eps_zz: DataArray = None
+
+    @property
+    def field_components(self) -> Dict[str, DataArray]:
+        return {"eps_xx": self.eps_xx, "eps_yy": self.eps_yy, "eps_zz": self.eps_zz}
+
+
+@dataclass
 class FluxTimeData:
     """ref monitor_data.py:1992 — flux(t) float32."""
     monitor: object
@@ -337,6 +351,48 @@ def _field_container(cls, mon, spec: SolverSpec, fp: FieldPlan, raw: np.ndarray,
                grid_expanded=_grid_expanded(spec, fp), **kw)
 
 
+def medium_eps_table(spec: SolverSpec, freq: float) -> np.ndarray:
+    """Complex eps_r(freq) per entry of ``spec.media`` (ref medium.py:1016-1038 conductivity term,
+    :2900-2913 pole-residue sum; PEC -> pec_val, ref constants.py:64)."""
+    from .constants import EPSILON_0
+    w = 2 * np.pi * freq
+    tab = []
+    for med in spec.media:
+        if med.pec:
+            tab.append(-1e8 + 0j)
+            continue
+        e = med.eps_inf + 0j
+        if med.sigma:
+            e += 1j * med.sigma / (w * EPSILON_0)
+        for a, c in med.poles:
+            e -= c / (1j * w + a) + np.conj(c) / (1j * w + np.conj(a))
+        tab.append(e)
+    return np.array(tab)
+
+
+def permittivity_data(sim, spec: SolverSpec, plan) -> "PermittivityData":
+    """PermittivityMonitor: background, then structures in order, sampled per component at its own
+    Yee nodes of the monitor sub-grid — zero-size dimensions snapped to the monitor plane — i.e. the
+    reference's epsilon_on_grid recipe (ref simulation.py:1135-1241) with the staircase rule the
+    kernels use (identical to ``spec.mat_idx`` wherever the nodes coincide)."""
+    mon, fp = plan.monitor, plan.fields[0]
+    freqs = np.asarray(mon.freqs, float)
+    kw = {}
+    for c, (name, fname) in enumerate((("eps_xx", "Ex"), ("eps_yy", "Ey"), ("eps_zz", "Ez"))):
+        tx, ty, tz = fp.target[fname]
+        X, Y, Z = np.meshgrid(tx, ty, tz, indexing="ij")
+        vals = np.empty(X.shape + (len(freqs),), dtype=complex)
+        vals[...] = np.asarray(sim.medium.eps_model(freqs), complex)
+        for st in sim.structures:
+            inside = st.geometry.inside(X, Y, Z)
+            if getattr(st.medium, "is_pec", False):
+                vals[inside] = -1e8 + 0j                      # pec_val, ref constants.py:64
+            else:
+                vals[inside] = np.asarray(st.medium.eps_model(freqs), complex)
+        kw[name] = DataArray(vals, {"x": tx, "y": ty, "z": tz, "f": freqs})
+    return PermittivityData(monitor=mon, **kw)
+
+
 def source_spectrum_fn(disc: Discretization, index: Optional[int]) -> Callable:
     """ref sim_data.py:931-953: spectrum / amplitude / exp(i phase) of source ``index``."""
     sim = disc.sim
@@ -392,6 +448,8 @@ def assemble(disc: Discretization, raw: Dict[str, np.ndarray], log: str = "", di
         elif plan.kind == "mode":
             from .modesource import mode_monitor_data
             out.append(mode_monitor_data(disc, plan, raw, norm))
+        elif plan.kind == "permittivity":
+            out.append(permittivity_data(sim, spec, plan))
         else:
             raise DataError(f"unknown monitor plan kind '{plan.kind}'")
     return SimulationData(simulation=sim, data=tuple(out), log=log, diverged=diverged)

@@ -43,20 +43,8 @@ class ModePlane:
 
 def _eps_plane(spec: SolverSpec, comp_axis: int, p: int, k: int, lo, hi, u: int, v: int, freq: float):
     """eps(freq) at the Yee nodes of E_{comp_axis} on plane index k (p axis), window [lo, hi)."""
-    eps_tab = []
-    for med in spec.media:
-        if med.pec:
-            eps_tab.append(-1e8 + 0j)           # pec_val, ref constants.py:64
-            continue
-        w = 2 * np.pi * freq
-        e = med.eps_inf + 0j
-        if med.sigma:
-            from .constants import EPSILON_0
-            e += 1j * med.sigma / (w * EPSILON_0)
-        for a, c in med.poles:
-            e -= c / (1j * w + a) + np.conj(c) / (1j * w + np.conj(a))
-        eps_tab.append(e)
-    eps_tab = np.array(eps_tab)
+    from .data import medium_eps_table
+    eps_tab = medium_eps_table(spec, freq)
     nu, nv = hi[0] - lo[0], hi[1] - lo[1]
     if spec.mat_idx is None:
         return np.full((nu, nv), eps_tab[1])

@@ -1040,6 +1040,24 @@ class ModeMonitor(_Monitor):
 
 @_register
 @dataclass
+class PermittivityMonitor(_Monitor):
+    """Diagonal of the complex relative permittivity at the Yee locations of E (ref monitor.py:447);
+    never colocated (ref monitor.py:469-474)."""
+
+    center: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    size: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    name: str = "eps"
+    freqs: Tuple[float, ...] = ()
+    interval_space: Tuple[int, int, int] = (1, 1, 1)
+    colocate: bool = False
+    apodization: ApodizationSpec = field(default_factory=ApodizationSpec)
+
+    def frequency_range(self):
+        return (min(self.freqs), max(self.freqs))
+
+
+@_register
+@dataclass
 class RunTimeSpec(_Model):
     """ref components/run_time_spec.py; evaluated in Simulation._run_time (simulation.py:3677)."""
 

@@ -127,7 +127,11 @@ def save_npz(sim_data: SimulationData, path: str) -> None:
     blobs = {"log": np.array(sim_data.log or ""), "diverged": np.array(sim_data.diverged)}
     for d in sim_data.data:
         name = d.monitor.name
-        arrays = getattr(d, "field_components", None) or {"flux": d.flux}
+        arrays = getattr(d, "field_components", None)
+        if arrays is None and hasattr(d, "amps"):
+            arrays = {"amps": d.amps, "n_complex": d.n_complex}
+        if arrays is None:
+            arrays = {"flux": d.flux}
         for k, v in arrays.items():
             blobs[f"{name}/{k}"] = v.values
             for dim, c in v.coords.items():
