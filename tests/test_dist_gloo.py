@@ -55,3 +55,33 @@ def test_two_rank_run_matches_single_slab(world, case, emu_lib, tmp_path):
     for k, v in oref.items():           # (scale-aware: see cases.run_case)
         den = max(np.linalg.norm(v), 0.5 * scale * np.sqrt(v.size))
         assert np.linalg.norm(got[f"mon_{k}"] - v) / den < 2e-5
+
+
+def test_balanced_slabs_follow_the_cost_model():
+    """Equal modelled cost, not equal plane counts: a dispersive block in the upper half and z-PML
+    at both ends shift the cuts; the partition stays contiguous, complete and PML-clear."""
+    from tidy3d_amd.engine import balanced_slabs, plane_costs
+    import tidy3d_amd.schema as td
+    sim = td.Simulation(
+        size=(1.0, 1.0, 4.0), grid_spec=td.GridSpec.uniform(dl=0.05), run_time=1e-13,
+        structures=[td.Structure(geometry=td.Box(center=(0, 0, 1.0), size=(td.inf, td.inf, 1.6)),
+                                 medium=td.Lorentz(eps_inf=2.0, coeffs=[(1.5, 4e14, 3e13), (0.5, 6e14, 3e13)]))],
+        sources=[td.PointDipole(center=(0, 0, -1), source_time=td.GaussianPulse(freq0=3e14, fwidth=3e13),
+                                polarization="Ex")],
+        monitors=[], boundary_spec=td.BoundarySpec(x=td.Boundary.periodic(), y=td.Boundary.periodic(),
+                                                   z=td.Boundary.pml(num_layers=8)))
+    spec = discretize(sim, n_steps=2).spec
+    nz = spec.shape[2]
+    cost = plane_costs(spec)
+    for world in (2, 3, 4):
+        slabs = balanced_slabs(spec, world)
+        assert slabs[0][0] == 0 and slabs[-1][1] == nz
+        assert all(a[1] == b[0] for a, b in zip(slabs, slabs[1:]))
+        assert all(z1 - z0 >= 4 for z0, z1 in slabs)
+        assert all(8 + 2 <= z0 <= nz - 8 - 2 for z0, _ in slabs[1:])
+        bal = [cost[a:b].sum() for a, b in slabs]
+        uni = [cost[a:b].sum() for a, b in split_slabs(nz, world)]
+        assert max(bal) <= max(uni) + 1e-9
+        assert HipEngine._fused_slabs_ok(spec, world, slabs)
+    assert max(cost[a:b].sum() for a, b in balanced_slabs(spec, 2)) < 0.9 * max(
+        cost[a:b].sum() for a, b in split_slabs(nz, 2))

@@ -15,7 +15,7 @@ from typing import Dict, Optional, Tuple
 
 import numpy as np
 
-from .engine import HipEngine, split_slabs
+from .engine import HipEngine, balanced_slabs, split_slabs
 from .spec import SolverSpec
 
 
@@ -34,10 +34,11 @@ def make_engine(spec: SolverSpec, lib=None, device: Optional[int] = None, **kw) 
     nz = spec.shape[2]
     if nz < 2 * world:
         raise ValueError(f"{nz} planes cannot be split into {world} slabs of >= 2 planes")
-    slabs = split_slabs(nz, world)
+    slabs = balanced_slabs(spec, world)       # equal modelled cost, not equal plane counts
     if device is None:
         device = env_ranks()[2]
-    eng = HipEngine(spec, lib=lib, device=device, slab=slabs[rank], rank=rank, n_ranks=world, **kw)
+    eng = HipEngine(spec, lib=lib, device=device, slab=slabs[rank], rank=rank, n_ranks=world,
+                    all_slabs=slabs, **kw)
     uid = [eng.unique_id() if rank == 0 else None]
     dist.broadcast_object_list(uid, src=0)
     eng.comm_init(uid[0])

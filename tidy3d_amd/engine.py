@@ -46,6 +46,54 @@ def split_slabs(nz: int, n_ranks: int) -> List[Tuple[int, int]]:
     return out
 
 
+def plane_costs(spec: SolverSpec) -> np.ndarray:
+    """Relative cost of one xy-plane per step, from the measured per-cell kernel times on MI355X
+    (DESIGN.md section 5): fused sweep 9.3 ps/cell (+5 % with material words), CPML slab kernels
+    24 ps per cell and PML-axis membership, ADE 21 ps per dispersive cell and pole."""
+    nx, ny, nz = spec.shape
+    cost = np.full(nz, nx * ny * 9.3 * (1.05 if spec.mat_idx is not None else 1.0))
+    (xl, xh), (yl, yh), (zl, zh) = [(p[0].num_layers, p[1].num_layers) for p in spec.pml]
+    cost += 24.0 * ((xl + xh) * ny + (yl + yh) * nx)
+    cost[:zl] += 24.0 * nx * ny
+    if zh:
+        cost[nz - zh:] += 24.0 * nx * ny
+    if spec.mat_idx is not None:
+        npoles = np.array([len(m.poles) for m in spec.media], dtype=np.float64)
+        if npoles.any():
+            for c in range(3):
+                cost += 7.0 * npoles[spec.mat_idx[c]].reshape(nz, -1).sum(axis=1)
+    return cost
+
+
+def balanced_slabs(spec: SolverSpec, n_ranks: int, min_planes: int = 4) -> List[Tuple[int, int]]:
+    """Contiguous z-slabs of (nearly) equal modelled cost instead of equal plane counts: PML z-slabs
+    and dispersive regions make some planes heavier (SURVEY.md section 8(e) "load balance").  Cuts
+    are kept two planes clear of the z-PML so that the fused z-slab schedule stays available; falls
+    back to ``split_slabs`` when the constraints cannot be met.  Deterministic: every rank derives
+    the same partition from the same spec."""
+    nz = spec.shape[2]
+    if n_ranks <= 1:
+        return [(0, nz)]
+    if nz < min_planes * n_ranks:
+        return split_slabs(nz, n_ranks)
+    cum = np.concatenate(([0.0], np.cumsum(plane_costs(spec))))
+    zl, zh = spec.pml[2][0].num_layers, spec.pml[2][1].num_layers
+    lo_ok = zl + 2 if zl else min_planes
+    hi_ok = nz - zh - 2 if zh else nz - min_planes
+    cuts = []
+    prev = 0
+    for r in range(1, n_ranks):
+        z = int(np.argmin(np.abs(cum - cum[-1] * r / n_ranks)))
+        z = max(z, prev + min_planes, lo_ok)
+        z = min(z, nz - min_planes * (n_ranks - r), hi_ok)
+        if z < prev + min_planes:
+            return split_slabs(nz, n_ranks)
+        cuts.append(z)
+        prev = z
+    edges = [0] + cuts + [nz]
+    return [(edges[i], edges[i + 1]) for i in range(n_ranks)]
+
+
 def _local_pml_counts(tables: List[np.ndarray]) -> Tuple[int, int]:
     """Leading/trailing run of planes whose CPML tables differ from identity (see engine notes):
     the library's slab ranges only need to be supersets of the true PML planes."""
@@ -65,7 +113,7 @@ class HipEngine:
     def __init__(self, spec: SolverSpec, lib: Optional[L.FdtdLib] = None, device: int = 0,
                  variant: int = L.VARIANT_AUTO, flags: int = 0, z_chunk: int = 0,
                  slab: Optional[Tuple[int, int]] = None, rank: int = 0, n_ranks: int = 1,
-                 force_comm: bool = False):
+                 force_comm: bool = False, all_slabs: Optional[List[Tuple[int, int]]] = None):
         self.lib = lib or L.load_library()
         self.spec = spec
         self.rank, self.n_ranks = rank, n_ranks
@@ -97,8 +145,9 @@ class HipEngine:
         if (n_ranks > 1 or force_comm) and variant in (L.VARIANT_AUTO, L.VARIANT_FUSED):
             # every rank takes the same decision (split_slabs is deterministic): fused z-slab schedule
             # iff float4-aligned rows, >= 4 planes in every slab and no slab cut inside the z-PML
-            ok = (self.nxp % 4 == 0 and min(b - a for a, b in split_slabs(nz, n_ranks)) >= 4
-                  and self._fused_slabs_ok(spec, n_ranks))
+            slabs = list(all_slabs) if all_slabs is not None else split_slabs(nz, n_ranks)
+            ok = (self.nxp % 4 == 0 and min(b - a for a, b in slabs) >= 4
+                  and self._fused_slabs_ok(spec, n_ranks, slabs))
             variant = L.VARIANT_FUSED if ok else L.VARIANT_ZMARCH
         cfg.device, cfg.variant, cfg.flags, cfg.z_chunk = device, variant, flags, z_chunk
         cfg.ch = float(h_coeff(spec.dt))
@@ -112,13 +161,13 @@ class HipEngine:
             raise
 
     @staticmethod
-    def _fused_slabs_ok(spec: SolverSpec, n_ranks: int) -> bool:
+    def _fused_slabs_ok(spec: SolverSpec, n_ranks: int, slabs=None) -> bool:
         """The fused sweep keeps H^{n+1/2} of the plane below a slab in registers only, so the E-side
         CPML correction of a slab's first plane (which differentiates H along z) cannot be formed
         for it: z-slab cuts must fall outside the z-PML.  Otherwise the two-pass kernels are used."""
         nz = spec.shape[2]
         n_lo, n_hi = spec.pml[2][0].num_layers, spec.pml[2][1].num_layers
-        cuts = [z0 for z0, _ in split_slabs(nz, n_ranks)][1:]
+        cuts = [z0 for z0, _ in (slabs if slabs is not None else split_slabs(nz, n_ranks))][1:]
         if spec.bc[2][0] == BC_PERIODIC and n_ranks >= 1:
             cuts = cuts + [0]
         # ... and leave two planes between a cut and the z-PML: the boundary chunk next to a cut
