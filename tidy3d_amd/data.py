@@ -21,7 +21,7 @@ import numpy as np
 from . import schema as td
 from .discretize import Discretization, FieldPlan, MonitorPlan
 from .exceptions import DataError
-from .spec import COMP_ID, SolverSpec
+from .spec import BC_PERIODIC, COMP_ID, SolverSpec
 
 
 class DataArray:
@@ -282,6 +282,13 @@ def _colocate_box(raw: np.ndarray, spec: SolverSpec, fp: FieldPlan, ic: int, fna
         lo = fp.lo[a]
         n = arr.shape[3 - a]
         src = yee[a][lo:lo + n]
+        on_boundary = (a == comp % 3) == (comp >= 3)      # nodes on the grid lines along a
+        if on_boundary and lo + n == spec.shape[a] and spec.bc[a][1] != BC_PERIODIC and n > 1:
+            # the top wall is not stored: wall-tangential E / wall-normal H are zero on it
+            src = np.append(src, spec.boundaries[a][-1])
+            pad = [(0, 0)] * arr.ndim
+            pad[3 - a] = (0, 1)
+            arr = np.pad(arr, pad)
         arr = interp_axis(arr, src, fp.target[fname][a], axis=3 - a)
     return arr
 
@@ -339,16 +346,59 @@ def plane_flux(fd: _FieldLike, axis: int, mon, sign: float = 1.0, box: Optional[
     return DataArray(flux.astype(np.float32), {lead: e1.coords[lead]})
 
 
+# parity of a field component under the mirror x_a -> -x_a (ref dataset.py:210-220); the value on the
+# lower side is  symmetry[a] * eigenvalue * value(mirror point)  (ref monitor_data.py:238-284)
+_SYM_EIG = {"Ex": (-1, 1, 1), "Ey": (1, -1, 1), "Ez": (1, 1, -1),
+            "Hx": (1, -1, -1), "Hy": (-1, 1, -1), "Hz": (-1, -1, 1)}
+
+
+def expand_symmetry(arr: np.ndarray, half: Sequence[np.ndarray], full: Sequence[np.ndarray], fname: str,
+                    symmetry, center) -> np.ndarray:
+    """arr (x, y, z, lead) on the computed upper-half coordinates -> the monitor's own coordinates:
+    points below a symmetry plane take the nearest mirror sample times the parity."""
+    for a in range(3):
+        if symmetry[a] == 0:
+            continue
+        cf, ch, c = np.asarray(full[a], float), np.asarray(half[a], float), center[a]
+        flip = cf < c
+        want = np.where(flip, 2 * c - cf, cf)
+        idx = np.abs(ch[None, :] - want[:, None]).argmin(axis=1)
+        arr = np.take(arr, idx, axis=a)
+        parity = float(symmetry[a] * _SYM_EIG[fname][a])
+        sign = np.where(flip, parity, 1.0)
+        # the mirror image of the lowest grid line is the top wall, which a recorded span never
+        # includes: wall-tangential E and wall-normal H vanish there (every outer face is PEC-backed)
+        if len(ch) > 1:
+            sign = np.where(want > ch[-1] + 0.5 * (ch[-1] - ch[-2]), 0.0, sign)
+        # a colocated sample ON the plane of a component whose nodes straddle it (E_a along a, H_b
+        # along a != b) is the mean of the two mirror nodes: zero for odd parity (the half-domain
+        # interpolation, which has no node below the plane, returned the upper node instead)
+        straddles = (fname[0] == "E") == ("xyz".index(fname[1]) == a)
+        if parity < 0 and straddles:
+            sign = np.where(np.isclose(cf, c, rtol=0, atol=1e-9 * max(1.0, abs(c))), 0.0, sign)
+        shape = [1] * arr.ndim
+        shape[a] = len(cf)
+        arr = arr * sign.reshape(shape).astype(arr.real.dtype)
+    return arr
+
+
 def _field_container(cls, mon, spec: SolverSpec, fp: FieldPlan, raw: np.ndarray, lead: str,
-                     lead_coords: np.ndarray, sim_center, dtype):
+                     lead_coords: np.ndarray, sim_center, dtype, full=None):
+    """``full`` = (FieldPlan on the full grid, full-grid spec, symmetry) when the solver ran on the
+    symmetry-reduced domain."""
     kw = {}
     for ic, fname in enumerate(fp.fields):
         arr = _colocate_box(raw, spec, fp, ic, fname)           # [lead, z, y, x]
         arr = np.transpose(arr, (3, 2, 1, 0)).astype(dtype)      # (x, y, z, lead)
         tx, ty, tz = fp.target[fname]
+        if full is not None:
+            fp_full, _, symmetry = full
+            arr = expand_symmetry(arr, (tx, ty, tz), fp_full.target[fname], fname, symmetry, sim_center)
+            tx, ty, tz = fp_full.target[fname]
         kw[fname] = DataArray(arr, {"x": tx, "y": ty, "z": tz, lead: lead_coords})
+    gexp = _grid_expanded(spec, fp) if full is None else _grid_expanded(full[1], full[0])
     return cls(monitor=mon, symmetry=(0, 0, 0), symmetry_center=tuple(sim_center),
-               grid_expanded=_grid_expanded(spec, fp), **kw)
+               grid_expanded=gexp, **kw)
 
 
 def medium_eps_table(spec: SolverSpec, freq: float) -> np.ndarray:
@@ -412,32 +462,38 @@ def assemble(disc: Discretization, raw: Dict[str, np.ndarray], log: str = "", di
     sim, spec = disc.sim, disc.spec
     norm = source_spectrum_fn(disc, sim.normalize_index)
     out = []
-    for plan in disc.plans:
+    sym = tuple(getattr(disc, "symmetry", (0, 0, 0)))
+    plans_full = disc.plans_full if any(sym) else [None] * len(disc.plans)
+
+    def full_of(pf, i):
+        return None if pf is None else (pf.fields[i], disc.spec_full, sym)
+
+    for plan, pfull in zip(disc.plans, plans_full):
         mon = plan.monitor
         if plan.kind == "field":
             fp = plan.fields[0]
             fd = _field_container(FieldData, mon, spec, fp, raw[fp.spec_name], "f",
-                                  np.asarray(mon.freqs, float), sim.center, np.complex64)
+                                  np.asarray(mon.freqs, float), sim.center, np.complex64, full_of(pfull, 0))
             out.append(fd.normalize(norm))
         elif plan.kind == "field_time":
             fp = plan.fields[0]
             t = disc.tmesh[plan.steps]
             out.append(_field_container(FieldTimeData, mon, spec, fp, raw[fp.spec_name], "t", t,
-                                        sim.center, np.float32))
+                                        sim.center, np.float32, full_of(pfull, 0)))
         elif plan.kind in ("flux", "flux_time"):
             is_time = plan.kind == "flux_time"
             lead = "t" if is_time else "f"
             lead_coords = disc.tmesh[plan.steps] if is_time else np.asarray(mon.freqs, float)
             total = None
             from .discretize import flux_surfaces
-            for fp, (sname, box, axis, sign) in zip(plan.fields, flux_surfaces(mon)):
+            for isurf, (fp, (sname, box, axis, sign)) in enumerate(zip(plan.fields, flux_surfaces(mon))):
                 class _M:
                     pass
                 m = _M()
                 m.size, m.center, m.geometry = box.size, box.center, box
                 fd = _field_container(FieldTimeData if is_time else FieldData, m, spec, fp,
                                       raw[fp.spec_name], lead, lead_coords, sim.center,
-                                      np.float64 if is_time else np.complex128)
+                                      np.float64 if is_time else np.complex128, full_of(pfull, isurf))
                 fl = plane_flux(fd, axis, m, sign=sign, box=box, lead=lead)
                 total = fl if total is None else DataArray(total.values + fl.values, fl.coords)
             if is_time:
@@ -449,7 +505,7 @@ def assemble(disc: Discretization, raw: Dict[str, np.ndarray], log: str = "", di
             from .modesource import mode_monitor_data
             out.append(mode_monitor_data(disc, plan, raw, norm))
         elif plan.kind == "permittivity":
-            out.append(permittivity_data(sim, spec, plan))
+            out.append(permittivity_data(sim, spec, plan if pfull is None else pfull))
         else:
             raise DataError(f"unknown monitor plan kind '{plan.kind}'")
     return SimulationData(simulation=sim, data=tuple(out), log=log, diverged=diverged)
