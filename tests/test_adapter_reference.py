@@ -108,3 +108,20 @@ def test_permittivity_monitor_matches_reference_epsilon(td_ref):
                 np.testing.assert_allclose(arr.coords["y"], c.y, atol=1e-12)
                 np.testing.assert_allclose(arr.coords["z"], c.z, atol=1e-12)
                 np.testing.assert_allclose(arr.values[..., i_f], ref, rtol=1e-12)
+
+
+@pytest.mark.parametrize("size", [(3.0, 2.2, 1.6), (2.98, 2.2, 1.64), (2.6, 1.32, 1.56)])
+def test_symmetric_grid_matches_reference(td_ref, size):
+    """Simulation.symmetry: the reference moves the nearest boundary onto the centre, keeps the upper
+    half and mirrors it (ref grid_spec.py:76-82), then appends the PML cells; same rule here."""
+    from tidy3d_amd.discretize import make_boundaries
+    from tidy3d_amd.web import _as_mirror
+    td = td_ref
+    sim = _sim(td).updated_copy(size=size, symmetry=(1, -1, 1), monitors=[], structures=[],
+                                boundary_spec=td.BoundarySpec.all_sides(td.PML(num_layers=5)))
+    mirror, _ = _as_mirror(sim)
+    got = make_boundaries(mirror)
+    for a, d in enumerate("xyz"):
+        ref = np.asarray(getattr(sim.grid.boundaries, d))
+        assert len(got[a]) == len(ref)
+        np.testing.assert_allclose(got[a], ref, rtol=0, atol=1e-13)
