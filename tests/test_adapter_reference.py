@@ -125,3 +125,35 @@ def test_symmetric_grid_matches_reference(td_ref, size):
         ref = np.asarray(getattr(sim.grid.boundaries, d))
         assert len(got[a]) == len(ref)
         np.testing.assert_allclose(got[a], ref, rtol=0, atol=1e-13)
+
+
+def test_anisotropic_medium_and_geometry_group_match_reference(td_ref):
+    """AnisotropicMedium (one medium per E component, ref medium.py:4863) and GeometryGroup (union,
+    ref geometry/base.py:2304) built with the reference's classes: raster == reference ``inside``,
+    per-component eps == reference ``eps_comp``, dt follows the reference's n_cfl."""
+    from tidy3d_amd.data import medium_eps_table
+    from tidy3d_amd.discretize import discretize
+    from tidy3d_amd.web import _as_mirror
+    td = td_ref
+    aniso = td.AnisotropicMedium(xx=td.Medium(permittivity=2.0), yy=td.Medium(permittivity=3.5, conductivity=0.02),
+                                 zz=td.Lorentz(eps_inf=1.3, coeffs=[(1.5, 4e14, 3e13)]))
+    group = td.GeometryGroup(geometries=[td.Box(center=(-0.6, 0.2, 0), size=(0.5, 0.4, 0.6)),
+                                         td.Sphere(center=(-0.2, 0.2, 0.1), radius=0.3),
+                                         td.Cylinder(center=(0.9, -0.3, 0), radius=0.25, length=0.8, axis=0)])
+    sim = _sim(td).updated_copy(structures=[td.Structure(geometry=group, medium=aniso),
+                                            td.Structure(geometry=td.Sphere(center=(0.2, 0, -0.1), radius=0.25),
+                                                         medium=td.Medium(permittivity=6.0))], monitors=[])
+    mirror, _ = _as_mirror(sim)
+    disc = discretize(mirror, n_steps=4)
+    spec = disc.spec
+    assert spec.dt == pytest.approx(sim.dt, rel=1e-13)
+    f = 2.7e14
+    tab = medium_eps_table(spec, f)
+    for c in range(3):
+        xs, ys, zs = spec.yee_coords(c)
+        X, Y, Z = np.meshgrid(xs, ys, zs, indexing="ij")
+        ref = np.full(X.shape, sim.medium.eps_model(f), dtype=complex)
+        for st in sim.structures:
+            ref[st.geometry.inside(X, Y, Z)] = st.medium.eps_comp(c, c, f)
+        got = tab[spec.mat_idx[c].transpose(2, 1, 0)]
+        np.testing.assert_allclose(got, ref, rtol=1e-12)

@@ -435,10 +435,11 @@ def permittivity_data(sim, spec: SolverSpec, plan) -> "PermittivityData":
         vals[...] = np.asarray(sim.medium.eps_model(freqs), complex)
         for st in sim.structures:
             inside = st.geometry.inside(X, Y, Z)
-            if getattr(st.medium, "is_pec", False):
+            med = st.medium.component(c) if hasattr(st.medium, "component") else st.medium
+            if getattr(med, "is_pec", False):
                 vals[inside] = -1e8 + 0j                      # pec_val, ref constants.py:64
             else:
-                vals[inside] = np.asarray(st.medium.eps_model(freqs), complex)
+                vals[inside] = np.asarray(med.eps_model(freqs), complex)
         kw[name] = DataArray(vals, {"x": tx, "y": ty, "z": tz, "f": freqs})
     return PermittivityData(monitor=mon, **kw)
 

@@ -235,6 +235,92 @@ class Cylinder(_Model):
         return (r2 <= self.radius ** 2) & (np.abs(za - z0) <= self.length / 2)
 
 
+@_register
+@dataclass
+class PolySlab(_Model):
+    """Polygon extruded along ``axis`` (ref geometry/polyslab.py:37); vertical side walls without
+    dilation only.  ``inside`` = slab bounds AND point-in-polygon; the reference delegates the
+    latter to ``matplotlib.path.Path.contains_points`` (polyslab.py:511-516, third party, absent
+    here): restated as the even-odd crossing-number test with the half-open edge rule
+    ``(y_i <= y) != (y_j <= y)`` — points exactly on an edge are implementation-defined in both."""
+
+    vertices: Any = ()
+    slab_bounds: Tuple[float, float] = (0.0, 0.0)
+    axis: int = 2
+    sidewall_angle: float = 0.0
+    dilation: float = 0.0
+    reference_plane: str = "middle"
+
+    def __post_init__(self):
+        self.vertices = tuple(tuple(float(c) for c in v) for v in np.asarray(self.vertices, float).reshape(-1, 2))
+        self.slab_bounds = tuple(float(_to_float(v)) for v in self.slab_bounds)
+        if self.sidewall_angle != 0.0 or self.dilation != 0.0:
+            raise Tidy3dNotImplementedError("PolySlab.sidewall_angle / dilation != 0 are not supported.")
+        if len(self.vertices) < 3:
+            raise ValidationError("PolySlab needs at least 3 vertices.")
+
+    @property
+    def _planar_axes(self):
+        return [a for a in range(3) if a != self.axis]       # (x,y,z) minus axis, order kept (ref pop_axis)
+
+    @property
+    def bounds(self):
+        v = np.array(self.vertices)
+        lo, hi = [0.0] * 3, [0.0] * 3
+        u, w = self._planar_axes
+        lo[u], hi[u] = v[:, 0].min(), v[:, 0].max()
+        lo[w], hi[w] = v[:, 1].min(), v[:, 1].max()
+        lo[self.axis], hi[self.axis] = self.slab_bounds
+        return tuple(lo), tuple(hi)
+
+    def inside(self, x, y, z):
+        p = [x, y, z]
+        za = p.pop(self.axis)
+        px, py, za = np.broadcast_arrays(np.asarray(p[0], float), np.asarray(p[1], float), np.asarray(za, float))
+        z0, z1 = self.slab_bounds
+        zc, half = 0.5 * (z0 + z1), 0.5 * (z1 - z0)
+        ok = np.abs(za - zc) <= half
+        if not np.any(ok):
+            return ok
+        v = np.array(self.vertices)
+        xs, ys = px[ok], py[ok]
+        odd = np.zeros(xs.shape, bool)
+        xj, yj = v[-1]
+        for xi, yi in v:
+            cross = (yi <= ys) != (yj <= ys)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                xint = xi + (ys - yi) * (xj - xi) / (yj - yi)
+            odd ^= cross & (xs < xint)
+            xj, yj = xi, yi
+        out = np.zeros(ok.shape, bool)
+        out[ok] = odd
+        return out
+
+
+@_register
+@dataclass
+class GeometryGroup(_Model):
+    """Union of geometries sharing one medium (ref geometry/base.py:2304)."""
+
+    geometries: Tuple[Any, ...] = ()
+
+    @property
+    def bounds(self):
+        b = [g.bounds for g in self.geometries]
+        lo = tuple(min(x[0][a] for x in b) for a in range(3))
+        hi = tuple(max(x[1][a] for x in b) for a in range(3))
+        return lo, hi
+
+    def inside(self, x, y, z):
+        out = None
+        for g in self.geometries:
+            if isinstance(g, Unsupported):
+                g.fail()
+            i = g.inside(x, y, z)
+            out = i if out is None else (out | i)
+        return out
+
+
 # --------------------------------------------------------------------------------------
 # media  (ref components/medium.py)
 # --------------------------------------------------------------------------------------
@@ -410,6 +496,49 @@ class Debye(_AbstractMedium):
             a = -2 * np.pi / tau + 0j
             poles.append((a, -0.5 * de * a))
         return float(self.eps_inf), 0.0, tuple(poles)
+
+
+@_register
+@dataclass
+class AnisotropicMedium(_AbstractMedium):
+    """Diagonally anisotropic medium (ref medium.py:4863): an isotropic medium per E component —
+    exactly what the per-component material indices of the kernels hold."""
+
+    xx: Any = None
+    yy: Any = None
+    zz: Any = None
+    name: Optional[str] = None
+    frequency_range: Optional[Tuple[float, float]] = None
+    allow_gain: Optional[bool] = None
+
+    @property
+    def components(self):
+        return [self.xx, self.yy, self.zz]
+
+    @property
+    def is_pec(self):
+        return False          # per component: see ``component(c).is_pec``
+
+    def component(self, c: int):
+        m = self.components[c]
+        if isinstance(m, Unsupported):
+            m.fail()
+        return m
+
+    @property
+    def n_cfl(self):
+        """ref medium.py:4950-4957: the smallest of the components."""
+        return min(m.n_cfl for m in self.components)
+
+    def eps_comp(self, c: int, frequency):
+        return self.component(c).eps_model(frequency)
+
+    def eps_model(self, frequency):
+        """ref medium.py:4960-4963: mean of the diagonal."""
+        return np.mean([self.eps_comp(c, frequency) for c in range(3)], axis=0)
+
+    def pole_residue(self):
+        raise Tidy3dNotImplementedError("AnisotropicMedium has one pole-residue model per component")
 
 
 @_register
