@@ -605,26 +605,32 @@ void record_monitors(FdtdSolver* h, long long n, bool post, hipStream_t st) {
     if (m.next >= m.steps.size() || m.steps[m.next] != n) continue;
     const long long rec = (long long)m.next;
     const int nc = (int)m.comps.size();
+    // one launch per monitor and phase.  pre (before the H update): E^n, and half of H^{n-1/2} for
+    // time monitors; post (after it): the other half of H / the H terms of the running DFT.
+    RecP r{};
     for (int ic = 0; ic < nc; ++ic) {
       const int c = m.comps[ic];
-      const float* F = field_ptr(h, c);
+      const bool is_h = c >= 3;
+      bool take;
+      if (m.kind == FDTD_MON_TIME) take = is_h || !post;
+      else take = is_h == post;
+      if (!take) continue;
+      r.f[r.n] = field_ptr(h, c);
+      r.slot[r.n] = ic;
+      r.scale[r.n] = is_h ? 0.5f : 1.0f;
+      r.acc[r.n] = is_h ? 1 : 0;
+      r.n++;
+    }
+    if (r.n > 0 && m.cells > 0) {
+      const dim3 grid(nblk(m.cells), r.n);
       if (m.kind == FDTD_MON_TIME) {
-        float* out = reinterpret_cast<float*>(m.data) + (rec * nc + ic) * m.cells;
-        if (c < 3) {
-          if (!post)
-            hipLaunchKernelGGL(time_record_kernel, dim3(nblk(m.cells)), dim3(256), 0, st, F, h->g, m.box, out, 1.0f, 0);
-        } else {
-          hipLaunchKernelGGL(time_record_kernel, dim3(nblk(m.cells)), dim3(256), 0, st, F, h->g, m.box, out, 0.5f, 1);
-        }
+        float* out = reinterpret_cast<float*>(m.data) + rec * nc * m.cells;
+        hipLaunchKernelGGL(time_record_multi_kernel, grid, dim3(256), 0, st, r, h->g, m.box, out, (long long)m.cells);
       } else {
-        float2* acc = reinterpret_cast<float2*>(m.data) + (long long)ic * m.cells;
         const long long fstride = (long long)nc * m.cells;
-        if (c < 3 && !post)
-          hipLaunchKernelGGL(dft_record_kernel, dim3(nblk(m.cells)), dim3(256), 0, st, F, h->g, m.box, acc, fstride,
-                             (const float2*)(m.phase_e + rec * m.nf), m.nf);
-        else if (c >= 3 && post)
-          hipLaunchKernelGGL(dft_record_kernel, dim3(nblk(m.cells)), dim3(256), 0, st, F, h->g, m.box, acc, fstride,
-                             (const float2*)(m.phase_h + rec * m.nf), m.nf);
+        hipLaunchKernelGGL(dft_record_multi_kernel, grid, dim3(256), 0, st, r, h->g, m.box,
+                           reinterpret_cast<float2*>(m.data), (long long)m.cells, fstride,
+                           (const float2*)((post ? m.phase_h : m.phase_e) + rec * m.nf), m.nf);
       }
     }
     if (post) m.next++;

@@ -1219,31 +1219,43 @@ __global__ void tfsf_aux_e_kernel(float* e1, const float* h1, const float* ae, c
 // =============================================================================================
 struct BoxP { int lo0, lo1, lo2; int nx, ny, nz; };   // box origin (i,j,k) and extents
 
-// out[cell] (=|+=) scale * F[box cell]
-__global__ __launch_bounds__(256) void time_record_kernel(const float* f, GridP g, BoxP b, float* out, float scale,
-                                                           int accumulate) {
-  const long long total = (long long)b.nx * b.ny * b.nz;
+// All components of one monitor in ONE launch (blockIdx.y = entry): small grids are launch-bound —
+// at 200^3 nine single-component record launches of 4.7 us each were 31 % of a step
+// (profiles/r01h_small_grid.txt).
+struct RecP {
+  const float* f[6];    // field array of each entry
+  int slot[6];          // component slot of the monitor buffer
+  float scale[6];       // time monitors: 1 for E, 0.5 for each of the two H half-samples
+  int acc[6];           // time monitors: accumulate (H) or overwrite (E)
+  int n;
+};
+
+// out[slot][cell] (=|+=) scale * F[box cell]
+__global__ __launch_bounds__(256) void time_record_multi_kernel(RecP r, GridP g, BoxP b, float* out, long long cells) {
+  const int q = blockIdx.y;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= total) return;
+  if (t >= cells) return;
   const int lx = (int)(t % b.nx), ly = (int)((t / b.nx) % b.ny), lz = (int)(t / ((long long)b.nx * b.ny));
-  const float v = scale * f[(long long)(b.lo2 + lz) * g.sxy + (long long)(b.lo1 + ly) * g.nx + b.lo0 + lx];
-  out[t] = accumulate ? out[t] + v : v;
+  const float v = r.scale[q] * r.f[q][(long long)(b.lo2 + lz) * g.sxy + (long long)(b.lo1 + ly) * g.nx + b.lo0 + lx];
+  float* o = out + (long long)r.slot[q] * cells;
+  o[t] = r.acc[q] ? o[t] + v : v;
 }
 
-// acc[f][cell] += F[box cell] * phase[f]     (acc stride between frequencies = fstride)
-__global__ __launch_bounds__(256) void dft_record_kernel(const float* f, GridP g, BoxP b, float2* acc,
-                                                          long long fstride, const float2* phase, int nf) {
-  const long long total = (long long)b.nx * b.ny * b.nz;
+// acc[f][slot][cell] += F[box cell] * phase[f]
+__global__ __launch_bounds__(256) void dft_record_multi_kernel(RecP r, GridP g, BoxP b, float2* acc, long long cells,
+                                                                long long fstride, const float2* phase, int nf) {
+  const int q = blockIdx.y;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= total) return;
+  if (t >= cells) return;
   const int lx = (int)(t % b.nx), ly = (int)((t / b.nx) % b.ny), lz = (int)(t / ((long long)b.nx * b.ny));
-  const float v = f[(long long)(b.lo2 + lz) * g.sxy + (long long)(b.lo1 + ly) * g.nx + b.lo0 + lx];
-  for (int q = 0; q < nf; ++q) {
-    const float2 ph = phase[q];
-    float2 a = acc[(long long)q * fstride + t];
+  const float v = r.f[q][(long long)(b.lo2 + lz) * g.sxy + (long long)(b.lo1 + ly) * g.nx + b.lo0 + lx];
+  float2* a0 = acc + (long long)r.slot[q] * cells;
+  for (int k = 0; k < nf; ++k) {
+    const float2 ph = phase[k];
+    float2 a = a0[(long long)k * fstride + t];
     a.x += v * ph.x;
     a.y += v * ph.y;
-    acc[(long long)q * fstride + t] = a;
+    a0[(long long)k * fstride + t] = a;
   }
 }
 
