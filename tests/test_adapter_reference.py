@@ -157,3 +157,45 @@ def test_anisotropic_medium_and_geometry_group_match_reference(td_ref):
             ref[st.geometry.inside(X, Y, Z)] = st.medium.eps_comp(c, c, f)
         got = tab[spec.mat_idx[c].transpose(2, 1, 0)]
         np.testing.assert_allclose(got, ref, rtol=1e-12)
+
+
+def test_hdf5_json_model_parses_with_reference_classes(td_ref):
+    """The JSON_STRING written to .hdf5 (tidy3d_amd/hdf5io.py) against the reference's own pydantic
+    classes: the simulation and every monitor parse back to the original objects, every key of a
+    monitor-data entry is a field of the reference class of that name, every DataArray placeholder
+    is a key of the reference's DATA_ARRAY_MAP (ref base.py:610-633 dict_from_hdf5)."""
+    from oracle.fdtd_numpy import OracleFdtd
+    from tidy3d.components.data.data_array import DATA_ARRAY_MAP
+    from tidy3d_amd.data import assemble
+    from tidy3d_amd.discretize import discretize
+    from tidy3d_amd.hdf5io import simulation_data_model
+    from tidy3d_amd.web import _as_mirror
+    td = td_ref
+    sim = _sim(td).updated_copy(size=(1.0, 0.8, 0.8), center=(0.2, 0.0, -0.1), structures=[], monitors=[
+        td.FieldMonitor(center=(0.2, 0, -0.1), size=(0.5, 0, 0.5), freqs=[2.4e14], name="xz"),
+        td.FluxMonitor(center=(0.2, 0, -0.3), size=(td.inf, td.inf, 0), freqs=[2.5e14], name="T"),
+        td.FieldTimeMonitor(center=(0.2, 0, 0), size=(0, 0, 0), name="probe", interval=4),
+        td.FluxTimeMonitor(center=(0.2, 0, -0.3), size=(td.inf, td.inf, 0), name="Tt", interval=10),
+        td.PermittivityMonitor(center=(0.2, 0, -0.1), size=(0.5, 0, 0.5), freqs=[2.4e14], name="eps")],
+        sources=[td.PointDipole(center=(0.3, 0.1, 0.0), source_time=td.GaussianPulse(freq0=2.5e14, fwidth=3e13),
+                                polarization="Ey")],
+        grid_spec=td.GridSpec.uniform(dl=0.05))
+    mirror, _ = _as_mirror(sim)
+    disc = discretize(mirror, n_steps=30)
+    sd = assemble(disc, OracleFdtd(disc.spec).run(), log="log text")
+    model, arrays = simulation_data_model(sd)
+    assert td.Simulation.parse_obj(model["simulation"]) == sim
+    for entry, m_ref in zip(model["data"], sim.monitors):
+        cls = getattr(td, entry["type"])
+        assert set(entry) - {"type"} <= set(cls.__fields__), (entry["type"], set(entry) - set(cls.__fields__))
+        assert type(m_ref).parse_obj(entry["monitor"]) == m_ref
+        if "grid_expanded" in entry:
+            grid = td.Grid.parse_obj(entry["grid_expanded"])
+            ref_grid = sim.discretize_monitor(m_ref)
+            for d in "xyz":
+                np.testing.assert_allclose(getattr(grid.boundaries, d), getattr(ref_grid.boundaries, d), atol=1e-12)
+        tags = {k: v for k, v in entry.items() if isinstance(v, str) and k not in ("type",)}
+        for k, v in tags.items():
+            assert v in DATA_ARRAY_MAP, (k, v)
+            ref_dims = DATA_ARRAY_MAP[v]._dims
+            assert tuple(arrays[f"/data/{model['data'].index(entry)}/{k}"].dims) == tuple(ref_dims)

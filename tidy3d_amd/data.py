@@ -215,6 +215,7 @@ class PermittivityData:
     eps_xx: DataArray = None
     eps_yy: DataArray = None
     eps_zz: DataArray = None
+    grid_expanded: Optional[Dict[str, np.ndarray]] = None
 
     @property
     def field_components(self) -> Dict[str, DataArray]:
@@ -293,12 +294,49 @@ def _colocate_box(raw: np.ndarray, spec: SolverSpec, fp: FieldPlan, ic: int, fna
     return arr
 
 
+def _extended_subspace(coords: np.ndarray, ind_beg: int, ind_end: int, periodic: bool) -> np.ndarray:
+    """Boundaries [ind_beg, ind_end) with out-of-range indices padded by the periodic image or the
+    mirror image about the end planes (ref grid.py:546-603)."""
+    coords = np.asarray(coords, float)
+    padded = coords
+    n = coords.size - 1
+    reverse = True
+    while ind_beg < 0:
+        if periodic or not reverse:
+            padded = np.concatenate([coords[:-1] + (padded[0] - coords[-1]), padded])
+            reverse = True
+        else:
+            padded = np.concatenate([(padded[0] + coords[0]) - coords[:0:-1], padded])
+            reverse = False
+        ind_beg += n
+        ind_end += n
+    reverse = True
+    while ind_end >= padded.size:
+        if periodic or not reverse:
+            padded = np.concatenate([padded, coords[1:] + (padded[-1] - coords[0])])
+            reverse = True
+        else:
+            padded = np.concatenate([padded, (padded[-1] + coords[-1]) - coords[-2::-1]])
+            reverse = False
+    return padded[ind_beg:ind_end]
+
+
 def _grid_expanded(spec: SolverSpec, fp: FieldPlan) -> Dict[str, np.ndarray]:
+    """``Simulation.discretize_monitor`` (ref simulation.py:1068-1073): sub-grid of the span (padded
+    beyond the walls, ref :973-987), zero-size monitor dimensions snapped to the monitor position
+    (ref grid.py:605-627), single-pixel simulation axes to the grid centre (ref :1019-1026)."""
     out = {}
     for a, d in enumerate("xyz"):
-        b = spec.boundaries[a]
-        lo, hi = max(int(fp.span[a, 0]), 0), min(int(fp.span[a, 1]), len(b) - 1)
-        out[d] = np.asarray(b[lo:hi + 1])
+        b = np.asarray(spec.boundaries[a], float)
+        periodic = spec.bc[a][0] == BC_PERIODIC and spec.bc[a][1] == BC_PERIODIC
+        sub = _extended_subspace(b, int(fp.span[a, 0]), int(fp.span[a, 1]) + 1, periodic)
+        if fp.box is not None and fp.box.size[a] == 0:
+            c = float(fp.box.center[a])
+            sub = np.array([c, c])
+        if len(b) == 2:
+            c = 0.5 * (b[0] + b[1])
+            sub = np.array([c, c])
+        out[d] = sub
     return out
 
 
@@ -441,7 +479,7 @@ def permittivity_data(sim, spec: SolverSpec, plan) -> "PermittivityData":
             else:
                 vals[inside] = np.asarray(med.eps_model(freqs), complex)
         kw[name] = DataArray(vals, {"x": tx, "y": ty, "z": tz, "f": freqs})
-    return PermittivityData(monitor=mon, **kw)
+    return PermittivityData(monitor=mon, grid_expanded=_grid_expanded(spec, fp), **kw)
 
 
 def source_spectrum_fn(disc: Discretization, index: Optional[int]) -> Callable:
@@ -506,7 +544,8 @@ def assemble(disc: Discretization, raw: Dict[str, np.ndarray], log: str = "", di
             from .modesource import mode_monitor_data
             out.append(mode_monitor_data(disc, plan, raw, norm))
         elif plan.kind == "permittivity":
-            out.append(permittivity_data(sim, spec, plan if pfull is None else pfull))
+            out.append(permittivity_data(sim, spec if pfull is None else disc.spec_full,
+                                         plan if pfull is None else pfull))
         else:
             raise DataError(f"unknown monitor plan kind '{plan.kind}'")
     return SimulationData(simulation=sim, data=tuple(out), log=log, diverged=diverged)

@@ -111,6 +111,8 @@ class _Model:
         def conv(v):
             if isinstance(v, _Model):
                 return v.dict()
+            if isinstance(v, Unsupported):
+                return v.raw
             if isinstance(v, (list, tuple)):
                 return [conv(x) for x in v]
             if isinstance(v, complex):
@@ -1265,6 +1267,7 @@ class Simulation(_Model):
         sim = parse(d)
         if not isinstance(sim, Simulation):
             raise SetupError("dict does not describe a tidy3d Simulation")
+        sim._source_dict = d          # the caller's own JSON form: written back verbatim to .hdf5 files
         return sim
 
     @classmethod

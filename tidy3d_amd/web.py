@@ -59,8 +59,8 @@ def run(simulation, task_name: Optional[str] = None, folder_name: str = "default
 
     Cloud-only arguments (``folder_name``, ``callback_url``, ``progress_callback_*``,
     ``solver_version``, ``worker_group``, ``parent_tasks``, ``local_gradient``) are accepted and
-    ignored.  ``path``: when given, the data is written there (tidy3d hdf5 when the real tidy3d
-    package is available, otherwise ``.npz``).  Extra keyword-only arguments select the GPU
+    ignored.  ``path``: when given, the data is written there — ``*.hdf5`` in the reference's file
+    layout (loadable with ``tidy3d.SimulationData.from_file``), any other name as ``.npz``.  Extra keyword-only arguments select the GPU
     (``device``), override the number of time steps (``n_steps``, tests/benchmarks) or pass an
     explicitly loaded library (``lib``, tests)."""
     from .engine import HipEngine
@@ -117,8 +117,24 @@ def run(simulation, task_name: Optional[str] = None, folder_name: str = "default
             out.to_file(path)
         return out
     if path:
-        save_npz(sim_data, path)
+        save(sim_data, path)
     return sim_data
+
+
+def save(sim_data: SimulationData, path: str) -> None:
+    """``.hdf5``: the reference's own file layout, written through the HDF5 C library
+    (tidy3d_amd/hdf5io.py) — loadable with ``tidy3d.SimulationData.from_file``; anything else: .npz."""
+    if path.endswith(".hdf5"):
+        from .hdf5io import write_simulation_data
+        write_simulation_data(sim_data, path)
+    else:
+        save_npz(sim_data, path)
+
+
+def load(path: str) -> SimulationData:
+    """Counterpart of ``tidy3d.web.load`` for a local file written by ``run(..., path=...)``."""
+    from .hdf5io import load_simulation_data
+    return load_simulation_data(path)
 
 
 def save_npz(sim_data: SimulationData, path: str) -> None:
