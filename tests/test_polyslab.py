@@ -1,7 +1,8 @@
 """PolySlab (vertical walls): slab bounds AND even-odd point-in-polygon.  The reference delegates
-the polygon test to matplotlib (absent here, ref polyslab.py:511-516) and its own PolySlab cannot
-be constructed under the stubbed shapely, so this is pinned by analytic cases: convex, concave and
-self-touching polygons, all three extrusion axes, and equivalence with Box for a rectangle."""
+the polygon test to ``matplotlib.path.Path.contains_points`` (ref polyslab.py:511-516) and its own
+PolySlab cannot be constructed under the stubbed shapely; pins: the real matplotlib function (run
+under the second python of the image that has it) on random simple and self-intersecting polygons,
+analytic masks, all three extrusion axes, and equivalence with Box for a rectangle."""
 import numpy as np
 import pytest
 
@@ -64,3 +65,44 @@ def test_parses_from_the_reference_json_form():
          "dilation": 0.0, "vertices": [[0, 0], [1, 0], [1, 1]]}
     g = td.parse(d)
     assert isinstance(g, td.PolySlab) and g.inside(np.array([0.7]), np.array([0.2]), np.array([0.0]))[0]
+
+
+_MPL = "/opt/conda/bin/python3.9"
+
+
+def _have_matplotlib():
+    import os
+    import subprocess
+    return os.path.exists(_MPL) and subprocess.run([_MPL, "-c", "import matplotlib.path"],
+                                                   capture_output=True).returncode == 0
+
+
+@pytest.mark.skipif(not _have_matplotlib(), reason="no python with matplotlib in this image")
+def test_point_in_polygon_equals_matplotlib_path(tmp_path):
+    """The reference's PolySlab.inside calls ``matplotlib.path.Path(vertices).contains_points``
+    (ref polyslab.py:511-516).  matplotlib is not importable by the product interpreter but a second
+    python in the image has it: random simple and self-intersecting polygons, random points."""
+    import json
+    import subprocess
+    rng = np.random.default_rng(7)
+    cases = []
+    for n in (3, 4, 7, 12, 25):
+        ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+        rad = rng.uniform(0.3, 1.0, n)
+        star = np.stack([rad * np.cos(ang), rad * np.sin(ang)], axis=1)     # simple, non-convex
+        cases.append(star)
+        cases.append(rng.uniform(-1, 1, (n, 2)))                             # generally self-intersecting
+    pts = rng.uniform(-1.1, 1.1, (3000, 2))
+    script = tmp_path / "mpl.py"
+    script.write_text("import json, sys\nimport numpy as np\nfrom matplotlib import path\n"
+                      "d = json.load(open(sys.argv[1]))\npts = np.array(d['pts'])\n"
+                      "print(json.dumps([path.Path(np.array(v)).contains_points(pts).tolist() for v in d['polys']]))\n")
+    inp = tmp_path / "in.json"
+    inp.write_text(json.dumps({"pts": pts.tolist(), "polys": [c.tolist() for c in cases]}))
+    r = subprocess.run([_MPL, str(script), str(inp)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = json.loads(r.stdout)
+    for verts, want in zip(cases, ref):
+        ps = td.PolySlab(vertices=verts, slab_bounds=(-1, 1), axis=2)
+        got = ps.inside(pts[:, 0], pts[:, 1], np.zeros(len(pts)))
+        assert np.array_equal(got, np.array(want)), len(verts)

@@ -243,7 +243,7 @@ class PolySlab(_Model):
     """Polygon extruded along ``axis`` (ref geometry/polyslab.py:37); vertical side walls without
     dilation only.  ``inside`` = slab bounds AND point-in-polygon; the reference delegates the
     latter to ``matplotlib.path.Path.contains_points`` (polyslab.py:511-516, third party, absent
-    here): restated as the even-odd crossing-number test with the half-open edge rule
+    here; pinned against the real function in tests/test_polyslab.py): restated as the even-odd crossing-number test with the half-open edge rule
     ``(y_i <= y) != (y_j <= y)`` — points exactly on an edge are implementation-defined in both."""
 
     vertices: Any = ()
