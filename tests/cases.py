@@ -24,6 +24,28 @@ def _sim(N, bspec, structures=(), sources=None, monitors=None, dl=DL, grid_spec=
                          boundary_spec=bspec, shutoff=0)
 
 
+def pipelined_slab_case(N=(28, 24, 32)):
+    """Everything the pipelined z-slab schedule splits between its two streams: x/y CPML slabs, ADE
+    (Lorentz sphere), a lossy box, electric and magnetic dipoles, a plane wave (incident-grid replica
+    on the comm stream), time / DFT / flux monitors.  Periodic z: runs as a 1-rank self exchange."""
+    structures = [
+        td.Structure(geometry=td.Sphere(center=(0.05, 0, 0.1), radius=0.2),
+                     medium=td.Lorentz(eps_inf=2.0, coeffs=[(1.5, 4e14, 3e13)])),
+        td.Structure(geometry=td.Box(center=(-0.3, 0, -0.3), size=(0.25, 0.3, 0.8)),
+                     medium=td.Medium(permittivity=3.0, conductivity=0.02))]
+    bspec = td.BoundarySpec(x=td.Boundary.pml(num_layers=5), y=td.Boundary.pml(num_layers=4), z=td.Boundary.periodic())
+    top = N[2] * DL / 2          # sources and monitors inside the top boundary chunk as well
+    sources = [td.PointDipole(center=(0.03, -0.07, 0.01), source_time=PULSE, polarization="Ez"),
+               td.PointDipole(center=(-0.1, 0.07, top - 0.04), source_time=PULSE, polarization="Hx"),
+               td.PlaneWave(center=(0.3, 0, 0), size=(0, td.inf, td.inf), source_time=PULSE, direction="-",
+                            pol_angle=0.4)]
+    monitors = [td.FieldTimeMonitor(center=(-0.1, 0.1, -0.05), size=(0.3, 0.2, td.inf), name="t", colocate=False,
+                                    interval=7),
+                td.FieldMonitor(center=(0, 0, top - 0.05), size=(0.4, 0.3, 0), freqs=[2.5e14, 3e14], name="f"),
+                td.FluxMonitor(center=(0, 0, 0), size=(0.5, 0.4, 1.5 * top), freqs=[3e14], name="box")]
+    return _sim(N, bspec, structures, sources=sources, monitors=monitors)
+
+
 def pec_box(N=(20, 16, 12)):
     return _sim(N, td.BoundarySpec.all_sides(td.PECBoundary()))
 

@@ -179,7 +179,21 @@ extern "C" void hipemu_set_exchange(hipemu_exchange_fn fn, void* user) { g_excha
 
 static ncclResult_t flush_ops() {
   if (g_ops.empty()) return ncclSuccess;
-  if (!g_exchange) { std::fprintf(stderr, "hipemu: ncclSend/Recv without exchange callback\n"); return ncclSystemError; }
+  if (!g_exchange) {
+    // no callback installed: a 1-rank communicator exchanging with itself — RCCL pairs the k-th
+    // send to a peer with the k-th receive from it
+    std::vector<hipemu_p2p_op> sends, recvs;
+    for (const hipemu_p2p_op& o : g_ops) (o.kind == 1 ? sends : recvs).push_back(o);
+    bool ok = sends.size() == recvs.size();
+    for (size_t k = 0; ok && k < sends.size(); ++k) ok = sends[k].bytes == recvs[k].bytes && recvs[k].kind == 0;
+    if (!ok) { std::fprintf(stderr, "hipemu: unmatched self Send/Recv and no exchange callback\n"); g_ops.clear(); return ncclSystemError; }
+    // receives may alias later sends' sources only through distinct planes: stage through copies
+    std::vector<std::vector<char>> tmp(sends.size());
+    for (size_t k = 0; k < sends.size(); ++k) tmp[k].assign((char*)sends[k].buf, (char*)sends[k].buf + sends[k].bytes);
+    for (size_t k = 0; k < sends.size(); ++k) std::memcpy(recvs[k].buf, tmp[k].data(), tmp[k].size());
+    g_ops.clear();
+    return ncclSuccess;
+  }
   int rc = g_exchange(g_ops.data(), (int)g_ops.size(), g_exchange_user);
   g_ops.clear();
   return rc == 0 ? ncclSuccess : ncclSystemError;

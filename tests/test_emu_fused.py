@@ -85,3 +85,32 @@ def test_fused_cpml_placement(mask, rows, zc, emu_lib):
         assert np.array_equal(got_f[c], ref_f[c]), c
     for k in ref_m:
         assert np.array_equal(got_m[k], ref_m[k]), k
+
+
+@pytest.mark.parametrize("bnd", [0, 3])
+def test_pipelined_slab_schedule_with_corrections(emu_lib, bnd):
+    """Logic of the pipelined z-slab schedule (boundary chunks + their corrections on the comm
+    stream, ONE exchange per step, joined tails on monitor / decay steps, re-priming across run
+    calls) with CPML, ADE, dipoles, a plane wave and monitors: 1-rank self exchange == plain run.
+    (tests/test_gpu_parity.py repeats it under real stream concurrency.)"""
+    from cases import pipelined_slab_case
+    disc = discretize(pipelined_slab_case((20, 16, 24)), n_steps=40)
+    disc.spec.decay_every = 16
+    assert disc.spec.tfsf
+    with HipEngine(disc.spec, lib=emu_lib) as e:
+        e.run()
+        ref = [e.get_field(c) for c in range(6)]
+        ref_m = e.results()
+    with HipEngine(disc.spec, lib=emu_lib, force_comm=True) as e:
+        assert e.variant == L.VARIANT_FUSED
+        e.comm_init(e.unique_id())
+        if bnd:
+            e.set_option(L.OPT_BND_PLANES, bnd)
+        e.run(17)
+        e.run(23)
+        got = [e.get_field(c) for c in range(6)]
+        got_m = e.results()
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    for k in ref_m:
+        assert np.array_equal(ref_m[k], got_m[k]), k

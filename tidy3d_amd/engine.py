@@ -149,6 +149,7 @@ class HipEngine:
             ok = (self.nxp % 4 == 0 and min(b - a for a, b in slabs) >= 4
                   and self._fused_slabs_ok(spec, n_ranks, slabs))
             variant = L.VARIANT_FUSED if ok else L.VARIANT_ZMARCH
+        self.variant = variant            # the schedule this engine (and every other rank) runs
         cfg.device, cfg.variant, cfg.flags, cfg.z_chunk = device, variant, flags, z_chunk
         cfg.ch = float(h_coeff(spec.dt))
         st = d.fdtd_create(C.byref(cfg), C.byref(self.handle))
