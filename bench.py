@@ -207,6 +207,8 @@ def main():
         "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]}; {n}^3 Yee cells, Ez point dipole "
                                "(GaussianPulse 200 THz), random +-1e-3 initial fields",
                    "grid": [n, n, n], "parallelism": f"z-slab x{world}",
+                   "tile": {"rows": int(st.tile_rows), "zchunk": int(st.tile_zchunk),
+                            "how": "library default" if not (args.rows or args.zchunk) else "flags"},
                    "bytes_per_cell_step": 2 * BYTES_PER_CELL_PASS,
                    "roofline_mcells_per_gpu": HBM_PEAK / (2 * BYTES_PER_CELL_PASS) / 1e6},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,

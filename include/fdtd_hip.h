@@ -66,6 +66,8 @@ typedef struct FdtdStats {
   int64_t device_bytes;      /* device memory held by the handle                                 */
   double  fused_kernel_ms;   /* ... and of the fused E+H sweep                                   */
   int64_t fused_kernel_launches;
+  int32_t tile_rows;         /* tile shape of the fused sweep in use (after autotuning)           */
+  int32_t tile_zchunk;
 } FdtdStats;
 
 /* progress callback: (step, time [s], field_decay) -> non-zero aborts the run (Ctrl-C path).
@@ -164,7 +166,8 @@ int fdtd_get_stats(FdtdSolver* h, FdtdStats* out);
 /* tuning knobs that may change between runs of one handle (bench A/B without re-upload) */
 enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_ROWS = 3, FDTD_OPT_XCD_REMAP = 4,
        FDTD_OPT_FUSED_LB = 5, FDTD_OPT_PML_FUSED = 6 /* axis bit mask: 0 (default), 6, 7 */,
-       FDTD_OPT_BND_PLANES = 7 /* planes per boundary chunk of the fused z-slab schedule, 0 = auto */ };
+       FDTD_OPT_BND_PLANES = 7 /* planes per boundary chunk of the fused z-slab schedule, 0 = auto */,
+       FDTD_OPT_AUTOTUNE = 8 /* 1: time a few tile shapes of the fused sweep on the first run of grids >= 2^20 cells (default 0) */ };
 int fdtd_set_option(FdtdSolver* h, int key, int value);
 int fdtd_reset(FdtdSolver* h);      /* zero fields, auxiliaries, monitors and the step counter */
 

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--zchunk", type=int, default=0)
     ap.add_argument("--bnd", type=int, default=0)
     ap.add_argument("--rows", type=int, default=0)
+    ap.add_argument("--autotune", type=int, default=1)
     args = ap.parse_args()
     n = 512
     steps, warm = args.steps, 30
@@ -56,6 +57,7 @@ def main():
                     e.set_option(L.OPT_BND_PLANES, args.bnd)
                 if args.rows:
                     e.set_option(L.OPT_ROWS, args.rows)
+                e.set_option(L.OPT_AUTOTUNE, args.autotune)
                 rng = np.random.default_rng(0)
                 for c in range(6):
                     e.set_field(c, rng.uniform(-1e-3, 1e-3, (nz, n, n)).astype(np.float32))
@@ -63,7 +65,8 @@ def main():
                 t0 = time.perf_counter()
                 e.run(steps)
                 dt = time.perf_counter() - t0
-                print(json.dumps({"slab_of": ngpu, "nz": nz, "mode": mode, "zchunk": args.zchunk, "bnd": args.bnd, "rows": args.rows, "ms_per_step": dt / steps * 1e3,
+                stt = e.stats()
+                print(json.dumps({"slab_of": ngpu, "nz": nz, "mode": mode, "zchunk": args.zchunk, "bnd": args.bnd, "rows": args.rows, "tile": [int(stt.tile_rows), int(stt.tile_zchunk)], "autotune": args.autotune, "ms_per_step": dt / steps * 1e3,
                                   "ideal_ms": 1.244 / ngpu,
                                   "implied_speedup_vs_1gpu": 1.244 / (dt / steps * 1e3)}), flush=True)
 

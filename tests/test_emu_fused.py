@@ -114,3 +114,29 @@ def test_pipelined_slab_schedule_with_corrections(emu_lib, bnd):
         assert np.array_equal(a, b)
     for k in ref_m:
         assert np.array_equal(ref_m[k], got_m[k]), k
+
+
+def test_autotuned_tile_shape_changes_nothing_but_the_shape(emu_lib):
+    """With FDTD_OPT_AUTOTUNE fdtd_run times a few (rows, z-chunk) shapes of the fused sweep on its
+    first call (grids of >= 2^20 cells; forced here) and keeps the fastest: the sweep only reads set A and writes set B,
+    so the probing has no side effect, and the arithmetic does not depend on the launch geometry."""
+    N, bspec, structures = CONFIGS["pml_media"]
+    disc = discretize(_sim(N, bspec, structures), n_steps=20)
+    with HipEngine(disc.spec, lib=emu_lib, variant=L.VARIANT_FUSED) as e:
+        e.set_option(L.OPT_AUTOTUNE, 0)
+        e.run()
+        ref = [e.get_field(c) for c in range(6)]
+        ref_m = e.results()
+        assert (e.stats().tile_rows, e.stats().tile_zchunk) == (3, 16)
+    with HipEngine(disc.spec, lib=emu_lib, variant=L.VARIANT_FUSED) as e:
+        e.set_option(L.OPT_AUTOTUNE, 2)
+        e.run(7)
+        e.run(13)
+        st = e.stats()
+        assert st.tile_rows in (2, 3) and st.tile_zchunk in (8, 16, 24, 32)
+        got = [e.get_field(c) for c in range(6)]
+        got_m = e.results()
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    for k in ref_m:
+        assert np.array_equal(ref_m[k], got_m[k]), k

@@ -125,6 +125,12 @@ struct FdtdSolver {
   // extra live registers drop the sweep from 3 to 2 (mask 6) or 1 (mask 7) waves per SIMD, which
   // costs more (+0.41 ms / +3.0 ms) than the slab kernels it removes (0.22 ms / 0.45 ms) -> default 0.
   int pml_fused = 0;
+  // opt-in (FDTD_OPT_AUTOTUNE): time a few (rows, z-chunk) tile shapes on the first run and keep the
+  // best.  Measured (profiles/r01h_autotune.txt): +6 % on a 64-plane slab (3 x 32 instead of 3 x 16),
+  // nothing at 512^3 (shapes within noise of each other, so the pick is noise too) and the wrong
+  // objective for the pipelined z-slab schedule (it times the whole range) -> off by default.
+  int autotune = 0;
+  bool tuned = false, user_geometry = false;
   int bnd_planes = 0;                // fused z-slab schedule: planes per boundary chunk (0 = heuristic)
   int rows = 4;
   // RCCL
@@ -345,6 +351,44 @@ void swap_sets(FdtdSolver* h) {
 int launch_fused(FdtdSolver* h, hipStream_t st, int pml_inside) {
   if (launch_fused_range(h, 0, h->g.nz, st, pml_inside)) return -1;
   swap_sets(h);
+  return 0;
+}
+
+// Tile-shape autotuning of the fused sweep.  Which (rows, z-chunk) shape is fastest depends on how
+// the tile count quantises onto 256 CUs x 3 workgroups and on the slab height (profiles/
+// r01g_probe_geometry.jsonl: 107 .. 111 Gcells/s across shapes at 512^3; a 64-plane slab prefers
+// taller chunks).  The sweep reads set A and writes set B only, so timing it has no side effect
+// and — the arithmetic being independent of the launch geometry — no effect on the results.
+int autotune_fused(FdtdSolver* h, hipStream_t st) {
+  h->tuned = true;
+  const int nz = h->g.nz;
+  if (ensure_second_set(h)) return -1;
+  const int flags = h->cfg.flags;
+  h->cfg.flags &= ~FDTD_FLAG_TIME_KERNELS;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const int rows_c[2] = {3, 2};
+  const int zc_c[4] = {16, 24, 32, 8};
+  int best_r = h->rows_f, best_z = h->zchunk_f;
+  float best = 1e30f;
+  for (int r : rows_c)
+    for (int z : zc_c) {
+      if (z > nz && z != 16) continue;
+      h->rows_f = r; h->zchunk_f = z;
+      if (launch_fused_range(h, 0, nz, st)) return -1;             // warm-up (instruction cache, TLB)
+      hipEventRecord(e0, st);
+      for (int k = 0; k < 2; ++k) if (launch_fused_range(h, 0, nz, st)) return -1;
+      hipEventRecord(e1, st);
+      if (hipEventSynchronize(e1) != hipSuccess) break;
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, e0, e1);
+      if (ms < best) { best = ms; best_r = r; best_z = z; }
+    }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  h->rows_f = best_r; h->zchunk_f = best_z;
+  h->cfg.flags = flags;
   return 0;
 }
 
@@ -681,6 +725,7 @@ int fdtd_create(const FdtdConfig* cfg, FdtdSolver** out) {
   // workgroups balance the 256 CUs better than long marches.
   h->zchunk = cfg->z_chunk > 0 ? cfg->z_chunk : 2;
   h->zchunk_f = cfg->z_chunk > 0 ? cfg->z_chunk : 16;
+  h->user_geometry = cfg->z_chunk > 0;
   h->rows = 4;
   int rc = 0;
   const size_t fcount = (size_t)g.sxy * (g.nz + 2);
@@ -1088,6 +1133,20 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     if ((nb_hi && b_hi < 1) || (nb_lo && b_lo < 1))
       return fail(h, "fdtd_run: the fused z-slab schedule needs at least 2 planes between a slab cut and the z-PML");
   }
+  // (autotune == 2 lifts the size threshold: test aid for the emulated library)
+  if ((fused || fused_multi) && h->autotune && !h->tuned && !h->user_geometry &&
+      (n_cells(h) >= (1LL << 20) || h->autotune == 2)) {
+    if (autotune_fused(h, st)) return -1;
+    if (fused_multi) {           // the boundary-chunk thickness follows the chosen z-chunk
+      int zb = h->bnd_planes > 0 ? h->bnd_planes : std::min(h->zchunk_f, nz / 4);
+      zb = std::max(1, std::min(zb, nz / 2));
+      const PmlAxisDev& pz = h->pml[2];
+      b_lo = nb_lo ? zb : 0;
+      b_hi = nb_hi ? zb : 0;
+      if (nb_hi && pz.n_lo > 0) b_hi = std::min(b_hi, nz - pz.n_lo - 1);
+      if (nb_lo && pz.n_hi > 0) b_lo = std::min(b_lo, nz - pz.n_hi - 1);
+    }
+  }
   bool primed = false;
   auto e_post = [&](long long n, int k0, int k1, hipStream_t s, bool replica) {
     launch_pml(h, true, k0, k1, s);
@@ -1327,11 +1386,12 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
   switch (key) {
     case FDTD_OPT_FLAGS: h->cfg.flags = value; return 0;
     case FDTD_OPT_VARIANT: h->cfg.variant = value; return 0;
-    case FDTD_OPT_ZCHUNK: if (value < 1) break; h->zchunk = value; h->zchunk_f = value; return 0;
-    case FDTD_OPT_ROWS: if (value < 1 || value > 15) break; h->rows = value > 8 ? 8 : value; h->rows_f = value; return 0;
+    case FDTD_OPT_ZCHUNK: if (value < 1) break; h->zchunk = value; h->zchunk_f = value; h->user_geometry = true; return 0;
+    case FDTD_OPT_ROWS: if (value < 1 || value > 15) break; h->rows = value > 8 ? 8 : value; h->rows_f = value; h->user_geometry = true; return 0;
     case FDTD_OPT_XCD_REMAP: h->xcd_remap = value != 0; return 0;
     case FDTD_OPT_PML_FUSED: h->pml_fused = value & 7; return 0;
     case FDTD_OPT_BND_PLANES: h->bnd_planes = value > 0 ? value : 0; return 0;
+    case FDTD_OPT_AUTOTUNE: h->autotune = value < 0 ? 0 : (value > 2 ? 1 : value); if (value) h->tuned = false; return 0;
     case FDTD_OPT_FUSED_LB: if (value != 0 && value != 256 && value != 512 && value != 1024) break; h->fused_lb = value; return 0;
     default: break;
   }
@@ -1341,6 +1401,8 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
 int fdtd_get_stats(FdtdSolver* h, FdtdStats* out) {
   if (!h || !out) return -1;
   *out = h->stats;
+  out->tile_rows = h->rows_f;
+  out->tile_zchunk = h->zchunk_f;
   return 0;
 }
 
