@@ -178,3 +178,27 @@ def test_reads_a_file_written_by_h5py_and_matches_its_structure(tmp_path):
         b = subprocess.run([dump, "-H", mine], capture_output=True, text=True).stdout.replace(mine, "F")
         norm = lambda s: sorted(line.strip() for line in s.splitlines())      # creation order may differ
         assert norm(a) == norm(b), (a, b)
+
+
+def test_job_and_batch_facade(emu_lib, tmp_path):
+    """ref web/api/container.py: Job.run(path) / Batch.run(path_dir) -> BatchData[task_name]."""
+    from tidy3d_amd.web import Batch, BatchData, Job
+    mk = lambda eps: td.Simulation(
+        size=(12 * DL, 10 * DL, 8 * DL), grid_spec=td.GridSpec.uniform(dl=DL), run_time=2e-14,
+        structures=[td.Structure(geometry=td.Box(center=(0, 0, 0), size=(0.2, 0.2, 0.2)), medium=td.Medium(permittivity=eps))],
+        sources=[td.PointDipole(center=(0, 0, 0), source_time=PULSE, polarization="Ez")],
+        monitors=[td.FluxMonitor(center=(0, 0, 0.1), size=(0.3, 0.3, 0), freqs=[3e14], name="fl")],
+        boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary()))
+    job = Job(mk(2.0), task_name="one", lib=emu_lib, n_steps=30, verbose=False)
+    sd = job.run(path=str(tmp_path / "one.hdf5"))
+    assert job.status == "success" and (tmp_path / "one.hdf5").exists() and sd["fl"].flux.shape == (1,)
+    batch = Batch({"a": mk(2.0), "b": mk(6.0)}, lib=emu_lib, n_steps=30, verbose=False)
+    bd = batch.run(path_dir=str(tmp_path / "batch"))
+    assert isinstance(bd, BatchData) and len(bd) == 2 and batch.num_jobs == 2
+    names = [n for n, _ in bd.items()]
+    assert names == ["a", "b"]
+    assert np.array_equal(bd["a"]["fl"].flux.values, sd["fl"].flux.values)
+    assert not np.array_equal(bd["b"]["fl"].flux.values, sd["fl"].flux.values)
+    # a fresh BatchData reads the files back
+    again = BatchData(task_paths=bd.task_paths, task_ids=bd.task_ids)
+    assert np.array_equal(again["b"]["fl"].flux.values, bd["b"]["fl"].flux.values)

@@ -96,6 +96,8 @@ def install(td_module=None):
     tests use for ``run_emulated`` (ref tests/test_plugins/test_adjoint.py:95)."""
     if td_module is None:
         import tidy3d as td_module
-    from .web import run
+    from .web import Batch, Job, run
     td_module.web.run = run
+    # the containers the plugins and user scripts reach for (ref web/api/container.py)
+    td_module.web.Job, td_module.web.Batch = Job, Batch
     return run

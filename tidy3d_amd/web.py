@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import json
 import logging
+import os
 import time
 from typing import Optional
 
@@ -153,3 +154,155 @@ def save_npz(sim_data: SimulationData, path: str) -> None:
             for dim, c in v.coords.items():
                 blobs[f"{name}/{k}/{dim}"] = c
     np.savez(path if path.endswith(".npz") else path + ".npz", **blobs)
+
+
+# ----------------------------------------------------------------------------------------------
+# Job / Batch façade (ref web/api/container.py): the cloud life cycle upload -> start -> monitor ->
+# download -> load collapses to one local solve; names, arguments and return types are kept so that
+# scripts written against tidy3d.web.Job / Batch run unchanged.
+# ----------------------------------------------------------------------------------------------
+
+DEFAULT_DATA_PATH = "simulation_data.hdf5"       # ref web/api/webapi.py / container.py defaults
+DEFAULT_DATA_DIR = "."
+
+
+class Job:
+    """ref container.py:35 — one simulation; ``run(path)`` returns its SimulationData."""
+
+    def __init__(self, simulation, task_name: str, folder_name: str = "default", callback_url: Optional[str] = None,
+                 solver_version: Optional[str] = None, verbose: bool = True, simulation_type: str = "tidy3d",
+                 parent_tasks=None, **run_kwargs):
+        self.simulation, self.task_name, self.folder_name = simulation, task_name, folder_name
+        self.verbose, self.run_kwargs = verbose, run_kwargs
+        self.task_id = f"local-{task_name}"
+        self._data: Optional[SimulationData] = None
+        self._path: Optional[str] = None
+
+    def upload(self) -> None:                       # nothing leaves this machine
+        pass
+
+    def start(self) -> None:
+        if self._data is None:
+            self._data = run(self.simulation, task_name=self.task_name, folder_name=self.folder_name,
+                             verbose=self.verbose, **self.run_kwargs)
+
+    def monitor(self) -> None:
+        pass
+
+    @property
+    def status(self) -> str:
+        return "success" if self._data is not None else "draft"
+
+    def download(self, path: str = DEFAULT_DATA_PATH) -> None:
+        self.start()
+        data = self._data
+        if hasattr(data, "to_file"):               # a genuine tidy3d.SimulationData
+            data.to_file(path)
+        else:
+            save(data, path)
+        self._path = path
+
+    def load(self, path: str = DEFAULT_DATA_PATH):
+        if self._data is None or self._path != path:
+            self.download(path)
+        return self._data
+
+    def run(self, path: str = DEFAULT_DATA_PATH):
+        """ref container.py:190-207."""
+        self.upload()
+        self.start()
+        self.monitor()
+        return self.load(path=path)
+
+    def delete(self) -> None:
+        self._data = None
+
+    def estimate_cost(self, verbose: bool = True) -> float:
+        return 0.0                                   # no FlexCredits on your own GPU
+
+    real_cost = estimate_cost
+
+
+class BatchData:
+    """ref container.py:342 — maps task names to data files and loads them one at a time."""
+
+    def __init__(self, task_paths: dict, task_ids: dict, verbose: bool = True, _cache: Optional[dict] = None):
+        self.task_paths, self.task_ids, self.verbose = dict(task_paths), dict(task_ids), verbose
+        self._cache = _cache or {}
+
+    def load_sim_data(self, task_name: str):
+        if task_name in self._cache:
+            return self._cache[task_name]
+        return load(self.task_paths[task_name])
+
+    def items(self):
+        for task_name in self.task_paths:
+            yield task_name, self.load_sim_data(task_name)
+
+    def __getitem__(self, task_name: str):
+        return self.load_sim_data(task_name)
+
+    def __len__(self):
+        return len(self.task_paths)
+
+
+class Batch:
+    """ref container.py:426 — several simulations; ``run(path_dir)`` returns a BatchData.  The jobs
+    run one after the other on the local GPU (``device=`` in ``run_kwargs`` selects it)."""
+
+    def __init__(self, simulations: dict, folder_name: str = "default", verbose: bool = True,
+                 solver_version: Optional[str] = None, callback_url: Optional[str] = None,
+                 simulation_type: str = "tidy3d", parent_tasks=None, **run_kwargs):
+        self.simulations, self.folder_name, self.verbose = dict(simulations), folder_name, verbose
+        self.run_kwargs = run_kwargs
+        self.jobs = {name: Job(sim, task_name=name, folder_name=folder_name, verbose=verbose, **run_kwargs)
+                     for name, sim in self.simulations.items()}
+
+    @property
+    def num_jobs(self) -> int:
+        return len(self.jobs)
+
+    def upload(self) -> None:
+        pass
+
+    def start(self) -> None:
+        for job in self.jobs.values():
+            job.start()
+
+    def monitor(self) -> None:
+        pass
+
+    @staticmethod
+    def _job_data_path(task_id: str, path_dir: str = DEFAULT_DATA_DIR) -> str:
+        return os.path.join(path_dir, f"{task_id}.hdf5")          # ref container.py:762-778
+
+    def download(self, path_dir: str = DEFAULT_DATA_DIR) -> None:
+        os.makedirs(path_dir, exist_ok=True)
+        for job in self.jobs.values():
+            job.download(self._job_data_path(job.task_id, path_dir))
+
+    def load(self, path_dir: str = DEFAULT_DATA_DIR) -> BatchData:
+        paths = {name: self._job_data_path(job.task_id, path_dir) for name, job in self.jobs.items()}
+        for name, job in self.jobs.items():
+            if job._path != paths[name]:
+                job.download(paths[name])
+        return BatchData(task_paths=paths, task_ids={n: j.task_id for n, j in self.jobs.items()},
+                         verbose=self.verbose, _cache={n: j._data for n, j in self.jobs.items()})
+
+    def run(self, path_dir: str = DEFAULT_DATA_DIR) -> BatchData:
+        """ref container.py:523-557."""
+        os.makedirs(path_dir, exist_ok=True)
+        self.upload()
+        self.start()
+        self.monitor()
+        self.download(path_dir=path_dir)
+        return self.load(path_dir=path_dir)
+
+    def delete(self) -> None:
+        for job in self.jobs.values():
+            job.delete()
+
+    def estimate_cost(self, verbose: bool = True) -> float:
+        return 0.0
+
+    real_cost = estimate_cost
