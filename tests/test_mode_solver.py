@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import tidy3d_amd.schema as td
-from tidy3d_amd.constants import C_0
+from tidy3d_amd.constants import C_0, ETA_0
 from tidy3d_amd.mode_solver import mode_flux, solve_modes
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -126,3 +126,38 @@ def test_mode_source_launches_one_way_with_unit_power():
     lo = np.cos(beta * dl / 2) ** 2
     assert np.all(sd["fwd"].flux.values > lo - 5e-3) and np.all(sd["fwd"].flux.values < 1.005)
     assert abs(sd["bwd"].flux.values[0]) < 1e-5
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/tidy3d"), reason="reference checkout not present")
+@pytest.mark.parametrize("symmetry", [(1, 0), (0, 1), (1, -1), (-1, 1), (1, 1)])
+def test_symmetry_walls_match_reference(symmetry):
+    """PMC (+1) / PEC (-1, 0) walls on the min edges == ref solver.py:182-197 (dmin_pmc) on the
+    upper-right quadrant of a symmetric rib; effective indices and tangential fields."""
+    import sys
+    sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..")))
+    from oracle.tidy3d_ref_loader import load_mode_solver
+    _, solver = load_mode_solver()
+    xb = np.linspace(0.0, 1.2, 41)
+    yb = np.concatenate(([0.0], np.cumsum(np.linspace(0.02, 0.045, 30))))
+    xc, yc = (xb[1:] + xb[:-1]) / 2, (yb[1:] + yb[:-1]) / 2
+
+    def eps_at(x, y):
+        X, Y = np.meshgrid(x, y, indexing="ij")
+        e = np.full(X.shape, 1.44 ** 2, complex)
+        e[(X <= 0.25) & (Y <= 0.11)] = 3.48 ** 2
+        return e
+    exx, eyy, ezz = eps_at(xc, yb[:-1]), eps_at(xb[:-1], yc), eps_at(xb[:-1], yb[:-1])
+    z = np.zeros_like(exx)
+    ms = SimpleNamespace(num_modes=2, bend_radius=None, bend_axis=None, angle_theta=0.0, angle_phi=0.0,
+                         num_pml=(0, 0), target_neff=None, precision="double")
+    fields, n_ref, _ = solver.compute_modes(eps_cross=[exx, z, z, z, eyy, z, z, z, ezz], coords=[xb, yb],
+                                            freq=C_0 / 1.55, mode_spec=ms, symmetry=symmetry, direction="+")
+    r = solve_modes(exx, eyy, ezz, xb, yb, C_0 / 1.55, num_modes=2, pmc_min=tuple(s == 1 for s in symmetry))
+    np.testing.assert_allclose(r.n_complex, n_ref, rtol=1e-7)
+    for m in range(2):
+        mine = np.concatenate([r.Eu[:, :, m].ravel(), r.Ev[:, :, m].ravel(), ETA_0 * r.Hu[:, :, m].ravel(),
+                               ETA_0 * r.Hv[:, :, m].ravel()])
+        ref = np.concatenate([fields[0, 0, :, :, 0, m].ravel(), fields[0, 1, :, :, 0, m].ravel(),
+                              ETA_0 * fields[1, 0, :, :, 0, m].ravel(), ETA_0 * fields[1, 1, :, :, 0, m].ravel()])
+        ov = abs(np.vdot(ref, mine)) / (np.linalg.norm(ref) * np.linalg.norm(mine))
+        assert ov > 1 - 1e-6, (symmetry, m, ov)

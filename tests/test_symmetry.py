@@ -95,3 +95,41 @@ def test_unsupported_combinations_are_named():
     with pytest.raises(Tidy3dNotImplementedError, match="TFSF"):
         D.discretize(_sim((1, 0, 0), sources=[td.TFSF(center=(0.1, -0.05, 0), size=(0.3, 0.3, 0.3), source_time=PULSE,
                                                        injection_axis=2, direction="+")]), n_steps=4)
+
+
+def _waveguide(symmetry, n_steps_unused=None):
+    """Si strip in oxide, TE0 launched along +x.  E_y of TE0 is even in y, where it is the normal
+    component (PEC plane, -1), and even in z (PMC plane, +1)."""
+    dl = 0.0625
+    pulse = td.GaussianPulse(freq0=2e14, fwidth=3e13)
+    ms = td.ModeSpec(num_modes=1, target_neff=2.85, precision="double")      # TE0 in both runs
+    plane = (0, 1.3, 1.1)
+    return td.Simulation(
+        size=(32 * dl, 28 * dl, 24 * dl), grid_spec=td.GridSpec.uniform(dl=dl), run_time=1e-13, symmetry=symmetry,
+        medium=td.Medium(permittivity=1.44 ** 2),
+        structures=[td.Structure(geometry=td.Box(center=(0, 0, 0), size=(td.inf, 0.5, 0.25)),
+                                 medium=td.Medium(permittivity=3.48 ** 2))],
+        sources=[td.ModeSource(center=(-0.5, 0, 0), size=plane, source_time=pulse, mode_spec=ms, mode_index=0,
+                               direction="+")],
+        monitors=[td.ModeMonitor(center=(0.45, 0, 0), size=plane, freqs=[1.9e14, 2e14], mode_spec=ms, name="modes"),
+                  td.FluxMonitor(center=(0.45, 0, 0), size=plane, freqs=[2e14], name="flux"),
+                  td.FieldMonitor(center=(0.2, 0, 0), size=(0, 0.83, 0.57), freqs=[2e14], name="xs")],
+        boundary_spec=td.BoundarySpec.all_sides(td.PML(num_layers=4)))
+
+
+def test_mode_source_and_monitor_with_symmetry():
+    """ModeSource + ModeMonitor on a quarter domain: the mode plane is solved behind the PEC / PMC
+    walls (== reference compute_modes(symmetry=...), tests/test_mode_solver.py), launched with 1 W
+    over the WHOLE plane, and decomposed on the computed quarter — same amplitudes, effective
+    indices, flux and fields as the full run."""
+    _, full = _run_oracle(_waveguide((0, 0, 0)), 620)
+    disc, quarter = _run_oracle(_waveguide((0, -1, 1)), 620)
+    assert np.prod(disc.spec.shape) < 0.4 * 40 * 36 * 32
+    np.testing.assert_allclose(quarter["modes"].n_complex.values, full["modes"].n_complex.values, rtol=1e-6)
+    a_f, a_q = full["modes"].amps.values, quarter["modes"].amps.values
+    # mode 0 (TE0, the launched one): equal amplitudes; the sign of an eigenvector is arbitrary
+    assert np.abs(a_f[0, :, 0]).max() > 0.1
+    np.testing.assert_allclose(np.abs(a_q[:, :, 0]), np.abs(a_f[:, :, 0]), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(quarter["flux"].flux.values, full["flux"].flux.values, rtol=2e-4)
+    ez_f, ez_q = full["xs"].Ey.values, quarter["xs"].Ey.values
+    assert np.abs(ez_f - ez_q).max() <= 2e-4 * np.abs(ez_f).max()

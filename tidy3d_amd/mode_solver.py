@@ -48,31 +48,36 @@ class ModeResult:
     Hw: np.ndarray
 
 
-def _diff_ops(nu: int, nv: int, du_p, dv_p, du_d, dv_d, pec_min=(True, True)):
+def _diff_ops(nu: int, nv: int, du_p, dv_p, du_d, dv_d, pmc_min=(False, False)):
     """Sparse forward (on primal steps) and backward (on dual steps) difference operators for
-    fields flattened as index = iu * nv + iv."""
+    fields flattened as index = iu * nv + iv.  Min edge of each axis: PEC wall, or a PMC wall
+    (``pmc_min``: the symmetry plane of an even mode, ref derivatives.py:9-62 ``dmin_pmc``)."""
     def fwd(n, d):
         D = sp.diags([-np.ones(n), np.ones(n - 1)], [0, 1], shape=(n, n), format="csr")
         return sp.diags(1.0 / d) @ D            # last row: (0 - f[n-1]) -> truncation = PEC
-    def bwd(n, d):
+    def bwd(n, d, pmc):
         main = np.ones(n)
-        main[0] = 0.0     # row 0 lives on the PEC wall: it only feeds wall-tangential E (clamped to
-        #                   zero) and wall-normal H (zero on a PEC) -> ref derivatives.py:43-62
+        # row 0 lives on the wall.  PEC: it only feeds wall-tangential E (clamped to zero) and
+        # wall-normal H (zero on a PEC) -> 0.  PMC: the H node below the wall is minus the one above
+        # it -> H[0] - (-H[0]) = 2 H[0]   (ref derivatives.py:24-35)
+        main[0] = 2.0 if pmc else 0.0
         D = sp.diags([main, -np.ones(n - 1)], [0, -1], shape=(n, n), format="csr")
         return sp.diags(1.0 / d) @ D
     Iu, Iv = sp.identity(nu, format="csr"), sp.identity(nv, format="csr")
     Duf = sp.kron(fwd(nu, du_p), Iv, format="csr")
     Dvf = sp.kron(Iu, fwd(nv, dv_p), format="csr")
-    Dub = sp.kron(bwd(nu, du_d), Iv, format="csr")
-    Dvb = sp.kron(Iu, bwd(nv, dv_d), format="csr")
+    Dub = sp.kron(bwd(nu, du_d, pmc_min[0]), Iv, format="csr")
+    Dvb = sp.kron(Iu, bwd(nv, dv_d, pmc_min[1]), format="csr")
     return Duf, Dvf, Dub, Dvb
 
 
 def solve_modes(eps_u: np.ndarray, eps_v: np.ndarray, eps_w: np.ndarray, ub: np.ndarray,
                 vb: np.ndarray, freq: float, num_modes: int = 1,
-                target_neff: Optional[float] = None, precision: str = "double") -> ModeResult:
+                target_neff: Optional[float] = None, precision: str = "double",
+                pmc_min: Tuple[bool, bool] = (False, False)) -> ModeResult:
     """eps_* are [Nu, Nv] (complex allowed) sampled at E_u (uc, vb), E_v (ub, vc), E_w (ub, vb);
-    ub / vb the Nu+1 / Nv+1 cell boundaries."""
+    ub / vb the Nu+1 / Nv+1 cell boundaries.  ``pmc_min``: PMC instead of PEC on the min edge of
+    u / v (a symmetry plane with eigenvalue +1; PEC covers -1 and the default truncation)."""
     nu, nv = eps_u.shape
     N = nu * nv
     # lossless cross-sections give a real operator (half the LU cost); "single" follows
@@ -85,13 +90,19 @@ def solve_modes(eps_u: np.ndarray, eps_v: np.ndarray, eps_w: np.ndarray, ub: np.
     du_p, dv_p = np.diff(ub), np.diff(vb)
     du_d = np.concatenate(([du_p[0]], 0.5 * (du_p[1:] + du_p[:-1])))
     dv_d = np.concatenate(([dv_p[0]], 0.5 * (dv_p[1:] + dv_p[:-1])))
-    Duf, Dvf, Dub, Dvb = _diff_ops(nu, nv, du_p, dv_p, du_d, dv_d)
+    Duf, Dvf, Dub, Dvb = _diff_ops(nu, nv, du_p, dv_p, du_d, dv_d, pmc_min)
     eu, ev, ew = (sp.diags(np.asarray(a).reshape(-1)) for a in (eps_u, eps_v, eps_w))
     ewi = sp.diags(1.0 / np.asarray(eps_w).reshape(-1))
     # PEC on the min edges: the tangential E that sits on a wall is clamped to zero
-    mask_u = np.ones((nu, nv)); mask_u[:, 0] = 0        # E_u at vb[0]
-    mask_v = np.ones((nu, nv)); mask_v[0, :] = 0        # E_v at ub[0]
-    mask_w = np.ones((nu, nv)); mask_w[0, :] = 0; mask_w[:, 0] = 0
+    mask_u = np.ones((nu, nv))
+    mask_v = np.ones((nu, nv))
+    mask_w = np.ones((nu, nv))
+    if not pmc_min[1]:
+        mask_u[:, 0] = 0        # E_u at vb[0]
+        mask_w[:, 0] = 0
+    if not pmc_min[0]:
+        mask_v[0, :] = 0        # E_v at ub[0]
+        mask_w[0, :] = 0
     Mu, Mv, Mw = (sp.diags(m.reshape(-1)) for m in (mask_u, mask_v, mask_w))
     I = sp.identity(N, format="csr")
     # E_w = (i/(k0 eps_w)) (Dub Ht_v - Dvb Ht_u)   -> rows of P

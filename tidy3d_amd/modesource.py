@@ -27,7 +27,7 @@ from .discretize import discretize_inds
 from .exceptions import SetupError, Tidy3dNotImplementedError
 from .mode_solver import ModeResult, solve_modes
 from .planewave import surface_legs
-from .spec import PointSourceSet, SolverSpec
+from .spec import BC_PMC, PointSourceSet, SolverSpec
 
 
 @dataclass
@@ -83,9 +83,12 @@ def mode_profile(spec: SolverSpec, box: td.Box, mode_spec, freq: float) -> ModeP
     eps_w = _eps_plane(spec, p, p, k0, lo, hi, u, v, freq)
     ub = b[u][lo[0]:hi[0] + 1]
     vb = b[v][lo[1]:hi[1] + 1]
+    # a plane that reaches a PMC wall of the grid (a symmetry plane with eigenvalue +1) gets the PMC
+    # edge there; PEC walls / the plane's own truncation are the solver's default (ref solver.py:182-197)
+    pmc_min = tuple(bool(lo[i] == 0 and spec.bc[a][0] == BC_PMC) for i, a in enumerate((u, v)))
     res = solve_modes(eps_u, eps_v, eps_w, ub, vb, freq, num_modes=int(mode_spec.num_modes),
                       target_neff=mode_spec.target_neff,
-                      precision=getattr(mode_spec, "precision", "single") or "single")
+                      precision=getattr(mode_spec, "precision", "single") or "single", pmc_min=pmc_min)
     return ModePlane(p=p, u=u, v=v, k0=k0, lo=lo, hi=hi, result=res)
 
 
@@ -111,8 +114,15 @@ def build_mode_source(disc, mt, src) -> Callable:
     legs = surface_legs(spec, mt, lo, hi, (u, v), (u, v))
     d = spec.primal_steps(p)
     # backward-travelling mode: tangential H flips sign
-    fields = {u: r.Eu[:, :, mi], v: r.Ev[:, :, mi], 3 + u: direction * r.Hu[:, :, mi],
-              3 + v: direction * r.Hv[:, :, mi]}
+    # symmetry: the solved plane is one half / quarter of the user's plane and its mode carries
+    # unit power on that part — the launched mode carries 1 W over the whole plane (ref source.py:1003)
+    sym = getattr(sim, "_symmetry", (0, 0, 0))
+    scale = 1.0
+    for i, a in enumerate((u, v)):
+        if sym[a] != 0 and plane.lo[i] == 0:
+            scale /= np.sqrt(2.0)
+    fields = {u: scale * r.Eu[:, :, mi], v: scale * r.Ev[:, :, mi], 3 + u: scale * direction * r.Hu[:, :, mi],
+              3 + v: scale * direction * r.Hv[:, :, mi]}
 
     def sample(nb_comp, nb_ijk):
         iu = nb_ijk[:, u] - plane.lo[0]
@@ -196,6 +206,7 @@ def mode_monitor_data(disc, plan, raw, norm):
     mon = plan.monitor
     spec = disc.spec
     fp = plan.fields[0]
+    box = fp.box if fp.box is not None else mon.geometry       # symmetry: the image inside the computed half
     freqs = np.asarray(mon.freqs, float)
     fd = _field_container(FieldData, mon, spec, fp, raw[fp.spec_name], "f", freqs, disc.sim.center,
                           np.complex128).normalize(norm)
@@ -215,18 +226,43 @@ def mode_monitor_data(disc, plan, raw, norm):
         return arr                                # (u, v, f)
     F = {"Eu": plane_vals("E" + names[u]), "Ev": plane_vals("E" + names[v]),
          "Hu": plane_vals("H" + names[u]), "Hv": plane_vals("H" + names[v])}
-    w = _diff_area(mon.geometry, None, None, p, gu, gv)
+
+    # symmetry planes inside the monitor plane: the decomposition runs on the computed part; a
+    # component that is odd across the plane and straddles it is zero ON it (the one-sided
+    # colocation returned the upper node), and amplitudes refer to modes of unit power over the
+    # whole plane: sqrt(2) per halving
+    from .data import _SYM_EIG
+    sym = tuple(getattr(disc, "symmetry", (0, 0, 0)))
+    comp_of = {"Eu": "E" + names[u], "Ev": "E" + names[v], "Hu": "H" + names[u], "Hv": "H" + names[v]}
+    wall = []                                    # (array axis, in-plane axis) of symmetry walls touched
+    for i, (a, g) in enumerate(((u, gu), (v, gv))):
+        c = disc.sim.center[a]
+        if sym[a] != 0 and len(g) and abs(g[0] - c) <= 1e-9 * max(1.0, abs(c)):
+            wall.append((i, a))
+    amp_scale = np.sqrt(2.0) ** len(wall)
+
+    def zero_on_walls(fields):
+        for key, cname in comp_of.items():
+            for i, a in wall:
+                straddles = (cname[0] == "E") == ("xyz".index(cname[1]) == a)
+                if straddles and sym[a] * _SYM_EIG[cname][a] < 0:
+                    idx = [slice(None)] * fields[key].ndim
+                    idx[i] = 0
+                    fields[key][tuple(idx)] = 0.0
+        return fields
+    F = zero_on_walls({k: np.array(a) for k, a in F.items()})
+    w = _diff_area(box, None, None, p, gu, gv)
     nm = int(mon.mode_spec.num_modes)
     amps = np.zeros((2, len(freqs), nm), complex)
     neff = np.zeros((len(freqs), nm), complex)
     for i, f in enumerate(freqs):
-        plane = mode_profile(spec, mon.geometry, mon.mode_spec, float(f))
+        plane = mode_profile(spec, box, mon.mode_spec, float(f))
         neff[i] = plane.result.n_complex
         Ff = {k: a[:, :, i] for k, a in F.items()}
         for m in range(nm):
             for d_i, direction in enumerate((1, -1)):
-                M = colocated_mode(plane, spec, m, direction, gu, gv)
-                amps[d_i, i, m] = overlap(M, Ff, w) / overlap(M, M, w)
+                M = zero_on_walls(colocated_mode(plane, spec, m, direction, gu, gv))
+                amps[d_i, i, m] = amp_scale * overlap(M, Ff, w) / overlap(M, M, w)
     return ModeData(monitor=mon,
                     amps=DataArray(amps.astype(np.complex64), {"direction": np.array(["+", "-"]), "f": freqs,
                                                                "mode_index": np.arange(nm)}),
