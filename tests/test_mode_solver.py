@@ -161,3 +161,41 @@ def test_symmetry_walls_match_reference(symmetry):
                               ETA_0 * fields[1, 0, :, :, 0, m].ravel(), ETA_0 * fields[1, 1, :, :, 0, m].ravel()])
         ov = abs(np.vdot(ref, mine)) / (np.linalg.norm(ref) * np.linalg.norm(mine))
         assert ov > 1 - 1e-6, (symmetry, m, ov)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/tidy3d"), reason="reference checkout not present")
+@pytest.mark.parametrize("num_pml,symmetry", [((6, 5), (0, 0)), ((0, 7), (0, 0)), ((5, 6), (1, 0)), ((6, 6), (-1, 1))])
+def test_mode_plane_pml_matches_reference(num_pml, symmetry):
+    """ModeSpec.num_pml: stretched-coordinate PML inside the mode plane == ref derivatives.py:80-232
+    (cubic kappa / sigma profiles, speed-averaged sigma_max, no PML on a symmetric min edge); a
+    leaky rib on a high-index substrate, complex effective indices."""
+    import sys
+    sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..")))
+    from oracle.tidy3d_ref_loader import load_mode_solver
+    _, solver = load_mode_solver()
+    xb = np.linspace(0.0, 1.6, 49) - (0.0 if symmetry[0] else 0.8)
+    yb = np.concatenate(([0.0], np.cumsum(np.linspace(0.025, 0.04, 34)))) - (0.0 if symmetry[1] else 0.5)
+    xc, yc = (xb[1:] + xb[:-1]) / 2, (yb[1:] + yb[:-1]) / 2
+
+    def eps_at(x, y):
+        X, Y = np.meshgrid(x, y, indexing="ij")
+        e = np.full(X.shape, 1.44 ** 2, complex)
+        e[(np.abs(X) <= 0.22) & (np.abs(Y) <= 0.11)] = 3.48 ** 2
+        e[Y < -0.35] = 3.48 ** 2                         # substrate: the mode leaks into it
+        return e
+    exx, eyy, ezz = eps_at(xc, yb[:-1]), eps_at(xb[:-1], yc), eps_at(xb[:-1], yb[:-1])
+    z = np.zeros_like(exx)
+    ms = SimpleNamespace(num_modes=2, bend_radius=None, bend_axis=None, angle_theta=0.0, angle_phi=0.0,
+                         num_pml=num_pml, target_neff=2.3, precision="double")
+    fields, n_ref, _ = solver.compute_modes(eps_cross=[exx, z, z, z, eyy, z, z, z, ezz], coords=[xb, yb],
+                                            freq=C_0 / 1.55, mode_spec=ms, symmetry=symmetry, direction="+")
+    r = solve_modes(exx, eyy, ezz, xb, yb, C_0 / 1.55, num_modes=2, target_neff=2.3,
+                    pmc_min=tuple(s == 1 for s in symmetry), num_pml=num_pml,
+                    pml_min=tuple(s == 0 for s in symmetry))
+    order = np.argsort(-np.real(n_ref))
+    np.testing.assert_allclose(r.n_complex, np.asarray(n_ref)[order], rtol=1e-7, atol=1e-9)
+    for m, mr in enumerate(order):
+        mine = np.concatenate([r.Eu[:, :, m].ravel(), r.Ev[:, :, m].ravel()])
+        ref = np.concatenate([fields[0, 0, :, :, 0, mr].ravel(), fields[0, 1, :, :, 0, mr].ravel()])
+        ov = abs(np.vdot(ref, mine)) / (np.linalg.norm(ref) * np.linalg.norm(mine))
+        assert ov > 1 - 1e-6, (m, ov)

@@ -21,7 +21,10 @@ i.e. beta [E] = P [Ht], beta [Ht] = Q [E]  =>  (P Q) [E] = beta^2 [E], with forw
 staggering of ref plugins/mode/derivatives.py:9-76.  Node layout in the plane (ref
 grid/grid.py:465-491): E_u at (uc, vb), E_v at (ub, vc), E_w at (ub, vb), H_u at (ub, vc),
 H_v at (uc, vb), H_w at (uc, vc).  The outer edge is PEC (min edge: tangential E on the wall is
-zero; max edge: truncation), like the reference's default.
+zero; max edge: truncation), like the reference's default.  Options held to the reference by direct
+comparison (tests/test_mode_solver.py): PMC walls on the min edges (symmetry eigenvalue +1, ref
+solver.py:182-197) and the stretched-coordinate PML inside the plane (``ModeSpec.num_pml``, ref
+derivatives.py:80-232).
 """
 from __future__ import annotations
 
@@ -32,7 +35,7 @@ import numpy as np
 import scipy.sparse as sp
 import scipy.sparse.linalg as spl
 
-from .constants import C_0, ETA_0
+from .constants import C_0, EPSILON_0, ETA_0
 
 
 @dataclass
@@ -48,10 +51,39 @@ class ModeResult:
     Hw: np.ndarray
 
 
-def _diff_ops(nu: int, nv: int, du_p, dv_p, du_d, dv_d, pmc_min=(False, False)):
+def _pml_s(direction: str, omega: float, d: np.ndarray, n: int, n_pml: int, at_min: bool, speed) -> np.ndarray:
+    """Coordinate-stretching factors s = kappa + i sigma / (omega eps0) of the mode-plane PML
+    (ref plugins/mode/derivatives.py:166-232): cubic profiles, kappa 1 -> 3, sigma_max = 2 in units
+    of avg_speed / (eta0 dl); 'f' factors sit half a cell off the 'b' factors."""
+    s = np.ones(n, dtype=complex)
+    if n_pml == 0:
+        return s
+
+    def val(dl, step, sp_):
+        kappa = 1.0 + 2.0 * step ** 3
+        sigma = 2.0 * sp_ / (ETA_0 * dl) * step ** 3
+        return kappa + 1j * sigma / (omega * EPSILON_0)
+    for i in range(n):
+        if direction == "f":
+            if i <= n_pml - 1 and at_min:
+                s[i] = val(d[0], (n_pml - i - 0.5) / n_pml, speed[0])
+            elif i >= n - n_pml:
+                s[i] = val(d[-1], (i - (n - n_pml) + 0.5) / n_pml, speed[1])
+        else:
+            if i < n_pml and at_min:
+                s[i] = val(d[0], (n_pml - i) / n_pml, speed[0])
+            elif i > n - n_pml:
+                s[i] = val(d[-1], (i - (n - n_pml)) / n_pml, speed[1])
+    return s
+
+
+def _diff_ops(nu: int, nv: int, du_p, dv_p, du_d, dv_d, pmc_min=(False, False), s_fac=None):
     """Sparse forward (on primal steps) and backward (on dual steps) difference operators for
     fields flattened as index = iu * nv + iv.  Min edge of each axis: PEC wall, or a PMC wall
     (``pmc_min``: the symmetry plane of an even mode, ref derivatives.py:9-62 ``dmin_pmc``)."""
+    if s_fac is not None:           # PML: derivatives divided by the stretching factors
+        du_p, du_d, dv_p, dv_d = du_p * s_fac[0], du_d * s_fac[1], dv_p * s_fac[2], dv_d * s_fac[3]
+
     def fwd(n, d):
         D = sp.diags([-np.ones(n), np.ones(n - 1)], [0, 1], shape=(n, n), format="csr")
         return sp.diags(1.0 / d) @ D            # last row: (0 - f[n-1]) -> truncation = PEC
@@ -74,23 +106,42 @@ def _diff_ops(nu: int, nv: int, du_p, dv_p, du_d, dv_d, pmc_min=(False, False)):
 def solve_modes(eps_u: np.ndarray, eps_v: np.ndarray, eps_w: np.ndarray, ub: np.ndarray,
                 vb: np.ndarray, freq: float, num_modes: int = 1,
                 target_neff: Optional[float] = None, precision: str = "double",
-                pmc_min: Tuple[bool, bool] = (False, False)) -> ModeResult:
+                pmc_min: Tuple[bool, bool] = (False, False), num_pml: Tuple[int, int] = (0, 0),
+                pml_min: Tuple[bool, bool] = (True, True)) -> ModeResult:
     """eps_* are [Nu, Nv] (complex allowed) sampled at E_u (uc, vb), E_v (ub, vc), E_w (ub, vb);
     ub / vb the Nu+1 / Nv+1 cell boundaries.  ``pmc_min``: PMC instead of PEC on the min edge of
-    u / v (a symmetry plane with eigenvalue +1; PEC covers -1 and the default truncation)."""
+    u / v (a symmetry plane with eigenvalue +1; PEC covers -1 and the default truncation).
+    ``num_pml``: PML cells inside the plane along u / v (ref ModeSpec.num_pml, mode.py); ``pml_min``:
+    False on an axis whose min edge is a symmetry plane (ref solver.py:196-198)."""
     nu, nv = eps_u.shape
     N = nu * nv
     # lossless cross-sections give a real operator (half the LU cost); "single" follows
     # ModeSpec.precision (ref mode.py:164, solver.py:247: the reference's default) and runs the
     # factorisation and ARPACK in 32-bit
-    is_real = all(np.all(np.imag(a) == 0) for a in (eps_u, eps_v, eps_w))
+    has_pml = any(int(v) > 0 for v in num_pml)
+    is_real = all(np.all(np.imag(a) == 0) for a in (eps_u, eps_v, eps_w)) and not has_pml
     if is_real:
         eps_u, eps_v, eps_w = (np.real(a) for a in (eps_u, eps_v, eps_w))
     k0 = 2 * np.pi * freq / C_0
     du_p, dv_p = np.diff(ub), np.diff(vb)
     du_d = np.concatenate(([du_p[0]], 0.5 * (du_p[1:] + du_p[:-1])))
     dv_d = np.concatenate(([dv_p[0]], 0.5 * (dv_p[1:] + dv_p[:-1])))
-    Duf, Dvf, Dub, Dvb = _diff_ops(nu, nv, du_p, dv_p, du_d, dv_d, pmc_min)
+    s_fac = None
+    if has_pml:
+        pu, pv = int(num_pml[0]), int(num_pml[1])
+        diag = np.stack([np.asarray(eps_u), np.asarray(eps_v), np.asarray(eps_w)])       # (3, Nu, Nv)
+
+        def mean(a):
+            return 1.0 if a.size == 0 else np.mean(a)
+        # relative wave speed in the four PML regions (ref derivatives.py:131-160; mu = 1)
+        speed = [1 / np.sqrt(mean(diag[:, :pu, :])), 1 / np.sqrt(mean(diag[:, nu - pu + 1:, :])),
+                 1 / np.sqrt(mean(diag[:, :, :pv])), 1 / np.sqrt(mean(diag[:, :, nv - pv + 1:]))]
+        omega = 2 * np.pi * freq
+        s_fac = (_pml_s("f", omega, du_p, nu, pu, pml_min[0], speed[:2]),
+                 _pml_s("b", omega, du_d, nu, pu, pml_min[0], speed[:2]),
+                 _pml_s("f", omega, dv_p, nv, pv, pml_min[1], speed[2:]),
+                 _pml_s("b", omega, dv_d, nv, pv, pml_min[1], speed[2:]))
+    Duf, Dvf, Dub, Dvb = _diff_ops(nu, nv, du_p, dv_p, du_d, dv_d, pmc_min, s_fac)
     eu, ev, ew = (sp.diags(np.asarray(a).reshape(-1)) for a in (eps_u, eps_v, eps_w))
     ewi = sp.diags(1.0 / np.asarray(eps_w).reshape(-1))
     # PEC on the min edges: the tangential E that sits on a wall is clamped to zero

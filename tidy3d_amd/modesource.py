@@ -61,8 +61,9 @@ def _eps_plane(spec: SolverSpec, comp_axis: int, p: int, k: int, lo, hi, u: int,
     return eps_tab[m]
 
 
-def mode_profile(spec: SolverSpec, box: td.Box, mode_spec, freq: float) -> ModePlane:
-    """Solve the cross-section eigenproblem on the plane of ``box`` (one zero-size dimension)."""
+def mode_profile(spec: SolverSpec, box: td.Box, mode_spec, freq: float, symmetry=(0, 0, 0)) -> ModePlane:
+    """Solve the cross-section eigenproblem on the plane of ``box`` (one zero-size dimension).
+    ``symmetry``: the simulation's symmetry — a plane edge lying on a symmetry plane gets no PML."""
     zd = [a for a in range(3) if box.size[a] == 0]
     if len(zd) != 1:
         raise SetupError("a mode plane needs exactly one zero-size dimension")
@@ -70,8 +71,6 @@ def mode_profile(spec: SolverSpec, box: td.Box, mode_spec, freq: float) -> ModeP
     u, v = (p + 1) % 3, (p + 2) % 3
     if getattr(mode_spec, "angle_theta", 0.0) or getattr(mode_spec, "bend_radius", None):
         raise Tidy3dNotImplementedError("angled / bent mode planes are not supported")
-    if any(getattr(mode_spec, "num_pml", (0, 0))):
-        raise Tidy3dNotImplementedError("ModeSpec.num_pml is not supported (PEC-terminated mode plane)")
     b = spec.boundaries
     k0 = int(np.argmin(np.abs(b[p] - box.center[p])))
     k0 = int(np.clip(k0, 1, spec.shape[p] - 1))
@@ -88,7 +87,9 @@ def mode_profile(spec: SolverSpec, box: td.Box, mode_spec, freq: float) -> ModeP
     pmc_min = tuple(bool(lo[i] == 0 and spec.bc[a][0] == BC_PMC) for i, a in enumerate((u, v)))
     res = solve_modes(eps_u, eps_v, eps_w, ub, vb, freq, num_modes=int(mode_spec.num_modes),
                       target_neff=mode_spec.target_neff,
-                      precision=getattr(mode_spec, "precision", "single") or "single", pmc_min=pmc_min)
+                      precision=getattr(mode_spec, "precision", "single") or "single", pmc_min=pmc_min,
+                      num_pml=tuple(int(n) for n in (getattr(mode_spec, "num_pml", (0, 0)) or (0, 0))),
+                      pml_min=tuple(not (lo[i] == 0 and symmetry[a] != 0) for i, a in enumerate((u, v))))
     return ModePlane(p=p, u=u, v=v, k0=k0, lo=lo, hi=hi, result=res)
 
 
@@ -97,7 +98,7 @@ def build_mode_source(disc, mt, src) -> Callable:
     st = src.source_time
     if int(getattr(src, "num_freqs", 1)) != 1:
         raise Tidy3dNotImplementedError("ModeSource.num_freqs > 1 (broadband profile) is not supported")
-    plane = mode_profile(spec, src.geometry, src.mode_spec, st.freq0)
+    plane = mode_profile(spec, src.geometry, src.mode_spec, st.freq0, getattr(sim, "_symmetry", (0, 0, 0)))
     p, u, v, k0 = plane.p, plane.u, plane.v, plane.k0
     r = plane.result
     mi = int(src.mode_index)
@@ -256,7 +257,7 @@ def mode_monitor_data(disc, plan, raw, norm):
     amps = np.zeros((2, len(freqs), nm), complex)
     neff = np.zeros((len(freqs), nm), complex)
     for i, f in enumerate(freqs):
-        plane = mode_profile(spec, box, mon.mode_spec, float(f))
+        plane = mode_profile(spec, box, mon.mode_spec, float(f), sym)
         neff[i] = plane.result.n_complex
         Ff = {k: a[:, :, i] for k, a in F.items()}
         for m in range(nm):
