@@ -15,14 +15,21 @@ from tidy3d_amd.discretize import discretize
 from tidy3d_amd.engine import HipEngine
 
 
-def spec_for(n, nz, steps):
+def spec_for(n, nz, steps, pml=False):
     dl = 0.05
     pulse = td.GaussianPulse(freq0=2e14, fwidth=2e13)
     b = td.BoundarySpec(x=td.Boundary(minus=td.PECBoundary(), plus=td.PECBoundary()),
                         y=td.Boundary(minus=td.PECBoundary(), plus=td.PECBoundary()),
                         z=td.Boundary.periodic())
-    sim = td.Simulation(size=(n * dl, n * dl, nz * dl), grid_spec=td.GridSpec.uniform(dl=dl), run_time=1e-12,
-                        sources=[td.PointDipole(center=(0, 0, 0), source_time=pulse, polarization="Ez")],
+    structures = []
+    nxy = n
+    if pml:          # V2/V3-like slab: CPML on x and y (inside the cell count), a Lorentz cylinder along z
+        b = td.BoundarySpec(x=td.Boundary.pml(num_layers=12), y=td.Boundary.pml(num_layers=12), z=td.Boundary.periodic())
+        nxy = n - 24
+        structures = [td.Structure(geometry=td.Cylinder(center=(0, 0, 0), radius=100 * dl, length=td.inf, axis=2),
+                                   medium=td.Lorentz(eps_inf=2.0, coeffs=[(2.0, 4e14, 2e13)]))]
+    sim = td.Simulation(size=(nxy * dl, nxy * dl, nz * dl), grid_spec=td.GridSpec.uniform(dl=dl), run_time=1e-12,
+                        structures=structures, sources=[td.PointDipole(center=(0, 0, 0), source_time=pulse, polarization="Ez")],
                         monitors=[], boundary_spec=b, shutoff=0)
     sp = discretize(sim, n_steps=steps).spec
     sp.decay_every = 0
@@ -38,7 +45,8 @@ def main():
     ap.add_argument("--zchunk", type=int, default=0)
     ap.add_argument("--bnd", type=int, default=0)
     ap.add_argument("--rows", type=int, default=0)
-    ap.add_argument("--autotune", type=int, default=1)
+    ap.add_argument("--autotune", type=int, default=0)
+    ap.add_argument("--pml", type=int, default=0)
     args = ap.parse_args()
     n = 512
     steps, warm = args.steps, 30
@@ -47,7 +55,7 @@ def main():
                  "comm_two_pass": dict(variant=L.VARIANT_ZMARCH, force_comm=True)}
     for ngpu in [int(x) for x in args.slabs.split(",")]:
         nz = n // ngpu
-        sp = spec_for(n, nz, steps + warm + 8)
+        sp = spec_for(n, nz, steps + warm + 8, bool(args.pml))
         for mode in args.modes.split(","):
             kw = dict(all_modes[mode], z_chunk=args.zchunk)
             with HipEngine(sp, **kw) as e:
@@ -66,7 +74,7 @@ def main():
                 e.run(steps)
                 dt = time.perf_counter() - t0
                 stt = e.stats()
-                print(json.dumps({"slab_of": ngpu, "nz": nz, "mode": mode, "zchunk": args.zchunk, "bnd": args.bnd, "rows": args.rows, "tile": [int(stt.tile_rows), int(stt.tile_zchunk)], "autotune": args.autotune, "ms_per_step": dt / steps * 1e3,
+                print(json.dumps({"slab_of": ngpu, "nz": nz, "mode": mode, "zchunk": args.zchunk, "bnd": args.bnd, "rows": args.rows, "tile": [int(stt.tile_rows), int(stt.tile_zchunk)], "autotune": args.autotune, "pml": args.pml, "ms_per_step": dt / steps * 1e3,
                                   "ideal_ms": 1.244 / ngpu,
                                   "implied_speedup_vs_1gpu": 1.244 / (dt / steps * 1e3)}), flush=True)
 
