@@ -415,49 +415,59 @@ void launch_pml(FdtdSolver* h, bool e_side, int kbeg, int kend, hipStream_t st, 
     PmlAxisDev& P = h->pml[a];
     if (P.n_lo + P.n_hi == 0 || !((axes >> a) & 1)) continue;
     const int c1 = (a + 1) % 3, c2 = (a + 2) % 3;
+    // the two faces of an axis touch disjoint cells: ONE launch (blockIdx.y = face) — small and
+    // mid-size grids are bound by the number of dependent launches, not by the slab work
+    SlabP sl[2];
+    long long cells[2] = {0, 0};
+    int n_sl = 0;
     for (int side = 0; side < 2; ++side) {
       int s_lo, s_n, base;
       if (side == 0) { s_lo = 0; s_n = P.n_lo; base = 0; }
       else if (e_side) { s_lo = N[a] - P.n_hi + 1; s_n = P.n_hi - 1; base = P.n_lo; }
       else { s_lo = N[a] - P.n_hi; s_n = P.n_hi; base = P.n_lo; }
       if (s_n <= 0) continue;
-      SlabP sl;
-      sl.a = a; sl.s_lo = s_lo; sl.s_n = s_n; sl.psi_base = base;
-      sl.psi_ns = e_side ? P.ns_e : P.ns_h;
-      sl.kbeg = kbeg; sl.kend = kend; sl.kpsi0 = 0;
+      SlabP q;
+      q.a = a; q.s_lo = s_lo; q.s_n = s_n; q.psi_base = base;
+      q.psi_ns = e_side ? P.ns_e : P.ns_h;
+      q.kbeg = kbeg; q.kend = kend; q.kpsi0 = 0;
       if (a == 2) {          // intersect the slab with the launch z-range
         int lo = s_lo > kbeg ? s_lo : kbeg;
         int hi = (s_lo + s_n) < kend ? (s_lo + s_n) : kend;
         if (hi <= lo) continue;
-        sl.kbeg = lo; sl.kend = hi;
+        q.kbeg = lo; q.kend = hi;
       }
       const long long bx = (a == 0) ? s_n : g.nx, by = (a == 1) ? s_n : g.ny;
-      const long long total = bx * by * (sl.kend - sl.kbeg);
+      const long long total = bx * by * (q.kend - q.kbeg);
       if (total <= 0) continue;
-      const bool vec4 = (a != 0) && (g.nx % 4 == 0);      // y / z slabs: float4 along x
-      if (vec4 && e_side)
-        hipLaunchKernelGGL(pml_e4_kernel, dim3(nblk(total / 4)), dim3(256), 0, st, g, sl, field_ptr(h, c1),
-                           field_ptr(h, c2), (const float*)field_ptr(h, 3 + c1), (const float*)field_ptr(h, 3 + c2),
-                           P.psi_e[0], P.psi_e[1], (const float*)P.kinv_e, (const float*)P.b_e,
-                           (const float*)P.c_e, (const float*)h->idl[a], (const uint32_t*)h->mat4,
-                           (const float2*)h->lut, h->cb1);
-      else if (vec4)
-        hipLaunchKernelGGL(pml_h4_kernel, dim3(nblk(total / 4)), dim3(256), 0, st, g, sl, field_ptr(h, 3 + c1),
-                           field_ptr(h, 3 + c2), (const float*)field_ptr(h, c1), (const float*)field_ptr(h, c2),
-                           P.psi_h[0], P.psi_h[1], (const float*)P.kinv_h, (const float*)P.b_h,
-                           (const float*)P.c_h, (const float*)h->ip[a]);
-      else if (e_side)
-        hipLaunchKernelGGL(pml_e_kernel, dim3(nblk(total)), dim3(256), 0, st, g, sl, field_ptr(h, c1),
-                           field_ptr(h, c2), (const float*)field_ptr(h, 3 + c1), (const float*)field_ptr(h, 3 + c2),
-                           P.psi_e[0], P.psi_e[1], (const float*)P.kinv_e, (const float*)P.b_e,
-                           (const float*)P.c_e, (const float*)h->idl[a], (const uint32_t*)h->mat4,
-                           (const float2*)h->lut, h->cb1);
-      else
-        hipLaunchKernelGGL(pml_h_kernel, dim3(nblk(total)), dim3(256), 0, st, g, sl, field_ptr(h, 3 + c1),
-                           field_ptr(h, 3 + c2), (const float*)field_ptr(h, c1), (const float*)field_ptr(h, c2),
-                           P.psi_h[0], P.psi_h[1], (const float*)P.kinv_h, (const float*)P.b_h,
-                           (const float*)P.c_h, (const float*)h->ip[a]);
+      sl[n_sl] = q; cells[n_sl] = total; ++n_sl;
     }
+    if (n_sl == 0) continue;
+    if (n_sl == 1) sl[1] = sl[0];
+    const bool vec4 = (a != 0) && (g.nx % 4 == 0);      // y / z slabs: float4 along x
+    const long long most = std::max(cells[0], cells[1]);
+    const dim3 grid(nblk(vec4 ? most / 4 : most), n_sl);
+    if (vec4 && e_side)
+      hipLaunchKernelGGL(pml_e4_kernel, grid, dim3(256), 0, st, g, sl[0], sl[1], field_ptr(h, c1),
+                         field_ptr(h, c2), (const float*)field_ptr(h, 3 + c1), (const float*)field_ptr(h, 3 + c2),
+                         P.psi_e[0], P.psi_e[1], (const float*)P.kinv_e, (const float*)P.b_e,
+                         (const float*)P.c_e, (const float*)h->idl[a], (const uint32_t*)h->mat4,
+                         (const float2*)h->lut, h->cb1);
+    else if (vec4)
+      hipLaunchKernelGGL(pml_h4_kernel, grid, dim3(256), 0, st, g, sl[0], sl[1], field_ptr(h, 3 + c1),
+                         field_ptr(h, 3 + c2), (const float*)field_ptr(h, c1), (const float*)field_ptr(h, c2),
+                         P.psi_h[0], P.psi_h[1], (const float*)P.kinv_h, (const float*)P.b_h,
+                         (const float*)P.c_h, (const float*)h->ip[a]);
+    else if (e_side)
+      hipLaunchKernelGGL(pml_e_kernel, grid, dim3(256), 0, st, g, sl[0], sl[1], field_ptr(h, c1),
+                         field_ptr(h, c2), (const float*)field_ptr(h, 3 + c1), (const float*)field_ptr(h, 3 + c2),
+                         P.psi_e[0], P.psi_e[1], (const float*)P.kinv_e, (const float*)P.b_e,
+                         (const float*)P.c_e, (const float*)h->idl[a], (const uint32_t*)h->mat4,
+                         (const float2*)h->lut, h->cb1);
+    else
+      hipLaunchKernelGGL(pml_h_kernel, grid, dim3(256), 0, st, g, sl[0], sl[1], field_ptr(h, 3 + c1),
+                         field_ptr(h, 3 + c2), (const float*)field_ptr(h, c1), (const float*)field_ptr(h, c2),
+                         P.psi_h[0], P.psi_h[1], (const float*)P.kinv_h, (const float*)P.b_h,
+                         (const float*)P.c_h, (const float*)h->ip[a]);
   }
 }
 

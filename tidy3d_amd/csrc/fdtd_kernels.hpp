@@ -900,11 +900,12 @@ __device__ __forceinline__ long long psi_index(const GridP& g, const SlabP& sl, 
 }
 
 // E-side:  E_{a+1} -= Cb * ((kinv-1) d(H_{a+2})/da + psi1),  E_{a+2} += Cb * ((kinv-1) d(H_{a+1})/da + psi2)
-__global__ __launch_bounds__(256) void pml_e_kernel(GridP g, SlabP sl, float* e1, float* e2, const float* h1,
+__global__ __launch_bounds__(256) void pml_e_kernel(GridP g, SlabP sl_lo, SlabP sl_hi, float* e1, float* e2, const float* h1,
                                                      const float* h2, float* psi1, float* psi2,
                                                      const float* kinv, const float* bb, const float* cc,
                                                      const float* idl, const uint32_t* m4,
                                                      const float2* lut, float cb_uniform) {
+  const SlabP sl = blockIdx.y ? sl_hi : sl_lo;   // both faces of an axis in one launch (disjoint cells)
   const int bx = (sl.a == 0) ? sl.s_n : g.nx;
   const int by = (sl.a == 1) ? sl.s_n : g.ny;
   const int bz = sl.kend - sl.kbeg;
@@ -952,10 +953,11 @@ __global__ __launch_bounds__(256) void pml_e_kernel(GridP g, SlabP sl, float* e1
 }
 
 // H-side:  H_{a+1} += ch * ((kinv-1) d(E_{a+2})/da + psi1),  H_{a+2} -= ch * ((kinv-1) d(E_{a+1})/da + psi2)
-__global__ __launch_bounds__(256) void pml_h_kernel(GridP g, SlabP sl, float* h1, float* h2, const float* e1,
+__global__ __launch_bounds__(256) void pml_h_kernel(GridP g, SlabP sl_lo, SlabP sl_hi, float* h1, float* h2, const float* e1,
                                                      const float* e2, float* psi1, float* psi2,
                                                      const float* kinv, const float* bb, const float* cc,
                                                      const float* ipl) {
+  const SlabP sl = blockIdx.y ? sl_hi : sl_lo;   // both faces of an axis in one launch (disjoint cells)
   const int bx = (sl.a == 0) ? sl.s_n : g.nx;
   const int by = (sl.a == 1) ? sl.s_n : g.ny;
   const int bz = sl.kend - sl.kbeg;
@@ -996,11 +998,12 @@ __global__ __launch_bounds__(256) void pml_h_kernel(GridP g, SlabP sl, float* h1
 
 // float4 versions for the y and z slabs (rows are contiguous along x): one thread = 4 cells, same
 // per-element arithmetic as the scalar kernels above.
-__global__ __launch_bounds__(256) void pml_e4_kernel(GridP g, SlabP sl, float* e1, float* e2, const float* h1,
+__global__ __launch_bounds__(256) void pml_e4_kernel(GridP g, SlabP sl_lo, SlabP sl_hi, float* e1, float* e2, const float* h1,
                                                       const float* h2, float* psi1, float* psi2,
                                                       const float* kinv, const float* bb, const float* cc,
                                                       const float* idl, const uint32_t* m4,
                                                       const float2* lut, float cb_uniform) {
+  const SlabP sl = blockIdx.y ? sl_hi : sl_lo;   // both faces of an axis in one launch (disjoint cells)
   constexpr int V = 4;
   const int bx = g.nx / V;
   const int by = (sl.a == 1) ? sl.s_n : g.ny;
@@ -1067,10 +1070,11 @@ __global__ __launch_bounds__(256) void pml_e4_kernel(GridP g, SlabP sl, float* e
   stv<V>(e2 + p, x2);
 }
 
-__global__ __launch_bounds__(256) void pml_h4_kernel(GridP g, SlabP sl, float* h1, float* h2, const float* e1,
+__global__ __launch_bounds__(256) void pml_h4_kernel(GridP g, SlabP sl_lo, SlabP sl_hi, float* h1, float* h2, const float* e1,
                                                       const float* e2, float* psi1, float* psi2,
                                                       const float* kinv, const float* bb, const float* cc,
                                                       const float* ipl) {
+  const SlabP sl = blockIdx.y ? sl_hi : sl_lo;   // both faces of an axis in one launch (disjoint cells)
   constexpr int V = 4;
   const int bx = g.nx / V;
   const int by = (sl.a == 1) ? sl.s_n : g.ny;
