@@ -226,7 +226,9 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            out["roofline"]["traffic"] = json.load(open(pmc)).get(dom)
+            t512 = json.load(open(pmc)).get(dom)       # PMC bytes of one 512^3 launch (rocprofv3 passes)
+            # per launch like `achieved`: this rank's share of the cells (z-slabs at N > 1, --size)
+            out["roofline"]["traffic"] = None if t512 is None else t512 * local_cells / 512 ** 3
         except Exception:
             pass
 
