@@ -140,3 +140,22 @@ def test_autotuned_tile_shape_changes_nothing_but_the_shape(emu_lib):
         assert np.array_equal(a, b)
     for k in ref_m:
         assert np.array_equal(ref_m[k], got_m[k]), k
+
+
+@pytest.mark.parametrize("faces", ["y-", "y+", "z-", "z+", "y-z+", "x-y+z-"])
+def test_split_cpml_launch_one_sided(emu_lib, faces):
+    """The y/z recursions folded into the sweep run only in the tile rows / plane ranges that meet a
+    slab (three launches: z-slab planes, y-slab tile rows, plain middle); absorbers on single faces
+    move every range boundary.  Bit-for-bit the two-pass result."""
+    def edge(axis, side):
+        return td.PML(num_layers=4) if f"{axis}{side}" in faces else td.PECBoundary()
+    bspec = td.BoundarySpec(x=td.Boundary(minus=edge("x", "-"), plus=edge("x", "+")),
+                            y=td.Boundary(minus=edge("y", "-"), plus=edge("y", "+")),
+                            z=td.Boundary(minus=edge("z", "-"), plus=edge("z", "+")))
+    disc = discretize(_sim((24, 22, 21), bspec, MEDIA), n_steps=20)
+    ref_f, ref_m = _run(disc.spec, emu_lib, L.VARIANT_ZMARCH, 4, 2)
+    got_f, got_m = _run(disc.spec, emu_lib, L.VARIANT_FUSED, 3, 5, 6)
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), c
+    for k in ref_m:
+        assert np.array_equal(got_m[k], ref_m[k]), k

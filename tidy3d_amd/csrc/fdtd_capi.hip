@@ -301,15 +301,22 @@ bool any_pml(const FdtdSolver* h) {
   return false;
 }
 
+// Tile rows: all of them (ty_n < 0) or  [0, ty_a) + [ty_a + ty_gap, ty_a + ty_gap + (ty_n - ty_a)).
 int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pml_inside = 0, int k2beg = 0,
-                       int k2end = 0) {
-  if (kend <= kbeg) return 0;
+                       int k2end = 0, int ty_n = -1, int ty_a = 0, int ty_gap = 0) {
+  if (kend <= kbeg) {                 // first plane range empty: the second one takes its place
+    if (k2end <= k2beg) return 0;
+    kbeg = k2beg; kend = k2end; k2beg = k2end = 0;
+  }
+  if (ty_n == 0) return 0;
   const GridP& g = h->g;
   if (ensure_second_set(h)) return -1;
   const int R = h->rows_f;
   const int zc = h->zchunk_f;
   dim3 block(64, R + 1, 1);
-  const int nbx = (g.nx + 255) / 256, nby = (g.ny + R - 1) / R, nbz1 = (kend - kbeg + zc - 1) / zc;
+  const int nby_all = (g.ny + R - 1) / R;
+  if (ty_n < 0) { ty_n = nby_all; ty_a = nby_all; ty_gap = 0; }
+  const int nbx = (g.nx + 255) / 256, nby = ty_n, nbz1 = (kend - kbeg + zc - 1) / zc;
   const int nbz = nbz1 + (k2end > k2beg ? (k2end - k2beg + zc - 1) / zc : 0);
   const int total = nbx * nby * nbz;
   const int remap = h->xcd_remap ? 1 : 0;
@@ -326,7 +333,7 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pm
   const PmlP pm = pml_params(h);
 #define FDTD_LAUNCH_FUSED(MATV, LBV, PMLV)                                                            \
   hipLaunchKernelGGL((fused_step_kernel<MATV, LBV, PMLV>), grid, block, shmem, st, g, h->f, h->f2, s, m, kbeg, \
-                     kend, zc, pmc, nbx, nby, nbz, remap, pm, nbz1, k2beg, k2end)
+                     kend, zc, pmc, nbx, nby, nbz, remap, pm, nbz1, k2beg, k2end, ty_a, ty_gap)
   if (pml_inside == 7) {    // CPML of all axes folded into the sweep (256- and 512-thread workgroups)
     if (h->mat4) { if (lb == 256) FDTD_LAUNCH_FUSED(true, 256, 7); else FDTD_LAUNCH_FUSED(true, 512, 7); }
     else { if (lb == 256) FDTD_LAUNCH_FUSED(false, 256, 7); else FDTD_LAUNCH_FUSED(false, 512, 7); }
@@ -1270,7 +1277,29 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       launch_pml(h, false, 0, nz, st, 7 & ~pml_in);
       advance_tfsf_aux(h, false, n, st);
       if (h->cfg.bc[4] == FDTD_BC_PERIODIC) fill_ghost_h(h, st);   // ghost(-1) must carry the pre-corrections too
-      if (launch_fused(h, st, pml_in)) return -1;
+      if (pml_in == 6) {
+        // y / z recursions inside the sweep, but only in the tiles that meet a slab: the instantiation
+        // that carries them needs ~250 VGPRs (2 waves per SIMD), the plain one 150 (3 waves).
+        //   (1) planes of the z slabs (+1 plane: the next chunk's prologue must not see a slab), all rows
+        //   (2) planes in between: bottom and top tile rows (those with a row or the halo row in a y slab)
+        //   (3) planes in between, middle tile rows: plain sweep
+        const int R = h->rows_f, nby_all = (h->g.ny + R - 1) / R;
+        const PmlAxisDev &py = h->pml[1], &pz = h->pml[2];
+        const int za = pz.n_lo > 0 ? std::min(nz, pz.n_lo + 1) : 0;
+        const int zc = pz.n_hi > 0 ? std::max(za, nz - pz.n_hi) : nz;
+        const int ty_a = py.n_lo > 0 ? std::min(nby_all, py.n_lo / R + 1) : 0;
+        const int ty_c = py.n_hi > 0 ? std::max(ty_a, (h->g.ny - py.n_hi) / R) : nby_all;
+        // (1) and (2) are small launches (less than one wave of workgroups each): they go to the second
+        // stream and run concurrently with (3) — the three touch disjoint tiles
+        HIPCHK(h, hipEventRecord(h->ev_h_int, st));
+        HIPCHK(h, hipStreamWaitEvent(cs, h->ev_h_int, 0));
+        if (launch_fused_range(h, 0, za, cs, 6, zc, nz)) return -1;
+        if (launch_fused_range(h, za, zc, cs, 6, 0, 0, ty_a + (nby_all - ty_c), ty_a, ty_c - ty_a)) return -1;
+        HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
+        if (launch_fused_range(h, za, zc, st, 0, 0, 0, ty_c - ty_a, 0, ty_a)) return -1;
+        HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
+        swap_sets(h);
+      } else if (launch_fused(h, st, pml_in)) return -1;
       for (int a = 0; a < 3; ++a)
         if ((pml_in >> a) & 1) { std::swap(h->pml[a].psi_h[0], h->pml[a].psi_h2[0]); std::swap(h->pml[a].psi_h[1], h->pml[a].psi_h2[1]); }
       if (rec) record_monitors(h, n, true, st);

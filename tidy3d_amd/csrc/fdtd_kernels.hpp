@@ -377,7 +377,7 @@ template <bool MAT, int LB, int PML>   // PML: bit a set = CPML of axis a runs i
 __global__ __launch_bounds__(LB) void fused_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
                                                           int kbeg, int kend, int zchunk, int pmc_z0,
                                                           int nbx, int nby, int nbz, int xcd_remap, PmlP pm,
-                                                          int nbz1, int k2beg, int k2end) {
+                                                          int nbz1, int k2beg, int k2end, int ty_a, int ty_gap) {
   constexpr int V = 4;
   // 1-D launch; logical tile (bx, by, bz) with by fastest.  XCD-aware remap: hardware block L runs
   // on XCD L % 8 (observed dispatch order, used for speed only), so XCD x is handed the contiguous
@@ -390,7 +390,10 @@ __global__ __launch_bounds__(LB) void fused_step_kernel(GridP g, FieldP a, Field
     t = (t & 7) * per + (t >> 3);
     if (t >= total) return;              // whole workgroup leaves before any barrier
   }
-  const int tile_y = t % nby;
+  // tile rows of this launch: the first ty_a, then (after a gap of ty_gap) the rest — the launch
+  // that folds the y-CPML in covers the bottom and top tile rows only, a plain launch the middle
+  int tile_y = t % nby;
+  if (tile_y >= ty_a) tile_y += ty_gap;
   const int tile_x = (t / nby) % nbx;
   const int tile_z = t / (nby * nbx);
   __shared__ float2 lut_s[256];
