@@ -199,3 +199,40 @@ def test_mode_plane_pml_matches_reference(num_pml, symmetry):
         ref = np.concatenate([fields[0, 0, :, :, 0, mr].ravel(), fields[0, 1, :, :, 0, mr].ravel()])
         ov = abs(np.vdot(ref, mine)) / (np.linalg.norm(ref) * np.linalg.norm(mine))
         assert ov > 1 - 1e-6, (m, ov)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/tidy3d"), reason="reference checkout not present")
+@pytest.mark.parametrize("radius,bend_axis,num_pml", [(6.0, 1, (8, 0)), (-4.0, 1, (7, 6)), (5.0, 0, (0, 8))])
+def test_bent_waveguide_matches_reference(radius, bend_axis, num_pml):
+    """ModeSpec.bend_radius / bend_axis: the conformal transformation of ref transforms.py:14-75
+    (diagonal eps', mu') — complex effective indices (radiation loss into the PML) and fields."""
+    import sys
+    sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..")))
+    from oracle.tidy3d_ref_loader import load_mode_solver
+    _, solver = load_mode_solver()
+    xb = np.linspace(-1.0, 1.0, 57)
+    yb = np.concatenate(([0.0], np.cumsum(np.linspace(0.03, 0.04, 40)))) - 0.7
+    xc, yc = (xb[1:] + xb[:-1]) / 2, (yb[1:] + yb[:-1]) / 2
+
+    def eps_at(x, y):
+        X, Y = np.meshgrid(x, y, indexing="ij")
+        e = np.full(X.shape, 1.44 ** 2, complex)
+        e[(np.abs(X) <= 0.25) & (np.abs(Y) <= 0.11)] = 3.48 ** 2
+        return e
+    exx, eyy, ezz = eps_at(xc, yb[:-1]), eps_at(xb[:-1], yc), eps_at(xb[:-1], yb[:-1])
+    z = np.zeros_like(exx)
+    ms = SimpleNamespace(num_modes=2, bend_radius=radius, bend_axis=bend_axis, angle_theta=0.0, angle_phi=0.0,
+                         num_pml=num_pml, target_neff=2.4, precision="double")
+    fields, n_ref, _ = solver.compute_modes(eps_cross=[exx, z, z, z, eyy, z, z, z, ezz], coords=[xb, yb],
+                                            freq=C_0 / 1.55, mode_spec=ms, symmetry=(0, 0), direction="+")
+    r = solve_modes(exx, eyy, ezz, xb, yb, C_0 / 1.55, num_modes=2, target_neff=2.4, num_pml=num_pml,
+                    bend_radius=radius, bend_axis=bend_axis)
+    order = np.argsort(-np.real(n_ref))
+    np.testing.assert_allclose(r.n_complex, np.asarray(n_ref)[order], rtol=1e-7, atol=1e-10)
+    for m, mr in enumerate(order):
+        mine = np.concatenate([getattr(r, k)[:, :, m].ravel() for k in ("Eu", "Ev", "Ew")] +
+                              [ETA_0 * getattr(r, k)[:, :, m].ravel() for k in ("Hu", "Hv", "Hw")])
+        ref = np.concatenate([fields[0, c, :, :, 0, mr].ravel() for c in range(3)] +
+                             [ETA_0 * fields[1, c, :, :, 0, mr].ravel() for c in range(3)])
+        ov = abs(np.vdot(ref, mine)) / (np.linalg.norm(ref) * np.linalg.norm(mine))
+        assert ov > 1 - 1e-6, (m, ov)

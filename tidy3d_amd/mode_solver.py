@@ -107,17 +107,34 @@ def solve_modes(eps_u: np.ndarray, eps_v: np.ndarray, eps_w: np.ndarray, ub: np.
                 vb: np.ndarray, freq: float, num_modes: int = 1,
                 target_neff: Optional[float] = None, precision: str = "double",
                 pmc_min: Tuple[bool, bool] = (False, False), num_pml: Tuple[int, int] = (0, 0),
-                pml_min: Tuple[bool, bool] = (True, True)) -> ModeResult:
+                pml_min: Tuple[bool, bool] = (True, True), bend_radius: Optional[float] = None,
+                bend_axis: int = 0) -> ModeResult:
     """eps_* are [Nu, Nv] (complex allowed) sampled at E_u (uc, vb), E_v (ub, vc), E_w (ub, vb);
     ub / vb the Nu+1 / Nv+1 cell boundaries.  ``pmc_min``: PMC instead of PEC on the min edge of
     u / v (a symmetry plane with eigenvalue +1; PEC covers -1 and the default truncation).
     ``num_pml``: PML cells inside the plane along u / v (ref ModeSpec.num_pml, mode.py); ``pml_min``:
-    False on an axis whose min edge is a symmetry plane (ref solver.py:196-198)."""
+    False on an axis whose min edge is a symmetry plane (ref solver.py:196-198).
+    ``bend_radius`` / ``bend_axis`` (0 = u, 1 = v: the in-plane axis normal to the bend plane): the
+    conformal straightening of ref transforms.py:14-75 — w = R phi, J = diag(1, 1, R / r) — turns the
+    bend into diagonal eps' = J eps J^T / det J and mu' = J J^T / det J; n_eff refers to k_w = R k_phi."""
     nu, nv = eps_u.shape
     N = nu * nv
     # lossless cross-sections give a real operator (half the LU cost); "single" follows
     # ModeSpec.precision (ref mode.py:164, solver.py:247: the reference's default) and runs the
     # factorisation and ARPACK in 32-bit
+    n_guess = float(np.sqrt(np.max(np.abs([np.max(np.abs(a)) for a in (eps_u, eps_v, eps_w)]))))
+    mu_u = mu_v = mu_w = None
+    if bend_radius is not None:
+        na = 0 if bend_axis == 1 else 1                      # axis along which the radius varies
+        c = (ub, vb)[na]
+        r = c + (bend_radius - c[(len(c) - 1) // 2])           # plane centre at the bend radius
+        s_e = bend_radius / r[:-1]                             # dw/dz at the E nodes ...
+        s_h = bend_radius / (r[:-1] + r[1:]) * 2               # ... and at the H nodes (ref :55-56)
+        shp = (-1, 1) if na == 0 else (1, -1)
+        s_e, s_h = s_e.reshape(shp), s_h.reshape(shp)
+        eps_u, eps_v, eps_w = eps_u / s_e, eps_v / s_e, eps_w * s_e
+        ones = np.ones((nu, nv))
+        mu_u, mu_v, mu_w = ones / s_h, ones / s_h, ones * s_h
     has_pml = any(int(v) > 0 for v in num_pml)
     is_real = all(np.all(np.imag(a) == 0) for a in (eps_u, eps_v, eps_w)) and not has_pml
     if is_real:
@@ -130,12 +147,13 @@ def solve_modes(eps_u: np.ndarray, eps_v: np.ndarray, eps_w: np.ndarray, ub: np.
     if has_pml:
         pu, pv = int(num_pml[0]), int(num_pml[1])
         diag = np.stack([np.asarray(eps_u), np.asarray(eps_v), np.asarray(eps_w)])       # (3, Nu, Nv)
+        mdiag = np.ones_like(diag) if mu_u is None else np.stack([mu_u, mu_v, mu_w])
 
         def mean(a):
             return 1.0 if a.size == 0 else np.mean(a)
-        # relative wave speed in the four PML regions (ref derivatives.py:131-160; mu = 1)
-        speed = [1 / np.sqrt(mean(diag[:, :pu, :])), 1 / np.sqrt(mean(diag[:, nu - pu + 1:, :])),
-                 1 / np.sqrt(mean(diag[:, :, :pv])), 1 / np.sqrt(mean(diag[:, :, nv - pv + 1:]))]
+        # relative wave speed in the four PML regions (ref derivatives.py:131-160)
+        regions = [np.s_[:, :pu, :], np.s_[:, nu - pu + 1:, :], np.s_[:, :, :pv], np.s_[:, :, nv - pv + 1:]]
+        speed = [1 / np.sqrt(mean(diag[r_]) * mean(mdiag[r_])) for r_ in regions]
         omega = 2 * np.pi * freq
         s_fac = (_pml_s("f", omega, du_p, nu, pu, pml_min[0], speed[:2]),
                  _pml_s("b", omega, du_d, nu, pu, pml_min[0], speed[:2]),
@@ -159,11 +177,16 @@ def solve_modes(eps_u: np.ndarray, eps_v: np.ndarray, eps_w: np.ndarray, ub: np.
     # E_w = (i/(k0 eps_w)) (Dub Ht_v - Dvb Ht_u)   -> rows of P
     curl_h = sp.hstack([-Dvb, Dub], format="csr")                       # acts on [Ht_u; Ht_v]
     Ew_op = Mw @ ewi @ curl_h                                           # (without the i/k0 factor)
+    # diagonal mu (bends):  beta E_u = k0 mu_v Ht_v + ...,  beta E_v = -k0 mu_u Ht_u + ...,
+    #                       Ht_w = (-i / (k0 mu_w)) (Duf E_v - Dvf E_u)
+    Iu_m = I if mu_u is None else sp.diags(mu_u.reshape(-1))
+    Iv_m = I if mu_v is None else sp.diags(mu_v.reshape(-1))
+    mwi = I if mu_w is None else sp.diags(1.0 / mu_w.reshape(-1))
     P = sp.vstack([
-        Mu @ (sp.hstack([sp.csr_matrix((N, N)), k0 * I]) + (1 / k0) * Duf @ Ew_op),
-        Mv @ (sp.hstack([-k0 * I, sp.csr_matrix((N, N))]) + (1 / k0) * Dvf @ Ew_op),
+        Mu @ (sp.hstack([sp.csr_matrix((N, N)), k0 * Iv_m]) + (1 / k0) * Duf @ Ew_op),
+        Mv @ (sp.hstack([-k0 * Iu_m, sp.csr_matrix((N, N))]) + (1 / k0) * Dvf @ Ew_op),
     ], format="csr")
-    curl_e = sp.hstack([-Dvf, Duf], format="csr")                       # Duf E_v - Dvf E_u on [E_u; E_v]
+    curl_e = mwi @ sp.hstack([-Dvf, Duf], format="csr")                 # (1/mu_w)(Duf E_v - Dvf E_u) on [E_u; E_v]
     Q = sp.vstack([
         sp.hstack([sp.csr_matrix((N, N)), -k0 * ev]) - (1 / k0) * Dub @ curl_e,
         sp.hstack([k0 * eu, sp.csr_matrix((N, N))]) - (1 / k0) * Dvb @ curl_e,
@@ -172,7 +195,7 @@ def solve_modes(eps_u: np.ndarray, eps_v: np.ndarray, eps_w: np.ndarray, ub: np.
     if precision == "single":
         A = A.astype(np.float32 if is_real else np.complex64)
     if target_neff is None:
-        target_neff = float(np.sqrt(np.max(np.real([eps_u.max(), eps_v.max(), eps_w.max()]))))
+        target_neff = n_guess                       # from the physical eps (ref solver.py:202-207)
     sigma = (target_neff * k0) ** 2
     rng = np.random.default_rng(0)
     v0 = rng.standard_normal(2 * N).astype(A.dtype if not np.iscomplexobj(A) else np.float64)
@@ -192,6 +215,9 @@ def solve_modes(eps_u: np.ndarray, eps_v: np.ndarray, eps_w: np.ndarray, ub: np.
         Htu, Htv = Ht[:N], Ht[N:]
         Ew_ = (1j / k0) * (Ew_op @ Ht)
         Htw = (-1j / k0) * (curl_e @ E)
+        if bend_radius is not None:             # back to the physical frame: F = J^T F' (ref solver.py:254-259)
+            Ew_ = Ew_ * np.broadcast_to(s_e, (nu, nv)).reshape(-1)
+            Htw = Htw * np.broadcast_to(s_h, (nu, nv)).reshape(-1)
         f = dict(Eu=Eu_, Ev=Ev_, Ew=Ew_, Hu=Htu / ETA_0, Hv=Htv / ETA_0, Hw=Htw / ETA_0)
         f = {k: v.reshape(nu, nv) for k, v in f.items()}
         # gauge: the largest tangential E sample is real and positive (ref mode_solver.py:803-806)

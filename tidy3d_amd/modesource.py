@@ -69,8 +69,15 @@ def mode_profile(spec: SolverSpec, box: td.Box, mode_spec, freq: float, symmetry
         raise SetupError("a mode plane needs exactly one zero-size dimension")
     p = zd[0]
     u, v = (p + 1) % 3, (p + 2) % 3
-    if getattr(mode_spec, "angle_theta", 0.0) or getattr(mode_spec, "bend_radius", None):
-        raise Tidy3dNotImplementedError("angled / bent mode planes are not supported")
+    if getattr(mode_spec, "angle_theta", 0.0):
+        raise Tidy3dNotImplementedError("angled mode planes (ModeSpec.angle_theta) are not supported")
+    bend_radius = getattr(mode_spec, "bend_radius", None)
+    bend_axis = 0
+    if bend_radius is not None:
+        # ModeSpec.bend_axis counts the plane's axes in x, y, z order (ref mode.py bend_axis); the
+        # solver's (u, v) are cyclic
+        phys = [a for a in range(3) if a != p][int(getattr(mode_spec, "bend_axis", 0) or 0)]
+        bend_axis = (u, v).index(phys)
     b = spec.boundaries
     k0 = int(np.argmin(np.abs(b[p] - box.center[p])))
     k0 = int(np.clip(k0, 1, spec.shape[p] - 1))
@@ -89,7 +96,8 @@ def mode_profile(spec: SolverSpec, box: td.Box, mode_spec, freq: float, symmetry
                       target_neff=mode_spec.target_neff,
                       precision=getattr(mode_spec, "precision", "single") or "single", pmc_min=pmc_min,
                       num_pml=tuple(int(n) for n in (getattr(mode_spec, "num_pml", (0, 0)) or (0, 0))),
-                      pml_min=tuple(not (lo[i] == 0 and symmetry[a] != 0) for i, a in enumerate((u, v))))
+                      pml_min=tuple(not (lo[i] == 0 and symmetry[a] != 0) for i, a in enumerate((u, v))),
+                      bend_radius=bend_radius, bend_axis=bend_axis)
     return ModePlane(p=p, u=u, v=v, k0=k0, lo=lo, hi=hi, result=res)
 
 
