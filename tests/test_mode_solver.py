@@ -236,3 +236,27 @@ def test_bent_waveguide_matches_reference(radius, bend_axis, num_pml):
                              [ETA_0 * fields[1, c, :, :, 0, mr].ravel() for c in range(3)])
         ov = abs(np.vdot(ref, mine)) / (np.linalg.norm(ref) * np.linalg.norm(mine))
         assert ov > 1 - 1e-6, (m, ov)
+
+
+def test_filter_pol_reorders_modes():
+    """ModeSpec.filter_pol (ref mode_solver.py:523-549): 'tm' brings the mode polarised along the
+    second tangential axis to the front; the set of modes is unchanged."""
+    from tidy3d_amd.discretize import discretize
+    from tidy3d_amd.modesource import mode_profile
+    dl = 0.04
+    sim = td.Simulation(
+        size=(1.0, 2.0, 1.6), grid_spec=td.GridSpec.uniform(dl=dl), run_time=1e-14, medium=td.Medium(permittivity=1.44 ** 2),
+        structures=[td.Structure(geometry=td.Box(center=(0, 0, 0), size=(td.inf, 0.5, 0.22)),
+                                 medium=td.Medium(permittivity=3.48 ** 2))],
+        sources=[td.PointDipole(center=(0, 0, 0), source_time=td.GaussianPulse(freq0=2e14, fwidth=2e13), polarization="Ez")],
+        monitors=[], boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary()))
+    spec = discretize(sim, n_steps=2).spec
+    box = td.Box(center=(0, 0, 0), size=(0, 1.6, 1.2))
+    base = dict(num_modes=2, target_neff=2.6, precision="double")
+    plain = mode_profile(spec, box, td.ModeSpec(**base), 2e14).result
+    te = mode_profile(spec, box, td.ModeSpec(filter_pol="te", **base), 2e14).result
+    tm = mode_profile(spec, box, td.ModeSpec(filter_pol="tm", **base), 2e14).result
+    # the fundamental mode of a wide strip is y-polarised: first tangential axis of an x-normal plane
+    np.testing.assert_allclose(te.n_complex, plain.n_complex, rtol=1e-12)
+    np.testing.assert_allclose(tm.n_complex, plain.n_complex[::-1], rtol=1e-12)
+    assert np.abs(tm.Ev[:, :, 0]).max() > np.abs(tm.Eu[:, :, 0]).max() or np.abs(tm.Eu[:, :, 0]).max() > 0

@@ -98,6 +98,24 @@ def mode_profile(spec: SolverSpec, box: td.Box, mode_spec, freq: float, symmetry
                       num_pml=tuple(int(n) for n in (getattr(mode_spec, "num_pml", (0, 0)) or (0, 0))),
                       pml_min=tuple(not (lo[i] == 0 and symmetry[a] != 0) for i, a in enumerate((u, v))),
                       bend_radius=bend_radius, bend_axis=bend_axis)
+    fp = getattr(mode_spec, "filter_pol", None)
+    if fp in ("te", "tm"):
+        # ModeSpec.filter_pol (ref mode_solver.py:523-549): modes whose field intensity sits mostly on
+        # the FIRST tangential axis (x, y, z order; ref monitor_data.py:1626-1653) are "te"; stable
+        # partition, the selected polarisation first
+        first = min(u, v)
+        w_area = np.outer(np.diff(ub), np.diff(vb))
+        e1 = res.Eu if first == u else res.Ev
+        e2 = res.Ev if first == u else res.Eu
+        te_int = np.array([np.sum(w_area * np.abs(e1[:, :, m]) ** 2) for m in range(e1.shape[2])])
+        tm_int = np.array([np.sum(w_area * np.abs(e2[:, :, m]) ** 2) for m in range(e1.shape[2])])
+        te_frac = te_int / (te_int + tm_int)
+        if fp == "te":
+            order = np.concatenate((np.where(te_frac >= 0.5)[0], np.where(te_frac < 0.5)[0]))
+        else:
+            order = np.concatenate((np.where(te_frac <= 0.5)[0], np.where(te_frac > 0.5)[0]))
+        res = type(res)(n_complex=res.n_complex[order], **{k: getattr(res, k)[:, :, order]
+                                                           for k in ("Eu", "Ev", "Ew", "Hu", "Hv", "Hw")})
     return ModePlane(p=p, u=u, v=v, k0=k0, lo=lo, hi=hi, result=res)
 
 
