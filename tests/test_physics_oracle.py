@@ -157,8 +157,8 @@ def test_energy_conservation_lossless_cavity():
     disc = discretize(sim, n_steps=900)
     o = OracleFdtd(disc.spec)
     end = int(np.ceil(pulse.end_time() / disc.spec.dt)) + 2
-    eps = [disc.spec.media[1].eps_inf * (disc.spec.mat_idx[c] == 1) + 3.0 * (disc.spec.mat_idx[c] == 2)
-           for c in range(3)]
+    tab = np.array([m.eps_inf for m in disc.spec.media])      # incl. the sub-pixel averaged interface media
+    eps = [np.real(tab[disc.spec.mat_idx[c]]) for c in range(3)]
     vals = []
     for n in range(900):
         h_prev = [h.copy() for h in o.H]

@@ -1206,9 +1206,10 @@ class Staircasing(_Model):
 @_register
 @dataclass
 class SubpixelSpec(_Model):
-    """ref components/subpixel_spec.py:117.  This solver staircases every interface (the
-    averaging algorithms are server-side and absent from the reference, SURVEY.md section 7);
-    the spec is honoured only through ``courant_ratio`` (:148)."""
+    """ref components/subpixel_spec.py:117.  ``dielectric``: PolarizedAveraging (default) /
+    VolumetricAveraging / Staircasing are honoured by the rasteriser (discretize._subpixel_average —
+    the published methods; the reference's own code is server-side); ``metal`` / ``pec`` interfaces
+    are staircased; ``courant_ratio`` follows :148."""
 
     dielectric: Any = None
     metal: Any = None
