@@ -166,7 +166,38 @@ def au_array(N=(12, 12, 24), dl=0.01):
                          sources=[src], monitors=mons, boundary_spec=bspec, shutoff=0)
 
 
+def two_d(N=(36, 30)):
+    """2-D simulation: zero size along y (one cell, periodic; ref simulation.py:2272), PML in x and z,
+    a dielectric bar, out-of-plane (TE) and in-plane (TM) dipoles."""
+    size = (N[0] * DL, 0.0, N[1] * DL)
+    return td.Simulation(
+        size=size, grid_spec=td.GridSpec.uniform(dl=DL), run_time=1e-12, shutoff=0,
+        structures=[td.Structure(geometry=td.Box(center=(0.1, 0, 0.1), size=(0.3, td.inf, 0.2)),
+                                 medium=td.Medium(permittivity=4.0))],
+        sources=[td.PointDipole(center=(0.03, 0, -0.2), source_time=PULSE, polarization="Ey"),
+                 td.PointDipole(center=(-0.2, 0, 0.07), source_time=PULSE, polarization="Ex")],
+        monitors=[td.FieldTimeMonitor(center=(0.1, 0, 0.2), size=(0.3, 0, 0.2), name="t", interval=5, colocate=False),
+                  td.FieldMonitor(center=(0, 0, 0), size=(0.8, 0, 0.6), freqs=[2.5e14, 3e14], name="f")],
+        boundary_spec=td.BoundarySpec(x=td.Boundary.pml(num_layers=6), y=td.Boundary.periodic(),
+                                      z=td.Boundary.pml(num_layers=6)))
+
+
+def one_d(N=60):
+    """1-D simulation along z (zero size in x and y): a current sheet, a lossy slab, PML at both ends."""
+    return td.Simulation(
+        size=(0.0, 0.0, N * DL), grid_spec=td.GridSpec.uniform(dl=DL), run_time=1e-12, shutoff=0,
+        structures=[td.Structure(geometry=td.Box(center=(0, 0, 0.5), size=(td.inf, td.inf, 0.4)),
+                                 medium=td.Medium(permittivity=2.25, conductivity=0.02))],
+        sources=[td.UniformCurrentSource(center=(0, 0, -0.8), size=(td.inf, td.inf, 0), source_time=PULSE,
+                                         polarization="Ex")],
+        monitors=[td.FieldTimeMonitor(center=(0, 0, 1.0), size=(0, 0, 0), name="t", interval=3),
+                  td.FluxMonitor(center=(0, 0, 1.1), size=(td.inf, td.inf, 0), freqs=[2.5e14, 3e14], name="f")],
+        boundary_spec=td.BoundarySpec(x=td.Boundary.periodic(), y=td.Boundary.periodic(),
+                                      z=td.Boundary.pml(num_layers=8)))
+
+
 CASES = {
+    "two_d": two_d, "one_d": one_d,
     "tfsf_box": tfsf_box, "planewave_periodic": planewave_periodic, "au_array": au_array,
     "pec_box": pec_box, "pec_box_vec": pec_box_vec, "periodic_box": periodic_box,
     "periodic_box_tall": periodic_box_tall,
