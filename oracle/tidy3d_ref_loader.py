@@ -42,6 +42,49 @@ def _stub(name):
     return m
 
 
+def _mesher_shims():
+    """The reference's mesher (components/grid/mesher.py) makes three third-party calls that are not
+    installed here: a 2-D box, an R-tree query over boxes (shapely) and a bracketed root find
+    (pyroots.Brentq).  Minimal functional stand-ins so that the REFERENCE'S OWN mesher code runs and
+    AutoGrid goldens can be generated from it (tests/golden/make_golden.py); nothing here is mesher
+    logic.  The root finder is scipy's brentq at the tolerance the reference passes."""
+    class _Box:
+        def __init__(self, minx, miny, maxx, maxy):
+            self.bounds = (float(minx), float(miny), float(maxx), float(maxy))
+
+    class _STRtree:
+        def __init__(self, geoms):
+            self.geoms = list(geoms)
+
+        def query(self, geom):
+            a = geom.bounds
+            return [i for i, g in enumerate(self.geoms)
+                    if not (g.bounds[2] < a[0] or g.bounds[0] > a[2] or g.bounds[3] < a[1] or g.bounds[1] > a[3])]
+
+    class _Result:
+        def __init__(self, x0, converged):
+            self.x0, self.converged = x0, converged
+
+    class _Brentq:
+        def __init__(self, raise_on_fail=True, epsilon=1e-6, **kw):
+            self.epsilon, self.raise_on_fail = epsilon, raise_on_fail
+
+        def __call__(self, f, a, b):
+            from scipy.optimize import brentq
+            try:
+                x0 = brentq(f, a, b, xtol=self.epsilon * 1e-3, rtol=8.9e-16, maxiter=500)
+                return _Result(x0, True)
+            except Exception:       # noqa: BLE001 - no sign change etc.: "not converged", as pyroots reports it
+                if self.raise_on_fail:
+                    raise
+                return _Result(None, False)
+
+    sys.modules["shapely.geometry"].box = _Box
+    sys.modules["shapely.strtree"].STRtree = _STRtree
+    sys.modules["shapely.errors"].ShapelyDeprecationWarning = type("ShapelyDeprecationWarning", (Warning,), {})
+    sys.modules["pyroots"].Brentq = _Brentq
+
+
 _loaded = None
 
 
@@ -64,6 +107,7 @@ def load_tidy3d(numpy1_semantics: bool = True):
               "xarray.core.variable", "xarray.core.types", "xarray.core.options"]:
         if n not in sys.modules:
             _stub(n)
+    _mesher_shims()
     if "xarray" not in sys.modules:
         xr = types.ModuleType("xarray")
         xr.__path__ = []
@@ -113,6 +157,9 @@ def load_tidy3d(numpy1_semantics: bool = True):
     if numpy1_semantics:
         import tidy3d.components.simulation as simmod
         simmod.fp_eps = float(simmod.fp_eps)
+        # same in the mesher: ``max_scale - fp_eps`` (mesher.py:702,707) would be rounded to float32
+        import tidy3d.components.grid.mesher as meshmod
+        meshmod.fp_eps = float(meshmod.fp_eps)
     _loaded = td
     return td
 

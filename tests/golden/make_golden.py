@@ -216,6 +216,74 @@ def mode_solver_cases():
     return out
 
 
+def autogrid_cases():
+    """Simulations meshed by the reference's OWN GradedMesher (components/grid/mesher.py; its three
+    third-party calls — a 2-D box, an R-tree query, a bracketed root find — are stood in for by
+    oracle/tidy3d_ref_loader.py).  Stored: the simulation in the reference's JSON form and the cell
+    boundaries ``sim.grid.boundaries`` the reference produces."""
+    pulse = td.GaussianPulse(freq0=2e14, fwidth=2e13)
+
+    def base(**kw):
+        d = dict(size=(4, 3, 2), run_time=1e-13, grid_spec=td.GridSpec.auto(min_steps_per_wvl=12),
+                 structures=[td.Structure(geometry=td.Box(center=(0, 0, 0), size=(1, 0.5, 0.22)),
+                                          medium=td.Medium(permittivity=12.0)),
+                             td.Structure(geometry=td.Sphere(center=(1.2, 0.3, 0.1), radius=0.3),
+                                          medium=td.Medium(permittivity=4.0))],
+                 sources=[td.PointDipole(center=(0.3, 0, 0), source_time=pulse, polarization="Ez")],
+                 boundary_spec=td.BoundarySpec.all_sides(td.PML()))
+        d.update(kw)
+        return td.Simulation(**d)
+
+    rng = np.random.default_rng(11)
+
+    def random_boxes(n):
+        out = []
+        for _ in range(n):
+            c = rng.uniform(-1.2, 1.2, 3) * (1.0, 0.8, 0.5)
+            sz = rng.uniform(0.02, 1.5, 3) * (1.0, 0.8, 0.5)
+            med = [td.Medium(permittivity=float(rng.uniform(1.5, 13))), td.PEC,
+                   td.Lorentz(eps_inf=2.0, coeffs=[(1.5, 4e14, 3e13)]),
+                   td.Medium(permittivity=2.0, conductivity=float(rng.uniform(0, 2)))][int(rng.integers(0, 4))]
+            geo = [td.Box(center=tuple(c), size=tuple(sz)), td.Sphere(center=tuple(c), radius=float(sz[0] / 2)),
+                   td.Cylinder(center=tuple(c), radius=float(sz[1] / 2), length=float(sz[2]), axis=2)][int(rng.integers(0, 3))]
+            out.append(td.Structure(geometry=geo, medium=med))
+        return out
+
+    sims = {
+        "default_grid_spec": base(grid_spec=td.GridSpec()),
+        "base": base(),
+        "fine_gentle": base(grid_spec=td.GridSpec.auto(min_steps_per_wvl=20, max_scale=1.2)),
+        "symmetry": base(symmetry=(1, -1, 0)),
+        "periodic": base(boundary_spec=td.BoundarySpec(x=td.Boundary.periodic(), y=td.Boundary.periodic(),
+                                                       z=td.Boundary.pml())),
+        "mixed_axes": base(grid_spec=td.GridSpec(grid_x=td.AutoGrid(min_steps_per_wvl=15), grid_y=td.UniformGrid(dl=0.05),
+                                                 grid_z=td.AutoGrid(), wavelength=1.3)),
+        "waveguide_on_substrate": base(medium=td.Medium(permittivity=2.1), structures=[
+            td.Structure(geometry=td.Box(center=(0, 0, -0.5), size=(td.inf, td.inf, 1.0)), medium=td.Medium(permittivity=2.1)),
+            td.Structure(geometry=td.Box(center=(0, 0, 0.11), size=(td.inf, 0.45, 0.22)), medium=td.Medium(permittivity=12.1)),
+            td.Structure(geometry=td.Cylinder(center=(0.7, 0.2, 0.11), radius=0.25, length=0.22, axis=2),
+                         medium=td.Lorentz(eps_inf=2.0, coeffs=[(1.5, 4e14, 3e13)])),
+            td.Structure(geometry=td.Box(center=(-1.0, 0.5, 0.05), size=(0.3, 0.02, 0.1)), medium=td.PEC)]),
+        "two_d": base(size=(4, 0, 2), boundary_spec=td.BoundarySpec(x=td.Boundary.pml(), y=td.Boundary.periodic(),
+                                                                    z=td.Boundary.pml())),
+        "overrides_snapping_dlmin": base(grid_spec=td.GridSpec.auto(min_steps_per_wvl=12, override_structures=[
+            td.MeshOverrideStructure(geometry=td.Box(center=(0, 0, 0), size=(1.4, 0.8, 0.5)), dl=(0.02, None, 0.015)),
+            td.MeshOverrideStructure(geometry=td.Box(center=(1.2, 0.3, 0.1), size=(0.5, 0.5, 0.5)), dl=(0.04, 0.04, 0.04),
+                                     enforce=True)],
+            snapping_points=[(0.33, 0.41, -0.27), (1.9, 0, 0)], dl_min=0.012)),
+        "empty_domain": base(structures=[]),
+    }
+    for k in range(6):
+        sims[f"random_{k}"] = base(structures=random_boxes(3 + 2 * k),
+                                   grid_spec=td.GridSpec.auto(min_steps_per_wvl=float(rng.uniform(8, 18)),
+                                                              max_scale=float(rng.uniform(1.2, 1.6))))
+    out = {}
+    for name, sim in sims.items():
+        out[name] = {"simulation": json.loads(sim.json()),
+                     "boundaries": {d: np.asarray(getattr(sim.grid.boundaries, d)).tolist() for d in "xyz"}}
+    return out
+
+
 if __name__ == "__main__":
     gold = {"_generator": "tests/golden/make_golden.py (reference tidy3d v%s, numpy-1 fp_eps semantics)" % td.__version__,
             "simulations": {k: record_sim(s) for k, s in simulations().items()},
@@ -225,5 +293,7 @@ if __name__ == "__main__":
         json.dump(gold, f)
     with open(os.path.join(HERE, "mode_golden.json"), "w") as f:
         json.dump({"_generator": gold["_generator"], "cases": mode_solver_cases()}, f)
+    with open(os.path.join(HERE, "autogrid_golden.json"), "w") as f:
+        json.dump({"_generator": gold["_generator"], "cases": autogrid_cases()}, f)
     print("wrote", os.path.getsize(os.path.join(HERE, "schema_golden.json")), "+",
           os.path.getsize(os.path.join(HERE, "mode_golden.json")), "bytes")

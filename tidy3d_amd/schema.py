@@ -622,13 +622,50 @@ class CustomGridBoundaries(_Model):
 
 @_register
 @dataclass
+class AutoGrid(_Model):
+    """Graded non-uniform grid (ref grid_spec.py:386); meshed by ``tidy3d_amd.autogrid``."""
+
+    min_steps_per_wvl: float = 10.0
+    max_scale: float = 1.4
+    dl_min: float = 0.0
+    mesher: Any = None
+
+
+@_register
+@dataclass
+class MeshOverrideStructure(_Model):
+    """Box that overrides the step inside it (ref structure.py MeshOverrideStructure)."""
+
+    geometry: Any = None
+    dl: Tuple[Optional[float], Optional[float], Optional[float]] = (None, None, None)
+    enforce: bool = False
+    name: Optional[str] = None
+
+
+@_register
+@dataclass
 class GridSpec(_Model):
-    """ref grid_spec.py:520; ``make_grid`` :670; ``uniform`` classmethod :745."""
+    """ref grid_spec.py:520; ``make_grid`` :670; ``uniform`` classmethod :745; ``auto`` :757."""
 
     grid_x: Any = None
     grid_y: Any = None
     grid_z: Any = None
     wavelength: Optional[float] = None
+    override_structures: Tuple[Any, ...] = ()
+    snapping_points: Tuple[Any, ...] = ()
+
+    def __post_init__(self):
+        # the reference's default GridSpec is AutoGrid on all three axes (ref grid_spec.py:562-581)
+        for name in ("grid_x", "grid_y", "grid_z"):
+            if getattr(self, name) is None:
+                setattr(self, name, AutoGrid())
+
+    @classmethod
+    def auto(cls, wavelength: Optional[float] = None, min_steps_per_wvl: float = 10.0, max_scale: float = 1.4,
+             override_structures=(), snapping_points=(), dl_min: float = 0.0) -> "GridSpec":
+        g = dict(min_steps_per_wvl=min_steps_per_wvl, max_scale=max_scale, dl_min=dl_min)
+        return cls(grid_x=AutoGrid(**g), grid_y=AutoGrid(**g), grid_z=AutoGrid(**g), wavelength=wavelength,
+                   override_structures=tuple(override_structures), snapping_points=tuple(snapping_points))
 
     @classmethod
     def uniform(cls, dl: float) -> "GridSpec":
