@@ -425,7 +425,13 @@ def wavelength_of(sim) -> float:
         return float(w)
     if len(sim.sources) == 0:
         raise SetupError("Automatic grid generation requires the input of 'wavelength' or sources.")
-    freqs = np.array([s.source_time.freq0 for s in sim.sources])
+    def f0(src):
+        # source (or source-time) types the solver does not run still carry freq0 in their JSON form
+        st = src.raw.get("source_time", {}) if isinstance(src, td.Unsupported) else src.source_time
+        if isinstance(st, td.Unsupported):
+            st = st.raw
+        return float(st["freq0"] if isinstance(st, dict) else st.freq0)
+    freqs = np.array([f0(s) for s in sim.sources])
     if not np.all(np.isclose(freqs, freqs[0])):
         raise SetupError("Sources of different central frequencies are supplied. "
                          "Please supply a 'wavelength' value for 'grid_spec'.")
