@@ -199,3 +199,22 @@ def test_hdf5_json_model_parses_with_reference_classes(td_ref):
             assert v in DATA_ARRAY_MAP, (k, v)
             ref_dims = DATA_ARRAY_MAP[v]._dims
             assert tuple(arrays[f"/data/{model['data'].index(entry)}/{k}"].dims) == tuple(ref_dims)
+
+
+@pytest.mark.parametrize("operation", ["union", "intersection", "difference", "symmetric_difference"])
+def test_clip_operation_matches_reference(td_ref, operation):
+    """ClipOperation built with the reference's classes: same bounds and same ``inside`` after the
+    JSON round trip into the mirror (ref geometry/base.py:2772-2960)."""
+    import json
+    import tidy3d_amd.schema as mirror
+    td = td_ref
+    geo = td.ClipOperation(operation=operation,
+                           geometry_a=td.Box(center=(0.1, 0, 0), size=(1.0, 0.8, 0.6)),
+                           geometry_b=td.ClipOperation(operation="union", geometry_a=td.Sphere(center=(0.5, 0.2, 0), radius=0.45),
+                                                       geometry_b=td.Cylinder(center=(-0.3, 0, 0.1), radius=0.2, length=1.0, axis=2)))
+    g = mirror.parse(json.loads(geo.json()))
+    assert isinstance(g, mirror.ClipOperation)
+    np.testing.assert_allclose(np.array(g.bounds), np.array(geo.bounds), atol=1e-12)
+    rng = np.random.default_rng(5)
+    x, y, z = rng.uniform(-1, 1.2, (3, 20000))
+    assert np.array_equal(g.inside(x, y, z), geo.inside(x, y, z))

@@ -323,6 +323,49 @@ class GeometryGroup(_Model):
         return out
 
 
+@_register
+@dataclass
+class ClipOperation(_Model):
+    """Set operation between two geometries (ref geometry/base.py:2772): ``inside`` combines the two
+    membership tests, ``bounds`` are the reference's (over)estimates (:2894-2921)."""
+
+    operation: str = "union"
+    geometry_a: Any = None
+    geometry_b: Any = None
+
+    _OPS = {"union": np.logical_or, "intersection": np.logical_and,
+            "difference": lambda a, b: a & ~b, "symmetric_difference": np.logical_xor}
+
+    def __post_init__(self):
+        if self.operation not in self._OPS:
+            raise ValidationError("'operation' must be one of 'union', 'intersection', 'difference', or "
+                                  "'symmetric_difference'.")
+
+    def _parts(self):
+        for g in (self.geometry_a, self.geometry_b):
+            if isinstance(g, Unsupported):
+                g.fail()
+        return self.geometry_a, self.geometry_b
+
+    @property
+    def bounds(self):
+        a, b = self._parts()
+        if self.operation == "difference":
+            return a.bounds
+        ba, bb = a.bounds, b.bounds
+        if self.operation == "intersection":
+            lo = tuple(max(ba[0][i], bb[0][i]) for i in range(3))
+            hi = tuple(min(ba[1][i], bb[1][i]) for i in range(3))
+            if any(lo[i] > hi[i] for i in range(3)):
+                return (0, 0, 0), (0, 0, 0)
+            return lo, hi
+        return (tuple(min(ba[0][i], bb[0][i]) for i in range(3)), tuple(max(ba[1][i], bb[1][i]) for i in range(3)))
+
+    def inside(self, x, y, z):
+        a, b = self._parts()
+        return self._OPS[self.operation](np.asarray(a.inside(x, y, z), bool), np.asarray(b.inside(x, y, z), bool))
+
+
 # --------------------------------------------------------------------------------------
 # media  (ref components/medium.py)
 # --------------------------------------------------------------------------------------
