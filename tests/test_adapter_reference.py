@@ -218,3 +218,26 @@ def test_clip_operation_matches_reference(td_ref, operation):
     rng = np.random.default_rng(5)
     x, y, z = rng.uniform(-1, 1.2, (3, 20000))
     assert np.array_equal(g.inside(x, y, z), geo.inside(x, y, z))
+
+
+@pytest.mark.parametrize("kw", [dict(size=(0.5, 0.4, 0.4), exclude_surfaces=["z-"]), dict(size=(0.5, 0.4, 0.4)),
+                                dict(size=(0.5, 0, 0.4), normal_dir="-"), dict(size=(0.6, 0.5, 0), normal_dir="+")])
+def test_projection_surfaces_match_reference(td_ref, kw):
+    """The near-field surfaces of a FieldProjectionAngleMonitor (what the kernels record and what the
+    .hdf5 file lists as ``projection_surfaces``) == ref monitor.py:874-889 on the reference's object."""
+    import json
+    import tidy3d_amd.schema as mirror
+    from tidy3d_amd.discretize import flux_surfaces
+    td = td_ref
+    m_ref = td.FieldProjectionAngleMonitor(center=(0.2, 0, -0.1), freqs=[2.5e14], theta=[0.3, 1.2], phi=[0.0, 1.0],
+                                           proj_distance=1e5, name="far", **kw)
+    m = mirror.parse(json.loads(m_ref.json()))
+    assert isinstance(m, mirror.FieldProjectionAngleMonitor) and m.local_origin == tuple(m_ref.local_origin)
+    mine = flux_surfaces(m)
+    ref = m_ref.projection_surfaces
+    assert len(mine) == len(ref)
+    for (sname, box, axis, sign), r in zip(mine, ref):
+        assert tuple(box.center) == pytest.approx(tuple(r.monitor.center)) and tuple(box.size) == pytest.approx(tuple(r.monitor.size))
+        assert ("+" if sign > 0 else "-") == r.normal_dir and axis == r.axis
+        from tidy3d_amd.hdf5io import surface_name
+        assert surface_name(m, sname) == r.monitor.name

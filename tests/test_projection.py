@@ -1,0 +1,45 @@
+"""FieldProjectionAngleMonitor (far-field approximation; tidy3d_amd/projection.py restating ref
+components/field_projection.py).  The reference's projector needs xarray and cannot run here, so the
+pins are analytic: a Hertzian dipole radiates E_theta ~ sin(theta) with no E_phi, and the power
+integrated over the far sphere equals the flux through the near-field box."""
+import numpy as np
+
+import tidy3d_amd.schema as td
+from tidy3d_amd.data import assemble
+from tidy3d_amd.discretize import discretize
+from oracle.fdtd_numpy import OracleFdtd
+
+
+def test_dipole_pattern_and_power():
+    dl = 1.0 / 20
+    f0 = 3e14                       # lambda = 1 um
+    pulse = td.GaussianPulse(freq0=f0, fwidth=f0 / 6)
+    theta = np.linspace(0, np.pi, 19)
+    phi = np.linspace(0, 2 * np.pi, 13)
+    sim = td.Simulation(
+        size=(1.6, 1.6, 1.6), grid_spec=td.GridSpec.uniform(dl=dl), run_time=40 / f0,
+        sources=[td.PointDipole(center=(0, 0, 0), source_time=pulse, polarization="Ez")],
+        monitors=[td.FieldProjectionAngleMonitor(center=(0, 0, 0), size=(1.0, 1.0, 1.0), freqs=[f0], theta=theta, phi=phi,
+                                                 proj_distance=1e4, name="far"),
+                  td.FluxMonitor(center=(0, 0, 0), size=(1.0, 1.0, 1.0), freqs=[f0], name="flux")],
+        boundary_spec=td.BoundarySpec.all_sides(td.PML(num_layers=8)), shutoff=1e-5)
+    disc = discretize(sim)
+    sd = assemble(disc, OracleFdtd(disc.spec).run())
+    far = sd["far"]
+    e_t = np.abs(far.Etheta.values[0, :, :, 0])
+    e_p = np.abs(far.Ephi.values[0, :, :, 0])
+    assert far.Etheta.dims == ("r", "theta", "phi", "f") and far.Etheta.shape == (1, 19, 13, 1)
+    # pattern: |E_theta| = A sin(theta), independent of phi; E_phi vanishes
+    amp = e_t[9].mean()
+    np.testing.assert_allclose(e_t, amp * np.sin(theta)[:, None] * np.ones((1, 13)), atol=0.03 * amp)
+    assert e_p.max() < 0.02 * amp
+    # power through the far sphere == flux through the near box
+    p = far.power.values[0, :, :, 0]                       # W / um^2 at r
+    r = 1e4
+    integrand = p * np.sin(theta)[:, None] * r ** 2
+    trap = getattr(np, "trapezoid", None) or np.trapz
+    total = trap(trap(integrand, phi, axis=1), theta)
+    np.testing.assert_allclose(total, float(sd["flux"].flux.values[0]), rtol=0.03)
+    # impedance of free space in the far zone
+    ratio = far.Etheta.values[0, 9, 0, 0] / far.Hphi.values[0, 9, 0, 0]
+    assert abs(abs(ratio) - 376.73) < 0.5

@@ -85,6 +85,11 @@ def to_tidy3d(sim_data: SimulationData, td_simulation=None):
                 amps=td.ModeAmpsDataArray(d.amps.values, coords={dim: d.amps.coords[dim] for dim in d.amps.dims}),
                 n_complex=td.ModeIndexDataArray(d.n_complex.values,
                                                 coords={dim: d.n_complex.coords[dim] for dim in d.n_complex.dims})))
+        elif type(d).__name__ == "FieldProjectionAngleData":
+            comps = {k: td.FieldProjectionAngleDataArray(v.values, coords={dim: v.coords[dim] for dim in v.dims})
+                     for k, v in d.field_components.items()}
+            out.append(td.FieldProjectionAngleData(monitor=mon, projection_surfaces=mon.projection_surfaces,
+                                                   medium=mon.medium or td_simulation.medium, **comps))
         else:
             raise Tidy3dNotImplementedError(f"no tidy3d conversion for {type(d).__name__}")
     return td.SimulationData(simulation=td_simulation, data=tuple(out), log=sim_data.log,

@@ -322,6 +322,11 @@ _ARRAY_TYPES = {          # container field -> tidy3d DataArray class name (ref 
 }
 
 
+def surface_name(mon, sname: str) -> str:
+    """Name the reference gives the near-field surface monitors (ref monitor.py:518-566)."""
+    return mon.name if sname == "plane" else f"{mon.name}_{sname}"
+
+
 def _grid_json(ge: Dict[str, np.ndarray]) -> dict:
     return {"type": "Grid", "boundaries": {"type": "Coords", **{d: np.asarray(ge[d], float).tolist() for d in "xyz"}}}
 
@@ -361,6 +366,21 @@ def simulation_data_model(sim_data) -> Tuple[dict, Dict[str, Any]]:
         elif kind == "ModeData":
             entry["amps"], entry["n_complex"] = "ModeAmpsDataArray", "ModeIndexDataArray"
             arrays[f"{base}/amps"], arrays[f"{base}/n_complex"] = d.amps, d.n_complex
+        elif kind == "FieldProjectionAngleData":
+            from .discretize import flux_surfaces
+            mon = d.monitor
+            # ref monitor.py:874-889: the near-field surfaces as colocated FieldMonitors
+            entry["projection_surfaces"] = [
+                {"type": "FieldProjectionSurface", "normal_dir": "+" if sign > 0 else "-",
+                 "monitor": {"type": "FieldMonitor", "center": [float(c) for c in box.center],
+                             "size": [float(c) for c in box.size], "freqs": [float(f) for f in mon.freqs],
+                             "name": surface_name(mon, sname), "colocate": True}}
+                for sname, box, axis, sign in flux_surfaces(mon)]
+            entry["medium"] = (mon.medium if mon.medium is not None else sim.medium).dict()
+            entry["is_2d_simulation"] = False
+            for name, arr in d.field_components.items():
+                entry[name] = "FieldProjectionAngleDataArray"
+                arrays[f"{base}/{name}"] = arr
         else:
             raise Tidy3dNotImplementedError(f"no hdf5 layout for {kind}")
         data_json.append(entry)
@@ -408,7 +428,8 @@ def load_simulation_data(path: str):
     by_name = {m.name: m for m in sim.monitors}
     dims = {"ScalarFieldDataArray": ("x", "y", "z", "f"), "ScalarFieldTimeDataArray": ("x", "y", "z", "t"),
             "FluxDataArray": ("f",), "FluxTimeDataArray": ("t",), "ModeAmpsDataArray": ("direction", "f", "mode_index"),
-            "ModeIndexDataArray": ("f", "mode_index")}
+            "ModeIndexDataArray": ("f", "mode_index"),
+            "FieldProjectionAngleDataArray": ("r", "theta", "phi", "f")}
 
     def arr(gpath: str, tag: str) -> DataArray:
         coords = {d: (np.asarray(tree[f"{gpath}/{d}"]) if not isinstance(tree[f"{gpath}/{d}"], list)
@@ -435,6 +456,9 @@ def load_simulation_data(path: str):
             out.append(FluxTimeData(monitor=mon, flux=fields["flux"]))
         elif kind == "ModeData":
             out.append(ModeData(monitor=mon, amps=fields["amps"], n_complex=fields["n_complex"]))
+        elif kind == "FieldProjectionAngleData":
+            from .projection import FieldProjectionAngleData
+            out.append(FieldProjectionAngleData(monitor=mon, **fields))
         else:
             raise Tidy3dNotImplementedError(f"no mirror container for {kind}")
     return SimulationData(simulation=sim, data=tuple(out), log=model.get("log") or "",

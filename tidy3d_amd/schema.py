@@ -1269,6 +1269,42 @@ class PermittivityMonitor(_Monitor):
 
 @_register
 @dataclass
+class FieldProjectionAngleMonitor(_Monitor):
+    """Near-to-far projection to points (r, theta, phi) (ref monitor.py:930-1040); the near fields
+    are recorded on the monitor's surfaces like a flux box and projected after the run
+    (tidy3d_amd/projection.py; far-field approximation only)."""
+
+    center: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    size: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    name: str = "proj"
+    freqs: Tuple[float, ...] = ()
+    theta: Tuple[float, ...] = ()
+    phi: Tuple[float, ...] = ()
+    proj_distance: float = 1e6
+    normal_dir: Optional[str] = None
+    exclude_surfaces: Optional[Tuple[str, ...]] = None
+    custom_origin: Optional[Tuple[float, float, float]] = None
+    far_field_approx: bool = True
+    interval_space: Tuple[int, int, int] = (1, 1, 1)
+    window_size: Tuple[float, float] = (0.0, 0.0)
+    medium: Any = None
+    colocate: bool = True
+    apodization: ApodizationSpec = field(default_factory=ApodizationSpec)
+
+    def __post_init__(self):
+        self.theta = tuple(float(v) for v in np.atleast_1d(self.theta))
+        self.phi = tuple(float(v) for v in np.atleast_1d(self.phi))
+
+    def frequency_range(self):
+        return (min(self.freqs), max(self.freqs))
+
+    @property
+    def local_origin(self):
+        return tuple(self.center) if self.custom_origin is None else tuple(self.custom_origin)
+
+
+@_register
+@dataclass
 class RunTimeSpec(_Model):
     """ref components/run_time_spec.py; evaluated in Simulation._run_time (simulation.py:3677)."""
 
