@@ -202,3 +202,34 @@ def test_job_and_batch_facade(emu_lib, tmp_path):
     # a fresh BatchData reads the files back
     again = BatchData(task_paths=bd.task_paths, task_ids=bd.task_ids)
     assert np.array_equal(again["b"]["fl"].flux.values, bd["b"]["fl"].flux.values)
+
+
+def test_projection_data_round_trip(tmp_path):
+    """FieldProjection{Angle,Cartesian,KSpace}Data through the .hdf5 layout (ref DATA_ARRAY_MAP names)."""
+    from oracle.fdtd_numpy import OracleFdtd
+    from tidy3d_amd.data import assemble
+    from tidy3d_amd.discretize import discretize
+    from tidy3d_amd.web import save
+    common = dict(center=(0, 0, 0.2), size=(0.5, 0.4, 0), freqs=[3e14], normal_dir="+")
+    sim = td.Simulation(
+        size=(12 * DL, 10 * DL, 10 * DL), grid_spec=td.GridSpec.uniform(dl=DL), run_time=2e-14,
+        sources=[td.PointDipole(center=(0, 0, 0), source_time=PULSE, polarization="Ex")],
+        monitors=[td.FieldProjectionAngleMonitor(theta=[0.2, 0.5], phi=[0.0], proj_distance=1e3, name="a", **common),
+                  td.FieldProjectionCartesianMonitor(x=[10.0, 20.0], y=[5.0], proj_distance=1e3, name="c", **common),
+                  td.FieldProjectionKSpaceMonitor(ux=[0.1, 0.2], uy=[0.0, 0.3], proj_distance=1e3, name="k", **common)],
+        boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary()))
+    disc = discretize(sim, n_steps=40)
+    sd = assemble(disc, OracleFdtd(disc.spec).run())
+    path = str(tmp_path / "proj.hdf5")
+    save(sd, path)
+    tree = hdf5io.read_tree(path)
+    model = json.loads(tree["/JSON_STRING"])
+    assert [e["type"] for e in model["data"]] == ["FieldProjectionAngleData", "FieldProjectionCartesianData",
+                                                  "FieldProjectionKSpaceData"]
+    assert model["data"][1]["Etheta"] == "FieldProjectionCartesianDataArray"
+    assert model["data"][0]["projection_surfaces"][0]["monitor"]["name"] == "a"
+    back = load(path)
+    for name in ("a", "c", "k"):
+        for comp in ("Etheta", "Hphi"):
+            assert np.array_equal(getattr(back[name], comp).values, getattr(sd[name], comp).values)
+            assert getattr(back[name], comp).dims == getattr(sd[name], comp).dims

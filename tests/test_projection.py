@@ -43,3 +43,34 @@ def test_dipole_pattern_and_power():
     # impedance of free space in the far zone
     ratio = far.Etheta.values[0, 9, 0, 0] / far.Hphi.values[0, 9, 0, 0]
     assert abs(abs(ratio) - 376.73) < 0.5
+
+
+def test_cartesian_and_kspace_agree_with_the_angular_projection():
+    """The three monitor types are three parametrisations of the same far field (ref
+    field_projection.py:584-829): a Cartesian point and a k-space direction must reproduce the
+    angular projection at the (r, theta, phi) they map to."""
+    dl = 1.0 / 16
+    f0 = 3e14
+    pulse = td.GaussianPulse(freq0=f0, fwidth=f0 / 6)
+    th, ph = 0.6, 0.9
+    rr = 5e3
+    ux, uy = np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph)
+    common = dict(center=(0, 0, 0.3), size=(1.2, 1.2, 0), freqs=[f0], normal_dir="+")
+    sim = td.Simulation(
+        size=(1.6, 1.6, 1.2), grid_spec=td.GridSpec.uniform(dl=dl), run_time=30 / f0,
+        sources=[td.PointDipole(center=(0.1, 0, -0.1), source_time=pulse, polarization="Ex")],
+        monitors=[td.FieldProjectionAngleMonitor(theta=[th], phi=[ph], proj_distance=rr, name="a", **common),
+                  td.FieldProjectionCartesianMonitor(x=[rr * ux], y=[rr * uy], proj_axis=2, proj_distance=rr * np.cos(th),
+                                                     name="c", **common),
+                  td.FieldProjectionKSpaceMonitor(ux=[ux, 2.0], uy=[uy], proj_axis=2, proj_distance=rr, name="k", **common)],
+        boundary_spec=td.BoundarySpec.all_sides(td.PML(num_layers=8)), shutoff=1e-5)
+    disc = discretize(sim)
+    sd = assemble(disc, OracleFdtd(disc.spec).run())
+    a, c, k = sd["a"], sd["c"], sd["k"]
+    assert c.Etheta.dims == ("x", "y", "z", "f") and k.Etheta.dims == ("ux", "uy", "r", "f")
+    for name in ("Etheta", "Ephi", "Htheta", "Hphi"):
+        va = getattr(a, name).values[0, 0, 0, 0]
+        np.testing.assert_allclose(getattr(c, name).values[0, 0, 0, 0], va, rtol=1e-9)
+        np.testing.assert_allclose(getattr(k, name).values[0, 0, 0, 0], va, rtol=1e-9)
+    assert np.isnan(k.Etheta.values[1, 0, 0, 0])              # ux = 2: not a propagating direction
+    assert abs(a.Etheta.values[0, 0, 0, 0]) > 0

@@ -543,9 +543,11 @@ def assemble(disc: Discretization, raw: Dict[str, np.ndarray], log: str = "", di
         elif plan.kind == "mode":
             from .modesource import mode_monitor_data
             out.append(mode_monitor_data(disc, plan, raw, norm))
-        elif plan.kind == "projection_angle":
-            from .projection import project_angle
-            out.append(project_angle(disc, plan, raw, norm))
+        elif plan.kind.startswith("projection_"):
+            from . import projection
+            fn = {"projection_angle": projection.project_angle, "projection_cartesian": projection.project_cartesian,
+                  "projection_kspace": projection.project_kspace}[plan.kind]
+            out.append(fn(disc, plan, raw, norm))
         elif plan.kind == "permittivity":
             out.append(permittivity_data(sim, spec if pfull is None else disc.spec_full,
                                          plan if pfull is None else pfull))

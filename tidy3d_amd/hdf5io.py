@@ -366,7 +366,7 @@ def simulation_data_model(sim_data) -> Tuple[dict, Dict[str, Any]]:
         elif kind == "ModeData":
             entry["amps"], entry["n_complex"] = "ModeAmpsDataArray", "ModeIndexDataArray"
             arrays[f"{base}/amps"], arrays[f"{base}/n_complex"] = d.amps, d.n_complex
-        elif kind == "FieldProjectionAngleData":
+        elif kind in ("FieldProjectionAngleData", "FieldProjectionCartesianData", "FieldProjectionKSpaceData"):
             from .discretize import flux_surfaces
             mon = d.monitor
             # ref monitor.py:874-889: the near-field surfaces as colocated FieldMonitors
@@ -379,7 +379,7 @@ def simulation_data_model(sim_data) -> Tuple[dict, Dict[str, Any]]:
             entry["medium"] = (mon.medium if mon.medium is not None else sim.medium).dict()
             entry["is_2d_simulation"] = False
             for name, arr in d.field_components.items():
-                entry[name] = "FieldProjectionAngleDataArray"
+                entry[name] = kind.replace("Data", "DataArray")
                 arrays[f"{base}/{name}"] = arr
         else:
             raise Tidy3dNotImplementedError(f"no hdf5 layout for {kind}")
@@ -429,7 +429,9 @@ def load_simulation_data(path: str):
     dims = {"ScalarFieldDataArray": ("x", "y", "z", "f"), "ScalarFieldTimeDataArray": ("x", "y", "z", "t"),
             "FluxDataArray": ("f",), "FluxTimeDataArray": ("t",), "ModeAmpsDataArray": ("direction", "f", "mode_index"),
             "ModeIndexDataArray": ("f", "mode_index"),
-            "FieldProjectionAngleDataArray": ("r", "theta", "phi", "f")}
+            "FieldProjectionAngleDataArray": ("r", "theta", "phi", "f"),
+            "FieldProjectionCartesianDataArray": ("x", "y", "z", "f"),
+            "FieldProjectionKSpaceDataArray": ("ux", "uy", "r", "f")}
 
     def arr(gpath: str, tag: str) -> DataArray:
         coords = {d: (np.asarray(tree[f"{gpath}/{d}"]) if not isinstance(tree[f"{gpath}/{d}"], list)
@@ -456,9 +458,9 @@ def load_simulation_data(path: str):
             out.append(FluxTimeData(monitor=mon, flux=fields["flux"]))
         elif kind == "ModeData":
             out.append(ModeData(monitor=mon, amps=fields["amps"], n_complex=fields["n_complex"]))
-        elif kind == "FieldProjectionAngleData":
-            from .projection import FieldProjectionAngleData
-            out.append(FieldProjectionAngleData(monitor=mon, **fields))
+        elif kind in ("FieldProjectionAngleData", "FieldProjectionCartesianData", "FieldProjectionKSpaceData"):
+            from . import projection
+            out.append(getattr(projection, kind)(monitor=mon, **fields))
         else:
             raise Tidy3dNotImplementedError(f"no mirror container for {kind}")
     return SimulationData(simulation=sim, data=tuple(out), log=model.get("log") or "",

@@ -1305,6 +1305,34 @@ class FieldProjectionAngleMonitor(_Monitor):
 
 @_register
 @dataclass
+class FieldProjectionCartesianMonitor(FieldProjectionAngleMonitor):
+    """Projection to points (x, y) of a plane at ``proj_distance`` along ``proj_axis`` (ref monitor.py:1043)."""
+
+    x: Tuple[float, ...] = ()
+    y: Tuple[float, ...] = ()
+    proj_axis: int = 2
+
+    def __post_init__(self):
+        self.x = tuple(float(v) for v in np.atleast_1d(self.x))
+        self.y = tuple(float(v) for v in np.atleast_1d(self.y))
+
+
+@_register
+@dataclass
+class FieldProjectionKSpaceMonitor(FieldProjectionAngleMonitor):
+    """Projection to directions (ux, uy) around ``proj_axis`` (ref monitor.py:1173)."""
+
+    ux: Tuple[float, ...] = ()
+    uy: Tuple[float, ...] = ()
+    proj_axis: int = 2
+
+    def __post_init__(self):
+        self.ux = tuple(float(v) for v in np.atleast_1d(self.ux))
+        self.uy = tuple(float(v) for v in np.atleast_1d(self.uy))
+
+
+@_register
+@dataclass
 class RunTimeSpec(_Model):
     """ref components/run_time_spec.py; evaluated in Simulation._run_time (simulation.py:3677)."""
 
