@@ -260,3 +260,27 @@ def test_filter_pol_reorders_modes():
     np.testing.assert_allclose(te.n_complex, plain.n_complex, rtol=1e-12)
     np.testing.assert_allclose(tm.n_complex, plain.n_complex[::-1], rtol=1e-12)
     assert np.abs(tm.Ev[:, :, 0]).max() > np.abs(tm.Eu[:, :, 0]).max() or np.abs(tm.Eu[:, :, 0]).max() > 0
+
+
+def test_mode_solver_facade_matches_baseline_config1_golden():
+    """``tidy3d_amd.plugins.mode.ModeSolver`` on the BASELINE config-1 strip: same n_eff as the
+    reference golden used above (through discretize + mode_profile instead of raw arrays)."""
+    from tidy3d_amd.plugins.mode import ModeSolver
+    wg_w, wg_h = 0.45, 0.22
+    sim = td.Simulation(
+        size=(2.0, 3.0, 2.0), grid_spec=td.GridSpec.uniform(dl=0.02), run_time=1e-14, subpixel=False,
+        medium=td.Medium(permittivity=1.44 ** 2),
+        structures=[td.Structure(geometry=td.Box(center=(0, 0, 0), size=(td.inf, wg_w, wg_h)),
+                                 medium=td.Medium(permittivity=3.48 ** 2))],
+        sources=[td.PointDipole(center=(0, 0, 0), source_time=td.GaussianPulse(freq0=C_0 / 1.55, fwidth=1e13), polarization="Ey")],
+        boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary()))
+    ms = ModeSolver(sim, td.Box(center=(0, 0, 0), size=(0, 2.4, 1.6)), td.ModeSpec(num_modes=2, precision="double"),
+                    freqs=[C_0 / 1.55, C_0 / 1.5])
+    data = ms.solve()
+    assert data.n_complex.shape == (2, 2) and data.Ey.dims == ("x", "y", "z", "f", "mode_index")
+    assert data.Ey.shape[0] == 1 and data.Ey.shape[3:] == (2, 2)
+    n = data.n_eff.values
+    assert 2.2 < n[0, 0] < 2.6 and n[0, 0] > n[0, 1] and n[1, 0] > n[0, 0]      # TE0 of a 450 x 220 nm Si strip
+    # TE0: E mostly along y, even in y
+    ey = np.abs(data.Ey.values[0, :, :, 0, 0])
+    assert ey.max() > np.abs(data.Ez.values[0, :, :, 0, 0]).max()
