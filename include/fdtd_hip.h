@@ -107,6 +107,14 @@ int fdtd_set_pml(FdtdSolver* h, int axis, int n_lo, int n_hi,
                  const float* kinv_e, const float* b_e, const float* c_e,
                  const float* kinv_h, const float* b_h, const float* c_h, int n);
 
+/* Absorber layers of one axis (ref boundary.py:427-476 Absorber, :166-192 AbsorberParams; layer
+ * counts = Simulation.num_pml_layers, ref simulation.py:1002): per-step damping factors of length n
+ * (1 outside the layers), fb sampled at the cell boundaries, fc at the cell centres; the layers are
+ * [0, n_lo) and [n - n_hi, n).  Every component inside them is multiplied once per step by the
+ * product of its three axis factors (tidy3d_amd/coeffs.py damping_tables).  On a z-slab the host
+ * passes slab-local tables and counts. */
+int fdtd_set_absorber(FdtdSolver* h, int axis, int n_lo, int n_hi, const float* fb, const float* fc, int n);
+
 /* pole-residue ADE group: the cells (linear index k*ny*nx + j*nx + i within the slab) of E
  * component `comp` filled with one dispersive medium; kap/bet are n_poles complex pairs
  * (re,im interleaved), cc the memory-term coefficient (ref medium.py:2900-2913). */

@@ -29,7 +29,7 @@ from typing import Dict, Optional
 
 import numpy as np
 
-from tidy3d_amd.coeffs import h_coeff, inv_steps, material_table, pml_axis
+from tidy3d_amd.coeffs import damping_tables, h_coeff, inv_steps, material_table, pml_axis
 from tidy3d_amd.spec import BC_PEC, BC_PERIODIC, BC_PMC, SolverSpec
 
 
@@ -56,6 +56,19 @@ class OracleFdtd:
         self.ip = [_bcast(v.astype(dtype), a) for a, v in enumerate(ip)]
         self.id = [_bcast(v.astype(dtype), a) for a, v in enumerate(idl)]
         self.ch = dtype(h_coeff(spec.dt))
+        # absorber layers: per-step damping factors at each component's Yee location
+        # (tidy3d_amd.coeffs.damping_tables; Absorber of ref boundary.py:427-476)
+        self.damp_e = self.damp_h = None
+        dm = damping_tables(spec)
+        if dm is not None:
+            def factor(c, is_h):
+                f = np.ones(shp, np.float64)
+                for a in range(3):
+                    on_center = (a == c) != is_h
+                    f = f * _bcast(dm[a].fc if on_center else dm[a].fb, a)
+                return f.astype(dtype)
+            self.damp_e = [factor(c, False) for c in range(3)]
+            self.damp_h = [factor(c, True) for c in range(3)]
         self.mt = material_table(spec.media, spec.dt)
         if spec.mat_idx is not None:
             self.ca = [self.mt.ca[spec.mat_idx[c]].astype(dtype) for c in range(3)]
@@ -187,6 +200,10 @@ class OracleFdtd:
                     ijk = s.ijk[m]
                     np.add.at(E[cc], (ijk[:, 2], ijk[:, 1], ijk[:, 0]),
                               np.real(w[m] * s.wave_e[n]).astype(self.dtype))
+        # absorber layers: damp the updated E before the ADE memory term is added
+        if self.damp_e is not None:
+            for c in range(3):
+                E[c] *= self.damp_e[c]
         # ADE memory term + auxiliary update
         for (c, m, idx, q, _), eo in zip(self.ade, e_old):
             kap, bet = self.mt.kap[m][:, None], self.mt.bet[m][:, None]
@@ -274,6 +291,9 @@ class OracleFdtd:
     def step(self):
         n = self.step_index
         self._record(n, "pre")
+        if self.damp_h is not None:
+            for c in range(3):
+                self.H[c] *= self.damp_h[c]
         self.update_h(n)
         self._record(n, "post")
         self.update_e(n)

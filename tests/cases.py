@@ -196,8 +196,32 @@ def one_d(N=60):
                                       z=td.Boundary.pml(num_layers=8)))
 
 
+def absorber_mix(N=(16, 12, 16)):
+    """Absorber layers (ref boundary.py:427) on x (both faces), y+ (PML on y-) and z (both faces), with a
+    Drude slab and a lossy box running through them: the damping kernel next to CPML and ADE."""
+    structures = [
+        td.Structure(geometry=td.Box(center=(0, 0, -0.15), size=(td.inf, td.inf, 0.2)),
+                     medium=td.Drude(eps_inf=1.5, coeffs=[(1.2e15, 8e13)])),
+        td.Structure(geometry=td.Box(center=(0.2, 0, 0.2), size=(td.inf, 0.2, 0.15)),
+                     medium=td.Medium(permittivity=2.5, conductivity=0.01))]
+    ab = lambda n, s: td.Absorber(num_layers=n, parameters=td.AbsorberParams(sigma_max=s))
+    bspec = td.BoundarySpec(x=td.Boundary(minus=ab(4, 1.0), plus=ab(4, 2.0)),
+                            y=td.Boundary(minus=td.PML(num_layers=3), plus=ab(5, 0.8)),
+                            z=td.Boundary(minus=ab(3, 1.5), plus=ab(4, 1.5)))
+    return _sim(N, bspec, structures)
+
+
+def absorber_odd_rows(N=(13, 10, 9)):
+    """Absorber on x+ / z- with a row length that needs PEC padding (nx % 4 != 0), PMC at x-."""
+    ab = td.Absorber(num_layers=4, parameters=td.AbsorberParams(sigma_max=1.2, sigma_min=0.05, sigma_order=2))
+    bspec = td.BoundarySpec(x=td.Boundary(minus=td.PMCBoundary(), plus=ab),
+                            y=td.Boundary.periodic(),
+                            z=td.Boundary(minus=ab, plus=td.PECBoundary()))
+    return _sim(N, bspec)
+
+
 CASES = {
-    "two_d": two_d, "one_d": one_d,
+    "two_d": two_d, "one_d": one_d, "absorber_mix": absorber_mix, "absorber_odd_rows": absorber_odd_rows,
     "tfsf_box": tfsf_box, "planewave_periodic": planewave_periodic, "au_array": au_array,
     "pec_box": pec_box, "pec_box_vec": pec_box_vec, "periodic_box": periodic_box,
     "periodic_box_tall": periodic_box_tall,

@@ -39,7 +39,12 @@ MEDIA = [td.Structure(geometry=td.Sphere(center=(0.05, 0, 0), radius=0.2),
                       medium=td.Medium(permittivity=3.0, conductivity=0.02)),
          td.Structure(geometry=td.Box(center=(0.3, 0.1, 0), size=(0.1, 0.1, 0.1)), medium=td.PEC)]
 
+ABS = td.BoundarySpec(x=td.Boundary.absorber(num_layers=4, parameters=td.AbsorberParams(sigma_max=1.5)),
+                      y=td.Boundary(minus=td.PML(num_layers=3), plus=td.Absorber(num_layers=3)),
+                      z=td.Boundary.absorber(num_layers=3))
+
 CONFIGS = {
+    "absorber_media": ((32, 14, 10), ABS, MEDIA),
     "periodic_two_x_tiles": ((264, 10, 9), PER, ()),
     "pec_two_x_tiles": ((260, 9, 8), PEC, ()),
     "pmc_min_faces": ((16, 10, 9), PMC, ()),

@@ -159,6 +159,41 @@ def pml_axis(spec: SolverSpec, axis: int) -> PmlAxis:
     return PmlAxis(n_lo, n_hi, kinv_e, b_e, c_e, kinv_h, b_h, c_h)
 
 
+@dataclass
+class DampingAxis:
+    """Per-step damping factors of the absorber layers along one axis (identity outside):
+    ``fb`` at the cell boundaries b[i], ``fc`` at the cell centres; layers [0, n_lo) and [N - n_hi, N)."""
+
+    n_lo: int
+    n_hi: int
+    fb: np.ndarray
+    fc: np.ndarray
+
+
+def damping_tables(spec: SolverSpec):
+    """Adiabatic absorber (ref boundary.py:427-476: "a multilayer system with gradually increasing
+    conductivity" in front of a PEC wall; the reference's discretisation of it is server-side) as a
+    *matched* conductivity: the same decay rate sigma/eps0 for E and H, whatever the medium, so the
+    layers are impedance-matched at normal incidence in the continuum limit and media (also
+    dispersive ones) may run through them.  The decay is integrated exactly over one step, operator-
+    split from the curl updates:
+
+        H^{n-1/2} <- f_H H^{n-1/2}   (start of step n),
+        E^{n+1}   <- f_E (Ca E^n + Cb (curl H - J) + CPML terms) - Cc S^n    (memory term added after)
+        f = exp(-2 (s_x + s_y + s_z)),   s_a = profile of axis a at the component's Yee location
+                                         (sigma in units of 2 eps0/dt: sigma dt/eps0 = 2 s).
+
+    Returns None or one DampingAxis per axis; a component's factor is the product of its three axis
+    factors (``fc`` along the axes where it sits on cell centres, ``fb`` elsewhere)."""
+    if spec.absorber is None:
+        return None
+    out = []
+    for sb, sc, n_lo, n_hi in spec.absorber:
+        out.append(DampingAxis(n_lo=int(n_lo), n_hi=int(n_hi), fb=np.exp(-2.0 * np.asarray(sb, np.float64)),
+                               fc=np.exp(-2.0 * np.asarray(sc, np.float64))))
+    return out
+
+
 def inv_steps(spec: SolverSpec):
     """(1/primal, 1/dual) per axis: what the curls multiply differences with."""
     ip = [1.0 / spec.primal_steps(a) for a in range(3)]

@@ -99,6 +99,10 @@ struct FdtdSolver {
   float ca1 = 1.f, cb1 = 0.f;
   std::vector<float> cb_host;
   PmlAxisDev pml[3];
+  // absorber layers: per-axis damping tables (identity tables of length N for axes without layers)
+  float *damp_fb[3] = {}, *damp_fc[3] = {};
+  int damp_lo[3] = {0, 0, 0}, damp_hi[3] = {0, 0, 0};   // layers: index < lo or index >= hi
+  bool has_damp = false;
   std::vector<AdeGroup> ade;
   std::vector<PointSrc> psrc;
   std::vector<Tfsf> tfsf;
@@ -476,6 +480,32 @@ void launch_pml(FdtdSolver* h, bool e_side, int kbeg, int kend, hipStream_t st, 
                          P.psi_h[0], P.psi_h[1], (const float*)P.kinv_h, (const float*)P.b_h,
                          (const float*)P.c_h, (const float*)h->ip[a]);
   }
+}
+
+// absorber layers over the planes [kbeg, kend): E components (end of the E phase) or H components
+// (start of the H phase, before the H-side corrections).  One launch per axis and face.
+void launch_damp(FdtdSolver* h, bool e_side, int kbeg, int kend, hipStream_t st) {
+  if (!h->has_damp || kend <= kbeg) return;
+  const GridP& g = h->g;
+  const int N[3] = {g.nx, g.ny, g.nz};
+  DampP d;
+  for (int a = 0; a < 3; ++a) {
+    d.fb[a] = h->damp_fb[a]; d.fc[a] = h->damp_fc[a];
+    d.lo[a] = h->damp_lo[a]; d.hi[a] = h->damp_hi[a];
+  }
+  const int off = e_side ? 0 : 3;
+  float *f0 = field_ptr(h, off), *f1 = field_ptr(h, off + 1), *f2 = field_ptr(h, off + 2);
+  for (int a = 0; a < 3; ++a)
+    for (int side = 0; side < 2; ++side) {
+      int s_lo = side == 0 ? 0 : h->damp_hi[a];
+      int s_hi = side == 0 ? h->damp_lo[a] : N[a];
+      if (a == 2) { s_lo = std::max(s_lo, kbeg); s_hi = std::min(s_hi, kend); }
+      if (s_hi <= s_lo) continue;
+      const long long bx = (a == 0) ? (s_hi - s_lo) : g.nx, by = (a == 1) ? (s_hi - s_lo) : g.ny;
+      const long long bz = (a == 2) ? (s_hi - s_lo) : (kend - kbeg);
+      hipLaunchKernelGGL(damp_kernel, dim3(nblk(bx * by * bz)), dim3(256), 0, st, g, d, f0, f1, f2,
+                         e_side ? 0 : 1, a, s_lo, s_hi - s_lo, kbeg, kend);
+    }
 }
 
 void launch_sources(FdtdSolver* h, bool e_side, long long n, int kbeg, int kend, hipStream_t st, bool replica = false) {
@@ -891,6 +921,29 @@ int fdtd_set_pml(FdtdSolver* h, int axis, int n_lo, int n_hi, const float* kinv_
   return 0;
 }
 
+int fdtd_set_absorber(FdtdSolver* h, int axis, int n_lo, int n_hi, const float* fb, const float* fc, int n) {
+  if (!h) return -1;
+  if (axis < 0 || axis > 2) return fail(h, "fdtd_set_absorber: bad axis %d", axis);
+  const int N[3] = {h->g.nx, h->g.ny, h->g.nz};
+  if (n != N[axis]) return fail(h, "fdtd_set_absorber: axis %d has %d cells, got %d", axis, N[axis], n);
+  if (n_lo < 0 || n_hi < 0 || n_lo + n_hi > n) return fail(h, "fdtd_set_absorber: bad layer counts %d + %d", n_lo, n_hi);
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  // identity tables on the other axes, so that the kernel always forms the full product
+  for (int a = 0; a < 3; ++a) {
+    if (h->damp_fb[a]) continue;
+    std::vector<float> one((size_t)N[a], 1.0f);
+    if (dev_upload(h, &h->damp_fb[a], one.data(), one.size())) return -1;
+    if (dev_upload(h, &h->damp_fc[a], one.data(), one.size())) return -1;
+    h->damp_lo[a] = 0; h->damp_hi[a] = N[a];
+  }
+  HIPCHK(h, hipMemcpy(h->damp_fb[axis], fb, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->damp_fc[axis], fc, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  h->damp_lo[axis] = n_lo; h->damp_hi[axis] = n - n_hi;
+  h->has_damp = false;
+  for (int a = 0; a < 3; ++a) if (h->damp_lo[a] > 0 || h->damp_hi[a] < N[a]) h->has_damp = true;
+  return 0;
+}
+
 int fdtd_add_ade(FdtdSolver* h, int comp, int64_t n, const uint32_t* cell_index, int n_poles, const float* kap,
                  const float* bet, float cc) {
   if (!h) return -1;
@@ -1168,9 +1221,11 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   auto e_post = [&](long long n, int k0, int k1, hipStream_t s, bool replica) {
     launch_pml(h, true, k0, k1, s);
     launch_sources(h, true, n, k0, k1, s, replica);
+    launch_damp(h, true, k0, k1, s);       // before the ADE pass: its stored E^{n+1} is the damped one
     launch_ade(h, k0, k1, s);
   };
   auto h_pre = [&](long long n, int k0, int k1, hipStream_t s, bool replica) {
+    launch_damp(h, false, k0, k1, s);
     launch_sources(h, false, n, k0, k1, s, replica);
     launch_pml(h, false, k0, k1, s);
   };
@@ -1273,6 +1328,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
           for (int q = 0; q < 2; ++q)
             if (P.psi_h[q] && !P.psi_h2[q] && dev_alloc(h, &P.psi_h2[q], P.psi_h_count)) return -1;
         }
+      launch_damp(h, false, 0, nz, st);
       launch_sources(h, false, n, 0, nz, st);
       launch_pml(h, false, 0, nz, st, 7 & ~pml_in);
       advance_tfsf_aux(h, false, n, st);
@@ -1305,6 +1361,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       if (rec) record_monitors(h, n, true, st);
       launch_pml(h, true, 0, nz, st, 7 & ~pml_in);
       launch_sources(h, true, n, 0, nz, st);
+      launch_damp(h, true, 0, nz, st);
       launch_ade(h, 0, nz, st);
       advance_tfsf_aux(h, true, n, st);
       fill_ghost_fused(h, st);
@@ -1314,12 +1371,14 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     const int h_top = (multi && nb_hi) ? nz - 1 : nz;      // planes [0, h_top) on st, [h_top, nz) on cs
     if (multi && nb_hi) {
       HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
+      launch_damp(h, false, h_top, nz, cs);          // absorber layers damp H^{n-1/2} before anything is added
       launch_sources(h, false, n, h_top, nz, cs);    // H-side corrections first (they only read E^n),
       launch_pml(h, false, h_top, nz, cs);           // in the summation order of the fused sweep
       launch_h_main(h, h_top, nz, cs);
       HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
     }
     if (multi) HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
+    launch_damp(h, false, 0, h_top, st);
     launch_sources(h, false, n, 0, h_top, st);
     launch_pml(h, false, 0, h_top, st);
     launch_h_main(h, 0, h_top, st);
@@ -1342,6 +1401,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       launch_e_main(h, 0, e_bot, cs);
       launch_pml(h, true, 0, e_bot, cs);
       launch_sources(h, true, n, 0, e_bot, cs);
+      launch_damp(h, true, 0, e_bot, cs);
       launch_ade(h, 0, e_bot, cs);
       HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
     }
@@ -1349,6 +1409,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     launch_e_main(h, e_bot, nz, st);
     launch_pml(h, true, e_bot, nz, st);
     launch_sources(h, true, n, e_bot, nz, st);
+    launch_damp(h, true, e_bot, nz, st);
     launch_ade(h, e_bot, nz, st);
     advance_tfsf_aux(h, true, n, st);
     if (multi) {

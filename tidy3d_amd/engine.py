@@ -13,7 +13,7 @@ from typing import Callable, Dict, List, Optional, Tuple
 import numpy as np
 
 from . import lib as L
-from .coeffs import h_coeff, inv_steps, material_table, pml_axis
+from .coeffs import damping_tables, h_coeff, inv_steps, material_table, pml_axis
 from .exceptions import SolverLibraryError
 from .spec import BC_PERIODIC, MonitorSpec, SolverSpec
 
@@ -57,6 +57,12 @@ def plane_costs(spec: SolverSpec) -> np.ndarray:
     cost[:zl] += 24.0 * nx * ny
     if zh:
         cost[nz - zh:] += 24.0 * nx * ny
+    if spec.absorber is not None:            # damping kernel: 48 B per cell of a layer
+        (_, _, axl, axh), (_, _, ayl, ayh), (_, _, azl, azh) = spec.absorber
+        cost += 8.0 * ((axl + axh) * ny + (ayl + ayh) * nx)
+        cost[:azl] += 8.0 * nx * ny
+        if azh:
+            cost[nz - azh:] += 8.0 * nx * ny
     if spec.mat_idx is not None:
         npoles = np.array([len(m.poles) for m in spec.media], dtype=np.float64)
         if npoles.any():
@@ -222,6 +228,24 @@ class HipEngine:
             t32 = [_f32(t) for t in tabs]
             self._chk(d.fdtd_set_pml(h, a, n_lo, n_hi, *[_ptr(t) for t in t32], len(t32[0])),
                       "fdtd_set_pml")
+        # absorber layers (damping tables, slab-local along z)
+        dm = damping_tables(spec)
+        if dm is not None:
+            for a in range(3):
+                D = dm[a]
+                fb, fc, n_lo, n_hi = D.fb, D.fc, D.n_lo, D.n_hi
+                if a == 0 and pad:      # identity in the PEC padding; the hi layers grow to cover it
+                    fb, fc = np.append(fb, [1.0] * pad), np.append(fc, [1.0] * pad)
+                    n_hi = n_hi + pad if n_hi else 0
+                if a == 2:
+                    fb, fc = fb[z0:z1], fc[z0:z1]
+                    n_lo = int(np.clip(n_lo - z0, 0, nzl))
+                    n_hi = int(np.clip(z1 - (nz - n_hi), 0, nzl))
+                if n_lo + n_hi == 0:
+                    continue
+                fb32, fc32 = _f32(fb), _f32(fc)
+                self._chk(d.fdtd_set_absorber(h, a, n_lo, n_hi, _ptr(fb32), _ptr(fc32), len(fb32)),
+                          "fdtd_set_absorber")
         # ADE groups
         for c in range(3):
             for m in range(mt.n_media):

@@ -769,6 +769,27 @@ class StablePML(_Model):
 
 @_register
 @dataclass
+class AbsorberParams(_Model):
+    """ref boundary.py:166-192; sigma in units of 2*EPSILON_0/dt (ref constants.py:120)."""
+
+    sigma_order: int = 3
+    sigma_min: float = 0.0
+    sigma_max: float = 1.5
+
+
+@_register
+@dataclass
+class Absorber(_Model):
+    """Adiabatic absorber: layers of polynomially rising electric conductivity in front of a PEC
+    wall (ref boundary.py:427-476; 40 layers, DefaultAbsorberParameters sigma_max 6.4 :232)."""
+
+    num_layers: int = 40
+    parameters: AbsorberParams = field(default_factory=lambda: AbsorberParams(sigma_max=6.4))
+    name: Optional[str] = None
+
+
+@_register
+@dataclass
 class PECBoundary(_Model):
     """ref boundary.py:40."""
     name: Optional[str] = None
@@ -813,6 +834,13 @@ class Boundary(_Model):
         p = parameters or dataclasses.replace(DefaultStablePMLParameters)
         return cls(plus=StablePML(num_layers=num_layers, parameters=p),
                    minus=StablePML(num_layers=num_layers, parameters=p))
+
+    @classmethod
+    def absorber(cls, num_layers: int = 40, parameters: AbsorberParams = None):
+        """ref boundary.py:676-700."""
+        p = parameters or AbsorberParams(sigma_max=6.4)
+        return cls(plus=Absorber(num_layers=num_layers, parameters=p),
+                   minus=Absorber(num_layers=num_layers, parameters=p))
 
     @classmethod
     def pec(cls):

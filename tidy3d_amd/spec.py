@@ -153,6 +153,9 @@ class SolverSpec:
     sources: List[PointSourceSet] = field(default_factory=list)
     tfsf: List[TfsfSpec] = field(default_factory=list)
     monitors: List[MonitorSpec] = field(default_factory=list)
+    # Absorber layers (ref boundary.py:427): per axis (sigma at cell boundaries [N], sigma at cell
+    # centres [N], n_lo, n_hi), sigma in units of 2 eps0/dt; None = no absorber (coeffs.damping_tables)
+    absorber: Optional[List[Tuple[np.ndarray, np.ndarray, int, int]]] = None
     shutoff: float = 0.0                                # 0 disables the early stop
     decay_every: int = 0                                # 0 = never evaluate field decay
     decay_ref_step: int = 0                             # steps before this never shut off
