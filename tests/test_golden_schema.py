@@ -149,3 +149,24 @@ def test_full_reference_fixture_parses():
     from tidy3d_amd.exceptions import Tidy3dNotImplementedError
     with pytest.raises(Tidy3dNotImplementedError):
         D.make_boundaries(sim)        # AutoGrid along x is outside the supported subset
+
+
+GEO = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "geometry_golden.json")))
+
+
+@pytest.mark.parametrize("i", range(len(GEO["geometry"])))
+def test_slanted_cylinder_and_transformed_inside_match_reference(i):
+    """Slanted ``Cylinder`` (ref primitives.py:600-633, :720-737) and ``Transformed`` (ref geometry/
+    base.py:2495-2632): ``inside`` and ``bounds`` recorded from the reference's own classes
+    (tests/golden/make_geometry_golden.py)."""
+    rec = GEO["geometry"][i]
+    g = td.parse(rec["json"])
+    p = np.array(GEO["points"])
+    got = "".join("1" if b else "0" for b in np.asarray(g.inside(p[:, 0], p[:, 1], p[:, 2])).reshape(-1))
+    assert got == rec["inside"]
+    assert 0 < got.count("1") < len(got)
+    np.testing.assert_allclose(np.array(g.bounds), np.array(rec["bounds"]), atol=1e-12)
+    # broadcastable inputs (what the rasteriser passes) give the same answer as flat ones
+    X, Y, Z = p[:7, 0][None, None, :], p[:5, 1][None, :, None], p[:3, 2][:, None, None]
+    Xf, Yf, Zf = np.broadcast_arrays(X, Y, Z)
+    assert np.array_equal(np.broadcast_to(g.inside(X, Y, Z), Xf.shape), g.inside(Xf.ravel(), Yf.ravel(), Zf.ravel()).reshape(Xf.shape))

@@ -207,7 +207,8 @@ class Sphere(_Model):
 @_register
 @dataclass
 class Cylinder(_Model):
-    """ref geometry/primitives.py:179; straight side walls only (sidewall_angle == 0)."""
+    """ref geometry/primitives.py:179; slanted side walls as ref :720-737 ``_radius_z`` (the radius
+    shrinks by tan(sidewall_angle) per unit length along +axis from its value on the reference plane)."""
 
     radius: float = 1.0
     length: float = 1.0
@@ -218,23 +219,47 @@ class Cylinder(_Model):
 
     def __post_init__(self):
         self.length = float(_to_float(self.length))
-        if self.sidewall_angle != 0.0:
-            raise Tidy3dNotImplementedError("Cylinder.sidewall_angle != 0 is not supported.")
+        if abs(self.sidewall_angle) >= np.pi / 2:
+            raise ValidationError("Cylinder.sidewall_angle must lie in (-pi/2, pi/2) (ref base.py:1613).")
+        if self.sidewall_angle != 0.0 and np.isinf(self.length) and self.reference_plane != "middle":
+            raise SetupError("A slanted cylinder of infinite length needs reference_plane 'middle' "
+                             "(ref primitives.py:212-226).")
+
+    @property
+    def _finite_length(self) -> float:
+        return min(self.length, 1e10)                     # ref base.py:1642 LARGE_NUMBER
+
+    def _radius_z(self, z):
+        """ref primitives.py:720-737."""
+        if np.isclose(self.sidewall_angle, 0):
+            return self.radius + 0.0 * np.asarray(z, float)
+        tanq = np.tan(self.sidewall_angle)
+        r_mid = self.radius
+        if self.reference_plane == "top":
+            r_mid += self._finite_length / 2 * tanq
+        elif self.reference_plane == "bottom":
+            r_mid -= self._finite_length / 2 * tanq
+        return r_mid - (np.asarray(z, float) - self.center[self.axis]) * tanq
 
     @property
     def bounds(self):
+        """ref primitives.py:636-648 (radius_max = the larger of the two end radii)."""
         c = np.array(self.center, float)
-        h = np.full(3, self.radius)
+        z0 = self.center[self.axis]
+        r_max = float(max(self._radius_z(z0 - self._finite_length / 2), self._radius_z(z0 + self._finite_length / 2)))
+        h = np.full(3, r_max)
         h[self.axis] = self.length / 2
         return tuple(c - h), tuple(c + h)
 
     def inside(self, x, y, z):
+        """ref primitives.py:600-633."""
         p = [x, y, z]
         c = list(self.center)
         za = p.pop(self.axis)
         z0 = c.pop(self.axis)
+        r = self._radius_z(za)
         r2 = (p[0] - c[0]) ** 2 + (p[1] - c[1]) ** 2
-        return (r2 <= self.radius ** 2) & (np.abs(za - z0) <= self.length / 2)
+        return (r > 0) & (r2 <= r ** 2) & (np.abs(za - z0) <= self._finite_length / 2)
 
 
 @_register
@@ -321,6 +346,82 @@ class GeometryGroup(_Model):
             i = g.inside(x, y, z)
             out = i if out is None else (out | i)
         return out
+
+
+@_register
+@dataclass
+class Transformed(_Model):
+    """Affine image of a geometry (ref geometry/base.py:2495): ``inside`` tests the base geometry at
+    the inverse-transformed points (:2603-2632), ``bounds`` are the reference's (over)estimate from the
+    8 transformed corners of the base bounds (:2566-2578); nested transforms collapse (:2525-2531)."""
+
+    geometry: Any = None
+    transform: Any = None
+
+    def __post_init__(self):
+        t = np.eye(4) if self.transform is None else np.asarray(self.transform, dtype=np.float64)
+        if t.shape != (4, 4):
+            raise ValidationError("Transformed.transform must be a 4 x 4 matrix.")
+        while isinstance(self.geometry, Transformed):
+            t = np.dot(t, np.asarray(self.geometry.transform, dtype=np.float64))
+            self.geometry = self.geometry.geometry
+        try:
+            np.linalg.inv(t)                                   # ref :2509-2513
+        except np.linalg.LinAlgError as e:
+            raise ValidationError("Transformed.transform is not invertible.") from e
+        self.transform = tuple(tuple(float(v) for v in row) for row in t)
+        if not isinstance(self.geometry, Unsupported) and not np.isfinite(self.geometry.bounds).all():
+            raise ValidationError("Transformations are only supported on geometries with finite dimensions "
+                                  "(ref geometry/base.py:2515-2523).")
+
+    @property
+    def inverse(self):
+        return np.linalg.inv(np.asarray(self.transform))
+
+    @property
+    def bounds(self):
+        if isinstance(self.geometry, Unsupported):
+            self.geometry.fail()
+        (x0, y0, z0), (x1, y1, z1) = self.geometry.bounds
+        v = np.array(((x0, x0, x0, x0, x1, x1, x1, x1), (y0, y0, y1, y1, y0, y0, y1, y1),
+                      (z0, z1, z0, z1, z0, z1, z0, z1), (1.0,) * 8))
+        v = np.dot(np.asarray(self.transform), v)[:3]
+        return tuple(v.min(axis=1)), tuple(v.max(axis=1))
+
+    def inside(self, x, y, z):
+        if isinstance(self.geometry, Unsupported):
+            self.geometry.fail()
+        x, y, z = np.broadcast_arrays(np.asarray(x, float), np.asarray(y, float), np.asarray(z, float))
+        xyz = np.dot(self.inverse, np.vstack((x.ravel(), y.ravel(), z.ravel(), np.ones(x.size))))
+        return np.asarray(self.geometry.inside(xyz[0], xyz[1], xyz[2])).reshape(x.shape)
+
+    @staticmethod
+    def translation(x: float, y: float, z: float):
+        """ref geometry/base.py:2648."""
+        t = np.eye(4)
+        t[:3, 3] = (x, y, z)
+        return t
+
+    @staticmethod
+    def scaling(x: float = 1.0, y: float = 1.0, z: float = 1.0):
+        """ref geometry/base.py:2676."""
+        if np.isclose((x, y, z), 0.0).any():
+            raise ValidationError("Scaling factors cannot be zero in any dimensions.")
+        return np.diag((float(x), float(y), float(z), 1.0))
+
+    @staticmethod
+    def rotation(angle: float, axis):
+        """ref geometry/base.py:2706 (rotation matrix of ref components/transformation.py:113-131)."""
+        n = np.zeros(3)
+        if isinstance(axis, (int, np.integer)):
+            n[int(axis)] = 1.0
+        else:
+            n = np.asarray(axis, float) / np.linalg.norm(axis)
+        c, s_ = np.cos(angle), np.sin(angle)
+        K = np.array(((0, -n[2], n[1]), (n[2], 0, -n[0]), (-n[1], n[0], 0)))
+        t = np.eye(4)
+        t[:3, :3] = c * np.eye(3) + s_ * K + (1 - c) * np.outer(n, n)
+        return t
 
 
 @_register
