@@ -44,7 +44,30 @@ def cases():
         out.append({"json": json.loads(g.json()),
                     "inside": "".join("1" if b else "0" for b in np.asarray(ins).reshape(-1)),
                     "bounds": [list(map(float, b)) for b in g.bounds]})
-    return {"points": np.round(pts, 6).tolist(), "geometry": out}
+    return {"points": np.round(pts, 6).tolist(), "geometry": out, "polyslab_helpers": polyslab_helpers()}
+
+
+def polyslab_helpers():
+    """The reference's own static polygon helpers (a PolySlab instance cannot be built here: its
+    validators need shapely): _proper_vertices, _shift_vertices, _maximal_erosion, _area."""
+    P = td.PolySlab
+    rng = np.random.default_rng(2)
+    polys = [[(0, 0), (1, 0), (1, 1), (0, 1)],
+             [(0, 0), (0, 1), (1, 1), (1, 0)],                       # clockwise
+             [(0, 0), (2, 0), (2, 0), (2, 1), (1, 0.4), (0, 1)],       # duplicate vertex, concave
+             [(-1, -0.5), (0.2, -0.7), (1.1, 0.1), (0.4, 0.2), (0.6, 0.9), (-0.3, 0.5), (-0.9, 0.8)],
+             [(np.cos(t), 0.6 * np.sin(t)) for t in np.linspace(0, 2 * np.pi, 9)[:-1]],
+             [(0, 0), (1, 0), (2, 0), (2, 1), (0, 1)]]                 # collinear vertex
+    out = []
+    for v in polys:
+        prop = P._proper_vertices(v)
+        rec = {"vertices": [list(map(float, q)) for q in v], "proper": prop.tolist(), "area": float(P._area(prop)),
+               "max_erosion": float(P._maximal_erosion(prop)), "shifts": []}
+        for d in (0.05, -0.03, 0.2, float(-0.5 * P._maximal_erosion(prop))):
+            sv, par, _ = P._shift_vertices(prop, d)
+            rec["shifts"].append({"dist": d, "vertices": np.asarray(sv).tolist(), "parallel": np.asarray(par).tolist()})
+        out.append(rec)
+    return out
 
 
 if __name__ == "__main__":

@@ -1,8 +1,12 @@
-"""PolySlab (vertical walls): slab bounds AND even-odd point-in-polygon.  The reference delegates
+"""PolySlab: slab bounds AND even-odd point-in-polygon of the cross-section at that height (dilation and
+slanted side walls: the reference's own mitred edge offset, pinned on its static helpers).  The reference delegates
 the polygon test to ``matplotlib.path.Path.contains_points`` (ref polyslab.py:511-516) and its own
 PolySlab cannot be constructed under the stubbed shapely; pins: the real matplotlib function (run
 under the second python of the image that has it) on random simple and self-intersecting polygons,
 analytic masks, all three extrusion axes, and equivalence with Box for a rectangle."""
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -55,9 +59,72 @@ def test_regular_polygon_approaches_the_circle():
     assert np.array_equal(ps.inside(x, y, z)[sel], cyl.inside(x, y, z)[sel])
 
 
-def test_slanted_walls_are_named():
-    with pytest.raises(Tidy3dNotImplementedError, match="sidewall_angle"):
-        td.PolySlab(vertices=[(0, 0), (1, 0), (0, 1)], slab_bounds=(0, 1), sidewall_angle=0.1)
+GEO = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "geometry_golden.json")))
+
+
+@pytest.mark.parametrize("i", range(len(GEO["polyslab_helpers"])))
+def test_polygon_helpers_match_the_reference(i):
+    """_proper_vertices / _area / _shift_vertices / _maximal_erosion recorded from the reference's
+    static methods (ref polyslab.py:1019-1310; tests/golden/make_geometry_golden.py)."""
+    rec = GEO["polyslab_helpers"][i]
+    P = td.PolySlab
+    prop = P._proper_vertices(rec["vertices"])
+    np.testing.assert_allclose(prop, np.array(rec["proper"]), atol=1e-15)
+    assert P._area(prop) == pytest.approx(rec["area"], rel=1e-14)
+    assert P._maximal_erosion(prop) == pytest.approx(rec["max_erosion"], rel=1e-12)
+    for sh in rec["shifts"]:
+        v, par = P._shift_vertices(prop, sh["dist"])
+        np.testing.assert_allclose(v, np.array(sh["vertices"]), rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(par, np.array(sh["parallel"]), rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize("plane", ["middle", "bottom", "top"])
+@pytest.mark.parametrize("angle", [0.3, -0.2])
+def test_slanted_rectangle_is_a_frustum(plane, angle):
+    """Every wall of a rectangle moves inward by (z - z_ref) tan(angle) (ref polyslab.py:498-499, :396-412)."""
+    hx, hy, z0, z1 = 0.5, 0.3, -0.2, 0.4
+    ps = td.PolySlab(vertices=[(-hx, -hy), (hx, -hy), (hx, hy), (-hx, hy)], slab_bounds=(z0, z1),
+                     sidewall_angle=angle, reference_plane=plane)
+    z_ref = {"middle": 0.5 * (z0 + z1), "bottom": z0, "top": z1}[plane]
+    rng = np.random.default_rng(3)
+    x, y, z = rng.uniform(-0.8, 0.8, (3, 40000))
+    z = np.round(z * 20) / 20 + 0.013                     # grid planes, as the rasteriser asks
+    off = (z - z_ref) * np.tan(angle)
+    want = (np.abs(x) <= hx - off) & (np.abs(y) <= hy - off) & (z >= z0) & (z <= z1)
+    near = (np.abs(np.abs(x) - (hx - off)) < 1e-9) | (np.abs(np.abs(y) - (hy - off)) < 1e-9)
+    got = ps.inside(x, y, z)
+    assert np.array_equal(got[~near], want[~near]) and 0 < got.sum() < got.size
+    (bx0, by0, bz0), (bx1, by1, bz1) = ps.bounds
+    assert bx1 >= np.max(x[got]) and bx0 <= np.min(x[got]) and (bz0, bz1) == (z0, z1)
+
+
+def test_slanted_polygon_equals_slanted_cylinder():
+    t = np.linspace(0, 2 * np.pi, 721)[:-1]
+    ps = td.PolySlab(vertices=np.stack([0.7 * np.cos(t), 0.7 * np.sin(t)], 1), slab_bounds=(-0.5, 0.5), axis=0,
+                     sidewall_angle=0.25, reference_plane="bottom")
+    cyl = td.Cylinder(center=(0, 0, 0), radius=0.7, length=1.0, axis=0, sidewall_angle=0.25, reference_plane="bottom")
+    rng = np.random.default_rng(4)
+    x, y, z = rng.uniform(-1, 1, (3, 20000))
+    x = np.round(x * 16) / 16 + 0.007
+    r = cyl._radius_z(x)
+    sel = np.abs(np.hypot(y, z) - r) > 2e-4
+    assert np.array_equal(ps.inside(x, y, z)[sel], cyl.inside(x, y, z)[sel])
+
+
+def test_dilation_of_a_rectangle():
+    ps = td.PolySlab(vertices=[(0, 0), (1, 0), (1, 0.5), (0, 0.5)], slab_bounds=(0, 1), dilation=0.1)
+    np.testing.assert_allclose(sorted(map(tuple, ps.reference_polygon)),
+                               sorted([(-0.1, -0.1), (1.1, -0.1), (1.1, 0.6), (-0.1, 0.6)]), atol=1e-15)
+    assert ps.inside(np.array([-0.05, 1.05, -0.15]), np.array([0.55, -0.05, 0.2]), np.array([0.5, 0.5, 0.5])).tolist() == [True, True, False]
+    np.testing.assert_allclose(np.array(ps.bounds), [[-0.1, -0.1, 0], [1.1, 0.6, 1]], atol=1e-15)
+
+
+def test_vanishing_edges_are_refused():
+    """The reference heals such polygons with shapely (polyslab.py:1313); not available here."""
+    with pytest.raises(Tidy3dNotImplementedError, match="healing"):
+        td.PolySlab(vertices=[(0, 0), (1, 0), (1, 0.2), (0, 0.2)], slab_bounds=(0, 1), sidewall_angle=0.3)
+    with pytest.raises(Tidy3dNotImplementedError, match="healing"):
+        td.PolySlab(vertices=[(0, 0), (1, 0), (1, 0.2), (0, 0.2)], slab_bounds=(0, 1), dilation=-0.15)
 
 
 def test_parses_from_the_reference_json_form():

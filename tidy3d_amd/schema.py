@@ -265,11 +265,16 @@ class Cylinder(_Model):
 @_register
 @dataclass
 class PolySlab(_Model):
-    """Polygon extruded along ``axis`` (ref geometry/polyslab.py:37); vertical side walls without
-    dilation only.  ``inside`` = slab bounds AND point-in-polygon; the reference delegates the
-    latter to ``matplotlib.path.Path.contains_points`` (polyslab.py:511-516, third party, absent
-    here; pinned against the real function in tests/test_polyslab.py): restated as the even-odd crossing-number test with the half-open edge rule
-    ``(y_i <= y) != (y_j <= y)`` — points exactly on an edge are implementation-defined in both."""
+    """Polygon extruded along ``axis`` (ref geometry/polyslab.py:37), with ``dilation`` and slanted
+    side walls.  ``inside`` = slab bounds AND point-in-polygon of the cross-section at that height;
+    the reference delegates the latter to ``matplotlib.path.Path.contains_points`` (polyslab.py:511-552,
+    third party, absent here; pinned against the real function in tests/test_polyslab.py): restated as
+    the even-odd crossing-number test with the half-open edge rule ``(y_i <= y) != (y_j <= y)`` —
+    points exactly on an edge are implementation-defined in both.  The cross-section at height z is
+    the middle polygon with every edge moved outward by -(z - z_mid) tan(sidewall_angle), mitred at the
+    vertices (ref ``_shift_vertices`` :1214-1274).  The reference repairs polygons that self-intersect
+    after dilation with shapely (``_heal_polygon`` :1313); that repair is not available here: an offset
+    that makes an edge vanish is refused instead."""
 
     vertices: Any = ()
     slab_bounds: Tuple[float, float] = (0.0, 0.0)
@@ -278,13 +283,126 @@ class PolySlab(_Model):
     dilation: float = 0.0
     reference_plane: str = "middle"
 
+    _RTOL = np.finfo(float).eps                               # ref polyslab.py:38
+
     def __post_init__(self):
         self.vertices = tuple(tuple(float(c) for c in v) for v in np.asarray(self.vertices, float).reshape(-1, 2))
         self.slab_bounds = tuple(float(_to_float(v)) for v in self.slab_bounds)
-        if self.sidewall_angle != 0.0 or self.dilation != 0.0:
-            raise Tidy3dNotImplementedError("PolySlab.sidewall_angle / dilation != 0 are not supported.")
         if len(self.vertices) < 3:
             raise ValidationError("PolySlab needs at least 3 vertices.")
+        if abs(self.sidewall_angle) >= np.pi / 2:
+            raise ValidationError("PolySlab.sidewall_angle must lie in (-pi/2, pi/2) (ref base.py:1613).")
+        if self.sidewall_angle != 0.0 and self.reference_plane != "middle" and not np.isfinite(self.slab_bounds).all():
+            raise SetupError("A slanted PolySlab of infinite length needs reference_plane 'middle' "
+                             "(ref polyslab.py:66-84).")
+        self._cache = {}
+        if self.sidewall_angle != 0.0 or self.dilation != 0.0:
+            # most negative offset any cross-section gets, against the offset at which an edge vanishes
+            prop = self._proper_vertices(self.vertices)
+            worst = min(self.dilation, 0.0)
+            ref = self.reference_polygon
+            tq, L = abs(np.tan(self.sidewall_angle)), self._finite_length
+            reach = {"middle": tq * L / 2, "bottom": max(0.0, np.tan(self.sidewall_angle)) * L,
+                     "top": max(0.0, -np.tan(self.sidewall_angle)) * L}[self.reference_plane]
+            if -worst >= self._first_edge_event(prop) or reach >= self._first_edge_event(ref):
+                raise Tidy3dNotImplementedError(
+                    "PolySlab: the dilation / side-wall slant erodes an edge of the polygon completely; the "
+                    "polygon healing the reference applies in that case needs shapely and is not supported.")
+
+    # ---- polygon helpers (static, same arithmetic as the reference's) -------------------------
+    @staticmethod
+    def _area(v: np.ndarray) -> float:
+        """Signed area, positive for CCW (ref polyslab.py:1019-1039)."""
+        w = np.roll(v, axis=0, shift=-1)
+        return float(np.sum(v[:, 0] * w[:, 1] - v[:, 1] * w[:, 0]) * 0.5)
+
+    @classmethod
+    def _proper_vertices(cls, vertices) -> np.ndarray:
+        """Duplicate neighbours removed, CCW orientation (ref polyslab.py:1066-1113)."""
+        v = np.asarray(vertices, float).reshape(-1, 2)
+        d = np.linalg.norm(v - np.roll(v, shift=-1, axis=0), axis=1)
+        v = v[~np.isclose(d, 0, rtol=cls._RTOL)]
+        return v if cls._area(v) > 0 else v[::-1, :]
+
+    @classmethod
+    def _shift_vertices(cls, vertices: np.ndarray, dist: float):
+        """Move every edge outward by ``dist`` and re-intersect neighbours (mitre joints); returns
+        (vertices, parallel shift per vertex) (ref polyslab.py:1214-1274)."""
+        if np.isclose(dist, 0):
+            return vertices, np.zeros(vertices.shape[0])
+        rot90 = lambda u: np.stack((-u[1], u[0]), axis=0)
+        cross = lambda u, w: u[0] * w[1] - u[1] * w[0]
+        vs = vertices.T.copy()
+        nxt, prv = np.roll(vs, axis=-1, shift=-1), np.roll(vs, axis=-1, shift=+1)
+        asp = (nxt - vs) / np.linalg.norm(nxt - vs, axis=0)
+        asm = (vs - prv) / np.linalg.norm(vs - prv, axis=0)
+        det = cross(asm, asp)
+        flat = np.isclose(det, 0, rtol=cls._RTOL)
+        tan_half = np.where(flat, 0.0, cross(asm, rot90(asm - asp)) / (det + flat))
+        par = dist * tan_half
+        return (vs + (-dist) * rot90(asm) + par * asm).T, par
+
+    @classmethod
+    def _first_edge_event(cls, vertices: np.ndarray) -> float:
+        """Inward offset at which the FIRST edge shrinks to nothing (edge lengths change linearly with
+        the offset, ref polyslab.py:1277-1301); beyond it the mitred offset polygon self-intersects."""
+        nxt = np.roll(vertices, axis=0, shift=-1)
+        length = np.linalg.norm(nxt - vertices, axis=1)
+        par = cls._shift_vertices(vertices, 1.0)[1]
+        grow = par + np.roll(par, shift=-1)                  # growth of each edge per unit outward offset
+        shrink = grow > np.finfo(np.float32).eps
+        return float(np.min(length[shrink] / grow[shrink])) if shrink.any() else np.inf
+
+    @classmethod
+    def _maximal_erosion(cls, vertices: np.ndarray) -> float:
+        """Inward offset that reduces ALL edges to nothing (ref polyslab.py:1303-1310)."""
+        nxt = np.roll(vertices, axis=0, shift=-1)
+        length = np.linalg.norm(nxt - vertices, axis=1)
+        par = cls._shift_vertices(vertices, 1.0)[1]
+        red = -(par + np.roll(par, shift=-1))
+        nz = np.abs(red) > np.finfo(np.float32).eps
+        return float(-np.min(length[nz] / red[nz])) if nz.any() else np.inf
+
+    # ---- derived polygons -----------------------------------------------------------------------
+    @property
+    def _finite_length(self) -> float:
+        z0, z1 = self.slab_bounds
+        return min(z1 - z0, 1e10)                           # ref base.py:1642 LARGE_NUMBER
+
+    @property
+    def _center_axis(self) -> float:
+        """ref polyslab.py:365-373."""
+        z0, z1 = self.slab_bounds
+        if np.isneginf(z0) and np.isposinf(z1):
+            return 0.0
+        return (min(z1, 1e10) + max(z0, -1e10)) / 2.0
+
+    @property
+    def _tanq(self) -> float:
+        return 0.0 if np.isclose(self.sidewall_angle, 0) else float(np.tan(self.sidewall_angle))
+
+    @property
+    def reference_polygon(self) -> np.ndarray:
+        """ref polyslab.py:381-394 (without the shapely repair)."""
+        if "ref" not in self._cache:
+            v = self._proper_vertices(self.vertices)
+            if not np.isclose(self.dilation, 0):
+                v = self._shift_vertices(v, self.dilation)[0]
+            self._cache["ref"] = v
+        return self._cache["ref"]
+
+    @property
+    def middle_polygon(self) -> np.ndarray:
+        """ref polyslab.py:396-412."""
+        if "mid" not in self._cache:
+            dist = -(self._finite_length / 2) * self._tanq
+            v = self.reference_polygon
+            if self.reference_plane == "bottom":
+                v = self._shift_vertices(v, dist)[0]
+            elif self.reference_plane == "top":
+                v = self._shift_vertices(v, -dist)[0]
+            self._cache["mid"] = v
+        return self._cache["mid"]
 
     @property
     def _planar_axes(self):
@@ -292,7 +410,20 @@ class PolySlab(_Model):
 
     @property
     def bounds(self):
+        """ref polyslab.py:970-1010: the largest offset any cross-section can have, applied to the
+        given vertices (an over-estimate by construction)."""
+        max_offset = self.dilation
+        if self._tanq != 0.0:
+            L = self._finite_length
+            if self.reference_plane == "bottom":
+                max_offset += max(0.0, -self._tanq * L)
+            elif self.reference_plane == "top":
+                max_offset += max(0.0, self._tanq * L)
+            else:
+                max_offset += max(0.0, abs(self._tanq) * L / 2)
         v = np.array(self.vertices)
+        if max_offset > 0:
+            v = self._shift_vertices(self._proper_vertices(self.vertices), max_offset)[0]
         lo, hi = [0.0] * 3, [0.0] * 3
         u, w = self._planar_axes
         lo[u], hi[u] = v[:, 0].min(), v[:, 0].max()
@@ -300,17 +431,8 @@ class PolySlab(_Model):
         lo[self.axis], hi[self.axis] = self.slab_bounds
         return tuple(lo), tuple(hi)
 
-    def inside(self, x, y, z):
-        p = [x, y, z]
-        za = p.pop(self.axis)
-        px, py, za = np.broadcast_arrays(np.asarray(p[0], float), np.asarray(p[1], float), np.asarray(za, float))
-        z0, z1 = self.slab_bounds
-        zc, half = 0.5 * (z0 + z1), 0.5 * (z1 - z0)
-        ok = np.abs(za - zc) <= half
-        if not np.any(ok):
-            return ok
-        v = np.array(self.vertices)
-        xs, ys = px[ok], py[ok]
+    @staticmethod
+    def _in_polygon(v: np.ndarray, xs: np.ndarray, ys: np.ndarray) -> np.ndarray:
         odd = np.zeros(xs.shape, bool)
         xj, yj = v[-1]
         for xi, yi in v:
@@ -319,6 +441,31 @@ class PolySlab(_Model):
                 xint = xi + (ys - yi) * (xj - xi) / (yj - yi)
             odd ^= cross & (xs < xint)
             xj, yj = xi, yi
+        return odd
+
+    def inside(self, x, y, z):
+        """ref polyslab.py:464-559."""
+        p = [x, y, z]
+        za = p.pop(self.axis)
+        px, py, za = np.broadcast_arrays(np.asarray(p[0], float), np.asarray(p[1], float), np.asarray(za, float))
+        zc = self._center_axis
+        ok = np.abs(za - zc) <= self._finite_length / 2
+        if not np.any(ok):
+            return ok
+        xs, ys = px[ok], py[ok]
+        if self._tanq == 0.0:
+            odd = self._in_polygon(self.reference_polygon if self.dilation else np.array(self.vertices), xs, ys)
+        else:
+            zs = za[ok]
+            odd = np.zeros(xs.shape, bool)
+            mid = self.middle_polygon
+            uz, inv = np.unique(zs, return_inverse=True)      # one offset polygon per height
+            order = np.argsort(inv.ravel(), kind="stable")
+            cuts = np.searchsorted(inv.ravel()[order], np.arange(len(uz) + 1))
+            for q, zv in enumerate(uz):
+                sel = order[cuts[q]:cuts[q + 1]]
+                vz = self._shift_vertices(mid, -(zv - zc) * self._tanq)[0]
+                odd[sel] = self._in_polygon(vz, xs[sel], ys[sel])
         out = np.zeros(ok.shape, bool)
         out[ok] = odd
         return out
