@@ -241,3 +241,35 @@ def test_projection_surfaces_match_reference(td_ref, kw):
         assert ("+" if sign > 0 else "-") == r.normal_dir and axis == r.axis
         from tidy3d_amd.hdf5io import surface_name
         assert surface_name(m, sname) == r.monitor.name
+
+
+def test_diffraction_data_entry_fits_the_reference_classes(td_ref):
+    """DiffractionData in the .hdf5 JSON model: every key is a field of the reference's DiffractionData,
+    the monitor parses with the reference's DiffractionMonitor, the arrays carry the reference's dims.
+    (A reference Simulation holding a DiffractionMonitor cannot be validated under the stubbed shapely,
+    so the entry is checked class by class.)"""
+    from oracle.fdtd_numpy import OracleFdtd
+    from tidy3d.components.data.data_array import DATA_ARRAY_MAP
+    import tidy3d_amd.schema as mt
+    from tidy3d_amd.data import assemble
+    from tidy3d_amd.discretize import discretize
+    from tidy3d_amd.hdf5io import simulation_data_model
+    td = td_ref
+    pulse = mt.GaussianPulse(freq0=2.5e14, fwidth=3e13)
+    sim = mt.Simulation(size=(1.6, 0.2, 1.2), grid_spec=mt.GridSpec.uniform(dl=0.05), run_time=1e-13,
+                        sources=[mt.PlaneWave(center=(0, 0, -0.4), size=(mt.inf, mt.inf, 0), source_time=pulse, direction="+")],
+                        monitors=[mt.DiffractionMonitor(center=(0, 0, 0.3), size=(mt.inf, mt.inf, 0), freqs=[2.4e14, 2.6e14],
+                                                        name="orders", normal_dir="+")],
+                        boundary_spec=mt.BoundarySpec(x=mt.Boundary.periodic(), y=mt.Boundary.periodic(),
+                                                      z=mt.Boundary.pml(num_layers=6)))
+    disc = discretize(sim, n_steps=20)
+    model, arrays = simulation_data_model(assemble(disc, OracleFdtd(disc.spec).run()))
+    entry = model["data"][0]
+    assert entry["type"] == "DiffractionData"
+    assert set(entry) - {"type"} <= set(td.DiffractionData.__fields__), set(entry) - set(td.DiffractionData.__fields__)
+    m_ref = td.DiffractionMonitor.parse_obj(entry["monitor"])
+    assert m_ref.name == "orders" and m_ref.normal_dir == "+" and tuple(m_ref.freqs) == (2.4e14, 2.6e14)
+    assert td.Medium.parse_obj(entry["medium"]) == td.Medium()
+    for k in ("Er", "Etheta", "Ephi", "Hr", "Htheta", "Hphi"):
+        assert entry[k] == "DiffractionDataArray"
+        assert tuple(arrays[f"/data/0/{k}"].dims) == tuple(DATA_ARRAY_MAP["DiffractionDataArray"]._dims)

@@ -90,6 +90,12 @@ def to_tidy3d(sim_data: SimulationData, td_simulation=None):
                      for k, v in d.field_components.items()}
             out.append(td.FieldProjectionAngleData(monitor=mon, projection_surfaces=mon.projection_surfaces,
                                                    medium=mon.medium or td_simulation.medium, **comps))
+        elif type(d).__name__ == "DiffractionData":
+            comps = {k: td.DiffractionDataArray(v.values, coords={dim: v.coords[dim] for dim in v.dims})
+                     for k, v in d.field_components.items()}
+            out.append(td.DiffractionData(monitor=mon, sim_size=tuple(d.sim_size), bloch_vecs=tuple(d.bloch_vecs),
+                                          medium=td_simulation.medium if d.structure_index < 0
+                                          else td_simulation.structures[d.structure_index].medium, **comps))
         else:
             raise Tidy3dNotImplementedError(f"no tidy3d conversion for {type(d).__name__}")
     return td.SimulationData(simulation=td_simulation, data=tuple(out), log=sim_data.log,

@@ -548,6 +548,9 @@ def assemble(disc: Discretization, raw: Dict[str, np.ndarray], log: str = "", di
             fn = {"projection_angle": projection.project_angle, "projection_cartesian": projection.project_cartesian,
                   "projection_kspace": projection.project_kspace}[plan.kind]
             out.append(fn(disc, plan, raw, norm))
+        elif plan.kind == "diffraction":
+            from . import projection
+            out.append(projection.diffraction(disc, plan, raw, norm))
         elif plan.kind == "permittivity":
             out.append(permittivity_data(sim, spec if pfull is None else disc.spec_full,
                                          plan if pfull is None else pfull))

@@ -381,6 +381,15 @@ def simulation_data_model(sim_data) -> Tuple[dict, Dict[str, Any]]:
             for name, arr in d.field_components.items():
                 entry[name] = kind.replace("Data", "DataArray")
                 arrays[f"{base}/{name}"] = arr
+        elif kind == "DiffractionData":
+            # ref monitor_data.py:2672-2751: six DiffractionDataArrays + sim_size, bloch_vecs, medium
+            entry["sim_size"] = [float(v) for v in d.sim_size]
+            entry["bloch_vecs"] = [float(v) for v in d.bloch_vecs]
+            entry["medium"] = d.medium.dict()
+            entry["is_2d_simulation"] = False
+            for name, arr in d.field_components.items():
+                entry[name] = "DiffractionDataArray"
+                arrays[f"{base}/{name}"] = arr
         else:
             raise Tidy3dNotImplementedError(f"no hdf5 layout for {kind}")
         data_json.append(entry)
@@ -431,7 +440,8 @@ def load_simulation_data(path: str):
             "ModeIndexDataArray": ("f", "mode_index"),
             "FieldProjectionAngleDataArray": ("r", "theta", "phi", "f"),
             "FieldProjectionCartesianDataArray": ("x", "y", "z", "f"),
-            "FieldProjectionKSpaceDataArray": ("ux", "uy", "r", "f")}
+            "FieldProjectionKSpaceDataArray": ("ux", "uy", "r", "f"),
+            "DiffractionDataArray": ("orders_x", "orders_y", "f")}
 
     def arr(gpath: str, tag: str) -> DataArray:
         coords = {d: (np.asarray(tree[f"{gpath}/{d}"]) if not isinstance(tree[f"{gpath}/{d}"], list)
@@ -461,6 +471,10 @@ def load_simulation_data(path: str):
         elif kind in ("FieldProjectionAngleData", "FieldProjectionCartesianData", "FieldProjectionKSpaceData"):
             from . import projection
             out.append(getattr(projection, kind)(monitor=mon, **fields))
+        elif kind == "DiffractionData":
+            from . import projection
+            out.append(projection.DiffractionData(monitor=mon, sim_size=tuple(e["sim_size"]),
+                                                  bloch_vecs=tuple(e["bloch_vecs"]), medium=td.parse(e["medium"]), **fields))
         else:
             raise Tidy3dNotImplementedError(f"no mirror container for {kind}")
     return SimulationData(simulation=sim, data=tuple(out), log=model.get("log") or "",

@@ -58,13 +58,15 @@ def _trapz2(f: np.ndarray, u: np.ndarray, v: np.ndarray) -> complex:
     return _trap(g, v, axis=0) if len(v) > 1 else g[0]
 
 
-def _far_fields(disc, plan, raw, norm, theta: np.ndarray, phi: np.ndarray):
+def _far_fields(disc, plan, raw, norm, theta: np.ndarray, phi: np.ndarray, medium=None, f_sel=None):
     """E_theta, E_phi (without the propagation factor) at the direction PAIRS (theta[n], phi[n]), summed
-    over the monitor's surfaces: arrays [n, n_freq]; also k and eta per frequency."""
+    over the monitor's surfaces: arrays [n, n_freq]; also k and eta per frequency.  ``f_sel`` restricts
+    the evaluation to some frequency indices (the other columns stay 0)."""
     from .data import FieldData, _field_container, interp_axis
     mon, sim, spec = plan.monitor, disc.sim, disc.spec
     freqs = np.asarray(mon.freqs, float)
-    medium = mon.medium if mon.medium is not None else sim.medium
+    if medium is None:
+        medium = mon.medium if mon.medium is not None else sim.medium
     origin = mon.local_origin
     names = "xyz"
     eps_f = np.array([complex(np.asarray(medium.eps_model(float(f))).ravel()[0]) for f in freqs])
@@ -109,7 +111,7 @@ def _far_fields(disc, plan, raw, norm, theta: np.ndarray, phi: np.ndarray):
         J = {u: signs[0] * sampled("H" + cv), v: signs[1] * sampled("H" + cu)}
         M = {v: signs[0] * sampled("E" + cu), u: signs[1] * sampled("E" + cv)}
         rel = [pts[a] - origin[a] for a in range(3)]
-        for i_f in range(len(freqs)):
+        for i_f in (range(len(freqs)) if f_sel is None else f_sel):
             k, eta = k_f[i_f], eta_f[i_f]
             Jv = np.zeros((3, len(theta)), complex)
             Mv = np.zeros_like(Jv)
@@ -199,3 +201,150 @@ def project_kspace(disc, plan, raw, norm) -> FieldProjectionKSpaceData:
     r = np.full(th.size, float(mon.proj_distance))
     coords = {"ux": ux, "uy": uy, "r": np.atleast_1d(float(mon.proj_distance)), "f": freqs}
     return _package(FieldProjectionKSpaceData, mon, e_t, e_p, k_f, eta_f, r, (len(ux), len(uy), 1, len(freqs)), coords)
+
+
+# ----------------------------------------------------------------------------------------
+# diffraction orders of a periodic structure  (ref monitor.py:1353, monitor_data.py:2672-2900)
+# ----------------------------------------------------------------------------------------
+
+@dataclass
+class DiffractionData(FieldProjectionAngleData):
+    """Mirror of tidy3d DiffractionData (ref monitor_data.py:2672): Er .. Hphi with dims
+    (orders_x, orders_y, f) in the monitor's local frame (z' = monitor normal, x', y' = the transverse
+    axes in x, y, z order), normalised like the reference's: ``abs(amps)**2`` = power carried by an
+    order and polarisation through one period (ref :2840-2860)."""
+    sim_size: tuple = (0.0, 0.0)
+    bloch_vecs: tuple = (0.0, 0.0)
+    medium: object = None
+    structure_index: int = -1            # structure whose medium fills the monitor plane (-1: background)
+
+    @property
+    def orders_x(self):
+        return np.atleast_1d(np.asarray(self.Etheta.coords["orders_x"]))
+
+    @property
+    def orders_y(self):
+        return np.atleast_1d(np.asarray(self.Etheta.coords["orders_y"]))
+
+    @property
+    def f(self):
+        return np.asarray(self.Etheta.coords["f"], float)
+
+    @property
+    def eta(self):
+        """Wave impedance of the projection medium per frequency."""
+        eps = np.array([complex(np.asarray(self.medium.eps_model(float(f))).ravel()[0]) for f in self.f])
+        return np.real(ETA_0 / np.sqrt(eps))
+
+    def _u(self, orders, size, bloch):
+        """ref monitor_data.py:2758-2767 reciprocal_coords."""
+        if size == 0:
+            return np.zeros((1, len(self.f)))
+        eps = np.array([complex(np.asarray(self.medium.eps_model(float(f))).ravel()[0]) for f in self.f])
+        return (bloch + np.atleast_1d(orders))[:, None] / size * C_0 / self.f[None, :] / np.real(np.sqrt(eps))[None, :]
+
+    @property
+    def ux(self):
+        return self._u(self.orders_x, self.sim_size[0], self.bloch_vecs[0])
+
+    @property
+    def uy(self):
+        return self._u(self.orders_y, self.sim_size[1], self.bloch_vecs[1])
+
+    @property
+    def angles(self):
+        """(theta, phi) per (orders_x, orders_y, f) in the local frame, NaN outside the light cone
+        (ref :2769-2781, :2830-2838)."""
+        from .data import DataArray
+        ux, uy = self.ux[:, None, :], self.uy[None, :, :]
+        with np.errstate(invalid="ignore"):
+            theta = np.arcsin(np.sqrt(ux ** 2 + uy ** 2))
+        phi = np.where(np.isfinite(theta), np.arctan2(uy, ux) + 0.0 * theta, np.nan)
+        return DataArray(theta, self.Etheta.coords), DataArray(phi, self.Etheta.coords)
+
+    @property
+    def amps(self):
+        """ref :2840-2860: dims (orders_x, orders_y, f, polarization = [s, p])."""
+        from .data import DataArray
+        cos_theta = np.cos(np.nan_to_num(self.angles[0].values))
+        cos_theta[cos_theta <= 0] = np.inf
+        nrm = 1.0 / np.sqrt(2.0 * self.eta)[None, None, :] / np.sqrt(cos_theta)
+        coords = dict(self.Etheta.coords)
+        coords["polarization"] = np.array(["s", "p"])
+        return DataArray(np.stack([self.Ephi.values * nrm, self.Etheta.values * nrm], axis=3), coords)
+
+    @property
+    def power(self):
+        """Total power per order, both polarisations (ref :2862-2868)."""
+        from .data import DataArray
+        return DataArray(np.sum(np.abs(self.amps.values) ** 2, axis=3), self.Etheta.coords)
+
+
+def _medium_at(sim, point):
+    """(medium, structure index) that fills ``point``: the last structure containing it, else the
+    background with index -1 (ref simulation.py:1228-1230 overwrite order)."""
+    x, y, z = (np.array([float(v)]) for v in point)
+    for i in reversed(range(len(sim.structures))):
+        st = sim.structures[i]
+        if bool(np.asarray(st.geometry.inside(x, y, z)).ravel()[0]):
+            return st.medium, i
+    return sim.medium, -1
+
+
+def diffraction(disc, plan, raw, norm) -> DiffractionData:
+    """Order amplitudes from the surface-equivalence integrals over ONE period: a periodic sheet of
+    currents radiates the plane waves  E_mn = [far-field integrand at the order's direction] /
+    (2 A cos(theta_mn))  (A = area of the period; the uniform sheet J_s radiating -eta J_s / 2 is the
+    m = n = 0 case), and an order carries |E_mn|^2 A cos(theta) / (2 eta).  Stored like the reference
+    (ref monitor_data.py:2840-2850: power = |E|^2 / (2 eta cos(theta))):  E = E_mn cos(theta) sqrt(A).
+    Orders outside the light cone hold 0.  The reference's own order bookkeeping is server-side."""
+    from .data import DataArray
+    mon, sim = plan.monitor, disc.sim
+    freqs = np.asarray(mon.freqs, float)
+    axis = [a for a in range(3) if mon.size[a] == 0][0]
+    u, v = [a for a in range(3) if a != axis]
+    sgn = 1.0 if (mon.normal_dir or "+") == "+" else -1.0
+    Lu, Lv = float(sim.size[u]), float(sim.size[v])
+    medium, s_index = _medium_at(sim, mon.center)
+    eps_f = np.array([complex(np.asarray(medium.eps_model(float(f))).ravel()[0]) for f in freqs])
+    n_f = np.real(np.sqrt(eps_f))
+    n_max = float(np.max(n_f * freqs)) / C_0                       # 1 / shortest wavelength in the medium
+    mx = int(np.floor(Lu * n_max + 1e-9)) if Lu > 0 else 0
+    my = int(np.floor(Lv * n_max + 1e-9)) if Lv > 0 else 0
+    ox, oy = np.arange(-mx, mx + 1), np.arange(-my, my + 1)
+    area = (Lu if Lu > 0 else 1.0) * (Lv if Lv > 0 else 1.0)
+    shape = (len(ox), len(oy), len(freqs))
+    e_th, e_ph = np.zeros(shape, complex), np.zeros(shape, complex)
+    for i_f, f in enumerate(freqs):
+        lam = C_0 / (f * n_f[i_f])
+        UX = (ox[:, None] * lam / Lu if Lu > 0 else np.zeros((1, 1))) + np.zeros((len(ox), len(oy)))
+        UY = (oy[None, :] * lam / Lv if Lv > 0 else np.zeros((1, 1))) + np.zeros((len(ox), len(oy)))
+        ok = (UX ** 2 + UY ** 2) < 1.0 - 1e-9
+        if not ok.any():
+            continue
+        uxv, uyv = UX[ok], UY[ok]
+        uz = np.sqrt(1.0 - uxv ** 2 - uyv ** 2)
+        d = np.zeros((3, uxv.size))                                 # global propagation direction
+        d[u], d[v], d[axis] = uxv, uyv, sgn * uz
+        th_g, ph_g = np.arccos(np.clip(d[2], -1, 1)), np.arctan2(d[1], d[0])
+        et, ep, _, _ = _far_fields(disc, plan, raw, norm, th_g, ph_g, medium=medium, f_sel=[i_f])
+        # global Cartesian field vector, then the local spherical components
+        st, ct, sp_, cp = np.sin(th_g), np.cos(th_g), np.sin(ph_g), np.cos(ph_g)
+        t_hat = np.stack([ct * cp, ct * sp_, -st])
+        p_hat = np.stack([-sp_, cp, np.zeros_like(cp)])
+        E = et[:, i_f][None, :] * t_hat + ep[:, i_f][None, :] * p_hat
+        th_l, ph_l = np.arcsin(np.sqrt(uxv ** 2 + uyv ** 2)), np.arctan2(uyv, uxv)
+        stl, ctl, spl, cpl = np.sin(th_l), np.cos(th_l), np.sin(ph_l), np.cos(ph_l)
+        E_l = np.stack([E[u], E[v], sgn * E[axis]])                # local (x', y', z') components
+        e_t_l = E_l[0] * ctl * cpl + E_l[1] * ctl * spl - E_l[2] * stl
+        e_p_l = -E_l[0] * spl + E_l[1] * cpl
+        scale = 1.0 / (2.0 * np.sqrt(area))
+        tmp_t, tmp_p = np.zeros(ok.shape, complex), np.zeros(ok.shape, complex)
+        tmp_t[ok], tmp_p[ok] = e_t_l * scale, e_p_l * scale
+        e_th[:, :, i_f], e_ph[:, :, i_f] = tmp_t, tmp_p
+    eta = np.real(ETA_0 / np.sqrt(eps_f))[None, None, :]
+    coords = {"orders_x": ox, "orders_y": oy, "f": freqs}
+    comps = {"Er": np.zeros(shape, complex), "Etheta": e_th, "Ephi": e_ph, "Hr": np.zeros(shape, complex),
+             "Htheta": -e_ph / eta, "Hphi": e_th / eta}
+    return DiffractionData(monitor=mon, sim_size=(Lu, Lv), bloch_vecs=(0.0, 0.0), medium=medium, structure_index=s_index,
+                           **{k: DataArray(a, coords) for k, a in comps.items()})

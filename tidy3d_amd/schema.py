@@ -1609,6 +1609,42 @@ class FieldProjectionKSpaceMonitor(FieldProjectionAngleMonitor):
 
 @_register
 @dataclass
+class DiffractionMonitor(_Monitor):
+    """Diffraction orders of a periodic structure through an infinite plane (ref monitor.py:1353-1407):
+    the near fields of one period are recorded like a projection surface and decomposed into the
+    allowed orders after the run (tidy3d_amd/projection.py ``diffraction``)."""
+
+    center: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    size: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    name: str = "diffraction"
+    interval_space: Tuple[int, int, int] = (1, 1, 1)
+    colocate: bool = False
+    freqs: Tuple[float, ...] = ()
+    apodization: ApodizationSpec = field(default_factory=ApodizationSpec)
+    normal_dir: str = "+"
+
+    # what the projection core reads from a projection monitor (not part of the reference's fields)
+    medium = None
+    exclude_surfaces = None
+    custom_origin = None
+
+    def __post_init__(self):
+        if [np.isinf(_to_float(v)) for v in self.size].count(True) != 2:
+            raise SetupError("A 'DiffractionMonitor' must have a size of 'td.inf' along both transverse "
+                             f"directions, given size={self.size}.")          # ref monitor.py:1390-1398
+        if [float(_to_float(v)) == 0 for v in self.size].count(True) != 1:
+            raise SetupError("A 'DiffractionMonitor' must be planar.")
+
+    def frequency_range(self):
+        return (min(self.freqs), max(self.freqs))
+
+    @property
+    def local_origin(self):
+        return tuple(self.center)
+
+
+@_register
+@dataclass
 class RunTimeSpec(_Model):
     """ref components/run_time_spec.py; evaluated in Simulation._run_time (simulation.py:3677)."""
 
