@@ -169,6 +169,13 @@ int fdtd_comm_init(FdtdSolver* h, const char id[128], int rank, int n_ranks);
  * of the cloud path (ref web/api/webapi.py:266,:337); the step count is Simulation.num_time_steps
  * (ref simulation.py:4226). */
 int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user);
+/* Bloch boundaries (ref boundary.py:55-79 BlochBoundary: F(r + L_a) = bloch_phase_a F(r), complex
+ * fields): two handles created from the same configuration carry the real and the imaginary part
+ * (the host gives the second one the source weights times -i) and are advanced together;
+ * phase[a] = 2 pi bloch_vec of axis a, used on the axes whose faces are FDTD_BC_PERIODIC.  One GPU,
+ * no communicator.  Monitors of the pair are read per handle; a DFT value is re + i im. */
+int fdtd_run_bloch(FdtdSolver* h_re, FdtdSolver* h_im, int64_t n_steps, const double phase[3],
+                   FdtdProgressFn progress, void* user);
 /* ref web/api/webapi.py:370 (task status incl. "diverged"), web/core/task_core.py:537 (run info) */
 int fdtd_get_stats(FdtdSolver* h, FdtdStats* out);
 /* tuning knobs that may change between runs of one handle (bench A/B without re-upload) */

@@ -47,6 +47,12 @@ def _bcast(v: np.ndarray, axis: int) -> np.ndarray:
 class OracleFdtd:
     def __init__(self, spec: SolverSpec, dtype=np.float64):
         self.spec = spec
+        # Bloch boundaries (ref boundary.py:55-79): complex fields, F(r + L_a) = exp(i phi_a) F(r); the
+        # HIP engine carries them as a (Re, Im) pair of real solvers (fdtd_run_bloch)
+        self.bloch = getattr(spec, "bloch", None)
+        self.rdtype = dtype
+        if self.bloch is not None:
+            dtype = np.complex128
         self.dtype = dtype
         nx, ny, nz = spec.shape
         shp = (nz, ny, nx)
@@ -66,16 +72,16 @@ class OracleFdtd:
                 for a in range(3):
                     on_center = (a == c) != is_h
                     f = f * _bcast(dm[a].fc if on_center else dm[a].fb, a)
-                return f.astype(dtype)
+                return f.astype(self.rdtype)
             self.damp_e = [factor(c, False) for c in range(3)]
             self.damp_h = [factor(c, True) for c in range(3)]
         self.mt = material_table(spec.media, spec.dt)
         if spec.mat_idx is not None:
-            self.ca = [self.mt.ca[spec.mat_idx[c]].astype(dtype) for c in range(3)]
-            self.cb = [self.mt.cb[spec.mat_idx[c]].astype(dtype) for c in range(3)]
+            self.ca = [self.mt.ca[spec.mat_idx[c]].astype(self.rdtype) for c in range(3)]
+            self.cb = [self.mt.cb[spec.mat_idx[c]].astype(self.rdtype) for c in range(3)]
         else:
-            self.ca = [dtype(self.mt.ca[1])] * 3
-            self.cb = [dtype(self.mt.cb[1])] * 3
+            self.ca = [self.rdtype(self.mt.ca[1])] * 3
+            self.cb = [self.rdtype(self.mt.cb[1])] * 3
         # CPML
         self.pml = [pml_axis(spec, a) for a in range(3)]
         self.has_pml = [p.n_lo + p.n_hi > 0 for p in self.pml]
@@ -96,12 +102,12 @@ class OracleFdtd:
                     if self.mt.is_dispersive(m):
                         idx = np.nonzero(flat == m)[0]
                         if idx.size:
-                            q = np.zeros((len(self.mt.kap[m]), idx.size), complex)
+                            q = np.zeros((2 if self.bloch is not None else 1, len(self.mt.kap[m]), idx.size), complex)
                             self.ade.append([c, m, idx, q, np.zeros(idx.size, dtype)])
         elif self.mt.is_dispersive(1):
             for c in range(3):
                 idx = np.arange(nx * ny * nz)
-                q = np.zeros((len(self.mt.kap[1]), idx.size), complex)
+                q = np.zeros((2 if self.bloch is not None else 1, len(self.mt.kap[1]), idx.size), complex)
                 self.ade.append([c, 1, idx, q, np.zeros(idx.size, dtype)])
         # TFSF auxiliary 1-D grids
         self.tfsf_state = [self._tfsf_init(t) for t in spec.tfsf]
@@ -111,7 +117,7 @@ class OracleFdtd:
         for m in spec.monitors:
             bz, by, bx = m.shape
             if m.kind == "time":
-                self.mon_data.append(np.zeros((len(m.steps), len(m.comps), bz, by, bx), dtype))
+                self.mon_data.append(np.zeros((len(m.steps), len(m.comps), bz, by, bx), self.rdtype))
             else:
                 self.mon_data.append(np.zeros((len(m.freqs), len(m.comps), bz, by, bx), complex))
             self.mon_count.append(0)
@@ -127,10 +133,12 @@ class OracleFdtd:
         (ref derivatives.py:9-40: truncation at the max edge = PEC)."""
         ax = _ax(axis)
         nxt = np.roll(F, -1, axis=ax)
+        sl = [slice(None)] * 3
+        sl[ax] = -1
         if self.spec.bc[axis][1] != BC_PERIODIC:
-            sl = [slice(None)] * 3
-            sl[ax] = -1
             nxt[tuple(sl)] = 0
+        elif self.bloch is not None and self.bloch[axis] != 0.0:
+            nxt[tuple(sl)] *= np.exp(1j * self.bloch[axis])          # F[N] = exp(+i phi) F[0]
         return (nxt - F) * self.ip[axis]
 
     def _bwd(self, F: np.ndarray, axis: int) -> np.ndarray:
@@ -139,10 +147,12 @@ class OracleFdtd:
         ax = _ax(axis)
         prv = np.roll(F, 1, axis=ax)
         bc = self.spec.bc[axis][0]
+        sl = [slice(None)] * 3
+        sl[ax] = 0
         if bc != BC_PERIODIC:
-            sl = [slice(None)] * 3
-            sl[ax] = 0
             prv[tuple(sl)] = -F[tuple(sl)] if bc == BC_PMC else 0
+        elif self.bloch is not None and self.bloch[axis] != 0.0:
+            prv[tuple(sl)] *= np.exp(-1j * self.bloch[axis])         # F[-1] = exp(-i phi) F[N-1]
         return (F - prv) * self.id[axis]
 
     def _pml_h(self, c: int, a: int, d: np.ndarray) -> np.ndarray:
@@ -178,8 +188,11 @@ class OracleFdtd:
                 m = s.comp == cc
                 if m.any():
                     ijk = s.ijk[m]
-                    np.add.at(H[cc - 3], (ijk[:, 2], ijk[:, 1], ijk[:, 0]),
-                              np.real(w[m] * s.wave_h[n]).astype(self.dtype))
+                    np.add.at(H[cc - 3], (ijk[:, 2], ijk[:, 1], ijk[:, 0]), self._amp(w[m] * s.wave_h[n]))
+
+    def _amp(self, z: np.ndarray) -> np.ndarray:
+        """Injected amplitude: the real part for real fields, the full complex value under Bloch boundaries."""
+        return z.astype(self.dtype) if self.bloch is not None else np.real(z).astype(self.dtype)
 
     def update_e(self, n: int):
         E, H = self.E, self.H
@@ -198,8 +211,7 @@ class OracleFdtd:
                 m = s.comp == cc
                 if m.any():
                     ijk = s.ijk[m]
-                    np.add.at(E[cc], (ijk[:, 2], ijk[:, 1], ijk[:, 0]),
-                              np.real(w[m] * s.wave_e[n]).astype(self.dtype))
+                    np.add.at(E[cc], (ijk[:, 2], ijk[:, 1], ijk[:, 0]), self._amp(w[m] * s.wave_e[n]))
         # absorber layers: damp the updated E before the ADE memory term is added
         if self.damp_e is not None:
             for c in range(3):
@@ -208,11 +220,15 @@ class OracleFdtd:
         for (c, m, idx, q, _), eo in zip(self.ade, e_old):
             kap, bet = self.mt.kap[m][:, None], self.mt.bet[m][:, None]
             flat = E[c].reshape(-1)
-            S = np.sum(2.0 * np.real((kap - 1.0) * q), axis=0)
+            S = np.sum(2.0 * np.real((kap - 1.0) * q[0]), axis=0)
+            if self.bloch is not None:            # Re and Im parts are two independent real problems
+                S = S + 1j * np.sum(2.0 * np.real((kap - 1.0) * q[1]), axis=0)
             en = flat[idx] - self.mt.cc[m] * S
             flat[idx] = en
-            q *= kap
-            q += bet * (en + eo)[None, :]
+            q *= kap[None]
+            q[0] += bet * np.real(en + eo)[None, :]
+            if self.bloch is not None:
+                q[1] += bet * np.imag(en + eo)[None, :]
         # PEC walls at the min faces (tangential components living on the wall)
         for c in range(3):
             for a in range(3):
@@ -272,9 +288,9 @@ class OracleFdtd:
             for ic, c in enumerate(m.comps):
                 if m.kind == "time":
                     if c < 3 and phase == "pre":
-                        data[k, ic] = self._box(self.E[c], m)
+                        data[k, ic] = np.real(self._box(self.E[c], m))
                     elif c >= 3:
-                        data[k, ic] += 0.5 * self._box(self.H[c - 3], m)
+                        data[k, ic] += 0.5 * np.real(self._box(self.H[c - 3], m))
                 else:
                     if c < 3 and phase == "pre":
                         data[:, ic] += m.phase_e[k][:, None, None, None] * self._box(self.E[c], m)
@@ -286,7 +302,7 @@ class OracleFdtd:
 
     # ------------------------------------------------------------------ driver
     def energy(self) -> float:
-        return float(sum(np.sum(np.square(e, dtype=np.float64)) for e in self.E))
+        return float(sum(np.sum(np.square(np.abs(e), dtype=np.float64)) for e in self.E))
 
     def step(self):
         n = self.step_index

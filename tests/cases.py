@@ -220,7 +220,37 @@ def absorber_odd_rows(N=(13, 10, 9)):
     return _sim(N, bspec)
 
 
+def bloch_box(N=(12, 10, 9)):
+    """Bloch boundaries on all three axes (complex fields as a (Re, Im) pair of solvers): Lorentz sphere
+    (ADE on both parts), lossy box, electric and magnetic dipoles; odd row length -> scalar kernels."""
+    structures = [
+        td.Structure(geometry=td.Sphere(center=(0.05, 0, 0.05), radius=0.15),
+                     medium=td.Lorentz(eps_inf=2.0, coeffs=[(1.5, 4e14, 3e13)])),
+        td.Structure(geometry=td.Box(center=(-0.25, 0, -0.2), size=(0.2, td.inf, 0.15)),
+                     medium=td.Medium(permittivity=3.0, conductivity=0.02))]
+    bspec = td.BoundarySpec(x=td.Boundary.bloch(0.31), y=td.Boundary.bloch(-0.17), z=td.Boundary.bloch(0.45))
+    return _sim(N, bspec, structures)
+
+
+def bloch_xy_pml_z(N=(16, 12, 12)):
+    """The usual periodic-array set-up at oblique incidence: Bloch in x and y, CPML in z, a Drude film
+    through the cell, float4 rows."""
+    structures = [td.Structure(geometry=td.Box(center=(0, 0, -0.15), size=(td.inf, td.inf, 0.1)),
+                               medium=td.Drude(eps_inf=1.5, coeffs=[(1.2e15, 8e13)])),
+                  td.Structure(geometry=td.Box(center=(0.1, 0.1, 0.1), size=(0.3, 0.2, 0.2)), medium=td.PEC)]
+    bspec = td.BoundarySpec(x=td.Boundary.bloch(0.2), y=td.Boundary.bloch(0.35), z=td.Boundary.pml(num_layers=4))
+    return _sim(N, bspec, structures)
+
+
+def bloch_x_only(N=(16, 10, 8)):
+    """Bloch along x only; y periodic, z PMC / PEC walls."""
+    bspec = td.BoundarySpec(x=td.Boundary.bloch(-0.4), y=td.Boundary.periodic(),
+                            z=td.Boundary(minus=td.PMCBoundary(), plus=td.PECBoundary()))
+    return _sim(N, bspec)
+
+
 CASES = {
+    "bloch_box": bloch_box, "bloch_xy_pml_z": bloch_xy_pml_z, "bloch_x_only": bloch_x_only,
     "two_d": two_d, "one_d": one_d, "absorber_mix": absorber_mix, "absorber_odd_rows": absorber_odd_rows,
     "tfsf_box": tfsf_box, "planewave_periodic": planewave_periodic, "au_array": au_array,
     "pec_box": pec_box, "pec_box_vec": pec_box_vec, "periodic_box": periodic_box,

@@ -1,0 +1,73 @@
+"""Bloch boundaries (ref boundary.py:55-160): complex fields, F(r + L) = exp(2 pi i bloch_vec) F(r).
+The HIP engine carries them as a (Re, Im) pair of real solvers coupled by the Bloch fix-up kernels
+(fdtd_run_bloch); the oracle uses complex arrays directly — two independent formulations held together
+by the ``bloch_*`` parity cases (tests/cases.py).  Here: schema pins and the physics of the oracle."""
+import numpy as np
+import pytest
+
+import tidy3d_amd.schema as td
+from tidy3d_amd.constants import C_0
+from tidy3d_amd.discretize import discretize
+from tidy3d_amd.exceptions import SetupError
+
+from test_physics_oracle import solve
+
+
+def test_bloch_boundary_schema():
+    b = td.BlochBoundary(bloch_vec=0.25)
+    assert b.bloch_phase == pytest.approx(1j)                                   # ref boundary.py:75-79
+    assert td.parse({"type": "BlochBoundary", "bloch_vec": -0.4, "name": None}).bloch_vec == -0.4
+    with pytest.raises(SetupError, match="both sides"):
+        td.Boundary(plus=td.BlochBoundary(bloch_vec=0.1), minus=td.Periodic())
+    with pytest.raises(SetupError, match="same"):
+        td.Boundary(plus=td.BlochBoundary(bloch_vec=0.1), minus=td.BlochBoundary(bloch_vec=0.2))
+    # from_source (ref boundary.py:81-160): bloch_vec = L k_axis / 2 pi of the source's centre frequency
+    pulse = td.GaussianPulse(freq0=2e14, fwidth=2e13)
+    pw = td.PlaneWave(size=(td.inf, td.inf, 0), source_time=pulse, direction="+", angle_theta=0.3, angle_phi=0.4)
+    bx = td.BlochBoundary.from_source(pw, domain_size=2.0, axis=0)
+    assert bx.bloch_vec == pytest.approx(2.0 * 2e14 / C_0 * np.sin(0.3) * np.cos(0.4), rel=1e-12)
+    by = td.BlochBoundary.from_source(pw, domain_size=1.5, axis=1, medium=td.Medium(permittivity=4.0))
+    assert by.bloch_vec == pytest.approx(1.5 * 2 * 2e14 / C_0 * np.sin(0.3) * np.sin(0.4), rel=1e-12)
+    minus = td.PlaneWave(size=(td.inf, td.inf, 0), source_time=pulse, direction="-", angle_theta=0.3, angle_phi=0.4)
+    assert td.BlochBoundary.from_source(minus, 2.0, 0).bloch_vec == pytest.approx(-bx.bloch_vec, rel=1e-12)
+    with pytest.raises(SetupError, match="orthogonal"):
+        td.BlochBoundary.from_source(pw, 2.0, 2)
+
+
+def test_spec_carries_the_phases():
+    sim = td.Simulation(size=(1, 1, 1), grid_spec=td.GridSpec.uniform(dl=0.1), run_time=1e-14,
+                        sources=[td.PointDipole(source_time=td.GaussianPulse(freq0=2e14, fwidth=2e13), polarization="Ex")],
+                        boundary_spec=td.BoundarySpec(x=td.Boundary.bloch(0.25), y=td.Boundary.periodic(),
+                                                      z=td.Boundary.pml(num_layers=3)))
+    spec = discretize(sim, n_steps=2).spec
+    assert spec.bloch == pytest.approx((np.pi / 2, 0.0, 0.0)) and spec.bc[0] == (2, 2) and spec.bc[1] == (2, 2)
+    import dataclasses
+    plain = dataclasses.replace(sim, boundary_spec=td.BoundarySpec(x=td.Boundary.bloch(0.0), y=td.Boundary.periodic(),
+                                                                   z=td.Boundary.pml(num_layers=3)))
+    assert discretize(plain, n_steps=2).spec.bloch is None
+
+
+@pytest.mark.parametrize("bvec", [0.0, 0.3, -0.2])
+def test_empty_lattice_bands(bvec):
+    """1-D cell of length L with Bloch vector b: the plane-wave bands f_m = c |b + m| / L (ref
+    boundary.py:69-73: bloch_vec in units of 2 pi / L)."""
+    L, dl = 2.0, 0.02
+    pulse = td.GaussianPulse(freq0=1.5e14, fwidth=1.2e14)
+    sim = td.Simulation(size=(0, 0, L), grid_spec=td.GridSpec.uniform(dl=dl), run_time=6e-13, shutoff=0,
+                        sources=[td.PointDipole(center=(0, 0, 0.13), source_time=pulse, polarization="Ex")],
+                        monitors=[td.FieldTimeMonitor(center=(0, 0, -0.61), size=(0, 0, 0), name="p", fields=["Ex"],
+                                                      colocate=False)],
+                        boundary_spec=td.BoundarySpec(x=td.Boundary.periodic(), y=td.Boundary.periodic(),
+                                                      z=td.Boundary.bloch(bvec)))
+    sd, disc, _ = solve(sim)
+    x = sd["p"].Ex.values.reshape(-1)
+    t = np.asarray(sd["p"].Ex.coords["t"])
+    n0 = int(np.searchsorted(t, 1.2e-13))                     # after the pulse
+    x, dt = x[n0:] * np.hanning(len(x) - n0), t[1] - t[0]
+    spec = np.abs(np.fft.rfft(x, 8 * len(x)))
+    f = np.fft.rfftfreq(8 * len(x), dt)
+    want = sorted({round(C_0 * abs(bvec + m) / L, 3) for m in range(-3, 4) if 0.3e14 < C_0 * abs(bvec + m) / L < 2.9e14})
+    peaks = [f[i] for i in range(1, len(f) - 1) if spec[i] > spec[i - 1] and spec[i] > spec[i + 1]
+             and spec[i] > 0.05 * spec.max() and 0.3e14 < f[i] < 2.9e14]
+    assert len(peaks) == len(want), (peaks, want)
+    np.testing.assert_allclose(peaks, want, rtol=4e-3)

@@ -1481,6 +1481,137 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   return 0;
 }
 
+// Complex (Bloch-periodic) fields: two solvers carry Re and Im of the same simulation (identical grid,
+// media, CPML, ADE and monitors; the Im solver's source weights are the Re solver's times -i) and are
+// stepped together on the Re solver's stream; they only meet in the Bloch fix-ups (fdtd_kernels.hpp).
+// Two-pass kernels, one GPU.  phase[a] = 2 pi bloch_vec of axis a (ref boundary.py:55-79 bloch_phase);
+// axes that are not periodic in the configuration ignore it.
+int fdtd_run_bloch(FdtdSolver* hr, FdtdSolver* hi, int64_t n_steps, const double phase[3], FdtdProgressFn progress,
+                   void* user) {
+  if (!hr || !hi) return -1;
+  if (hr->comm || hi->comm) return fail(hr, "fdtd_run_bloch: z-slab communicators are not supported with Bloch boundaries");
+  if (hr->g.nx != hi->g.nx || hr->g.ny != hi->g.ny || hr->g.nz != hi->g.nz || hr->cfg.device != hi->cfg.device ||
+      hr->mons.size() != hi->mons.size() || hr->step != hi->step)
+    return fail(hr, "fdtd_run_bloch: the two solvers must describe the same simulation");
+  HIPCHK(hr, hipSetDevice(hr->cfg.device));
+  const GridP& g = hr->g;
+  const int nz = g.nz;
+  hipStream_t st = hr->stream;
+  HIPCHK(hr, hipStreamSynchronize(hi->stream));
+  FdtdSolver* both[2] = {hr, hi};
+  for (FdtdSolver* h : both) {
+    for (hipEvent_t e : h->kev) hipEventDestroy(e);
+    h->kev.clear(); h->kev_kind.clear();
+    h->stats.stopped_early = 0;
+  }
+  HIPCHK(hr, hipEventRecord(hr->ev0, st));
+  const bool per[3] = {hr->cfg.bc[0] == FDTD_BC_PERIODIC, hr->cfg.bc[2] == FDTD_BC_PERIODIC,
+                       hr->cfg.bc[4] == FDTD_BC_PERIODIC};
+  float cph[3], sph[3];
+  for (int a = 0; a < 3; ++a) { cph[a] = (float)std::cos(phase[a]); sph[a] = (float)std::sin(phase[a]); }
+  const long long pc = plane_cells(hr);
+  auto cp = [&](int comp) { CplxP c; c.re = field_ptr(hr, comp); c.im = field_ptr(hi, comp); return c; };
+  const int N[3] = {g.nx, g.ny, nz};
+  int64_t done = 0;
+  for (; done < n_steps; ++done) {
+    const long long n = hr->step;
+    bool rec = false;
+    for (Monitor& m : hr->mons) if (m.next < m.steps.size() && m.steps[m.next] == n) rec = true;
+    if (rec) for (FdtdSolver* h : both) record_monitors(h, n, false, st);
+    // ---------------- H phase ----------------
+    for (FdtdSolver* h : both) {
+      launch_damp(h, false, 0, nz, st);
+      launch_sources(h, false, n, 0, nz, st);
+      launch_pml(h, false, 0, nz, st);
+      launch_h_main(h, 0, nz, st);
+    }
+    for (int a = 0; a < 2; ++a) {
+      if (!per[a] || phase[a] == 0.0) continue;
+      const int c1 = (a + 1) % 3, c2 = (a + 2) % 3;
+      const long long cells = (long long)N[c1] * N[c2];
+      hipLaunchKernelGGL(bloch_h_fix_kernel, dim3(nblk(cells)), dim3(256), 0, st, g, a, cp(3 + c1), cp(3 + c2),
+                         cp(c1), cp(c2), (const float*)hr->ip[a], cph[a], sph[a], nz);
+    }
+    if (per[2]) {      // ghost(-1) = exp(-i phi_z) H[nz-1]
+      for (int c = 3; c < 5; ++c)
+        hipLaunchKernelGGL(bloch_plane_kernel, dim3(nblk(pc)), dim3(256), 0, st, field_ptr(hr, c) - pc, field_ptr(hi, c) - pc,
+                           (const float*)(field_ptr(hr, c) + (long long)(nz - 1) * pc),
+                           (const float*)(field_ptr(hi, c) + (long long)(nz - 1) * pc), cph[2], -sph[2], pc);
+    } else {
+      for (FdtdSolver* h : both) fill_ghost_h(h, st);
+    }
+    if (rec) for (FdtdSolver* h : both) record_monitors(h, n, true, st);
+    // ---------------- E phase ----------------
+    for (FdtdSolver* h : both) {
+      launch_e_main(h, 0, nz, st);
+      launch_pml(h, true, 0, nz, st);
+      launch_sources(h, true, n, 0, nz, st);
+    }
+    for (int a = 0; a < 2; ++a) {
+      if (!per[a] || phase[a] == 0.0) continue;
+      const int c1 = (a + 1) % 3, c2 = (a + 2) % 3;
+      const long long cells = (long long)N[c1] * N[c2];
+      hipLaunchKernelGGL(bloch_e_fix_kernel, dim3(nblk(cells)), dim3(256), 0, st, g, a, cp(c1), cp(c2), cp(3 + c1),
+                         cp(3 + c2), (const float*)hr->idl[a], (const uint32_t*)hr->mat4, (const float2*)hr->lut,
+                         hr->cb1, cph[a], sph[a], nz);
+    }
+    for (FdtdSolver* h : both) {
+      launch_damp(h, true, 0, nz, st);
+      launch_ade(h, 0, nz, st);
+    }
+    if (per[2]) {      // ghost(nz) = exp(+i phi_z) E[0]
+      for (int c = 0; c < 2; ++c)
+        hipLaunchKernelGGL(bloch_plane_kernel, dim3(nblk(pc)), dim3(256), 0, st, field_ptr(hr, c) + (long long)nz * pc,
+                           field_ptr(hi, c) + (long long)nz * pc, (const float*)field_ptr(hr, c),
+                           (const float*)field_ptr(hi, c), cph[2], sph[2], pc);
+    } else {
+      for (FdtdSolver* h : both) fill_ghost_e(h, st);
+    }
+    hr->step = hi->step = n + 1;
+    // ---------------- field decay / divergence (|E|^2 of both parts) ----------------
+    if (hr->decay_every > 0 && (hr->step % hr->decay_every) == 0) {
+      double en = 0.0;
+      for (FdtdSolver* h : both) {
+        HIPCHK(hr, hipMemsetAsync(h->energy_dev, 0, sizeof(double), st));
+        const long long nc = n_cells(h);
+        unsigned blocks = nblk(nc);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(energy_kernel, dim3(blocks), dim3(256), 0, st, (const float*)h->f.ex, (const float*)h->f.ey,
+                           (const float*)h->f.ez, nc, h->energy_dev);
+        double part = 0.0;
+        HIPCHK(hr, hipMemcpyAsync(&part, h->energy_dev, sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hr, hipStreamSynchronize(st));
+        en += part;
+      }
+      if (!std::isfinite(en)) {
+        hr->stats.diverged = hi->stats.diverged = 1;
+        ++done;
+        break;
+      }
+      if (en > hr->energy_max) hr->energy_max = hi->energy_max = en;
+      hr->stats.field_decay = hi->stats.field_decay = hr->energy_max > 0 ? en / hr->energy_max : 1.0;
+      if (progress && progress(hr->step, 0.0, hr->stats.field_decay, user)) { ++done; break; }
+      if (hr->shutoff > 0 && hr->step > hr->decay_ref && hr->stats.field_decay < hr->shutoff) {
+        hr->stats.stopped_early = hi->stats.stopped_early = 1;
+        ++done;
+        break;
+      }
+    }
+  }
+  HIPCHK(hr, hipEventRecord(hr->ev1, st));
+  HIPCHK(hr, hipStreamSynchronize(st));
+  HIPCHK(hr, hipGetLastError());
+  float ms = 0.f;
+  HIPCHK(hr, hipEventElapsedTime(&ms, hr->ev0, hr->ev1));
+  for (FdtdSolver* h : both) {
+    h->stats.run_ms = ms;
+    h->stats.steps_done = h->step;
+    h->stats.h_kernel_ms = h->stats.e_kernel_ms = h->stats.fused_kernel_ms = 0.0;
+    h->stats.h_kernel_launches = h->stats.e_kernel_launches = h->stats.fused_kernel_launches = 0;
+  }
+  return 0;
+}
+
 int fdtd_set_option(FdtdSolver* h, int key, int value) {
   if (!h) return -1;
   switch (key) {

@@ -1328,6 +1328,86 @@ __global__ __launch_bounds__(256) void damp_kernel(GridP g, DampP d, float* f0, 
   f2[idx] *= w2;
 }
 
+// ---- Bloch boundaries (complex fields as a (Re, Im) pair of real field sets) ------------------
+// F(r + L_a) = exp(i phi_a) F(r).  The update kernels wrap periodic axes with phase 1; because the
+// updates are linear in the wrapped neighbour the phase is restored afterwards on the one column /
+// row that uses it (x, y), and the z ghost planes are filled with the rotated copy directly.
+//   H side, last index L of axis a:  ghost E[L+1] = exp(+i phi) E[0]
+//       H_{a+1}[L] += ch ip[L] (exp(i phi) - 1) E_{a+2}[0],   H_{a+2}[L] -= ch ip[L] (exp(i phi) - 1) E_{a+1}[0]
+//   E side, index 0:                 ghost H[-1] = exp(-i phi) H[L]
+//       E_{a+1}[0] += Cb id[0] (exp(-i phi) - 1) H_{a+2}[L],  E_{a+2}[0] -= Cb id[0] (exp(-i phi) - 1) H_{a+1}[L]
+struct CplxP {
+  float* re; float* im;
+};
+
+__global__ __launch_bounds__(256) void bloch_h_fix_kernel(GridP g, int a, CplxP h1, CplxP h2, CplxP e1, CplxP e2,
+                                                          const float* ip, float cphi, float sphi, int nz) {
+  const int N[3] = {g.nx, g.ny, nz};
+  const int u = (a + 1) % 3, v = (a + 2) % 3;
+  const long long total = (long long)N[u] * N[v];
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  // thread -> (other two indices), x fastest when it is one of them
+  int idx[3];
+  const int lo = u < v ? u : v, hi = u < v ? v : u;
+  idx[lo] = (int)(t % N[lo]); idx[hi] = (int)(t / N[lo]);
+  idx[a] = 0;
+  const long long p0 = (long long)idx[2] * g.sxy + (long long)idx[1] * g.nx + idx[0];
+  const long long stride = (a == 0) ? 1 : (a == 1 ? (long long)g.nx : g.sxy);
+  const long long pl = p0 + (long long)(N[a] - 1) * stride;
+  const float w = g.ch * ip[N[a] - 1];
+  const float cm = cphi - 1.f;
+  const float e1r = e1.re[p0], e1i = e1.im[p0], e2r = e2.re[p0], e2i = e2.im[p0];
+  h1.re[pl] += w * (cm * e2r - sphi * e2i);
+  h1.im[pl] += w * (cm * e2i + sphi * e2r);
+  h2.re[pl] -= w * (cm * e1r - sphi * e1i);
+  h2.im[pl] -= w * (cm * e1i + sphi * e1r);
+}
+
+__global__ __launch_bounds__(256) void bloch_e_fix_kernel(GridP g, int a, CplxP e1, CplxP e2, CplxP h1, CplxP h2,
+                                                          const float* idl, const uint32_t* m4, const float2* lut,
+                                                          float cb_uniform, float cphi, float sphi, int nz) {
+  const int N[3] = {g.nx, g.ny, nz};
+  const int c1 = (a + 1) % 3, c2 = (a + 2) % 3;
+  const long long total = (long long)N[c1] * N[c2];
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  int idx[3];
+  const int lo = c1 < c2 ? c1 : c2, hi = c1 < c2 ? c2 : c1;
+  idx[lo] = (int)(t % N[lo]); idx[hi] = (int)(t / N[lo]);
+  idx[a] = 0;
+  const long long p0 = (long long)idx[2] * g.sxy + (long long)idx[1] * g.nx + idx[0];
+  const long long stride = (a == 0) ? 1 : (a == 1 ? (long long)g.nx : g.sxy);
+  const long long pl = p0 + (long long)(N[a] - 1) * stride;
+  const uint32_t mw = m4 ? m4[p0] : 0u;
+  const float cb1 = m4 ? lut[(mw >> (8 * c1)) & 255u].y : cb_uniform;
+  const float cb2 = m4 ? lut[(mw >> (8 * c2)) & 255u].y : cb_uniform;
+  const int bc0[3] = {g.bcx0, g.bcy0, g.pec_z0 ? BC_PEC : BC_NEIGHBOR};
+  const bool w1 = (idx[c2] == 0) && (bc0[c2] == BC_PEC);   // E_{c1} is tangential to the c2-wall
+  const bool w2 = (idx[c1] == 0) && (bc0[c1] == BC_PEC);
+  const float cm = cphi - 1.f, id0 = idl[0];
+  const float h1r = h1.re[pl], h1i = h1.im[pl], h2r = h2.re[pl], h2i = h2.im[pl];
+  // (exp(-i phi) - 1) (hr + i hi) = (cm hr + s hi) + i (cm hi - s hr)
+  if (!w1) {
+    e1.re[p0] += cb1 * id0 * (cm * h2r + sphi * h2i);
+    e1.im[p0] += cb1 * id0 * (cm * h2i - sphi * h2r);
+  }
+  if (!w2) {
+    e2.re[p0] -= cb2 * id0 * (cm * h1r + sphi * h1i);
+    e2.im[p0] -= cb2 * id0 * (cm * h1i - sphi * h1r);
+  }
+}
+
+// dst = exp(i phi) src on one xy-plane (z ghost planes; pass -sin(phi) for exp(-i phi))
+__global__ __launch_bounds__(256) void bloch_plane_kernel(float* dre, float* dim, const float* sre, const float* sim,
+                                                          float cphi, float sphi, long long n) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const float a = sre[t], b = sim[t];
+  dre[t] = cphi * a - sphi * b;
+  dim[t] = cphi * b + sphi * a;
+}
+
 // ghost-plane helpers (single-GPU z boundary conditions)
 __global__ __launch_bounds__(256) void negate_copy_kernel(float* dst, const float* src, long long n) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -123,6 +123,16 @@ class HipEngine:
         self.lib = lib or L.load_library()
         self.spec = spec
         self.rank, self.n_ranks = rank, n_ranks
+        # Bloch boundaries: complex fields = this engine (real part) + a twin engine (imaginary part,
+        # source weights times -i), advanced together by fdtd_run_bloch (two-pass kernels, one GPU)
+        self.twin: Optional["HipEngine"] = None
+        if spec.bloch is not None:
+            if n_ranks > 1 or force_comm or slab is not None:
+                raise SolverLibraryError("Bloch boundaries run on one GPU (no z-slab decomposition)")
+            if spec.tfsf:
+                raise SolverLibraryError("TFSF sources cannot be combined with Bloch boundaries")
+            if variant != L.VARIANT_SIMPLE:
+                variant = L.VARIANT_ZMARCH
         nx, ny, nz = spec.shape
         self.z0, self.z1 = slab if slab is not None else (0, nz)
         self.nzl = self.z1 - self.z0
@@ -163,6 +173,12 @@ class HipEngine:
             raise SolverLibraryError(f"fdtd_create failed: {self.lib.error(None)}")
         try:
             self._setup(spec)
+            if spec.bloch is not None:
+                import dataclasses
+                rot = [dataclasses.replace(sc, w_re=np.asarray(sc.w_im, float), w_im=-np.asarray(sc.w_re, float))
+                       for sc in spec.sources]                   # -i (w_re + i w_im) = w_im - i w_re
+                self.twin = HipEngine(dataclasses.replace(spec, bloch=None, sources=rot), lib=self.lib, device=device,
+                                      variant=variant, flags=flags, z_chunk=z_chunk)
         except Exception:
             self.close()
             raise
@@ -343,7 +359,12 @@ class HipEngine:
             except KeyboardInterrupt:
                 return 1
         cb = L.PROGRESS_FN(_cb) if progress else C.cast(None, L.PROGRESS_FN)
-        self._chk(self.lib.dll.fdtd_run(self.handle, int(n_steps), cb, None), "fdtd_run")
+        if self.twin is not None:
+            ph = (C.c_double * 3)(*[float(v) for v in self.spec.bloch])
+            self._chk(self.lib.dll.fdtd_run_bloch(self.handle, self.twin.handle, int(n_steps), ph, cb, None),
+                      "fdtd_run_bloch")
+        else:
+            self._chk(self.lib.dll.fdtd_run(self.handle, int(n_steps), cb, None), "fdtd_run")
         return self.stats()
 
     def stats(self) -> L.FdtdStats:
@@ -356,8 +377,15 @@ class HipEngine:
 
     def reset(self):
         self._chk(self.lib.dll.fdtd_reset(self.handle), "fdtd_reset")
+        if self.twin is not None:
+            self.twin.reset()
 
     def get_field(self, comp: int) -> np.ndarray:
+        if self.twin is not None:
+            return self._get_field_real(comp) + 1j * self.twin.get_field(comp)
+        return self._get_field_real(comp)
+
+    def _get_field_real(self, comp: int) -> np.ndarray:
         nx, ny, _ = self.spec.shape
         out = np.empty((self.nzl, ny, self.nxp), dtype=np.float32)
         self._chk(self.lib.dll.fdtd_get_field(self.handle, comp, _ptr(out), out.nbytes),
@@ -365,6 +393,9 @@ class HipEngine:
         return np.ascontiguousarray(out[..., :nx]) if self.pad_x else out
 
     def set_field(self, comp: int, arr: np.ndarray):
+        if self.twin is not None:
+            self.twin.set_field(comp, np.imag(arr))
+            arr = np.real(arr)
         a = _f32(arr)
         if self.pad_x:
             a = _f32(np.pad(a, ((0, 0), (0, 0), (0, self.pad_x))))
@@ -386,6 +417,11 @@ class HipEngine:
             self._chk(self.lib.dll.fdtd_get_monitor(self.handle, mid, _ptr(arr), arr.nbytes),
                       "fdtd_get_monitor")
             out[m.name] = (arr, (lo2, hi2))
+        if self.twin is not None:       # complex fields: a DFT value is re + i im; time monitors keep the real part
+            im = self.twin.monitor_data()
+            for m, mid, _ in self.mon_ids:
+                if mid >= 0 and m.kind == "dft":
+                    out[m.name] = (out[m.name][0] + 1j * im[m.name][0], out[m.name][1])
         return out
 
     def results(self) -> Dict[str, np.ndarray]:
@@ -393,6 +429,9 @@ class HipEngine:
         return {k: v[0] for k, v in self.monitor_data().items()}
 
     def close(self):
+        if getattr(self, "twin", None) is not None:
+            self.twin.close()
+            self.twin = None
         if getattr(self, "handle", None) and self.handle.value:
             self.lib.dll.fdtd_destroy(self.handle)
             self.handle = C.c_void_p()

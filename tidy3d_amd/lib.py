@@ -22,7 +22,7 @@ SYMBOLS = (
     "fdtd_set_media", "fdtd_set_material", "fdtd_set_pml", "fdtd_set_absorber", "fdtd_add_ade",
     "fdtd_add_point_source", "fdtd_add_tfsf", "fdtd_add_monitor", "fdtd_get_monitor",
     "fdtd_set_field", "fdtd_get_field", "fdtd_set_shutoff", "fdtd_comm_unique_id",
-    "fdtd_comm_init", "fdtd_run", "fdtd_get_stats", "fdtd_reset", "fdtd_set_option",
+    "fdtd_comm_init", "fdtd_run", "fdtd_run_bloch", "fdtd_get_stats", "fdtd_reset", "fdtd_set_option",
 )
 
 BC_PEC, BC_PMC, BC_PERIODIC, BC_NEIGHBOR = 0, 1, 2, 3
@@ -86,6 +86,7 @@ class FdtdLib:
         d.fdtd_comm_unique_id.argtypes = [vp]
         d.fdtd_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
         d.fdtd_run.argtypes = [vp, i64, PROGRESS_FN, vp]
+        d.fdtd_run_bloch.argtypes = [vp, vp, i64, vp, PROGRESS_FN, vp]
         d.fdtd_get_stats.argtypes = [vp, C.POINTER(FdtdStats)]
         d.fdtd_reset.argtypes = [vp]
         d.fdtd_set_option.argtypes = [vp, C.c_int, C.c_int]

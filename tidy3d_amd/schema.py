@@ -1059,6 +1059,39 @@ class Periodic(_Model):
 
 @_register
 @dataclass
+class BlochBoundary(_Model):
+    """ref boundary.py:55-160: F(r + L) = bloch_phase F(r), bloch_vec in units of 2 pi / L."""
+
+    bloch_vec: float = 0.0
+    name: Optional[str] = None
+
+    @property
+    def bloch_phase(self) -> complex:
+        """ref boundary.py:75-79."""
+        return complex(np.exp(1j * 2.0 * np.pi * self.bloch_vec))
+
+    @classmethod
+    def from_source(cls, source, domain_size: float, axis: int, medium=None):
+        """Bloch vector of an angled source at its centre frequency (ref boundary.py:81-160)."""
+        if axis == source.injection_axis:
+            raise SetupError("Bloch boundary axis must be orthogonal to the injection axis of 'source'.")
+        freq0 = source.source_time.freq0
+        eps = 1.0 if medium is None else complex(np.asarray(medium.eps_model(freq0)).ravel()[0])
+        from .constants import EPSILON_0, MU_0
+        kmag = float(np.real(freq0 * np.sqrt(eps * EPSILON_0 * MU_0)))
+        theta, phi = float(source.angle_theta), float(source.angle_phi)
+        if theta == 0:
+            return cls(bloch_vec=0)
+        if source.direction == "-":
+            theta += np.pi
+        k_local = [kmag * np.sin(theta) * np.cos(phi), kmag * np.sin(theta) * np.sin(phi), kmag * np.cos(theta)]
+        k_global = [k_local[0], k_local[1]]
+        k_global.insert(source.injection_axis, k_local[2])          # unpop_axis
+        return cls(bloch_vec=float(domain_size * k_global[axis]))
+
+
+@_register
+@dataclass
 class Boundary(_Model):
     """Pair of edges along one axis (ref boundary.py:492); default PML both (:520-531)."""
 
@@ -1070,6 +1103,10 @@ class Boundary(_Model):
         if any(per) and not all(per):
             raise SetupError("Periodic boundaries must be applied on both sides of an axis "
                              "(ref boundary.py:536-560).")
+        blo = [isinstance(e, BlochBoundary) for e in (self.plus, self.minus)]
+        if any(blo) and not (all(blo) and self.plus.bloch_vec == self.minus.bloch_vec):
+            raise SetupError("Bloch boundaries must be applied on both sides of an axis with the same "
+                             "Bloch vector (ref boundary.py:536-575).")
 
     @classmethod
     def pml(cls, num_layers: int = 12, parameters: PMLParams = None):
@@ -1101,6 +1138,17 @@ class Boundary(_Model):
     @classmethod
     def periodic(cls):
         return cls(plus=Periodic(), minus=Periodic())
+
+    @classmethod
+    def bloch(cls, bloch_vec: float):
+        """ref boundary.py:592-607."""
+        return cls(plus=BlochBoundary(bloch_vec=bloch_vec), minus=BlochBoundary(bloch_vec=bloch_vec))
+
+    @classmethod
+    def bloch_from_source(cls, source, domain_size: float, axis: int, medium=None):
+        """ref boundary.py:609-640."""
+        b = BlochBoundary.from_source(source, domain_size, axis, medium)
+        return cls(plus=b, minus=dataclasses.replace(b))
 
 
 @_register

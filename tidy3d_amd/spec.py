@@ -156,6 +156,9 @@ class SolverSpec:
     # Absorber layers (ref boundary.py:427): per axis (sigma at cell boundaries [N], sigma at cell
     # centres [N], n_lo, n_hi), sigma in units of 2 eps0/dt; None = no absorber (coeffs.damping_tables)
     absorber: Optional[List[Tuple[np.ndarray, np.ndarray, int, int]]] = None
+    # Bloch boundaries (ref boundary.py:55-79): phase advance 2 pi bloch_vec per axis across the domain,
+    # F(r + L_a) = exp(i bloch[a]) F(r), on axes whose bc is BC_PERIODIC; None = real fields
+    bloch: Optional[Tuple[float, float, float]] = None
     shutoff: float = 0.0                                # 0 disables the early stop
     decay_every: int = 0                                # 0 = never evaluate field decay
     decay_ref_step: int = 0                             # steps before this never shut off
