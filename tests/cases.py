@@ -249,8 +249,23 @@ def bloch_x_only(N=(16, 10, 8)):
     return _sim(N, bspec)
 
 
+def bloch_planewave(N=(12, 10, 24)):
+    """Oblique PlaneWave (current sheets with the Bloch phase gradient) onto a dielectric block, Bloch in
+    x and y from the source, CPML in z, flux and field monitors either side."""
+    pw = td.PlaneWave(center=(0, 0, -0.35), size=(td.inf, td.inf, 0), source_time=PULSE, direction="+",
+                      angle_theta=0.5, angle_phi=0.6, pol_angle=0.4)
+    size = tuple(n * DL for n in N)
+    bspec = td.BoundarySpec(x=td.Boundary.bloch_from_source(pw, size[0], 0), y=td.Boundary.bloch_from_source(pw, size[1], 1),
+                            z=td.Boundary.pml(num_layers=5))
+    structures = [td.Structure(geometry=td.Box(center=(0.1, 0, 0.25), size=(0.3, td.inf, 0.2)), medium=td.Medium(permittivity=3.0))]
+    monitors = [td.FluxMonitor(center=(0, 0, 0.45), size=(td.inf, td.inf, 0), freqs=[2.8e14, 3e14], name="T"),
+                td.FieldMonitor(center=(0, 0, -0.5), size=(td.inf, td.inf, 0), freqs=[3e14], name="r", colocate=False),
+                td.FieldTimeMonitor(center=(0, 0, 0.1), size=(0.2, 0.2, 0), name="t", interval=6, colocate=False)]
+    return _sim(N, bspec, structures, sources=[pw], monitors=monitors)
+
+
 CASES = {
-    "bloch_box": bloch_box, "bloch_xy_pml_z": bloch_xy_pml_z, "bloch_x_only": bloch_x_only,
+    "bloch_box": bloch_box, "bloch_planewave": bloch_planewave, "bloch_xy_pml_z": bloch_xy_pml_z, "bloch_x_only": bloch_x_only,
     "two_d": two_d, "one_d": one_d, "absorber_mix": absorber_mix, "absorber_odd_rows": absorber_odd_rows,
     "tfsf_box": tfsf_box, "planewave_periodic": planewave_periodic, "au_array": au_array,
     "pec_box": pec_box, "pec_box_vec": pec_box_vec, "periodic_box": periodic_box,

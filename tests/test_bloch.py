@@ -71,3 +71,77 @@ def test_empty_lattice_bands(bvec):
              and spec[i] > 0.05 * spec.max() and 0.3e14 < f[i] < 2.9e14]
     assert len(peaks) == len(want), (peaks, want)
     np.testing.assert_allclose(peaks, want, rtol=4e-3)
+
+
+F0 = 2e14
+NARROW = td.GaussianPulse(freq0=F0, fwidth=1e13)
+
+
+def _oblique(theta, phi, pol, direction="+", structures=(), Lx=0.9, Ly=0.0, dl=0.03, monitors=()):
+    zs = -1.0 if direction == "+" else 1.0
+    pw = td.PlaneWave(center=(0, 0, zs), size=(td.inf, td.inf, 0), source_time=NARROW, direction=direction,
+                      angle_theta=theta, angle_phi=phi, pol_angle=pol)
+    by = td.Boundary.bloch_from_source(pw, Ly, 1) if Ly > 0 else td.Boundary.periodic()
+    return td.Simulation(size=(Lx, Ly, 3.0), grid_spec=td.GridSpec.uniform(dl=dl), run_time=5e-13, shutoff=0,
+                         structures=list(structures), sources=[pw], monitors=list(monitors),
+                         boundary_spec=td.BoundarySpec(x=td.Boundary.bloch_from_source(pw, Lx, 0), y=by,
+                                                       z=td.Boundary.pml(num_layers=20)))
+
+
+@pytest.mark.parametrize("theta,phi,pol,direction", [(0.6, 0.7, 0.3, "+"), (0.5, 0.3, 1.2, "-")])
+def test_oblique_plane_wave_is_one_way_and_carries_cos_theta(theta, phi, pol, direction):
+    """1 W/um^2 along the propagation direction (ref source.py:1210-1214) = cos(theta) W/um^2 through the
+    injection plane, nothing behind the source; normalised data are those of a real-field run."""
+    sg = 1.0 if direction == "+" else -1.0
+    mons = [td.FluxMonitor(center=(0, 0, sg * 0.5), size=(td.inf, td.inf, 0), freqs=[F0], name="fwd"),
+            td.FluxMonitor(center=(0, 0, -sg * 1.3), size=(td.inf, td.inf, 0), freqs=[F0], name="behind")]
+    sd, disc, _ = solve(_oblique(theta, phi, pol, direction, Lx=0.9, Ly=0.6, dl=0.05, monitors=mons))
+    area = 0.9 * 0.6
+    assert sg * sd["fwd"].flux.values[0] == pytest.approx(np.cos(theta) * area, rel=1.5e-2)
+    assert abs(sd["behind"].flux.values[0]) < 1e-3 * np.cos(theta) * area
+
+
+@pytest.mark.parametrize("pol,name", [(0.0, "p"), (np.pi / 2, "s")])
+@pytest.mark.parametrize("theta", [0.5, float(np.arctan(2.0))])
+def test_fresnel_reflection_at_oblique_incidence(theta, pol, name):
+    """Half-space of index 2: R_s, R_p of the Fresnel formulas; theta = atan(2) is Brewster's angle, where
+    the p wave is not reflected at all.  Pins angle_theta / pol_angle (pol_angle = 0 is P, ref source.py:
+    931-944) and the refraction angle through the diffraction orders."""
+    eps = 4.0
+    sub = td.Structure(geometry=td.Box(center=(0, 0, 2.0), size=(td.inf, td.inf, 4.0)), medium=td.Medium(permittivity=eps))
+    mons = [td.FluxMonitor(center=(0, 0, -1.3), size=(td.inf, td.inf, 0), freqs=[F0], name="R"),
+            td.FluxMonitor(center=(0, 0, 0.8), size=(td.inf, td.inf, 0), freqs=[F0], name="T"),
+            td.DiffractionMonitor(center=(0, 0, -1.3), size=(td.inf, td.inf, 0), freqs=[F0], name="dR", normal_dir="-"),
+            td.DiffractionMonitor(center=(0, 0, 0.8), size=(td.inf, td.inf, 0), freqs=[F0], name="dT")]
+    sd, _, _ = solve(_oblique(theta, 0.0, pol, structures=[sub], monitors=mons))
+    inc = np.cos(theta) * 0.9
+    R, T = -sd["R"].flux.values[0] / inc, sd["T"].flux.values[0] / inc
+    ct, ct2 = np.cos(theta), np.sqrt(1 - (np.sin(theta) / 2) ** 2)
+    want = ((ct - 2 * ct2) / (ct + 2 * ct2)) ** 2 if name == "s" else ((2 * ct - ct2) / (2 * ct + ct2)) ** 2
+    assert R == pytest.approx(want, abs=4e-3)
+    assert R + T == pytest.approx(1.0, abs=8e-3)
+    # diffraction orders under Bloch boundaries: the specular order leaves at theta, the refracted one obeys Snell
+    dR, dT = sd["dR"], sd["dT"]
+    i0 = list(dR.orders_x).index(0)
+    assert dR.bloch_vecs[0] == pytest.approx(0.9 * F0 / C_0 * np.sin(theta), rel=1e-9)
+    assert dR.angles[0].values[i0, 0, 0] == pytest.approx(theta, abs=1e-9)
+    j0 = list(dT.orders_x).index(0)
+    assert np.sin(dT.angles[0].values[j0, 0, 0]) == pytest.approx(np.sin(theta) / 2, abs=1e-9)
+    assert dR.power.values.sum() / inc == pytest.approx(R, abs=2e-3)
+    a = np.abs(dR.amps.values[i0, 0, 0])                    # [s, p]
+    if want > 1e-3:
+        assert (a[0] > 50 * a[1]) if name == "s" else (a[1] > 50 * a[0])
+
+
+def test_angled_plane_wave_needs_matching_bloch_boundaries():
+    pw = td.PlaneWave(center=(0, 0, -1), size=(td.inf, td.inf, 0), source_time=NARROW, angle_theta=0.4)
+    kw = dict(size=(1, 1, 3), grid_spec=td.GridSpec.uniform(dl=0.1), run_time=1e-14, sources=[pw])
+    with pytest.raises(SetupError, match="Bloch"):
+        discretize(td.Simulation(boundary_spec=td.BoundarySpec(x=td.Boundary.periodic(), y=td.Boundary.periodic(),
+                                                               z=td.Boundary.pml()), **kw), n_steps=2)
+    with pytest.raises(SetupError, match="Bloch"):
+        discretize(td.Simulation(boundary_spec=td.BoundarySpec(x=td.Boundary.pml(), y=td.Boundary.periodic(),
+                                                               z=td.Boundary.pml()), **kw), n_steps=2)
+    with pytest.raises(SetupError, match="does not match"):
+        discretize(td.Simulation(boundary_spec=td.BoundarySpec(x=td.Boundary.bloch(0.05), y=td.Boundary.periodic(),
+                                                               z=td.Boundary.pml()), **kw), n_steps=2)

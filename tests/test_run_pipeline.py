@@ -132,3 +132,35 @@ def test_missing_library_fails_loudly(tmp_path):
     from tidy3d_amd.lib import load_library
     with pytest.raises(SolverLibraryError):
         load_library(str(tmp_path / "nope.so"))
+
+
+def test_bloch_run_end_to_end(emu_lib, tmp_path):
+    """run() with Bloch boundaries, an oblique PlaneWave, an Absorber face and a DiffractionMonitor: the
+    (Re, Im) solver pair behind the same entry point equals the complex-array oracle, and the result goes
+    through the .hdf5 layout."""
+    from oracle.fdtd_numpy import OracleFdtd
+    from tidy3d_amd.data import assemble
+    from tidy3d_amd.web import load
+    pw = td.PlaneWave(center=(0, 0, -0.3), size=(td.inf, td.inf, 0), source_time=PULSE, direction="+", angle_theta=0.4,
+                      angle_phi=0.3)
+    sim = _sim(size=(12 * DL, 8 * DL, 24 * DL), sources=[pw], shutoff=0,
+               structures=[td.Structure(geometry=td.Box(center=(0, 0, 0.2), size=(0.3, td.inf, 0.15)),
+                                        medium=td.Medium(permittivity=4.0))],
+               monitors=[td.DiffractionMonitor(center=(0, 0, 0.45), size=(td.inf, td.inf, 0), freqs=[3e14], name="orders"),
+                         td.FluxMonitor(center=(0, 0, 0.45), size=(td.inf, td.inf, 0), freqs=[3e14], name="T"),
+                         td.FieldTimeMonitor(center=(0, 0, 0.1), size=(0.2, 0, 0), name="t", interval=5)],
+               boundary_spec=td.BoundarySpec(x=td.Boundary.bloch_from_source(pw, 12 * DL, 0),
+                                             y=td.Boundary.bloch_from_source(pw, 8 * DL, 1),
+                                             z=td.Boundary(minus=td.PML(num_layers=6), plus=td.Absorber(num_layers=8))))
+    path = str(tmp_path / "bloch.hdf5")
+    sd = run(sim, task_name="bloch", verbose=False, lib=emu_lib, n_steps=200, path=path)
+    disc = D.discretize(sim, n_steps=200)
+    ref = assemble(disc, OracleFdtd(disc.spec).run())
+    assert sd["T"].flux.values == pytest.approx(ref["T"].flux.values, rel=1e-4)
+    assert np.allclose(sd["orders"].power.values, ref["orders"].power.values, rtol=1e-3, atol=1e-6 * ref["T"].flux.values.max())
+    assert np.allclose(sd["t"].Ex.values, ref["t"].Ex.values, rtol=0, atol=2e-4 * np.abs(ref["t"].Ex.values).max())
+    assert sd["orders"].bloch_vecs == pytest.approx((12 * DL * 3e14 / 299792458e6 * np.sin(0.4) * np.cos(0.3),
+                                                     8 * DL * 3e14 / 299792458e6 * np.sin(0.4) * np.sin(0.3)))
+    back = load(path)
+    assert np.array_equal(back["orders"].Etheta.values, sd["orders"].Etheta.values)
+    assert back.simulation.boundary_spec.x.plus.bloch_vec == sim.boundary_spec.x.plus.bloch_vec

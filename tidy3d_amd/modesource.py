@@ -186,7 +186,7 @@ def build_mode_source(disc, mt, src) -> Callable:
     disc.mode_planes[id(src)] = plane
 
     def fn(freqs):
-        return st.spectrum(tmesh, np.asarray(freqs, float), dt)
+        return st.spectrum(tmesh, np.asarray(freqs, float), dt, complex_fields=spec.bloch is not None)
     return fn
 
 

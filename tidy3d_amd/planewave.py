@@ -219,11 +219,124 @@ def make_tfsf(spec: SolverSpec, mt, lo, hi, p: int, direction: int, e: int, e_sc
     return t, int(face)
 
 
+def _rot(vec: np.ndarray, axis: int, angle: float) -> np.ndarray:
+    """Right-handed rotation about a coordinate axis (ref geometry/base.py rotate_points)."""
+    c, s = np.cos(angle), np.sin(angle)
+    a, b = [(1, 2), (2, 0), (0, 1)][axis]
+    out = np.array(vec, float)
+    out[a], out[b] = c * vec[a] - s * vec[b], s * vec[a] + c * vec[b]
+    return out
+
+
+def direction_vectors(src) -> Tuple[np.ndarray, np.ndarray]:
+    """(propagation unit vector, E polarisation unit vector) of an angled field source in x, y, z
+    (ref source.py:948-990 ``_dir_vector`` / ``_pol_vector``: built for injection along z, then moved
+    to the injection axis with unpop_axis; pol_angle = 0 is P polarisation)."""
+    p = int(src.injection_axis)
+    sgn = 1.0 if src.direction == "+" else -1.0
+    th, ph = float(src.angle_theta), float(src.angle_phi)
+    d_loc = sgn * np.array([np.cos(ph) * np.sin(th), np.sin(ph) * np.sin(th), np.cos(th)])
+    e_loc = _rot(_rot(_rot(np.array([1.0, 0.0, 0.0]), 2, float(src.pol_angle)), 1, th), 2, ph)
+
+    def unpop(v):
+        out = [v[0], v[1]]
+        out.insert(p, v[2])
+        return np.array(out)
+    return unpop(d_loc), unpop(e_loc)
+
+
+def build_angled_planewave(disc, mt, src) -> Callable:
+    """PlaneWave at oblique incidence (or any PlaneWave under Bloch boundaries), launched by a sheet of
+    electric and magnetic currents on its plane: the total-field/scattered-field legs of the plane
+    (``surface_legs``) fed with the incident plane wave of the centre frequency,
+
+        E_inc(r, t) = E0 exp(i k . (r - r0)) amp(t),   H_inc = k_hat x E_inc / eta,   |k| = 2 pi f0 n / c,
+
+    evaluated at every leg's own Yee location (E at t_n, H at t_n + dt/2).  Like the reference's angled
+    sources the in-plane wave vector is fixed by the centre frequency (ref boundary.py:84-88: "only the
+    frequency components near the center frequency will exhibit angled incidence at the expected angle"),
+    which is also what the Bloch boundaries impose.  Amplitude as for normal incidence: 1 W/um^2 along
+    the propagation direction for a unit-amplitude source time (ref source.py:1210-1214)."""
+    from .spec import BC_PERIODIC, PointSourceSet
+    sim, spec, tmesh = disc.sim, disc.spec, disc.tmesh
+    st = src.source_time
+    p = int(src.injection_axis)
+    u, v = [a for a in range(3) if a != p]
+    direction = 1 if src.direction == "+" else -1
+    b = spec.boundaries
+    for a in (u, v):
+        if np.isfinite(src.size[a]) and src.size[a] < (b[a][-1] - b[a][0]) * 0.999 and spec.shape[a] > 1:
+            raise Tidy3dNotImplementedError("an angled PlaneWave must span the whole cross-section of the domain")
+    if spec.media[1].poles or spec.media[1].sigma:
+        raise Tidy3dNotImplementedError("plane-wave injection needs a lossless, dispersionless background")
+    eps_bg = float(np.real(spec.media[1].eps_inf))
+    n_bg = np.sqrt(eps_bg)
+    k_hat, e_hat = direction_vectors(src)
+    kvec = 2 * np.pi * st.freq0 * n_bg / C_0 * k_hat
+    # the transverse wave vector must be what the boundaries impose (ref simulation.py:2309-2389)
+    for a in (u, v):
+        if spec.shape[a] == 1 and sim.size[a] == 0:
+            continue
+        L = b[a][-1] - b[a][0]
+        if spec.bc[a][0] == BC_PERIODIC:
+            want = kvec[a] * L
+            have = spec.bloch[a] if spec.bloch is not None else 0.0
+            if abs(np.angle(np.exp(1j * (want - have)))) > 1e-3:
+                raise SetupError(
+                    f"The Bloch vector along axis {a} does not match the angled PlaneWave: expected bloch_vec = "
+                    f"{want / (2 * np.pi):.6g} (+ integer), see BlochBoundary.from_source (ref boundary.py:81).")
+        elif abs(kvec[a]) > 1e-12:
+            raise SetupError("An angled PlaneWave needs Bloch boundaries along the axes in which it is tilted "
+                             "(ref simulation.py:2309-2389).")
+    e_unit = np.sqrt(2 * ETA_0 / n_bg)                   # 1 W/um^2 along k for amplitude 1
+    E0 = e_unit * e_hat
+    H0 = np.cross(k_hat, E0) * n_bg / ETA_0
+    big = 10 ** 9
+    lo, hi = [-big] * 3, [big] * 3
+    face = int(np.argmin(np.abs(b[p] - src.center[p])))
+    if direction > 0:
+        lo[p] = face
+    else:
+        hi[p] = face
+    legs = surface_legs(spec, mt, lo, hi, (u, v), (u, v))
+    r0 = np.array([float(c) if np.isfinite(c) else 0.0 for c in src.center])
+    r0[p] = b[p][face]
+    amp = {c: E0[c] for c in (u, v)}
+    amp.update({3 + c: H0[c] for c in (u, v)})
+    comps, ijks, ws = [], [], []
+    for key in ("e", "h"):
+        comp, ijk, w, nbc, nbi = legs[key]
+        val = np.zeros(len(w), complex)
+        for c in np.unique(nbc):
+            m = nbc == c
+            xs = spec.yee_coords(int(c))
+            phase = sum(kvec[a] * (xs[a][nbi[m, a]] - r0[a]) for a in range(3))
+            val[m] = amp[int(c)] * np.exp(1j * phase)
+        keep = val != 0
+        comps.append(comp[keep])
+        ijks.append(ijk[keep])
+        ws.append(w[keep] * val[keep])
+    comp = np.concatenate(comps).astype(np.int32)
+    ijk = np.concatenate(ijks).astype(np.int32)
+    w = np.concatenate(ws)
+    dt = spec.dt
+    spec.sources.append(PointSourceSet(
+        comp=comp, ijk=ijk, w_re=w.real.copy(), w_im=w.imag.copy(),
+        wave_e=np.asarray(st.amp_time(tmesh + dt / 2), complex),
+        wave_h=np.asarray(st.amp_time(tmesh), complex), name=getattr(src, "name", None) or "PlaneWave"))
+
+    def fn(freqs):
+        return st.spectrum(tmesh, np.asarray(freqs, float), dt, complex_fields=spec.bloch is not None)
+    return fn
+
+
 def build_planewave(disc, mt, src) -> Callable:
     """Discretise a PlaneWave or TFSF source; returns its normalisation spectrum function."""
     sim, spec = disc.sim, disc.spec
+    if isinstance(src, td.PlaneWave) and (src.angle_theta != 0.0 or spec.bloch is not None):
+        return build_angled_planewave(disc, mt, src)
     if src.angle_theta != 0.0:
-        raise Tidy3dNotImplementedError("angled plane waves (angle_theta != 0) are not supported yet")
+        raise Tidy3dNotImplementedError("angled TFSF sources (angle_theta != 0) are not supported")
     is_box = isinstance(src, td.TFSF)
     p = int(src.injection_axis)
     direction = 1 if src.direction == "+" else -1

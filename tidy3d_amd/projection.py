@@ -309,16 +309,22 @@ def diffraction(disc, plan, raw, norm) -> DiffractionData:
     eps_f = np.array([complex(np.asarray(medium.eps_model(float(f))).ravel()[0]) for f in freqs])
     n_f = np.real(np.sqrt(eps_f))
     n_max = float(np.max(n_f * freqs)) / C_0                       # 1 / shortest wavelength in the medium
-    mx = int(np.floor(Lu * n_max + 1e-9)) if Lu > 0 else 0
-    my = int(np.floor(Lv * n_max + 1e-9)) if Lv > 0 else 0
-    ox, oy = np.arange(-mx, mx + 1), np.arange(-my, my + 1)
+    # Bloch vectors in units of 2 pi / size (ref monitor_data.py:2746-2751): orders are m + bloch_vec
+    bl = disc.spec.bloch if disc.spec.bloch is not None else (0.0, 0.0, 0.0)
+    bu, bv = bl[u] / (2 * np.pi), bl[v] / (2 * np.pi)
+
+    def order_range(L, bvec):
+        if L <= 0:
+            return np.arange(0, 1)
+        return np.arange(int(np.ceil(-L * n_max - bvec - 1e-9)), int(np.floor(L * n_max - bvec + 1e-9)) + 1)
+    ox, oy = order_range(Lu, bu), order_range(Lv, bv)
     area = (Lu if Lu > 0 else 1.0) * (Lv if Lv > 0 else 1.0)
     shape = (len(ox), len(oy), len(freqs))
     e_th, e_ph = np.zeros(shape, complex), np.zeros(shape, complex)
     for i_f, f in enumerate(freqs):
         lam = C_0 / (f * n_f[i_f])
-        UX = (ox[:, None] * lam / Lu if Lu > 0 else np.zeros((1, 1))) + np.zeros((len(ox), len(oy)))
-        UY = (oy[None, :] * lam / Lv if Lv > 0 else np.zeros((1, 1))) + np.zeros((len(ox), len(oy)))
+        UX = ((ox[:, None] + bu) * lam / Lu if Lu > 0 else np.zeros((1, 1))) + np.zeros((len(ox), len(oy)))
+        UY = ((oy[None, :] + bv) * lam / Lv if Lv > 0 else np.zeros((1, 1))) + np.zeros((len(ox), len(oy)))
         ok = (UX ** 2 + UY ** 2) < 1.0 - 1e-9
         if not ok.any():
             continue
@@ -346,5 +352,6 @@ def diffraction(disc, plan, raw, norm) -> DiffractionData:
     coords = {"orders_x": ox, "orders_y": oy, "f": freqs}
     comps = {"Er": np.zeros(shape, complex), "Etheta": e_th, "Ephi": e_ph, "Hr": np.zeros(shape, complex),
              "Htheta": -e_ph / eta, "Hphi": e_th / eta}
-    return DiffractionData(monitor=mon, sim_size=(Lu, Lv), bloch_vecs=(0.0, 0.0), medium=medium, structure_index=s_index,
+    return DiffractionData(monitor=mon, sim_size=(Lu, Lv), bloch_vecs=(float(bu), float(bv)), medium=medium,
+                           structure_index=s_index,
                            **{k: DataArray(a, coords) for k, a in comps.items()})

@@ -1197,12 +1197,15 @@ class _SourceTime(_Model):
         w = num_fwidth * self.fwidth
         return (max(0.0, self.freq0 - w), self.freq0 + w)
 
-    def spectrum(self, times, freqs, dt):
+    def spectrum(self, times, freqs, dt, complex_fields: bool = False):
         """dt/sqrt(2 pi) * sum_n Re[amp(t_n)] e^{+i 2 pi f t_n}, times cut where the relative
-        amplitude is below DFT_CUTOFF (ref time.py:46-105)."""
+        amplitude is below DFT_CUTOFF (ref time.py:46-105).  ``complex_fields`` (simulations with Bloch
+        boundaries): the complex amplitude itself is injected, so the sum runs over amp(t_n), which
+        is twice the positive-frequency part of the real signal; data normalised by it equal those of a
+        real-field run."""
         times = np.asarray(times, float)
         freqs = np.atleast_1d(np.asarray(freqs, float))
-        amps = np.real(self.amp_time(times))
+        amps = self.amp_time(times) if complex_fields else np.real(self.amp_time(times))
         if np.all(amps == 0.0):
             return np.zeros(len(freqs), complex)
         rel = np.where(np.abs(amps) / np.amax(np.abs(amps)) > DFT_CUTOFF)[0]

@@ -9,7 +9,7 @@ from .discretize import current_source
 from .exceptions import Tidy3dNotImplementedError
 
 
-def _spectrum_fn(src, tmesh, dt):
+def _spectrum_fn(src, tmesh, dt, cplx=False):
     """Normalisation spectrum: the DTFT (ref time.py:46-105) of the samples that are actually
     injected.  Currents enter the E-update at t_n + dt/2, so the time axis is shifted by dt/2;
     monitor DFTs use the true sample times as well, hence no spurious frequency-dependent phase
@@ -17,7 +17,7 @@ def _spectrum_fn(src, tmesh, dt):
     st = src.source_time
 
     def fn(freqs):
-        return st.spectrum(tmesh + dt / 2, np.asarray(freqs, float), dt)
+        return st.spectrum(tmesh + dt / 2, np.asarray(freqs, float), dt, complex_fields=cplx)
     return fn
 
 
@@ -29,7 +29,7 @@ def build_sources(disc, mt) -> None:
             src.fail()
         if isinstance(src, (td.PointDipole, td.UniformCurrentSource)):
             spec.sources.append(current_source(spec, mt, src, tmesh))
-            disc.source_norm.append(_spectrum_fn(src, tmesh, spec.dt))
+            disc.source_norm.append(_spectrum_fn(src, tmesh, spec.dt, spec.bloch is not None))
         elif isinstance(src, (td.PlaneWave, td.TFSF)):
             from .planewave import build_planewave
             disc.source_norm.append(build_planewave(disc, mt, src))
