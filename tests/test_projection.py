@@ -74,3 +74,50 @@ def test_cartesian_and_kspace_agree_with_the_angular_projection():
         np.testing.assert_allclose(getattr(k, name).values[0, 0, 0, 0], va, rtol=1e-9)
     assert np.isnan(k.Etheta.values[1, 0, 0, 0])              # ux = 2: not a propagating direction
     assert abs(a.Etheta.values[0, 0, 0, 0]) > 0
+
+
+def test_exact_projection_reproduces_the_simulated_field_and_tends_to_the_far_field():
+    """far_field_approx=False (ref field_projection.py:831-1010, exact Green's function): projected to a
+    point that lies INSIDE the simulation domain (outside the near-field box) the result must be the field
+    the FDTD run itself has there; at a large distance it must agree with the far-field approximation."""
+    dl = 1.0 / 20
+    f0 = 3e14
+    pulse = td.GaussianPulse(freq0=f0, fwidth=f0 / 6)
+    # observation points in Cartesian form: x = 0.3, 0.45 at y = 0.2 on the plane z = 0.8 (local origin = centre)
+    sim = td.Simulation(
+        size=(2.2, 2.2, 2.2), grid_spec=td.GridSpec.uniform(dl=dl), run_time=40 / f0,
+        sources=[td.PointDipole(center=(0, 0, 0), source_time=pulse, polarization="Ex"),
+                 td.PointDipole(center=(0.1, -0.1, 0.05), source_time=pulse, polarization="Ez")],
+        monitors=[td.FieldProjectionCartesianMonitor(center=(0, 0, 0), size=(1.0, 1.0, 1.0), freqs=[f0], x=[0.3, 0.45],
+                                                     y=[0.2], proj_distance=0.8, proj_axis=2, far_field_approx=False,
+                                                     name="near"),
+                  td.FieldMonitor(center=(0.375, 0.2, 0.8), size=(0.15, 0, 0), freqs=[f0], name="probe"),
+                  td.FieldProjectionAngleMonitor(center=(0, 0, 0), size=(1.0, 1.0, 1.0), freqs=[f0], theta=[0.7, 1.9],
+                                                 phi=[0.4], proj_distance=3e3, far_field_approx=False, name="exact"),
+                  td.FieldProjectionAngleMonitor(center=(0, 0, 0), size=(1.0, 1.0, 1.0), freqs=[f0], theta=[0.7, 1.9],
+                                                 phi=[0.4], proj_distance=3e3, name="far")],
+        boundary_spec=td.BoundarySpec.all_sides(td.PML(num_layers=8)), shutoff=1e-5)
+    disc = discretize(sim)
+    sd = assemble(disc, OracleFdtd(disc.spec).run())
+    near, probe = sd["near"], sd["probe"]
+    assert near.Etheta.dims == ("x", "y", "z", "f")
+    for ix, x in enumerate((0.3, 0.45)):
+        pt = np.array([x, 0.2, 0.8])
+        r = np.linalg.norm(pt)
+        th, ph = np.arccos(pt[2] / r), np.arctan2(pt[1], pt[0])
+        unit = {"r": (np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)),
+                "theta": (np.cos(th) * np.cos(ph), np.cos(th) * np.sin(ph), -np.sin(th)),
+                "phi": (-np.sin(ph), np.cos(ph), 0.0)}
+        for F in "EH":
+            cart = np.array([np.interp(x, np.asarray(probe[F + c].coords["x"]), probe[F + c].values[:, 0, 0, 0].real)
+                             + 1j * np.interp(x, np.asarray(probe[F + c].coords["x"]), probe[F + c].values[:, 0, 0, 0].imag)
+                             for c in "xyz"])
+            scale = np.linalg.norm(cart)
+            for name, uvec in unit.items():
+                got = getattr(near, F + name).values[ix, 0, 0, 0]
+                assert abs(got - np.dot(uvec, cart)) < 0.03 * scale, (F, name, got, np.dot(uvec, cart))
+    ex, fa = sd["exact"], sd["far"]
+    for comp in ("Etheta", "Ephi", "Htheta", "Hphi"):
+        a, b = getattr(ex, comp).values, getattr(fa, comp).values
+        assert np.max(np.abs(a - b)) < 2e-3 * np.max(np.abs(b)), comp
+    assert np.max(np.abs(ex.Er.values)) < 1e-2 * np.max(np.abs(ex.Etheta.values))

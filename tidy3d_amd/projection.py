@@ -58,24 +58,14 @@ def _trapz2(f: np.ndarray, u: np.ndarray, v: np.ndarray) -> complex:
     return _trap(g, v, axis=0) if len(v) > 1 else g[0]
 
 
-def _far_fields(disc, plan, raw, norm, theta: np.ndarray, phi: np.ndarray, medium=None, f_sel=None):
-    """E_theta, E_phi (without the propagation factor) at the direction PAIRS (theta[n], phi[n]), summed
-    over the monitor's surfaces: arrays [n, n_freq]; also k and eta per frequency.  ``f_sel`` restricts
-    the evaluation to some frequency indices (the other columns stay 0)."""
+def _surface_currents(disc, plan, raw, norm, medium):
+    """Per surface of the monitor: (axis, u, v, sample points [3 arrays], J {axis: (u, v, f)}, M {...}):
+    equivalent currents J = n x H, M = -n x E (ref field_projection.py:231-278) on a regular lattice of
+    10 points per wavelength clipped to the simulation domain (ref :280-349)."""
     from .data import FieldData, _field_container, interp_axis
     mon, sim, spec = plan.monitor, disc.sim, disc.spec
     freqs = np.asarray(mon.freqs, float)
-    if medium is None:
-        medium = mon.medium if mon.medium is not None else sim.medium
-    origin = mon.local_origin
     names = "xyz"
-    eps_f = np.array([complex(np.asarray(medium.eps_model(float(f))).ravel()[0]) for f in freqs])
-    k_f = 2 * np.pi * freqs * np.sqrt(eps_f) / C_0
-    eta_f = ETA_0 / np.sqrt(eps_f)
-    st, ct, sp_, cp = np.sin(theta), np.cos(theta), np.sin(phi), np.cos(phi)
-    r_hat = np.stack([st * cp, st * sp_, ct])                       # (3, n)
-    e_t = np.zeros((len(theta), len(freqs)), complex)
-    e_p = np.zeros_like(e_t)
     for fp, (sname, box, axis, sign) in zip(plan.fields, flux_surfaces(mon)):
         class _M:
             pass
@@ -84,8 +74,6 @@ def _far_fields(disc, plan, raw, norm, theta: np.ndarray, phi: np.ndarray, mediu
         fd = _field_container(FieldData, m, spec, fp, raw[fp.spec_name], "f", freqs, sim.center,
                               np.complex128).normalize(norm)
         u, v = [a for a in range(3) if a != axis]
-        # regular sample lattice on the surface: 10 points per wavelength in the projection medium at the
-        # highest frequency, clipped to the simulation domain (ref field_projection.py:292-343)
         n_idx = float(np.real(np.sqrt(complex(np.asarray(medium.eps_model(float(freqs.max()))).ravel()[0]))))
         wavelength = C_0 / float(freqs.max()) / n_idx
         pts = [None, None, None]
@@ -110,6 +98,29 @@ def _far_fields(disc, plan, raw, norm, theta: np.ndarray, phi: np.ndarray, mediu
             return np.take(arr, 0, axis=axis)                         # (u, v, f) in x, y, z order
         J = {u: signs[0] * sampled("H" + cv), v: signs[1] * sampled("H" + cu)}
         M = {v: signs[0] * sampled("E" + cu), u: signs[1] * sampled("E" + cv)}
+        yield axis, u, v, pts, J, M
+
+
+def _medium_params(mon, sim, medium, freqs):
+    if medium is None:
+        medium = mon.medium if mon.medium is not None else sim.medium
+    eps_f = np.array([complex(np.asarray(medium.eps_model(float(f))).ravel()[0]) for f in freqs])
+    return medium, eps_f, 2 * np.pi * freqs * np.sqrt(eps_f) / C_0, ETA_0 / np.sqrt(eps_f)
+
+
+def _far_fields(disc, plan, raw, norm, theta: np.ndarray, phi: np.ndarray, medium=None, f_sel=None):
+    """E_theta, E_phi (without the propagation factor) at the direction PAIRS (theta[n], phi[n]), summed
+    over the monitor's surfaces: arrays [n, n_freq]; also k and eta per frequency.  ``f_sel`` restricts
+    the evaluation to some frequency indices (the other columns stay 0)."""
+    mon, sim = plan.monitor, disc.sim
+    freqs = np.asarray(mon.freqs, float)
+    medium, eps_f, k_f, eta_f = _medium_params(mon, sim, medium, freqs)
+    origin = mon.local_origin
+    st, ct, sp_, cp = np.sin(theta), np.cos(theta), np.sin(phi), np.cos(phi)
+    r_hat = np.stack([st * cp, st * sp_, ct])                       # (3, n)
+    e_t = np.zeros((len(theta), len(freqs)), complex)
+    e_p = np.zeros_like(e_t)
+    for axis, u, v, pts, J, M in _surface_currents(disc, plan, raw, norm, medium):
         rel = [pts[a] - origin[a] for a in range(3)]
         for i_f in (range(len(freqs)) if f_sel is None else f_sel):
             k, eta = k_f[i_f], eta_f[i_f]
@@ -130,6 +141,65 @@ def _far_fields(disc, plan, raw, norm, theta: np.ndarray, phi: np.ndarray, mediu
     return e_t, e_p, k_f, eta_f
 
 
+def _exact_fields(disc, plan, raw, norm, points: np.ndarray, medium=None):
+    """E and H (Cartesian, [3, n_points, n_freq]) at the observation ``points`` [n, 3] (relative to the
+    monitor's local origin) from the homogeneous-medium Green's function without the far-field
+    approximation (ref field_projection.py:831-1010), e^{-i w t} convention:
+
+        E = i w mu int [G J + (1/k^2) grad grad G . J] dS - int grad G x M dS
+        H = i w eps int [G M + (1/k^2) grad grad G . M] dS + int grad G x J dS
+        G = exp(i k R) / (4 pi R),  grad G = R_hat G',  grad grad G = R_hat R_hat G'' + (1 - R_hat R_hat) G' / R."""
+    from .constants import EPSILON_0, MU_0
+    mon, sim = plan.monitor, disc.sim
+    freqs = np.asarray(mon.freqs, float)
+    medium, eps_f, k_f, eta_f = _medium_params(mon, sim, medium, freqs)
+    origin = np.asarray(mon.local_origin, float)
+    E = np.zeros((3, len(points), len(freqs)), complex)
+    H = np.zeros_like(E)
+    for axis, u, v, pts, J, M in _surface_currents(disc, plan, raw, norm, medium):
+        src = np.zeros((len(pts[u]), len(pts[v]), 3))
+        src[..., u], src[..., v], src[..., axis] = pts[u][:, None], pts[v][None, :], pts[axis][0]
+        zero = np.zeros_like(J[u][:, :, 0])
+        for i_f, f in enumerate(freqs):
+            k, w = k_f[i_f], 2 * np.pi * f
+            Jc = [zero, zero, zero]
+            Mc = [zero, zero, zero]
+            for a in (u, v):
+                Jc[a], Mc[a] = J[a][:, :, i_f], M[a][:, :, i_f]
+            for n, pt in enumerate(points):
+                Rv = (pt + origin)[None, None, :] - src
+                R = np.sqrt(np.sum(Rv ** 2, axis=-1))
+                Rh = [Rv[..., a] / R for a in range(3)]
+                G = np.exp(1j * k * R) / (4 * np.pi * R)
+                G1 = G * (1j * k - 1.0 / R)
+                G2 = G1 * (1j * k - 1.0 / R) + G / R ** 2
+                for cur, oth, out, oth_out, const in ((Jc, Mc, E, H, 1j * w * MU_0), (Mc, Jc, H, E, 1j * w * EPSILON_0 * eps_f[i_f])):
+                    rd = Rh[0] * cur[0] + Rh[1] * cur[1] + Rh[2] * cur[2]
+                    for a in range(3):
+                        pot = G * cur[a] + (Rh[a] * rd * G2 + (cur[a] - Rh[a] * rd) * G1 / R) / k ** 2
+                        out[a, n, i_f] += const * _trapz2(pot, pts[u], pts[v])
+                # curl terms: E -= int grad G x M,  H += int grad G x J
+                for cur, out, sgn in ((Mc, E, -1.0), (Jc, H, 1.0)):
+                    cx = [Rh[1] * cur[2] - Rh[2] * cur[1], Rh[2] * cur[0] - Rh[0] * cur[2], Rh[0] * cur[1] - Rh[1] * cur[0]]
+                    for a in range(3):
+                        out[a, n, i_f] += sgn * _trapz2(G1 * cx[a], pts[u], pts[v])
+    return E, H
+
+
+def _package_exact(cls, mon, E, H, theta, phi, shape, coords):
+    """Spherical components (about the local origin) of Cartesian E, H [3, n, f]."""
+    from .data import DataArray
+    st, ct, sp_, cp = np.sin(theta)[:, None], np.cos(theta)[:, None], np.sin(phi)[:, None], np.cos(phi)[:, None]
+
+    def sph(F):
+        return (F[0] * st * cp + F[1] * st * sp_ + F[2] * ct, F[0] * ct * cp + F[1] * ct * sp_ - F[2] * st,
+                -F[0] * sp_ + F[1] * cp)
+    er, et, ep = sph(E)
+    hr, ht, hp = sph(H)
+    comps = {"Er": er, "Etheta": et, "Ephi": ep, "Hr": hr, "Htheta": ht, "Hphi": hp}
+    return cls(monitor=mon, **{k: DataArray(np.asarray(a).reshape(shape), coords) for k, a in comps.items()})
+
+
 def _package(cls, mon, e_t, e_p, k_f, eta_f, r, shape, coords):
     """Apply the propagation factor -i k exp(i k r) / (4 pi r) (ref monitor_data.py:2170-2178) per
     point and frequency and box the six spherical components."""
@@ -146,9 +216,14 @@ def project_angle(disc, plan, raw, norm) -> FieldProjectionAngleData:
     freqs = np.asarray(mon.freqs, float)
     theta, phi = np.asarray(mon.theta, float), np.asarray(mon.phi, float)
     T, P = np.meshgrid(theta, phi, indexing="ij")
+    coords = {"r": np.atleast_1d(float(mon.proj_distance)), "theta": theta, "phi": phi, "f": freqs}
+    if not mon.far_field_approx:
+        t, p_, r0 = T.ravel(), P.ravel(), float(mon.proj_distance)
+        pts = r0 * np.stack([np.sin(t) * np.cos(p_), np.sin(t) * np.sin(p_), np.cos(t)], axis=1)
+        E, H = _exact_fields(disc, plan, raw, norm, pts)
+        return _package_exact(FieldProjectionAngleData, mon, E, H, t, p_, (1, len(theta), len(phi), len(freqs)), coords)
     e_t, e_p, k_f, eta_f = _far_fields(disc, plan, raw, norm, T.ravel(), P.ravel())
     r = np.full(T.size, float(mon.proj_distance))
-    coords = {"r": np.atleast_1d(float(mon.proj_distance)), "theta": theta, "phi": phi, "f": freqs}
     return _package(FieldProjectionAngleData, mon, e_t, e_p, k_f, eta_f, r, (1, len(theta), len(phi), len(freqs)), coords)
 
 
@@ -172,8 +247,11 @@ def project_cartesian(disc, plan, raw, norm) -> FieldProjectionCartesianData:
     r = np.sqrt(X ** 2 + Y ** 2 + Z ** 2).ravel()
     theta = np.arccos(Z.ravel() / r)
     phi = np.arctan2(Y.ravel(), X.ravel())
-    e_t, e_p, k_f, eta_f = _far_fields(disc, plan, raw, norm, theta, phi)
     coords = {"x": loc[0], "y": loc[1], "z": loc[2], "f": freqs}
+    if not mon.far_field_approx:
+        E, H = _exact_fields(disc, plan, raw, norm, np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1))
+        return _package_exact(FieldProjectionCartesianData, mon, E, H, theta, phi, X.shape + (len(freqs),), coords)
+    e_t, e_p, k_f, eta_f = _far_fields(disc, plan, raw, norm, theta, phi)
     return _package(FieldProjectionCartesianData, mon, e_t, e_p, k_f, eta_f, r, X.shape + (len(freqs),), coords)
 
 
