@@ -245,32 +245,84 @@ def direction_vectors(src) -> Tuple[np.ndarray, np.ndarray]:
     return unpop(d_loc), unpop(e_loc)
 
 
-def build_angled_planewave(disc, mt, src) -> Callable:
-    """PlaneWave at oblique incidence (or any PlaneWave under Bloch boundaries), launched by a sheet of
-    electric and magnetic currents on its plane: the total-field/scattered-field legs of the plane
-    (``surface_legs``) fed with the incident plane wave of the centre frequency,
-
-        E_inc(r, t) = E0 exp(i k . (r - r0)) amp(t),   H_inc = k_hat x E_inc / eta,   |k| = 2 pi f0 n / c,
-
-    evaluated at every leg's own Yee location (E at t_n, H at t_n + dt/2).  Like the reference's angled
-    sources the in-plane wave vector is fixed by the centre frequency (ref boundary.py:84-88: "only the
-    frequency components near the center frequency will exhibit angled incidence at the expected angle"),
-    which is also what the Bloch boundaries impose.  Amplitude as for normal incidence: 1 W/um^2 along
-    the propagation direction for a unit-amplitude source time (ref source.py:1210-1214)."""
-    from .spec import BC_PERIODIC, PointSourceSet
-    sim, spec, tmesh = disc.sim, disc.spec, disc.tmesh
+def _sheet_source(disc, mt, src, incident, name: str) -> Callable:
+    """Launch an incident field from the source plane with a sheet of electric and magnetic currents:
+    the total-field/scattered-field legs of the plane (``surface_legs``; total field on the side the
+    source points to) weighted with ``incident(comp, x, y, z)`` — the complex amplitude of the incident
+    E (comp 0-2) or H (comp 3-5) component at the leg's own Yee location — times the source time
+    (E at t_n, H at t_n + dt/2).  Points outside the source rectangle carry nothing."""
+    from .spec import PointSourceSet
+    spec, tmesh = disc.spec, disc.tmesh
     st = src.source_time
     p = int(src.injection_axis)
     u, v = [a for a in range(3) if a != p]
-    direction = 1 if src.direction == "+" else -1
+    b = spec.boundaries
+    big = 10 ** 9
+    lo, hi = [-big] * 3, [big] * 3
+    face = int(np.argmin(np.abs(b[p] - src.center[p])))
+    if src.direction == "+":
+        lo[p] = face
+    else:
+        hi[p] = face
+    legs = surface_legs(spec, mt, lo, hi, (u, v), (u, v))
+    comps, ijks, ws = [], [], []
+    for key in ("e", "h"):
+        comp, ijk, w, nbc, nbi = legs[key]
+        val = np.zeros(len(w), complex)
+        for c in np.unique(nbc):
+            m = nbc == c
+            xs = spec.yee_coords(int(c))
+            pos = [xs[a][nbi[m, a]] for a in range(3)]
+            inside = np.ones(m.sum(), bool)
+            for a in (u, v):
+                if np.isfinite(src.size[a]) and spec.shape[a] > 1:
+                    inside &= np.abs(pos[a] - src.center[a]) <= src.size[a] / 2
+            val[m] = np.where(inside, incident(int(c), *pos), 0.0)
+        keep = val != 0
+        comps.append(comp[keep])
+        ijks.append(ijk[keep])
+        ws.append(w[keep] * val[keep])
+    comp = np.concatenate(comps).astype(np.int32)
+    ijk = np.concatenate(ijks).astype(np.int32)
+    w = np.concatenate(ws)
+    dt = spec.dt
+    spec.sources.append(PointSourceSet(
+        comp=comp, ijk=ijk, w_re=w.real.copy(), w_im=w.imag.copy(),
+        wave_e=np.asarray(st.amp_time(tmesh + dt / 2), complex),
+        wave_h=np.asarray(st.amp_time(tmesh), complex), name=getattr(src, "name", None) or name))
+
+    def fn(freqs):
+        return st.spectrum(tmesh, np.asarray(freqs, float), dt, complex_fields=spec.bloch is not None)
+    return fn
+
+
+def _background_index(spec: SolverSpec) -> float:
+    if spec.media[1].poles or spec.media[1].sigma:
+        raise Tidy3dNotImplementedError("field-source injection needs a lossless, dispersionless background")
+    return float(np.sqrt(np.real(spec.media[1].eps_inf)))
+
+
+def build_angled_planewave(disc, mt, src) -> Callable:
+    """PlaneWave at oblique incidence (or any PlaneWave under Bloch boundaries): the sheet source of
+    ``_sheet_source`` fed with the incident plane wave of the centre frequency,
+
+        E_inc(r, t) = E0 exp(i k . (r - r0)) amp(t),   H_inc = k_hat x E_inc / eta,   |k| = 2 pi f0 n / c.
+
+    Like the reference's angled sources the in-plane wave vector is fixed by the centre frequency (ref
+    boundary.py:84-88: "only the frequency components near the center frequency will exhibit angled
+    incidence at the expected angle"), which is also what the Bloch boundaries impose.  Amplitude as for
+    normal incidence: 1 W/um^2 along the propagation direction for a unit-amplitude source time (ref
+    source.py:1210-1214)."""
+    from .spec import BC_PERIODIC
+    sim, spec = disc.sim, disc.spec
+    st = src.source_time
+    p = int(src.injection_axis)
+    u, v = [a for a in range(3) if a != p]
     b = spec.boundaries
     for a in (u, v):
         if np.isfinite(src.size[a]) and src.size[a] < (b[a][-1] - b[a][0]) * 0.999 and spec.shape[a] > 1:
             raise Tidy3dNotImplementedError("an angled PlaneWave must span the whole cross-section of the domain")
-    if spec.media[1].poles or spec.media[1].sigma:
-        raise Tidy3dNotImplementedError("plane-wave injection needs a lossless, dispersionless background")
-    eps_bg = float(np.real(spec.media[1].eps_inf))
-    n_bg = np.sqrt(eps_bg)
+    n_bg = _background_index(spec)
     k_hat, e_hat = direction_vectors(src)
     kvec = 2 * np.pi * st.freq0 * n_bg / C_0 * k_hat
     # the transverse wave vector must be what the boundaries impose (ref simulation.py:2309-2389)
@@ -288,46 +340,61 @@ def build_angled_planewave(disc, mt, src) -> Callable:
         elif abs(kvec[a]) > 1e-12:
             raise SetupError("An angled PlaneWave needs Bloch boundaries along the axes in which it is tilted "
                              "(ref simulation.py:2309-2389).")
-    e_unit = np.sqrt(2 * ETA_0 / n_bg)                   # 1 W/um^2 along k for amplitude 1
-    E0 = e_unit * e_hat
+    E0 = np.sqrt(2 * ETA_0 / n_bg) * e_hat                # 1 W/um^2 along k for amplitude 1
     H0 = np.cross(k_hat, E0) * n_bg / ETA_0
-    big = 10 ** 9
-    lo, hi = [-big] * 3, [big] * 3
-    face = int(np.argmin(np.abs(b[p] - src.center[p])))
-    if direction > 0:
-        lo[p] = face
-    else:
-        hi[p] = face
-    legs = surface_legs(spec, mt, lo, hi, (u, v), (u, v))
     r0 = np.array([float(c) if np.isfinite(c) else 0.0 for c in src.center])
-    r0[p] = b[p][face]
-    amp = {c: E0[c] for c in (u, v)}
-    amp.update({3 + c: H0[c] for c in (u, v)})
-    comps, ijks, ws = [], [], []
-    for key in ("e", "h"):
-        comp, ijk, w, nbc, nbi = legs[key]
-        val = np.zeros(len(w), complex)
-        for c in np.unique(nbc):
-            m = nbc == c
-            xs = spec.yee_coords(int(c))
-            phase = sum(kvec[a] * (xs[a][nbi[m, a]] - r0[a]) for a in range(3))
-            val[m] = amp[int(c)] * np.exp(1j * phase)
-        keep = val != 0
-        comps.append(comp[keep])
-        ijks.append(ijk[keep])
-        ws.append(w[keep] * val[keep])
-    comp = np.concatenate(comps).astype(np.int32)
-    ijk = np.concatenate(ijks).astype(np.int32)
-    w = np.concatenate(ws)
-    dt = spec.dt
-    spec.sources.append(PointSourceSet(
-        comp=comp, ijk=ijk, w_re=w.real.copy(), w_im=w.imag.copy(),
-        wave_e=np.asarray(st.amp_time(tmesh + dt / 2), complex),
-        wave_h=np.asarray(st.amp_time(tmesh), complex), name=getattr(src, "name", None) or "PlaneWave"))
+    r0[p] = b[p][int(np.argmin(np.abs(b[p] - src.center[p])))]
 
-    def fn(freqs):
-        return st.spectrum(tmesh, np.asarray(freqs, float), dt, complex_fields=spec.bloch is not None)
-    return fn
+    def incident(c, x, y, z):
+        amp = E0[c] if c < 3 else H0[c - 3]
+        return amp * np.exp(1j * (kvec[0] * (x - r0[0]) + kvec[1] * (y - r0[1]) + kvec[2] * (z - r0[2])))
+    return _sheet_source(disc, mt, src, incident, "PlaneWave")
+
+
+def build_gaussian_beam(disc, mt, src) -> Callable:
+    """GaussianBeam / AstigmaticGaussianBeam (ref source.py:1109-1201): the paraxial (simple astigmatic)
+    Gaussian beam of the centre frequency on the source plane, launched by ``_sheet_source``.  In beam
+    coordinates (zeta along the propagation direction, x' along the P-polarisation vector of
+    ``direction_vectors`` at pol_angle = 0, y' = k_hat x x'), per transverse axis q with waist w0_q at
+    zeta_q = zeta + waist_distance_q (a positive waist distance puts the waist behind the source):
+
+        E = E0 prod_q sqrt(w0_q / w_q) exp(-q^2 / w_q^2) exp(i (k q^2 / (2 R_q) - psi_q / 2)) * exp(i k zeta)
+        w_q = w0_q sqrt(1 + (zeta_q / zR_q)^2),  R_q = zeta_q (1 + (zR_q / zeta_q)^2),  psi_q = atan(zeta_q / zR_q),
+        zR_q = k w0_q^2 / 2,   H = k_hat x E / eta.
+
+    Amplitude: the reference's normalisation of beams is server-side (parity unpinned); here the peak
+    intensity at a circular waist is 1 W/um^2 for a unit-amplitude source time, i.e. the beam carries
+    pi w0x w0y / 2 W."""
+    import dataclasses
+    spec = disc.spec
+    st = src.source_time
+    n_bg = _background_index(spec)
+    k_hat, e_hat = direction_vectors(src)
+    x_hat = direction_vectors(dataclasses.replace(src, pol_angle=0.0))[1]
+    y_hat = np.cross(k_hat, x_hat)
+    if src.direction == "-":
+        y_hat = -y_hat                                  # keep (x', y', propagation) as built for '+'
+    k = 2 * np.pi * st.freq0 * n_bg / C_0
+    if isinstance(src, td.AstigmaticGaussianBeam):
+        w0, wd = [float(v) for v in src.waist_sizes], [float(v) for v in src.waist_distances]
+    else:
+        w0, wd = [float(src.waist_radius)] * 2, [float(src.waist_distance)] * 2
+    E0 = np.sqrt(2 * ETA_0 / n_bg) * e_hat
+    H0 = np.cross(k_hat, E0) * n_bg / ETA_0
+    r0 = np.array([float(c) for c in src.center])
+
+    def incident(c, x, y, z):
+        s = np.stack([x - r0[0], y - r0[1], z - r0[2]])
+        zeta = k_hat @ s
+        out = np.exp(1j * k * zeta).astype(complex)
+        for q_hat, w0q, wdq in ((x_hat, w0[0], wd[0]), (y_hat, w0[1], wd[1])):
+            q = q_hat @ s
+            zq, zr = zeta + wdq, k * w0q ** 2 / 2
+            wq = w0q * np.sqrt(1 + (zq / zr) ** 2)
+            inv_r = zq / (zq ** 2 + zr ** 2)                            # 1 / R_q, regular at the waist
+            out = out * np.sqrt(w0q / wq) * np.exp(-q ** 2 / wq ** 2 + 1j * (k * q ** 2 * inv_r / 2 - np.arctan(zq / zr) / 2))
+        return (E0[c] if c < 3 else H0[c - 3]) * out
+    return _sheet_source(disc, mt, src, incident, src.type)
 
 
 def build_planewave(disc, mt, src) -> Callable:

@@ -1350,6 +1350,25 @@ class PlaneWave(_Source):
 
 @_register
 @dataclass
+class GaussianBeam(PlaneWave):
+    """ref source.py:1109-1154: Gaussian beam on a finite plane; a positive ``waist_distance`` puts the
+    waist behind the source plane (w.r.t. the propagation direction)."""
+
+    waist_radius: float = 1.0
+    waist_distance: float = 0.0
+
+
+@_register
+@dataclass
+class AstigmaticGaussianBeam(PlaneWave):
+    """ref source.py:1157-1201: simple astigmatic Gaussian beam (two waist sizes / distances)."""
+
+    waist_sizes: Tuple[float, float] = (1.0, 1.0)
+    waist_distances: Tuple[float, float] = (0.0, 0.0)
+
+
+@_register
+@dataclass
 class TFSF(_Source):
     """Total-field/scattered-field box source (ref source.py:1204-1257): plane wave
     of 1 W/um^2 along ``injection_axis`` inside the box, nothing outside."""

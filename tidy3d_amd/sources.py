@@ -30,6 +30,9 @@ def build_sources(disc, mt) -> None:
         if isinstance(src, (td.PointDipole, td.UniformCurrentSource)):
             spec.sources.append(current_source(spec, mt, src, tmesh))
             disc.source_norm.append(_spectrum_fn(src, tmesh, spec.dt, spec.bloch is not None))
+        elif isinstance(src, (td.GaussianBeam, td.AstigmaticGaussianBeam)):
+            from .planewave import build_gaussian_beam
+            disc.source_norm.append(build_gaussian_beam(disc, mt, src))
         elif isinstance(src, (td.PlaneWave, td.TFSF)):
             from .planewave import build_planewave
             disc.source_norm.append(build_planewave(disc, mt, src))
