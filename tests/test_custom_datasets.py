@@ -1,0 +1,184 @@
+"""Dataset-defined objects (custom media and sources, triangle meshes, custom source times): the JSON form of
+a Simulation holds only placeholders for them — the data travel in the reference's .hdf5 layout (ref
+base.py:691-738), read here through tidy3d_amd/hdf5io.py ``load_simulation`` / ``Simulation.from_file``.
+Pins: the reference's own sample file (tests/sims/simulation_sample.h5) loads with its datasets; analytic
+rasters; physics of the injected sources on the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import tidy3d_amd.schema as td
+from tidy3d_amd.data import DataArray
+from tidy3d_amd.discretize import discretize
+from tidy3d_amd.exceptions import SetupError, Tidy3dNotImplementedError
+from tidy3d_amd.web import load, save
+
+from test_physics_oracle import solve
+
+SAMPLE = "/root/reference/tests/sims/simulation_sample"
+PULSE = td.GaussianPulse(freq0=2e14, fwidth=4e13)
+
+
+def _spatial(values, x, y, z):
+    a = DataArray(np.asarray(values), {"x": np.asarray(x, float), "y": np.asarray(y, float), "z": np.asarray(z, float)})
+    a.tag = "SpatialDataArray"
+    return a
+
+
+@pytest.mark.skipif(not os.path.exists(SAMPLE + ".h5"), reason="reference checkout not present")
+def test_reference_sample_file_loads_with_its_datasets():
+    sim = td.Simulation.from_file(SAMPLE + ".h5")
+    plain = td.parse(json.load(open(SAMPLE + ".json")))
+    assert [type(s.geometry).__name__ for s in sim.structures] == [type(s.geometry).__name__ for s in plain.structures]
+    med = sim.structures[16].medium
+    assert isinstance(med, td.CustomMedium) and med.permittivity.dims == ("x", "y", "z") and med.permittivity.shape == (2, 2, 2)
+    assert med.n_cfl == pytest.approx(np.sqrt(np.min(med.permittivity.values)))
+    with pytest.raises(SetupError, match="hdf5"):
+        plain.structures[16].medium.n_cfl                        # the JSON form has only the placeholder
+    mesh = sim.structures[8].geometry
+    assert isinstance(mesh, td.TriangleMesh) and mesh.triangles.shape == (4, 3, 3)
+    st = sim.sources[9].source_time
+    assert isinstance(st, td.CustomSourceTime) and st.end_time() == pytest.approx(9.99e-12)
+    assert sim.sources[6].field_dataset.Ex.dims == ("x", "y", "z", "f")
+    assert sim.sources[7].current_dataset.Ex.shape == (101, 101, 1, 1)
+    with pytest.raises(Tidy3dNotImplementedError, match="unstructured"):
+        sim.structures[22].medium.n_cfl
+
+
+def test_custom_medium_raster_interpolation_and_time_step():
+    x = np.linspace(-0.5, 0.5, 11)
+    eps = 2.0 + 2.0 * (x[:, None, None] + 0.5) * np.ones((1, 3, 3))             # 2 .. 4 along x
+    sig = 0.01 * np.ones((11, 3, 3))
+    sig[:5] = 0.0
+    med = td.CustomMedium(permittivity=_spatial(eps, x, [-1, 0, 1], [-1, 0, 1]),
+                          conductivity=_spatial(sig, x, [-1, 0, 1], [-1, 0, 1]), interp_method="linear")
+    assert med.n_cfl == pytest.approx(np.sqrt(2.0))
+    sim = td.Simulation(size=(2, 1, 1), grid_spec=td.GridSpec.uniform(dl=0.05), run_time=1e-14, subpixel=False,
+                        structures=[td.Structure(geometry=td.Box(size=(0.8, 0.6, 0.6)), medium=med)],
+                        sources=[td.PointDipole(source_time=PULSE, polarization="Ez")],
+                        boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary()))
+    spec = discretize(sim, n_steps=2).spec
+    plain = discretize(td.Simulation(**{**sim.__dict__, "structures": []}), n_steps=2).spec if False else None
+    eps_of = np.array([m.eps_inf for m in spec.media])
+    sig_of = np.array([m.sigma for m in spec.media])
+    xs, ys, zs = spec.yee_coords(2)
+    got = eps_of[spec.mat_idx[2]][10, 10, :]                                        # a row of Ez nodes along x
+    inside = np.abs(xs) <= 0.4
+    want = np.where(inside, 2.0 + 2.0 * (np.clip(xs, -0.5, 0.5) + 0.5), 1.0)
+    np.testing.assert_allclose(got, want, rtol=6e-3)                                # 1 % quantisation steps
+    s_row = sig_of[spec.mat_idx[2]][10, 10, :]
+    assert np.all(s_row[inside & (xs > 0.05)] == pytest.approx(0.01, rel=0.03)) and np.all(s_row[xs < -0.15] == 0)
+    # dt follows the smallest permittivity of the data like any medium (ref simulation.py:4194-4211)
+    assert spec.dt == pytest.approx(discretize(td.Simulation(
+        size=(2, 1, 1), grid_spec=td.GridSpec.uniform(dl=0.05), run_time=1e-14,
+        sources=[td.PointDipole(source_time=PULSE, polarization="Ez")],
+        boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary())), n_steps=2).spec.dt)
+    nearest = td.CustomMedium(permittivity=_spatial(eps, x, [-1, 0, 1], [-1, 0, 1]), interp_method="nearest")
+    e, _ = nearest.eps_sigma_at(0, np.array([0.04, 0.06, 9.0]), np.zeros(3), np.zeros(3))
+    np.testing.assert_allclose(e, [3.0, 3.2, 4.0])                                  # nearest sample; edge value outside
+
+
+def test_custom_medium_slab_transmits_like_the_uniform_slab():
+    """A CustomMedium with constant data is the plain medium: same Airy transmission (1 % quantisation of eps)."""
+    freqs = [1.8e14, 2e14, 2.2e14]
+
+    def run(medium):
+        sim = td.Simulation(size=(0, 0, 3.0), grid_spec=td.GridSpec.uniform(dl=0.02), run_time=4e-13, shutoff=0,
+                            structures=[td.Structure(geometry=td.Box(center=(0, 0, 0.5), size=(td.inf, td.inf, 0.4)),
+                                                     medium=medium)],
+                            sources=[td.UniformCurrentSource(center=(0, 0, -1.2), size=(td.inf, td.inf, 0),
+                                                             source_time=PULSE, polarization="Ex")],
+                            monitors=[td.FluxMonitor(center=(0, 0, 1.2), size=(td.inf, td.inf, 0), freqs=freqs, name="T")],
+                            boundary_spec=td.BoundarySpec(x=td.Boundary.periodic(), y=td.Boundary.periodic(),
+                                                          z=td.Boundary.pml()))
+        return solve(sim)[0]["T"].flux.values
+    const = td.CustomMedium(permittivity=_spatial(np.full((2, 2, 2), 6.25), [-9, 9], [-9, 9], [-9, 9]))
+    np.testing.assert_allclose(run(const), run(td.Medium(permittivity=6.25)), rtol=2e-2)
+
+
+def test_triangle_mesh_equals_the_solid_it_bounds():
+    v = np.array([[x, y, z] for x in (-.5, .5) for y in (-.3, .3) for z in (-.2, .4)])
+    faces = [[0, 1, 3], [0, 3, 2], [4, 6, 7], [4, 7, 5], [0, 4, 5], [0, 5, 1], [2, 3, 7], [2, 7, 6], [0, 2, 6], [0, 6, 4],
+             [1, 5, 7], [1, 7, 3]]
+    mesh = td.TriangleMesh.from_vertices_faces(v, faces)
+    box = td.Box(center=(0, 0, 0.1), size=(1, 0.6, 0.6))
+    np.testing.assert_allclose(np.array(mesh.bounds), np.array(box.bounds))
+    p = np.random.default_rng(0).uniform(-0.8, 0.8, (20000, 3))
+    assert np.array_equal(mesh.inside(p[:, 0], p[:, 1], p[:, 2]), box.inside(p[:, 0], p[:, 1], p[:, 2]))
+    kw = dict(size=(2, 1.6, 1.6), grid_spec=td.GridSpec.uniform(dl=0.05), run_time=1e-14, subpixel=False,
+              sources=[td.PointDipole(source_time=PULSE, polarization="Ez")],
+              boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary()))
+    med = td.Medium(permittivity=4)
+    geo_b = td.Box(center=(0.011, 0.007, 0.113), size=(1, 0.6, 0.6))                 # faces off the grid lines
+    shift = np.array([0.011, 0.007, 0.013])
+    a = discretize(td.Simulation(structures=[td.Structure(geometry=geo_b, medium=med)], **kw), n_steps=2).spec
+    b = discretize(td.Simulation(structures=[td.Structure(geometry=td.TriangleMesh.from_vertices_faces(v + shift, faces),
+                                                          medium=med)], **kw), n_steps=2).spec
+    assert np.array_equal(a.mat_idx, b.mat_idx)
+    # an octahedron |x| + |y| + |z| <= 0.5
+    ov = np.array([[.5, 0, 0], [-.5, 0, 0], [0, .5, 0], [0, -.5, 0], [0, 0, .5], [0, 0, -.5]])
+    of = [[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]]
+    octa = td.TriangleMesh.from_vertices_faces(ov, of)
+    d = np.abs(p).sum(axis=1)
+    sel = np.abs(d - 0.5) > 1e-6
+    assert np.array_equal(octa.inside(p[:, 0], p[:, 1], p[:, 2])[sel], (d <= 0.5)[sel])
+
+
+def test_custom_source_time_follows_the_reference_formula():
+    t = np.linspace(0, 2e-13, 201)
+    env = np.exp(-((t - 1e-13) / 3e-14) ** 2) * (1 + 0.3j)
+    arr = DataArray(env, {"t": t})
+    arr.tag = "TimeDataArray"
+    st = td.CustomSourceTime(freq0=2e14, fwidth=2e13, offset=1.5, amplitude=2.0, phase=0.4,
+                             source_time_dataset=td.TimeDataset(values=arr))
+    tt = np.array([-1e-14, 3.3e-14, 1.234e-13, 5e-13])
+    shift = tt - 1.5 / (2 * np.pi * 2e13)
+    e = np.interp(shift, t, env.real) + 1j * np.interp(shift, t, env.imag)
+    np.testing.assert_allclose(st.amp_time(tt), 2.0 * np.exp(1j * 0.4 - 2j * np.pi * 2e14 * tt) * e, rtol=1e-12)
+    assert st.end_time() == pytest.approx(t[np.nonzero(~np.isclose(np.abs(env), 0))[0][-1]])
+
+
+def test_custom_field_and_current_sources_on_the_oracle(tmp_path):
+    """CustomFieldSource fed with the E and H of a +z plane wave launches exactly that wave one way;
+    with E only it radiates half the amplitude (a quarter of the power) to each side.  CustomCurrentSource with
+    a constant J_x sheet is the UniformCurrentSource.  All three through the .hdf5 round trip."""
+    from tidy3d_amd.constants import ETA_0
+    x = np.array([-5.0, 5.0])
+    ones = np.ones((2, 2, 1, 1))
+    def field(v):
+        a = DataArray(v * ones, {"x": x, "y": x, "z": np.array([0.0]), "f": np.array([2e14])})
+        a.tag = "ScalarFieldDataArray"
+        return a
+    mons = [td.FluxMonitor(center=(0, 0, 0.8), size=(td.inf, td.inf, 0), freqs=[2e14], name="fwd"),
+            td.FluxMonitor(center=(0, 0, -0.8), size=(td.inf, td.inf, 0), freqs=[2e14], name="bwd")]
+
+    def run(source, normalize_index=0):
+        sim = td.Simulation(size=(0, 0, 3.0), grid_spec=td.GridSpec.uniform(dl=0.02), run_time=3e-13, shutoff=0,
+                            sources=[source], monitors=mons, normalize_index=normalize_index,
+                            boundary_spec=td.BoundarySpec(x=td.Boundary.periodic(), y=td.Boundary.periodic(),
+                                                          z=td.Boundary.pml()))
+        return sim, solve(sim)[0]
+    both = td.CustomFieldSource(center=(0, 0, 0), size=(td.inf, td.inf, 0), source_time=PULSE,
+                                field_dataset=td.FieldDataset(Ex=field(1.0), Hy=field(1.0 / ETA_0)))
+    sim, sd = run(both)
+    p0 = 1.0 / (2 * ETA_0)                                        # |E|^2 / (2 eta) per um^2, cell area 1 (collapsed axes)
+    assert sd["fwd"].flux.values[0] == pytest.approx(p0, rel=5e-3)
+    assert abs(sd["bwd"].flux.values[0]) < 1e-3 * p0          # data on one plane, Yee H half a cell off
+    _, sd_e = run(td.CustomFieldSource(center=(0, 0, 0), size=(td.inf, td.inf, 0), source_time=PULSE,
+                                       field_dataset=td.FieldDataset(Ex=field(1.0))))
+    assert sd_e["fwd"].flux.values[0] == pytest.approx(p0 / 4, rel=5e-3)
+    assert -sd_e["bwd"].flux.values[0] == pytest.approx(p0 / 4, rel=5e-3)
+    _, sd_j = run(td.CustomCurrentSource(center=(0, 0, 0), size=(td.inf, td.inf, 0), source_time=PULSE,
+                                         current_dataset=td.FieldDataset(Ex=field(1.0))))
+    _, sd_u = run(td.UniformCurrentSource(center=(0, 0, 0), size=(td.inf, td.inf, 0), source_time=PULSE, polarization="Ex"))
+    np.testing.assert_allclose(sd_j["fwd"].flux.values, sd_u["fwd"].flux.values, rtol=1e-12)
+    # the datasets survive the file: simulation -> .hdf5 -> simulation
+    path = str(tmp_path / "custom.hdf5")
+    save(sd, path)
+    back = load(path).simulation
+    assert isinstance(back.sources[0], td.CustomFieldSource)
+    assert np.array_equal(back.sources[0].field_dataset.Hy.values, both.field_dataset.Hy.values)
+    assert back.sources[0].field_dataset.Hy.dims == ("x", "y", "z", "f")
+    assert td.Simulation.from_file(path).sources[0].field_dataset.Ex.shape == (2, 2, 1, 1)

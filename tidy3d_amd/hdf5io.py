@@ -340,12 +340,77 @@ def _monitor_json(sim_data, mon) -> dict:
     return mon.dict()
 
 
+# dims of the reference's DataArray classes that describe a Simulation (ref data/data_array.py)
+SIM_ARRAY_DIMS = {"SpatialDataArray": ("x", "y", "z"), "ScalarFieldDataArray": ("x", "y", "z", "f"),
+                  "TimeDataArray": ("t",), "TriangleMeshDataArray": ("face_index", "vertex_index", "axis"),
+                  "PointDataArray": ("index", "axis"), "IndexedDataArray": ("index",), "CellDataArray": ("cell_index", "vertex_index")}
+
+
+def _split_arrays(node, path: str, arrays: Dict[str, Any]):
+    """Copy of a JSON-like tree with every DataArray replaced by its class tag; the arrays are collected
+    under their hdf5 group path."""
+    from .data import DataArray
+    if isinstance(node, DataArray):
+        arrays[path] = node
+        return getattr(node, "tag", None) or "DataArray"
+    if isinstance(node, dict):
+        return {k: _split_arrays(v, f"{path}/{k}", arrays) for k, v in node.items()}
+    if isinstance(node, (list, tuple)):
+        return [_split_arrays(v, f"{path}/{i}", arrays) for i, v in enumerate(node)]
+    return node
+
+
+def _join_arrays(node, path: str, tree: Dict[str, Any]):
+    """Inverse of ``_split_arrays`` on a tree read from an hdf5 file: "...DataArray" placeholders whose group
+    holds a value dataset become DataArrays (dims from SIM_ARRAY_DIMS, else matched by length)."""
+    from .data import DataArray
+    if isinstance(node, dict):
+        return {k: _join_arrays(v, f"{path}/{k}", tree) for k, v in node.items()}
+    if isinstance(node, list):
+        return [_join_arrays(v, f"{path}/{i}", tree) for i, v in enumerate(node)]
+    if isinstance(node, str) and node.endswith("DataArray") and f"{path}/{DATA_ARRAY_VALUE_NAME}" in tree:
+        values = np.asarray(tree[f"{path}/{DATA_ARRAY_VALUE_NAME}"])
+        names = [k[len(path) + 1:] for k in tree if k.startswith(path + "/") and "/" not in k[len(path) + 1:]
+                 and k != f"{path}/{DATA_ARRAY_VALUE_NAME}" and tree[k] is not None]
+        dims = SIM_ARRAY_DIMS.get(node)
+        if dims is None or len(dims) != values.ndim:
+            dims, left = [], list(names)
+            for i_d, n in enumerate(values.shape):
+                pick = next((d for d in left if len(np.atleast_1d(tree[f"{path}/{d}"])) == n), f"dim_{i_d}")
+                dims.append(pick)
+                if pick in left:
+                    left.remove(pick)
+        coords = {d: (np.atleast_1d(np.asarray(tree[f"{path}/{d}"])) if tree.get(f"{path}/{d}") is not None
+                      else np.arange(values.shape[i_d])) for i_d, d in enumerate(dims)}
+        arr = DataArray(values, coords)
+        arr.tag = node
+        return arr
+    return node
+
+
+def load_simulation(path: str):
+    """Read a ``tidy3d.Simulation`` from an .hdf5 file written by the reference's ``to_file`` / ``to_hdf5``
+    (ref base.py:560-738) or from a SimulationData file: unlike the JSON form, datasets (custom media and
+    sources, triangle meshes, custom source times) come along."""
+    from . import schema as td
+    tree = read_tree(path)
+    keys = sorted((k for k in tree if k.lstrip("/").split("_")[0] == "JSON" and k.lstrip("/").startswith(JSON_TAG)),
+                  key=lambda k: int(k.rsplit("_", 1)[1]) if k.lstrip("/") != JSON_TAG else 0)
+    model = json.loads("".join(tree[k] for k in keys))
+    base = ""
+    if model.get("type") == "SimulationData":
+        model, base = model["simulation"], "/simulation"
+    return td.Simulation.from_dict(_join_arrays(model, base, tree))
+
+
 def simulation_data_model(sim_data) -> Tuple[dict, Dict[str, Any]]:
     """(JSON model with DataArray placeholders, {hdf5 group path: DataArray}) of a SimulationData in
     the reference's layout (ref sim_data.py:826, monitor_data.py)."""
     sim = sim_data.simulation
-    sim_json = getattr(sim, "_source_dict", None) or sim.dict()
     arrays: Dict[str, Any] = {}
+    # dataset-defined objects of the simulation (custom media / sources, triangle meshes): placeholders in
+    # the JSON, arrays under the same path (ref base.py:691-738 to_hdf5)
+    sim_json = _split_arrays(getattr(sim, "_source_dict", None) or sim.dict(), "/simulation", arrays)
     data_json = []
     for i, d in enumerate(sim_data.data):
         kind = type(d).__name__
@@ -433,7 +498,7 @@ def load_simulation_data(path: str):
     keys = sorted((k for k in tree if k.lstrip("/").startswith(JSON_TAG) and not k.endswith("/")),
                   key=lambda k: int(k.rsplit("_", 1)[1]) if k.lstrip("/") != JSON_TAG else 0)
     model = json.loads("".join(tree[k] for k in keys))
-    sim = td.Simulation.from_dict(model["simulation"])
+    sim = td.Simulation.from_dict(_join_arrays(model["simulation"], "/simulation", tree))
     by_name = {m.name: m for m in sim.monitors}
     dims = {"ScalarFieldDataArray": ("x", "y", "z", "f"), "ScalarFieldTimeDataArray": ("x", "y", "z", "t"),
             "FluxDataArray": ("f",), "FluxTimeDataArray": ("t",), "ModeAmpsDataArray": ("direction", "f", "mode_index"),

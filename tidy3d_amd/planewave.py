@@ -397,6 +397,35 @@ def build_gaussian_beam(disc, mt, src) -> Callable:
     return _sheet_source(disc, mt, src, incident, src.type)
 
 
+def build_custom_field_source(disc, mt, src) -> Callable:
+    """CustomFieldSource (ref source.py:781-900): the tangential E and H of the dataset (coordinates relative
+    to the source centre, entry nearest the centre frequency) become the equivalent currents J = n x H,
+    M = -n x E of the plane, n = +axis — the jump conditions ``_sheet_source`` imposes with the data as the
+    incident field.  Data of a wave travelling along +n are reproduced on the + side and nothing is sent
+    back; E-only or H-only data radiate to both sides."""
+    ds = td._need_data(src.field_dataset, "CustomFieldSource")
+    p = int(src.injection_axis)
+    comps = {}
+    for name, arr in ds.field_components.items():
+        c = "xyz".index(name[1]) + (3 if name[0] == "H" else 0)
+        if c % 3 == p:
+            continue                                     # normal components play no role (ref :792-795)
+        if "f" in arr.dims:
+            f = np.asarray(arr.coords["f"], float)
+            arr = arr.sel(f=float(f[np.argmin(np.abs(f - src.source_time.freq0))]))
+        comps[c] = arr
+    if not comps:
+        raise SetupError("CustomFieldSource needs at least one field component tangential to its plane "
+                         "(ref source.py:792-795).")
+
+    def incident(c, x, y, z):
+        if c not in comps:
+            return np.zeros(np.shape(x), complex)
+        pts = {"x": x - src.center[0], "y": y - src.center[1], "z": z - src.center[2]}
+        return td.interp_dataset(comps[c], pts, "linear").astype(complex)
+    return _sheet_source(disc, mt, src, incident, "CustomFieldSource")
+
+
 def build_planewave(disc, mt, src) -> Callable:
     """Discretise a PlaneWave or TFSF source; returns its normalisation spectrum function."""
     sim, spec = disc.sim, disc.spec

@@ -473,6 +473,101 @@ class PolySlab(_Model):
 
 @_register
 @dataclass
+class TriangleMeshDataset(_Model):
+    """ref data/dataset.py TriangleMeshDataset: ``surface_mesh`` = TriangleMeshDataArray
+    (face_index, vertex_index, axis)."""
+
+    surface_mesh: Any = None
+
+
+@_register
+@dataclass
+class TriangleMesh(_Model):
+    """Closed triangulated surface (ref geometry/mesh.py:31).  ``inside`` counts the crossings of a ray
+    along +z with the faces (the reference asks trimesh for the same test, mesh.py ``inside``; third party,
+    absent here): odd = inside.  Points exactly on a face, edge or vertex are implementation-defined in
+    both; the ray origin is nudged by 1e-9 of the mesh size off such degeneracies."""
+
+    mesh_dataset: Any = None
+
+    @property
+    def triangles(self) -> np.ndarray:
+        v = getattr(self.mesh_dataset, "surface_mesh", None)
+        if v is None or isinstance(v, str):
+            raise SetupError("TriangleMesh: the JSON form carries no data; load the simulation from its .hdf5 "
+                             "file (Simulation.from_file) or use TriangleMesh.from_triangles.")
+        return np.asarray(v.values, float).reshape(-1, 3, 3)
+
+    @classmethod
+    def from_triangles(cls, triangles):
+        """ref geometry/mesh.py:100-125."""
+        from .data import DataArray
+        tri = np.asarray(triangles, float).reshape(-1, 3, 3)
+        arr = DataArray(tri, {"face_index": np.arange(len(tri)), "vertex_index": np.arange(3), "axis": np.arange(3)})
+        arr.tag = "TriangleMeshDataArray"
+        return cls(mesh_dataset=TriangleMeshDataset(surface_mesh=arr))
+
+    @classmethod
+    def from_vertices_faces(cls, vertices, faces):
+        """ref geometry/mesh.py:160-180."""
+        return cls.from_triangles(np.asarray(vertices, float)[np.asarray(faces, int)])
+
+    @property
+    def bounds(self):
+        t = self.triangles.reshape(-1, 3)
+        return tuple(t.min(axis=0)), tuple(t.max(axis=0))
+
+    def inside(self, x, y, z):
+        tri = self.triangles
+        x, y, z = (np.asarray(v, float) for v in (x, y, z))
+        shape = np.broadcast(x, y, z).shape
+        span = float(np.max(tri.max(axis=(0, 1)) - tri.min(axis=(0, 1)))) or 1.0
+        ex, ey = 1.2345e-9 * span, 2.7183e-9 * span          # off edges / vertices shared by several faces
+        # a lattice (x along the last axis, y along the one before, z along the first — what the rasteriser
+        # passes) is handled face by face on the footprint of the face only
+        grid = (x.ndim == 3 and x.shape[:2] == (1, 1) and y.ndim == 3 and y.shape[0] == 1 and y.shape[2] == 1
+                and z.ndim == 3 and z.shape[1:] == (1, 1))
+        if not grid:
+            xf, yf, zf = (np.broadcast_to(v, shape).ravel() for v in (x, y, z))
+            odd = np.zeros(xf.shape, bool)
+            for a, b, c in tri:
+                odd ^= self._hits(a, b, c, xf + ex, yf + ey, zf)
+            return odd.reshape(shape)
+        xs, ys, zs = x.ravel() + ex, y.ravel() + ey, z.ravel()
+        odd = np.zeros((len(zs), len(ys), len(xs)), bool)
+        for a, b, c in tri:
+            lo, hi = np.minimum(np.minimum(a, b), c), np.maximum(np.maximum(a, b), c)
+            i0, i1 = np.searchsorted(xs, lo[0]), np.searchsorted(xs, hi[0], side="right")
+            j0, j1 = np.searchsorted(ys, lo[1]), np.searchsorted(ys, hi[1], side="right")
+            if i1 <= i0 or j1 <= j0:
+                continue
+            X, Y = np.meshgrid(xs[i0:i1], ys[j0:j1], indexing="xy")        # (ny, nx)
+            zt, ok = self._cross_z(a, b, c, X, Y)
+            if not ok.any():
+                continue
+            odd[:, j0:j1, i0:i1] ^= ok[None] & (zs[:, None, None] < zt[None])
+        return odd
+
+    @staticmethod
+    def _cross_z(a, b, c, X, Y):
+        """z at which the vertical line through (X, Y) meets the plane of triangle abc, and whether it
+        does so inside the triangle (barycentric test in the xy projection)."""
+        d = (b[0] - a[0]) * (c[1] - a[1]) - (c[0] - a[0]) * (b[1] - a[1])
+        if d == 0.0:
+            return np.zeros_like(X), np.zeros(X.shape, bool)             # vertical face: never crossed
+        l1 = ((X - a[0]) * (c[1] - a[1]) - (c[0] - a[0]) * (Y - a[1])) / d
+        l2 = ((b[0] - a[0]) * (Y - a[1]) - (X - a[0]) * (b[1] - a[1])) / d
+        ok = (l1 >= 0) & (l2 >= 0) & (l1 + l2 <= 1)
+        return a[2] + l1 * (b[2] - a[2]) + l2 * (c[2] - a[2]), ok
+
+    @classmethod
+    def _hits(cls, a, b, c, x, y, z):
+        zt, ok = cls._cross_z(a, b, c, x, y)
+        return ok & (z < zt)
+
+
+@_register
+@dataclass
 class GeometryGroup(_Model):
     """Union of geometries sharing one medium (ref geometry/base.py:2304)."""
 
@@ -667,6 +762,126 @@ class Medium(_AbstractMedium):
         eps_c = (n + 1j * k) ** 2
         sigma = 2 * np.pi * freq * eps_c.imag * EPSILON_0
         return cls(permittivity=eps_c.real, conductivity=sigma, **kw)
+
+
+def interp_dataset(arr, points: Dict[str, np.ndarray], method: str = "linear") -> np.ndarray:
+    """Values of a labelled array (dims = a subset of x, y, z [, f, t]) at POINTS given per dimension
+    (equal-shaped arrays); dimensions of length one are constant, positions outside the coordinate range
+    take the edge value (what xarray's interp with extrapolation gives for the reference's use:
+    ref medium.py:1077-1120 ``_interp`` / ``fill_value="extrapolate"`` on nearest data)."""
+    from scipy.interpolate import RegularGridInterpolator
+    vals = np.asarray(arr.values)
+    dims = list(arr.dims)
+    keep, grids, pts = [], [], []
+    shape = np.broadcast(*[np.asarray(points[d]) for d in dims if d in points]).shape if points else ()
+    index = []
+    for i, d in enumerate(dims):
+        c = np.asarray(arr.coords[d], float)
+        if len(c) == 1 or d not in points:
+            index.append(0)
+            continue
+        order = np.argsort(c)
+        vals = np.take(vals, order, axis=i)
+        c = c[order]
+        index.append(slice(None))
+        grids.append(c)
+        pts.append(np.clip(np.broadcast_to(np.asarray(points[d], float), shape), c[0], c[-1]).ravel())
+    vals = vals[tuple(index)]
+    if not grids:
+        return np.full(shape, vals)
+    rgi = RegularGridInterpolator(tuple(grids), vals, method="nearest" if method == "nearest" else "linear")
+    return rgi(np.stack(pts, axis=1)).reshape(shape)
+
+
+@_register
+@dataclass
+class PermittivityDataset(_Model):
+    """ref data/dataset.py PermittivityDataset: eps_xx / eps_yy / eps_zz on (x, y, z, f)."""
+
+    eps_xx: Any = None
+    eps_yy: Any = None
+    eps_zz: Any = None
+
+
+@_register
+@dataclass
+class CustomMedium(_AbstractMedium):
+    """Spatially varying dispersionless medium (ref medium.py:1648-2050): ``permittivity`` (+ optional
+    ``conductivity``) as SpatialDataArrays, or ``eps_dataset`` with one complex permittivity per E component
+    at one frequency; evaluated at every Yee location with ``interp_method`` (edge values outside the
+    data).  Datasets are not part of the JSON form: load the simulation from .hdf5 (Simulation.from_file)."""
+
+    permittivity: Any = None
+    conductivity: Any = None
+    eps_dataset: Any = None
+    interp_method: str = "nearest"
+    subpixel: bool = False
+    name: Optional[str] = None
+    frequency_range: Optional[Tuple[float, float]] = None
+    is_custom = True
+
+    def _check(self):
+        """Raised on use, not on parsing (unsupported / data-less objects may sit unused in a file)."""
+        from .data import DataArray
+        if isinstance(self.permittivity, Unsupported) or isinstance(self.conductivity, Unsupported):
+            raise Tidy3dNotImplementedError("CustomMedium on unstructured grids (TriangularGridDataset / "
+                                            "TetrahedralGridDataset) is not supported")
+        if isinstance(self.permittivity, str) or (self.eps_dataset is not None and isinstance(
+                getattr(self.eps_dataset, "eps_xx", None), str)):
+            raise SetupError("CustomMedium: the JSON form carries no data (only the placeholder "
+                             f"'{self.permittivity}'); load the simulation from its .hdf5 file "
+                             "(Simulation.from_file) or pass DataArrays.")
+        if self.permittivity is None and self.eps_dataset is None:
+            raise SetupError("CustomMedium needs 'permittivity' or 'eps_dataset' (ref medium.py:1740-1760).")
+        if self.permittivity is not None:
+            if not isinstance(self.permittivity, DataArray):
+                raise SetupError("CustomMedium.permittivity must be a SpatialDataArray.")
+            if np.any(np.asarray(self.permittivity.values).real < 1.0):
+                raise SetupError("CustomMedium.permittivity must be >= 1 everywhere (ref medium.py:1800-1815).")
+
+    def _component_arrays(self, c: int):
+        """(eps DataArray, sigma DataArray or None, frequency of an eps_dataset or None) of E component c."""
+        self._check()
+        if self.permittivity is not None:
+            return self.permittivity, self.conductivity, None
+        arr = getattr(self.eps_dataset, ("eps_xx", "eps_yy", "eps_zz")[c])
+        return arr, None, float(np.asarray(arr.coords["f"]).ravel()[0])
+
+    def eps_sigma_at(self, c: int, x, y, z):
+        """(permittivity, conductivity) of E component c at the points (ref medium.py:1016-1038
+        eps_complex_to_eps_sigma for the dataset form)."""
+        arr, sig, freq = self._component_arrays(c)
+        pts = {"x": x, "y": y, "z": z}
+        if freq is None:
+            eps = np.real(interp_dataset(arr, pts, self.interp_method))
+            sigma = np.real(interp_dataset(sig, pts, self.interp_method)) if sig is not None else np.zeros_like(eps)
+            return eps, sigma
+        ec = interp_dataset(arr, pts, self.interp_method)
+        return np.real(ec), np.imag(ec) * 2 * np.pi * freq * EPSILON_0
+
+    def pole_residue(self):
+        """Representative medium (mean permittivity) — what keys the structure in the material table; the
+        per-cell values are written by the rasteriser."""
+        arr = self._component_arrays(0)[0]
+        return float(np.mean(np.real(arr.values))), 1e-300, ()
+
+    @property
+    def n_cfl(self):
+        """ref medium.py:1703-1720: sqrt of the smallest permittivity in the data."""
+        lo = min(float(np.min(np.real(self._component_arrays(c)[0].values))) for c in range(3))
+        return float(np.sqrt(lo))
+
+    def eps_model(self, frequency):
+        eps, sig, _ = self.pole_residue()
+        return eps + 0j * np.asarray(frequency, float)
+
+    def dict(self):
+        out = {"type": "CustomMedium", "interp_method": self.interp_method, "subpixel": self.subpixel,
+               "name": self.name, "frequency_range": self.frequency_range, "permittivity": self.permittivity,
+               "conductivity": self.conductivity,
+               "eps_dataset": None if self.eps_dataset is None else {
+                   "type": "PermittivityDataset", **{k: getattr(self.eps_dataset, k) for k in ("eps_xx", "eps_yy", "eps_zz")}}}
+        return out
 
 
 @_register
@@ -1281,6 +1496,54 @@ class ContinuousWave(_SourceTime):
         return self.amplitude * np.exp(1j * self.phase)
 
 
+@_register
+@dataclass
+class TimeDataset(_Model):
+    """ref data/dataset.py TimeDataset: ``values`` = TimeDataArray over t."""
+
+    values: Any = None
+
+
+@_register
+@dataclass
+class CustomSourceTime(_SourceTime):
+    """ref source.py:259-435: amp_time(t) = amplitude e^{i phase - 2 pi i freq0 t} envelope(t - offset twidth),
+    envelope = linear interpolation of the dataset, its end values outside."""
+
+    freq0: float = 1.0
+    fwidth: float = 1.0
+    offset: float = 0.0
+    amplitude: float = 1.0
+    phase: float = 0.0
+    source_time_dataset: Any = None
+
+    def _data(self):
+        v = getattr(self.source_time_dataset, "values", None)
+        if v is None or isinstance(v, str):
+            raise SetupError("CustomSourceTime: the JSON form carries no data; load the simulation from its "
+                             ".hdf5 file (Simulation.from_file) or pass a TimeDataArray.")
+        t = np.asarray(v.coords["t"], float).ravel()
+        order = np.argsort(t)
+        return t[order], np.asarray(v.values).ravel()[order]
+
+    def amp_time(self, time):
+        time = np.asarray(time, float)
+        t, env = self._data()
+        ts = time - self.offset * self.twidth
+        e = np.interp(ts, t, env.real) + 1j * np.interp(ts, t, env.imag)        # np.interp clamps to the end values
+        return np.exp(1j * self.phase) * np.exp(-2j * np.pi * self.freq0 * time) * self.amplitude * e
+
+    def end_time(self):
+        """ref source.py:423-435: last time with a non-zero envelope."""
+        t, env = self._data()
+        nz = ~np.isclose(np.abs(env), 0)
+        return float(np.max(t[nz])) if nz.any() else None
+
+    @property
+    def amp_complex(self):
+        return self.amplitude * np.exp(1j * self.phase)
+
+
 # --------------------------------------------------------------------------------------
 # sources  (ref components/source.py)
 # --------------------------------------------------------------------------------------
@@ -1346,6 +1609,68 @@ class PlaneWave(_Source):
         if len(zd) != 1:
             raise SetupError("PlaneWave must have exactly one zero-size dimension.")
         return zd[0]
+
+
+@_register
+@dataclass
+class FieldDataset(_Model):
+    """ref data/dataset.py FieldDataset: Ex .. Hz ScalarFieldDataArrays over (x, y, z, f)."""
+
+    Ex: Any = None
+    Ey: Any = None
+    Ez: Any = None
+    Hx: Any = None
+    Hy: Any = None
+    Hz: Any = None
+
+    @property
+    def field_components(self):
+        return {k: getattr(self, k) for k in ("Ex", "Ey", "Ez", "Hx", "Hy", "Hz") if getattr(self, k) is not None}
+
+
+def _need_data(ds, what: str):
+    if ds is None or any(isinstance(v, str) for v in ds.field_components.values()):
+        raise SetupError(f"{what}: the JSON form carries no data; load the simulation from its .hdf5 file "
+                         "(Simulation.from_file) or pass ScalarFieldDataArrays.")
+    if not ds.field_components:
+        raise SetupError(f"{what}: the dataset holds no field component.")
+    return ds
+
+
+@_register
+@dataclass
+class CustomFieldSource(_Source):
+    """Planar source from E / H data through the equivalence principle (ref source.py:781-900): coordinates
+    relative to the source centre, tangential components only, normal = +axis."""
+
+    source_time: Any = None
+    center: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    size: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    field_dataset: Any = None
+    name: Optional[str] = None
+    direction = "+"
+
+    @property
+    def injection_axis(self) -> int:
+        zd = [d for d, s in enumerate(self.size) if s == 0]
+        if len(zd) != 1:
+            raise SetupError("CustomFieldSource must have exactly one zero-size dimension.")
+        return zd[0]
+
+
+@_register
+@dataclass
+class CustomCurrentSource(_Source):
+    """Current densities J (Ex .. Ez) and M (Hx .. Hz) from a dataset (ref source.py:632-700), coordinates
+    relative to the source centre."""
+
+    source_time: Any = None
+    center: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    size: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    current_dataset: Any = None
+    interpolate: bool = True
+    confine_to_bounds: bool = False
+    name: Optional[str] = None
 
 
 @_register
@@ -1799,7 +2124,11 @@ class Simulation(_Model):
 
     @classmethod
     def from_file(cls, fname: str) -> "Simulation":
+        """.json, or .hdf5 / .h5 in the reference's layout (datasets included; ref base.py:364-420)."""
         import json
+        if str(fname).endswith((".hdf5", ".h5")):
+            from .hdf5io import load_simulation
+            return load_simulation(fname)
         with open(fname) as f:
             return cls.from_dict(json.load(f))
 

@@ -30,6 +30,22 @@ def build_sources(disc, mt) -> None:
         if isinstance(src, (td.PointDipole, td.UniformCurrentSource)):
             spec.sources.append(current_source(spec, mt, src, tmesh))
             disc.source_norm.append(_spectrum_fn(src, tmesh, spec.dt, spec.bloch is not None))
+        elif isinstance(src, td.CustomCurrentSource):
+            # current densities from a dataset, coordinates relative to the source centre (ref source.py:632-700)
+            ds = td._need_data(src.current_dataset, "CustomCurrentSource")
+            for name, arr in ds.field_components.items():
+                f_sel = float(np.asarray(arr.coords["f"])[np.argmin(np.abs(np.asarray(arr.coords["f"], float)
+                                                                             - src.source_time.freq0))]) if "f" in arr.dims else None
+
+                def profile(x, y, z, arr=arr, f_sel=f_sel):
+                    pts = {"x": x - src.center[0], "y": y - src.center[1], "z": z - src.center[2]}
+                    a = arr if f_sel is None else arr.sel(f=f_sel)
+                    return td.interp_dataset(a, pts, "linear")
+                spec.sources.append(current_source(spec, mt, src, tmesh, polarization=name, profile=profile))
+            disc.source_norm.append(_spectrum_fn(src, tmesh, spec.dt, spec.bloch is not None))
+        elif isinstance(src, td.CustomFieldSource):
+            from .planewave import build_custom_field_source
+            disc.source_norm.append(build_custom_field_source(disc, mt, src))
         elif isinstance(src, (td.GaussianBeam, td.AstigmaticGaussianBeam)):
             from .planewave import build_gaussian_beam
             disc.source_norm.append(build_gaussian_beam(disc, mt, src))

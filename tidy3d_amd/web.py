@@ -38,7 +38,17 @@ def _as_mirror(simulation):
     if isinstance(simulation, dict):
         return td.Simulation.from_dict(simulation), False
     if hasattr(simulation, "json") and callable(simulation.json):
-        return td.Simulation.from_dict(json.loads(simulation.json())), True
+        text = simulation.json()
+        if 'DataArray"' in text and hasattr(simulation, "to_file"):
+            # dataset-defined objects (custom media / sources, triangle meshes): the JSON form holds only
+            # placeholders, the data go through the reference's own .hdf5 writer (ref base.py:364-420)
+            import os
+            import tempfile
+            with tempfile.TemporaryDirectory() as tmp:
+                fname = os.path.join(tmp, "simulation.hdf5")
+                simulation.to_file(fname)
+                return td.Simulation.from_file(fname), True
+        return td.Simulation.from_dict(json.loads(text)), True
     raise SetupError(f"cannot interpret {type(simulation)!r} as a tidy3d Simulation")
 
 
