@@ -249,7 +249,7 @@ def bloch_x_only(N=(16, 10, 8)):
     return _sim(N, bspec)
 
 
-def bloch_planewave(N=(12, 10, 24)):
+def bloch_planewave(N=(12, 8, 20)):
     """Oblique PlaneWave (current sheets with the Bloch phase gradient) onto a dielectric block, Bloch in
     x and y from the source, CPML in z, flux and field monitors either side."""
     pw = td.PlaneWave(center=(0, 0, -0.35), size=(td.inf, td.inf, 0), source_time=PULSE, direction="+",

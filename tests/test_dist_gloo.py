@@ -31,7 +31,7 @@ def test_split_slabs():
 
 @pytest.mark.parametrize("world,case", [(2, "media_mix"), (2, "pml_box"), (3, "periodic_box"), (2, "drude_in_pml"),
                                         (2, "periodic_box_tall"), (4, "periodic_box_tall"), (2, "planewave_periodic"),
-                                        (2, "tfsf_box"), (3, "au_array"), (2, "absorber_mix"), (3, "absorber_mix")])
+                                        (2, "tfsf_box"), (3, "au_array"), (3, "absorber_mix")])
 def test_two_rank_run_matches_single_slab(world, case, emu_lib, tmp_path):
     n_steps = 60 if case == "planewave_periodic" else 30     # let the injected wave reach the monitors
     out = str(tmp_path / "dist.npz")

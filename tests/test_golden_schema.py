@@ -145,10 +145,18 @@ def test_full_reference_fixture_parses():
     assert len(sim.monitors) == len(d["monitors"])
     kinds = {type(s).__name__ for s in sim.sources}
     assert {"UniformCurrentSource", "PointDipole", "ModeSource", "PlaneWave", "TFSF"} <= kinds
-    assert any(isinstance(s, td.Unsupported) for s in sim.sources)
-    from tidy3d_amd.exceptions import Tidy3dNotImplementedError
+    assert {"GaussianBeam", "AstigmaticGaussianBeam", "CustomFieldSource", "CustomCurrentSource"} <= kinds
+    assert not any(isinstance(s, td.Unsupported) for s in sim.sources)
+    # still placeholders: custom dispersive media, Medium2D (raise only when used)
+    assert any(isinstance(st.medium, td.Unsupported) for st in sim.structures)
+    from tidy3d_amd.exceptions import SetupError, Tidy3dNotImplementedError
+    with pytest.raises(SetupError, match="hdf5"):
+        D.make_boundaries(sim)        # the AutoGrid axis asks the TriangleMesh for its bounds: no data in JSON
+    h5 = REF_SAMPLE[:-5] + ".h5"
+    full = td.Simulation.from_file(h5)          # the same simulation with its datasets
+    assert isinstance(full.structures[8].geometry, td.TriangleMesh) and full.structures[8].geometry.bounds[0][0] == -1.5
     with pytest.raises(Tidy3dNotImplementedError):
-        D.make_boundaries(sim)        # AutoGrid along x is outside the supported subset
+        D.discretize(full, n_steps=2)           # Medium2D, custom dispersive media: named when used
 
 
 GEO = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "geometry_golden.json")))

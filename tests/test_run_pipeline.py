@@ -143,7 +143,7 @@ def test_bloch_run_end_to_end(emu_lib, tmp_path):
     from tidy3d_amd.web import load
     pw = td.PlaneWave(center=(0, 0, -0.3), size=(td.inf, td.inf, 0), source_time=PULSE, direction="+", angle_theta=0.4,
                       angle_phi=0.3)
-    sim = _sim(size=(12 * DL, 8 * DL, 24 * DL), sources=[pw], shutoff=0,
+    sim = _sim(size=(12 * DL, 8 * DL, 20 * DL), sources=[pw], shutoff=0,
                structures=[td.Structure(geometry=td.Box(center=(0, 0, 0.2), size=(0.3, td.inf, 0.15)),
                                         medium=td.Medium(permittivity=4.0))],
                monitors=[td.DiffractionMonitor(center=(0, 0, 0.45), size=(td.inf, td.inf, 0), freqs=[3e14], name="orders"),
@@ -153,8 +153,8 @@ def test_bloch_run_end_to_end(emu_lib, tmp_path):
                                              y=td.Boundary.bloch_from_source(pw, 8 * DL, 1),
                                              z=td.Boundary(minus=td.PML(num_layers=6), plus=td.Absorber(num_layers=8))))
     path = str(tmp_path / "bloch.hdf5")
-    sd = run(sim, task_name="bloch", verbose=False, lib=emu_lib, n_steps=200, path=path)
-    disc = D.discretize(sim, n_steps=200)
+    sd = run(sim, task_name="bloch", verbose=False, lib=emu_lib, n_steps=110, path=path)
+    disc = D.discretize(sim, n_steps=110)
     ref = assemble(disc, OracleFdtd(disc.spec).run())
     assert sd["T"].flux.values == pytest.approx(ref["T"].flux.values, rel=1e-4)
     assert np.allclose(sd["orders"].power.values, ref["orders"].power.values, rtol=1e-3, atol=1e-6 * ref["T"].flux.values.max())

@@ -58,6 +58,8 @@ def _index_for_step(medium, freq: float, axis: int) -> float:
             return 1.0
         eps = np.array([complex(np.asarray(medium.eps_comp(c, freq)).ravel()[0]) for c in range(3)])
     else:
+        if isinstance(medium, td.Unsupported):
+            medium.fail()
         eps = np.array([complex(np.asarray(medium.eps_model(freq)).ravel()[0])] * 3)
     nk = np.sqrt(eps)
     return float(max(np.max(np.abs(nk.real)), np.max(np.abs(nk.imag))))
@@ -460,7 +462,10 @@ def make_coords_initial(sim, axis: int, g1d, wavelength: float, periodic: bool) 
             raise SetupError("unsupported mesh override structure")
         b0, b1 = ov.geometry.bounds
         if all(b0[d] <= d1[d] and b1[d] >= d0[d] for d in range(3)):
-            items.append(_Item((b0, b1), dl=tuple(ov.dl), enforce=getattr(ov, "enforce", False)))
+            if hasattr(ov, "dl"):
+                items.append(_Item((b0, b1), dl=tuple(ov.dl), enforce=getattr(ov, "enforce", False)))
+            else:       # a plain Structure among the overrides meshes like a structure of the simulation
+                items.append(_Item((b0, b1), medium=ov.medium))           # (ref grid_spec.py:471-480 StructureType)
     is_periodic = bool(periodic) and sim.symmetry[axis] == 0
     coords, max_dl = parse_structures(axis, items, wavelength, float(g1d.min_steps_per_wvl), float(g1d.dl_min or 0.0))
     coords, max_dl = insert_snapping_points(axis, coords, max_dl, getattr(sim.grid_spec, "snapping_points", None) or ())
