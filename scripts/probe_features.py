@@ -1,0 +1,46 @@
+"""Throughput of the paths added after the headline kernels: Bloch boundaries (complex fields = a (Re, Im)
+pair of solvers on the two-pass kernels + fix-up kernels) and Absorber layers (damping kernel), on a
+256 x 256 x 320-cell periodic-array set-up (Bloch / periodic in x, y; 40-layer absorber or 12-layer CPML in z).
+One JSON line per case: ms per step and Mcells/s of REAL cells (a complex cell counts once)."""
+import json
+import sys
+import time
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import tidy3d_amd.schema as td
+from tidy3d_amd.discretize import discretize
+from tidy3d_amd.engine import HipEngine
+
+
+def case(name, bx, by, bz, steps):
+    dl = 0.01
+    pulse = td.GaussianPulse(freq0=2e14, fwidth=2e13)
+    sim = td.Simulation(size=(2.56 - 1e-6, 2.56 - 1e-6, 2.4 - 1e-6), grid_spec=td.GridSpec.uniform(dl=dl), run_time=1e-12,
+                        subpixel=False,
+                        structures=[td.Structure(geometry=td.Cylinder(radius=0.6, length=0.3, axis=2),
+                                                 medium=td.Medium(permittivity=6.0))],
+                        sources=[td.PointDipole(center=(0.1, 0.2, -0.8), source_time=pulse, polarization="Ex")], monitors=[],
+                        boundary_spec=td.BoundarySpec(x=bx, y=by, z=bz), shutoff=0)
+    sp = discretize(sim, n_steps=steps + 40).spec
+    sp.decay_every = 0
+    with HipEngine(sp) as e:
+        e.run(20)
+        t0 = time.perf_counter()
+        e.run(steps)
+        dt = time.perf_counter() - t0
+    n = sp.shape[0] * sp.shape[1] * sp.shape[2]
+    print(json.dumps({"case": name, "shape": sp.shape, "complex": sp.bloch is not None, "ms_per_step": dt / steps * 1e3,
+                      "mcells_per_s": n * steps / dt / 1e6}), flush=True)
+
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    per, pml, ab = td.Boundary.periodic(), td.Boundary.pml(), td.Boundary.absorber()
+    case("periodic_xy_pml_z (fused sweep)", per, per, pml, steps)
+    case("periodic_xy_absorber_z (fused sweep + damp_kernel)", per, per, ab, steps)
+    case("bloch_xy_pml_z (two-pass pair + fix-ups)", td.Boundary.bloch(0.21), td.Boundary.bloch(0.13), pml, steps)
+    case("bloch_xy_absorber_z", td.Boundary.bloch(0.21), td.Boundary.bloch(0.13), ab, steps)
+
+
+if __name__ == "__main__":
+    main()
