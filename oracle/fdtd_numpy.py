@@ -117,7 +117,7 @@ class OracleFdtd:
         for m in spec.monitors:
             bz, by, bx = m.shape
             if m.kind == "time":
-                self.mon_data.append(np.zeros((len(m.steps), len(m.comps), bz, by, bx), self.rdtype))
+                self.mon_data.append(np.zeros((len(m.steps), len(m.comps), bz, by, bx), dtype))
             else:
                 self.mon_data.append(np.zeros((len(m.freqs), len(m.comps), bz, by, bx), complex))
             self.mon_count.append(0)
@@ -288,9 +288,9 @@ class OracleFdtd:
             for ic, c in enumerate(m.comps):
                 if m.kind == "time":
                     if c < 3 and phase == "pre":
-                        data[k, ic] = np.real(self._box(self.E[c], m))
+                        data[k, ic] = self._box(self.E[c], m)
                     elif c >= 3:
-                        data[k, ic] += 0.5 * np.real(self._box(self.H[c - 3], m))
+                        data[k, ic] += 0.5 * self._box(self.H[c - 3], m)
                 else:
                     if c < 3 and phase == "pre":
                         data[:, ic] += m.phase_e[k][:, None, None, None] * self._box(self.E[c], m)

@@ -517,8 +517,10 @@ def assemble(disc: Discretization, raw: Dict[str, np.ndarray], log: str = "", di
         elif plan.kind == "field_time":
             fp = plan.fields[0]
             t = disc.tmesh[plan.steps]
+            # real fields; complex ones under Bloch boundaries (ref simulation.py:4396-4411 complex_fields)
             out.append(_field_container(FieldTimeData, mon, spec, fp, raw[fp.spec_name], "t", t,
-                                        sim.center, np.float32, full_of(pfull, 0)))
+                                        sim.center, np.complex64 if spec.bloch is not None else np.float32,
+                                        full_of(pfull, 0)))
         elif plan.kind in ("flux", "flux_time"):
             is_time = plan.kind == "flux_time"
             lead = "t" if is_time else "f"
@@ -530,8 +532,9 @@ def assemble(disc: Discretization, raw: Dict[str, np.ndarray], log: str = "", di
                     pass
                 m = _M()
                 m.size, m.center, m.geometry = box.size, box.center, box
+                # the time-domain flux of a complex-field (Bloch) run is that of the physical field Re(E), Re(H)
                 fd = _field_container(FieldTimeData if is_time else FieldData, m, spec, fp,
-                                      raw[fp.spec_name], lead, lead_coords, sim.center,
+                                      np.real(raw[fp.spec_name]) if is_time else raw[fp.spec_name], lead, lead_coords, sim.center,
                                       np.float64 if is_time else np.complex128, full_of(pfull, isurf))
                 fl = plane_flux(fd, axis, m, sign=sign, box=box, lead=lead)
                 total = fl if total is None else DataArray(total.values + fl.values, fl.coords)

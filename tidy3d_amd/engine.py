@@ -417,10 +417,10 @@ class HipEngine:
             self._chk(self.lib.dll.fdtd_get_monitor(self.handle, mid, _ptr(arr), arr.nbytes),
                       "fdtd_get_monitor")
             out[m.name] = (arr, (lo2, hi2))
-        if self.twin is not None:       # complex fields: a DFT value is re + i im; time monitors keep the real part
+        if self.twin is not None:       # complex fields (ref simulation.py:4396 complex_fields): value = re + i im
             im = self.twin.monitor_data()
             for m, mid, _ in self.mon_ids:
-                if mid >= 0 and m.kind == "dft":
+                if mid >= 0:
                     out[m.name] = (out[m.name][0] + 1j * im[m.name][0], out[m.name][1])
         return out
 

@@ -2137,6 +2137,11 @@ class Simulation(_Model):
         return Box(center=self.center, size=self.size)
 
     @property
+    def complex_fields(self) -> bool:
+        """ref simulation.py:4396-4411: complex time-stepping fields with Bloch boundaries."""
+        return any(isinstance(e, BlochBoundary) for pair in self.boundary_spec.to_list for e in pair)
+
+    @property
     def mediums(self):
         """Distinct media, background first (ref scene.py:192)."""
         out = [self.medium]
