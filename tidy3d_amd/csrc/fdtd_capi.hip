@@ -503,8 +503,12 @@ void launch_damp(FdtdSolver* h, bool e_side, int kbeg, int kend, hipStream_t st)
       if (s_hi <= s_lo) continue;
       const long long bx = (a == 0) ? (s_hi - s_lo) : g.nx, by = (a == 1) ? (s_hi - s_lo) : g.ny;
       const long long bz = (a == 2) ? (s_hi - s_lo) : (kend - kbeg);
-      hipLaunchKernelGGL(damp_kernel, dim3(nblk(bx * by * bz)), dim3(256), 0, st, g, d, f0, f1, f2,
-                         e_side ? 0 : 1, a, s_lo, s_hi - s_lo, kbeg, kend);
+      if (a != 0 && g.nx % 4 == 0)
+        hipLaunchKernelGGL(damp4_kernel, dim3(nblk(bx / 4 * by * bz)), dim3(256), 0, st, g, d, f0, f1, f2,
+                           e_side ? 0 : 1, a, s_lo, s_hi - s_lo, kbeg, kend);
+      else
+        hipLaunchKernelGGL(damp_kernel, dim3(nblk(bx * by * bz)), dim3(256), 0, st, g, d, f0, f1, f2,
+                           e_side ? 0 : 1, a, s_lo, s_hi - s_lo, kbeg, kend);
     }
 }
 

@@ -1328,6 +1328,43 @@ __global__ __launch_bounds__(256) void damp_kernel(GridP g, DampP d, float* f0, 
   f2[idx] *= w2;
 }
 
+// y / z layers on float4-aligned rows: four x cells per thread (one 16-byte load and store per component)
+__global__ __launch_bounds__(256) void damp4_kernel(GridP g, DampP d, float* f0, float* f1, float* f2, int is_h,
+                                                    int a, int s_lo, int s_n, int kbeg, int kend) {
+  const long long bx = g.nx / 4, by = (a == 1) ? s_n : g.ny;
+  const long long bz = (a == 2) ? s_n : (kend - kbeg);
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= bx * by * bz) return;
+  const int i = 4 * (int)(t % bx);
+  const int j = (int)((t / bx) % by) + (a == 1 ? s_lo : 0);
+  const int k = (int)(t / (bx * by)) + (a == 2 ? s_lo : kbeg);
+  if (a == 2 && (j < d.lo[1] || j >= d.hi[1])) return;
+  const float4 bx4 = *reinterpret_cast<const float4*>(d.fb[0] + i);
+  const float4 cx4 = *reinterpret_cast<const float4*>(d.fc[0] + i);
+  const float byv = d.fb[1][j], cyv = d.fc[1][j];
+  const float bzv = d.fb[2][k], czv = d.fc[2][k];
+  const float bxs[4] = {bx4.x, bx4.y, bx4.z, bx4.w}, cxs[4] = {cx4.x, cx4.y, cx4.z, cx4.w};
+  const long long idx = (long long)k * g.sxy + (long long)j * g.nx + i;
+  float4 v0 = *reinterpret_cast<float4*>(f0 + idx);
+  float4 v1 = *reinterpret_cast<float4*>(f1 + idx);
+  float4 v2 = *reinterpret_cast<float4*>(f2 + idx);
+  float* p0 = reinterpret_cast<float*>(&v0);
+  float* p1 = reinterpret_cast<float*>(&v1);
+  float* p2 = reinterpret_cast<float*>(&v2);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    // cells of this row that lie in an x layer belong to the x launch (scalar kernel)
+    if (i + q < d.lo[0] || i + q >= d.hi[0]) continue;
+    float w0, w1, w2;            // same products, in the same order, as damp_kernel
+    if (is_h) { w0 = bxs[q] * cyv * czv; w1 = cxs[q] * byv * czv; w2 = cxs[q] * cyv * bzv; }
+    else      { w0 = cxs[q] * byv * bzv; w1 = bxs[q] * cyv * bzv; w2 = bxs[q] * byv * czv; }
+    p0[q] *= w0; p1[q] *= w1; p2[q] *= w2;
+  }
+  *reinterpret_cast<float4*>(f0 + idx) = v0;
+  *reinterpret_cast<float4*>(f1 + idx) = v1;
+  *reinterpret_cast<float4*>(f2 + idx) = v2;
+}
+
 // ---- Bloch boundaries (complex fields as a (Re, Im) pair of real field sets) ------------------
 // F(r + L_a) = exp(i phi_a) F(r).  The update kernels wrap periodic axes with phase 1; because the
 // updates are linear in the wrapped neighbour the phase is restored afterwards on the one column /

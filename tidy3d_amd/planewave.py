@@ -1,4 +1,7 @@
-"""PlaneWave and TFSF sources -> TfsfSpec (1-D auxiliary incident grid + surface correction lists).
+"""Field sources.  PlaneWave (normal incidence) and TFSF -> TfsfSpec (1-D auxiliary incident grid + surface
+correction lists); oblique PlaneWave, GaussianBeam / AstigmaticGaussianBeam and CustomFieldSource -> a sheet
+of electric and magnetic currents on the source plane (``_sheet_source``: the same surface legs, fed with
+an analytic or tabulated incident field instead of the 1-D grid).
 
 ref components/source.py:1090 (PlaneWave), :1204-1257 (TFSF: the box is the total-field region,
 the plane wave carries 1 W/um^2 along the injection axis), :966-990 (polarisation vector:
