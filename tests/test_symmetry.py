@@ -133,3 +133,22 @@ def test_mode_source_and_monitor_with_symmetry():
     np.testing.assert_allclose(quarter["flux"].flux.values, full["flux"].flux.values, rtol=2e-4)
     ez_f, ez_q = full["xs"].Ey.values, quarter["xs"].Ey.values
     assert np.abs(ez_f - ez_q).max() <= 2e-4 * np.abs(ez_f).max()
+
+
+def test_symmetry_with_absorber_and_bloch_boundaries():
+    """Absorber layers sit behind the plus faces of the computed half; a Bloch axis (no symmetry along it,
+    ref simulation.py bloch_with_symmetry) keeps its phase."""
+    ab = td.BoundarySpec(x=td.Boundary.absorber(num_layers=5, parameters=td.AbsorberParams(sigma_max=1.5)),
+                         y=td.Boundary.pml(num_layers=4), z=td.Boundary.absorber(num_layers=4))
+    _, full = _run_oracle(_sim((0, 0, 0), boundary_spec=ab), 80)
+    _, half = _run_oracle(_sim((1, 1, -1), boundary_spec=ab), 80)
+    _compare(full, half, 3e-6)
+    bl = td.BoundarySpec(x=td.Boundary.pml(num_layers=4), y=td.Boundary.bloch(0.23), z=td.Boundary.pml(num_layers=4))
+    mons = [m for m in _sim((0, 0, 0)).monitors if m.name in ("plane", "box", "below")]
+    dfull, full = _run_oracle(_sim((0, 0, 0), boundary_spec=bl, monitors=mons), 80)
+    dhalf, half = _run_oracle(_sim((1, 0, -1), boundary_spec=bl, monitors=mons), 80)
+    assert dhalf.spec.bloch == pytest.approx(dfull.spec.bloch) and dhalf.spec.bloch[1] != 0
+    _compare(full, half, 3e-6)
+    from tidy3d_amd.exceptions import SetupError
+    with pytest.raises(SetupError, match="symmetry along the same axis"):
+        D.discretize(_sim((0, 1, 0), boundary_spec=bl, monitors=mons), n_steps=2)
