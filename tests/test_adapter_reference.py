@@ -273,3 +273,31 @@ def test_diffraction_data_entry_fits_the_reference_classes(td_ref):
     for k in ("Er", "Etheta", "Ephi", "Hr", "Htheta", "Hphi"):
         assert entry[k] == "DiffractionDataArray"
         assert tuple(arrays[f"/data/0/{k}"].dims) == tuple(DATA_ARRAY_MAP["DiffractionDataArray"]._dims)
+
+
+def test_mode_solver_data_entry_fits_the_reference_classes(td_ref):
+    """ModeSolverData in the .hdf5 JSON model against the reference's ModeSolverData / ModeSolverMonitor."""
+    from oracle.fdtd_numpy import OracleFdtd
+    from tidy3d.components.data.data_array import DATA_ARRAY_MAP
+    import tidy3d_amd.schema as mt
+    from tidy3d_amd.data import assemble
+    from tidy3d_amd.discretize import discretize
+    from tidy3d_amd.hdf5io import simulation_data_model
+    td = td_ref
+    sim = mt.Simulation(size=(0.4, 1.2, 0.8), grid_spec=mt.GridSpec.uniform(dl=0.05), run_time=1e-14, subpixel=False,
+                        structures=[mt.Structure(geometry=mt.Box(size=(mt.inf, 0.45, 0.22)), medium=mt.Medium(permittivity=12.0))],
+                        sources=[mt.PointDipole(source_time=mt.GaussianPulse(freq0=2e14, fwidth=2e13), polarization="Ey")],
+                        monitors=[mt.ModeSolverMonitor(center=(0, 0, 0), size=(0, 1.0, 0.6), freqs=[2e14], name="modes",
+                                                       mode_spec=mt.ModeSpec(num_modes=2))],
+                        boundary_spec=mt.BoundarySpec.all_sides(mt.PECBoundary()))
+    disc = discretize(sim, n_steps=2)
+    model, arrays = simulation_data_model(assemble(disc, OracleFdtd(disc.spec).run()))
+    entry = model["data"][0]
+    assert entry["type"] == "ModeSolverData"
+    assert set(entry) - {"type"} <= set(td.ModeSolverData.__fields__), set(entry) - set(td.ModeSolverData.__fields__)
+    m_ref = td.ModeSolverMonitor.parse_obj(entry["monitor"])
+    assert m_ref.name == "modes" and m_ref.mode_spec.num_modes == 2 and m_ref.direction == "+"
+    td.Grid.parse_obj(entry["grid_expanded"])
+    for k in ("Ex", "Ey", "Ez", "Hx", "Hy", "Hz"):
+        assert tuple(arrays[f"/data/0/{k}"].dims) == tuple(DATA_ARRAY_MAP[entry[k]]._dims)
+    assert tuple(arrays["/data/0/n_complex"].dims) == tuple(DATA_ARRAY_MAP[entry["n_complex"]]._dims)

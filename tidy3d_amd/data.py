@@ -551,6 +551,13 @@ def assemble(disc: Discretization, raw: Dict[str, np.ndarray], log: str = "", di
             fn = {"projection_angle": projection.project_angle, "projection_cartesian": projection.project_cartesian,
                   "projection_kspace": projection.project_kspace}[plan.kind]
             out.append(fn(disc, plan, raw, norm))
+        elif plan.kind == "mode_solver":
+            from .plugins.mode import ModeSolver
+            ms = ModeSolver(simulation=sim, plane=mon.geometry, mode_spec=mon.mode_spec, freqs=mon.freqs,
+                            direction=mon.direction, colocate=bool(mon.colocate))
+            md = ms.solve(spec=spec)
+            md.monitor, md.grid_expanded = mon, _grid_expanded(spec, plan.fields[0])
+            out.append(md)
         elif plan.kind == "diffraction":
             from . import projection
             out.append(projection.diffraction(disc, plan, raw, norm))

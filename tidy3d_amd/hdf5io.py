@@ -431,6 +431,16 @@ def simulation_data_model(sim_data) -> Tuple[dict, Dict[str, Any]]:
         elif kind == "ModeData":
             entry["amps"], entry["n_complex"] = "ModeAmpsDataArray", "ModeIndexDataArray"
             arrays[f"{base}/amps"], arrays[f"{base}/n_complex"] = d.amps, d.n_complex
+        elif kind == "ModeSolverData":
+            # ref monitor_data.py ModeSolverData: six ScalarModeFieldDataArrays + n_complex
+            entry["symmetry"] = [0, 0, 0]
+            entry["symmetry_center"] = [float(v) for v in sim.center]
+            entry["grid_expanded"] = _grid_json(d.grid_expanded)
+            entry["n_complex"] = "ModeIndexDataArray"
+            arrays[f"{base}/n_complex"] = d.n_complex
+            for name, arr in d.field_components.items():
+                entry[name] = "ScalarModeFieldDataArray"
+                arrays[f"{base}/{name}"] = arr
         elif kind in ("FieldProjectionAngleData", "FieldProjectionCartesianData", "FieldProjectionKSpaceData"):
             from .discretize import flux_surfaces
             mon = d.monitor
@@ -503,6 +513,7 @@ def load_simulation_data(path: str):
     dims = {"ScalarFieldDataArray": ("x", "y", "z", "f"), "ScalarFieldTimeDataArray": ("x", "y", "z", "t"),
             "FluxDataArray": ("f",), "FluxTimeDataArray": ("t",), "ModeAmpsDataArray": ("direction", "f", "mode_index"),
             "ModeIndexDataArray": ("f", "mode_index"),
+            "ScalarModeFieldDataArray": ("x", "y", "z", "f", "mode_index"),
             "FieldProjectionAngleDataArray": ("r", "theta", "phi", "f"),
             "FieldProjectionCartesianDataArray": ("x", "y", "z", "f"),
             "FieldProjectionKSpaceDataArray": ("ux", "uy", "r", "f"),
@@ -533,6 +544,10 @@ def load_simulation_data(path: str):
             out.append(FluxTimeData(monitor=mon, flux=fields["flux"]))
         elif kind == "ModeData":
             out.append(ModeData(monitor=mon, amps=fields["amps"], n_complex=fields["n_complex"]))
+        elif kind == "ModeSolverData":
+            from .plugins.mode import ModeSolverData
+            out.append(ModeSolverData(monitor=mon, grid_expanded={d: np.asarray(e["grid_expanded"]["boundaries"][d])
+                                                                  for d in "xyz"}, **fields))
         elif kind in ("FieldProjectionAngleData", "FieldProjectionCartesianData", "FieldProjectionKSpaceData"):
             from . import projection
             out.append(getattr(projection, kind)(monitor=mon, **fields))

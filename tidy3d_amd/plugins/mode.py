@@ -29,6 +29,7 @@ class ModeSolverData:
     Hx: Optional[DataArray] = None
     Hy: Optional[DataArray] = None
     Hz: Optional[DataArray] = None
+    grid_expanded: Optional[Dict[str, np.ndarray]] = None
 
     @property
     def n_eff(self) -> DataArray:
@@ -53,12 +54,13 @@ class ModeSolver:
             raise SetupError("a mode plane needs exactly one zero-size dimension")
         self.normal_axis = zd[0]
 
-    def solve(self) -> ModeSolverData:
+    def solve(self, spec=None) -> ModeSolverData:
+        """``spec``: an already discretised simulation (the FDTD run's own SolverSpec)."""
         sim = self.simulation
         if any(sim.symmetry):
             raise NotImplementedError("ModeSolver façade: run on the symmetry-free simulation")
-        disc = discretize(sim, n_steps=1)
-        spec = disc.spec
+        if spec is None:
+            spec = discretize(sim, n_steps=1).spec
         p = self.normal_axis
         nm = int(self.mode_spec.num_modes)
         sign = 1 if self.direction == "+" else -1

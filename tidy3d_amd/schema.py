@@ -1922,6 +1922,18 @@ class ModeMonitor(_Monitor):
 
 @_register
 @dataclass
+class ModeSolverMonitor(ModeMonitor):
+    """Stores the modes of its plane themselves (ref monitor.py:712-760): ModeSolverData with the six field
+    components per frequency and mode index, computed by the mode solver the FDTD run uses
+    (tidy3d_amd/plugins/mode.py)."""
+
+    name: str = "mode_solver"
+    colocate: bool = True
+    direction: str = "+"
+
+
+@_register
+@dataclass
 class PermittivityMonitor(_Monitor):
     """Diagonal of the complex relative permittivity at the Yee locations of E (ref monitor.py:447);
     never colocated (ref monitor.py:469-474)."""
