@@ -124,16 +124,32 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("BENCH_SINGLE_DEVICE"):      # debugging aid: several ranks on one GPU
         local_rank = 0
+    # BENCH_EMULATE=1 (tests/test_bench_dryrun.py): the same rank logic on CPU — gloo instead of RCCL for the
+    # torch side, the HIP sources under the emulator with its RCCL shim.  Never set on a GPU box.
+    emulate = bool(os.environ.get("BENCH_EMULATE"))
+    lib = None
+    if emulate:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+        import build_emu
+        import dist_worker
+        lib = L.load_library(build_emu.build())
+        _cb = dist_worker.EXCHANGE_FN(dist_worker._exchange)
+        lib.dll.hipemu_set_exchange(_cb, None)
+        local_rank = 0
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if emulate:
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     n, K, W = args.n, args.steps, args.warmup
     spec = build_spec(n, K + W + 64, args.workload)
     slabs = split_slabs(n, world)
-    eng = HipEngine(spec, device=local_rank, variant=args.variant, z_chunk=args.zchunk,
+    eng = HipEngine(spec, lib=lib, device=local_rank, variant=args.variant, z_chunk=args.zchunk,
                     slab=slabs[rank], rank=rank, n_ranks=world)
     if args.rows:
         eng.set_option(L.OPT_ROWS, args.rows)
@@ -152,8 +168,12 @@ def main():
             arr[k - z0] = np.random.default_rng(c * 100003 + k).uniform(-1e-3, 1e-3, (n, n)).astype(np.float32)
         eng.set_field(c, arr)
 
+    def dev_sync():
+        if not emulate:
+            torch.cuda.synchronize()
+
     def sync():
-        torch.cuda.synchronize()
+        dev_sync()
         if world > 1:
             dist.barrier()
 
@@ -161,7 +181,7 @@ def main():
         sync()
         t0 = time.perf_counter()
         eng.run(k)
-        torch.cuda.synchronize()
+        dev_sync()
         if world > 1:
             dist.barrier()
         return time.perf_counter() - t0
@@ -169,7 +189,7 @@ def main():
     eng.run(W)
     elapsed = timed(K)
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda")
+        t = torch.tensor([elapsed], device="cpu" if emulate else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     cells = n ** 3
