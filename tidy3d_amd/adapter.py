@@ -90,6 +90,14 @@ def to_tidy3d(sim_data: SimulationData, td_simulation=None):
                      for k, v in d.field_components.items()}
             out.append(td.FieldProjectionAngleData(monitor=mon, projection_surfaces=mon.projection_surfaces,
                                                    medium=mon.medium or td_simulation.medium, **comps))
+        elif type(d).__name__ == "ModeSolverData":
+            comps = {k: td.ScalarModeFieldDataArray(v.values, coords={dim: v.coords[dim] for dim in v.dims})
+                     for k, v in d.field_components.items()}
+            out.append(td.ModeSolverData(
+                monitor=mon, symmetry=(0, 0, 0), symmetry_center=td_simulation.center,
+                grid_expanded=td_simulation.discretize_monitor(mon),
+                n_complex=td.ModeIndexDataArray(d.n_complex.values,
+                                                coords={dim: d.n_complex.coords[dim] for dim in d.n_complex.dims}), **comps))
         elif type(d).__name__ == "DiffractionData":
             comps = {k: td.DiffractionDataArray(v.values, coords={dim: v.coords[dim] for dim in v.dims})
                      for k, v in d.field_components.items()}
