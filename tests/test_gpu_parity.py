@@ -33,7 +33,8 @@ def test_gpu_matches_oracle_small(name, hip_lib):
     assert worst < TOL, (name, disc.spec.shape, worst)
 
 
-@pytest.mark.parametrize("name", ["pec_box_vec", "media_mix", "drude_in_pml", "pml_box"])
+@pytest.mark.parametrize("name", ["pec_box_vec", "media_mix", "drude_in_pml", "pml_box", "absorber_mix", "bloch_xy_pml_z",
+                                  "bloch_planewave"])
 def test_gpu_matches_oracle_medium(name, hip_lib):
     """~3x larger grids (several workgroups per axis, several z-chunks), 100 steps."""
     worst, disc = run_case(name, hip_lib, n_steps=100, scale=3, z_chunk=8)
