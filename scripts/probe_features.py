@@ -12,10 +12,10 @@ from tidy3d_amd.discretize import discretize
 from tidy3d_amd.engine import HipEngine
 
 
-def case(name, bx, by, bz, steps):
+def case(name, bx, by, bz, steps, lxy=2.56):
     dl = 0.01
     pulse = td.GaussianPulse(freq0=2e14, fwidth=2e13)
-    sim = td.Simulation(size=(2.56 - 1e-6, 2.56 - 1e-6, 2.4 - 1e-6), grid_spec=td.GridSpec.uniform(dl=dl), run_time=1e-12,
+    sim = td.Simulation(size=(lxy - 1e-6, lxy - 1e-6, 2.4 - 1e-6), grid_spec=td.GridSpec.uniform(dl=dl), run_time=1e-12,
                         subpixel=False,
                         structures=[td.Structure(geometry=td.Cylinder(radius=0.6, length=0.3, axis=2),
                                                  medium=td.Medium(permittivity=6.0))],
@@ -38,8 +38,11 @@ def main():
     per, pml, ab = td.Boundary.periodic(), td.Boundary.pml(), td.Boundary.absorber()
     case("periodic_xy_pml_z (fused sweep)", per, per, pml, steps)
     case("periodic_xy_absorber_z (fused sweep + damp_kernel)", per, per, ab, steps)
-    case("bloch_xy_pml_z (two-pass pair + fix-ups)", td.Boundary.bloch(0.21), td.Boundary.bloch(0.13), pml, steps)
+    case("bloch_xy_pml_z (solver pair on the ghost-cell layout)", td.Boundary.bloch(0.21), td.Boundary.bloch(0.13), pml, steps)
     case("bloch_xy_absorber_z", td.Boundary.bloch(0.21), td.Boundary.bloch(0.13), ab, steps)
+    # 248 real cells + 2 ghost cells stay inside one 256-cell x tile of the fused sweep
+    case("periodic_xy_pml_z 248", per, per, pml, steps, 2.48)
+    case("bloch_xy_pml_z 248", td.Boundary.bloch(0.21), td.Boundary.bloch(0.13), pml, steps, 2.48)
 
 
 if __name__ == "__main__":

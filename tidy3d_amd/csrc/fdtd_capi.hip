@@ -1487,19 +1487,25 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
 
 // Complex (Bloch-periodic) fields: two solvers carry Re and Im of the same simulation (identical grid,
 // media, CPML, ADE and monitors; the Im solver's source weights are the Re solver's times -i) and are
-// stepped together on the Re solver's stream; they only meet in the Bloch fix-ups (fdtd_kernels.hpp).
-// Two-pass kernels, one GPU.  phase[a] = 2 pi bloch_vec of axis a (ref boundary.py:55-79 bloch_phase);
-// axes that are not periodic in the configuration ignore it.
-int fdtd_run_bloch(FdtdSolver* hr, FdtdSolver* hi, int64_t n_steps, const double phase[3], FdtdProgressFn progress,
-                   void* user) {
+// stepped together on the Re solver's stream; they only meet in the ghost fills (fdtd_kernels.hpp).
+// phase[a] = 2 pi bloch_vec of axis a (ref boundary.py:55-79 bloch_phase).  n_real[a] > 0 (a = x, y): the
+// axis carries ghost cells at device index 0 and n_real[a] + 1 (the host builds the grid that way and
+// declares PEC walls); z uses its ghost planes when the z faces are FDTD_BC_PERIODIC.  One GPU; the
+// fused sweep unless the handles ask for the two-pass kernels.
+int fdtd_run_bloch(FdtdSolver* hr, FdtdSolver* hi, int64_t n_steps, const double phase[3], const int n_real[3],
+                   FdtdProgressFn progress, void* user) {
   if (!hr || !hi) return -1;
   if (hr->comm || hi->comm) return fail(hr, "fdtd_run_bloch: z-slab communicators are not supported with Bloch boundaries");
   if (hr->g.nx != hi->g.nx || hr->g.ny != hi->g.ny || hr->g.nz != hi->g.nz || hr->cfg.device != hi->cfg.device ||
       hr->mons.size() != hi->mons.size() || hr->step != hi->step)
     return fail(hr, "fdtd_run_bloch: the two solvers must describe the same simulation");
-  HIPCHK(hr, hipSetDevice(hr->cfg.device));
   const GridP& g = hr->g;
   const int nz = g.nz;
+  const int N[3] = {g.nx, g.ny, nz};
+  for (int a = 0; a < 2; ++a)
+    if (n_real[a] < 0 || (n_real[a] > 0 && n_real[a] + 2 > N[a]))
+      return fail(hr, "fdtd_run_bloch: axis %d has %d cells, cannot hold %d real cells + 2 ghost cells", a, N[a], n_real[a]);
+  HIPCHK(hr, hipSetDevice(hr->cfg.device));
   hipStream_t st = hr->stream;
   HIPCHK(hr, hipStreamSynchronize(hi->stream));
   FdtdSolver* both[2] = {hr, hi};
@@ -1509,67 +1515,68 @@ int fdtd_run_bloch(FdtdSolver* hr, FdtdSolver* hi, int64_t n_steps, const double
     h->stats.stopped_early = 0;
   }
   HIPCHK(hr, hipEventRecord(hr->ev0, st));
-  const bool per[3] = {hr->cfg.bc[0] == FDTD_BC_PERIODIC, hr->cfg.bc[2] == FDTD_BC_PERIODIC,
-                       hr->cfg.bc[4] == FDTD_BC_PERIODIC};
+  const bool per_z = hr->cfg.bc[4] == FDTD_BC_PERIODIC;
+  const bool fused = (g.nx % 4 == 0) && hr->rows_f <= 15 &&
+                     (hr->cfg.variant == FDTD_VARIANT_FUSED || hr->cfg.variant == FDTD_VARIANT_AUTO);
+  if (fused) for (FdtdSolver* h : both) if (ensure_second_set(h)) return -1;
   float cph[3], sph[3];
   for (int a = 0; a < 3; ++a) { cph[a] = (float)std::cos(phase[a]); sph[a] = (float)std::sin(phase[a]); }
   const long long pc = plane_cells(hr);
-  auto cp = [&](int comp) { CplxP c; c.re = field_ptr(hr, comp); c.im = field_ptr(hi, comp); return c; };
-  const int N[3] = {g.nx, g.ny, nz};
+  // (pointers are taken at call time: the fused sweep swaps the field sets every step)
+  auto six = [&]() { Cplx6P F; for (int c = 0; c < 6; ++c) { F.f[c].re = field_ptr(hr, c); F.f[c].im = field_ptr(hi, c); } return F; };
+  auto fill_xy = [&]() {          // y first, then x over all rows (ghost rows included): corners get both phases
+    for (int a = 1; a >= 0; --a) {
+      if (n_real[a] <= 0) continue;
+      const long long cells = (long long)(a == 0 ? g.ny : g.nx) * nz;
+      hipLaunchKernelGGL(bloch_ghost_fill_kernel, dim3(nblk(cells)), dim3(256), 0, st, g, a, n_real[a], six(), cph[a], sph[a], nz);
+    }
+  };
+  auto plane = [&](int c, long long dst_plane, long long src_plane, float s) {
+    hipLaunchKernelGGL(bloch_plane_kernel, dim3(nblk(pc)), dim3(256), 0, st, field_ptr(hr, c) + dst_plane * pc,
+                       field_ptr(hi, c) + dst_plane * pc, (const float*)(field_ptr(hr, c) + src_plane * pc),
+                       (const float*)(field_ptr(hi, c) + src_plane * pc), cph[2], s, pc);
+  };
   int64_t done = 0;
   for (; done < n_steps; ++done) {
     const long long n = hr->step;
     bool rec = false;
     for (Monitor& m : hr->mons) if (m.next < m.steps.size() && m.steps[m.next] == n) rec = true;
     if (rec) for (FdtdSolver* h : both) record_monitors(h, n, false, st);
-    // ---------------- H phase ----------------
+    // H-side corrections of both parts, then the ghost cells (they must carry the corrections too)
     for (FdtdSolver* h : both) {
       launch_damp(h, false, 0, nz, st);
       launch_sources(h, false, n, 0, nz, st);
       launch_pml(h, false, 0, nz, st);
-      launch_h_main(h, 0, nz, st);
     }
-    for (int a = 0; a < 2; ++a) {
-      if (!per[a] || phase[a] == 0.0) continue;
-      const int c1 = (a + 1) % 3, c2 = (a + 2) % 3;
-      const long long cells = (long long)N[c1] * N[c2];
-      hipLaunchKernelGGL(bloch_h_fix_kernel, dim3(nblk(cells)), dim3(256), 0, st, g, a, cp(3 + c1), cp(3 + c2),
-                         cp(c1), cp(c2), (const float*)hr->ip[a], cph[a], sph[a], nz);
-    }
-    if (per[2]) {      // ghost(-1) = exp(-i phi_z) H[nz-1]
-      for (int c = 3; c < 5; ++c)
-        hipLaunchKernelGGL(bloch_plane_kernel, dim3(nblk(pc)), dim3(256), 0, st, field_ptr(hr, c) - pc, field_ptr(hi, c) - pc,
-                           (const float*)(field_ptr(hr, c) + (long long)(nz - 1) * pc),
-                           (const float*)(field_ptr(hi, c) + (long long)(nz - 1) * pc), cph[2], -sph[2], pc);
+    fill_xy();
+    if (fused) {
+      if (per_z) {       // ghost(-1) = exp(-i phi_z) [E (3 comps), H_x, H_y][nz-1];  ghost(nz) = exp(+i phi_z) E_{x,y}[0]
+        for (int c = 0; c < 5; ++c) plane(c, -1, nz - 1, -sph[2]);
+        plane(0, nz, 0, sph[2]);
+        plane(1, nz, 0, sph[2]);
+      }
+      for (FdtdSolver* h : both) if (launch_fused(h, st, 0)) return -1;
+      if (rec) for (FdtdSolver* h : both) record_monitors(h, n, true, st);
+      for (FdtdSolver* h : both) {
+        launch_pml(h, true, 0, nz, st);
+        launch_sources(h, true, n, 0, nz, st);
+        launch_damp(h, true, 0, nz, st);
+        launch_ade(h, 0, nz, st);
+      }
     } else {
-      for (FdtdSolver* h : both) fill_ghost_h(h, st);
-    }
-    if (rec) for (FdtdSolver* h : both) record_monitors(h, n, true, st);
-    // ---------------- E phase ----------------
-    for (FdtdSolver* h : both) {
-      launch_e_main(h, 0, nz, st);
-      launch_pml(h, true, 0, nz, st);
-      launch_sources(h, true, n, 0, nz, st);
-    }
-    for (int a = 0; a < 2; ++a) {
-      if (!per[a] || phase[a] == 0.0) continue;
-      const int c1 = (a + 1) % 3, c2 = (a + 2) % 3;
-      const long long cells = (long long)N[c1] * N[c2];
-      hipLaunchKernelGGL(bloch_e_fix_kernel, dim3(nblk(cells)), dim3(256), 0, st, g, a, cp(c1), cp(c2), cp(3 + c1),
-                         cp(3 + c2), (const float*)hr->idl[a], (const uint32_t*)hr->mat4, (const float2*)hr->lut,
-                         hr->cb1, cph[a], sph[a], nz);
-    }
-    for (FdtdSolver* h : both) {
-      launch_damp(h, true, 0, nz, st);
-      launch_ade(h, 0, nz, st);
-    }
-    if (per[2]) {      // ghost(nz) = exp(+i phi_z) E[0]
-      for (int c = 0; c < 2; ++c)
-        hipLaunchKernelGGL(bloch_plane_kernel, dim3(nblk(pc)), dim3(256), 0, st, field_ptr(hr, c) + (long long)nz * pc,
-                           field_ptr(hi, c) + (long long)nz * pc, (const float*)field_ptr(hr, c),
-                           (const float*)field_ptr(hi, c), cph[2], sph[2], pc);
-    } else {
-      for (FdtdSolver* h : both) fill_ghost_e(h, st);
+      if (per_z) { plane(0, nz, 0, sph[2]); plane(1, nz, 0, sph[2]); }      // E ghost(nz) of E^n (first step / after set_field)
+      for (FdtdSolver* h : both) launch_h_main(h, 0, nz, st);
+      if (per_z) { plane(3, -1, nz - 1, -sph[2]); plane(4, -1, nz - 1, -sph[2]); }
+      else for (FdtdSolver* h : both) fill_ghost_h(h, st);
+      if (rec) for (FdtdSolver* h : both) record_monitors(h, n, true, st);
+      for (FdtdSolver* h : both) {
+        launch_e_main(h, 0, nz, st);
+        launch_pml(h, true, 0, nz, st);
+        launch_sources(h, true, n, 0, nz, st);
+        launch_damp(h, true, 0, nz, st);
+        launch_ade(h, 0, nz, st);
+      }
+      if (!per_z) for (FdtdSolver* h : both) fill_ghost_e(h, st);
     }
     hr->step = hi->step = n + 1;
     // ---------------- field decay / divergence (|E|^2 of both parts) ----------------
@@ -1602,6 +1609,8 @@ int fdtd_run_bloch(FdtdSolver* hr, FdtdSolver* hi, int64_t n_steps, const double
       }
     }
   }
+  // leave the ghost cells of E^n, H^{n-1/2} consistent for whoever reads the fields next
+  fill_xy();
   HIPCHK(hr, hipEventRecord(hr->ev1, st));
   HIPCHK(hr, hipStreamSynchronize(st));
   HIPCHK(hr, hipGetLastError());

@@ -1366,72 +1366,42 @@ __global__ __launch_bounds__(256) void damp4_kernel(GridP g, DampP d, float* f0,
 }
 
 // ---- Bloch boundaries (complex fields as a (Re, Im) pair of real field sets) ------------------
-// F(r + L_a) = exp(i phi_a) F(r).  The update kernels wrap periodic axes with phase 1; because the
-// updates are linear in the wrapped neighbour the phase is restored afterwards on the one column /
-// row that uses it (x, y), and the z ghost planes are filled with the rotated copy directly.
-//   H side, last index L of axis a:  ghost E[L+1] = exp(+i phi) E[0]
-//       H_{a+1}[L] += ch ip[L] (exp(i phi) - 1) E_{a+2}[0],   H_{a+2}[L] -= ch ip[L] (exp(i phi) - 1) E_{a+1}[0]
-//   E side, index 0:                 ghost H[-1] = exp(-i phi) H[L]
-//       E_{a+1}[0] += Cb id[0] (exp(-i phi) - 1) H_{a+2}[L],  E_{a+2}[0] -= Cb id[0] (exp(-i phi) - 1) H_{a+1}[L]
+// F(r + L_a) = exp(i phi_a) F(r).  A Bloch axis carries one ghost cell at each end of the device grid
+// (index 0 and n_real + 1; the real cells are 1 .. n_real; the kernels see PEC walls there and never
+// wrap), refilled once per step, before the main kernels, with the rotated copy of the cell one period
+// away:   F[0] = exp(-i phi) F[n_real],   F[n_real + 1] = exp(+i phi) F[1]   (all six components).
+// The update kernels — the fused sweep included — then run unchanged: every real cell finds valid
+// neighbours, what they write INTO the ghost cells is overwritten by the next fill, and the z direction
+// uses the ghost planes it always had, filled with the rotated copy (bloch_plane_kernel).
 struct CplxP {
   float* re; float* im;
 };
 
-__global__ __launch_bounds__(256) void bloch_h_fix_kernel(GridP g, int a, CplxP h1, CplxP h2, CplxP e1, CplxP e2,
-                                                          const float* ip, float cphi, float sphi, int nz) {
-  const int N[3] = {g.nx, g.ny, nz};
-  const int u = (a + 1) % 3, v = (a + 2) % 3;
-  const long long total = (long long)N[u] * N[v];
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= total) return;
-  // thread -> (other two indices), x fastest when it is one of them
-  int idx[3];
-  const int lo = u < v ? u : v, hi = u < v ? v : u;
-  idx[lo] = (int)(t % N[lo]); idx[hi] = (int)(t / N[lo]);
-  idx[a] = 0;
-  const long long p0 = (long long)idx[2] * g.sxy + (long long)idx[1] * g.nx + idx[0];
-  const long long stride = (a == 0) ? 1 : (a == 1 ? (long long)g.nx : g.sxy);
-  const long long pl = p0 + (long long)(N[a] - 1) * stride;
-  const float w = g.ch * ip[N[a] - 1];
-  const float cm = cphi - 1.f;
-  const float e1r = e1.re[p0], e1i = e1.im[p0], e2r = e2.re[p0], e2i = e2.im[p0];
-  h1.re[pl] += w * (cm * e2r - sphi * e2i);
-  h1.im[pl] += w * (cm * e2i + sphi * e2r);
-  h2.re[pl] -= w * (cm * e1r - sphi * e1i);
-  h2.im[pl] -= w * (cm * e1i + sphi * e1r);
-}
+struct Cplx6P {
+  CplxP f[6];
+};
 
-__global__ __launch_bounds__(256) void bloch_e_fix_kernel(GridP g, int a, CplxP e1, CplxP e2, CplxP h1, CplxP h2,
-                                                          const float* idl, const uint32_t* m4, const float2* lut,
-                                                          float cb_uniform, float cphi, float sphi, int nz) {
-  const int N[3] = {g.nx, g.ny, nz};
-  const int c1 = (a + 1) % 3, c2 = (a + 2) % 3;
-  const long long total = (long long)N[c1] * N[c2];
+// axis a in {0, 1}; threads over the planes perpendicular to a (the other in-plane axis with ITS ghost
+// cells — corners — and all nz planes)
+__global__ __launch_bounds__(256) void bloch_ghost_fill_kernel(GridP g, int a, int n_real, Cplx6P F, float cphi,
+                                                               float sphi, int nz) {
+  const int nb = (a == 0) ? g.ny : g.nx;
+  const long long total = (long long)nb * nz;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
-  int idx[3];
-  const int lo = c1 < c2 ? c1 : c2, hi = c1 < c2 ? c2 : c1;
-  idx[lo] = (int)(t % N[lo]); idx[hi] = (int)(t / N[lo]);
-  idx[a] = 0;
-  const long long p0 = (long long)idx[2] * g.sxy + (long long)idx[1] * g.nx + idx[0];
-  const long long stride = (a == 0) ? 1 : (a == 1 ? (long long)g.nx : g.sxy);
-  const long long pl = p0 + (long long)(N[a] - 1) * stride;
-  const uint32_t mw = m4 ? m4[p0] : 0u;
-  const float cb1 = m4 ? lut[(mw >> (8 * c1)) & 255u].y : cb_uniform;
-  const float cb2 = m4 ? lut[(mw >> (8 * c2)) & 255u].y : cb_uniform;
-  const int bc0[3] = {g.bcx0, g.bcy0, g.pec_z0 ? BC_PEC : BC_NEIGHBOR};
-  const bool w1 = (idx[c2] == 0) && (bc0[c2] == BC_PEC);   // E_{c1} is tangential to the c2-wall
-  const bool w2 = (idx[c1] == 0) && (bc0[c1] == BC_PEC);
-  const float cm = cphi - 1.f, id0 = idl[0];
-  const float h1r = h1.re[pl], h1i = h1.im[pl], h2r = h2.re[pl], h2i = h2.im[pl];
-  // (exp(-i phi) - 1) (hr + i hi) = (cm hr + s hi) + i (cm hi - s hr)
-  if (!w1) {
-    e1.re[p0] += cb1 * id0 * (cm * h2r + sphi * h2i);
-    e1.im[p0] += cb1 * id0 * (cm * h2i - sphi * h2r);
-  }
-  if (!w2) {
-    e2.re[p0] -= cb2 * id0 * (cm * h1r + sphi * h1i);
-    e2.im[p0] -= cb2 * id0 * (cm * h1i - sphi * h1r);
+  const int o = (int)(t % nb), k = (int)(t / nb);
+  const long long stride = (a == 0) ? 1 : (long long)g.nx;
+  const long long base = (long long)k * g.sxy + ((a == 0) ? (long long)o * g.nx : (long long)o);
+  const long long p_lo = base, p_first = base + stride, p_last = base + (long long)n_real * stride,
+                  p_hi = base + (long long)(n_real + 1) * stride;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const float lr = F.f[c].re[p_last], li = F.f[c].im[p_last];
+    const float fr = F.f[c].re[p_first], fi = F.f[c].im[p_first];
+    F.f[c].re[p_lo] = cphi * lr + sphi * li;          // exp(-i phi) (lr + i li)
+    F.f[c].im[p_lo] = cphi * li - sphi * lr;
+    F.f[c].re[p_hi] = cphi * fr - sphi * fi;          // exp(+i phi) (fr + i fi)
+    F.f[c].im[p_hi] = cphi * fi + sphi * fr;
   }
 }
 

@@ -100,6 +100,45 @@ def balanced_slabs(spec: SolverSpec, n_ranks: int, min_planes: int = 4) -> List[
     return [(edges[i], edges[i + 1]) for i in range(n_ranks)]
 
 
+def bloch_device_spec(spec: SolverSpec):
+    """Device layout of a simulation with Bloch boundaries: every x / y axis with a non-trivial phase
+    gets one ghost cell at each end (PEC faces for the kernels; the ghost cells are refilled every step
+    with the rotated copy of the cell one period away, fdtd_run_bloch) — so the fused sweep and every
+    other kernel run unchanged.  Returns (device spec, n_real per axis (0 = no ghost cells)); sources
+    and monitors are shifted by the ghost offset, the ghost cells hold the background medium.  A Bloch
+    z keeps its periodic faces: the z ghost planes the engine always had do the same job."""
+    import dataclasses
+    from .spec import BC_PEC
+    n_real = [0, 0, 0]
+    bounds = [np.asarray(b, float) for b in spec.boundaries]
+    bc = [tuple(b) for b in spec.bc]
+    mat = spec.mat_idx
+    absorber = spec.absorber
+    shape = list(spec.shape)
+    for a in (0, 1):
+        if spec.bloch[a] == 0.0 or spec.bc[a][0] != BC_PERIODIC or spec.shape[a] == 1:
+            continue
+        n_real[a] = spec.shape[a]
+        b = bounds[a]
+        bounds[a] = np.concatenate(([b[0] - (b[-1] - b[-2])], b, [b[-1] + (b[1] - b[0])]))
+        bc[a] = (BC_PEC, BC_PEC)
+        shape[a] += 2
+        if mat is not None:
+            pad = [(0, 0)] * 4
+            pad[3 - a] = (1, 1)                          # mat_idx is [3, nz, ny, nx]
+            mat = np.pad(mat, pad, mode="constant", constant_values=1)
+        if absorber is not None:
+            absorber = [((np.pad(sb, 1), np.pad(sc, 1), lo, hi) if ax == a else (sb, sc, lo, hi))
+                        for ax, (sb, sc, lo, hi) in enumerate(absorber)]
+    off = np.array([1 if n_real[a] else 0 for a in range(3)], dtype=np.int32)
+    sources = [dataclasses.replace(sc, ijk=(np.asarray(sc.ijk) + off[None, :]).astype(np.int32)) for sc in spec.sources]
+    monitors = [dataclasses.replace(m, lo=tuple(int(v) for v in np.asarray(m.lo) + off),
+                                    hi=tuple(int(v) for v in np.asarray(m.hi) + off)) for m in spec.monitors]
+    dev = dataclasses.replace(spec, shape=tuple(shape), boundaries=tuple(bounds), bc=tuple(bc), mat_idx=mat,
+                              absorber=absorber, sources=sources, monitors=monitors)
+    return dev, n_real
+
+
 def _local_pml_counts(tables: List[np.ndarray]) -> Tuple[int, int]:
     """Leading/trailing run of planes whose CPML tables differ from identity (see engine notes):
     the library's slab ranges only need to be supersets of the true PML planes."""
@@ -119,20 +158,27 @@ class HipEngine:
     def __init__(self, spec: SolverSpec, lib: Optional[L.FdtdLib] = None, device: int = 0,
                  variant: int = L.VARIANT_AUTO, flags: int = 0, z_chunk: int = 0,
                  slab: Optional[Tuple[int, int]] = None, rank: int = 0, n_ranks: int = 1,
-                 force_comm: bool = False, all_slabs: Optional[List[Tuple[int, int]]] = None):
+                 force_comm: bool = False, all_slabs: Optional[List[Tuple[int, int]]] = None, _bloch_twin=None):
         self.lib = lib or L.load_library()
         self.spec = spec
         self.rank, self.n_ranks = rank, n_ranks
         # Bloch boundaries: complex fields = this engine (real part) + a twin engine (imaginary part,
-        # source weights times -i), advanced together by fdtd_run_bloch (two-pass kernels, one GPU)
+        # source weights times -i) on the ghost-cell device layout of bloch_device_spec, advanced together
+        # by fdtd_run_bloch (one GPU)
         self.twin: Optional["HipEngine"] = None
+        self.ghost = (0, 0, 0)            # ghost cells per axis in front of the real cells (Bloch device layout)
+        self.user_shape = tuple(spec.shape)
         if spec.bloch is not None:
             if n_ranks > 1 or force_comm or slab is not None:
                 raise SolverLibraryError("Bloch boundaries run on one GPU (no z-slab decomposition)")
             if spec.tfsf:
                 raise SolverLibraryError("TFSF sources cannot be combined with Bloch boundaries")
-            if variant != L.VARIANT_SIMPLE:
-                variant = L.VARIANT_ZMARCH
+            if _bloch_twin is None:
+                spec, self.n_real = bloch_device_spec(spec)
+                self.spec = spec
+            else:
+                self.n_real = list(_bloch_twin)
+            self.ghost = tuple(1 if n else 0 for n in self.n_real)
         nx, ny, nz = spec.shape
         self.z0, self.z1 = slab if slab is not None else (0, nz)
         self.nzl = self.z1 - self.z0
@@ -173,12 +219,13 @@ class HipEngine:
             raise SolverLibraryError(f"fdtd_create failed: {self.lib.error(None)}")
         try:
             self._setup(spec)
-            if spec.bloch is not None:
+            if spec.bloch is not None and _bloch_twin is None:
                 import dataclasses
                 rot = [dataclasses.replace(sc, w_re=np.asarray(sc.w_im, float), w_im=-np.asarray(sc.w_re, float))
                        for sc in spec.sources]                   # -i (w_re + i w_im) = w_im - i w_re
-                self.twin = HipEngine(dataclasses.replace(spec, bloch=None, sources=rot), lib=self.lib, device=device,
-                                      variant=variant, flags=flags, z_chunk=z_chunk)
+                self.twin = HipEngine(dataclasses.replace(spec, sources=rot), lib=self.lib, device=device,
+                                      variant=variant, flags=flags, z_chunk=z_chunk, _bloch_twin=tuple(self.n_real))
+                self.twin.user_shape = self.user_shape
         except Exception:
             self.close()
             raise
@@ -361,7 +408,8 @@ class HipEngine:
         cb = L.PROGRESS_FN(_cb) if progress else C.cast(None, L.PROGRESS_FN)
         if self.twin is not None:
             ph = (C.c_double * 3)(*[float(v) for v in self.spec.bloch])
-            self._chk(self.lib.dll.fdtd_run_bloch(self.handle, self.twin.handle, int(n_steps), ph, cb, None),
+            nr = (C.c_int * 3)(*[int(v) for v in self.n_real])
+            self._chk(self.lib.dll.fdtd_run_bloch(self.handle, self.twin.handle, int(n_steps), ph, nr, cb, None),
                       "fdtd_run_bloch")
         else:
             self._chk(self.lib.dll.fdtd_run(self.handle, int(n_steps), cb, None), "fdtd_run")
@@ -390,6 +438,10 @@ class HipEngine:
         out = np.empty((self.nzl, ny, self.nxp), dtype=np.float32)
         self._chk(self.lib.dll.fdtd_get_field(self.handle, comp, _ptr(out), out.nbytes),
                   "fdtd_get_field")
+        if any(self.ghost):                 # Bloch device layout: strip the ghost cells
+            gx, gy = self.ghost[0], self.ghost[1]
+            ux, uy = self.user_shape[0], self.user_shape[1]
+            return np.ascontiguousarray(out[:, gy:gy + uy, gx:gx + ux])
         return np.ascontiguousarray(out[..., :nx]) if self.pad_x else out
 
     def set_field(self, comp: int, arr: np.ndarray):
@@ -397,6 +449,9 @@ class HipEngine:
             self.twin.set_field(comp, np.imag(arr))
             arr = np.real(arr)
         a = _f32(arr)
+        if any(self.ghost):                 # ghost cells are filled by the library before the first step
+            gx, gy = self.ghost[0], self.ghost[1]
+            a = _f32(np.pad(a, ((0, 0), (gy, gy), (gx, gx))))
         if self.pad_x:
             a = _f32(np.pad(a, ((0, 0), (0, 0), (0, self.pad_x))))
         self._chk(self.lib.dll.fdtd_set_field(self.handle, comp, _ptr(a), a.nbytes),

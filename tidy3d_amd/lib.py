@@ -86,7 +86,7 @@ class FdtdLib:
         d.fdtd_comm_unique_id.argtypes = [vp]
         d.fdtd_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
         d.fdtd_run.argtypes = [vp, i64, PROGRESS_FN, vp]
-        d.fdtd_run_bloch.argtypes = [vp, vp, i64, vp, PROGRESS_FN, vp]
+        d.fdtd_run_bloch.argtypes = [vp, vp, i64, vp, vp, PROGRESS_FN, vp]
         d.fdtd_get_stats.argtypes = [vp, C.POINTER(FdtdStats)]
         d.fdtd_reset.argtypes = [vp]
         d.fdtd_set_option.argtypes = [vp, C.c_int, C.c_int]
