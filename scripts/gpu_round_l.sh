@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU-box visit of round l: parity tests, bench, rocprofv3 kernel stats of the bench and of the feature probe.
+# GPU-box visit (rounds l, m): parity tests, bench, rocprofv3 kernel stats of the bench and of the feature probe.
 set -x
 mkdir -p gpurun_out
 export TMPDIR=/tmp
