@@ -1,0 +1,60 @@
+"""Cyclic renaming of the axes (tidy3d_amd/engine.py ``permute_spec``): Maxwell's curl keeps its form under
+x -> y -> z -> x, so a narrow grid can be laid out with its best-filled axis along x (where a wavefront owns 256
+consecutive cells) and the results renamed back.  The renamed run must reproduce the plain one."""
+import numpy as np
+import pytest
+
+from cases import CASES
+from tidy3d_amd.discretize import discretize
+from tidy3d_amd.engine import HipEngine, best_axis_shift, lane_efficiency, permute_spec, unpermute_array
+
+
+def test_policy():
+    assert lane_efficiency(256) == 1.0 and lane_efficiency(60) == pytest.approx(60 / 256) and lane_efficiency(258) == pytest.approx(258 / 512)
+    assert best_axis_shift((512, 512, 512)) == 0 and best_axis_shift((424, 224, 824)) == 0      # BASELINE shapes stay
+    assert best_axis_shift((60, 60, 400)) == 2 and best_axis_shift((60, 400, 60)) == 1
+    assert best_axis_shift((258, 250, 264)) == 1            # 258 spills into a second tile, 250 does not
+    assert best_axis_shift((8, 12, 20)) == 0                # tiny grids: launch-bound, left alone
+
+
+@pytest.mark.parametrize("s", [1, 2])
+def test_permute_spec_is_a_renaming(s):
+    spec = discretize(CASES["media_mix"](), n_steps=3).spec
+    p = permute_spec(spec, s)
+    sig = [(a + s) % 3 for a in range(3)]
+    assert p.shape == tuple(spec.shape[sig[a]] for a in range(3)) and p.bc == tuple(spec.bc[sig[a]] for a in range(3))
+    # component c' of the renamed problem is component sig[c'] of the original, transposed
+    for c in range(3):
+        assert np.array_equal(unpermute_array(p.mat_idx[c], s), spec.mat_idx[sig[c]])
+    back = permute_spec(p, 3 - s)
+    assert back.shape == spec.shape and np.array_equal(back.mat_idx, spec.mat_idx)
+    assert all(np.array_equal(a.ijk, b.ijk) and np.array_equal(a.comp, b.comp) for a, b in zip(back.sources, spec.sources))
+    assert [(m.comps, m.lo, m.hi) for m in back.monitors] == [(tuple(m.comps), tuple(m.lo), tuple(m.hi)) for m in spec.monitors]
+
+
+@pytest.mark.parametrize("case", ["media_mix", "drude_in_pml", "tfsf_box", "bloch_box", "absorber_mix"])
+def test_renamed_run_equals_plain_run(case, emu_lib):
+    disc = discretize(CASES[case](), n_steps=25)
+    outs = []
+    for s in (0, 1, 2):
+        with HipEngine(disc.spec, lib=emu_lib, axis_shift=s) as e:
+            assert e.axis_shift == s
+            e.run()
+            outs.append(([e.get_field(c) for c in range(6)], e.results()))
+    for s in (1, 2):
+        for c in range(6):      # the sums of the CPML / Bloch corrections run in a different order: fp32 rounding
+            assert np.abs(outs[s][0][c] - outs[0][0][c]).max() <= 1e-6 * max(np.abs(outs[0][0][c]).max(), 1e-30), (s, c)
+        for k, v in outs[0][1].items():
+            assert outs[s][1][k].shape == v.shape
+            assert np.abs(outs[s][1][k] - v).max() <= 1e-6 * max(np.abs(v).max(), 1e-30), (s, k)
+
+
+def test_set_field_round_trip(emu_lib):
+    disc = discretize(CASES["pec_box"](), n_steps=2)
+    rng = np.random.default_rng(0)
+    nx, ny, nz = disc.spec.shape
+    with HipEngine(disc.spec, lib=emu_lib, axis_shift=2) as e:
+        for c in range(6):
+            a = rng.standard_normal((nz, ny, nx)).astype(np.float32)
+            e.set_field(c, a)
+            assert np.array_equal(e.get_field(c), a)

@@ -100,6 +100,68 @@ def balanced_slabs(spec: SolverSpec, n_ranks: int, min_planes: int = 4) -> List[
     return [(edges[i], edges[i + 1]) for i in range(n_ranks)]
 
 
+def lane_efficiency(n: int) -> float:
+    """Busy fraction of the 256-cell row segments (64 lanes x float4) the main kernels give a wavefront."""
+    return n / (256.0 * -(-n // 256))
+
+
+def best_axis_shift(shape) -> int:
+    """Cyclic axis shift s (new axis a holds old axis (a + s) % 3) that puts the axis with the best lane
+    efficiency along x; 0 unless it buys more than 25 % on a grid of at least 2^18 cells (below that a run is
+    bound by launches, not lanes)."""
+    if int(np.prod([int(n) for n in shape])) < (1 << 18):
+        return 0
+    eff = [lane_efficiency(int(n)) for n in shape]
+    s = int(np.argmax(eff))
+    return s if eff[s] > 1.25 * eff[0] else 0
+
+
+def permute_spec(spec: SolverSpec, s: int) -> SolverSpec:
+    """The same problem with its axes cyclically renamed: new axis a = old axis (a + s) % 3, for fields,
+    components, boundaries, sources and monitors alike.  Maxwell's curl is invariant under CYCLIC renaming
+    (x -> y -> z -> x keeps the handedness), so the kernels solve the renamed problem unchanged; the host uses
+    it to lay narrow grids out with their longest axis along x (see ``best_axis_shift``)."""
+    import dataclasses
+    if s % 3 == 0:
+        return spec
+    sig = [(a + s) % 3 for a in range(3)]                # old axis held by new axis a
+    inv = [(p - s) % 3 for p in range(3)]                # new axis that holds old axis p
+    tr = tuple(2 - sig[2 - q] for q in range(3))         # numpy axes (z', y', x') <- positions of old axes
+
+    def comp_map(c):
+        c = np.asarray(c)
+        return (np.asarray(inv)[c % 3] + 3 * (c // 3)).astype(np.int32)
+
+    def pick(seq):
+        return tuple(seq[sig[a]] for a in range(3))
+    mat = None
+    if spec.mat_idx is not None:
+        mat = np.ascontiguousarray(np.stack([np.transpose(spec.mat_idx[sig[c]], tr) for c in range(3)]))
+    sources = [dataclasses.replace(sc, comp=comp_map(sc.comp), ijk=np.ascontiguousarray(np.asarray(sc.ijk)[:, sig]).astype(np.int32))
+               for sc in spec.sources]
+    tfsf = [dataclasses.replace(t, e_corr_comp=comp_map(t.e_corr_comp), h_corr_comp=comp_map(t.h_corr_comp),
+                                e_corr_ijk=np.ascontiguousarray(np.asarray(t.e_corr_ijk)[:, sig]).astype(np.int32),
+                                h_corr_ijk=np.ascontiguousarray(np.asarray(t.h_corr_ijk)[:, sig]).astype(np.int32))
+            for t in spec.tfsf]
+    monitors = [dataclasses.replace(m, comps=tuple(int(v) for v in comp_map(m.comps)), lo=pick(m.lo), hi=pick(m.hi))
+                for m in spec.monitors]
+    return dataclasses.replace(
+        spec, shape=pick(spec.shape), boundaries=pick(spec.boundaries), bc=pick(spec.bc), pml=pick(spec.pml),
+        mat_idx=mat, sources=sources, tfsf=tfsf, monitors=monitors,
+        absorber=None if spec.absorber is None else list(pick(spec.absorber)),
+        bloch=None if spec.bloch is None else pick(spec.bloch))
+
+
+def unpermute_array(arr: np.ndarray, s: int) -> np.ndarray:
+    """[..., z', y', x'] of the renamed problem -> [..., z, y, x]."""
+    if s % 3 == 0:
+        return arr
+    inv = [(p - s) % 3 for p in range(3)]
+    lead = arr.ndim - 3
+    axes = tuple(range(lead)) + tuple(lead + 2 - inv[p] for p in (2, 1, 0))
+    return np.ascontiguousarray(np.transpose(arr, axes))
+
+
 def bloch_device_spec(spec: SolverSpec):
     """Device layout of a simulation with Bloch boundaries: every x / y axis with a non-trivial phase
     gets one ghost cell at each end (PEC faces for the kernels; the ghost cells are refilled every step
@@ -158,7 +220,8 @@ class HipEngine:
     def __init__(self, spec: SolverSpec, lib: Optional[L.FdtdLib] = None, device: int = 0,
                  variant: int = L.VARIANT_AUTO, flags: int = 0, z_chunk: int = 0,
                  slab: Optional[Tuple[int, int]] = None, rank: int = 0, n_ranks: int = 1,
-                 force_comm: bool = False, all_slabs: Optional[List[Tuple[int, int]]] = None, _bloch_twin=None):
+                 force_comm: bool = False, all_slabs: Optional[List[Tuple[int, int]]] = None, _bloch_twin=None,
+                 axis_shift: Optional[int] = None):
         self.lib = lib or L.load_library()
         self.spec = spec
         self.rank, self.n_ranks = rank, n_ranks
@@ -166,6 +229,13 @@ class HipEngine:
         # source weights times -i) on the ghost-cell device layout of bloch_device_spec, advanced together
         # by fdtd_run_bloch (one GPU)
         self.twin: Optional["HipEngine"] = None
+        # narrow grids: cyclic renaming of the axes so that the best-filled one runs along x (single GPU)
+        self.axis_shift = 0
+        self.user_zrange = {m.name: (int(m.lo[2]), int(m.hi[2])) for m in spec.monitors}
+        if _bloch_twin is None and n_ranks == 1 and slab is None and not force_comm and axis_shift != 0:
+            self.axis_shift = best_axis_shift(spec.shape) if axis_shift is None else int(axis_shift) % 3
+            spec = permute_spec(spec, self.axis_shift)
+            self.spec = spec
         self.ghost = (0, 0, 0)            # ghost cells per axis in front of the real cells (Bloch device layout)
         self.user_shape = tuple(spec.shape)
         if spec.bloch is not None:
@@ -428,10 +498,16 @@ class HipEngine:
         if self.twin is not None:
             self.twin.reset()
 
+    def _dev_comp(self, comp: int) -> int:
+        """Component id on the device (axes cyclically renamed by ``axis_shift``)."""
+        return (comp % 3 - self.axis_shift) % 3 + 3 * (comp // 3)
+
     def get_field(self, comp: int) -> np.ndarray:
+        dc = self._dev_comp(comp)
+        a = self._get_field_real(dc)
         if self.twin is not None:
-            return self._get_field_real(comp) + 1j * self.twin.get_field(comp)
-        return self._get_field_real(comp)
+            a = a + 1j * self.twin._get_field_real(dc)
+        return unpermute_array(a, self.axis_shift)
 
     def _get_field_real(self, comp: int) -> np.ndarray:
         nx, ny, _ = self.spec.shape
@@ -445,6 +521,15 @@ class HipEngine:
         return np.ascontiguousarray(out[..., :nx]) if self.pad_x else out
 
     def set_field(self, comp: int, arr: np.ndarray):
+        if self.axis_shift:
+            sig = [(a + self.axis_shift) % 3 for a in range(3)]
+            arr = np.transpose(np.asarray(arr), tuple(2 - sig[2 - q] for q in range(3)))
+            comp = self._dev_comp(comp)
+            shift, self.axis_shift = self.axis_shift, 0          # the device-oriented array goes straight down
+            try:
+                return self.set_field(comp, arr)
+            finally:
+                self.axis_shift = shift
         if self.twin is not None:
             self.twin.set_field(comp, np.imag(arr))
             arr = np.real(arr)
@@ -477,6 +562,8 @@ class HipEngine:
             for m, mid, _ in self.mon_ids:
                 if mid >= 0:
                     out[m.name] = (out[m.name][0] + 1j * im[m.name][0], out[m.name][1])
+        if self.axis_shift:                 # back to the user's axes (single slab: the z range is the box's own)
+            out = {k: (unpermute_array(v[0], self.axis_shift), self.user_zrange[k]) for k, v in out.items()}
         return out
 
     def results(self) -> Dict[str, np.ndarray]:
