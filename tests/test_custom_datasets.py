@@ -60,7 +60,6 @@ def test_custom_medium_raster_interpolation_and_time_step():
                         sources=[td.PointDipole(source_time=PULSE, polarization="Ez")],
                         boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary()))
     spec = discretize(sim, n_steps=2).spec
-    plain = discretize(td.Simulation(**{**sim.__dict__, "structures": []}), n_steps=2).spec if False else None
     eps_of = np.array([m.eps_inf for m in spec.media])
     sig_of = np.array([m.sigma for m in spec.media])
     xs, ys, zs = spec.yee_coords(2)
