@@ -85,7 +85,7 @@ def test_exact_projection_reproduces_the_simulated_field_and_tends_to_the_far_fi
     pulse = td.GaussianPulse(freq0=f0, fwidth=f0 / 6)
     # observation points in Cartesian form: x = 0.3, 0.45 at y = 0.2 on the plane z = 0.8 (local origin = centre)
     sim = td.Simulation(
-        size=(2.2, 2.2, 2.2), grid_spec=td.GridSpec.uniform(dl=dl), run_time=40 / f0,
+        size=(2.2, 2.2, 2.2), grid_spec=td.GridSpec.uniform(dl=dl), run_time=30 / f0,
         sources=[td.PointDipole(center=(0, 0, 0), source_time=pulse, polarization="Ex"),
                  td.PointDipole(center=(0.1, -0.1, 0.05), source_time=pulse, polarization="Ez")],
         monitors=[td.FieldProjectionCartesianMonitor(center=(0, 0, 0), size=(1.0, 1.0, 1.0), freqs=[f0], x=[0.3, 0.45],

@@ -153,8 +153,8 @@ def test_bloch_run_end_to_end(emu_lib, tmp_path):
                                              y=td.Boundary.bloch_from_source(pw, 8 * DL, 1),
                                              z=td.Boundary(minus=td.PML(num_layers=6), plus=td.Absorber(num_layers=8))))
     path = str(tmp_path / "bloch.hdf5")
-    sd = run(sim, task_name="bloch", verbose=False, lib=emu_lib, n_steps=110, path=path)
-    disc = D.discretize(sim, n_steps=110)
+    sd = run(sim, task_name="bloch", verbose=False, lib=emu_lib, n_steps=80, path=path)
+    disc = D.discretize(sim, n_steps=80)
     ref = assemble(disc, OracleFdtd(disc.spec).run())
     assert sd["T"].flux.values == pytest.approx(ref["T"].flux.values, rel=1e-4)
     assert np.allclose(sd["orders"].power.values, ref["orders"].power.values, rtol=1e-3, atol=1e-6 * ref["T"].flux.values.max())
