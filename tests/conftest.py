@@ -8,6 +8,23 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The CPU suite (-m "not gpu") is ~11 min of independent oracle / emulator runs when taken one by one:
+    spread it over 4 workers when pytest-xdist is there and the caller did not choose.  GPU tests stay serial."""
+    try:
+        import xdist  # noqa: F401
+    except ImportError:
+        return None
+    opt = config.option
+    if getattr(opt, "markexpr", "") == "not gpu" and not getattr(opt, "numprocesses", None) \
+            and not os.environ.get("PYTEST_XDIST_WORKER") and (os.cpu_count() or 1) >= 4:
+        opt.numprocesses = 4
+        opt.dist = "load"
+        opt.tx = ["popen"] * 4             # what xdist's own (earlier) hook derives from -n 4
+    return None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 

@@ -29,13 +29,16 @@ def test_split_slabs():
     assert split_slabs(512, 8)[3] == (192, 256)
 
 
-@pytest.mark.parametrize("world,case", [(2, "media_mix"), (2, "pml_box"), (3, "periodic_box"), (2, "drude_in_pml"),
+GLOO_CASES = [(2, "media_mix"), (2, "pml_box"), (3, "periodic_box"), (2, "drude_in_pml"),
                                         (2, "periodic_box_tall"), (4, "periodic_box_tall"), (2, "planewave_periodic"),
-                                        (2, "tfsf_box"), (3, "au_array"), (3, "absorber_mix")])
+                                        (2, "tfsf_box"), (3, "au_array"), (3, "absorber_mix")]
+
+
+@pytest.mark.parametrize("world,case", GLOO_CASES)
 def test_two_rank_run_matches_single_slab(world, case, emu_lib, tmp_path):
     n_steps = 60 if case == "planewave_periodic" else 30     # let the injected wave reach the monitors
     out = str(tmp_path / "dist.npz")
-    _launch(world, case, n_steps, out, 29511 + world + len(case))
+    _launch(world, case, n_steps, out, 29511 + GLOO_CASES.index((world, case)))      # one port per case (parallel runs)
     got = np.load(out)
     disc = discretize(CASES[case](), n_steps=n_steps)
     disc.spec.decay_every = 10
