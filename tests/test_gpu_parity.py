@@ -380,3 +380,25 @@ def test_config5_au_nanoparticle_array_1024x1024x256(hip_lib):
     # 16 periods along x: the line scan repeats every 64 cells
     per = line[:1024].reshape(16, 64)
     assert np.max(np.abs(per - per[0])) < 2e-3 * np.max(np.abs(per))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["media_mix", "bloch_xy_pml_z", "absorber_mix"])
+def test_axis_renaming_on_the_gpu(case, hip_lib):
+    """Cyclic renaming of the axes (engine.permute_spec, the default layout choice for narrow grids): the renamed
+    runs reproduce the plain one on the real kernels (different summation order of the corrections: fp32 rounding)."""
+    from tidy3d_amd.discretize import discretize
+    from tidy3d_amd.engine import HipEngine
+    fn = CASES[case]
+    sim = fn(tuple(int(n * 3) for n in fn.__defaults__[0]))
+    disc = discretize(sim, n_steps=80)
+    outs = []
+    for s in (0, 1, 2):
+        with HipEngine(disc.spec, lib=hip_lib, axis_shift=s) as e:
+            e.run()
+            outs.append(([e.get_field(c) for c in range(6)], e.results()))
+    for s in (1, 2):
+        for c in range(6):
+            assert np.abs(outs[s][0][c] - outs[0][0][c]).max() <= 2e-6 * max(np.abs(outs[0][0][c]).max(), 1e-30), (s, c)
+        for k, v in outs[0][1].items():
+            assert np.abs(outs[s][1][k] - v).max() <= 2e-6 * max(np.abs(v).max(), 1e-30), (s, k)
