@@ -12,7 +12,7 @@ from tidy3d_amd.discretize import discretize
 from tidy3d_amd.engine import HipEngine
 
 
-def case(name, bx, by, bz, steps, lxy=2.56, lz=2.4, axis_shift=None):
+def case(name, bx, by, bz, steps, lxy=2.56, lz=2.4, axis_shift=None, zchunk=0):
     dl = 0.01
     pulse = td.GaussianPulse(freq0=2e14, fwidth=2e13)
     sim = td.Simulation(size=(lxy - 1e-6, lxy - 1e-6, lz - 1e-6), grid_spec=td.GridSpec.uniform(dl=dl), run_time=1e-12,
@@ -25,12 +25,15 @@ def case(name, bx, by, bz, steps, lxy=2.56, lz=2.4, axis_shift=None):
     sp.decay_every = 0
     with HipEngine(sp, axis_shift=axis_shift) as e:
         shift = e.axis_shift
+        if zchunk:
+            from tidy3d_amd import lib as L
+            e.set_option(L.OPT_ZCHUNK, zchunk)
         e.run(20)
         t0 = time.perf_counter()
         e.run(steps)
         dt = time.perf_counter() - t0
     n = sp.shape[0] * sp.shape[1] * sp.shape[2]
-    print(json.dumps({"case": name, "shape": sp.shape, "complex": sp.bloch is not None, "axis_shift": shift, "ms_per_step": dt / steps * 1e3,
+    print(json.dumps({"case": name, "shape": sp.shape, "complex": sp.bloch is not None, "axis_shift": shift, "zchunk": zchunk, "ms_per_step": dt / steps * 1e3,
                       "mcells_per_s": n * steps / dt / 1e6}), flush=True)
 
 
@@ -52,12 +55,22 @@ def narrow(steps):
     per, pml = td.Boundary.periodic(), td.Boundary.pml()
     case("narrow 64x64x1048 as given", per, per, pml, steps, lxy=0.64, lz=10.24, axis_shift=0)
     case("narrow 64x64x1048 renamed (default)", per, per, pml, steps, lxy=0.64, lz=10.24)
+    for zc in (8, 4, 2):
+        case("narrow renamed, z-chunk %d" % zc, per, per, pml, steps, lxy=0.64, lz=10.24, zchunk=zc)
+        case("narrow as given, z-chunk %d" % zc, per, per, pml, steps, lxy=0.64, lz=10.24, axis_shift=0, zchunk=zc)
+    for zc in (16, 8, 4):
+        case("128^3-ish cube, z-chunk %d" % zc, per, per, pml, steps, lxy=1.28, lz=1.04, zchunk=zc)
     case("narrow bloch as given", td.Boundary.bloch(0.21), td.Boundary.bloch(0.13), pml, steps, lxy=0.64, lz=10.24, axis_shift=0)
     case("narrow bloch renamed (default)", td.Boundary.bloch(0.21), td.Boundary.bloch(0.13), pml, steps, lxy=0.64, lz=10.24)
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[2] == "narrow":
+    if len(sys.argv) > 2 and sys.argv[2] == "cube":
+        per, pml = td.Boundary.periodic(), td.Boundary.pml()
+        case("128^3-ish cube, default shape choice", per, per, pml, int(sys.argv[1]), lxy=1.28, lz=1.04)
+        case("128^3-ish cube, z-chunk 16", per, per, pml, int(sys.argv[1]), lxy=1.28, lz=1.04, zchunk=16)
+        case("200^3-ish cube, default shape choice", per, per, pml, int(sys.argv[1]), lxy=2.0, lz=1.76)
+    elif len(sys.argv) > 2 and sys.argv[2] == "narrow":
         narrow(int(sys.argv[1]))
     else:
         main()

@@ -1207,8 +1207,18 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     if ((nb_hi && b_hi < 1) || (nb_lo && b_lo < 1))
       return fail(h, "fdtd_run: the fused z-slab schedule needs at least 2 planes between a slab cut and the z-PML");
   }
-  // (autotune == 2 lifts the size threshold: test aid for the emulated library)
-  if ((fused || fused_multi) && h->autotune && !h->tuned && !h->user_geometry &&
+  // Tile-shape probing: on request (FDTD_OPT_AUTOTUNE), and by default on one GPU when the default shape
+  // launches less than one wave of workgroups (256 CUs x 3): there the z-chunk decides how much of the chip a
+  // sweep fills (128^3: 344 workgroups at 16 planes per chunk, 0.045 ms per step; 688 at 8 planes, 0.034 ms —
+  // profiles/r01m_narrow_grid_axis_shift.log) and the probe costs a dozen sweeps once.  Results do not depend
+  // on the shape.  (autotune == 2 lifts the size threshold: test aid for the emulated library)
+  bool under_one_wave = false;
+  if (fused && !h->tuned && !h->user_geometry) {
+    const long long wgs = (long long)((h->g.nx + 255) / 256) * ((h->g.ny + h->rows_f - 1) / h->rows_f) *
+                          ((nz + h->zchunk_f - 1) / h->zchunk_f);
+    under_one_wave = wgs < 768;
+  }
+  if ((fused || fused_multi) && (h->autotune || under_one_wave) && !h->tuned && !h->user_geometry &&
       (n_cells(h) >= (1LL << 20) || h->autotune == 2)) {
     if (autotune_fused(h, st)) return -1;
     if (fused_multi) {           // the boundary-chunk thickness follows the chosen z-chunk
