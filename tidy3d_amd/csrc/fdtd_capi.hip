@@ -1529,6 +1529,16 @@ int fdtd_run_bloch(FdtdSolver* hr, FdtdSolver* hi, int64_t n_steps, const double
   const bool fused = (g.nx % 4 == 0) && hr->rows_f <= 15 &&
                      (hr->cfg.variant == FDTD_VARIANT_FUSED || hr->cfg.variant == FDTD_VARIANT_AUTO);
   if (fused) for (FdtdSolver* h : both) if (ensure_second_set(h)) return -1;
+  if (fused && !hr->tuned && !hr->user_geometry && !hi->user_geometry &&
+      (n_cells(hr) >= (1LL << 20) || hr->autotune == 2)) {
+    // same rule as fdtd_run: probe the tile shape when the default one launches less than a wave of workgroups
+    const long long wgs = (long long)((g.nx + 255) / 256) * ((g.ny + hr->rows_f - 1) / hr->rows_f) *
+                          ((nz + hr->zchunk_f - 1) / hr->zchunk_f);
+    if (wgs < 768 || hr->autotune) {
+      if (autotune_fused(hr, st)) return -1;
+      hi->rows_f = hr->rows_f; hi->zchunk_f = hr->zchunk_f; hi->tuned = true;
+    }
+  }
   float cph[3], sph[3];
   for (int a = 0; a < 3; ++a) { cph[a] = (float)std::cos(phase[a]); sph[a] = (float)std::sin(phase[a]); }
   const long long pc = plane_cells(hr);
