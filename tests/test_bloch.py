@@ -145,3 +145,29 @@ def test_angled_plane_wave_needs_matching_bloch_boundaries():
     with pytest.raises(SetupError, match="does not match"):
         discretize(td.Simulation(boundary_spec=td.BoundarySpec(x=td.Boundary.bloch(0.05), y=td.Boundary.periodic(),
                                                                z=td.Boundary.pml()), **kw), n_steps=2)
+
+
+def test_device_layout_with_ghost_cells():
+    """engine.bloch_device_spec: a Bloch x / y axis gets one ghost cell per end (PEC faces for the kernels, cell widths
+    wrapped), sources and monitors move by the offset, a Bloch z keeps its periodic faces (ghost planes)."""
+    from tidy3d_amd.engine import bloch_device_spec
+    from tidy3d_amd.spec import BC_PEC, BC_PERIODIC
+    from cases import CASES
+    spec = discretize(CASES["bloch_box"](), n_steps=2).spec           # Bloch on x, y and z
+    dev, n_real = bloch_device_spec(spec)
+    nx, ny, nz = spec.shape
+    assert n_real == [nx, ny, 0] and dev.shape == (nx + 2, ny + 2, nz)
+    assert dev.bc[0] == (BC_PEC, BC_PEC) and dev.bc[1] == (BC_PEC, BC_PEC) and dev.bc[2] == (BC_PERIODIC, BC_PERIODIC)
+    for a in (0, 1):
+        b, d = np.asarray(spec.boundaries[a]), np.asarray(dev.boundaries[a])
+        np.testing.assert_allclose(d[1:-1], b)
+        assert d[1] - d[0] == pytest.approx(b[-1] - b[-2]) and d[-1] - d[-2] == pytest.approx(b[1] - b[0])
+    assert np.array_equal(dev.mat_idx[:, :, 1:-1, 1:-1], spec.mat_idx) and np.all(dev.mat_idx[:, :, 0, :] == 1)
+    for s0, s1 in zip(spec.sources, dev.sources):
+        assert np.array_equal(s1.ijk, s0.ijk + np.array([1, 1, 0]))
+    for m0, m1 in zip(spec.monitors, dev.monitors):
+        assert m1.lo == (m0.lo[0] + 1, m0.lo[1] + 1, m0.lo[2]) and m1.shape == m0.shape
+    assert dev.bloch == spec.bloch
+    only_x = discretize(CASES["bloch_x_only"](), n_steps=2).spec
+    dev, n_real = bloch_device_spec(only_x)
+    assert n_real == [only_x.shape[0], 0, 0] and dev.bc[1] == only_x.bc[1] and dev.shape[1:] == only_x.shape[1:]
