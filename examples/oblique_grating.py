@@ -4,8 +4,12 @@ installed; here the tidy3d-free mirror classes are used.
 
     python examples/oblique_grating.py            # needs an MI355X and the built library
 """
+import os
+import sys
+
 import numpy as np
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # run from a checkout
 import tidy3d_amd
 import tidy3d_amd.schema as td
 
