@@ -10,3 +10,10 @@ def run(simulation, task_name=None, folder_name="default", path=None, **kwargs):
     """Drop-in for ``tidy3d.web.run`` (ref web/api/webapi.py:49) — see tidy3d_amd.web.run."""
     from .web import run as _run
     return _run(simulation, task_name=task_name, folder_name=folder_name, path=path, **kwargs)
+
+
+def load(path):
+    """Read a SimulationData .hdf5 / .npz written by ``run(..., path=...)`` (or by the reference, for the data
+    types the mirror has) — see tidy3d_amd.web.load."""
+    from .web import load as _load
+    return _load(path)
