@@ -56,16 +56,20 @@ def main():
     sim = cases.CASES[case]() if case in cases.CASES else getattr(cases, case)()
     disc = discretize(sim, n_steps=n_steps)
     disc.spec.decay_every = 10          # exercise the scalar all-reduce too
-    eng = tdist.make_engine(disc.spec, lib=lib, device=0)   # the emulator exposes one device
+    shift = os.environ.get("SLAB_SHIFT")                    # force a slab-axis renaming (tests)
+    eng = tdist.make_engine(disc.spec, lib=lib, device=0,   # the emulator exposes one device
+                            axis_shift=None if shift is None else int(shift))
     st = eng.run()
     raw = tdist.gather_results(eng)
-    fields = [eng.get_field(c) for c in range(6)]
+    s_ax = getattr(eng, "slab_shift", 0)
+    fields = [eng.get_field((c % 3 - s_ax) % 3 + 3 * (c // 3)) for c in range(6)]     # device component of user c
     allf = [None] * world if rank == 0 else None
     dist.gather_object((eng.z0, fields), allf, dst=0)
     eng.close()
     if rank == 0:
         allf.sort(key=lambda p: p[0])
-        full = {f"field{c}": np.concatenate([p[1][c] for p in allf], axis=0) for c in range(6)}
+        from tidy3d_amd.engine import unpermute_array
+        full = {f"field{c}": unpermute_array(np.concatenate([p[1][c] for p in allf], axis=0), s_ax) for c in range(6)}
         np.savez(out, decay=st.field_decay, **{f"mon_{k}": v for k, v in raw.items()}, **full)
     dist.barrier()
     dist.destroy_process_group()

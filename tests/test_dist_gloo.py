@@ -15,8 +15,10 @@ from tidy3d_amd.engine import HipEngine, split_slabs
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def _launch(world, case, n_steps, out, port):
+def _launch(world, case, n_steps, out, port, slab_shift=None):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if slab_shift is not None:
+        env["SLAB_SHIFT"] = str(slab_shift)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "dist_worker.py"), case, str(n_steps), out]
@@ -88,3 +90,28 @@ def test_balanced_slabs_follow_the_cost_model():
         assert HipEngine._fused_slabs_ok(spec, world, slabs)
     assert max(cost[a:b].sum() for a, b in balanced_slabs(spec, 2)) < 0.9 * max(
         cost[a:b].sum() for a, b in split_slabs(nz, 2))
+
+
+@pytest.mark.parametrize("shift,world,case", [(1, 2, "media_mix"), (2, 3, "drude_in_pml")])
+def test_slab_axis_renaming_matches_single_slab(shift, world, case, emu_lib, tmp_path):
+    """tidy3d_amd.dist.make_engine may rename the axes cyclically so that the slab axis is the one with the most
+    planes (best_slab_shift): the stitched, renamed-back result equals the plain single-GPU run (fp32 rounding of the
+    correction sums)."""
+    from tidy3d_amd.dist import best_slab_shift
+    assert best_slab_shift((1024, 1024, 256), 8) == 1 and best_slab_shift((512, 512, 512), 8) == 0
+    assert best_slab_shift((60, 60, 400), 2) == 0              # already along the longest axis
+    out = str(tmp_path / "dist.npz")
+    _launch(world, case, 30, out, 29561 + shift, slab_shift=shift)
+    got = np.load(out)
+    disc = discretize(CASES[case](), n_steps=30)
+    disc.spec.decay_every = 10
+    with HipEngine(disc.spec, lib=emu_lib, axis_shift=0) as e:
+        e.run()
+        ref = e.results()
+        fields = [e.get_field(c) for c in range(6)]
+    for c in range(6):
+        assert got[f"field{c}"].shape == fields[c].shape
+        assert np.abs(got[f"field{c}"] - fields[c]).max() <= 1e-6 * max(np.abs(fields[c]).max(), 1e-30), c
+    for k, v in ref.items():
+        assert got[f"mon_{k}"].shape == v.shape
+        assert np.abs(got[f"mon_{k}"] - v).max() <= 1e-6 * max(np.abs(v).max(), 1e-30), k
