@@ -115,3 +115,23 @@ def test_slab_axis_renaming_matches_single_slab(shift, world, case, emu_lib, tmp
     for k, v in ref.items():
         assert got[f"mon_{k}"].shape == v.shape
         assert np.abs(got[f"mon_{k}"] - v).max() <= 1e-6 * max(np.abs(v).max(), 1e-30), k
+
+
+def test_distributed_run_entry_point(emu_lib, tmp_path):
+    """``tidy3d_amd.dist.run`` (every rank calls it, rank 0 returns the SimulationData) == ``web.run`` on one slab."""
+    from tidy3d_amd.web import run
+    out = str(tmp_path / "run.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", os.path.join(ROOT, "tests", "dist_run_worker.py"), "pml_box", "40", out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.load(out)
+    sd = run(CASES["pml_box"](), verbose=False, lib=emu_lib, n_steps=40)
+    n = 0
+    for d in sd.data:
+        comps = getattr(d, "field_components", None) or {"flux": d.flux}
+        for k, v in comps.items():
+            assert np.array_equal(got[f"{d.monitor.name}__{k}"], np.asarray(v.values)), (d.monitor.name, k)
+            n += 1
+    assert n >= 12
