@@ -264,6 +264,15 @@ def bloch_planewave(N=(12, 8, 20)):
     return _sim(N, bspec, structures, sources=[pw], monitors=monitors)
 
 
+def wide_flat(N=(128, 128, 16)):
+    """2^18 cells, 16 planes: a z-slab run renames the axes so that a 128-cell axis becomes the slab axis
+    (dist.best_slab_shift).  Not in CASES (too slow for the per-case parity lists under the emulator)."""
+    structures = [td.Structure(geometry=td.Box(center=(0.5, -0.3, 0), size=(1.0, 0.8, 0.3)), medium=td.Medium(permittivity=3.0))]
+    monitors = [td.FieldMonitor(center=(0, 0, 0), size=(td.inf, td.inf, 0), freqs=[3e14], name="f"),
+                td.FieldTimeMonitor(center=(0.4, 0.2, 0.1), size=(0.5, 0, 0.3), name="t", interval=2, colocate=False)]
+    return _sim(N, td.BoundarySpec.all_sides(td.PECBoundary()), structures, monitors=monitors)
+
+
 CASES = {
     "bloch_box": bloch_box, "bloch_planewave": bloch_planewave, "bloch_xy_pml_z": bloch_xy_pml_z, "bloch_x_only": bloch_x_only,
     "two_d": two_d, "one_d": one_d, "absorber_mix": absorber_mix, "absorber_odd_rows": absorber_odd_rows,

@@ -135,3 +135,25 @@ def test_distributed_run_entry_point(emu_lib, tmp_path):
             assert np.array_equal(got[f"{d.monitor.name}__{k}"], np.asarray(v.values)), (d.monitor.name, k)
             n += 1
     assert n >= 12
+
+
+def test_automatic_slab_axis_choice(emu_lib, tmp_path):
+    """128 x 128 x 16 cells on 2 ranks: make_engine picks the renaming by itself (8-plane slabs would become
+    64-plane slabs); the stitched result equals the plain single-GPU run."""
+    import cases
+    from tidy3d_amd.dist import best_slab_shift
+    disc = discretize(cases.wide_flat(), n_steps=6)
+    assert disc.spec.shape == (128, 128, 16) and best_slab_shift(disc.spec.shape, 2) == 1
+    out = str(tmp_path / "dist.npz")
+    _launch(2, "wide_flat", 6, out, 29569)
+    got = np.load(out)
+    disc.spec.decay_every = 10
+    with HipEngine(disc.spec, lib=emu_lib, axis_shift=0) as e:
+        e.run()
+        ref = e.results()
+        fields = [e.get_field(c) for c in range(6)]
+    for c in range(6):
+        assert got[f"field{c}"].shape == fields[c].shape
+        assert np.abs(got[f"field{c}"] - fields[c]).max() <= 1e-6 * max(np.abs(fields[c]).max(), 1e-30), c
+    for k, v in ref.items():
+        assert np.abs(got[f"mon_{k}"] - v).max() <= 1e-6 * max(np.abs(v).max(), 1e-30), k
