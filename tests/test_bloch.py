@@ -1,5 +1,5 @@
 """Bloch boundaries (ref boundary.py:55-160): complex fields, F(r + L) = exp(2 pi i bloch_vec) F(r).
-The HIP engine carries them as a (Re, Im) pair of real solvers coupled by the Bloch fix-up kernels
+The HIP engine carries them as a (Re, Im) pair of real solvers on a ghost-cell device layout, coupled by the ghost fills
 (fdtd_run_bloch); the oracle uses complex arrays directly — two independent formulations held together
 by the ``bloch_*`` parity cases (tests/cases.py).  Here: schema pins and the physics of the oracle."""
 import numpy as np
