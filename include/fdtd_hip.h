@@ -57,7 +57,7 @@ typedef struct FdtdStats {
   int64_t steps_done;
   int32_t diverged;          /* NaN/Inf seen in the field-energy reduction                       */
   int32_t stopped_early;     /* shutoff reached                                                  */
-  double  field_decay;       /* last  sum|E|^2 / max sum|E|^2                                    */
+  double  field_decay;       /* last W / max W,  W = sum|E|^2 + (mu0/eps0) sum|H|^2              */
   double  run_ms;            /* hipEvent time of the last fdtd_run (whole step loop)             */
   double  h_kernel_ms;       /* with FDTD_FLAG_TIME_KERNELS: summed durations of the main H ...  */
   double  e_kernel_ms;       /* ... and E update kernels in the last fdtd_run                    */
@@ -96,8 +96,13 @@ int fdtd_set_steps(FdtdSolver* h, int axis, const float* inv_primal, const float
  * volumes mat[3][nz][ny][nx] (uint8, one per E component, ref simulation.py:1135-1241).
  * Without fdtd_set_material every cell uses entry 1.  (Ca, Cb) follow from Medium.permittivity /
  * conductivity (ref medium.py:1499, :1016-1038) or the pole-residue form (ref medium.py:2739). */
-int fdtd_set_media(FdtdSolver* h, const float* ca, const float* cb, int n_media);
+int fdtd_set_media(FdtdSolver* h, const float* ca, const float* cb, int n_media);   /* n_media <= 1024 */
 int fdtd_set_material(FdtdSolver* h, const uint8_t* mat, size_t bytes);
+/* the same with 16-bit indices mat[3][nz][ny][nx] (count = 3 nz ny nx entries): more than 255 media (the
+ * reference allows 65,530 structures, ref components/scene.py:52; the device packs three 10-bit indices
+ * into one 32-bit word per cell, so 1023 distinct media per simulation) — what sub-pixel averaging and
+ * CustomMedium need to quantise permittivity in 0.2 % steps */
+int fdtd_set_material16(FdtdSolver* h, const uint16_t* mat, size_t count);
 
 /* CPML tables of one axis, each of length n (identity outside the slabs); the slab index ranges
  * are derived from n_lo/n_hi = Simulation.num_pml_layers (ref simulation.py:1002) and the profile
@@ -155,8 +160,10 @@ int fdtd_get_monitor(FdtdSolver* h, int monitor_id, void* host, size_t bytes);
 int fdtd_set_field(FdtdSolver* h, int comp, const float* host, size_t bytes);
 int fdtd_get_field(FdtdSolver* h, int comp, float* host, size_t bytes);
 
-/* field-decay / shutoff: evaluate sum|E|^2 every `every` steps; stop when it falls below
- * shutoff * max after step `ref_step` (ref simulation.py:2089-2096). every = 0 disables. */
+/* field-decay / shutoff: evaluate W = sum|E|^2 + (mu0/eps0) sum|H|^2 over the slab every `every` steps
+ * (fixed-order reduction: bitwise repeatable); stop when W falls below shutoff * max W after step
+ * `ref_step` (ref simulation.py:2089-2096 shutoff, "field decay" of web/core/task_core.py:537).
+ * every = 0 disables.  A non-finite W ends the run with FdtdStats.diverged (ref sim_data.py:909). */
 int fdtd_set_shutoff(FdtdSolver* h, int every, double shutoff, int64_t ref_step);
 
 /* z-slab decomposition over RCCL (one process per GPU).  Rank 0 creates the id, the host
@@ -182,7 +189,8 @@ int fdtd_run_bloch(FdtdSolver* h_re, FdtdSolver* h_im, int64_t n_steps, const do
 int fdtd_get_stats(FdtdSolver* h, FdtdStats* out);
 /* tuning knobs that may change between runs of one handle (bench A/B without re-upload) */
 enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_ROWS = 3, FDTD_OPT_XCD_REMAP = 4,
-       FDTD_OPT_FUSED_LB = 5, FDTD_OPT_PML_FUSED = 6 /* axis bit mask: 0 (default), 6, 7 */,
+       FDTD_OPT_FUSED_LB = 5,
+       FDTD_OPT_PML_FUSED = 6 /* axes (bit mask) whose CPML recursions run inside the fused sweep: -1 = all (default), 0 = slab kernels */,
        FDTD_OPT_BND_PLANES = 7 /* planes per boundary chunk of the fused z-slab schedule, 0 = auto */,
        FDTD_OPT_AUTOTUNE = 8 /* 1: time a few tile shapes of the fused sweep on the first run of grids >= 2^20 cells (default 0) */ };
 int fdtd_set_option(FdtdSolver* h, int key, int value);

@@ -39,6 +39,10 @@ MEDIA = [td.Structure(geometry=td.Sphere(center=(0.05, 0, 0), radius=0.2),
                       medium=td.Medium(permittivity=3.0, conductivity=0.02)),
          td.Structure(geometry=td.Box(center=(0.3, 0.1, 0), size=(0.1, 0.1, 0.1)), medium=td.PEC)]
 
+PML_ODD = td.BoundarySpec(x=td.Boundary(minus=td.PML(num_layers=5), plus=td.PML(num_layers=3)), y=td.Boundary.pml(num_layers=2),
+                          z=td.Boundary(minus=td.PECBoundary(), plus=td.PML(num_layers=3)))
+PML_MEET = td.BoundarySpec(x=td.Boundary.pml(num_layers=7), y=td.Boundary.pml(num_layers=3), z=td.Boundary.periodic())
+
 ABS = td.BoundarySpec(x=td.Boundary.absorber(num_layers=4, parameters=td.AbsorberParams(sigma_max=1.5)),
                       y=td.Boundary(minus=td.PML(num_layers=3), plus=td.Absorber(num_layers=3)),
                       z=td.Boundary.absorber(num_layers=3))
@@ -49,6 +53,11 @@ CONFIGS = {
     "pec_two_x_tiles": ((260, 9, 8), PEC, ()),
     "pmc_min_faces": ((16, 10, 9), PMC, ()),
     "pml_media": ((32, 14, 10), PML, MEDIA),
+    # x layer counts that are not multiples of 4, rows padded to a multiple of 4 (x slab ranges are rounded
+    # outwards inside the sweep); a PEC z-min wall under the z recursion
+    "pml_odd_layers_padded_rows": ((22, 9, 8), PML_ODD, MEDIA),
+    # the rounded x ranges meet: the whole axis is a member
+    "pml_x_ranges_meet": ((2, 6, 8), PML_MEET, ()),
     "periodic_media": ((32, 12, 10), PER, MEDIA),
 }
 
@@ -67,7 +76,6 @@ def _run(spec, lib, variant, rows, zc, pml_mask=None):
 def test_fused_equals_two_pass(name, rows, zc, emu_lib):
     N, bspec, structures = CONFIGS[name]
     disc = discretize(_sim(N, bspec, structures), n_steps=24)
-    assert disc.spec.shape[0] % 4 == 0
     ref_f, ref_m = _run(disc.spec, emu_lib, L.VARIANT_ZMARCH, 4, 2)
     got_f, got_m = _run(disc.spec, emu_lib, L.VARIANT_FUSED, rows, zc)
     # explicit fma's + -ffp-contract=off + identical summation order: bit-for-bit agreement

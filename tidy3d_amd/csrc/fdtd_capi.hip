@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <utility>
 #include <algorithm>
@@ -27,14 +28,17 @@ struct DevBuf {
 };
 
 struct PmlAxisDev {
-  int n_lo = 0, n_hi = 0, n = 0;
-  float *kinv_e = nullptr, *b_e = nullptr, *c_e = nullptr, *kinv_h = nullptr, *b_h = nullptr, *c_h = nullptr;
-  // psi arrays: [side E/H][comp slot 0/1]
+  int n_lo = 0, n_hi = 0, n = 0;   // true layer counts (what the slab kernels visit)
+  // membership of the psi arrays (same on the E and the H side, fdtd_kernels.hpp PmlAxisP): index ia is
+  // held when ia < lo or ia >= hi0; along x both are multiples of 4 cells
+  int lo = 0, hi0 = 0, ns = 0;
+  float4 *ce4 = nullptr, *ch4 = nullptr;                       // {1/kappa - 1, b, c, 0} per index
+  float *kv_e = nullptr, *b_e = nullptr, *c_e = nullptr, *kv_h = nullptr, *b_h = nullptr, *c_h = nullptr;
+  // psi arrays: [comp slot 0/1]
   float* psi_e[2] = {nullptr, nullptr};
   float* psi_h[2] = {nullptr, nullptr};
-  float* psi_h2[2] = {nullptr, nullptr};   // write set of the fused in-kernel CPML (ping-pong)
-  size_t psi_h_count = 0;
-  int ns_e = 0, ns_h = 0;          // slab extents along the axis (lo + hi entries)
+  float* psi_h2[2] = {nullptr, nullptr};   // write set of the in-sweep CPML (ping-pong), lazily allocated
+  size_t psi_count = 0;                    // entries per psi array
 };
 
 struct AdeGroup {
@@ -55,15 +59,20 @@ struct PointSrc {
   long long n_steps = 0;
 };
 
+// correction list of one side (E or H) of a TFSF box, grouped by target node (tfsf_corr_kernel)
+struct TfsfList {
+  long long n_targets = 0;
+  int32_t *comp = nullptr, *start = nullptr, *aux = nullptr;
+  uint32_t* cell = nullptr;
+  float* w = nullptr;
+};
+
 struct Tfsf {
   int n_aux = 0, src_cell = 0;
   float *ae = nullptr, *be = nullptr, *ah = nullptr, *bh = nullptr, *e1 = nullptr, *h1 = nullptr, *wave = nullptr;
   float *e1c = nullptr, *h1c = nullptr;   // replica advanced on the comm stream (pipelined z-slab schedule)
   long long n_steps = 0;
-  long long n_e = 0, n_h = 0;
-  int32_t *e_comp = nullptr, *h_comp = nullptr, *e_aux = nullptr, *h_aux = nullptr;
-  uint32_t *e_cell = nullptr, *h_cell = nullptr;
-  float *e_w = nullptr, *h_w = nullptr;
+  TfsfList e, h;
 };
 
 struct Monitor {
@@ -94,6 +103,7 @@ struct FdtdSolver {
   size_t field_bytes = 0;
   float *ip[3] = {}, *idl[3] = {};
   uint32_t* mat4 = nullptr;          // packed material words (interior plane 0), nullptr = uniform
+  uint32_t* roww = nullptr;          // row-segment words [nz][ny][ceil(nx / 256)]
   float2* lut = nullptr;
   int n_media = 0;
   float ca1 = 1.f, cb1 = 0.f;
@@ -111,7 +121,7 @@ struct FdtdSolver {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> kev;       // per-launch timing events (FDTD_FLAG_TIME_KERNELS)
   std::vector<int> kev_kind;
-  double* energy_dev = nullptr;
+  double* energy_dev = nullptr;      // [0] = total, [1 .. 1 + kEnergyBlocks) = per-workgroup partial sums
   int decay_every = 0;
   double shutoff = 0.0;
   long long decay_ref = 0;
@@ -128,7 +138,7 @@ struct FdtdSolver {
   // 6 = y and z, 7 = all.  Measured on 512^3 + 12-layer PML (profiles/r01h_pml_placement.txt): the
   // extra live registers drop the sweep from 3 to 2 (mask 6) or 1 (mask 7) waves per SIMD, which
   // costs more (+0.41 ms / +3.0 ms) than the slab kernels it removes (0.22 ms / 0.45 ms) -> default 0.
-  int pml_fused = 0;
+  int pml_fused = -1;                // -1 = default
   // opt-in (FDTD_OPT_AUTOTUNE): time a few (rows, z-chunk) tile shapes on the first run and keep the
   // best.  Measured (profiles/r01h_autotune.txt): +6 % on a 64-plane slab (3 x 32 instead of 3 x 16),
   // nothing at 512^3 (shapes within noise of each other, so the pick is noise too) and the wrong
@@ -137,6 +147,8 @@ struct FdtdSolver {
   bool tuned = false, user_geometry = false;
   int bnd_planes = 0;                // fused z-slab schedule: planes per boundary chunk (0 = heuristic)
   int rows = 4;
+  PmlP* pml_blk[2] = {nullptr, nullptr};   // device parameter blocks of the in-sweep CPML, one per psi_h parity
+  int pml_parity = 0, pml_blk_mask = 0;
   // RCCL
   ncclComm_t comm = nullptr;
   int rank = 0, n_ranks = 1;
@@ -211,6 +223,7 @@ StepP step_params(const FdtdSolver* h) {
 MatP mat_params(const FdtdSolver* h) {
   MatP m;
   m.m4 = h->mat4;
+  m.roww = h->roww;
   m.lut = h->lut; m.n_media = h->n_media; m.ca1 = h->ca1; m.cb1 = h->cb1;
   return m;
 }
@@ -285,42 +298,79 @@ int ensure_second_set(FdtdSolver* h) {
   return 0;
 }
 
-PmlP pml_params(const FdtdSolver* h) {
-  PmlP pm{};
-  const int N[3] = {h->g.nx, h->g.ny, h->g.nz};
-  for (int a = 0; a < 3; ++a) {
-    const PmlAxisDev& P = h->pml[a];
-    PmlAxisP& A = pm.ax[a];
-    A.kinv_e = P.kinv_e; A.b_e = P.b_e; A.c_e = P.c_e;
-    A.kinv_h = P.kinv_h; A.b_h = P.b_h; A.c_h = P.c_h;
-    A.pe0 = P.psi_e[0]; A.pe1 = P.psi_e[1]; A.ph0 = P.psi_h[0]; A.ph1 = P.psi_h[1];
-    A.ph0n = P.psi_h2[0]; A.ph1n = P.psi_h2[1];
-    A.n_lo = P.n_lo; A.n_hi = P.n_hi; A.ns_e = P.ns_e; A.ns_h = P.ns_h; A.n = N[a];
-  }
-  return pm;
-}
-
 bool any_pml(const FdtdSolver* h) {
   for (int a = 0; a < 3; ++a) if (h->pml[a].n_lo + h->pml[a].n_hi > 0) return true;
   return false;
 }
 
-// Tile rows: all of them (ty_n < 0) or  [0, ty_a) + [ty_a + ty_gap, ty_a + ty_gap + (ty_n - ty_a)).
+// Device parameter blocks of the in-sweep CPML: block q reads psi_h (q = 0) or psi_h2 (q = 1) and
+// writes the other set; the sweep alternates between them.  Built on first use.
+int ensure_pml_blocks(FdtdSolver* h, int mask) {
+  if (h->pml_blk[0] && h->pml_blk_mask == mask) return 0;
+  const int N[3] = {h->g.nx, h->g.ny, h->g.nz};
+  for (int a = 0; a < 3; ++a) {
+    PmlAxisDev& P = h->pml[a];
+    if (P.ns == 0) continue;
+    for (int q = 0; q < 2; ++q)
+      if (!P.psi_h2[q] && dev_alloc(h, &P.psi_h2[q], P.psi_count)) return -1;
+  }
+  for (int par = 0; par < 2; ++par) {
+    PmlP pm{};
+    for (int a = 0; a < 3; ++a) {
+      const PmlAxisDev& P = h->pml[a];
+      PmlAxisP& A = pm.ax[a];
+      A.ce4 = P.ce4; A.ch4 = P.ch4;
+      A.kv_e = P.kv_e; A.b_e = P.b_e; A.c_e = P.c_e;
+      A.kv_h = P.kv_h; A.b_h = P.b_h; A.c_h = P.c_h;
+      A.pe0 = P.psi_e[0]; A.pe1 = P.psi_e[1];
+      // parity 0: the CURRENT read set is psi_h (as the handle holds it now)
+      A.ph0 = par ? P.psi_h2[0] : P.psi_h[0]; A.ph1 = par ? P.psi_h2[1] : P.psi_h[1];
+      A.ph0n = par ? P.psi_h[0] : P.psi_h2[0]; A.ph1n = par ? P.psi_h[1] : P.psi_h2[1];
+      // an axis without CPML, or one whose recursions stay in the slab kernels, has no members
+      const bool in = P.ns > 0 && ((mask >> a) & 1);
+      A.lo = in ? P.lo : 0; A.hi0 = in ? P.hi0 : N[a]; A.ns = P.ns; A.n = N[a];
+    }
+    if (!h->pml_blk[par] && dev_alloc(h, &h->pml_blk[par], 1, false)) return -1;
+    if (hipMemcpy(h->pml_blk[par], &pm, sizeof(PmlP), hipMemcpyHostToDevice) != hipSuccess)
+      return fail(h, "upload of the CPML parameter block failed");
+  }
+  h->pml_parity = 0;
+  h->pml_blk_mask = mask;
+  return 0;
+}
+
+// axes whose CPML recursions can run inside the sweep
+int pml_in_sweep_mask(const FdtdSolver* h) {
+  int mask = 0;
+  for (int a = 0; a < 3; ++a) if (h->pml[a].ns > 0) mask |= 1 << a;
+  return mask;
+}
+
+// after a sweep that carried CPML recursions: the write set becomes the read set
+void swap_psi_h(FdtdSolver* h, int pml_inside) {
+  if (!pml_inside) return;
+  for (int a = 0; a < 3; ++a) {
+    PmlAxisDev& P = h->pml[a];
+    if (P.ns == 0 || !((pml_inside >> a) & 1)) continue;
+    std::swap(P.psi_h[0], P.psi_h2[0]);
+    std::swap(P.psi_h[1], P.psi_h2[1]);
+  }
+  h->pml_parity ^= 1;
+}
+
 int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pml_inside = 0, int k2beg = 0,
-                       int k2end = 0, int ty_n = -1, int ty_a = 0, int ty_gap = 0) {
+                       int k2end = 0) {
   if (kend <= kbeg) {                 // first plane range empty: the second one takes its place
     if (k2end <= k2beg) return 0;
     kbeg = k2beg; kend = k2end; k2beg = k2end = 0;
   }
-  if (ty_n == 0) return 0;
   const GridP& g = h->g;
   if (ensure_second_set(h)) return -1;
+  if (pml_inside && ensure_pml_blocks(h, pml_inside)) return -1;
   const int R = h->rows_f;
   const int zc = h->zchunk_f;
   dim3 block(64, R + 1, 1);
-  const int nby_all = (g.ny + R - 1) / R;
-  if (ty_n < 0) { ty_n = nby_all; ty_a = nby_all; ty_gap = 0; }
-  const int nbx = (g.nx + 255) / 256, nby = ty_n, nbz1 = (kend - kbeg + zc - 1) / zc;
+  const int nbx = (g.nx + 255) / 256, nby = (g.ny + R - 1) / R, nbz1 = (kend - kbeg + zc - 1) / zc;
   const int nbz = nbz1 + (k2end > k2beg ? (k2end - k2beg + zc - 1) / zc : 0);
   const int total = nbx * nby * nbz;
   const int remap = h->xcd_remap ? 1 : 0;
@@ -334,16 +384,14 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pm
   int lb = h->fused_lb ? h->fused_lb : (threads <= 256 ? 256 : (threads <= 512 ? 512 : 1024));
   if (lb < threads) lb = threads <= 512 ? 512 : 1024;
   time_begin(h, 2, st);
-  const PmlP pm = pml_params(h);
+  const PmlP* pm = pml_inside ? h->pml_blk[h->pml_parity] : nullptr;
 #define FDTD_LAUNCH_FUSED(MATV, LBV, PMLV)                                                            \
   hipLaunchKernelGGL((fused_step_kernel<MATV, LBV, PMLV>), grid, block, shmem, st, g, h->f, h->f2, s, m, kbeg, \
-                     kend, zc, pmc, nbx, nby, nbz, remap, pm, nbz1, k2beg, k2end, ty_a, ty_gap)
-  if (pml_inside == 7) {    // CPML of all axes folded into the sweep (256- and 512-thread workgroups)
+                     kend, zc, pmc, nbx, nby, nbz, remap, pm, nbz1, k2beg, k2end)
+  // one CPML-carrying instantiation (all axes; axes outside `pml_inside` have no members in the block)
+  if (pml_inside) {
     if (h->mat4) { if (lb == 256) FDTD_LAUNCH_FUSED(true, 256, 7); else FDTD_LAUNCH_FUSED(true, 512, 7); }
     else { if (lb == 256) FDTD_LAUNCH_FUSED(false, 256, 7); else FDTD_LAUNCH_FUSED(false, 512, 7); }
-  } else if (pml_inside == 6) {   // y and z only (wave-uniform membership, float4 psi accesses)
-    if (h->mat4) { if (lb == 256) FDTD_LAUNCH_FUSED(true, 256, 6); else FDTD_LAUNCH_FUSED(true, 512, 6); }
-    else { if (lb == 256) FDTD_LAUNCH_FUSED(false, 256, 6); else FDTD_LAUNCH_FUSED(false, 512, 6); }
   } else if (h->mat4) {
     if (lb == 256) FDTD_LAUNCH_FUSED(true, 256, 0); else if (lb == 512) FDTD_LAUNCH_FUSED(true, 512, 0); else FDTD_LAUNCH_FUSED(true, 1024, 0);
   } else {
@@ -362,6 +410,7 @@ void swap_sets(FdtdSolver* h) {
 int launch_fused(FdtdSolver* h, hipStream_t st, int pml_inside) {
   if (launch_fused_range(h, 0, h->g.nz, st, pml_inside)) return -1;
   swap_sets(h);
+  swap_psi_h(h, pml_inside);
   return 0;
 }
 
@@ -434,12 +483,12 @@ void launch_pml(FdtdSolver* h, bool e_side, int kbeg, int kend, hipStream_t st, 
     for (int side = 0; side < 2; ++side) {
       int s_lo, s_n, base;
       if (side == 0) { s_lo = 0; s_n = P.n_lo; base = 0; }
-      else if (e_side) { s_lo = N[a] - P.n_hi + 1; s_n = P.n_hi - 1; base = P.n_lo; }
-      else { s_lo = N[a] - P.n_hi; s_n = P.n_hi; base = P.n_lo; }
+      else if (e_side) { s_lo = N[a] - P.n_hi + 1; s_n = P.n_hi - 1; base = P.lo + (s_lo - P.hi0); }
+      else { s_lo = N[a] - P.n_hi; s_n = P.n_hi; base = P.lo + (s_lo - P.hi0); }
       if (s_n <= 0) continue;
       SlabP q;
       q.a = a; q.s_lo = s_lo; q.s_n = s_n; q.psi_base = base;
-      q.psi_ns = e_side ? P.ns_e : P.ns_h;
+      q.psi_ns = P.ns;
       q.kbeg = kbeg; q.kend = kend; q.kpsi0 = 0;
       if (a == 2) {          // intersect the slab with the launch z-range
         int lo = s_lo > kbeg ? s_lo : kbeg;
@@ -460,25 +509,21 @@ void launch_pml(FdtdSolver* h, bool e_side, int kbeg, int kend, hipStream_t st, 
     if (vec4 && e_side)
       hipLaunchKernelGGL(pml_e4_kernel, grid, dim3(256), 0, st, g, sl[0], sl[1], field_ptr(h, c1),
                          field_ptr(h, c2), (const float*)field_ptr(h, 3 + c1), (const float*)field_ptr(h, 3 + c2),
-                         P.psi_e[0], P.psi_e[1], (const float*)P.kinv_e, (const float*)P.b_e,
-                         (const float*)P.c_e, (const float*)h->idl[a], (const uint32_t*)h->mat4,
+                         P.psi_e[0], P.psi_e[1], (const float4*)P.ce4, (const float*)h->idl[a], (const uint32_t*)h->mat4,
                          (const float2*)h->lut, h->cb1);
     else if (vec4)
       hipLaunchKernelGGL(pml_h4_kernel, grid, dim3(256), 0, st, g, sl[0], sl[1], field_ptr(h, 3 + c1),
                          field_ptr(h, 3 + c2), (const float*)field_ptr(h, c1), (const float*)field_ptr(h, c2),
-                         P.psi_h[0], P.psi_h[1], (const float*)P.kinv_h, (const float*)P.b_h,
-                         (const float*)P.c_h, (const float*)h->ip[a]);
+                         P.psi_h[0], P.psi_h[1], (const float4*)P.ch4, (const float*)h->ip[a]);
     else if (e_side)
       hipLaunchKernelGGL(pml_e_kernel, grid, dim3(256), 0, st, g, sl[0], sl[1], field_ptr(h, c1),
                          field_ptr(h, c2), (const float*)field_ptr(h, 3 + c1), (const float*)field_ptr(h, 3 + c2),
-                         P.psi_e[0], P.psi_e[1], (const float*)P.kinv_e, (const float*)P.b_e,
-                         (const float*)P.c_e, (const float*)h->idl[a], (const uint32_t*)h->mat4,
+                         P.psi_e[0], P.psi_e[1], (const float4*)P.ce4, (const float*)h->idl[a], (const uint32_t*)h->mat4,
                          (const float2*)h->lut, h->cb1);
     else
       hipLaunchKernelGGL(pml_h_kernel, grid, dim3(256), 0, st, g, sl[0], sl[1], field_ptr(h, 3 + c1),
                          field_ptr(h, 3 + c2), (const float*)field_ptr(h, c1), (const float*)field_ptr(h, c2),
-                         P.psi_h[0], P.psi_h[1], (const float*)P.kinv_h, (const float*)P.b_h,
-                         (const float*)P.c_h, (const float*)h->ip[a]);
+                         P.psi_h[0], P.psi_h[1], (const float4*)P.ch4, (const float*)h->ip[a]);
   }
 }
 
@@ -519,17 +564,13 @@ void launch_sources(FdtdSolver* h, bool e_side, long long n, int kbeg, int kend,
   float *f0 = field_ptr(h, off), *f1 = field_ptr(h, off + 1), *f2 = field_ptr(h, off + 2);
   for (Tfsf& t : h->tfsf) {
     if (n >= t.n_steps) continue;
-    if (e_side) {
-      if (t.n_e)
-        hipLaunchKernelGGL(tfsf_corr_kernel, dim3(nblk(t.n_e)), dim3(256), 0, st, f0, f1, f2,
-                           (const int32_t*)t.e_comp, (const uint32_t*)t.e_cell, (const float*)t.e_w,
-                           (const int32_t*)t.e_aux, (const float*)(replica ? t.h1c : t.h1), t.n_e, zlo, zhi);
-    } else {
-      if (t.n_h)
-        hipLaunchKernelGGL(tfsf_corr_kernel, dim3(nblk(t.n_h)), dim3(256), 0, st, f0, f1, f2,
-                           (const int32_t*)t.h_comp, (const uint32_t*)t.h_cell, (const float*)t.h_w,
-                           (const int32_t*)t.h_aux, (const float*)(replica ? t.e1c : t.e1), t.n_h, zlo, zhi);
-    }
+    const TfsfList& L = e_side ? t.e : t.h;
+    // E-side corrections read the incident H (h1), H-side ones the incident E (e1)
+    const float* aux = e_side ? (replica ? t.h1c : t.h1) : (replica ? t.e1c : t.e1);
+    if (L.n_targets)
+      hipLaunchKernelGGL(tfsf_corr_kernel, dim3(nblk(L.n_targets)), dim3(256), 0, st, f0, f1, f2,
+                         (const int32_t*)L.comp, (const uint32_t*)L.cell, (const int32_t*)L.start, (const float*)L.w,
+                         (const int32_t*)L.aux, aux, L.n_targets, zlo, zhi);
   }
   for (PointSrc& s : h->psrc) {
     if (n >= s.n_steps) continue;
@@ -694,6 +735,22 @@ int exchange_fused_all(FdtdSolver* h, hipStream_t st) {
   return 0;
 }
 
+// ---- field energy (K7) ------------------------------------------------------------------------
+// W = sum |E|^2 + eta0^2 sum |H|^2 over the slab: fixed launch geometry, two passes, no atomics
+int eval_energy(FdtdSolver* h, hipStream_t st, double* out) {
+  const long long nc = n_cells(h);
+  unsigned blocks = nblk(nc);
+  if (blocks > (unsigned)kEnergyBlocks) blocks = kEnergyBlocks;
+  hipLaunchKernelGGL(energy_partial_kernel, dim3(blocks), dim3(256), 0, st, (const float*)h->f.ex, (const float*)h->f.ey,
+                     (const float*)h->f.ez, (const float*)h->f.hx, (const float*)h->f.hy, (const float*)h->f.hz, nc,
+                     h->energy_dev + 1);
+  hipLaunchKernelGGL(energy_final_kernel, dim3(1), dim3(256), 0, st, (const double*)(h->energy_dev + 1), (int)blocks,
+                     h->energy_dev);
+  HIPCHK(h, hipMemcpyAsync(out, h->energy_dev, sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  return 0;
+}
+
 // ---- monitors ---------------------------------------------------------------------------------
 void record_monitors(FdtdSolver* h, long long n, bool post, hipStream_t st) {
   for (Monitor& m : h->mons) {
@@ -785,7 +842,7 @@ int fdtd_create(const FdtdConfig* cfg, FdtdSolver** out) {
   if (!rc) {
     h->f.ex = h->fbase[0] + g.sxy; h->f.ey = h->fbase[1] + g.sxy; h->f.ez = h->fbase[2] + g.sxy;
     h->f.hx = h->fbase[3] + g.sxy; h->f.hy = h->fbase[4] + g.sxy; h->f.hz = h->fbase[5] + g.sxy;
-    rc = dev_alloc(h, &h->energy_dev, 1);
+    rc = dev_alloc(h, &h->energy_dev, 1 + kEnergyBlocks);
   }
   if (!rc) {
     // default: unit steps, vacuum
@@ -872,7 +929,7 @@ int fdtd_set_steps(FdtdSolver* h, int axis, const float* inv_primal, const float
 
 int fdtd_set_media(FdtdSolver* h, const float* ca, const float* cb, int n_media) {
   if (!h) return -1;
-  if (n_media < 2 || n_media > 256) return fail(h, "fdtd_set_media: n_media must be in [2, 256], got %d", n_media);
+  if (n_media < 2 || n_media > kMaxMedia) return fail(h, "fdtd_set_media: n_media must be in [2, %d], got %d", kMaxMedia, n_media);
   HIPCHK(h, hipSetDevice(h->cfg.device));
   std::vector<float2> lut(n_media);
   for (int i = 0; i < n_media; ++i) { lut[i].x = ca[i]; lut[i].y = cb[i]; }
@@ -884,21 +941,53 @@ int fdtd_set_media(FdtdSolver* h, const float* ca, const float* cb, int n_media)
   return 0;
 }
 
-int fdtd_set_material(FdtdSolver* h, const uint8_t* mat, size_t bytes) {
-  if (!h) return -1;
+extern "C++" {
+namespace {
+// pack the three index volumes into one word per cell (10 bits per component), derive the
+// row-segment words and upload both
+template <typename T>
+int upload_material(FdtdSolver* h, const T* mat, size_t count) {
   const size_t nc = (size_t)n_cells(h);
-  if (bytes != 3 * nc) return fail(h, "fdtd_set_material: expected %zu bytes, got %zu", 3 * nc, bytes);
+  if (count != 3 * nc) return fail(h, "fdtd_set_material: expected %zu entries, got %zu", 3 * nc, count);
   if (h->n_media == 0) return fail(h, "fdtd_set_material: call fdtd_set_media first");
   HIPCHK(h, hipSetDevice(h->cfg.device));
-  const size_t fcount = (size_t)h->g.sxy * (h->g.nz + 2);
-  std::vector<uint32_t> packed(fcount, 0x00010101u);          // ghost planes: background medium
-  uint32_t* dst = packed.data() + h->g.sxy;
-  for (size_t i = 0; i < nc; ++i)
-    dst[i] = (uint32_t)mat[i] | ((uint32_t)mat[nc + i] << 8) | ((uint32_t)mat[2 * nc + i] << 16);
+  const GridP& g = h->g;
+  const size_t fcount = (size_t)g.sxy * (g.nz + 2);
+  std::vector<uint32_t> packed(fcount, kBgWord);                 // ghost planes: background medium
+  uint32_t* dst = packed.data() + g.sxy;
+  const uint32_t nm = (uint32_t)h->n_media;
+  for (size_t i = 0; i < nc; ++i) {
+    const uint32_t m0 = mat[i], m1 = mat[nc + i], m2 = mat[2 * nc + i];
+    if (m0 >= nm || m1 >= nm || m2 >= nm) return fail(h, "fdtd_set_material: medium index out of range at cell %zu", i);
+    dst[i] = m0 | (m1 << 10) | (m2 << 20);
+  }
+  const int nbx = (g.nx + 255) / 256;
+  std::vector<uint32_t> roww((size_t)g.nz * g.ny * nbx);
+  for (size_t r = 0; r < (size_t)g.nz * g.ny; ++r)
+    for (int bx = 0; bx < nbx; ++bx) {
+      const uint32_t* row = dst + r * g.nx;
+      const int i1 = std::min(g.nx, (bx + 1) * 256);
+      uint32_t w = row[bx * 256];
+      for (int i = bx * 256 + 1; i < i1; ++i) if (row[i] != w) { w = kMixedWord; break; }
+      roww[r * nbx + bx] = w;
+    }
   uint32_t* base = nullptr;
   if (dev_upload(h, &base, (const uint32_t*)packed.data(), fcount)) return -1;
-  h->mat4 = base + h->g.sxy;
+  if (dev_upload(h, &h->roww, (const uint32_t*)roww.data(), roww.size())) return -1;
+  h->mat4 = base + g.sxy;
   return 0;
+}
+}  // namespace
+}  // extern "C++"
+
+int fdtd_set_material(FdtdSolver* h, const uint8_t* mat, size_t bytes) {
+  if (!h) return -1;
+  return upload_material(h, mat, bytes);
+}
+
+int fdtd_set_material16(FdtdSolver* h, const uint16_t* mat, size_t count) {
+  if (!h) return -1;
+  return upload_material(h, mat, count);
 }
 
 int fdtd_set_pml(FdtdSolver* h, int axis, int n_lo, int n_hi, const float* kinv_e, const float* b_e,
@@ -910,18 +999,32 @@ int fdtd_set_pml(FdtdSolver* h, int axis, int n_lo, int n_hi, const float* kinv_
   HIPCHK(h, hipSetDevice(h->cfg.device));
   PmlAxisDev& P = h->pml[axis];
   P.n_lo = n_lo; P.n_hi = n_hi; P.n = n;
-  if (dev_upload(h, &P.kinv_e, kinv_e, (size_t)n) || dev_upload(h, &P.b_e, b_e, (size_t)n) ||
-      dev_upload(h, &P.c_e, c_e, (size_t)n) || dev_upload(h, &P.kinv_h, kinv_h, (size_t)n) ||
+  // membership of the psi arrays: [0, lo) and [hi0, n); along x rounded outwards to multiples of 4 cells
+  // (the tables are identity on the cells this adds), the whole axis when the two ranges would meet
+  P.lo = n_lo; P.hi0 = n - n_hi;
+  if (axis == 0) { P.lo = (n_lo + 3) / 4 * 4; P.hi0 = (n - n_hi) / 4 * 4; }
+  if (P.lo >= P.hi0) { P.lo = n; P.hi0 = n; }
+  P.ns = P.lo + (n - P.hi0);
+  std::vector<float4> ce(n), chh(n);
+  std::vector<float> kve(n), kvh(n);
+  for (int i = 0; i < n; ++i) {
+    kve[i] = kinv_e[i] - 1.f; kvh[i] = kinv_h[i] - 1.f;
+    ce[i].x = kve[i]; ce[i].y = b_e[i]; ce[i].z = c_e[i]; ce[i].w = 0.f;
+    chh[i].x = kvh[i]; chh[i].y = b_h[i]; chh[i].z = c_h[i]; chh[i].w = 0.f;
+  }
+  if (dev_upload(h, &P.ce4, (const float4*)ce.data(), (size_t)n) || dev_upload(h, &P.ch4, (const float4*)chh.data(), (size_t)n) ||
+      dev_upload(h, &P.kv_e, (const float*)kve.data(), (size_t)n) || dev_upload(h, &P.b_e, b_e, (size_t)n) ||
+      dev_upload(h, &P.c_e, c_e, (size_t)n) || dev_upload(h, &P.kv_h, (const float*)kvh.data(), (size_t)n) ||
       dev_upload(h, &P.b_h, b_h, (size_t)n) || dev_upload(h, &P.c_h, c_h, (size_t)n))
     return -1;
-  P.ns_e = n_lo + (n_hi > 0 ? n_hi - 1 : 0);
-  P.ns_h = n_lo + n_hi;
   const size_t other = (size_t)n_cells(h) / (size_t)n;
-  for (int s = 0; s < 2; ++s) {
-    if (P.ns_e > 0 && dev_alloc(h, &P.psi_e[s], other * P.ns_e)) return -1;
-    if (P.ns_h > 0 && dev_alloc(h, &P.psi_h[s], other * P.ns_h)) return -1;
-    P.psi_h_count = other * P.ns_h;
+  P.psi_count = other * P.ns;
+  for (int q = 0; q < 2; ++q) {
+    if (P.ns > 0 && dev_alloc(h, &P.psi_e[q], P.psi_count)) return -1;
+    if (P.ns > 0 && dev_alloc(h, &P.psi_h[q], P.psi_count)) return -1;
+    P.psi_h2[q] = nullptr;
   }
+  h->pml_blk_mask = -1;          // parameter blocks are rebuilt on next use
   return 0;
 }
 
@@ -973,15 +1076,24 @@ int fdtd_add_point_source(FdtdSolver* h, int64_t n, const int32_t* comp, const u
                           const float* w_im, int64_t n_steps, const float* wave_e, const float* wave_h) {
   if (!h) return -1;
   HIPCHK(h, hipSetDevice(h->cfg.device));
-  std::vector<int32_t> ce, chh;
-  std::vector<uint32_t> le, lh;
-  std::vector<float> re_e, im_e, re_h, im_h;
   const uint64_t ncell = (uint64_t)n_cells(h);
+  // Entries that address the same node are merged (their weights multiply the same waveform), so the
+  // kernel's plain read-modify-write touches every node once: no race, no atomics, repeatable bits.
+  std::map<std::pair<int32_t, uint32_t>, std::pair<double, double>> merged;
   for (int64_t i = 0; i < n; ++i) {
     if (comp[i] < 0 || comp[i] > 5) return fail(h, "fdtd_add_point_source: bad component %d", comp[i]);
     if (cell[i] >= ncell) return fail(h, "fdtd_add_point_source: cell index out of range");
-    if (comp[i] < 3) { ce.push_back(comp[i]); le.push_back(cell[i]); re_e.push_back(w_re[i]); im_e.push_back(w_im[i]); }
-    else { chh.push_back(comp[i]); lh.push_back(cell[i]); re_h.push_back(w_re[i]); im_h.push_back(w_im[i]); }
+    auto& acc = merged[{comp[i], cell[i]}];
+    acc.first += (double)w_re[i];
+    acc.second += (double)w_im[i];
+  }
+  std::vector<int32_t> ce, chh;
+  std::vector<uint32_t> le, lh;
+  std::vector<float> re_e, im_e, re_h, im_h;
+  for (const auto& kv : merged) {
+    const int32_t c = kv.first.first;
+    if (c < 3) { ce.push_back(c); le.push_back(kv.first.second); re_e.push_back((float)kv.second.first); im_e.push_back((float)kv.second.second); }
+    else { chh.push_back(c); lh.push_back(kv.first.second); re_h.push_back((float)kv.second.first); im_h.push_back((float)kv.second.second); }
   }
   PointSrc s{};
   s.n_e = (long long)ce.size(); s.n_h = (long long)chh.size(); s.n_steps = n_steps;
@@ -1001,6 +1113,41 @@ int fdtd_add_point_source(FdtdSolver* h, int64_t n, const int32_t* comp, const u
   return 0;
 }
 
+namespace {
+// group a TFSF correction list by target node (component, cell), entries of a node in their given order
+int build_tfsf_list(FdtdSolver* h, TfsfList& L, int64_t n, const int32_t* comp, const uint32_t* cell, const float* w,
+                    const int32_t* aux, int n_aux_max) {
+  if (n <= 0) return 0;
+  const uint64_t ncell = (uint64_t)n_cells(h);
+  std::vector<int64_t> order((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    if (comp[i] < 0 || comp[i] > 5) return fail(h, "fdtd_add_tfsf: bad component %d", comp[i]);
+    if (cell[i] >= ncell) return fail(h, "fdtd_add_tfsf: cell index out of range");
+    if (aux[i] < 0 || aux[i] > n_aux_max) return fail(h, "fdtd_add_tfsf: auxiliary index out of range");
+    order[(size_t)i] = i;
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
+    return comp[x] != comp[y] ? comp[x] < comp[y] : cell[x] < cell[y];
+  });
+  std::vector<int32_t> tc, st, ax((size_t)n);
+  std::vector<uint32_t> tl;
+  std::vector<float> ww((size_t)n);
+  for (int64_t e = 0; e < n; ++e) {
+    const int64_t i = order[(size_t)e];
+    if (e == 0 || comp[i] != tc.back() || cell[i] != tl.back()) { tc.push_back(comp[i]); tl.push_back(cell[i]); st.push_back((int32_t)e); }
+    ww[(size_t)e] = w[i];
+    ax[(size_t)e] = aux[i];
+  }
+  st.push_back((int32_t)n);
+  L.n_targets = (long long)tc.size();
+  if (dev_upload(h, &L.comp, (const int32_t*)tc.data(), tc.size()) || dev_upload(h, &L.cell, (const uint32_t*)tl.data(), tl.size()) ||
+      dev_upload(h, &L.start, (const int32_t*)st.data(), st.size()) || dev_upload(h, &L.w, (const float*)ww.data(), ww.size()) ||
+      dev_upload(h, &L.aux, (const int32_t*)ax.data(), ax.size()))
+    return -1;
+  return 0;
+}
+}  // namespace
+
 int fdtd_add_tfsf(FdtdSolver* h, int n_aux, const float* ae, const float* be, const float* ah, const float* bh,
                   int src_cell, int64_t n_steps, const float* wave, int64_t n_e, const int32_t* e_comp,
                   const uint32_t* e_index, const float* e_w, const int32_t* e_aux, int64_t n_h,
@@ -1010,18 +1157,16 @@ int fdtd_add_tfsf(FdtdSolver* h, int n_aux, const float* ae, const float* be, co
   HIPCHK(h, hipSetDevice(h->cfg.device));
   Tfsf t{};
   t.n_aux = n_aux; t.src_cell = src_cell;
-  t.n_steps = n_steps; t.n_e = n_e; t.n_h = n_h;
+  t.n_steps = n_steps;
   if (dev_upload(h, &t.ae, ae, (size_t)n_aux + 1) || dev_upload(h, &t.be, be, (size_t)n_aux + 1) ||
       dev_upload(h, &t.ah, ah, (size_t)n_aux) || dev_upload(h, &t.bh, bh, (size_t)n_aux) ||
       dev_alloc(h, &t.e1, (size_t)n_aux + 1) || dev_alloc(h, &t.h1, (size_t)n_aux) ||
       dev_alloc(h, &t.e1c, (size_t)n_aux + 1) || dev_alloc(h, &t.h1c, (size_t)n_aux) ||
       dev_upload(h, &t.wave, wave, (size_t)n_steps))
     return -1;
-  if (n_e && (dev_upload(h, &t.e_comp, e_comp, (size_t)n_e) || dev_upload(h, &t.e_cell, e_index, (size_t)n_e) ||
-              dev_upload(h, &t.e_w, e_w, (size_t)n_e) || dev_upload(h, &t.e_aux, e_aux, (size_t)n_e)))
-    return -1;
-  if (n_h && (dev_upload(h, &t.h_comp, h_comp, (size_t)n_h) || dev_upload(h, &t.h_cell, h_index, (size_t)n_h) ||
-              dev_upload(h, &t.h_w, h_w, (size_t)n_h) || dev_upload(h, &t.h_aux, h_aux, (size_t)n_h)))
+  // E-side corrections read h1 (n_aux entries), H-side ones e1 (n_aux + 1 entries)
+  if (build_tfsf_list(h, t.e, n_e, e_comp, e_index, e_w, e_aux, n_aux - 1) ||
+      build_tfsf_list(h, t.h, n_h, h_comp, h_index, h_w, h_aux, n_aux))
     return -1;
   h->tfsf.push_back(t);
   return 0;
@@ -1084,6 +1229,13 @@ int fdtd_set_field(FdtdSolver* h, int comp, const float* host, size_t bytes) {
   if (bytes != (size_t)n_cells(h) * 4) return fail(h, "fdtd_set_field: expected %zu bytes", (size_t)n_cells(h) * 4);
   HIPCHK(h, hipSetDevice(h->cfg.device));
   HIPCHK(h, hipMemcpy(field_ptr(h, comp), host, bytes, hipMemcpyHostToDevice));
+  // the ADE recursion forms Q^{n+1} from E^{n+1} + E^n: E^n of its cells is the value just uploaded
+  for (AdeGroup& a : h->ade)
+    if (a.comp == comp) {
+      hipLaunchKernelGGL(ade_gather_kernel, dim3(nblk(a.n)), dim3(256), 0, h->stream, (const float*)field_ptr(h, comp),
+                         (const uint32_t*)a.cell, a.e_old, a.n);
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
   // keep single-slab ghost planes consistent with the new interior
   if (h->comm == nullptr) { fill_ghost_h(h, h->stream); fill_ghost_e(h, h->stream); fill_ghost_fused(h, h->stream); HIPCHK(h, hipStreamSynchronize(h->stream)); }
   else if (comp == 0 || comp == 1 || comp == 3 || comp == 4) {
@@ -1135,14 +1287,13 @@ int fdtd_reset(FdtdSolver* h) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   for (int c = 0; c < 6; ++c) HIPCHK(h, hipMemset(h->fbase[c], 0, h->field_bytes));
   for (int c = 0; c < 6; ++c) if (h->fbase2[c]) HIPCHK(h, hipMemset(h->fbase2[c], 0, h->field_bytes));
-  const size_t nc = (size_t)n_cells(h);
   for (int a = 0; a < 3; ++a) {
     PmlAxisDev& P = h->pml[a];
     if (P.n == 0) continue;
-    const size_t other = nc / (size_t)P.n;
     for (int s = 0; s < 2; ++s) {
-      if (P.psi_e[s]) HIPCHK(h, hipMemset(P.psi_e[s], 0, other * P.ns_e * 4));
-      if (P.psi_h[s]) HIPCHK(h, hipMemset(P.psi_h[s], 0, other * P.ns_h * 4));
+      if (P.psi_e[s]) HIPCHK(h, hipMemset(P.psi_e[s], 0, P.psi_count * 4));
+      if (P.psi_h[s]) HIPCHK(h, hipMemset(P.psi_h[s], 0, P.psi_count * 4));
+      if (P.psi_h2[s]) HIPCHK(h, hipMemset(P.psi_h2[s], 0, P.psi_count * 4));
     }
   }
   for (AdeGroup& a : h->ade) {
@@ -1333,45 +1484,18 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     } else if (fused) {
       // H-side corrections are additive: pre-apply them to H^{n-1/2}; E-side ones follow the sweep.
       // With pml_in the CPML recursions run inside the sweep (same arithmetic, no slab kernels).
-      int pml_in = 0;           // axes whose recursions run inside the sweep: none, {y, z} or all
-      if (h->pml_fused && any_pml(h) && 64 * (h->rows_f + 1) <= 512) pml_in = (h->pml_fused & 1) ? 7 : 6;
-      if (pml_in)
-        for (int a = 0; a < 3; ++a) {
-          if (!((pml_in >> a) & 1)) continue;
-          PmlAxisDev& P = h->pml[a];
-          for (int q = 0; q < 2; ++q)
-            if (P.psi_h[q] && !P.psi_h2[q] && dev_alloc(h, &P.psi_h2[q], P.psi_h_count)) return -1;
-        }
+      // pml_in = axes whose recursions run inside the sweep (default: all that have layers; FDTD_OPT_PML_FUSED
+      // = 0 keeps the slab kernels, any other mask selects axes).  Inside the sweep the field values a slab
+      // kernel would re-read and re-write stay in registers: only psi moves (32 B per cell and axis membership).
+      int pml_in = 0;
+      if (any_pml(h) && 64 * (h->rows_f + 1) <= 512)
+        pml_in = (h->pml_fused < 0 ? 7 : h->pml_fused) & pml_in_sweep_mask(h);
       launch_damp(h, false, 0, nz, st);
       launch_sources(h, false, n, 0, nz, st);
       launch_pml(h, false, 0, nz, st, 7 & ~pml_in);
       advance_tfsf_aux(h, false, n, st);
       if (h->cfg.bc[4] == FDTD_BC_PERIODIC) fill_ghost_h(h, st);   // ghost(-1) must carry the pre-corrections too
-      if (pml_in == 6) {
-        // y / z recursions inside the sweep, but only in the tiles that meet a slab: the instantiation
-        // that carries them needs ~250 VGPRs (2 waves per SIMD), the plain one 150 (3 waves).
-        //   (1) planes of the z slabs (+1 plane: the next chunk's prologue must not see a slab), all rows
-        //   (2) planes in between: bottom and top tile rows (those with a row or the halo row in a y slab)
-        //   (3) planes in between, middle tile rows: plain sweep
-        const int R = h->rows_f, nby_all = (h->g.ny + R - 1) / R;
-        const PmlAxisDev &py = h->pml[1], &pz = h->pml[2];
-        const int za = pz.n_lo > 0 ? std::min(nz, pz.n_lo + 1) : 0;
-        const int zc = pz.n_hi > 0 ? std::max(za, nz - pz.n_hi) : nz;
-        const int ty_a = py.n_lo > 0 ? std::min(nby_all, py.n_lo / R + 1) : 0;
-        const int ty_c = py.n_hi > 0 ? std::max(ty_a, (h->g.ny - py.n_hi) / R) : nby_all;
-        // (1) and (2) are small launches (less than one wave of workgroups each): they go to the second
-        // stream and run concurrently with (3) — the three touch disjoint tiles
-        HIPCHK(h, hipEventRecord(h->ev_h_int, st));
-        HIPCHK(h, hipStreamWaitEvent(cs, h->ev_h_int, 0));
-        if (launch_fused_range(h, 0, za, cs, 6, zc, nz)) return -1;
-        if (launch_fused_range(h, za, zc, cs, 6, 0, 0, ty_a + (nby_all - ty_c), ty_a, ty_c - ty_a)) return -1;
-        HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
-        if (launch_fused_range(h, za, zc, st, 0, 0, 0, ty_c - ty_a, 0, ty_a)) return -1;
-        HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
-        swap_sets(h);
-      } else if (launch_fused(h, st, pml_in)) return -1;
-      for (int a = 0; a < 3; ++a)
-        if ((pml_in >> a) & 1) { std::swap(h->pml[a].psi_h[0], h->pml[a].psi_h2[0]); std::swap(h->pml[a].psi_h[1], h->pml[a].psi_h2[1]); }
+      if (launch_fused(h, st, pml_in)) return -1;
       if (rec) record_monitors(h, n, true, st);
       launch_pml(h, true, 0, nz, st, 7 & ~pml_in);
       launch_sources(h, true, n, 0, nz, st);
@@ -1438,15 +1562,8 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     // ---------------- field decay / divergence ----------------
     if (h->decay_every > 0 && (h->step % h->decay_every) == 0) {
       if (multi) HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
-      HIPCHK(h, hipMemsetAsync(h->energy_dev, 0, sizeof(double), st));
-      const long long nc = n_cells(h);
-      unsigned blocks = nblk(nc);
-      if (blocks > 2048) blocks = 2048;
-      hipLaunchKernelGGL(energy_kernel, dim3(blocks), dim3(256), 0, st, (const float*)h->f.ex, (const float*)h->f.ey,
-                         (const float*)h->f.ez, nc, h->energy_dev);
       double en = 0.0;
-      HIPCHK(h, hipMemcpyAsync(&en, h->energy_dev, sizeof(double), hipMemcpyDeviceToHost, st));
-      HIPCHK(h, hipStreamSynchronize(st));
+      if (eval_energy(h, st, &en)) return -1;
       if (multi) {
         // sum over ranks (1 double every decay_every steps).  Every RCCL call of this communicator
         // is issued on the comm stream, in the same order on all ranks — never from two streams.
@@ -1603,15 +1720,8 @@ int fdtd_run_bloch(FdtdSolver* hr, FdtdSolver* hi, int64_t n_steps, const double
     if (hr->decay_every > 0 && (hr->step % hr->decay_every) == 0) {
       double en = 0.0;
       for (FdtdSolver* h : both) {
-        HIPCHK(hr, hipMemsetAsync(h->energy_dev, 0, sizeof(double), st));
-        const long long nc = n_cells(h);
-        unsigned blocks = nblk(nc);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(energy_kernel, dim3(blocks), dim3(256), 0, st, (const float*)h->f.ex, (const float*)h->f.ey,
-                           (const float*)h->f.ez, nc, h->energy_dev);
         double part = 0.0;
-        HIPCHK(hr, hipMemcpyAsync(&part, h->energy_dev, sizeof(double), hipMemcpyDeviceToHost, st));
-        HIPCHK(hr, hipStreamSynchronize(st));
+        if (eval_energy(h, st, &part)) { hr->err = h->err; return -1; }
         en += part;
       }
       if (!std::isfinite(en)) {
@@ -1653,7 +1763,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_ZCHUNK: if (value < 1) break; h->zchunk = value; h->zchunk_f = value; h->user_geometry = true; return 0;
     case FDTD_OPT_ROWS: if (value < 1 || value > 15) break; h->rows = value > 8 ? 8 : value; h->rows_f = value; h->user_geometry = true; return 0;
     case FDTD_OPT_XCD_REMAP: h->xcd_remap = value != 0; return 0;
-    case FDTD_OPT_PML_FUSED: h->pml_fused = value & 7; return 0;
+    case FDTD_OPT_PML_FUSED: h->pml_fused = value < 0 ? -1 : (value & 7); return 0;
     case FDTD_OPT_BND_PLANES: h->bnd_planes = value > 0 ? value : 0; return 0;
     case FDTD_OPT_AUTOTUNE: h->autotune = value < 0 ? 0 : (value > 2 ? 1 : value); if (value) h->tuned = false; return 0;
     case FDTD_OPT_FUSED_LB: if (value != 0 && value != 256 && value != 512 && value != 1024) break; h->fused_lb = value; return 0;

@@ -39,11 +39,20 @@ struct StepP {
   const float* idx; const float* idy; const float* idz;   // 1 / dual steps
 };
 
+// Material words: one 32-bit word per cell, bits [10c, 10c+10) = medium index of E_c (<= 1023 media:
+// enough for the 0.2 % permittivity steps sub-pixel averaging and CustomMedium quantise to, at the
+// same 4 B/cell as 8-bit indices).  `roww` holds one word per row segment of 256 cells (one wavefront
+// of the sweep): the word all its cells share, or kMixedWord — a scalar load that lets the sweep skip
+// the packed words and the per-cell table look-ups wherever the medium is uniform along the segment.
+constexpr int kMaxMedia = 1024;
+constexpr uint32_t kBgWord = 1u | (1u << 10) | (1u << 20);
+constexpr uint32_t kMixedWord = 0xFFFFFFFFu;
 struct MatP {
-  const uint32_t* m4;             // packed material indices, one word per cell: byte c = index of E_c
-  const float2* lut;                                        // (ca, cb) per medium
+  const uint32_t* m4;             // packed material indices
+  const uint32_t* roww;           // [nz][ny][ceil(nx / 256)] row-segment words
+  const float2* lut;              // (ca, cb) per medium
   int n_media;
-  float ca1, cb1;                                           // uniform medium (entry 1)
+  float ca1, cb1;                 // uniform medium (entry 1)
 };
 
 // ---- small vector helpers -------------------------------------------------------------------
@@ -185,7 +194,7 @@ __global__ __launch_bounds__(512) void h_update_kernel(GridP g, FieldP f, StepP 
 template <int V, bool MAT>
 __global__ __launch_bounds__(512) void e_update_kernel(GridP g, FieldP f, StepP s, MatP m, int kbeg,
                                                         int kend, int zchunk) {
-  __shared__ float2 lut_s[256];
+  __shared__ float2 lut_s[MAT ? kMaxMedia : 1];
   if constexpr (MAT) {
     for (int t = threadIdx.y * blockDim.x + threadIdx.x; t < m.n_media; t += blockDim.x * blockDim.y)
       lut_s[t] = m.lut[t];
@@ -255,9 +264,9 @@ __global__ __launch_bounds__(512) void e_update_kernel(GridP g, FieldP f, StepP 
         ldm<V>(mw, m.m4 + p);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-          const float2 c0 = lut_s[mw[e] & 255u];
-          const float2 c1 = lut_s[(mw[e] >> 8) & 255u];
-          const float2 c2 = lut_s[(mw[e] >> 16) & 255u];
+          const float2 c0 = lut_s[mw[e] & 1023u];
+          const float2 c1 = lut_s[(mw[e] >> 10) & 1023u];
+          const float2 c2 = lut_s[(mw[e] >> 20) & 1023u];
           cax[e] = c0.x; cbx[e] = c0.y; cay[e] = c1.x; cby[e] = c1.y; caz[e] = c2.x; cbz[e] = c2.y;
         }
       } else {
@@ -293,29 +302,34 @@ __global__ __launch_bounds__(512) void e_update_kernel(GridP g, FieldP f, StepP 
 // ---- CPML inside the fused sweep ------------------------------------------------------------
 // Same recursion and the same operation order as the slab kernels pml_h_kernel / pml_e_kernel
 // (K3 below), applied to registers: H-side corrections to H^{n-1/2} before upd_h, E-side ones to
-// E^{n+1} after upd_e, axes in the order x, y, z.  Halo rows / columns / prologue planes recompute
-// the corrected value from psi without storing it, so psi is updated exactly once per cell.
+// E^{n+1} after upd_e.  Halo rows / columns / prologue planes recompute the corrected value from
+// psi without storing it, so psi is updated exactly once per cell.
+//
+// Slab membership is the same on the E and the H side: index ia of axis a is a member when
+// ia < lo or ia >= hi0 (the tables are identity on the few extra cells this adds on the E side),
+// slab index si = ia (low face) or lo + ia - hi0 (high face), psi extent ns = lo + n - hi0.
+// Along x the ranges are rounded to multiples of 4 cells, so the float4 of a lane lies entirely
+// inside or outside a slab and its psi values are ONE 16-byte load per array.
+//
+// The parameter block lives in device memory and is passed by pointer: its fields are fetched by
+// scalar loads where they are used instead of occupying ~90 SGPRs for the whole kernel (the
+// by-value form spilled SGPRs into VGPR lanes and cost an occupancy step).
 struct PmlAxisP {
-  const float* kinv_e; const float* b_e; const float* c_e;
-  const float* kinv_h; const float* b_h; const float* c_h;
-  float* pe0; float* pe1;        // psi of E_{a+1}, E_{a+2}
-  const float* ph0; const float* ph1;   // psi of H_{a+1}, H_{a+2}: READ set  (halo rows, the x-halo
-  float* ph0n; float* ph1n;             // column and chunk prologues of OTHER workgroups re-read the old
-                                        // values, so the H-side psi is ping-ponged like the fields) / WRITE set
-  int n_lo, n_hi, ns_e, ns_h, n;
+  const float4* ce4;      // [n] {1/kappa_e - 1, b_e, c_e, 0}  (y / z: wave-uniform index -> scalar load)
+  const float4* ch4;      // [n] {1/kappa_h - 1, b_h, c_h, 0}
+  const float* kv_e; const float* b_e; const float* c_e;     // the same, one array each (x: float4 loads along the row)
+  const float* kv_h; const float* b_h; const float* c_h;
+  float* pe0; float* pe1;               // psi of E_{a+1}, E_{a+2}
+  const float* ph0; const float* ph1;   // psi of H_{a+1}, H_{a+2}: READ set  (halo rows, the x-halo column and
+  float* ph0n; float* ph1n;             // chunk prologues of OTHER workgroups re-read the old values, so the
+                                        // H-side psi is ping-ponged like the fields) / WRITE set
+  int lo, hi0, ns, n;
 };
 struct PmlP { PmlAxisP ax[3]; };
 
-__device__ __forceinline__ int pml_si_h(const PmlAxisP& A, int ia) {
-  if (ia < A.n_lo) return ia;
-  const int s0 = A.n - A.n_hi;
-  if (A.n_hi > 0 && ia >= s0) return A.n_lo + (ia - s0);
-  return -1;
-}
-__device__ __forceinline__ int pml_si_e(const PmlAxisP& A, int ia) {
-  if (ia < A.n_lo) return ia;
-  const int s0 = A.n - A.n_hi + 1;
-  if (A.n_hi > 1 && ia >= s0) return A.n_lo + (ia - s0);
+__device__ __forceinline__ int pml_si(const PmlAxisP& A, int ia) {
+  if (ia < A.lo) return ia;
+  if (ia >= A.hi0) return A.lo + (ia - A.hi0);
   return -1;
 }
 __device__ __forceinline__ long long pml_q(const GridP& g, int a, int ns, int i, int j, int k, int si) {
@@ -323,16 +337,16 @@ __device__ __forceinline__ long long pml_q(const GridP& g, int a, int ns, int i,
   if (a == 1) return ((long long)k * ns + si) * g.nx + i;
   return ((long long)si * g.ny + j) * g.nx + i;
 }
-// one cell, one axis:  h1 += ch (kv d2 + p1),  h2 -= ch (kv d1 + p2)
+// one cell, one axis, read-only psi:  h1 += ch (kv d2 + p1),  h2 -= ch (kv d1 + p2)
 __device__ __forceinline__ void pml_h_cell(float& h1, float& h2, float d1, float d2, const PmlAxisP& A,
-                                           long long q, float kv, float b, float c, float ch, bool store) {
-  const float p1 = b * A.ph0[q] + c * d2;
-  const float p2 = b * A.ph1[q] + c * d1;
-  if (store) { A.ph0n[q] = p1; A.ph1n[q] = p2; }
-  h1 += ch * (kv * d2 + p1);
-  h2 -= ch * (kv * d1 + p2);
+                                           long long q, int ia, float ch) {
+  const float4 cf = A.ch4[ia];
+  const float p1 = cf.y * A.ph0[q] + cf.z * d2;
+  const float p2 = cf.y * A.ph1[q] + cf.z * d1;
+  h1 += ch * (cf.x * d2 + p1);
+  h2 -= ch * (cf.x * d1 + p2);
 }
-// same recursion on psi values already in registers (s1, s2 are replaced by their new values)
+// the recursion on psi values in registers (s1, s2 are replaced by their new values)
 __device__ __forceinline__ void pml_h_apply(float& h1, float& h2, float d1, float d2, float& s1, float& s2,
                                             float kv, float b, float c, float ch) {
   const float p1 = b * s1 + c * d2;
@@ -341,23 +355,14 @@ __device__ __forceinline__ void pml_h_apply(float& h1, float& h2, float d1, floa
   h1 += ch * (kv * d2 + p1);
   h2 -= ch * (kv * d1 + p2);
 }
-// four consecutive x cells of a row, axis y or z (uniform membership)
-__device__ __forceinline__ void pml_h_vec(float (&h1)[4], float (&h2)[4], const float (&d1)[4], const float (&d2)[4],
-                                          const PmlAxisP& A, long long q, float kv, float b, float c,
-                                          float ch, bool store) {
-  float q1[4], q2[4];
-  ldv<4>(q1, A.ph0 + q);
-  ldv<4>(q2, A.ph1 + q);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float p1 = b * q1[e] + c * d2[e];
-    const float p2 = b * q2[e] + c * d1[e];
-    q1[e] = p1; q2[e] = p2;
-    h1[e] += ch * (kv * d2[e] + p1);
-    h2[e] -= ch * (kv * d1[e] + p2);
-  }
-  if (store) { stv<4>(A.ph0n + q, q1); stv<4>(A.ph1n + q, q2); }
-}
+
+// The sweep is compiled for 3 waves per SIMD (<= 168 VGPRs): the measured optimum of the plain
+// sweep, and the budget the CPML-carrying instantiations are written to stay inside.
+#if defined(__HIPCC__)
+#define FDTD_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
+#else
+#define FDTD_WAVES_PER_EU(lo, hi)
+#endif
 
 // =============================================================================================
 // K1+K2 fused: one sweep advances H by curl E AND E by curl of the *new* H, reading set `a`
@@ -367,17 +372,20 @@ __device__ __forceinline__ void pml_h_vec(float (&h1)[4], float (&h2)[4], const 
 // corrections are pre-applied to H^{n-1/2} in `a`, E-side ones post-applied to E^{n+1} in `b`.
 //
 // Workgroup = (64 lanes x 4 cells) x (R rows + 1 halo row below); marches `zchunk` planes.
-//   * H^{n+1/2}[k] is computed in registers by every wave (the halo wave recomputes row j0-1);
+//   * H^{n+1/2}[k] is computed in registers by every wave (the halo wave recomputes H_x, H_z of
+//     row j0-1);
 //   * E^{n+1}[k] needs H^{n+1/2} at x-1 (lane-1 via __shfl_up; the lane at the tile edge
 //     recomputes the x-halo column itself), at y-1 (previous wave via a double-buffered LDS
 //     slot, one barrier per plane) and at z-1 (registers carried from the previous plane; the
 //     first plane of a chunk recomputes H^{n+1/2}[k0-1] in a prologue).
+// Everything that depends on the row only (threadIdx.y is wave-uniform) is kept in SGPRs.
 // =============================================================================================
 template <bool MAT, int LB, int PML>   // PML: bit a set = CPML of axis a runs inside the sweep
-__global__ __launch_bounds__(LB) void fused_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
+__global__ __launch_bounds__(LB, (LB == 256 ? 3 : (LB == 512 ? 2 : 4))) void fused_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
                                                           int kbeg, int kend, int zchunk, int pmc_z0,
-                                                          int nbx, int nby, int nbz, int xcd_remap, PmlP pm,
-                                                          int nbz1, int k2beg, int k2end, int ty_a, int ty_gap) {
+                                                          int nbx, int nby, int nbz, int xcd_remap,
+                                                          const PmlP* __restrict__ pmq,
+                                                          int nbz1, int k2beg, int k2end) {
   constexpr int V = 4;
   // 1-D launch; logical tile (bx, by, bz) with by fastest.  XCD-aware remap: hardware block L runs
   // on XCD L % 8 (observed dispatch order, used for speed only), so XCD x is handed the contiguous
@@ -390,28 +398,26 @@ __global__ __launch_bounds__(LB) void fused_step_kernel(GridP g, FieldP a, Field
     t = (t & 7) * per + (t >> 3);
     if (t >= total) return;              // whole workgroup leaves before any barrier
   }
-  // tile rows of this launch: the first ty_a, then (after a gap of ty_gap) the rest — the launch
-  // that folds the y-CPML in covers the bottom and top tile rows only, a plain launch the middle
-  int tile_y = t % nby;
-  if (tile_y >= ty_a) tile_y += ty_gap;
+  const int tile_y = t % nby;
   const int tile_x = (t / nby) % nbx;
   const int tile_z = t / (nby * nbx);
-  __shared__ float2 lut_s[256];
+  __shared__ float2 lut_s[MAT ? kMaxMedia : 1];
   HIP_DYNAMIC_SHARED(float4, xch)      // [2 buffers][2 comps][blockDim.y][64]
   if constexpr (MAT) {
-    for (int t = threadIdx.y * blockDim.x + threadIdx.x; t < m.n_media; t += blockDim.x * blockDim.y)
-      lut_s[t] = m.lut[t];
+    for (int q = threadIdx.y * blockDim.x + threadIdx.x; q < m.n_media; q += blockDim.x * blockDim.y)
+      lut_s[q] = m.lut[q];
     __syncthreads();
   }
-  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int tx = threadIdx.x;
+  const int ty = __builtin_amdgcn_readfirstlane((int)threadIdx.y);     // one row per wave
   const int R = blockDim.y - 1;
-  const PmlP& pmp = pm;
   const int i0 = (tile_x * 64 + tx) * V;
   const bool halo = (ty == 0);
   const bool per_x = g.bcx0 == BC_PERIODIC, per_y = g.bcy0 == BC_PERIODIC;
   int j = tile_y * R + ty - 1;
   bool row_ok = (j >= 0) && (j < g.ny);
   if (j < 0 && per_y) { j = g.ny - 1; row_ok = true; }
+  if (!row_ok) j = 0;                    // keeps every address of an idle wave inside the arrays
   const bool act = row_ok && (i0 < g.nx);
   // z tiles [0, nbz1) march through [kbeg, kend), tiles [nbz1, nbz) through a second plane range
   // [k2beg, k2end): the bottom and top boundary chunks of a z-slab go out as ONE launch
@@ -422,13 +428,11 @@ __global__ __launch_bounds__(LB) void fused_step_kernel(GridP g, FieldP a, Field
   const bool last_x = (i0 + V >= g.nx);
   const bool first_x = (i0 == 0);
   const bool use_jp = (j + 1 < g.ny) || (g.bcy1 == BC_PERIODIC);
-  const long long row = (long long)j * g.nx + i0;
-  const long long rowp = (j + 1 < g.ny) ? row + g.nx : (long long)i0;
+  const long long rowb = (long long)j * g.nx;                               // scalar row bases
+  const long long rowpb = (j + 1 < g.ny) ? rowb + g.nx : 0;
   // x-halo column handled by the first lane of the tile (or the wrapped column for periodic x)
   const bool xh = act && (tx == 0) && (!first_x || per_x);
   const int im = first_x ? g.nx - 1 : i0 - 1;
-  const long long rowm_x = (long long)j * g.nx + im;
-  const long long rowpm_x = (j + 1 < g.ny) ? rowm_x + g.nx : (long long)im;
   const bool wall_y = (j == 0) && (g.bcy0 == BC_PEC);
   const bool wall_x0 = first_x && (g.bcx0 == BC_PEC);
 
@@ -438,83 +442,99 @@ __global__ __launch_bounds__(LB) void fused_step_kernel(GridP g, FieldP a, Field
   if (act) {
     ldv<V>(ipx, s.ipx + i0);
     ldv<V>(idx, s.idx + i0);
-    ipy = s.ipy[j];
-    idy = s.idy[j];
     ipx_m = s.ipx[im];
   }
+  if (row_ok) { ipy = s.ipy[j]; idy = s.idy[j]; }
+  // CPML membership that does not change along the march (x: per lane, y: per row)
+  [[maybe_unused]] int sx = -1, sx_m = -1, sy = -1;
+  if constexpr ((PML & 1) != 0) {
+    if (act) sx = pml_si(pmq->ax[0], i0);
+    if (xh) sx_m = pml_si(pmq->ax[0], im);
+  }
+  if constexpr ((PML & 2) != 0) { if (row_ok) sy = pml_si(pmq->ax[1], j); }
+
   float exk[V], eyk[V], hxm[V], hym[V];
   zero<V>(exk); zero<V>(eyk); zero<V>(hxm); zero<V>(hym);
   float exk_m = 0.f;
-  if (act) {
-    ldv<V>(exk, a.ex + (long long)k0 * g.sxy + row);
-    ldv<V>(eyk, a.ey + (long long)k0 * g.sxy + row);
-  }
-  if (xh) exk_m = a.ex[(long long)k0 * g.sxy + rowm_x];
-  // ---- prologue: H^{n+1/2}[k0-1] (x, y components) of the own cells --------------------------
   {
+    const long long p0 = (long long)k0 * g.sxy + rowb;
+    if (act) {
+      ldv<V>(exk, a.ex + p0 + i0);
+      ldv<V>(eyk, a.ey + p0 + i0);
+    }
+    if (xh) exk_m = a.ex[p0 + im];
+  }
+  // ---- prologue: H^{n+1/2}[k0-1] (x, y components) of the own cells --------------------------
+  if (!halo) {
     const bool skip = (pmc_z0 && k0 == 0);
-    const long long p = (long long)(k0 - 1) * g.sxy + row;
-    float ezm[V], ezj[V], exm[V], eym[V], ho[V];
+    const long long pb = (long long)(k0 - 1) * g.sxy + rowb;
+    float ezm[V], ezj[V], exm[V], eym[V], ho[V], hoy[V];
     zero<V>(ezm); zero<V>(ezj); zero<V>(exm); zero<V>(eym);
     if (act && !skip) {
-      ldv<V>(ezm, a.ez + p);
-      ldv<V>(exm, a.ex + p);
-      ldv<V>(eym, a.ey + p);
-      if (use_jp) ldv<V>(ezj, a.ez + (long long)(k0 - 1) * g.sxy + rowp);
+      ldv<V>(ezm, a.ez + pb + i0);
+      ldv<V>(exm, a.ex + pb + i0);
+      ldv<V>(eym, a.ey + pb + i0);
+      if (use_jp) ldv<V>(ezj, a.ez + (long long)(k0 - 1) * g.sxy + rowpb + i0);
     }
     float ezx = __shfl_down(ezm[0], 1);
     if (act && !skip) {
       if (tx == 63 || last_x) {
-        if (!last_x) ezx = a.ez[p + V];
-        else if (g.bcx1 == BC_PERIODIC) ezx = a.ez[p - i0];
+        if (!last_x) ezx = a.ez[pb + i0 + V];
+        else if (g.bcx1 == BC_PERIODIC) ezx = a.ez[pb];
         else ezx = 0.f;
       }
       const float ipz = s.ipz[k0 - 1];
-      float hoy[V];
-      ldv<V>(ho, a.hx + p);
-      ldv<V>(hoy, a.hy + p);
+      ldv<V>(ho, a.hx + pb + i0);
+      ldv<V>(hoy, a.hy + pb + i0);
       if constexpr (PML != 0) {
         // corrected H^{n-1/2}_{x,y} of plane k0-1 (read-only psi; the plane's owner stores it)
         const int kk = (k0 - 1 < 0) ? g.nz - 1 : k0 - 1;          // periodic z: ghost = top plane
         if (k0 > 0 || !g.pec_z0) {
-          float dum[V];
-          // axis x: Hy += ch (kv dEz/dx + p1)        (all psi loads first, then the arithmetic)
+          // axis x: Hy += ch (kv dEz/dx + p1)
           if constexpr ((PML & 1) != 0) {
-            int si[V]; float s1[V];
+            if (sx >= 0) {
+              const PmlAxisP& A = pmq->ax[0];
+              float s1[V], kv[V], bb[V], cc[V];
+              ldv<V>(s1, A.ph0 + pml_q(g, 0, A.ns, 0, j, kk, sx));
+              ldv<V>(kv, A.kv_h + i0); ldv<V>(bb, A.b_h + i0); ldv<V>(cc, A.c_h + i0);
 #pragma unroll
-            for (int e = 0; e < V; ++e) {
-              si[e] = pml_si_h(pm.ax[0], i0 + e);
-              s1[e] = (si[e] >= 0) ? pm.ax[0].ph0[pml_q(g, 0, pm.ax[0].ns_h, i0 + e, j, kk, max(si[e], 0))] : 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < V; ++e)
-              if (si[e] >= 0) {
+              for (int e = 0; e < V; ++e) {
                 const float ez_ip = (e + 1 < V) ? ezm[(e + 1) % V] : ezx;
                 const float d2 = (ez_ip - ezm[e]) * ipx[e];
-                float hz_d = 0.f, s2 = 0.f;
-                pml_h_apply(hoy[e], hz_d, 0.f, d2, s1[e], s2, pm.ax[0].kinv_h[i0 + e] - 1.f, pm.ax[0].b_h[i0 + e],
-                            pm.ax[0].c_h[i0 + e], ch);
+                const float p1 = bb[e] * s1[e] + cc[e] * d2;
+                hoy[e] += ch * (kv[e] * d2 + p1);
               }
+            }
           }
           // axis y: Hx -= ch (kv dEz/dy + p2)
           if constexpr ((PML & 2) != 0) {
-            const int si = pml_si_h(pm.ax[1], j);
-            if (si >= 0) {
-              float d1[V], d2[V];
+            if (sy >= 0) {
+              const PmlAxisP& A = pmq->ax[1];
+              const float4 cf = A.ch4[j];
+              float s2[V];
+              ldv<V>(s2, A.ph1 + pml_q(g, 1, A.ns, i0, j, kk, sy));
 #pragma unroll
-              for (int e = 0; e < V; ++e) { d1[e] = (ezj[e] - ezm[e]) * ipy; d2[e] = 0.f; dum[e] = 0.f; }
-              pml_h_vec(dum, ho, d1, d2, pm.ax[1], pml_q(g, 1, pm.ax[1].ns_h, i0, j, kk, si),
-                        pm.ax[1].kinv_h[j] - 1.f, pm.ax[1].b_h[j], pm.ax[1].c_h[j], ch, false);
-            } }
+              for (int e = 0; e < V; ++e) {
+                const float d1 = (ezj[e] - ezm[e]) * ipy;
+                const float p2 = cf.y * s2[e] + cf.z * d1;
+                ho[e] -= ch * (cf.x * d1 + p2);
+              }
+            }
+          }
           // axis z: Hx += ch (kv dEy/dz + p1), Hy -= ch (kv dEx/dz + p2)   (only inside this slab)
-          if ((PML & 4) != 0 && k0 - 1 >= 0) {
-            const int si = pml_si_h(pm.ax[2], k0 - 1);
-            if (si >= 0) {
-              float d1[V], d2[V];
+          if constexpr ((PML & 4) != 0) {
+            const PmlAxisP& A = pmq->ax[2];
+            const int sz = (k0 - 1 >= 0) ? pml_si(A, k0 - 1) : -1;
+            if (sz >= 0) {
+              const float4 cf = A.ch4[k0 - 1];
+              float s1[V], s2[V];
+              const long long q = pml_q(g, 2, A.ns, i0, j, k0 - 1, sz);
+              ldv<V>(s1, A.ph0 + q);
+              ldv<V>(s2, A.ph1 + q);
 #pragma unroll
-              for (int e = 0; e < V; ++e) { d1[e] = (exk[e] - exm[e]) * ipz; d2[e] = (eyk[e] - eym[e]) * ipz; }
-              pml_h_vec(ho, hoy, d1, d2, pm.ax[2], pml_q(g, 2, pm.ax[2].ns_h, i0, j, k0 - 1, si),
-                        pm.ax[2].kinv_h[k0 - 1] - 1.f, pm.ax[2].b_h[k0 - 1], pm.ax[2].c_h[k0 - 1], ch, false);
+              for (int e = 0; e < V; ++e)
+                pml_h_apply(ho[e], hoy[e], (exk[e] - exm[e]) * ipz, (eyk[e] - eym[e]) * ipz, s1[e], s2[e],
+                            cf.x, cf.y, cf.z, ch);
             }
           }
         }
@@ -527,137 +547,89 @@ __global__ __launch_bounds__(LB) void fused_step_kernel(GridP g, FieldP a, Field
         hym[e] = upd_h(hoy[e], ch, exk[e] - exm[e], ipz, ez_ip - ezm[e], ipx[e]);
       }
     }
-  }
-  // CPML membership that does not change along the march (x: per cell, y: per row)
-  [[maybe_unused]] int sxh[V] = {-1, -1, -1, -1}, sxe[V] = {-1, -1, -1, -1};
-  [[maybe_unused]] bool xin_h = false, xin_e = false;
-  [[maybe_unused]] int syh = -1, sye = -1;
-  [[maybe_unused]] float hyc[3] = {0.f, 0.f, 0.f}, eyc[3] = {0.f, 0.f, 0.f};
-  if constexpr (PML != 0) {
-    if (act) {
-      if constexpr ((PML & 1) != 0) {
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-          sxh[e] = pml_si_h(pm.ax[0], i0 + e);
-          sxe[e] = pml_si_e(pm.ax[0], i0 + e);
-          if (i0 + e == 0 && g.bcx0 == BC_PEC) sxe[e] = -1;       // E on the PEC wall stays clamped
-          xin_h = xin_h || sxh[e] >= 0;
-          xin_e = xin_e || sxe[e] >= 0;
-        }
-      }
-      if constexpr ((PML & 2) != 0) {
-        syh = pml_si_h(pm.ax[1], j);
-        sye = pml_si_e(pm.ax[1], j);
-        if (j == 0 && g.bcy0 == BC_PEC) sye = -1;
-        if (syh >= 0) { hyc[0] = pm.ax[1].kinv_h[j] - 1.f; hyc[1] = pm.ax[1].b_h[j]; hyc[2] = pm.ax[1].c_h[j]; }
-        if (sye >= 0) { eyc[0] = pm.ax[1].kinv_e[j] - 1.f; eyc[1] = pm.ax[1].b_e[j]; eyc[2] = pm.ax[1].c_e[j]; }
-      }
-    }
-  }
+  }                                      // (the halo wave needs no H^{n+1/2}[k0-1])
   int cur = 0;
   const int slot = (int)blockDim.y * 64;           // float4 entries per component per buffer
   for (int k = k0; k < k1; ++k) {
-    const long long p = (long long)k * g.sxy + row;
-    const long long pj = (long long)k * g.sxy + rowp;
+    const long long pb = (long long)k * g.sxy + rowb;      // scalar
+    const long long pjb = (long long)k * g.sxy + rowpb;
     float exn[V], eyn[V], ezk[V], exj[V], ezj[V], hxn[V], hyn[V], hzn[V];
     zero<V>(exn); zero<V>(eyn); zero<V>(ezk); zero<V>(exj); zero<V>(ezj);
     zero<V>(hxn); zero<V>(hyn); zero<V>(hzn);
-    float ipz = 0.f, idz = 0.f;
+    const float ipz = s.ipz[k], idz = s.idz[k];
     if (act) {
-      ipz = s.ipz[k];
-      idz = s.idz[k];
-      ldv<V>(exn, a.ex + p + g.sxy);
-      ldv<V>(eyn, a.ey + p + g.sxy);
-      ldv<V>(ezk, a.ez + p);
+      ldv<V>(exn, a.ex + pb + g.sxy + i0);
+      ldv<V>(eyn, a.ey + pb + g.sxy + i0);
+      ldv<V>(ezk, a.ez + pb + i0);
       if (use_jp) {
-        ldv<V>(exj, a.ex + pj);
-        ldv<V>(ezj, a.ez + pj);
+        ldv<V>(exj, a.ex + pjb + i0);
+        ldv<V>(ezj, a.ez + pjb + i0);
       }
-      ldv<V>(hxn, a.hx + p);
-      ldv<V>(hyn, a.hy + p);
-      ldv<V>(hzn, a.hz + p);
-    }
-    // H-side CPML state of this plane: issued with the field loads so that the latencies overlap
-    [[maybe_unused]] float hx1[V], hx2[V], hxk[V], hxb[V], hxc[V], hy1[V], hy2[V], hz1[V], hz2[V], hzc[3];
-    [[maybe_unused]] long long qxh = 0, qyh = 0, qzh = 0;
-    [[maybe_unused]] int szh = -1;
-    if constexpr (PML != 0) {
-      if (act) {
-        if constexpr ((PML & 1) != 0) {
-          if (xin_h) {
-            qxh = ((long long)k * g.ny + j) * pm.ax[0].ns_h;
-#pragma unroll
-            for (int e = 0; e < V; ++e)
-              if (sxh[e] >= 0) { hx1[e] = pm.ax[0].ph0[qxh + sxh[e]]; hx2[e] = pm.ax[0].ph1[qxh + sxh[e]]; }
-            ldv<V>(hxk, pm.ax[0].kinv_h + i0);
-            ldv<V>(hxb, pm.ax[0].b_h + i0);
-            ldv<V>(hxc, pm.ax[0].c_h + i0);
-          }
-        }
-        if constexpr ((PML & 2) != 0) {
-          if (syh >= 0) {
-            qyh = ((long long)k * pm.ax[1].ns_h + syh) * g.nx + i0;
-            ldv<V>(hy1, pm.ax[1].ph0 + qyh);
-            ldv<V>(hy2, pm.ax[1].ph1 + qyh);
-          }
-        }
-        if constexpr ((PML & 4) != 0) {
-          szh = pml_si_h(pm.ax[2], k);
-          if (szh >= 0) {
-            qzh = ((long long)szh * g.ny + j) * g.nx + i0;
-            ldv<V>(hz1, pm.ax[2].ph0 + qzh);
-            ldv<V>(hz2, pm.ax[2].ph1 + qzh);
-            hzc[0] = pm.ax[2].kinv_h[k] - 1.f; hzc[1] = pm.ax[2].b_h[k]; hzc[2] = pm.ax[2].c_h[k];
-          }
-        }
-      }
+      ldv<V>(hxn, a.hx + pb + i0);
+      if (!halo) ldv<V>(hyn, a.hy + pb + i0);    // the halo wave only publishes H_x and H_z
+      ldv<V>(hzn, a.hz + pb + i0);
     }
     float eyx = __shfl_down(eyk[0], 1);
     float ezx = __shfl_down(ezk[0], 1);
     if (act && (tx == 63 || last_x)) {
-      if (!last_x) { eyx = a.ey[p + V]; ezx = a.ez[p + V]; }
-      else if (g.bcx1 == BC_PERIODIC) { eyx = a.ey[p - i0]; ezx = a.ez[p - i0]; }
+      if (!last_x) { eyx = a.ey[pb + i0 + V]; ezx = a.ez[pb + i0 + V]; }
+      else if (g.bcx1 == BC_PERIODIC) { eyx = a.ey[pb]; ezx = a.ez[pb]; }
       else { eyx = 0.f; ezx = 0.f; }
     }
+    // ---- H-side CPML: pre-corrections of H^{n-1/2}, axes in the order x, y, z ----------------
+    [[maybe_unused]] int sz = -1;
     if constexpr (PML != 0) {
       if (act) {
-        const bool st_ok = !halo;            // the halo wave recomputes, the row's owner stores psi
         // axis x: Hy += ch (kv dEz/dx + p1), Hz -= ch (kv dEy/dx + p2)
         if constexpr ((PML & 1) != 0) {
-          if (xin_h) {
+          if (sx >= 0) {
+            const PmlAxisP& A = pmq->ax[0];
+            const long long q = pml_q(g, 0, A.ns, 0, j, k, sx);
+            float s1[V], s2[V], kv[V], bb[V], cc[V];
+            ldv<V>(s1, A.ph0 + q);
+            ldv<V>(s2, A.ph1 + q);
+            ldv<V>(kv, A.kv_h + i0); ldv<V>(bb, A.b_h + i0); ldv<V>(cc, A.c_h + i0);
 #pragma unroll
-            for (int e = 0; e < V; ++e)
-              if (sxh[e] >= 0) {
-                const float ey_ip = (e + 1 < V) ? eyk[(e + 1) % V] : eyx;
-                const float ez_ip = (e + 1 < V) ? ezk[(e + 1) % V] : ezx;
-                pml_h_apply(hyn[e], hzn[e], (ey_ip - eyk[e]) * ipx[e], (ez_ip - ezk[e]) * ipx[e], hx1[e], hx2[e],
-                            hxk[e] - 1.f, hxb[e], hxc[e], ch);
-              }
-            if (st_ok) {
-#pragma unroll
-              for (int e = 0; e < V; ++e)
-                if (sxh[e] >= 0) { pm.ax[0].ph0n[qxh + sxh[e]] = hx1[e]; pm.ax[0].ph1n[qxh + sxh[e]] = hx2[e]; }
+            for (int e = 0; e < V; ++e) {
+              const float ey_ip = (e + 1 < V) ? eyk[(e + 1) % V] : eyx;
+              const float ez_ip = (e + 1 < V) ? ezk[(e + 1) % V] : ezx;
+              pml_h_apply(hyn[e], hzn[e], (ey_ip - eyk[e]) * ipx[e], (ez_ip - ezk[e]) * ipx[e], s1[e], s2[e],
+                          kv[e], bb[e], cc[e], ch);
             }
+            if (!halo) { stv<V>(A.ph0n + q, s1); stv<V>(A.ph1n + q, s2); }
           }
         }
         // axis y: Hz += ch (kv dEx/dy + p1), Hx -= ch (kv dEz/dy + p2)
         if constexpr ((PML & 2) != 0) {
-          if (syh >= 0) {
+          if (sy >= 0) {
+            const PmlAxisP& A = pmq->ax[1];
+            const float4 cf = A.ch4[j];
+            const long long q = pml_q(g, 1, A.ns, i0, j, k, sy);
+            float s1[V], s2[V];
+            ldv<V>(s1, A.ph0 + q);
+            ldv<V>(s2, A.ph1 + q);
 #pragma unroll
             for (int e = 0; e < V; ++e)
-              pml_h_apply(hzn[e], hxn[e], (ezj[e] - ezk[e]) * ipy, (exj[e] - exk[e]) * ipy, hy1[e], hy2[e],
-                          hyc[0], hyc[1], hyc[2], ch);
-            if (st_ok) { stv<V>(pm.ax[1].ph0n + qyh, hy1); stv<V>(pm.ax[1].ph1n + qyh, hy2); }
+              pml_h_apply(hzn[e], hxn[e], (ezj[e] - ezk[e]) * ipy, (exj[e] - exk[e]) * ipy, s1[e], s2[e],
+                          cf.x, cf.y, cf.z, ch);
+            if (!halo) { stv<V>(A.ph0n + q, s1); stv<V>(A.ph1n + q, s2); }
           }
         }
         // axis z: Hx += ch (kv dEy/dz + p1), Hy -= ch (kv dEx/dz + p2)
         if constexpr ((PML & 4) != 0) {
-          if (szh >= 0) {
+          const PmlAxisP& A = pmq->ax[2];
+          sz = pml_si(A, k);
+          if (sz >= 0) {
+            const float4 cf = A.ch4[k];
+            const long long q = pml_q(g, 2, A.ns, i0, j, k, sz);
+            float s1[V], s2[V];
+            ldv<V>(s1, A.ph0 + q);
+            ldv<V>(s2, A.ph1 + q);
 #pragma unroll
             for (int e = 0; e < V; ++e)
-              pml_h_apply(hxn[e], hyn[e], (exn[e] - exk[e]) * ipz, (eyn[e] - eyk[e]) * ipz, hz1[e], hz2[e],
-                          hzc[0], hzc[1], hzc[2], ch);
-            if (st_ok) { stv<V>(pm.ax[2].ph0n + qzh, hz1); stv<V>(pm.ax[2].ph1n + qzh, hz2); }
+              pml_h_apply(hxn[e], hyn[e], (exn[e] - exk[e]) * ipz, (eyn[e] - eyk[e]) * ipz, s1[e], s2[e],
+                          cf.x, cf.y, cf.z, ch);
+            if (!halo) { stv<V>(A.ph0n + q, s1); stv<V>(A.ph1n + q, s2); }
           }
         }
       }
@@ -668,85 +640,43 @@ __global__ __launch_bounds__(LB) void fused_step_kernel(GridP g, FieldP a, Field
         const float ey_ip = (e + 1 < V) ? eyk[(e + 1) % V] : eyx;
         const float ez_ip = (e + 1 < V) ? ezk[(e + 1) % V] : ezx;
         hxn[e] = upd_h(hxn[e], ch, ezj[e] - ezk[e], ipy, eyn[e] - eyk[e], ipz);
-        hyn[e] = upd_h(hyn[e], ch, exn[e] - exk[e], ipz, ez_ip - ezk[e], ipx[e]);
+        if (!halo) hyn[e] = upd_h(hyn[e], ch, exn[e] - exk[e], ipz, ez_ip - ezk[e], ipx[e]);
         hzn[e] = upd_h(hzn[e], ch, ey_ip - eyk[e], ipx[e], exj[e] - exk[e], ipy);
-      }
-    }
-    // E-side CPML state: in flight across the LDS exchange and the barrier
-    [[maybe_unused]] float ex1[V], ex2[V], exk_[V], exb[V], exc[V], ey1[V], ey2[V], ez1[V], ez2[V], ezc[3];
-    [[maybe_unused]] long long qxe = 0, qye = 0, qze = 0;
-    [[maybe_unused]] int sze = -1;
-    if constexpr (PML != 0) {
-      if (act && !halo) {
-        if constexpr ((PML & 1) != 0) {
-          if (xin_e) {
-            qxe = ((long long)k * g.ny + j) * pmp.ax[0].ns_e;
-#pragma unroll
-            for (int e = 0; e < V; ++e)
-              if (sxe[e] >= 0) { ex1[e] = pmp.ax[0].pe0[qxe + sxe[e]]; ex2[e] = pmp.ax[0].pe1[qxe + sxe[e]]; }
-            ldv<V>(exk_, pmp.ax[0].kinv_e + i0);
-            ldv<V>(exb, pmp.ax[0].b_e + i0);
-            ldv<V>(exc, pmp.ax[0].c_e + i0);
-          }
-        }
-        if constexpr ((PML & 2) != 0) {
-          if (sye >= 0) {
-            qye = ((long long)k * pmp.ax[1].ns_e + sye) * g.nx + i0;
-            ldv<V>(ey1, pmp.ax[1].pe0 + qye);
-            ldv<V>(ey2, pmp.ax[1].pe1 + qye);
-          }
-        }
-        if constexpr ((PML & 4) != 0) {
-          sze = pml_si_e(pmp.ax[2], k);
-          if (k == 0 && g.pec_z0) sze = -1;
-          if (sze >= 0) {
-            qze = ((long long)sze * g.ny + j) * g.nx + i0;
-            ldv<V>(ez1, pmp.ax[2].pe0 + qze);
-            ldv<V>(ez2, pmp.ax[2].pe1 + qze);
-            ezc[0] = pmp.ax[2].kinv_e[k] - 1.f; ezc[1] = pmp.ax[2].b_e[k]; ezc[2] = pmp.ax[2].c_e[k];
-          }
-        }
       }
     }
     // x-halo column: H^{n+1/2}_{y,z} at i0-1 recomputed by the tile's first lane
     float hy_m = 0.f, hz_m = 0.f, exn_m = 0.f;
-    if (xh) {
-      const long long pm = (long long)k * g.sxy + rowm_x;
+    if (xh && !halo) {
+      const long long pm = pb + im;
       exn_m = a.ex[pm + g.sxy];
       const float ez_mm = a.ez[pm], ey_mm = a.ey[pm];
-      const float ex_jm = use_jp ? a.ex[(long long)k * g.sxy + rowpm_x] : 0.f;
+      const float ex_jm = use_jp ? a.ex[pjb + im] : 0.f;
       float hy_o = a.hy[pm], hz_o = a.hz[pm];
       if constexpr (PML != 0) {
         float dum = 0.f;
-        if constexpr ((PML & 1) != 0) {
-          const int si = pml_si_h(pmp.ax[0], im);      // axis x: Hy += .., Hz -= ..
-          if (si >= 0)
-            pml_h_cell(hy_o, hz_o, (eyk[0] - ey_mm) * ipx_m, (ezk[0] - ez_mm) * ipx_m, pmp.ax[0],
-                       pml_q(g, 0, pmp.ax[0].ns_h, im, j, k, si), pmp.ax[0].kinv_h[im] - 1.f, pmp.ax[0].b_h[im],
-                       pmp.ax[0].c_h[im], ch, false); }
-        if constexpr ((PML & 2) != 0) {
-          const int si = pml_si_h(pmp.ax[1], j);       // axis y: Hz += ch (kv dEx/dy + p1)
-          if (si >= 0)
-            pml_h_cell(hz_o, dum, 0.f, (ex_jm - exk_m) * ipy, pmp.ax[1],
-                       pml_q(g, 1, pmp.ax[1].ns_h, im, j, k, si), pmp.ax[1].kinv_h[j] - 1.f, pmp.ax[1].b_h[j],
-                       pmp.ax[1].c_h[j], ch, false); }
-        if constexpr ((PML & 4) != 0) {
-          const int si = pml_si_h(pmp.ax[2], k);       // axis z: Hy -= ch (kv dEx/dz + p2)
-          if (si >= 0)
-            pml_h_cell(dum, hy_o, (exn_m - exk_m) * ipz, 0.f, pmp.ax[2],
-                       pml_q(g, 2, pmp.ax[2].ns_h, im, j, k, si), pmp.ax[2].kinv_h[k] - 1.f, pmp.ax[2].b_h[k],
-                       pmp.ax[2].c_h[k], ch, false); }
+        if constexpr ((PML & 1) != 0) {                 // axis x: Hy += .., Hz -= ..
+          if (sx_m >= 0)
+            pml_h_cell(hy_o, hz_o, (eyk[0] - ey_mm) * ipx_m, (ezk[0] - ez_mm) * ipx_m, pmq->ax[0],
+                       pml_q(g, 0, pmq->ax[0].ns, im, j, k, sx_m), im, ch); }
+        if constexpr ((PML & 2) != 0) {                 // axis y: Hz += ch (kv dEx/dy + p1)
+          if (sy >= 0)
+            pml_h_cell(hz_o, dum, 0.f, (ex_jm - exk_m) * ipy, pmq->ax[1],
+                       pml_q(g, 1, pmq->ax[1].ns, im, j, k, sy), j, ch); }
+        if constexpr ((PML & 4) != 0) {                 // axis z: Hy -= ch (kv dEx/dz + p2)
+          if (sz >= 0)
+            pml_h_cell(dum, hy_o, (exn_m - exk_m) * ipz, 0.f, pmq->ax[2],
+                       pml_q(g, 2, pmq->ax[2].ns, im, j, k, sz), k, ch); }
       }
       hy_m = upd_h(hy_o, ch, exn_m - exk_m, ipz, ezk[0] - ez_mm, ipx_m);
       hz_m = upd_h(hz_o, ch, eyk[0] - ey_mm, ipx_m, ex_jm - exk_m, ipy);
     }
     // publish H^{n+1/2}_{x,z} of this row for the row above
     {
-      float4 t;
-      t.x = hxn[0]; t.y = hxn[1]; t.z = hxn[2]; t.w = hxn[3];
-      xch[(cur * 2 + 0) * slot + ty * 64 + tx] = t;
-      t.x = hzn[0]; t.y = hzn[1]; t.z = hzn[2]; t.w = hzn[3];
-      xch[(cur * 2 + 1) * slot + ty * 64 + tx] = t;
+      float4 t4;
+      t4.x = hxn[0]; t4.y = hxn[1]; t4.z = hxn[2]; t4.w = hxn[3];
+      xch[(cur * 2 + 0) * slot + ty * 64 + tx] = t4;
+      t4.x = hzn[0]; t4.y = hzn[1]; t4.z = hzn[2]; t4.w = hzn[3];
+      xch[(cur * 2 + 1) * slot + ty * 64 + tx] = t4;
     }
     __syncthreads();
     float hyx = __shfl_up(hyn[V - 1], 1);
@@ -755,7 +685,10 @@ __global__ __launch_bounds__(LB) void fused_step_kernel(GridP g, FieldP a, Field
 #pragma unroll
       for (int e = 0; e < V; ++e) { hxm[e] = -hxn[e]; hym[e] = -hyn[e]; }
     }
-    if (act && !halo) {
+    // E^{n+1} of the own rows.  `coef(c, e)` yields (Ca, Cb) of component c of the lane's e-th cell: scalars
+    // for a uniform medium, per-cell look-ups in the LDS table otherwise, fetched where they are used so
+    // that no coefficient stays live across the update (the packed words are all that is held).
+    auto e_phase = [&](auto coef) {
       if (tx == 0 || first_x) {
         if (xh) { hyx = hy_m; hzx = hz_m; }
         else if (g.bcx0 == BC_PMC) { hyx = -hyn[0]; hzx = -hzn[0]; }
@@ -773,33 +706,15 @@ __global__ __launch_bounds__(LB) void fused_step_kernel(GridP g, FieldP a, Field
       } else {
         zero<V>(hxj); zero<V>(hzj);
       }
-      float cax[V], cbx[V], cay[V], cby[V], caz[V], cbz[V];
-      if constexpr (MAT) {
-        uint32_t mw[V];
-        ldm<V>(mw, m.m4 + p);
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-          const float2 c0 = lut_s[mw[e] & 255u];
-          const float2 c1 = lut_s[(mw[e] >> 8) & 255u];
-          const float2 c2 = lut_s[(mw[e] >> 16) & 255u];
-          cax[e] = c0.x; cbx[e] = c0.y; cay[e] = c1.x; cby[e] = c1.y; caz[e] = c2.x; cbz[e] = c2.y;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-          cax[e] = cay[e] = caz[e] = m.ca1;
-          cbx[e] = cby[e] = cbz[e] = m.cb1;
-        }
-      }
       const bool wall_z = (k == 0) && g.pec_z0;
       float ex[V], ey[V], ez[V];
 #pragma unroll
       for (int e = 0; e < V; ++e) {
         const float hy_im = (e > 0) ? hyn[(e + V - 1) % V] : hyx;
         const float hz_im = (e > 0) ? hzn[(e + V - 1) % V] : hzx;
-        float nex = upd_e(exk[e], cax[e], cbx[e], hzn[e] - hzj[e], idy, hyn[e] - hym[e], idz);
-        float ney = upd_e(eyk[e], cay[e], cby[e], hxn[e] - hxm[e], idz, hzn[e] - hz_im, idx[e]);
-        float nez = upd_e(ezk[e], caz[e], cbz[e], hyn[e] - hy_im, idx[e], hxn[e] - hxj[e], idy);
+        float nex = upd_e(exk[e], coef(0, e).x, coef(0, e).y, hzn[e] - hzj[e], idy, hyn[e] - hym[e], idz);
+        float ney = upd_e(eyk[e], coef(1, e).x, coef(1, e).y, hxn[e] - hxm[e], idz, hzn[e] - hz_im, idx[e]);
+        float nez = upd_e(ezk[e], coef(2, e).x, coef(2, e).y, hyn[e] - hy_im, idx[e], hxn[e] - hxj[e], idy);
         const bool wx = wall_x0 && (e == 0);
         if (wall_y || wall_z) nex = 0.f;
         if (wx || wall_z) ney = 0.f;
@@ -809,71 +724,109 @@ __global__ __launch_bounds__(LB) void fused_step_kernel(GridP g, FieldP a, Field
       if constexpr (PML != 0) {
         // E-side CPML, axes in the order y, z, x (= launch_pml's E-side order):
         //   E_{a+1} -= cb (kv d2 + p1),  E_{a+2} += cb (kv d1 + p2),  d1 = d_a H_{a+1}, d2 = d_a H_{a+2}
+        // A cell on the min wall of the PML axis itself keeps its psi untouched (both components
+        // are wall-tangential there), exactly like the slab kernels.
         // axis y: E_z -= cb (kv dHx/dy + p1),  E_x += cb (kv dHz/dy + p2)
         if constexpr ((PML & 2) != 0) {
-          if (sye >= 0) {
+          if (sy >= 0 && !wall_y) {
+            const PmlAxisP& A = pmq->ax[1];
+            const float4 cf = A.ce4[j];
+            const long long q = pml_q(g, 1, A.ns, i0, j, k, sy);
+            float s1[V], s2[V];
+            ldv<V>(s1, A.pe0 + q);
+            ldv<V>(s2, A.pe1 + q);
 #pragma unroll
             for (int e = 0; e < V; ++e) {
               const float d1 = (hzn[e] - hzj[e]) * idy;
               const float d2 = (hxn[e] - hxj[e]) * idy;
-              const float p1 = eyc[1] * ey1[e] + eyc[2] * d2;
-              const float p2 = eyc[1] * ey2[e] + eyc[2] * d1;
-              ey1[e] = p1; ey2[e] = p2;
+              const float p1 = cf.y * s1[e] + cf.z * d2;
+              const float p2 = cf.y * s2[e] + cf.z * d1;
+              s1[e] = p1; s2[e] = p2;
               const bool wx = wall_x0 && (e == 0);
-              if (!wx) ez[e] -= cbz[e] * (eyc[0] * d2 + p1);       // E_z is tangential to the x wall
-              if (!wall_z) ex[e] += cbx[e] * (eyc[0] * d1 + p2);   // E_x is tangential to the z wall
+              if (!wx) ez[e] -= coef(2, e).y * (cf.x * d2 + p1);       // E_z is tangential to the x wall
+              if (!wall_z) ex[e] += coef(0, e).y * (cf.x * d1 + p2);   // E_x is tangential to the z wall
             }
-            stv<V>(pmp.ax[1].pe0 + qye, ey1);
-            stv<V>(pmp.ax[1].pe1 + qye, ey2);
+            stv<V>(A.pe0 + q, s1);
+            stv<V>(A.pe1 + q, s2);
           }
         }
         // axis z: E_x -= cb (kv dHy/dz + p1),  E_y += cb (kv dHx/dz + p2)
         if constexpr ((PML & 4) != 0) {
-          if (sze >= 0) {
+          if (sz >= 0 && !wall_z) {
+            const PmlAxisP& A = pmq->ax[2];
+            const float4 cf = A.ce4[k];
+            const long long q = pml_q(g, 2, A.ns, i0, j, k, sz);
+            float s1[V], s2[V];
+            ldv<V>(s1, A.pe0 + q);
+            ldv<V>(s2, A.pe1 + q);
 #pragma unroll
             for (int e = 0; e < V; ++e) {
               const float d1 = (hxn[e] - hxm[e]) * idz;
               const float d2 = (hyn[e] - hym[e]) * idz;
-              const float p1 = ezc[1] * ez1[e] + ezc[2] * d2;
-              const float p2 = ezc[1] * ez2[e] + ezc[2] * d1;
-              ez1[e] = p1; ez2[e] = p2;
+              const float p1 = cf.y * s1[e] + cf.z * d2;
+              const float p2 = cf.y * s2[e] + cf.z * d1;
+              s1[e] = p1; s2[e] = p2;
               const bool wx = wall_x0 && (e == 0);
-              if (!wall_y) ex[e] -= cbx[e] * (ezc[0] * d2 + p1);   // E_x is tangential to the y wall
-              if (!wx) ey[e] += cby[e] * (ezc[0] * d1 + p2);       // E_y is tangential to the x wall
+              if (!wall_y) ex[e] -= coef(0, e).y * (cf.x * d2 + p1);   // E_x is tangential to the y wall
+              if (!wx) ey[e] += coef(1, e).y * (cf.x * d1 + p2);       // E_y is tangential to the x wall
             }
-            stv<V>(pmp.ax[2].pe0 + qze, ez1);
-            stv<V>(pmp.ax[2].pe1 + qze, ez2);
+            stv<V>(A.pe0 + q, s1);
+            stv<V>(A.pe1 + q, s2);
           }
         }
         // axis x: E_y -= cb (kv dHz/dx + p1),  E_z += cb (kv dHy/dx + p2)
         if constexpr ((PML & 1) != 0) {
-          if (xin_e) {
+          if (sx >= 0) {
+            const PmlAxisP& A = pmq->ax[0];
+            const long long q = pml_q(g, 0, A.ns, 0, j, k, sx);
+            float s1[V], s2[V], kv[V], bb[V], cc[V];
+            ldv<V>(s1, A.pe0 + q);
+            ldv<V>(s2, A.pe1 + q);
+            ldv<V>(kv, A.kv_e + i0); ldv<V>(bb, A.b_e + i0); ldv<V>(cc, A.c_e + i0);
 #pragma unroll
-            for (int e = 0; e < V; ++e)
-              if (sxe[e] >= 0) {
+            for (int e = 0; e < V; ++e) {
+              const bool wx = wall_x0 && (e == 0);
+              if (!wx) {
                 const float hy_im = (e > 0) ? hyn[(e + V - 1) % V] : hyx;
                 const float hz_im = (e > 0) ? hzn[(e + V - 1) % V] : hzx;
                 const float d1 = (hyn[e] - hy_im) * idx[e];
                 const float d2 = (hzn[e] - hz_im) * idx[e];
-                const float kv = exk_[e] - 1.f;
-                const float p1 = exb[e] * ex1[e] + exc[e] * d2;
-                const float p2 = exb[e] * ex2[e] + exc[e] * d1;
-                ex1[e] = p1; ex2[e] = p2;
-                if (!wall_z) ey[e] -= cby[e] * (kv * d2 + p1);     // E_y is tangential to the z wall
-                if (!wall_y) ez[e] += cbz[e] * (kv * d1 + p2);     // E_z is tangential to the y wall
+                const float p1 = bb[e] * s1[e] + cc[e] * d2;
+                const float p2 = bb[e] * s2[e] + cc[e] * d1;
+                s1[e] = p1; s2[e] = p2;
+                if (!wall_z) ey[e] -= coef(1, e).y * (kv[e] * d2 + p1);     // E_y is tangential to the z wall
+                if (!wall_y) ez[e] += coef(2, e).y * (kv[e] * d1 + p2);     // E_z is tangential to the y wall
               }
-#pragma unroll
-            for (int e = 0; e < V; ++e)
-              if (sxe[e] >= 0) { pmp.ax[0].pe0[qxe + sxe[e]] = ex1[e]; pmp.ax[0].pe1[qxe + sxe[e]] = ex2[e]; }
+            }
+            stv<V>(A.pe0 + q, s1);
+            stv<V>(A.pe1 + q, s2);
           }
         }
       }
-      stv<V>(b.hx + p, hxn);
-      stv<V>(b.hy + p, hyn);
-      stv<V>(b.hz + p, hzn);
-      stv<V>(b.ex + p, ex);
-      stv<V>(b.ey + p, ey);
-      stv<V>(b.ez + p, ez);
+      stv<V>(b.hx + pb + i0, hxn);
+      stv<V>(b.hy + pb + i0, hyn);
+      stv<V>(b.hz + pb + i0, hzn);
+      stv<V>(b.ex + pb + i0, ex);
+      stv<V>(b.ey + pb + i0, ey);
+      stv<V>(b.ez + pb + i0, ez);
+    };
+    if (act && !halo) {
+      if constexpr (MAT) {
+        // one word per row segment (256 cells of one row): the medium word of all its cells when they
+        // agree — then the packed words are not read at all — or kMixedWord
+        const uint32_t rw = m.roww[((long long)k * g.ny + j) * nbx + tile_x];
+        if (rw != kMixedWord) {
+          const float2 c0 = m.lut[rw & 1023u], c1 = m.lut[(rw >> 10) & 1023u], c2 = m.lut[(rw >> 20) & 1023u];
+          e_phase([&](int c, int) { return c == 0 ? c0 : (c == 1 ? c1 : c2); });
+        } else {
+          uint32_t mw[V];
+          ldm<V>(mw, m.m4 + pb + i0);
+          e_phase([&](int c, int e) { return lut_s[(mw[e] >> (10 * c)) & 1023u]; });
+        }
+      } else {
+        const float2 c1 = make_float2(m.ca1, m.cb1);
+        e_phase([&](int, int) { return c1; });
+      }
     }
 #pragma unroll
     for (int e = 0; e < V; ++e) { hxm[e] = hxn[e]; hym[e] = hyn[e]; exk[e] = exn[e]; eyk[e] = eyn[e]; }
@@ -905,7 +858,7 @@ __device__ __forceinline__ long long psi_index(const GridP& g, const SlabP& sl, 
 // E-side:  E_{a+1} -= Cb * ((kinv-1) d(H_{a+2})/da + psi1),  E_{a+2} += Cb * ((kinv-1) d(H_{a+1})/da + psi2)
 __global__ __launch_bounds__(256) void pml_e_kernel(GridP g, SlabP sl_lo, SlabP sl_hi, float* e1, float* e2, const float* h1,
                                                      const float* h2, float* psi1, float* psi2,
-                                                     const float* kinv, const float* bb, const float* cc,
+                                                     const float4* cf4,
                                                      const float* idl, const uint32_t* m4,
                                                      const float2* lut, float cb_uniform) {
   const SlabP sl = blockIdx.y ? sl_hi : sl_lo;   // both faces of an axis in one launch (disjoint cells)
@@ -940,14 +893,15 @@ __global__ __launch_bounds__(256) void pml_e_kernel(GridP g, SlabP sl_lo, SlabP 
   }
   const int si = sl.psi_base + (ia - sl.s_lo);
   const long long q = psi_index(g, sl, i, j, k, si);
-  const float kv = kinv[ia] - 1.f, b = bb[ia], c = cc[ia];
+  const float4 cf = cf4[ia];
+  const float kv = cf.x, b = cf.y, c = cf.z;
   const float p1 = b * psi1[q] + c * d2;     // psi of E_{a+1} follows d(H_{a+2})/da
   const float p2 = b * psi2[q] + c * d1;     // psi of E_{a+2} follows d(H_{a+1})/da
   psi1[q] = p1;
   psi2[q] = p2;
   const uint32_t mw = m4 ? m4[p] : 0u;
-  const float cb1 = m4 ? lut[(mw >> (8 * c1)) & 255u].y : cb_uniform;
-  const float cb2 = m4 ? lut[(mw >> (8 * c2)) & 255u].y : cb_uniform;
+  const float cb1 = m4 ? lut[(mw >> (10 * c1)) & 1023u].y : cb_uniform;
+  const float cb2 = m4 ? lut[(mw >> (10 * c2)) & 1023u].y : cb_uniform;
   // PEC walls of the other transverse axis
   const bool w1 = (idx3[c2] == 0) && (bc0[c2] == BC_PEC);   // E_{c1} is tangential to the c2-wall
   const bool w2 = (idx3[c1] == 0) && (bc0[c1] == BC_PEC);
@@ -958,7 +912,7 @@ __global__ __launch_bounds__(256) void pml_e_kernel(GridP g, SlabP sl_lo, SlabP 
 // H-side:  H_{a+1} += ch * ((kinv-1) d(E_{a+2})/da + psi1),  H_{a+2} -= ch * ((kinv-1) d(E_{a+1})/da + psi2)
 __global__ __launch_bounds__(256) void pml_h_kernel(GridP g, SlabP sl_lo, SlabP sl_hi, float* h1, float* h2, const float* e1,
                                                      const float* e2, float* psi1, float* psi2,
-                                                     const float* kinv, const float* bb, const float* cc,
+                                                     const float4* cf4,
                                                      const float* ipl) {
   const SlabP sl = blockIdx.y ? sl_hi : sl_lo;   // both faces of an axis in one launch (disjoint cells)
   const int bx = (sl.a == 0) ? sl.s_n : g.nx;
@@ -990,7 +944,8 @@ __global__ __launch_bounds__(256) void pml_h_kernel(GridP g, SlabP sl_lo, SlabP 
   const float d2 = (n2 - e2[p]) * ipl[ia];
   const int si = sl.psi_base + (ia - sl.s_lo);
   const long long q = psi_index(g, sl, i, j, k, si);
-  const float kv = kinv[ia] - 1.f, b = bb[ia], c = cc[ia];
+  const float4 cf = cf4[ia];
+  const float kv = cf.x, b = cf.y, c = cf.z;
   const float p1 = b * psi1[q] + c * d2;
   const float p2 = b * psi2[q] + c * d1;
   psi1[q] = p1;
@@ -1003,7 +958,7 @@ __global__ __launch_bounds__(256) void pml_h_kernel(GridP g, SlabP sl_lo, SlabP 
 // per-element arithmetic as the scalar kernels above.
 __global__ __launch_bounds__(256) void pml_e4_kernel(GridP g, SlabP sl_lo, SlabP sl_hi, float* e1, float* e2, const float* h1,
                                                       const float* h2, float* psi1, float* psi2,
-                                                      const float* kinv, const float* bb, const float* cc,
+                                                      const float4* cf4,
                                                       const float* idl, const uint32_t* m4,
                                                       const float2* lut, float cb_uniform) {
   const SlabP sl = blockIdx.y ? sl_hi : sl_lo;   // both faces of an axis in one launch (disjoint cells)
@@ -1039,7 +994,8 @@ __global__ __launch_bounds__(256) void pml_e4_kernel(GridP g, SlabP sl_lo, SlabP
   }
   const int si = sl.psi_base + (ia - sl.s_lo);
   const long long q = psi_index(g, sl, i0, j, k, si);
-  const float kv = kinv[ia] - 1.f, b = bb[ia], c = cc[ia], w = idl[ia];
+  const float4 cf = cf4[ia];
+  const float kv = cf.x, b = cf.y, c = cf.z, w = idl[ia];
   float q1[V], q2[V], x1[V], x2[V];
   ldv<V>(q1, psi1 + q);
   ldv<V>(q2, psi2 + q);
@@ -1058,8 +1014,8 @@ __global__ __launch_bounds__(256) void pml_e4_kernel(GridP g, SlabP sl_lo, SlabP
     const float p2 = b * q2[e] + c * d1;
     q1[e] = p1;
     q2[e] = p2;
-    const float cb1 = m4 ? lut[(mw[e] >> (8 * c1)) & 255u].y : cb_uniform;
-    const float cb2 = m4 ? lut[(mw[e] >> (8 * c2)) & 255u].y : cb_uniform;
+    const float cb1 = m4 ? lut[(mw[e] >> (10 * c1)) & 1023u].y : cb_uniform;
+    const float cb2 = m4 ? lut[(mw[e] >> (10 * c2)) & 1023u].y : cb_uniform;
     const int i3c2 = (c2 == 0) ? i0 + e : jk[c2];
     const int i3c1 = (c1 == 0) ? i0 + e : jk[c1];
     const bool w1 = (i3c2 == 0) && (bc0[c2] == BC_PEC);
@@ -1075,7 +1031,7 @@ __global__ __launch_bounds__(256) void pml_e4_kernel(GridP g, SlabP sl_lo, SlabP
 
 __global__ __launch_bounds__(256) void pml_h4_kernel(GridP g, SlabP sl_lo, SlabP sl_hi, float* h1, float* h2, const float* e1,
                                                       const float* e2, float* psi1, float* psi2,
-                                                      const float* kinv, const float* bb, const float* cc,
+                                                      const float4* cf4,
                                                       const float* ipl) {
   const SlabP sl = blockIdx.y ? sl_hi : sl_lo;   // both faces of an axis in one launch (disjoint cells)
   constexpr int V = 4;
@@ -1107,7 +1063,8 @@ __global__ __launch_bounds__(256) void pml_h4_kernel(GridP g, SlabP sl_lo, SlabP
   ldv<V>(c2v, e2 + p);
   const int si = sl.psi_base + (ia - sl.s_lo);
   const long long q = psi_index(g, sl, i0, j, k, si);
-  const float kv = kinv[ia] - 1.f, b = bb[ia], c = cc[ia], w = ipl[ia];
+  const float4 cf = cf4[ia];
+  const float kv = cf.x, b = cf.y, c = cf.z, w = ipl[ia];
   float q1[V], q2[V], x1[V], x2[V];
   ldv<V>(q1, psi1 + q);
   ldv<V>(q2, psi2 + q);
@@ -1193,17 +1150,23 @@ __global__ __launch_bounds__(256) void point_source_kernel(float* f0, float* f1,
   f[p] += w_re[t] * a.x - w_im[t] * a.y;
 }
 
-// TFSF surface correction:  F[comp][cell] += w * aux[aux_index]
+// TFSF surface correction:  F[comp][cell] += sum_e w[e] * aux[aux_index[e]]
+// One thread per TARGET node (the host groups the entries by (component, cell), entries of a node in
+// their given order: a node on a box edge or corner receives two or three): no atomics, the sum is
+// formed in a fixed order and the result is bitwise repeatable.
 __global__ __launch_bounds__(256) void tfsf_corr_kernel(float* f0, float* f1, float* f2, const int32_t* comp,
-                                                         const uint32_t* cell, const float* w, const int32_t* ai,
-                                                         const float* aux, long long n, long long zlo, long long zhi) {
+                                                         const uint32_t* cell, const int32_t* start, const float* w,
+                                                         const int32_t* ai, const float* aux, long long n_targets,
+                                                         long long zlo, long long zhi) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
+  if (t >= n_targets) return;
   const long long p = cell[t];
   if (p < zlo || p >= zhi) return;
   const int c = comp[t] % 3;
   float* f = (c == 0) ? f0 : (c == 1 ? f1 : f2);
-  atomicAdd(f + p, w[t] * aux[ai[t]]);      // a node on a box edge may appear in two entries
+  float acc = 0.f;
+  for (int e = start[t]; e < start[t + 1]; ++e) acc += w[e] * aux[ai[e]];
+  f[p] += acc;
 }
 
 // 1-D auxiliary grid of the incident plane wave
@@ -1267,26 +1230,52 @@ __global__ __launch_bounds__(256) void dft_record_multi_kernel(RecP r, GridP g, 
 }
 
 // =============================================================================================
-// K7  field-energy reduction  sum |E|^2  (shutoff / divergence detection)
+// K7  field-energy reduction  W = sum |E|^2 + eta0^2 sum |H|^2  over the slab (shutoff / divergence
+//     detection; eta0^2 = mu0 / eps0 puts the two terms on the same scale, so a standing wave whose
+//     electric energy passes through zero twice per period does not look decayed).  Two passes with a
+//     FIXED launch geometry and fixed summation trees — no atomics: the value, and with it the step a run
+//     shuts off at, is bitwise repeatable.
 // =============================================================================================
-__global__ __launch_bounds__(256) void energy_kernel(const float* ex, const float* ey, const float* ez, long long n,
-                                                      double* out) {
-  __shared__ double part[4];
-  double acc = 0.0;
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n;
-       t += (long long)gridDim.x * blockDim.x) {
-    const float a = ex[t], b = ey[t], c = ez[t];
-    acc += (double)(a * a + b * b + c * c);
-  }
+constexpr double kEta0Sq = 376.730313668 * 376.730313668;     // (mu0 c0)^2, ref constants.py:32
+constexpr int kEnergyBlocks = 1024;
+
+__device__ __forceinline__ double block_sum_256(double acc, double* part) {
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (lane == 0) part[wv] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double sblk = 0.0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sblk += part[w];
-    atomicAdd(out, sblk);
+  return (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void energy_partial_kernel(const float* ex, const float* ey, const float* ez,
+                                                              const float* hx, const float* hy, const float* hz,
+                                                              long long n, double* partial) {
+  __shared__ double part[4];
+  double ae = 0.0, ah = 0.0;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+       t += (long long)gridDim.x * blockDim.x) {
+    const float a = ex[t], b = ey[t], c = ez[t];
+    const float u = hx[t], v = hy[t], w = hz[t];
+    ae += (double)(a * a + b * b + c * c);
+    ah += (double)(u * u + v * v + w * w);
   }
+  const double tot = block_sum_256(ae + kEta0Sq * ah, part);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// one workgroup: partial[0 .. n_part) -> out[0]
+__global__ __launch_bounds__(256) void energy_final_kernel(const double* partial, int n_part, double* out) {
+  __shared__ double part[4];
+  double acc = 0.0;
+  for (int t = threadIdx.x; t < n_part; t += 256) acc += partial[t];
+  const double tot = block_sum_256(acc, part);
+  if (threadIdx.x == 0) out[0] = tot;
+}
+
+// e_old[t] = E[cell[t]]   (after fdtd_set_field: the ADE recursion needs E^n of its cells)
+__global__ __launch_bounds__(256) void ade_gather_kernel(const float* e, const uint32_t* cell, float* e_old, long long n) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) e_old[t] = e[cell[t]];
 }
 
 // ---- absorber layers (K3b) -------------------------------------------------------------------

@@ -339,9 +339,13 @@ class HipEngine:
         ca, cb = _f32(mt.ca), _f32(mt.cb)
         self._chk(d.fdtd_set_media(h, _ptr(ca), _ptr(cb), len(ca)), "fdtd_set_media")
         if spec.mat_idx is not None or pad:
-            m = np.zeros((3, nzl, ny, nx), dtype=np.uint8)         # index 0 = PEC in the padding
+            wide = len(ca) > 256               # more than 8 bits of medium index: the 16-bit entry point
+            m = np.zeros((3, nzl, ny, nx), dtype=np.uint16 if wide else np.uint8)   # index 0 = PEC in the padding
             m[..., :nx0] = spec.mat_idx[:, z0:z1] if spec.mat_idx is not None else 1
-            self._chk(d.fdtd_set_material(h, _ptr(m), m.nbytes), "fdtd_set_material")
+            if wide:
+                self._chk(d.fdtd_set_material16(h, _ptr(m), m.size), "fdtd_set_material16")
+            else:
+                self._chk(d.fdtd_set_material(h, _ptr(m), m.nbytes), "fdtd_set_material")
         # CPML
         for a in range(3):
             P = pml_axis(spec, a)

@@ -19,7 +19,7 @@ DEFAULT_LIB = os.path.join(_HERE, "libfdtd_hip.so")
 # every symbol include/fdtd_hip.h declares (tests check the library exports all of them)
 SYMBOLS = (
     "fdtd_last_error", "fdtd_device_count", "fdtd_create", "fdtd_destroy", "fdtd_set_steps",
-    "fdtd_set_media", "fdtd_set_material", "fdtd_set_pml", "fdtd_set_absorber", "fdtd_add_ade",
+    "fdtd_set_media", "fdtd_set_material", "fdtd_set_material16", "fdtd_set_pml", "fdtd_set_absorber", "fdtd_add_ade",
     "fdtd_add_point_source", "fdtd_add_tfsf", "fdtd_add_monitor", "fdtd_get_monitor",
     "fdtd_set_field", "fdtd_get_field", "fdtd_set_shutoff", "fdtd_comm_unique_id",
     "fdtd_comm_init", "fdtd_run", "fdtd_run_bloch", "fdtd_get_stats", "fdtd_reset", "fdtd_set_option",
@@ -72,6 +72,7 @@ class FdtdLib:
         d.fdtd_set_steps.argtypes = [vp, C.c_int, vp, vp, C.c_int]
         d.fdtd_set_media.argtypes = [vp, vp, vp, C.c_int]
         d.fdtd_set_material.argtypes = [vp, vp, C.c_size_t]
+        d.fdtd_set_material16.argtypes = [vp, vp, C.c_size_t]
         d.fdtd_set_pml.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int]
         d.fdtd_set_absorber.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int]
         d.fdtd_add_ade.argtypes = [vp, C.c_int, i64, vp, C.c_int, vp, vp, f32]
