@@ -29,8 +29,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     # fused kernels) then performs the same IEEE operations in the same order, so results do not
     # depend on the launch geometry and the variants agree bit for bit (the kernels are HBM-bound;
     # the few extra VALU instructions are free).
+    # -mllvm -disable-lsr: loop strength reduction turns the sweep's  uniform base + lane offset  addresses
+    # into per-lane 64-bit induction pointers (a VGPR pair per array for the whole z-march): 110 -> 100
+    # VGPRs for the plain sweep, 167 + spills -> 153 for the one that carries materials and CPML.
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value", "-I/opt/rocm/include",
+           "-mllvm", "-disable-lsr", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value", "-I/opt/rocm/include",
            *SOURCES, "-o", LIB, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -104,6 +104,29 @@ __device__ __forceinline__ float upd_e(float e, float ca, float cb, float a, flo
   return fmaf(cb, fmaf(-b, wb, a * wa), ca * e);
 }
 
+// A wave-uniform pointer, pinned to SGPRs and opaque to the optimiser.  Without it loop-invariant code
+// motion splits  base + k * plane + lane offset  into a per-lane 64-bit (base + lane offset) that it
+// keeps in a VGPR pair for the whole z-march — one pair per array, ~30 VGPRs of the sweep — instead
+// of the scalar-base + 32-bit lane offset addressing the hardware offers.  Emits no instruction.
+template <typename T>
+__device__ __forceinline__ T* uni(T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+s"(p));
+#endif
+  return p;
+}
+
+// uniform base pointer + per-lane 32-bit byte offset: the form the scalar-base global loads take
+__device__ __forceinline__ const float* at(const float* base, unsigned byte_off) {
+  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ float* at(float* base, unsigned byte_off) {
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off);
+}
+__device__ __forceinline__ const uint32_t* at(const uint32_t* base, unsigned byte_off) {
+  return reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
 template <int V>
 __device__ __forceinline__ void zero(float (&r)[V]) {
 #pragma unroll
@@ -314,6 +337,39 @@ __global__ __launch_bounds__(512) void e_update_kernel(GridP g, FieldP f, StepP 
 // The parameter block lives in device memory and is passed by pointer: its fields are fetched by
 // scalar loads where they are used instead of occupying ~90 SGPRs for the whole kernel (the
 // by-value form spilled SGPRs into VGPR lanes and cost an occupancy step).
+// Pointers that come out of a parameter block in memory have no known address space: a plain access
+// through them is a FLAT load with a 64-bit VGPR address.  These helpers say what they are — global
+// memory for psi, constant (never written while a kernel runs) for the coefficient tables — so the
+// accesses become scalar-base global loads / scalar loads.  (The host-side emulator build has one
+// address space.)
+#if defined(__HIPCC__)
+#define FDTD_AS_GLOBAL __attribute__((address_space(1)))
+#define FDTD_AS_CONST __attribute__((address_space(4)))
+#else
+#define FDTD_AS_GLOBAL
+#define FDTD_AS_CONST
+#endif
+typedef float v4f __attribute__((ext_vector_type(4)));
+// (base = wave-uniform pointer, off = the lane's 32-bit byte offset)
+__device__ __forceinline__ void ldg4(float (&r)[4], const float* base, unsigned off) {
+  const v4f t = *(const FDTD_AS_GLOBAL v4f*)((const FDTD_AS_GLOBAL char*)base + off);
+  r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+}
+__device__ __forceinline__ void stg4(float* base, unsigned off, const float (&r)[4]) {
+  v4f t; t.x = r[0]; t.y = r[1]; t.z = r[2]; t.w = r[3];
+  *(FDTD_AS_GLOBAL v4f*)((FDTD_AS_GLOBAL char*)base + off) = t;
+}
+__device__ __forceinline__ float ldg1(const float* p) { return *(const FDTD_AS_GLOBAL float*)p; }
+__device__ __forceinline__ void ldc4(float (&r)[4], const float* base, unsigned off) {
+  const v4f t = *(const FDTD_AS_CONST v4f*)((const FDTD_AS_CONST char*)base + off);
+  r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+}
+__device__ __forceinline__ float4 ldc_f4(const float4* p) {
+  const v4f t = *(const FDTD_AS_CONST v4f*)p;
+  float4 o; o.x = t.x; o.y = t.y; o.z = t.z; o.w = t.w;
+  return o;
+}
+
 struct PmlAxisP {
   const float4* ce4;      // [n] {1/kappa_e - 1, b_e, c_e, 0}  (y / z: wave-uniform index -> scalar load)
   const float4* ch4;      // [n] {1/kappa_h - 1, b_h, c_h, 0}
@@ -340,9 +396,9 @@ __device__ __forceinline__ long long pml_q(const GridP& g, int a, int ns, int i,
 // one cell, one axis, read-only psi:  h1 += ch (kv d2 + p1),  h2 -= ch (kv d1 + p2)
 __device__ __forceinline__ void pml_h_cell(float& h1, float& h2, float d1, float d2, const PmlAxisP& A,
                                            long long q, int ia, float ch) {
-  const float4 cf = A.ch4[ia];
-  const float p1 = cf.y * A.ph0[q] + cf.z * d2;
-  const float p2 = cf.y * A.ph1[q] + cf.z * d1;
+  const float4 cf = ldc_f4(A.ch4 + ia);
+  const float p1 = cf.y * ldg1(A.ph0 + q) + cf.z * d2;
+  const float p2 = cf.y * ldg1(A.ph1 + q) + cf.z * d1;
   h1 += ch * (cf.x * d2 + p1);
   h2 -= ch * (cf.x * d1 + p2);
 }
@@ -381,7 +437,7 @@ __device__ __forceinline__ void pml_h_apply(float& h1, float& h2, float d1, floa
 // Everything that depends on the row only (threadIdx.y is wave-uniform) is kept in SGPRs.
 // =============================================================================================
 template <bool MAT, int LB, int PML>   // PML: bit a set = CPML of axis a runs inside the sweep
-__global__ __launch_bounds__(LB, (LB == 256 ? 3 : (LB == 512 ? 2 : 4))) void fused_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
+__global__ __launch_bounds__(LB, (LB == 256 ? (PML ? 3 : 4) : (LB == 512 ? (PML ? 2 : 4) : 4))) void fused_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
                                                           int kbeg, int kend, int zchunk, int pmc_z0,
                                                           int nbx, int nby, int nbz, int xcd_remap,
                                                           const PmlP* __restrict__ pmq,
@@ -412,6 +468,8 @@ __global__ __launch_bounds__(LB, (LB == 256 ? 3 : (LB == 512 ? 2 : 4))) void fus
   const int ty = __builtin_amdgcn_readfirstlane((int)threadIdx.y);     // one row per wave
   const int R = blockDim.y - 1;
   const int i0 = (tile_x * 64 + tx) * V;
+  const unsigned ux = (unsigned)i0;
+  const unsigned ub = ux * 4u;            // lane's byte offset along the row: every row access is  uniform base + 32-bit lane offset
   const bool halo = (ty == 0);
   const bool per_x = g.bcx0 == BC_PERIODIC, per_y = g.bcy0 == BC_PERIODIC;
   int j = tile_y * R + ty - 1;
@@ -440,15 +498,17 @@ __global__ __launch_bounds__(LB, (LB == 256 ? 3 : (LB == 512 ? 2 : 4))) void fus
   zero<V>(ipx); zero<V>(idx);
   float ipy = 0.f, idy = 0.f, ipx_m = 0.f;
   if (act) {
-    ldv<V>(ipx, s.ipx + i0);
-    ldv<V>(idx, s.idx + i0);
+    ldv<V>(ipx, at(uni(s.ipx), ub));
+    ldv<V>(idx, at(uni(s.idx), ub));
     ipx_m = s.ipx[im];
   }
   if (row_ok) { ipy = s.ipy[j]; idy = s.idy[j]; }
   // CPML membership that does not change along the march (x: per lane, y: per row)
   [[maybe_unused]] int sx = -1, sx_m = -1, sy = -1;
+  [[maybe_unused]] unsigned sxb = 0;      // lane's byte offset into an x-slab psi row
   if constexpr ((PML & 1) != 0) {
     if (act) sx = pml_si(pmq->ax[0], i0);
+    sxb = (unsigned)max(sx, 0) * 4u;
     if (xh) sx_m = pml_si(pmq->ax[0], im);
   }
   if constexpr ((PML & 2) != 0) { if (row_ok) sy = pml_si(pmq->ax[1], j); }
@@ -459,8 +519,8 @@ __global__ __launch_bounds__(LB, (LB == 256 ? 3 : (LB == 512 ? 2 : 4))) void fus
   {
     const long long p0 = (long long)k0 * g.sxy + rowb;
     if (act) {
-      ldv<V>(exk, a.ex + p0 + i0);
-      ldv<V>(eyk, a.ey + p0 + i0);
+      ldv<V>(exk, at(uni(a.ex + p0), ub));
+      ldv<V>(eyk, at(uni(a.ey + p0), ub));
     }
     if (xh) exk_m = a.ex[p0 + im];
   }
@@ -471,21 +531,21 @@ __global__ __launch_bounds__(LB, (LB == 256 ? 3 : (LB == 512 ? 2 : 4))) void fus
     float ezm[V], ezj[V], exm[V], eym[V], ho[V], hoy[V];
     zero<V>(ezm); zero<V>(ezj); zero<V>(exm); zero<V>(eym);
     if (act && !skip) {
-      ldv<V>(ezm, a.ez + pb + i0);
-      ldv<V>(exm, a.ex + pb + i0);
-      ldv<V>(eym, a.ey + pb + i0);
-      if (use_jp) ldv<V>(ezj, a.ez + (long long)(k0 - 1) * g.sxy + rowpb + i0);
+      ldv<V>(ezm, at(uni(a.ez + pb), ub));
+      ldv<V>(exm, at(uni(a.ex + pb), ub));
+      ldv<V>(eym, at(uni(a.ey + pb), ub));
+      if (use_jp) ldv<V>(ezj, at(uni(a.ez + (long long)(k0 - 1) * g.sxy + rowpb), ub));
     }
     float ezx = __shfl_down(ezm[0], 1);
     if (act && !skip) {
       if (tx == 63 || last_x) {
-        if (!last_x) ezx = a.ez[pb + i0 + V];
+        if (!last_x) ezx = a.ez[pb + ux + V];
         else if (g.bcx1 == BC_PERIODIC) ezx = a.ez[pb];
         else ezx = 0.f;
       }
       const float ipz = s.ipz[k0 - 1];
-      ldv<V>(ho, a.hx + pb + i0);
-      ldv<V>(hoy, a.hy + pb + i0);
+      ldv<V>(ho, at(uni(a.hx + pb), ub));
+      ldv<V>(hoy, at(uni(a.hy + pb), ub));
       if constexpr (PML != 0) {
         // corrected H^{n-1/2}_{x,y} of plane k0-1 (read-only psi; the plane's owner stores it)
         const int kk = (k0 - 1 < 0) ? g.nz - 1 : k0 - 1;          // periodic z: ghost = top plane
@@ -495,8 +555,8 @@ __global__ __launch_bounds__(LB, (LB == 256 ? 3 : (LB == 512 ? 2 : 4))) void fus
             if (sx >= 0) {
               const PmlAxisP& A = pmq->ax[0];
               float s1[V], kv[V], bb[V], cc[V];
-              ldv<V>(s1, A.ph0 + pml_q(g, 0, A.ns, 0, j, kk, sx));
-              ldv<V>(kv, A.kv_h + i0); ldv<V>(bb, A.b_h + i0); ldv<V>(cc, A.c_h + i0);
+              ldg4(s1, uni(A.ph0 + ((long long)kk * g.ny + j) * A.ns), sxb);
+              ldc4(kv, uni(A.kv_h), ub); ldc4(bb, uni(A.b_h), ub); ldc4(cc, uni(A.c_h), ub);
 #pragma unroll
               for (int e = 0; e < V; ++e) {
                 const float ez_ip = (e + 1 < V) ? ezm[(e + 1) % V] : ezx;
@@ -510,9 +570,9 @@ __global__ __launch_bounds__(LB, (LB == 256 ? 3 : (LB == 512 ? 2 : 4))) void fus
           if constexpr ((PML & 2) != 0) {
             if (sy >= 0) {
               const PmlAxisP& A = pmq->ax[1];
-              const float4 cf = A.ch4[j];
+              const float4 cf = ldc_f4(A.ch4 + j);
               float s2[V];
-              ldv<V>(s2, A.ph1 + pml_q(g, 1, A.ns, i0, j, kk, sy));
+              ldg4(s2, uni(A.ph1 + ((long long)kk * A.ns + sy) * g.nx), ub);
 #pragma unroll
               for (int e = 0; e < V; ++e) {
                 const float d1 = (ezj[e] - ezm[e]) * ipy;
@@ -526,11 +586,11 @@ __global__ __launch_bounds__(LB, (LB == 256 ? 3 : (LB == 512 ? 2 : 4))) void fus
             const PmlAxisP& A = pmq->ax[2];
             const int sz = (k0 - 1 >= 0) ? pml_si(A, k0 - 1) : -1;
             if (sz >= 0) {
-              const float4 cf = A.ch4[k0 - 1];
+              const float4 cf = ldc_f4(A.ch4 + k0 - 1);
               float s1[V], s2[V];
-              const long long q = pml_q(g, 2, A.ns, i0, j, k0 - 1, sz);
-              ldv<V>(s1, A.ph0 + q);
-              ldv<V>(s2, A.ph1 + q);
+              const long long q = ((long long)sz * g.ny + j) * g.nx;           // uniform part of the psi index
+              ldg4(s1, uni(A.ph0 + q), ub);
+              ldg4(s2, uni(A.ph1 + q), ub);
 #pragma unroll
               for (int e = 0; e < V; ++e)
                 pml_h_apply(ho[e], hoy[e], (exk[e] - exm[e]) * ipz, (eyk[e] - eym[e]) * ipz, s1[e], s2[e],
@@ -558,37 +618,38 @@ __global__ __launch_bounds__(LB, (LB == 256 ? 3 : (LB == 512 ? 2 : 4))) void fus
     zero<V>(hxn); zero<V>(hyn); zero<V>(hzn);
     const float ipz = s.ipz[k], idz = s.idz[k];
     if (act) {
-      ldv<V>(exn, a.ex + pb + g.sxy + i0);
-      ldv<V>(eyn, a.ey + pb + g.sxy + i0);
-      ldv<V>(ezk, a.ez + pb + i0);
+      ldv<V>(exn, at(uni(a.ex + pb + g.sxy), ub));
+      ldv<V>(eyn, at(uni(a.ey + pb + g.sxy), ub));
+      ldv<V>(ezk, at(uni(a.ez + pb), ub));
       if (use_jp) {
-        ldv<V>(exj, a.ex + pjb + i0);
-        ldv<V>(ezj, a.ez + pjb + i0);
+        ldv<V>(exj, at(uni(a.ex + pjb), ub));
+        ldv<V>(ezj, at(uni(a.ez + pjb), ub));
       }
-      ldv<V>(hxn, a.hx + pb + i0);
-      if (!halo) ldv<V>(hyn, a.hy + pb + i0);    // the halo wave only publishes H_x and H_z
-      ldv<V>(hzn, a.hz + pb + i0);
+      ldv<V>(hxn, at(uni(a.hx + pb), ub));
+      if (!halo) ldv<V>(hyn, at(uni(a.hy + pb), ub));    // the halo wave only publishes H_x and H_z
+      ldv<V>(hzn, at(uni(a.hz + pb), ub));
     }
     float eyx = __shfl_down(eyk[0], 1);
     float ezx = __shfl_down(ezk[0], 1);
     if (act && (tx == 63 || last_x)) {
-      if (!last_x) { eyx = a.ey[pb + i0 + V]; ezx = a.ez[pb + i0 + V]; }
+      if (!last_x) { eyx = a.ey[pb + ux + V]; ezx = a.ez[pb + ux + V]; }
       else if (g.bcx1 == BC_PERIODIC) { eyx = a.ey[pb]; ezx = a.ez[pb]; }
       else { eyx = 0.f; ezx = 0.f; }
     }
     // ---- H-side CPML: pre-corrections of H^{n-1/2}, axes in the order x, y, z ----------------
     [[maybe_unused]] int sz = -1;
+    if constexpr ((PML & 4) != 0) sz = pml_si(pmq->ax[2], k);       // outside the lane predicate: stays wave-uniform
     if constexpr (PML != 0) {
       if (act) {
         // axis x: Hy += ch (kv dEz/dx + p1), Hz -= ch (kv dEy/dx + p2)
         if constexpr ((PML & 1) != 0) {
           if (sx >= 0) {
             const PmlAxisP& A = pmq->ax[0];
-            const long long q = pml_q(g, 0, A.ns, 0, j, k, sx);
+            const long long q = ((long long)k * g.ny + j) * A.ns;            // uniform part of the psi index
             float s1[V], s2[V], kv[V], bb[V], cc[V];
-            ldv<V>(s1, A.ph0 + q);
-            ldv<V>(s2, A.ph1 + q);
-            ldv<V>(kv, A.kv_h + i0); ldv<V>(bb, A.b_h + i0); ldv<V>(cc, A.c_h + i0);
+            ldg4(s1, uni(A.ph0 + q), sxb);
+            ldg4(s2, uni(A.ph1 + q), sxb);
+            ldc4(kv, uni(A.kv_h), ub); ldc4(bb, uni(A.b_h), ub); ldc4(cc, uni(A.c_h), ub);
 #pragma unroll
             for (int e = 0; e < V; ++e) {
               const float ey_ip = (e + 1 < V) ? eyk[(e + 1) % V] : eyx;
@@ -596,40 +657,39 @@ __global__ __launch_bounds__(LB, (LB == 256 ? 3 : (LB == 512 ? 2 : 4))) void fus
               pml_h_apply(hyn[e], hzn[e], (ey_ip - eyk[e]) * ipx[e], (ez_ip - ezk[e]) * ipx[e], s1[e], s2[e],
                           kv[e], bb[e], cc[e], ch);
             }
-            if (!halo) { stv<V>(A.ph0n + q, s1); stv<V>(A.ph1n + q, s2); }
+            if (!halo) { stg4(uni(A.ph0n + q), sxb, s1); stg4(uni(A.ph1n + q), sxb, s2); }
           }
         }
         // axis y: Hz += ch (kv dEx/dy + p1), Hx -= ch (kv dEz/dy + p2)
         if constexpr ((PML & 2) != 0) {
           if (sy >= 0) {
             const PmlAxisP& A = pmq->ax[1];
-            const float4 cf = A.ch4[j];
-            const long long q = pml_q(g, 1, A.ns, i0, j, k, sy);
+            const float4 cf = ldc_f4(A.ch4 + j);
+            const long long q = ((long long)k * A.ns + sy) * g.nx;           // uniform part of the psi index
             float s1[V], s2[V];
-            ldv<V>(s1, A.ph0 + q);
-            ldv<V>(s2, A.ph1 + q);
+            ldg4(s1, uni(A.ph0 + q), ub);
+            ldg4(s2, uni(A.ph1 + q), ub);
 #pragma unroll
             for (int e = 0; e < V; ++e)
               pml_h_apply(hzn[e], hxn[e], (ezj[e] - ezk[e]) * ipy, (exj[e] - exk[e]) * ipy, s1[e], s2[e],
                           cf.x, cf.y, cf.z, ch);
-            if (!halo) { stv<V>(A.ph0n + q, s1); stv<V>(A.ph1n + q, s2); }
+            if (!halo) { stg4(uni(A.ph0n + q), ub, s1); stg4(uni(A.ph1n + q), ub, s2); }
           }
         }
         // axis z: Hx += ch (kv dEy/dz + p1), Hy -= ch (kv dEx/dz + p2)
         if constexpr ((PML & 4) != 0) {
           const PmlAxisP& A = pmq->ax[2];
-          sz = pml_si(A, k);
           if (sz >= 0) {
-            const float4 cf = A.ch4[k];
-            const long long q = pml_q(g, 2, A.ns, i0, j, k, sz);
+            const float4 cf = ldc_f4(A.ch4 + k);
+            const long long q = ((long long)sz * g.ny + j) * g.nx;           // uniform part of the psi index
             float s1[V], s2[V];
-            ldv<V>(s1, A.ph0 + q);
-            ldv<V>(s2, A.ph1 + q);
+            ldg4(s1, uni(A.ph0 + q), ub);
+            ldg4(s2, uni(A.ph1 + q), ub);
 #pragma unroll
             for (int e = 0; e < V; ++e)
               pml_h_apply(hxn[e], hyn[e], (exn[e] - exk[e]) * ipz, (eyn[e] - eyk[e]) * ipz, s1[e], s2[e],
                           cf.x, cf.y, cf.z, ch);
-            if (!halo) { stv<V>(A.ph0n + q, s1); stv<V>(A.ph1n + q, s2); }
+            if (!halo) { stg4(uni(A.ph0n + q), ub, s1); stg4(uni(A.ph1n + q), ub, s2); }
           }
         }
       }
@@ -730,11 +790,11 @@ __global__ __launch_bounds__(LB, (LB == 256 ? 3 : (LB == 512 ? 2 : 4))) void fus
         if constexpr ((PML & 2) != 0) {
           if (sy >= 0 && !wall_y) {
             const PmlAxisP& A = pmq->ax[1];
-            const float4 cf = A.ce4[j];
-            const long long q = pml_q(g, 1, A.ns, i0, j, k, sy);
+            const float4 cf = ldc_f4(A.ce4 + j);
+            const long long q = ((long long)k * A.ns + sy) * g.nx;           // uniform part of the psi index
             float s1[V], s2[V];
-            ldv<V>(s1, A.pe0 + q);
-            ldv<V>(s2, A.pe1 + q);
+            ldg4(s1, uni(A.pe0 + q), ub);
+            ldg4(s2, uni(A.pe1 + q), ub);
 #pragma unroll
             for (int e = 0; e < V; ++e) {
               const float d1 = (hzn[e] - hzj[e]) * idy;
@@ -746,19 +806,19 @@ __global__ __launch_bounds__(LB, (LB == 256 ? 3 : (LB == 512 ? 2 : 4))) void fus
               if (!wx) ez[e] -= coef(2, e).y * (cf.x * d2 + p1);       // E_z is tangential to the x wall
               if (!wall_z) ex[e] += coef(0, e).y * (cf.x * d1 + p2);   // E_x is tangential to the z wall
             }
-            stv<V>(A.pe0 + q, s1);
-            stv<V>(A.pe1 + q, s2);
+            stg4(uni(A.pe0 + q), ub, s1);
+            stg4(uni(A.pe1 + q), ub, s2);
           }
         }
         // axis z: E_x -= cb (kv dHy/dz + p1),  E_y += cb (kv dHx/dz + p2)
         if constexpr ((PML & 4) != 0) {
           if (sz >= 0 && !wall_z) {
             const PmlAxisP& A = pmq->ax[2];
-            const float4 cf = A.ce4[k];
-            const long long q = pml_q(g, 2, A.ns, i0, j, k, sz);
+            const float4 cf = ldc_f4(A.ce4 + k);
+            const long long q = ((long long)sz * g.ny + j) * g.nx;           // uniform part of the psi index
             float s1[V], s2[V];
-            ldv<V>(s1, A.pe0 + q);
-            ldv<V>(s2, A.pe1 + q);
+            ldg4(s1, uni(A.pe0 + q), ub);
+            ldg4(s2, uni(A.pe1 + q), ub);
 #pragma unroll
             for (int e = 0; e < V; ++e) {
               const float d1 = (hxn[e] - hxm[e]) * idz;
@@ -770,19 +830,19 @@ __global__ __launch_bounds__(LB, (LB == 256 ? 3 : (LB == 512 ? 2 : 4))) void fus
               if (!wall_y) ex[e] -= coef(0, e).y * (cf.x * d2 + p1);   // E_x is tangential to the y wall
               if (!wx) ey[e] += coef(1, e).y * (cf.x * d1 + p2);       // E_y is tangential to the x wall
             }
-            stv<V>(A.pe0 + q, s1);
-            stv<V>(A.pe1 + q, s2);
+            stg4(uni(A.pe0 + q), ub, s1);
+            stg4(uni(A.pe1 + q), ub, s2);
           }
         }
         // axis x: E_y -= cb (kv dHz/dx + p1),  E_z += cb (kv dHy/dx + p2)
         if constexpr ((PML & 1) != 0) {
           if (sx >= 0) {
             const PmlAxisP& A = pmq->ax[0];
-            const long long q = pml_q(g, 0, A.ns, 0, j, k, sx);
+            const long long q = ((long long)k * g.ny + j) * A.ns;            // uniform part of the psi index
             float s1[V], s2[V], kv[V], bb[V], cc[V];
-            ldv<V>(s1, A.pe0 + q);
-            ldv<V>(s2, A.pe1 + q);
-            ldv<V>(kv, A.kv_e + i0); ldv<V>(bb, A.b_e + i0); ldv<V>(cc, A.c_e + i0);
+            ldg4(s1, uni(A.pe0 + q), sxb);
+            ldg4(s2, uni(A.pe1 + q), sxb);
+            ldc4(kv, uni(A.kv_e), ub); ldc4(bb, uni(A.b_e), ub); ldc4(cc, uni(A.c_e), ub);
 #pragma unroll
             for (int e = 0; e < V; ++e) {
               const bool wx = wall_x0 && (e == 0);
@@ -798,8 +858,8 @@ __global__ __launch_bounds__(LB, (LB == 256 ? 3 : (LB == 512 ? 2 : 4))) void fus
                 if (!wall_y) ez[e] += coef(2, e).y * (kv[e] * d1 + p2);     // E_z is tangential to the y wall
               }
             }
-            stv<V>(A.pe0 + q, s1);
-            stv<V>(A.pe1 + q, s2);
+            stg4(uni(A.pe0 + q), sxb, s1);
+            stg4(uni(A.pe1 + q), sxb, s2);
           }
         }
       }
@@ -820,7 +880,7 @@ __global__ __launch_bounds__(LB, (LB == 256 ? 3 : (LB == 512 ? 2 : 4))) void fus
           e_phase([&](int c, int) { return c == 0 ? c0 : (c == 1 ? c1 : c2); });
         } else {
           uint32_t mw[V];
-          ldm<V>(mw, m.m4 + pb + i0);
+          ldm<V>(mw, at(uni(m.m4 + pb), ub));
           e_phase([&](int c, int e) { return lut_s[(mw[e] >> (10 * c)) & 1023u]; });
         }
       } else {
