@@ -99,6 +99,116 @@ def cpu_baseline(n: int = 320, steps: int = 18):
                       f"(single thread; host has {os.cpu_count()} cores)"}
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources: ties a PMC traffic figure to the code it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("tidy3d_amd/csrc/fdtd_kernels.hpp", "tidy3d_amd/csrc/fdtd_capi.hip"):
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def min_bytes_per_cell(workload: str, spec) -> float:
+    """The fused sweep's OWN minimum HBM traffic per cell-step: 6 field reads + 6 writes = 48 B, plus 32 B
+    per cell and CPML-axis membership (4 psi values read and written) when the recursions run inside it.
+    Material words cost nothing where a 256-cell row segment is uniform (row-segment words) and 4 B/cell
+    elsewhere; they are left out, so the fraction is a lower bound."""
+    b = 48.0
+    n = np.array(spec.shape, dtype=np.float64)
+    for a in range(3):
+        lay = spec.pml[a][0].num_layers + spec.pml[a][1].num_layers
+        b += 32.0 * lay / n[a]
+    return b
+
+
+def roofline_entry(st, kr, local_cells, cells, K, elapsed, world, workload, spec):
+    h_ms = st.h_kernel_ms / max(1, st.h_kernel_launches)
+    e_ms = st.e_kernel_ms / max(1, st.e_kernel_launches)
+    f_ms = st.fused_kernel_ms / max(1, st.fused_kernel_launches)
+    # when boundary planes are launched separately, normalise to the per-step duration
+    h_step = st.h_kernel_ms / kr
+    e_step = st.e_kernel_ms / kr
+    f_step = st.fused_kernel_ms / kr
+    survey_bytes = 2 * BYTES_PER_CELL_PASS * local_cells        # SURVEY.md 8(d): 72 B per cell-step, two passes
+    if st.fused_kernel_launches:
+        # one launch advances E and H.  `frac` is priced against what THIS kernel must move at least
+        # (48 B per cell-step + psi), so it cannot exceed 1; the two-pass figure of SURVEY.md 8(d) that the
+        # north-star target (>= 70 %) is quoted on is reported beside it as frac_vs_survey_8d
+        dom, dom_ms = "fused_step_kernel", f_step
+        dom_bytes = min_bytes_per_cell(workload, spec) * local_cells
+    elif e_step >= h_step:
+        dom, dom_ms, dom_bytes = "e_update_kernel", e_step, BYTES_PER_CELL_PASS * local_cells
+        survey_bytes = dom_bytes
+    else:
+        dom, dom_ms, dom_bytes = "h_update_kernel", h_step, BYTES_PER_CELL_PASS * local_cells
+        survey_bytes = dom_bytes
+    achieved = dom_bytes / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
+    r = {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None, "traffic_source": None,
+         "frac_vs_survey_8d": (survey_bytes / (dom_ms * 1e-3) / HBM_PEAK) if dom_ms > 0 else 0.0,
+         "avg_launch_ms": {"h_update_kernel": h_ms, "e_update_kernel": e_ms, "fused_step_kernel": f_ms},
+         "per_step_ms": {"h_update_kernel": h_step, "e_update_kernel": e_step, "fused_step_kernel": f_step},
+         "algorithmic_bytes_per_launch": dom_bytes,
+         "algorithmic_bytes_per_cell": dom_bytes / local_cells,
+         "whole_step_frac": (dom_bytes / local_cells * cells * K / elapsed) / (HBM_PEAK * world),
+         "whole_step_frac_vs_survey_8d": (2 * BYTES_PER_CELL_PASS * cells * K / elapsed) / (HBM_PEAK * world)}
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc) and workload == "v0":
+        try:
+            rec = json.load(open(pmc))
+            t512 = rec.get(dom)                        # PMC bytes of one 512^3 launch (separate rocprofv3 --pmc passes)
+            # only a figure measured on THIS code counts (the record carries the hash of the kernel sources)
+            if t512 is not None and rec.get("source_hash") == source_hash():
+                r["traffic"] = t512 * local_cells / 512 ** 3      # per launch like `achieved`
+                r["traffic_source"] = {"file": rec.get("file"), "commit": rec.get("commit"),
+                                       "source_hash": rec.get("source_hash")}
+        except Exception:
+            pass
+    return r
+
+
+def secondary_workload(HipEngine, L, n, workload, device, args, steps=40, repeats=3):
+    """One more single-GPU measurement on the same box: same grid, materials + CPML on all six faces."""
+    spec = build_spec(n, steps * (repeats + 2) + 64, workload)
+    eng = HipEngine(spec, device=device, variant=args.variant, z_chunk=args.zchunk)
+    try:
+        if args.rows:
+            eng.set_option(L.OPT_ROWS, args.rows)
+        if args.pml_fused >= 0:
+            eng.set_option(L.OPT_PML_FUSED, args.pml_fused)
+        for c in range(6):
+            arr = np.empty((n, n, n), dtype=np.float32)
+            for k in range(n):
+                arr[k] = np.random.default_rng(c * 100003 + k).uniform(-1e-3, 1e-3, (n, n)).astype(np.float32)
+            eng.set_field(c, arr)
+        import torch
+        eng.run(10)
+        samples = []
+        for _ in range(repeats):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.run(steps)
+            torch.cuda.synchronize()
+            samples.append(time.perf_counter() - t0)
+        el = float(np.median(samples))
+        eng.set_option(L.OPT_FLAGS, L.FLAG_TIME_KERNELS)
+        eng.run(10)
+        st = eng.stats()
+        cells = n ** 3
+        own = min_bytes_per_cell(workload, spec)
+        survey = 72.0 + (own - 48.0) + 4.0          # two passes + psi + material word: the SURVEY.md 8(d) accounting
+        return {"workload": f"{workload}: {WORKLOADS[workload]}", "value": cells * steps / el / 1e6, "unit": "Mcells/s",
+                "ms_per_step": el / steps * 1e3, "steps": steps, "repeats": repeats,
+                "ms_per_step_samples": [e / steps * 1e3 for e in samples],
+                "fused_kernel_ms_per_step": st.fused_kernel_ms / 10,
+                "bytes_per_cell_own_minimum": own,
+                "whole_step_frac": own * cells * steps / el / HBM_PEAK,
+                "bytes_per_cell_survey_8d": survey,
+                "whole_step_frac_vs_survey_8d": survey * cells * steps / el / HBM_PEAK}
+    finally:
+        eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +221,8 @@ def main():
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--pml-fused", type=int, default=-1, help="axis mask of the CPML recursions folded into the fused sweep (0, 6, 7)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the secondary V2 (materials + CPML) measurement")
     ap.add_argument("--sweep", action="store_true", help="A/B kernel launch parameters (N=1)")
     args = ap.parse_args()
 
@@ -187,38 +299,28 @@ def main():
         return time.perf_counter() - t0
 
     eng.run(W)
-    elapsed = timed(K)
-    if world > 1:
-        t = torch.tensor([elapsed], device="cpu" if emulate else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # REPEATS timed regions of exactly K steps each (barrier + device sync on both sides, max over ranks);
+    # the median is the reported number, the spread is reported beside it (median of 5)
+    R = max(1, args.repeats)
+    samples = []
+    for _ in range(R):
+        e = timed(K)
+        if world > 1:
+            t = torch.tensor([e], device="cpu" if emulate else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e = float(t.item())
+        samples.append(e)
+    elapsed = float(np.median(samples))
     cells = n ** 3
     value = cells * K / elapsed / 1e6
 
-    # roofline of the dominant kernel: separate short run with per-launch hipEvents
+    # roofline of the dominant kernel: separate short run with per-launch hipEvents on the launch stream
     eng.set_option(L.OPT_FLAGS, L.FLAG_TIME_KERNELS)
     kr = min(K, 20)
     eng.run(kr)
     st = eng.stats()
     eng.set_option(L.OPT_FLAGS, 0)
     local_cells = (z1 - z0) * n * n
-    h_ms = st.h_kernel_ms / max(1, st.h_kernel_launches)
-    e_ms = st.e_kernel_ms / max(1, st.e_kernel_launches)
-    f_ms = st.fused_kernel_ms / max(1, st.fused_kernel_launches)
-    # when boundary planes are launched separately, normalise to the per-step duration
-    h_step = st.h_kernel_ms / kr
-    e_step = st.e_kernel_ms / kr
-    f_step = st.fused_kernel_ms / kr
-    if st.fused_kernel_launches:
-        # one launch advances E and H: algorithmic bytes of the launch = both passes (72 B/cell,
-        # the SURVEY.md section 8(d) figure); its real minimum traffic is 48 B/cell
-        dom, dom_ms, dom_bytes = "fused_step_kernel", f_step, 2 * BYTES_PER_CELL_PASS * local_cells
-    elif e_step >= h_step:
-        dom, dom_ms, dom_bytes = "e_update_kernel", e_step, BYTES_PER_CELL_PASS * local_cells
-    else:
-        dom, dom_ms, dom_bytes = "h_update_kernel", h_step, BYTES_PER_CELL_PASS * local_cells
-    achieved = dom_bytes / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
-
     out = {
         "metric": "Mcells/s on 512^3 Yee grid", "value": value, "unit": "Mcells/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
@@ -231,28 +333,17 @@ def main():
                             "how": "library default" if not (args.rows or args.zchunk) else "flags"},
                    "bytes_per_cell_step": 2 * BYTES_PER_CELL_PASS,
                    "roofline_mcells_per_gpu": HBM_PEAK / (2 * BYTES_PER_CELL_PASS) / 1e6},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
-                     "avg_launch_ms": {"h_update_kernel": h_ms, "e_update_kernel": e_ms,
-                                       "fused_step_kernel": f_ms},
-                     "per_step_ms": {"h_update_kernel": h_step, "e_update_kernel": e_step,
-                                     "fused_step_kernel": f_step},
-                     "algorithmic_bytes_per_launch": dom_bytes,
-                     "note": ("fused sweep: frac uses the 72 B/cell-step two-pass figure of SURVEY.md 8(d); "
-                              "its own minimum traffic is 48 B/cell-step, i.e. frac_vs_48B = %.3f"
-                              % (achieved * 48.0 / 72.0 / HBM_PEAK)) if dom == "fused_step_kernel" else "",
-                     "whole_step_frac": (2 * BYTES_PER_CELL_PASS * cells * K / elapsed) / (HBM_PEAK * world)},
+        "repeats": {"n": R, "statistic": "median", "ms_per_step": [e / K * 1e3 for e in samples],
+                    "min_ms_per_step": min(samples) / K * 1e3, "max_ms_per_step": max(samples) / K * 1e3},
+        "roofline": roofline_entry(st, kr, local_cells, cells, K, elapsed, world, args.workload, spec),
     }
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
-        try:
-            t512 = json.load(open(pmc)).get(dom)       # PMC bytes of one 512^3 launch (rocprofv3 passes)
-            # per launch like `achieved`: this rank's share of the cells (z-slabs at N > 1, --size)
-            out["roofline"]["traffic"] = None if t512 is None else t512 * local_cells / 512 ** 3
-        except Exception:
-            pass
+    if world == 1 and not emulate and args.workload == "v0" and not args.no_workloads:
+        # the workload every real simulation resembles (materials + CPML on all faces), same grid, same box
+        eng.close()
+        eng = None
+        out["workloads"] = {"v2": secondary_workload(HipEngine, L, n, "v2", local_rank, args)}
 
-    if args.sweep and world == 1:
+    if args.sweep and world == 1 and eng is not None:
         res = []
         for rows in (1, 2, 4, 8):
             for zc in (1, 4, 8, 16, 32, 64, 128):
@@ -266,7 +357,8 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline()
-    eng.close()
+    if eng is not None:
+        eng.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -18,10 +18,38 @@ the leapfrog/CPML/ADE recursions is the textbook scheme documented in
 (PEC-cavity eigenfrequencies, PML reflection, Fresnel transmission of a dispersive
 slab, energy conservation).
 
-It consumes the same ``SolverSpec`` and the same fp64 coefficient tables
-(``tidy3d_amd.coeffs``) as the HIP engine, so GPU-vs-oracle differences are pure
-fp32 round-off.  It also *is* the "naive NumPy curl-loop" CPU baseline that
-BASELINE.md section 4 asks to be timed next to the GPU number.
+It consumes the same ``SolverSpec`` (the *statement* of the problem: grid boundaries,
+material indices, source lists, monitor boxes) as the HIP engine, but derives every
+update coefficient ITSELF from that statement — 1/steps, dt/mu0, (Ca, Cb, Cc), the ADE
+(kappa, beta) pairs, the CPML (1/kappa, b, c) profiles and their sampling positions, the
+absorber factors and the DFT phase tables — with the formulas written out below
+(``_own_*``), not by importing ``tidy3d_amd.coeffs``.  tests/test_oracle_coeffs.py asserts
+the two derivations agree to 1e-13, so a coefficient error in the product is not
+common-mode with the oracle.  GPU-vs-oracle differences are then pure fp32 round-off.
+It also *is* the "naive NumPy curl-loop" CPU baseline that BASELINE.md section 4 asks to
+be timed next to the GPU number.
+
+Discrete system restated here (all times in s, lengths in um, e^{-i w t}):
+
+  H^{n+1/2} = H^{n-1/2} - (dt/mu0) curl_primal E^n
+  E^{n+1}   = Ca E^n + Cb curl_dual H^{n+1/2} - Cc S^n          S^n = sum_k 2 Re[(kap_k - 1) Q_k^n]
+  Q_k^{n+1} = kap_k Q_k^n + bet_k (E^{n+1} + E^n)
+
+  medium  eps(w) = eps_inf + i sigma/(w eps0) - sum_k [c_k/(jw + a_k) + c.c.]   (ref medium.py:2900-2913)
+      kap_k = (2 + a_k dt)/(2 - a_k dt),   bet_k = c_k dt/(2 - a_k dt)           (trapezoidal rule)
+      D  = eps_inf + sum_k 2 Re bet_k + sigma dt/(2 eps0)
+      Ca = (2 eps_inf - D)/D,   Cb = dt/(eps0 D),   Cc = 1/D
+  CPML   d/du -> (1/kappa) d/du + psi,  psi <- b psi + c d/du   (ref boundary.py:195-254, units 2 eps0/dt)
+      b = exp(-2 (sigma/kappa + alpha)),  c = sigma (b - 1)/(kappa (sigma + kappa alpha))
+      profiles  p(d) = p_min + (p_max - p_min) d^order  at depth d in [0, 1] from the PML entrance
+      (alpha runs the other way: 1 - d); sampled at i/n (E side) and (i + 1/2)/n (H side)
+      (ref plugins/mode/derivatives.py:174-197)
+  DFT    acc += w(t) (stride dt / sqrt(2 pi)) exp(+2 pi i f t) F,  E at t_n, H at t_n + dt/2
+      (same kernel as SourceTime.spectrum, ref time.py:95-105; w = ApodizationSpec window,
+      ref apodization.py:87-94)
+  decay  W = sum |E|^2 + (mu0/eps0) sum |H|^2 over all cells (H half a step later than E), evaluated every
+      decay_every steps; field_decay = W / max W; shutoff when it falls below Simulation.shutoff after
+      the sources have ended (ref simulation.py:2089-2096); non-finite W = diverged (ref sim_data.py:909)
 """
 from __future__ import annotations
 
@@ -29,8 +57,121 @@ from typing import Dict, Optional
 
 import numpy as np
 
-from tidy3d_amd.coeffs import damping_tables, h_coeff, inv_steps, material_table, pml_axis
 from tidy3d_amd.spec import BC_PEC, BC_PERIODIC, BC_PMC, SolverSpec
+
+# physical constants in tidy3d's unit system (um, s): ref constants.py:16-32
+_C0 = 2.99792458e14
+_MU0 = 1.25663706212e-12
+_EPS0 = 1.0 / (_MU0 * _C0 * _C0)
+_ETA0_SQ = _MU0 / _EPS0
+
+
+# ---------------------------------------------------------------------------------------------
+# the oracle's own coefficient derivations (deliberately NOT shared with tidy3d_amd/coeffs.py)
+# ---------------------------------------------------------------------------------------------
+class _OwnMaterials:
+    """(Ca, Cb, Cc) and the ADE pairs of every medium of the spec, one medium at a time in plain Python
+    complex arithmetic."""
+
+    def __init__(self, media, dt: float):
+        self.ca, self.cb, self.cc, self.kap, self.bet = [], [], [], [], []
+        for med in media:
+            if med.pec:
+                self.ca.append(0.0); self.cb.append(0.0); self.cc.append(0.0)
+                self.kap.append(np.zeros(0, complex)); self.bet.append(np.zeros(0, complex))
+                continue
+            kaps, bets, two_re_beta = [], [], 0.0
+            for a, c in med.poles:
+                a, c = complex(a), complex(c)
+                kaps.append((2.0 + a * dt) / (2.0 - a * dt))
+                beta = c * dt / (2.0 - a * dt)
+                bets.append(beta)
+                two_re_beta += 2.0 * beta.real
+            D = med.eps_inf + two_re_beta + med.sigma * dt / (2.0 * _EPS0)
+            self.ca.append((2.0 * med.eps_inf - D) / D)
+            self.cb.append(dt / (_EPS0 * D))
+            self.cc.append(1.0 / D)
+            self.kap.append(np.array(kaps, complex))
+            self.bet.append(np.array(bets, complex))
+        self.ca, self.cb, self.cc = np.array(self.ca), np.array(self.cb), np.array(self.cc)
+
+    @property
+    def n_media(self) -> int:
+        return len(self.ca)
+
+    def is_dispersive(self, m: int) -> bool:
+        return len(self.kap[m]) > 0
+
+
+class _OwnPml:
+    """CPML tables of one axis, identity outside the layers: cell i of the low face lies at depth
+    (n_lo - i)/n_lo (E side, on the cell boundary) and (n_lo - i - 1/2)/n_lo (H side, cell centre); cell i
+    of the high face at (i - (N - n_hi))/n_hi and (i + 1/2 - (N - n_hi))/n_hi."""
+
+    def __init__(self, spec: SolverSpec, axis: int):
+        N = spec.shape[axis]
+        lo, hi = spec.pml[axis]
+        self.n_lo, self.n_hi = int(lo.num_layers), int(hi.num_layers)
+        self.kinv_e, self.b_e, self.c_e = np.ones(N), np.zeros(N), np.zeros(N)
+        self.kinv_h, self.b_h, self.c_h = np.ones(N), np.zeros(N), np.zeros(N)
+        for i in range(self.n_lo):
+            self._set("e", i, lo, (self.n_lo - i) / self.n_lo)
+            self._set("h", i, lo, (self.n_lo - i - 0.5) / self.n_lo)
+        for i in range(N - self.n_hi, N):
+            if i > N - self.n_hi:                       # the first boundary of the high face IS the entrance
+                self._set("e", i, hi, (i - (N - self.n_hi)) / self.n_hi)
+            self._set("h", i, hi, (i + 0.5 - (N - self.n_hi)) / self.n_hi)
+
+    def _set(self, side: str, i: int, face, depth: float):
+        d = min(max(depth, 0.0), 1.0)
+        sigma = face.sigma_min + (face.sigma_max - face.sigma_min) * d ** face.sigma_order
+        kappa = face.kappa_min + (face.kappa_max - face.kappa_min) * d ** face.kappa_order
+        alpha = face.alpha_min + (face.alpha_max - face.alpha_min) * (1.0 - d) ** face.alpha_order
+        b = np.exp(-2.0 * (sigma / kappa + alpha))
+        den = kappa * (sigma + kappa * alpha)
+        c = sigma * (b - 1.0) / den if den > 0 else 0.0
+        getattr(self, "kinv_" + side)[i] = 1.0 / kappa
+        getattr(self, "b_" + side)[i] = b
+        getattr(self, "c_" + side)[i] = c
+
+
+def _own_inv_steps(spec: SolverSpec):
+    """1/primal (forward differences of E) and 1/dual (backward differences of H) steps per axis; the dual
+    step of cell 0 pairs it with cell N-1 on a periodic axis and with itself otherwise (ref grid.py:393-417)."""
+    ip, idl = [], []
+    for a in range(3):
+        b = np.asarray(spec.boundaries[a], np.float64)
+        d = b[1:] - b[:-1]
+        dd = np.empty_like(d)
+        dd[1:] = 0.5 * (d[1:] + d[:-1])
+        dd[0] = 0.5 * (d[0] + d[-1]) if spec.bc[a][0] == BC_PERIODIC else d[0]
+        ip.append(1.0 / d)
+        idl.append(1.0 / dd)
+    return ip, idl
+
+
+def _own_dft_phases(m, dt: float):
+    """(phase_e, phase_h) [n_rec, nf] of a running-DFT monitor from its recording steps, stride, frequencies
+    and apodisation (MonitorSpec.stride / .apod); falls back to the tables in the spec when the spec does not
+    carry them (specs built by hand in older tests)."""
+    if getattr(m, "stride", None) is None:
+        return np.asarray(m.phase_e), np.asarray(m.phase_h)
+    f = np.asarray(m.freqs, np.float64)[None, :]
+    pref = m.stride * dt / np.sqrt(2.0 * np.pi)
+
+    def window(t):
+        w = np.ones_like(t)
+        if m.apod is not None:
+            start, end, width = m.apod
+            if start is not None:
+                w = np.where(t < start, w * np.exp(-0.5 * ((t - start) / width) ** 2), w)
+            if end is not None:
+                w = np.where(t > end, w * np.exp(-0.5 * ((t - end) / width) ** 2), w)
+        return w
+    te = np.asarray(m.steps, np.float64) * dt
+    th = te + 0.5 * dt
+    return (window(te)[:, None] * pref * np.exp(2j * np.pi * f * te[:, None]),
+            window(th)[:, None] * pref * np.exp(2j * np.pi * f * th[:, None]))
 
 
 def _ax(axis: int) -> int:
@@ -58,24 +199,26 @@ class OracleFdtd:
         shp = (nz, ny, nx)
         self.E = [np.zeros(shp, dtype) for _ in range(3)]
         self.H = [np.zeros(shp, dtype) for _ in range(3)]
-        ip, idl = inv_steps(spec)
+        ip, idl = _own_inv_steps(spec)
         self.ip = [_bcast(v.astype(dtype), a) for a, v in enumerate(ip)]
         self.id = [_bcast(v.astype(dtype), a) for a, v in enumerate(idl)]
-        self.ch = dtype(h_coeff(spec.dt))
+        self.ch = dtype(spec.dt / _MU0)
         # absorber layers: per-step damping factors at each component's Yee location
         # (tidy3d_amd.coeffs.damping_tables; Absorber of ref boundary.py:427-476)
         self.damp_e = self.damp_h = None
-        dm = damping_tables(spec)
-        if dm is not None:
+        if spec.absorber is not None:
+            # per-step factor exp(-2 s) of each axis (s = conductivity in units of 2 eps0/dt at the cell
+            # boundaries / centres); a component's factor is the product over the axes at ITS Yee location
             def factor(c, is_h):
                 f = np.ones(shp, np.float64)
                 for a in range(3):
+                    s_b, s_c = spec.absorber[a][0], spec.absorber[a][1]
                     on_center = (a == c) != is_h
-                    f = f * _bcast(dm[a].fc if on_center else dm[a].fb, a)
+                    f = f * _bcast(np.exp(-2.0 * np.asarray(s_c if on_center else s_b, np.float64)), a)
                 return f.astype(self.rdtype)
             self.damp_e = [factor(c, False) for c in range(3)]
             self.damp_h = [factor(c, True) for c in range(3)]
-        self.mt = material_table(spec.media, spec.dt)
+        self.mt = _OwnMaterials(spec.media, spec.dt)
         if spec.mat_idx is not None:
             self.ca = [self.mt.ca[spec.mat_idx[c]].astype(self.rdtype) for c in range(3)]
             self.cb = [self.mt.cb[spec.mat_idx[c]].astype(self.rdtype) for c in range(3)]
@@ -83,7 +226,7 @@ class OracleFdtd:
             self.ca = [self.rdtype(self.mt.ca[1])] * 3
             self.cb = [self.rdtype(self.mt.cb[1])] * 3
         # CPML
-        self.pml = [pml_axis(spec, a) for a in range(3)]
+        self.pml = [_OwnPml(spec, a) for a in range(3)]
         self.has_pml = [p.n_lo + p.n_hi > 0 for p in self.pml]
         self.psi_h: Dict = {}
         self.psi_e: Dict = {}
@@ -114,6 +257,7 @@ class OracleFdtd:
         # monitor accumulators
         self.mon_data = []
         self.mon_count = []
+        self.mon_phase = [(_own_dft_phases(m, spec.dt) if m.kind != "time" else None) for m in spec.monitors]
         for m in spec.monitors:
             bz, by, bx = m.shape
             if m.kind == "time":
@@ -292,17 +436,20 @@ class OracleFdtd:
                     elif c >= 3:
                         data[k, ic] += 0.5 * self._box(self.H[c - 3], m)
                 else:
+                    pe, ph = self.mon_phase[im]
                     if c < 3 and phase == "pre":
-                        data[:, ic] += m.phase_e[k][:, None, None, None] * self._box(self.E[c], m)
+                        data[:, ic] += pe[k][:, None, None, None] * self._box(self.E[c], m)
                     elif c >= 3 and phase == "post":
-                        data[:, ic] += (m.phase_h[k][:, None, None, None]
-                                        * self._box(self.H[c - 3], m))
+                        data[:, ic] += ph[k][:, None, None, None] * self._box(self.H[c - 3], m)
             if phase == "post":
                 self.mon_count[im] += 1
 
     # ------------------------------------------------------------------ driver
     def energy(self) -> float:
-        return float(sum(np.sum(np.square(np.abs(e), dtype=np.float64)) for e in self.E))
+        """W = sum |E|^2 + (mu0/eps0) sum |H|^2 (E^{n}, H^{n-1/2} as they stand after a step)."""
+        we = sum(np.sum(np.square(np.abs(e), dtype=np.float64)) for e in self.E)
+        wh = sum(np.sum(np.square(np.abs(h), dtype=np.float64)) for h in self.H)
+        return float(we + _ETA0_SQ * wh)
 
     def step(self):
         n = self.step_index

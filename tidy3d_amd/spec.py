@@ -133,6 +133,10 @@ class MonitorSpec:
     phase_e: Optional[np.ndarray] = None                # complex128 [n_rec,nf] (dft)
     phase_h: Optional[np.ndarray] = None                # complex128 [n_rec,nf] (dft)
     name: str = ""
+    # how the phase tables were formed (the oracle re-derives them from these): recording stride in steps
+    # and the apodisation window (start, end, width) or None
+    stride: Optional[int] = None
+    apod: Optional[Tuple[Optional[float], Optional[float], Optional[float]]] = None
 
     @property
     def shape(self) -> Tuple[int, int, int]:
