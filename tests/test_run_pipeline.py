@@ -164,3 +164,22 @@ def test_bloch_run_end_to_end(emu_lib, tmp_path):
     back = load(path)
     assert np.array_equal(back["orders"].Etheta.values, sd["orders"].Etheta.values)
     assert back.simulation.boundary_spec.x.plus.bloch_vec == sim.boundary_spec.x.plus.bloch_vec
+
+
+def test_time_monitors_end_where_the_run_stopped(emu_lib):
+    """A run that shuts off early returns time-domain data for the steps it took, not zeros up to run_time."""
+    sim = _sim(run_time=6e-13, shutoff=1e-2)
+    sd = run(sim, task_name="shutoff", verbose=False, lib=emu_lib)
+    msg = [ln for ln in sd.log.splitlines() if "exiting solver" in ln]
+    assert msg, sd.log[-400:]
+    stop = int(msg[0].split("time step")[1].strip(" )."))
+    spec = D.discretize(sim).spec
+    assert 0 < stop < spec.n_steps
+    for name, interval in (("t", 4), ("flt", 8)):
+        arr = sd[name].Ez if name == "t" else sd[name].flux
+        t = arr.coords["t"]
+        n_expected = len(np.arange(0, stop, interval))
+        assert len(t) == n_expected and arr.shape[-1] == n_expected
+        assert t[-1] < stop * spec.dt
+    tail = np.asarray(sd["t"].Ez.values)[..., -3:]
+    assert np.any(tail != 0)                  # the last samples are recorded data, not padding

@@ -1316,8 +1316,9 @@ __global__ __launch_bounds__(256) void energy_partial_kernel(const float* ex, co
        t += (long long)gridDim.x * blockDim.x) {
     const float a = ex[t], b = ey[t], c = ez[t];
     const float u = hx[t], v = hy[t], w = hz[t];
-    ae += (double)(a * a + b * b + c * c);
-    ah += (double)(u * u + v * v + w * w);
+    // squares in double: a field that has grown past 1.8e19 must not overflow the sum before it is itself Inf
+    ae += (double)a * a + (double)b * b + (double)c * c;
+    ah += (double)u * u + (double)v * v + (double)w * w;
   }
   const double tot = block_sum_256(ae + kEta0Sq * ah, part);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;

@@ -497,8 +497,17 @@ def source_spectrum_fn(disc: Discretization, index: Optional[int]) -> Callable:
 
 def assemble(disc: Discretization, raw: Dict[str, np.ndarray], log: str = "", diverged: bool = False,
              n_steps_run: Optional[int] = None) -> SimulationData:
-    """Raw monitor buffers (name -> array as returned by the engine / oracle) -> SimulationData."""
+    """Raw monitor buffers (name -> array as returned by the engine / oracle) -> SimulationData.
+    ``n_steps_run``: time steps actually taken (a run that stopped on the shutoff criterion or diverged took
+    fewer than ``spec.n_steps``): time-domain monitors then keep only the samples that were recorded — steps
+    after the stop never happened and must not come back as zeros on the full ``tmesh`` axis."""
     sim, spec = disc.sim, disc.spec
+
+    def recorded(steps):
+        """number of leading entries of ``steps`` that were reached"""
+        steps = np.asarray(steps)
+        return len(steps) if n_steps_run is None else int(np.searchsorted(steps, int(n_steps_run), side="left"))
+
     norm = source_spectrum_fn(disc, sim.normalize_index)
     out = []
     sym = tuple(getattr(disc, "symmetry", (0, 0, 0)))
@@ -516,15 +525,17 @@ def assemble(disc: Discretization, raw: Dict[str, np.ndarray], log: str = "", di
             out.append(fd.normalize(norm))
         elif plan.kind == "field_time":
             fp = plan.fields[0]
-            t = disc.tmesh[plan.steps]
+            nk = recorded(plan.steps)
+            t = disc.tmesh[plan.steps[:nk]]
             # real fields; complex ones under Bloch boundaries (ref simulation.py:4396-4411 complex_fields)
-            out.append(_field_container(FieldTimeData, mon, spec, fp, raw[fp.spec_name], "t", t,
+            out.append(_field_container(FieldTimeData, mon, spec, fp, raw[fp.spec_name][:nk], "t", t,
                                         sim.center, np.complex64 if spec.bloch is not None else np.float32,
                                         full_of(pfull, 0)))
         elif plan.kind in ("flux", "flux_time"):
             is_time = plan.kind == "flux_time"
             lead = "t" if is_time else "f"
-            lead_coords = disc.tmesh[plan.steps] if is_time else np.asarray(mon.freqs, float)
+            nk = recorded(plan.steps) if is_time else None
+            lead_coords = disc.tmesh[plan.steps[:nk]] if is_time else np.asarray(mon.freqs, float)
             total = None
             from .discretize import flux_surfaces
             for isurf, (fp, (sname, box, axis, sign)) in enumerate(zip(plan.fields, flux_surfaces(mon))):
@@ -534,7 +545,7 @@ def assemble(disc: Discretization, raw: Dict[str, np.ndarray], log: str = "", di
                 m.size, m.center, m.geometry = box.size, box.center, box
                 # the time-domain flux of a complex-field (Bloch) run is that of the physical field Re(E), Re(H)
                 fd = _field_container(FieldTimeData if is_time else FieldData, m, spec, fp,
-                                      np.real(raw[fp.spec_name]) if is_time else raw[fp.spec_name], lead, lead_coords, sim.center,
+                                      np.real(raw[fp.spec_name][:nk]) if is_time else raw[fp.spec_name], lead, lead_coords, sim.center,
                                       np.float64 if is_time else np.complex128, full_of(pfull, isurf))
                 fl = plane_flux(fd, axis, m, sign=sign, box=box, lead=lead)
                 total = fl if total is None else DataArray(total.values + fl.values, fl.coords)

@@ -111,4 +111,5 @@ def run(simulation, verbose: bool = True, n_steps: Optional[int] = None, lib=Non
     rank = dist.get_rank() if dist.is_initialized() else 0
     if rank != 0:
         return None
-    return assemble(disc, raw, log=f"distributed run over {eng.n_ranks} z-slabs", diverged=bool(stats.diverged))
+    return assemble(disc, raw, log=f"distributed run over {eng.n_ranks} z-slabs", diverged=bool(stats.diverged),
+                    n_steps_run=int(stats.steps_done))
