@@ -45,10 +45,13 @@ shapes = [dict(rows=3, zc=16), dict(rows=7, zc=16), dict(rows=3, zc=32), dict(ro
           dict(rows=5, zc=16), dict(rows=3, zc=16, remap=0)]
 if quick:
     shapes = shapes[:2]
+custom = json.loads(os.environ["PROBE_CFGS"]) if os.environ.get("PROBE_CFGS") else None
 for wl in wls:
     cfgs = list(shapes)
     if wl in ("v2", "v3", "v4"):
         cfgs = [dict(c, pml=p) for p in (-1, 0) for c in shapes[:4]] + [dict(rows=3, zc=16, pml=6)]
+    if custom is not None:
+        cfgs = custom.get(wl, custom.get("*", cfgs))
     r = subprocess.run([sys.executable, "-c", CHILD, str(n), wl, json.dumps(cfgs)], capture_output=True, text=True)
     sys.stdout.write(r.stdout)
     if r.returncode != 0:

@@ -147,8 +147,9 @@ struct FdtdSolver {
   bool tuned = false, user_geometry = false;
   int bnd_planes = 0;                // fused z-slab schedule: planes per boundary chunk (0 = heuristic)
   int rows = 4;
-  PmlP* pml_blk[2] = {nullptr, nullptr};   // device parameter blocks of the in-sweep CPML, one per psi_h parity
-  int pml_parity = 0, pml_blk_mask = 0;
+  PmlP* pml_blk[8][2] = {};          // device parameter blocks of the in-sweep CPML: [axis mask][psi_h parity]
+  bool pml_blk_ok[8] = {};
+  int pml_parity = 0;
   // RCCL
   ncclComm_t comm = nullptr;
   int rank = 0, n_ranks = 1;
@@ -306,7 +307,7 @@ bool any_pml(const FdtdSolver* h) {
 // Device parameter blocks of the in-sweep CPML: block q reads psi_h (q = 0) or psi_h2 (q = 1) and
 // writes the other set; the sweep alternates between them.  Built on first use.
 int ensure_pml_blocks(FdtdSolver* h, int mask) {
-  if (h->pml_blk[0] && h->pml_blk_mask == mask) return 0;
+  if (h->pml_blk_ok[mask]) return 0;
   const int N[3] = {h->g.nx, h->g.ny, h->g.nz};
   for (int a = 0; a < 3; ++a) {
     PmlAxisDev& P = h->pml[a];
@@ -314,7 +315,10 @@ int ensure_pml_blocks(FdtdSolver* h, int mask) {
     for (int q = 0; q < 2; ++q)
       if (!P.psi_h2[q] && dev_alloc(h, &P.psi_h2[q], P.psi_count)) return -1;
   }
+  // The two sets of an axis keep their identity: `psi_h` / `psi_h2` swap names on the host after every
+  // sweep, so block [parity p] must read what the host calls psi_h when pml_parity == p.
   for (int par = 0; par < 2; ++par) {
+    const bool flip = par != h->pml_parity;
     PmlP pm{};
     for (int a = 0; a < 3; ++a) {
       const PmlAxisDev& P = h->pml[a];
@@ -323,19 +327,17 @@ int ensure_pml_blocks(FdtdSolver* h, int mask) {
       A.kv_e = P.kv_e; A.b_e = P.b_e; A.c_e = P.c_e;
       A.kv_h = P.kv_h; A.b_h = P.b_h; A.c_h = P.c_h;
       A.pe0 = P.psi_e[0]; A.pe1 = P.psi_e[1];
-      // parity 0: the CURRENT read set is psi_h (as the handle holds it now)
-      A.ph0 = par ? P.psi_h2[0] : P.psi_h[0]; A.ph1 = par ? P.psi_h2[1] : P.psi_h[1];
-      A.ph0n = par ? P.psi_h[0] : P.psi_h2[0]; A.ph1n = par ? P.psi_h[1] : P.psi_h2[1];
+      A.ph0 = flip ? P.psi_h2[0] : P.psi_h[0]; A.ph1 = flip ? P.psi_h2[1] : P.psi_h[1];
+      A.ph0n = flip ? P.psi_h[0] : P.psi_h2[0]; A.ph1n = flip ? P.psi_h[1] : P.psi_h2[1];
       // an axis without CPML, or one whose recursions stay in the slab kernels, has no members
       const bool in = P.ns > 0 && ((mask >> a) & 1);
       A.lo = in ? P.lo : 0; A.hi0 = in ? P.hi0 : N[a]; A.ns = P.ns; A.n = N[a];
     }
-    if (!h->pml_blk[par] && dev_alloc(h, &h->pml_blk[par], 1, false)) return -1;
-    if (hipMemcpy(h->pml_blk[par], &pm, sizeof(PmlP), hipMemcpyHostToDevice) != hipSuccess)
+    if (!h->pml_blk[mask][par] && dev_alloc(h, &h->pml_blk[mask][par], 1, false)) return -1;
+    if (hipMemcpy(h->pml_blk[mask][par], &pm, sizeof(PmlP), hipMemcpyHostToDevice) != hipSuccess)
       return fail(h, "upload of the CPML parameter block failed");
   }
-  h->pml_parity = 0;
-  h->pml_blk_mask = mask;
+  h->pml_blk_ok[mask] = true;
   return 0;
 }
 
@@ -358,24 +360,30 @@ void swap_psi_h(FdtdSolver* h, int pml_inside) {
   h->pml_parity ^= 1;
 }
 
+// Tile rows: all of them (ty_n < 0) or  [0, ty_a) + [ty_a + ty_gap, ty_a + ty_gap + (ty_n - ty_a)).
+// pml_inside: axes whose CPML recursions this launch carries (its tiles must not touch members of other
+// in-sweep axes): 0 -> plain instantiation, 1 -> the x-only one, anything else -> the all-axes one.
 int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pml_inside = 0, int k2beg = 0,
-                       int k2end = 0) {
+                       int k2end = 0, int ty_n = -1, int ty_a = 0, int ty_gap = 0) {
   if (kend <= kbeg) {                 // first plane range empty: the second one takes its place
     if (k2end <= k2beg) return 0;
     kbeg = k2beg; kend = k2end; k2beg = k2end = 0;
   }
+  if (ty_n == 0) return 0;
   const GridP& g = h->g;
   if (ensure_second_set(h)) return -1;
   if (pml_inside && ensure_pml_blocks(h, pml_inside)) return -1;
   const int R = h->rows_f;
   const int zc = h->zchunk_f;
   dim3 block(64, R + 1, 1);
-  const int nbx = (g.nx + 255) / 256, nby = (g.ny + R - 1) / R, nbz1 = (kend - kbeg + zc - 1) / zc;
+  const int nby_all = (g.ny + R - 1) / R;
+  if (ty_n < 0) { ty_n = nby_all; ty_a = nby_all; ty_gap = 0; }
+  const int nbx = (g.nx + 255) / 256, nby = ty_n, nbz1 = (kend - kbeg + zc - 1) / zc;
   const int nbz = nbz1 + (k2end > k2beg ? (k2end - k2beg + zc - 1) / zc : 0);
   const int total = nbx * nby * nbz;
   const int remap = h->xcd_remap ? 1 : 0;
   dim3 grid(remap ? ((total + 7) / 8) * 8 : total, 1, 1);
-  const size_t shmem = (size_t)2 * 2 * (R + 1) * 64 * sizeof(float4);
+  const size_t shmem = ((size_t)2 * 2 * (R + 1) * 64 + (pml_inside ? 6 * 64 : 0)) * sizeof(float4);   // both CPML instantiations stage the x coefficients
   const int pmc = h->cfg.bc[4] == FDTD_BC_PMC;
   MatP m = mat_params(h);
   StepP s = step_params(h);
@@ -384,12 +392,14 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pm
   int lb = h->fused_lb ? h->fused_lb : (threads <= 256 ? 256 : (threads <= 512 ? 512 : 1024));
   if (lb < threads) lb = threads <= 512 ? 512 : 1024;
   time_begin(h, 2, st);
-  const PmlP* pm = pml_inside ? h->pml_blk[h->pml_parity] : nullptr;
+  const PmlP* pm = pml_inside ? h->pml_blk[pml_inside][h->pml_parity] : nullptr;
 #define FDTD_LAUNCH_FUSED(MATV, LBV, PMLV)                                                            \
   hipLaunchKernelGGL((fused_step_kernel<MATV, LBV, PMLV>), grid, block, shmem, st, g, h->f, h->f2, s, m, kbeg, \
-                     kend, zc, pmc, nbx, nby, nbz, remap, pm, nbz1, k2beg, k2end)
-  // one CPML-carrying instantiation (all axes; axes outside `pml_inside` have no members in the block)
-  if (pml_inside) {
+                     kend, zc, pmc, nbx, nby, nbz, remap, pm, nbz1, k2beg, k2end, ty_a, ty_gap)
+  if (pml_inside == 1) {        // x recursions only: every tile of a grid with x layers
+    if (h->mat4) { if (lb == 256) FDTD_LAUNCH_FUSED(true, 256, 1); else FDTD_LAUNCH_FUSED(true, 512, 1); }
+    else { if (lb == 256) FDTD_LAUNCH_FUSED(false, 256, 1); else FDTD_LAUNCH_FUSED(false, 512, 1); }
+  } else if (pml_inside) {      // all axes (axes outside `pml_inside` have no members in the block)
     if (h->mat4) { if (lb == 256) FDTD_LAUNCH_FUSED(true, 256, 7); else FDTD_LAUNCH_FUSED(true, 512, 7); }
     else { if (lb == 256) FDTD_LAUNCH_FUSED(false, 256, 7); else FDTD_LAUNCH_FUSED(false, 512, 7); }
   } else if (h->mat4) {
@@ -1024,7 +1034,7 @@ int fdtd_set_pml(FdtdSolver* h, int axis, int n_lo, int n_hi, const float* kinv_
     if (P.ns > 0 && dev_alloc(h, &P.psi_h[q], P.psi_count)) return -1;
     P.psi_h2[q] = nullptr;
   }
-  h->pml_blk_mask = -1;          // parameter blocks are rebuilt on next use
+  for (bool& ok : h->pml_blk_ok) ok = false;          // parameter blocks are rebuilt on next use
   return 0;
 }
 
@@ -1495,7 +1505,32 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       launch_pml(h, false, 0, nz, st, 7 & ~pml_in);
       advance_tfsf_aux(h, false, n, st);
       if (h->cfg.bc[4] == FDTD_BC_PERIODIC) fill_ghost_h(h, st);   // ghost(-1) must carry the pre-corrections too
-      if (launch_fused(h, st, pml_in)) return -1;
+      if ((pml_in & 6) == 0) {
+        if (launch_fused(h, st, pml_in)) return -1;
+      } else {
+        // The instantiation that carries the y / z recursions holds their psi values in registers from the
+        // top of a plane (occupancy 2-3); the one most tiles need carries x only.  Three launches over
+        // disjoint tiles, the two small ones on the second stream, concurrent with the big one:
+        //   (1) planes of the z slabs (+1 plane: the next chunk's prologue must not see a slab), all rows   [x y z]
+        //   (2) planes in between: bottom and top tile rows (a row or the halo row in a y slab)              [x y]
+        //   (3) planes in between, middle tile rows                                                         [x]
+        const int R = h->rows_f, nby_all = (h->g.ny + R - 1) / R;
+        const PmlAxisDev &py = h->pml[1], &pz = h->pml[2];
+        const bool in_y = (pml_in & 2) && py.ns > 0, in_z = (pml_in & 4) && pz.ns > 0;
+        const int za = (in_z && pz.lo > 0) ? std::min(nz, pz.lo + 1) : 0;
+        const int zc = (in_z && pz.hi0 < nz) ? std::max(za, pz.hi0) : nz;
+        const int ty_a = (in_y && py.lo > 0) ? std::min(nby_all, py.lo / R + 1) : 0;
+        const int ty_c = (in_y && py.hi0 < h->g.ny) ? std::max(ty_a, py.hi0 / R) : nby_all;
+        HIPCHK(h, hipEventRecord(h->ev_h_int, st));
+        HIPCHK(h, hipStreamWaitEvent(cs, h->ev_h_int, 0));
+        if (launch_fused_range(h, 0, za, cs, pml_in, zc, nz)) return -1;
+        if (launch_fused_range(h, za, zc, cs, pml_in & 3, 0, 0, ty_a + (nby_all - ty_c), ty_a, ty_c - ty_a)) return -1;
+        HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
+        if (launch_fused_range(h, za, zc, st, pml_in & 1, 0, 0, ty_c - ty_a, 0, ty_a)) return -1;
+        HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
+        swap_sets(h);
+        swap_psi_h(h, pml_in);
+      }
       if (rec) record_monitors(h, n, true, st);
       launch_pml(h, true, 0, nz, st, 7 & ~pml_in);
       launch_sources(h, true, n, 0, nz, st);
@@ -1763,7 +1798,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_ZCHUNK: if (value < 1) break; h->zchunk = value; h->zchunk_f = value; h->user_geometry = true; return 0;
     case FDTD_OPT_ROWS: if (value < 1 || value > 15) break; h->rows = value > 8 ? 8 : value; h->rows_f = value; h->user_geometry = true; return 0;
     case FDTD_OPT_XCD_REMAP: h->xcd_remap = value != 0; return 0;
-    case FDTD_OPT_PML_FUSED: h->pml_fused = value < 0 ? -1 : (value & 7); return 0;
+    case FDTD_OPT_PML_FUSED: h->pml_fused = value < 0 ? -1 : (value & 7); for (bool& ok : h->pml_blk_ok) ok = false; return 0;
     case FDTD_OPT_BND_PLANES: h->bnd_planes = value > 0 ? value : 0; return 0;
     case FDTD_OPT_AUTOTUNE: h->autotune = value < 0 ? 0 : (value > 2 ? 1 : value); if (value) h->tuned = false; return 0;
     case FDTD_OPT_FUSED_LB: if (value != 0 && value != 256 && value != 512 && value != 1024) break; h->fused_lb = value; return 0;

@@ -437,11 +437,11 @@ __device__ __forceinline__ void pml_h_apply(float& h1, float& h2, float d1, floa
 // Everything that depends on the row only (threadIdx.y is wave-uniform) is kept in SGPRs.
 // =============================================================================================
 template <bool MAT, int LB, int PML>   // PML: bit a set = CPML of axis a runs inside the sweep
-__global__ __launch_bounds__(LB, (LB == 256 ? (PML ? 3 : 4) : (LB == 512 ? (PML ? 2 : 4) : 4))) void fused_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
+__global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)) : (LB == 512 ? (PML ? 2 : 4) : 4))) void fused_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
                                                           int kbeg, int kend, int zchunk, int pmc_z0,
                                                           int nbx, int nby, int nbz, int xcd_remap,
                                                           const PmlP* __restrict__ pmq,
-                                                          int nbz1, int k2beg, int k2end) {
+                                                          int nbz1, int k2beg, int k2end, int ty_a, int ty_gap) {
   constexpr int V = 4;
   // 1-D launch; logical tile (bx, by, bz) with by fastest.  XCD-aware remap: hardware block L runs
   // on XCD L % 8 (observed dispatch order, used for speed only), so XCD x is handed the contiguous
@@ -454,16 +454,33 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML ? 3 : 4) : (LB == 512 ? (PML 
     t = (t & 7) * per + (t >> 3);
     if (t >= total) return;              // whole workgroup leaves before any barrier
   }
-  const int tile_y = t % nby;
+  // tile rows of this launch: the first ty_a, then (after a gap of ty_gap) the rest — the launch that
+  // carries the y / z recursions covers the bottom and top tile rows only, a leaner one the middle
+  int tile_y = t % nby;
+  if (tile_y >= ty_a) tile_y += ty_gap;
   const int tile_x = (t / nby) % nbx;
   const int tile_z = t / (nby * nbx);
   __shared__ float2 lut_s[MAT ? kMaxMedia : 1];
-  HIP_DYNAMIC_SHARED(float4, xch)      // [2 buffers][2 comps][blockDim.y][64]
+  HIP_DYNAMIC_SHARED(float4, xch)      // [2 buffers][2 comps][blockDim.y][64] (+ [6][64] x-CPML coefficients)
   if constexpr (MAT) {
     for (int q = threadIdx.y * blockDim.x + threadIdx.x; q < m.n_media; q += blockDim.x * blockDim.y)
       lut_s[q] = m.lut[q];
-    __syncthreads();
   }
+  // x-CPML coefficients of the tile's 256 cells {kv_h, b_h, c_h, kv_e, b_e, c_e}: read from LDS where they
+  // are used (24 VGPRs if held, a global round trip if fetched on the spot)
+  [[maybe_unused]] float4* xco = xch + 2 * 2 * blockDim.y * 64;
+  if constexpr ((PML & 1) != 0) {
+    const PmlAxisP& A = pmq->ax[0];
+    const unsigned o = (unsigned)((tile_x * 64 + threadIdx.x) * V) * 4u;
+    for (int q = threadIdx.y; q < 6; q += blockDim.y) {
+      const float* src = q == 0 ? A.kv_h : (q == 1 ? A.b_h : (q == 2 ? A.c_h : (q == 3 ? A.kv_e : (q == 4 ? A.b_e : A.c_e))));
+      float r[V] = {0.f, 0.f, 0.f, 0.f};
+      if ((int)(o / 4u) < g.nx && (A.lo > 0 || A.hi0 < A.n)) ldc4(r, src, o);   // (no tables on an axis without members)
+      float4 t4; t4.x = r[0]; t4.y = r[1]; t4.z = r[2]; t4.w = r[3];
+      xco[q * 64 + threadIdx.x] = t4;
+    }
+  }
+  if constexpr (MAT || (PML & 1) != 0) __syncthreads();
   const int tx = threadIdx.x;
   const int ty = __builtin_amdgcn_readfirstlane((int)threadIdx.y);     // one row per wave
   const int R = blockDim.y - 1;
@@ -511,7 +528,11 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML ? 3 : 4) : (LB == 512 ? (PML 
     sxb = (unsigned)max(sx, 0) * 4u;
     if (xh) sx_m = pml_si(pmq->ax[0], im);
   }
-  if constexpr ((PML & 2) != 0) { if (row_ok) sy = pml_si(pmq->ax[1], j); }
+  [[maybe_unused]] float4 cyh = {0.f, 0.f, 0.f, 0.f}, cye = {0.f, 0.f, 0.f, 0.f};
+  if constexpr ((PML & 2) != 0) {
+    if (row_ok) sy = pml_si(pmq->ax[1], j);
+    if (sy >= 0) { cyh = ldc_f4(pmq->ax[1].ch4 + j); cye = ldc_f4(pmq->ax[1].ce4 + j); }
+  }
 
   float exk[V], eyk[V], hxm[V], hym[V];
   zero<V>(exk); zero<V>(eyk); zero<V>(hxm); zero<V>(hym);
@@ -554,9 +575,11 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML ? 3 : 4) : (LB == 512 ? (PML 
           if constexpr ((PML & 1) != 0) {
             if (sx >= 0) {
               const PmlAxisP& A = pmq->ax[0];
-              float s1[V], kv[V], bb[V], cc[V];
+              float s1[V];
               ldg4(s1, uni(A.ph0 + ((long long)kk * g.ny + j) * A.ns), sxb);
-              ldc4(kv, uni(A.kv_h), ub); ldc4(bb, uni(A.b_h), ub); ldc4(cc, uni(A.c_h), ub);
+              const float4 kv4 = xco[0 * 64 + tx], bb4 = xco[1 * 64 + tx], cc4 = xco[2 * 64 + tx];
+              const float kv[V] = {kv4.x, kv4.y, kv4.z, kv4.w}, bb[V] = {bb4.x, bb4.y, bb4.z, bb4.w},
+                          cc[V] = {cc4.x, cc4.y, cc4.z, cc4.w};
 #pragma unroll
               for (int e = 0; e < V; ++e) {
                 const float ez_ip = (e + 1 < V) ? ezm[(e + 1) % V] : ezx;
@@ -570,7 +593,7 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML ? 3 : 4) : (LB == 512 ? (PML 
           if constexpr ((PML & 2) != 0) {
             if (sy >= 0) {
               const PmlAxisP& A = pmq->ax[1];
-              const float4 cf = ldc_f4(A.ch4 + j);
+              const float4 cf = cyh;
               float s2[V];
               ldg4(s2, uni(A.ph1 + ((long long)kk * A.ns + sy) * g.nx), ub);
 #pragma unroll
@@ -629,6 +652,60 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML ? 3 : 4) : (LB == 512 ? (PML 
       if (!halo) ldv<V>(hyn, at(uni(a.hy + pb), ub));    // the halo wave only publishes H_x and H_z
       ldv<V>(hzn, at(uni(a.hz + pb), ub));
     }
+    // ---- CPML state of this plane: EVERY psi load is issued here, with the field loads, so that ONE memory
+    // round trip per plane covers them.  Loaded where they are used they chain two more round trips per plane
+    // (H side, then E side behind the barrier): +0.63 ms per 512^3 step, worse than the slab kernels
+    // (profiles/r02a_probe_shapes_pml.jsonl).
+    [[maybe_unused]] float xh1[V], xh2[V], xe1[V], xe2[V], yh1[V], yh2[V], ye1[V], ye2[V], zh1[V], zh2[V], ze1[V], ze2[V];
+    // uniform parts of the psi indices (formed outside the lane predicate: they must stay wave-uniform)
+    [[maybe_unused]] long long qx = 0, qy = 0, qz = 0;
+    [[maybe_unused]] int sz = -1;
+    [[maybe_unused]] float4 czh = {0.f, 0.f, 0.f, 0.f}, cze = {0.f, 0.f, 0.f, 0.f};
+    const bool wall_z = (k == 0) && g.pec_z0;
+    if constexpr ((PML & 4) != 0) {
+      sz = pml_si(pmq->ax[2], k);                                 // outside the lane predicate: stays wave-uniform
+      if (sz >= 0) { czh = ldc_f4(pmq->ax[2].ch4 + k); cze = ldc_f4(pmq->ax[2].ce4 + k); }
+      qz = ((long long)max(sz, 0) * g.ny + j) * g.nx;
+    }
+    if constexpr ((PML & 1) != 0) qx = ((long long)k * g.ny + j) * pmq->ax[0].ns;
+    if constexpr ((PML & 2) != 0) qy = ((long long)k * pmq->ax[1].ns + max(sy, 0)) * g.nx;
+    if constexpr (PML != 0) {
+      if (act) {
+        if constexpr ((PML & 1) != 0) {
+          if (sx >= 0) {
+            const PmlAxisP& A = pmq->ax[0];
+            ldg4(xh1, uni(A.ph0 + qx), sxb);
+            ldg4(xh2, uni(A.ph1 + qx), sxb);
+            if (!halo) { ldg4(xe1, uni(A.pe0 + qx), sxb); ldg4(xe2, uni(A.pe1 + qx), sxb); }
+          }
+        }
+        if constexpr ((PML & 2) != 0) {
+          if (sy >= 0) {
+            const PmlAxisP& A = pmq->ax[1];
+            ldg4(yh1, uni(A.ph0 + qy), ub);
+            ldg4(yh2, uni(A.ph1 + qy), ub);
+            if (!halo && !wall_y) { ldg4(ye1, uni(A.pe0 + qy), ub); ldg4(ye2, uni(A.pe1 + qy), ub); }
+          }
+        }
+        if constexpr ((PML & 4) != 0) {
+          if (sz >= 0) {
+            const PmlAxisP& A = pmq->ax[2];
+            ldg4(zh1, uni(A.ph0 + qz), ub);
+            ldg4(zh2, uni(A.ph1 + qz), ub);
+            if (!halo && !wall_z) { ldg4(ze1, uni(A.pe0 + qz), ub); ldg4(ze2, uni(A.pe1 + qz), ub); }
+          }
+        }
+      }
+    }
+    // material row-segment word of this plane (scalar load) and, where the segment is mixed, the packed words
+    [[maybe_unused]] uint32_t rw = kBgWord;
+    [[maybe_unused]] uint32_t mw[V] = {kBgWord, kBgWord, kBgWord, kBgWord};
+    if constexpr (MAT) {
+      if (!halo && row_ok) {
+        rw = m.roww[((long long)k * g.ny + j) * nbx + tile_x];
+        if (rw == kMixedWord && act) ldm<V>(mw, at(uni(m.m4 + pb), ub));
+      }
+    }
     float eyx = __shfl_down(eyk[0], 1);
     float ezx = __shfl_down(ezk[0], 1);
     if (act && (tx == 63 || last_x)) {
@@ -637,59 +714,45 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML ? 3 : 4) : (LB == 512 ? (PML 
       else { eyx = 0.f; ezx = 0.f; }
     }
     // ---- H-side CPML: pre-corrections of H^{n-1/2}, axes in the order x, y, z ----------------
-    [[maybe_unused]] int sz = -1;
-    if constexpr ((PML & 4) != 0) sz = pml_si(pmq->ax[2], k);       // outside the lane predicate: stays wave-uniform
     if constexpr (PML != 0) {
       if (act) {
         // axis x: Hy += ch (kv dEz/dx + p1), Hz -= ch (kv dEy/dx + p2)
         if constexpr ((PML & 1) != 0) {
           if (sx >= 0) {
             const PmlAxisP& A = pmq->ax[0];
-            const long long q = ((long long)k * g.ny + j) * A.ns;            // uniform part of the psi index
-            float s1[V], s2[V], kv[V], bb[V], cc[V];
-            ldg4(s1, uni(A.ph0 + q), sxb);
-            ldg4(s2, uni(A.ph1 + q), sxb);
-            ldc4(kv, uni(A.kv_h), ub); ldc4(bb, uni(A.b_h), ub); ldc4(cc, uni(A.c_h), ub);
+            const float4 kv4 = xco[0 * 64 + tx], bb4 = xco[1 * 64 + tx], cc4 = xco[2 * 64 + tx];
+            const float kv[V] = {kv4.x, kv4.y, kv4.z, kv4.w}, bb[V] = {bb4.x, bb4.y, bb4.z, bb4.w},
+                        cc[V] = {cc4.x, cc4.y, cc4.z, cc4.w};
 #pragma unroll
             for (int e = 0; e < V; ++e) {
               const float ey_ip = (e + 1 < V) ? eyk[(e + 1) % V] : eyx;
               const float ez_ip = (e + 1 < V) ? ezk[(e + 1) % V] : ezx;
-              pml_h_apply(hyn[e], hzn[e], (ey_ip - eyk[e]) * ipx[e], (ez_ip - ezk[e]) * ipx[e], s1[e], s2[e],
+              pml_h_apply(hyn[e], hzn[e], (ey_ip - eyk[e]) * ipx[e], (ez_ip - ezk[e]) * ipx[e], xh1[e], xh2[e],
                           kv[e], bb[e], cc[e], ch);
             }
-            if (!halo) { stg4(uni(A.ph0n + q), sxb, s1); stg4(uni(A.ph1n + q), sxb, s2); }
+            if (!halo) { stg4(uni(A.ph0n + qx), sxb, xh1); stg4(uni(A.ph1n + qx), sxb, xh2); }
           }
         }
         // axis y: Hz += ch (kv dEx/dy + p1), Hx -= ch (kv dEz/dy + p2)
         if constexpr ((PML & 2) != 0) {
           if (sy >= 0) {
             const PmlAxisP& A = pmq->ax[1];
-            const float4 cf = ldc_f4(A.ch4 + j);
-            const long long q = ((long long)k * A.ns + sy) * g.nx;           // uniform part of the psi index
-            float s1[V], s2[V];
-            ldg4(s1, uni(A.ph0 + q), ub);
-            ldg4(s2, uni(A.ph1 + q), ub);
 #pragma unroll
             for (int e = 0; e < V; ++e)
-              pml_h_apply(hzn[e], hxn[e], (ezj[e] - ezk[e]) * ipy, (exj[e] - exk[e]) * ipy, s1[e], s2[e],
-                          cf.x, cf.y, cf.z, ch);
-            if (!halo) { stg4(uni(A.ph0n + q), ub, s1); stg4(uni(A.ph1n + q), ub, s2); }
+              pml_h_apply(hzn[e], hxn[e], (ezj[e] - ezk[e]) * ipy, (exj[e] - exk[e]) * ipy, yh1[e], yh2[e],
+                          cyh.x, cyh.y, cyh.z, ch);
+            if (!halo) { stg4(uni(A.ph0n + qy), ub, yh1); stg4(uni(A.ph1n + qy), ub, yh2); }
           }
         }
         // axis z: Hx += ch (kv dEy/dz + p1), Hy -= ch (kv dEx/dz + p2)
         if constexpr ((PML & 4) != 0) {
-          const PmlAxisP& A = pmq->ax[2];
           if (sz >= 0) {
-            const float4 cf = ldc_f4(A.ch4 + k);
-            const long long q = ((long long)sz * g.ny + j) * g.nx;           // uniform part of the psi index
-            float s1[V], s2[V];
-            ldg4(s1, uni(A.ph0 + q), ub);
-            ldg4(s2, uni(A.ph1 + q), ub);
+            const PmlAxisP& A = pmq->ax[2];
 #pragma unroll
             for (int e = 0; e < V; ++e)
-              pml_h_apply(hxn[e], hyn[e], (exn[e] - exk[e]) * ipz, (eyn[e] - eyk[e]) * ipz, s1[e], s2[e],
-                          cf.x, cf.y, cf.z, ch);
-            if (!halo) { stg4(uni(A.ph0n + q), ub, s1); stg4(uni(A.ph1n + q), ub, s2); }
+              pml_h_apply(hxn[e], hyn[e], (exn[e] - exk[e]) * ipz, (eyn[e] - eyk[e]) * ipz, zh1[e], zh2[e],
+                          czh.x, czh.y, czh.z, ch);
+            if (!halo) { stg4(uni(A.ph0n + qz), ub, zh1); stg4(uni(A.ph1n + qz), ub, zh2); }
           }
         }
       }
@@ -766,7 +829,6 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML ? 3 : 4) : (LB == 512 ? (PML 
       } else {
         zero<V>(hxj); zero<V>(hzj);
       }
-      const bool wall_z = (k == 0) && g.pec_z0;
       float ex[V], ey[V], ez[V];
 #pragma unroll
       for (int e = 0; e < V; ++e) {
@@ -790,11 +852,8 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML ? 3 : 4) : (LB == 512 ? (PML 
         if constexpr ((PML & 2) != 0) {
           if (sy >= 0 && !wall_y) {
             const PmlAxisP& A = pmq->ax[1];
-            const float4 cf = ldc_f4(A.ce4 + j);
-            const long long q = ((long long)k * A.ns + sy) * g.nx;           // uniform part of the psi index
-            float s1[V], s2[V];
-            ldg4(s1, uni(A.pe0 + q), ub);
-            ldg4(s2, uni(A.pe1 + q), ub);
+            const float4 cf = cye;
+            float (&s1)[V] = ye1, (&s2)[V] = ye2;
 #pragma unroll
             for (int e = 0; e < V; ++e) {
               const float d1 = (hzn[e] - hzj[e]) * idy;
@@ -806,19 +865,16 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML ? 3 : 4) : (LB == 512 ? (PML 
               if (!wx) ez[e] -= coef(2, e).y * (cf.x * d2 + p1);       // E_z is tangential to the x wall
               if (!wall_z) ex[e] += coef(0, e).y * (cf.x * d1 + p2);   // E_x is tangential to the z wall
             }
-            stg4(uni(A.pe0 + q), ub, s1);
-            stg4(uni(A.pe1 + q), ub, s2);
+            stg4(uni(A.pe0 + qy), ub, s1);
+            stg4(uni(A.pe1 + qy), ub, s2);
           }
         }
         // axis z: E_x -= cb (kv dHy/dz + p1),  E_y += cb (kv dHx/dz + p2)
         if constexpr ((PML & 4) != 0) {
           if (sz >= 0 && !wall_z) {
             const PmlAxisP& A = pmq->ax[2];
-            const float4 cf = ldc_f4(A.ce4 + k);
-            const long long q = ((long long)sz * g.ny + j) * g.nx;           // uniform part of the psi index
-            float s1[V], s2[V];
-            ldg4(s1, uni(A.pe0 + q), ub);
-            ldg4(s2, uni(A.pe1 + q), ub);
+            const float4 cf = cze;
+            float (&s1)[V] = ze1, (&s2)[V] = ze2;
 #pragma unroll
             for (int e = 0; e < V; ++e) {
               const float d1 = (hxn[e] - hxm[e]) * idz;
@@ -830,19 +886,18 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML ? 3 : 4) : (LB == 512 ? (PML 
               if (!wall_y) ex[e] -= coef(0, e).y * (cf.x * d2 + p1);   // E_x is tangential to the y wall
               if (!wx) ey[e] += coef(1, e).y * (cf.x * d1 + p2);       // E_y is tangential to the x wall
             }
-            stg4(uni(A.pe0 + q), ub, s1);
-            stg4(uni(A.pe1 + q), ub, s2);
+            stg4(uni(A.pe0 + qz), ub, s1);
+            stg4(uni(A.pe1 + qz), ub, s2);
           }
         }
         // axis x: E_y -= cb (kv dHz/dx + p1),  E_z += cb (kv dHy/dx + p2)
         if constexpr ((PML & 1) != 0) {
           if (sx >= 0) {
             const PmlAxisP& A = pmq->ax[0];
-            const long long q = ((long long)k * g.ny + j) * A.ns;            // uniform part of the psi index
-            float s1[V], s2[V], kv[V], bb[V], cc[V];
-            ldg4(s1, uni(A.pe0 + q), sxb);
-            ldg4(s2, uni(A.pe1 + q), sxb);
-            ldc4(kv, uni(A.kv_e), ub); ldc4(bb, uni(A.b_e), ub); ldc4(cc, uni(A.c_e), ub);
+            float (&s1)[V] = xe1, (&s2)[V] = xe2;
+            const float4 kv4 = xco[3 * 64 + tx], bb4 = xco[4 * 64 + tx], cc4 = xco[5 * 64 + tx];
+            const float kv[V] = {kv4.x, kv4.y, kv4.z, kv4.w}, bb[V] = {bb4.x, bb4.y, bb4.z, bb4.w},
+                        cc[V] = {cc4.x, cc4.y, cc4.z, cc4.w};
 #pragma unroll
             for (int e = 0; e < V; ++e) {
               const bool wx = wall_x0 && (e == 0);
@@ -858,8 +913,8 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML ? 3 : 4) : (LB == 512 ? (PML 
                 if (!wall_y) ez[e] += coef(2, e).y * (kv[e] * d1 + p2);     // E_z is tangential to the y wall
               }
             }
-            stg4(uni(A.pe0 + q), sxb, s1);
-            stg4(uni(A.pe1 + q), sxb, s2);
+            stg4(uni(A.pe0 + qx), sxb, s1);
+            stg4(uni(A.pe1 + qx), sxb, s2);
           }
         }
       }
@@ -873,14 +928,11 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML ? 3 : 4) : (LB == 512 ? (PML 
     if (act && !halo) {
       if constexpr (MAT) {
         // one word per row segment (256 cells of one row): the medium word of all its cells when they
-        // agree — then the packed words are not read at all — or kMixedWord
-        const uint32_t rw = m.roww[((long long)k * g.ny + j) * nbx + tile_x];
+        // agree — then the packed words are not read at all — or kMixedWord (both fetched at the top of the plane)
         if (rw != kMixedWord) {
           const float2 c0 = m.lut[rw & 1023u], c1 = m.lut[(rw >> 10) & 1023u], c2 = m.lut[(rw >> 20) & 1023u];
           e_phase([&](int c, int) { return c == 0 ? c0 : (c == 1 ? c1 : c2); });
         } else {
-          uint32_t mw[V];
-          ldm<V>(mw, at(uni(m.m4 + pb), ub));
           e_phase([&](int c, int e) { return lut_s[(mw[e] >> (10 * c)) & 1023u]; });
         }
       } else {
