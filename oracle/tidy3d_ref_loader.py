@@ -109,20 +109,10 @@ def load_tidy3d(numpy1_semantics: bool = True):
             _stub(n)
     _mesher_shims()
     if "xarray" not in sys.modules:
-        xr = types.ModuleType("xarray")
-        xr.__path__ = []
-
-        class DataArray:
-            __slots__ = ()
-
-            def __init__(self, *a, **k):
-                pass
-
-        class Dataset:
-            pass
-        xr.DataArray, xr.Dataset = DataArray, Dataset
-        xr.__getattr__ = lambda name: MagicMock(name=name)
-        sys.modules["xarray"] = xr
+        # a small FUNCTIONAL DataArray (oracle/mini_xarray.py): the reference's data containers and their
+        # validators run on the output of tidy3d_amd.adapter.to_tidy3d (tests/test_adapter_reference.py)
+        from oracle import mini_xarray
+        mini_xarray.install()
     if "autograd" not in sys.modules:
         ag = types.ModuleType("autograd")
         ag.__path__ = []

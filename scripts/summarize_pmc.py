@@ -8,7 +8,7 @@ from collections import defaultdict
 
 root = sys.argv[1]
 out = {}
-for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+for counter in [c for c in sys.argv[2:]] or ("FETCH_SIZE", "WRITE_SIZE"):
     files = glob.glob(os.path.join(root, f"pmc_{counter}", "**", "*counter_collection.csv"), recursive=True)
     acc = defaultdict(lambda: [0.0, 0])
     for f in files:
@@ -16,7 +16,9 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             for row in csv.DictReader(fh):
                 if row.get("Counter_Name") != counter:
                     continue
-                name = row["Kernel_Name"].split("(")[0].replace("void fdtd::", "").split("<")[0]
+                name = row["Kernel_Name"].split("(")[0].replace("void fdtd::", "")
+                if not name.startswith("fused_step_kernel"):       # keep <MAT, launch bounds, CPML axes> of the sweep
+                    name = name.split("<")[0]
                 acc[name][0] += float(row["Counter_Value"])
                 acc[name][1] += 1
     for name, (tot, n) in acc.items():

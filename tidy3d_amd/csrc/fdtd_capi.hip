@@ -132,7 +132,7 @@ struct FdtdSolver {
   int zchunk_f = 16;                 // planes marched per workgroup by the fused sweep
   int rows_f = 3;                    // rows per workgroup of the fused sweep (+1 halo wave = 256 threads:
                                      // ~150 VGPRs without spills, 3 workgroups per CU; measured best, profiles/r01g)
-  int xcd_remap = 1;
+  int xcd_remap = 0;                 // measured r02b: the plain tile order wins once the sweep runs at 4 waves per SIMD (V1: 1.25 vs 1.30 ms)
   int fused_lb = 0;                  // 0 = by workgroup size, else forced __launch_bounds__ variant
   // axis mask of the CPML recursions folded into the fused sweep (single GPU): 0 = slab kernels,
   // 6 = y and z, 7 = all.  Measured on 512^3 + 12-layer PML (profiles/r01h_pml_placement.txt): the

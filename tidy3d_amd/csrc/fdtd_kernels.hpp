@@ -133,6 +133,21 @@ __device__ __forceinline__ void zero(float (&r)[V]) {
   for (int e = 0; e < V; ++e) r[e] = 0.f;
 }
 
+// Registers of lanes that take no part (cells beyond the row end, rows beyond the grid): nothing they hold is
+// ever stored or read by an active lane, so they need no defined value — and no v_mov per plane to give them
+// one (the zero-fills were 32 of the ~200 vector instructions of a plane).
+template <int V>
+__device__ __forceinline__ void unspecified(float (&r)[V]) {
+#if defined(__has_builtin)
+#if __has_builtin(__builtin_nondeterministic_value)
+#pragma unroll
+  for (int e = 0; e < V; ++e) r[e] = __builtin_nondeterministic_value(r[e]);
+  return;
+#endif
+#endif
+  zero<V>(r);
+}
+
 // =============================================================================================
 // K1  H-update:  H -= ch * curl_primal(E)      (one workgroup = ROWS rows x 64*V cells, marched
 //                                               over `zchunk` planes with E_x,E_y carried in
@@ -487,6 +502,7 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
   const int i0 = (tile_x * 64 + tx) * V;
   const unsigned ux = (unsigned)i0;
   const unsigned ub = ux * 4u;            // lane's byte offset along the row: every row access is  uniform base + 32-bit lane offset
+  const unsigned ubc = (i0 < g.nx) ? ub : 0u;   // the same, clamped into the row for loads of idle lanes
   const bool halo = (ty == 0);
   const bool per_x = g.bcx0 == BC_PERIODIC, per_y = g.bcy0 == BC_PERIODIC;
   int j = tile_y * R + ty - 1;
@@ -535,14 +551,12 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
   }
 
   float exk[V], eyk[V], hxm[V], hym[V];
-  zero<V>(exk); zero<V>(eyk); zero<V>(hxm); zero<V>(hym);
+  zero<V>(hxm); zero<V>(hym);
   float exk_m = 0.f;
   {
     const long long p0 = (long long)k0 * g.sxy + rowb;
-    if (act) {
-      ldv<V>(exk, at(uni(a.ex + p0), ub));
-      ldv<V>(eyk, at(uni(a.ey + p0), ub));
-    }
+    ldv<V>(exk, at(uni(a.ex + p0), ubc));
+    ldv<V>(eyk, at(uni(a.ey + p0), ubc));
     if (xh) exk_m = a.ex[p0 + im];
   }
   // ---- prologue: H^{n+1/2}[k0-1] (x, y components) of the own cells --------------------------
@@ -636,22 +650,24 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
   for (int k = k0; k < k1; ++k) {
     const long long pb = (long long)k * g.sxy + rowb;      // scalar
     const long long pjb = (long long)k * g.sxy + rowpb;
+    // Field loads of the plane: unconditional.  Lanes beyond the row end read the row's first cells instead
+    // (ubc), waves beyond the grid read row 0 (j): same cache lines as their neighbours, no bandwidth, no
+    // lane predicate, no per-plane zero-fill of 32 registers; nothing such a lane computes is ever stored.
     float exn[V], eyn[V], ezk[V], exj[V], ezj[V], hxn[V], hyn[V], hzn[V];
-    zero<V>(exn); zero<V>(eyn); zero<V>(ezk); zero<V>(exj); zero<V>(ezj);
-    zero<V>(hxn); zero<V>(hyn); zero<V>(hzn);
     const float ipz = s.ipz[k], idz = s.idz[k];
-    if (act) {
-      ldv<V>(exn, at(uni(a.ex + pb + g.sxy), ub));
-      ldv<V>(eyn, at(uni(a.ey + pb + g.sxy), ub));
-      ldv<V>(ezk, at(uni(a.ez + pb), ub));
-      if (use_jp) {
-        ldv<V>(exj, at(uni(a.ex + pjb), ub));
-        ldv<V>(ezj, at(uni(a.ez + pjb), ub));
-      }
-      ldv<V>(hxn, at(uni(a.hx + pb), ub));
-      if (!halo) ldv<V>(hyn, at(uni(a.hy + pb), ub));    // the halo wave only publishes H_x and H_z
-      ldv<V>(hzn, at(uni(a.hz + pb), ub));
+    ldv<V>(exn, at(uni(a.ex + pb + g.sxy), ubc));
+    ldv<V>(eyn, at(uni(a.ey + pb + g.sxy), ubc));
+    ldv<V>(ezk, at(uni(a.ez + pb), ubc));
+    if (use_jp) {
+      ldv<V>(exj, at(uni(a.ex + pjb), ubc));
+      ldv<V>(ezj, at(uni(a.ez + pjb), ubc));
+    } else {
+      zero<V>(exj); zero<V>(ezj);                // row j+1 beyond a wall: E = 0 there
     }
+    ldv<V>(hxn, at(uni(a.hx + pb), ubc));
+    if (!halo) ldv<V>(hyn, at(uni(a.hy + pb), ubc));      // the halo wave only publishes H_x and H_z
+    else zero<V>(hyn);
+    ldv<V>(hzn, at(uni(a.hz + pb), ubc));
     // ---- CPML state of this plane: EVERY psi load is issued here, with the field loads, so that ONE memory
     // round trip per plane covers them.  Loaded where they are used they chain two more round trips per plane
     // (H side, then E side behind the barrier): +0.63 ms per 512^3 step, worse than the slab kernels
