@@ -301,3 +301,113 @@ def test_mode_solver_data_entry_fits_the_reference_classes(td_ref):
     for k in ("Ex", "Ey", "Ez", "Hx", "Hy", "Hz"):
         assert tuple(arrays[f"/data/0/{k}"].dims) == tuple(DATA_ARRAY_MAP[entry[k]]._dims)
     assert tuple(arrays["/data/0/n_complex"].dims) == tuple(DATA_ARRAY_MAP[entry["n_complex"]]._dims)
+
+
+def test_to_tidy3d_builds_genuine_reference_simulation_data(td_ref, emu_lib):
+    """north_star's literal contract: a real ``tidy3d.Simulation`` in, a real ``tidy3d.SimulationData`` out.
+    The HIP sources run under the CPU emulator; ``adapter.to_tidy3d`` rebuilds the reference's own containers
+    (their pydantic validators run: dims, coords, monitor fields, grid_expanded, symmetry) on a functional
+    xarray stand-in (oracle/mini_xarray.py).  Structure follows the reference's fake backend ``run_emulated``
+    (ref tests/utils.py:880-1035): coords per component, dims order, dtypes, ``final_decay_value`` from the log."""
+    from tidy3d_amd.web import run
+    td = td_ref
+    sim = _sim(td).updated_copy(size=(1.0, 0.8, 0.8), center=(0.2, 0.0, -0.1), structures=[
+        td.Structure(geometry=td.Box(center=(0.2, 0, -0.1), size=(0.3, 0.3, 0.3)), medium=td.Medium(permittivity=2.0))],
+        monitors=[
+        td.FieldMonitor(center=(0.2, 0, -0.1), size=(0.5, 0, 0.5), freqs=[2.4e14, 2.6e14], name="xz"),
+        td.FieldMonitor(center=(0.2, 0, -0.1), size=(0.5, 0.3, 0), freqs=[2.5e14], name="nc", colocate=False, fields=["Ex", "Hz"]),
+        td.FluxMonitor(center=(0.2, 0, -0.3), size=(td.inf, td.inf, 0), freqs=[2.5e14], name="T"),
+        td.FieldTimeMonitor(center=(0.2, 0, 0), size=(0, 0, 0), name="probe", interval=4),
+        td.FluxTimeMonitor(center=(0.2, 0, -0.3), size=(td.inf, td.inf, 0), name="Tt", interval=10),
+        td.PermittivityMonitor(center=(0.2, 0, -0.1), size=(0.5, 0, 0.5), freqs=[2.4e14], name="eps")],
+        sources=[td.PointDipole(center=(0.3, 0.1, 0.0), source_time=td.GaussianPulse(freq0=2.5e14, fwidth=3e13),
+                                polarization="Ey")],
+        grid_spec=td.GridSpec.uniform(dl=0.05), shutoff=1e-5)
+    out = run(sim, task_name="td", verbose=False, lib=emu_lib, n_steps=120)        # tidy3d in -> tidy3d out by default
+    assert isinstance(out, td.SimulationData) and out.simulation == sim
+    assert [type(d).__name__ for d in out.data] == ["FieldData", "FieldData", "FluxData", "FieldTimeData", "FluxTimeData",
+                                                    "PermittivityData"]
+    assert [d.monitor for d in out.data] == list(sim.monitors)
+    # coordinates exactly as the reference's discretisation says (run_emulated builds them the same way)
+    for name in ("xz", "nc"):
+        mon = [m for m in sim.monitors if m.name == name][0]
+        grid = sim.discretize_monitor(mon)
+        for fld, arr in out[name].field_components.items():
+            assert arr.dims == ("x", "y", "z", "f") and arr.dtype == np.complex64
+            if mon.colocate:
+                for d in "xyz":
+                    want = getattr(grid.boundaries, d)[:-1] if mon.size["xyz".index(d)] > 0 else [mon.center["xyz".index(d)]]
+                    np.testing.assert_allclose(arr.coords[d].values, want, atol=1e-12)
+            else:
+                yee = grid[fld]
+                for d in "xyz":
+                    if mon.size["xyz".index(d)] > 0:
+                        np.testing.assert_allclose(arr.coords[d].values, getattr(yee, d), atol=1e-12)
+            np.testing.assert_allclose(arr.coords["f"].values, mon.freqs)
+            assert arr.attrs.get("long_name") and arr.coords["x"].attrs.get("units") == "um"
+        ge = out[name].grid_expanded
+        for d in "xyz":
+            np.testing.assert_allclose(getattr(ge.boundaries, d), getattr(grid.boundaries, d), atol=1e-12)
+    assert out["T"].flux.dims == ("f",) and np.isfinite(out["T"].flux.values).all()
+    assert out["probe"].Ey.dims == ("x", "y", "z", "t") and out["probe"].Ey.dtype == np.float32
+    assert out["Tt"].flux.dims == ("t",)
+    assert np.abs(out["xz"].Ey.values).max() > 0
+    # the reference's own accessors work on it
+    assert 0 < out.final_decay_value <= 1.0
+    assert out.monitor_data["T"].monitor == out["T"].monitor
+    np.testing.assert_allclose(out["eps"].eps_xx.values.real.max(), 2.0, rtol=1e-6)
+    # the same numbers as the mirror containers hold
+    mirror = run(sim, task_name="td", verbose=False, lib=emu_lib, n_steps=120, return_tidy3d=False)
+    np.testing.assert_array_equal(out["xz"].Ey.values, mirror["xz"].Ey.values)
+    np.testing.assert_array_equal(out["T"].flux.values, mirror["T"].flux.values)
+
+
+def test_install_routes_tidy3d_web_run(td_ref, emu_lib):
+    """``adapter.install`` swaps ``tidy3d.web.run`` for the local solver (the seam the reference's tests use for
+    run_emulated, ref tests/test_plugins/test_adjoint.py:95)."""
+    import functools
+    from tidy3d_amd import adapter, web
+    import types
+    td = td_ref
+    if not hasattr(td, "web"):          # the cloud client does not import here (boto3 / requests stack stubbed away)
+        td.web = types.SimpleNamespace(run=None, Job=None, Batch=None)
+    saved = (td.web.run, getattr(td.web, "Job", None), getattr(td.web, "Batch", None))
+    try:
+        adapter.install(td)
+        assert td.web.run is web.run
+        sim = _sim(td).updated_copy(size=(0.8, 0.6, 0.6), structures=[], grid_spec=td.GridSpec.uniform(dl=0.05), monitors=[
+            td.FluxMonitor(center=(0.2, 0, -0.3), size=(td.inf, td.inf, 0), freqs=[2.5e14], name="T")],
+            sources=[td.PointDipole(center=(0.3, 0.1, 0.0), source_time=td.GaussianPulse(freq0=2.5e14, fwidth=3e13),
+                                    polarization="Ey")])
+        out = functools.partial(td.web.run, lib=emu_lib, n_steps=40)(sim, task_name="x", verbose=False)
+        assert isinstance(out, td.SimulationData) and out["T"].flux.dims == ("f",)
+    finally:
+        td.web.run, td.web.Job, td.web.Batch = saved
+
+
+def test_to_tidy3d_projection_data(td_ref, emu_lib, monkeypatch):
+    """The three field-projection containers are accepted by the reference's own classes (a run that ends in
+    Tidy3dNotImplementedError after the solve would throw the results away)."""
+    from tidy3d_amd.web import run
+    from tidy3d.components.scene import Scene
+    td = td_ref
+    # the reference's "projection monitor lies in a homogeneous medium" validator intersects shapely shapes, which
+    # are inert stubs in this container: answer it directly (vacuum everywhere in this simulation)
+    monkeypatch.setattr(Scene, "intersecting_media", staticmethod(lambda test_object, structures: {td.Medium()}))
+    pulse = td.GaussianPulse(freq0=2.5e14, fwidth=3e13)
+    far = dict(center=(0, 0, 0), size=(0.6, 0.6, 0.6), freqs=[2.5e14])
+    sim = td.Simulation(
+        size=(1.2, 1.2, 1.2), grid_spec=td.GridSpec.uniform(dl=0.06), run_time=1e-13,
+        sources=[td.PointDipole(center=(0, 0, 0), source_time=pulse, polarization="Ez")],
+        monitors=[td.FieldProjectionAngleMonitor(name="ang", theta=[0.3, 1.2], phi=[0.0, 1.0], **far),
+                  td.FieldProjectionCartesianMonitor(name="car", x=[-1.0, 1.0], y=[0.5], proj_axis=2, proj_distance=50.0, **far),
+                  td.FieldProjectionKSpaceMonitor(name="ksp", ux=[-0.2, 0.3], uy=[0.1], proj_axis=2, **far)],
+        boundary_spec=td.BoundarySpec.all_sides(td.PML(num_layers=4)))
+    out = run(sim, task_name="proj", verbose=False, lib=emu_lib, n_steps=50)
+    assert isinstance(out, td.SimulationData)
+    assert [type(d).__name__ for d in out.data] == ["FieldProjectionAngleData", "FieldProjectionCartesianData",
+                                                    "FieldProjectionKSpaceData"]
+    assert out["ang"].Etheta.dims == ("r", "theta", "phi", "f")
+    assert out["car"].Ephi.dims == ("x", "y", "z", "f")
+    assert out["ksp"].Er.dims == ("ux", "uy", "r", "f")
+    assert np.abs(out["ang"].Etheta.values).max() > 0

@@ -12,9 +12,10 @@ tests/utils.py:880-1035: ``symmetry=(0,0,0)``, ``symmetry_center=simulation.cent
 component with coords (x, y, z, f|t)), so everything downstream of ``web.run`` (plugins,
 ``FieldData.dot``, ``.flux``, ``to_file``) works on our results unchanged.
 
-tidy3d is not importable in the build container nor on the GPU box (h5py, xarray, shapely,
-autograd missing), so this module is exercised for real only on hosts that have it; the mirror
-path it wraps is what the test-suite covers.
+tidy3d itself is not installed in the build container nor on the GPU box (h5py, xarray, shapely,
+autograd missing).  tests/test_adapter_reference.py runs this module against the reference checkout
+(/root/reference) with a functional xarray stand-in: the reference's own container classes and their
+validators accept what ``to_tidy3d`` builds, for every monitor-data type converted below.
 """
 from __future__ import annotations
 
@@ -85,11 +86,14 @@ def to_tidy3d(sim_data: SimulationData, td_simulation=None):
                 amps=td.ModeAmpsDataArray(d.amps.values, coords={dim: d.amps.coords[dim] for dim in d.amps.dims}),
                 n_complex=td.ModeIndexDataArray(d.n_complex.values,
                                                 coords={dim: d.n_complex.coords[dim] for dim in d.n_complex.dims})))
-        elif type(d).__name__ == "FieldProjectionAngleData":
-            comps = {k: td.FieldProjectionAngleDataArray(v.values, coords={dim: v.coords[dim] for dim in v.dims})
+        elif type(d).__name__ in ("FieldProjectionAngleData", "FieldProjectionCartesianData", "FieldProjectionKSpaceData"):
+            # the three projection containers differ in their coordinates only (r, theta, phi | x, y, z | ux, uy, r)
+            kind = type(d).__name__[len("FieldProjection"):-len("Data")]
+            arr_cls = getattr(td, f"FieldProjection{kind}DataArray")
+            comps = {k: arr_cls(v.values, coords={dim: v.coords[dim] for dim in v.dims})
                      for k, v in d.field_components.items()}
-            out.append(td.FieldProjectionAngleData(monitor=mon, projection_surfaces=mon.projection_surfaces,
-                                                   medium=mon.medium or td_simulation.medium, **comps))
+            out.append(getattr(td, type(d).__name__)(monitor=mon, projection_surfaces=mon.projection_surfaces,
+                                                     medium=mon.medium or td_simulation.medium, **comps))
         elif type(d).__name__ == "ModeSolverData":
             comps = {k: td.ScalarModeFieldDataArray(v.values, coords={dim: v.coords[dim] for dim in v.dims})
                      for k, v in d.field_components.items()}

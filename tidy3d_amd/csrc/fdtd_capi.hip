@@ -132,7 +132,10 @@ struct FdtdSolver {
   int zchunk_f = 16;                 // planes marched per workgroup by the fused sweep
   int rows_f = 3;                    // rows per workgroup of the fused sweep (+1 halo wave = 256 threads:
                                      // ~150 VGPRs without spills, 3 workgroups per CU; measured best, profiles/r01g)
-  int xcd_remap = 0;                 // measured r02b: the plain tile order wins once the sweep runs at 4 waves per SIMD (V1: 1.25 vs 1.30 ms)
+  // XCD-aware tile order (fdtd_kernels.hpp): -1 = automatic.  Same-box A/B, 512^3 (profiles/r02e_probe_ab_same_box.jsonl):
+  // a sweep that goes out as ONE launch gains from it (V0 1.170 vs 1.249 ms, V1 1.209 vs 1.226), the three
+  // concurrent launches of a CPML-carrying step lose (V2 1.625 vs 1.513 ms) -> on for whole-grid launches only.
+  int xcd_remap = -1;
   int fused_lb = 0;                  // 0 = by workgroup size, else forced __launch_bounds__ variant
   // axis mask of the CPML recursions folded into the fused sweep (single GPU): 0 = slab kernels,
   // 6 = y and z, 7 = all.  Measured on 512^3 + 12-layer PML (profiles/r01h_pml_placement.txt): the
@@ -381,7 +384,8 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pm
   const int nbx = (g.nx + 255) / 256, nby = ty_n, nbz1 = (kend - kbeg + zc - 1) / zc;
   const int nbz = nbz1 + (k2end > k2beg ? (k2end - k2beg + zc - 1) / zc : 0);
   const int total = nbx * nby * nbz;
-  const int remap = h->xcd_remap ? 1 : 0;
+  const bool whole = ty_gap == 0 && ty_n == nby_all && k2end <= k2beg;
+  const int remap = h->xcd_remap < 0 ? (whole ? 1 : 0) : (h->xcd_remap ? 1 : 0);
   dim3 grid(remap ? ((total + 7) / 8) * 8 : total, 1, 1);
   const size_t shmem = ((size_t)2 * 2 * (R + 1) * 64 + (pml_inside ? 6 * 64 : 0)) * sizeof(float4);   // both CPML instantiations stage the x coefficients
   const int pmc = h->cfg.bc[4] == FDTD_BC_PMC;
@@ -1797,7 +1801,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_VARIANT: h->cfg.variant = value; return 0;
     case FDTD_OPT_ZCHUNK: if (value < 1) break; h->zchunk = value; h->zchunk_f = value; h->user_geometry = true; return 0;
     case FDTD_OPT_ROWS: if (value < 1 || value > 15) break; h->rows = value > 8 ? 8 : value; h->rows_f = value; h->user_geometry = true; return 0;
-    case FDTD_OPT_XCD_REMAP: h->xcd_remap = value != 0; return 0;
+    case FDTD_OPT_XCD_REMAP: h->xcd_remap = value < 0 ? -1 : (value != 0); return 0;
     case FDTD_OPT_PML_FUSED: h->pml_fused = value < 0 ? -1 : (value & 7); for (bool& ok : h->pml_blk_ok) ok = false; return 0;
     case FDTD_OPT_BND_PLANES: h->bnd_planes = value > 0 ? value : 0; return 0;
     case FDTD_OPT_AUTOTUNE: h->autotune = value < 0 ? 0 : (value > 2 ? 1 : value); if (value) h->tuned = false; return 0;
