@@ -309,12 +309,14 @@ def test_config3_si_strip_waveguide_mode_launch(hip_lib):
         raw = e.results()
     t2 = time.time()
     sd = assemble(disc, raw, log="")
-    neff = list(disc.mode_planes.values())[0].result.n_complex[0].real
+    src_plane = list(disc.mode_planes.values())[0]
+    beta = src_plane.beta[0].real                   # propagation constant of the mode ON THE GRID (modesource.mode_profile)
+    neff = beta * C_0 / (2 * np.pi * f0)
     fwd, bwd = float(sd["fwd"].flux.values[0]), float(sd["bwd"].flux.values[0])
     a = sd["mm"].amps.values
-    purity = abs(a[0, 0, 0]) ** 2 / fwd
+    # power found in the CPU eigenmode / total power through the same plane, both as the monitors measure them
+    purity = abs(a[0, 0, 0]) ** 2 * float(sd["mm"].mode_power.values[0, 0, 0]) / fwd
     dphi = np.angle(sd["p2"].Ex.values.ravel()[0] / sd["p1"].Ex.values.ravel()[0])
-    beta = 2 * np.pi * f0 / C_0 * neff
     dphi_ref = np.angle(np.exp(1j * beta * 1.0))
     print(f"\n[config3] setup {t1 - t0:.1f}s solve {t2 - t1:.1f}s ({st.steps_done} steps, "
           f"{disc.spec.n_cells * st.steps_done / (st.run_ms * 1e-3) / 1e6:.0f} Mcells/s) neff={neff:.6f} "
@@ -322,10 +324,13 @@ def test_config3_si_strip_waveguide_mode_launch(hip_lib):
           f"dphi={dphi:.5f} vs {dphi_ref:.5f}")
     assert not st.diverged
     assert 0.985 < fwd < 1.002                 # 1 W launched (x colocation factor of the flux measurement)
-    assert abs(bwd) < 1e-5                     # one-way launch: backward power below -50 dB
-    # the propagating FDTD field vs the (continuous-z) eigenmode: 1 - purity ~ (beta dl)^2 / 12 ~ 5e-4
-    assert abs(1 - purity) < 1e-3
-    assert abs(np.angle(np.exp(1j * (dphi - dphi_ref)))) < 0.02      # beta of the FDTD mode vs the eigenvalue
+    assert abs(bwd) < 1e-6                     # one-way launch: backward power below -60 dB
+    # north_star: "injected mode vs CPU ModeSolver to 1e-5" — the field 6.5 um downstream is the eigenmode:
+    # all but 1e-5 of the power through the plane is found in it (k = 1; fp32 solve, 9000 steps)
+    assert abs(1 - purity) < 1e-5
+    assert abs(a[1, 0, 0]) ** 2 < 1e-6         # nothing comes back from the far end
+    # phase advance over 1 um between two probes vs the propagation constant the grid dispersion predicts
+    assert abs(np.angle(np.exp(1j * (dphi - dphi_ref)))) < 2e-3
 
 
 def test_config5_au_nanoparticle_array_1024x1024x256(hip_lib):

@@ -315,3 +315,48 @@ def test_mode_solver_monitor_through_run(emu_lib, tmp_path):
     assert entry["type"] == "ModeSolverData" and entry["Ex"] == "ScalarModeFieldDataArray" and entry["n_complex"] == "ModeIndexDataArray"
     back = load(path)["modes"]
     assert np.array_equal(back.Hz.values, md.Hz.values) and np.array_equal(back.n_complex.values, md.n_complex.values)
+
+
+def test_mode_launch_and_readback_on_the_oracle():
+    """ModeSource -> ModeMonitor through the fp64 oracle at a coarse grid (lambda/16 in the core): the mode is
+    launched with the grid's own dispersion (modesource.mode_profile(grid_dispersion=True)) and read back with the
+    reference's grid correction.  All but 5e-5 of the power through the far plane is in the eigenmode, -50 dB goes
+    backwards, and the phase advance between two planes follows the GRID's propagation constant
+    (2/dz) asin(.) — the continuum one is 0.07 rad per um off at this resolution."""
+    import tidy3d_amd.schema as td
+    from oracle.fdtd_numpy import OracleFdtd
+    from tidy3d_amd.constants import C_0
+    from tidy3d_amd.data import assemble
+    from tidy3d_amd.discretize import discretize
+    f0 = C_0 / 1.55
+    pulse = td.GaussianPulse(freq0=f0, fwidth=f0 / 10)
+    plane = (td.inf, td.inf, 0)
+    sim = td.Simulation(
+        size=(1.44, 1.04, 2.4), grid_spec=td.GridSpec.uniform(dl=0.04), run_time=1.2e-13,
+        medium=td.Medium(permittivity=1.44 ** 2),
+        structures=[td.Structure(geometry=td.Box(center=(0, 0, 0), size=(0.44, 0.24, td.inf)),
+                                 medium=td.Medium(permittivity=3.48 ** 2))],
+        sources=[td.ModeSource(center=(0, 0, -0.8), size=plane, source_time=pulse, direction="+",
+                               mode_spec=td.ModeSpec(num_modes=1), mode_index=0)],
+        monitors=[td.FluxMonitor(center=(0, 0, 0.6), size=plane, freqs=[f0], name="fwd"),
+                  td.FluxMonitor(center=(0, 0, -1.0), size=plane, freqs=[f0], name="bwd"),
+                  td.ModeMonitor(center=(0, 0, 0.6), size=plane, freqs=[f0], mode_spec=td.ModeSpec(num_modes=1), name="mm"),
+                  td.FieldMonitor(center=(0, 0, -0.2), size=(0, 0, 0), freqs=[f0], name="p1", fields=["Ex"]),
+                  td.FieldMonitor(center=(0, 0, 0.4), size=(0, 0, 0), freqs=[f0], name="p2", fields=["Ex"])],
+        boundary_spec=td.BoundarySpec.all_sides(td.PML(num_layers=8)), shutoff=1e-6, subpixel=False)
+    disc = discretize(sim)
+    o = OracleFdtd(disc.spec)
+    sd = assemble(disc, o.run(), log="")
+    src_plane = list(disc.mode_planes.values())[0]
+    fwd, bwd = float(sd["fwd"].flux.values[0]), float(sd["bwd"].flux.values[0])
+    a = sd["mm"].amps.values
+    purity = abs(a[0, 0, 0]) ** 2 * float(sd["mm"].mode_power.values[0, 0, 0]) / fwd
+    assert abs(1 - purity) < 5e-5, purity
+    assert abs(bwd) < 1e-5 and abs(a[1, 0, 0]) ** 2 < 1e-6       # -50 dB behind the source (8 PML layers, 0.4 um away)
+    assert 0.95 < fwd < 1.0
+    dphi = np.angle(sd["p2"].Ex.values.ravel()[0] / sd["p1"].Ex.values.ravel()[0])
+    beta_grid = src_plane.beta[0].real
+    beta_cont = 2 * np.pi * f0 / C_0 * float(np.real(sd["mm"].n_complex.values[0, 0]))
+    err_grid = abs(np.angle(np.exp(1j * (dphi - beta_grid * 0.6))))
+    err_cont = abs(np.angle(np.exp(1j * (dphi - beta_cont * 0.6))))
+    assert err_grid < 2e-3 and err_cont > 10 * err_grid, (err_grid, err_cont)

@@ -39,6 +39,15 @@ class ModePlane:
     lo: Tuple[int, int]          # first cell of the window along (u, v)
     hi: Tuple[int, int]
     result: ModeResult
+    # propagation constants [rad/um] of the modes ON THE GRID when the plane was solved with the grid's own
+    # dispersion (``grid_dispersion``), else the continuum values 2 pi f n / c
+    beta: np.ndarray = None
+
+
+def grid_frequency(freq: float, dt: float) -> float:
+    """The frequency the leapfrog scheme really applies to a field oscillating at ``freq``: its time
+    difference is -i w~ with  w~ = (2/dt) sin(w dt/2)."""
+    return float(np.sin(np.pi * freq * dt) / (np.pi * dt))
 
 
 def _eps_plane(spec: SolverSpec, comp_axis: int, p: int, k: int, lo, hi, u: int, v: int, freq: float):
@@ -61,9 +70,18 @@ def _eps_plane(spec: SolverSpec, comp_axis: int, p: int, k: int, lo, hi, u: int,
     return eps_tab[m]
 
 
-def mode_profile(spec: SolverSpec, box: td.Box, mode_spec, freq: float, symmetry=(0, 0, 0)) -> ModePlane:
+def mode_profile(spec: SolverSpec, box: td.Box, mode_spec, freq: float, symmetry=(0, 0, 0),
+                 grid_dispersion: bool = False) -> ModePlane:
     """Solve the cross-section eigenproblem on the plane of ``box`` (one zero-size dimension).
-    ``symmetry``: the simulation's symmetry — a plane edge lying on a symmetry plane gets no PML."""
+    ``symmetry``: the simulation's symmetry — a plane edge lying on a symmetry plane gets no PML.
+
+    ``grid_dispersion``: solve for the mode AS THE YEE GRID PROPAGATES IT.  A field ~ exp(i (beta w - omega t))
+    sampled on the staggered grid obeys the same six curl equations with the derivative along w replaced by
+    i b~, b~ = (2/dw) sin(beta dw/2), and the time derivative by -i w~, w~ = (2/dt) sin(omega dt/2) (phasors taken
+    at each component's own staggered position and time).  So the cross-section problem is solved at k0~ = w~/c;
+    its eigenvalue is b~^2, its eigenvector the E/H profile with the impedance the grid supports, and
+    beta = (2/dw) asin(b~ dw/2).  A source built from it launches no backward wave to order (beta dw)^2
+    (the continuum mode leaves an impedance mismatch of (beta dw)^2/24, -75 dB at 24 cells per wavelength)."""
     zd = [a for a in range(3) if box.size[a] == 0]
     if len(zd) != 1:
         raise SetupError("a mode plane needs exactly one zero-size dimension")
@@ -92,7 +110,8 @@ def mode_profile(spec: SolverSpec, box: td.Box, mode_spec, freq: float, symmetry
     # a plane that reaches a PMC wall of the grid (a symmetry plane with eigenvalue +1) gets the PMC
     # edge there; PEC walls / the plane's own truncation are the solver's default (ref solver.py:182-197)
     pmc_min = tuple(bool(lo[i] == 0 and spec.bc[a][0] == BC_PMC) for i, a in enumerate((u, v)))
-    res = solve_modes(eps_u, eps_v, eps_w, ub, vb, freq, num_modes=int(mode_spec.num_modes),
+    f_solve = grid_frequency(freq, spec.dt) if grid_dispersion else freq
+    res = solve_modes(eps_u, eps_v, eps_w, ub, vb, f_solve, num_modes=int(mode_spec.num_modes),
                       target_neff=mode_spec.target_neff,
                       precision=getattr(mode_spec, "precision", "single") or "single", pmc_min=pmc_min,
                       num_pml=tuple(int(n) for n in (getattr(mode_spec, "num_pml", (0, 0)) or (0, 0))),
@@ -116,7 +135,13 @@ def mode_profile(spec: SolverSpec, box: td.Box, mode_spec, freq: float, symmetry
             order = np.concatenate((np.where(te_frac <= 0.5)[0], np.where(te_frac > 0.5)[0]))
         res = type(res)(n_complex=res.n_complex[order], **{k: getattr(res, k)[:, :, order]
                                                            for k in ("Eu", "Ev", "Ew", "Hu", "Hv", "Hw")})
-    return ModePlane(p=p, u=u, v=v, k0=k0, lo=lo, hi=hi, result=res)
+    if grid_dispersion:
+        dw = float(spec.dual_steps(p)[k0])                       # spacing of the H planes either side of the plane
+        b_tilde = res.n_complex * (2 * np.pi * f_solve / C_0)
+        beta = (2.0 / dw) * np.arcsin(b_tilde * dw / 2.0 + 0j)
+    else:
+        beta = res.n_complex * (2 * np.pi * freq / C_0)
+    return ModePlane(p=p, u=u, v=v, k0=k0, lo=lo, hi=hi, result=res, beta=beta)
 
 
 def build_mode_source(disc, mt, src) -> Callable:
@@ -124,14 +149,16 @@ def build_mode_source(disc, mt, src) -> Callable:
     st = src.source_time
     if int(getattr(src, "num_freqs", 1)) != 1:
         raise Tidy3dNotImplementedError("ModeSource.num_freqs > 1 (broadband profile) is not supported")
-    plane = mode_profile(spec, src.geometry, src.mode_spec, st.freq0, getattr(sim, "_symmetry", (0, 0, 0)))
+    # the launched profile, its E / H ratio and the half-cell phase are those of the mode the grid carries
+    plane = mode_profile(spec, src.geometry, src.mode_spec, st.freq0, getattr(sim, "_symmetry", (0, 0, 0)),
+                         grid_dispersion=bool(getattr(disc, "mode_grid_dispersion", True)))
     p, u, v, k0 = plane.p, plane.u, plane.v, plane.k0
     r = plane.result
     mi = int(src.mode_index)
     if mi >= len(r.n_complex):
         raise SetupError("mode_index exceeds mode_spec.num_modes")
     direction = 1 if src.direction == "+" else -1
-    beta = 2 * np.pi * st.freq0 / C_0 * r.n_complex[mi]
+    beta = plane.beta[mi]
     big = 10 ** 9
     lo, hi = [-big] * 3, [big] * 3
     if direction > 0:
@@ -222,10 +249,32 @@ def overlap(a: Dict[str, np.ndarray], b: Dict[str, np.ndarray], w: np.ndarray) -
 class ModeData:
     """Mirror of tidy3d ModeData (ref monitor_data.py:1223): complex amplitudes of the forward (+)
     and backward (-) modes, ``amps`` dims (direction, f, mode_index); ``n_complex`` (f, mode_index).
-    Modes are normalised to unit directed flux, amps = (mode, field)/(mode, mode) (CHANGELOG:534-538)."""
+    Modes are normalised to unit directed flux, amps = (mode, field)/(mode, mode) (CHANGELOG:534-538).
+    ``mode_power`` (not part of the reference's container): the flux (mode, mode) a unit-amplitude mode carries
+    AS THIS MONITOR MEASURES IT — on fields colocated to the plane like the monitor data — so that
+    |amps|^2 mode_power is directly comparable with a FluxMonitor on the same plane."""
     monitor: object
     amps: object = None
     n_complex: object = None
+    mode_power: object = None
+
+
+def grid_correction(spec: SolverSpec, p: int, pos: float, beta) -> Tuple[complex, complex]:
+    """Factors that bring a mode given on the plane ``pos`` to what a monitor records there (the reference's
+    ``ModeSolver._grid_correction``, ref plugins/mode/mode_solver.py:847-904): monitor fields are linear
+    interpolations between the grid planes that carry tangential E (cell boundaries along the normal axis p)
+    resp. tangential H (cell centres); a field ~ exp(i beta w) interpolated that way is multiplied by the
+    interpolated phase — cos(beta dw/2) for H on a uniform grid when the plane sits on a cell boundary."""
+    b = np.asarray(spec.boundaries[p], float)
+    c = 0.5 * (b[1:] + b[:-1])
+    out = []
+    for nodes in (b, c):
+        if len(nodes) < 2:
+            out.append(1.0 + 0j)
+            continue
+        ph = np.exp(1j * beta * (nodes - pos))
+        out.append(complex(np.interp(pos, nodes, ph.real) + 1j * np.interp(pos, nodes, ph.imag)))
+    return out[0], out[1]
 
 
 def mode_monitor_data(disc, plan, raw, norm):
@@ -281,7 +330,9 @@ def mode_monitor_data(disc, plan, raw, norm):
     w = _diff_area(box, None, None, p, gu, gv)
     nm = int(mon.mode_spec.num_modes)
     amps = np.zeros((2, len(freqs), nm), complex)
+    power = np.zeros((2, len(freqs), nm))
     neff = np.zeros((len(freqs), nm), complex)
+    pos = float(box.center[p])
     for i, f in enumerate(freqs):
         plane = mode_profile(spec, box, mon.mode_spec, float(f), sym)
         neff[i] = plane.result.n_complex
@@ -289,8 +340,12 @@ def mode_monitor_data(disc, plan, raw, norm):
         for m in range(nm):
             for d_i, direction in enumerate((1, -1)):
                 M = zero_on_walls(colocated_mode(plane, spec, m, direction, gu, gv))
-                amps[d_i, i, m] = amp_scale * overlap(M, Ff, w) / overlap(M, M, w)
-    return ModeData(monitor=mon,
-                    amps=DataArray(amps.astype(np.complex64), {"direction": np.array(["+", "-"]), "f": freqs,
-                                                               "mode_index": np.arange(nm)}),
-                    n_complex=DataArray(neff, {"f": freqs, "mode_index": np.arange(nm)}))
+                ce, chh = grid_correction(spec, p, pos, direction * plane.beta[m])
+                M = {k: a * (ce if k[0] == "E" else chh) for k, a in M.items()}
+                mm = overlap(M, M, w)
+                amps[d_i, i, m] = amp_scale * overlap(M, Ff, w) / mm
+                power[d_i, i, m] = mm.real / amp_scale ** 2
+    coords = {"direction": np.array(["+", "-"]), "f": freqs, "mode_index": np.arange(nm)}
+    return ModeData(monitor=mon, amps=DataArray(amps.astype(np.complex64), coords),
+                    n_complex=DataArray(neff, {"f": freqs, "mode_index": np.arange(nm)}),
+                    mode_power=DataArray(power, coords))
