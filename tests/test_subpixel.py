@@ -62,10 +62,10 @@ def test_modes_and_scope():
         assert 0 < changed.mean() < 0.2                         # interface nodes only
         assert np.all((ep[changed] > 1.0) & (ep[changed] < 4.0))  # strictly between the two media
         # harmonic-weighted (polarised) never exceeds the arithmetic (volumetric) average
-        assert np.all(ep <= ev * (1 + 0.016))
+        assert np.all(ep <= ev * (1 + 0.0025))                  # (0.2 % quantisation steps of the 10-bit material table)
         # the volume average conserves  int (eps - 1) dV  to the quantisation error
         exact = 3.0 * 4 / 3 * np.pi * 0.3 ** 3
-        assert (ev - 1).sum() * 0.05 ** 3 == pytest.approx(exact, rel=0.01)
+        assert (ev - 1).sum() * 0.05 ** 3 == pytest.approx(exact, rel=0.003)
     # lossy, dispersive and PEC interfaces keep the staircase rule (ref subpixel_spec.py:131-137)
     for med in (td.Medium(permittivity=4.0, conductivity=0.1), td.Lorentz(eps_inf=2.0, coeffs=[(1.5, 4e14, 3e13)]),
                 td.PECMedium()):

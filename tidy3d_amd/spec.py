@@ -153,7 +153,7 @@ class SolverSpec:
     bc: Tuple[Tuple[int, int], ...] = ((0, 0), (0, 0), (0, 0))   # [axis][minus, plus]
     pml: Tuple[Tuple[PmlFace, PmlFace], ...] = None
     media: List[MediumCoeffs] = field(default_factory=list)      # [0] = PEC, [1] = background
-    mat_idx: Optional[np.ndarray] = None                # uint8 [3, nz, ny, nx]; None = all [1]
+    mat_idx: Optional[np.ndarray] = None                # uint16 [3, nz, ny, nx] (< 1024); None = all [1]
     sources: List[PointSourceSet] = field(default_factory=list)
     tfsf: List[TfsfSpec] = field(default_factory=list)
     monitors: List[MonitorSpec] = field(default_factory=list)
