@@ -100,11 +100,11 @@ def cpu_baseline(n: int = 320, steps: int = 18):
 
 
 def source_hash() -> str:
-    """sha256 over the kernel sources: ties a PMC traffic figure to the code it was measured on."""
+    """sha256 over the kernel source (every __global__ function lives in fdtd_kernels.hpp): ties a PMC traffic
+    figure to the kernel code it was measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("tidy3d_amd/csrc/fdtd_kernels.hpp", "tidy3d_amd/csrc/fdtd_capi.hip"):
-        h.update(open(os.path.join(ROOT, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "tidy3d_amd/csrc/fdtd_kernels.hpp"), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -181,8 +181,10 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
  * (the host gives the second one the source weights times -i) and are advanced together;
  * phase[a] = 2 pi bloch_vec of axis a.  A Bloch axis x or y is laid out by the host with one ghost cell
  * at each end (device index 0 and n_real[a] + 1, PEC faces in FdtdConfig; n_real[a] = 0: no ghost
- * cells on that axis); a Bloch z uses the ghost planes of FDTD_BC_PERIODIC z faces.  One GPU, no
- * communicator.  Monitors of the pair are read per handle; a value is re + i im. */
+ * cells on that axis); a Bloch z uses the ghost planes of FDTD_BC_PERIODIC z faces.  On a z-slab
+ * (FDTD_BC_NEIGHBOR faces) the first handle carries the communicator (fdtd_comm_init) and both parts
+ * exchange their ghost planes through it; planes that wrap around a Bloch z axis are rotated where they
+ * arrive.  Monitors of the pair are read per handle; a value is re + i im. */
 int fdtd_run_bloch(FdtdSolver* h_re, FdtdSolver* h_im, int64_t n_steps, const double phase[3], const int n_real[3],
                    FdtdProgressFn progress, void* user);
 /* ref web/api/webapi.py:370 (task status incl. "diverged"), web/core/task_core.py:537 (run info) */

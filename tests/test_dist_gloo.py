@@ -33,7 +33,10 @@ def test_split_slabs():
 
 GLOO_CASES = [(2, "media_mix"), (2, "pml_box"), (3, "periodic_box"), (2, "drude_in_pml"),
                                         (2, "periodic_box_tall"), (4, "periodic_box_tall"), (2, "planewave_periodic"),
-                                        (2, "tfsf_box"), (3, "au_array"), (3, "absorber_mix")]
+                                        (2, "tfsf_box"), (3, "au_array"), (3, "absorber_mix"),
+                                        # complex fields on z-slabs: Bloch x / y with CPML in z; Bloch on all axes (the
+                                        # wrap-around planes rank n-1 <-> rank 0 are rotated by exp(-+ i phi_z))
+                                        (2, "bloch_xy_pml_z"), (2, "bloch_box"), (3, "bloch_box")]
 
 
 @pytest.mark.parametrize("world,case", GLOO_CASES)
@@ -44,7 +47,10 @@ def test_two_rank_run_matches_single_slab(world, case, emu_lib, tmp_path):
     got = np.load(out)
     disc = discretize(CASES[case](), n_steps=n_steps)
     disc.spec.decay_every = 10
-    with HipEngine(disc.spec, lib=emu_lib) as e:
+    # complex (Bloch) fields run the two-pass kernels on z-slabs: same bits as the single-slab two-pass run (the fused
+    # sweep rotates a Bloch-z ghost plane BEFORE updating it — one rounding apart, tests/test_emu_fused.py)
+    from tidy3d_amd import lib as L
+    with HipEngine(disc.spec, lib=emu_lib, variant=L.VARIANT_ZMARCH if disc.spec.bloch is not None else L.VARIANT_AUTO) as e:
         st = e.run()
         ref = e.results()
         fields = [e.get_field(c) for c in range(6)]

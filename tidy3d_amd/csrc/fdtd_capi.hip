@@ -1661,7 +1661,15 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
 int fdtd_run_bloch(FdtdSolver* hr, FdtdSolver* hi, int64_t n_steps, const double phase[3], const int n_real[3],
                    FdtdProgressFn progress, void* user) {
   if (!hr || !hi) return -1;
-  if (hr->comm || hi->comm) return fail(hr, "fdtd_run_bloch: z-slab communicators are not supported with Bloch boundaries");
+  if (hi->comm) return fail(hr, "fdtd_run_bloch: the communicator of a z-slab belongs to the first (real-part) handle");
+  // z-slab decomposition (hr->comm): both parts exchange their ghost planes through the real-part handle's
+  // communicator; the planes that wrap around a Bloch z axis (rank n-1 <-> rank 0) are rotated by exp(-+ i phi_z)
+  // on arrival.  Two-pass kernels, exchanges on the step stream (correct by construction; not overlapped).
+  const bool multi = hr->comm != nullptr;
+  const bool nb_lo = hr->cfg.bc[4] == FDTD_BC_NEIGHBOR, nb_hi = hr->cfg.bc[5] == FDTD_BC_NEIGHBOR;
+  if ((nb_lo || nb_hi) && !multi) return fail(hr, "fdtd_run_bloch: neighbour faces need fdtd_comm_init on the first handle");
+  if (hi->cfg.bc[4] != hr->cfg.bc[4] || hi->cfg.bc[5] != hr->cfg.bc[5])
+    return fail(hr, "fdtd_run_bloch: the two solvers must have the same z faces");
   if (hr->g.nx != hi->g.nx || hr->g.ny != hi->g.ny || hr->g.nz != hi->g.nz || hr->cfg.device != hi->cfg.device ||
       hr->mons.size() != hi->mons.size() || hr->step != hi->step)
     return fail(hr, "fdtd_run_bloch: the two solvers must describe the same simulation");
@@ -1682,7 +1690,7 @@ int fdtd_run_bloch(FdtdSolver* hr, FdtdSolver* hi, int64_t n_steps, const double
   }
   HIPCHK(hr, hipEventRecord(hr->ev0, st));
   const bool per_z = hr->cfg.bc[4] == FDTD_BC_PERIODIC;
-  const bool fused = (g.nx % 4 == 0) && hr->rows_f <= 15 &&
+  const bool fused = !multi && (g.nx % 4 == 0) && hr->rows_f <= 15 &&
                      (hr->cfg.variant == FDTD_VARIANT_FUSED || hr->cfg.variant == FDTD_VARIANT_AUTO);
   if (fused) for (FdtdSolver* h : both) if (ensure_second_set(h)) return -1;
   if (fused && !hr->tuned && !hr->user_geometry && !hi->user_geometry &&
@@ -1711,6 +1719,30 @@ int fdtd_run_bloch(FdtdSolver* hr, FdtdSolver* hi, int64_t n_steps, const double
     hipLaunchKernelGGL(bloch_plane_kernel, dim3(nblk(pc)), dim3(256), 0, st, field_ptr(hr, c) + dst_plane * pc,
                        field_ptr(hi, c) + dst_plane * pc, (const float*)(field_ptr(hr, c) + src_plane * pc),
                        (const float*)(field_ptr(hi, c) + src_plane * pc), cph[2], s, pc);
+  };
+  // ghost-plane exchange of both parts with the z neighbours (two-pass schedule): H phase = top H_x, H_y planes
+  // up, E phase = bottom E_x, E_y planes down; a plane that crossed the periodic wrap is rotated where it lands
+  const int lo_rank = (hr->rank - 1 + hr->n_ranks) % hr->n_ranks, hi_rank = (hr->rank + 1) % hr->n_ranks;
+  const bool wrap_lo = nb_lo && hr->rank == 0, wrap_hi = nb_hi && hr->rank == hr->n_ranks - 1;
+  auto exchange_pair = [&](bool e_side) -> int {
+    const int c0 = e_side ? 0 : 3;
+    NCCLCHK(hr, ncclGroupStart());
+    for (FdtdSolver* h : both)
+      for (int c = c0; c < c0 + 2; ++c) {
+        float* f = field_ptr(h, c);
+        if (!e_side && nb_hi) NCCLCHK(hr, ncclSend(f + (long long)(nz - 1) * pc, pc, ncclFloat, hi_rank, hr->comm, st));
+        if (e_side && nb_lo) NCCLCHK(hr, ncclSend(f, pc, ncclFloat, lo_rank, hr->comm, st));
+      }
+    for (FdtdSolver* h : both)
+      for (int c = c0; c < c0 + 2; ++c) {
+        float* f = field_ptr(h, c);
+        if (!e_side && nb_lo) NCCLCHK(hr, ncclRecv(f - pc, pc, ncclFloat, lo_rank, hr->comm, st));
+        if (e_side && nb_hi) NCCLCHK(hr, ncclRecv(f + (long long)nz * pc, pc, ncclFloat, hi_rank, hr->comm, st));
+      }
+    NCCLCHK(hr, ncclGroupEnd());
+    if (!e_side && wrap_lo) { plane(3, -1, -1, -sph[2]); plane(4, -1, -1, -sph[2]); }       // exp(-i phi_z), in place
+    if (e_side && wrap_hi) { plane(0, nz, nz, sph[2]); plane(1, nz, nz, sph[2]); }          // exp(+i phi_z)
+    return 0;
   };
   int64_t done = 0;
   for (; done < n_steps; ++done) {
@@ -1741,9 +1773,11 @@ int fdtd_run_bloch(FdtdSolver* hr, FdtdSolver* hi, int64_t n_steps, const double
       }
     } else {
       if (per_z) { plane(0, nz, 0, sph[2]); plane(1, nz, 0, sph[2]); }      // E ghost(nz) of E^n (first step / after set_field)
+      if (multi && exchange_pair(true)) return -1;                          // ... or the upper neighbour's bottom plane
       for (FdtdSolver* h : both) launch_h_main(h, 0, nz, st);
       if (per_z) { plane(3, -1, nz - 1, -sph[2]); plane(4, -1, nz - 1, -sph[2]); }
-      else for (FdtdSolver* h : both) fill_ghost_h(h, st);
+      else if (!nb_lo) for (FdtdSolver* h : both) fill_ghost_h(h, st);
+      if (multi && exchange_pair(false)) return -1;
       if (rec) for (FdtdSolver* h : both) record_monitors(h, n, true, st);
       for (FdtdSolver* h : both) {
         launch_e_main(h, 0, nz, st);
@@ -1752,7 +1786,7 @@ int fdtd_run_bloch(FdtdSolver* hr, FdtdSolver* hi, int64_t n_steps, const double
         launch_damp(h, true, 0, nz, st);
         launch_ade(h, 0, nz, st);
       }
-      if (!per_z) for (FdtdSolver* h : both) fill_ghost_e(h, st);
+      if (!per_z && !nb_hi) for (FdtdSolver* h : both) fill_ghost_e(h, st);
     }
     hr->step = hi->step = n + 1;
     // ---------------- field decay / divergence (|E|^2 of both parts) ----------------
@@ -1762,6 +1796,13 @@ int fdtd_run_bloch(FdtdSolver* hr, FdtdSolver* hi, int64_t n_steps, const double
         double part = 0.0;
         if (eval_energy(h, st, &part)) { hr->err = h->err; return -1; }
         en += part;
+      }
+      if (multi) {            // sum over the ranks (same stream as every other RCCL call of this run)
+        double* tmp = hr->energy_dev;
+        HIPCHK(hr, hipMemcpyAsync(tmp, &en, sizeof(double), hipMemcpyHostToDevice, st));
+        NCCLCHK(hr, ncclAllReduce(tmp, tmp, 1, ncclDouble, ncclSum, hr->comm, st));
+        HIPCHK(hr, hipMemcpyAsync(&en, tmp, sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hr, hipStreamSynchronize(st));
       }
       if (!std::isfinite(en)) {
         hr->stats.diverged = hi->stats.diverged = 1;

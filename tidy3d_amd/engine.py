@@ -239,8 +239,6 @@ class HipEngine:
         self.ghost = (0, 0, 0)            # ghost cells per axis in front of the real cells (Bloch device layout)
         self.user_shape = tuple(spec.shape)
         if spec.bloch is not None:
-            if n_ranks > 1 or force_comm or slab is not None:
-                raise SolverLibraryError("Bloch boundaries run on one GPU (no z-slab decomposition)")
             if spec.tfsf:
                 raise SolverLibraryError("TFSF sources cannot be combined with Bloch boundaries")
             if _bloch_twin is None:
@@ -274,7 +272,9 @@ class HipEngine:
                 bc[5] = L.BC_NEIGHBOR
         for i, b in enumerate(bc):
             cfg.bc[i] = int(b)
-        if (n_ranks > 1 or force_comm) and variant in (L.VARIANT_AUTO, L.VARIANT_FUSED):
+        if (n_ranks > 1 or force_comm) and spec.bloch is not None:
+            variant = L.VARIANT_ZMARCH          # complex fields on z-slabs: two-pass kernels (fdtd_run_bloch)
+        elif (n_ranks > 1 or force_comm) and variant in (L.VARIANT_AUTO, L.VARIANT_FUSED):
             # every rank takes the same decision (split_slabs is deterministic): fused z-slab schedule
             # iff float4-aligned rows, >= 4 planes in every slab and no slab cut inside the z-PML
             slabs = list(all_slabs) if all_slabs is not None else split_slabs(nz, n_ranks)
@@ -294,7 +294,8 @@ class HipEngine:
                 rot = [dataclasses.replace(sc, w_re=np.asarray(sc.w_im, float), w_im=-np.asarray(sc.w_re, float))
                        for sc in spec.sources]                   # -i (w_re + i w_im) = w_im - i w_re
                 self.twin = HipEngine(dataclasses.replace(spec, sources=rot), lib=self.lib, device=device,
-                                      variant=variant, flags=flags, z_chunk=z_chunk, _bloch_twin=tuple(self.n_real))
+                                      variant=variant, flags=flags, z_chunk=z_chunk, _bloch_twin=tuple(self.n_real),
+                                      slab=slab, rank=rank, n_ranks=n_ranks, force_comm=force_comm, all_slabs=all_slabs)
                 self.twin.user_shape = self.user_shape
         except Exception:
             self.close()
