@@ -163,3 +163,22 @@ def test_automatic_slab_axis_choice(emu_lib, tmp_path):
         assert np.abs(got[f"field{c}"] - fields[c]).max() <= 1e-6 * max(np.abs(fields[c]).max(), 1e-30), c
     for k, v in ref.items():
         assert np.abs(got[f"mon_{k}"] - v).max() <= 1e-6 * max(np.abs(v).max(), 1e-30), k
+
+
+def test_web_run_devices_spawns_the_ranks(emu_lib, tmp_path):
+    """``web.run(sim, devices=[0, 1])`` is the whole multi-GPU run: it spawns one rank per device
+    (tidy3d_amd.dist_main), the ranks split the grid into z-slabs and exchange ghost planes, rank 0 hands the
+    SimulationData back.  Here: emulated library + gloo on CPU; monitors span the slab cut; equal to the
+    single-process run of the same library."""
+    from tidy3d_amd.web import run
+    sim = CASES["au_array"]()
+    opt = dict(backend="gloo", lib=emu_lib.path, hook="dist_hook:setup",
+               pythonpath=[os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "hipemu")])
+    multi = run(sim, task_name="two", verbose=False, n_steps=40, devices=[0, 1], _dist_options=opt)
+    single = run(sim, task_name="one", verbose=False, n_steps=40, lib=emu_lib)
+    assert [d.monitor.name for d in multi.data] == [d.monitor.name for d in single.data]
+    for a, b in zip(multi.data, single.data):
+        comps = getattr(a, "field_components", None) or {"flux": a.flux}
+        for k, v in comps.items():
+            w = (getattr(b, "field_components", None) or {"flux": b.flux})[k]
+            np.testing.assert_array_equal(np.asarray(v.values), np.asarray(w.values))

@@ -152,3 +152,19 @@ def test_symmetry_with_absorber_and_bloch_boundaries():
     from tidy3d_amd.exceptions import SetupError
     with pytest.raises(SetupError, match="symmetry along the same axis"):
         D.discretize(_sim((0, 1, 0), boundary_spec=bl, monitors=mons), n_steps=2)
+
+
+def test_symmetric_run_keeps_the_users_run_time_and_dft_stride():
+    """RunTimeSpec measures the LONGEST side of the user's simulation and the DFT stride follows the monitors'
+    frequencies too (ref simulation.py:3677-3711, :4414-4443) — also when the solver only computes one half."""
+    from tidy3d_amd.discretize import discretize
+    pulse = td.GaussianPulse(freq0=2e14, fwidth=2e13)
+    kw = dict(size=(4.0, 1.0, 1.0), grid_spec=td.GridSpec.uniform(dl=0.05), run_time=td.RunTimeSpec(quality_factor=3.0),
+              sources=[td.PointDipole(center=(0, 0, 0), source_time=pulse, polarization="Ez")],
+              monitors=[td.FieldMonitor(center=(0.5, 0, 0), size=(1, 1, 0), freqs=[6e14], name="f")],
+              boundary_spec=td.BoundarySpec.all_sides(td.PML(num_layers=4)))
+    full = discretize(td.Simulation(**kw))
+    half = discretize(td.Simulation(symmetry=(-1, 0, 0), **kw))          # x is the longest AND the symmetric axis
+    assert half.spec.n_steps == full.spec.n_steps
+    assert half.nyquist_step == full.nyquist_step
+    assert np.array_equal(half.spec.monitors[0].steps, full.spec.monitors[0].steps)

@@ -23,7 +23,7 @@ import numpy as np
 from . import schema as td
 from .data import SimulationData, assemble
 from .discretize import discretize
-from .exceptions import SetupError
+from .exceptions import SetupError, SolverLibraryError
 
 log = logging.getLogger("tidy3d_amd")
 
@@ -65,7 +65,7 @@ def run(simulation, task_name: Optional[str] = None, folder_name: str = "default
         solver_version: Optional[str] = None, worker_group: Optional[str] = None,
         simulation_type: str = "tidy3d", parent_tasks=None, local_gradient: bool = False,
         *, device: int = 0, n_steps: Optional[int] = None, lib=None,
-        return_tidy3d: Optional[bool] = None) -> SimulationData:
+        return_tidy3d: Optional[bool] = None, devices=None, _dist_options: Optional[dict] = None) -> SimulationData:
     """Solve ``simulation`` on the local MI355X and return its ``SimulationData``.
 
     Cloud-only arguments (``folder_name``, ``callback_url``, ``progress_callback_*``,
@@ -73,11 +73,27 @@ def run(simulation, task_name: Optional[str] = None, folder_name: str = "default
     ignored.  ``path``: when given, the data is written there — ``*.hdf5`` in the reference's file
     layout (loadable with ``tidy3d.SimulationData.from_file``), any other name as ``.npz``.  Extra keyword-only arguments select the GPU
     (``device``), override the number of time steps (``n_steps``, tests/benchmarks) or pass an
-    explicitly loaded library (``lib``, tests)."""
+    explicitly loaded library (``lib``, tests).  ``devices=[0, 1, ...]``: one worker process per listed GPU, the
+    grid split into z-slabs with RCCL ghost-plane exchange (``tidy3d_amd.dist``) — the whole multi-GPU run is this
+    one call."""
     from .engine import HipEngine
 
     sim, was_tidy3d = _as_mirror(simulation)
     sim.validate_pre_upload(source_required=True)
+    if devices is not None and len(devices) > 1:
+        sim_data = _run_on_devices(sim, [int(d) for d in devices], n_steps, verbose, _dist_options or {})
+        want_td = was_tidy3d if return_tidy3d is None else return_tidy3d
+        if want_td:
+            from .adapter import to_tidy3d
+            out = to_tidy3d(sim_data, simulation if was_tidy3d else None)
+            if path:
+                out.to_file(path)
+            return out
+        if path:
+            save(sim_data, path)
+        return sim_data
+    if devices is not None and len(devices) == 1:
+        device = int(devices[0])
     t_setup = time.perf_counter()
     disc = discretize(sim, n_steps=n_steps)
     spec = disc.spec
@@ -130,6 +146,47 @@ def run(simulation, task_name: Optional[str] = None, folder_name: str = "default
     if path:
         save(sim_data, path)
     return sim_data
+
+
+def _run_on_devices(sim, devices, n_steps, verbose: bool, opt: dict) -> SimulationData:
+    """Spawn one ``python -m tidy3d_amd.dist_main`` per GPU (ranks in the order of ``devices``; rendezvous on
+    127.0.0.1), wait, and load what rank 0 wrote."""
+    import pickle
+    import socket
+    import subprocess
+    import sys
+    import tempfile
+    with socket.socket() as sck:                    # a free port for the rendezvous
+        sck.bind(("127.0.0.1", 0))
+        port = sck.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory(prefix="tidy3d_amd_") as tmp:
+        f_sim, f_out = os.path.join(tmp, "sim.pkl"), os.path.join(tmp, "data.pkl")
+        with open(f_sim, "wb") as f:
+            pickle.dump(sim, f, protocol=pickle.HIGHEST_PROTOCOL)
+        procs = []
+        for rank, dev in enumerate(devices):
+            env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(len(devices)), LOCAL_RANK=str(dev),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            env["PYTHONPATH"] = os.pathsep.join([root] + [p for p in (opt.get("pythonpath") or []) if p]
+                                                + ([env["PYTHONPATH"]] if env.get("PYTHONPATH") else []))
+            cmd = [sys.executable, "-m", "tidy3d_amd.dist_main", "--sim", f_sim, "--out", f_out,
+                   "--backend", opt.get("backend", "nccl")]
+            if n_steps is not None:
+                cmd += ["--n-steps", str(int(n_steps))]
+            if opt.get("lib"):
+                cmd += ["--lib", opt["lib"]]
+            if opt.get("hook"):
+                cmd += ["--hook", opt["hook"]]
+            procs.append(subprocess.Popen(cmd, env=env, stdout=None if verbose else subprocess.DEVNULL,
+                                          stderr=subprocess.PIPE, text=True))
+        errs = [p.communicate()[1] for p in procs]
+        bad = [(r, p.returncode, e) for r, (p, e) in enumerate(zip(procs, errs)) if p.returncode != 0]
+        if bad:
+            r, rc, e = bad[0]
+            raise SolverLibraryError(f"multi-GPU run: rank {r} exited with status {rc}: {(e or '')[-2000:]}")
+        with open(f_out, "rb") as f:
+            return pickle.load(f)
 
 
 def save(sim_data: SimulationData, path: str) -> None:
