@@ -62,9 +62,12 @@ CONFIGS = {
 }
 
 
-def _run(spec, lib, variant, rows, zc, pml_mask=None):
+def _run(spec, lib, variant, rows, zc, pml_mask=None, split=1):
     with HipEngine(spec, lib=lib, variant=variant, z_chunk=zc) as e:
         e.set_option(L.OPT_ROWS, rows)
+        # (grids this small default to ONE launch of the all-axes instantiation: ask for the three-launch split,
+        # which is what large grids run, unless a test wants the single launch)
+        e.set_option(L.OPT_PML_SPLIT, split)
         if pml_mask is not None:
             e.set_option(L.OPT_PML_FUSED, pml_mask)
         e.run()
@@ -85,7 +88,7 @@ def test_fused_equals_two_pass(name, rows, zc, emu_lib):
         assert np.array_equal(got_m[k], ref_m[k]), k
 
 
-@pytest.mark.parametrize("mask", [0, 6, 7])
+@pytest.mark.parametrize("mask", [0, 6, 7, -7])
 @pytest.mark.parametrize("rows,zc", [(3, 16), (4, 3)])
 def test_fused_cpml_placement(mask, rows, zc, emu_lib):
     """The CPML recursions as slab kernels (0), y/z inside the sweep (6), all inside (7): identical
@@ -93,7 +96,8 @@ def test_fused_cpml_placement(mask, rows, zc, emu_lib):
     N, bspec, structures = CONFIGS["pml_media"]
     disc = discretize(_sim(N, bspec, structures), n_steps=24)
     ref_f, ref_m = _run(disc.spec, emu_lib, L.VARIANT_ZMARCH, 4, 2)
-    got_f, got_m = _run(disc.spec, emu_lib, L.VARIANT_FUSED, rows, zc, mask)
+    # mask < 0: all axes inside the sweep as ONE launch (the small-grid default) instead of the three-launch split
+    got_f, got_m = _run(disc.spec, emu_lib, L.VARIANT_FUSED, rows, zc, abs(mask), split=0 if mask < 0 else 1)
     for c in range(6):
         assert np.array_equal(got_f[c], ref_f[c]), c
     for k in ref_m:

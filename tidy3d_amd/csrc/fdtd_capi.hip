@@ -142,6 +142,7 @@ struct FdtdSolver {
   // extra live registers drop the sweep from 3 to 2 (mask 6) or 1 (mask 7) waves per SIMD, which
   // costs more (+0.41 ms / +3.0 ms) than the slab kernels it removes (0.22 ms / 0.45 ms) -> default 0.
   int pml_fused = -1;                // -1 = default
+  int pml_split = -1;                // three launches (interior / y-edge / z-edge tiles): -1 = by grid size, 0 = one launch, 1 = always
   // opt-in (FDTD_OPT_AUTOTUNE): time a few (rows, z-chunk) tile shapes on the first run and keep the
   // best.  Measured (profiles/r01h_autotune.txt): +6 % on a 64-plane slab (3 x 32 instead of 3 x 16),
   // nothing at 512^3 (shapes within noise of each other, so the pick is noise too) and the wrong
@@ -1381,7 +1382,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   if (fused && !h->tuned && !h->user_geometry) {
     const long long wgs = (long long)((h->g.nx + 255) / 256) * ((h->g.ny + h->rows_f - 1) / h->rows_f) *
                           ((nz + h->zchunk_f - 1) / h->zchunk_f);
-    under_one_wave = wgs < 768;
+    under_one_wave = wgs < 2048;       // (two waves of workgroups at 4 waves per SIMD)
   }
   if ((fused || fused_multi) && (h->autotune || under_one_wave) && !h->tuned && !h->user_geometry &&
       (n_cells(h) >= (1LL << 20) || h->autotune == 2)) {
@@ -1509,7 +1510,9 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       launch_pml(h, false, 0, nz, st, 7 & ~pml_in);
       advance_tfsf_aux(h, false, n, st);
       if (h->cfg.bc[4] == FDTD_BC_PERIODIC) fill_ghost_h(h, st);   // ghost(-1) must carry the pre-corrections too
-      if ((pml_in & 6) == 0) {
+      // small grids are bound by dependent launches, not by occupancy: one launch of the all-axes instantiation
+      const bool split = h->pml_split < 0 ? n_cells(h) >= (1LL << 24) : h->pml_split != 0;
+      if ((pml_in & 6) == 0 || !split) {
         if (launch_fused(h, st, pml_in)) return -1;
       } else {
         // The instantiation that carries the y / z recursions holds their psi values in registers from the
@@ -1846,6 +1849,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_PML_FUSED: h->pml_fused = value < 0 ? -1 : (value & 7); for (bool& ok : h->pml_blk_ok) ok = false; return 0;
     case FDTD_OPT_BND_PLANES: h->bnd_planes = value > 0 ? value : 0; return 0;
     case FDTD_OPT_AUTOTUNE: h->autotune = value < 0 ? 0 : (value > 2 ? 1 : value); if (value) h->tuned = false; return 0;
+    case FDTD_OPT_PML_SPLIT: h->pml_split = value < 0 ? -1 : (value != 0); return 0;
     case FDTD_OPT_FUSED_LB: if (value != 0 && value != 256 && value != 512 && value != 1024) break; h->fused_lb = value; return 0;
     default: break;
   }
