@@ -360,3 +360,82 @@ def test_mode_launch_and_readback_on_the_oracle():
     err_grid = abs(np.angle(np.exp(1j * (dphi - beta_grid * 0.6))))
     err_cont = abs(np.angle(np.exp(1j * (dphi - beta_cont * 0.6))))
     assert err_grid < 2e-3 and err_cont > 10 * err_grid, (err_grid, err_cont)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/tidy3d"), reason="reference checkout not present")
+@pytest.mark.parametrize("theta,phi", [(0.3, 0.0), (0.2, 0.7), (-0.25, 1.9)])
+def test_angled_plane_against_reference_compute_modes(theta, phi):
+    """ModeSpec.angle_theta / angle_phi (ref solver.py:89-160, transforms.py:74-111): the tensorial 4N x 4N problem
+    of mode_solver.solve_modes_angled against the LIVE reference ``compute_modes`` on a non-uniform grid: n_eff
+    (which has an imaginary part in the sheared frame's truncated plane, in both) and all six field components."""
+    from oracle.tidy3d_ref_loader import load_mode_solver
+    from tidy3d_amd.mode_solver import solve_modes_angled
+    _, solver = load_mode_solver()
+    rng = np.random.default_rng(3)
+    xb = np.concatenate(([0.0], np.cumsum(0.04 + 0.02 * rng.random(36)))) - 1.0
+    yb = np.concatenate(([0.0], np.cumsum(0.035 + 0.02 * rng.random(28)))) - 0.6
+    xc, yc = (xb[1:] + xb[:-1]) / 2, (yb[1:] + yb[:-1]) / 2
+
+    def eps_at(x, y):
+        X, Y = np.meshgrid(x, y, indexing="ij")
+        e = np.full(X.shape, 1.44 ** 2, complex)
+        e[(np.abs(X - 0.1) <= 0.3) & (Y >= -0.1) & (Y <= 0.15)] = 3.48 ** 2
+        return e
+    exx, eyy, ezz = eps_at(xc, yb[:-1]), eps_at(xb[:-1], yc), eps_at(xb[:-1], yb[:-1])
+    z = np.zeros_like(exx)
+    ms = SimpleNamespace(num_modes=2, bend_radius=None, bend_axis=None, angle_theta=theta, angle_phi=phi,
+                         num_pml=(0, 0), target_neff=None, precision="double")
+    fields, n_ref, kind = solver.compute_modes(eps_cross=[exx, z, z, z, eyy, z, z, z, ezz], coords=[xb, yb],
+                                               freq=C_0 / 1.55, mode_spec=ms, symmetry=(0, 0), direction="+")
+    assert kind.startswith("tensorial")
+    r = solve_modes_angled(exx, eyy, ezz, xb, yb, C_0 / 1.55, theta, phi, num_modes=2)
+    # (the reference runs ARPACK at tol = fp_eps: its own eigenvalues are good to ~1e-6)
+    np.testing.assert_allclose(r.n_complex, n_ref, rtol=5e-5)
+    for m in range(2):
+        for blk, comps in ((0, (r.Eu, r.Ev, r.Ew)), (1, (r.Hu, r.Hv, r.Hw))):
+            mine = np.concatenate([c[:, :, m].ravel() for c in comps])
+            ref = np.concatenate([fields[blk, q, :, :, 0, m].ravel() for q in range(3)])
+            ov = abs(np.vdot(ref, mine)) / (np.linalg.norm(ref) * np.linalg.norm(mine))
+            assert ov > 1 - 1e-4, (m, blk, ov)
+        a = np.vdot(fields[0, 0, :, :, 0, m], r.Eu[:, :, m]) / np.vdot(fields[0, 0, :, :, 0, m], fields[0, 0, :, :, 0, m])
+        b = np.vdot(fields[1, 1, :, :, 0, m], r.Hv[:, :, m]) / np.vdot(fields[1, 1, :, :, 0, m], fields[1, 1, :, :, 0, m])
+        assert abs(a / b - 1) < 2e-4          # impedance and relative phase of E and H
+
+
+def test_angled_solver_reduces_to_the_straight_one():
+    """theta -> 0: the tensorial problem gives the straight waveguide's n_eff and profile; a small angle lowers
+    n_eff like cos(theta) to first order in the transverse confinement."""
+    from tidy3d_amd.mode_solver import solve_modes_angled
+    c = GOLD[0]
+    eu, ev, ew, xb, yb = _strip(dict(c, dl=0.05))
+    f = C_0 / c["wavelength"]
+    r0 = solve_modes(eu, ev, ew, xb, yb, f, num_modes=1)
+    r1 = solve_modes_angled(eu, ev, ew, xb, yb, f, 1e-6, 0.3, num_modes=1)
+    assert abs(r1.n_complex[0] - r0.n_complex[0]) < 1e-7
+    ov = abs(np.vdot(r0.Eu[:, :, 0], r1.Eu[:, :, 0])) / (np.linalg.norm(r0.Eu[:, :, 0]) * np.linalg.norm(r1.Eu[:, :, 0]))
+    assert ov > 1 - 1e-8
+
+
+def test_mode_profile_accepts_an_angled_mode_spec():
+    """Through the product path (modesource.mode_profile): an angled ModeSpec selects the tensorial solver; the
+    wave number along the plane normal is k n_eff / cos(theta) (what the half-cell phase of the launch and the
+    monitor's grid correction use, ref plugins/mode/mode_solver.py:883-887)."""
+    from tidy3d_amd.discretize import discretize
+    from tidy3d_amd.modesource import mode_profile
+    f0 = C_0 / 1.55
+    sim = td.Simulation(size=(1.6, 1.2, 1.0), grid_spec=td.GridSpec.uniform(dl=0.05), run_time=1e-14,
+                        medium=td.Medium(permittivity=1.44 ** 2), subpixel=False,
+                        structures=[td.Structure(geometry=td.Box(center=(0, 0, 0), size=(0.45, 0.25, td.inf)),
+                                                 medium=td.Medium(permittivity=3.48 ** 2))],
+                        sources=[td.PointDipole(center=(0, 0, 0), source_time=td.GaussianPulse(freq0=f0, fwidth=f0 / 10),
+                                                polarization="Ex")],
+                        boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary()))
+    spec = discretize(sim, n_steps=2).spec
+    box = td.Box(center=(0, 0, 0), size=(td.inf, td.inf, 0))
+    straight = mode_profile(spec, box, td.ModeSpec(num_modes=1, precision="double"), f0)
+    angled = mode_profile(spec, box, td.ModeSpec(num_modes=1, precision="double", angle_theta=0.15, angle_phi=0.4), f0)
+    n0, n1 = straight.result.n_complex[0].real, angled.result.n_complex[0].real
+    assert 0.97 * n0 < n1 < n0                       # the guided mode sees a slightly lower index along the plane normal
+    k0 = 2 * np.pi * f0 / C_0
+    assert angled.beta[0].real == pytest.approx(k0 * n1 / np.cos(0.15), rel=1e-12)
+    assert np.abs(angled.result.Ew).max() > np.abs(straight.result.Ew).max()      # the tilt shows in the normal component

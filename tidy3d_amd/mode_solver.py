@@ -25,6 +25,23 @@ zero; max edge: truncation), like the reference's default.  Options held to the 
 comparison (tests/test_mode_solver.py): PMC walls on the min edges (symmetry eigenvalue +1, ref
 solver.py:182-197) and the stretched-coordinate PML inside the plane (``ModeSpec.num_pml``, ref
 derivatives.py:80-232).
+
+Angled waveguides (``ModeSpec.angle_theta / angle_phi``, ref solver.py:89-160, transforms.py:74-111): the
+shear u' = u - tan(theta) cos(phi) w, v' = v - tan(theta) sin(phi) w makes the structure invariant along w;
+with J = [[1, 0, a], [0, 1, b], [0, 0, 1]] (a, b = -tan(theta) cos / sin(phi)) the media become the full tensors
+eps' = J eps J^T, mu' = J J^T (det J = 1) and the problem no longer reduces to E alone.  With E_w and Ht_w
+eliminated from the six curl equations (derivatives in units of k0, n = beta / k0):
+
+    E_w  = (1/eps_ww) [  i (Dub Ht_v - Dvb Ht_u) - eps_wu E_u - eps_wv E_v ]
+    Ht_w = (1/mu_ww)  [ -i (Duf E_v - Dvf E_u)   - mu_wu Ht_u - mu_wv Ht_v ]
+    i n E_u  = Duf E_w  + i (mu_vu Ht_u + mu_vv Ht_v + mu_vw Ht_w)
+    i n E_v  = Dvf E_w  - i (mu_uu Ht_u + mu_uv Ht_v + mu_uw Ht_w)
+    i n Ht_u = Dub Ht_w - i (eps_vu E_u + eps_vv E_v + eps_vw E_w)
+    i n Ht_v = Dvb Ht_w + i (eps_uu E_u + eps_uv E_v + eps_uw E_w)
+
+a first-order 4N x 4N eigenproblem in [E_u, E_v, Ht_u, Ht_v] (``solve_modes_angled``); tensor entries multiply
+pointwise on the flattened Yee arrays (no averaging between staggered nodes — the reference's choice too, which
+is what makes the two comparable to 1e-7).  Back in the physical frame F = J^T F' and n_eff = n' cos(theta).
 """
 from __future__ import annotations
 
@@ -230,6 +247,87 @@ def solve_modes(eps_u: np.ndarray, eps_v: np.ndarray, eps_w: np.ndarray, ub: np.
         for k in out:
             out[k][:, :, m] = f[k] * s
     return ModeResult(n_complex=beta / k0, **out)
+
+
+def solve_modes_angled(eps_u: np.ndarray, eps_v: np.ndarray, eps_w: np.ndarray, ub: np.ndarray, vb: np.ndarray,
+                       freq: float, angle_theta: float, angle_phi: float = 0.0, num_modes: int = 1,
+                       target_neff: Optional[float] = None, precision: str = "double",
+                       pmc_min: Tuple[bool, bool] = (False, False)) -> ModeResult:
+    """Modes of a waveguide that crosses the plane at polar angle ``angle_theta`` from its normal, azimuth
+    ``angle_phi`` from the plane's u axis (module docstring).  Same arguments and result layout as
+    ``solve_modes``; the tensorial problem is complex even for lossless media (eigenvalue i n)."""
+    nu, nv = eps_u.shape
+    N = nu * nv
+    k0 = 2 * np.pi * freq / C_0
+    a = -np.tan(angle_theta) * np.cos(angle_phi)
+    b = -np.tan(angle_theta) * np.sin(angle_phi)
+    eu, ev, ew = (np.asarray(x, complex).reshape(-1) for x in (eps_u, eps_v, eps_w))
+    one = np.ones(N, complex)
+    # eps' = J diag(eu, ev, ew) J^T,  mu' = J J^T
+    eps = {"uu": eu + a * a * ew, "uv": a * b * ew, "uw": a * ew, "vu": a * b * ew, "vv": ev + b * b * ew, "vw": b * ew,
+           "wu": a * ew, "wv": b * ew, "ww": ew}
+    mu = {"uu": (1 + a * a) * one, "uv": a * b * one, "uw": a * one, "vu": a * b * one, "vv": (1 + b * b) * one,
+          "vw": b * one, "wu": a * one, "wv": b * one, "ww": one}
+    du_p, dv_p = np.diff(ub), np.diff(vb)
+    du_d = np.concatenate(([du_p[0]], 0.5 * (du_p[1:] + du_p[:-1])))
+    dv_d = np.concatenate(([dv_p[0]], 0.5 * (dv_p[1:] + dv_p[:-1])))
+    Duf, Dvf, Dub, Dvb = (D / k0 for D in _diff_ops(nu, nv, du_p, dv_p, du_d, dv_d, pmc_min, None))
+    dg = lambda v: sp.diags(np.asarray(v).reshape(-1))           # noqa: E731
+    mask_u, mask_v, mask_w = np.ones((nu, nv)), np.ones((nu, nv)), np.ones((nu, nv))
+    if not pmc_min[1]:
+        mask_u[:, 0] = 0
+        mask_w[:, 0] = 0
+    if not pmc_min[0]:
+        mask_v[0, :] = 0
+        mask_w[0, :] = 0
+    Mu, Mv, Mw = dg(mask_u), dg(mask_v), dg(mask_w)
+    Z = sp.csr_matrix((N, N), dtype=complex)
+    Ie, Im = dg(1.0 / eps["ww"]), dg(1.0 / mu["ww"])
+    # E_w and Ht_w as operators on x = [E_u, E_v, Ht_u, Ht_v]
+    Ew = [Mw @ (-Ie @ dg(eps["wu"])), Mw @ (-Ie @ dg(eps["wv"])), Mw @ (-1j * Ie @ Dvb), Mw @ (1j * Ie @ Dub)]
+    Hw = [1j * Im @ Dvf, -1j * Im @ Duf, -Im @ dg(mu["wu"]), -Im @ dg(mu["wv"])]
+
+    def row(Dl, Ow, sgn, t_u, t_v, t_w, on_h: bool, mask=None):
+        """D . O_w  + sgn i (t_u X_u + t_v X_v + t_w O2_w): the X are Ht (on_h) or E components."""
+        O2 = Hw if on_h else Ew
+        blocks = [Dl @ Ow[q] + sgn * 1j * dg(t_w) @ O2[q] for q in range(4)]
+        off = 2 if on_h else 0
+        blocks[off] = blocks[off] + sgn * 1j * dg(t_u)
+        blocks[off + 1] = blocks[off + 1] + sgn * 1j * dg(t_v)
+        return [b_ if mask is None else mask @ b_ for b_ in blocks]
+    rows = [row(Duf, Ew, +1, mu["vu"], mu["vv"], mu["vw"], True, Mu),
+            row(Dvf, Ew, -1, mu["uu"], mu["uv"], mu["uw"], True, Mv),
+            row(Dub, Hw, -1, eps["vu"], eps["vv"], eps["vw"], False),
+            row(Dvb, Hw, +1, eps["uu"], eps["uv"], eps["uw"], False)]
+    A = (-1j * sp.bmat(rows, format="csc")).astype(np.complex64 if precision == "single" else np.complex128)
+    cos_t = float(np.cos(angle_theta))
+    if target_neff is None:
+        target_neff = float(np.sqrt(np.max(np.abs([np.max(np.abs(x)) for x in (eps_u, eps_v, eps_w)]))))
+    sigma = target_neff / cos_t
+    rng = np.random.default_rng(0)
+    v0 = rng.standard_normal(4 * N).astype(A.dtype)
+    vals, vecs = spl.eigs(A, k=num_modes, sigma=A.dtype.type(sigma), v0=v0, tol=(1e-6 if precision == "single" else 1e-10))
+    vals, vecs = vals.astype(complex), vecs.astype(complex)
+    order = np.argsort(-vals.real)
+    vals, vecs = vals[order], vecs[:, order]
+    out = {k: np.zeros((nu, nv, num_modes), complex) for k in ("Eu", "Ev", "Ew", "Hu", "Hv", "Hw")}
+    for m in range(num_modes):
+        x = vecs[:, m]
+        Eu_, Ev_, Htu, Htv = x[:N], x[N:2 * N], x[2 * N:3 * N], x[3 * N:]
+        Ew_p = sum(Ew[q] @ x[q * N:(q + 1) * N] for q in range(4))
+        Hw_p = sum(Hw[q] @ x[q * N:(q + 1) * N] for q in range(4))
+        # physical frame: F = J^T F'
+        f = dict(Eu=Eu_, Ev=Ev_, Ew=a * Eu_ + b * Ev_ + Ew_p, Hu=Htu / ETA_0, Hv=Htv / ETA_0,
+                 Hw=(a * Htu + b * Htv + Hw_p) / ETA_0)
+        f = {k: v.reshape(nu, nv) for k, v in f.items()}
+        big = f["Eu"] if np.abs(f["Eu"]).max() >= np.abs(f["Ev"]).max() else f["Ev"]
+        ph = np.exp(-1j * np.angle(big.reshape(-1)[np.argmax(np.abs(big))]))
+        f = {k: v * ph for k, v in f.items()}
+        pw = mode_flux(f, ub, vb)
+        sc = 1.0 / np.sqrt(abs(pw)) if pw != 0 else 1.0
+        for k in out:
+            out[k][:, :, m] = f[k] * sc
+    return ModeResult(n_complex=vals * cos_t, **out)
 
 
 def _to_centres(f: np.ndarray, on_b_u: bool, on_b_v: bool) -> np.ndarray:

@@ -25,7 +25,7 @@ from . import schema as td
 from .constants import C_0
 from .discretize import discretize_inds
 from .exceptions import SetupError, Tidy3dNotImplementedError
-from .mode_solver import ModeResult, solve_modes
+from .mode_solver import ModeResult, solve_modes, solve_modes_angled
 from .planewave import surface_legs
 from .spec import BC_PMC, PointSourceSet, SolverSpec
 
@@ -87,9 +87,11 @@ def mode_profile(spec: SolverSpec, box: td.Box, mode_spec, freq: float, symmetry
         raise SetupError("a mode plane needs exactly one zero-size dimension")
     p = zd[0]
     u, v = (p + 1) % 3, (p + 2) % 3
-    if getattr(mode_spec, "angle_theta", 0.0):
-        raise Tidy3dNotImplementedError("angled mode planes (ModeSpec.angle_theta) are not supported")
+    angle_theta = float(getattr(mode_spec, "angle_theta", 0.0) or 0.0)
+    angle_phi = float(getattr(mode_spec, "angle_phi", 0.0) or 0.0)
     bend_radius = getattr(mode_spec, "bend_radius", None)
+    if angle_theta and (bend_radius is not None or any(int(n) for n in (getattr(mode_spec, "num_pml", (0, 0)) or (0, 0)))):
+        raise Tidy3dNotImplementedError("an angled mode plane together with bend_radius or num_pml is not supported")
     bend_axis = 0
     if bend_radius is not None:
         # ModeSpec.bend_axis counts the plane's axes in x, y, z order (ref mode.py bend_axis); the
@@ -111,12 +113,20 @@ def mode_profile(spec: SolverSpec, box: td.Box, mode_spec, freq: float, symmetry
     # edge there; PEC walls / the plane's own truncation are the solver's default (ref solver.py:182-197)
     pmc_min = tuple(bool(lo[i] == 0 and spec.bc[a][0] == BC_PMC) for i, a in enumerate((u, v)))
     f_solve = grid_frequency(freq, spec.dt) if grid_dispersion else freq
-    res = solve_modes(eps_u, eps_v, eps_w, ub, vb, f_solve, num_modes=int(mode_spec.num_modes),
-                      target_neff=mode_spec.target_neff,
-                      precision=getattr(mode_spec, "precision", "single") or "single", pmc_min=pmc_min,
-                      num_pml=tuple(int(n) for n in (getattr(mode_spec, "num_pml", (0, 0)) or (0, 0))),
-                      pml_min=tuple(not (lo[i] == 0 and symmetry[a] != 0) for i, a in enumerate((u, v))),
-                      bend_radius=bend_radius, bend_axis=bend_axis)
+    if angle_theta:
+        # ModeSpec.angle_phi counts from the FIRST in-plane axis in x, y, z order (ref mode.py angle_phi); the
+        # solver's (u, v) are cyclic: for a y-normal plane they are (z, x), the azimuth is measured from v there
+        phi_uv = angle_phi if (u, v) == tuple(sorted((u, v))) else 0.5 * np.pi - angle_phi
+        res = solve_modes_angled(eps_u, eps_v, eps_w, ub, vb, f_solve, angle_theta, phi_uv,
+                                 num_modes=int(mode_spec.num_modes), target_neff=mode_spec.target_neff,
+                                 precision=getattr(mode_spec, "precision", "single") or "single", pmc_min=pmc_min)
+    else:
+        res = solve_modes(eps_u, eps_v, eps_w, ub, vb, f_solve, num_modes=int(mode_spec.num_modes),
+                          target_neff=mode_spec.target_neff,
+                          precision=getattr(mode_spec, "precision", "single") or "single", pmc_min=pmc_min,
+                          num_pml=tuple(int(n) for n in (getattr(mode_spec, "num_pml", (0, 0)) or (0, 0))),
+                          pml_min=tuple(not (lo[i] == 0 and symmetry[a] != 0) for i, a in enumerate((u, v))),
+                          bend_radius=bend_radius, bend_axis=bend_axis)
     fp = getattr(mode_spec, "filter_pol", None)
     if fp in ("te", "tm"):
         # ModeSpec.filter_pol (ref mode_solver.py:523-549): modes whose field intensity sits mostly on
@@ -135,12 +145,16 @@ def mode_profile(spec: SolverSpec, box: td.Box, mode_spec, freq: float, symmetry
             order = np.concatenate((np.where(te_frac <= 0.5)[0], np.where(te_frac > 0.5)[0]))
         res = type(res)(n_complex=res.n_complex[order], **{k: getattr(res, k)[:, :, order]
                                                            for k in ("Eu", "Ev", "Ew", "Hu", "Hv", "Hw")})
+    # wave number ALONG THE NORMAL: an angled mode advances by k n_eff / cos(theta) per unit of w at fixed
+    # transverse position of the sheared frame (the reference's grid correction uses the same, ref
+    # plugins/mode/mode_solver.py:883-887)
+    cos_t = float(np.cos(angle_theta))
     if grid_dispersion:
         dw = float(spec.dual_steps(p)[k0])                       # spacing of the H planes either side of the plane
-        b_tilde = res.n_complex * (2 * np.pi * f_solve / C_0)
+        b_tilde = res.n_complex * (2 * np.pi * f_solve / C_0) / cos_t
         beta = (2.0 / dw) * np.arcsin(b_tilde * dw / 2.0 + 0j)
     else:
-        beta = res.n_complex * (2 * np.pi * freq / C_0)
+        beta = res.n_complex * (2 * np.pi * freq / C_0) / cos_t
     return ModePlane(p=p, u=u, v=v, k0=k0, lo=lo, hi=hi, result=res, beta=beta)
 
 
