@@ -4,7 +4,8 @@ launch failure cannot poison the next.  One JSON line per configuration.
 
     python scripts/probe_r02.py [n] [workloads]          configurations: $PROBE_CFGS = {"v2": [{...}, ...], "*": [...]}
     keys of a configuration: rows, zc, pml (-1 = default), remap (absent = library default),
-                             lib (tag: tidy3d_amd/libfdtd_<tag>.so instead of the product library)"""
+                             lib (tag: tidy3d_amd/libfdtd_<tag>.so instead of the product library),
+                             lds_pad (bytes of extra LDS per workgroup: 0 -> 4, 30000 -> 3, 60000 -> 2, 100000 -> 1 workgroups per CU)"""
 import json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -35,6 +36,8 @@ def child(n, wl, cfgs):
             eng.set_option(L.OPT_ROWS, cfg.get("rows", 3))
             eng.set_option(L.OPT_ZCHUNK, cfg.get("zc", 16))
             eng.set_option(L.OPT_PML_FUSED, cfg.get("pml", -1))
+            if cfg.get("lds_pad"):
+                eng.set_option(L.OPT_LDS_PAD, cfg["lds_pad"])
             if "remap" in cfg:
                 eng.set_option(L.OPT_XCD_REMAP, cfg["remap"])
             eng.set_option(L.OPT_FLAGS, 0)
@@ -45,7 +48,7 @@ def child(n, wl, cfgs):
             t = sorted(ts)[1]
             eng.set_option(L.OPT_FLAGS, L.FLAG_TIME_KERNELS)
             st = eng.run(10)
-            print(json.dumps({"wl": wl, "n": n, **cfg, "ms_per_step": t / 20 * 1e3, "gcells": n**3 * 20 / t / 1e9,
+            print(json.dumps({"wl": wl, "n": n, **{k: v for k, v in cfg.items()}, "ms_per_step": t / 20 * 1e3, "gcells": n**3 * 20 / t / 1e9,
                               "fused_ms_per_step": st.fused_kernel_ms / 10}), flush=True)
         except Exception as e:
             print(json.dumps({"wl": wl, **cfg, "error": str(e)[:200]}), flush=True)
@@ -63,9 +66,17 @@ if __name__ == "__main__":
     default = [dict(rows=3, zc=16), dict(rows=7, zc=16)]
     for wl in wls:
         cfgs = custom.get(wl, custom.get("*", default))
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(n), wl, json.dumps(cfgs)],
-                           capture_output=True, text=True)
-        sys.stdout.write(r.stdout)
-        if r.returncode != 0:
-            print(json.dumps({"wl": wl, "error": r.stderr.strip().splitlines()[-1][:300] if r.stderr.strip() else "rc %d" % r.returncode}))
-        sys.stdout.flush()
+        # one process per configuration that names a library or an environment ("env": {...}): device allocations of
+        # engines created one after the other in ONE process land differently, and the sweep is sensitive to that
+        # (profiles/r02m: the first engine of a process ran a byte-identical kernel 12 % faster than the third)
+        groups = [(None, [cfg]) for cfg in cfgs]
+        for _, grp in groups:
+            env = dict(os.environ)
+            for c in grp:
+                env.update({k: str(v) for k, v in (c.get("env") or {}).items()})
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(n), wl, json.dumps(grp)],
+                               capture_output=True, text=True, env=env)
+            sys.stdout.write(r.stdout)
+            if r.returncode != 0:
+                print(json.dumps({"wl": wl, "error": r.stderr.strip().splitlines()[-1][:300] if r.stderr.strip() else "rc %d" % r.returncode}))
+            sys.stdout.flush()

@@ -418,3 +418,23 @@ def test_axis_renaming_on_the_gpu(case, hip_lib):
             assert np.abs(outs[s][0][c] - outs[0][0][c]).max() <= 2e-6 * max(np.abs(outs[0][0][c]).max(), 1e-30), (s, c)
         for k, v in outs[0][1].items():
             assert np.abs(outs[s][1][k] - v).max() <= 2e-6 * max(np.abs(v).max(), 1e-30), (s, k)
+
+
+def test_near_to_far_projection_from_gpu_fields(hip_lib):
+    """the near fields a FieldProjectionAngleMonitor needs are accumulated ON the device
+    (running DFT on the six surfaces of its box, K6); the N / L integrals over those surfaces run on the host
+    afterwards.  Same analytic pins as the oracle-driven test (sin(theta) pattern, far-sphere power = near-box flux,
+    E / H = eta0) and the far field itself against the oracle's to fp32 accuracy."""
+    from test_projection import _dipole_sim, check_dipole_far_field
+    from oracle.fdtd_numpy import OracleFdtd
+    from tidy3d_amd.data import assemble
+    sim, theta, phi = _dipole_sim()
+    disc = discretize(sim)
+    with HipEngine(disc.spec, lib=hip_lib) as e:
+        st = e.run()
+        raw = e.results()
+    sd = assemble(disc, raw, n_steps_run=int(st.steps_done))
+    check_dipole_far_field(sd, theta, phi)
+    ref = assemble(disc, OracleFdtd(disc.spec).run())
+    a, b = sd["far"].Etheta.values, ref["far"].Etheta.values
+    assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max()

@@ -10,7 +10,7 @@ from tidy3d_amd.discretize import discretize
 from oracle.fdtd_numpy import OracleFdtd
 
 
-def test_dipole_pattern_and_power():
+def _dipole_sim():
     dl = 1.0 / 20
     f0 = 3e14                       # lambda = 1 um
     pulse = td.GaussianPulse(freq0=f0, fwidth=f0 / 6)
@@ -23,8 +23,10 @@ def test_dipole_pattern_and_power():
                                                  proj_distance=1e4, name="far"),
                   td.FluxMonitor(center=(0, 0, 0), size=(1.0, 1.0, 1.0), freqs=[f0], name="flux")],
         boundary_spec=td.BoundarySpec.all_sides(td.PML(num_layers=8)), shutoff=1e-5)
-    disc = discretize(sim)
-    sd = assemble(disc, OracleFdtd(disc.spec).run())
+    return sim, theta, phi
+
+
+def check_dipole_far_field(sd, theta, phi):
     far = sd["far"]
     e_t = np.abs(far.Etheta.values[0, :, :, 0])
     e_p = np.abs(far.Ephi.values[0, :, :, 0])
@@ -43,6 +45,13 @@ def test_dipole_pattern_and_power():
     # impedance of free space in the far zone
     ratio = far.Etheta.values[0, 9, 0, 0] / far.Hphi.values[0, 9, 0, 0]
     assert abs(abs(ratio) - 376.73) < 0.5
+
+
+def test_dipole_pattern_and_power():
+    sim, theta, phi = _dipole_sim()
+    disc = discretize(sim)
+    sd = assemble(disc, OracleFdtd(disc.spec).run())
+    check_dipole_far_field(sd, theta, phi)
 
 
 def test_cartesian_and_kspace_agree_with_the_angular_projection():

@@ -34,6 +34,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     # VGPRs for the plain sweep, 167 + spills -> 153 for the one that carries materials and CPML.
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
            "-mllvm", "-disable-lsr", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value", "-I/opt/rocm/include",
+           *os.environ.get("FDTD_EXTRA_HIPCC_FLAGS", "").split(),     # e.g. -DFDTD_PLACEMENT_PROBE for scripts/probe_layout.py
            *SOURCES, "-o", LIB, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd), flush=True)

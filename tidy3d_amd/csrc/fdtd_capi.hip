@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -142,6 +143,7 @@ struct FdtdSolver {
   // extra live registers drop the sweep from 3 to 2 (mask 6) or 1 (mask 7) waves per SIMD, which
   // costs more (+0.41 ms / +3.0 ms) than the slab kernels it removes (0.22 ms / 0.45 ms) -> default 0.
   int pml_fused = -1;                // -1 = default
+  int lds_pad = 0;                   // extra dynamic LDS per workgroup of the sweep (bytes): lowers its occupancy — a measuring aid
   int pml_split = -1;                // three launches (interior / y-edge / z-edge tiles): -1 = by grid size, 0 = one launch, 1 = always
   // opt-in (FDTD_OPT_AUTOTUNE): time a few (rows, z-chunk) tile shapes on the first run and keep the
   // best.  Measured (profiles/r01h_autotune.txt): +6 % on a 64-plane slab (3 x 32 instead of 3 x 16),
@@ -205,6 +207,69 @@ int dev_upload(FdtdSolver* h, T** out, const T* host, size_t count) {
   if (count) HIPCHK(h, hipMemcpy(*out, host, count * sizeof(T), hipMemcpyHostToDevice));
   return 0;
 }
+
+// The twelve field arrays: one allocation per array.
+//
+// WHERE they land in device memory decides up to 15 % of the sweep's speed (profiles/r02q_probe_series.jsonl,
+// r02t_probe_memory_depth.jsonl: the same kernel on the same box runs 1.174, 1.25 or 1.35 ms per 512^3 step depending
+// on the engine's allocations, to +-0.2 % within an engine and with all clocks unchanged; a fresh process's first
+// engine normally gets the fast state).  Virtual addresses do not show it, distances between the arrays inside one
+// allocation do not change it (r02r), so it is a property of the physical pages — nothing this library controls.
+// -DFDTD_PLACEMENT_PROBE compiles the placements those measurements used ($FDTD_FIELD_LAYOUT, scripts/probe_layout.py).
+#ifdef FDTD_PLACEMENT_PROBE
+// $FDTD_FIELD_LAYOUT, read at every fdtd_create:
+//   0  one allocation per array (default)          1  one allocation per field set (six arrays back to back)
+//   3  ONE allocation: array c of set q starts at  q * (6 * stride + $FDTD_FIELD_S2) + c * stride  bytes,
+//      stride = array bytes + $FDTD_FIELD_S1  (both multiples of 16)
+inline long env_long(const char* name, long dflt) {
+  const char* e = std::getenv(name);
+  return e ? std::atol(e) : dflt;
+}
+int alloc_field_set(FdtdSolver* h, float** base, size_t fcount, int set) {
+  const int mode = (int)env_long("FDTD_FIELD_LAYOUT", 0);
+  if (mode == 3 || mode == 4) {
+    if (set == 1) return 0;                                   // both sets were placed by the first call
+    const size_t s0 = (size_t)env_long("FDTD_FIELD_S0", 0) / 16 * 4;
+    const size_t s1 = (size_t)env_long("FDTD_FIELD_S1", 0) / 16 * 4, s2 = (size_t)env_long("FDTD_FIELD_S2", 0) / 16 * 4;
+    const size_t stride = fcount + s1;
+    float* blk = nullptr;
+    if (mode == 4) {                                          // 4: as 3, inside a pool that lives as long as the process
+      static float* pool = nullptr;                           //    (the SAME memory for every engine; $FDTD_FIELD_S0 = offset into it)
+      const size_t pool_floats = (size_t)env_long("FDTD_FIELD_POOL", 16L << 30) / 4;
+      if (!pool) HIPCHK(h, hipMalloc((void**)&pool, pool_floats * 4));
+      if (s0 + 12 * stride + s2 > pool_floats) return fail(h, "field pool too small");
+      blk = pool + s0;
+      HIPCHK(h, hipMemset(blk, 0, (12 * stride + s2) * 4));
+    } else if (dev_alloc(h, &blk, 12 * stride + s2)) return -1;
+    for (int c = 0; c < 6; ++c) {
+      h->fbase[c] = blk + (size_t)c * stride;
+      h->fbase2[c] = blk + 6 * stride + s2 + (size_t)c * stride;
+    }
+    if (env_long("FDTD_DEBUG_ADDR", 0)) std::fprintf(stderr, "field block at %p, stride %zu bytes\n", (void*)blk, stride * 4);
+    return 0;
+  }
+  if (mode == 1) {
+    float* blk = nullptr;
+    if (dev_alloc(h, &blk, 6 * fcount)) return -1;
+    for (int c = 0; c < 6; ++c) base[c] = blk + (size_t)c * fcount;
+    return 0;
+  }
+  // 5: one allocation per array, its size rounded up to a multiple of $FDTD_FIELD_ROUND bytes
+  const size_t round = mode == 5 ? (size_t)env_long("FDTD_FIELD_ROUND", 1L << 30) / 4 : 1;
+  for (int c = 0; c < 6; ++c) {
+    if (dev_alloc(h, &base[c], (fcount + round - 1) / round * round)) return -1;
+    if (env_long("FDTD_DEBUG_ADDR", 0)) std::fprintf(stderr, "field set %d array %d at %p\n", set, c, (void*)base[c]);
+  }
+  return 0;
+}
+
+#else
+int alloc_field_set(FdtdSolver* h, float** base, size_t fcount, int) {
+  for (int c = 0; c < 6; ++c)
+    if (dev_alloc(h, &base[c], fcount)) return -1;
+  return 0;
+}
+#endif
 
 inline unsigned nblk(long long n, int b = 256) { return (unsigned)((n + b - 1) / b); }
 
@@ -294,10 +359,9 @@ void launch_e_main(FdtdSolver* h, int kbeg, int kend, hipStream_t st) {
 // fused E+H sweep over the planes [kbeg, kend): reads the current set, writes the other one
 int ensure_second_set(FdtdSolver* h) {
   const GridP& g = h->g;
-  if (h->fbase2[0]) return 0;
+  if (h->f2.ex) return 0;
   const size_t fcount = (size_t)g.sxy * (g.nz + 2);
-  for (int c = 0; c < 6; ++c)
-    if (dev_alloc(h, &h->fbase2[c], fcount)) return -1;
+  if (!h->fbase2[0] && alloc_field_set(h, h->fbase2, fcount, 1)) return -1;
   h->f2.ex = h->fbase2[0] + g.sxy; h->f2.ey = h->fbase2[1] + g.sxy; h->f2.ez = h->fbase2[2] + g.sxy;
   h->f2.hx = h->fbase2[3] + g.sxy; h->f2.hy = h->fbase2[4] + g.sxy; h->f2.hz = h->fbase2[5] + g.sxy;
   return 0;
@@ -388,7 +452,7 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pm
   const bool whole = ty_gap == 0 && ty_n == nby_all && k2end <= k2beg;
   const int remap = h->xcd_remap < 0 ? (whole ? 1 : 0) : (h->xcd_remap ? 1 : 0);
   dim3 grid(remap ? ((total + 7) / 8) * 8 : total, 1, 1);
-  const size_t shmem = ((size_t)2 * 2 * (R + 1) * 64 + (pml_inside ? 6 * 64 : 0)) * sizeof(float4);   // both CPML instantiations stage the x coefficients
+  const size_t shmem = ((size_t)2 * 2 * (R + 1) * 64 + (pml_inside ? 6 * 64 : 0)) * sizeof(float4) + (size_t)h->lds_pad;   // both CPML instantiations stage the x coefficients
   const int pmc = h->cfg.bc[4] == FDTD_BC_PMC;
   MatP m = mat_params(h);
   StepP s = step_params(h);
@@ -853,7 +917,7 @@ int fdtd_create(const FdtdConfig* cfg, FdtdSolver** out) {
   int rc = 0;
   const size_t fcount = (size_t)g.sxy * (g.nz + 2);
   h->field_bytes = fcount * sizeof(float);
-  for (int c = 0; c < 6 && !rc; ++c) rc = dev_alloc(h, &h->fbase[c], fcount);
+  rc = alloc_field_set(h, h->fbase, fcount, 0);
   if (!rc) {
     h->f.ex = h->fbase[0] + g.sxy; h->f.ey = h->fbase[1] + g.sxy; h->f.ez = h->fbase[2] + g.sxy;
     h->f.hx = h->fbase[3] + g.sxy; h->f.hy = h->fbase[4] + g.sxy; h->f.hz = h->fbase[5] + g.sxy;
@@ -1849,6 +1913,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_PML_FUSED: h->pml_fused = value < 0 ? -1 : (value & 7); for (bool& ok : h->pml_blk_ok) ok = false; return 0;
     case FDTD_OPT_BND_PLANES: h->bnd_planes = value > 0 ? value : 0; return 0;
     case FDTD_OPT_AUTOTUNE: h->autotune = value < 0 ? 0 : (value > 2 ? 1 : value); if (value) h->tuned = false; return 0;
+    case FDTD_OPT_LDS_PAD: if (value < 0 || value > 120000) break; h->lds_pad = value; return 0;
     case FDTD_OPT_PML_SPLIT: h->pml_split = value < 0 ? -1 : (value != 0); return 0;
     case FDTD_OPT_FUSED_LB: if (value != 0 && value != 256 && value != 512 && value != 1024) break; h->fused_lb = value; return 0;
     default: break;

@@ -946,7 +946,7 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
         // one word per row segment (256 cells of one row): the medium word of all its cells when they
         // agree — then the packed words are not read at all — or kMixedWord (both fetched at the top of the plane)
         if (rw != kMixedWord) {
-          const float2 c0 = m.lut[rw & 1023u], c1 = m.lut[(rw >> 10) & 1023u], c2 = m.lut[(rw >> 20) & 1023u];
+          const float2 c0 = lut_s[rw & 1023u], c1 = lut_s[(rw >> 10) & 1023u], c2 = lut_s[(rw >> 20) & 1023u];
           e_phase([&](int c, int) { return c == 0 ? c0 : (c == 1 ? c1 : c2); });
         } else {
           e_phase([&](int c, int e) { return lut_s[(mw[e] >> (10 * c)) & 1023u]; });
