@@ -214,7 +214,9 @@ int dev_upload(FdtdSolver* h, T** out, const T* host, size_t count) {
 // r02t_probe_memory_depth.jsonl: the same kernel on the same box runs 1.174, 1.25 or 1.35 ms per 512^3 step depending
 // on the engine's allocations, to +-0.2 % within an engine and with all clocks unchanged; a fresh process's first
 // engine normally gets the fast state).  Virtual addresses do not show it, distances between the arrays inside one
-// allocation do not change it (r02r), so it is a property of the physical pages — nothing this library controls.
+// allocation do not change it (r02r), nor does aligning the virtual addresses to the array size — through
+// $HSA_MAX_VA_ALIGN or through hipMemAddressReserve + hipMemMap (r02u, r02v: 1.25 ms mapped against 1.17-1.19 ms
+// hipMalloc'ed on the same box) — so it is a property of the physical pages, nothing this library controls.
 // -DFDTD_PLACEMENT_PROBE compiles the placements those measurements used ($FDTD_FIELD_LAYOUT, scripts/probe_layout.py).
 #ifdef FDTD_PLACEMENT_PROBE
 // $FDTD_FIELD_LAYOUT, read at every fdtd_create:
