@@ -220,6 +220,8 @@ def main():
     ap.add_argument("--zchunk", type=int, default=0)
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--pml-fused", type=int, default=-1, help="axis mask of the CPML recursions folded into the fused sweep (0, 6, 7)")
+    ap.add_argument("--tile-order", type=int, default=-1, help="-1: the library times both tile orders on the first sweep (default); "
+                    "0 / 1: plain / XCD-aware (profiling runs: keeps the probe sweeps out of the counters)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--no-workloads", action="store_true", help="skip the secondary V2 (materials + CPML) measurement")
@@ -267,6 +269,8 @@ def main():
         eng.set_option(L.OPT_ROWS, args.rows)
     if args.pml_fused >= 0:
         eng.set_option(L.OPT_PML_FUSED, args.pml_fused)
+    if args.tile_order >= 0:
+        eng.set_option(L.OPT_XCD_REMAP, args.tile_order)
     if world > 1:
         uid = [eng.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -329,7 +333,7 @@ def main():
         "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]}; {n}^3 Yee cells, Ez point dipole "
                                "(GaussianPulse 200 THz), random +-1e-3 initial fields",
                    "grid": [n, n, n], "parallelism": f"z-slab x{world}",
-                   "tile": {"rows": int(st.tile_rows), "zchunk": int(st.tile_zchunk),
+                   "tile": {"rows": int(st.tile_rows), "zchunk": int(st.tile_zchunk), "xcd_order": int(st.tile_order),
                             "how": "library default" if not (args.rows or args.zchunk) else "flags"},
                    "bytes_per_cell_step": 2 * BYTES_PER_CELL_PASS,
                    "roofline_mcells_per_gpu": HBM_PEAK / (2 * BYTES_PER_CELL_PASS) / 1e6},

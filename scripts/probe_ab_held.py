@@ -1,0 +1,35 @@
+"""GPU probe: A/B of option sets inside each of several engines that are all kept alive (each has its own placement in
+device memory): does the better setting depend on the placement?
+    python scripts/probe_ab_held.py <n> <workload> "<set>;<set>;..." <engines>"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import bench
+from tidy3d_amd import lib as L
+from tidy3d_amd.engine import HipEngine
+
+n = int(sys.argv[1]); wl = sys.argv[2]; sets = sys.argv[3].split(";"); n_eng = int(sys.argv[4])
+rng = np.random.default_rng(1)
+arr = np.empty((n, n, n), dtype=np.float32)
+pl = [rng.uniform(-1e-3, 1e-3, (n, n)).astype(np.float32) for _ in range(8)]
+for k in range(n):
+    arr[k] = pl[k % 8]
+spec = bench.build_spec(n, 100000, wl)
+held = []
+for i in range(n_eng):
+    eng = HipEngine(spec)
+    held.append(eng)
+    for c in range(6):
+        eng.set_field(c, np.roll(arr, c, axis=0))
+    eng.set_option(L.OPT_FLAGS, 0)
+    eng.run(10)
+    res = {s_: [] for s_ in sets}
+    for _ in range(2):
+        for s_ in sets:
+            for kv in s_.split(","):
+                k_, x_ = kv.split("=")
+                eng.set_option(getattr(L, k_), int(x_))
+            eng.run(4)
+            t0 = time.perf_counter(); eng.run(40); res[s_].append(round((time.perf_counter() - t0) / 40 * 1e3, 4))
+    print(json.dumps({"wl": wl, "engine": i, "ms_per_step": res}), flush=True)

@@ -143,6 +143,9 @@ struct FdtdSolver {
   // extra live registers drop the sweep from 3 to 2 (mask 6) or 1 (mask 7) waves per SIMD, which
   // costs more (+0.41 ms / +3.0 ms) than the slab kernels it removes (0.22 ms / 0.45 ms) -> default 0.
   int pml_fused = -1;                // -1 = default
+  int tile_order = 1;                // what xcd_remap = -1 (auto) resolves to for whole-grid launches; pick_tile_order() decides
+  bool order_picked = false;
+  int mem_hints = 1;                 // FDTD_OPT_MEM_HINTS: 1 = non-temporal field stores in the sweep's instantiations without CPML
   int lds_pad = 0;                   // extra dynamic LDS per workgroup of the sweep (bytes): lowers its occupancy — a measuring aid
   int pml_split = -1;                // three launches (interior / y-edge / z-edge tiles): -1 = by grid size, 0 = one launch, 1 = always
   // opt-in (FDTD_OPT_AUTOTUNE): time a few (rows, z-chunk) tile shapes on the first run and keep the
@@ -452,7 +455,7 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pm
   const int nbz = nbz1 + (k2end > k2beg ? (k2end - k2beg + zc - 1) / zc : 0);
   const int total = nbx * nby * nbz;
   const bool whole = ty_gap == 0 && ty_n == nby_all && k2end <= k2beg;
-  const int remap = h->xcd_remap < 0 ? (whole ? 1 : 0) : (h->xcd_remap ? 1 : 0);
+  const int remap = h->xcd_remap < 0 ? (whole ? h->tile_order : 0) : (h->xcd_remap ? 1 : 0);
   dim3 grid(remap ? ((total + 7) / 8) * 8 : total, 1, 1);
   const size_t shmem = ((size_t)2 * 2 * (R + 1) * 64 + (pml_inside ? 6 * 64 : 0)) * sizeof(float4) + (size_t)h->lds_pad;   // both CPML instantiations stage the x coefficients
   const int pmc = h->cfg.bc[4] == FDTD_BC_PMC;
@@ -464,9 +467,17 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pm
   if (lb < threads) lb = threads <= 512 ? 512 : 1024;
   time_begin(h, 2, st);
   const PmlP* pm = pml_inside ? h->pml_blk[pml_inside][h->pml_parity] : nullptr;
-#define FDTD_LAUNCH_FUSED(MATV, LBV, PMLV)                                                            \
-  hipLaunchKernelGGL((fused_step_kernel<MATV, LBV, PMLV>), grid, block, shmem, st, g, h->f, h->f2, s, m, kbeg, \
+#define FDTD_LAUNCH_FUSED_H(MATV, LBV, PMLV, HV)                                                       \
+  hipLaunchKernelGGL((fused_step_kernel<MATV, LBV, PMLV, HV>), grid, block, shmem, st, g, h->f, h->f2, s, m, kbeg, \
                      kend, zc, pmc, nbx, nby, nbz, remap, pm, nbz1, k2beg, k2end, ty_a, ty_gap)
+  // Non-temporal field stores (FDTD_OPT_MEM_HINTS) in the instantiations WITHOUT CPML only: measured inside one engine
+  // (profiles/r02z_probe_same_engine_cache_hints.jsonl) they take 2.1 % off the plain sweep and 3.1 % off the one with
+  // materials, and ADD 13 % to the CPML-carrying ones (2-3 waves per SIMD: the slower store completion is not hidden).
+#define FDTD_LAUNCH_FUSED(MATV, LBV, PMLV)                                                            \
+  do {                                                                                                \
+    if (PMLV == 0 && h->mem_hints) FDTD_LAUNCH_FUSED_H(MATV, LBV, 0, 1);                              \
+    else FDTD_LAUNCH_FUSED_H(MATV, LBV, PMLV, 0);                                                     \
+  } while (0)
   if (pml_inside == 1) {        // x recursions only: every tile of a grid with x layers
     if (h->mat4) { if (lb == 256) FDTD_LAUNCH_FUSED(true, 256, 1); else FDTD_LAUNCH_FUSED(true, 512, 1); }
     else { if (lb == 256) FDTD_LAUNCH_FUSED(false, 256, 1); else FDTD_LAUNCH_FUSED(false, 512, 1); }
@@ -492,6 +503,39 @@ int launch_fused(FdtdSolver* h, hipStream_t st, int pml_inside) {
   if (launch_fused_range(h, 0, h->g.nz, st, pml_inside)) return -1;
   swap_sets(h);
   swap_psi_h(h, pml_inside);
+  return 0;
+}
+
+// Which tile order is faster — XCD-aware or plain — depends on where the arrays landed in device memory: measured
+// INSIDE ten engines held side by side (profiles/r03b_probe_tile_order_vs_placement.jsonl) the plain order wins in
+// seven (by up to 4.5 %) and the XCD-aware one in three (by up to 2 %).  So the first large sweep of an engine
+// times both (the sweep reads set A and writes set B: repeating it has no side effect, and the results do not
+// depend on the order) and keeps the faster — eight sweeps, once.  Only for sweeps without in-sweep CPML (those
+// update psi_E in place) and only when the order is left to the library.
+int pick_tile_order(FdtdSolver* h, hipStream_t st) {
+  h->order_picked = true;
+  if (ensure_second_set(h)) return -1;
+  const int flags = h->cfg.flags;
+  h->cfg.flags &= ~FDTD_FLAG_TIME_KERNELS;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  float t[2] = {0.f, 0.f};
+  int rc = 0;
+  for (int o = 1; o >= 0 && !rc; --o) {
+    h->tile_order = o;
+    if (launch_fused_range(h, 0, h->g.nz, st)) { rc = -1; break; }         // warm-up
+    hipEventRecord(e0, st);
+    for (int k = 0; k < 3 && !rc; ++k) rc = launch_fused_range(h, 0, h->g.nz, st);
+    hipEventRecord(e1, st);
+    if (hipEventSynchronize(e1) != hipSuccess) { rc = fail(h, "pick_tile_order: %s", hipGetErrorString(hipGetLastError())); break; }
+    hipEventElapsedTime(&t[o], e0, e1);
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  h->cfg.flags = flags;
+  if (rc) return -1;
+  h->tile_order = t[1] <= t[0] ? 1 : 0;
   return 0;
 }
 
@@ -1579,6 +1623,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       // small grids are bound by dependent launches, not by occupancy: one launch of the all-axes instantiation
       const bool split = h->pml_split < 0 ? n_cells(h) >= (1LL << 24) : h->pml_split != 0;
       if ((pml_in & 6) == 0 || !split) {
+        if (!pml_in && !h->order_picked && h->xcd_remap < 0 && n_cells(h) >= (1LL << 24) && pick_tile_order(h, st)) return -1;
         if (launch_fused(h, st, pml_in)) return -1;
       } else {
         // The instantiation that carries the y / z recursions holds their psi values in registers from the
@@ -1915,6 +1960,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_PML_FUSED: h->pml_fused = value < 0 ? -1 : (value & 7); for (bool& ok : h->pml_blk_ok) ok = false; return 0;
     case FDTD_OPT_BND_PLANES: h->bnd_planes = value > 0 ? value : 0; return 0;
     case FDTD_OPT_AUTOTUNE: h->autotune = value < 0 ? 0 : (value > 2 ? 1 : value); if (value) h->tuned = false; return 0;
+    case FDTD_OPT_MEM_HINTS: h->mem_hints = value != 0; return 0;
     case FDTD_OPT_LDS_PAD: if (value < 0 || value > 120000) break; h->lds_pad = value; return 0;
     case FDTD_OPT_PML_SPLIT: h->pml_split = value < 0 ? -1 : (value != 0); return 0;
     case FDTD_OPT_FUSED_LB: if (value != 0 && value != 256 && value != 512 && value != 1024) break; h->fused_lb = value; return 0;
@@ -1928,6 +1974,8 @@ int fdtd_get_stats(FdtdSolver* h, FdtdStats* out) {
   *out = h->stats;
   out->tile_rows = h->rows_f;
   out->tile_zchunk = h->zchunk_f;
+  out->tile_order = h->xcd_remap < 0 ? h->tile_order : (h->xcd_remap ? 1 : 0);
+  out->reserved0 = 0;
   return 0;
 }
 

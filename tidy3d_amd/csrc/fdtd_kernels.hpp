@@ -78,6 +78,22 @@ __device__ __forceinline__ void stv(float* __restrict__ p, const float (&r)[V]) 
   }
 }
 
+// Streaming store: what the sweep writes is not read again before the next step, 6 GB of traffic later.  The
+// non-temporal hint keeps those lines from displacing the rows that NEIGHBOURING workgroups are about to re-read
+// (halo rows) from the 4 MiB L2 of the XCD.
+template <int V, bool NT>
+__device__ __forceinline__ void stv_h(float* __restrict__ p, const float (&r)[V]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (NT && V == 4) {
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    v4f_ t; t.x = r[0]; t.y = r[1]; t.z = r[2]; t.w = r[3];
+    __builtin_nontemporal_store(t, reinterpret_cast<v4f_*>(p));
+    return;
+  }
+#endif
+  stv<V>(p, r);
+}
+
 // packed material words of V consecutive cells: ONE 16-byte load per thread (V = 4) instead of
 // three 4-byte ones
 template <int V>
@@ -370,6 +386,18 @@ __device__ __forceinline__ void ldg4(float (&r)[4], const float* base, unsigned 
   const v4f t = *(const FDTD_AS_GLOBAL v4f*)((const FDTD_AS_GLOBAL char*)base + off);
   r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
 }
+// Streaming load of data no other wave reads (E_y and H_y have no y-neighbour in the curl).
+template <int V, bool NT>
+__device__ __forceinline__ void ldv_h(float (&r)[V], const float* base, unsigned off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (NT && V == 4) {
+    const v4f t = __builtin_nontemporal_load((const FDTD_AS_GLOBAL v4f*)((const FDTD_AS_GLOBAL char*)base + off));
+    r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+    return;
+  }
+#endif
+  ldv<V>(r, at(base, off));
+}
 __device__ __forceinline__ void stg4(float* base, unsigned off, const float (&r)[4]) {
   v4f t; t.x = r[0]; t.y = r[1]; t.z = r[2]; t.w = r[3];
   *(FDTD_AS_GLOBAL v4f*)((FDTD_AS_GLOBAL char*)base + off) = t;
@@ -451,7 +479,7 @@ __device__ __forceinline__ void pml_h_apply(float& h1, float& h2, float d1, floa
 //     first plane of a chunk recomputes H^{n+1/2}[k0-1] in a prologue).
 // Everything that depends on the row only (threadIdx.y is wave-uniform) is kept in SGPRs.
 // =============================================================================================
-template <bool MAT, int LB, int PML>   // PML: bit a set = CPML of axis a runs inside the sweep
+template <bool MAT, int LB, int PML, int HINT = 0>   // PML: bit a set = CPML of axis a runs inside the sweep; HINT: bit 0 = non-temporal field stores, bit 1 = non-temporal loads of E_y, H_y (bit 1 measured: +0.7 %, not instantiated)
 __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)) : (LB == 512 ? (PML ? 2 : 4) : 4))) void fused_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
                                                           int kbeg, int kend, int zchunk, int pmc_z0,
                                                           int nbx, int nby, int nbz, int xcd_remap,
@@ -656,7 +684,7 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
     float exn[V], eyn[V], ezk[V], exj[V], ezj[V], hxn[V], hyn[V], hzn[V];
     const float ipz = s.ipz[k], idz = s.idz[k];
     ldv<V>(exn, at(uni(a.ex + pb + g.sxy), ubc));
-    ldv<V>(eyn, at(uni(a.ey + pb + g.sxy), ubc));
+    ldv_h<V, (HINT & 2) != 0>(eyn, uni(a.ey + pb + g.sxy), ubc);
     ldv<V>(ezk, at(uni(a.ez + pb), ubc));
     if (use_jp) {
       ldv<V>(exj, at(uni(a.ex + pjb), ubc));
@@ -665,7 +693,7 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
       zero<V>(exj); zero<V>(ezj);                // row j+1 beyond a wall: E = 0 there
     }
     ldv<V>(hxn, at(uni(a.hx + pb), ubc));
-    if (!halo) ldv<V>(hyn, at(uni(a.hy + pb), ubc));      // the halo wave only publishes H_x and H_z
+    if (!halo) ldv_h<V, (HINT & 2) != 0>(hyn, uni(a.hy + pb), ubc);      // the halo wave only publishes H_x and H_z
     else zero<V>(hyn);
     ldv<V>(hzn, at(uni(a.hz + pb), ubc));
     // ---- CPML state of this plane: EVERY psi load is issued here, with the field loads, so that ONE memory
@@ -934,12 +962,12 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
           }
         }
       }
-      stv<V>(b.hx + pb + i0, hxn);
-      stv<V>(b.hy + pb + i0, hyn);
-      stv<V>(b.hz + pb + i0, hzn);
-      stv<V>(b.ex + pb + i0, ex);
-      stv<V>(b.ey + pb + i0, ey);
-      stv<V>(b.ez + pb + i0, ez);
+      stv_h<V, (HINT & 1) != 0>(b.hx + pb + i0, hxn);
+      stv_h<V, (HINT & 1) != 0>(b.hy + pb + i0, hyn);
+      stv_h<V, (HINT & 1) != 0>(b.hz + pb + i0, hzn);
+      stv_h<V, (HINT & 1) != 0>(b.ex + pb + i0, ex);
+      stv_h<V, (HINT & 1) != 0>(b.ey + pb + i0, ey);
+      stv_h<V, (HINT & 1) != 0>(b.ez + pb + i0, ez);
     };
     if (act && !halo) {
       if constexpr (MAT) {
