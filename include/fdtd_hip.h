@@ -192,7 +192,7 @@ int fdtd_run_bloch(FdtdSolver* h_re, FdtdSolver* h_im, int64_t n_steps, const do
 /* ref web/api/webapi.py:370 (task status incl. "diverged"), web/core/task_core.py:537 (run info) */
 int fdtd_get_stats(FdtdSolver* h, FdtdStats* out);
 /* tuning knobs that may change between runs of one handle (bench A/B without re-upload) */
-enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_ROWS = 3, FDTD_OPT_XCD_REMAP = 4 /* -1 = automatic (default), 0, 1 */,
+enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_ROWS = 3, FDTD_OPT_XCD_REMAP = 4 /* tile order of the sweep: -1 = default (runs of 8 tiles per XCD), 0 = plain, 1 = a contiguous eighth per XCD, G > 1 = runs of G tiles */,
        FDTD_OPT_FUSED_LB = 5,
        FDTD_OPT_PML_FUSED = 6 /* axes (bit mask) whose CPML recursions run inside the fused sweep: -1 = all (default), 0 = slab kernels */,
        FDTD_OPT_BND_PLANES = 7 /* planes per boundary chunk of the fused z-slab schedule, 0 = auto */,

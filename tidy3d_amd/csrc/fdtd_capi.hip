@@ -133,9 +133,8 @@ struct FdtdSolver {
   int zchunk_f = 16;                 // planes marched per workgroup by the fused sweep
   int rows_f = 3;                    // rows per workgroup of the fused sweep (+1 halo wave = 256 threads:
                                      // ~150 VGPRs without spills, 3 workgroups per CU; measured best, profiles/r01g)
-  // XCD-aware tile order (fdtd_kernels.hpp): -1 = automatic.  Same-box A/B, 512^3 (profiles/r02e_probe_ab_same_box.jsonl):
-  // a sweep that goes out as ONE launch gains from it (V0 1.170 vs 1.249 ms, V1 1.209 vs 1.226), the three
-  // concurrent launches of a CPML-carrying step lose (V2 1.625 vs 1.513 ms) -> on for whole-grid launches only.
+  // tile order of the sweep: -1 = default (runs of kTileRun tiles per XCD), 0 = plain, 1 = one contiguous eighth of
+  // the tiles per XCD (round 1), G > 1 = runs of G tiles per XCD; measurements at launch_fused_range
   int xcd_remap = -1;
   int fused_lb = 0;                  // 0 = by workgroup size, else forced __launch_bounds__ variant
   // axis mask of the CPML recursions folded into the fused sweep (single GPU): 0 = slab kernels,
@@ -143,8 +142,6 @@ struct FdtdSolver {
   // extra live registers drop the sweep from 3 to 2 (mask 6) or 1 (mask 7) waves per SIMD, which
   // costs more (+0.41 ms / +3.0 ms) than the slab kernels it removes (0.22 ms / 0.45 ms) -> default 0.
   int pml_fused = -1;                // -1 = default
-  int tile_order = 1;                // what xcd_remap = -1 (auto) resolves to for whole-grid launches; pick_tile_order() decides
-  bool order_picked = false;
   int mem_hints = 1;                 // FDTD_OPT_MEM_HINTS: 1 = non-temporal field stores in the sweep's instantiations without CPML
   int lds_pad = 0;                   // extra dynamic LDS per workgroup of the sweep (bytes): lowers its occupancy — a measuring aid
   int pml_split = -1;                // three launches (interior / y-edge / z-edge tiles): -1 = by grid size, 0 = one launch, 1 = always
@@ -275,6 +272,8 @@ int alloc_field_set(FdtdSolver* h, float** base, size_t fcount, int) {
   return 0;
 }
 #endif
+
+constexpr int kTileRun = 8;          // default tile order of the sweep: runs of 8 tiles per XCD (launch_fused_range)
 
 inline unsigned nblk(long long n, int b = 256) { return (unsigned)((n + b - 1) / b); }
 
@@ -454,8 +453,14 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pm
   const int nbx = (g.nx + 255) / 256, nby = ty_n, nbz1 = (kend - kbeg + zc - 1) / zc;
   const int nbz = nbz1 + (k2end > k2beg ? (k2end - k2beg + zc - 1) / zc : 0);
   const int total = nbx * nby * nbz;
-  const bool whole = ty_gap == 0 && ty_n == nby_all && k2end <= k2beg;
-  const int remap = h->xcd_remap < 0 ? (whole ? h->tile_order : 0) : (h->xcd_remap ? 1 : 0);
+  // Tile order (kernel: launch argument xcd_remap).  Default: runs of 8 consecutive tiles (y-neighbours) per XCD, the
+  // runs round-robin over the XCDs.  Measured INSIDE engines held side by side (the only comparison free of the
+  // placement effect; profiles/r03d_probe_grouped_tile_order.jsonl, r03e_*): faster than the plain order in every
+  // engine (plain sweep -1.4 ... -5 %, materials -1.2 ... -3.8 %, CPML-carrying three-launch step -1.3 ... -2.3 %)
+  // and than the contiguous one-eighth-per-XCD split of round 1 (-1.8 ... -9 %), which moves fewer bytes (7.1 vs
+  // 8.6 GB per 512^3 sweep in the plain order) but has the eight XCDs stream eight distant regions of every array.
+  // Runs of 6 ... 32 tiles are within 0.5 % of each other.
+  const int remap = h->xcd_remap < 0 ? kTileRun : h->xcd_remap;
   dim3 grid(remap ? ((total + 7) / 8) * 8 : total, 1, 1);
   const size_t shmem = ((size_t)2 * 2 * (R + 1) * 64 + (pml_inside ? 6 * 64 : 0)) * sizeof(float4) + (size_t)h->lds_pad;   // both CPML instantiations stage the x coefficients
   const int pmc = h->cfg.bc[4] == FDTD_BC_PMC;
@@ -503,39 +508,6 @@ int launch_fused(FdtdSolver* h, hipStream_t st, int pml_inside) {
   if (launch_fused_range(h, 0, h->g.nz, st, pml_inside)) return -1;
   swap_sets(h);
   swap_psi_h(h, pml_inside);
-  return 0;
-}
-
-// Which tile order is faster — XCD-aware or plain — depends on where the arrays landed in device memory: measured
-// INSIDE ten engines held side by side (profiles/r03b_probe_tile_order_vs_placement.jsonl) the plain order wins in
-// seven (by up to 4.5 %) and the XCD-aware one in three (by up to 2 %).  So the first large sweep of an engine
-// times both (the sweep reads set A and writes set B: repeating it has no side effect, and the results do not
-// depend on the order) and keeps the faster — eight sweeps, once.  Only for sweeps without in-sweep CPML (those
-// update psi_E in place) and only when the order is left to the library.
-int pick_tile_order(FdtdSolver* h, hipStream_t st) {
-  h->order_picked = true;
-  if (ensure_second_set(h)) return -1;
-  const int flags = h->cfg.flags;
-  h->cfg.flags &= ~FDTD_FLAG_TIME_KERNELS;
-  hipEvent_t e0, e1;
-  hipEventCreate(&e0);
-  hipEventCreate(&e1);
-  float t[2] = {0.f, 0.f};
-  int rc = 0;
-  for (int o = 1; o >= 0 && !rc; --o) {
-    h->tile_order = o;
-    if (launch_fused_range(h, 0, h->g.nz, st)) { rc = -1; break; }         // warm-up
-    hipEventRecord(e0, st);
-    for (int k = 0; k < 3 && !rc; ++k) rc = launch_fused_range(h, 0, h->g.nz, st);
-    hipEventRecord(e1, st);
-    if (hipEventSynchronize(e1) != hipSuccess) { rc = fail(h, "pick_tile_order: %s", hipGetErrorString(hipGetLastError())); break; }
-    hipEventElapsedTime(&t[o], e0, e1);
-  }
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  h->cfg.flags = flags;
-  if (rc) return -1;
-  h->tile_order = t[1] <= t[0] ? 1 : 0;
   return 0;
 }
 
@@ -1623,7 +1595,6 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       // small grids are bound by dependent launches, not by occupancy: one launch of the all-axes instantiation
       const bool split = h->pml_split < 0 ? n_cells(h) >= (1LL << 24) : h->pml_split != 0;
       if ((pml_in & 6) == 0 || !split) {
-        if (!pml_in && !h->order_picked && h->xcd_remap < 0 && n_cells(h) >= (1LL << 24) && pick_tile_order(h, st)) return -1;
         if (launch_fused(h, st, pml_in)) return -1;
       } else {
         // The instantiation that carries the y / z recursions holds their psi values in registers from the
@@ -1956,7 +1927,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_VARIANT: h->cfg.variant = value; return 0;
     case FDTD_OPT_ZCHUNK: if (value < 1) break; h->zchunk = value; h->zchunk_f = value; h->user_geometry = true; return 0;
     case FDTD_OPT_ROWS: if (value < 1 || value > 15) break; h->rows = value > 8 ? 8 : value; h->rows_f = value; h->user_geometry = true; return 0;
-    case FDTD_OPT_XCD_REMAP: h->xcd_remap = value < 0 ? -1 : (value != 0); return 0;
+    case FDTD_OPT_XCD_REMAP: if (value > 1024) break; h->xcd_remap = value < 0 ? -1 : value; return 0;
     case FDTD_OPT_PML_FUSED: h->pml_fused = value < 0 ? -1 : (value & 7); for (bool& ok : h->pml_blk_ok) ok = false; return 0;
     case FDTD_OPT_BND_PLANES: h->bnd_planes = value > 0 ? value : 0; return 0;
     case FDTD_OPT_AUTOTUNE: h->autotune = value < 0 ? 0 : (value > 2 ? 1 : value); if (value) h->tuned = false; return 0;
@@ -1974,7 +1945,7 @@ int fdtd_get_stats(FdtdSolver* h, FdtdStats* out) {
   *out = h->stats;
   out->tile_rows = h->rows_f;
   out->tile_zchunk = h->zchunk_f;
-  out->tile_order = h->xcd_remap < 0 ? h->tile_order : (h->xcd_remap ? 1 : 0);
+  out->tile_order = h->xcd_remap < 0 ? kTileRun : h->xcd_remap;
   out->reserved0 = 0;
   return 0;
 }

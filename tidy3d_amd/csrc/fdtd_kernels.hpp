@@ -486,16 +486,26 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
                                                           const PmlP* __restrict__ pmq,
                                                           int nbz1, int k2beg, int k2end, int ty_a, int ty_gap) {
   constexpr int V = 4;
-  // 1-D launch; logical tile (bx, by, bz) with by fastest.  XCD-aware remap: hardware block L runs
-  // on XCD L % 8 (observed dispatch order, used for speed only), so XCD x is handed the contiguous
-  // range of logical tiles [x * per, (x+1) * per): y-neighbouring tiles — which share their halo
-  // row — are resident on the same XCD at about the same time and meet in its L2.
+  // 1-D launch; logical tile (bx, by, bz) with by fastest.  Hardware block L runs on XCD L % 8 (observed dispatch
+  // order, used for speed only); y-neighbouring tiles share their halo row, and meet in an XCD's L2 when they are
+  // resident there at about the same time.  xcd_remap = 0: plain order (neighbours on different XCDs);
+  // 1: XCD x gets the contiguous range [x * per, (x+1) * per) of tiles; G > 1: see below (the default, G = 8).
   const int total = nbx * nby * nbz;
   int t = blockIdx.x;
-  if (xcd_remap) {
+  if (xcd_remap == 1) {
     const int per = (total + 7) >> 3;
     t = (t & 7) * per + (t >> 3);
     if (t >= total) return;              // whole workgroup leaves before any barrier
+  } else if (xcd_remap > 1) {
+    // grouped order: runs of G = xcd_remap consecutive tiles (y-neighbours) go to one XCD, the runs round-robin over
+    // the XCDs — the halo rows inside a run still meet in that XCD's L2, while all eight XCDs work in the same
+    // few z-chunks (the contiguous split above has them stream eight distant regions of every array at once)
+    const int G = xcd_remap, full = total / (8 * G) * (8 * G);
+    if (t < full) {
+      const int x = t & 7, mloc = t >> 3;
+      t = ((mloc / G) * 8 + x) * G + mloc % G;
+    }
+    if (t >= total) return;
   }
   // tile rows of this launch: the first ty_a, then (after a gap of ty_gap) the rest — the launch that
   // carries the y / z recursions covers the bottom and top tile rows only, a leaner one the middle
