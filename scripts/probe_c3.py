@@ -24,13 +24,25 @@ def main():
         boundary_spec=td.BoundarySpec.all_sides(td.PML(num_layers=12)), shutoff=0)
     sp = discretize(sim, n_steps=steps + 40).spec
     sp.decay_every = 0
-    with HipEngine(sp) as e:
-        e.run(30)
-        t0 = time.perf_counter()
-        e.run(steps)
-        dt = time.perf_counter() - t0
     n = sp.shape[0] * sp.shape[1] * sp.shape[2]
-    print(json.dumps({"shape": sp.shape, "ms_per_step": dt / steps * 1e3, "mcells_per_s": n * steps / dt / 1e6}), flush=True)
+    # optional: cyclic axis shifts to compare (each its own engine, all kept alive; the list is walked twice)
+    shifts = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [None]
+    held = []
+    for rnd in range(2 if len(shifts) > 1 else 1):
+        for sh in shifts:
+            e = HipEngine(sp, axis_shift=sh)
+            held.append(e)
+            e.run(30)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                e.run(steps)
+                ts.append(time.perf_counter() - t0)
+            dt = sorted(ts)[1]
+            print(json.dumps({"shape": sp.shape, "axis_shift": e.axis_shift, "device_shape": list(e.spec.shape), "ms_per_step": dt / steps * 1e3,
+                              "mcells_per_s": n * steps / dt / 1e6}), flush=True)
+    for e in held:
+        e.close()
 
 
 if __name__ == "__main__":

@@ -11,7 +11,10 @@ from tidy3d_amd.engine import HipEngine, best_axis_shift, lane_efficiency, permu
 
 def test_policy():
     assert lane_efficiency(256) == 1.0 and lane_efficiency(60) == pytest.approx(60 / 256) and lane_efficiency(258) == pytest.approx(258 / 512)
-    assert best_axis_shift((512, 512, 512)) == 0 and best_axis_shift((424, 224, 824)) == 0      # BASELINE shapes stay
+    assert best_axis_shift((512, 512, 512)) == 0 and best_axis_shift((512, 512, 512), ((12, 12),) * 3) == 0
+    assert best_axis_shift((1024, 1024, 256), ((0, 0), (0, 0), (12, 12))) == 0                  # config 5 stays
+    # config 3: x = 224 fills its one row segment better than 424 fills two, and fewer tiles meet a y / z slab
+    assert best_axis_shift((424, 224, 824), ((12, 12),) * 3) == 1
     assert best_axis_shift((60, 60, 400)) == 2 and best_axis_shift((60, 400, 60)) == 1
     assert best_axis_shift((258, 250, 264)) == 1            # 258 spills into a second tile, 250 does not
     assert best_axis_shift((8, 12, 20)) == 0                # tiny grids: launch-bound, left alone

@@ -105,15 +105,32 @@ def lane_efficiency(n: int) -> float:
     return n / (256.0 * -(-n // 256))
 
 
-def best_axis_shift(shape) -> int:
-    """Cyclic axis shift s (new axis a holds old axis (a + s) % 3) that puts the axis with the best lane
-    efficiency along x; 0 unless it buys more than 25 % on a grid of at least 2^18 cells (below that a run is
-    bound by launches, not lanes)."""
+def sweep_cost(shape, pml_layers=None) -> float:
+    """Relative cost per cell of the fused sweep for a grid laid out as ``shape`` = (nx, ny, nz): idle lanes of the
+    256-cell row segments, idle rows of the 3-row tiles, and the tiles that meet a y or z CPML slab — those run the
+    all-axes instantiation at 2 waves per SIMD, about half the rate of the others; x layers put
+    every tile on the x-CPML instantiation (+10 %).  Measured on
+    424 x 224 x 824 with 12 layers per face (profiles/r03i_probe_c3_axis_shift.jsonl): x = 224 runs a step in
+    0.82-0.99 ms, x = 424 in 1.08-1.11, x = 824 in 1.05; the model says 1.24 : 1.37 : 1.44."""
+    nx, ny, nz = (int(n) for n in shape)
+    lay = pml_layers if pml_layers is not None else ((0, 0),) * 3
+    rows = 3.0 * -(-ny // 3) / ny
+    fy = min(1.0, (lay[1][0] + lay[1][1]) / ny)
+    fz = min(1.0, (lay[2][0] + lay[2][1]) / nz)
+    fx = 1.10 if (lay[0][0] + lay[0][1]) > 0 else 1.0          # x layers: every tile runs the x-CPML instantiation (V2 vs V1, r03g)
+    return rows / lane_efficiency(nx) * (2.0 - (1.0 - fy) * (1.0 - fz)) * fx
+
+
+def best_axis_shift(shape, pml_layers=None) -> int:
+    """Cyclic axis shift s (new axis a holds old axis (a + s) % 3) with the lowest ``sweep_cost``; 0 unless that buys
+    more than 5 % on a grid of at least 2^18 cells (below that a run is bound by launches, not lanes).
+    ``pml_layers`` = ((minus, plus), ...) CPML layer counts per axis."""
     if int(np.prod([int(n) for n in shape])) < (1 << 18):
         return 0
-    eff = [lane_efficiency(int(n)) for n in shape]
-    s = int(np.argmax(eff))
-    return s if eff[s] > 1.25 * eff[0] else 0
+    lay = pml_layers if pml_layers is not None else ((0, 0),) * 3
+    cost = [sweep_cost([shape[(a + s) % 3] for a in range(3)], [lay[(a + s) % 3] for a in range(3)]) for s in range(3)]
+    s = int(np.argmin(cost))
+    return s if cost[s] < 0.95 * cost[0] else 0
 
 
 def permute_spec(spec: SolverSpec, s: int) -> SolverSpec:
@@ -233,7 +250,8 @@ class HipEngine:
         self.axis_shift = 0
         self.user_zrange = {m.name: (int(m.lo[2]), int(m.hi[2])) for m in spec.monitors}
         if _bloch_twin is None and n_ranks == 1 and slab is None and not force_comm and axis_shift != 0:
-            self.axis_shift = best_axis_shift(spec.shape) if axis_shift is None else int(axis_shift) % 3
+            layers = tuple((int(f0.num_layers), int(f1.num_layers)) for f0, f1 in spec.pml)
+            self.axis_shift = best_axis_shift(spec.shape, layers) if axis_shift is None else int(axis_shift) % 3
             spec = permute_spec(spec, self.axis_shift)
             self.spec = spec
         self.ghost = (0, 0, 0)            # ghost cells per axis in front of the real cells (Bloch device layout)
