@@ -707,6 +707,9 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
     // lane predicate, no per-plane zero-fill of 32 registers; nothing such a lane computes is ever stored.
     float exn[V], eyn[V], ezk[V], exj[V], ezj[V], hxn[V], hyn[V], hzn[V];
     const float ipz = s.ipz[k], idz = s.idz[k];
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr ((HINT & 16) != 0) __builtin_amdgcn_s_setprio(3);      // memory requests of a plane go out ahead of other waves' arithmetic
+#endif
     ldf<V, PML == 0>(exn, uni(a.ex + pb + g.sxy), ubc);
     ldv_h<V, (HINT & 2) != 0>(eyn, uni(a.ey + pb + g.sxy), ubc);
     ldf<V, PML == 0>(ezk, uni(a.ez + pb), ubc);
@@ -720,6 +723,9 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
     if (!halo) ldv_h<V, (HINT & 2) != 0>(hyn, uni(a.hy + pb), ubc);      // the halo wave only publishes H_x and H_z
     else zero<V>(hyn);
     ldf<V, PML == 0>(hzn, uni(a.hz + pb), ubc);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr ((HINT & 16) != 0) __builtin_amdgcn_s_setprio(0);
+#endif
     // ---- CPML state of this plane: EVERY psi load is issued here, with the field loads, so that ONE memory
     // round trip per plane covers them.  Loaded where they are used they chain two more round trips per plane
     // (H side, then E side behind the barrier): +0.63 ms per 512^3 step, worse than the slab kernels
@@ -861,6 +867,13 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
       hy_m = upd_h(hy_o, ch, exn_m - exk_m, ipz, ezk[0] - ez_mm, ipx_m);
       hz_m = upd_h(hz_o, ch, eyk[0] - ey_mm, ipx_m, ex_jm - exk_m, ipy);
     }
+    if constexpr ((HINT & 8) != 0) {      // H stores ahead of the exchange: their completion overlaps the E phase
+      if (act && !halo) {
+        stv_h<V, (HINT & 1) != 0>(b.hx + pb + i0, hxn);
+        stv_h<V, (HINT & 1) != 0>(b.hy + pb + i0, hyn);
+        stv_h<V, (HINT & 1) != 0>(b.hz + pb + i0, hzn);
+      }
+    }
     // publish H^{n+1/2}_{x,z} of this row for the row above
     {
       float4 t4;
@@ -986,9 +999,11 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
           }
         }
       }
-      stv_h<V, (HINT & 1) != 0>(b.hx + pb + i0, hxn);
-      stv_h<V, (HINT & 1) != 0>(b.hy + pb + i0, hyn);
-      stv_h<V, (HINT & 1) != 0>(b.hz + pb + i0, hzn);
+      if constexpr ((HINT & 8) == 0) {
+        stv_h<V, (HINT & 1) != 0>(b.hx + pb + i0, hxn);
+        stv_h<V, (HINT & 1) != 0>(b.hy + pb + i0, hyn);
+        stv_h<V, (HINT & 1) != 0>(b.hz + pb + i0, hzn);
+      }
       stv_h<V, (HINT & 1) != 0>(b.ex + pb + i0, ex);
       stv_h<V, (HINT & 1) != 0>(b.ey + pb + i0, ey);
       stv_h<V, (HINT & 1) != 0>(b.ez + pb + i0, ez);
