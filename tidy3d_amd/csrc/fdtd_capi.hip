@@ -478,14 +478,12 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pm
   // Non-temporal field stores (FDTD_OPT_MEM_HINTS) in the instantiations WITHOUT CPML only: measured inside one engine
   // (profiles/r02z_probe_same_engine_cache_hints.jsonl) they take 2.1 % off the plain sweep and 3.1 % off the one with
   // materials, and ADD 13 % to the CPML-carrying ones (2-3 waves per SIMD: the slower store completion is not hidden).
+  // With them goes the order of the stores: H ahead of the row exchange instead of behind the E update (-0.5 % there,
+  // +12 % in the CPML-carrying instantiations; raising the wave priority while a plane's loads go out: +0.6 %;
+  // profiles/r03k_probe_early_h_stores_setprio.jsonl).
 #define FDTD_LAUNCH_FUSED(MATV, LBV, PMLV)                                                            \
   do {                                                                                                \
-    if (PMLV == 0 && LBV == 256 && h->mem_hints == 9) FDTD_LAUNCH_FUSED_H(MATV, 256, 0, 9);           \
-    else if (PMLV == 0 && LBV == 256 && h->mem_hints == 17) FDTD_LAUNCH_FUSED_H(MATV, 256, 0, 17);    \
-    else if (PMLV != 0 && LBV == 256 && h->mem_hints == 8) FDTD_LAUNCH_FUSED_H(MATV, 256, PMLV, 8);   \
-    else if (PMLV != 0 && LBV == 256 && h->mem_hints == 9) FDTD_LAUNCH_FUSED_H(MATV, 256, PMLV, 9);   \
-    else if (PMLV != 0 && LBV == 256 && h->mem_hints == 16) FDTD_LAUNCH_FUSED_H(MATV, 256, PMLV, 16); \
-    else if (PMLV == 0 && h->mem_hints) FDTD_LAUNCH_FUSED_H(MATV, LBV, 0, 1);                         \
+    if (PMLV == 0 && h->mem_hints) FDTD_LAUNCH_FUSED_H(MATV, LBV, 0, 9);                              \
     else FDTD_LAUNCH_FUSED_H(MATV, LBV, PMLV, 0);                                                     \
   } while (0)
   if (pml_inside == 1) {        // x recursions only: every tile of a grid with x layers
@@ -1936,7 +1934,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_PML_FUSED: h->pml_fused = value < 0 ? -1 : (value & 7); for (bool& ok : h->pml_blk_ok) ok = false; return 0;
     case FDTD_OPT_BND_PLANES: h->bnd_planes = value > 0 ? value : 0; return 0;
     case FDTD_OPT_AUTOTUNE: h->autotune = value < 0 ? 0 : (value > 2 ? 1 : value); if (value) h->tuned = false; return 0;
-    case FDTD_OPT_MEM_HINTS: h->mem_hints = value; return 0;
+    case FDTD_OPT_MEM_HINTS: h->mem_hints = value != 0; return 0;
     case FDTD_OPT_LDS_PAD: if (value < 0 || value > 120000) break; h->lds_pad = value; return 0;
     case FDTD_OPT_PML_SPLIT: h->pml_split = value < 0 ? -1 : (value != 0); return 0;
     case FDTD_OPT_FUSED_LB: if (value != 0 && value != 256 && value != 512 && value != 1024) break; h->fused_lb = value; return 0;

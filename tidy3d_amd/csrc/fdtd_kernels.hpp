@@ -493,7 +493,7 @@ __device__ __forceinline__ void pml_h_apply(float& h1, float& h2, float d1, floa
 //     first plane of a chunk recomputes H^{n+1/2}[k0-1] in a prologue).
 // Everything that depends on the row only (threadIdx.y is wave-uniform) is kept in SGPRs.
 // =============================================================================================
-template <bool MAT, int LB, int PML, int HINT = 0>   // PML: bit a set = CPML of axis a runs inside the sweep; HINT: bit 0 = non-temporal field stores, bit 1 = non-temporal loads of E_y, H_y (bit 1 measured: +0.7 %, not instantiated)
+template <bool MAT, int LB, int PML, int HINT = 0>   // PML: bit a set = CPML of axis a runs inside the sweep; HINT: bit 0 = non-temporal field stores, bit 1 = non-temporal loads of E_y, H_y (measured: +0.7 %, not instantiated), bit 3 = H stores ahead of the row exchange
 __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)) : (LB == 512 ? (PML ? 2 : 4) : 4))) void fused_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
                                                           int kbeg, int kend, int zchunk, int pmc_z0,
                                                           int nbx, int nby, int nbz, int xcd_remap,
@@ -707,9 +707,6 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
     // lane predicate, no per-plane zero-fill of 32 registers; nothing such a lane computes is ever stored.
     float exn[V], eyn[V], ezk[V], exj[V], ezj[V], hxn[V], hyn[V], hzn[V];
     const float ipz = s.ipz[k], idz = s.idz[k];
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr ((HINT & 16) != 0) __builtin_amdgcn_s_setprio(3);      // memory requests of a plane go out ahead of other waves' arithmetic
-#endif
     ldf<V, PML == 0>(exn, uni(a.ex + pb + g.sxy), ubc);
     ldv_h<V, (HINT & 2) != 0>(eyn, uni(a.ey + pb + g.sxy), ubc);
     ldf<V, PML == 0>(ezk, uni(a.ez + pb), ubc);
@@ -723,9 +720,6 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
     if (!halo) ldv_h<V, (HINT & 2) != 0>(hyn, uni(a.hy + pb), ubc);      // the halo wave only publishes H_x and H_z
     else zero<V>(hyn);
     ldf<V, PML == 0>(hzn, uni(a.hz + pb), ubc);
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr ((HINT & 16) != 0) __builtin_amdgcn_s_setprio(0);
-#endif
     // ---- CPML state of this plane: EVERY psi load is issued here, with the field loads, so that ONE memory
     // round trip per plane covers them.  Loaded where they are used they chain two more round trips per plane
     // (H side, then E side behind the barrier): +0.63 ms per 512^3 step, worse than the slab kernels
