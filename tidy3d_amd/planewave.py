@@ -123,7 +123,16 @@ def surface_legs(spec: SolverSpec, mt, lo, hi, inc_e, inc_h):
                 pts.append(np.stack([I.ravel(), J.ravel(), K.ravel()], axis=1))
         if not pts:
             return np.zeros((0, 3), int)
-        return np.unique(np.concatenate(pts), axis=0)
+        # union of the slabs through ONE integer key per node (np.unique over rows sorts structured records:
+        # 14 s of a 10 s set-up for a plane wave across a 1024 x 1024 period)
+        allp = np.concatenate(pts)
+        key = np.unique((allp[:, 0].astype(np.int64) * N[1] + allp[:, 1]) * N[2] + allp[:, 2])
+        out_ = np.empty((key.size, 3), dtype=allp.dtype)
+        out_[:, 2] = key % N[2]
+        key //= N[2]
+        out_[:, 1] = key % N[1]
+        out_[:, 0] = key // N[1]
+        return out_
 
     # ---- E-phase: E_c += Cb * sgn * (H_q[n] - H_q[n - e_a]) / dual_a for the term d_a H_q in (curl H)_c
     for c in range(3):
