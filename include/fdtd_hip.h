@@ -79,6 +79,18 @@ typedef int (*FdtdProgressFn)(int64_t step, double time, double field_decay, voi
 const char* fdtd_last_error(const FdtdSolver* h);   /* h may be NULL: error of the last create */
 int  fdtd_device_count(void);
 
+/* Near -> far projection, the integration step on the device (ref components/field_projection.py:360-368
+ * `integrate_2d` and :370 `_far_fields_for_surface`).  For one surface of a projection
+ * monitor at one frequency: the equivalent currents J_u, J_v, M_u, M_v on the (u, v) lattice of the surface
+ * (`currents`: [4][n_u][n_v] complex as (re, im) pairs of doubles; coordinates u[n_u], v[n_v] relative to the
+ * monitor's local origin, w0 = the surface's coordinate along its normal; wu, wv = the trapezoid weights of
+ * np.trapz, 1 for a single point) are integrated against exp(-i k r_hat . r') for n_dir directions given by their
+ * cosines (r_u, r_v, r_w) along u, v and the normal; k = k_re + i k_im in the projection medium.
+ * out[n_dir][4][2] = the four integrals (re, im) per direction.  Returns 0, or -1 with fdtd_last_error(NULL). */
+int  fdtd_far_field(int device, int n_u, int n_v, const double* u, const double* v, const double* wu, const double* wv,
+                    const double* currents, double w0, double k_re, double k_im, int n_dir, const double* r_u,
+                    const double* r_v, const double* r_w, double* out);
+
 /* One solve = one handle.  Stands in for SimulationTask.create + upload_simulation of the cloud
  * path (ref web/api/webapi.py:219,237; web/core/task_core.py:121); the grid size is
  * Simulation.grid.num_cells incl. the PML cells (ref simulation.py:4296, grid_spec.py:114-137),

@@ -422,9 +422,10 @@ def test_axis_renaming_on_the_gpu(case, hip_lib):
 
 def test_near_to_far_projection_from_gpu_fields(hip_lib):
     """the near fields a FieldProjectionAngleMonitor needs are accumulated ON the device
-    (running DFT on the six surfaces of its box, K6); the N / L integrals over those surfaces run on the host
-    afterwards.  Same analytic pins as the oracle-driven test (sin(theta) pattern, far-sphere power = near-box flux,
-    E / H = eta0) and the far field itself against the oracle's to fp32 accuracy."""
+    (running DFT on the six surfaces of its box, K6) and the N / L integrals over those surfaces are taken ON the
+    device as well (``fdtd_far_field``, K9 — what ``web.run`` does).  Same analytic pins as the oracle-driven test
+    (sin(theta) pattern, far-sphere power = near-box flux, E / H = eta0); the device integrals against the NumPy sums
+    over the same near fields to rounding; the far field against the oracle's to fp32 accuracy."""
     from test_projection import _dipole_sim, check_dipole_far_field
     from oracle.fdtd_numpy import OracleFdtd
     from tidy3d_amd.data import assemble
@@ -433,8 +434,31 @@ def test_near_to_far_projection_from_gpu_fields(hip_lib):
     with HipEngine(disc.spec, lib=hip_lib) as e:
         st = e.run()
         raw = e.results()
-    sd = assemble(disc, raw, n_steps_run=int(st.steps_done))
+    sd = assemble(disc, raw, n_steps_run=int(st.steps_done), device_lib=hip_lib)
     check_dipole_far_field(sd, theta, phi)
+    host = assemble(disc, raw, n_steps_run=int(st.steps_done))
+    for comp, arr in host["far"].field_components.items():
+        a, b = np.asarray(arr.values), np.asarray(sd["far"].field_components[comp].values)
+        assert np.abs(a - b).max() <= 1e-11 * max(np.abs(a).max(), 1e-300), comp
     ref = assemble(disc, OracleFdtd(disc.spec).run())
     a, b = sd["far"].Etheta.values, ref["far"].Etheta.values
     assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max()
+
+
+def test_far_field_kernel_many_directions(hip_lib):
+    """K9 at a size the NumPy loop takes minutes for: 96 x 80 lattice points, 4096 directions, complex k.  Checked
+    against a direct fp64 evaluation of a sample of directions, and for repeatability (fixed reduction tree)."""
+    rng = np.random.default_rng(5)
+    nu, nv, nd = 96, 80, 4096
+    u, v = np.sort(rng.uniform(-2, 2, nu)), np.sort(rng.uniform(-1.5, 1.5, nv))
+    wu, wv = np.gradient(u), np.gradient(v)
+    cur = rng.normal(size=(4, nu, nv)) + 1j * rng.normal(size=(4, nu, nv))
+    th, ph = rng.uniform(0, np.pi, nd), rng.uniform(0, 2 * np.pi, nd)
+    ru, rv, rw = np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)
+    k, w0 = 2 * np.pi / 0.5 * (1.0 + 0.002j), 0.7
+    got = hip_lib.far_field(u, v, wu, wv, cur, w0, k, ru, rv, rw)
+    assert np.array_equal(got, hip_lib.far_field(u, v, wu, wv, cur, w0, k, ru, rv, rw))
+    for d in range(0, nd, 257):
+        phase = np.exp(-1j * k * (u[:, None] * ru[d] + v[None, :] * rv[d] + w0 * rw[d])) * wu[:, None] * wv[None, :]
+        want = (cur * phase[None]).sum(axis=(1, 2))
+        np.testing.assert_allclose(got[d], want, rtol=0, atol=1e-11 * np.abs(want).max())

@@ -130,3 +130,27 @@ def test_exact_projection_reproduces_the_simulated_field_and_tends_to_the_far_fi
         a, b = getattr(ex, comp).values, getattr(fa, comp).values
         assert np.max(np.abs(a - b)) < 2e-3 * np.max(np.abs(b)), comp
     assert np.max(np.abs(ex.Er.values)) < 1e-2 * np.max(np.abs(ex.Etheta.values))
+
+
+def test_device_integration_equals_the_numpy_sums(emu_lib):
+    """``fdtd_far_field`` (kernel K9, here compiled for the host by tests/hipemu) takes the same surface integrals as
+    the NumPy path: every projected component agrees to rounding, for a lossless and for a lossy projection medium,
+    for the angular and the k-space monitor."""
+    sim, theta, phi = _dipole_sim()
+    lossy = td.Medium(permittivity=2.0, conductivity=0.01)
+    mons = list(sim.monitors) + [
+        td.FieldProjectionAngleMonitor(center=(0, 0, 0), size=(1.0, 1.0, 1.0), freqs=[2.7e14, 3e14], theta=theta[::3], phi=phi[::4],
+                                       proj_distance=50.0, medium=lossy, name="far_lossy"),
+        td.FieldProjectionKSpaceMonitor(center=(0, 0, 0.5), size=(1.0, 1.0, 0), freqs=[3e14], ux=np.linspace(-0.6, 0.6, 5),
+                                        uy=np.linspace(-0.5, 0.5, 4), proj_axis=2, proj_distance=1e3, name="far_k")]
+    sim = sim.copy(monitors=mons, run_time=12 / 3e14, shutoff=0)
+    disc = discretize(sim)
+    raw = OracleFdtd(disc.spec).run()
+    host = assemble(disc, raw)
+    dev = assemble(disc, raw, device_lib=emu_lib)
+    for name in ("far", "far_lossy", "far_k"):
+        for comp, arr in host[name].field_components.items():
+            a, b = np.asarray(arr.values), np.asarray(dev[name].field_components[comp].values)
+            scale = max(float(np.nanmax(np.abs(a))), 1e-300)
+            assert np.nanmax(np.abs(a - b)) <= 1e-11 * scale + 1e-300, (name, comp)
+            assert np.array_equal(np.isnan(a), np.isnan(b))

@@ -904,6 +904,38 @@ int fdtd_device_count(void) {
   return n;
 }
 
+int fdtd_far_field(int device, int n_u, int n_v, const double* u, const double* v, const double* wu, const double* wv,
+                   const double* currents, double w0, double k_re, double k_im, int n_dir, const double* r_u,
+                   const double* r_v, const double* r_w, double* out) {
+  if (n_u < 1 || n_v < 1 || n_dir < 0 || !u || !v || !wu || !wv || !currents || (n_dir && (!r_u || !r_v || !r_w || !out)))
+    return fail(nullptr, "fdtd_far_field: bad argument");
+  if (n_dir == 0) return 0;
+  if (hipSetDevice(device) != hipSuccess) return fail(nullptr, "fdtd_far_field: hipSetDevice(%d) failed", device);
+  const size_t n = (size_t)n_u * n_v;
+  const size_t sizes[9] = {(size_t)n_u, (size_t)n_v, (size_t)n_u, (size_t)n_v, 8 * n, (size_t)n_dir, (size_t)n_dir,
+                           (size_t)n_dir, 8 * (size_t)n_dir};
+  const double* host[8] = {u, v, wu, wv, currents, r_u, r_v, r_w};
+  double* dev[9] = {};
+  int rc = 0;
+  for (int i = 0; i < 9 && !rc; ++i) {
+    if (hipMalloc((void**)&dev[i], sizes[i] * sizeof(double)) != hipSuccess) rc = fail(nullptr, "fdtd_far_field: out of device memory");
+    else if (i < 8 && hipMemcpy(dev[i], host[i], sizes[i] * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+      rc = fail(nullptr, "fdtd_far_field: upload failed");
+  }
+  if (!rc) {
+    FarP p;
+    p.u = dev[0]; p.v = dev[1]; p.wu = dev[2]; p.wv = dev[3];
+    p.cur = reinterpret_cast<const double2*>(dev[4]);
+    p.n_u = n_u; p.n_v = n_v; p.w0 = w0; p.k_re = k_re; p.k_im = k_im;
+    p.r_u = dev[5]; p.r_v = dev[6]; p.r_w = dev[7]; p.out = dev[8];
+    hipLaunchKernelGGL(far_field_kernel, dim3((unsigned)n_dir), dim3(256), 0, 0, p);
+    if (hipMemcpy(out, dev[8], sizes[8] * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+      rc = fail(nullptr, "fdtd_far_field: %s", hipGetErrorString(hipGetLastError()));
+  }
+  for (double* q : dev) if (q) hipFree(q);
+  return rc;
+}
+
 int fdtd_create(const FdtdConfig* cfg, FdtdSolver** out) {
   if (!cfg || !out) return fail(nullptr, "fdtd_create: null argument");
   if (cfg->nx < 1 || cfg->ny < 1 || cfg->nz < 1) return fail(nullptr, "fdtd_create: bad grid %d x %d x %d", cfg->nx, cfg->ny, cfg->nz);

@@ -1594,6 +1594,55 @@ __global__ __launch_bounds__(256) void bloch_plane_kernel(float* dre, float* dim
   dim[t] = cphi * b + sphi * a;
 }
 
+// =============================================================================================
+// K9  far-field integration (near -> far projection): for every observation direction d the four surface integrals
+//         N_c(d) = sum_{iu,iv} w_u[iu] w_v[iv] F_c[iu,iv] exp(-i k r_hat(d) . r'[iu,iv]),   F = (J_u, J_v, M_u, M_v)
+//     over one surface of a projection monitor (ref components/field_projection.py:360-368 `integrate_2d`, :370
+//     `_far_fields_for_surface`: the phase is exp(-i k (u r_u + v r_v + w r_w)), trapezoid weights in u and v).
+//     One workgroup per direction; phases and sums in fp64 (k r' reaches 1e3 rad); fixed reduction tree -> repeatable.
+// =============================================================================================
+struct FarP {
+  const double* u; const double* v; const double* wu; const double* wv;
+  const double2* cur;                    // [4][n_u * n_v]: J_u, J_v, M_u, M_v on the (u, v) lattice, v fastest
+  int n_u, n_v;
+  double w0, k_re, k_im;
+  const double* r_u; const double* r_v; const double* r_w;      // direction cosines along u, v and the surface normal
+  double* out;                           // [n_dir][4][2]
+};
+
+__global__ __launch_bounds__(256) void far_field_kernel(FarP p) {
+  __shared__ double red[256][8];
+  const int d = blockIdx.x;
+  const double ru = p.r_u[d], rv = p.r_v[d], rw = p.r_w[d];
+  double acc[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+  const int n = p.n_u * p.n_v;
+  for (int q = threadIdx.x; q < n; q += 256) {
+    const int iu = q / p.n_v, iv = q - iu * p.n_v;
+    const double x = p.u[iu] * ru + p.v[iv] * rv + p.w0 * rw;
+    // exp(-i k x), k = k_re + i k_im:  exp(k_im x) (cos(k_re x) - i sin(k_re x))
+    const double ang = p.k_re * x;
+    const double a = (p.k_im != 0.0 ? exp(p.k_im * x) : 1.0) * p.wu[iu] * p.wv[iv];
+    const double pr = a * cos(ang), pi = -a * sin(ang);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const double2 f = p.cur[(long long)m * n + q];
+      acc[2 * m] += f.x * pr - f.y * pi;
+      acc[2 * m + 1] += f.x * pi + f.y * pr;
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 8; ++m) red[threadIdx.x][m] = acc[m];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) red[threadIdx.x][m] += red[threadIdx.x + s][m];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 8) p.out[(long long)d * 8 + threadIdx.x] = red[0][threadIdx.x];
+}
+
 // ghost-plane helpers (single-GPU z boundary conditions)
 __global__ __launch_bounds__(256) void negate_copy_kernel(float* dst, const float* src, long long n) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;

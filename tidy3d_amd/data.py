@@ -496,11 +496,12 @@ def source_spectrum_fn(disc: Discretization, index: Optional[int]) -> Callable:
 
 
 def assemble(disc: Discretization, raw: Dict[str, np.ndarray], log: str = "", diverged: bool = False,
-             n_steps_run: Optional[int] = None) -> SimulationData:
+             n_steps_run: Optional[int] = None, device_lib=None) -> SimulationData:
     """Raw monitor buffers (name -> array as returned by the engine / oracle) -> SimulationData.
     ``n_steps_run``: time steps actually taken (a run that stopped on the shutoff criterion or diverged took
     fewer than ``spec.n_steps``): time-domain monitors then keep only the samples that were recorded — steps
-    after the stop never happened and must not come back as zeros on the full ``tmesh`` axis."""
+    after the stop never happened and must not come back as zeros on the full ``tmesh`` axis.
+    ``device_lib``: the loaded HIP library — projection and diffraction monitors then integrate on the device."""
     sim, spec = disc.sim, disc.spec
 
     def recorded(steps):
@@ -561,7 +562,7 @@ def assemble(disc: Discretization, raw: Dict[str, np.ndarray], log: str = "", di
             from . import projection
             fn = {"projection_angle": projection.project_angle, "projection_cartesian": projection.project_cartesian,
                   "projection_kspace": projection.project_kspace}[plan.kind]
-            out.append(fn(disc, plan, raw, norm))
+            out.append(fn(disc, plan, raw, norm, lib=device_lib))
         elif plan.kind == "mode_solver":
             from .plugins.mode import ModeSolver
             ms = ModeSolver(simulation=sim, plane=mon.geometry, mode_spec=mon.mode_spec, freqs=mon.freqs,
@@ -571,7 +572,7 @@ def assemble(disc: Discretization, raw: Dict[str, np.ndarray], log: str = "", di
             out.append(md)
         elif plan.kind == "diffraction":
             from . import projection
-            out.append(projection.diffraction(disc, plan, raw, norm))
+            out.append(projection.diffraction(disc, plan, raw, norm, lib=device_lib))
         elif plan.kind == "permittivity":
             out.append(permittivity_data(sim, spec if pfull is None else disc.spec_full,
                                          plan if pfull is None else pfull))

@@ -23,6 +23,7 @@ SYMBOLS = (
     "fdtd_add_point_source", "fdtd_add_tfsf", "fdtd_add_monitor", "fdtd_get_monitor",
     "fdtd_set_field", "fdtd_get_field", "fdtd_set_shutoff", "fdtd_comm_unique_id",
     "fdtd_comm_init", "fdtd_run", "fdtd_run_bloch", "fdtd_get_stats", "fdtd_reset", "fdtd_set_option",
+    "fdtd_far_field",
 )
 
 BC_PEC, BC_PMC, BC_PERIODIC, BC_NEIGHBOR = 0, 1, 2, 3
@@ -92,6 +93,23 @@ class FdtdLib:
         d.fdtd_get_stats.argtypes = [vp, C.POINTER(FdtdStats)]
         d.fdtd_reset.argtypes = [vp]
         d.fdtd_set_option.argtypes = [vp, C.c_int, C.c_int]
+        f64 = C.c_double
+        d.fdtd_far_field.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, f64, f64, f64, C.c_int, vp, vp, vp, vp]
+
+    def far_field(self, u, v, wu, wv, currents, w0: float, k: complex, r_u, r_v, r_w, device: int = 0):
+        """Surface integrals of the near -> far projection on the device (``fdtd_far_field``): ``currents`` [4, n_u, n_v]
+        complex (J_u, J_v, M_u, M_v), directions as cosines along u, v and the surface normal -> complex [n_dir, 4]."""
+        import numpy as np
+        u, v, wu, wv = (np.ascontiguousarray(a, dtype=np.float64) for a in (u, v, wu, wv))
+        cur = np.ascontiguousarray(currents, dtype=np.complex128)
+        assert cur.shape == (4, u.size, v.size), cur.shape
+        r_u, r_v, r_w = (np.ascontiguousarray(a, dtype=np.float64) for a in (r_u, r_v, r_w))
+        out = np.empty((r_u.size, 4), dtype=np.complex128)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)           # noqa: E731
+        self.check(self.dll.fdtd_far_field(int(device), int(u.size), int(v.size), p(u), p(v), p(wu), p(wv), p(cur), float(w0),
+                                           float(np.real(k)), float(np.imag(k)), int(r_u.size), p(r_u), p(r_v), p(r_w), p(out)),
+                   None, "fdtd_far_field")
+        return out
 
     def error(self, handle) -> str:
         msg = self.dll.fdtd_last_error(handle)

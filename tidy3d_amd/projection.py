@@ -108,10 +108,27 @@ def _medium_params(mon, sim, medium, freqs):
     return medium, eps_f, 2 * np.pi * freqs * np.sqrt(eps_f) / C_0, ETA_0 / np.sqrt(eps_f)
 
 
-def _far_fields(disc, plan, raw, norm, theta: np.ndarray, phi: np.ndarray, medium=None, f_sel=None):
+def _trap_weights(x: np.ndarray) -> np.ndarray:
+    """weights w with  sum(w * f) == np.trapz(f, x)  (1 for a single point: ``_trapz2`` takes the value itself)"""
+    x = np.asarray(x, float)
+    if x.size == 1:
+        return np.ones(1)
+    w = np.zeros(x.size)
+    d = np.diff(x)
+    w[:-1] += 0.5 * d
+    w[1:] += 0.5 * d
+    return w
+
+
+def _far_fields(disc, plan, raw, norm, theta: np.ndarray, phi: np.ndarray, medium=None, f_sel=None, lib=None, device=0):
     """E_theta, E_phi (without the propagation factor) at the direction PAIRS (theta[n], phi[n]), summed
     over the monitor's surfaces: arrays [n, n_freq]; also k and eta per frequency.  ``f_sel`` restricts
-    the evaluation to some frequency indices (the other columns stay 0)."""
+    the evaluation to some frequency indices (the other columns stay 0).
+
+    ``lib`` = the loaded HIP library: the surface integrals (directions x lattice points x frequencies — all of the
+    cost) run on the device (``fdtd_far_field``, kernel K9); ``web.run`` passes it.  Without it the same sums are
+    taken in NumPy — that is how stored data are projected after the fact, as the reference's ``FieldProjector`` does
+    (ref field_projection.py:370), and what the device path is tested against."""
     mon, sim = plan.monitor, disc.sim
     freqs = np.asarray(mon.freqs, float)
     medium, eps_f, k_f, eta_f = _medium_params(mon, sim, medium, freqs)
@@ -126,7 +143,12 @@ def _far_fields(disc, plan, raw, norm, theta: np.ndarray, phi: np.ndarray, mediu
             k, eta = k_f[i_f], eta_f[i_f]
             Jv = np.zeros((3, len(theta)), complex)
             Mv = np.zeros_like(Jv)
-            for n in range(len(theta)):
+            if lib is not None:
+                cur = np.stack([J[u][:, :, i_f], J[v][:, :, i_f], M[u][:, :, i_f], M[v][:, :, i_f]])
+                got = lib.far_field(rel[u], rel[v], _trap_weights(pts[u]), _trap_weights(pts[v]), cur, float(rel[axis][0]), k,
+                                    r_hat[u], r_hat[v], r_hat[axis], device=device)
+                Jv[u], Jv[v], Mv[u], Mv[v] = got[:, 0], got[:, 1], got[:, 2], got[:, 3]
+            for n in (range(len(theta)) if lib is None else ()):
                 ph = (np.exp(-1j * k * rel[u] * r_hat[u, n])[:, None] * np.exp(-1j * k * rel[v] * r_hat[v, n])[None, :] *
                       np.exp(-1j * k * rel[axis][0] * r_hat[axis, n]))
                 for a in (u, v):
@@ -211,7 +233,7 @@ def _package(cls, mon, e_t, e_p, k_f, eta_f, r, shape, coords):
     return cls(monitor=mon, **{k: DataArray(v.reshape(shape), coords) for k, v in comps.items()})
 
 
-def project_angle(disc, plan, raw, norm) -> FieldProjectionAngleData:
+def project_angle(disc, plan, raw, norm, lib=None) -> FieldProjectionAngleData:
     mon = plan.monitor
     freqs = np.asarray(mon.freqs, float)
     theta, phi = np.asarray(mon.theta, float), np.asarray(mon.phi, float)
@@ -222,7 +244,7 @@ def project_angle(disc, plan, raw, norm) -> FieldProjectionAngleData:
         pts = r0 * np.stack([np.sin(t) * np.cos(p_), np.sin(t) * np.sin(p_), np.cos(t)], axis=1)
         E, H = _exact_fields(disc, plan, raw, norm, pts)
         return _package_exact(FieldProjectionAngleData, mon, E, H, t, p_, (1, len(theta), len(phi), len(freqs)), coords)
-    e_t, e_p, k_f, eta_f = _far_fields(disc, plan, raw, norm, T.ravel(), P.ravel())
+    e_t, e_p, k_f, eta_f = _far_fields(disc, plan, raw, norm, T.ravel(), P.ravel(), lib=lib)
     r = np.full(T.size, float(mon.proj_distance))
     return _package(FieldProjectionAngleData, mon, e_t, e_p, k_f, eta_f, r, (1, len(theta), len(phi), len(freqs)), coords)
 
@@ -237,7 +259,7 @@ class FieldProjectionKSpaceData(FieldProjectionAngleData):
     """ref monitor_data.py FieldProjectionKSpaceData: dims (ux, uy, r, f)."""
 
 
-def project_cartesian(disc, plan, raw, norm) -> FieldProjectionCartesianData:
+def project_cartesian(disc, plan, raw, norm, lib=None) -> FieldProjectionCartesianData:
     """Observation points on a plane at ``proj_distance`` along ``proj_axis`` (ref field_projection.py:665-746)."""
     mon = plan.monitor
     freqs = np.asarray(mon.freqs, float)
@@ -251,11 +273,11 @@ def project_cartesian(disc, plan, raw, norm) -> FieldProjectionCartesianData:
     if not mon.far_field_approx:
         E, H = _exact_fields(disc, plan, raw, norm, np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1))
         return _package_exact(FieldProjectionCartesianData, mon, E, H, theta, phi, X.shape + (len(freqs),), coords)
-    e_t, e_p, k_f, eta_f = _far_fields(disc, plan, raw, norm, theta, phi)
+    e_t, e_p, k_f, eta_f = _far_fields(disc, plan, raw, norm, theta, phi, lib=lib)
     return _package(FieldProjectionCartesianData, mon, e_t, e_p, k_f, eta_f, r, X.shape + (len(freqs),), coords)
 
 
-def project_kspace(disc, plan, raw, norm) -> FieldProjectionKSpaceData:
+def project_kspace(disc, plan, raw, norm, lib=None) -> FieldProjectionKSpaceData:
     """Observation directions given by the in-plane unit-vector components (ux, uy) around
     ``proj_axis`` (ref field_projection.py:748-829, geometry/base.py:963-985)."""
     mon = plan.monitor
@@ -274,7 +296,7 @@ def project_kspace(disc, plan, raw, norm) -> FieldProjectionKSpaceData:
         theta, phi = np.arccos(z), np.arctan2(y, x)
     valid = np.isfinite(theta).ravel()
     th, ph = np.where(valid, theta.ravel(), 0.0), np.where(valid, phi.ravel(), 0.0)
-    e_t, e_p, k_f, eta_f = _far_fields(disc, plan, raw, norm, th, ph)
+    e_t, e_p, k_f, eta_f = _far_fields(disc, plan, raw, norm, th, ph, lib=lib)
     e_t[~valid], e_p[~valid] = np.nan, np.nan              # evanescent directions (ux^2 + uy^2 > 1)
     r = np.full(th.size, float(mon.proj_distance))
     coords = {"ux": ux, "uy": uy, "r": np.atleast_1d(float(mon.proj_distance)), "f": freqs}
@@ -369,7 +391,7 @@ def _medium_at(sim, point):
     return sim.medium, -1
 
 
-def diffraction(disc, plan, raw, norm) -> DiffractionData:
+def diffraction(disc, plan, raw, norm, lib=None) -> DiffractionData:
     """Order amplitudes from the surface-equivalence integrals over ONE period: a periodic sheet of
     currents radiates the plane waves  E_mn = [far-field integrand at the order's direction] /
     (2 A cos(theta_mn))  (A = area of the period; the uniform sheet J_s radiating -eta J_s / 2 is the
@@ -411,7 +433,7 @@ def diffraction(disc, plan, raw, norm) -> DiffractionData:
         d = np.zeros((3, uxv.size))                                 # global propagation direction
         d[u], d[v], d[axis] = uxv, uyv, sgn * uz
         th_g, ph_g = np.arccos(np.clip(d[2], -1, 1)), np.arctan2(d[1], d[0])
-        et, ep, _, _ = _far_fields(disc, plan, raw, norm, th_g, ph_g, medium=medium, f_sel=[i_f])
+        et, ep, _, _ = _far_fields(disc, plan, raw, norm, th_g, ph_g, medium=medium, f_sel=[i_f], lib=lib)
         # global Cartesian field vector, then the local spherical components
         st, ct, sp_, cp = np.sin(th_g), np.cos(th_g), np.sin(ph_g), np.cos(ph_g)
         t_hat = np.stack([ct * cp, ct * sp_, -st])
