@@ -15,10 +15,17 @@ arr = np.empty((n, n, n), dtype=np.float32)
 pl = [rng.uniform(-1e-3, 1e-3, (n, n)).astype(np.float32) for _ in range(8)]
 for k in range(n):
     arr[k] = pl[k % 8]
-spec = bench.build_spec(n, 100000, wl)
+nz = int(os.environ.get("PROBE_SLAB_NZ", n))                    # a z-slab of the cube: what one rank of an N-GPU run holds
+if nz != n:
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import probe_slab
+    spec = probe_slab.spec_for(n, nz, 100000, wl == "v2")
+    arr = arr[:nz]
+else:
+    spec = bench.build_spec(n, 100000, wl)
 held = []
 for i in range(n_eng):
-    eng = HipEngine(spec)
+    eng = HipEngine(spec, axis_shift=0) if nz != n else HipEngine(spec)
     held.append(eng)
     for c in range(6):
         eng.set_field(c, np.roll(arr, c, axis=0))
@@ -31,5 +38,6 @@ for i in range(n_eng):
                 k_, x_ = kv.split("=")
                 eng.set_option(getattr(L, k_), int(x_))
             eng.run(4)
-            t0 = time.perf_counter(); eng.run(40); res[s_].append(round((time.perf_counter() - t0) / 40 * 1e3, 4))
+            reps = 40 * max(1, n // nz)
+            t0 = time.perf_counter(); eng.run(reps); res[s_].append(round((time.perf_counter() - t0) / reps * 1e3, 4))
     print(json.dumps({"wl": wl, "engine": i, "ms_per_step": res}), flush=True)

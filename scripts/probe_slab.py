@@ -75,8 +75,8 @@ def main():
                 dt = time.perf_counter() - t0
                 stt = e.stats()
                 print(json.dumps({"slab_of": ngpu, "nz": nz, "mode": mode, "zchunk": args.zchunk, "bnd": args.bnd, "rows": args.rows, "tile": [int(stt.tile_rows), int(stt.tile_zchunk)], "autotune": args.autotune, "pml": args.pml, "ms_per_step": dt / steps * 1e3,
-                                  "ideal_ms": 1.244 / ngpu,
-                                  "implied_speedup_vs_1gpu": 1.244 / (dt / steps * 1e3)}), flush=True)
+                                  "ideal_ms": 1.10 / ngpu,
+                                  "implied_speedup_vs_1gpu": 1.10 / (dt / steps * 1e3)}), flush=True)
 
 
 if __name__ == "__main__":

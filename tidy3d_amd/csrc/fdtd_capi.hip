@@ -130,7 +130,8 @@ struct FdtdSolver {
   long long step = 0;
   FdtdStats stats{};
   int zchunk = 2;
-  int zchunk_f = 16;                 // planes marched per workgroup by the fused sweep
+  int zchunk_f = 16;                 // planes marched per workgroup by the fused sweep (8 without in-sweep CPML: launch_fused_range)
+  int last_zc = 0;
   int rows_f = 3;                    // rows per workgroup of the fused sweep (+1 halo wave = 256 threads:
                                      // ~150 VGPRs without spills, 3 workgroups per CU; measured best, profiles/r01g)
   // tile order of the sweep: -1 = default (runs of kTileRun tiles per XCD), 0 = plain, 1 = one contiguous eighth of
@@ -273,6 +274,7 @@ int alloc_field_set(FdtdSolver* h, float** base, size_t fcount, int) {
 }
 #endif
 
+constexpr int kPlainZChunk = 8;      // z-chunk of sweeps without in-sweep CPML (launch_fused_range)
 constexpr int kTileRun = 8;          // default tile order of the sweep: runs of 8 tiles per XCD (launch_fused_range)
 
 inline unsigned nblk(long long n, int b = 256) { return (unsigned)((n + b - 1) / b); }
@@ -446,7 +448,12 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pm
   if (ensure_second_set(h)) return -1;
   if (pml_inside && ensure_pml_blocks(h, pml_inside)) return -1;
   const int R = h->rows_f;
-  const int zc = h->zchunk_f;
+  // z-chunk: 16 planes per workgroup when CPML runs inside the sweep, 8 when not — measured inside engines: 8 is
+  // 0 ... 1.5 % faster on the 512^3 plain / materials sweeps and 2 % slower on the CPML-carrying step (profiles/
+  // r03f), 2.5 ... 4.5 % faster on the 64- and 128-plane slabs a rank of an 8- / 4-GPU run holds (r03n).  A shape set
+  // through fdtd_set_option or found by the tile-shape probe is kept.
+  const int zc = (h->user_geometry || h->tuned || pml_inside) ? h->zchunk_f : std::min(h->zchunk_f, kPlainZChunk);
+  if (ty_gap == 0) h->last_zc = zc;            // (the interior launch of a step, not its edge launches)
   dim3 block(64, R + 1, 1);
   const int nby_all = (g.ny + R - 1) / R;
   if (ty_n < 0) { ty_n = nby_all; ty_a = nby_all; ty_gap = 0; }
@@ -1979,7 +1986,7 @@ int fdtd_get_stats(FdtdSolver* h, FdtdStats* out) {
   if (!h || !out) return -1;
   *out = h->stats;
   out->tile_rows = h->rows_f;
-  out->tile_zchunk = h->zchunk_f;
+  out->tile_zchunk = h->last_zc > 0 ? h->last_zc : h->zchunk_f;      // what the last sweep used
   out->tile_order = h->xcd_remap < 0 ? kTileRun : h->xcd_remap;
   out->reserved0 = 0;
   return 0;
