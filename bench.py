@@ -334,6 +334,8 @@ def main():
                                "(GaussianPulse 200 THz), random +-1e-3 initial fields",
                    "grid": [n, n, n], "parallelism": f"z-slab x{world}",
                    "tile": {"rows": int(st.tile_rows), "zchunk": int(st.tile_zchunk), "xcd_order": int(st.tile_order),
+                            "placement": {"tried": int(st.placement) >> 8, "kept": int(st.placement) & 255,
+                                          "probe_ms_first": float(st.placement_ms_first), "probe_ms_kept": float(st.placement_ms_kept)},
                             "how": "library default" if not (args.rows or args.zchunk) else "flags"},
                    "bytes_per_cell_step": 2 * BYTES_PER_CELL_PASS,
                    "roofline_mcells_per_gpu": HBM_PEAK / (2 * BYTES_PER_CELL_PASS) / 1e6},

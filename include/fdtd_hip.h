@@ -69,7 +69,9 @@ typedef struct FdtdStats {
   int32_t tile_rows;         /* tile shape of the fused sweep in use (after autotuning)           */
   int32_t tile_zchunk;
   int32_t tile_order;        /* 1 = XCD-aware tile order, 0 = plain (chosen by timing both on the first large sweep) */
-  int32_t reserved0;
+  int32_t placement;         /* placement probe of the field arrays: (candidates timed << 8) | index kept (0 = the first allocations) */
+  float   placement_ms_first;/* three probe sweeps on the first allocations ...                 */
+  float   placement_ms_kept; /* ... and on the set that was kept (0 when the probe did not run) */
 } FdtdStats;
 
 /* progress callback: (step, time [s], field_decay) -> non-zero aborts the run (Ctrl-C path).
@@ -210,6 +212,7 @@ enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_R
        FDTD_OPT_BND_PLANES = 7 /* planes per boundary chunk of the fused z-slab schedule, 0 = auto */,
        FDTD_OPT_AUTOTUNE = 8 /* 1: time a few tile shapes of the fused sweep on the first run of grids >= 2^20 cells (default 0) */,
        FDTD_OPT_PML_SPLIT = 9 /* CPML-carrying step as three launches over interior / edge tiles: -1 = by grid size (default), 0, 1 */,
+       FDTD_OPT_PLACEMENT_TRIES = 12, /* alternative placements of the field arrays the first large one-GPU run samples (0 ... 3, default 3; 0 = keep the first allocations): each costs four sweeps and, while it is timed, a second copy of the field memory */
        FDTD_OPT_MEM_HINTS = 11, /* 1 (default): the sweep's instantiations without CPML store the fields with the non-temporal hint, H ahead of the row exchange; 0: plain stores at the end of the plane */
        FDTD_OPT_LDS_PAD = 10 /* measuring aid: extra dynamic LDS per workgroup of the sweep in bytes (lowers its occupancy) */ };
 int fdtd_set_option(FdtdSolver* h, int key, int value);

@@ -143,6 +143,11 @@ struct FdtdSolver {
   // extra live registers drop the sweep from 3 to 2 (mask 6) or 1 (mask 7) waves per SIMD, which
   // costs more (+0.41 ms / +3.0 ms) than the slab kernels it removes (0.22 ms / 0.45 ms) -> default 0.
   int pml_fused = -1;                // -1 = default
+  // placement of the field arrays: how many alternative sets of allocations the first large run tries (probe_placement)
+  int placement_tries = 3;
+  bool placement_done = false;
+  float placement_ms[4] = {0.f, 0.f, 0.f, 0.f};      // time of the probe sweeps per candidate (the first is the original)
+  int placement_tried = 0, placement_kept = 0;        // candidates timed beyond the original / index of the one kept (0 = original)
   int mem_hints = 1;                 // FDTD_OPT_MEM_HINTS: 1 = non-temporal field stores in the sweep's instantiations without CPML
   int lds_pad = 0;                   // extra dynamic LDS per workgroup of the sweep (bytes): lowers its occupancy — a measuring aid
   int pml_split = -1;                // three launches (interior / y-edge / z-edge tiles): -1 = by grid size, 0 = one launch, 1 = always
@@ -519,6 +524,98 @@ int launch_fused(FdtdSolver* h, hipStream_t st, int pml_inside) {
   swap_sets(h);
   swap_psi_h(h, pml_inside);
   return 0;
+}
+
+// Placement of the field arrays.  Where the twelve arrays land in device memory moves the sweep by up to 15 % (DESIGN.md
+// section 7; 1.08 ... 1.24 ms per 512^3 step over the 40 engines of profiles/r03d-r03t) and nothing in HIP steers it — but
+// it can be sampled: before its first large run an engine allocates up to `placement_tries` further sets of the
+// twelve arrays, times three plain sweeps on each (the sweep reads one set and writes the other: no side effect) and
+// keeps the fastest set, copying the fields over.  Costs ten-odd sweeps and, for their duration, twice the field memory
+// (skipped when that is not free).  Only for one-GPU fused runs of at least 2^24 cells.  Measured (profiles/
+// r03u_probe_placement_probe.jsonl, 10 engines, 3 candidates each): the set kept is 0.8 ... 8.1 % faster than the first
+// allocations (mean 4 %), and the first allocations never won.
+float time_plain_sweeps(FdtdSolver* h, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+  if (launch_fused_range(h, 0, h->g.nz, st)) return -1.f;              // warm-up
+  hipEventRecord(e0, st);
+  for (int k = 0; k < 3; ++k) if (launch_fused_range(h, 0, h->g.nz, st)) return -1.f;
+  hipEventRecord(e1, st);
+  if (hipEventSynchronize(e1) != hipSuccess) return -1.f;
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  return ms;
+}
+void set_field_views(FdtdSolver* h) {
+  const long long o = h->g.sxy;
+  h->f.ex = h->fbase[0] + o; h->f.ey = h->fbase[1] + o; h->f.ez = h->fbase[2] + o;
+  h->f.hx = h->fbase[3] + o; h->f.hy = h->fbase[4] + o; h->f.hz = h->fbase[5] + o;
+  h->f2.ex = h->fbase2[0] + o; h->f2.ey = h->fbase2[1] + o; h->f2.ez = h->fbase2[2] + o;
+  h->f2.hx = h->fbase2[3] + o; h->f2.hy = h->fbase2[4] + o; h->f2.hz = h->fbase2[5] + o;
+}
+void release_buf(FdtdSolver* h, void* p) {
+  for (size_t i = 0; i < h->bufs.size(); ++i)
+    if (h->bufs[i].p == p) {
+      hipFree(p);
+      h->stats.device_bytes -= (int64_t)h->bufs[i].bytes;
+      h->bufs.erase(h->bufs.begin() + (long)i);
+      return;
+    }
+}
+int probe_placement(FdtdSolver* h, hipStream_t st) {
+  h->placement_done = true;
+#ifdef FDTD_PLACEMENT_PROBE
+  return 0;                                      // (measurement build: the arrays may live in one pooled allocation)
+#else
+  if (ensure_second_set(h)) return -1;
+  const size_t fcount = (size_t)h->g.sxy * (h->g.nz + 2);
+  const size_t need = 12 * fcount * sizeof(float);
+  const int flags = h->cfg.flags;
+  h->cfg.flags &= ~FDTD_FLAG_TIME_KERNELS;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  float best = time_plain_sweeps(h, st, e0, e1);
+  h->placement_ms[0] = best;
+  float* cur[12];                                 // the set that holds the fields: at most this one and one candidate exist
+  for (int c = 0; c < 6; ++c) { cur[c] = h->fbase[c]; cur[6 + c] = h->fbase2[c]; }
+  int rc = best < 0.f ? -1 : 0;
+  for (int t = 0; t < h->placement_tries && t < 3 && !rc; ++t) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + need / 4) break;
+    float* cand[12] = {};
+    bool ok = true;
+    for (int c = 0; c < 12 && ok; ++c) ok = dev_alloc(h, &cand[c], fcount) == 0;
+    if (!ok) {                                    // out of memory after all: give back what was taken
+      for (float* q : cand) if (q) release_buf(h, q);
+      (void)hipGetLastError();
+      h->err.clear();
+      break;
+    }
+    for (int c = 0; c < 6; ++c) { h->fbase[c] = cand[c]; h->fbase2[c] = cand[6 + c]; }
+    set_field_views(h);
+    const float ms = time_plain_sweeps(h, st, e0, e1);
+    h->placement_ms[t + 1] = ms;
+    h->placement_tried = t + 1;
+    if (ms < 0.f) { rc = -1; break; }
+    if (ms < best) {                              // the candidate wins: the fields move over, the loser goes
+      for (int c = 0; c < 12 && !rc; ++c)
+        if (hipMemcpyAsync(cand[c], cur[c], fcount * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+          rc = fail(h, "probe_placement: copy failed");
+      if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail(h, "probe_placement: %s", hipGetErrorString(hipGetLastError()));
+      if (rc) break;
+      for (int c = 0; c < 12; ++c) { release_buf(h, cur[c]); cur[c] = cand[c]; }
+      best = ms;
+      h->placement_kept = t + 1;
+    } else {
+      for (int c = 0; c < 12; ++c) release_buf(h, cand[c]);
+    }
+  }
+  for (int c = 0; c < 6; ++c) { h->fbase[c] = cur[c]; h->fbase2[c] = cur[6 + c]; }
+  set_field_views(h);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  h->cfg.flags = flags;
+  return rc;
+#endif
 }
 
 // Tile-shape autotuning of the fused sweep.  Which (rows, z-chunk) shape is fastest depends on how
@@ -1521,6 +1618,14 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       if (nb_lo && pz.n_hi > 0) b_lo = std::min(b_lo, nz - pz.n_hi - 1);
     }
   }
+  if (fused && !h->placement_done && (h->placement_tries % 100) > 0 &&
+      (n_cells(h) >= (1LL << 24) || h->placement_tries >= 100)) {       // (>= 100: any size — test aid for the emulated library)
+    const int tries = h->placement_tries;
+    h->placement_tries = tries % 100;
+    const int prc = probe_placement(h, st);
+    h->placement_tries = tries;
+    if (prc) return -1;
+  }
   bool primed = false;
   auto e_post = [&](long long n, int k0, int k1, hipStream_t s, bool replica) {
     launch_pml(h, true, k0, k1, s);
@@ -1974,6 +2079,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_BND_PLANES: h->bnd_planes = value > 0 ? value : 0; return 0;
     case FDTD_OPT_AUTOTUNE: h->autotune = value < 0 ? 0 : (value > 2 ? 1 : value); if (value) h->tuned = false; return 0;
     case FDTD_OPT_MEM_HINTS: h->mem_hints = value != 0; return 0;
+    case FDTD_OPT_PLACEMENT_TRIES: if (value < 0 || (value % 100) > 3) break; h->placement_tries = value; h->placement_done = false; return 0;
     case FDTD_OPT_LDS_PAD: if (value < 0 || value > 120000) break; h->lds_pad = value; return 0;
     case FDTD_OPT_PML_SPLIT: h->pml_split = value < 0 ? -1 : (value != 0); return 0;
     case FDTD_OPT_FUSED_LB: if (value != 0 && value != 256 && value != 512 && value != 1024) break; h->fused_lb = value; return 0;
@@ -1988,7 +2094,9 @@ int fdtd_get_stats(FdtdSolver* h, FdtdStats* out) {
   out->tile_rows = h->rows_f;
   out->tile_zchunk = h->last_zc > 0 ? h->last_zc : h->zchunk_f;      // what the last sweep used
   out->tile_order = h->xcd_remap < 0 ? kTileRun : h->xcd_remap;
-  out->reserved0 = 0;
+  out->placement = (h->placement_tried << 8) | h->placement_kept;
+  out->placement_ms_first = h->placement_ms[0];
+  out->placement_ms_kept = h->placement_ms[h->placement_kept];
   return 0;
 }
 

@@ -30,7 +30,7 @@ BC_PEC, BC_PMC, BC_PERIODIC, BC_NEIGHBOR = 0, 1, 2, 3
 MON_TIME, MON_DFT = 0, 1
 VARIANT_AUTO, VARIANT_SIMPLE, VARIANT_ZMARCH, VARIANT_FUSED = 0, 1, 2, 3
 FLAG_TIME_KERNELS = 1
-OPT_FLAGS, OPT_VARIANT, OPT_ZCHUNK, OPT_ROWS, OPT_XCD_REMAP, OPT_FUSED_LB, OPT_PML_FUSED, OPT_BND_PLANES, OPT_AUTOTUNE, OPT_PML_SPLIT, OPT_LDS_PAD, OPT_MEM_HINTS = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+OPT_FLAGS, OPT_VARIANT, OPT_ZCHUNK, OPT_ROWS, OPT_XCD_REMAP, OPT_FUSED_LB, OPT_PML_FUSED, OPT_BND_PLANES, OPT_AUTOTUNE, OPT_PML_SPLIT, OPT_LDS_PAD, OPT_MEM_HINTS, OPT_PLACEMENT_TRIES = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
 
 
 class FdtdConfig(C.Structure):
@@ -47,7 +47,8 @@ class FdtdStats(C.Structure):
                 ("e_kernel_launches", C.c_int64), ("device_bytes", C.c_int64),
                 ("fused_kernel_ms", C.c_double), ("fused_kernel_launches", C.c_int64),
                 ("tile_rows", C.c_int32), ("tile_zchunk", C.c_int32),
-                ("tile_order", C.c_int32), ("reserved0", C.c_int32)]
+                ("tile_order", C.c_int32), ("placement", C.c_int32),
+                ("placement_ms_first", C.c_float), ("placement_ms_kept", C.c_float)]
 
 
 PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_int64, C.c_double, C.c_double, C.c_void_p)
