@@ -25,7 +25,11 @@ else:
     spec = bench.build_spec(n, 100000, wl)
 held = []
 for i in range(n_eng):
-    eng = HipEngine(spec, axis_shift=0) if nz != n else HipEngine(spec)
+    if os.environ.get("PROBE_COMM"):                         # the z-slab schedule with RCCL looped back onto the one rank
+        eng = HipEngine(spec, axis_shift=0, variant=L.VARIANT_FUSED, force_comm=True)
+        eng.comm_init(eng.unique_id())
+    else:
+        eng = HipEngine(spec, axis_shift=0) if nz != n else HipEngine(spec)
     held.append(eng)
     for c in range(6):
         eng.set_field(c, np.roll(arr, c, axis=0))

@@ -15,10 +15,12 @@ from tidy3d_amd.engine import HipEngine, split_slabs
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def _launch(world, case, n_steps, out, port, slab_shift=None):
+def _launch(world, case, n_steps, out, port, slab_shift=None, placement_tries=None):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if slab_shift is not None:
         env["SLAB_SHIFT"] = str(slab_shift)
+    if placement_tries is not None:
+        env["PLACEMENT_TRIES"] = str(placement_tries)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "dist_worker.py"), case, str(n_steps), out]
@@ -66,6 +68,25 @@ def test_two_rank_run_matches_single_slab(world, case, emu_lib, tmp_path):
     for k, v in oref.items():           # (scale-aware: see cases.run_case)
         den = max(np.linalg.norm(v), 0.5 * scale * np.sqrt(v.size))
         assert np.linalg.norm(got[f"mon_{k}"] - v) / den < 2e-5
+
+
+@pytest.mark.parametrize("world,case", [(2, "media_mix"), (3, "periodic_box")])
+def test_placement_probe_on_slabs_changes_nothing(world, case, emu_lib, tmp_path):
+    """Every rank samples alternative placements of its slab's field arrays before the first step (forced on for
+    these small grids): same bits as the single-slab run."""
+    out = str(tmp_path / "dist.npz")
+    _launch(world, case, 30, out, 29571 + world, placement_tries=102)
+    got = np.load(out)
+    disc = discretize(CASES[case](), n_steps=30)
+    disc.spec.decay_every = 10
+    with HipEngine(disc.spec, lib=emu_lib) as e:
+        e.run()
+        ref = e.results()
+        fields = [e.get_field(c) for c in range(6)]
+    for c in range(6):
+        assert np.array_equal(got[f"field{c}"], fields[c]), c
+    for k, v in ref.items():
+        assert np.array_equal(got[f"mon_{k}"], v), k
 
 
 def test_balanced_slabs_follow_the_cost_model():

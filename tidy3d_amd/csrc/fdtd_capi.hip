@@ -279,6 +279,7 @@ int alloc_field_set(FdtdSolver* h, float** base, size_t fcount, int) {
 }
 #endif
 
+constexpr int kBndPlanes = 2;        // boundary chunk of the z-slab schedule, planes per neighbour face (fdtd_run)
 constexpr int kPlainZChunk = 8;      // z-chunk of sweeps without in-sweep CPML (launch_fused_range)
 constexpr int kTileRun = 8;          // default tile order of the sweep: runs of 8 tiles per XCD (launch_fused_range)
 
@@ -531,7 +532,7 @@ int launch_fused(FdtdSolver* h, hipStream_t st, int pml_inside) {
 // it can be sampled: before its first large run an engine allocates up to `placement_tries` further sets of the
 // twelve arrays, times three plain sweeps on each (the sweep reads one set and writes the other: no side effect) and
 // keeps the fastest set, copying the fields over.  Costs ten-odd sweeps and, for their duration, twice the field memory
-// (skipped when that is not free).  Only for one-GPU fused runs of at least 2^24 cells.  Measured (profiles/
+// (skipped when that is not free).  For fused runs of at least 2^24 cells (2^22 per rank on z-slabs).  Measured (profiles/
 // r03u_probe_placement_probe.jsonl, 10 engines, 3 candidates each): the set kept is 0.8 ... 8.1 % faster than the first
 // allocations (mean 4 %), and the first allocations never won.
 float time_plain_sweeps(FdtdSolver* h, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
@@ -1580,9 +1581,11 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   // monitors, check the field decay or end the run use a joined tail on st instead and re-prime.
   int b_lo = 0, b_hi = 0;
   if (fused_multi) {
-    // boundary chunk = one z-chunk per neighbour face, a quarter slab at most (measured on the
-    // 512 x 512 x 64 proxy, profiles/r01h_slab_timeline.txt: 16 planes 0.181 ms, 8: 0.190, 4: 0.187)
-    int zb = h->bnd_planes > 0 ? h->bnd_planes : std::min(h->zchunk_f, nz / 4);
+    // boundary chunk: TWO planes per neighbour face (all the exchange needs, and it starts that much earlier).
+    // Measured inside engines on the per-rank proxy, RCCL looped back (profiles/r03y_probe_boundary_chunk_thickness
+    // .jsonl): 512 x 512 x 64 plain 0.186 ms per step at 16 planes, 0.175 at 8, 0.167 at 4, 0.163 at 2 and at 1; with
+    // materials + CPML 0.319 -> 0.287; 128 planes 0.301 -> 0.297.  (Round 1's kernels preferred 16: r01h.)
+    int zb = h->bnd_planes > 0 ? h->bnd_planes : std::min(kBndPlanes, nz / 4);
     zb = std::max(1, std::min(zb, nz / 2));
     b_lo = nb_lo ? zb : 0;
     b_hi = nb_hi ? zb : 0;
@@ -1609,7 +1612,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       (n_cells(h) >= (1LL << 20) || h->autotune == 2)) {
     if (autotune_fused(h, st)) return -1;
     if (fused_multi) {           // the boundary-chunk thickness follows the chosen z-chunk
-      int zb = h->bnd_planes > 0 ? h->bnd_planes : std::min(h->zchunk_f, nz / 4);
+      int zb = h->bnd_planes > 0 ? h->bnd_planes : std::min(kBndPlanes, nz / 4);
       zb = std::max(1, std::min(zb, nz / 2));
       const PmlAxisDev& pz = h->pml[2];
       b_lo = nb_lo ? zb : 0;
@@ -1618,8 +1621,9 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       if (nb_lo && pz.n_hi > 0) b_lo = std::min(b_lo, nz - pz.n_hi - 1);
     }
   }
-  if (fused && !h->placement_done && (h->placement_tries % 100) > 0 &&
-      (n_cells(h) >= (1LL << 24) || h->placement_tries >= 100)) {       // (>= 100: any size — test aid for the emulated library)
+  // (a rank of a z-slab run samples its own slab; nothing is exchanged while it does.  >= 100: any size — test aid)
+  if ((fused || fused_multi) && !h->placement_done && (h->placement_tries % 100) > 0 &&
+      (n_cells(h) >= (fused ? (1LL << 24) : (1LL << 22)) || h->placement_tries >= 100)) {
     const int tries = h->placement_tries;
     h->placement_tries = tries % 100;
     const int prc = probe_placement(h, st);
