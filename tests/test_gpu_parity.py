@@ -462,3 +462,34 @@ def test_far_field_kernel_many_directions(hip_lib):
         phase = np.exp(-1j * k * (u[:, None] * ru[d] + v[None, :] * rv[d] + w0 * rw[d])) * wu[:, None] * wv[None, :]
         want = (cur * phase[None]).sum(axis=(1, 2))
         np.testing.assert_allclose(got[d], want, rtol=0, atol=1e-11 * np.abs(want).max())
+
+
+def test_placement_probe_is_invisible_in_the_results(hip_lib):
+    """A run of 2^24 cells samples three alternative placements of its field arrays before the first step
+    (fdtd_capi.hip ``probe_placement``) and may move the fields, set before the run, to another set of allocations:
+    bit-identical to the run that keeps its first allocations."""
+    n = 256
+    sim = td.Simulation(size=(n * 0.05 - 1e-9,) * 3, grid_spec=td.GridSpec.uniform(dl=0.05), run_time=1e-12,
+                        structures=[td.Structure(geometry=td.Sphere(center=(0, 0, 0), radius=2.0), medium=td.Medium(permittivity=4.0))],
+                        sources=[td.PointDipole(center=(0, 0, 0), source_time=td.GaussianPulse(freq0=2e14, fwidth=2e13), polarization="Ez")],
+                        monitors=[td.FieldTimeMonitor(center=(1.0, 0.5, 0.2), size=(0, 0, 0), name="p")],
+                        boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary()), shutoff=0)
+    disc = discretize(sim, n_steps=24)
+    assert disc.spec.shape == (n, n, n)
+    rng = np.random.default_rng(11)
+    init = [rng.uniform(-1e-3, 1e-3, (n, n, n)).astype(np.float32) for _ in range(6)]
+
+    def run(tries):
+        with HipEngine(disc.spec, lib=hip_lib) as e:
+            e.set_option(L.OPT_PLACEMENT_TRIES, tries)
+            for c in range(6):
+                e.set_field(c, init[c])
+            st = e.run()
+            return int(st.placement) >> 8, [e.get_field(c) for c in range(6)], e.results()
+    tried0, f0, m0 = run(0)
+    tried3, f3, m3 = run(3)
+    assert tried0 == 0 and tried3 == 3
+    for a, b in zip(f0, f3):
+        assert np.array_equal(a, b)
+    for k in m0:
+        assert np.array_equal(m0[k], m3[k])
