@@ -62,11 +62,13 @@ CONFIGS = {
 }
 
 
-def _run(spec, lib, variant, rows, zc, pml_mask=None, split=1, order=None):
+def _run(spec, lib, variant, rows, zc, pml_mask=None, split=1, order=None, hints=None):
     with HipEngine(spec, lib=lib, variant=variant, z_chunk=zc) as e:
         e.set_option(L.OPT_ROWS, rows)
         if order is not None:
             e.set_option(L.OPT_XCD_REMAP, order)
+        if hints is not None:
+            e.set_option(L.OPT_MEM_HINTS, hints)
         # (grids this small default to ONE launch of the all-axes instantiation: ask for the three-launch split,
         # which is what large grids run, unless a test wants the single launch)
         e.set_option(L.OPT_PML_SPLIT, split)
@@ -103,6 +105,20 @@ def test_tile_order_changes_nothing(order, name, emu_lib):
         assert np.array_equal(got_f[c], ref_f[c]), c
     for k in ref_m:
         assert np.array_equal(got_m[k], ref_m[k]), k
+
+
+@pytest.mark.parametrize("name", ["pec_two_x_tiles", "periodic_two_x_tiles", "absorber_media"])
+def test_store_order_changes_nothing(name, emu_lib):
+    """FDTD_OPT_MEM_HINTS = 0 selects the instantiation that stores H behind the E update (plain stores) instead of ahead
+    of the row exchange (non-temporal on the device): same values to the same places."""
+    N, bspec, structures = CONFIGS[name]
+    disc = discretize(_sim(N, bspec, structures), n_steps=12)
+    a_f, a_m = _run(disc.spec, emu_lib, L.VARIANT_FUSED, 3, 4, hints=1)
+    b_f, b_m = _run(disc.spec, emu_lib, L.VARIANT_FUSED, 3, 4, hints=0)
+    for c in range(6):
+        assert np.array_equal(a_f[c], b_f[c]), c
+    for k in a_m:
+        assert np.array_equal(a_m[k], b_m[k]), k
 
 
 @pytest.mark.parametrize("mask", [0, 6, 7, -7])
