@@ -388,7 +388,7 @@ __device__ __forceinline__ void ldg4(float (&r)[4], const float* base, unsigned 
 }
 // Field row load: uniform base + the lane's byte offset.  GLOBAL = through an explicit global-address-space pointer
 // (a pointer that went through uni()'s asm is generic to the compiler, which then emits flat_load): -0.15 ... -0.35 %
-// measured inside engines on the instantiations without CPML (profiles/r03h), the only ones that use it.
+// measured inside engines on the instantiations without CPML (profiles/r03h), -0.3 ... -0.5 % on the CPML step (r04h).
 template <int V, bool GLOBAL>
 __device__ __forceinline__ void ldf(float (&r)[V], const float* base, unsigned off) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -607,8 +607,8 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
   float exk_m = 0.f;
   {
     const long long p0 = (long long)k0 * g.sxy + rowb;
-    ldf<V, PML == 0>(exk, uni(a.ex + p0), ubc);
-    ldf<V, PML == 0>(eyk, uni(a.ey + p0), ubc);
+    ldf<V, true>(exk, uni(a.ex + p0), ubc);
+    ldf<V, true>(eyk, uni(a.ey + p0), ubc);
     if (xh) exk_m = a.ex[p0 + im];
   }
   // ---- prologue: H^{n+1/2}[k0-1] (x, y components) of the own cells --------------------------
@@ -618,10 +618,10 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
     float ezm[V], ezj[V], exm[V], eym[V], ho[V], hoy[V];
     zero<V>(ezm); zero<V>(ezj); zero<V>(exm); zero<V>(eym);
     if (act && !skip) {
-      ldf<V, PML == 0>(ezm, uni(a.ez + pb), ub);
-      ldf<V, PML == 0>(exm, uni(a.ex + pb), ub);
-      ldf<V, PML == 0>(eym, uni(a.ey + pb), ub);
-      if (use_jp) ldf<V, PML == 0>(ezj, uni(a.ez + (long long)(k0 - 1) * g.sxy + rowpb), ub);
+      ldf<V, true>(ezm, uni(a.ez + pb), ub);
+      ldf<V, true>(exm, uni(a.ex + pb), ub);
+      ldf<V, true>(eym, uni(a.ey + pb), ub);
+      if (use_jp) ldf<V, true>(ezj, uni(a.ez + (long long)(k0 - 1) * g.sxy + rowpb), ub);
     }
     float ezx = __shfl_down(ezm[0], 1);
     if (act && !skip) {
@@ -631,8 +631,8 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
         else ezx = 0.f;
       }
       const float ipz = s.ipz[k0 - 1];
-      ldf<V, PML == 0>(ho, uni(a.hx + pb), ub);
-      ldf<V, PML == 0>(hoy, uni(a.hy + pb), ub);
+      ldf<V, true>(ho, uni(a.hx + pb), ub);
+      ldf<V, true>(hoy, uni(a.hy + pb), ub);
       if constexpr (PML != 0) {
         // corrected H^{n-1/2}_{x,y} of plane k0-1 (read-only psi; the plane's owner stores it)
         const int kk = (k0 - 1 < 0) ? g.nz - 1 : k0 - 1;          // periodic z: ghost = top plane
@@ -707,19 +707,19 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
     // lane predicate, no per-plane zero-fill of 32 registers; nothing such a lane computes is ever stored.
     float exn[V], eyn[V], ezk[V], exj[V], ezj[V], hxn[V], hyn[V], hzn[V];
     const float ipz = s.ipz[k], idz = s.idz[k];
-    ldf<V, PML == 0>(exn, uni(a.ex + pb + g.sxy), ubc);
+    ldf<V, true>(exn, uni(a.ex + pb + g.sxy), ubc);
     ldv_h<V, (HINT & 2) != 0>(eyn, uni(a.ey + pb + g.sxy), ubc);
-    ldf<V, PML == 0>(ezk, uni(a.ez + pb), ubc);
+    ldf<V, true>(ezk, uni(a.ez + pb), ubc);
     if (use_jp) {
-      ldf<V, PML == 0>(exj, uni(a.ex + pjb), ubc);
-      ldf<V, PML == 0>(ezj, uni(a.ez + pjb), ubc);
+      ldf<V, true>(exj, uni(a.ex + pjb), ubc);
+      ldf<V, true>(ezj, uni(a.ez + pjb), ubc);
     } else {
       zero<V>(exj); zero<V>(ezj);                // row j+1 beyond a wall: E = 0 there
     }
-    ldf<V, PML == 0>(hxn, uni(a.hx + pb), ubc);
+    ldf<V, true>(hxn, uni(a.hx + pb), ubc);
     if (!halo) ldv_h<V, (HINT & 2) != 0>(hyn, uni(a.hy + pb), ubc);      // the halo wave only publishes H_x and H_z
     else zero<V>(hyn);
-    ldf<V, PML == 0>(hzn, uni(a.hz + pb), ubc);
+    ldf<V, true>(hzn, uni(a.hz + pb), ubc);
     // ---- CPML state of this plane: EVERY psi load is issued here, with the field loads, so that ONE memory
     // round trip per plane covers them.  Loaded where they are used they chain two more round trips per plane
     // (H side, then E side behind the barrier): +0.63 ms per 512^3 step, worse than the slab kernels
