@@ -213,7 +213,7 @@ enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_R
        FDTD_OPT_AUTOTUNE = 8 /* 1: time a few tile shapes of the fused sweep on the first run of grids >= 2^20 cells (default 0) */,
        FDTD_OPT_PML_SPLIT = 9 /* CPML-carrying step as three launches over interior / edge tiles: -1 = by grid size (default), 0, 1 */,
        FDTD_OPT_PLACEMENT_TRIES = 12, /* alternative placements of the field arrays the first large one-GPU run samples (0 ... 3, default 3; 0 = keep the first allocations): each costs four sweeps and, while it is timed, a second copy of the field memory */
-       FDTD_OPT_MEM_HINTS = 11, /* 1 (default): the sweep's instantiations without CPML store the fields with the non-temporal hint, H ahead of the row exchange; 0: plain stores at the end of the plane */
+       FDTD_OPT_MEM_HINTS = 11, /* 1 (default): the measured store placement of the sweep (without CPML: non-temporal field stores, H ahead of the row exchange; with CPML: the H-side psi behind the E update); 0: plain stores, fields at the end of the plane, H-side psi in the H phase */
        FDTD_OPT_LDS_PAD = 10 /* measuring aid: extra dynamic LDS per workgroup of the sweep in bytes (lowers its occupancy) */ };
 int fdtd_set_option(FdtdSolver* h, int key, int value);
 int fdtd_reset(FdtdSolver* h);      /* zero fields, auxiliaries, monitors and the step counter */

@@ -107,10 +107,11 @@ def test_tile_order_changes_nothing(order, name, emu_lib):
         assert np.array_equal(got_m[k], ref_m[k]), k
 
 
-@pytest.mark.parametrize("name", ["pec_two_x_tiles", "periodic_two_x_tiles", "absorber_media"])
+@pytest.mark.parametrize("name", ["pec_two_x_tiles", "periodic_two_x_tiles", "absorber_media", "pml_media", "pml_odd_layers_padded_rows"])
 def test_store_order_changes_nothing(name, emu_lib):
-    """FDTD_OPT_MEM_HINTS = 0 selects the instantiation that stores H behind the E update (plain stores) instead of ahead
-    of the row exchange (non-temporal on the device): same values to the same places."""
+    """FDTD_OPT_MEM_HINTS = 0 selects the instantiations with the plain store placement (fields at the end of the plane,
+    the H-side psi of the CPML in the H phase) instead of the measured one (H ahead of the row exchange, non-temporal on
+    the device, without CPML; H-side psi behind the E update with CPML): same values to the same places."""
     N, bspec, structures = CONFIGS[name]
     disc = discretize(_sim(N, bspec, structures), n_steps=12)
     a_f, a_m = _run(disc.spec, emu_lib, L.VARIANT_FUSED, 3, 4, hints=1)
