@@ -497,9 +497,12 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pm
   // The CPML-carrying instantiations store their H-side psi behind the E update instead of in the H phase in front of
   // the row exchange: -2.7 ... -3.3 % of the whole CPML step (profiles/r04j_probe_late_psi_h_stores_all.jsonl).
   // Non-temporal field stores on top of that: +13 % again (r04k).
+  // Without CPML (256-thread instantiations) the E values of a plane are stored one H phase later, behind the loads of
+  // the next plane (12 more live registers): -0.3 ... -0.9 % (r04l); the same in the CPML instantiations: +10 % (r04m).
 #define FDTD_LAUNCH_FUSED(MATV, LBV, PMLV)                                                            \
   do {                                                                                                \
-    if (PMLV == 0 && h->mem_hints) FDTD_LAUNCH_FUSED_H(MATV, LBV, 0, 9);                              \
+    if (PMLV == 0 && LBV == 256 && h->mem_hints) FDTD_LAUNCH_FUSED_H(MATV, 256, 0, 265);              \
+    else if (PMLV == 0 && h->mem_hints) FDTD_LAUNCH_FUSED_H(MATV, LBV, 0, 9);                         \
     else if (PMLV != 0 && h->mem_hints) FDTD_LAUNCH_FUSED_H(MATV, LBV, PMLV, 128);                    \
     else FDTD_LAUNCH_FUSED_H(MATV, LBV, PMLV, 0);                                                     \
   } while (0)
@@ -2086,7 +2089,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_PML_FUSED: h->pml_fused = value < 0 ? -1 : (value & 7); for (bool& ok : h->pml_blk_ok) ok = false; return 0;
     case FDTD_OPT_BND_PLANES: h->bnd_planes = value > 0 ? value : 0; return 0;
     case FDTD_OPT_AUTOTUNE: h->autotune = value < 0 ? 0 : (value > 2 ? 1 : value); if (value) h->tuned = false; return 0;
-    case FDTD_OPT_MEM_HINTS: h->mem_hints = value; return 0;
+    case FDTD_OPT_MEM_HINTS: h->mem_hints = value != 0; return 0;
     case FDTD_OPT_PLACEMENT_TRIES: if (value < 0 || (value % 100) > 3) break; h->placement_tries = value; h->placement_done = false; return 0;
     case FDTD_OPT_LDS_PAD: if (value < 0 || value > 120000) break; h->lds_pad = value; return 0;
     case FDTD_OPT_PML_SPLIT: h->pml_split = value < 0 ? -1 : (value != 0); return 0;

@@ -699,6 +699,9 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
   }                                      // (the halo wave needs no H^{n+1/2}[k0-1])
   int cur = 0;
   const int slot = (int)blockDim.y * 64;           // float4 entries per component per buffer
+  // HINT bit 8 (256): the E values of a plane are stored one H phase later, behind the loads of the next plane
+  [[maybe_unused]] float pend_ex[V], pend_ey[V], pend_ez[V];
+  [[maybe_unused]] long long pend_p = -1;
   for (int k = k0; k < k1; ++k) {
     const long long pb = (long long)k * g.sxy + rowb;      // scalar
     const long long pjb = (long long)k * g.sxy + rowpb;
@@ -861,6 +864,13 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
       hy_m = upd_h(hy_o, ch, exn_m - exk_m, ipz, ezk[0] - ez_mm, ipx_m);
       hz_m = upd_h(hz_o, ch, eyk[0] - ey_mm, ipx_m, ex_jm - exk_m, ipy);
     }
+    if constexpr ((HINT & 256) != 0) {
+      if (act && !halo && pend_p >= 0) {
+        stv_h<V, (HINT & 1) != 0>(b.ex + pend_p + i0, pend_ex);
+        stv_h<V, (HINT & 1) != 0>(b.ey + pend_p + i0, pend_ey);
+        stv_h<V, (HINT & 1) != 0>(b.ez + pend_p + i0, pend_ez);
+      }
+    }
     if constexpr ((HINT & 8) != 0) {      // H stores ahead of the exchange: their completion overlaps the E phase
       if (act && !halo) {
         stv_h<V, (HINT & 1) != 0>(b.hx + pb + i0, hxn);
@@ -1012,9 +1022,15 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
         stv_h<V, (HINT & 1) != 0>(b.hy + pb + i0, hyn);
         stv_h<V, (HINT & 1) != 0>(b.hz + pb + i0, hzn);
       }
-      stv_h<V, (HINT & 1) != 0>(b.ex + pb + i0, ex);
-      stv_h<V, (HINT & 1) != 0>(b.ey + pb + i0, ey);
-      stv_h<V, (HINT & 1) != 0>(b.ez + pb + i0, ez);
+      if constexpr ((HINT & 256) != 0) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) { pend_ex[e] = ex[e]; pend_ey[e] = ey[e]; pend_ez[e] = ez[e]; }
+        pend_p = pb;
+      } else {
+        stv_h<V, (HINT & 1) != 0>(b.ex + pb + i0, ex);
+        stv_h<V, (HINT & 1) != 0>(b.ey + pb + i0, ey);
+        stv_h<V, (HINT & 1) != 0>(b.ez + pb + i0, ez);
+      }
     };
     if (act && !halo) {
       if constexpr (MAT) {
@@ -1035,6 +1051,13 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
     for (int e = 0; e < V; ++e) { hxm[e] = hxn[e]; hym[e] = hyn[e]; exk[e] = exn[e]; eyk[e] = eyn[e]; }
     exk_m = exn_m;
     cur ^= 1;
+  }
+  if constexpr ((HINT & 256) != 0) {
+    if (act && !halo && pend_p >= 0) {
+      stv_h<V, (HINT & 1) != 0>(b.ex + pend_p + i0, pend_ex);
+      stv_h<V, (HINT & 1) != 0>(b.ey + pend_p + i0, pend_ey);
+      stv_h<V, (HINT & 1) != 0>(b.ez + pend_p + i0, pend_ez);
+    }
   }
 }
 
