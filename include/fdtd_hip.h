@@ -208,7 +208,7 @@ int fdtd_get_stats(FdtdSolver* h, FdtdStats* out);
 /* tuning knobs that may change between runs of one handle (bench A/B without re-upload) */
 enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_ROWS = 3, FDTD_OPT_XCD_REMAP = 4 /* tile order of the sweep: -1 = default (runs of 8 tiles per XCD), 0 = plain, 1 = a contiguous eighth per XCD, G > 1 = runs of G tiles */,
        FDTD_OPT_FUSED_LB = 5,
-       FDTD_OPT_PML_FUSED = 6 /* axes (bit mask) whose CPML recursions run inside the fused sweep: -1 = all (default), 0 = slab kernels */,
+       FDTD_OPT_PML_FUSED = 6 /* axes (bit mask) whose CPML recursions run inside the fused sweep: -1 = default (one GPU: all; z-slab ranks: slab kernels), 0 = slab kernels, 6 / 7 = y z / all inside the sweep — on z-slab ranks too (set it on every rank) */,
        FDTD_OPT_BND_PLANES = 7 /* planes per boundary chunk of the fused z-slab schedule, 0 = default (2) */,
        FDTD_OPT_AUTOTUNE = 8 /* 1: time a few tile shapes of the fused sweep on the first run of grids >= 2^20 cells (default 0) */,
        FDTD_OPT_PML_SPLIT = 9 /* CPML-carrying step as three launches over interior / edge tiles: -1 = by grid size (default), 0, 1 */,

@@ -59,6 +59,9 @@ def main():
     shift = os.environ.get("SLAB_SHIFT")                    # force a slab-axis renaming (tests)
     eng = tdist.make_engine(disc.spec, lib=lib, device=0,   # the emulator exposes one device
                             axis_shift=None if shift is None else int(shift))
+    if os.environ.get("PML_FUSED"):                         # CPML recursions inside the sweeps of the slab ranks (tests)
+        from tidy3d_amd import lib as L
+        eng.set_option(L.OPT_PML_FUSED, int(os.environ["PML_FUSED"]))
     if os.environ.get("PLACEMENT_TRIES"):                   # force the placement probe of the library on (tests)
         from tidy3d_amd import lib as L
         eng.set_option(L.OPT_PLACEMENT_TRIES, int(os.environ["PLACEMENT_TRIES"]))

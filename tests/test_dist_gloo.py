@@ -15,12 +15,14 @@ from tidy3d_amd.engine import HipEngine, split_slabs
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def _launch(world, case, n_steps, out, port, slab_shift=None, placement_tries=None):
+def _launch(world, case, n_steps, out, port, slab_shift=None, placement_tries=None, pml_fused=None):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if slab_shift is not None:
         env["SLAB_SHIFT"] = str(slab_shift)
     if placement_tries is not None:
         env["PLACEMENT_TRIES"] = str(placement_tries)
+    if pml_fused is not None:
+        env["PML_FUSED"] = str(pml_fused)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "dist_worker.py"), case, str(n_steps), out]
@@ -70,12 +72,35 @@ def test_two_rank_run_matches_single_slab(world, case, emu_lib, tmp_path):
         assert np.linalg.norm(got[f"mon_{k}"] - v) / den < 2e-5
 
 
+IN_SWEEP_CASES = [(2, "pml_box", 7), (3, "pml_box", 7), (2, "drude_in_pml", 7), (2, "media_mix", 7), (3, "au_array", 7), (2, "pml_box", 6)]
+
+
+@pytest.mark.parametrize("world,case,mask", IN_SWEEP_CASES)
+def test_cpml_inside_the_sweeps_of_slab_ranks(world, case, mask, emu_lib, tmp_path):
+    """FDTD_OPT_PML_FUSED > 0 on z-slab ranks: the recursions run inside the sweeps as on one GPU; the H-side psi of a
+    rank's ghost plane -1 (x, y axes) arrives with the ghost fields.  Same arithmetic and summation order: same bits as
+    the single-slab run (whose CPML is inside the sweep too)."""
+    out = str(tmp_path / "dist.npz")
+    _launch(world, case, 30, out, 29581 + IN_SWEEP_CASES.index((world, case, mask)), pml_fused=mask)      # one port per case
+    got = np.load(out)
+    disc = discretize(CASES[case](), n_steps=30)
+    disc.spec.decay_every = 10
+    with HipEngine(disc.spec, lib=emu_lib) as e:
+        e.run()
+        ref = e.results()
+        fields = [e.get_field(c) for c in range(6)]
+    for c in range(6):
+        assert np.array_equal(got[f"field{c}"], fields[c]), c
+    for k, v in ref.items():
+        assert np.array_equal(got[f"mon_{k}"], v), k
+
+
 @pytest.mark.parametrize("world,case", [(2, "media_mix"), (3, "periodic_box")])
 def test_placement_probe_on_slabs_changes_nothing(world, case, emu_lib, tmp_path):
     """Every rank samples alternative placements of its slab's field arrays before the first step (forced on for
     these small grids): same bits as the single-slab run."""
     out = str(tmp_path / "dist.npz")
-    _launch(world, case, 30, out, 29571 + world, placement_tries=102)
+    _launch(world, case, 30, out, 29561 + world, placement_tries=102)
     got = np.load(out)
     disc = discretize(CASES[case](), n_steps=30)
     disc.spec.decay_every = 10

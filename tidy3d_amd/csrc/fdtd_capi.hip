@@ -40,6 +40,7 @@ struct PmlAxisDev {
   float* psi_h[2] = {nullptr, nullptr};
   float* psi_h2[2] = {nullptr, nullptr};   // write set of the in-sweep CPML (ping-pong), lazily allocated
   size_t psi_count = 0;                    // entries per psi array
+  size_t psi_plane = 0;                    // entries of one z-plane of it (x, y axes: the H-side arrays carry one more, the ghost slot)
 };
 
 struct AdeGroup {
@@ -393,7 +394,7 @@ int ensure_pml_blocks(FdtdSolver* h, int mask) {
     PmlAxisDev& P = h->pml[a];
     if (P.ns == 0) continue;
     for (int q = 0; q < 2; ++q)
-      if (!P.psi_h2[q] && dev_alloc(h, &P.psi_h2[q], P.psi_count)) return -1;
+      if (!P.psi_h2[q] && dev_alloc(h, &P.psi_h2[q], P.psi_count + P.psi_plane)) return -1;
   }
   // The two sets of an axis keep their identity: `psi_h` / `psi_h2` swap names on the host after every
   // sweep, so block [parity p] must read what the host calls psi_h when pml_parity == p.
@@ -923,21 +924,34 @@ int exchange_fused_e(FdtdSolver* h, hipStream_t st) {
 // Pipelined z-slab schedule: ONE exchange per step carries everything the neighbours' boundary
 // chunks need for the next sweep — up: E_x,E_y,E_z and the pre-corrected H_x,H_y of my top plane
 // (-> upper ghost(-1)); down: E_x,E_y of my bottom plane (-> lower ghost(nz)).
-int exchange_fused_all(FdtdSolver* h, hipStream_t st) {
+int exchange_fused_all(FdtdSolver* h, hipStream_t st, bool pml_with_sweep = false) {
   const long long pc = plane_cells(h);
   const int nz = h->g.nz;
   const bool has_lo = h->cfg.bc[4] == FDTD_BC_NEIGHBOR, has_hi = h->cfg.bc[5] == FDTD_BC_NEIGHBOR;
   if (!has_lo && !has_hi) return 0;
   const int lo = (h->rank - 1 + h->n_ranks) % h->n_ranks, hi = (h->rank + 1) % h->n_ranks;
   float* up5[5] = {h->f.ex, h->f.ey, h->f.ez, h->f.hx, h->f.hy};
+  // With the x / y CPML inside the sweep the chunk prologue of the upper rank corrects H[-1] itself and needs the
+  // H-side psi of that plane — my top plane, CURRENT set (what the next sweep reads): into slot nz of its arrays.
+  // Decided by the configuration alone (both sides must post the same messages), not by what a rank's sweep ends up doing.
+  const bool psi_too = pml_with_sweep && h->pml_fused > 0;
   // posting order mirrors the peer's (see exchange_fused_e): [to-hi][to-lo] <-> [from-lo][from-hi]
   NCCLCHK(h, ncclGroupStart());
-  if (has_hi)
+  if (has_hi) {
     for (float* p : up5) NCCLCHK(h, ncclSend(p + (long long)(nz - 1) * pc, pc, ncclFloat, hi, h->comm, st));
+    if (psi_too)
+      for (int a = 0; a < 2; ++a)
+        for (int q = 0; q < 2 && h->pml[a].ns > 0; ++q)
+          NCCLCHK(h, ncclSend(h->pml[a].psi_h[q] + (size_t)(nz - 1) * h->pml[a].psi_plane, h->pml[a].psi_plane, ncclFloat, hi, h->comm, st));
+  }
   if (has_lo) {
     NCCLCHK(h, ncclSend(h->f.ex, pc, ncclFloat, lo, h->comm, st));
     NCCLCHK(h, ncclSend(h->f.ey, pc, ncclFloat, lo, h->comm, st));
     for (float* p : up5) NCCLCHK(h, ncclRecv(p - pc, pc, ncclFloat, lo, h->comm, st));
+    if (psi_too)
+      for (int a = 0; a < 2; ++a)
+        for (int q = 0; q < 2 && h->pml[a].ns > 0; ++q)
+          NCCLCHK(h, ncclRecv(h->pml[a].psi_h[q] + (size_t)nz * h->pml[a].psi_plane, h->pml[a].psi_plane, ncclFloat, lo, h->comm, st));
   }
   if (has_hi) {
     NCCLCHK(h, ncclRecv(h->f.ex + (long long)nz * pc, pc, ncclFloat, hi, h->comm, st));
@@ -1071,6 +1085,7 @@ int fdtd_create(const FdtdConfig* cfg, FdtdSolver** out) {
   g.sxy = (long long)cfg->nx * cfg->ny;
   g.bcx0 = cfg->bc[0]; g.bcx1 = cfg->bc[1]; g.bcy0 = cfg->bc[2]; g.bcy1 = cfg->bc[3];
   g.pec_z0 = cfg->bc[4] == FDTD_BC_PEC;
+  g.psi_ghost = cfg->bc[4] == FDTD_BC_NEIGHBOR ? 1 : 0;
   g.ch = cfg->ch;
   // measured on MI355X, 512^3 (profiles/r01a_probe_geometry_512.jsonl): short z-marches win —
   // the 256 MiB Infinity Cache already serves the k+1 plane re-read, and more, smaller
@@ -1263,9 +1278,12 @@ int fdtd_set_pml(FdtdSolver* h, int axis, int n_lo, int n_hi, const float* kinv_
     return -1;
   const size_t other = (size_t)n_cells(h) / (size_t)n;
   P.psi_count = other * P.ns;
+  // (x, y axes: one more plane behind the H-side arrays — the ghost slot a z-slab rank receives its lower neighbour's
+  //  top-plane psi into, fdtd_kernels.hpp GridP::psi_ghost)
+  P.psi_plane = axis < 2 ? P.psi_count / (size_t)h->cfg.nz : 0;
   for (int q = 0; q < 2; ++q) {
     if (P.ns > 0 && dev_alloc(h, &P.psi_e[q], P.psi_count)) return -1;
-    if (P.ns > 0 && dev_alloc(h, &P.psi_h[q], P.psi_count)) return -1;
+    if (P.ns > 0 && dev_alloc(h, &P.psi_h[q], P.psi_count + P.psi_plane)) return -1;
     P.psi_h2[q] = nullptr;
   }
   for (bool& ok : h->pml_blk_ok) ok = false;          // parameter blocks are rebuilt on next use
@@ -1536,8 +1554,8 @@ int fdtd_reset(FdtdSolver* h) {
     if (P.n == 0) continue;
     for (int s = 0; s < 2; ++s) {
       if (P.psi_e[s]) HIPCHK(h, hipMemset(P.psi_e[s], 0, P.psi_count * 4));
-      if (P.psi_h[s]) HIPCHK(h, hipMemset(P.psi_h[s], 0, P.psi_count * 4));
-      if (P.psi_h2[s]) HIPCHK(h, hipMemset(P.psi_h2[s], 0, P.psi_count * 4));
+      if (P.psi_h[s]) HIPCHK(h, hipMemset(P.psi_h[s], 0, (P.psi_count + P.psi_plane) * 4));
+      if (P.psi_h2[s]) HIPCHK(h, hipMemset(P.psi_h2[s], 0, (P.psi_count + P.psi_plane) * 4));
     }
   }
   for (AdeGroup& a : h->ade) {
@@ -1638,8 +1656,20 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     if (prc) return -1;
   }
   bool primed = false;
+  // z-slab ranks carry the CPML recursions inside their sweeps as one GPU does (same arithmetic and summation order):
+  // the x / y recursions are local in z, the z recursion stays two planes clear of the cuts, and the one thing a rank
+  // lacks — the H-side psi of its ghost plane -1, for the chunk prologue at plane 0 — comes with the ghost planes
+  // (exchange_fused_all).  pml_in_m: axes inside the sweep; bits 0 / 1 agree on all ranks, bit 2 only end ranks have.
+  // ON REQUEST only (FDTD_OPT_PML_FUSED > 0 on every rank): measured inside engines on the per-rank proxy (profiles/
+  // r04p, r04q: 512 x 512 slabs with CPML on x and y, exchange included) the slab kernels win on thin slabs — 64 planes
+  // 0.304 vs 0.352 ms, 128 planes 0.565 vs 0.594 — and tie at 256 (1.069 vs 1.067): the interior goes out as three
+  // partial launches on one stream there, and the all-axes instantiation runs its few tiles at 2 waves per SIMD.
+  int pml_in_m = 0;
+  if (fused_multi && any_pml(h) && h->pml_fused > 0 && 64 * (h->rows_f + 1) <= 512)
+    pml_in_m = h->pml_fused & pml_in_sweep_mask(h);
+  const bool psi_ghosts = fused_multi && (pml_in_m & 3) != 0;
   auto e_post = [&](long long n, int k0, int k1, hipStream_t s, bool replica) {
-    launch_pml(h, true, k0, k1, s);
+    launch_pml(h, true, k0, k1, s, 7 & ~pml_in_m);
     launch_sources(h, true, n, k0, k1, s, replica);
     launch_damp(h, true, k0, k1, s);       // before the ADE pass: its stored E^{n+1} is the damped one
     launch_ade(h, k0, k1, s);
@@ -1647,7 +1677,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   auto h_pre = [&](long long n, int k0, int k1, hipStream_t s, bool replica) {
     launch_damp(h, false, k0, k1, s);
     launch_sources(h, false, n, k0, k1, s, replica);
-    launch_pml(h, false, k0, k1, s);
+    launch_pml(h, false, k0, k1, s, 7 & ~pml_in_m);
   };
   auto rec_at = [&](long long n) {
     for (Monitor& m : h->mons) if (m.next < m.steps.size() && m.steps[m.next] == n) return true;
@@ -1662,7 +1692,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     HIPCHK(h, hipEventRecord(h->ev_e_int, st));
     HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
     HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
-    if (exchange_fused_all(h, cs)) return -1;
+    if (exchange_fused_all(h, cs, psi_ghosts)) return -1;
     primed = true;
     return 0;
   };
@@ -1698,13 +1728,30 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       const bool last = (done + 1 == n_steps) || decay_step;
       // sweeps: boundary chunks (one launch) on cs, interior on st
       HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
-      if (b_lo > 0 && b_hi > 0) { if (launch_fused_range(h, 0, b_lo, cs, 0, nz - b_hi, nz)) return -1; }
-      else if (b_lo > 0) { if (launch_fused_range(h, 0, b_lo, cs)) return -1; }
-      else if (b_hi > 0) { if (launch_fused_range(h, nz - b_hi, nz, cs)) return -1; }
+      // (the boundary chunks lie clear of the z slabs: their launch carries x / y at most)
+      const int pml_b = pml_in_m & 3;
+      if (b_lo > 0 && b_hi > 0) { if (launch_fused_range(h, 0, b_lo, cs, pml_b, nz - b_hi, nz)) return -1; }
+      else if (b_lo > 0) { if (launch_fused_range(h, 0, b_lo, cs, pml_b)) return -1; }
+      else if (b_hi > 0) { if (launch_fused_range(h, nz - b_hi, nz, cs, pml_b)) return -1; }
       HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
       HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
-      if (launch_fused_range(h, b_lo, nz - b_hi, st)) return -1;
+      if ((pml_in_m & 6) == 0) {
+        if (launch_fused_range(h, b_lo, nz - b_hi, st, pml_in_m)) return -1;
+      } else {
+        // interior planes by tile class, as on one GPU (all three on the main stream: the other one ships ghost planes)
+        const int R = h->rows_f, nby_all = (h->g.ny + R - 1) / R, ki = b_lo, ke = nz - b_hi;
+        const PmlAxisDev &py = h->pml[1], &pz = h->pml[2];
+        const bool in_y = (pml_in_m & 2) && py.ns > 0, in_z = (pml_in_m & 4) && pz.ns > 0;
+        const int za = std::min(ke, std::max(ki, (in_z && pz.lo > 0) ? std::min(nz, pz.lo + 1) : 0));
+        const int zc = std::max(za, std::min(ke, (in_z && pz.hi0 < nz) ? pz.hi0 : nz));
+        const int ty_a = (in_y && py.lo > 0) ? std::min(nby_all, py.lo / R + 1) : 0;
+        const int ty_c = (in_y && py.hi0 < h->g.ny) ? std::max(ty_a, py.hi0 / R) : nby_all;
+        if ((za > ki || zc < ke) && launch_fused_range(h, ki, za, st, pml_in_m, zc, ke)) return -1;
+        if (launch_fused_range(h, za, zc, st, pml_in_m & 3, 0, 0, ty_a + (nby_all - ty_c), ty_a, ty_c - ty_a)) return -1;
+        if (launch_fused_range(h, za, zc, st, pml_in_m & 1, 0, 0, ty_c - ty_a, 0, ty_a)) return -1;
+      }
       swap_sets(h);
+      swap_psi_h(h, pml_in_m);
       const bool rec_post = rec_at(n);
       if (rec_post || last || rec_at(n + 1)) {
         // joined tail: everything after the sweeps on st
@@ -1728,7 +1775,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
         h_pre(n + 1, nz - b_hi, nz, cs, true);
         advance_tfsf_aux(h, false, n + 1, cs, true);
         HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
-        if (exchange_fused_all(h, cs)) return -1;
+        if (exchange_fused_all(h, cs, psi_ghosts)) return -1;
         e_post(n, b_lo, nz - b_hi, st, false);
         advance_tfsf_aux(h, true, n, st, false);
         h_pre(n + 1, b_lo, nz - b_hi, st, false);

@@ -27,6 +27,7 @@ struct GridP {
   int bcx0, bcx1, bcy0, bcy1;    // boundary codes of the x / y faces
   int pec_z0;                    // tangential E on local plane k == 0 is a PEC wall
   float ch;                      // dt / mu0
+  int psi_ghost;                 // plane -1 belongs to another rank: its H-side psi (x, y axes) sits in slot nz of the psi arrays
 };
 
 struct FieldP {
@@ -635,7 +636,9 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
       ldf<V, true>(hoy, uni(a.hy + pb), ub);
       if constexpr (PML != 0) {
         // corrected H^{n-1/2}_{x,y} of plane k0-1 (read-only psi; the plane's owner stores it)
-        const int kk = (k0 - 1 < 0) ? g.nz - 1 : k0 - 1;          // periodic z: ghost = top plane
+        // periodic z on one GPU: the ghost plane is the top plane; on a z-slab: the lower neighbour's top plane, whose psi
+        // arrives with the ghost fields in an extra plane (slot nz) of the x / y psi arrays
+        const int kk = (k0 - 1 < 0) ? (g.psi_ghost ? g.nz : g.nz - 1) : k0 - 1;
         if (k0 > 0 || !g.pec_z0) {
           // axis x: Hy += ch (kv dEz/dx + p1)
           if constexpr ((PML & 1) != 0) {
