@@ -186,13 +186,15 @@ def test_rccl_self_exchange_matches_ghost_copy(hip_lib):
         assert np.array_equal(ref_m[k], got_m[k])
 
 
-@pytest.mark.parametrize("bnd", [0, 3])
-def test_pipelined_slab_schedule_with_corrections_on_real_streams(hip_lib, bnd):
+@pytest.mark.parametrize("bnd,pml_fused", [(0, -1), (3, -1), (0, 7), (5, 7)])
+def test_pipelined_slab_schedule_with_corrections_on_real_streams(hip_lib, bnd, pml_fused):
     """The pipelined z-slab schedule under REAL stream concurrency with everything it splits
     between the two streams: x/y CPML slabs, ADE (Lorentz sphere), a lossy box, electric and
     magnetic dipoles, a plane wave (TFSF machinery: the replica of the 1-D incident grid on the comm
     stream), time and DFT monitors, field-decay checks (joined tails).  Periodic z, one rank,
-    RCCL exchange with itself == the plain single-stream run, bit for bit."""
+    RCCL exchange with itself == the plain single-stream run, bit for bit.  pml_fused = 7: the CPML recursions inside
+    the sweeps of the slab rank (the H-side psi of the ghost plane exchanged with the ghost fields, edge tiles on a
+    third stream) instead of slab kernels."""
     from cases import pipelined_slab_case
     sim = pipelined_slab_case()
     disc = discretize(sim, n_steps=90)
@@ -207,6 +209,8 @@ def test_pipelined_slab_schedule_with_corrections_on_real_streams(hip_lib, bnd):
         e.comm_init(e.unique_id())
         if bnd:
             e.set_option(L.OPT_BND_PLANES, bnd)
+        if pml_fused >= 0:
+            e.set_option(L.OPT_PML_FUSED, pml_fused)
         e.run(40)
         e.run(50)                      # a second call re-primes the pipeline
         got = [e.get_field(c) for c in range(6)]
