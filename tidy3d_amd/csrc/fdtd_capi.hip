@@ -167,8 +167,6 @@ struct FdtdSolver {
   ncclComm_t comm = nullptr;
   int rank = 0, n_ranks = 1;
   hipEvent_t ev_h_int = nullptr, ev_h_bnd = nullptr, ev_e_int = nullptr, ev_e_bnd = nullptr;
-  hipStream_t edge_stream = nullptr;               // edge-tile launches of a slab rank's interior sweep (created on first use)
-  hipEvent_t ev_edge_0 = nullptr, ev_edge_1 = nullptr;
 };
 
 namespace {
@@ -1160,9 +1158,6 @@ void fdtd_destroy(FdtdSolver* h) {
   if (h->ev_e_bnd) hipEventDestroy(h->ev_e_bnd);
   if (h->stream) hipStreamDestroy(h->stream);
   if (h->comm_stream) hipStreamDestroy(h->comm_stream);
-  if (h->edge_stream) hipStreamDestroy(h->edge_stream);
-  if (h->ev_edge_0) hipEventDestroy(h->ev_edge_0);
-  if (h->ev_edge_1) hipEventDestroy(h->ev_edge_1);
   delete h;
 }
 
@@ -1751,20 +1746,12 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
         const int zc = std::max(za, std::min(ke, (in_z && pz.hi0 < nz) ? pz.hi0 : nz));
         const int ty_a = (in_y && py.lo > 0) ? std::min(nby_all, py.lo / R + 1) : 0;
         const int ty_c = (in_y && py.hi0 < h->g.ny) ? std::max(ty_a, py.hi0 / R) : nby_all;
-        // the few edge tiles on a third stream, next to the many middle ones (alone they leave most of the machine idle)
-        if (!h->edge_stream) {
-          HIPCHK(h, hipStreamCreateWithFlags(&h->edge_stream, hipStreamNonBlocking));
-          HIPCHK(h, hipEventCreateWithFlags(&h->ev_edge_0, hipEventDisableTiming));
-          HIPCHK(h, hipEventCreateWithFlags(&h->ev_edge_1, hipEventDisableTiming));
-        }
-        hipStream_t es = h->edge_stream;
-        HIPCHK(h, hipEventRecord(h->ev_edge_0, st));
-        HIPCHK(h, hipStreamWaitEvent(es, h->ev_edge_0, 0));
-        if ((za > ki || zc < ke) && launch_fused_range(h, ki, za, es, pml_in_m, zc, ke)) return -1;
-        if (launch_fused_range(h, za, zc, es, pml_in_m & 3, 0, 0, ty_a + (nby_all - ty_c), ty_a, ty_c - ty_a)) return -1;
-        HIPCHK(h, hipEventRecord(h->ev_edge_1, es));
+        // (all on the main stream.  Edge launches on a third stream were tried: no gain, and an engine with three
+        //  streams pushed the next engine of the process onto shared hardware queues — its two streams serialised,
+        //  3x slower steps, profiles/r04r)
+        if ((za > ki || zc < ke) && launch_fused_range(h, ki, za, st, pml_in_m, zc, ke)) return -1;
+        if (launch_fused_range(h, za, zc, st, pml_in_m & 3, 0, 0, ty_a + (nby_all - ty_c), ty_a, ty_c - ty_a)) return -1;
         if (launch_fused_range(h, za, zc, st, pml_in_m & 1, 0, 0, ty_c - ty_a, 0, ty_a)) return -1;
-        HIPCHK(h, hipStreamWaitEvent(st, h->ev_edge_1, 0));
       }
       swap_sets(h);
       swap_psi_h(h, pml_in_m);
