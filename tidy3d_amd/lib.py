@@ -16,6 +16,13 @@ from .exceptions import SolverLibraryError
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libfdtd_hip.so")
 
+# The solver overlaps work on TWO streams per engine (boundary chunks + exchange / interior sweep; the edge and interior
+# launches of a CPML step).  The HIP runtime multiplexes a process's streams onto $GPU_MAX_HW_QUEUES hardware queues
+# (default 4); once an engine's two streams share one, their launches serialise — measured: a 64-plane z-slab step
+# 0.83 ms instead of 0.28 ms with six more streams alive in the process, 0.28 ms again with 8 queues (profiles/
+# r04u_probe_hw_queues.jsonl).  Ask for 8 unless the user chose; read by the runtime when it first touches the device.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 # every symbol include/fdtd_hip.h declares (tests check the library exports all of them)
 SYMBOLS = (
     "fdtd_last_error", "fdtd_device_count", "fdtd_create", "fdtd_destroy", "fdtd_set_steps",
