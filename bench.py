@@ -200,7 +200,11 @@ def secondary_workload(HipEngine, L, n, workload, device, args, steps=40, repeat
         return {"workload": f"{workload}: {WORKLOADS[workload]}", "value": cells * steps / el / 1e6, "unit": "Mcells/s",
                 "ms_per_step": el / steps * 1e3, "steps": steps, "repeats": repeats,
                 "ms_per_step_samples": [e / steps * 1e3 for e in samples],
-                "fused_kernel_ms_per_step": st.fused_kernel_ms / 10,
+                # the step goes out as three CONCURRENT sweep launches (interior tiles on the main stream, z-slab planes and
+                # y-edge tile rows on the second): their durations overlap, so the sum is not a time per step
+                "sweep_launches_per_step": st.fused_kernel_launches / 10,
+                "sweep_launch_ms_sum_concurrent": st.fused_kernel_ms / 10,
+                "stream_overlap": int(st.stream_overlap),
                 "bytes_per_cell_own_minimum": own,
                 "whole_step_frac": own * cells * steps / el / HBM_PEAK,
                 "bytes_per_cell_survey_8d": survey,
@@ -222,6 +226,10 @@ def main():
     ap.add_argument("--pml-fused", type=int, default=-1, help="axis mask of the CPML recursions folded into the fused sweep (0, 6, 7)")
     ap.add_argument("--tile-order", type=int, default=-1, help="-1: the library times both tile orders on the first sweep (default); "
                     "0 / 1: plain / XCD-aware (profiling runs: keeps the probe sweeps out of the counters)")
+    ap.add_argument("--tblock", type=int, default=-1, help="planes per slab of the two-step slab-interleaved schedule (FDTD_OPT_TBLOCK; "
+                    "0 = single steps, -1 = library default)")
+    ap.add_argument("--placement-tries", type=int, default=-1, help="FDTD_OPT_PLACEMENT_TRIES (0 = keep the first allocations: profiling "
+                    "runs, so that the kernel statistics hold the timed sweeps only)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--no-workloads", action="store_true", help="skip the secondary V2 (materials + CPML) measurement")
@@ -242,6 +250,8 @@ def main():
     # torch side, the HIP sources under the emulator with its RCCL shim.  Never set on a GPU box.
     emulate = bool(os.environ.get("BENCH_EMULATE"))
     lib = None
+    if not emulate:
+        L.load_library()          # before the first HIP call of this process (torch.cuda.set_device below): see lib._prefer_hw_queues
     if emulate:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
@@ -271,6 +281,10 @@ def main():
         eng.set_option(L.OPT_PML_FUSED, args.pml_fused)
     if args.tile_order >= 0:
         eng.set_option(L.OPT_XCD_REMAP, args.tile_order)
+    if args.tblock >= 0:
+        eng.set_option(L.OPT_TBLOCK, args.tblock)
+    if args.placement_tries >= 0:
+        eng.set_option(L.OPT_PLACEMENT_TRIES, args.placement_tries)
     if world > 1:
         uid = [eng.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -306,13 +320,17 @@ def main():
     # REPEATS timed regions of exactly K steps each (barrier + device sync on both sides, max over ranks);
     # the median is the reported number, the spread is reported beside it (median of 5)
     R = max(1, args.repeats)
-    samples = []
+    samples, rank_samples = [], []
     for _ in range(R):
         e = timed(K)
         if world > 1:
-            t = torch.tensor([e], device="cpu" if emulate else "cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            e = float(t.item())
+            # every rank's own clock around the same K steps: the max is the job's time, min / max per rank go on the line
+            t = torch.tensor([e], dtype=torch.float64, device="cpu" if emulate else "cuda")
+            allt = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            per_rank = [float(x.item()) for x in allt]
+            rank_samples.append(per_rank)
+            e = max(per_rank)
         samples.append(e)
     elapsed = float(np.median(samples))
     cells = n ** 3
@@ -342,7 +360,21 @@ def main():
         "repeats": {"n": R, "statistic": "median", "ms_per_step": [e / K * 1e3 for e in samples],
                     "min_ms_per_step": min(samples) / K * 1e3, "max_ms_per_step": max(samples) / K * 1e3},
         "roofline": roofline_entry(st, kr, local_cells, cells, K, elapsed, world, args.workload, spec),
+        "schedule": {"two_step_pairs_in_roofline_run": int(st.two_step_pairs), "tblock_planes": int(st.tblock_planes),
+                     "stream_overlap": int(st.stream_overlap), "stream_retries": int(st.stream_retries)},
     }
+    if world > 1:
+        # proof that the halo communicator (RCCL; the emulator's shim under BENCH_EMULATE) spans `world` ranks: every rank
+        # reports what ncclCommCount / ncclCommUserRank return for ITS communicator
+        mine = torch.tensor([int(st.comm_ranks), int(st.comm_rank), z1 - z0], dtype=torch.int64, device="cpu" if emulate else "cuda")
+        allc = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allc, mine)
+        rows = [[int(v) for v in x.tolist()] for x in allc]
+        med = np.median(np.asarray(rank_samples), axis=0) / K * 1e3
+        out["rccl"] = {"rccl_ranks": sorted({r[0] for r in rows}), "comm_user_ranks": [r[1] for r in rows],
+                       "planes_per_rank": [r[2] for r in rows],
+                       "ms_per_step_per_rank": [float(v) for v in med],
+                       "ms_per_step_rank_min": float(med.min()), "ms_per_step_rank_max": float(med.max())}
     if world == 1 and not emulate and args.workload == "v0" and not args.no_workloads:
         # the workload every real simulation resembles (materials + CPML on all faces), same grid, same box
         eng.close()

@@ -72,6 +72,14 @@ typedef struct FdtdStats {
   int32_t placement;         /* placement probe of the field arrays: (candidates timed << 8) | index kept (0 = the first allocations) */
   float   placement_ms_first;/* three probe sweeps on the first allocations ...                 */
   float   placement_ms_kept; /* ... and on the set that was kept (0 when the probe did not run) */
+  int32_t stream_overlap;    /* the engine's two streams: 1 = measured to run concurrently, 0 = not probed yet (no run used
+                                both), -1 = they serialised on every attempt (shared hardware queue): ONE stream is used */
+  int32_t stream_retries;    /* fresh second streams created until two overlapped                */
+  int32_t comm_ranks;        /* ncclCommCount of the halo communicator (0 = none)                */
+  int32_t comm_rank;         /* ncclCommUserRank                                                 */
+  int64_t two_step_pairs;    /* step pairs advanced by the slab-interleaved two-step schedule (FDTD_OPT_TBLOCK) in the last fdtd_run */
+  int32_t tblock_planes;     /* its slab thickness in planes (0 = schedule off)                  */
+  int32_t reserved0;
 } FdtdStats;
 
 /* progress callback: (step, time [s], field_decay) -> non-zero aborts the run (Ctrl-C path).
@@ -214,6 +222,10 @@ enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_R
        FDTD_OPT_PML_SPLIT = 9 /* CPML-carrying step as three launches over interior / edge tiles: -1 = by grid size (default), 0, 1 */,
        FDTD_OPT_PLACEMENT_TRIES = 12, /* alternative placements of the field arrays the first large one-GPU run samples (0 ... 3, default 3; 0 = keep the first allocations): each costs four sweeps and, while it is timed, a second copy of the field memory */
        FDTD_OPT_MEM_HINTS = 11, /* 1 (default): the measured store placement of the sweep (without CPML: non-temporal field stores, H ahead of the row exchange; with CPML: the H-side psi behind the E update); 0: plain stores, fields at the end of the plane, H-side psi in the H phase */
+       FDTD_OPT_TBLOCK = 13, /* one-GPU fused runs without CPML / TFSF / periodic z: advance TWO time steps per pass over
+                                the grid, slab by slab (slab s+1 takes step n, then slab s takes step n+1 while the
+                                intermediate planes are still in the 256 MiB Infinity Cache): planes per slab; 0 = off,
+                                -1 = default */
        FDTD_OPT_LDS_PAD = 10 /* measuring aid: extra dynamic LDS per workgroup of the sweep in bytes (lowers its occupancy) */ };
 int fdtd_set_option(FdtdSolver* h, int key, int value);
 int fdtd_reset(FdtdSolver* h);      /* zero fields, auxiliaries, monitors and the step counter */

@@ -201,6 +201,8 @@ static ncclResult_t flush_ops() {
 ncclResult_t ncclGetUniqueId(ncclUniqueId* id) { std::memset(id, 0x5a, sizeof(*id)); return ncclSuccess; }
 ncclResult_t ncclCommInitRank(ncclComm_t* c, int n, ncclUniqueId, int r) { *c = new ncclCommEmu{r, n}; return ncclSuccess; }
 ncclResult_t ncclCommDestroy(ncclComm_t c) { delete c; return ncclSuccess; }
+ncclResult_t ncclCommCount(const ncclComm_t c, int* n) { *n = c->nranks; return ncclSuccess; }
+ncclResult_t ncclCommUserRank(const ncclComm_t c, int* r) { *r = c->rank; return ncclSuccess; }
 ncclResult_t ncclGroupStart() { ++g_group_depth; return ncclSuccess; }
 ncclResult_t ncclGroupEnd() { if (--g_group_depth == 0) return flush_ops(); return ncclSuccess; }
 static size_t dsize(ncclDataType_t t) { return t == ncclFloat ? 4 : (t == ncclDouble ? 8 : 1); }

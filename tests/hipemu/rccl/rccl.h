@@ -23,6 +23,8 @@ extern "C" void hipemu_set_exchange(hipemu_exchange_fn fn, void* user);
 ncclResult_t ncclGetUniqueId(ncclUniqueId* id);
 ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int rank);
 ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count);
+ncclResult_t ncclCommUserRank(const ncclComm_t comm, int* rank);
 ncclResult_t ncclGroupStart();
 ncclResult_t ncclGroupEnd();
 ncclResult_t ncclSend(const void* buf, size_t count, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t s);

@@ -33,3 +33,11 @@ def test_bench_contract_line(world, emu_lib):
     assert out["value"] == pytest.approx(16 ** 3 * 3 / (out["ms_per_step"] * 3e-3) / 1e6, rel=1e-6)
     assert out["config"]["parallelism"] == f"z-slab x{world}" and out["roofline"]["bound"] == "hbm"
     assert out["roofline"]["kernel"] == "fused_step_kernel"     # every rank takes the fused z-slab schedule
+    if world > 1:
+        # the line itself proves the halo communicator spans `world` ranks (ncclCommCount / ncclCommUserRank per rank)
+        rc = out["rccl"]
+        assert rc["rccl_ranks"] == [world] and rc["comm_user_ranks"] == list(range(world))
+        assert sum(rc["planes_per_rank"]) == 16 and len(rc["ms_per_step_per_rank"]) == world
+        assert rc["ms_per_step_rank_min"] <= rc["ms_per_step_rank_max"] <= out["ms_per_step"] * 1.0001
+    else:
+        assert "rccl" not in out

@@ -228,3 +228,18 @@ def test_web_run_devices_spawns_the_ranks(emu_lib, tmp_path):
         for k, v in comps.items():
             w = (getattr(b, "field_components", None) or {"flux": b.flux})[k]
             np.testing.assert_array_equal(np.asarray(v.values), np.asarray(w.values))
+
+
+def test_web_run_devices_a_dying_rank_raises_instead_of_hanging(emu_lib):
+    """A rank that floods stderr and dies: its siblings are terminated and ``run`` raises with that
+    rank's status and the tail of its stderr — within seconds, not after a collective times out."""
+    import time
+    from tidy3d_amd.exceptions import SolverLibraryError
+    from tidy3d_amd.web import run
+    sim = CASES["au_array"]()
+    opt = dict(backend="gloo", lib=emu_lib.path, hook="dist_hook:setup_rank1_dies_noisily", timeout=240,
+               pythonpath=[os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "hipemu")])
+    t0 = time.monotonic()
+    with pytest.raises(SolverLibraryError, match=r"(?s)rank 1 exited with status 7.*rccl warning line"):
+        run(sim, task_name="two", verbose=False, n_steps=40, devices=[0, 1], _dist_options=opt)
+    assert time.monotonic() - t0 < 120

@@ -39,6 +39,12 @@ MEDIA = [td.Structure(geometry=td.Sphere(center=(0.05, 0, 0), radius=0.2),
                       medium=td.Medium(permittivity=3.0, conductivity=0.02)),
          td.Structure(geometry=td.Box(center=(0.3, 0.1, 0), size=(0.1, 0.1, 0.1)), medium=td.PEC)]
 
+MEDIA_WIDE = [td.Structure(geometry=td.Box(center=(-3.0, 0, 0), size=(8.0, 0.3, 0.2)),
+                           medium=td.Medium(permittivity=3.0, conductivity=0.02)),
+              td.Structure(geometry=td.Sphere(center=(6.3, 0, 0), radius=0.25),
+                           medium=td.Lorentz(eps_inf=2.0, coeffs=[(1.5, 4e14, 3e13)])),
+              td.Structure(geometry=td.Box(center=(0.1, 0.1, 0), size=(0.1, 0.1, 0.1)), medium=td.PEC)]
+
 PML_ODD = td.BoundarySpec(x=td.Boundary(minus=td.PML(num_layers=5), plus=td.PML(num_layers=3)), y=td.Boundary.pml(num_layers=2),
                           z=td.Boundary(minus=td.PECBoundary(), plus=td.PML(num_layers=3)))
 PML_MEET = td.BoundarySpec(x=td.Boundary.pml(num_layers=7), y=td.Boundary.pml(num_layers=3), z=td.Boundary.periodic())
@@ -59,6 +65,9 @@ CONFIGS = {
     # the rounded x ranges meet: the whole axis is a member
     "pml_x_ranges_meet": ((2, 6, 8), PML_MEET, ()),
     "periodic_media": ((32, 12, 10), PER, MEDIA),
+    # x-CPML across x-tiles: the low-x slab lies in tile 0, the high-x slab in the LAST tile
+    # (tile_x > 0: the LDS coefficient table is filled from offset tile_x * 256), odd layer counts, media through both
+    "pml_two_x_tiles": ((256, 8, 7), PML_ODD, MEDIA_WIDE),
 }
 
 
@@ -122,13 +131,14 @@ def test_store_order_changes_nothing(name, emu_lib):
         assert np.array_equal(a_m[k], b_m[k]), k
 
 
+@pytest.mark.parametrize("name", ["pml_media", "pml_two_x_tiles"])
 @pytest.mark.parametrize("mask", [0, 6, 7, -7])
 @pytest.mark.parametrize("rows,zc", [(3, 16), (4, 3)])
-def test_fused_cpml_placement(mask, rows, zc, emu_lib):
+def test_fused_cpml_placement(mask, rows, zc, name, emu_lib):
     """The CPML recursions as slab kernels (0), y/z inside the sweep (6), all inside (7): identical
     arithmetic and summation order (H: x, y, z; E: y, z, x) -> bit-for-bit the two-pass result."""
-    N, bspec, structures = CONFIGS["pml_media"]
-    disc = discretize(_sim(N, bspec, structures), n_steps=24)
+    N, bspec, structures = CONFIGS[name]
+    disc = discretize(_sim(N, bspec, structures), n_steps=24 if name == "pml_media" else 14)
     ref_f, ref_m = _run(disc.spec, emu_lib, L.VARIANT_ZMARCH, 4, 2)
     # mask < 0: all axes inside the sweep as ONE launch (the small-grid default) instead of the three-launch split
     got_f, got_m = _run(disc.spec, emu_lib, L.VARIANT_FUSED, rows, zc, abs(mask), split=0 if mask < 0 else 1)
@@ -264,3 +274,42 @@ def test_placement_probe_changes_nothing(name, emu_lib):
         assert np.array_equal(a, b)
     for k in ref[2]:
         assert np.array_equal(ref[2][k], got[2][k]), k
+
+
+@pytest.mark.parametrize("tb", [3, 4, 7, 4096 + 4])
+@pytest.mark.parametrize("name", ["absorber_media", "pec_two_x_tiles", "pmc_min_faces", "pec_media_tall"])
+def test_two_step_slab_schedule_changes_nothing(name, tb, emu_lib):
+    """FDTD_OPT_TBLOCK: two time steps per pass over the grid, slab by slab (A(s+1) = step n on slab s+1, then B(s) = step
+    n+1 on slab s, in place) with the corrections (dipoles on E and H, ADE, absorber layers, lossy and PEC media) applied
+    per slab.  Same kernels on the same values -> the same bits as single steps; pairs give way to single steps around
+    monitor records (the time monitor records every 3rd step) and field-decay checks, and across run() calls."""
+    if name == "pec_media_tall":
+        N, bspec, structures = (24, 10, 19), PEC, MEDIA
+    elif name == "absorber_media":
+        ab = td.Boundary.absorber(num_layers=3)
+        N, bspec, structures = (24, 12, 10), td.BoundarySpec(x=ab, y=td.Boundary(minus=td.PECBoundary(), plus=td.Absorber(num_layers=4)), z=ab), MEDIA
+    else:
+        N, bspec, structures = CONFIGS[name]
+    disc = discretize(_sim(N, bspec, structures), n_steps=26)
+    disc.spec.decay_every = 8
+
+    def run(tblock):
+        with HipEngine(disc.spec, lib=emu_lib, variant=L.VARIANT_FUSED, z_chunk=2) as e:
+            e.set_option(L.OPT_ROWS, 3)
+            e.set_option(L.OPT_TBLOCK, tblock)
+            st = e.run(11)
+            pairs = int(st.two_step_pairs)
+            st = e.run(15)
+            return [e.get_field(c) for c in range(6)], e.results(), pairs + int(st.two_step_pairs), int(st.tblock_planes)
+    ref_f, ref_m, p0, t0 = run(0)
+    got_f, got_m, p1, t1 = run(tb)
+    assert p0 == 0 and t0 == 0
+    nz = disc.spec.shape[2]
+    if nz >= 2 * (tb % 4096):
+        assert t1 == tb % 4096 and p1 >= 3, (p1, t1)          # pairs were really taken
+    else:
+        assert p1 == 0
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), c
+    for k in ref_m:
+        assert np.array_equal(got_m[k], ref_m[k]), k

@@ -1,0 +1,209 @@
+"""The code path every LARGE CPML run takes, under bit-level test on real hardware ("weak" 1 and 2).
+
+For >= 2^24 cells a step with CPML goes out as three concurrent launches on two streams (interior tiles: x-only
+instantiation on the main stream; z-slab planes and y-edge tile rows: all-axes instantiation on the second stream).
+The small parity cases never reach it: they are one workgroup column wide (tile_x == 0 always) and default to ONE launch.
+Here:
+
+  (a) a 520 x 72 x 72 grid — three x-tiles (256 + 256 + 8 cells), odd x layer counts 5 / 3, CPML on all six faces,
+      a Lorentz sphere, a lossy box and a PEC box — forced onto the three-launch split with the recursions
+      inside the sweep (mask 7), y / z inside and x as slab kernels (6), all as slab kernels (0), as ONE launch
+      (the small-grid default) and as the two-pass kernels: all bit-identical, and <= 2e-5 from the fp64 oracle;
+  (b) the bench V2 spec at BASELINE's full 512^3 (materials + 12 CPML layers on six faces, random initial fields):
+      the default path (three launches, two streams) three times over — run-to-run identical bits: no stream race —
+      and identical to the slab-kernel placement and to the two-pass kernels;
+  (c) the bench V0 spec (random +-1e-3 initial fields, PEC walls, a dipole) at 128^3 x 40 steps against the oracle
+      <= 1e-5, and at 512^3 x 12 steps fused == two-pass bit for bit.
+"""
+import numpy as np
+import pytest
+
+import tidy3d_amd.schema as td
+from tidy3d_amd import lib as L
+from tidy3d_amd.discretize import discretize
+from tidy3d_amd.engine import HipEngine
+
+from cases import DL, PULSE, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def two_x_tile_cpml_sim(N=(512, 64, 64)):
+    sx, sy, sz = (n * DL for n in N)
+    structures = [
+        td.Structure(geometry=td.Sphere(center=(0.35 * sx, 0.05, 0.1), radius=0.9),
+                     medium=td.Lorentz(eps_inf=2.0, coeffs=[(1.5, 4e14, 3e13)])),
+        # a lossy bar that runs through the x tile boundary at cell 256 and into the low-x CPML
+        td.Structure(geometry=td.Box(center=(-0.2 * sx, -0.4, -0.3), size=(0.7 * sx, 0.8, 0.6)),
+                     medium=td.Medium(permittivity=3.0, conductivity=0.02)),
+        td.Structure(geometry=td.Box(center=(0.1 * sx, 0.6, 0.5), size=(0.5, 0.4, 0.3)), medium=td.PEC)]
+    bspec = td.BoundarySpec(x=td.Boundary(minus=td.PML(num_layers=5), plus=td.PML(num_layers=3)),
+                            y=td.Boundary.pml(num_layers=4),
+                            z=td.Boundary(minus=td.PML(num_layers=3), plus=td.PML(num_layers=5)))
+    # dipoles next to the x tile boundaries (cells 256 and 512 of the 520) and next to both x slabs
+    sources = [td.PointDipole(center=(-0.5 * sx + 251.3 * DL, 0.13, 0.07), source_time=PULSE, polarization="Ez"),
+               td.PointDipole(center=(-0.5 * sx + 3.2 * DL, -0.21, 0.33), source_time=PULSE, polarization="Hy"),
+               td.PointDipole(center=(0.5 * sx - 6.6 * DL, 0.4, -0.5), source_time=PULSE, polarization="Ex"),
+               td.PointDipole(center=(0.0, -1.2, 1.1), source_time=PULSE, polarization="Hz")]
+    monitors = [td.FieldTimeMonitor(center=(0, 0, 0), size=(td.inf, 0.4, 0), name="t", colocate=False, interval=9),
+                td.FieldMonitor(center=(0, 0, 0.2), size=(td.inf, td.inf, 0), freqs=[2.5e14, 3e14], name="f")]
+    return td.Simulation(size=(sx, sy, sz), grid_spec=td.GridSpec.uniform(dl=DL), run_time=1e-12,
+                         structures=structures, sources=sources, monitors=monitors, boundary_spec=bspec, shutoff=0)
+
+
+def _run(spec, lib, variant=L.VARIANT_AUTO, split=None, mask=None, init=None, steps=None, rows=None, zc=0):
+    with HipEngine(spec, lib=lib, variant=variant, axis_shift=0, z_chunk=zc) as e:
+        if rows:
+            e.set_option(L.OPT_ROWS, rows)
+        if split is not None:
+            e.set_option(L.OPT_PML_SPLIT, split)
+        if mask is not None:
+            e.set_option(L.OPT_PML_FUSED, mask)
+        if init is not None:
+            for c in range(6):
+                e.set_field(c, init[c])
+        e.run(steps)
+        return [e.get_field(c) for c in range(6)], e.results()
+
+
+def test_three_launch_cpml_two_x_tiles_bit_identical_and_oracle(hip_lib):
+    from oracle.fdtd_numpy import OracleFdtd
+    disc = discretize(two_x_tile_cpml_sim(), n_steps=48)
+    spec = disc.spec
+    assert spec.shape == (520, 72, 72), spec.shape
+    ref_f, ref_m = _run(spec, hip_lib, variant=L.VARIANT_ZMARCH, rows=4, zc=2)
+    runs = {"split_mask7": dict(variant=L.VARIANT_FUSED, split=1, mask=7),
+            "split_mask6": dict(variant=L.VARIANT_FUSED, split=1, mask=6),
+            "slab_kernels": dict(variant=L.VARIANT_FUSED, split=1, mask=0),
+            "one_launch": dict(variant=L.VARIANT_FUSED, split=0, mask=7),
+            "split_mask7_rows7": dict(variant=L.VARIANT_FUSED, split=1, mask=7, rows=7, zc=5),
+            "default": dict()}
+    for name, kw in runs.items():
+        f, m = _run(spec, hip_lib, **kw)
+        for c in range(6):
+            assert np.array_equal(f[c], ref_f[c]), (name, c, float(np.abs(f[c] - ref_f[c]).max()))
+        for k in ref_m:
+            assert np.array_equal(m[k], ref_m[k]), (name, k)
+    o = OracleFdtd(spec)
+    om = o.run()
+    for k in om:
+        assert rel_err(ref_m[k], om[k]) < 2e-5, (k, rel_err(ref_m[k], om[k]))
+    en = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in o.E))
+    hn = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in o.H))
+    for c in range(3):
+        assert np.linalg.norm(ref_f[c] - o.E[c]) / en < 2e-5, c
+        assert np.linalg.norm(ref_f[3 + c] - o.H[c]) / hn < 2e-5, c
+
+
+def _bench_init(n, seed_offset=0):
+    out = []
+    for c in range(6):
+        arr = np.empty((n, n, n), dtype=np.float32)
+        for k in range(n):
+            arr[k] = np.random.default_rng(c * 100003 + k + seed_offset).uniform(-1e-3, 1e-3, (n, n)).astype(np.float32)
+        out.append(arr)
+    return out
+
+
+def test_bench_v2_spec_512_default_path_repeatable_and_equal_to_slab_and_two_pass(hip_lib):
+    """bench.py's `workloads.v2` at full size: what the CPML throughput number is measured on."""
+    from bench import build_spec
+    n, steps = 512, 12
+    spec = build_spec(n, steps + 4, "v2")
+    init = _bench_init(n)
+    ref, _ = _run(spec, hip_lib, init=init, steps=steps)                       # default: three launches, two streams
+    assert all(np.isfinite(x).all() for x in ref) and max(np.abs(x).max() for x in ref) > 0
+    for rep in range(2):                                                        # stream races would show as differing bits
+        got, _ = _run(spec, hip_lib, init=init, steps=steps)
+        for c in range(6):
+            assert np.array_equal(got[c], ref[c]), ("repeat", rep, c)
+    got, _ = _run(spec, hip_lib, init=init, steps=steps, mask=0)               # CPML as slab kernels around the sweep
+    for c in range(6):
+        assert np.array_equal(got[c], ref[c]), ("slab kernels", c)
+    del got
+    got, _ = _run(spec, hip_lib, init=init, steps=steps, variant=L.VARIANT_ZMARCH)
+    for c in range(6):
+        assert np.array_equal(got[c], ref[c]), ("two-pass", c)
+
+
+def test_bench_v0_spec_vs_oracle_128_and_two_pass_512(hip_lib):
+    """bench.py's headline workload: random initial fields, PEC walls, a dipole."""
+    from bench import build_spec
+    from oracle.fdtd_numpy import OracleFdtd
+    n, steps = 128, 40
+    spec = build_spec(n, steps + 4, "v0")
+    init = _bench_init(n)
+    got, _ = _run(spec, hip_lib, init=init, steps=steps)
+    o = OracleFdtd(spec)
+    for c in range(3):
+        o.E[c][...] = init[c]
+        o.H[c][...] = init[3 + c]
+    for _ in range(steps):
+        o.step()
+    en = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in o.E))
+    hn = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in o.H))
+    for c in range(3):
+        assert np.linalg.norm(got[c] - o.E[c]) / en < 1e-5, c
+        assert np.linalg.norm(got[3 + c] - o.H[c]) / hn < 1e-5, c
+    n, steps = 512, 12
+    spec = build_spec(n, steps + 4, "v0")
+    init = _bench_init(n)
+    a, _ = _run(spec, hip_lib, init=init, steps=steps)
+    b, _ = _run(spec, hip_lib, init=init, steps=steps, variant=L.VARIANT_ZMARCH)
+    for c in range(6):
+        assert np.array_equal(a[c], b[c]), c
+
+
+def test_two_streams_overlap_is_measured_with_idle_torch_streams_alive(hip_lib):
+    """with more live streams in the process than the runtime has hardware queues an engine's two
+    streams can land on ONE queue and silently serialise (3x slower z-slab steps).  The engine now measures the overlap
+    before its first two-stream run, tries fresh streams, and falls back to one stream — flagged in FdtdStats — if none
+    overlaps.  Eight idle torch streams alive: whatever the outcome, it is reported, and the results are the same bits."""
+    import torch
+    from cases import pipelined_slab_case
+    idle = [torch.cuda.Stream() for _ in range(8)]
+    for s_ in idle:                                   # make the runtime really create them
+        with torch.cuda.stream(s_):
+            torch.zeros(16, device="cuda").add_(1.0)
+    torch.cuda.synchronize()
+    disc = discretize(pipelined_slab_case(), n_steps=40)
+    with HipEngine(disc.spec, lib=hip_lib) as e:
+        e.run()
+        ref = [e.get_field(c) for c in range(6)]
+        ref_m = e.results()
+    with HipEngine(disc.spec, lib=hip_lib, force_comm=True) as e:
+        e.comm_init(e.unique_id())
+        st = e.run()
+        assert st.stream_overlap in (1, -1), st.stream_overlap          # probed: verified, or the flagged fallback
+        assert st.comm_ranks == 1 and st.comm_rank == 0
+        print(f"stream_overlap={st.stream_overlap} retries={st.stream_retries}")
+        got = [e.get_field(c) for c in range(6)]
+        got_m = e.results()
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    for k in ref_m:
+        assert np.array_equal(ref_m[k], got_m[k]), k
+    del idle
+
+
+@pytest.mark.parametrize("tb", [8, 16, 4096 + 16])
+def test_two_step_slab_schedule_bit_identical_256(hip_lib, tb):
+    """FDTD_OPT_TBLOCK on real hardware (single stream, and A / B chains on the two streams): bench V1-like spec at 256^3
+    (dielectric sphere, random initial fields, a dipole) == single steps, bit for bit."""
+    from bench import build_spec
+    n, steps = 256, 14
+    spec = build_spec(n, steps + 4, "v1")
+    init = _bench_init(n)
+
+    def run(tblock):
+        with HipEngine(spec, lib=hip_lib, axis_shift=0) as e:
+            e.set_option(L.OPT_TBLOCK, tblock)
+            for c in range(6):
+                e.set_field(c, init[c])
+            st = e.run(steps)
+            return [e.get_field(c) for c in range(6)], int(st.two_step_pairs)
+    ref, p0 = run(0)
+    got, p1 = run(tb)
+    assert p0 == 0 and p1 == steps // 2
+    for c in range(6):
+        assert np.array_equal(got[c], ref[c]), c

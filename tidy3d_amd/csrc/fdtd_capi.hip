@@ -45,6 +45,7 @@ struct PmlAxisDev {
 
 struct AdeGroup {
   int comp;
+  int k0 = 0, k1 = 0;              // planes [k0, k1) that hold its cells: launches over other plane ranges are skipped
   long long n;
   uint32_t* cell;
   float* e_old;
@@ -59,10 +60,12 @@ struct PointSrc {
   float *wre_e = nullptr, *wim_e = nullptr, *wre_h = nullptr, *wim_h = nullptr;
   float2 *wave_e = nullptr, *wave_h = nullptr;
   long long n_steps = 0;
+  int ke0 = 0, ke1 = 0, kh0 = 0, kh1 = 0;   // planes [k0, k1) that hold its E / H points
 };
 
 // correction list of one side (E or H) of a TFSF box, grouped by target node (tfsf_corr_kernel)
 struct TfsfList {
+  int k0 = 0, k1 = 0;              // planes [k0, k1) that hold its target nodes
   long long n_targets = 0;
   int32_t *comp = nullptr, *start = nullptr, *aux = nullptr;
   uint32_t* cell = nullptr;
@@ -167,6 +170,13 @@ struct FdtdSolver {
   ncclComm_t comm = nullptr;
   int rank = 0, n_ranks = 1;
   hipEvent_t ev_h_int = nullptr, ev_h_bnd = nullptr, ev_e_int = nullptr, ev_e_bnd = nullptr;
+  // the two streams must really overlap (probe_stream_overlap): 0 = not probed, 1 = verified, -1 = one stream in use
+  int stream_overlap = 0, stream_retries = 0;
+  bool streams_shared = false;       // comm_stream is an alias of stream (fallback)
+  // slab-interleaved two-step schedule (fdtd_run): planes per slab; 0 = off, -1 = default
+  int tblock = -1;
+  long long two_step_pairs = 0;
+  int tblock_used = 0;
 };
 
 namespace {
@@ -285,6 +295,17 @@ constexpr int kPlainZChunk = 8;      // z-chunk of sweeps without in-sweep CPML 
 constexpr int kTileRun = 8;          // default tile order of the sweep: runs of 8 tiles per XCD (launch_fused_range)
 
 inline unsigned nblk(long long n, int b = 256) { return (unsigned)((n + b - 1) / b); }
+
+// planes [k0, k1) touched by a list of linear cell indices (empty list: k0 == k1 == 0)
+inline void plane_range(const uint32_t* cell, long long n, long long sxy, int* k0, int* k1) {
+  *k0 = *k1 = 0;
+  if (n <= 0) return;
+  uint32_t lo = cell[0], hi = cell[0];
+  for (long long i = 1; i < n; ++i) { lo = std::min(lo, cell[i]); hi = std::max(hi, cell[i]); }
+  *k0 = (int)(lo / (uint64_t)sxy);
+  *k1 = (int)(hi / (uint64_t)sxy) + 1;
+}
+inline bool planes_meet(int k0, int k1, int kbeg, int kend) { return k0 < kend && kbeg < k1; }
 
 long long plane_cells(const FdtdSolver* h) { return (long long)h->cfg.nx * h->cfg.ny; }
 long long n_cells(const FdtdSolver* h) { return plane_cells(h) * h->cfg.nz; }
@@ -665,6 +686,67 @@ int autotune_fused(FdtdSolver* h, hipStream_t st) {
   return 0;
 }
 
+// Do the engine's two streams really run concurrently?  The HIP runtime multiplexes a process's streams onto
+// $GPU_MAX_HW_QUEUES hardware queues (default 4); two streams that land on ONE queue execute their launches one after
+// the other.  For this engine that is a silent 3x cliff: the boundary chunks and the interior sweep of a z-slab step
+// (0.83 instead of 0.28 ms, profiles/r04u), the edge and interior launches of a CPML step.  So it is MEASURED, once,
+// before the first run that uses both streams: a 200 us spin kernel on each; if the pair takes two spins instead of one,
+// a fresh second stream is tried (the runtime gives a new stream the least-loaded queue of its priority class), a few
+// times over; if none overlaps, the engine uses ONE stream for both roles and says so in FdtdStats.stream_overlap.
+int probe_stream_overlap(FdtdSolver* h) {
+  if (h->stream_overlap != 0) return 0;
+#if defined(__HIPCC__)
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device) != hipSuccess || khz <= 0) khz = 100000;
+  const long long ticks = (long long)khz / 5;                 // 200 us of the constant-rate clock
+  hipEvent_t e0, e1, e2;
+  HIPCHK(h, hipEventCreate(&e0));
+  HIPCHK(h, hipEventCreate(&e1));
+  HIPCHK(h, hipEventCreate(&e2));
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; }
+  std::vector<hipStream_t> rejected;
+  int rc = 0;
+  bool ok = false;
+  for (int attempt = 0; attempt < 6 && !rc; ++attempt) {
+    hipStream_t a = h->stream, b = h->comm_stream;
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, 0LL);       // (code object resident, queues awake)
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, 0LL);
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) { rc = fail(h, "probe_stream_overlap: %s", hipGetErrorString(hipGetLastError())); break; }
+    hipEventRecord(e0, a);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, ticks);
+    hipEventRecord(e1, a);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, ticks);
+    hipEventRecord(e2, b);
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventSynchronize(e2) != hipSuccess) { rc = fail(h, "probe_stream_overlap: %s", hipGetErrorString(hipGetLastError())); break; }
+    float t1 = 0.f, t2 = 0.f;
+    hipEventElapsedTime(&t1, e0, e1);
+    hipEventElapsedTime(&t2, e0, e2);
+    if (std::max(t1, t2) < 0.32f) { ok = true; break; }      // one spin (0.2 ms) + launch latencies; two spins would be >= 0.4
+    // serialised: another second stream
+    hipStream_t fresh = nullptr;
+    if (hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, attempt % 2 ? least : greatest) != hipSuccess) break;
+    rejected.push_back(h->comm_stream);
+    h->comm_stream = fresh;
+    h->stream_retries++;
+  }
+  for (hipStream_t r : rejected) hipStreamDestroy(r);
+  hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
+  if (rc) return rc;
+  if (ok) { h->stream_overlap = 1; return 0; }
+  // fallback: one stream carries both roles (correct — every cross-stream edge becomes stream order — just not overlapped)
+  hipStreamDestroy(h->comm_stream);
+  h->comm_stream = h->stream;
+  h->streams_shared = true;
+  h->stream_overlap = -1;
+  std::fprintf(stderr, "libfdtd_hip: the engine's two HIP streams do not run concurrently (shared hardware queue; "
+                       "GPU_MAX_HW_QUEUES too low for this process?) - using one stream\n");
+  return 0;
+#else
+  return 0;        // (the emulator runs every launch to completion: nothing to measure)
+#endif
+}
+
 // periodic z, fused sweep: the prologue recomputes H^{n+1/2}[-1] from ghost copies of E (all three
 // components) and H_x, H_y of plane nz-1; the top plane needs E_x, E_y of plane 0
 void fill_ghost_fused(FdtdSolver* h, hipStream_t st) {
@@ -780,18 +862,18 @@ void launch_sources(FdtdSolver* h, bool e_side, long long n, int kbeg, int kend,
     const TfsfList& L = e_side ? t.e : t.h;
     // E-side corrections read the incident H (h1), H-side ones the incident E (e1)
     const float* aux = e_side ? (replica ? t.h1c : t.h1) : (replica ? t.e1c : t.e1);
-    if (L.n_targets)
+    if (L.n_targets && planes_meet(L.k0, L.k1, kbeg, kend))
       hipLaunchKernelGGL(tfsf_corr_kernel, dim3(nblk(L.n_targets)), dim3(256), 0, st, f0, f1, f2,
                          (const int32_t*)L.comp, (const uint32_t*)L.cell, (const int32_t*)L.start, (const float*)L.w,
                          (const int32_t*)L.aux, aux, L.n_targets, zlo, zhi);
   }
   for (PointSrc& s : h->psrc) {
     if (n >= s.n_steps) continue;
-    if (e_side && s.n_e)
+    if (e_side && s.n_e && planes_meet(s.ke0, s.ke1, kbeg, kend))
       hipLaunchKernelGGL(point_source_kernel, dim3(nblk(s.n_e)), dim3(256), 0, st, f0, f1, f2,
                          (const int32_t*)s.comp_e, (const uint32_t*)s.cell_e, (const float*)s.wre_e,
                          (const float*)s.wim_e, (const float2*)s.wave_e, n, s.n_e, zlo, zhi);
-    if (!e_side && s.n_h)
+    if (!e_side && s.n_h && planes_meet(s.kh0, s.kh1, kbeg, kend))
       hipLaunchKernelGGL(point_source_kernel, dim3(nblk(s.n_h)), dim3(256), 0, st, f0, f1, f2,
                          (const int32_t*)s.comp_h, (const uint32_t*)s.cell_h, (const float*)s.wre_h,
                          (const float*)s.wim_h, (const float2*)s.wave_h, n, s.n_h, zlo, zhi);
@@ -817,6 +899,7 @@ void launch_ade(FdtdSolver* h, int kbeg, int kend, hipStream_t st) {
   if (kend <= kbeg) return;
   const long long zlo = (long long)kbeg * h->g.sxy, zhi = (long long)kend * h->g.sxy;
   for (AdeGroup& a : h->ade)
+    if (planes_meet(a.k0, a.k1, kbeg, kend))
     hipLaunchKernelGGL(ade_kernel, dim3(nblk(a.n)), dim3(256), 0, st, field_ptr(h, a.comp),
                        (const uint32_t*)a.cell, a.e_old, a.q, a.n, zlo, zhi, a.p);
 }
@@ -1157,7 +1240,7 @@ void fdtd_destroy(FdtdSolver* h) {
   if (h->ev_e_int) hipEventDestroy(h->ev_e_int);
   if (h->ev_e_bnd) hipEventDestroy(h->ev_e_bnd);
   if (h->stream) hipStreamDestroy(h->stream);
-  if (h->comm_stream) hipStreamDestroy(h->comm_stream);
+  if (h->comm_stream && !h->streams_shared) hipStreamDestroy(h->comm_stream);
   delete h;
 }
 
@@ -1322,6 +1405,7 @@ int fdtd_add_ade(FdtdSolver* h, int comp, int64_t n, const uint32_t* cell_index,
   HIPCHK(h, hipSetDevice(h->cfg.device));
   AdeGroup a{};
   a.comp = comp; a.n = n;
+  plane_range(cell_index, n, h->g.sxy, &a.k0, &a.k1);
   if (dev_upload(h, &a.cell, cell_index, (size_t)n) || dev_alloc(h, &a.e_old, (size_t)n) ||
       dev_alloc(h, &a.q, (size_t)n * n_poles))
     return -1;
@@ -1359,6 +1443,8 @@ int fdtd_add_point_source(FdtdSolver* h, int64_t n, const int32_t* comp, const u
   }
   PointSrc s{};
   s.n_e = (long long)ce.size(); s.n_h = (long long)chh.size(); s.n_steps = n_steps;
+  plane_range(le.data(), s.n_e, h->g.sxy, &s.ke0, &s.ke1);
+  plane_range(lh.data(), s.n_h, h->g.sxy, &s.kh0, &s.kh1);
   if (s.n_e) {
     if (dev_upload(h, &s.comp_e, (const int32_t*)ce.data(), ce.size()) || dev_upload(h, &s.cell_e, (const uint32_t*)le.data(), le.size()) ||
         dev_upload(h, &s.wre_e, (const float*)re_e.data(), re_e.size()) || dev_upload(h, &s.wim_e, (const float*)im_e.data(), im_e.size()) ||
@@ -1402,6 +1488,7 @@ int build_tfsf_list(FdtdSolver* h, TfsfList& L, int64_t n, const int32_t* comp, 
   }
   st.push_back((int32_t)n);
   L.n_targets = (long long)tc.size();
+  plane_range(tl.data(), L.n_targets, h->g.sxy, &L.k0, &L.k1);
   if (dev_upload(h, &L.comp, (const int32_t*)tc.data(), tc.size()) || dev_upload(h, &L.cell, (const uint32_t*)tl.data(), tl.size()) ||
       dev_upload(h, &L.start, (const int32_t*)st.data(), st.size()) || dev_upload(h, &L.w, (const float*)ww.data(), ww.size()) ||
       dev_upload(h, &L.aux, (const int32_t*)ax.data(), ax.size()))
@@ -1540,6 +1627,11 @@ int fdtd_comm_init(FdtdSolver* h, const char id[128], int rank, int n_ranks) {
   std::memcpy(&u, id, 128);
   NCCLCHK(h, ncclCommInitRank(&h->comm, n_ranks, u, rank));
   h->rank = rank; h->n_ranks = n_ranks;
+  // what the communicator itself reports goes into FdtdStats (bench.py --gpus N prints it: proof that RCCL saw N ranks)
+  int cnt = 0, ur = -1;
+  NCCLCHK(h, ncclCommCount(h->comm, &cnt));
+  NCCLCHK(h, ncclCommUserRank(h->comm, &ur));
+  h->stats.comm_ranks = cnt; h->stats.comm_rank = ur;
   return 0;
 }
 
@@ -1579,6 +1671,8 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   const bool nb_lo = h->cfg.bc[4] == FDTD_BC_NEIGHBOR, nb_hi = h->cfg.bc[5] == FDTD_BC_NEIGHBOR;
   if ((nb_lo || nb_hi) && !multi) return fail(h, "fdtd_run: neighbour faces need fdtd_comm_init");
   const int nz = h->g.nz;
+  // runs that use BOTH streams first make sure the two really overlap (once per engine; falls back to one stream)
+  if ((multi || any_pml(h) || h->tblock > 4096) && probe_stream_overlap(h)) return -1;
   hipStream_t st = h->stream, cs = h->comm_stream;
   for (hipEvent_t e : h->kev) hipEventDestroy(e);
   h->kev.clear(); h->kev_kind.clear();
@@ -1713,6 +1807,74 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   //   ev_h_int : H interior done                 -> cs may update E plane 0 (reads H[0])
   //   ev_h_bnd : H top plane done (cs)           -> st may run E interior (reads H[nz-1])
   // Ghost planes are only touched on cs, in stream order.  No host synchronisation in the loop.
+  // ---- slab-interleaved two-step schedule (one GPU, fused sweep; FDTD_OPT_TBLOCK) ---------------------------------
+  // Two time steps per pass over the grid, slab by slab of T planes:  A(s) = step n on slab s (set a -> set b),
+  // B(s) = step n+1 on slab s (b -> a, IN PLACE of what A read), issued  A(0) A(1) B(0) A(2) B(1) ... : B(s) follows
+  // A(s+1) because its top plane differentiates E^{n+1} of slab s+1's first plane, and it must not overwrite a's slab s
+  // before A(s+1)'s chunk prologue has read its top plane.  What B(s) reads was written two launches earlier — 2 T planes
+  // x 6 arrays, within the 256 MiB Infinity Cache for T <= 16 at 512^2 cells per plane — so per step pair the arrays
+  // cross the HBM interface about three times (read a, write b, write a) instead of four.  Every correction launch takes
+  // a plane range already (the z-slab schedule uses them the same way): H-side pre-corrections of a slab go out in front
+  // of its sweep, E-side ones behind it.  The same kernels, the same arithmetic on the same values: bit-identical to
+  // single steps (tests/test_emu_fused.py, tests/test_gpu_production_path.py).  Not with CPML or TFSF (their state is
+  // advanced per whole step), not across a periodic z (the ghost planes wrap around the slab order), and only for step
+  // pairs in which no monitor records and no field-decay check falls on the middle step.
+  const int tb_req = h->tblock < 0 ? 0 : (h->tblock % 4096);
+  const bool tb_two_streams = h->tblock > 4096 && h->stream_overlap == 1;
+  const bool tb_ok = fused && tb_req > 0 && !any_pml(h) && h->tfsf.empty() && h->cfg.bc[4] != FDTD_BC_PERIODIC &&
+                     nz >= 2 * tb_req;
+  h->two_step_pairs = 0;
+  h->tblock_used = tb_ok ? tb_req : 0;
+  std::vector<hipEvent_t> tb_ev;                         // [2 s] = A(s) done, [2 s + 1] = B(s) done (two-stream mode)
+  auto tb_pair = [&](long long n) -> int {
+    const int T = tb_req, S = (nz + T - 1) / T;
+    if (ensure_second_set(h)) return -1;
+    if (tb_two_streams && tb_ev.empty()) {
+      tb_ev.resize((size_t)2 * S);
+      for (hipEvent_t& e : tb_ev) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    auto zs = [&](int s) { return std::min(nz, s * T); };
+    auto stage_a = [&](int s) -> int {                     // h->f = a
+      hipStream_t q = st;
+      if (tb_two_streams && s >= 3) HIPCHK(h, hipStreamWaitEvent(q, tb_ev[(size_t)2 * (s - 3) + 1], 0));   // stay <= 3 slabs ahead of B
+      const int k0 = zs(s), k1 = zs(s + 1);
+      launch_damp(h, false, k0, k1, q);
+      launch_sources(h, false, n, k0, k1, q);
+      if (launch_fused_range(h, k0, k1, q)) return -1;
+      swap_sets(h);                                        // h->f = b: the E-side corrections of step n act on E^{n+1}
+      launch_sources(h, true, n, k0, k1, q);
+      launch_damp(h, true, k0, k1, q);
+      launch_ade(h, k0, k1, q);
+      swap_sets(h);
+      if (tb_two_streams) HIPCHK(h, hipEventRecord(tb_ev[(size_t)2 * s], q));
+      return 0;
+    };
+    auto stage_b = [&](int s) -> int {
+      hipStream_t q = tb_two_streams ? cs : st;
+      if (tb_two_streams) HIPCHK(h, hipStreamWaitEvent(q, tb_ev[(size_t)2 * std::min(s + 1, S - 1)], 0));
+      const int k0 = zs(s), k1 = zs(s + 1);
+      swap_sets(h);                                        // h->f = b (E^{n+1}, H^{n+1/2}), h->f2 = a
+      launch_damp(h, false, k0, k1, q);
+      launch_sources(h, false, n + 1, k0, k1, q);
+      const int rc = launch_fused_range(h, k0, k1, q);
+      swap_sets(h);                                        // h->f = a again: slab s now holds E^{n+2}, H^{n+3/2}
+      if (rc) return -1;
+      launch_sources(h, true, n + 1, k0, k1, q);
+      launch_damp(h, true, k0, k1, q);
+      launch_ade(h, k0, k1, q);
+      if (tb_two_streams) HIPCHK(h, hipEventRecord(tb_ev[(size_t)2 * s + 1], q));
+      return 0;
+    };
+    if (stage_a(0)) return -1;
+    for (int s = 1; s < S; ++s) {
+      if (stage_a(s)) return -1;
+      if (stage_b(s - 1)) return -1;
+    }
+    if (stage_b(S - 1)) return -1;
+    if (tb_two_streams) HIPCHK(h, hipStreamWaitEvent(st, tb_ev[(size_t)2 * (S - 1) + 1], 0));
+    h->two_step_pairs++;
+    return 0;
+  };
   int64_t done = 0;
   for (; done < n_steps; ++done) {
     const long long n = h->step;
@@ -1786,6 +1948,11 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
         HIPCHK(h, hipEventRecord(h->ev_e_int, st));
       }
       h->step = n + 1;
+    } else if (fused && tb_ok && done + 2 <= n_steps && !rec && !rec_at(n + 1) &&
+               !(h->decay_every > 0 && ((n + 1) % h->decay_every) == 0)) {
+      if (tb_pair(n)) return -1;
+      h->step = n + 2;
+      ++done;                                              // (the loop header counts the second step)
     } else if (fused) {
       // H-side corrections are additive: pre-apply them to H^{n-1/2}; E-side ones follow the sweep.
       // With pml_in the CPML recursions run inside the sweep (same arithmetic, no slab kernels).
@@ -1927,6 +2094,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   HIPCHK(h, hipEventRecord(h->ev1, st));
   HIPCHK(h, hipStreamSynchronize(st));
   HIPCHK(h, hipStreamSynchronize(cs));
+  for (hipEvent_t e : tb_ev) hipEventDestroy(e);
   HIPCHK(h, hipGetLastError());
   float ms = 0.f;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
@@ -2142,6 +2310,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_MEM_HINTS: h->mem_hints = value != 0; return 0;
     case FDTD_OPT_PLACEMENT_TRIES: if (value < 0 || (value % 100) > 3) break; h->placement_tries = value; h->placement_done = false; return 0;
     case FDTD_OPT_LDS_PAD: if (value < 0 || value > 120000) break; h->lds_pad = value; return 0;
+    case FDTD_OPT_TBLOCK: h->tblock = value < 0 ? -1 : value; return 0;
     case FDTD_OPT_PML_SPLIT: h->pml_split = value < 0 ? -1 : (value != 0); return 0;
     case FDTD_OPT_FUSED_LB: if (value != 0 && value != 256 && value != 512 && value != 1024) break; h->fused_lb = value; return 0;
     default: break;
@@ -2158,6 +2327,10 @@ int fdtd_get_stats(FdtdSolver* h, FdtdStats* out) {
   out->placement = (h->placement_tried << 8) | h->placement_kept;
   out->placement_ms_first = h->placement_ms[0];
   out->placement_ms_kept = h->placement_ms[h->placement_kept];
+  out->stream_overlap = h->stream_overlap;
+  out->stream_retries = h->stream_retries;
+  out->two_step_pairs = h->two_step_pairs;
+  out->tblock_planes = h->tblock_used;
   return 0;
 }
 

@@ -1683,6 +1683,17 @@ __global__ __launch_bounds__(256) void far_field_kernel(FarP p) {
   if (threadIdx.x < 8) p.out[(long long)d * 8 + threadIdx.x] = red[0][threadIdx.x];
 }
 
+// Occupies one wavefront for `ticks` of the constant-rate wall clock: the host times two of these on the engine's two
+// streams to see whether the streams really run concurrently (fdtd_capi.hip probe_stream_overlap).
+__global__ void spin_kernel(long long ticks) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+#else
+  (void)ticks;
+#endif
+}
+
 // ghost-plane helpers (single-GPU z boundary conditions)
 __global__ __launch_bounds__(256) void negate_copy_kernel(float* dst, const float* src, long long n) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;

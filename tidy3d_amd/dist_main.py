@@ -28,12 +28,17 @@ def main(argv=None) -> int:
     import torch.distributed as dist
     from . import dist as tdist
     from .lib import load_library
+    import datetime
     rank, world, local = tdist.env_ranks()
+    if not args.lib:
+        load_library()            # before the first HIP call of this process: see lib._prefer_hw_queues
+    # a rank whose siblings never arrive (one died at import, ran out of memory, ...) gives up instead of waiting for ever
+    tmo = datetime.timedelta(seconds=int(os.environ.get("TIDY3D_AMD_RDV_TIMEOUT", "300")))
     if args.backend == "nccl":
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local), timeout=tmo)
     else:
-        dist.init_process_group(backend="gloo")
+        dist.init_process_group(backend="gloo", timeout=tmo)
     try:
         lib = load_library(args.lib) if args.lib else load_library()
         if args.hook:

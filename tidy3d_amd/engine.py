@@ -421,9 +421,15 @@ class HipEngine:
                 self._chk(d.fdtd_add_ade(h, c, idx.size, _ptr(idx), len(mt.kap[m]), _ptr(kap),
                                          _ptr(bet), float(mt.cc[m])), "fdtd_add_ade")
         # sources
+        from .spec import BC_PEC
         for s in spec.sources:
             k = s.ijk[:, 2]
             keep = (k >= z0) & (k < z1)
+            # an electric current on a PEC min wall, tangential to it, drives nothing: the wall holds that node at
+            # zero (the kernels apply source terms after the wall condition, so such an entry would un-zero it)
+            for a in range(3):
+                if spec.bc[a][0] == BC_PEC:
+                    keep &= ~((s.ijk[:, a] == 0) & (s.comp < 3) & (s.comp != a))
             if not keep.any():
                 continue
             ijk = s.ijk[keep]

@@ -16,12 +16,20 @@ from .exceptions import SolverLibraryError
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libfdtd_hip.so")
 
-# The solver overlaps work on TWO streams per engine (boundary chunks + exchange / interior sweep; the edge and interior
-# launches of a CPML step).  The HIP runtime multiplexes a process's streams onto $GPU_MAX_HW_QUEUES hardware queues
-# (default 4); once an engine's two streams share one, their launches serialise — measured: a 64-plane z-slab step
-# 0.83 ms instead of 0.28 ms with six more streams alive in the process, 0.28 ms again with 8 queues (profiles/
-# r04u_probe_hw_queues.jsonl).  Ask for 8 unless the user chose; read by the runtime when it first touches the device.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
+def _prefer_hw_queues() -> None:
+    """The solver overlaps work on TWO streams per engine (boundary chunks + exchange / interior sweep; the edge and
+    interior launches of a CPML step).  The HIP runtime multiplexes a process's streams onto $GPU_MAX_HW_QUEUES hardware
+    queues (default 4); once an engine's two streams share one, their launches serialise (measured: a 64-plane z-slab step
+    0.83 ms instead of 0.28 ms with six more streams alive in the process, 0.28 ms again with 8 queues: profiles/
+    r04u_probe_hw_queues.jsonl).  The library does not rely on this variable: every engine MEASURES whether its two streams
+    overlap before the first run that uses both, tries fresh streams if not, and otherwise falls back to one stream and
+    says so (``FdtdStats.stream_overlap``, include/fdtd_hip.h).  Asking the runtime for 8 queues merely makes the good
+    case the common one.  It is done when the product library is loaded — not at import — only if the user has not chosen
+    a value, and it is without effect when the HIP runtime of this process is already initialised."""
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 
 # every symbol include/fdtd_hip.h declares (tests check the library exports all of them)
 SYMBOLS = (
@@ -37,7 +45,7 @@ BC_PEC, BC_PMC, BC_PERIODIC, BC_NEIGHBOR = 0, 1, 2, 3
 MON_TIME, MON_DFT = 0, 1
 VARIANT_AUTO, VARIANT_SIMPLE, VARIANT_ZMARCH, VARIANT_FUSED = 0, 1, 2, 3
 FLAG_TIME_KERNELS = 1
-OPT_FLAGS, OPT_VARIANT, OPT_ZCHUNK, OPT_ROWS, OPT_XCD_REMAP, OPT_FUSED_LB, OPT_PML_FUSED, OPT_BND_PLANES, OPT_AUTOTUNE, OPT_PML_SPLIT, OPT_LDS_PAD, OPT_MEM_HINTS, OPT_PLACEMENT_TRIES = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
+OPT_FLAGS, OPT_VARIANT, OPT_ZCHUNK, OPT_ROWS, OPT_XCD_REMAP, OPT_FUSED_LB, OPT_PML_FUSED, OPT_BND_PLANES, OPT_AUTOTUNE, OPT_PML_SPLIT, OPT_LDS_PAD, OPT_MEM_HINTS, OPT_PLACEMENT_TRIES, OPT_TBLOCK = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13
 
 
 class FdtdConfig(C.Structure):
@@ -55,7 +63,10 @@ class FdtdStats(C.Structure):
                 ("fused_kernel_ms", C.c_double), ("fused_kernel_launches", C.c_int64),
                 ("tile_rows", C.c_int32), ("tile_zchunk", C.c_int32),
                 ("tile_order", C.c_int32), ("placement", C.c_int32),
-                ("placement_ms_first", C.c_float), ("placement_ms_kept", C.c_float)]
+                ("placement_ms_first", C.c_float), ("placement_ms_kept", C.c_float),
+                ("stream_overlap", C.c_int32), ("stream_retries", C.c_int32),
+                ("comm_ranks", C.c_int32), ("comm_rank", C.c_int32),
+                ("two_step_pairs", C.c_int64), ("tblock_planes", C.c_int32), ("reserved0", C.c_int32)]
 
 
 PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_int64, C.c_double, C.c_double, C.c_void_p)
@@ -142,6 +153,7 @@ def load_library(path: Optional[str] = None) -> FdtdLib:
             raise SolverLibraryError(
                 f"{DEFAULT_LIB} not found: build it with `python -m tidy3d_amd.build` "
                 "(hipcc --offload-arch=gfx950); there is no CPU fallback.")
+        _prefer_hw_queues()
         _cached = FdtdLib(DEFAULT_LIB)
         return _cached
     return FdtdLib(path)

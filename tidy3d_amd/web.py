@@ -157,35 +157,82 @@ def _run_on_devices(sim, devices, n_steps, verbose: bool, opt: dict) -> Simulati
     import subprocess
     import sys
     import tempfile
-    with socket.socket() as sck:                    # a free port for the rendezvous
-        sck.bind(("127.0.0.1", 0))
-        port = sck.getsockname()[1]
+    import time as _time
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    timeout_s = float(opt.get("timeout", 0) or 0)                 # whole multi-GPU call; 0 = none
+    rdv_timeout = int(opt.get("rendezvous_timeout", 300))         # init_process_group of every rank
     with tempfile.TemporaryDirectory(prefix="tidy3d_amd_") as tmp:
         f_sim, f_out = os.path.join(tmp, "sim.pkl"), os.path.join(tmp, "data.pkl")
         with open(f_sim, "wb") as f:
             pickle.dump(sim, f, protocol=pickle.HIGHEST_PROTOCOL)
-        procs = []
-        for rank, dev in enumerate(devices):
-            env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(len(devices)), LOCAL_RANK=str(dev),
-                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-            env["PYTHONPATH"] = os.pathsep.join([root] + [p for p in (opt.get("pythonpath") or []) if p]
-                                                + ([env["PYTHONPATH"]] if env.get("PYTHONPATH") else []))
-            cmd = [sys.executable, "-m", "tidy3d_amd.dist_main", "--sim", f_sim, "--out", f_out,
-                   "--backend", opt.get("backend", "nccl")]
-            if n_steps is not None:
-                cmd += ["--n-steps", str(int(n_steps))]
-            if opt.get("lib"):
-                cmd += ["--lib", opt["lib"]]
-            if opt.get("hook"):
-                cmd += ["--hook", opt["hook"]]
-            procs.append(subprocess.Popen(cmd, env=env, stdout=None if verbose else subprocess.DEVNULL,
-                                          stderr=subprocess.PIPE, text=True))
-        errs = [p.communicate()[1] for p in procs]
-        bad = [(r, p.returncode, e) for r, (p, e) in enumerate(zip(procs, errs)) if p.returncode != 0]
-        if bad:
-            r, rc, e = bad[0]
-            raise SolverLibraryError(f"multi-GPU run: rank {r} exited with status {rc}: {(e or '')[-2000:]}")
+        # rank 0 binds the rendezvous port itself (MASTER_PORT=0 is not portable across torch versions), so the port is
+        # chosen here — but held open until just before the ranks start, and a start that loses the race is retried
+        for attempt in range(3):
+            with socket.socket() as sck:
+                sck.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                sck.bind(("127.0.0.1", 0))
+                port = sck.getsockname()[1]
+            procs, logs = [], []
+            for rank, dev in enumerate(devices):
+                env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(len(devices)), LOCAL_RANK=str(dev),
+                           MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TIDY3D_AMD_RDV_TIMEOUT=str(rdv_timeout))
+                env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (what this driver supports) unless the user chose
+                env["PYTHONPATH"] = os.pathsep.join([root] + [p for p in (opt.get("pythonpath") or []) if p]
+                                                    + ([env["PYTHONPATH"]] if env.get("PYTHONPATH") else []))
+                cmd = [sys.executable, "-m", "tidy3d_amd.dist_main", "--sim", f_sim, "--out", f_out,
+                       "--backend", opt.get("backend", "nccl")]
+                if n_steps is not None:
+                    cmd += ["--n-steps", str(int(n_steps))]
+                if opt.get("lib"):
+                    cmd += ["--lib", opt["lib"]]
+                if opt.get("hook"):
+                    cmd += ["--hook", opt["hook"]]
+                # stderr goes to a FILE per rank: a pipe nobody drains blocks its rank after ~64 KiB (HIP / RCCL warnings,
+                # AMD_LOG_LEVEL) — and with it every sibling waiting for that rank in a collective
+                lf = open(os.path.join(tmp, f"rank{rank}.attempt{attempt}.err"), "w+")
+                logs.append(lf)
+                procs.append(subprocess.Popen(cmd, env=env, stdout=None if verbose else subprocess.DEVNULL, stderr=lf, text=True))
+            # poll ALL ranks: the first one that fails takes its siblings down (they would otherwise sit in
+            # init_process_group or in an RCCL send / recv for ever); an overall timeout does the same
+            t0 = _time.monotonic()
+            failed = None
+            while True:
+                codes = [p.poll() for p in procs]
+                bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+                if bad:
+                    failed = (bad[0], codes[bad[0]])
+                    break
+                if all(c == 0 for c in codes):
+                    break
+                if timeout_s and _time.monotonic() - t0 > timeout_s:
+                    failed = (-1, None)
+                    break
+                _time.sleep(0.05)
+            if failed is not None:
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                for p in procs:
+                    try:
+                        p.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        p.wait()
+            tails = []
+            for lf in logs:
+                lf.seek(0)
+                tails.append(lf.read()[-2000:])
+                lf.close()
+            if failed is None:
+                break
+            r, rc = failed
+            lost_port = r >= 0 and ("eaddrinuse" in tails[r].lower() or "address already in use" in tails[r].lower())
+            if lost_port and attempt < 2:
+                continue                                   # lost the race for the port: once more with another one
+            if r < 0:
+                raise SolverLibraryError(f"multi-GPU run: no result after {timeout_s:.0f} s (timeout); ranks terminated. "
+                                         f"rank 0 stderr: {tails[0]}")
+            raise SolverLibraryError(f"multi-GPU run: rank {r} exited with status {rc} (its siblings were terminated): {tails[r]}")
         with open(f_out, "rb") as f:
             return pickle.load(f)
 
