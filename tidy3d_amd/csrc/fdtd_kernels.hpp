@@ -494,8 +494,19 @@ __device__ __forceinline__ void pml_h_apply(float& h1, float& h2, float d1, floa
 //     first plane of a chunk recomputes H^{n+1/2}[k0-1] in a prologue).
 // Everything that depends on the row only (threadIdx.y is wave-uniform) is kept in SGPRs.
 // =============================================================================================
+// PML bit 3 (8), with bit 0: the x recursions are POOLED on the halo wave.  Along x only the first / last few lanes of a
+// wavefront hold slab cells (12 layers = 3 of 64 lanes), but every wave pays the instructions of four cells per lane for
+// them: ~150 vector instructions per wave and plane, the reason the x axis cost 0.2 ms of a 512^3 step for 0.2 GB of psi
+// (DESIGN.md section 5).  Pooled, the slab cells of ALL rows of the workgroup (rows x 12) sit one per lane on the halo
+// wave — which has no E phase of its own — and the recursion is executed once per workgroup and plane:
+//   * H side (depends on E^n only): computed one plane AHEAD, the additive terms handed to the owner lanes through LDS
+//     (they add them where the per-lane code added them: same operations, same order, same bits);
+//   * E side: the owners publish H_y of their row next to the H_x, H_z the row exchange already carries; behind the
+//     barrier the halo wave forms the terms of plane k, the owners pick them up behind the NEXT barrier and store the
+//     E_y, E_z of their slab lanes one plane late (8 registers pending instead of 16 of psi).
+constexpr int kXpCells = 64;       // capacity: slab cells per row of a tile (the host falls back to the per-lane form beyond)
 template <bool MAT, int LB, int PML, int HINT = 0>   // PML: bit a set = CPML of axis a runs inside the sweep; HINT: bit 0 = non-temporal field stores, bit 1 = non-temporal loads of E_y, H_y (measured: +0.7 %, not instantiated), bit 3 = H stores ahead of the row exchange
-__global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)) : (LB == 512 ? (PML ? 2 : 4) : 4))) void fused_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
+__global__ __launch_bounds__(LB, (LB == 256 ? ((PML & 7) == 0 ? 4 : ((PML & 7) == 1 ? 3 : 2)) : (LB == 512 ? (PML ? 2 : 4) : 4))) void fused_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
                                                           int kbeg, int kend, int zchunk, int pmc_z0,
                                                           int nbx, int nby, int nbz, int xcd_remap,
                                                           const PmlP* __restrict__ pmq,
@@ -552,6 +563,13 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
   const int tx = threadIdx.x;
   const int ty = __builtin_amdgcn_readfirstlane((int)threadIdx.y);     // one row per wave
   const int R = blockDim.y - 1;
+  constexpr bool XP = (PML & 9) == 9;            // x recursions pooled on the halo wave
+  // pooled form, LDS behind the coefficient tables: H_y rows [2][R+1][64] float4, the additive terms of the H side and of
+  // the E side [2 buffers][2 components][R+1 rows][kXpCells] each, and what lane 0 of every row uses as its x-1 neighbour
+  [[maybe_unused]] float4* hyrow = xco + 6 * 64;
+  [[maybe_unused]] float* xdh = reinterpret_cast<float*>(hyrow + 2 * (R + 1) * 64);
+  [[maybe_unused]] float* xde = xdh + 2 * 2 * (R + 1) * kXpCells;
+  [[maybe_unused]] float* hmc = xde + 2 * 2 * (R + 1) * kXpCells;
   const int i0 = (tile_x * 64 + tx) * V;
   const unsigned ux = (unsigned)i0;
   const unsigned ub = ux * 4u;            // lane's byte offset along the row: every row access is  uniform base + 32-bit lane offset
@@ -602,6 +620,94 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
     if (row_ok) sy = pml_si(pmq->ax[1], j);
     if (sy >= 0) { cyh = ldc_f4(pmq->ax[1].ch4 + j); cye = ldc_f4(pmq->ax[1].ce4 + j); }
   }
+
+  // ---- pooled x recursions: the slab cells of this tile, one per lane of the halo wave --------------------------
+  // slab cells of the tile: [xp_t0, xp_t0 + xp_nlo) on the low side, [xp_hs, tile end) on the high side, xp_nm in all;
+  // pooled item q = (row r, slab cell m): r = 0 is the halo row (only its H_z term is used), r >= 1 the own rows
+  [[maybe_unused]] int xp_t0 = 0, xp_nlo = 0, xp_hs = 0, xp_nm = 0, xp_m0 = 0;
+  if constexpr (XP) {
+    const PmlAxisP& A = pmq->ax[0];
+    xp_t0 = tile_x * 256;
+    const int t1 = min(xp_t0 + 256, g.nx);
+    xp_nlo = max(0, min(A.lo, t1) - xp_t0);
+    xp_hs = max(A.hi0, xp_t0);
+    xp_nm = xp_nlo + max(0, t1 - xp_hs);
+    xp_m0 = (i0 < A.lo) ? (i0 - xp_t0) : xp_nlo + (i0 - xp_hs);     // first slab cell of a member lane (sx >= 0)
+  }
+  // H side of plane k: psi_h (read set -> write set) and the terms  ch (kv dEz/dx + p1)  [H_y +=],  ch (kv dEy/dx + p2)  [H_z -=]
+  [[maybe_unused]] auto xp_h = [&](int k, int buf) {
+    const PmlAxisP& A = pmq->ax[0];
+    for (int q = tx; q < xp_nm * (R + 1); q += 64) {
+      const int r = q / xp_nm, mm = q - r * xp_nm;
+      int jr = tile_y * R + r - 1;
+      bool ok = (jr >= 0) && (jr < g.ny);
+      if (jr < 0 && per_y) { jr = g.ny - 1; ok = true; }
+      float d_hy = 0.f, d_hz = 0.f;
+      if (ok) {
+        const int i = mm < xp_nlo ? xp_t0 + mm : xp_hs + (mm - xp_nlo);
+        const int si = i < A.lo ? i : A.lo + (i - A.hi0);
+        const long long p = (long long)k * g.sxy + (long long)jr * g.nx + i;
+        const float ey_i = ldg1(a.ey + p), ez_i = ldg1(a.ez + p);
+        float ey_ip = 0.f, ez_ip = 0.f;
+        if (i + 1 < g.nx) { ey_ip = ldg1(a.ey + p + 1); ez_ip = ldg1(a.ez + p + 1); }
+        else if (g.bcx1 == BC_PERIODIC) { ey_ip = ldg1(a.ey + p - i); ez_ip = ldg1(a.ez + p - i); }
+        const float ipxi = s.ipx[i];
+        const float kv = A.kv_h[i], bb = A.b_h[i], cc = A.c_h[i];
+        const long long qq = ((long long)k * g.ny + jr) * A.ns + si;
+        const float s1 = ldg1(A.ph0 + qq), s2 = ldg1(A.ph1 + qq);
+        const float d1 = (ey_ip - ey_i) * ipxi, d2 = (ez_ip - ez_i) * ipxi;
+        const float p1 = bb * s1 + cc * d2;
+        const float p2 = bb * s2 + cc * d1;
+        if (r > 0) { A.ph0n[qq] = p1; A.ph1n[qq] = p2; }        // (the halo row's psi belongs to the tile below)
+        d_hy = ch * (kv * d2 + p1);
+        d_hz = ch * (kv * d1 + p2);
+      }
+      xdh[((buf * 2 + 0) * (R + 1) + r) * kXpCells + mm] = d_hy;
+      xdh[((buf * 2 + 1) * (R + 1) + r) * kXpCells + mm] = d_hz;
+    }
+  };
+  // E side of plane k (behind the barrier: H^{n+1/2}_{y,z} of the own rows are in LDS): psi_e in place and the terms
+  // cb (kv dHz/dx + p1)  [E_y -=],  cb (kv dHy/dx + p2)  [E_z +=]
+  [[maybe_unused]] auto xp_e = [&](int k, int cur_, int buf) {
+    const PmlAxisP& A = pmq->ax[0];
+    const int slot_ = (int)blockDim.y * 64;
+    for (int q = tx; q < xp_nm * R; q += 64) {
+      const int r = 1 + q / xp_nm, mm = q - (r - 1) * xp_nm;
+      const int jr = tile_y * R + r - 1;
+      float d_ey = 0.f, d_ez = 0.f;
+      const int i = mm < xp_nlo ? xp_t0 + mm : xp_hs + (mm - xp_nlo);
+      if (jr < g.ny && !(i == 0 && g.bcx0 == BC_PEC)) {          // (a cell on the x wall keeps its psi: both components are tangential)
+        const int si = i < A.lo ? i : A.lo + (i - A.hi0);
+        const int c = i - xp_t0;
+        const float* hyf = reinterpret_cast<const float*>(hyrow + (cur_ * (R + 1) + r) * 64);
+        const float* hzf = reinterpret_cast<const float*>(xch + (cur_ * 2 + 1) * slot_ + r * 64);
+        const float hy_i = hyf[c], hz_i = hzf[c];
+        const float hy_im = c > 0 ? hyf[c - 1] : hmc[(cur_ * (R + 1) + r) * 2 + 0];
+        const float hz_im = c > 0 ? hzf[c - 1] : hmc[(cur_ * (R + 1) + r) * 2 + 1];
+        const float idxi = s.idx[i];
+        const float kv = A.kv_e[i], bb = A.b_e[i], cc = A.c_e[i];
+        const long long qq = ((long long)k * g.ny + jr) * A.ns + si;
+        const float s1 = ldg1(A.pe0 + qq), s2 = ldg1(A.pe1 + qq);
+        const float d1 = (hy_i - hy_im) * idxi;
+        const float d2 = (hz_i - hz_im) * idxi;
+        const float p1 = bb * s1 + cc * d2;
+        const float p2 = bb * s2 + cc * d1;
+        A.pe0[qq] = p1; A.pe1[qq] = p2;
+        float cb_y = m.cb1, cb_z = m.cb1;
+        if constexpr (MAT) {
+          uint32_t w = m.roww[((long long)k * g.ny + jr) * nbx + tile_x];
+          if (w == kMixedWord) w = m.m4[(long long)k * g.sxy + (long long)jr * g.nx + i];
+          cb_y = lut_s[(w >> 10) & 1023u].y;
+          cb_z = lut_s[(w >> 20) & 1023u].y;
+        }
+        const bool wz = (k == 0) && g.pec_z0, wy = (jr == 0) && (g.bcy0 == BC_PEC);
+        if (!wz) d_ey = cb_y * (kv * d2 + p1);                  // E_y is tangential to the z wall
+        if (!wy) d_ez = cb_z * (kv * d1 + p2);                  // E_z is tangential to the y wall
+      }
+      xde[((buf * 2 + 0) * (R + 1) + r) * kXpCells + mm] = d_ey;
+      xde[((buf * 2 + 1) * (R + 1) + r) * kXpCells + mm] = d_ez;
+    }
+  };
 
   float exk[V], eyk[V], hxm[V], hym[V];
   zero<V>(hxm); zero<V>(hym);
@@ -700,12 +806,17 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
       }
     }
   }                                      // (the halo wave needs no H^{n+1/2}[k0-1])
+  if constexpr (XP) {
+    if (halo && k0 < k1) xp_h(k0, 0);    // the H-side terms of the chunk's first plane (every later plane: one plane ahead)
+    __syncthreads();
+  }
   int cur = 0;
   const int slot = (int)blockDim.y * 64;           // float4 entries per component per buffer
   // HINT bit 8 (256): the E values of a plane are stored one H phase later, behind the loads of the next plane
   [[maybe_unused]] float pend_ex[V], pend_ey[V], pend_ez[V];
   [[maybe_unused]] long long pend_p = -1;
   for (int k = k0; k < k1; ++k) {
+    [[maybe_unused]] const int kb = (k - k0) & 1;           // buffer of the pooled x terms of this plane
     const long long pb = (long long)k * g.sxy + rowb;      // scalar
     const long long pjb = (long long)k * g.sxy + rowpb;
     // Field loads of the plane: unconditional.  Lanes beyond the row end read the row's first cells instead
@@ -745,7 +856,7 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
     if constexpr ((PML & 2) != 0) qy = ((long long)k * pmq->ax[1].ns + max(sy, 0)) * g.nx;
     if constexpr (PML != 0) {
       if (act) {
-        if constexpr ((PML & 1) != 0) {
+        if constexpr ((PML & 1) != 0 && !XP) {
           if (sx >= 0) {
             const PmlAxisP& A = pmq->ax[0];
             ldg4(xh1, uni(A.ph0 + qx), sxb);
@@ -791,7 +902,15 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
     if constexpr (PML != 0) {
       if (act) {
         // axis x: Hy += ch (kv dEz/dx + p1), Hz -= ch (kv dEy/dx + p2)
-        if constexpr ((PML & 1) != 0) {
+        if constexpr (XP) {
+          if (sx >= 0) {                 // the terms were formed by the halo wave one plane ago
+            const float4 dy = *reinterpret_cast<const float4*>(xdh + ((kb * 2 + 0) * (R + 1) + ty) * kXpCells + xp_m0);
+            const float4 dz = *reinterpret_cast<const float4*>(xdh + ((kb * 2 + 1) * (R + 1) + ty) * kXpCells + xp_m0);
+            hyn[0] += dy.x; hyn[1] += dy.y; hyn[2] += dy.z; hyn[3] += dy.w;
+            hzn[0] -= dz.x; hzn[1] -= dz.y; hzn[2] -= dz.z; hzn[3] -= dz.w;
+          }
+        }
+        if constexpr ((PML & 1) != 0 && !XP) {
           if (sx >= 0) {
             const PmlAxisP& A = pmq->ax[0];
             const float4 kv4 = xco[0 * 64 + tx], bb4 = xco[1 * 64 + tx], cc4 = xco[2 * 64 + tx];
@@ -888,8 +1007,20 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
       xch[(cur * 2 + 0) * slot + ty * 64 + tx] = t4;
       t4.x = hzn[0]; t4.y = hzn[1]; t4.z = hzn[2]; t4.w = hzn[3];
       xch[(cur * 2 + 1) * slot + ty * 64 + tx] = t4;
+      if constexpr (XP) {
+        if (!halo) {                      // H_y of the row, and what its first lane uses at x-1, for the pooled E side
+          t4.x = hyn[0]; t4.y = hyn[1]; t4.z = hyn[2]; t4.w = hyn[3];
+          hyrow[(cur * (R + 1) + ty) * 64 + tx] = t4;
+          if (tx == 0) {
+            hmc[(cur * (R + 1) + ty) * 2 + 0] = xh ? hy_m : (g.bcx0 == BC_PMC ? -hyn[0] : 0.f);
+            hmc[(cur * (R + 1) + ty) * 2 + 1] = xh ? hz_m : (g.bcx0 == BC_PMC ? -hzn[0] : 0.f);
+          }
+        }
+      }
     }
+    if constexpr (XP) { if (halo && k + 1 < k1) xp_h(k + 1, kb ^ 1); }
     __syncthreads();
+    if constexpr (XP) { if (halo) xp_e(k, cur, kb); }
     float hyx = __shfl_up(hyn[V - 1], 1);
     float hzx = __shfl_up(hzn[V - 1], 1);
     if (pmc_z0 && k == 0) {
@@ -978,8 +1109,8 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
             stg4(uni(A.pe1 + qz), ub, s2);
           }
         }
-        // axis x: E_y -= cb (kv dHz/dx + p1),  E_z += cb (kv dHy/dx + p2)
-        if constexpr ((PML & 1) != 0) {
+        // axis x: E_y -= cb (kv dHz/dx + p1),  E_z += cb (kv dHy/dx + p2)      (pooled form: below, one plane late)
+        if constexpr ((PML & 1) != 0 && !XP) {
           if (sx >= 0) {
             const PmlAxisP& A = pmq->ax[0];
             float (&s1)[V] = xe1, (&s2)[V] = xe2;
@@ -1010,7 +1141,7 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
       // row exchange (the values wait in registers): a store issued before the barrier costs the CPML instantiations
       // 2.4 ... 3 % of the whole step (profiles/r04i), as the H field stores do (+12 %, r03k)
       if constexpr (PML != 0 && (HINT & 128) != 0) {
-        if constexpr ((PML & 1) != 0) {
+        if constexpr ((PML & 1) != 0 && !XP) {
           if (sx >= 0) { const PmlAxisP& A = pmq->ax[0]; stg4(uni(A.ph0n + qx), sxb, xh1); stg4(uni(A.ph1n + qx), sxb, xh2); }
         }
         if constexpr ((PML & 2) != 0) {
@@ -1025,7 +1156,27 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
         stv_h<V, (HINT & 1) != 0>(b.hy + pb + i0, hyn);
         stv_h<V, (HINT & 1) != 0>(b.hz + pb + i0, hzn);
       }
-      if constexpr ((HINT & 256) != 0) {
+      if constexpr (XP) {
+        // slab lanes: E_y, E_z of plane k-1 get the x terms the halo wave formed behind the last barrier, and go out now;
+        // those of this plane wait for the next barrier
+        if (sx >= 0) {
+          if (k > k0) {
+            const float4 dy = *reinterpret_cast<const float4*>(xde + (((kb ^ 1) * 2 + 0) * (R + 1) + ty) * kXpCells + xp_m0);
+            const float4 dz = *reinterpret_cast<const float4*>(xde + (((kb ^ 1) * 2 + 1) * (R + 1) + ty) * kXpCells + xp_m0);
+            pend_ey[0] -= dy.x; pend_ey[1] -= dy.y; pend_ey[2] -= dy.z; pend_ey[3] -= dy.w;
+            pend_ez[0] += dz.x; pend_ez[1] += dz.y; pend_ez[2] += dz.z; pend_ez[3] += dz.w;
+            stv<V>(b.ey + pend_p + i0, pend_ey);
+            stv<V>(b.ez + pend_p + i0, pend_ez);
+          }
+#pragma unroll
+          for (int e = 0; e < V; ++e) { pend_ey[e] = ey[e]; pend_ez[e] = ez[e]; }
+          pend_p = pb;
+        } else {
+          stv_h<V, (HINT & 1) != 0>(b.ey + pb + i0, ey);
+          stv_h<V, (HINT & 1) != 0>(b.ez + pb + i0, ez);
+        }
+        stv_h<V, (HINT & 1) != 0>(b.ex + pb + i0, ex);
+      } else if constexpr ((HINT & 256) != 0) {
 #pragma unroll
         for (int e = 0; e < V; ++e) { pend_ex[e] = ex[e]; pend_ey[e] = ey[e]; pend_ez[e] = ez[e]; }
         pend_p = pb;
@@ -1060,6 +1211,18 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
       stv_h<V, (HINT & 1) != 0>(b.ex + pend_p + i0, pend_ex);
       stv_h<V, (HINT & 1) != 0>(b.ey + pend_p + i0, pend_ey);
       stv_h<V, (HINT & 1) != 0>(b.ez + pend_p + i0, pend_ez);
+    }
+  }
+  if constexpr (XP) {                     // the last plane's x terms
+    __syncthreads();
+    if (act && !halo && sx >= 0 && k1 > k0) {
+      const int kl = (k1 - 1 - k0) & 1;
+      const float4 dy = *reinterpret_cast<const float4*>(xde + ((kl * 2 + 0) * (R + 1) + ty) * kXpCells + xp_m0);
+      const float4 dz = *reinterpret_cast<const float4*>(xde + ((kl * 2 + 1) * (R + 1) + ty) * kXpCells + xp_m0);
+      pend_ey[0] -= dy.x; pend_ey[1] -= dy.y; pend_ey[2] -= dy.z; pend_ey[3] -= dy.w;
+      pend_ez[0] += dz.x; pend_ez[1] += dz.y; pend_ez[2] += dz.z; pend_ez[3] += dz.w;
+      stv<V>(b.ey + pend_p + i0, pend_ey);
+      stv<V>(b.ez + pend_p + i0, pend_ez);
     }
   }
 }
