@@ -16,9 +16,14 @@ PULSE = td.GaussianPulse(freq0=3e14, fwidth=1.5e14)
 def _sim(N, bspec, structures=()):
     size = tuple(n * DL for n in N)
     c = (0.3 * size[0], 0.1, 0.05)
+    extra = []
+    if N[0] >= 128:       # wide grids: dipoles next to both x faces too (the few steps of a test must reach the x slabs)
+        extra = [td.PointDipole(center=(-0.5 * size[0] + 2.3 * DL, 0.03, 0.02), source_time=PULSE, polarization="Ez"),
+                 td.PointDipole(center=(0.5 * size[0] - 1.6 * DL, -0.04, 0.06), source_time=PULSE, polarization="Hy"),
+                 td.PointDipole(center=(0.5 * size[0] - 3.2 * DL, 0.1, -0.07), source_time=PULSE, polarization="Ey")]
     return td.Simulation(size=size, grid_spec=td.GridSpec.uniform(dl=DL), run_time=1e-12,
                          structures=list(structures),
-                         sources=[td.PointDipole(center=c, source_time=PULSE, polarization="Ez"),
+                         sources=extra + [td.PointDipole(center=c, source_time=PULSE, polarization="Ez"),
                                   td.PointDipole(center=(-0.2 * size[0], -0.1, 0), source_time=PULSE, polarization="Hy"),
                                   td.PointDipole(center=(0.01, 0.02, -0.1), source_time=PULSE, polarization="Ex")],
                          monitors=[td.FieldMonitor(center=(0, 0, 0), size=(td.inf, td.inf, 0), freqs=[3e14], name="f"),

@@ -283,11 +283,15 @@ def test_config4_mie_sphere_512_cube(hip_lib):
     # at most 0.3 %, the series matches every point to 1 %.
     np.testing.assert_allclose(got, ana, rtol=0.035)
     assert np.sum(np.abs(got / ana - 1) < 0.011) >= 4
-    shifts = np.linspace(-0.003, 0.003, 25)
-    best = [min(abs(got[i] / mie_cross_sections(r, eps, [f * (1 + sh)])[1][0] - 1) for sh in shifts)
-            for i, f in enumerate(freqs)]
-    print("[mie 512^3] best agreement within a +-0.3 % frequency shift:", np.round(best, 4))
-    assert max(best) < 0.01
+    # No fitted parameter (the earlier version let each of the five points pick its own best of 25
+    # frequency shifts).  What a single physical parameter can and cannot explain was checked on the measured values
+    # (profiles/r3c_mie_residual.txt): the shift the Yee dispersion relation predicts for the sphere's resonances,
+    #   delta(f) = (n k0 dl)^2 / 24 (3/5 - (c dt / (n dl))^2) = 0.09 ... 0.16 %,
+    # moves the 0.95 f0 point the WRONG way (0.968 -> 0.963), and no common frequency shift or radius scale brings all
+    # five within 1 % (best: radius x 0.9995, worst point 2.5 %): the residue is the staircase / sub-pixel representation
+    # of the curved interface acting on a resonance flank, not dispersion.  So the unshifted numbers are the statement:
+    # worst point 3.5 %, four of five within 1.1 %, mean deviation below 1.5 %.
+    assert np.mean(np.abs(got / ana - 1)) < 0.015
 
 
 def test_config3_si_strip_waveguide_mode_launch(hip_lib):
@@ -400,6 +404,46 @@ def test_config5_au_nanoparticle_array_1024x1024x256(hip_lib):
     # 16 periods along x: the line scan repeats every 64 cells
     per = line[:1024].reshape(16, 64)
     assert np.max(np.abs(per - per[0])) < 2e-3 * np.max(np.abs(per))
+
+
+def test_config5_stack_au_film_vs_airy(hip_lib):
+    """The quantitative pin of BASELINE config[4]'s physics: the same stack — vacuum, 40 nm of
+    Johnson & Christy Au (5 pole pairs: the ADE kernel), glass half-space running into the CPML, plane wave from above,
+    flux planes at the same places — with a continuous film instead of the discs, whose reflectance and transmittance
+    are the Airy formula with ``PoleResidue.eps_model(f)`` (ref medium.py:2900-2913).  Periodic 16 x 16 x 256 cells on the
+    GPU; tolerance 0.5 % of the incident power (dl = 5 nm: the film is 8 cells, interfaces on grid planes; measured
+    with the fp64 oracle: |dR| <= 0.003, |dT| <= 0.002)."""
+    from cases import gold_johnson_christy
+    from tidy3d_amd.analytic import thin_film_RT
+    from tidy3d_amd.data import assemble
+    au = gold_johnson_christy()
+    dl, nxy, nz, d = 0.005, 16, 256 - 24, 0.04
+    L, Lz = nxy * dl, nz * dl
+    freqs = np.array([4.2e14, 4.6e14, 5.0e14, 5.4e14, 5.8e14])
+    pulse = td.GaussianPulse(freq0=5e14, fwidth=1e14)
+    plane = (td.inf, td.inf, 0)
+    sim = td.Simulation(
+        size=(L, L, Lz), grid_spec=td.GridSpec.uniform(dl=dl), run_time=1.2e-13,
+        structures=[td.Structure(geometry=td.Box(center=(0, 0, -Lz / 4 - d / 2 - Lz), size=(td.inf, td.inf, Lz / 2 + 2 * Lz)),
+                                 medium=td.Medium(permittivity=2.1)),
+                    td.Structure(geometry=td.Box(center=(0, 0, 0), size=(td.inf, td.inf, d)), medium=au)],
+        sources=[td.PlaneWave(center=(0, 0, Lz / 2 - 0.1), size=plane, source_time=pulse, direction="-")],
+        monitors=[td.FluxMonitor(center=(0, 0, Lz / 2 - 0.05), size=plane, freqs=list(freqs), name="R"),
+                  td.FluxMonitor(center=(0, 0, -Lz / 2 + 0.1), size=plane, freqs=list(freqs), name="T")],
+        boundary_spec=td.BoundarySpec(x=td.Boundary.periodic(), y=td.Boundary.periodic(), z=td.Boundary.pml()), shutoff=1e-5)
+    disc = discretize(sim)
+    assert disc.spec.shape == (16, 16, 256)
+    with HipEngine(disc.spec, lib=hip_lib) as e:
+        st = e.run()
+        raw = e.results()
+    sd = assemble(disc, raw, log="")
+    R = sd["R"].flux.values / (L * L)
+    T = -sd["T"].flux.values / (L * L)
+    Ra, Ta = thin_film_RT(au.eps_model(freqs), d, 2.1, freqs)
+    print(f"\n[config5 film] R={np.round(R, 4)} Airy {np.round(Ra, 4)}  T={np.round(T, 4)} Airy {np.round(Ta, 4)}")
+    assert not st.diverged
+    assert np.max(np.abs(R - Ra)) < 0.005 and np.max(np.abs(T - Ta)) < 0.005
+    assert np.all(1 - R - T > 0.02)                       # the film absorbs: A = 0.04 ... 0.34 over the band
 
 
 @pytest.mark.gpu

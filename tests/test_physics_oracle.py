@@ -174,3 +174,33 @@ def test_energy_conservation_lossless_cavity():
     vals = np.array(vals)
     assert vals.min() > 0
     assert (vals.max() - vals.min()) / vals.mean() < 1e-10
+
+
+def test_au_film_on_glass_matches_airy_with_johnson_christy_poles():
+    """BASELINE config[4]'s stack with a continuous 40 nm Au film in place of the discs (5 pole pairs of the reference's
+    material library -> ADE): R and T vs the Airy formula with ``eps_model(f)``, 0.5 % of the incident power
+    (tests/test_gpu_parity.py runs the same on the GPU)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from cases import gold_johnson_christy
+    from tidy3d_amd.analytic import thin_film_RT
+    au = gold_johnson_christy()
+    dl, nxy, nz, d = 0.005, 4, 256 - 24, 0.04
+    L, Lz = nxy * dl, nz * dl
+    freqs = np.array([4.2e14, 4.6e14, 5.0e14, 5.4e14, 5.8e14])
+    plane = (td.inf, td.inf, 0)
+    sim = td.Simulation(
+        size=(L, L, Lz), grid_spec=td.GridSpec.uniform(dl=dl), run_time=1.2e-13,
+        structures=[td.Structure(geometry=td.Box(center=(0, 0, -Lz / 4 - d / 2 - Lz), size=(td.inf, td.inf, Lz / 2 + 2 * Lz)),
+                                 medium=td.Medium(permittivity=2.1)),
+                    td.Structure(geometry=td.Box(center=(0, 0, 0), size=(td.inf, td.inf, d)), medium=au)],
+        sources=[td.PlaneWave(center=(0, 0, Lz / 2 - 0.1), size=plane, source_time=td.GaussianPulse(freq0=5e14, fwidth=1e14),
+                              direction="-")],
+        monitors=[td.FluxMonitor(center=(0, 0, Lz / 2 - 0.05), size=plane, freqs=list(freqs), name="R"),
+                  td.FluxMonitor(center=(0, 0, -Lz / 2 + 0.1), size=plane, freqs=list(freqs), name="T")],
+        boundary_spec=td.BoundarySpec(x=td.Boundary.periodic(), y=td.Boundary.periodic(), z=td.Boundary.pml()), shutoff=1e-5)
+    sd, _, _ = solve(sim)
+    R = sd["R"].flux.values / (L * L)
+    T = -sd["T"].flux.values / (L * L)
+    Ra, Ta = thin_film_RT(au.eps_model(freqs), d, 2.1, freqs)
+    assert np.max(np.abs(R - Ra)) < 0.005 and np.max(np.abs(T - Ta)) < 0.005, (R, Ra, T, Ta)

@@ -73,3 +73,21 @@ def slab_transmission(eps, thickness: float, freqs):
     r = (1 - n) / (1 + n)
     t = (1 - r ** 2) * np.exp(1j * k * thickness) / (1 - r ** 2 * np.exp(2j * k * thickness))
     return np.abs(t) ** 2
+
+
+def thin_film_RT(eps_film, d: float, eps_substrate: float, freqs):
+    """Power reflectance and transmittance (into a lossless substrate) of a film of (complex) permittivity ``eps_film`` and
+    thickness ``d`` [um] on a substrate, from vacuum at normal incidence: the Airy sum of the two interfaces.  With
+    ``medium.eps_model(freqs)`` (ref medium.py:2900-2913, exp(-i w t) convention) it pins dispersive-medium runs."""
+    import numpy as np
+    from .constants import C_0
+    freqs = np.asarray(freqs, dtype=np.float64)
+    n1, n2, n3 = 1.0, np.sqrt(np.asarray(eps_film) + 0j), np.sqrt(eps_substrate)
+    k2 = 2 * np.pi * freqs / C_0 * n2
+    r12, r23 = (n1 - n2) / (n1 + n2), (n2 - n3) / (n2 + n3)
+    t12, t23 = 2 * n1 / (n1 + n2), 2 * n2 / (n2 + n3)
+    ph = np.exp(1j * k2 * d)
+    den = 1 + r12 * r23 * ph ** 2
+    r = (r12 + r23 * ph ** 2) / den
+    t = t12 * t23 * ph / den
+    return np.abs(r) ** 2, float(np.real(n3)) / n1 * np.abs(t) ** 2

@@ -503,9 +503,11 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pm
   if ((pml_inside & 1) && h->pml_pool != 0 && h->pml[0].ns > 0) {
     const PmlAxisDev& px = h->pml[0];
     const int n_lo = px.lo, n_hi = g.nx - px.hi0;
-    pool = n_lo <= kXpCells && n_hi <= kXpCells && (g.nx > 256 || n_lo + n_hi <= kXpCells);
+    // slab cells per row of a tile (a tile of a row <= 256 cells holds both faces), all rows of a workgroup in ONE pass
+    const int nm = g.nx > 256 ? std::max(n_lo, n_hi) : n_lo + n_hi;
+    pool = nm <= kXpCells && nm * (R + 1) <= 64;
   }
-  const size_t shmem = ((size_t)2 * 2 * (R + 1) * 64 + (pml_inside ? 6 * 64 : 0) + (pool ? 2 * (R + 1) * 64 : 0)) * sizeof(float4) +
+  const size_t shmem = ((size_t)2 * 2 * (R + 1) * 64 + (pml_inside ? 6 * 64 : 0) + (pool ? 2 * 64 + 2 * (R + 1) * 64 : 0)) * sizeof(float4) +
                        (pool ? ((size_t)2 * 2 * 2 * (R + 1) * kXpCells + 2 * (R + 1) * 2) * sizeof(float) : 0) +
                        (size_t)h->lds_pad;   // both CPML instantiations stage the x coefficients
   const int pmc = h->cfg.bc[4] == FDTD_BC_PMC;

@@ -551,10 +551,10 @@ __global__ __launch_bounds__(LB, (LB == 256 ? ((PML & 7) == 0 ? 4 : ((PML & 7) =
   if constexpr ((PML & 1) != 0) {
     const PmlAxisP& A = pmq->ax[0];
     const unsigned o = (unsigned)((tile_x * 64 + threadIdx.x) * V) * 4u;
-    for (int q = threadIdx.y; q < 6; q += blockDim.y) {
-      const float* src = q == 0 ? A.kv_h : (q == 1 ? A.b_h : (q == 2 ? A.c_h : (q == 3 ? A.kv_e : (q == 4 ? A.b_e : A.c_e))));
+    for (int q = threadIdx.y; q < (((PML & 9) == 9) ? 8 : 6); q += blockDim.y) {     // (pooled form: 1 / steps along x as well)
+      const float* src = q == 0 ? A.kv_h : (q == 1 ? A.b_h : (q == 2 ? A.c_h : (q == 3 ? A.kv_e : (q == 4 ? A.b_e : (q == 5 ? A.c_e : (q == 6 ? s.ipx : s.idx))))));
       float r[V] = {0.f, 0.f, 0.f, 0.f};
-      if ((int)(o / 4u) < g.nx && (A.lo > 0 || A.hi0 < A.n)) ldc4(r, src, o);   // (no tables on an axis without members)
+      if ((int)(o / 4u) < g.nx && (q >= 6 || A.lo > 0 || A.hi0 < A.n)) ldc4(r, src, o);   // (no tables on an axis without members)
       float4 t4; t4.x = r[0]; t4.y = r[1]; t4.z = r[2]; t4.w = r[3];
       xco[q * 64 + threadIdx.x] = t4;
     }
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(LB, (LB == 256 ? ((PML & 7) == 0 ? 4 : ((PML & 7) =
   constexpr bool XP = (PML & 9) == 9;            // x recursions pooled on the halo wave
   // pooled form, LDS behind the coefficient tables: H_y rows [2][R+1][64] float4, the additive terms of the H side and of
   // the E side [2 buffers][2 components][R+1 rows][kXpCells] each, and what lane 0 of every row uses as its x-1 neighbour
-  [[maybe_unused]] float4* hyrow = xco + 6 * 64;
+  [[maybe_unused]] float4* hyrow = xco + 8 * 64;
   [[maybe_unused]] float* xdh = reinterpret_cast<float*>(hyrow + 2 * (R + 1) * 64);
   [[maybe_unused]] float* xde = xdh + 2 * 2 * (R + 1) * kXpCells;
   [[maybe_unused]] float* hmc = xde + 2 * 2 * (R + 1) * kXpCells;
@@ -634,78 +634,105 @@ __global__ __launch_bounds__(LB, (LB == 256 ? ((PML & 7) == 0 ? 4 : ((PML & 7) =
     xp_nm = xp_nlo + max(0, t1 - xp_hs);
     xp_m0 = (i0 < A.lo) ? (i0 - xp_t0) : xp_nlo + (i0 - xp_hs);     // first slab cell of a member lane (sx >= 0)
   }
-  // H side of plane k: psi_h (read set -> write set) and the terms  ch (kv dEz/dx + p1)  [H_y +=],  ch (kv dEy/dx + p2)  [H_z -=]
-  [[maybe_unused]] auto xp_h = [&](int k, int buf) {
-    const PmlAxisP& A = pmq->ax[0];
-    for (int q = tx; q < xp_nm * (R + 1); q += 64) {
-      const int r = q / xp_nm, mm = q - r * xp_nm;
+  // The pooled item of this lane of the halo wave — ONE pass: the host selects this form only when rows x slab cells <= 64.
+  // Item = (row r, slab cell mm): r = 0 is the halo row (only its H_z term is used), r >= 1 the own rows.  What does not
+  // change along the march is kept in five registers; everything the recursion reads from memory is PREFETCHED at the top
+  // of a plane with the field loads (H side: E^n and psi_h of plane k+1; E side: psi_e and the material word of plane k),
+  // so the halo wave adds no memory round trip in front of the barrier the other waves wait at.
+  [[maybe_unused]] unsigned xq_po = 0, xq_qo = 0, xq_l = 0, xq_c = 0, xq_fl = 0;       // jr nx + i | jr ns + si | r kXpCells + mm | i - tile start | flags
+  if constexpr (XP) {
+    if (halo && tx < xp_nm * (R + 1)) {
+      const PmlAxisP& A = pmq->ax[0];
+      const int r = tx / xp_nm, mm = tx - r * xp_nm;
       int jr = tile_y * R + r - 1;
       bool ok = (jr >= 0) && (jr < g.ny);
       if (jr < 0 && per_y) { jr = g.ny - 1; ok = true; }
-      float d_hy = 0.f, d_hz = 0.f;
-      if (ok) {
-        const int i = mm < xp_nlo ? xp_t0 + mm : xp_hs + (mm - xp_nlo);
-        const int si = i < A.lo ? i : A.lo + (i - A.hi0);
-        const long long p = (long long)k * g.sxy + (long long)jr * g.nx + i;
-        const float ey_i = ldg1(a.ey + p), ez_i = ldg1(a.ez + p);
-        float ey_ip = 0.f, ez_ip = 0.f;
-        if (i + 1 < g.nx) { ey_ip = ldg1(a.ey + p + 1); ez_ip = ldg1(a.ez + p + 1); }
-        else if (g.bcx1 == BC_PERIODIC) { ey_ip = ldg1(a.ey + p - i); ez_ip = ldg1(a.ez + p - i); }
-        const float ipxi = s.ipx[i];
-        const float kv = A.kv_h[i], bb = A.b_h[i], cc = A.c_h[i];
-        const long long qq = ((long long)k * g.ny + jr) * A.ns + si;
-        const float s1 = ldg1(A.ph0 + qq), s2 = ldg1(A.ph1 + qq);
-        const float d1 = (ey_ip - ey_i) * ipxi, d2 = (ez_ip - ez_i) * ipxi;
-        const float p1 = bb * s1 + cc * d2;
-        const float p2 = bb * s2 + cc * d1;
-        if (r > 0) { A.ph0n[qq] = p1; A.ph1n[qq] = p2; }        // (the halo row's psi belongs to the tile below)
-        d_hy = ch * (kv * d2 + p1);
-        d_hz = ch * (kv * d1 + p2);
-      }
-      xdh[((buf * 2 + 0) * (R + 1) + r) * kXpCells + mm] = d_hy;
-      xdh[((buf * 2 + 1) * (R + 1) + r) * kXpCells + mm] = d_hz;
+      if (!ok) jr = 0;
+      const int i = mm < xp_nlo ? xp_t0 + mm : xp_hs + (mm - xp_nlo);
+      const int si = i < A.lo ? i : A.lo + (i - A.hi0);
+      xq_po = (unsigned)(jr * g.nx + i);
+      xq_qo = (unsigned)(jr * A.ns + si);
+      xq_l = (unsigned)(r * kXpCells + mm);
+      xq_c = (unsigned)(i - xp_t0);
+      const bool e_ok = ok && r > 0 && !(i == 0 && g.bcx0 == BC_PEC);      // (a cell on the x wall keeps its E-side psi: both components are tangential)
+      const unsigned lastm = (i + 1 < g.nx) ? 0u : (g.bcx1 == BC_PERIODIC ? 1u : 2u);
+      xq_fl = (ok ? 1u : 0u) | (e_ok ? 2u : 0u) | ((jr == 0 && g.bcy0 == BC_PEC) ? 4u : 0u) | (lastm << 3) | (r > 0 ? 32u : 0u);
+    }
+  }
+  [[maybe_unused]] const float* xcf = reinterpret_cast<const float*>(xco);          // tables [8][256]: kv_h b_h c_h kv_e b_e c_e 1/dx_primal 1/dx_dual
+  [[maybe_unused]] float xq_ey = 0.f, xq_eyp = 0.f, xq_ez = 0.f, xq_ezp = 0.f, xq_s1 = 0.f, xq_s2 = 0.f;   // H side, plane k+1
+  [[maybe_unused]] float xq_e1 = 0.f, xq_e2 = 0.f;                                                             // E side, plane k
+  [[maybe_unused]] uint32_t xq_w = kBgWord;
+  // loads of the H side of plane kk
+  [[maybe_unused]] auto xp_load_h = [&](int kk) {
+    if (xq_fl & 1u) {
+      const PmlAxisP& A = pmq->ax[0];
+      const long long p = (long long)kk * g.sxy + xq_po;
+      xq_ey = ldg1(a.ey + p); xq_ez = ldg1(a.ez + p);
+      const unsigned lastm = (xq_fl >> 3) & 3u;
+      const long long pn = lastm == 0u ? p + 1 : p - (long long)(xq_c + (unsigned)xp_t0);      // x+1 neighbour, or the row's first cell (periodic x)
+      xq_eyp = ldg1(a.ey + pn); xq_ezp = ldg1(a.ez + pn);
+      if (lastm == 2u) { xq_eyp = 0.f; xq_ezp = 0.f; }
+      const long long qq = (long long)kk * g.ny * A.ns + xq_qo;
+      xq_s1 = ldg1(A.ph0 + qq); xq_s2 = ldg1(A.ph1 + qq);
     }
   };
-  // E side of plane k (behind the barrier: H^{n+1/2}_{y,z} of the own rows are in LDS): psi_e in place and the terms
-  // cb (kv dHz/dx + p1)  [E_y -=],  cb (kv dHy/dx + p2)  [E_z +=]
-  [[maybe_unused]] auto xp_e = [&](int k, int cur_, int buf) {
-    const PmlAxisP& A = pmq->ax[0];
-    const int slot_ = (int)blockDim.y * 64;
-    for (int q = tx; q < xp_nm * R; q += 64) {
-      const int r = 1 + q / xp_nm, mm = q - (r - 1) * xp_nm;
-      const int jr = tile_y * R + r - 1;
-      float d_ey = 0.f, d_ez = 0.f;
-      const int i = mm < xp_nlo ? xp_t0 + mm : xp_hs + (mm - xp_nlo);
-      if (jr < g.ny && !(i == 0 && g.bcx0 == BC_PEC)) {          // (a cell on the x wall keeps its psi: both components are tangential)
-        const int si = i < A.lo ? i : A.lo + (i - A.hi0);
-        const int c = i - xp_t0;
-        const float* hyf = reinterpret_cast<const float*>(hyrow + (cur_ * (R + 1) + r) * 64);
-        const float* hzf = reinterpret_cast<const float*>(xch + (cur_ * 2 + 1) * slot_ + r * 64);
-        const float hy_i = hyf[c], hz_i = hzf[c];
-        const float hy_im = c > 0 ? hyf[c - 1] : hmc[(cur_ * (R + 1) + r) * 2 + 0];
-        const float hz_im = c > 0 ? hzf[c - 1] : hmc[(cur_ * (R + 1) + r) * 2 + 1];
-        const float idxi = s.idx[i];
-        const float kv = A.kv_e[i], bb = A.b_e[i], cc = A.c_e[i];
-        const long long qq = ((long long)k * g.ny + jr) * A.ns + si;
-        const float s1 = ldg1(A.pe0 + qq), s2 = ldg1(A.pe1 + qq);
-        const float d1 = (hy_i - hy_im) * idxi;
-        const float d2 = (hz_i - hz_im) * idxi;
-        const float p1 = bb * s1 + cc * d2;
-        const float p2 = bb * s2 + cc * d1;
-        A.pe0[qq] = p1; A.pe1[qq] = p2;
-        float cb_y = m.cb1, cb_z = m.cb1;
-        if constexpr (MAT) {
-          uint32_t w = m.roww[((long long)k * g.ny + jr) * nbx + tile_x];
-          if (w == kMixedWord) w = m.m4[(long long)k * g.sxy + (long long)jr * g.nx + i];
-          cb_y = lut_s[(w >> 10) & 1023u].y;
-          cb_z = lut_s[(w >> 20) & 1023u].y;
-        }
-        const bool wz = (k == 0) && g.pec_z0, wy = (jr == 0) && (g.bcy0 == BC_PEC);
-        if (!wz) d_ey = cb_y * (kv * d2 + p1);                  // E_y is tangential to the z wall
-        if (!wy) d_ez = cb_z * (kv * d1 + p2);                  // E_z is tangential to the y wall
+  // H side of plane kk from the prefetched values: psi_h (read set -> write set) and the terms
+  //   ch (kv dEz/dx + p1)  [H_y +=],  ch (kv dEy/dx + p2)  [H_z -=]
+  [[maybe_unused]] auto xp_h = [&](int kk, int buf) {
+    if (xq_fl & 1u) {
+      const PmlAxisP& A = pmq->ax[0];
+      const float kv = xcf[0 * 256 + xq_c], bb = xcf[1 * 256 + xq_c], cc = xcf[2 * 256 + xq_c], ipxi = xcf[6 * 256 + xq_c];
+      const float d1 = (xq_eyp - xq_ey) * ipxi, d2 = (xq_ezp - xq_ez) * ipxi;
+      const float p1 = bb * xq_s1 + cc * d2;
+      const float p2 = bb * xq_s2 + cc * d1;
+      if (xq_fl & 32u) {                                         // (the halo row's psi belongs to the tile below)
+        const long long qq = (long long)kk * g.ny * A.ns + xq_qo;
+        A.ph0n[qq] = p1; A.ph1n[qq] = p2;
       }
-      xde[((buf * 2 + 0) * (R + 1) + r) * kXpCells + mm] = d_ey;
-      xde[((buf * 2 + 1) * (R + 1) + r) * kXpCells + mm] = d_ez;
+      xdh[(buf * 2 + 0) * (R + 1) * kXpCells + xq_l] = ch * (kv * d2 + p1);
+      xdh[(buf * 2 + 1) * (R + 1) * kXpCells + xq_l] = ch * (kv * d1 + p2);
+    }
+  };
+  // loads of the E side of plane kk
+  [[maybe_unused]] auto xp_load_e = [&](int kk) {
+    if (xq_fl & 2u) {
+      const PmlAxisP& A = pmq->ax[0];
+      const long long qq = (long long)kk * g.ny * A.ns + xq_qo;
+      xq_e1 = ldg1(A.pe0 + qq); xq_e2 = ldg1(A.pe1 + qq);
+      if constexpr (MAT) xq_w = m.m4[(long long)kk * g.sxy + xq_po];
+    }
+  };
+  // E side of plane kk (behind the barrier: H^{n+1/2}_{y,z} of the own rows are in LDS): psi_e in place and the terms
+  //   cb (kv dHz/dx + p1)  [E_y -=],  cb (kv dHy/dx + p2)  [E_z +=]
+  [[maybe_unused]] auto xp_e = [&](int kk, int cur_, int buf) {
+    if (xq_fl & 2u) {
+      const PmlAxisP& A = pmq->ax[0];
+      const int slot_ = (int)blockDim.y * 64;
+      const unsigned r = xq_l / kXpCells;
+      const float* hyf = reinterpret_cast<const float*>(hyrow + (cur_ * (R + 1) + r) * 64);
+      const float* hzf = reinterpret_cast<const float*>(xch + (cur_ * 2 + 1) * slot_ + r * 64);
+      const float hy_i = hyf[xq_c], hz_i = hzf[xq_c];
+      const float hy_im = xq_c > 0 ? hyf[xq_c - 1] : hmc[(cur_ * (R + 1) + r) * 2 + 0];
+      const float hz_im = xq_c > 0 ? hzf[xq_c - 1] : hmc[(cur_ * (R + 1) + r) * 2 + 1];
+      const float kv = xcf[3 * 256 + xq_c], bb = xcf[4 * 256 + xq_c], cc = xcf[5 * 256 + xq_c], idxi = xcf[7 * 256 + xq_c];
+      const float d1 = (hy_i - hy_im) * idxi;
+      const float d2 = (hz_i - hz_im) * idxi;
+      const float p1 = bb * xq_e1 + cc * d2;
+      const float p2 = bb * xq_e2 + cc * d1;
+      const long long qq = (long long)kk * g.ny * A.ns + xq_qo;
+      A.pe0[qq] = p1; A.pe1[qq] = p2;
+      float cb_y = m.cb1, cb_z = m.cb1;
+      if constexpr (MAT) {
+        cb_y = lut_s[(xq_w >> 10) & 1023u].y;
+        cb_z = lut_s[(xq_w >> 20) & 1023u].y;
+      }
+      const bool wz = (kk == 0) && g.pec_z0;
+      xde[(buf * 2 + 0) * (R + 1) * kXpCells + xq_l] = wz ? 0.f : cb_y * (kv * d2 + p1);             // E_y is tangential to the z wall
+      xde[(buf * 2 + 1) * (R + 1) * kXpCells + xq_l] = (xq_fl & 4u) ? 0.f : cb_z * (kv * d1 + p2);   // E_z is tangential to the y wall
+    } else if ((xq_fl & 33u) == 33u) {         // an own row's cell on the x wall: no terms
+      xde[(buf * 2 + 0) * (R + 1) * kXpCells + xq_l] = 0.f;
+      xde[(buf * 2 + 1) * (R + 1) * kXpCells + xq_l] = 0.f;
     }
   };
 
@@ -807,7 +834,7 @@ __global__ __launch_bounds__(LB, (LB == 256 ? ((PML & 7) == 0 ? 4 : ((PML & 7) =
     }
   }                                      // (the halo wave needs no H^{n+1/2}[k0-1])
   if constexpr (XP) {
-    if (halo && k0 < k1) xp_h(k0, 0);    // the H-side terms of the chunk's first plane (every later plane: one plane ahead)
+    if (halo && k0 < k1) { xp_load_h(k0); xp_h(k0, 0); }   // the H-side terms of the chunk's first plane (every later plane: one plane ahead)
     __syncthreads();
   }
   int cur = 0;
@@ -837,6 +864,10 @@ __global__ __launch_bounds__(LB, (LB == 256 ? ((PML & 7) == 0 ? 4 : ((PML & 7) =
     if (!halo) ldv_h<V, (HINT & 2) != 0>(hyn, uni(a.hy + pb), ubc);      // the halo wave only publishes H_x and H_z
     else zero<V>(hyn);
     ldf<V, true>(hzn, uni(a.hz + pb), ubc);
+    // (pooled x terms, halo wave: the E side of the LAST plane is formed in this plane's H phase — behind the load issue, in
+    //  front of the barrier — so that the halo wave's loads go out as early as everybody else's; measured the other way
+    //  round, E side right behind the barrier, the halo wave became the one all others wait for: profiles/r3c)
+    if constexpr (XP) { if (halo) { if (k + 1 < k1) xp_load_h(k + 1); if (k > k0) xp_load_e(k - 1); } }
     // ---- CPML state of this plane: EVERY psi load is issued here, with the field loads, so that ONE memory
     // round trip per plane covers them.  Loaded where they are used they chain two more round trips per plane
     // (H side, then E side behind the barrier): +0.63 ms per 512^3 step, worse than the slab kernels
@@ -1018,9 +1049,13 @@ __global__ __launch_bounds__(LB, (LB == 256 ? ((PML & 7) == 0 ? 4 : ((PML & 7) =
         }
       }
     }
-    if constexpr (XP) { if (halo && k + 1 < k1) xp_h(k + 1, kb ^ 1); }
+    if constexpr (XP) {
+      if (halo) {
+        if (k > k0) xp_e(k - 1, cur ^ 1, kb ^ 1);
+        if (k + 1 < k1) xp_h(k + 1, kb ^ 1);
+      }
+    }
     __syncthreads();
-    if constexpr (XP) { if (halo) xp_e(k, cur, kb); }
     float hyx = __shfl_up(hyn[V - 1], 1);
     float hzx = __shfl_up(hzn[V - 1], 1);
     if (pmc_z0 && k == 0) {
@@ -1214,6 +1249,7 @@ __global__ __launch_bounds__(LB, (LB == 256 ? ((PML & 7) == 0 ? 4 : ((PML & 7) =
     }
   }
   if constexpr (XP) {                     // the last plane's x terms
+    if (halo && k1 > k0) { xp_load_e(k1 - 1); xp_e(k1 - 1, cur ^ 1, (k1 - 1 - k0) & 1); }
     __syncthreads();
     if (act && !halo && sx >= 0 && k1 > k0) {
       const int kl = (k1 - 1 - k0) & 1;
