@@ -230,6 +230,7 @@ def main():
                     "0 = single steps, -1 = library default)")
     ap.add_argument("--placement-tries", type=int, default=-1, help="FDTD_OPT_PLACEMENT_TRIES (0 = keep the first allocations: profiling "
                     "runs, so that the kernel statistics hold the timed sweeps only)")
+    ap.add_argument("--opt", action="append", default=[], help="extra engine option NAME=VALUE (tidy3d_amd.lib.OPT_*), e.g. OPT_PML_POOL=0; repeatable")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--no-workloads", action="store_true", help="skip the secondary V2 (materials + CPML) measurement")
@@ -285,6 +286,9 @@ def main():
         eng.set_option(L.OPT_TBLOCK, args.tblock)
     if args.placement_tries >= 0:
         eng.set_option(L.OPT_PLACEMENT_TRIES, args.placement_tries)
+    for kv in args.opt:
+        name, val = kv.split("=")
+        eng.set_option(getattr(L, name), int(val))
     if world > 1:
         uid = [eng.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)

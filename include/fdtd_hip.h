@@ -226,9 +226,6 @@ enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_R
                                 the grid, slab by slab (slab s+1 takes step n, then slab s takes step n+1 while the
                                 intermediate planes are still in the 256 MiB Infinity Cache): planes per slab; 0 = off,
                                 -1 = default */
-       FDTD_OPT_PML_POOL = 14, /* in-sweep CPML: the x recursions of a workgroup's rows pooled on its halo wave (one slab cell per
-                                  lane, terms handed over through LDS) instead of four cells per lane on every wave: -1 = default
-                                  (pooled where the x slabs are at most 64 cells per face), 0 = per lane, 1 = pooled */
        FDTD_OPT_LDS_PAD = 10 /* measuring aid: extra dynamic LDS per workgroup of the sweep in bytes (lowers its occupancy) */ };
 int fdtd_set_option(FdtdSolver* h, int key, int value);
 int fdtd_reset(FdtdSolver* h);      /* zero fields, auxiliaries, monitors and the step counter */

@@ -175,7 +175,6 @@ struct FdtdSolver {
   bool streams_shared = false;       // comm_stream is an alias of stream (fallback)
   // slab-interleaved two-step schedule (fdtd_run): planes per slab; 0 = off, -1 = default
   int tblock = -1;
-  int pml_pool = -1;                 // x recursions of the in-sweep CPML pooled on the halo wave: -1 = default (on where the slabs fit), 0, 1
   long long two_step_pairs = 0;
   int tblock_used = 0;
 };
@@ -498,18 +497,7 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pm
   // Runs of 6 ... 32 tiles are within 0.5 % of each other.
   const int remap = h->xcd_remap < 0 ? kTileRun : h->xcd_remap;
   dim3 grid(remap ? ((total + 7) / 8) * 8 : total, 1, 1);
-  // x recursions pooled on the halo wave (fdtd_kernels.hpp, PML bit 3): when the x slabs of every tile fit the pool
-  bool pool = false;
-  if ((pml_inside & 1) && h->pml_pool != 0 && h->pml[0].ns > 0) {
-    const PmlAxisDev& px = h->pml[0];
-    const int n_lo = px.lo, n_hi = g.nx - px.hi0;
-    // slab cells per row of a tile (a tile of a row <= 256 cells holds both faces), all rows of a workgroup in ONE pass
-    const int nm = g.nx > 256 ? std::max(n_lo, n_hi) : n_lo + n_hi;
-    pool = nm <= kXpCells && nm * (R + 1) <= 64;
-  }
-  const size_t shmem = ((size_t)2 * 2 * (R + 1) * 64 + (pml_inside ? 6 * 64 : 0) + (pool ? 2 * 64 + 2 * (R + 1) * 64 : 0)) * sizeof(float4) +
-                       (pool ? ((size_t)2 * 2 * 2 * (R + 1) * kXpCells + 2 * (R + 1) * 2) * sizeof(float) : 0) +
-                       (size_t)h->lds_pad;   // both CPML instantiations stage the x coefficients
+  const size_t shmem = ((size_t)2 * 2 * (R + 1) * 64 + (pml_inside ? 6 * 64 : 0)) * sizeof(float4) + (size_t)h->lds_pad;   // both CPML instantiations stage the x coefficients
   const int pmc = h->cfg.bc[4] == FDTD_BC_PMC;
   MatP m = mat_params(h);
   StepP s = step_params(h);
@@ -540,13 +528,7 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pm
     else if (PMLV != 0 && h->mem_hints) FDTD_LAUNCH_FUSED_H(MATV, LBV, PMLV, 128);                    \
     else FDTD_LAUNCH_FUSED_H(MATV, LBV, PMLV, 0);                                                     \
   } while (0)
-  if (pml_inside == 1 && pool) {
-    if (h->mat4) { if (lb == 256) FDTD_LAUNCH_FUSED(true, 256, 9); else FDTD_LAUNCH_FUSED(true, 512, 9); }
-    else { if (lb == 256) FDTD_LAUNCH_FUSED(false, 256, 9); else FDTD_LAUNCH_FUSED(false, 512, 9); }
-  } else if (pml_inside && pool) {
-    if (h->mat4) { if (lb == 256) FDTD_LAUNCH_FUSED(true, 256, 15); else FDTD_LAUNCH_FUSED(true, 512, 15); }
-    else { if (lb == 256) FDTD_LAUNCH_FUSED(false, 256, 15); else FDTD_LAUNCH_FUSED(false, 512, 15); }
-  } else if (pml_inside == 1) {        // x recursions only: every tile of a grid with x layers
+  if (pml_inside == 1) {        // x recursions only: every tile of a grid with x layers
     if (h->mat4) { if (lb == 256) FDTD_LAUNCH_FUSED(true, 256, 1); else FDTD_LAUNCH_FUSED(true, 512, 1); }
     else { if (lb == 256) FDTD_LAUNCH_FUSED(false, 256, 1); else FDTD_LAUNCH_FUSED(false, 512, 1); }
   } else if (pml_inside) {      // all axes (axes outside `pml_inside` have no members in the block)
@@ -2329,7 +2311,6 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_PLACEMENT_TRIES: if (value < 0 || (value % 100) > 3) break; h->placement_tries = value; h->placement_done = false; return 0;
     case FDTD_OPT_LDS_PAD: if (value < 0 || value > 120000) break; h->lds_pad = value; return 0;
     case FDTD_OPT_TBLOCK: h->tblock = value < 0 ? -1 : value; return 0;
-    case FDTD_OPT_PML_POOL: h->pml_pool = value < 0 ? -1 : (value != 0); return 0;
     case FDTD_OPT_PML_SPLIT: h->pml_split = value < 0 ? -1 : (value != 0); return 0;
     case FDTD_OPT_FUSED_LB: if (value != 0 && value != 256 && value != 512 && value != 1024) break; h->fused_lb = value; return 0;
     default: break;

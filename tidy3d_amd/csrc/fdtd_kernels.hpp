@@ -494,19 +494,8 @@ __device__ __forceinline__ void pml_h_apply(float& h1, float& h2, float d1, floa
 //     first plane of a chunk recomputes H^{n+1/2}[k0-1] in a prologue).
 // Everything that depends on the row only (threadIdx.y is wave-uniform) is kept in SGPRs.
 // =============================================================================================
-// PML bit 3 (8), with bit 0: the x recursions are POOLED on the halo wave.  Along x only the first / last few lanes of a
-// wavefront hold slab cells (12 layers = 3 of 64 lanes), but every wave pays the instructions of four cells per lane for
-// them: ~150 vector instructions per wave and plane, the reason the x axis cost 0.2 ms of a 512^3 step for 0.2 GB of psi
-// (DESIGN.md section 5).  Pooled, the slab cells of ALL rows of the workgroup (rows x 12) sit one per lane on the halo
-// wave — which has no E phase of its own — and the recursion is executed once per workgroup and plane:
-//   * H side (depends on E^n only): computed one plane AHEAD, the additive terms handed to the owner lanes through LDS
-//     (they add them where the per-lane code added them: same operations, same order, same bits);
-//   * E side: the owners publish H_y of their row next to the H_x, H_z the row exchange already carries; behind the
-//     barrier the halo wave forms the terms of plane k, the owners pick them up behind the NEXT barrier and store the
-//     E_y, E_z of their slab lanes one plane late (8 registers pending instead of 16 of psi).
-constexpr int kXpCells = 64;       // capacity: slab cells per row of a tile (the host falls back to the per-lane form beyond)
 template <bool MAT, int LB, int PML, int HINT = 0>   // PML: bit a set = CPML of axis a runs inside the sweep; HINT: bit 0 = non-temporal field stores, bit 1 = non-temporal loads of E_y, H_y (measured: +0.7 %, not instantiated), bit 3 = H stores ahead of the row exchange
-__global__ __launch_bounds__(LB, (LB == 256 ? ((PML & 7) == 0 ? 4 : ((PML & 7) == 1 ? 3 : 2)) : (LB == 512 ? (PML ? 2 : 4) : 4))) void fused_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
+__global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)) : (LB == 512 ? (PML ? 2 : 4) : 4))) void fused_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
                                                           int kbeg, int kend, int zchunk, int pmc_z0,
                                                           int nbx, int nby, int nbz, int xcd_remap,
                                                           const PmlP* __restrict__ pmq,
@@ -551,10 +540,10 @@ __global__ __launch_bounds__(LB, (LB == 256 ? ((PML & 7) == 0 ? 4 : ((PML & 7) =
   if constexpr ((PML & 1) != 0) {
     const PmlAxisP& A = pmq->ax[0];
     const unsigned o = (unsigned)((tile_x * 64 + threadIdx.x) * V) * 4u;
-    for (int q = threadIdx.y; q < (((PML & 9) == 9) ? 8 : 6); q += blockDim.y) {     // (pooled form: 1 / steps along x as well)
-      const float* src = q == 0 ? A.kv_h : (q == 1 ? A.b_h : (q == 2 ? A.c_h : (q == 3 ? A.kv_e : (q == 4 ? A.b_e : (q == 5 ? A.c_e : (q == 6 ? s.ipx : s.idx))))));
+    for (int q = threadIdx.y; q < 6; q += blockDim.y) {
+      const float* src = q == 0 ? A.kv_h : (q == 1 ? A.b_h : (q == 2 ? A.c_h : (q == 3 ? A.kv_e : (q == 4 ? A.b_e : A.c_e))));
       float r[V] = {0.f, 0.f, 0.f, 0.f};
-      if ((int)(o / 4u) < g.nx && (q >= 6 || A.lo > 0 || A.hi0 < A.n)) ldc4(r, src, o);   // (no tables on an axis without members)
+      if ((int)(o / 4u) < g.nx && (A.lo > 0 || A.hi0 < A.n)) ldc4(r, src, o);   // (no tables on an axis without members)
       float4 t4; t4.x = r[0]; t4.y = r[1]; t4.z = r[2]; t4.w = r[3];
       xco[q * 64 + threadIdx.x] = t4;
     }
@@ -563,13 +552,6 @@ __global__ __launch_bounds__(LB, (LB == 256 ? ((PML & 7) == 0 ? 4 : ((PML & 7) =
   const int tx = threadIdx.x;
   const int ty = __builtin_amdgcn_readfirstlane((int)threadIdx.y);     // one row per wave
   const int R = blockDim.y - 1;
-  constexpr bool XP = (PML & 9) == 9;            // x recursions pooled on the halo wave
-  // pooled form, LDS behind the coefficient tables: H_y rows [2][R+1][64] float4, the additive terms of the H side and of
-  // the E side [2 buffers][2 components][R+1 rows][kXpCells] each, and what lane 0 of every row uses as its x-1 neighbour
-  [[maybe_unused]] float4* hyrow = xco + 8 * 64;
-  [[maybe_unused]] float* xdh = reinterpret_cast<float*>(hyrow + 2 * (R + 1) * 64);
-  [[maybe_unused]] float* xde = xdh + 2 * 2 * (R + 1) * kXpCells;
-  [[maybe_unused]] float* hmc = xde + 2 * 2 * (R + 1) * kXpCells;
   const int i0 = (tile_x * 64 + tx) * V;
   const unsigned ux = (unsigned)i0;
   const unsigned ub = ux * 4u;            // lane's byte offset along the row: every row access is  uniform base + 32-bit lane offset
@@ -620,121 +602,6 @@ __global__ __launch_bounds__(LB, (LB == 256 ? ((PML & 7) == 0 ? 4 : ((PML & 7) =
     if (row_ok) sy = pml_si(pmq->ax[1], j);
     if (sy >= 0) { cyh = ldc_f4(pmq->ax[1].ch4 + j); cye = ldc_f4(pmq->ax[1].ce4 + j); }
   }
-
-  // ---- pooled x recursions: the slab cells of this tile, one per lane of the halo wave --------------------------
-  // slab cells of the tile: [xp_t0, xp_t0 + xp_nlo) on the low side, [xp_hs, tile end) on the high side, xp_nm in all;
-  // pooled item q = (row r, slab cell m): r = 0 is the halo row (only its H_z term is used), r >= 1 the own rows
-  [[maybe_unused]] int xp_t0 = 0, xp_nlo = 0, xp_hs = 0, xp_nm = 0, xp_m0 = 0;
-  if constexpr (XP) {
-    const PmlAxisP& A = pmq->ax[0];
-    xp_t0 = tile_x * 256;
-    const int t1 = min(xp_t0 + 256, g.nx);
-    xp_nlo = max(0, min(A.lo, t1) - xp_t0);
-    xp_hs = max(A.hi0, xp_t0);
-    xp_nm = xp_nlo + max(0, t1 - xp_hs);
-    xp_m0 = (i0 < A.lo) ? (i0 - xp_t0) : xp_nlo + (i0 - xp_hs);     // first slab cell of a member lane (sx >= 0)
-  }
-  // The pooled item of this lane of the halo wave — ONE pass: the host selects this form only when rows x slab cells <= 64.
-  // Item = (row r, slab cell mm): r = 0 is the halo row (only its H_z term is used), r >= 1 the own rows.  What does not
-  // change along the march is kept in five registers; everything the recursion reads from memory is PREFETCHED at the top
-  // of a plane with the field loads (H side: E^n and psi_h of plane k+1; E side: psi_e and the material word of plane k),
-  // so the halo wave adds no memory round trip in front of the barrier the other waves wait at.
-  [[maybe_unused]] unsigned xq_po = 0, xq_qo = 0, xq_l = 0, xq_c = 0, xq_fl = 0;       // jr nx + i | jr ns + si | r kXpCells + mm | i - tile start | flags
-  if constexpr (XP) {
-    if (halo && tx < xp_nm * (R + 1)) {
-      const PmlAxisP& A = pmq->ax[0];
-      const int r = tx / xp_nm, mm = tx - r * xp_nm;
-      int jr = tile_y * R + r - 1;
-      bool ok = (jr >= 0) && (jr < g.ny);
-      if (jr < 0 && per_y) { jr = g.ny - 1; ok = true; }
-      if (!ok) jr = 0;
-      const int i = mm < xp_nlo ? xp_t0 + mm : xp_hs + (mm - xp_nlo);
-      const int si = i < A.lo ? i : A.lo + (i - A.hi0);
-      xq_po = (unsigned)(jr * g.nx + i);
-      xq_qo = (unsigned)(jr * A.ns + si);
-      xq_l = (unsigned)(r * kXpCells + mm);
-      xq_c = (unsigned)(i - xp_t0);
-      const bool e_ok = ok && r > 0 && !(i == 0 && g.bcx0 == BC_PEC);      // (a cell on the x wall keeps its E-side psi: both components are tangential)
-      const unsigned lastm = (i + 1 < g.nx) ? 0u : (g.bcx1 == BC_PERIODIC ? 1u : 2u);
-      xq_fl = (ok ? 1u : 0u) | (e_ok ? 2u : 0u) | ((jr == 0 && g.bcy0 == BC_PEC) ? 4u : 0u) | (lastm << 3) | (r > 0 ? 32u : 0u);
-    }
-  }
-  [[maybe_unused]] const float* xcf = reinterpret_cast<const float*>(xco);          // tables [8][256]: kv_h b_h c_h kv_e b_e c_e 1/dx_primal 1/dx_dual
-  [[maybe_unused]] float xq_ey = 0.f, xq_eyp = 0.f, xq_ez = 0.f, xq_ezp = 0.f, xq_s1 = 0.f, xq_s2 = 0.f;   // H side, plane k+1
-  [[maybe_unused]] float xq_e1 = 0.f, xq_e2 = 0.f;                                                             // E side, plane k
-  [[maybe_unused]] uint32_t xq_w = kBgWord;
-  // loads of the H side of plane kk
-  [[maybe_unused]] auto xp_load_h = [&](int kk) {
-    if (xq_fl & 1u) {
-      const PmlAxisP& A = pmq->ax[0];
-      const long long p = (long long)kk * g.sxy + xq_po;
-      xq_ey = ldg1(a.ey + p); xq_ez = ldg1(a.ez + p);
-      const unsigned lastm = (xq_fl >> 3) & 3u;
-      const long long pn = lastm == 0u ? p + 1 : p - (long long)(xq_c + (unsigned)xp_t0);      // x+1 neighbour, or the row's first cell (periodic x)
-      xq_eyp = ldg1(a.ey + pn); xq_ezp = ldg1(a.ez + pn);
-      if (lastm == 2u) { xq_eyp = 0.f; xq_ezp = 0.f; }
-      const long long qq = (long long)kk * g.ny * A.ns + xq_qo;
-      xq_s1 = ldg1(A.ph0 + qq); xq_s2 = ldg1(A.ph1 + qq);
-    }
-  };
-  // H side of plane kk from the prefetched values: psi_h (read set -> write set) and the terms
-  //   ch (kv dEz/dx + p1)  [H_y +=],  ch (kv dEy/dx + p2)  [H_z -=]
-  [[maybe_unused]] auto xp_h = [&](int kk, int buf) {
-    if (xq_fl & 1u) {
-      const PmlAxisP& A = pmq->ax[0];
-      const float kv = xcf[0 * 256 + xq_c], bb = xcf[1 * 256 + xq_c], cc = xcf[2 * 256 + xq_c], ipxi = xcf[6 * 256 + xq_c];
-      const float d1 = (xq_eyp - xq_ey) * ipxi, d2 = (xq_ezp - xq_ez) * ipxi;
-      const float p1 = bb * xq_s1 + cc * d2;
-      const float p2 = bb * xq_s2 + cc * d1;
-      if (xq_fl & 32u) {                                         // (the halo row's psi belongs to the tile below)
-        const long long qq = (long long)kk * g.ny * A.ns + xq_qo;
-        A.ph0n[qq] = p1; A.ph1n[qq] = p2;
-      }
-      xdh[(buf * 2 + 0) * (R + 1) * kXpCells + xq_l] = ch * (kv * d2 + p1);
-      xdh[(buf * 2 + 1) * (R + 1) * kXpCells + xq_l] = ch * (kv * d1 + p2);
-    }
-  };
-  // loads of the E side of plane kk
-  [[maybe_unused]] auto xp_load_e = [&](int kk) {
-    if (xq_fl & 2u) {
-      const PmlAxisP& A = pmq->ax[0];
-      const long long qq = (long long)kk * g.ny * A.ns + xq_qo;
-      xq_e1 = ldg1(A.pe0 + qq); xq_e2 = ldg1(A.pe1 + qq);
-      if constexpr (MAT) xq_w = m.m4[(long long)kk * g.sxy + xq_po];
-    }
-  };
-  // E side of plane kk (behind the barrier: H^{n+1/2}_{y,z} of the own rows are in LDS): psi_e in place and the terms
-  //   cb (kv dHz/dx + p1)  [E_y -=],  cb (kv dHy/dx + p2)  [E_z +=]
-  [[maybe_unused]] auto xp_e = [&](int kk, int cur_, int buf) {
-    if (xq_fl & 2u) {
-      const PmlAxisP& A = pmq->ax[0];
-      const int slot_ = (int)blockDim.y * 64;
-      const unsigned r = xq_l / kXpCells;
-      const float* hyf = reinterpret_cast<const float*>(hyrow + (cur_ * (R + 1) + r) * 64);
-      const float* hzf = reinterpret_cast<const float*>(xch + (cur_ * 2 + 1) * slot_ + r * 64);
-      const float hy_i = hyf[xq_c], hz_i = hzf[xq_c];
-      const float hy_im = xq_c > 0 ? hyf[xq_c - 1] : hmc[(cur_ * (R + 1) + r) * 2 + 0];
-      const float hz_im = xq_c > 0 ? hzf[xq_c - 1] : hmc[(cur_ * (R + 1) + r) * 2 + 1];
-      const float kv = xcf[3 * 256 + xq_c], bb = xcf[4 * 256 + xq_c], cc = xcf[5 * 256 + xq_c], idxi = xcf[7 * 256 + xq_c];
-      const float d1 = (hy_i - hy_im) * idxi;
-      const float d2 = (hz_i - hz_im) * idxi;
-      const float p1 = bb * xq_e1 + cc * d2;
-      const float p2 = bb * xq_e2 + cc * d1;
-      const long long qq = (long long)kk * g.ny * A.ns + xq_qo;
-      A.pe0[qq] = p1; A.pe1[qq] = p2;
-      float cb_y = m.cb1, cb_z = m.cb1;
-      if constexpr (MAT) {
-        cb_y = lut_s[(xq_w >> 10) & 1023u].y;
-        cb_z = lut_s[(xq_w >> 20) & 1023u].y;
-      }
-      const bool wz = (kk == 0) && g.pec_z0;
-      xde[(buf * 2 + 0) * (R + 1) * kXpCells + xq_l] = wz ? 0.f : cb_y * (kv * d2 + p1);             // E_y is tangential to the z wall
-      xde[(buf * 2 + 1) * (R + 1) * kXpCells + xq_l] = (xq_fl & 4u) ? 0.f : cb_z * (kv * d1 + p2);   // E_z is tangential to the y wall
-    } else if ((xq_fl & 33u) == 33u) {         // an own row's cell on the x wall: no terms
-      xde[(buf * 2 + 0) * (R + 1) * kXpCells + xq_l] = 0.f;
-      xde[(buf * 2 + 1) * (R + 1) * kXpCells + xq_l] = 0.f;
-    }
-  };
 
   float exk[V], eyk[V], hxm[V], hym[V];
   zero<V>(hxm); zero<V>(hym);
@@ -833,17 +700,12 @@ __global__ __launch_bounds__(LB, (LB == 256 ? ((PML & 7) == 0 ? 4 : ((PML & 7) =
       }
     }
   }                                      // (the halo wave needs no H^{n+1/2}[k0-1])
-  if constexpr (XP) {
-    if (halo && k0 < k1) { xp_load_h(k0); xp_h(k0, 0); }   // the H-side terms of the chunk's first plane (every later plane: one plane ahead)
-    __syncthreads();
-  }
   int cur = 0;
   const int slot = (int)blockDim.y * 64;           // float4 entries per component per buffer
   // HINT bit 8 (256): the E values of a plane are stored one H phase later, behind the loads of the next plane
   [[maybe_unused]] float pend_ex[V], pend_ey[V], pend_ez[V];
   [[maybe_unused]] long long pend_p = -1;
   for (int k = k0; k < k1; ++k) {
-    [[maybe_unused]] const int kb = (k - k0) & 1;           // buffer of the pooled x terms of this plane
     const long long pb = (long long)k * g.sxy + rowb;      // scalar
     const long long pjb = (long long)k * g.sxy + rowpb;
     // Field loads of the plane: unconditional.  Lanes beyond the row end read the row's first cells instead
@@ -864,10 +726,6 @@ __global__ __launch_bounds__(LB, (LB == 256 ? ((PML & 7) == 0 ? 4 : ((PML & 7) =
     if (!halo) ldv_h<V, (HINT & 2) != 0>(hyn, uni(a.hy + pb), ubc);      // the halo wave only publishes H_x and H_z
     else zero<V>(hyn);
     ldf<V, true>(hzn, uni(a.hz + pb), ubc);
-    // (pooled x terms, halo wave: the E side of the LAST plane is formed in this plane's H phase — behind the load issue, in
-    //  front of the barrier — so that the halo wave's loads go out as early as everybody else's; measured the other way
-    //  round, E side right behind the barrier, the halo wave became the one all others wait for: profiles/r3c)
-    if constexpr (XP) { if (halo) { if (k + 1 < k1) xp_load_h(k + 1); if (k > k0) xp_load_e(k - 1); } }
     // ---- CPML state of this plane: EVERY psi load is issued here, with the field loads, so that ONE memory
     // round trip per plane covers them.  Loaded where they are used they chain two more round trips per plane
     // (H side, then E side behind the barrier): +0.63 ms per 512^3 step, worse than the slab kernels
@@ -887,7 +745,7 @@ __global__ __launch_bounds__(LB, (LB == 256 ? ((PML & 7) == 0 ? 4 : ((PML & 7) =
     if constexpr ((PML & 2) != 0) qy = ((long long)k * pmq->ax[1].ns + max(sy, 0)) * g.nx;
     if constexpr (PML != 0) {
       if (act) {
-        if constexpr ((PML & 1) != 0 && !XP) {
+        if constexpr ((PML & 1) != 0) {
           if (sx >= 0) {
             const PmlAxisP& A = pmq->ax[0];
             ldg4(xh1, uni(A.ph0 + qx), sxb);
@@ -933,15 +791,7 @@ __global__ __launch_bounds__(LB, (LB == 256 ? ((PML & 7) == 0 ? 4 : ((PML & 7) =
     if constexpr (PML != 0) {
       if (act) {
         // axis x: Hy += ch (kv dEz/dx + p1), Hz -= ch (kv dEy/dx + p2)
-        if constexpr (XP) {
-          if (sx >= 0) {                 // the terms were formed by the halo wave one plane ago
-            const float4 dy = *reinterpret_cast<const float4*>(xdh + ((kb * 2 + 0) * (R + 1) + ty) * kXpCells + xp_m0);
-            const float4 dz = *reinterpret_cast<const float4*>(xdh + ((kb * 2 + 1) * (R + 1) + ty) * kXpCells + xp_m0);
-            hyn[0] += dy.x; hyn[1] += dy.y; hyn[2] += dy.z; hyn[3] += dy.w;
-            hzn[0] -= dz.x; hzn[1] -= dz.y; hzn[2] -= dz.z; hzn[3] -= dz.w;
-          }
-        }
-        if constexpr ((PML & 1) != 0 && !XP) {
+        if constexpr ((PML & 1) != 0) {
           if (sx >= 0) {
             const PmlAxisP& A = pmq->ax[0];
             const float4 kv4 = xco[0 * 64 + tx], bb4 = xco[1 * 64 + tx], cc4 = xco[2 * 64 + tx];
@@ -1038,22 +888,6 @@ __global__ __launch_bounds__(LB, (LB == 256 ? ((PML & 7) == 0 ? 4 : ((PML & 7) =
       xch[(cur * 2 + 0) * slot + ty * 64 + tx] = t4;
       t4.x = hzn[0]; t4.y = hzn[1]; t4.z = hzn[2]; t4.w = hzn[3];
       xch[(cur * 2 + 1) * slot + ty * 64 + tx] = t4;
-      if constexpr (XP) {
-        if (!halo) {                      // H_y of the row, and what its first lane uses at x-1, for the pooled E side
-          t4.x = hyn[0]; t4.y = hyn[1]; t4.z = hyn[2]; t4.w = hyn[3];
-          hyrow[(cur * (R + 1) + ty) * 64 + tx] = t4;
-          if (tx == 0) {
-            hmc[(cur * (R + 1) + ty) * 2 + 0] = xh ? hy_m : (g.bcx0 == BC_PMC ? -hyn[0] : 0.f);
-            hmc[(cur * (R + 1) + ty) * 2 + 1] = xh ? hz_m : (g.bcx0 == BC_PMC ? -hzn[0] : 0.f);
-          }
-        }
-      }
-    }
-    if constexpr (XP) {
-      if (halo) {
-        if (k > k0) xp_e(k - 1, cur ^ 1, kb ^ 1);
-        if (k + 1 < k1) xp_h(k + 1, kb ^ 1);
-      }
     }
     __syncthreads();
     float hyx = __shfl_up(hyn[V - 1], 1);
@@ -1144,8 +978,8 @@ __global__ __launch_bounds__(LB, (LB == 256 ? ((PML & 7) == 0 ? 4 : ((PML & 7) =
             stg4(uni(A.pe1 + qz), ub, s2);
           }
         }
-        // axis x: E_y -= cb (kv dHz/dx + p1),  E_z += cb (kv dHy/dx + p2)      (pooled form: below, one plane late)
-        if constexpr ((PML & 1) != 0 && !XP) {
+        // axis x: E_y -= cb (kv dHz/dx + p1),  E_z += cb (kv dHy/dx + p2)
+        if constexpr ((PML & 1) != 0) {
           if (sx >= 0) {
             const PmlAxisP& A = pmq->ax[0];
             float (&s1)[V] = xe1, (&s2)[V] = xe2;
@@ -1176,7 +1010,7 @@ __global__ __launch_bounds__(LB, (LB == 256 ? ((PML & 7) == 0 ? 4 : ((PML & 7) =
       // row exchange (the values wait in registers): a store issued before the barrier costs the CPML instantiations
       // 2.4 ... 3 % of the whole step (profiles/r04i), as the H field stores do (+12 %, r03k)
       if constexpr (PML != 0 && (HINT & 128) != 0) {
-        if constexpr ((PML & 1) != 0 && !XP) {
+        if constexpr ((PML & 1) != 0) {
           if (sx >= 0) { const PmlAxisP& A = pmq->ax[0]; stg4(uni(A.ph0n + qx), sxb, xh1); stg4(uni(A.ph1n + qx), sxb, xh2); }
         }
         if constexpr ((PML & 2) != 0) {
@@ -1191,27 +1025,7 @@ __global__ __launch_bounds__(LB, (LB == 256 ? ((PML & 7) == 0 ? 4 : ((PML & 7) =
         stv_h<V, (HINT & 1) != 0>(b.hy + pb + i0, hyn);
         stv_h<V, (HINT & 1) != 0>(b.hz + pb + i0, hzn);
       }
-      if constexpr (XP) {
-        // slab lanes: E_y, E_z of plane k-1 get the x terms the halo wave formed behind the last barrier, and go out now;
-        // those of this plane wait for the next barrier
-        if (sx >= 0) {
-          if (k > k0) {
-            const float4 dy = *reinterpret_cast<const float4*>(xde + (((kb ^ 1) * 2 + 0) * (R + 1) + ty) * kXpCells + xp_m0);
-            const float4 dz = *reinterpret_cast<const float4*>(xde + (((kb ^ 1) * 2 + 1) * (R + 1) + ty) * kXpCells + xp_m0);
-            pend_ey[0] -= dy.x; pend_ey[1] -= dy.y; pend_ey[2] -= dy.z; pend_ey[3] -= dy.w;
-            pend_ez[0] += dz.x; pend_ez[1] += dz.y; pend_ez[2] += dz.z; pend_ez[3] += dz.w;
-            stv<V>(b.ey + pend_p + i0, pend_ey);
-            stv<V>(b.ez + pend_p + i0, pend_ez);
-          }
-#pragma unroll
-          for (int e = 0; e < V; ++e) { pend_ey[e] = ey[e]; pend_ez[e] = ez[e]; }
-          pend_p = pb;
-        } else {
-          stv_h<V, (HINT & 1) != 0>(b.ey + pb + i0, ey);
-          stv_h<V, (HINT & 1) != 0>(b.ez + pb + i0, ez);
-        }
-        stv_h<V, (HINT & 1) != 0>(b.ex + pb + i0, ex);
-      } else if constexpr ((HINT & 256) != 0) {
+      if constexpr ((HINT & 256) != 0) {
 #pragma unroll
         for (int e = 0; e < V; ++e) { pend_ex[e] = ex[e]; pend_ey[e] = ey[e]; pend_ez[e] = ez[e]; }
         pend_p = pb;
@@ -1246,19 +1060,6 @@ __global__ __launch_bounds__(LB, (LB == 256 ? ((PML & 7) == 0 ? 4 : ((PML & 7) =
       stv_h<V, (HINT & 1) != 0>(b.ex + pend_p + i0, pend_ex);
       stv_h<V, (HINT & 1) != 0>(b.ey + pend_p + i0, pend_ey);
       stv_h<V, (HINT & 1) != 0>(b.ez + pend_p + i0, pend_ez);
-    }
-  }
-  if constexpr (XP) {                     // the last plane's x terms
-    if (halo && k1 > k0) { xp_load_e(k1 - 1); xp_e(k1 - 1, cur ^ 1, (k1 - 1 - k0) & 1); }
-    __syncthreads();
-    if (act && !halo && sx >= 0 && k1 > k0) {
-      const int kl = (k1 - 1 - k0) & 1;
-      const float4 dy = *reinterpret_cast<const float4*>(xde + ((kl * 2 + 0) * (R + 1) + ty) * kXpCells + xp_m0);
-      const float4 dz = *reinterpret_cast<const float4*>(xde + ((kl * 2 + 1) * (R + 1) + ty) * kXpCells + xp_m0);
-      pend_ey[0] -= dy.x; pend_ey[1] -= dy.y; pend_ey[2] -= dy.z; pend_ey[3] -= dy.w;
-      pend_ez[0] += dz.x; pend_ez[1] += dz.y; pend_ez[2] += dz.z; pend_ez[3] += dz.w;
-      stv<V>(b.ey + pend_p + i0, pend_ey);
-      stv<V>(b.ez + pend_p + i0, pend_ez);
     }
   }
 }
