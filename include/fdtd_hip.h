@@ -226,6 +226,8 @@ enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_R
                                 the grid, slab by slab (slab s+1 takes step n, then slab s takes step n+1 while the
                                 intermediate planes are still in the 256 MiB Infinity Cache): planes per slab; 0 = off,
                                 -1 = default */
+       FDTD_OPT_EDGE_ZCHUNK = 14, /* planes per workgroup of the EDGE launches of a CPML step (tiles that meet a y / z slab):
+                                     -1 = default (about one wave of workgroups, at least 2 planes), 0 = as the interior launch, N */
        FDTD_OPT_LDS_PAD = 10 /* measuring aid: extra dynamic LDS per workgroup of the sweep in bytes (lowers its occupancy) */ };
 int fdtd_set_option(FdtdSolver* h, int key, int value);
 int fdtd_reset(FdtdSolver* h);      /* zero fields, auxiliaries, monitors and the step counter */

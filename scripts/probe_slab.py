@@ -27,7 +27,8 @@ def spec_for(n, nz, steps, pml=False):
         b = td.BoundarySpec(x=td.Boundary.pml(num_layers=12), y=td.Boundary.pml(num_layers=12), z=td.Boundary.periodic())
         nxy = n - 24
         structures = [td.Structure(geometry=td.Cylinder(center=(0, 0, 0), radius=100 * dl, length=td.inf, axis=2),
-                                   medium=td.Lorentz(eps_inf=2.0, coeffs=[(2.0, 4e14, 2e13)]))]
+                                   medium=td.Lorentz(eps_inf=2.0, coeffs=[(2.0, 4e14, 2e13)]) if int(pml) == 1
+                                   else td.Medium(permittivity=4.0))]             # --pml 2: V2-like (no ADE)
     sim = td.Simulation(size=(nxy * dl, nxy * dl, nz * dl), grid_spec=td.GridSpec.uniform(dl=dl), run_time=1e-12,
                         structures=structures, sources=[td.PointDipole(center=(0, 0, 0), source_time=pulse, polarization="Ez")],
                         monitors=[], boundary_spec=b, shutoff=0)
@@ -47,15 +48,18 @@ def main():
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--autotune", type=int, default=0)
     ap.add_argument("--pml", type=int, default=0)
+    ap.add_argument("--pml-fused", type=int, default=-1)
+    ap.add_argument("--warm", type=int, default=30)
+    ap.add_argument("--opt", action="append", default=[], help="NAME=VALUE engine options (tidy3d_amd.lib.OPT_*)")
     args = ap.parse_args()
     n = 512
-    steps, warm = args.steps, 30
+    steps, warm = args.steps, args.warm
     all_modes = {"single_fused": dict(variant=L.VARIANT_FUSED),
                  "comm_fused": dict(variant=L.VARIANT_FUSED, force_comm=True),
                  "comm_two_pass": dict(variant=L.VARIANT_ZMARCH, force_comm=True)}
     for ngpu in [int(x) for x in args.slabs.split(",")]:
         nz = n // ngpu
-        sp = spec_for(n, nz, steps + warm + 8, bool(args.pml))
+        sp = spec_for(n, nz, steps + warm + 8, args.pml)
         for mode in args.modes.split(","):
             kw = dict(all_modes[mode], z_chunk=args.zchunk)
             with HipEngine(sp, **kw) as e:
@@ -66,6 +70,10 @@ def main():
                 if args.rows:
                     e.set_option(L.OPT_ROWS, args.rows)
                 e.set_option(L.OPT_AUTOTUNE, args.autotune)
+                if args.pml_fused >= 0:
+                    e.set_option(L.OPT_PML_FUSED, args.pml_fused)
+                for kv in args.opt:
+                    e.set_option(getattr(L, kv.split("=")[0]), int(kv.split("=")[1]))
                 rng = np.random.default_rng(0)
                 for c in range(6):
                     e.set_field(c, rng.uniform(-1e-3, 1e-3, (nz, n, n)).astype(np.float32))
@@ -74,7 +82,7 @@ def main():
                 e.run(steps)
                 dt = time.perf_counter() - t0
                 stt = e.stats()
-                print(json.dumps({"slab_of": ngpu, "nz": nz, "mode": mode, "zchunk": args.zchunk, "bnd": args.bnd, "rows": args.rows, "tile": [int(stt.tile_rows), int(stt.tile_zchunk)], "autotune": args.autotune, "pml": args.pml, "ms_per_step": dt / steps * 1e3,
+                print(json.dumps({"slab_of": ngpu, "nz": nz, "mode": mode, "zchunk": args.zchunk, "bnd": args.bnd, "rows": args.rows, "tile": [int(stt.tile_rows), int(stt.tile_zchunk)], "autotune": args.autotune, "pml": args.pml, "pml_fused": args.pml_fused, "opt": args.opt, "ms_per_step": dt / steps * 1e3,
                                   "ideal_ms": 1.10 / ngpu,
                                   "implied_speedup_vs_1gpu": 1.10 / (dt / steps * 1e3)}), flush=True)
 

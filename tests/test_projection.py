@@ -154,3 +154,68 @@ def test_device_integration_equals_the_numpy_sums(emu_lib):
             scale = max(float(np.nanmax(np.abs(a))), 1e-300)
             assert np.nanmax(np.abs(a - b)) <= 1e-11 * scale + 1e-300, (name, comp)
             assert np.array_equal(np.isnan(a), np.isnan(b))
+
+
+def test_window_function_equals_the_reference():
+    """``window_size`` of a surface projection monitor (ref monitor.py:898-951): the factor projection._window applies to
+    the equivalent currents == the reference's own ``window_parameters`` + ``window_function`` on the same sample points,
+    for a finite surface and for an infinite one clipped to the sampled range (``custom_bounds``, ref field_projection.py:
+    533-541)."""
+    import os
+    import pytest
+    if not os.path.isdir("/root/reference/tidy3d"):
+        pytest.skip("reference checkout not present")
+    from oracle.tidy3d_ref_loader import load_tidy3d
+    from tidy3d_amd.projection import _window
+    tdr = load_tidy3d()
+    for size, ws in (((1.2, 0.8, 0), (0.3, 0.6)), ((td.inf, 0.9, 0), (1.0, 0.2)), ((0.7, td.inf, 0), (0.0, 0.5))):
+        kw = dict(center=(0.1, -0.2, 0.3), size=size, freqs=[3e14], theta=[0.1], phi=[0.0], name="far", window_size=ws)
+        mine, ref = td.FieldProjectionAngleMonitor(**kw), tdr.FieldProjectionAngleMonitor(**kw)
+        pts = [np.linspace(-0.9, 1.0, 41), np.linspace(-0.8, 0.5, 33), np.array([0.3])]
+        pts = [np.clip(p, c - s / 2, c + s / 2) if np.isfinite(s) else p for p, c, s in zip(pts, kw["center"], size)]
+        pts = [np.unique(p) for p in pts]
+        got = _window(mine, (0, 1), pts)[:, :, 0]
+        bounds = [[p[0] for p in pts], [p[-1] for p in pts]]
+        wsz, wmin, wplus = ref.window_parameters(custom_bounds=bounds)
+        want = np.ones((pts[0].size, pts[1].size))
+        for dim in (0, 1):
+            if wsz[dim] > 0:
+                f = ref.window_function(points=pts[dim], window_size=wsz, window_minus=wmin, window_plus=wplus, dim=dim)
+                want = want * (f[:, None] if dim == 0 else f[None, :])
+        np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-300)
+
+
+def test_projection_under_symmetry_equals_the_full_run():
+    """Projection monitors together with ``Simulation.symmetry`` (ref monitor.py / monitor_data.py:238-284 symmetry
+    expansion): the surfaces are recorded on their images in the computed quarter and expanded with the parity rules; a
+    symmetric problem gives the same far field with and without the flag.  Also a windowed surface monitor."""
+    DL = 0.0625
+    f0 = 3e14
+    pulse = td.GaussianPulse(freq0=f0, fwidth=f0 / 6)
+    theta = np.linspace(0.05, 3.0, 9)
+    phi = np.linspace(0, 2 * np.pi, 7)
+
+    def sim(symmetry):
+        return td.Simulation(
+            size=(24 * DL, 20 * DL, 22 * DL), grid_spec=td.GridSpec.uniform(dl=DL), run_time=30 / f0, symmetry=symmetry,
+            structures=[td.Structure(geometry=td.Sphere(radius=0.2), medium=td.Medium(permittivity=3.0))],
+            sources=[td.PointDipole(center=(0, 0, 0), source_time=pulse, polarization="Ez")],
+            monitors=[td.FieldProjectionAngleMonitor(center=(0, 0, 0), size=(0.83, 0.71, 0.77), freqs=[f0], theta=theta, phi=phi,
+                                                     proj_distance=1e3, name="box"),
+                      td.FieldProjectionAngleMonitor(center=(0, 0, 0.41), size=(td.inf, td.inf, 0), freqs=[f0], theta=theta[:4], phi=phi,
+                                                     proj_distance=1e3, name="top", window_size=(0.4, 0.7)),
+                      td.FieldProjectionCartesianMonitor(center=(0, 0, 0.41), size=(0.9, 0.8, 0), freqs=[f0], x=[-3.0, 0.5, 2.0], y=[0.0, 1.5],
+                                                         proj_axis=2, proj_distance=50.0, name="cart", far_field_approx=False)],
+            boundary_spec=td.BoundarySpec.all_sides(td.PML(num_layers=6)), shutoff=0)
+
+    def run(symmetry):
+        disc = discretize(sim(symmetry), n_steps=260)
+        return assemble(disc, OracleFdtd(disc.spec).run())
+    full = run((0, 0, 0))
+    half = run((1, 1, -1))        # E_z of a z dipole: even in x and y (PMC), normal to the z plane (PEC)
+    for name in ("box", "top", "cart"):
+        for comp, arr in full[name].field_components.items():
+            a, b = np.asarray(arr.values), np.asarray(half[name].field_components[comp].values)
+            scale = max(np.abs(np.asarray(v.values)).max() for v in full[name].field_components.values())
+            assert np.abs(a - b).max() <= 2e-6 * scale, (name, comp, np.abs(a - b).max() / scale)
+    assert np.abs(full["top"].Etheta.values).max() > 0

@@ -46,6 +46,7 @@ struct PmlAxisDev {
 struct AdeGroup {
   int comp;
   int k0 = 0, k1 = 0;              // planes [k0, k1) that hold its cells: launches over other plane ranges are skipped
+  std::vector<long long> plane_off;  // sorted lists: entries of plane k are [plane_off[k], plane_off[k + 1]); empty = unsorted
   long long n;
   uint32_t* cell;
   float* e_old;
@@ -175,6 +176,7 @@ struct FdtdSolver {
   bool streams_shared = false;       // comm_stream is an alias of stream (fallback)
   // slab-interleaved two-step schedule (fdtd_run): planes per slab; 0 = off, -1 = default
   int tblock = -1;
+  int edge_zchunk = -1;              // z-chunk of the edge launches of a CPML step: -1 = about one wave of workgroups, 0 = as the interior, N = planes
   long long two_step_pairs = 0;
   int tblock_used = 0;
 };
@@ -466,7 +468,7 @@ void swap_psi_h(FdtdSolver* h, int pml_inside) {
 // pml_inside: axes whose CPML recursions this launch carries (its tiles must not touch members of other
 // in-sweep axes): 0 -> plain instantiation, 1 -> the x-only one, anything else -> the all-axes one.
 int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pml_inside = 0, int k2beg = 0,
-                       int k2end = 0, int ty_n = -1, int ty_a = 0, int ty_gap = 0) {
+                       int k2end = 0, int ty_n = -1, int ty_a = 0, int ty_gap = 0, bool edge = false) {
   if (kend <= kbeg) {                 // first plane range empty: the second one takes its place
     if (k2end <= k2beg) return 0;
     kbeg = k2beg; kend = k2end; k2beg = k2end = 0;
@@ -480,8 +482,18 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pm
   // 0 ... 1.5 % faster on the 512^3 plain / materials sweeps and 2 % slower on the CPML-carrying step (profiles/
   // r03f), 2.5 ... 4.5 % faster on the 64- and 128-plane slabs a rank of an 8- / 4-GPU run holds (r03n).  A shape set
   // through fdtd_set_option or found by the tile-shape probe is kept.
-  const int zc = (h->user_geometry || h->tuned || pml_inside) ? h->zchunk_f : std::min(h->zchunk_f, kPlainZChunk);
-  if (ty_gap == 0) h->last_zc = zc;            // (the interior launch of a step, not its edge launches)
+  int zc = (h->user_geometry || h->tuned || pml_inside) ? h->zchunk_f : std::min(h->zchunk_f, kPlainZChunk);
+  if (ty_gap == 0 && !edge) h->last_zc = zc;            // (the interior launch of a step, not its edge launches)
+  // Edge launches of a CPML step (the few tiles that meet a y / z slab, all-axes instantiation): on a thin z-slab they are a
+  // handful of workgroups marching the whole slab one plane at a time — 80 workgroups x 16 planes took 83 us alone on the
+  // machine, in front of the 179 us interior launch of the same stream (profiles/r3e: 64-plane slab, CPML on x and y).
+  // Shorter chunks turn them into about one wave of workgroups (the prologue plane per chunk is cheap on 6 % of the tiles).
+  if (edge && h->edge_zchunk != 0) {
+    const int nby_e = ty_n < 0 ? (g.ny + R - 1) / R : ty_n;
+    const long long wg_planes = (long long)((g.nx + 255) / 256) * nby_e * ((kend - kbeg) + std::max(0, k2end - k2beg));
+    const int want = h->edge_zchunk > 0 ? h->edge_zchunk : (int)std::max(2LL, std::min((long long)zc, wg_planes / 1024));
+    zc = std::min(zc, want);
+  }
   dim3 block(64, R + 1, 1);
   const int nby_all = (g.ny + R - 1) / R;
   if (ty_n < 0) { ty_n = nby_all; ty_a = nby_all; ty_gap = 0; }
@@ -898,10 +910,16 @@ void advance_tfsf_aux(FdtdSolver* h, bool e_side, long long n, hipStream_t st, b
 void launch_ade(FdtdSolver* h, int kbeg, int kend, hipStream_t st) {
   if (kend <= kbeg) return;
   const long long zlo = (long long)kbeg * h->g.sxy, zhi = (long long)kend * h->g.sxy;
-  for (AdeGroup& a : h->ade)
-    if (planes_meet(a.k0, a.k1, kbeg, kend))
-    hipLaunchKernelGGL(ade_kernel, dim3(nblk(a.n)), dim3(256), 0, st, field_ptr(h, a.comp),
-                       (const uint32_t*)a.cell, a.e_old, a.q, a.n, zlo, zhi, a.p);
+  for (AdeGroup& a : h->ade) {
+    if (!planes_meet(a.k0, a.k1, kbeg, kend)) continue;
+    // a sorted list: the launch covers the entries of the planes [kbeg, kend) only — the boundary chunks of a z-slab step
+    // (2 planes each, three launches per component and step) no longer scan the whole list three times
+    long long t0 = 0, t1 = a.n;
+    if (!a.plane_off.empty()) { t0 = a.plane_off[(size_t)std::max(kbeg, 0)]; t1 = a.plane_off[(size_t)std::min(kend, h->g.nz)]; }
+    if (t1 <= t0) continue;
+    hipLaunchKernelGGL(ade_kernel, dim3(nblk(t1 - t0)), dim3(256), 0, st, field_ptr(h, a.comp),
+                       (const uint32_t*)a.cell + t0, a.e_old + t0, a.q + t0, t1 - t0, a.n, zlo, zhi, a.p);
+  }
 }
 
 // z boundary conditions of a single slab (no neighbour): fill ghost planes
@@ -1406,6 +1424,18 @@ int fdtd_add_ade(FdtdSolver* h, int comp, int64_t n, const uint32_t* cell_index,
   AdeGroup a{};
   a.comp = comp; a.n = n;
   plane_range(cell_index, n, h->g.sxy, &a.k0, &a.k1);
+  {
+    bool sorted = true;
+    for (int64_t i = 1; i < n && sorted; ++i) sorted = cell_index[i - 1] <= cell_index[i];
+    if (sorted) {
+      a.plane_off.assign((size_t)h->g.nz + 1, n);
+      int64_t i = 0;
+      for (int k = 0; k <= h->g.nz; ++k) {
+        while (i < n && (long long)cell_index[i] < (long long)k * h->g.sxy) ++i;
+        a.plane_off[(size_t)k] = i;
+      }
+    }
+  }
   if (dev_upload(h, &a.cell, cell_index, (size_t)n) || dev_alloc(h, &a.e_old, (size_t)n) ||
       dev_alloc(h, &a.q, (size_t)n * n_poles))
     return -1;
@@ -1911,8 +1941,8 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
         // (all on the main stream.  Edge launches on a third stream were tried: no gain, and an engine with three
         //  streams pushed the next engine of the process onto shared hardware queues — its two streams serialised,
         //  3x slower steps, profiles/r04r)
-        if ((za > ki || zc < ke) && launch_fused_range(h, ki, za, st, pml_in_m, zc, ke)) return -1;
-        if (launch_fused_range(h, za, zc, st, pml_in_m & 3, 0, 0, ty_a + (nby_all - ty_c), ty_a, ty_c - ty_a)) return -1;
+        if ((za > ki || zc < ke) && launch_fused_range(h, ki, za, st, pml_in_m, zc, ke, -1, 0, 0, true)) return -1;
+        if (launch_fused_range(h, za, zc, st, pml_in_m & 3, 0, 0, ty_a + (nby_all - ty_c), ty_a, ty_c - ty_a, true)) return -1;
         if (launch_fused_range(h, za, zc, st, pml_in_m & 1, 0, 0, ty_c - ty_a, 0, ty_a)) return -1;
       }
       swap_sets(h);
@@ -1987,8 +2017,8 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
         const int ty_c = (in_y && py.hi0 < h->g.ny) ? std::max(ty_a, py.hi0 / R) : nby_all;
         HIPCHK(h, hipEventRecord(h->ev_h_int, st));
         HIPCHK(h, hipStreamWaitEvent(cs, h->ev_h_int, 0));
-        if (launch_fused_range(h, 0, za, cs, pml_in, zc, nz)) return -1;
-        if (launch_fused_range(h, za, zc, cs, pml_in & 3, 0, 0, ty_a + (nby_all - ty_c), ty_a, ty_c - ty_a)) return -1;
+        if (launch_fused_range(h, 0, za, cs, pml_in, zc, nz, -1, 0, 0, true)) return -1;
+        if (launch_fused_range(h, za, zc, cs, pml_in & 3, 0, 0, ty_a + (nby_all - ty_c), ty_a, ty_c - ty_a, true)) return -1;
         HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
         if (launch_fused_range(h, za, zc, st, pml_in & 1, 0, 0, ty_c - ty_a, 0, ty_a)) return -1;
         HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
@@ -2311,6 +2341,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_PLACEMENT_TRIES: if (value < 0 || (value % 100) > 3) break; h->placement_tries = value; h->placement_done = false; return 0;
     case FDTD_OPT_LDS_PAD: if (value < 0 || value > 120000) break; h->lds_pad = value; return 0;
     case FDTD_OPT_TBLOCK: h->tblock = value < 0 ? -1 : value; return 0;
+    case FDTD_OPT_EDGE_ZCHUNK: h->edge_zchunk = value < 0 ? -1 : value; return 0;
     case FDTD_OPT_PML_SPLIT: h->pml_split = value < 0 ? -1 : (value != 0); return 0;
     case FDTD_OPT_FUSED_LB: if (value != 0 && value != 256 && value != 512 && value != 1024) break; h->fused_lb = value; return 0;
     default: break;

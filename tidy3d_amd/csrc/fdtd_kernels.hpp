@@ -1328,12 +1328,14 @@ struct AdeP {
   float2 bet[kMaxPoles];
 };
 
+// (the list is sorted by cell index: a launch over a plane range covers the entries [t0, t0 + n) of those planes only —
+//  `cell`, `e_old`, `q` arrive offset by t0, `qs` is the stride between the poles of one entry = the length of the list)
 __global__ __launch_bounds__(256) void ade_kernel(float* e, const uint32_t* cell, float* e_old, float2* q,
-                                                   long long n, long long zlo, long long zhi, AdeP a) {
+                                                   long long n, long long qs, long long zlo, long long zhi, AdeP a) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const long long p = cell[t];
-  if (p < zlo || p >= zhi) return;        // z-range filter (multi-stream boundary planes)
+  if (p < zlo || p >= zhi) return;        // z-range filter (unsorted lists)
   const float es = e[p];
   const float eo = e_old[t];
   float S = 0.f;
@@ -1341,7 +1343,7 @@ __global__ __launch_bounds__(256) void ade_kernel(float* e, const uint32_t* cell
 #pragma unroll
   for (int k = 0; k < kMaxPoles; ++k) {
     if (k < a.n_poles) {
-      qq[k] = q[(long long)k * n + t];
+      qq[k] = q[(long long)k * qs + t];
       // 2 Re[(kap - 1) Q]
       S += 2.f * ((a.kap[k].x - 1.f) * qq[k].x - a.kap[k].y * qq[k].y);
     }
@@ -1356,7 +1358,7 @@ __global__ __launch_bounds__(256) void ade_kernel(float* e, const uint32_t* cell
       float2 r;
       r.x = a.kap[k].x * qq[k].x - a.kap[k].y * qq[k].y + a.bet[k].x * se;
       r.y = a.kap[k].x * qq[k].y + a.kap[k].y * qq[k].x + a.bet[k].y * se;
-      q[(long long)k * n + t] = r;
+      q[(long long)k * qs + t] = r;
     }
   }
 }

@@ -66,13 +66,19 @@ def _surface_currents(disc, plan, raw, norm, medium):
     mon, sim, spec = plan.monitor, disc.sim, disc.spec
     freqs = np.asarray(mon.freqs, float)
     names = "xyz"
-    for fp, (sname, box, axis, sign) in zip(plan.fields, flux_surfaces(mon)):
+    # Simulation.symmetry: the surfaces were recorded on their images inside the computed sub-domain (discretize.py
+    # symmetry_box_map) and are expanded to the user's surfaces with the reference's parity rules (ref monitor_data.py:
+    # 238-284), exactly like the surfaces of a FluxMonitor
+    sym = tuple(getattr(disc, "symmetry", (0, 0, 0)))
+    pfull = disc.plans_full[[id(p_) for p_ in disc.plans].index(id(plan))] if any(sym) else None
+    for isurf, (fp, (sname, box, axis, sign)) in enumerate(zip(plan.fields, flux_surfaces(mon))):
         class _M:
             pass
         m = _M()
         m.size, m.center, m.geometry, m.name = box.size, box.center, box, fp.spec_name
+        full = None if pfull is None else (pfull.fields[isurf], disc.spec_full, sym)
         fd = _field_container(FieldData, m, spec, fp, raw[fp.spec_name], "f", freqs, sim.center,
-                              np.complex128).normalize(norm)
+                              np.complex128, full).normalize(norm)
         u, v = [a for a in range(3) if a != axis]
         n_idx = float(np.real(np.sqrt(complex(np.asarray(medium.eps_model(float(freqs.max()))).ravel()[0]))))
         wavelength = C_0 / float(freqs.max()) / n_idx
@@ -98,7 +104,38 @@ def _surface_currents(disc, plan, raw, norm, medium):
             return np.take(arr, 0, axis=axis)                         # (u, v, f) in x, y, z order
         J = {u: signs[0] * sampled("H" + cv), v: signs[1] * sampled("H" + cu)}
         M = {v: signs[0] * sampled("E" + cu), u: signs[1] * sampled("E" + cv)}
+        win = _window(mon, (u, v), pts)
+        if win is not None:
+            J = {a: arr * win for a, arr in J.items()}
+            M = {a: arr * win for a, arr in M.items()}
         yield axis, u, v, pts, J, M
+
+
+WINDOW_FACTOR = 15          # ref monitor.py:44
+
+
+def _window(mon, plane_axes, pts):
+    """``window_size`` of a SURFACE projection monitor (ref monitor.py:819-848 field, :898-951 ``window_parameters`` /
+    ``window_function``, applied to the equivalent currents in ref field_projection.py:522-558): along each tangential
+    direction the currents are scaled by exp(-WINDOW_FACTOR/2 ((x - x_edge)/w)^2) beyond the points x_edge that lie
+    w = window_size[i] * size / 2 inside the (sampled, i.e. clipped to the simulation) ends of the surface.  Returns
+    the (u, v, 1) factor, or None without windowing."""
+    ws = tuple(getattr(mon, "window_size", (0, 0)) or (0, 0))
+    if not any(ws) or list(mon.size).count(0.0) != 1:
+        return None
+    fac = []
+    for i, a in enumerate(plane_axes):
+        p = np.asarray(pts[a], float)
+        f = np.ones_like(p)
+        lo_m, hi_m = mon.center[a] - mon.size[a] / 2.0, mon.center[a] + mon.size[a] / 2.0
+        size = min(mon.size[a], p[-1] - p[0])
+        w = ws[i] * size / 2.0
+        if w > 0:
+            minus, plus = max(lo_m, p[0]) + w, min(hi_m, p[-1]) - w
+            f[p < minus] = np.exp(-0.5 * WINDOW_FACTOR * ((p[p < minus] - minus) / w) ** 2)
+            f[p > plus] = np.exp(-0.5 * WINDOW_FACTOR * ((p[p > plus] - plus) / w) ** 2)
+        fac.append(f)
+    return fac[0][:, None, None] * fac[1][None, :, None]
 
 
 def _medium_params(mon, sim, medium, freqs):
