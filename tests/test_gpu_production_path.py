@@ -225,3 +225,56 @@ def test_two_step_slab_schedule_bit_identical_256(hip_lib, tb):
     assert p0 == 0 and p1 == steps // 2
     for c in range(6):
         assert np.array_equal(got[c], ref[c]), c
+
+
+@pytest.mark.parametrize("name", ["media_mix", "drude_in_pml", "tfsf_box", "periodic_box_tall", "absorber_mix"])
+def test_captured_step_pairs_bit_identical(hip_lib, name):
+    """FDTD_OPT_GRAPH: runs of steps without monitor records or decay checks replayed as captured hipGraphs of two steps
+    (source kernels read the step counter from device memory) == direct launches, bit for bit: CPML (one launch of the
+    all-axes instantiation), ADE, TFSF incident grid, periodic ghost copies, absorber layers, monitors every 7th step,
+    decay checks every 16th, two run() calls."""
+    from cases import CASES
+    fn = CASES[name]
+    sim = fn(tuple(int(n * 3) for n in fn.__defaults__[0]))
+    disc = discretize(sim, n_steps=90)
+    disc.spec.decay_every = 16
+
+    def run(graph):
+        with HipEngine(disc.spec, lib=hip_lib, axis_shift=0) as e:
+            e.set_option(L.OPT_GRAPH, graph)
+            st = e.run(41)
+            pairs = int(st.graph_pairs)
+            st = e.run(49)
+            return [e.get_field(c) for c in range(6)], e.results(), pairs + int(st.graph_pairs)
+    ref_f, ref_m, p0 = run(0)
+    got_f, got_m, p1 = run(1)
+    assert p0 == 0 and p1 >= 15, (p0, p1)
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), c
+    for k in ref_m:
+        assert np.array_equal(got_m[k], ref_m[k]), k
+
+
+def test_captured_step_pairs_small_grid_speed(hip_lib):
+    """What the graphs are for: grids bound by dependent launches.  Vacuum PEC cubes with a dipole, 2000 steps each way;
+    prints us per step (profiles/), asserts only that replaying is not slower."""
+    import time
+    out = {}
+    for n in (64, 128, 200):
+        sim = td.Simulation(size=(n * DL,) * 3, grid_spec=td.GridSpec.uniform(dl=DL), run_time=1e-12,
+                            sources=[td.PointDipole(center=(0.1, 0, 0), source_time=PULSE, polarization="Ez")], monitors=[],
+                            boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary()), shutoff=0)
+        disc = discretize(sim, n_steps=4400)
+        disc.spec.decay_every = 0
+        t = {}
+        for graph in (0, 1):
+            with HipEngine(disc.spec, lib=hip_lib, axis_shift=0) as e:
+                e.set_option(L.OPT_GRAPH, graph)
+                e.run(200)
+                t0 = time.perf_counter()
+                e.run(2000)
+                t[graph] = (time.perf_counter() - t0) / 2000 * 1e6
+        out[n] = t
+    print("\n[graphs] us per step, direct vs captured pairs:", {n: (round(v[0], 1), round(v[1], 1)) for n, v in out.items()})
+    for n, v in out.items():
+        assert v[1] < 1.05 * v[0], (n, v)

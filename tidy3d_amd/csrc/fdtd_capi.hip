@@ -176,7 +176,15 @@ struct FdtdSolver {
   bool streams_shared = false;       // comm_stream is an alias of stream (fallback)
   // slab-interleaved two-step schedule (fdtd_run): planes per slab; 0 = off, -1 = default
   int tblock = -1;
-  int edge_zchunk = -1;              // z-chunk of the edge launches of a CPML step: -1 = about one wave of workgroups, 0 = as the interior, N = planes
+  int edge_zchunk = -1;
+  // Captured step pairs (small grids): a run of steps without monitor records or field-decay checks is replayed as
+  // hipGraphs of TWO steps each (set a -> b -> a, psi parity back where it was), one per (field set, psi parity) state
+  int use_graph = -1;                // -1 = default (grids below 2^22 cells), 0 = never, 1 = whenever possible
+  long long* step_dev = nullptr;     // device-side step counter the captured source kernels read
+  long long step_dev_value = -1;     // what it holds (host mirror)
+  bool step_dev_mode = false;        // launches are being captured: source kernels take step_dev + step_dev_off
+  long long step_dev_off = 0;
+  long long graph_pairs = 0;              // z-chunk of the edge launches of a CPML step: -1 = about one wave of workgroups, 0 = as the interior, N = planes
   long long two_step_pairs = 0;
   int tblock_used = 0;
 };
@@ -488,7 +496,9 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pm
   // handful of workgroups marching the whole slab one plane at a time — 80 workgroups x 16 planes took 83 us alone on the
   // machine, in front of the 179 us interior launch of the same stream (profiles/r3e: 64-plane slab, CPML on x and y).
   // Shorter chunks turn them into about one wave of workgroups (the prologue plane per chunk is cheap on 6 % of the tiles).
-  if (edge && h->edge_zchunk != 0) {
+  // On ONE GPU the edge launches run on the second stream beside the interior launch and are off the critical path: there
+  // the long chunks stay (512^3 V2 inside one engine, profiles/r3f: 16 planes 1.367 ms, 8 planes 1.377, 4 planes 1.394).
+  if (edge && (h->edge_zchunk > 0 || (h->edge_zchunk < 0 && h->comm != nullptr))) {
     const int nby_e = ty_n < 0 ? (g.ny + R - 1) / R : ty_n;
     const long long wg_planes = (long long)((g.nx + 255) / 256) * nby_e * ((kend - kbeg) + std::max(0, k2end - k2beg));
     const int want = h->edge_zchunk > 0 ? h->edge_zchunk : (int)std::max(2LL, std::min((long long)zc, wg_planes / 1024));
@@ -884,11 +894,13 @@ void launch_sources(FdtdSolver* h, bool e_side, long long n, int kbeg, int kend,
     if (e_side && s.n_e && planes_meet(s.ke0, s.ke1, kbeg, kend))
       hipLaunchKernelGGL(point_source_kernel, dim3(nblk(s.n_e)), dim3(256), 0, st, f0, f1, f2,
                          (const int32_t*)s.comp_e, (const uint32_t*)s.cell_e, (const float*)s.wre_e,
-                         (const float*)s.wim_e, (const float2*)s.wave_e, n, s.n_e, zlo, zhi);
+                         (const float*)s.wim_e, (const float2*)s.wave_e, h->step_dev_mode ? h->step_dev_off : n, s.n_e, zlo, zhi,
+                         (const long long*)(h->step_dev_mode ? h->step_dev : nullptr));
     if (!e_side && s.n_h && planes_meet(s.kh0, s.kh1, kbeg, kend))
       hipLaunchKernelGGL(point_source_kernel, dim3(nblk(s.n_h)), dim3(256), 0, st, f0, f1, f2,
                          (const int32_t*)s.comp_h, (const uint32_t*)s.cell_h, (const float*)s.wre_h,
-                         (const float*)s.wim_h, (const float2*)s.wave_h, n, s.n_h, zlo, zhi);
+                         (const float*)s.wim_h, (const float2*)s.wave_h, h->step_dev_mode ? h->step_dev_off : n, s.n_h, zlo, zhi,
+                         (const long long*)(h->step_dev_mode ? h->step_dev : nullptr));
   }
 }
 
@@ -900,7 +912,8 @@ void advance_tfsf_aux(FdtdSolver* h, bool e_side, long long n, hipStream_t st, b
     float* h1 = replica ? t.h1c : t.h1;
     if (e_side)
       hipLaunchKernelGGL(tfsf_aux_e_kernel, dim3(1), dim3(1024), 0, st, e1, (const float*)h1,
-                         (const float*)t.ae, (const float*)t.be, t.n_aux, t.src_cell, (const float*)t.wave, n);
+                         (const float*)t.ae, (const float*)t.be, t.n_aux, t.src_cell, (const float*)t.wave,
+                         h->step_dev_mode ? h->step_dev_off : n, (const long long*)(h->step_dev_mode ? h->step_dev : nullptr));
     else
       hipLaunchKernelGGL(tfsf_aux_h_kernel, dim3(nblk(t.n_aux)), dim3(256), 0, st, h1, (const float*)e1,
                          (const float*)t.ah, (const float*)t.bh, t.n_aux);
@@ -1905,6 +1918,115 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     h->two_step_pairs++;
     return 0;
   };
+  // one step of the one-GPU fused path (n = its time step; rec_post: monitors record behind the sweep)
+  auto fused_one = [&](long long n, bool rec_post) -> int {
+    // H-side corrections are additive: pre-apply them to H^{n-1/2}; E-side ones follow the sweep.
+    // With pml_in the CPML recursions run inside the sweep (same arithmetic, no slab kernels).
+    // pml_in = axes whose recursions run inside the sweep (default: all that have layers; FDTD_OPT_PML_FUSED
+    // = 0 keeps the slab kernels, any other mask selects axes).  Inside the sweep the field values a slab
+    // kernel would re-read and re-write stay in registers: only psi moves (32 B per cell and axis membership).
+    int pml_in = 0;
+    if (any_pml(h) && 64 * (h->rows_f + 1) <= 512)
+      pml_in = (h->pml_fused < 0 ? 7 : h->pml_fused) & pml_in_sweep_mask(h);
+    launch_damp(h, false, 0, nz, st);
+    launch_sources(h, false, n, 0, nz, st);
+    launch_pml(h, false, 0, nz, st, 7 & ~pml_in);
+    advance_tfsf_aux(h, false, n, st);
+    if (h->cfg.bc[4] == FDTD_BC_PERIODIC) fill_ghost_h(h, st);   // ghost(-1) must carry the pre-corrections too
+    // small grids are bound by dependent launches, not by occupancy: one launch of the all-axes instantiation
+    const bool split = h->pml_split < 0 ? n_cells(h) >= (1LL << 24) : h->pml_split != 0;
+    if ((pml_in & 6) == 0 || !split) {
+      if (launch_fused(h, st, pml_in)) return -1;
+    } else {
+      // The instantiation that carries the y / z recursions holds their psi values in registers from the
+      // top of a plane (occupancy 2-3); the one most tiles need carries x only.  Three launches over
+      // disjoint tiles, the two small ones on the second stream, concurrent with the big one:
+      //   (1) planes of the z slabs (+1 plane: the next chunk's prologue must not see a slab), all rows   [x y z]
+      //   (2) planes in between: bottom and top tile rows (a row or the halo row in a y slab)              [x y]
+      //   (3) planes in between, middle tile rows                                                         [x]
+      const int R = h->rows_f, nby_all = (h->g.ny + R - 1) / R;
+      const PmlAxisDev &py = h->pml[1], &pz = h->pml[2];
+      const bool in_y = (pml_in & 2) && py.ns > 0, in_z = (pml_in & 4) && pz.ns > 0;
+      const int za = (in_z && pz.lo > 0) ? std::min(nz, pz.lo + 1) : 0;
+      const int zc = (in_z && pz.hi0 < nz) ? std::max(za, pz.hi0) : nz;
+      const int ty_a = (in_y && py.lo > 0) ? std::min(nby_all, py.lo / R + 1) : 0;
+      const int ty_c = (in_y && py.hi0 < h->g.ny) ? std::max(ty_a, py.hi0 / R) : nby_all;
+      HIPCHK(h, hipEventRecord(h->ev_h_int, st));
+      HIPCHK(h, hipStreamWaitEvent(cs, h->ev_h_int, 0));
+      if (launch_fused_range(h, 0, za, cs, pml_in, zc, nz, -1, 0, 0, true)) return -1;
+      if (launch_fused_range(h, za, zc, cs, pml_in & 3, 0, 0, ty_a + (nby_all - ty_c), ty_a, ty_c - ty_a, true)) return -1;
+      HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
+      if (launch_fused_range(h, za, zc, st, pml_in & 1, 0, 0, ty_c - ty_a, 0, ty_a)) return -1;
+      HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
+      swap_sets(h);
+      swap_psi_h(h, pml_in);
+    }
+    if (rec_post) record_monitors(h, n, true, st);
+    launch_pml(h, true, 0, nz, st, 7 & ~pml_in);
+    launch_sources(h, true, n, 0, nz, st);
+    launch_damp(h, true, 0, nz, st);
+    launch_ade(h, 0, nz, st);
+    advance_tfsf_aux(h, true, n, st);
+    fill_ghost_fused(h, st);
+    return 0;
+  };
+  // ---- captured step pairs (hipGraph) ------------------------------------------------------------------------------
+  // Small grids are bound by dependent launches (64^3: three launches, 31 us per step; profiles/r02h): a run of steps
+  // without monitor records or decay checks is captured ONCE as a graph of two steps (set a -> b -> a, psi parity back)
+  // and replayed.  A graph bakes its kernel arguments, so the source kernels of a captured launch read the step counter
+  // from device memory (step_dev + offset; the graph's last node advances it by two).  Same launches, same order, same
+  // arguments otherwise: bit-identical to direct launches (tests/test_gpu_production_path.py).  One stream only: not
+  // with the three-launch CPML split of large grids, not on z-slabs, not with per-launch timing events.
+  const bool split_now = (h->pml_split < 0 ? n_cells(h) >= (1LL << 24) : h->pml_split != 0) && any_pml(h) &&
+                         (((h->pml_fused < 0 ? 7 : h->pml_fused) & pml_in_sweep_mask(h)) & 6) != 0;
+  bool graph_ok = fused && !tb_ok && !split_now && !(h->cfg.flags & FDTD_FLAG_TIME_KERNELS) &&
+                  (h->use_graph < 0 ? n_cells(h) < (1LL << 22) : h->use_graph != 0);
+  struct GraphRec { const float* set; int parity; hipGraphExec_t exec; };
+  std::vector<GraphRec> graphs;
+  h->graph_pairs = 0;
+  auto sources_alive = [&](long long n) {
+    for (const PointSrc& s : h->psrc) if (n >= s.n_steps) return false;
+    for (const Tfsf& t : h->tfsf) if (n >= t.n_steps) return false;
+    return true;
+  };
+  // 0 = the pair (n, n + 1) was replayed; 1 = capture not available (caller launches directly); < 0 = error
+  auto graph_pair = [&](long long n) -> int {
+    hipGraphExec_t exec = nullptr;
+    for (const GraphRec& r : graphs) if (r.set == h->f.ex && r.parity == h->pml_parity) exec = r.exec;
+    if (!exec) {
+      // everything a captured launch may allocate or upload must exist before the capture starts
+      if (ensure_second_set(h)) return -1;
+      if (any_pml(h) && 64 * (h->rows_f + 1) <= 512) {
+        const int pml_in = (h->pml_fused < 0 ? 7 : h->pml_fused) & pml_in_sweep_mask(h);
+        if (pml_in && ensure_pml_blocks(h, pml_in)) return -1;
+      }
+      if (!h->step_dev && dev_alloc(h, &h->step_dev, 1)) return -1;
+      const float* set0 = h->f.ex;
+      const int par0 = h->pml_parity;
+      if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); graph_ok = false; return 1; }
+      h->step_dev_mode = true;
+      int rc = 0;
+      for (int q = 0; q < 2 && !rc; ++q) { h->step_dev_off = q; rc = fused_one(n + q, false); }
+      h->step_dev_mode = false;
+      if (!rc) hipLaunchKernelGGL(step_counter_kernel, dim3(1), dim3(1), 0, st, h->step_dev, 2LL, 1);
+      hipGraph_t graph = nullptr;
+      const hipError_t ee = hipStreamEndCapture(st, &graph);
+      if (rc) { if (graph) hipGraphDestroy(graph); return -1; }
+      if (ee != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (graph) hipGraphDestroy(graph);
+        graph_ok = false;
+        return h->f.ex == set0 && h->pml_parity == par0 ? 1 : fail(h, "fdtd_run: graph capture failed half way");
+      }
+      hipGraphDestroy(graph);
+      graphs.push_back({set0, par0, exec});
+    }
+    if (h->step_dev_value != n) hipLaunchKernelGGL(step_counter_kernel, dim3(1), dim3(1), 0, st, h->step_dev, n, 0);
+    if (hipGraphLaunch(exec, st) != hipSuccess) return fail(h, "hipGraphLaunch failed: %s", hipGetErrorString(hipGetLastError()));
+    h->step_dev_value = n + 2;
+    h->graph_pairs++;
+    return 0;
+  };
   int64_t done = 0;
   for (; done < n_steps; ++done) {
     const long long n = h->step;
@@ -1983,55 +2105,19 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       if (tb_pair(n)) return -1;
       h->step = n + 2;
       ++done;                                              // (the loop header counts the second step)
-    } else if (fused) {
-      // H-side corrections are additive: pre-apply them to H^{n-1/2}; E-side ones follow the sweep.
-      // With pml_in the CPML recursions run inside the sweep (same arithmetic, no slab kernels).
-      // pml_in = axes whose recursions run inside the sweep (default: all that have layers; FDTD_OPT_PML_FUSED
-      // = 0 keeps the slab kernels, any other mask selects axes).  Inside the sweep the field values a slab
-      // kernel would re-read and re-write stay in registers: only psi moves (32 B per cell and axis membership).
-      int pml_in = 0;
-      if (any_pml(h) && 64 * (h->rows_f + 1) <= 512)
-        pml_in = (h->pml_fused < 0 ? 7 : h->pml_fused) & pml_in_sweep_mask(h);
-      launch_damp(h, false, 0, nz, st);
-      launch_sources(h, false, n, 0, nz, st);
-      launch_pml(h, false, 0, nz, st, 7 & ~pml_in);
-      advance_tfsf_aux(h, false, n, st);
-      if (h->cfg.bc[4] == FDTD_BC_PERIODIC) fill_ghost_h(h, st);   // ghost(-1) must carry the pre-corrections too
-      // small grids are bound by dependent launches, not by occupancy: one launch of the all-axes instantiation
-      const bool split = h->pml_split < 0 ? n_cells(h) >= (1LL << 24) : h->pml_split != 0;
-      if ((pml_in & 6) == 0 || !split) {
-        if (launch_fused(h, st, pml_in)) return -1;
-      } else {
-        // The instantiation that carries the y / z recursions holds their psi values in registers from the
-        // top of a plane (occupancy 2-3); the one most tiles need carries x only.  Three launches over
-        // disjoint tiles, the two small ones on the second stream, concurrent with the big one:
-        //   (1) planes of the z slabs (+1 plane: the next chunk's prologue must not see a slab), all rows   [x y z]
-        //   (2) planes in between: bottom and top tile rows (a row or the halo row in a y slab)              [x y]
-        //   (3) planes in between, middle tile rows                                                         [x]
-        const int R = h->rows_f, nby_all = (h->g.ny + R - 1) / R;
-        const PmlAxisDev &py = h->pml[1], &pz = h->pml[2];
-        const bool in_y = (pml_in & 2) && py.ns > 0, in_z = (pml_in & 4) && pz.ns > 0;
-        const int za = (in_z && pz.lo > 0) ? std::min(nz, pz.lo + 1) : 0;
-        const int zc = (in_z && pz.hi0 < nz) ? std::max(za, pz.hi0) : nz;
-        const int ty_a = (in_y && py.lo > 0) ? std::min(nby_all, py.lo / R + 1) : 0;
-        const int ty_c = (in_y && py.hi0 < h->g.ny) ? std::max(ty_a, py.hi0 / R) : nby_all;
-        HIPCHK(h, hipEventRecord(h->ev_h_int, st));
-        HIPCHK(h, hipStreamWaitEvent(cs, h->ev_h_int, 0));
-        if (launch_fused_range(h, 0, za, cs, pml_in, zc, nz, -1, 0, 0, true)) return -1;
-        if (launch_fused_range(h, za, zc, cs, pml_in & 3, 0, 0, ty_a + (nby_all - ty_c), ty_a, ty_c - ty_a, true)) return -1;
-        HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
-        if (launch_fused_range(h, za, zc, st, pml_in & 1, 0, 0, ty_c - ty_a, 0, ty_a)) return -1;
-        HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
-        swap_sets(h);
-        swap_psi_h(h, pml_in);
+    } else if (fused && graph_ok && done + 2 <= n_steps && !rec && !rec_at(n + 1) &&
+               !(h->decay_every > 0 && ((n + 1) % h->decay_every) == 0) && sources_alive(n + 1)) {
+      const int grc = graph_pair(n);
+      if (grc < 0) return -1;
+      if (grc == 0) {                                      // replayed: two steps done
+        h->step = n + 2;
+        ++done;
+      } else {                                             // capture not available: this step directly, no more attempts
+        if (fused_one(n, rec)) return -1;
+        h->step = n + 1;
       }
-      if (rec) record_monitors(h, n, true, st);
-      launch_pml(h, true, 0, nz, st, 7 & ~pml_in);
-      launch_sources(h, true, n, 0, nz, st);
-      launch_damp(h, true, 0, nz, st);
-      launch_ade(h, 0, nz, st);
-      advance_tfsf_aux(h, true, n, st);
-      fill_ghost_fused(h, st);
+    } else if (fused) {
+      if (fused_one(n, rec)) return -1;
       h->step = n + 1;
     } else {
     // ---------------- H phase ----------------
@@ -2125,6 +2211,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   HIPCHK(h, hipStreamSynchronize(st));
   HIPCHK(h, hipStreamSynchronize(cs));
   for (hipEvent_t e : tb_ev) hipEventDestroy(e);
+  for (const GraphRec& r : graphs) hipGraphExecDestroy(r.exec);
   HIPCHK(h, hipGetLastError());
   float ms = 0.f;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
@@ -2342,6 +2429,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_LDS_PAD: if (value < 0 || value > 120000) break; h->lds_pad = value; return 0;
     case FDTD_OPT_TBLOCK: h->tblock = value < 0 ? -1 : value; return 0;
     case FDTD_OPT_EDGE_ZCHUNK: h->edge_zchunk = value < 0 ? -1 : value; return 0;
+    case FDTD_OPT_GRAPH: h->use_graph = value < 0 ? -1 : (value != 0); return 0;
     case FDTD_OPT_PML_SPLIT: h->pml_split = value < 0 ? -1 : (value != 0); return 0;
     case FDTD_OPT_FUSED_LB: if (value != 0 && value != 256 && value != 512 && value != 1024) break; h->fused_lb = value; return 0;
     default: break;
@@ -2362,6 +2450,7 @@ int fdtd_get_stats(FdtdSolver* h, FdtdStats* out) {
   out->stream_retries = h->stream_retries;
   out->two_step_pairs = h->two_step_pairs;
   out->tblock_planes = h->tblock_used;
+  out->graph_pairs = h->graph_pairs;
   return 0;
 }
 

@@ -1367,14 +1367,18 @@ __global__ __launch_bounds__(256) void ade_kernel(float* e, const uint32_t* cell
 // K5  sources
 // =============================================================================================
 // F[comp][cell] += w_re * Re(wave[n]) - w_im * Im(wave[n])
+// (time step n = step, or *step_dev + step when the launch is a node of a captured graph: a graph bakes its kernel
+//  arguments, so the step counter of a replayed step pair lives in device memory, fdtd_capi.hip graph_pair)
 __global__ __launch_bounds__(256) void point_source_kernel(float* f0, float* f1, float* f2, const int32_t* comp,
                                                             const uint32_t* cell, const float* w_re,
                                                             const float* w_im, const float2* wave, long long step,
-                                                            long long n, long long zlo, long long zhi) {
+                                                            long long n, long long zlo, long long zhi,
+                                                            const long long* step_dev) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const long long p = cell[t];
   if (p < zlo || p >= zhi) return;
+  if (step_dev) step += *step_dev;
   const float2 a = wave[step];
   const int c = comp[t] % 3;
   float* f = (c == 0) ? f0 : (c == 1 ? f1 : f2);
@@ -1408,11 +1412,16 @@ __global__ void tfsf_aux_h_kernel(float* h1, const float* e1, const float* ah, c
 
 // single workgroup: interior update (the grid ends in matched lossy pads; end nodes stay 0), soft source
 __global__ void tfsf_aux_e_kernel(float* e1, const float* h1, const float* ae, const float* be, int n_aux,
-                                  int src_cell, const float* wave, long long step) {
+                                  int src_cell, const float* wave, long long step, const long long* step_dev) {
   for (int i = 1 + threadIdx.x; i < n_aux; i += blockDim.x)
     e1[i] = ae[i] * e1[i] - be[i] * (h1[i] - h1[i - 1]);
   __syncthreads();
-  if (threadIdx.x == 0) e1[src_cell] += wave[step];
+  if (threadIdx.x == 0) e1[src_cell] += wave[step_dev ? *step_dev + step : step];
+}
+
+// the device-side step counter of captured step pairs: set (when the host stepped outside a graph) / advanced (last node)
+__global__ void step_counter_kernel(long long* step_dev, long long value, int add) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *step_dev = add ? *step_dev + value : value;
 }
 
 // =============================================================================================
