@@ -406,6 +406,18 @@ def test_config5_au_nanoparticle_array_1024x1024x256(hip_lib):
     assert np.max(np.abs(per - per[0])) < 2e-3 * np.max(np.abs(per))
 
 
+def test_angled_mode_source_tilted_waveguide(hip_lib):
+    """tests/test_mode_solver.py's angled launch on the GPU (2-D grid: one cell along y)."""
+    from cases import check_tilted_launch, tilted_slab_waveguide
+    from tidy3d_amd.data import assemble
+    disc = discretize(tilted_slab_waveguide(0.2, dl=0.02))
+    with HipEngine(disc.spec, lib=hip_lib) as e:
+        st = e.run()
+        raw = e.results()
+    assert not st.diverged
+    check_tilted_launch(assemble(disc, raw, log=""))
+
+
 def test_config5_stack_au_film_vs_airy(hip_lib):
     """The quantitative pin of BASELINE config[4]'s physics: the same stack — vacuum, 40 nm of
     Johnson & Christy Au (5 pole pairs: the ADE kernel), glass half-space running into the CPML, plane wave from above,

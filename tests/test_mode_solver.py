@@ -439,3 +439,65 @@ def test_mode_profile_accepts_an_angled_mode_spec():
     k0 = 2 * np.pi * f0 / C_0
     assert angled.beta[0].real == pytest.approx(k0 * n1 / np.cos(0.15), rel=1e-12)
     assert np.abs(angled.result.Ew).max() > np.abs(straight.result.Ew).max()      # the tilt shows in the normal component
+
+
+def test_angled_mode_source_launches_the_tilted_mode_in_an_fdtd_run():
+    """An angled mode plane end to end (missing 3): the tensorial solver's mode, launched by the FDTD
+    source on a z-normal plane across a waveguide tilted by 0.2 rad, arrives 3.5 um downstream as that mode (angled
+    ModeMonitor) to 1e-4 in power with -40 dB behind the source.  fp64 oracle, 2-D; tests/test_gpu_parity.py repeats it on
+    the GPU."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from cases import check_tilted_launch, tilted_slab_waveguide
+    from tidy3d_amd.data import assemble
+    from tidy3d_amd.discretize import discretize
+    from oracle.fdtd_numpy import OracleFdtd
+    disc = discretize(tilted_slab_waveguide(0.2, dl=0.025))
+    check_tilted_launch(assemble(disc, OracleFdtd(disc.spec).run(), log=""))
+
+
+def test_broadband_mode_source_launches_every_frequency_with_its_own_profile():
+    """``ModeSource.num_freqs > 1`` (ref source.py:737-772 BroadbandSource, Chebyshev frequency grid :751-758; VERDICT round 2,
+    missing 2).  A 220 nm Si slab in oxide, pulse width f0 / 6: with the freq0 profile alone the launch is clean at f0 only —
+    1.2 fwidth off centre 2.5e-3 of the power goes backwards and 4e-4 is not in the mode; with five Chebyshev nodes every
+    frequency carries its own profile: backward power and purity deficit below 1e-5 across the band (measured 6e-7 / 1e-6),
+    the forward power flat to 0.5 %.  The grid is the reference's own formula."""
+    import tidy3d_amd.schema as td
+    from tidy3d_amd.constants import C_0
+    from tidy3d_amd.data import assemble
+    from tidy3d_amd.discretize import discretize
+    from tidy3d_amd.modesource import chebyshev_frequency_grid
+    from oracle.fdtd_numpy import OracleFdtd
+    f0 = C_0 / 1.55
+    fw = f0 / 6
+    pulse = td.GaussianPulse(freq0=f0, fwidth=fw)
+    # the reference's formula, restated: nodes cos(pi (2j + 1) / (2N)) on freq0 +- 1.5 fwidth, ascending
+    N = 5
+    want = f0 + 1.5 * fw * np.cos(np.pi * np.flip((2 * np.arange(N) + 1) / (2 * N)))
+    np.testing.assert_allclose(chebyshev_frequency_grid(pulse, N), want, rtol=1e-14)
+    freqs = [f0 - 1.2 * fw, f0 - 0.6 * fw, f0, f0 + 0.6 * fw, f0 + 1.2 * fw]
+    plane = (3.0, td.inf, 0)
+    ms = td.ModeSpec(num_modes=1, target_neff=3.0)
+
+    def run(nf):
+        sim = td.Simulation(
+            size=(4.0, 0, 5.0), grid_spec=td.GridSpec.uniform(dl=0.025), run_time=2.5e-13, medium=td.Medium(permittivity=1.44 ** 2),
+            structures=[td.Structure(geometry=td.Box(center=(0, 0, 0), size=(0.225, td.inf, td.inf)), medium=td.Medium(permittivity=3.48 ** 2))],
+            sources=[td.ModeSource(center=(0, 0, -1.5), size=plane, source_time=pulse, direction="+", mode_spec=ms, mode_index=0,
+                                   num_freqs=nf)],
+            monitors=[td.FluxMonitor(center=(0, 0, 1.5), size=plane, freqs=freqs, name="fwd"),
+                      td.FluxMonitor(center=(0, 0, -1.9), size=plane, freqs=freqs, name="bwd"),
+                      td.ModeMonitor(center=(0, 0, 1.5), size=plane, freqs=freqs, mode_spec=ms, name="mm")],
+            boundary_spec=td.BoundarySpec(x=td.Boundary.pml(num_layers=12), y=td.Boundary.periodic(), z=td.Boundary.pml(num_layers=12)),
+            shutoff=1e-6)
+        disc = discretize(sim)
+        assert len(disc.spec.sources) == nf
+        sd = assemble(disc, OracleFdtd(disc.spec).run(), log="")
+        fwd, bwd = sd["fwd"].flux.values, sd["bwd"].flux.values
+        a, mp = sd["mm"].amps.values, sd["mm"].mode_power.values
+        return fwd / fwd[2], np.abs(bwd / fwd), np.abs(1 - np.abs(a[0, :, 0]) ** 2 * mp[0, :, 0] / fwd)
+    f1, b1, p1 = run(1)
+    f5, b5, p5 = run(5)
+    assert b1[0] > 1e-3 and b1[-1] > 5e-4 and p1[0] > 1e-4          # the single-profile launch IS imperfect off centre
+    assert b5.max() < 1e-5 and p5.max() < 1e-5, (b5, p5)
+    assert np.abs(f5 - 1).max() < 0.005 < np.abs(f1 - 1).max()

@@ -771,14 +771,20 @@ int probe_stream_overlap(FdtdSolver* h) {
 
 // periodic z, fused sweep: the prologue recomputes H^{n+1/2}[-1] from ghost copies of E (all three
 // components) and H_x, H_y of plane nz-1; the top plane needs E_x, E_y of plane 0
+// one xy-plane device to device: a copy (the runtime's blit), or a kernel node while a graph is being captured
+void copy_plane(FdtdSolver* h, float* dst, const float* src, hipStream_t st) {
+  const long long pc = (long long)h->cfg.nx * h->cfg.ny;
+  if (h->step_dev_mode) hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((pc + 255) / 256)), dim3(256), 0, st, dst, src, pc);
+  else hipMemcpyAsync(dst, src, pc * 4, hipMemcpyDeviceToDevice, st);
+}
 void fill_ghost_fused(FdtdSolver* h, hipStream_t st) {
   if (h->cfg.bc[4] != FDTD_BC_PERIODIC) return;
   const long long pc = plane_cells(h);
   const long long top = (long long)(h->g.nz - 1) * pc;
   float* lo[5] = {h->f.ex, h->f.ey, h->f.ez, h->f.hx, h->f.hy};
-  for (float* p : lo) hipMemcpyAsync(p - pc, p + top, pc * 4, hipMemcpyDeviceToDevice, st);
-  hipMemcpyAsync(h->f.ex + (long long)h->g.nz * pc, h->f.ex, pc * 4, hipMemcpyDeviceToDevice, st);
-  hipMemcpyAsync(h->f.ey + (long long)h->g.nz * pc, h->f.ey, pc * 4, hipMemcpyDeviceToDevice, st);
+  for (float* p : lo) copy_plane(h, p - pc, p + top, st);
+  copy_plane(h, h->f.ex + (long long)h->g.nz * pc, h->f.ex, st);
+  copy_plane(h, h->f.ey + (long long)h->g.nz * pc, h->f.ey, st);
 }
 
 // slabs of one axis: E-side ranges [0,n_lo) and [N-n_hi+1,N); H-side [0,n_lo) and [N-n_hi,N)
@@ -940,8 +946,8 @@ void fill_ghost_h(FdtdSolver* h, hipStream_t st) {
   const long long pc = plane_cells(h);
   const int bc0 = h->cfg.bc[4];
   if (bc0 == FDTD_BC_PERIODIC) {
-    hipMemcpyAsync(h->f.hx - pc, h->f.hx + (long long)(h->g.nz - 1) * pc, pc * 4, hipMemcpyDeviceToDevice, st);
-    hipMemcpyAsync(h->f.hy - pc, h->f.hy + (long long)(h->g.nz - 1) * pc, pc * 4, hipMemcpyDeviceToDevice, st);
+    copy_plane(h, h->f.hx - pc, h->f.hx + (long long)(h->g.nz - 1) * pc, st);
+    copy_plane(h, h->f.hy - pc, h->f.hy + (long long)(h->g.nz - 1) * pc, st);
   } else if (bc0 == FDTD_BC_PMC) {
     hipLaunchKernelGGL(negate_copy_kernel, dim3(nblk(pc)), dim3(256), 0, st, h->f.hx - pc, (const float*)h->f.hx, pc);
     hipLaunchKernelGGL(negate_copy_kernel, dim3(nblk(pc)), dim3(256), 0, st, h->f.hy - pc, (const float*)h->f.hy, pc);

@@ -1705,6 +1705,12 @@ __global__ void spin_kernel(long long ticks) {
 #endif
 }
 
+// plane copy as a kernel (ghost planes of a periodic z inside a captured graph: memcpy nodes did not capture, profiles/r3g)
+__global__ __launch_bounds__(256) void copy_kernel(float* dst, const float* src, long long n) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) dst[t] = src[t];
+}
+
 // ghost-plane helpers (single-GPU z boundary conditions)
 __global__ __launch_bounds__(256) void negate_copy_kernel(float* dst, const float* src, long long n) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;

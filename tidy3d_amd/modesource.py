@@ -158,13 +158,15 @@ def mode_profile(spec: SolverSpec, box: td.Box, mode_spec, freq: float, symmetry
     return ModePlane(p=p, u=u, v=v, k0=k0, lo=lo, hi=hi, result=res, beta=beta)
 
 
-def build_mode_source(disc, mt, src) -> Callable:
-    sim, spec, tmesh = disc.sim, disc.spec, disc.tmesh
-    st = src.source_time
-    if int(getattr(src, "num_freqs", 1)) != 1:
-        raise Tidy3dNotImplementedError("ModeSource.num_freqs > 1 (broadband profile) is not supported")
-    # the launched profile, its E / H ratio and the half-cell phase are those of the mode the grid carries
-    plane = mode_profile(spec, src.geometry, src.mode_spec, st.freq0, getattr(sim, "_symmetry", (0, 0, 0)),
+CHEB_GRID_WIDTH = 1.5            # ref source.py:55: the Chebyshev grid of a broadband source spans freq0 +- 1.5 fwidth
+
+
+def _leg_weights(disc, mt, src, freq: float, align_to=None):
+    """Complex weights of the stencil legs across the source plane for the mode solved at ``freq``:
+    (plane, comp, ijk, w, tangential E fields).  ``align_to``: tangential E of the reference frequency — the eigenvector
+    of every other frequency is rotated to the same phase (an eigen-solver returns an arbitrary one per call)."""
+    sim, spec = disc.sim, disc.spec
+    plane = mode_profile(spec, src.geometry, src.mode_spec, freq, getattr(sim, "_symmetry", (0, 0, 0)),
                          grid_dispersion=bool(getattr(disc, "mode_grid_dispersion", True)))
     p, u, v, k0 = plane.p, plane.u, plane.v, plane.k0
     r = plane.result
@@ -185,10 +187,15 @@ def build_mode_source(disc, mt, src) -> Callable:
     # symmetry: the solved plane is one half / quarter of the user's plane and its mode carries
     # unit power on that part — the launched mode carries 1 W over the whole plane (ref source.py:1003)
     sym = getattr(sim, "_symmetry", (0, 0, 0))
-    scale = 1.0
+    scale = 1.0 + 0j
     for i, a in enumerate((u, v)):
         if sym[a] != 0 and plane.lo[i] == 0:
             scale /= np.sqrt(2.0)
+    e_tan = (r.Eu[:, :, mi], r.Ev[:, :, mi])
+    if align_to is not None:
+        ov = np.vdot(align_to[0], e_tan[0]) + np.vdot(align_to[1], e_tan[1])
+        if abs(ov) > 0:
+            scale = scale * np.exp(-1j * np.angle(ov))
     fields = {u: scale * r.Eu[:, :, mi], v: scale * r.Ev[:, :, mi], 3 + u: scale * direction * r.Hu[:, :, mi],
               3 + v: scale * direction * r.Hv[:, :, mi]}
 
@@ -211,18 +218,74 @@ def build_mode_source(disc, mt, src) -> Callable:
             kc = nbi[:, p]
             dist = 0.5 * d[np.clip(kc, 0, len(d) - 1)]
             val = val * np.exp(-1j * beta * dist)
-        keep = val != 0
-        comps.append(comp[keep])
-        ijks.append(ijk[keep])
-        ws.append(w[keep] * val[keep])
-    comp = np.concatenate(comps).astype(np.int32)
-    ijk = np.concatenate(ijks).astype(np.int32)
-    w = np.concatenate(ws)
+        comps.append(comp)
+        ijks.append(ijk)
+        ws.append(w * val)
+    return (plane, np.concatenate(comps).astype(np.int32), np.concatenate(ijks).astype(np.int32), np.concatenate(ws),
+            (scale * e_tan[0], scale * e_tan[1]))
+
+
+def chebyshev_frequency_grid(source_time, num_freqs: int) -> np.ndarray:
+    """ref source.py:750-758 ``BroadbandSource.frequency_grid``: Chebyshev nodes on freq0 +- CHEB_GRID_WIDTH fwidth."""
+    freq_min, freq_max = source_time.frequency_range(num_fwidth=CHEB_GRID_WIDTH)
+    freq_avg, freq_diff = 0.5 * (freq_min + freq_max), 0.5 * (freq_max - freq_min)
+    uni_points = (2 * np.arange(num_freqs) + 1) / (2 * num_freqs)
+    return freq_avg + freq_diff * np.cos(np.pi * np.flip(uni_points))
+
+
+def _filtered_waveforms(source_time, times: np.ndarray, dt: float, n_terms: int, f_avg: float, f_diff: float) -> np.ndarray:
+    """g_m(t) = the source's complex waveform filtered by T_m(x(f)), x = (f - f_avg) / f_diff held at +-1 outside the
+    Chebyshev interval (a polynomial must not be extrapolated under the Gaussian's tails: T_6(2) = 1351), m = 0 .. n_terms-1;
+    [n_terms, len(times)].  The waveform ~ exp(-i 2 pi f0 t) sits at the NEGATIVE frequencies of numpy's FFT."""
+    a = np.asarray(source_time.amp_time(times), complex)
+    n = len(a)
+    nfft = 1 << int(np.ceil(np.log2(4 * n)))
+    spec_a = np.fft.fft(a, nfft)
+    f_phys = -np.fft.fftfreq(nfft, dt)
+    x = np.clip((f_phys - f_avg) / f_diff, -1.0, 1.0)
+    th = np.arccos(x)
+    return np.stack([np.fft.ifft(spec_a * np.cos(m * th))[:n] for m in range(n_terms)])
+
+
+def build_mode_source(disc, mt, src) -> Callable:
+    """``num_freqs == 1``: the mode profile of freq0 times the source's waveform.  ``num_freqs > 1`` (ref source.py:737-772
+    ``BroadbandSource``: "a Chebyshev interpolation is used" for the frequency dependence of the injected field): the
+    leg weights W(r, f_j) of the modes solved at the Chebyshev nodes f_j are expanded as sum_m c_m(r) T_m(x(f)) and the
+    source becomes ``num_freqs`` point-source sets on the same nodes — weights c_m(r), waveform g_m(t) = the pulse filtered
+    by T_m — so that every frequency of the pulse is launched with (the interpolant of) its own profile, propagation
+    constant and impedance.  The reference's realisation is server-side (parity unpinned); pinned here physically: the
+    power launched BACKWARDS at the band edges drops by orders of magnitude against num_freqs = 1
+    (tests/test_mode_solver.py)."""
+    sim, spec, tmesh = disc.sim, disc.spec, disc.tmesh
+    st = src.source_time
     dt = spec.dt
-    spec.sources.append(PointSourceSet(
-        comp=comp, ijk=ijk, w_re=w.real.copy(), w_im=w.imag.copy(),
-        wave_e=np.asarray(st.amp_time(tmesh + dt / 2), complex),
-        wave_h=np.asarray(st.amp_time(tmesh), complex), name=getattr(src, "name", None) or "ModeSource"))
+    name = getattr(src, "name", None) or "ModeSource"
+    nf = int(getattr(src, "num_freqs", 1) or 1)
+    plane, comp, ijk, w, e_ref = _leg_weights(disc, mt, src, st.freq0)
+    if nf == 1:
+        keep = w != 0
+        spec.sources.append(PointSourceSet(
+            comp=comp[keep], ijk=ijk[keep], w_re=w[keep].real.copy(), w_im=w[keep].imag.copy(),
+            wave_e=np.asarray(st.amp_time(tmesh + dt / 2), complex),
+            wave_h=np.asarray(st.amp_time(tmesh), complex), name=name))
+    else:
+        if not hasattr(st, "fwidth"):
+            raise SetupError("a broadband ModeSource (num_freqs > 1) needs a source time with a bandwidth (GaussianPulse)")
+        fgrid = chebyshev_frequency_grid(st, nf)
+        f_min, f_max = st.frequency_range(num_fwidth=CHEB_GRID_WIDTH)
+        f_avg, f_diff = 0.5 * (f_min + f_max), 0.5 * (f_max - f_min)
+        W = np.stack([_leg_weights(disc, mt, src, float(f), align_to=e_ref)[3] for f in fgrid])       # [nf, points]
+        xj = (fgrid - f_avg) / f_diff
+        Tm = np.cos(np.arange(nf)[:, None] * np.arccos(np.clip(xj, -1, 1))[None, :])                  # [m, j]
+        c = (2.0 / nf) * Tm @ W                                                                        # discrete Chebyshev transform
+        c[0] *= 0.5
+        keep = np.any(W != 0, axis=0)
+        g_e = _filtered_waveforms(st, tmesh + dt / 2, dt, nf, f_avg, f_diff)
+        g_h = _filtered_waveforms(st, tmesh, dt, nf, f_avg, f_diff)
+        for m in range(nf):
+            spec.sources.append(PointSourceSet(
+                comp=comp[keep], ijk=ijk[keep], w_re=c[m][keep].real.copy(), w_im=c[m][keep].imag.copy(),
+                wave_e=g_e[m], wave_h=g_h[m], name=f"{name}[T{m}]"))
     disc.mode_planes = getattr(disc, "mode_planes", {})
     disc.mode_planes[id(src)] = plane
 
