@@ -79,7 +79,7 @@ typedef struct FdtdStats {
   int32_t comm_rank;         /* ncclCommUserRank                                                 */
   int64_t two_step_pairs;    /* step pairs advanced by the slab-interleaved two-step schedule (FDTD_OPT_TBLOCK) in the last fdtd_run */
   int32_t tblock_planes;     /* its slab thickness in planes (0 = schedule off)                  */
-  int32_t reserved0;
+  int32_t reserved0;         /* graph capture diagnostics: 0 = none attempted, 1 = captured, < 0 = -(100 stage + hipError) */
   int64_t graph_pairs;       /* step pairs replayed as captured hipGraphs in the last fdtd_run (FDTD_OPT_GRAPH) */
 } FdtdStats;
 
@@ -231,7 +231,8 @@ enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_R
                                      -1 = default (z-slab ranks, where they share the interior launch's stream: about one wave of
                                      workgroups, at least 2 planes; one GPU: as the interior launch), 0 = as the interior launch, N */
        FDTD_OPT_GRAPH = 15, /* one-GPU fused runs on one stream: steps without monitor records / decay checks replayed as captured
-                               hipGraphs of two steps: -1 = default (grids below 2^22 cells), 0 = never, 1 = whenever possible */
+                               hipGraphs of two steps: -1 = default (off: on ROCm 7.2 replaying costs ~3 us per step MORE than the
+                               launches it replaces, profiles/r3i), 0 = never, 1 = whenever possible */
        FDTD_OPT_LDS_PAD = 10 /* measuring aid: extra dynamic LDS per workgroup of the sweep in bytes (lowers its occupancy) */ };
 int fdtd_set_option(FdtdSolver* h, int key, int value);
 int fdtd_reset(FdtdSolver* h);      /* zero fields, auxiliaries, monitors and the step counter */

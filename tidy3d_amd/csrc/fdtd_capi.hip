@@ -179,12 +179,13 @@ struct FdtdSolver {
   int edge_zchunk = -1;
   // Captured step pairs (small grids): a run of steps without monitor records or field-decay checks is replayed as
   // hipGraphs of TWO steps each (set a -> b -> a, psi parity back where it was), one per (field set, psi parity) state
-  int use_graph = -1;                // -1 = default (grids below 2^22 cells), 0 = never, 1 = whenever possible
+  int use_graph = -1;                // -1 = default (= never: no gain measured, fdtd_run), 0 = never, 1 = whenever possible
   long long* step_dev = nullptr;     // device-side step counter the captured source kernels read
   long long step_dev_value = -1;     // what it holds (host mirror)
   bool step_dev_mode = false;        // launches are being captured: source kernels take step_dev + step_dev_off
   long long step_dev_off = 0;
-  long long graph_pairs = 0;              // z-chunk of the edge launches of a CPML step: -1 = about one wave of workgroups, 0 = as the interior, N = planes
+  long long graph_pairs = 0;
+  int graph_status = 0;              // 0 = no capture attempted, 1 = captured, < 0 = -(100 * stage + hipError) of the failed capture              // z-chunk of the edge launches of a CPML step: -1 = about one wave of workgroups, 0 = as the interior, N = planes
   long long two_step_pairs = 0;
   int tblock_used = 0;
 };
@@ -622,9 +623,13 @@ int probe_placement(FdtdSolver* h, hipStream_t st) {
   const size_t need = 12 * fcount * sizeof(float);
   const int flags = h->cfg.flags;
   h->cfg.flags &= ~FDTD_FLAG_TIME_KERNELS;
-  hipEvent_t e0, e1;
-  hipEventCreate(&e0);
-  hipEventCreate(&e1);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {      // no timing, no probe: keep what we have
+    if (e0) hipEventDestroy(e0);
+    (void)hipGetLastError();
+    h->cfg.flags = flags;
+    return 0;
+  }
   float best = time_plain_sweeps(h, st, e0, e1);
   h->placement_ms[0] = best;
   float* cur[12];                                 // the set that holds the fields: at most this one and one candidate exist
@@ -647,13 +652,20 @@ int probe_placement(FdtdSolver* h, hipStream_t st) {
     const float ms = time_plain_sweeps(h, st, e0, e1);
     h->placement_ms[t + 1] = ms;
     h->placement_tried = t + 1;
-    if (ms < 0.f) { rc = -1; break; }
+    if (ms < 0.f) {                               // (the candidate goes on every exit path: nothing stays allocated until destroy)
+      for (int c = 0; c < 12; ++c) release_buf(h, cand[c]);
+      rc = -1;
+      break;
+    }
     if (ms < best) {                              // the candidate wins: the fields move over, the loser goes
       for (int c = 0; c < 12 && !rc; ++c)
         if (hipMemcpyAsync(cand[c], cur[c], fcount * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
           rc = fail(h, "probe_placement: copy failed");
       if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail(h, "probe_placement: %s", hipGetErrorString(hipGetLastError()));
-      if (rc) break;
+      if (rc) {
+        for (int c = 0; c < 12; ++c) release_buf(h, cand[c]);
+        break;
+      }
       for (int c = 0; c < 12; ++c) { release_buf(h, cur[c]); cur[c] = cand[c]; }
       best = ms;
       h->placement_kept = t + 1;
@@ -1986,7 +1998,8 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   const bool split_now = (h->pml_split < 0 ? n_cells(h) >= (1LL << 24) : h->pml_split != 0) && any_pml(h) &&
                          (((h->pml_fused < 0 ? 7 : h->pml_fused) & pml_in_sweep_mask(h)) & 6) != 0;
   bool graph_ok = fused && !tb_ok && !split_now && !(h->cfg.flags & FDTD_FLAG_TIME_KERNELS) &&
-                  (h->use_graph < 0 ? n_cells(h) < (1LL << 22) : h->use_graph != 0);
+                  h->use_graph > 0;      // on request only: measured on ROCm 7.2 (profiles/r3i) a replayed pair is ~3 us per step
+                                         // SLOWER than launching its kernels (64^3 17.6 -> 20.8, 128^3 28.8 -> 31.4, 200^3 81.5 -> 84.0)
   struct GraphRec { const float* set; int parity; hipGraphExec_t exec; };
   std::vector<GraphRec> graphs;
   h->graph_pairs = 0;
@@ -2009,7 +2022,8 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       if (!h->step_dev && dev_alloc(h, &h->step_dev, 1)) return -1;
       const float* set0 = h->f.ex;
       const int par0 = h->pml_parity;
-      if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); graph_ok = false; return 1; }
+      const hipError_t eb = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+      if (eb != hipSuccess) { (void)hipGetLastError(); graph_ok = false; h->graph_status = -(100 + (int)eb % 100); return 1; }
       h->step_dev_mode = true;
       int rc = 0;
       for (int q = 0; q < 2 && !rc; ++q) { h->step_dev_off = q; rc = fused_one(n + q, false); }
@@ -2018,7 +2032,9 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       hipGraph_t graph = nullptr;
       const hipError_t ee = hipStreamEndCapture(st, &graph);
       if (rc) { if (graph) hipGraphDestroy(graph); return -1; }
-      if (ee != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+      hipError_t ei = hipSuccess;
+      if (ee != hipSuccess || !graph || (ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0)) != hipSuccess) {
+        h->graph_status = ee != hipSuccess ? -(200 + (int)ee % 100) : -(300 + (int)ei % 100);
         (void)hipGetLastError();
         if (graph) hipGraphDestroy(graph);
         graph_ok = false;
@@ -2026,6 +2042,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       }
       hipGraphDestroy(graph);
       graphs.push_back({set0, par0, exec});
+      h->graph_status = 1;
     }
     if (h->step_dev_value != n) hipLaunchKernelGGL(step_counter_kernel, dim3(1), dim3(1), 0, st, h->step_dev, n, 0);
     if (hipGraphLaunch(exec, st) != hipSuccess) return fail(h, "hipGraphLaunch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -2457,6 +2474,7 @@ int fdtd_get_stats(FdtdSolver* h, FdtdStats* out) {
   out->two_step_pairs = h->two_step_pairs;
   out->tblock_planes = h->tblock_used;
   out->graph_pairs = h->graph_pairs;
+  out->reserved0 = h->graph_status;
   return 0;
 }
 

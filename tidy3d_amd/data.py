@@ -496,12 +496,13 @@ def source_spectrum_fn(disc: Discretization, index: Optional[int]) -> Callable:
 
 
 def assemble(disc: Discretization, raw: Dict[str, np.ndarray], log: str = "", diverged: bool = False,
-             n_steps_run: Optional[int] = None, device_lib=None) -> SimulationData:
+             n_steps_run: Optional[int] = None, device_lib=None, device: int = 0) -> SimulationData:
     """Raw monitor buffers (name -> array as returned by the engine / oracle) -> SimulationData.
     ``n_steps_run``: time steps actually taken (a run that stopped on the shutoff criterion or diverged took
     fewer than ``spec.n_steps``): time-domain monitors then keep only the samples that were recorded — steps
     after the stop never happened and must not come back as zeros on the full ``tmesh`` axis.
-    ``device_lib``: the loaded HIP library — projection and diffraction monitors then integrate on the device."""
+    ``device_lib``: the loaded HIP library — projection and diffraction monitors then integrate on the device
+    (``device``: the GPU that ran the solve)."""
     sim, spec = disc.sim, disc.spec
 
     def recorded(steps):
@@ -562,7 +563,7 @@ def assemble(disc: Discretization, raw: Dict[str, np.ndarray], log: str = "", di
             from . import projection
             fn = {"projection_angle": projection.project_angle, "projection_cartesian": projection.project_cartesian,
                   "projection_kspace": projection.project_kspace}[plan.kind]
-            out.append(fn(disc, plan, raw, norm, lib=device_lib))
+            out.append(fn(disc, plan, raw, norm, lib=device_lib, device=device))
         elif plan.kind == "mode_solver":
             from .plugins.mode import ModeSolver
             ms = ModeSolver(simulation=sim, plane=mon.geometry, mode_spec=mon.mode_spec, freqs=mon.freqs,
@@ -572,7 +573,7 @@ def assemble(disc: Discretization, raw: Dict[str, np.ndarray], log: str = "", di
             out.append(md)
         elif plan.kind == "diffraction":
             from . import projection
-            out.append(projection.diffraction(disc, plan, raw, norm, lib=device_lib))
+            out.append(projection.diffraction(disc, plan, raw, norm, lib=device_lib, device=device))
         elif plan.kind == "permittivity":
             out.append(permittivity_data(sim, spec if pfull is None else disc.spec_full,
                                          plan if pfull is None else pfull))

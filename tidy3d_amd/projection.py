@@ -270,7 +270,7 @@ def _package(cls, mon, e_t, e_p, k_f, eta_f, r, shape, coords):
     return cls(monitor=mon, **{k: DataArray(v.reshape(shape), coords) for k, v in comps.items()})
 
 
-def project_angle(disc, plan, raw, norm, lib=None) -> FieldProjectionAngleData:
+def project_angle(disc, plan, raw, norm, lib=None, device: int = 0) -> FieldProjectionAngleData:
     mon = plan.monitor
     freqs = np.asarray(mon.freqs, float)
     theta, phi = np.asarray(mon.theta, float), np.asarray(mon.phi, float)
@@ -281,7 +281,7 @@ def project_angle(disc, plan, raw, norm, lib=None) -> FieldProjectionAngleData:
         pts = r0 * np.stack([np.sin(t) * np.cos(p_), np.sin(t) * np.sin(p_), np.cos(t)], axis=1)
         E, H = _exact_fields(disc, plan, raw, norm, pts)
         return _package_exact(FieldProjectionAngleData, mon, E, H, t, p_, (1, len(theta), len(phi), len(freqs)), coords)
-    e_t, e_p, k_f, eta_f = _far_fields(disc, plan, raw, norm, T.ravel(), P.ravel(), lib=lib)
+    e_t, e_p, k_f, eta_f = _far_fields(disc, plan, raw, norm, T.ravel(), P.ravel(), lib=lib, device=device)
     r = np.full(T.size, float(mon.proj_distance))
     return _package(FieldProjectionAngleData, mon, e_t, e_p, k_f, eta_f, r, (1, len(theta), len(phi), len(freqs)), coords)
 
@@ -296,7 +296,7 @@ class FieldProjectionKSpaceData(FieldProjectionAngleData):
     """ref monitor_data.py FieldProjectionKSpaceData: dims (ux, uy, r, f)."""
 
 
-def project_cartesian(disc, plan, raw, norm, lib=None) -> FieldProjectionCartesianData:
+def project_cartesian(disc, plan, raw, norm, lib=None, device: int = 0) -> FieldProjectionCartesianData:
     """Observation points on a plane at ``proj_distance`` along ``proj_axis`` (ref field_projection.py:665-746)."""
     mon = plan.monitor
     freqs = np.asarray(mon.freqs, float)
@@ -310,11 +310,11 @@ def project_cartesian(disc, plan, raw, norm, lib=None) -> FieldProjectionCartesi
     if not mon.far_field_approx:
         E, H = _exact_fields(disc, plan, raw, norm, np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1))
         return _package_exact(FieldProjectionCartesianData, mon, E, H, theta, phi, X.shape + (len(freqs),), coords)
-    e_t, e_p, k_f, eta_f = _far_fields(disc, plan, raw, norm, theta, phi, lib=lib)
+    e_t, e_p, k_f, eta_f = _far_fields(disc, plan, raw, norm, theta, phi, lib=lib, device=device)
     return _package(FieldProjectionCartesianData, mon, e_t, e_p, k_f, eta_f, r, X.shape + (len(freqs),), coords)
 
 
-def project_kspace(disc, plan, raw, norm, lib=None) -> FieldProjectionKSpaceData:
+def project_kspace(disc, plan, raw, norm, lib=None, device: int = 0) -> FieldProjectionKSpaceData:
     """Observation directions given by the in-plane unit-vector components (ux, uy) around
     ``proj_axis`` (ref field_projection.py:748-829, geometry/base.py:963-985)."""
     mon = plan.monitor
@@ -333,7 +333,7 @@ def project_kspace(disc, plan, raw, norm, lib=None) -> FieldProjectionKSpaceData
         theta, phi = np.arccos(z), np.arctan2(y, x)
     valid = np.isfinite(theta).ravel()
     th, ph = np.where(valid, theta.ravel(), 0.0), np.where(valid, phi.ravel(), 0.0)
-    e_t, e_p, k_f, eta_f = _far_fields(disc, plan, raw, norm, th, ph, lib=lib)
+    e_t, e_p, k_f, eta_f = _far_fields(disc, plan, raw, norm, th, ph, lib=lib, device=device)
     e_t[~valid], e_p[~valid] = np.nan, np.nan              # evanescent directions (ux^2 + uy^2 > 1)
     r = np.full(th.size, float(mon.proj_distance))
     coords = {"ux": ux, "uy": uy, "r": np.atleast_1d(float(mon.proj_distance)), "f": freqs}
@@ -428,7 +428,7 @@ def _medium_at(sim, point):
     return sim.medium, -1
 
 
-def diffraction(disc, plan, raw, norm, lib=None) -> DiffractionData:
+def diffraction(disc, plan, raw, norm, lib=None, device: int = 0) -> DiffractionData:
     """Order amplitudes from the surface-equivalence integrals over ONE period: a periodic sheet of
     currents radiates the plane waves  E_mn = [far-field integrand at the order's direction] /
     (2 A cos(theta_mn))  (A = area of the period; the uniform sheet J_s radiating -eta J_s / 2 is the
@@ -470,7 +470,7 @@ def diffraction(disc, plan, raw, norm, lib=None) -> DiffractionData:
         d = np.zeros((3, uxv.size))                                 # global propagation direction
         d[u], d[v], d[axis] = uxv, uyv, sgn * uz
         th_g, ph_g = np.arccos(np.clip(d[2], -1, 1)), np.arctan2(d[1], d[0])
-        et, ep, _, _ = _far_fields(disc, plan, raw, norm, th_g, ph_g, medium=medium, f_sel=[i_f], lib=lib)
+        et, ep, _, _ = _far_fields(disc, plan, raw, norm, th_g, ph_g, medium=medium, f_sel=[i_f], lib=lib, device=device)
         # global Cartesian field vector, then the local spherical components
         st, ct, sp_, cp = np.sin(th_g), np.cos(th_g), np.sin(ph_g), np.cos(ph_g)
         t_hat = np.stack([ct * cp, ct * sp_, -st])

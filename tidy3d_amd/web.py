@@ -127,7 +127,7 @@ def run(simulation, task_name: Optional[str] = None, folder_name: str = "default
             lines.append("WARNING: field divergence detected, exiting solver.")
     lines += ["", f"Setup time (s):  {setup_s:.4f}", f"Solver time (s): {solve_s:.4f}",
               f"Time-stepping speed (cells/s): {spec.n_cells * steps_done / max(solve_s, 1e-9):.2e}"]
-    sim_data = assemble(disc, raw, log="\n".join(lines), diverged=diverged, n_steps_run=steps_done, device_lib=used_lib)
+    sim_data = assemble(disc, raw, log="\n".join(lines), diverged=diverged, n_steps_run=steps_done, device_lib=used_lib, device=device)
 
     # post-run warnings, ref web/api/tidy3d_stub.py:219-233
     if diverged:
