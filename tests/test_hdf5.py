@@ -233,3 +233,29 @@ def test_projection_data_round_trip(tmp_path):
         for comp in ("Etheta", "Hphi"):
             assert np.array_equal(getattr(back[name], comp).values, getattr(sd[name], comp).values)
             assert getattr(back[name], comp).dims == getattr(sd[name], comp).dims
+
+
+def test_mode_power_survives_the_file(emu_lib, tmp_path):
+    """``ModeData.mode_power`` (what makes |amps|^2 comparable with a FluxMonitor) was dropped by every
+    save / load.  It is stored as an extra DataArray group beside the two the JSON model names (the reference's loader
+    ignores it) and in the .npz dump."""
+    from tidy3d_amd.web import save_npz
+    plane = (td.inf, td.inf, 0)
+    ms = td.ModeSpec(num_modes=2, target_neff=2.0)
+    sim = td.Simulation(
+        size=(24 * DL, 0, 28 * DL), grid_spec=td.GridSpec.uniform(dl=DL), run_time=4e-14, medium=td.Medium(permittivity=2.0),
+        structures=[td.Structure(geometry=td.Box(center=(0, 0, 0), size=(0.3, td.inf, td.inf)), medium=td.Medium(permittivity=6.0))],
+        sources=[td.ModeSource(center=(0, 0, -0.4), size=plane, source_time=PULSE, direction="+", mode_spec=ms, mode_index=0)],
+        monitors=[td.ModeMonitor(center=(0, 0, 0.3), size=plane, freqs=[2.8e14, 3e14], mode_spec=ms, name="mm")],
+        boundary_spec=td.BoundarySpec(x=td.Boundary.pml(num_layers=4), y=td.Boundary.periodic(), z=td.Boundary.pml(num_layers=4)))
+    path = str(tmp_path / "mode.hdf5")
+    sd = run(sim, task_name="mp", verbose=False, lib=emu_lib, n_steps=40, path=path)
+    mp = np.asarray(sd["mm"].mode_power.values)
+    assert mp.shape == (2, 2, 2) and np.all(np.isfinite(mp)) and np.abs(mp).max() > 0
+    back = load(path)
+    np.testing.assert_array_equal(np.asarray(back["mm"].mode_power.values), mp)
+    np.testing.assert_array_equal(np.asarray(back["mm"].amps.values), np.asarray(sd["mm"].amps.values))
+    assert "mode_power" not in json.loads(hdf5io.read_tree(path)["/JSON_STRING"])["data"][0]       # the model stays the reference's
+    save_npz(sd, str(tmp_path / "mode.npz"))
+    z = np.load(str(tmp_path / "mode.npz"))
+    np.testing.assert_array_equal(z["mm/mode_power"], mp)

@@ -431,6 +431,11 @@ def simulation_data_model(sim_data) -> Tuple[dict, Dict[str, Any]]:
         elif kind == "ModeData":
             entry["amps"], entry["n_complex"] = "ModeAmpsDataArray", "ModeIndexDataArray"
             arrays[f"{base}/amps"], arrays[f"{base}/n_complex"] = d.amps, d.n_complex
+            # mode_power (the flux a unit-amplitude mode carries as this monitor measures it; not a field of the
+            # reference's ModeData): an extra DataArray group beside the two the JSON model names — the reference's
+            # loader never looks at it, this package's reader picks it up
+            if getattr(d, "mode_power", None) is not None:
+                arrays[f"{base}/mode_power"] = d.mode_power
         elif kind == "ModeSolverData":
             # ref monitor_data.py ModeSolverData: six ScalarModeFieldDataArrays + n_complex
             entry["symmetry"] = [0, 0, 0]
@@ -543,7 +548,8 @@ def load_simulation_data(path: str):
         elif kind == "FluxTimeData":
             out.append(FluxTimeData(monitor=mon, flux=fields["flux"]))
         elif kind == "ModeData":
-            out.append(ModeData(monitor=mon, amps=fields["amps"], n_complex=fields["n_complex"]))
+            mp = arr(f"{base}/mode_power", "ModeAmpsDataArray") if f"{base}/mode_power/{DATA_ARRAY_VALUE_NAME}" in tree else None
+            out.append(ModeData(monitor=mon, amps=fields["amps"], n_complex=fields["n_complex"], mode_power=mp))
         elif kind == "ModeSolverData":
             from .plugins.mode import ModeSolverData
             out.append(ModeSolverData(monitor=mon, grid_expanded={d: np.asarray(e["grid_expanded"]["boundaries"][d])

@@ -65,7 +65,8 @@ def run(simulation, task_name: Optional[str] = None, folder_name: str = "default
         solver_version: Optional[str] = None, worker_group: Optional[str] = None,
         simulation_type: str = "tidy3d", parent_tasks=None, local_gradient: bool = False,
         *, device: int = 0, n_steps: Optional[int] = None, lib=None,
-        return_tidy3d: Optional[bool] = None, devices=None, _dist_options: Optional[dict] = None) -> SimulationData:
+        return_tidy3d: Optional[bool] = None, devices=None, _dist_options: Optional[dict] = None,
+        mode_grid_dispersion: Optional[bool] = None) -> SimulationData:
     """Solve ``simulation`` on the local MI355X and return its ``SimulationData``.
 
     Cloud-only arguments (``folder_name``, ``callback_url``, ``progress_callback_*``,
@@ -75,7 +76,8 @@ def run(simulation, task_name: Optional[str] = None, folder_name: str = "default
     (``device``), override the number of time steps (``n_steps``, tests/benchmarks) or pass an
     explicitly loaded library (``lib``, tests).  ``devices=[0, 1, ...]``: one worker process per listed GPU, the
     grid split into z-slabs with RCCL ghost-plane exchange (``tidy3d_amd.dist``) — the whole multi-GPU run is this
-    one call."""
+    one call.  ``mode_grid_dispersion``: False launches mode sources with the continuum mode instead of the one the Yee
+    grid propagates (``discretize.MODE_SOURCE_GRID_DISPERSION``, default True; one-GPU runs)."""
     from .engine import HipEngine
 
     sim, was_tidy3d = _as_mirror(simulation)
@@ -95,7 +97,7 @@ def run(simulation, task_name: Optional[str] = None, folder_name: str = "default
     if devices is not None and len(devices) == 1:
         device = int(devices[0])
     t_setup = time.perf_counter()
-    disc = discretize(sim, n_steps=n_steps)
+    disc = discretize(sim, n_steps=n_steps, mode_grid_dispersion=mode_grid_dispersion)
     spec = disc.spec
     lines = [f"Simulation domain Nx, Ny, Nz: {list(spec.shape)}",
              f"Applied symmetries: {tuple(sim.symmetry)}",
@@ -262,6 +264,8 @@ def save_npz(sim_data: SimulationData, path: str) -> None:
         arrays = getattr(d, "field_components", None)
         if arrays is None and hasattr(d, "amps"):
             arrays = {"amps": d.amps, "n_complex": d.n_complex}
+            if getattr(d, "mode_power", None) is not None:
+                arrays["mode_power"] = d.mode_power
         if arrays is None:
             arrays = {"flux": d.flux}
         for k, v in arrays.items():
