@@ -167,6 +167,18 @@ def roofline_entry(st, kr, local_cells, cells, K, elapsed, world, workload, spec
     return r
 
 
+def _v2_traffic(cells):
+    """PMC bytes of one V2 step (its three sweep launches), from profiles/pmc_traffic.json when it was measured on THIS
+    kernel source (hash), scaled from 512^3; else None."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if rec.get("v2_step_bytes") and rec.get("source_hash") == source_hash():
+            return rec["v2_step_bytes"] * cells / 512 ** 3
+    except Exception:
+        pass
+    return None
+
+
 def secondary_workload(HipEngine, L, n, workload, device, args, steps=40, repeats=3):
     """One more single-GPU measurement on the same box: same grid, materials + CPML on all six faces."""
     spec = build_spec(n, steps * (repeats + 2) + 64, workload)
@@ -205,6 +217,7 @@ def secondary_workload(HipEngine, L, n, workload, device, args, steps=40, repeat
                 "sweep_launches_per_step": st.fused_kernel_launches / 10,
                 "sweep_launch_ms_sum_concurrent": st.fused_kernel_ms / 10,
                 "stream_overlap": int(st.stream_overlap),
+                "traffic": _v2_traffic(cells),
                 "bytes_per_cell_own_minimum": own,
                 "whole_step_frac": own * cells * steps / el / HBM_PEAK,
                 "bytes_per_cell_survey_8d": survey,

@@ -281,3 +281,26 @@ def test_captured_step_pairs_small_grid_speed(hip_lib):
     print("\n[graphs] us per step, direct vs captured pairs:", {n: (round(v[0], 1), round(v[1], 1)) for n, v in out.items()})
     for n, v in out.items():
         assert v[1] < 1.5 * v[0] and v[0] < 1.5 * v[1], (n, v)
+
+
+@pytest.mark.parametrize("workload", ["v0", "v1", "v2"])
+def test_store_hints_and_address_space_paths_change_nothing_on_the_device(hip_lib, workload):
+    """non-temporal stores, global-address-space loads and the deferred E / psi stores exist on the
+    device only (the emulator compiles them away).  FDTD_OPT_MEM_HINTS = 0 selects the instantiations without them: same
+    bits on the bench specs at 256^3 (V2 forced onto the three-launch split), 12 steps from random fields."""
+    from bench import build_spec
+    n, steps = 256, 12
+    spec = build_spec(n, steps + 4, workload)
+    init = _bench_init(n, seed_offset=7)
+
+    def run(hints):
+        with HipEngine(spec, lib=hip_lib, axis_shift=0) as e:
+            e.set_option(L.OPT_MEM_HINTS, hints)
+            e.set_option(L.OPT_PML_SPLIT, 1)
+            for c in range(6):
+                e.set_field(c, init[c])
+            e.run(steps)
+            return [e.get_field(c) for c in range(6)]
+    a, b = run(1), run(0)
+    for c in range(6):
+        assert np.array_equal(a[c], b[c]), c

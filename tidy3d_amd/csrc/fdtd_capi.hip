@@ -582,15 +582,20 @@ int launch_fused(FdtdSolver* h, hipStream_t st, int pml_inside) {
 // Placement of the field arrays.  Where the twelve arrays land in device memory moves the sweep by up to 15 % (DESIGN.md
 // section 7; 1.08 ... 1.24 ms per 512^3 step over the 40 engines of profiles/r03d-r03t) and nothing in HIP steers it — but
 // it can be sampled: before its first large run an engine allocates up to `placement_tries` further sets of the
-// twelve arrays, times three plain sweeps on each (the sweep reads one set and writes the other: no side effect) and
+// twelve arrays, times two PAIRS of plain sweeps (a -> b, b -> a: what a run does) on a copy of the live fields in each, and
 // keeps the fastest set, copying the fields over.  Costs ten-odd sweeps and, for their duration, twice the field memory
 // (skipped when that is not free).  For fused runs of at least 2^24 cells (2^22 per rank on z-slabs).  Measured (profiles/
 // r03u_probe_placement_probe.jsonl, 10 engines, 3 candidates each): the set kept is 0.8 ... 8.1 % faster than the first
 // allocations (mean 4 %), and the first allocations never won.
-float time_plain_sweeps(FdtdSolver* h, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-  if (launch_fused_range(h, 0, h->g.nz, st)) return -1.f;              // warm-up
-  hipEventRecord(e0, st);
-  for (int k = 0; k < 3; ++k) if (launch_fused_range(h, 0, h->g.nz, st)) return -1.f;
+// What a run does: PAIRS of sweeps, set a -> b then b -> a.  The two directions read and write different arrays and differ
+// in speed with the placement (one-directional timing said 1.094 ms per sweep where the run then took 1.146 ms per step,
+// profiles/r3j), so both are timed: one warm-up pair, two timed pairs.  Advances the fields of the set it runs on.
+float time_sweep_pairs(FdtdSolver* h, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+  for (int k = 0; k < 6; ++k) {
+    if (k == 2) hipEventRecord(e0, st);
+    if (launch_fused_range(h, 0, h->g.nz, st)) return -1.f;
+    swap_sets(h);
+  }
   hipEventRecord(e1, st);
   if (hipEventSynchronize(e1) != hipSuccess) return -1.f;
   float ms = 0.f;
@@ -630,11 +635,18 @@ int probe_placement(FdtdSolver* h, hipStream_t st) {
     h->cfg.flags = flags;
     return 0;
   }
-  float best = time_plain_sweeps(h, st, e0, e1);
-  h->placement_ms[0] = best;
+  // Every set is timed on the SAME data — a copy of the live fields — in the mode a run uses (time_sweep_pairs); the
+  // live set is timed in place, once, and restored from the first candidate's copy.
+  float best = -1.f;
   float* cur[12];                                 // the set that holds the fields: at most this one and one candidate exist
   for (int c = 0; c < 6; ++c) { cur[c] = h->fbase[c]; cur[6 + c] = h->fbase2[c]; }
-  int rc = best < 0.f ? -1 : 0;
+  auto copy6 = [&](float* const* dst, float* const* src) -> int {
+    for (int c = 0; c < 6; ++c)
+      if (hipMemcpyAsync(dst[c], src[c], fcount * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return fail(h, "probe_placement: copy failed");
+    return 0;
+  };
+  int rc = 0;
   for (int t = 0; t < h->placement_tries && t < 3 && !rc; ++t) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + need / 4) break;
@@ -647,30 +659,38 @@ int probe_placement(FdtdSolver* h, hipStream_t st) {
       h->err.clear();
       break;
     }
+    auto drop_cand = [&]() { for (int c = 0; c < 12; ++c) release_buf(h, cand[c]); };
+    rc = copy6(cand, cur);                        // the live fields (E, H of the current set), ghost planes included
+    if (!rc && best < 0.f) {                      // the incumbent, in place; its fields come back from the copy
+      best = time_sweep_pairs(h, st, e0, e1);
+      h->placement_ms[0] = best;
+      if (best < 0.f) rc = -1;
+      if (!rc) rc = copy6(cur, cand);
+    }
+    if (rc) { drop_cand(); break; }
     for (int c = 0; c < 6; ++c) { h->fbase[c] = cand[c]; h->fbase2[c] = cand[6 + c]; }
     set_field_views(h);
-    const float ms = time_plain_sweeps(h, st, e0, e1);
+    const float ms = time_sweep_pairs(h, st, e0, e1);
+    for (int c = 0; c < 6; ++c) { h->fbase[c] = cur[c]; h->fbase2[c] = cur[6 + c]; }
+    set_field_views(h);
     h->placement_ms[t + 1] = ms;
     h->placement_tried = t + 1;
-    if (ms < 0.f) {                               // (the candidate goes on every exit path: nothing stays allocated until destroy)
-      for (int c = 0; c < 12; ++c) release_buf(h, cand[c]);
-      rc = -1;
-      break;
-    }
-    if (ms < best) {                              // the candidate wins: the fields move over, the loser goes
-      for (int c = 0; c < 12 && !rc; ++c)
-        if (hipMemcpyAsync(cand[c], cur[c], fcount * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
-          rc = fail(h, "probe_placement: copy failed");
+    if (ms < 0.f) { drop_cand(); rc = -1; break; }
+    // The candidate wins only by a clear margin.  Measured on 8 engines of one process (profiles/r3k): moves for a 0.6 ... 1.8 %
+    // advantage in the probe ended 0.6 ... 2 % SLOWER in the run that followed, moves for 3.4 % and 5.8 % ended 2.6 % and
+    // 4.5 % faster (first allocations 1.113 / 1.145 ms per step -> 1.084 / 1.093): the probe is there to escape a bad
+    // placement, not to polish a good one.
+    if (ms < 0.98f * best) {
+      rc = copy6(cand, cur);
+      if (!rc) rc = copy6(cand + 6, cur + 6);
       if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail(h, "probe_placement: %s", hipGetErrorString(hipGetLastError()));
-      if (rc) {
-        for (int c = 0; c < 12; ++c) release_buf(h, cand[c]);
-        break;
-      }
+      if (rc) { drop_cand(); break; }
       for (int c = 0; c < 12; ++c) { release_buf(h, cur[c]); cur[c] = cand[c]; }
       best = ms;
       h->placement_kept = t + 1;
     } else {
-      for (int c = 0; c < 12; ++c) release_buf(h, cand[c]);
+      if (hipStreamSynchronize(st) != hipSuccess) rc = fail(h, "probe_placement: %s", hipGetErrorString(hipGetLastError()));
+      drop_cand();
     }
   }
   for (int c = 0; c < 6; ++c) { h->fbase[c] = cur[c]; h->fbase2[c] = cur[6 + c]; }
