@@ -109,8 +109,16 @@ def surface_legs(spec: SolverSpec, mt, lo, hi, inc_e, inc_h):
             m &= (ijk[:, a] >= lo[a]) & (ijk[:, a] <= (hi[a] - 1 if oc else hi[a]))
         return m
 
+    _cand_cache = {}
+
     def candidates(comp):
-        """Nodes of `comp` within one cell of the box surface (union of 6 face slabs), clipped."""
+        """Nodes of `comp` within one cell of the box surface (union of 6 face slabs), clipped.  (The node set does not
+        depend on the component — only the box does — and both curl terms of a component ask for it: built once.)"""
+        if "nodes" not in _cand_cache:
+            _cand_cache["nodes"] = _candidates()
+        return _cand_cache["nodes"]
+
+    def _candidates():
         rng = [np.arange(max(lo[a] - 1, 0), min(hi[a] + 2, N[a])) for a in range(3)]
         pts = []
         for a in range(3):
