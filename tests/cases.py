@@ -126,6 +126,17 @@ def tfsf_box(N=(20, 16, 16)):
                 monitors=mons)
 
 
+def tfsf_angled_box(N=(20, 16, 16)):
+    """TFSF box at oblique incidence (incident grid along k_hat, cubic interpolation: four aux entries per leg) around a
+    dielectric sphere."""
+    src = td.TFSF(center=(0, 0, 0), size=(0.5, 0.4, 0.4), source_time=PULSE, injection_axis=2, direction="+", pol_angle=0.4,
+                  angle_theta=0.45, angle_phi=0.8)
+    structures = [td.Structure(geometry=td.Sphere(center=(0, 0, 0), radius=0.12), medium=td.Medium(permittivity=4.0))]
+    mons = [td.FieldTimeMonitor(center=(0, 0, 0), size=(0.7, 0.6, 0.6), name="t", colocate=False, interval=7),
+            td.FluxMonitor(center=(0, 0, 0), size=(0.7, 0.6, 0.6), freqs=[2.5e14, 3e14], name="sca")]
+    return _sim(N, td.BoundarySpec.all_sides(td.PML(num_layers=4)), structures, sources=[src], monitors=mons)
+
+
 def planewave_periodic(N=(8, 12, 20)):
     """PlaneWave launched along -x through a periodic cross-section, PML along x."""
     src = td.PlaneWave(center=(0.2, 0, 0), size=(0, td.inf, td.inf), source_time=PULSE, direction="-",
@@ -276,7 +287,7 @@ def wide_flat(N=(128, 128, 16)):
 CASES = {
     "bloch_box": bloch_box, "bloch_planewave": bloch_planewave, "bloch_xy_pml_z": bloch_xy_pml_z, "bloch_x_only": bloch_x_only,
     "two_d": two_d, "one_d": one_d, "absorber_mix": absorber_mix, "absorber_odd_rows": absorber_odd_rows,
-    "tfsf_box": tfsf_box, "planewave_periodic": planewave_periodic, "au_array": au_array,
+    "tfsf_box": tfsf_box, "tfsf_angled_box": tfsf_angled_box, "planewave_periodic": planewave_periodic, "au_array": au_array,
     "pec_box": pec_box, "pec_box_vec": pec_box_vec, "periodic_box": periodic_box,
     "periodic_box_tall": periodic_box_tall,
     "pml_box": pml_box, "stable_pml_box": stable_pml_box, "media_mix": media_mix,

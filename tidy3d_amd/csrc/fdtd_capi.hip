@@ -222,7 +222,12 @@ int dev_alloc(FdtdSolver* h, T** out, size_t count, bool zero_fill = true) {
   size_t bytes = count * sizeof(T);
   if (bytes == 0) bytes = sizeof(T);
   HIPCHK(h, hipMalloc(&p, bytes));
-  if (zero_fill) HIPCHK(h, hipMemset(p, 0, bytes));
+  if (zero_fill) {
+    // hipMemset on device memory may return before the fill has run, and it runs on the NULL stream — which the engine's
+    // non-blocking streams do not wait for.  Every allocation is handed out filled.
+    HIPCHK(h, hipMemset(p, 0, bytes));
+    HIPCHK(h, hipStreamSynchronize(nullptr));
+  }
   h->bufs.push_back({p, bytes});
   h->stats.device_bytes += (int64_t)bytes;
   *out = reinterpret_cast<T*>(p);
@@ -660,6 +665,10 @@ int probe_placement(FdtdSolver* h, hipStream_t st) {
       break;
     }
     auto drop_cand = [&]() { for (int c = 0; c < 12; ++c) release_buf(h, cand[c]); };
+    // dev_alloc zero-fills on the NULL stream, which this engine's non-blocking stream does not wait for: without this the
+    // memset of a candidate could land AFTER the copy below and the "restored" fields came back partly zero (caught by
+    // tests/test_gpu_production_path.py on the first visit with this probe, profiles/r3l)
+    if (hipDeviceSynchronize() != hipSuccess) { drop_cand(); rc = fail(h, "probe_placement: %s", hipGetErrorString(hipGetLastError())); break; }
     rc = copy6(cand, cur);                        // the live fields (E, H of the current set), ghost planes included
     if (!rc && best < 0.f) {                      // the incumbent, in place; its fields come back from the copy
       best = time_sweep_pairs(h, st, e0, e1);

@@ -1,5 +1,6 @@
-"""Field sources.  PlaneWave (normal incidence) and TFSF -> TfsfSpec (1-D auxiliary incident grid + surface
-correction lists); oblique PlaneWave, GaussianBeam / AstigmaticGaussianBeam and CustomFieldSource -> a sheet
+"""Field sources.  PlaneWave (normal incidence) and TFSF (normal incidence: incident grid along the axis, exact; oblique:
+incident grid along k_hat with matched numerical dispersion, ``make_tfsf_angled``) -> TfsfSpec (1-D auxiliary incident grid +
+surface correction lists); oblique PlaneWave, GaussianBeam / AstigmaticGaussianBeam and CustomFieldSource -> a sheet
 of electric and magnetic currents on the source plane (``_sheet_source``: the same surface legs, fed with
 an analytic or tabulated incident field instead of the 1-D grid).
 
@@ -239,6 +240,119 @@ def make_tfsf(spec: SolverSpec, mt, lo, hi, p: int, direction: int, e: int, e_sc
     return t, int(face)
 
 
+def numerical_wavenumber(omega: float, dt: float, u: np.ndarray, dl, v: float) -> float:
+    """k~ of a plane wave along the unit vector ``u`` ON THE YEE GRID (steps ``dl``, speed ``v`` in the background):
+        sin^2(omega dt / 2) / (v dt)^2 = sum_a sin^2(k~ u_a dl_a / 2) / dl_a^2          (Newton from k = omega / v)."""
+    rhs = (np.sin(omega * dt / 2) / (v * dt)) ** 2
+    u, dl = np.asarray(u, float), np.asarray(dl, float)
+    k = omega / v
+    for _ in range(50):
+        f = np.sum(np.sin(k * u * dl / 2) ** 2 / dl ** 2) - rhs
+        df = np.sum(np.sin(k * u * dl) * u / (2 * dl))
+        step = f / df
+        k -= step
+        if abs(step) < 1e-14 * k:
+            break
+    return float(k)
+
+
+def matched_aux_step(omega: float, dt: float, k_num: float, v: float, d_max: float) -> float:
+    """Step of a 1-D Yee grid (same dt) whose numerical wavenumber at ``omega`` equals ``k_num``:
+        sin(k~ d / 2) / d = sin(omega dt / 2) / (v dt)   (bisection; the left side falls monotonically for k~ d < pi)."""
+    rhs = np.sin(omega * dt / 2) / (v * dt)
+    lo, hi = v * dt, 4.0 * d_max
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        if np.sin(k_num * mid / 2) / mid > rhs:
+            lo = mid
+        else:
+            hi = mid
+    return 0.5 * (lo + hi)
+
+
+def _lagrange4(fr: np.ndarray):
+    """weights of the cubic through the samples at -1, 0, 1, 2 evaluated at fr in [0, 1)"""
+    return (-fr * (fr - 1) * (fr - 2) / 6, (fr + 1) * (fr - 1) * (fr - 2) / 2, -(fr + 1) * fr * (fr - 2) / 2, (fr + 1) * fr * (fr - 1) / 6)
+
+
+def make_tfsf_angled(spec: SolverSpec, mt, lo, hi, k_hat: np.ndarray, e_hat: np.ndarray, e_scale: float,
+                     wave_fn: Callable[[np.ndarray], np.ndarray], eps_bg: float, freq0: float, ref_point,
+                     name: str = "") -> Tuple[TfsfSpec, int]:
+    """A plane wave at OBLIQUE incidence into a TFSF box (ref source.py:1204 ``TFSF(AngledFieldSource, ...)``, angles
+    :899-990).  The incident wave still lives on a 1-D auxiliary Yee grid — along the propagation direction now, with a
+    uniform step chosen so that its numerical wavenumber at the centre frequency equals that of the 3-D grid along k_hat
+    (matched numerical dispersion, Taflove & Hagness 5.9) — and every stencil leg across the box surface reads it at
+    zeta = k_hat . (r - r_entry) by cubic interpolation: four (weight, aux index) entries per leg, polarisation folded into
+    the weight, for the SAME device machinery as normal incidence (nothing new in the kernels).
+        E_inc = e_hat E_s(zeta),   H_inc = (e_hat x k_hat) H_s(zeta)     [(E_s, H_s): the s = +1 pair of the module docstring]
+    Needs a uniform 3-D grid around the box.  Returns (TfsfSpec, aux index nearest ``ref_point``)."""
+    N = spec.shape
+    b = [np.asarray(x, float) for x in spec.boundaries]
+    dl = []
+    for a in range(3):
+        i0, i1 = max(lo[a] - 2, 0), min(hi[a] + 2, N[a])
+        d = np.diff(b[a][i0:i1 + 1])
+        if d.size and np.ptp(d) > 1e-9 * d.mean():
+            raise Tidy3dNotImplementedError("an angled TFSF source needs a uniform grid around its box")
+        dl.append(float(d.mean()) if d.size else float(np.diff(b[a]).mean()))
+    v = C_0 / np.sqrt(eps_bg)
+    dt = spec.dt
+    omega = 2 * np.pi * freq0
+    k_num = numerical_wavenumber(omega, dt, k_hat, dl, v)
+    d_aux = matched_aux_step(omega, dt, k_num, v, max(dl))
+    h_hat = np.cross(e_hat, k_hat)
+    # entry corner of the (clipped) box: the corner with the smallest projection on k_hat
+    cl = [b[a][int(np.clip(lo[a], 0, N[a]))] for a in range(3)]
+    ch = [b[a][int(np.clip(hi[a], 0, N[a]))] for a in range(3)]
+    r_entry = np.array([cl[a] if k_hat[a] >= 0 else ch[a] for a in range(3)])
+    r_exit = np.array([ch[a] if k_hat[a] >= 0 else cl[a] for a in range(3)])
+    span = float(k_hat @ (r_exit - r_entry))
+    off = N_PAD + N_EXT + 4                                  # aux index of zeta = 0 (4 nodes of room for the cubic and the legs one cell outside)
+    n = off + int(np.ceil((span + 3 * max(dl)) / d_aux)) + 4 + N_PAD + N_EXT
+    # uniform padded 1-D grid (s = +1), matched lossy pads as in _aux_grid
+    def g_at(pos):
+        depth = np.clip(np.maximum(N_PAD - pos, pos - (n - N_PAD)) / N_PAD, 0.0, 1.0)
+        return 4.0 * v / (N_PAD * d_aux) * np.log(1e4) / 2.0 * depth ** 3
+    xe, xh = g_at(np.arange(n + 1, dtype=float)) * dt / 2, g_at(np.arange(n, dtype=float) + 0.5) * dt / 2
+    ae, ah = (1 - xe) / (1 + xe), (1 - xh) / (1 + xh)
+    be = (-dt / (EPSILON_0 * eps_bg)) / d_aux / (1 + xe)
+    bh = (-dt / MU_0) / d_aux / (1 + xh)
+    src = off - 6
+    tmesh = dt * np.arange(spec.n_steps)
+    wave = e_scale * wave_fn(tmesh + dt) * (2 * v * dt / d_aux)
+    inc_e = tuple(a for a in range(3) if abs(e_hat[a]) > 1e-12)
+    inc_h = tuple(a for a in range(3) if abs(h_hat[a]) > 1e-12)
+    legs = surface_legs(spec, mt, lo, hi, inc_e, inc_h)
+    out = {}
+    for key in ("e", "h"):
+        comp, ijk, w, nbc, nbi = legs[key]
+        pol = np.zeros(len(w))
+        zeta = np.zeros(len(w))
+        for c in np.unique(nbc):
+            m = nbc == c
+            xs = spec.yee_coords(int(c))
+            r = np.stack([xs[a][nbi[m, a]] for a in range(3)], axis=1)
+            zeta[m] = (r - r_entry[None, :]) @ k_hat
+            pol[m] = h_hat[c - 3] if c >= 3 else e_hat[c]
+        # E-phase legs read H_s (h1[m] sits at (m + 1/2) d_aux), H-phase legs read E_s (e1[m] at m d_aux)
+        pos = zeta / d_aux + off - (0.5 if key == "e" else 0.0)
+        m0 = np.floor(pos).astype(np.int64)
+        wts = _lagrange4(pos - m0)
+        comp4 = np.repeat(comp, 4)
+        ijk4 = np.repeat(ijk, 4, axis=0)
+        w4 = (np.stack(wts, axis=1) * (w * pol)[:, None]).reshape(-1)
+        aux4 = (m0[:, None] + np.arange(-1, 3)[None, :]).reshape(-1)
+        keep = w4 != 0
+        out[key] = (comp4[keep].astype(np.int32), ijk4[keep].astype(np.int32), w4[keep], aux4[keep].astype(np.int32))
+        if keep.any() and (aux4[keep].min() < src + 2 or aux4[keep].max() > n - N_PAD - 1):
+            raise SetupError("angled TFSF: the incident grid does not cover the box")           # (internal consistency)
+    t = TfsfSpec(n_aux=n, ae=ae, be=be, ah=ah, bh=bh, src_cell=int(src), wave=wave,
+                 e_corr_comp=out["e"][0], e_corr_ijk=out["e"][1], e_corr_w=out["e"][2], e_corr_aux=out["e"][3],
+                 h_corr_comp=out["h"][0], h_corr_ijk=out["h"][1], h_corr_w=out["h"][2], h_corr_aux=out["h"][3], name=name)
+    ref_idx = int(round(float((np.asarray(ref_point, float) - r_entry) @ k_hat) / d_aux)) + off
+    return t, int(np.clip(ref_idx, src + 1, n - N_PAD - 1))
+
+
 def _rot(vec: np.ndarray, axis: int, angle: float) -> np.ndarray:
     """Right-handed rotation about a coordinate axis (ref geometry/base.py rotate_points)."""
     c, s = np.cos(angle), np.sin(angle)
@@ -451,8 +565,6 @@ def build_planewave(disc, mt, src) -> Callable:
     sim, spec = disc.sim, disc.spec
     if isinstance(src, td.PlaneWave) and (src.angle_theta != 0.0 or spec.bloch is not None):
         return build_angled_planewave(disc, mt, src)
-    if src.angle_theta != 0.0:
-        raise Tidy3dNotImplementedError("angled TFSF sources (angle_theta != 0) are not supported")
     is_box = isinstance(src, td.TFSF)
     p = int(src.injection_axis)
     direction = 1 if src.direction == "+" else -1
@@ -490,6 +602,26 @@ def build_planewave(disc, mt, src) -> Callable:
     pol = float(src.pol_angle)
     # 1 W/um^2 for amplitude 1: |E0|^2 = 2 eta / n  (ref source.py:1210-1214)
     e_unit = np.sqrt(2 * ETA_0 / np.sqrt(eps_bg))
+    if src.angle_theta != 0.0:
+        # oblique incidence into the box (ref source.py:1204, angles :899-990): one incident grid along k_hat
+        k_hat, e_hat = direction_vectors(src)
+        for a in range(3):
+            if a != p and abs(k_hat[a]) > 1e-9 and not np.isfinite(src.size[a]):
+                raise Tidy3dNotImplementedError("an angled TFSF source must be finite along the axes in which it is tilted "
+                                                "(an infinite extent needs Bloch boundaries: use an angled PlaneWave)")
+        ref = [float(c) if np.isfinite(c) else 0.0 for c in src.center]
+        ref[p] = b[p][int(np.clip(lo[p] if direction > 0 else hi[p], 0, N[p]))]
+        t, face_aux = make_tfsf_angled(spec, mt, lo, hi, k_hat, e_hat, e_unit, lambda tt: np.real(st.amp_time(tt)), eps_bg,
+                                       float(st.freq0), ref, name=getattr(src, "name", None) or src.type)
+        spec.tfsf.append(t)
+        inc_a = replay_aux(t, spec.n_steps, face_aux) / e_unit
+        tmesh_a = disc.tmesh
+
+        def fn_angled(freqs):
+            freqs = np.atleast_1d(np.asarray(freqs, float))
+            ph = np.exp(2j * np.pi * freqs[:, None] * tmesh_a[None, :])
+            return spec.dt / np.sqrt(2 * np.pi) * (ph @ inc_a)
+        return fn_angled
     comps = [(tang[0], np.cos(pol)), (tang[1], np.sin(pol))]
     specs = []
     for e_axis, wgt in comps:
