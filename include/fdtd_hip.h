@@ -137,6 +137,13 @@ int fdtd_set_pml(FdtdSolver* h, int axis, int n_lo, int n_hi,
                  const float* kinv_e, const float* b_e, const float* c_e,
                  const float* kinv_h, const float* b_h, const float* c_h, int n);
 
+/* PMC on the PLUS face of an axis (ref boundary.py:45 PMCBoundary; the min face is FDTD_BC_PMC in FdtdConfig.bc).  The host
+ * lays the axis out with two ghost cells beyond the wall (its plus face declared FDTD_BC_PEC: plain truncation) and names the
+ * wall's cell-boundary index, wall == n_cells(axis) - 2; the library refreshes the mirror images beyond the wall at the
+ * start of every step (tangential E and normal H even, normal E and tangential H odd).  wall < 0 switches it off.
+ * One GPU (not on z-slabs, not with fdtd_run_bloch). */
+int fdtd_set_mirror_plus(FdtdSolver* h, int axis, int wall);
+
 /* Absorber layers of one axis (ref boundary.py:427-476 Absorber, :166-192 AbsorberParams; layer
  * counts = Simulation.num_pml_layers, ref simulation.py:1002): per-step damping factors of length n
  * (1 outside the layers), fb sampled at the cell boundaries, fc at the cell centres; the layers are

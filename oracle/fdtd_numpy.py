@@ -451,9 +451,34 @@ class OracleFdtd:
         wh = sum(np.sum(np.square(np.abs(h), dtype=np.float64)) for h in self.H)
         return float(we + _ETA0_SQ * wh)
 
+    def _mirror_fill(self):
+        """PMC on plus faces (SolverSpec.mirror_plus): beyond the wall index N of axis a the fields are the mirror image of
+        the inside — components on cell boundaries along a (E_tan, H_a): F[N + 1] = +F[N - 1]; components on cell centres
+        (E_a, H_tan): F[N] = -F[N - 1], F[N + 1] = -F[N - 2]."""
+        mp = getattr(self.spec, "mirror_plus", None)
+        if not mp:
+            return
+        for a, N in enumerate(mp):
+            if N < 0:
+                continue
+            ax = 2 - a                      # numpy axis of the (z, y, x) arrays
+            def sl(i):
+                idx = [slice(None)] * 3
+                idx[ax] = i
+                return tuple(idx)
+            for c in range(3):
+                for F, is_h in ((self.E[c], False), (self.H[c], True)):
+                    on_center = (c == a) != is_h
+                    if on_center:
+                        F[sl(N)] = -F[sl(N - 1)]
+                        F[sl(N + 1)] = -F[sl(N - 2)]
+                    else:
+                        F[sl(N + 1)] = F[sl(N - 1)]
+
     def step(self):
         n = self.step_index
         self._record(n, "pre")
+        self._mirror_fill()
         if self.damp_h is not None:
             for c in range(3):
                 self.H[c] *= self.damp_h[c]

@@ -207,6 +207,25 @@ def one_d(N=60):
                                       z=td.Boundary.pml(num_layers=8)))
 
 
+def pmc_plus_mix(N=(20, 16, 14)):
+    """PMC on PLUS faces (x and z; SolverSpec.mirror_plus: two ghost cells beyond each wall, mirror images refreshed every
+    step) with CPML on the opposite faces and on y, a Lorentz sphere cut by the x wall, a lossy box at the z wall, dipoles
+    near both walls."""
+    structures = [
+        td.Structure(geometry=td.Sphere(center=(0.45, 0, 0.1), radius=0.2), medium=td.Lorentz(eps_inf=2.0, coeffs=[(1.5, 4e14, 3e13)])),
+        td.Structure(geometry=td.Box(center=(-0.1, 0.1, 0.3), size=(0.3, 0.2, 0.2)), medium=td.Medium(permittivity=3.0, conductivity=0.02))]
+    bspec = td.BoundarySpec(x=td.Boundary(minus=td.PML(num_layers=4), plus=td.PMCBoundary()), y=td.Boundary.pml(num_layers=3),
+                            z=td.Boundary(minus=td.PML(num_layers=3), plus=td.PMCBoundary()))
+    size = tuple(n * DL for n in N)
+    sources = [td.PointDipole(center=(size[0] / 2 - 0.16, -0.07, 0.01), source_time=PULSE, polarization="Ez"),
+               td.PointDipole(center=(-0.1, 0.07, size[2] / 2 - 0.13), source_time=PULSE, polarization="Hx"),
+               td.PointDipole(center=(0.2, 0.02, 0.1), source_time=PULSE, polarization="Ey")]
+    monitors = [td.FieldTimeMonitor(center=(0.3, 0.05, 0.2), size=(0.5, 0.2, 0.4), name="t", colocate=False, interval=7),
+                td.FieldMonitor(center=(0, 0, 0.1), size=(td.inf, td.inf, 0), freqs=[2.5e14, 3e14], name="f"),
+                td.FluxMonitor(center=(size[0] / 2 - 0.2, 0, 0), size=(0, td.inf, td.inf), freqs=[3e14], name="fx")]
+    return _sim(N, bspec, structures, sources=sources, monitors=monitors)
+
+
 def absorber_mix(N=(16, 12, 16)):
     """Absorber layers (ref boundary.py:427) on x (both faces), y+ (PML on y-) and z (both faces), with a
     Drude slab and a lossy box running through them: the damping kernel next to CPML and ADE."""
@@ -286,7 +305,7 @@ def wide_flat(N=(128, 128, 16)):
 
 CASES = {
     "bloch_box": bloch_box, "bloch_planewave": bloch_planewave, "bloch_xy_pml_z": bloch_xy_pml_z, "bloch_x_only": bloch_x_only,
-    "two_d": two_d, "one_d": one_d, "absorber_mix": absorber_mix, "absorber_odd_rows": absorber_odd_rows,
+    "two_d": two_d, "one_d": one_d, "absorber_mix": absorber_mix, "pmc_plus_mix": pmc_plus_mix, "absorber_odd_rows": absorber_odd_rows,
     "tfsf_box": tfsf_box, "tfsf_angled_box": tfsf_angled_box, "planewave_periodic": planewave_periodic, "au_array": au_array,
     "pec_box": pec_box, "pec_box_vec": pec_box_vec, "periodic_box": periodic_box,
     "periodic_box_tall": periodic_box_tall,
@@ -322,11 +341,18 @@ def run_case(name, lib, n_steps=60, scale=1, **engine_kw):
     for k in ref:
         den = max(np.linalg.norm(ref[k]), 0.5 * scale * np.sqrt(ref[k].size), 1e-300)
         worst = max(worst, float(np.linalg.norm(np.asarray(got[k]) - ref[k]) / den))
-    en = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in o.E))
-    hn = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in o.H))
+    # PMC plus faces: the cells beyond a wall are mirror images that are refreshed every step; what an update leaves in
+    # them in between (e.g. the ADE history of an image cell) is implementation detail and never read — compare the inside
+    sl = [slice(None)] * 3
+    for a, w in enumerate(getattr(disc.spec, "mirror_plus", None) or ()):
+        if w >= 0:
+            sl[2 - a] = slice(0, w)
+    sl = tuple(sl)
+    en = np.sqrt(sum(np.linalg.norm(x[sl]) ** 2 for x in o.E))
+    hn = np.sqrt(sum(np.linalg.norm(x[sl]) ** 2 for x in o.H))
     for c in range(3):
-        worst = max(worst, float(np.linalg.norm(fields[c] - o.E[c]) / en))
-        worst = max(worst, float(np.linalg.norm(fields[3 + c] - o.H[c]) / hn))
+        worst = max(worst, float(np.linalg.norm((fields[c] - o.E[c])[sl]) / en))
+        worst = max(worst, float(np.linalg.norm((fields[3 + c] - o.H[c])[sl]) / hn))
     return worst, disc
 
 

@@ -168,3 +168,35 @@ def test_symmetric_run_keeps_the_users_run_time_and_dft_stride():
     assert half.spec.n_steps == full.spec.n_steps
     assert half.nyquist_step == full.nyquist_step
     assert np.array_equal(half.spec.monitors[0].steps, full.spec.monitors[0].steps)
+
+
+@pytest.mark.parametrize("symmetry", [(-1, 0, 0), (0, 1, 0), (-1, 1, 0)])
+def test_symmetric_unit_cell_of_a_periodic_array(symmetry):
+    """Symmetry on PERIODIC axes (the unit cell of a metasurface, symmetry = (1, -1, 0) style): mirror + translation put a
+    second symmetry plane on the cell's ends, so the half cell is closed by the same kind of wall on its plus face — PEC is
+    the plain truncation, PMC the mirror-image layout of discretize._discretize_pmc_plus.  x-polarised plane wave onto a
+    dielectric disc: E_x is normal to the x plane (-1) and tangential to the y plane (+1).  Fields and flux equal the full
+    periodic run to rounding."""
+    pulse = td.GaussianPulse(freq0=3e14, fwidth=1e14)
+
+    def sim(sym):
+        return td.Simulation(
+            size=(16 * DL, 12 * DL, 32 * DL), grid_spec=td.GridSpec.uniform(dl=DL), run_time=1e-13, symmetry=sym, shutoff=0,
+            structures=[td.Structure(geometry=td.Cylinder(center=(0, 0, 0), radius=0.3, length=0.25, axis=2),
+                                     medium=td.Medium(permittivity=6.0))],
+            sources=[td.PlaneWave(center=(0, 0, 0.6), size=(td.inf, td.inf, 0), source_time=pulse, direction="-", pol_angle=0.0)],
+            monitors=[td.FieldMonitor(center=(0, 0, -0.3), size=(td.inf, td.inf, 0), freqs=[2.5e14, 3e14], name="f"),
+                      td.FluxMonitor(center=(0, 0, -0.6), size=(td.inf, td.inf, 0), freqs=[3e14], name="T"),
+                      td.FieldTimeMonitor(center=(0.2, 0.1, -0.3), size=(0, 0, 0), name="p", interval=3)],
+            boundary_spec=td.BoundarySpec(x=td.Boundary.periodic(), y=td.Boundary.periodic(), z=td.Boundary.pml(num_layers=6)))
+    _, full = _run_oracle(sim((0, 0, 0)), 240)
+    disc, half = _run_oracle(sim(symmetry), 240)
+    assert disc.spec.shape[0] == (8 if symmetry[0] else 16)
+    assert (disc.spec.mirror_plus is not None and disc.spec.mirror_plus[1] == 6) == (symmetry[1] == 1)
+    for c in ("Ex", "Ey", "Ez", "Hx", "Hy", "Hz"):
+        a, b = np.asarray(full["f"][c].values), np.asarray(half["f"][c].values)
+        scale = max(np.abs(np.asarray(full["f"][k].values)).max() for k in (("Ex", "Ey", "Ez") if c[0] == "E" else ("Hx", "Hy", "Hz")))
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-9 * scale, c
+    assert float(half["T"].flux.values[0]) == pytest.approx(float(full["T"].flux.values[0]), rel=1e-9)
+    np.testing.assert_allclose(np.asarray(half["p"].Ex.values), np.asarray(full["p"].Ex.values), rtol=0,
+                               atol=1e-9 * np.abs(np.asarray(full["p"].Ex.values)).max())

@@ -185,6 +185,7 @@ struct FdtdSolver {
   bool step_dev_mode = false;        // launches are being captured: source kernels take step_dev + step_dev_off
   long long step_dev_off = 0;
   long long graph_pairs = 0;
+  int mirror_wall[3] = {-1, -1, -1}; // PMC on plus faces: wall index per axis (fdtd_set_mirror_plus), -1 = none
   int graph_status = 0;              // 0 = no capture attempted, 1 = captured, < 0 = -(100 * stage + hipError) of the failed capture              // z-chunk of the edge launches of a CPML step: -1 = about one wave of workgroups, 0 = as the interior, N = planes
   long long two_step_pairs = 0;
   int tblock_used = 0;
@@ -812,6 +813,16 @@ int probe_stream_overlap(FdtdSolver* h) {
 
 // periodic z, fused sweep: the prologue recomputes H^{n+1/2}[-1] from ghost copies of E (all three
 // components) and H_x, H_y of plane nz-1; the top plane needs E_x, E_y of plane 0
+// PMC on plus faces: refresh the mirror images beyond the walls (start of a step: E^n, H^{n-1/2} are complete)
+void fill_mirror(FdtdSolver* h, hipStream_t st) {
+  const GridP& g = h->g;
+  for (int a = 0; a < 3; ++a) {
+    if (h->mirror_wall[a] < 0) continue;
+    const long long lines = (a == 0) ? (long long)g.ny * g.nz : (a == 1 ? (long long)g.nx * g.nz : g.sxy);
+    hipLaunchKernelGGL(mirror_fill_kernel, dim3(nblk(lines)), dim3(256), 0, st, g, h->f, a, h->mirror_wall[a], g.nz);
+  }
+}
+
 // one xy-plane device to device: a copy (the runtime's blit), or a kernel node while a graph is being captured
 void copy_plane(FdtdSolver* h, float* dst, const float* src, hipStream_t st) {
   const long long pc = (long long)h->cfg.nx * h->cfg.ny;
@@ -1451,6 +1462,17 @@ int fdtd_set_pml(FdtdSolver* h, int axis, int n_lo, int n_hi, const float* kinv_
   return 0;
 }
 
+int fdtd_set_mirror_plus(FdtdSolver* h, int axis, int wall) {
+  if (!h) return -1;
+  if (axis < 0 || axis > 2) return fail(h, "fdtd_set_mirror_plus: bad axis %d", axis);
+  const int N[3] = {h->g.nx, h->g.ny, h->g.nz};
+  if (wall >= 0 && (wall < 2 || wall + 2 > N[axis]))        // (rows padded to a multiple of 4 put more PEC cells behind the ghosts)
+    return fail(h, "fdtd_set_mirror_plus: two ghost cells are needed beyond the wall (wall %d of %d cells)", wall, N[axis]);
+  if (wall >= 0 && h->cfg.bc[2 * axis + 1] != FDTD_BC_PEC) return fail(h, "fdtd_set_mirror_plus: the plus face of the axis must be declared PEC (plain truncation behind the ghost cells)");
+  h->mirror_wall[axis] = wall < 0 ? -1 : wall;
+  return 0;
+}
+
 int fdtd_set_absorber(FdtdSolver* h, int axis, int n_lo, int n_hi, const float* fb, const float* fc, int n) {
   if (!h) return -1;
   if (axis < 0 || axis > 2) return fail(h, "fdtd_set_absorber: bad axis %d", axis);
@@ -1760,6 +1782,8 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   const bool multi = h->comm != nullptr;     // also true for a 1-rank communicator (self exchange)
   const bool nb_lo = h->cfg.bc[4] == FDTD_BC_NEIGHBOR, nb_hi = h->cfg.bc[5] == FDTD_BC_NEIGHBOR;
   if ((nb_lo || nb_hi) && !multi) return fail(h, "fdtd_run: neighbour faces need fdtd_comm_init");
+  if (multi && (h->mirror_wall[0] >= 0 || h->mirror_wall[1] >= 0 || h->mirror_wall[2] >= 0))
+    return fail(h, "fdtd_run: PMC on a plus face is not available on z-slabs");
   const int nz = h->g.nz;
   // runs that use BOTH streams first make sure the two really overlap (once per engine; falls back to one stream)
   if ((multi || any_pml(h) || h->tblock > 4096) && probe_stream_overlap(h)) return -1;
@@ -1912,6 +1936,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   const int tb_req = h->tblock < 0 ? 0 : (h->tblock % 4096);
   const bool tb_two_streams = h->tblock > 4096 && h->stream_overlap == 1;
   const bool tb_ok = fused && tb_req > 0 && !any_pml(h) && h->tfsf.empty() && h->cfg.bc[4] != FDTD_BC_PERIODIC &&
+                     h->mirror_wall[0] < 0 && h->mirror_wall[1] < 0 && h->mirror_wall[2] < 0 &&
                      nz >= 2 * tb_req;
   h->two_step_pairs = 0;
   h->tblock_used = tb_ok ? tb_req : 0;
@@ -1975,6 +2000,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     int pml_in = 0;
     if (any_pml(h) && 64 * (h->rows_f + 1) <= 512)
       pml_in = (h->pml_fused < 0 ? 7 : h->pml_fused) & pml_in_sweep_mask(h);
+    fill_mirror(h, st);
     launch_damp(h, false, 0, nz, st);
     launch_sources(h, false, n, 0, nz, st);
     launch_pml(h, false, 0, nz, st, 7 & ~pml_in);
@@ -2183,6 +2209,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
     }
     if (multi) HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
+    fill_mirror(h, st);
     launch_damp(h, false, 0, h_top, st);
     launch_sources(h, false, n, 0, h_top, st);
     launch_pml(h, false, 0, h_top, st);
@@ -2292,6 +2319,8 @@ int fdtd_run_bloch(FdtdSolver* hr, FdtdSolver* hi, int64_t n_steps, const double
                    FdtdProgressFn progress, void* user) {
   if (!hr || !hi) return -1;
   if (hi->comm) return fail(hr, "fdtd_run_bloch: the communicator of a z-slab belongs to the first (real-part) handle");
+  for (int a = 0; a < 3; ++a)
+    if (hr->mirror_wall[a] >= 0 || hi->mirror_wall[a] >= 0) return fail(hr, "fdtd_run_bloch: PMC on a plus face is not available together with Bloch boundaries");
   // z-slab decomposition (hr->comm): both parts exchange their ghost planes through the real-part handle's
   // communicator; the planes that wrap around a Bloch z axis (rank n-1 <-> rank 0) are rotated by exp(-+ i phi_z)
   // on arrival.  Two-pass kernels, exchanges on the step stream (correct by construction; not overlapped).

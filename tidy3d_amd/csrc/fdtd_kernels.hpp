@@ -1705,6 +1705,40 @@ __global__ void spin_kernel(long long ticks) {
 #endif
 }
 
+// ---- PMC on a PLUS face ------------------------------------------------------------------------------------------
+// The wall is the cell boundary of index N along axis a; the grid carries two ghost cells beyond it.  The wall nodes
+// (tangential E, normal H: located on boundaries along a) are unknowns like any other; everything beyond is the mirror
+// image of the inside, refreshed at the start of every step — E_tan, H_norm even, E_norm, H_tan odd:
+//   components on cell boundaries along a:  F[N + 1] = +F[N - 1]
+//   components on cell centres along a:     F[N] = -F[N - 1],  F[N + 1] = -F[N - 2]
+// The update equations preserve the mirror symmetry, so the sweep itself produces the right H^{n+1/2} in the ghost cell N
+// (which the E update of the wall nodes differentiates); only what the truncation at N + 2 spoils is refreshed here.
+// One thread per line along a.
+__global__ __launch_bounds__(256) void mirror_fill_kernel(GridP g, FieldP f, int a, int N, int nz) {
+  const int n1 = (a == 0) ? g.ny : g.nx;                // fastest transverse extent
+  const int n2 = (a == 2) ? g.ny : nz;                  // slowest transverse extent
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n1 * n2) return;
+  const int u = (int)(t % n1), w = (int)(t / n1);
+  const long long stride = (a == 0) ? 1 : (a == 1 ? (long long)g.nx : g.sxy);
+  long long base;
+  if (a == 0) base = (long long)w * g.sxy + (long long)u * g.nx;          // u = j, w = k
+  else if (a == 1) base = (long long)w * g.sxy + u;                       // u = i, w = k
+  else base = (long long)w * g.nx + u;                                    // u = i, w = j
+  float* F[6] = {f.ex, f.ey, f.ez, f.hx, f.hy, f.hz};
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const bool on_center = ((c % 3) == a) != (c >= 3);
+    float* p = F[c] + base;
+    if (on_center) {
+      p[(long long)N * stride] = -p[(long long)(N - 1) * stride];
+      p[(long long)(N + 1) * stride] = -p[(long long)(N - 2) * stride];
+    } else {
+      p[(long long)(N + 1) * stride] = p[(long long)(N - 1) * stride];
+    }
+  }
+}
+
 // plane copy as a kernel (ghost planes of a periodic z inside a captured graph: memcpy nodes did not capture, profiles/r3g)
 __global__ __launch_bounds__(256) void copy_kernel(float* dst, const float* src, long long n) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;

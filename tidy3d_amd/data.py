@@ -290,6 +290,18 @@ def _colocate_box(raw: np.ndarray, spec: SolverSpec, fp: FieldPlan, ic: int, fna
             pad = [(0, 0)] * arr.ndim
             pad[3 - a] = (0, 1)
             arr = np.pad(arr, pad)
+        elif lo == 0 and n == spec.shape[a] and n > 1 and spec.bc[a][0] == BC_PERIODIC and spec.bc[a][1] == BC_PERIODIC:
+            # a box that spans a whole PERIODIC axis: the samples one period away close the interpolation at both ends (the
+            # node on the plus face IS node 0; without this the last target took the value of its neighbour — 1e-3 of a flux
+            # through a unit cell, found against the symmetric half-cell run, tests/test_symmetry.py)
+            period = float(spec.boundaries[a][-1] - spec.boundaries[a][0])
+            first = np.take(arr, [0], axis=3 - a)
+            last = np.take(arr, [n - 1], axis=3 - a)
+            phi = 0.0 if getattr(spec, "bloch", None) is None else float(spec.bloch[a])
+            if phi != 0.0:                      # Bloch axis: F(r + L) = exp(i phi) F(r)   (ref boundary.py:55-79)
+                first, last = first * np.exp(1j * phi), last * np.exp(-1j * phi)
+            src = np.concatenate([[src[-1] - period], src, [src[0] + period]])
+            arr = np.concatenate([last, arr, first], axis=3 - a)
         arr = interp_axis(arr, src, fp.target[fname][a], axis=3 - a)
     return arr
 

@@ -166,7 +166,8 @@ def permute_spec(spec: SolverSpec, s: int) -> SolverSpec:
         spec, shape=pick(spec.shape), boundaries=pick(spec.boundaries), bc=pick(spec.bc), pml=pick(spec.pml),
         mat_idx=mat, sources=sources, tfsf=tfsf, monitors=monitors,
         absorber=None if spec.absorber is None else list(pick(spec.absorber)),
-        bloch=None if spec.bloch is None else pick(spec.bloch))
+        bloch=None if spec.bloch is None else pick(spec.bloch),
+        mirror_plus=None if getattr(spec, "mirror_plus", None) is None else pick(spec.mirror_plus))
 
 
 def unpermute_array(arr: np.ndarray, s: int) -> np.ndarray:
@@ -384,6 +385,15 @@ class HipEngine:
             t32 = [_f32(t) for t in tabs]
             self._chk(d.fdtd_set_pml(h, a, n_lo, n_hi, *[_ptr(t) for t in t32], len(t32[0])),
                       "fdtd_set_pml")
+        # PMC on plus faces: the wall index of every mirrored axis (two ghost cells lie beyond it)
+        mp = getattr(spec, "mirror_plus", None)
+        if mp is not None and any(w >= 0 for w in mp):
+            if self.n_ranks > 1 or (z0, z1) != (0, nz):
+                from .exceptions import Tidy3dNotImplementedError
+                raise Tidy3dNotImplementedError("PMCBoundary on a plus face is not available in z-slab (multi-GPU) runs")
+            for a, w in enumerate(mp):
+                if w >= 0:
+                    self._chk(d.fdtd_set_mirror_plus(h, a, int(w)), "fdtd_set_mirror_plus")
         # absorber layers (damping tables, slab-local along z)
         dm = damping_tables(spec)
         if dm is not None:

@@ -163,6 +163,11 @@ class SolverSpec:
     # Bloch boundaries (ref boundary.py:55-79): phase advance 2 pi bloch_vec per axis across the domain,
     # F(r + L_a) = exp(i bloch[a]) F(r), on axes whose bc is BC_PERIODIC; None = real fields
     bloch: Optional[Tuple[float, float, float]] = None
+    # PMC on PLUS faces (ref boundary.py:45 PMCBoundary on any face): per axis the index N of the wall (a cell boundary), or
+    # -1.  The grid then carries two ghost cells beyond the wall (shape[a] == N + 2): the wall nodes themselves (tangential
+    # E, normal H at index N) are unknowns, everything beyond is the mirror image of the inside — E_tan, H_norm even,
+    # E_norm, H_tan odd — refreshed at the start of every step (discretize._discretize_pmc_plus, kernel mirror_fill_kernel)
+    mirror_plus: Optional[Tuple[int, int, int]] = None
     shutoff: float = 0.0                                # 0 disables the early stop
     decay_every: int = 0                                # 0 = never evaluate field decay
     decay_ref_step: int = 0                             # steps before this never shut off
