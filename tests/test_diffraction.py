@@ -119,3 +119,27 @@ def test_hdf5_round_trip(grating, tmp_path):
     back = load(path)
     assert back["t"].Etheta.dims == ("orders_x", "orders_y", "f")
     assert np.array_equal(back["t"].power.values, grating["t"].power.values)
+
+
+@pytest.mark.parametrize("symmetry", [(1, 0, 0), (1, -1, 0)])
+def test_diffraction_monitor_on_a_symmetric_unit_cell(symmetry):
+    """DiffractionMonitor together with ``Simulation.symmetry`` on the periodic axes (round 3: symmetric unit cells are
+    closed by a wall on the plus face; the near fields are expanded to the whole period before the order integrals): the
+    amplitudes of a mirror-symmetric grating under a y-polarised plane wave (E_y tangential to the x plane: +1, normal to
+    the y plane: -1) equal the full-cell run."""
+    plane = (td.inf, td.inf, 0)
+
+    def sim(sym):
+        return td.Simulation(
+            size=(2.4, 0.3, 4.0), grid_spec=td.GridSpec.uniform(dl=0.05), run_time=2.5e-13, shutoff=0, symmetry=sym,
+            structures=[td.Structure(geometry=td.Box(center=(0, 0, 0), size=(1.0, td.inf, 0.6)), medium=td.Medium(permittivity=4.0))],
+            sources=[td.PlaneWave(center=(0, 0, -1.5), size=plane, source_time=PULSE, direction="+", pol_angle=np.pi / 2)],
+            monitors=[td.DiffractionMonitor(center=(0, 0, 1.2), size=plane, freqs=FREQS, name="t"),
+                      td.DiffractionMonitor(center=(0, 0, -1.8), size=plane, freqs=FREQS, name="r", normal_dir="-")],
+            boundary_spec=td.BoundarySpec(x=td.Boundary.periodic(), y=td.Boundary.periodic(), z=td.Boundary.pml()))
+    full = solve(sim((0, 0, 0)))[0]
+    half = solve(sim(symmetry))[0]
+    for name in ("t", "r"):
+        a, b = np.asarray(full[name].amps.values), np.asarray(half[name].amps.values)
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-9 * np.abs(a).max(), name
+    assert np.asarray(full["t"].power.values).sum() > 1.0
