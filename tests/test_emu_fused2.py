@@ -1,0 +1,115 @@
+"""Two time steps per sweep (fused2_step_kernel + the seam kernels, fdtd_kernels2.hpp) against single steps of the same
+library on the CPU emulator: same formulas in the same order -> the same bits.  Tile edges in x (seams between 256-cell
+tiles, ragged last tile), y (two halo rows below, one above, ragged last tile row) and z (chunk prologue, chunks of every
+length, the walls), sources between the two steps, pairs giving way to single steps around monitor records."""
+import numpy as np
+import pytest
+
+import tidy3d_amd.schema as td
+from tidy3d_amd import lib as L
+from tidy3d_amd.discretize import discretize
+from tidy3d_amd.engine import HipEngine
+
+DL = 0.05
+PULSE = td.GaussianPulse(freq0=3e14, fwidth=1.5e14)
+PEC = td.BoundarySpec.all_sides(td.PECBoundary())
+
+
+def _sim(N, monitors=True, extra=()):
+    size = tuple(n * DL for n in N)
+    srcs = [td.PointDipole(center=(0.3 * size[0] - 0.5 * size[0] + 0.02, 0.01, 0.03), source_time=PULSE, polarization="Ez"),
+            td.PointDipole(center=(0.01, 0.02, -0.1), source_time=PULSE, polarization="Ex")]
+    if N[0] >= 128:       # next to both x faces and on both sides of the seam at column 256
+        srcs += [td.PointDipole(center=(-0.5 * size[0] + 2.3 * DL, 0.03, 0.02), source_time=PULSE, polarization="Ez"),
+                 td.PointDipole(center=(0.5 * size[0] - 3.2 * DL, 0.1, -0.07), source_time=PULSE, polarization="Ey"),
+                 td.PointDipole(center=(-0.5 * size[0] + 255.0 * DL, -0.05, 0.04), source_time=PULSE, polarization="Ey"),
+                 td.PointDipole(center=(-0.5 * size[0] + 256.5 * DL, 0.0, 0.0), source_time=PULSE, polarization="Ex")]
+    mons = []
+    if monitors:
+        mons = [td.FieldMonitor(center=(0, 0, 0), size=(td.inf, td.inf, 0), freqs=[3e14], name="f", interval_space=(1, 1, 1)),
+                td.FieldTimeMonitor(center=(0, 0, 0), size=(0.2, 0.2, 0.2), name="t", interval=5, colocate=False)]
+    return td.Simulation(size=size, grid_spec=td.GridSpec.uniform(dl=DL), run_time=1e-12, sources=srcs + list(extra),
+                         monitors=mons, boundary_spec=PEC, shutoff=0)
+
+
+def _run(spec, lib, twostep, runs=(11, 15)):
+    with HipEngine(spec, lib=lib, variant=L.VARIANT_FUSED, z_chunk=2) as e:
+        e.set_option(L.OPT_ROWS, 3)
+        e.set_option(L.OPT_TWOSTEP, twostep)
+        pairs = 0
+        for r in runs:
+            st = e.run(r)
+            pairs += int(st.fused2_pairs)
+        return [e.get_field(c) for c in range(6)], e.results(), pairs
+
+
+SHAPES = {
+    "one_tile": (32, 14, 10),
+    "ragged_rows": (36, 9, 7),
+    "two_x_tiles": (260, 9, 8),
+    "three_x_tiles_tall": (516, 6, 13),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SHAPES))
+@pytest.mark.parametrize("w,zc", [(16, 32), (4, 2), (5, 3), (8, 5)])
+def test_two_steps_per_sweep_equal_single_steps(name, w, zc, emu_lib):
+    N = SHAPES[name]
+    disc = discretize(_sim(N, monitors=False), n_steps=26)
+    disc.spec.decay_every = 0
+    ref_f, _, p0 = _run(disc.spec, emu_lib, 0)
+    got_f, _, p1 = _run(disc.spec, emu_lib, w + 64 * zc)
+    assert p0 == 0 and p1 == 5 + 7, p1          # runs of 11 and 15 steps: 5 + 7 pairs and a single step each
+    assert max(float(np.abs(f).max()) for f in ref_f) > 0
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), c
+
+
+@pytest.mark.parametrize("name", ["ragged_rows", "two_x_tiles"])
+def test_pairs_give_way_to_monitor_records_and_decay_checks(name, emu_lib):
+    N = SHAPES[name]
+    disc = discretize(_sim(N), n_steps=26)
+    disc.spec.decay_every = 8
+    ref_f, ref_m, p0 = _run(disc.spec, emu_lib, 0)
+    got_f, got_m, p1 = _run(disc.spec, emu_lib, 6 + 64 * 4)
+    assert p0 == 0                        # (the DFT monitor samples at its Nyquist interval: pairs fit in between)
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), c
+    for k in ref_m:
+        assert np.array_equal(got_m[k], ref_m[k]), k
+    # without the DFT monitor: pairs between the time monitor's records (every 5th step) and the decay checks
+    sim = _sim(N)
+    sim = sim.updated_copy(monitors=[m for m in sim.monitors if m.name == "t"]) if hasattr(sim, "updated_copy") else sim
+    disc = discretize(sim, n_steps=26)
+    disc.spec.decay_every = 8
+    ref_f, ref_m, p0 = _run(disc.spec, emu_lib, 0)
+    got_f, got_m, p1 = _run(disc.spec, emu_lib, 6 + 64 * 4)
+    assert p0 == 0 and p1 >= 4, p1
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), c
+    for k in ref_m:
+        assert np.array_equal(got_m[k], ref_m[k]), k
+
+
+def test_not_eligible_runs_take_single_steps(emu_lib):
+    """a magnetic dipole (H-side source), a periodic face or a medium: the option changes nothing, no pair is taken"""
+    N = (32, 10, 9)
+    cases = [dict(extra=[td.PointDipole(center=(0.1, 0, 0), source_time=PULSE, polarization="Hy")]),
+             dict(bspec=td.BoundarySpec(x=td.Boundary.periodic(), y=td.Boundary(minus=td.PECBoundary(), plus=td.PECBoundary()),
+                                        z=td.Boundary(minus=td.PECBoundary(), plus=td.PECBoundary()))),
+             dict(structures=[td.Structure(geometry=td.Box(center=(0, 0, 0), size=(0.3, 0.3, 0.2)), medium=td.Medium(permittivity=2.0))])]
+    for kw in cases:
+        sim = _sim(N, monitors=False, extra=kw.get("extra", ()))
+        if "bspec" in kw:
+            sim = td.Simulation(size=sim.size, grid_spec=sim.grid_spec, run_time=sim.run_time, sources=list(sim.sources),
+                                monitors=[], boundary_spec=kw["bspec"], shutoff=0)
+        if "structures" in kw:
+            sim = td.Simulation(size=sim.size, grid_spec=sim.grid_spec, run_time=sim.run_time, sources=list(sim.sources),
+                                monitors=[], boundary_spec=PEC, structures=kw["structures"], shutoff=0)
+        disc = discretize(sim, n_steps=12)
+        disc.spec.decay_every = 0
+        ref_f, _, p0 = _run(disc.spec, emu_lib, 0, runs=(12,))
+        got_f, _, p1 = _run(disc.spec, emu_lib, 8 + 64 * 4, runs=(12,))
+        assert p0 == 0 and p1 == 0
+        for c in range(6):
+            assert np.array_equal(got_f[c], ref_f[c]), c

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfdtd_hip.so")
 SOURCES = [os.path.join(CSRC, "fdtd_capi.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "fdtd_kernels.hpp"),
+DEPS = SOURCES + [os.path.join(CSRC, "fdtd_kernels.hpp"), os.path.join(CSRC, "fdtd_kernels2.hpp"),
                   os.path.join(HERE, "..", "include", "fdtd_hip.h"), os.path.abspath(__file__)]
 
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -16,6 +17,7 @@
 
 #include "../../include/fdtd_hip.h"
 #include "fdtd_kernels.hpp"
+#include "fdtd_kernels2.hpp"
 
 using namespace fdtd;
 
@@ -62,6 +64,8 @@ struct PointSrc {
   float2 *wave_e = nullptr, *wave_h = nullptr;
   long long n_steps = 0;
   int ke0 = 0, ke1 = 0, kh0 = 0, kh1 = 0;   // planes [k0, k1) that hold its E / H points
+  std::vector<int32_t> host_comp_e;         // host copies of the E nodes (the two-step sweep applies them in-kernel)
+  std::vector<uint32_t> host_cell_e;
 };
 
 // correction list of one side (E or H) of a TFSF box, grouped by target node (tfsf_corr_kernel)
@@ -189,6 +193,14 @@ struct FdtdSolver {
   int graph_status = 0;              // 0 = no capture attempted, 1 = captured, < 0 = -(100 * stage + hipError) of the failed capture              // z-chunk of the edge launches of a CPML step: -1 = about one wave of workgroups, 0 = as the interior, N = planes
   long long two_step_pairs = 0;
   int tblock_used = 0;
+  // two time steps per sweep (fused2_step_kernel): waves per workgroup (0 = off) and planes per chunk
+  int twostep_w = 0, twostep_zc = 32;
+  long long fused2_pairs = 0;
+  float* seam_buf = nullptr;          // intermediate values on the seams between x tiles
+  float* inj_val = nullptr;           // source terms applied between the two steps
+  int* inj_start = nullptr;           // their nodes, sorted by plane (InjP)
+  int4* inj_ent = nullptr;
+  size_t inj_sources = 0;             // point-source lists the table was built from
 };
 
 namespace {
@@ -582,6 +594,110 @@ int launch_fused(FdtdSolver* h, hipStream_t st, int pml_inside) {
   if (launch_fused_range(h, 0, h->g.nz, st, pml_inside)) return -1;
   swap_sets(h);
   swap_psi_h(h, pml_inside);
+  return 0;
+}
+
+// ---- two time steps per sweep (fdtd_kernels2.hpp) --------------------------------------------------------------------
+// What fused2_step_kernel covers: the plain curl stencil of a uniform medium inside six PEC walls on one GPU, driven by
+// E-side point sources.  Anything else (materials, CPML, absorbers, ADE, TFSF, periodic / PMC / Bloch faces, mirror
+// faces, magnetic dipoles, z-slabs) takes single steps.
+bool fused2_eligible(const FdtdSolver* h) {
+  if (h->twostep_w <= 0) return false;
+  if (h->comm || h->mat4 || any_pml(h) || h->has_damp || !h->ade.empty() || !h->tfsf.empty()) return false;
+  for (int f = 0; f < 6; ++f) if (h->cfg.bc[f] != FDTD_BC_PEC) return false;
+  if (!h->g.pec_z0 || h->g.nx % 4 || h->g.nz < 2) return false;
+  for (int a = 0; a < 3; ++a) if (h->mirror_wall[a] >= 0) return false;
+  long long n_e = 0;
+  for (const PointSrc& s : h->psrc) {
+    if (s.n_h) return false;
+    n_e += s.n_e;
+  }
+  return n_e <= kMaxInj;
+}
+// the point sources of step n: all alive or all spent (the kernel applies the whole table or nothing)
+bool fused2_sources_uniform(const FdtdSolver* h, long long n) {
+  bool any_alive = false, any_spent = false;
+  for (const PointSrc& s : h->psrc) {
+    if (!s.n_e) continue;
+    if (n < s.n_steps) any_alive = true; else any_spent = true;
+  }
+  return !(any_alive && any_spent);
+}
+
+// steps n and n + 1 in one sweep: set a (E^n, H^{n-1/2}) -> set b (E^{n+2}, H^{n+3/2}); the E-side sources of step n are
+// applied inside the kernel, those of step n + 1 by the caller afterwards
+int launch_fused2(FdtdSolver* h, long long n, hipStream_t st) {
+  const GridP& g = h->g;
+  if (ensure_second_set(h)) return -1;
+  const int W = h->twostep_w, R = W - 3;
+  const int nbx = (g.nx + 255) / 256, nby = (g.ny + R - 1) / R;
+  const int zc = std::max(2, std::min(h->twostep_zc, g.nz));
+  const int nbz = (g.nz + zc - 1) / zc;
+  if (nbx > 1 && !h->seam_buf &&
+      dev_alloc(h, &h->seam_buf, (size_t)(nbx - 1) * kSeamArrays * (size_t)(g.nz + 2) * (size_t)g.ny)) return -1;
+  if (!h->inj_val && dev_alloc(h, &h->inj_val, (size_t)kMaxInj)) return -1;
+  if (!h->inj_ent || h->inj_sources != h->psrc.size()) {
+    // the nodes of all E-side lists, sorted by plane; nodes of one plane keep their list order (a node two lists share
+    // receives their terms in the order the source kernels would add them)
+    std::vector<std::array<int, 5>> ent;        // k, i, j, c, index into val
+    int off = 0;
+    for (const PointSrc& s : h->psrc)
+      for (long long t = 0; t < s.n_e; ++t, ++off) {
+        const long long cell = s.host_cell_e[(size_t)t];
+        ent.push_back({(int)(cell / g.sxy), (int)(cell % g.nx), (int)((cell % g.sxy) / g.nx), s.host_comp_e[(size_t)t] % 3, off});
+      }
+    std::stable_sort(ent.begin(), ent.end(), [](const std::array<int, 5>& x, const std::array<int, 5>& y) { return x[0] < y[0]; });
+    std::vector<int> start((size_t)g.nz + 2, 0);
+    std::vector<int4> e4(std::max<size_t>(1, ent.size()));
+    for (size_t q = 0; q < ent.size(); ++q) {
+      start[(size_t)ent[q][0] + 1]++;
+      e4[q].x = ent[q][1]; e4[q].y = ent[q][2]; e4[q].z = ent[q][3]; e4[q].w = ent[q][4];
+    }
+    for (int k = 0; k <= g.nz; ++k) start[(size_t)k + 1] += start[(size_t)k];
+    if (dev_upload(h, &h->inj_start, (const int*)start.data(), start.size()) ||
+        dev_upload(h, &h->inj_ent, (const int4*)e4.data(), e4.size())) return -1;
+    h->inj_sources = h->psrc.size();
+  }
+  InjP inj{};
+  {
+    int off = 0;
+    bool alive = false;
+    for (const PointSrc& s : h->psrc) {
+      if (s.n_e && n < s.n_steps) {
+        alive = true;
+        hipLaunchKernelGGL(inject_values_kernel, dim3(1), dim3(256), 0, st, h->inj_val + off, (const float*)s.wre_e,
+                           (const float*)s.wim_e, (const float2*)s.wave_e, n, (int)s.n_e);
+      }
+      off += (int)s.n_e;
+    }
+    inj.n = alive ? off : 0;                 // (all lists alive or all spent: fused2_sources_uniform)
+    inj.start = h->inj_start; inj.ent = h->inj_ent; inj.val = h->inj_val;
+  }
+  const int total = nbx * nby * nbz;
+  const int remap = h->xcd_remap < 0 ? kTileRun : h->xcd_remap;
+  dim3 grid(remap ? ((total + 7) / 8) * 8 : total, 1, 1), block(64, W, 1);
+  const size_t shmem = (size_t)8 * W * 64 * sizeof(float4);
+  StepP sp = step_params(h);
+  time_begin(h, 2, st);
+#define FDTD_LAUNCH_FUSED2(LBV)                                                                                      \
+  do {                                                                                                               \
+    if (h->mem_hints) hipLaunchKernelGGL((fused2_step_kernel<LBV, true>), grid, block, shmem, st, g, h->f, h->f2, sp, \
+                                         h->ca1, h->cb1, zc, nbx, nby, nbz, remap, inj, h->seam_buf);                \
+    else hipLaunchKernelGGL((fused2_step_kernel<LBV, false>), grid, block, shmem, st, g, h->f, h->f2, sp, h->ca1,     \
+                            h->cb1, zc, nbx, nby, nbz, remap, inj, h->seam_buf);                                     \
+  } while (0)
+  if (W <= 8) FDTD_LAUNCH_FUSED2(512);
+  else if (W <= 12) FDTD_LAUNCH_FUSED2(768);
+  else FDTD_LAUNCH_FUSED2(1024);
+#undef FDTD_LAUNCH_FUSED2
+  if (nbx > 1) {
+    const long long nt = (long long)(nbx - 1) * g.ny * g.nz;
+    hipLaunchKernelGGL(seam_h_kernel, dim3(nblk(nt)), dim3(256), 0, st, g, h->f2, sp, (const float*)h->seam_buf, nbx - 1);
+    hipLaunchKernelGGL(seam_e_kernel, dim3(nblk(nt)), dim3(256), 0, st, g, h->f2, sp, h->ca1, h->cb1,
+                       (const float*)h->seam_buf, nbx - 1);
+  }
+  time_end(h, st);
+  swap_sets(h);
   return 0;
 }
 
@@ -1569,6 +1685,8 @@ int fdtd_add_point_source(FdtdSolver* h, int64_t n, const int32_t* comp, const u
         dev_upload(h, &s.wave_h, reinterpret_cast<const float2*>(wave_h), (size_t)n_steps))
       return -1;
   }
+  s.host_comp_e = ce;
+  s.host_cell_e = le;
   h->psrc.push_back(s);
   return 0;
 }
@@ -2105,6 +2223,8 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     h->graph_pairs++;
     return 0;
   };
+  const bool f2_ok = fused && !tb_ok && fused2_eligible(h);
+  h->fused2_pairs = 0;
   int64_t done = 0;
   for (; done < n_steps; ++done) {
     const long long n = h->step;
@@ -2183,6 +2303,15 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       if (tb_pair(n)) return -1;
       h->step = n + 2;
       ++done;                                              // (the loop header counts the second step)
+    } else if (fused && f2_ok && done + 2 <= n_steps && !rec && !rec_at(n + 1) &&
+               !(h->decay_every > 0 && ((n + 1) % h->decay_every) == 0) && fused2_sources_uniform(h, n)) {
+      // two steps in one sweep; the E-side sources of step n + 1 follow it like those of a single step
+      if (launch_fused2(h, n, st)) return -1;
+      launch_sources(h, true, n + 1, 0, nz, st);
+      fill_ghost_fused(h, st);
+      h->fused2_pairs++;
+      h->step = n + 2;
+      ++done;
     } else if (fused && graph_ok && done + 2 <= n_steps && !rec && !rec_at(n + 1) &&
                !(h->decay_every > 0 && ((n + 1) % h->decay_every) == 0) && sources_alive(n + 1)) {
       const int grc = graph_pair(n);
@@ -2511,6 +2640,14 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_TBLOCK: h->tblock = value < 0 ? -1 : value; return 0;
     case FDTD_OPT_EDGE_ZCHUNK: h->edge_zchunk = value < 0 ? -1 : value; return 0;
     case FDTD_OPT_GRAPH: h->use_graph = value < 0 ? -1 : (value != 0); return 0;
+    case FDTD_OPT_TWOSTEP: {
+      if (value <= 0) { h->twostep_w = 0; return 0; }
+      const int w = value % 64, zc = value / 64;
+      if (w < 4 || w > 16) return fail(h, "FDTD_OPT_TWOSTEP: %d waves per workgroup (4 ... 16)", w);
+      h->twostep_w = w;
+      h->twostep_zc = zc > 0 ? zc : 32;
+      return 0;
+    }
     case FDTD_OPT_PML_SPLIT: h->pml_split = value < 0 ? -1 : (value != 0); return 0;
     case FDTD_OPT_FUSED_LB: if (value != 0 && value != 256 && value != 512 && value != 1024) break; h->fused_lb = value; return 0;
     default: break;
@@ -2533,6 +2670,7 @@ int fdtd_get_stats(FdtdSolver* h, FdtdStats* out) {
   out->tblock_planes = h->tblock_used;
   out->graph_pairs = h->graph_pairs;
   out->reserved0 = h->graph_status;
+  out->fused2_pairs = h->fused2_pairs;
   return 0;
 }
 

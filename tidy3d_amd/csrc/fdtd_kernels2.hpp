@@ -1,0 +1,424 @@
+// Two time steps per sweep (in-kernel temporal blocking of the plain curl stencil), gfx950.
+//
+// fused2_step_kernel reads set `a` (E^n, H^{n-1/2}) and writes set `b` (E^{n+2}, H^{n+3/2}): the intermediate
+// fields E^{n+1}, H^{n+1/2} live in registers and LDS only, so a pair of steps moves 6 reads + 6 writes per cell
+// instead of 12 + 12.  Same update formulas (upd_h / upd_e), same operand order, same wall handling as
+// fused_step_kernel -> the same bits as two single sweeps (tests/test_emu_fused2.py, tests/test_gpu_production_path.py).
+//
+// Workgroup = W waves = W rows of 256 cells: rows j0-2 .. j0+R, R = W - 3 of them written (j0 .. j0+R-1); the two rows
+// below and the one above are recomputed halos.  The z-march is a two-stage pipeline with TWO barriers per plane:
+//   iteration k:  S1  H1[k]   = H^{n+1/2}[k]      from E^n, H^{n-1/2}         (all rows)            publish H1_{x,z}
+//                 ---- barrier ----
+//                 S2  E1[k]   = E^{n+1}[k]        (+ the E-side point sources of step n)            publish E1_{x,z}
+//                 S3  H2[k-1] = H^{n+3/2}[k-1]    from H1[k-1], E1[k-1], E1[k], E1[j+1][k-1]        publish H2_{x,z}
+//                 ---- barrier ----
+//                 S4  E2[k-1] = E^{n+2}[k-1]      from E1[k-1], H2[k-1], H2[k-2], H2[j-1][k-1]      store E2, H2
+// A chunk [k0, k1) runs iterations k0-1 .. k1 (its first iteration is S1 + S2 only; a prologue supplies
+// H1_{x,y}[k0-2]).  Along x a wave covers its 256 cells exactly as in fused_step_kernel for step one (edge lanes load /
+// recompute the neighbouring column from set `a`); the second step would need the NEIGHBOUR tile's intermediate
+// values on the seam: those five values per seam row are computed wrong here and repaired afterwards by
+// seam_h_kernel / seam_e_kernel from the intermediate values both tiles leave in a small scratch array.
+//
+// Scope (fdtd_capi.hip checks it): uniform medium, PEC on all six faces, no CPML / absorber / ADE / TFSF / Bloch /
+// mirror faces, E-side point sources only (<= kMaxInj nodes), one GPU.  Everything else takes single steps.
+#pragma once
+#include "fdtd_kernels.hpp"
+
+namespace fdtd {
+
+constexpr int kMaxInj = 256;
+struct InjP {
+  int n;                                   // nodes that receive a source term between the two steps (0: none alive)
+  const int* start;                        // [nz + 1] entries of plane k: [start[k], start[k + 1])
+  const int4* ent;                         // (i, j, component, index into val), sorted by plane, list order kept within a plane
+  const float* val;                        // the terms (inject_values_kernel)
+};
+
+// val[t] = w_re[t] * Re(wave[step]) - w_im[t] * Im(wave[step]): the term point_source_kernel adds, formed by the same
+// operations
+__global__ __launch_bounds__(256) void inject_values_kernel(float* val, const float* w_re, const float* w_im,
+                                                            const float2* wave, long long step, int n) {
+  const int t = threadIdx.x;
+  if (t >= n) return;
+  const float2 a = wave[step];
+  val[t] = w_re[t] * a.x - w_im[t] * a.y;
+}
+
+constexpr int kSeamArrays = 7;   // H1_y, H1_z, E1_x, E1_y, E1_z of column c-1;  E1_y, E1_z of column c  (c = first column of the right tile)
+__device__ __forceinline__ long long seam_at(const GridP& g, int seam, int arr, int j, int k) {
+  return (((long long)seam * kSeamArrays + arr) * (g.nz + 2) + (k + 1)) * g.ny + j;
+}
+
+template <int LB, bool NT>
+__global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, FieldP b, StepP s, float ca, float cb,
+                                                         int zchunk, int nbx, int nby, int nbz, int xcd_remap,
+                                                         InjP inj, float* __restrict__ seam) {
+  constexpr int V = 4;
+  const int total = nbx * nby * nbz;
+  int t = blockIdx.x;
+  if (xcd_remap == 1) {
+    const int per = (total + 7) >> 3;
+    t = (t & 7) * per + (t >> 3);
+    if (t >= total) return;
+  } else if (xcd_remap > 1) {
+    const int G = xcd_remap, full = total / (8 * G) * (8 * G);
+    if (t < full) {
+      const int x = t & 7, mloc = t >> 3;
+      t = ((mloc / G) * 8 + x) * G + mloc % G;
+    }
+    if (t >= total) return;
+  }
+  const int tile_y = t % nby;
+  const int tile_x = (t / nby) % nbx;
+  const int tile_z = t / (nby * nbx);
+  HIP_DYNAMIC_SHARED(float4, xch)      // [8][W][64]: H1_x H1_z | H2_x H2_z | E1_x E1_z (buffer 0) | E1_x E1_z (buffer 1)
+  const int tx = threadIdx.x;
+  const int ty = __builtin_amdgcn_readfirstlane((int)threadIdx.y);     // one row per wave
+  const int W = blockDim.y, R = W - 3;
+  const int slot = W * 64;
+  const int me = ty * 64 + tx;
+  {
+    const float4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) xch[q * slot + me] = z4;     // rows beyond the grid publish E = 0, H = 0
+  }
+  __syncthreads();
+  const int k0 = tile_z * zchunk;
+  const int k1 = min(k0 + zchunk, g.nz);
+  const int kA = k0 > 0 ? k0 - 1 : 0;
+  int j = tile_y * R + ty - 2;
+  const bool row_ok = (j >= 0) && (j < g.ny);
+  if (!row_ok) {                          // takes part in the barriers only
+    for (int k = kA; k <= k1; ++k) { __syncthreads(); __syncthreads(); }
+    return;
+  }
+  const int i0 = (tile_x * 64 + tx) * V;
+  const unsigned ux = (unsigned)i0;
+  const unsigned ub = ux * 4u;
+  const unsigned ubc = (i0 < g.nx) ? ub : 0u;
+  const bool act = (i0 < g.nx);
+  const bool do_e1 = ty >= 1;                       // rows j0-1 .. j0+R
+  const bool do_h2 = ty >= 1 && ty <= W - 2;        // rows j0-1 .. j0+R-1
+  const bool own = ty >= 2 && ty <= W - 2;          // rows j0 .. j0+R-1: stored
+  const float ch = g.ch;
+  const bool last_x = (i0 + V >= g.nx);
+  const bool first_x = (i0 == 0);
+  const bool use_jp = (j + 1 < g.ny);
+  const long long rowb = (long long)j * g.nx;
+  const long long rowpb = use_jp ? rowb + g.nx : 0;
+  const bool xh = act && (tx == 0) && !first_x;     // the tile's first lane recomputes H1_{y,z} of column i0-1
+  const int im = first_x ? 0 : i0 - 1;
+  const bool wall_y = (j == 0);
+  const bool wall_x0 = first_x;
+
+  float ipx[V], idx[V];
+  zero<V>(ipx); zero<V>(idx);
+  float ipx_m = 0.f;
+  if (act) {
+    ldv<V>(ipx, at(uni(s.ipx), ub));
+    ldv<V>(idx, at(uni(s.idx), ub));
+    ipx_m = s.ipx[im];
+  }
+  const float ipy = s.ipy[j], idy = s.idy[j];
+
+  // carried along the march
+  float exk[V], eyk[V];                    // E^n_{x,y}[k]
+  float h1x[V], h1y[V], h1z[V];            // H1[k-1]
+  float e1x[V], e1y[V], e1z[V];            // E1[k-1]
+  float h2xm[V], h2ym[V];                  // H2_{x,y}[k-2]
+  zero<V>(h1x); zero<V>(h1y); zero<V>(h1z); zero<V>(e1x); zero<V>(e1y); zero<V>(e1z); zero<V>(h2xm); zero<V>(h2ym);
+  float exk_m = 0.f;
+  float ipz_m = 0.f, idz_m = 0.f;          // 1 / steps of plane k-1
+  {
+    const long long p0 = (long long)kA * g.sxy + rowb;
+    ldf<V, true>(exk, uni(a.ex + p0), ubc);
+    ldf<V, true>(eyk, uni(a.ey + p0), ubc);
+    if (xh) exk_m = a.ex[p0 + im];
+  }
+  // ---- prologue: H1_{x,y}[kA-1] (a chunk that starts on the z-min wall needs none: E1_{x,y}[0] = 0 there) ----------
+  if (kA > 0 && do_e1) {
+    const long long pb = (long long)(kA - 1) * g.sxy + rowb;
+    float ezm[V], ezj[V], exm[V], eym[V], ho[V], hoy[V];
+    zero<V>(ezj);
+    ldf<V, true>(ezm, uni(a.ez + pb), ubc);
+    ldf<V, true>(exm, uni(a.ex + pb), ubc);
+    ldf<V, true>(eym, uni(a.ey + pb), ubc);
+    if (use_jp) ldf<V, true>(ezj, uni(a.ez + (long long)(kA - 1) * g.sxy + rowpb), ubc);
+    float ezx = __shfl_down(ezm[0], 1);
+    if (act && (tx == 63 || last_x)) ezx = last_x ? 0.f : a.ez[pb + ux + V];
+    const float ipz = s.ipz[kA - 1];
+    ldf<V, true>(ho, uni(a.hx + pb), ubc);
+    ldf<V, true>(hoy, uni(a.hy + pb), ubc);
+#pragma unroll
+    for (int e = 0; e < V; ++e) h1x[e] = upd_h(ho[e], ch, ezj[e] - ezm[e], ipy, eyk[e] - eym[e], ipz);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float ez_ip = (e + 1 < V) ? ezm[(e + 1) % V] : ezx;
+      h1y[e] = upd_h(hoy[e], ch, exk[e] - exm[e], ipz, ez_ip - ezm[e], ipx[e]);
+    }
+  }
+  int cur = 0;
+  for (int k = kA; k <= k1; ++k) {
+    const bool top = (k >= g.nz);          // the z-max wall: E1_{x,y} = 0, nothing to load
+    const long long pb = (long long)k * g.sxy + rowb;
+    const long long pjb = (long long)k * g.sxy + rowpb;
+    float exn[V], eyn[V], ezk[V], exj[V], ezj[V], hxn[V], hyn[V], hzn[V];
+    float ipz = 0.f, idz = 0.f;
+    float hy_m = 0.f, hz_m = 0.f, exn_m = 0.f;
+    if (!top) {
+      ipz = s.ipz[k]; idz = s.idz[k];
+      ldf<V, true>(exn, uni(a.ex + pb + g.sxy), ubc);
+      ldf<V, true>(eyn, uni(a.ey + pb + g.sxy), ubc);
+      ldf<V, true>(ezk, uni(a.ez + pb), ubc);
+      if (use_jp) {
+        ldf<V, true>(exj, uni(a.ex + pjb), ubc);
+        ldf<V, true>(ezj, uni(a.ez + pjb), ubc);
+      } else {
+        zero<V>(exj); zero<V>(ezj);
+      }
+      ldf<V, true>(hxn, uni(a.hx + pb), ubc);
+      ldf<V, true>(hyn, uni(a.hy + pb), ubc);
+      ldf<V, true>(hzn, uni(a.hz + pb), ubc);
+      float eyx = __shfl_down(eyk[0], 1);
+      float ezx = __shfl_down(ezk[0], 1);
+      if (act && (tx == 63 || last_x)) {
+        if (!last_x) { eyx = a.ey[pb + ux + V]; ezx = a.ez[pb + ux + V]; }
+        else { eyx = 0.f; ezx = 0.f; }
+      }
+      // ---- S1: H1[k] ----
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float ey_ip = (e + 1 < V) ? eyk[(e + 1) % V] : eyx;
+        const float ez_ip = (e + 1 < V) ? ezk[(e + 1) % V] : ezx;
+        hxn[e] = upd_h(hxn[e], ch, ezj[e] - ezk[e], ipy, eyn[e] - eyk[e], ipz);
+        hyn[e] = upd_h(hyn[e], ch, exn[e] - exk[e], ipz, ez_ip - ezk[e], ipx[e]);
+        hzn[e] = upd_h(hzn[e], ch, ey_ip - eyk[e], ipx[e], exj[e] - exk[e], ipy);
+      }
+      // x-halo column: H1_{y,z} at i0-1 recomputed by the tile's first lane
+      if (xh && do_e1) {
+        const long long pm = pb + im;
+        exn_m = a.ex[pm + g.sxy];
+        const float ez_mm = a.ez[pm], ey_mm = a.ey[pm];
+        const float ex_jm = use_jp ? a.ex[pjb + im] : 0.f;
+        const float hy_o = a.hy[pm], hz_o = a.hz[pm];
+        hy_m = upd_h(hy_o, ch, exn_m - exk_m, ipz, ezk[0] - ez_mm, ipx_m);
+        hz_m = upd_h(hz_o, ch, eyk[0] - ey_mm, ipx_m, ex_jm - exk_m, ipy);
+      }
+    } else {
+      zero<V>(exn); zero<V>(eyn); zero<V>(ezk); zero<V>(hxn); zero<V>(hyn); zero<V>(hzn);
+    }
+    {
+      float4 t4;
+      t4.x = hxn[0]; t4.y = hxn[1]; t4.z = hxn[2]; t4.w = hxn[3];
+      xch[0 * slot + me] = t4;
+      t4.x = hzn[0]; t4.y = hzn[1]; t4.z = hzn[2]; t4.w = hzn[3];
+      xch[1 * slot + me] = t4;
+    }
+    __syncthreads();
+    // ---- S2: E1[k] ----
+    float e1xn[V], e1yn[V], e1zn[V];
+    zero<V>(e1xn); zero<V>(e1yn); zero<V>(e1zn);
+    if (do_e1) {
+      float hyx = __shfl_up(hyn[V - 1], 1);
+      float hzx = __shfl_up(hzn[V - 1], 1);
+      if (!top) {
+        if (tx == 0 || first_x) {
+          if (xh) { hyx = hy_m; hzx = hz_m; }
+          else { hyx = 0.f; hzx = 0.f; }
+        }
+        float hxj[V], hzj[V];
+        if (j > 0) {
+          const float4 t0 = xch[0 * slot + me - 64];
+          const float4 t1 = xch[1 * slot + me - 64];
+          hxj[0] = t0.x; hxj[1] = t0.y; hxj[2] = t0.z; hxj[3] = t0.w;
+          hzj[0] = t1.x; hzj[1] = t1.y; hzj[2] = t1.z; hzj[3] = t1.w;
+        } else {
+          zero<V>(hxj); zero<V>(hzj);
+        }
+        const bool wall_z = (k == 0);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const float hy_im = (e > 0) ? hyn[(e + V - 1) % V] : hyx;
+          const float hz_im = (e > 0) ? hzn[(e + V - 1) % V] : hzx;
+          float nex = upd_e(exk[e], ca, cb, hzn[e] - hzj[e], idy, hyn[e] - h1y[e], idz);
+          float ney = upd_e(eyk[e], ca, cb, hxn[e] - h1x[e], idz, hzn[e] - hz_im, idx[e]);
+          float nez = upd_e(ezk[e], ca, cb, hyn[e] - hy_im, idx[e], hxn[e] - hxj[e], idy);
+          const bool wx = wall_x0 && (e == 0);
+          if (wall_y || wall_z) nex = 0.f;
+          if (wx || wall_z) ney = 0.f;
+          if (wx || wall_y) nez = 0.f;
+          e1xn[e] = nex; e1yn[e] = ney; e1zn[e] = nez;
+        }
+        // the E-side point sources of step n act on E^{n+1} before step n+1 reads it
+        if (inj.n > 0) {
+          const int q1 = inj.start[k + 1];
+          for (int q = inj.start[k]; q < q1; ++q) {
+            const int4 en = inj.ent[q];
+            if (en.y == j) {
+              const int d = en.x - i0;
+              const float v = inj.val[en.w];
+#pragma unroll
+              for (int e = 0; e < V; ++e) {
+                if (d == e) {
+                  if (en.z == 0) e1xn[e] += v;
+                  else if (en.z == 1) e1yn[e] += v;
+                  else e1zn[e] += v;
+                }
+              }
+            }
+          }
+        }
+        // what the neighbouring x tile needs of this step: repaired on the seam by seam_h / seam_e
+        if (own && k >= k0 && k < k1 && act) {
+          if (tx == 63 && !last_x) {
+            seam[seam_at(g, tile_x, 0, j, k)] = hyn[V - 1];
+            seam[seam_at(g, tile_x, 1, j, k)] = hzn[V - 1];
+            seam[seam_at(g, tile_x, 2, j, k)] = e1xn[V - 1];
+            seam[seam_at(g, tile_x, 3, j, k)] = e1yn[V - 1];
+            seam[seam_at(g, tile_x, 4, j, k)] = e1zn[V - 1];
+          }
+          if (tx == 0 && tile_x > 0) {
+            seam[seam_at(g, tile_x - 1, 5, j, k)] = e1yn[0];
+            seam[seam_at(g, tile_x - 1, 6, j, k)] = e1zn[0];
+          }
+        }
+      }
+    }
+    // ---- S3: H2[k-1] ----
+    float h2x[V], h2y[V], h2z[V];
+    zero<V>(h2x); zero<V>(h2y); zero<V>(h2z);
+    if (do_h2 && k > kA) {
+      float eyx = __shfl_down(e1y[0], 1);
+      float ezx = __shfl_down(e1z[0], 1);
+      if (tx == 63 || last_x) { eyx = 0.f; ezx = 0.f; }      // the wall, or a seam (repaired by seam_h_kernel)
+      const float4 t0 = xch[(4 + (cur ^ 1) * 2 + 0) * slot + me + 64];
+      const float4 t1 = xch[(4 + (cur ^ 1) * 2 + 1) * slot + me + 64];
+      const float exj1[V] = {t0.x, t0.y, t0.z, t0.w}, ezj1[V] = {t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float ey_ip = (e + 1 < V) ? e1y[(e + 1) % V] : eyx;
+        const float ez_ip = (e + 1 < V) ? e1z[(e + 1) % V] : ezx;
+        h2x[e] = upd_h(h1x[e], ch, ezj1[e] - e1z[e], ipy, e1yn[e] - e1y[e], ipz_m);
+        h2y[e] = upd_h(h1y[e], ch, e1xn[e] - e1x[e], ipz_m, ez_ip - e1z[e], ipx[e]);
+        h2z[e] = upd_h(h1z[e], ch, ey_ip - e1y[e], ipx[e], exj1[e] - e1x[e], ipy);
+      }
+    }
+    {
+      float4 t4;
+      t4.x = e1xn[0]; t4.y = e1xn[1]; t4.z = e1xn[2]; t4.w = e1xn[3];
+      xch[(4 + cur * 2 + 0) * slot + me] = t4;
+      t4.x = e1zn[0]; t4.y = e1zn[1]; t4.z = e1zn[2]; t4.w = e1zn[3];
+      xch[(4 + cur * 2 + 1) * slot + me] = t4;
+      t4.x = h2x[0]; t4.y = h2x[1]; t4.z = h2x[2]; t4.w = h2x[3];
+      xch[2 * slot + me] = t4;
+      t4.x = h2z[0]; t4.y = h2z[1]; t4.z = h2z[2]; t4.w = h2z[3];
+      xch[3 * slot + me] = t4;
+    }
+    __syncthreads();
+    // ---- S4: E2[k-1] ----
+    if (own && k > k0) {
+      float hyx = __shfl_up(h2y[V - 1], 1);
+      float hzx = __shfl_up(h2z[V - 1], 1);
+      if (tx == 0 || first_x) { hyx = 0.f; hzx = 0.f; }      // the wall, or a seam (repaired by seam_e_kernel)
+      float hxj[V], hzj[V];
+      if (j > 0) {
+        const float4 t0 = xch[2 * slot + me - 64];
+        const float4 t1 = xch[3 * slot + me - 64];
+        hxj[0] = t0.x; hxj[1] = t0.y; hxj[2] = t0.z; hxj[3] = t0.w;
+        hzj[0] = t1.x; hzj[1] = t1.y; hzj[2] = t1.z; hzj[3] = t1.w;
+      } else {
+        zero<V>(hxj); zero<V>(hzj);
+      }
+      const bool wall_z = (k - 1 == 0);
+      float ex[V], ey[V], ez[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float hy_im = (e > 0) ? h2y[(e + V - 1) % V] : hyx;
+        const float hz_im = (e > 0) ? h2z[(e + V - 1) % V] : hzx;
+        float nex = upd_e(e1x[e], ca, cb, h2z[e] - hzj[e], idy, h2y[e] - h2ym[e], idz_m);
+        float ney = upd_e(e1y[e], ca, cb, h2x[e] - h2xm[e], idz_m, h2z[e] - hz_im, idx[e]);
+        float nez = upd_e(e1z[e], ca, cb, h2y[e] - hy_im, idx[e], h2x[e] - hxj[e], idy);
+        const bool wx = wall_x0 && (e == 0);
+        if (wall_y || wall_z) nex = 0.f;
+        if (wx || wall_z) ney = 0.f;
+        if (wx || wall_y) nez = 0.f;
+        ex[e] = nex; ey[e] = ney; ez[e] = nez;
+      }
+      if (act) {
+        const long long po = pb - g.sxy + i0;
+        stv_h<V, NT>(b.hx + po, h2x);
+        stv_h<V, NT>(b.hy + po, h2y);
+        stv_h<V, NT>(b.hz + po, h2z);
+        stv_h<V, NT>(b.ex + po, ex);
+        stv_h<V, NT>(b.ey + po, ey);
+        stv_h<V, NT>(b.ez + po, ez);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      h2xm[e] = h2x[e]; h2ym[e] = h2y[e];
+      h1x[e] = hxn[e]; h1y[e] = hyn[e]; h1z[e] = hzn[e];
+      e1x[e] = e1xn[e]; e1y[e] = e1yn[e]; e1z[e] = e1zn[e];
+      exk[e] = exn[e]; eyk[e] = eyn[e];
+    }
+    exk_m = exn_m;
+    ipz_m = ipz; idz_m = idz;
+    cur ^= 1;
+  }
+}
+
+// ---- the seams between x tiles -------------------------------------------------------------------------------------
+// One thread per (seam, j, k).  c = first column of the right tile.  H2_{y,z}[c-1] needs E1_{y,z}[c] of the right tile.
+__global__ __launch_bounds__(256) void seam_h_kernel(GridP g, FieldP b, StepP s, const float* __restrict__ seam,
+                                                     int n_seams) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long per = (long long)g.ny * g.nz;
+  if (t >= per * n_seams) return;
+  const int sm = (int)(t / per);
+  const int k = (int)((t % per) / g.ny), j = (int)(t % g.ny);
+  const int c = (sm + 1) * 256;
+  const float ch = g.ch;
+  const float h1y = seam[seam_at(g, sm, 0, j, k)], h1z = seam[seam_at(g, sm, 1, j, k)];
+  const float e1x = seam[seam_at(g, sm, 2, j, k)], e1y = seam[seam_at(g, sm, 3, j, k)], e1z = seam[seam_at(g, sm, 4, j, k)];
+  const float e1x_kp = seam[seam_at(g, sm, 2, j, k + 1)];                       // plane nz of the scratch stays 0: the wall
+  const float e1x_jp = (j + 1 < g.ny) ? seam[seam_at(g, sm, 2, j + 1, k)] : 0.f;
+  const float e1y_c = seam[seam_at(g, sm, 5, j, k)], e1z_c = seam[seam_at(g, sm, 6, j, k)];
+  const float ipx = s.ipx[c - 1], ipy = s.ipy[j], ipz = s.ipz[k];
+  const long long p = (long long)k * g.sxy + (long long)j * g.nx + (c - 1);
+  b.hy[p] = upd_h(h1y, ch, e1x_kp - e1x, ipz, e1z_c - e1z, ipx);
+  b.hz[p] = upd_h(h1z, ch, e1y_c - e1y, ipx, e1x_jp - e1x, ipy);
+}
+
+// E2_{x,y,z}[c-1] and E2_{y,z}[c]: everything that differentiates H2_{y,z}[c-1]  (after seam_h_kernel)
+__global__ __launch_bounds__(256) void seam_e_kernel(GridP g, FieldP b, StepP s, float ca, float cb,
+                                                     const float* __restrict__ seam, int n_seams) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long per = (long long)g.ny * g.nz;
+  if (t >= per * n_seams) return;
+  const int sm = (int)(t / per);
+  const int k = (int)((t % per) / g.ny), j = (int)(t % g.ny);
+  const int c = (sm + 1) * 256;
+  const bool wall_y = (j == 0), wall_z = (k == 0);
+  const long long p = (long long)k * g.sxy + (long long)j * g.nx + c;       // column c; p - 1 = column c-1
+  const long long pj = p - g.nx, pk = p - g.sxy;
+  const float idy = s.idy[j], idz = s.idz[k], idx_m = s.idx[c - 1], idx_c = s.idx[c];
+  const float e1x = seam[seam_at(g, sm, 2, j, k)], e1y = seam[seam_at(g, sm, 3, j, k)], e1z = seam[seam_at(g, sm, 4, j, k)];
+  const float e1y_c = seam[seam_at(g, sm, 5, j, k)], e1z_c = seam[seam_at(g, sm, 6, j, k)];
+  const float hx_m = b.hx[p - 1], hy_m = b.hy[p - 1], hz_m = b.hz[p - 1];      // column c-1
+  const float hx_c = b.hx[p], hy_c = b.hy[p], hz_c = b.hz[p];                  // column c
+  const float hy_mm = b.hy[p - 2], hz_mm = b.hz[p - 2];                        // column c-2
+  float ex_m = 0.f, ey_m = 0.f, ez_m = 0.f, ey_c = 0.f, ez_c = 0.f;
+  if (!wall_y && !wall_z) ex_m = upd_e(e1x, ca, cb, hz_m - b.hz[pj - 1], idy, hy_m - b.hy[pk - 1], idz);
+  if (!wall_z) {
+    ey_m = upd_e(e1y, ca, cb, hx_m - b.hx[pk - 1], idz, hz_m - hz_mm, idx_m);
+    ey_c = upd_e(e1y_c, ca, cb, hx_c - b.hx[pk], idz, hz_c - hz_m, idx_c);
+  }
+  if (!wall_y) {
+    ez_m = upd_e(e1z, ca, cb, hy_m - hy_mm, idx_m, hx_m - b.hx[pj - 1], idy);
+    ez_c = upd_e(e1z_c, ca, cb, hy_c - hy_m, idx_c, hx_c - b.hx[pj], idy);
+  }
+  b.ex[p - 1] = ex_m; b.ey[p - 1] = ey_m; b.ez[p - 1] = ez_m;
+  b.ey[p] = ey_c; b.ez[p] = ez_c;
+}
+
+}  // namespace fdtd

@@ -45,7 +45,7 @@ BC_PEC, BC_PMC, BC_PERIODIC, BC_NEIGHBOR = 0, 1, 2, 3
 MON_TIME, MON_DFT = 0, 1
 VARIANT_AUTO, VARIANT_SIMPLE, VARIANT_ZMARCH, VARIANT_FUSED = 0, 1, 2, 3
 FLAG_TIME_KERNELS = 1
-OPT_FLAGS, OPT_VARIANT, OPT_ZCHUNK, OPT_ROWS, OPT_XCD_REMAP, OPT_FUSED_LB, OPT_PML_FUSED, OPT_BND_PLANES, OPT_AUTOTUNE, OPT_PML_SPLIT, OPT_LDS_PAD, OPT_MEM_HINTS, OPT_PLACEMENT_TRIES, OPT_TBLOCK, OPT_EDGE_ZCHUNK, OPT_GRAPH = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
+OPT_FLAGS, OPT_VARIANT, OPT_ZCHUNK, OPT_ROWS, OPT_XCD_REMAP, OPT_FUSED_LB, OPT_PML_FUSED, OPT_BND_PLANES, OPT_AUTOTUNE, OPT_PML_SPLIT, OPT_LDS_PAD, OPT_MEM_HINTS, OPT_PLACEMENT_TRIES, OPT_TBLOCK, OPT_EDGE_ZCHUNK, OPT_GRAPH, OPT_TWOSTEP = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16
 
 
 class FdtdConfig(C.Structure):
@@ -67,7 +67,7 @@ class FdtdStats(C.Structure):
                 ("stream_overlap", C.c_int32), ("stream_retries", C.c_int32),
                 ("comm_ranks", C.c_int32), ("comm_rank", C.c_int32),
                 ("two_step_pairs", C.c_int64), ("tblock_planes", C.c_int32), ("reserved0", C.c_int32),
-                ("graph_pairs", C.c_int64)]
+                ("graph_pairs", C.c_int64), ("fused2_pairs", C.c_int64)]
 
 
 PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_int64, C.c_double, C.c_double, C.c_void_p)
