@@ -304,3 +304,27 @@ def test_store_hints_and_address_space_paths_change_nothing_on_the_device(hip_li
     a, b = run(1), run(0)
     for c in range(6):
         assert np.array_equal(a[c], b[c]), c
+
+
+@pytest.mark.parametrize("w,zc,n", [(16, 32, 512), (12, 16, 512), (8, 64, 512), (16, 32, 320)])
+def test_two_steps_per_sweep_bit_identical_bench_v0(hip_lib, w, zc, n):
+    """FDTD_OPT_TWOSTEP on real hardware: bench.py's headline workload (random initial fields, PEC walls, a dipole; two x tiles
+    -> the seam kernels) advanced by fused2_step_kernel == single sweeps, bit for bit; odd step count -> one single step."""
+    from bench import build_spec
+    steps = 13
+    spec = build_spec(n, steps + 4, "v0")
+    init = _bench_init(n)
+
+    def run(twostep):
+        with HipEngine(spec, lib=hip_lib, axis_shift=0) as e:
+            e.set_option(L.OPT_TWOSTEP, twostep)
+            e.set_option(L.OPT_PLACEMENT_TRIES, 0)
+            for c in range(6):
+                e.set_field(c, init[c])
+            st = e.run(steps)
+            return [e.get_field(c) for c in range(6)], int(st.fused2_pairs)
+    ref, p0 = run(0)
+    got, p1 = run(w + 64 * zc)
+    assert p0 == 0 and p1 == steps // 2
+    for c in range(6):
+        assert np.array_equal(got[c], ref[c]), c
