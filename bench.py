@@ -100,11 +100,12 @@ def cpu_baseline(n: int = 320, steps: int = 18):
 
 
 def source_hash() -> str:
-    """sha256 over the kernel source (every __global__ function lives in fdtd_kernels.hpp): ties a PMC traffic
-    figure to the kernel code it was measured on."""
+    """sha256 over the kernel sources (every __global__ function lives in fdtd_kernels.hpp / fdtd_kernels2.hpp): ties a
+    PMC traffic figure to the kernel code it was measured on."""
     import hashlib
     h = hashlib.sha256()
-    h.update(open(os.path.join(ROOT, "tidy3d_amd/csrc/fdtd_kernels.hpp"), "rb").read())
+    for f in ("fdtd_kernels.hpp", "fdtd_kernels2.hpp", "fdtd_fused2.hip"):
+        h.update(open(os.path.join(ROOT, "tidy3d_amd/csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -130,7 +131,16 @@ def roofline_entry(st, kr, local_cells, cells, K, elapsed, world, workload, spec
     e_step = st.e_kernel_ms / kr
     f_step = st.fused_kernel_ms / kr
     survey_bytes = 2 * BYTES_PER_CELL_PASS * local_cells        # 72 B per cell-step, two passes
-    if st.fused_kernel_launches:
+    two_step = int(getattr(st, "fused2_pairs", 0)) > 0
+    if two_step:
+        # ONE launch advances E and H by TWO time steps (fused2_step_kernel + the two seam kernels, timed together).
+        # `frac` stays priced on the single sweep's minimum, 48 B per cell-step x 2 steps per launch — the yardstick of
+        # every earlier round — so temporal blocking shows as a fraction ABOVE what a one-step-per-pass kernel can reach;
+        # `frac_own_minimum` prices the launch on what IT must move at least (6 reads + 6 writes per cell, once).
+        dom, dom_ms = "fused2_step_kernel", f_ms
+        dom_bytes = 2 * min_bytes_per_cell(workload, spec) * local_cells
+        survey_bytes = 2 * survey_bytes
+    elif st.fused_kernel_launches:
         # one launch advances E and H.  `frac` is priced against what THIS kernel must move at least
         # (48 B per cell-step + psi), so it cannot exceed 1; the two-pass figure of SURVEY.md 8(d) that the
         # north-star target (>= 70 %) is quoted on is reported beside it as frac_vs_survey_8d
@@ -150,8 +160,15 @@ def roofline_entry(st, kr, local_cells, cells, K, elapsed, world, workload, spec
          "per_step_ms": {"h_update_kernel": h_step, "e_update_kernel": e_step, "fused_step_kernel": f_step},
          "algorithmic_bytes_per_launch": dom_bytes,
          "algorithmic_bytes_per_cell": dom_bytes / local_cells,
+         "time_steps_per_launch": 2 if two_step else 1,
          "whole_step_frac": (dom_bytes / local_cells * cells * K / elapsed) / (HBM_PEAK * world),
          "whole_step_frac_vs_survey_8d": (2 * BYTES_PER_CELL_PASS * cells * K / elapsed) / (HBM_PEAK * world)}
+    if two_step:
+        shape = int(st.fused2_shape)
+        r["two_steps_per_sweep"] = {"waves_per_workgroup": shape & 63, "planes_per_chunk": shape >> 6,
+                                    "pairs_in_this_run": int(st.fused2_pairs),
+                                    "own_minimum_bytes_per_launch": 48.0 * local_cells,
+                                    "frac_own_minimum": (48.0 * local_cells / (dom_ms * 1e-3) / HBM_PEAK) if dom_ms > 0 else 0.0}
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc) and workload == "v0":
         try:
@@ -377,7 +394,8 @@ def main():
         "repeats": {"n": R, "statistic": "median", "ms_per_step": [e / K * 1e3 for e in samples],
                     "min_ms_per_step": min(samples) / K * 1e3, "max_ms_per_step": max(samples) / K * 1e3},
         "roofline": roofline_entry(st, kr, local_cells, cells, K, elapsed, world, args.workload, spec),
-        "schedule": {"two_step_pairs_in_roofline_run": int(st.two_step_pairs), "tblock_planes": int(st.tblock_planes),
+        "schedule": {"two_steps_per_sweep_pairs_in_roofline_run": int(st.fused2_pairs),
+                     "two_step_pairs_in_roofline_run": int(st.two_step_pairs), "tblock_planes": int(st.tblock_planes),
                      "stream_overlap": int(st.stream_overlap), "stream_retries": int(st.stream_retries)},
     }
     if world > 1:
@@ -392,6 +410,16 @@ def main():
                        "planes_per_rank": [r[2] for r in rows],
                        "ms_per_step_per_rank": [float(v) for v in med],
                        "ms_per_step_rank_min": float(med.min()), "ms_per_step_rank_max": float(med.max())}
+    if world == 1 and int(st.fused2_pairs) > 0:
+        # the same engine (same placement of the arrays) advancing ONE step per sweep: what the headline was before
+        # the two-step kernel, and what every run outside its scope still gets
+        eng.set_option(L.OPT_TWOSTEP, 0)
+        eng.run(10)
+        ss = [timed(40) for _ in range(3)]
+        eng.set_option(L.OPT_TWOSTEP, -1)
+        el1 = float(np.median(ss))
+        out["single_steps"] = {"value": cells * 40 / el1 / 1e6, "unit": "Mcells/s", "ms_per_step": el1 / 40 * 1e3,
+                               "steps": 40, "repeats": 3, "kernel": "fused_step_kernel"}
     if world == 1 and not emulate and args.workload == "v0" and not args.no_workloads:
         # the workload every real simulation resembles (materials + CPML on all faces), same grid, same box
         eng.close()

@@ -82,6 +82,7 @@ typedef struct FdtdStats {
   int32_t reserved0;         /* graph capture diagnostics: 0 = none attempted, 1 = captured, < 0 = -(100 stage + hipError) */
   int64_t graph_pairs;       /* step pairs replayed as captured hipGraphs in the last fdtd_run (FDTD_OPT_GRAPH) */
   int64_t fused2_pairs;      /* step pairs advanced by the two-steps-per-sweep kernel in the last fdtd_run (FDTD_OPT_TWOSTEP) */
+  int64_t fused2_shape;      /* its tile shape: waves per workgroup | planes per chunk << 6 (0 = no pair was taken) */
 } FdtdStats;
 
 /* progress callback: (step, time [s], field_decay) -> non-zero aborts the run (Ctrl-C path).
@@ -242,8 +243,9 @@ enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_R
                                hipGraphs of two steps: -1 = default (off: on ROCm 7.2 replaying costs ~3 us per step MORE than the
                                launches it replaces, profiles/r3i), 0 = never, 1 = whenever possible */
        FDTD_OPT_TWOSTEP = 16, /* two time steps per sweep (in-kernel temporal blocking; uniform medium inside six PEC walls, E-side
-                                 point sources, one GPU — everything else takes single steps): 0 = off, else
-                                 waves per workgroup (4 ... 16; W - 3 rows of a tile are written) + 64 * planes per chunk (0 = 32) */
+                                 point sources, one GPU, no record / decay check on the middle step — everything else takes
+                                 single steps): -1 = default (on, tile shape by grid size), 0 = off, else waves per workgroup
+                                 (4 ... 16; W - 3 rows of a tile are written) + 64 * planes per chunk (0 = by grid size) */
        FDTD_OPT_LDS_PAD = 10 /* measuring aid: extra dynamic LDS per workgroup of the sweep in bytes (lowers its occupancy) */ };
 int fdtd_set_option(FdtdSolver* h, int key, int value);
 int fdtd_reset(FdtdSolver* h);      /* zero fields, auxiliaries, monitors and the step counter */

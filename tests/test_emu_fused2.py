@@ -52,7 +52,7 @@ SHAPES = {
 
 
 @pytest.mark.parametrize("name", sorted(SHAPES))
-@pytest.mark.parametrize("w,zc", [(16, 32), (4, 2), (5, 3), (8, 5)])
+@pytest.mark.parametrize("w,zc", [(16, 32), (4, 2), (5, 3), (8, 5), (8 + (1 << 16), 3), (6 + (1 << 16), 32)])
 def test_two_steps_per_sweep_equal_single_steps(name, w, zc, emu_lib):
     N = SHAPES[name]
     disc = discretize(_sim(N, monitors=False), n_steps=26)

@@ -9,8 +9,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfdtd_hip.so")
-SOURCES = [os.path.join(CSRC, "fdtd_capi.hip")]
+SOURCES = [os.path.join(CSRC, "fdtd_capi.hip"), os.path.join(CSRC, "fdtd_fused2.hip")]
+# per-source flags: the two-steps-per-sweep kernels are built with the SLP vectorizer off (fdtd_fused2.hpp)
+SOURCE_FLAGS = {"fdtd_fused2.hip": ["-fno-slp-vectorize"]}
 DEPS = SOURCES + [os.path.join(CSRC, "fdtd_kernels.hpp"), os.path.join(CSRC, "fdtd_kernels2.hpp"),
+                  os.path.join(CSRC, "fdtd_fused2.hpp"),
                   os.path.join(HERE, "..", "include", "fdtd_hip.h"), os.path.abspath(__file__)]
 
 
@@ -32,13 +35,26 @@ def build(force: bool = False, verbose: bool = True) -> str:
     # -mllvm -disable-lsr: loop strength reduction turns the sweep's  uniform base + lane offset  addresses
     # into per-lane 64-bit induction pointers (a VGPR pair per array for the whole z-march): 110 -> 100
     # VGPRs for the plain sweep, 167 + spills -> 153 for the one that carries materials and CPML.
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-mllvm", "-disable-lsr", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value", "-I/opt/rocm/include",
-           *os.environ.get("FDTD_EXTRA_HIPCC_FLAGS", "").split(),     # e.g. -DFDTD_PLACEMENT_PROBE for scripts/probe_layout.py
-           *SOURCES, "-o", LIB, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+              "-mllvm", "-disable-lsr", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value", "-I/opt/rocm/include",
+              *os.environ.get("FDTD_EXTRA_HIPCC_FLAGS", "").split()]     # e.g. -DFDTD_PLACEMENT_PROBE for scripts/probe_layout.py
+    objs, procs = [], []
+    for src in SOURCES:                    # the translation units compile side by side
+        obj = os.path.join(CSRC, os.path.basename(src) + ".o")
+        cmd = [*common, *SOURCE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    for o in objs:
+        os.remove(o)
     return LIB
 
 

@@ -17,7 +17,7 @@
 
 #include "../../include/fdtd_hip.h"
 #include "fdtd_kernels.hpp"
-#include "fdtd_kernels2.hpp"
+#include "fdtd_fused2.hpp"
 
 using namespace fdtd;
 
@@ -194,7 +194,8 @@ struct FdtdSolver {
   long long two_step_pairs = 0;
   int tblock_used = 0;
   // two time steps per sweep (fused2_step_kernel): waves per workgroup (0 = off) and planes per chunk
-  int twostep_w = 0, twostep_zc = 32;
+  int twostep_w = -1, twostep_zc = 0, twostep_pf = 0;      // -1 / 0: chosen by fused2_shape
+  int twostep_w_used = 0, twostep_zc_used = 0;
   long long fused2_pairs = 0;
   float* seam_buf = nullptr;          // intermediate values on the seams between x tiles
   float* inj_val = nullptr;           // source terms applied between the two steps
@@ -601,8 +602,24 @@ int launch_fused(FdtdSolver* h, hipStream_t st, int pml_inside) {
 // What fused2_step_kernel covers: the plain curl stencil of a uniform medium inside six PEC walls on one GPU, driven by
 // E-side point sources.  Anything else (materials, CPML, absorbers, ADE, TFSF, periodic / PMC / Bloch faces, mirror
 // faces, magnetic dipoles, z-slabs) takes single steps.
+// Tile shape of the two-step sweep: waves per workgroup and planes per chunk.  Asked for through FDTD_OPT_TWOSTEP, or
+// (default) 16 waves and the longest chunk of 32 / 24 / 16 / 12 / 8 planes that still gives the 256 CUs four workgroups
+// each; grids too small for that at 8 planes keep single steps (a chunk recomputes two planes below it).
+bool fused2_shape(const FdtdSolver* h, int* W, int* zc) {
+  const GridP& g = h->g;
+  *W = h->twostep_w > 0 ? h->twostep_w : 16;
+  const int R = *W - 3, nbx = (g.nx + 255) / 256, nby = (g.ny + R - 1) / R;
+  if (h->twostep_zc > 0) { *zc = std::max(2, std::min(h->twostep_zc, g.nz)); return true; }
+  for (int c : {32, 24, 16, 12, 8}) {
+    *zc = c;
+    if ((long long)nbx * nby * ((g.nz + c - 1) / c) >= 1024) return true;
+  }
+  return h->twostep_w > 0;
+}
+
 bool fused2_eligible(const FdtdSolver* h) {
-  if (h->twostep_w <= 0) return false;
+  if (h->twostep_w == 0) return false;
+  { int W, zc; if (!fused2_shape(h, &W, &zc)) return false; }
   if (h->comm || h->mat4 || any_pml(h) || h->has_damp || !h->ade.empty() || !h->tfsf.empty()) return false;
   for (int f = 0; f < 6; ++f) if (h->cfg.bc[f] != FDTD_BC_PEC) return false;
   if (!h->g.pec_z0 || h->g.nx % 4 || h->g.nz < 2) return false;
@@ -629,9 +646,12 @@ bool fused2_sources_uniform(const FdtdSolver* h, long long n) {
 int launch_fused2(FdtdSolver* h, long long n, hipStream_t st) {
   const GridP& g = h->g;
   if (ensure_second_set(h)) return -1;
-  const int W = h->twostep_w, R = W - 3;
+  int W = 16, zc = 32;
+  fused2_shape(h, &W, &zc);
+  zc = std::max(2, std::min(zc, g.nz));
+  h->twostep_w_used = W; h->twostep_zc_used = zc;
+  const int R = W - 3;
   const int nbx = (g.nx + 255) / 256, nby = (g.ny + R - 1) / R;
-  const int zc = std::max(2, std::min(h->twostep_zc, g.nz));
   const int nbz = (g.nz + zc - 1) / zc;
   if (nbx > 1 && !h->seam_buf &&
       dev_alloc(h, &h->seam_buf, (size_t)(nbx - 1) * kSeamArrays * (size_t)(g.nz + 2) * (size_t)g.ny)) return -1;
@@ -665,8 +685,7 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st) {
     for (const PointSrc& s : h->psrc) {
       if (s.n_e && n < s.n_steps) {
         alive = true;
-        hipLaunchKernelGGL(inject_values_kernel, dim3(1), dim3(256), 0, st, h->inj_val + off, (const float*)s.wre_e,
-                           (const float*)s.wim_e, (const float2*)s.wave_e, n, (int)s.n_e);
+        launch_inject_values(st, h->inj_val + off, s.wre_e, s.wim_e, s.wave_e, n, (int)s.n_e);
       }
       off += (int)s.n_e;
     }
@@ -675,27 +694,11 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st) {
   }
   const int total = nbx * nby * nbz;
   const int remap = h->xcd_remap < 0 ? kTileRun : h->xcd_remap;
-  dim3 grid(remap ? ((total + 7) / 8) * 8 : total, 1, 1), block(64, W, 1);
-  const size_t shmem = (size_t)8 * W * 64 * sizeof(float4);
   StepP sp = step_params(h);
   time_begin(h, 2, st);
-#define FDTD_LAUNCH_FUSED2(LBV)                                                                                      \
-  do {                                                                                                               \
-    if (h->mem_hints) hipLaunchKernelGGL((fused2_step_kernel<LBV, true>), grid, block, shmem, st, g, h->f, h->f2, sp, \
-                                         h->ca1, h->cb1, zc, nbx, nby, nbz, remap, inj, h->seam_buf);                \
-    else hipLaunchKernelGGL((fused2_step_kernel<LBV, false>), grid, block, shmem, st, g, h->f, h->f2, sp, h->ca1,     \
-                            h->cb1, zc, nbx, nby, nbz, remap, inj, h->seam_buf);                                     \
-  } while (0)
-  if (W <= 8) FDTD_LAUNCH_FUSED2(512);
-  else if (W <= 12) FDTD_LAUNCH_FUSED2(768);
-  else FDTD_LAUNCH_FUSED2(1024);
-#undef FDTD_LAUNCH_FUSED2
-  if (nbx > 1) {
-    const long long nt = (long long)(nbx - 1) * g.ny * g.nz;
-    hipLaunchKernelGGL(seam_h_kernel, dim3(nblk(nt)), dim3(256), 0, st, g, h->f2, sp, (const float*)h->seam_buf, nbx - 1);
-    hipLaunchKernelGGL(seam_e_kernel, dim3(nblk(nt)), dim3(256), 0, st, g, h->f2, sp, h->ca1, h->cb1,
-                       (const float*)h->seam_buf, nbx - 1);
-  }
+  launch_fused2_step(st, W, (h->mem_hints ? 1 : 0) | (h->twostep_pf ? 2 : 0), remap ? ((total + 7) / 8) * 8 : total, g, h->f,
+                     h->f2, sp, h->ca1, h->cb1, zc, nbx, nby, nbz, remap, inj, h->seam_buf);
+  if (nbx > 1) launch_seams(st, g, h->f2, sp, h->ca1, h->cb1, h->seam_buf, nbx - 1);
   time_end(h, st);
   swap_sets(h);
   return 0;
@@ -2641,11 +2644,12 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_EDGE_ZCHUNK: h->edge_zchunk = value < 0 ? -1 : value; return 0;
     case FDTD_OPT_GRAPH: h->use_graph = value < 0 ? -1 : (value != 0); return 0;
     case FDTD_OPT_TWOSTEP: {
-      if (value <= 0) { h->twostep_w = 0; return 0; }
-      const int w = value % 64, zc = value / 64;
+      if (value <= 0) { h->twostep_w = value < 0 ? -1 : 0; h->twostep_zc = 0; h->twostep_pf = 0; return 0; }
+      const int w = value % 64, zc = (value / 64) % 1024;
+      h->twostep_pf = (value >> 16) & 1;
       if (w < 4 || w > 16) return fail(h, "FDTD_OPT_TWOSTEP: %d waves per workgroup (4 ... 16)", w);
       h->twostep_w = w;
-      h->twostep_zc = zc > 0 ? zc : 32;
+      h->twostep_zc = zc;
       return 0;
     }
     case FDTD_OPT_PML_SPLIT: h->pml_split = value < 0 ? -1 : (value != 0); return 0;
@@ -2671,6 +2675,7 @@ int fdtd_get_stats(FdtdSolver* h, FdtdStats* out) {
   out->graph_pairs = h->graph_pairs;
   out->reserved0 = h->graph_status;
   out->fused2_pairs = h->fused2_pairs;
+  out->fused2_shape = h->fused2_pairs ? (h->twostep_w_used | (h->twostep_zc_used << 6)) : 0;
   return 0;
 }
 

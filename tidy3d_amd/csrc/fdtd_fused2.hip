@@ -1,0 +1,50 @@
+// Translation unit of the two-steps-per-sweep kernels (fdtd_kernels2.hpp) and their host-side launchers.
+// Built with -fno-slp-vectorize (tidy3d_amd/build.py): see fdtd_fused2.hpp.
+#include <hip/hip_runtime.h>
+// fdtd_kernels.hpp defines its kernels in the header (it was written for one translation unit).  This second unit only
+// needs its types and device helpers: here every kernel gets internal linkage, and the ones not launched from this
+// file are dropped.
+#undef __global__
+#if defined(__HIPCC__)
+#define __global__ static __attribute__((global))
+#else
+#define __global__ static
+#endif
+#include "fdtd_kernels2.hpp"
+
+namespace fdtd {
+
+void launch_inject_values(hipStream_t st, float* val, const float* w_re, const float* w_im, const float2* wave,
+                          long long step, int n) {
+  hipLaunchKernelGGL(inject_values_kernel, dim3(1), dim3(256), 0, st, val, w_re, w_im, wave, step, n);
+}
+
+void launch_fused2_step(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
+                        const FieldP& b, const StepP& s, float ca, float cb, int zchunk, int nbx, int nby, int nbz,
+                        int xcd_remap, const InjP& inj, float* seam) {
+  const dim3 grid(grid_blocks, 1, 1), block(64, waves, 1);
+  const size_t shmem = (size_t)8 * waves * 64 * sizeof(float4);
+#define FDTD_F2_O(LBV, OV)                                                                                             \
+  hipLaunchKernelGGL((fused2_step_kernel<LBV, OV>), grid, block, shmem, st, g, a, b, s, ca, cb, zchunk, nbx, nby, nbz, \
+                     xcd_remap, inj, seam)
+#define FDTD_F2(LBV)                                                                                                   \
+  do {                                                                                                                 \
+    if ((opt & 3) == 3) FDTD_F2_O(LBV, 3); else if ((opt & 3) == 2) FDTD_F2_O(LBV, 2);                                 \
+    else if ((opt & 3) == 1) FDTD_F2_O(LBV, 1); else FDTD_F2_O(LBV, 0);                                                \
+  } while (0)
+  if (waves <= 8) FDTD_F2(512);
+  else if (waves <= 12) FDTD_F2(768);
+  else FDTD_F2(1024);
+#undef FDTD_F2
+#undef FDTD_F2_O
+}
+
+void launch_seams(hipStream_t st, const GridP& g, const FieldP& b, const StepP& s, float ca, float cb, const float* seam,
+                  int n_seams) {
+  const long long nt = (long long)n_seams * g.ny * g.nz;
+  const unsigned blocks = (unsigned)((nt + 255) / 256);
+  hipLaunchKernelGGL(seam_h_kernel, dim3(blocks), dim3(256), 0, st, g, b, s, seam, n_seams);
+  hipLaunchKernelGGL(seam_e_kernel, dim3(blocks), dim3(256), 0, st, g, b, s, ca, cb, seam, n_seams);
+}
+
+}  // namespace fdtd

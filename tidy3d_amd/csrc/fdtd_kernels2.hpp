@@ -22,17 +22,9 @@
 // Scope (fdtd_capi.hip checks it): uniform medium, PEC on all six faces, no CPML / absorber / ADE / TFSF / Bloch /
 // mirror faces, E-side point sources only (<= kMaxInj nodes), one GPU.  Everything else takes single steps.
 #pragma once
-#include "fdtd_kernels.hpp"
+#include "fdtd_fused2.hpp"
 
 namespace fdtd {
-
-constexpr int kMaxInj = 256;
-struct InjP {
-  int n;                                   // nodes that receive a source term between the two steps (0: none alive)
-  const int* start;                        // [nz + 1] entries of plane k: [start[k], start[k + 1])
-  const int4* ent;                         // (i, j, component, index into val), sorted by plane, list order kept within a plane
-  const float* val;                        // the terms (inject_values_kernel)
-};
 
 // val[t] = w_re[t] * Re(wave[step]) - w_im[t] * Im(wave[step]): the term point_source_kernel adds, formed by the same
 // operations
@@ -44,16 +36,17 @@ __global__ __launch_bounds__(256) void inject_values_kernel(float* val, const fl
   val[t] = w_re[t] * a.x - w_im[t] * a.y;
 }
 
-constexpr int kSeamArrays = 7;   // H1_y, H1_z, E1_x, E1_y, E1_z of column c-1;  E1_y, E1_z of column c  (c = first column of the right tile)
 __device__ __forceinline__ long long seam_at(const GridP& g, int seam, int arr, int j, int k) {
   return (((long long)seam * kSeamArrays + arr) * (g.nz + 2) + (k + 1)) * g.ny + j;
 }
 
-template <int LB, bool NT>
+// OPT: bit 0 = non-temporal stores, bit 1 = the loads of plane k+1 are issued behind the second barrier of plane k
+template <int LB, int OPT>
 __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, FieldP b, StepP s, float ca, float cb,
                                                          int zchunk, int nbx, int nby, int nbz, int xcd_remap,
                                                          InjP inj, float* __restrict__ seam) {
   constexpr int V = 4;
+  constexpr bool NT = (OPT & 1) != 0, PF = (OPT & 2) != 0;
   const int total = nbx * nby * nbz;
   int t = blockIdx.x;
   if (xcd_remap == 1) {
@@ -158,31 +151,59 @@ __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, Fiel
     }
   }
   int cur = 0;
-  for (int k = kA; k <= k1; ++k) {
-    const bool top = (k >= g.nz);          // the z-max wall: E1_{x,y} = 0, nothing to load
+  const long long seam_arr = (long long)(g.nz + 2) * g.ny;               // one scratch array
+  const long long seam_row = seam_at(g, tile_x, 0, j, 0);                // this row in array 0 of the seam to the right, plane 0
+  // what one plane loads from set `a` (edge lanes: the neighbouring columns)
+  struct Ld {
+    float exn[V], eyn[V], ezk[V], exj[V], ezj[V], hxn[V], hyn[V], hzn[V];
+    float eyx_g, ezx_g;                                  // E^n_{y,z} of column i0 + 256 (last lane of a tile with a right neighbour)
+    float exn_m, ez_mm, ey_mm, ex_jm, hy_o, hz_o;        // column i0 - 1 (first lane of a tile with a left neighbour)
+  };
+  auto issue = [&](int k, Ld& L) __attribute__((always_inline)) {
     const long long pb = (long long)k * g.sxy + rowb;
     const long long pjb = (long long)k * g.sxy + rowpb;
-    float exn[V], eyn[V], ezk[V], exj[V], ezj[V], hxn[V], hyn[V], hzn[V];
-    float ipz = 0.f, idz = 0.f;
-    float hy_m = 0.f, hz_m = 0.f, exn_m = 0.f;
-    if (!top) {
-      ipz = s.ipz[k]; idz = s.idz[k];
-      ldf<V, true>(exn, uni(a.ex + pb + g.sxy), ubc);
-      ldf<V, true>(eyn, uni(a.ey + pb + g.sxy), ubc);
-      ldf<V, true>(ezk, uni(a.ez + pb), ubc);
-      if (use_jp) {
-        ldf<V, true>(exj, uni(a.ex + pjb), ubc);
-        ldf<V, true>(ezj, uni(a.ez + pjb), ubc);
-      } else {
-        zero<V>(exj); zero<V>(ezj);
-      }
-      ldf<V, true>(hxn, uni(a.hx + pb), ubc);
-      ldf<V, true>(hyn, uni(a.hy + pb), ubc);
-      ldf<V, true>(hzn, uni(a.hz + pb), ubc);
+    const long long up = (k < g.nz) ? g.sxy : 0;         // (iteration nz only needs E1_{x,y}[nz] = 0: it reads the ghost plane twice)
+    ldf<V, true>(L.exn, uni(a.ex + pb + up), ubc);
+    ldf<V, true>(L.eyn, uni(a.ey + pb + up), ubc);
+    ldf<V, true>(L.ezk, uni(a.ez + pb), ubc);
+    if (use_jp) {
+      ldf<V, true>(L.exj, uni(a.ex + pjb), ubc);
+      ldf<V, true>(L.ezj, uni(a.ez + pjb), ubc);
+    } else {
+      zero<V>(L.exj); zero<V>(L.ezj);
+    }
+    ldf<V, true>(L.hxn, uni(a.hx + pb), ubc);
+    ldf<V, true>(L.hyn, uni(a.hy + pb), ubc);
+    ldf<V, true>(L.hzn, uni(a.hz + pb), ubc);
+    L.eyx_g = 0.f; L.ezx_g = 0.f;
+    if (act && tx == 63 && !last_x) { L.eyx_g = a.ey[pb + ux + V]; L.ezx_g = a.ez[pb + ux + V]; }
+    L.exn_m = 0.f; L.ez_mm = 0.f; L.ey_mm = 0.f; L.ex_jm = 0.f; L.hy_o = 0.f; L.hz_o = 0.f;
+    if (xh && do_e1) {
+      const long long pm = pb + im;
+      L.exn_m = a.ex[pm + up];
+      L.ez_mm = a.ez[pm]; L.ey_mm = a.ey[pm];
+      L.ex_jm = use_jp ? a.ex[pjb + im] : 0.f;
+      L.hy_o = a.hy[pm]; L.hz_o = a.hz[pm];
+    }
+  };
+  Ld LA, LB2;
+  if constexpr (PF) issue(kA, LA);
+  auto body = [&](int k, Ld& L, Ld& Lnext) __attribute__((always_inline)) {
+    // (iteration k = nz, last chunk only: plane nz is the z-max wall, E1_{x,y}[nz] = 0 is all it contributes; its loads
+    //  read the ghost plane, its other results are never used)
+    const long long pb = (long long)k * g.sxy + rowb;
+    const float ipz = s.ipz[k], idz = s.idz[k];          // (the step arrays carry one ghost entry at each end)
+    int q0 = 0, q1 = 0;
+    if (inj.n > 0) { q0 = inj.start[k]; q1 = inj.start[k + 1]; }     // ([nz + 2] entries: plane nz holds none)
+    float hy_m = 0.f, hz_m = 0.f;
+    float (&exn)[V] = L.exn, (&eyn)[V] = L.eyn, (&ezk)[V] = L.ezk, (&exj)[V] = L.exj, (&ezj)[V] = L.ezj;
+    float (&hxn)[V] = L.hxn, (&hyn)[V] = L.hyn, (&hzn)[V] = L.hzn;
+    {
+      if constexpr (!PF) issue(k, L);
       float eyx = __shfl_down(eyk[0], 1);
       float ezx = __shfl_down(ezk[0], 1);
       if (act && (tx == 63 || last_x)) {
-        if (!last_x) { eyx = a.ey[pb + ux + V]; ezx = a.ez[pb + ux + V]; }
+        if (!last_x) { eyx = L.eyx_g; ezx = L.ezx_g; }
         else { eyx = 0.f; ezx = 0.f; }
       }
       // ---- S1: H1[k] ----
@@ -196,16 +217,9 @@ __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, Fiel
       }
       // x-halo column: H1_{y,z} at i0-1 recomputed by the tile's first lane
       if (xh && do_e1) {
-        const long long pm = pb + im;
-        exn_m = a.ex[pm + g.sxy];
-        const float ez_mm = a.ez[pm], ey_mm = a.ey[pm];
-        const float ex_jm = use_jp ? a.ex[pjb + im] : 0.f;
-        const float hy_o = a.hy[pm], hz_o = a.hz[pm];
-        hy_m = upd_h(hy_o, ch, exn_m - exk_m, ipz, ezk[0] - ez_mm, ipx_m);
-        hz_m = upd_h(hz_o, ch, eyk[0] - ey_mm, ipx_m, ex_jm - exk_m, ipy);
+        hy_m = upd_h(L.hy_o, ch, L.exn_m - exk_m, ipz, ezk[0] - L.ez_mm, ipx_m);
+        hz_m = upd_h(L.hz_o, ch, eyk[0] - L.ey_mm, ipx_m, L.ex_jm - exk_m, ipy);
       }
-    } else {
-      zero<V>(exn); zero<V>(eyn); zero<V>(ezk); zero<V>(hxn); zero<V>(hyn); zero<V>(hzn);
     }
     {
       float4 t4;
@@ -217,11 +231,11 @@ __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, Fiel
     __syncthreads();
     // ---- S2: E1[k] ----
     float e1xn[V], e1yn[V], e1zn[V];
-    zero<V>(e1xn); zero<V>(e1yn); zero<V>(e1zn);
+    unspecified<V>(e1xn); unspecified<V>(e1yn); unspecified<V>(e1zn);     // (row j0-2: nobody reads its E1)
     if (do_e1) {
       float hyx = __shfl_up(hyn[V - 1], 1);
       float hzx = __shfl_up(hzn[V - 1], 1);
-      if (!top) {
+      {
         if (tx == 0 || first_x) {
           if (xh) { hyx = hy_m; hzx = hz_m; }
           else { hyx = 0.f; hzx = 0.f; }
@@ -235,7 +249,7 @@ __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, Fiel
         } else {
           zero<V>(hxj); zero<V>(hzj);
         }
-        const bool wall_z = (k == 0);
+        const bool wall_z = (k == 0) || (k == g.nz);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
           const float hy_im = (e > 0) ? hyn[(e + V - 1) % V] : hyx;
@@ -250,9 +264,8 @@ __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, Fiel
           e1xn[e] = nex; e1yn[e] = ney; e1zn[e] = nez;
         }
         // the E-side point sources of step n act on E^{n+1} before step n+1 reads it
-        if (inj.n > 0) {
-          const int q1 = inj.start[k + 1];
-          for (int q = inj.start[k]; q < q1; ++q) {
+        {
+          for (int q = q0; q < q1; ++q) {
             const int4 en = inj.ent[q];
             if (en.y == j) {
               const int d = en.x - i0;
@@ -270,23 +283,24 @@ __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, Fiel
         }
         // what the neighbouring x tile needs of this step: repaired on the seam by seam_h / seam_e
         if (own && k >= k0 && k < k1 && act) {
+          float* sp = seam + seam_row + (long long)k * g.ny;
           if (tx == 63 && !last_x) {
-            seam[seam_at(g, tile_x, 0, j, k)] = hyn[V - 1];
-            seam[seam_at(g, tile_x, 1, j, k)] = hzn[V - 1];
-            seam[seam_at(g, tile_x, 2, j, k)] = e1xn[V - 1];
-            seam[seam_at(g, tile_x, 3, j, k)] = e1yn[V - 1];
-            seam[seam_at(g, tile_x, 4, j, k)] = e1zn[V - 1];
+            sp[0] = hyn[V - 1];
+            sp[seam_arr] = hzn[V - 1];
+            sp[2 * seam_arr] = e1xn[V - 1];
+            sp[3 * seam_arr] = e1yn[V - 1];
+            sp[4 * seam_arr] = e1zn[V - 1];
           }
           if (tx == 0 && tile_x > 0) {
-            seam[seam_at(g, tile_x - 1, 5, j, k)] = e1yn[0];
-            seam[seam_at(g, tile_x - 1, 6, j, k)] = e1zn[0];
+            sp[5 * seam_arr - kSeamArrays * seam_arr] = e1yn[0];
+            sp[6 * seam_arr - kSeamArrays * seam_arr] = e1zn[0];
           }
         }
       }
     }
     // ---- S3: H2[k-1] ----
     float h2x[V], h2y[V], h2z[V];
-    zero<V>(h2x); zero<V>(h2y); zero<V>(h2z);
+    unspecified<V>(h2x); unspecified<V>(h2y); unspecified<V>(h2z);       // (rows j0-2, j0+R and the first iteration: nobody reads their H2)
     if (do_h2 && k > kA) {
       float eyx = __shfl_down(e1y[0], 1);
       float ezx = __shfl_down(e1z[0], 1);
@@ -315,6 +329,8 @@ __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, Fiel
       xch[3 * slot + me] = t4;
     }
     __syncthreads();
+    // the loads of the next plane go out here: their latency runs under S4 and the stores of this plane
+    if constexpr (PF) { if (k + 1 <= k1 && k + 1 < g.nz) issue(k + 1, Lnext); }
     // ---- S4: E2[k-1] ----
     if (own && k > k0) {
       float hyx = __shfl_up(h2y[V - 1], 1);
@@ -361,9 +377,14 @@ __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, Fiel
       e1x[e] = e1xn[e]; e1y[e] = e1yn[e]; e1z[e] = e1zn[e];
       exk[e] = exn[e]; eyk[e] = eyn[e];
     }
-    exk_m = exn_m;
+    exk_m = L.exn_m;
     ipz_m = ipz; idz_m = idz;
     cur ^= 1;
+  };
+  // two planes per trip: the carried values alternate between two register sets instead of being copied
+  for (int k = kA; k <= k1; k += 2) {
+    body(k, LA, LB2);
+    if (k + 1 <= k1) body(k + 1, LB2, LA);
   }
 }
 

@@ -67,7 +67,7 @@ class FdtdStats(C.Structure):
                 ("stream_overlap", C.c_int32), ("stream_retries", C.c_int32),
                 ("comm_ranks", C.c_int32), ("comm_rank", C.c_int32),
                 ("two_step_pairs", C.c_int64), ("tblock_planes", C.c_int32), ("reserved0", C.c_int32),
-                ("graph_pairs", C.c_int64), ("fused2_pairs", C.c_int64)]
+                ("graph_pairs", C.c_int64), ("fused2_pairs", C.c_int64), ("fused2_shape", C.c_int64)]
 
 
 PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_int64, C.c_double, C.c_double, C.c_void_p)
