@@ -306,7 +306,7 @@ def test_store_hints_and_address_space_paths_change_nothing_on_the_device(hip_li
         assert np.array_equal(a[c], b[c]), c
 
 
-@pytest.mark.parametrize("w,zc,n", [(16, 32, 512), (12, 16, 512), (8, 64, 512), (16, 32, 320)])
+@pytest.mark.parametrize("w,zc,n", [(16, 32, 512), (12, 16, 512), (8, 64, 512), (16, 32, 320), (-1, 0, 256), (-1, 0, 512)])
 def test_two_steps_per_sweep_bit_identical_bench_v0(hip_lib, w, zc, n):
     """FDTD_OPT_TWOSTEP on real hardware: bench.py's headline workload (random initial fields, PEC walls, a dipole; two x tiles
     -> the seam kernels) advanced by fused2_step_kernel == single sweeps, bit for bit; odd step count -> one single step."""
@@ -324,7 +324,7 @@ def test_two_steps_per_sweep_bit_identical_bench_v0(hip_lib, w, zc, n):
             st = e.run(steps)
             return [e.get_field(c) for c in range(6)], int(st.fused2_pairs)
     ref, p0 = run(0)
-    got, p1 = run(w + 64 * zc)
+    got, p1 = run(w + 64 * zc if w > 0 else -1)          # (-1: the library's default, shape by grid size)
     assert p0 == 0 and p1 == steps // 2
     for c in range(6):
         assert np.array_equal(got[c], ref[c]), c

@@ -602,19 +602,39 @@ int launch_fused(FdtdSolver* h, hipStream_t st, int pml_inside) {
 // What fused2_step_kernel covers: the plain curl stencil of a uniform medium inside six PEC walls on one GPU, driven by
 // E-side point sources.  Anything else (materials, CPML, absorbers, ADE, TFSF, periodic / PMC / Bloch faces, mirror
 // faces, magnetic dipoles, z-slabs) takes single steps.
-// Tile shape of the two-step sweep: waves per workgroup and planes per chunk.  Asked for through FDTD_OPT_TWOSTEP, or
-// (default) 16 waves and the longest chunk of 32 / 24 / 16 / 12 / 8 planes that still gives the 256 CUs four workgroups
-// each; grids too small for that at 8 planes keep single steps (a chunk recomputes two planes below it).
+// Tile shape of the two-step sweep: waves per workgroup W (W - 3 rows of a tile are written) and planes per chunk zc (a
+// chunk runs zc + 2 plane iterations).  Asked for through FDTD_OPT_TWOSTEP, or (default) the cheapest of W = 8 / 16 x
+// zc = 8 ... 48 under a two-parameter model fitted to profiles/r3r_two_step_small.jsonl, r3r_two_step_shapes512.jsonl and
+// r3s_two_step_auto_shapes.jsonl:
+//   time ~ rounds of workgroups x (zc + 2) x t_W,   16 waves: one workgroup per CU, t = 8.2 us per plane iteration;
+//                                                    8 waves: two per CU, t = 6.0 us
+// (rounds counted whole while there are fewer than four: the tail of a short launch is real).  It picks the measured best
+// or a shape within 3 % of it at 128^3 ... 512^3: 8 waves on grids up to 256^3 (416 workgroups of 5 rows fill the 512 slots
+// at once: 195 Gcells/s against 140 with 16 waves), 16 waves from 320^3 on.  Grids below 2^20 cells keep single steps.
 bool fused2_shape(const FdtdSolver* h, int* W, int* zc) {
   const GridP& g = h->g;
-  *W = h->twostep_w > 0 ? h->twostep_w : 16;
-  const int R = *W - 3, nbx = (g.nx + 255) / 256, nby = (g.ny + R - 1) / R;
-  if (h->twostep_zc > 0) { *zc = std::max(2, std::min(h->twostep_zc, g.nz)); return true; }
-  for (int c : {32, 24, 16, 12, 8}) {
-    *zc = c;
-    if ((long long)nbx * nby * ((g.nz + c - 1) / c) >= 1024) return true;
+  const int nbx = (g.nx + 255) / 256;
+  if (h->twostep_w > 0 && h->twostep_zc > 0) { *W = h->twostep_w; *zc = std::max(2, std::min(h->twostep_zc, g.nz)); return true; }
+  if (h->twostep_w <= 0 && (long long)g.nx * g.ny * g.nz < (1LL << 20)) return false;
+  double best = 0.0;
+  bool found = false;
+  for (int w : {16, 8}) {
+    if (h->twostep_w > 0 && w != h->twostep_w) {
+      if (w == 16) w = h->twostep_w; else continue;        // a requested W: only the chunk length is chosen
+    }
+    const int R = w - 3, nby = (g.ny + R - 1) / R;
+    const double slots = w <= 8 ? 512.0 : 256.0, t = w <= 8 ? 6.0 : (w >= 16 ? 8.2 : 6.0 + (8.2 - 6.0) * (w - 8) / 8.0);
+    for (int c : {48, 32, 24, 16, 12, 8}) {
+      if (c > std::max(8, g.nz)) continue;
+      const double wg = (double)nbx * nby * ((g.nz + c - 1) / c);
+      double rounds = wg / slots;
+      if (rounds < 4.0) rounds = std::ceil(rounds);
+      const double cost = rounds * (c + 2) * t;
+      if (!found || cost < best * 0.999) { best = cost; *W = w; *zc = c; found = true; }
+    }
   }
-  return h->twostep_w > 0;
+  *zc = std::max(2, std::min(*zc, g.nz));
+  return found;
 }
 
 bool fused2_eligible(const FdtdSolver* h) {

@@ -41,6 +41,26 @@ __device__ __forceinline__ long long seam_at(const GridP& g, int seam, int arr, 
 }
 
 // OPT: bit 0 = non-temporal stores, bit 1 = the loads of plane k+1 are issued behind the second barrier of plane k
+// x neighbours across the wave: lane i takes the value of lane i+1 / i-1 (the last / first lane keeps its own, as __shfl_down /
+// __shfl_up do).  One DPP move (wave_shl:1 / wave_shr:1, GFX9) instead of a ds_bpermute through the LDS crossbar with its
+// address arithmetic and its lgkmcnt wait on the critical path of every stage.
+__device__ __forceinline__ float lane_next(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int x = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0x130, 0xf, 0xf, false));
+#else
+  return __shfl_down(v, 1);
+#endif
+}
+__device__ __forceinline__ float lane_prev(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int x = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false));
+#else
+  return __shfl_up(v, 1);
+#endif
+}
+
 template <int LB, int OPT>
 __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, FieldP b, StepP s, float ca, float cb,
                                                          int zchunk, int nbx, int nby, int nbz, int xcd_remap,
@@ -137,7 +157,7 @@ __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, Fiel
     ldf<V, true>(exm, uni(a.ex + pb), ubc);
     ldf<V, true>(eym, uni(a.ey + pb), ubc);
     if (use_jp) ldf<V, true>(ezj, uni(a.ez + (long long)(kA - 1) * g.sxy + rowpb), ubc);
-    float ezx = __shfl_down(ezm[0], 1);
+    float ezx = lane_next(ezm[0]);
     if (act && (tx == 63 || last_x)) ezx = last_x ? 0.f : a.ez[pb + ux + V];
     const float ipz = s.ipz[kA - 1];
     ldf<V, true>(ho, uni(a.hx + pb), ubc);
@@ -200,8 +220,8 @@ __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, Fiel
     float (&hxn)[V] = L.hxn, (&hyn)[V] = L.hyn, (&hzn)[V] = L.hzn;
     {
       if constexpr (!PF) issue(k, L);
-      float eyx = __shfl_down(eyk[0], 1);
-      float ezx = __shfl_down(ezk[0], 1);
+      float eyx = lane_next(eyk[0]);
+      float ezx = lane_next(ezk[0]);
       if (act && (tx == 63 || last_x)) {
         if (!last_x) { eyx = L.eyx_g; ezx = L.ezx_g; }
         else { eyx = 0.f; ezx = 0.f; }
@@ -233,8 +253,8 @@ __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, Fiel
     float e1xn[V], e1yn[V], e1zn[V];
     unspecified<V>(e1xn); unspecified<V>(e1yn); unspecified<V>(e1zn);     // (row j0-2: nobody reads its E1)
     if (do_e1) {
-      float hyx = __shfl_up(hyn[V - 1], 1);
-      float hzx = __shfl_up(hzn[V - 1], 1);
+      float hyx = lane_prev(hyn[V - 1]);
+      float hzx = lane_prev(hzn[V - 1]);
       {
         if (tx == 0 || first_x) {
           if (xh) { hyx = hy_m; hzx = hz_m; }
@@ -302,8 +322,8 @@ __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, Fiel
     float h2x[V], h2y[V], h2z[V];
     unspecified<V>(h2x); unspecified<V>(h2y); unspecified<V>(h2z);       // (rows j0-2, j0+R and the first iteration: nobody reads their H2)
     if (do_h2 && k > kA) {
-      float eyx = __shfl_down(e1y[0], 1);
-      float ezx = __shfl_down(e1z[0], 1);
+      float eyx = lane_next(e1y[0]);
+      float ezx = lane_next(e1z[0]);
       if (tx == 63 || last_x) { eyx = 0.f; ezx = 0.f; }      // the wall, or a seam (repaired by seam_h_kernel)
       const float4 t0 = xch[(4 + (cur ^ 1) * 2 + 0) * slot + me + 64];
       const float4 t1 = xch[(4 + (cur ^ 1) * 2 + 1) * slot + me + 64];
@@ -333,8 +353,8 @@ __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, Fiel
     if constexpr (PF) { if (k + 1 <= k1 && k + 1 < g.nz) issue(k + 1, Lnext); }
     // ---- S4: E2[k-1] ----
     if (own && k > k0) {
-      float hyx = __shfl_up(h2y[V - 1], 1);
-      float hzx = __shfl_up(h2z[V - 1], 1);
+      float hyx = lane_prev(h2y[V - 1]);
+      float hzx = lane_prev(h2z[V - 1]);
       if (tx == 0 || first_x) { hyx = 0.f; hzx = 0.f; }      // the wall, or a seam (repaired by seam_e_kernel)
       float hxj[V], hzj[V];
       if (j > 0) {
