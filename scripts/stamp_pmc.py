@@ -2,7 +2,7 @@
 bytes per 512^3 launch of the headline kernel and per V2 step (its three sweep launches together), stamped with the hash of
 the kernel sources they were measured on — bench.py only reports a traffic figure whose hash matches the code it runs.
 
-    python scripts/stamp_pmc.py <v0_summary.json> <v2_summary.json> <tag, e.g. r3j>"""
+    python scripts/stamp_pmc.py <v0_summary.json (single steps)> <v2_summary.json> <tag, e.g. r3j> [<v0 two-step summary.json>]"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,6 +17,7 @@ assert len(k0) == 1, list(v0)
 fused2 = {k: v for k, v in v2.items() if k.startswith("fused_step_kernel")}
 steps = min(v["launches_FETCH_SIZE"] for k, v in fused2.items() if ", 1," in k or ", 9," in k)       # the interior launch: one per step
 v2_step = sum(v["hbm_bytes_per_launch"] * v["launches_FETCH_SIZE"] for v in fused2.values()) / steps
+two = json.load(open(sys.argv[4])) if len(sys.argv) > 4 else None
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
 out = {
     "fused_step_kernel": v0[k0[0]]["hbm_bytes_per_launch"],
@@ -29,5 +30,12 @@ out = {
     "h_update_kernel": old.get("h_update_kernel"), "e_update_kernel": old.get("e_update_kernel"),
     "_two_pass_source": old.get("_two_pass_source"),
 }
+if two is not None:
+    # one launch of the two-step sweep = fused2_step_kernel + the two seam kernels (two time steps)
+    parts = {k: two[k] for k in ("fused2_step_kernel", "seam_h_kernel", "seam_e_kernel") if k in two}
+    out["fused2_step_kernel"] = sum(v["hbm_bytes_per_launch"] for v in parts.values())
+    out["fused2_parts"] = {k: {"bytes_per_launch": v["hbm_bytes_per_launch"], "read": v["read_bytes_per_launch"],
+                               "write": v["write_bytes_per_launch"]} for k, v in parts.items()}
+    out["file"] += f", profiles/{tag}_pmc_v0_two_step_summary.json"
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
-print(json.dumps({k: out[k] for k in ("fused_step_kernel", "v2_step_bytes", "source_hash", "commit")}))
+print(json.dumps({k: out.get(k) for k in ("fused_step_kernel", "fused2_step_kernel", "v2_step_bytes", "source_hash", "commit")}))

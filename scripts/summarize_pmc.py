@@ -16,7 +16,7 @@ for counter in [c for c in sys.argv[2:]] or ("FETCH_SIZE", "WRITE_SIZE"):
             for row in csv.DictReader(fh):
                 if row.get("Counter_Name") != counter:
                     continue
-                name = row["Kernel_Name"].split("(")[0].replace("void fdtd::", "")
+                name = row["Kernel_Name"].split("(")[0].replace("void fdtd::", "").replace("fdtd::", "")
                 if not name.startswith("fused_step_kernel"):       # keep <MAT, launch bounds, CPML axes> of the sweep
                     name = name.split("<")[0]
                 acc[name][0] += float(row["Counter_Value"])

@@ -148,6 +148,14 @@ _cached: Optional[FdtdLib] = None
 def load_library(path: Optional[str] = None) -> FdtdLib:
     """Load the HIP library (in-tree build).  Fails loudly — never substitutes a CPU path."""
     global _cached
+    if path is None and os.environ.get("TIDY3D_AMD_LIBRARY"):
+        path = os.environ["TIDY3D_AMD_LIBRARY"]          # another build of the same library (A/B of compiler flags)
+        if _cached is not None and getattr(_cached, "_path", None) == path:
+            return _cached
+        _prefer_hw_queues()
+        _cached = FdtdLib(path)
+        _cached._path = path
+        return _cached
     if path is None:
         if _cached is not None:
             return _cached
