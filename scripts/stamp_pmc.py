@@ -31,8 +31,8 @@ out = {
     "_two_pass_source": old.get("_two_pass_source"),
 }
 if two is not None:
-    # one launch of the two-step sweep = fused2_step_kernel + the two seam kernels (two time steps)
-    parts = {k: two[k] for k in ("fused2_step_kernel", "seam_h_kernel", "seam_e_kernel") if k in two}
+    # one launch of the two-step sweep = fused2_step_kernel + the seam kernel (two time steps)
+    parts = {k: two[k] for k in ("fused2_step_kernel", "seam_kernel") if k in two}
     out["fused2_step_kernel"] = sum(v["hbm_bytes_per_launch"] for v in parts.values())
     out["fused2_parts"] = {k: {"bytes_per_launch": v["hbm_bytes_per_launch"], "read": v["read_bytes_per_launch"],
                                "write": v["write_bytes_per_launch"]} for k, v in parts.items()}

@@ -604,7 +604,7 @@ int launch_fused(FdtdSolver* h, hipStream_t st, int pml_inside) {
 // faces, magnetic dipoles, z-slabs) takes single steps.
 // Tile shape of the two-step sweep: waves per workgroup W (W - 3 rows of a tile are written) and planes per chunk zc (a
 // chunk runs zc + 2 plane iterations).  Asked for through FDTD_OPT_TWOSTEP, or (default) the cheapest of W = 8 / 16 x
-// zc = 8 ... 48 under a two-parameter model fitted to profiles/r3r_two_step_small.jsonl, r3r_two_step_shapes512.jsonl and
+// zc = 8 ... 64 under a two-parameter model fitted to profiles/r3r_two_step_small.jsonl, r3r_two_step_shapes512.jsonl and
 // r3s_two_step_auto_shapes.jsonl:
 //   time ~ rounds of workgroups x (zc + 2) x t_W,   16 waves: one workgroup per CU, t = 8.2 us per plane iteration;
 //                                                    8 waves: two per CU, t = 6.0 us
@@ -624,7 +624,7 @@ bool fused2_shape(const FdtdSolver* h, int* W, int* zc) {
     }
     const int R = w - 3, nby = (g.ny + R - 1) / R;
     const double slots = w <= 8 ? 512.0 : 256.0, t = w <= 8 ? 6.0 : (w >= 16 ? 8.2 : 6.0 + (8.2 - 6.0) * (w - 8) / 8.0);
-    for (int c : {48, 32, 24, 16, 12, 8}) {
+    for (int c : {64, 48, 32, 24, 16, 12, 8}) {
       if (c > std::max(8, g.nz)) continue;
       const double wg = (double)nbx * nby * ((g.nz + c - 1) / c);
       double rounds = wg / slots;

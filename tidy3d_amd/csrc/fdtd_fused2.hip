@@ -43,8 +43,7 @@ void launch_seams(hipStream_t st, const GridP& g, const FieldP& b, const StepP& 
                   int n_seams) {
   const long long nt = (long long)n_seams * g.ny * g.nz;
   const unsigned blocks = (unsigned)((nt + 255) / 256);
-  hipLaunchKernelGGL(seam_h_kernel, dim3(blocks), dim3(256), 0, st, g, b, s, seam, n_seams);
-  hipLaunchKernelGGL(seam_e_kernel, dim3(blocks), dim3(256), 0, st, g, b, s, ca, cb, seam, n_seams);
+  hipLaunchKernelGGL(seam_kernel, dim3(blocks), dim3(256), 0, st, g, b, s, ca, cb, seam, n_seams);
 }
 
 }  // namespace fdtd

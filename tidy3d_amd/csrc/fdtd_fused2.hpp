@@ -14,7 +14,8 @@ struct InjP {
   const int4* ent;                         // (i, j, component, index into val), sorted by plane, list order kept within a plane
   const float* val;                        // the terms (inject_values_kernel)
 };
-constexpr int kSeamArrays = 7;   // H1_y, H1_z, E1_x, E1_y, E1_z of column c-1;  E1_y, E1_z of column c  (c = first column of the right tile)
+constexpr int kSeamArrays = 13;  // of step one: H1_y, H1_z, E1_x, E1_y, E1_z [c-1], E1_y, E1_z [c]; of step two: H2_x [c-1], H2_y, H2_z [c-2], H2_x, H2_y, H2_z [c]
+                                 // (c = first column of the right tile)
 
 // host-side launchers (fdtd_fused2.hip)
 void launch_inject_values(hipStream_t st, float* val, const float* w_re, const float* w_im, const float2* wave,

@@ -17,7 +17,7 @@
 // H1_{x,y}[k0-2]).  Along x a wave covers its 256 cells exactly as in fused_step_kernel for step one (edge lanes load /
 // recompute the neighbouring column from set `a`); the second step would need the NEIGHBOUR tile's intermediate
 // values on the seam: those five values per seam row are computed wrong here and repaired afterwards by
-// seam_h_kernel / seam_e_kernel from the intermediate values both tiles leave in a small scratch array.
+// seam_kernel from the intermediate values both tiles leave in a small scratch array.
 //
 // Scope (fdtd_capi.hip checks it): uniform medium, PEC on all six faces, no CPML / absorber / ADE / TFSF / Bloch /
 // mirror faces, E-side point sources only (<= kMaxInj nodes), one GPU.  Everything else takes single steps.
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, Fiel
             }
           }
         }
-        // what the neighbouring x tile needs of this step: repaired on the seam by seam_h / seam_e
+        // what the neighbouring x tile needs of this step: repaired on the seam by seam_kernel
         if (own && k >= k0 && k < k1 && act) {
           float* sp = seam + seam_row + (long long)k * g.ny;
           if (tx == 63 && !last_x) {
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, Fiel
     if (do_h2 && k > kA) {
       float eyx = lane_next(e1y[0]);
       float ezx = lane_next(e1z[0]);
-      if (tx == 63 || last_x) { eyx = 0.f; ezx = 0.f; }      // the wall, or a seam (repaired by seam_h_kernel)
+      if (tx == 63 || last_x) { eyx = 0.f; ezx = 0.f; }      // the wall, or a seam (repaired by seam_kernel)
       const float4 t0 = xch[(4 + (cur ^ 1) * 2 + 0) * slot + me + 64];
       const float4 t1 = xch[(4 + (cur ^ 1) * 2 + 1) * slot + me + 64];
       const float exj1[V] = {t0.x, t0.y, t0.z, t0.w}, ezj1[V] = {t1.x, t1.y, t1.z, t1.w};
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, Fiel
     if (own && k > k0) {
       float hyx = lane_prev(h2y[V - 1]);
       float hzx = lane_prev(h2z[V - 1]);
-      if (tx == 0 || first_x) { hyx = 0.f; hzx = 0.f; }      // the wall, or a seam (repaired by seam_e_kernel)
+      if (tx == 0 || first_x) { hyx = 0.f; hzx = 0.f; }      // the wall, or a seam (repaired by seam_kernel)
       float hxj[V], hzj[V];
       if (j > 0) {
         const float4 t0 = xch[2 * slot + me - 64];
@@ -381,6 +381,18 @@ __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, Fiel
         ex[e] = nex; ey[e] = ney; ez[e] = nez;
       }
       if (act) {
+        // H2 next to the seams, for seam_kernel (so that it reads nothing but the scratch array, row-contiguous)
+        float* sq = seam + seam_row + (long long)(k - 1) * g.ny;
+        if (tx == 63 && !last_x) {
+          sq[7 * seam_arr] = h2x[V - 1];
+          sq[8 * seam_arr] = h2y[V - 2];
+          sq[9 * seam_arr] = h2z[V - 2];
+        }
+        if (tx == 0 && tile_x > 0) {
+          sq[10 * seam_arr - kSeamArrays * seam_arr] = h2x[0];
+          sq[11 * seam_arr - kSeamArrays * seam_arr] = h2y[0];
+          sq[12 * seam_arr - kSeamArrays * seam_arr] = h2z[0];
+        }
         const long long po = pb - g.sxy + i0;
         stv_h<V, NT>(b.hx + po, h2x);
         stv_h<V, NT>(b.hy + po, h2y);
@@ -409,9 +421,12 @@ __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, Fiel
 }
 
 // ---- the seams between x tiles -------------------------------------------------------------------------------------
-// One thread per (seam, j, k).  c = first column of the right tile.  H2_{y,z}[c-1] needs E1_{y,z}[c] of the right tile.
-__global__ __launch_bounds__(256) void seam_h_kernel(GridP g, FieldP b, StepP s, const float* __restrict__ seam,
-                                                     int n_seams) {
+// One thread per (seam, j, k); c = first column of the right tile.  H2_{y,z}[c-1] needs E1_{y,z}[c] of the right tile, and
+// E2_{x,y,z}[c-1], E2_{y,z}[c] differentiate H2_{y,z}[c-1]: recomputed here with the formulas of the sweep from what both
+// tiles left in the scratch array [seam][13][nz + 2][ny] (read row-contiguously; plane nz and what lies beyond the walls
+// stay zero).  H2_{y,z}[c-1] of the row below and of the plane below are recomputed rather than exchanged: one launch.
+__global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, float ca, float cb,
+                                                   const float* __restrict__ seam, int n_seams) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long per = (long long)g.ny * g.nz;
   if (t >= per * n_seams) return;
@@ -419,44 +434,35 @@ __global__ __launch_bounds__(256) void seam_h_kernel(GridP g, FieldP b, StepP s,
   const int k = (int)((t % per) / g.ny), j = (int)(t % g.ny);
   const int c = (sm + 1) * 256;
   const float ch = g.ch;
-  const float h1y = seam[seam_at(g, sm, 0, j, k)], h1z = seam[seam_at(g, sm, 1, j, k)];
-  const float e1x = seam[seam_at(g, sm, 2, j, k)], e1y = seam[seam_at(g, sm, 3, j, k)], e1z = seam[seam_at(g, sm, 4, j, k)];
-  const float e1x_kp = seam[seam_at(g, sm, 2, j, k + 1)];                       // plane nz of the scratch stays 0: the wall
-  const float e1x_jp = (j + 1 < g.ny) ? seam[seam_at(g, sm, 2, j + 1, k)] : 0.f;
-  const float e1y_c = seam[seam_at(g, sm, 5, j, k)], e1z_c = seam[seam_at(g, sm, 6, j, k)];
-  const float ipx = s.ipx[c - 1], ipy = s.ipy[j], ipz = s.ipz[k];
-  const long long p = (long long)k * g.sxy + (long long)j * g.nx + (c - 1);
-  b.hy[p] = upd_h(h1y, ch, e1x_kp - e1x, ipz, e1z_c - e1z, ipx);
-  b.hz[p] = upd_h(h1z, ch, e1y_c - e1y, ipx, e1x_jp - e1x, ipy);
-}
-
-// E2_{x,y,z}[c-1] and E2_{y,z}[c]: everything that differentiates H2_{y,z}[c-1]  (after seam_h_kernel)
-__global__ __launch_bounds__(256) void seam_e_kernel(GridP g, FieldP b, StepP s, float ca, float cb,
-                                                     const float* __restrict__ seam, int n_seams) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long per = (long long)g.ny * g.nz;
-  if (t >= per * n_seams) return;
-  const int sm = (int)(t / per);
-  const int k = (int)((t % per) / g.ny), j = (int)(t % g.ny);
-  const int c = (sm + 1) * 256;
+  const float ipx = s.ipx[c - 1];
+  auto A = [&](int a, int jj, int kk) { return seam[seam_at(g, sm, a, jj, kk)]; };
+  // H2_{y,z}[c-1] at (jj, kk)
+  auto h2 = [&](int jj, int kk, float& hy, float& hz) {
+    const float e1x = A(2, jj, kk), e1y = A(3, jj, kk), e1z = A(4, jj, kk);
+    const float e1x_jp = (jj + 1 < g.ny) ? A(2, jj + 1, kk) : 0.f;
+    hy = upd_h(A(0, jj, kk), ch, A(2, jj, kk + 1) - e1x, s.ipz[kk], A(6, jj, kk) - e1z, ipx);
+    hz = upd_h(A(1, jj, kk), ch, A(5, jj, kk) - e1y, ipx, e1x_jp - e1x, s.ipy[jj]);
+  };
+  float hy_m, hz_m;
+  h2(j, k, hy_m, hz_m);
   const bool wall_y = (j == 0), wall_z = (k == 0);
   const long long p = (long long)k * g.sxy + (long long)j * g.nx + c;       // column c; p - 1 = column c-1
-  const long long pj = p - g.nx, pk = p - g.sxy;
+  b.hy[p - 1] = hy_m; b.hz[p - 1] = hz_m;
   const float idy = s.idy[j], idz = s.idz[k], idx_m = s.idx[c - 1], idx_c = s.idx[c];
-  const float e1x = seam[seam_at(g, sm, 2, j, k)], e1y = seam[seam_at(g, sm, 3, j, k)], e1z = seam[seam_at(g, sm, 4, j, k)];
-  const float e1y_c = seam[seam_at(g, sm, 5, j, k)], e1z_c = seam[seam_at(g, sm, 6, j, k)];
-  const float hx_m = b.hx[p - 1], hy_m = b.hy[p - 1], hz_m = b.hz[p - 1];      // column c-1
-  const float hx_c = b.hx[p], hy_c = b.hy[p], hz_c = b.hz[p];                  // column c
-  const float hy_mm = b.hy[p - 2], hz_mm = b.hz[p - 2];                        // column c-2
+  const float hx_m = A(7, j, k), hy_mm = A(8, j, k), hz_mm = A(9, j, k);
+  const float hx_c = A(10, j, k), hy_c = A(11, j, k), hz_c = A(12, j, k);
   float ex_m = 0.f, ey_m = 0.f, ez_m = 0.f, ey_c = 0.f, ez_c = 0.f;
-  if (!wall_y && !wall_z) ex_m = upd_e(e1x, ca, cb, hz_m - b.hz[pj - 1], idy, hy_m - b.hy[pk - 1], idz);
+  float hy_k = 0.f, hz_j = 0.f, dum;
+  if (!wall_z) h2(j, k - 1, hy_k, dum);
+  if (!wall_y) h2(j - 1, k, dum, hz_j);
+  if (!wall_y && !wall_z) ex_m = upd_e(A(2, j, k), ca, cb, hz_m - hz_j, idy, hy_m - hy_k, idz);
   if (!wall_z) {
-    ey_m = upd_e(e1y, ca, cb, hx_m - b.hx[pk - 1], idz, hz_m - hz_mm, idx_m);
-    ey_c = upd_e(e1y_c, ca, cb, hx_c - b.hx[pk], idz, hz_c - hz_m, idx_c);
+    ey_m = upd_e(A(3, j, k), ca, cb, hx_m - A(7, j, k - 1), idz, hz_m - hz_mm, idx_m);
+    ey_c = upd_e(A(5, j, k), ca, cb, hx_c - A(10, j, k - 1), idz, hz_c - hz_m, idx_c);
   }
   if (!wall_y) {
-    ez_m = upd_e(e1z, ca, cb, hy_m - hy_mm, idx_m, hx_m - b.hx[pj - 1], idy);
-    ez_c = upd_e(e1z_c, ca, cb, hy_c - hy_m, idx_c, hx_c - b.hx[pj], idy);
+    ez_m = upd_e(A(4, j, k), ca, cb, hy_m - hy_mm, idx_m, hx_m - A(7, j - 1, k), idy);
+    ez_c = upd_e(A(6, j, k), ca, cb, hy_c - hy_m, idx_c, hx_c - A(10, j - 1, k), idy);
   }
   b.ex[p - 1] = ex_m; b.ey[p - 1] = ey_m; b.ez[p - 1] = ez_m;
   b.ey[p] = ey_c; b.ez[p] = ez_c;
