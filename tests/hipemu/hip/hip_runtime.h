@@ -147,6 +147,23 @@ template <typename T> static inline T __shfl_xor(T v, int m, int width = 64) {
   return hipemu::shfl_generic(v, src);
 }
 
+// wave-wide vote: bit l = predicate of lane l (lanes that have left the kernel vote 0); one rendezvous
+static inline unsigned long long __ballot(int pred) {
+  hipemu::State& s = hipemu::S();
+  const int lin = s.cur->lin, wave = lin / hipemu::kWave, lane = lin % hipemu::kWave;
+  const int ph = s.wave_phase[wave] & 1;
+  const size_t base = (size_t)(ph * (s.fibers.size() + hipemu::kWave)) + (size_t)wave * hipemu::kWave;
+  s.xbuf[base + lane] = pred ? 1 : 0;
+  hipemu::wave_rendezvous();
+  unsigned long long out = 0;
+  for (int l = 0; l < hipemu::kWave; ++l) {
+    const size_t gl = (size_t)wave * hipemu::kWave + l;
+    if (gl < s.fibers.size() && s.fibers[gl].state != 4 && s.xbuf[base + l]) out |= 1ull << l;
+  }
+  return out;
+}
+static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+
 // atomics (single OS thread: plain RMW is atomic w.r.t. fibers because fibers only switch at
 // explicit rendezvous points)
 template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }

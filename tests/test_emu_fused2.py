@@ -51,9 +51,15 @@ SHAPES = {
 }
 
 
-@pytest.mark.parametrize("name", sorted(SHAPES))
-@pytest.mark.parametrize("w,zc", [(16, 32), (4, 2), (5, 3), (8, 5), (8 + (1 << 16), 3), (6 + (1 << 16), 32)])
+CASES = [("one_tile", 16, 32), ("one_tile", 4, 2), ("one_tile", 8 + (1 << 16), 3),
+         ("ragged_rows", 16, 32), ("ragged_rows", 5, 3), ("ragged_rows", 8, 5), ("ragged_rows", 6 + (1 << 16), 32),
+         ("two_x_tiles", 16, 32), ("two_x_tiles", 4, 2), ("two_x_tiles", 5, 3), ("two_x_tiles", 8 + (1 << 16), 3),
+         ("three_x_tiles_tall", 8, 5), ("three_x_tiles_tall", 5, 3), ("three_x_tiles_tall", 6 + (1 << 16), 32)]
+
+
+@pytest.mark.parametrize("name,w,zc", CASES)
 def test_two_steps_per_sweep_equal_single_steps(name, w, zc, emu_lib):
+    """(bit 16 of w: the loads of the next plane issued behind the second barrier)"""
     N = SHAPES[name]
     disc = discretize(_sim(N, monitors=False), n_steps=26)
     disc.spec.decay_every = 0
@@ -88,6 +94,37 @@ def test_pairs_give_way_to_monitor_records_and_decay_checks(name, emu_lib):
     for c in range(6):
         assert np.array_equal(got_f[c], ref_f[c]), c
     for k in ref_m:
+        assert np.array_equal(got_m[k], ref_m[k]), k
+
+
+@pytest.mark.parametrize("name", ["one_tile", "two_x_tiles"])
+@pytest.mark.parametrize("interval", [1, 2, 3])
+def test_small_time_monitors_sample_the_middle_step(name, interval, emu_lib):
+    """Point-like FieldTimeMonitors (E and H components; H is the mean of two half-steps) do not stop pairs: the sweep copies
+    E^{n+1} (behind the sources of step n) and H^{n+1/2} of their cells out, and the records equal those of single steps."""
+    N = SHAPES[name]
+    size = tuple(n * DL for n in N)
+    sim = _sim(N, monitors=False)
+    mons = [td.FieldTimeMonitor(center=(0.11, 0.02, -0.03), size=(0, 0, 0), name="p", interval=interval, colocate=False),
+            td.FieldTimeMonitor(center=(-0.5 * size[0] + 0.32, 0.1, 0.1), size=(0.1, 0, 0), name="q", interval=1,
+                                fields=["Ez", "Hx"], colocate=False, start=1e-15),
+            # on the source node of the first dipole: E^{n+1} must be taken behind the source term
+            td.FieldTimeMonitor(center=(0.3 * size[0] - 0.5 * size[0] + 0.02, 0.01, 0.03), size=(0, 0, 0), name="s", interval=2,
+                                fields=["Ez"], colocate=False)]
+    if N[0] > 256:        # H_y / H_z samples in the column left of the seam: repaired only behind the sweep -> recorded around it
+        mons.insert(0, td.FieldTimeMonitor(center=(-0.5 * size[0] + 255.4 * DL, 0.0, 0.05), size=(0, 0, 0), name="seam",
+                                           interval=1, fields=["Ex", "Hy", "Hz"], colocate=False))
+    sim = sim.updated_copy(monitors=mons)
+    disc = discretize(sim, n_steps=26)
+    disc.spec.decay_every = 0
+    ref_f, ref_m, p0 = _run(disc.spec, emu_lib, 0)
+    got_f, got_m, p1 = _run(disc.spec, emu_lib, 8 + 64 * 4)
+    assert p0 == 0 and p1 == 5 + 7, p1
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), c
+    assert set(ref_m) >= {"p", "q", "s"}
+    for k in ref_m:
+        assert np.abs(ref_m[k]).max() > 0, k
         assert np.array_equal(got_m[k], ref_m[k]), k
 
 

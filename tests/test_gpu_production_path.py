@@ -328,3 +328,37 @@ def test_two_steps_per_sweep_bit_identical_bench_v0(hip_lib, w, zc, n):
     assert p0 == 0 and p1 == steps // 2
     for c in range(6):
         assert np.array_equal(got[c], ref[c]), c
+
+
+def test_two_steps_per_sweep_config2_probe_records_bit_identical(hip_lib):
+    """BASELINE config[1] (200^3 PEC cavity, dipole, a point FieldTimeMonitor recording EVERY step): the two-step sweep copies the
+    probe's samples of the middle step out on the way — same records, same fields as single steps; prints both speeds."""
+    import time
+    import tidy3d_amd.schema as td
+    from tidy3d_amd.discretize import discretize
+    n, dl = 200, 0.05
+    pulse = td.GaussianPulse(freq0=3.5e13, fwidth=1.2e13)
+    sim = td.Simulation(size=(n * dl,) * 3, grid_spec=td.GridSpec.uniform(dl=dl), run_time=1e-12,
+                        sources=[td.PointDipole(center=(1.3, -0.7, 2.1), source_time=pulse, polarization="Ez")],
+                        monitors=[td.FieldTimeMonitor(center=(-2.1, 1.2, -0.6), size=(0, 0, 0), name="t", colocate=False)],
+                        boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary()), shutoff=0)
+    steps = 2001
+    disc = discretize(sim, n_steps=steps)
+    disc.spec.decay_every = 0
+
+    def run(twostep):
+        with HipEngine(disc.spec, lib=hip_lib) as e:
+            e.set_option(L.OPT_TWOSTEP, twostep)
+            e.run(1)
+            t0 = time.perf_counter()
+            st = e.run(steps - 1)
+            dt = time.perf_counter() - t0
+            return [e.get_field(c) for c in range(6)], e.results(), int(st.fused2_pairs), dt / (steps - 1) * 1e6
+    ref, ref_m, p0, us0 = run(0)
+    got, got_m, p1, us1 = run(-1)
+    print(f"[config2 200^3 + probe] single steps {us0:.1f} us per step, two steps per sweep {us1:.1f} us ({p1} pairs)")
+    assert p0 == 0 and p1 == (steps - 1) // 2
+    assert np.abs(ref_m["t"]).max() > 0
+    for c in range(6):
+        assert np.array_equal(got[c], ref[c]), c
+    assert np.array_equal(got_m["t"], ref_m["t"])

@@ -98,6 +98,18 @@ struct Monitor {
   long long cells = 0;
 };
 
+// node table of one kind of step pair of the two-step sweep: the E-side source nodes and the nodes small time monitors
+// sample of the middle step (InjP), for one set of recording monitors
+struct F2Table {
+  std::vector<int> mons;           // monitors whose middle-step samples the sweep copies out (ascending)
+  std::vector<int> cap_off;        // their offsets into the sample buffer
+  int* start = nullptr;
+  int4* ent = nullptr;
+};
+struct F2Plan {                    // one step pair: the monitors that record at its first or middle step
+  std::vector<int> mons;
+};
+
 }  // namespace
 
 struct FdtdSolver {
@@ -199,9 +211,12 @@ struct FdtdSolver {
   long long fused2_pairs = 0;
   float* seam_buf = nullptr;          // intermediate values on the seams between x tiles
   float* inj_val = nullptr;           // source terms applied between the two steps
-  int* inj_start = nullptr;           // their nodes, sorted by plane (InjP)
-  int4* inj_ent = nullptr;
-  size_t inj_sources = 0;             // point-source lists the table was built from
+  float* cap_val = nullptr;           // samples of the middle step (small time monitors)
+  std::vector<F2Table> f2_tables;     // node tables, one per set of recording monitors met so far
+  size_t inj_sources = 0;             // point-source lists the tables were built from
+  float* src_tab = nullptr;           // [step][node] source terms of every step, formed once (nullptr: per pair)
+  long long src_tab_steps = 0, src_tab_nodes = 0;
+  bool src_on_seam = false;           // a source node lies next to a seam between x tiles: step n+1's terms go behind the launch
 };
 
 namespace {
@@ -661,9 +676,106 @@ bool fused2_sources_uniform(const FdtdSolver* h, long long n) {
   return !(any_alive && any_spent);
 }
 
-// steps n and n + 1 in one sweep: set a (E^n, H^{n-1/2}) -> set b (E^{n+2}, H^{n+3/2}); the E-side sources of step n are
-// applied inside the kernel, those of step n + 1 by the caller afterwards
-int launch_fused2(FdtdSolver* h, long long n, hipStream_t st) {
+// A time monitor whose record of a middle step the sweep can copy out on the way: every component of every cell of its box,
+// a few hundred values at most (each costs every wave of its plane a scalar table entry).
+bool fused2_capturable(const FdtdSolver* h, const Monitor& m) {
+  if (m.kind != FDTD_MON_TIME || m.cells <= 0 || (long long)m.comps.size() * m.cells > kMaxCap) return false;
+  const BoxP& b = m.box;
+  return b.lo0 >= 0 && b.lo1 >= 0 && b.lo2 >= 0 && b.lo0 + b.nx <= h->g.nx && b.lo1 + b.ny <= h->g.ny && b.lo2 + b.nz <= h->g.nz;
+}
+
+// The monitors that record at step n or at step n + 1: the pair (n, n + 1) can go out as one sweep if they are all small
+// time monitors (at most kPairMons).  The sweep copies their samples of the middle step (E^{n+1}, H^{n+1/2}) out; ONE launch
+// behind it (pair_record_kernel) writes everything they record of the pair — E^n and H^{n-1/2} are still in the set the
+// sweep read, H^{n+3/2} is in the set it wrote — so such a pair costs no record launch in front of the sweep.
+bool fused2_plan(const FdtdSolver* h, long long n, F2Plan* plan) {
+  plan->mons.clear();
+  long long total = 0;
+  for (size_t q = 0; q < h->mons.size(); ++q) {
+    const Monitor& m = h->mons[q];
+    bool at = false;
+    for (size_t r = m.next; r < m.steps.size() && m.steps[r] <= n + 1; ++r) at = at || m.steps[r] >= n;
+    if (!at) continue;
+    if (!fused2_capturable(h, m) || m.comps.size() > 6) return false;
+    total += (long long)m.comps.size() * m.cells;
+    plan->mons.push_back((int)q);
+  }
+  return total <= kMaxCap && (int)plan->mons.size() <= kPairMons;
+}
+
+const F2Table* fused2_table(FdtdSolver* h, const F2Plan& plan) {
+  const GridP& g = h->g;
+  if (h->inj_sources != h->psrc.size()) {
+    h->f2_tables.clear();
+    h->inj_sources = h->psrc.size();
+    // the source terms of every step, formed once with the operations of point_source_kernel
+    h->src_tab = nullptr;
+    h->src_on_seam = false;
+    long long nodes = 0, steps = 0;
+    for (const PointSrc& s : h->psrc) {
+      nodes += s.n_e;
+      if (s.n_e) steps = std::max(steps, s.n_steps);
+      for (long long t = 0; t < s.n_e; ++t) {
+        const int i = (int)(s.host_cell_e[(size_t)t] % g.nx);
+        h->src_on_seam = h->src_on_seam || (i % 256 == 255 && i + 1 < g.nx) || (i % 256 == 0 && i > 0);
+      }
+    }
+    if (nodes > 0 && nodes * steps <= (1LL << 24)) {
+      if (dev_alloc(h, &h->src_tab, (size_t)(nodes * steps))) return nullptr;
+      long long off = 0;
+      for (const PointSrc& s : h->psrc) {
+        if (s.n_e) launch_inject_table(h->stream, h->src_tab, nodes, off, s.wre_e, s.wim_e, s.wave_e, s.n_steps, (int)s.n_e);
+        off += s.n_e;
+      }
+      h->src_tab_steps = steps; h->src_tab_nodes = nodes;
+    }
+  }
+  for (const F2Table& t : h->f2_tables) if (t.mons == plan.mons) return &t;
+  // the nodes of all E-side lists, sorted by plane; nodes of one plane keep their list order (a node two lists share
+  // receives their terms in the order the source kernels would add them); the monitor samples of a plane follow them
+  std::vector<std::array<int, 5>> ent;        // k, i, j, code, index
+  int off = 0;
+  for (const PointSrc& s : h->psrc)
+    for (long long t = 0; t < s.n_e; ++t, ++off) {
+      const long long cell = s.host_cell_e[(size_t)t];
+      ent.push_back({(int)(cell / g.sxy), (int)(cell % g.nx), (int)((cell % g.sxy) / g.nx), s.host_comp_e[(size_t)t] % 3, off});
+    }
+  F2Table tb;
+  tb.mons = plan.mons;
+  int coff = 0;
+  for (size_t q = 0; q < plan.mons.size(); ++q) {
+    Monitor& m = h->mons[(size_t)plan.mons[q]];
+    tb.cap_off.push_back(coff);
+    const BoxP& b = m.box;
+    long long idx = 0;
+    for (size_t ic = 0; ic < m.comps.size(); ++ic)
+      for (long long t = 0; t < m.cells; ++t, ++idx) {
+        const int lx = (int)(t % b.nx), ly = (int)((t / b.nx) % b.ny), lz = (int)(t / ((long long)b.nx * b.ny));
+        ent.push_back({b.lo2 + lz, b.lo0 + lx, b.lo1 + ly, 8 + m.comps[ic], coff + (int)idx});
+      }
+    coff += (int)idx;
+  }
+  std::stable_sort(ent.begin(), ent.end(), [](const std::array<int, 5>& x, const std::array<int, 5>& y) {
+    return x[0] != y[0] ? x[0] < y[0] : (x[3] >= 8) < (y[3] >= 8);
+  });
+  std::vector<int> start((size_t)g.nz + 2, 0);
+  std::vector<int4> e4(std::max<size_t>(1, ent.size()));
+  for (size_t q = 0; q < ent.size(); ++q) {
+    start[(size_t)ent[q][0] + 1]++;
+    e4[q].x = ent[q][1]; e4[q].y = ent[q][2]; e4[q].z = ent[q][3]; e4[q].w = ent[q][4];
+  }
+  for (int k = 0; k <= g.nz; ++k) start[(size_t)k + 1] += start[(size_t)k];
+  if (dev_upload(h, &tb.start, (const int*)start.data(), start.size()) ||
+      dev_upload(h, &tb.ent, (const int4*)e4.data(), e4.size())) return nullptr;
+  h->f2_tables.push_back(tb);
+  return &h->f2_tables.back();
+}
+
+// steps n and n + 1 in one sweep: set a (E^n, H^{n-1/2}) -> set b (E^{n+2}, H^{n+3/2}).  The E-side sources of step n are
+// applied inside the kernel; so are those of step n + 1 (*sources2_done) when their terms come from the table of all steps
+// and no source node lies next to a seam — else the caller applies them afterwards.  The middle step is copied out for the
+// monitors of `tb` (fused2_plan); pair_record (called by the caller behind the launch) writes their records.
+int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb, bool* sources2_done) {
   const GridP& g = h->g;
   if (ensure_second_set(h)) return -1;
   int W = 16, zc = 32;
@@ -676,52 +788,60 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st) {
   if (nbx > 1 && !h->seam_buf &&
       dev_alloc(h, &h->seam_buf, (size_t)(nbx - 1) * kSeamArrays * (size_t)(g.nz + 2) * (size_t)g.ny)) return -1;
   if (!h->inj_val && dev_alloc(h, &h->inj_val, (size_t)kMaxInj)) return -1;
-  if (!h->inj_ent || h->inj_sources != h->psrc.size()) {
-    // the nodes of all E-side lists, sorted by plane; nodes of one plane keep their list order (a node two lists share
-    // receives their terms in the order the source kernels would add them)
-    std::vector<std::array<int, 5>> ent;        // k, i, j, c, index into val
-    int off = 0;
-    for (const PointSrc& s : h->psrc)
-      for (long long t = 0; t < s.n_e; ++t, ++off) {
-        const long long cell = s.host_cell_e[(size_t)t];
-        ent.push_back({(int)(cell / g.sxy), (int)(cell % g.nx), (int)((cell % g.sxy) / g.nx), s.host_comp_e[(size_t)t] % 3, off});
-      }
-    std::stable_sort(ent.begin(), ent.end(), [](const std::array<int, 5>& x, const std::array<int, 5>& y) { return x[0] < y[0]; });
-    std::vector<int> start((size_t)g.nz + 2, 0);
-    std::vector<int4> e4(std::max<size_t>(1, ent.size()));
-    for (size_t q = 0; q < ent.size(); ++q) {
-      start[(size_t)ent[q][0] + 1]++;
-      e4[q].x = ent[q][1]; e4[q].y = ent[q][2]; e4[q].z = ent[q][3]; e4[q].w = ent[q][4];
-    }
-    for (int k = 0; k <= g.nz; ++k) start[(size_t)k + 1] += start[(size_t)k];
-    if (dev_upload(h, &h->inj_start, (const int*)start.data(), start.size()) ||
-        dev_upload(h, &h->inj_ent, (const int4*)e4.data(), e4.size())) return -1;
-    h->inj_sources = h->psrc.size();
-  }
+  if (!h->cap_val && dev_alloc(h, &h->cap_val, (size_t)kMaxCap)) return -1;
   InjP inj{};
+  *sources2_done = false;
   {
-    int off = 0;
-    bool alive = false;
-    for (const PointSrc& s : h->psrc) {
-      if (s.n_e && n < s.n_steps) {
-        alive = true;
-        launch_inject_values(st, h->inj_val + off, s.wre_e, s.wim_e, s.wave_e, n, (int)s.n_e);
+    bool alive = false, alive2 = true;
+    for (const PointSrc& s : h->psrc)
+      if (s.n_e) { alive = alive || n < s.n_steps; alive2 = alive2 && n + 1 < s.n_steps; }
+    // (all lists alive or all spent: fused2_sources_uniform.  Spent lists add nothing — not + 0 — so their table is only
+    //  walked when there are none or when they are alive: pairs with monitor samples AND spent sources are not taken, fdtd_run)
+    if (alive && h->src_tab && n + 1 < h->src_tab_steps) {
+      inj.val = h->src_tab + n * h->src_tab_nodes;
+      if (alive2 && !h->src_on_seam) { inj.val2 = h->src_tab + (n + 1) * h->src_tab_nodes; *sources2_done = true; }
+    } else if (alive) {
+      int off = 0;
+      for (const PointSrc& s : h->psrc) {
+        if (s.n_e) launch_inject_values(st, h->inj_val + off, s.wre_e, s.wim_e, s.wave_e, n, (int)s.n_e);
+        off += (int)s.n_e;
       }
-      off += (int)s.n_e;
+      inj.val = h->inj_val;
     }
-    inj.n = alive ? off : 0;                 // (all lists alive or all spent: fused2_sources_uniform)
-    inj.start = h->inj_start; inj.ent = h->inj_ent; inj.val = h->inj_val;
+    inj.n = (alive || !tb->mons.empty()) ? 1 : 0;
+    inj.start = tb->start; inj.ent = tb->ent; inj.cap = h->cap_val;
   }
   const int total = nbx * nby * nbz;
   const int remap = h->xcd_remap < 0 ? kTileRun : h->xcd_remap;
   StepP sp = step_params(h);
   time_begin(h, 2, st);
-  launch_fused2_step(st, W, (h->mem_hints ? 1 : 0) | (h->twostep_pf ? 2 : 0), remap ? ((total + 7) / 8) * 8 : total, g, h->f,
+  launch_fused2_step(st, W, (h->mem_hints ? 1 : 0) | (h->twostep_pf ? 2 : 0) | (tb->mons.empty() ? 0 : 4), remap ? ((total + 7) / 8) * 8 : total, g, h->f,
                      h->f2, sp, h->ca1, h->cb1, zc, nbx, nby, nbz, remap, inj, h->seam_buf);
   if (nbx > 1) launch_seams(st, g, h->f2, sp, h->ca1, h->cb1, h->seam_buf, nbx - 1);
   time_end(h, st);
   swap_sets(h);
   return 0;
+}
+
+// behind the sweep of the pair (n, n + 1) (the sets are swapped: h->f2 = what it read, h->f = what it wrote): everything the
+// monitors of `tb` record of steps n and n + 1, in one launch
+void pair_record(FdtdSolver* h, const F2Table* tb, long long n, hipStream_t st) {
+  if (tb->mons.empty()) return;
+  PairRecP r{};
+  long long max_cells = 0;
+  for (size_t q = 0; q < tb->mons.size(); ++q) {
+    Monitor& m = h->mons[(size_t)tb->mons[q]];
+    const long long rs = (long long)m.comps.size() * m.cells;
+    r.box[q] = m.box;
+    r.nc[q] = (int)m.comps.size();
+    for (size_t ic = 0; ic < m.comps.size(); ++ic) r.comp[q][ic] = m.comps[ic];
+    r.cap_off[q] = tb->cap_off[q];
+    if (m.next < m.steps.size() && m.steps[m.next] == n) { r.out_n[q] = reinterpret_cast<float*>(m.data) + (long long)m.next * rs; m.next++; }
+    if (m.next < m.steps.size() && m.steps[m.next] == n + 1) { r.out_m[q] = reinterpret_cast<float*>(m.data) + (long long)m.next * rs; m.next++; }
+    max_cells = std::max(max_cells, m.cells);
+  }
+  r.n_mon = (int)tb->mons.size();
+  launch_pair_record(st, r, max_cells, h->g, h->f2, h->f, h->cap_val);
 }
 
 // Placement of the field arrays.  Where the twelve arrays land in device memory moves the sweep by up to 15 % (DESIGN.md
@@ -1289,9 +1409,15 @@ int eval_energy(FdtdSolver* h, hipStream_t st, double* out) {
 }
 
 // ---- monitors ---------------------------------------------------------------------------------
-void record_monitors(FdtdSolver* h, long long n, bool post, hipStream_t st) {
-  for (Monitor& m : h->mons) {
+void record_monitors(FdtdSolver* h, long long n, bool post, hipStream_t st, const F2Plan* in_sweep = nullptr) {
+  for (size_t mi = 0; mi < h->mons.size(); ++mi) {
+    Monitor& m = h->mons[mi];
     if (m.next >= m.steps.size() || m.steps[m.next] != n) continue;
+    if (in_sweep) {                    // monitors recorded behind the two-step sweep (pair_record)
+      bool skip = false;
+      for (int q : in_sweep->mons) skip = skip || q == (int)mi;
+      if (skip) continue;
+    }
     const long long rec = (long long)m.next;
     const int nc = (int)m.comps.size();
     // one launch per monitor and phase.  pre (before the H update): E^n, and half of H^{n-1/2} for
@@ -2247,6 +2373,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     return 0;
   };
   const bool f2_ok = fused && !tb_ok && fused2_eligible(h);
+  F2Plan f2_plan;
   h->fused2_pairs = 0;
   int64_t done = 0;
   for (; done < n_steps; ++done) {
@@ -2256,7 +2383,12 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
       HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
     }
-    if (rec) record_monitors(h, n, false, st);
+    // steps n and n + 1 as ONE sweep?  (fdtd_kernels2.hpp; no decay check on the middle step, sources all alive or all spent,
+    // every monitor that records at n or n + 1 a small time monitor the sweep can sample)
+    const bool pair = fused && f2_ok && done + 2 <= n_steps && !(h->decay_every > 0 && ((n + 1) % h->decay_every) == 0) &&
+                      fused2_sources_uniform(h, n) && fused2_plan(h, n, &f2_plan) &&
+                      (f2_plan.mons.empty() || sources_alive(n) || h->psrc.empty());
+    if (rec) record_monitors(h, n, false, st, pair ? &f2_plan : nullptr);
     if (fused_multi) {
       if (!primed && prime(n)) return -1;
       const bool decay_step = h->decay_every > 0 && ((n + 1) % h->decay_every) == 0;
@@ -2326,11 +2458,13 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       if (tb_pair(n)) return -1;
       h->step = n + 2;
       ++done;                                              // (the loop header counts the second step)
-    } else if (fused && f2_ok && done + 2 <= n_steps && !rec && !rec_at(n + 1) &&
-               !(h->decay_every > 0 && ((n + 1) % h->decay_every) == 0) && fused2_sources_uniform(h, n)) {
-      // two steps in one sweep; the E-side sources of step n + 1 follow it like those of a single step
-      if (launch_fused2(h, n, st)) return -1;
-      launch_sources(h, true, n + 1, 0, nz, st);
+    } else if (pair) {
+      const F2Table* tb = fused2_table(h, f2_plan);
+      if (!tb) return -1;
+      bool sources2_done = false;
+      if (launch_fused2(h, n, st, tb, &sources2_done)) return -1;
+      pair_record(h, tb, n, st);                           // (H^{n+3/2} is not touched by the E-side sources that follow)
+      if (!sources2_done) launch_sources(h, true, n + 1, 0, nz, st);
       fill_ghost_fused(h, st);
       h->fused2_pairs++;
       h->step = n + 2;

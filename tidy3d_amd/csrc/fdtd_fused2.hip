@@ -29,14 +29,29 @@ void launch_fused2_step(hipStream_t st, int waves, int opt, int grid_blocks, con
                      xcd_remap, inj, seam)
 #define FDTD_F2(LBV)                                                                                                   \
   do {                                                                                                                 \
-    if ((opt & 3) == 3) FDTD_F2_O(LBV, 3); else if ((opt & 3) == 2) FDTD_F2_O(LBV, 2);                                 \
-    else if ((opt & 3) == 1) FDTD_F2_O(LBV, 1); else FDTD_F2_O(LBV, 0);                                                \
+    switch (opt & 7) {                                                                                                 \
+      case 0: FDTD_F2_O(LBV, 0); break; case 1: FDTD_F2_O(LBV, 1); break; case 2: FDTD_F2_O(LBV, 2); break;            \
+      case 3: FDTD_F2_O(LBV, 3); break; case 4: FDTD_F2_O(LBV, 4); break; case 5: FDTD_F2_O(LBV, 5); break;            \
+      case 6: FDTD_F2_O(LBV, 6); break; default: FDTD_F2_O(LBV, 7); break;                                             \
+    }                                                                                                                  \
   } while (0)
   if (waves <= 8) FDTD_F2(512);
   else if (waves <= 12) FDTD_F2(768);
   else FDTD_F2(1024);
 #undef FDTD_F2
 #undef FDTD_F2_O
+}
+
+void launch_inject_table(hipStream_t st, float* tab, long long stride, long long off, const float* w_re, const float* w_im,
+                         const float2* wave, long long n_steps, int n) {
+  const unsigned blocks = (unsigned)((n_steps * n + 255) / 256);
+  hipLaunchKernelGGL(inject_table_kernel, dim3(blocks), dim3(256), 0, st, tab, stride, off, w_re, w_im, wave, n_steps, n);
+}
+
+void launch_pair_record(hipStream_t st, const PairRecP& r, long long max_cells, const GridP& g, const FieldP& a, const FieldP& b,
+                        const float* cap) {
+  const dim3 grid((unsigned)((max_cells + 255) / 256), (unsigned)(r.n_mon * 6));
+  hipLaunchKernelGGL(pair_record_kernel, grid, dim3(256), 0, st, r, g, a, b, cap);
 }
 
 void launch_seams(hipStream_t st, const GridP& g, const FieldP& b, const StepP& s, float ca, float cb, const float* seam,

@@ -9,21 +9,40 @@ namespace fdtd {
 
 constexpr int kMaxInj = 256;
 struct InjP {
-  int n;                                   // nodes that receive a source term between the two steps (0: none alive)
-  const int* start;                        // [nz + 2] entries of plane k: [start[k], start[k + 1])
-  const int4* ent;                         // (i, j, component, index into val), sorted by plane, list order kept within a plane
-  const float* val;                        // the terms (inject_values_kernel)
+  int n;                                   // 0: the node table is not walked (no source alive, no monitor sampling)
+  const int* start;                        // [nz + 2] rows of plane k: [start[k], start[k + 1])
+  const int4* ent;                         // (i, j, code, index), sorted by plane, sources first, list order kept:
+                                           //   code 0 - 2: E-side source node of that component, index into val / val2
+                                           //   code 8 + c: a time monitor's sample of component c (0 - 5) of the middle step -> cap[index]
+  const float* val;                        // source terms of step n
+  const float* val2;                       // source terms of step n+1, or nullptr: the caller applies them behind the launch
+  float* cap;                              // samples of the middle step (pair_record_kernel)
 };
+constexpr int kMaxCap = 1024;
 constexpr int kSeamArrays = 13;  // of step one: H1_y, H1_z, E1_x, E1_y, E1_z [c-1], E1_y, E1_z [c]; of step two: H2_x [c-1], H2_y, H2_z [c-2], H2_x, H2_y, H2_z [c]
                                  // (c = first column of the right tile)
 
 // host-side launchers (fdtd_fused2.hip)
 void launch_inject_values(hipStream_t st, float* val, const float* w_re, const float* w_im, const float2* wave,
                           long long step, int n);
-// waves = rows per workgroup (W - 3 of them written); opt: bit 0 non-temporal stores, bit 1 prefetch
+// waves = rows per workgroup (W - 3 of them written); opt: bit 0 non-temporal stores, bit 1 prefetch, bit 2 monitor samples in the table
 void launch_fused2_step(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
                         const FieldP& b, const StepP& s, float ca, float cb, int zchunk, int nbx, int nby, int nbz,
                         int xcd_remap, const InjP& inj, float* seam);
+void launch_inject_table(hipStream_t st, float* tab, long long stride, long long off, const float* w_re, const float* w_im,
+                         const float2* wave, long long n_steps, int n);
+constexpr int kPairMons = 4;
+struct PairRecP {
+  int n_mon;
+  BoxP box[kPairMons];
+  int nc[kPairMons];
+  int comp[kPairMons][6];
+  int cap_off[kPairMons];
+  float* out_n[kPairMons];       // the record of step n / n+1, nullptr = the monitor does not record then
+  float* out_m[kPairMons];
+};
+void launch_pair_record(hipStream_t st, const PairRecP& r, long long max_cells, const GridP& g, const FieldP& a, const FieldP& b,
+                        const float* cap);
 void launch_seams(hipStream_t st, const GridP& g, const FieldP& b, const StepP& s, float ca, float cb, const float* seam,
                   int n_seams);
 

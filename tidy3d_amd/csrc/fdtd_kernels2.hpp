@@ -28,6 +28,46 @@ namespace fdtd {
 
 // val[t] = w_re[t] * Re(wave[step]) - w_im[t] * Im(wave[step]): the term point_source_kernel adds, formed by the same
 // operations
+// What small time monitors record of a step pair (n, n+1), in ONE launch behind the sweep: E^n and H^{n-1/2} from the set the
+// sweep read, the middle step from the samples it copied out, H^{n+3/2} from the set it wrote (behind the seam repair) — with
+// the operations and in the order of time_record_multi_kernel's four launches (E: = 1 * E; H: += 0.5 * H per half-sample).
+// One thread per (monitor, component, cell): blockIdx.y = monitor * 6 + component slot.
+__global__ __launch_bounds__(256) void pair_record_kernel(PairRecP r, GridP g, FieldP a, FieldP b, const float* cap) {
+  const int mi = blockIdx.y / 6, ic = blockIdx.y % 6;
+  if (mi >= r.n_mon || ic >= r.nc[mi]) return;
+  const BoxP bx = r.box[mi];
+  const long long cells = (long long)bx.nx * bx.ny * bx.nz;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= cells) return;
+  const int c = r.comp[mi][ic];
+  const int lx = (int)(t % bx.nx), ly = (int)((t / bx.nx) % bx.ny), lz = (int)(t / ((long long)bx.nx * bx.ny));
+  const long long p = (long long)(bx.lo2 + lz) * g.sxy + (long long)(bx.lo1 + ly) * g.nx + bx.lo0 + lx;
+  const long long idx = (long long)ic * cells + t;
+  const float* fa = c == 0 ? a.ex : (c == 1 ? a.ey : (c == 2 ? a.ez : (c == 3 ? a.hx : (c == 4 ? a.hy : a.hz))));
+  const float* fb = c == 0 ? b.ex : (c == 1 ? b.ey : (c == 2 ? b.ez : (c == 3 ? b.hx : (c == 4 ? b.hy : b.hz))));
+  const float mid = cap[r.cap_off[mi] + idx];
+  float* on = r.out_n[mi];
+  float* om = r.out_m[mi];
+  if (c < 3) {
+    if (on) on[idx] = 1.0f * fa[p];
+    if (om) om[idx] = 1.0f * mid;
+  } else {
+    if (on) { float o = on[idx]; o = o + 0.5f * fa[p]; o = o + 0.5f * mid; on[idx] = o; }
+    if (om) { float o = om[idx]; o = o + 0.5f * mid; o = o + 0.5f * fb[p]; om[idx] = o; }
+  }
+}
+
+// the same for every step at once: tab[step * stride + off + t]
+__global__ __launch_bounds__(256) void inject_table_kernel(float* tab, long long stride, long long off, const float* w_re,
+                                                           const float* w_im, const float2* wave, long long n_steps, int n) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_steps * n) return;
+  const long long step = g / n;
+  const int t = (int)(g % n);
+  const float2 a = wave[step];
+  tab[step * stride + off + t] = w_re[t] * a.x - w_im[t] * a.y;
+}
+
 __global__ __launch_bounds__(256) void inject_values_kernel(float* val, const float* w_re, const float* w_im,
                                                             const float2* wave, long long step, int n) {
   const int t = threadIdx.x;
@@ -40,7 +80,8 @@ __device__ __forceinline__ long long seam_at(const GridP& g, int seam, int arr, 
   return (((long long)seam * kSeamArrays + arr) * (g.nz + 2) + (k + 1)) * g.ny + j;
 }
 
-// OPT: bit 0 = non-temporal stores, bit 1 = the loads of plane k+1 are issued behind the second barrier of plane k
+// OPT: bit 0 = non-temporal stores, bit 1 = the loads of plane k+1 are issued behind the second barrier of plane k,
+// bit 2 = the node table holds monitor samples (8-wave workgroups: two per CU, hence <= 128 VGPRs for LB = 512)
 // x neighbours across the wave: lane i takes the value of lane i+1 / i-1 (the last / first lane keeps its own, as __shfl_down /
 // __shfl_up do).  One DPP move (wave_shl:1 / wave_shr:1, GFX9) instead of a ds_bpermute through the LDS crossbar with its
 // address arithmetic and its lgkmcnt wait on the critical path of every stage.
@@ -61,12 +102,21 @@ __device__ __forceinline__ float lane_prev(float v) {
 #endif
 }
 
+// lane l's value of v, l wave-uniform
+__device__ __forceinline__ int lane_value(int v, int l) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_readlane(v, l);
+#else
+  return __shfl(v, l);
+#endif
+}
+
 template <int LB, int OPT>
-__global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, FieldP b, StepP s, float ca, float cb,
+__global__ __launch_bounds__(LB, (LB == 512 ? 2 : 1)) void fused2_step_kernel(GridP g, FieldP a, FieldP b, StepP s, float ca, float cb,
                                                          int zchunk, int nbx, int nby, int nbz, int xcd_remap,
                                                          InjP inj, float* __restrict__ seam) {
   constexpr int V = 4;
-  constexpr bool NT = (OPT & 1) != 0, PF = (OPT & 2) != 0;
+  constexpr bool NT = (OPT & 1) != 0, PF = (OPT & 2) != 0, MON = (OPT & 4) != 0;     // MON: the node table may hold monitor samples
   const int total = nbx * nby * nbz;
   int t = blockIdx.x;
   if (xcd_remap == 1) {
@@ -142,6 +192,7 @@ __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, Fiel
   zero<V>(h1x); zero<V>(h1y); zero<V>(h1z); zero<V>(e1x); zero<V>(e1y); zero<V>(e1z); zero<V>(h2xm); zero<V>(h2ym);
   float exk_m = 0.f;
   float ipz_m = 0.f, idz_m = 0.f;          // 1 / steps of plane k-1
+  int qm0 = 0, qm1 = 0;                    // table rows of plane k-1
   {
     const long long p0 = (long long)kA * g.sxy + rowb;
     ldf<V, true>(exk, uni(a.ex + p0), ubc);
@@ -283,12 +334,23 @@ __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, Fiel
           if (wx || wall_y) nez = 0.f;
           e1xn[e] = nex; e1yn[e] = ney; e1zn[e] = nez;
         }
-        // the E-side point sources of step n act on E^{n+1} before step n+1 reads it
-        {
-          for (int q = q0; q < q1; ++q) {
-            const int4 en = inj.ent[q];
-            if (en.y == j) {
-              const int d = en.x - i0;
+        // The node table of the plane.  Codes 0 - 2: the E-side point sources of step n act on E^{n+1} before step n+1 reads
+        // it.  Codes 8 - 13 (listed behind the sources of the plane; taken by the row's owner, once): what small time
+        // monitors need of the middle step — E^{n+1} behind the sources, H^{n+1/2} — is copied out for pair_record_kernel.
+        // (The rows of a plane are fetched 64 at a time, one per lane, and the lanes that hold a row of THIS wave's grid row are
+        //  found by a vote: a plane with entries costs one vector load, not one scalar round trip per entry — a probe's 16
+        //  entries per plane had added 30 us to every 200^3 step, profiles/r3x.)
+        for (int qb = q0; qb < q1; qb += 64) {
+          int4 ev = {0, -1, 0, 0};
+          if (qb + tx < q1) ev = inj.ent[qb + tx];
+          unsigned long long hit = __ballot(ev.y == j);
+          while (hit) {
+            const int l = __ffsll(hit) - 1;
+            hit &= hit - 1;
+            int4 en;
+            en.x = lane_value(ev.x, l); en.z = lane_value(ev.z, l); en.w = lane_value(ev.w, l);
+            const int d = en.x - i0;
+            if (en.z < 3) {
               const float v = inj.val[en.w];
 #pragma unroll
               for (int e = 0; e < V; ++e) {
@@ -297,6 +359,13 @@ __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, Fiel
                   else if (en.z == 1) e1yn[e] += v;
                   else e1zn[e] += v;
                 }
+              }
+            } else if (MON && own && k >= k0 && k < k1) {
+              const int c = en.z - 8;
+#pragma unroll
+              for (int e = 0; e < V; ++e) {
+                if (d == e)
+                  inj.cap[en.w] = c == 0 ? e1xn[e] : (c == 1 ? e1yn[e] : (c == 2 ? e1zn[e] : (c == 3 ? hxn[e] : (c == 4 ? hyn[e] : hzn[e]))));
               }
             }
           }
@@ -380,6 +449,28 @@ __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, Fiel
         if (wx || wall_y) nez = 0.f;
         ex[e] = nex; ey[e] = ney; ez[e] = nez;
       }
+      // the node table of plane k-1: the E-side sources of step n+1 (when the launch carries them) act on E^{n+2}
+      if (inj.val2) {
+        for (int qb = qm0; qb < qm1; qb += 64) {
+          int4 ev = {0, -1, 8, 0};
+          if (qb + tx < qm1) ev = inj.ent[qb + tx];
+          unsigned long long hit = __ballot(ev.y == j && ev.z < 3);
+          while (hit) {
+            const int l = __ffsll(hit) - 1;
+            hit &= hit - 1;
+            const int d = lane_value(ev.x, l) - i0, code = lane_value(ev.z, l);
+            const float v = inj.val2[lane_value(ev.w, l)];
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+              if (d == e) {
+                if (code == 0) ex[e] += v;
+                else if (code == 1) ey[e] += v;
+                else ez[e] += v;
+              }
+            }
+          }
+        }
+      }
       if (act) {
         // H2 next to the seams, for seam_kernel (so that it reads nothing but the scratch array, row-contiguous)
         float* sq = seam + seam_row + (long long)(k - 1) * g.ny;
@@ -411,6 +502,7 @@ __global__ __launch_bounds__(LB) void fused2_step_kernel(GridP g, FieldP a, Fiel
     }
     exk_m = L.exn_m;
     ipz_m = ipz; idz_m = idz;
+    qm0 = q0; qm1 = q1;
     cur ^= 1;
   };
   // two planes per trip: the carried values alternate between two register sets instead of being copied
