@@ -15,7 +15,16 @@ PULSE = td.GaussianPulse(freq0=3e14, fwidth=1.5e14)
 PEC = td.BoundarySpec.all_sides(td.PECBoundary())
 
 
-def _sim(N, monitors=True, extra=()):
+MEDIA = [td.Structure(geometry=td.Box(center=(-0.3, 0, 0), size=(0.25, 0.3, 0.2)), medium=td.Medium(permittivity=3.0, conductivity=0.02)),
+         td.Structure(geometry=td.Sphere(center=(0.05, 0, 0), radius=0.2), medium=td.Medium(permittivity=2.0)),
+         td.Structure(geometry=td.Box(center=(0.3, 0.1, 0), size=(0.1, 0.1, 0.1)), medium=td.PEC)]
+# a lossy bar through the seam at column 256, a sphere right of it, a PEC box (wide grids)
+MEDIA_WIDE = [td.Structure(geometry=td.Box(center=(-0.5, 0, 0), size=(3.0, 0.3, 0.2)), medium=td.Medium(permittivity=3.0, conductivity=0.02)),
+              td.Structure(geometry=td.Sphere(center=(6.3, 0, 0), radius=0.25), medium=td.Medium(permittivity=2.5)),
+              td.Structure(geometry=td.Box(center=(0.1, 0.1, 0), size=(0.1, 0.1, 0.1)), medium=td.PEC)]
+
+
+def _sim(N, monitors=True, extra=(), structures=()):
     size = tuple(n * DL for n in N)
     srcs = [td.PointDipole(center=(0.3 * size[0] - 0.5 * size[0] + 0.02, 0.01, 0.03), source_time=PULSE, polarization="Ez"),
             td.PointDipole(center=(0.01, 0.02, -0.1), source_time=PULSE, polarization="Ex")]
@@ -29,7 +38,7 @@ def _sim(N, monitors=True, extra=()):
         mons = [td.FieldMonitor(center=(0, 0, 0), size=(td.inf, td.inf, 0), freqs=[3e14], name="f", interval_space=(1, 1, 1)),
                 td.FieldTimeMonitor(center=(0, 0, 0), size=(0.2, 0.2, 0.2), name="t", interval=5, colocate=False)]
     return td.Simulation(size=size, grid_spec=td.GridSpec.uniform(dl=DL), run_time=1e-12, sources=srcs + list(extra),
-                         monitors=mons, boundary_spec=PEC, shutoff=0)
+                         structures=list(structures), monitors=mons, boundary_spec=PEC, shutoff=0)
 
 
 def _run(spec, lib, twostep, runs=(11, 15)):
@@ -51,15 +60,14 @@ SHAPES = {
 }
 
 
-CASES = [("one_tile", 16, 32), ("one_tile", 4, 2), ("one_tile", 8 + (1 << 16), 3),
-         ("ragged_rows", 16, 32), ("ragged_rows", 5, 3), ("ragged_rows", 8, 5), ("ragged_rows", 6 + (1 << 16), 32),
-         ("two_x_tiles", 16, 32), ("two_x_tiles", 4, 2), ("two_x_tiles", 5, 3), ("two_x_tiles", 8 + (1 << 16), 3),
-         ("three_x_tiles_tall", 8, 5), ("three_x_tiles_tall", 5, 3), ("three_x_tiles_tall", 6 + (1 << 16), 32)]
+CASES = [("one_tile", 16, 32), ("one_tile", 4, 2), ("one_tile", 8, 3),
+         ("ragged_rows", 16, 32), ("ragged_rows", 5, 3), ("ragged_rows", 8, 5), ("ragged_rows", 6, 32),
+         ("two_x_tiles", 16, 32), ("two_x_tiles", 4, 2), ("two_x_tiles", 5, 3), ("two_x_tiles", 8, 3),
+         ("three_x_tiles_tall", 8, 5), ("three_x_tiles_tall", 5, 3), ("three_x_tiles_tall", 6, 32)]
 
 
 @pytest.mark.parametrize("name,w,zc", CASES)
 def test_two_steps_per_sweep_equal_single_steps(name, w, zc, emu_lib):
-    """(bit 16 of w: the loads of the next plane issued behind the second barrier)"""
     N = SHAPES[name]
     disc = discretize(_sim(N, monitors=False), n_steps=26)
     disc.spec.decay_every = 0
@@ -67,6 +75,23 @@ def test_two_steps_per_sweep_equal_single_steps(name, w, zc, emu_lib):
     got_f, _, p1 = _run(disc.spec, emu_lib, w + 64 * zc)
     assert p0 == 0 and p1 == 5 + 7, p1          # runs of 11 and 15 steps: 5 + 7 pairs and a single step each
     assert max(float(np.abs(f).max()) for f in ref_f) > 0
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), c
+
+
+@pytest.mark.parametrize("name,w,zc", [("one_tile", 16, 32), ("one_tile", 5, 3), ("ragged_rows", 8, 5), ("two_x_tiles", 16, 32),
+                                       ("two_x_tiles", 6, 4), ("three_x_tiles_tall", 8, 5)])
+def test_two_steps_per_sweep_with_materials(name, w, zc, emu_lib):
+    """Non-dispersive media (a lossy dielectric bar through the seam of the wide grids, a sphere with sub-pixel-averaged
+    surface cells, a PEC box): uniform row segments take their coefficients as scalars, mixed ones per cell, the seam kernel
+    looks them up per cell — the same bits as single sweeps."""
+    N = SHAPES[name]
+    disc = discretize(_sim(N, monitors=False, structures=MEDIA_WIDE if N[0] >= 128 else MEDIA), n_steps=26)
+    disc.spec.decay_every = 0
+    assert len(disc.spec.media) > 2
+    ref_f, _, p0 = _run(disc.spec, emu_lib, 0)
+    got_f, _, p1 = _run(disc.spec, emu_lib, w + 64 * zc)
+    assert p0 == 0 and p1 == 5 + 7, p1
     for c in range(6):
         assert np.array_equal(got_f[c], ref_f[c]), c
 
@@ -129,12 +154,13 @@ def test_small_time_monitors_sample_the_middle_step(name, interval, emu_lib):
 
 
 def test_not_eligible_runs_take_single_steps(emu_lib):
-    """a magnetic dipole (H-side source), a periodic face or a medium: the option changes nothing, no pair is taken"""
+    """a magnetic dipole (H-side source), a periodic face or a dispersive medium: the option changes nothing, no pair is taken"""
     N = (32, 10, 9)
     cases = [dict(extra=[td.PointDipole(center=(0.1, 0, 0), source_time=PULSE, polarization="Hy")]),
              dict(bspec=td.BoundarySpec(x=td.Boundary.periodic(), y=td.Boundary(minus=td.PECBoundary(), plus=td.PECBoundary()),
                                         z=td.Boundary(minus=td.PECBoundary(), plus=td.PECBoundary()))),
-             dict(structures=[td.Structure(geometry=td.Box(center=(0, 0, 0), size=(0.3, 0.3, 0.2)), medium=td.Medium(permittivity=2.0))])]
+             dict(structures=[td.Structure(geometry=td.Box(center=(0, 0, 0), size=(0.3, 0.3, 0.2)),
+                                           medium=td.Lorentz(eps_inf=2.0, coeffs=[(1.5, 4e14, 3e13)]))])]
     for kw in cases:
         sim = _sim(N, monitors=False, extra=kw.get("extra", ()))
         if "bspec" in kw:

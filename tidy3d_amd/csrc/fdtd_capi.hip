@@ -206,7 +206,7 @@ struct FdtdSolver {
   long long two_step_pairs = 0;
   int tblock_used = 0;
   // two time steps per sweep (fused2_step_kernel): waves per workgroup (0 = off) and planes per chunk
-  int twostep_w = -1, twostep_zc = 0, twostep_pf = 0;      // -1 / 0: chosen by fused2_shape
+  int twostep_w = -1, twostep_zc = 0;      // -1 / 0: chosen by fused2_shape
   int twostep_w_used = 0, twostep_zc_used = 0;
   long long fused2_pairs = 0;
   float* seam_buf = nullptr;          // intermediate values on the seams between x tiles
@@ -614,9 +614,10 @@ int launch_fused(FdtdSolver* h, hipStream_t st, int pml_inside) {
 }
 
 // ---- two time steps per sweep (fdtd_kernels2.hpp) --------------------------------------------------------------------
-// What fused2_step_kernel covers: the plain curl stencil of a uniform medium inside six PEC walls on one GPU, driven by
-// E-side point sources.  Anything else (materials, CPML, absorbers, ADE, TFSF, periodic / PMC / Bloch faces, mirror
-// faces, magnetic dipoles, z-slabs) takes single steps.
+// What fused2_step_kernel covers: the curl stencil with non-dispersive media (uniform, or packed medium words + (Ca, Cb)
+// table: dielectrics, conductors, PEC bodies) inside six PEC walls on one GPU, driven by E-side point sources, recorded by
+// small time monitors.  Anything else (CPML, absorbers, ADE, TFSF, periodic / PMC / Bloch faces, mirror faces, magnetic
+// dipoles, z-slabs) takes single steps.
 // Tile shape of the two-step sweep: waves per workgroup W (W - 3 rows of a tile are written) and planes per chunk zc (a
 // chunk runs zc + 2 plane iterations).  Asked for through FDTD_OPT_TWOSTEP, or (default) the cheapest of W = 8 / 16 x
 // zc = 8 ... 64 under a two-parameter model fitted to profiles/r3r_two_step_small.jsonl, r3r_two_step_shapes512.jsonl and
@@ -638,7 +639,10 @@ bool fused2_shape(const FdtdSolver* h, int* W, int* zc) {
       if (w == 16) w = h->twostep_w; else continue;        // a requested W: only the chunk length is chosen
     }
     const int R = w - 3, nby = (g.ny + R - 1) / R;
-    const double slots = w <= 8 ? 512.0 : 256.0, t = w <= 8 ? 6.0 : (w >= 16 ? 8.2 : 6.0 + (8.2 - 6.0) * (w - 8) / 8.0);
+    // (with materials the instantiation sits at 128 VGPRs with spills and looks coefficients up: 512^3 V1 0.927 ms per step with
+    //  16 waves, 1.062 with 8 against 1.198 for single sweeps, profiles/r3z)
+    const double t8 = h->mat4 ? 9.1 : 6.0, t16 = h->mat4 ? 10.9 : 8.2;
+    const double slots = w <= 8 ? 512.0 : 256.0, t = w <= 8 ? t8 : (w >= 16 ? t16 : t8 + (t16 - t8) * (w - 8) / 8.0);
     for (int c : {64, 48, 32, 24, 16, 12, 8}) {
       if (c > std::max(8, g.nz)) continue;
       const double wg = (double)nbx * nby * ((g.nz + c - 1) / c);
@@ -655,7 +659,7 @@ bool fused2_shape(const FdtdSolver* h, int* W, int* zc) {
 bool fused2_eligible(const FdtdSolver* h) {
   if (h->twostep_w == 0) return false;
   { int W, zc; if (!fused2_shape(h, &W, &zc)) return false; }
-  if (h->comm || h->mat4 || any_pml(h) || h->has_damp || !h->ade.empty() || !h->tfsf.empty()) return false;
+  if (h->comm || any_pml(h) || h->has_damp || !h->ade.empty() || !h->tfsf.empty()) return false;
   for (int f = 0; f < 6; ++f) if (h->cfg.bc[f] != FDTD_BC_PEC) return false;
   if (!h->g.pec_z0 || h->g.nx % 4 || h->g.nz < 2) return false;
   for (int a = 0; a < 3; ++a) if (h->mirror_wall[a] >= 0) return false;
@@ -815,9 +819,10 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
   const int remap = h->xcd_remap < 0 ? kTileRun : h->xcd_remap;
   StepP sp = step_params(h);
   time_begin(h, 2, st);
-  launch_fused2_step(st, W, (h->mem_hints ? 1 : 0) | (h->twostep_pf ? 2 : 0) | (tb->mons.empty() ? 0 : 4), remap ? ((total + 7) / 8) * 8 : total, g, h->f,
-                     h->f2, sp, h->ca1, h->cb1, zc, nbx, nby, nbz, remap, inj, h->seam_buf);
-  if (nbx > 1) launch_seams(st, g, h->f2, sp, h->ca1, h->cb1, h->seam_buf, nbx - 1);
+  const MatP mp = mat_params(h);
+  launch_fused2_step(st, W, (h->mem_hints ? 1 : 0) | (h->mat4 ? 2 : 0) | (tb->mons.empty() ? 0 : 4), remap ? ((total + 7) / 8) * 8 : total, g, h->f,
+                     h->f2, sp, mp, zc, nbx, nby, nbz, remap, inj, h->seam_buf);
+  if (nbx > 1) launch_seams(st, g, h->f2, sp, mp, h->seam_buf, nbx - 1);
   time_end(h, st);
   swap_sets(h);
   return 0;
@@ -2798,9 +2803,8 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_EDGE_ZCHUNK: h->edge_zchunk = value < 0 ? -1 : value; return 0;
     case FDTD_OPT_GRAPH: h->use_graph = value < 0 ? -1 : (value != 0); return 0;
     case FDTD_OPT_TWOSTEP: {
-      if (value <= 0) { h->twostep_w = value < 0 ? -1 : 0; h->twostep_zc = 0; h->twostep_pf = 0; return 0; }
+      if (value <= 0) { h->twostep_w = value < 0 ? -1 : 0; h->twostep_zc = 0; return 0; }
       const int w = value % 64, zc = (value / 64) % 1024;
-      h->twostep_pf = (value >> 16) & 1;
       if (w < 4 || w > 16) return fail(h, "FDTD_OPT_TWOSTEP: %d waves per workgroup (4 ... 16)", w);
       h->twostep_w = w;
       h->twostep_zc = zc;

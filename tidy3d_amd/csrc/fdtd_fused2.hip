@@ -20,12 +20,12 @@ void launch_inject_values(hipStream_t st, float* val, const float* w_re, const f
 }
 
 void launch_fused2_step(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
-                        const FieldP& b, const StepP& s, float ca, float cb, int zchunk, int nbx, int nby, int nbz,
+                        const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,
                         int xcd_remap, const InjP& inj, float* seam) {
   const dim3 grid(grid_blocks, 1, 1), block(64, waves, 1);
   const size_t shmem = (size_t)8 * waves * 64 * sizeof(float4);
 #define FDTD_F2_O(LBV, OV)                                                                                             \
-  hipLaunchKernelGGL((fused2_step_kernel<LBV, OV>), grid, block, shmem, st, g, a, b, s, ca, cb, zchunk, nbx, nby, nbz, \
+  hipLaunchKernelGGL((fused2_step_kernel<LBV, OV>), grid, block, shmem, st, g, a, b, s, m, zchunk, nbx, nby, nbz,     \
                      xcd_remap, inj, seam)
 #define FDTD_F2(LBV)                                                                                                   \
   do {                                                                                                                 \
@@ -54,11 +54,11 @@ void launch_pair_record(hipStream_t st, const PairRecP& r, long long max_cells, 
   hipLaunchKernelGGL(pair_record_kernel, grid, dim3(256), 0, st, r, g, a, b, cap);
 }
 
-void launch_seams(hipStream_t st, const GridP& g, const FieldP& b, const StepP& s, float ca, float cb, const float* seam,
+void launch_seams(hipStream_t st, const GridP& g, const FieldP& b, const StepP& s, const MatP& m, const float* seam,
                   int n_seams) {
   const long long nt = (long long)n_seams * g.ny * g.nz;
   const unsigned blocks = (unsigned)((nt + 255) / 256);
-  hipLaunchKernelGGL(seam_kernel, dim3(blocks), dim3(256), 0, st, g, b, s, ca, cb, seam, n_seams);
+  hipLaunchKernelGGL(seam_kernel, dim3(blocks), dim3(256), 0, st, g, b, s, m, seam, n_seams);
 }
 
 }  // namespace fdtd

@@ -25,9 +25,10 @@ constexpr int kSeamArrays = 13;  // of step one: H1_y, H1_z, E1_x, E1_y, E1_z [c
 // host-side launchers (fdtd_fused2.hip)
 void launch_inject_values(hipStream_t st, float* val, const float* w_re, const float* w_im, const float2* wave,
                           long long step, int n);
-// waves = rows per workgroup (W - 3 of them written); opt: bit 0 non-temporal stores, bit 1 prefetch, bit 2 monitor samples in the table
+// waves = rows per workgroup (W - 3 of them written); opt: bit 0 non-temporal stores, bit 1 materials (m.m4 set), bit 2 monitor
+// samples in the table
 void launch_fused2_step(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
-                        const FieldP& b, const StepP& s, float ca, float cb, int zchunk, int nbx, int nby, int nbz,
+                        const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,
                         int xcd_remap, const InjP& inj, float* seam);
 void launch_inject_table(hipStream_t st, float* tab, long long stride, long long off, const float* w_re, const float* w_im,
                          const float2* wave, long long n_steps, int n);
@@ -43,7 +44,7 @@ struct PairRecP {
 };
 void launch_pair_record(hipStream_t st, const PairRecP& r, long long max_cells, const GridP& g, const FieldP& a, const FieldP& b,
                         const float* cap);
-void launch_seams(hipStream_t st, const GridP& g, const FieldP& b, const StepP& s, float ca, float cb, const float* seam,
+void launch_seams(hipStream_t st, const GridP& g, const FieldP& b, const StepP& s, const MatP& m, const float* seam,
                   int n_seams);
 
 }  // namespace fdtd

@@ -80,8 +80,8 @@ __device__ __forceinline__ long long seam_at(const GridP& g, int seam, int arr, 
   return (((long long)seam * kSeamArrays + arr) * (g.nz + 2) + (k + 1)) * g.ny + j;
 }
 
-// OPT: bit 0 = non-temporal stores, bit 1 = the loads of plane k+1 are issued behind the second barrier of plane k,
-// bit 2 = the node table holds monitor samples (8-wave workgroups: two per CU, hence <= 128 VGPRs for LB = 512)
+// OPT: bit 0 = non-temporal stores, bit 1 = materials (packed medium words + (Ca, Cb) table, as fused_step_kernel<MAT>),
+// bit 2 = the node table holds monitor samples (8-wave workgroups run two per CU: LB = 512 asks for 4 waves per SIMD, i.e. <= 128 VGPRs)
 // x neighbours across the wave: lane i takes the value of lane i+1 / i-1 (the last / first lane keeps its own, as __shfl_down /
 // __shfl_up do).  One DPP move (wave_shl:1 / wave_shr:1, GFX9) instead of a ds_bpermute through the LDS crossbar with its
 // address arithmetic and its lgkmcnt wait on the critical path of every stage.
@@ -112,11 +112,13 @@ __device__ __forceinline__ int lane_value(int v, int l) {
 }
 
 template <int LB, int OPT>
-__global__ __launch_bounds__(LB, (LB == 512 ? 2 : 1)) void fused2_step_kernel(GridP g, FieldP a, FieldP b, StepP s, float ca, float cb,
+__global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
                                                          int zchunk, int nbx, int nby, int nbz, int xcd_remap,
                                                          InjP inj, float* __restrict__ seam) {
   constexpr int V = 4;
-  constexpr bool NT = (OPT & 1) != 0, PF = (OPT & 2) != 0, MON = (OPT & 4) != 0;     // MON: the node table may hold monitor samples
+  constexpr bool NT = (OPT & 1) != 0, MAT = (OPT & 2) != 0, MON = (OPT & 4) != 0;     // MON: the node table may hold monitor samples
+  constexpr bool PF = false;      // (the loads of plane k+1 issued behind the second barrier of plane k: + 60 registers, slower at
+                                  //  every workgroup size, profiles/r3q — the code path is kept for the record, never instantiated)
   const int total = nbx * nby * nbz;
   int t = blockIdx.x;
   if (xcd_remap == 1) {
@@ -145,7 +147,12 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 2 : 1)) void fused2_step_kernel(Gr
 #pragma unroll
     for (int q = 0; q < 8; ++q) xch[q * slot + me] = z4;     // rows beyond the grid publish E = 0, H = 0
   }
+  __shared__ float2 lut_s[MAT ? kMaxMedia : 1];
+  if constexpr (MAT) {
+    for (int q = me; q < m.n_media; q += slot) lut_s[q] = m.lut[q];
+  }
   __syncthreads();
+  const float ca = m.ca1, cb = m.cb1;
   const int k0 = tile_z * zchunk;
   const int k1 = min(k0 + zchunk, g.nz);
   const int kA = k0 > 0 ? k0 - 1 : 0;
@@ -193,6 +200,8 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 2 : 1)) void fused2_step_kernel(Gr
   float exk_m = 0.f;
   float ipz_m = 0.f, idz_m = 0.f;          // 1 / steps of plane k-1
   int qm0 = 0, qm1 = 0;                    // table rows of plane k-1
+  [[maybe_unused]] uint32_t rw_m = kBgWord;                                        // material words of plane k-1 (S4)
+  [[maybe_unused]] uint32_t mw_m[V] = {kBgWord, kBgWord, kBgWord, kBgWord};
   {
     const long long p0 = (long long)kA * g.sxy + rowb;
     ldf<V, true>(exk, uni(a.ex + p0), ubc);
@@ -269,6 +278,15 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 2 : 1)) void fused2_step_kernel(Gr
     float hy_m = 0.f, hz_m = 0.f;
     float (&exn)[V] = L.exn, (&eyn)[V] = L.eyn, (&ezk)[V] = L.ezk, (&exj)[V] = L.exj, (&ezj)[V] = L.ezj;
     float (&hxn)[V] = L.hxn, (&hyn)[V] = L.hyn, (&hzn)[V] = L.hzn;
+    // material row-segment word of this plane (scalar load) and, where the segment is mixed, the packed words
+    [[maybe_unused]] uint32_t rw = kBgWord;
+    [[maybe_unused]] uint32_t mw[V] = {kBgWord, kBgWord, kBgWord, kBgWord};
+    if constexpr (MAT) {
+      if (do_e1) {
+        rw = m.roww[((long long)min(k, g.nz - 1) * g.ny + j) * nbx + tile_x];     // (plane nz: the wall, E1 = 0 whatever the medium)
+        if (rw == kMixedWord && act) ldm<V>(mw, at(uni(m.m4 + pb), ub));
+      }
+    }
     {
       if constexpr (!PF) issue(k, L);
       float eyx = lane_next(eyk[0]);
@@ -321,18 +339,32 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 2 : 1)) void fused2_step_kernel(Gr
           zero<V>(hxj); zero<V>(hzj);
         }
         const bool wall_z = (k == 0) || (k == g.nz);
+        // `coef(c, e)` yields (Ca, Cb) of component c of the lane's e-th cell (fused_step_kernel's e_phase)
+        auto s2 = [&](auto coef) __attribute__((always_inline)) {
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-          const float hy_im = (e > 0) ? hyn[(e + V - 1) % V] : hyx;
-          const float hz_im = (e > 0) ? hzn[(e + V - 1) % V] : hzx;
-          float nex = upd_e(exk[e], ca, cb, hzn[e] - hzj[e], idy, hyn[e] - h1y[e], idz);
-          float ney = upd_e(eyk[e], ca, cb, hxn[e] - h1x[e], idz, hzn[e] - hz_im, idx[e]);
-          float nez = upd_e(ezk[e], ca, cb, hyn[e] - hy_im, idx[e], hxn[e] - hxj[e], idy);
-          const bool wx = wall_x0 && (e == 0);
-          if (wall_y || wall_z) nex = 0.f;
-          if (wx || wall_z) ney = 0.f;
-          if (wx || wall_y) nez = 0.f;
-          e1xn[e] = nex; e1yn[e] = ney; e1zn[e] = nez;
+          for (int e = 0; e < V; ++e) {
+            const float hy_im = (e > 0) ? hyn[(e + V - 1) % V] : hyx;
+            const float hz_im = (e > 0) ? hzn[(e + V - 1) % V] : hzx;
+            float nex = upd_e(exk[e], coef(0, e).x, coef(0, e).y, hzn[e] - hzj[e], idy, hyn[e] - h1y[e], idz);
+            float ney = upd_e(eyk[e], coef(1, e).x, coef(1, e).y, hxn[e] - h1x[e], idz, hzn[e] - hz_im, idx[e]);
+            float nez = upd_e(ezk[e], coef(2, e).x, coef(2, e).y, hyn[e] - hy_im, idx[e], hxn[e] - hxj[e], idy);
+            const bool wx = wall_x0 && (e == 0);
+            if (wall_y || wall_z) nex = 0.f;
+            if (wx || wall_z) ney = 0.f;
+            if (wx || wall_y) nez = 0.f;
+            e1xn[e] = nex; e1yn[e] = ney; e1zn[e] = nez;
+          }
+        };
+        if constexpr (MAT) {
+          if (rw != kMixedWord) {
+            const float2 c0 = lut_s[rw & 1023u], c1 = lut_s[(rw >> 10) & 1023u], c2 = lut_s[(rw >> 20) & 1023u];
+            s2([&](int c, int) { return c == 0 ? c0 : (c == 1 ? c1 : c2); });
+          } else {
+            s2([&](int c, int e) { return lut_s[(mw[e] >> (10 * c)) & 1023u]; });
+          }
+        } else {
+          const float2 c1 = make_float2(ca, cb);
+          s2([&](int, int) { return c1; });
         }
         // The node table of the plane.  Codes 0 - 2: the E-side point sources of step n act on E^{n+1} before step n+1 reads
         // it.  Codes 8 - 13 (listed behind the sources of the plane; taken by the row's owner, once): what small time
@@ -436,18 +468,31 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 2 : 1)) void fused2_step_kernel(Gr
       }
       const bool wall_z = (k - 1 == 0);
       float ex[V], ey[V], ez[V];
+      auto s4 = [&](auto coef) __attribute__((always_inline)) {
 #pragma unroll
-      for (int e = 0; e < V; ++e) {
-        const float hy_im = (e > 0) ? h2y[(e + V - 1) % V] : hyx;
-        const float hz_im = (e > 0) ? h2z[(e + V - 1) % V] : hzx;
-        float nex = upd_e(e1x[e], ca, cb, h2z[e] - hzj[e], idy, h2y[e] - h2ym[e], idz_m);
-        float ney = upd_e(e1y[e], ca, cb, h2x[e] - h2xm[e], idz_m, h2z[e] - hz_im, idx[e]);
-        float nez = upd_e(e1z[e], ca, cb, h2y[e] - hy_im, idx[e], h2x[e] - hxj[e], idy);
-        const bool wx = wall_x0 && (e == 0);
-        if (wall_y || wall_z) nex = 0.f;
-        if (wx || wall_z) ney = 0.f;
-        if (wx || wall_y) nez = 0.f;
-        ex[e] = nex; ey[e] = ney; ez[e] = nez;
+        for (int e = 0; e < V; ++e) {
+          const float hy_im = (e > 0) ? h2y[(e + V - 1) % V] : hyx;
+          const float hz_im = (e > 0) ? h2z[(e + V - 1) % V] : hzx;
+          float nex = upd_e(e1x[e], coef(0, e).x, coef(0, e).y, h2z[e] - hzj[e], idy, h2y[e] - h2ym[e], idz_m);
+          float ney = upd_e(e1y[e], coef(1, e).x, coef(1, e).y, h2x[e] - h2xm[e], idz_m, h2z[e] - hz_im, idx[e]);
+          float nez = upd_e(e1z[e], coef(2, e).x, coef(2, e).y, h2y[e] - hy_im, idx[e], h2x[e] - hxj[e], idy);
+          const bool wx = wall_x0 && (e == 0);
+          if (wall_y || wall_z) nex = 0.f;
+          if (wx || wall_z) ney = 0.f;
+          if (wx || wall_y) nez = 0.f;
+          ex[e] = nex; ey[e] = ney; ez[e] = nez;
+        }
+      };
+      if constexpr (MAT) {
+        if (rw_m != kMixedWord) {
+          const float2 c0 = lut_s[rw_m & 1023u], c1 = lut_s[(rw_m >> 10) & 1023u], c2 = lut_s[(rw_m >> 20) & 1023u];
+          s4([&](int c, int) { return c == 0 ? c0 : (c == 1 ? c1 : c2); });
+        } else {
+          s4([&](int c, int e) { return lut_s[(mw_m[e] >> (10 * c)) & 1023u]; });
+        }
+      } else {
+        const float2 c1 = make_float2(ca, cb);
+        s4([&](int, int) { return c1; });
       }
       // the node table of plane k-1: the E-side sources of step n+1 (when the launch carries them) act on E^{n+2}
       if (inj.val2) {
@@ -503,6 +548,11 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 2 : 1)) void fused2_step_kernel(Gr
     exk_m = L.exn_m;
     ipz_m = ipz; idz_m = idz;
     qm0 = q0; qm1 = q1;
+    if constexpr (MAT) {
+      rw_m = rw;
+#pragma unroll
+      for (int e = 0; e < V; ++e) mw_m[e] = mw[e];
+    }
     cur ^= 1;
   };
   // two planes per trip: the carried values alternate between two register sets instead of being copied
@@ -517,7 +567,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 2 : 1)) void fused2_step_kernel(Gr
 // E2_{x,y,z}[c-1], E2_{y,z}[c] differentiate H2_{y,z}[c-1]: recomputed here with the formulas of the sweep from what both
 // tiles left in the scratch array [seam][13][nz + 2][ny] (read row-contiguously; plane nz and what lies beyond the walls
 // stay zero).  H2_{y,z}[c-1] of the row below and of the plane below are recomputed rather than exchanged: one launch.
-__global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, float ca, float cb,
+__global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, MatP m,
                                                    const float* __restrict__ seam, int n_seams) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long per = (long long)g.ny * g.nz;
@@ -543,18 +593,24 @@ __global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, f
   const float idy = s.idy[j], idz = s.idz[k], idx_m = s.idx[c - 1], idx_c = s.idx[c];
   const float hx_m = A(7, j, k), hy_mm = A(8, j, k), hz_mm = A(9, j, k);
   const float hx_c = A(10, j, k), hy_c = A(11, j, k), hz_c = A(12, j, k);
+  // (Ca, Cb) of component c at column c-1 (p - 1) / c (p): the table entry of the cell's medium word, or the uniform medium
+  auto coef = [&](long long cell, int c) {
+    return m.m4 ? m.lut[(m.m4[cell] >> (10 * c)) & 1023u] : make_float2(m.ca1, m.cb1);
+  };
   float ex_m = 0.f, ey_m = 0.f, ez_m = 0.f, ey_c = 0.f, ez_c = 0.f;
   float hy_k = 0.f, hz_j = 0.f, dum;
   if (!wall_z) h2(j, k - 1, hy_k, dum);
   if (!wall_y) h2(j - 1, k, dum, hz_j);
-  if (!wall_y && !wall_z) ex_m = upd_e(A(2, j, k), ca, cb, hz_m - hz_j, idy, hy_m - hy_k, idz);
+  if (!wall_y && !wall_z) { const float2 q = coef(p - 1, 0); ex_m = upd_e(A(2, j, k), q.x, q.y, hz_m - hz_j, idy, hy_m - hy_k, idz); }
   if (!wall_z) {
-    ey_m = upd_e(A(3, j, k), ca, cb, hx_m - A(7, j, k - 1), idz, hz_m - hz_mm, idx_m);
-    ey_c = upd_e(A(5, j, k), ca, cb, hx_c - A(10, j, k - 1), idz, hz_c - hz_m, idx_c);
+    const float2 qm = coef(p - 1, 1), qc = coef(p, 1);
+    ey_m = upd_e(A(3, j, k), qm.x, qm.y, hx_m - A(7, j, k - 1), idz, hz_m - hz_mm, idx_m);
+    ey_c = upd_e(A(5, j, k), qc.x, qc.y, hx_c - A(10, j, k - 1), idz, hz_c - hz_m, idx_c);
   }
   if (!wall_y) {
-    ez_m = upd_e(A(4, j, k), ca, cb, hy_m - hy_mm, idx_m, hx_m - A(7, j - 1, k), idy);
-    ez_c = upd_e(A(6, j, k), ca, cb, hy_c - hy_m, idx_c, hx_c - A(10, j - 1, k), idy);
+    const float2 qm = coef(p - 1, 2), qc = coef(p, 2);
+    ez_m = upd_e(A(4, j, k), qm.x, qm.y, hy_m - hy_mm, idx_m, hx_m - A(7, j - 1, k), idy);
+    ez_c = upd_e(A(6, j, k), qc.x, qc.y, hy_c - hy_m, idx_c, hx_c - A(10, j - 1, k), idy);
   }
   b.ex[p - 1] = ex_m; b.ey[p - 1] = ey_m; b.ez[p - 1] = ez_m;
   b.ey[p] = ey_c; b.ez[p] = ez_c;
