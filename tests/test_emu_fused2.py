@@ -24,7 +24,15 @@ MEDIA_WIDE = [td.Structure(geometry=td.Box(center=(-0.5, 0, 0), size=(3.0, 0.3, 
               td.Structure(geometry=td.Box(center=(0.1, 0.1, 0), size=(0.1, 0.1, 0.1)), medium=td.PEC)]
 
 
-def _sim(N, monitors=True, extra=(), structures=()):
+PMC_MIN = td.BoundarySpec(x=td.Boundary(minus=td.PMCBoundary(), plus=td.PECBoundary()),
+                          y=td.Boundary(minus=td.PMCBoundary(), plus=td.PECBoundary()),
+                          z=td.Boundary(minus=td.PMCBoundary(), plus=td.PECBoundary()))
+PMC_MIX = td.BoundarySpec(x=td.Boundary(minus=td.PECBoundary(), plus=td.PECBoundary()),
+                          y=td.Boundary(minus=td.PMCBoundary(), plus=td.PECBoundary()),
+                          z=td.Boundary(minus=td.PMCBoundary(), plus=td.PECBoundary()))
+
+
+def _sim(N, monitors=True, extra=(), structures=(), bspec=PEC):
     size = tuple(n * DL for n in N)
     srcs = [td.PointDipole(center=(0.3 * size[0] - 0.5 * size[0] + 0.02, 0.01, 0.03), source_time=PULSE, polarization="Ez"),
             td.PointDipole(center=(0.01, 0.02, -0.1), source_time=PULSE, polarization="Ex")]
@@ -38,7 +46,7 @@ def _sim(N, monitors=True, extra=(), structures=()):
         mons = [td.FieldMonitor(center=(0, 0, 0), size=(td.inf, td.inf, 0), freqs=[3e14], name="f", interval_space=(1, 1, 1)),
                 td.FieldTimeMonitor(center=(0, 0, 0), size=(0.2, 0.2, 0.2), name="t", interval=5, colocate=False)]
     return td.Simulation(size=size, grid_spec=td.GridSpec.uniform(dl=DL), run_time=1e-12, sources=srcs + list(extra),
-                         structures=list(structures), monitors=mons, boundary_spec=PEC, shutoff=0)
+                         structures=list(structures), monitors=mons, boundary_spec=bspec, shutoff=0)
 
 
 def _run(spec, lib, twostep, runs=(11, 15)):
@@ -94,6 +102,28 @@ def test_two_steps_per_sweep_with_materials(name, w, zc, emu_lib):
     assert p0 == 0 and p1 == 5 + 7, p1
     for c in range(6):
         assert np.array_equal(got_f[c], ref_f[c]), c
+
+
+@pytest.mark.parametrize("name,w,zc,bspec", [("one_tile", 16, 32, PMC_MIN), ("ragged_rows", 5, 3, PMC_MIN), ("two_x_tiles", 8, 5, PMC_MIN),
+                                             ("two_x_tiles", 16, 32, PMC_MIX), ("three_x_tiles_tall", 6, 4, PMC_MIN)])
+def test_two_steps_per_sweep_with_pmc_min_faces(name, w, zc, bspec, emu_lib):
+    """PMC walls on the min faces (the symmetry planes of a half / quarter / eighth domain): H mirrored with the opposite sign
+    behind them in both steps, in the sweep and in the seam kernel; with materials and a probe next to the walls."""
+    N = SHAPES[name]
+    size = tuple(n * DL for n in N)
+    sim = _sim(N, monitors=False, structures=MEDIA_WIDE if N[0] >= 128 else MEDIA, bspec=bspec)
+    srcs = list(sim.sources) + [td.PointDipole(center=(-0.5 * size[0] + 0.6 * DL, -0.5 * size[1] + 0.4 * DL, -0.5 * size[2] + 1.2 * DL),
+                                               source_time=PULSE, polarization="Ey")]
+    mons = [td.FieldTimeMonitor(center=(-0.5 * size[0] + 1.1 * DL, -0.5 * size[1] + 1.2 * DL, -0.5 * size[2] + 0.9 * DL), size=(0, 0, 0),
+                                name="corner", interval=1, colocate=False)]
+    disc = discretize(sim.updated_copy(sources=srcs, monitors=mons), n_steps=26)
+    disc.spec.decay_every = 0
+    ref_f, ref_m, p0 = _run(disc.spec, emu_lib, 0)
+    got_f, got_m, p1 = _run(disc.spec, emu_lib, w + 64 * zc)
+    assert p0 == 0 and p1 == 5 + 7, p1
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), c
+    assert np.abs(ref_m["corner"]).max() > 0 and np.array_equal(got_m["corner"], ref_m["corner"])
 
 
 @pytest.mark.parametrize("name", ["ragged_rows", "two_x_tiles"])

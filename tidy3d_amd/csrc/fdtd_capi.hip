@@ -616,8 +616,8 @@ int launch_fused(FdtdSolver* h, hipStream_t st, int pml_inside) {
 // ---- two time steps per sweep (fdtd_kernels2.hpp) --------------------------------------------------------------------
 // What fused2_step_kernel covers: the curl stencil with non-dispersive media (uniform, or packed medium words + (Ca, Cb)
 // table: dielectrics, conductors, PEC bodies) inside six PEC walls on one GPU, driven by E-side point sources, recorded by
-// small time monitors.  Anything else (CPML, absorbers, ADE, TFSF, periodic / PMC / Bloch faces, mirror faces, magnetic
-// dipoles, z-slabs) takes single steps.
+// small time monitors; the min faces may be PMC walls.  Anything else (CPML, absorbers, ADE, TFSF, periodic / Bloch faces,
+// PMC on max faces, magnetic dipoles, z-slabs) takes single steps.
 // Tile shape of the two-step sweep: waves per workgroup W (W - 3 rows of a tile are written) and planes per chunk zc (a
 // chunk runs zc + 2 plane iterations).  Asked for through FDTD_OPT_TWOSTEP, or (default) the cheapest of W = 8 / 16 x
 // zc = 8 ... 64 under a two-parameter model fitted to profiles/r3r_two_step_small.jsonl, r3r_two_step_shapes512.jsonl and
@@ -660,8 +660,10 @@ bool fused2_eligible(const FdtdSolver* h) {
   if (h->twostep_w == 0) return false;
   { int W, zc; if (!fused2_shape(h, &W, &zc)) return false; }
   if (h->comm || any_pml(h) || h->has_damp || !h->ade.empty() || !h->tfsf.empty()) return false;
-  for (int f = 0; f < 6; ++f) if (h->cfg.bc[f] != FDTD_BC_PEC) return false;
-  if (!h->g.pec_z0 || h->g.nx % 4 || h->g.nz < 2) return false;
+  // PEC walls; the min faces may be PMC (the symmetry planes of a half / quarter / eighth domain)
+  for (int f = 0; f < 6; ++f)
+    if (h->cfg.bc[f] != FDTD_BC_PEC && !((f & 1) == 0 && h->cfg.bc[f] == FDTD_BC_PMC)) return false;
+  if ((h->g.pec_z0 != 0) != (h->cfg.bc[4] == FDTD_BC_PEC) || h->g.nx % 4 || h->g.nz < 2) return false;
   for (int a = 0; a < 3; ++a) if (h->mirror_wall[a] >= 0) return false;
   long long n_e = 0;
   for (const PointSrc& s : h->psrc) {

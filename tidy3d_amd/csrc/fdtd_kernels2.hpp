@@ -19,8 +19,10 @@
 // values on the seam: those five values per seam row are computed wrong here and repaired afterwards by
 // seam_kernel from the intermediate values both tiles leave in a small scratch array.
 //
-// Scope (fdtd_capi.hip checks it): uniform medium, PEC on all six faces, no CPML / absorber / ADE / TFSF / Bloch /
-// mirror faces, E-side point sources only (<= kMaxInj nodes), one GPU.  Everything else takes single steps.
+// Scope (fdtd_capi.hip checks it): non-dispersive media (uniform, or packed medium words + (Ca, Cb) table), PEC walls (PMC
+// allowed on the min faces: symmetry planes), no CPML / absorber / ADE / TFSF / Bloch / mirror faces, E-side point sources only (<= kMaxInj nodes; those of step
+// n+1 are applied in S4), small time monitors (their samples of the middle step are copied out for pair_record_kernel), one
+// GPU.  Everything else takes single steps.
 #pragma once
 #include "fdtd_fused2.hpp"
 
@@ -178,8 +180,11 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
   const long long rowpb = use_jp ? rowb + g.nx : 0;
   const bool xh = act && (tx == 0) && !first_x;     // the tile's first lane recomputes H1_{y,z} of column i0-1
   const int im = first_x ? 0 : i0 - 1;
-  const bool wall_y = (j == 0);
-  const bool wall_x0 = first_x;
+  // min faces: a PEC wall (tangential E = 0 on it) or a PMC one (H mirrored with the opposite sign behind it), as in
+  // fused_step_kernel; max faces are PEC walls
+  const bool pmc_x0 = g.bcx0 == BC_PMC, pmc_y0 = g.bcy0 == BC_PMC, pmc_z0 = !g.pec_z0;
+  const bool wall_y = (j == 0) && !pmc_y0;
+  const bool wall_x0 = first_x && !pmc_x0;
 
   float ipx[V], idx[V];
   zero<V>(ipx); zero<V>(idx);
@@ -327,6 +332,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
       {
         if (tx == 0 || first_x) {
           if (xh) { hyx = hy_m; hzx = hz_m; }
+          else if (pmc_x0) { hyx = -hyn[0]; hzx = -hzn[0]; }
           else { hyx = 0.f; hzx = 0.f; }
         }
         float hxj[V], hzj[V];
@@ -335,10 +341,17 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
           const float4 t1 = xch[1 * slot + me - 64];
           hxj[0] = t0.x; hxj[1] = t0.y; hxj[2] = t0.z; hxj[3] = t0.w;
           hzj[0] = t1.x; hzj[1] = t1.y; hzj[2] = t1.z; hzj[3] = t1.w;
+        } else if (pmc_y0) {
+#pragma unroll
+          for (int e = 0; e < V; ++e) { hxj[e] = -hxn[e]; hzj[e] = -hzn[e]; }
         } else {
           zero<V>(hxj); zero<V>(hzj);
         }
-        const bool wall_z = (k == 0) || (k == g.nz);
+        if (pmc_z0 && k == 0) {
+#pragma unroll
+          for (int e = 0; e < V; ++e) { h1x[e] = -hxn[e]; h1y[e] = -hyn[e]; }
+        }
+        const bool wall_z = (k == 0 && !pmc_z0) || (k == g.nz);
         // `coef(c, e)` yields (Ca, Cb) of component c of the lane's e-th cell (fused_step_kernel's e_phase)
         auto s2 = [&](auto coef) __attribute__((always_inline)) {
 #pragma unroll
@@ -456,17 +469,27 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     if (own && k > k0) {
       float hyx = lane_prev(h2y[V - 1]);
       float hzx = lane_prev(h2z[V - 1]);
-      if (tx == 0 || first_x) { hyx = 0.f; hzx = 0.f; }      // the wall, or a seam (repaired by seam_kernel)
+      if (tx == 0 || first_x) {                              // a seam (repaired by seam_kernel), or the wall
+        if (first_x && pmc_x0) { hyx = -h2y[0]; hzx = -h2z[0]; }
+        else { hyx = 0.f; hzx = 0.f; }
+      }
       float hxj[V], hzj[V];
       if (j > 0) {
         const float4 t0 = xch[2 * slot + me - 64];
         const float4 t1 = xch[3 * slot + me - 64];
         hxj[0] = t0.x; hxj[1] = t0.y; hxj[2] = t0.z; hxj[3] = t0.w;
         hzj[0] = t1.x; hzj[1] = t1.y; hzj[2] = t1.z; hzj[3] = t1.w;
+      } else if (pmc_y0) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) { hxj[e] = -h2x[e]; hzj[e] = -h2z[e]; }
       } else {
         zero<V>(hxj); zero<V>(hzj);
       }
-      const bool wall_z = (k - 1 == 0);
+      if (pmc_z0 && k - 1 == 0) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) { h2xm[e] = -h2x[e]; h2ym[e] = -h2y[e]; }
+      }
+      const bool wall_z = (k - 1 == 0) && !pmc_z0;
       float ex[V], ey[V], ez[V];
       auto s4 = [&](auto coef) __attribute__((always_inline)) {
 #pragma unroll
@@ -587,7 +610,10 @@ __global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, M
   };
   float hy_m, hz_m;
   h2(j, k, hy_m, hz_m);
-  const bool wall_y = (j == 0), wall_z = (k == 0);
+  // (row 0 / plane 0: a PEC wall, or a PMC one with H mirrored behind it)
+  const bool pmc_y0 = g.bcy0 == BC_PMC, pmc_z0 = !g.pec_z0;
+  const bool wall_y = (j == 0) && !pmc_y0, wall_z = (k == 0) && !pmc_z0;
+  const bool mir_y = (j == 0) && pmc_y0, mir_z = (k == 0) && pmc_z0;
   const long long p = (long long)k * g.sxy + (long long)j * g.nx + c;       // column c; p - 1 = column c-1
   b.hy[p - 1] = hy_m; b.hz[p - 1] = hz_m;
   const float idy = s.idy[j], idz = s.idz[k], idx_m = s.idx[c - 1], idx_c = s.idx[c];
@@ -599,18 +625,21 @@ __global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, M
   };
   float ex_m = 0.f, ey_m = 0.f, ez_m = 0.f, ey_c = 0.f, ez_c = 0.f;
   float hy_k = 0.f, hz_j = 0.f, dum;
-  if (!wall_z) h2(j, k - 1, hy_k, dum);
-  if (!wall_y) h2(j - 1, k, dum, hz_j);
+  if (mir_z) hy_k = -hy_m; else if (!wall_z) h2(j, k - 1, hy_k, dum);
+  if (mir_y) hz_j = -hz_m; else if (!wall_y) h2(j - 1, k, dum, hz_j);
+  // H2_x of the plane / row below (columns c-1 and c)
+  const float hxm_k = wall_z ? 0.f : (mir_z ? -hx_m : A(7, j, k - 1)), hxc_k = wall_z ? 0.f : (mir_z ? -hx_c : A(10, j, k - 1));
+  const float hxm_j = wall_y ? 0.f : (mir_y ? -hx_m : A(7, j - 1, k)), hxc_j = wall_y ? 0.f : (mir_y ? -hx_c : A(10, j - 1, k));
   if (!wall_y && !wall_z) { const float2 q = coef(p - 1, 0); ex_m = upd_e(A(2, j, k), q.x, q.y, hz_m - hz_j, idy, hy_m - hy_k, idz); }
   if (!wall_z) {
     const float2 qm = coef(p - 1, 1), qc = coef(p, 1);
-    ey_m = upd_e(A(3, j, k), qm.x, qm.y, hx_m - A(7, j, k - 1), idz, hz_m - hz_mm, idx_m);
-    ey_c = upd_e(A(5, j, k), qc.x, qc.y, hx_c - A(10, j, k - 1), idz, hz_c - hz_m, idx_c);
+    ey_m = upd_e(A(3, j, k), qm.x, qm.y, hx_m - hxm_k, idz, hz_m - hz_mm, idx_m);
+    ey_c = upd_e(A(5, j, k), qc.x, qc.y, hx_c - hxc_k, idz, hz_c - hz_m, idx_c);
   }
   if (!wall_y) {
     const float2 qm = coef(p - 1, 2), qc = coef(p, 2);
-    ez_m = upd_e(A(4, j, k), qm.x, qm.y, hy_m - hy_mm, idx_m, hx_m - A(7, j - 1, k), idy);
-    ez_c = upd_e(A(6, j, k), qc.x, qc.y, hy_c - hy_m, idx_c, hx_c - A(10, j - 1, k), idy);
+    ez_m = upd_e(A(4, j, k), qm.x, qm.y, hy_m - hy_mm, idx_m, hx_m - hxm_j, idy);
+    ez_c = upd_e(A(6, j, k), qc.x, qc.y, hy_c - hy_m, idx_c, hx_c - hxc_j, idy);
   }
   b.ex[p - 1] = ex_m; b.ey[p - 1] = ey_m; b.ez[p - 1] = ez_m;
   b.ey[p] = ey_c; b.ez[p] = ez_c;
