@@ -11,11 +11,17 @@ to uniform random +-1e-3 (rng seed 0), fp32, curl-stencil only.  A "step" = one 
 (H pass + E pass) of all 6 components of every cell.  Inputs are resident in HBM before the
 timed region.
 
+On one GPU the library advances this workload TWO time steps per sweep (fused2_step_kernel, bit-identical
+to single sweeps): K steps are K / 2 launches.  `single_steps` on the line is the same
+engine advancing one step per sweep.
+
 Extra objects on the JSON line:
-  roofline     — dominant kernel (the E- or H-update, whichever is slower): algorithmic bytes per
-                 launch (36 B/cell x cells of the launch) / its average
+  roofline     — dominant kernel: algorithmic bytes per launch (the fused sweep's own minimum, 48 B per
+                 cell-step — x 2 steps per launch for the two-step sweep — see roofline_entry; SURVEY.md
+                 8(d)'s 72 B two-pass figure is reported beside it as frac_vs_survey_8d) / its average
                  launch duration measured with hipEvents on the launch stream inside the library
-                 (FDTD_FLAG_TIME_KERNELS), against the 8 TB/s HBM peak.
+                 (FDTD_FLAG_TIME_KERNELS), against the 8 TB/s HBM peak; `traffic` = PMC bytes per launch
+                 from profiles/pmc_traffic.json when they were measured on these kernel sources.
   cpu_baseline — the fp64->fp32 NumPy curl loop of oracle/fdtd_numpy.py (kind "port": the
                  reference has no solver to time), on a bounded sample (smaller grid, few
                  steps), rank 0 at N = 1 only.
