@@ -391,3 +391,43 @@ def test_two_steps_per_sweep_config2_probe_records_bit_identical(hip_lib):
     for c in range(6):
         assert np.array_equal(got[c], ref[c]), c
     assert np.array_equal(got_m["t"], ref_m["t"])
+
+
+@pytest.mark.parametrize("w,zc", [(16, 32), (8, 5), (5, 3)])
+def test_two_steps_per_sweep_everything_at_once_on_the_device(hip_lib, w, zc):
+    """The device-only pieces of the two-step sweep (DPP wave shifts, the vote-based node-table walk, readlane) with everything
+    it covers at once: three x tiles (two seams), ragged rows and chunks, PMC walls on the min faces, a lossy bar through a
+    seam + sub-pixel sphere + PEC box, dipoles next to the seams and the walls, probes (E and H components, one in the column
+    left of a seam, one on a source node) at intervals 1 / 2 — same fields and records as single sweeps."""
+    import tidy3d_amd.schema as td
+    from tidy3d_amd.discretize import discretize
+    import test_emu_fused2 as T
+    N = (520, 37, 45)
+    size = tuple(n * T.DL for n in N)
+    sim = T._sim(N, monitors=False, structures=T.MEDIA_WIDE, bspec=T.PMC_MIN)
+    srcs = list(sim.sources) + [td.PointDipole(center=(-0.5 * size[0] + 0.6 * T.DL, -0.5 * size[1] + 0.4 * T.DL, -0.5 * size[2] + 1.2 * T.DL),
+                                               source_time=T.PULSE, polarization="Ey")]
+    mons = [td.FieldTimeMonitor(center=(-0.5 * size[0] + 255.4 * T.DL, 0.0, 0.05), size=(0, 0, 0), name="seam", interval=1,
+                                fields=["Ex", "Hy", "Hz"], colocate=False),
+            td.FieldTimeMonitor(center=(-0.5 * size[0] + 1.1 * T.DL, -0.5 * size[1] + 1.2 * T.DL, -0.5 * size[2] + 0.9 * T.DL), size=(0, 0, 0),
+                                name="corner", interval=2, colocate=False),
+            td.FieldTimeMonitor(center=(0.3 * size[0] - 0.5 * size[0] + 0.02, 0.01, 0.03), size=(0, 0, 0), name="src", interval=1,
+                                fields=["Ez"], colocate=False)]
+    disc = discretize(sim.updated_copy(sources=srcs, monitors=mons), n_steps=61)
+    disc.spec.decay_every = 16
+
+    def run(twostep):
+        with HipEngine(disc.spec, lib=hip_lib, variant=L.VARIANT_FUSED) as e:
+            e.set_option(L.OPT_TWOSTEP, twostep)
+            pairs = 0
+            for r in (25, 36):
+                pairs += int(e.run(r).fused2_pairs)
+            return [e.get_field(c) for c in range(6)], e.results(), pairs
+    ref_f, ref_m, p0 = run(0)
+    got_f, got_m, p1 = run(w + 64 * zc)
+    assert p0 == 0 and p1 >= 24, p1
+    assert max(float(np.abs(f).max()) for f in ref_f) > 0
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), c
+    for k in ("seam", "corner", "src"):
+        assert np.abs(ref_m[k]).max() > 0 and np.array_equal(got_m[k], ref_m[k]), k
