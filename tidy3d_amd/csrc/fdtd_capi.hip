@@ -639,9 +639,9 @@ bool fused2_shape(const FdtdSolver* h, int* W, int* zc) {
       if (w == 16) w = h->twostep_w; else continue;        // a requested W: only the chunk length is chosen
     }
     const int R = w - 3, nby = (g.ny + R - 1) / R;
-    // (with materials the instantiation sits at 128 VGPRs with spills and looks coefficients up: 512^3 V1 0.927 ms per step with
-    //  16 waves, 1.062 with 8 against 1.198 for single sweeps, profiles/r3z)
-    const double t8 = h->mat4 ? 9.1 : 6.0, t16 = h->mat4 ? 10.9 : 8.2;
+    // (with materials the instantiation sits at 128 VGPRs with 4 spills and looks coefficients up: 512^3 V1 0.800 ms per step
+    //  with 16 waves, 0.882 with 8 against 1.136 for single sweeps, profiles/r3zx)
+    const double t8 = h->mat4 ? 7.6 : 6.0, t16 = h->mat4 ? 9.4 : 8.2;
     const double slots = w <= 8 ? 512.0 : 256.0, t = w <= 8 ? t8 : (w >= 16 ? t16 : t8 + (t16 - t8) * (w - 8) / 8.0);
     for (int c : {64, 48, 32, 24, 16, 12, 8}) {
       if (c > std::max(8, g.nz)) continue;

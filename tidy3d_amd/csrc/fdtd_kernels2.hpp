@@ -205,8 +205,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
   float exk_m = 0.f;
   float ipz_m = 0.f, idz_m = 0.f;          // 1 / steps of plane k-1
   int qm0 = 0, qm1 = 0;                    // table rows of plane k-1
-  [[maybe_unused]] uint32_t rw_m = kBgWord;                                        // material words of plane k-1 (S4)
-  [[maybe_unused]] uint32_t mw_m[V] = {kBgWord, kBgWord, kBgWord, kBgWord};
+  [[maybe_unused]] uint32_t rw_m = kBgWord;                                        // material row-segment word of plane k-1 (S4)
   {
     const long long p0 = (long long)kA * g.sxy + rowb;
     ldf<V, true>(exk, uni(a.ex + p0), ubc);
@@ -283,14 +282,11 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     float hy_m = 0.f, hz_m = 0.f;
     float (&exn)[V] = L.exn, (&eyn)[V] = L.eyn, (&ezk)[V] = L.ezk, (&exj)[V] = L.exj, (&ezj)[V] = L.ezj;
     float (&hxn)[V] = L.hxn, (&hyn)[V] = L.hyn, (&hzn)[V] = L.hzn;
-    // material row-segment word of this plane (scalar load) and, where the segment is mixed, the packed words
+    // material row-segment word of this plane (scalar load); where the segment is mixed (6 % of them around a sphere) the
+    // packed words are fetched where they are used: held from here they cost four registers the instantiation does not have
     [[maybe_unused]] uint32_t rw = kBgWord;
-    [[maybe_unused]] uint32_t mw[V] = {kBgWord, kBgWord, kBgWord, kBgWord};
     if constexpr (MAT) {
-      if (do_e1) {
-        rw = m.roww[((long long)min(k, g.nz - 1) * g.ny + j) * nbx + tile_x];     // (plane nz: the wall, E1 = 0 whatever the medium)
-        if (rw == kMixedWord && act) ldm<V>(mw, at(uni(m.m4 + pb), ub));
-      }
+      if (do_e1) rw = m.roww[((long long)min(k, g.nz - 1) * g.ny + j) * nbx + tile_x];     // (plane nz: the wall, E1 = 0 whatever the medium)
     }
     {
       if constexpr (!PF) issue(k, L);
@@ -373,6 +369,8 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
             const float2 c0 = lut_s[rw & 1023u], c1 = lut_s[(rw >> 10) & 1023u], c2 = lut_s[(rw >> 20) & 1023u];
             s2([&](int c, int) { return c == 0 ? c0 : (c == 1 ? c1 : c2); });
           } else {
+            uint32_t mw[V] = {kBgWord, kBgWord, kBgWord, kBgWord};
+            if (act) ldm<V>(mw, at(uni(m.m4 + pb), ub));
             s2([&](int c, int e) { return lut_s[(mw[e] >> (10 * c)) & 1023u]; });
           }
         } else {
@@ -511,6 +509,9 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
           const float2 c0 = lut_s[rw_m & 1023u], c1 = lut_s[(rw_m >> 10) & 1023u], c2 = lut_s[(rw_m >> 20) & 1023u];
           s4([&](int c, int) { return c == 0 ? c0 : (c == 1 ? c1 : c2); });
         } else {
+          // (the packed words of plane k-1 are read again rather than carried: four registers the instantiation does not have)
+          uint32_t mw_m[V] = {kBgWord, kBgWord, kBgWord, kBgWord};
+          if (act) ldm<V>(mw_m, at(uni(m.m4 + pb - g.sxy), ub));
           s4([&](int c, int e) { return lut_s[(mw_m[e] >> (10 * c)) & 1023u]; });
         }
       } else {
@@ -571,11 +572,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     exk_m = L.exn_m;
     ipz_m = ipz; idz_m = idz;
     qm0 = q0; qm1 = q1;
-    if constexpr (MAT) {
-      rw_m = rw;
-#pragma unroll
-      for (int e = 0; e < V; ++e) mw_m[e] = mw[e];
-    }
+    if constexpr (MAT) rw_m = rw;
     cur ^= 1;
   };
   // two planes per trip: the carried values alternate between two register sets instead of being copied
