@@ -119,8 +119,8 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
                                                          InjP inj, float* __restrict__ seam) {
   constexpr int V = 4;
   constexpr bool NT = (OPT & 1) != 0, MAT = (OPT & 2) != 0, MON = (OPT & 4) != 0;     // MON: the node table may hold monitor samples
-  constexpr bool PF = false;      // (the loads of plane k+1 issued behind the second barrier of plane k: + 60 registers, slower at
-                                  //  every workgroup size, profiles/r3q — the code path is kept for the record, never instantiated)
+  // (Issuing the loads of plane k+1 behind the second barrier of plane k — the one way to overlap them with compute inside a wave —
+  //  was measured: + 60 registers, slower at every workgroup size, profiles/r3q; taken out.)
   const int total = nbx * nby * nbz;
   int t = blockIdx.x;
   if (xcd_remap == 1) {
@@ -271,8 +271,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     }
   };
   Ld LA, LB2;
-  if constexpr (PF) issue(kA, LA);
-  auto body = [&](int k, Ld& L, Ld& Lnext) __attribute__((always_inline)) {
+  auto body = [&](int k, Ld& L) __attribute__((always_inline)) {
     // (iteration k = nz, last chunk only: plane nz is the z-max wall, E1_{x,y}[nz] = 0 is all it contributes; its loads
     //  read the ghost plane, its other results are never used)
     const long long pb = (long long)k * g.sxy + rowb;
@@ -289,7 +288,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
       if (do_e1) rw = m.roww[((long long)min(k, g.nz - 1) * g.ny + j) * nbx + tile_x];     // (plane nz: the wall, E1 = 0 whatever the medium)
     }
     {
-      if constexpr (!PF) issue(k, L);
+      issue(k, L);
       float eyx = lane_next(eyk[0]);
       float ezx = lane_next(ezk[0]);
       if (act && (tx == 63 || last_x)) {
@@ -461,8 +460,6 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
       xch[3 * slot + me] = t4;
     }
     __syncthreads();
-    // the loads of the next plane go out here: their latency runs under S4 and the stores of this plane
-    if constexpr (PF) { if (k + 1 <= k1 && k + 1 < g.nz) issue(k + 1, Lnext); }
     // ---- S4: E2[k-1] ----
     if (own && k > k0) {
       float hyx = lane_prev(h2y[V - 1]);
@@ -577,8 +574,8 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
   };
   // two planes per trip: the carried values alternate between two register sets instead of being copied
   for (int k = kA; k <= k1; k += 2) {
-    body(k, LA, LB2);
-    if (k + 1 <= k1) body(k + 1, LB2, LA);
+    body(k, LA);
+    if (k + 1 <= k1) body(k + 1, LB2);
   }
 }
 
