@@ -104,6 +104,17 @@ __device__ __forceinline__ float lane_prev(float v) {
 #endif
 }
 
+// A per-lane value the optimiser cannot see through.  Lane-constant predicates (first / last lane of a tile, cells beyond the row
+// end) are re-derived from it inside the march: hoisted out of the loop each of them is a 64-bit lane mask that lives in an
+// SGPR pair for the whole kernel — a dozen of them were a third of the SGPRs this kernel spills to VGPR lanes and reads back
+// (v_readlane) inside every plane.
+__device__ __forceinline__ int opaque_lane(int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(v));
+#endif
+  return v;
+}
+
 // lane l's value of v, l wave-uniform
 __device__ __forceinline__ int lane_value(int v, int l) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -244,6 +255,11 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     float exn_m, ez_mm, ey_mm, ex_jm, hy_o, hz_o;        // column i0 - 1 (first lane of a tile with a left neighbour)
   };
   auto issue = [&](int k, Ld& L) __attribute__((always_inline)) {
+    const int txo = MAT ? tx : opaque_lane(tx);       // (the materials instantiation has no VGPR to spare for the re-derivation)
+    const int i0o = (tile_x * 64 + txo) * V;
+    const bool act = i0o < g.nx, last_x = i0o + V >= g.nx, first_x = i0o == 0;
+    const bool xh = act && txo == 0 && !first_x;
+    [[maybe_unused]] const bool wall_x0 = first_x && !pmc_x0;
     const long long pb = (long long)k * g.sxy + rowb;
     const long long pjb = (long long)k * g.sxy + rowpb;
     const long long up = (k < g.nz) ? g.sxy : 0;         // (iteration nz only needs E1_{x,y}[nz] = 0: it reads the ghost plane twice)
@@ -260,7 +276,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     ldf<V, true>(L.hyn, uni(a.hy + pb), ubc);
     ldf<V, true>(L.hzn, uni(a.hz + pb), ubc);
     L.eyx_g = 0.f; L.ezx_g = 0.f;
-    if (act && tx == 63 && !last_x) { L.eyx_g = a.ey[pb + ux + V]; L.ezx_g = a.ez[pb + ux + V]; }
+    if (act && txo == 63 && !last_x) { L.eyx_g = a.ey[pb + ux + V]; L.ezx_g = a.ez[pb + ux + V]; }
     L.exn_m = 0.f; L.ez_mm = 0.f; L.ey_mm = 0.f; L.ex_jm = 0.f; L.hy_o = 0.f; L.hz_o = 0.f;
     if (xh && do_e1) {
       const long long pm = pb + im;
@@ -272,6 +288,11 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
   };
   Ld LA, LB2;
   auto body = [&](int k, Ld& L) __attribute__((always_inline)) {
+    const int txo = MAT ? tx : opaque_lane(tx);       // (the materials instantiation has no VGPR to spare for the re-derivation)
+    const int i0o = (tile_x * 64 + txo) * V;
+    const bool act = i0o < g.nx, last_x = i0o + V >= g.nx, first_x = i0o == 0;
+    const bool xh = act && txo == 0 && !first_x;
+    [[maybe_unused]] const bool wall_x0 = first_x && !pmc_x0;
     // (iteration k = nz, last chunk only: plane nz is the z-max wall, E1_{x,y}[nz] = 0 is all it contributes; its loads
     //  read the ghost plane, its other results are never used)
     const long long pb = (long long)k * g.sxy + rowb;
@@ -291,7 +312,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
       issue(k, L);
       float eyx = lane_next(eyk[0]);
       float ezx = lane_next(ezk[0]);
-      if (act && (tx == 63 || last_x)) {
+      if (act && (txo == 63 || last_x)) {
         if (!last_x) { eyx = L.eyx_g; ezx = L.ezx_g; }
         else { eyx = 0.f; ezx = 0.f; }
       }
@@ -325,7 +346,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
       float hyx = lane_prev(hyn[V - 1]);
       float hzx = lane_prev(hzn[V - 1]);
       {
-        if (tx == 0 || first_x) {
+        if (txo == 0 || first_x) {
           if (xh) { hyx = hy_m; hzx = hz_m; }
           else if (pmc_x0) { hyx = -hyn[0]; hzx = -hzn[0]; }
           else { hyx = 0.f; hzx = 0.f; }
@@ -415,14 +436,14 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
         // what the neighbouring x tile needs of this step: repaired on the seam by seam_kernel
         if (own && k >= k0 && k < k1 && act) {
           float* sp = seam + seam_row + (long long)k * g.ny;
-          if (tx == 63 && !last_x) {
+          if (txo == 63 && !last_x) {
             sp[0] = hyn[V - 1];
             sp[seam_arr] = hzn[V - 1];
             sp[2 * seam_arr] = e1xn[V - 1];
             sp[3 * seam_arr] = e1yn[V - 1];
             sp[4 * seam_arr] = e1zn[V - 1];
           }
-          if (tx == 0 && tile_x > 0) {
+          if (txo == 0 && tile_x > 0) {
             sp[5 * seam_arr - kSeamArrays * seam_arr] = e1yn[0];
             sp[6 * seam_arr - kSeamArrays * seam_arr] = e1zn[0];
           }
@@ -435,7 +456,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     if (do_h2 && k > kA) {
       float eyx = lane_next(e1y[0]);
       float ezx = lane_next(e1z[0]);
-      if (tx == 63 || last_x) { eyx = 0.f; ezx = 0.f; }      // the wall, or a seam (repaired by seam_kernel)
+      if (txo == 63 || last_x) { eyx = 0.f; ezx = 0.f; }      // the wall, or a seam (repaired by seam_kernel)
       const float4 t0 = xch[(4 + (cur ^ 1) * 2 + 0) * slot + me + 64];
       const float4 t1 = xch[(4 + (cur ^ 1) * 2 + 1) * slot + me + 64];
       const float exj1[V] = {t0.x, t0.y, t0.z, t0.w}, ezj1[V] = {t1.x, t1.y, t1.z, t1.w};
@@ -464,7 +485,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     if (own && k > k0) {
       float hyx = lane_prev(h2y[V - 1]);
       float hzx = lane_prev(h2z[V - 1]);
-      if (tx == 0 || first_x) {                              // a seam (repaired by seam_kernel), or the wall
+      if (txo == 0 || first_x) {                              // a seam (repaired by seam_kernel), or the wall
         if (first_x && pmc_x0) { hyx = -h2y[0]; hzx = -h2z[0]; }
         else { hyx = 0.f; hzx = 0.f; }
       }
@@ -540,12 +561,12 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
       if (act) {
         // H2 next to the seams, for seam_kernel (so that it reads nothing but the scratch array, row-contiguous)
         float* sq = seam + seam_row + (long long)(k - 1) * g.ny;
-        if (tx == 63 && !last_x) {
+        if (txo == 63 && !last_x) {
           sq[7 * seam_arr] = h2x[V - 1];
           sq[8 * seam_arr] = h2y[V - 2];
           sq[9 * seam_arr] = h2z[V - 2];
         }
-        if (tx == 0 && tile_x > 0) {
+        if (txo == 0 && tile_x > 0) {
           sq[10 * seam_arr - kSeamArrays * seam_arr] = h2x[0];
           sq[11 * seam_arr - kSeamArrays * seam_arr] = h2y[0];
           sq[12 * seam_arr - kSeamArrays * seam_arr] = h2z[0];
