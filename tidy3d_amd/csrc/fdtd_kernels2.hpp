@@ -195,7 +195,6 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
   // fused_step_kernel; max faces are PEC walls
   const bool pmc_x0 = g.bcx0 == BC_PMC, pmc_y0 = g.bcy0 == BC_PMC, pmc_z0 = !g.pec_z0;
   const bool wall_y = (j == 0) && !pmc_y0;
-  const bool wall_x0 = first_x && !pmc_x0;
 
   float ipx[V], idx[V];
   zero<V>(ipx); zero<V>(idx);
