@@ -232,6 +232,20 @@ def secondary_workload(HipEngine, L, n, workload, device, args, steps=40, repeat
         eng.run(10)
         st = eng.stats()
         cells = n ** 3
+        two_step = int(st.fused2_pairs) > 0
+        single = None
+        if two_step:                                   # the same engine advancing one step per sweep
+            eng.set_option(L.OPT_FLAGS, 0)
+            eng.set_option(L.OPT_TWOSTEP, 0)
+            eng.run(10)
+            ss = []
+            for _ in range(repeats):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                eng.run(steps)
+                torch.cuda.synchronize()
+                ss.append(time.perf_counter() - t0)
+            single = float(np.median(ss))
         own = min_bytes_per_cell(workload, spec)
         survey = 72.0 + (own - 48.0) + 4.0          # two passes + psi + material word: the SURVEY.md 8(d) accounting
         return {"workload": f"{workload}: {WORKLOADS[workload]}", "value": cells * steps / el / 1e6, "unit": "Mcells/s",
@@ -242,7 +256,11 @@ def secondary_workload(HipEngine, L, n, workload, device, args, steps=40, repeat
                 "sweep_launches_per_step": st.fused_kernel_launches / 10,
                 "sweep_launch_ms_sum_concurrent": st.fused_kernel_ms / 10,
                 "stream_overlap": int(st.stream_overlap),
-                "traffic": _v2_traffic(cells),
+                "two_steps_per_sweep": ({"pairs_in_10_steps": int(st.fused2_pairs), "waves_per_workgroup": int(st.fused2_shape) & 63,
+                                         "planes_per_chunk": int(st.fused2_shape) >> 6,
+                                         "single_steps_ms_per_step": single / steps * 1e3,
+                                         "single_steps_value": cells * steps / single / 1e6} if two_step else None),
+                "traffic": _v2_traffic(cells) if workload == "v2" else None,
                 "bytes_per_cell_own_minimum": own,
                 "whole_step_frac": own * cells * steps / el / HBM_PEAK,
                 "bytes_per_cell_survey_8d": survey,
@@ -432,7 +450,9 @@ def main():
         # the workload every real simulation resembles (materials + CPML on all faces), same grid, same box
         eng.close()
         eng = None
-        out["workloads"] = {"v2": secondary_workload(HipEngine, L, n, "v2", local_rank, args)}
+        out["workloads"] = {"v2": secondary_workload(HipEngine, L, n, "v2", local_rank, args),
+                            # materials inside PEC walls: the two-step sweep's materials instantiation
+                            "v1": secondary_workload(HipEngine, L, n, "v1", local_rank, args)}
 
     if args.sweep and world == 1 and eng is not None:
         res = []
