@@ -431,3 +431,15 @@ def test_two_steps_per_sweep_everything_at_once_on_the_device(hip_lib, w, zc):
         assert np.array_equal(got_f[c], ref_f[c]), c
     for k in ("seam", "corner", "src"):
         assert np.abs(ref_m[k]).max() > 0 and np.array_equal(got_m[k], ref_m[k]), k
+    if (w, zc) == (16, 32):
+        # ... and the two-step sweep against the fp64 oracle directly (fields and probe records; fp32 round-off over 61 steps)
+        from oracle.fdtd_numpy import OracleFdtd
+        o = OracleFdtd(disc.spec)
+        om = o.run()
+        for k in ("seam", "corner", "src"):
+            assert rel_err(got_m[k], om[k]) < 2e-5, (k, rel_err(got_m[k], om[k]))
+        en = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in o.E))
+        hn = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in o.H))
+        for c in range(3):
+            assert np.linalg.norm(got_f[c] - o.E[c]) / en < 2e-5, c
+            assert np.linalg.norm(got_f[3 + c] - o.H[c]) / hn < 2e-5, c
