@@ -1,7 +1,7 @@
 """A/B of the two-steps-per-sweep kernel inside ONE engine (same placement of the field arrays): option values of
 FDTD_OPT_TWOSTEP (0 = single steps) timed in turn on the bench workload, several rounds.
     python scripts/probe_twostep.py [--lib path.so] [--n 512] [--steps 60] [--rounds 3] v0 v1 ...
-v = waves + 64 * planes per chunk (+ 65536: loads of the next plane behind the second barrier)"""
+v = waves + 64 * planes per chunk; `auto` = the library's default (shape by grid size)"""
 import argparse
 import json
 import os
@@ -48,7 +48,7 @@ def main():
         for v in args.values:
             ms = sorted(res[v])[len(res[v]) // 2]
             print(json.dumps({"lib": os.path.basename(args.lib or "default"), "n": n, "twostep": v, "waves": shape[v] & 63,
-                              "zchunk": shape[v] >> 6, "prefetch": (v >> 16) & 1 if v > 0 else 0, "ms_per_step": round(ms, 5),
+                              "zchunk": shape[v] >> 6, "ms_per_step": round(ms, 5),
                               "all": [round(x, 5) for x in res[v]], "gcells_per_s": round(n ** 3 / ms / 1e6, 1)}), flush=True)
 
 
