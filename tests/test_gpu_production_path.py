@@ -397,7 +397,7 @@ def test_two_steps_per_sweep_config2_probe_records_bit_identical(hip_lib):
 def test_two_steps_per_sweep_everything_at_once_on_the_device(hip_lib, w, zc):
     """The device-only pieces of the two-step sweep (DPP wave shifts, the vote-based node-table walk, readlane) with everything
     it covers at once: three x tiles (two seams), ragged rows and chunks, PMC walls on the min faces, a lossy bar through a
-    seam + sub-pixel sphere + PEC box, dipoles next to the seams and the walls, probes (E and H components, one in the column
+    seam + sub-pixel sphere + PEC box, electric and magnetic dipoles next to the seams and the walls, probes (E and H components, one in the column
     left of a seam, one on a source node) at intervals 1 / 2 — same fields and records as single sweeps."""
     import tidy3d_amd.schema as td
     from tidy3d_amd.discretize import discretize
@@ -406,7 +406,9 @@ def test_two_steps_per_sweep_everything_at_once_on_the_device(hip_lib, w, zc):
     size = tuple(n * T.DL for n in N)
     sim = T._sim(N, monitors=False, structures=T.MEDIA_WIDE, bspec=T.PMC_MIN)
     srcs = list(sim.sources) + [td.PointDipole(center=(-0.5 * size[0] + 0.6 * T.DL, -0.5 * size[1] + 0.4 * T.DL, -0.5 * size[2] + 1.2 * T.DL),
-                                               source_time=T.PULSE, polarization="Ey")]
+                                               source_time=T.PULSE, polarization="Ey"),
+                                td.PointDipole(center=(0.12, 0.03, -0.02), source_time=T.PULSE, polarization="Hy"),
+                                td.PointDipole(center=(-0.5 * size[0] + 257.5 * T.DL, 0.02, 0.0), source_time=T.PULSE, polarization="Hz")]
     mons = [td.FieldTimeMonitor(center=(-0.5 * size[0] + 255.4 * T.DL, 0.0, 0.05), size=(0, 0, 0), name="seam", interval=1,
                                 fields=["Ex", "Hy", "Hz"], colocate=False),
             td.FieldTimeMonitor(center=(-0.5 * size[0] + 1.1 * T.DL, -0.5 * size[1] + 1.2 * T.DL, -0.5 * size[2] + 0.9 * T.DL), size=(0, 0, 0),

@@ -64,8 +64,8 @@ struct PointSrc {
   float2 *wave_e = nullptr, *wave_h = nullptr;
   long long n_steps = 0;
   int ke0 = 0, ke1 = 0, kh0 = 0, kh1 = 0;   // planes [k0, k1) that hold its E / H points
-  std::vector<int32_t> host_comp_e;         // host copies of the E nodes (the two-step sweep applies them in-kernel)
-  std::vector<uint32_t> host_cell_e;
+  std::vector<int32_t> host_comp_e, host_comp_h;   // host copies of the nodes (the two-step sweep applies them in-kernel)
+  std::vector<uint32_t> host_cell_e, host_cell_h;
 };
 
 // correction list of one side (E or H) of a TFSF box, grouped by target node (tfsf_corr_kernel)
@@ -216,7 +216,8 @@ struct FdtdSolver {
   size_t inj_sources = 0;             // point-source lists the tables were built from
   float* src_tab = nullptr;           // [step][node] source terms of every step, formed once (nullptr: per pair)
   long long src_tab_steps = 0, src_tab_nodes = 0;
-  bool src_on_seam = false;           // a source node lies next to a seam between x tiles: step n+1's terms go behind the launch
+  bool src_on_seam = false;           // an E-side source node lies next to a seam between x tiles: step n+1's terms go behind the launch
+  long long src_h_nodes = 0;          // H-side source nodes (need the table of all steps)
 };
 
 namespace {
@@ -615,9 +616,9 @@ int launch_fused(FdtdSolver* h, hipStream_t st, int pml_inside) {
 
 // ---- two time steps per sweep (fdtd_kernels2.hpp) --------------------------------------------------------------------
 // What fused2_step_kernel covers: the curl stencil with non-dispersive media (uniform, or packed medium words + (Ca, Cb)
-// table: dielectrics, conductors, PEC bodies) inside six PEC walls on one GPU, driven by E-side point sources, recorded by
+// table: dielectrics, conductors, PEC bodies) inside six PEC walls on one GPU, driven by point sources (electric and magnetic), recorded by
 // small time monitors; the min faces may be PMC walls.  Anything else (CPML, absorbers, ADE, TFSF, periodic / Bloch faces,
-// PMC on max faces, magnetic dipoles, z-slabs) takes single steps.
+// PMC on max faces, z-slabs) takes single steps.
 // Tile shape of the two-step sweep: waves per workgroup W (W - 3 rows of a tile are written) and planes per chunk zc (a
 // chunk runs zc + 2 plane iterations).  Asked for through FDTD_OPT_TWOSTEP, or (default) the cheapest of W = 8 / 16 x
 // zc = 8 ... 64 under a two-parameter model fitted to profiles/r3r_two_step_small.jsonl, r3r_two_step_shapes512.jsonl and
@@ -667,18 +668,22 @@ bool fused2_eligible(const FdtdSolver* h) {
     if (h->cfg.bc[f] != FDTD_BC_PEC && !((f & 1) == 0 && h->cfg.bc[f] == FDTD_BC_PMC)) return false;
   if ((h->g.pec_z0 != 0) != (h->cfg.bc[4] == FDTD_BC_PEC) || h->g.nx % 4 || h->g.nz < 2) return false;
   for (int a = 0; a < 3; ++a) if (h->mirror_wall[a] >= 0) return false;
-  long long n_e = 0;
+  long long nodes = 0;
   for (const PointSrc& s : h->psrc) {
-    if (s.n_h) return false;
-    n_e += s.n_e;
+    nodes += s.n_e + s.n_h;
+    // an H_y / H_z source node in the column left of a seam between x tiles: the seam kernel rebuilds that value without it
+    for (long long t = 0; t < s.n_h; ++t) {
+      const int i = (int)(s.host_cell_h[(size_t)t] % h->g.nx), c = s.host_comp_h[(size_t)t];
+      if (c != 3 && i % 256 == 255 && i + 1 < h->g.nx) return false;
+    }
   }
-  return n_e <= kMaxInj;
+  return nodes <= kMaxInj;
 }
 // the point sources of step n: all alive or all spent (the kernel applies the whole table or nothing)
 bool fused2_sources_uniform(const FdtdSolver* h, long long n) {
   bool any_alive = false, any_spent = false;
   for (const PointSrc& s : h->psrc) {
-    if (!s.n_e) continue;
+    if (!s.n_e && !s.n_h) continue;
     if (n < s.n_steps) any_alive = true; else any_spent = true;
   }
   return !(any_alive && any_spent);
@@ -711,7 +716,10 @@ bool fused2_plan(const FdtdSolver* h, long long n, F2Plan* plan) {
   return total <= kMaxCap && (int)plan->mons.size() <= kPairMons;
 }
 
-const F2Table* fused2_table(FdtdSolver* h, const F2Plan& plan) {
+// the source terms of every step, formed once with the operations of point_source_kernel: [step][node], nodes in the order of
+// the node tables (E nodes then H nodes of each list).  Rebuilt when lists were added.  0 = fine (src_tab may stay nullptr when
+// the table would be too large: then the terms of step n are formed per pair and those of step n+1 go behind the launch)
+int fused2_sources(FdtdSolver* h) {
   const GridP& g = h->g;
   if (h->inj_sources != h->psrc.size()) {
     h->f2_tables.clear();
@@ -720,34 +728,49 @@ const F2Table* fused2_table(FdtdSolver* h, const F2Plan& plan) {
     h->src_tab = nullptr;
     h->src_on_seam = false;
     long long nodes = 0, steps = 0;
+    h->src_h_nodes = 0;
     for (const PointSrc& s : h->psrc) {
-      nodes += s.n_e;
-      if (s.n_e) steps = std::max(steps, s.n_steps);
+      nodes += s.n_e + s.n_h;
+      h->src_h_nodes += s.n_h;
+      if (s.n_e || s.n_h) steps = std::max(steps, s.n_steps);
       for (long long t = 0; t < s.n_e; ++t) {
         const int i = (int)(s.host_cell_e[(size_t)t] % g.nx);
         h->src_on_seam = h->src_on_seam || (i % 256 == 255 && i + 1 < g.nx) || (i % 256 == 0 && i > 0);
       }
     }
     if (nodes > 0 && nodes * steps <= (1LL << 24)) {
-      if (dev_alloc(h, &h->src_tab, (size_t)(nodes * steps))) return nullptr;
+      if (dev_alloc(h, &h->src_tab, (size_t)(nodes * steps))) return -1;
       long long off = 0;
-      for (const PointSrc& s : h->psrc) {
+      for (const PointSrc& s : h->psrc) {          // node order: E nodes then H nodes of each list (as the node table below)
         if (s.n_e) launch_inject_table(h->stream, h->src_tab, nodes, off, s.wre_e, s.wim_e, s.wave_e, s.n_steps, (int)s.n_e);
         off += s.n_e;
+        if (s.n_h) launch_inject_table(h->stream, h->src_tab, nodes, off, s.wre_h, s.wim_h, s.wave_h, s.n_steps, (int)s.n_h);
+        off += s.n_h;
       }
       h->src_tab_steps = steps; h->src_tab_nodes = nodes;
     }
   }
+  return 0;
+}
+
+const F2Table* fused2_table(FdtdSolver* h, const F2Plan& plan) {
+  const GridP& g = h->g;
+  if (fused2_sources(h)) return nullptr;
   for (const F2Table& t : h->f2_tables) if (t.mons == plan.mons) return &t;
   // the nodes of all E-side lists, sorted by plane; nodes of one plane keep their list order (a node two lists share
   // receives their terms in the order the source kernels would add them); the monitor samples of a plane follow them
   std::vector<std::array<int, 5>> ent;        // k, i, j, code, index
   int off = 0;
-  for (const PointSrc& s : h->psrc)
+  for (const PointSrc& s : h->psrc) {
     for (long long t = 0; t < s.n_e; ++t, ++off) {
       const long long cell = s.host_cell_e[(size_t)t];
       ent.push_back({(int)(cell / g.sxy), (int)(cell % g.nx), (int)((cell % g.sxy) / g.nx), s.host_comp_e[(size_t)t] % 3, off});
     }
+    for (long long t = 0; t < s.n_h; ++t, ++off) {      // H-side nodes: codes 3 - 5, terms of step n+1 only (those of step n go out
+      const long long cell = s.host_cell_h[(size_t)t];  // in front of the sweep, launch_sources)
+      ent.push_back({(int)(cell / g.sxy), (int)(cell % g.nx), (int)((cell % g.sxy) / g.nx), 3 + s.host_comp_h[(size_t)t] % 3, off});
+    }
+  }
   F2Table tb;
   tb.mons = plan.mons;
   int coff = 0;
@@ -802,17 +825,20 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
   {
     bool alive = false, alive2 = true;
     for (const PointSrc& s : h->psrc)
-      if (s.n_e) { alive = alive || n < s.n_steps; alive2 = alive2 && n + 1 < s.n_steps; }
+      if (s.n_e || s.n_h) { alive = alive || n < s.n_steps; alive2 = alive2 && n + 1 < s.n_steps; }
     // (all lists alive or all spent: fused2_sources_uniform.  Spent lists add nothing — not + 0 — so their table is only
     //  walked when there are none or when they are alive: pairs with monitor samples AND spent sources are not taken, fdtd_run)
     if (alive && h->src_tab && n + 1 < h->src_tab_steps) {
       inj.val = h->src_tab + n * h->src_tab_nodes;
-      if (alive2 && !h->src_on_seam) { inj.val2 = h->src_tab + (n + 1) * h->src_tab_nodes; *sources2_done = true; }
+      if (alive2) {
+        inj.val2 = h->src_tab + (n + 1) * h->src_tab_nodes;
+        if (!h->src_on_seam) { inj.e2_in_sweep = 1; *sources2_done = true; }
+      }
     } else if (alive) {
       int off = 0;
       for (const PointSrc& s : h->psrc) {
         if (s.n_e) launch_inject_values(st, h->inj_val + off, s.wre_e, s.wim_e, s.wave_e, n, (int)s.n_e);
-        off += (int)s.n_e;
+        off += (int)(s.n_e + s.n_h);
       }
       inj.val = h->inj_val;
     }
@@ -824,7 +850,7 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
   StepP sp = step_params(h);
   time_begin(h, 2, st);
   const MatP mp = mat_params(h);
-  launch_fused2_step(st, W, (h->mem_hints ? 1 : 0) | (h->mat4 ? 2 : 0) | (tb->mons.empty() ? 0 : 4), remap ? ((total + 7) / 8) * 8 : total, g, h->f,
+  launch_fused2_step(st, W, (h->mem_hints ? 1 : 0) | (h->mat4 ? 2 : 0) | ((tb->mons.empty() && h->src_h_nodes == 0) ? 0 : 4), remap ? ((total + 7) / 8) * 8 : total, g, h->f,
                      h->f2, sp, mp, zc, nbx, nby, nbz, remap, inj, h->seam_buf);
   if (nbx > 1) launch_seams(st, g, h->f2, sp, mp, h->seam_buf, nbx - 1);
   time_end(h, st);
@@ -837,6 +863,7 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
 void pair_record(FdtdSolver* h, const F2Table* tb, long long n, hipStream_t st) {
   if (tb->mons.empty()) return;
   PairRecP r{};
+  r.pre_done = h->src_h_nodes > 0;            // (then fdtd_run has not skipped them at the top of the step)
   long long max_cells = 0;
   for (size_t q = 0; q < tb->mons.size(); ++q) {
     Monitor& m = h->mons[(size_t)tb->mons[q]];
@@ -1852,8 +1879,8 @@ int fdtd_add_point_source(FdtdSolver* h, int64_t n, const int32_t* comp, const u
         dev_upload(h, &s.wave_h, reinterpret_cast<const float2*>(wave_h), (size_t)n_steps))
       return -1;
   }
-  s.host_comp_e = ce;
-  s.host_cell_e = le;
+  s.host_comp_e = ce; s.host_comp_h = chh;
+  s.host_cell_e = le; s.host_cell_h = lh;
   h->psrc.push_back(s);
   return 0;
 }
@@ -2390,7 +2417,11 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     h->graph_pairs++;
     return 0;
   };
-  const bool f2_ok = fused && !tb_ok && fused2_eligible(h);
+  bool f2_ok = fused && !tb_ok && fused2_eligible(h);
+  if (f2_ok) {
+    if (fused2_sources(h)) return -1;
+    if (h->src_h_nodes > 0 && !h->src_tab) f2_ok = false;      // H-side nodes take their terms of step n+1 from the table only
+  }
   F2Plan f2_plan;
   h->fused2_pairs = 0;
   int64_t done = 0;
@@ -2406,7 +2437,9 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     const bool pair = fused && f2_ok && done + 2 <= n_steps && !(h->decay_every > 0 && ((n + 1) % h->decay_every) == 0) &&
                       fused2_sources_uniform(h, n) && fused2_plan(h, n, &f2_plan) &&
                       (f2_plan.mons.empty() || sources_alive(n) || h->psrc.empty());
-    if (rec) record_monitors(h, n, false, st, pair ? &f2_plan : nullptr);
+    // (with H-side sources the monitors of a pair still take E^n and H^{n-1/2} here: those sources change H^{n-1/2} before the
+    //  sweep, and pair_record reads the set afterwards)
+    if (rec) record_monitors(h, n, false, st, (pair && h->src_h_nodes == 0) ? &f2_plan : nullptr);
     if (fused_multi) {
       if (!primed && prime(n)) return -1;
       const bool decay_step = h->decay_every > 0 && ((n + 1) % h->decay_every) == 0;
@@ -2480,6 +2513,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       const F2Table* tb = fused2_table(h, f2_plan);
       if (!tb) return -1;
       bool sources2_done = false;
+      launch_sources(h, false, n, 0, nz, st);              // H-side sources of step n act on H^{n-1/2}, as before a single step
       if (launch_fused2(h, n, st, tb, &sources2_done)) return -1;
       pair_record(h, tb, n, st);                           // (H^{n+3/2} is not touched by the E-side sources that follow)
       if (!sources2_done) launch_sources(h, true, n + 1, 0, nz, st);

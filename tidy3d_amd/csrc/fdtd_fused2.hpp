@@ -13,9 +13,11 @@ struct InjP {
   const int* start;                        // [nz + 2] rows of plane k: [start[k], start[k + 1])
   const int4* ent;                         // (i, j, code, index), sorted by plane, sources first, list order kept:
                                            //   code 0 - 2: E-side source node of that component, index into val / val2
+                                           //   code 3 - 5: H-side source node (H_x, H_y, H_z), index into val2
                                            //   code 8 + c: a time monitor's sample of component c (0 - 5) of the middle step -> cap[index]
   const float* val;                        // source terms of step n
-  const float* val2;                       // source terms of step n+1, or nullptr: the caller applies them behind the launch
+  const float* val2;                       // source terms of step n+1 (nullptr: not available; then there are no H-side nodes)
+  int e2_in_sweep;                         // the E-side terms of step n+1 are added to E^{n+2} by the sweep (else: by the caller behind it)
   float* cap;                              // samples of the middle step (pair_record_kernel)
 };
 constexpr int kMaxCap = 1024;
@@ -35,6 +37,7 @@ void launch_inject_table(hipStream_t st, float* tab, long long stride, long long
 constexpr int kPairMons = 4;
 struct PairRecP {
   int n_mon;
+  int pre_done;                  // E^n and the first H half-sample of records at step n were taken in front of the sweep
   BoxP box[kPairMons];
   int nc[kPairMons];
   int comp[kPairMons][6];

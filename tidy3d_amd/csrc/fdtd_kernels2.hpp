@@ -20,8 +20,7 @@
 // seam_kernel from the intermediate values both tiles leave in a small scratch array.
 //
 // Scope (fdtd_capi.hip checks it): non-dispersive media (uniform, or packed medium words + (Ca, Cb) table), PEC walls (PMC
-// allowed on the min faces: symmetry planes), no CPML / absorber / ADE / TFSF / Bloch / mirror faces, E-side point sources only (<= kMaxInj nodes; those of step
-// n+1 are applied in S4), small time monitors (their samples of the middle step are copied out for pair_record_kernel), one
+// allowed on the min faces: symmetry planes), no CPML / absorber / ADE / TFSF / Bloch / mirror faces, point sources (<= kMaxInj nodes; the E-side ones of step n+1 are applied in S4, the H-side ones in S3), small time monitors (their samples of the middle step are copied out for pair_record_kernel), one
 // GPU.  Everything else takes single steps.
 #pragma once
 #include "fdtd_fused2.hpp"
@@ -50,11 +49,13 @@ __global__ __launch_bounds__(256) void pair_record_kernel(PairRecP r, GridP g, F
   const float mid = cap[r.cap_off[mi] + idx];
   float* on = r.out_n[mi];
   float* om = r.out_m[mi];
+  // (r.pre_done: E^n and the first H half-sample of a record at step n were taken in front of the sweep — H-side sources of
+  //  step n have changed H^{n-1/2} in the read set since)
   if (c < 3) {
-    if (on) on[idx] = 1.0f * fa[p];
+    if (on && !r.pre_done) on[idx] = 1.0f * fa[p];
     if (om) om[idx] = 1.0f * mid;
   } else {
-    if (on) { float o = on[idx]; o = o + 0.5f * fa[p]; o = o + 0.5f * mid; on[idx] = o; }
+    if (on) { float o = on[idx]; if (!r.pre_done) o = o + 0.5f * fa[p]; o = o + 0.5f * mid; on[idx] = o; }
     if (om) { float o = om[idx]; o = o + 0.5f * mid; o = o + 0.5f * fb[p]; om[idx] = o; }
   }
 }
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
                   else e1zn[e] += v;
                 }
               }
-            } else if (MON && own && k >= k0 && k < k1) {
+            } else if (MON && en.z >= 8 && own && k >= k0 && k < k1) {
               const int c = en.z - 8;
 #pragma unroll
               for (int e = 0; e < V; ++e) {
@@ -453,6 +454,31 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     float h2x[V], h2y[V], h2z[V];
     unspecified<V>(h2x); unspecified<V>(h2y); unspecified<V>(h2z);       // (rows j0-2, j0+R and the first iteration: nobody reads their H2)
     if (do_h2 && k > kA) {
+      // H-side point sources of step n+1 (codes 3 - 5 of the node table of plane k-1) act on H^{n+1/2} before step n+1 advances it
+      // — E^{n+1} above was formed from the value without them, as in two single steps; h1 is not read again in this iteration
+      if constexpr (MON) {
+        if (inj.val2) {
+          for (int qb = qm0; qb < qm1; qb += 64) {
+            int4 ev = {0, -1, 8, 0};
+            if (qb + tx < qm1) ev = inj.ent[qb + tx];
+            unsigned long long hit = __ballot(ev.y == j && ev.z >= 3 && ev.z < 8);
+            while (hit) {
+              const int l = __ffsll(hit) - 1;
+              hit &= hit - 1;
+              const int d = lane_value(ev.x, l) - i0o, code = lane_value(ev.z, l);
+              const float v = inj.val2[lane_value(ev.w, l)];
+#pragma unroll
+              for (int e = 0; e < V; ++e) {
+                if (d == e) {
+                  if (code == 3) h1x[e] += v;
+                  else if (code == 4) h1y[e] += v;
+                  else h1z[e] += v;
+                }
+              }
+            }
+          }
+        }
+      }
       float eyx = lane_next(e1y[0]);
       float ezx = lane_next(e1z[0]);
       if (txo == 63 || last_x) { eyx = 0.f; ezx = 0.f; }      // the wall, or a seam (repaired by seam_kernel)
@@ -536,7 +562,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
         s4([&](int, int) { return c1; });
       }
       // the node table of plane k-1: the E-side sources of step n+1 (when the launch carries them) act on E^{n+2}
-      if (inj.val2) {
+      if (inj.val2 && inj.e2_in_sweep) {
         for (int qb = qm0; qb < qm1; qb += 64) {
           int4 ev = {0, -1, 8, 0};
           if (qb + tx < qm1) ev = inj.ent[qb + tx];
