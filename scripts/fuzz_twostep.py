@@ -1,0 +1,90 @@
+"""Randomised self-check of the two-step sweep on the device: random grid shapes (1-3 x tiles, ragged rows / chunks), tile shapes,
+wall types, media, electric / magnetic dipoles and probes; two steps per sweep == single sweeps, bit for bit.
+    python scripts/fuzz_twostep.py [n_cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import tidy3d_amd.schema as td  # noqa: E402
+from tidy3d_amd import lib as L  # noqa: E402
+from tidy3d_amd.discretize import discretize  # noqa: E402
+from tidy3d_amd.engine import HipEngine  # noqa: E402
+
+DL = 0.05
+PULSE = td.GaussianPulse(freq0=3e14, fwidth=1.5e14)
+
+
+def case(rng):
+    nx = int(rng.choice([4, 8, 36, 120, 252, 256, 260, 300, 508, 512, 516, 600]))
+    ny, nz = int(rng.integers(2, 48)), int(rng.integers(2, 56))
+    N = (nx, ny, nz)
+    size = tuple(n * DL for n in N)
+    pmc = [bool(rng.integers(0, 2)) for _ in range(3)]
+    bspec = td.BoundarySpec(**{ax: td.Boundary(minus=td.PMCBoundary() if p else td.PECBoundary(), plus=td.PECBoundary())
+                               for ax, p in zip("xyz", pmc)})
+
+    def pos(margin=0.8):
+        return tuple(float(rng.uniform(-0.5 * s + min(margin * DL, 0.45 * s), 0.5 * s - min(margin * DL, 0.45 * s))) for s in size)
+    srcs = []
+    for _ in range(int(rng.integers(1, 5))):
+        pol = str(rng.choice(["Ex", "Ey", "Ez", "Hx", "Hy", "Hz"]))
+        c = list(pos())
+        if pol in ("Hy", "Hz") and nx > 256:          # not in the columns next to a seam (that case keeps single steps)
+            i = (c[0] + 0.5 * size[0]) / DL
+            if min(abs(i - 256), abs(i - 512)) < 3:
+                c[0] += 5 * DL if c[0] + 5 * DL < 0.5 * size[0] - DL else -5 * DL
+        srcs.append(td.PointDipole(center=tuple(c), source_time=PULSE, polarization=pol))
+    mons = []
+    for q in range(int(rng.integers(0, 4))):
+        fields = [str(f) for f in rng.choice(["Ex", "Ey", "Ez", "Hx", "Hy", "Hz"], size=int(rng.integers(1, 4)), replace=False)]
+        mons.append(td.FieldTimeMonitor(center=pos(2.5), size=(0, 0, 0), name=f"m{q}", interval=int(rng.integers(1, 4)), fields=fields,
+                                        colocate=False))
+    structures = []
+    if rng.integers(0, 2):
+        structures = [td.Structure(geometry=td.Box(center=pos(), size=tuple(float(rng.uniform(0.1, 0.6) * s) for s in size)),
+                                   medium=td.Medium(permittivity=float(rng.uniform(1.5, 6)), conductivity=float(rng.choice([0, 0.03])))),
+                      td.Structure(geometry=td.Sphere(center=pos(), radius=float(rng.uniform(0.05, 0.3) * min(size))),
+                                   medium=td.Medium(permittivity=2.5)),
+                      td.Structure(geometry=td.Box(center=pos(), size=(0.1, 0.1, 0.1)), medium=td.PEC)]
+    sim = td.Simulation(size=size, grid_spec=td.GridSpec.uniform(dl=DL), run_time=1e-12, sources=srcs, monitors=mons,
+                        structures=structures, boundary_spec=bspec, shutoff=0)
+    steps = int(rng.integers(9, 40))
+    disc = discretize(sim, n_steps=steps + 1)
+    disc.spec.decay_every = int(rng.choice([0, 0, 7, 16]))
+    w, zc = int(rng.integers(4, 17)), int(rng.integers(2, 40))
+    return N, disc, steps, w, zc, pmc, bool(structures)
+
+
+def run(disc, steps, twostep, split):
+    with HipEngine(disc.spec, variant=L.VARIANT_FUSED) as e:
+        e.set_option(L.OPT_TWOSTEP, twostep)
+        pairs = 0
+        for r in (split, steps - split):
+            if r > 0:
+                pairs += int(e.run(r).fused2_pairs)
+        return [e.get_field(c) for c in range(6)], e.results(), pairs
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    bad = 0
+    for q in range(n_cases):
+        N, disc, steps, w, zc, pmc, mat = case(rng)
+        split = int(rng.integers(0, steps))
+        ref_f, ref_m, p0 = run(disc, steps, 0, split)
+        got_f, got_m, p1 = run(disc, steps, w + 64 * zc, split)
+        ok = p0 == 0 and all(np.array_equal(a, b) for a, b in zip(ref_f, got_f)) and all(np.array_equal(ref_m[k], got_m[k]) for k in ref_m)
+        amp = max(float(np.abs(f).max()) for f in ref_f)
+        print(f"case {q}: N={disc.spec.shape} steps={steps} split={split} W={w} zc={zc} pmc={pmc} media={mat} monitors={len(ref_m)} "
+              f"pairs={p1} max|F|={amp:.3g} -> {'ok' if ok else 'MISMATCH'}", flush=True)
+        bad += not ok
+    print("fuzz:", n_cases - bad, "of", n_cases, "cases bit-identical")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
