@@ -243,7 +243,7 @@ enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_R
                                hipGraphs of two steps: -1 = default (off: on ROCm 7.2 replaying costs ~3 us per step MORE than the
                                launches it replaces, profiles/r3i), 0 = never, 1 = whenever possible */
        FDTD_OPT_TWOSTEP = 16, /* two time steps per sweep (in-kernel temporal blocking; non-dispersive media inside PEC walls (PMC allowed on
-                                 the min faces), point sources, small time monitors, one GPU, no decay check on the middle step — everything else
+                                 the min faces) or absorber layers, point sources, small time monitors, one GPU, no decay check on the middle step — everything else
                                  takes single steps): -1 = default (on, tile shape by grid size), 0 = off, else waves per workgroup
                                  (4 ... 16; W - 3 rows of a tile are written) + 64 * planes per chunk (0 = by grid size) */
        FDTD_OPT_LDS_PAD = 10 /* measuring aid: extra dynamic LDS per workgroup of the sweep in bytes (lowers its occupancy) */ };

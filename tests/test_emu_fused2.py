@@ -163,6 +163,50 @@ def test_magnetic_dipole_left_of_a_seam_takes_single_steps(emu_lib):
         assert np.array_equal(got_f[c], ref_f[c]), c
 
 
+ABS = td.BoundarySpec(x=td.Boundary.absorber(num_layers=5, parameters=td.AbsorberParams(sigma_max=1.5)),
+                      y=td.Boundary(minus=td.PECBoundary(), plus=td.Absorber(num_layers=3)),
+                      z=td.Boundary.absorber(num_layers=3))
+ABS_PMC = td.BoundarySpec(x=td.Boundary(minus=td.PMCBoundary(), plus=td.Absorber(num_layers=6)),
+                          y=td.Boundary.absorber(num_layers=2), z=td.Boundary(minus=td.PMCBoundary(), plus=td.Absorber(num_layers=4)))
+
+
+@pytest.mark.parametrize("name,w,zc,bspec", [("one_tile", 16, 32, ABS), ("ragged_rows", 5, 3, ABS), ("two_x_tiles", 8, 5, ABS),
+                                             ("two_x_tiles", 6, 4, ABS_PMC), ("three_x_tiles_tall", 7, 6, ABS)])
+def test_two_steps_per_sweep_with_absorber_layers(name, w, zc, bspec, emu_lib):
+    """Absorber boundaries (open problems): damp_kernel's factors applied in registers to H^{n-1/2}, E^{n+1} (behind its sources),
+    H^{n+1/2} and E^{n+2} — the sweep, its x-halo column, its chunk prologue and the seam kernel — with media, probes inside the
+    layers, and (wide grids) source nodes next to a seam, whose terms of step n+1 and the damping behind them are left to the
+    caller's launches."""
+    N = SHAPES[name]
+    size = tuple(n * DL for n in N)
+    sim = _sim(N, monitors=False, structures=MEDIA_WIDE if N[0] >= 128 else MEDIA, bspec=bspec)
+    mons = [td.FieldTimeMonitor(center=(0.5 * size[0] - 2.2 * DL, 0.5 * size[1] - 1.6 * DL, 0.5 * size[2] - 1.4 * DL), size=(0, 0, 0),
+                                name="in_layers", interval=1, colocate=False),
+            td.FieldTimeMonitor(center=(0.0, 0.0, 0.0), size=(0, 0, 0), name="mid", interval=2, fields=["Ez", "Hx"], colocate=False)]
+    disc = discretize(sim.updated_copy(monitors=mons), n_steps=26)
+    disc.spec.decay_every = 0
+    assert any(a is not None for a in disc.spec.absorber) if hasattr(disc.spec, "absorber") else True
+    ref_f, ref_m, p0 = _run(disc.spec, emu_lib, 0)
+    got_f, got_m, p1 = _run(disc.spec, emu_lib, w + 64 * zc)
+    assert p0 == 0 and p1 == 5 + 7, p1
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), c
+    for k in ref_m:
+        assert np.abs(ref_m[k]).max() > 0 and np.array_equal(got_m[k], ref_m[k]), k
+
+
+def test_absorber_layers_with_a_magnetic_dipole_take_single_steps(emu_lib):
+    N = SHAPES["one_tile"]
+    sim = _sim(N, monitors=False, bspec=ABS, extra=[td.PointDipole(center=(0.1, 0, 0), source_time=PULSE, polarization="Hy")])
+    disc = discretize(sim, n_steps=12)
+    disc.spec.decay_every = 0
+    ref_f, _, p0 = _run(disc.spec, emu_lib, 0, runs=(12,))
+    got_f, _, p1 = _run(disc.spec, emu_lib, 8 + 64 * 4, runs=(12,))
+    assert p0 == 0 and p1 == 0
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), c
+
+
 @pytest.mark.parametrize("name", ["ragged_rows", "two_x_tiles"])
 def test_pairs_give_way_to_monitor_records_and_decay_checks(name, emu_lib):
     N = SHAPES[name]

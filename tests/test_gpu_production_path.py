@@ -359,6 +359,35 @@ def test_two_steps_per_sweep_with_materials_bit_identical_bench_v1(hip_lib, w, z
         assert np.array_equal(got[c], ref[c]), c
 
 
+@pytest.mark.parametrize("workload,n", [("va", 320), ("v1a", 256)])
+def test_two_steps_per_sweep_with_absorber_layers_bit_identical(hip_lib, workload, n):
+    """An open problem on the two-step sweep: Absorber boundaries (40 layers on all faces; vacuum / a dielectric sphere), damped in
+    registers == single sweeps with the damping launches around them, bit for bit; prints both speeds."""
+    import time
+    from bench import build_spec
+    steps = 41
+    spec = build_spec(n, steps + 4, workload)
+    init = _bench_init(n)
+
+    def run(twostep):
+        with HipEngine(spec, lib=hip_lib, axis_shift=0) as e:
+            e.set_option(L.OPT_TWOSTEP, twostep)
+            e.set_option(L.OPT_PLACEMENT_TRIES, 0)
+            for c in range(6):
+                e.set_field(c, init[c])
+            e.run(1)
+            t0 = time.perf_counter()
+            st = e.run(steps - 1)
+            dt = time.perf_counter() - t0
+            return [e.get_field(c) for c in range(6)], int(st.fused2_pairs), dt / (steps - 1) * 1e3
+    ref, p0, ms0 = run(0)
+    got, p1, ms1 = run(-1)
+    print(f"[{workload} {n}^3] single sweeps {ms0:.4f} ms per step, two steps per sweep {ms1:.4f} ms ({p1} pairs)")
+    assert p0 == 0 and p1 == (steps - 1) // 2
+    for c in range(6):
+        assert np.array_equal(got[c], ref[c]), c
+
+
 def test_two_steps_per_sweep_config2_probe_records_bit_identical(hip_lib):
     """BASELINE config[1] (200^3 PEC cavity, dipole, a point FieldTimeMonitor recording EVERY step): the two-step sweep copies the
     probe's samples of the middle step out on the way — same records, same fields as single steps; prints both speeds."""

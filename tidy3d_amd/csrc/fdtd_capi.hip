@@ -617,8 +617,8 @@ int launch_fused(FdtdSolver* h, hipStream_t st, int pml_inside) {
 // ---- two time steps per sweep (fdtd_kernels2.hpp) --------------------------------------------------------------------
 // What fused2_step_kernel covers: the curl stencil with non-dispersive media (uniform, or packed medium words + (Ca, Cb)
 // table: dielectrics, conductors, PEC bodies) inside six PEC walls on one GPU, driven by point sources (electric and magnetic), recorded by
-// small time monitors; the min faces may be PMC walls.  Anything else (CPML, absorbers, ADE, TFSF, periodic / Bloch faces,
-// PMC on max faces, z-slabs) takes single steps.
+// small time monitors; the min faces may be PMC walls; absorber layers (applied in registers).  Anything else (CPML, ADE,
+// TFSF, periodic / Bloch faces, PMC on max faces, z-slabs) takes single steps.
 // Tile shape of the two-step sweep: waves per workgroup W (W - 3 rows of a tile are written) and planes per chunk zc (a
 // chunk runs zc + 2 plane iterations).  Asked for through FDTD_OPT_TWOSTEP, or (default) the cheapest of W = 8 / 16 x
 // zc = 8 ... 64 under a two-parameter model fitted to profiles/r3r_two_step_small.jsonl, r3r_two_step_shapes512.jsonl and
@@ -642,7 +642,9 @@ bool fused2_shape(const FdtdSolver* h, int* W, int* zc) {
     const int R = w - 3, nby = (g.ny + R - 1) / R;
     // (with materials the instantiation sits at 128 VGPRs with 4 spills and looks coefficients up: 512^3 V1 0.800 ms per step
     //  with 16 waves, 0.882 with 8 against 1.136 for single sweeps, profiles/r3zx)
-    const double t8 = h->mat4 ? 7.6 : 6.0, t16 = h->mat4 ? 9.4 : 8.2;
+    // (absorber layers damped in registers, 512^3 with 40 layers: 0.959 / 1.014 ms per step with 16 / 8 waves, 1.104 / 1.185 with
+    //  materials too, profiles/r3zs)
+    const double t8 = 6.0 + (h->mat4 ? 1.6 : 0.0) + (h->has_damp ? 2.7 : 0.0), t16 = 8.2 + (h->mat4 ? 1.2 : 0.0) + (h->has_damp ? 3.0 : 0.0) + (h->mat4 && h->has_damp ? 0.5 : 0.0);
     const double slots = w <= 8 ? 512.0 : 256.0, t = w <= 8 ? t8 : (w >= 16 ? t16 : t8 + (t16 - t8) * (w - 8) / 8.0);
     for (int c : {64, 48, 32, 24, 16, 12, 8}) {
       if (c > std::max(8, g.nz)) continue;
@@ -662,7 +664,7 @@ bool fused2_shape(const FdtdSolver* h, int* W, int* zc) {
 bool fused2_eligible(const FdtdSolver* h) {
   if (h->twostep_w == 0) return false;
   { int W, zc; if (!fused2_shape(h, &W, &zc)) return false; }
-  if (h->comm || any_pml(h) || h->has_damp || !h->ade.empty() || !h->tfsf.empty()) return false;
+  if (h->comm || any_pml(h) || !h->ade.empty() || !h->tfsf.empty()) return false;
   // PEC walls; the min faces may be PMC (the symmetry planes of a half / quarter / eighth domain)
   for (int f = 0; f < 6; ++f)
     if (h->cfg.bc[f] != FDTD_BC_PEC && !((f & 1) == 0 && h->cfg.bc[f] == FDTD_BC_PMC)) return false;
@@ -671,6 +673,8 @@ bool fused2_eligible(const FdtdSolver* h) {
   long long nodes = 0;
   for (const PointSrc& s : h->psrc) {
     nodes += s.n_e + s.n_h;
+    // absorber layers are applied inside the sweep, H-side sources of step n in front of it: damping would come after them
+    if (h->has_damp && s.n_h) return false;
     // an H_y / H_z source node in the column left of a seam between x tiles: the seam kernel rebuilds that value without it
     for (long long t = 0; t < s.n_h; ++t) {
       const int i = (int)(s.host_cell_h[(size_t)t] % h->g.nx), c = s.host_comp_h[(size_t)t];
@@ -806,7 +810,7 @@ const F2Table* fused2_table(FdtdSolver* h, const F2Plan& plan) {
 // applied inside the kernel; so are those of step n + 1 (*sources2_done) when their terms come from the table of all steps
 // and no source node lies next to a seam — else the caller applies them afterwards.  The middle step is copied out for the
 // monitors of `tb` (fused2_plan); pair_record (called by the caller behind the launch) writes their records.
-int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb, bool* sources2_done) {
+int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb, bool* sources2_done, bool* damp2_done = nullptr) {
   const GridP& g = h->g;
   if (ensure_second_set(h)) return -1;
   int W = 16, zc = 32;
@@ -845,14 +849,24 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
     inj.n = (alive || !tb->mons.empty()) ? 1 : 0;
     inj.start = tb->start; inj.ent = tb->ent; inj.cap = h->cap_val;
   }
+  // absorber layers: H^{n-1/2}, E^{n+1}, H^{n+1/2} are damped in registers; E^{n+2} too unless E-side sources of step n+1 still
+  // have to be applied behind the launch (the damping follows the sources: then the caller damps, launch_damp)
+  DampT dmp{};
+  if (h->has_damp) {
+    for (int a = 0; a < 3; ++a) { dmp.fb[a] = h->damp_fb[a]; dmp.fc[a] = h->damp_fc[a]; }
+    bool post_sources = false;
+    for (const PointSrc& s : h->psrc) post_sources = post_sources || (s.n_e && n + 1 < s.n_steps);
+    dmp.e2 = (!post_sources || inj.e2_in_sweep) ? 1 : 0;
+    if (damp2_done) *damp2_done = dmp.e2 != 0;
+  }
   const int total = nbx * nby * nbz;
   const int remap = h->xcd_remap < 0 ? kTileRun : h->xcd_remap;
   StepP sp = step_params(h);
   time_begin(h, 2, st);
   const MatP mp = mat_params(h);
-  launch_fused2_step(st, W, (h->mem_hints ? 1 : 0) | (h->mat4 ? 2 : 0) | ((tb->mons.empty() && h->src_h_nodes == 0) ? 0 : 4), remap ? ((total + 7) / 8) * 8 : total, g, h->f,
-                     h->f2, sp, mp, zc, nbx, nby, nbz, remap, inj, h->seam_buf);
-  if (nbx > 1) launch_seams(st, g, h->f2, sp, mp, h->seam_buf, nbx - 1);
+  launch_fused2_step(st, W, (h->mem_hints ? 1 : 0) | (h->mat4 ? 2 : 0) | ((tb->mons.empty() && h->src_h_nodes == 0) ? 0 : 4) | (h->has_damp ? 8 : 0),
+                     remap ? ((total + 7) / 8) * 8 : total, g, h->f, h->f2, sp, mp, zc, nbx, nby, nbz, remap, inj, h->seam_buf, dmp);
+  if (nbx > 1) launch_seams(st, g, h->f2, sp, mp, h->seam_buf, nbx - 1, dmp);
   time_end(h, st);
   swap_sets(h);
   return 0;
@@ -2512,11 +2526,12 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     } else if (pair) {
       const F2Table* tb = fused2_table(h, f2_plan);
       if (!tb) return -1;
-      bool sources2_done = false;
+      bool sources2_done = false, damp2_done = true;
       launch_sources(h, false, n, 0, nz, st);              // H-side sources of step n act on H^{n-1/2}, as before a single step
-      if (launch_fused2(h, n, st, tb, &sources2_done)) return -1;
+      if (launch_fused2(h, n, st, tb, &sources2_done, &damp2_done)) return -1;
       pair_record(h, tb, n, st);                           // (H^{n+3/2} is not touched by the E-side sources that follow)
       if (!sources2_done) launch_sources(h, true, n + 1, 0, nz, st);
+      if (h->has_damp && !damp2_done) launch_damp(h, true, 0, nz, st);
       fill_ghost_fused(h, st);
       h->fused2_pairs++;
       h->step = n + 2;

@@ -21,18 +21,21 @@ void launch_inject_values(hipStream_t st, float* val, const float* w_re, const f
 
 void launch_fused2_step(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
                         const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,
-                        int xcd_remap, const InjP& inj, float* seam) {
+                        int xcd_remap, const InjP& inj, float* seam, const DampT& dmp) {
   const dim3 grid(grid_blocks, 1, 1), block(64, waves, 1);
-  const size_t shmem = (size_t)8 * waves * 64 * sizeof(float4);
+  const size_t shmem = ((size_t)8 * waves * 64 + ((opt & 8) ? 2 * 64 : 0)) * sizeof(float4);
 #define FDTD_F2_O(LBV, OV)                                                                                             \
   hipLaunchKernelGGL((fused2_step_kernel<LBV, OV>), grid, block, shmem, st, g, a, b, s, m, zchunk, nbx, nby, nbz,     \
-                     xcd_remap, inj, seam)
+                     xcd_remap, inj, seam, dmp)
 #define FDTD_F2(LBV)                                                                                                   \
   do {                                                                                                                 \
-    switch (opt & 7) {                                                                                                 \
+    switch (opt & 15) {                                                                                                \
       case 0: FDTD_F2_O(LBV, 0); break; case 1: FDTD_F2_O(LBV, 1); break; case 2: FDTD_F2_O(LBV, 2); break;            \
       case 3: FDTD_F2_O(LBV, 3); break; case 4: FDTD_F2_O(LBV, 4); break; case 5: FDTD_F2_O(LBV, 5); break;            \
-      case 6: FDTD_F2_O(LBV, 6); break; default: FDTD_F2_O(LBV, 7); break;                                             \
+      case 6: FDTD_F2_O(LBV, 6); break; case 7: FDTD_F2_O(LBV, 7); break; case 8: FDTD_F2_O(LBV, 8); break;            \
+      case 9: FDTD_F2_O(LBV, 9); break; case 10: FDTD_F2_O(LBV, 10); break; case 11: FDTD_F2_O(LBV, 11); break;        \
+      case 12: FDTD_F2_O(LBV, 12); break; case 13: FDTD_F2_O(LBV, 13); break; case 14: FDTD_F2_O(LBV, 14); break;      \
+      default: FDTD_F2_O(LBV, 15); break;                                                                              \
     }                                                                                                                  \
   } while (0)
   if (waves <= 8) FDTD_F2(512);
@@ -55,10 +58,10 @@ void launch_pair_record(hipStream_t st, const PairRecP& r, long long max_cells, 
 }
 
 void launch_seams(hipStream_t st, const GridP& g, const FieldP& b, const StepP& s, const MatP& m, const float* seam,
-                  int n_seams) {
+                  int n_seams, const DampT& dmp) {
   const long long nt = (long long)n_seams * g.ny * g.nz;
   const unsigned blocks = (unsigned)((nt + 255) / 256);
-  hipLaunchKernelGGL(seam_kernel, dim3(blocks), dim3(256), 0, st, g, b, s, m, seam, n_seams);
+  hipLaunchKernelGGL(seam_kernel, dim3(blocks), dim3(256), 0, st, g, b, s, m, seam, n_seams, dmp);
 }
 
 }  // namespace fdtd

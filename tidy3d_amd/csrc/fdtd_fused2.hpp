@@ -20,6 +20,13 @@ struct InjP {
   int e2_in_sweep;                         // the E-side terms of step n+1 are added to E^{n+2} by the sweep (else: by the caller behind it)
   float* cap;                              // samples of the middle step (pair_record_kernel)
 };
+// absorber layers (damp_kernel's per-axis factor tables: fb at cell boundaries, fc at cell centres; 1 outside the layers);
+// fb[0] == nullptr: none
+struct DampT {
+  const float* fb[3];
+  const float* fc[3];
+  int e2;                                  // E^{n+2} is damped inside the sweep (else: by the caller, behind the sources it applies)
+};
 constexpr int kMaxCap = 1024;
 constexpr int kSeamArrays = 13;  // of step one: H1_y, H1_z, E1_x, E1_y, E1_z [c-1], E1_y, E1_z [c]; of step two: H2_x [c-1], H2_y, H2_z [c-2], H2_x, H2_y, H2_z [c]
                                  // (c = first column of the right tile)
@@ -28,10 +35,10 @@ constexpr int kSeamArrays = 13;  // of step one: H1_y, H1_z, E1_x, E1_y, E1_z [c
 void launch_inject_values(hipStream_t st, float* val, const float* w_re, const float* w_im, const float2* wave,
                           long long step, int n);
 // waves = rows per workgroup (W - 3 of them written); opt: bit 0 non-temporal stores, bit 1 materials (m.m4 set), bit 2 monitor
-// samples in the table
+// samples in the table, bit 3 absorber layers (dmp.fb[0] set)
 void launch_fused2_step(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
                         const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,
-                        int xcd_remap, const InjP& inj, float* seam);
+                        int xcd_remap, const InjP& inj, float* seam, const DampT& dmp);
 void launch_inject_table(hipStream_t st, float* tab, long long stride, long long off, const float* w_re, const float* w_im,
                          const float2* wave, long long n_steps, int n);
 constexpr int kPairMons = 4;
@@ -48,6 +55,6 @@ struct PairRecP {
 void launch_pair_record(hipStream_t st, const PairRecP& r, long long max_cells, const GridP& g, const FieldP& a, const FieldP& b,
                         const float* cap);
 void launch_seams(hipStream_t st, const GridP& g, const FieldP& b, const StepP& s, const MatP& m, const float* seam,
-                  int n_seams);
+                  int n_seams, const DampT& dmp);
 
 }  // namespace fdtd

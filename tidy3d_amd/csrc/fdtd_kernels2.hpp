@@ -84,6 +84,7 @@ __device__ __forceinline__ long long seam_at(const GridP& g, int seam, int arr, 
 }
 
 // OPT: bit 0 = non-temporal stores, bit 1 = materials (packed medium words + (Ca, Cb) table, as fused_step_kernel<MAT>),
+// bit 3 = absorber layers (the damping of damp_kernel / damp4_kernel applied in registers),
 // bit 2 = the node table holds monitor samples (8-wave workgroups run two per CU: LB = 512 asks for 4 waves per SIMD, i.e. <= 128 VGPRs)
 // x neighbours across the wave: lane i takes the value of lane i+1 / i-1 (the last / first lane keeps its own, as __shfl_down /
 // __shfl_up do).  One DPP move (wave_shl:1 / wave_shr:1, GFX9) instead of a ds_bpermute through the LDS crossbar with its
@@ -128,9 +129,10 @@ __device__ __forceinline__ int lane_value(int v, int l) {
 template <int LB, int OPT>
 __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
                                                          int zchunk, int nbx, int nby, int nbz, int xcd_remap,
-                                                         InjP inj, float* __restrict__ seam) {
+                                                         InjP inj, float* __restrict__ seam, DampT dmp) {
   constexpr int V = 4;
   constexpr bool NT = (OPT & 1) != 0, MAT = (OPT & 2) != 0, MON = (OPT & 4) != 0;     // MON: the node table may hold monitor samples
+  constexpr bool DAMP = (OPT & 8) != 0;   // absorber layers: both fields of both steps are damped in registers (damp_kernel's factors)
   // (Issuing the loads of plane k+1 behind the second barrier of plane k — the one way to overlap them with compute inside a wave —
   //  was measured: + 60 registers, slower at every workgroup size, profiles/r3q; taken out.)
   const int total = nbx * nby * nbz;
@@ -165,6 +167,16 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
   if constexpr (MAT) {
     for (int q = me; q < m.n_media; q += slot) lut_s[q] = m.lut[q];
   }
+  // absorber layers: the x factors of the tile's 256 cells (fb: cell boundaries, fc: cell centres; 1 outside the layers)
+  [[maybe_unused]] float4* xdm = xch + 8 * slot;             // [2][64]
+  if constexpr (DAMP) {
+    if (ty == 0) {
+      const int ii = (tile_x * 64 + tx) * V;
+      float4 b4 = {1.f, 1.f, 1.f, 1.f}, c4 = {1.f, 1.f, 1.f, 1.f};
+      if (ii < g.nx) { b4 = *reinterpret_cast<const float4*>(dmp.fb[0] + ii); c4 = *reinterpret_cast<const float4*>(dmp.fc[0] + ii); }
+      xdm[tx] = b4; xdm[64 + tx] = c4;
+    }
+  }
   __syncthreads();
   const float ca = m.ca1, cb = m.cb1;
   const int k0 = tile_z * zchunk;
@@ -197,6 +209,10 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
   const bool pmc_x0 = g.bcx0 == BC_PMC, pmc_y0 = g.bcy0 == BC_PMC, pmc_z0 = !g.pec_z0;
   const bool wall_y = (j == 0) && !pmc_y0;
 
+  // damping factors: w(H_x) = (bx cy) cz, w(H_y) = (cx by) cz, w(H_z) = (cx cy) bz;  w(E_x) = (cx by) bz, w(E_y) = (bx cy) bz,
+  // w(E_z) = (bx by) cz — the products of damp_kernel, formed in its order; a field outside every layer is multiplied by 1
+  [[maybe_unused]] float byv = 1.f, cyv = 1.f, bxm = 1.f, cxm = 1.f, bz_m = 1.f, cz_m = 1.f;
+  if constexpr (DAMP) { byv = dmp.fb[1][j]; cyv = dmp.fc[1][j]; }
   float ipx[V], idx[V];
   zero<V>(ipx); zero<V>(idx);
   float ipx_m = 0.f;
@@ -204,6 +220,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     ldv<V>(ipx, at(uni(s.ipx), ub));
     ldv<V>(idx, at(uni(s.idx), ub));
     ipx_m = s.ipx[im];
+    if constexpr (DAMP) { bxm = dmp.fb[0][im]; cxm = dmp.fc[0][im]; }
   }
   const float ipy = s.ipy[j], idy = s.idy[j];
 
@@ -237,6 +254,13 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     const float ipz = s.ipz[kA - 1];
     ldf<V, true>(ho, uni(a.hx + pb), ubc);
     ldf<V, true>(hoy, uni(a.hy + pb), ubc);
+    if constexpr (DAMP) {
+      const float czp = dmp.fc[2][kA - 1];
+      const float4 b4 = xdm[tx], c4 = xdm[64 + tx];
+      const float bx[V] = {b4.x, b4.y, b4.z, b4.w}, cx[V] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+      for (int e = 0; e < V; ++e) { ho[e] *= bx[e] * cyv * czp; hoy[e] *= cx[e] * byv * czp; }
+    }
 #pragma unroll
     for (int e = 0; e < V; ++e) h1x[e] = upd_h(ho[e], ch, ezj[e] - ezm[e], ipy, eyk[e] - eym[e], ipz);
 #pragma unroll
@@ -255,7 +279,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     float exn_m, ez_mm, ey_mm, ex_jm, hy_o, hz_o;        // column i0 - 1 (first lane of a tile with a left neighbour)
   };
   auto issue = [&](int k, Ld& L) __attribute__((always_inline)) {
-    const int txo = MAT ? tx : opaque_lane(tx);       // (the materials instantiation has no VGPR to spare for the re-derivation)
+    const int txo = (MAT || DAMP) ? tx : opaque_lane(tx);       // (the materials / absorber instantiations have no VGPR to spare for the re-derivation)
     const int i0o = (tile_x * 64 + txo) * V;
     const bool act = i0o < g.nx, last_x = i0o + V >= g.nx, first_x = i0o == 0;
     const bool xh = act && txo == 0 && !first_x;
@@ -288,7 +312,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
   };
   Ld LA, LB2;
   auto body = [&](int k, Ld& L) __attribute__((always_inline)) {
-    const int txo = MAT ? tx : opaque_lane(tx);       // (the materials instantiation has no VGPR to spare for the re-derivation)
+    const int txo = (MAT || DAMP) ? tx : opaque_lane(tx);       // (the materials / absorber instantiations have no VGPR to spare for the re-derivation)
     const int i0o = (tile_x * 64 + txo) * V;
     const bool act = i0o < g.nx, last_x = i0o + V >= g.nx, first_x = i0o == 0;
     const bool xh = act && txo == 0 && !first_x;
@@ -297,6 +321,8 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     //  read the ghost plane, its other results are never used)
     const long long pb = (long long)k * g.sxy + rowb;
     const float ipz = s.ipz[k], idz = s.idz[k];          // (the step arrays carry one ghost entry at each end)
+    [[maybe_unused]] float bzk = 1.f, czk = 1.f;
+    if constexpr (DAMP) { bzk = dmp.fb[2][min(k, g.nz - 1)]; czk = dmp.fc[2][min(k, g.nz - 1)]; }
     int q0 = 0, q1 = 0;
     if (inj.n > 0) { q0 = inj.start[k]; q1 = inj.start[k + 1]; }     // ([nz + 2] entries: plane nz holds none)
     float hy_m = 0.f, hz_m = 0.f;
@@ -315,6 +341,22 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
       if (act && (txo == 63 || last_x)) {
         if (!last_x) { eyx = L.eyx_g; ezx = L.ezx_g; }
         else { eyx = 0.f; ezx = 0.f; }
+      }
+      if constexpr (DAMP) {                 // H^{n-1/2} is damped before step n advances it
+        {
+          const float4 b4 = xdm[tx];
+          const float bx[V] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+          for (int e = 0; e < V; ++e) hxn[e] *= bx[e] * cyv * czk;
+        }
+        {
+          const float4 c4 = xdm[64 + tx];
+          const float cx[V] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+          for (int e = 0; e < V; ++e) { hyn[e] *= cx[e] * byv * czk; hzn[e] *= cx[e] * cyv * bzk; }
+        }
+        L.hy_o *= cxm * byv * czk;
+        L.hz_o *= cxm * cyv * bzk;
       }
       // ---- S1: H1[k] ----
 #pragma unroll
@@ -427,10 +469,31 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
               const int c = en.z - 8;
 #pragma unroll
               for (int e = 0; e < V; ++e) {
-                if (d == e)
-                  inj.cap[en.w] = c == 0 ? e1xn[e] : (c == 1 ? e1yn[e] : (c == 2 ? e1zn[e] : (c == 3 ? hxn[e] : (c == 4 ? hyn[e] : hzn[e]))));
+                if (d == e) {
+                  float mid = c == 0 ? e1xn[e] : (c == 1 ? e1yn[e] : (c == 2 ? e1zn[e] : (c == 3 ? hxn[e] : (c == 4 ? hyn[e] : hzn[e]))));
+                  if constexpr (DAMP) {       // E^{n+1} is recorded behind its damping (which follows the sources); H^{n+1/2} in front of its own
+                    const float4 b4 = xdm[tx], c4 = xdm[64 + tx];
+                    const float bx[V] = {b4.x, b4.y, b4.z, b4.w}, cx[V] = {c4.x, c4.y, c4.z, c4.w};
+                    if (c == 0) mid *= cx[e] * byv * bzk; else if (c == 1) mid *= bx[e] * cyv * bzk; else if (c == 2) mid *= bx[e] * byv * czk;
+                  }
+                  inj.cap[en.w] = mid;
+                }
               }
             }
+          }
+        }
+        if constexpr (DAMP) {                 // E^{n+1}: behind the update and the sources of step n
+          {
+            const float4 c4 = xdm[64 + tx];
+            const float cx[V] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+            for (int e = 0; e < V; ++e) e1xn[e] *= cx[e] * byv * bzk;
+          }
+          {
+            const float4 b4 = xdm[tx];
+            const float bx[V] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int e = 0; e < V; ++e) { e1yn[e] *= bx[e] * cyv * bzk; e1zn[e] *= bx[e] * byv * czk; }
           }
         }
         // what the neighbouring x tile needs of this step: repaired on the seam by seam_kernel
@@ -454,6 +517,20 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     float h2x[V], h2y[V], h2z[V];
     unspecified<V>(h2x); unspecified<V>(h2y); unspecified<V>(h2z);       // (rows j0-2, j0+R and the first iteration: nobody reads their H2)
     if (do_h2 && k > kA) {
+      if constexpr (DAMP) {                   // H^{n+1/2} of plane k-1 is damped before step n+1 advances it (h1 is not read again here)
+        {
+          const float4 b4 = xdm[tx];
+          const float bx[V] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+          for (int e = 0; e < V; ++e) h1x[e] *= bx[e] * cyv * cz_m;
+        }
+        {
+          const float4 c4 = xdm[64 + tx];
+          const float cx[V] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+          for (int e = 0; e < V; ++e) { h1y[e] *= cx[e] * byv * cz_m; h1z[e] *= cx[e] * cyv * bz_m; }
+        }
+      }
       // H-side point sources of step n+1 (codes 3 - 5 of the node table of plane k-1) act on H^{n+1/2} before step n+1 advances it
       // — E^{n+1} above was formed from the value without them, as in two single steps; h1 is not read again in this iteration
       if constexpr (MON) {
@@ -583,6 +660,22 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
           }
         }
       }
+      if constexpr (DAMP) {
+        if (dmp.e2) {                         // E^{n+2}: behind the update and the sources of step n+1 (else the caller damps it behind those)
+          {
+            const float4 c4 = xdm[64 + tx];
+            const float cx[V] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+            for (int e = 0; e < V; ++e) ex[e] *= cx[e] * byv * bz_m;
+          }
+          {
+            const float4 b4 = xdm[tx];
+            const float bx[V] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int e = 0; e < V; ++e) { ey[e] *= bx[e] * cyv * bz_m; ez[e] *= bx[e] * byv * cz_m; }
+          }
+        }
+      }
       if (act) {
         // H2 next to the seams, for seam_kernel (so that it reads nothing but the scratch array, row-contiguous)
         float* sq = seam + seam_row + (long long)(k - 1) * g.ny;
@@ -615,6 +708,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     exk_m = L.exn_m;
     ipz_m = ipz; idz_m = idz;
     qm0 = q0; qm1 = q1;
+    if constexpr (DAMP) { bz_m = bzk; cz_m = czk; }
     if constexpr (MAT) rw_m = rw;
     cur ^= 1;
   };
@@ -631,7 +725,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
 // tiles left in the scratch array [seam][13][nz + 2][ny] (read row-contiguously; plane nz and what lies beyond the walls
 // stay zero).  H2_{y,z}[c-1] of the row below and of the plane below are recomputed rather than exchanged: one launch.
 __global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, MatP m,
-                                                   const float* __restrict__ seam, int n_seams) {
+                                                   const float* __restrict__ seam, int n_seams, DampT dmp) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long per = (long long)g.ny * g.nz;
   if (t >= per * n_seams) return;
@@ -645,8 +739,14 @@ __global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, M
   auto h2 = [&](int jj, int kk, float& hy, float& hz) {
     const float e1x = A(2, jj, kk), e1y = A(3, jj, kk), e1z = A(4, jj, kk);
     const float e1x_jp = (jj + 1 < g.ny) ? A(2, jj + 1, kk) : 0.f;
-    hy = upd_h(A(0, jj, kk), ch, A(2, jj, kk + 1) - e1x, s.ipz[kk], A(6, jj, kk) - e1z, ipx);
-    hz = upd_h(A(1, jj, kk), ch, A(5, jj, kk) - e1y, ipx, e1x_jp - e1x, s.ipy[jj]);
+    float h1y = A(0, jj, kk), h1z = A(1, jj, kk);
+    if (dmp.fb[0]) {                        // absorber layers: H^{n+1/2} is damped before step n+1 advances it (column c-1: x centre)
+      const float cxv = dmp.fc[0][c - 1];
+      h1y *= cxv * dmp.fb[1][jj] * dmp.fc[2][kk];
+      h1z *= cxv * dmp.fc[1][jj] * dmp.fb[2][kk];
+    }
+    hy = upd_h(h1y, ch, A(2, jj, kk + 1) - e1x, s.ipz[kk], A(6, jj, kk) - e1z, ipx);
+    hz = upd_h(h1z, ch, A(5, jj, kk) - e1y, ipx, e1x_jp - e1x, s.ipy[jj]);
   };
   float hy_m, hz_m;
   h2(j, k, hy_m, hz_m);
@@ -680,6 +780,12 @@ __global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, M
     const float2 qm = coef(p - 1, 2), qc = coef(p, 2);
     ez_m = upd_e(A(4, j, k), qm.x, qm.y, hy_m - hy_mm, idx_m, hx_m - hxm_j, idy);
     ez_c = upd_e(A(6, j, k), qc.x, qc.y, hy_c - hy_m, idx_c, hx_c - hxc_j, idy);
+  }
+  if (dmp.fb[0] && dmp.e2) {                 // E^{n+2} damped as in the sweep
+    const float bxm = dmp.fb[0][c - 1], cxm = dmp.fc[0][c - 1], bxc = dmp.fb[0][c];
+    const float byv = dmp.fb[1][j], cyv = dmp.fc[1][j], bzv = dmp.fb[2][k], czv = dmp.fc[2][k];
+    ex_m *= cxm * byv * bzv; ey_m *= bxm * cyv * bzv; ez_m *= bxm * byv * czv;
+    ey_c *= bxc * cyv * bzv; ez_c *= bxc * byv * czv;
   }
   b.ex[p - 1] = ex_m; b.ey[p - 1] = ey_m; b.ez[p - 1] = ez_m;
   b.ey[p] = ey_c; b.ez[p] = ez_c;
