@@ -1,5 +1,5 @@
 """Randomised self-check of the two-step sweep on the device: random grid shapes (1-3 x tiles, ragged rows / chunks), tile shapes,
-wall types, media, electric / magnetic dipoles and probes; two steps per sweep == single sweeps, bit for bit.
+wall types (PEC, PMC, absorber layers), media, electric / magnetic dipoles and probes; two steps per sweep == single sweeps, bit for bit.
     python scripts/fuzz_twostep.py [n_cases] [seed]"""
 import os
 import sys
@@ -23,14 +23,20 @@ def case(rng):
     N = (nx, ny, nz)
     size = tuple(n * DL for n in N)
     pmc = [bool(rng.integers(0, 2)) for _ in range(3)]
-    bspec = td.BoundarySpec(**{ax: td.Boundary(minus=td.PMCBoundary() if p else td.PECBoundary(), plus=td.PECBoundary())
-                               for ax, p in zip("xyz", pmc)})
+    absorb = bool(rng.integers(0, 3) == 0)          # a third of the cases: absorber layers on some faces (then no magnetic dipoles)
+
+    def face(ax_n, minus, p):
+        if absorb and rng.integers(0, 2) and ax_n >= 8:
+            return td.Absorber(num_layers=int(rng.integers(2, min(7, ax_n // 2))))
+        return td.PMCBoundary() if (minus and p) else td.PECBoundary()
+    bspec = td.BoundarySpec(**{ax: td.Boundary(minus=face(n_, True, p), plus=face(n_, False, p))
+                               for ax, p, n_ in zip("xyz", pmc, N)})
 
     def pos(margin=0.8):
         return tuple(float(rng.uniform(-0.5 * s + min(margin * DL, 0.45 * s), 0.5 * s - min(margin * DL, 0.45 * s))) for s in size)
     srcs = []
     for _ in range(int(rng.integers(1, 5))):
-        pol = str(rng.choice(["Ex", "Ey", "Ez", "Hx", "Hy", "Hz"]))
+        pol = str(rng.choice(["Ex", "Ey", "Ez"] if absorb else ["Ex", "Ey", "Ez", "Hx", "Hy", "Hz"]))
         c = list(pos())
         if pol in ("Hy", "Hz") and nx > 256:          # not in the columns next to a seam (that case keeps single steps)
             i = (c[0] + 0.5 * size[0]) / DL
@@ -55,7 +61,7 @@ def case(rng):
     disc = discretize(sim, n_steps=steps + 1)
     disc.spec.decay_every = int(rng.choice([0, 0, 7, 16]))
     w, zc = int(rng.integers(4, 17)), int(rng.integers(2, 40))
-    return N, disc, steps, w, zc, pmc, bool(structures)
+    return N, disc, steps, w, zc, (pmc, "abs" if absorb else ""), bool(structures)
 
 
 def run(disc, steps, twostep, split):
