@@ -68,10 +68,10 @@ SHAPES = {
 }
 
 
-CASES = [("one_tile", 16, 32), ("one_tile", 4, 2), ("one_tile", 8, 3),
-         ("ragged_rows", 16, 32), ("ragged_rows", 5, 3), ("ragged_rows", 8, 5), ("ragged_rows", 6, 32),
-         ("two_x_tiles", 16, 32), ("two_x_tiles", 4, 2), ("two_x_tiles", 5, 3), ("two_x_tiles", 8, 3),
-         ("three_x_tiles_tall", 8, 5), ("three_x_tiles_tall", 5, 3), ("three_x_tiles_tall", 6, 32)]
+CASES = [("one_tile", 16, 32), ("one_tile", 4, 2),
+         ("ragged_rows", 16, 32), ("ragged_rows", 5, 3), ("ragged_rows", 8, 5),
+         ("two_x_tiles", 16, 32), ("two_x_tiles", 4, 2), ("two_x_tiles", 8, 3),
+         ("three_x_tiles_tall", 5, 3), ("three_x_tiles_tall", 6, 32)]
 
 
 @pytest.mark.parametrize("name,w,zc", CASES)
@@ -87,8 +87,7 @@ def test_two_steps_per_sweep_equal_single_steps(name, w, zc, emu_lib):
         assert np.array_equal(got_f[c], ref_f[c]), c
 
 
-@pytest.mark.parametrize("name,w,zc", [("one_tile", 16, 32), ("one_tile", 5, 3), ("ragged_rows", 8, 5), ("two_x_tiles", 16, 32),
-                                       ("two_x_tiles", 6, 4), ("three_x_tiles_tall", 8, 5)])
+@pytest.mark.parametrize("name,w,zc", [("one_tile", 16, 32), ("ragged_rows", 8, 5), ("two_x_tiles", 6, 4), ("three_x_tiles_tall", 8, 5)])
 def test_two_steps_per_sweep_with_materials(name, w, zc, emu_lib):
     """Non-dispersive media (a lossy dielectric bar through the seam of the wide grids, a sphere with sub-pixel-averaged
     surface cells, a PEC box): uniform row segments take their coefficients as scalars, mixed ones per cell, the seam kernel
@@ -104,8 +103,7 @@ def test_two_steps_per_sweep_with_materials(name, w, zc, emu_lib):
         assert np.array_equal(got_f[c], ref_f[c]), c
 
 
-@pytest.mark.parametrize("name,w,zc,bspec", [("one_tile", 16, 32, PMC_MIN), ("ragged_rows", 5, 3, PMC_MIN), ("two_x_tiles", 8, 5, PMC_MIN),
-                                             ("two_x_tiles", 16, 32, PMC_MIX), ("three_x_tiles_tall", 6, 4, PMC_MIN)])
+@pytest.mark.parametrize("name,w,zc,bspec", [("ragged_rows", 5, 3, PMC_MIN), ("two_x_tiles", 16, 32, PMC_MIX), ("three_x_tiles_tall", 6, 4, PMC_MIN)])
 def test_two_steps_per_sweep_with_pmc_min_faces(name, w, zc, bspec, emu_lib):
     """PMC walls on the min faces (the symmetry planes of a half / quarter / eighth domain): H mirrored with the opposite sign
     behind them in both steps, in the sweep and in the seam kernel; with materials and a probe next to the walls."""
@@ -126,7 +124,7 @@ def test_two_steps_per_sweep_with_pmc_min_faces(name, w, zc, bspec, emu_lib):
     assert np.abs(ref_m["corner"]).max() > 0 and np.array_equal(got_m["corner"], ref_m["corner"])
 
 
-@pytest.mark.parametrize("name,w,zc", [("one_tile", 16, 32), ("ragged_rows", 5, 3), ("two_x_tiles", 8, 5), ("three_x_tiles_tall", 6, 4)])
+@pytest.mark.parametrize("name,w,zc", [("one_tile", 16, 32), ("two_x_tiles", 8, 5), ("three_x_tiles_tall", 6, 4)])
 def test_two_steps_per_sweep_with_magnetic_dipoles(name, w, zc, emu_lib):
     """H-side point sources: those of step n act on H^{n-1/2} in front of the sweep, those of step n+1 on H^{n+1/2} inside it —
     behind E^{n+1}, which is formed from the value without them; a probe on a source node records H^{n+1/2} without the term
@@ -170,8 +168,8 @@ ABS_PMC = td.BoundarySpec(x=td.Boundary(minus=td.PMCBoundary(), plus=td.Absorber
                           y=td.Boundary.absorber(num_layers=2), z=td.Boundary(minus=td.PMCBoundary(), plus=td.Absorber(num_layers=4)))
 
 
-@pytest.mark.parametrize("name,w,zc,bspec", [("one_tile", 16, 32, ABS), ("ragged_rows", 5, 3, ABS), ("two_x_tiles", 8, 5, ABS),
-                                             ("two_x_tiles", 6, 4, ABS_PMC), ("three_x_tiles_tall", 7, 6, ABS)])
+@pytest.mark.parametrize("name,w,zc,bspec", [("ragged_rows", 16, 32, ABS), ("two_x_tiles", 8, 5, ABS), ("two_x_tiles", 6, 4, ABS_PMC),
+                                             ("three_x_tiles_tall", 7, 6, ABS)])
 def test_two_steps_per_sweep_with_absorber_layers(name, w, zc, bspec, emu_lib):
     """Absorber boundaries (open problems): damp_kernel's factors applied in registers to H^{n-1/2}, E^{n+1} (behind its sources),
     H^{n+1/2} and E^{n+2} — the sweep, its x-halo column, its chunk prologue and the seam kernel — with media, probes inside the
@@ -233,8 +231,7 @@ def test_pairs_give_way_to_monitor_records_and_decay_checks(name, emu_lib):
         assert np.array_equal(got_m[k], ref_m[k]), k
 
 
-@pytest.mark.parametrize("name", ["one_tile", "two_x_tiles"])
-@pytest.mark.parametrize("interval", [1, 2, 3])
+@pytest.mark.parametrize("name,interval", [("one_tile", 1), ("one_tile", 3), ("two_x_tiles", 1), ("two_x_tiles", 2)])
 def test_small_time_monitors_sample_the_middle_step(name, interval, emu_lib):
     """Point-like FieldTimeMonitors (E and H components; H is the mean of two half-steps) do not stop pairs: the sweep copies
     E^{n+1} (behind the sources of step n) and H^{n+1/2} of their cells out, and the records equal those of single steps."""
