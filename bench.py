@@ -52,6 +52,7 @@ WORKLOADS = {
     "v4": "v3 + closed FluxMonitor box (300 cells), running DFT at 3 frequencies",
     "va": "v0 with Absorber boundaries, 40 layers x 6 faces (inside the cell count): an open problem without CPML",
     "v1a": "v1 with Absorber boundaries, 40 layers x 6 faces (inside the cell count)",
+    "v4a": "v1a + closed FluxMonitor box (300 cells), running DFT at 3 frequencies: a complete open scattering problem",
 }
 
 
@@ -64,7 +65,7 @@ def build_spec(n: int, n_steps: int, workload: str):
     pulse = td.GaussianPulse(freq0=2e14, fwidth=2e13)
     structures = []
     bspec = td.BoundarySpec.all_sides(td.PECBoundary())
-    if workload in ("v1", "v2", "v3", "v4", "v1a"):
+    if workload in ("v1", "v2", "v3", "v4", "v1a", "v4a"):
         structures.append(td.Structure(geometry=td.Sphere(center=(0, 0, 0), radius=100 * dl * n / 512),
                                        medium=td.Medium(permittivity=4.0)))
     if workload in ("v3", "v4"):
@@ -73,11 +74,11 @@ def build_spec(n: int, n_steps: int, workload: str):
     if workload in ("v2", "v3", "v4"):
         size = ((n - 24) * dl - 1e-6 * dl,) * 3      # a hair under n - 24 cells: ceil(size / dl) must not round up
         bspec = td.BoundarySpec.all_sides(td.PML(num_layers=12))
-    if workload in ("va", "v1a"):
+    if workload in ("va", "v1a", "v4a"):
         size = ((n - 80) * dl - 1e-6 * dl,) * 3
         bspec = td.BoundarySpec.all_sides(td.Absorber(num_layers=40))
     monitors = []
-    if workload == "v4":      # closed flux box around the sphere, running DFT at 3 frequencies
+    if workload in ("v4", "v4a"):      # closed flux box around the sphere, running DFT at 3 frequencies
         monitors.append(td.FluxMonitor(center=(0, 0, 0), size=(300 * dl * n / 512,) * 3, name="flux",
                                        freqs=[1.8e14, 2.0e14, 2.2e14]))
     sim = td.Simulation(size=size, grid_spec=td.GridSpec.uniform(dl=dl), run_time=1e-12,
@@ -280,7 +281,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", "--n", dest="n", type=int, default=512, help="cells per axis")
-    ap.add_argument("--workload", default="v0", choices=["v0", "v1", "v2", "v3", "v4", "va", "v1a"])
+    ap.add_argument("--workload", default="v0", choices=["v0", "v1", "v2", "v3", "v4", "va", "v1a", "v4a"])
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--zchunk", type=int, default=0)
     ap.add_argument("--rows", type=int, default=0)

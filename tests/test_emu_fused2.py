@@ -205,6 +205,36 @@ def test_absorber_layers_with_a_magnetic_dipole_take_single_steps(emu_lib):
         assert np.array_equal(got_f[c], ref_f[c]), c
 
 
+@pytest.mark.parametrize("name,w,zc,bspec", [("one_tile", 16, 32, PEC), ("two_x_tiles", 8, 5, PEC), ("two_x_tiles", 6, 4, ABS),
+                                             ("three_x_tiles_tall", 5, 3, PMC_MIN)])
+def test_dft_monitors_do_not_stop_pairs(name, w, zc, bspec, emu_lib):
+    """DFT monitors (field planes normal to x, y and z — the x-normal one through a seam column on wide grids —, a volume, a flux
+    plane; each at its own sampling interval): a record on the FIRST step of a pair takes E^n in front of the sweep and its H
+    terms from the sweep's copy of H^{n+1/2} over the box; a record on a middle step costs one single step that moves it onto
+    a first step.  Same spectra, bit for bit; and all but a few steps go out as pairs."""
+    N = SHAPES[name]
+    size = tuple(n * DL for n in N)
+    xs = -0.5 * size[0] + 255.4 * DL if N[0] > 256 else 0.1
+    mons = [td.FieldMonitor(center=(0, 0, 0.02), size=(td.inf, td.inf, 0), freqs=[3e14, 3.3e14], name="fz", interval_space=(1, 1, 1)),
+            td.FieldMonitor(center=(0, 0.03, 0), size=(td.inf, 0, td.inf), freqs=[3e14], name="fy", fields=["Ex", "Hy", "Hz"]),
+            td.FieldMonitor(center=(xs, 0, 0), size=(0, td.inf, td.inf), freqs=[2.8e14], name="fx", fields=["Hx", "Hz", "Ey"]),
+            td.FieldMonitor(center=(0.05, 0.02, 0.0), size=(0.3, 0.2, 0.15), freqs=[3e14], name="vol"),
+            td.FluxMonitor(center=(0, 0, -0.1), size=(td.inf, td.inf, 0), freqs=[3e14, 3.1e14], name="flux"),
+            td.FieldMonitor(center=(0, 0, 0), size=(0.2, 0.2, 0), freqs=[3e14], name="e_only", fields=["Ex", "Ey"])]
+    sim = _sim(N, monitors=False, structures=MEDIA_WIDE if N[0] >= 128 else MEDIA, bspec=bspec).updated_copy(monitors=mons)
+    disc = discretize(sim, n_steps=40)
+    disc.spec.decay_every = 0
+    ref_f, ref_m, p0 = _run(disc.spec, emu_lib, 0, runs=(17, 23))
+    got_f, got_m, p1 = _run(disc.spec, emu_lib, w + 64 * zc, runs=(17, 23))
+    assert p0 == 0 and p1 >= 12, p1
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), c
+    assert len(ref_m) >= 6 and set(ref_m) == set(got_m), sorted(ref_m)
+    for k in ref_m:
+        assert np.abs(ref_m[k]).max() > 0, k
+        assert np.array_equal(got_m[k], ref_m[k]), k
+
+
 @pytest.mark.parametrize("name", ["ragged_rows", "two_x_tiles"])
 def test_pairs_give_way_to_monitor_records_and_decay_checks(name, emu_lib):
     N = SHAPES[name]

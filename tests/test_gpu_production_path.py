@@ -359,7 +359,7 @@ def test_two_steps_per_sweep_with_materials_bit_identical_bench_v1(hip_lib, w, z
         assert np.array_equal(got[c], ref[c]), c
 
 
-@pytest.mark.parametrize("workload,n", [("va", 320), ("v1a", 256)])
+@pytest.mark.parametrize("workload,n", [("va", 320), ("v1a", 256), ("v4a", 256)])
 def test_two_steps_per_sweep_with_absorber_layers_bit_identical(hip_lib, workload, n):
     """An open problem on the two-step sweep: Absorber boundaries (40 layers on all faces; vacuum / a dielectric sphere), damped in
     registers == single sweeps with the damping launches around them, bit for bit; prints both speeds."""
@@ -379,13 +379,15 @@ def test_two_steps_per_sweep_with_absorber_layers_bit_identical(hip_lib, workloa
             t0 = time.perf_counter()
             st = e.run(steps - 1)
             dt = time.perf_counter() - t0
-            return [e.get_field(c) for c in range(6)], int(st.fused2_pairs), dt / (steps - 1) * 1e3
-    ref, p0, ms0 = run(0)
-    got, p1, ms1 = run(-1)
+            return [e.get_field(c) for c in range(6)], int(st.fused2_pairs), dt / (steps - 1) * 1e3, e.results()
+    ref, p0, ms0, ref_m = run(0)
+    got, p1, ms1, got_m = run(-1)
     print(f"[{workload} {n}^3] single sweeps {ms0:.4f} ms per step, two steps per sweep {ms1:.4f} ms ({p1} pairs)")
-    assert p0 == 0 and p1 == (steps - 1) // 2
+    assert p0 == 0 and p1 >= (steps - 1) // 2 - 4          # (v4a: a DFT record on a middle step costs a single step)
     for c in range(6):
         assert np.array_equal(got[c], ref[c]), c
+    for k in ref_m:                                        # v4a: the flux box's running DFT
+        assert np.array_equal(got_m[k], ref_m[k]), k
 
 
 def test_two_steps_per_sweep_config2_probe_records_bit_identical(hip_lib):
@@ -444,6 +446,9 @@ def test_two_steps_per_sweep_everything_at_once_on_the_device(hip_lib, w, zc):
                                 name="corner", interval=2, colocate=False),
             td.FieldTimeMonitor(center=(0.3 * size[0] - 0.5 * size[0] + 0.02, 0.01, 0.03), size=(0, 0, 0), name="src", interval=1,
                                 fields=["Ez"], colocate=False)]
+    mons += [td.FieldMonitor(center=(-0.5 * size[0] + 255.4 * T.DL, 0, 0), size=(0, td.inf, td.inf), freqs=[2.8e14], name="dft_x",
+                             fields=["Hx", "Hz", "Ey"]),
+             td.FluxMonitor(center=(0, 0, -0.1), size=(td.inf, td.inf, 0), freqs=[3e14, 3.1e14], name="flux")]
     disc = discretize(sim.updated_copy(sources=srcs, monitors=mons), n_steps=61)
     disc.spec.decay_every = 16
 
@@ -456,11 +461,11 @@ def test_two_steps_per_sweep_everything_at_once_on_the_device(hip_lib, w, zc):
             return [e.get_field(c) for c in range(6)], e.results(), pairs
     ref_f, ref_m, p0 = run(0)
     got_f, got_m, p1 = run(w + 64 * zc)
-    assert p0 == 0 and p1 >= 24, p1
+    assert p0 == 0 and p1 >= 20, p1
     assert max(float(np.abs(f).max()) for f in ref_f) > 0
     for c in range(6):
         assert np.array_equal(got_f[c], ref_f[c]), c
-    for k in ("seam", "corner", "src"):
+    for k in ref_m:
         assert np.abs(ref_m[k]).max() > 0 and np.array_equal(got_m[k], ref_m[k]), k
     if (w, zc) == (16, 32):
         # ... and the two-step sweep against the fp64 oracle directly (fields and probe records; fp32 round-off over 61 steps)

@@ -101,13 +101,19 @@ struct Monitor {
 // node table of one kind of step pair of the two-step sweep: the E-side source nodes and the nodes small time monitors
 // sample of the middle step (InjP), for one set of recording monitors
 struct F2Table {
-  std::vector<int> mons;           // monitors whose middle-step samples the sweep copies out (ascending)
+  std::vector<int> mons;           // time monitors whose middle-step samples the sweep copies out (ascending)
   std::vector<int> cap_off;        // their offsets into the sample buffer
+  std::vector<int> dfts;           // DFT monitors that record at the first step: the sweep copies H^{n+1/2} over their boxes out
+  std::vector<std::array<int, 3>> dft_off;     // offsets of their H_x / H_y / H_z blocks in the dump buffer (-1: not recorded)
   int* start = nullptr;
   int4* ent = nullptr;
+  int *dstart = nullptr, *dlist = nullptr;
+  DumpBox* dboxes = nullptr;
+  long long dump_floats = 0;
 };
 struct F2Plan {                    // one step pair: the monitors that record at its first or middle step
-  std::vector<int> mons;
+  std::vector<int> mons;           // small time monitors
+  std::vector<int> dfts;           // DFT monitors recording at the FIRST step
 };
 
 }  // namespace
@@ -212,6 +218,8 @@ struct FdtdSolver {
   float* seam_buf = nullptr;          // intermediate values on the seams between x tiles
   float* inj_val = nullptr;           // source terms applied between the two steps
   float* cap_val = nullptr;           // samples of the middle step (small time monitors)
+  float* dump_buf = nullptr;          // H^{n+1/2} over the boxes of DFT monitors recording at the first step of a pair
+  long long dump_cap = 0;
   std::vector<F2Table> f2_tables;     // node tables, one per set of recording monitors met so far
   size_t inj_sources = 0;             // point-source lists the tables were built from
   float* src_tab = nullptr;           // [step][node] source terms of every step, formed once (nullptr: per pair)
@@ -706,18 +714,29 @@ bool fused2_capturable(const FdtdSolver* h, const Monitor& m) {
 // behind it (pair_record_kernel) writes everything they record of the pair — E^n and H^{n-1/2} are still in the set the
 // sweep read, H^{n+3/2} is in the set it wrote — so such a pair costs no record launch in front of the sweep.
 bool fused2_plan(const FdtdSolver* h, long long n, F2Plan* plan) {
-  plan->mons.clear();
-  long long total = 0;
+  plan->mons.clear(); plan->dfts.clear();
+  long long total = 0, dump = 0;
   for (size_t q = 0; q < h->mons.size(); ++q) {
     const Monitor& m = h->mons[q];
-    bool at = false;
-    for (size_t r = m.next; r < m.steps.size() && m.steps[r] <= n + 1; ++r) at = at || m.steps[r] >= n;
-    if (!at) continue;
+    bool at_n = false, at_m = false;
+    for (size_t r = m.next; r < m.steps.size() && m.steps[r] <= n + 1; ++r) { at_n = at_n || m.steps[r] == n; at_m = at_m || m.steps[r] == n + 1; }
+    if (!at_n && !at_m) continue;
+    const BoxP& b = m.box;
+    const bool inside = b.lo0 >= 0 && b.lo1 >= 0 && b.lo2 >= 0 && b.lo0 + b.nx <= h->g.nx && b.lo1 + b.ny <= h->g.ny && b.lo2 + b.nz <= h->g.nz;
+    if (m.kind == FDTD_MON_DFT) {
+      // A DFT monitor that records at the FIRST step: E^n is taken in front of the sweep as always; its H terms need H^{n+1/2},
+      // which the sweep copies out over the box (any size).  A record on the middle step: no pair here — the single step taken
+      // instead moves the record onto the first step of the next pair.
+      if (at_m || !inside || m.cells <= 0) return false;
+      for (int c : m.comps) if (c >= 3) dump += m.cells;
+      plan->dfts.push_back((int)q);
+      continue;
+    }
     if (!fused2_capturable(h, m) || m.comps.size() > 6) return false;
     total += (long long)m.comps.size() * m.cells;
     plan->mons.push_back((int)q);
   }
-  return total <= kMaxCap && (int)plan->mons.size() <= kPairMons;
+  return total <= kMaxCap && (int)plan->mons.size() <= kPairMons && (int)plan->dfts.size() <= kMaxDumps && dump <= (1LL << 26);
 }
 
 // the source terms of every step, formed once with the operations of point_source_kernel: [step][node], nodes in the order of
@@ -760,7 +779,7 @@ int fused2_sources(FdtdSolver* h) {
 const F2Table* fused2_table(FdtdSolver* h, const F2Plan& plan) {
   const GridP& g = h->g;
   if (fused2_sources(h)) return nullptr;
-  for (const F2Table& t : h->f2_tables) if (t.mons == plan.mons) return &t;
+  for (const F2Table& t : h->f2_tables) if (t.mons == plan.mons && t.dfts == plan.dfts) return &t;
   // the nodes of all E-side lists, sorted by plane; nodes of one plane keep their list order (a node two lists share
   // receives their terms in the order the source kernels would add them); the monitor samples of a plane follow them
   std::vector<std::array<int, 5>> ent;        // k, i, j, code, index
@@ -802,6 +821,31 @@ const F2Table* fused2_table(FdtdSolver* h, const F2Plan& plan) {
   for (int k = 0; k <= g.nz; ++k) start[(size_t)k + 1] += start[(size_t)k];
   if (dev_upload(h, &tb.start, (const int*)start.data(), start.size()) ||
       dev_upload(h, &tb.ent, (const int4*)e4.data(), e4.size())) return nullptr;
+  // boxes of the DFT monitors that record at the first step, indexed by plane
+  tb.dfts = plan.dfts;
+  if (!plan.dfts.empty()) {
+    std::vector<DumpBox> boxes;
+    std::vector<std::vector<int>> per_plane((size_t)g.nz + 1);
+    long long off = 0;
+    for (size_t q = 0; q < plan.dfts.size(); ++q) {
+      const Monitor& m = h->mons[(size_t)plan.dfts[q]];
+      DumpBox bx{m.box.lo0, m.box.lo1, m.box.lo2, m.box.nx, m.box.ny, m.box.nz, {-1, -1, -1}};
+      for (int c : m.comps) if (c >= 3) { bx.off[c - 3] = (int)off; off += m.cells; }
+      tb.dft_off.push_back({bx.off[0], bx.off[1], bx.off[2]});
+      if (bx.off[0] < 0 && bx.off[1] < 0 && bx.off[2] < 0) continue;        // E components only: nothing to copy out
+      for (int k = m.box.lo2; k < m.box.lo2 + m.box.nz; ++k) per_plane[(size_t)k].push_back((int)boxes.size());
+      boxes.push_back(bx);
+    }
+    tb.dump_floats = off;
+    if (!boxes.empty()) {
+      std::vector<int> ds((size_t)g.nz + 2, 0), dl;
+      for (int k = 0; k <= g.nz; ++k) { ds[(size_t)k] = (int)dl.size(); if (k < g.nz) for (int b : per_plane[(size_t)k]) dl.push_back(b); }
+      ds[(size_t)g.nz + 1] = (int)dl.size();
+      if (dl.empty()) dl.push_back(0);
+      if (dev_upload(h, &tb.dstart, (const int*)ds.data(), ds.size()) || dev_upload(h, &tb.dlist, (const int*)dl.data(), dl.size()) ||
+          dev_upload(h, &tb.dboxes, (const DumpBox*)boxes.data(), boxes.size())) return nullptr;
+    }
+  }
   h->f2_tables.push_back(tb);
   return &h->f2_tables.back();
 }
@@ -848,6 +892,14 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
     }
     inj.n = (alive || !tb->mons.empty()) ? 1 : 0;
     inj.start = tb->start; inj.ent = tb->ent; inj.cap = h->cap_val;
+    if (tb->dstart) {
+      if (tb->dump_floats > h->dump_cap) {
+        if (dev_alloc(h, &h->dump_buf, (size_t)tb->dump_floats, false)) return -1;
+        h->dump_cap = tb->dump_floats;
+      }
+      inj.dstart = tb->dstart; inj.dlist = tb->dlist; inj.dboxes = tb->dboxes; inj.dump = h->dump_buf;
+      inj.n = 1;
+    }
   }
   // absorber layers: H^{n-1/2}, E^{n+1}, H^{n+1/2} are damped in registers; E^{n+2} too unless E-side sources of step n+1 still
   // have to be applied behind the launch (the damping follows the sources: then the caller damps, launch_damp)
@@ -864,7 +916,7 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
   StepP sp = step_params(h);
   time_begin(h, 2, st);
   const MatP mp = mat_params(h);
-  launch_fused2_step(st, W, (h->mem_hints ? 1 : 0) | (h->mat4 ? 2 : 0) | ((tb->mons.empty() && h->src_h_nodes == 0) ? 0 : 4) | (h->has_damp ? 8 : 0),
+  launch_fused2_step(st, W, (h->mem_hints ? 1 : 0) | (h->mat4 ? 2 : 0) | ((tb->mons.empty() && h->src_h_nodes == 0 && !tb->dstart) ? 0 : 4) | (h->has_damp ? 8 : 0),
                      remap ? ((total + 7) / 8) * 8 : total, g, h->f, h->f2, sp, mp, zc, nbx, nby, nbz, remap, inj, h->seam_buf, dmp);
   if (nbx > 1) launch_seams(st, g, h->f2, sp, mp, h->seam_buf, nbx - 1, dmp);
   time_end(h, st);
@@ -875,6 +927,18 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
 // behind the sweep of the pair (n, n + 1) (the sets are swapped: h->f2 = what it read, h->f = what it wrote): everything the
 // monitors of `tb` record of steps n and n + 1, in one launch
 void pair_record(FdtdSolver* h, const F2Table* tb, long long n, hipStream_t st) {
+  // DFT monitors that recorded E^n in front of the sweep: their H terms from the sweep's copy of H^{n+1/2}
+  for (size_t q = 0; q < tb->dfts.size(); ++q) {
+    Monitor& m = h->mons[(size_t)tb->dfts[q]];
+    if (m.next >= m.steps.size() || m.steps[m.next] != n) continue;
+    DftDumpP r{};
+    for (size_t ic = 0; ic < m.comps.size(); ++ic)
+      if (m.comps[ic] >= 3) { r.slot[r.n] = (int)ic; r.off[r.n] = tb->dft_off[q][(size_t)(m.comps[ic] - 3)]; r.n++; }
+    if (r.n > 0)
+      launch_dft_record_dump(st, r, h->dump_buf, reinterpret_cast<float2*>(m.data), m.cells, (long long)m.comps.size() * m.cells,
+                             (const float2*)(m.phase_h + (long long)m.next * m.nf), m.nf);
+    m.next++;
+  }
   if (tb->mons.empty()) return;
   PairRecP r{};
   r.pre_done = h->src_h_nodes > 0;            // (then fdtd_run has not skipped them at the top of the step)
@@ -2450,7 +2514,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     // every monitor that records at n or n + 1 a small time monitor the sweep can sample)
     const bool pair = fused && f2_ok && done + 2 <= n_steps && !(h->decay_every > 0 && ((n + 1) % h->decay_every) == 0) &&
                       fused2_sources_uniform(h, n) && fused2_plan(h, n, &f2_plan) &&
-                      (f2_plan.mons.empty() || sources_alive(n) || h->psrc.empty());
+                      ((f2_plan.mons.empty() && f2_plan.dfts.empty()) || sources_alive(n) || h->psrc.empty());
     // (with H-side sources the monitors of a pair still take E^n and H^{n-1/2} here: those sources change H^{n-1/2} before the
     //  sweep, and pair_record reads the set afterwards)
     if (rec) record_monitors(h, n, false, st, (pair && h->src_h_nodes == 0) ? &f2_plan : nullptr);

@@ -57,6 +57,12 @@ void launch_pair_record(hipStream_t st, const PairRecP& r, long long max_cells, 
   hipLaunchKernelGGL(pair_record_kernel, grid, dim3(256), 0, st, r, g, a, b, cap);
 }
 
+void launch_dft_record_dump(hipStream_t st, const DftDumpP& r, const float* dump, float2* acc, long long cells, long long fstride,
+                            const float2* phase, int nf) {
+  const dim3 grid((unsigned)((cells + 255) / 256), (unsigned)r.n);
+  hipLaunchKernelGGL(dft_record_dump_kernel, grid, dim3(256), 0, st, r, dump, acc, cells, fstride, phase, nf);
+}
+
 void launch_seams(hipStream_t st, const GridP& g, const FieldP& b, const StepP& s, const MatP& m, const float* seam,
                   int n_seams, const DampT& dmp) {
   const long long nt = (long long)n_seams * g.ny * g.nz;

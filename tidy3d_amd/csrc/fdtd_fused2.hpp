@@ -19,7 +19,18 @@ struct InjP {
   const float* val2;                       // source terms of step n+1 (nullptr: not available; then there are no H-side nodes)
   int e2_in_sweep;                         // the E-side terms of step n+1 are added to E^{n+2} by the sweep (else: by the caller behind it)
   float* cap;                              // samples of the middle step (pair_record_kernel)
+  // H^{n+1/2} over the boxes of DFT monitors that record at step n (their H terms are accumulated behind the sweep,
+  // dft_record_dump_kernel): boxes of plane k = dlist[dstart[k] .. dstart[k + 1])
+  const int* dstart;
+  const int* dlist;
+  const struct DumpBox* dboxes;
+  float* dump;
 };
+struct DumpBox {
+  int lo0, lo1, lo2, nx, ny, nz;           // the monitor's box
+  int off[3];                              // offset of the H_x / H_y / H_z block ([nz][ny][nx], the monitor's cell order) in `dump`, -1 = not recorded
+};
+constexpr int kMaxDumps = 8;
 // absorber layers (damp_kernel's per-axis factor tables: fb at cell boundaries, fc at cell centres; 1 outside the layers);
 // fb[0] == nullptr: none
 struct DampT {
@@ -54,6 +65,11 @@ struct PairRecP {
 };
 void launch_pair_record(hipStream_t st, const PairRecP& r, long long max_cells, const GridP& g, const FieldP& a, const FieldP& b,
                         const float* cap);
+// acc[f][slot][cell] += dump[cell] * phase[f]: the H terms of a DFT record from the sweep's copy of H^{n+1/2} (the operations of
+// dft_record_multi_kernel); n_h entries: (slot, offset into dump)
+struct DftDumpP { int n; int slot[3]; int off[3]; };
+void launch_dft_record_dump(hipStream_t st, const DftDumpP& r, const float* dump, float2* acc, long long cells, long long fstride,
+                            const float2* phase, int nf);
 void launch_seams(hipStream_t st, const GridP& g, const FieldP& b, const StepP& s, const MatP& m, const float* seam,
                   int n_seams, const DampT& dmp);
 

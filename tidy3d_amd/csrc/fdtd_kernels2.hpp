@@ -60,6 +60,22 @@ __global__ __launch_bounds__(256) void pair_record_kernel(PairRecP r, GridP g, F
   }
 }
 
+__global__ __launch_bounds__(256) void dft_record_dump_kernel(DftDumpP r, const float* dump, float2* acc, long long cells,
+                                                              long long fstride, const float2* phase, int nf) {
+  const int q = blockIdx.y;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= cells || q >= r.n) return;
+  const float v = dump[r.off[q] + t];
+  float2* a0 = acc + (long long)r.slot[q] * cells;
+  for (int k = 0; k < nf; ++k) {
+    const float2 ph = phase[k];
+    float2 a = a0[(long long)k * fstride + t];
+    a.x += v * ph.x;
+    a.y += v * ph.y;
+    a0[(long long)k * fstride + t] = a;
+  }
+}
+
 // the same for every step at once: tab[step * stride + off + t]
 __global__ __launch_bounds__(256) void inject_table_kernel(float* tab, long long stride, long long off, const float* w_re,
                                                            const float* w_im, const float2* wave, long long n_steps, int n) {
@@ -325,6 +341,8 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     if constexpr (DAMP) { bzk = dmp.fb[2][min(k, g.nz - 1)]; czk = dmp.fc[2][min(k, g.nz - 1)]; }
     int q0 = 0, q1 = 0;
     if (inj.n > 0) { q0 = inj.start[k]; q1 = inj.start[k + 1]; }     // ([nz + 2] entries: plane nz holds none)
+    [[maybe_unused]] int d0 = 0, d1 = 0;
+    if constexpr (MON) { if (inj.dstart) { d0 = inj.dstart[k]; d1 = inj.dstart[k + 1]; } }
     float hy_m = 0.f, hz_m = 0.f;
     float (&exn)[V] = L.exn, (&eyn)[V] = L.eyn, (&ezk)[V] = L.ezk, (&exj)[V] = L.exj, (&ezj)[V] = L.ezj;
     float (&hxn)[V] = L.hxn, (&hyn)[V] = L.hyn, (&hzn)[V] = L.hzn;
@@ -494,6 +512,28 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
             const float bx[V] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
             for (int e = 0; e < V; ++e) { e1yn[e] *= bx[e] * cyv * bzk; e1zn[e] *= bx[e] * byv * czk; }
+          }
+        }
+        // H^{n+1/2} over the boxes of DFT monitors that record at step n (in front of the damping / sources of step n+1, as between two
+        // single steps)
+        if constexpr (MON) {
+          if (own && k >= k0 && k < k1) {
+            for (int q = d0; q < d1; ++q) {
+              const DumpBox bx = inj.dboxes[inj.dlist[q]];
+              const int ly = j - bx.lo1, lz = k - bx.lo2;
+              if (ly >= 0 && ly < bx.ny) {
+                const long long rowo = ((long long)lz * bx.ny + ly) * bx.nx;
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                  const int lx = i0o + e - bx.lo0;
+                  if (lx >= 0 && lx < bx.nx && act) {
+                    if (bx.off[0] >= 0) inj.dump[bx.off[0] + rowo + lx] = hxn[e];
+                    if (bx.off[1] >= 0) inj.dump[bx.off[1] + rowo + lx] = hyn[e];
+                    if (bx.off[2] >= 0) inj.dump[bx.off[2] + rowo + lx] = hzn[e];
+                  }
+                }
+              }
+            }
           }
         }
         // what the neighbouring x tile needs of this step: repaired on the seam by seam_kernel
