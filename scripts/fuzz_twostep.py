@@ -1,5 +1,5 @@
 """Randomised self-check of the two-step sweep on the device: random grid shapes (1-3 x tiles, ragged rows / chunks), tile shapes,
-wall types (PEC, PMC, absorber layers), media, electric / magnetic dipoles and probes; two steps per sweep == single sweeps, bit for bit.
+wall types (PEC, PMC, absorber layers), media, electric / magnetic dipoles, probes and DFT monitors; two steps per sweep == single sweeps, bit for bit.
     python scripts/fuzz_twostep.py [n_cases] [seed]"""
 import os
 import sys
@@ -48,6 +48,19 @@ def case(rng):
         fields = [str(f) for f in rng.choice(["Ex", "Ey", "Ez", "Hx", "Hy", "Hz"], size=int(rng.integers(1, 4)), replace=False)]
         mons.append(td.FieldTimeMonitor(center=pos(2.5), size=(0, 0, 0), name=f"m{q}", interval=int(rng.integers(1, 4)), fields=fields,
                                         colocate=False))
+    for q in range(int(rng.integers(0, 3))):           # DFT monitors: planes of any orientation, volumes, flux planes
+        kind = int(rng.integers(0, 4))
+        c = pos(2.5)
+        if kind < 3:
+            sz = [td.inf, td.inf, td.inf]
+            sz[kind] = 0
+            fields = [str(f) for f in rng.choice(["Ex", "Ey", "Ez", "Hx", "Hy", "Hz"], size=int(rng.integers(1, 5)), replace=False)]
+            if rng.integers(0, 3) == 0:
+                mons.append(td.FluxMonitor(center=c, size=tuple(sz), freqs=[3e14, 3.2e14], name=f"fl{q}"))
+            else:
+                mons.append(td.FieldMonitor(center=c, size=tuple(sz), freqs=[3e14], name=f"d{q}", fields=fields))
+        else:
+            mons.append(td.FieldMonitor(center=c, size=tuple(float(rng.uniform(0.1, 0.5) * s_) for s_ in size), freqs=[2.9e14, 3e14], name=f"v{q}"))
     structures = []
     if rng.integers(0, 2):
         structures = [td.Structure(geometry=td.Box(center=pos(), size=tuple(float(rng.uniform(0.1, 0.6) * s) for s in size)),
