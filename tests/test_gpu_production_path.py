@@ -383,7 +383,7 @@ def test_two_steps_per_sweep_with_absorber_layers_bit_identical(hip_lib, workloa
     ref, p0, ms0, ref_m = run(0)
     got, p1, ms1, got_m = run(-1)
     print(f"[{workload} {n}^3] single sweeps {ms0:.4f} ms per step, two steps per sweep {ms1:.4f} ms ({p1} pairs)")
-    assert p0 == 0 and p1 >= (steps - 1) // 2 - 4          # (v4a: a DFT record on a middle step costs a single step)
+    assert p0 == 0 and p1 == (steps - 1) // 2
     for c in range(6):
         assert np.array_equal(got[c], ref[c]), c
     for k in ref_m:                                        # v4a: the flux box's running DFT

@@ -103,8 +103,9 @@ struct Monitor {
 struct F2Table {
   std::vector<int> mons;           // time monitors whose middle-step samples the sweep copies out (ascending)
   std::vector<int> cap_off;        // their offsets into the sample buffer
-  std::vector<int> dfts;           // DFT monitors that record at the first step: the sweep copies H^{n+1/2} over their boxes out
-  std::vector<std::array<int, 3>> dft_off;     // offsets of their H_x / H_y / H_z blocks in the dump buffer (-1: not recorded)
+  std::vector<int> dfts;           // DFT monitors that record at the first (flag 1) / middle (flag 2) step: the sweep copies
+  std::vector<int> dft_when;       // H^{n+1/2} / E^{n+1} over their boxes out
+  std::vector<std::array<int, 6>> dft_off;     // offsets of their E_x .. H_z blocks in the dump buffer (-1: not needed)
   int* start = nullptr;
   int4* ent = nullptr;
   int *dstart = nullptr, *dlist = nullptr;
@@ -113,7 +114,8 @@ struct F2Table {
 };
 struct F2Plan {                    // one step pair: the monitors that record at its first or middle step
   std::vector<int> mons;           // small time monitors
-  std::vector<int> dfts;           // DFT monitors recording at the FIRST step
+  std::vector<int> dfts;           // DFT monitors recording at the first and / or the middle step
+  std::vector<int> dft_when;       // bit 0: at step n, bit 1: at step n + 1
 };
 
 }  // namespace
@@ -714,7 +716,7 @@ bool fused2_capturable(const FdtdSolver* h, const Monitor& m) {
 // behind it (pair_record_kernel) writes everything they record of the pair — E^n and H^{n-1/2} are still in the set the
 // sweep read, H^{n+3/2} is in the set it wrote — so such a pair costs no record launch in front of the sweep.
 bool fused2_plan(const FdtdSolver* h, long long n, F2Plan* plan) {
-  plan->mons.clear(); plan->dfts.clear();
+  plan->mons.clear(); plan->dfts.clear(); plan->dft_when.clear();
   long long total = 0, dump = 0;
   for (size_t q = 0; q < h->mons.size(); ++q) {
     const Monitor& m = h->mons[q];
@@ -724,12 +726,13 @@ bool fused2_plan(const FdtdSolver* h, long long n, F2Plan* plan) {
     const BoxP& b = m.box;
     const bool inside = b.lo0 >= 0 && b.lo1 >= 0 && b.lo2 >= 0 && b.lo0 + b.nx <= h->g.nx && b.lo1 + b.ny <= h->g.ny && b.lo2 + b.nz <= h->g.nz;
     if (m.kind == FDTD_MON_DFT) {
-      // A DFT monitor that records at the FIRST step: E^n is taken in front of the sweep as always; its H terms need H^{n+1/2},
-      // which the sweep copies out over the box (any size).  A record on the middle step: no pair here — the single step taken
-      // instead moves the record onto the first step of the next pair.
-      if (at_m || !inside || m.cells <= 0) return false;
-      for (int c : m.comps) if (c >= 3) dump += m.cells;
+      // A DFT record at the FIRST step: E^n is taken in front of the sweep as always; its H terms need H^{n+1/2}.  A record at
+      // the MIDDLE step: its E terms need E^{n+1}; its H terms, H^{n+3/2}, are in the write set afterwards.  The sweep copies
+      // what is needed of the middle step out over the box (any size).
+      if (!inside || m.cells <= 0) return false;
+      for (int c : m.comps) if ((c >= 3 && at_n) || (c < 3 && at_m)) dump += m.cells;
       plan->dfts.push_back((int)q);
+      plan->dft_when.push_back((at_n ? 1 : 0) | (at_m ? 2 : 0));
       continue;
     }
     if (!fused2_capturable(h, m) || m.comps.size() > 6) return false;
@@ -779,7 +782,7 @@ int fused2_sources(FdtdSolver* h) {
 const F2Table* fused2_table(FdtdSolver* h, const F2Plan& plan) {
   const GridP& g = h->g;
   if (fused2_sources(h)) return nullptr;
-  for (const F2Table& t : h->f2_tables) if (t.mons == plan.mons && t.dfts == plan.dfts) return &t;
+  for (const F2Table& t : h->f2_tables) if (t.mons == plan.mons && t.dfts == plan.dfts && t.dft_when == plan.dft_when) return &t;
   // the nodes of all E-side lists, sorted by plane; nodes of one plane keep their list order (a node two lists share
   // receives their terms in the order the source kernels would add them); the monitor samples of a plane follow them
   std::vector<std::array<int, 5>> ent;        // k, i, j, code, index
@@ -822,17 +825,20 @@ const F2Table* fused2_table(FdtdSolver* h, const F2Plan& plan) {
   if (dev_upload(h, &tb.start, (const int*)start.data(), start.size()) ||
       dev_upload(h, &tb.ent, (const int4*)e4.data(), e4.size())) return nullptr;
   // boxes of the DFT monitors that record at the first step, indexed by plane
-  tb.dfts = plan.dfts;
+  tb.dfts = plan.dfts; tb.dft_when = plan.dft_when;
   if (!plan.dfts.empty()) {
     std::vector<DumpBox> boxes;
     std::vector<std::vector<int>> per_plane((size_t)g.nz + 1);
     long long off = 0;
     for (size_t q = 0; q < plan.dfts.size(); ++q) {
       const Monitor& m = h->mons[(size_t)plan.dfts[q]];
-      DumpBox bx{m.box.lo0, m.box.lo1, m.box.lo2, m.box.nx, m.box.ny, m.box.nz, {-1, -1, -1}};
-      for (int c : m.comps) if (c >= 3) { bx.off[c - 3] = (int)off; off += m.cells; }
-      tb.dft_off.push_back({bx.off[0], bx.off[1], bx.off[2]});
-      if (bx.off[0] < 0 && bx.off[1] < 0 && bx.off[2] < 0) continue;        // E components only: nothing to copy out
+      DumpBox bx{m.box.lo0, m.box.lo1, m.box.lo2, m.box.nx, m.box.ny, m.box.nz, {-1, -1, -1, -1, -1, -1}};
+      const int when = plan.dft_when[q];
+      for (int c : m.comps) if ((c >= 3 && (when & 1)) || (c < 3 && (when & 2))) { bx.off[c] = (int)off; off += m.cells; }
+      tb.dft_off.push_back({bx.off[0], bx.off[1], bx.off[2], bx.off[3], bx.off[4], bx.off[5]});
+      bool any = false;
+      for (int c = 0; c < 6; ++c) any = any || bx.off[c] >= 0;
+      if (!any) continue;                                                     // nothing of the middle step is needed
       for (int k = m.box.lo2; k < m.box.lo2 + m.box.nz; ++k) per_plane[(size_t)k].push_back((int)boxes.size());
       boxes.push_back(bx);
     }
@@ -927,17 +933,20 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
 // behind the sweep of the pair (n, n + 1) (the sets are swapped: h->f2 = what it read, h->f = what it wrote): everything the
 // monitors of `tb` record of steps n and n + 1, in one launch
 void pair_record(FdtdSolver* h, const F2Table* tb, long long n, hipStream_t st) {
-  // DFT monitors that recorded E^n in front of the sweep: their H terms from the sweep's copy of H^{n+1/2}
+  // DFT monitors: a record at step n took E^n in front of the sweep — its H terms from the sweep's copy of H^{n+1/2}; a record at
+  // step n+1 takes its E terms from the copy of E^{n+1} here and its H terms (H^{n+3/2}) from the write set, record_monitors
   for (size_t q = 0; q < tb->dfts.size(); ++q) {
     Monitor& m = h->mons[(size_t)tb->dfts[q]];
-    if (m.next >= m.steps.size() || m.steps[m.next] != n) continue;
-    DftDumpP r{};
-    for (size_t ic = 0; ic < m.comps.size(); ++ic)
-      if (m.comps[ic] >= 3) { r.slot[r.n] = (int)ic; r.off[r.n] = tb->dft_off[q][(size_t)(m.comps[ic] - 3)]; r.n++; }
-    if (r.n > 0)
-      launch_dft_record_dump(st, r, h->dump_buf, reinterpret_cast<float2*>(m.data), m.cells, (long long)m.comps.size() * m.cells,
-                             (const float2*)(m.phase_h + (long long)m.next * m.nf), m.nf);
-    m.next++;
+    for (int pass = 0; pass < 2; ++pass) {
+      if (m.next >= m.steps.size() || m.steps[m.next] != n + pass) continue;
+      DftDumpP r{};
+      for (size_t ic = 0; ic < m.comps.size(); ++ic)
+        if ((m.comps[ic] >= 3) == (pass == 0)) { r.slot[r.n] = (int)ic; r.off[r.n] = tb->dft_off[q][(size_t)m.comps[ic]]; r.n++; }
+      if (r.n > 0)
+        launch_dft_record_dump(st, r, h->dump_buf, reinterpret_cast<float2*>(m.data), m.cells, (long long)m.comps.size() * m.cells,
+                               (const float2*)((pass == 0 ? m.phase_h : m.phase_e) + (long long)m.next * m.nf), m.nf);
+      if (pass == 0) m.next++;
+    }
   }
   if (tb->mons.empty()) return;
   PairRecP r{};
@@ -2594,6 +2603,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       launch_sources(h, false, n, 0, nz, st);              // H-side sources of step n act on H^{n-1/2}, as before a single step
       if (launch_fused2(h, n, st, tb, &sources2_done, &damp2_done)) return -1;
       pair_record(h, tb, n, st);                           // (H^{n+3/2} is not touched by the E-side sources that follow)
+      if (rec_at(n + 1)) record_monitors(h, n + 1, true, st);      // DFT records at the middle step: their H terms, from the write set
       if (!sources2_done) launch_sources(h, true, n + 1, 0, nz, st);
       if (h->has_damp && !damp2_done) launch_damp(h, true, 0, nz, st);
       fill_ghost_fused(h, st);

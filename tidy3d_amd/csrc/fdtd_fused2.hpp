@@ -19,8 +19,8 @@ struct InjP {
   const float* val2;                       // source terms of step n+1 (nullptr: not available; then there are no H-side nodes)
   int e2_in_sweep;                         // the E-side terms of step n+1 are added to E^{n+2} by the sweep (else: by the caller behind it)
   float* cap;                              // samples of the middle step (pair_record_kernel)
-  // H^{n+1/2} over the boxes of DFT monitors that record at step n (their H terms are accumulated behind the sweep,
-  // dft_record_dump_kernel): boxes of plane k = dlist[dstart[k] .. dstart[k + 1])
+  // The middle step over the boxes of DFT monitors: H^{n+1/2} for a record at step n (its H terms), E^{n+1} for a record at step
+  // n+1 (its E terms) — accumulated behind the sweep, dft_record_dump_kernel.  Boxes of plane k = dlist[dstart[k] .. dstart[k + 1])
   const int* dstart;
   const int* dlist;
   const struct DumpBox* dboxes;
@@ -28,7 +28,7 @@ struct InjP {
 };
 struct DumpBox {
   int lo0, lo1, lo2, nx, ny, nz;           // the monitor's box
-  int off[3];                              // offset of the H_x / H_y / H_z block ([nz][ny][nx], the monitor's cell order) in `dump`, -1 = not recorded
+  int off[6];                              // offset of the E_x .. H_z block ([nz][ny][nx], the monitor's cell order) in `dump`, -1 = not needed
 };
 constexpr int kMaxDumps = 8;
 // absorber layers (damp_kernel's per-axis factor tables: fb at cell boundaries, fc at cell centres; 1 outside the layers);
@@ -65,8 +65,8 @@ struct PairRecP {
 };
 void launch_pair_record(hipStream_t st, const PairRecP& r, long long max_cells, const GridP& g, const FieldP& a, const FieldP& b,
                         const float* cap);
-// acc[f][slot][cell] += dump[cell] * phase[f]: the H terms of a DFT record from the sweep's copy of H^{n+1/2} (the operations of
-// dft_record_multi_kernel); n_h entries: (slot, offset into dump)
+// acc[f][slot][cell] += dump[cell] * phase[f]: terms of a DFT record from the sweep's copy of the middle step (the operations of
+// dft_record_multi_kernel); n entries: (slot, offset into dump)
 struct DftDumpP { int n; int slot[3]; int off[3]; };
 void launch_dft_record_dump(hipStream_t st, const DftDumpP& r, const float* dump, float2* acc, long long cells, long long fstride,
                             const float2* phase, int nf);

@@ -514,8 +514,8 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
             for (int e = 0; e < V; ++e) { e1yn[e] *= bx[e] * cyv * bzk; e1zn[e] *= bx[e] * byv * czk; }
           }
         }
-        // H^{n+1/2} over the boxes of DFT monitors that record at step n (in front of the damping / sources of step n+1, as between two
-        // single steps)
+        // the middle step over the boxes of DFT monitors: H^{n+1/2} for records at step n, E^{n+1} (behind its sources and damping)
+        // for records at step n+1 — what the record launches of two single steps would read
         if constexpr (MON) {
           if (own && k >= k0 && k < k1) {
             for (int q = d0; q < d1; ++q) {
@@ -527,9 +527,12 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
                 for (int e = 0; e < V; ++e) {
                   const int lx = i0o + e - bx.lo0;
                   if (lx >= 0 && lx < bx.nx && act) {
-                    if (bx.off[0] >= 0) inj.dump[bx.off[0] + rowo + lx] = hxn[e];
-                    if (bx.off[1] >= 0) inj.dump[bx.off[1] + rowo + lx] = hyn[e];
-                    if (bx.off[2] >= 0) inj.dump[bx.off[2] + rowo + lx] = hzn[e];
+                    if (bx.off[0] >= 0) inj.dump[bx.off[0] + rowo + lx] = e1xn[e];
+                    if (bx.off[1] >= 0) inj.dump[bx.off[1] + rowo + lx] = e1yn[e];
+                    if (bx.off[2] >= 0) inj.dump[bx.off[2] + rowo + lx] = e1zn[e];
+                    if (bx.off[3] >= 0) inj.dump[bx.off[3] + rowo + lx] = hxn[e];
+                    if (bx.off[4] >= 0) inj.dump[bx.off[4] + rowo + lx] = hyn[e];
+                    if (bx.off[5] >= 0) inj.dump[bx.off[5] + rowo + lx] = hzn[e];
                   }
                 }
               }
