@@ -127,6 +127,9 @@ def run(simulation, task_name: Optional[str] = None, folder_name: str = "default
                          f"(time step {steps_done}).")
         if diverged:
             lines.append("WARNING: field divergence detected, exiting solver.")
+        pairs = int(getattr(stats, "fused2_pairs", 0))
+    if pairs:
+        lines.append(f"Two time steps per sweep: {pairs} step pairs ({2 * pairs} of {steps_done} steps).")
     lines += ["", f"Setup time (s):  {setup_s:.4f}", f"Solver time (s): {solve_s:.4f}",
               f"Time-stepping speed (cells/s): {spec.n_cells * steps_done / max(solve_s, 1e-9):.2e}"]
     sim_data = assemble(disc, raw, log="\n".join(lines), diverged=diverged, n_steps_run=steps_done, device_lib=used_lib, device=device)
