@@ -175,7 +175,7 @@ def roofline_entry(st, kr, local_cells, cells, K, elapsed, world, workload, spec
          "algorithmic_bytes_per_launch": dom_bytes,
          "algorithmic_bytes_per_cell": dom_bytes / local_cells,
          "time_steps_per_launch": 2 if two_step else 1,
-         "whole_step_frac": (dom_bytes / local_cells * cells * K / elapsed) / (HBM_PEAK * world),
+         "whole_step_frac": (dom_bytes / local_cells / (2 if two_step else 1) * cells * K / elapsed) / (HBM_PEAK * world),
          "whole_step_frac_vs_survey_8d": (2 * BYTES_PER_CELL_PASS * cells * K / elapsed) / (HBM_PEAK * world)}
     if two_step:
         shape = int(st.fused2_shape)
