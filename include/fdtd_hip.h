@@ -83,7 +83,28 @@ typedef struct FdtdStats {
   int64_t graph_pairs;       /* step pairs replayed as captured hipGraphs in the last fdtd_run (FDTD_OPT_GRAPH) */
   int64_t fused2_pairs;      /* step pairs advanced by the two-steps-per-sweep kernel in the last fdtd_run (FDTD_OPT_TWOSTEP) */
   int64_t fused2_shape;      /* its tile shape: waves per workgroup | planes per chunk << 6 (0 = no pair was taken) */
+  int64_t shell_pairs;       /* of those: pairs of a CPML-walled grid — the two-step sweep over the bulk, the shell (CPML slabs + collar)
+                                as two single steps beside it on the second stream (FDTD_OPT_SHELL_PAIRS) */
+  double  shell_kernel_ms;   /* with FDTD_FLAG_TIME_KERNELS: summed durations of the shell launches (they overlap the bulk sweep) */
+  int64_t shell_kernel_launches;
+  int32_t fused2_off_reason; /* why the last fdtd_run took NO step pairs: FDTD_F2_OFF_* (0 = it took some, or had no chance to: < 2 steps) */
+  int32_t struct_bytes;      /* sizeof(FdtdStats) of the library that filled this in (a binding checks it against its own layout) */
 } FdtdStats;
+
+/* FdtdStats.fused2_off_reason: what keeps a run on single steps (the first reason found) */
+enum { FDTD_F2_OFF_NONE = 0,
+       FDTD_F2_OFF_DISABLED = 1,          /* FDTD_OPT_TWOSTEP = 0 (or another schedule was asked for) */
+       FDTD_F2_OFF_TOO_SMALL = 2,         /* grids below 2^20 cells are bound by launches, not by bytes */
+       FDTD_F2_OFF_COMM = 3,              /* z-slab rank (RCCL communicator): ghost planes are exchanged every step */
+       FDTD_F2_OFF_PML = 4,               /* CPML present and shell pairs not possible: switched off, slab-kernel CPML asked for,
+                                             layers too thick for the grid, absorber layers on another axis */
+       FDTD_F2_OFF_ADE = 5,               /* dispersive media (auxiliary differential equation state per step) */
+       FDTD_F2_OFF_TFSF = 6,              /* total-field / scattered-field surfaces */
+       FDTD_F2_OFF_BOUNDARY = 7,          /* periodic / Bloch faces, PMC on a plus face, rows not a multiple of 4 cells */
+       FDTD_F2_OFF_H_SOURCE_ABSORBER = 8, /* magnetic point sources together with absorber layers */
+       FDTD_F2_OFF_SEAM_SOURCE = 9,       /* an H_y / H_z source node in the column left of a seam between 256-cell x tiles */
+       FDTD_F2_OFF_SOURCES = 10,          /* more than 256 source nodes (mode planes, current sheets), or H-side nodes without room for their table */
+       FDTD_F2_OFF_VARIANT = 11 };        /* the run is not on the fused sweep at all (two-pass kernels) */
 
 /* progress callback: (step, time [s], field_decay) -> non-zero aborts the run (Ctrl-C path).
  * Mirrors the (perc_done, field_decay) pair the cloud reports (ref web/core/task_core.py:537). */
@@ -246,6 +267,9 @@ enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_R
                                  the min faces) or absorber layers, point sources, small time monitors, one GPU, no decay check on the middle step — everything else
                                  takes single steps): -1 = default (on, tile shape by grid size), 0 = off, else waves per workgroup
                                  (4 ... 16; W - 3 rows of a tile are written) + 64 * planes per chunk (0 = by grid size) */
+       FDTD_OPT_SHELL_PAIRS = 17, /* step pairs on grids walled by CPML (the two-step sweep over the bulk, the shell — CPML slabs + a
+                                     two-cell collar — as two single steps beside it; bit-identical to single steps): -1 = default (on), 0 = off */
+       FDTD_OPT_STRIP = 18, /* x strips of a shell step: planes per workgroup (1 ... 63) + 64 * workgroups per CU their registers are cut for (3 or 4) */
        FDTD_OPT_LDS_PAD = 10 /* measuring aid: extra dynamic LDS per workgroup of the sweep in bytes (lowers its occupancy) */ };
 int fdtd_set_option(FdtdSolver* h, int key, int value);
 int fdtd_reset(FdtdSolver* h);      /* zero fields, auxiliaries, monitors and the step counter */

@@ -1,0 +1,130 @@
+"""Shell pairs on the device (fdtd_capi.hip): step pairs on grids walled by CPML — the two-step sweep over the bulk, the shell
+(CPML slabs + collar) as two single steps beside it on the second stream — held to single steps bit for bit and to the fp64
+oracle directly:
+
+  (a) the parity cases `pml_box` and `stable_pml_box` (three times their size) THROUGH pairs <= 2e-5 from the oracle;
+  (b) a 520 x 72 x 72 grid — three x tiles, odd x layer counts 5 / 3, CPML on all six faces, a lossy bar through the seam and
+      into the low-x layers, a PEC box, dipoles next to the seams and to both x slabs, monitors that reach into the shell
+      (their pairs give way) — pairs == single steps bit for bit (fields and records), and <= 2e-5 from the oracle;
+  (c) the bench V2 spec (materials + 12 CPML layers on six faces, random initial fields) at 320^3 and at BASELINE's 512^3:
+      pairs == single steps bit for bit, three times over (two streams: a race would show as differing bits).
+"""
+import numpy as np
+import pytest
+
+import tidy3d_amd.schema as td
+from tidy3d_amd import lib as L
+from tidy3d_amd.discretize import discretize
+from tidy3d_amd.engine import HipEngine
+
+from cases import CASES, DL, PULSE, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def _run(spec, lib, twostep=-1, init=None, steps=None, runs=None):
+    with HipEngine(spec, lib=lib, axis_shift=0) as e:
+        e.set_option(L.OPT_TWOSTEP, twostep)
+        if init is not None:
+            for c in range(6):
+                e.set_field(c, init[c])
+        pairs = 0
+        for r in (runs or [steps]):
+            st = e.run(r)
+            pairs += int(st.shell_pairs)
+        return [e.get_field(c) for c in range(6)], e.results(), pairs
+
+
+@pytest.mark.parametrize("name,w,zc", [("pml_box", 5, 4), ("pml_box", 16, 32), ("stable_pml_box", 8, 8)])
+def test_parity_cases_through_shell_pairs_vs_oracle(name, w, zc, hip_lib):
+    from oracle.fdtd_numpy import OracleFdtd
+    fn = CASES[name]
+    sim = fn(tuple(int(n * 3) for n in fn.__defaults__[0]))
+    disc = discretize(sim, n_steps=100)
+    o = OracleFdtd(disc.spec)
+    ref = o.run()
+    f, got, pairs = _run(disc.spec, hip_lib, twostep=w + 64 * zc)
+    assert pairs > 20, pairs
+    scale = max(np.linalg.norm(v) / np.sqrt(v.size) for v in ref.values())
+    for k in ref:
+        den = max(np.linalg.norm(ref[k]), 0.5 * scale * np.sqrt(ref[k].size))
+        assert np.linalg.norm(np.asarray(got[k]) - ref[k]) / den < TOL, k
+    en = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in o.E))
+    hn = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in o.H))
+    for c in range(3):
+        assert np.linalg.norm(f[c] - o.E[c]) / en < TOL, c
+        assert np.linalg.norm(f[3 + c] - o.H[c]) / hn < TOL, c
+
+
+def three_x_tile_cpml_sim(N=(512, 64, 64)):
+    sx, sy, sz = (n * DL for n in N)
+    structures = [
+        td.Structure(geometry=td.Sphere(center=(0.35 * sx, 0.05, 0.1), radius=0.9), medium=td.Medium(permittivity=2.2)),
+        # a lossy bar that runs through the x tile boundary at cell 256 and into the low-x CPML
+        td.Structure(geometry=td.Box(center=(-0.2 * sx, -0.4, -0.3), size=(0.7 * sx, 0.8, 0.6)),
+                     medium=td.Medium(permittivity=3.0, conductivity=0.02)),
+        td.Structure(geometry=td.Box(center=(0.1 * sx, 0.6, 0.5), size=(0.5, 0.4, 0.3)), medium=td.PEC)]
+    bspec = td.BoundarySpec(x=td.Boundary(minus=td.PML(num_layers=5), plus=td.PML(num_layers=3)),
+                            y=td.Boundary.pml(num_layers=4),
+                            z=td.Boundary(minus=td.PML(num_layers=3), plus=td.PML(num_layers=5)))
+    sources = [td.PointDipole(center=(-0.5 * sx + 251.3 * DL, 0.13, 0.07), source_time=PULSE, polarization="Ez"),
+               td.PointDipole(center=(-0.5 * sx + 3.2 * DL, -0.21, 0.33), source_time=PULSE, polarization="Hy"),
+               td.PointDipole(center=(0.5 * sx - 6.6 * DL, 0.4, -0.5), source_time=PULSE, polarization="Ex"),
+               td.PointDipole(center=(0.0, -1.2, 1.1), source_time=PULSE, polarization="Hz")]
+    monitors = [td.FieldTimeMonitor(center=(0, 0, 0), size=(td.inf, 0.4, 0), name="t", colocate=False, interval=9),
+                td.FieldMonitor(center=(0, 0, 0.2), size=(td.inf, td.inf, 0), freqs=[2.5e14, 3e14], name="f"),
+                td.FieldTimeMonitor(center=(0.2, 0.1, -0.1), size=(0, 0, 0), name="probe", colocate=False, interval=1),
+                td.FieldMonitor(center=(0, 0.1, 0), size=(8.0, 0, 1.5), freqs=[2.5e14, 3e14], name="f_in", colocate=False)]
+    return td.Simulation(size=(sx, sy, sz), grid_spec=td.GridSpec.uniform(dl=DL), run_time=1e-12,
+                         structures=structures, sources=sources, monitors=monitors, boundary_spec=bspec, shutoff=0)
+
+
+def test_three_x_tiles_shell_pairs_bit_identical_and_oracle(hip_lib):
+    from oracle.fdtd_numpy import OracleFdtd
+    disc = discretize(three_x_tile_cpml_sim(), n_steps=60)
+    spec = disc.spec
+    assert spec.shape == (520, 72, 72), spec.shape
+    ref_f, ref_m, p0 = _run(spec, hip_lib, twostep=0, runs=[25, 35])
+    assert p0 == 0
+    for ts in (-1, 5 + 64 * 7, 16 + 64 * 32):
+        f, m, p1 = _run(spec, hip_lib, twostep=ts, runs=[25, 35])
+        assert p1 > 8, (ts, p1)
+        for c in range(6):
+            assert np.array_equal(f[c], ref_f[c]), (ts, c, float(np.abs(f[c] - ref_f[c]).max()))
+        for k in ref_m:
+            assert np.array_equal(m[k], ref_m[k]), (ts, k)
+    o = OracleFdtd(spec)
+    om = o.run()
+    for k in om:
+        assert rel_err(ref_m[k], om[k]) < TOL, (k, rel_err(ref_m[k], om[k]))
+    en = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in o.E))
+    hn = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in o.H))
+    for c in range(3):
+        assert np.linalg.norm(ref_f[c] - o.E[c]) / en < TOL, c
+        assert np.linalg.norm(ref_f[3 + c] - o.H[c]) / hn < TOL, c
+
+
+def _bench_init(n):
+    out = []
+    for c in range(6):
+        arr = np.empty((n, n, n), dtype=np.float32)
+        for k in range(n):
+            arr[k] = np.random.default_rng(c * 100003 + k).uniform(-1e-3, 1e-3, (n, n)).astype(np.float32)
+        out.append(arr)
+    return out
+
+
+@pytest.mark.parametrize("n,steps", [(320, 14), (512, 12)])
+def test_bench_v2_spec_shell_pairs_equal_single_steps(n, steps, hip_lib):
+    """bench.py's `workloads.v2`: what the CPML throughput number is measured on."""
+    from bench import build_spec
+    spec = build_spec(n, steps + 4, "v2")
+    init = _bench_init(n)
+    ref, _, p0 = _run(spec, hip_lib, twostep=0, init=init, steps=steps)
+    assert p0 == 0 and all(np.isfinite(x).all() for x in ref) and max(np.abs(x).max() for x in ref) > 0
+    for rep in range(3):
+        got, _, p1 = _run(spec, hip_lib, init=init, steps=steps)
+        assert p1 == steps // 2, p1
+        for c in range(6):
+            assert np.array_equal(got[c], ref[c]), (rep, c, float(np.abs(got[c] - ref[c]).max()))

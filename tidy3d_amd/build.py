@@ -5,15 +5,16 @@ import os
 import shutil
 import subprocess
 import sys
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfdtd_hip.so")
-SOURCES = [os.path.join(CSRC, "fdtd_capi.hip"), os.path.join(CSRC, "fdtd_fused2.hip")]
+SOURCES = [os.path.join(CSRC, "fdtd_capi.hip"), os.path.join(CSRC, "fdtd_fused2.hip"), os.path.join(CSRC, "fdtd_fused2c.hip")]
 # per-source flags: the two-steps-per-sweep kernels are built with the SLP vectorizer off (fdtd_fused2.hpp)
-SOURCE_FLAGS = {"fdtd_fused2.hip": ["-fno-slp-vectorize"]}
+SOURCE_FLAGS = {"fdtd_fused2.hip": ["-fno-slp-vectorize"], "fdtd_fused2c.hip": ["-fno-slp-vectorize"]}
 DEPS = SOURCES + [os.path.join(CSRC, "fdtd_kernels.hpp"), os.path.join(CSRC, "fdtd_kernels2.hpp"),
-                  os.path.join(CSRC, "fdtd_fused2.hpp"),
+                  os.path.join(CSRC, "fdtd_fused2.hpp"), os.path.join(CSRC, "fdtd_strip.hpp"),
                   os.path.join(HERE, "..", "include", "fdtd_hip.h"), os.path.abspath(__file__)]
 
 
@@ -38,23 +39,40 @@ def build(force: bool = False, verbose: bool = True) -> str:
     common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
               "-mllvm", "-disable-lsr", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value", "-I/opt/rocm/include",
               *os.environ.get("FDTD_EXTRA_HIPCC_FLAGS", "").split()]     # e.g. -DFDTD_PLACEMENT_PROBE for scripts/probe_layout.py
+    # objects go to a private directory (two builds at once — ranks, CI jobs — must not race on fixed object paths), and a
+    # failed compile takes its siblings down before it is reported
+    tmp = tempfile.mkdtemp(prefix="fdtd_build_")
     objs, procs = [], []
-    for src in SOURCES:                    # the translation units compile side by side
-        obj = os.path.join(CSRC, os.path.basename(src) + ".o")
-        cmd = [*common, *SOURCE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
+    try:
+        for src in SOURCES:                    # the translation units compile side by side
+            obj = os.path.join(tmp, os.path.basename(src) + ".o")
+            cmd = [*common, *SOURCE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((cmd, subprocess.Popen(cmd)))
+            objs.append(obj)
+        failed = None
+        for cmd, pr in procs:
+            rc = pr.wait()
+            if rc != 0 and failed is None:
+                failed = subprocess.CalledProcessError(rc, cmd)
+                for _, other in procs:
+                    if other.poll() is None:
+                        other.kill()
+        if failed is not None:
+            raise failed
+        out = os.path.join(tmp, "libfdtd_hip.so")
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd)))
-        objs.append(obj)
-    for cmd, pr in procs:
-        if pr.wait() != 0:
-            raise subprocess.CalledProcessError(pr.returncode, cmd)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
-    for o in objs:
-        os.remove(o)
+        subprocess.run(cmd, check=True)
+        shutil.move(out, LIB)
+    finally:
+        for _, pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+                pr.wait()
+        shutil.rmtree(tmp, ignore_errors=True)
     return LIB
 
 

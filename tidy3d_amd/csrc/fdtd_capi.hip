@@ -18,6 +18,7 @@
 #include "../../include/fdtd_hip.h"
 #include "fdtd_kernels.hpp"
 #include "fdtd_fused2.hpp"
+#include "fdtd_strip.hpp"
 
 using namespace fdtd;
 
@@ -129,6 +130,8 @@ struct FdtdSolver {
   FieldP f{};                        // interior plane 0 of the CURRENT field set
   float* fbase2[6] = {};             // second set for the fused (ping-pong) sweep, lazily allocated
   FieldP f2{};
+  float* fbase3[6] = {};             // third set: the middle step of a shell pair over the shell (lazily allocated)
+  FieldP f3{};
   float* step_base[2] = {};          // 1/primal_z, 1/dual_z with one ghost entry on each side
   size_t field_bytes = 0;
   float *ip[3] = {}, *idl[3] = {};
@@ -217,6 +220,14 @@ struct FdtdSolver {
   int twostep_w = -1, twostep_zc = 0;      // -1 / 0: chosen by fused2_shape
   int twostep_w_used = 0, twostep_zc_used = 0;
   long long fused2_pairs = 0;
+  // shell pairs: the two-step sweep over the bulk of a CPML-walled grid, its shell (slabs + collar) by two single steps beside
+  // it (fdtd_run).  shell_on: -1 = default (on), 0 = off
+  int shell_on = -1;
+  int strip_zc = 8;                   // planes per workgroup of the x strips
+  int strip_occ = 3;                  // their register budget: workgroups per CU (3 or 4)
+  long long shell_pairs = 0;
+  int f2_off_reason = 0;              // why the last fdtd_run took no step pairs (FDTD_F2_OFF_*), 0 = it did / could
+  hipEvent_t ev_shell_a = nullptr, ev_shell_b = nullptr;
   float* seam_buf = nullptr;          // intermediate values on the seams between x tiles
   float* inj_val = nullptr;           // source terms applied between the two steps
   float* cap_val = nullptr;           // samples of the middle step (small time monitors)
@@ -521,8 +532,11 @@ void swap_psi_h(FdtdSolver* h, int pml_inside) {
 // Tile rows: all of them (ty_n < 0) or  [0, ty_a) + [ty_a + ty_gap, ty_a + ty_gap + (ty_n - ty_a)).
 // pml_inside: axes whose CPML recursions this launch carries (its tiles must not touch members of other
 // in-sweep axes): 0 -> plain instantiation, 1 -> the x-only one, anything else -> the all-axes one.
+// A shell step (ShellSets) names its own read / write sets and psi parity, and the rows [ex_j0, ex_j1) its launch leaves alone.
+struct ShellSets { FieldP src, dst; int parity; int ex_j0, ex_j1; };
 int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pml_inside = 0, int k2beg = 0,
-                       int k2end = 0, int ty_n = -1, int ty_a = 0, int ty_gap = 0, bool edge = false) {
+                       int k2end = 0, int ty_n = -1, int ty_a = 0, int ty_gap = 0, bool edge = false,
+                       const ShellSets* sh = nullptr) {
   if (kend <= kbeg) {                 // first plane range empty: the second one takes its place
     if (k2end <= k2beg) return 0;
     kbeg = k2beg; kend = k2end; k2beg = k2end = 0;
@@ -544,7 +558,8 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pm
   // Shorter chunks turn them into about one wave of workgroups (the prologue plane per chunk is cheap on 6 % of the tiles).
   // On ONE GPU the edge launches run on the second stream beside the interior launch and are off the critical path: there
   // the long chunks stay (512^3 V2 inside one engine, profiles/r3f: 16 planes 1.367 ms, 8 planes 1.377, 4 planes 1.394).
-  if (edge && (h->edge_zchunk > 0 || (h->edge_zchunk < 0 && h->comm != nullptr))) {
+  if (edge && sh && h->edge_zchunk < 0) zc = std::min(zc, 8);       // shell steps (beside the bulk sweep of a shell pair): profiles/r4d
+  else if (edge && (h->edge_zchunk > 0 || (h->edge_zchunk < 0 && h->comm != nullptr))) {
     const int nby_e = ty_n < 0 ? (g.ny + R - 1) / R : ty_n;
     const long long wg_planes = (long long)((g.nx + 255) / 256) * nby_e * ((kend - kbeg) + std::max(0, k2end - k2beg));
     const int want = h->edge_zchunk > 0 ? h->edge_zchunk : (int)std::max(2LL, std::min((long long)zc, wg_planes / 1024));
@@ -573,11 +588,13 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pm
   const int threads = 64 * (R + 1);
   int lb = h->fused_lb ? h->fused_lb : (threads <= 256 ? 256 : (threads <= 512 ? 512 : 1024));
   if (lb < threads) lb = threads <= 512 ? 512 : 1024;
-  time_begin(h, 2, st);
-  const PmlP* pm = pml_inside ? h->pml_blk[pml_inside][h->pml_parity] : nullptr;
+  time_begin(h, sh ? 3 : 2, st);
+  const PmlP* pm = pml_inside ? h->pml_blk[pml_inside][sh ? sh->parity : h->pml_parity] : nullptr;
+  const FieldP fa = sh ? sh->src : h->f, fb = sh ? sh->dst : h->f2;
+  const int ex_j0 = sh ? sh->ex_j0 : 0, ex_j1 = sh ? sh->ex_j1 : 0;
 #define FDTD_LAUNCH_FUSED_H(MATV, LBV, PMLV, HV)                                                       \
-  hipLaunchKernelGGL((fused_step_kernel<MATV, LBV, PMLV, HV>), grid, block, shmem, st, g, h->f, h->f2, s, m, kbeg, \
-                     kend, zc, pmc, nbx, nby, nbz, remap, pm, nbz1, k2beg, k2end, ty_a, ty_gap)
+  hipLaunchKernelGGL((fused_step_kernel<MATV, LBV, PMLV, HV>), grid, block, shmem, st, g, fa, fb, s, m, kbeg, \
+                     kend, zc, pmc, nbx, nby, nbz, remap, pm, nbz1, k2beg, k2end, ty_a, ty_gap, ex_j0, ex_j1)
   // Non-temporal field stores (FDTD_OPT_MEM_HINTS) in the instantiations WITHOUT CPML only: measured inside one engine
   // (profiles/r02z_probe_same_engine_cache_hints.jsonl) they take 2.1 % off the plain sweep and 3.1 % off the one with
   // materials, and ADD 13 % to the CPML-carrying ones (2-3 waves per SIMD: the slower store completion is not hidden).
@@ -673,28 +690,33 @@ bool fused2_shape(const FdtdSolver* h, int* W, int* zc) {
   return found;
 }
 
-bool fused2_eligible(const FdtdSolver* h) {
-  if (h->twostep_w == 0) return false;
-  { int W, zc; if (!fused2_shape(h, &W, &zc)) return false; }
-  if (h->comm || any_pml(h) || !h->ade.empty() || !h->tfsf.empty()) return false;
+// Why a run takes no step pairs (FDTD_F2_OFF_*, include/fdtd_hip.h); 0 = nothing in the problem keeps the two-step sweep
+// from it.  CPML is not a reason here: the caller then asks shell_eligible.
+int fused2_why_not(const FdtdSolver* h) {
+  if (h->twostep_w == 0) return FDTD_F2_OFF_DISABLED;
+  { int W, zc; if (!fused2_shape(h, &W, &zc)) return FDTD_F2_OFF_TOO_SMALL; }
+  if (h->comm) return FDTD_F2_OFF_COMM;
+  if (!h->ade.empty()) return FDTD_F2_OFF_ADE;
+  if (!h->tfsf.empty()) return FDTD_F2_OFF_TFSF;
   // PEC walls; the min faces may be PMC (the symmetry planes of a half / quarter / eighth domain)
   for (int f = 0; f < 6; ++f)
-    if (h->cfg.bc[f] != FDTD_BC_PEC && !((f & 1) == 0 && h->cfg.bc[f] == FDTD_BC_PMC)) return false;
-  if ((h->g.pec_z0 != 0) != (h->cfg.bc[4] == FDTD_BC_PEC) || h->g.nx % 4 || h->g.nz < 2) return false;
-  for (int a = 0; a < 3; ++a) if (h->mirror_wall[a] >= 0) return false;
+    if (h->cfg.bc[f] != FDTD_BC_PEC && !((f & 1) == 0 && h->cfg.bc[f] == FDTD_BC_PMC)) return FDTD_F2_OFF_BOUNDARY;
+  if ((h->g.pec_z0 != 0) != (h->cfg.bc[4] == FDTD_BC_PEC) || h->g.nx % 4 || h->g.nz < 2) return FDTD_F2_OFF_BOUNDARY;
+  for (int a = 0; a < 3; ++a) if (h->mirror_wall[a] >= 0) return FDTD_F2_OFF_BOUNDARY;
   long long nodes = 0;
   for (const PointSrc& s : h->psrc) {
     nodes += s.n_e + s.n_h;
     // absorber layers are applied inside the sweep, H-side sources of step n in front of it: damping would come after them
-    if (h->has_damp && s.n_h) return false;
+    if (h->has_damp && s.n_h) return FDTD_F2_OFF_H_SOURCE_ABSORBER;
     // an H_y / H_z source node in the column left of a seam between x tiles: the seam kernel rebuilds that value without it
     for (long long t = 0; t < s.n_h; ++t) {
       const int i = (int)(s.host_cell_h[(size_t)t] % h->g.nx), c = s.host_comp_h[(size_t)t];
-      if (c != 3 && i % 256 == 255 && i + 1 < h->g.nx) return false;
+      if (c != 3 && i % 256 == 255 && i + 1 < h->g.nx) return FDTD_F2_OFF_SEAM_SOURCE;
     }
   }
-  return nodes <= kMaxInj;
+  return nodes <= kMaxInj ? 0 : FDTD_F2_OFF_SOURCES;
 }
+bool fused2_eligible(const FdtdSolver* h) { return !any_pml(h) && fused2_why_not(h) == 0; }
 // the point sources of step n: all alive or all spent (the kernel applies the whole table or nothing)
 bool fused2_sources_uniform(const FdtdSolver* h, long long n) {
   bool any_alive = false, any_spent = false;
@@ -717,7 +739,8 @@ bool fused2_capturable(const FdtdSolver* h, const Monitor& m) {
 // time monitors (at most kPairMons).  The sweep copies their samples of the middle step (E^{n+1}, H^{n+1/2}) out; ONE launch
 // behind it (pair_record_kernel) writes everything they record of the pair — E^n and H^{n-1/2} are still in the set the
 // sweep read, H^{n+3/2} is in the set it wrote — so such a pair costs no record launch in front of the sweep.
-bool fused2_plan(const FdtdSolver* h, long long n, F2Plan* plan) {
+// `box` (shell pairs): the bulk the sweep covers — a monitor that records at either step must lie inside it.
+bool fused2_plan(const FdtdSolver* h, long long n, F2Plan* plan, const int* box_lo = nullptr, const int* box_hi = nullptr) {
   plan->mons.clear(); plan->dfts.clear(); plan->dft_when.clear();
   long long total = 0, dump = 0;
   for (size_t q = 0; q < h->mons.size(); ++q) {
@@ -727,6 +750,8 @@ bool fused2_plan(const FdtdSolver* h, long long n, F2Plan* plan) {
     if (!at_n && !at_m) continue;
     const BoxP& b = m.box;
     const bool inside = b.lo0 >= 0 && b.lo1 >= 0 && b.lo2 >= 0 && b.lo0 + b.nx <= h->g.nx && b.lo1 + b.ny <= h->g.ny && b.lo2 + b.nz <= h->g.nz;
+    if (box_lo && (b.lo0 < box_lo[0] || b.lo1 < box_lo[1] || b.lo2 < box_lo[2] || b.lo0 + b.nx > box_hi[0] ||
+                   b.lo1 + b.ny > box_hi[1] || b.lo2 + b.nz > box_hi[2])) return false;
     if (m.kind == FDTD_MON_DFT) {
       // A DFT record at the FIRST step: E^n is taken in front of the sweep as always; its H terms need H^{n+1/2}.  A record at
       // the MIDDLE step: its E terms need E^{n+1}; its H terms, H^{n+3/2}, are in the write set afterwards.  The sweep copies
@@ -862,16 +887,24 @@ const F2Table* fused2_table(FdtdSolver* h, const F2Plan& plan) {
 // applied inside the kernel; so are those of step n + 1 (*sources2_done) when their terms come from the table of all steps
 // and no source node lies next to a seam — else the caller applies them afterwards.  The middle step is copied out for the
 // monitors of `tb` (fused2_plan); pair_record (called by the caller behind the launch) writes their records.
-int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb, bool* sources2_done, bool* damp2_done = nullptr) {
+// With `clip` the launch covers that box only (the bulk of a shell pair): nothing outside it is written, the E-side sources
+// of step n + 1 are left to the caller, and the sets are NOT swapped (the shell launches beside it still name them).
+int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb, bool* sources2_done, bool* damp2_done = nullptr,
+                  const ClipP* clip = nullptr) {
   const GridP& g = h->g;
   if (ensure_second_set(h)) return -1;
   int W = 16, zc = 32;
   fused2_shape(h, &W, &zc);
-  zc = std::max(2, std::min(zc, g.nz));
+  const ClipP box = clip ? *clip : ClipP{0, g.nx, 0, g.ny, 0, g.nz};
+  // (beside the shell launches of a shell pair shorter chunks do better — workgroups retire, and hand their CU to a shell
+  //  workgroup, twice as often: 512^3 V2 inside one engine 16 x 16 1.206 / 1.219 ms per step, 16 x 24 1.225, 16 x 32 1.249 / 1.231,
+  //  profiles/r4d)
+  if (clip && h->twostep_zc <= 0) zc = std::min(zc, 16);
+  zc = std::max(2, std::min(zc, box.k1 - box.k0));
   h->twostep_w_used = W; h->twostep_zc_used = zc;
   const int R = W - 3;
-  const int nbx = (g.nx + 255) / 256, nby = (g.ny + R - 1) / R;
-  const int nbz = (g.nz + zc - 1) / zc;
+  const int nbx = (g.nx + 255) / 256, nby = (box.j1 - box.j0 + R - 1) / R;
+  const int nbz = (box.k1 - box.k0 + zc - 1) / zc;
   if (nbx > 1 && !h->seam_buf &&
       dev_alloc(h, &h->seam_buf, (size_t)(nbx - 1) * kSeamArrays * (size_t)(g.nz + 2) * (size_t)g.ny)) return -1;
   if (!h->inj_val && dev_alloc(h, &h->inj_val, (size_t)kMaxInj)) return -1;
@@ -888,7 +921,7 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
       inj.val = h->src_tab + n * h->src_tab_nodes;
       if (alive2) {
         inj.val2 = h->src_tab + (n + 1) * h->src_tab_nodes;
-        if (!h->src_on_seam) { inj.e2_in_sweep = 1; *sources2_done = true; }
+        if (!h->src_on_seam && !clip) { inj.e2_in_sweep = 1; *sources2_done = true; }
       }
     } else if (alive) {
       int off = 0;
@@ -926,11 +959,110 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
   StepP sp = step_params(h);
   time_begin(h, 2, st);
   const MatP mp = mat_params(h);
-  launch_fused2_step(st, W, (h->mem_hints ? 1 : 0) | (h->mat4 ? 2 : 0) | ((tb->mons.empty() && h->src_h_nodes == 0 && !tb->dstart) ? 0 : 4) | (h->has_damp ? 8 : 0),
-                     remap ? ((total + 7) / 8) * 8 : total, g, h->f, h->f2, sp, mp, zc, nbx, nby, nbz, remap, inj, h->seam_buf, dmp);
-  if (nbx > 1) launch_seams(st, g, h->f2, sp, mp, h->seam_buf, nbx - 1, dmp);
+  launch_fused2_step(st, W, (h->mem_hints ? 1 : 0) | (h->mat4 ? 2 : 0) | ((tb->mons.empty() && h->src_h_nodes == 0 && !tb->dstart) ? 0 : 4) |
+                     (clip ? 16 : (h->has_damp ? 8 : 0)),
+                     remap ? ((total + 7) / 8) * 8 : total, g, h->f, h->f2, sp, mp, zc, nbx, nby, nbz, remap, inj, h->seam_buf, dmp, box);
+  if (nbx > 1) launch_seams(st, g, h->f2, sp, mp, h->seam_buf, nbx - 1, dmp, box);
   time_end(h, st);
-  swap_sets(h);
+  if (!clip) swap_sets(h);
+  return 0;
+}
+
+// ---- shell pairs: two steps per sweep on grids walled by CPML ------------------------------------------------------------
+// An error made by ignoring a per-step feature travels one cell per half step, so after a step pair it is confined to the
+// feature's cells plus a collar.  The CPML recursions live in slabs on the faces: the two-step sweep (plain formulas) advances
+// the BULK  O = [lo + 2, hi0 - 1) per CPML axis (x rounded inwards to multiples of 4) — every intermediate value it forms for O
+// lies in cells where the plain update is the exact one — and the SHELL (the rest: slabs + collar, 16 % of a 512^3 grid with 12
+// layers) takes two single steps of the production kernels beside it, on the second stream:
+//     step one   set A -> set T (third set)   over the shell grown by one cell into the bulk (what step two differentiates)
+//                E-side sources of step n, H-side ones of step n + 1 on T
+//     step two   set T -> set B               over the shell
+// The shell is cut into z slabs (all rows: all-axes instantiation), y slabs between them (tile rows that meet a slab, the
+// rows of the bulk excluded: x + y instantiation) and x strips between those (strip_step_kernel).  Bulk and shell read A and
+// write disjoint cells of B: no order between them inside a pair.  psi is touched by the shell launches only (H-side
+// ping-pong: parity p in step one, p ^ 1 in step two, back to p).  Same kernels / formulas as single steps: the same bits.
+struct ShellGeom { int o0[3], o1[3]; };
+bool shell_geometry(const FdtdSolver* h, ShellGeom* G) {
+  const int N[3] = {h->g.nx, h->g.ny, h->g.nz};
+  for (int a = 0; a < 3; ++a) {
+    const PmlAxisDev& P = h->pml[a];
+    const int lo = P.ns > 0 ? P.lo : 0, hi0 = P.ns > 0 ? P.hi0 : N[a];
+    int o0 = lo > 0 ? lo + 2 : 0, o1 = hi0 < N[a] ? hi0 - 1 : N[a];
+    if (a == 0) { o0 = (o0 + 3) / 4 * 4; o1 = o1 / 4 * 4; }
+    if (o1 - o0 < (a == 0 ? 16 : 8)) return false;        // (also: the rounded x ranges met, lo == hi0 == n)
+    G->o0[a] = o0; G->o1[a] = o1;
+  }
+  return true;
+}
+
+int ensure_third_set(FdtdSolver* h) {
+  const GridP& g = h->g;
+  if (h->f3.ex) return 0;
+  const size_t fcount = (size_t)g.sxy * (g.nz + 2);
+  if (!h->fbase3[0] && alloc_field_set(h, h->fbase3, fcount, 2)) return -1;
+  h->f3.ex = h->fbase3[0] + g.sxy; h->f3.ey = h->fbase3[1] + g.sxy; h->f3.ez = h->fbase3[2] + g.sxy;
+  h->f3.hx = h->fbase3[3] + g.sxy; h->f3.hy = h->fbase3[4] + g.sxy; h->f3.hz = h->fbase3[5] + g.sxy;
+  return 0;
+}
+
+// one x strip of a shell step: columns [ci0, ci1), rows [j0, j1), planes [k0, k1)
+void launch_strip(FdtdSolver* h, const FieldP& src, const FieldP& dst, const PmlP* pm, int ci0, int ci1, int j0, int j1,
+                  int k0, int k1, hipStream_t st) {
+  if (ci1 <= ci0 || j1 <= j0 || k1 <= k0) return;
+  StripP sp;
+  sp.q = std::min(kStripMaxQ, (ci1 - ci0) / 4);             // lanes per row: the strip's width (16 columns: 4; 20: 5), 64 columns per x tile at most
+  sp.xorg = ci0; sp.ci0 = ci0; sp.ci1 = ci1; sp.j0 = j0; sp.j1 = j1; sp.kbeg = k0; sp.kend = k1;
+  sp.zchunk = h->strip_zc;
+  const int slots = (64 / sp.q) * kStripWaves;
+  sp.nbx = (ci1 - ci0 + 4 * sp.q - 1) / (4 * sp.q);
+  sp.nby = (j1 - j0 + slots - 2) / (slots - 1);
+  sp.nbz = (k1 - k0 + sp.zchunk - 1) / sp.zchunk;
+  const int pmc = h->cfg.bc[4] == FDTD_BC_PMC;
+  const dim3 grid((unsigned)(sp.nbx * sp.nby * sp.nbz)), block(64, kStripWaves);
+  time_begin(h, 3, st);
+  if (h->mat4 && h->strip_occ == 4) hipLaunchKernelGGL((strip_step_kernel<true, 4>), grid, block, 0, st, h->g, src, dst, step_params(h), mat_params(h), pm, sp, pmc);
+  else if (h->mat4) hipLaunchKernelGGL((strip_step_kernel<true, 3>), grid, block, 0, st, h->g, src, dst, step_params(h), mat_params(h), pm, sp, pmc);
+  else if (h->strip_occ == 4) hipLaunchKernelGGL((strip_step_kernel<false, 4>), grid, block, 0, st, h->g, src, dst, step_params(h), mat_params(h), pm, sp, pmc);
+  else hipLaunchKernelGGL((strip_step_kernel<false, 3>), grid, block, 0, st, h->g, src, dst, step_params(h), mat_params(h), pm, sp, pmc);
+  time_end(h, st);
+}
+
+// One step of the shell: set `src` -> set `dst`, H-side psi parity `parity`.  in[a] = [in0[a], in1[a]): the part of axis a that
+// belongs to someone else in this step (the bulk O in step two, O shrunk by one cell on its CPML sides in step one).
+int launch_shell_step(FdtdSolver* h, const FieldP& src, const FieldP& dst, int parity, const int in0[3], const int in1[3],
+                      int pml_in, hipStream_t st) {
+  const GridP& g = h->g;
+  const int R = h->rows_f, nby_all = (g.ny + R - 1) / R;
+  ShellSets sh{src, dst, parity, 0, 0};
+  // z slabs: the planes outside in[2], all rows
+  if (in0[2] > 0 || in1[2] < g.nz)
+    if (launch_fused_range(h, 0, in0[2], st, pml_in, in1[2], g.nz, -1, 0, 0, true, &sh)) return -1;
+  // y slabs: the planes of in[2], the tile rows that hold a row outside in[1] (the rows inside it excluded)
+  if (in0[1] > 0 || in1[1] < g.ny) {
+    const int ty_a = in0[1] > 0 ? std::min(nby_all, (in0[1] + R - 1) / R) : 0;
+    const int ty_c = in1[1] < g.ny ? std::max(ty_a, in1[1] / R) : nby_all;
+    sh.ex_j0 = in0[1]; sh.ex_j1 = in1[1];
+    if (launch_fused_range(h, in0[2], in1[2], st, pml_in & 3, 0, 0, ty_a + (nby_all - ty_c), ty_a, ty_c - ty_a, true, &sh)) return -1;
+  }
+  // x strips: planes of in[2], rows of in[1], the columns outside in[0]
+  if (in0[0] > 0 || in1[0] < g.nx) {
+    const PmlP* pm = h->pml_blk[pml_in][parity];
+    launch_strip(h, src, dst, pm, 0, in0[0], in0[1], in1[1], in0[2], in1[2], st);
+    launch_strip(h, src, dst, pm, in1[0], g.nx, in0[1], in1[1], in0[2], in1[2], st);
+  }
+  return 0;
+}
+
+// 0 = the run can take shell pairs (and *G holds the bulk), else the reason it cannot
+int shell_why_not(const FdtdSolver* h, ShellGeom* G) {
+  const int why = fused2_why_not(h);
+  if (why) return why;
+  if (!any_pml(h)) return FDTD_F2_OFF_PML;              // (nothing to do here: the plain pairs cover it)
+  if (h->shell_on == 0) return FDTD_F2_OFF_PML;
+  if (h->has_damp) return FDTD_F2_OFF_PML;              // absorber layers on one axis, CPML on another: single steps
+  // the shell runs the CPML recursions inside its sweeps (all axes), as a one-GPU step does by default
+  if (64 * (h->rows_f + 1) > 512 || (h->pml_fused >= 0 && (h->pml_fused & pml_in_sweep_mask(h)) != pml_in_sweep_mask(h))) return FDTD_F2_OFF_PML;
+  if (!shell_geometry(h, G)) return FDTD_F2_OFF_PML;
   return 0;
 }
 
@@ -1327,11 +1459,13 @@ void launch_damp(FdtdSolver* h, bool e_side, int kbeg, int kend, hipStream_t st)
     }
 }
 
-void launch_sources(FdtdSolver* h, bool e_side, long long n, int kbeg, int kend, hipStream_t st, bool replica = false) {
+void launch_sources(FdtdSolver* h, bool e_side, long long n, int kbeg, int kend, hipStream_t st, bool replica = false,
+                    const FieldP* fs = nullptr) {
   if (kend <= kbeg) return;
   const long long zlo = (long long)kbeg * h->g.sxy, zhi = (long long)kend * h->g.sxy;
   const int off = e_side ? 0 : 3;
   float *f0 = field_ptr(h, off), *f1 = field_ptr(h, off + 1), *f2 = field_ptr(h, off + 2);
+  if (fs) { f0 = e_side ? fs->ex : fs->hx; f1 = e_side ? fs->ey : fs->hy; f2 = e_side ? fs->ez : fs->hz; }
   for (Tfsf& t : h->tfsf) {
     if (n >= t.n_steps) continue;
     const TfsfList& L = e_side ? t.e : t.h;
@@ -1729,6 +1863,8 @@ void fdtd_destroy(FdtdSolver* h) {
   if (h->ev_h_bnd) hipEventDestroy(h->ev_h_bnd);
   if (h->ev_e_int) hipEventDestroy(h->ev_e_int);
   if (h->ev_e_bnd) hipEventDestroy(h->ev_e_bnd);
+  if (h->ev_shell_a) hipEventDestroy(h->ev_shell_a);
+  if (h->ev_shell_b) hipEventDestroy(h->ev_shell_b);
   if (h->stream) hipStreamDestroy(h->stream);
   if (h->comm_stream && !h->streams_shared) hipStreamDestroy(h->comm_stream);
   delete h;
@@ -2156,6 +2292,7 @@ int fdtd_reset(FdtdSolver* h) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   for (int c = 0; c < 6; ++c) HIPCHK(h, hipMemset(h->fbase[c], 0, h->field_bytes));
   for (int c = 0; c < 6; ++c) if (h->fbase2[c]) HIPCHK(h, hipMemset(h->fbase2[c], 0, h->field_bytes));
+  for (int c = 0; c < 6; ++c) if (h->fbase3[c]) HIPCHK(h, hipMemset(h->fbase3[c], 0, h->field_bytes));
   for (int a = 0; a < 3; ++a) {
     PmlAxisDev& P = h->pml[a];
     if (P.n == 0) continue;
@@ -2509,12 +2646,57 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     return 0;
   };
   bool f2_ok = fused && !tb_ok && fused2_eligible(h);
-  if (f2_ok) {
-    if (fused2_sources(h)) return -1;
-    if (h->src_h_nodes > 0 && !h->src_tab) f2_ok = false;      // H-side nodes take their terms of step n+1 from the table only
+  ShellGeom sg{};
+  bool f2s_ok = false;
+  h->f2_off_reason = !fused ? FDTD_F2_OFF_VARIANT : (tb_ok ? FDTD_F2_OFF_DISABLED : 0);
+  if (fused && !tb_ok && !f2_ok) {
+    h->f2_off_reason = any_pml(h) ? shell_why_not(h, &sg) : fused2_why_not(h);
+    f2s_ok = any_pml(h) && h->f2_off_reason == 0;
   }
+  if (f2_ok || f2s_ok) {
+    if (fused2_sources(h)) return -1;
+    if (h->src_h_nodes > 0 && !h->src_tab) { f2_ok = f2s_ok = false; h->f2_off_reason = FDTD_F2_OFF_SOURCES; }      // H-side nodes take their terms of step n+1 from the table only
+  }
+  if (f2s_ok && probe_stream_overlap(h)) return -1;
+  // steps n and n + 1 of a grid walled by CPML: the bulk as ONE two-step sweep on st, the shell as two single steps on cs
+  auto shell_pair = [&](long long n, const F2Table* tb) -> int {
+    hipStream_t cs = (h->shell_on == 2) ? st : h->comm_stream;       // (2: shell behind the bulk on ONE stream — a measuring aid)
+    const int pml_in = 7 & pml_in_sweep_mask(h);
+    if (ensure_second_set(h) || ensure_third_set(h) || ensure_pml_blocks(h, pml_in)) return -1;
+    if (!h->ev_shell_a) {
+      HIPCHK(h, hipEventCreateWithFlags(&h->ev_shell_a, hipEventDisableTiming));
+      HIPCHK(h, hipEventCreateWithFlags(&h->ev_shell_b, hipEventDisableTiming));
+    }
+    const int N[3] = {h->g.nx, h->g.ny, nz};
+    int in0[3], in1[3];                                    // step one: the bulk shrunk by one cell (x: one lane) on its CPML sides
+    for (int a = 0; a < 3; ++a) {
+      in0[a] = sg.o0[a] > 0 ? sg.o0[a] + (a == 0 ? 4 : 1) : 0;
+      in1[a] = sg.o1[a] < N[a] ? sg.o1[a] - (a == 0 ? 4 : 1) : N[a];
+    }
+    launch_sources(h, false, n, 0, nz, st);                // H-side sources of step n act on H^{n-1/2}, as before a single step
+    HIPCHK(h, hipEventRecord(h->ev_shell_a, st));
+    HIPCHK(h, hipStreamWaitEvent(cs, h->ev_shell_a, 0));
+    const FieldP A = h->f, B = h->f2, T = h->f3;
+    const int par = h->pml_parity;
+    const ClipP clip{sg.o0[0], sg.o1[0], sg.o0[1], sg.o1[1], sg.o0[2], sg.o1[2]};
+    bool s2 = false;
+    if (launch_fused2(h, n, st, tb, &s2, nullptr, &clip)) return -1;
+    if (launch_shell_step(h, A, T, par, in0, in1, pml_in, cs)) return -1;
+    launch_sources(h, true, n, 0, nz, cs, false, &T);      // E-side sources of step n, H-side ones of step n + 1: on the middle step
+    launch_sources(h, false, n + 1, 0, nz, cs, false, &T);
+    if (launch_shell_step(h, T, B, par ^ 1, sg.o0, sg.o1, pml_in, cs)) return -1;
+    HIPCHK(h, hipEventRecord(h->ev_shell_b, cs));
+    HIPCHK(h, hipStreamWaitEvent(st, h->ev_shell_b, 0));
+    swap_sets(h);
+    pair_record(h, tb, n, st);
+    if (rec_at(n + 1)) record_monitors(h, n + 1, true, st);
+    launch_sources(h, true, n + 1, 0, nz, st);
+    fill_ghost_fused(h, st);
+    return 0;
+  };
   F2Plan f2_plan;
   h->fused2_pairs = 0;
+  h->shell_pairs = 0;
   int64_t done = 0;
   for (; done < n_steps; ++done) {
     const long long n = h->step;
@@ -2525,8 +2707,8 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     }
     // steps n and n + 1 as ONE sweep?  (fdtd_kernels2.hpp; no decay check on the middle step, sources all alive or all spent,
     // every monitor that records at n or n + 1 a small time monitor the sweep can sample)
-    const bool pair = fused && f2_ok && done + 2 <= n_steps && !(h->decay_every > 0 && ((n + 1) % h->decay_every) == 0) &&
-                      fused2_sources_uniform(h, n) && fused2_plan(h, n, &f2_plan) &&
+    const bool pair = fused && (f2_ok || f2s_ok) && done + 2 <= n_steps && !(h->decay_every > 0 && ((n + 1) % h->decay_every) == 0) &&
+                      fused2_sources_uniform(h, n) && fused2_plan(h, n, &f2_plan, f2s_ok ? sg.o0 : nullptr, f2s_ok ? sg.o1 : nullptr) &&
                       ((f2_plan.mons.empty() && f2_plan.dfts.empty()) || sources_alive(n) || h->psrc.empty());
     // (with H-side sources the monitors of a pair still take E^n and H^{n-1/2} here: those sources change H^{n-1/2} before the
     //  sweep, and pair_record reads the set afterwards)
@@ -2600,6 +2782,14 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       if (tb_pair(n)) return -1;
       h->step = n + 2;
       ++done;                                              // (the loop header counts the second step)
+    } else if (pair && f2s_ok) {
+      const F2Table* tb = fused2_table(h, f2_plan);
+      if (!tb) return -1;
+      if (shell_pair(n, tb)) return -1;
+      h->fused2_pairs++;
+      h->shell_pairs++;
+      h->step = n + 2;
+      ++done;
     } else if (pair) {
       const F2Table* tb = fused2_table(h, f2_plan);
       if (!tb) return -1;
@@ -2727,13 +2917,14 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->stats.run_ms = ms;
   h->stats.steps_done = h->step;
-  h->stats.h_kernel_ms = h->stats.e_kernel_ms = h->stats.fused_kernel_ms = 0.0;
-  h->stats.h_kernel_launches = h->stats.e_kernel_launches = h->stats.fused_kernel_launches = 0;
+  h->stats.h_kernel_ms = h->stats.e_kernel_ms = h->stats.fused_kernel_ms = h->stats.shell_kernel_ms = 0.0;
+  h->stats.h_kernel_launches = h->stats.e_kernel_launches = h->stats.fused_kernel_launches = h->stats.shell_kernel_launches = 0;
   for (size_t i = 0; i < h->kev_kind.size(); ++i) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, h->kev[2 * i], h->kev[2 * i + 1]) != hipSuccess) continue;
     if (h->kev_kind[i] == 0) { h->stats.h_kernel_ms += t; h->stats.h_kernel_launches++; }
     else if (h->kev_kind[i] == 1) { h->stats.e_kernel_ms += t; h->stats.e_kernel_launches++; }
+    else if (h->kev_kind[i] == 3) { h->stats.shell_kernel_ms += t; h->stats.shell_kernel_launches++; }
     else { h->stats.fused_kernel_ms += t; h->stats.fused_kernel_launches++; }
   }
   return 0;
@@ -2951,6 +3142,8 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
       return 0;
     }
     case FDTD_OPT_PML_SPLIT: h->pml_split = value < 0 ? -1 : (value != 0); return 0;
+    case FDTD_OPT_SHELL_PAIRS: h->shell_on = value < 0 ? -1 : value; return 0;
+    case FDTD_OPT_STRIP: if (value % 64 < 1 || (value / 64 != 3 && value / 64 != 4)) break; h->strip_zc = value % 64; h->strip_occ = value / 64; return 0;
     case FDTD_OPT_FUSED_LB: if (value != 0 && value != 256 && value != 512 && value != 1024) break; h->fused_lb = value; return 0;
     default: break;
   }
@@ -2974,6 +3167,9 @@ int fdtd_get_stats(FdtdSolver* h, FdtdStats* out) {
   out->reserved0 = h->graph_status;
   out->fused2_pairs = h->fused2_pairs;
   out->fused2_shape = h->fused2_pairs ? (h->twostep_w_used | (h->twostep_zc_used << 6)) : 0;
+  out->shell_pairs = h->shell_pairs;
+  out->fused2_off_reason = h->fused2_pairs ? 0 : h->f2_off_reason;
+  out->struct_bytes = (int32_t)sizeof(FdtdStats);
   return 0;
 }
 

@@ -21,12 +21,16 @@ void launch_inject_values(hipStream_t st, float* val, const float* w_re, const f
 
 void launch_fused2_step(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
                         const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,
-                        int xcd_remap, const InjP& inj, float* seam, const DampT& dmp) {
+                        int xcd_remap, const InjP& inj, float* seam, const DampT& dmp, const ClipP& clip) {
+  if (opt & 16) {
+    launch_fused2_step_clip(st, waves, opt, grid_blocks, g, a, b, s, m, zchunk, nbx, nby, nbz, xcd_remap, inj, seam, dmp, clip);
+    return;
+  }
   const dim3 grid(grid_blocks, 1, 1), block(64, waves, 1);
   const size_t shmem = ((size_t)8 * waves * 64 + ((opt & 8) ? 2 * 64 : 0)) * sizeof(float4);
 #define FDTD_F2_O(LBV, OV)                                                                                             \
   hipLaunchKernelGGL((fused2_step_kernel<LBV, OV>), grid, block, shmem, st, g, a, b, s, m, zchunk, nbx, nby, nbz,     \
-                     xcd_remap, inj, seam, dmp)
+                     xcd_remap, inj, seam, dmp, clip)
 #define FDTD_F2(LBV)                                                                                                   \
   do {                                                                                                                 \
     switch (opt & 15) {                                                                                                \
@@ -64,10 +68,11 @@ void launch_dft_record_dump(hipStream_t st, const DftDumpP& r, const float* dump
 }
 
 void launch_seams(hipStream_t st, const GridP& g, const FieldP& b, const StepP& s, const MatP& m, const float* seam,
-                  int n_seams, const DampT& dmp) {
-  const long long nt = (long long)n_seams * g.ny * g.nz;
+                  int n_seams, const DampT& dmp, const ClipP& clip) {
+  const long long nt = (long long)n_seams * (clip.j1 - clip.j0) * (clip.k1 - clip.k0);
+  if (nt <= 0) return;
   const unsigned blocks = (unsigned)((nt + 255) / 256);
-  hipLaunchKernelGGL(seam_kernel, dim3(blocks), dim3(256), 0, st, g, b, s, m, seam, n_seams, dmp);
+  hipLaunchKernelGGL(seam_kernel, dim3(blocks), dim3(256), 0, st, g, b, s, m, seam, n_seams, dmp, clip);
 }
 
 }  // namespace fdtd

@@ -38,6 +38,9 @@ struct DampT {
   const float* fc[3];
   int e2;                                  // E^{n+2} is damped inside the sweep (else: by the caller, behind the sources it applies)
 };
+// the box a clipped launch of the two-step sweep writes: [i0, i1) x [j0, j1) x [k0, k1), i0 and i1 multiples of 4 — the bulk of a
+// grid whose shell (CPML slabs + collar, boundary planes of a z-slab rank) is advanced by single steps (fdtd_capi.hip, shell pairs)
+struct ClipP { int i0, i1, j0, j1, k0, k1; };
 constexpr int kMaxCap = 1024;
 constexpr int kSeamArrays = 13;  // of step one: H1_y, H1_z, E1_x, E1_y, E1_z [c-1], E1_y, E1_z [c]; of step two: H2_x [c-1], H2_y, H2_z [c-2], H2_x, H2_y, H2_z [c]
                                  // (c = first column of the right tile)
@@ -46,10 +49,14 @@ constexpr int kSeamArrays = 13;  // of step one: H1_y, H1_z, E1_x, E1_y, E1_z [c
 void launch_inject_values(hipStream_t st, float* val, const float* w_re, const float* w_im, const float2* wave,
                           long long step, int n);
 // waves = rows per workgroup (W - 3 of them written); opt: bit 0 non-temporal stores, bit 1 materials (m.m4 set), bit 2 monitor
-// samples in the table, bit 3 absorber layers (dmp.fb[0] set)
+// samples in the table, bit 3 absorber layers (dmp.fb[0] set), bit 4 the launch covers the box `clip` only (not with bit 3)
 void launch_fused2_step(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
                         const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,
-                        int xcd_remap, const InjP& inj, float* seam, const DampT& dmp);
+                        int xcd_remap, const InjP& inj, float* seam, const DampT& dmp, const ClipP& clip);
+// the clipped instantiations live in their own translation unit (fdtd_fused2c.hip): the two compile side by side
+void launch_fused2_step_clip(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
+                             const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,
+                             int xcd_remap, const InjP& inj, float* seam, const DampT& dmp, const ClipP& clip);
 void launch_inject_table(hipStream_t st, float* tab, long long stride, long long off, const float* w_re, const float* w_im,
                          const float2* wave, long long n_steps, int n);
 constexpr int kPairMons = 4;
@@ -71,6 +78,6 @@ struct DftDumpP { int n; int slot[3]; int off[3]; };
 void launch_dft_record_dump(hipStream_t st, const DftDumpP& r, const float* dump, float2* acc, long long cells, long long fstride,
                             const float2* phase, int nf);
 void launch_seams(hipStream_t st, const GridP& g, const FieldP& b, const StepP& s, const MatP& m, const float* seam,
-                  int n_seams, const DampT& dmp);
+                  int n_seams, const DampT& dmp, const ClipP& clip);
 
 }  // namespace fdtd

@@ -499,7 +499,8 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
                                                           int kbeg, int kend, int zchunk, int pmc_z0,
                                                           int nbx, int nby, int nbz, int xcd_remap,
                                                           const PmlP* __restrict__ pmq,
-                                                          int nbz1, int k2beg, int k2end, int ty_a, int ty_gap) {
+                                                          int nbz1, int k2beg, int k2end, int ty_a, int ty_gap,
+                                                          int ex_j0, int ex_j1) {
   constexpr int V = 4;
   // 1-D launch; logical tile (bx, by, bz) with by fastest.  Hardware block L runs on XCD L % 8 (observed dispatch
   // order, used for speed only); y-neighbouring tiles share their halo row, and meet in an XCD's L2 when they are
@@ -556,9 +557,11 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
   const unsigned ux = (unsigned)i0;
   const unsigned ub = ux * 4u;            // lane's byte offset along the row: every row access is  uniform base + 32-bit lane offset
   const unsigned ubc = (i0 < g.nx) ? ub : 0u;   // the same, clamped into the row for loads of idle lanes
-  const bool halo = (ty == 0);
   const bool per_x = g.bcx0 == BC_PERIODIC, per_y = g.bcy0 == BC_PERIODIC;
   int j = tile_y * R + ty - 1;
+  // rows [ex_j0, ex_j1) belong to another launch (the y slabs of a shell step leave the rows of the bulk alone): a wave on
+  // such a row acts as a halo wave — it publishes H_x, H_z for the row above and stores nothing
+  const bool halo = (ty == 0) || (j >= ex_j0 && j < ex_j1);
   bool row_ok = (j >= 0) && (j < g.ny);
   if (j < 0 && per_y) { j = g.ny - 1; row_ok = true; }
   if (!row_ok) j = 0;                    // keeps every address of an idle wave inside the arrays

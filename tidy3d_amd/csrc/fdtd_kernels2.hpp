@@ -145,10 +145,15 @@ __device__ __forceinline__ int lane_value(int v, int l) {
 template <int LB, int OPT>
 __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
                                                          int zchunk, int nbx, int nby, int nbz, int xcd_remap,
-                                                         InjP inj, float* __restrict__ seam, DampT dmp) {
+                                                         InjP inj, float* __restrict__ seam, DampT dmp, ClipP clip) {
   constexpr int V = 4;
   constexpr bool NT = (OPT & 1) != 0, MAT = (OPT & 2) != 0, MON = (OPT & 4) != 0;     // MON: the node table may hold monitor samples
   constexpr bool DAMP = (OPT & 8) != 0;   // absorber layers: both fields of both steps are damped in registers (damp_kernel's factors)
+  // CLIP: the launch covers the box `clip` only — the bulk of a grid whose shell (CPML slabs + a two-cell collar, the boundary
+  // planes of a z-slab rank) is advanced by single steps beside it.  Tile rows and chunks start at the box's origin, nothing is
+  // stored outside it, and the seam scratch is written for every row / plane this workgroup computes (the seam kernel
+  // differentiates the row and plane below the box's first ones, which no workgroup owns).
+  constexpr bool CLIP = (OPT & 16) != 0;
   // (Issuing the loads of plane k+1 behind the second barrier of plane k — the one way to overlap them with compute inside a wave —
   //  was measured: + 60 registers, slower at every workgroup size, profiles/r3q; taken out.)
   const int total = nbx * nby * nbz;
@@ -195,10 +200,10 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
   }
   __syncthreads();
   const float ca = m.ca1, cb = m.cb1;
-  const int k0 = tile_z * zchunk;
-  const int k1 = min(k0 + zchunk, g.nz);
+  const int k0 = (CLIP ? clip.k0 : 0) + tile_z * zchunk;
+  const int k1 = min(k0 + zchunk, CLIP ? clip.k1 : g.nz);
   const int kA = k0 > 0 ? k0 - 1 : 0;
-  int j = tile_y * R + ty - 2;
+  int j = (CLIP ? clip.j0 : 0) + tile_y * R + ty - 2;
   const bool row_ok = (j >= 0) && (j < g.ny);
   if (!row_ok) {                          // takes part in the barriers only
     for (int k = kA; k <= k1; ++k) { __syncthreads(); __syncthreads(); }
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
   const bool act = (i0 < g.nx);
   const bool do_e1 = ty >= 1;                       // rows j0-1 .. j0+R
   const bool do_h2 = ty >= 1 && ty <= W - 2;        // rows j0-1 .. j0+R-1
-  const bool own = ty >= 2 && ty <= W - 2;          // rows j0 .. j0+R-1: stored
+  const bool own = ty >= 2 && ty <= W - 2 && (!CLIP || j < clip.j1);          // rows j0 .. j0+R-1: stored
   const float ch = g.ch;
   const bool last_x = (i0 + V >= g.nx);
   const bool first_x = (i0 == 0);
@@ -540,7 +545,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
           }
         }
         // what the neighbouring x tile needs of this step: repaired on the seam by seam_kernel
-        if (own && k >= k0 && k < k1 && act) {
+        if ((CLIP || (own && k >= k0 && k < k1)) && act) {
           float* sp = seam + seam_row + (long long)k * g.ny;
           if (txo == 63 && !last_x) {
             sp[0] = hyn[V - 1];
@@ -612,6 +617,21 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
         h2x[e] = upd_h(h1x[e], ch, ezj1[e] - e1z[e], ipy, e1yn[e] - e1y[e], ipz_m);
         h2y[e] = upd_h(h1y[e], ch, e1xn[e] - e1x[e], ipz_m, ez_ip - e1z[e], ipx[e]);
         h2z[e] = upd_h(h1z[e], ch, ey_ip - e1y[e], ipx[e], exj1[e] - e1x[e], ipy);
+      }
+      if constexpr (CLIP) {                    // H2 next to the seams, of every row / plane computed here (S4 writes the owned ones otherwise)
+        if (act) {
+          float* sq = seam + seam_row + (long long)(k - 1) * g.ny;
+          if (txo == 63 && !last_x) {
+            sq[7 * seam_arr] = h2x[V - 1];
+            sq[8 * seam_arr] = h2y[V - 2];
+            sq[9 * seam_arr] = h2z[V - 2];
+          }
+          if (txo == 0 && tile_x > 0) {
+            sq[10 * seam_arr - kSeamArrays * seam_arr] = h2x[0];
+            sq[11 * seam_arr - kSeamArrays * seam_arr] = h2y[0];
+            sq[12 * seam_arr - kSeamArrays * seam_arr] = h2z[0];
+          }
+        }
       }
     }
     {
@@ -719,15 +739,15 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
           }
         }
       }
-      if (act) {
+      if (act && (!CLIP || (i0o >= clip.i0 && i0o < clip.i1))) {
         // H2 next to the seams, for seam_kernel (so that it reads nothing but the scratch array, row-contiguous)
         float* sq = seam + seam_row + (long long)(k - 1) * g.ny;
-        if (txo == 63 && !last_x) {
+        if (!CLIP && txo == 63 && !last_x) {
           sq[7 * seam_arr] = h2x[V - 1];
           sq[8 * seam_arr] = h2y[V - 2];
           sq[9 * seam_arr] = h2z[V - 2];
         }
-        if (txo == 0 && tile_x > 0) {
+        if (!CLIP && txo == 0 && tile_x > 0) {
           sq[10 * seam_arr - kSeamArrays * seam_arr] = h2x[0];
           sq[11 * seam_arr - kSeamArrays * seam_arr] = h2y[0];
           sq[12 * seam_arr - kSeamArrays * seam_arr] = h2z[0];
@@ -768,13 +788,18 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
 // tiles left in the scratch array [seam][13][nz + 2][ny] (read row-contiguously; plane nz and what lies beyond the walls
 // stay zero).  H2_{y,z}[c-1] of the row below and of the plane below are recomputed rather than exchanged: one launch.
 __global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, MatP m,
-                                                   const float* __restrict__ seam, int n_seams, DampT dmp) {
+                                                   const float* __restrict__ seam, int n_seams, DampT dmp, ClipP clip) {
+  // (clip: the box the sweep wrote — the whole grid, or the bulk of a grid whose shell takes single steps; rows and planes
+  //  are those of the box, and a seam column that lies outside it is left alone)
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long per = (long long)g.ny * g.nz;
+  const int nj = clip.j1 - clip.j0;
+  const long long per = (long long)nj * (clip.k1 - clip.k0);
   if (t >= per * n_seams) return;
   const int sm = (int)(t / per);
-  const int k = (int)((t % per) / g.ny), j = (int)(t % g.ny);
+  const int k = clip.k0 + (int)((t % per) / nj), j = clip.j0 + (int)(t % nj);
   const int c = (sm + 1) * 256;
+  const bool wl = c - 1 >= clip.i0 && c - 1 < clip.i1, wr = c >= clip.i0 && c < clip.i1;
+  if (!wl && !wr) return;
   const float ch = g.ch;
   const float ipx = s.ipx[c - 1];
   auto A = [&](int a, int jj, int kk) { return seam[seam_at(g, sm, a, jj, kk)]; };
@@ -798,7 +823,7 @@ __global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, M
   const bool wall_y = (j == 0) && !pmc_y0, wall_z = (k == 0) && !pmc_z0;
   const bool mir_y = (j == 0) && pmc_y0, mir_z = (k == 0) && pmc_z0;
   const long long p = (long long)k * g.sxy + (long long)j * g.nx + c;       // column c; p - 1 = column c-1
-  b.hy[p - 1] = hy_m; b.hz[p - 1] = hz_m;
+  if (wl) { b.hy[p - 1] = hy_m; b.hz[p - 1] = hz_m; }
   const float idy = s.idy[j], idz = s.idz[k], idx_m = s.idx[c - 1], idx_c = s.idx[c];
   const float hx_m = A(7, j, k), hy_mm = A(8, j, k), hz_mm = A(9, j, k);
   const float hx_c = A(10, j, k), hy_c = A(11, j, k), hz_c = A(12, j, k);
@@ -830,8 +855,8 @@ __global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, M
     ex_m *= cxm * byv * bzv; ey_m *= bxm * cyv * bzv; ez_m *= bxm * byv * czv;
     ey_c *= bxc * cyv * bzv; ez_c *= bxc * byv * czv;
   }
-  b.ex[p - 1] = ex_m; b.ey[p - 1] = ey_m; b.ez[p - 1] = ez_m;
-  b.ey[p] = ey_c; b.ez[p] = ez_c;
+  if (wl) { b.ex[p - 1] = ex_m; b.ey[p - 1] = ey_m; b.ez[p - 1] = ez_m; }
+  if (wr) { b.ey[p] = ey_c; b.ez[p] = ez_c; }
 }
 
 }  // namespace fdtd
