@@ -7,6 +7,7 @@ import sys
 import time
 
 import numpy as np
+import torch  # noqa: F401  (before the solver library: one HIP runtime per process)
 
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import tidy3d_amd.schema as td
@@ -51,9 +52,26 @@ def main():
     ap.add_argument("--pml-fused", type=int, default=-1)
     ap.add_argument("--warm", type=int, default=30)
     ap.add_argument("--opt", action="append", default=[], help="NAME=VALUE engine options (tidy3d_amd.lib.OPT_*)")
+    ap.add_argument("--twostep", default="0,-1", help="FDTD_OPT_TWOSTEP values tried inside each engine (0 = single steps, -1 = default shape, W + 64 zc)")
+    ap.add_argument("--ref512", type=int, default=1, help="time the one-GPU 512^3 V0 run (two steps per sweep) first: the denominator of implied_speedup_vs_1gpu")
     args = ap.parse_args()
     n = 512
     steps, warm = args.steps, args.warm
+    ref_ms = 1.10
+    if args.ref512 and not args.pml:
+        sp = spec_for(n, n, 200, 0)
+        import dataclasses
+        from tidy3d_amd.spec import BC_PEC
+        sp = dataclasses.replace(sp, bc=(sp.bc[0], sp.bc[1], (BC_PEC, BC_PEC)))
+        with HipEngine(sp, variant=L.VARIANT_FUSED) as e:
+            rng = np.random.default_rng(0)
+            for c in range(6):
+                e.set_field(c, rng.uniform(-1e-3, 1e-3, (n, n, n)).astype(np.float32))
+            e.run(20)
+            t0 = time.perf_counter()
+            st = e.run(100)
+            ref_ms = (time.perf_counter() - t0) / 100 * 1e3
+            print(json.dumps({"ref": "512^3 V0 on one GPU", "ms_per_step": ref_ms, "fused2_pairs": int(st.fused2_pairs)}), flush=True)
     all_modes = {"single_fused": dict(variant=L.VARIANT_FUSED),
                  "comm_fused": dict(variant=L.VARIANT_FUSED, force_comm=True),
                  "comm_two_pass": dict(variant=L.VARIANT_ZMARCH, force_comm=True)}
@@ -77,14 +95,17 @@ def main():
                 rng = np.random.default_rng(0)
                 for c in range(6):
                     e.set_field(c, rng.uniform(-1e-3, 1e-3, (nz, n, n)).astype(np.float32))
-                e.run(warm)
-                t0 = time.perf_counter()
-                e.run(steps)
-                dt = time.perf_counter() - t0
-                stt = e.stats()
-                print(json.dumps({"slab_of": ngpu, "nz": nz, "mode": mode, "zchunk": args.zchunk, "bnd": args.bnd, "rows": args.rows, "tile": [int(stt.tile_rows), int(stt.tile_zchunk)], "autotune": args.autotune, "pml": args.pml, "pml_fused": args.pml_fused, "opt": args.opt, "ms_per_step": dt / steps * 1e3,
-                                  "ideal_ms": 1.10 / ngpu,
-                                  "implied_speedup_vs_1gpu": 1.10 / (dt / steps * 1e3)}), flush=True)
+                for ts in [int(x) for x in args.twostep.split(",")]:
+                    e.set_option(L.OPT_TWOSTEP, ts)
+                    e.run(warm)
+                    t0 = time.perf_counter()
+                    stt = e.run(steps)
+                    dt = time.perf_counter() - t0
+                    print(json.dumps({"slab_of": ngpu, "nz": nz, "mode": mode, "twostep": ts, "fused2_pairs": int(stt.fused2_pairs), "shape": [int(stt.fused2_shape) & 63, int(stt.fused2_shape) >> 6],
+                                      "why": int(stt.fused2_off_reason), "zchunk": args.zchunk, "bnd": args.bnd, "rows": args.rows,
+                                      "tile": [int(stt.tile_rows), int(stt.tile_zchunk)], "autotune": args.autotune, "pml": args.pml, "pml_fused": args.pml_fused, "opt": args.opt,
+                                      "ms_per_step": dt / steps * 1e3, "one_gpu_ms_per_step": ref_ms, "ideal_ms": ref_ms / ngpu,
+                                      "implied_speedup_vs_1gpu": ref_ms / (dt / steps * 1e3)}), flush=True)
 
 
 if __name__ == "__main__":

@@ -46,6 +46,32 @@ def pipelined_slab_case(N=(28, 24, 32)):
     return _sim(N, bspec, structures, sources=sources, monitors=monitors)
 
 
+def slab_pairs_box(N=(24, 20, 44), periodic_z=False):
+    """PEC / PMC walls (or a periodic z), a lossy block and a PEC box, electric and magnetic dipoles next to where 2- and 3-rank
+    runs cut the grid, a probe and an x-z plane recorded every 7th / 10th step: what z-slab ranks advance in step pairs
+    (tests/test_dist_gloo.py)."""
+    sx, sy, sz = (n * DL for n in N)
+    zb = td.Boundary.periodic() if periodic_z else td.Boundary(minus=td.PECBoundary(), plus=td.PECBoundary())
+    bspec = td.BoundarySpec(x=td.Boundary(minus=td.PMCBoundary(), plus=td.PECBoundary()),
+                            y=td.Boundary(minus=td.PECBoundary(), plus=td.PECBoundary()), z=zb)
+    structures = [td.Structure(geometry=td.Box(center=(0.1, 0, 0), size=(0.4, 0.3, td.inf)), medium=td.Medium(permittivity=2.5, conductivity=0.03)),
+                  td.Structure(geometry=td.Box(center=(-0.3, 0.2, 0.05), size=(0.15, 0.15, 0.3)), medium=td.PEC)]
+    sources = [td.PointDipole(center=(0.02, 0.01, 0.03), source_time=PULSE, polarization="Ez"),
+               td.PointDipole(center=(-0.2, 0.12, -0.5 * sz + 14.6 * DL), source_time=PULSE, polarization="Ex"),      # next to the 3-rank cut at 15
+               td.PointDipole(center=(0.25, -0.2, -0.5 * sz + 21.4 * DL), source_time=PULSE, polarization="Hy"),      # below the 2-rank cut at 22
+               td.PointDipole(center=(-0.1, -0.3, -0.5 * sz + 22.6 * DL), source_time=PULSE, polarization="Ey"),      # above it
+               td.PointDipole(center=(0.3, 0.3, -0.5 * sz + 29.5 * DL), source_time=PULSE, polarization="Hx"),
+               td.PointDipole(center=(0.0, 0.2, 0.5 * sz - 1.4 * DL), source_time=PULSE, polarization="Ez")]
+    monitors = [td.FieldTimeMonitor(center=(0.1, 0.05, 0.1), size=(0, 0, 0), name="probe", interval=7, colocate=False),
+                td.FieldTimeMonitor(center=(0, 0, 0), size=(td.inf, 0, td.inf), name="plane", interval=10, colocate=False)]
+    return td.Simulation(size=(sx, sy, sz), grid_spec=td.GridSpec.uniform(dl=DL), run_time=1e-12, structures=structures,
+                         sources=sources, monitors=monitors, boundary_spec=bspec, shutoff=0)
+
+
+def slab_pairs_box_periodic():
+    return slab_pairs_box(periodic_z=True)
+
+
 def pec_box(N=(20, 16, 12)):
     return _sim(N, td.BoundarySpec.all_sides(td.PECBoundary()))
 

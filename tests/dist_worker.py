@@ -62,10 +62,16 @@ def main():
     if os.environ.get("PML_FUSED"):                         # CPML recursions inside the sweeps of the slab ranks (tests)
         from tidy3d_amd import lib as L
         eng.set_option(L.OPT_PML_FUSED, int(os.environ["PML_FUSED"]))
+    if os.environ.get("TWOSTEP"):                           # step pairs on the slab ranks, whatever the grid size (tests)
+        from tidy3d_amd import lib as L
+        eng.set_option(L.OPT_TWOSTEP, int(os.environ["TWOSTEP"]))
     if os.environ.get("PLACEMENT_TRIES"):                   # force the placement probe of the library on (tests)
         from tidy3d_amd import lib as L
         eng.set_option(L.OPT_PLACEMENT_TRIES, int(os.environ["PLACEMENT_TRIES"]))
     st = eng.run()
+    pairs = torch.tensor([int(st.fused2_pairs)], dtype=torch.int64)
+    allp = [torch.zeros_like(pairs) for _ in range(world)]
+    dist.all_gather(allp, pairs)
     raw = tdist.gather_results(eng)
     s_ax = getattr(eng, "slab_shift", 0)
     fields = [eng.get_field((c % 3 - s_ax) % 3 + 3 * (c // 3)) for c in range(6)]     # device component of user c
@@ -76,7 +82,7 @@ def main():
         allf.sort(key=lambda p: p[0])
         from tidy3d_amd.engine import unpermute_array
         full = {f"field{c}": unpermute_array(np.concatenate([p[1][c] for p in allf], axis=0), s_ax) for c in range(6)}
-        np.savez(out, decay=st.field_decay, **{f"mon_{k}": v for k, v in raw.items()}, **full)
+        np.savez(out, decay=st.field_decay, pairs=np.asarray([int(x.item()) for x in allp]), **{f"mon_{k}": v for k, v in raw.items()}, **full)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -15,8 +15,10 @@ from tidy3d_amd.engine import HipEngine, split_slabs
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def _launch(world, case, n_steps, out, port, slab_shift=None, placement_tries=None, pml_fused=None):
+def _launch(world, case, n_steps, out, port, slab_shift=None, placement_tries=None, pml_fused=None, twostep=None):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if twostep is not None:
+        env["TWOSTEP"] = str(twostep)
     if slab_shift is not None:
         env["SLAB_SHIFT"] = str(slab_shift)
     if placement_tries is not None:
@@ -93,6 +95,36 @@ def test_cpml_inside_the_sweeps_of_slab_ranks(world, case, mask, emu_lib, tmp_pa
         assert np.array_equal(got[f"field{c}"], fields[c]), c
     for k, v in ref.items():
         assert np.array_equal(got[f"mon_{k}"], v), k
+
+
+SLAB_PAIR_CASES = [(2, "slab_pairs_box", 5 + 64 * 4), (3, "slab_pairs_box", 16 + 64 * 32), (2, "slab_pairs_box_periodic", 6 + 64 * 5),
+                   (4, "slab_pairs_box_periodic", 4 + 64 * 3)]
+
+
+@pytest.mark.parametrize("world,case,twostep", SLAB_PAIR_CASES)
+def test_step_pairs_on_slab_ranks(world, case, twostep, emu_lib, tmp_path):
+    """z-slab ranks advance two time steps per sweep: the planes two or more away from a cut by the two-step sweep, the two
+    planes next to it by two single steps on the comm stream through the third field set, shipping their planes after each —
+    the messages of two single steps.  Same bits as the single-slab run (which takes single steps here: the grid is small),
+    with dipoles of both kinds next to the cuts, materials through them, monitors whose records end pairs."""
+    import cases
+    out = str(tmp_path / "dist.npz")
+    _launch(world, case, 46, out, 29641 + SLAB_PAIR_CASES.index((world, case, twostep)), twostep=twostep)
+    got = np.load(out)
+    assert (got["pairs"] >= 8).all(), got["pairs"]
+    disc = discretize(getattr(cases, case)(), n_steps=46)
+    disc.spec.decay_every = 10
+    with HipEngine(disc.spec, lib=emu_lib) as e:
+        st = e.run()
+        assert int(st.fused2_pairs) == 0
+        ref = e.results()
+        fields = [e.get_field(c) for c in range(6)]
+    assert max(float(np.abs(f).max()) for f in fields) > 0
+    for c in range(6):
+        assert np.array_equal(got[f"field{c}"], fields[c]), c
+    for k, v in ref.items():
+        assert np.array_equal(got[f"mon_{k}"], v), k
+    assert float(got["decay"]) == pytest.approx(st.field_decay, rel=1e-6)
 
 
 @pytest.mark.parametrize("world,case", [(2, "media_mix"), (3, "periodic_box")])

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <string>
 #include <utility>
@@ -233,7 +234,7 @@ struct FdtdSolver {
   float* cap_val = nullptr;           // samples of the middle step (small time monitors)
   float* dump_buf = nullptr;          // H^{n+1/2} over the boxes of DFT monitors recording at the first step of a pair
   long long dump_cap = 0;
-  std::vector<F2Table> f2_tables;     // node tables, one per set of recording monitors met so far
+  std::deque<F2Table> f2_tables;      // node tables, one per set of recording monitors met so far (a deque: pointers to its entries stay valid)
   size_t inj_sources = 0;             // point-source lists the tables were built from
   float* src_tab = nullptr;           // [step][node] source terms of every step, formed once (nullptr: per pair)
   long long src_tab_steps = 0, src_tab_nodes = 0;
@@ -655,13 +656,40 @@ int launch_fused(FdtdSolver* h, hipStream_t st, int pml_inside) {
 // (rounds counted whole while there are fewer than four: the tail of a short launch is real).  It picks the measured best
 // or a shape within 3 % of it at 128^3 ... 512^3: 8 waves on grids up to 256^3 (416 workgroups of 5 rows fill the 512 slots
 // at once: 195 Gcells/s against 140 with 16 waves), 16 waves from 320^3 on.  Grids below 2^20 cells keep single steps.
-bool fused2_shape(const FdtdSolver* h, int* W, int* zc) {
+// `box` (a clipped launch: the bulk of a shell pair or of a z-slab rank's pair): rows and planes of the box, and chunks of
+// EQUAL length — on the 60 bulk planes of a 64-plane slab rank the fixed lengths leave one round of 412 8-wave workgroups
+// marching 32 iterations (237 us) where 240 16-wave ones march 22 (profiles/r4e).
+bool fused2_shape(const FdtdSolver* h, int* W, int* zc, const ClipP* box = nullptr) {
   const GridP& g = h->g;
   const int nbx = (g.nx + 255) / 256;
   if (h->twostep_w > 0 && h->twostep_zc > 0) { *W = h->twostep_w; *zc = std::max(2, std::min(h->twostep_zc, g.nz)); return true; }
   if (h->twostep_w <= 0 && (long long)g.nx * g.ny * g.nz < (1LL << 20)) return false;
   double best = 0.0;
   bool found = false;
+  if (box) {
+    const int nyb = box->j1 - box->j0, nzb = box->k1 - box->k0;
+    for (int w : {16, 8}) {
+      if (h->twostep_w > 0 && w != h->twostep_w) {
+        if (w == 16) w = h->twostep_w; else continue;
+      }
+      const int R = w - 3, nby = (nyb + R - 1) / R;
+      // (one round of one 16-wave workgroup per CU exposes every plane's latency: 64-plane slab 16 x 20 0.1436 ms per step against
+      //  8 x 30 0.1263, profiles/r4f — 10.5 us per plane iteration here, not the 8.2 of a five-round launch)
+      const double t8 = 6.0 + (h->mat4 ? 1.6 : 0.0), t16 = 10.5 + (h->mat4 ? 1.2 : 0.0);
+      const double slots = w <= 8 ? 512.0 : 256.0, t = w <= 8 ? t8 : (w >= 16 ? t16 : t8 + (t16 - t8) * (w - 8) / 8.0);
+      for (int nch = 1; nch <= std::max(1, nzb / 4); ++nch) {
+        const int c = (nzb + nch - 1) / nch;
+        if (c > 64) continue;
+        const double wg = (double)nbx * nby * ((nzb + c - 1) / c);
+        double rounds = wg / slots;
+        if (rounds < 4.0) rounds = std::ceil(rounds);
+        const double cost = rounds * (c + 2) * t;
+        if (!found || cost < best * 0.999) { best = cost; *W = w; *zc = c; found = true; }
+      }
+    }
+    *zc = std::max(2, std::min(*zc, nzb));
+    return found;
+  }
   for (int w : {16, 8}) {
     if (h->twostep_w > 0 && w != h->twostep_w) {
       if (w == 16) w = h->twostep_w; else continue;        // a requested W: only the chunk length is chosen
@@ -692,15 +720,17 @@ bool fused2_shape(const FdtdSolver* h, int* W, int* zc) {
 
 // Why a run takes no step pairs (FDTD_F2_OFF_*, include/fdtd_hip.h); 0 = nothing in the problem keeps the two-step sweep
 // from it.  CPML is not a reason here: the caller then asks shell_eligible.
-int fused2_why_not(const FdtdSolver* h) {
+int fused2_why_not(const FdtdSolver* h, bool slab_rank = false) {
   if (h->twostep_w == 0) return FDTD_F2_OFF_DISABLED;
   { int W, zc; if (!fused2_shape(h, &W, &zc)) return FDTD_F2_OFF_TOO_SMALL; }
-  if (h->comm) return FDTD_F2_OFF_COMM;
+  if (h->comm && !slab_rank) return FDTD_F2_OFF_COMM;
   if (!h->ade.empty()) return FDTD_F2_OFF_ADE;
   if (!h->tfsf.empty()) return FDTD_F2_OFF_TFSF;
   // PEC walls; the min faces may be PMC (the symmetry planes of a half / quarter / eighth domain)
+  // (a z-slab rank: a neighbour face is no wall — the sweep stays two planes clear of it, fdtd_run)
   for (int f = 0; f < 6; ++f)
-    if (h->cfg.bc[f] != FDTD_BC_PEC && !((f & 1) == 0 && h->cfg.bc[f] == FDTD_BC_PMC)) return FDTD_F2_OFF_BOUNDARY;
+    if (h->cfg.bc[f] != FDTD_BC_PEC && !((f & 1) == 0 && h->cfg.bc[f] == FDTD_BC_PMC) &&
+        !(slab_rank && f >= 4 && h->cfg.bc[f] == FDTD_BC_NEIGHBOR)) return FDTD_F2_OFF_BOUNDARY;
   if ((h->g.pec_z0 != 0) != (h->cfg.bc[4] == FDTD_BC_PEC) || h->g.nx % 4 || h->g.nz < 2) return FDTD_F2_OFF_BOUNDARY;
   for (int a = 0; a < 3; ++a) if (h->mirror_wall[a] >= 0) return FDTD_F2_OFF_BOUNDARY;
   long long nodes = 0;
@@ -894,12 +924,12 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
   const GridP& g = h->g;
   if (ensure_second_set(h)) return -1;
   int W = 16, zc = 32;
-  fused2_shape(h, &W, &zc);
   const ClipP box = clip ? *clip : ClipP{0, g.nx, 0, g.ny, 0, g.nz};
+  fused2_shape(h, &W, &zc, (clip && h->comm) ? clip : nullptr);
   // (beside the shell launches of a shell pair shorter chunks do better — workgroups retire, and hand their CU to a shell
   //  workgroup, twice as often: 512^3 V2 inside one engine 16 x 16 1.206 / 1.219 ms per step, 16 x 24 1.225, 16 x 32 1.249 / 1.231,
   //  profiles/r4d)
-  if (clip && h->twostep_zc <= 0) zc = std::min(zc, 16);
+  if (clip && !h->comm && h->twostep_zc <= 0) zc = std::min(zc, 16);
   zc = std::max(2, std::min(zc, box.k1 - box.k0));
   h->twostep_w_used = W; h->twostep_zc_used = zc;
   const int R = W - 3;
@@ -1625,13 +1655,15 @@ int exchange_fused_e(FdtdSolver* h, hipStream_t st) {
 // Pipelined z-slab schedule: ONE exchange per step carries everything the neighbours' boundary
 // chunks need for the next sweep — up: E_x,E_y,E_z and the pre-corrected H_x,H_y of my top plane
 // (-> upper ghost(-1)); down: E_x,E_y of my bottom plane (-> lower ghost(nz)).
-int exchange_fused_all(FdtdSolver* h, hipStream_t st, bool pml_with_sweep = false) {
+// `fs`: the set whose planes travel (default: the current one) — the middle step of a slab pair ships the third set's.
+int exchange_fused_all(FdtdSolver* h, hipStream_t st, bool pml_with_sweep = false, const FieldP* fs = nullptr) {
   const long long pc = plane_cells(h);
   const int nz = h->g.nz;
   const bool has_lo = h->cfg.bc[4] == FDTD_BC_NEIGHBOR, has_hi = h->cfg.bc[5] == FDTD_BC_NEIGHBOR;
   if (!has_lo && !has_hi) return 0;
   const int lo = (h->rank - 1 + h->n_ranks) % h->n_ranks, hi = (h->rank + 1) % h->n_ranks;
-  float* up5[5] = {h->f.ex, h->f.ey, h->f.ez, h->f.hx, h->f.hy};
+  const FieldP F = fs ? *fs : h->f;
+  float* up5[5] = {F.ex, F.ey, F.ez, F.hx, F.hy};
   // With the x / y CPML inside the sweep the chunk prologue of the upper rank corrects H[-1] itself and needs the
   // H-side psi of that plane — my top plane, CURRENT set (what the next sweep reads): into slot nz of its arrays.
   // Decided by the configuration alone (both sides must post the same messages), not by what a rank's sweep ends up doing.
@@ -1646,8 +1678,8 @@ int exchange_fused_all(FdtdSolver* h, hipStream_t st, bool pml_with_sweep = fals
           NCCLCHK(h, ncclSend(h->pml[a].psi_h[q] + (size_t)(nz - 1) * h->pml[a].psi_plane, h->pml[a].psi_plane, ncclFloat, hi, h->comm, st));
   }
   if (has_lo) {
-    NCCLCHK(h, ncclSend(h->f.ex, pc, ncclFloat, lo, h->comm, st));
-    NCCLCHK(h, ncclSend(h->f.ey, pc, ncclFloat, lo, h->comm, st));
+    NCCLCHK(h, ncclSend(F.ex, pc, ncclFloat, lo, h->comm, st));
+    NCCLCHK(h, ncclSend(F.ey, pc, ncclFloat, lo, h->comm, st));
     for (float* p : up5) NCCLCHK(h, ncclRecv(p - pc, pc, ncclFloat, lo, h->comm, st));
     if (psi_too)
       for (int a = 0; a < 2; ++a)
@@ -1655,8 +1687,8 @@ int exchange_fused_all(FdtdSolver* h, hipStream_t st, bool pml_with_sweep = fals
           NCCLCHK(h, ncclRecv(h->pml[a].psi_h[q] + (size_t)nz * h->pml[a].psi_plane, h->pml[a].psi_plane, ncclFloat, lo, h->comm, st));
   }
   if (has_hi) {
-    NCCLCHK(h, ncclRecv(h->f.ex + (long long)nz * pc, pc, ncclFloat, hi, h->comm, st));
-    NCCLCHK(h, ncclRecv(h->f.ey + (long long)nz * pc, pc, ncclFloat, hi, h->comm, st));
+    NCCLCHK(h, ncclRecv(F.ex + (long long)nz * pc, pc, ncclFloat, hi, h->comm, st));
+    NCCLCHK(h, ncclRecv(F.ey + (long long)nz * pc, pc, ncclFloat, hi, h->comm, st));
   }
   NCCLCHK(h, ncclGroupEnd());
   return 0;
@@ -2658,6 +2690,13 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     if (h->src_h_nodes > 0 && !h->src_tab) { f2_ok = f2s_ok = false; h->f2_off_reason = FDTD_F2_OFF_SOURCES; }      // H-side nodes take their terms of step n+1 from the table only
   }
   if (f2s_ok && probe_stream_overlap(h)) return -1;
+  // z-slab ranks (pipelined schedule): step pairs with the planes next to the neighbour faces as the shell
+  bool f2m_ok = fused_multi && !any_pml(h) && !h->has_damp && h->shell_on != 0 && nz >= 8 && fused2_why_not(h, true) == 0;
+  if (fused_multi) h->f2_off_reason = f2m_ok ? 0 : (any_pml(h) || h->has_damp ? FDTD_F2_OFF_COMM : (fused2_why_not(h, true) ? fused2_why_not(h, true) : FDTD_F2_OFF_COMM));
+  if (f2m_ok) {
+    if (fused2_sources(h) || ensure_third_set(h)) return -1;
+    if (h->src_h_nodes > 0 && !h->src_tab) { f2m_ok = false; h->f2_off_reason = FDTD_F2_OFF_SOURCES; }
+  }
   // steps n and n + 1 of a grid walled by CPML: the bulk as ONE two-step sweep on st, the shell as two single steps on cs
   auto shell_pair = [&](long long n, const F2Table* tb) -> int {
     hipStream_t cs = (h->shell_on == 2) ? st : h->comm_stream;       // (2: shell behind the bulk on ONE stream — a measuring aid)
@@ -2715,6 +2754,53 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     if (rec) record_monitors(h, n, false, st, (pair && h->src_h_nodes == 0) ? &f2_plan : nullptr);
     if (fused_multi) {
       if (!primed && prime(n)) return -1;
+      // ---- slab pair: steps n and n + 1 of a z-slab rank -----------------------------------------------------------------
+      // The two-step sweep advances the planes two or more away from a neighbour face (it reads the slab's own planes
+      // only: no ghost plane, no dependence on the wire); the two planes next to a neighbour face — its shell — take two
+      // single steps on the comm stream, through the third set, and ship their planes after EACH of them: the messages a
+      // neighbour receives are those of two single steps, in the same order (a rank may take a pair while its neighbour
+      // takes single steps).  Same kernels and formulas: the same bits (tests/test_dist_gloo.py).  Entry and exit state:
+      // "primed" (above).  Pairs keep clear of monitor records, decay checks and the end of the run (joined tails).
+      auto decay_at = [&](long long m) { return h->decay_every > 0 && (m % h->decay_every) == 0; };
+      if (f2m_ok && done + 3 <= n_steps && !rec_at(n) && !rec_at(n + 1) && !rec_at(n + 2) && !decay_at(n + 1) && !decay_at(n + 2) &&
+          fused2_sources_uniform(h, n)) {
+        F2Plan none;
+        const F2Table* tb = fused2_table(h, none);
+        if (!tb) return -1;
+        const int bl = nb_lo ? 2 : 0, bh = nb_hi ? 2 : 0;
+        const FieldP A = h->f, B = h->f2, T = h->f3;
+        ShellSets s1{A, T, 0, 0, 0}, s2{T, B, 0, 0, 0};
+        // (host order: the long bulk sweep is handed to the device first — the comm stream's dozen launches and two RCCL groups
+        //  take the host longer to issue than the device needs for them; issued first they left the device idle for 30 us per
+        //  pair in front of the bulk, profiles/r4e)
+        HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
+        // bulk: both steps in one sweep, set A -> set B
+        HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
+        const ClipP clip{0, h->g.nx, 0, h->g.ny, bl, nz - bh};
+        bool s2done = false;
+        if (launch_fused2(h, n, st, tb, &s2done, nullptr, &clip)) return -1;
+        // shell, step one: the boundary planes and one more (what step two differentiates), set A -> set T
+        if (launch_fused_range(h, 0, bl ? bl + 1 : 0, cs, 0, bh ? nz - bh - 1 : nz, nz, -1, 0, 0, false, &s1)) return -1;
+        HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
+        if (bl) { launch_sources(h, true, n, 0, bl + 1, cs, false, &T); launch_sources(h, false, n + 1, 0, bl + 1, cs, false, &T); }
+        if (bh) { launch_sources(h, true, n, nz - bh - 1, nz, cs, false, &T); launch_sources(h, false, n + 1, nz - bh - 1, nz, cs, false, &T); }
+        if (exchange_fused_all(h, cs, false, &T)) return -1;                  // what the neighbours expect after step n
+        // shell, step two: set T -> set B
+        if (launch_fused_range(h, 0, bl, cs, 0, nz - bh, nz, -1, 0, 0, false, &s2)) return -1;
+        // corrections of step n + 1 (E side) and n + 2 (H side): boundary planes on cs, then their planes travel
+        if (bl) { launch_sources(h, true, n + 1, 0, bl, cs, false, &B); launch_sources(h, false, n + 2, 0, bl, cs, false, &B); }
+        if (bh) { launch_sources(h, true, n + 1, nz - bh, nz, cs, false, &B); launch_sources(h, false, n + 2, nz - bh, nz, cs, false, &B); }
+        HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
+        if (exchange_fused_all(h, cs, false, &B)) return -1;
+        swap_sets(h);                                                          // h->f = B: E^{n+2}, H^{n+3/2}
+        launch_sources(h, true, n + 1, bl, nz - bh, st);
+        launch_sources(h, false, n + 2, bl, nz - bh, st);
+        HIPCHK(h, hipEventRecord(h->ev_e_int, st));
+        h->fused2_pairs++;
+        h->step = n + 2;
+        ++done;
+        continue;
+      }
       const bool decay_step = h->decay_every > 0 && ((n + 1) % h->decay_every) == 0;
       const bool last = (done + 1 == n_steps) || decay_step;
       // sweeps: boundary chunks (one launch) on cs, interior on st
