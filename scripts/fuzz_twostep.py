@@ -1,6 +1,8 @@
 """Randomised self-check of the two-step sweep on the device: random grid shapes (1-3 x tiles, ragged rows / chunks), tile shapes,
-wall types (PEC, PMC, absorber layers), media, electric / magnetic dipoles, probes and DFT monitors; two steps per sweep == single sweeps, bit for bit.
-    python scripts/fuzz_twostep.py [n_cases] [seed]"""
+wall types (PEC, PMC, absorber layers, CPML of random thickness -> shell pairs), media, electric / magnetic dipoles, probes and DFT
+monitors; two steps per sweep == single sweeps, bit for bit.
+    python scripts/fuzz_twostep.py [n_cases] [seed]
+Also run by the GPU suite (tests/test_gpu_production_path.py, run_cases)."""
 import os
 import sys
 
@@ -23,11 +25,19 @@ def case(rng):
     N = (nx, ny, nz)
     size = tuple(n * DL for n in N)
     pmc = [bool(rng.integers(0, 2)) for _ in range(3)]
-    absorb = bool(rng.integers(0, 3) == 0)          # a third of the cases: absorber layers on some faces (then no magnetic dipoles)
+    kind = int(rng.integers(0, 3))
+    absorb = kind == 0          # a third of the cases: absorber layers on some faces (then no magnetic dipoles)
+    cpml = kind == 1            # a third: CPML on some faces (step pairs with a shell of single steps when the grid has a bulk left)
+    if cpml:
+        ny, nz = max(ny, 14), max(nz, 14)
+        N = (nx, ny, nz)
+        size = tuple(n * DL for n in N)
 
     def face(ax_n, minus, p):
         if absorb and rng.integers(0, 2) and ax_n >= 8:
             return td.Absorber(num_layers=int(rng.integers(2, min(7, ax_n // 2))))
+        if cpml and rng.integers(0, 4) and ax_n >= 8:
+            return td.PML(num_layers=int(rng.integers(2, 7)))
         return td.PMCBoundary() if (minus and p) else td.PECBoundary()
     bspec = td.BoundarySpec(**{ax: td.Boundary(minus=face(n_, True, p), plus=face(n_, False, p))
                                for ax, p, n_ in zip("xyz", pmc, N)})
@@ -74,11 +84,11 @@ def case(rng):
     disc = discretize(sim, n_steps=steps + 1)
     disc.spec.decay_every = int(rng.choice([0, 0, 7, 16]))
     w, zc = int(rng.integers(4, 17)), int(rng.integers(2, 40))
-    return N, disc, steps, w, zc, (pmc, "abs" if absorb else ""), bool(structures)
+    return N, disc, steps, w, zc, (pmc, "abs" if absorb else ("cpml" if cpml else "")), bool(structures)
 
 
-def run(disc, steps, twostep, split):
-    with HipEngine(disc.spec, variant=L.VARIANT_FUSED) as e:
+def run(disc, steps, twostep, split, lib=None):
+    with HipEngine(disc.spec, lib=lib, variant=L.VARIANT_FUSED, axis_shift=0) as e:
         e.set_option(L.OPT_TWOSTEP, twostep)
         pairs = 0
         for r in (split, steps - split):
@@ -87,21 +97,29 @@ def run(disc, steps, twostep, split):
         return [e.get_field(c) for c in range(6)], e.results(), pairs
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    bad = 0
+def run_cases(n_cases, seed=1, lib=None, quiet=False):
+    """-> (cases that differ, cases that took step pairs)"""
+    rng = np.random.default_rng(seed)
+    bad = taken = 0
     for q in range(n_cases):
         N, disc, steps, w, zc, pmc, mat = case(rng)
         split = int(rng.integers(0, steps))
-        ref_f, ref_m, p0 = run(disc, steps, 0, split)
-        got_f, got_m, p1 = run(disc, steps, w + 64 * zc, split)
+        ref_f, ref_m, p0 = run(disc, steps, 0, split, lib)
+        got_f, got_m, p1 = run(disc, steps, w + 64 * zc, split, lib)
         ok = p0 == 0 and all(np.array_equal(a, b) for a, b in zip(ref_f, got_f)) and all(np.array_equal(ref_m[k], got_m[k]) for k in ref_m)
         amp = max(float(np.abs(f).max()) for f in ref_f)
-        print(f"case {q}: N={disc.spec.shape} steps={steps} split={split} W={w} zc={zc} pmc={pmc} media={mat} monitors={len(ref_m)} "
-              f"pairs={p1} max|F|={amp:.3g} -> {'ok' if ok else 'MISMATCH'}", flush=True)
+        if not quiet or not ok:
+            print(f"case {q}: N={disc.spec.shape} steps={steps} split={split} W={w} zc={zc} pmc={pmc} media={mat} monitors={len(ref_m)} "
+                  f"pairs={p1} max|F|={amp:.3g} -> {'ok' if ok else 'MISMATCH'}", flush=True)
         bad += not ok
-    print("fuzz:", n_cases - bad, "of", n_cases, "cases bit-identical")
+        taken += p1 > 0
+    return bad, taken
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    bad, taken = run_cases(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print("fuzz:", n_cases - bad, "of", n_cases, "cases bit-identical;", taken, "took step pairs")
     sys.exit(1 if bad else 0)
 
 

@@ -239,59 +239,80 @@ def test_fused_sweep_equals_two_pass_bit_for_bit(hip_lib, rows, zc):
             assert np.array_equal(x, y)
 
 
-def test_config4_mie_sphere_512_cube(hip_lib):
-    """BASELINE config[3]: Mie scattering, dielectric sphere, PlaneWave TFSF + PML, 512^3 cells on
-    one MI355X; scattering cross-section from the flux through a box in the scattered-field region
-    (normalised to 1 W/um^2 incident) vs the Mie series.  dl = lambda0/40 (lambda/25 inside the
-    sphere), radius 56 cells (size parameter ~8.8, several Mie resonances in the band):
-    sub-pixel averaged interface (0.2 % permittivity steps); error budget: 1 % plus the grid's numerical dispersion
-    (a 0.3 % frequency shift of the resonances), see the assertions."""
+_MIE_CACHE = {}
+
+
+def _mie_run(ppw, hip_lib):
+    """BASELINE config[3] at ``ppw`` cells per vacuum wavelength (40 = the 512^3 grid): dielectric sphere (radius 1.4 lambda0, size
+    parameter ~8.8: several Mie resonances in the band), PlaneWave TFSF + 12-layer PML, a closed flux box in the scattered-field
+    region with a running DFT at 25 frequencies.  The run ends on the field decay (shutoff 1e-5), not on run_time: the resonances
+    ring for ~220 periods, and a record cut at 70 periods (what this test did until round 4) moves sigma_sca by up to 4 % at the
+    resonance flanks whatever the grid (profiles/r4/r4i_mie_*: 0.95 f0 read -2.8 % after 70 periods, +0.9 % after 140, +1.1 %
+    after 280 at lambda0 / 30)."""
     import time
     from tidy3d_amd.analytic import mie_cross_sections
     from tidy3d_amd.data import assemble
+    if ppw in _MIE_CACHE:
+        return _MIE_CACHE[ppw]
     lam0 = 1.0
     f0 = C_0 / lam0
-    dl = lam0 / 40
-    n = 512 - 24
-    r, eps = 56 * dl, 2.56
-    pulse = td.GaussianPulse(freq0=f0, fwidth=f0 / 6)
-    freqs = [0.85 * f0, 0.95 * f0, f0, 1.05 * f0, 1.15 * f0]
-    box = 2 * r + 40 * dl
+    dl = lam0 / ppw
+    n = (512 - 24) * ppw // 40
+    r, eps = 56 * lam0 / 40, 2.56
+    freqs = [float(v) * f0 for v in np.linspace(0.85, 1.15, 25)]
+    box = 2 * r + lam0
     sim = td.Simulation(
-        size=(n * dl,) * 3, grid_spec=td.GridSpec.uniform(dl=dl), run_time=70 / f0,
+        size=(n * dl,) * 3, grid_spec=td.GridSpec.uniform(dl=dl), run_time=400 / f0,
         structures=[td.Structure(geometry=td.Sphere(radius=r), medium=td.Medium(permittivity=eps))],
-        sources=[td.TFSF(center=(0, 0, 0), size=(box,) * 3, source_time=pulse, injection_axis=2, direction="+")],
-        monitors=[td.FluxMonitor(center=(0, 0, 0), size=(box + 40 * dl,) * 3, freqs=freqs, name="sca")],
+        sources=[td.TFSF(center=(0, 0, 0), size=(box,) * 3, source_time=td.GaussianPulse(freq0=f0, fwidth=f0 / 6), injection_axis=2, direction="+")],
+        monitors=[td.FluxMonitor(center=(0, 0, 0), size=(box + lam0,) * 3, freqs=freqs, name="sca")],
         boundary_spec=td.BoundarySpec.all_sides(td.PML(num_layers=12)), shutoff=1e-5)
     t0 = time.time()
     disc = discretize(sim)
-    assert disc.spec.shape == (512, 512, 512)
+    assert disc.spec.shape == (n + 24,) * 3
     t1 = time.time()
     with HipEngine(disc.spec, lib=hip_lib) as e:
         st = e.run()
         raw = e.results()
     t2 = time.time()
-    sd = assemble(disc, raw, log="")
+    assert not st.diverged and st.stopped_early            # ended on the field decay
+    got = assemble(disc, raw, log="")["sca"].flux.values
     _, ana = mie_cross_sections(r, eps, freqs)
-    got = sd["sca"].flux.values
-    print(f"\n[mie 512^3] setup {t1 - t0:.1f}s, solve {t2 - t1:.1f}s ({st.steps_done} steps, "
-          f"{512**3 * st.steps_done / (st.run_ms * 1e-3) / 1e6:.0f} Mcells/s), sigma_sca/analytic = {got / ana}")
-    assert not st.diverged
-    # Unshifted: four of the five frequencies agree to 1 %, the one on the flank of a sharp resonance (0.95 f0: the
-    # series moves by 15 % per 1 % of frequency there) to 3.2 %.  That residue IS the grid's numerical dispersion
-    # (lambda/25 inside the sphere: resonances sit (k dl)^2/24 ~ 0.26 % low): evaluated at a frequency shifted by
-    # at most 0.3 %, the series matches every point to 1 %.
-    np.testing.assert_allclose(got, ana, rtol=0.035)
-    assert np.sum(np.abs(got / ana - 1) < 0.011) >= 4
-    # No fitted parameter (VERDICT round 2, weak 3: the earlier version let each of the five points pick its own best of 25
-    # frequency shifts).  What a single physical parameter can and cannot explain was checked on the measured values
-    # (profiles/r3c_mie_residual.txt): the shift the Yee dispersion relation predicts for the sphere's resonances,
-    #   delta(f) = (n k0 dl)^2 / 24 (3/5 - (c dt / (n dl))^2) = 0.09 ... 0.16 %,
-    # moves the 0.95 f0 point the WRONG way (0.968 -> 0.963), and no common frequency shift or radius scale brings all
-    # five within 1 % (best: radius x 0.9995, worst point 2.5 %): the residue is the staircase / sub-pixel representation
-    # of the curved interface acting on a resonance flank, not dispersion.  So the unshifted numbers are the statement:
-    # worst point 3.5 %, four of five within 1.1 %, mean deviation below 1.5 %.
-    assert np.mean(np.abs(got / ana - 1)) < 0.015
+    N = disc.spec.shape[0]
+    print(f"\n[mie {N}^3, lambda0/{ppw}] setup {t1 - t0:.1f}s, solve {t2 - t1:.1f}s ({st.steps_done} steps, "
+          f"{N**3 * st.steps_done / (st.run_ms * 1e-3) / 1e6:.0f} Mcells/s, {int(st.fused2_pairs)} step pairs, reason {int(st.fused2_off_reason)}), "
+          f"sigma_sca/analytic - 1 [%] = {np.round((got / ana - 1) * 100, 2)}")
+    _MIE_CACHE[ppw] = (got / ana - 1, np.asarray(freqs) / f0)
+    return _MIE_CACHE[ppw]
+
+
+def test_config4_mie_sphere_512_cube(hip_lib):
+    """BASELINE config[3]: Mie scattering, dielectric sphere, PlaneWave TFSF + PML, 512^3 cells on one MI355X; scattering
+    cross-section from the flux through a box in the scattered-field region (normalised to 1 W/um^2 incident) vs the Mie series
+    at 25 frequencies across the band (dl = lambda0/40, lambda/25 inside the sphere; sub-pixel averaged interface).  No fitted
+    parameter: mean deviation <= 1.3 %, worst point (the steepest flank of the sharpest resonance in the band) <= 5 %, and at the
+    five frequencies the earlier rounds quoted (0.85, 0.95, 1, 1.05, 1.15 f0) <= 2.5 %."""
+    dev, f = _mie_run(40, hip_lib)
+    assert np.abs(dev).mean() < 0.013, np.abs(dev).mean()
+    assert np.abs(dev).max() < 0.05, np.abs(dev).max()
+    five = [int(np.argmin(np.abs(f - v))) for v in (0.85, 0.95, 1.0, 1.05, 1.15)]
+    assert np.abs(dev[five]).max() < 0.025, dev[five]
+
+
+def test_mie_grid_refinement_second_order(hip_lib):
+    """The physics pin that separates "interface representation error" from "bug" while the oracle stays unpinned by reference
+    field data: the config-4 problem — same sphere, same physical box, same TFSF source, flux box and
+    25 frequencies, both runs ended by the field decay — at lambda0/20 (268^3 cells) and lambda0/40 (512^3).  A second-order scheme
+    brings sigma_sca / Mie series towards 1 by 4x per halving of dl: measured 3.65x on the mean deviation (3.87 % -> 1.06 %) and
+    3.75x on the worst point (15.6 % -> 4.2 %) (profiles/r4/r4i_mie_converged_25f.jsonl); asserted >= 3.3x and >= 3x.  The one
+    global frequency shift that fits each spectrum best — the grid's numerical dispersion — falls 0.35 % -> 0.18 % -> 0.11 % at
+    lambda0 / 20, 30, 40 (scripts/probe_mie_refinement.py)."""
+    d20, _ = _mie_run(20, hip_lib)
+    d40, _ = _mie_run(40, hip_lib)
+    m20, m40, w20, w40 = np.abs(d20).mean(), np.abs(d40).mean(), np.abs(d20).max(), np.abs(d40).max()
+    print(f"[mie refinement] mean deviation {m20:.4f} -> {m40:.4f} (x {m20 / m40:.2f}), worst {w20:.4f} -> {w40:.4f} (x {w20 / w40:.2f})")
+    assert m20 / m40 >= 3.3
+    assert w20 / w40 >= 3.0
 
 
 def test_config3_si_strip_waveguide_mode_launch(hip_lib):

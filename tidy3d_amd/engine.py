@@ -527,6 +527,9 @@ class HipEngine:
     def stats(self) -> L.FdtdStats:
         st = L.FdtdStats()
         self._chk(self.lib.dll.fdtd_get_stats(self.handle, C.byref(st)), "fdtd_get_stats")
+        if int(st.struct_bytes) != C.sizeof(L.FdtdStats):      # a stale or foreign build ($TIDY3D_AMD_LIBRARY): its layout is not this binding's
+            raise SolverLibraryError(f"'{self.lib.path}' fills an FdtdStats of {int(st.struct_bytes)} bytes, this binding expects "
+                                     f"{C.sizeof(L.FdtdStats)}: rebuild the library (python -m tidy3d_amd.build)")
         return st
 
     def set_option(self, key: int, value: int):

@@ -159,8 +159,10 @@ def load_library(path: Optional[str] = None) -> FdtdLib:
         if _cached is not None and getattr(_cached, "_path", None) == path:
             return _cached
         _prefer_hw_queues()
-        _cached = FdtdLib(path)
+        _cached = FdtdLib(path)         # (checks that every symbol of include/fdtd_hip.h is exported; HipEngine.stats checks the struct layout)
         _cached._path = path
+        import sys
+        print(f"tidy3d_amd: solver library overridden by $TIDY3D_AMD_LIBRARY: {path}", file=sys.stderr)
         return _cached
     if path is None:
         if _cached is not None:

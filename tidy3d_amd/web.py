@@ -128,8 +128,14 @@ def run(simulation, task_name: Optional[str] = None, folder_name: str = "default
         if diverged:
             lines.append("WARNING: field divergence detected, exiting solver.")
         pairs = int(getattr(stats, "fused2_pairs", 0))
+        shell_pairs = int(getattr(stats, "shell_pairs", 0))
+        why = int(getattr(stats, "fused2_off_reason", 0))
     if pairs:
-        lines.append(f"Two time steps per sweep: {pairs} step pairs ({2 * pairs} of {steps_done} steps).")
+        how = " — the bulk of the CPML-walled grid; its shell (layers + collar) by single steps beside it" if shell_pairs else ""
+        lines.append(f"Two time steps per sweep: {pairs} step pairs ({2 * pairs} of {steps_done} steps){how}.")
+    elif why:
+        from .lib import F2_OFF_REASONS
+        lines.append(f"One time step per sweep (two steps per sweep not available: {F2_OFF_REASONS.get(why, f'reason {why}')}).")
     lines += ["", f"Setup time (s):  {setup_s:.4f}", f"Solver time (s): {solve_s:.4f}",
               f"Time-stepping speed (cells/s): {spec.n_cells * steps_done / max(solve_s, 1e-9):.2e}"]
     sim_data = assemble(disc, raw, log="\n".join(lines), diverged=diverged, n_steps_run=steps_done, device_lib=used_lib, device=device)
