@@ -204,12 +204,17 @@ def roofline_entry(st, kr, local_cells, cells, K, elapsed, world, workload, spec
     return r
 
 
-def _v2_traffic(cells):
-    """PMC bytes of one V2 step (its three sweep launches), from profiles/pmc_traffic.json when it was measured on THIS
-    kernel source (hash), scaled from 512^3; else None."""
+def _workload_traffic(workload, cells, two_step):
+    """PMC bytes of one time step of a secondary workload (all its launches; half a step pair's when it runs in pairs), from
+    profiles/pmc_traffic.json when it was measured on THIS kernel source (hash), scaled from 512^3; else None."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if rec.get("v2_step_bytes") and rec.get("source_hash") == source_hash():
+        if rec.get("source_hash") != source_hash():
+            return None
+        w = (rec.get("workloads") or {}).get(workload)
+        if two_step and w:
+            return w["bytes_per_pair"] / 2 * cells / 512 ** 3
+        if not two_step and workload == "v2" and rec.get("v2_step_bytes") and not w:
             return rec["v2_step_bytes"] * cells / 512 ** 3
     except Exception:
         pass
@@ -262,7 +267,9 @@ def secondary_workload(HipEngine, L, n, workload, device, args, steps=40, repeat
         survey = 72.0 + (own - 48.0) + 4.0          # two passes + psi + material word: the SURVEY.md 8(d) accounting
         if two_step:
             # two steps per sweep: the fields cross the HBM interface once per PAIR (24 B per cell-step); psi moves every step
+            # (a lower bound for shell pairs too: their shell — CPML slabs + collar — still moves its fields every step)
             own = 24.0 + (own - 48.0)
+        traffic = _workload_traffic(workload, cells, two_step)
         return {"workload": f"{workload}: {WORKLOADS[workload]}", "value": cells * steps / el / 1e6, "unit": "Mcells/s",
                 "ms_per_step": el / steps * 1e3, "steps": steps, "repeats": repeats,
                 "ms_per_step_samples": [e / steps * 1e3 for e in samples],
@@ -275,7 +282,9 @@ def secondary_workload(HipEngine, L, n, workload, device, args, steps=40, repeat
                                          "planes_per_chunk": int(st.fused2_shape) >> 6,
                                          "single_steps_ms_per_step": single / steps * 1e3,
                                          "single_steps_value": cells * steps / single / 1e6} if two_step else None),
-                "traffic": _v2_traffic(cells) if workload == "v2" else None,
+                "traffic_per_step": traffic, "traffic_frac": (traffic / (el / steps) / HBM_PEAK) if traffic else None,
+                "traffic_over_minimum": (traffic / (own * cells)) if traffic else None,
+                "shell_pairs_in_10_steps": int(st.shell_pairs),
                 "bytes_per_cell_own_minimum": own,
                 "whole_step_frac": own * cells * steps / el / HBM_PEAK,
                 "bytes_per_cell_survey_8d": survey,
@@ -442,13 +451,20 @@ def main():
     if world > 1:
         # proof that the halo communicator (RCCL; the emulator's shim under BENCH_EMULATE) spans `world` ranks: every rank
         # reports what ncclCommCount / ncclCommUserRank return for ITS communicator
-        mine = torch.tensor([int(st.comm_ranks), int(st.comm_rank), z1 - z0], dtype=torch.int64, device="cpu" if emulate else "cuda")
+        mine = torch.tensor([int(st.comm_ranks), int(st.comm_rank), z1 - z0, int(st.fused2_pairs), int(st.fused2_shape), int(st.fused2_off_reason)],
+                            dtype=torch.int64, device="cpu" if emulate else "cuda")
         allc = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allc, mine)
         rows = [[int(v) for v in x.tolist()] for x in allc]
         med = np.median(np.asarray(rank_samples), axis=0) / K * 1e3
         out["rccl"] = {"rccl_ranks": sorted({r[0] for r in rows}), "comm_user_ranks": [r[1] for r in rows],
                        "planes_per_rank": [r[2] for r in rows],
+                       # z-slab ranks advance two time steps per sweep too (the planes next to a cut by single steps on the comm
+                       # stream, shipping after each): step pairs of every rank in the roofline run, their tile shape, and — where
+                       # a rank took none — why (FDTD_F2_OFF_*)
+                       "two_steps_per_sweep": {"steps_in_this_run": kr, "pairs_per_rank": [r[3] for r in rows],
+                                               "waves_per_workgroup": [r[4] & 63 for r in rows], "planes_per_chunk": [r[4] >> 6 for r in rows],
+                                               "off_reason_per_rank": [r[5] for r in rows]},
                        "ms_per_step_per_rank": [float(v) for v in med],
                        "ms_per_step_rank_min": float(med.min()), "ms_per_step_rank_max": float(med.max())}
     if world == 1 and int(st.fused2_pairs) > 0:
