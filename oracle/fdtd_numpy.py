@@ -327,6 +327,8 @@ class OracleFdtd:
             H[c] -= ch * (d1 - d2)
         self._tfsf_h(n)
         for s in self.spec.sources:
+            if n >= len(s.wave_h):                   # the list is spent (its waveform ends where the source ends)
+                continue
             w = s.w_re + 1j * s.w_im
             for cc in range(3, 6):
                 m = s.comp == cc
@@ -350,6 +352,8 @@ class OracleFdtd:
             E[c] += self.cb[c] * (d1 - d2)
         self._tfsf_e(n)
         for s in spec.sources:
+            if n >= len(s.wave_e):
+                continue
             w = s.w_re + 1j * s.w_im
             for cc in range(3):
                 m = s.comp == cc
@@ -389,6 +393,8 @@ class OracleFdtd:
         """Advance the incident 1-D H (uses e_inc^n), then correct the 3-D H nodes whose
         stencil straddles the TFSF surface with the incident E they miss / have in excess."""
         for t, st in zip(self.spec.tfsf, self.tfsf_state):
+            if n >= len(t.wave):                     # spent: no corrections, the incident grid rests
+                continue
             e1, h1 = st["e"], st["h"]
             # 3-D corrections use e_inc at t_n (the same time level as E^n in the H update)
             if len(t.h_corr_w):
@@ -404,6 +410,8 @@ class OracleFdtd:
 
     def _tfsf_e(self, n: int):
         for t, st in zip(self.spec.tfsf, self.tfsf_state):
+            if n >= len(t.wave):
+                continue
             e1, h1 = st["e"], st["h"]
             if len(t.e_corr_w):
                 vals = t.e_corr_w * h1[t.e_corr_aux]

@@ -358,7 +358,7 @@ def test_config3_si_strip_waveguide_mode_launch(hip_lib):
     purity = abs(a[0, 0, 0]) ** 2 * float(sd["mm"].mode_power.values[0, 0, 0]) / fwd
     dphi = np.angle(sd["p2"].Ex.values.ravel()[0] / sd["p1"].Ex.values.ravel()[0])
     dphi_ref = np.angle(np.exp(1j * beta * 1.0))
-    print(f"\n[config3] setup {t1 - t0:.1f}s solve {t2 - t1:.1f}s ({st.steps_done} steps, "
+    print(f"\n[config3] setup {t1 - t0:.1f}s solve {t2 - t1:.1f}s ({st.steps_done} steps, {int(st.fused2_pairs)} step pairs (reason {int(st.fused2_off_reason)}), "
           f"{disc.spec.n_cells * st.steps_done / (st.run_ms * 1e-3) / 1e6:.0f} Mcells/s) neff={neff:.6f} "
           f"fwd={fwd:.6f} bwd={bwd:.3e} purity={purity:.7f} |a-|^2={abs(a[1, 0, 0])**2:.3e} "
           f"dphi={dphi:.5f} vs {dphi_ref:.5f}")

@@ -128,3 +128,32 @@ def test_bench_v2_spec_shell_pairs_equal_single_steps(n, steps, hip_lib):
         assert p1 == steps // 2, p1
         for c in range(6):
             assert np.array_equal(got[c], ref[c]), (rep, c, float(np.abs(got[c] - ref[c]).max()))
+
+
+@pytest.mark.parametrize("kind", ["current_sheet", "tfsf"])
+def test_pairs_resume_when_sources_are_spent(kind, hip_lib):
+    """A current sheet of thousands of nodes / a TFSF box keep single steps for the length of their pulse only (the waveforms end
+    where the reference says the sources end; a TFSF list rests after four more transits of its incident grid): the rest of the
+    run goes out in shell pairs, bit-identical to single steps, with a flux DFT inside the bulk recording all along."""
+    N = (300, 120, 112)
+    size = tuple(n * DL for n in N)
+    pulse = td.GaussianPulse(freq0=3e14, fwidth=1.2e14)
+    srcs = {"current_sheet": [td.UniformCurrentSource(center=(0, 0, -1.5), size=(9.0, 3.5, 0), source_time=pulse, polarization="Ex")],
+            "tfsf": [td.TFSF(center=(0, 0, 0), size=(9.0, 3.0, 2.6), source_time=pulse, injection_axis=2, direction="+")]}[kind]
+    sim = td.Simulation(size=size, grid_spec=td.GridSpec.uniform(dl=DL), run_time=1.3e-13, sources=srcs,
+                        structures=[td.Structure(geometry=td.Sphere(center=(0.5, 0.1, 0.0), radius=0.8), medium=td.Medium(permittivity=3.0))],
+                        monitors=[td.FluxMonitor(center=(0.5, 0.1, 0), size=(2.4, 2.2, 2.0), freqs=[2.6e14, 3e14], name="flux"),
+                                  td.FieldTimeMonitor(center=(1.5, 0.3, 0.2), size=(0, 0, 0), name="probe", interval=3, colocate=False)],
+                        boundary_spec=td.BoundarySpec.all_sides(td.PML(num_layers=8)), shutoff=0)
+    disc = discretize(sim)
+    disc.spec.decay_every = 0
+    spec = disc.spec
+    n_src = max([len(s.wave_e) for s in spec.sources] + [len(t.wave) for t in spec.tfsf])
+    assert n_src < spec.n_steps - 200, (n_src, spec.n_steps)
+    ref_f, ref_m, p0 = _run(spec, hip_lib, twostep=0, steps=spec.n_steps)
+    got_f, got_m, p1 = _run(spec, hip_lib, steps=spec.n_steps)
+    assert p0 == 0 and p1 >= 0.3 * (spec.n_steps - n_src), (p1, spec.n_steps, n_src)
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), c
+    for k in ref_m:
+        assert np.abs(ref_m[k]).max() > 0 and np.array_equal(got_m[k], ref_m[k]), k

@@ -103,6 +103,7 @@ struct Monitor {
 // node table of one kind of step pair of the two-step sweep: the E-side source nodes and the nodes small time monitors
 // sample of the middle step (InjP), for one set of recording monitors
 struct F2Table {
+  bool with_sources = true;        // the source nodes are listed (false: the table of a pair whose source lists are all spent)
   std::vector<int> mons;           // time monitors whose middle-step samples the sweep copies out (ascending)
   std::vector<int> cap_off;        // their offsets into the sample buffer
   std::vector<int> dfts;           // DFT monitors that record at the first (flag 1) / middle (flag 2) step: the sweep copies
@@ -239,6 +240,9 @@ struct FdtdSolver {
   float* src_tab = nullptr;           // [step][node] source terms of every step, formed once (nullptr: per pair)
   long long src_tab_steps = 0, src_tab_nodes = 0;
   bool src_on_seam = false;           // an E-side source node lies next to a seam between x tiles: step n+1's terms go behind the launch
+  bool src_h_on_seam = false;         // an H_y / H_z source node in the column left of a seam: no pairs while that list is alive
+  long long src_nodes = 0;            // source nodes of all lists
+  int f2_dyn_reason = 0;              // the last reason a step of this run could not open a pair because of its sources (FDTD_F2_OFF_*)
   long long src_h_nodes = 0;          // H-side source nodes (need the table of all steps)
 };
 
@@ -725,7 +729,7 @@ int fused2_why_not(const FdtdSolver* h, bool slab_rank = false) {
   { int W, zc; if (!fused2_shape(h, &W, &zc)) return FDTD_F2_OFF_TOO_SMALL; }
   if (h->comm && !slab_rank) return FDTD_F2_OFF_COMM;
   if (!h->ade.empty()) return FDTD_F2_OFF_ADE;
-  if (!h->tfsf.empty()) return FDTD_F2_OFF_TFSF;
+  // (sources are judged step by step, fused2_sources_why_not: a TFSF box or a mode plane keeps single steps only while it injects)
   // PEC walls; the min faces may be PMC (the symmetry planes of a half / quarter / eighth domain)
   // (a z-slab rank: a neighbour face is no wall — the sweep stays two planes clear of it, fdtd_run)
   for (int f = 0; f < 6; ++f)
@@ -733,28 +737,29 @@ int fused2_why_not(const FdtdSolver* h, bool slab_rank = false) {
         !(slab_rank && f >= 4 && h->cfg.bc[f] == FDTD_BC_NEIGHBOR)) return FDTD_F2_OFF_BOUNDARY;
   if ((h->g.pec_z0 != 0) != (h->cfg.bc[4] == FDTD_BC_PEC) || h->g.nx % 4 || h->g.nz < 2) return FDTD_F2_OFF_BOUNDARY;
   for (int a = 0; a < 3; ++a) if (h->mirror_wall[a] >= 0) return FDTD_F2_OFF_BOUNDARY;
-  long long nodes = 0;
-  for (const PointSrc& s : h->psrc) {
-    nodes += s.n_e + s.n_h;
-    // absorber layers are applied inside the sweep, H-side sources of step n in front of it: damping would come after them
-    if (h->has_damp && s.n_h) return FDTD_F2_OFF_H_SOURCE_ABSORBER;
-    // an H_y / H_z source node in the column left of a seam between x tiles: the seam kernel rebuilds that value without it
-    for (long long t = 0; t < s.n_h; ++t) {
-      const int i = (int)(s.host_cell_h[(size_t)t] % h->g.nx), c = s.host_comp_h[(size_t)t];
-      if (c != 3 && i % 256 == 255 && i + 1 < h->g.nx) return FDTD_F2_OFF_SEAM_SOURCE;
-    }
-  }
-  return nodes <= kMaxInj ? 0 : FDTD_F2_OFF_SOURCES;
+  return 0;
 }
 bool fused2_eligible(const FdtdSolver* h) { return !any_pml(h) && fused2_why_not(h) == 0; }
-// the point sources of step n: all alive or all spent (the kernel applies the whole table or nothing)
-bool fused2_sources_uniform(const FdtdSolver* h, long long n) {
+// Can the pair (n, n + 1) be taken as far as the sources go?  0 = yes, else the reason.  The sweep applies the node table of ALL
+// point-source lists or none: they must be all alive (then at most kMaxInj nodes — a dipole, a few; not a mode plane or a current
+// sheet —, no H_y / H_z node left of a tile seam, no magnetic node together with absorber layers, and the table of all steps
+// for magnetic nodes) or all spent (then nothing is injected and their number does not matter: a mode source or a TFSF box
+// keeps single steps for the length of its pulse, the rest of the run goes out in pairs).  `*alive`: the lists inject at step n.
+int fused2_sources_why_not(const FdtdSolver* h, long long n, bool* alive = nullptr) {
   bool any_alive = false, any_spent = false;
   for (const PointSrc& s : h->psrc) {
     if (!s.n_e && !s.n_h) continue;
     if (n < s.n_steps) any_alive = true; else any_spent = true;
   }
-  return !(any_alive && any_spent);
+  if (alive) *alive = any_alive;
+  for (const Tfsf& t : h->tfsf) if (n < t.n_steps) return FDTD_F2_OFF_TFSF;
+  if (any_alive && any_spent) return FDTD_F2_OFF_SOURCES;
+  if (!any_alive) return 0;
+  if (h->src_nodes > kMaxInj) return FDTD_F2_OFF_SOURCES;
+  if (h->src_h_nodes > 0 && !h->src_tab) return FDTD_F2_OFF_SOURCES;      // H-side nodes take their terms of step n+1 from the table only
+  if (h->has_damp && h->src_h_nodes > 0) return FDTD_F2_OFF_H_SOURCE_ABSORBER;  // absorber layers are applied inside the sweep, H-side sources of step n in front of it
+  if (h->src_h_on_seam) return FDTD_F2_OFF_SEAM_SOURCE;                    // the seam kernel rebuilds that value without the source term
+  return 0;
 }
 
 // A time monitor whose record of a middle step the sweep can copy out on the way: every component of every cell of its box,
@@ -810,6 +815,7 @@ int fused2_sources(FdtdSolver* h) {
     // the source terms of every step, formed once with the operations of point_source_kernel
     h->src_tab = nullptr;
     h->src_on_seam = false;
+    h->src_h_on_seam = false;
     long long nodes = 0, steps = 0;
     h->src_h_nodes = 0;
     for (const PointSrc& s : h->psrc) {
@@ -820,7 +826,12 @@ int fused2_sources(FdtdSolver* h) {
         const int i = (int)(s.host_cell_e[(size_t)t] % g.nx);
         h->src_on_seam = h->src_on_seam || (i % 256 == 255 && i + 1 < g.nx) || (i % 256 == 0 && i > 0);
       }
+      for (long long t = 0; t < s.n_h; ++t) {
+        const int i = (int)(s.host_cell_h[(size_t)t] % g.nx), c = s.host_comp_h[(size_t)t];
+        h->src_h_on_seam = h->src_h_on_seam || (c != 3 && i % 256 == 255 && i + 1 < g.nx);
+      }
     }
+    h->src_nodes = nodes;
     if (nodes > 0 && nodes * steps <= (1LL << 24)) {
       if (dev_alloc(h, &h->src_tab, (size_t)(nodes * steps))) return -1;
       long long off = 0;
@@ -836,15 +847,17 @@ int fused2_sources(FdtdSolver* h) {
   return 0;
 }
 
-const F2Table* fused2_table(FdtdSolver* h, const F2Plan& plan) {
+const F2Table* fused2_table(FdtdSolver* h, const F2Plan& plan, bool with_sources) {
   const GridP& g = h->g;
   if (fused2_sources(h)) return nullptr;
-  for (const F2Table& t : h->f2_tables) if (t.mons == plan.mons && t.dfts == plan.dfts && t.dft_when == plan.dft_when) return &t;
+  for (const F2Table& t : h->f2_tables)
+    if (t.with_sources == with_sources && t.mons == plan.mons && t.dfts == plan.dfts && t.dft_when == plan.dft_when) return &t;
   // the nodes of all E-side lists, sorted by plane; nodes of one plane keep their list order (a node two lists share
   // receives their terms in the order the source kernels would add them); the monitor samples of a plane follow them
   std::vector<std::array<int, 5>> ent;        // k, i, j, code, index
   int off = 0;
   for (const PointSrc& s : h->psrc) {
+    if (!with_sources) break;          // (spent lists: nothing is injected, and a mode plane's 10^5 nodes would be walked per plane for nothing)
     for (long long t = 0; t < s.n_e; ++t, ++off) {
       const long long cell = s.host_cell_e[(size_t)t];
       ent.push_back({(int)(cell / g.sxy), (int)(cell % g.nx), (int)((cell % g.sxy) / g.nx), s.host_comp_e[(size_t)t] % 3, off});
@@ -855,6 +868,7 @@ const F2Table* fused2_table(FdtdSolver* h, const F2Plan& plan) {
     }
   }
   F2Table tb;
+  tb.with_sources = with_sources;
   tb.mons = plan.mons;
   int coff = 0;
   for (size_t q = 0; q < plan.mons.size(); ++q) {
@@ -989,7 +1003,7 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
   StepP sp = step_params(h);
   time_begin(h, 2, st);
   const MatP mp = mat_params(h);
-  launch_fused2_step(st, W, (h->mem_hints ? 1 : 0) | (h->mat4 ? 2 : 0) | ((tb->mons.empty() && h->src_h_nodes == 0 && !tb->dstart) ? 0 : 4) |
+  launch_fused2_step(st, W, (h->mem_hints ? 1 : 0) | (h->mat4 ? 2 : 0) | ((tb->mons.empty() && (!tb->with_sources || h->src_h_nodes == 0) && !tb->dstart) ? 0 : 4) |
                      (clip ? 16 : (h->has_damp ? 8 : 0)),
                      remap ? ((total + 7) / 8) * 8 : total, g, h->f, h->f2, sp, mp, zc, nbx, nby, nbz, remap, inj, h->seam_buf, dmp, box);
   if (nbx > 1) launch_seams(st, g, h->f2, sp, mp, h->seam_buf, nbx - 1, dmp, box);
@@ -1148,7 +1162,7 @@ float time_sweep_pairs(FdtdSolver* h, hipStream_t st, hipEvent_t e0, hipEvent_t 
   // a run the two-step sweep covers is timed on THAT kernel (its access pattern — 16 rows per workgroup, 32-plane chunks — is
   // not the single sweep's): launches without sources or monitor samples, set a -> b -> a as in the run
   const F2Table* tb = nullptr;
-  if (fused2_eligible(h)) { F2Plan none; tb = fused2_table(h, none); }
+  if (fused2_eligible(h)) { F2Plan none; tb = fused2_table(h, none, false); }
   for (int k = 0; k < 6; ++k) {
     if (k == 2) hipEventRecord(e0, st);
     if (tb) {
@@ -2685,9 +2699,9 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     h->f2_off_reason = any_pml(h) ? shell_why_not(h, &sg) : fused2_why_not(h);
     f2s_ok = any_pml(h) && h->f2_off_reason == 0;
   }
+  h->f2_dyn_reason = 0;
   if (f2_ok || f2s_ok) {
     if (fused2_sources(h)) return -1;
-    if (h->src_h_nodes > 0 && !h->src_tab) { f2_ok = f2s_ok = false; h->f2_off_reason = FDTD_F2_OFF_SOURCES; }      // H-side nodes take their terms of step n+1 from the table only
   }
   if (f2s_ok && probe_stream_overlap(h)) return -1;
   // z-slab ranks (pipelined schedule): step pairs with the planes next to the neighbour faces as the shell
@@ -2695,7 +2709,6 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   if (fused_multi) h->f2_off_reason = f2m_ok ? 0 : (any_pml(h) || h->has_damp ? FDTD_F2_OFF_COMM : (fused2_why_not(h, true) ? fused2_why_not(h, true) : FDTD_F2_OFF_COMM));
   if (f2m_ok) {
     if (fused2_sources(h) || ensure_third_set(h)) return -1;
-    if (h->src_h_nodes > 0 && !h->src_tab) { f2m_ok = false; h->f2_off_reason = FDTD_F2_OFF_SOURCES; }
   }
   // steps n and n + 1 of a grid walled by CPML: the bulk as ONE two-step sweep on st, the shell as two single steps on cs
   auto shell_pair = [&](long long n, const F2Table* tb) -> int {
@@ -2746,9 +2759,12 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     }
     // steps n and n + 1 as ONE sweep?  (fdtd_kernels2.hpp; no decay check on the middle step, sources all alive or all spent,
     // every monitor that records at n or n + 1 a small time monitor the sweep can sample)
+    bool src_alive = false;
+    int src_why = 0;
     const bool pair = fused && (f2_ok || f2s_ok) && done + 2 <= n_steps && !(h->decay_every > 0 && ((n + 1) % h->decay_every) == 0) &&
-                      fused2_sources_uniform(h, n) && fused2_plan(h, n, &f2_plan, f2s_ok ? sg.o0 : nullptr, f2s_ok ? sg.o1 : nullptr) &&
-                      ((f2_plan.mons.empty() && f2_plan.dfts.empty()) || sources_alive(n) || h->psrc.empty());
+                      (src_why = fused2_sources_why_not(h, n, &src_alive)) == 0 &&
+                      fused2_plan(h, n, &f2_plan, f2s_ok ? sg.o0 : nullptr, f2s_ok ? sg.o1 : nullptr);
+    if (src_why) h->f2_dyn_reason = src_why;
     // (with H-side sources the monitors of a pair still take E^n and H^{n-1/2} here: those sources change H^{n-1/2} before the
     //  sweep, and pair_record reads the set afterwards)
     if (rec) record_monitors(h, n, false, st, (pair && h->src_h_nodes == 0) ? &f2_plan : nullptr);
@@ -2762,10 +2778,11 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       // takes single steps).  Same kernels and formulas: the same bits (tests/test_dist_gloo.py).  Entry and exit state:
       // "primed" (above).  Pairs keep clear of monitor records, decay checks and the end of the run (joined tails).
       auto decay_at = [&](long long m) { return h->decay_every > 0 && (m % h->decay_every) == 0; };
+      bool src_alive_m = false;
       if (f2m_ok && done + 3 <= n_steps && !rec_at(n) && !rec_at(n + 1) && !rec_at(n + 2) && !decay_at(n + 1) && !decay_at(n + 2) &&
-          fused2_sources_uniform(h, n)) {
+          fused2_sources_why_not(h, n, &src_alive_m) == 0) {
         F2Plan none;
-        const F2Table* tb = fused2_table(h, none);
+        const F2Table* tb = fused2_table(h, none, src_alive_m);
         if (!tb) return -1;
         const int bl = nb_lo ? 2 : 0, bh = nb_hi ? 2 : 0;
         const FieldP A = h->f, B = h->f2, T = h->f3;
@@ -2869,7 +2886,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       h->step = n + 2;
       ++done;                                              // (the loop header counts the second step)
     } else if (pair && f2s_ok) {
-      const F2Table* tb = fused2_table(h, f2_plan);
+      const F2Table* tb = fused2_table(h, f2_plan, src_alive);
       if (!tb) return -1;
       if (shell_pair(n, tb)) return -1;
       h->fused2_pairs++;
@@ -2877,7 +2894,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       h->step = n + 2;
       ++done;
     } else if (pair) {
-      const F2Table* tb = fused2_table(h, f2_plan);
+      const F2Table* tb = fused2_table(h, f2_plan, src_alive);
       if (!tb) return -1;
       bool sources2_done = false, damp2_done = true;
       launch_sources(h, false, n, 0, nz, st);              // H-side sources of step n act on H^{n-1/2}, as before a single step
@@ -3254,7 +3271,7 @@ int fdtd_get_stats(FdtdSolver* h, FdtdStats* out) {
   out->fused2_pairs = h->fused2_pairs;
   out->fused2_shape = h->fused2_pairs ? (h->twostep_w_used | (h->twostep_zc_used << 6)) : 0;
   out->shell_pairs = h->shell_pairs;
-  out->fused2_off_reason = h->fused2_pairs ? 0 : h->f2_off_reason;
+  out->fused2_off_reason = h->fused2_pairs ? 0 : (h->f2_off_reason ? h->f2_off_reason : h->f2_dyn_reason);
   out->struct_bytes = (int32_t)sizeof(FdtdStats);
   return 0;
 }
