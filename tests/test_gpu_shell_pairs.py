@@ -157,3 +157,45 @@ def test_pairs_resume_when_sources_are_spent(kind, hip_lib):
         assert np.array_equal(got_f[c], ref_f[c]), c
     for k in ref_m:
         assert np.abs(ref_m[k]).max() > 0 and np.array_equal(got_m[k], ref_m[k]), k
+
+
+def test_periodic_unit_cell_in_step_pairs(hip_lib):
+    """A metasurface's unit cell — periodic x and y, CPML in z, a dielectric pillar and a lossy film, dipoles of both kinds in the
+    first / last rows and columns — goes out in shell pairs: periodic x wraps inside the two-step sweep (the wrap is one more seam
+    for the seam kernel, beside the tile seam at column 256), the two rows next to a periodic y face and the CPML planes are the
+    shell.  Pairs == single steps bit for bit, and <= 2e-5 from the fp64 oracle directly."""
+    from oracle.fdtd_numpy import OracleFdtd
+    N = (320, 48, 120)
+    size = tuple((n - 1e-6) * DL for n in N)
+    hx, hy, hz = (0.5 * v for v in size)
+    per = td.Boundary.periodic()
+    structures = [td.Structure(geometry=td.Cylinder(center=(0.4, 0.1, 0.0), radius=0.6, length=1.2, axis=2), medium=td.Medium(permittivity=6.0)),
+                  td.Structure(geometry=td.Box(center=(0, 0, -1.0), size=(td.inf, td.inf, 0.3)), medium=td.Medium(permittivity=2.1, conductivity=0.05))]
+    sources = [td.PointDipole(center=(-hx + 0.3 * DL, -hy + 0.6 * DL, 0.4), source_time=PULSE, polarization="Ey"),
+               td.PointDipole(center=(hx - 0.4 * DL, 0.1, -0.3), source_time=PULSE, polarization="Ez"),
+               td.PointDipole(center=(hx - 0.6 * DL, hy - 0.3 * DL, 0.1), source_time=PULSE, polarization="Hz"),
+               td.PointDipole(center=(-hx + 255.2 * DL, -hy + 1.4 * DL, 0.9), source_time=PULSE, polarization="Ex"),
+               td.PointDipole(center=(0.1, 0.0, 0.2), source_time=PULSE, polarization="Ez")]
+    monitors = [td.FieldTimeMonitor(center=(0.3, 0.1, 0.5), size=(0, 0, 0), name="probe", interval=1, colocate=False),
+                td.FluxMonitor(center=(0, 0, 1.6), size=(td.inf, td.inf, 0), freqs=[2.8e14, 3.2e14], name="T")]
+    sim = td.Simulation(size=size, grid_spec=td.GridSpec.uniform(dl=DL), run_time=1e-12, structures=structures, sources=sources,
+                        monitors=monitors, boundary_spec=td.BoundarySpec(x=per, y=per, z=td.Boundary.pml(num_layers=8)), shutoff=0)
+    disc = discretize(sim, n_steps=70)
+    disc.spec.decay_every = 0
+    assert disc.spec.shape == (320, 48, 136), disc.spec.shape
+    ref_f, ref_m, p0 = _run(disc.spec, hip_lib, twostep=0, steps=70)
+    got_f, got_m, p1 = _run(disc.spec, hip_lib, steps=70)
+    assert p0 == 0 and p1 >= 12, p1          # (the flux plane spans the periodic axes: its records — every 2nd or 3rd step here — end pairs)
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), c
+    for k in ref_m:
+        assert np.abs(ref_m[k]).max() > 0 and np.array_equal(got_m[k], ref_m[k]), k
+    o = OracleFdtd(disc.spec)
+    om = o.run()
+    for k in om:
+        assert rel_err(got_m[k], om[k]) < TOL, (k, rel_err(got_m[k], om[k]))
+    en = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in o.E))
+    hn = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in o.H))
+    for c in range(3):
+        assert np.linalg.norm(got_f[c] - o.E[c]) / en < TOL, c
+        assert np.linalg.norm(got_f[3 + c] - o.H[c]) / hn < TOL, c

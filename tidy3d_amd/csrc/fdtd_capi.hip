@@ -724,7 +724,7 @@ bool fused2_shape(const FdtdSolver* h, int* W, int* zc, const ClipP* box = nullp
 
 // Why a run takes no step pairs (FDTD_F2_OFF_*, include/fdtd_hip.h); 0 = nothing in the problem keeps the two-step sweep
 // from it.  CPML is not a reason here: the caller then asks shell_eligible.
-int fused2_why_not(const FdtdSolver* h, bool slab_rank = false) {
+int fused2_why_not(const FdtdSolver* h, bool slab_rank = false, bool shell = false) {
   if (h->twostep_w == 0) return FDTD_F2_OFF_DISABLED;
   { int W, zc; if (!fused2_shape(h, &W, &zc)) return FDTD_F2_OFF_TOO_SMALL; }
   if (h->comm && !slab_rank) return FDTD_F2_OFF_COMM;
@@ -732,9 +732,11 @@ int fused2_why_not(const FdtdSolver* h, bool slab_rank = false) {
   // (sources are judged step by step, fused2_sources_why_not: a TFSF box or a mode plane keeps single steps only while it injects)
   // PEC walls; the min faces may be PMC (the symmetry planes of a half / quarter / eighth domain)
   // (a z-slab rank: a neighbour face is no wall — the sweep stays two planes clear of it, fdtd_run)
+  // (a shell pair: a periodic y / z face has the two rows / planes next to it in the shell, periodic x wraps inside the sweep)
   for (int f = 0; f < 6; ++f)
     if (h->cfg.bc[f] != FDTD_BC_PEC && !((f & 1) == 0 && h->cfg.bc[f] == FDTD_BC_PMC) &&
-        !(slab_rank && f >= 4 && h->cfg.bc[f] == FDTD_BC_NEIGHBOR)) return FDTD_F2_OFF_BOUNDARY;
+        !(slab_rank && f >= 4 && h->cfg.bc[f] == FDTD_BC_NEIGHBOR) &&
+        !(shell && h->cfg.bc[f] == FDTD_BC_PERIODIC && h->cfg.bc[f ^ 1] == FDTD_BC_PERIODIC)) return FDTD_F2_OFF_BOUNDARY;
   if ((h->g.pec_z0 != 0) != (h->cfg.bc[4] == FDTD_BC_PEC) || h->g.nx % 4 || h->g.nz < 2) return FDTD_F2_OFF_BOUNDARY;
   for (int a = 0; a < 3; ++a) if (h->mirror_wall[a] >= 0) return FDTD_F2_OFF_BOUNDARY;
   return 0;
@@ -949,8 +951,9 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
   const int R = W - 3;
   const int nbx = (g.nx + 255) / 256, nby = (box.j1 - box.j0 + R - 1) / R;
   const int nbz = (box.k1 - box.k0 + zc - 1) / zc;
-  if (nbx > 1 && !h->seam_buf &&
-      dev_alloc(h, &h->seam_buf, (size_t)(nbx - 1) * kSeamArrays * (size_t)(g.nz + 2) * (size_t)g.ny)) return -1;
+  const int n_seams = nbx - 1 + ((clip && h->cfg.bc[0] == FDTD_BC_PERIODIC) ? 1 : 0);        // (periodic x: the wrap is a seam too)
+  if (!h->seam_buf && (nbx > 1 || h->cfg.bc[0] == FDTD_BC_PERIODIC) &&
+      dev_alloc(h, &h->seam_buf, (size_t)nbx * kSeamArrays * (size_t)(g.nz + 2) * (size_t)g.ny)) return -1;
   if (!h->inj_val && dev_alloc(h, &h->inj_val, (size_t)kMaxInj)) return -1;
   if (!h->cap_val && dev_alloc(h, &h->cap_val, (size_t)kMaxCap)) return -1;
   InjP inj{};
@@ -1006,7 +1009,7 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
   launch_fused2_step(st, W, (h->mem_hints ? 1 : 0) | (h->mat4 ? 2 : 0) | ((tb->mons.empty() && (!tb->with_sources || h->src_h_nodes == 0) && !tb->dstart) ? 0 : 4) |
                      (clip ? 16 : (h->has_damp ? 8 : 0)),
                      remap ? ((total + 7) / 8) * 8 : total, g, h->f, h->f2, sp, mp, zc, nbx, nby, nbz, remap, inj, h->seam_buf, dmp, box);
-  if (nbx > 1) launch_seams(st, g, h->f2, sp, mp, h->seam_buf, nbx - 1, dmp, box);
+  if (n_seams > 0) launch_seams(st, g, h->f2, sp, mp, h->seam_buf, n_seams, dmp, box);
   time_end(h, st);
   if (!clip) swap_sets(h);
   return 0;
@@ -1032,6 +1035,9 @@ bool shell_geometry(const FdtdSolver* h, ShellGeom* G) {
     const PmlAxisDev& P = h->pml[a];
     const int lo = P.ns > 0 ? P.lo : 0, hi0 = P.ns > 0 ? P.hi0 : N[a];
     int o0 = lo > 0 ? lo + 2 : 0, o1 = hi0 < N[a] ? hi0 - 1 : N[a];
+    // a periodic y / z axis: the bulk stays two cells clear of the wrap (what it reads then lies inside the grid; the shell's
+    // single steps wrap as they always did); periodic x wraps inside the sweep
+    if (a > 0 && h->cfg.bc[2 * a] == FDTD_BC_PERIODIC) { o0 = 2; o1 = N[a] - 2; }
     if (a == 0) { o0 = (o0 + 3) / 4 * 4; o1 = o1 / 4 * 4; }
     if (o1 - o0 < (a == 0 ? 16 : 8)) return false;        // (also: the rounded x ranges met, lo == hi0 == n)
     G->o0[a] = o0; G->o1[a] = o1;
@@ -1098,10 +1104,14 @@ int launch_shell_step(FdtdSolver* h, const FieldP& src, const FieldP& dst, int p
 }
 
 // 0 = the run can take shell pairs (and *G holds the bulk), else the reason it cannot
+bool any_periodic(const FdtdSolver* h) {
+  for (int f = 0; f < 6; ++f) if (h->cfg.bc[f] == FDTD_BC_PERIODIC) return true;
+  return false;
+}
 int shell_why_not(const FdtdSolver* h, ShellGeom* G) {
-  const int why = fused2_why_not(h);
+  const int why = fused2_why_not(h, false, true);
   if (why) return why;
-  if (!any_pml(h)) return FDTD_F2_OFF_PML;              // (nothing to do here: the plain pairs cover it)
+  if (!any_pml(h) && !any_periodic(h)) return FDTD_F2_OFF_PML;              // (nothing to do here: the plain pairs cover it)
   if (h->shell_on == 0) return FDTD_F2_OFF_PML;
   if (h->has_damp) return FDTD_F2_OFF_PML;              // absorber layers on one axis, CPML on another: single steps
   // the shell runs the CPML recursions inside its sweeps (all axes), as a one-GPU step does by default
@@ -1400,14 +1410,15 @@ void copy_plane(FdtdSolver* h, float* dst, const float* src, hipStream_t st) {
   if (h->step_dev_mode) hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((pc + 255) / 256)), dim3(256), 0, st, dst, src, pc);
   else hipMemcpyAsync(dst, src, pc * 4, hipMemcpyDeviceToDevice, st);
 }
-void fill_ghost_fused(FdtdSolver* h, hipStream_t st) {
+void fill_ghost_fused(FdtdSolver* h, hipStream_t st, const FieldP* fs = nullptr) {
   if (h->cfg.bc[4] != FDTD_BC_PERIODIC) return;
+  const FieldP F = fs ? *fs : h->f;
   const long long pc = plane_cells(h);
   const long long top = (long long)(h->g.nz - 1) * pc;
-  float* lo[5] = {h->f.ex, h->f.ey, h->f.ez, h->f.hx, h->f.hy};
+  float* lo[5] = {F.ex, F.ey, F.ez, F.hx, F.hy};
   for (float* p : lo) copy_plane(h, p - pc, p + top, st);
-  copy_plane(h, h->f.ex + (long long)h->g.nz * pc, h->f.ex, st);
-  copy_plane(h, h->f.ey + (long long)h->g.nz * pc, h->f.ey, st);
+  copy_plane(h, F.ex + (long long)h->g.nz * pc, F.ex, st);
+  copy_plane(h, F.ey + (long long)h->g.nz * pc, F.ey, st);
 }
 
 // slabs of one axis: E-side ranges [0,n_lo) and [N-n_hi+1,N); H-side [0,n_lo) and [N-n_hi,N)
@@ -2696,8 +2707,9 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   bool f2s_ok = false;
   h->f2_off_reason = !fused ? FDTD_F2_OFF_VARIANT : (tb_ok ? FDTD_F2_OFF_DISABLED : 0);
   if (fused && !tb_ok && !f2_ok) {
-    h->f2_off_reason = any_pml(h) ? shell_why_not(h, &sg) : fused2_why_not(h);
-    f2s_ok = any_pml(h) && h->f2_off_reason == 0;
+    const bool shell = any_pml(h) || any_periodic(h);
+    h->f2_off_reason = shell ? shell_why_not(h, &sg) : fused2_why_not(h);
+    f2s_ok = shell && h->f2_off_reason == 0;
   }
   h->f2_dyn_reason = 0;
   if (f2_ok || f2s_ok) {
@@ -2726,6 +2738,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       in1[a] = sg.o1[a] < N[a] ? sg.o1[a] - (a == 0 ? 4 : 1) : N[a];
     }
     launch_sources(h, false, n, 0, nz, st);                // H-side sources of step n act on H^{n-1/2}, as before a single step
+    if (h->cfg.bc[4] == FDTD_BC_PERIODIC) fill_ghost_h(h, st);   // ghost(-1) must carry them too (as in a single step)
     HIPCHK(h, hipEventRecord(h->ev_shell_a, st));
     HIPCHK(h, hipStreamWaitEvent(cs, h->ev_shell_a, 0));
     const FieldP A = h->f, B = h->f2, T = h->f3;
@@ -2736,6 +2749,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     if (launch_shell_step(h, A, T, par, in0, in1, pml_in, cs)) return -1;
     launch_sources(h, true, n, 0, nz, cs, false, &T);      // E-side sources of step n, H-side ones of step n + 1: on the middle step
     launch_sources(h, false, n + 1, 0, nz, cs, false, &T);
+    fill_ghost_fused(h, cs, &T);                           // periodic z: the middle step's wrapped planes (its top and bottom planes are the shell's)
     if (launch_shell_step(h, T, B, par ^ 1, sg.o0, sg.o1, pml_in, cs)) return -1;
     HIPCHK(h, hipEventRecord(h->ev_shell_b, cs));
     HIPCHK(h, hipStreamWaitEvent(st, h->ev_shell_b, 0));

@@ -154,6 +154,10 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
   // stored outside it, and the seam scratch is written for every row / plane this workgroup computes (the seam kernel
   // differentiates the row and plane below the box's first ones, which no workgroup owns).
   constexpr bool CLIP = (OPT & 16) != 0;
+  // periodic x (clipped launches only; periodic y / z faces are part of the shell: the box stays two cells clear of them): the
+  // first lane of a row takes column nx - 1 as its x-halo column, the last one column 0 as its right neighbour — step one is
+  // exact — and the wrap is one more seam for step two (the row's last column | its first), repaired by seam_kernel
+  const bool per_x = CLIP && g.bcx0 == BC_PERIODIC;
   // (Issuing the loads of plane k+1 behind the second barrier of plane k — the one way to overlap them with compute inside a wave —
   //  was measured: + 60 registers, slower at every workgroup size, profiles/r3q; taken out.)
   const int total = nbx * nby * nbz;
@@ -223,8 +227,8 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
   const bool use_jp = (j + 1 < g.ny);
   const long long rowb = (long long)j * g.nx;
   const long long rowpb = use_jp ? rowb + g.nx : 0;
-  const bool xh = act && (tx == 0) && !first_x;     // the tile's first lane recomputes H1_{y,z} of column i0-1
-  const int im = first_x ? 0 : i0 - 1;
+  const bool xh = act && (tx == 0) && (!first_x || per_x);     // the tile's first lane recomputes H1_{y,z} of column i0-1
+  const int im = first_x ? (per_x ? g.nx - 1 : 0) : i0 - 1;
   // min faces: a PEC wall (tangential E = 0 on it) or a PMC one (H mirrored with the opposite sign behind it), as in
   // fused_step_kernel; max faces are PEC walls
   const bool pmc_x0 = g.bcx0 == BC_PMC, pmc_y0 = g.bcy0 == BC_PMC, pmc_z0 = !g.pec_z0;
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     ldf<V, true>(eym, uni(a.ey + pb), ubc);
     if (use_jp) ldf<V, true>(ezj, uni(a.ez + (long long)(kA - 1) * g.sxy + rowpb), ubc);
     float ezx = lane_next(ezm[0]);
-    if (act && (tx == 63 || last_x)) ezx = last_x ? 0.f : a.ez[pb + ux + V];
+    if (act && (tx == 63 || last_x)) ezx = last_x ? (per_x ? a.ez[pb] : 0.f) : a.ez[pb + ux + V];
     const float ipz = s.ipz[kA - 1];
     ldf<V, true>(ho, uni(a.hx + pb), ubc);
     ldf<V, true>(hoy, uni(a.hy + pb), ubc);
@@ -303,8 +307,8 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     const int txo = (MAT || DAMP) ? tx : opaque_lane(tx);       // (the materials / absorber instantiations have no VGPR to spare for the re-derivation)
     const int i0o = (tile_x * 64 + txo) * V;
     const bool act = i0o < g.nx, last_x = i0o + V >= g.nx, first_x = i0o == 0;
-    const bool xh = act && txo == 0 && !first_x;
-    [[maybe_unused]] const bool wall_x0 = first_x && !pmc_x0;
+    const bool xh = act && txo == 0 && (!first_x || per_x);
+    [[maybe_unused]] const bool wall_x0 = first_x && !pmc_x0 && !per_x;
     const long long pb = (long long)k * g.sxy + rowb;
     const long long pjb = (long long)k * g.sxy + rowpb;
     const long long up = (k < g.nz) ? g.sxy : 0;         // (iteration nz only needs E1_{x,y}[nz] = 0: it reads the ghost plane twice)
@@ -322,6 +326,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     ldf<V, true>(L.hzn, uni(a.hz + pb), ubc);
     L.eyx_g = 0.f; L.ezx_g = 0.f;
     if (act && txo == 63 && !last_x) { L.eyx_g = a.ey[pb + ux + V]; L.ezx_g = a.ez[pb + ux + V]; }
+    if (per_x && act && last_x) { L.eyx_g = a.ey[pb]; L.ezx_g = a.ez[pb]; }        // (the row's first column)
     L.exn_m = 0.f; L.ez_mm = 0.f; L.ey_mm = 0.f; L.ex_jm = 0.f; L.hy_o = 0.f; L.hz_o = 0.f;
     if (xh && do_e1) {
       const long long pm = pb + im;
@@ -336,8 +341,11 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     const int txo = (MAT || DAMP) ? tx : opaque_lane(tx);       // (the materials / absorber instantiations have no VGPR to spare for the re-derivation)
     const int i0o = (tile_x * 64 + txo) * V;
     const bool act = i0o < g.nx, last_x = i0o + V >= g.nx, first_x = i0o == 0;
-    const bool xh = act && txo == 0 && !first_x;
-    [[maybe_unused]] const bool wall_x0 = first_x && !pmc_x0;
+    const bool xh = act && txo == 0 && (!first_x || per_x);
+    [[maybe_unused]] const bool wall_x0 = first_x && !pmc_x0 && !per_x;
+    // (the left / right side of a seam: a tile edge with a neighbour, or — periodic x — the row's ends)
+    const bool seam_l = (txo == 63 && !last_x) || (per_x && last_x), seam_r = txo == 0 && (tile_x > 0 || per_x);
+    const long long seam_back = (tile_x > 0 ? -1 : (long long)(nbx - 1)) * kSeamArrays * seam_arr;     // from this tile's seam to the one on its left
     // (iteration k = nz, last chunk only: plane nz is the z-max wall, E1_{x,y}[nz] = 0 is all it contributes; its loads
     //  read the ghost plane, its other results are never used)
     const long long pb = (long long)k * g.sxy + rowb;
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
       float eyx = lane_next(eyk[0]);
       float ezx = lane_next(ezk[0]);
       if (act && (txo == 63 || last_x)) {
-        if (!last_x) { eyx = L.eyx_g; ezx = L.ezx_g; }
+        if (!last_x || per_x) { eyx = L.eyx_g; ezx = L.ezx_g; }
         else { eyx = 0.f; ezx = 0.f; }
       }
       if constexpr (DAMP) {                 // H^{n-1/2} is damped before step n advances it
@@ -547,16 +555,16 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
         // what the neighbouring x tile needs of this step: repaired on the seam by seam_kernel
         if ((CLIP || (own && k >= k0 && k < k1)) && act) {
           float* sp = seam + seam_row + (long long)k * g.ny;
-          if (txo == 63 && !last_x) {
+          if (seam_l) {
             sp[0] = hyn[V - 1];
             sp[seam_arr] = hzn[V - 1];
             sp[2 * seam_arr] = e1xn[V - 1];
             sp[3 * seam_arr] = e1yn[V - 1];
             sp[4 * seam_arr] = e1zn[V - 1];
           }
-          if (txo == 0 && tile_x > 0) {
-            sp[5 * seam_arr - kSeamArrays * seam_arr] = e1yn[0];
-            sp[6 * seam_arr - kSeamArrays * seam_arr] = e1zn[0];
+          if (seam_r) {
+            sp[5 * seam_arr + seam_back] = e1yn[0];
+            sp[6 * seam_arr + seam_back] = e1zn[0];
           }
         }
       }
@@ -621,15 +629,15 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
       if constexpr (CLIP) {                    // H2 next to the seams, of every row / plane computed here (S4 writes the owned ones otherwise)
         if (act) {
           float* sq = seam + seam_row + (long long)(k - 1) * g.ny;
-          if (txo == 63 && !last_x) {
+          if (seam_l) {
             sq[7 * seam_arr] = h2x[V - 1];
             sq[8 * seam_arr] = h2y[V - 2];
             sq[9 * seam_arr] = h2z[V - 2];
           }
-          if (txo == 0 && tile_x > 0) {
-            sq[10 * seam_arr - kSeamArrays * seam_arr] = h2x[0];
-            sq[11 * seam_arr - kSeamArrays * seam_arr] = h2y[0];
-            sq[12 * seam_arr - kSeamArrays * seam_arr] = h2z[0];
+          if (seam_r) {
+            sq[10 * seam_arr + seam_back] = h2x[0];
+            sq[11 * seam_arr + seam_back] = h2y[0];
+            sq[12 * seam_arr + seam_back] = h2z[0];
           }
         }
       }
@@ -797,8 +805,11 @@ __global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, M
   if (t >= per * n_seams) return;
   const int sm = (int)(t / per);
   const int k = clip.k0 + (int)((t % per) / nj), j = clip.j0 + (int)(t % nj);
-  const int c = (sm + 1) * 256;
-  const bool wl = c - 1 >= clip.i0 && c - 1 < clip.i1, wr = c >= clip.i0 && c < clip.i1;
+  // (periodic x: the last seam is the wrap — its left column is the row's last, nx - 1, its right column the row's first)
+  const bool wrap = g.bcx0 == BC_PERIODIC && sm == n_seams - 1;
+  const int c = wrap ? g.nx : (sm + 1) * 256;
+  const int cc = wrap ? 0 : c;                          // the right column's index in its row
+  const bool wl = c - 1 >= clip.i0 && c - 1 < clip.i1, wr = cc >= clip.i0 && cc < clip.i1;
   if (!wl && !wr) return;
   const float ch = g.ch;
   const float ipx = s.ipx[c - 1];
@@ -822,9 +833,10 @@ __global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, M
   const bool pmc_y0 = g.bcy0 == BC_PMC, pmc_z0 = !g.pec_z0;
   const bool wall_y = (j == 0) && !pmc_y0, wall_z = (k == 0) && !pmc_z0;
   const bool mir_y = (j == 0) && pmc_y0, mir_z = (k == 0) && pmc_z0;
-  const long long p = (long long)k * g.sxy + (long long)j * g.nx + c;       // column c; p - 1 = column c-1
-  if (wl) { b.hy[p - 1] = hy_m; b.hz[p - 1] = hz_m; }
-  const float idy = s.idy[j], idz = s.idz[k], idx_m = s.idx[c - 1], idx_c = s.idx[c];
+  const long long pr = (long long)k * g.sxy + (long long)j * g.nx;
+  const long long p = pr + cc, pl = pr + c - 1;                              // the right column (c, or the row's first) / the left one
+  if (wl) { b.hy[pl] = hy_m; b.hz[pl] = hz_m; }
+  const float idy = s.idy[j], idz = s.idz[k], idx_m = s.idx[c - 1], idx_c = s.idx[cc];
   const float hx_m = A(7, j, k), hy_mm = A(8, j, k), hz_mm = A(9, j, k);
   const float hx_c = A(10, j, k), hy_c = A(11, j, k), hz_c = A(12, j, k);
   // (Ca, Cb) of component c at column c-1 (p - 1) / c (p): the table entry of the cell's medium word, or the uniform medium
@@ -838,24 +850,24 @@ __global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, M
   // H2_x of the plane / row below (columns c-1 and c)
   const float hxm_k = wall_z ? 0.f : (mir_z ? -hx_m : A(7, j, k - 1)), hxc_k = wall_z ? 0.f : (mir_z ? -hx_c : A(10, j, k - 1));
   const float hxm_j = wall_y ? 0.f : (mir_y ? -hx_m : A(7, j - 1, k)), hxc_j = wall_y ? 0.f : (mir_y ? -hx_c : A(10, j - 1, k));
-  if (!wall_y && !wall_z) { const float2 q = coef(p - 1, 0); ex_m = upd_e(A(2, j, k), q.x, q.y, hz_m - hz_j, idy, hy_m - hy_k, idz); }
+  if (!wall_y && !wall_z) { const float2 q = coef(pl, 0); ex_m = upd_e(A(2, j, k), q.x, q.y, hz_m - hz_j, idy, hy_m - hy_k, idz); }
   if (!wall_z) {
-    const float2 qm = coef(p - 1, 1), qc = coef(p, 1);
+    const float2 qm = coef(pl, 1), qc = coef(p, 1);
     ey_m = upd_e(A(3, j, k), qm.x, qm.y, hx_m - hxm_k, idz, hz_m - hz_mm, idx_m);
     ey_c = upd_e(A(5, j, k), qc.x, qc.y, hx_c - hxc_k, idz, hz_c - hz_m, idx_c);
   }
   if (!wall_y) {
-    const float2 qm = coef(p - 1, 2), qc = coef(p, 2);
+    const float2 qm = coef(pl, 2), qc = coef(p, 2);
     ez_m = upd_e(A(4, j, k), qm.x, qm.y, hy_m - hy_mm, idx_m, hx_m - hxm_j, idy);
     ez_c = upd_e(A(6, j, k), qc.x, qc.y, hy_c - hy_m, idx_c, hx_c - hxc_j, idy);
   }
   if (dmp.fb[0] && dmp.e2) {                 // E^{n+2} damped as in the sweep
-    const float bxm = dmp.fb[0][c - 1], cxm = dmp.fc[0][c - 1], bxc = dmp.fb[0][c];
+    const float bxm = dmp.fb[0][c - 1], cxm = dmp.fc[0][c - 1], bxc = dmp.fb[0][cc];
     const float byv = dmp.fb[1][j], cyv = dmp.fc[1][j], bzv = dmp.fb[2][k], czv = dmp.fc[2][k];
     ex_m *= cxm * byv * bzv; ey_m *= bxm * cyv * bzv; ez_m *= bxm * byv * czv;
     ey_c *= bxc * cyv * bzv; ez_c *= bxc * byv * czv;
   }
-  if (wl) { b.ex[p - 1] = ex_m; b.ey[p - 1] = ey_m; b.ez[p - 1] = ez_m; }
+  if (wl) { b.ex[pl] = ex_m; b.ey[pl] = ey_m; b.ez[pl] = ez_m; }
   if (wr) { b.ey[p] = ey_c; b.ez[p] = ez_c; }
 }
 
