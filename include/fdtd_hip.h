@@ -263,12 +263,18 @@ enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_R
        FDTD_OPT_GRAPH = 15, /* one-GPU fused runs on one stream: steps without monitor records / decay checks replayed as captured
                                hipGraphs of two steps: -1 = default (off: on ROCm 7.2 replaying costs ~3 us per step MORE than the
                                launches it replaces, profiles/r3i), 0 = never, 1 = whenever possible */
-       FDTD_OPT_TWOSTEP = 16, /* two time steps per sweep (in-kernel temporal blocking; non-dispersive media inside PEC walls (PMC allowed on
-                                 the min faces) or absorber layers, point sources, small time monitors, one GPU, no decay check on the middle step — everything else
-                                 takes single steps): -1 = default (on, tile shape by grid size), 0 = off, else waves per workgroup
-                                 (4 ... 16; W - 3 rows of a tile are written) + 64 * planes per chunk (0 = by grid size) */
-       FDTD_OPT_SHELL_PAIRS = 17, /* step pairs on grids walled by CPML (the two-step sweep over the bulk, the shell — CPML slabs + a
-                                     two-cell collar — as two single steps beside it; bit-identical to single steps): -1 = default (on), 0 = off */
+       FDTD_OPT_TWOSTEP = 16, /* two time steps per sweep (in-kernel temporal blocking, bit-identical to single steps; non-dispersive media, PEC
+                                 walls (PMC allowed on the min faces), absorber layers, point sources while they inject (any sources once
+                                 they are spent), small time monitors, DFT monitors, no decay check on the middle step; CPML and periodic
+                                 faces through shell pairs (FDTD_OPT_SHELL_PAIRS), z-slab ranks without CPML with their boundary planes as
+                                 the shell — everything else takes single steps, FdtdStats.fused2_off_reason says why): -1 = default (on,
+                                 tile shape by grid size), 0 = off, else waves per workgroup (4 ... 16; W - 3 rows of a tile are written)
+                                 + 64 * planes per chunk (0 = by grid size) */
+       FDTD_OPT_SHELL_PAIRS = 17, /* step pairs on grids with CPML or periodic faces (the two-step sweep over the bulk; the shell — CPML slabs +
+                                     a two-cell collar, the two rows / planes next to a periodic y / z face — as two single steps beside it
+                                     on the second stream, through a third field set; periodic x wraps inside the sweep; bit-identical to
+                                     single steps), and on z-slab ranks: -1 = default (on), 0 = off, 2 = shell behind the bulk on ONE stream
+                                     (a measuring aid) */
        FDTD_OPT_STRIP = 18, /* x strips of a shell step: planes per workgroup (1 ... 63) + 64 * workgroups per CU their registers are cut for (3 or 4) */
        FDTD_OPT_LDS_PAD = 10 /* measuring aid: extra dynamic LDS per workgroup of the sweep in bytes (lowers its occupancy) */ };
 int fdtd_set_option(FdtdSolver* h, int key, int value);

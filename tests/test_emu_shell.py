@@ -192,19 +192,20 @@ def test_pairs_resume_when_a_source_plane_is_spent(emu_lib):
     """A current sheet of several hundred nodes (more than the sweep's node table takes) keeps single steps only for the length of
     its pulse: the waveform ends where the reference says the source ends (SourceTime.end_time), and from there on the run goes
     out in pairs — CPML shell included — with the same bits as single steps.  (A TFSF box likewise: GPU suite.)"""
-    N = SHAPES["one_tile"]
-    size = tuple(n * DL for n in N)
-    pulse = td.GaussianPulse(freq0=3e14, fwidth=1.2e14)
-    srcs = [td.UniformCurrentSource(center=(0, 0, -0.2), size=(1.2, 0.6, 0), source_time=pulse, polarization="Ex")]
-    sim = td.Simulation(size=size, grid_spec=td.GridSpec.uniform(dl=DL), run_time=2.5e-14, sources=srcs, structures=MEDIA,
+    N = (32, 16, 14)
+    size = tuple((n - 1e-6) * DL for n in N)
+    pulse = td.GaussianPulse(freq0=3e14, fwidth=2.4e14)
+    srcs = [td.UniformCurrentSource(center=(0, 0, -0.1), size=(1.4, 0.7, 0), source_time=pulse, polarization="Ex")]
+    sim = td.Simulation(size=size, grid_spec=td.GridSpec.uniform(dl=DL), run_time=1.3e-14, sources=srcs, structures=MEDIA,
                         monitors=[td.FieldTimeMonitor(center=(0.1, 0.05, 0.0), size=(0, 0, 0), name="probe", interval=1, colocate=False)],
-                        boundary_spec=B_ALL, shutoff=0)
+                        boundary_spec=td.BoundarySpec(x=td.Boundary.pml(num_layers=4), y=td.Boundary.pml(num_layers=2), z=td.Boundary.pml(num_layers=2)),
+                        shutoff=0)
     disc = discretize(sim)
     disc.spec.decay_every = 0
     spec = disc.spec
     assert sum(len(s.comp) for s in spec.sources) > 256
     n_src = max(len(s.wave_e) for s in spec.sources)
-    assert 50 < n_src < spec.n_steps - 40, (n_src, spec.n_steps)              # the list ends before the run does
+    assert 50 < n_src < spec.n_steps - 30, (n_src, spec.n_steps)              # the list ends before the run does
     ref_f, ref_m, p0, _, _ = _run(spec, emu_lib, 0, runs=(spec.n_steps,))
     got_f, got_m, p1, s1, why = _run(spec, emu_lib, 5 + 64 * 4, runs=(spec.n_steps,))
     assert p0 == 0 and s1 == p1 and p1 >= (spec.n_steps - n_src) // 2 - 1, (p1, spec.n_steps, n_src)
