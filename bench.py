@@ -314,6 +314,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--no-workloads", action="store_true", help="skip the secondary V2 (materials + CPML) measurement")
+    ap.add_argument("--no-single-steps", action="store_true", help="skip the single-steps leg of a run that goes out in step pairs "
+                    "(profiling runs: the counters then hold the launches of the pairs only)")
     ap.add_argument("--sweep", action="store_true", help="A/B kernel launch parameters (N=1)")
     args = ap.parse_args()
 
@@ -467,7 +469,7 @@ def main():
                                                "off_reason_per_rank": [r[5] for r in rows]},
                        "ms_per_step_per_rank": [float(v) for v in med],
                        "ms_per_step_rank_min": float(med.min()), "ms_per_step_rank_max": float(med.max())}
-    if world == 1 and int(st.fused2_pairs) > 0:
+    if world == 1 and int(st.fused2_pairs) > 0 and not args.no_single_steps:
         # the same engine (same placement of the arrays) advancing ONE step per sweep: what the headline was before
         # the two-step kernel, and what every run outside its scope still gets
         eng.set_option(L.OPT_TWOSTEP, 0)

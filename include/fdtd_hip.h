@@ -104,7 +104,8 @@ enum { FDTD_F2_OFF_NONE = 0,
        FDTD_F2_OFF_H_SOURCE_ABSORBER = 8, /* magnetic point sources together with absorber layers */
        FDTD_F2_OFF_SEAM_SOURCE = 9,       /* an H_y / H_z source node in the column left of a seam between 256-cell x tiles */
        FDTD_F2_OFF_SOURCES = 10,          /* more than 256 source nodes (mode planes, current sheets), or H-side nodes without room for their table */
-       FDTD_F2_OFF_VARIANT = 11 };        /* the run is not on the fused sweep at all (two-pass kernels) */
+       FDTD_F2_OFF_VARIANT = 11,          /* the run is not on the fused sweep at all (two-pass kernels) */
+       FDTD_F2_OFF_SHELL = 12 };          /* CPML shell too large a part of the grid for shell pairs to pay (cost model, fdtd_capi.hip shell_why_not) */
 
 /* progress callback: (step, time [s], field_decay) -> non-zero aborts the run (Ctrl-C path).
  * Mirrors the (perc_done, field_decay) pair the cloud reports (ref web/core/task_core.py:537). */

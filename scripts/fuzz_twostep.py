@@ -90,6 +90,7 @@ def case(rng):
 def run(disc, steps, twostep, split, lib=None):
     with HipEngine(disc.spec, lib=lib, variant=L.VARIANT_FUSED, axis_shift=0) as e:
         e.set_option(L.OPT_TWOSTEP, twostep)
+        e.set_option(L.OPT_SHELL_PAIRS, 1)          # CPML grids: shell pairs whatever the cost model says of these small grids
         pairs = 0
         for r in (split, steps - split):
             if r > 0:

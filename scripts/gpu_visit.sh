@@ -33,7 +33,7 @@ PY
       cd /tmp
       for W in v0 v0s v2; do
         case $W in v0) A="";; v0s) A="--opt OPT_TWOSTEP=0";; v2) A="--workload v2";; esac
-        timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$W -o trace -- python $R/bench.py $A --steps 100 --warmup 10 --repeats 2 --no-cpu --no-workloads --placement-tries 0 > $O/prof_${W}_bench.json 2> $O/prof_$W.err
+        timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$W -o trace -- python $R/bench.py $A --steps 100 --warmup 10 --repeats 2 --no-cpu --no-workloads --no-single-steps --placement-tries 0 > $O/prof_${W}_bench.json 2> $O/prof_$W.err
         head -6 $O/prof_$W/trace_kernel_stats.csv | cut -c1-160
       done
       find $O -name '*kernel_trace*' -size +8M -delete
@@ -43,7 +43,7 @@ PY
       for W in v0 v0s v1 va v2; do
         case $W in v0) A="";; v0s) A="--opt OPT_TWOSTEP=0";; *) A="--workload $W";; esac
         for C in FETCH_SIZE WRITE_SIZE; do
-          timeout 240 rocprofv3 --pmc $C --output-format csv -d $O/pmc_$W/pmc_$C -o pmc -- python $R/bench.py $A --steps 6 --warmup 2 --repeats 1 --no-cpu --no-workloads --placement-tries 0 > /dev/null 2> $O/pmc_${W}_$C.err
+          timeout 240 rocprofv3 --pmc $C --output-format csv -d $O/pmc_$W/pmc_$C -o pmc -- python $R/bench.py $A --steps 6 --warmup 2 --repeats 1 --no-cpu --no-workloads --no-single-steps --placement-tries 0 > /dev/null 2> $O/pmc_${W}_$C.err
         done
         python $R/scripts/summarize_pmc.py $O/pmc_$W > $O/pmc_${W}_summary.json
       done

@@ -67,7 +67,7 @@ def _sim(N, bspec, structures=(), monitors=(), extra=()):
                          structures=list(structures), monitors=list(monitors), boundary_spec=bspec, shutoff=0)
 
 
-def _run(spec, lib, twostep, shell=-1, runs=(11, 15), split=1):
+def _run(spec, lib, twostep, shell=1, runs=(11, 15), split=1):       # (shell = 1: pairs whatever the cost model says of these small grids)
     with HipEngine(spec, lib=lib, variant=L.VARIANT_FUSED, z_chunk=2) as e:
         e.set_option(L.OPT_ROWS, 3)
         e.set_option(L.OPT_PML_SPLIT, split)

@@ -23,9 +23,11 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-5
 
 
-def _run(spec, lib, twostep=-1, init=None, steps=None, runs=None):
+def _run(spec, lib, twostep=-1, init=None, steps=None, runs=None, shell=1):
+    """shell = 1: shell pairs whatever the cost model says of the grid (these tests are about bits, not about speed); -1: its call"""
     with HipEngine(spec, lib=lib, axis_shift=0) as e:
         e.set_option(L.OPT_TWOSTEP, twostep)
+        e.set_option(L.OPT_SHELL_PAIRS, shell)
         if init is not None:
             for c in range(6):
                 e.set_field(c, init[c])
@@ -199,3 +201,16 @@ def test_periodic_unit_cell_in_step_pairs(hip_lib):
     for c in range(3):
         assert np.linalg.norm(got_f[c] - o.E[c]) / en < TOL, c
         assert np.linalg.norm(got_f[3 + c] - o.H[c]) / hn < TOL, c
+
+
+def test_shell_pairs_are_taken_where_they_pay(hip_lib):
+    """The cost model's call (fdtd_capi.hip shell_why_not): a shell cell costs two single steps and more, a bulk cell half of one —
+    the bench V2 grid at 512^3 (shell: 16 % of the cells) goes out in pairs by default, the same problem at 320^3 (25 %) keeps
+    single steps and says why."""
+    from bench import build_spec
+    for n, want in ((512, True), (320, False)):
+        spec = build_spec(n, 16, "v2")
+        with HipEngine(spec, lib=hip_lib, axis_shift=0) as e:
+            st = e.run(12)
+            assert (int(st.shell_pairs) == 6) == want, (n, int(st.shell_pairs))
+            assert int(st.fused2_off_reason) == (0 if want else 12), int(st.fused2_off_reason)

@@ -1117,6 +1117,22 @@ int shell_why_not(const FdtdSolver* h, ShellGeom* G) {
   // the shell runs the CPML recursions inside its sweeps (all axes), as a one-GPU step does by default
   if (64 * (h->rows_f + 1) > 512 || (h->pml_fused >= 0 && (h->pml_fused & pml_in_sweep_mask(h)) != pml_in_sweep_mask(h))) return FDTD_F2_OFF_PML;
   if (!shell_geometry(h, G)) return FDTD_F2_OFF_PML;
+  // Is it worth it?  A shell cell costs a single step's bytes and more (fields + psi, through the third set, in launches that
+  // cannot fill the machine), twice per pair; a bulk cell costs half a single step's.  Measured on MI355X, 512^3 V2, each kernel
+  // alone on the machine (profiles/r4/r4c_kernel_trace_shell_pair_one_stream.txt; scaled to a single step of 10.1 ps per cell):
+  // the bulk's two steps 10.3 ps per cell (12 with materials), a slab cell 25 ps per step, a strip cell 42 ps per step (64-byte
+  // pieces at a 2 KB stride), and the two streams overlap to about 0.9 of the sum.  V2 (shell: 16 % of the cells): predicted 0.89
+  // of two single steps, measured 0.88-0.89 (r4n).  BASELINE config 3 laid out with x = 224 (strips: 13 % of the cells): predicted
+  // 1.11, measured 1.14-1.16 — pairs LOSE there (r4o), as on the V2 problem at 320^3 (1.08).  shell_on = 1 forces pairs (tests).
+  if (h->shell_on != 1) {
+    const double N[3] = {(double)h->g.nx, (double)h->g.ny, (double)h->g.nz};
+    const double ox = G->o1[0] - G->o0[0], oy = G->o1[1] - G->o0[1], oz = G->o1[2] - G->o0[2];
+    const double all = N[0] * N[1] * N[2], bulk = ox * oy * oz;
+    const double strips = (N[0] - ox) * oy * oz, slabs = all - bulk - strips;
+    const double pair_ps = 0.9 * (bulk * (h->mat4 ? 12.0 : 10.3) + 2.0 * (slabs * 25.0 + strips * 42.0));
+    const double single_ps = 2.0 * all * 10.1;
+    if (pair_ps > 0.97 * single_ps) return FDTD_F2_OFF_SHELL;
+  }
   return 0;
 }
 

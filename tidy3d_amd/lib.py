@@ -49,7 +49,8 @@ OPT_FLAGS, OPT_VARIANT, OPT_ZCHUNK, OPT_ROWS, OPT_XCD_REMAP, OPT_FUSED_LB, OPT_P
 # FdtdStats.fused2_off_reason (include/fdtd_hip.h FDTD_F2_OFF_*)
 F2_OFF_REASONS = {0: "", 1: "switched off", 2: "grid too small", 3: "z-slab rank", 4: "CPML (shell pairs not possible)",
                   5: "dispersive media", 6: "TFSF source", 7: "periodic / Bloch / PMC-plus faces", 8: "magnetic sources with absorber layers",
-                  9: "magnetic source node on a tile seam", 10: "too many source nodes", 11: "two-pass kernels"}
+                  9: "magnetic source node on a tile seam", 10: "too many source nodes", 11: "two-pass kernels",
+                  12: "CPML shell too large a part of the grid"}
 
 
 class FdtdConfig(C.Structure):
