@@ -213,3 +213,48 @@ def test_pairs_resume_when_a_source_plane_is_spent(emu_lib):
     for c in range(6):
         assert np.array_equal(got_f[c], ref_f[c]), c
     assert np.array_equal(got_m["probe"], ref_m["probe"])
+
+
+LORENTZ = td.Lorentz(eps_inf=2.0, coeffs=[(1.5, 4e14, 3e13)])
+
+
+@pytest.mark.parametrize("kind", ["ade_layer_cpml", "ade_sphere_pec_box", "sheet_and_ade_periodic", "plane_wave_unit_cell"])
+def test_shell_pairs_with_z_holes(kind, emu_lib):
+    """z holes: plane ranges inside the bulk's box that take single steps with the shell — the planes that hold dispersive cells
+    (their ADE state advances every step) and, while the lists inject, the planes of sources the sweep cannot apply itself (a
+    current sheet of hundreds of nodes, the injection plane of a plane wave: TFSF corrections + its 1-D incident grid).  The
+    two-step sweep runs once per interval of the remaining planes.  Same bits as single steps, through the pulse and after it."""
+    N = (40, 18, 44)
+    size = tuple((n - 1e-6) * DL for n in N)
+    pulse = td.GaussianPulse(freq0=3e14, fwidth=2.4e14)
+    dip = [td.PointDipole(center=(0.1, 0.05, 0.7), source_time=PULSE, polarization="Ex"),
+           td.PointDipole(center=(-0.2, 0.1, -0.6), source_time=PULSE, polarization="Hy")]
+    film = td.Structure(geometry=td.Box(center=(0, 0, 0.1), size=(td.inf, td.inf, 0.2)), medium=LORENTZ)
+    ball = td.Structure(geometry=td.Sphere(center=(0.1, 0.0, -0.1), radius=0.22), medium=td.Drude(eps_inf=1.5, coeffs=[(6e14, 5e13)]))
+    glass = td.Structure(geometry=td.Box(center=(0, 0, -0.7), size=(td.inf, td.inf, 0.5)), medium=td.Medium(permittivity=2.1))
+    per = td.Boundary.periodic()
+    if kind == "ade_layer_cpml":
+        sim = dict(structures=[glass, film], sources=dip, boundary_spec=B_ALL)
+    elif kind == "ade_sphere_pec_box":
+        sim = dict(structures=[glass, ball], sources=dip, boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary()))
+    elif kind == "sheet_and_ade_periodic":
+        sheet = td.UniformCurrentSource(center=(0, 0, 0.75), size=(1.9, 0.8, 0), source_time=pulse, polarization="Ey")
+        sim = dict(structures=[glass, film], sources=[sheet], boundary_spec=td.BoundarySpec(x=per, y=per, z=td.Boundary.pml(num_layers=3)))
+    else:
+        pw = td.PlaneWave(center=(0, 0, 0.8), size=(td.inf, td.inf, 0), source_time=pulse, direction="-")
+        sim = dict(structures=[glass, ball], sources=[pw], boundary_spec=td.BoundarySpec(x=per, y=per, z=td.Boundary.pml(num_layers=3)))
+    sim = td.Simulation(size=size, grid_spec=td.GridSpec.uniform(dl=DL), run_time=1.1e-14,
+                        monitors=[td.FieldTimeMonitor(center=(0.1, 0.05, -0.45), size=(0, 0, 0), name="probe", interval=1, colocate=False)],
+                        shutoff=0, **sim)
+    disc = discretize(sim)
+    disc.spec.decay_every = 0
+    spec = disc.spec
+    n1 = 60
+    assert spec.n_steps > n1 + 40
+    ref_f, ref_m, p0, _, _ = _run(spec, emu_lib, 0, runs=(n1 - 1, spec.n_steps - n1 + 1))
+    got_f, got_m, p1, s1, why = _run(spec, emu_lib, 5 + 64 * 4, runs=(n1 - 1, spec.n_steps - n1 + 1))
+    assert p0 == 0 and s1 == p1 and p1 >= spec.n_steps // 2 - 3, (p1, spec.n_steps, why)
+    assert max(float(np.abs(f).max()) for f in ref_f) > 0
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), (c, float(np.abs(got_f[c] - ref_f[c]).max()))
+    assert np.abs(ref_m["probe"]).max() > 0 and np.array_equal(got_m["probe"], ref_m["probe"])

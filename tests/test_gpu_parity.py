@@ -418,7 +418,7 @@ def test_config5_au_nanoparticle_array_1024x1024x256(hip_lib):
     T = -float(sd["T"].flux.values[0]) / area          # transmitted wave travels -z
     A = 1 - R - T
     line = sd["line"].Ex.values[:, 0, 0, 0]
-    print(f"\n[config5] setup {t1 - t0:.1f}s solve {t2 - t1:.1f}s ({st.steps_done} steps, "
+    print(f"\n[config5] setup {t1 - t0:.1f}s solve {t2 - t1:.1f}s ({st.steps_done} steps, {int(st.fused2_pairs)} step pairs (reason {int(st.fused2_off_reason)}), "
           f"{disc.spec.n_cells * st.steps_done / (st.run_ms * 1e-3) / 1e6:.0f} Mcells/s) R={R:.4f} T={T:.4f} A={A:.4f}")
     assert not st.diverged
     assert 0.0 < R < 1.0 and 0.0 < T < 1.0 and 0.005 < A < 0.9

@@ -38,16 +38,20 @@ def _run(spec, lib, twostep=-1, init=None, steps=None, runs=None, shell=1):
         return [e.get_field(c) for c in range(6)], e.results(), pairs
 
 
-@pytest.mark.parametrize("name,w,zc", [("pml_box", 5, 4), ("pml_box", 16, 32), ("stable_pml_box", 8, 8)])
+@pytest.mark.parametrize("name,w,zc", [("pml_box", 5, 4), ("pml_box", 16, 32), ("stable_pml_box", 8, 8),
+                                       # dispersive media (z holes of the bulk) running into the layers; the Au array of config 5 in miniature:
+                                       # periodic x / y, CPML z, 5 pole pairs, a plane wave (TFSF corrections + incident grid: a z hole too)
+                                       ("drude_in_pml", 6, 5), ("au_array", 5, 6)])
 def test_parity_cases_through_shell_pairs_vs_oracle(name, w, zc, hip_lib):
     from oracle.fdtd_numpy import OracleFdtd
     fn = CASES[name]
-    sim = fn(tuple(int(n * 3) for n in fn.__defaults__[0]))
+    d0 = fn.__defaults__[0]
+    sim = fn(tuple(int(n * 3) for n in d0)) if name != "au_array" else fn(tuple(int(n * 3) for n in d0), fn.__defaults__[1] / 3)
     disc = discretize(sim, n_steps=100)
     o = OracleFdtd(disc.spec)
     ref = o.run()
     f, got, pairs = _run(disc.spec, hip_lib, twostep=w + 64 * zc)
-    assert pairs > 20, pairs
+    assert pairs > (20 if name != "drude_in_pml" else 10), (name, pairs)      # (drude_in_pml: its DFT plane spans the layers, records end pairs)
     scale = max(np.linalg.norm(v) / np.sqrt(v.size) for v in ref.values())
     for k in ref:
         den = max(np.linalg.norm(ref[k]), 0.5 * scale * np.sqrt(ref[k].size))

@@ -225,7 +225,7 @@ struct FdtdSolver {
   // shell pairs: the two-step sweep over the bulk of a CPML-walled grid, its shell (slabs + collar) by two single steps beside
   // it (fdtd_run).  shell_on: -1 = default (on), 0 = off
   int shell_on = -1;
-  int strip_zc = 8;                   // planes per workgroup of the x strips
+  int strip_zc = 4;                   // planes per workgroup of the x strips (4: 1.199 ms per V2 step, 8: 1.205, 16: 1.228 inside one engine, profiles/r4/r4n)
   int strip_occ = 3;                  // their register budget: workgroups per CU (3 or 4)
   long long shell_pairs = 0;
   int f2_off_reason = 0;              // why the last fdtd_run took no step pairs (FDTD_F2_OFF_*), 0 = it did / could
@@ -728,7 +728,7 @@ int fused2_why_not(const FdtdSolver* h, bool slab_rank = false, bool shell = fal
   if (h->twostep_w == 0) return FDTD_F2_OFF_DISABLED;
   { int W, zc; if (!fused2_shape(h, &W, &zc)) return FDTD_F2_OFF_TOO_SMALL; }
   if (h->comm && !slab_rank) return FDTD_F2_OFF_COMM;
-  if (!h->ade.empty()) return FDTD_F2_OFF_ADE;
+  if (!h->ade.empty() && !shell) return FDTD_F2_OFF_ADE;       // (a shell pair: the planes that hold dispersive cells are a z hole of the bulk)
   // (sources are judged step by step, fused2_sources_why_not: a TFSF box or a mode plane keeps single steps only while it injects)
   // PEC walls; the min faces may be PMC (the symmetry planes of a half / quarter / eighth domain)
   // (a z-slab rank: a neighbour face is no wall — the sweep stays two planes clear of it, fdtd_run)
@@ -937,6 +937,7 @@ const F2Table* fused2_table(FdtdSolver* h, const F2Plan& plan, bool with_sources
 // of step n + 1 are left to the caller, and the sets are NOT swapped (the shell launches beside it still name them).
 int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb, bool* sources2_done, bool* damp2_done = nullptr,
                   const ClipP* clip = nullptr) {
+  const bool inject = tb->with_sources;      // (false: the lists are spent, or — shell pairs with z holes — their planes take single steps)
   const GridP& g = h->g;
   if (ensure_second_set(h)) return -1;
   int W = 16, zc = 32;
@@ -961,7 +962,7 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
   {
     bool alive = false, alive2 = true;
     for (const PointSrc& s : h->psrc)
-      if (s.n_e || s.n_h) { alive = alive || n < s.n_steps; alive2 = alive2 && n + 1 < s.n_steps; }
+      if (inject && (s.n_e || s.n_h)) { alive = alive || n < s.n_steps; alive2 = alive2 && n + 1 < s.n_steps; }
     // (all lists alive or all spent: fused2_sources_uniform.  Spent lists add nothing — not + 0 — so their table is only
     //  walked when there are none or when they are alive: pairs with monitor samples AND spent sources are not taken, fdtd_run)
     if (alive && h->src_tab && n + 1 < h->src_tab_steps) {
@@ -1077,43 +1078,106 @@ void launch_strip(FdtdSolver* h, const FieldP& src, const FieldP& dst, const Pml
   time_end(h, st);
 }
 
-// One step of the shell: set `src` -> set `dst`, H-side psi parity `parity`.  in[a] = [in0[a], in1[a]): the part of axis a that
-// belongs to someone else in this step (the bulk O in step two, O shrunk by one cell on its CPML sides in step one).
+// The bulk's planes: the box's z range minus the z HOLES — plane ranges that take single steps with the shell although they lie
+// inside the box: the planes that hold dispersive cells (their ADE state advances every step), and, while the lists inject, the
+// planes of sources the sweep cannot apply itself (a mode plane, a current sheet, the injection plane of a plane wave: more than
+// kMaxInj nodes, or TFSF corrections) — each grown by two planes (the reach of what the sweep gets wrong by ignoring them).
+struct ZPlan {
+  int n = 0;                 // bulk intervals [a[i], b[i]), ascending
+  int a[4] = {}, b[4] = {};
+  bool ok = false;           // a plan exists and the cost model likes it
+};
+bool zplan_build(const FdtdSolver* h, const ShellGeom& G, bool source_holes, ZPlan* P) {
+  std::vector<std::pair<int, int>> holes;
+  for (const AdeGroup& a : h->ade) if (a.n > 0) holes.push_back({a.k0 - 2, a.k1 + 2});
+  if (source_holes) {
+    for (const PointSrc& s : h->psrc) {
+      if (s.n_e) holes.push_back({s.ke0 - 2, s.ke1 + 2});
+      if (s.n_h) holes.push_back({s.kh0 - 2, s.kh1 + 2});
+    }
+    for (const Tfsf& t : h->tfsf) {
+      if (t.e.n_targets) holes.push_back({t.e.k0 - 2, t.e.k1 + 2});
+      if (t.h.n_targets) holes.push_back({t.h.k0 - 2, t.h.k1 + 2});
+    }
+  }
+  std::sort(holes.begin(), holes.end());
+  P->n = 0;
+  int lo = G.o0[2];
+  auto close = [&](int hi) {           // the bulk interval [lo, hi): kept when it is worth a launch
+    if (hi - lo >= 8) {
+      if (P->n == 4) return false;
+      P->a[P->n] = lo; P->b[P->n] = hi; P->n++;
+    }
+    return true;
+  };
+  for (const auto& hz : holes) {
+    if (hz.second <= lo) continue;
+    if (hz.first >= G.o1[2]) break;
+    if (hz.first > lo && !close(std::min(hz.first, G.o1[2]))) return false;
+    lo = std::max(lo, hz.second);
+  }
+  if (lo < G.o1[2] && !close(G.o1[2])) return false;
+  return P->n > 0;
+}
+// the part of the bulk interval i that belongs to someone else in a shell step that reaches `grow` planes into the bulk
+inline void zplan_in(const ZPlan& P, int i, int grow, int nz, int* k0, int* k1) {
+  *k0 = P.a[i] + (P.a[i] > 0 ? grow : 0);
+  *k1 = P.b[i] - (P.b[i] < nz ? grow : 0);
+}
+
+// One step of the shell: set `src` -> set `dst`, H-side psi parity `parity`.  in[a] = [in0[a], in1[a]) (a = x, y): the part of
+// axis a that belongs to someone else in this step (the bulk O in step two, O shrunk by one cell on its CPML sides in step one);
+// along z the bulk's intervals of `P`, shrunk by `grow` planes each.
 int launch_shell_step(FdtdSolver* h, const FieldP& src, const FieldP& dst, int parity, const int in0[3], const int in1[3],
-                      int pml_in, hipStream_t st) {
+                      int pml_in, hipStream_t st, const ZPlan& P, int grow) {
   const GridP& g = h->g;
   const int R = h->rows_f, nby_all = (g.ny + R - 1) / R;
   ShellSets sh{src, dst, parity, 0, 0};
-  // z slabs: the planes outside in[2], all rows
-  if (in0[2] > 0 || in1[2] < g.nz)
-    if (launch_fused_range(h, 0, in0[2], st, pml_in, in1[2], g.nz, -1, 0, 0, true, &sh)) return -1;
-  // y slabs: the planes of in[2], the tile rows that hold a row outside in[1] (the rows inside it excluded)
-  if (in0[1] > 0 || in1[1] < g.ny) {
-    const int ty_a = in0[1] > 0 ? std::min(nby_all, (in0[1] + R - 1) / R) : 0;
-    const int ty_c = in1[1] < g.ny ? std::max(ty_a, in1[1] / R) : nby_all;
-    sh.ex_j0 = in0[1]; sh.ex_j1 = in1[1];
-    if (launch_fused_range(h, in0[2], in1[2], st, pml_in & 3, 0, 0, ty_a + (nby_all - ty_c), ty_a, ty_c - ty_a, true, &sh)) return -1;
+  // z slabs and z holes: the planes outside the bulk's intervals, all rows (two plane ranges per launch)
+  {
+    int r0[6], r1[6], nr = 0, lo = 0;
+    for (int i = 0; i < P.n; ++i) {
+      int k0, k1;
+      zplan_in(P, i, grow, g.nz, &k0, &k1);
+      if (k0 > lo) { r0[nr] = lo; r1[nr] = k0; ++nr; }
+      lo = k1;
+    }
+    if (lo < g.nz) { r0[nr] = lo; r1[nr] = g.nz; ++nr; }
+    for (int q = 0; q < nr; q += 2)
+      if (launch_fused_range(h, r0[q], r1[q], st, pml_in, q + 1 < nr ? r0[q + 1] : 0, q + 1 < nr ? r1[q + 1] : 0, -1, 0, 0, true, &sh)) return -1;
   }
-  // x strips: planes of in[2], rows of in[1], the columns outside in[0]
-  if (in0[0] > 0 || in1[0] < g.nx) {
-    const PmlP* pm = h->pml_blk[pml_in][parity];
-    launch_strip(h, src, dst, pm, 0, in0[0], in0[1], in1[1], in0[2], in1[2], st);
-    launch_strip(h, src, dst, pm, in1[0], g.nx, in0[1], in1[1], in0[2], in1[2], st);
+  for (int i = 0; i < P.n; ++i) {
+    int k0, k1;
+    zplan_in(P, i, grow, g.nz, &k0, &k1);
+    if (k1 <= k0) continue;
+    // y slabs: the planes of the interval, the tile rows that hold a row outside in[1] (the rows inside it excluded)
+    if (in0[1] > 0 || in1[1] < g.ny) {
+      const int ty_a = in0[1] > 0 ? std::min(nby_all, (in0[1] + R - 1) / R) : 0;
+      const int ty_c = in1[1] < g.ny ? std::max(ty_a, in1[1] / R) : nby_all;
+      sh.ex_j0 = in0[1]; sh.ex_j1 = in1[1];
+      if (launch_fused_range(h, k0, k1, st, pml_in & 3, 0, 0, ty_a + (nby_all - ty_c), ty_a, ty_c - ty_a, true, &sh)) return -1;
+      sh.ex_j0 = sh.ex_j1 = 0;
+    }
+    // x strips: planes of the interval, rows of in[1], the columns outside in[0]
+    if (in0[0] > 0 || in1[0] < g.nx) {
+      const PmlP* pm = h->pml_blk[pml_in][parity];
+      launch_strip(h, src, dst, pm, 0, in0[0], in0[1], in1[1], k0, k1, st);
+      launch_strip(h, src, dst, pm, in1[0], g.nx, in0[1], in1[1], k0, k1, st);
+    }
   }
   return 0;
 }
 
-// 0 = the run can take shell pairs (and *G holds the bulk), else the reason it cannot
 bool any_periodic(const FdtdSolver* h) {
   for (int f = 0; f < 6; ++f) if (h->cfg.bc[f] == FDTD_BC_PERIODIC) return true;
   return false;
 }
-int shell_why_not(const FdtdSolver* h, ShellGeom* G) {
+int shell_why_not(const FdtdSolver* h, ShellGeom* G, ZPlan* base, ZPlan* with_src) {
   const int why = fused2_why_not(h, false, true);
   if (why) return why;
-  if (!any_pml(h) && !any_periodic(h)) return FDTD_F2_OFF_PML;              // (nothing to do here: the plain pairs cover it)
+  if (!any_pml(h) && !any_periodic(h) && h->ade.empty()) return FDTD_F2_OFF_PML;              // (nothing to do here: the plain pairs cover it)
   if (h->shell_on == 0) return FDTD_F2_OFF_PML;
-  if (h->has_damp) return FDTD_F2_OFF_PML;              // absorber layers on one axis, CPML on another: single steps
+  if (h->has_damp) return h->ade.empty() ? FDTD_F2_OFF_PML : FDTD_F2_OFF_ADE;   // absorber layers with CPML or dispersive media: single steps
   // the shell runs the CPML recursions inside its sweeps (all axes), as a one-GPU step does by default
   if (64 * (h->rows_f + 1) > 512 || (h->pml_fused >= 0 && (h->pml_fused & pml_in_sweep_mask(h)) != pml_in_sweep_mask(h))) return FDTD_F2_OFF_PML;
   if (!shell_geometry(h, G)) return FDTD_F2_OFF_PML;
@@ -1124,15 +1188,27 @@ int shell_why_not(const FdtdSolver* h, ShellGeom* G) {
   // pieces at a 2 KB stride), and the two streams overlap to about 0.9 of the sum.  V2 (shell: 16 % of the cells): predicted 0.89
   // of two single steps, measured 0.88-0.89 (r4n).  BASELINE config 3 laid out with x = 224 (strips: 13 % of the cells): predicted
   // 1.11, measured 1.14-1.16 — pairs LOSE there (r4o), as on the V2 problem at 320^3 (1.08).  shell_on = 1 forces pairs (tests).
-  if (h->shell_on != 1) {
-    const double N[3] = {(double)h->g.nx, (double)h->g.ny, (double)h->g.nz};
-    const double ox = G->o1[0] - G->o0[0], oy = G->o1[1] - G->o0[1], oz = G->o1[2] - G->o0[2];
-    const double all = N[0] * N[1] * N[2], bulk = ox * oy * oz;
-    const double strips = (N[0] - ox) * oy * oz, slabs = all - bulk - strips;
-    const double pair_ps = 0.9 * (bulk * (h->mat4 ? 12.0 : 10.3) + 2.0 * (slabs * 25.0 + strips * 42.0));
-    const double single_ps = 2.0 * all * 10.1;
-    if (pair_ps > 0.97 * single_ps) return FDTD_F2_OFF_SHELL;
-  }
+  // Two plans: the bulk's planes with the z holes of the dispersive cells only (`base`), and with those of every source list
+  // too (`with_src`: what a pair uses while lists inject that the sweep cannot apply itself).
+  auto judge = [&](bool source_holes, ZPlan* P) {
+    P->ok = false;
+    if (!zplan_build(h, *G, source_holes, P)) return;
+    if (h->shell_on != 1) {
+      const double N[3] = {(double)h->g.nx, (double)h->g.ny, (double)h->g.nz};
+      const double ox = G->o1[0] - G->o0[0], oy = G->o1[1] - G->o0[1];
+      double oz = 0.0;
+      for (int i = 0; i < P->n; ++i) oz += P->b[i] - P->a[i];
+      const double all = N[0] * N[1] * N[2], bulk = ox * oy * oz;
+      const double strips = (N[0] - ox) * oy * oz, slabs = all - bulk - strips;
+      const double pair_ps = 0.9 * (bulk * (h->mat4 ? 12.0 : 10.3) + 2.0 * (slabs * 25.0 + strips * 42.0));
+      const double single_ps = 2.0 * all * 10.1;
+      if (pair_ps > 0.97 * single_ps) return;
+    }
+    P->ok = true;
+  };
+  judge(false, base);
+  judge(true, with_src);
+  if (!base->ok) return h->ade.empty() ? FDTD_F2_OFF_SHELL : FDTD_F2_OFF_ADE;
   return 0;
 }
 
@@ -1578,7 +1654,7 @@ void advance_tfsf_aux(FdtdSolver* h, bool e_side, long long n, hipStream_t st, b
   }
 }
 
-void launch_ade(FdtdSolver* h, int kbeg, int kend, hipStream_t st) {
+void launch_ade(FdtdSolver* h, int kbeg, int kend, hipStream_t st, const FieldP* fs = nullptr) {
   if (kend <= kbeg) return;
   const long long zlo = (long long)kbeg * h->g.sxy, zhi = (long long)kend * h->g.sxy;
   for (AdeGroup& a : h->ade) {
@@ -1588,7 +1664,8 @@ void launch_ade(FdtdSolver* h, int kbeg, int kend, hipStream_t st) {
     long long t0 = 0, t1 = a.n;
     if (!a.plane_off.empty()) { t0 = a.plane_off[(size_t)std::max(kbeg, 0)]; t1 = a.plane_off[(size_t)std::min(kend, h->g.nz)]; }
     if (t1 <= t0) continue;
-    hipLaunchKernelGGL(ade_kernel, dim3(nblk(t1 - t0)), dim3(256), 0, st, field_ptr(h, a.comp),
+    float* ef = fs ? (a.comp == 0 ? fs->ex : (a.comp == 1 ? fs->ey : fs->ez)) : field_ptr(h, a.comp);
+    hipLaunchKernelGGL(ade_kernel, dim3(nblk(t1 - t0)), dim3(256), 0, st, ef,
                        (const uint32_t*)a.cell + t0, a.e_old + t0, a.q + t0, t1 - t0, a.n, zlo, zhi, a.p);
   }
 }
@@ -2722,9 +2799,10 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   ShellGeom sg{};
   bool f2s_ok = false;
   h->f2_off_reason = !fused ? FDTD_F2_OFF_VARIANT : (tb_ok ? FDTD_F2_OFF_DISABLED : 0);
+  ZPlan zp_base, zp_src;               // the bulk's planes: without / with the z holes of the source lists
   if (fused && !tb_ok && !f2_ok) {
-    const bool shell = any_pml(h) || any_periodic(h);
-    h->f2_off_reason = shell ? shell_why_not(h, &sg) : fused2_why_not(h);
+    const bool shell = any_pml(h) || any_periodic(h) || !h->ade.empty();
+    h->f2_off_reason = shell ? shell_why_not(h, &sg, &zp_base, &zp_src) : fused2_why_not(h);
     f2s_ok = shell && h->f2_off_reason == 0;
   }
   h->f2_dyn_reason = 0;
@@ -2739,7 +2817,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     if (fused2_sources(h) || ensure_third_set(h)) return -1;
   }
   // steps n and n + 1 of a grid walled by CPML: the bulk as ONE two-step sweep on st, the shell as two single steps on cs
-  auto shell_pair = [&](long long n, const F2Table* tb) -> int {
+  auto shell_pair = [&](long long n, const F2Table* tb, const ZPlan& zp) -> int {
     hipStream_t cs = (h->shell_on == 2) ? st : h->comm_stream;       // (2: shell behind the bulk on ONE stream — a measuring aid)
     const int pml_in = 7 & pml_in_sweep_mask(h);
     if (ensure_second_set(h) || ensure_third_set(h) || ensure_pml_blocks(h, pml_in)) return -1;
@@ -2753,28 +2831,49 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       in0[a] = sg.o0[a] > 0 ? sg.o0[a] + (a == 0 ? 4 : 1) : 0;
       in1[a] = sg.o1[a] < N[a] ? sg.o1[a] - (a == 0 ? 4 : 1) : N[a];
     }
-    launch_sources(h, false, n, 0, nz, st);                // H-side sources of step n act on H^{n-1/2}, as before a single step
+    // (the order of a single step: H-side sources and TFSF corrections of step n on H^{n-1/2}, then the incident grid's H)
+    launch_sources(h, false, n, 0, nz, st);
+    advance_tfsf_aux(h, false, n, st);
     if (h->cfg.bc[4] == FDTD_BC_PERIODIC) fill_ghost_h(h, st);   // ghost(-1) must carry them too (as in a single step)
     HIPCHK(h, hipEventRecord(h->ev_shell_a, st));
     HIPCHK(h, hipStreamWaitEvent(cs, h->ev_shell_a, 0));
     const FieldP A = h->f, B = h->f2, T = h->f3;
     const int par = h->pml_parity;
-    const ClipP clip{sg.o0[0], sg.o1[0], sg.o0[1], sg.o1[1], sg.o0[2], sg.o1[2]};
     bool s2 = false;
-    if (launch_fused2(h, n, st, tb, &s2, nullptr, &clip)) return -1;
-    if (launch_shell_step(h, A, T, par, in0, in1, pml_in, cs)) return -1;
-    launch_sources(h, true, n, 0, nz, cs, false, &T);      // E-side sources of step n, H-side ones of step n + 1: on the middle step
+    for (int i = 0; i < zp.n; ++i) {                       // the bulk: one clipped two-step sweep per interval of its planes
+      const ClipP clip{sg.o0[0], sg.o1[0], sg.o0[1], sg.o1[1], zp.a[i], zp.b[i]};
+      if (launch_fused2(h, n, st, tb, &s2, nullptr, &clip)) return -1;
+    }
+    if (launch_shell_step(h, A, T, par, in0, in1, pml_in, cs, zp, 1)) return -1;
+    // the middle step: E-side sources / TFSF corrections of step n, the dispersive cells' memory term, the incident grid's E;
+    // then what precedes step n + 1: its H-side sources / corrections, the incident grid's H
+    launch_sources(h, true, n, 0, nz, cs, false, &T);
+    launch_ade(h, 0, nz, cs, &T);
+    advance_tfsf_aux(h, true, n, cs);
     launch_sources(h, false, n + 1, 0, nz, cs, false, &T);
+    advance_tfsf_aux(h, false, n + 1, cs);
     fill_ghost_fused(h, cs, &T);                           // periodic z: the middle step's wrapped planes (its top and bottom planes are the shell's)
-    if (launch_shell_step(h, T, B, par ^ 1, sg.o0, sg.o1, pml_in, cs)) return -1;
+    if (launch_shell_step(h, T, B, par ^ 1, sg.o0, sg.o1, pml_in, cs, zp, 0)) return -1;
     HIPCHK(h, hipEventRecord(h->ev_shell_b, cs));
     HIPCHK(h, hipStreamWaitEvent(st, h->ev_shell_b, 0));
     swap_sets(h);
     pair_record(h, tb, n, st);
     if (rec_at(n + 1)) record_monitors(h, n + 1, true, st);
     launch_sources(h, true, n + 1, 0, nz, st);
+    launch_ade(h, 0, nz, st);
+    advance_tfsf_aux(h, true, n + 1, st);
     fill_ghost_fused(h, st);
     return 0;
+  };
+  // every monitor of the pair's plan inside ONE interval of the bulk's planes (the sweep copies the middle step out only there)
+  auto plan_in_bulk = [&](const F2Plan& pl, const ZPlan& zp) {
+    auto inside = [&](const Monitor& m) {
+      for (int i = 0; i < zp.n; ++i) if (m.box.lo2 >= zp.a[i] && m.box.lo2 + m.box.nz <= zp.b[i]) return true;
+      return false;
+    };
+    for (int q : pl.mons) if (!inside(h->mons[(size_t)q])) return false;
+    for (int q : pl.dfts) if (!inside(h->mons[(size_t)q])) return false;
+    return true;
   };
   F2Plan f2_plan;
   h->fused2_pairs = 0;
@@ -2791,10 +2890,16 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     // every monitor that records at n or n + 1 a small time monitor the sweep can sample)
     bool src_alive = false;
     int src_why = 0;
-    const bool pair = fused && (f2_ok || f2s_ok) && done + 2 <= n_steps && !(h->decay_every > 0 && ((n + 1) % h->decay_every) == 0) &&
-                      (src_why = fused2_sources_why_not(h, n, &src_alive)) == 0 &&
-                      fused2_plan(h, n, &f2_plan, f2s_ok ? sg.o0 : nullptr, f2s_ok ? sg.o1 : nullptr);
-    if (src_why) h->f2_dyn_reason = src_why;
+    const ZPlan* zp = &zp_base;
+    bool pair = fused && (f2_ok || f2s_ok) && done + 2 <= n_steps && !(h->decay_every > 0 && ((n + 1) % h->decay_every) == 0);
+    if (pair) {
+      src_why = fused2_sources_why_not(h, n, &src_alive);
+      // lists that inject and that the sweep cannot apply itself: a shell pair whose bulk leaves their planes to the shell
+      if (src_why && f2s_ok && zp_src.ok) { src_why = 0; src_alive = false; zp = &zp_src; }
+      if (src_why) h->f2_dyn_reason = src_why;
+      pair = src_why == 0 && fused2_plan(h, n, &f2_plan, f2s_ok ? sg.o0 : nullptr, f2s_ok ? sg.o1 : nullptr) &&
+             (!f2s_ok || plan_in_bulk(f2_plan, *zp));
+    }
     // (with H-side sources the monitors of a pair still take E^n and H^{n-1/2} here: those sources change H^{n-1/2} before the
     //  sweep, and pair_record reads the set afterwards)
     if (rec) record_monitors(h, n, false, st, (pair && h->src_h_nodes == 0) ? &f2_plan : nullptr);
@@ -2918,7 +3023,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     } else if (pair && f2s_ok) {
       const F2Table* tb = fused2_table(h, f2_plan, src_alive);
       if (!tb) return -1;
-      if (shell_pair(n, tb)) return -1;
+      if (shell_pair(n, tb, *zp)) return -1;
       h->fused2_pairs++;
       h->shell_pairs++;
       h->step = n + 2;
