@@ -98,12 +98,14 @@ enum { FDTD_F2_OFF_NONE = 0,
        FDTD_F2_OFF_COMM = 3,              /* z-slab rank (RCCL communicator): ghost planes are exchanged every step */
        FDTD_F2_OFF_PML = 4,               /* CPML present and shell pairs not possible: switched off, slab-kernel CPML asked for,
                                              layers too thick for the grid, absorber layers on another axis */
-       FDTD_F2_OFF_ADE = 5,               /* dispersive media (auxiliary differential equation state per step) */
-       FDTD_F2_OFF_TFSF = 6,              /* total-field / scattered-field surfaces */
+       FDTD_F2_OFF_ADE = 5,               /* dispersive media whose cells are not confined to a few plane ranges along z (their planes take single
+                                             steps as z holes of the bulk; what is left must be worth a two-step launch), or with absorber layers */
+       FDTD_F2_OFF_TFSF = 6,              /* a TFSF box while it injects (a plane wave's injection PLANE is a z hole of the bulk: pairs) */
        FDTD_F2_OFF_BOUNDARY = 7,          /* periodic / Bloch faces, PMC on a plus face, rows not a multiple of 4 cells */
        FDTD_F2_OFF_H_SOURCE_ABSORBER = 8, /* magnetic point sources together with absorber layers */
        FDTD_F2_OFF_SEAM_SOURCE = 9,       /* an H_y / H_z source node in the column left of a seam between 256-cell x tiles */
-       FDTD_F2_OFF_SOURCES = 10,          /* more than 256 source nodes (mode planes, current sheets), or H-side nodes without room for their table */
+       FDTD_F2_OFF_SOURCES = 10,          /* while they inject: more than 256 source nodes that are not confined to a few planes along z (a mode plane /
+                                             current sheet normal to z is a z hole of the bulk: pairs), or H-side nodes without room for their table */
        FDTD_F2_OFF_VARIANT = 11,          /* the run is not on the fused sweep at all (two-pass kernels) */
        FDTD_F2_OFF_SHELL = 12 };          /* CPML shell too large a part of the grid for shell pairs to pay (cost model, fdtd_capi.hip shell_why_not) */
 
