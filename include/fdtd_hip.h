@@ -107,7 +107,8 @@ enum { FDTD_F2_OFF_NONE = 0,
        FDTD_F2_OFF_SOURCES = 10,          /* while they inject: more than 256 source nodes that are not confined to a few planes along z (a mode plane /
                                              current sheet normal to z is a z hole of the bulk: pairs), or H-side nodes without room for their table */
        FDTD_F2_OFF_VARIANT = 11,          /* the run is not on the fused sweep at all (two-pass kernels) */
-       FDTD_F2_OFF_SHELL = 12 };          /* CPML shell too large a part of the grid for shell pairs to pay (cost model, fdtd_capi.hip shell_why_not) */
+       FDTD_F2_OFF_SHELL = 12,            /* CPML shell too large a part of the grid for shell pairs to pay (cost model, fdtd_capi.hip shell_why_not) */
+       FDTD_F2_OFF_MEMORY = 13 };         /* no room for the third field set that shell pairs / slab pairs keep the middle step in (+ 50 % field memory) */
 
 /* progress callback: (step, time [s], field_decay) -> non-zero aborts the run (Ctrl-C path).
  * Mirrors the (perc_done, field_decay) pair the cloud reports (ref web/core/task_core.py:537). */

@@ -1046,11 +1046,15 @@ bool shell_geometry(const FdtdSolver* h, ShellGeom* G) {
   return true;
 }
 
+void release_buf(FdtdSolver* h, void* p);
 int ensure_third_set(FdtdSolver* h) {
   const GridP& g = h->g;
   if (h->f3.ex) return 0;
   const size_t fcount = (size_t)g.sxy * (g.nz + 2);
-  if (!h->fbase3[0] && alloc_field_set(h, h->fbase3, fcount, 2)) return -1;
+  if (!h->fbase3[0] && alloc_field_set(h, h->fbase3, fcount, 2)) {
+    for (int c = 0; c < 6; ++c) { if (h->fbase3[c]) release_buf(h, h->fbase3[c]); h->fbase3[c] = nullptr; }
+    return -1;
+  }
   h->f3.ex = h->fbase3[0] + g.sxy; h->f3.ey = h->fbase3[1] + g.sxy; h->f3.ez = h->fbase3[2] + g.sxy;
   h->f3.hx = h->fbase3[3] + g.sxy; h->f3.hy = h->fbase3[4] + g.sxy; h->f3.hz = h->fbase3[5] + g.sxy;
   return 0;
@@ -2809,12 +2813,20 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   if (f2_ok || f2s_ok) {
     if (fused2_sources(h)) return -1;
   }
+  // (the third field set: + 50 % field memory.  Where it does not fit, the run keeps single steps instead of failing)
+  if (f2s_ok && ensure_third_set(h)) {
+    (void)hipGetLastError();
+    h->err.clear();
+    f2s_ok = false;
+    h->f2_off_reason = FDTD_F2_OFF_MEMORY;
+  }
   if (f2s_ok && probe_stream_overlap(h)) return -1;
   // z-slab ranks (pipelined schedule): step pairs with the planes next to the neighbour faces as the shell
   bool f2m_ok = fused_multi && !any_pml(h) && !h->has_damp && h->shell_on != 0 && nz >= 8 && fused2_why_not(h, true) == 0;
   if (fused_multi) h->f2_off_reason = f2m_ok ? 0 : (any_pml(h) || h->has_damp ? FDTD_F2_OFF_COMM : (fused2_why_not(h, true) ? fused2_why_not(h, true) : FDTD_F2_OFF_COMM));
   if (f2m_ok) {
-    if (fused2_sources(h) || ensure_third_set(h)) return -1;
+    if (fused2_sources(h)) return -1;
+    if (ensure_third_set(h)) { (void)hipGetLastError(); h->err.clear(); f2m_ok = false; h->f2_off_reason = FDTD_F2_OFF_MEMORY; }
   }
   // steps n and n + 1 of a grid walled by CPML: the bulk as ONE two-step sweep on st, the shell as two single steps on cs
   auto shell_pair = [&](long long n, const F2Table* tb, const ZPlan& zp) -> int {

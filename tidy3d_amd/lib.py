@@ -50,7 +50,7 @@ OPT_FLAGS, OPT_VARIANT, OPT_ZCHUNK, OPT_ROWS, OPT_XCD_REMAP, OPT_FUSED_LB, OPT_P
 F2_OFF_REASONS = {0: "", 1: "switched off", 2: "grid too small", 3: "z-slab rank", 4: "CPML (shell pairs not possible)",
                   5: "dispersive media not confined to a few planes along z", 6: "TFSF box while it injects", 7: "Bloch / PMC-plus faces (or rows not a multiple of 4 cells)", 8: "magnetic sources with absorber layers",
                   9: "magnetic source node on a tile seam", 10: "too many source nodes", 11: "two-pass kernels",
-                  12: "CPML shell too large a part of the grid"}
+                  12: "CPML shell too large a part of the grid", 13: "no device memory for the third field set"}
 
 
 class FdtdConfig(C.Structure):
