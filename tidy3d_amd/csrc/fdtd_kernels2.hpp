@@ -19,9 +19,13 @@
 // values on the seam: those five values per seam row are computed wrong here and repaired afterwards by
 // seam_kernel from the intermediate values both tiles leave in a small scratch array.
 //
-// Scope (fdtd_capi.hip checks it): non-dispersive media (uniform, or packed medium words + (Ca, Cb) table), PEC walls (PMC
-// allowed on the min faces: symmetry planes), no CPML / absorber / ADE / TFSF / Bloch / mirror faces, point sources (<= kMaxInj nodes; the E-side ones of step n+1 are applied in S4, the H-side ones in S3), small time monitors (their samples of the middle step are copied out for pair_record_kernel), one
-// GPU.  Everything else takes single steps.
+// Scope (fdtd_capi.hip checks it): non-dispersive media (uniform, or packed medium words + (Ca, Cb) table), PEC walls (PMC allowed on
+// the min faces: symmetry planes), absorber layers (damped in registers), point sources (<= kMaxInj nodes while they inject; the
+// E-side ones of step n+1 are applied in S4, the H-side ones in S3), small time monitors (their samples of the middle step are
+// copied out for pair_record_kernel) and DFT monitors, one box per launch.  Round 4: the CLIP instantiations (OPT bit 4) write one
+// box only — the bulk of a grid whose shell takes single steps beside it (fdtd_capi.hip: CPML slabs + collar, the rows / planes
+// next to periodic y / z faces, the boundary planes of a z-slab rank, z holes around dispersive cells and big source planes) —
+// and wrap a periodic x axis inside the sweep.  Everything else takes single steps.
 #pragma once
 #include "fdtd_fused2.hpp"
 
