@@ -37,7 +37,8 @@ with HipEngine(spec, device=0) as e:
              ("pairs_edge4", {**P, L.OPT_EDGE_ZCHUNK: 4}), ("pairs_edge8_one_stream", {**P, L.OPT_EDGE_ZCHUNK: 8, L.OPT_SHELL_PAIRS: 2}),
              ("pairs_16x16_edge8", {**P, L.OPT_EDGE_ZCHUNK: 8, L.OPT_TWOSTEP: 16 + 64 * 16}),
              ("pairs_16x24_edge8", {**P, L.OPT_EDGE_ZCHUNK: 8, L.OPT_TWOSTEP: 16 + 64 * 24}),
-             ("pairs_16x16", {**P, L.OPT_TWOSTEP: 16 + 64 * 16}),
+             ("pairs_16x16", {**P, L.OPT_TWOSTEP: 16 + 64 * 16}), ("pairs_16x32", {**P, L.OPT_TWOSTEP: 16 + 64 * 32}),
+             ("pairs_16x64", {**P, L.OPT_TWOSTEP: 16 + 64 * 64}),
              ("pairs_16x16_strip8x4", {**P, L.OPT_TWOSTEP: 16 + 64 * 16, L.OPT_STRIP: 8 + 64 * 4}),
              ("single", {L.OPT_TWOSTEP: 0}), ("pairs", P)]
     if os.environ.get("PROBE_MODES"):

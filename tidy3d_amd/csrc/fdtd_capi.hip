@@ -946,7 +946,9 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
   // (beside the shell launches of a shell pair shorter chunks do better — workgroups retire, and hand their CU to a shell
   //  workgroup, twice as often: 512^3 V2 inside one engine 16 x 16 1.206 / 1.219 ms per step, 16 x 24 1.225, 16 x 32 1.249 / 1.231,
   //  profiles/r4d)
-  if (clip && !h->comm && h->twostep_zc <= 0) zc = std::min(zc, 16);
+  // (... up to 512^3; larger grids have tile rounds to spare and prefer the long chunks of the plain sweep: V2 at 768^3 117.6 /
+  //  119.6 / 123.1 Gcells/s with 16 / 32 / 64 planes, at 1024^3 127.2 / 131.5 / 134.7, profiles/r4/r4u)
+  if (clip && !h->comm && h->twostep_zc <= 0 && (long long)g.nx * g.ny * g.nz < (1LL << 28)) zc = std::min(zc, 16);
   zc = std::max(2, std::min(zc, box.k1 - box.k0));
   h->twostep_w_used = W; h->twostep_zc_used = zc;
   const int R = W - 3;
