@@ -42,7 +42,9 @@ GLOO_CASES = [(2, "media_mix"), (2, "pml_box"), (3, "periodic_box"), (2, "drude_
                                         (2, "tfsf_box"), (3, "au_array"), (3, "absorber_mix"),
                                         # complex fields on z-slabs: Bloch x / y with CPML in z; Bloch on all axes (the
                                         # wrap-around planes rank n-1 <-> rank 0 are rotated by exp(-+ i phi_z))
-                                        (2, "bloch_xy_pml_z"), (2, "bloch_box"), (3, "bloch_box")]
+                                        (2, "bloch_xy_pml_z"), (2, "bloch_box"), (3, "bloch_box"),
+                                        # PMC on plus faces: the x wall crosses every slab, the z wall is the last rank's
+                                        (2, "pmc_plus_mix")]
 
 
 @pytest.mark.parametrize("world,case", GLOO_CASES)
@@ -97,7 +99,7 @@ def test_cpml_inside_the_sweeps_of_slab_ranks(world, case, mask, emu_lib, tmp_pa
         assert np.array_equal(got[f"mon_{k}"], v), k
 
 
-SLAB_PAIR_CASES = [(2, "slab_pairs_box", 5 + 64 * 4), (3, "slab_pairs_box", 16 + 64 * 32), (2, "slab_pairs_box_periodic", 6 + 64 * 5),
+SLAB_PAIR_CASES = [(2, "slab_pairs_box", 8 + 64 * 6), (3, "slab_pairs_box", 16 + 64 * 32), (2, "slab_pairs_box_periodic", 6 + 64 * 5),
                    (4, "slab_pairs_box_periodic", 4 + 64 * 3)]
 
 

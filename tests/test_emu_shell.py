@@ -252,7 +252,7 @@ def test_shell_pairs_with_z_holes(kind, emu_lib):
     n1 = 60
     assert spec.n_steps > n1 + 40
     ref_f, ref_m, p0, _, _ = _run(spec, emu_lib, 0, runs=(n1 - 1, spec.n_steps - n1 + 1))
-    got_f, got_m, p1, s1, why = _run(spec, emu_lib, 5 + 64 * 4, runs=(n1 - 1, spec.n_steps - n1 + 1))
+    got_f, got_m, p1, s1, why = _run(spec, emu_lib, 8 + 64 * 6, runs=(n1 - 1, spec.n_steps - n1 + 1))
     assert p0 == 0 and s1 == p1 and p1 >= spec.n_steps // 2 - 3, (p1, spec.n_steps, why)
     assert max(float(np.abs(f).max()) for f in ref_f) > 0
     for c in range(6):

@@ -1493,12 +1493,18 @@ int probe_stream_overlap(FdtdSolver* h) {
 // periodic z, fused sweep: the prologue recomputes H^{n+1/2}[-1] from ghost copies of E (all three
 // components) and H_x, H_y of plane nz-1; the top plane needs E_x, E_y of plane 0
 // PMC on plus faces: refresh the mirror images beyond the walls (start of a step: E^n, H^{n-1/2} are complete)
-void fill_mirror(FdtdSolver* h, hipStream_t st) {
+// (k0, k1): the planes of this call — x / y walls are refreshed plane by plane; a z wall (the last rank's: images in its last two
+//  planes, of the two below them) with the call that holds all four of its planes (fdtd_run checks that one does)
+void fill_mirror(FdtdSolver* h, hipStream_t st, int k0 = 0, int k1 = -1) {
   const GridP& g = h->g;
+  if (k1 < 0) k1 = g.nz;
+  if (k1 <= k0) return;
   for (int a = 0; a < 3; ++a) {
-    if (h->mirror_wall[a] < 0) continue;
-    const long long lines = (a == 0) ? (long long)g.ny * g.nz : (a == 1 ? (long long)g.nx * g.nz : g.sxy);
-    hipLaunchKernelGGL(mirror_fill_kernel, dim3(nblk(lines)), dim3(256), 0, st, g, h->f, a, h->mirror_wall[a], g.nz);
+    const int N = h->mirror_wall[a];
+    if (N < 0) continue;
+    if (a == 2 && !(k0 <= N - 2 && N + 2 <= k1)) continue;
+    const long long lines = (a == 0) ? (long long)g.ny * (k1 - k0) : (a == 1 ? (long long)g.nx * (k1 - k0) : g.sxy);
+    hipLaunchKernelGGL(mirror_fill_kernel, dim3(nblk(lines)), dim3(256), 0, st, g, h->f, a, N, k0, k1 - k0);
   }
 }
 
@@ -2478,8 +2484,10 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   const bool multi = h->comm != nullptr;     // also true for a 1-rank communicator (self exchange)
   const bool nb_lo = h->cfg.bc[4] == FDTD_BC_NEIGHBOR, nb_hi = h->cfg.bc[5] == FDTD_BC_NEIGHBOR;
   if ((nb_lo || nb_hi) && !multi) return fail(h, "fdtd_run: neighbour faces need fdtd_comm_init");
-  if (multi && (h->mirror_wall[0] >= 0 || h->mirror_wall[1] >= 0 || h->mirror_wall[2] >= 0))
-    return fail(h, "fdtd_run: PMC on a plus face is not available on z-slabs");
+  // (PMC on a plus face of a z-slab rank: x / y walls are local to every plane; a z wall belongs to the rank without an upper
+  //  neighbour, whose interior launch must hold the wall's two image planes and the two they mirror)
+  if (multi && h->mirror_wall[2] >= 0 && (nb_hi || h->mirror_wall[2] != h->g.nz - 2 || h->g.nz < 8))
+    return fail(h, "fdtd_run: a PMC plus face along z needs the last z-slab to hold the wall and at least 8 planes");
   const int nz = h->g.nz;
   // runs that use BOTH streams first make sure the two really overlap (once per engine; falls back to one stream)
   if ((multi || any_pml(h) || h->tblock > 4096) && probe_stream_overlap(h)) return -1;
@@ -2579,6 +2587,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     launch_ade(h, k0, k1, s);
   };
   auto h_pre = [&](long long n, int k0, int k1, hipStream_t s, bool replica) {
+    fill_mirror(h, s, k0, k1);             // (E^n and H^{n-1/2} of these planes are complete: the images beyond PMC plus walls first)
     launch_damp(h, false, k0, k1, s);
     launch_sources(h, false, n, k0, k1, s, replica);
     launch_pml(h, false, k0, k1, s, 7 & ~pml_in_m);
@@ -3075,6 +3084,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     const int h_top = (multi && nb_hi) ? nz - 1 : nz;      // planes [0, h_top) on st, [h_top, nz) on cs
     if (multi && nb_hi) {
       HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
+      fill_mirror(h, cs, h_top, nz);
       launch_damp(h, false, h_top, nz, cs);          // absorber layers damp H^{n-1/2} before anything is added
       launch_sources(h, false, n, h_top, nz, cs);    // H-side corrections first (they only read E^n),
       launch_pml(h, false, h_top, nz, cs);           // in the summation order of the fused sweep
@@ -3082,7 +3092,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
     }
     if (multi) HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
-    fill_mirror(h, st);
+    fill_mirror(h, st, 0, h_top);
     launch_damp(h, false, 0, h_top, st);
     launch_sources(h, false, n, 0, h_top, st);
     launch_pml(h, false, 0, h_top, st);

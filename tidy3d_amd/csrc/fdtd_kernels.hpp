@@ -1717,12 +1717,13 @@ __global__ void spin_kernel(long long ticks) {
 // The update equations preserve the mirror symmetry, so the sweep itself produces the right H^{n+1/2} in the ghost cell N
 // (which the E update of the wall nodes differentiates); only what the truncation at N + 2 spoils is refreshed here.
 // One thread per line along a.
-__global__ __launch_bounds__(256) void mirror_fill_kernel(GridP g, FieldP f, int a, int N, int nz) {
+// (x / y walls: the planes [k0, k0 + nk) — a z-slab rank refreshes its boundary planes and its interior on different streams)
+__global__ __launch_bounds__(256) void mirror_fill_kernel(GridP g, FieldP f, int a, int N, int k0, int nk) {
   const int n1 = (a == 0) ? g.ny : g.nx;                // fastest transverse extent
-  const int n2 = (a == 2) ? g.ny : nz;                  // slowest transverse extent
+  const int n2 = (a == 2) ? g.ny : nk;                  // slowest transverse extent
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)n1 * n2) return;
-  const int u = (int)(t % n1), w = (int)(t / n1);
+  const int u = (int)(t % n1), w = (int)(t / n1) + (a == 2 ? 0 : k0);
   const long long stride = (a == 0) ? 1 : (a == 1 ? (long long)g.nx : g.sxy);
   long long base;
   if (a == 0) base = (long long)w * g.sxy + (long long)u * g.nx;          // u = j, w = k

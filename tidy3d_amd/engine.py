@@ -14,7 +14,7 @@ import numpy as np
 
 from . import lib as L
 from .coeffs import damping_tables, h_coeff, inv_steps, material_table, pml_axis
-from .exceptions import SolverLibraryError
+from .exceptions import SetupError, SolverLibraryError
 from .spec import BC_PERIODIC, MonitorSpec, SolverSpec
 
 
@@ -388,12 +388,13 @@ class HipEngine:
         # PMC on plus faces: the wall index of every mirrored axis (two ghost cells lie beyond it)
         mp = getattr(spec, "mirror_plus", None)
         if mp is not None and any(w >= 0 for w in mp):
-            if self.n_ranks > 1 or (z0, z1) != (0, nz):
-                from .exceptions import Tidy3dNotImplementedError
-                raise Tidy3dNotImplementedError("PMCBoundary on a plus face is not available in z-slab (multi-GPU) runs")
+            # (z-slab ranks: x / y walls cross every slab; a z wall and its two image planes belong to the last one)
             for a, w in enumerate(mp):
-                if w >= 0:
-                    self._chk(d.fdtd_set_mirror_plus(h, a, int(w)), "fdtd_set_mirror_plus")
+                if w < 0 or (a == 2 and z1 != nz):
+                    continue
+                if a == 2 and w - 2 < z0:
+                    raise SetupError("a PMC plus face along z needs the last z-slab to hold at least the four planes around the wall")
+                self._chk(d.fdtd_set_mirror_plus(h, a, int(w) - (z0 if a == 2 else 0)), "fdtd_set_mirror_plus")
         # absorber layers (damping tables, slab-local along z)
         dm = damping_tables(spec)
         if dm is not None:
