@@ -501,3 +501,47 @@ def test_broadband_mode_source_launches_every_frequency_with_its_own_profile():
     assert b1[0] > 1e-3 and b1[-1] > 5e-4 and p1[0] > 1e-4          # the single-profile launch IS imperfect off centre
     assert b5.max() < 1e-5 and p5.max() < 1e-5, (b5, p5)
     assert np.abs(f5 - 1).max() < 0.005 < np.abs(f1 - 1).max()
+
+
+@pytest.mark.parametrize("colocate", [True, False])
+def test_mode_solver_monitor_under_symmetry(colocate):
+    """ModeSolverMonitor together with Simulation.symmetry (ref monitor.py:688, mode_solver.py:413-438): the plane is solved on
+    the computed quarter — PEC wall on the y symmetry plane, PMC wall on the z one, as the run's own sources and monitors see it —
+    normalised to unit power over the WHOLE plane and expanded with the parities of the components.  Same n_eff and (up to the
+    eigenvector's free phase) the same six components as the solve of the whole plane."""
+    from tidy3d_amd.data import assemble
+    from tidy3d_amd.discretize import discretize
+    from tidy3d_amd.plugins.mode import ModeSolver
+    f0 = C_0 / 1.55
+    plane = td.Box(center=(0, 0, 0), size=(0, 1.22, 0.82))       # (edges clear of the grid lines)
+    ms = td.ModeSpec(num_modes=1, precision="double")
+
+    def sim(symmetry):
+        return td.Simulation(
+            size=(0.4, 1.6, 1.2), grid_spec=td.GridSpec.uniform(dl=0.04), run_time=1e-14, subpixel=False, symmetry=symmetry,
+            medium=td.Medium(permittivity=1.44 ** 2),
+            structures=[td.Structure(geometry=td.Box(center=(0, 0, 0), size=(td.inf, 0.45, 0.22)), medium=td.Medium(permittivity=3.48 ** 2))],
+            sources=[td.PointDipole(center=(0, 0, 0), source_time=td.GaussianPulse(freq0=f0, fwidth=1e13), polarization="Ey")],
+            monitors=[td.ModeSolverMonitor(center=plane.center, size=plane.size, freqs=[f0], name="modes", mode_spec=ms, colocate=colocate)],
+            boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary()))
+    ref = ModeSolver(sim((0, 0, 0)), plane, ms, freqs=[f0], colocate=colocate).solve()
+    s = sim((0, -1, 1))
+    disc = discretize(s, n_steps=2)
+    assert disc.spec.shape[1] * 2 == disc.spec_full.shape[1] and disc.spec.shape[2] * 2 == disc.spec_full.shape[2]
+    md = assemble(disc, {})["modes"]                                     # (a host-side monitor: nothing comes from the device)
+    np.testing.assert_allclose(md.n_complex.values, ref.n_complex.values, rtol=1e-9)
+    a0 = ref.Ey.values.ravel()
+    ph = np.vdot(md.Ey.values.ravel(), a0)
+    ph /= abs(ph)
+    scale = max(np.abs(getattr(ref, k).values).max() for k in ("Ey", "Hz"))
+    for k in ("Ex", "Ey", "Ez", "Hx", "Hy", "Hz"):
+        got, want = getattr(md, k), getattr(ref, k)
+        assert got.values.shape == want.values.shape, k
+        for d in "xyz":
+            np.testing.assert_allclose(got.coords[d], want.coords[d], atol=1e-12, err_msg=k + d)
+        big = np.abs(want.values).max()
+        assert np.abs(got.values * ph - want.values).max() < 1e-6 * max(big, 1e-3 * scale * (1 if k[0] == "E" else 1)), k
+    # the standalone facade takes the same route
+    alone = ModeSolver(s, plane, ms, freqs=[f0], colocate=colocate).solve()
+    np.testing.assert_allclose(alone.n_complex.values, md.n_complex.values, rtol=1e-12)
+    assert np.abs(np.abs(alone.Ey.values) - np.abs(md.Ey.values)).max() < 1e-9 * np.abs(md.Ey.values).max()

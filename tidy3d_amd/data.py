@@ -580,8 +580,9 @@ def assemble(disc: Discretization, raw: Dict[str, np.ndarray], log: str = "", di
             from .plugins.mode import ModeSolver
             ms = ModeSolver(simulation=sim, plane=mon.geometry, mode_spec=mon.mode_spec, freqs=mon.freqs,
                             direction=mon.direction, colocate=bool(mon.colocate))
-            md = ms.solve(spec=spec)
-            md.monitor, md.grid_expanded = mon, _grid_expanded(spec, plan.fields[0])
+            md = ms.solve(spec=spec, disc=disc if any(sym) else None)
+            md.monitor = mon
+            md.grid_expanded = _grid_expanded(spec, plan.fields[0]) if pfull is None else _grid_expanded(disc.spec_full, pfull.fields[0])
             out.append(md)
         elif plan.kind == "diffraction":
             from . import projection

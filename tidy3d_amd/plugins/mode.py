@@ -13,7 +13,7 @@ import numpy as np
 from .. import schema as td
 from ..data import DataArray
 from ..discretize import discretize
-from ..exceptions import SetupError
+from ..exceptions import SetupError, Tidy3dNotImplementedError
 from ..modesource import colocated_mode, mode_profile
 
 
@@ -54,47 +54,109 @@ class ModeSolver:
             raise SetupError("a mode plane needs exactly one zero-size dimension")
         self.normal_axis = zd[0]
 
-    def solve(self, spec=None) -> ModeSolverData:
-        """``spec``: an already discretised simulation (the FDTD run's own SolverSpec)."""
+    def solve(self, spec=None, disc=None) -> ModeSolverData:
+        """``spec``: an already discretised simulation (the FDTD run's own SolverSpec); ``disc``: its Discretization —
+        needed with ``Simulation.symmetry``, where the plane is solved on the computed half / quarter (symmetry walls on
+        its edges, as the run's mode sources and monitors see it) and the fields are expanded to the user's plane with the
+        parities of the components (ref mode_solver.py:413-438 ``_data_on_yee_grid`` + ``symmetry_expanded_copy``)."""
         sim = self.simulation
-        if any(sim.symmetry):
-            raise NotImplementedError("ModeSolver façade: run on the symmetry-free simulation")
-        if spec is None:
-            spec = discretize(sim, n_steps=1).spec
+        sym = tuple(int(v) for v in sim.symmetry)
         p = self.normal_axis
+        box = self.plane
+        spec_full = None
+        if any(sym):
+            if disc is None:
+                import dataclasses
+                disc = discretize(dataclasses.replace(sim, monitors=()), n_steps=1)
+            spec, spec_full = disc.spec, disc.spec_full
+            if sym[p] != 0 and box.center[p] < sim.center[p]:
+                raise Tidy3dNotImplementedError("a mode plane below a symmetry plane normal to it (the mirror image swaps the "
+                                                "directions) is not supported")
+            from ..discretize import symmetry_box_map
+            box = symmetry_box_map(sim, list(spec_full.boundaries))(box, False)
+        elif spec is None:
+            spec = discretize(sim, n_steps=1).spec
         nm = int(self.mode_spec.num_modes)
         sign = 1 if self.direction == "+" else -1
         n_complex = np.zeros((len(self.freqs), nm), complex)
         names = "xyz"
         fields = None
         for i_f, f in enumerate(self.freqs):
-            plane = mode_profile(spec, self.plane, self.mode_spec, f)
+            plane = mode_profile(spec, box, self.mode_spec, f, sym)
             u, v = plane.u, plane.v
             b = spec.boundaries
             ub = np.asarray(b[u][plane.lo[0]:plane.hi[0] + 1])
             vb = np.asarray(b[v][plane.lo[1]:plane.hi[1] + 1])
+            uc, vc = 0.5 * (ub[1:] + ub[:-1]), 0.5 * (vb[1:] + vb[:-1])
             n_complex[i_f] = plane.result.n_complex
+            # where each component lives in the plane: everything on the cell boundaries when colocated, else its own Yee nodes
+            yee = {"E" + names[u]: (uc, vb[:-1]), "E" + names[v]: (ub[:-1], vc), "E" + names[p]: (ub[:-1], vb[:-1]),
+                   "H" + names[u]: (ub[:-1], vc), "H" + names[v]: (uc, vb[:-1]), "H" + names[p]: (uc, vc)}
+            # (colocated + symmetry: the window's top grid line too — it is the mirror image of the user's lowest one)
+            col_u = ub if (spec_full is not None and sym[u]) else ub[:-1]
+            col_v = vb if (spec_full is not None and sym[v]) else vb[:-1]
             if fields is None:
-                shape = [1, 1, 1]
-                shape[u], shape[v] = len(ub) - 1, len(vb) - 1
-                fields = {k: np.zeros(tuple(shape) + (len(self.freqs), nm), complex)
-                          for k in ("Ex", "Ey", "Ez", "Hx", "Hy", "Hz")}
-                coords = {names[u]: ub[:-1], names[v]: vb[:-1], names[p]: np.array([self.plane.center[p]])}
+                fields, coords = {}, {}
+                for k in ("Ex", "Ey", "Ez", "Hx", "Hy", "Hz"):
+                    cu, cv = (col_u, col_v) if self.colocate else yee[k]
+                    shape = [1, 1, 1]
+                    shape[u], shape[v] = len(cu), len(cv)
+                    fields[k] = np.zeros(tuple(shape) + (len(self.freqs), nm), complex)
+                    by_axis = {u: cu, v: cv, p: np.array([self.plane.center[p]])}
+                    coords[k] = {names[a]: by_axis[a] for a in range(3)}
             r = plane.result
+            # symmetry: the solved part carries unit power; the mode of the whole plane does (ref source.py:1003)
+            scale = 1.0
+            for i, a in enumerate((u, v)):
+                if sym[a] != 0 and plane.lo[i] == 0:
+                    scale /= np.sqrt(2.0)
             for m in range(nm):
                 if self.colocate:
-                    tang = colocated_mode(plane, spec, m, sign, ub[:-1], vb[:-1])
+                    tang = colocated_mode(plane, spec, m, sign, col_u, col_v)
+                    from ..modesource import _interp_nodes
                     comp = {"E" + names[u]: tang["Eu"], "E" + names[v]: tang["Ev"], "H" + names[u]: tang["Hu"],
-                            "H" + names[v]: tang["Hv"], "E" + names[p]: r.Ew[:, :, m], "H" + names[p]: sign * r.Hw[:, :, m]}
+                            "H" + names[v]: tang["Hv"],
+                            # (a backward mode: tangential H and normal E change sign, ref plugins/mode/solver.py:369-372)
+                            "E" + names[p]: sign * _interp_nodes(r.Ew[:, :, m], ub[:-1], vb[:-1], col_u, col_v),
+                            "H" + names[p]: _interp_nodes(r.Hw[:, :, m], uc, vc, col_u, col_v)}
+                    # the top grid line is the window's own PEC truncation: what lives ON the lines along an axis (E across it,
+                    # H along it) vanishes there — the interpolation above held the last node's value instead
+                    for k in comp:
+                        on_line = {a: (k[0] == "E") != (names.index(k[1]) == a) for a in (u, v)}
+                        if len(col_u) == len(ub) and on_line[u]:
+                            comp[k][-1, :] = 0.0
+                        if len(col_v) == len(vb) and on_line[v]:
+                            comp[k][:, -1] = 0.0
                 else:
-                    comp = {"E" + names[u]: r.Eu[:, :, m], "E" + names[v]: r.Ev[:, :, m], "E" + names[p]: r.Ew[:, :, m],
+                    comp = {"E" + names[u]: r.Eu[:, :, m], "E" + names[v]: r.Ev[:, :, m], "E" + names[p]: sign * r.Ew[:, :, m],
                             "H" + names[u]: sign * r.Hu[:, :, m], "H" + names[v]: sign * r.Hv[:, :, m],
                             "H" + names[p]: r.Hw[:, :, m]}
                 for k, arr in comp.items():
                     a3 = np.expand_dims(arr if (u < v) else arr.T, axis=p)       # (x, y, z) order
-                    fields[k][..., i_f, m] = a3
+                    fields[k][..., i_f, m] = scale * a3
         cf = {"f": np.asarray(self.freqs), "mode_index": np.arange(nm)}
-        data = {k: DataArray(v, {**{d: coords[d] for d in "xyz"}, **cf}) for k, v in fields.items()}
+        if spec_full is not None:
+            # the user's plane on the full grid: mirror samples times the parity of each component (data.expand_symmetry)
+            from ..data import expand_symmetry
+            from ..discretize import discretize_inds
+            bf = spec_full.boundaries
+            span = discretize_inds(list(bf), self.plane)
+            for k in fields:
+                full = []
+                for a in range(3):
+                    if a == p:
+                        full.append(coords[k][names[a]])
+                        continue
+                    lo_a, hi_a = max(span[a][0], 0), min(span[a][1], spec_full.shape[a])
+                    ba = np.asarray(bf[a][lo_a:hi_a + 1])
+                    centred = (not self.colocate) and ((k[0] == "E") == (names.index(k[1]) == a))
+                    full.append(0.5 * (ba[1:] + ba[:-1]) if centred else ba[:-1])
+                half = [coords[k][d] for d in names]
+                arr = fields[k].reshape(fields[k].shape[:3] + (-1,))
+                arr = expand_symmetry(arr, half, full, k, sym, sim.center)
+                fields[k] = arr.reshape(arr.shape[:3] + (len(self.freqs), nm))
+                coords[k] = {d: full[i] for i, d in enumerate(names)}
+        data = {k: DataArray(v, {**coords[k], **cf}) for k, v in fields.items()}
         return ModeSolverData(monitor=self.plane, n_complex=DataArray(n_complex, cf), **data)
 
     data = property(lambda self: self.solve())
