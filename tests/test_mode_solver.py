@@ -402,6 +402,46 @@ def test_angled_plane_against_reference_compute_modes(theta, phi):
         assert abs(a / b - 1) < 2e-4          # impedance and relative phase of E and H
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/tidy3d"), reason="reference checkout not present")
+@pytest.mark.parametrize("theta,phi,radius,bend_axis,num_pml", [(0.2, 0.0, 6.0, 1, (0, 0)), (0.25, 0.6, None, 0, (6, 5)),
+                                                                 (-0.15, 1.2, 5.0, 0, (5, 6))])
+def test_angled_plane_with_bend_and_pml_against_reference(theta, phi, radius, bend_axis, num_pml):
+    """An angled mode plane together with ``bend_radius`` and / or ``num_pml`` (ref solver.py:141-147: the shear and the
+    conformal map composed; derivatives.py:79-127: the stretched derivatives) against the LIVE reference ``compute_modes``:
+    complex n_eff and all six components."""
+    from oracle.tidy3d_ref_loader import load_mode_solver
+    from tidy3d_amd.mode_solver import solve_modes_angled
+    _, solver = load_mode_solver()
+    rng = np.random.default_rng(5)
+    xb = np.concatenate(([0.0], np.cumsum(0.04 + 0.02 * rng.random(38)))) - 1.1
+    yb = np.concatenate(([0.0], np.cumsum(0.035 + 0.02 * rng.random(30)))) - 0.7
+    xc, yc = (xb[1:] + xb[:-1]) / 2, (yb[1:] + yb[:-1]) / 2
+
+    def eps_at(x, y):
+        X, Y = np.meshgrid(x, y, indexing="ij")
+        e = np.full(X.shape, 1.44 ** 2, complex)
+        e[(np.abs(X - 0.05) <= 0.3) & (Y >= -0.1) & (Y <= 0.15)] = 3.48 ** 2
+        return e
+    exx, eyy, ezz = eps_at(xc, yb[:-1]), eps_at(xb[:-1], yc), eps_at(xb[:-1], yb[:-1])
+    z = np.zeros_like(exx)
+    ms = SimpleNamespace(num_modes=1, bend_radius=radius, bend_axis=bend_axis, angle_theta=theta, angle_phi=phi,
+                         num_pml=num_pml, target_neff=None, precision="double")
+    fields, n_ref, kind = solver.compute_modes(eps_cross=[exx, z, z, z, eyy, z, z, z, ezz], coords=[xb, yb],
+                                               freq=C_0 / 1.55, mode_spec=ms, symmetry=(0, 0), direction="+")
+    assert kind.startswith("tensorial")
+    r = solve_modes_angled(exx, eyy, ezz, xb, yb, C_0 / 1.55, theta, phi, num_modes=1, num_pml=num_pml,
+                           bend_radius=radius, bend_axis=bend_axis)
+    np.testing.assert_allclose(r.n_complex, n_ref, rtol=5e-5)
+    for blk, comps in ((0, (r.Eu, r.Ev, r.Ew)), (1, (r.Hu, r.Hv, r.Hw))):
+        mine = np.concatenate([c[:, :, 0].ravel() for c in comps])
+        ref = np.concatenate([fields[blk, q, :, :, 0, 0].ravel() for q in range(3)])
+        ov = abs(np.vdot(ref, mine)) / (np.linalg.norm(ref) * np.linalg.norm(mine))
+        assert ov > 1 - 1e-4, (blk, ov)
+    a = np.vdot(fields[0, 0, :, :, 0, 0], r.Eu[:, :, 0]) / np.vdot(fields[0, 0, :, :, 0, 0], fields[0, 0, :, :, 0, 0])
+    b = np.vdot(fields[1, 1, :, :, 0, 0], r.Hv[:, :, 0]) / np.vdot(fields[1, 1, :, :, 0, 0], fields[1, 1, :, :, 0, 0])
+    assert abs(a / b - 1) < 2e-4          # impedance and relative phase of E and H
+
+
 def test_angled_solver_reduces_to_the_straight_one():
     """theta -> 0: the tensorial problem gives the straight waveguide's n_eff and profile; a small angle lowers
     n_eff like cos(theta) to first order in the transverse confinement."""

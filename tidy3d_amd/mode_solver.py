@@ -252,10 +252,16 @@ def solve_modes(eps_u: np.ndarray, eps_v: np.ndarray, eps_w: np.ndarray, ub: np.
 def solve_modes_angled(eps_u: np.ndarray, eps_v: np.ndarray, eps_w: np.ndarray, ub: np.ndarray, vb: np.ndarray,
                        freq: float, angle_theta: float, angle_phi: float = 0.0, num_modes: int = 1,
                        target_neff: Optional[float] = None, precision: str = "double",
-                       pmc_min: Tuple[bool, bool] = (False, False)) -> ModeResult:
+                       pmc_min: Tuple[bool, bool] = (False, False), num_pml: Tuple[int, int] = (0, 0),
+                       pml_min: Tuple[bool, bool] = (True, True), bend_radius: Optional[float] = None,
+                       bend_axis: int = 0) -> ModeResult:
     """Modes of a waveguide that crosses the plane at polar angle ``angle_theta`` from its normal, azimuth
     ``angle_phi`` from the plane's u axis (module docstring).  Same arguments and result layout as
-    ``solve_modes``; the tensorial problem is complex even for lossless media (eigenvalue i n)."""
+    ``solve_modes``; the tensorial problem is complex even for lossless media (eigenvalue i n).
+    With ``bend_radius`` the two straightening maps are composed as the reference composes them (ref solver.py:141-147:
+    the shear first, then the conformal map): J = diag(1, 1, s) [[1, 0, a], [0, 1, b], [0, 0, 1]], s = R / r, det J = s;
+    ``num_pml`` stretches the derivative operators as in ``solve_modes`` (wave speeds from the diagonals of the
+    transformed tensors, ref derivatives.py:129-155)."""
     nu, nv = eps_u.shape
     N = nu * nv
     k0 = 2 * np.pi * freq / C_0
@@ -263,15 +269,36 @@ def solve_modes_angled(eps_u: np.ndarray, eps_v: np.ndarray, eps_w: np.ndarray, 
     b = -np.tan(angle_theta) * np.sin(angle_phi)
     eu, ev, ew = (np.asarray(x, complex).reshape(-1) for x in (eps_u, eps_v, eps_w))
     one = np.ones(N, complex)
-    # eps' = J diag(eu, ev, ew) J^T,  mu' = J J^T
-    eps = {"uu": eu + a * a * ew, "uv": a * b * ew, "uw": a * ew, "vu": a * b * ew, "vv": ev + b * b * ew, "vw": b * ew,
-           "wu": a * ew, "wv": b * ew, "ww": ew}
-    mu = {"uu": (1 + a * a) * one, "uv": a * b * one, "uw": a * one, "vu": a * b * one, "vv": (1 + b * b) * one,
-          "vw": b * one, "wu": a * one, "wv": b * one, "ww": one}
+    s_e = s_h = one
+    if bend_radius is not None:
+        na = 0 if bend_axis == 1 else 1                      # axis along which the radius varies
+        c = (ub, vb)[na]
+        r = c + (bend_radius - c[(len(c) - 1) // 2])
+        shp = (-1, 1) if na == 0 else (1, -1)
+        s_e = np.broadcast_to((bend_radius / r[:-1]).reshape(shp), (nu, nv)).reshape(-1).astype(complex)
+        s_h = np.broadcast_to((bend_radius / (r[:-1] + r[1:]) * 2).reshape(shp), (nu, nv)).reshape(-1).astype(complex)
+    # eps' = J diag(eu, ev, ew) J^T / det J,  mu' = J J^T / det J
+    eps = {"uu": (eu + a * a * ew) / s_e, "uv": a * b * ew / s_e, "uw": a * ew, "vu": a * b * ew / s_e,
+           "vv": (ev + b * b * ew) / s_e, "vw": b * ew, "wu": a * ew, "wv": b * ew, "ww": ew * s_e}
+    mu = {"uu": (1 + a * a) * one / s_h, "uv": a * b * one / s_h, "uw": a * one, "vu": a * b * one / s_h,
+          "vv": (1 + b * b) * one / s_h, "vw": b * one, "wu": a * one, "wv": b * one, "ww": one * s_h}
     du_p, dv_p = np.diff(ub), np.diff(vb)
     du_d = np.concatenate(([du_p[0]], 0.5 * (du_p[1:] + du_p[:-1])))
     dv_d = np.concatenate(([dv_p[0]], 0.5 * (dv_p[1:] + dv_p[:-1])))
-    Duf, Dvf, Dub, Dvb = (D / k0 for D in _diff_ops(nu, nv, du_p, dv_p, du_d, dv_d, pmc_min, None))
+    s_fac = None
+    if any(int(n_) > 0 for n_ in num_pml):
+        pu, pv = int(num_pml[0]), int(num_pml[1])
+        diag = np.stack([eps[k].reshape(nu, nv) for k in ("uu", "vv", "ww")])
+        mdiag = np.stack([mu[k].reshape(nu, nv) for k in ("uu", "vv", "ww")])
+
+        def mean(x):
+            return 1.0 if x.size == 0 else np.mean(x)
+        regions = [np.s_[:, :pu, :], np.s_[:, nu - pu + 1:, :], np.s_[:, :, :pv], np.s_[:, :, nv - pv + 1:]]
+        speed = [1 / np.sqrt(mean(diag[r_]) * mean(mdiag[r_])) for r_ in regions]
+        omega = 2 * np.pi * freq
+        s_fac = (_pml_s("f", omega, du_p, nu, pu, pml_min[0], speed[:2]), _pml_s("b", omega, du_d, nu, pu, pml_min[0], speed[:2]),
+                 _pml_s("f", omega, dv_p, nv, pv, pml_min[1], speed[2:]), _pml_s("b", omega, dv_d, nv, pv, pml_min[1], speed[2:]))
+    Duf, Dvf, Dub, Dvb = (D / k0 for D in _diff_ops(nu, nv, du_p, dv_p, du_d, dv_d, pmc_min, s_fac))
     dg = lambda v: sp.diags(np.asarray(v).reshape(-1))           # noqa: E731
     mask_u, mask_v, mask_w = np.ones((nu, nv)), np.ones((nu, nv)), np.ones((nu, nv))
     if not pmc_min[1]:
@@ -317,8 +344,8 @@ def solve_modes_angled(eps_u: np.ndarray, eps_v: np.ndarray, eps_w: np.ndarray, 
         Ew_p = sum(Ew[q] @ x[q * N:(q + 1) * N] for q in range(4))
         Hw_p = sum(Hw[q] @ x[q * N:(q + 1) * N] for q in range(4))
         # physical frame: F = J^T F'
-        f = dict(Eu=Eu_, Ev=Ev_, Ew=a * Eu_ + b * Ev_ + Ew_p, Hu=Htu / ETA_0, Hv=Htv / ETA_0,
-                 Hw=(a * Htu + b * Htv + Hw_p) / ETA_0)
+        f = dict(Eu=Eu_, Ev=Ev_, Ew=a * Eu_ + b * Ev_ + s_e * Ew_p, Hu=Htu / ETA_0, Hv=Htv / ETA_0,
+                 Hw=(a * Htu + b * Htv + s_h * Hw_p) / ETA_0)
         f = {k: v.reshape(nu, nv) for k, v in f.items()}
         big = f["Eu"] if np.abs(f["Eu"]).max() >= np.abs(f["Ev"]).max() else f["Ev"]
         ph = np.exp(-1j * np.angle(big.reshape(-1)[np.argmax(np.abs(big))]))

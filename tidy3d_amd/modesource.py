@@ -90,8 +90,6 @@ def mode_profile(spec: SolverSpec, box: td.Box, mode_spec, freq: float, symmetry
     angle_theta = float(getattr(mode_spec, "angle_theta", 0.0) or 0.0)
     angle_phi = float(getattr(mode_spec, "angle_phi", 0.0) or 0.0)
     bend_radius = getattr(mode_spec, "bend_radius", None)
-    if angle_theta and (bend_radius is not None or any(int(n) for n in (getattr(mode_spec, "num_pml", (0, 0)) or (0, 0)))):
-        raise Tidy3dNotImplementedError("an angled mode plane together with bend_radius or num_pml is not supported")
     bend_axis = 0
     if bend_radius is not None:
         # ModeSpec.bend_axis counts the plane's axes in x, y, z order (ref mode.py bend_axis); the
@@ -119,7 +117,10 @@ def mode_profile(spec: SolverSpec, box: td.Box, mode_spec, freq: float, symmetry
         phi_uv = angle_phi if (u, v) == tuple(sorted((u, v))) else 0.5 * np.pi - angle_phi
         res = solve_modes_angled(eps_u, eps_v, eps_w, ub, vb, f_solve, angle_theta, phi_uv,
                                  num_modes=int(mode_spec.num_modes), target_neff=mode_spec.target_neff,
-                                 precision=getattr(mode_spec, "precision", "single") or "single", pmc_min=pmc_min)
+                                 precision=getattr(mode_spec, "precision", "single") or "single", pmc_min=pmc_min,
+                                 num_pml=tuple(int(n) for n in (getattr(mode_spec, "num_pml", (0, 0)) or (0, 0))),
+                                 pml_min=tuple(not (lo[i] == 0 and symmetry[a] != 0) for i, a in enumerate((u, v))),
+                                 bend_radius=bend_radius, bend_axis=bend_axis)
     else:
         res = solve_modes(eps_u, eps_v, eps_w, ub, vb, f_solve, num_modes=int(mode_spec.num_modes),
                           target_neff=mode_spec.target_neff,
