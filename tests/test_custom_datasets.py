@@ -79,6 +79,32 @@ def test_custom_medium_raster_interpolation_and_time_step():
     np.testing.assert_allclose(e, [3.0, 3.2, 4.0])                                  # nearest sample; edge value outside
 
 
+def test_custom_medium_with_many_permittivity_conductivity_pairs_is_coarsened_not_refused():
+    """Permittivity and conductivity varying independently: at the fine steps (1 % x 2 %) the pairs would need ~2900 table
+    slots — the raster coarsens both grids (steps squared, at most 3 % / 30 %) until the 1022-entry table holds them."""
+    rng = np.random.default_rng(0)
+    n = 24
+    x = np.linspace(-0.6, 0.6, n)
+    eps = 2.0 + 2.0 * rng.random((n, n, n))                       # 2 .. 4: 70 levels of 1 %
+    sig = 10.0 ** rng.uniform(-3, -2, (n, n, n))                  # a decade: 116 levels of 2 %
+    med = td.CustomMedium(permittivity=_spatial(eps, x, x, x), conductivity=_spatial(sig, x, x, x), interp_method="nearest")
+    sim = td.Simulation(size=(1.2, 1.2, 1.2), grid_spec=td.GridSpec.uniform(dl=0.025), run_time=1e-14, subpixel=False,
+                        structures=[td.Structure(geometry=td.Box(size=(1.0, 1.0, 1.0)), medium=med)],
+                        sources=[td.PointDipole(source_time=PULSE, polarization="Ez")],
+                        boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary()))
+    spec = discretize(sim, n_steps=2).spec
+    assert 200 < len(spec.media) <= 1023
+    eps_of = np.array([m.eps_inf for m in spec.media])
+    sig_of = np.array([m.sigma for m in spec.media])
+    xs, ys, zs = spec.yee_coords(2)
+    X, Y, Z = np.meshgrid(xs, ys, zs, indexing="ij")
+    inside = (np.abs(X) <= 0.5) & (np.abs(Y) <= 0.5) & (np.abs(Z) <= 0.5)
+    e_true, s_true = med.eps_sigma_at(2, X[inside], Y[inside], Z[inside])
+    idx = spec.mat_idx[2].transpose(2, 1, 0)[inside]
+    assert np.max(np.abs(eps_of[idx] / e_true - 1)) < 0.016       # half a 3 % step
+    assert np.max(np.abs(sig_of[idx] / s_true - 1)) < 0.15        # half a 30 % step
+
+
 def test_custom_medium_slab_transmits_like_the_uniform_slab():
     """A CustomMedium with constant data is the plain medium: same Airy transmission (1 % quantisation of eps)."""
     freqs = [1.8e14, 2e14, 2.2e14]
