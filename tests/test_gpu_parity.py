@@ -221,6 +221,45 @@ def test_pipelined_slab_schedule_with_corrections_on_real_streams(hip_lib, bnd, 
         assert np.array_equal(ref_m[k], got_m[k]), k
 
 
+@pytest.mark.parametrize("variant", ["fused", "two_pass"])
+def test_pmc_plus_face_on_a_slab_rank_on_real_streams(hip_lib, variant):
+    """PMC on a PLUS face (x) of a z-slab rank: the mirror images beyond the wall are refreshed plane range by plane range on
+    the stream that owns the planes — boundary planes on the comm stream in front of their H-side corrections, the interior on
+    the main one.  Periodic z, one rank, RCCL exchange with itself == the plain run, bit for bit (the 2-rank gloo run of
+    tests/test_dist_gloo.py has the z wall on the last rank too)."""
+    import tidy3d_amd.schema as tds
+    from cases import DL, PULSE
+    N = (44, 36, 40)
+    size = tuple(n * DL for n in N)
+    sim = tds.Simulation(
+        size=size, grid_spec=tds.GridSpec.uniform(dl=DL), run_time=1e-12, shutoff=0,
+        structures=[tds.Structure(geometry=tds.Sphere(center=(0.5 * size[0] - 0.1, 0, 0.1), radius=0.3), medium=tds.Medium(permittivity=2.5, conductivity=0.01))],
+        sources=[tds.PointDipole(center=(0.5 * size[0] - 0.16, -0.07, 0.01), source_time=PULSE, polarization="Ez"),
+                 tds.PointDipole(center=(-0.1, 0.07, 0.5 * size[2] - 0.08), source_time=PULSE, polarization="Hx")],
+        monitors=[tds.FieldTimeMonitor(center=(0.3, 0.05, 0.2), size=(0.5, 0.2, 0.4), name="t", colocate=False, interval=7)],
+        boundary_spec=tds.BoundarySpec(x=tds.Boundary(minus=tds.PML(num_layers=4), plus=tds.PMCBoundary()), y=tds.Boundary.pml(num_layers=3),
+                                       z=tds.Boundary.periodic()))
+    disc = discretize(sim, n_steps=70)
+    disc.spec.decay_every = 16
+    assert disc.spec.mirror_plus[0] >= 0
+    v = L.VARIANT_FUSED if variant == "fused" else L.VARIANT_ZMARCH
+    with HipEngine(disc.spec, lib=hip_lib, variant=v, axis_shift=0) as e:
+        e.run()
+        ref = [e.get_field(c) for c in range(6)]
+        ref_m = e.results()
+    assert max(float(np.abs(f).max()) for f in ref) > 0
+    with HipEngine(disc.spec, lib=hip_lib, variant=v, force_comm=True) as e:
+        e.comm_init(e.unique_id())
+        e.run(30)
+        e.run(40)
+        got = [e.get_field(c) for c in range(6)]
+        got_m = e.results()
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    for k in ref_m:
+        assert np.array_equal(ref_m[k], got_m[k]), k
+
+
 @pytest.mark.parametrize("rows,zc", [(7, 16), (3, 5), (15, 64)])
 def test_fused_sweep_equals_two_pass_bit_for_bit(hip_lib, rows, zc):
     """The fused single-sweep kernel and the two-pass kernels perform the same IEEE operations

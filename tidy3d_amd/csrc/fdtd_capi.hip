@@ -1502,7 +1502,7 @@ void fill_mirror(FdtdSolver* h, hipStream_t st, int k0 = 0, int k1 = -1) {
   for (int a = 0; a < 3; ++a) {
     const int N = h->mirror_wall[a];
     if (N < 0) continue;
-    if (a == 2 && !(k0 <= N - 2 && N + 2 <= k1)) continue;
+    if (a == 2 && !(k0 <= N - 2 && N + 2 <= k1 && k0 >= 0 && k1 <= g.nz)) continue;
     const long long lines = (a == 0) ? (long long)g.ny * (k1 - k0) : (a == 1 ? (long long)g.nx * (k1 - k0) : g.sxy);
     hipLaunchKernelGGL(mirror_fill_kernel, dim3(nblk(lines)), dim3(256), 0, st, g, h->f, a, N, k0, k1 - k0);
   }
@@ -2705,7 +2705,10 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     int pml_in = 0;
     if (any_pml(h) && 64 * (h->rows_f + 1) <= 512)
       pml_in = (h->pml_fused < 0 ? 7 : h->pml_fused) & pml_in_sweep_mask(h);
-    fill_mirror(h, st);
+    // (periodic z: the wrapped copies in the ghost planes were taken at the end of the last step, in front of this refresh —
+    //  their images beyond an x / y wall are refreshed with the planes they copy; a z-slab rank receives its ghost planes
+    //  refreshed by their owner)
+    fill_mirror(h, st, h->cfg.bc[4] == FDTD_BC_PERIODIC ? -1 : 0, h->cfg.bc[4] == FDTD_BC_PERIODIC ? nz + 1 : nz);
     launch_damp(h, false, 0, nz, st);
     launch_sources(h, false, n, 0, nz, st);
     launch_pml(h, false, 0, nz, st, 7 & ~pml_in);
