@@ -551,3 +551,17 @@ def test_randomised_two_step_self_check_on_the_device(hip_lib):
     bad, taken = fz.run_cases(40, seed=4, lib=hip_lib, quiet=True)
     assert bad == 0
     assert taken >= 30, taken          # (cases whose random features keep single steps are few)
+
+
+def test_randomised_variant_cross_check_on_the_device(hip_lib):
+    """scripts/fuzz_variants.py inside the driver-run suite: 40 seeded random simulations (walls of every kind per face incl. PMC on
+    plus faces, CPML / StablePML / absorber layers, periodic axes; dielectric, lossy, PEC, Lorentz and Drude bodies; dipoles of both
+    kinds; time / DFT / flux monitors; decay checks; runs cut in two; a second x tile now and then) — the fused sweep == the
+    two-pass kernels == (periodic z) a z-slab rank exchanging with itself over RCCL, bit for bit, and <= 2e-5 from the fp64 oracle."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_variants", os.path.join(os.path.dirname(__file__), "..", "scripts", "fuzz_variants.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    bad, far, worst = fz.run_cases(40, seed=7, lib=hip_lib, quiet=True, big=True)
+    assert bad == 0 and far == 0, (bad, far, worst)
