@@ -8,6 +8,7 @@
 #   stats        rocprofv3 --kernel-trace --stats of the bench workloads v0 (step pairs), v0 single steps, v2 (placement probe off)
 #   pmc          HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes) of v0, v0 single steps, v1, va, v2 -> pmc_*_summary.json
 #   shell        shell pairs against single steps inside one engine (scripts/probe_shell.py), 512^3 v2
+#   variants     A/B of the library builds under variants/ (compiler flags), V0 bench line, two interleaved rounds
 #   slab         per-rank proxy of the 8 / 4 / 2-GPU strong-scaling run (scripts/probe_slab.py)
 #   mie          config-4 problem at lambda0 / 20, 30, 40 (scripts/probe_mie_refinement.py)
 #   bench1024    1024^3 on one GPU
@@ -60,6 +61,14 @@ PY
       ;;
     shell)
       timeout 600 python scripts/probe_shell.py 512 v2 40 > $O/probe_shell_v2_512.jsonl 2> $O/probe_shell.err; cut -c1-130 $O/probe_shell_v2_512.jsonl;;
+    variants)    # A/B of builds of the library under variants/ (TIDY3D_AMD_LIBRARY): the V0 bench line of each, two rounds interleaved
+      for ROUND in 1 2; do
+        for F in $R/variants/libfdtd_hip_*.so; do
+          T=$(basename $F .so | sed 's/libfdtd_hip_//')
+          TIDY3D_AMD_LIBRARY=$F timeout 200 python bench.py --steps 100 --warmup 10 --repeats 3 --no-cpu --no-workloads --no-single-steps 2> /dev/null \
+            | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'variant': '$T', 'round': $ROUND, 'ms_per_step': d['ms_per_step'], 'gcells_per_s': d['value']}))" | tee -a $O/variants.jsonl
+        done
+      done;;
     slab)
       timeout 600 python scripts/probe_slab.py --slabs 8,4,2 --modes comm_fused --twostep 0,-1 > $O/slab.jsonl 2> $O/slab.err; cut -c1-200 $O/slab.jsonl;;
     mie)

@@ -540,17 +540,18 @@ def test_two_steps_per_sweep_absorber_layers_and_flux_dft_vs_oracle(hip_lib):
 
 
 def test_randomised_two_step_self_check_on_the_device(hip_lib):
-    """scripts/fuzz_twostep.py inside the driver-run suite: 40 seeded random cases — grid shapes with 1 - 3 x tiles, tile shapes,
-    walls (PEC, PMC, absorber layers, CPML -> shell pairs), media, electric / magnetic dipoles, probes, DFT and flux monitors,
-    decay checks — step pairs == single steps, bit for bit (fields and every record)."""
+    """scripts/fuzz_twostep.py inside the driver-run suite: 60 seeded random cases — grid shapes with 1 - 3 x tiles, tile shapes,
+    walls (PEC, PMC, absorber layers, CPML -> shell pairs), media, dispersive bodies and plane waves across a unit cell (-> z holes
+    in the bulk), electric / magnetic dipoles, probes, DFT and flux monitors, decay checks — step pairs == single steps, bit for
+    bit (fields and every record)."""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location("fuzz_twostep", os.path.join(os.path.dirname(__file__), "..", "scripts", "fuzz_twostep.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
-    bad, taken = fz.run_cases(40, seed=4, lib=hip_lib, quiet=True)
+    bad, taken = fz.run_cases(60, seed=4, lib=hip_lib, quiet=True)
     assert bad == 0
-    assert taken >= 30, taken          # (cases whose random features keep single steps are few)
+    assert taken >= 42, taken          # (cases whose random features keep single steps are few)
 
 
 def test_randomised_variant_cross_check_on_the_device(hip_lib):
