@@ -484,6 +484,8 @@ def permittivity_data(sim, spec: SolverSpec, plan) -> "PermittivityData":
         vals = np.empty(X.shape + (len(freqs),), dtype=complex)
         vals[...] = np.asarray(sim.medium.eps_model(freqs), complex)
         for st in sim.structures:
+            if isinstance(st.medium, td.Medium2D):
+                continue                   # (a sheet has no volume; its volumetric equivalent on the plane's nodes is not reported here)
             inside = st.geometry.inside(X, Y, Z)
             med = st.medium.component(c) if hasattr(st.medium, "component") else st.medium
             if getattr(med, "is_pec", False):

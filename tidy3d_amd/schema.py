@@ -1051,12 +1051,84 @@ class AnisotropicMedium(_AbstractMedium):
 
 @_register
 @dataclass
+class Medium2D(_AbstractMedium):
+    """2-D material on a zero-thickness geometry (ref medium.py:6090): ``ss`` / ``tt`` describe the two in-plane components
+    (in x, y, z order without the normal) as SHEET quantities — permittivity x thickness, sheet conductivity [S].  The front
+    end gives the tangential E nodes on the sheet's plane (snapped to the nearest grid line, ref utils_2d.py:41-45) the
+    volumetric equivalent of ref medium.py:6170-6238: the media either side averaged with the adjacent cell sizes, plus the
+    sheet's contribution divided by the mean of those sizes (discretize.rasterize)."""
+
+    ss: Any = None
+    tt: Any = None
+    name: Optional[str] = None
+    frequency_range: Optional[Tuple[float, float]] = None
+    allow_gain: Optional[bool] = None
+
+    @property
+    def is_pec(self):
+        return False          # (per component; a PEC sheet has both of them PEC, ref medium.py:6137-6146)
+
+    @property
+    def is_pec_sheet(self):
+        return bool(getattr(self.ss, "is_pec", False))
+
+    @property
+    def n_cfl(self):
+        return 1.0            # ref medium.py Medium2D.n_cfl: the sheet does not enter the time step
+
+    def eps_model(self, frequency):
+        """ref medium.py Medium2D.eps_model: the mean of the in-plane components (sheet quantities)."""
+        return np.mean([self.ss.eps_model(frequency), self.tt.eps_model(frequency)], axis=0)
+
+    def pole_residue(self):
+        raise Tidy3dNotImplementedError("Medium2D has no volumetric pole-residue model of its own (see discretize.rasterize)")
+
+
+@_register
+@dataclass
 class Structure(_Model):
     """geometry + medium (ref components/structure.py:147)."""
 
     geometry: Any = None
     medium: Any = None
     name: Optional[str] = None
+
+
+@_register
+@dataclass
+class LumpedResistor(_Model):
+    """Rectangular lumped resistor (ref lumped_element.py:72): a planar box that enters the simulation as a ``Medium2D`` sheet
+    of conductance  L_voltage / (L_lateral R)  (ref :150-168), behind the user's structures."""
+
+    center: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    size: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    resistance: float = 50.0
+    voltage_axis: int = 0
+    name: Optional[str] = None
+    num_grid_cells: Optional[int] = 3
+
+    def __post_init__(self):
+        self.center = tuple(float(c) for c in self.center)
+        self.size = tuple(float(v) for v in self.size)
+        if sum(1 for v in self.size if v == 0.0) != 1:
+            raise SetupError(f"lumped element '{self.name}' must be planar: exactly one zero-size dimension (ref lumped_element.py assert_plane)")
+        if self.size.index(0.0) == int(self.voltage_axis):
+            raise SetupError(f"'voltage_axis' must be in the plane of lumped element '{self.name}' (ref lumped_element.py:134-147)")
+        if not self.resistance > 0:
+            raise ValidationError("resistance must be positive")
+
+    @property
+    def normal_axis(self) -> int:
+        return self.size.index(0.0)
+
+    @property
+    def sheet_conductance(self) -> float:
+        lateral = 3 - int(self.voltage_axis) - self.normal_axis
+        return self.size[int(self.voltage_axis)] / self.size[lateral] / float(self.resistance)
+
+    def to_structure(self) -> "Structure":
+        med = Medium(conductivity=self.sheet_conductance)
+        return Structure(geometry=Box(center=self.center, size=self.size), medium=Medium2D(ss=med, tt=med), name=self.name)
 
 
 # --------------------------------------------------------------------------------------
@@ -2113,11 +2185,13 @@ class Simulation(_Model):
     normalize_index: Optional[int] = 0
     shutoff: float = 1e-5
     subpixel: Any = True
+    lumped_elements: Tuple[Any, ...] = ()
 
     def __post_init__(self):
         self.size = tuple(float(s) for s in self.size)
         self.center = tuple(float(c) for c in self.center)
         self.structures = tuple(self.structures)
+        self.lumped_elements = tuple(self.lumped_elements or ())
         self.sources = tuple(self.sources)
         self.monitors = tuple(self.monitors)
         names = [m.name for m in self.monitors if not isinstance(m, Unsupported)]
@@ -2152,6 +2226,16 @@ class Simulation(_Model):
     def complex_fields(self) -> bool:
         """ref simulation.py:4396-4411: complex time-stepping fields with Bloch boundaries."""
         return any(isinstance(e, BlochBoundary) for pair in self.boundary_spec.to_list for e in pair)
+
+    @property
+    def all_structures(self) -> Tuple[Structure, ...]:
+        """The user's structures followed by the lumped elements as structures (ref simulation.py:1283-1289)."""
+        extra = []
+        for le in self.lumped_elements:
+            if isinstance(le, Unsupported):
+                le.fail()
+            extra.append(le.to_structure())
+        return tuple(self.structures) + tuple(extra)
 
     @property
     def mediums(self):
