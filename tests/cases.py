@@ -329,7 +329,21 @@ def wide_flat(N=(128, 128, 16)):
     return _sim(N, td.BoundarySpec.all_sides(td.PECBoundary()), structures, monitors=monitors)
 
 
+def sheets_box(N=(18, 14, 16)):
+    """Medium2D sheets (ref medium.py:6090) and a LumpedResistor: an ohmic / Drude sheet across a dielectric step and through the
+    x layers, a resistor patch on another plane; CPML on x, PEC / PMC elsewhere."""
+    structures = [td.Structure(geometry=td.Box(center=(0, 0, -0.25), size=(td.inf, td.inf, 0.5)), medium=td.Medium(permittivity=2.25)),
+                  td.Structure(geometry=td.Box(center=(0, 0, 0.0), size=(td.inf, 0.4, 0)),
+                               medium=td.Medium2D(ss=td.Medium(conductivity=2e-3), tt=td.Drude(eps_inf=1.0, coeffs=[(3e14, 2e13)])))]
+    bspec = td.BoundarySpec(x=td.Boundary.pml(num_layers=4), y=td.Boundary(minus=td.PMCBoundary(), plus=td.PECBoundary()),
+                            z=td.Boundary(minus=td.PECBoundary(), plus=td.PECBoundary()))
+    sim = _sim(N, bspec, structures)
+    sim.lumped_elements = (td.LumpedResistor(center=(0.1, 0.1, 0.2), size=(0.3, 0, 0.2), resistance=120.0, voltage_axis=2, name="R"),)
+    return sim
+
+
 CASES = {
+    "sheets_box": sheets_box,
     "bloch_box": bloch_box, "bloch_planewave": bloch_planewave, "bloch_xy_pml_z": bloch_xy_pml_z, "bloch_x_only": bloch_x_only,
     "two_d": two_d, "one_d": one_d, "absorber_mix": absorber_mix, "pmc_plus_mix": pmc_plus_mix, "absorber_odd_rows": absorber_odd_rows,
     "tfsf_box": tfsf_box, "tfsf_angled_box": tfsf_angled_box, "planewave_periodic": planewave_periodic, "au_array": au_array,
