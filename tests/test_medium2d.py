@@ -120,6 +120,17 @@ def test_lumped_resistor_enters_as_a_conductive_sheet():
     assert d["lumped_elements"][0]["type"] == "LumpedResistor"
     back = td.Simulation.from_dict(d)
     assert back.lumped_elements[0].sheet_conductance == pytest.approx(r.sheet_conductance)
-    d["lumped_elements"] = [{"type": "CoaxialLumpedResistor", "resistance": 50.0}]
+    d["lumped_elements"] = [{"type": "LumpedPort", "impedance": 50.0}]
     with pytest.raises(Tidy3dNotImplementedError):
         discretize(td.Simulation.from_dict(d), n_steps=2)
+    # the coaxial form (ref lumped_element.py:170): an annulus of conductance ln(r_out / r_in) / (2 pi R)
+    cx = td.CoaxialLumpedResistor(center=(0, 0, 0), outer_diameter=0.6, inner_diameter=0.2, normal_axis=2, resistance=50.0, name="C")
+    assert cx.sheet_conductance == pytest.approx(np.log(3.0) / (2 * np.pi * 50.0))
+    spec = discretize(sim.copy(lumped_elements=(cx,)), n_steps=2).spec
+    idx = [i for i, m in enumerate(spec.media) if m.name.startswith("medium2d_")]
+    assert len(idx) == 1 and spec.media[idx[0]].sigma == pytest.approx(cx.sheet_conductance / 0.05)
+    on = spec.mat_idx[1][k] == idx[0]
+    xs, ys, _ = spec.yee_coords(1)
+    X, Y = np.meshgrid(xs, ys, indexing="xy")
+    rr = np.hypot(X, Y)
+    assert np.array_equal(on, (rr <= 0.3) & ~(rr <= 0.1)) and on.sum() > 20

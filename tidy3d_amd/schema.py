@@ -1131,6 +1131,40 @@ class LumpedResistor(_Model):
         return Structure(geometry=Box(center=self.center, size=self.size), medium=Medium2D(ss=med, tt=med), name=self.name)
 
 
+@_register
+@dataclass
+class CoaxialLumpedResistor(_Model):
+    """Coaxial lumped resistor (ref lumped_element.py:170): an annular ``Medium2D`` sheet between two concentric circles, of
+    conductance  ln(r_out / r_in) / (2 pi R)  (ref :269-274)."""
+
+    center: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    outer_diameter: float = 1.0
+    inner_diameter: float = 0.5
+    normal_axis: int = 2
+    resistance: float = 50.0
+    name: Optional[str] = None
+    num_grid_cells: Optional[int] = 3
+
+    def __post_init__(self):
+        self.center = tuple(float(c) for c in self.center)
+        if not self.resistance > 0:
+            raise ValidationError("resistance must be positive")
+        if not 0 < self.inner_diameter < self.outer_diameter:
+            raise ValidationError(f"The 'inner_diameter' {self.inner_diameter} of a coaxial lumped element must be less than its "
+                                  f"'outer_diameter' {self.outer_diameter}.")
+
+    @property
+    def sheet_conductance(self) -> float:
+        return float(np.log(self.outer_diameter / self.inner_diameter) / (2 * np.pi * self.resistance))
+
+    def to_structure(self) -> "Structure":
+        med = Medium(conductivity=self.sheet_conductance)
+        disks = [Cylinder(axis=int(self.normal_axis), radius=0.5 * d, length=0.0, center=self.center)
+                 for d in (self.outer_diameter, self.inner_diameter)]
+        return Structure(geometry=ClipOperation(operation="difference", geometry_a=disks[0], geometry_b=disks[1]),
+                         medium=Medium2D(ss=med, tt=med), name=self.name)
+
+
 # --------------------------------------------------------------------------------------
 # grid specification  (ref components/grid/grid_spec.py)
 # --------------------------------------------------------------------------------------
