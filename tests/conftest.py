@@ -11,7 +11,7 @@ if ROOT not in sys.path:
 @pytest.hookimpl(tryfirst=True)
 def pytest_cmdline_main(config):
     """The CPU suite (-m "not gpu") is ~11 min of independent oracle / emulator runs when taken one by one:
-    spread it over 4 workers when pytest-xdist is there and the caller did not choose.  GPU tests stay serial."""
+    spread it over 4 (6 on eight cores and more) workers when pytest-xdist is there and the caller did not choose.  GPU tests stay serial."""
     try:
         import xdist  # noqa: F401
     except ImportError:
@@ -19,9 +19,10 @@ def pytest_cmdline_main(config):
     opt = config.option
     if getattr(opt, "markexpr", "") == "not gpu" and not getattr(opt, "numprocesses", None) \
             and not os.environ.get("PYTEST_XDIST_WORKER") and (os.cpu_count() or 1) >= 4:
-        opt.numprocesses = 4
+        n = 6 if (os.cpu_count() or 1) >= 8 else 4      # (the multi-rank gloo tests start 2 - 4 processes of their own)
+        opt.numprocesses = n
         opt.dist = "load"
-        opt.tx = ["popen"] * 4             # what xdist's own (earlier) hook derives from -n 4
+        opt.tx = ["popen"] * n             # what xdist's own (earlier) hook derives from -n N
     return None
 
 

@@ -207,3 +207,97 @@ def test_custom_field_and_current_sources_on_the_oracle(tmp_path):
     assert np.array_equal(back.sources[0].field_dataset.Hy.values, both.field_dataset.Hy.values)
     assert back.sources[0].field_dataset.Hy.dims == ("x", "y", "z", "f")
     assert td.Simulation.from_file(path).sources[0].field_dataset.Ex.shape == (2, 2, 1, 1)
+
+
+def _const(v, n=2):
+    return _spatial(np.full((n, n, n), v), [-9, 9][:n], [-9, 9][:n], [-9, 9][:n])
+
+
+CUSTOM_DISPERSIVE = [
+    ("lorentz", lambda: td.CustomLorentz(eps_inf=_const(2.0), coeffs=[(_const(1.5), _const(3.2e14), _const(2e13))]),
+     td.Lorentz(eps_inf=2.0, coeffs=[(1.5, 3.2e14, 2e13)])),
+    ("lorentz_overdamped", lambda: td.CustomLorentz(eps_inf=_const(1.5), coeffs=[(_const(0.8), _const(1e14), _const(3e14))]),
+     td.Lorentz(eps_inf=1.5, coeffs=[(0.8, 1e14, 3e14)])),
+    ("drude", lambda: td.CustomDrude(eps_inf=_const(1.2), coeffs=[(_const(4e14), _const(3e13))]), td.Drude(eps_inf=1.2, coeffs=[(4e14, 3e13)])),
+    ("debye", lambda: td.CustomDebye(eps_inf=_const(2.0), coeffs=[(_const(1.0), _const(3e-15))]), td.Debye(eps_inf=2.0, coeffs=[(1.0, 3e-15)])),
+    ("sellmeier", lambda: td.CustomSellmeier(coeffs=[(_const(1.04), _const(0.006)), (_const(0.23), _const(0.02))]),
+     td.Sellmeier(coeffs=[(1.04, 0.006), (0.23, 0.02)])),
+    ("pole_residue", lambda: td.CustomPoleResidue(eps_inf=_const(1.8), poles=[(_const(-1e13 - 2e15j), _const(3e14 + 1e15j))]),
+     td.PoleResidue(eps_inf=1.8, poles=[(-1e13 - 2e15j, 3e14 + 1e15j)])),
+]
+
+
+@pytest.mark.parametrize("name,custom,uniform", CUSTOM_DISPERSIVE, ids=[c[0] for c in CUSTOM_DISPERSIVE])
+def test_custom_dispersive_medium_with_constant_data_is_the_uniform_model(name, custom, uniform):
+    """CustomLorentz / CustomDrude / CustomDebye / CustomSellmeier / CustomPoleResidue (ref medium.py:3275-4720): with constant
+    data the raster holds ONE group whose eps(f) is the uniform model's; the time step follows eps_inf."""
+    from tidy3d_amd.data import medium_eps_table
+    sims = [td.Simulation(size=(1, 1, 1), grid_spec=td.GridSpec.uniform(dl=0.05), run_time=1e-14, subpixel=False,
+                          structures=[td.Structure(geometry=td.Box(size=(0.5, 0.4, 0.6)), medium=m)],
+                          sources=[td.PointDipole(source_time=PULSE, polarization="Ez")],
+                          boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary())) for m in (custom(), uniform)]
+    sa, sb = (discretize(s, n_steps=2).spec for s in sims)
+    assert sa.dt == pytest.approx(sb.dt, rel=1e-12)
+    freqs = np.array([1.5e14, 2e14, 3e14])
+    for c in range(3):
+        ia, ib = sa.mat_idx[c][10, 10, 10], sb.mat_idx[c][10, 10, 10]
+        assert sa.media[ia].name.startswith("custom_disp_") and np.array_equal(sa.mat_idx[c] == ia, sb.mat_idx[c] == ib)
+        for f in freqs:
+            assert medium_eps_table(sa, f)[ia] == pytest.approx(medium_eps_table(sb, f)[ib], rel=1e-9)
+            assert medium_eps_table(sb, f)[ib] == pytest.approx(complex(uniform.eps_model(f)), rel=1e-9)
+    assert sum(m.name.startswith("custom_disp_") for m in sa.media) == 1
+
+
+def test_custom_dispersive_medium_groups_follow_the_data():
+    """Piecewise data: one group per piece; smoothly varying data: groups of 0.5 % (coarser only if the table would overflow)."""
+    x = np.array([-0.3, -0.1, 0.1, 0.3])
+    de = np.array([1.0, 1.0, 2.0, 2.0])[:, None, None] * np.ones((1, 2, 2))
+    med = td.CustomLorentz(eps_inf=_spatial(np.full((4, 2, 2), 2.0), x, [-9, 9], [-9, 9]),
+                           coeffs=[(_spatial(de, x, [-9, 9], [-9, 9]), _spatial(np.full((4, 2, 2), 3.2e14), x, [-9, 9], [-9, 9]),
+                                    _spatial(np.full((4, 2, 2), 2e13), x, [-9, 9], [-9, 9]))], interp_method="nearest")
+    sim = td.Simulation(size=(1, 1, 1), grid_spec=td.GridSpec.uniform(dl=0.05), run_time=1e-14, subpixel=False,
+                        structures=[td.Structure(geometry=td.Box(size=(0.8, 0.4, 0.6)), medium=med)],
+                        sources=[td.PointDipole(source_time=PULSE, polarization="Ez")], boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary()))
+    spec = discretize(sim, n_steps=2).spec
+    groups = [i for i, m in enumerate(spec.media) if m.name.startswith("custom_disp_")]
+    assert len(groups) == 2
+    xs, _, _ = spec.yee_coords(2)
+    row = spec.mat_idx[2][10, 10, :]
+    inside = np.abs(np.asarray(xs)) <= 0.4
+    left, right = row[inside & (np.asarray(xs) < -1e-9)], row[inside & (np.asarray(xs) > 1e-9)]
+    assert len(set(left)) == 1 and len(set(right)) == 1 and left[0] != right[0]
+    c_left = sum(abs(c) for _, c in spec.media[left[0]].poles)
+    c_right = sum(abs(c) for _, c in spec.media[right[0]].poles)
+    assert c_right == pytest.approx(2 * c_left, rel=1e-9)
+    lin = td.CustomLorentz(eps_inf=med.eps_inf, coeffs=med.coeffs, interp_method="linear")
+    spec2 = discretize(sim.copy(structures=[td.Structure(geometry=td.Box(size=(0.8, 0.4, 0.6)), medium=lin)]), n_steps=2).spec
+    n2 = sum(m.name.startswith("custom_disp_") for m in spec2.media)
+    assert 3 <= n2 <= 20                                   # the ramp between x = -0.1 and 0.1 in 0.5 % steps of the residue
+
+
+@pytest.mark.skipif(not os.path.exists(SAMPLE + ".h5"), reason="reference checkout not present")
+def test_reference_sample_file_custom_dispersive_media_carry_their_data():
+    sim = td.Simulation.from_file(SAMPLE + ".h5")
+    kinds = {17: td.CustomDrude, 18: td.CustomLorentz, 19: td.CustomDebye, 20: td.CustomPoleResidue, 21: td.CustomSellmeier}
+    for i, cls in kinds.items():
+        med = sim.structures[i].medium
+        assert isinstance(med, cls), (i, type(med))
+        eps_inf, poles = med.pole_params_at(np.array([0.0]), np.array([0.0]), np.array([0.0]))
+        assert np.isfinite(eps_inf).all() and len(poles) >= 1 and all(np.isfinite(a).all() and np.isfinite(c).all() for a, c in poles)
+        assert med.n_cfl >= 1.0 - 1e-12
+    with pytest.raises(Tidy3dNotImplementedError, match="unstructured"):
+        sim.structures[23].medium.n_cfl
+
+
+def test_custom_drude_slab_transmits_like_the_drude_slab():
+    freqs = [1.8e14, 2e14, 2.2e14]
+
+    def run(medium):
+        sim = td.Simulation(size=(0, 0, 3.0), grid_spec=td.GridSpec.uniform(dl=0.02), run_time=4e-13, shutoff=0,
+                            structures=[td.Structure(geometry=td.Box(center=(0, 0, 0.5), size=(td.inf, td.inf, 0.4)), medium=medium)],
+                            sources=[td.UniformCurrentSource(center=(0, 0, -1.2), size=(td.inf, td.inf, 0), source_time=PULSE, polarization="Ex")],
+                            monitors=[td.FluxMonitor(center=(0, 0, 1.2), size=(td.inf, td.inf, 0), freqs=freqs, name="T")],
+                            boundary_spec=td.BoundarySpec(x=td.Boundary.periodic(), y=td.Boundary.periodic(), z=td.Boundary.pml()))
+        return solve(sim)[0]["T"].flux.values
+    cd = td.CustomDrude(eps_inf=_const(1.0), coeffs=[(_const(3e14), _const(3e13))])
+    np.testing.assert_allclose(run(cd), run(td.Drude(eps_inf=1.0, coeffs=[(3e14, 3e13)])), rtol=1e-9)

@@ -224,7 +224,7 @@ def test_shell_pairs_with_z_holes(kind, emu_lib):
     (their ADE state advances every step) and, while the lists inject, the planes of sources the sweep cannot apply itself (a
     current sheet of hundreds of nodes, the injection plane of a plane wave: TFSF corrections + its 1-D incident grid).  The
     two-step sweep runs once per interval of the remaining planes.  Same bits as single steps, through the pulse and after it."""
-    N = (40, 18, 44)
+    N = (28, 18, 44)
     size = tuple((n - 1e-6) * DL for n in N)
     pulse = td.GaussianPulse(freq0=3e14, fwidth=2.4e14)
     dip = [td.PointDipole(center=(0.1, 0.05, 0.7), source_time=PULSE, polarization="Ex"),

@@ -884,6 +884,178 @@ class CustomMedium(_AbstractMedium):
         return out
 
 
+class _CustomDispersive(_AbstractMedium):
+    """Spatially varying dispersive media (ref medium.py:3275 CustomPoleResidue, :3804 CustomSellmeier, :4110 CustomLorentz,
+    :4455 CustomDrude, :4720 CustomDebye): the model's coefficients as SpatialDataArrays.  ``pole_params_at`` interpolates the
+    coefficients at the Yee nodes (``interp_method``, edge values outside the data) and converts them to (eps_inf, poles) with
+    the formulas of the uniform models, point by point; the rasteriser groups the nodes into table entries
+    (discretize.rasterize).  Datasets are not part of the JSON form: load the simulation from .hdf5."""
+
+    is_custom_dispersive = True
+
+    def _arrays(self):
+        raise NotImplementedError
+
+    def _check(self):
+        from .data import DataArray
+        for a in self._arrays():
+            if isinstance(a, Unsupported):
+                raise Tidy3dNotImplementedError(f"{self.type} on unstructured grids (TriangularGridDataset / TetrahedralGridDataset) "
+                                                "is not supported")
+            if isinstance(a, str):
+                raise SetupError(f"{self.type}: the JSON form carries no data (only the placeholder '{a}'); load the simulation "
+                                 "from its .hdf5 file (Simulation.from_file) or pass DataArrays.")
+            if not isinstance(a, DataArray):
+                raise SetupError(f"{self.type}: coefficients must be SpatialDataArrays")
+
+    def _at(self, arr, x, y, z):
+        return interp_dataset(arr, {"x": x, "y": y, "z": z}, self.interp_method)
+
+    def pole_params_at(self, x, y, z):
+        """-> (eps_inf [points], [(a [points], c [points]), ...])"""
+        raise NotImplementedError
+
+    def pole_residue(self):
+        """Representative medium (the data's mean eps_inf, no poles) — what keys the structure in the material table."""
+        e, _ = self.pole_params_at(*[np.asarray([float(np.mean(np.asarray(self._arrays()[0].coords[d], float)))]) for d in "xyz"])
+        return float(np.real(e[0])), 1e-300, ()
+
+    @property
+    def n_cfl(self):
+        """ref medium.py: sqrt of the smallest eps_inf in the data (1 for Sellmeier)."""
+        self._check()
+        return float(np.sqrt(max(self._eps_inf_min(), 1e-12)))
+
+    def _eps_inf_min(self):
+        return float(np.min(np.real(np.asarray(self.eps_inf.values))))
+
+    def eps_model(self, frequency):
+        raise Tidy3dNotImplementedError(f"{self.type}.eps_model needs a position (use pole_params_at)")
+
+
+@_register
+@dataclass
+class CustomPoleResidue(_CustomDispersive):
+    eps_inf: Any = None
+    poles: Tuple[Tuple[Any, Any], ...] = ()
+    interp_method: str = "nearest"
+    subpixel: bool = False
+    name: Optional[str] = None
+    frequency_range: Optional[Tuple[float, float]] = None
+    allow_gain: Optional[bool] = None
+
+    def _arrays(self):
+        return [self.eps_inf] + [v for p in self.poles for v in p]
+
+    def pole_params_at(self, x, y, z):
+        self._check()
+        return np.real(self._at(self.eps_inf, x, y, z)), [(self._at(a, x, y, z) + 0j, self._at(c, x, y, z) + 0j) for a, c in self.poles]
+
+
+@_register
+@dataclass
+class CustomLorentz(_CustomDispersive):
+    eps_inf: Any = None
+    coeffs: Tuple[Tuple[Any, Any, Any], ...] = ()
+    interp_method: str = "nearest"
+    subpixel: bool = False
+    name: Optional[str] = None
+    frequency_range: Optional[Tuple[float, float]] = None
+    allow_gain: Optional[bool] = None
+
+    def _arrays(self):
+        return [self.eps_inf] + [v for p in self.coeffs for v in p]
+
+    def pole_params_at(self, x, y, z):
+        self._check()
+        poles = []
+        for de, f, delta in self.coeffs:            # the point-wise form of Lorentz.pole_residue (ref medium.py:4021-4047)
+            de_, w, d = (np.real(self._at(v, x, y, z)) for v in (de, f, delta))
+            w, d = 2 * np.pi * w, 2 * np.pi * d
+            over = d * d > w * w
+            r = np.sqrt(np.abs(d * d - w * w))
+            r_safe = np.where(r == 0, 1.0, r)
+            c_over = de_ * w ** 2 / 4 / r_safe
+            poles.append((np.where(over, -d + r, -d - 1j * r), np.where(over, c_over + 0j, 1j * de_ * w ** 2 / 2 / r_safe)))
+            poles.append((np.where(over, -d - r, 0.0) + 0j, np.where(over, -c_over, 0.0) + 0j))
+        return np.real(self._at(self.eps_inf, x, y, z)), poles
+
+
+@_register
+@dataclass
+class CustomDrude(_CustomDispersive):
+    eps_inf: Any = None
+    coeffs: Tuple[Tuple[Any, Any], ...] = ()
+    interp_method: str = "nearest"
+    subpixel: bool = False
+    name: Optional[str] = None
+    frequency_range: Optional[Tuple[float, float]] = None
+    allow_gain: Optional[bool] = None
+
+    def _arrays(self):
+        return [self.eps_inf] + [v for p in self.coeffs for v in p]
+
+    def pole_params_at(self, x, y, z):
+        self._check()
+        poles = []
+        for f, delta in self.coeffs:                # Drude.pole_residue point by point (ref medium.py:4384-4409)
+            w, d = (2 * np.pi * np.real(self._at(v, x, y, z)) for v in (f, delta))
+            c0 = (w ** 2) / 2 / d + 0j
+            poles.append((np.zeros_like(c0), c0))
+            poles.append((-d + 0j, -c0))
+        return np.real(self._at(self.eps_inf, x, y, z)), poles
+
+
+@_register
+@dataclass
+class CustomDebye(_CustomDispersive):
+    eps_inf: Any = None
+    coeffs: Tuple[Tuple[Any, Any], ...] = ()
+    interp_method: str = "nearest"
+    subpixel: bool = False
+    name: Optional[str] = None
+    frequency_range: Optional[Tuple[float, float]] = None
+    allow_gain: Optional[bool] = None
+
+    def _arrays(self):
+        return [self.eps_inf] + [v for p in self.coeffs for v in p]
+
+    def pole_params_at(self, x, y, z):
+        self._check()
+        poles = []
+        for de, tau in self.coeffs:                 # Debye.pole_residue point by point (ref medium.py:4652-4666)
+            de_, tau_ = (np.real(self._at(v, x, y, z)) for v in (de, tau))
+            a = -2 * np.pi / tau_ + 0j
+            poles.append((a, -0.5 * de_ * a))
+        return np.real(self._at(self.eps_inf, x, y, z)), poles
+
+
+@_register
+@dataclass
+class CustomSellmeier(_CustomDispersive):
+    coeffs: Tuple[Tuple[Any, Any], ...] = ()
+    interp_method: str = "nearest"
+    subpixel: bool = False
+    name: Optional[str] = None
+    frequency_range: Optional[Tuple[float, float]] = None
+    allow_gain: Optional[bool] = None
+
+    def _arrays(self):
+        return [v for p in self.coeffs for v in p]
+
+    def _eps_inf_min(self):
+        return 1.0
+
+    def pole_params_at(self, x, y, z):
+        self._check()
+        poles = []
+        for B, C in self.coeffs:                    # Sellmeier.pole_residue point by point (ref medium.py:3677-3686)
+            B_, C_ = (np.real(self._at(v, x, y, z)) for v in (B, C))
+            beta = 2 * np.pi * C_0 / np.sqrt(C_)
+            poles.append((1j * beta, -0.5j * beta * B_))
+        return np.ones(np.broadcast(x, y, z).shape), poles
+
+
 @_register
 @dataclass
 class PECMedium(_AbstractMedium):
