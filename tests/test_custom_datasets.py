@@ -301,3 +301,31 @@ def test_custom_drude_slab_transmits_like_the_drude_slab():
         return solve(sim)[0]["T"].flux.values
     cd = td.CustomDrude(eps_inf=_const(1.0), coeffs=[(_const(3e14), _const(3e13))])
     np.testing.assert_allclose(run(cd), run(td.Drude(eps_inf=1.0, coeffs=[(3e14, 3e13)])), rtol=1e-9)
+
+
+def test_autogrid_sizes_its_steps_with_the_largest_permittivity_of_the_data():
+    """ref mesher.py:509 + medium.py:1324-1336: inside a spatially varying medium AutoGrid takes the data value of largest modulus
+    (CustomMedium and the custom dispersive media alike), not the mean."""
+    from tidy3d_amd import discretize as D
+    x = np.linspace(-0.5, 0.5, 5)
+    eps = np.array([2.0, 2.0, 4.0, 9.0, 2.0])[:, None, None] * np.ones((1, 2, 2))
+    cm = td.CustomMedium(permittivity=_spatial(eps, x, [-9, 9], [-9, 9]))
+    assert cm.eps_diagonal(2e14)[0] == pytest.approx(9.0)
+    cl = td.CustomLorentz(eps_inf=_spatial(eps, x, [-9, 9], [-9, 9]),
+                          coeffs=[(_spatial(0 * eps + 1.0, x, [-9, 9], [-9, 9]), _spatial(0 * eps + 6e14, x, [-9, 9], [-9, 9]),
+                                   _spatial(0 * eps + 1e13, x, [-9, 9], [-9, 9]))])
+    want = td.Lorentz(eps_inf=9.0, coeffs=[(1.0, 6e14, 1e13)]).eps_model(2e14)
+    assert cl.eps_diagonal(2e14)[0] == pytest.approx(complex(want), rel=1e-9)
+    assert cl.eps_model(2e14) == pytest.approx(np.mean([complex(td.Lorentz(eps_inf=e, coeffs=[(1.0, 6e14, 1e13)]).eps_model(2e14))
+                                                        for e in (2.0, 2.0, 4.0, 9.0, 2.0)]), rel=1e-9)
+
+    def steps(medium):
+        sim = td.Simulation(size=(3, 1, 1), grid_spec=td.GridSpec.auto(min_steps_per_wvl=12, wavelength=1.5), run_time=1e-14,
+                            structures=[td.Structure(geometry=td.Box(size=(1.0, td.inf, td.inf)), medium=medium)],
+                            sources=[td.PointDipole(center=(1.2, 0, 0), source_time=PULSE, polarization="Ez")],
+                            boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary()))
+        b = np.asarray(D.make_boundaries(sim)[0])
+        inside = (b[:-1] >= -0.5 - 1e-9) & (b[1:] <= 0.5 + 1e-9)
+        return np.diff(b)[inside]
+    np.testing.assert_allclose(steps(cm), steps(td.Medium(permittivity=9.0)), rtol=1e-12)
+    assert steps(cm).max() <= 1.5 / 3.0 / 12 * (1 + 1e-9)

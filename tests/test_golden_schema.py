@@ -147,8 +147,10 @@ def test_full_reference_fixture_parses():
     assert {"UniformCurrentSource", "PointDipole", "ModeSource", "PlaneWave", "TFSF"} <= kinds
     assert {"GaussianBeam", "AstigmaticGaussianBeam", "CustomFieldSource", "CustomCurrentSource"} <= kinds
     assert not any(isinstance(s, td.Unsupported) for s in sim.sources)
-    # still placeholders: custom dispersive media, Medium2D (raise only when used)
-    assert any(isinstance(st.medium, td.Unsupported) for st in sim.structures)
+    # (round 4: Medium2D and the custom dispersive media parse into their own classes; nothing in the sample's structures is left
+    #  as a placeholder)
+    assert not any(isinstance(st.medium, td.Unsupported) for st in sim.structures)
+    assert {"Medium2D", "CustomDrude", "CustomLorentz", "CustomDebye", "CustomPoleResidue", "CustomSellmeier"} <= {st.medium.type for st in sim.structures}
     from tidy3d_amd.exceptions import SetupError, Tidy3dNotImplementedError
     with pytest.raises(SetupError, match="hdf5"):
         D.make_boundaries(sim)        # the AutoGrid axis asks the TriangleMesh for its bounds: no data in JSON
@@ -156,7 +158,7 @@ def test_full_reference_fixture_parses():
     full = td.Simulation.from_file(h5)          # the same simulation with its datasets
     assert isinstance(full.structures[8].geometry, td.TriangleMesh) and full.structures[8].geometry.bounds[0][0] == -1.5
     with pytest.raises(Tidy3dNotImplementedError):
-        D.discretize(full, n_steps=2)           # Medium2D, custom dispersive media: named when used
+        D.discretize(full, n_steps=2)           # data on unstructured grids (structures 22 - 27): named when used
 
 
 GEO = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "geometry_golden.json")))

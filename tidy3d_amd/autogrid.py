@@ -51,8 +51,12 @@ class _Item:
 def _index_for_step(medium, freq: float, axis: int) -> float:
     """Refractive index that sets the step inside a medium (ref mesher.py:495-517): PEC (and a PEC
     component along the axis) count as vacuum, otherwise the largest |n| or |k| over the diagonal."""
-    if getattr(medium, "is_pec", False):
+    if getattr(medium, "is_pec", False) or isinstance(medium, td.Medium2D):      # (2-D sheets never set the step, ref mesher.py:499-506)
         return 1.0
+    if hasattr(medium, "eps_diagonal"):       # spatially varying media: the value of largest modulus over the data (ref medium.py:1324-1336)
+        eps = np.asarray(medium.eps_diagonal(freq), complex)
+        nk = np.sqrt(eps)
+        return float(max(np.max(np.abs(nk.real)), np.max(np.abs(nk.imag))))
     if isinstance(medium, td.AnisotropicMedium):
         if getattr(medium.component(axis), "is_pec", False):
             return 1.0

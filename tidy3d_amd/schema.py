@@ -875,6 +875,18 @@ class CustomMedium(_AbstractMedium):
         eps, sig, _ = self.pole_residue()
         return eps + 0j * np.asarray(frequency, float)
 
+    def eps_diagonal(self, frequency):
+        """ref medium.py:1324-1336: per component the data value of largest modulus (what AutoGrid sizes its steps with)."""
+        w = 2 * np.pi * float(np.atleast_1d(frequency)[0])
+        out = []
+        for c in range(3):
+            arr, sig, freq = self._component_arrays(c)
+            e = np.asarray(arr.values, complex).ravel()
+            if freq is None and sig is not None:
+                e = e + 1j * np.asarray(sig.values, float).ravel() / (w * EPSILON_0)
+            out.append(e[np.argmax(np.abs(e))])
+        return tuple(out)
+
     def dict(self):
         out = {"type": "CustomMedium", "interp_method": self.interp_method, "subpixel": self.subpixel,
                "name": self.name, "frequency_range": self.frequency_range, "permittivity": self.permittivity,
@@ -929,8 +941,30 @@ class _CustomDispersive(_AbstractMedium):
     def _eps_inf_min(self):
         return float(np.min(np.real(np.asarray(self.eps_inf.values))))
 
+    def _eps_on_data(self, frequency: float) -> np.ndarray:
+        """eps(frequency) at every point of the coefficients' own grid"""
+        self._check()
+        first = self._arrays()[0]
+        X, Y, Z = np.meshgrid(*[np.asarray(first.coords[d], float) for d in "xyz"], indexing="ij")
+        eps_inf, poles = self.pole_params_at(X.ravel(), Y.ravel(), Z.ravel())
+        w = 2 * np.pi * float(frequency)
+        eps = np.asarray(eps_inf, complex).copy()
+        for a, c in poles:
+            ok = c != 0
+            eps[ok] -= (c[ok] / (1j * w + a[ok]) + np.conj(c[ok]) / (1j * w + np.conj(a[ok])))
+        return eps
+
     def eps_model(self, frequency):
-        raise Tidy3dNotImplementedError(f"{self.type}.eps_model needs a position (use pole_params_at)")
+        """ref medium.py:1315-1322: the spatial mean."""
+        f = np.atleast_1d(np.asarray(frequency, float))
+        out = np.array([np.mean(self._eps_on_data(v)) for v in f])
+        return out if np.ndim(frequency) else complex(out[0])
+
+    def eps_diagonal(self, frequency):
+        """ref medium.py:1324-1336: the value of largest modulus over the data (what AutoGrid sizes its steps with)."""
+        e = self._eps_on_data(float(np.atleast_1d(frequency)[0]))
+        v = e[np.argmax(np.abs(e))]
+        return (v, v, v)
 
 
 @_register
