@@ -7,7 +7,8 @@ walls too), time / DFT / flux monitors, decay checks, runs cut in two —
     python scripts/fuzz_variants.py [n_cases] [seed]
 Also run by the suites (tests/test_fuzz_variants.py on the CPU emulator, tests/test_gpu_production_path.py on the device).
 Found in round 4: the fused step of a grid with a PMC plus wall across a periodic z took the image cells of the wrapped ghost
-planes from before their refresh."""
+planes from before their refresh; and, on the device only, a race of the two-pass z-slab schedule (a monitor record on the main
+stream against the comm stream's update of the slab's top plane, tests/test_gpu_parity.py)."""
 import os
 import sys
 

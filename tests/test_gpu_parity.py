@@ -221,6 +221,45 @@ def test_pipelined_slab_schedule_with_corrections_on_real_streams(hip_lib, bnd, 
         assert np.array_equal(ref_m[k], got_m[k]), k
 
 
+def test_two_pass_slab_rank_records_before_the_comm_stream_moves_on(hip_lib):
+    """A race scripts/fuzz_variants.py found on the device (round 4; the CPU emulator runs the streams in issue order and cannot
+    see it): in the two-pass z-slab schedule the comm stream advanced H of the slab's top plane — H-side corrections and
+    update, waiting for the E interior of the LAST step only — while the main stream's monitor record of the new step was still
+    reading H^{n-1/2} of that plane.  A volume time monitor that reaches the top plane came back with that plane's H
+    half-sample from the wrong side of the update in one run out of a few.  The record now posts an event the comm stream waits
+    for.  Periodic box (x periodic and not a multiple of four cells: the two-pass kernels), H and E dipoles, records every 4th
+    step, six runs == the plain run, bit for bit."""
+    import tidy3d_amd.schema as tds
+    from cases import DL, PULSE
+    N = (30, 35, 18)
+    size = tuple(n * DL for n in N)
+    per = tds.Boundary.periodic()
+    sim = tds.Simulation(
+        size=size, grid_spec=tds.GridSpec.uniform(dl=DL), run_time=1e-12, shutoff=0,
+        structures=[tds.Structure(geometry=tds.Sphere(center=(0.2, 0.1, 0.1), radius=0.3), medium=tds.Drude(eps_inf=1.5, coeffs=[(6e14, 5e13)]))],
+        sources=[tds.PointDipole(center=(0.1, -0.2, 0.3), source_time=PULSE, polarization="Hx"),
+                 tds.PointDipole(center=(-0.3, 0.2, -0.1), source_time=PULSE, polarization="Ey")],
+        monitors=[tds.FieldTimeMonitor(center=(0.4, -0.5, 0.25), size=(0.7, 0.6, 0.5), name="vol", interval=4, colocate=False),
+                  tds.FieldTimeMonitor(center=(0, 0, -0.3), size=(0, 0, 0), name="probe", interval=3, colocate=False)],
+        boundary_spec=tds.BoundarySpec(x=per, y=tds.Boundary(minus=tds.PECBoundary(), plus=tds.PECBoundary()), z=per))
+    disc = discretize(sim, n_steps=41)
+    vol = [m for m in disc.spec.monitors if m.name == "vol"][0]
+    assert vol.hi[2] == disc.spec.shape[2]                      # the monitor reaches the slab's top plane
+    with HipEngine(disc.spec, lib=hip_lib, variant=L.VARIANT_ZMARCH, axis_shift=0) as e:
+        e.run()
+        ref_m = e.results()
+    assert float(np.abs(ref_m["vol"]).max()) > 0
+    for rep in range(6):
+        with HipEngine(disc.spec, lib=hip_lib, variant=L.VARIANT_ZMARCH, force_comm=True) as e:
+            assert e.variant == L.VARIANT_ZMARCH
+            e.comm_init(e.unique_id())
+            e.run(24)
+            e.run(17)
+            got_m = e.results()
+        for k in ref_m:
+            assert np.array_equal(ref_m[k], got_m[k]), (rep, k)
+
+
 @pytest.mark.parametrize("variant", ["fused", "two_pass"])
 def test_pmc_plus_face_on_a_slab_rank_on_real_streams(hip_lib, variant):
     """PMC on a PLUS face (x) of a z-slab rank: the mirror images beyond the wall are refreshed plane range by plane range on

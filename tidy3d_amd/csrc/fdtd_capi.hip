@@ -230,6 +230,7 @@ struct FdtdSolver {
   long long shell_pairs = 0;
   int f2_off_reason = 0;              // why the last fdtd_run took no step pairs (FDTD_F2_OFF_*), 0 = it did / could
   hipEvent_t ev_shell_a = nullptr, ev_shell_b = nullptr;
+  hipEvent_t ev_rec = nullptr;        // z-slab ranks: a monitor record on the main stream done (the comm stream's next boundary work waits for it)
   float* seam_buf = nullptr;          // intermediate values on the seams between x tiles
   float* inj_val = nullptr;           // source terms applied between the two steps
   float* cap_val = nullptr;           // samples of the middle step (small time monitors)
@@ -2026,6 +2027,7 @@ void fdtd_destroy(FdtdSolver* h) {
   if (h->ev_e_int) hipEventDestroy(h->ev_e_int);
   if (h->ev_e_bnd) hipEventDestroy(h->ev_e_bnd);
   if (h->ev_shell_a) hipEventDestroy(h->ev_shell_a);
+  if (h->ev_rec) hipEventDestroy(h->ev_rec);
   if (h->ev_shell_b) hipEventDestroy(h->ev_shell_b);
   if (h->stream) hipStreamDestroy(h->stream);
   if (h->comm_stream && !h->streams_shared) hipStreamDestroy(h->comm_stream);
@@ -2929,6 +2931,15 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     // (with H-side sources the monitors of a pair still take E^n and H^{n-1/2} here: those sources change H^{n-1/2} before the
     //  sweep, and pair_record reads the set afterwards)
     if (rec) record_monitors(h, n, false, st, (pair && h->src_h_nodes == 0) ? &f2_plan : nullptr);
+    if (rec && multi) {
+      // The record reads H^{n-1/2} of the top plane, which the comm stream is about to advance (its H-side corrections and
+      // update of that plane wait for the E interior of the LAST step only): it must let the record finish first.  Found by
+      // scripts/fuzz_variants.py on the device (round 4): a volume time monitor reaching the slab's top plane came back with
+      // that plane's H half-sample taken during / after the update, in one run out of a few.
+      if (!h->ev_rec) HIPCHK(h, hipEventCreateWithFlags(&h->ev_rec, hipEventDisableTiming));
+      HIPCHK(h, hipEventRecord(h->ev_rec, st));
+      HIPCHK(h, hipStreamWaitEvent(cs, h->ev_rec, 0));
+    }
     if (fused_multi) {
       if (!primed && prime(n)) return -1;
       // ---- slab pair: steps n and n + 1 of a z-slab rank -----------------------------------------------------------------
