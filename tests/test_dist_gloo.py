@@ -111,7 +111,7 @@ def test_step_pairs_on_slab_ranks(world, case, twostep, emu_lib, tmp_path):
     with dipoles of both kinds next to the cuts, materials through them, monitors whose records end pairs."""
     import cases
     out = str(tmp_path / "dist.npz")
-    _launch(world, case, 46, out, 29641 + SLAB_PAIR_CASES.index((world, case, twostep)), twostep=twostep)
+    _launch(world, case, 46, out, 29701 + SLAB_PAIR_CASES.index((world, case, twostep)), twostep=twostep)
     got = np.load(out)
     assert (got["pairs"] >= 8).all(), got["pairs"]
     disc = discretize(getattr(cases, case)(), n_steps=46)
@@ -134,7 +134,7 @@ def test_placement_probe_on_slabs_changes_nothing(world, case, emu_lib, tmp_path
     """Every rank samples alternative placements of its slab's field arrays before the first step (forced on for
     these small grids): same bits as the single-slab run."""
     out = str(tmp_path / "dist.npz")
-    _launch(world, case, 30, out, 29561 + world, placement_tries=102)
+    _launch(world, case, 30, out, 29721 + world, placement_tries=102)
     got = np.load(out)
     disc = discretize(CASES[case](), n_steps=30)
     disc.spec.decay_every = 10
@@ -187,7 +187,7 @@ def test_slab_axis_renaming_matches_single_slab(shift, world, case, emu_lib, tmp
     assert best_slab_shift((1024, 1024, 256), 8) == 1 and best_slab_shift((512, 512, 512), 8) == 0
     assert best_slab_shift((60, 60, 400), 2) == 0              # already along the longest axis
     out = str(tmp_path / "dist.npz")
-    _launch(world, case, 30, out, 29561 + shift, slab_shift=shift)
+    _launch(world, case, 30, out, 29731 + shift, slab_shift=shift)
     got = np.load(out)
     disc = discretize(CASES[case](), n_steps=30)
     disc.spec.decay_every = 10

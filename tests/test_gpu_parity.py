@@ -273,7 +273,10 @@ def test_pmc_plus_face_on_a_slab_rank_on_real_streams(hip_lib, variant):
     sim = tds.Simulation(
         size=size, grid_spec=tds.GridSpec.uniform(dl=DL), run_time=1e-12, shutoff=0,
         structures=[tds.Structure(geometry=tds.Sphere(center=(0.5 * size[0] - 0.1, 0, 0.1), radius=0.3), medium=tds.Medium(permittivity=2.5, conductivity=0.01))],
-        sources=[tds.PointDipole(center=(0.5 * size[0] - 0.16, -0.07, 0.01), source_time=PULSE, polarization="Ez"),
+        # (a dipole within two cells of the wall, in the slab's top planes: its mirror image lies beyond the stored image cells, so
+        #  refreshing them is more than a no-op there — the order of refresh and update is visible in the bits)
+        sources=[tds.PointDipole(center=(0.5 * size[0] - 0.06, -0.07, 0.5 * size[2] - 0.03), source_time=PULSE, polarization="Ez"),
+                 tds.PointDipole(center=(0.5 * size[0] - 0.16, 0.07, 0.01), source_time=PULSE, polarization="Ey"),
                  tds.PointDipole(center=(-0.1, 0.07, 0.5 * size[2] - 0.08), source_time=PULSE, polarization="Hx")],
         monitors=[tds.FieldTimeMonitor(center=(0.3, 0.05, 0.2), size=(0.5, 0.2, 0.4), name="t", colocate=False, interval=7)],
         boundary_spec=tds.BoundarySpec(x=tds.Boundary(minus=tds.PML(num_layers=4), plus=tds.PMCBoundary()), y=tds.Boundary.pml(num_layers=3),
@@ -287,16 +290,18 @@ def test_pmc_plus_face_on_a_slab_rank_on_real_streams(hip_lib, variant):
         ref = [e.get_field(c) for c in range(6)]
         ref_m = e.results()
     assert max(float(np.abs(f).max()) for f in ref) > 0
-    with HipEngine(disc.spec, lib=hip_lib, variant=v, force_comm=True) as e:
-        e.comm_init(e.unique_id())
-        e.run(30)
-        e.run(40)
-        got = [e.get_field(c) for c in range(6)]
-        got_m = e.results()
-    for a, b in zip(ref, got):
-        assert np.array_equal(a, b)
-    for k in ref_m:
-        assert np.array_equal(ref_m[k], got_m[k]), k
+    N_wall = disc.spec.mirror_plus[0]
+    for rep in range(4):                        # (a race shows in one run out of a few)
+        with HipEngine(disc.spec, lib=hip_lib, variant=v, force_comm=True) as e:
+            e.comm_init(e.unique_id())
+            e.run(30)
+            e.run(40)
+            got = [e.get_field(c) for c in range(6)]
+            got_m = e.results()
+        for c, (a, b) in enumerate(zip(ref, got)):
+            assert np.array_equal(a[:, :, :N_wall], b[:, :, :N_wall]), (rep, c)      # (inside the wall: the images are refreshed before they are read)
+        for k in ref_m:
+            assert np.array_equal(ref_m[k], got_m[k]), (rep, k)
 
 
 @pytest.mark.parametrize("rows,zc", [(7, 16), (3, 5), (15, 64)])

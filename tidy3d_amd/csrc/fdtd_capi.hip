@@ -3096,9 +3096,20 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     } else {
     // ---------------- H phase ----------------
     const int h_top = (multi && nb_hi) ? nz - 1 : nz;      // planes [0, h_top) on st, [h_top, nz) on cs
+    const bool mirrors = h->mirror_wall[0] >= 0 || h->mirror_wall[1] >= 0 || h->mirror_wall[2] >= 0;
+    if (multi && mirrors) {
+      // PMC plus walls on a z-slab rank: the images of ALL planes are refreshed on the main stream before either stream goes on —
+      // its H pass differentiates E of the top plane (image columns included: the update of an image cell feeds the wall's own
+      // unknowns in the same step), so the comm stream must not refresh that plane beside it (a race the device showed in one
+      // visit out of three, tests/test_gpu_parity.py)
+      HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
+      fill_mirror(h, st, 0, nz);
+      if (!h->ev_rec) HIPCHK(h, hipEventCreateWithFlags(&h->ev_rec, hipEventDisableTiming));
+      HIPCHK(h, hipEventRecord(h->ev_rec, st));
+      HIPCHK(h, hipStreamWaitEvent(cs, h->ev_rec, 0));
+    }
     if (multi && nb_hi) {
       HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
-      fill_mirror(h, cs, h_top, nz);
       launch_damp(h, false, h_top, nz, cs);          // absorber layers damp H^{n-1/2} before anything is added
       launch_sources(h, false, n, h_top, nz, cs);    // H-side corrections first (they only read E^n),
       launch_pml(h, false, h_top, nz, cs);           // in the summation order of the fused sweep
@@ -3106,7 +3117,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
     }
     if (multi) HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
-    fill_mirror(h, st, 0, h_top);
+    if (!multi) fill_mirror(h, st, 0, nz);
     launch_damp(h, false, 0, h_top, st);
     launch_sources(h, false, n, 0, h_top, st);
     launch_pml(h, false, 0, h_top, st);
