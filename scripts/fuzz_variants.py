@@ -98,12 +98,14 @@ def case(rng, big=False):
     return disc, steps, periodic[2], desc
 
 
-def run(disc, steps, split, variant, lib, comm=False, rows=0, zc=0):
+def run(disc, steps, split, variant, lib, comm=False, rows=0, zc=0, opts=None):
     with HipEngine(disc.spec, lib=lib, variant=variant, axis_shift=0, force_comm=comm, z_chunk=zc) as e:
         if comm:
             e.comm_init(e.unique_id())
         if rows:
             e.set_option(L.OPT_ROWS, rows)
+        for k, v in (opts or {}).items():
+            e.set_option(k, v)
         for r in (split, steps - split):
             if r > 0:
                 e.run(r)
@@ -119,6 +121,21 @@ def inside(disc):
     return tuple(sl)
 
 
+def draw(rng, big):
+    """everything random about one case (scripts/repro_fuzz_variants.py replays the same draws)"""
+    while True:
+        try:
+            disc, steps, per_z, desc = case(rng, big)
+            break
+        except (Tidy3dNotImplementedError, SetupError):       # a combination the front end refuses: draw again
+            continue
+    split = int(rng.integers(0, steps))
+    rows, zc = int(rng.choice([0, 3, 4, 7])), int(rng.choice([0, 2, 5, 16]))
+    so = {L.OPT_BND_PLANES: int(rng.choice([0, 1, 3])), L.OPT_PML_FUSED: int(rng.choice([-1, 7]))}
+    po = {L.OPT_TWOSTEP: int(rng.integers(4, 17)) + 64 * int(rng.integers(2, 12))}
+    return disc, steps, per_z, desc, split, rows, zc, so, po
+
+
 def run_cases(n_cases, seed=1, lib=None, quiet=False, oracle=True, big=False):
     """-> (cases whose variants differ, cases beyond 2e-5 from the oracle, worst oracle error)"""
     from oracle.fdtd_numpy import OracleFdtd
@@ -126,19 +143,17 @@ def run_cases(n_cases, seed=1, lib=None, quiet=False, oracle=True, big=False):
     bad = far = 0
     worst = 0.0
     for q in range(n_cases):
-        while True:
-            try:
-                disc, steps, per_z, desc = case(rng, big)
-                break
-            except (Tidy3dNotImplementedError, SetupError):       # a combination the front end refuses: draw again
-                continue
-        split = int(rng.integers(0, steps))
-        rows, zc = int(rng.choice([0, 3, 4, 7])), int(rng.choice([0, 2, 5, 16]))
+        disc, steps, per_z, desc, split, rows, zc, so, po = draw(rng, big)
         sl = inside(disc)
         ref_f, ref_m = run(disc, steps, split, L.VARIANT_FUSED, lib, rows=rows, zc=zc)
         outs = {"two_pass": run(disc, steps, split, L.VARIANT_ZMARCH, lib, zc=zc)}
+        # the three-launch CPML step of large grids (edge tiles on the second stream beside the interior launch), forced
+        outs["fused_split"] = run(disc, steps, split, L.VARIANT_FUSED, lib, rows=3, zc=zc, opts={L.OPT_PML_SPLIT: 1})
         if per_z and disc.spec.shape[2] >= 8:
-            outs["fused_slab"] = run(disc, steps, split, L.VARIANT_FUSED, lib, comm=True)
+            # a z-slab rank exchanging with itself: boundary chunks of random thickness, CPML as slab kernels or inside the sweeps,
+            # step pairs on request (taken where the rank has nothing that keeps single steps)
+            outs["fused_slab"] = run(disc, steps, split, L.VARIANT_FUSED, lib, comm=True, opts=so)
+            outs["fused_slab_pairs"] = run(disc, steps, split, L.VARIANT_FUSED, lib, comm=True, opts=po)
             outs["two_pass_slab"] = run(disc, steps, split, L.VARIANT_ZMARCH, lib, comm=True)
         diff = [k for k, (f, m) in outs.items()
                 if not (all(np.array_equal(a[sl], b[sl]) for a, b in zip(ref_f, f)) and all(np.array_equal(ref_m[n], m[n]) for n in ref_m))]

@@ -9,29 +9,25 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import fuzz_variants as F  # noqa: E402
 from tidy3d_amd import lib as L  # noqa: E402
-from tidy3d_amd.exceptions import SetupError, Tidy3dNotImplementedError  # noqa: E402
 
 target, seed = int(sys.argv[1]), int(sys.argv[2])
 repeats = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 big = bool(int(os.environ.get("FUZZ_BIG", "0")))
 rng = np.random.default_rng(seed)
 for q in range(target + 1):
-    while True:
-        try:
-            disc, steps, per_z, desc = F.case(rng, big)
-            break
-        except (Tidy3dNotImplementedError, SetupError):
-            continue
-    split = int(rng.integers(0, steps))
-    rows, zc = int(rng.choice([0, 3, 4, 7])), int(rng.choice([0, 2, 5, 16]))
+    disc, steps, per_z, desc, split, rows, zc, so, po = F.draw(rng, big)
 print(desc, "split", split, "rows", rows, "zc", zc, flush=True)
 for m in disc.spec.monitors:
     print("  monitor", m.name, m.kind, "lo", m.lo, "hi", m.hi, "steps", list(m.steps[:6]), "...", len(m.steps))
 sl = F.inside(disc)
 ref_f, ref_m = F.run(disc, steps, split, L.VARIANT_FUSED, None, rows=rows, zc=zc)
 for rep in range(repeats):
-    for name, var, comm in (("fused", L.VARIANT_FUSED, False), ("fused_slab", L.VARIANT_FUSED, True), ("two_pass_slab", L.VARIANT_ZMARCH, True)):
-        f, m = F.run(disc, steps, split, var, None, comm=comm)
+    for name, var, comm, opts in (("fused", L.VARIANT_FUSED, False, None), ("fused_split", L.VARIANT_FUSED, False, {L.OPT_PML_SPLIT: 1}),
+                                  ("fused_slab", L.VARIANT_FUSED, True, so), ("fused_slab_pairs", L.VARIANT_FUSED, True, po),
+                                  ("two_pass_slab", L.VARIANT_ZMARCH, True, None)):
+        if comm and not per_z:
+            continue
+        f, m = F.run(disc, steps, split, var, None, comm=comm, opts=opts)
         bad_f = [c for c, (a, b) in enumerate(zip(ref_f, f)) if not np.array_equal(a[sl], b[sl])]
         bad_m = [k for k in ref_m if not np.array_equal(ref_m[k], m[k])]
         print(rep, name, "fields differ:", bad_f, "monitors differ:", bad_m, flush=True)
