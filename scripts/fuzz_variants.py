@@ -1,7 +1,7 @@
 """Randomised cross-check of the hot path's variants against each other and against the oracle: random small simulations —
 walls of every kind per face (PEC, PMC on min AND plus faces, CPML / StablePML of random thickness, absorber layers, periodic
 axes), dielectric / lossy / PEC / Lorentz / Drude bodies through the layers, electric and magnetic dipoles anywhere (next to
-walls too), time / DFT / flux monitors, decay checks, runs cut in two —
+walls too), a plane wave across a periodic cell now and then, time / DFT / flux monitors, decay checks, runs cut in two —
     fused sweep  ==  two-pass kernels  ==  a z-slab rank exchanging with itself (periodic z)      bit for bit
     fused sweep  vs  the fp64 oracle (oracle/fdtd_numpy.py)                                      <= 2e-5
     python scripts/fuzz_variants.py [n_cases] [seed]
@@ -33,13 +33,20 @@ def case(rng, big=False):
     size = tuple(n * DL for n in N)
     periodic = [bool(rng.integers(0, 4) == 0) for _ in range(3)]
     kind = int(rng.integers(0, 3))                        # 0: CPML world, 1: absorber world, 2: walls only
+    wave = bool(rng.integers(0, 6) == 0)                  # a plane wave along x across a cell periodic in y and z (CPML on x): the
+    if wave:                                              # TFSF corrections and the 1-D incident grid, with its comm-stream replica on slab ranks
+        periodic, kind = [False, True, True], 0
+        N[0] = max(N[0], 16)
+        size = tuple(n * DL for n in N)
 
     faces = []
 
     def face(a):
         r = int(rng.integers(0, 6))
         f = td.PECBoundary()
-        if kind == 0 and r < 3:
+        if wave:
+            f = td.PML(num_layers=int(rng.integers(3, 6)))
+        elif kind == 0 and r < 3:
             n = int(rng.integers(2, 6))
             f = td.StablePML(num_layers=n) if r == 0 else td.PML(num_layers=n)
         elif kind == 1 and r < 3 and N[a] >= 12:
@@ -64,6 +71,9 @@ def case(rng, big=False):
     for _ in range(int(rng.integers(1, 4))):
         pols = ["Ex", "Ey", "Ez"] if has_absorber else ["Ex", "Ey", "Ez", "Hx", "Hy", "Hz"]
         srcs.append(td.PointDipole(center=pos(), source_time=PULSE, polarization=str(rng.choice(pols))))
+    if wave:
+        srcs = srcs[:1] + [td.PlaneWave(center=(0.5 * size[0] - float(rng.uniform(2.5, 4.5)) * DL, 0, 0), size=(0, td.inf, td.inf), source_time=PULSE,
+                                        direction="-", pol_angle=float(rng.uniform(0, 1.5)))]
     structures = []
     if rng.integers(0, 3) > 0:
         meds = [td.Medium(permittivity=float(rng.uniform(1.5, 5)), conductivity=float(rng.choice([0, 0.02]))), td.PEC,
@@ -93,7 +103,7 @@ def case(rng, big=False):
     disc = discretize(sim, n_steps=steps)
     disc.spec.decay_every = int(rng.choice([0, 0, 8, 16]))
     desc = f"N={disc.spec.shape} bc={[f if isinstance(f, str) else type(f).__name__[:4] for f in faces]} " \
-           f"src={[s.polarization for s in srcs]} media={[type(s.medium).__name__[:4] for s in structures]} mon={[m.name for m in mons]} steps={steps} " \
+           f"src={[getattr(s, 'polarization', 'wave') for s in srcs]} media={[type(s.medium).__name__[:4] for s in structures]} mon={[m.name for m in mons]} steps={steps} " \
            f"decay={disc.spec.decay_every}"
     return disc, steps, periodic[2], desc
 
@@ -158,13 +168,15 @@ def run_cases(n_cases, seed=1, lib=None, quiet=False, oracle=True, big=False):
         diff = [k for k, (f, m) in outs.items()
                 if not (all(np.array_equal(a[sl], b[sl]) for a, b in zip(ref_f, f)) and all(np.array_equal(ref_m[n], m[n]) for n in ref_m))]
         err = 0.0
+        amp = max(float(np.abs(f).max()) for f in ref_f)
         if oracle:
             o = OracleFdtd(disc.spec).run()
-            scale = max(np.linalg.norm(v) / np.sqrt(v.size) for v in o.values())
+            # (records the wave has not reached yet hold fp32 denormals — 1e-42 of a field of 1e4, case 136 of seed 901: judged on
+            #  the scale of the largest record, and no finer than 1e-9 of the field's amplitude)
+            scale = max(max(np.linalg.norm(v) / np.sqrt(v.size) for v in o.values()), 1e-9 * amp)
             for k, v in o.items():
                 den = max(np.linalg.norm(v), 0.5 * scale * np.sqrt(v.size), 1e-300)
                 err = max(err, float(np.linalg.norm(np.asarray(ref_m[k]) - v) / den))
-        amp = max(float(np.abs(f).max()) for f in ref_f)
         ok = not diff and err < 2e-5 and np.isfinite(amp)
         if not quiet or not ok:
             print(f"case {q}: {desc} split={split} rows={rows} zc={zc} variants={['fused'] + list(outs)} max|F|={amp:.3g} oracle={err:.2e} -> "
