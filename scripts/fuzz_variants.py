@@ -1,6 +1,6 @@
 """Randomised cross-check of the hot path's variants against each other and against the oracle: random small simulations —
 walls of every kind per face (PEC, PMC on min AND plus faces, CPML / StablePML of random thickness, absorber layers, periodic
-axes), dielectric / lossy / PEC / Lorentz / Drude bodies through the layers, electric and magnetic dipoles anywhere (next to
+axes), uniform or varying cell sizes, dielectric / lossy / PEC / Lorentz / Drude / diagonally anisotropic bodies through the layers, electric and magnetic dipoles anywhere (next to
 walls too), a plane wave across a periodic cell now and then, time / DFT / flux monitors, decay checks, runs cut in two —
     fused sweep  ==  two-pass kernels  ==  a z-slab rank exchanging with itself (periodic z)      bit for bit
     fused sweep  vs  the fp64 oracle (oracle/fdtd_numpy.py)                                      <= 2e-5
@@ -77,9 +77,11 @@ def case(rng, big=False):
     structures = []
     if rng.integers(0, 3) > 0:
         meds = [td.Medium(permittivity=float(rng.uniform(1.5, 5)), conductivity=float(rng.choice([0, 0.02]))), td.PEC,
-                td.Lorentz(eps_inf=2.0, coeffs=[(1.5, 4e14, 3e13)]), td.Drude(eps_inf=1.5, coeffs=[(6e14, 5e13)])]
+                td.AnisotropicMedium(xx=td.Medium(permittivity=2.0), yy=td.Medium(permittivity=3.5, conductivity=0.01), zz=td.PEC),
+                td.Lorentz(eps_inf=2.0, coeffs=[(1.5, 4e14, 3e13)]), td.Drude(eps_inf=1.5, coeffs=[(6e14, 5e13)]),
+                td.AnisotropicMedium(xx=td.Drude(eps_inf=1.5, coeffs=[(6e14, 5e13)]), yy=td.Medium(permittivity=2.2), zz=td.Medium(permittivity=4.0))]
         for _ in range(int(rng.integers(1, 4))):
-            med = meds[int(rng.integers(0, 2 if has_absorber else 4))]
+            med = meds[int(rng.integers(0, 3 if has_absorber else 6))]
             if rng.integers(0, 2):
                 geo = td.Box(center=pos(0.0), size=tuple(float(rng.uniform(0.15, 0.7) * s) for s in size))
             else:
@@ -97,7 +99,14 @@ def case(rng, big=False):
         sz = [td.inf, td.inf, td.inf]
         sz[int(rng.integers(0, 3))] = 0
         mons.append(td.FluxMonitor(center=pos(2.0), size=tuple(sz), freqs=[3e14], name="flux"))
-    sim = td.Simulation(size=size, grid_spec=td.GridSpec.uniform(dl=DL), run_time=1e-12, sources=srcs, monitors=mons,
+    grid = td.GridSpec.uniform(dl=DL)
+    if rng.integers(0, 3) == 0:                           # a third of the cases: cell sizes that vary along every axis (0.7 ... 1.3 dl)
+        def coords(n, s_):
+            d = rng.uniform(0.7, 1.3, n)
+            return tuple(np.concatenate(([0.0], np.cumsum(d))) * (s_ / d.sum()) - 0.5 * s_)
+        grid = td.GridSpec(grid_x=td.CustomGridBoundaries(coords=coords(N[0], size[0])), grid_y=td.CustomGridBoundaries(coords=coords(N[1], size[1])),
+                           grid_z=td.CustomGridBoundaries(coords=coords(N[2], size[2])))
+    sim = td.Simulation(size=size, grid_spec=grid, run_time=1e-12, sources=srcs, monitors=mons,
                         structures=structures, boundary_spec=bspec, shutoff=0)
     steps = int(rng.integers(20, 60))
     disc = discretize(sim, n_steps=steps)

@@ -447,7 +447,7 @@ def test_angled_solver_reduces_to_the_straight_one():
     n_eff like cos(theta) to first order in the transverse confinement."""
     from tidy3d_amd.mode_solver import solve_modes_angled
     c = GOLD[0]
-    eu, ev, ew, xb, yb = _strip(dict(c, dl=0.05))
+    eu, ev, ew, xb, yb = _strip(dict(c, dl=0.07))
     f = C_0 / c["wavelength"]
     r0 = solve_modes(eu, ev, ew, xb, yb, f, num_modes=1)
     r1 = solve_modes_angled(eu, ev, ew, xb, yb, f, 1e-6, 0.3, num_modes=1)
