@@ -44,7 +44,10 @@ GLOO_CASES = [(2, "media_mix"), (2, "pml_box"), (3, "periodic_box"), (2, "drude_
                                         # wrap-around planes rank n-1 <-> rank 0 are rotated by exp(-+ i phi_z))
                                         (2, "bloch_xy_pml_z"), (2, "bloch_box"), (3, "bloch_box"),
                                         # PMC on plus faces: the x wall crosses every slab, the z wall is the last rank's
-                                        (2, "pmc_plus_mix")]
+                                        (2, "pmc_plus_mix"),
+                                        # graded cells along z: a rank needs its neighbours' cell sizes next to the cuts (the ghost
+                                        # entries of the step arrays; replicas of its own until round 4's variant fuzz noticed)
+                                        (2, "nonuniform_grid"), (3, "nonuniform_grid")]
 
 
 @pytest.mark.parametrize("world,case", GLOO_CASES)

@@ -243,6 +243,7 @@ class HipEngine:
         self.lib = lib or L.load_library()
         self.spec = spec
         self.rank, self.n_ranks = rank, n_ranks
+        self.force_comm = bool(force_comm)
         # Bloch boundaries: complex fields = this engine (real part) + a twin engine (imaginary part,
         # source weights times -i) on the ghost-cell device layout of bloch_device_spec, advanced together
         # by fdtd_run_bloch (one GPU)
@@ -353,7 +354,17 @@ class HipEngine:
             if a == 0 and pad:
                 p, q = _f32(np.append(p, [p[-1]] * pad)), _f32(np.append(q, [q[-1]] * pad))
             if a == 2:
-                p, q = _f32(p[z0:z1]), _f32(q[z0:z1])
+                if (z0, z1) != (0, nz) or self.n_ranks > 1 or self.force_comm:
+                    # a z-slab: the steps of the planes beyond its cuts come along as ghost entries (the library only knows how to
+                    # wrap / replicate its own) — the neighbour's cell below, the neighbour's cell above; across a periodic z
+                    # the wrap; beyond an outer wall the replica
+                    per = spec.bc[2][0] == BC_PERIODIC
+                    lo_i = z0 - 1 if z0 > 0 else (nz - 1 if per else 0)
+                    hi_i = z1 if z1 < nz else (0 if per else nz - 1)
+                    p = _f32(np.concatenate(([p[lo_i]], p[z0:z1], [p[hi_i]])))
+                    q = _f32(np.concatenate(([q[lo_i]], q[z0:z1], [q[hi_i]])))
+                else:
+                    p, q = _f32(p[z0:z1]), _f32(q[z0:z1])
             self._chk(d.fdtd_set_steps(h, a, _ptr(p), _ptr(q), len(p)), "fdtd_set_steps")
         self.mt = mt = material_table(spec.media, spec.dt)
         ca, cb = _f32(mt.ca), _f32(mt.cb)
