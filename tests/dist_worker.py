@@ -53,12 +53,28 @@ def main():
     lib = load_library(build_emu.build())
     cb = EXCHANGE_FN(_exchange)
     lib.dll.hipemu_set_exchange(cb, None)
-    sim = cases.CASES[case]() if case in cases.CASES else getattr(cases, case)()
-    disc = discretize(sim, n_steps=n_steps)
-    disc.spec.decay_every = 10          # exercise the scalar all-reduce too
+    if case.startswith("fuzz:"):            # "fuzz:<seed>:<index>": a random simulation of scripts/fuzz_variants.py (every rank draws the same)
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import fuzz_variants
+        _, seed, index = case.split(":")
+        rng = np.random.default_rng(int(seed))
+        for _ in range(int(index) + 1):
+            disc = fuzz_variants.draw(rng, False)[0]
+    else:
+        sim = cases.CASES[case]() if case in cases.CASES else getattr(cases, case)()
+        disc = discretize(sim, n_steps=n_steps)
+        disc.spec.decay_every = 10          # exercise the scalar all-reduce too
     shift = os.environ.get("SLAB_SHIFT")                    # force a slab-axis renaming (tests)
-    eng = tdist.make_engine(disc.spec, lib=lib, device=0,   # the emulator exposes one device
-                            axis_shift=None if shift is None else int(shift))
+    from tidy3d_amd.exceptions import SetupError
+    try:
+        eng = tdist.make_engine(disc.spec, lib=lib, device=0,   # the emulator exposes one device
+                                axis_shift=None if shift is None else int(shift))
+    except SetupError as err:               # a split the front end refuses — on every rank alike (decided from the split alone)
+        if rank == 0:
+            np.savez(out, refused=str(err))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if os.environ.get("PML_FUSED"):                         # CPML recursions inside the sweeps of the slab ranks (tests)
         from tidy3d_amd import lib as L
         eng.set_option(L.OPT_PML_FUSED, int(os.environ["PML_FUSED"]))

@@ -132,6 +132,41 @@ def test_step_pairs_on_slab_ranks(world, case, twostep, emu_lib, tmp_path):
     assert float(got["decay"]) == pytest.approx(st.field_decay, rel=1e-6)
 
 
+FUZZ_RANK_CASES = [(2, 31, 0), (3, 31, 1), (2, 31, 2), (3, 31, 3), (2, 31, 4), (2, 31, 5), (3, 31, 6), (2, 31, 7)]
+
+
+@pytest.mark.parametrize("world,seed,index", FUZZ_RANK_CASES)
+def test_random_simulations_on_two_and_three_ranks(world, seed, index, emu_lib, tmp_path):
+    """Random simulations of scripts/fuzz_variants.py (walls of every kind, graded cells, dispersive / anisotropic bodies, dipoles of
+    both kinds, plane waves, monitors across the cuts, decay checks) cut into 2 or 3 z-slabs at whatever planes the split puts
+    them: fields inside the walls and every record == the single-slab run of the same library, bit for bit.  (On the device
+    the same cases run as a slab rank exchanging with itself over RCCL, tests/test_gpu_production_path.py; real cuts — unequal
+    slabs, a neighbour's cell sizes, records gathered from several ranks — only exist here.)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import fuzz_variants
+    from tidy3d_amd import lib as L
+    rng = np.random.default_rng(seed)
+    for _ in range(index + 1):
+        disc, steps, per_z, desc, *_ = fuzz_variants.draw(rng, False)
+    if disc.spec.shape[2] < 4 * world:
+        pytest.skip("too few planes for %d slabs: %s" % (world, desc))
+    out = str(tmp_path / "dist.npz")
+    _launch(world, f"fuzz:{seed}:{index}", steps, out, 29751 + FUZZ_RANK_CASES.index((world, seed, index)))
+    got = np.load(out)
+    if "refused" in got:
+        pytest.skip("the split is refused on every rank: %s (%s)" % (got["refused"], desc))
+    sl = fuzz_variants.inside(disc)
+    with HipEngine(disc.spec, lib=emu_lib, variant=L.VARIANT_ZMARCH if disc.spec.bloch is not None else L.VARIANT_AUTO, axis_shift=0) as e:
+        st = e.run()
+        ref = e.results()
+        fields = [e.get_field(c) for c in range(6)]
+    for c in range(6):
+        assert np.array_equal(got[f"field{c}"][sl], fields[c][sl]), (desc, c)
+    for k, v in ref.items():
+        assert np.array_equal(got[f"mon_{k}"], v), (desc, k)
+
+
 @pytest.mark.parametrize("world,case", [(2, "media_mix"), (3, "periodic_box")])
 def test_placement_probe_on_slabs_changes_nothing(world, case, emu_lib, tmp_path):
     """Every rank samples alternative placements of its slab's field arrays before the first step (forced on for

@@ -2488,8 +2488,9 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   if ((nb_lo || nb_hi) && !multi) return fail(h, "fdtd_run: neighbour faces need fdtd_comm_init");
   // (PMC on a plus face of a z-slab rank: x / y walls are local to every plane; a z wall belongs to the rank without an upper
   //  neighbour, whose interior launch must hold the wall's two image planes and the two they mirror)
-  if (multi && h->mirror_wall[2] >= 0 && (nb_hi || h->mirror_wall[2] != h->g.nz - 2 || h->g.nz < 8))
-    return fail(h, "fdtd_run: a PMC plus face along z needs the last z-slab to hold the wall and at least 8 planes");
+  // (six planes: the boundary chunk next to the lower neighbour is one plane thick below eight planes, two from there on)
+  if (multi && h->mirror_wall[2] >= 0 && (nb_hi || h->mirror_wall[2] != h->g.nz - 2 || h->g.nz < 6))
+    return fail(h, "fdtd_run: a PMC plus face along z needs the last z-slab to hold the wall and at least 6 planes");
   const int nz = h->g.nz;
   // runs that use BOTH streams first make sure the two really overlap (once per engine; falls back to one stream)
   if ((multi || any_pml(h) || h->tblock > 4096) && probe_stream_overlap(h)) return -1;

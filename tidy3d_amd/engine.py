@@ -244,6 +244,7 @@ class HipEngine:
         self.spec = spec
         self.rank, self.n_ranks = rank, n_ranks
         self.force_comm = bool(force_comm)
+        self._all_slabs = list(all_slabs) if all_slabs is not None else None
         # Bloch boundaries: complex fields = this engine (real part) + a twin engine (imaginary part,
         # source weights times -i) on the ghost-cell device layout of bloch_device_spec, advanced together
         # by fdtd_run_bloch (one GPU)
@@ -400,11 +401,15 @@ class HipEngine:
         mp = getattr(spec, "mirror_plus", None)
         if mp is not None and any(w >= 0 for w in mp):
             # (z-slab ranks: x / y walls cross every slab; a z wall and its two image planes belong to the last one)
+            # (decided from the split alone, so that every rank raises — a lone rank giving up would leave the others waiting)
+            if mp[2] >= 0 and (self.n_ranks > 1 or (z0, z1) != (0, nz)):
+                last = (self._all_slabs or split_slabs(nz, self.n_ranks))[-1]
+                if last[1] - last[0] < 6:
+                    raise SetupError("a PMC plus face along z needs a last z-slab of at least 6 planes (the wall's two image planes and "
+                                     f"the two they mirror inside its interior launch); it has {last[1] - last[0]}")
             for a, w in enumerate(mp):
                 if w < 0 or (a == 2 and z1 != nz):
                     continue
-                if a == 2 and w - 2 < z0:
-                    raise SetupError("a PMC plus face along z needs the last z-slab to hold at least the four planes around the wall")
                 self._chk(d.fdtd_set_mirror_plus(h, a, int(w) - (z0 if a == 2 else 0)), "fdtd_set_mirror_plus")
         # absorber layers (damping tables, slab-local along z)
         dm = damping_tables(spec)
