@@ -103,5 +103,29 @@ def test_random_reference_simulations_discretise_as_the_reference_says(td_ref, s
             assert D.discretize_inds_monitor(b, m).tolist() == np.asarray(sim._discretize_inds_monitor(m_ref)).tolist(), m.name
             if hasattr(m_ref, "time_inds"):
                 assert list(m.time_inds(tmesh)) == list(m_ref.time_inds(sim.tmesh)), m.name
+        if done % 5 == 0 and int(np.prod([len(x) - 1 for x in b])) < 400_000:
+            # the staircase raster at the Ex / Ez Yee nodes: geometry.inside of the reference's own objects, later structures on top
+            spec = D.discretize(mirror.copy(subpixel=False, monitors=()), n_steps=2).spec
+            if any(mirror.symmetry) or any(w >= 0 for w in (getattr(spec, "mirror_plus", None) or ())):
+                done += 1
+                continue                                  # (the raster covers the computed half only / carries image cells beyond a PMC plus wall)
+            for c in (0, 2):
+                xs, ys, zs = spec.yee_coords(c)
+                X, Y, Z = np.meshgrid(xs, ys, zs, indexing="ij")
+                expect = np.ones(X.shape, int)
+                for idx, st_ref in enumerate(sim.structures):
+                    expect[st_ref.geometry.inside(X, Y, Z)] = idx + 2
+                got = spec.mat_idx[c].transpose(2, 1, 0) if spec.mat_idx is not None else np.ones(X.shape, int)
+                # table indices follow first use, PEC is entry 0: compare the partition of the nodes, medium by medium
+                for idx, st_ref in enumerate(sim.structures):
+                    sel = expect == idx + 2
+                    if sel.any():
+                        vals = np.unique(got[sel])
+                        assert len(vals) == 1, (seed, done, idx)
+                        med = spec.media[int(vals[0])]
+                        assert med.pec == isinstance(st_ref.medium, td_ref.PECMedium), (seed, done, idx)
+                        if not med.pec:
+                            assert med.eps_inf == pytest.approx(float(np.real(st_ref.medium.eps_model(np.inf) if hasattr(st_ref.medium, "eps_model") else 1.0)), rel=1e-9)
+                assert (got[expect == 1] == 1).all()
         done += 1
     assert done >= 10, done
