@@ -99,6 +99,9 @@ def test_random_reference_simulations_discretise_as_the_reference_says(td_ref, s
         tmesh = D.make_tmesh(D.run_time(mirror), dt)
         assert len(tmesh) == sim.num_time_steps
         assert D.nyquist_step(mirror, dt) == sim.nyquist_step
+        t = tmesh[:: max(1, len(tmesh) // 40)]
+        np.testing.assert_allclose(mirror.sources[0].source_time.amp_time(t), sim.sources[0].source_time.amp_time(t), rtol=1e-12, atol=1e-300)
+        assert list(D.frequency_range(mirror)) == pytest.approx(list(sim.frequency_range), rel=1e-12)
         for m_ref, m in zip(sim.monitors, mirror.monitors):
             assert D.discretize_inds_monitor(b, m).tolist() == np.asarray(sim._discretize_inds_monitor(m_ref)).tolist(), m.name
             if hasattr(m_ref, "time_inds"):
