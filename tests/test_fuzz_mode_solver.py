@@ -43,9 +43,7 @@ def test_random_cross_sections_match_the_reference_solver(seed):
     num_pml = (int(rng.choice([0, 0, 6, 8])), int(rng.choice([0, 0, 5, 7])))
     radius = float(rng.choice([-1, 1]) * rng.uniform(4.0, 9.0)) if rng.integers(0, 3) == 0 else None
     bend_axis = int(rng.integers(0, 2))
-    # (an angle only with a well-confined mode: the tensorial problem's rows on the window's walls are not the reference's to the
-    #  last term — a weakly guided mode that reaches the walls agrees to 3e-4 in n_eff only)
-    theta = float(rng.uniform(-0.3, 0.3)) if (rng.integers(0, 3) == 0 and not any(sym) and np.real(n_core) >= 2.8 and w * h >= 0.1) else 0.0
+    theta = float(rng.uniform(-0.3, 0.3)) if rng.integers(0, 3) == 0 else 0.0
     phi = float(rng.uniform(0, 2.0)) if theta else 0.0
     freq = C_0 / float(rng.uniform(1.2, 1.7))
     target = float(np.real(n_core))

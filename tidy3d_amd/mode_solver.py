@@ -94,15 +94,20 @@ def _pml_s(direction: str, omega: float, d: np.ndarray, n: int, n_pml: int, at_m
     return s
 
 
-def _diff_ops(nu: int, nv: int, du_p, dv_p, du_d, dv_d, pmc_min=(False, False), s_fac=None):
+def _diff_ops(nu: int, nv: int, du_p, dv_p, du_d, dv_d, pmc_min=(False, False), s_fac=None, wall_in_fwd: bool = False):
     """Sparse forward (on primal steps) and backward (on dual steps) difference operators for
     fields flattened as index = iu * nv + iv.  Min edge of each axis: PEC wall, or a PMC wall
     (``pmc_min``: the symmetry plane of an even mode, ref derivatives.py:9-62 ``dmin_pmc``)."""
     if s_fac is not None:           # PML: derivatives divided by the stretching factors
         du_p, du_d, dv_p, dv_d = du_p * s_fac[0], du_d * s_fac[1], dv_p * s_fac[2], dv_d * s_fac[3]
 
-    def fwd(n, d):
-        D = sp.diags([-np.ones(n), np.ones(n - 1)], [0, 1], shape=(n, n), format="csr")
+    def fwd(n, d, pmc=True):
+        main = -np.ones(n)
+        # ``wall_in_fwd`` (the tensorial problem, which has no clamped rows): a PEC min wall enters as in ref derivatives.py:9-19 —
+        # the wall's own node does not contribute to the first difference
+        if wall_in_fwd and not pmc:
+            main[0] = 0.0
+        D = sp.diags([main, np.ones(n - 1)], [0, 1], shape=(n, n), format="csr")
         return sp.diags(1.0 / d) @ D            # last row: (0 - f[n-1]) -> truncation = PEC
     def bwd(n, d, pmc):
         main = np.ones(n)
@@ -113,8 +118,8 @@ def _diff_ops(nu: int, nv: int, du_p, dv_p, du_d, dv_d, pmc_min=(False, False), 
         D = sp.diags([main, -np.ones(n - 1)], [0, -1], shape=(n, n), format="csr")
         return sp.diags(1.0 / d) @ D
     Iu, Iv = sp.identity(nu, format="csr"), sp.identity(nv, format="csr")
-    Duf = sp.kron(fwd(nu, du_p), Iv, format="csr")
-    Dvf = sp.kron(Iu, fwd(nv, dv_p), format="csr")
+    Duf = sp.kron(fwd(nu, du_p, pmc_min[0]), Iv, format="csr")
+    Dvf = sp.kron(Iu, fwd(nv, dv_p, pmc_min[1]), format="csr")
     Dub = sp.kron(bwd(nu, du_d, pmc_min[0]), Iv, format="csr")
     Dvb = sp.kron(Iu, bwd(nv, dv_d, pmc_min[1]), format="csr")
     return Duf, Dvf, Dub, Dvb
@@ -298,15 +303,12 @@ def solve_modes_angled(eps_u: np.ndarray, eps_v: np.ndarray, eps_w: np.ndarray, 
         omega = 2 * np.pi * freq
         s_fac = (_pml_s("f", omega, du_p, nu, pu, pml_min[0], speed[:2]), _pml_s("b", omega, du_d, nu, pu, pml_min[0], speed[:2]),
                  _pml_s("f", omega, dv_p, nv, pv, pml_min[1], speed[2:]), _pml_s("b", omega, dv_d, nv, pv, pml_min[1], speed[2:]))
-    Duf, Dvf, Dub, Dvb = (D / k0 for D in _diff_ops(nu, nv, du_p, dv_p, du_d, dv_d, pmc_min, s_fac))
+    # the walls live in the derivative matrices alone, as in the reference's tensorial problem (ref solver.py:595-668,
+    # derivatives.py:9-62) — no rows are clamped.  (Clamped like the diagonal solver's, a weakly guided mode that reaches the
+    # walls came out 2e-4 off in n_eff: tests/test_fuzz_mode_solver.py)
+    Duf, Dvf, Dub, Dvb = (D / k0 for D in _diff_ops(nu, nv, du_p, dv_p, du_d, dv_d, pmc_min, s_fac, wall_in_fwd=True))
     dg = lambda v: sp.diags(np.asarray(v).reshape(-1))           # noqa: E731
     mask_u, mask_v, mask_w = np.ones((nu, nv)), np.ones((nu, nv)), np.ones((nu, nv))
-    if not pmc_min[1]:
-        mask_u[:, 0] = 0
-        mask_w[:, 0] = 0
-    if not pmc_min[0]:
-        mask_v[0, :] = 0
-        mask_w[0, :] = 0
     Mu, Mv, Mw = dg(mask_u), dg(mask_v), dg(mask_w)
     Z = sp.csr_matrix((N, N), dtype=complex)
     Ie, Im = dg(1.0 / eps["ww"]), dg(1.0 / mu["ww"])
