@@ -218,3 +218,30 @@ def test_shell_pairs_are_taken_where_they_pay(hip_lib):
             st = e.run(12)
             assert (int(st.shell_pairs) == 6) == want, (n, int(st.shell_pairs))
             assert int(st.fused2_off_reason) == (0 if want else 12), int(st.fused2_off_reason)
+
+
+@pytest.mark.gpu
+def test_reciprocity_through_step_pairs_on_the_device(hip_lib):
+    """Lorentz reciprocity (tests/test_reciprocity.py: the fp64 oracle holds it to 1e-11) through the production path at a size no
+    oracle run reaches in a test: 320 x 96 x 136 cells + CPML on every face, a lossy block and a dielectric sphere across the
+    x-tile seam, shell pairs.  E_y at B driven from A along x == E_x at A driven from B along y, 500 steps, to fp32 rounding —
+    a pin of the two-step sweep, the shell's single steps, the seam repair and the CPML that does not go through the oracle."""
+    from test_reciprocity import reciprocity_sims, series
+    cfg = dict(N=(320, 96, 136), A=(100, 40, 50), ca=0, B=(290, 70, 90), cb=1,
+               bspec=td.BoundarySpec.all_sides(td.PML(num_layers=8)),
+               structures=[td.Structure(geometry=td.Box(center=(0.5, 0, 0), size=(6.0, 1.5, 2.0)), medium=td.Medium(permittivity=4.0, conductivity=0.01)),
+                           td.Structure(geometry=td.Sphere(center=(4.5, 0.5, 1.0), radius=1.2), medium=td.Medium(permittivity=2.2))])
+    (d1, at1), (d2, at2) = reciprocity_sims(n_steps=500, **cfg)
+    out, pairs = [], []
+    for d, at in ((d1, at1), (d2, at2)):
+        with HipEngine(d.spec, lib=hip_lib, variant=L.VARIANT_FUSED, axis_shift=0) as e:
+            e.set_option(L.OPT_TWOSTEP, 16 + 64 * 16)
+            e.set_option(L.OPT_SHELL_PAIRS, 1)
+            st = e.run()
+            pairs.append(int(st.shell_pairs))
+            out.append(series(e.results(), at))
+    assert min(pairs) >= 200, pairs
+    assert np.abs(out[0]).max() > 0
+    err = float(np.abs(out[0] - out[1]).max() / np.abs(out[0]).max())
+    print(f"\n[reciprocity through {pairs} shell pairs] max |E_B<-A - E_A<-B| / max = {err:.2e}")
+    assert err < 5e-5
