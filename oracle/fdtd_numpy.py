@@ -16,7 +16,9 @@ source waveform/spectrum (ref source.py:174-193, time.py:72-105).  The arithmeti
 the leapfrog/CPML/ADE recursions is the textbook scheme documented in
 ``tidy3d_amd/coeffs.py``; it is validated by physics in tests/test_physics_oracle.py
 (PEC-cavity eigenfrequencies, PML reflection, Fresnel transmission of a dispersive
-slab, energy conservation).
+slab, energy conservation) and by a structural property that needs no reference data: discrete Lorentz
+reciprocity, held to 1e-11 through CPML, walls of either kind, periodic axes, graded cells and lossy /
+dispersive / anisotropic bodies (tests/test_reciprocity.py).
 
 It consumes the same ``SolverSpec`` (the *statement* of the problem: grid boundaries,
 material indices, source lists, monitor boxes) as the HIP engine, but derives every
