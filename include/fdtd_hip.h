@@ -185,6 +185,15 @@ int fdtd_set_absorber(FdtdSolver* h, int axis, int n_lo, int n_hi, const float* 
 int fdtd_add_ade(FdtdSolver* h, int comp, int64_t n_cells, const uint32_t* cell_index,
                  int n_poles, const float* kap, const float* bet, float cc);
 
+/* fully anisotropic bodies (ref tidy3d medium.py:5058 FullyAnisotropicMedium): the off-diagonal coupling of E component `comp`
+ * at n nodes.  The sweep advances every component with the diagonal of eps^-1 (table media); behind it
+ *     E_comp[cell[i]] += sum_{s<8} w_new[8i+s] * Eb^{n+1}[nbr[8i+s]] - w_old[8i+s] * Eb^n[nbr[8i+s]],
+ * slots 0-3: component (comp+1)%3, slots 4-7: (comp+2)%3; nbr = 0xFFFFFFFF: no node (weight ignored).  The host forms
+ * w_new = (dt/eps0) g / Cb(nbr), w_old = w_new * Ca(nbr) (tidy3d_amd/spec.py AnisoSet).  Single steps only; not on z-slabs,
+ * not with Bloch boundaries. */
+int fdtd_add_aniso(FdtdSolver* h, int comp, int64_t n_nodes, const uint32_t* cell_index, const uint32_t* nbr_index,
+                   const float* w_new, const float* w_old);
+
 /* current source: F[comp[p]][index[p]] += w_re[p]*Re(wave[n]) - w_im[p]*Im(wave[n]);
  * E components use wave_e (sampled at t_n + dt/2), H components wave_h (t_n);
  * waves are n_steps complex values (re,im interleaved)  (ref source.py:174-193, :543-632). */

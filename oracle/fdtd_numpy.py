@@ -346,6 +346,8 @@ class OracleFdtd:
         E, H = self.E, self.H
         spec = self.spec
         e_old = [E[c].ravel()[idx].copy() for (c, m, idx, q, _) in self.ade]
+        aniso = getattr(spec, "aniso", None) or []
+        e_prev = [E[c].copy() for c in range(3)] if aniso else None
         for c in range(3):
             a1, a2 = (c + 1) % 3, (c + 2) % 3
             d1 = self._pml_e(c, a1, self._bwd(H[a2], a1))
@@ -362,6 +364,25 @@ class OracleFdtd:
                 if m.any():
                     ijk = s.ijk[m]
                     np.add.at(E[cc], (ijk[:, 2], ijk[:, 1], ijk[:, 0]), self._amp(w[m] * s.wave_e[n]))
+        # fully anisotropic bodies (spec.AnisoSet): dE_a(i) = (dt / eps0) sum_j g(i, j) curl_b(j), the curl recovered from what the
+        # update above did to E_b(j) — (E_b^{n+1} - Ca E_b^n) / Cb, zero on PEC nodes — all components from the unpatched values
+        if aniso:
+            deltas = []
+            for st in aniso:
+                d = np.zeros(len(st.ijk), dtype=E[0].dtype)
+                for slot in range(8):
+                    b = st.nbr_comp[slot]
+                    j = st.nbr_ijk[:, slot]
+                    ok = j[:, 0] >= 0
+                    kk, jj, ii = j[ok, 2], j[ok, 1], j[ok, 0]
+                    ca_b = self.ca[b][kk, jj, ii] if np.ndim(self.ca[b]) else self.ca[b]
+                    cb_b = self.cb[b][kk, jj, ii] if np.ndim(self.cb[b]) else self.cb[b]
+                    cb_safe = np.where(cb_b == 0, 1.0, cb_b)
+                    curl = np.where(cb_b == 0, 0.0, (E[b][kk, jj, ii] - ca_b * e_prev[b][kk, jj, ii]) / cb_safe)
+                    d[ok] += (spec.dt / _EPS0) * st.g[ok, slot] * curl
+                deltas.append(d)
+            for st, d in zip(aniso, deltas):
+                E[st.comp][st.ijk[:, 2], st.ijk[:, 1], st.ijk[:, 0]] += d
         # absorber layers: damp the updated E before the ADE memory term is added
         if self.damp_e is not None:
             for c in range(3):

@@ -342,7 +342,22 @@ def sheets_box(N=(18, 14, 16)):
     return sim
 
 
+def fully_aniso_box(N=(18, 16, 14)):
+    """FullyAnisotropicMedium (ref medium.py:5058): a rotated biaxial sphere (the off-diagonal coupling lists of csrc/fdtd_aniso.hpp)
+    next to a lossy block and a PEC box; CPML on x, PEC / CPML on y, periodic z."""
+    def rot(axis, ang):
+        c, s = np.cos(ang), np.sin(ang)
+        return np.array({2: [[c, -s, 0], [s, c, 0], [0, 0, 1]], 1: [[c, 0, s], [0, 1, 0], [-s, 0, c]]}[axis])
+    med = td.FullyAnisotropicMedium.from_diagonal(2.0, 5.0, 3.2, rot(2, 0.7) @ rot(1, 0.4))
+    structures = [td.Structure(geometry=td.Sphere(center=(0.05, 0, 0.02), radius=0.28), medium=med),
+                  td.Structure(geometry=td.Box(center=(-0.2, 0.1, 0), size=(0.2, 0.3, td.inf)), medium=td.Medium(permittivity=2.5, conductivity=0.02)),
+                  td.Structure(geometry=td.Box(center=(0.2, -0.15, 0.1), size=(0.15, 0.15, 0.15)), medium=td.PEC)]
+    bspec = td.BoundarySpec(x=td.Boundary.pml(num_layers=4), y=td.Boundary(minus=td.PECBoundary(), plus=td.PML(num_layers=3)), z=td.Boundary.periodic())
+    return _sim(N, bspec, structures)
+
+
 CASES = {
+    "fully_aniso_box": fully_aniso_box,
     "sheets_box": sheets_box,
     "bloch_box": bloch_box, "bloch_planewave": bloch_planewave, "bloch_xy_pml_z": bloch_xy_pml_z, "bloch_x_only": bloch_x_only,
     "two_d": two_d, "one_d": one_d, "absorber_mix": absorber_mix, "pmc_plus_mix": pmc_plus_mix, "absorber_odd_rows": absorber_odd_rows,

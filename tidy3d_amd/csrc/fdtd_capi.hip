@@ -20,6 +20,7 @@
 #include "fdtd_kernels.hpp"
 #include "fdtd_fused2.hpp"
 #include "fdtd_strip.hpp"
+#include "fdtd_aniso.hpp"
 
 using namespace fdtd;
 
@@ -56,6 +57,13 @@ struct AdeGroup {
   float* e_old;
   float2* q;
   AdeP p;
+};
+
+struct AnisoGroup {                 // fdtd_aniso.hpp: the off-diagonal coupling of E component `comp` inside fully anisotropic bodies
+  int comp;
+  long long n;
+  uint32_t *cell, *nbr;
+  float *w_new, *w_old, *old, *delta;
 };
 
 struct PointSrc {
@@ -149,6 +157,7 @@ struct FdtdSolver {
   int damp_lo[3] = {0, 0, 0}, damp_hi[3] = {0, 0, 0};   // layers: index < lo or index >= hi
   bool has_damp = false;
   std::vector<AdeGroup> ade;
+  std::vector<AnisoGroup> aniso;
   std::vector<PointSrc> psrc;
   std::vector<Tfsf> tfsf;
   std::vector<Monitor> mons;
@@ -730,6 +739,7 @@ int fused2_why_not(const FdtdSolver* h, bool slab_rank = false, bool shell = fal
   { int W, zc; if (!fused2_shape(h, &W, &zc)) return FDTD_F2_OFF_TOO_SMALL; }
   if (h->comm && !slab_rank) return FDTD_F2_OFF_COMM;
   if (!h->ade.empty() && !shell) return FDTD_F2_OFF_ADE;       // (a shell pair: the planes that hold dispersive cells are a z hole of the bulk)
+  if (!h->aniso.empty()) return FDTD_F2_OFF_ADE;               // fully anisotropic bodies: their coupling follows every single step
   // (sources are judged step by step, fused2_sources_why_not: a TFSF box or a mode plane keeps single steps only while it injects)
   // PEC walls; the min faces may be PMC (the symmetry planes of a half / quarter / eighth domain)
   // (a z-slab rank: a neighbour face is no wall — the sweep stays two planes clear of it, fdtd_run)
@@ -1667,6 +1677,27 @@ void advance_tfsf_aux(FdtdSolver* h, bool e_side, long long n, hipStream_t st, b
   }
 }
 
+// fully anisotropic bodies: E^n of the neighbour nodes, saved in front of the E update ...
+void aniso_save(FdtdSolver* h, hipStream_t st) {
+  for (AnisoGroup& a : h->aniso) {
+    const float* b1 = field_ptr(h, (a.comp + 1) % 3);
+    const float* b2 = field_ptr(h, (a.comp + 2) % 3);
+    hipLaunchKernelGGL(aniso_save_kernel, dim3(nblk(8 * a.n)), dim3(256), 0, st, b1, b2, (const uint32_t*)a.nbr, a.old, 8 * a.n);
+  }
+}
+// ... and the coupling, behind the E update and its sources: every component's correction from the unpatched values, then applied
+void aniso_apply(FdtdSolver* h, hipStream_t st) {
+  for (AnisoGroup& a : h->aniso) {
+    const float* b1 = field_ptr(h, (a.comp + 1) % 3);
+    const float* b2 = field_ptr(h, (a.comp + 2) % 3);
+    hipLaunchKernelGGL(aniso_delta_kernel, dim3(nblk(a.n)), dim3(256), 0, st, b1, b2, (const uint32_t*)a.nbr, (const float*)a.w_new,
+                       (const float*)a.w_old, (const float*)a.old, a.delta, a.n);
+  }
+  for (AnisoGroup& a : h->aniso)
+    hipLaunchKernelGGL(aniso_apply_kernel, dim3(nblk(a.n)), dim3(256), 0, st, field_ptr(h, a.comp), (const uint32_t*)a.cell,
+                       (const float*)a.delta, a.n);
+}
+
 void launch_ade(FdtdSolver* h, int kbeg, int kend, hipStream_t st, const FieldP* fs = nullptr) {
   if (kend <= kbeg) return;
   const long long zlo = (long long)kbeg * h->g.sxy, zhi = (long long)kend * h->g.sxy;
@@ -2231,6 +2262,26 @@ int fdtd_add_ade(FdtdSolver* h, int comp, int64_t n, const uint32_t* cell_index,
   return 0;
 }
 
+int fdtd_add_aniso(FdtdSolver* h, int comp, int64_t n, const uint32_t* cell_index, const uint32_t* nbr_index, const float* w_new,
+                   const float* w_old) {
+  if (!h) return -1;
+  if (comp < 0 || comp > 2) return fail(h, "fdtd_add_aniso: comp must be 0..2");
+  if (n <= 0) return 0;
+  const uint64_t ncell = (uint64_t)n_cells(h);
+  for (int64_t i = 0; i < n; ++i) if (cell_index[i] >= ncell) return fail(h, "fdtd_add_aniso: cell index out of range");
+  for (int64_t q = 0; q < 8 * n; ++q)
+    if (nbr_index[q] != kNoNode && nbr_index[q] >= ncell) return fail(h, "fdtd_add_aniso: neighbour index out of range");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  AnisoGroup a{};
+  a.comp = comp; a.n = n;
+  if (dev_upload(h, &a.cell, cell_index, (size_t)n) || dev_upload(h, &a.nbr, nbr_index, (size_t)8 * n) ||
+      dev_upload(h, &a.w_new, w_new, (size_t)8 * n) || dev_upload(h, &a.w_old, w_old, (size_t)8 * n) ||
+      dev_alloc(h, &a.old, (size_t)8 * n) || dev_alloc(h, &a.delta, (size_t)n))
+    return -1;
+  h->aniso.push_back(a);
+  return 0;
+}
+
 int fdtd_add_point_source(FdtdSolver* h, int64_t n, const int32_t* comp, const uint32_t* cell, const float* w_re,
                           const float* w_im, int64_t n_steps, const float* wave_e, const float* wave_h) {
   if (!h) return -1;
@@ -2486,6 +2537,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   const bool multi = h->comm != nullptr;     // also true for a 1-rank communicator (self exchange)
   const bool nb_lo = h->cfg.bc[4] == FDTD_BC_NEIGHBOR, nb_hi = h->cfg.bc[5] == FDTD_BC_NEIGHBOR;
   if ((nb_lo || nb_hi) && !multi) return fail(h, "fdtd_run: neighbour faces need fdtd_comm_init");
+  if (multi && !h->aniso.empty()) return fail(h, "fdtd_run: fully anisotropic media are not available on z-slabs");
   // (PMC on a plus face of a z-slab rank: x / y walls are local to every plane; a z wall belongs to the rank without an upper
   //  neighbour, whose interior launch must hold the wall's two image planes and the two they mirror)
   // (six planes: the boundary chunk next to the lower neighbour is one plane thick below eight planes, two from there on)
@@ -2644,7 +2696,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   const int tb_req = h->tblock < 0 ? 0 : (h->tblock % 4096);
   const bool tb_two_streams = h->tblock > 4096 && h->stream_overlap == 1;
   const bool tb_ok = fused && tb_req > 0 && !any_pml(h) && h->tfsf.empty() && h->cfg.bc[4] != FDTD_BC_PERIODIC &&
-                     h->mirror_wall[0] < 0 && h->mirror_wall[1] < 0 && h->mirror_wall[2] < 0 &&
+                     h->mirror_wall[0] < 0 && h->mirror_wall[1] < 0 && h->mirror_wall[2] < 0 && h->aniso.empty() &&
                      nz >= 2 * tb_req;
   h->two_step_pairs = 0;
   h->tblock_used = tb_ok ? tb_req : 0;
@@ -2712,6 +2764,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     //  their images beyond an x / y wall are refreshed with the planes they copy; a z-slab rank receives its ghost planes
     //  refreshed by their owner)
     fill_mirror(h, st, h->cfg.bc[4] == FDTD_BC_PERIODIC ? -1 : 0, h->cfg.bc[4] == FDTD_BC_PERIODIC ? nz + 1 : nz);
+    aniso_save(h, st);                     // (E^n of the nodes around fully anisotropic cells: the sweep's read set is this set)
     launch_damp(h, false, 0, nz, st);
     launch_sources(h, false, n, 0, nz, st);
     launch_pml(h, false, 0, nz, st, 7 & ~pml_in);
@@ -2748,6 +2801,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     if (rec_post) record_monitors(h, n, true, st);
     launch_pml(h, true, 0, nz, st, 7 & ~pml_in);
     launch_sources(h, true, n, 0, nz, st);
+    aniso_apply(h, st);
     launch_damp(h, true, 0, nz, st);
     launch_ade(h, 0, nz, st);
     advance_tfsf_aux(h, true, n, st);
@@ -2763,7 +2817,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   // with the three-launch CPML split of large grids, not on z-slabs, not with per-launch timing events.
   const bool split_now = (h->pml_split < 0 ? n_cells(h) >= (1LL << 24) : h->pml_split != 0) && any_pml(h) &&
                          (((h->pml_fused < 0 ? 7 : h->pml_fused) & pml_in_sweep_mask(h)) & 6) != 0;
-  bool graph_ok = fused && !tb_ok && !split_now && !(h->cfg.flags & FDTD_FLAG_TIME_KERNELS) &&
+  bool graph_ok = fused && !tb_ok && !split_now && !(h->cfg.flags & FDTD_FLAG_TIME_KERNELS) && h->aniso.empty() &&
                   h->use_graph > 0;      // on request only: measured on ROCm 7.2 (profiles/r3i) a replayed pair is ~3 us per step
                                          // SLOWER than launching its kernels (64^3 17.6 -> 20.8, 128^3 28.8 -> 31.4, 200^3 81.5 -> 84.0)
   struct GraphRec { const float* set; int parity; hipGraphExec_t exec; };
@@ -3147,9 +3201,11 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
     }
     if (multi && nb_hi) HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
+    aniso_save(h, st);                     // (these kernels update E in place: E^n of the nodes around fully anisotropic cells first)
     launch_e_main(h, e_bot, nz, st);
     launch_pml(h, true, e_bot, nz, st);
     launch_sources(h, true, n, e_bot, nz, st);
+    aniso_apply(h, st);
     launch_damp(h, true, e_bot, nz, st);
     launch_ade(h, e_bot, nz, st);
     advance_tfsf_aux(h, true, n, st);
@@ -3229,6 +3285,7 @@ int fdtd_run_bloch(FdtdSolver* hr, FdtdSolver* hi, int64_t n_steps, const double
                    FdtdProgressFn progress, void* user) {
   if (!hr || !hi) return -1;
   if (hi->comm) return fail(hr, "fdtd_run_bloch: the communicator of a z-slab belongs to the first (real-part) handle");
+  if (!hr->aniso.empty() || !hi->aniso.empty()) return fail(hr, "fdtd_run_bloch: fully anisotropic media are not available together with Bloch boundaries");
   for (int a = 0; a < 3; ++a)
     if (hr->mirror_wall[a] >= 0 || hi->mirror_wall[a] >= 0) return fail(hr, "fdtd_run_bloch: PMC on a plus face is not available together with Bloch boundaries");
   // z-slab decomposition (hr->comm): both parts exchange their ghost planes through the real-part handle's

@@ -252,6 +252,8 @@ class HipEngine:
         # narrow grids: cyclic renaming of the axes so that the best-filled one runs along x (single GPU)
         self.axis_shift = 0
         self.user_zrange = {m.name: (int(m.lo[2]), int(m.hi[2])) for m in spec.monitors}
+        if getattr(spec, "aniso", None):
+            axis_shift = 0                  # (the coupling lists are laid out for the user's axes)
         if _bloch_twin is None and n_ranks == 1 and slab is None and not force_comm and axis_shift != 0:
             layers = tuple((int(f0.num_layers), int(f1.num_layers)) for f0, f1 in spec.pml)
             self.axis_shift = best_axis_shift(spec.shape, layers) if axis_shift is None else int(axis_shift) % 3
@@ -447,6 +449,38 @@ class HipEngine:
                 kap, bet = _cplx_f32(mt.kap[m]), _cplx_f32(mt.bet[m])
                 self._chk(d.fdtd_add_ade(h, c, idx.size, _ptr(idx), len(mt.kap[m]), _ptr(kap),
                                          _ptr(bet), float(mt.cc[m])), "fdtd_add_ade")
+        # fully anisotropic bodies: the off-diagonal coupling lists (spec.AnisoSet) with the weights folded with the material
+        # coefficients of the neighbour nodes — the curl the sweep applied at node j is (E^{n+1} - Ca E^n) / Cb there
+        aniso = getattr(spec, "aniso", None) or []
+        if aniso:
+            if self.n_ranks > 1 or self.force_comm or (z0, z1) != (0, nz):
+                from .exceptions import Tidy3dNotImplementedError
+                raise Tidy3dNotImplementedError("FullyAnisotropicMedium is not available in z-slab (multi-GPU) runs")
+            from .constants import EPSILON_0
+            for st_ in aniso:
+                n = len(st_.ijk)
+                cells = (st_.ijk[:, 2] * sxy + st_.ijk[:, 1] * nx + st_.ijk[:, 0]).astype(np.uint32)
+                nbr = np.full((n, 8), 0xFFFFFFFF, np.uint32)
+                w_new = np.zeros((n, 8), np.float64)
+                w_old = np.zeros((n, 8), np.float64)
+                for slot in range(8):
+                    b = st_.nbr_comp[slot]
+                    j = st_.nbr_ijk[:, slot]
+                    ok = j[:, 0] >= 0
+                    if spec.mat_idx is not None:
+                        mi = spec.mat_idx[b][j[ok, 2], j[ok, 1], j[ok, 0]]
+                        ca_b, cb_b = np.asarray(mt.ca)[mi], np.asarray(mt.cb)[mi]
+                    else:
+                        ca_b, cb_b = np.full(int(ok.sum()), mt.ca[1]), np.full(int(ok.sum()), mt.cb[1])
+                    live = cb_b != 0
+                    wn = np.where(live, (spec.dt / EPSILON_0) * st_.g[ok, slot] / np.where(live, cb_b, 1.0), 0.0)
+                    idx = (j[ok, 2] * sxy + j[ok, 1] * nx + j[ok, 0]).astype(np.uint32)
+                    nbr[ok, slot] = np.where(wn != 0, idx, 0xFFFFFFFF)
+                    w_new[ok, slot] = wn
+                    w_old[ok, slot] = wn * ca_b
+                c32, n32 = np.ascontiguousarray(cells), np.ascontiguousarray(nbr.reshape(-1))
+                wn32, wo32 = _f32(w_new.reshape(-1)), _f32(w_old.reshape(-1))
+                self._chk(d.fdtd_add_aniso(h, int(st_.comp), n, _ptr(c32), _ptr(n32), _ptr(wn32), _ptr(wo32)), "fdtd_add_aniso")
         # sources
         from .spec import BC_PEC
         for s in spec.sources:

@@ -38,7 +38,7 @@ SYMBOLS = (
     "fdtd_add_point_source", "fdtd_add_tfsf", "fdtd_add_monitor", "fdtd_get_monitor",
     "fdtd_set_field", "fdtd_get_field", "fdtd_set_shutoff", "fdtd_comm_unique_id",
     "fdtd_comm_init", "fdtd_run", "fdtd_run_bloch", "fdtd_get_stats", "fdtd_reset", "fdtd_set_option",
-    "fdtd_far_field", "fdtd_set_mirror_plus",
+    "fdtd_far_field", "fdtd_set_mirror_plus", "fdtd_add_aniso",
 )
 
 BC_PEC, BC_PMC, BC_PERIODIC, BC_NEIGHBOR = 0, 1, 2, 3
@@ -106,6 +106,7 @@ class FdtdLib:
         d.fdtd_set_absorber.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int]
         d.fdtd_set_mirror_plus.argtypes = [vp, C.c_int, C.c_int]
         d.fdtd_add_ade.argtypes = [vp, C.c_int, i64, vp, C.c_int, vp, vp, f32]
+        d.fdtd_add_aniso.argtypes = [vp, C.c_int, i64, vp, vp, vp, vp]
         d.fdtd_add_point_source.argtypes = [vp, i64, vp, vp, vp, vp, i64, vp, vp]
         d.fdtd_add_tfsf.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, i64, vp,
                                     i64, vp, vp, vp, vp, i64, vp, vp, vp, vp]

@@ -1257,6 +1257,68 @@ class AnisotropicMedium(_AbstractMedium):
 
 @_register
 @dataclass
+class FullyAnisotropicMedium(_AbstractMedium):
+    """Lossless medium with a full (symmetric, positive-definite, eigenvalues >= 1) permittivity tensor (ref medium.py:5058).  The
+    sweep advances every E component with the diagonal of eps^-1; the off-diagonal coupling is added by a patch behind it
+    (spec.AnisoSet).  A conductivity tensor is not supported."""
+
+    permittivity: Any = ((1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0))
+    conductivity: Any = ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (0.0, 0.0, 0.0))
+    name: Optional[str] = None
+    frequency_range: Optional[Tuple[float, float]] = None
+    allow_gain: Optional[bool] = None
+
+    def __post_init__(self):
+        eps = np.asarray(self.permittivity, float).reshape(3, 3)
+        if not np.allclose(eps, eps.T, atol=1e-6):
+            raise ValidationError("Provided permittivity tensor is not symmetric.")
+        if np.any(np.linalg.eigvalsh(0.5 * (eps + eps.T)) < 1 - 1e-6):
+            raise ValidationError("Main diagonal of provided permittivity tensor is not >= 1.")
+        self.permittivity = tuple(tuple(float(v) for v in row) for row in 0.5 * (eps + eps.T))
+        self.conductivity = tuple(tuple(float(v) for v in row) for row in np.asarray(self.conductivity, float).reshape(3, 3))
+
+    @classmethod
+    def from_diagonal(cls, xx, yy, zz, rotation_matrix, **kw):
+        """The diagonal medium diag(xx, yy, zz) (permittivities) in axes rotated by ``rotation_matrix`` (3 x 3; ref
+        medium.py:5173: R eps R^T)."""
+        R = np.asarray(rotation_matrix, float).reshape(3, 3)
+        d = np.diag([float(getattr(m, "permittivity", m)) for m in (xx, yy, zz)])
+        return cls(permittivity=R @ d @ R.T, **kw)
+
+    @property
+    def eps_tensor(self) -> np.ndarray:
+        return np.asarray(self.permittivity, float)
+
+    @property
+    def inv_tensor(self) -> np.ndarray:
+        return np.linalg.inv(self.eps_tensor)
+
+    @property
+    def is_lossless(self) -> bool:
+        return not np.any(np.asarray(self.conductivity, float))
+
+    def component(self, c: int):
+        """The isotropic medium the sweep uses for E_c: permittivity 1 / [eps^-1]_cc."""
+        return Medium(permittivity=float(1.0 / self.inv_tensor[c, c]))
+
+    @property
+    def n_cfl(self):
+        """ref medium.py FullyAnisotropicMedium.n_cfl: sqrt of the smallest eigenvalue."""
+        return float(np.sqrt(np.min(np.linalg.eigvalsh(self.eps_tensor))))
+
+    def eps_model(self, frequency):
+        """ref medium.py: the mean of the eigenvalues."""
+        return float(np.mean(np.linalg.eigvalsh(self.eps_tensor))) + 0j * np.asarray(frequency, float)
+
+    def eps_diagonal(self, frequency):
+        return tuple(complex(v) for v in np.linalg.eigvalsh(self.eps_tensor))
+
+    def pole_residue(self):
+        raise Tidy3dNotImplementedError("FullyAnisotropicMedium has no scalar pole-residue model (see component(c) and spec.AnisoSet)")
+
+
+@_register
+@dataclass
 class Medium2D(_AbstractMedium):
     """2-D material on a zero-thickness geometry (ref medium.py:6090): ``ss`` / ``tt`` describe the two in-plane components
     (in x, y, z order without the normal) as SHEET quantities — permittivity x thickness, sheet conductivity [S].  The front

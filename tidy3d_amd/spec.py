@@ -40,6 +40,24 @@ class MediumCoeffs:
 
 
 @dataclass
+class AnisoSet:
+    """Off-diagonal coupling of one E component inside fully anisotropic bodies (ref medium.py:5058).  The sweep advances
+    E_a with the diagonal part, (dt / eps0) [eps^-1]_aa curl_a (a table medium of permittivity 1 / [eps^-1]_aa); this adds
+
+        dE_a(i) = (dt / eps0) sum_{b != a} sum_{j in the four E_b nodes around i} g(i, j) curl_b(j),
+        g(i, j) = ([eps^-1]_ab at i + [eps^-1]_ab at j) / 8        (0 outside such bodies)
+
+    — the symmetric average keeps the discrete operator self-adjoint (stable, reciprocal) across body faces; curl_b(j) is
+    recovered from what the sweep did to E_b(j): (E_b^{n+1} - Ca E_b^n) / Cb."""
+
+    comp: int                         # a
+    ijk: np.ndarray                   # [n, 3] nodes (i, j, k)
+    nbr_comp: Tuple[int, ...]         # [8]: slots 0-3 component (a+1)%3, 4-7 component (a+2)%3
+    nbr_ijk: np.ndarray               # [n, 8, 3]; -1 = no node (beyond a non-periodic wall)
+    g: np.ndarray                     # [n, 8] float64
+
+
+@dataclass
 class PmlFace:
     """CPML profile of one face (ref boundary.py:195-254; units of sigma/alpha: 2 eps0/dt)."""
 
@@ -168,6 +186,7 @@ class SolverSpec:
     # E, normal H at index N) are unknowns, everything beyond is the mirror image of the inside — E_tan, H_norm even,
     # E_norm, H_tan odd — refreshed at the start of every step (discretize._discretize_pmc_plus, kernel mirror_fill_kernel)
     mirror_plus: Optional[Tuple[int, int, int]] = None
+    aniso: List[AnisoSet] = field(default_factory=list)   # fully anisotropic bodies: off-diagonal coupling per E component
     shutoff: float = 0.0                                # 0 disables the early stop
     decay_every: int = 0                                # 0 = never evaluate field decay
     decay_ref_step: int = 0                             # steps before this never shut off
