@@ -367,6 +367,9 @@ class OracleFdtd:
         # fully anisotropic bodies (spec.AnisoSet): dE_a(i) = (dt / eps0) sum_j g(i, j) curl_b(j), the curl recovered from what the
         # update above did to E_b(j) — (E_b^{n+1} - Ca E_b^n) / Cb, zero on PEC nodes — all components from the unpatched values
         if aniso:
+            # (the kernels write the wall-tangential E as zero inside the sweep: the curl recovered at a wall node is zero — the
+            #  walls are applied here as well, before the coupling reads those nodes)
+            self._pec_walls()
             deltas = []
             for st in aniso:
                 d = np.zeros(len(st.ijk), dtype=E[0].dtype)
@@ -400,13 +403,16 @@ class OracleFdtd:
             q[0] += bet * np.real(en + eo)[None, :]
             if self.bloch is not None:
                 q[1] += bet * np.imag(en + eo)[None, :]
-        # PEC walls at the min faces (tangential components living on the wall)
+        self._pec_walls()
+
+    def _pec_walls(self):
+        """PEC walls at the min faces (tangential components living on the wall)"""
         for c in range(3):
             for a in range(3):
-                if a != c and spec.bc[a][0] == BC_PEC:
+                if a != c and self.spec.bc[a][0] == BC_PEC:
                     sl = [slice(None)] * 3
                     sl[_ax(a)] = 0
-                    E[c][tuple(sl)] = 0
+                    self.E[c][tuple(sl)] = 0
 
     # ------------------------------------------------------------------ TFSF (1-D auxiliary grid)
     def _tfsf_init(self, t):

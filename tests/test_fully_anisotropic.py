@@ -132,3 +132,57 @@ def test_what_is_refused(emu_lib):
                                     td.Structure(geometry=td.Box(size=(0.6, 0.6, 0.6)), medium=td.Medium(permittivity=2.0))],
                         sources=[td.PointDipole(source_time=PULSE, polarization="Ez")], boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary()))
     assert discretize(sim, n_steps=2).spec.aniso == []
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_bodies_fused_two_pass_and_oracle_agree(seed, emu_lib):
+    """Random tensors (random principal values and rotations), random bodies overlapping each other and ordinary media, random
+    walls and cell sizes: fused sweep == two-pass kernels bit for bit (the coupling lists are the same launches), both <= 2e-5
+    from the oracle."""
+    from cases import DL, PULSE as P3, rel_err
+    from tidy3d_amd import lib as L
+    from tidy3d_amd.engine import HipEngine
+    rng = np.random.default_rng(40 + seed)
+    N = [int(rng.integers(12, 20)) for _ in range(3)]
+    size = tuple(n * DL for n in N)
+
+    def pos():
+        return tuple(float(rng.uniform(-0.3, 0.3) * s) for s in size)
+    structures = []
+    for _ in range(int(rng.integers(1, 4))):
+        R = rot(2, float(rng.uniform(0, 3))) @ rot(1, float(rng.uniform(0, 3))) @ rot(0, float(rng.uniform(0, 3)))
+        med = td.FullyAnisotropicMedium.from_diagonal(*[float(v) for v in rng.uniform(1.0, 8.0, 3)], R)
+        geo = td.Sphere(center=pos(), radius=float(rng.uniform(0.15, 0.3))) if rng.integers(0, 2) else \
+            td.Box(center=pos(), size=tuple(float(rng.uniform(0.2, 0.6) * s) for s in size))
+        structures.append(td.Structure(geometry=geo, medium=med))
+    structures.insert(int(rng.integers(0, len(structures) + 1)),
+                      td.Structure(geometry=td.Box(center=pos(), size=tuple(float(rng.uniform(0.2, 0.5) * s) for s in size)),
+                                   medium=[td.Medium(permittivity=3.0, conductivity=0.02), td.PEC, td.Lorentz(eps_inf=2.0, coeffs=[(1.5, 4e14, 3e13)])][int(rng.integers(0, 3))]))
+    faces = [td.PML(num_layers=3), td.PECBoundary(), td.PMCBoundary(), td.StablePML(num_layers=4)]
+    edges = [td.Boundary.periodic() if rng.integers(0, 4) == 0 else
+             td.Boundary(minus=faces[int(rng.integers(0, 4))], plus=faces[int(rng.choice([0, 1, 3]))]) for _ in range(3)]
+    grid = td.GridSpec.uniform(dl=DL)
+    if rng.integers(0, 2):
+        def coords(n, s_):
+            d = rng.uniform(0.8, 1.2, n)
+            return tuple(np.concatenate(([0.0], np.cumsum(d))) * (s_ / d.sum()) - 0.5 * s_)
+        grid = td.GridSpec(grid_x=td.CustomGridBoundaries(coords=coords(N[0], size[0])), grid_y=td.CustomGridBoundaries(coords=coords(N[1], size[1])),
+                           grid_z=td.CustomGridBoundaries(coords=coords(N[2], size[2])))
+    sim = td.Simulation(size=size, grid_spec=grid, run_time=1e-12, shutoff=0, subpixel=False, structures=structures,
+                        sources=[td.PointDipole(center=pos(), source_time=P3, polarization=str(rng.choice(["Ex", "Ey", "Ez", "Hy"])))],
+                        monitors=[td.FieldTimeMonitor(center=pos(), size=(0.2, 0.2, 0.2), name="t", interval=3, colocate=False),
+                                  td.FieldMonitor(center=pos(), size=(td.inf, td.inf, 0), freqs=[3e14], name="f")],
+                        boundary_spec=td.BoundarySpec(x=edges[0], y=edges[1], z=edges[2]))
+    disc = discretize(sim, n_steps=70)
+    assert disc.spec.aniso
+    ref = OracleFdtd(disc.spec).run()
+    out = []
+    for variant in (L.VARIANT_FUSED, L.VARIANT_ZMARCH):
+        with HipEngine(disc.spec, lib=emu_lib, variant=variant) as e:
+            e.run(30)
+            e.run(40)
+            out.append((e.results(), [e.get_field(c) for c in range(6)]))
+    for k in ref:
+        assert np.array_equal(out[0][0][k], out[1][0][k]), k
+        assert rel_err(out[0][0][k], ref[k]) < 2e-5, (k, rel_err(out[0][0][k], ref[k]))
+    assert all(np.array_equal(a, b) for a, b in zip(out[0][1], out[1][1]))
