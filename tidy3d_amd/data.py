@@ -487,6 +487,9 @@ def permittivity_data(sim, spec: SolverSpec, plan) -> "PermittivityData":
             if isinstance(st.medium, td.Medium2D):
                 continue                   # (a sheet has no volume; its volumetric equivalent on the plane's nodes is not reported here)
             inside = st.geometry.inside(X, Y, Z)
+            if isinstance(st.medium, td.FullyAnisotropicMedium):      # the tensor's own diagonal (ref medium.py eps_comp), not what the sweep uses
+                vals[inside] = st.medium.eps_tensor[c, c]
+                continue
             med = st.medium.component(c) if hasattr(st.medium, "component") else st.medium
             if getattr(med, "is_pec", False):
                 vals[inside] = -1e8 + 0j                      # pec_val, ref constants.py:64
