@@ -19,7 +19,7 @@ def test_random_cross_sections_match_the_reference_solver(seed):
     from oracle.tidy3d_ref_loader import load_mode_solver
     _, solver = load_mode_solver()
     rng = np.random.default_rng(500 + seed)
-    nx, ny = int(rng.integers(30, 52)), int(rng.integers(24, 40))
+    nx, ny = int(rng.integers(26, 42)), int(rng.integers(20, 32))
     sym = (int(rng.choice([0, 0, 1, -1])), int(rng.choice([0, 0, 1, -1])))
     xb = np.concatenate(([0.0], np.cumsum(rng.uniform(0.03, 0.06, nx))))
     yb = np.concatenate(([0.0], np.cumsum(rng.uniform(0.03, 0.055, ny))))
