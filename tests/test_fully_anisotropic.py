@@ -32,9 +32,9 @@ def test_wave_plate_matches_the_jones_calculus():
     per = td.Boundary.periodic()
 
     def run(structures, dl=0.02):
-        sim = td.Simulation(size=(4 * dl, 4 * dl, 6.0), grid_spec=td.GridSpec.uniform(dl=dl), run_time=5e-13, structures=structures, subpixel=False,
-                            sources=[td.UniformCurrentSource(center=(0, 0, -2.0), size=(td.inf, td.inf, 0), source_time=PULSE, polarization="Ex")],
-                            monitors=[td.FieldMonitor(center=(0, 0, 1.5), size=(0, 0, 0), freqs=list(freqs), name="p", fields=["Ex", "Ey"], colocate=False)],
+        sim = td.Simulation(size=(4 * dl, 4 * dl, 4.4), grid_spec=td.GridSpec.uniform(dl=dl), run_time=4e-13, structures=structures, subpixel=False,
+                            sources=[td.UniformCurrentSource(center=(0, 0, -1.4), size=(td.inf, td.inf, 0), source_time=PULSE, polarization="Ex")],
+                            monitors=[td.FieldMonitor(center=(0, 0, 1.3), size=(0, 0, 0), freqs=list(freqs), name="p", fields=["Ex", "Ey"], colocate=False)],
                             boundary_spec=td.BoundarySpec(x=per, y=per, z=td.Boundary.pml(num_layers=12)), shutoff=0)
         disc = discretize(sim)
         sd = assemble(disc, OracleFdtd(disc.spec).run(), log="")
