@@ -149,8 +149,11 @@ def test_full_reference_fixture_parses():
     assert not any(isinstance(s, td.Unsupported) for s in sim.sources)
     # (round 4: Medium2D and the custom dispersive media parse into their own classes; nothing in the sample's structures is left
     #  as a placeholder)
-    assert not any(isinstance(st.medium, td.Unsupported) for st in sim.structures)
+    left = {i: st.medium.type for i, st in enumerate(sim.structures) if isinstance(st.medium, td.Unsupported)}
+    assert left == {28: "Medium with 'nonlinear_spec'", 29: "Medium with 'nonlinear_spec'"}       # (physics this solver does not model: raises when used)
     assert {"Medium2D", "CustomDrude", "CustomLorentz", "CustomDebye", "CustomPoleResidue", "CustomSellmeier"} <= {st.medium.type for st in sim.structures}
+    with pytest.raises(Exception, match="nonlinear_spec"):
+        sim.structures[28].medium.fail()
     from tidy3d_amd.exceptions import SetupError, Tidy3dNotImplementedError
     with pytest.raises(SetupError, match="hdf5"):
         D.make_boundaries(sim)        # the AutoGrid axis asks the TriangleMesh for its bounds: no data in JSON

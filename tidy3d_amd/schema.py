@@ -86,6 +86,11 @@ def parse(obj: Any):
     cls = _REGISTRY.get(tname)
     if cls is None:
         return Unsupported(type=str(tname), raw=obj)
+    # fields that change the physics and that this solver does not model: a medium that carries one becomes a placeholder
+    # that raises when the medium is used — never silently the linear / static medium
+    for k in ("nonlinear_spec", "modulation_spec"):
+        if obj.get(k) is not None:
+            return Unsupported(type=f"{tname} with '{k}'", raw=obj)
     names = {f.name for f in dataclasses.fields(cls)}
     kwargs = {}
     for k, v in obj.items():
@@ -2488,6 +2493,7 @@ class Simulation(_Model):
     shutoff: float = 1e-5
     subpixel: Any = True
     lumped_elements: Tuple[Any, ...] = ()
+    post_norm: Any = 1.0                # (ref simulation.py post_norm: a factor on the recorded fields, used by the adjoint pipeline; only 1 here)
 
     def __post_init__(self):
         self.size = tuple(float(s) for s in self.size)
