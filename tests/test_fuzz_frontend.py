@@ -132,3 +132,26 @@ def test_random_reference_simulations_discretise_as_the_reference_says(td_ref, s
                 assert (got[expect == 1] == 1).all()
         done += 1
     assert done >= 10, done
+
+
+def test_mirror_classes_cover_every_field_of_the_reference_classes(td_ref):
+    """A JSON key the mirror does not know is ignored on parsing — so every field of the reference's pydantic classes must either be
+    a field of the mirror class, or be without effect on the fields (plotting, adjoint bookkeeping), or make the object a placeholder
+    that raises when used (``nonlinear_spec``, ``modulation_spec``).  A new reference field shows up here."""
+    import dataclasses
+    import tidy3d_amd.schema as td
+    harmless = {"attrs", "type", "name", "frequency_range", "allow_gain", "viz_spec", "heat_spec", "plot_params", "version",
+                "background_permittivity", "simulation_type"}
+    loud = {"nonlinear_spec", "modulation_spec"}
+    unknown = {}
+    for name, cls in td._REGISTRY.items():
+        ref = getattr(td_ref, name, None)
+        if ref is None or not hasattr(ref, "__fields__"):
+            continue
+        mine = {f.name for f in dataclasses.fields(cls)}
+        extra = [k for k in ref.__fields__ if k not in mine and k not in harmless and k not in loud]
+        if extra:
+            unknown[name] = extra
+    assert unknown == {}, unknown
+    m = td.parse({"type": "Lorentz", "eps_inf": 2.0, "coeffs": [[1.0, 3e14, 1e13]], "modulation_spec": {"type": "ModulationSpec"}})
+    assert isinstance(m, td.Unsupported) and "modulation_spec" in m.type
