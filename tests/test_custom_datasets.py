@@ -329,3 +329,36 @@ def test_autogrid_sizes_its_steps_with_the_largest_permittivity_of_the_data():
         return np.diff(b)[inside]
     np.testing.assert_allclose(steps(cm), steps(td.Medium(permittivity=9.0)), rtol=1e-12)
     assert steps(cm).max() <= 1.5 / 3.0 / 12 * (1 + 1e-9)
+
+
+def test_custom_anisotropic_and_perturbation_media():
+    """CustomAnisotropicMedium (ref medium.py:5300): each component a spatially varying medium, rasterised at its own E nodes;
+    PerturbationMedium / PerturbationPoleResidue (ref medium.py:5648, :5851): an FDTD run sees the unperturbed medium."""
+    from tidy3d_amd.data import medium_eps_table
+    x = np.array([-0.3, 0.3])
+    exx = np.array([2.0, 4.0])[:, None, None] * np.ones((1, 2, 2))
+    med = td.CustomAnisotropicMedium(
+        xx=td.CustomMedium(permittivity=_spatial(exx, x, [-9, 9], [-9, 9]), interp_method="nearest"),
+        yy=td.Medium(permittivity=3.0),
+        zz=td.CustomDrude(eps_inf=_const(1.5), coeffs=[(_const(4e14), _const(3e13))]))
+    sim = td.Simulation(size=(1, 1, 1), grid_spec=td.GridSpec.uniform(dl=0.05), run_time=1e-14, subpixel=False,
+                        structures=[td.Structure(geometry=td.Box(size=(0.8, 0.4, 0.6)), medium=med)],
+                        sources=[td.PointDipole(source_time=PULSE, polarization="Ez")], boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary()))
+    spec = discretize(sim, n_steps=2).spec
+    eps_of = np.array([m.eps_inf for m in spec.media])
+    xs, _, _ = spec.yee_coords(0)
+    row = eps_of[spec.mat_idx[0][10, 10, :]]
+    inside = np.abs(np.asarray(xs)) <= 0.4
+    np.testing.assert_allclose(row[inside & (np.asarray(xs) < 0)], 2.0, rtol=6e-3)
+    np.testing.assert_allclose(row[inside & (np.asarray(xs) > 0)], 4.0, rtol=6e-3)
+    assert eps_of[spec.mat_idx[1][10, 10, 10]] == pytest.approx(3.0)
+    mz = spec.media[spec.mat_idx[2][10, 10, 10]]
+    assert mz.name.startswith("custom_disp_") and medium_eps_table(spec, 2e14)[spec.mat_idx[2][10, 10, 10]] == pytest.approx(
+        complex(td.Drude(eps_inf=1.5, coeffs=[(4e14, 3e13)]).eps_model(2e14)), rel=1e-9)
+    # perturbation media parse from the reference's JSON form and act as their base media
+    pm = td.parse({"type": "PerturbationMedium", "permittivity": 4.0, "conductivity": 0.01,
+                   "permittivity_perturbation": {"type": "ParameterPerturbation", "heat": {"type": "LinearHeatPerturbation", "coeff": 1e-4, "temperature_ref": 300}}})
+    assert isinstance(pm, td.PerturbationMedium) and pm.pole_residue() == td.Medium(permittivity=4.0, conductivity=0.01).pole_residue()
+    pp = td.parse({"type": "PerturbationPoleResidue", "eps_inf": 2.0, "poles": [[{"real": -1e13, "imag": -2e15}, {"real": 3e14, "imag": 1e15}]]})
+    assert isinstance(pp, td.PerturbationPoleResidue)
+    assert pp.eps_model(2e14) == pytest.approx(td.PoleResidue(eps_inf=2.0, poles=[(-1e13 - 2e15j, 3e14 + 1e15j)]).eps_model(2e14))

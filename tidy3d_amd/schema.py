@@ -1359,6 +1359,48 @@ class Medium2D(_AbstractMedium):
 
 @_register
 @dataclass
+class CustomAnisotropicMedium(AnisotropicMedium):
+    """Diagonally anisotropic medium whose components vary in space (ref medium.py:5300): each of xx / yy / zz a ``CustomMedium`` or a
+    custom dispersive medium, rasterised at the nodes of its own E component."""
+
+    interp_method: Optional[str] = None
+    subpixel: bool = False
+
+    def component(self, c: int):
+        m = super().component(c)
+        if self.interp_method is not None and hasattr(m, "interp_method"):      # ref medium.py:5365-5375: overrides the components' own
+            m = dataclasses.replace(m, interp_method=self.interp_method)
+        return m
+
+
+@_register
+@dataclass
+class PerturbationMedium(Medium):
+    """``Medium`` with heat / charge perturbation models attached (ref medium.py:5648).  An FDTD run sees the UNPERTURBED medium — the
+    reference applies the models only through ``Simulation.perturbed_mediums_copy``, which hands over custom media — so the models are
+    carried along and not used."""
+
+    permittivity_perturbation: Any = None
+    conductivity_perturbation: Any = None
+    perturbation_spec: Any = None
+    interp_method: str = "linear"
+    subpixel: bool = True
+
+
+@_register
+@dataclass
+class PerturbationPoleResidue(PoleResidue):
+    """``PoleResidue`` with perturbation models attached (ref medium.py:5851); the FDTD run sees the unperturbed medium."""
+
+    eps_inf_perturbation: Any = None
+    poles_perturbation: Any = None
+    perturbation_spec: Any = None
+    interp_method: str = "linear"
+    subpixel: bool = True
+
+
+@_register
+@dataclass
 class Structure(_Model):
     """geometry + medium (ref components/structure.py:147)."""
 
