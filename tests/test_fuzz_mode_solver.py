@@ -64,4 +64,15 @@ def test_random_cross_sections_match_the_reference_solver(seed):
     mine = np.concatenate([getattr(r, k)[:, :, 0].ravel() for k in ("Eu", "Ev", "Ew")] + [ETA_0 * getattr(r, k)[:, :, 0].ravel() for k in ("Hu", "Hv", "Hw")])
     ref = np.concatenate([fields[0, c, :, :, 0, 0].ravel() for c in range(3)] + [ETA_0 * fields[1, c, :, :, 0, 0].ravel() for c in range(3)])
     ov = abs(np.vdot(ref, mine)) / (np.linalg.norm(ref) * np.linalg.norm(mine))
+    if ov <= 1 - 1e-4:
+        # two modes a few 1e-6 apart in index (PML corner modes come in such pairs) mix freely inside their pair: the reference's
+        # mode then has to lie in the span of mine of the same index
+        kw = dict(num_modes=3, target_neff=target, num_pml=num_pml, pmc_min=pmc_min, pml_min=pml_min, bend_radius=radius, bend_axis=bend_axis)
+        r = solve_modes_angled(exx, eyy, ezz, xb, yb, freq, theta, phi, **kw) if theta else solve_modes(exx, eyy, ezz, xb, yb, freq, **kw)
+        near = [m for m in range(3) if abs(r.n_complex[m] - n_ref[0]) < 2e-5 * abs(n_ref[0])]
+        assert len(near) > 1, (desc, ov, r.n_complex)
+        span = np.stack([np.concatenate([getattr(r, k)[:, :, m].ravel() for k in ("Eu", "Ev", "Ew")] +
+                                        [ETA_0 * getattr(r, k)[:, :, m].ravel() for k in ("Hu", "Hv", "Hw")]) for m in near], axis=1)
+        q, _ = np.linalg.qr(span)
+        ov = np.linalg.norm(q.conj().T @ ref) / np.linalg.norm(ref)
     assert ov > 1 - 1e-4, (desc, ov)
