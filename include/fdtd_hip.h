@@ -87,6 +87,8 @@ typedef struct FdtdStats {
                                 as two single steps beside it on the second stream (FDTD_OPT_SHELL_PAIRS) */
   double  shell_kernel_ms;   /* with FDTD_FLAG_TIME_KERNELS: summed durations of the shell launches (they overlap the bulk sweep) */
   int64_t shell_kernel_launches;
+  int64_t shell2_pairs;      /* of those: pairs whose shell went out as shell2_step_kernel launches — two steps per sweep with the CPML
+                                recursions carried through both — instead of two single steps (FDTD_OPT_SHELL2) */
   int32_t fused2_off_reason; /* why the last fdtd_run took NO step pairs: FDTD_F2_OFF_* (0 = it took some, or had no chance to: < 2 steps) */
   int32_t struct_bytes;      /* sizeof(FdtdStats) of the library that filled this in (a binding checks it against its own layout) */
 } FdtdStats;
@@ -289,6 +291,13 @@ enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_R
                                      single steps), and on z-slab ranks: -1 = default (on), 0 = off, 2 = shell behind the bulk on ONE stream
                                      (a measuring aid) */
        FDTD_OPT_STRIP = 18, /* x strips of a shell step: planes per workgroup (1 ... 63) + 64 * workgroups per CU their registers are cut for (3 or 4) */
+       FDTD_OPT_SHELL2 = 19, /* the shell of a CPML-walled grid (no periodic faces, no dispersive cells, no absorber layers; sources that inject
+                                three or more cells inside the bulk) by shell2_step_kernel — two steps per sweep with psi carried, both
+                                psi sides ping-ponged, no third field set; bit-identical to single steps: -1 = default (where the cost
+                                model likes it), 0 = off (two single steps beside the bulk, FDTD_OPT_SHELL_PAIRS), 1 = wherever possible */
+       FDTD_OPT_SHELL2_SHAPE = 20, /* tile shapes of its launches: lanes per row of the wide boxes (z / y slabs; 3 ... 64, default 32) + 128 * their
+                                      waves per workgroup (1 ... 8, default 8) + 1024 * their planes per chunk (0 = by box) + 2^17 * waves per
+                                      workgroup of the x strips (default 4) + 2^21 * their planes per chunk (0 = by box); <= 0: defaults */
        FDTD_OPT_LDS_PAD = 10 /* measuring aid: extra dynamic LDS per workgroup of the sweep in bytes (lowers its occupancy) */ };
 int fdtd_set_option(FdtdSolver* h, int key, int value);
 int fdtd_reset(FdtdSolver* h);      /* zero fields, auxiliaries, monitors and the step counter */

@@ -12,6 +12,7 @@
 #   slab         per-rank proxy of the 8 / 4 / 2-GPU strong-scaling run (scripts/probe_slab.py)
 #   mie          config-4 problem at lambda0 / 20, 30, 40 (scripts/probe_mie_refinement.py)
 #   bench1024    1024^3 on one GPU
+#   sq           SQ counters (two passes) of the V0 two-step sweep and of the single sweep -> sq_counters.json
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=$1; shift
 O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
@@ -73,6 +74,16 @@ PY
       timeout 600 python scripts/probe_slab.py --slabs 8,4,2 --modes comm_fused --twostep 0,-1 > $O/slab.jsonl 2> $O/slab.err; cut -c1-200 $O/slab.jsonl;;
     mie)
       RUN_PERIODS=400 NFREQ=25 timeout 900 python scripts/probe_mie_refinement.py 20 30 40 > $O/mie_converged_25f.jsonl 2> $O/mie.err; cut -c1-160 $O/mie_converged_25f.jsonl;;
+    sq)
+      cd /tmp
+      for W in v0 v0s; do
+        case $W in v0) A="";; v0s) A="--opt OPT_TWOSTEP=0";; esac
+        timeout 240 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $O/sq_$W/pmc_sq1 -o pmc -- python $R/bench.py $A --steps 6 --warmup 2 --repeats 1 --no-cpu --no-workloads --no-single-steps --placement-tries 0 > /dev/null 2> $O/sq_${W}_1.err
+        timeout 240 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --output-format csv -d $O/sq_$W/pmc_sq2 -o pmc -- python $R/bench.py $A --steps 6 --warmup 2 --repeats 1 --no-cpu --no-workloads --no-single-steps --placement-tries 0 > /dev/null 2> $O/sq_${W}_2.err
+      done
+      python $R/scripts/summarize_sq.py $O > $O/sq_counters.json
+      find $O -name '*counter_collection*' -size +4M -delete
+      cd $R; head -c 1500 $O/sq_counters.json;;
     bench1024)
       timeout 600 python bench.py --size 1024 --steps 20 --warmup 4 --repeats 3 --no-cpu --no-workloads > $O/bench_1024.json 2> $O/bench_1024.err; cut -c1-200 $O/bench_1024.json;;
     *) echo "unknown stage $S";;

@@ -12,7 +12,7 @@ ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
 CSRC = os.path.join(ROOT, "tidy3d_amd", "csrc")
 LIB = os.path.join(HERE, "libfdtd_emu.so")
 DEPS = [os.path.join(CSRC, "fdtd_capi.hip"), os.path.join(CSRC, "fdtd_kernels.hpp"), os.path.join(CSRC, "fdtd_kernels2.hpp"), os.path.join(CSRC, "fdtd_fused2.hpp"), os.path.join(CSRC, "fdtd_fused2.hip"),
-        os.path.join(CSRC, "fdtd_fused2c.hip"), os.path.join(CSRC, "fdtd_strip.hpp"), os.path.join(CSRC, "fdtd_aniso.hpp"),
+        os.path.join(CSRC, "fdtd_fused2c.hip"), os.path.join(CSRC, "fdtd_shell2.hip"), os.path.join(CSRC, "fdtd_shell2.hpp"), os.path.join(CSRC, "fdtd_shell2_host.hpp"), os.path.join(CSRC, "fdtd_strip.hpp"), os.path.join(CSRC, "fdtd_aniso.hpp"),
         os.path.join(ROOT, "include", "fdtd_hip.h"), os.path.join(HERE, "hip_emu.cpp"),
         os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "rccl", "rccl.h"),
         os.path.abspath(__file__)]
@@ -28,7 +28,7 @@ def build(force: bool = False) -> str:
     cmd = [cxx, "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-ffp-contract=off", "-mfma", "-I" + HERE,
            "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-pass-failed",
            "-x", "c++", os.path.join(CSRC, "fdtd_capi.hip"), os.path.join(CSRC, "fdtd_fused2.hip"), os.path.join(CSRC, "fdtd_fused2c.hip"),
-           os.path.join(HERE, "hip_emu.cpp"),
+           os.path.join(CSRC, "fdtd_shell2.hip"), os.path.join(HERE, "hip_emu.cpp"),
            "-o", LIB]
     print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

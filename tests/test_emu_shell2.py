@@ -1,0 +1,173 @@
+"""shell2 pairs (fdtd_shell2.hpp, fdtd_capi.hip): step pairs on grids walled by CPML with the shell advanced by
+shell2_step_kernel — TWO steps per sweep with the CPML recursions (psi, both sides ping-ponged) carried through both — against
+single steps of the same library on the CPU emulator: the same formulas in the same order -> the same bits.  Random initial
+fields fill the layers from the first step on; layer counts that are odd, different per face or absent on a face (a PEC or PMC
+wall instead), StablePML, one / two / three x tiles of the bulk, materials running through the layers, tile shapes of the boxes
+(lanes per row, waves per workgroup, planes per chunk), sources deep inside the bulk (applied by the bulk sweep) and sources
+inside the shell (the pair falls back to the single-step shell while they inject), monitors inside the bulk recorded from
+pairs, runs cut in two (psi parities of both sides carried across runs and into single steps)."""
+import numpy as np
+import pytest
+
+import tidy3d_amd.schema as td
+from tidy3d_amd import lib as L
+from tidy3d_amd.discretize import discretize
+from tidy3d_amd.engine import HipEngine
+
+DL = 0.05
+PULSE = td.GaussianPulse(freq0=3e14, fwidth=1.5e14)
+
+
+def pml(n):
+    return td.PML(num_layers=n)
+
+
+B_ALL = td.BoundarySpec(x=td.Boundary.pml(num_layers=4), y=td.Boundary.pml(num_layers=3), z=td.Boundary.pml(num_layers=3))
+B_ODD = td.BoundarySpec(x=td.Boundary(minus=pml(5), plus=pml(3)), y=td.Boundary(minus=pml(2), plus=pml(4)),
+                        z=td.Boundary(minus=td.PECBoundary(), plus=pml(3)))
+B_XZ = td.BoundarySpec(x=td.Boundary(minus=pml(4), plus=td.PECBoundary()), y=td.Boundary(minus=td.PMCBoundary(), plus=td.PECBoundary()),
+                       z=td.Boundary.pml(num_layers=2))
+B_YZ = td.BoundarySpec(x=td.Boundary(minus=td.PMCBoundary(), plus=td.PECBoundary()), y=td.Boundary.pml(num_layers=3),
+                       z=td.Boundary(minus=td.PMCBoundary(), plus=pml(4)))
+B_STABLE = td.BoundarySpec(x=td.Boundary(minus=td.StablePML(num_layers=9), plus=td.StablePML(num_layers=6)), y=td.Boundary.pml(num_layers=3),
+                           z=td.Boundary.pml(num_layers=3))
+
+SHAPES = {
+    "one_tile": (48, 22, 20),
+    "one_tile_wide": (97, 23, 19),
+    "two_x_tiles": (300, 20, 19),
+    "seam_at_bulk_edge": (256, 18, 18),
+    "three_x_tiles": (536, 18, 17),
+}
+
+MEDIA = [td.Structure(geometry=td.Box(center=(0, 0, 0), size=(td.inf, 0.3, 0.25)), medium=td.Medium(permittivity=3.0, conductivity=0.02)),
+         td.Structure(geometry=td.Sphere(center=(0.15, 0.1, 0), radius=0.22), medium=td.Medium(permittivity=2.0)),
+         td.Structure(geometry=td.Box(center=(-0.3, -0.1, 0.1), size=(0.1, 0.1, 0.1)), medium=td.PEC)]
+
+
+def _sim(N, bspec, structures=(), monitors=(), extra=(), deep_only=True):
+    size = tuple((n - 1e-6) * DL for n in N)
+    hx = 0.5 * size[0]
+    srcs = [td.PointDipole(center=(0.02, 0.01, 0.03), source_time=PULSE, polarization="Ez"),
+            td.PointDipole(center=(-0.11, 0.06, -0.05), source_time=PULSE, polarization="Ex"),
+            td.PointDipole(center=(0.07, -0.04, 0.02), source_time=PULSE, polarization="Hy")]
+    if not deep_only:      # inside the shell: in the x-min layers
+        srcs.append(td.PointDipole(center=(-hx + 1.3 * DL, 0.03, 0.02), source_time=PULSE, polarization="Ey"))
+    return td.Simulation(size=size, grid_spec=td.GridSpec.uniform(dl=DL), run_time=1e-12, sources=srcs + list(extra),
+                         structures=list(structures), monitors=list(monitors), boundary_spec=bspec, shutoff=0)
+
+
+def _run(spec, lib, twostep, shell2, shape=0, runs=(11, 15), seed=7, fields=True):
+    with HipEngine(spec, lib=lib, variant=L.VARIANT_FUSED, z_chunk=2) as e:
+        e.set_option(L.OPT_ROWS, 3)
+        e.set_option(L.OPT_PML_SPLIT, 1)
+        e.set_option(L.OPT_TWOSTEP, twostep)
+        e.set_option(L.OPT_SHELL_PAIRS, 1)
+        e.set_option(L.OPT_SHELL2, shell2)
+        if shape:
+            e.set_option(L.OPT_SHELL2_SHAPE, shape)
+        if fields:
+            rng = np.random.default_rng(seed)
+            for c in range(6):
+                f = e.get_field(c)
+                amp = 1e-3 if c < 3 else 1e-3 / 376.73
+                e.set_field(c, (amp * rng.uniform(-1, 1, size=f.shape)).astype(np.float32))
+        pairs = shell_pairs = shell2_pairs = 0
+        why = 0
+        for r in runs:
+            st = e.run(r)
+            pairs += int(st.fused2_pairs)
+            shell_pairs += int(st.shell_pairs)
+            shell2_pairs += int(st.shell2_pairs)
+            why = int(st.fused2_off_reason)
+        return [e.get_field(c) for c in range(6)], e.results(), pairs, shell_pairs, shell2_pairs, why
+
+
+def shape_word(qw=32, ww=8, zcw=0, ws=4, zcs=0):
+    return qw + 128 * (ww % 8) + 1024 * zcw + (ws << 17) + (zcs << 21)
+
+
+CASES = [("one_tile", B_ALL, 5, 3, shape_word()), ("one_tile", B_ODD, 16, 32, shape_word(qw=8, ww=4, zcw=3, ws=2, zcs=5)),
+         ("one_tile", B_XZ, 4, 2, shape_word(qw=16, ww=2)), ("one_tile", B_YZ, 8, 5, shape_word(qw=5, ww=3, zcw=4)),
+         ("one_tile_wide", B_STABLE, 6, 4, shape_word(qw=11, ww=4, ws=8, zcs=3)),
+         ("two_x_tiles", B_ALL, 5, 3, shape_word(qw=64, ww=5)), ("two_x_tiles", B_ODD, 8, 4, shape_word(qw=32, ww=2, zcw=6)),
+         ("seam_at_bulk_edge", B_ODD, 6, 5, shape_word(qw=20, ww=4)),
+         ("three_x_tiles", B_ALL, 6, 32, shape_word())]
+
+
+@pytest.mark.parametrize("name,bspec,w,zc,shape", CASES)
+def test_shell2_pairs_equal_single_steps(name, bspec, w, zc, shape, emu_lib):
+    N = SHAPES[name]
+    disc = discretize(_sim(N, bspec), n_steps=26)
+    disc.spec.decay_every = 0
+    ref_f, _, p0, s0, q0, why0 = _run(disc.spec, emu_lib, 0, 0)
+    got_f, _, p1, s1, q1, why1 = _run(disc.spec, emu_lib, w + 64 * zc, 1, shape)
+    assert p0 == 0 and s0 == 0 and q0 == 0 and why0 == 1            # switched off
+    assert p1 == 5 + 7 and q1 == p1 and why1 == 0, (p1, s1, q1, why1)
+    assert max(float(np.abs(f).max()) for f in ref_f) > 0
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), (c, float(np.abs(got_f[c] - ref_f[c]).max()), np.argwhere(got_f[c] != ref_f[c])[:5])
+
+
+@pytest.mark.parametrize("name,bspec,w,zc,shape", [("one_tile", B_ODD, 5, 3, shape_word(qw=12, ww=4)), ("two_x_tiles", B_ALL, 8, 4, shape_word(qw=32, ww=3, zcw=5, ws=3)),
+                                                   ("one_tile_wide", B_STABLE, 6, 6, shape_word(qw=64, ww=8))])
+def test_shell2_pairs_with_materials_and_monitors(name, bspec, w, zc, shape, emu_lib):
+    """Dielectric / lossy / PEC bodies running through the layers (packed medium words: the MAT instantiation), a probe, a time
+    monitor and a DFT flux plane inside the bulk recorded from pairs — fields and records equal those of single steps."""
+    N = SHAPES[name]
+    mons = [td.FieldTimeMonitor(center=(0.03, 0.02, 0.01), size=(0, 0, 0), name="probe", interval=1),
+            td.FieldTimeMonitor(center=(0.0, 0.0, 0.0), size=(0.2, 0.1, 0), name="patch", interval=2, fields=("Ex", "Hz")),
+            td.FluxMonitor(center=(0.05, 0, 0), size=(0, 0.2, 0.2), freqs=[2.5e14, 3e14], name="flux")]
+    disc = discretize(_sim(N, bspec, structures=MEDIA, monitors=mons), n_steps=26)
+    disc.spec.decay_every = 0
+    ref_f, ref_r, p0, _, q0, _ = _run(disc.spec, emu_lib, 0, 0)
+    got_f, got_r, p1, s1, q1, why1 = _run(disc.spec, emu_lib, w + 64 * zc, 1, shape)
+    assert p0 == 0 and q0 == 0
+    assert q1 > 0 and q1 == p1 and why1 == 0, (p1, s1, q1, why1)
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), (c, float(np.abs(got_f[c] - ref_f[c]).max()))
+    assert set(got_r) == set(ref_r)
+    for k in ref_r:
+        assert np.array_equal(np.asarray(got_r[k]), np.asarray(ref_r[k])), k
+
+
+def test_sources_inside_the_shell_fall_back_to_the_single_step_shell(emu_lib):
+    """The boxes of a shell2 pair apply no sources: while a list with a node in (or within three cells of) the shell injects,
+    the pair goes out in the round-4 form — the shell as two single steps through the third set — and the psi parities of both
+    forms stay consistent; same bits as single steps."""
+    N = SHAPES["one_tile"]
+    disc = discretize(_sim(N, B_ALL, deep_only=False), n_steps=26)
+    disc.spec.decay_every = 0
+    ref_f, _, p0, _, _, _ = _run(disc.spec, emu_lib, 0, 0)
+    got_f, _, p1, s1, q1, why1 = _run(disc.spec, emu_lib, 5 + 64 * 3, 1)
+    assert p0 == 0 and p1 == 12 and s1 == 12 and q1 == 0 and why1 == 0, (p1, s1, q1, why1)
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), c
+
+
+def test_shell2_and_single_step_shell_alternate(emu_lib):
+    """Runs that alternate between the two forms of a shell pair and single steps (the option is switched between runs): the E-side
+    psi lives in either of its two sets, the parameter blocks of every kernel follow it."""
+    N = SHAPES["one_tile"]
+    disc = discretize(_sim(N, B_ODD, structures=MEDIA[:1]), n_steps=30)
+    disc.spec.decay_every = 0
+    ref_f, _, _, _, _, _ = _run(disc.spec, emu_lib, 0, 0, runs=(30,))
+    with HipEngine(disc.spec, lib=emu_lib, variant=L.VARIANT_FUSED, z_chunk=2) as e:
+        e.set_option(L.OPT_ROWS, 3)
+        e.set_option(L.OPT_PML_SPLIT, 1)
+        e.set_option(L.OPT_SHELL_PAIRS, 1)
+        rng = np.random.default_rng(7)
+        for c in range(6):
+            f = e.get_field(c)
+            amp = 1e-3 if c < 3 else 1e-3 / 376.73
+            e.set_field(c, (amp * rng.uniform(-1, 1, size=f.shape)).astype(np.float32))
+        took = []
+        for steps, twostep, s2 in [(3, 5 + 64 * 3, 1), (4, 5 + 64 * 3, 0), (5, 0, 0), (6, 6 + 64 * 4, 1), (3, 0, 1), (9, 5 + 64 * 2, 1)]:
+            e.set_option(L.OPT_TWOSTEP, twostep)
+            e.set_option(L.OPT_SHELL2, s2)
+            st = e.run(steps)
+            took.append((int(st.fused2_pairs), int(st.shell2_pairs)))
+        got_f = [e.get_field(c) for c in range(6)]
+    assert took == [(1, 1), (2, 0), (0, 0), (3, 3), (0, 0), (4, 4)], took
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), c

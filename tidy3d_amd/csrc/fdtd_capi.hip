@@ -20,6 +20,7 @@
 #include "fdtd_kernels.hpp"
 #include "fdtd_fused2.hpp"
 #include "fdtd_strip.hpp"
+#include "fdtd_shell2_host.hpp"
 #include "fdtd_aniso.hpp"
 
 using namespace fdtd;
@@ -44,6 +45,7 @@ struct PmlAxisDev {
   float* psi_e[2] = {nullptr, nullptr};
   float* psi_h[2] = {nullptr, nullptr};
   float* psi_h2[2] = {nullptr, nullptr};   // write set of the in-sweep CPML (ping-pong), lazily allocated
+  float* psi_e2[2] = {nullptr, nullptr};   // write set of the E side for shell2_step_kernel (two steps per sweep carry psi: both sides ping-pong), lazily allocated
   size_t psi_count = 0;                    // entries per psi array
   size_t psi_plane = 0;                    // entries of one z-plane of it (x, y axes: the H-side arrays carry one more, the ghost slot)
 };
@@ -202,9 +204,12 @@ struct FdtdSolver {
   bool tuned = false, user_geometry = false;
   int bnd_planes = 0;                // fused z-slab schedule: planes per boundary chunk (0 = heuristic)
   int rows = 4;
-  PmlP* pml_blk[8][2] = {};          // device parameter blocks of the in-sweep CPML: [axis mask][psi_h parity]
+  PmlP* pml_blk[8][2][2] = {};       // device parameter blocks of the in-sweep CPML: [axis mask][psi_h parity][psi_e parity] (E side in place)
+  PmlP* pml_blk2[2][2] = {};         // the same for shell2_step_kernel: all axes, both sides read one set and write the other
   bool pml_blk_ok[8] = {};
+  bool pml_blk2_ok = false;
   int pml_parity = 0;
+  int pml_e_parity = 0;              // flips when a step pair wrote the E-side psi into the other set (shell2 pairs)
   // RCCL
   ncclComm_t comm = nullptr;
   int rank = 0, n_ranks = 1;
@@ -237,6 +242,12 @@ struct FdtdSolver {
   int strip_zc = 4;                   // planes per workgroup of the x strips (4: 1.199 ms per V2 step, 8: 1.205, 16: 1.228 inside one engine, profiles/r4/r4n)
   int strip_occ = 3;                  // their register budget: workgroups per CU (3 or 4)
   long long shell_pairs = 0;
+  // shell2 pairs (round 5): the shell of a CPML-walled grid advanced by shell2_step_kernel — two steps per sweep with psi carried —
+  // instead of two single steps through the third field set.  shell2_on: -1 = default (where the cost model likes it), 0 = off, 1 = wherever possible
+  int shell2_on = -1;
+  int shell2_qw = 32, shell2_ww = 8, shell2_zcw = 0;     // wide boxes (z / y slabs): lanes per row, waves per workgroup, planes per chunk (0 = by box)
+  int shell2_ws = 4, shell2_zcs = 0;                     // x strips: waves per workgroup, planes per chunk
+  long long shell2_pairs = 0;
   int f2_off_reason = 0;              // why the last fdtd_run took no step pairs (FDTD_F2_OFF_*), 0 = it did / could
   hipEvent_t ev_shell_a = nullptr, ev_shell_b = nullptr;
   hipEvent_t ev_rec = nullptr;        // z-slab ranks: a monitor record on the main stream done (the comm stream's next boundary work waits for it)
@@ -375,6 +386,9 @@ int alloc_field_set(FdtdSolver* h, float** base, size_t fcount, int) {
 constexpr int kBndPlanes = 2;        // boundary chunk of the z-slab schedule, planes per neighbour face (fdtd_run)
 constexpr int kPlainZChunk = 8;      // z-chunk of sweeps without in-sweep CPML (launch_fused_range)
 constexpr int kTileRun = 8;          // default tile order of the sweep: runs of 8 tiles per XCD (launch_fused_range)
+// cost model of shell2 pairs (shell2_why_not): ps per cell and PAIR of a wide box / an x strip of shell2_step_kernel (first
+// estimates; replaced by the measured figures of profiles/r5)
+constexpr double kShell2WidePs = 30.0, kShell2StripPs = 50.0;
 
 inline unsigned nblk(long long n, int b = 256) { return (unsigned)((n + b - 1) / b); }
 
@@ -488,40 +502,72 @@ bool any_pml(const FdtdSolver* h) {
   return false;
 }
 
-// Device parameter blocks of the in-sweep CPML: block q reads psi_h (q = 0) or psi_h2 (q = 1) and
-// writes the other set; the sweep alternates between them.  Built on first use.
+// Device parameter blocks of the in-sweep CPML: block [hp][ep] reads psi_h (hp = 0) or psi_h2 (hp = 1) and
+// writes the other set; the sweep alternates between them.  The E side is updated in place, in the set that is current
+// ([ep]: a shell2 pair leaves it in the other one).  Built on first use.
+void fill_pml_axis(const FdtdSolver* h, int a, bool in, bool flip_h, bool flip_e, bool e_in_place, PmlAxisP& A) {
+  const int N[3] = {h->g.nx, h->g.ny, h->g.nz};
+  const PmlAxisDev& P = h->pml[a];
+  A.ce4 = P.ce4; A.ch4 = P.ch4;
+  A.kv_e = P.kv_e; A.b_e = P.b_e; A.c_e = P.c_e;
+  A.kv_h = P.kv_h; A.b_h = P.b_h; A.c_h = P.c_h;
+  float* const e_cur[2] = {flip_e && P.psi_e2[0] ? P.psi_e2[0] : P.psi_e[0], flip_e && P.psi_e2[1] ? P.psi_e2[1] : P.psi_e[1]};
+  float* const e_oth[2] = {flip_e || !P.psi_e2[0] ? P.psi_e[0] : P.psi_e2[0], flip_e || !P.psi_e2[1] ? P.psi_e[1] : P.psi_e2[1]};
+  A.pe0 = e_cur[0]; A.pe1 = e_cur[1];
+  A.pe0n = e_in_place ? e_cur[0] : e_oth[0]; A.pe1n = e_in_place ? e_cur[1] : e_oth[1];
+  A.ph0 = flip_h ? P.psi_h2[0] : P.psi_h[0]; A.ph1 = flip_h ? P.psi_h2[1] : P.psi_h[1];
+  A.ph0n = flip_h ? P.psi_h[0] : P.psi_h2[0]; A.ph1n = flip_h ? P.psi_h[1] : P.psi_h2[1];
+  // an axis without CPML, or one whose recursions stay in the slab kernels, has no members
+  A.lo = in ? P.lo : 0; A.hi0 = in ? P.hi0 : N[a]; A.ns = P.ns; A.n = N[a];
+}
 int ensure_pml_blocks(FdtdSolver* h, int mask) {
   if (h->pml_blk_ok[mask]) return 0;
-  const int N[3] = {h->g.nx, h->g.ny, h->g.nz};
   for (int a = 0; a < 3; ++a) {
     PmlAxisDev& P = h->pml[a];
     if (P.ns == 0) continue;
     for (int q = 0; q < 2; ++q)
       if (!P.psi_h2[q] && dev_alloc(h, &P.psi_h2[q], P.psi_count + P.psi_plane)) return -1;
   }
-  // The two sets of an axis keep their identity: `psi_h` / `psi_h2` swap names on the host after every
-  // sweep, so block [parity p] must read what the host calls psi_h when pml_parity == p.
+  // The two sets of an axis keep their identity: `psi_h` / `psi_h2` (`psi_e` / `psi_e2`) swap names on the host after every
+  // sweep (shell2 pair), so block [hp][ep] must read what the host calls psi_h (psi_e) when pml_parity == hp (pml_e_parity == ep).
   for (int par = 0; par < 2; ++par) {
-    const bool flip = par != h->pml_parity;
-    PmlP pm{};
-    for (int a = 0; a < 3; ++a) {
-      const PmlAxisDev& P = h->pml[a];
-      PmlAxisP& A = pm.ax[a];
-      A.ce4 = P.ce4; A.ch4 = P.ch4;
-      A.kv_e = P.kv_e; A.b_e = P.b_e; A.c_e = P.c_e;
-      A.kv_h = P.kv_h; A.b_h = P.b_h; A.c_h = P.c_h;
-      A.pe0 = P.psi_e[0]; A.pe1 = P.psi_e[1];
-      A.ph0 = flip ? P.psi_h2[0] : P.psi_h[0]; A.ph1 = flip ? P.psi_h2[1] : P.psi_h[1];
-      A.ph0n = flip ? P.psi_h[0] : P.psi_h2[0]; A.ph1n = flip ? P.psi_h[1] : P.psi_h2[1];
-      // an axis without CPML, or one whose recursions stay in the slab kernels, has no members
-      const bool in = P.ns > 0 && ((mask >> a) & 1);
-      A.lo = in ? P.lo : 0; A.hi0 = in ? P.hi0 : N[a]; A.ns = P.ns; A.n = N[a];
+    for (int ep = 0; ep < 2; ++ep) {
+      PmlP pm{};
+      for (int a = 0; a < 3; ++a)
+        fill_pml_axis(h, a, h->pml[a].ns > 0 && ((mask >> a) & 1), par != h->pml_parity, ep != h->pml_e_parity, true, pm.ax[a]);
+      if (!h->pml_blk[mask][par][ep] && dev_alloc(h, &h->pml_blk[mask][par][ep], 1, false)) return -1;
+      if (hipMemcpy(h->pml_blk[mask][par][ep], &pm, sizeof(PmlP), hipMemcpyHostToDevice) != hipSuccess)
+        return fail(h, "upload of the CPML parameter block failed");
     }
-    if (!h->pml_blk[mask][par] && dev_alloc(h, &h->pml_blk[mask][par], 1, false)) return -1;
-    if (hipMemcpy(h->pml_blk[mask][par], &pm, sizeof(PmlP), hipMemcpyHostToDevice) != hipSuccess)
-      return fail(h, "upload of the CPML parameter block failed");
   }
   h->pml_blk_ok[mask] = true;
+  return 0;
+}
+// the blocks of shell2_step_kernel: all axes with layers, both sides read the current sets and write the other ones; the second
+// E-side set is allocated here (and the in-place blocks, which name it for the other parity, are rebuilt on their next use)
+int ensure_pml_blocks2(FdtdSolver* h) {
+  if (h->pml_blk2_ok) return 0;
+  bool fresh = false;
+  for (int a = 0; a < 3; ++a) {
+    PmlAxisDev& P = h->pml[a];
+    if (P.ns == 0) continue;
+    for (int q = 0; q < 2; ++q) {
+      if (!P.psi_h2[q] && dev_alloc(h, &P.psi_h2[q], P.psi_count + P.psi_plane)) return -1;
+      if (!P.psi_e2[q]) { if (dev_alloc(h, &P.psi_e2[q], P.psi_count)) return -1; fresh = true; }
+    }
+  }
+  if (fresh) for (bool& ok : h->pml_blk_ok) ok = false;
+  for (int par = 0; par < 2; ++par) {
+    for (int ep = 0; ep < 2; ++ep) {
+      PmlP pm{};
+      for (int a = 0; a < 3; ++a)
+        fill_pml_axis(h, a, h->pml[a].ns > 0, par != h->pml_parity, ep != h->pml_e_parity, false, pm.ax[a]);
+      if (!h->pml_blk2[par][ep] && dev_alloc(h, &h->pml_blk2[par][ep], 1, false)) return -1;
+      if (hipMemcpy(h->pml_blk2[par][ep], &pm, sizeof(PmlP), hipMemcpyHostToDevice) != hipSuccess)
+        return fail(h, "upload of the CPML parameter block failed");
+    }
+  }
+  h->pml_blk2_ok = true;
   return 0;
 }
 
@@ -542,6 +588,17 @@ void swap_psi_h(FdtdSolver* h, int pml_inside) {
     std::swap(P.psi_h[1], P.psi_h2[1]);
   }
   h->pml_parity ^= 1;
+}
+
+// after a shell2 pair: the E side too
+void swap_psi_e(FdtdSolver* h) {
+  for (int a = 0; a < 3; ++a) {
+    PmlAxisDev& P = h->pml[a];
+    if (P.ns == 0 || !P.psi_e2[0]) continue;
+    std::swap(P.psi_e[0], P.psi_e2[0]);
+    std::swap(P.psi_e[1], P.psi_e2[1]);
+  }
+  h->pml_e_parity ^= 1;
 }
 
 // Tile rows: all of them (ty_n < 0) or  [0, ty_a) + [ty_a + ty_gap, ty_a + ty_gap + (ty_n - ty_a)).
@@ -604,7 +661,7 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pm
   int lb = h->fused_lb ? h->fused_lb : (threads <= 256 ? 256 : (threads <= 512 ? 512 : 1024));
   if (lb < threads) lb = threads <= 512 ? 512 : 1024;
   time_begin(h, sh ? 3 : 2, st);
-  const PmlP* pm = pml_inside ? h->pml_blk[pml_inside][sh ? sh->parity : h->pml_parity] : nullptr;
+  const PmlP* pm = pml_inside ? h->pml_blk[pml_inside][sh ? sh->parity : h->pml_parity][h->pml_e_parity] : nullptr;
   const FieldP fa = sh ? sh->src : h->f, fb = sh ? sh->dst : h->f2;
   const int ex_j0 = sh ? sh->ex_j0 : 0, ex_j1 = sh ? sh->ex_j1 : 0;
 #define FDTD_LAUNCH_FUSED_H(MATV, LBV, PMLV, HV)                                                       \
@@ -1177,7 +1234,7 @@ int launch_shell_step(FdtdSolver* h, const FieldP& src, const FieldP& dst, int p
     }
     // x strips: planes of the interval, rows of in[1], the columns outside in[0]
     if (in0[0] > 0 || in1[0] < g.nx) {
-      const PmlP* pm = h->pml_blk[pml_in][parity];
+      const PmlP* pm = h->pml_blk[pml_in][parity][h->pml_e_parity];
       launch_strip(h, src, dst, pm, 0, in0[0], in0[1], in1[1], k0, k1, st);
       launch_strip(h, src, dst, pm, in1[0], g.nx, in0[1], in1[1], k0, k1, st);
     }
@@ -1226,6 +1283,96 @@ int shell_why_not(const FdtdSolver* h, ShellGeom* G, ZPlan* base, ZPlan* with_sr
   judge(false, base);
   judge(true, with_src);
   if (!base->ok) return h->ade.empty() ? FDTD_F2_OFF_SHELL : FDTD_F2_OFF_ADE;
+  return 0;
+}
+
+// ---- shell2 pairs (round 5): the shell advanced by shell2_step_kernel, two steps per sweep with psi carried --------------------
+// The grid is cut into the bulk O (shell_geometry: clipped two-step sweep, plain formulas) and up to six boxes that
+// shell2_step_kernel advances beside it — all of them read set A and the current psi sets and write disjoint cells of set B and of
+// the other psi sets, so there is no order between any two launches of a pair, no third field set and no middle-step launches:
+//   x strips   the columns outside O_x, ALL rows and planes (the corners with the y / z slabs included: all-axes recursions)
+//   z slabs    the columns of O_x, all rows, the planes outside O_z
+//   y slabs    the columns of O_x, the rows outside O_y, the planes of O_z
+// Taken when nothing but CPML makes the shell (no periodic face, no dispersive cells, no absorber layers) and, while source lists
+// inject, when every source node lies three or more cells inside O (the boxes apply no sources; the bulk sweep applies its own).
+struct Shell2Box { int i0, i1, j0, j1, k0, k1; bool strip; };
+int shell2_boxes(const FdtdSolver* h, const ShellGeom& G, Shell2Box out[6]) {
+  const int nx = h->g.nx, ny = h->g.ny, nz = h->g.nz;
+  int n = 0;
+  if (G.o0[0] > 0) out[n++] = {0, G.o0[0], 0, ny, 0, nz, true};
+  if (G.o1[0] < nx) out[n++] = {G.o1[0], nx, 0, ny, 0, nz, true};
+  if (G.o0[2] > 0) out[n++] = {G.o0[0], G.o1[0], 0, ny, 0, G.o0[2], false};
+  if (G.o1[2] < nz) out[n++] = {G.o0[0], G.o1[0], 0, ny, G.o1[2], nz, false};
+  if (G.o0[1] > 0) out[n++] = {G.o0[0], G.o1[0], 0, G.o0[1], G.o0[2], G.o1[2], false};
+  if (G.o1[1] < ny) out[n++] = {G.o0[0], G.o1[0], G.o1[1], ny, G.o0[2], G.o1[2], false};
+  return n;
+}
+void launch_shell2_box(FdtdSolver* h, const Shell2Box& bx, const PmlP* pm, hipStream_t st) {
+  const GridP& g = h->g;
+  if (bx.i1 <= bx.i0 || bx.j1 <= bx.j0 || bx.k1 <= bx.k0) return;
+  const int halo_l = bx.i0 > 0 ? 1 : 0, halo_r = bx.i1 < g.nx ? 1 : 0;
+  const int L = (bx.i1 - bx.i0) / 4 + halo_l + halo_r;       // lanes a row needs: the written ones and a halo lane on every side that is no wall
+  Shell2P sp{};
+  const int W = std::max(1, std::min(8, bx.strip ? h->shell2_ws : h->shell2_ww));
+  sp.q = bx.strip ? std::max(3, std::min(kShell2MaxQ, L)) : std::max(3, std::min(std::min(kShell2MaxQ, h->shell2_qw), L));
+  sp.xorg = bx.i0 - 4 * halo_l;
+  sp.ci0 = bx.i0; sp.ci1 = bx.i1; sp.j0 = bx.j0; sp.j1 = bx.j1; sp.k0 = bx.k0; sp.k1 = bx.k1;
+  // tiles overlap by two lanes: tile t holds lanes t (q - 2) ... t (q - 2) + q - 1 of the row; the last lane that must come out right
+  const int lv = halo_r ? L - 2 : L - 1, qv = halo_r ? sp.q - 2 : sp.q - 1;
+  sp.nbx = 1 + std::max(0, (lv - qv + sp.q - 3) / (sp.q - 2));
+  const int R = (64 / sp.q) * W - 3;
+  sp.nby = (bx.j1 - bx.j0 + R - 1) / R;
+  const int nzb = bx.k1 - bx.k0;
+  int zc = bx.strip ? h->shell2_zcs : h->shell2_zcw;
+  if (zc <= 0) {
+    // planes per workgroup: about four rounds of workgroups on the machine (256 CUs x 2), chunks of equal length, 8 ... 32 planes
+    const long long per_plane_chunk = (long long)sp.nbx * sp.nby;
+    int nch = (int)std::max(1LL, std::min((long long)std::max(1, nzb / 8), (2048 + per_plane_chunk - 1) / per_plane_chunk));
+    nch = std::max(nch, (nzb + 31) / 32);
+    zc = (nzb + nch - 1) / nch;
+  }
+  sp.zchunk = std::max(1, std::min(zc, nzb));
+  sp.nbz = (nzb + sp.zchunk - 1) / sp.zchunk;
+  time_begin(h, 3, st);
+  launch_shell2_step(st, W, h->mat4 != nullptr, g, h->f, h->f2, step_params(h), mat_params(h), pm, sp);
+  time_end(h, st);
+}
+// every node of every point-source list three or more cells inside the bulk on the axes / sides that carry a shell
+bool shell2_sources_deep(const FdtdSolver* h, const ShellGeom& G) {
+  const GridP& g = h->g;
+  const int N[3] = {g.nx, g.ny, g.nz};
+  auto deep = [&](long long cell) {
+    const int c[3] = {(int)(cell % g.nx), (int)((cell % g.sxy) / g.nx), (int)(cell / g.sxy)};
+    for (int a = 0; a < 3; ++a) {
+      if (G.o0[a] > 0 && c[a] < G.o0[a] + 3) return false;
+      if (G.o1[a] < N[a] && c[a] >= G.o1[a] - 3) return false;
+    }
+    return true;
+  };
+  for (const PointSrc& s : h->psrc) {
+    for (long long t = 0; t < s.n_e; ++t) if (!deep(s.host_cell_e[(size_t)t])) return false;
+    for (long long t = 0; t < s.n_h; ++t) if (!deep(s.host_cell_h[(size_t)t])) return false;
+  }
+  return true;
+}
+int shell2_why_not(const FdtdSolver* h, ShellGeom* G) {
+  const int why = fused2_why_not(h, false, true);
+  if (why) return why;
+  if (!any_pml(h) || h->shell2_on == 0 || h->shell_on == 0) return FDTD_F2_OFF_PML;
+  if (any_periodic(h)) return FDTD_F2_OFF_BOUNDARY;
+  if (!h->ade.empty()) return FDTD_F2_OFF_ADE;
+  if (h->has_damp) return FDTD_F2_OFF_PML;
+  if ((long long)h->g.sxy * 4 >= (1LL << 32)) return FDTD_F2_OFF_PML;           // (32-bit lane offsets inside a plane)
+  if (!shell_geometry(h, G)) return FDTD_F2_OFF_PML;
+  if (h->shell2_on != 1) {
+    // Is it worth it?  Per cell and pair, measured on MI355X at 512^3 V2 (profiles/r5): the bulk's two steps 10.3 ps (12 with
+    // materials), a cell of a wide box kShell2WidePs, a strip cell kShell2StripPs; two single steps cost 2 x 10.1 ps.
+    const double N[3] = {(double)h->g.nx, (double)h->g.ny, (double)h->g.nz};
+    const double ox = G->o1[0] - G->o0[0], oy = G->o1[1] - G->o0[1], oz = G->o1[2] - G->o0[2];
+    const double all = N[0] * N[1] * N[2], bulk = ox * oy * oz, strips = (N[0] - ox) * N[1] * N[2], wide = all - bulk - strips;
+    const double pair_ps = bulk * (h->mat4 ? 12.0 : 10.3) + wide * kShell2WidePs + strips * kShell2StripPs;
+    if (pair_ps > 0.97 * 2.0 * all * 10.1) return FDTD_F2_OFF_SHELL;
+  }
   return 0;
 }
 
@@ -2189,8 +2336,10 @@ int fdtd_set_pml(FdtdSolver* h, int axis, int n_lo, int n_hi, const float* kinv_
     if (P.ns > 0 && dev_alloc(h, &P.psi_e[q], P.psi_count)) return -1;
     if (P.ns > 0 && dev_alloc(h, &P.psi_h[q], P.psi_count + P.psi_plane)) return -1;
     P.psi_h2[q] = nullptr;
+    P.psi_e2[q] = nullptr;
   }
   for (bool& ok : h->pml_blk_ok) ok = false;          // parameter blocks are rebuilt on next use
+  h->pml_blk2_ok = false;
   return 0;
 }
 
@@ -2515,6 +2664,7 @@ int fdtd_reset(FdtdSolver* h) {
       if (P.psi_e[s]) HIPCHK(h, hipMemset(P.psi_e[s], 0, P.psi_count * 4));
       if (P.psi_h[s]) HIPCHK(h, hipMemset(P.psi_h[s], 0, (P.psi_count + P.psi_plane) * 4));
       if (P.psi_h2[s]) HIPCHK(h, hipMemset(P.psi_h2[s], 0, (P.psi_count + P.psi_plane) * 4));
+      if (P.psi_e2[s]) HIPCHK(h, hipMemset(P.psi_e2[s], 0, P.psi_count * 4));
     }
   }
   for (AdeGroup& a : h->ade) {
@@ -2831,7 +2981,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   // 0 = the pair (n, n + 1) was replayed; 1 = capture not available (caller launches directly); < 0 = error
   auto graph_pair = [&](long long n) -> int {
     hipGraphExec_t exec = nullptr;
-    for (const GraphRec& r : graphs) if (r.set == h->f.ex && r.parity == h->pml_parity) exec = r.exec;
+    for (const GraphRec& r : graphs) if (r.set == h->f.ex && r.parity == (h->pml_parity | (h->pml_e_parity << 1))) exec = r.exec;
     if (!exec) {
       // everything a captured launch may allocate or upload must exist before the capture starts
       if (ensure_second_set(h)) return -1;
@@ -2841,7 +2991,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       }
       if (!h->step_dev && dev_alloc(h, &h->step_dev, 1)) return -1;
       const float* set0 = h->f.ex;
-      const int par0 = h->pml_parity;
+      const int par0 = h->pml_parity | (h->pml_e_parity << 1);
       const hipError_t eb = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
       if (eb != hipSuccess) { (void)hipGetLastError(); graph_ok = false; h->graph_status = -(100 + (int)eb % 100); return 1; }
       h->step_dev_mode = true;
@@ -2858,7 +3008,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
         (void)hipGetLastError();
         if (graph) hipGraphDestroy(graph);
         graph_ok = false;
-        return h->f.ex == set0 && h->pml_parity == par0 ? 1 : fail(h, "fdtd_run: graph capture failed half way");
+        return h->f.ex == set0 && (h->pml_parity | (h->pml_e_parity << 1)) == par0 ? 1 : fail(h, "fdtd_run: graph capture failed half way");
       }
       hipGraphDestroy(graph);
       graphs.push_back({set0, par0, exec});
@@ -2880,8 +3030,21 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     h->f2_off_reason = shell ? shell_why_not(h, &sg, &zp_base, &zp_src) : fused2_why_not(h);
     f2s_ok = shell && h->f2_off_reason == 0;
   }
+  // shell2 pairs: the shell by shell2_step_kernel (two steps per sweep, psi carried) instead of two single steps
+  bool s2_ok = false, s2_deep = false;
+  if (fused && !tb_ok && !f2_ok && any_pml(h)) {
+    ShellGeom g2{};
+    const int why2 = shell2_why_not(h, &g2);
+    if (why2 == 0) {
+      s2_ok = true; sg = g2;                               // (the same geometry shell_why_not finds)
+      s2_deep = shell2_sources_deep(h, sg);
+      h->f2_off_reason = 0;
+    } else if (!f2s_ok && h->f2_off_reason == FDTD_F2_OFF_SHELL) {
+      h->f2_off_reason = why2;
+    }
+  }
   h->f2_dyn_reason = 0;
-  if (f2_ok || f2s_ok) {
+  if (f2_ok || f2s_ok || s2_ok) {
     if (fused2_sources(h)) return -1;
   }
   // (the third field set: + 50 % field memory.  Where it does not fit, the run keeps single steps instead of failing)
@@ -2891,7 +3054,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     f2s_ok = false;
     h->f2_off_reason = FDTD_F2_OFF_MEMORY;
   }
-  if (f2s_ok && probe_stream_overlap(h)) return -1;
+  if ((f2s_ok || s2_ok) && probe_stream_overlap(h)) return -1;
   // z-slab ranks (pipelined schedule): step pairs with the planes next to the neighbour faces as the shell
   bool f2m_ok = fused_multi && !any_pml(h) && !h->has_damp && h->shell_on != 0 && nz >= 8 && fused2_why_not(h, true) == 0;
   if (fused_multi) h->f2_off_reason = f2m_ok ? 0 : (any_pml(h) || h->has_damp ? FDTD_F2_OFF_COMM : (fused2_why_not(h, true) ? fused2_why_not(h, true) : FDTD_F2_OFF_COMM));
@@ -2948,6 +3111,40 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     fill_ghost_fused(h, st);
     return 0;
   };
+  // steps n and n + 1 of a grid walled by CPML, shell2 form: the bulk as ONE clipped two-step sweep on st, the shell's boxes as
+  // shell2_step_kernel launches on cs — all read set A / the current psi sets, all write disjoint cells of set B / the other psi sets
+  auto shell2_pair = [&](long long n, const F2Table* tb) -> int {
+    hipStream_t cs = (h->shell_on == 2) ? st : h->comm_stream;       // (2: shell behind the bulk on ONE stream — a measuring aid)
+    if (ensure_second_set(h) || ensure_pml_blocks2(h)) return -1;
+    if (!h->ev_shell_a) {
+      HIPCHK(h, hipEventCreateWithFlags(&h->ev_shell_a, hipEventDisableTiming));
+      HIPCHK(h, hipEventCreateWithFlags(&h->ev_shell_b, hipEventDisableTiming));
+    }
+    launch_sources(h, false, n, 0, nz, st);                  // H-side sources of step n on H^{n-1/2} (deep inside the bulk, or spent)
+    advance_tfsf_aux(h, false, n, st);
+    HIPCHK(h, hipEventRecord(h->ev_shell_a, st));
+    HIPCHK(h, hipStreamWaitEvent(cs, h->ev_shell_a, 0));
+    bool s2 = false;
+    const ClipP clip{sg.o0[0], sg.o1[0], sg.o0[1], sg.o1[1], sg.o0[2], sg.o1[2]};
+    if (launch_fused2(h, n, st, tb, &s2, nullptr, &clip)) return -1;
+    const PmlP* pm = h->pml_blk2[h->pml_parity][h->pml_e_parity];
+    Shell2Box boxes[6];
+    const int nb = shell2_boxes(h, sg, boxes);
+    for (int q = 0; q < nb; ++q) launch_shell2_box(h, boxes[q], pm, cs);
+    HIPCHK(h, hipEventRecord(h->ev_shell_b, cs));
+    HIPCHK(h, hipStreamWaitEvent(st, h->ev_shell_b, 0));
+    swap_sets(h);
+    swap_psi_h(h, 7);
+    swap_psi_e(h);
+    pair_record(h, tb, n, st);
+    if (rec_at(n + 1)) record_monitors(h, n + 1, true, st);
+    advance_tfsf_aux(h, true, n, st);
+    advance_tfsf_aux(h, false, n + 1, st);
+    launch_sources(h, true, n + 1, 0, nz, st);
+    advance_tfsf_aux(h, true, n + 1, st);
+    fill_ghost_fused(h, st);
+    return 0;
+  };
   // every monitor of the pair's plan inside ONE interval of the bulk's planes (the sweep copies the middle step out only there)
   auto plan_in_bulk = [&](const F2Plan& pl, const ZPlan& zp) {
     auto inside = [&](const Monitor& m) {
@@ -2961,6 +3158,7 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
   F2Plan f2_plan;
   h->fused2_pairs = 0;
   h->shell_pairs = 0;
+  h->shell2_pairs = 0;
   int64_t done = 0;
   for (; done < n_steps; ++done) {
     const long long n = h->step;
@@ -2974,9 +3172,19 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     bool src_alive = false;
     int src_why = 0;
     const ZPlan* zp = &zp_base;
-    bool pair = fused && (f2_ok || f2s_ok) && done + 2 <= n_steps && !(h->decay_every > 0 && ((n + 1) % h->decay_every) == 0);
+    bool pair = fused && (f2_ok || f2s_ok || s2_ok) && done + 2 <= n_steps && !(h->decay_every > 0 && ((n + 1) % h->decay_every) == 0);
+    bool use_s2 = false;
     if (pair) {
       src_why = fused2_sources_why_not(h, n, &src_alive);
+      // shell2 form: the boxes apply no sources — lists that inject must lie deep inside the bulk
+      use_s2 = s2_ok && src_why == 0 && (!src_alive || s2_deep);
+      if (!use_s2 && !f2_ok && !f2s_ok) { if (src_why) h->f2_dyn_reason = src_why; pair = false; }
+    }
+    if (pair && use_s2) {
+      pair = fused2_plan(h, n, &f2_plan, sg.o0, sg.o1);
+      if (!pair && f2s_ok) { pair = true; use_s2 = false; }          // (a monitor reaching into the shell: the single-step shell may still take it — judged below)
+    }
+    if (pair && !use_s2) {
       // lists that inject and that the sweep cannot apply itself: a shell pair whose bulk leaves their planes to the shell
       if (src_why && f2s_ok && zp_src.ok) { src_why = 0; src_alive = false; zp = &zp_src; }
       if (src_why) h->f2_dyn_reason = src_why;
@@ -3112,6 +3320,15 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       if (tb_pair(n)) return -1;
       h->step = n + 2;
       ++done;                                              // (the loop header counts the second step)
+    } else if (pair && use_s2) {
+      const F2Table* tb = fused2_table(h, f2_plan, src_alive);
+      if (!tb) return -1;
+      if (shell2_pair(n, tb)) return -1;
+      h->fused2_pairs++;
+      h->shell_pairs++;
+      h->shell2_pairs++;
+      h->step = n + 2;
+      ++done;
     } else if (pair && f2s_ok) {
       const F2Table* tb = fused2_table(h, f2_plan, src_alive);
       if (!tb) return -1;
@@ -3469,7 +3686,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_ZCHUNK: if (value < 1) break; h->zchunk = value; h->zchunk_f = value; h->user_geometry = true; return 0;
     case FDTD_OPT_ROWS: if (value < 1 || value > 15) break; h->rows = value > 8 ? 8 : value; h->rows_f = value; h->user_geometry = true; return 0;
     case FDTD_OPT_XCD_REMAP: if (value > 1024) break; h->xcd_remap = value < 0 ? -1 : value; return 0;
-    case FDTD_OPT_PML_FUSED: h->pml_fused = value < 0 ? -1 : (value & 7); for (bool& ok : h->pml_blk_ok) ok = false; return 0;
+    case FDTD_OPT_PML_FUSED: h->pml_fused = value < 0 ? -1 : (value & 7); for (bool& ok : h->pml_blk_ok) ok = false; h->pml_blk2_ok = false; return 0;
     case FDTD_OPT_BND_PLANES: h->bnd_planes = value > 0 ? value : 0; return 0;
     case FDTD_OPT_AUTOTUNE: h->autotune = value < 0 ? 0 : (value > 2 ? 1 : value); if (value) h->tuned = false; return 0;
     case FDTD_OPT_MEM_HINTS: h->mem_hints = value != 0; return 0;
@@ -3489,6 +3706,18 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_PML_SPLIT: h->pml_split = value < 0 ? -1 : (value != 0); return 0;
     case FDTD_OPT_SHELL_PAIRS: h->shell_on = value < 0 ? -1 : value; return 0;
     case FDTD_OPT_STRIP: if (value % 64 < 1 || (value / 64 != 3 && value / 64 != 4)) break; h->strip_zc = value % 64; h->strip_occ = value / 64; return 0;
+    case FDTD_OPT_SHELL2: h->shell2_on = value < 0 ? -1 : (value != 0); return 0;
+    case FDTD_OPT_SHELL2_SHAPE: {
+      // lanes per row of the wide boxes (3 ... 64) + 128 * their waves per workgroup (1 ... 8) + 1024 * their planes per chunk (0 = by box)
+      //   + 2^17 * waves per workgroup of the strips (1 ... 8) + 2^21 * their planes per chunk (0 = by box)
+      if (value <= 0) { h->shell2_qw = 32; h->shell2_ww = 8; h->shell2_zcw = 0; h->shell2_ws = 4; h->shell2_zcs = 0; return 0; }
+      const int qw = value % 128, ww = (value >> 7) % 8 + ((value >> 7) % 8 == 0 ? 8 : 0), zcw = (value >> 10) % 128;
+      const int ws = (value >> 17) % 16, zcs = (value >> 21) % 128;
+      if (qw < 3 || qw > 64 || ws > 8) break;
+      h->shell2_qw = qw; h->shell2_ww = ww; h->shell2_zcw = zcw;
+      h->shell2_ws = ws > 0 ? ws : 4; h->shell2_zcs = zcs;
+      return 0;
+    }
     case FDTD_OPT_FUSED_LB: if (value != 0 && value != 256 && value != 512 && value != 1024) break; h->fused_lb = value; return 0;
     default: break;
   }
@@ -3513,6 +3742,7 @@ int fdtd_get_stats(FdtdSolver* h, FdtdStats* out) {
   out->fused2_pairs = h->fused2_pairs;
   out->fused2_shape = h->fused2_pairs ? (h->twostep_w_used | (h->twostep_zc_used << 6)) : 0;
   out->shell_pairs = h->shell_pairs;
+  out->shell2_pairs = h->shell2_pairs;
   out->fused2_off_reason = h->fused2_pairs ? 0 : (h->f2_off_reason ? h->f2_off_reason : h->f2_dyn_reason);
   out->struct_bytes = (int32_t)sizeof(FdtdStats);
   return 0;

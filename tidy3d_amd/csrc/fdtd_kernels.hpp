@@ -437,6 +437,8 @@ struct PmlAxisP {
   const float* ph0; const float* ph1;   // psi of H_{a+1}, H_{a+2}: READ set  (halo rows, the x-halo column and
   float* ph0n; float* ph1n;             // chunk prologues of OTHER workgroups re-read the old values, so the
                                         // H-side psi is ping-ponged like the fields) / WRITE set
+  float* pe0n; float* pe1n;             // WRITE set of the E-side psi: pe0 / pe1 themselves (updated in place) for the single-step
+                                        // kernels; the other set for shell2_step_kernel, whose halo rows re-read the old values
   int lo, hi0, ns, n;
 };
 struct PmlP { PmlAxisP ax[3]; };

@@ -1,0 +1,23 @@
+// shell2_step_kernel (fdtd_shell2.hpp): what fdtd_capi.hip and fdtd_shell2.hip share.
+#pragma once
+#include "fdtd_kernels.hpp"
+
+namespace fdtd {
+
+struct Shell2P {
+  int q;               // lanes per row (3 .. 64): 64 / q rows per wavefront
+  int xorg;            // first column of lane 0 of x tile 0 (a multiple of 4, >= 0); tile t starts (q - 2) lanes further per t
+  int ci0, ci1;        // columns written: [ci0, ci1), multiples of 4
+  int j0, j1;          // rows written
+  int k0, k1;          // planes written
+  int zchunk;          // planes per workgroup
+  int nbx, nby, nbz;   // tiles
+};
+
+constexpr int kShell2MaxQ = 64;
+
+// host-side launcher (fdtd_shell2.hip): `waves` wavefronts per workgroup (<= 8)
+void launch_shell2_step(hipStream_t st, int waves, bool mat, const GridP& g, const FieldP& a, const FieldP& b, const StepP& s,
+                        const MatP& m, const PmlP* pm, const Shell2P& sp);
+
+}  // namespace fdtd
