@@ -269,6 +269,8 @@ def secondary_workload(HipEngine, L, n, workload, device, args, steps=40, repeat
             # two steps per sweep: the fields cross the HBM interface once per PAIR (24 B per cell-step); psi moves every step
             # (a lower bound for shell pairs too: their shell — CPML slabs + collar — still moves its fields every step)
             own = 24.0 + (own - 48.0)
+            if int(getattr(st, "shell2_pairs", 0)) > 0:     # shell2 pairs: psi crosses the interface once per PAIR too (both sides ping-ponged)
+                own = 24.0 + 0.5 * (own - 24.0)
         traffic = _workload_traffic(workload, cells, two_step)
         return {"workload": f"{workload}: {WORKLOADS[workload]}", "value": cells * steps / el / 1e6, "unit": "Mcells/s",
                 "ms_per_step": el / steps * 1e3, "steps": steps, "repeats": repeats,
@@ -285,6 +287,9 @@ def secondary_workload(HipEngine, L, n, workload, device, args, steps=40, repeat
                 "traffic_per_step": traffic, "traffic_frac": (traffic / (el / steps) / HBM_PEAK) if traffic else None,
                 "traffic_over_minimum": (traffic / (own * cells)) if traffic else None,
                 "shell_pairs_in_10_steps": int(st.shell_pairs),
+                # of those: pairs whose shell (CPML slabs + collar) went out as shell2_step_kernel launches — two steps per sweep with
+                # psi carried — instead of two single steps (round 5)
+                "shell2_pairs_in_10_steps": int(getattr(st, "shell2_pairs", 0)),
                 "bytes_per_cell_own_minimum": own,
                 "whole_step_frac": own * cells * steps / el / HBM_PEAK,
                 "bytes_per_cell_survey_8d": survey,

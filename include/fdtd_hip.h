@@ -294,10 +294,13 @@ enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_R
        FDTD_OPT_SHELL2 = 19, /* the shell of a CPML-walled grid (no periodic faces, no dispersive cells, no absorber layers; sources that inject
                                 three or more cells inside the bulk) by shell2_step_kernel — two steps per sweep with psi carried, both
                                 psi sides ping-ponged, no third field set; bit-identical to single steps: -1 = default (where the cost
-                                model likes it), 0 = off (two single steps beside the bulk, FDTD_OPT_SHELL_PAIRS), 1 = wherever possible */
-       FDTD_OPT_SHELL2_SHAPE = 20, /* tile shapes of its launches: lanes per row of the wide boxes (z / y slabs; 3 ... 64, default 32) + 128 * their
-                                      waves per workgroup (1 ... 8, default 8) + 1024 * their planes per chunk (0 = by box) + 2^17 * waves per
-                                      workgroup of the x strips (default 4) + 2^21 * their planes per chunk (0 = by box); <= 0: defaults */
+                                model likes it), 0 = off (two single steps beside the bulk, FDTD_OPT_SHELL_PAIRS), 1 = wherever possible, 2 / 3 = wherever possible with
+                                one launch per instantiation (x / y / z only, all axes) / per box (measuring aids) */
+       FDTD_OPT_SHELL2_SHAPE = 20, /* tile shapes of its launches (one per instantiation: x / y / z only, all axes; each over all of its boxes): lanes
+                                      per row of the wide boxes (z / y slabs; 3 ... 64, 0 = by box: the shape that wastes the fewest lane-planes)
+                                      + 128 * waves per workgroup of the all-axes launch (1 ... 8, default 8) + 1024 * planes per chunk of the wide
+                                      boxes (0 = by box) + 2^17 * waves per workgroup of the one-axis launches (1 ... 8, default 6) + 2^21 * planes
+                                      per chunk of the x strips (0 = by box); <= 0: defaults */
        FDTD_OPT_LDS_PAD = 10 /* measuring aid: extra dynamic LDS per workgroup of the sweep in bytes (lowers its occupancy) */ };
 int fdtd_set_option(FdtdSolver* h, int key, int value);
 int fdtd_reset(FdtdSolver* h);      /* zero fields, auxiliaries, monitors and the step counter */

@@ -32,15 +32,21 @@ def main():
         for sh in shifts:
             e = HipEngine(sp, axis_shift=sh)
             held.append(e)
+            import os
+            from tidy3d_amd import lib as L
+            for key, env in ((L.OPT_TWOSTEP, "C3_TWOSTEP"), (L.OPT_SHELL_PAIRS, "C3_SHELL"), (L.OPT_SHELL2, "C3_SHELL2"), (L.OPT_SHELL2_SHAPE, "C3_SHELL2_SHAPE")):
+                if os.environ.get(env):
+                    e.set_option(key, int(os.environ[env]))
             e.run(30)
             ts = []
             for _ in range(3):
                 t0 = time.perf_counter()
-                e.run(steps)
+                st = e.run(steps)
                 ts.append(time.perf_counter() - t0)
             dt = sorted(ts)[1]
             print(json.dumps({"shape": sp.shape, "axis_shift": e.axis_shift, "device_shape": list(e.spec.shape), "ms_per_step": dt / steps * 1e3,
-                              "mcells_per_s": n * steps / dt / 1e6}), flush=True)
+                              "mcells_per_s": n * steps / dt / 1e6,
+                              "fused2_pairs": int(st.fused2_pairs), "shell_pairs": int(st.shell_pairs), "shell2_pairs": int(st.shell2_pairs), "why": int(st.fused2_off_reason)}), flush=True)
     for e in held:
         e.close()
 

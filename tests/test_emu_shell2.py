@@ -58,6 +58,7 @@ def _sim(N, bspec, structures=(), monitors=(), extra=(), deep_only=True):
 
 
 def _run(spec, lib, twostep, shell2, shape=0, runs=(11, 15), seed=7, fields=True):
+    # (shell2 = 1: one launch of the all-axes instantiation over the six boxes; 2: one launch per instantiation over finer boxes; 3: one per box)
     with HipEngine(spec, lib=lib, variant=L.VARIANT_FUSED, z_chunk=2) as e:
         e.set_option(L.OPT_ROWS, 3)
         e.set_option(L.OPT_PML_SPLIT, 1)
@@ -83,14 +84,14 @@ def _run(spec, lib, twostep, shell2, shape=0, runs=(11, 15), seed=7, fields=True
         return [e.get_field(c) for c in range(6)], e.results(), pairs, shell_pairs, shell2_pairs, why
 
 
-def shape_word(qw=32, ww=8, zcw=0, ws=4, zcs=0):
+def shape_word(qw=0, ww=8, zcw=0, ws=4, zcs=0):
     return qw + 128 * (ww % 8) + 1024 * zcw + (ws << 17) + (zcs << 21)
 
 
-CASES = [("one_tile", B_ALL, 5, 3, shape_word()), ("one_tile", B_ODD, 16, 32, shape_word(qw=8, ww=4, zcw=3, ws=2, zcs=5)),
+CASES = [("one_tile", B_ALL, 5, 3, shape_word()), ("one_tile", B_ALL, 5, 3, shape_word(qw=9, ww=7)), ("one_tile_wide", B_ALL, 5, 3, shape_word(qw=21, ww=3)), ("one_tile", B_ODD, 16, 32, shape_word(qw=8, ww=4, zcw=3, ws=2, zcs=5)),
          ("one_tile", B_XZ, 4, 2, shape_word(qw=16, ww=2)), ("one_tile", B_YZ, 8, 5, shape_word(qw=5, ww=3, zcw=4)),
          ("one_tile_wide", B_STABLE, 6, 4, shape_word(qw=11, ww=4, ws=8, zcs=3)),
-         ("two_x_tiles", B_ALL, 5, 3, shape_word(qw=64, ww=5)), ("two_x_tiles", B_ODD, 8, 4, shape_word(qw=32, ww=2, zcw=6)),
+         ("two_x_tiles", B_ALL, 5, 3, shape_word(qw=64, ww=5)), ("two_x_tiles", B_ALL, 5, 3, shape_word(qw=62, ww=5)), ("two_x_tiles", B_STABLE, 7, 3, shape_word(qw=31, ww=6)), ("two_x_tiles", B_ODD, 8, 4, shape_word(qw=32, ww=2, zcw=6)),
          ("seam_at_bulk_edge", B_ODD, 6, 5, shape_word(qw=20, ww=4)),
          ("three_x_tiles", B_ALL, 6, 32, shape_word())]
 
@@ -101,7 +102,7 @@ def test_shell2_pairs_equal_single_steps(name, bspec, w, zc, shape, emu_lib):
     disc = discretize(_sim(N, bspec), n_steps=26)
     disc.spec.decay_every = 0
     ref_f, _, p0, s0, q0, why0 = _run(disc.spec, emu_lib, 0, 0)
-    got_f, _, p1, s1, q1, why1 = _run(disc.spec, emu_lib, w + 64 * zc, 1, shape)
+    got_f, _, p1, s1, q1, why1 = _run(disc.spec, emu_lib, w + 64 * zc, 1 + (w + zc) % 3, shape)
     assert p0 == 0 and s0 == 0 and q0 == 0 and why0 == 1            # switched off
     assert p1 == 5 + 7 and q1 == p1 and why1 == 0, (p1, s1, q1, why1)
     assert max(float(np.abs(f).max()) for f in ref_f) > 0

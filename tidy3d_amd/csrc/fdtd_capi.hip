@@ -245,8 +245,8 @@ struct FdtdSolver {
   // shell2 pairs (round 5): the shell of a CPML-walled grid advanced by shell2_step_kernel — two steps per sweep with psi carried —
   // instead of two single steps through the third field set.  shell2_on: -1 = default (where the cost model likes it), 0 = off, 1 = wherever possible
   int shell2_on = -1;
-  int shell2_qw = 32, shell2_ww = 8, shell2_zcw = 0;     // wide boxes (z / y slabs): lanes per row, waves per workgroup, planes per chunk (0 = by box)
-  int shell2_ws = 4, shell2_zcs = 0;                     // x strips: waves per workgroup, planes per chunk
+  int shell2_qw = 0, shell2_ww = 8, shell2_zcw = 0;      // lanes per row of the wide boxes (z / y slabs; 0 = by box), waves per workgroup of the launch, planes per chunk (0 = by box)
+  int shell2_ws = 6, shell2_zcs = 0;                     // waves per workgroup of the one-axis launches; x strips: planes per chunk (0 = by box)
   long long shell2_pairs = 0;
   int f2_off_reason = 0;              // why the last fdtd_run took no step pairs (FDTD_F2_OFF_*), 0 = it did / could
   hipEvent_t ev_shell_a = nullptr, ev_shell_b = nullptr;
@@ -386,9 +386,12 @@ int alloc_field_set(FdtdSolver* h, float** base, size_t fcount, int) {
 constexpr int kBndPlanes = 2;        // boundary chunk of the z-slab schedule, planes per neighbour face (fdtd_run)
 constexpr int kPlainZChunk = 8;      // z-chunk of sweeps without in-sweep CPML (launch_fused_range)
 constexpr int kTileRun = 8;          // default tile order of the sweep: runs of 8 tiles per XCD (launch_fused_range)
-// cost model of shell2 pairs (shell2_why_not): ps per cell and PAIR of a wide box / an x strip of shell2_step_kernel (first
-// estimates; replaced by the measured figures of profiles/r5)
-constexpr double kShell2WidePs = 30.0, kShell2StripPs = 50.0;
+// cost model of shell2 pairs (shell2_why_not): ps per cell and PAIR, measured on MI355X at 512^3 V2 with each launch alone on
+// the machine (profiles/r5/r5d, r5e): the clipped bulk sweep 12.9 (with materials; 11.3 without), a cell of a wide box 27, a
+// strip cell 41 (the boxes as one launch: 0.69 ms for 21.3 M cells, half of it the strips); the two streams overlap to 0.93 of
+// the sum; a single step costs 10.1 ps per cell.  V2: predicted 0.74 of two single steps, measured 0.76; BASELINE config 3 laid
+// out with x = 224: predicted 0.83, measured 0.86.
+constexpr double kShell2BulkPs = 11.3, kShell2BulkMatPs = 12.9, kShell2WidePs = 27.0, kShell2StripPs = 41.0, kShell2Overlap = 0.93;
 
 inline unsigned nblk(long long n, int b = 256) { return (unsigned)((n + b - 1) / b); }
 
@@ -1295,47 +1298,127 @@ int shell_why_not(const FdtdSolver* h, ShellGeom* G, ZPlan* base, ZPlan* with_sr
 //   y slabs    the columns of O_x, the rows outside O_y, the planes of O_z
 // Taken when nothing but CPML makes the shell (no periodic face, no dispersive cells, no absorber layers) and, while source lists
 // inject, when every source node lies three or more cells inside O (the boxes apply no sources; the bulk sweep applies its own).
-struct Shell2Box { int i0, i1, j0, j1, k0, k1; bool strip; };
-int shell2_boxes(const FdtdSolver* h, const ShellGeom& G, Shell2Box out[6]) {
+struct Shell2Box { int i0, i1, j0, j1, k0, k1; bool strip; int axes; };
+constexpr int kShell2MaxBoxes = 24;
+// Every box is cut so that most of its cells meet the recursions of ONE axis (the middle of an x strip: x; a y slab: y; the
+// middle rows of a z slab: z) — their instantiation carries 32 psi registers instead of 96 — and the edges and corners, where two
+// or three slabs cross, go out as small boxes of the all-axes instantiation.
+int shell2_boxes_by_axes(const FdtdSolver* h, const ShellGeom& G, Shell2Box out[kShell2MaxBoxes]);
+int shell2_boxes(const FdtdSolver* h, const ShellGeom& G, Shell2Box out[kShell2MaxBoxes]) {
+  if (h->shell2_on != 2 && h->shell2_on != 3) {      // the default: six boxes, all of the all-axes instantiation (one launch)
+    const int nx = h->g.nx, ny = h->g.ny, nz = h->g.nz;
+    int n = 0;
+    if (G.o0[0] > 0) out[n++] = {0, G.o0[0], 0, ny, 0, nz, true, 7};
+    if (G.o1[0] < nx) out[n++] = {G.o1[0], nx, 0, ny, 0, nz, true, 7};
+    if (G.o0[2] > 0) out[n++] = {G.o0[0], G.o1[0], 0, ny, 0, G.o0[2], false, 7};
+    if (G.o1[2] < nz) out[n++] = {G.o0[0], G.o1[0], 0, ny, G.o1[2], nz, false, 7};
+    if (G.o0[1] > 0) out[n++] = {G.o0[0], G.o1[0], 0, G.o0[1], G.o0[2], G.o1[2], false, 7};
+    if (G.o1[1] < ny) out[n++] = {G.o0[0], G.o1[0], G.o1[1], ny, G.o0[2], G.o1[2], false, 7};
+    return n;
+  }
+  return shell2_boxes_by_axes(h, G, out);
+}
+int shell2_boxes_by_axes(const FdtdSolver* h, const ShellGeom& G, Shell2Box out[kShell2MaxBoxes]) {
   const int nx = h->g.nx, ny = h->g.ny, nz = h->g.nz;
+  const int ox0 = G.o0[0], ox1 = G.o1[0], oy0 = G.o0[1], oy1 = G.o1[1], oz0 = G.o0[2], oz1 = G.o1[2];
   int n = 0;
-  if (G.o0[0] > 0) out[n++] = {0, G.o0[0], 0, ny, 0, nz, true};
-  if (G.o1[0] < nx) out[n++] = {G.o1[0], nx, 0, ny, 0, nz, true};
-  if (G.o0[2] > 0) out[n++] = {G.o0[0], G.o1[0], 0, ny, 0, G.o0[2], false};
-  if (G.o1[2] < nz) out[n++] = {G.o0[0], G.o1[0], 0, ny, G.o1[2], nz, false};
-  if (G.o0[1] > 0) out[n++] = {G.o0[0], G.o1[0], 0, G.o0[1], G.o0[2], G.o1[2], false};
-  if (G.o1[1] < ny) out[n++] = {G.o0[0], G.o1[0], G.o1[1], ny, G.o0[2], G.o1[2], false};
+  auto add = [&](int i0, int i1, int j0, int j1, int k0, int k1, bool strip, int axes) {
+    if (i1 > i0 && j1 > j0 && k1 > k0) out[n++] = {i0, i1, j0, j1, k0, k1, strip, axes};
+  };
+  // x strips (all rows and planes): the z-slab planes and the y-slab rows of the planes between them as all-axes boxes, the rest x only
+  for (int side = 0; side < 2; ++side) {
+    const int i0 = side == 0 ? 0 : ox1, i1 = side == 0 ? ox0 : nx;
+    if (i1 <= i0) continue;
+    add(i0, i1, 0, ny, 0, oz0, true, 7);
+    add(i0, i1, 0, ny, oz1, nz, true, 7);
+    add(i0, i1, 0, oy0, oz0, oz1, true, 7);
+    add(i0, i1, oy1, ny, oz0, oz1, true, 7);
+    add(i0, i1, oy0, oy1, oz0, oz1, true, 1);
+  }
+  // z slabs (the bulk's columns, all rows): the y-slab rows as all-axes boxes, the rows between them z only
+  for (int side = 0; side < 2; ++side) {
+    const int k0 = side == 0 ? 0 : oz1, k1 = side == 0 ? oz0 : nz;
+    if (k1 <= k0) continue;
+    add(ox0, ox1, 0, oy0, k0, k1, false, 7);
+    add(ox0, ox1, oy1, ny, k0, k1, false, 7);
+    add(ox0, ox1, oy0, oy1, k0, k1, false, 4);
+  }
+  // y slabs (the bulk's columns and planes): y only
+  add(ox0, ox1, 0, oy0, oz0, oz1, false, 2);
+  add(ox0, ox1, oy1, ny, oz0, oz1, false, 2);
   return n;
 }
-void launch_shell2_box(FdtdSolver* h, const Shell2Box& bx, const PmlP* pm, hipStream_t st) {
+// tile shape of one box: lanes per row q for `W` waves per workgroup — the shape that wastes the fewest lane-planes (row slots of
+// the last tile row and the three halo slots, halo lanes and the last x tile's idle lanes, the two extra iterations per chunk)
+void shell2_shape(const FdtdSolver* h, const Shell2Box& bx, int W, Shell2P* out) {
   const GridP& g = h->g;
-  if (bx.i1 <= bx.i0 || bx.j1 <= bx.j0 || bx.k1 <= bx.k0) return;
   const int halo_l = bx.i0 > 0 ? 1 : 0, halo_r = bx.i1 < g.nx ? 1 : 0;
-  const int L = (bx.i1 - bx.i0) / 4 + halo_l + halo_r;       // lanes a row needs: the written ones and a halo lane on every side that is no wall
-  Shell2P sp{};
-  const int W = std::max(1, std::min(8, bx.strip ? h->shell2_ws : h->shell2_ww));
-  sp.q = bx.strip ? std::max(3, std::min(kShell2MaxQ, L)) : std::max(3, std::min(std::min(kShell2MaxQ, h->shell2_qw), L));
-  sp.xorg = bx.i0 - 4 * halo_l;
-  sp.ci0 = bx.i0; sp.ci1 = bx.i1; sp.j0 = bx.j0; sp.j1 = bx.j1; sp.k0 = bx.k0; sp.k1 = bx.k1;
-  // tiles overlap by two lanes: tile t holds lanes t (q - 2) ... t (q - 2) + q - 1 of the row; the last lane that must come out right
-  const int lv = halo_r ? L - 2 : L - 1, qv = halo_r ? sp.q - 2 : sp.q - 1;
-  sp.nbx = 1 + std::max(0, (lv - qv + sp.q - 3) / (sp.q - 2));
-  const int R = (64 / sp.q) * W - 3;
-  sp.nby = (bx.j1 - bx.j0 + R - 1) / R;
-  const int nzb = bx.k1 - bx.k0;
-  int zc = bx.strip ? h->shell2_zcs : h->shell2_zcw;
-  if (zc <= 0) {
-    // planes per workgroup: about four rounds of workgroups on the machine (256 CUs x 2), chunks of equal length, 8 ... 32 planes
-    const long long per_plane_chunk = (long long)sp.nbx * sp.nby;
-    int nch = (int)std::max(1LL, std::min((long long)std::max(1, nzb / 8), (2048 + per_plane_chunk - 1) / per_plane_chunk));
-    nch = std::max(nch, (nzb + 31) / 32);
-    zc = (nzb + nch - 1) / nch;
+  const int lanes_w = (bx.i1 - bx.i0) / 4;
+  const int L = lanes_w + halo_l + halo_r;                   // lanes a row needs: the written ones and a halo lane on every side that is no wall
+  const int rows = bx.j1 - bx.j0, nzb = bx.k1 - bx.k0;
+  Shell2P best{};
+  double best_cost = 0.0;
+  int forced_q = bx.strip ? 0 : h->shell2_qw;
+  if (forced_q > 0 && (64 / std::max(3, std::min(forced_q, L))) * W < 4) forced_q = 0;      // (a shape without a row to write: by box)
+  for (int q = 3; q <= kShell2MaxQ; ++q) {
+    if (forced_q > 0 && q != std::max(3, std::min(forced_q, L))) continue;
+    if (q > std::max(3, L)) break;
+    const int S = (64 / q) * W, R = S - 3;
+    if (R < 1) continue;
+    // tiles overlap by two lanes: tile t holds lanes t (q - 2) ... t (q - 2) + q - 1 of the row; lv = the last lane that must come out right
+    const int lv = halo_r ? L - 2 : L - 1, qv = halo_r ? q - 2 : q - 1;
+    const int nbx = 1 + std::max(0, (lv - qv + q - 3) / (q - 2));
+    const int nby = (rows + R - 1) / R;
+    int zc = bx.strip ? h->shell2_zcs : h->shell2_zcw;
+    if (zc <= 0) {
+      // planes per workgroup: chunks of equal length, 32 planes at most (each chunk pays two extra iterations and a prologue:
+      // 512^3 V2 inside one engine 8 planes 1.054, 16: 1.031 / 1.054, 32: 1.005 / 1.028, 64: 0.998 / 1.026 ms per step, profiles/r5),
+      // shorter where the box alone would otherwise not give the machine a round of workgroups
+      const long long per_chunk = (long long)nbx * nby;
+      int nch = (nzb + 31) / 32;
+      if (per_chunk * nch < 256) nch = (int)std::min((long long)std::max(1, nzb / 8), (256 + per_chunk - 1) / per_chunk);
+      nch = std::max(1, nch);
+      zc = (nzb + nch - 1) / nch;
+    }
+    zc = std::max(1, std::min(zc, nzb));
+    const int nbz = (nzb + zc - 1) / zc;
+    const double cost = (double)nbx * nby * nbz * (zc + 2.5) * W;          // wave-iterations of the launch
+    if (best.q == 0 || cost < best_cost * 0.999) {
+      best_cost = cost;
+      best.q = q; best.xorg = bx.i0 - 4 * halo_l;
+      best.ci0 = bx.i0; best.ci1 = bx.i1; best.j0 = bx.j0; best.j1 = bx.j1; best.k0 = bx.k0; best.k1 = bx.k1;
+      best.zchunk = zc; best.nbx = nbx; best.nby = nby; best.nbz = nbz;
+    }
   }
-  sp.zchunk = std::max(1, std::min(zc, nzb));
-  sp.nbz = (nzb + sp.zchunk - 1) / sp.zchunk;
-  time_begin(h, 3, st);
-  launch_shell2_step(st, W, h->mat4 != nullptr, g, h->f, h->f2, step_params(h), mat_params(h), pm, sp);
-  time_end(h, st);
+  *out = best;
+}
+// The boxes of the shell as ONE launch of the all-axes instantiation (the default): six launches one behind the other left the
+// machine half empty between them (0.92 against 0.69 ms per 512^3 V2 pair alone on the machine, profiles/r5/r5e), and one launch
+// per instantiation — x / y / z only at three waves per SIMD for 94 % of the cells, all axes for the edges and corners — lost
+// more to the four half-empty launches than the third wave bought (0.84 ms, profiles/r5/r5f).  shell2_on = 2 / 3: one launch per
+// instantiation / per box (measuring aids).
+void launch_shell2_boxes(FdtdSolver* h, const Shell2Box* bx, int n, const PmlP* pm, hipStream_t st) {
+  const bool by_axes = h->shell2_on == 2 || h->shell2_on == 3;
+  for (int axes : {1, 4, 2, 7}) {
+    if (!by_axes && axes != 7) continue;
+    Shell2M mb{};
+    const int W = std::max(1, std::min(8, (by_axes && axes != 7) ? h->shell2_ws : h->shell2_ww));
+    auto flush = [&]() {
+      if (mb.n == 0) return;
+      time_begin(h, 3, st);
+      launch_shell2_step(st, W, h->mat4 != nullptr, axes, h->g, h->f, h->f2, step_params(h), mat_params(h), pm, mb);
+      time_end(h, st);
+      mb = Shell2M{};
+    };
+    for (int q = 0; q < n; ++q) {
+      if (by_axes && bx[q].axes != axes) continue;
+      shell2_shape(h, bx[q], W, &mb.box[mb.n]);
+      mb.first[mb.n + 1] = mb.first[mb.n] + mb.box[mb.n].nbx * mb.box[mb.n].nby * mb.box[mb.n].nbz;
+      mb.n++;
+      if (mb.n == kShell2Boxes || h->shell2_on == 3) flush();
+    }
+    flush();
+  }
 }
 // every node of every point-source list three or more cells inside the bulk on the axes / sides that carry a shell
 bool shell2_sources_deep(const FdtdSolver* h, const ShellGeom& G) {
@@ -1364,14 +1447,13 @@ int shell2_why_not(const FdtdSolver* h, ShellGeom* G) {
   if (h->has_damp) return FDTD_F2_OFF_PML;
   if ((long long)h->g.sxy * 4 >= (1LL << 32)) return FDTD_F2_OFF_PML;           // (32-bit lane offsets inside a plane)
   if (!shell_geometry(h, G)) return FDTD_F2_OFF_PML;
-  if (h->shell2_on != 1) {
-    // Is it worth it?  Per cell and pair, measured on MI355X at 512^3 V2 (profiles/r5): the bulk's two steps 10.3 ps (12 with
-    // materials), a cell of a wide box kShell2WidePs, a strip cell kShell2StripPs; two single steps cost 2 x 10.1 ps.
+  if (h->shell2_on < 1) {
+    // Is it worth it?  (constants and their source: kShell2*Ps above)
     const double N[3] = {(double)h->g.nx, (double)h->g.ny, (double)h->g.nz};
     const double ox = G->o1[0] - G->o0[0], oy = G->o1[1] - G->o0[1], oz = G->o1[2] - G->o0[2];
     const double all = N[0] * N[1] * N[2], bulk = ox * oy * oz, strips = (N[0] - ox) * N[1] * N[2], wide = all - bulk - strips;
-    const double pair_ps = bulk * (h->mat4 ? 12.0 : 10.3) + wide * kShell2WidePs + strips * kShell2StripPs;
-    if (pair_ps > 0.97 * 2.0 * all * 10.1) return FDTD_F2_OFF_SHELL;
+    const double pair_ps = kShell2Overlap * (bulk * (h->mat4 ? kShell2BulkMatPs : kShell2BulkPs) + wide * kShell2WidePs + strips * kShell2StripPs);
+    if (pair_ps > 0.95 * 2.0 * all * 10.1) return FDTD_F2_OFF_SHELL;
   }
   return 0;
 }
@@ -3128,9 +3210,9 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     const ClipP clip{sg.o0[0], sg.o1[0], sg.o0[1], sg.o1[1], sg.o0[2], sg.o1[2]};
     if (launch_fused2(h, n, st, tb, &s2, nullptr, &clip)) return -1;
     const PmlP* pm = h->pml_blk2[h->pml_parity][h->pml_e_parity];
-    Shell2Box boxes[6];
+    Shell2Box boxes[kShell2MaxBoxes];
     const int nb = shell2_boxes(h, sg, boxes);
-    for (int q = 0; q < nb; ++q) launch_shell2_box(h, boxes[q], pm, cs);
+    launch_shell2_boxes(h, boxes, nb, pm, cs);
     HIPCHK(h, hipEventRecord(h->ev_shell_b, cs));
     HIPCHK(h, hipStreamWaitEvent(st, h->ev_shell_b, 0));
     swap_sets(h);
@@ -3706,16 +3788,16 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_PML_SPLIT: h->pml_split = value < 0 ? -1 : (value != 0); return 0;
     case FDTD_OPT_SHELL_PAIRS: h->shell_on = value < 0 ? -1 : value; return 0;
     case FDTD_OPT_STRIP: if (value % 64 < 1 || (value / 64 != 3 && value / 64 != 4)) break; h->strip_zc = value % 64; h->strip_occ = value / 64; return 0;
-    case FDTD_OPT_SHELL2: h->shell2_on = value < 0 ? -1 : (value != 0); return 0;
+    case FDTD_OPT_SHELL2: h->shell2_on = value < 0 ? -1 : (value > 3 ? 1 : value); return 0;
     case FDTD_OPT_SHELL2_SHAPE: {
       // lanes per row of the wide boxes (3 ... 64) + 128 * their waves per workgroup (1 ... 8) + 1024 * their planes per chunk (0 = by box)
       //   + 2^17 * waves per workgroup of the strips (1 ... 8) + 2^21 * their planes per chunk (0 = by box)
-      if (value <= 0) { h->shell2_qw = 32; h->shell2_ww = 8; h->shell2_zcw = 0; h->shell2_ws = 4; h->shell2_zcs = 0; return 0; }
+      if (value <= 0) { h->shell2_qw = 0; h->shell2_ww = 8; h->shell2_zcw = 0; h->shell2_ws = 6; h->shell2_zcs = 0; return 0; }
       const int qw = value % 128, ww = (value >> 7) % 8 + ((value >> 7) % 8 == 0 ? 8 : 0), zcw = (value >> 10) % 128;
       const int ws = (value >> 17) % 16, zcs = (value >> 21) % 128;
-      if (qw < 3 || qw > 64 || ws > 8) break;
+      if ((qw != 0 && qw < 3) || qw > 64 || ws > 8) break;
       h->shell2_qw = qw; h->shell2_ww = ww; h->shell2_zcw = zcw;
-      h->shell2_ws = ws > 0 ? ws : 4; h->shell2_zcs = zcs;
+      h->shell2_ws = ws > 0 ? ws : 6; h->shell2_zcs = zcs;
       return 0;
     }
     case FDTD_OPT_FUSED_LB: if (value != 0 && value != 256 && value != 512 && value != 1024) break; h->fused_lb = value; return 0;

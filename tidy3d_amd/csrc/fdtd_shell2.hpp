@@ -34,15 +34,23 @@
 
 namespace fdtd {
 
-template <bool MAT>
-__global__ __launch_bounds__(512) void shell2_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
-                                                          const PmlP* __restrict__ pmq, Shell2P sp) {
+// AXES: the axes whose recursions the boxes of this launch can meet (bit a = axis a): a box off the slabs of an axis — its halo
+// rows / lanes / planes then lie off them too (the collar) — runs an instantiation without that axis' 32 psi registers
+template <bool MAT, int AXES>
+__global__ __launch_bounds__(512, (AXES == 7 ? 2 : 3)) void shell2_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
+                                                          const PmlP* __restrict__ pmq, Shell2M boxes) {
   constexpr int V = 4;
+  // ONE launch covers all boxes of the shell (the workgroups of box q are [first[q], first[q + 1])): six small launches one
+  // behind the other on a stream left the machine half empty between them (profiles/r5)
+  int bq = 0;
+#pragma unroll
+  for (int q = 1; q < kShell2Boxes; ++q) if (q < boxes.n && (int)blockIdx.x >= boxes.first[q]) bq = q;
+  const Shell2P& sp = boxes.box[bq];
   const int Q = sp.q, RW = 64 / Q;
   const int W = blockDim.y;
   const int S = RW * W;                                  // row slots of the workgroup
   const int SL = W * 64;                                 // float4 entries per exchange array
-  const int t = blockIdx.x;
+  const int t = (int)blockIdx.x - boxes.first[bq];
   const int tile_y = t % sp.nby;
   const int tile_x = (t / sp.nby) % sp.nbx;
   const int tile_z = t / (sp.nby * sp.nbx);
@@ -58,7 +66,7 @@ __global__ __launch_bounds__(512) void shell2_step_kernel(GridP g, FieldP a, Fie
   const bool lane_on = tx < Q * RW;                      // (64 is not a multiple of every Q: the last lanes of a wavefront idle)
   const int q = lane_on ? tx % Q : 0, r = lane_on ? tx / Q : 0;
   const int slot_i = ty * RW + r;
-  const int me = lane_on ? slot_i * Q + q : SL - 1 - (ty * 4 + (tx & 3));   // compact index: the row below is me - Q, the row above me + Q (idle lanes: a corner of their own)
+  const int me = lane_on ? slot_i * Q + q : 0;             // compact index: the row below is me - Q, the row above me + Q (idle lanes publish nothing)
   const int mb = slot_i > 0 ? me - Q : me;               // (slot 0 / the top slot read their own entry: what they form from it is never used)
   const int ma = slot_i < S - 1 ? me + Q : me;
   const int R = S - 3;
@@ -91,8 +99,8 @@ __global__ __launch_bounds__(512) void shell2_step_kernel(GridP g, FieldP a, Fie
   const PmlAxisP& AX = pmq->ax[0];
   const PmlAxisP& AY = pmq->ax[1];
   const PmlAxisP& AZ = pmq->ax[2];
-  const int sx = act ? pml_si(AX, i0) : -1;
-  const int sy = row_ok ? pml_si(AY, j) : -1;
+  const int sx = ((AXES & 1) && act) ? pml_si(AX, i0) : -1;
+  const int sy = ((AXES & 2) && row_ok) ? pml_si(AY, j) : -1;
   const unsigned oxb = (unsigned)(j * AX.ns + max(sx, 0)) * 4u;            // the lane's byte offset inside a plane of the x psi arrays
   const unsigned oyb = (unsigned)(max(sy, 0) * g.nx + i0) * 4u;            //                                      ... of the y psi arrays
   const long long xpl = (long long)g.ny * AX.ns, ypl = (long long)AY.ns * g.nx;   // entries per plane of them
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(512) void shell2_step_kernel(GridP g, FieldP a, Fie
   };
   auto put = [&](int w, const float (&v)[V]) __attribute__((always_inline)) {
     float4 t4; t4.x = v[0]; t4.y = v[1]; t4.z = v[2]; t4.w = v[3];
-    xch[w * SL + me] = t4;
+    if (lane_on) xch[w * SL + me] = t4;
   };
   auto get = [&](int w, int at_i, float (&o)[V]) __attribute__((always_inline)) {
     const float4 t4 = xch[w * SL + at_i]; o[0] = t4.x; o[1] = t4.y; o[2] = t4.z; o[3] = t4.w;
@@ -144,6 +152,7 @@ __global__ __launch_bounds__(512) void shell2_step_kernel(GridP g, FieldP a, Fie
   zero<V>(pxh1); zero<V>(pxh2); zero<V>(pyh1); zero<V>(pyh2); zero<V>(pzh1); zero<V>(pzh2);
   zero<V>(pxe1); zero<V>(pxe2); zero<V>(pye1); zero<V>(pye2); zero<V>(pze1); zero<V>(pze2);
   float ipz_m = 0.f, idz_m = 0.f;          // 1 / steps of plane k-1
+  [[maybe_unused]] uint32_t mwm[V] = {kBgWord, kBgWord, kBgWord, kBgWord};       // packed medium words of plane k-1 (S4)
   int sz_m = -1;                           // z membership of plane k-1 and its coefficients
   float4 czh_m = {0.f, 0.f, 0.f, 0.f}, cze_m = {0.f, 0.f, 0.f, 0.f};
   {
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(512) void shell2_step_kernel(GridP g, FieldP a, Fie
     }
     // axis z: Hx += ch (kv dEy/dz + p1), Hy -= ch (kv dEx/dz + p2)
     {
-      const int sz = pml_si(AZ, kk);
+      const int sz = (AXES & 4) ? pml_si(AZ, kk) : -1;
       if (sz >= 0) {
         const float4 cf = ldc_f4(AZ.ch4 + kk);
         float s1[V], s2[V];
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(512) void shell2_step_kernel(GridP g, FieldP a, Fie
     const long long pk = (long long)k * g.sxy;
     const long long up = in_z ? g.sxy : 0;
     const float ipz = s.ipz[k], idz = s.idz[k];          // (the step arrays carry one ghost entry at each end)
-    const int sz = in_z ? pml_si(AZ, k) : -1;
+    const int sz = ((AXES & 4) && in_z) ? pml_si(AZ, k) : -1;
     float4 czh = {0.f, 0.f, 0.f, 0.f}, cze = {0.f, 0.f, 0.f, 0.f};
     if (sz >= 0) { czh = ldc_f4(AZ.ch4 + k); cze = ldc_f4(AZ.ce4 + k); }
     const bool mem_x = sx >= 0 && in_z, mem_y = sy >= 0 && in_z;
@@ -444,8 +453,6 @@ __global__ __launch_bounds__(512) void shell2_step_kernel(GridP g, FieldP a, Fie
         for (int e = 0; e < V; ++e) { h2xm[e] = -h2x[e]; h2ym[e] = -h2y[e]; }
       }
       const bool wall_z = (k - 1 == 0) && !pmc_z0;
-      [[maybe_unused]] uint32_t mwm[V] = {kBgWord, kBgWord, kBgWord, kBgWord};
-      if constexpr (MAT) ldm<V>(mwm, at(uni(m.m4 + pk - g.sxy), ob));
       float ex[V], ey[V], ez[V];
 #pragma unroll
       for (int e = 0; e < V; ++e) {
@@ -542,6 +549,10 @@ __global__ __launch_bounds__(512) void shell2_step_kernel(GridP g, FieldP a, Fie
     }
     ipz_m = ipz; idz_m = idz;
     sz_m = sz; czh_m = czh; cze_m = cze;
+    if constexpr (MAT) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) mwm[e] = mw[e];
+    }
     cur ^= 1;
   }
 }

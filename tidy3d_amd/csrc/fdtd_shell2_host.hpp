@@ -15,9 +15,16 @@ struct Shell2P {
 };
 
 constexpr int kShell2MaxQ = 64;
+constexpr int kShell2Boxes = 12;
+struct Shell2M {
+  int n;                             // boxes of this launch
+  int first[kShell2Boxes + 1];       // workgroups of box q: [first[q], first[q + 1])
+  Shell2P box[kShell2Boxes];
+};
 
-// host-side launcher (fdtd_shell2.hip): `waves` wavefronts per workgroup (<= 8)
-void launch_shell2_step(hipStream_t st, int waves, bool mat, const GridP& g, const FieldP& a, const FieldP& b, const StepP& s,
-                        const MatP& m, const PmlP* pm, const Shell2P& sp);
+// host-side launcher (fdtd_shell2.hip): `waves` wavefronts per workgroup (<= 8); axes: the axes whose recursions the boxes can
+// meet (1, 2, 4: that axis only; anything else: all)
+void launch_shell2_step(hipStream_t st, int waves, bool mat, int axes, const GridP& g, const FieldP& a, const FieldP& b, const StepP& s,
+                        const MatP& m, const PmlP* pm, const Shell2M& boxes);
 
 }  // namespace fdtd
