@@ -106,17 +106,27 @@ def case(rng):
     return N, disc, steps, w, zc, (pmc, "abs" if absorb else (("wave" if wave else "holes") if holes else ("cpml" if cpml else ""))), bool(structures)
 
 
-def run(disc, steps, twostep, split, lib=None):
+def run(disc, steps, twostep, split, lib=None, shell2=1, shape=0):
     with HipEngine(disc.spec, lib=lib, variant=L.VARIANT_FUSED, axis_shift=0) as e:
         e.set_option(L.OPT_TWOSTEP, twostep)
         e.set_option(L.OPT_SHELL_PAIRS, 1)          # CPML grids: shell pairs whatever the cost model says of these small grids
-        pairs = why = 0
+        # the form of a shell pair: 0 = the shell as two single steps (round 4), 1 = as shell2_step_kernel launches (two steps per sweep, psi
+        # carried) wherever that applies, 2 / 3 = the same with one launch per instantiation / per box; and the tile shapes of its boxes
+        e.set_option(L.OPT_SHELL2, shell2)
+        if shape:
+            e.set_option(L.OPT_SHELL2_SHAPE, shape)
+        pairs = why = s2 = 0
         for r in (split, steps - split):
             if r > 0:
                 st = e.run(r)
                 pairs += int(st.fused2_pairs)
+                s2 += int(st.shell2_pairs)
                 why = int(st.fused2_off_reason)
+        S2[0] = s2
         return [e.get_field(c) for c in range(6)], e.results(), pairs, why
+
+
+S2 = [0]
 
 
 def run_cases(n_cases, seed=1, lib=None, quiet=False):
@@ -126,13 +136,18 @@ def run_cases(n_cases, seed=1, lib=None, quiet=False):
     for q in range(n_cases):
         N, disc, steps, w, zc, pmc, mat = case(rng)
         split = int(rng.integers(0, steps))
+        # (drawn from a generator of their own: the simulations of a seed stay those of round 4)
+        r2 = np.random.default_rng([seed, q, 5])
+        shell2 = int(r2.integers(0, 4))
+        qw = int(r2.choice([0, 0, int(r2.integers(3, 65))]))
+        shape = qw + 128 * int(r2.integers(1, 8)) + 1024 * int(r2.choice([0, int(r2.integers(1, 40))])) + (int(r2.integers(1, 9)) << 17) + (int(r2.choice([0, int(r2.integers(1, 40))])) << 21)
         ref_f, ref_m, p0, _ = run(disc, steps, 0, split, lib)
-        got_f, got_m, p1, why = run(disc, steps, w + 64 * zc, split, lib)
+        got_f, got_m, p1, why = run(disc, steps, w + 64 * zc, split, lib, shell2, shape)
         ok = p0 == 0 and all(np.array_equal(a, b) for a, b in zip(ref_f, got_f)) and all(np.array_equal(ref_m[k], got_m[k]) for k in ref_m)
         amp = max(float(np.abs(f).max()) for f in ref_f)
         if not quiet or not ok:
             print(f"case {q}: N={disc.spec.shape} steps={steps} split={split} W={w} zc={zc} pmc={pmc} media={mat} monitors={len(ref_m)} "
-                  f"pairs={p1}{'' if p1 else ' (reason %d)' % why} max|F|={amp:.3g} -> {'ok' if ok else 'MISMATCH'}", flush=True)
+                  f"pairs={p1}{'' if p1 else ' (reason %d)' % why} shell2={shell2}:{S2[0]} max|F|={amp:.3g} -> {'ok' if ok else 'MISMATCH'}", flush=True)
         bad += not ok
         taken += p1 > 0
     return bad, taken

@@ -172,3 +172,16 @@ def test_shell2_and_single_step_shell_alternate(emu_lib):
     assert took == [(1, 1), (2, 0), (0, 0), (3, 3), (0, 0), (4, 4)], took
     for c in range(6):
         assert np.array_equal(got_f[c], ref_f[c]), c
+
+
+def test_random_simulations_in_shell2_pairs(emu_lib):
+    """scripts/fuzz_shell2.py on the emulator: random grids, walls (CPML / StablePML of random thickness, PEC, PMC on min faces), bodies
+    through the layers, random initial fields, dipoles deep inside the bulk, monitors inside the bulk, split runs, the three forms
+    of the launches and random tile shapes of the boxes — shell2 pairs == single steps, bit for bit (the GPU suite runs 40 more)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_shell2", os.path.join(os.path.dirname(__file__), "..", "scripts", "fuzz_shell2.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, taken = mod.run_cases(6, seed=21, lib=emu_lib, quiet=True, small=True)
+    assert bad == 0 and taken >= 5, (bad, taken)

@@ -554,6 +554,21 @@ def test_randomised_two_step_self_check_on_the_device(hip_lib):
     assert taken >= 42, taken          # (cases whose random features keep single steps are few)
 
 
+def test_randomised_shell2_pairs_on_the_device(hip_lib):
+    """scripts/fuzz_shell2.py inside the driver-run suite: 40 seeded random CPML-walled simulations (1 - 3 x tiles of the bulk, CPML /
+    StablePML of random thickness, PEC, PMC on min faces, bodies through the layers, random initial fields, dipoles deep inside the
+    bulk, monitors inside it, split runs, the three launch forms and random tile shapes of the boxes) — the shell advanced by
+    shell2_step_kernel (two steps per sweep, psi carried and ping-ponged) == single steps, bit for bit (fields and every record)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_shell2", os.path.join(os.path.dirname(__file__), "..", "scripts", "fuzz_shell2.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    bad, taken = fz.run_cases(40, seed=5, lib=hip_lib, quiet=True)
+    assert bad == 0
+    assert taken >= 36, taken
+
+
 def test_randomised_variant_cross_check_on_the_device(hip_lib):
     """scripts/fuzz_variants.py inside the driver-run suite: 40 seeded random simulations (walls of every kind per face incl. PMC on
     plus faces, CPML / StablePML / absorber layers, periodic axes; dielectric, lossy, PEC, Lorentz and Drude bodies; dipoles of both

@@ -8,6 +8,8 @@ oracle directly:
       (their pairs give way) — pairs == single steps bit for bit (fields and records), and <= 2e-5 from the oracle;
   (c) the bench V2 spec (materials + 12 CPML layers on six faces, random initial fields) at 320^3 and at BASELINE's 512^3:
       pairs == single steps bit for bit, three times over (two streams: a race would show as differing bits).
+Round 5: the same tests cover both forms of a shell pair — the shell as shell2_step_kernel launches (two steps per sweep with the
+CPML recursions carried, fdtd_shell2.hpp; the default wherever it applies) and as two single steps through the third field set.
 """
 import numpy as np
 import pytest
@@ -23,11 +25,19 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-5
 
 
-def _run(spec, lib, twostep=-1, init=None, steps=None, runs=None, shell=1):
-    """shell = 1: shell pairs whatever the cost model says of the grid (these tests are about bits, not about speed); -1: its call"""
+S2_PAIRS = [0]      # shell2 pairs of the last _run
+
+
+def _run(spec, lib, twostep=-1, init=None, steps=None, runs=None, shell=1, shell2=1):
+    """shell = 1: shell pairs whatever the cost model says of the grid (these tests are about bits, not about speed); -1: its call.
+    shell2 = 1: the shell as shell2_step_kernel launches (two steps per sweep, psi carried) wherever that form applies — the
+    round-4 form (two single steps through the third set) where it does not (sources inside the shell while they inject,
+    periodic faces, dispersive cells); 0: the round-4 form only"""
     with HipEngine(spec, lib=lib, axis_shift=0) as e:
         e.set_option(L.OPT_TWOSTEP, twostep)
         e.set_option(L.OPT_SHELL_PAIRS, shell)
+        e.set_option(L.OPT_SHELL2, shell2)
+        S2_PAIRS[0] = 0
         if init is not None:
             for c in range(6):
                 e.set_field(c, init[c])
@@ -35,6 +45,7 @@ def _run(spec, lib, twostep=-1, init=None, steps=None, runs=None, shell=1):
         for r in (runs or [steps]):
             st = e.run(r)
             pairs += int(st.shell_pairs)
+            S2_PAIRS[0] += int(st.shell2_pairs)
         return [e.get_field(c) for c in range(6)], e.results(), pairs
 
 
@@ -50,8 +61,10 @@ def test_parity_cases_through_shell_pairs_vs_oracle(name, w, zc, hip_lib):
     disc = discretize(sim, n_steps=100)
     o = OracleFdtd(disc.spec)
     ref = o.run()
-    f, got, pairs = _run(disc.spec, hip_lib, twostep=w + 64 * zc)
+    f, got, pairs = _run(disc.spec, hip_lib, twostep=w + 64 * zc, shell2=(w + zc) % 2)
     assert pairs > (20 if name != "drude_in_pml" else 10), (name, pairs)      # (drude_in_pml: its DFT plane spans the layers, records end pairs)
+    if name in ("pml_box", "stable_pml_box") and (w + zc) % 2:               # (CPML only: the shell2 form, once the dipole's margin allows)
+        print(f"\n[{name}] {pairs} shell pairs, {S2_PAIRS[0]} of them in the shell2 form")
     scale = max(np.linalg.norm(v) / np.sqrt(v.size) for v in ref.values())
     for k in ref:
         den = max(np.linalg.norm(ref[k]), 0.5 * scale * np.sqrt(ref[k].size))
@@ -93,8 +106,8 @@ def test_three_x_tiles_shell_pairs_bit_identical_and_oracle(hip_lib):
     assert spec.shape == (520, 72, 72), spec.shape
     ref_f, ref_m, p0 = _run(spec, hip_lib, twostep=0, runs=[25, 35])
     assert p0 == 0
-    for ts in (-1, 5 + 64 * 7, 16 + 64 * 32):
-        f, m, p1 = _run(spec, hip_lib, twostep=ts, runs=[25, 35])
+    for ts, s2 in ((-1, 1), (5 + 64 * 7, 0), (16 + 64 * 32, 1)):
+        f, m, p1 = _run(spec, hip_lib, twostep=ts, runs=[25, 35], shell2=s2)
         assert p1 > 8, (ts, p1)
         for c in range(6):
             assert np.array_equal(f[c], ref_f[c]), (ts, c, float(np.abs(f[c] - ref_f[c]).max()))
@@ -129,9 +142,10 @@ def test_bench_v2_spec_shell_pairs_equal_single_steps(n, steps, hip_lib):
     init = _bench_init(n)
     ref, _, p0 = _run(spec, hip_lib, twostep=0, init=init, steps=steps)
     assert p0 == 0 and all(np.isfinite(x).all() for x in ref) and max(np.abs(x).max() for x in ref) > 0
-    for rep in range(3):
-        got, _, p1 = _run(spec, hip_lib, init=init, steps=steps)
-        assert p1 == steps // 2, p1
+    for rep in range(4):
+        # three times in the shell2 form (two streams: a race would show as differing bits), once in the round-4 form
+        got, _, p1 = _run(spec, hip_lib, init=init, steps=steps, shell2=1 if rep < 3 else 0)
+        assert p1 == steps // 2 and S2_PAIRS[0] == (p1 if rep < 3 else 0), (p1, S2_PAIRS[0])
         for c in range(6):
             assert np.array_equal(got[c], ref[c]), (rep, c, float(np.abs(got[c] - ref[c]).max()))
 
@@ -208,16 +222,21 @@ def test_periodic_unit_cell_in_step_pairs(hip_lib):
 
 
 def test_shell_pairs_are_taken_where_they_pay(hip_lib):
-    """The cost model's call (fdtd_capi.hip shell_why_not): a shell cell costs two single steps and more, a bulk cell half of one —
-    the bench V2 grid at 512^3 (shell: 16 % of the cells) goes out in pairs by default, the same problem at 320^3 (25 %) keeps
-    single steps and says why."""
+    """The cost models' calls (fdtd_capi.hip shell2_why_not / shell_why_not).  Round 5: the shell as shell2_step_kernel launches (two
+    steps per sweep, psi carried) pays on every size measured (192^3 x 1.25 ... 512^3 x 1.32, profiles/r5/r5h): the bench V2 grid
+    goes out in shell2 pairs by default at 512^3 and at 320^3.  With that form switched off the round-4 form decides as before:
+    a shell cell then costs two single steps and more — 512^3 (shell: 16 % of the cells) in pairs, 320^3 (25 %) in single steps,
+    and the run says why."""
     from bench import build_spec
-    for n, want in ((512, True), (320, False)):
+    for n, want_r4 in ((512, True), (320, False)):
         spec = build_spec(n, 16, "v2")
         with HipEngine(spec, lib=hip_lib, axis_shift=0) as e:
             st = e.run(12)
-            assert (int(st.shell_pairs) == 6) == want, (n, int(st.shell_pairs))
-            assert int(st.fused2_off_reason) == (0 if want else 12), int(st.fused2_off_reason)
+            assert int(st.shell_pairs) == 6 and int(st.shell2_pairs) == 6 and int(st.fused2_off_reason) == 0, (n, int(st.shell_pairs), int(st.shell2_pairs))
+            e.set_option(L.OPT_SHELL2, 0)
+            st = e.run(12)
+            assert int(st.shell2_pairs) == 0 and (int(st.shell_pairs) == 6) == want_r4, (n, int(st.shell_pairs), int(st.shell2_pairs))
+            assert int(st.fused2_off_reason) == (0 if want_r4 else 12), int(st.fused2_off_reason)
 
 
 @pytest.mark.gpu
