@@ -76,8 +76,8 @@ PY
       RUN_PERIODS=400 NFREQ=25 timeout 900 python scripts/probe_mie_refinement.py 20 30 40 > $O/mie_converged_25f.jsonl 2> $O/mie.err; cut -c1-160 $O/mie_converged_25f.jsonl;;
     sq)
       cd /tmp
-      for W in v0 v0s; do
-        case $W in v0) A="";; v0s) A="--opt OPT_TWOSTEP=0";; esac
+      for W in ${SQ_WORKLOADS:-v0 v0s}; do
+        case $W in v0) A="";; v0s) A="--opt OPT_TWOSTEP=0";; *) A="--workload $W";; esac
         timeout 240 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $O/sq_$W/pmc_sq1 -o pmc -- python $R/bench.py $A --steps 6 --warmup 2 --repeats 1 --no-cpu --no-workloads --no-single-steps --placement-tries 0 > /dev/null 2> $O/sq_${W}_1.err
         timeout 240 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --output-format csv -d $O/sq_$W/pmc_sq2 -o pmc -- python $R/bench.py $A --steps 6 --warmup 2 --repeats 1 --no-cpu --no-workloads --no-single-steps --placement-tries 0 > /dev/null 2> $O/sq_${W}_2.err
       done

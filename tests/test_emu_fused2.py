@@ -193,6 +193,26 @@ def test_two_steps_per_sweep_with_absorber_layers(name, w, zc, bspec, emu_lib):
         assert np.abs(ref_m[k]).max() > 0 and np.array_equal(got_m[k], ref_m[k]), k
 
 
+def test_seam_sources_inside_and_outside_the_absorber_layers(emu_lib):
+    """An E-side source node next to a seam has its term of step n+1 added behind the launch.  Outside the layers the damping factor
+    is exactly 1, so the sweep damps E^{n+2} itself (round 5: the bench's dipole sits on column 256 — six damping launches over
+    40 % of the grid went out behind every pair); a seam node INSIDE a layer leaves that damping to the caller's launches, behind
+    the source.  Same bits as single steps in both cases."""
+    N = SHAPES["two_x_tiles"]
+    size = tuple(n * DL for n in N)
+    for inside in (False, True):
+        y = 0.5 * size[1] - 1.4 * DL if inside else 0.02
+        extra = [td.PointDipole(center=(-0.5 * size[0] + 256.0 * DL, y, 0.03), source_time=PULSE, polarization="Ey"),
+                 td.PointDipole(center=(-0.5 * size[0] + 255.5 * DL, y, -0.04), source_time=PULSE, polarization="Ex")]
+        disc = discretize(_sim(N, monitors=False, structures=MEDIA_WIDE, bspec=ABS, extra=extra), n_steps=26)
+        disc.spec.decay_every = 0
+        ref_f, _, p0 = _run(disc.spec, emu_lib, 0)
+        got_f, _, p1 = _run(disc.spec, emu_lib, 8 + 64 * 5)
+        assert p0 == 0 and p1 == 5 + 7, (inside, p1)
+        for c in range(6):
+            assert np.array_equal(got_f[c], ref_f[c]), (inside, c)
+
+
 def test_absorber_layers_with_a_magnetic_dipole_take_single_steps(emu_lib):
     N = SHAPES["one_tile"]
     sim = _sim(N, monitors=False, bspec=ABS, extra=[td.PointDipole(center=(0.1, 0, 0), source_time=PULSE, polarization="Hy")])
