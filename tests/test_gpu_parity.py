@@ -373,10 +373,10 @@ def test_config4_mie_sphere_512_cube(hip_lib):
     """BASELINE config[3]: Mie scattering, dielectric sphere, PlaneWave TFSF + PML, 512^3 cells on one MI355X; scattering
     cross-section from the flux through a box in the scattered-field region (normalised to 1 W/um^2 incident) vs the Mie series
     at 25 frequencies across the band (dl = lambda0/40, lambda/25 inside the sphere; sub-pixel averaged interface).  No fitted
-    parameter: mean deviation <= 1.3 %, worst point (the steepest flank of the sharpest resonance in the band) <= 5 %, and at the
+    parameter: mean deviation <= 1.1 % (measured 1.06 %; round 5: tightened from 1.3 %), worst point (the steepest flank of the sharpest resonance in the band) <= 5 %, and at the
     five frequencies the earlier rounds quoted (0.85, 0.95, 1, 1.05, 1.15 f0) <= 2.5 %."""
     dev, f = _mie_run(40, hip_lib)
-    assert np.abs(dev).mean() < 0.013, np.abs(dev).mean()
+    assert np.abs(dev).mean() < 0.011, np.abs(dev).mean()
     assert np.abs(dev).max() < 0.05, np.abs(dev).max()
     five = [int(np.argmin(np.abs(f - v))) for v in (0.85, 0.95, 1.0, 1.05, 1.15)]
     assert np.abs(dev[five]).max() < 0.025, dev[five]
@@ -459,8 +459,11 @@ def test_config3_si_strip_waveguide_mode_launch(hip_lib):
 def test_config5_au_nanoparticle_array_1024x1024x256(hip_lib):
     """BASELINE config[4] on ONE MI355X (the 8-GPU z-slab run of the same grid is the driver's):
     dispersive Au (Johnson & Christy, 5 pole pairs -> ADE) nano-disc array, 1024 x 1024 x 256 cells,
-    periodic in x/y, CPML in z, plane wave.  Checks stability of the 5-pole ADE over the whole run,
-    energy balance R + T + A = 1 with 0 < A, and the 16-fold translation symmetry of the array."""
+    periodic in x/y, CPML in z, plane wave.  Checks stability of the 5-pole ADE over the whole run, the 16-fold translation
+    symmetry of the array, and — round 5 — R, T and A against the array's UNIT CELL (64 x 64 x 256, one disc) run through the fp64
+    oracle for the whole run time (tests/golden/config5_unit_cell_oracle.json, made by scripts/make_config5_unit_cell_golden.py): to
+    1e-3 of the incident power — a wrong ADE coefficient, a wrong CPML term or a wrong TFSF / flux normalisation cannot pass; the
+    same unit cell on the HIP engine agrees with the full array to 2e-4 (the periodic images are the array)."""
     import time
     from cases import gold_johnson_christy
     from tidy3d_amd.data import assemble
@@ -505,6 +508,19 @@ def test_config5_au_nanoparticle_array_1024x1024x256(hip_lib):
           f"{disc.spec.n_cells * st.steps_done / (st.run_ms * 1e-3) / 1e6:.0f} Mcells/s) R={R:.4f} T={T:.4f} A={A:.4f}")
     assert not st.diverged
     assert 0.0 < R < 1.0 and 0.0 < T < 1.0 and 0.005 < A < 0.9
+    import json
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "scripts"))
+    from make_config5_unit_cell_golden import config5_sim, rta
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config5_unit_cell_oracle.json")))
+    d1 = discretize(config5_sim(64, shutoff=1e-4))
+    with HipEngine(d1.spec, lib=hip_lib) as e1:
+        st1 = e1.run()
+        R1, T1, A1 = rta(assemble(d1, e1.results(), log=""), 64 * dl)
+    print(f"[config5] unit cell on the engine R={R1:.5f} T={T1:.5f} A={A1:.5f} ({st1.steps_done} steps); fp64 oracle R={gold['R']:.5f} T={gold['T']:.5f} A={gold['A']:.5f}")
+    assert abs(R - R1) < 2e-4 and abs(T - T1) < 2e-4, (R, R1, T, T1)
+    assert abs(R - gold["R"]) < 1e-3 and abs(T - gold["T"]) < 1e-3 and abs(A - gold["A"]) < 1e-3, (R, T, A, gold)
     # 16 periods along x: the line scan repeats every 64 cells
     per = line[:1024].reshape(16, 64)
     assert np.max(np.abs(per - per[0])) < 2e-3 * np.max(np.abs(per))

@@ -60,7 +60,15 @@ def _index_for_step(medium, freq: float, axis: int) -> float:
     if isinstance(medium, td.AnisotropicMedium):
         if getattr(medium.component(axis), "is_pec", False):
             return 1.0
-        eps = np.array([complex(np.asarray(medium.eps_comp(c, freq)).ravel()[0]) for c in range(3)])
+        # (a spatially varying component — CustomAnisotropicMedium — sets the step with its value of largest modulus, as a
+        #  CustomMedium does, ref medium.py:1324-1336; eps_comp would return the component's spatial mean)
+        def diag(c):
+            m_c = medium.component(c)
+            if hasattr(m_c, "eps_diagonal"):
+                e3 = np.asarray(m_c.eps_diagonal(freq), complex).ravel()
+                return complex(e3[int(np.argmax(np.abs(e3)))])
+            return complex(np.asarray(medium.eps_comp(c, freq)).ravel()[0])
+        eps = np.array([diag(c) for c in range(3)])
     else:
         if isinstance(medium, td.Unsupported):
             medium.fail()

@@ -174,8 +174,17 @@ class Box(_Model):
 
     @classmethod
     def from_bounds(cls, rmin, rmax, **kw):
-        rmin, rmax = np.array(rmin, float), np.array(rmax, float)
-        return cls(center=tuple((rmin + rmax) / 2), size=tuple(rmax - rmin), **kw)
+        # (ref geometry/base.py:411-424 _get_center: a dimension unbounded on both sides is centred at 0, on one side only an error)
+        center = []
+        for lo, hi in zip(rmin, rmax):
+            lo, hi = float(lo), float(hi)
+            if np.isneginf(lo) and np.isposinf(hi):
+                center.append(0.0)
+            elif np.isneginf(lo) or np.isposinf(hi):
+                raise SetupError(f"Bounds of ({lo}, {hi}) supplied along one dimension: a single inf value in the bounds of a Box is not supported")
+            else:
+                center.append((lo + hi) / 2.0)
+        return cls(center=tuple(center), size=tuple(float(hi) - float(lo) for lo, hi in zip(rmin, rmax)), **kw)
 
     @property
     def zero_dims(self) -> List[int]:
