@@ -301,6 +301,9 @@ enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_R
                                       + 128 * waves per workgroup of the all-axes launch (1 ... 8, default 8) + 1024 * planes per chunk of the wide
                                       boxes (0 = by box) + 2^17 * waves per workgroup of the one-axis launches (1 ... 8, default 6) + 2^21 * planes
                                       per chunk of the x strips (0 = by box); <= 0: defaults */
+       FDTD_OPT_DEBUG_SYNC = 21, /* 1: a device-wide synchronisation in front of and behind every launch group of fdtd_run (no two launches ever
+                                    overlap): a debugging aid — a schedule whose result then differs from the normal run's has a missing
+                                    cross-stream edge.  Default 0 */
        FDTD_OPT_LDS_PAD = 10 /* measuring aid: extra dynamic LDS per workgroup of the sweep in bytes (lowers its occupancy) */ };
 int fdtd_set_option(FdtdSolver* h, int key, int value);
 int fdtd_reset(FdtdSolver* h);      /* zero fields, auxiliaries, monitors and the step counter */

@@ -79,6 +79,9 @@ def test_random_sheets_have_the_reference_volumetric_equivalent(td_ref, seed):
         ss, tt = _random_medium(td_ref, rng), _random_medium(td_ref, rng)
         below, above = _random_medium(td_ref, rng), _random_medium(td_ref, rng)
         sheet_ref = td_ref.Medium2D(ss=ss, tt=tt)
+        # the neighbours are those at the sheet's OWN plane, before it is snapped to the grid plane z = 0 (ref simulation.py:1317,
+        # geometry/utils_2d.py:61-70): on the interface -> (below, above); 4 nm above it -> the upper medium on both sides
+        z_sheet = 0.0 if q % 2 == 0 else 0.004
         dz = np.concatenate([np.full(10, 0.05), rng.uniform(0.03, 0.07, 10)])
         zb = np.concatenate(([0.0], np.cumsum(dz))) - 0.5
         conv = lambda m_: td.parse(json.loads(m_.json()))      # noqa: E731
@@ -87,14 +90,14 @@ def test_random_sheets_have_the_reference_volumetric_equivalent(td_ref, seed):
             grid_spec=td.GridSpec(grid_x=td.UniformGrid(dl=0.05), grid_y=td.UniformGrid(dl=0.05), grid_z=td.CustomGridBoundaries(coords=tuple(zb))),
             structures=[td.Structure(geometry=td.Box(center=(0, 0, -5.0), size=(td.inf, td.inf, 10.0)), medium=conv(below)),
                         td.Structure(geometry=td.Box(center=(0, 0, 5.0), size=(td.inf, td.inf, 10.0)), medium=conv(above)),
-                        td.Structure(geometry=td.Box(center=(0, 0, 0.004), size=(td.inf, td.inf, 0)), medium=conv(sheet_ref))],
+                        td.Structure(geometry=td.Box(center=(0, 0, z_sheet), size=(td.inf, td.inf, 0)), medium=conv(sheet_ref))],
             sources=[td.PointDipole(center=(0, 0, 0.2), source_time=td.GaussianPulse(freq0=2e14, fwidth=4e13), polarization="Ex")],
             boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary()))
         spec = discretize(sim, n_steps=2).spec
         b = np.asarray(spec.boundaries[2])
         k = int(np.argmin(np.abs(b)))
         assert abs(b[k]) < 1e-12
-        vol = sheet_ref.volumetric_equivalent(axis=2, adjacent_media=(below, above), adjacent_dls=(b[k] - b[k - 1], b[k + 1] - b[k]))
+        vol = sheet_ref.volumetric_equivalent(axis=2, adjacent_media=(below if z_sheet == 0.0 else above, above), adjacent_dls=(b[k] - b[k - 1], b[k + 1] - b[k]))
         for c, name in ((0, "xx"), (1, "yy")):
             idx = spec.mat_idx[c][k, 3, 3]
             got = np.array([medium_eps_table(spec, f)[idx] for f in freqs])

@@ -186,6 +186,70 @@ def test_rccl_self_exchange_matches_ghost_copy(hip_lib):
         assert np.array_equal(ref_m[k], got_m[k])
 
 
+@pytest.mark.parametrize("schedule", ["cpml_three_launches", "shell_pairs_r4", "shell2_pairs", "slab_rank_fused", "slab_rank_fused_pml_in_sweep",
+                                      "slab_rank_pairs", "slab_rank_two_pass"])
+def test_schedules_do_not_depend_on_stream_timing(schedule, hip_lib):
+    """every schedule that splits a step between the two streams, run normally (three times: a race shows as
+    run-to-run differences too) and with FDTD_OPT_DEBUG_SYNC — a device-wide synchronisation in front of and behind every launch
+    group, so that no two launches ever overlap.  A schedule with a missing cross-stream edge (the two races the round-4 device
+    fuzz found were of that kind) gives different bits in the two modes; here: the same, fields and records."""
+    from cases import pipelined_slab_case
+    opts, comm = {}, False
+    if schedule in ("cpml_three_launches", "shell_pairs_r4", "shell2_pairs"):
+        N = (96, 72, 64)
+        size = tuple(n * DL for n in N)
+        sim = td.Simulation(size=size, grid_spec=td.GridSpec.uniform(dl=DL), run_time=1e-12, shutoff=0,
+                            structures=[td.Structure(geometry=td.Sphere(center=(0.4, 0.1, -0.2), radius=0.7), medium=td.Medium(permittivity=2.5)),
+                                        td.Structure(geometry=td.Box(center=(0, -1.0, 0), size=(td.inf, 0.5, 0.6)), medium=td.Medium(permittivity=3.0, conductivity=0.02))],
+                            sources=[td.PointDipole(center=(0.05, 0.02, 0.03), source_time=PULSE, polarization="Ez"),
+                                     td.PointDipole(center=(-0.1, 0.06, -0.05), source_time=PULSE, polarization="Hy")],
+                            monitors=[td.FieldTimeMonitor(center=(0.1, 0.1, 0.05), size=(0, 0, 0), name="probe", interval=3, colocate=False),
+                                      td.FieldMonitor(center=(0, 0, 0.1), size=(1.0, 0.8, 0), freqs=[2.5e14, 3e14], name="f")],
+                            boundary_spec=td.BoundarySpec.all_sides(td.PML(num_layers=6)))
+        disc = discretize(sim, n_steps=100)
+        disc.spec.decay_every = 0
+        opts = {"cpml_three_launches": {L.OPT_TWOSTEP: 0, L.OPT_PML_SPLIT: 1},
+                "shell_pairs_r4": {L.OPT_TWOSTEP: 8 + 64 * 8, L.OPT_SHELL_PAIRS: 1, L.OPT_SHELL2: 0},
+                "shell2_pairs": {L.OPT_TWOSTEP: 8 + 64 * 8, L.OPT_SHELL_PAIRS: 1, L.OPT_SHELL2: 1}}[schedule]
+    else:
+        comm = True
+        if schedule == "slab_rank_pairs":
+            from cases import slab_pairs_box
+            disc = discretize(slab_pairs_box((72, 60, 132), periodic_z=True), n_steps=80)
+            disc.spec.decay_every = 0
+        else:
+            disc = discretize(pipelined_slab_case(), n_steps=90)
+            disc.spec.decay_every = 16
+        opts = {"slab_rank_fused": {}, "slab_rank_fused_pml_in_sweep": {L.OPT_PML_FUSED: 7, L.OPT_BND_PLANES: 3},
+                "slab_rank_pairs": {L.OPT_TWOSTEP: 8 + 64 * 8}, "slab_rank_two_pass": {}}[schedule]
+
+    def run(debug_sync):
+        kw = dict(force_comm=True) if comm else dict(axis_shift=0)
+        if schedule == "slab_rank_two_pass":
+            kw["variant"] = L.VARIANT_ZMARCH
+        with HipEngine(disc.spec, lib=hip_lib, **kw) as e:
+            if comm:
+                e.comm_init(e.unique_id())
+            for k, v in opts.items():
+                e.set_option(k, v)
+            e.set_option(L.OPT_DEBUG_SYNC, debug_sync)
+            st = e.run()
+            return [e.get_field(c) for c in range(6)], e.results(), int(st.fused2_pairs), int(st.shell2_pairs)
+    ref_f, ref_m, p_ref, q_ref = run(1)
+    assert max(float(np.abs(f).max()) for f in ref_f) > 0
+    if schedule in ("shell_pairs_r4", "shell2_pairs", "slab_rank_pairs"):
+        assert p_ref > 10, p_ref
+    if schedule == "shell2_pairs":
+        assert q_ref > 10, q_ref
+    for rep in range(3):
+        f, m, p, q = run(0)
+        assert (p, q) == (p_ref, q_ref)
+        for c in range(6):
+            assert np.array_equal(f[c], ref_f[c]), (schedule, rep, c, float(np.abs(f[c] - ref_f[c]).max()))
+        for k in ref_m:
+            assert np.array_equal(np.asarray(m[k]), np.asarray(ref_m[k])), (schedule, rep, k)
+
+
 @pytest.mark.parametrize("bnd,pml_fused", [(0, -1), (3, -1), (0, 7), (5, 7)])
 def test_pipelined_slab_schedule_with_corrections_on_real_streams(hip_lib, bnd, pml_fused):
     """The pipelined z-slab schedule under REAL stream concurrency with everything it splits

@@ -249,6 +249,7 @@ struct FdtdSolver {
   int shell2_ws = 6, shell2_zcs = 0;                     // waves per workgroup of the one-axis launches; x strips: planes per chunk (0 = by box)
   long long shell2_pairs = 0;
   int f2_off_reason = 0;              // why the last fdtd_run took no step pairs (FDTD_F2_OFF_*), 0 = it did / could
+  int debug_sync = 0;                 // FDTD_OPT_DEBUG_SYNC: a device-wide synchronisation behind every launch group (dbg_sync) — no two launches ever overlap
   hipEvent_t ev_shell_a = nullptr, ev_shell_b = nullptr;
   hipEvent_t ev_rec = nullptr;        // z-slab ranks: a monitor record on the main stream done (the comm stream's next boundary work waits for it)
   float* seam_buf = nullptr;          // intermediate values on the seams between x tiles
@@ -433,7 +434,13 @@ MatP mat_params(const FdtdSolver* h) {
 }
 
 // ---- timing of the main kernels -----------------------------------------------------------
+// FDTD_OPT_DEBUG_SYNC: everything issued so far — on either stream — has finished before the next launch group goes out.  Called at
+// the head of every launch helper and around every sweep launch: with it no two launches of a run ever overlap, so a result that
+// differs from the normal run's points at a missing cross-stream edge (tests/test_gpu_parity.py).
+inline void dbg_sync(const FdtdSolver* h) { if (h->debug_sync) (void)hipDeviceSynchronize(); }
+
 void time_begin(FdtdSolver* h, int kind, hipStream_t st) {
+  dbg_sync(h);
   if (!(h->cfg.flags & FDTD_FLAG_TIME_KERNELS)) return;
   hipEvent_t a, b;
   hipEventCreate(&a);
@@ -444,6 +451,7 @@ void time_begin(FdtdSolver* h, int kind, hipStream_t st) {
   h->kev_kind.push_back(kind);
 }
 void time_end(FdtdSolver* h, hipStream_t st) {
+  dbg_sync(h);
   if (!(h->cfg.flags & FDTD_FLAG_TIME_KERNELS)) return;
   hipEventRecord(h->kev.back(), st);
 }
@@ -1471,6 +1479,7 @@ int shell2_why_not(const FdtdSolver* h, ShellGeom* G) {
 // behind the sweep of the pair (n, n + 1) (the sets are swapped: h->f2 = what it read, h->f = what it wrote): everything the
 // monitors of `tb` record of steps n and n + 1, in one launch
 void pair_record(FdtdSolver* h, const F2Table* tb, long long n, hipStream_t st) {
+  dbg_sync(h);
   // DFT monitors: a record at step n took E^n in front of the sweep — its H terms from the sweep's copy of H^{n+1/2}; a record at
   // step n+1 takes its E terms from the copy of E^{n+1} here and its H terms (H^{n+3/2}) from the write set, record_monitors
   for (size_t q = 0; q < tb->dfts.size(); ++q) {
@@ -1746,6 +1755,7 @@ int probe_stream_overlap(FdtdSolver* h) {
 // (k0, k1): the planes of this call — x / y walls are refreshed plane by plane; a z wall (the last rank's: images in its last two
 //  planes, of the two below them) with the call that holds all four of its planes (fdtd_run checks that one does)
 void fill_mirror(FdtdSolver* h, hipStream_t st, int k0 = 0, int k1 = -1) {
+  dbg_sync(h);
   const GridP& g = h->g;
   if (k1 < 0) k1 = g.nz;
   if (k1 <= k0) return;
@@ -1765,6 +1775,7 @@ void copy_plane(FdtdSolver* h, float* dst, const float* src, hipStream_t st) {
   else hipMemcpyAsync(dst, src, pc * 4, hipMemcpyDeviceToDevice, st);
 }
 void fill_ghost_fused(FdtdSolver* h, hipStream_t st, const FieldP* fs = nullptr) {
+  dbg_sync(h);
   if (h->cfg.bc[4] != FDTD_BC_PERIODIC) return;
   const FieldP F = fs ? *fs : h->f;
   const long long pc = plane_cells(h);
@@ -1779,6 +1790,7 @@ void fill_ghost_fused(FdtdSolver* h, hipStream_t st, const FieldP* fs = nullptr)
 // Axis order: H side x, y, z; E side y, z, x — so that a sweep that folds only the y and z
 // recursions into the fused kernel (x stays a slab kernel before / after it) sums in the same order.
 void launch_pml(FdtdSolver* h, bool e_side, int kbeg, int kend, hipStream_t st, int axes = 7) {
+  dbg_sync(h);
   const GridP& g = h->g;
   const int N[3] = {g.nx, g.ny, g.nz};
   for (int ai = 0; ai < 3; ++ai) {
@@ -1841,6 +1853,7 @@ void launch_pml(FdtdSolver* h, bool e_side, int kbeg, int kend, hipStream_t st, 
 // absorber layers over the planes [kbeg, kend): E components (end of the E phase) or H components
 // (start of the H phase, before the H-side corrections).  One launch per axis and face.
 void launch_damp(FdtdSolver* h, bool e_side, int kbeg, int kend, hipStream_t st) {
+  dbg_sync(h);
   if (!h->has_damp || kend <= kbeg) return;
   const GridP& g = h->g;
   const int N[3] = {g.nx, g.ny, g.nz};
@@ -1870,6 +1883,7 @@ void launch_damp(FdtdSolver* h, bool e_side, int kbeg, int kend, hipStream_t st)
 
 void launch_sources(FdtdSolver* h, bool e_side, long long n, int kbeg, int kend, hipStream_t st, bool replica = false,
                     const FieldP* fs = nullptr) {
+  dbg_sync(h);
   if (kend <= kbeg) return;
   const long long zlo = (long long)kbeg * h->g.sxy, zhi = (long long)kend * h->g.sxy;
   const int off = e_side ? 0 : 3;
@@ -1902,6 +1916,7 @@ void launch_sources(FdtdSolver* h, bool e_side, long long n, int kbeg, int kend,
 
 // the 1-D incident grids advance once per phase on the main stream (not z-range dependent)
 void advance_tfsf_aux(FdtdSolver* h, bool e_side, long long n, hipStream_t st, bool replica = false) {
+  dbg_sync(h);
   for (Tfsf& t : h->tfsf) {
     if (n >= t.n_steps) continue;
     float* e1 = replica ? t.e1c : t.e1;
@@ -1918,6 +1933,7 @@ void advance_tfsf_aux(FdtdSolver* h, bool e_side, long long n, hipStream_t st, b
 
 // fully anisotropic bodies: E^n of the neighbour nodes, saved in front of the E update ...
 void aniso_save(FdtdSolver* h, hipStream_t st) {
+  dbg_sync(h);
   for (AnisoGroup& a : h->aniso) {
     const float* b1 = field_ptr(h, (a.comp + 1) % 3);
     const float* b2 = field_ptr(h, (a.comp + 2) % 3);
@@ -1926,6 +1942,7 @@ void aniso_save(FdtdSolver* h, hipStream_t st) {
 }
 // ... and the coupling, behind the E update and its sources: every component's correction from the unpatched values, then applied
 void aniso_apply(FdtdSolver* h, hipStream_t st) {
+  dbg_sync(h);
   for (AnisoGroup& a : h->aniso) {
     const float* b1 = field_ptr(h, (a.comp + 1) % 3);
     const float* b2 = field_ptr(h, (a.comp + 2) % 3);
@@ -1938,6 +1955,7 @@ void aniso_apply(FdtdSolver* h, hipStream_t st) {
 }
 
 void launch_ade(FdtdSolver* h, int kbeg, int kend, hipStream_t st, const FieldP* fs = nullptr) {
+  dbg_sync(h);
   if (kend <= kbeg) return;
   const long long zlo = (long long)kbeg * h->g.sxy, zhi = (long long)kend * h->g.sxy;
   for (AdeGroup& a : h->ade) {
@@ -1955,6 +1973,7 @@ void launch_ade(FdtdSolver* h, int kbeg, int kend, hipStream_t st, const FieldP*
 
 // z boundary conditions of a single slab (no neighbour): fill ghost planes
 void fill_ghost_h(FdtdSolver* h, hipStream_t st) {
+  dbg_sync(h);
   const long long pc = plane_cells(h);
   const int bc0 = h->cfg.bc[4];
   if (bc0 == FDTD_BC_PERIODIC) {
@@ -1966,6 +1985,7 @@ void fill_ghost_h(FdtdSolver* h, hipStream_t st) {
   }
 }
 void fill_ghost_e(FdtdSolver* h, hipStream_t st) {
+  dbg_sync(h);
   const long long pc = plane_cells(h);
   if (h->cfg.bc[5] == FDTD_BC_PERIODIC) {
     hipMemcpyAsync(h->f.ex + (long long)h->g.nz * pc, h->f.ex, pc * 4, hipMemcpyDeviceToDevice, st);
@@ -1977,6 +1997,7 @@ void fill_ghost_e(FdtdSolver* h, hipStream_t st) {
 // H phase: my top Hx,Hy plane -> upper neighbour's ghost(-1); E phase: my bottom Ex,Ey plane
 // -> lower neighbour's ghost(nz).  Periodic z wraps rank n-1 <-> 0.
 int exchange(FdtdSolver* h, bool e_side, hipStream_t st) {
+  dbg_sync(h);
   const long long pc = plane_cells(h);
   const int nz = h->g.nz;
   const bool has_lo = h->cfg.bc[4] == FDTD_BC_NEIGHBOR, has_hi = h->cfg.bc[5] == FDTD_BC_NEIGHBOR;
@@ -2011,6 +2032,7 @@ int exchange(FdtdSolver* h, bool e_side, hipStream_t st) {
 //   exchange_fused_e : E_x,E_y,E_z of my top plane -> upper ghost(-1); E_x,E_y of my bottom plane
 //                      -> lower neighbour's ghost(nz)
 int exchange_fused_h(FdtdSolver* h, hipStream_t st) {
+  dbg_sync(h);
   const long long pc = plane_cells(h);
   const int nz = h->g.nz;
   const bool has_lo = h->cfg.bc[4] == FDTD_BC_NEIGHBOR, has_hi = h->cfg.bc[5] == FDTD_BC_NEIGHBOR;
@@ -2029,6 +2051,7 @@ int exchange_fused_h(FdtdSolver* h, hipStream_t st) {
 }
 
 int exchange_fused_e(FdtdSolver* h, hipStream_t st) {
+  dbg_sync(h);
   const long long pc = plane_cells(h);
   const int nz = h->g.nz;
   const bool has_lo = h->cfg.bc[4] == FDTD_BC_NEIGHBOR, has_hi = h->cfg.bc[5] == FDTD_BC_NEIGHBOR;
@@ -2058,6 +2081,7 @@ int exchange_fused_e(FdtdSolver* h, hipStream_t st) {
 // (-> upper ghost(-1)); down: E_x,E_y of my bottom plane (-> lower ghost(nz)).
 // `fs`: the set whose planes travel (default: the current one) — the middle step of a slab pair ships the third set's.
 int exchange_fused_all(FdtdSolver* h, hipStream_t st, bool pml_with_sweep = false, const FieldP* fs = nullptr) {
+  dbg_sync(h);
   const long long pc = plane_cells(h);
   const int nz = h->g.nz;
   const bool has_lo = h->cfg.bc[4] == FDTD_BC_NEIGHBOR, has_hi = h->cfg.bc[5] == FDTD_BC_NEIGHBOR;
@@ -2113,6 +2137,7 @@ int eval_energy(FdtdSolver* h, hipStream_t st, double* out) {
 
 // ---- monitors ---------------------------------------------------------------------------------
 void record_monitors(FdtdSolver* h, long long n, bool post, hipStream_t st, const F2Plan* in_sweep = nullptr) {
+  dbg_sync(h);
   for (size_t mi = 0; mi < h->mons.size(); ++mi) {
     Monitor& m = h->mons[mi];
     if (m.next >= m.steps.size() || m.steps[m.next] != n) continue;
@@ -2773,128 +2798,174 @@ int fdtd_reset(FdtdSolver* h) {
   return 0;
 }
 
-int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user) {
-  if (!h) return -1;
-  HIPCHK(h, hipSetDevice(h->cfg.device));
-  const bool multi = h->comm != nullptr;     // also true for a 1-rank communicator (self exchange)
-  const bool nb_lo = h->cfg.bc[4] == FDTD_BC_NEIGHBOR, nb_hi = h->cfg.bc[5] == FDTD_BC_NEIGHBOR;
-  if ((nb_lo || nb_hi) && !multi) return fail(h, "fdtd_run: neighbour faces need fdtd_comm_init");
-  if (multi && !h->aniso.empty()) return fail(h, "fdtd_run: fully anisotropic media are not available on z-slabs");
-  // (PMC on a plus face of a z-slab rank: x / y walls are local to every plane; a z wall belongs to the rank without an upper
-  //  neighbour, whose interior launch must hold the wall's two image planes and the two they mirror)
-  // (six planes: the boundary chunk next to the lower neighbour is one plane thick below eight planes, two from there on)
-  if (multi && h->mirror_wall[2] >= 0 && (nb_hi || h->mirror_wall[2] != h->g.nz - 2 || h->g.nz < 6))
-    return fail(h, "fdtd_run: a PMC plus face along z needs the last z-slab to hold the wall and at least 6 planes");
-  const int nz = h->g.nz;
-  // runs that use BOTH streams first make sure the two really overlap (once per engine; falls back to one stream)
-  if ((multi || any_pml(h) || h->tblock > 4096) && probe_stream_overlap(h)) return -1;
-  hipStream_t st = h->stream, cs = h->comm_stream;
-  for (hipEvent_t e : h->kev) hipEventDestroy(e);
-  h->kev.clear(); h->kev_kind.clear();
-  h->stats.stopped_early = 0;
-  HIPCHK(h, hipEventRecord(h->ev0, st));
-  if (multi && (nb_lo || nb_hi) && nz < 2) return fail(h, "fdtd_run: a z-slab needs at least 2 planes");
-  // the fused sweep is the default single-GPU path whenever rows are float4-aligned
-  const bool fused_ok = (h->g.nx % 4 == 0) && h->rows_f <= 15 &&
-                        (h->cfg.variant == FDTD_VARIANT_FUSED || h->cfg.variant == FDTD_VARIANT_AUTO);
-  const bool fused = !multi && fused_ok;
-  // with a communicator every rank must take the same path: the fused z-slab schedule runs only on
-  // explicit request (the host decides for all ranks, tidy3d_amd/engine.py), AUTO = two-pass
-  if (multi && h->cfg.variant == FDTD_VARIANT_FUSED && !(fused_ok && nz >= 4))
-    return fail(h, "fdtd_run: the fused z-slab schedule needs nx %% 4 == 0 and >= 4 planes per slab");
-  const bool fused_multi = multi && h->cfg.variant == FDTD_VARIANT_FUSED;
-  // ---- pipelined fused z-slab schedule (fused_multi) -------------------------------------------
-  // Per step, with  b_lo / b_hi  boundary planes next to a neighbour face:
-  //   cs: sweep [0,b_lo) + [nz-b_hi,nz)  -> E-side corrections and next step's H-side pre-corrections
-  //       of those planes -> ONE exchange (exchange_fused_all), which overlaps the interior sweep
-  //   st: sweep [b_lo, nz-b_hi)          -> the same corrections of the interior planes
-  // The next boundary sweep needs this exchange and the interior planes next to it (ev_e_int); the
-  // next interior sweep needs only the boundary planes next to it (ev_e_bnd, recorded BEFORE the
-  // exchange).  Invariant at the top of a step ("primed"): monitors pre-recorded, H-side
-  // pre-corrections applied on all planes, ghost planes in flight on cs.  Steps that record
-  // monitors, check the field decay or end the run use a joined tail on st instead and re-prime.
-  int b_lo = 0, b_hi = 0;
-  if (fused_multi) {
-    // boundary chunk: TWO planes per neighbour face (all the exchange needs, and it starts that much earlier).
-    // Measured inside engines on the per-rank proxy, RCCL looped back (profiles/r03y_probe_boundary_chunk_thickness
-    // .jsonl): 512 x 512 x 64 plain 0.186 ms per step at 16 planes, 0.175 at 8, 0.167 at 4, 0.163 at 2 and at 1; with
-    // materials + CPML 0.319 -> 0.287; 128 planes 0.301 -> 0.297.  (Round 1's kernels preferred 16: r01h.)
-    int zb = h->bnd_planes > 0 ? h->bnd_planes : std::min(kBndPlanes, nz / 4);
-    zb = std::max(1, std::min(zb, nz / 2));
-    b_lo = nb_lo ? zb : 0;
-    b_hi = nb_hi ? zb : 0;
-    // the z-CPML differentiates along z: its slabs must stay clear of the boundary chunks (whose
-    // corrections run on the other stream and before the ghost planes of the new step arrive)
-    const PmlAxisDev& pz = h->pml[2];
-    if (nb_hi && pz.n_lo > 0) b_hi = std::min(b_hi, nz - pz.n_lo - 1);
-    if (nb_lo && pz.n_hi > 0) b_lo = std::min(b_lo, nz - pz.n_hi - 1);
-    if ((nb_hi && b_hi < 1) || (nb_lo && b_lo < 1))
-      return fail(h, "fdtd_run: the fused z-slab schedule needs at least 2 planes between a slab cut and the z-PML");
-  }
-  // Tile-shape probing: on request (FDTD_OPT_AUTOTUNE), and by default on one GPU when the default shape
-  // launches less than one wave of workgroups (256 CUs x 3): there the z-chunk decides how much of the chip a
-  // sweep fills (128^3: 344 workgroups at 16 planes per chunk, 0.045 ms per step; 688 at 8 planes, 0.034 ms —
-  // profiles/r01m_narrow_grid_axis_shift.log) and the probe costs a dozen sweeps once.  Results do not depend
-  // on the shape.  (autotune == 2 lifts the size threshold: test aid for the emulated library)
-  bool under_one_wave = false;
-  if (fused && !h->tuned && !h->user_geometry) {
-    const long long wgs = (long long)((h->g.nx + 255) / 256) * ((h->g.ny + h->rows_f - 1) / h->rows_f) *
-                          ((nz + h->zchunk_f - 1) / h->zchunk_f);
-    under_one_wave = wgs < 2048;       // (two waves of workgroups at 4 waves per SIMD)
-  }
-  if ((fused || fused_multi) && (h->autotune || under_one_wave) && !h->tuned && !h->user_geometry &&
-      (n_cells(h) >= (1LL << 20) || h->autotune == 2)) {
-    if (autotune_fused(h, st)) return -1;
-    if (fused_multi) {           // the boundary-chunk thickness follows the chosen z-chunk
+// ---- fdtd_run ---------------------------------------------------------------------------------------------------------------
+// One `Run` object per call: its members are the state of the run (what the locals of the former 800-line function held), its
+// methods the schedules — each with the streams it issues on and the field sets it reads / writes in its header.  Conventions:
+//   st = main stream, cs = comm stream (the second stream of the engine; an alias of st when the two were found not to overlap);
+//   set A = h->f (current: E^n, H^{n-1/2}), set B = h->f2 (the other set of the ping-pong), set T = h->f3 (third set: the middle
+//   step of shell / slab pairs, round-4 form); "swap" = swap_sets: B becomes current.
+//   Cross-stream edges are hipEvents recorded on the producer and waited for on the consumer; nothing waits on the host inside
+//   the loop except field-decay checks.  FDTD_OPT_DEBUG_SYNC = 1 puts a device-wide synchronisation behind every launch
+//   (time_end) and every step: a schedule whose result then differs from the normal run has a missing edge
+//   (tests/test_gpu_parity.py::test_schedules_do_not_depend_on_stream_timing).
+}  // extern "C"
+namespace {
+struct GraphRec { const float* set; int parity; hipGraphExec_t exec; };
+struct Run {
+  FdtdSolver* h;
+  int64_t n_steps;
+  FdtdProgressFn progress;
+  void* user;
+  // the run's configuration (setup)
+  bool multi = false, nb_lo = false, nb_hi = false;
+  int nz = 0;
+  hipStream_t st = nullptr, cs = nullptr;
+  bool fused_ok = false, fused = false, fused_multi = false;
+  int b_lo = 0, b_hi = 0;              // fused z-slab schedule: boundary planes next to the lower / upper neighbour
+  bool primed = false;                 // fused z-slab schedule: monitors pre-recorded, H-side pre-corrections applied, ghost planes in flight
+  int pml_in_m = 0;                    // z-slab ranks: axes whose CPML recursions run inside the sweeps
+  bool psi_ghosts = false;
+  int tb_req = 0;
+  bool tb_two_streams = false, tb_ok = false;
+  std::vector<hipEvent_t> tb_ev;       // [2 s] = A(s) done, [2 s + 1] = B(s) done (two-stream mode)
+  bool split_now = false, graph_ok = false;
+  std::vector<GraphRec> graphs;
+  bool f2_ok = false, f2s_ok = false, s2_ok = false, s2_deep = false, f2m_ok = false;
+  ShellGeom sg{};
+  ZPlan zp_base, zp_src;               // the bulk's planes: without / with the z holes of the source lists
+  F2Plan f2_plan;
+  int64_t done = 0;
+  // the step being issued (begin_step)
+  long long n = 0;
+  bool rec = false, src_alive = false, pair = false, use_s2 = false;
+  int src_why = 0;
+  const ZPlan* zp = nullptr;
+
+  // a debugging aid (FDTD_OPT_DEBUG_SYNC): everything issued so far has finished before anything else is issued
+  void sync_point() { if (h->debug_sync) (void)hipDeviceSynchronize(); }
+  // checks, streams, the variant (fused / two-pass, one GPU / z-slab rank), tile-shape and placement probes (both on st)
+  int setup() {
+    multi = h->comm != nullptr;     // also true for a 1-rank communicator (self exchange)
+    nb_lo = h->cfg.bc[4] == FDTD_BC_NEIGHBOR, nb_hi = h->cfg.bc[5] == FDTD_BC_NEIGHBOR;
+    if ((nb_lo || nb_hi) && !multi) return fail(h, "fdtd_run: neighbour faces need fdtd_comm_init");
+    if (multi && !h->aniso.empty()) return fail(h, "fdtd_run: fully anisotropic media are not available on z-slabs");
+    // (PMC on a plus face of a z-slab rank: x / y walls are local to every plane; a z wall belongs to the rank without an upper
+    //  neighbour, whose interior launch must hold the wall's two image planes and the two they mirror)
+    // (six planes: the boundary chunk next to the lower neighbour is one plane thick below eight planes, two from there on)
+    if (multi && h->mirror_wall[2] >= 0 && (nb_hi || h->mirror_wall[2] != h->g.nz - 2 || h->g.nz < 6))
+      return fail(h, "fdtd_run: a PMC plus face along z needs the last z-slab to hold the wall and at least 6 planes");
+    nz = h->g.nz;
+    // runs that use BOTH streams first make sure the two really overlap (once per engine; falls back to one stream)
+    if ((multi || any_pml(h) || h->tblock > 4096) && probe_stream_overlap(h)) return -1;
+    st = h->stream, cs = h->comm_stream;
+    for (hipEvent_t e : h->kev) hipEventDestroy(e);
+    h->kev.clear(); h->kev_kind.clear();
+    h->stats.stopped_early = 0;
+    HIPCHK(h, hipEventRecord(h->ev0, st));
+    if (multi && (nb_lo || nb_hi) && nz < 2) return fail(h, "fdtd_run: a z-slab needs at least 2 planes");
+    // the fused sweep is the default single-GPU path whenever rows are float4-aligned
+    fused_ok = (h->g.nx % 4 == 0) && h->rows_f <= 15 &&
+                          (h->cfg.variant == FDTD_VARIANT_FUSED || h->cfg.variant == FDTD_VARIANT_AUTO);
+    fused = !multi && fused_ok;
+    // with a communicator every rank must take the same path: the fused z-slab schedule runs only on
+    // explicit request (the host decides for all ranks, tidy3d_amd/engine.py), AUTO = two-pass
+    if (multi && h->cfg.variant == FDTD_VARIANT_FUSED && !(fused_ok && nz >= 4))
+      return fail(h, "fdtd_run: the fused z-slab schedule needs nx %% 4 == 0 and >= 4 planes per slab");
+    fused_multi = multi && h->cfg.variant == FDTD_VARIANT_FUSED;
+    // ---- pipelined fused z-slab schedule (fused_multi) -------------------------------------------
+    // Per step, with  b_lo / b_hi  boundary planes next to a neighbour face:
+    //   cs: sweep [0,b_lo) + [nz-b_hi,nz)  -> E-side corrections and next step's H-side pre-corrections
+    //       of those planes -> ONE exchange (exchange_fused_all), which overlaps the interior sweep
+    //   st: sweep [b_lo, nz-b_hi)          -> the same corrections of the interior planes
+    // The next boundary sweep needs this exchange and the interior planes next to it (ev_e_int); the
+    // next interior sweep needs only the boundary planes next to it (ev_e_bnd, recorded BEFORE the
+    // exchange).  Invariant at the top of a step ("primed"): monitors pre-recorded, H-side
+    // pre-corrections applied on all planes, ghost planes in flight on cs.  Steps that record
+    // monitors, check the field decay or end the run use a joined tail on st instead and re-prime.
+    b_lo = 0, b_hi = 0;
+    if (fused_multi) {
+      // boundary chunk: TWO planes per neighbour face (all the exchange needs, and it starts that much earlier).
+      // Measured inside engines on the per-rank proxy, RCCL looped back (profiles/r03y_probe_boundary_chunk_thickness
+      // .jsonl): 512 x 512 x 64 plain 0.186 ms per step at 16 planes, 0.175 at 8, 0.167 at 4, 0.163 at 2 and at 1; with
+      // materials + CPML 0.319 -> 0.287; 128 planes 0.301 -> 0.297.  (Round 1's kernels preferred 16: r01h.)
       int zb = h->bnd_planes > 0 ? h->bnd_planes : std::min(kBndPlanes, nz / 4);
       zb = std::max(1, std::min(zb, nz / 2));
-      const PmlAxisDev& pz = h->pml[2];
       b_lo = nb_lo ? zb : 0;
       b_hi = nb_hi ? zb : 0;
+      // the z-CPML differentiates along z: its slabs must stay clear of the boundary chunks (whose
+      // corrections run on the other stream and before the ghost planes of the new step arrive)
+      const PmlAxisDev& pz = h->pml[2];
       if (nb_hi && pz.n_lo > 0) b_hi = std::min(b_hi, nz - pz.n_lo - 1);
       if (nb_lo && pz.n_hi > 0) b_lo = std::min(b_lo, nz - pz.n_hi - 1);
+      if ((nb_hi && b_hi < 1) || (nb_lo && b_lo < 1))
+        return fail(h, "fdtd_run: the fused z-slab schedule needs at least 2 planes between a slab cut and the z-PML");
     }
+    // Tile-shape probing: on request (FDTD_OPT_AUTOTUNE), and by default on one GPU when the default shape
+    // launches less than one wave of workgroups (256 CUs x 3): there the z-chunk decides how much of the chip a
+    // sweep fills (128^3: 344 workgroups at 16 planes per chunk, 0.045 ms per step; 688 at 8 planes, 0.034 ms —
+    // profiles/r01m_narrow_grid_axis_shift.log) and the probe costs a dozen sweeps once.  Results do not depend
+    // on the shape.  (autotune == 2 lifts the size threshold: test aid for the emulated library)
+    bool under_one_wave = false;
+    if (fused && !h->tuned && !h->user_geometry) {
+      const long long wgs = (long long)((h->g.nx + 255) / 256) * ((h->g.ny + h->rows_f - 1) / h->rows_f) *
+                            ((nz + h->zchunk_f - 1) / h->zchunk_f);
+      under_one_wave = wgs < 2048;       // (two waves of workgroups at 4 waves per SIMD)
+    }
+    if ((fused || fused_multi) && (h->autotune || under_one_wave) && !h->tuned && !h->user_geometry &&
+        (n_cells(h) >= (1LL << 20) || h->autotune == 2)) {
+      if (autotune_fused(h, st)) return -1;
+      if (fused_multi) {           // the boundary-chunk thickness follows the chosen z-chunk
+        int zb = h->bnd_planes > 0 ? h->bnd_planes : std::min(kBndPlanes, nz / 4);
+        zb = std::max(1, std::min(zb, nz / 2));
+        const PmlAxisDev& pz = h->pml[2];
+        b_lo = nb_lo ? zb : 0;
+        b_hi = nb_hi ? zb : 0;
+        if (nb_hi && pz.n_lo > 0) b_hi = std::min(b_hi, nz - pz.n_lo - 1);
+        if (nb_lo && pz.n_hi > 0) b_lo = std::min(b_lo, nz - pz.n_hi - 1);
+      }
+    }
+    // (a rank of a z-slab run samples its own slab; nothing is exchanged while it does.  >= 100: any size — test aid)
+    if ((fused || fused_multi) && !h->placement_done && (h->placement_tries % 100) > 0 &&
+        (n_cells(h) >= (fused ? (1LL << 24) : (1LL << 22)) || h->placement_tries >= 100)) {
+      const int tries = h->placement_tries;
+      h->placement_tries = tries % 100;
+      const int prc = probe_placement(h, st);
+      h->placement_tries = tries;
+      if (prc) return -1;
+    }
+    primed = false;
+    // z-slab ranks carry the CPML recursions inside their sweeps as one GPU does (same arithmetic and summation order):
+    // the x / y recursions are local in z, the z recursion stays two planes clear of the cuts, and the one thing a rank
+    // lacks — the H-side psi of its ghost plane -1, for the chunk prologue at plane 0 — comes with the ghost planes
+    // (exchange_fused_all).  pml_in_m: axes inside the sweep; bits 0 / 1 agree on all ranks, bit 2 only end ranks have.
+    // ON REQUEST only (FDTD_OPT_PML_FUSED > 0 on every rank): measured inside engines on the per-rank proxy (profiles/
+    // r04p, r04q: 512 x 512 slabs with CPML on x and y, exchange included) the slab kernels win on thin slabs — 64 planes
+    // 0.304 vs 0.352 ms, 128 planes 0.565 vs 0.594 — and tie at 256 (1.069 vs 1.067): the interior goes out as three
+    // partial launches on one stream there, and the all-axes instantiation runs its few tiles at 2 waves per SIMD.
+    pml_in_m = 0;
+    if (fused_multi && any_pml(h) && h->pml_fused > 0 && 64 * (h->rows_f + 1) <= 512)
+      pml_in_m = h->pml_fused & pml_in_sweep_mask(h);
+    psi_ghosts = fused_multi && (pml_in_m & 3) != 0;
+    return 0;
   }
-  // (a rank of a z-slab run samples its own slab; nothing is exchanged while it does.  >= 100: any size — test aid)
-  if ((fused || fused_multi) && !h->placement_done && (h->placement_tries % 100) > 0 &&
-      (n_cells(h) >= (fused ? (1LL << 24) : (1LL << 22)) || h->placement_tries >= 100)) {
-    const int tries = h->placement_tries;
-    h->placement_tries = tries % 100;
-    const int prc = probe_placement(h, st);
-    h->placement_tries = tries;
-    if (prc) return -1;
-  }
-  bool primed = false;
-  // z-slab ranks carry the CPML recursions inside their sweeps as one GPU does (same arithmetic and summation order):
-  // the x / y recursions are local in z, the z recursion stays two planes clear of the cuts, and the one thing a rank
-  // lacks — the H-side psi of its ghost plane -1, for the chunk prologue at plane 0 — comes with the ghost planes
-  // (exchange_fused_all).  pml_in_m: axes inside the sweep; bits 0 / 1 agree on all ranks, bit 2 only end ranks have.
-  // ON REQUEST only (FDTD_OPT_PML_FUSED > 0 on every rank): measured inside engines on the per-rank proxy (profiles/
-  // r04p, r04q: 512 x 512 slabs with CPML on x and y, exchange included) the slab kernels win on thin slabs — 64 planes
-  // 0.304 vs 0.352 ms, 128 planes 0.565 vs 0.594 — and tie at 256 (1.069 vs 1.067): the interior goes out as three
-  // partial launches on one stream there, and the all-axes instantiation runs its few tiles at 2 waves per SIMD.
-  int pml_in_m = 0;
-  if (fused_multi && any_pml(h) && h->pml_fused > 0 && 64 * (h->rows_f + 1) <= 512)
-    pml_in_m = h->pml_fused & pml_in_sweep_mask(h);
-  const bool psi_ghosts = fused_multi && (pml_in_m & 3) != 0;
-  auto e_post = [&](long long n, int k0, int k1, hipStream_t s, bool replica) {
+  void e_post(long long n, int k0, int k1, hipStream_t s, bool replica) {
     launch_pml(h, true, k0, k1, s, 7 & ~pml_in_m);
     launch_sources(h, true, n, k0, k1, s, replica);
     launch_damp(h, true, k0, k1, s);       // before the ADE pass: its stored E^{n+1} is the damped one
     launch_ade(h, k0, k1, s);
-  };
-  auto h_pre = [&](long long n, int k0, int k1, hipStream_t s, bool replica) {
+  }
+  void h_pre(long long n, int k0, int k1, hipStream_t s, bool replica) {
     fill_mirror(h, s, k0, k1);             // (E^n and H^{n-1/2} of these planes are complete: the images beyond PMC plus walls first)
     launch_damp(h, false, k0, k1, s);
     launch_sources(h, false, n, k0, k1, s, replica);
     launch_pml(h, false, k0, k1, s, 7 & ~pml_in_m);
-  };
-  auto rec_at = [&](long long n) {
+  }
+  bool rec_at(long long n) {
     for (Monitor& m : h->mons) if (m.next < m.steps.size() && m.steps[m.next] == n) return true;
     return false;
-  };
+  }
   // all planes on st: monitors of step n, H-side pre-corrections, then the exchange on cs
-  auto prime = [&](long long n) -> int {
+  int prime(long long n) {
     if (rec_at(n)) record_monitors(h, n, false, st);
     h_pre(n, 0, nz, st, false);
     advance_tfsf_aux(h, false, n, st, false);
@@ -2905,45 +2976,61 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     if (exchange_fused_all(h, cs, psi_ghosts)) return -1;
     primed = true;
     return 0;
-  };
-  if (fused_multi) {
-    // the comm-stream replica of the 1-D incident grids starts from the main one
-    for (Tfsf& t : h->tfsf) {
-      HIPCHK(h, hipMemcpyAsync(t.e1c, t.e1, ((size_t)t.n_aux + 1) * 4, hipMemcpyDeviceToDevice, st));
-      HIPCHK(h, hipMemcpyAsync(t.h1c, t.h1, (size_t)t.n_aux * 4, hipMemcpyDeviceToDevice, st));
-    }
-    if (ensure_second_set(h)) return -1;
   }
-  // Two-stream schedule of one step (st = main stream, cs = comm stream):
-  //   cs: [H top plane] -> send/recv H -> [E bottom plane] -> send/recv E      (boundary planes first)
-  //   st: [H interior ] ----------------> [E interior    ]
-  // Cross-stream edges (RAW and WAR), one event each:
-  //   ev_e_int : E interior of step n-1 done     -> cs may update/ship H top plane (reads E[nz-1])
-  //   ev_e_bnd : E plane 0 of step n-1 done (cs) -> st may run H interior (reads E[0]) and monitors
-  //   ev_h_int : H interior done                 -> cs may update E plane 0 (reads H[0])
-  //   ev_h_bnd : H top plane done (cs)           -> st may run E interior (reads H[nz-1])
-  // Ghost planes are only touched on cs, in stream order.  No host synchronisation in the loop.
-  // ---- slab-interleaved two-step schedule (one GPU, fused sweep; FDTD_OPT_TBLOCK) ---------------------------------
-  // Two time steps per pass over the grid, slab by slab of T planes:  A(s) = step n on slab s (set a -> set b),
-  // B(s) = step n+1 on slab s (b -> a, IN PLACE of what A read), issued  A(0) A(1) B(0) A(2) B(1) ... : B(s) follows
-  // A(s+1) because its top plane differentiates E^{n+1} of slab s+1's first plane, and it must not overwrite a's slab s
-  // before A(s+1)'s chunk prologue has read its top plane.  What B(s) reads was written two launches earlier — 2 T planes
-  // x 6 arrays, within the 256 MiB Infinity Cache for T <= 16 at 512^2 cells per plane — so per step pair the arrays
-  // cross the HBM interface about three times (read a, write b, write a) instead of four.  Every correction launch takes
-  // a plane range already (the z-slab schedule uses them the same way): H-side pre-corrections of a slab go out in front
-  // of its sweep, E-side ones behind it.  The same kernels, the same arithmetic on the same values: bit-identical to
-  // single steps (tests/test_emu_fused.py, tests/test_gpu_production_path.py).  Not with CPML or TFSF (their state is
-  // advanced per whole step), not across a periodic z (the ghost planes wrap around the slab order), and only for step
-  // pairs in which no monitor records and no field-decay check falls on the middle step.
-  const int tb_req = h->tblock < 0 ? 0 : (h->tblock % 4096);
-  const bool tb_two_streams = h->tblock > 4096 && h->stream_overlap == 1;
-  const bool tb_ok = fused && tb_req > 0 && !any_pml(h) && h->tfsf.empty() && h->cfg.bc[4] != FDTD_BC_PERIODIC &&
-                     h->mirror_wall[0] < 0 && h->mirror_wall[1] < 0 && h->mirror_wall[2] < 0 && h->aniso.empty() &&
-                     nz >= 2 * tb_req;
-  h->two_step_pairs = 0;
-  h->tblock_used = tb_ok ? tb_req : 0;
-  std::vector<hipEvent_t> tb_ev;                         // [2 s] = A(s) done, [2 s + 1] = B(s) done (two-stream mode)
-  auto tb_pair = [&](long long n) -> int {
+  // the schedules a run may use besides single steps: the fused z-slab pipeline, the slab-interleaved two-step schedule, captured step pairs
+  int setup_schedules() {
+    if (fused_multi) {
+      // the comm-stream replica of the 1-D incident grids starts from the main one
+      for (Tfsf& t : h->tfsf) {
+        HIPCHK(h, hipMemcpyAsync(t.e1c, t.e1, ((size_t)t.n_aux + 1) * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(t.h1c, t.h1, (size_t)t.n_aux * 4, hipMemcpyDeviceToDevice, st));
+      }
+      if (ensure_second_set(h)) return -1;
+    }
+    // Two-stream schedule of one step (st = main stream, cs = comm stream):
+    //   cs: [H top plane] -> send/recv H -> [E bottom plane] -> send/recv E      (boundary planes first)
+    //   st: [H interior ] ----------------> [E interior    ]
+    // Cross-stream edges (RAW and WAR), one event each:
+    //   ev_e_int : E interior of step n-1 done     -> cs may update/ship H top plane (reads E[nz-1])
+    //   ev_e_bnd : E plane 0 of step n-1 done (cs) -> st may run H interior (reads E[0]) and monitors
+    //   ev_h_int : H interior done                 -> cs may update E plane 0 (reads H[0])
+    //   ev_h_bnd : H top plane done (cs)           -> st may run E interior (reads H[nz-1])
+    // Ghost planes are only touched on cs, in stream order.  No host synchronisation in the loop.
+    // ---- slab-interleaved two-step schedule (one GPU, fused sweep; FDTD_OPT_TBLOCK) ---------------------------------
+    // Two time steps per pass over the grid, slab by slab of T planes:  A(s) = step n on slab s (set a -> set b),
+    // B(s) = step n+1 on slab s (b -> a, IN PLACE of what A read), issued  A(0) A(1) B(0) A(2) B(1) ... : B(s) follows
+    // A(s+1) because its top plane differentiates E^{n+1} of slab s+1's first plane, and it must not overwrite a's slab s
+    // before A(s+1)'s chunk prologue has read its top plane.  What B(s) reads was written two launches earlier — 2 T planes
+    // x 6 arrays, within the 256 MiB Infinity Cache for T <= 16 at 512^2 cells per plane — so per step pair the arrays
+    // cross the HBM interface about three times (read a, write b, write a) instead of four.  Every correction launch takes
+    // a plane range already (the z-slab schedule uses them the same way): H-side pre-corrections of a slab go out in front
+    // of its sweep, E-side ones behind it.  The same kernels, the same arithmetic on the same values: bit-identical to
+    // single steps (tests/test_emu_fused.py, tests/test_gpu_production_path.py).  Not with CPML or TFSF (their state is
+    // advanced per whole step), not across a periodic z (the ghost planes wrap around the slab order), and only for step
+    // pairs in which no monitor records and no field-decay check falls on the middle step.
+    tb_req = h->tblock < 0 ? 0 : (h->tblock % 4096);
+    tb_two_streams = h->tblock > 4096 && h->stream_overlap == 1;
+    tb_ok = fused && tb_req > 0 && !any_pml(h) && h->tfsf.empty() && h->cfg.bc[4] != FDTD_BC_PERIODIC &&
+                       h->mirror_wall[0] < 0 && h->mirror_wall[1] < 0 && h->mirror_wall[2] < 0 && h->aniso.empty() &&
+                       nz >= 2 * tb_req;
+    h->two_step_pairs = 0;
+    h->tblock_used = tb_ok ? tb_req : 0;
+    // ---- captured step pairs (hipGraph) ------------------------------------------------------------------------------
+    // Small grids are bound by dependent launches (64^3: three launches, 31 us per step; profiles/r02h): a run of steps
+    // without monitor records or decay checks is captured ONCE as a graph of two steps (set a -> b -> a, psi parity back)
+    // and replayed.  A graph bakes its kernel arguments, so the source kernels of a captured launch read the step counter
+    // from device memory (step_dev + offset; the graph's last node advances it by two).  Same launches, same order, same
+    // arguments otherwise: bit-identical to direct launches (tests/test_gpu_production_path.py).  One stream only: not
+    // with the three-launch CPML split of large grids, not on z-slabs, not with per-launch timing events.
+    split_now = (h->pml_split < 0 ? n_cells(h) >= (1LL << 24) : h->pml_split != 0) && any_pml(h) &&
+                           (((h->pml_fused < 0 ? 7 : h->pml_fused) & pml_in_sweep_mask(h)) & 6) != 0;
+    graph_ok = fused && !tb_ok && !split_now && !(h->cfg.flags & FDTD_FLAG_TIME_KERNELS) && h->aniso.empty() &&
+                    h->use_graph > 0;      // on request only: measured on ROCm 7.2 (profiles/r3i) a replayed pair is ~3 us per step
+                                           // SLOWER than launching its kernels (64^3 17.6 -> 20.8, 128^3 28.8 -> 31.4, 200^3 81.5 -> 84.0)
+    h->graph_pairs = 0;
+    return 0;
+  }
+  int tb_pair(long long n) {
     const int T = tb_req, S = (nz + T - 1) / T;
     if (ensure_second_set(h)) return -1;
     if (tb_two_streams && tb_ev.empty()) {
@@ -2991,9 +3078,9 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     if (tb_two_streams) HIPCHK(h, hipStreamWaitEvent(st, tb_ev[(size_t)2 * (S - 1) + 1], 0));
     h->two_step_pairs++;
     return 0;
-  };
+  }
   // one step of the one-GPU fused path (n = its time step; rec_post: monitors record behind the sweep)
-  auto fused_one = [&](long long n, bool rec_post) -> int {
+  int fused_one(long long n, bool rec_post) {
     // H-side corrections are additive: pre-apply them to H^{n-1/2}; E-side ones follow the sweep.
     // With pml_in the CPML recursions run inside the sweep (same arithmetic, no slab kernels).
     // pml_in = axes whose recursions run inside the sweep (default: all that have layers; FDTD_OPT_PML_FUSED
@@ -3049,29 +3136,14 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     advance_tfsf_aux(h, true, n, st);
     fill_ghost_fused(h, st);
     return 0;
-  };
-  // ---- captured step pairs (hipGraph) ------------------------------------------------------------------------------
-  // Small grids are bound by dependent launches (64^3: three launches, 31 us per step; profiles/r02h): a run of steps
-  // without monitor records or decay checks is captured ONCE as a graph of two steps (set a -> b -> a, psi parity back)
-  // and replayed.  A graph bakes its kernel arguments, so the source kernels of a captured launch read the step counter
-  // from device memory (step_dev + offset; the graph's last node advances it by two).  Same launches, same order, same
-  // arguments otherwise: bit-identical to direct launches (tests/test_gpu_production_path.py).  One stream only: not
-  // with the three-launch CPML split of large grids, not on z-slabs, not with per-launch timing events.
-  const bool split_now = (h->pml_split < 0 ? n_cells(h) >= (1LL << 24) : h->pml_split != 0) && any_pml(h) &&
-                         (((h->pml_fused < 0 ? 7 : h->pml_fused) & pml_in_sweep_mask(h)) & 6) != 0;
-  bool graph_ok = fused && !tb_ok && !split_now && !(h->cfg.flags & FDTD_FLAG_TIME_KERNELS) && h->aniso.empty() &&
-                  h->use_graph > 0;      // on request only: measured on ROCm 7.2 (profiles/r3i) a replayed pair is ~3 us per step
-                                         // SLOWER than launching its kernels (64^3 17.6 -> 20.8, 128^3 28.8 -> 31.4, 200^3 81.5 -> 84.0)
-  struct GraphRec { const float* set; int parity; hipGraphExec_t exec; };
-  std::vector<GraphRec> graphs;
-  h->graph_pairs = 0;
-  auto sources_alive = [&](long long n) {
+  }
+  bool sources_alive(long long n) {
     for (const PointSrc& s : h->psrc) if (n >= s.n_steps) return false;
     for (const Tfsf& t : h->tfsf) if (n >= t.n_steps) return false;
     return true;
-  };
+  }
   // 0 = the pair (n, n + 1) was replayed; 1 = capture not available (caller launches directly); < 0 = error
-  auto graph_pair = [&](long long n) -> int {
+  int graph_pair(long long n) {
     hipGraphExec_t exec = nullptr;
     for (const GraphRec& r : graphs) if (r.set == h->f.ex && r.parity == (h->pml_parity | (h->pml_e_parity << 1))) exec = r.exec;
     if (!exec) {
@@ -3111,49 +3183,57 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     h->step_dev_value = n + 2;
     h->graph_pairs++;
     return 0;
-  };
-  bool f2_ok = fused && !tb_ok && fused2_eligible(h);
-  ShellGeom sg{};
-  bool f2s_ok = false;
-  h->f2_off_reason = !fused ? FDTD_F2_OFF_VARIANT : (tb_ok ? FDTD_F2_OFF_DISABLED : 0);
-  ZPlan zp_base, zp_src;               // the bulk's planes: without / with the z holes of the source lists
-  if (fused && !tb_ok && !f2_ok) {
-    const bool shell = any_pml(h) || any_periodic(h) || !h->ade.empty();
-    h->f2_off_reason = shell ? shell_why_not(h, &sg, &zp_base, &zp_src) : fused2_why_not(h);
-    f2s_ok = shell && h->f2_off_reason == 0;
   }
-  // shell2 pairs: the shell by shell2_step_kernel (two steps per sweep, psi carried) instead of two single steps
-  bool s2_ok = false, s2_deep = false;
-  if (fused && !tb_ok && !f2_ok && any_pml(h)) {
-    ShellGeom g2{};
-    const int why2 = shell2_why_not(h, &g2);
-    if (why2 == 0) {
-      s2_ok = true; sg = g2;                               // (the same geometry shell_why_not finds)
-      s2_deep = shell2_sources_deep(h, sg);
-      h->f2_off_reason = 0;
-    }
-  }
-  h->f2_dyn_reason = 0;
-  if (f2_ok || f2s_ok || s2_ok) {
-    if (fused2_sources(h)) return -1;
-  }
-  // (the third field set: + 50 % field memory.  Where it does not fit, the run keeps single steps instead of failing)
-  if (f2s_ok && ensure_third_set(h)) {
-    (void)hipGetLastError();
-    h->err.clear();
+  // which forms of step pairs this run may take (decided once; begin_step judges every pair): plain pairs, shell pairs (round-4
+  // form), shell2 pairs, slab pairs of a z-slab rank — and what they need (source tables, the third field set, two streams)
+  int setup_pairs() {
+    f2_ok = fused && !tb_ok && fused2_eligible(h);
+    sg = ShellGeom{};
     f2s_ok = false;
-    h->f2_off_reason = FDTD_F2_OFF_MEMORY;
-  }
-  if ((f2s_ok || s2_ok) && probe_stream_overlap(h)) return -1;
-  // z-slab ranks (pipelined schedule): step pairs with the planes next to the neighbour faces as the shell
-  bool f2m_ok = fused_multi && !any_pml(h) && !h->has_damp && h->shell_on != 0 && nz >= 8 && fused2_why_not(h, true) == 0;
-  if (fused_multi) h->f2_off_reason = f2m_ok ? 0 : (any_pml(h) || h->has_damp ? FDTD_F2_OFF_COMM : (fused2_why_not(h, true) ? fused2_why_not(h, true) : FDTD_F2_OFF_COMM));
-  if (f2m_ok) {
-    if (fused2_sources(h)) return -1;
-    if (ensure_third_set(h)) { (void)hipGetLastError(); h->err.clear(); f2m_ok = false; h->f2_off_reason = FDTD_F2_OFF_MEMORY; }
+    h->f2_off_reason = !fused ? FDTD_F2_OFF_VARIANT : (tb_ok ? FDTD_F2_OFF_DISABLED : 0);
+    if (fused && !tb_ok && !f2_ok) {
+      const bool shell = any_pml(h) || any_periodic(h) || !h->ade.empty();
+      h->f2_off_reason = shell ? shell_why_not(h, &sg, &zp_base, &zp_src) : fused2_why_not(h);
+      f2s_ok = shell && h->f2_off_reason == 0;
+    }
+    // shell2 pairs: the shell by shell2_step_kernel (two steps per sweep, psi carried) instead of two single steps
+    s2_ok = false, s2_deep = false;
+    if (fused && !tb_ok && !f2_ok && any_pml(h)) {
+      ShellGeom g2{};
+      const int why2 = shell2_why_not(h, &g2);
+      if (why2 == 0) {
+        s2_ok = true; sg = g2;                               // (the same geometry shell_why_not finds)
+        s2_deep = shell2_sources_deep(h, sg);
+        h->f2_off_reason = 0;
+      }
+    }
+    h->f2_dyn_reason = 0;
+    if (f2_ok || f2s_ok || s2_ok) {
+      if (fused2_sources(h)) return -1;
+    }
+    // (the third field set: + 50 % field memory.  Where it does not fit, the run keeps single steps instead of failing)
+    if (f2s_ok && ensure_third_set(h)) {
+      (void)hipGetLastError();
+      h->err.clear();
+      f2s_ok = false;
+      h->f2_off_reason = FDTD_F2_OFF_MEMORY;
+    }
+    if ((f2s_ok || s2_ok) && probe_stream_overlap(h)) return -1;
+    // z-slab ranks (pipelined schedule): step pairs with the planes next to the neighbour faces as the shell
+    f2m_ok = fused_multi && !any_pml(h) && !h->has_damp && h->shell_on != 0 && nz >= 8 && fused2_why_not(h, true) == 0;
+    if (fused_multi) h->f2_off_reason = f2m_ok ? 0 : (any_pml(h) || h->has_damp ? FDTD_F2_OFF_COMM : (fused2_why_not(h, true) ? fused2_why_not(h, true) : FDTD_F2_OFF_COMM));
+    if (f2m_ok) {
+      if (fused2_sources(h)) return -1;
+      if (ensure_third_set(h)) { (void)hipGetLastError(); h->err.clear(); f2m_ok = false; h->f2_off_reason = FDTD_F2_OFF_MEMORY; }
+    }
+    h->fused2_pairs = 0;
+    h->shell_pairs = 0;
+    h->shell2_pairs = 0;
+    done = 0;
+    return 0;
   }
   // steps n and n + 1 of a grid walled by CPML: the bulk as ONE two-step sweep on st, the shell as two single steps on cs
-  auto shell_pair = [&](long long n, const F2Table* tb, const ZPlan& zp) -> int {
+  int shell_pair(long long n, const F2Table* tb, const ZPlan& zp) {
     hipStream_t cs = (h->shell_on == 2) ? st : h->comm_stream;       // (2: shell behind the bulk on ONE stream — a measuring aid)
     const int pml_in = 7 & pml_in_sweep_mask(h);
     if (ensure_second_set(h) || ensure_third_set(h) || ensure_pml_blocks(h, pml_in)) return -1;
@@ -3200,10 +3280,10 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     advance_tfsf_aux(h, true, n + 1, st);
     fill_ghost_fused(h, st);
     return 0;
-  };
+  }
   // steps n and n + 1 of a grid walled by CPML, shell2 form: the bulk as ONE clipped two-step sweep on st, the shell's boxes as
   // shell2_step_kernel launches on cs — all read set A / the current psi sets, all write disjoint cells of set B / the other psi sets
-  auto shell2_pair = [&](long long n, const F2Table* tb) -> int {
+  int shell2_pair(long long n, const F2Table* tb) {
     hipStream_t cs = (h->shell_on == 2) ? st : h->comm_stream;       // (2: shell behind the bulk on ONE stream — a measuring aid)
     if (ensure_second_set(h) || ensure_pml_blocks2(h)) return -1;
     if (!h->ev_shell_a) {
@@ -3234,9 +3314,9 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     advance_tfsf_aux(h, true, n + 1, st);
     fill_ghost_fused(h, st);
     return 0;
-  };
+  }
   // every monitor of the pair's plan inside ONE interval of the bulk's planes (the sweep copies the middle step out only there)
-  auto plan_in_bulk = [&](const F2Plan& pl, const ZPlan& zp) {
+  bool plan_in_bulk(const F2Plan& pl, const ZPlan& zp) {
     auto inside = [&](const Monitor& m) {
       for (int i = 0; i < zp.n; ++i) if (m.box.lo2 >= zp.a[i] && m.box.lo2 + m.box.nz <= zp.b[i]) return true;
       return false;
@@ -3244,26 +3324,22 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     for (int q : pl.mons) if (!inside(h->mons[(size_t)q])) return false;
     for (int q : pl.dfts) if (!inside(h->mons[(size_t)q])) return false;
     return true;
-  };
-  F2Plan f2_plan;
-  h->fused2_pairs = 0;
-  h->shell_pairs = 0;
-  h->shell2_pairs = 0;
-  int64_t done = 0;
-  for (; done < n_steps; ++done) {
-    const long long n = h->step;
-    const bool rec = !fused_multi && rec_at(n);
+  }
+  // the step about to be issued: does a monitor record at it (rec), can steps n and n + 1 go out as one sweep (pair), in which form (use_s2, zp)
+  int begin_step() {
+    n = h->step;
+    rec = !fused_multi && rec_at(n);
     if (rec && multi) {
       HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
       HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
     }
     // steps n and n + 1 as ONE sweep?  (fdtd_kernels2.hpp; no decay check on the middle step, sources all alive or all spent,
     // every monitor that records at n or n + 1 a small time monitor the sweep can sample)
-    bool src_alive = false;
-    int src_why = 0;
-    const ZPlan* zp = &zp_base;
-    bool pair = fused && (f2_ok || f2s_ok || s2_ok) && done + 2 <= n_steps && !(h->decay_every > 0 && ((n + 1) % h->decay_every) == 0);
-    bool use_s2 = false;
+    src_alive = false;
+    src_why = 0;
+    zp = &zp_base;
+    pair = fused && (f2_ok || f2s_ok || s2_ok) && done + 2 <= n_steps && !(h->decay_every > 0 && ((n + 1) % h->decay_every) == 0);
+    use_s2 = false;
     if (pair) {
       src_why = fused2_sources_why_not(h, n, &src_alive);
       // shell2 form: the boxes apply no sources — lists that inject must lie deep inside the bulk
@@ -3293,169 +3369,140 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
       HIPCHK(h, hipEventRecord(h->ev_rec, st));
       HIPCHK(h, hipStreamWaitEvent(cs, h->ev_rec, 0));
     }
-    if (fused_multi) {
-      if (!primed && prime(n)) return -1;
-      // ---- slab pair: steps n and n + 1 of a z-slab rank -----------------------------------------------------------------
-      // The two-step sweep advances the planes two or more away from a neighbour face (it reads the slab's own planes
-      // only: no ghost plane, no dependence on the wire); the two planes next to a neighbour face — its shell — take two
-      // single steps on the comm stream, through the third set, and ship their planes after EACH of them: the messages a
-      // neighbour receives are those of two single steps, in the same order (a rank may take a pair while its neighbour
-      // takes single steps).  Same kernels and formulas: the same bits (tests/test_dist_gloo.py).  Entry and exit state:
-      // "primed" (above).  Pairs keep clear of monitor records, decay checks and the end of the run (joined tails).
-      auto decay_at = [&](long long m) { return h->decay_every > 0 && (m % h->decay_every) == 0; };
-      bool src_alive_m = false;
-      if (f2m_ok && done + 3 <= n_steps && !rec_at(n) && !rec_at(n + 1) && !rec_at(n + 2) && !decay_at(n + 1) && !decay_at(n + 2) &&
-          fused2_sources_why_not(h, n, &src_alive_m) == 0) {
-        F2Plan none;
-        const F2Table* tb = fused2_table(h, none, src_alive_m);
-        if (!tb) return -1;
-        const int bl = nb_lo ? 2 : 0, bh = nb_hi ? 2 : 0;
-        const FieldP A = h->f, B = h->f2, T = h->f3;
-        ShellSets s1{A, T, 0, 0, 0}, s2{T, B, 0, 0, 0};
-        // (host order: the long bulk sweep is handed to the device first — the comm stream's dozen launches and two RCCL groups
-        //  take the host longer to issue than the device needs for them; issued first they left the device idle for 30 us per
-        //  pair in front of the bulk, profiles/r4e)
-        HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
-        // bulk: both steps in one sweep, set A -> set B
-        HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
-        const ClipP clip{0, h->g.nx, 0, h->g.ny, bl, nz - bh};
-        bool s2done = false;
-        if (launch_fused2(h, n, st, tb, &s2done, nullptr, &clip)) return -1;
-        // shell, step one: the boundary planes and one more (what step two differentiates), set A -> set T
-        if (launch_fused_range(h, 0, bl ? bl + 1 : 0, cs, 0, bh ? nz - bh - 1 : nz, nz, -1, 0, 0, false, &s1)) return -1;
-        HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
-        if (bl) { launch_sources(h, true, n, 0, bl + 1, cs, false, &T); launch_sources(h, false, n + 1, 0, bl + 1, cs, false, &T); }
-        if (bh) { launch_sources(h, true, n, nz - bh - 1, nz, cs, false, &T); launch_sources(h, false, n + 1, nz - bh - 1, nz, cs, false, &T); }
-        if (exchange_fused_all(h, cs, false, &T)) return -1;                  // what the neighbours expect after step n
-        // shell, step two: set T -> set B
-        if (launch_fused_range(h, 0, bl, cs, 0, nz - bh, nz, -1, 0, 0, false, &s2)) return -1;
-        // corrections of step n + 1 (E side) and n + 2 (H side): boundary planes on cs, then their planes travel
-        if (bl) { launch_sources(h, true, n + 1, 0, bl, cs, false, &B); launch_sources(h, false, n + 2, 0, bl, cs, false, &B); }
-        if (bh) { launch_sources(h, true, n + 1, nz - bh, nz, cs, false, &B); launch_sources(h, false, n + 2, nz - bh, nz, cs, false, &B); }
-        HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
-        if (exchange_fused_all(h, cs, false, &B)) return -1;
-        swap_sets(h);                                                          // h->f = B: E^{n+2}, H^{n+3/2}
-        launch_sources(h, true, n + 1, bl, nz - bh, st);
-        launch_sources(h, false, n + 2, bl, nz - bh, st);
-        HIPCHK(h, hipEventRecord(h->ev_e_int, st));
-        h->fused2_pairs++;
-        h->step = n + 2;
-        ++done;
-        continue;
-      }
-      const bool decay_step = h->decay_every > 0 && ((n + 1) % h->decay_every) == 0;
-      const bool last = (done + 1 == n_steps) || decay_step;
-      // sweeps: boundary chunks (one launch) on cs, interior on st
+    return 0;
+  }
+  // one step — or, where it can, a step pair — of a z-slab rank on the pipelined fused schedule (header comment: setup; slab pair: below).
+  // -> 1: a pair was taken (two steps, no decay check due), 0: one step, < 0: error
+  int slab_rank_step() {
+    if (!primed && prime(n)) return -1;
+    // ---- slab pair: steps n and n + 1 of a z-slab rank -----------------------------------------------------------------
+    // The two-step sweep advances the planes two or more away from a neighbour face (it reads the slab's own planes
+    // only: no ghost plane, no dependence on the wire); the two planes next to a neighbour face — its shell — take two
+    // single steps on the comm stream, through the third set, and ship their planes after EACH of them: the messages a
+    // neighbour receives are those of two single steps, in the same order (a rank may take a pair while its neighbour
+    // takes single steps).  Same kernels and formulas: the same bits (tests/test_dist_gloo.py).  Entry and exit state:
+    // "primed" (above).  Pairs keep clear of monitor records, decay checks and the end of the run (joined tails).
+    auto decay_at = [&](long long m) { return h->decay_every > 0 && (m % h->decay_every) == 0; };
+    bool src_alive_m = false;
+    if (f2m_ok && done + 3 <= n_steps && !rec_at(n) && !rec_at(n + 1) && !rec_at(n + 2) && !decay_at(n + 1) && !decay_at(n + 2) &&
+        fused2_sources_why_not(h, n, &src_alive_m) == 0) {
+      F2Plan none;
+      const F2Table* tb = fused2_table(h, none, src_alive_m);
+      if (!tb) return -1;
+      const int bl = nb_lo ? 2 : 0, bh = nb_hi ? 2 : 0;
+      const FieldP A = h->f, B = h->f2, T = h->f3;
+      ShellSets s1{A, T, 0, 0, 0}, s2{T, B, 0, 0, 0};
+      // (host order: the long bulk sweep is handed to the device first — the comm stream's dozen launches and two RCCL groups
+      //  take the host longer to issue than the device needs for them; issued first they left the device idle for 30 us per
+      //  pair in front of the bulk, profiles/r4e)
       HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
-      // (the boundary chunks lie clear of the z slabs: their launch carries x / y at most)
-      const int pml_b = pml_in_m & 3;
-      if (b_lo > 0 && b_hi > 0) { if (launch_fused_range(h, 0, b_lo, cs, pml_b, nz - b_hi, nz)) return -1; }
-      else if (b_lo > 0) { if (launch_fused_range(h, 0, b_lo, cs, pml_b)) return -1; }
-      else if (b_hi > 0) { if (launch_fused_range(h, nz - b_hi, nz, cs, pml_b)) return -1; }
-      HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
+      // bulk: both steps in one sweep, set A -> set B
       HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
-      if ((pml_in_m & 6) == 0) {
-        if (launch_fused_range(h, b_lo, nz - b_hi, st, pml_in_m)) return -1;
-      } else {
-        // interior planes by tile class, as on one GPU (all three on the main stream: the other one ships ghost planes)
-        const int R = h->rows_f, nby_all = (h->g.ny + R - 1) / R, ki = b_lo, ke = nz - b_hi;
-        const PmlAxisDev &py = h->pml[1], &pz = h->pml[2];
-        const bool in_y = (pml_in_m & 2) && py.ns > 0, in_z = (pml_in_m & 4) && pz.ns > 0;
-        const int za = std::min(ke, std::max(ki, (in_z && pz.lo > 0) ? std::min(nz, pz.lo + 1) : 0));
-        const int zc = std::max(za, std::min(ke, (in_z && pz.hi0 < nz) ? pz.hi0 : nz));
-        const int ty_a = (in_y && py.lo > 0) ? std::min(nby_all, py.lo / R + 1) : 0;
-        const int ty_c = (in_y && py.hi0 < h->g.ny) ? std::max(ty_a, py.hi0 / R) : nby_all;
-        // (all on the main stream.  Edge launches on a third stream were tried: no gain, and an engine with three
-        //  streams pushed the next engine of the process onto shared hardware queues — its two streams serialised,
-        //  3x slower steps, profiles/r04r)
-        if ((za > ki || zc < ke) && launch_fused_range(h, ki, za, st, pml_in_m, zc, ke, -1, 0, 0, true)) return -1;
-        if (launch_fused_range(h, za, zc, st, pml_in_m & 3, 0, 0, ty_a + (nby_all - ty_c), ty_a, ty_c - ty_a, true)) return -1;
-        if (launch_fused_range(h, za, zc, st, pml_in_m & 1, 0, 0, ty_c - ty_a, 0, ty_a)) return -1;
-      }
-      swap_sets(h);
-      swap_psi_h(h, pml_in_m);
-      const bool rec_post = rec_at(n);
-      if (rec_post || last || rec_at(n + 1)) {
-        // joined tail: everything after the sweeps on st
-        HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
-        if (rec_post) record_monitors(h, n, true, st);
-        e_post(n, 0, nz, st, false);
-        advance_tfsf_aux(h, true, n, st, false);
-        advance_tfsf_aux(h, true, n, st, true);
-        primed = false;
-        if (!last && prime(n + 1)) return -1;
-        if (last) {           // leave both streams joined; the next step (or run) primes again
-          HIPCHK(h, hipEventRecord(h->ev_e_int, st));
-          HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
-          HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
-        }
-      } else {
-        e_post(n, 0, b_lo, cs, true);
-        e_post(n, nz - b_hi, nz, cs, true);
-        advance_tfsf_aux(h, true, n, cs, true);
-        h_pre(n + 1, 0, b_lo, cs, true);
-        h_pre(n + 1, nz - b_hi, nz, cs, true);
-        advance_tfsf_aux(h, false, n + 1, cs, true);
-        HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
-        if (exchange_fused_all(h, cs, psi_ghosts)) return -1;
-        e_post(n, b_lo, nz - b_hi, st, false);
-        advance_tfsf_aux(h, true, n, st, false);
-        h_pre(n + 1, b_lo, nz - b_hi, st, false);
-        advance_tfsf_aux(h, false, n + 1, st, false);
-        HIPCHK(h, hipEventRecord(h->ev_e_int, st));
-      }
-      h->step = n + 1;
-    } else if (fused && tb_ok && done + 2 <= n_steps && !rec && !rec_at(n + 1) &&
-               !(h->decay_every > 0 && ((n + 1) % h->decay_every) == 0)) {
-      if (tb_pair(n)) return -1;
-      h->step = n + 2;
-      ++done;                                              // (the loop header counts the second step)
-    } else if (pair && use_s2) {
-      const F2Table* tb = fused2_table(h, f2_plan, src_alive);
-      if (!tb) return -1;
-      if (shell2_pair(n, tb)) return -1;
-      h->fused2_pairs++;
-      h->shell_pairs++;
-      h->shell2_pairs++;
-      h->step = n + 2;
-      ++done;
-    } else if (pair && f2s_ok) {
-      const F2Table* tb = fused2_table(h, f2_plan, src_alive);
-      if (!tb) return -1;
-      if (shell_pair(n, tb, *zp)) return -1;
-      h->fused2_pairs++;
-      h->shell_pairs++;
-      h->step = n + 2;
-      ++done;
-    } else if (pair) {
-      const F2Table* tb = fused2_table(h, f2_plan, src_alive);
-      if (!tb) return -1;
-      bool sources2_done = false, damp2_done = true;
-      launch_sources(h, false, n, 0, nz, st);              // H-side sources of step n act on H^{n-1/2}, as before a single step
-      if (launch_fused2(h, n, st, tb, &sources2_done, &damp2_done)) return -1;
-      pair_record(h, tb, n, st);                           // (H^{n+3/2} is not touched by the E-side sources that follow)
-      if (rec_at(n + 1)) record_monitors(h, n + 1, true, st);      // DFT records at the middle step: their H terms, from the write set
-      if (!sources2_done) launch_sources(h, true, n + 1, 0, nz, st);
-      if (h->has_damp && !damp2_done) launch_damp(h, true, 0, nz, st);
-      fill_ghost_fused(h, st);
+      const ClipP clip{0, h->g.nx, 0, h->g.ny, bl, nz - bh};
+      bool s2done = false;
+      if (launch_fused2(h, n, st, tb, &s2done, nullptr, &clip)) return -1;
+      // shell, step one: the boundary planes and one more (what step two differentiates), set A -> set T
+      if (launch_fused_range(h, 0, bl ? bl + 1 : 0, cs, 0, bh ? nz - bh - 1 : nz, nz, -1, 0, 0, false, &s1)) return -1;
+      HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
+      if (bl) { launch_sources(h, true, n, 0, bl + 1, cs, false, &T); launch_sources(h, false, n + 1, 0, bl + 1, cs, false, &T); }
+      if (bh) { launch_sources(h, true, n, nz - bh - 1, nz, cs, false, &T); launch_sources(h, false, n + 1, nz - bh - 1, nz, cs, false, &T); }
+      if (exchange_fused_all(h, cs, false, &T)) return -1;                  // what the neighbours expect after step n
+      // shell, step two: set T -> set B
+      if (launch_fused_range(h, 0, bl, cs, 0, nz - bh, nz, -1, 0, 0, false, &s2)) return -1;
+      // corrections of step n + 1 (E side) and n + 2 (H side): boundary planes on cs, then their planes travel
+      if (bl) { launch_sources(h, true, n + 1, 0, bl, cs, false, &B); launch_sources(h, false, n + 2, 0, bl, cs, false, &B); }
+      if (bh) { launch_sources(h, true, n + 1, nz - bh, nz, cs, false, &B); launch_sources(h, false, n + 2, nz - bh, nz, cs, false, &B); }
+      HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
+      if (exchange_fused_all(h, cs, false, &B)) return -1;
+      swap_sets(h);                                                          // h->f = B: E^{n+2}, H^{n+3/2}
+      launch_sources(h, true, n + 1, bl, nz - bh, st);
+      launch_sources(h, false, n + 2, bl, nz - bh, st);
+      HIPCHK(h, hipEventRecord(h->ev_e_int, st));
       h->fused2_pairs++;
       h->step = n + 2;
-      ++done;
-    } else if (fused && graph_ok && done + 2 <= n_steps && !rec && !rec_at(n + 1) &&
-               !(h->decay_every > 0 && ((n + 1) % h->decay_every) == 0) && sources_alive(n + 1)) {
-      const int grc = graph_pair(n);
-      if (grc < 0) return -1;
-      if (grc == 0) {                                      // replayed: two steps done
-        h->step = n + 2;
-        ++done;
-      } else {                                             // capture not available: this step directly, no more attempts
-        if (fused_one(n, rec)) return -1;
-        h->step = n + 1;
-      }
-    } else if (fused) {
-      if (fused_one(n, rec)) return -1;
-      h->step = n + 1;
+      return 1;
+    }
+    const bool decay_step = h->decay_every > 0 && ((n + 1) % h->decay_every) == 0;
+    const bool last = (done + 1 == n_steps) || decay_step;
+    // sweeps: boundary chunks (one launch) on cs, interior on st
+    HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
+    // (the boundary chunks lie clear of the z slabs: their launch carries x / y at most)
+    const int pml_b = pml_in_m & 3;
+    if (b_lo > 0 && b_hi > 0) { if (launch_fused_range(h, 0, b_lo, cs, pml_b, nz - b_hi, nz)) return -1; }
+    else if (b_lo > 0) { if (launch_fused_range(h, 0, b_lo, cs, pml_b)) return -1; }
+    else if (b_hi > 0) { if (launch_fused_range(h, nz - b_hi, nz, cs, pml_b)) return -1; }
+    HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
+    HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
+    if ((pml_in_m & 6) == 0) {
+      if (launch_fused_range(h, b_lo, nz - b_hi, st, pml_in_m)) return -1;
     } else {
+      // interior planes by tile class, as on one GPU (all three on the main stream: the other one ships ghost planes)
+      const int R = h->rows_f, nby_all = (h->g.ny + R - 1) / R, ki = b_lo, ke = nz - b_hi;
+      const PmlAxisDev &py = h->pml[1], &pz = h->pml[2];
+      const bool in_y = (pml_in_m & 2) && py.ns > 0, in_z = (pml_in_m & 4) && pz.ns > 0;
+      const int za = std::min(ke, std::max(ki, (in_z && pz.lo > 0) ? std::min(nz, pz.lo + 1) : 0));
+      const int zc = std::max(za, std::min(ke, (in_z && pz.hi0 < nz) ? pz.hi0 : nz));
+      const int ty_a = (in_y && py.lo > 0) ? std::min(nby_all, py.lo / R + 1) : 0;
+      const int ty_c = (in_y && py.hi0 < h->g.ny) ? std::max(ty_a, py.hi0 / R) : nby_all;
+      // (all on the main stream.  Edge launches on a third stream were tried: no gain, and an engine with three
+      //  streams pushed the next engine of the process onto shared hardware queues — its two streams serialised,
+      //  3x slower steps, profiles/r04r)
+      if ((za > ki || zc < ke) && launch_fused_range(h, ki, za, st, pml_in_m, zc, ke, -1, 0, 0, true)) return -1;
+      if (launch_fused_range(h, za, zc, st, pml_in_m & 3, 0, 0, ty_a + (nby_all - ty_c), ty_a, ty_c - ty_a, true)) return -1;
+      if (launch_fused_range(h, za, zc, st, pml_in_m & 1, 0, 0, ty_c - ty_a, 0, ty_a)) return -1;
+    }
+    swap_sets(h);
+    swap_psi_h(h, pml_in_m);
+    const bool rec_post = rec_at(n);
+    if (rec_post || last || rec_at(n + 1)) {
+      // joined tail: everything after the sweeps on st
+      HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
+      if (rec_post) record_monitors(h, n, true, st);
+      e_post(n, 0, nz, st, false);
+      advance_tfsf_aux(h, true, n, st, false);
+      advance_tfsf_aux(h, true, n, st, true);
+      primed = false;
+      if (!last && prime(n + 1)) return -1;
+      if (last) {           // leave both streams joined; the next step (or run) primes again
+        HIPCHK(h, hipEventRecord(h->ev_e_int, st));
+        HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
+        HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
+      }
+    } else {
+      e_post(n, 0, b_lo, cs, true);
+      e_post(n, nz - b_hi, nz, cs, true);
+      advance_tfsf_aux(h, true, n, cs, true);
+      h_pre(n + 1, 0, b_lo, cs, true);
+      h_pre(n + 1, nz - b_hi, nz, cs, true);
+      advance_tfsf_aux(h, false, n + 1, cs, true);
+      HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
+      if (exchange_fused_all(h, cs, psi_ghosts)) return -1;
+      e_post(n, b_lo, nz - b_hi, st, false);
+      advance_tfsf_aux(h, true, n, st, false);
+      h_pre(n + 1, b_lo, nz - b_hi, st, false);
+      advance_tfsf_aux(h, false, n + 1, st, false);
+      HIPCHK(h, hipEventRecord(h->ev_e_int, st));
+    }
+    h->step = n + 1;
+    return 0;
+  }
+  // steps n and n + 1 of a run without CPML as ONE two-step sweep, all on st: set A -> set B, swap
+  int plain_pair() {
+    const F2Table* tb = fused2_table(h, f2_plan, src_alive);
+    if (!tb) return -1;
+    bool sources2_done = false, damp2_done = true;
+    launch_sources(h, false, n, 0, nz, st);              // H-side sources of step n act on H^{n-1/2}, as before a single step
+    if (launch_fused2(h, n, st, tb, &sources2_done, &damp2_done)) return -1;
+    pair_record(h, tb, n, st);                           // (H^{n+3/2} is not touched by the E-side sources that follow)
+    if (rec_at(n + 1)) record_monitors(h, n + 1, true, st);      // DFT records at the middle step: their H terms, from the write set
+    if (!sources2_done) launch_sources(h, true, n + 1, 0, nz, st);
+    if (h->has_damp && !damp2_done) launch_damp(h, true, 0, nz, st);
+    fill_ghost_fused(h, st);
+    return 0;
+  }
+  // one step of the two-pass kernels (H pass, E pass; odd row lengths, FDTD_VARIANT_ZMARCH, z-slab ranks on the AUTO variant): interior on st,
+  // the plane next to a neighbour face and the exchanges on cs; edges: ev_e_int, ev_e_bnd, ev_h_int, ev_h_bnd (setup_schedules)
+  int two_pass_step() {
     // ---------------- H phase ----------------
     const int h_top = (multi && nb_hi) ? nz - 1 : nz;      // planes [0, h_top) on st, [h_top, nz) on cs
     const bool mirrors = h->mirror_wall[0] >= 0 || h->mirror_wall[1] >= 0 || h->mirror_wall[2] >= 0;
@@ -3524,63 +3571,136 @@ int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user
     }
     if (!multi || !nb_hi) fill_ghost_e(h, st);   // physical z-max face of this slab (periodic)
     h->step = n + 1;
+    return 0;
+  }
+  // field decay / divergence every decay_every steps (joins the streams; the only host synchronisation of the loop).  -> 1: the run ends here
+  int decay_check() {
+  // ---------------- field decay / divergence ----------------
+  if (h->decay_every > 0 && (h->step % h->decay_every) == 0) {
+    if (multi) HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
+    double en = 0.0;
+    if (eval_energy(h, st, &en)) return -1;
+    if (multi) {
+      // sum over ranks (1 double every decay_every steps).  Every RCCL call of this communicator
+      // is issued on the comm stream, in the same order on all ranks — never from two streams.
+      double* tmp = h->energy_dev;
+      HIPCHK(h, hipMemcpyAsync(tmp, &en, sizeof(double), hipMemcpyHostToDevice, cs));
+      NCCLCHK(h, ncclAllReduce(tmp, tmp, 1, ncclDouble, ncclSum, h->comm, cs));
+      HIPCHK(h, hipMemcpyAsync(&en, tmp, sizeof(double), hipMemcpyDeviceToHost, cs));
+      HIPCHK(h, hipStreamSynchronize(cs));
     }
-    // ---------------- field decay / divergence ----------------
-    if (h->decay_every > 0 && (h->step % h->decay_every) == 0) {
-      if (multi) HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
-      double en = 0.0;
-      if (eval_energy(h, st, &en)) return -1;
-      if (multi) {
-        // sum over ranks (1 double every decay_every steps).  Every RCCL call of this communicator
-        // is issued on the comm stream, in the same order on all ranks — never from two streams.
-        double* tmp = h->energy_dev;
-        HIPCHK(h, hipMemcpyAsync(tmp, &en, sizeof(double), hipMemcpyHostToDevice, cs));
-        NCCLCHK(h, ncclAllReduce(tmp, tmp, 1, ncclDouble, ncclSum, h->comm, cs));
-        HIPCHK(h, hipMemcpyAsync(&en, tmp, sizeof(double), hipMemcpyDeviceToHost, cs));
-        HIPCHK(h, hipStreamSynchronize(cs));
-      }
-      if (!std::isfinite(en)) {
-        h->stats.diverged = 1;
-        ++done;
-        break;
-      }
-      if (en > h->energy_max) h->energy_max = en;
-      h->stats.field_decay = h->energy_max > 0 ? en / h->energy_max : 1.0;
-      if (progress && progress(h->step, 0.0, h->stats.field_decay, user)) { ++done; break; }
-      if (h->shutoff > 0 && h->step > h->decay_ref && h->stats.field_decay < h->shutoff) {
-        h->stats.stopped_early = 1;
-        ++done;
-        break;
-      }
+    if (!std::isfinite(en)) {
+      h->stats.diverged = 1;
+      return 1;
+    }
+    if (en > h->energy_max) h->energy_max = en;
+    h->stats.field_decay = h->energy_max > 0 ? en / h->energy_max : 1.0;
+    if (progress && progress(h->step, 0.0, h->stats.field_decay, user)) return 1;
+    if (h->shutoff > 0 && h->step > h->decay_ref && h->stats.field_decay < h->shutoff) {
+      h->stats.stopped_early = 1;
+      return 1;
     }
   }
-  if (multi) {
-    HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
-    HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
+    return 0;
   }
-  HIPCHK(h, hipEventRecord(h->ev1, st));
-  HIPCHK(h, hipStreamSynchronize(st));
-  HIPCHK(h, hipStreamSynchronize(cs));
-  for (hipEvent_t e : tb_ev) hipEventDestroy(e);
-  for (const GraphRec& r : graphs) hipGraphExecDestroy(r.exec);
-  HIPCHK(h, hipGetLastError());
-  float ms = 0.f;
-  HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-  h->stats.run_ms = ms;
-  h->stats.steps_done = h->step;
-  h->stats.h_kernel_ms = h->stats.e_kernel_ms = h->stats.fused_kernel_ms = h->stats.shell_kernel_ms = 0.0;
-  h->stats.h_kernel_launches = h->stats.e_kernel_launches = h->stats.fused_kernel_launches = h->stats.shell_kernel_launches = 0;
-  for (size_t i = 0; i < h->kev_kind.size(); ++i) {
-    float t = 0.f;
-    if (hipEventElapsedTime(&t, h->kev[2 * i], h->kev[2 * i + 1]) != hipSuccess) continue;
-    if (h->kev_kind[i] == 0) { h->stats.h_kernel_ms += t; h->stats.h_kernel_launches++; }
-    else if (h->kev_kind[i] == 1) { h->stats.e_kernel_ms += t; h->stats.e_kernel_launches++; }
-    else if (h->kev_kind[i] == 3) { h->stats.shell_kernel_ms += t; h->stats.shell_kernel_launches++; }
-    else { h->stats.fused_kernel_ms += t; h->stats.fused_kernel_launches++; }
+  // joins the streams, reads the timers
+  int finish() {
+    if (multi) {
+      HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
+      HIPCHK(h, hipStreamWaitEvent(st, h->ev_h_bnd, 0));
+    }
+    HIPCHK(h, hipEventRecord(h->ev1, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    HIPCHK(h, hipStreamSynchronize(cs));
+    for (hipEvent_t e : tb_ev) hipEventDestroy(e);
+    for (const GraphRec& r : graphs) hipGraphExecDestroy(r.exec);
+    HIPCHK(h, hipGetLastError());
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->stats.run_ms = ms;
+    h->stats.steps_done = h->step;
+    h->stats.h_kernel_ms = h->stats.e_kernel_ms = h->stats.fused_kernel_ms = h->stats.shell_kernel_ms = 0.0;
+    h->stats.h_kernel_launches = h->stats.e_kernel_launches = h->stats.fused_kernel_launches = h->stats.shell_kernel_launches = 0;
+    for (size_t i = 0; i < h->kev_kind.size(); ++i) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, h->kev[2 * i], h->kev[2 * i + 1]) != hipSuccess) continue;
+      if (h->kev_kind[i] == 0) { h->stats.h_kernel_ms += t; h->stats.h_kernel_launches++; }
+      else if (h->kev_kind[i] == 1) { h->stats.e_kernel_ms += t; h->stats.e_kernel_launches++; }
+      else if (h->kev_kind[i] == 3) { h->stats.shell_kernel_ms += t; h->stats.shell_kernel_launches++; }
+      else { h->stats.fused_kernel_ms += t; h->stats.fused_kernel_launches++; }
+    }
+    return 0;
   }
-  return 0;
-}
+  int loop() {
+    for (; done < n_steps; ++done) {
+      if (begin_step()) return -1;
+      if (fused_multi) {
+        const int rc = slab_rank_step();
+        if (rc < 0) return -1;
+        if (rc > 0) { ++done; continue; }
+      } else if (fused && tb_ok && done + 2 <= n_steps && !rec && !rec_at(n + 1) &&
+                 !(h->decay_every > 0 && ((n + 1) % h->decay_every) == 0)) {
+        if (tb_pair(n)) return -1;
+        h->step = n + 2;
+        ++done;                                              // (the loop header counts the second step)
+      } else if (pair && use_s2) {
+        const F2Table* tb = fused2_table(h, f2_plan, src_alive);
+        if (!tb) return -1;
+        if (shell2_pair(n, tb)) return -1;
+        h->fused2_pairs++;
+        h->shell_pairs++;
+        h->shell2_pairs++;
+        h->step = n + 2;
+        ++done;
+      } else if (pair && f2s_ok) {
+        const F2Table* tb = fused2_table(h, f2_plan, src_alive);
+        if (!tb) return -1;
+        if (shell_pair(n, tb, *zp)) return -1;
+        h->fused2_pairs++;
+        h->shell_pairs++;
+        h->step = n + 2;
+        ++done;
+      } else if (pair) {
+        if (plain_pair()) return -1;
+        h->fused2_pairs++;
+        h->step = n + 2;
+        ++done;
+      } else if (fused && graph_ok && done + 2 <= n_steps && !rec && !rec_at(n + 1) &&
+                 !(h->decay_every > 0 && ((n + 1) % h->decay_every) == 0) && sources_alive(n + 1)) {
+        const int grc = graph_pair(n);
+        if (grc < 0) return -1;
+        if (grc == 0) {                                      // replayed: two steps done
+          h->step = n + 2;
+          ++done;
+        } else {                                             // capture not available: this step directly, no more attempts
+          if (fused_one(n, rec)) return -1;
+          h->step = n + 1;
+        }
+      } else if (fused) {
+        if (fused_one(n, rec)) return -1;
+        h->step = n + 1;
+      } else {
+        if (two_pass_step()) return -1;
+      }
+      sync_point();
+      const int dc = decay_check();
+      if (dc < 0) return -1;
+      if (dc > 0) { ++done; break; }
+    }
+    return 0;
+  }
+};
+}  // namespace
+extern "C" {
 
+int fdtd_run(FdtdSolver* h, int64_t n_steps, FdtdProgressFn progress, void* user) {
+  if (!h) return -1;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  Run r{h, n_steps, progress, user};
+  if (r.setup() || r.setup_schedules() || r.setup_pairs()) return -1;
+  if (r.loop()) return -1;
+  return r.finish();
+}
 // Complex (Bloch-periodic) fields: two solvers carry Re and Im of the same simulation (identical grid,
 // media, CPML, ADE and monitors; the Im solver's source weights are the Re solver's times -i) and are
 // stepped together on the Re solver's stream; they only meet in the ghost fills (fdtd_kernels.hpp).
@@ -3797,6 +3917,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_SHELL_PAIRS: h->shell_on = value < 0 ? -1 : value; return 0;
     case FDTD_OPT_STRIP: if (value % 64 < 1 || (value / 64 != 3 && value / 64 != 4)) break; h->strip_zc = value % 64; h->strip_occ = value / 64; return 0;
     case FDTD_OPT_SHELL2: h->shell2_on = value < 0 ? -1 : (value > 3 ? 1 : value); return 0;
+    case FDTD_OPT_DEBUG_SYNC: h->debug_sync = value != 0; return 0;
     case FDTD_OPT_SHELL2_SHAPE: {
       // lanes per row of the wide boxes (3 ... 64) + 128 * their waves per workgroup (1 ... 8) + 1024 * their planes per chunk (0 = by box)
       //   + 2^17 * waves per workgroup of the strips (1 ... 8) + 2^21 * their planes per chunk (0 = by box)
