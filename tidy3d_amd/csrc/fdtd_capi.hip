@@ -1368,7 +1368,7 @@ int shell2_boxes_by_axes(const FdtdSolver* h, const ShellGeom& G, Shell2Box out[
 }
 // tile shape of one box: lanes per row q for `W` waves per workgroup — the shape that wastes the fewest lane-planes (row slots of
 // the last tile row and the three halo slots, halo lanes and the last x tile's idle lanes, the two extra iterations per chunk)
-void shell2_shape(const FdtdSolver* h, const Shell2Box& bx, int W, Shell2P* out) {
+void shell2_shape(const FdtdSolver* h, const Shell2Box& bx, int W, int zc_cap, Shell2P* out) {
   const GridP& g = h->g;
   const int halo_l = bx.i0 > 0 ? 1 : 0, halo_r = bx.i1 < g.nx ? 1 : 0;
   const int lanes_w = (bx.i1 - bx.i0) / 4;
@@ -1389,13 +1389,10 @@ void shell2_shape(const FdtdSolver* h, const Shell2Box& bx, int W, Shell2P* out)
     const int nby = (rows + R - 1) / R;
     int zc = bx.strip ? h->shell2_zcs : h->shell2_zcw;
     if (zc <= 0) {
-      // planes per workgroup: chunks of equal length, 32 planes at most (each chunk pays two extra iterations and a prologue:
-      // 512^3 V2 inside one engine 8 planes 1.054, 16: 1.031 / 1.054, 32: 1.005 / 1.028, 64: 0.998 / 1.026 ms per step, profiles/r5),
-      // shorter where the box alone would otherwise not give the machine a round of workgroups
-      const long long per_chunk = (long long)nbx * nby;
-      int nch = (nzb + 31) / 32;
-      if (per_chunk * nch < 256) nch = (int)std::min((long long)std::max(1, nzb / 8), (256 + per_chunk - 1) / per_chunk);
-      nch = std::max(1, nch);
+      // planes per workgroup: chunks of equal length, zc_cap planes at most (each chunk pays two extra iterations and a prologue:
+      // 512^3 V2 inside one engine 8 planes 1.054, 16: 1.031 / 1.054, 32: 1.005 / 1.028, 64: 0.998 / 1.026 ms per step, profiles/r5);
+      // the caller lowers the cap until the launch as a whole gives the machine two rounds of workgroups
+      const int nch = std::max(1, (nzb + zc_cap - 1) / zc_cap);
       zc = (nzb + nch - 1) / nch;
     }
     zc = std::max(1, std::min(zc, nzb));
@@ -1428,9 +1425,21 @@ void launch_shell2_boxes(FdtdSolver* h, const Shell2Box* bx, int n, const PmlP* 
       time_end(h, st);
       mb = Shell2M{};
     };
+    // planes per chunk: 32 at most, fewer while the boxes of this launch together make less than two rounds of workgroups
+    int zc_cap = 32;
+    for (; zc_cap > 8; zc_cap -= (zc_cap > 16 ? 8 : 4)) {
+      long long wgs = 0;
+      for (int q = 0; q < n; ++q) {
+        if (by_axes && bx[q].axes != axes) continue;
+        Shell2P sp{};
+        shell2_shape(h, bx[q], W, zc_cap, &sp);
+        wgs += (long long)sp.nbx * sp.nby * sp.nbz;
+      }
+      if (wgs >= 2 * 256 * (W <= 4 ? 2 : 1)) break;
+    }
     for (int q = 0; q < n; ++q) {
       if (by_axes && bx[q].axes != axes) continue;
-      shell2_shape(h, bx[q], W, &mb.box[mb.n]);
+      shell2_shape(h, bx[q], W, zc_cap, &mb.box[mb.n]);
       mb.first[mb.n + 1] = mb.first[mb.n] + mb.box[mb.n].nbx * mb.box[mb.n].nby * mb.box[mb.n].nbz;
       mb.n++;
       if (mb.n == kShell2Boxes || h->shell2_on == 3) flush();

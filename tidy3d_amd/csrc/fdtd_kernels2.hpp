@@ -28,6 +28,9 @@
 // and wrap a periodic x axis inside the sweep.  Everything else takes single steps.
 #pragma once
 #include "fdtd_fused2.hpp"
+#ifndef FDTD_WHATIF
+#define FDTD_WHATIF 0     // 1 / 2 / 3: measuring builds of profiles/r5 (scripts/whatif_builds.sh) that skip work to bound what an optimisation could gain; never shipped
+#endif
 
 namespace fdtd {
 
@@ -308,6 +311,13 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     float exn_m, ez_mm, ey_mm, ex_jm, hy_o, hz_o;        // column i0 - 1 (first lane of a tile with a left neighbour)
   };
   auto issue = [&](int k, Ld& L) __attribute__((always_inline)) {
+#if FDTD_WHATIF == 3      // (what-if build: the three halo rows of a workgroup cost no loads — the upper bound of sharing them with the neighbouring workgroups)
+    if (ty < 2 || ty == W - 1) {
+      zero<V>(L.exn); zero<V>(L.eyn); zero<V>(L.ezk); zero<V>(L.exj); zero<V>(L.ezj); zero<V>(L.hxn); zero<V>(L.hyn); zero<V>(L.hzn);
+      L.eyx_g = L.ezx_g = L.exn_m = L.ez_mm = L.ey_mm = L.ex_jm = L.hy_o = L.hz_o = 0.f;
+      return;
+    }
+#endif
     const int txo = (MAT || DAMP) ? tx : opaque_lane(tx);       // (the materials / absorber instantiations have no VGPR to spare for the re-derivation)
     const int i0o = (tile_x * 64 + txo) * V;
     const bool act = i0o < g.nx, last_x = i0o + V >= g.nx, first_x = i0o == 0;
@@ -317,7 +327,11 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     const long long pjb = (long long)k * g.sxy + rowpb;
     const long long up = (k < g.nz) ? g.sxy : 0;         // (iteration nz only needs E1_{x,y}[nz] = 0: it reads the ghost plane twice)
     ldf<V, true>(L.exn, uni(a.ex + pb + up), ubc);
+#if FDTD_WHATIF == 1      // (what-if build, scripts/whatif_builds.sh: E_y / H_y not loaded at all — the upper bound of prefetching them; results are wrong)
+    zero<V>(L.eyn);
+#else
     ldf<V, true>(L.eyn, uni(a.ey + pb + up), ubc);
+#endif
     ldf<V, true>(L.ezk, uni(a.ez + pb), ubc);
     if (use_jp) {
       ldf<V, true>(L.exj, uni(a.ex + pjb), ubc);
@@ -326,7 +340,11 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
       zero<V>(L.exj); zero<V>(L.ezj);
     }
     ldf<V, true>(L.hxn, uni(a.hx + pb), ubc);
+#if FDTD_WHATIF == 1
+    zero<V>(L.hyn);
+#else
     ldf<V, true>(L.hyn, uni(a.hy + pb), ubc);
+#endif
     ldf<V, true>(L.hzn, uni(a.hz + pb), ubc);
     L.eyx_g = 0.f; L.ezx_g = 0.f;
     if (act && txo == 63 && !last_x) { L.eyx_g = a.ey[pb + ux + V]; L.ezx_g = a.ez[pb + ux + V]; }
@@ -657,7 +675,9 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
       t4.x = h2z[0]; t4.y = h2z[1]; t4.z = h2z[2]; t4.w = h2z[3];
       xch[3 * slot + me] = t4;
     }
+#if FDTD_WHATIF != 2      // (what-if build 2: no second barrier — the upper bound of a one-barrier pipeline; results are wrong)
     __syncthreads();
+#endif
     // ---- S4: E2[k-1] ----
     if (own && k > k0) {
       float hyx = lane_prev(h2y[V - 1]);
