@@ -79,9 +79,10 @@ def test_custom_medium_raster_interpolation_and_time_step():
     np.testing.assert_allclose(e, [3.0, 3.2, 4.0])                                  # nearest sample; edge value outside
 
 
-def test_custom_medium_with_many_permittivity_conductivity_pairs_is_coarsened_not_refused():
-    """Permittivity and conductivity varying independently: at the fine steps (1 % x 2 %) the pairs would need ~2900 table
-    slots — the raster coarsens both grids (steps squared, at most 3 % / 30 %) until the 1022-entry table holds them."""
+def test_custom_medium_with_many_permittivity_conductivity_pairs_takes_the_wide_table():
+    """Permittivity and conductivity varying independently: at the fine steps (1 % x 2 %) the pairs need thousands of table slots.
+    Until round 4 the raster coarsened both grids (steps squared, at most 3 % / 30 %) until the 1022-entry table held them; now the
+    data get the WIDE table (ref scene.py:52 allows 65530 media; 16-bit indices, tests/test_wide_media.py) at the fine steps."""
     rng = np.random.default_rng(0)
     n = 24
     x = np.linspace(-0.6, 0.6, n)
@@ -93,7 +94,7 @@ def test_custom_medium_with_many_permittivity_conductivity_pairs_is_coarsened_no
                         sources=[td.PointDipole(source_time=PULSE, polarization="Ez")],
                         boundary_spec=td.BoundarySpec.all_sides(td.PECBoundary()))
     spec = discretize(sim, n_steps=2).spec
-    assert 200 < len(spec.media) <= 1023
+    assert 1023 < len(spec.media) <= 65531
     eps_of = np.array([m.eps_inf for m in spec.media])
     sig_of = np.array([m.sigma for m in spec.media])
     xs, ys, zs = spec.yee_coords(2)
@@ -101,8 +102,8 @@ def test_custom_medium_with_many_permittivity_conductivity_pairs_is_coarsened_no
     inside = (np.abs(X) <= 0.5) & (np.abs(Y) <= 0.5) & (np.abs(Z) <= 0.5)
     e_true, s_true = med.eps_sigma_at(2, X[inside], Y[inside], Z[inside])
     idx = spec.mat_idx[2].transpose(2, 1, 0)[inside]
-    assert np.max(np.abs(eps_of[idx] / e_true - 1)) < 0.016       # half a 3 % step
-    assert np.max(np.abs(sig_of[idx] / s_true - 1)) < 0.15        # half a 30 % step
+    assert np.max(np.abs(eps_of[idx] / e_true - 1)) < 0.0051      # half a 1 % step
+    assert np.max(np.abs(sig_of[idx] / s_true - 1)) < 0.024       # half a 4.7 % step (a decade on 50 levels)
 
 
 def test_custom_medium_slab_transmits_like_the_uniform_slab():

@@ -148,6 +148,7 @@ struct FdtdSolver {
   size_t field_bytes = 0;
   float *ip[3] = {}, *idl[3] = {};
   uint32_t* mat4 = nullptr;          // packed material words (interior plane 0), nullptr = uniform
+  uint32_t* mat4b = nullptr;         // wide layout (more than 1023 media): the second word per cell; mat4 then holds E_x | E_y << 16
   uint32_t* roww = nullptr;          // row-segment words [nz][ny][ceil(nx / 256)]
   float2* lut = nullptr;
   int n_media = 0;
@@ -428,6 +429,7 @@ StepP step_params(const FdtdSolver* h) {
 MatP mat_params(const FdtdSolver* h) {
   MatP m;
   m.m4 = h->mat4;
+  m.m4b = h->mat4b;
   m.roww = h->roww;
   m.lut = h->lut; m.n_media = h->n_media; m.ca1 = h->ca1; m.cb1 = h->cb1;
   return m;
@@ -1842,7 +1844,7 @@ void launch_pml(FdtdSolver* h, bool e_side, int kbeg, int kend, hipStream_t st, 
       hipLaunchKernelGGL(pml_e4_kernel, grid, dim3(256), 0, st, g, sl[0], sl[1], field_ptr(h, c1),
                          field_ptr(h, c2), (const float*)field_ptr(h, 3 + c1), (const float*)field_ptr(h, 3 + c2),
                          P.psi_e[0], P.psi_e[1], (const float4*)P.ce4, (const float*)h->idl[a], (const uint32_t*)h->mat4,
-                         (const float2*)h->lut, h->cb1);
+                         (const float2*)h->lut, h->cb1, (const uint32_t*)h->mat4b);
     else if (vec4)
       hipLaunchKernelGGL(pml_h4_kernel, grid, dim3(256), 0, st, g, sl[0], sl[1], field_ptr(h, 3 + c1),
                          field_ptr(h, 3 + c2), (const float*)field_ptr(h, c1), (const float*)field_ptr(h, c2),
@@ -1851,7 +1853,7 @@ void launch_pml(FdtdSolver* h, bool e_side, int kbeg, int kend, hipStream_t st, 
       hipLaunchKernelGGL(pml_e_kernel, grid, dim3(256), 0, st, g, sl[0], sl[1], field_ptr(h, c1),
                          field_ptr(h, c2), (const float*)field_ptr(h, 3 + c1), (const float*)field_ptr(h, 3 + c2),
                          P.psi_e[0], P.psi_e[1], (const float4*)P.ce4, (const float*)h->idl[a], (const uint32_t*)h->mat4,
-                         (const float2*)h->lut, h->cb1);
+                         (const float2*)h->lut, h->cb1, (const uint32_t*)h->mat4b);
     else
       hipLaunchKernelGGL(pml_h_kernel, grid, dim3(256), 0, st, g, sl[0], sl[1], field_ptr(h, 3 + c1),
                          field_ptr(h, 3 + c2), (const float*)field_ptr(h, c1), (const float*)field_ptr(h, c2),
@@ -2365,7 +2367,7 @@ int fdtd_set_steps(FdtdSolver* h, int axis, const float* inv_primal, const float
 
 int fdtd_set_media(FdtdSolver* h, const float* ca, const float* cb, int n_media) {
   if (!h) return -1;
-  if (n_media < 2 || n_media > kMaxMedia) return fail(h, "fdtd_set_media: n_media must be in [2, %d], got %d", kMaxMedia, n_media);
+  if (n_media < 2 || n_media > kMaxMediaWide) return fail(h, "fdtd_set_media: n_media must be in [2, %d], got %d", kMaxMediaWide, n_media);
   HIPCHK(h, hipSetDevice(h->cfg.device));
   std::vector<float2> lut(n_media);
   for (int i = 0; i < n_media; ++i) { lut[i].x = ca[i]; lut[i].y = cb[i]; }
@@ -2392,10 +2394,21 @@ int upload_material(FdtdSolver* h, const T* mat, size_t count) {
   std::vector<uint32_t> packed(fcount, kBgWord);                 // ghost planes: background medium
   uint32_t* dst = packed.data() + g.sxy;
   const uint32_t nm = (uint32_t)h->n_media;
+  const bool wide = h->n_media > kMaxMedia - 1;           // more media than 10-bit indices name: two words per cell (fdtd_kernels.hpp MatP)
+  std::vector<uint32_t> packed_b(wide ? fcount : 0, 1u);
+  uint32_t* dst_b = wide ? packed_b.data() + g.sxy : nullptr;
+  if (wide) std::fill(packed.begin(), packed.end(), 1u | (1u << 16));
   for (size_t i = 0; i < nc; ++i) {
     const uint32_t m0 = mat[i], m1 = mat[nc + i], m2 = mat[2 * nc + i];
     if (m0 >= nm || m1 >= nm || m2 >= nm) return fail(h, "fdtd_set_material: medium index out of range at cell %zu", i);
-    dst[i] = m0 | (m1 << 10) | (m2 << 20);
+    if (wide) { dst[i] = m0 | (m1 << 16); dst_b[i] = m2; }
+    else dst[i] = m0 | (m1 << 10) | (m2 << 20);
+  }
+  h->mat4b = nullptr;
+  if (wide) {
+    uint32_t* base_b = nullptr;
+    if (dev_upload(h, &base_b, (const uint32_t*)packed_b.data(), fcount)) return -1;
+    h->mat4b = base_b + g.sxy;
   }
   const int nbx = (g.nx + 255) / 256;
   std::vector<uint32_t> roww((size_t)g.nz * g.ny * nbx);
@@ -2873,7 +2886,10 @@ struct Run {
     HIPCHK(h, hipEventRecord(h->ev0, st));
     if (multi && (nb_lo || nb_hi) && nz < 2) return fail(h, "fdtd_run: a z-slab needs at least 2 planes");
     // the fused sweep is the default single-GPU path whenever rows are float4-aligned
-    fused_ok = (h->g.nx % 4 == 0) && h->rows_f <= 15 &&
+    // (a wide material table — more than 1023 media — has no LDS copy and no packed 10-bit words: the two-pass kernels take it)
+  if (h->mat4b && h->cfg.variant == FDTD_VARIANT_FUSED)
+    return fail(h, "fdtd_run: more than %d media need the two-pass kernels (FDTD_VARIANT_ZMARCH / AUTO), not FDTD_VARIANT_FUSED", kMaxMedia - 1);
+  fused_ok = !h->mat4b && (h->g.nx % 4 == 0) && h->rows_f <= 15 &&
                           (h->cfg.variant == FDTD_VARIANT_FUSED || h->cfg.variant == FDTD_VARIANT_AUTO);
     fused = !multi && fused_ok;
     // with a communicator every rank must take the same path: the fused z-slab schedule runs only on
@@ -3752,7 +3768,7 @@ int fdtd_run_bloch(FdtdSolver* hr, FdtdSolver* hi, int64_t n_steps, const double
   }
   HIPCHK(hr, hipEventRecord(hr->ev0, st));
   const bool per_z = hr->cfg.bc[4] == FDTD_BC_PERIODIC;
-  const bool fused = !multi && (g.nx % 4 == 0) && hr->rows_f <= 15 &&
+  const bool fused = !multi && !hr->mat4b && (g.nx % 4 == 0) && hr->rows_f <= 15 &&
                      (hr->cfg.variant == FDTD_VARIANT_FUSED || hr->cfg.variant == FDTD_VARIANT_AUTO);
   if (fused) for (FdtdSolver* h : both) if (ensure_second_set(h)) return -1;
   if (fused && !hr->tuned && !hr->user_geometry && !hi->user_geometry &&

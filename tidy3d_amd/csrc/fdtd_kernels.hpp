@@ -48,8 +48,14 @@ struct StepP {
 constexpr int kMaxMedia = 1024;
 constexpr uint32_t kBgWord = 1u | (1u << 10) | (1u << 20);
 constexpr uint32_t kMixedWord = 0xFFFFFFFFu;
+// More than 1022 media (ref scene.py:52 allows 65530; a CustomMedium with thousands of distinct (permittivity, conductivity)
+// levels): the WIDE layout — 16-bit indices, two words per cell (m4: E_x | E_y << 16, m4b: E_z), coefficients read from the table in
+// global memory (it does not fit LDS).  Two-pass kernels only (e_update_kernel, the slab-form CPML): the sweeps keep the packed
+// 10-bit words and their LDS table; a run with a wide table takes FDTD_VARIANT_ZMARCH.
+constexpr int kMaxMediaWide = 65531;
 struct MatP {
   const uint32_t* m4;             // packed material indices
+  const uint32_t* m4b;            // wide layout: the second word per cell (E_z index); nullptr = 10-bit packed words in m4
   const uint32_t* roww;           // [nz][ny][ceil(nx / 256)] row-segment words
   const float2* lut;              // (ca, cb) per medium
   int n_media;
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(512) void e_update_kernel(GridP g, FieldP f, StepP 
                                                         int kend, int zchunk) {
   __shared__ float2 lut_s[MAT ? kMaxMedia : 1];
   if constexpr (MAT) {
-    for (int t = threadIdx.y * blockDim.x + threadIdx.x; t < m.n_media; t += blockDim.x * blockDim.y)
+    for (int t = threadIdx.y * blockDim.x + threadIdx.x; t < min(m.n_media, kMaxMedia); t += blockDim.x * blockDim.y)
       lut_s[t] = m.lut[t];
     __syncthreads();
   }
@@ -317,6 +323,15 @@ __global__ __launch_bounds__(512) void e_update_kernel(GridP g, FieldP f, StepP 
       if constexpr (MAT) {
         uint32_t mw[V];
         ldm<V>(mw, m.m4 + p);
+        if (m.m4b) {                 // wide layout (wave-uniform): 16-bit indices, the table in global memory
+          uint32_t mz[V];
+          ldm<V>(mz, m.m4b + p);
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+            const float2 c0 = m.lut[mw[e] & 0xFFFFu], c1 = m.lut[mw[e] >> 16], c2 = m.lut[mz[e] & 0xFFFFu];
+            cax[e] = c0.x; cbx[e] = c0.y; cay[e] = c1.x; cby[e] = c1.y; caz[e] = c2.x; cbz[e] = c2.y;
+          }
+        } else
 #pragma unroll
         for (int e = 0; e < V; ++e) {
           const float2 c0 = lut_s[mw[e] & 1023u];
@@ -1074,6 +1089,13 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
 //     everywhere; inside a slab the difference  (1/kappa - 1) d + psi  is added afterwards,
 //     which is exact because both updates are linear in the curl).
 // =============================================================================================
+// medium index of component c of a cell: from its packed word (10 bits per component), or — wide layout — 16 bits per component in
+// two words per cell (mw: E_x | E_y << 16; m4b[cell]: E_z)
+__device__ __forceinline__ uint32_t medium_of(uint32_t mw, const uint32_t* m4b, long long cell, int c) {
+  if (!m4b) return (mw >> (10 * c)) & 1023u;
+  return c == 0 ? (mw & 0xFFFFu) : (c == 1 ? (mw >> 16) : (m4b[cell] & 0xFFFFu));
+}
+
 struct SlabP {
   int a;              // PML axis
   int s_lo, s_n;      // slab index range [s_lo, s_lo + s_n) along a
@@ -1094,7 +1116,7 @@ __global__ __launch_bounds__(256) void pml_e_kernel(GridP g, SlabP sl_lo, SlabP 
                                                      const float* h2, float* psi1, float* psi2,
                                                      const float4* cf4,
                                                      const float* idl, const uint32_t* m4,
-                                                     const float2* lut, float cb_uniform) {
+                                                     const float2* lut, float cb_uniform, const uint32_t* m4b) {
   const SlabP sl = blockIdx.y ? sl_hi : sl_lo;   // both faces of an axis in one launch (disjoint cells)
   const int bx = (sl.a == 0) ? sl.s_n : g.nx;
   const int by = (sl.a == 1) ? sl.s_n : g.ny;
@@ -1134,8 +1156,8 @@ __global__ __launch_bounds__(256) void pml_e_kernel(GridP g, SlabP sl_lo, SlabP 
   psi1[q] = p1;
   psi2[q] = p2;
   const uint32_t mw = m4 ? m4[p] : 0u;
-  const float cb1 = m4 ? lut[(mw >> (10 * c1)) & 1023u].y : cb_uniform;
-  const float cb2 = m4 ? lut[(mw >> (10 * c2)) & 1023u].y : cb_uniform;
+  const float cb1 = m4 ? lut[medium_of(mw, m4b, p, c1)].y : cb_uniform;
+  const float cb2 = m4 ? lut[medium_of(mw, m4b, p, c2)].y : cb_uniform;
   // PEC walls of the other transverse axis
   const bool w1 = (idx3[c2] == 0) && (bc0[c2] == BC_PEC);   // E_{c1} is tangential to the c2-wall
   const bool w2 = (idx3[c1] == 0) && (bc0[c1] == BC_PEC);
@@ -1194,7 +1216,7 @@ __global__ __launch_bounds__(256) void pml_e4_kernel(GridP g, SlabP sl_lo, SlabP
                                                       const float* h2, float* psi1, float* psi2,
                                                       const float4* cf4,
                                                       const float* idl, const uint32_t* m4,
-                                                      const float2* lut, float cb_uniform) {
+                                                      const float2* lut, float cb_uniform, const uint32_t* m4b) {
   const SlabP sl = blockIdx.y ? sl_hi : sl_lo;   // both faces of an axis in one launch (disjoint cells)
   constexpr int V = 4;
   const int bx = g.nx / V;
@@ -1248,8 +1270,8 @@ __global__ __launch_bounds__(256) void pml_e4_kernel(GridP g, SlabP sl_lo, SlabP
     const float p2 = b * q2[e] + c * d1;
     q1[e] = p1;
     q2[e] = p2;
-    const float cb1 = m4 ? lut[(mw[e] >> (10 * c1)) & 1023u].y : cb_uniform;
-    const float cb2 = m4 ? lut[(mw[e] >> (10 * c2)) & 1023u].y : cb_uniform;
+    const float cb1 = m4 ? lut[medium_of(mw[e], m4b, p + e, c1)].y : cb_uniform;
+    const float cb2 = m4 ? lut[medium_of(mw[e], m4b, p + e, c2)].y : cb_uniform;
     const int i3c2 = (c2 == 0) ? i0 + e : jk[c2];
     const int i3c1 = (c1 == 0) ? i0 + e : jk[c1];
     const bool w1 = (i3c2 == 0) && (bc0[c2] == BC_PEC);

@@ -295,7 +295,13 @@ class HipEngine:
                 bc[5] = L.BC_NEIGHBOR
         for i, b in enumerate(bc):
             cfg.bc[i] = int(b)
-        if (n_ranks > 1 or force_comm) and spec.bloch is not None:
+        if len(spec.media) > 1023:
+            # a WIDE material table (more than 1022 media, ref scene.py:52 allows 65530): 16-bit indices, coefficients from global memory —
+            # the two-pass kernels take it; the sweeps keep their 10-bit words and LDS table (fdtd_kernels.hpp MatP)
+            if variant == L.VARIANT_FUSED:
+                raise ValueError("more than 1022 media need the two-pass kernels (VARIANT_AUTO / VARIANT_ZMARCH)")
+            variant = L.VARIANT_ZMARCH
+        elif (n_ranks > 1 or force_comm) and spec.bloch is not None:
             variant = L.VARIANT_ZMARCH          # complex fields on z-slabs: two-pass kernels (fdtd_run_bloch)
         elif (n_ranks > 1 or force_comm) and variant in (L.VARIANT_AUTO, L.VARIANT_FUSED):
             # every rank takes the same decision (split_slabs is deterministic): fused z-slab schedule
