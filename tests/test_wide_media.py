@@ -22,13 +22,13 @@ def _spatial(values, x, y, z):
     return a
 
 
-def wide_sim(N, n_data, seed=0):
+def wide_sim(N, n_data, seed=0, eps_span=1.3):
     """A block of CustomMedium (eps 2 ... 2.6 in 1 % steps x sigma over a factor of 3 in 2 % steps, drawn independently per data point)
     that runs into the CPML on the x faces, a uniform lossy bar beside it, two dipoles, a probe and a DFT plane."""
     rng = np.random.default_rng(seed)
     size = tuple(n * DL for n in N)
     ax = [np.linspace(-0.5 * s_, 0.5 * s_, n_data) for s_ in size]
-    eps = 2.0 * 1.3 ** rng.random((n_data,) * 3)
+    eps = 2.0 * eps_span ** rng.random((n_data,) * 3)
     sig = 0.01 * 3.0 ** rng.random((n_data,) * 3)
     med = td.CustomMedium(permittivity=_spatial(eps, *ax), conductivity=_spatial(sig, *ax), interp_method="nearest")
     return td.Simulation(
@@ -77,7 +77,7 @@ def test_wide_material_table_on_the_emulator(emu_lib):
 
 @pytest.mark.gpu
 def test_five_thousand_media_on_the_device(hip_lib):
-    disc = discretize(wide_sim((96, 80, 64), 32), n_steps=150)
+    disc = discretize(wide_sim((96, 80, 64), 48, eps_span=3.0), n_steps=150)
     n_media = len(disc.spec.media)
     print(f"\n[wide table] {n_media} media on a {disc.spec.shape} grid")
     assert n_media >= 5000, n_media
