@@ -113,11 +113,11 @@ def cpu_baseline(n: int = 320, steps: int = 18):
 
 
 def source_hash() -> str:
-    """sha256 over the kernel sources (every __global__ function lives in fdtd_kernels.hpp / fdtd_kernels2.hpp): ties a
+    """sha256 over the kernel sources (every __global__ function lives in fdtd_kernels.hpp / fdtd_kernels2.hpp / fdtd_strip.hpp / fdtd_shell2.hpp): ties a
     PMC traffic figure to the kernel code it was measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("fdtd_kernels.hpp", "fdtd_kernels2.hpp", "fdtd_fused2.hip", "fdtd_fused2c.hip", "fdtd_strip.hpp"):
+    for f in ("fdtd_kernels.hpp", "fdtd_kernels2.hpp", "fdtd_fused2.hip", "fdtd_fused2c.hip", "fdtd_strip.hpp", "fdtd_shell2.hpp", "fdtd_shell2.hip"):
         h.update(open(os.path.join(ROOT, "tidy3d_amd/csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -56,7 +56,7 @@ import json
 for w in ["v0", "v0s", "v1", "va", "v2"]:
     d = json.load(open("$O/pmc_%s_summary.json" % w))
     for k, v in d.items():
-        if "hbm_bytes_per_launch" in v and ("fused" in k or "seam" in k or "strip" in k):
+        if "hbm_bytes_per_launch" in v and ("fused" in k or "seam" in k or "strip" in k or "shell2" in k):
             print(w, k, round(v["hbm_bytes_per_launch"] / 1e9, 3), "GB  read", round(v["read_bytes_per_launch"] / 1e9, 3), "write", round(v["write_bytes_per_launch"] / 1e9, 3), "x", v.get("launches_FETCH_SIZE"))
 PY
       ;;

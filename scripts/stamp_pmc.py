@@ -19,7 +19,7 @@ if sys.argv[1] == "--visit":
     rec["fused_step_kernel"] = S["v0s"][k0[0]]["hbm_bytes_per_launch"]
     wl = {}
     for w in ("v0", "v1", "va", "v2"):
-        ks = {k: v for k, v in S[w].items() if "hbm_bytes_per_launch" in v and any(t in k for t in ("fused", "seam_kernel", "strip_step"))}
+        ks = {k: v for k, v in S[w].items() if "hbm_bytes_per_launch" in v and any(t in k for t in ("fused", "seam_kernel", "strip_step", "shell2_step"))}
         pairs = ks.get("fused2_step_kernel", {}).get("launches_FETCH_SIZE", 0)
         if pairs:
             tot = sum(v["hbm_bytes_per_launch"] * v["launches_FETCH_SIZE"] for v in ks.values())
