@@ -185,3 +185,26 @@ def test_random_simulations_in_shell2_pairs(emu_lib):
     spec.loader.exec_module(mod)
     bad, taken = mod.run_cases(6, seed=21, lib=emu_lib, quiet=True, small=True)
     assert bad == 0 and taken >= 5, (bad, taken)
+
+
+@pytest.mark.parametrize("name,bspec,w,zc,form", [("one_tile", B_ALL, 5, 3, 1), ("two_x_tiles", B_ODD, 8, 4, 2), ("one_tile_wide", B_STABLE, 6, 6, 3)])
+def test_dft_monitors_reaching_into_the_shell_do_not_stop_shell2_pairs(name, bspec, w, zc, form, emu_lib):
+    """Flux planes and field monitors normally span the whole cross-section, layers included.  In shell2 pairs the shell's boxes
+    copy the middle step out over the monitors' boxes as the bulk sweep does over its own (H^{n+1/2} for a record at the first
+    step of a pair, E^{n+1} for one at the middle step; each cell by the launch that owns it): every step goes out in a pair and
+    the spectra equal those of single steps, bit for bit.  (The round-4 form ends its pairs on such records.)"""
+    N = SHAPES[name]
+    mons = [td.FluxMonitor(center=(0.1, 0, 0), size=(0, td.inf, td.inf), freqs=[2.5e14, 3e14], name="flux_x"),
+            td.FluxMonitor(center=(0, 0, 0.1), size=(td.inf, td.inf, 0), freqs=[3e14], name="flux_z", interval_space=(1, 1, 1)),
+            td.FieldMonitor(center=(0, 0.05, 0), size=(td.inf, 0, td.inf), freqs=[2.5e14, 3e14], name="plane_y", colocate=False),
+            td.FieldMonitor(center=(0, 0, 0), size=(0.5, td.inf, 0.3), freqs=[3e14], name="volume", colocate=False)]
+    disc = discretize(_sim(N, bspec, structures=MEDIA[:2], monitors=mons), n_steps=26)
+    disc.spec.decay_every = 0
+    ref_f, ref_r, p0, _, q0, _ = _run(disc.spec, emu_lib, 0, 0)
+    got_f, got_r, p1, s1, q1, why1 = _run(disc.spec, emu_lib, w + 64 * zc, form)
+    assert p0 == 0 and q0 == 0
+    assert p1 == 5 + 7 and q1 == p1 and why1 == 0, (p1, s1, q1, why1)
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), c
+    for k in ref_r:
+        assert np.abs(np.asarray(ref_r[k])).max() > 0 and np.array_equal(np.asarray(got_r[k]), np.asarray(ref_r[k])), k

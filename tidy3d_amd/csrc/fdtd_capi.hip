@@ -859,7 +859,7 @@ bool fused2_capturable(const FdtdSolver* h, const Monitor& m) {
 // behind it (pair_record_kernel) writes everything they record of the pair — E^n and H^{n-1/2} are still in the set the
 // sweep read, H^{n+3/2} is in the set it wrote — so such a pair costs no record launch in front of the sweep.
 // `box` (shell pairs): the bulk the sweep covers — a monitor that records at either step must lie inside it.
-bool fused2_plan(const FdtdSolver* h, long long n, F2Plan* plan, const int* box_lo = nullptr, const int* box_hi = nullptr) {
+bool fused2_plan(const FdtdSolver* h, long long n, F2Plan* plan, const int* box_lo = nullptr, const int* box_hi = nullptr, bool dft_anywhere = false) {
   plan->mons.clear(); plan->dfts.clear(); plan->dft_when.clear();
   long long total = 0, dump = 0;
   for (size_t q = 0; q < h->mons.size(); ++q) {
@@ -869,8 +869,11 @@ bool fused2_plan(const FdtdSolver* h, long long n, F2Plan* plan, const int* box_
     if (!at_n && !at_m) continue;
     const BoxP& b = m.box;
     const bool inside = b.lo0 >= 0 && b.lo1 >= 0 && b.lo2 >= 0 && b.lo0 + b.nx <= h->g.nx && b.lo1 + b.ny <= h->g.ny && b.lo2 + b.nz <= h->g.nz;
-    if (box_lo && (b.lo0 < box_lo[0] || b.lo1 < box_lo[1] || b.lo2 < box_lo[2] || b.lo0 + b.nx > box_hi[0] ||
-                   b.lo1 + b.ny > box_hi[1] || b.lo2 + b.nz > box_hi[2])) return false;
+    // (shell2 pairs: the shell's boxes copy the middle step out too — a DFT monitor may reach into the layers, as flux planes and mode
+    //  monitors normally do; time monitors' samples come from the bulk sweep's node table only)
+    if (box_lo && !(dft_anywhere && m.kind == FDTD_MON_DFT) &&
+        (b.lo0 < box_lo[0] || b.lo1 < box_lo[1] || b.lo2 < box_lo[2] || b.lo0 + b.nx > box_hi[0] ||
+         b.lo1 + b.ny > box_hi[1] || b.lo2 + b.nz > box_hi[2])) return false;
     if (m.kind == FDTD_MON_DFT) {
       // A DFT record at the FIRST step: E^n is taken in front of the sweep as always; its H terms need H^{n+1/2}.  A record at
       // the MIDDLE step: its E terms need E^{n+1}; its H terms, H^{n+3/2}, are in the write set afterwards.  The sweep copies
@@ -1414,7 +1417,10 @@ void shell2_shape(const FdtdSolver* h, const Shell2Box& bx, int W, int zc_cap, S
 // per instantiation — x / y / z only at three waves per SIMD for 94 % of the cells, all axes for the edges and corners — lost
 // more to the four half-empty launches than the third wave bought (0.84 ms, profiles/r5/r5f).  shell2_on = 2 / 3: one launch per
 // instantiation / per box (measuring aids).
-void launch_shell2_boxes(FdtdSolver* h, const Shell2Box* bx, int n, const PmlP* pm, hipStream_t st) {
+void launch_shell2_boxes(FdtdSolver* h, const Shell2Box* bx, int n, const PmlP* pm, hipStream_t st, const F2Table* tb) {
+  // (the DFT monitors of the pair's plan that reach into the shell: the boxes copy the middle step out over them; the dump buffer was sized by launch_fused2)
+  Shell2Dump dmp{};
+  if (tb && tb->dstart && h->dump_buf) { dmp.dstart = tb->dstart; dmp.dlist = tb->dlist; dmp.dboxes = tb->dboxes; dmp.dump = h->dump_buf; }
   const bool by_axes = h->shell2_on == 2 || h->shell2_on == 3;
   for (int axes : {1, 4, 2, 7}) {
     if (!by_axes && axes != 7) continue;
@@ -1423,7 +1429,7 @@ void launch_shell2_boxes(FdtdSolver* h, const Shell2Box* bx, int n, const PmlP* 
     auto flush = [&]() {
       if (mb.n == 0) return;
       time_begin(h, 3, st);
-      launch_shell2_step(st, W, h->mat4 != nullptr, axes, h->g, h->f, h->f2, step_params(h), mat_params(h), pm, mb);
+      launch_shell2_step(st, W, h->mat4 != nullptr, axes, h->g, h->f, h->f2, step_params(h), mat_params(h), pm, mb, dmp);
       time_end(h, st);
       mb = Shell2M{};
     };
@@ -3325,7 +3331,7 @@ struct Run {
     const PmlP* pm = h->pml_blk2[h->pml_parity][h->pml_e_parity];
     Shell2Box boxes[kShell2MaxBoxes];
     const int nb = shell2_boxes(h, sg, boxes);
-    launch_shell2_boxes(h, boxes, nb, pm, cs);
+    launch_shell2_boxes(h, boxes, nb, pm, cs, tb);
     HIPCHK(h, hipEventRecord(h->ev_shell_b, cs));
     HIPCHK(h, hipStreamWaitEvent(st, h->ev_shell_b, 0));
     swap_sets(h);
@@ -3372,7 +3378,7 @@ struct Run {
       if (!use_s2 && !f2_ok && !f2s_ok) { if (src_why) h->f2_dyn_reason = src_why; pair = false; }
     }
     if (pair && use_s2) {
-      pair = fused2_plan(h, n, &f2_plan, sg.o0, sg.o1);
+      pair = fused2_plan(h, n, &f2_plan, sg.o0, sg.o1, true);
       if (!pair && f2s_ok) { pair = true; use_s2 = false; }          // (a monitor reaching into the shell: the single-step shell may still take it — judged below)
     }
     if (pair && !use_s2) {

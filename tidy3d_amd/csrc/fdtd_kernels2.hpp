@@ -561,7 +561,8 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
                   const int lx = i0o + e - bx.lo0;
-                  if (lx >= 0 && lx < bx.nx && act) {
+                  // (a clipped launch: the columns outside its box belong to the shell's launches — shell2 pairs let DFT monitors reach into the shell)
+                  if (lx >= 0 && lx < bx.nx && act && (!CLIP || (i0o + e >= clip.i0 && i0o + e < clip.i1))) {
                     if (bx.off[0] >= 0) inj.dump[bx.off[0] + rowo + lx] = e1xn[e];
                     if (bx.off[1] >= 0) inj.dump[bx.off[1] + rowo + lx] = e1yn[e];
                     if (bx.off[2] >= 0) inj.dump[bx.off[2] + rowo + lx] = e1zn[e];

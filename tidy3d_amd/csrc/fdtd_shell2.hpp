@@ -38,7 +38,7 @@ namespace fdtd {
 // rows / lanes / planes then lie off them too (the collar) — runs an instantiation without that axis' 32 psi registers
 template <bool MAT, int AXES>
 __global__ __launch_bounds__(512, (AXES == 7 ? 2 : 3)) void shell2_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
-                                                          const PmlP* __restrict__ pmq, Shell2M boxes) {
+                                                          const PmlP* __restrict__ pmq, Shell2M boxes, Shell2Dump dmp) {
   constexpr int V = 4;
   // ONE launch covers all boxes of the shell (the workgroups of box q are [first[q], first[q + 1])): six small launches one
   // behind the other on a stream left the machine half empty between them (profiles/r5)
@@ -391,6 +391,29 @@ __global__ __launch_bounds__(512, (AXES == 7 ? 2 : 3)) void shell2_step_kernel(G
         }
       }
       if (!row_ok) { zero<V>(e1xn); zero<V>(e1zn); }      // rows beyond the grid publish E = 0 (the wall)
+      // the middle step over the boxes of DFT monitors that reach into the shell (fused2_step_kernel does the same over the bulk):
+      // H^{n+1/2} for records at step n, E^{n+1} for records at step n + 1 — of the cells this box owns
+      if (dmp.dstart && st_lane && k >= kc0 && k < kc1) {
+        for (int qd = dmp.dstart[k]; qd < dmp.dstart[k + 1]; ++qd) {
+          const DumpBox bx = dmp.dboxes[dmp.dlist[qd]];
+          const int ly = j - bx.lo1, lz = k - bx.lo2;
+          if (ly >= 0 && ly < bx.ny) {
+            const long long rowd = ((long long)lz * bx.ny + ly) * bx.nx;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+              const int lx = i0 + e - bx.lo0;
+              if (lx >= 0 && lx < bx.nx) {
+                if (bx.off[0] >= 0) dmp.dump[bx.off[0] + rowd + lx] = e1xn[e];
+                if (bx.off[1] >= 0) dmp.dump[bx.off[1] + rowd + lx] = e1yn[e];
+                if (bx.off[2] >= 0) dmp.dump[bx.off[2] + rowd + lx] = e1zn[e];
+                if (bx.off[3] >= 0) dmp.dump[bx.off[3] + rowd + lx] = hxn[e];
+                if (bx.off[4] >= 0) dmp.dump[bx.off[4] + rowd + lx] = hyn[e];
+                if (bx.off[5] >= 0) dmp.dump[bx.off[5] + rowd + lx] = hzn[e];
+              }
+            }
+          }
+        }
+      }
     }
     // ---- S3: H2[k-1] = H^{n+3/2}[k-1]; H-side recursions of step n+1 on H1[k-1] -----------------------------------------------
     float h2x[V], h2y[V], h2z[V];

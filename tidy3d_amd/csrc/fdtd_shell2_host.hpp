@@ -1,6 +1,6 @@
 // shell2_step_kernel (fdtd_shell2.hpp): what fdtd_capi.hip and fdtd_shell2.hip share.
 #pragma once
-#include "fdtd_kernels.hpp"
+#include "fdtd_fused2.hpp"
 
 namespace fdtd {
 
@@ -14,6 +14,14 @@ struct Shell2P {
   int nbx, nby, nbz;   // tiles
 };
 
+// the middle step over the boxes of DFT monitors (as InjP's dump fields, fdtd_fused2.hpp): H^{n+1/2} for records at step n, E^{n+1} for
+// records at step n + 1, written by the box that owns the cell; dstart == nullptr: none
+struct Shell2Dump {
+  const int* dstart;
+  const int* dlist;
+  const DumpBox* dboxes;
+  float* dump;
+};
 constexpr int kShell2MaxQ = 64;
 constexpr int kShell2Boxes = 12;
 struct Shell2M {
@@ -25,6 +33,6 @@ struct Shell2M {
 // host-side launcher (fdtd_shell2.hip): `waves` wavefronts per workgroup (<= 8); axes: the axes whose recursions the boxes can
 // meet (1, 2, 4: that axis only; anything else: all)
 void launch_shell2_step(hipStream_t st, int waves, bool mat, int axes, const GridP& g, const FieldP& a, const FieldP& b, const StepP& s,
-                        const MatP& m, const PmlP* pm, const Shell2M& boxes);
+                        const MatP& m, const PmlP* pm, const Shell2M& boxes, const Shell2Dump& dmp);
 
 }  // namespace fdtd
