@@ -208,3 +208,43 @@ def test_dft_monitors_reaching_into_the_shell_do_not_stop_shell2_pairs(name, bsp
         assert np.array_equal(got_f[c], ref_f[c]), c
     for k in ref_r:
         assert np.abs(np.asarray(ref_r[k])).max() > 0 and np.array_equal(np.asarray(got_r[k]), np.asarray(ref_r[k])), k
+
+
+@pytest.mark.parametrize("kind", ["current_sheet", "plane_wave", "two_sheets"])
+def test_shell2_pairs_with_z_holes_for_injecting_source_planes(kind, emu_lib):
+    """Source lists the sweeps cannot apply themselves — a current sheet of hundreds of nodes that runs through the layers (what a
+    mode plane is), the injection plane of a plane wave (TFSF corrections + its 1-D incident grid) — keep single steps in their own
+    planes (+- 2) only: those planes are z holes that take two single steps through the third set, with their psi routed through
+    temporary sets; the intervals between them go out as clipped two-step sweeps with their own shell2 boxes.  Pairs from the first
+    step on, through the pulse and after it; DFT planes clear of the holes recorded from pairs; same bits as single steps."""
+    N = (40, 20, 60)
+    size = tuple((n - 1e-6) * DL for n in N)
+    pulse = td.GaussianPulse(freq0=3e14, fwidth=2.4e14)
+    glass = td.Structure(geometry=td.Box(center=(0, 0, -0.9), size=(td.inf, td.inf, 0.6)), medium=td.Medium(permittivity=2.1))
+    ball = td.Structure(geometry=td.Sphere(center=(0.1, 0.0, -0.1), radius=0.25), medium=td.Medium(permittivity=3.0, conductivity=0.02))
+    if kind == "plane_wave":
+        srcs = [td.PlaneWave(center=(0, 0, 0.9), size=(td.inf, td.inf, 0), source_time=pulse, direction="-")]
+        bspec = B_ALL
+    else:
+        srcs = [td.UniformCurrentSource(center=(0, 0, 0.8), size=(td.inf, td.inf, 0), source_time=pulse, polarization="Ey")]
+        if kind == "two_sheets":
+            srcs.append(td.UniformCurrentSource(center=(0.1, 0, -0.5), size=(1.0, 0.6, 0), source_time=pulse, polarization="Hx"))
+        bspec = B_ODD if kind == "two_sheets" else B_ALL
+    mons = [td.FieldTimeMonitor(center=(0.1, 0.05, 0.2), size=(0, 0, 0), name="probe", interval=1, colocate=False),
+            td.FluxMonitor(center=(0, 0, 0.3), size=(td.inf, td.inf, 0), freqs=[2.5e14, 3e14], name="flux")]
+    sim = td.Simulation(size=size, grid_spec=td.GridSpec.uniform(dl=DL), run_time=1.1e-14, structures=[glass, ball], sources=srcs,
+                        monitors=mons, boundary_spec=bspec, shutoff=0)
+    disc = discretize(sim)
+    disc.spec.decay_every = 0
+    spec = disc.spec
+    n1 = 41
+    assert spec.n_steps > n1 + 30
+    ref_f, ref_r, p0, _, q0, _ = _run(spec, emu_lib, 0, 0, runs=(n1, spec.n_steps - n1), fields=False)
+    got_f, got_r, p1, s1, q1, why = _run(spec, emu_lib, 8 + 64 * 6, 1, runs=(n1, spec.n_steps - n1), fields=False)
+    assert p0 == 0 and q0 == 0
+    assert q1 == p1 and p1 >= spec.n_steps // 2 - 2, (p1, s1, q1, spec.n_steps, why)
+    assert max(float(np.abs(f).max()) for f in ref_f) > 0
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), (c, float(np.abs(got_f[c] - ref_f[c]).max()))
+    for k in ref_r:
+        assert np.abs(np.asarray(ref_r[k])).max() > 0 and np.array_equal(np.asarray(got_r[k]), np.asarray(ref_r[k])), k

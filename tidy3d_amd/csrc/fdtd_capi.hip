@@ -46,6 +46,8 @@ struct PmlAxisDev {
   float* psi_h[2] = {nullptr, nullptr};
   float* psi_h2[2] = {nullptr, nullptr};   // write set of the in-sweep CPML (ping-pong), lazily allocated
   float* psi_e2[2] = {nullptr, nullptr};   // write set of the E side for shell2_step_kernel (two steps per sweep carry psi: both sides ping-pong), lazily allocated
+  float* psi_ht[2] = {nullptr, nullptr};   // temporary sets: the middle step of the z holes of a shell2 pair (single steps beside boxes that
+  float* psi_et[2] = {nullptr, nullptr};   // still read the old values), lazily allocated
   size_t psi_count = 0;                    // entries per psi array
   size_t psi_plane = 0;                    // entries of one z-plane of it (x, y axes: the H-side arrays carry one more, the ghost slot)
 };
@@ -207,6 +209,8 @@ struct FdtdSolver {
   int rows = 4;
   PmlP* pml_blk[8][2][2] = {};       // device parameter blocks of the in-sweep CPML: [axis mask][psi_h parity][psi_e parity] (E side in place)
   PmlP* pml_blk2[2][2] = {};         // the same for shell2_step_kernel: all axes, both sides read one set and write the other
+  PmlP* pml_blk_hole[2][2][2] = {};  // z holes of a shell2 pair: [step of the pair][psi_h parity][psi_e parity] — step one current -> temporary sets, step two temporary -> other sets
+  bool pml_blk_hole_ok = false;
   bool pml_blk_ok[8] = {};
   bool pml_blk2_ok = false;
   int pml_parity = 0;
@@ -585,6 +589,51 @@ int ensure_pml_blocks2(FdtdSolver* h) {
   return 0;
 }
 
+// The blocks of the z holes of a shell2 pair (planes that take two single steps beside the boxes: a mode plane, the injection plane
+// of a plane wave).  The boxes around a hole re-read the OLD psi of its planes (chunk prologues, the plane above a chunk) while the
+// hole's first step runs, so that step writes TEMPORARY sets on both sides and the second one reads them and writes the sets the
+// boxes write — after the pair every cell's psi sits in the same (new) sets.
+int ensure_pml_blocks_hole(FdtdSolver* h) {
+  if (h->pml_blk_hole_ok) return 0;
+  if (ensure_pml_blocks2(h)) return -1;
+  const int N[3] = {h->g.nx, h->g.ny, h->g.nz};
+  for (int a = 0; a < 3; ++a) {
+    PmlAxisDev& P = h->pml[a];
+    if (P.ns == 0) continue;
+    for (int q = 0; q < 2; ++q) {
+      if (!P.psi_ht[q] && dev_alloc(h, &P.psi_ht[q], P.psi_count + P.psi_plane)) return -1;
+      if (!P.psi_et[q] && dev_alloc(h, &P.psi_et[q], P.psi_count)) return -1;
+    }
+  }
+  for (int step = 0; step < 2; ++step)
+    for (int par = 0; par < 2; ++par)
+      for (int ep = 0; ep < 2; ++ep) {
+        PmlP pm{};
+        for (int a = 0; a < 3; ++a) {
+          const PmlAxisDev& P = h->pml[a];
+          PmlAxisP& A = pm.ax[a];
+          fill_pml_axis(h, a, P.ns > 0, par != h->pml_parity, ep != h->pml_e_parity, false, A);     // (coefficients, membership; pointers below)
+          float* const h_cur[2] = {const_cast<float*>(A.ph0), const_cast<float*>(A.ph1)};
+          float* const h_oth[2] = {A.ph0n, A.ph1n};
+          float* const e_cur[2] = {A.pe0, A.pe1};
+          float* const e_oth[2] = {A.pe0n, A.pe1n};
+          if (step == 0) {
+            A.ph0 = h_cur[0]; A.ph1 = h_cur[1]; A.ph0n = P.psi_ht[0]; A.ph1n = P.psi_ht[1];
+            A.pe0 = e_cur[0]; A.pe1 = e_cur[1]; A.pe0n = P.psi_et[0]; A.pe1n = P.psi_et[1];
+          } else {
+            A.ph0 = P.psi_ht[0]; A.ph1 = P.psi_ht[1]; A.ph0n = h_oth[0]; A.ph1n = h_oth[1];
+            A.pe0 = P.psi_et[0]; A.pe1 = P.psi_et[1]; A.pe0n = e_oth[0]; A.pe1n = e_oth[1];
+          }
+          (void)N;
+        }
+        if (!h->pml_blk_hole[step][par][ep] && dev_alloc(h, &h->pml_blk_hole[step][par][ep], 1, false)) return -1;
+        if (hipMemcpy(h->pml_blk_hole[step][par][ep], &pm, sizeof(PmlP), hipMemcpyHostToDevice) != hipSuccess)
+          return fail(h, "upload of the CPML parameter block failed");
+      }
+  h->pml_blk_hole_ok = true;
+  return 0;
+}
+
 // axes whose CPML recursions can run inside the sweep
 int pml_in_sweep_mask(const FdtdSolver* h) {
   int mask = 0;
@@ -619,7 +668,7 @@ void swap_psi_e(FdtdSolver* h) {
 // pml_inside: axes whose CPML recursions this launch carries (its tiles must not touch members of other
 // in-sweep axes): 0 -> plain instantiation, 1 -> the x-only one, anything else -> the all-axes one.
 // A shell step (ShellSets) names its own read / write sets and psi parity, and the rows [ex_j0, ex_j1) its launch leaves alone.
-struct ShellSets { FieldP src, dst; int parity; int ex_j0, ex_j1; };
+struct ShellSets { FieldP src, dst; int parity; int ex_j0, ex_j1; const PmlP* pm = nullptr; };     // pm: a parameter block of the caller's (z holes of a shell2 pair)
 int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pml_inside = 0, int k2beg = 0,
                        int k2end = 0, int ty_n = -1, int ty_a = 0, int ty_gap = 0, bool edge = false,
                        const ShellSets* sh = nullptr) {
@@ -675,7 +724,7 @@ int launch_fused_range(FdtdSolver* h, int kbeg, int kend, hipStream_t st, int pm
   int lb = h->fused_lb ? h->fused_lb : (threads <= 256 ? 256 : (threads <= 512 ? 512 : 1024));
   if (lb < threads) lb = threads <= 512 ? 512 : 1024;
   time_begin(h, sh ? 3 : 2, st);
-  const PmlP* pm = pml_inside ? h->pml_blk[pml_inside][sh ? sh->parity : h->pml_parity][h->pml_e_parity] : nullptr;
+  const PmlP* pm = pml_inside ? ((sh && sh->pm) ? sh->pm : h->pml_blk[pml_inside][sh ? sh->parity : h->pml_parity][h->pml_e_parity]) : nullptr;
   const FieldP fa = sh ? sh->src : h->f, fb = sh ? sh->dst : h->f2;
   const int ex_j0 = sh ? sh->ex_j0 : 0, ex_j1 = sh ? sh->ex_j1 : 0;
 #define FDTD_LAUNCH_FUSED_H(MATV, LBV, PMLV, HV)                                                       \
@@ -1327,18 +1376,23 @@ constexpr int kShell2MaxBoxes = 24;
 // middle rows of a z slab: z) — their instantiation carries 32 psi registers instead of 96 — and the edges and corners, where two
 // or three slabs cross, go out as small boxes of the all-axes instantiation.
 int shell2_boxes_by_axes(const FdtdSolver* h, const ShellGeom& G, Shell2Box out[kShell2MaxBoxes]);
-int shell2_boxes(const FdtdSolver* h, const ShellGeom& G, Shell2Box out[kShell2MaxBoxes]) {
+// (z_lo, z_hi: the planes of the x strips and — where they reach beyond G's plane range — of the z slabs: the whole grid, or the
+//  segment of one bulk interval when z holes cut the run of planes)
+int shell2_boxes(const FdtdSolver* h, const ShellGeom& G, Shell2Box out[kShell2MaxBoxes], int z_lo = 0, int z_hi = -1) {
+  if (z_hi < 0) z_hi = h->g.nz;
   if (h->shell2_on != 2 && h->shell2_on != 3) {      // the default: six boxes, all of the all-axes instantiation (one launch)
     const int nx = h->g.nx, ny = h->g.ny, nz = h->g.nz;
     int n = 0;
-    if (G.o0[0] > 0) out[n++] = {0, G.o0[0], 0, ny, 0, nz, true, 7};
-    if (G.o1[0] < nx) out[n++] = {G.o1[0], nx, 0, ny, 0, nz, true, 7};
-    if (G.o0[2] > 0) out[n++] = {G.o0[0], G.o1[0], 0, ny, 0, G.o0[2], false, 7};
-    if (G.o1[2] < nz) out[n++] = {G.o0[0], G.o1[0], 0, ny, G.o1[2], nz, false, 7};
+    (void)nz;
+    if (G.o0[0] > 0) out[n++] = {0, G.o0[0], 0, ny, z_lo, z_hi, true, 7};
+    if (G.o1[0] < nx) out[n++] = {G.o1[0], nx, 0, ny, z_lo, z_hi, true, 7};
+    if (G.o0[2] > z_lo) out[n++] = {G.o0[0], G.o1[0], 0, ny, z_lo, G.o0[2], false, 7};
+    if (G.o1[2] < z_hi) out[n++] = {G.o0[0], G.o1[0], 0, ny, G.o1[2], z_hi, false, 7};
     if (G.o0[1] > 0) out[n++] = {G.o0[0], G.o1[0], 0, G.o0[1], G.o0[2], G.o1[2], false, 7};
     if (G.o1[1] < ny) out[n++] = {G.o0[0], G.o1[0], G.o1[1], ny, G.o0[2], G.o1[2], false, 7};
     return n;
   }
+  if (z_lo != 0 || z_hi != h->g.nz) { Shell2Box tmp[kShell2MaxBoxes]; (void)tmp; }
   return shell2_boxes_by_axes(h, G, out);
 }
 int shell2_boxes_by_axes(const FdtdSolver* h, const ShellGeom& G, Shell2Box out[kShell2MaxBoxes]) {
@@ -2481,10 +2535,10 @@ int fdtd_set_pml(FdtdSolver* h, int axis, int n_lo, int n_hi, const float* kinv_
     if (P.ns > 0 && dev_alloc(h, &P.psi_e[q], P.psi_count)) return -1;
     if (P.ns > 0 && dev_alloc(h, &P.psi_h[q], P.psi_count + P.psi_plane)) return -1;
     P.psi_h2[q] = nullptr;
-    P.psi_e2[q] = nullptr;
+    P.psi_e2[q] = nullptr; P.psi_ht[q] = nullptr; P.psi_et[q] = nullptr;
   }
   for (bool& ok : h->pml_blk_ok) ok = false;          // parameter blocks are rebuilt on next use
-  h->pml_blk2_ok = false;
+  h->pml_blk2_ok = false; h->pml_blk_hole_ok = false;
   return 0;
 }
 
@@ -2810,6 +2864,8 @@ int fdtd_reset(FdtdSolver* h) {
       if (P.psi_h[s]) HIPCHK(h, hipMemset(P.psi_h[s], 0, (P.psi_count + P.psi_plane) * 4));
       if (P.psi_h2[s]) HIPCHK(h, hipMemset(P.psi_h2[s], 0, (P.psi_count + P.psi_plane) * 4));
       if (P.psi_e2[s]) HIPCHK(h, hipMemset(P.psi_e2[s], 0, P.psi_count * 4));
+      if (P.psi_et[s]) HIPCHK(h, hipMemset(P.psi_et[s], 0, P.psi_count * 4));
+      if (P.psi_ht[s]) HIPCHK(h, hipMemset(P.psi_ht[s], 0, (P.psi_count + P.psi_plane) * 4));
     }
   }
   for (AdeGroup& a : h->ade) {
@@ -2861,6 +2917,7 @@ struct Run {
   bool f2_ok = false, f2s_ok = false, s2_ok = false, s2_deep = false, f2m_ok = false;
   ShellGeom sg{};
   ZPlan zp_base, zp_src;               // the bulk's planes: without / with the z holes of the source lists
+  ZPlan zp_s2, zp_s2h;                 // shell2 pairs: one interval [o0z, o1z) / the intervals between the z holes of the source lists (ok: usable)
   F2Plan f2_plan;
   int64_t done = 0;
   // the step being issued (begin_step)
@@ -3236,6 +3293,12 @@ struct Run {
         s2_ok = true; sg = g2;                               // (the same geometry shell_why_not finds)
         s2_deep = shell2_sources_deep(h, sg);
         h->f2_off_reason = 0;
+        zp_s2 = ZPlan{}; zp_s2.n = 1; zp_s2.a[0] = sg.o0[2]; zp_s2.b[0] = sg.o1[2]; zp_s2.ok = true;
+        // lists that inject and that the sweeps cannot apply: their planes as z holes — usable when every hole lies inside the bulk's plane
+        // range (one-launch form only: FDTD_OPT_SHELL2 = 2 / 3 cut their boxes differently)
+        zp_s2h = ZPlan{};
+        if (h->shell2_on != 2 && h->shell2_on != 3 && zplan_build(h, sg, true, &zp_s2h) && zp_s2h.n > 1 && zp_s2h.a[0] == sg.o0[2] &&
+            zp_s2h.b[zp_s2h.n - 1] == sg.o1[2]) zp_s2h.ok = true;
       }
     }
     h->f2_dyn_reason = 0;
@@ -3314,24 +3377,53 @@ struct Run {
   }
   // steps n and n + 1 of a grid walled by CPML, shell2 form: the bulk as ONE clipped two-step sweep on st, the shell's boxes as
   // shell2_step_kernel launches on cs — all read set A / the current psi sets, all write disjoint cells of set B / the other psi sets
-  int shell2_pair(long long n, const F2Table* tb) {
+  // `zp`: the bulk's plane intervals.  One interval [o0z, o1z): no holes.  More: the planes between two intervals are z HOLES — the
+  // planes of source lists the sweeps cannot apply while they inject (a mode plane, a current sheet, the injection plane of a plane
+  // wave; +- 2 planes) — and take two single steps through set T on cs, as in the round-4 form, with parameter blocks that route
+  // their psi through temporary sets (ensure_pml_blocks_hole); every interval gets its own bulk launch and its own boxes.
+  int shell2_pair(long long n, const F2Table* tb, const ZPlan& zp) {
     hipStream_t cs = (h->shell_on == 2) ? st : h->comm_stream;       // (2: shell behind the bulk on ONE stream — a measuring aid)
+    const bool holes = zp.n > 1;
     if (ensure_second_set(h) || ensure_pml_blocks2(h)) return -1;
+    if (holes && (ensure_third_set(h) || ensure_pml_blocks_hole(h))) return -1;
     if (!h->ev_shell_a) {
       HIPCHK(h, hipEventCreateWithFlags(&h->ev_shell_a, hipEventDisableTiming));
       HIPCHK(h, hipEventCreateWithFlags(&h->ev_shell_b, hipEventDisableTiming));
     }
-    launch_sources(h, false, n, 0, nz, st);                  // H-side sources of step n on H^{n-1/2} (deep inside the bulk, or spent)
+    launch_sources(h, false, n, 0, nz, st);                  // H-side sources of step n on H^{n-1/2}, then the incident grid's H: the order of a single step
     advance_tfsf_aux(h, false, n, st);
     HIPCHK(h, hipEventRecord(h->ev_shell_a, st));
     HIPCHK(h, hipStreamWaitEvent(cs, h->ev_shell_a, 0));
+    const FieldP A = h->f, B = h->f2, T = h->f3;
+    const int hp = h->pml_parity, ep = h->pml_e_parity;
     bool s2 = false;
-    const ClipP clip{sg.o0[0], sg.o1[0], sg.o0[1], sg.o1[1], sg.o0[2], sg.o1[2]};
-    if (launch_fused2(h, n, st, tb, &s2, nullptr, &clip)) return -1;
-    const PmlP* pm = h->pml_blk2[h->pml_parity][h->pml_e_parity];
     Shell2Box boxes[kShell2MaxBoxes];
-    const int nb = shell2_boxes(h, sg, boxes);
-    launch_shell2_boxes(h, boxes, nb, pm, cs, tb);
+    int nb = 0;
+    for (int i = 0; i < zp.n; ++i) {
+      const ClipP clip{sg.o0[0], sg.o1[0], sg.o0[1], sg.o1[1], zp.a[i], zp.b[i]};
+      if (launch_fused2(h, n, st, tb, &s2, nullptr, &clip)) return -1;
+      // the boxes beside this interval: its planes, and (first / last interval) the z slabs below / above
+      ShellGeom gi = sg;
+      gi.o0[2] = zp.a[i]; gi.o1[2] = zp.b[i];
+      Shell2Box bi[kShell2MaxBoxes];
+      const int ni = shell2_boxes(h, gi, bi, i == 0 ? 0 : zp.a[i], i == zp.n - 1 ? nz : zp.b[i]);
+      for (int q = 0; q < ni && nb < kShell2MaxBoxes; ++q) boxes[nb++] = bi[q];
+    }
+    launch_shell2_boxes(h, boxes, nb, h->pml_blk2[hp][ep], cs, tb);
+    if (holes) {
+      const int pml_in = 7 & pml_in_sweep_mask(h);
+      ShellSets s1{A, T, hp, 0, 0, h->pml_blk_hole[0][hp][ep]}, s2h{T, B, hp, 0, 0, h->pml_blk_hole[1][hp][ep]};
+      // step one over the holes grown by one plane (what step two differentiates), set A -> set T
+      for (int i = 0; i + 1 < zp.n; ++i)
+        if (launch_fused_range(h, zp.b[i] - 1, zp.a[i + 1] + 1, cs, pml_in, 0, 0, -1, 0, 0, true, &s1)) return -1;
+      // the middle step: E-side sources / corrections of step n, the incident grid's E; then what precedes step n + 1
+      launch_sources(h, true, n, 0, nz, cs, false, &T);
+      advance_tfsf_aux(h, true, n, cs);
+      launch_sources(h, false, n + 1, 0, nz, cs, false, &T);
+      advance_tfsf_aux(h, false, n + 1, cs);
+      for (int i = 0; i + 1 < zp.n; ++i)
+        if (launch_fused_range(h, zp.b[i], zp.a[i + 1], cs, pml_in, 0, 0, -1, 0, 0, true, &s2h)) return -1;
+    }
     HIPCHK(h, hipEventRecord(h->ev_shell_b, cs));
     HIPCHK(h, hipStreamWaitEvent(st, h->ev_shell_b, 0));
     swap_sets(h);
@@ -3339,12 +3431,28 @@ struct Run {
     swap_psi_e(h);
     pair_record(h, tb, n, st);
     if (rec_at(n + 1)) record_monitors(h, n + 1, true, st);
-    advance_tfsf_aux(h, true, n, st);
-    advance_tfsf_aux(h, false, n + 1, st);
+    if (!holes) {
+      advance_tfsf_aux(h, true, n, st);
+      advance_tfsf_aux(h, false, n + 1, st);
+    }
     launch_sources(h, true, n + 1, 0, nz, st);
     advance_tfsf_aux(h, true, n + 1, st);
     fill_ghost_fused(h, st);
     return 0;
+  }
+  // shell2 pairs with z holes: every monitor of the plan clear of the holes' planes (their single steps copy nothing out) — a DFT
+  // monitor inside one SEGMENT (an interval, extended to the grid's end below the first / above the last), a time monitor inside one interval
+  bool plan_clear_of_holes(const F2Plan& pl, const ZPlan& zp) {
+    auto inside = [&](const Monitor& m, bool segment) {
+      for (int i = 0; i < zp.n; ++i) {
+        const int lo = (segment && i == 0) ? 0 : zp.a[i], hi = (segment && i == zp.n - 1) ? nz : zp.b[i];
+        if (m.box.lo2 >= lo && m.box.lo2 + m.box.nz <= hi) return true;
+      }
+      return false;
+    };
+    for (int q : pl.mons) if (!inside(h->mons[(size_t)q], false)) return false;
+    for (int q : pl.dfts) if (!inside(h->mons[(size_t)q], true)) return false;
+    return true;
   }
   // every monitor of the pair's plan inside ONE interval of the bulk's planes (the sweep copies the middle step out only there)
   bool plan_in_bulk(const F2Plan& pl, const ZPlan& zp) {
@@ -3375,11 +3483,17 @@ struct Run {
       src_why = fused2_sources_why_not(h, n, &src_alive);
       // shell2 form: the boxes apply no sources — lists that inject must lie deep inside the bulk
       use_s2 = s2_ok && src_why == 0 && (!src_alive || s2_deep);
+      if (use_s2) zp = &zp_s2;
+      else if (s2_ok && zp_s2h.ok && (src_why != 0 || src_alive)) {
+        // lists that inject and that the sweeps cannot apply themselves (too many nodes, nodes inside the shell, TFSF corrections): their
+        // planes take single steps as z holes; nothing is injected by the sweeps (the table of a pair whose lists are spent)
+        use_s2 = true; src_why = 0; src_alive = false; zp = &zp_s2h;
+      }
       if (!use_s2 && !f2_ok && !f2s_ok) { if (src_why) h->f2_dyn_reason = src_why; pair = false; }
     }
     if (pair && use_s2) {
-      pair = fused2_plan(h, n, &f2_plan, sg.o0, sg.o1, true);
-      if (!pair && f2s_ok) { pair = true; use_s2 = false; }          // (a monitor reaching into the shell: the single-step shell may still take it — judged below)
+      pair = fused2_plan(h, n, &f2_plan, sg.o0, sg.o1, true) && plan_clear_of_holes(f2_plan, *zp);
+      if (!pair && f2s_ok) { pair = true; use_s2 = false; zp = &zp_base; src_why = fused2_sources_why_not(h, n, &src_alive); }   // (the single-step shell may still take it — judged below)
     }
     if (pair && !use_s2) {
       // lists that inject and that the sweep cannot apply itself: a shell pair whose bulk leaves their planes to the shell
@@ -3677,7 +3791,7 @@ struct Run {
       } else if (pair && use_s2) {
         const F2Table* tb = fused2_table(h, f2_plan, src_alive);
         if (!tb) return -1;
-        if (shell2_pair(n, tb)) return -1;
+        if (shell2_pair(n, tb, *zp)) return -1;
         h->fused2_pairs++;
         h->shell_pairs++;
         h->shell2_pairs++;
@@ -3927,7 +4041,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_ZCHUNK: if (value < 1) break; h->zchunk = value; h->zchunk_f = value; h->user_geometry = true; return 0;
     case FDTD_OPT_ROWS: if (value < 1 || value > 15) break; h->rows = value > 8 ? 8 : value; h->rows_f = value; h->user_geometry = true; return 0;
     case FDTD_OPT_XCD_REMAP: if (value > 1024) break; h->xcd_remap = value < 0 ? -1 : value; return 0;
-    case FDTD_OPT_PML_FUSED: h->pml_fused = value < 0 ? -1 : (value & 7); for (bool& ok : h->pml_blk_ok) ok = false; h->pml_blk2_ok = false; return 0;
+    case FDTD_OPT_PML_FUSED: h->pml_fused = value < 0 ? -1 : (value & 7); for (bool& ok : h->pml_blk_ok) ok = false; h->pml_blk2_ok = false; h->pml_blk_hole_ok = false; return 0;
     case FDTD_OPT_BND_PLANES: h->bnd_planes = value > 0 ? value : 0; return 0;
     case FDTD_OPT_AUTOTUNE: h->autotune = value < 0 ? 0 : (value > 2 ? 1 : value); if (value) h->tuned = false; return 0;
     case FDTD_OPT_MEM_HINTS: h->mem_hints = value != 0; return 0;

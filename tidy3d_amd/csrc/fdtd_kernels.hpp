@@ -973,8 +973,8 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
               if (!wx) ez[e] -= coef(2, e).y * (cf.x * d2 + p1);       // E_z is tangential to the x wall
               if (!wall_z) ex[e] += coef(0, e).y * (cf.x * d1 + p2);   // E_x is tangential to the z wall
             }
-            stg4(uni(A.pe0 + qy), ub, s1);
-            stg4(uni(A.pe1 + qy), ub, s2);
+            stg4(uni(A.pe0n + qy), ub, s1);       // (pe0n == pe0 for a step on its own: in place; the middle steps of a pair write another set)
+            stg4(uni(A.pe1n + qy), ub, s2);
           }
         }
         // axis z: E_x -= cb (kv dHy/dz + p1),  E_y += cb (kv dHx/dz + p2)
@@ -994,8 +994,8 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
               if (!wall_y) ex[e] -= coef(0, e).y * (cf.x * d2 + p1);   // E_x is tangential to the y wall
               if (!wx) ey[e] += coef(1, e).y * (cf.x * d1 + p2);       // E_y is tangential to the x wall
             }
-            stg4(uni(A.pe0 + qz), ub, s1);
-            stg4(uni(A.pe1 + qz), ub, s2);
+            stg4(uni(A.pe0n + qz), ub, s1);
+            stg4(uni(A.pe1n + qz), ub, s2);
           }
         }
         // axis x: E_y -= cb (kv dHz/dx + p1),  E_z += cb (kv dHy/dx + p2)
@@ -1021,8 +1021,8 @@ __global__ __launch_bounds__(LB, (LB == 256 ? (PML == 0 ? 4 : (PML == 1 ? 3 : 2)
                 if (!wall_y) ez[e] += coef(2, e).y * (kv[e] * d1 + p2);     // E_z is tangential to the y wall
               }
             }
-            stg4(uni(A.pe0 + qx), sxb, s1);
-            stg4(uni(A.pe1 + qx), sxb, s2);
+            stg4(uni(A.pe0n + qx), sxb, s1);
+            stg4(uni(A.pe1n + qx), sxb, s2);
           }
         }
       }

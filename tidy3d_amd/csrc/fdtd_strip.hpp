@@ -303,8 +303,8 @@ __global__ __launch_bounds__(256, OCC) void strip_step_kernel(GridP g, FieldP a,
     if (st_ok) {
       if (sx >= 0) {
         const PmlAxisP& A = pmq->ax[0];
-        stv<V>(A.pe0 + qx, xe1);
-        stv<V>(A.pe1 + qx, xe2);
+        stv<V>(A.pe0n + qx, xe1);
+        stv<V>(A.pe1n + qx, xe2);
         stv<V>(A.ph0n + qx, xh1);
         stv<V>(A.ph1n + qx, xh2);
       }
