@@ -448,6 +448,12 @@ def main():
                             "how": "library default" if not (args.rows or args.zchunk) else "flags"},
                    "bytes_per_cell_step": 2 * BYTES_PER_CELL_PASS,
                    "roofline_mcells_per_gpu": HBM_PEAK / (2 * BYTES_PER_CELL_PASS) / 1e6},
+        # where the twelve field arrays landed in device memory decides up to 15 % of the step time on this part (DESIGN.md section 7:
+        # "placement"): the engine times up to three alternative allocations on its first large run and keeps the fastest — the line
+        # says how many it tried, which it kept and what the probe sweeps took (on the top level, not in config)
+        "placement": {"tried": int(st.placement) >> 8, "kept": int(st.placement) & 255,
+                      "probe_ms_first": float(st.placement_ms_first), "probe_ms_kept": float(st.placement_ms_kept),
+                      "note": "box-to-box spread of the headline (181-198 Gcells/s over round 5's visits) is this effect, not the kernel"},
         "repeats": {"n": R, "statistic": "median", "ms_per_step": [e / K * 1e3 for e in samples],
                     "min_ms_per_step": min(samples) / K * 1e3, "max_ms_per_step": max(samples) / K * 1e3},
         "roofline": roofline_entry(st, kr, local_cells, cells, K, elapsed, world, args.workload, spec),
