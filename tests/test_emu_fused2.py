@@ -334,3 +334,36 @@ def test_not_eligible_runs_take_single_steps(emu_lib):
         assert p0 == 0 and p1 == (6 if "bspec" in kw else 0), p1
         for c in range(6):
             assert np.array_equal(got_f[c], ref_f[c]), c
+
+
+@pytest.mark.parametrize("bspec_name,w,zc", [("pec", 5, 3), ("abs", 6, 4), ("pec", 4, 2)])
+def test_background_only_tiles_on_the_plain_instantiation(bspec_name, w, zc, emu_lib):
+    """Tile classes (round 5, FDTD_OPT_TILE_SPLIT): the two-step sweep of a grid with bodies goes out as two launches over the same
+    tiles — the plain instantiation where a tile and its halo rows / planes hold only the background medium (the uniform
+    coefficients are the table's entry 1), the materials one elsewhere.  A tall three-tile grid with a small lossy block, a sphere
+    right of the seams and a PEC box: most tiles are background-only.  Forced split == never split == single steps, bit for bit;
+    with absorber layers too (the plain launch keeps the damping)."""
+    N = (516, 30, 40)
+    size = tuple(n * DL for n in N)
+    bspec = {"pec": PEC, "abs": ABS}[bspec_name]
+    structures = [td.Structure(geometry=td.Box(center=(-0.5, 0.2, 0.3), size=(3.0, 0.2, 0.2)), medium=td.Medium(permittivity=3.0, conductivity=0.02)),
+                  td.Structure(geometry=td.Sphere(center=(6.3, -0.3, -0.5), radius=0.25), medium=td.Medium(permittivity=2.5)),
+                  td.Structure(geometry=td.Box(center=(0.1, 0.1, 0), size=(0.1, 0.1, 0.1)), medium=td.PEC)]
+    mons = [td.FieldTimeMonitor(center=(0.0, 0.0, 0.0), size=(0, 0, 0), name="mid", interval=2, fields=["Ez", "Hx"], colocate=False),
+            td.FieldMonitor(center=(0, 0, 0.1), size=(td.inf, td.inf, 0), freqs=[3e14], name="f", colocate=False)]
+    disc = discretize(_sim(N, monitors=False, structures=structures, bspec=bspec).updated_copy(monitors=mons), n_steps=26)
+    disc.spec.decay_every = 0
+    outs = []
+    for twostep, split in ((0, -1), (w + 64 * zc, 1), (w + 64 * zc, 0)):
+        with HipEngine(disc.spec, lib=emu_lib, variant=L.VARIANT_FUSED, z_chunk=2) as e:
+            e.set_option(L.OPT_ROWS, 3)
+            e.set_option(L.OPT_TWOSTEP, twostep)
+            e.set_option(L.OPT_TILE_SPLIT, split)
+            pairs = sum(int(e.run(r).fused2_pairs) for r in (11, 15))
+            outs.append(([e.get_field(c) for c in range(6)], e.results(), pairs))
+    assert outs[0][2] == 0 and outs[1][2] == 12 and outs[2][2] == 12, [o[2] for o in outs]
+    for got in outs[1:]:
+        for c in range(6):
+            assert np.array_equal(got[0][c], outs[0][0][c]), c
+        for k in outs[0][1]:
+            assert np.array_equal(np.asarray(got[1][k]), np.asarray(outs[0][1][k])), k

@@ -152,6 +152,10 @@ struct FdtdSolver {
   uint32_t* mat4 = nullptr;          // packed material words (interior plane 0), nullptr = uniform
   uint32_t* mat4b = nullptr;         // wide layout (more than 1023 media): the second word per cell; mat4 then holds E_x | E_y << 16
   uint32_t* roww = nullptr;          // row-segment words [nz][ny][ceil(nx / 256)]
+  std::vector<uint32_t> roww_host;   // host copy of them: the tile classes of the two-step sweep are derived from it (tile_classes)
+  struct TileClasses { int W, zc; ClipP box; int nbx, nby, nbz; unsigned char* dev; long long n_bg, n_all; };
+  std::vector<TileClasses> tile_cls; // one entry per launch shape met so far
+  int tile_split = -1;               // FDTD_OPT_TILE_SPLIT: background-only tiles on the plain instantiation: -1 = default (where >= 25 % of the tiles are), 0 = never, 1 = always
   float2* lut = nullptr;
   int n_media = 0;
   float ca1 = 1.f, cb1 = 0.f;
@@ -1069,6 +1073,39 @@ const F2Table* fused2_table(FdtdSolver* h, const F2Plan& plan, bool with_sources
   return &h->f2_tables.back();
 }
 
+// Tile classes of a launch shape of the two-step sweep (round 5).  The materials instantiation sits at 128 VGPRs with spilled
+// registers and looks coefficients up per row segment: 12 % slower than the plain one (V1 174 against V0 197 Gcells/s) although nine
+// tiles in ten of a typical grid — a body in a box of background — hold nothing but the background medium.  cls[tile] = 1 where any
+// row segment the workgroup of that tile computes E for (its rows j0-1 .. j0+R, planes k0-1 .. k1) differs from the background
+// word; the launch then goes out twice over the same tiles: the plain instantiation where cls == 0 (the uniform coefficients ARE
+// the table's entry 1: the same bits), the materials one where cls == 1; a workgroup of the other class leaves at once.
+const FdtdSolver::TileClasses* tile_classes(FdtdSolver* h, int W, int zc, const ClipP& box, int nbx, int nby, int nbz) {
+  if (!h->mat4 || h->roww_host.empty() || h->tile_split == 0) return nullptr;
+  for (const auto& t : h->tile_cls)
+    if (t.W == W && t.zc == zc && t.nbx == nbx && t.nby == nby && t.nbz == nbz && t.box.j0 == box.j0 && t.box.j1 == box.j1 &&
+        t.box.k0 == box.k0 && t.box.k1 == box.k1) return &t;
+  const GridP& g = h->g;
+  const int R = W - 3, nbx_all = (g.nx + 255) / 256;
+  std::vector<unsigned char> cls((size_t)nbx * nby * nbz, 0);
+  long long n_bg = 0;
+  for (int tz = 0; tz < nbz; ++tz)
+    for (int tx = 0; tx < nbx; ++tx)
+      for (int ty = 0; ty < nby; ++ty) {
+        const int k0 = box.k0 + tz * zc, k1 = std::min(k0 + zc, box.k1);
+        const int j0 = box.j0 + ty * R;
+        unsigned char c = 0;
+        for (int k = std::max(k0 - 1, 0); k <= std::min(k1, g.nz - 1) && !c; ++k)
+          for (int j = std::max(j0 - 2, 0); j <= std::min(j0 + R, g.ny - 1); ++j)
+            if (h->roww_host[((size_t)k * g.ny + j) * nbx_all + tx] != kBgWord) { c = 1; break; }
+        cls[((size_t)tz * nbx + tx) * nby + ty] = c;
+        n_bg += !c;
+      }
+  FdtdSolver::TileClasses e{W, zc, box, nbx, nby, nbz, nullptr, n_bg, (long long)cls.size()};
+  if (dev_upload(h, &e.dev, (const unsigned char*)cls.data(), cls.size())) return nullptr;
+  h->tile_cls.push_back(e);
+  return &h->tile_cls.back();
+}
+
 // steps n and n + 1 in one sweep: set a (E^n, H^{n-1/2}) -> set b (E^{n+2}, H^{n+3/2}).  The E-side sources of step n are
 // applied inside the kernel; so are those of step n + 1 (*sources2_done) when their terms come from the table of all steps
 // and no source node lies next to a seam — else the caller applies them afterwards.  The middle step is copied out for the
@@ -1152,9 +1189,18 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
   StepP sp = step_params(h);
   time_begin(h, 2, st);
   const MatP mp = mat_params(h);
-  launch_fused2_step(st, W, (h->mem_hints ? 1 : 0) | (h->mat4 ? 2 : 0) | ((tb->mons.empty() && (!tb->with_sources || h->src_h_nodes == 0) && !tb->dstart) ? 0 : 4) |
-                     (clip ? 16 : (h->has_damp ? 8 : 0)),
-                     remap ? ((total + 7) / 8) * 8 : total, g, h->f, h->f2, sp, mp, zc, nbx, nby, nbz, remap, inj, h->seam_buf, dmp, box);
+  const int opt = (h->mem_hints ? 1 : 0) | (h->mat4 ? 2 : 0) | ((tb->mons.empty() && (!tb->with_sources || h->src_h_nodes == 0) && !tb->dstart) ? 0 : 4) |
+                  (clip ? 16 : (h->has_damp ? 8 : 0));
+  const int blocks = remap ? ((total + 7) / 8) * 8 : total;
+  const FdtdSolver::TileClasses* tc = tile_classes(h, W, zc, box, nbx, nby, nbz);
+  if (tc && tc->n_bg > 0 && (h->tile_split == 1 || 4 * tc->n_bg >= tc->n_all)) {
+    // background-only tiles on the plain instantiation, the rest on the materials one (two launches over the same tiles)
+    launch_fused2_step(st, W, opt & ~2, blocks, g, h->f, h->f2, sp, mp, zc, nbx, nby, nbz, remap, inj, h->seam_buf, dmp, box, TileClassP{tc->dev, 0});
+    if (tc->n_bg < tc->n_all)
+      launch_fused2_step(st, W, opt, blocks, g, h->f, h->f2, sp, mp, zc, nbx, nby, nbz, remap, inj, h->seam_buf, dmp, box, TileClassP{tc->dev, 1});
+  } else {
+    launch_fused2_step(st, W, opt, blocks, g, h->f, h->f2, sp, mp, zc, nbx, nby, nbz, remap, inj, h->seam_buf, dmp, box);
+  }
   if (n_seams > 0) launch_seams(st, g, h->f2, sp, mp, h->seam_buf, n_seams, dmp, box);
   time_end(h, st);
   if (!clip) swap_sets(h);
@@ -2483,6 +2529,8 @@ int upload_material(FdtdSolver* h, const T* mat, size_t count) {
   uint32_t* base = nullptr;
   if (dev_upload(h, &base, (const uint32_t*)packed.data(), fcount)) return -1;
   if (dev_upload(h, &h->roww, (const uint32_t*)roww.data(), roww.size())) return -1;
+  h->roww_host = wide ? std::vector<uint32_t>() : roww;
+  h->tile_cls.clear();
   h->mat4 = base + g.sxy;
   return 0;
 }
@@ -4063,6 +4111,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_STRIP: if (value % 64 < 1 || (value / 64 != 3 && value / 64 != 4)) break; h->strip_zc = value % 64; h->strip_occ = value / 64; return 0;
     case FDTD_OPT_SHELL2: h->shell2_on = value < 0 ? -1 : (value > 3 ? 1 : value); return 0;
     case FDTD_OPT_DEBUG_SYNC: h->debug_sync = value != 0; return 0;
+    case FDTD_OPT_TILE_SPLIT: h->tile_split = value < 0 ? -1 : (value != 0); return 0;
     case FDTD_OPT_SHELL2_SHAPE: {
       // lanes per row of the wide boxes (3 ... 64) + 128 * their waves per workgroup (1 ... 8) + 1024 * their planes per chunk (0 = by box)
       //   + 2^17 * waves per workgroup of the strips (1 ... 8) + 2^21 * their planes per chunk (0 = by box)

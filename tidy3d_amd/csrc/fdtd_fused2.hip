@@ -21,16 +21,16 @@ void launch_inject_values(hipStream_t st, float* val, const float* w_re, const f
 
 void launch_fused2_step(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
                         const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,
-                        int xcd_remap, const InjP& inj, float* seam, const DampT& dmp, const ClipP& clip) {
+                        int xcd_remap, const InjP& inj, float* seam, const DampT& dmp, const ClipP& clip, const TileClassP& tcl) {
   if (opt & 16) {
-    launch_fused2_step_clip(st, waves, opt, grid_blocks, g, a, b, s, m, zchunk, nbx, nby, nbz, xcd_remap, inj, seam, dmp, clip);
+    launch_fused2_step_clip(st, waves, opt, grid_blocks, g, a, b, s, m, zchunk, nbx, nby, nbz, xcd_remap, inj, seam, dmp, clip, tcl);
     return;
   }
   const dim3 grid(grid_blocks, 1, 1), block(64, waves, 1);
   const size_t shmem = ((size_t)8 * waves * 64 + ((opt & 8) ? 2 * 64 : 0)) * sizeof(float4);
 #define FDTD_F2_O(LBV, OV)                                                                                             \
   hipLaunchKernelGGL((fused2_step_kernel<LBV, OV>), grid, block, shmem, st, g, a, b, s, m, zchunk, nbx, nby, nbz,     \
-                     xcd_remap, inj, seam, dmp, clip)
+                     xcd_remap, inj, seam, dmp, clip, tcl)
 #define FDTD_F2(LBV)                                                                                                   \
   do {                                                                                                                 \
     switch (opt & 15) {                                                                                                \

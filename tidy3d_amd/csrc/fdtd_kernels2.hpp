@@ -152,7 +152,7 @@ __device__ __forceinline__ int lane_value(int v, int l) {
 template <int LB, int OPT>
 __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
                                                          int zchunk, int nbx, int nby, int nbz, int xcd_remap,
-                                                         InjP inj, float* __restrict__ seam, DampT dmp, ClipP clip) {
+                                                         InjP inj, float* __restrict__ seam, DampT dmp, ClipP clip, TileClassP tcl) {
   constexpr int V = 4;
   constexpr bool NT = (OPT & 1) != 0, MAT = (OPT & 2) != 0, MON = (OPT & 4) != 0;     // MON: the node table may hold monitor samples
   constexpr bool DAMP = (OPT & 8) != 0;   // absorber layers: both fields of both steps are damped in registers (damp_kernel's factors)
@@ -181,6 +181,10 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     }
     if (t >= total) return;
   }
+  // Tile classes (round 5): a grid with bodies goes out as TWO launches over the same tiles — the plain instantiation for the tiles
+  // whose cells (halo rows and planes included) all hold the background medium, the materials one for the rest; a workgroup whose
+  // tile belongs to the other launch leaves here, before any barrier.
+  if (tcl.cls && tcl.cls[t] != tcl.want) return;
   const int tile_y = t % nby;
   const int tile_x = (t / nby) % nbx;
   const int tile_z = t / (nby * nbx);
