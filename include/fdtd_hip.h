@@ -304,9 +304,9 @@ enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_R
        FDTD_OPT_DEBUG_SYNC = 21, /* 1: a device-wide synchronisation in front of and behind every launch group of fdtd_run (no two launches ever
                                     overlap): a debugging aid — a schedule whose result then differs from the normal run's has a missing
                                     cross-stream edge.  Default 0 */
-       FDTD_OPT_TILE_SPLIT = 22, /* the two-step sweep of a grid with bodies as two launches over the same tiles — the plain instantiation where a
-                                    tile (halo rows and planes included) holds only the background medium, the materials one elsewhere; same
-                                    bits: -1 = default (where at least a quarter of the tiles are background-only), 0 = never, 1 = always */
+       FDTD_OPT_TILE_SPLIT = 22, /* the two-step sweep of a grid with bodies: workgroups whose tile (halo rows and planes included) holds only
+                                    the background medium run the plain sweep inside the materials launch; same bits: -1 = default (where at
+                                    least one tile in eight is background-only), 0 = never, 1 = wherever such a tile exists */
        FDTD_OPT_LDS_PAD = 10 /* measuring aid: extra dynamic LDS per workgroup of the sweep in bytes (lowers its occupancy) */ };
 int fdtd_set_option(FdtdSolver* h, int key, int value);
 int fdtd_reset(FdtdSolver* h);      /* zero fields, auxiliaries, monitors and the step counter */

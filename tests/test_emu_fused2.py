@@ -338,11 +338,11 @@ def test_not_eligible_runs_take_single_steps(emu_lib):
 
 @pytest.mark.parametrize("bspec_name,w,zc", [("pec", 5, 3), ("abs", 6, 4), ("pec", 4, 2)])
 def test_background_only_tiles_on_the_plain_instantiation(bspec_name, w, zc, emu_lib):
-    """Tile classes (round 5, FDTD_OPT_TILE_SPLIT): the two-step sweep of a grid with bodies goes out as two launches over the same
-    tiles — the plain instantiation where a tile and its halo rows / planes hold only the background medium (the uniform
-    coefficients are the table's entry 1), the materials one elsewhere.  A tall three-tile grid with a small lossy block, a sphere
-    right of the seams and a PEC box: most tiles are background-only.  Forced split == never split == single steps, bit for bit;
-    with absorber layers too (the plain launch keeps the damping)."""
+    """Tile classes (round 5, FDTD_OPT_TILE_SPLIT): in the two-step sweep of a grid with bodies, the workgroup of a tile that — halo
+    rows / planes included — holds only the background medium runs the plain sweep inside the materials launch (the uniform
+    coefficients are the table's entry 1).  A tall three-tile grid with a small lossy block, a sphere right of the seams and a PEC
+    box: most tiles are background-only.  Forced split == never split == single steps, bit for bit; with absorber layers too
+    (the plain sweep keeps the damping)."""
     N = (516, 30, 40)
     size = tuple(n * DL for n in N)
     bspec = {"pec": PEC, "abs": ABS}[bspec_name]

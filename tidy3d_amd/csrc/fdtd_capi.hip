@@ -1073,12 +1073,10 @@ const F2Table* fused2_table(FdtdSolver* h, const F2Plan& plan, bool with_sources
   return &h->f2_tables.back();
 }
 
-// Tile classes of a launch shape of the two-step sweep (round 5).  The materials instantiation sits at 128 VGPRs with spilled
-// registers and looks coefficients up per row segment: 12 % slower than the plain one (V1 174 against V0 197 Gcells/s) although nine
-// tiles in ten of a typical grid — a body in a box of background — hold nothing but the background medium.  cls[tile] = 1 where any
-// row segment the workgroup of that tile computes E for (its rows j0-1 .. j0+R, planes k0-1 .. k1) differs from the background
-// word; the launch then goes out twice over the same tiles: the plain instantiation where cls == 0 (the uniform coefficients ARE
-// the table's entry 1: the same bits), the materials one where cls == 1; a workgroup of the other class leaves at once.
+// Tile classes of a launch shape of the two-step sweep (round 5): cls[tile] = 1 where any row segment the workgroup of that tile
+// computes E for (its rows j0-2 .. j0+R, planes k0-1 .. k1) differs from the background word, 0 where the tile is background only —
+// there the materials launch runs the plain sweep (fused2_step_kernel; the uniform coefficients ARE the table's entry 1: the same
+// bits).
 const FdtdSolver::TileClasses* tile_classes(FdtdSolver* h, int W, int zc, const ClipP& box, int nbx, int nby, int nbz) {
   if (!h->mat4 || h->roww_host.empty() || h->tile_split == 0) return nullptr;
   for (const auto& t : h->tile_cls)
@@ -1192,15 +1190,11 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
   const int opt = (h->mem_hints ? 1 : 0) | (h->mat4 ? 2 : 0) | ((tb->mons.empty() && (!tb->with_sources || h->src_h_nodes == 0) && !tb->dstart) ? 0 : 4) |
                   (clip ? 16 : (h->has_damp ? 8 : 0));
   const int blocks = remap ? ((total + 7) / 8) * 8 : total;
+  // background-only tiles take the plain sweep inside the materials launch (fdtd_kernels2.hpp, tile classes)
   const FdtdSolver::TileClasses* tc = tile_classes(h, W, zc, box, nbx, nby, nbz);
-  if (tc && tc->n_bg > 0 && (h->tile_split == 1 || 4 * tc->n_bg >= tc->n_all)) {
-    // background-only tiles on the plain instantiation, the rest on the materials one (two launches over the same tiles)
-    launch_fused2_step(st, W, opt & ~2, blocks, g, h->f, h->f2, sp, mp, zc, nbx, nby, nbz, remap, inj, h->seam_buf, dmp, box, TileClassP{tc->dev, 0});
-    if (tc->n_bg < tc->n_all)
-      launch_fused2_step(st, W, opt, blocks, g, h->f, h->f2, sp, mp, zc, nbx, nby, nbz, remap, inj, h->seam_buf, dmp, box, TileClassP{tc->dev, 1});
-  } else {
-    launch_fused2_step(st, W, opt, blocks, g, h->f, h->f2, sp, mp, zc, nbx, nby, nbz, remap, inj, h->seam_buf, dmp, box);
-  }
+  const bool split = tc && tc->n_bg > 0 && (h->tile_split == 1 || 8 * tc->n_bg >= tc->n_all);
+  launch_fused2_step(st, W, opt, blocks, g, h->f, h->f2, sp, mp, zc, nbx, nby, nbz, remap, inj, h->seam_buf, dmp, box,
+                     TileClassP{split ? tc->dev : nullptr});
   if (n_seams > 0) launch_seams(st, g, h->f2, sp, mp, h->seam_buf, n_seams, dmp, box);
   time_end(h, st);
   if (!clip) swap_sets(h);

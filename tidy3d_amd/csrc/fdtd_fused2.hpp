@@ -41,9 +41,9 @@ struct DampT {
 // the box a clipped launch of the two-step sweep writes: [i0, i1) x [j0, j1) x [k0, k1), i0 and i1 multiples of 4 — the bulk of a
 // grid whose shell (CPML slabs + collar, boundary planes of a z-slab rank) is advanced by single steps (fdtd_capi.hip, shell pairs)
 struct ClipP { int i0, i1, j0, j1, k0, k1; };
-// tile classes of a launch: cls[tile] (logical tile index, y fastest) = 1 where the tile holds a cell that is not the background medium;
-// a workgroup runs only where cls[tile] == want.  cls == nullptr: every tile
-struct TileClassP { const unsigned char* cls; int want; };
+// tile classes of a launch of a materials instantiation: cls[tile] (logical tile index, y fastest) = 0 where the tile holds only the
+// background medium — its workgroup runs the plain sweep.  cls == nullptr: the materials sweep everywhere
+struct TileClassP { const unsigned char* cls; };
 constexpr int kMaxCap = 1024;
 constexpr int kSeamArrays = 13;  // of step one: H1_y, H1_z, E1_x, E1_y, E1_z [c-1], E1_y, E1_z [c]; of step two: H2_x [c-1], H2_y, H2_z [c-2], H2_x, H2_y, H2_z [c]
                                  // (c = first column of the right tile)
@@ -55,11 +55,11 @@ void launch_inject_values(hipStream_t st, float* val, const float* w_re, const f
 // samples in the table, bit 3 absorber layers (dmp.fb[0] set), bit 4 the launch covers the box `clip` only (not with bit 3)
 void launch_fused2_step(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
                         const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,
-                        int xcd_remap, const InjP& inj, float* seam, const DampT& dmp, const ClipP& clip, const TileClassP& tcl = TileClassP{nullptr, 0});
+                        int xcd_remap, const InjP& inj, float* seam, const DampT& dmp, const ClipP& clip, const TileClassP& tcl = TileClassP{nullptr});
 // the clipped instantiations live in their own translation unit (fdtd_fused2c.hip): the two compile side by side
 void launch_fused2_step_clip(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
                              const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,
-                             int xcd_remap, const InjP& inj, float* seam, const DampT& dmp, const ClipP& clip, const TileClassP& tcl = TileClassP{nullptr, 0});
+                             int xcd_remap, const InjP& inj, float* seam, const DampT& dmp, const ClipP& clip, const TileClassP& tcl = TileClassP{nullptr});
 void launch_inject_table(hipStream_t st, float* tab, long long stride, long long off, const float* w_re, const float* w_im,
                          const float2* wave, long long n_steps, int n);
 constexpr int kPairMons = 4;

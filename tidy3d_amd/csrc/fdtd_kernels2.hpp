@@ -149,10 +149,11 @@ __device__ __forceinline__ int lane_value(int v, int l) {
 #endif
 }
 
+// the sweep of tile t (logical index, y fastest) by its workgroup; fused2_step_kernel below picks t and the instantiation
 template <int LB, int OPT>
-__global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
-                                                         int zchunk, int nbx, int nby, int nbz, int xcd_remap,
-                                                         InjP inj, float* __restrict__ seam, DampT dmp, ClipP clip, TileClassP tcl) {
+__device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a, const FieldP& b, const StepP& s, const MatP& m,
+                                                 int zchunk, int nbx, int nby, int nbz, const InjP& inj,
+                                                 float* __restrict__ seam, const DampT& dmp, const ClipP& clip, int t) {
   constexpr int V = 4;
   constexpr bool NT = (OPT & 1) != 0, MAT = (OPT & 2) != 0, MON = (OPT & 4) != 0;     // MON: the node table may hold monitor samples
   constexpr bool DAMP = (OPT & 8) != 0;   // absorber layers: both fields of both steps are damped in registers (damp_kernel's factors)
@@ -167,24 +168,6 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
   const bool per_x = CLIP && g.bcx0 == BC_PERIODIC;
   // (Issuing the loads of plane k+1 behind the second barrier of plane k — the one way to overlap them with compute inside a wave —
   //  was measured: + 60 registers, slower at every workgroup size, profiles/r3q; taken out.)
-  const int total = nbx * nby * nbz;
-  int t = blockIdx.x;
-  if (xcd_remap == 1) {
-    const int per = (total + 7) >> 3;
-    t = (t & 7) * per + (t >> 3);
-    if (t >= total) return;
-  } else if (xcd_remap > 1) {
-    const int G = xcd_remap, full = total / (8 * G) * (8 * G);
-    if (t < full) {
-      const int x = t & 7, mloc = t >> 3;
-      t = ((mloc / G) * 8 + x) * G + mloc % G;
-    }
-    if (t >= total) return;
-  }
-  // Tile classes (round 5): a grid with bodies goes out as TWO launches over the same tiles — the plain instantiation for the tiles
-  // whose cells (halo rows and planes included) all hold the background medium, the materials one for the rest; a workgroup whose
-  // tile belongs to the other launch leaves here, before any barrier.
-  if (tcl.cls && tcl.cls[t] != tcl.want) return;
   const int tile_y = t % nby;
   const int tile_x = (t / nby) % nbx;
   const int tile_z = t / (nby * nbx);
@@ -817,6 +800,39 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     body(k, LA);
     if (k + 1 <= k1) body(k + 1, LB2);
   }
+}
+
+// Tile classes (round 5): the materials instantiation sits at 128 VGPRs with spilled registers and looks coefficients up per row
+// segment — 12 % slower than the plain one (V1 174 against V0 197 Gcells/s) — although four tiles in five of a body in a box of
+// background hold nothing but the background medium.  With tcl.cls set, the workgroup of a tile whose cells (halo rows and planes
+// included) are all background runs the PLAIN sweep (the uniform coefficients are the table's entry 1: the same bits), inside the
+// same launch: two launches, one per class, were measured first and lose to the tail of the short one — 272 material tiles on 256
+// CUs are two rounds of workgroups (profiles/r5/tile_classes.md).
+template <int LB, int OPT>
+__global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
+                                                         int zchunk, int nbx, int nby, int nbz, int xcd_remap,
+                                                         InjP inj, float* __restrict__ seam, DampT dmp, ClipP clip, TileClassP tcl) {
+  const int total = nbx * nby * nbz;
+  int t = blockIdx.x;
+  if (xcd_remap == 1) {
+    const int per = (total + 7) >> 3;
+    t = (t & 7) * per + (t >> 3);
+    if (t >= total) return;
+  } else if (xcd_remap > 1) {
+    const int G = xcd_remap, full = total / (8 * G) * (8 * G);
+    if (t < full) {
+      const int x = t & 7, mloc = t >> 3;
+      t = ((mloc / G) * 8 + x) * G + mloc % G;
+    }
+    if (t >= total) return;
+  }
+  if constexpr ((OPT & 2) != 0) {
+    if (tcl.cls && !tcl.cls[t]) {
+      fused2_step_tile<LB, (OPT & ~2)>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t);
+      return;
+    }
+  }
+  fused2_step_tile<LB, OPT>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t);
 }
 
 // ---- the seams between x tiles -------------------------------------------------------------------------------------
