@@ -68,6 +68,35 @@ def slab_pairs_box(N=(24, 20, 44), periodic_z=False):
                          sources=sources, monitors=monitors, boundary_spec=bspec, shutoff=0)
 
 
+def slab_pairs_pml_box(N=(24, 20, 44), layers=(4, 5, 3), near_cut=False):
+    """CPML on every face (inside nothing: the layers are added to N), a lossy slab through the whole grid along z and a PEC box,
+    dipoles of both kinds deep inside the CPML-free box and away from where 2- and 3-rank runs cut the grid, a probe and an x-z plane
+    recorded every 7th / 10th step: what CPML-carrying z-slab ranks advance in shell2 pairs (tests/test_dist_gloo.py)."""
+    sx, sy, sz = (n * DL for n in N)
+    bspec = td.BoundarySpec(x=td.Boundary.pml(num_layers=layers[0]), y=td.Boundary.pml(num_layers=layers[1]),
+                            z=td.Boundary.pml(num_layers=layers[2]))
+    structures = [td.Structure(geometry=td.Box(center=(0.1, 0, 0), size=(0.4, 0.3, td.inf)), medium=td.Medium(permittivity=2.5, conductivity=0.03)),
+                  td.Structure(geometry=td.Box(center=(-0.3, 0.2, 0.05), size=(0.15, 0.15, 0.3)), medium=td.PEC)]
+    sources = [td.PointDipole(center=(0.02, 0.01, -0.5 * sz + 9.6 * DL), source_time=PULSE, polarization="Ez"),
+               td.PointDipole(center=(-0.1, 0.05, -0.5 * sz + 30.4 * DL), source_time=PULSE, polarization="Hy"),
+               td.PointDipole(center=(0.1, -0.1, -0.5 * sz + 35.5 * DL), source_time=PULSE, polarization="Ex")]
+    if near_cut:      # one plane above the lower cut of the tall box's 3-rank run (plane 21): that rank keeps single steps while the dipole injects
+        sources.append(td.PointDipole(center=(-0.15, 0.1, -0.5 * sz + 19.4 * DL), source_time=PULSE, polarization="Ey"))
+    monitors = [td.FieldTimeMonitor(center=(0.1, 0.05, 0.1), size=(0, 0, 0), name="probe", interval=7, colocate=False),
+                td.FieldTimeMonitor(center=(0, 0, 0), size=(td.inf, 0, td.inf), name="plane", interval=10, colocate=False)]
+    return td.Simulation(size=(sx, sy, sz), grid_spec=td.GridSpec.uniform(dl=DL), run_time=1e-12, structures=structures,
+                         sources=sources, monitors=monitors, boundary_spec=bspec, shutoff=0)
+
+
+def slab_pairs_pml_box_tall():
+    """66 planes for three ranks: the dipoles keep five or more planes from every cut a balanced split may choose."""
+    return slab_pairs_pml_box(N=(24, 20, 60))
+
+
+def slab_pairs_pml_box_near_cut():
+    return slab_pairs_pml_box(N=(24, 20, 60), near_cut=True)
+
+
 def slab_pairs_box_periodic():
     return slab_pairs_box(periodic_z=True)
 

@@ -132,6 +132,38 @@ def test_step_pairs_on_slab_ranks(world, case, twostep, emu_lib, tmp_path):
     assert float(got["decay"]) == pytest.approx(st.field_decay, rel=1e-6)
 
 
+CPML_PAIR_CASES = [(2, "slab_pairs_pml_box", 8 + 64 * 6), (2, "slab_pairs_pml_box", 16 + 64 * 8), (3, "slab_pairs_pml_box_tall", 8 + 64 * 5),
+                   (3, "slab_pairs_pml_box_near_cut", 8 + 64 * 4)]       # (the last one: a dipole next to a cut — its rank takes single steps beside ranks in pairs)
+
+
+@pytest.mark.parametrize("world,case,twostep", CPML_PAIR_CASES)
+def test_step_pairs_on_slab_ranks_that_carry_cpml(world, case, twostep, emu_lib, tmp_path):
+    """Round 5: z-slab ranks with CPML (x / y layers on every rank, z layers on the end ranks) advance in shell2 pairs — bulk and boxes
+    as on one GPU over the planes two or more away from a cut, the two planes next to a cut as a z hole that takes two single steps
+    and ships its planes (and the H-side psi of the top plane) after each.  Same bits as the single-slab run, materials through the
+    cuts, monitor records ending pairs; every rank takes pairs."""
+    import cases
+    out = str(tmp_path / "dist.npz")
+    _launch(world, case, 46, out, 29741 + CPML_PAIR_CASES.index((world, case, twostep)), twostep=twostep, pml_fused=7)
+    got = np.load(out)
+    if case == "slab_pairs_pml_box_near_cut":
+        assert got["pairs"].max() >= 8 and got["pairs"].min() == 0, got["pairs"]
+    else:
+        assert (got["pairs"] >= 8).all(), got["pairs"]
+    disc = discretize(getattr(cases, case)(), n_steps=46)
+    disc.spec.decay_every = 10
+    with HipEngine(disc.spec, lib=emu_lib) as e:
+        st = e.run()
+        ref = e.results()
+        fields = [e.get_field(c) for c in range(6)]
+    assert max(float(np.abs(f).max()) for f in fields) > 0
+    for c in range(6):
+        assert np.array_equal(got[f"field{c}"], fields[c]), c
+    for k, v in ref.items():
+        assert np.array_equal(got[f"mon_{k}"], v), k
+    assert float(got["decay"]) == pytest.approx(st.field_decay, rel=1e-6)
+
+
 FUZZ_RANK_CASES = [(2, 31, 0), (3, 31, 1), (2, 31, 2), (3, 31, 3), (2, 31, 4), (2, 31, 5), (3, 31, 6), (2, 31, 7)]
 
 

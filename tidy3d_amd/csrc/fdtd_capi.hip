@@ -2191,7 +2191,10 @@ int exchange_fused_e(FdtdSolver* h, hipStream_t st) {
 // chunks need for the next sweep — up: E_x,E_y,E_z and the pre-corrected H_x,H_y of my top plane
 // (-> upper ghost(-1)); down: E_x,E_y of my bottom plane (-> lower ghost(nz)).
 // `fs`: the set whose planes travel (default: the current one) — the middle step of a slab pair ships the third set's.
-int exchange_fused_all(FdtdSolver* h, hipStream_t st, bool pml_with_sweep = false, const FieldP* fs = nullptr) {
+// psi_set: which H-side psi arrays travel (the sender's newest top plane -> slot nz of the set the receiver's next sweep reads):
+// 0 = the current set, 1 = the temporary set of a z hole (after the first step of a CPML slab pair), 2 = the other set of the
+// ping-pong (after its second step, before the swap)
+int exchange_fused_all(FdtdSolver* h, hipStream_t st, bool pml_with_sweep = false, const FieldP* fs = nullptr, int psi_set = 0) {
   dbg_sync(h);
   const long long pc = plane_cells(h);
   const int nz = h->g.nz;
@@ -2204,6 +2207,7 @@ int exchange_fused_all(FdtdSolver* h, hipStream_t st, bool pml_with_sweep = fals
   // H-side psi of that plane — my top plane, CURRENT set (what the next sweep reads): into slot nz of its arrays.
   // Decided by the configuration alone (both sides must post the same messages), not by what a rank's sweep ends up doing.
   const bool psi_too = pml_with_sweep && h->pml_fused > 0;
+  auto psi_of = [&](int a, int q) { const PmlAxisDev& P = h->pml[a]; return psi_set == 1 ? P.psi_ht[q] : (psi_set == 2 ? P.psi_h2[q] : P.psi_h[q]); };
   // posting order mirrors the peer's (see exchange_fused_e): [to-hi][to-lo] <-> [from-lo][from-hi]
   NCCLCHK(h, ncclGroupStart());
   if (has_hi) {
@@ -2211,7 +2215,7 @@ int exchange_fused_all(FdtdSolver* h, hipStream_t st, bool pml_with_sweep = fals
     if (psi_too)
       for (int a = 0; a < 2; ++a)
         for (int q = 0; q < 2 && h->pml[a].ns > 0; ++q)
-          NCCLCHK(h, ncclSend(h->pml[a].psi_h[q] + (size_t)(nz - 1) * h->pml[a].psi_plane, h->pml[a].psi_plane, ncclFloat, hi, h->comm, st));
+          NCCLCHK(h, ncclSend(psi_of(a, q) + (size_t)(nz - 1) * h->pml[a].psi_plane, h->pml[a].psi_plane, ncclFloat, hi, h->comm, st));
   }
   if (has_lo) {
     NCCLCHK(h, ncclSend(F.ex, pc, ncclFloat, lo, h->comm, st));
@@ -2220,7 +2224,7 @@ int exchange_fused_all(FdtdSolver* h, hipStream_t st, bool pml_with_sweep = fals
     if (psi_too)
       for (int a = 0; a < 2; ++a)
         for (int q = 0; q < 2 && h->pml[a].ns > 0; ++q)
-          NCCLCHK(h, ncclRecv(h->pml[a].psi_h[q] + (size_t)nz * h->pml[a].psi_plane, h->pml[a].psi_plane, ncclFloat, lo, h->comm, st));
+          NCCLCHK(h, ncclRecv(psi_of(a, q) + (size_t)nz * h->pml[a].psi_plane, h->pml[a].psi_plane, ncclFloat, lo, h->comm, st));
   }
   if (has_hi) {
     NCCLCHK(h, ncclRecv(F.ex + (long long)nz * pc, pc, ncclFloat, hi, h->comm, st));
@@ -2957,7 +2961,8 @@ struct Run {
   bool split_now = false, graph_ok = false;
   std::vector<GraphRec> graphs;
   bool f2_ok = false, f2s_ok = false, s2_ok = false, s2_deep = false, f2m_ok = false;
-  ShellGeom sg{};
+  bool f2mc_ok = false, f2mc_deep = false;   // z-slab ranks with CPML: shell2 pairs with the planes next to a cut as z holes (sgm: their geometry)
+  ShellGeom sg{}, sgm{};
   ZPlan zp_base, zp_src;               // the bulk's planes: without / with the z holes of the source lists
   ZPlan zp_s2, zp_s2h;                 // shell2 pairs: one interval [o0z, o1z) / the intervals between the z holes of the source lists (ok: usable)
   F2Plan f2_plan;
@@ -3362,6 +3367,34 @@ struct Run {
       if (fused2_sources(h)) return -1;
       if (ensure_third_set(h)) { (void)hipGetLastError(); h->err.clear(); f2m_ok = false; h->f2_off_reason = FDTD_F2_OFF_MEMORY; }
     }
+    // z-slab ranks that carry CPML inside their sweeps (FDTD_OPT_PML_FUSED on every rank: tidy3d_amd/dist.py asks for it where the
+    // whole problem allows it): shell2 pairs — bulk and boxes as on one GPU, over the planes two or more away from a cut; the two
+    // planes next to a cut take two single steps as a z hole and ship their planes after each (slab_shell2_pair)
+    f2mc_ok = false;
+    if (fused_multi && any_pml(h) && pml_in_m != 0 && pml_in_m == pml_in_sweep_mask(h) && !h->has_damp && h->shell_on != 0 &&
+        h->shell2_on != 0 && h->ade.empty() && !any_periodic(h) && (long long)h->g.sxy * 4 < (1LL << 32)) {
+      int why = fused2_why_not(h, true, true);
+      if (!why && !shell_geometry(h, &sgm)) why = FDTD_F2_OFF_PML;
+      if (!why) {
+        const PmlAxisDev& pz = h->pml[2];
+        if (nb_lo) sgm.o0[2] = std::max(sgm.o0[2], 2);
+        if (nb_hi) sgm.o1[2] = std::min(sgm.o1[2], nz - 2);
+        // (the z recursion stays clear of the holes' planes and of what their first step reads)
+        if (sgm.o1[2] - sgm.o0[2] < 8 || (pz.ns > 0 && ((nb_lo && pz.lo > 0) || (nb_hi && pz.hi0 < nz)))) why = FDTD_F2_OFF_TOO_SMALL;
+      }
+      if (!why && (fused2_sources(h) || ensure_third_set(h) || ensure_pml_blocks2(h) || ensure_pml_blocks_hole(h))) {
+        (void)hipGetLastError();
+        h->err.clear();
+        why = FDTD_F2_OFF_MEMORY;
+      }
+      f2mc_ok = why == 0;
+      f2mc_deep = f2mc_ok && shell2_sources_deep(h, sgm);
+      h->f2_off_reason = why;
+      if (f2mc_ok && !h->ev_shell_b) {
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_shell_a, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_shell_b, hipEventDisableTiming));
+      }
+    }
     h->fused2_pairs = 0;
     h->shell_pairs = 0;
     h->shell2_pairs = 0;
@@ -3558,6 +3591,50 @@ struct Run {
     }
     return 0;
   }
+  // steps n and n + 1 of a z-slab rank that carries CPML (entry and exit state: "primed", as slab_rank_step's pair):
+  //   st: the bulk (sgm: the CPML-free box, two or more planes from a cut) as ONE clipped two-step sweep, set A -> set B
+  //   cs: the two planes next to each cut as a z hole — step one A -> T over the hole grown by one plane (psi: current sets ->
+  //       temporary sets), its E-side / the next H-side source terms, the planes (and the H-side psi of the top plane, temporary
+  //       set) travel; step two T -> B (psi: temporary -> the other sets), source terms, the planes travel again — the messages of
+  //       two single steps, in their order; then the shell's boxes (x strips, y / z slabs over the planes clear of the cuts) by
+  //       shell2_step_kernel, A -> B, psi current -> other sets.
+  // No launch reads what another one of the pair writes; st joins cs before it hands set B to the next step.
+  int slab_shell2_pair(const F2Table* tb) {
+    const int bl = nb_lo ? 2 : 0, bh = nb_hi ? 2 : 0;
+    const FieldP A = h->f, B = h->f2, T = h->f3;
+    const int hp = h->pml_parity, ep = h->pml_e_parity;
+    ShellSets s1{A, T, hp, 0, 0, h->pml_blk_hole[0][hp][ep]}, s2h{T, B, hp, 0, 0, h->pml_blk_hole[1][hp][ep]};
+    HIPCHK(h, hipStreamWaitEvent(cs, h->ev_e_int, 0));
+    HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
+    const ClipP clip{sgm.o0[0], sgm.o1[0], sgm.o0[1], sgm.o1[1], sgm.o0[2], sgm.o1[2]};
+    bool s2done = false;
+    if (launch_fused2(h, n, st, tb, &s2done, nullptr, &clip)) return -1;
+    if (launch_fused_range(h, 0, bl ? bl + 1 : 0, cs, pml_in_m, bh ? nz - bh - 1 : nz, nz, -1, 0, 0, true, &s1)) return -1;
+    HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
+    if (bl) { launch_sources(h, true, n, 0, bl + 1, cs, false, &T); launch_sources(h, false, n + 1, 0, bl + 1, cs, false, &T); }
+    if (bh) { launch_sources(h, true, n, nz - bh - 1, nz, cs, false, &T); launch_sources(h, false, n + 1, nz - bh - 1, nz, cs, false, &T); }
+    if (exchange_fused_all(h, cs, psi_ghosts, &T, 1)) return -1;
+    if (launch_fused_range(h, 0, bl, cs, pml_in_m, nz - bh, nz, -1, 0, 0, true, &s2h)) return -1;
+    if (bl) { launch_sources(h, true, n + 1, 0, bl, cs, false, &B); launch_sources(h, false, n + 2, 0, bl, cs, false, &B); }
+    if (bh) { launch_sources(h, true, n + 1, nz - bh, nz, cs, false, &B); launch_sources(h, false, n + 2, nz - bh, nz, cs, false, &B); }
+    HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
+    if (exchange_fused_all(h, cs, psi_ghosts, &B, 2)) return -1;
+    Shell2Box boxes[kShell2MaxBoxes];
+    const int nb = shell2_boxes(h, sgm, boxes, bl, nz - bh);
+    launch_shell2_boxes(h, boxes, nb, h->pml_blk2[hp][ep], cs, tb);
+    HIPCHK(h, hipEventRecord(h->ev_shell_b, cs));
+    HIPCHK(h, hipStreamWaitEvent(st, h->ev_shell_b, 0));
+    swap_sets(h);                                                            // h->f = B: E^{n+2}, H^{n+3/2}
+    swap_psi_h(h, 7);
+    swap_psi_e(h);
+    launch_sources(h, true, n + 1, bl, nz - bh, st);
+    launch_sources(h, false, n + 2, bl, nz - bh, st);
+    HIPCHK(h, hipEventRecord(h->ev_e_int, st));
+    h->fused2_pairs++;
+    h->shell2_pairs++;
+    h->step = n + 2;
+    return 1;
+  }
   // one step — or, where it can, a step pair — of a z-slab rank on the pipelined fused schedule (header comment: setup; slab pair: below).
   // -> 1: a pair was taken (two steps, no decay check due), 0: one step, < 0: error
   int slab_rank_step() {
@@ -3571,6 +3648,13 @@ struct Run {
     // "primed" (above).  Pairs keep clear of monitor records, decay checks and the end of the run (joined tails).
     auto decay_at = [&](long long m) { return h->decay_every > 0 && (m % h->decay_every) == 0; };
     bool src_alive_m = false;
+    if (f2mc_ok && done + 3 <= n_steps && !rec_at(n) && !rec_at(n + 1) && !rec_at(n + 2) && !decay_at(n + 1) && !decay_at(n + 2) &&
+        fused2_sources_why_not(h, n, &src_alive_m) == 0 && (!src_alive_m || f2mc_deep)) {
+      F2Plan none;
+      const F2Table* tb = fused2_table(h, none, src_alive_m);
+      if (!tb) return -1;
+      return slab_shell2_pair(tb);
+    }
     if (f2m_ok && done + 3 <= n_steps && !rec_at(n) && !rec_at(n + 1) && !rec_at(n + 2) && !decay_at(n + 1) && !decay_at(n + 2) &&
         fused2_sources_why_not(h, n, &src_alive_m) == 0) {
       F2Plan none;

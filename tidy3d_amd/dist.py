@@ -42,6 +42,20 @@ def best_slab_shift(shape, world: int) -> int:
     return best
 
 
+def cpml_pairs_possible(spec: SolverSpec) -> bool:
+    """May the z-slab ranks of this (already renamed) problem advance in step pairs although they carry CPML?  What the library's
+    shell2 pairs need of the WHOLE problem: CPML on some face, nothing else in the shell (no periodic x / y face, no absorber layers,
+    no dispersive or fully anisotropic media, no Bloch phases, no PMC-plus wall).  Every rank derives the same answer."""
+    from .spec import BC_PERIODIC
+    if not any(f.num_layers > 0 for ax in spec.pml for f in ax):
+        return False
+    if spec.absorber is not None or spec.bloch is not None or spec.aniso or spec.mirror_plus is not None:
+        return False
+    if any(m.poles for m in spec.media):
+        return False
+    return not any(int(b) == BC_PERIODIC for ax in spec.bc[:2] for b in ax)
+
+
 def make_engine(spec: SolverSpec, lib=None, device: Optional[int] = None, axis_shift: Optional[int] = None,
                 **kw) -> HipEngine:
     """This rank's slab engine with its RCCL communicator initialised (needs an initialised
@@ -62,6 +76,11 @@ def make_engine(spec: SolverSpec, lib=None, device: Optional[int] = None, axis_s
     eng = HipEngine(spec, lib=lib, device=device, slab=slabs[rank], rank=rank, n_ranks=world,
                     all_slabs=slabs, **kw)
     eng.slab_shift, eng.slab_user_z = shift, user_z     # gather_results renames the stitched boxes back
+    if cpml_pairs_possible(spec):
+        # CPML recursions inside the sweeps of EVERY rank (decided from the whole problem: the ranks then post the same messages):
+        # the state step pairs of CPML-carrying slab ranks start from and end in (fdtd_capi.hip, Run::slab_shell2_pair)
+        from . import lib as L
+        eng.set_option(L.OPT_PML_FUSED, 7)
     uid = [eng.unique_id() if rank == 0 else None]
     dist.broadcast_object_list(uid, src=0)
     eng.comm_init(uid[0])
