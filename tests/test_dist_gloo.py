@@ -164,6 +164,17 @@ def test_step_pairs_on_slab_ranks_that_carry_cpml(world, case, twostep, emu_lib,
     assert float(got["decay"]) == pytest.approx(st.field_decay, rel=1e-6)
 
 
+def test_in_sweep_cpml_is_asked_for_only_where_the_whole_problem_allows_pairs():
+    """dist.cpml_pairs_possible: decided from the whole (renamed) problem, so that every rank posts the same messages."""
+    import cases
+    from tidy3d_amd.dist import cpml_pairs_possible
+    yes = discretize(cases.slab_pairs_pml_box(), n_steps=4).spec
+    assert cpml_pairs_possible(yes)
+    for name in ("slab_pairs_box", "media_mix", "au_array", "drude_in_pml", "absorber_mix"):
+        sim = CASES[name]() if name in CASES else getattr(cases, name)()
+        assert not cpml_pairs_possible(discretize(sim, n_steps=4).spec), name
+
+
 FUZZ_RANK_CASES = [(2, 31, 0), (3, 31, 1), (2, 31, 2), (3, 31, 3), (2, 31, 4), (2, 31, 5), (3, 31, 6), (2, 31, 7)]
 
 
