@@ -97,6 +97,46 @@ def slab_pairs_pml_box_near_cut():
     return slab_pairs_pml_box(N=(24, 20, 60), near_cut=True)
 
 
+def random_slab_pml_box(seed, index):
+    """A random CPML-walled box for the step pairs of CPML-carrying z-slab ranks (scripts/fuzz_slab_cpml.py, tests/test_dist_gloo.py):
+    layers per axis 0 / 2 ... 6 (absent on at most one axis; PMC on a min face without layers now and then), lossy / PEC bodies anywhere
+    (through cuts and layers), two to four dipoles of either kind — most runs keep them deep inside, some put one next to a cut or
+    into the layers (that rank then keeps single steps while it injects) —, a probe and a plane recorded at random intervals.
+    -> (simulation, world, FDTD_OPT_TWOSTEP word, steps)"""
+    rng = np.random.default_rng([int(seed), int(index)])
+    world = int(rng.integers(2, 5))
+    N = (int(rng.integers(6, 10)) * 4, int(rng.integers(18, 30)), int(rng.integers(13, 20)) * world + int(rng.integers(0, 4)))
+    layers = [int(rng.integers(2, 7)) for _ in range(3)]
+    none = int(rng.integers(0, 5))
+    if none < 3:
+        layers[none] = 0
+    def bnd(a):
+        if layers[a]:
+            return td.Boundary.pml(num_layers=layers[a]) if rng.random() < 0.7 else td.Boundary.stable_pml(num_layers=layers[a])
+        return td.Boundary(minus=td.PMCBoundary() if rng.random() < 0.4 else td.PECBoundary(), plus=td.PECBoundary())
+    bspec = td.BoundarySpec(x=bnd(0), y=bnd(1), z=bnd(2))
+    size = tuple(n * DL for n in N)
+    structures = []
+    for _ in range(int(rng.integers(1, 4))):
+        c = tuple(float(rng.uniform(-0.4, 0.4) * s) for s in size)
+        sz = tuple(float(rng.uniform(0.1, 0.5) * s) if rng.random() < 0.8 else td.inf for s in size)
+        med = td.PEC if rng.random() < 0.25 else td.Medium(permittivity=float(rng.uniform(1.5, 4.0)), conductivity=float(rng.choice([0.0, 0.02])))
+        structures.append(td.Structure(geometry=td.Box(center=c, size=sz), medium=med))
+    sources = []
+    wild = rng.random() < 0.3
+    for _ in range(int(rng.integers(2, 5))):
+        f = 0.45 if wild else 0.18
+        c = tuple(float(rng.uniform(-f, f) * s) for s in size)
+        sources.append(td.PointDipole(center=c, source_time=PULSE, polarization=str(rng.choice(["Ex", "Ey", "Ez", "Hx", "Hy", "Hz"]))))
+    monitors = [td.FieldTimeMonitor(center=tuple(float(rng.uniform(-0.3, 0.3) * s) for s in size), size=(0, 0, 0), name="probe",
+                                    interval=int(rng.integers(3, 12)), colocate=False),
+                td.FieldTimeMonitor(center=(0, 0, 0), size=(td.inf, 0, td.inf), name="plane", interval=int(rng.integers(6, 16)), colocate=False)]
+    sim = td.Simulation(size=size, grid_spec=td.GridSpec.uniform(dl=DL), run_time=1e-12, structures=structures, sources=sources,
+                        monitors=monitors, boundary_spec=bspec, shutoff=0)
+    twostep = int(rng.choice([5, 6, 8, 16])) + 64 * int(rng.integers(3, 9))
+    return sim, world, twostep, int(rng.integers(30, 52))
+
+
 def slab_pairs_box_periodic():
     return slab_pairs_box(periodic_z=True)
 

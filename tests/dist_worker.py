@@ -60,6 +60,10 @@ def main():
         rng = np.random.default_rng(int(seed))
         for _ in range(int(index) + 1):
             disc = fuzz_variants.draw(rng, False)[0]
+    elif case.startswith("slabfuzz:"):      # "slabfuzz:<seed>:<index>": a random CPML-walled box (cases.random_slab_pml_box; every rank draws the same)
+        _, seed, index = case.split(":")
+        disc = discretize(cases.random_slab_pml_box(int(seed), int(index))[0], n_steps=n_steps)
+        disc.spec.decay_every = 10
     else:
         sim = cases.CASES[case]() if case in cases.CASES else getattr(cases, case)()
         disc = discretize(sim, n_steps=n_steps)

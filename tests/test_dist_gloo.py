@@ -164,6 +164,28 @@ def test_step_pairs_on_slab_ranks_that_carry_cpml(world, case, twostep, emu_lib,
     assert float(got["decay"]) == pytest.approx(st.field_decay, rel=1e-6)
 
 
+@pytest.mark.parametrize("seed,index", [(1, 0), (1, 5), (1, 7)])
+def test_random_cpml_boxes_in_step_pairs_on_two_to_four_ranks(seed, index, emu_lib, tmp_path):
+    """cases.random_slab_pml_box (scripts/fuzz_slab_cpml.py runs it unattended: 30 of 30 clean): layers absent on an axis, PMC min
+    walls, StablePML, bodies through cuts and layers, dipoles that keep single ranks in single steps, 3 - 4 ranks, four tile shapes."""
+    import cases
+    sim, world, twostep, steps = cases.random_slab_pml_box(seed, index)
+    out = str(tmp_path / "dist.npz")
+    _launch(world, f"slabfuzz:{seed}:{index}", steps, out, 29761 + index, twostep=twostep)
+    got = np.load(out)
+    assert got["pairs"].max() >= 6, got["pairs"]
+    disc = discretize(sim, n_steps=steps)
+    disc.spec.decay_every = 10
+    with HipEngine(disc.spec, lib=emu_lib) as e:
+        e.run()
+        ref = e.results()
+        fields = [e.get_field(c) for c in range(6)]
+    for c in range(6):
+        assert np.array_equal(got[f"field{c}"], fields[c]), c
+    for k, v in ref.items():
+        assert np.array_equal(got[f"mon_{k}"], v), k
+
+
 def test_in_sweep_cpml_is_asked_for_only_where_the_whole_problem_allows_pairs():
     """dist.cpml_pairs_possible: decided from the whole (renamed) problem, so that every rank posts the same messages."""
     import cases
