@@ -68,13 +68,13 @@ def slab_pairs_box(N=(24, 20, 44), periodic_z=False):
                          sources=sources, monitors=monitors, boundary_spec=bspec, shutoff=0)
 
 
-def slab_pairs_pml_box(N=(24, 20, 44), layers=(4, 5, 3), near_cut=False):
+def slab_pairs_pml_box(N=(24, 20, 44), layers=(4, 5, 3), near_cut=False, periodic_z=False):
     """CPML on every face (inside nothing: the layers are added to N), a lossy slab through the whole grid along z and a PEC box,
     dipoles of both kinds deep inside the CPML-free box and away from where 2- and 3-rank runs cut the grid, a probe and an x-z plane
     recorded every 7th / 10th step: what CPML-carrying z-slab ranks advance in shell2 pairs (tests/test_dist_gloo.py)."""
     sx, sy, sz = (n * DL for n in N)
     bspec = td.BoundarySpec(x=td.Boundary.pml(num_layers=layers[0]), y=td.Boundary.pml(num_layers=layers[1]),
-                            z=td.Boundary.pml(num_layers=layers[2]))
+                            z=td.Boundary.periodic() if periodic_z else td.Boundary.pml(num_layers=layers[2]))
     structures = [td.Structure(geometry=td.Box(center=(0.1, 0, 0), size=(0.4, 0.3, td.inf)), medium=td.Medium(permittivity=2.5, conductivity=0.03)),
                   td.Structure(geometry=td.Box(center=(-0.3, 0.2, 0.05), size=(0.15, 0.15, 0.3)), medium=td.PEC)]
     sources = [td.PointDipole(center=(0.02, 0.01, -0.5 * sz + 9.6 * DL), source_time=PULSE, polarization="Ez"),

@@ -187,7 +187,7 @@ def test_rccl_self_exchange_matches_ghost_copy(hip_lib):
 
 
 @pytest.mark.parametrize("schedule", ["cpml_three_launches", "shell_pairs_r4", "shell2_pairs", "slab_rank_fused", "slab_rank_fused_pml_in_sweep",
-                                      "slab_rank_pairs", "slab_rank_two_pass"])
+                                      "slab_rank_pairs", "slab_rank_cpml_pairs", "slab_rank_two_pass"])
 def test_schedules_do_not_depend_on_stream_timing(schedule, hip_lib):
     """every schedule that splits a step between the two streams, run normally (three times: a race shows as
     run-to-run differences too) and with FDTD_OPT_DEBUG_SYNC — a device-wide synchronisation in front of and behind every launch
@@ -217,11 +217,16 @@ def test_schedules_do_not_depend_on_stream_timing(schedule, hip_lib):
             from cases import slab_pairs_box
             disc = discretize(slab_pairs_box((72, 60, 132), periodic_z=True), n_steps=80)
             disc.spec.decay_every = 0
+        elif schedule == "slab_rank_cpml_pairs":      # round 5: a rank with x / y layers in shell2 pairs, the planes next to the cuts as z holes
+            from cases import slab_pairs_pml_box
+            disc = discretize(slab_pairs_pml_box((72, 60, 132), layers=(6, 5, 0), periodic_z=True), n_steps=80)
+            disc.spec.decay_every = 0
         else:
             disc = discretize(pipelined_slab_case(), n_steps=90)
             disc.spec.decay_every = 16
         opts = {"slab_rank_fused": {}, "slab_rank_fused_pml_in_sweep": {L.OPT_PML_FUSED: 7, L.OPT_BND_PLANES: 3},
-                "slab_rank_pairs": {L.OPT_TWOSTEP: 8 + 64 * 8}, "slab_rank_two_pass": {}}[schedule]
+                "slab_rank_pairs": {L.OPT_TWOSTEP: 8 + 64 * 8}, "slab_rank_cpml_pairs": {L.OPT_TWOSTEP: 8 + 64 * 8, L.OPT_PML_FUSED: 7},
+                "slab_rank_two_pass": {}}[schedule]
 
     def run(debug_sync):
         kw = dict(force_comm=True) if comm else dict(axis_shift=0)
@@ -237,10 +242,16 @@ def test_schedules_do_not_depend_on_stream_timing(schedule, hip_lib):
             return [e.get_field(c) for c in range(6)], e.results(), int(st.fused2_pairs), int(st.shell2_pairs)
     ref_f, ref_m, p_ref, q_ref = run(1)
     assert max(float(np.abs(f).max()) for f in ref_f) > 0
-    if schedule in ("shell_pairs_r4", "shell2_pairs", "slab_rank_pairs"):
+    if schedule in ("shell_pairs_r4", "shell2_pairs", "slab_rank_pairs", "slab_rank_cpml_pairs"):
         assert p_ref > 10, p_ref
-    if schedule == "shell2_pairs":
+    if schedule in ("shell2_pairs", "slab_rank_cpml_pairs"):
         assert q_ref > 10, q_ref
+    if schedule == "slab_rank_cpml_pairs":        # ... and the same bits as the plain one-GPU run of the same problem (periodic z, no exchange)
+        with HipEngine(disc.spec, lib=hip_lib, axis_shift=0) as e:
+            e.set_option(L.OPT_TWOSTEP, 0)
+            e.run()
+            for c in range(6):
+                assert np.array_equal(e.get_field(c), ref_f[c]), c
     for rep in range(3):
         f, m, p, q = run(0)
         assert (p, q) == (p_ref, q_ref)
