@@ -15,6 +15,10 @@ def test_policy():
     assert best_axis_shift((1024, 1024, 256), ((0, 0), (0, 0), (12, 12))) == 0                  # config 5 stays
     # config 3: x = 224 fills its one row segment better than 424 fills two, and fewer tiles meet a y / z slab
     assert best_axis_shift((424, 224, 824), ((12, 12),) * 3) == 1
+    # ... unless a long-lived source plane is normal to z (BASELINE config 3's mode plane): only there it can be a z hole of the step pairs
+    assert best_axis_shift((424, 224, 824), ((12, 12),) * 3, sheet=(2, 0.71)) == 0
+    assert best_axis_shift((424, 224, 824), ((12, 12),) * 3, sheet=(2, 0.10)) == 1            # a short pulse: the faster layout wins
+    assert best_axis_shift((424, 224, 824), ((12, 12),) * 3, sheet=(1, 0.71)) == 2            # normal to y: the layout that brings y to z
     assert best_axis_shift((60, 60, 400)) == 2 and best_axis_shift((60, 400, 60)) == 1
     assert best_axis_shift((258, 250, 264)) == 1            # 258 spills into a second tile, 250 does not
     assert best_axis_shift((8, 12, 20)) == 0                # tiny grids: launch-bound, left alone

@@ -121,14 +121,46 @@ def sweep_cost(shape, pml_layers=None) -> float:
     return rows / lane_efficiency(nx) * (2.0 - (1.0 - fy) * (1.0 - fz)) * fx
 
 
-def best_axis_shift(shape, pml_layers=None) -> int:
+def source_sheet(spec: SolverSpec):
+    """The long-lived source plane of a CPML-walled run, if it has one: (axis the plane is normal to, fraction of the run it injects
+    for) — a mode plane, a current sheet or the injection plane of a plane wave: more nodes than the two-step sweep's node table
+    takes (fdtd_fused2.hpp kMaxInj) on one grid plane (E and H nodes: two adjacent indices).  While such a list injects, its planes
+    take single steps as a Z HOLE of the step pairs (fdtd_capi.hip, Run::shell2_pair) — which needs the plane normal to the
+    device's z; laid out otherwise the whole grid takes single steps until the list ends.  None: no such plane."""
+    if not any(int(f.num_layers) > 0 for ax in spec.pml for f in ax) or spec.n_steps <= 0:
+        return None
+    best = None
+    lists = [(np.asarray(sc.ijk), max(len(sc.wave_e), len(sc.wave_h))) for sc in spec.sources]
+    lists += [(np.concatenate([np.asarray(t.e_corr_ijk).reshape(-1, 3), np.asarray(t.h_corr_ijk).reshape(-1, 3)]), len(t.wave)) for t in spec.tfsf]
+    for ijk, n_wave in lists:
+        if len(ijk) <= 256:
+            continue
+        span = ijk.max(axis=0) - ijk.min(axis=0)
+        flat = [a for a in range(3) if span[a] <= 1]
+        if len(flat) != 1:
+            continue                      # (a box of corrections — a TFSF volume — has no single plane)
+        # (a run with a shutoff level seldom uses its whole run time: BASELINE config 3 stops after 1.41 x its source's length)
+        n_run = min(spec.n_steps, int(1.5 * n_wave)) if spec.shutoff > 0 else spec.n_steps
+        frac = min(1.0, n_wave / float(max(n_run, 1)))
+        if best is None or frac > best[1]:
+            best = (flat[0], frac)
+    return best
+
+
+def best_axis_shift(shape, pml_layers=None, sheet=None) -> int:
     """Cyclic axis shift s (new axis a holds old axis (a + s) % 3) with the lowest ``sweep_cost``; 0 unless that buys
     more than 5 % on a grid of at least 2^18 cells (below that a run is bound by launches, not lanes).
-    ``pml_layers`` = ((minus, plus), ...) CPML layer counts per axis."""
+    ``pml_layers`` = ((minus, plus), ...) CPML layer counts per axis.  ``sheet`` = ``source_sheet(spec)``: a layout that does
+    not put the sheet's normal along the device's z pays single steps (1.3 x the cost of step pairs, profiles/r5) for that
+    fraction of the run — BASELINE config 3 (mode plane alive for 71 % of its steps): x = 224 99.8 Gcells/s over the run with
+    29 % of its steps in pairs, x = 424 (the plane normal to z) 106.1 with all of them (profiles/r5/r5zc_c3_full_layouts.jsonl)."""
     if int(np.prod([int(n) for n in shape])) < (1 << 18):
         return 0
     lay = pml_layers if pml_layers is not None else ((0, 0),) * 3
     cost = [sweep_cost([shape[(a + s) % 3] for a in range(3)], [lay[(a + s) % 3] for a in range(3)]) for s in range(3)]
+    if sheet is not None:
+        p, frac = sheet
+        cost = [c * (1.0 if (2 + s) % 3 == p else 1.0 + 0.3 * frac) for s, c in enumerate(cost)]
     s = int(np.argmin(cost))
     return s if cost[s] < 0.95 * cost[0] else 0
 
@@ -256,7 +288,7 @@ class HipEngine:
             axis_shift = 0                  # (the coupling lists are laid out for the user's axes)
         if _bloch_twin is None and n_ranks == 1 and slab is None and not force_comm and axis_shift != 0:
             layers = tuple((int(f0.num_layers), int(f1.num_layers)) for f0, f1 in spec.pml)
-            self.axis_shift = best_axis_shift(spec.shape, layers) if axis_shift is None else int(axis_shift) % 3
+            self.axis_shift = best_axis_shift(spec.shape, layers, source_sheet(spec)) if axis_shift is None else int(axis_shift) % 3
             spec = permute_spec(spec, self.axis_shift)
             self.spec = spec
         self.ghost = (0, 0, 0)            # ghost cells per axis in front of the real cells (Bloch device layout)
