@@ -29,7 +29,7 @@ def main():
         sim, world, twostep, steps = cases.random_slab_pml_box(seed, q)
         out = os.path.join(tempfile.mkdtemp(prefix="fuzz_slab_"), "dist.npz")
         port = 29850 + q % 100
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TWOSTEP=str(twostep))
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TWOSTEP=str(twostep), PML_FUSED="7")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), f"slabfuzz:{seed}:{q}", str(steps), out]
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)

@@ -171,7 +171,7 @@ def test_random_cpml_boxes_in_step_pairs_on_two_to_four_ranks(seed, index, emu_l
     import cases
     sim, world, twostep, steps = cases.random_slab_pml_box(seed, index)
     out = str(tmp_path / "dist.npz")
-    _launch(world, f"slabfuzz:{seed}:{index}", steps, out, 29761 + index, twostep=twostep)
+    _launch(world, f"slabfuzz:{seed}:{index}", steps, out, 29761 + index, twostep=twostep, pml_fused=7)
     got = np.load(out)
     assert got["pairs"].max() >= 6, got["pairs"]
     disc = discretize(sim, n_steps=steps)
@@ -192,6 +192,11 @@ def test_in_sweep_cpml_is_asked_for_only_where_the_whole_problem_allows_pairs():
     from tidy3d_amd.dist import cpml_pairs_possible
     yes = discretize(cases.slab_pairs_pml_box(), n_steps=4).spec
     assert cpml_pairs_possible(yes)
+    # ... and only where every rank's slab can take them (2^20 cells, a bulk of eight planes): else the slab kernels stay
+    assert not cpml_pairs_possible(yes, [(0, 25), (25, 50)])
+    import dataclasses
+    big = dataclasses.replace(yes, shape=(512, 512, 128))
+    assert cpml_pairs_possible(big, [(0, 64), (64, 128)]) and not cpml_pairs_possible(big, [(0, 12), (12, 128)])
     for name in ("slab_pairs_box", "media_mix", "au_array", "drude_in_pml", "absorber_mix"):
         sim = CASES[name]() if name in CASES else getattr(cases, name)()
         assert not cpml_pairs_possible(discretize(sim, n_steps=4).spec), name

@@ -42,7 +42,7 @@ def best_slab_shift(shape, world: int) -> int:
     return best
 
 
-def cpml_pairs_possible(spec: SolverSpec) -> bool:
+def cpml_pairs_possible(spec: SolverSpec, slabs=None) -> bool:
     """May the z-slab ranks of this (already renamed) problem advance in step pairs although they carry CPML?  What the library's
     shell2 pairs need of the WHOLE problem: CPML on some face, nothing else in the shell (no periodic x / y face, no absorber layers,
     no dispersive or fully anisotropic media, no Bloch phases, no PMC-plus wall).  Every rank derives the same answer."""
@@ -53,7 +53,18 @@ def cpml_pairs_possible(spec: SolverSpec) -> bool:
         return False
     if any(m.poles for m in spec.media):
         return False
-    return not any(int(b) == BC_PERIODIC for ax in spec.bc[:2] for b in ax)
+    if any(int(b) == BC_PERIODIC for ax in spec.bc[:2] for b in ax):
+        return False
+    if slabs is not None:
+        # every rank must be able to take them — else the in-sweep recursions only cost (on thin slabs the slab kernels are 4 - 16 %
+        # faster in single steps, profiles/r04p): 2^20 cells (the library's threshold for step pairs) and room for a bulk of eight
+        # planes between the cuts' holes and the z layers
+        lz = [int(f.num_layers) for f in spec.pml[2]]
+        for q, (z0, z1) in enumerate(slabs):
+            room = (z1 - z0) - (2 if q > 0 else lz[0] + 2) - (2 if q < len(slabs) - 1 else lz[1] + 1)
+            if room < 8 or spec.shape[0] * spec.shape[1] * (z1 - z0) < (1 << 20):
+                return False
+    return True
 
 
 def make_engine(spec: SolverSpec, lib=None, device: Optional[int] = None, axis_shift: Optional[int] = None,
@@ -76,7 +87,7 @@ def make_engine(spec: SolverSpec, lib=None, device: Optional[int] = None, axis_s
     eng = HipEngine(spec, lib=lib, device=device, slab=slabs[rank], rank=rank, n_ranks=world,
                     all_slabs=slabs, **kw)
     eng.slab_shift, eng.slab_user_z = shift, user_z     # gather_results renames the stitched boxes back
-    if cpml_pairs_possible(spec):
+    if cpml_pairs_possible(spec, slabs):
         # CPML recursions inside the sweeps of EVERY rank (decided from the whole problem: the ranks then post the same messages):
         # the state step pairs of CPML-carrying slab ranks start from and end in (fdtd_capi.hip, Run::slab_shell2_pair)
         from . import lib as L

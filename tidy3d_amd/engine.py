@@ -127,7 +127,8 @@ def source_sheet(spec: SolverSpec):
     takes (fdtd_fused2.hpp kMaxInj) on one grid plane (E and H nodes: two adjacent indices).  While such a list injects, its planes
     take single steps as a Z HOLE of the step pairs (fdtd_capi.hip, Run::shell2_pair) — which needs the plane normal to the
     device's z; laid out otherwise the whole grid takes single steps until the list ends.  None: no such plane."""
-    if not any(int(f.num_layers) > 0 for ax in spec.pml for f in ax) or spec.n_steps <= 0:
+    # (grids below 2^20 cells take single steps whatever their layout: fdtd_capi.hip fused2_shape)
+    if not any(int(f.num_layers) > 0 for ax in spec.pml for f in ax) or spec.n_steps <= 0 or spec.n_cells < (1 << 20):
         return None
     best = None
     lists = [(np.asarray(sc.ijk), max(len(sc.wave_e), len(sc.wave_h))) for sc in spec.sources]
