@@ -65,3 +65,34 @@ def test_set_field_round_trip(emu_lib):
             a = rng.standard_normal((nz, ny, nx)).astype(np.float32)
             e.set_field(c, a)
             assert np.array_equal(e.get_field(c), a)
+
+
+def test_long_lived_source_planes_are_found_for_the_layout_choice():
+    """engine.source_sheet: the plane of a mode source / a plane wave (more nodes than the two-step sweep's table takes, one grid
+    plane) with the fraction of the run it injects for — what lets best_axis_shift put the plane's normal along the device's z, where
+    it can be a z hole of the step pairs (BASELINE config 3: 99.8 -> 106.1 Gcells/s, profiles/r5/r5zc_c3_full_layouts.jsonl).  A
+    dipole, a grid below the pairs' threshold or a run without CPML give None."""
+    import tidy3d_amd.schema as td
+    from tidy3d_amd.constants import C_0
+    from tidy3d_amd.discretize import discretize
+    from tidy3d_amd.engine import source_sheet
+    f0 = C_0 / 1.55
+    pulse = td.GaussianPulse(freq0=f0, fwidth=f0 / 10)
+
+    def sim(source, size=(1.6, 0.8, 1.2), pml=True):
+        return td.Simulation(size=size, grid_spec=td.GridSpec.uniform(dl=0.01), run_time=4e-13, medium=td.Medium(permittivity=2.0),
+                             structures=[td.Structure(geometry=td.Box(center=(0, 0, 0), size=(td.inf, 0.22, 0.4)), medium=td.Medium(permittivity=12.0))],
+                             sources=[source], monitors=[],
+                             boundary_spec=td.BoundarySpec.all_sides(td.PML(num_layers=8) if pml else td.PECBoundary()), shutoff=1e-5)
+    mode = td.ModeSource(center=(-0.5, 0, 0), size=(0, td.inf, td.inf), source_time=pulse, direction="+", mode_spec=td.ModeSpec(num_modes=1))
+    spec = discretize(sim(mode)).spec
+    assert spec.n_cells >= 1 << 20
+    axis, frac = source_sheet(spec)
+    assert axis == 0 and 0.3 < frac <= 1.0
+    wave = td.PlaneWave(center=(0, 0, 0.4), size=(td.inf, td.inf, 0), source_time=pulse, direction="-")
+    sheet = source_sheet(discretize(sim(wave)).spec)
+    assert sheet is not None and sheet[0] == 2
+    dip = td.PointDipole(center=(0, 0, 0), source_time=pulse, polarization="Ey")
+    assert source_sheet(discretize(sim(dip)).spec) is None
+    assert source_sheet(discretize(sim(mode, pml=False)).spec) is None
+    assert source_sheet(discretize(sim(mode, size=(0.8, 0.4, 0.6))).spec) is None       # below 2^20 cells: single steps anyway
