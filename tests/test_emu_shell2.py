@@ -38,6 +38,7 @@ SHAPES = {
     "two_x_tiles": (300, 20, 19),
     "seam_at_bulk_edge": (256, 18, 18),
     "three_x_tiles": (536, 18, 17),
+    "one_tile_100": (100, 23, 19),      # (a periodic x needs rows of a multiple of four cells to stay on the fused sweep)
 }
 
 MEDIA = [td.Structure(geometry=td.Box(center=(0, 0, 0), size=(td.inf, 0.3, 0.25)), medium=td.Medium(permittivity=3.0, conductivity=0.02)),
@@ -243,6 +244,72 @@ def test_shell2_pairs_with_z_holes_for_injecting_source_planes(kind, emu_lib):
     got_f, got_r, p1, s1, q1, why = _run(spec, emu_lib, 8 + 64 * 6, 1, runs=(n1, spec.n_steps - n1), fields=False)
     assert p0 == 0 and q0 == 0
     assert q1 == p1 and p1 >= spec.n_steps // 2 - 2, (p1, s1, q1, spec.n_steps, why)
+    assert max(float(np.abs(f).max()) for f in ref_f) > 0
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), (c, float(np.abs(got_f[c] - ref_f[c]).max()))
+    for k in ref_r:
+        assert np.abs(np.asarray(ref_r[k])).max() > 0 and np.array_equal(np.asarray(got_r[k]), np.asarray(ref_r[k])), k
+
+
+# ---- periodic x / y faces and dispersive cells in shell2 pairs (round 5, last part) ---------------------------------------------------
+PER = td.Boundary.periodic()
+B_PXY_Z = td.BoundarySpec(x=PER, y=PER, z=td.Boundary.pml(num_layers=3))                                    # a metasurface cell: BASELINE config 5's walls
+B_PX_YZ = td.BoundarySpec(x=PER, y=td.Boundary(minus=pml(2), plus=pml(4)), z=td.Boundary.pml(num_layers=3))     # a grating: periodic x, layers on y and z
+B_PY_XZ = td.BoundarySpec(x=td.Boundary(minus=pml(5), plus=pml(3)), y=PER, z=td.Boundary(minus=td.PECBoundary(), plus=pml(3)))
+PER_CASES = [("one_tile", B_PXY_Z, 5, 3, shape_word()), ("one_tile", B_PXY_Z, 8, 4, shape_word(qw=9, ww=3, zcw=2)),
+             ("two_x_tiles", B_PXY_Z, 6, 4, shape_word(qw=62, ww=5)), ("three_x_tiles", B_PXY_Z, 6, 32, shape_word(qw=33, ww=4)),
+             ("one_tile_100", B_PX_YZ, 6, 3, shape_word(qw=13, ww=4)), ("two_x_tiles", B_PX_YZ, 5, 5, shape_word()),
+             ("one_tile", B_PY_XZ, 5, 3, shape_word()), ("two_x_tiles", B_PY_XZ, 7, 4, shape_word(qw=20, ww=6, ws=2, zcs=4))]
+
+
+@pytest.mark.parametrize("name,bspec,w,zc,shape", PER_CASES)
+def test_shell2_pairs_with_periodic_faces(name, bspec, w, zc, shape, emu_lib):
+    """A periodic x wraps through the halo lanes of the boxes (and as one more seam of the bulk sweep); a periodic y keeps boxes and
+    bulk two rows clear of the wrap — those rows take two single steps through the third set beside them, psi routed through the
+    temporary sets like a z hole.  Materials through the wrap, dipoles deep inside, random fields: the same bits as single steps."""
+    N = SHAPES[name]
+    disc = discretize(_sim(N, bspec, structures=MEDIA), n_steps=26)
+    disc.spec.decay_every = 0
+    ref_f, _, p0, s0, q0, why0 = _run(disc.spec, emu_lib, 0, 0)
+    got_f, _, p1, s1, q1, why1 = _run(disc.spec, emu_lib, w + 64 * zc, 1, shape)
+    assert p0 == 0 and q0 == 0
+    assert p1 == 5 + 7 and q1 == p1 and why1 == 0, (p1, s1, q1, why1)
+    assert max(float(np.abs(f).max()) for f in ref_f) > 0
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), (c, float(np.abs(got_f[c] - ref_f[c]).max()), np.argwhere(got_f[c] != ref_f[c])[:5])
+
+
+@pytest.mark.parametrize("walls", ["periodic_xy", "periodic_x", "pml"])
+def test_shell2_pairs_with_dispersive_planes_and_a_plane_wave(walls, emu_lib):
+    """BASELINE config 5 in small: a unit cell periodic in x and y with layers on z, a dispersive disc (Drude: its planes are a z hole
+    of the bulk — the ADE state advances every step — with the memory term applied in the middle step), a lossy substrate, a plane
+    wave (its injection plane: one more hole while it injects) and flux planes that span the wrap (their record steps take single
+    steps; between them: pairs).  Also with layers on y, and on every face.  Same bits as single steps: fields and records."""
+    N = (40, 24, 64)
+    size = tuple((n - 1e-6) * DL for n in N)
+    pulse = td.GaussianPulse(freq0=3e14, fwidth=2.4e14)
+    glass = td.Structure(geometry=td.Box(center=(0, 0, -1.0), size=(td.inf, td.inf, 0.8)), medium=td.Medium(permittivity=2.1, conductivity=0.01))
+    disc_m = td.Structure(geometry=td.Cylinder(center=(0.1, 0.05, -0.3), radius=0.3, length=0.2, axis=2), medium=td.Drude(eps_inf=2.0, coeffs=[(1.2e15, 9e13)]))
+    srcs = [td.PlaneWave(center=(0, 0, 0.8), size=(td.inf, td.inf, 0), source_time=pulse, direction="-")]
+    bspec = {"periodic_xy": td.BoundarySpec(x=PER, y=PER, z=td.Boundary.pml(num_layers=4)),
+             "periodic_x": td.BoundarySpec(x=PER, y=td.Boundary.pml(num_layers=3), z=td.Boundary.pml(num_layers=4)),
+             "pml": B_ALL}[walls]
+    if walls != "periodic_xy":      # (a plane wave needs periodic or far walls on its transverse axes: a finite sheet instead)
+        srcs = [td.UniformCurrentSource(center=(0, 0, 0.8), size=(td.inf, td.inf, 0), source_time=pulse, polarization="Ex")]
+    mons = [td.FieldTimeMonitor(center=(0.1, 0.05, 0.3), size=(0, 0, 0), name="probe", interval=3, colocate=False),
+            td.FluxMonitor(center=(0, 0, 0.5), size=(td.inf, td.inf, 0), freqs=[2.5e14, 3e14], name="R"),
+            td.FluxMonitor(center=(0, 0, -1.2), size=(td.inf, td.inf, 0), freqs=[3e14], name="T")]
+    sim = td.Simulation(size=size, grid_spec=td.GridSpec.uniform(dl=DL), run_time=1.3e-14, structures=[glass, disc_m], sources=srcs,
+                        monitors=mons, boundary_spec=bspec, shutoff=0)
+    disc = discretize(sim)
+    disc.spec.decay_every = 0
+    spec = disc.spec
+    n1 = 37
+    assert spec.n_steps > n1 + 40
+    ref_f, ref_r, p0, _, q0, _ = _run(spec, emu_lib, 0, 0, runs=(n1, spec.n_steps - n1), fields=False)
+    got_f, got_r, p1, s1, q1, why = _run(spec, emu_lib, 8 + 64 * 6, 1, runs=(n1, spec.n_steps - n1), fields=False)
+    assert p0 == 0 and q0 == 0
+    assert q1 >= spec.n_steps // 4, (p1, s1, q1, spec.n_steps, why)
     assert max(float(np.abs(f).max()) for f in ref_f) > 0
     for c in range(6):
         assert np.array_equal(got_f[c], ref_f[c]), (c, float(np.abs(got_f[c] - ref_f[c]).max()))

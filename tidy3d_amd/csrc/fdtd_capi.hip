@@ -1424,12 +1424,16 @@ int shell2_boxes(const FdtdSolver* h, const ShellGeom& G, Shell2Box out[kShell2M
     const int nx = h->g.nx, ny = h->g.ny, nz = h->g.nz;
     int n = 0;
     (void)nz;
-    if (G.o0[0] > 0) out[n++] = {0, G.o0[0], 0, ny, z_lo, z_hi, true, 7};
-    if (G.o1[0] < nx) out[n++] = {G.o1[0], nx, 0, ny, z_lo, z_hi, true, 7};
-    if (G.o0[2] > z_lo) out[n++] = {G.o0[0], G.o1[0], 0, ny, z_lo, G.o0[2], false, 7};
-    if (G.o1[2] < z_hi) out[n++] = {G.o0[0], G.o1[0], 0, ny, G.o1[2], z_hi, false, 7};
-    if (G.o0[1] > 0) out[n++] = {G.o0[0], G.o1[0], 0, G.o0[1], G.o0[2], G.o1[2], false, 7};
-    if (G.o1[1] < ny) out[n++] = {G.o0[0], G.o1[0], G.o1[1], ny, G.o0[2], G.o1[2], false, 7};
+    // (a periodic y: the two rows next to the wrap on either side belong to nobody here — they take single steps beside the
+    //  boxes, Run::shell2_pair — so the x strips and z slabs end there and there are no y slabs)
+    const bool per_y = h->cfg.bc[2] == FDTD_BC_PERIODIC;
+    const int r0 = per_y ? G.o0[1] : 0, r1 = per_y ? G.o1[1] : ny;
+    if (G.o0[0] > 0) out[n++] = {0, G.o0[0], r0, r1, z_lo, z_hi, true, 7};
+    if (G.o1[0] < nx) out[n++] = {G.o1[0], nx, r0, r1, z_lo, z_hi, true, 7};
+    if (G.o0[2] > z_lo) out[n++] = {G.o0[0], G.o1[0], r0, r1, z_lo, G.o0[2], false, 7};
+    if (G.o1[2] < z_hi) out[n++] = {G.o0[0], G.o1[0], r0, r1, G.o1[2], z_hi, false, 7};
+    if (!per_y && G.o0[1] > 0) out[n++] = {G.o0[0], G.o1[0], 0, G.o0[1], G.o0[2], G.o1[2], false, 7};
+    if (!per_y && G.o1[1] < ny) out[n++] = {G.o0[0], G.o1[0], G.o1[1], ny, G.o0[2], G.o1[2], false, 7};
     return n;
   }
   if (z_lo != 0 || z_hi != h->g.nz) { Shell2Box tmp[kShell2MaxBoxes]; (void)tmp; }
@@ -1469,7 +1473,8 @@ int shell2_boxes_by_axes(const FdtdSolver* h, const ShellGeom& G, Shell2Box out[
 // the last tile row and the three halo slots, halo lanes and the last x tile's idle lanes, the two extra iterations per chunk)
 void shell2_shape(const FdtdSolver* h, const Shell2Box& bx, int W, int zc_cap, Shell2P* out) {
   const GridP& g = h->g;
-  const int halo_l = bx.i0 > 0 ? 1 : 0, halo_r = bx.i1 < g.nx ? 1 : 0;
+  const bool per_x = h->cfg.bc[0] == FDTD_BC_PERIODIC;          // (the row wraps: a halo lane on both sides, holding the wrapped columns)
+  const int halo_l = (bx.i0 > 0 || per_x) ? 1 : 0, halo_r = (bx.i1 < g.nx || per_x) ? 1 : 0;
   const int lanes_w = (bx.i1 - bx.i0) / 4;
   const int L = lanes_w + halo_l + halo_r;                   // lanes a row needs: the written ones and a halo lane on every side that is no wall
   const int rows = bx.j1 - bx.j0, nzb = bx.k1 - bx.k0;
@@ -1571,8 +1576,12 @@ int shell2_why_not(const FdtdSolver* h, ShellGeom* G) {
   const int why = fused2_why_not(h, false, true);
   if (why) return why;
   if (!any_pml(h) || h->shell2_on == 0 || h->shell_on == 0) return FDTD_F2_OFF_PML;
-  if (any_periodic(h)) return FDTD_F2_OFF_BOUNDARY;
-  if (!h->ade.empty()) return FDTD_F2_OFF_ADE;
+  // periodic x (wraps through halo lanes) and y (its rows next to the wrap take single steps beside the boxes) — one launch only;
+  // a periodic z would put holes on the grid's ends: the round-4 form
+  if (h->cfg.bc[4] == FDTD_BC_PERIODIC) return FDTD_F2_OFF_BOUNDARY;
+  if (any_periodic(h) && (h->shell2_on == 2 || h->shell2_on == 3)) return FDTD_F2_OFF_BOUNDARY;
+  // (dispersive cells: their planes are z holes of the bulk, as in the round-4 form — Run::setup_pairs checks that they lie inside it)
+  if (!h->ade.empty() && (h->shell2_on == 2 || h->shell2_on == 3)) return FDTD_F2_OFF_ADE;
   if (h->has_damp) return FDTD_F2_OFF_PML;
   if ((long long)h->g.sxy * 4 >= (1LL << 32)) return FDTD_F2_OFF_PML;           // (32-bit lane offsets inside a plane)
   if (!shell_geometry(h, G)) return FDTD_F2_OFF_PML;
@@ -3337,10 +3346,15 @@ struct Run {
       ShellGeom g2{};
       const int why2 = shell2_why_not(h, &g2);
       if (why2 == 0) {
+        const int why_r4 = h->f2_off_reason;
         s2_ok = true; sg = g2;                               // (the same geometry shell_why_not finds)
         s2_deep = shell2_sources_deep(h, sg);
         h->f2_off_reason = 0;
-        zp_s2 = ZPlan{}; zp_s2.n = 1; zp_s2.a[0] = sg.o0[2]; zp_s2.b[0] = sg.o1[2]; zp_s2.ok = true;
+        // the bulk's planes: one interval, or — dispersive cells — the intervals between their planes (z holes, inside the bulk's range)
+        zp_s2 = ZPlan{};
+        if (h->ade.empty()) { zp_s2.n = 1; zp_s2.a[0] = sg.o0[2]; zp_s2.b[0] = sg.o1[2]; zp_s2.ok = true; }
+        else if (zplan_build(h, sg, false, &zp_s2) && zp_s2.a[0] == sg.o0[2] && zp_s2.b[zp_s2.n - 1] == sg.o1[2]) zp_s2.ok = true;
+        if (!zp_s2.ok) { s2_ok = false; h->f2_off_reason = why_r4; }       // (the round-4 form may still take the run)
         // lists that inject and that the sweeps cannot apply: their planes as z holes — usable when every hole lies inside the bulk's plane
         // range (one-launch form only: FDTD_OPT_SHELL2 = 2 / 3 cut their boxes differently)
         zp_s2h = ZPlan{};
@@ -3455,8 +3469,11 @@ struct Run {
   int shell2_pair(long long n, const F2Table* tb, const ZPlan& zp) {
     hipStream_t cs = (h->shell_on == 2) ? st : h->comm_stream;       // (2: shell behind the bulk on ONE stream — a measuring aid)
     const bool holes = zp.n > 1;
+    // a periodic y: the two rows on either side of the wrap belong to no box and to no bulk launch — they take two single steps
+    // through set T beside them, over every plane outside the holes (whose steps cover all rows), with the holes' parameter blocks
+    const bool per_y = h->cfg.bc[2] == FDTD_BC_PERIODIC;
     if (ensure_second_set(h) || ensure_pml_blocks2(h)) return -1;
-    if (holes && (ensure_third_set(h) || ensure_pml_blocks_hole(h))) return -1;
+    if ((holes || per_y) && (ensure_third_set(h) || ensure_pml_blocks_hole(h))) return -1;
     if (!h->ev_shell_a) {
       HIPCHK(h, hipEventCreateWithFlags(&h->ev_shell_a, hipEventDisableTiming));
       HIPCHK(h, hipEventCreateWithFlags(&h->ev_shell_b, hipEventDisableTiming));
@@ -3481,19 +3498,38 @@ struct Run {
       for (int q = 0; q < ni && nb < kShell2MaxBoxes; ++q) boxes[nb++] = bi[q];
     }
     launch_shell2_boxes(h, boxes, nb, h->pml_blk2[hp][ep], cs, tb);
-    if (holes) {
+    if (holes || per_y) {
       const int pml_in = 7 & pml_in_sweep_mask(h);
       ShellSets s1{A, T, hp, 0, 0, h->pml_blk_hole[0][hp][ep]}, s2h{T, B, hp, 0, 0, h->pml_blk_hole[1][hp][ep]};
+      // the rows next to a periodic y wrap, grown by `grow` rows: the tile rows that hold them, the rows between left alone
+      auto wrap_rows = [&](const ShellSets& base, int grow) {
+        const int R = h->rows_f, ny = h->g.ny, nby_all = (ny + R - 1) / R;
+        const int in0 = 2 + grow, in1 = ny - 2 - grow;
+        const int ty_a = std::min(nby_all, (in0 + R - 1) / R), ty_c = std::max(ty_a, in1 / R);
+        ShellSets sh = base;
+        sh.ex_j0 = in0; sh.ex_j1 = in1;
+        for (int i = 0; i < zp.n; ++i) {
+          const int lo = i == 0 ? 0 : zp.a[i], hi = i == zp.n - 1 ? nz : zp.b[i];
+          if (launch_fused_range(h, lo, hi, cs, pml_in, 0, 0, ty_a + (nby_all - ty_c), ty_a, ty_c - ty_a, true, &sh)) return -1;
+        }
+        return 0;
+      };
       // step one over the holes grown by one plane (what step two differentiates), set A -> set T
       for (int i = 0; i + 1 < zp.n; ++i)
         if (launch_fused_range(h, zp.b[i] - 1, zp.a[i + 1] + 1, cs, pml_in, 0, 0, -1, 0, 0, true, &s1)) return -1;
-      // the middle step: E-side sources / corrections of step n, the incident grid's E; then what precedes step n + 1
-      launch_sources(h, true, n, 0, nz, cs, false, &T);
-      advance_tfsf_aux(h, true, n, cs);
-      launch_sources(h, false, n + 1, 0, nz, cs, false, &T);
-      advance_tfsf_aux(h, false, n + 1, cs);
+      if (per_y && wrap_rows(s1, 1)) return -1;
+      if (holes) {
+        // the middle step: E-side sources / corrections of step n, the dispersive cells' memory term, the incident grid's E; then
+        // what precedes step n + 1
+        launch_sources(h, true, n, 0, nz, cs, false, &T);
+        launch_ade(h, 0, nz, cs, &T);
+        advance_tfsf_aux(h, true, n, cs);
+        launch_sources(h, false, n + 1, 0, nz, cs, false, &T);
+        advance_tfsf_aux(h, false, n + 1, cs);
+      }
       for (int i = 0; i + 1 < zp.n; ++i)
         if (launch_fused_range(h, zp.b[i], zp.a[i + 1], cs, pml_in, 0, 0, -1, 0, 0, true, &s2h)) return -1;
+      if (per_y && wrap_rows(s2h, 0)) return -1;
     }
     HIPCHK(h, hipEventRecord(h->ev_shell_b, cs));
     HIPCHK(h, hipStreamWaitEvent(st, h->ev_shell_b, 0));
@@ -3507,6 +3543,7 @@ struct Run {
       advance_tfsf_aux(h, false, n + 1, st);
     }
     launch_sources(h, true, n + 1, 0, nz, st);
+    launch_ade(h, 0, nz, st);
     advance_tfsf_aux(h, true, n + 1, st);
     fill_ghost_fused(h, st);
     return 0;
@@ -3523,6 +3560,12 @@ struct Run {
     };
     for (int q : pl.mons) if (!inside(h->mons[(size_t)q], false)) return false;
     for (int q : pl.dfts) if (!inside(h->mons[(size_t)q], true)) return false;
+    // (a periodic y: the single steps of the rows next to the wrap copy nothing out either)
+    if (h->cfg.bc[2] == FDTD_BC_PERIODIC)
+      for (int q : pl.dfts) {
+        const Monitor& m = h->mons[(size_t)q];
+        if (m.box.lo1 < 2 || m.box.lo1 + m.box.ny > h->g.ny - 2) return false;
+      }
     return true;
   }
   // every monitor of the pair's plan inside ONE interval of the bulk's planes (the sweep copies the middle step out only there)

@@ -26,8 +26,9 @@
 //   columns: x tiles OVERLAP by two lanes: lane 0 and lane Q-1 of a tile are halo lanes (what they hold after two steps is wrong
 //            two / one cells deep) unless they sit on an x wall — no seam scratch, no seam kernel, no edge-column loads.
 //   planes:  a chunk [k0, k1) runs iterations k0-1 .. k1; a prologue supplies H1_{x,y}[k0-2] from read-only psi.
-// Scope (fdtd_capi.hip checks it): one GPU, PEC walls behind the layers (PMC allowed on min faces), no periodic faces, non-
-// dispersive media (uniform or packed medium words), no sources / monitors inside the boxes while a pair is taken.
+// Scope (fdtd_capi.hip checks it): PEC walls behind the layers (PMC allowed on min faces); a periodic x wraps through halo lanes, a
+// periodic y keeps the boxes two rows clear of the wrap (those rows take single steps beside them, as z holes do); non-dispersive
+// media in the boxes (uniform or packed medium words), no sources / monitors inside the boxes while a pair is taken.
 #pragma once
 #include "fdtd_kernels2.hpp"
 #include "fdtd_shell2_host.hpp"
@@ -74,14 +75,17 @@ __global__ __launch_bounds__(512, (AXES == 7 ? 2 : 3)) void shell2_step_kernel(G
   const bool row_ok = lane_on && jr >= 0 && jr < g.ny;
   const int j = row_ok ? jr : 0;                         // (keeps every address inside the arrays)
   const int i0r = sp.xorg + (tile_x * (Q - 2) + q) * V;
-  const bool in_x = i0r < g.nx;
-  const int i0 = in_x ? i0r : 0;
+  // periodic x (a box that spans the whole row): the row has no wall — the tiles start one lane left of column 0 and end one lane
+  // right of column nx - 1, and those two lanes are halo lanes like any other tile edge, holding the wrapped columns
+  const bool per_x = g.bcx0 == BC_PERIODIC;
+  const bool in_x = per_x ? (i0r <= g.nx) : (i0r < g.nx);
+  const int i0 = in_x ? (per_x ? (i0r < 0 ? i0r + g.nx : (i0r >= g.nx ? i0r - g.nx : i0r)) : i0r) : 0;
   const bool act = row_ok && in_x;
-  const bool last_x = in_x && (i0 + V >= g.nx);
-  const bool first_x = in_x && (i0 == 0);
+  const bool last_x = !per_x && in_x && (i0 + V >= g.nx);
+  const bool first_x = !per_x && in_x && (i0 == 0);
   const bool own_row = slot_i >= 2 && slot_i <= S - 2 && row_ok && jr < sp.j1;
   // a lane on a tile edge holds wrong values two / one cells deep after two steps (its neighbour lane belongs to the next tile) — unless it sits on a wall
-  const bool own_col = act && i0 >= sp.ci0 && i0 < sp.ci1 && (q >= 1 || first_x) && (q <= Q - 2 || last_x);
+  const bool own_col = act && i0r >= sp.ci0 && i0r < sp.ci1 && (q >= 1 || first_x) && (q <= Q - 2 || last_x);
   const bool st_lane = own_row && own_col;
   const bool take_next = (q == Q - 1) || last_x || !lane_on;      // E of column i0 + 4 is not in the next lane
   const bool take_prev = (q == 0) || first_x || !lane_on;         // H of column i0 - 1 is not in the previous lane
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(512, (AXES == 7 ? 2 : 3)) void shell2_step_kernel(G
   const long long xpl = (long long)g.ny * AX.ns, ypl = (long long)AY.ns * g.nx;   // entries per plane of them
   if (ty == 0 && tx < Q) {
     const int ic = sp.xorg + (tile_x * (Q - 2) + tx) * V;
-    const int icc = ic < g.nx ? ic : 0;
+    const int icc = per_x ? (ic < 0 ? ic + g.nx : (ic == g.nx ? 0 : (ic < g.nx ? ic : 0))) : (ic < g.nx ? ic : 0);
     const float4 z4 = {0.f, 0.f, 0.f, 0.f};
     const bool mem = pml_si(AX, icc) >= 0;
     xco[0 * kShell2MaxQ + tx] = mem ? *reinterpret_cast<const float4*>(AX.kv_h + icc) : z4;
