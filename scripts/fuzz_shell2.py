@@ -5,7 +5,8 @@ PMC on min faces), dielectric / lossy / PEC bodies through the layers, random in
 step), dipoles of both kinds deep inside the bulk (applied by the bulk sweep) or none, probes / time monitors / DFT planes inside
 the bulk, runs cut in two, the form of the launches (one launch, one per instantiation, one per box) and the tile shapes of the
 boxes (lanes per row, waves per workgroup, planes per chunk).
-  python scripts/fuzz_shell2.py [cases] [seed]      (tests/test_emu_shell2.py runs a dozen on the emulator, the GPU suite 40)"""
+  python scripts/fuzz_shell2.py [cases] [seed] [periodic]     (tests/test_emu_shell2.py runs a dozen on the emulator, the GPU suite 40;
+  `periodic`: x and / or y periodic — the boxes wrap x through halo lanes, the rows next to a y wrap take single steps)"""
 import os
 import sys
 
@@ -21,7 +22,7 @@ DL = 0.05
 PULSE = td.GaussianPulse(freq0=3e14, fwidth=1.5e14)
 
 
-def case(rng, small=False):
+def case(rng, small=False, periodic=False):
     nx = int(rng.choice([int(rng.integers(40, 120)), int(rng.integers(250, 330)), int(rng.integers(500, 560))] if not small else [int(rng.integers(40, 90)), int(rng.integers(250, 280))]))
     ny, nz = int(rng.integers(18, 40 if small else 56)), int(rng.integers(18, 36 if small else 60))
     N = (nx, ny, nz)
@@ -38,8 +39,17 @@ def case(rng, small=False):
     faces = [[face(True), face(False)] for _ in range(3)]
     if not any(isinstance(f, (td.PML, td.StablePML)) for pair in faces for f in pair):
         faces[int(rng.integers(0, 3))][1] = td.PML(num_layers=4)
-    bspec = td.BoundarySpec(x=td.Boundary(minus=faces[0][0], plus=faces[0][1]), y=td.Boundary(minus=faces[1][0], plus=faces[1][1]),
-                            z=td.Boundary(minus=faces[2][0], plus=faces[2][1]))
+    bounds = [td.Boundary(minus=faces[a][0], plus=faces[a][1]) for a in range(3)]
+    if periodic:            # (round 5, last part) x and / or y periodic — a metasurface / grating cell; z then carries layers
+        which = int(rng.integers(0, 3))
+        if which in (0, 2):
+            bounds[0] = td.Boundary.periodic()
+            N = (max(40, N[0] // 4 * 4), N[1], N[2])      # (rows of a multiple of four cells: the fused sweep)
+        if which in (1, 2):
+            bounds[1] = td.Boundary.periodic()
+        if not any(isinstance(f, (td.PML, td.StablePML)) for f in faces[2]):
+            bounds[2] = td.Boundary.pml(num_layers=int(rng.integers(2, 8)))
+    bspec = td.BoundarySpec(x=bounds[0], y=bounds[1], z=bounds[2])
     size = tuple((n - 1e-6) * DL for n in N)
     h = [0.5 * v for v in size]
     structures = []
@@ -90,15 +100,17 @@ def run(disc, steps, split, lib, twostep, shell2, shape, seed):
         return [e.get_field(c) for c in range(6)], e.results(), pairs, s2, why
 
 
-def run_cases(n_cases, seed=1, lib=None, quiet=False, small=False):
+def run_cases(n_cases, seed=1, lib=None, quiet=False, small=False, periodic=False):
     """-> (cases that differ, cases that took shell2 pairs)"""
     rng = np.random.default_rng(seed)
     bad = taken = 0
     for q in range(n_cases):
-        disc, steps = case(rng, small)
+        disc, steps = case(rng, small, periodic)
         split = int(rng.integers(0, steps))
         w, zc = int(rng.integers(4, 17)), int(rng.integers(2, 40))
         shell2 = int(rng.integers(1, 4))
+        if periodic:
+            shell2 = 1          # (periodic faces: the one-launch form only)
         qw = int(rng.choice([0, 0, int(rng.integers(3, 65))]))
         shape = qw + 128 * int(rng.integers(1, 8)) + 1024 * int(rng.choice([0, int(rng.integers(1, 40))])) + (int(rng.integers(1, 9)) << 17) + (int(rng.choice([0, int(rng.integers(1, 40))])) << 21)
         ref_f, ref_m, p0, _, _ = run(disc, steps, split, lib, 0, 0, 0, q)
@@ -114,7 +126,7 @@ def run_cases(n_cases, seed=1, lib=None, quiet=False, small=False):
 
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-    bad, taken = run_cases(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    bad, taken = run_cases(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 1, periodic=len(sys.argv) > 3 and sys.argv[3] == "periodic")
     print("fuzz:", n_cases - bad, "of", n_cases, "cases bit-identical;", taken, "took shell2 pairs")
     sys.exit(1 if bad else 0)
 
