@@ -291,8 +291,10 @@ enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_R
                                      single steps), and on z-slab ranks: -1 = default (on), 0 = off, 2 = shell behind the bulk on ONE stream
                                      (a measuring aid) */
        FDTD_OPT_STRIP = 18, /* x strips of a shell step: planes per workgroup (1 ... 63) + 64 * workgroups per CU their registers are cut for (3 or 4) */
-       FDTD_OPT_SHELL2 = 19, /* the shell of a CPML-walled grid (no periodic faces, no dispersive cells, no absorber layers; sources that inject
-                                three or more cells inside the bulk) by shell2_step_kernel — two steps per sweep with psi carried, both
+       FDTD_OPT_SHELL2 = 19, /* the shell of a CPML-walled grid (no periodic z, no absorber layers; a periodic x wraps through the boxes' halo
+                                lanes, the rows next to a periodic y wrap and the planes of dispersive cells take single steps beside the
+                                boxes; sources that inject three or more cells inside the bulk, or on planes that become z holes; z-slab ranks
+                                that carry CPML inside their sweeps too) by shell2_step_kernel — two steps per sweep with psi carried, both
                                 psi sides ping-ponged, no third field set; bit-identical to single steps: -1 = default (where the cost
                                 model likes it), 0 = off (two single steps beside the bulk, FDTD_OPT_SHELL_PAIRS), 1 = wherever possible, 2 / 3 = wherever possible with
                                 one launch per instantiation (x / y / z only, all axes) / per box (measuring aids) */
