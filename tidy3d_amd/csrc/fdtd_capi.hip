@@ -1408,8 +1408,11 @@ int shell_why_not(const FdtdSolver* h, ShellGeom* G, ZPlan* base, ZPlan* with_sr
 //   x strips   the columns outside O_x, ALL rows and planes (the corners with the y / z slabs included: all-axes recursions)
 //   z slabs    the columns of O_x, all rows, the planes outside O_z
 //   y slabs    the columns of O_x, the rows outside O_y, the planes of O_z
-// Taken when nothing but CPML makes the shell (no periodic face, no dispersive cells, no absorber layers) and, while source lists
-// inject, when every source node lies three or more cells inside O (the boxes apply no sources; the bulk sweep applies its own).
+// Taken when CPML makes the shell (no absorber layers, no periodic z) and, while source lists inject, when every source node lies
+// three or more cells inside O (the boxes apply no sources; the bulk sweep applies its own) — or on planes that become z holes.
+// What the boxes cannot advance takes two single steps through set T beside them, psi routed through temporary sets
+// (Run::shell2_pair): z holes (the planes of dispersive cells and of big source planes), the two rows on either side of a periodic
+// y wrap.  A periodic x needs neither: the boxes' halo lanes hold the wrapped columns (fdtd_shell2.hpp) and there are no x strips.
 struct Shell2Box { int i0, i1, j0, j1, k0, k1; bool strip; int axes; };
 constexpr int kShell2MaxBoxes = 24;
 // Every box is cut so that most of its cells meet the recursions of ONE axis (the middle of an x strip: x; a y slab: y; the
