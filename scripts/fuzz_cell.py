@@ -62,16 +62,10 @@ def run(spec, lib, twostep, split):
         return [e.get_field(c) for c in range(6)], e.results(), pairs, s2
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    lib = None
-    if len(sys.argv) > 3 and sys.argv[3] == "emu":
-        sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
-        import build_emu
-        from tidy3d_amd.lib import load_library
-        lib = load_library(build_emu.build())
-    bad = 0
+def run_cases(n_cases, seed=1, lib=None, quiet=False):
+    """-> (cases that differ, cases that took shell2 pairs)"""
+    rng = np.random.default_rng(seed)
+    bad = taken = 0
     for q in range(n_cases):
         spec, desc = case(rng)
         split = int(rng.integers(5, 60))
@@ -79,9 +73,23 @@ def main():
         ref_f, ref_m, p0, _ = run(spec, lib, 0, split)
         got_f, got_m, p1, s2 = run(spec, lib, twostep, split)
         ok = p0 == 0 and all(np.array_equal(a, b) for a, b in zip(ref_f, got_f)) and all(np.array_equal(np.asarray(ref_m[k]), np.asarray(got_m[k])) for k in ref_m)
-        print(f"case {q}: N={spec.shape} steps={spec.n_steps} {desc} twostep={twostep & 63}x{twostep >> 6} pairs={p1} shell2={s2} -> {'ok' if ok else 'MISMATCH'}", flush=True)
+        if not quiet or not ok:
+            print(f"case {q}: N={spec.shape} steps={spec.n_steps} {desc} twostep={twostep & 63}x{twostep >> 6} pairs={p1} shell2={s2} -> {'ok' if ok else 'MISMATCH'}", flush=True)
         bad += not ok
-    print("fuzz_cell:", n_cases - bad, "of", n_cases, "cases bit-identical")
+        taken += s2 > 0
+    return bad, taken
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    lib = None
+    if len(sys.argv) > 3 and sys.argv[3] == "emu":
+        sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+        import build_emu
+        from tidy3d_amd.lib import load_library
+        lib = load_library(build_emu.build())
+    bad, taken = run_cases(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 1, lib)
+    print("fuzz_cell:", n_cases - bad, "of", n_cases, "cases bit-identical;", taken, "took shell2 pairs")
     sys.exit(1 if bad else 0)
 
 

@@ -581,3 +581,18 @@ def test_randomised_variant_cross_check_on_the_device(hip_lib):
     spec.loader.exec_module(fz)
     bad, far, worst = fz.run_cases(40, seed=7, lib=hip_lib, quiet=True, big=True)
     assert bad == 0 and far == 0, (bad, far, worst)
+
+
+@pytest.mark.gpu
+def test_randomised_metasurface_cells_in_shell2_pairs_on_the_device(hip_lib):
+    """scripts/fuzz_cell.py on the device (its unattended runs: 480 of 480, profiles/r5/r5zj): BASELINE config 5's kind of problem in
+    small — periodic x and / or y (the boxes wrap x through halo lanes, the rows next to a y wrap take single steps), CPML on z, a
+    Drude / Lorentz body whose planes are z holes of the bulk, a plane wave or a current sheet, flux planes through the wrap — in
+    shell2 pairs against single steps of the same library: fields and records, bit for bit."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "scripts"))
+    import fuzz_cell
+    bad, taken = fuzz_cell.run_cases(24, seed=5, lib=hip_lib, quiet=True)
+    assert bad == 0, bad
+    assert taken >= 16, taken
