@@ -4,13 +4,15 @@
 // hand-written gfx950 kernels (indexing, boundary rules, halo handling, wave shuffles, LDS
 // tiles) is first validated on the CPU by compiling the UNMODIFIED kernel sources
 // (tidy3d_amd/csrc/*.hip) with a host C++ compiler against this header instead of ROCm's
-// <hip/hip_runtime.h>.  Every GPU thread of a block becomes a ucontext fiber; __syncthreads
+// <hip/hip_runtime.h>.  Every GPU thread of a block becomes a fiber (own stack, hand-written context switch); __syncthreads
 // and the wave-64 shuffles are fiber rendezvous points.  Nothing here is shipped or used by
 // the product path: tests/hipemu/build_emu.py builds `libfdtd_emu.so`, which only
 // tests/test_emu_*.py load.  The product library is built by hipcc from the same sources and
 // fails loudly when absent.
 #pragma once
+#if !defined(__x86_64__)
 #include <ucontext.h>
+#endif
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -60,8 +62,17 @@ namespace hipemu {
 constexpr int kWave = 64;
 constexpr size_t kStack = 256 * 1024;
 
+// A fiber's saved context.  x86-64: the stack pointer of a frame that holds the callee-saved registers and the FP control words —
+// switched by twenty instructions (hip_emu.cpp hipemu_switch) instead of swapcontext's two signal-mask system calls per switch,
+// which were a third of the emulator's run time.  Elsewhere: ucontext.
+#if defined(__x86_64__)
+struct Ctx { void* sp = nullptr; };
+#else
+struct Ctx { ucontext_t uc; };
+#endif
+
 struct Fiber {
-  ucontext_t ctx;
+  Ctx ctx;
   char* stack = nullptr;
   int state = 0;   // 0 not started, 1 runnable, 2 at block barrier, 3 at wave rendezvous, 4 done
   dim3 tid;
@@ -69,7 +80,7 @@ struct Fiber {
 };
 
 struct State {
-  ucontext_t sched;
+  Ctx sched;
   Fiber* cur = nullptr;
   dim3 bidx, bdim, gdim;
   std::vector<Fiber> fibers;

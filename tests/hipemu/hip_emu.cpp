@@ -9,16 +9,75 @@ State& S() {
   return s;
 }
 
+#if defined(__x86_64__)
+// save the callee-saved registers and the FP control words of the running context on its stack, store its stack pointer in
+// *save_sp, continue on the stack load_sp (a frame of the same layout: another fiber, the scheduler, or a fresh fiber's first frame)
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .globl hipemu_switch
+    .type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    subq $8, %rsp
+    stmxcsr (%rsp)
+    fnstcw 4(%rsp)
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    ldmxcsr (%rsp)
+    fldcw 4(%rsp)
+    addq $8, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hipemu_switch,.-hipemu_switch
+)");
+static inline void switch_ctx(Ctx& from, Ctx& to) { hipemu_switch(&from.sp, to.sp); }
+static void trampoline();
+// the first frame of a fresh fiber: what hipemu_switch pops before it "returns" into the trampoline
+static void init_ctx(Ctx& c, char* stack, size_t size, State&) {
+  uintptr_t top = ((uintptr_t)stack + size) & ~(uintptr_t)15;
+  uint64_t* sp = (uint64_t*)(top - 8);          // (the slot a caller's return address would take: the trampoline never returns)
+  *sp = 0;
+  *--sp = (uint64_t)(uintptr_t)&trampoline;     // ret -> trampoline, with rsp = top - 8 (the alignment of a function entry)
+  for (int q = 0; q < 6; ++q) *--sp = 0;        // rbp, rbx, r12 ... r15
+  --sp;
+  uint32_t words[2] = {0x1F80u, 0x037Fu};       // MXCSR and the x87 control word at their defaults
+  std::memcpy(sp, words, 8);
+  c.sp = sp;
+}
+#else
+static inline void switch_ctx(Ctx& from, Ctx& to) { swapcontext(&from.uc, &to.uc); }
+static void trampoline();
+static void init_ctx(Ctx& c, char* stack, size_t size, State& s) {
+  getcontext(&c.uc);
+  c.uc.uc_stack.ss_sp = stack;
+  c.uc.uc_stack.ss_size = size;
+  c.uc.uc_link = &s.sched.uc;
+  makecontext(&c.uc, (void (*)())trampoline, 0);
+}
+#endif
+
 static void trampoline() {
   State& s = S();
   s.body();
   s.cur->state = 4;
-  swapcontext(&s.cur->ctx, &s.sched);
+  switch_ctx(s.cur->ctx, s.sched);
+  std::abort();                                 // (a finished fiber is never resumed)
 }
 
 void yield_to_sched() {
   State& s = S();
-  swapcontext(&s.cur->ctx, &s.sched);
+  switch_ctx(s.cur->ctx, s.sched);
 }
 
 void block_barrier() {
@@ -72,16 +131,12 @@ void run_grid(dim3 grid, dim3 block, size_t shmem, std::function<void()> body) {
             Fiber& f = s.fibers[i];
             if (f.state == 0) {
               f.stack = get_stack(s);
-              getcontext(&f.ctx);
-              f.ctx.uc_stack.ss_sp = f.stack;
-              f.ctx.uc_stack.ss_size = kStack;
-              f.ctx.uc_link = &s.sched;
-              makecontext(&f.ctx, (void (*)())trampoline, 0);
+              init_ctx(f.ctx, f.stack, kStack, s);
               f.state = 1;
             }
             if (f.state == 1) {
               s.cur = &f;
-              swapcontext(&s.sched, &f.ctx);
+              switch_ctx(s.sched, f.ctx);
               progress = true;
               if (f.state == 4) {
                 ++done;
