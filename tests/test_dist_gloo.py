@@ -166,7 +166,7 @@ def test_step_pairs_on_slab_ranks_that_carry_cpml(world, case, twostep, emu_lib,
 
 @pytest.mark.parametrize("seed,index", [(1, 0), (1, 5), (1, 7)])
 def test_random_cpml_boxes_in_step_pairs_on_two_to_four_ranks(seed, index, emu_lib, tmp_path):
-    """cases.random_slab_pml_box (scripts/fuzz_slab_cpml.py runs it unattended: 30 of 30 clean): layers absent on an axis, PMC min
+    """cases.random_slab_pml_box (scripts/fuzz_slab_cpml.py runs it unattended: 70 of 70 clean): layers absent on an axis, PMC min
     walls, StablePML, bodies through cuts and layers, dipoles that keep single ranks in single steps, 3 - 4 ranks, four tile shapes."""
     import cases
     sim, world, twostep, steps = cases.random_slab_pml_box(seed, index)
