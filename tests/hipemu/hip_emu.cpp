@@ -51,7 +51,12 @@ static void init_ctx(Ctx& c, char* stack, size_t size, State&) {
   *--sp = (uint64_t)(uintptr_t)&trampoline;     // ret -> trampoline, with rsp = top - 8 (the alignment of a function entry)
   for (int q = 0; q < 6; ++q) *--sp = 0;        // rbp, rbx, r12 ... r15
   --sp;
-  uint32_t words[2] = {0x1F80u, 0x037Fu};       // MXCSR and the x87 control word at their defaults
+  uint32_t words[2] = {0x1F80u, 0x037Fu};       // MXCSR and the x87 control word: those of the launching thread (as getcontext took them)
+  uint16_t cw = 0x037F;
+  asm volatile("stmxcsr %0" : "=m"(words[0]));
+  asm volatile("fnstcw %0" : "=m"(cw));
+  words[0] &= ~0x3Fu;                           // (no pending exception flags)
+  words[1] = cw;
   std::memcpy(sp, words, 8);
   c.sp = sp;
 }
