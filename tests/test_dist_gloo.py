@@ -164,14 +164,14 @@ def test_step_pairs_on_slab_ranks_that_carry_cpml(world, case, twostep, emu_lib,
     assert float(got["decay"]) == pytest.approx(st.field_decay, rel=1e-6)
 
 
-@pytest.mark.parametrize("seed,index", [(1, 0), (1, 5), (1, 7)])
+@pytest.mark.parametrize("seed,index", [(1, 0), (1, 2), (1, 4), (1, 5), (1, 7), (2, 0), (2, 3)])
 def test_random_cpml_boxes_in_step_pairs_on_two_to_four_ranks(seed, index, emu_lib, tmp_path):
     """cases.random_slab_pml_box (scripts/fuzz_slab_cpml.py runs it unattended: 70 of 70 clean): layers absent on an axis, PMC min
     walls, StablePML, bodies through cuts and layers, dipoles that keep single ranks in single steps, 3 - 4 ranks, four tile shapes."""
     import cases
     sim, world, twostep, steps = cases.random_slab_pml_box(seed, index)
     out = str(tmp_path / "dist.npz")
-    _launch(world, f"slabfuzz:{seed}:{index}", steps, out, 29761 + index, twostep=twostep, pml_fused=7)
+    _launch(world, f"slabfuzz:{seed}:{index}", steps, out, 29761 + 10 * seed + index, twostep=twostep, pml_fused=7)
     got = np.load(out)
     assert got["pairs"].max() >= 6, got["pairs"]
     disc = discretize(sim, n_steps=steps)
