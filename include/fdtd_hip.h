@@ -91,6 +91,7 @@ typedef struct FdtdStats {
                                 recursions carried through both — instead of two single steps (FDTD_OPT_SHELL2) */
   int32_t fused2_off_reason; /* why the last fdtd_run took NO step pairs: FDTD_F2_OFF_* (0 = it took some, or had no chance to: < 2 steps) */
   int32_t struct_bytes;      /* sizeof(FdtdStats) of the library that filled this in (a binding checks it against its own layout) */
+  int64_t disp_pairs;        /* of fused2_pairs: pairs whose sweep advanced the dispersive (ADE) cells itself (FDTD_OPT_DISP; round 6) */
 } FdtdStats;
 
 /* FdtdStats.fused2_off_reason: what keeps a run on single steps (the first reason found) */
@@ -309,6 +310,11 @@ enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_R
        FDTD_OPT_TILE_SPLIT = 22, /* the two-step sweep of a grid with bodies: workgroups whose tile (halo rows and planes included) holds only
                                     the background medium run the plain sweep inside the materials launch; same bits: -1 = default (where at
                                     least one tile in eight is background-only), 0 = never, 1 = wherever such a tile exists */
+       FDTD_OPT_DISP = 23, /* dispersive (pole-residue ADE) cells advanced INSIDE the two-step sweeps: their pole states move into paged storage
+                              (one block per 256-cell row segment that holds a dispersive cell, two sets) before the first run that may take
+                              step pairs, and single steps update them there too.  -1 / 1 = default (on one GPU, where the packed medium words
+                              name the ADE group of every dispersive cell), 0 = off: the planes of dispersive cells are z holes of the bulk
+                              (single steps, round 5).  Set it before the first fdtd_run. */
        FDTD_OPT_LDS_PAD = 10 /* measuring aid: extra dynamic LDS per workgroup of the sweep in bytes (lowers its occupancy) */ };
 int fdtd_set_option(FdtdSolver* h, int key, int value);
 int fdtd_reset(FdtdSolver* h);      /* zero fields, auxiliaries, monitors and the step counter */

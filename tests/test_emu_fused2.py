@@ -49,10 +49,12 @@ def _sim(N, monitors=True, extra=(), structures=(), bspec=PEC):
                          structures=list(structures), monitors=mons, boundary_spec=bspec, shutoff=0)
 
 
-def _run(spec, lib, twostep, runs=(11, 15)):
+def _run(spec, lib, twostep, runs=(11, 15), disp=-1):
     with HipEngine(spec, lib=lib, variant=L.VARIANT_FUSED, z_chunk=2) as e:
         e.set_option(L.OPT_ROWS, 3)
         e.set_option(L.OPT_TWOSTEP, twostep)
+        if disp >= 0:
+            e.set_option(L.OPT_DISP, disp)
         pairs = 0
         for r in runs:
             st = e.run(r)
@@ -312,7 +314,8 @@ def test_small_time_monitors_sample_the_middle_step(name, interval, emu_lib):
 
 
 def test_not_eligible_runs_take_single_steps(emu_lib):
-    """a dispersive medium: the option changes nothing, no pair is taken.  (A periodic x face was such a case until round 4: now the
+    """a dispersive medium with FDTD_OPT_DISP = 0 (the round-5 behaviour; by default the pairs advance dispersive cells since round 6,
+    tests/test_emu_disp.py): the option changes nothing, no pair is taken.  (A periodic x face was such a case until round 4: now the
     wrap is a seam of the clipped sweep — pairs, same bits; tests/test_emu_shell.py has the periodic cases proper.)"""
     N = (32, 10, 9)
     cases = [dict(bspec=td.BoundarySpec(x=td.Boundary.periodic(), y=td.Boundary(minus=td.PECBoundary(), plus=td.PECBoundary()),
@@ -329,8 +332,8 @@ def test_not_eligible_runs_take_single_steps(emu_lib):
                                 monitors=[], boundary_spec=PEC, structures=kw["structures"], shutoff=0)
         disc = discretize(sim, n_steps=12)
         disc.spec.decay_every = 0
-        ref_f, _, p0 = _run(disc.spec, emu_lib, 0, runs=(12,))
-        got_f, _, p1 = _run(disc.spec, emu_lib, 8 + 64 * 4, runs=(12,))
+        ref_f, _, p0 = _run(disc.spec, emu_lib, 0, runs=(12,), disp=0)
+        got_f, _, p1 = _run(disc.spec, emu_lib, 8 + 64 * 4, runs=(12,), disp=0)
         assert p0 == 0 and p1 == (6 if "bspec" in kw else 0), p1
         for c in range(6):
             assert np.array_equal(got_f[c], ref_f[c]), c

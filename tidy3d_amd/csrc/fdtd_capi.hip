@@ -56,11 +56,28 @@ struct AdeGroup {
   int comp;
   int k0 = 0, k1 = 0;              // planes [k0, k1) that hold its cells: launches over other plane ranges are skipped
   std::vector<long long> plane_off;  // sorted lists: entries of plane k are [plane_off[k], plane_off[k + 1]); empty = unsorted
+  bool strict = false;               // sorted and no cell listed twice
   long long n;
   uint32_t* cell;
   float* e_old;
   float2* q;
   AdeP p;
+  uint32_t* qoff = nullptr;        // slot of entry t in the paged arrays (Disp)
+};
+
+// Dispersive cells in step pairs (round 6; fdtd_fused2.hpp DispP).  What a two-step sweep needs of the ADE update of its first step is
+// the memory term cc S(Q^n) at the dispersive cells — known before the sweep starts.  Once a run may take such pairs it is kept in
+// paged storage (`cs`: one block per row segment that holds a dispersive cell) by every ADE kernel of this handle; the sweep subtracts
+// it and leaves E^{n+1} in `e1`; ade2_kernel behind the sweep advances the pole states two steps.  The lists stay what they were.
+struct Disp {
+  int state = 0;                   // 0 = not tried, 1 = ready, -1 = this problem cannot
+  int n_blocks = 0;
+  int* dseg = nullptr;             // [nz][ny][nbx]
+  std::vector<int> dseg_host;
+  float* cs = nullptr;             // [n_blocks][3][256]
+  float* e1 = nullptr;
+  int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};     // bounding box of the dispersive cells [lo, hi)
+  long long pairs = 0;             // pairs of the last run whose sweep carried the ADE update of its first step
 };
 
 struct AnisoGroup {                 // fdtd_aniso.hpp: the off-diagonal coupling of E component `comp` inside fully anisotropic bodies
@@ -153,7 +170,7 @@ struct FdtdSolver {
   uint32_t* mat4b = nullptr;         // wide layout (more than 1023 media): the second word per cell; mat4 then holds E_x | E_y << 16
   uint32_t* roww = nullptr;          // row-segment words [nz][ny][ceil(nx / 256)]
   std::vector<uint32_t> roww_host;   // host copy of them: the tile classes of the two-step sweep are derived from it (tile_classes)
-  struct TileClasses { int W, zc; ClipP box; int nbx, nby, nbz; unsigned char* dev; long long n_bg, n_all; };
+  struct TileClasses { int W, zc; ClipP box; int nbx, nby, nbz; unsigned char* dev; long long n_bg, n_all; bool disp; };
   std::vector<TileClasses> tile_cls; // one entry per launch shape met so far
   int tile_split = -1;               // FDTD_OPT_TILE_SPLIT: background-only tiles on the plain instantiation: -1 = default (where >= 25 % of the tiles are), 0 = never, 1 = always
   float2* lut = nullptr;
@@ -166,6 +183,8 @@ struct FdtdSolver {
   int damp_lo[3] = {0, 0, 0}, damp_hi[3] = {0, 0, 0};   // layers: index < lo or index >= hi
   bool has_damp = false;
   std::vector<AdeGroup> ade;
+  Disp disp;
+  int disp_on = -1;                  // FDTD_OPT_DISP: dispersive cells inside the two-step sweeps: -1 = default (on), 0 = off (their planes as z holes, round 5)
   std::vector<AnisoGroup> aniso;
   std::vector<PointSrc> psrc;
   std::vector<Tfsf> tfsf;
@@ -862,7 +881,9 @@ int fused2_why_not(const FdtdSolver* h, bool slab_rank = false, bool shell = fal
   if (h->twostep_w == 0) return FDTD_F2_OFF_DISABLED;
   { int W, zc; if (!fused2_shape(h, &W, &zc)) return FDTD_F2_OFF_TOO_SMALL; }
   if (h->comm && !slab_rank) return FDTD_F2_OFF_COMM;
-  if (!h->ade.empty() && !shell) return FDTD_F2_OFF_ADE;       // (a shell pair: the planes that hold dispersive cells are a z hole of the bulk)
+  // (a shell pair: the planes that hold dispersive cells are a z hole of the bulk; round 6: the pair advances them itself once
+  //  their memory terms are paged, disp_setup)
+  if (!h->ade.empty() && !shell && h->disp.state != 1) return FDTD_F2_OFF_ADE;
   if (!h->aniso.empty()) return FDTD_F2_OFF_ADE;               // fully anisotropic bodies: their coupling follows every single step
   // (sources are judged step by step, fused2_sources_why_not: a TFSF box or a mode plane keeps single steps only while it injects)
   // PEC walls; the min faces may be PMC (the symmetry planes of a half / quarter / eighth domain)
@@ -1077,11 +1098,12 @@ const F2Table* fused2_table(FdtdSolver* h, const F2Plan& plan, bool with_sources
 // computes E for (its rows j0-2 .. j0+R, planes k0-1 .. k1) differs from the background word, 0 where the tile is background only —
 // there the materials launch runs the plain sweep (fused2_step_kernel; the uniform coefficients ARE the table's entry 1: the same
 // bits).
-const FdtdSolver::TileClasses* tile_classes(FdtdSolver* h, int W, int zc, const ClipP& box, int nbx, int nby, int nbz) {
+// `disp` (a launch that advances dispersive cells): class 2 where a row segment the workgroup visits holds one, 1 for other tiles with bodies.
+const FdtdSolver::TileClasses* tile_classes(FdtdSolver* h, int W, int zc, const ClipP& box, int nbx, int nby, int nbz, bool disp = false) {
   if (!h->mat4 || h->roww_host.empty() || h->tile_split == 0) return nullptr;
   for (const auto& t : h->tile_cls)
     if (t.W == W && t.zc == zc && t.nbx == nbx && t.nby == nby && t.nbz == nbz && t.box.j0 == box.j0 && t.box.j1 == box.j1 &&
-        t.box.k0 == box.k0 && t.box.k1 == box.k1) return &t;
+        t.box.k0 == box.k0 && t.box.k1 == box.k1 && t.disp == disp) return &t;
   const GridP& g = h->g;
   const int R = W - 3, nbx_all = (g.nx + 255) / 256;
   std::vector<unsigned char> cls((size_t)nbx * nby * nbz, 0);
@@ -1095,10 +1117,14 @@ const FdtdSolver::TileClasses* tile_classes(FdtdSolver* h, int W, int zc, const 
         for (int k = std::max(k0 - 1, 0); k <= std::min(k1, g.nz - 1) && !c; ++k)
           for (int j = std::max(j0 - 2, 0); j <= std::min(j0 + R, g.ny - 1); ++j)
             if (h->roww_host[((size_t)k * g.ny + j) * nbx_all + tx] != kBgWord) { c = 1; break; }
+        if (disp && c)
+          for (int k = std::max(k0 - 1, 0); k <= std::min(k1, g.nz - 1) && c < 2; ++k)
+            for (int j = std::max(j0 - 2, 0); j <= std::min(j0 + R, g.ny - 1); ++j)
+              if (h->disp.dseg_host[((size_t)k * g.ny + j) * nbx_all + tx] >= 0) { c = 2; break; }
         cls[((size_t)tz * nbx + tx) * nby + ty] = c;
         n_bg += !c;
       }
-  FdtdSolver::TileClasses e{W, zc, box, nbx, nby, nbz, nullptr, n_bg, (long long)cls.size()};
+  FdtdSolver::TileClasses e{W, zc, box, nbx, nby, nbz, nullptr, n_bg, (long long)cls.size(), disp};
   if (dev_upload(h, &e.dev, (const unsigned char*)cls.data(), cls.size())) return nullptr;
   h->tile_cls.push_back(e);
   return &h->tile_cls.back();
@@ -1110,8 +1136,11 @@ const FdtdSolver::TileClasses* tile_classes(FdtdSolver* h, int W, int zc, const 
 // monitors of `tb` (fused2_plan); pair_record (called by the caller behind the launch) writes their records.
 // With `clip` the launch covers that box only (the bulk of a shell pair): nothing outside it is written, the E-side sources
 // of step n + 1 are left to the caller, and the sets are NOT swapped (the shell launches beside it still name them).
+// `use_disp`: the sweep subtracts the memory terms of the dispersive cells from E^{n+1} and leaves it for launch_ade2, which the
+// caller issues behind the launch (and behind the sources / damping of step n + 1 it applies itself).  `e2_clip`: a clipped launch
+// may apply the E-side sources of step n + 1 itself (the caller's ONE launch covers every source node).
 int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb, bool* sources2_done, bool* damp2_done = nullptr,
-                  const ClipP* clip = nullptr) {
+                  const ClipP* clip = nullptr, bool use_disp = false, bool e2_clip = false) {
   const bool inject = tb->with_sources;      // (false: the lists are spent, or — shell pairs with z holes — their planes take single steps)
   const GridP& g = h->g;
   if (ensure_second_set(h)) return -1;
@@ -1146,7 +1175,8 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
       inj.val = h->src_tab + n * h->src_tab_nodes;
       if (alive2) {
         inj.val2 = h->src_tab + (n + 1) * h->src_tab_nodes;
-        if (!h->src_on_seam && !clip) { inj.e2_in_sweep = 1; *sources2_done = true; }
+        // (round 6: a node next to a seam no longer sends them behind the launch — seam_kernel adds the terms of the values it repairs)
+        if (!clip || e2_clip) { inj.e2_in_sweep = 1; *sources2_done = true; }
       }
     } else if (alive) {
       int off = 0;
@@ -1187,16 +1217,19 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
   StepP sp = step_params(h);
   time_begin(h, 2, st);
   const MatP mp = mat_params(h);
+  DispP dp{nullptr, nullptr, nullptr};
+  if (use_disp) dp = DispP{h->disp.dseg, h->disp.cs, h->disp.e1};
   const int opt = (h->mem_hints ? 1 : 0) | (h->mat4 ? 2 : 0) | ((tb->mons.empty() && (!tb->with_sources || h->src_h_nodes == 0) && !tb->dstart) ? 0 : 4) |
-                  (clip ? 16 : (h->has_damp ? 8 : 0));
+                  (clip ? 16 : (h->has_damp ? 8 : 0)) | (use_disp ? 32 | 1 : 0);
   const int blocks = remap ? ((total + 7) / 8) * 8 : total;
   // background-only tiles take the plain sweep inside the materials launch (fdtd_kernels2.hpp, tile classes)
-  const FdtdSolver::TileClasses* tc = tile_classes(h, W, zc, box, nbx, nby, nbz);
-  const bool split = tc && tc->n_bg > 0 && (h->tile_split == 1 || 8 * tc->n_bg >= tc->n_all);
+  const FdtdSolver::TileClasses* tc = tile_classes(h, W, zc, box, nbx, nby, nbz, use_disp);
+  const bool split = tc && (use_disp || (tc->n_bg > 0 && (h->tile_split == 1 || 8 * tc->n_bg >= tc->n_all)));
   launch_fused2_step(st, W, opt, blocks, g, h->f, h->f2, sp, mp, zc, nbx, nby, nbz, remap, inj, h->seam_buf, dmp, box,
-                     TileClassP{split ? tc->dev : nullptr});
-  if (n_seams > 0) launch_seams(st, g, h->f2, sp, mp, h->seam_buf, n_seams, dmp, box);
+                     TileClassP{split ? tc->dev : nullptr}, dp);
+  if (n_seams > 0) launch_seams(st, g, h->f2, sp, mp, h->seam_buf, n_seams, dmp, box, inj);
   time_end(h, st);
+  if (use_disp) h->disp.pairs++;
   if (!clip) swap_sets(h);
   return 0;
 }
@@ -2089,9 +2122,78 @@ void launch_ade(FdtdSolver* h, int kbeg, int kend, hipStream_t st, const FieldP*
     if (!a.plane_off.empty()) { t0 = a.plane_off[(size_t)std::max(kbeg, 0)]; t1 = a.plane_off[(size_t)std::min(kend, h->g.nz)]; }
     if (t1 <= t0) continue;
     float* ef = fs ? (a.comp == 0 ? fs->ex : (a.comp == 1 ? fs->ey : fs->ez)) : field_ptr(h, a.comp);
+    const bool paged = h->disp.state == 1;      // (the memory term of the next step goes to the paged array the two-step sweeps read)
     hipLaunchKernelGGL(ade_kernel, dim3(nblk(t1 - t0)), dim3(256), 0, st, ef,
-                       (const uint32_t*)a.cell + t0, a.e_old + t0, a.q + t0, t1 - t0, a.n, zlo, zhi, a.p);
+                       (const uint32_t*)a.cell + t0, a.e_old + t0, a.q + t0, t1 - t0, a.n, zlo, zhi, a.p,
+                       paged ? h->disp.cs : nullptr, paged ? (const uint32_t*)a.qoff + t0 : nullptr);
   }
+}
+
+// behind a two-step sweep that carried the ADE update of its first step (launch_fused2 with use_disp; set B = `fs` or the current
+// set holds E^{n+2} with the sources and damping of step n + 1 applied): both steps of the pole states, E^{n+2} corrected
+void launch_ade2(FdtdSolver* h, hipStream_t st, const FieldP* fs = nullptr) {
+  dbg_sync(h);
+  for (AdeGroup& a : h->ade) {
+    float* ef = fs ? (a.comp == 0 ? fs->ex : (a.comp == 1 ? fs->ey : fs->ez)) : field_ptr(h, a.comp);
+    hipLaunchKernelGGL(ade2_kernel, dim3(nblk(a.n)), dim3(256), 0, st, ef, (const uint32_t*)a.cell, a.e_old, a.q, a.n, a.p,
+                       (const float*)h->disp.e1, h->disp.cs, (const uint32_t*)a.qoff);
+  }
+}
+
+// One-off, before the first run that may take step pairs: the memory terms cc S(Q) of all dispersive cells go to PAGED storage
+// (fdtd_fused2.hpp DispP) that the two-step sweeps address by position, and every ADE launch of the handle keeps them current from
+// then on.  Needs sorted lists without repeats (one slot per entry), one GPU, packed medium words (the instantiations that carry
+// the ADE lines are materials ones).  state = 1 (ready) or -1 (this problem keeps single steps / z holes as in round 5).
+// -1 = a HIP error.
+int disp_setup(FdtdSolver* h) {
+  Disp& D = h->disp;
+  if (D.state != 0) return 0;
+  D.state = -1;
+  const GridP& g = h->g;
+  if (h->ade.empty() || h->disp_on == 0 || !h->mat4 || h->mat4b || h->comm || !h->aniso.empty() || g.nx % 4 != 0) return 0;
+  for (const AdeGroup& a : h->ade) if (!a.strict) return 0;
+  const int nbx = (g.nx + 255) / 256;
+  const size_t nseg = (size_t)g.nz * g.ny * nbx;
+  hipStream_t st = h->stream;
+  auto give_up = [&]() { (void)hipGetLastError(); h->err.clear(); for (AdeGroup& a : h->ade) a.qoff = nullptr; return 0; };
+  if (dev_alloc(h, &D.dseg, nseg)) return give_up();
+  for (const AdeGroup& a : h->ade)
+    hipLaunchKernelGGL(disp_mark_kernel, dim3(nblk(a.n)), dim3(256), 0, st, (const uint32_t*)a.cell, a.n, g.nx, nbx, D.dseg);
+  D.dseg_host.assign(nseg, 0);
+  HIPCHK(h, hipMemcpyAsync(D.dseg_host.data(), D.dseg, nseg * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  long long nb = 0;
+  for (size_t q = 0; q < nseg; ++q) D.dseg_host[q] = D.dseg_host[q] ? (int)nb++ : -1;
+  const long long floats = nb * 3 * 256;
+  if (nb == 0 || floats >= (1LL << 32)) return give_up();             // (qoff is 32 bits wide)
+  HIPCHK(h, hipMemcpyAsync(D.dseg, D.dseg_host.data(), nseg * sizeof(int), hipMemcpyHostToDevice, st));
+  const int big = 1 << 30;
+  const int box0[6] = {big, -1, big, -1, big, -1};
+  int* box = nullptr;
+  if (dev_alloc(h, &D.cs, (size_t)floats) || dev_alloc(h, &D.e1, (size_t)floats) || dev_upload(h, &box, box0, 6)) return give_up();
+  for (AdeGroup& a : h->ade) {
+    if (dev_alloc(h, &a.qoff, (size_t)a.n, false)) return give_up();
+    hipLaunchKernelGGL(disp_qoff_kernel, dim3(nblk(a.n)), dim3(256), 0, st, (const uint32_t*)a.cell, a.n, g.nx, g.ny, nbx,
+                       (const int*)D.dseg, a.comp, (const float2*)a.q, a.p, a.qoff, D.cs, box);
+  }
+  int boxh[6];
+  HIPCHK(h, hipMemcpyAsync(boxh, box, sizeof(boxh), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  D.n_blocks = (int)nb;
+  for (int a = 0; a < 3; ++a) { D.lo[a] = boxh[2 * a]; D.hi[a] = boxh[2 * a + 1] + 1; }
+  h->tile_cls.clear();
+  D.state = 1;
+  return 0;
+}
+// every dispersive cell `margin` cells (x: 4) or more inside the box [lo, hi) — a bulk the shell's boxes never recompute
+bool disp_inside(const FdtdSolver* h, const int lo[3], const int hi[3], int margin) {
+  const Disp& D = h->disp;
+  if (D.state != 1) return false;
+  for (int a = 0; a < 3; ++a) {
+    const int m = a == 0 ? std::max(4, margin) : margin;
+    if (D.lo[a] < lo[a] + m || D.hi[a] > hi[a] - m) return false;
+  }
+  return true;
 }
 
 // z boundary conditions of a single slab (no neighbour): fill ghost planes
@@ -2503,6 +2605,7 @@ template <typename T>
 int upload_material(FdtdSolver* h, const T* mat, size_t count) {
   const size_t nc = (size_t)n_cells(h);
   if (count != 3 * nc) return fail(h, "fdtd_set_material: expected %zu entries, got %zu", 3 * nc, count);
+  if (h->disp.state == 1) h->tile_cls.clear();
   if (h->n_media == 0) return fail(h, "fdtd_set_material: call fdtd_set_media first");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   const GridP& g = h->g;
@@ -2640,13 +2743,16 @@ int fdtd_add_ade(FdtdSolver* h, int comp, int64_t n, const uint32_t* cell_index,
   if (comp < 0 || comp > 2) return fail(h, "fdtd_add_ade: comp must be 0..2");
   if (n_poles < 1 || n_poles > kMaxPoles) return fail(h, "fdtd_add_ade: n_poles must be in [1, %d]", kMaxPoles);
   if (n <= 0) return 0;
+  if (h->disp.state == 1) return fail(h, "fdtd_add_ade: the memory terms of this handle's dispersive cells are paged already (a run took step pairs); add every group before the first fdtd_run");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   AdeGroup a{};
   a.comp = comp; a.n = n;
   plane_range(cell_index, n, h->g.sxy, &a.k0, &a.k1);
   {
     bool sorted = true;
-    for (int64_t i = 1; i < n && sorted; ++i) sorted = cell_index[i - 1] <= cell_index[i];
+    a.strict = true;
+    for (int64_t i = 1; i < n && sorted; ++i) { sorted = cell_index[i - 1] <= cell_index[i]; a.strict = a.strict && cell_index[i - 1] != cell_index[i]; }
+    a.strict = a.strict && sorted;
     if (sorted) {
       a.plane_off.assign((size_t)h->g.nz + 1, n);
       int64_t i = 0;
@@ -2930,6 +3036,7 @@ int fdtd_reset(FdtdSolver* h) {
     HIPCHK(h, hipMemset(a.e_old, 0, (size_t)a.n * 4));
     HIPCHK(h, hipMemset(a.q, 0, (size_t)a.n * a.p.n_poles * 8));
   }
+  if (h->disp.state == 1) HIPCHK(h, hipMemset(h->disp.cs, 0, (size_t)h->disp.n_blocks * 3 * 256 * sizeof(float)));
   for (Tfsf& t : h->tfsf) {
     HIPCHK(h, hipMemset(t.e1, 0, ((size_t)t.n_aux + 1) * 4));
     HIPCHK(h, hipMemset(t.h1, 0, (size_t)t.n_aux * 4));
@@ -2973,6 +3080,8 @@ struct Run {
   bool split_now = false, graph_ok = false;
   std::vector<GraphRec> graphs;
   bool f2_ok = false, f2s_ok = false, s2_ok = false, s2_deep = false, f2m_ok = false;
+  bool s2_disp = false;                // shell2 pairs: every dispersive cell deep inside the bulk — its sweep advances them (no z holes)
+  bool pair_disp = false;              // the pair about to be issued does so
   bool f2mc_ok = false, f2mc_deep = false;   // z-slab ranks with CPML: shell2 pairs with the planes next to a cut as z holes (sgm: their geometry)
   ShellGeom sg{}, sgm{};
   ZPlan zp_base, zp_src;               // the bulk's planes: without / with the z holes of the source lists
@@ -3334,6 +3443,10 @@ struct Run {
   // which forms of step pairs this run may take (decided once; begin_step judges every pair): plain pairs, shell pairs (round-4
   // form), shell2 pairs, slab pairs of a z-slab rank — and what they need (source tables, the third field set, two streams)
   int setup_pairs() {
+    // dispersive cells inside the two-step sweeps (round 6): their pole states move into paged storage, once
+    if (fused && !tb_ok && !h->ade.empty() && disp_setup(h)) return -1;
+    h->disp.pairs = 0;
+    s2_disp = false;
     f2_ok = fused && !tb_ok && fused2_eligible(h);
     sg = ShellGeom{};
     f2s_ok = false;
@@ -3355,9 +3468,10 @@ struct Run {
         h->f2_off_reason = 0;
         // the bulk's planes: one interval, or — dispersive cells — the intervals between their planes (z holes, inside the bulk's range)
         zp_s2 = ZPlan{};
-        if (h->ade.empty()) { zp_s2.n = 1; zp_s2.a[0] = sg.o0[2]; zp_s2.b[0] = sg.o1[2]; zp_s2.ok = true; }
+        s2_disp = !h->ade.empty() && disp_inside(h, sg.o0, sg.o1, 3);
+        if (h->ade.empty() || s2_disp) { zp_s2.n = 1; zp_s2.a[0] = sg.o0[2]; zp_s2.b[0] = sg.o1[2]; zp_s2.ok = true; }
         else if (zplan_build(h, sg, false, &zp_s2) && zp_s2.a[0] == sg.o0[2] && zp_s2.b[zp_s2.n - 1] == sg.o1[2]) zp_s2.ok = true;
-        if (!zp_s2.ok) { s2_ok = false; h->f2_off_reason = why_r4; }       // (the round-4 form may still take the run)
+        if (!zp_s2.ok) { s2_ok = false; s2_disp = false; h->f2_off_reason = why_r4; }       // (the round-4 form may still take the run)
         // lists that inject and that the sweeps cannot apply: their planes as z holes — usable when every hole lies inside the bulk's plane
         // range (one-launch form only: FDTD_OPT_SHELL2 = 2 / 3 cut their boxes differently)
         zp_s2h = ZPlan{};
@@ -3492,7 +3606,8 @@ struct Run {
     int nb = 0;
     for (int i = 0; i < zp.n; ++i) {
       const ClipP clip{sg.o0[0], sg.o1[0], sg.o0[1], sg.o1[1], zp.a[i], zp.b[i]};
-      if (launch_fused2(h, n, st, tb, &s2, nullptr, &clip)) return -1;
+      // (one interval and every source node deep inside it: the sweep applies the E-side terms of step n + 1 itself)
+      if (launch_fused2(h, n, st, tb, &s2, nullptr, &clip, pair_disp, zp.n == 1 && s2_deep)) return -1;
       // the boxes beside this interval: its planes, and (first / last interval) the z slabs below / above
       ShellGeom gi = sg;
       gi.o0[2] = zp.a[i]; gi.o1[2] = zp.b[i];
@@ -3500,6 +3615,12 @@ struct Run {
       const int ni = shell2_boxes(h, gi, bi, i == 0 ? 0 : zp.a[i], i == zp.n - 1 ? nz : zp.b[i]);
       for (int q = 0; q < ni && nb < kShell2MaxBoxes; ++q) boxes[nb++] = bi[q];
     }
+    // dispersive cells (all deep inside the bulk): both steps of their pole states and the correction of E^{n+2} behind the bulk,
+    // beside the shell's boxes, once nothing else is due on E^{n+2} there — else at the end, behind the sources of step n + 1
+    bool src_due = false;
+    for (const PointSrc& sr : h->psrc) src_due = src_due || (sr.n_e && n + 1 < sr.n_steps);
+    const bool ade2_early = pair_disp && (s2 || !src_due);
+    if (ade2_early) launch_ade2(h, st, &B);
     launch_shell2_boxes(h, boxes, nb, h->pml_blk2[hp][ep], cs, tb);
     if (holes || per_y) {
       const int pml_in = 7 & pml_in_sweep_mask(h);
@@ -3545,8 +3666,9 @@ struct Run {
       advance_tfsf_aux(h, true, n, st);
       advance_tfsf_aux(h, false, n + 1, st);
     }
-    launch_sources(h, true, n + 1, 0, nz, st);
-    launch_ade(h, 0, nz, st);
+    if (!s2) launch_sources(h, true, n + 1, 0, nz, st);
+    if (!pair_disp) launch_ade(h, 0, nz, st);
+    else if (!ade2_early) launch_ade2(h, st);
     advance_tfsf_aux(h, true, n + 1, st);
     fill_ghost_fused(h, st);
     return 0;
@@ -3619,6 +3741,7 @@ struct Run {
       pair = src_why == 0 && fused2_plan(h, n, &f2_plan, f2s_ok ? sg.o0 : nullptr, f2s_ok ? sg.o1 : nullptr) &&
              (!f2s_ok || plan_in_bulk(f2_plan, *zp));
     }
+    pair_disp = pair && !h->ade.empty() && h->disp.state == 1 && (use_s2 ? (s2_disp && zp == &zp_s2) : !f2s_ok);
     // (with H-side sources the monitors of a pair still take E^n and H^{n-1/2} here: those sources change H^{n-1/2} before the
     //  sweep, and pair_record reads the set afterwards)
     if (rec) record_monitors(h, n, false, st, (pair && h->src_h_nodes == 0) ? &f2_plan : nullptr);
@@ -3806,11 +3929,12 @@ struct Run {
     if (!tb) return -1;
     bool sources2_done = false, damp2_done = true;
     launch_sources(h, false, n, 0, nz, st);              // H-side sources of step n act on H^{n-1/2}, as before a single step
-    if (launch_fused2(h, n, st, tb, &sources2_done, &damp2_done)) return -1;
+    if (launch_fused2(h, n, st, tb, &sources2_done, &damp2_done, nullptr, pair_disp)) return -1;
     pair_record(h, tb, n, st);                           // (H^{n+3/2} is not touched by the E-side sources that follow)
     if (rec_at(n + 1)) record_monitors(h, n + 1, true, st);      // DFT records at the middle step: their H terms, from the write set
     if (!sources2_done) launch_sources(h, true, n + 1, 0, nz, st);
     if (h->has_damp && !damp2_done) launch_damp(h, true, 0, nz, st);
+    if (pair_disp) launch_ade2(h, st);                   // (the ADE update of step n + 1 follows its sources and damping, as launch_ade does)
     fill_ghost_fused(h, st);
     return 0;
   }
@@ -4233,6 +4357,11 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_SHELL2: h->shell2_on = value < 0 ? -1 : (value > 3 ? 1 : value); return 0;
     case FDTD_OPT_DEBUG_SYNC: h->debug_sync = value != 0; return 0;
     case FDTD_OPT_TILE_SPLIT: h->tile_split = value < 0 ? -1 : (value != 0); return 0;
+    case FDTD_OPT_DISP:
+      if (h->disp.state == 1 && value == 0) break;       // (every ADE launch keeps the paged memory terms by now: set it before the first run)
+      h->disp_on = value < 0 ? -1 : (value != 0);
+      if (h->disp.state == -1 && value != 0) h->disp.state = 0;
+      return 0;
     case FDTD_OPT_SHELL2_SHAPE: {
       // lanes per row of the wide boxes (3 ... 64) + 128 * their waves per workgroup (1 ... 8) + 1024 * their planes per chunk (0 = by box)
       //   + 2^17 * waves per workgroup of the strips (1 ... 8) + 2^21 * their planes per chunk (0 = by box)
@@ -4270,6 +4399,7 @@ int fdtd_get_stats(FdtdSolver* h, FdtdStats* out) {
   out->shell_pairs = h->shell_pairs;
   out->shell2_pairs = h->shell2_pairs;
   out->fused2_off_reason = h->fused2_pairs ? 0 : (h->f2_off_reason ? h->f2_off_reason : h->f2_dyn_reason);
+  out->disp_pairs = h->disp.pairs;
   out->struct_bytes = (int32_t)sizeof(FdtdStats);
   return 0;
 }

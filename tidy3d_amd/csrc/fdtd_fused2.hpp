@@ -42,8 +42,18 @@ struct DampT {
 // grid whose shell (CPML slabs + collar, boundary planes of a z-slab rank) is advanced by single steps (fdtd_capi.hip, shell pairs)
 struct ClipP { int i0, i1, j0, j1, k0, k1; };
 // tile classes of a launch of a materials instantiation: cls[tile] (logical tile index, y fastest) = 0 where the tile holds only the
-// background medium — its workgroup runs the plain sweep.  cls == nullptr: the materials sweep everywhere
+// background medium — its workgroup runs the plain sweep; 2 (launches that carry dispersive cells) where a row segment of the tile
+// holds a dispersive cell, 1 elsewhere — the materials sweep without the ADE lines.  cls == nullptr: the launch's own instantiation everywhere
 struct TileClassP { const unsigned char* cls; };
+// Dispersive cells in step pairs (round 6; K4 twice per pair): paged storage — one block [3 components][256 cells] of floats per row
+// segment (256 cells of one row = one wavefront of the sweep) that holds a dispersive cell, found through dseg.  `cs` holds the
+// memory term cc S(Q^n) of the current state at the dispersive cells (0 elsewhere), written by whichever ADE kernel formed Q^n;
+// the sweep subtracts it from E^{n+1} in S2 and leaves E^{n+1} of the rows it owns in `e1` for ade2_kernel.  dseg == nullptr: none.
+struct DispP {
+  const int* dseg;                         // [nz][ny][ceil(nx / 256)]: block of the row segment, -1 = no dispersive cell in it
+  const float* cs;                         // cc S(Q^n)
+  float* e1;                               // E^{n+1} behind its ADE update
+};
 constexpr int kMaxCap = 1024;
 constexpr int kSeamArrays = 13;  // of step one: H1_y, H1_z, E1_x, E1_y, E1_z [c-1], E1_y, E1_z [c]; of step two: H2_x [c-1], H2_y, H2_z [c-2], H2_x, H2_y, H2_z [c]
                                  // (c = first column of the right tile)
@@ -52,10 +62,16 @@ constexpr int kSeamArrays = 13;  // of step one: H1_y, H1_z, E1_x, E1_y, E1_z [c
 void launch_inject_values(hipStream_t st, float* val, const float* w_re, const float* w_im, const float2* wave,
                           long long step, int n);
 // waves = rows per workgroup (W - 3 of them written); opt: bit 0 non-temporal stores, bit 1 materials (m.m4 set), bit 2 monitor
-// samples in the table, bit 3 absorber layers (dmp.fb[0] set), bit 4 the launch covers the box `clip` only (not with bit 3)
+// samples in the table, bit 3 absorber layers (dmp.fb[0] set), bit 4 the launch covers the box `clip` only (not with bit 3),
+// bit 5 the memory terms of dispersive cells subtracted from E^{n+1} in the sweep (dp.dseg set; with bit 1; always non-temporal stores)
 void launch_fused2_step(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
                         const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,
-                        int xcd_remap, const InjP& inj, float* seam, const DampT& dmp, const ClipP& clip, const TileClassP& tcl = TileClassP{nullptr});
+                        int xcd_remap, const InjP& inj, float* seam, const DampT& dmp, const ClipP& clip, const TileClassP& tcl = TileClassP{nullptr},
+                        const DispP& dp = DispP{nullptr, nullptr, nullptr});
+// the instantiations that carry dispersive cells live in their own translation unit too (fdtd_fused2d.hip)
+void launch_fused2_step_disp(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
+                             const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,
+                             int xcd_remap, const InjP& inj, float* seam, const DampT& dmp, const ClipP& clip, const TileClassP& tcl, const DispP& dp);
 // the clipped instantiations live in their own translation unit (fdtd_fused2c.hip): the two compile side by side
 void launch_fused2_step_clip(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
                              const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,
@@ -80,7 +96,8 @@ void launch_pair_record(hipStream_t st, const PairRecP& r, long long max_cells, 
 struct DftDumpP { int n; int slot[3]; int off[3]; };
 void launch_dft_record_dump(hipStream_t st, const DftDumpP& r, const float* dump, float2* acc, long long cells, long long fstride,
                             const float2* phase, int nf);
+// (inj: the seam kernel adds the E-side source terms of step n+1 when the sweep did — inj.e2_in_sweep)
 void launch_seams(hipStream_t st, const GridP& g, const FieldP& b, const StepP& s, const MatP& m, const float* seam,
-                  int n_seams, const DampT& dmp, const ClipP& clip);
+                  int n_seams, const DampT& dmp, const ClipP& clip, const InjP& inj);
 
 }  // namespace fdtd

@@ -1357,8 +1357,11 @@ struct AdeP {
 
 // (the list is sorted by cell index: a launch over a plane range covers the entries [t0, t0 + n) of those planes only —
 //  `cell`, `e_old`, `q` arrive offset by t0, `qs` is the stride between the poles of one entry = the length of the list)
+// (`cs` != nullptr — round 6, runs whose step pairs advance the dispersive cells, fdtd_fused2.hpp DispP: the memory term of the
+//  NEXT step, cc S(Q^{n+1}), goes to the paged array the two-step sweep subtracts from E^{n+2}; qoff[t] = the entry's slot in it)
 __global__ __launch_bounds__(256) void ade_kernel(float* e, const uint32_t* cell, float* e_old, float2* q,
-                                                   long long n, long long qs, long long zlo, long long zhi, AdeP a) {
+                                                   long long n, long long qs, long long zlo, long long zhi, AdeP a,
+                                                   float* cs, const uint32_t* qoff) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const long long p = cell[t];
@@ -1379,6 +1382,7 @@ __global__ __launch_bounds__(256) void ade_kernel(float* e, const uint32_t* cell
   e[p] = en;
   e_old[t] = en;
   const float se = en + eo;
+  float S1 = 0.f;
 #pragma unroll
   for (int k = 0; k < kMaxPoles; ++k) {
     if (k < a.n_poles) {
@@ -1386,8 +1390,82 @@ __global__ __launch_bounds__(256) void ade_kernel(float* e, const uint32_t* cell
       r.x = a.kap[k].x * qq[k].x - a.kap[k].y * qq[k].y + a.bet[k].x * se;
       r.y = a.kap[k].x * qq[k].y + a.kap[k].y * qq[k].x + a.bet[k].y * se;
       q[(long long)k * qs + t] = r;
+      S1 += 2.f * ((a.kap[k].x - 1.f) * r.x - a.kap[k].y * r.y);
     }
   }
+  if (cs) cs[qoff[t]] = a.cc * S1;
+}
+
+// K4 twice, behind a two-step sweep that subtracted the memory term of step n itself (fused2_step_kernel, OPT bit 5) and left
+// E^{n+1} of the dispersive cells in the paged array `e1`: per entry  Q^{n+1} = kap Q^n + bet (E^{n+1} + E^n),
+// E^{n+2} <- E^{n+2} - cc S(Q^{n+1}),  Q^{n+2} = kap Q^{n+1} + bet (E^{n+2} + E^{n+1}),  and the memory term of the step after,
+// cc S(Q^{n+2}), into `cs` — the operations of two ade_kernel launches in their order, the pole states read and written once.
+// e = E^{n+2} as the sweep (and the sources / damping of step n+1) left it; e_old[t] = E^n on entry, E^{n+2} on exit.
+__global__ __launch_bounds__(256) void ade2_kernel(float* e, const uint32_t* cell, float* e_old, float2* q, long long n, AdeP a,
+                                                    const float* e1, float* cs, const uint32_t* qoff) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const long long p = cell[t];
+  const uint32_t o = qoff[t];
+  const float em = e1[o];
+  const float se1 = em + e_old[t];
+  float S = 0.f;
+  float2 qq[kMaxPoles];
+#pragma unroll
+  for (int k = 0; k < kMaxPoles; ++k) {
+    if (k < a.n_poles) {
+      const float2 q0 = q[(long long)k * n + t];
+      qq[k].x = a.kap[k].x * q0.x - a.kap[k].y * q0.y + a.bet[k].x * se1;
+      qq[k].y = a.kap[k].x * q0.y + a.kap[k].y * q0.x + a.bet[k].y * se1;
+      S += 2.f * ((a.kap[k].x - 1.f) * qq[k].x - a.kap[k].y * qq[k].y);
+    }
+  }
+  const float en = e[p] - a.cc * S;
+  e[p] = en;
+  e_old[t] = en;
+  const float se = en + em;
+  float S1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < kMaxPoles; ++k) {
+    if (k < a.n_poles) {
+      float2 r;
+      r.x = a.kap[k].x * qq[k].x - a.kap[k].y * qq[k].y + a.bet[k].x * se;
+      r.y = a.kap[k].x * qq[k].y + a.kap[k].y * qq[k].x + a.bet[k].y * se;
+      q[(long long)k * n + t] = r;
+      S1 += 2.f * ((a.kap[k].x - 1.f) * r.x - a.kap[k].y * r.y);
+    }
+  }
+  cs[o] = a.cc * S1;
+}
+
+// ---- paged memory terms (round 6): set-up kernels, each run once per engine ----------------------------------------------------
+// mark the row segments (256 cells of a row) that hold an entry of the list
+__global__ __launch_bounds__(256) void disp_mark_kernel(const uint32_t* cell, long long n, int nx, int nbx, int* flag) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const long long p = cell[t];
+  flag[(p / nx) * nbx + (int)(p % nx) / 256] = 1;
+}
+// qoff[t]: the slot of entry t of a list of component `comp` in the paged arrays, and the memory term of the state as it is,
+// cc S(Q), into it; box[0 .. 5]: the bounding box of the dispersive cells
+__global__ __launch_bounds__(256) void disp_qoff_kernel(const uint32_t* cell, long long n, int nx, int ny, int nbx, const int* dseg,
+                                                         int comp, const float2* q, AdeP a, uint32_t* qoff, float* cs, int* box) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const long long p = cell[t];
+  const int i = (int)(p % nx);
+  const long long blk = dseg[(p / nx) * nbx + i / 256];
+  const uint32_t o = (uint32_t)((blk * 3 + comp) * 256 + (i & 255));
+  qoff[t] = o;
+  float S = 0.f;
+  for (int k = 0; k < a.n_poles; ++k) {
+    const float2 qk = q[(long long)k * n + t];
+    S += 2.f * ((a.kap[k].x - 1.f) * qk.x - a.kap[k].y * qk.y);
+  }
+  cs[o] = a.cc * S;
+  const int j = (int)((p / nx) % ny), k = (int)(p / ((long long)nx * ny));
+  // (one atomic per lane on six words: a one-off of a few ms for 10^7 entries)
+  atomicMin(&box[0], i); atomicMax(&box[1], i); atomicMin(&box[2], j); atomicMax(&box[3], j); atomicMin(&box[4], k); atomicMax(&box[5], k);
 }
 
 // =============================================================================================

@@ -153,9 +153,17 @@ __device__ __forceinline__ int lane_value(int v, int l) {
 template <int LB, int OPT>
 __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a, const FieldP& b, const StepP& s, const MatP& m,
                                                  int zchunk, int nbx, int nby, int nbz, const InjP& inj,
-                                                 float* __restrict__ seam, const DampT& dmp, const ClipP& clip, int t) {
+                                                 float* __restrict__ seam, const DampT& dmp, const ClipP& clip, int t,
+                                                 const DispP& dp) {
   constexpr int V = 4;
   constexpr bool NT = (OPT & 1) != 0, MAT = (OPT & 2) != 0, MON = (OPT & 4) != 0;     // MON: the node table may hold monitor samples
+  // DISP (round 6): the grid holds dispersive cells and the pair advances them (K4 twice).  What the sweep needs of step n's ADE
+  // update is E^{n+1} <- E^{n+1} - cc S(Q^n) at those cells — H^{n+3/2} differentiates it — and that memory term is known before
+  // the sweep starts: it lies in paged storage (DispP::cs, one block per row segment that holds a dispersive cell, zero at the
+  // segment's other cells), kept up to date by the ADE kernels.  S2 subtracts it last of all (as launch_ade follows the damping
+  // launch) and leaves E^{n+1} of the rows it owns in DispP::e1; ade2_kernel behind the sweep forms Q^{n+1} from it, corrects
+  // E^{n+2} and forms Q^{n+2} — ade_kernel's operations in its order, twice.
+  constexpr bool DISP = (OPT & 32) != 0;
   constexpr bool DAMP = (OPT & 8) != 0;   // absorber layers: both fields of both steps are damped in registers (damp_kernel's factors)
   // CLIP: the launch covers the box `clip` only — the bulk of a grid whose shell (CPML slabs + a two-cell collar, the boundary
   // planes of a z-slab rank) is advanced by single steps beside it.  Tile rows and chunks start at the box's origin, nothing is
@@ -374,6 +382,10 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
     if constexpr (MAT) {
       if (do_e1) rw = m.roww[((long long)min(k, g.nz - 1) * g.ny + j) * nbx + tile_x];     // (plane nz: the wall, E1 = 0 whatever the medium)
     }
+    [[maybe_unused]] int ds = -1;              // block of the row segment's memory terms (DISP), -1 = no dispersive cell in it
+    if constexpr (DISP) {
+      if (do_e1 && k < g.nz) ds = dp.dseg[((long long)k * g.ny + j) * nbx + tile_x];
+    }
     {
       issue(k, L);
       float eyx = lane_next(eyk[0]);
@@ -505,7 +517,7 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
                   else e1zn[e] += v;
                 }
               }
-            } else if (MON && en.z >= 8 && own && k >= k0 && k < k1) {
+            } else if (MON && en.z >= (DISP ? 11 : 8) && own && k >= k0 && k < k1) {     // (DISP: E^{n+1} is sampled behind the ADE update, below)
               const int c = en.z - 8;
 #pragma unroll
               for (int e = 0; e < V; ++e) {
@@ -534,6 +546,33 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
             const float bx[V] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
             for (int e = 0; e < V; ++e) { e1yn[e] *= bx[e] * cyv * bzk; e1zn[e] *= bx[e] * byv * czk; }
+          }
+        }
+        if constexpr (DISP) {
+          if (ds >= 0 && act) {
+            const long long qb = ((long long)ds * 3) * 256 + tx * V;
+            float cx[V], cy[V], cz[V];
+            ldv<V>(cx, dp.cs + qb); ldv<V>(cy, dp.cs + qb + 256); ldv<V>(cz, dp.cs + qb + 512);
+#pragma unroll
+            for (int e = 0; e < V; ++e) { e1xn[e] = e1xn[e] - cx[e]; e1yn[e] = e1yn[e] - cy[e]; e1zn[e] = e1zn[e] - cz[e]; }
+            if (own && k >= k0 && k < k1) { stv<V>(dp.e1 + qb, e1xn); stv<V>(dp.e1 + qb + 256, e1yn); stv<V>(dp.e1 + qb + 512, e1zn); }
+          }
+          if constexpr (MON) {                 // small time monitors: their E samples of the middle step, behind everything
+            if (own && k >= k0 && k < k1) {
+              for (int qb = q0; qb < q1; qb += 64) {
+                int4 ev = {0, -1, 0, 0};
+                if (qb + tx < q1) ev = inj.ent[qb + tx];
+                unsigned long long hit = __ballot(ev.y == j && ev.z >= 8 && ev.z < 11);
+                while (hit) {
+                  const int l = __ffsll(hit) - 1;
+                  hit &= hit - 1;
+                  const int d = lane_value(ev.x, l) - i0, c = lane_value(ev.z, l) - 8, w = lane_value(ev.w, l);
+#pragma unroll
+                  for (int e = 0; e < V; ++e)
+                    if (d == e) inj.cap[w] = c == 0 ? e1xn[e] : (c == 1 ? e1yn[e] : e1zn[e]);
+                }
+              }
+            }
           }
         }
         // the middle step over the boxes of DFT monitors: H^{n+1/2} for records at step n, E^{n+1} (behind its sources and damping)
@@ -610,13 +649,14 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
               hit &= hit - 1;
               const int d = lane_value(ev.x, l) - i0o, code = lane_value(ev.z, l);
               const float v = inj.val2[lane_value(ev.w, l)];
+              // (selects, not conditional stores: merged into h1x[d] += v they send the three arrays to scratch memory — every
+              //  instantiation that carries the monitor table ran 49 % slower for it at 512^3, profiles/r6/r6e)
 #pragma unroll
               for (int e = 0; e < V; ++e) {
-                if (d == e) {
-                  if (code == 3) h1x[e] += v;
-                  else if (code == 4) h1y[e] += v;
-                  else h1z[e] += v;
-                }
+                const bool mine = d == e;
+                h1x[e] = (mine && code == 3) ? h1x[e] + v : h1x[e];
+                h1y[e] = (mine && code == 4) ? h1y[e] + v : h1y[e];
+                h1z[e] = (mine && code == 5) ? h1z[e] + v : h1z[e];
               }
             }
           }
@@ -811,7 +851,7 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
 template <int LB, int OPT>
 __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
                                                          int zchunk, int nbx, int nby, int nbz, int xcd_remap,
-                                                         InjP inj, float* __restrict__ seam, DampT dmp, ClipP clip, TileClassP tcl) {
+                                                         InjP inj, float* __restrict__ seam, DampT dmp, ClipP clip, TileClassP tcl, DispP dp) {
   const int total = nbx * nby * nbz;
   int t = blockIdx.x;
   if (xcd_remap == 1) {
@@ -827,12 +867,21 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     if (t >= total) return;
   }
   if constexpr ((OPT & 2) != 0) {
-    if (tcl.cls && !tcl.cls[t]) {
-      fused2_step_tile<LB, (OPT & ~2)>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t);
-      return;
+    if (tcl.cls) {
+      const int cl = tcl.cls[t];
+      if (cl == 0) {
+        fused2_step_tile<LB, (OPT & ~(2 | 32))>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t, dp);
+        return;
+      }
+      if constexpr ((OPT & 32) != 0) {       // (a tile without dispersive cells in a launch that carries them: the materials sweep)
+        if (cl == 1) {
+          fused2_step_tile<LB, (OPT & ~32)>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t, dp);
+          return;
+        }
+      }
     }
   }
-  fused2_step_tile<LB, OPT>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t);
+  fused2_step_tile<LB, OPT>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t, dp);
 }
 
 // ---- the seams between x tiles -------------------------------------------------------------------------------------
@@ -840,8 +889,10 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
 // E2_{x,y,z}[c-1], E2_{y,z}[c] differentiate H2_{y,z}[c-1]: recomputed here with the formulas of the sweep from what both
 // tiles left in the scratch array [seam][13][nz + 2][ny] (read row-contiguously; plane nz and what lies beyond the walls
 // stay zero).  H2_{y,z}[c-1] of the row below and of the plane below are recomputed rather than exchanged: one launch.
+// Round 6: the E-side source terms of step n+1 on a seam column are added here when the sweep added the others (inj.e2_in_sweep):
+// a node next to a seam no longer sends all of them behind the launch.
 __global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, MatP m,
-                                                   const float* __restrict__ seam, int n_seams, DampT dmp, ClipP clip) {
+                                                   const float* __restrict__ seam, int n_seams, DampT dmp, ClipP clip, InjP inj) {
   // (clip: the box the sweep wrote — the whole grid, or the bulk of a grid whose shell takes single steps; rows and planes
   //  are those of the box, and a seam column that lies outside it is left alone)
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -905,6 +956,16 @@ __global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, M
     const float2 qm = coef(pl, 2), qc = coef(p, 2);
     ez_m = upd_e(A(4, j, k), qm.x, qm.y, hy_m - hy_mm, idx_m, hx_m - hxm_j, idy);
     ez_c = upd_e(A(6, j, k), qc.x, qc.y, hy_c - hy_m, idx_c, hx_c - hxc_j, idy);
+  }
+  if (inj.val2 && inj.e2_in_sweep) {         // the E-side sources of step n+1 on these two columns (the plane's table rows in their order)
+    const int q0 = inj.start[k], q1 = inj.start[k + 1];
+    for (int q = q0; q < q1; ++q) {
+      const int4 en = inj.ent[q];
+      if (en.y != j || en.z >= 3) continue;
+      const float v = inj.val2[en.w];
+      if (en.x == c - 1) { if (en.z == 0) ex_m += v; else if (en.z == 1) ey_m += v; else ez_m += v; }
+      else if (en.x == cc) { if (en.z == 1) ey_c += v; else if (en.z == 2) ez_c += v; }
+    }
   }
   if (dmp.fb[0] && dmp.e2) {                 // E^{n+2} damped as in the sweep
     const float bxm = dmp.fb[0][c - 1], cxm = dmp.fc[0][c - 1], bxc = dmp.fb[0][cc];
