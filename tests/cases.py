@@ -197,6 +197,21 @@ def drude_in_pml(N=(16, 12, 12)):
     return _sim(N, td.BoundarySpec.all_sides(td.PML(num_layers=4)), structures)
 
 
+def lorentz_sphere(N=(20, 18, 16), pml=True):
+    """A volumetric dispersive body away from every wall — SURVEY 8(d)'s V3 in miniature: a Lorentz sphere (one pole pair) with a
+    two-pole Drude block inside it and a dielectric collar, CPML on all faces (or PEC walls), the dipole ON a dispersive cell,
+    a DFT plane and a probe through the sphere.  At three times the size the step pairs advance its cells themselves (round 6:
+    the sweep subtracts the paged memory terms, ade2_kernel follows), tests/test_gpu_disp.py."""
+    structures = [
+        td.Structure(geometry=td.Sphere(center=(0.02, -0.03, 0.0), radius=0.3), medium=td.Lorentz(eps_inf=2.0, coeffs=[(2.0, 4e14, 2e13)])),
+        td.Structure(geometry=td.Box(center=(0.05, 0.0, 0.05), size=(0.2, 0.15, 0.1)), medium=td.Drude(eps_inf=1.5, coeffs=[(3e14, 1e13), (5e14, 3e13)])),
+        td.Structure(geometry=td.Box(center=(-0.32, 0.0, 0.0), size=(0.1, 0.3, 0.3)), medium=td.Medium(permittivity=2.5))]
+    bspec = td.BoundarySpec.all_sides(td.PML(num_layers=4)) if pml else td.BoundarySpec.all_sides(td.PECBoundary())
+    monitors = [td.FieldTimeMonitor(center=(0.1, 0.05, -0.05), size=(0, 0, 0), name="t", colocate=False, interval=1),
+                td.FieldMonitor(center=(0, 0, 0), size=(0.5, 0.4, 0), freqs=[2.5e14, 3e14], name="f")]
+    return _sim(N, bspec, structures, monitors=monitors)
+
+
 def nonuniform_grid(N=(16, 12, 10)):
     """CustomGrid with graded steps along x and z."""
     dlx = tuple(0.03 + 0.02 * np.abs(np.linspace(-1, 1, 20)))
@@ -434,7 +449,7 @@ CASES = {
     "pec_box": pec_box, "pec_box_vec": pec_box_vec, "periodic_box": periodic_box,
     "periodic_box_tall": periodic_box_tall,
     "pml_box": pml_box, "stable_pml_box": stable_pml_box, "media_mix": media_mix,
-    "drude_in_pml": drude_in_pml, "nonuniform_grid": nonuniform_grid,
+    "drude_in_pml": drude_in_pml, "nonuniform_grid": nonuniform_grid, "lorentz_sphere": lorentz_sphere,
 }
 
 
