@@ -221,8 +221,24 @@ def _workload_traffic(workload, cells, two_step):
     return None
 
 
-def secondary_workload(HipEngine, L, n, workload, device, args, steps=40, repeats=3):
-    """One more single-GPU measurement on the same box: same grid, materials + CPML on all six faces."""
+_INIT = {}
+
+
+def init_plane(c, k, n):
+    """synthetic initial data: uniform random +-1e-3, one generator per (component, plane) -> the same global field at any N"""
+    key = (c, k, n)
+    if key not in _INIT:
+        if len(_INIT) > 6 * 512:
+            _INIT.clear()
+        _INIT[key] = np.random.default_rng(c * 100003 + k).uniform(-1e-3, 1e-3, (n, n)).astype(np.float32)
+    return _INIT[key]
+
+
+MIN_TIMED_STEPS = 100        # a timed region shorter than this is raised to it (VERDICT round 5, weak 8: 20 steps are 14 ms)
+
+
+def secondary_workload(HipEngine, L, n, workload, device, args, steps=100, repeats=3):
+    """One more single-GPU measurement on the same box: same grid, another SURVEY 8(d) variant (build_spec)."""
     spec = build_spec(n, steps * (repeats + 2) + 64, workload)
     eng = HipEngine(spec, device=device, variant=args.variant, z_chunk=args.zchunk)
     try:
@@ -233,7 +249,7 @@ def secondary_workload(HipEngine, L, n, workload, device, args, steps=40, repeat
         for c in range(6):
             arr = np.empty((n, n, n), dtype=np.float32)
             for k in range(n):
-                arr[k] = np.random.default_rng(c * 100003 + k).uniform(-1e-3, 1e-3, (n, n)).astype(np.float32)
+                arr[k] = init_plane(c, k, n)
             eng.set_field(c, arr)
         import torch
         eng.run(10)
@@ -290,6 +306,9 @@ def secondary_workload(HipEngine, L, n, workload, device, args, steps=40, repeat
                 # of those: pairs whose shell (CPML slabs + collar) went out as shell2_step_kernel launches — two steps per sweep with
                 # psi carried — instead of two single steps (round 5)
                 "shell2_pairs_in_10_steps": int(getattr(st, "shell2_pairs", 0)),
+                # pairs that advanced the dispersive (ADE) cells themselves: the sweep subtracts their paged memory terms, ade2_kernel
+                # follows it (round 6; without it the planes of a dispersive body take single steps)
+                "disp_pairs_in_10_steps": int(getattr(st, "disp_pairs", 0)),
                 "bytes_per_cell_own_minimum": own,
                 "whole_step_frac": own * cells * steps / el / HBM_PEAK,
                 "bytes_per_cell_survey_8d": survey,
@@ -358,7 +377,9 @@ def main():
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
-    n, K, W = args.n, args.steps, args.warmup
+    n, K_asked, W = args.n, args.steps, args.warmup
+    # timed regions of at least MIN_TIMED_STEPS steps: a caller that asks for fewer gets that many, and the line says so
+    K = max(K_asked, MIN_TIMED_STEPS) if not os.environ.get("BENCH_EMULATE") else K_asked
     spec = build_spec(n, K + W + 64, args.workload)
     slabs = split_slabs(n, world)
     eng = HipEngine(spec, lib=lib, device=local_rank, variant=args.variant, z_chunk=args.zchunk,
@@ -386,7 +407,7 @@ def main():
         # generate only this slab's planes, reproducibly: one generator per (component, plane)
         arr = np.empty((z1 - z0, n, n), dtype=np.float32)
         for k in range(z0, z1):
-            arr[k - z0] = np.random.default_rng(c * 100003 + k).uniform(-1e-3, 1e-3, (n, n)).astype(np.float32)
+            arr[k - z0] = init_plane(c, k, n)
         eng.set_field(c, arr)
 
     def dev_sync():
@@ -436,7 +457,7 @@ def main():
     local_cells = (z1 - z0) * n * n
     out = {
         "metric": "Mcells/s on 512^3 Yee grid", "value": value, "unit": "Mcells/s",
-        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
+        "n_gpus": world, "steps": K, "steps_requested": K_asked, "warmup": W, "ms_per_step": elapsed / K * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]}; {n}^3 Yee cells, Ez point dipole "
@@ -485,11 +506,11 @@ def main():
         # the two-step kernel, and what every run outside its scope still gets
         eng.set_option(L.OPT_TWOSTEP, 0)
         eng.run(10)
-        ss = [timed(40) for _ in range(3)]
+        ss = [timed(MIN_TIMED_STEPS) for _ in range(3)]
         eng.set_option(L.OPT_TWOSTEP, -1)
         el1 = float(np.median(ss))
-        out["single_steps"] = {"value": cells * 40 / el1 / 1e6, "unit": "Mcells/s", "ms_per_step": el1 / 40 * 1e3,
-                               "steps": 40, "repeats": 3, "kernel": "fused_step_kernel"}
+        out["single_steps"] = {"value": cells * MIN_TIMED_STEPS / el1 / 1e6, "unit": "Mcells/s", "ms_per_step": el1 / MIN_TIMED_STEPS * 1e3,
+                               "steps": MIN_TIMED_STEPS, "repeats": 3, "kernel": "fused_step_kernel"}
     if world == 1 and not emulate and args.workload == "v0" and not args.no_workloads:
         # the workload every real simulation resembles (materials + CPML on all faces), same grid, same box
         eng.close()
@@ -498,7 +519,11 @@ def main():
                             # materials inside PEC walls: the two-step sweep's materials instantiation
                             "v1": secondary_workload(HipEngine, L, n, "v1", local_rank, args),
                             # an open problem without CPML: Absorber boundaries, damped inside the two-step sweep
-                            "va": secondary_workload(HipEngine, L, n, "va", local_rank, args)}
+                            "va": secondary_workload(HipEngine, L, n, "va", local_rank, args),
+                            # + a Lorentz pole in the sphere — K4 (ADE) inside the step pairs since round 6
+                            "v3": secondary_workload(HipEngine, L, n, "v3", local_rank, args),
+                            # + a closed flux box with a running DFT at three frequencies — K6 inside the pairs
+                            "v4": secondary_workload(HipEngine, L, n, "v4", local_rank, args)}
 
     if args.sweep and world == 1 and eng is not None:
         res = []

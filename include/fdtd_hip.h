@@ -91,7 +91,11 @@ typedef struct FdtdStats {
                                 recursions carried through both — instead of two single steps (FDTD_OPT_SHELL2) */
   int32_t fused2_off_reason; /* why the last fdtd_run took NO step pairs: FDTD_F2_OFF_* (0 = it took some, or had no chance to: < 2 steps) */
   int32_t struct_bytes;      /* sizeof(FdtdStats) of the library that filled this in (a binding checks it against its own layout) */
-  int64_t disp_pairs;        /* of fused2_pairs: pairs whose sweep advanced the dispersive (ADE) cells itself (FDTD_OPT_DISP; round 6) */
+  int64_t disp_pairs;        /* of fused2_pairs: pairs that advanced the dispersive (ADE) cells themselves (FDTD_OPT_DISP; round 6) */
+  int32_t single_step_reason;/* a run that took pairs AND single steps: the last FDTD_F2_OFF_* that kept a step from opening a pair because of its
+                                sources (a TFSF box / mode plane while it injects ...); 0 = none (single steps then are record / decay-check /
+                                odd-count steps) */
+  int32_t reserved1;
 } FdtdStats;
 
 /* FdtdStats.fused2_off_reason: what keeps a run on single steps (the first reason found) */
@@ -315,6 +319,8 @@ enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_R
                               step pairs, and single steps update them there too.  -1 / 1 = default (on one GPU, where the packed medium words
                               name the ADE group of every dispersive cell), 0 = off: the planes of dispersive cells are z holes of the bulk
                               (single steps, round 5).  Set it before the first fdtd_run. */
+       FDTD_OPT_WHATIF = 24, /* measuring aid (round 6): 1 ... 8 = a what-if instantiation of the vacuum two-step sweep that skips part of its work
+                                (csrc/fdtd_kernels2.hpp lists them) — WRONG results, meaningful times; 0 = off (default) */
        FDTD_OPT_LDS_PAD = 10 /* measuring aid: extra dynamic LDS per workgroup of the sweep in bytes (lowers its occupancy) */ };
 int fdtd_set_option(FdtdSolver* h, int key, int value);
 int fdtd_reset(FdtdSolver* h);      /* zero fields, auxiliaries, monitors and the step counter */

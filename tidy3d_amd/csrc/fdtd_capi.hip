@@ -184,6 +184,7 @@ struct FdtdSolver {
   bool has_damp = false;
   std::vector<AdeGroup> ade;
   Disp disp;
+  int whatif = 0;                    // FDTD_OPT_WHATIF: a what-if instantiation of the vacuum two-step sweep (fdtd_kernels2.hpp; wrong results, meaningful times)
   int disp_on = -1;                  // FDTD_OPT_DISP: dispersive cells inside the two-step sweeps: -1 = default (on), 0 = off (their planes as z holes, round 5)
   std::vector<AnisoGroup> aniso;
   std::vector<PointSrc> psrc;
@@ -1219,8 +1220,9 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
   const MatP mp = mat_params(h);
   DispP dp{nullptr, nullptr, nullptr};
   if (use_disp) dp = DispP{h->disp.dseg, h->disp.cs, h->disp.e1};
-  const int opt = (h->mem_hints ? 1 : 0) | (h->mat4 ? 2 : 0) | ((tb->mons.empty() && (!tb->with_sources || h->src_h_nodes == 0) && !tb->dstart) ? 0 : 4) |
-                  (clip ? 16 : (h->has_damp ? 8 : 0)) | (use_disp ? 32 | 1 : 0);
+  int opt = (h->mem_hints ? 1 : 0) | (h->mat4 ? 2 : 0) | ((tb->mons.empty() && (!tb->with_sources || h->src_h_nodes == 0) && !tb->dstart) ? 0 : 4) |
+            (clip ? 16 : (h->has_damp ? 8 : 0)) | (use_disp ? 32 | 1 : 0);
+  if (h->whatif > 0 && opt == 1 && W == 16) opt |= h->whatif << 8;        // (measuring aid: the vacuum sweep with part of its work skipped)
   const int blocks = remap ? ((total + 7) / 8) * 8 : total;
   // background-only tiles take the plain sweep inside the materials launch (fdtd_kernels2.hpp, tile classes)
   const FdtdSolver::TileClasses* tc = tile_classes(h, W, zc, box, nbx, nby, nbz, use_disp);
@@ -4357,6 +4359,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_SHELL2: h->shell2_on = value < 0 ? -1 : (value > 3 ? 1 : value); return 0;
     case FDTD_OPT_DEBUG_SYNC: h->debug_sync = value != 0; return 0;
     case FDTD_OPT_TILE_SPLIT: h->tile_split = value < 0 ? -1 : (value != 0); return 0;
+    case FDTD_OPT_WHATIF: if (value < 0 || value > 8) break; h->whatif = value; return 0;
     case FDTD_OPT_DISP:
       if (h->disp.state == 1 && value == 0) break;       // (every ADE launch keeps the paged memory terms by now: set it before the first run)
       h->disp_on = value < 0 ? -1 : (value != 0);
@@ -4400,6 +4403,8 @@ int fdtd_get_stats(FdtdSolver* h, FdtdStats* out) {
   out->shell2_pairs = h->shell2_pairs;
   out->fused2_off_reason = h->fused2_pairs ? 0 : (h->f2_off_reason ? h->f2_off_reason : h->f2_dyn_reason);
   out->disp_pairs = h->disp.pairs;
+  out->single_step_reason = h->f2_dyn_reason;
+  out->reserved1 = 0;
   out->struct_bytes = (int32_t)sizeof(FdtdStats);
   return 0;
 }

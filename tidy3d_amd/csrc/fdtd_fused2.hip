@@ -22,6 +22,10 @@ void launch_inject_values(hipStream_t st, float* val, const float* w_re, const f
 void launch_fused2_step(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
                         const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,
                         int xcd_remap, const InjP& inj, float* seam, const DampT& dmp, const ClipP& clip, const TileClassP& tcl, const DispP& dp) {
+  if (opt >> 8) {
+    launch_fused2_step_whatif(st, waves, opt, grid_blocks, g, a, b, s, m, zchunk, nbx, nby, nbz, xcd_remap, inj, seam, dmp, clip);
+    return;
+  }
   if (opt & 32) {
     launch_fused2_step_disp(st, waves, opt, grid_blocks, g, a, b, s, m, zchunk, nbx, nby, nbz, xcd_remap, inj, seam, dmp, clip, tcl, dp);
     return;

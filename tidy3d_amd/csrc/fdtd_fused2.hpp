@@ -68,6 +68,10 @@ void launch_fused2_step(hipStream_t st, int waves, int opt, int grid_blocks, con
                         const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,
                         int xcd_remap, const InjP& inj, float* seam, const DampT& dmp, const ClipP& clip, const TileClassP& tcl = TileClassP{nullptr},
                         const DispP& dp = DispP{nullptr, nullptr, nullptr});
+// what-if instantiations (opt >> 8 = 1 ... 8 on top of opt = 1, 16 waves): fdtd_fused2w.hip
+void launch_fused2_step_whatif(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
+                               const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,
+                               int xcd_remap, const InjP& inj, float* seam, const DampT& dmp, const ClipP& clip);
 // the instantiations that carry dispersive cells live in their own translation unit too (fdtd_fused2d.hip)
 void launch_fused2_step_disp(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
                              const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,

@@ -28,9 +28,13 @@
 // and wrap a periodic x axis inside the sweep.  Everything else takes single steps.
 #pragma once
 #include "fdtd_fused2.hpp"
-#ifndef FDTD_WHATIF
-#define FDTD_WHATIF 0     // 1 / 2 / 3: measuring builds of profiles/r5 (scripts/whatif_builds.sh) that skip work to bound what an optimisation could gain; never shipped
-#endif
+// WHAT-IF instantiations (OPT bits 8 - 11; FDTD_OPT_WHATIF, fdtd_fused2w.hip): measuring aids that SKIP part of the work — their
+// results are wrong, their times say where the sweep's time goes and bound what an optimisation could gain.  Switched inside one
+// engine (same allocations, same clocks: the only A/B this part resolves), vacuum instantiation only:
+//   1  E_y / H_y of a plane not loaded            2  no second barrier per plane        3  the three halo rows load nothing
+//   4  every plane load reads the same (cached) row: no HBM reads, same instructions    5  no field stores
+//   6  no barriers and no LDS exchange (own values instead of the neighbour rows')      7  loads + stores only (the copy floor of this tiling)
+//   8  no barriers, LDS traffic kept
 
 namespace fdtd {
 
@@ -164,6 +168,7 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
   // launch) and leaves E^{n+1} of the rows it owns in DispP::e1; ade2_kernel behind the sweep forms Q^{n+1} from it, corrects
   // E^{n+2} and forms Q^{n+2} — ade_kernel's operations in its order, twice.
   constexpr bool DISP = (OPT & 32) != 0;
+  constexpr int WHATIF = (OPT >> 8) & 15;
   constexpr bool DAMP = (OPT & 8) != 0;   // absorber layers: both fields of both steps are damped in registers (damp_kernel's factors)
   // CLIP: the launch covers the box `clip` only — the bulk of a grid whose shell (CPML slabs + a two-cell collar, the boundary
   // planes of a z-slab rank) is advanced by single steps beside it.  Tile rows and chunks start at the box's origin, nothing is
@@ -212,7 +217,8 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
   int j = (CLIP ? clip.j0 : 0) + tile_y * R + ty - 2;
   const bool row_ok = (j >= 0) && (j < g.ny);
   if (!row_ok) {                          // takes part in the barriers only
-    for (int k = kA; k <= k1; ++k) { __syncthreads(); __syncthreads(); }
+    if constexpr (WHATIF != 6 && WHATIF != 7 && WHATIF != 8)
+      for (int k = kA; k <= k1; ++k) { __syncthreads(); if constexpr (WHATIF != 2) __syncthreads(); }
     return;
   }
   const int i0 = (tile_x * 64 + tx) * V;
@@ -306,27 +312,25 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
     float exn_m, ez_mm, ey_mm, ex_jm, hy_o, hz_o;        // column i0 - 1 (first lane of a tile with a left neighbour)
   };
   auto issue = [&](int k, Ld& L) __attribute__((always_inline)) {
-#if FDTD_WHATIF == 3      // (what-if build: the three halo rows of a workgroup cost no loads — the upper bound of sharing them with the neighbouring workgroups)
-    if (ty < 2 || ty == W - 1) {
-      zero<V>(L.exn); zero<V>(L.eyn); zero<V>(L.ezk); zero<V>(L.exj); zero<V>(L.ezj); zero<V>(L.hxn); zero<V>(L.hyn); zero<V>(L.hzn);
-      L.eyx_g = L.ezx_g = L.exn_m = L.ez_mm = L.ey_mm = L.ex_jm = L.hy_o = L.hz_o = 0.f;
-      return;
+    if constexpr (WHATIF == 3) {      // (the three halo rows of a workgroup cost no loads — the upper bound of sharing them with the neighbouring workgroups)
+      if (ty < 2 || ty == W - 1) {
+        zero<V>(L.exn); zero<V>(L.eyn); zero<V>(L.ezk); zero<V>(L.exj); zero<V>(L.ezj); zero<V>(L.hxn); zero<V>(L.hyn); zero<V>(L.hzn);
+        L.eyx_g = L.ezx_g = L.exn_m = L.ez_mm = L.ey_mm = L.ex_jm = L.hy_o = L.hz_o = 0.f;
+        return;
+      }
     }
-#endif
     const int txo = (MAT || DAMP) ? tx : opaque_lane(tx);       // (the materials / absorber instantiations have no VGPR to spare for the re-derivation)
     const int i0o = (tile_x * 64 + txo) * V;
     const bool act = i0o < g.nx, last_x = i0o + V >= g.nx, first_x = i0o == 0;
     const bool xh = act && txo == 0 && (!first_x || per_x);
     [[maybe_unused]] const bool wall_x0 = first_x && !pmc_x0 && !per_x;
-    const long long pb = (long long)k * g.sxy + rowb;
-    const long long pjb = (long long)k * g.sxy + rowpb;
-    const long long up = (k < g.nz) ? g.sxy : 0;         // (iteration nz only needs E1_{x,y}[nz] = 0: it reads the ghost plane twice)
+    // (WHATIF 4: every plane reads plane (k & 1), row 0 — the same instructions, all of them cache hits)
+    const long long pb = WHATIF == 4 ? (long long)(k & 1) * g.sxy : (long long)k * g.sxy + rowb;
+    const long long pjb = WHATIF == 4 ? (long long)(k & 1) * g.sxy + g.nx : (long long)k * g.sxy + rowpb;
+    const long long up = WHATIF == 4 ? 0 : ((k < g.nz) ? g.sxy : 0);         // (iteration nz only needs E1_{x,y}[nz] = 0: it reads the ghost plane twice)
     ldf<V, true>(L.exn, uni(a.ex + pb + up), ubc);
-#if FDTD_WHATIF == 1      // (what-if build, scripts/whatif_builds.sh: E_y / H_y not loaded at all — the upper bound of prefetching them; results are wrong)
-    zero<V>(L.eyn);
-#else
-    ldf<V, true>(L.eyn, uni(a.ey + pb + up), ubc);
-#endif
+    if constexpr (WHATIF == 1) zero<V>(L.eyn);      // (E_y / H_y not loaded at all — the upper bound of prefetching them)
+    else ldf<V, true>(L.eyn, uni(a.ey + pb + up), ubc);
     ldf<V, true>(L.ezk, uni(a.ez + pb), ubc);
     if (use_jp) {
       ldf<V, true>(L.exj, uni(a.ex + pjb), ubc);
@@ -335,11 +339,8 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
       zero<V>(L.exj); zero<V>(L.ezj);
     }
     ldf<V, true>(L.hxn, uni(a.hx + pb), ubc);
-#if FDTD_WHATIF == 1
-    zero<V>(L.hyn);
-#else
-    ldf<V, true>(L.hyn, uni(a.hy + pb), ubc);
-#endif
+    if constexpr (WHATIF == 1) zero<V>(L.hyn);
+    else ldf<V, true>(L.hyn, uni(a.hy + pb), ubc);
     ldf<V, true>(L.hzn, uni(a.hz + pb), ubc);
     L.eyx_g = 0.f; L.ezx_g = 0.f;
     if (act && txo == 63 && !last_x) { L.eyx_g = a.ey[pb + ux + V]; L.ezx_g = a.ez[pb + ux + V]; }
@@ -386,6 +387,18 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
     if constexpr (DISP) {
       if (do_e1 && k < g.nz) ds = dp.dseg[((long long)k * g.ny + j) * nbx + tile_x];
     }
+    if constexpr (WHATIF == 7) {          // loads + stores only: every array of the plane read as the sweep reads it, six written
+      issue(k, L);
+      if (own && k > k0 && act) {
+        const long long po = pb - g.sxy + i0;
+        float o0[V], o1[V], o2[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) { o0[e] = L.exn[e] + L.exj[e]; o1[e] = L.ezk[e] + L.ezj[e]; o2[e] = L.eyn[e]; }
+        stv_h<V, NT>(b.ex + po, o0); stv_h<V, NT>(b.ey + po, o2); stv_h<V, NT>(b.ez + po, o1);
+        stv_h<V, NT>(b.hx + po, L.hxn); stv_h<V, NT>(b.hy + po, L.hyn); stv_h<V, NT>(b.hz + po, L.hzn);
+      }
+      return;
+    }
     {
       issue(k, L);
       float eyx = lane_next(eyk[0]);
@@ -425,14 +438,14 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
         hz_m = upd_h(L.hz_o, ch, eyk[0] - L.ey_mm, ipx_m, L.ex_jm - exk_m, ipy);
       }
     }
-    {
+    if constexpr (WHATIF != 6) {
       float4 t4;
       t4.x = hxn[0]; t4.y = hxn[1]; t4.z = hxn[2]; t4.w = hxn[3];
       xch[0 * slot + me] = t4;
       t4.x = hzn[0]; t4.y = hzn[1]; t4.z = hzn[2]; t4.w = hzn[3];
       xch[1 * slot + me] = t4;
     }
-    __syncthreads();
+    if constexpr (WHATIF != 6 && WHATIF != 8) __syncthreads();
     // ---- S2: E1[k] ----
     float e1xn[V], e1yn[V], e1zn[V];
     unspecified<V>(e1xn); unspecified<V>(e1yn); unspecified<V>(e1zn);     // (row j0-2: nobody reads its E1)
@@ -446,7 +459,10 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
           else { hyx = 0.f; hzx = 0.f; }
         }
         float hxj[V], hzj[V];
-        if (j > 0) {
+        if (WHATIF == 6) {                    // (no LDS exchange: the row's own values stand in for the row below)
+#pragma unroll
+          for (int e = 0; e < V; ++e) { hxj[e] = hxn[e]; hzj[e] = hzn[e]; }
+        } else if (j > 0) {
           const float4 t0 = xch[0 * slot + me - 64];
           const float4 t1 = xch[1 * slot + me - 64];
           hxj[0] = t0.x; hxj[1] = t0.y; hxj[2] = t0.z; hxj[3] = t0.w;
@@ -665,8 +681,13 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
       float eyx = lane_next(e1y[0]);
       float ezx = lane_next(e1z[0]);
       if (txo == 63 || last_x) { eyx = 0.f; ezx = 0.f; }      // the wall, or a seam (repaired by seam_kernel)
-      const float4 t0 = xch[(4 + (cur ^ 1) * 2 + 0) * slot + me + 64];
-      const float4 t1 = xch[(4 + (cur ^ 1) * 2 + 1) * slot + me + 64];
+      float4 t0, t1;
+      if constexpr (WHATIF == 6) {
+        t0 = make_float4(e1x[0], e1x[1], e1x[2], e1x[3]); t1 = make_float4(e1z[0], e1z[1], e1z[2], e1z[3]);
+      } else {
+        t0 = xch[(4 + (cur ^ 1) * 2 + 0) * slot + me + 64];
+        t1 = xch[(4 + (cur ^ 1) * 2 + 1) * slot + me + 64];
+      }
       const float exj1[V] = {t0.x, t0.y, t0.z, t0.w}, ezj1[V] = {t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
       for (int e = 0; e < V; ++e) {
@@ -692,7 +713,7 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
         }
       }
     }
-    {
+    if constexpr (WHATIF != 6) {
       float4 t4;
       t4.x = e1xn[0]; t4.y = e1xn[1]; t4.z = e1xn[2]; t4.w = e1xn[3];
       xch[(4 + cur * 2 + 0) * slot + me] = t4;
@@ -703,9 +724,7 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
       t4.x = h2z[0]; t4.y = h2z[1]; t4.z = h2z[2]; t4.w = h2z[3];
       xch[3 * slot + me] = t4;
     }
-#if FDTD_WHATIF != 2      // (what-if build 2: no second barrier — the upper bound of a one-barrier pipeline; results are wrong)
-    __syncthreads();
-#endif
+    if constexpr (WHATIF != 2 && WHATIF != 6 && WHATIF != 8) __syncthreads();      // (2: no second barrier — the upper bound of a one-barrier pipeline)
     // ---- S4: E2[k-1] ----
     if (own && k > k0) {
       float hyx = lane_prev(h2y[V - 1]);
@@ -715,7 +734,10 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
         else { hyx = 0.f; hzx = 0.f; }
       }
       float hxj[V], hzj[V];
-      if (j > 0) {
+      if (WHATIF == 6) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) { hxj[e] = h2x[e]; hzj[e] = h2z[e]; }
+      } else if (j > 0) {
         const float4 t0 = xch[2 * slot + me - 64];
         const float4 t1 = xch[3 * slot + me - 64];
         hxj[0] = t0.x; hxj[1] = t0.y; hxj[2] = t0.z; hxj[3] = t0.w;
@@ -813,12 +835,14 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
           sq[12 * seam_arr - kSeamArrays * seam_arr] = h2z[0];
         }
         const long long po = pb - g.sxy + i0;
-        stv_h<V, NT>(b.hx + po, h2x);
-        stv_h<V, NT>(b.hy + po, h2y);
-        stv_h<V, NT>(b.hz + po, h2z);
-        stv_h<V, NT>(b.ex + po, ex);
-        stv_h<V, NT>(b.ey + po, ey);
-        stv_h<V, NT>(b.ez + po, ez);
+        if (WHATIF != 5 || ex[0] == 3.0e38f) {          // (5: no field stores — the condition keeps what leads to them alive)
+          stv_h<V, NT>(b.hx + po, h2x);
+          stv_h<V, NT>(b.hy + po, h2y);
+          stv_h<V, NT>(b.hz + po, h2z);
+          stv_h<V, NT>(b.ex + po, ex);
+          stv_h<V, NT>(b.ey + po, ey);
+          stv_h<V, NT>(b.ez + po, ez);
+        }
       }
     }
 #pragma unroll
