@@ -172,14 +172,29 @@ def test_dispersive_cells_deep_inside_the_bulk_of_shell2_pairs(N, w, zc, shell2,
     same(ref, got)
 
 
-def test_dispersive_cells_inside_the_layers_keep_the_z_holes(emu_lib):
-    """a Lorentz bar running into the x layers: not every dispersive cell is deep inside the bulk — the planes of the bar stay z holes
-    of the bulk (round 5), no sweep subtracts memory terms; the same bits"""
-    N = (48, 26, 40)
-    structures = [td.Structure(geometry=td.Box(center=(0, 0, 0), size=(td.inf, 0.2, 0.2)), medium=LOR)]
-    disc = discretize(sim_for(N, bspec=PML, structures=structures, inner=0.5), n_steps=26)
+@pytest.mark.parametrize("N,w,zc,bspec", [((48, 26, 40), 5, 3, PML), ((300, 24, 22), 6, 4, PML), ((100, 23, 19), 8, 5, "periodic_x"),
+                                          ((48, 26, 24), 16, 32, "odd")])
+def test_dispersive_cells_inside_the_layers(N, w, zc, bspec, emu_lib):
+    """a Lorentz bar running through the x layers, a Drude slab through the y layers, a three-pole block in a corner of the shell: the
+    shell's boxes (shell2_step_kernel) subtract the paged memory terms as the bulk sweep does, ade2_kernel follows both; a periodic x
+    (the boxes' halo lanes hold the wrapped columns); odd layer counts, a PEC z-min wall"""
+    if bspec == "periodic_x":
+        bspec = td.BoundarySpec(x=td.Boundary.periodic(), y=td.Boundary.pml(num_layers=3), z=td.Boundary.pml(num_layers=4))
+    elif bspec == "odd":
+        bspec = td.BoundarySpec(x=td.Boundary(minus=td.PML(num_layers=5), plus=td.PML(num_layers=3)), y=td.Boundary(minus=td.PML(num_layers=2), plus=td.PML(num_layers=4)),
+                                z=td.Boundary(minus=td.PECBoundary(), plus=td.PML(num_layers=3)))
+    sx, sy, sz = ((n - 1e-6) * DL for n in N)
+    structures = [td.Structure(geometry=td.Box(center=(0, 0, 0), size=(td.inf, 0.2, 0.2)), medium=LOR),
+                  td.Structure(geometry=td.Box(center=(0.1, 0, 0.3), size=(0.3, td.inf, 0.15)), medium=DRU),
+                  td.Structure(geometry=td.Box(center=(0.5 * sx, 0.5 * sy, 0.5 * sz), size=(0.5, 0.5, 0.5)), medium=LOR3),
+                  td.Structure(geometry=td.Sphere(center=(-0.2, 0.1, -0.2), radius=0.15), medium=td.Medium(permittivity=2.5))]
+    mons = [td.FieldMonitor(center=(0, 0, 0), size=(td.inf, td.inf, 0), freqs=[3e14], name="f", colocate=False)]
+    disc = discretize(sim_for(N, bspec=bspec, structures=structures, monitors=mons, inner=0.5), n_steps=26)
     disc.spec.decay_every = 0
     ref = run(disc.spec, emu_lib, 0, shell2=1, seed=5)
-    got = run(disc.spec, emu_lib, 5 + 64 * 3, shell2=1, seed=5)
-    assert ref[2] == 0 and got[2] > 0 and got[3] == 0, got[2:]
+    got = run(disc.spec, emu_lib, w + 64 * zc, shell2=1, seed=5)
+    assert ref[2] == 0 and got[2] == 12 and got[3] == 12 and got[4] == 12, got[2:]
     same(ref, got)
+    off = run(disc.spec, emu_lib, w + 64 * zc, shell2=1, seed=5, disp=0)        # the round-5 form: the bodies' planes as z holes — here: every plane
+    assert off[3] == 0
+    same(ref, off)

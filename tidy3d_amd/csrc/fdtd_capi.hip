@@ -1554,7 +1554,8 @@ void shell2_shape(const FdtdSolver* h, const Shell2Box& bx, int W, int zc_cap, S
 // per instantiation — x / y / z only at three waves per SIMD for 94 % of the cells, all axes for the edges and corners — lost
 // more to the four half-empty launches than the third wave bought (0.84 ms, profiles/r5/r5f).  shell2_on = 2 / 3: one launch per
 // instantiation / per box (measuring aids).
-void launch_shell2_boxes(FdtdSolver* h, const Shell2Box* bx, int n, const PmlP* pm, hipStream_t st, const F2Table* tb) {
+void launch_shell2_boxes(FdtdSolver* h, const Shell2Box* bx, int n, const PmlP* pm, hipStream_t st, const F2Table* tb, bool use_disp = false) {
+  const DispP dp = use_disp ? DispP{h->disp.dseg, h->disp.cs, h->disp.e1} : DispP{nullptr, nullptr, nullptr};
   // (the DFT monitors of the pair's plan that reach into the shell: the boxes copy the middle step out over them; the dump buffer was sized by launch_fused2)
   Shell2Dump dmp{};
   if (tb && tb->dstart && h->dump_buf) { dmp.dstart = tb->dstart; dmp.dlist = tb->dlist; dmp.dboxes = tb->dboxes; dmp.dump = h->dump_buf; }
@@ -1566,7 +1567,7 @@ void launch_shell2_boxes(FdtdSolver* h, const Shell2Box* bx, int n, const PmlP* 
     auto flush = [&]() {
       if (mb.n == 0) return;
       time_begin(h, 3, st);
-      launch_shell2_step(st, W, h->mat4 != nullptr, axes, h->g, h->f, h->f2, step_params(h), mat_params(h), pm, mb, dmp);
+      launch_shell2_step(st, W, h->mat4 != nullptr, axes, h->g, h->f, h->f2, step_params(h), mat_params(h), pm, mb, dmp, dp);
       time_end(h, st);
       mb = Shell2M{};
     };
@@ -3470,7 +3471,9 @@ struct Run {
         h->f2_off_reason = 0;
         // the bulk's planes: one interval, or — dispersive cells — the intervals between their planes (z holes, inside the bulk's range)
         zp_s2 = ZPlan{};
-        s2_disp = !h->ade.empty() && disp_inside(h, sg.o0, sg.o1, 3);
+        // (round 6: the pair advances the dispersive cells itself — the bulk sweep and the shell's boxes subtract their paged memory
+        //  terms, ade2_kernel follows; not beside the single steps of a periodic y's wrap rows, not with the measuring-aid box cuts)
+        s2_disp = !h->ade.empty() && h->disp.state == 1 && h->cfg.bc[2] != FDTD_BC_PERIODIC && h->shell2_on != 2 && h->shell2_on != 3;
         if (h->ade.empty() || s2_disp) { zp_s2.n = 1; zp_s2.a[0] = sg.o0[2]; zp_s2.b[0] = sg.o1[2]; zp_s2.ok = true; }
         else if (zplan_build(h, sg, false, &zp_s2) && zp_s2.a[0] == sg.o0[2] && zp_s2.b[zp_s2.n - 1] == sg.o1[2]) zp_s2.ok = true;
         if (!zp_s2.ok) { s2_ok = false; s2_disp = false; h->f2_off_reason = why_r4; }       // (the round-4 form may still take the run)
@@ -3621,9 +3624,9 @@ struct Run {
     // beside the shell's boxes, once nothing else is due on E^{n+2} there — else at the end, behind the sources of step n + 1
     bool src_due = false;
     for (const PointSrc& sr : h->psrc) src_due = src_due || (sr.n_e && n + 1 < sr.n_steps);
-    const bool ade2_early = pair_disp && (s2 || !src_due);
+    const bool ade2_early = pair_disp && (s2 || !src_due) && disp_inside(h, sg.o0, sg.o1, 0);
     if (ade2_early) launch_ade2(h, st, &B);
-    launch_shell2_boxes(h, boxes, nb, h->pml_blk2[hp][ep], cs, tb);
+    launch_shell2_boxes(h, boxes, nb, h->pml_blk2[hp][ep], cs, tb, pair_disp);
     if (holes || per_y) {
       const int pml_in = 7 & pml_in_sweep_mask(h);
       ShellSets s1{A, T, hp, 0, 0, h->pml_blk_hole[0][hp][ep]}, s2h{T, B, hp, 0, 0, h->pml_blk_hole[1][hp][ep]};

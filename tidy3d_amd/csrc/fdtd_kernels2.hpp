@@ -571,7 +571,10 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
             ldv<V>(cx, dp.cs + qb); ldv<V>(cy, dp.cs + qb + 256); ldv<V>(cz, dp.cs + qb + 512);
 #pragma unroll
             for (int e = 0; e < V; ++e) { e1xn[e] = e1xn[e] - cx[e]; e1yn[e] = e1yn[e] - cy[e]; e1zn[e] = e1zn[e] - cz[e]; }
-            if (own && k >= k0 && k < k1) { stv<V>(dp.e1 + qb, e1xn); stv<V>(dp.e1 + qb + 256, e1yn); stv<V>(dp.e1 + qb + 512, e1zn); }
+            // (a clipped launch: the columns outside its box belong to the shell's boxes, which leave their own E^{n+1} there)
+            if (own && k >= k0 && k < k1 && (!CLIP || (i0o >= clip.i0 && i0o < clip.i1))) {
+              stv<V>(dp.e1 + qb, e1xn); stv<V>(dp.e1 + qb + 256, e1yn); stv<V>(dp.e1 + qb + 512, e1zn);
+            }
           }
           if constexpr (MON) {                 // small time monitors: their E samples of the middle step, behind everything
             if (own && k >= k0 && k < k1) {

@@ -39,7 +39,7 @@ namespace fdtd {
 // rows / lanes / planes then lie off them too (the collar) — runs an instantiation without that axis' 32 psi registers
 template <bool MAT, int AXES>
 __global__ __launch_bounds__(512, (AXES == 7 ? 2 : 3)) void shell2_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
-                                                          const PmlP* __restrict__ pmq, Shell2M boxes, Shell2Dump dmp) {
+                                                          const PmlP* __restrict__ pmq, Shell2M boxes, Shell2Dump dmp, DispP dp) {
   constexpr int V = 4;
   // ONE launch covers all boxes of the shell (the workgroups of box q are [first[q], first[q + 1])): six small launches one
   // behind the other on a stream left the machine half empty between them (profiles/r5)
@@ -395,6 +395,19 @@ __global__ __launch_bounds__(512, (AXES == 7 ? 2 : 3)) void shell2_step_kernel(G
         }
       }
       if (!row_ok) { zero<V>(e1xn); zero<V>(e1zn); }      // rows beyond the grid publish E = 0 (the wall)
+      // dispersive cells inside the shell (round 6, as fused2_step_kernel's OPT bit 5): E^{n+1} <- E^{n+1} - cc S(Q^n) from the paged
+      // memory terms, last of all; the lane that owns the cells leaves E^{n+1} for ade2_kernel
+      if (dp.dseg && act && in_z) {
+        const int ds = dp.dseg[((long long)k * g.ny + j) * ((g.nx + 255) >> 8) + (i0 >> 8)];
+        if (ds >= 0) {
+          const long long qb = ((long long)ds * 3) * 256 + (i0 & 255);
+          float cx[V], cy[V], cz[V];
+          ldv<V>(cx, dp.cs + qb); ldv<V>(cy, dp.cs + qb + 256); ldv<V>(cz, dp.cs + qb + 512);
+#pragma unroll
+          for (int e = 0; e < V; ++e) { e1xn[e] = e1xn[e] - cx[e]; e1yn[e] = e1yn[e] - cy[e]; e1zn[e] = e1zn[e] - cz[e]; }
+          if (st_lane && k >= kc0 && k < kc1) { stv<V>(dp.e1 + qb, e1xn); stv<V>(dp.e1 + qb + 256, e1yn); stv<V>(dp.e1 + qb + 512, e1zn); }
+        }
+      }
       // the middle step over the boxes of DFT monitors that reach into the shell (fused2_step_kernel does the same over the bulk):
       // H^{n+1/2} for records at step n, E^{n+1} for records at step n + 1 — of the cells this box owns
       if (dmp.dstart && st_lane && k >= kc0 && k < kc1) {

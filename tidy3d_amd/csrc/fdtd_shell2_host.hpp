@@ -33,6 +33,7 @@ struct Shell2M {
 // host-side launcher (fdtd_shell2.hip): `waves` wavefronts per workgroup (<= 8); axes: the axes whose recursions the boxes can
 // meet (1, 2, 4: that axis only; anything else: all)
 void launch_shell2_step(hipStream_t st, int waves, bool mat, int axes, const GridP& g, const FieldP& a, const FieldP& b, const StepP& s,
-                        const MatP& m, const PmlP* pm, const Shell2M& boxes, const Shell2Dump& dmp);
+                        const MatP& m, const PmlP* pm, const Shell2M& boxes, const Shell2Dump& dmp,
+                        const DispP& dp = DispP{nullptr, nullptr, nullptr});
 
 }  // namespace fdtd
