@@ -117,7 +117,7 @@ def source_hash() -> str:
     PMC traffic figure to the kernel code it was measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("fdtd_kernels.hpp", "fdtd_kernels2.hpp", "fdtd_fused2.hip", "fdtd_fused2c.hip", "fdtd_fused2d.hip", "fdtd_strip.hpp", "fdtd_shell2.hpp", "fdtd_shell2.hip"):
+    for f in ("fdtd_kernels.hpp", "fdtd_kernels2.hpp", "fdtd_fused2.hip", "fdtd_fused2c.hip", "fdtd_fused2d.hip", "fdtd_fused2s.hip", "fdtd_strip.hpp", "fdtd_shell2.hpp", "fdtd_shell2.hip"):
         h.update(open(os.path.join(ROOT, "tidy3d_amd/csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -95,7 +95,7 @@ typedef struct FdtdStats {
   int32_t single_step_reason;/* a run that took pairs AND single steps: the last FDTD_F2_OFF_* that kept a step from opening a pair because of its
                                 sources (a TFSF box / mode plane while it injects ...); 0 = none (single steps then are record / decay-check /
                                 odd-count steps) */
-  int32_t reserved1;
+  int32_t src_paged_pairs;   /* of fused2_pairs: pairs that carried paged source terms (FDTD_OPT_SRC_PAGED; round 6) */
 } FdtdStats;
 
 /* FdtdStats.fused2_off_reason: what keeps a run on single steps (the first reason found) */
@@ -319,6 +319,11 @@ enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_R
                               step pairs, and single steps update them there too.  -1 / 1 = default (on one GPU, where the packed medium words
                               name the ADE group of every dispersive cell), 0 = off: the planes of dispersive cells are z holes of the bulk
                               (single steps, round 5).  Set it before the first fdtd_run. */
+       FDTD_OPT_SRC_PAGED = 25, /* step pairs WHILE a TFSF box, a mode plane, a current sheet or any list of more than 256 nodes injects (round 6):
+                                   in front of each pair list kernels leave what the lists add at steps n (E side), n + 1 (H side) and n + 1
+                                   (E side) in paged storage — one block per 256-cell row segment that holds a source node — and the
+                                   two-step sweep, its seam kernel and the shell's boxes add them.  -1 / 1 = default (on one GPU, where no
+                                   two lists meet on a node), 0 = off: single steps (or the lists' planes as z holes) while they inject. */
        FDTD_OPT_WHATIF = 24, /* measuring aid (round 6): 1 ... 8 = a what-if instantiation of the vacuum two-step sweep that skips part of its work
                                 (csrc/fdtd_kernels2.hpp lists them) — WRONG results, meaningful times; 0 = off (default) */
        FDTD_OPT_LDS_PAD = 10 /* measuring aid: extra dynamic LDS per workgroup of the sweep in bytes (lowers its occupancy) */ };

@@ -12,7 +12,7 @@ ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
 CSRC = os.path.join(ROOT, "tidy3d_amd", "csrc")
 LIB = os.path.join(HERE, "libfdtd_emu.so")
 DEPS = [os.path.join(CSRC, "fdtd_capi.hip"), os.path.join(CSRC, "fdtd_kernels.hpp"), os.path.join(CSRC, "fdtd_kernels2.hpp"), os.path.join(CSRC, "fdtd_fused2.hpp"), os.path.join(CSRC, "fdtd_fused2.hip"),
-        os.path.join(CSRC, "fdtd_fused2c.hip"), os.path.join(CSRC, "fdtd_fused2d.hip"), os.path.join(CSRC, "fdtd_fused2w.hip"), os.path.join(CSRC, "fdtd_shell2.hip"), os.path.join(CSRC, "fdtd_shell2.hpp"), os.path.join(CSRC, "fdtd_shell2_host.hpp"), os.path.join(CSRC, "fdtd_strip.hpp"), os.path.join(CSRC, "fdtd_aniso.hpp"),
+        os.path.join(CSRC, "fdtd_fused2c.hip"), os.path.join(CSRC, "fdtd_fused2d.hip"), os.path.join(CSRC, "fdtd_fused2w.hip"), os.path.join(CSRC, "fdtd_fused2s.hip"), os.path.join(CSRC, "fdtd_shell2.hip"), os.path.join(CSRC, "fdtd_shell2.hpp"), os.path.join(CSRC, "fdtd_shell2_host.hpp"), os.path.join(CSRC, "fdtd_strip.hpp"), os.path.join(CSRC, "fdtd_aniso.hpp"),
         os.path.join(ROOT, "include", "fdtd_hip.h"), os.path.join(HERE, "hip_emu.cpp"),
         os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "rccl", "rccl.h"),
         os.path.abspath(__file__)]
@@ -31,7 +31,7 @@ def build(force: bool = False) -> str:
     flags = [cxx, "-O2", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mfma", "-I" + HERE,
              "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-pass-failed"]
     srcs = [os.path.join(CSRC, "fdtd_capi.hip"), os.path.join(CSRC, "fdtd_fused2.hip"), os.path.join(CSRC, "fdtd_fused2c.hip"),
-            os.path.join(CSRC, "fdtd_fused2d.hip"), os.path.join(CSRC, "fdtd_fused2w.hip"), os.path.join(CSRC, "fdtd_shell2.hip"),
+            os.path.join(CSRC, "fdtd_fused2d.hip"), os.path.join(CSRC, "fdtd_fused2w.hip"), os.path.join(CSRC, "fdtd_fused2s.hip"), os.path.join(CSRC, "fdtd_shell2.hip"),
             os.path.join(HERE, "hip_emu.cpp")]
     tmp = tempfile.mkdtemp(prefix="fdtd_emu_")
     try:

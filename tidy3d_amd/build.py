@@ -10,9 +10,9 @@ import tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfdtd_hip.so")
-SOURCES = [os.path.join(CSRC, "fdtd_capi.hip"), os.path.join(CSRC, "fdtd_fused2.hip"), os.path.join(CSRC, "fdtd_fused2c.hip"), os.path.join(CSRC, "fdtd_fused2d.hip"), os.path.join(CSRC, "fdtd_fused2w.hip"), os.path.join(CSRC, "fdtd_shell2.hip")]
+SOURCES = [os.path.join(CSRC, "fdtd_capi.hip"), os.path.join(CSRC, "fdtd_fused2.hip"), os.path.join(CSRC, "fdtd_fused2c.hip"), os.path.join(CSRC, "fdtd_fused2d.hip"), os.path.join(CSRC, "fdtd_fused2w.hip"), os.path.join(CSRC, "fdtd_fused2s.hip"), os.path.join(CSRC, "fdtd_shell2.hip")]
 # per-source flags: the two-steps-per-sweep kernels are built with the SLP vectorizer off (fdtd_fused2.hpp)
-SOURCE_FLAGS = {"fdtd_fused2.hip": ["-fno-slp-vectorize"], "fdtd_fused2c.hip": ["-fno-slp-vectorize"], "fdtd_fused2d.hip": ["-fno-slp-vectorize"], "fdtd_fused2w.hip": ["-fno-slp-vectorize"],
+SOURCE_FLAGS = {"fdtd_fused2.hip": ["-fno-slp-vectorize"], "fdtd_fused2c.hip": ["-fno-slp-vectorize"], "fdtd_fused2d.hip": ["-fno-slp-vectorize"], "fdtd_fused2w.hip": ["-fno-slp-vectorize"], "fdtd_fused2s.hip": ["-fno-slp-vectorize"],
                 "fdtd_shell2.hip": ["-fno-slp-vectorize"]}
 DEPS = SOURCES + [os.path.join(CSRC, "fdtd_kernels.hpp"), os.path.join(CSRC, "fdtd_kernels2.hpp"),
                   os.path.join(CSRC, "fdtd_fused2.hpp"), os.path.join(CSRC, "fdtd_shell2.hpp"), os.path.join(CSRC, "fdtd_shell2_host.hpp"), os.path.join(CSRC, "fdtd_strip.hpp"), os.path.join(CSRC, "fdtd_aniso.hpp"),

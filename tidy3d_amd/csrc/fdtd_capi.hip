@@ -95,6 +95,7 @@ struct PointSrc {
   float2 *wave_e = nullptr, *wave_h = nullptr;
   long long n_steps = 0;
   int ke0 = 0, ke1 = 0, kh0 = 0, kh1 = 0;   // planes [k0, k1) that hold its E / H points
+  uint32_t *soff_e = nullptr, *soff_h = nullptr;   // slots of the nodes in the paged source terms (SrcPaged)
   std::vector<int32_t> host_comp_e, host_comp_h;   // host copies of the nodes (the two-step sweep applies them in-kernel)
   std::vector<uint32_t> host_cell_e, host_cell_h;
 };
@@ -106,6 +107,7 @@ struct TfsfList {
   int32_t *comp = nullptr, *start = nullptr, *aux = nullptr;
   uint32_t* cell = nullptr;
   float* w = nullptr;
+  uint32_t* soff = nullptr;        // slots of the target nodes in the paged source terms (SrcPaged)
 };
 
 struct Tfsf {
@@ -152,6 +154,18 @@ struct F2Plan {                    // one step pair: the monitors that record at
 
 }  // namespace
 
+// Paged source terms (round 6; fdtd_fused2.hpp SrcP): step pairs while a TFSF box, a mode plane, a current sheet — any list the
+// two-step sweep's node table cannot hold — injects.  In front of every such pair list kernels leave what the lists would add at steps
+// n (E side), n + 1 (H side) and n + 1 (E side) in three paged arrays; the sweep, the seam kernel and the shell's boxes add them.
+struct SrcPaged {
+  int state = 0;                   // 0 = not tried, 1 = ready, -1 = this problem cannot (two lists meet on a node, ...)
+  int n_blocks = 0;
+  int* sseg = nullptr;             // [nz][ny][nbx]
+  float *e1 = nullptr, *h2 = nullptr, *e2 = nullptr;     // [n_blocks][3][256]
+  bool any_h = false;              // a list has H-side nodes
+  long long pairs = 0;
+};
+
 struct FdtdSolver {
   FdtdConfig cfg{};
   GridP g{};
@@ -184,6 +198,8 @@ struct FdtdSolver {
   bool has_damp = false;
   std::vector<AdeGroup> ade;
   Disp disp;
+  SrcPaged spg;
+  int spg_on = -1;                   // FDTD_OPT_SRC_PAGED: -1 / 1 = default (on), 0 = off (single steps / z holes while such lists inject, round 5)
   int whatif = 0;                    // FDTD_OPT_WHATIF: a what-if instantiation of the vacuum two-step sweep (fdtd_kernels2.hpp; wrong results, meaningful times)
   int disp_on = -1;                  // FDTD_OPT_DISP: dispersive cells inside the two-step sweeps: -1 = default (on), 0 = off (their planes as z holes, round 5)
   std::vector<AnisoGroup> aniso;
@@ -1140,8 +1156,9 @@ const FdtdSolver::TileClasses* tile_classes(FdtdSolver* h, int W, int zc, const 
 // `use_disp`: the sweep subtracts the memory terms of the dispersive cells from E^{n+1} and leaves it for launch_ade2, which the
 // caller issues behind the launch (and behind the sources / damping of step n + 1 it applies itself).  `e2_clip`: a clipped launch
 // may apply the E-side sources of step n + 1 itself (the caller's ONE launch covers every source node).
+// `sr`: paged source terms of this pair (the caller has filled them, spg_fill; the node table then lists no sources).
 int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb, bool* sources2_done, bool* damp2_done = nullptr,
-                  const ClipP* clip = nullptr, bool use_disp = false, bool e2_clip = false) {
+                  const ClipP* clip = nullptr, bool use_disp = false, bool e2_clip = false, const SrcP& sr = SrcP{nullptr, nullptr, nullptr, nullptr, 0, 0}) {
   const bool inject = tb->with_sources;      // (false: the lists are spent, or — shell pairs with z holes — their planes take single steps)
   const GridP& g = h->g;
   if (ensure_second_set(h)) return -1;
@@ -1208,7 +1225,7 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
     // (... unless every E-side source node lies outside the layers: there the factor is exactly 1 — damp (E + s) == damp (E) + s bit
     //  for bit — and the sweep damps E^{n+2} itself.  The bench's dipole sits on the seam column 256 of a 512-cell row, which sent
     //  six damping launches over 40 % of the grid behind every pair: 20 % of the `va` step)
-    dmp.e2 = (!post_sources || inj.e2_in_sweep || !h->src_e_in_damp) ? 1 : 0;
+    dmp.e2 = (!post_sources || inj.e2_in_sweep || sr.sseg || !h->src_e_in_damp) ? 1 : 0;
     if (damp2_done) *damp2_done = dmp.e2 != 0;
   }
   const int total = nbx * nby * nbz;
@@ -1223,13 +1240,14 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
   int opt = (h->mem_hints ? 1 : 0) | (h->mat4 ? 2 : 0) | ((tb->mons.empty() && (!tb->with_sources || h->src_h_nodes == 0) && !tb->dstart) ? 0 : 4) |
             (clip ? 16 : (h->has_damp ? 8 : 0)) | (use_disp ? 32 | 1 : 0);
   if (h->whatif > 0 && opt == 1 && W == 16) opt |= h->whatif << 8;        // (measuring aid: the vacuum sweep with part of its work skipped)
+  if (sr.sseg) { opt |= 64 | 4 | 1; *sources2_done = true; h->spg.pairs++; }
   const int blocks = remap ? ((total + 7) / 8) * 8 : total;
   // background-only tiles take the plain sweep inside the materials launch (fdtd_kernels2.hpp, tile classes)
   const FdtdSolver::TileClasses* tc = tile_classes(h, W, zc, box, nbx, nby, nbz, use_disp);
   const bool split = tc && (use_disp || (tc->n_bg > 0 && (h->tile_split == 1 || 8 * tc->n_bg >= tc->n_all)));
   launch_fused2_step(st, W, opt, blocks, g, h->f, h->f2, sp, mp, zc, nbx, nby, nbz, remap, inj, h->seam_buf, dmp, box,
-                     TileClassP{split ? tc->dev : nullptr}, dp);
-  if (n_seams > 0) launch_seams(st, g, h->f2, sp, mp, h->seam_buf, n_seams, dmp, box, inj);
+                     TileClassP{split ? tc->dev : nullptr}, dp, sr);
+  if (n_seams > 0) launch_seams(st, g, h->f2, sp, mp, h->seam_buf, n_seams, dmp, box, inj, sr);
   time_end(h, st);
   if (use_disp) h->disp.pairs++;
   if (!clip) swap_sets(h);
@@ -1554,7 +1572,8 @@ void shell2_shape(const FdtdSolver* h, const Shell2Box& bx, int W, int zc_cap, S
 // per instantiation — x / y / z only at three waves per SIMD for 94 % of the cells, all axes for the edges and corners — lost
 // more to the four half-empty launches than the third wave bought (0.84 ms, profiles/r5/r5f).  shell2_on = 2 / 3: one launch per
 // instantiation / per box (measuring aids).
-void launch_shell2_boxes(FdtdSolver* h, const Shell2Box* bx, int n, const PmlP* pm, hipStream_t st, const F2Table* tb, bool use_disp = false) {
+void launch_shell2_boxes(FdtdSolver* h, const Shell2Box* bx, int n, const PmlP* pm, hipStream_t st, const F2Table* tb, bool use_disp = false,
+                         const SrcP& sr = SrcP{nullptr, nullptr, nullptr, nullptr, 0, 0}) {
   const DispP dp = use_disp ? DispP{h->disp.dseg, h->disp.cs, h->disp.e1} : DispP{nullptr, nullptr, nullptr};
   // (the DFT monitors of the pair's plan that reach into the shell: the boxes copy the middle step out over them; the dump buffer was sized by launch_fused2)
   Shell2Dump dmp{};
@@ -1567,7 +1586,7 @@ void launch_shell2_boxes(FdtdSolver* h, const Shell2Box* bx, int n, const PmlP* 
     auto flush = [&]() {
       if (mb.n == 0) return;
       time_begin(h, 3, st);
-      launch_shell2_step(st, W, h->mat4 != nullptr, axes, h->g, h->f, h->f2, step_params(h), mat_params(h), pm, mb, dmp, dp);
+      launch_shell2_step(st, W, h->mat4 != nullptr, axes, h->g, h->f, h->f2, step_params(h), mat_params(h), pm, mb, dmp, dp, sr);
       time_end(h, st);
       mb = Shell2M{};
     };
@@ -2197,6 +2216,103 @@ bool disp_inside(const FdtdSolver* h, const int lo[3], const int hi[3], int marg
     if (D.lo[a] < lo[a] + m || D.hi[a] > hi[a] - m) return false;
   }
   return true;
+}
+
+// One-off: slots for the nodes of every source list in paged storage (fdtd_fused2.hpp SrcP).  Needs one GPU and, per side (E / H), at
+// most ONE node per slot: where two lists (or a list twice) meet on a node the pair cannot form E + term as the list kernels would
+// one after the other.  state = 1 (ready) or -1.  -1 = a HIP error.
+int spg_setup(FdtdSolver* h) {
+  SrcPaged& S = h->spg;
+  if (S.state != 0) return 0;
+  S.state = -1;
+  const GridP& g = h->g;
+  if (h->spg_on == 0 || h->comm || g.nx % 4 != 0) return 0;
+  long long total = 0;
+  for (const PointSrc& s : h->psrc) total += s.n_e + s.n_h;
+  for (const Tfsf& t : h->tfsf) total += t.e.n_targets + t.h.n_targets;
+  if (total == 0) return 0;
+  const int nbx = (g.nx + 255) / 256;
+  const size_t nseg = (size_t)g.nz * g.ny * nbx;
+  hipStream_t st = h->stream;
+  auto give_up = [&]() { (void)hipGetLastError(); h->err.clear(); return 0; };
+  if (dev_alloc(h, &S.sseg, nseg)) return give_up();
+  auto each = [&](auto fn) {                 // every (cells, comps, n, soff slot, H side?) of every list
+    for (PointSrc& s : h->psrc) {
+      if (s.n_e) fn((const uint32_t*)s.cell_e, (const int32_t*)s.comp_e, s.n_e, &s.soff_e, false);
+      if (s.n_h) fn((const uint32_t*)s.cell_h, (const int32_t*)s.comp_h, s.n_h, &s.soff_h, true);
+    }
+    for (Tfsf& t : h->tfsf) {
+      if (t.e.n_targets) fn((const uint32_t*)t.e.cell, (const int32_t*)t.e.comp, t.e.n_targets, &t.e.soff, false);
+      if (t.h.n_targets) fn((const uint32_t*)t.h.cell, (const int32_t*)t.h.comp, t.h.n_targets, &t.h.soff, true);
+    }
+  };
+  each([&](const uint32_t* cell, const int32_t*, long long n, uint32_t**, bool) {
+    hipLaunchKernelGGL(disp_mark_kernel, dim3(nblk(n)), dim3(256), 0, st, cell, n, g.nx, nbx, S.sseg);
+  });
+  std::vector<int> seg(nseg, 0);
+  HIPCHK(h, hipMemcpyAsync(seg.data(), S.sseg, nseg * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  long long nb = 0;
+  for (size_t q = 0; q < nseg; ++q) seg[q] = seg[q] ? (int)nb++ : -1;
+  const long long floats = nb * 3 * 256;
+  if (nb == 0 || floats >= (1LL << 32)) return give_up();
+  HIPCHK(h, hipMemcpyAsync(S.sseg, seg.data(), nseg * sizeof(int), hipMemcpyHostToDevice, st));
+  int *cnt_e = nullptr, *cnt_h = nullptr, *box = nullptr;
+  const int big = 1 << 30;
+  const int box0[7] = {big, -1, big, -1, big, -1, 0};
+  if (dev_alloc(h, &S.e1, (size_t)floats) || dev_alloc(h, &S.h2, (size_t)floats) || dev_alloc(h, &S.e2, (size_t)floats) ||
+      dev_alloc(h, &cnt_e, (size_t)floats) || dev_alloc(h, &cnt_h, (size_t)floats) || dev_upload(h, &box, box0, 7)) return give_up();
+  bool failed = false;
+  S.any_h = false;
+  each([&](const uint32_t* cell, const int32_t* comp, long long n, uint32_t** soff, bool h_side) {
+    if (failed || dev_alloc(h, soff, (size_t)n, false)) { failed = true; return; }
+    S.any_h = S.any_h || h_side;
+    hipLaunchKernelGGL(src_soff_kernel, dim3(nblk(n)), dim3(256), 0, st, cell, comp, n, g.nx, g.ny, nbx, (const int*)S.sseg, *soff,
+                       h_side ? cnt_h : cnt_e, box);
+  });
+  if (failed) return give_up();
+  hipLaunchKernelGGL(src_max_kernel, dim3(nblk(floats)), dim3(256), 0, st, (const int*)cnt_e, floats, box + 6);
+  hipLaunchKernelGGL(src_max_kernel, dim3(nblk(floats)), dim3(256), 0, st, (const int*)cnt_h, floats, box + 6);
+  int boxh[7];
+  HIPCHK(h, hipMemcpyAsync(boxh, box, sizeof(boxh), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  release_buf(h, cnt_e); release_buf(h, cnt_h);
+  if (boxh[6] > 1) return give_up();                     // two nodes of one side on one slot
+  S.n_blocks = (int)nb;
+  S.state = 1;
+  return 0;
+}
+// the three arrays of the pair (n, n + 1), and the incident grids of the TFSF boxes advanced through both steps — in the order of two
+// single steps (the H-side terms of step n were added to H^{n-1/2} in place just before, launch_sources):
+//   incident H(n) | E-side terms of n | incident E(n) | H-side terms of n+1 | incident H(n+1) | E-side terms of n+1 | incident E(n+1)
+void spg_fill(FdtdSolver* h, long long n, hipStream_t st) {
+  SrcPaged& S = h->spg;
+  auto fill = [&](float* val, bool e_side, long long step) {
+    for (Tfsf& t : h->tfsf) {
+      const TfsfList& L = e_side ? t.e : t.h;
+      if (!L.n_targets) continue;
+      hipLaunchKernelGGL(src_fill_tfsf_kernel, dim3(nblk(L.n_targets)), dim3(256), 0, st, val, (const uint32_t*)L.soff, (const int32_t*)L.start,
+                         (const float*)L.w, (const int32_t*)L.aux, (const float*)(e_side ? t.h1 : t.e1), L.n_targets, step >= t.n_steps ? 1 : 0);
+    }
+    for (PointSrc& s : h->psrc) {
+      const long long nn = e_side ? s.n_e : s.n_h;
+      if (!nn) continue;
+      hipLaunchKernelGGL(src_fill_points_kernel, dim3(nblk(nn)), dim3(256), 0, st, val, (const uint32_t*)(e_side ? s.soff_e : s.soff_h),
+                         (const float*)(e_side ? s.wre_e : s.wre_h), (const float*)(e_side ? s.wim_e : s.wim_h),
+                         (const float2*)(e_side ? s.wave_e : s.wave_h), step, nn, step >= s.n_steps ? 1 : 0);
+    }
+  };
+  advance_tfsf_aux(h, false, n, st, false);
+  fill(S.e1, true, n);
+  advance_tfsf_aux(h, true, n, st, false);
+  if (S.any_h) fill(S.h2, false, n + 1);
+  advance_tfsf_aux(h, false, n + 1, st, false);
+  fill(S.e2, true, n + 1);
+  advance_tfsf_aux(h, true, n + 1, st, false);
+}
+SrcP spg_params(const FdtdSolver* h) {
+  const SrcPaged& S = h->spg;
+  return SrcP{S.sseg, S.e1, S.h2, S.e2, S.any_h ? 1 : 0, 1};
 }
 
 // z boundary conditions of a single slab (no neighbour): fill ghost planes
@@ -3085,6 +3201,8 @@ struct Run {
   bool f2_ok = false, f2s_ok = false, s2_ok = false, s2_deep = false, f2m_ok = false;
   bool s2_disp = false;                // shell2 pairs: every dispersive cell deep inside the bulk — its sweep advances them (no z holes)
   bool pair_disp = false;              // the pair about to be issued does so
+  bool spg_ok = false;                 // lists the node table cannot hold go out as paged source terms while they inject (spg_setup)
+  bool pair_spg = false;               // the pair about to be issued carries them
   bool f2mc_ok = false, f2mc_deep = false;   // z-slab ranks with CPML: shell2 pairs with the planes next to a cut as z holes (sgm: their geometry)
   ShellGeom sg{}, sgm{};
   ZPlan zp_base, zp_src;               // the bulk's planes: without / with the z holes of the source lists
@@ -3450,6 +3568,20 @@ struct Run {
     if (fused && !tb_ok && !h->ade.empty() && disp_setup(h)) return -1;
     h->disp.pairs = 0;
     s2_disp = false;
+    // paged source terms (round 6): a TFSF box, a mode plane, a current sheet, any list of more than kMaxInj nodes
+    spg_ok = false;
+    h->spg.pairs = 0;
+    if (fused && !tb_ok && !multi && (!h->tfsf.empty() || !h->psrc.empty())) {
+      if (fused2_sources(h)) return -1;            // (src_nodes, the seam flags)
+      bool needs = !h->tfsf.empty() || h->src_nodes > kMaxInj || h->src_h_on_seam || (h->src_h_nodes > 0 && !h->src_tab);
+      if (!needs) {                                // lists of different lengths: mixed alive / spent pairs
+        long long len = -1;
+        for (const PointSrc& s : h->psrc) if (s.n_e || s.n_h) { if (len >= 0 && s.n_steps != len) needs = true; len = s.n_steps; }
+      }
+      if (needs && spg_setup(h)) return -1;
+      // (absorber layers damp H^{n-1/2} inside the sweep, behind the H-side terms of step n that precede it: FDTD_F2_OFF_H_SOURCE_ABSORBER stays)
+      spg_ok = needs && h->spg.state == 1 && !(h->has_damp && h->spg.any_h);
+    }
     f2_ok = fused && !tb_ok && fused2_eligible(h);
     sg = ShellGeom{};
     f2s_ok = false;
@@ -3601,7 +3733,9 @@ struct Run {
       HIPCHK(h, hipEventCreateWithFlags(&h->ev_shell_b, hipEventDisableTiming));
     }
     launch_sources(h, false, n, 0, nz, st);                  // H-side sources of step n on H^{n-1/2}, then the incident grid's H: the order of a single step
-    advance_tfsf_aux(h, false, n, st);
+    if (pair_spg) spg_fill(h, n, st);                        // (paged source terms of the pair; the incident grids through both steps)
+    else advance_tfsf_aux(h, false, n, st);
+    const SrcP sr = pair_spg ? spg_params(h) : SrcP{nullptr, nullptr, nullptr, nullptr, 0, 0};
     HIPCHK(h, hipEventRecord(h->ev_shell_a, st));
     HIPCHK(h, hipStreamWaitEvent(cs, h->ev_shell_a, 0));
     const FieldP A = h->f, B = h->f2, T = h->f3;
@@ -3612,7 +3746,7 @@ struct Run {
     for (int i = 0; i < zp.n; ++i) {
       const ClipP clip{sg.o0[0], sg.o1[0], sg.o0[1], sg.o1[1], zp.a[i], zp.b[i]};
       // (one interval and every source node deep inside it: the sweep applies the E-side terms of step n + 1 itself)
-      if (launch_fused2(h, n, st, tb, &s2, nullptr, &clip, pair_disp, zp.n == 1 && s2_deep)) return -1;
+      if (launch_fused2(h, n, st, tb, &s2, nullptr, &clip, pair_disp, zp.n == 1 && s2_deep, sr)) return -1;
       // the boxes beside this interval: its planes, and (first / last interval) the z slabs below / above
       ShellGeom gi = sg;
       gi.o0[2] = zp.a[i]; gi.o1[2] = zp.b[i];
@@ -3626,7 +3760,7 @@ struct Run {
     for (const PointSrc& sr : h->psrc) src_due = src_due || (sr.n_e && n + 1 < sr.n_steps);
     const bool ade2_early = pair_disp && (s2 || !src_due) && disp_inside(h, sg.o0, sg.o1, 0);
     if (ade2_early) launch_ade2(h, st, &B);
-    launch_shell2_boxes(h, boxes, nb, h->pml_blk2[hp][ep], cs, tb, pair_disp);
+    launch_shell2_boxes(h, boxes, nb, h->pml_blk2[hp][ep], cs, tb, pair_disp, sr);
     if (holes || per_y) {
       const int pml_in = 7 & pml_in_sweep_mask(h);
       ShellSets s1{A, T, hp, 0, 0, h->pml_blk_hole[0][hp][ep]}, s2h{T, B, hp, 0, 0, h->pml_blk_hole[1][hp][ep]};
@@ -3667,14 +3801,14 @@ struct Run {
     swap_psi_e(h);
     pair_record(h, tb, n, st);
     if (rec_at(n + 1)) record_monitors(h, n + 1, true, st);
-    if (!holes) {
+    if (!holes && !pair_spg) {
       advance_tfsf_aux(h, true, n, st);
       advance_tfsf_aux(h, false, n + 1, st);
     }
     if (!s2) launch_sources(h, true, n + 1, 0, nz, st);
     if (!pair_disp) launch_ade(h, 0, nz, st);
     else if (!ade2_early) launch_ade2(h, st);
-    advance_tfsf_aux(h, true, n + 1, st);
+    if (!pair_spg) advance_tfsf_aux(h, true, n + 1, st);
     fill_ghost_fused(h, st);
     return 0;
   }
@@ -3726,7 +3860,14 @@ struct Run {
     if (pair) {
       src_why = fused2_sources_why_not(h, n, &src_alive);
       // shell2 form: the boxes apply no sources — lists that inject must lie deep inside the bulk
-      use_s2 = s2_ok && src_why == 0 && (!src_alive || s2_deep);
+      // lists the node table cannot hold, while they inject: paged source terms in the sweep, the seam kernel and the shell's boxes —
+      // plain pairs and shell2 pairs without z holes (a periodic y's wrap rows take single steps: the round-5 forms there)
+      pair_spg = false;
+      if (src_why != 0 && spg_ok && (src_why == FDTD_F2_OFF_TFSF || src_why == FDTD_F2_OFF_SOURCES || src_why == FDTD_F2_OFF_SEAM_SOURCE)) {
+        const bool s2_form = s2_ok && zp_s2.ok && zp_s2.n == 1 && h->cfg.bc[2] != FDTD_BC_PERIODIC;
+        if (s2_form || (f2_ok && h->ade.empty())) { pair_spg = true; src_why = 0; src_alive = false; }
+      }
+      use_s2 = s2_ok && src_why == 0 && (!src_alive || s2_deep || pair_spg);
       if (use_s2) zp = &zp_s2;
       else if (s2_ok && zp_s2h.ok && (src_why != 0 || src_alive)) {
         // lists that inject and that the sweeps cannot apply themselves (too many nodes, nodes inside the shell, TFSF corrections): their
@@ -3747,6 +3888,7 @@ struct Run {
              (!f2s_ok || plan_in_bulk(f2_plan, *zp));
     }
     pair_disp = pair && !h->ade.empty() && h->disp.state == 1 && (use_s2 ? (s2_disp && zp == &zp_s2) : !f2s_ok);
+    pair_spg = pair_spg && pair && (use_s2 ? zp == &zp_s2 : (f2_ok && !f2s_ok));
     // (with H-side sources the monitors of a pair still take E^n and H^{n-1/2} here: those sources change H^{n-1/2} before the
     //  sweep, and pair_record reads the set afterwards)
     if (rec) record_monitors(h, n, false, st, (pair && h->src_h_nodes == 0) ? &f2_plan : nullptr);
@@ -3934,7 +4076,8 @@ struct Run {
     if (!tb) return -1;
     bool sources2_done = false, damp2_done = true;
     launch_sources(h, false, n, 0, nz, st);              // H-side sources of step n act on H^{n-1/2}, as before a single step
-    if (launch_fused2(h, n, st, tb, &sources2_done, &damp2_done, nullptr, pair_disp)) return -1;
+    if (pair_spg) spg_fill(h, n, st);                    // (the other source terms of the pair into paged storage, the incident grids through both steps)
+    if (launch_fused2(h, n, st, tb, &sources2_done, &damp2_done, nullptr, pair_disp, false, pair_spg ? spg_params(h) : SrcP{nullptr, nullptr, nullptr, nullptr, 0, 0})) return -1;
     pair_record(h, tb, n, st);                           // (H^{n+3/2} is not touched by the E-side sources that follow)
     if (rec_at(n + 1)) record_monitors(h, n + 1, true, st);      // DFT records at the middle step: their H terms, from the write set
     if (!sources2_done) launch_sources(h, true, n + 1, 0, nz, st);
@@ -4362,6 +4505,10 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_SHELL2: h->shell2_on = value < 0 ? -1 : (value > 3 ? 1 : value); return 0;
     case FDTD_OPT_DEBUG_SYNC: h->debug_sync = value != 0; return 0;
     case FDTD_OPT_TILE_SPLIT: h->tile_split = value < 0 ? -1 : (value != 0); return 0;
+    case FDTD_OPT_SRC_PAGED:
+      h->spg_on = value < 0 ? -1 : (value != 0);
+      if (h->spg.state == -1 && value != 0) h->spg.state = 0;
+      return 0;
     case FDTD_OPT_WHATIF: if (value < 0 || value > 8) break; h->whatif = value; return 0;
     case FDTD_OPT_DISP:
       if (h->disp.state == 1 && value == 0) break;       // (every ADE launch keeps the paged memory terms by now: set it before the first run)
@@ -4407,7 +4554,7 @@ int fdtd_get_stats(FdtdSolver* h, FdtdStats* out) {
   out->fused2_off_reason = h->fused2_pairs ? 0 : (h->f2_off_reason ? h->f2_off_reason : h->f2_dyn_reason);
   out->disp_pairs = h->disp.pairs;
   out->single_step_reason = h->f2_dyn_reason;
-  out->reserved1 = 0;
+  out->src_paged_pairs = (int32_t)std::min<long long>(h->spg.pairs, 0x7fffffff);
   out->struct_bytes = (int32_t)sizeof(FdtdStats);
   return 0;
 }

@@ -21,7 +21,11 @@ void launch_inject_values(hipStream_t st, float* val, const float* w_re, const f
 
 void launch_fused2_step(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
                         const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,
-                        int xcd_remap, const InjP& inj, float* seam, const DampT& dmp, const ClipP& clip, const TileClassP& tcl, const DispP& dp) {
+                        int xcd_remap, const InjP& inj, float* seam, const DampT& dmp, const ClipP& clip, const TileClassP& tcl, const DispP& dp, const SrcP& sr) {
+  if (opt & 64) {
+    launch_fused2_step_src(st, waves, opt, grid_blocks, g, a, b, s, m, zchunk, nbx, nby, nbz, xcd_remap, inj, seam, dmp, clip, tcl, dp, sr);
+    return;
+  }
   if (opt >> 8) {
     launch_fused2_step_whatif(st, waves, opt, grid_blocks, g, a, b, s, m, zchunk, nbx, nby, nbz, xcd_remap, inj, seam, dmp, clip);
     return;
@@ -38,7 +42,7 @@ void launch_fused2_step(hipStream_t st, int waves, int opt, int grid_blocks, con
   const size_t shmem = ((size_t)8 * waves * 64 + ((opt & 8) ? 2 * 64 : 0)) * sizeof(float4);
 #define FDTD_F2_O(LBV, OV)                                                                                             \
   hipLaunchKernelGGL((fused2_step_kernel<LBV, OV>), grid, block, shmem, st, g, a, b, s, m, zchunk, nbx, nby, nbz,     \
-                     xcd_remap, inj, seam, dmp, clip, tcl, dp)
+                     xcd_remap, inj, seam, dmp, clip, tcl, dp, sr)
 #define FDTD_F2(LBV)                                                                                                   \
   do {                                                                                                                 \
     switch (opt & 15) {                                                                                                \
@@ -76,11 +80,11 @@ void launch_dft_record_dump(hipStream_t st, const DftDumpP& r, const float* dump
 }
 
 void launch_seams(hipStream_t st, const GridP& g, const FieldP& b, const StepP& s, const MatP& m, const float* seam,
-                  int n_seams, const DampT& dmp, const ClipP& clip, const InjP& inj) {
+                  int n_seams, const DampT& dmp, const ClipP& clip, const InjP& inj, const SrcP& sr) {
   const long long nt = (long long)n_seams * (clip.j1 - clip.j0) * (clip.k1 - clip.k0);
   if (nt <= 0) return;
   const unsigned blocks = (unsigned)((nt + 255) / 256);
-  hipLaunchKernelGGL(seam_kernel, dim3(blocks), dim3(256), 0, st, g, b, s, m, seam, n_seams, dmp, clip, inj);
+  hipLaunchKernelGGL(seam_kernel, dim3(blocks), dim3(256), 0, st, g, b, s, m, seam, n_seams, dmp, clip, inj, sr);
 }
 
 }  // namespace fdtd

@@ -54,6 +54,20 @@ struct DispP {
   const float* cs;                         // cc S(Q^n)
   float* e1;                               // E^{n+1} behind its ADE update
 };
+// Source terms of a step pair in paged storage (round 6): what TFSF boxes, mode planes, current sheets and other lists of more than
+// kMaxInj nodes add to the fields while they inject — one block [3 components][256 cells] per row segment that holds a source node
+// (sseg), three arrays filled in front of every pair by list kernels with the operations of point_source_kernel / tfsf_corr_kernel:
+// e1 = the E-side terms of step n (added to E^{n+1} in S2, behind the walls, in front of damping and ADE), h2 = the H-side terms of
+// step n+1 (added to H^{n+1/2} at the top of S3), e2 = the E-side terms of step n+1 (added to E^{n+2} in S4).  The H-side terms of
+// step n act on H^{n-1/2} in front of the sweep, as always.  One term per node and side (the host checks that no two lists meet
+// on a node): E + term is what the list kernel would have formed.  sseg == nullptr: none.
+struct SrcP {
+  const int* sseg;                         // [nz][ny][ceil(nx / 256)]: block of the row segment, -1 = no source node in it
+  const float* e1;
+  const float* h2;
+  const float* e2;
+  int use_h2, use_e2;                      // a list is alive at step n+1
+};
 constexpr int kMaxCap = 1024;
 constexpr int kSeamArrays = 13;  // of step one: H1_y, H1_z, E1_x, E1_y, E1_z [c-1], E1_y, E1_z [c]; of step two: H2_x [c-1], H2_y, H2_z [c-2], H2_x, H2_y, H2_z [c]
                                  // (c = first column of the right tile)
@@ -67,7 +81,11 @@ void launch_inject_values(hipStream_t st, float* val, const float* w_re, const f
 void launch_fused2_step(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
                         const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,
                         int xcd_remap, const InjP& inj, float* seam, const DampT& dmp, const ClipP& clip, const TileClassP& tcl = TileClassP{nullptr},
-                        const DispP& dp = DispP{nullptr, nullptr, nullptr});
+                        const DispP& dp = DispP{nullptr, nullptr, nullptr}, const SrcP& sr = SrcP{nullptr, nullptr, nullptr, nullptr, 0, 0});
+// the instantiations that add paged source terms (opt bit 6; always with bits 0 and 2): fdtd_fused2s.hip
+void launch_fused2_step_src(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
+                            const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,
+                            int xcd_remap, const InjP& inj, float* seam, const DampT& dmp, const ClipP& clip, const TileClassP& tcl, const DispP& dp, const SrcP& sr);
 // what-if instantiations (opt >> 8 = 1 ... 8 on top of opt = 1, 16 waves): fdtd_fused2w.hip
 void launch_fused2_step_whatif(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
                                const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,
@@ -102,6 +120,6 @@ void launch_dft_record_dump(hipStream_t st, const DftDumpP& r, const float* dump
                             const float2* phase, int nf);
 // (inj: the seam kernel adds the E-side source terms of step n+1 when the sweep did — inj.e2_in_sweep)
 void launch_seams(hipStream_t st, const GridP& g, const FieldP& b, const StepP& s, const MatP& m, const float* seam,
-                  int n_seams, const DampT& dmp, const ClipP& clip, const InjP& inj);
+                  int n_seams, const DampT& dmp, const ClipP& clip, const InjP& inj, const SrcP& sr = SrcP{nullptr, nullptr, nullptr, nullptr, 0, 0});
 
 }  // namespace fdtd

@@ -1524,6 +1524,45 @@ __global__ void tfsf_aux_e_kernel(float* e1, const float* h1, const float* ae, c
   if (threadIdx.x == 0) e1[src_cell] += wave[step_dev ? *step_dev + step : step];
 }
 
+// ---- paged source terms of a step pair (round 6, fdtd_fused2.hpp SrcP) -------------------------------------------------------------
+// soff[t]: the slot of node t of a list in the paged arrays; count[slot] += 1 (two nodes of one side on one slot: the pair cannot
+// form E + term exactly — the host then keeps single steps while the lists inject); box: bounding box of the nodes
+__global__ __launch_bounds__(256) void src_soff_kernel(const uint32_t* cell, const int32_t* comp, long long n, int nx, int ny, int nbx,
+                                                        const int* sseg, uint32_t* soff, int* count, int* box) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const long long p = cell[t];
+  const int i = (int)(p % nx);
+  const long long blk = sseg[(p / nx) * nbx + i / 256];
+  const uint32_t o = (uint32_t)((blk * 3 + comp[t] % 3) * 256 + (i & 255));
+  soff[t] = o;
+  atomicAdd(&count[o], 1);
+  const int j = (int)((p / nx) % ny), k = (int)(p / ((long long)nx * ny));
+  atomicMin(&box[0], i); atomicMax(&box[1], i); atomicMin(&box[2], j); atomicMax(&box[3], j); atomicMin(&box[4], k); atomicMax(&box[5], k);
+}
+__global__ __launch_bounds__(256) void src_max_kernel(const int* count, long long n, int* out) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n && count[t] > 1) atomicMax(out, count[t]);
+}
+// the term point_source_kernel would add at `step`, formed by its operations, into the node's slot (zero != 0: the list is spent)
+__global__ __launch_bounds__(256) void src_fill_points_kernel(float* val, const uint32_t* soff, const float* w_re, const float* w_im,
+                                                               const float2* wave, long long step, long long n, int zero) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  if (zero) { val[soff[t]] = 0.f; return; }
+  const float2 a = wave[step];
+  val[soff[t]] = w_re[t] * a.x - w_im[t] * a.y;
+}
+// the term tfsf_corr_kernel would add from the incident grid as it stands, formed by its operations
+__global__ __launch_bounds__(256) void src_fill_tfsf_kernel(float* val, const uint32_t* soff, const int32_t* start, const float* w,
+                                                             const int32_t* ai, const float* aux, long long n_targets, int zero) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_targets) return;
+  float acc = 0.f;
+  if (!zero) for (int e = start[t]; e < start[t + 1]; ++e) acc += w[e] * aux[ai[e]];
+  val[soff[t]] = acc;
+}
+
 // the device-side step counter of captured step pairs: set (when the host stepped outside a graph) / advanced (last node)
 __global__ void step_counter_kernel(long long* step_dev, long long value, int add) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *step_dev = add ? *step_dev + value : value;

@@ -158,8 +158,9 @@ template <int LB, int OPT>
 __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a, const FieldP& b, const StepP& s, const MatP& m,
                                                  int zchunk, int nbx, int nby, int nbz, const InjP& inj,
                                                  float* __restrict__ seam, const DampT& dmp, const ClipP& clip, int t,
-                                                 const DispP& dp) {
+                                                 const DispP& dp, const SrcP& sr) {
   constexpr int V = 4;
+  constexpr bool SRC = (OPT & 64) != 0;    // paged source terms (fdtd_fused2.hpp SrcP): TFSF boxes, mode planes, sheets while they inject
   constexpr bool NT = (OPT & 1) != 0, MAT = (OPT & 2) != 0, MON = (OPT & 4) != 0;     // MON: the node table may hold monitor samples
   // DISP (round 6): the grid holds dispersive cells and the pair advances them (K4 twice).  What the sweep needs of step n's ADE
   // update is E^{n+1} <- E^{n+1} - cc S(Q^n) at those cells — H^{n+3/2} differentiates it — and that memory term is known before
@@ -267,6 +268,7 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
   float ipz_m = 0.f, idz_m = 0.f;          // 1 / steps of plane k-1
   int qm0 = 0, qm1 = 0;                    // table rows of plane k-1
   [[maybe_unused]] uint32_t rw_m = kBgWord;                                        // material row-segment word of plane k-1 (S4)
+  [[maybe_unused]] int ss_m = -1;                                                  // block of the segment's source terms, plane k-1 (S3, S4)
   {
     const long long p0 = (long long)kA * g.sxy + rowb;
     ldf<V, true>(exk, uni(a.ex + p0), ubc);
@@ -382,6 +384,10 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
     [[maybe_unused]] uint32_t rw = kBgWord;
     if constexpr (MAT) {
       if (do_e1) rw = m.roww[((long long)min(k, g.nz - 1) * g.ny + j) * nbx + tile_x];     // (plane nz: the wall, E1 = 0 whatever the medium)
+    }
+    [[maybe_unused]] int ss = -1;              // block of the row segment's source terms (SRC), -1 = no source node in it
+    if constexpr (SRC) {
+      if (do_e1 && k < g.nz) ss = sr.sseg[((long long)k * g.ny + j) * nbx + tile_x];
     }
     [[maybe_unused]] int ds = -1;              // block of the row segment's memory terms (DISP), -1 = no dispersive cell in it
     if constexpr (DISP) {
@@ -506,6 +512,15 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
         } else {
           const float2 c1 = make_float2(ca, cb);
           s2([&](int, int) { return c1; });
+        }
+        if constexpr (SRC) {                  // the E-side source terms of step n (behind the walls: a list kernel adds to what the sweep wrote)
+          if (ss >= 0 && act) {
+            const long long qs = ((long long)ss * 3) * 256 + tx * V;
+            float tx_[V], ty_[V], tz_[V];
+            ldv<V>(tx_, sr.e1 + qs); ldv<V>(ty_, sr.e1 + qs + 256); ldv<V>(tz_, sr.e1 + qs + 512);
+#pragma unroll
+            for (int e = 0; e < V; ++e) { e1xn[e] = e1xn[e] + tx_[e]; e1yn[e] = e1yn[e] + ty_[e]; e1zn[e] = e1zn[e] + tz_[e]; }
+          }
         }
         // The node table of the plane.  Codes 0 - 2: the E-side point sources of step n act on E^{n+1} before step n+1 reads
         // it.  Codes 8 - 13 (listed behind the sources of the plane; taken by the row's owner, once): what small time
@@ -655,6 +670,15 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
           for (int e = 0; e < V; ++e) { h1y[e] *= cx[e] * byv * cz_m; h1z[e] *= cx[e] * cyv * bz_m; }
         }
       }
+      if constexpr (SRC) {                    // the H-side source terms of step n+1 (behind the damping of H^{n+1/2}, as launch_sources follows launch_damp)
+        if (sr.use_h2 && ss_m >= 0 && act) {
+          const long long qs = ((long long)ss_m * 3) * 256 + tx * V;
+          float tx_[V], ty_[V], tz_[V];
+          ldv<V>(tx_, sr.h2 + qs); ldv<V>(ty_, sr.h2 + qs + 256); ldv<V>(tz_, sr.h2 + qs + 512);
+#pragma unroll
+          for (int e = 0; e < V; ++e) { h1x[e] = h1x[e] + tx_[e]; h1y[e] = h1y[e] + ty_[e]; h1z[e] = h1z[e] + tz_[e]; }
+        }
+      }
       // H-side point sources of step n+1 (codes 3 - 5 of the node table of plane k-1) act on H^{n+1/2} before step n+1 advances it
       // — E^{n+1} above was formed from the value without them, as in two single steps; h1 is not read again in this iteration
       if constexpr (MON) {
@@ -786,6 +810,15 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
         const float2 c1 = make_float2(ca, cb);
         s4([&](int, int) { return c1; });
       }
+      if constexpr (SRC) {                    // the E-side source terms of step n+1
+        if (sr.use_e2 && ss_m >= 0 && act) {
+          const long long qs = ((long long)ss_m * 3) * 256 + tx * V;
+          float tx_[V], ty_[V], tz_[V];
+          ldv<V>(tx_, sr.e2 + qs); ldv<V>(ty_, sr.e2 + qs + 256); ldv<V>(tz_, sr.e2 + qs + 512);
+#pragma unroll
+          for (int e = 0; e < V; ++e) { ex[e] = ex[e] + tx_[e]; ey[e] = ey[e] + ty_[e]; ez[e] = ez[e] + tz_[e]; }
+        }
+      }
       // the node table of plane k-1: the E-side sources of step n+1 (when the launch carries them) act on E^{n+2}
       if (inj.val2 && inj.e2_in_sweep) {
         for (int qb = qm0; qb < qm1; qb += 64) {
@@ -860,6 +893,7 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
     qm0 = q0; qm1 = q1;
     if constexpr (DAMP) { bz_m = bzk; cz_m = czk; }
     if constexpr (MAT) rw_m = rw;
+    if constexpr (SRC) ss_m = ss;
     cur ^= 1;
   };
   // two planes per trip: the carried values alternate between two register sets instead of being copied
@@ -878,7 +912,7 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
 template <int LB, int OPT>
 __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
                                                          int zchunk, int nbx, int nby, int nbz, int xcd_remap,
-                                                         InjP inj, float* __restrict__ seam, DampT dmp, ClipP clip, TileClassP tcl, DispP dp) {
+                                                         InjP inj, float* __restrict__ seam, DampT dmp, ClipP clip, TileClassP tcl, DispP dp, SrcP sr) {
   const int total = nbx * nby * nbz;
   int t = blockIdx.x;
   if (xcd_remap == 1) {
@@ -897,18 +931,18 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     if (tcl.cls) {
       const int cl = tcl.cls[t];
       if (cl == 0) {
-        fused2_step_tile<LB, (OPT & ~(2 | 32))>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t, dp);
+        fused2_step_tile<LB, (OPT & ~(2 | 32))>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t, dp, sr);
         return;
       }
       if constexpr ((OPT & 32) != 0) {       // (a tile without dispersive cells in a launch that carries them: the materials sweep)
         if (cl == 1) {
-          fused2_step_tile<LB, (OPT & ~32)>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t, dp);
+          fused2_step_tile<LB, (OPT & ~32)>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t, dp, sr);
           return;
         }
       }
     }
   }
-  fused2_step_tile<LB, OPT>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t, dp);
+  fused2_step_tile<LB, OPT>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t, dp, sr);
 }
 
 // ---- the seams between x tiles -------------------------------------------------------------------------------------
@@ -919,7 +953,7 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
 // Round 6: the E-side source terms of step n+1 on a seam column are added here when the sweep added the others (inj.e2_in_sweep):
 // a node next to a seam no longer sends all of them behind the launch.
 __global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, MatP m,
-                                                   const float* __restrict__ seam, int n_seams, DampT dmp, ClipP clip, InjP inj) {
+                                                   const float* __restrict__ seam, int n_seams, DampT dmp, ClipP clip, InjP inj, SrcP sr) {
   // (clip: the box the sweep wrote — the whole grid, or the bulk of a grid whose shell takes single steps; rows and planes
   //  are those of the box, and a seam column that lies outside it is left alone)
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -946,6 +980,14 @@ __global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, M
       const float cxv = dmp.fc[0][c - 1];
       h1y *= cxv * dmp.fb[1][jj] * dmp.fc[2][kk];
       h1z *= cxv * dmp.fc[1][jj] * dmp.fb[2][kk];
+    }
+    if (sr.sseg && sr.use_h2) {             // paged H-side source terms of step n+1 at column c-1
+      const int blk = sr.sseg[((long long)kk * g.ny + jj) * ((g.nx + 255) >> 8) + ((c - 1) >> 8)];
+      if (blk >= 0) {
+        const long long qs = ((long long)blk * 3) * 256 + ((c - 1) & 255);
+        h1y = h1y + sr.h2[qs + 256];
+        h1z = h1z + sr.h2[qs + 512];
+      }
     }
     hy = upd_h(h1y, ch, A(2, jj, kk + 1) - e1x, s.ipz[kk], A(6, jj, kk) - e1z, ipx);
     hz = upd_h(h1z, ch, A(5, jj, kk) - e1y, ipx, e1x_jp - e1x, s.ipy[jj]);
@@ -983,6 +1025,18 @@ __global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, M
     const float2 qm = coef(pl, 2), qc = coef(p, 2);
     ez_m = upd_e(A(4, j, k), qm.x, qm.y, hy_m - hy_mm, idx_m, hx_m - hxm_j, idy);
     ez_c = upd_e(A(6, j, k), qc.x, qc.y, hy_c - hy_m, idx_c, hx_c - hxc_j, idy);
+  }
+  if (sr.sseg && sr.use_e2) {                // paged E-side source terms of step n+1 on these two columns
+    const int nbxg = (g.nx + 255) >> 8;
+    const int bl = sr.sseg[((long long)k * g.ny + j) * nbxg + ((c - 1) >> 8)], br = sr.sseg[((long long)k * g.ny + j) * nbxg + (cc >> 8)];
+    if (bl >= 0) {
+      const long long qs = ((long long)bl * 3) * 256 + ((c - 1) & 255);
+      ex_m = ex_m + sr.e2[qs]; ey_m = ey_m + sr.e2[qs + 256]; ez_m = ez_m + sr.e2[qs + 512];
+    }
+    if (br >= 0) {
+      const long long qs = ((long long)br * 3) * 256 + (cc & 255);
+      ey_c = ey_c + sr.e2[qs + 256]; ez_c = ez_c + sr.e2[qs + 512];
+    }
   }
   if (inj.val2 && inj.e2_in_sweep) {         // the E-side sources of step n+1 on these two columns (the plane's table rows in their order)
     const int q0 = inj.start[k], q1 = inj.start[k + 1];

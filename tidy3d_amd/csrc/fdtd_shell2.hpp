@@ -39,7 +39,7 @@ namespace fdtd {
 // rows / lanes / planes then lie off them too (the collar) — runs an instantiation without that axis' 32 psi registers
 template <bool MAT, int AXES>
 __global__ __launch_bounds__(512, (AXES == 7 ? 2 : 3)) void shell2_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
-                                                          const PmlP* __restrict__ pmq, Shell2M boxes, Shell2Dump dmp, DispP dp) {
+                                                          const PmlP* __restrict__ pmq, Shell2M boxes, Shell2Dump dmp, DispP dp, SrcP sr) {
   constexpr int V = 4;
   // ONE launch covers all boxes of the shell (the workgroups of box q are [first[q], first[q + 1])): six small launches one
   // behind the other on a stream left the machine half empty between them (profiles/r5)
@@ -395,6 +395,18 @@ __global__ __launch_bounds__(512, (AXES == 7 ? 2 : 3)) void shell2_step_kernel(G
         }
       }
       if (!row_ok) { zero<V>(e1xn); zero<V>(e1zn); }      // rows beyond the grid publish E = 0 (the wall)
+      // paged source terms (round 6, fdtd_fused2.hpp SrcP: a mode plane / current sheet that runs through the layers while it injects):
+      // the E-side terms of step n, behind the E-side recursions as launch_sources follows the sweep
+      if (sr.sseg && act && in_z) {
+        const int ss = sr.sseg[((long long)k * g.ny + j) * ((g.nx + 255) >> 8) + (i0 >> 8)];
+        if (ss >= 0) {
+          const long long qs = ((long long)ss * 3) * 256 + (i0 & 255);
+          float tx_[V], ty_[V], tz_[V];
+          ldv<V>(tx_, sr.e1 + qs); ldv<V>(ty_, sr.e1 + qs + 256); ldv<V>(tz_, sr.e1 + qs + 512);
+#pragma unroll
+          for (int e = 0; e < V; ++e) { e1xn[e] = e1xn[e] + tx_[e]; e1yn[e] = e1yn[e] + ty_[e]; e1zn[e] = e1zn[e] + tz_[e]; }
+        }
+      }
       // dispersive cells inside the shell (round 6, as fused2_step_kernel's OPT bit 5): E^{n+1} <- E^{n+1} - cc S(Q^n) from the paged
       // memory terms, last of all; the lane that owns the cells leaves E^{n+1} for ade2_kernel
       if (dp.dseg && act && in_z) {
@@ -441,6 +453,17 @@ __global__ __launch_bounds__(512, (AXES == 7 ? 2 : 3)) void shell2_step_kernel(G
       float exj1[V], ezj1[V];
       get(4 + (cur ^ 1) * 2 + 0, ma, exj1);
       get(4 + (cur ^ 1) * 2 + 1, ma, ezj1);
+      // paged H-side source terms of step n+1 on H^{n+1/2}[k-1], in front of the H-side recursions (launch_sources precedes the sweep)
+      if (sr.sseg && sr.use_h2 && act && k > kA) {
+        const int ss = sr.sseg[((long long)(k - 1) * g.ny + j) * ((g.nx + 255) >> 8) + (i0 >> 8)];
+        if (ss >= 0) {
+          const long long qs = ((long long)ss * 3) * 256 + (i0 & 255);
+          float tx_[V], ty_[V], tz_[V];
+          ldv<V>(tx_, sr.h2 + qs); ldv<V>(ty_, sr.h2 + qs + 256); ldv<V>(tz_, sr.h2 + qs + 512);
+#pragma unroll
+          for (int e = 0; e < V; ++e) { h1x[e] = h1x[e] + tx_[e]; h1y[e] = h1y[e] + ty_[e]; h1z[e] = h1z[e] + tz_[e]; }
+        }
+      }
       if (sx >= 0) {
         float kv[V], bb[V], cc[V];
         co(0, kv); co(1, bb); co(2, cc);
@@ -551,6 +574,16 @@ __global__ __launch_bounds__(512, (AXES == 7 ? 2 : 3)) void shell2_step_kernel(G
             if (!wall_z) ey[e] -= coef(mwm, 1, e).y * (kv[e] * d2 + p1);
             if (!wall_y) ez[e] += coef(mwm, 2, e).y * (kv[e] * d1 + p2);
           }
+        }
+      }
+      if (sr.sseg && sr.use_e2 && act) {        // paged E-side source terms of step n+1 on E^{n+2}[k-1]
+        const int ss = sr.sseg[((long long)(k - 1) * g.ny + j) * ((g.nx + 255) >> 8) + (i0 >> 8)];
+        if (ss >= 0) {
+          const long long qs = ((long long)ss * 3) * 256 + (i0 & 255);
+          float tx_[V], ty_[V], tz_[V];
+          ldv<V>(tx_, sr.e2 + qs); ldv<V>(ty_, sr.e2 + qs + 256); ldv<V>(tz_, sr.e2 + qs + 512);
+#pragma unroll
+          for (int e = 0; e < V; ++e) { ex[e] = ex[e] + tx_[e]; ey[e] = ey[e] + ty_[e]; ez[e] = ez[e] + tz_[e]; }
         }
       }
       if (st_lane && k > kc0) {
