@@ -128,13 +128,23 @@ def test_electric_sheet_inside_absorber_layers(emu_lib):
     check(disc.spec, emu_lib, 5 + 64 * 3, (11, 16, 13))
 
 
-def test_two_lists_on_one_node_keep_single_steps(emu_lib):
-    """two sheets that cross: nodes both lists add to — E + term cannot stand for two additions one after the other, the lists keep
-    single steps while they inject (and the run is what it was)"""
+def test_lists_that_meet_on_nodes(emu_lib):
+    """two sheets that cross, and a TFSF box with a polarisation angle (two incident grids correcting the same nodes): the second list
+    goes to layer 1, added behind layer 0 as the list kernels add one after the other; a third sheet through the crossing would need
+    a third layer — such a problem keeps single steps while its lists inject (and the run is what it was)"""
     N = (40, 30, 28)
-    srcs = [td.UniformCurrentSource(center=(0, 0.2, 0), size=(td.inf, 0, td.inf), source_time=PULSE, polarization="Ez"),
-            td.UniformCurrentSource(center=(0.1, 0, 0), size=(0, td.inf, td.inf), source_time=PULSE, polarization="Ez")]
-    disc = discretize(sim(N, PEC, srcs, [BALL]), n_steps=30)
+    two = [td.UniformCurrentSource(center=(0, 0.2, 0), size=(td.inf, 0, td.inf), source_time=PULSE, polarization="Ez"),
+           td.UniformCurrentSource(center=(0.1, 0, 0), size=(0, td.inf, td.inf), source_time=PULSE, polarization="Ez")]
+    disc = discretize(sim(N, PEC, two, [BALL], MON), n_steps=40)
+    disc.spec.decay_every = 0
+    check(disc.spec, emu_lib, 5 + 64 * 3, (11, 16, 13))
+    box = [td.TFSF(center=(0, 0, 0), size=(1.0, 0.7, 0.6), source_time=PULSE, injection_axis=2, direction="+", pol_angle=0.4)]
+    disc = discretize(sim((44, 36, 32), PML, box, [BALL], MON), n_steps=40)
+    disc.spec.decay_every = 0
+    assert len(disc.spec.tfsf) == 2
+    check(disc.spec, emu_lib, 6 + 64 * 4, (11, 16, 13), shell2=1, seed=2)
+    three = two + [td.UniformCurrentSource(center=(0, 0, 0.1), size=(td.inf, td.inf, 0), source_time=PULSE, polarization="Ez")]
+    disc = discretize(sim(N, PEC, three, [BALL]), n_steps=30)
     disc.spec.decay_every = 0
     ref = run(disc.spec, emu_lib, 0, (11, 16))
     got = run(disc.spec, emu_lib, 5 + 64 * 3, (11, 16))

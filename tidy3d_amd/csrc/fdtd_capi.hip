@@ -96,6 +96,7 @@ struct PointSrc {
   long long n_steps = 0;
   int ke0 = 0, ke1 = 0, kh0 = 0, kh1 = 0;   // planes [k0, k1) that hold its E / H points
   uint32_t *soff_e = nullptr, *soff_h = nullptr;   // slots of the nodes in the paged source terms (SrcPaged)
+  int layer_e = 0, layer_h = 0;                    // their layers
   std::vector<int32_t> host_comp_e, host_comp_h;   // host copies of the nodes (the two-step sweep applies them in-kernel)
   std::vector<uint32_t> host_cell_e, host_cell_h;
 };
@@ -108,6 +109,7 @@ struct TfsfList {
   uint32_t* cell = nullptr;
   float* w = nullptr;
   uint32_t* soff = nullptr;        // slots of the target nodes in the paged source terms (SrcPaged)
+  int layer = 0;                   // their layer
 };
 
 struct Tfsf {
@@ -161,7 +163,8 @@ struct SrcPaged {
   int state = 0;                   // 0 = not tried, 1 = ready, -1 = this problem cannot (two lists meet on a node, ...)
   int n_blocks = 0;
   int* sseg = nullptr;             // [nz][ny][nbx]
-  float *e1 = nullptr, *h2 = nullptr, *e2 = nullptr;     // [n_blocks][3][256]
+  float *e1 = nullptr, *h2 = nullptr, *e2 = nullptr;     // [n_blocks][3][256]: layer 0
+  float *e1b = nullptr, *h2b = nullptr, *e2b = nullptr;  // layer 1: lists that meet an earlier list on a node (nullptr: none does)
   bool any_h = false;              // a list has H-side nodes
   long long pairs = 0;
 };
@@ -1158,7 +1161,7 @@ const FdtdSolver::TileClasses* tile_classes(FdtdSolver* h, int W, int zc, const 
 // may apply the E-side sources of step n + 1 itself (the caller's ONE launch covers every source node).
 // `sr`: paged source terms of this pair (the caller has filled them, spg_fill; the node table then lists no sources).
 int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb, bool* sources2_done, bool* damp2_done = nullptr,
-                  const ClipP* clip = nullptr, bool use_disp = false, bool e2_clip = false, const SrcP& sr = SrcP{nullptr, nullptr, nullptr, nullptr, 0, 0}) {
+                  const ClipP* clip = nullptr, bool use_disp = false, bool e2_clip = false, const SrcP& sr = SrcP{}) {
   const bool inject = tb->with_sources;      // (false: the lists are spent, or — shell pairs with z holes — their planes take single steps)
   const GridP& g = h->g;
   if (ensure_second_set(h)) return -1;
@@ -1573,7 +1576,7 @@ void shell2_shape(const FdtdSolver* h, const Shell2Box& bx, int W, int zc_cap, S
 // more to the four half-empty launches than the third wave bought (0.84 ms, profiles/r5/r5f).  shell2_on = 2 / 3: one launch per
 // instantiation / per box (measuring aids).
 void launch_shell2_boxes(FdtdSolver* h, const Shell2Box* bx, int n, const PmlP* pm, hipStream_t st, const F2Table* tb, bool use_disp = false,
-                         const SrcP& sr = SrcP{nullptr, nullptr, nullptr, nullptr, 0, 0}) {
+                         const SrcP& sr = SrcP{}) {
   const DispP dp = use_disp ? DispP{h->disp.dseg, h->disp.cs, h->disp.e1} : DispP{nullptr, nullptr, nullptr};
   // (the DFT monitors of the pair's plan that reach into the shell: the boxes copy the middle step out over them; the dump buffer was sized by launch_fused2)
   Shell2Dump dmp{};
@@ -2218,9 +2221,10 @@ bool disp_inside(const FdtdSolver* h, const int lo[3], const int hi[3], int marg
   return true;
 }
 
-// One-off: slots for the nodes of every source list in paged storage (fdtd_fused2.hpp SrcP).  Needs one GPU and, per side (E / H), at
-// most ONE node per slot: where two lists (or a list twice) meet on a node the pair cannot form E + term as the list kernels would
-// one after the other.  state = 1 (ready) or -1.  -1 = a HIP error.
+// One-off: slots for the nodes of every source list in paged storage (fdtd_fused2.hpp SrcP).  Needs one GPU and at most two LAYERS:
+// a list goes to layer 0, or — where it meets an earlier list of its side (E / H) on a node: the second polarisation component of
+// a TFSF box — to layer 1, which the kernels add behind layer 0 as the list kernels would one after the other; a list that meets a
+// layer-1 list, or lists a node twice, leaves the problem to single steps.  state = 1 (ready) or -1.  -1 = a HIP error.
 int spg_setup(FdtdSolver* h) {
   SrcPaged& S = h->spg;
   if (S.state != 0) return 0;
@@ -2236,17 +2240,18 @@ int spg_setup(FdtdSolver* h) {
   hipStream_t st = h->stream;
   auto give_up = [&]() { (void)hipGetLastError(); h->err.clear(); return 0; };
   if (dev_alloc(h, &S.sseg, nseg)) return give_up();
-  auto each = [&](auto fn) {                 // every (cells, comps, n, soff slot, H side?) of every list
-    for (PointSrc& s : h->psrc) {
-      if (s.n_e) fn((const uint32_t*)s.cell_e, (const int32_t*)s.comp_e, s.n_e, &s.soff_e, false);
-      if (s.n_h) fn((const uint32_t*)s.cell_h, (const int32_t*)s.comp_h, s.n_h, &s.soff_h, true);
-    }
+  // every (cells, comps, n, soff, layer, H side?) of every list, in the order launch_sources adds them: TFSF boxes, then point lists
+  auto each = [&](auto fn) {
     for (Tfsf& t : h->tfsf) {
-      if (t.e.n_targets) fn((const uint32_t*)t.e.cell, (const int32_t*)t.e.comp, t.e.n_targets, &t.e.soff, false);
-      if (t.h.n_targets) fn((const uint32_t*)t.h.cell, (const int32_t*)t.h.comp, t.h.n_targets, &t.h.soff, true);
+      if (t.e.n_targets) fn((const uint32_t*)t.e.cell, (const int32_t*)t.e.comp, t.e.n_targets, &t.e.soff, &t.e.layer, false);
+      if (t.h.n_targets) fn((const uint32_t*)t.h.cell, (const int32_t*)t.h.comp, t.h.n_targets, &t.h.soff, &t.h.layer, true);
+    }
+    for (PointSrc& s : h->psrc) {
+      if (s.n_e) fn((const uint32_t*)s.cell_e, (const int32_t*)s.comp_e, s.n_e, &s.soff_e, &s.layer_e, false);
+      if (s.n_h) fn((const uint32_t*)s.cell_h, (const int32_t*)s.comp_h, s.n_h, &s.soff_h, &s.layer_h, true);
     }
   };
-  each([&](const uint32_t* cell, const int32_t*, long long n, uint32_t**, bool) {
+  each([&](const uint32_t* cell, const int32_t*, long long n, uint32_t**, int*, bool) {
     hipLaunchKernelGGL(disp_mark_kernel, dim3(nblk(n)), dim3(256), 0, st, cell, n, g.nx, nbx, S.sseg);
   });
   std::vector<int> seg(nseg, 0);
@@ -2257,62 +2262,83 @@ int spg_setup(FdtdSolver* h) {
   const long long floats = nb * 3 * 256;
   if (nb == 0 || floats >= (1LL << 32)) return give_up();
   HIPCHK(h, hipMemcpyAsync(S.sseg, seg.data(), nseg * sizeof(int), hipMemcpyHostToDevice, st));
-  int *cnt_e = nullptr, *cnt_h = nullptr, *box = nullptr;
+  int *occ[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *box = nullptr, *hit = nullptr;       // [side][layer]
   const int big = 1 << 30;
-  const int box0[7] = {big, -1, big, -1, big, -1, 0};
+  const int box0[6] = {big, -1, big, -1, big, -1};
   if (dev_alloc(h, &S.e1, (size_t)floats) || dev_alloc(h, &S.h2, (size_t)floats) || dev_alloc(h, &S.e2, (size_t)floats) ||
-      dev_alloc(h, &cnt_e, (size_t)floats) || dev_alloc(h, &cnt_h, (size_t)floats) || dev_upload(h, &box, box0, 7)) return give_up();
-  bool failed = false;
+      dev_upload(h, &box, box0, 6) || dev_alloc(h, &hit, 2)) return give_up();
+  for (int sd = 0; sd < 2; ++sd) for (int ly = 0; ly < 2; ++ly) if (dev_alloc(h, &occ[sd][ly], (size_t)floats)) return give_up();
+  bool failed = false, hip_failed = false;
+  int layers = 1;
   S.any_h = false;
-  each([&](const uint32_t* cell, const int32_t* comp, long long n, uint32_t** soff, bool h_side) {
-    if (failed || dev_alloc(h, soff, (size_t)n, false)) { failed = true; return; }
+  each([&](const uint32_t* cell, const int32_t* comp, long long n, uint32_t** soff, int* layer, bool h_side) {
+    if (failed || hip_failed) return;
+    if (dev_alloc(h, soff, (size_t)n, false)) { failed = true; return; }
     S.any_h = S.any_h || h_side;
-    hipLaunchKernelGGL(src_soff_kernel, dim3(nblk(n)), dim3(256), 0, st, cell, comp, n, g.nx, g.ny, nbx, (const int*)S.sseg, *soff,
-                       h_side ? cnt_h : cnt_e, box);
+    hipLaunchKernelGGL(src_soff_kernel, dim3(nblk(n)), dim3(256), 0, st, cell, comp, n, g.nx, g.ny, nbx, (const int*)S.sseg, *soff, box);
+    // the layer: above every earlier list of this side it meets
+    int hh[2] = {0, 0};
+    auto probe = [&](int ly, int mark) {
+      if (hipMemsetAsync(hit, 0, 2 * sizeof(int), st) != hipSuccess) { hip_failed = true; return; }
+      hipLaunchKernelGGL(src_layer_kernel, dim3(nblk(n)), dim3(256), 0, st, (const uint32_t*)*soff, n, occ[h_side ? 1 : 0][ly], hit, mark);
+      if (hipMemcpyAsync(hh, hit, sizeof(hh), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) hip_failed = true;
+    };
+    probe(1, 0);
+    if (hip_failed) return;
+    if (hh[0] > 0) { failed = true; return; }            // it would need a third layer
+    probe(0, 0);
+    if (hip_failed) return;
+    *layer = hh[0] > 0 ? 1 : 0;
+    layers = std::max(layers, *layer + 1);
+    probe(*layer, 1);
+    if (!hip_failed && hh[1] > 0) failed = true;         // a node listed twice
   });
+  for (int sd = 0; sd < 2; ++sd) for (int ly = 0; ly < 2; ++ly) release_buf(h, occ[sd][ly]);
+  if (hip_failed) return fail(h, "spg_setup: a HIP call failed");
   if (failed) return give_up();
-  hipLaunchKernelGGL(src_max_kernel, dim3(nblk(floats)), dim3(256), 0, st, (const int*)cnt_e, floats, box + 6);
-  hipLaunchKernelGGL(src_max_kernel, dim3(nblk(floats)), dim3(256), 0, st, (const int*)cnt_h, floats, box + 6);
-  int boxh[7];
-  HIPCHK(h, hipMemcpyAsync(boxh, box, sizeof(boxh), hipMemcpyDeviceToHost, st));
+  if (layers > 1 && (dev_alloc(h, &S.e1b, (size_t)floats) || dev_alloc(h, &S.h2b, (size_t)floats) || dev_alloc(h, &S.e2b, (size_t)floats)))
+    return give_up();
   HIPCHK(h, hipStreamSynchronize(st));
-  release_buf(h, cnt_e); release_buf(h, cnt_h);
-  if (boxh[6] > 1) return give_up();                     // two nodes of one side on one slot
   S.n_blocks = (int)nb;
   S.state = 1;
   return 0;
 }
-// the three arrays of the pair (n, n + 1), and the incident grids of the TFSF boxes advanced through both steps — in the order of two
-// single steps (the H-side terms of step n were added to H^{n-1/2} in place just before, launch_sources):
+// the three arrays (per layer) of the pair (n, n + 1), and the incident grids of the TFSF boxes advanced through both steps — in the
+// order of two single steps (the H-side terms of step n were added to H^{n-1/2} in place just before, launch_sources):
 //   incident H(n) | E-side terms of n | incident E(n) | H-side terms of n+1 | incident H(n+1) | E-side terms of n+1 | incident E(n+1)
 void spg_fill(FdtdSolver* h, long long n, hipStream_t st) {
   SrcPaged& S = h->spg;
-  auto fill = [&](float* val, bool e_side, long long step) {
+  auto fill = [&](float* val0, float* val1, bool e_side, long long step) {
     for (Tfsf& t : h->tfsf) {
       const TfsfList& L = e_side ? t.e : t.h;
       if (!L.n_targets) continue;
-      hipLaunchKernelGGL(src_fill_tfsf_kernel, dim3(nblk(L.n_targets)), dim3(256), 0, st, val, (const uint32_t*)L.soff, (const int32_t*)L.start,
-                         (const float*)L.w, (const int32_t*)L.aux, (const float*)(e_side ? t.h1 : t.e1), L.n_targets, step >= t.n_steps ? 1 : 0);
+      hipLaunchKernelGGL(src_fill_tfsf_kernel, dim3(nblk(L.n_targets)), dim3(256), 0, st, L.layer ? val1 : val0, (const uint32_t*)L.soff,
+                         (const int32_t*)L.start, (const float*)L.w, (const int32_t*)L.aux, (const float*)(e_side ? t.h1 : t.e1), L.n_targets,
+                         step >= t.n_steps ? 1 : 0);
     }
     for (PointSrc& s : h->psrc) {
       const long long nn = e_side ? s.n_e : s.n_h;
       if (!nn) continue;
-      hipLaunchKernelGGL(src_fill_points_kernel, dim3(nblk(nn)), dim3(256), 0, st, val, (const uint32_t*)(e_side ? s.soff_e : s.soff_h),
-                         (const float*)(e_side ? s.wre_e : s.wre_h), (const float*)(e_side ? s.wim_e : s.wim_h),
-                         (const float2*)(e_side ? s.wave_e : s.wave_h), step, nn, step >= s.n_steps ? 1 : 0);
+      hipLaunchKernelGGL(src_fill_points_kernel, dim3(nblk(nn)), dim3(256), 0, st, (e_side ? s.layer_e : s.layer_h) ? val1 : val0,
+                         (const uint32_t*)(e_side ? s.soff_e : s.soff_h), (const float*)(e_side ? s.wre_e : s.wre_h),
+                         (const float*)(e_side ? s.wim_e : s.wim_h), (const float2*)(e_side ? s.wave_e : s.wave_h), step, nn,
+                         step >= s.n_steps ? 1 : 0);
     }
   };
   advance_tfsf_aux(h, false, n, st, false);
-  fill(S.e1, true, n);
+  fill(S.e1, S.e1b, true, n);
   advance_tfsf_aux(h, true, n, st, false);
-  if (S.any_h) fill(S.h2, false, n + 1);
+  if (S.any_h) fill(S.h2, S.h2b, false, n + 1);
   advance_tfsf_aux(h, false, n + 1, st, false);
-  fill(S.e2, true, n + 1);
+  fill(S.e2, S.e2b, true, n + 1);
   advance_tfsf_aux(h, true, n + 1, st, false);
 }
 SrcP spg_params(const FdtdSolver* h) {
   const SrcPaged& S = h->spg;
-  return SrcP{S.sseg, S.e1, S.h2, S.e2, S.any_h ? 1 : 0, 1};
+  SrcP p;
+  p.sseg = S.sseg; p.e1 = S.e1; p.h2 = S.h2; p.e2 = S.e2; p.use_h2 = S.any_h ? 1 : 0; p.use_e2 = 1;
+  p.e1b = S.e1b; p.h2b = S.h2b; p.e2b = S.e2b;
+  return p;
 }
 
 // z boundary conditions of a single slab (no neighbour): fill ghost planes
@@ -3735,7 +3761,7 @@ struct Run {
     launch_sources(h, false, n, 0, nz, st);                  // H-side sources of step n on H^{n-1/2}, then the incident grid's H: the order of a single step
     if (pair_spg) spg_fill(h, n, st);                        // (paged source terms of the pair; the incident grids through both steps)
     else advance_tfsf_aux(h, false, n, st);
-    const SrcP sr = pair_spg ? spg_params(h) : SrcP{nullptr, nullptr, nullptr, nullptr, 0, 0};
+    const SrcP sr = pair_spg ? spg_params(h) : SrcP{};
     HIPCHK(h, hipEventRecord(h->ev_shell_a, st));
     HIPCHK(h, hipStreamWaitEvent(cs, h->ev_shell_a, 0));
     const FieldP A = h->f, B = h->f2, T = h->f3;
@@ -4077,7 +4103,7 @@ struct Run {
     bool sources2_done = false, damp2_done = true;
     launch_sources(h, false, n, 0, nz, st);              // H-side sources of step n act on H^{n-1/2}, as before a single step
     if (pair_spg) spg_fill(h, n, st);                    // (the other source terms of the pair into paged storage, the incident grids through both steps)
-    if (launch_fused2(h, n, st, tb, &sources2_done, &damp2_done, nullptr, pair_disp, false, pair_spg ? spg_params(h) : SrcP{nullptr, nullptr, nullptr, nullptr, 0, 0})) return -1;
+    if (launch_fused2(h, n, st, tb, &sources2_done, &damp2_done, nullptr, pair_disp, false, pair_spg ? spg_params(h) : SrcP{})) return -1;
     pair_record(h, tb, n, st);                           // (H^{n+3/2} is not touched by the E-side sources that follow)
     if (rec_at(n + 1)) record_monitors(h, n + 1, true, st);      // DFT records at the middle step: their H terms, from the write set
     if (!sources2_done) launch_sources(h, true, n + 1, 0, nz, st);

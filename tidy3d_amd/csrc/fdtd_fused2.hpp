@@ -60,13 +60,18 @@ struct DispP {
 // e1 = the E-side terms of step n (added to E^{n+1} in S2, behind the walls, in front of damping and ADE), h2 = the H-side terms of
 // step n+1 (added to H^{n+1/2} at the top of S3), e2 = the E-side terms of step n+1 (added to E^{n+2} in S4).  The H-side terms of
 // step n act on H^{n-1/2} in front of the sweep, as always.  One term per node and side (the host checks that no two lists meet
-// on a node): E + term is what the list kernel would have formed.  sseg == nullptr: none.
+// One term per node, side and LAYER: lists that meet on a node (the two polarisation components of a TFSF box with a pol_angle) go to
+// different layers in their launch order, and (E + term_0) + term_1 is what the list kernels would have formed one after the other
+// (a node only the second list touches adds a zero first).  sseg == nullptr: none.
 struct SrcP {
-  const int* sseg;                         // [nz][ny][ceil(nx / 256)]: block of the row segment, -1 = no source node in it
-  const float* e1;
-  const float* h2;
-  const float* e2;
-  int use_h2, use_e2;                      // a list is alive at step n+1
+  const int* sseg = nullptr;               // [nz][ny][ceil(nx / 256)]: block of the row segment, -1 = no source node in it
+  const float* e1 = nullptr;
+  const float* h2 = nullptr;
+  const float* e2 = nullptr;
+  int use_h2 = 0, use_e2 = 0;              // a list is alive at step n+1
+  const float* e1b = nullptr;              // layer 1 (nullptr: no two lists meet)
+  const float* h2b = nullptr;
+  const float* e2b = nullptr;
 };
 constexpr int kMaxCap = 1024;
 constexpr int kSeamArrays = 13;  // of step one: H1_y, H1_z, E1_x, E1_y, E1_z [c-1], E1_y, E1_z [c]; of step two: H2_x [c-1], H2_y, H2_z [c-2], H2_x, H2_y, H2_z [c]
@@ -81,7 +86,7 @@ void launch_inject_values(hipStream_t st, float* val, const float* w_re, const f
 void launch_fused2_step(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
                         const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,
                         int xcd_remap, const InjP& inj, float* seam, const DampT& dmp, const ClipP& clip, const TileClassP& tcl = TileClassP{nullptr},
-                        const DispP& dp = DispP{nullptr, nullptr, nullptr}, const SrcP& sr = SrcP{nullptr, nullptr, nullptr, nullptr, 0, 0});
+                        const DispP& dp = DispP{nullptr, nullptr, nullptr}, const SrcP& sr = SrcP{});
 // the instantiations that add paged source terms (opt bit 6; always with bits 0 and 2): fdtd_fused2s.hip
 void launch_fused2_step_src(hipStream_t st, int waves, int opt, int grid_blocks, const GridP& g, const FieldP& a,
                             const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,
@@ -120,6 +125,6 @@ void launch_dft_record_dump(hipStream_t st, const DftDumpP& r, const float* dump
                             const float2* phase, int nf);
 // (inj: the seam kernel adds the E-side source terms of step n+1 when the sweep did — inj.e2_in_sweep)
 void launch_seams(hipStream_t st, const GridP& g, const FieldP& b, const StepP& s, const MatP& m, const float* seam,
-                  int n_seams, const DampT& dmp, const ClipP& clip, const InjP& inj, const SrcP& sr = SrcP{nullptr, nullptr, nullptr, nullptr, 0, 0});
+                  int n_seams, const DampT& dmp, const ClipP& clip, const InjP& inj, const SrcP& sr = SrcP{});
 
 }  // namespace fdtd

@@ -19,7 +19,7 @@ void launch_fused2_step_clip(hipStream_t st, int waves, int opt, int grid_blocks
   const size_t shmem = ((size_t)8 * waves * 64) * sizeof(float4);
 #define FDTD_F2_O(LBV, OV)                                                                                             \
   hipLaunchKernelGGL((fused2_step_kernel<LBV, OV>), grid, block, shmem, st, g, a, b, s, m, zchunk, nbx, nby, nbz,     \
-                     xcd_remap, inj, seam, dmp, clip, tcl, DispP{nullptr, nullptr, nullptr}, SrcP{nullptr, nullptr, nullptr, nullptr, 0, 0})
+                     xcd_remap, inj, seam, dmp, clip, tcl, DispP{nullptr, nullptr, nullptr}, SrcP{})
 #define FDTD_F2(LBV)                                                                                                   \
   do {                                                                                                                 \
     switch (opt & 7) {                                                                                                 \

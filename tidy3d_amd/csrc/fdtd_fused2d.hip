@@ -20,7 +20,7 @@ void launch_fused2_step_disp(hipStream_t st, int waves, int opt, int grid_blocks
   const size_t shmem = ((size_t)8 * waves * 64 + ((opt & 8) ? 2 * 64 : 0)) * sizeof(float4);
 #define FDTD_F2_O(LBV, OV)                                                                                             \
   hipLaunchKernelGGL((fused2_step_kernel<LBV, OV>), grid, block, shmem, st, g, a, b, s, m, zchunk, nbx, nby, nbz,     \
-                     xcd_remap, inj, seam, dmp, clip, tcl, dp, SrcP{nullptr, nullptr, nullptr, nullptr, 0, 0})
+                     xcd_remap, inj, seam, dmp, clip, tcl, dp, SrcP{})
   // 32 + 2 + 1 = 35: materials + ADE, non-temporal stores; + 4: monitor table; + 8: absorber layers; + 16: clipped
 #define FDTD_F2(LBV)                                                                                                   \
   do {                                                                                                                 \

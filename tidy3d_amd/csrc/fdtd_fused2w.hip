@@ -21,7 +21,7 @@ void launch_fused2_step_whatif(hipStream_t st, int waves, int opt, int grid_bloc
   const DispP dp{nullptr, nullptr, nullptr};
 #define FDTD_F2_W(WV)                                                                                                  \
   case WV: hipLaunchKernelGGL((fused2_step_kernel<1024, 1 | (WV << 8)>), grid, block, shmem, st, g, a, b, s, m, zchunk, nbx, nby,  \
-                              nbz, xcd_remap, inj, seam, dmp, clip, tcl, dp, SrcP{nullptr, nullptr, nullptr, nullptr, 0, 0}); break
+                              nbz, xcd_remap, inj, seam, dmp, clip, tcl, dp, SrcP{}); break
   switch (opt >> 8) {
     FDTD_F2_W(1); FDTD_F2_W(2); FDTD_F2_W(3); FDTD_F2_W(4); FDTD_F2_W(5); FDTD_F2_W(6); FDTD_F2_W(7); FDTD_F2_W(8);
     default: break;

@@ -1528,7 +1528,7 @@ __global__ void tfsf_aux_e_kernel(float* e1, const float* h1, const float* ae, c
 // soff[t]: the slot of node t of a list in the paged arrays; count[slot] += 1 (two nodes of one side on one slot: the pair cannot
 // form E + term exactly — the host then keeps single steps while the lists inject); box: bounding box of the nodes
 __global__ __launch_bounds__(256) void src_soff_kernel(const uint32_t* cell, const int32_t* comp, long long n, int nx, int ny, int nbx,
-                                                        const int* sseg, uint32_t* soff, int* count, int* box) {
+                                                        const int* sseg, uint32_t* soff, int* box) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const long long p = cell[t];
@@ -1536,13 +1536,16 @@ __global__ __launch_bounds__(256) void src_soff_kernel(const uint32_t* cell, con
   const long long blk = sseg[(p / nx) * nbx + i / 256];
   const uint32_t o = (uint32_t)((blk * 3 + comp[t] % 3) * 256 + (i & 255));
   soff[t] = o;
-  atomicAdd(&count[o], 1);
   const int j = (int)((p / nx) % ny), k = (int)(p / ((long long)nx * ny));
   atomicMin(&box[0], i); atomicMax(&box[1], i); atomicMin(&box[2], j); atomicMax(&box[3], j); atomicMin(&box[4], k); atomicMax(&box[5], k);
 }
-__global__ __launch_bounds__(256) void src_max_kernel(const int* count, long long n, int* out) {
+// mark != 0: the list takes its slots in this layer's occupancy map (hit[1] counts slots taken twice: a node listed twice);
+// mark == 0: hit[0] counts the list's slots an earlier list holds in this layer
+__global__ __launch_bounds__(256) void src_layer_kernel(const uint32_t* soff, long long n, int* occ, int* hit, int mark) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n && count[t] > 1) atomicMax(out, count[t]);
+  if (t >= n) return;
+  if (mark) { if (atomicAdd(&occ[soff[t]], 1) > 0) atomicAdd(&hit[1], 1); }
+  else if (occ[soff[t]] > 0) atomicAdd(&hit[0], 1);
 }
 // the term point_source_kernel would add at `step`, formed by its operations, into the node's slot (zero != 0: the list is spent)
 __global__ __launch_bounds__(256) void src_fill_points_kernel(float* val, const uint32_t* soff, const float* w_re, const float* w_im,

@@ -520,6 +520,11 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
             ldv<V>(tx_, sr.e1 + qs); ldv<V>(ty_, sr.e1 + qs + 256); ldv<V>(tz_, sr.e1 + qs + 512);
 #pragma unroll
             for (int e = 0; e < V; ++e) { e1xn[e] = e1xn[e] + tx_[e]; e1yn[e] = e1yn[e] + ty_[e]; e1zn[e] = e1zn[e] + tz_[e]; }
+            if (sr.e1b) {
+              ldv<V>(tx_, sr.e1b + qs); ldv<V>(ty_, sr.e1b + qs + 256); ldv<V>(tz_, sr.e1b + qs + 512);
+#pragma unroll
+              for (int e = 0; e < V; ++e) { e1xn[e] = e1xn[e] + tx_[e]; e1yn[e] = e1yn[e] + ty_[e]; e1zn[e] = e1zn[e] + tz_[e]; }
+            }
           }
         }
         // The node table of the plane.  Codes 0 - 2: the E-side point sources of step n act on E^{n+1} before step n+1 reads
@@ -677,6 +682,11 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
           ldv<V>(tx_, sr.h2 + qs); ldv<V>(ty_, sr.h2 + qs + 256); ldv<V>(tz_, sr.h2 + qs + 512);
 #pragma unroll
           for (int e = 0; e < V; ++e) { h1x[e] = h1x[e] + tx_[e]; h1y[e] = h1y[e] + ty_[e]; h1z[e] = h1z[e] + tz_[e]; }
+          if (sr.h2b) {
+            ldv<V>(tx_, sr.h2b + qs); ldv<V>(ty_, sr.h2b + qs + 256); ldv<V>(tz_, sr.h2b + qs + 512);
+#pragma unroll
+            for (int e = 0; e < V; ++e) { h1x[e] = h1x[e] + tx_[e]; h1y[e] = h1y[e] + ty_[e]; h1z[e] = h1z[e] + tz_[e]; }
+          }
         }
       }
       // H-side point sources of step n+1 (codes 3 - 5 of the node table of plane k-1) act on H^{n+1/2} before step n+1 advances it
@@ -817,6 +827,11 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
           ldv<V>(tx_, sr.e2 + qs); ldv<V>(ty_, sr.e2 + qs + 256); ldv<V>(tz_, sr.e2 + qs + 512);
 #pragma unroll
           for (int e = 0; e < V; ++e) { ex[e] = ex[e] + tx_[e]; ey[e] = ey[e] + ty_[e]; ez[e] = ez[e] + tz_[e]; }
+          if (sr.e2b) {
+            ldv<V>(tx_, sr.e2b + qs); ldv<V>(ty_, sr.e2b + qs + 256); ldv<V>(tz_, sr.e2b + qs + 512);
+#pragma unroll
+            for (int e = 0; e < V; ++e) { ex[e] = ex[e] + tx_[e]; ey[e] = ey[e] + ty_[e]; ez[e] = ez[e] + tz_[e]; }
+          }
         }
       }
       // the node table of plane k-1: the E-side sources of step n+1 (when the launch carries them) act on E^{n+2}
@@ -987,6 +1002,7 @@ __global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, M
         const long long qs = ((long long)blk * 3) * 256 + ((c - 1) & 255);
         h1y = h1y + sr.h2[qs + 256];
         h1z = h1z + sr.h2[qs + 512];
+        if (sr.h2b) { h1y = h1y + sr.h2b[qs + 256]; h1z = h1z + sr.h2b[qs + 512]; }
       }
     }
     hy = upd_h(h1y, ch, A(2, jj, kk + 1) - e1x, s.ipz[kk], A(6, jj, kk) - e1z, ipx);
@@ -1032,10 +1048,12 @@ __global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, M
     if (bl >= 0) {
       const long long qs = ((long long)bl * 3) * 256 + ((c - 1) & 255);
       ex_m = ex_m + sr.e2[qs]; ey_m = ey_m + sr.e2[qs + 256]; ez_m = ez_m + sr.e2[qs + 512];
+      if (sr.e2b) { ex_m = ex_m + sr.e2b[qs]; ey_m = ey_m + sr.e2b[qs + 256]; ez_m = ez_m + sr.e2b[qs + 512]; }
     }
     if (br >= 0) {
       const long long qs = ((long long)br * 3) * 256 + (cc & 255);
       ey_c = ey_c + sr.e2[qs + 256]; ez_c = ez_c + sr.e2[qs + 512];
+      if (sr.e2b) { ey_c = ey_c + sr.e2b[qs + 256]; ez_c = ez_c + sr.e2b[qs + 512]; }
     }
   }
   if (inj.val2 && inj.e2_in_sweep) {         // the E-side sources of step n+1 on these two columns (the plane's table rows in their order)

@@ -405,6 +405,11 @@ __global__ __launch_bounds__(512, (AXES == 7 ? 2 : 3)) void shell2_step_kernel(G
           ldv<V>(tx_, sr.e1 + qs); ldv<V>(ty_, sr.e1 + qs + 256); ldv<V>(tz_, sr.e1 + qs + 512);
 #pragma unroll
           for (int e = 0; e < V; ++e) { e1xn[e] = e1xn[e] + tx_[e]; e1yn[e] = e1yn[e] + ty_[e]; e1zn[e] = e1zn[e] + tz_[e]; }
+          if (sr.e1b) {
+            ldv<V>(tx_, sr.e1b + qs); ldv<V>(ty_, sr.e1b + qs + 256); ldv<V>(tz_, sr.e1b + qs + 512);
+#pragma unroll
+            for (int e = 0; e < V; ++e) { e1xn[e] = e1xn[e] + tx_[e]; e1yn[e] = e1yn[e] + ty_[e]; e1zn[e] = e1zn[e] + tz_[e]; }
+          }
         }
       }
       // dispersive cells inside the shell (round 6, as fused2_step_kernel's OPT bit 5): E^{n+1} <- E^{n+1} - cc S(Q^n) from the paged
@@ -462,6 +467,11 @@ __global__ __launch_bounds__(512, (AXES == 7 ? 2 : 3)) void shell2_step_kernel(G
           ldv<V>(tx_, sr.h2 + qs); ldv<V>(ty_, sr.h2 + qs + 256); ldv<V>(tz_, sr.h2 + qs + 512);
 #pragma unroll
           for (int e = 0; e < V; ++e) { h1x[e] = h1x[e] + tx_[e]; h1y[e] = h1y[e] + ty_[e]; h1z[e] = h1z[e] + tz_[e]; }
+          if (sr.h2b) {
+            ldv<V>(tx_, sr.h2b + qs); ldv<V>(ty_, sr.h2b + qs + 256); ldv<V>(tz_, sr.h2b + qs + 512);
+#pragma unroll
+            for (int e = 0; e < V; ++e) { h1x[e] = h1x[e] + tx_[e]; h1y[e] = h1y[e] + ty_[e]; h1z[e] = h1z[e] + tz_[e]; }
+          }
         }
       }
       if (sx >= 0) {
@@ -584,6 +594,11 @@ __global__ __launch_bounds__(512, (AXES == 7 ? 2 : 3)) void shell2_step_kernel(G
           ldv<V>(tx_, sr.e2 + qs); ldv<V>(ty_, sr.e2 + qs + 256); ldv<V>(tz_, sr.e2 + qs + 512);
 #pragma unroll
           for (int e = 0; e < V; ++e) { ex[e] = ex[e] + tx_[e]; ey[e] = ey[e] + ty_[e]; ez[e] = ez[e] + tz_[e]; }
+          if (sr.e2b) {
+            ldv<V>(tx_, sr.e2b + qs); ldv<V>(ty_, sr.e2b + qs + 256); ldv<V>(tz_, sr.e2b + qs + 512);
+#pragma unroll
+            for (int e = 0; e < V; ++e) { ex[e] = ex[e] + tx_[e]; ey[e] = ey[e] + ty_[e]; ez[e] = ez[e] + tz_[e]; }
+          }
         }
       }
       if (st_lane && k > kc0) {

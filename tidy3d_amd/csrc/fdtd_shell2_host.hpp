@@ -34,6 +34,6 @@ struct Shell2M {
 // meet (1, 2, 4: that axis only; anything else: all)
 void launch_shell2_step(hipStream_t st, int waves, bool mat, int axes, const GridP& g, const FieldP& a, const FieldP& b, const StepP& s,
                         const MatP& m, const PmlP* pm, const Shell2M& boxes, const Shell2Dump& dmp,
-                        const DispP& dp = DispP{nullptr, nullptr, nullptr}, const SrcP& sr = SrcP{nullptr, nullptr, nullptr, nullptr, 0, 0});
+                        const DispP& dp = DispP{nullptr, nullptr, nullptr}, const SrcP& sr = SrcP{});
 
 }  // namespace fdtd

@@ -289,7 +289,10 @@ class HipEngine:
             axis_shift = 0                  # (the coupling lists are laid out for the user's axes)
         if _bloch_twin is None and n_ranks == 1 and slab is None and not force_comm and axis_shift != 0:
             layers = tuple((int(f0.num_layers), int(f1.num_layers)) for f0, f1 in spec.pml)
-            self.axis_shift = best_axis_shift(spec.shape, layers, source_sheet(spec)) if axis_shift is None else int(axis_shift) % 3
+            # (round 6: lists the node table cannot hold go out as paged source terms inside the pairs — FDTD_OPT_SRC_PAGED — whatever the
+            #  plane's orientation; only beside a periodic face do their planes still have to be z holes: the sheet's say in the layout)
+            sheet = source_sheet(spec) if any(b == BC_PERIODIC for ax in spec.bc for b in ax) else None
+            self.axis_shift = best_axis_shift(spec.shape, layers, sheet) if axis_shift is None else int(axis_shift) % 3
             spec = permute_spec(spec, self.axis_shift)
             self.spec = spec
         self.ghost = (0, 0, 0)            # ghost cells per axis in front of the real cells (Bloch device layout)
