@@ -167,6 +167,8 @@ struct SrcPaged {
   float *e1b = nullptr, *h2b = nullptr, *e2b = nullptr;  // layer 1: lists that meet an earlier list on a node (nullptr: none does)
   bool any_h = false;              // a list has H-side nodes
   long long pairs = 0;
+  std::vector<int> sseg_host;
+  SrcT* tab = nullptr;             // the arrays' addresses, in device memory (SrcP::t)
 };
 
 struct FdtdSolver {
@@ -187,7 +189,7 @@ struct FdtdSolver {
   uint32_t* mat4b = nullptr;         // wide layout (more than 1023 media): the second word per cell; mat4 then holds E_x | E_y << 16
   uint32_t* roww = nullptr;          // row-segment words [nz][ny][ceil(nx / 256)]
   std::vector<uint32_t> roww_host;   // host copy of them: the tile classes of the two-step sweep are derived from it (tile_classes)
-  struct TileClasses { int W, zc; ClipP box; int nbx, nby, nbz; unsigned char* dev; long long n_bg, n_all; bool disp; };
+  struct TileClasses { int W, zc; ClipP box; int nbx, nby, nbz; unsigned char* dev; long long n_bg, n_all; bool disp, src; };
   std::vector<TileClasses> tile_cls; // one entry per launch shape met so far
   int tile_split = -1;               // FDTD_OPT_TILE_SPLIT: background-only tiles on the plain instantiation: -1 = default (where >= 25 % of the tiles are), 0 = never, 1 = always
   float2* lut = nullptr;
@@ -202,6 +204,7 @@ struct FdtdSolver {
   std::vector<AdeGroup> ade;
   Disp disp;
   SrcPaged spg;
+  std::map<std::array<int, 6>, int> box_paged;       // Shell2P::paged of the shell's boxes met so far (cleared when either paging is set up)
   int spg_on = -1;                   // FDTD_OPT_SRC_PAGED: -1 / 1 = default (on), 0 = off (single steps / z holes while such lists inject, round 5)
   int whatif = 0;                    // FDTD_OPT_WHATIF: a what-if instantiation of the vacuum two-step sweep (fdtd_kernels2.hpp; wrong results, meaningful times)
   int disp_on = -1;                  // FDTD_OPT_DISP: dispersive cells inside the two-step sweeps: -1 = default (on), 0 = off (their planes as z holes, round 5)
@@ -1119,11 +1122,14 @@ const F2Table* fused2_table(FdtdSolver* h, const F2Plan& plan, bool with_sources
 // there the materials launch runs the plain sweep (fused2_step_kernel; the uniform coefficients ARE the table's entry 1: the same
 // bits).
 // `disp` (a launch that advances dispersive cells): class 2 where a row segment the workgroup visits holds one, 1 for other tiles with bodies.
-const FdtdSolver::TileClasses* tile_classes(FdtdSolver* h, int W, int zc, const ClipP& box, int nbx, int nby, int nbz, bool disp = false) {
-  if (!h->mat4 || h->roww_host.empty() || h->tile_split == 0) return nullptr;
+// `src` (a launch that adds paged source terms): + 4 where a row segment the workgroup visits holds a source node — the other tiles run
+// the instantiation without those lines (a launch over a uniform medium has this bit only).
+const FdtdSolver::TileClasses* tile_classes(FdtdSolver* h, int W, int zc, const ClipP& box, int nbx, int nby, int nbz, bool disp = false, bool src = false) {
+  const bool mats = h->mat4 && !h->roww_host.empty();
+  if ((!mats && !src) || h->tile_split == 0) return nullptr;
   for (const auto& t : h->tile_cls)
     if (t.W == W && t.zc == zc && t.nbx == nbx && t.nby == nby && t.nbz == nbz && t.box.j0 == box.j0 && t.box.j1 == box.j1 &&
-        t.box.k0 == box.k0 && t.box.k1 == box.k1 && t.disp == disp) return &t;
+        t.box.k0 == box.k0 && t.box.k1 == box.k1 && t.disp == disp && t.src == src) return &t;
   const GridP& g = h->g;
   const int R = W - 3, nbx_all = (g.nx + 255) / 256;
   std::vector<unsigned char> cls((size_t)nbx * nby * nbz, 0);
@@ -1134,17 +1140,24 @@ const FdtdSolver::TileClasses* tile_classes(FdtdSolver* h, int W, int zc, const 
         const int k0 = box.k0 + tz * zc, k1 = std::min(k0 + zc, box.k1);
         const int j0 = box.j0 + ty * R;
         unsigned char c = 0;
-        for (int k = std::max(k0 - 1, 0); k <= std::min(k1, g.nz - 1) && !c; ++k)
+        for (int k = std::max(k0 - 1, 0); mats && k <= std::min(k1, g.nz - 1) && !c; ++k)
           for (int j = std::max(j0 - 2, 0); j <= std::min(j0 + R, g.ny - 1); ++j)
             if (h->roww_host[((size_t)k * g.ny + j) * nbx_all + tx] != kBgWord) { c = 1; break; }
         if (disp && c)
           for (int k = std::max(k0 - 1, 0); k <= std::min(k1, g.nz - 1) && c < 2; ++k)
             for (int j = std::max(j0 - 2, 0); j <= std::min(j0 + R, g.ny - 1); ++j)
               if (h->disp.dseg_host[((size_t)k * g.ny + j) * nbx_all + tx] >= 0) { c = 2; break; }
-        cls[((size_t)tz * nbx + tx) * nby + ty] = c;
         n_bg += !c;
+        if (src) {
+          bool found = false;
+          for (int k = std::max(k0 - 1, 0); k <= std::min(k1, g.nz - 1) && !found; ++k)
+            for (int j = std::max(j0 - 2, 0); j <= std::min(j0 + R, g.ny - 1); ++j)
+              if (h->spg.sseg_host[((size_t)k * g.ny + j) * nbx_all + tx] >= 0) { found = true; break; }
+          if (found) c |= 4;
+        }
+        cls[((size_t)tz * nbx + tx) * nby + ty] = c;
       }
-  FdtdSolver::TileClasses e{W, zc, box, nbx, nby, nbz, nullptr, n_bg, (long long)cls.size(), disp};
+  FdtdSolver::TileClasses e{W, zc, box, nbx, nby, nbz, nullptr, n_bg, (long long)cls.size(), disp, src};
   if (dev_upload(h, &e.dev, (const unsigned char*)cls.data(), cls.size())) return nullptr;
   h->tile_cls.push_back(e);
   return &h->tile_cls.back();
@@ -1246,8 +1259,8 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
   if (sr.sseg) { opt |= 64 | 4 | 1; *sources2_done = true; h->spg.pairs++; }
   const int blocks = remap ? ((total + 7) / 8) * 8 : total;
   // background-only tiles take the plain sweep inside the materials launch (fdtd_kernels2.hpp, tile classes)
-  const FdtdSolver::TileClasses* tc = tile_classes(h, W, zc, box, nbx, nby, nbz, use_disp);
-  const bool split = tc && (use_disp || (tc->n_bg > 0 && (h->tile_split == 1 || 8 * tc->n_bg >= tc->n_all)));
+  const FdtdSolver::TileClasses* tc = tile_classes(h, W, zc, box, nbx, nby, nbz, use_disp, sr.sseg != nullptr);
+  const bool split = tc && (use_disp || sr.sseg || (tc->n_bg > 0 && (h->tile_split == 1 || 8 * tc->n_bg >= tc->n_all)));
   launch_fused2_step(st, W, opt, blocks, g, h->f, h->f2, sp, mp, zc, nbx, nby, nbz, remap, inj, h->seam_buf, dmp, box,
                      TileClassP{split ? tc->dev : nullptr}, dp, sr);
   if (n_seams > 0) launch_seams(st, g, h->f2, sp, mp, h->seam_buf, n_seams, dmp, box, inj, sr);
@@ -1575,6 +1588,7 @@ void shell2_shape(const FdtdSolver* h, const Shell2Box& bx, int W, int zc_cap, S
 // per instantiation — x / y / z only at three waves per SIMD for 94 % of the cells, all axes for the edges and corners — lost
 // more to the four half-empty launches than the third wave bought (0.84 ms, profiles/r5/r5f).  shell2_on = 2 / 3: one launch per
 // instantiation / per box (measuring aids).
+int shell2_box_paged(FdtdSolver* h, const Shell2Box& bx);
 void launch_shell2_boxes(FdtdSolver* h, const Shell2Box* bx, int n, const PmlP* pm, hipStream_t st, const F2Table* tb, bool use_disp = false,
                          const SrcP& sr = SrcP{}) {
   const DispP dp = use_disp ? DispP{h->disp.dseg, h->disp.cs, h->disp.e1} : DispP{nullptr, nullptr, nullptr};
@@ -1608,6 +1622,7 @@ void launch_shell2_boxes(FdtdSolver* h, const Shell2Box* bx, int n, const PmlP* 
     for (int q = 0; q < n; ++q) {
       if (by_axes && bx[q].axes != axes) continue;
       shell2_shape(h, bx[q], W, zc_cap, &mb.box[mb.n]);
+      mb.box[mb.n].paged = (sr.sseg || dp.dseg) ? shell2_box_paged(h, bx[q]) : 0;
       mb.first[mb.n + 1] = mb.first[mb.n] + mb.box[mb.n].nbx * mb.box[mb.n].nby * mb.box[mb.n].nbz;
       mb.n++;
       if (mb.n == kShell2Boxes || h->shell2_on == 3) flush();
@@ -2207,6 +2222,7 @@ int disp_setup(FdtdSolver* h) {
   D.n_blocks = (int)nb;
   for (int a = 0; a < 3; ++a) { D.lo[a] = boxh[2 * a]; D.hi[a] = boxh[2 * a + 1] + 1; }
   h->tile_cls.clear();
+  h->box_paged.clear();
   D.state = 1;
   return 0;
 }
@@ -2254,7 +2270,8 @@ int spg_setup(FdtdSolver* h) {
   each([&](const uint32_t* cell, const int32_t*, long long n, uint32_t**, int*, bool) {
     hipLaunchKernelGGL(disp_mark_kernel, dim3(nblk(n)), dim3(256), 0, st, cell, n, g.nx, nbx, S.sseg);
   });
-  std::vector<int> seg(nseg, 0);
+  std::vector<int>& seg = S.sseg_host;
+  seg.assign(nseg, 0);
   HIPCHK(h, hipMemcpyAsync(seg.data(), S.sseg, nseg * sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
   long long nb = 0;
@@ -2299,9 +2316,36 @@ int spg_setup(FdtdSolver* h) {
   if (layers > 1 && (dev_alloc(h, &S.e1b, (size_t)floats) || dev_alloc(h, &S.h2b, (size_t)floats) || dev_alloc(h, &S.e2b, (size_t)floats)))
     return give_up();
   HIPCHK(h, hipStreamSynchronize(st));
+  const SrcT tab{S.e1, S.h2, S.e2, S.any_h ? 1 : 0, 1, S.e1b, S.h2b, S.e2b};
+  if (dev_upload(h, &S.tab, &tab, 1)) return give_up();
   S.n_blocks = (int)nb;
   S.state = 1;
+  h->box_paged.clear();
   return 0;
+}
+// Shell2P::paged of a box: does a row segment it visits — rows j0 - 2 .. j1, planes k0 - 1 .. k1, columns i0 - 8 .. i1 + 7 — hold a
+// source node (bit 0) / a dispersive cell (bit 1)?  Found once per box on the host maps of the segments.
+int shell2_box_paged(FdtdSolver* h, const Shell2Box& bx) {
+  const std::array<int, 6> key{bx.i0, bx.i1, bx.j0, bx.j1, bx.k0, bx.k1};
+  auto it = h->box_paged.find(key);
+  if (it != h->box_paged.end()) return it->second;
+  const GridP& g = h->g;
+  const int nbx = (g.nx + 255) / 256;
+  const bool per_x = h->cfg.bc[0] == FDTD_BC_PERIODIC;
+  const int t0 = per_x ? 0 : std::max(0, bx.i0 - 8) / 256, t1 = per_x ? nbx - 1 : std::min(g.nx - 1, bx.i1 + 7) / 256;
+  int flags = 0;
+  const std::vector<int>* maps[2] = {h->spg.state == 1 ? &h->spg.sseg_host : nullptr, h->disp.state == 1 ? &h->disp.dseg_host : nullptr};
+  for (int m = 0; m < 2; ++m) {
+    if (!maps[m] || maps[m]->empty()) continue;
+    bool found = false;
+    for (int k = std::max(0, bx.k0 - 1); k <= std::min(g.nz - 1, bx.k1) && !found; ++k)
+      for (int j = std::max(0, bx.j0 - 2); j <= std::min(g.ny - 1, bx.j1) && !found; ++j)
+        for (int t = t0; t <= t1; ++t)
+          if ((*maps[m])[((size_t)k * g.ny + j) * nbx + t] >= 0) { found = true; break; }
+    if (found) flags |= 1 << m;
+  }
+  h->box_paged[key] = flags;
+  return flags;
 }
 // the three arrays (per layer) of the pair (n, n + 1), and the incident grids of the TFSF boxes advanced through both steps — in the
 // order of two single steps (the H-side terms of step n were added to H^{n-1/2} in place just before, launch_sources):
@@ -2336,8 +2380,7 @@ void spg_fill(FdtdSolver* h, long long n, hipStream_t st) {
 SrcP spg_params(const FdtdSolver* h) {
   const SrcPaged& S = h->spg;
   SrcP p;
-  p.sseg = S.sseg; p.e1 = S.e1; p.h2 = S.h2; p.e2 = S.e2; p.use_h2 = S.any_h ? 1 : 0; p.use_e2 = 1;
-  p.e1b = S.e1b; p.h2b = S.h2b; p.e2b = S.e2b;
+  p.sseg = S.sseg; p.t = S.tab;
   return p;
 }
 

@@ -63,15 +63,18 @@ struct DispP {
 // One term per node, side and LAYER: lists that meet on a node (the two polarisation components of a TFSF box with a pol_angle) go to
 // different layers in their launch order, and (E + term_0) + term_1 is what the list kernels would have formed one after the other
 // (a node only the second list touches adds a zero first).  sseg == nullptr: none.
+struct SrcT {                              // (in device memory: a sweep reads it only in the few row segments that hold source nodes —
+  const float* e1;                         //  as kernel arguments the eight words cost the sweep 16 scalar registers it spills for)
+  const float* h2;
+  const float* e2;
+  int use_h2, use_e2;                      // a list has H-side / E-side nodes
+  const float* e1b;                        // layer 1 (nullptr: no two lists meet)
+  const float* h2b;
+  const float* e2b;
+};
 struct SrcP {
   const int* sseg = nullptr;               // [nz][ny][ceil(nx / 256)]: block of the row segment, -1 = no source node in it
-  const float* e1 = nullptr;
-  const float* h2 = nullptr;
-  const float* e2 = nullptr;
-  int use_h2 = 0, use_e2 = 0;              // a list is alive at step n+1
-  const float* e1b = nullptr;              // layer 1 (nullptr: no two lists meet)
-  const float* h2b = nullptr;
-  const float* e2b = nullptr;
+  const SrcT* t = nullptr;
 };
 constexpr int kMaxCap = 1024;
 constexpr int kSeamArrays = 13;  // of step one: H1_y, H1_z, E1_x, E1_y, E1_z [c-1], E1_y, E1_z [c]; of step two: H2_x [c-1], H2_y, H2_z [c-2], H2_x, H2_y, H2_z [c]

@@ -517,11 +517,11 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
           if (ss >= 0 && act) {
             const long long qs = ((long long)ss * 3) * 256 + tx * V;
             float tx_[V], ty_[V], tz_[V];
-            ldv<V>(tx_, sr.e1 + qs); ldv<V>(ty_, sr.e1 + qs + 256); ldv<V>(tz_, sr.e1 + qs + 512);
+            ldv<V>(tx_, sr.t->e1 + qs); ldv<V>(ty_, sr.t->e1 + qs + 256); ldv<V>(tz_, sr.t->e1 + qs + 512);
 #pragma unroll
             for (int e = 0; e < V; ++e) { e1xn[e] = e1xn[e] + tx_[e]; e1yn[e] = e1yn[e] + ty_[e]; e1zn[e] = e1zn[e] + tz_[e]; }
-            if (sr.e1b) {
-              ldv<V>(tx_, sr.e1b + qs); ldv<V>(ty_, sr.e1b + qs + 256); ldv<V>(tz_, sr.e1b + qs + 512);
+            if (sr.t->e1b) {
+              ldv<V>(tx_, sr.t->e1b + qs); ldv<V>(ty_, sr.t->e1b + qs + 256); ldv<V>(tz_, sr.t->e1b + qs + 512);
 #pragma unroll
               for (int e = 0; e < V; ++e) { e1xn[e] = e1xn[e] + tx_[e]; e1yn[e] = e1yn[e] + ty_[e]; e1zn[e] = e1zn[e] + tz_[e]; }
             }
@@ -676,14 +676,14 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
         }
       }
       if constexpr (SRC) {                    // the H-side source terms of step n+1 (behind the damping of H^{n+1/2}, as launch_sources follows launch_damp)
-        if (sr.use_h2 && ss_m >= 0 && act) {
+        if (ss_m >= 0 && act && sr.t->use_h2) {
           const long long qs = ((long long)ss_m * 3) * 256 + tx * V;
           float tx_[V], ty_[V], tz_[V];
-          ldv<V>(tx_, sr.h2 + qs); ldv<V>(ty_, sr.h2 + qs + 256); ldv<V>(tz_, sr.h2 + qs + 512);
+          ldv<V>(tx_, sr.t->h2 + qs); ldv<V>(ty_, sr.t->h2 + qs + 256); ldv<V>(tz_, sr.t->h2 + qs + 512);
 #pragma unroll
           for (int e = 0; e < V; ++e) { h1x[e] = h1x[e] + tx_[e]; h1y[e] = h1y[e] + ty_[e]; h1z[e] = h1z[e] + tz_[e]; }
-          if (sr.h2b) {
-            ldv<V>(tx_, sr.h2b + qs); ldv<V>(ty_, sr.h2b + qs + 256); ldv<V>(tz_, sr.h2b + qs + 512);
+          if (sr.t->h2b) {
+            ldv<V>(tx_, sr.t->h2b + qs); ldv<V>(ty_, sr.t->h2b + qs + 256); ldv<V>(tz_, sr.t->h2b + qs + 512);
 #pragma unroll
             for (int e = 0; e < V; ++e) { h1x[e] = h1x[e] + tx_[e]; h1y[e] = h1y[e] + ty_[e]; h1z[e] = h1z[e] + tz_[e]; }
           }
@@ -821,14 +821,14 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
         s4([&](int, int) { return c1; });
       }
       if constexpr (SRC) {                    // the E-side source terms of step n+1
-        if (sr.use_e2 && ss_m >= 0 && act) {
+        if (ss_m >= 0 && act && sr.t->use_e2) {
           const long long qs = ((long long)ss_m * 3) * 256 + tx * V;
           float tx_[V], ty_[V], tz_[V];
-          ldv<V>(tx_, sr.e2 + qs); ldv<V>(ty_, sr.e2 + qs + 256); ldv<V>(tz_, sr.e2 + qs + 512);
+          ldv<V>(tx_, sr.t->e2 + qs); ldv<V>(ty_, sr.t->e2 + qs + 256); ldv<V>(tz_, sr.t->e2 + qs + 512);
 #pragma unroll
           for (int e = 0; e < V; ++e) { ex[e] = ex[e] + tx_[e]; ey[e] = ey[e] + ty_[e]; ez[e] = ez[e] + tz_[e]; }
-          if (sr.e2b) {
-            ldv<V>(tx_, sr.e2b + qs); ldv<V>(ty_, sr.e2b + qs + 256); ldv<V>(tz_, sr.e2b + qs + 512);
+          if (sr.t->e2b) {
+            ldv<V>(tx_, sr.t->e2b + qs); ldv<V>(ty_, sr.t->e2b + qs + 256); ldv<V>(tz_, sr.t->e2b + qs + 512);
 #pragma unroll
             for (int e = 0; e < V; ++e) { ex[e] = ex[e] + tx_[e]; ey[e] = ey[e] + ty_[e]; ez[e] = ez[e] + tz_[e]; }
           }
@@ -925,6 +925,28 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
 // same launch: two launches, one per class, were measured first and lose to the tail of the short one — 272 material tiles on 256
 // CUs are two rounds of workgroups (profiles/r5/tile_classes.md).
 template <int LB, int OPT>
+__device__ __forceinline__ void fused2_tile_by_class(const GridP& g, const FieldP& a, const FieldP& b, const StepP& s, const MatP& m,
+                                                     int zchunk, int nbx, int nby, int nbz, const InjP& inj, float* __restrict__ seam,
+                                                     const DampT& dmp, const ClipP& clip, int t, const DispP& dp, const SrcP& sr, const TileClassP& tcl) {
+  if constexpr ((OPT & 2) != 0) {
+    if (tcl.cls) {
+      const int cl = tcl.cls[t] & 3;
+      if (cl == 0) {
+        fused2_step_tile<LB, (OPT & ~(2 | 32))>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t, dp, sr);
+        return;
+      }
+      if constexpr ((OPT & 32) != 0) {       // (a tile without dispersive cells in a launch that carries them: the materials sweep)
+        if (cl == 1) {
+          fused2_step_tile<LB, (OPT & ~32)>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t, dp, sr);
+          return;
+        }
+      }
+    }
+  }
+  fused2_step_tile<LB, OPT>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t, dp, sr);
+}
+
+template <int LB, int OPT>
 __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(GridP g, FieldP a, FieldP b, StepP s, MatP m,
                                                          int zchunk, int nbx, int nby, int nbz, int xcd_remap,
                                                          InjP inj, float* __restrict__ seam, DampT dmp, ClipP clip, TileClassP tcl, DispP dp, SrcP sr) {
@@ -942,22 +964,15 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
     }
     if (t >= total) return;
   }
-  if constexpr ((OPT & 2) != 0) {
-    if (tcl.cls) {
-      const int cl = tcl.cls[t];
-      if (cl == 0) {
-        fused2_step_tile<LB, (OPT & ~(2 | 32))>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t, dp, sr);
-        return;
-      }
-      if constexpr ((OPT & 32) != 0) {       // (a tile without dispersive cells in a launch that carries them: the materials sweep)
-        if (cl == 1) {
-          fused2_step_tile<LB, (OPT & ~32)>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t, dp, sr);
-          return;
-        }
-      }
+  // (bit 2 of a tile's class, launches that add paged source terms: a row segment of the tile holds a source node — the others run
+  //  the instantiation without those lines: the mode plane of BASELINE config 3 crosses 1 tile row in 64, and the lines cost 8 %)
+  if constexpr ((OPT & 64) != 0) {
+    if (tcl.cls && !(tcl.cls[t] & 4)) {
+      fused2_tile_by_class<LB, (OPT & ~64)>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t, dp, sr, tcl);
+      return;
     }
   }
-  fused2_step_tile<LB, OPT>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t, dp, sr);
+  fused2_tile_by_class<LB, OPT>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t, dp, sr, tcl);
 }
 
 // ---- the seams between x tiles -------------------------------------------------------------------------------------
@@ -996,13 +1011,13 @@ __global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, M
       h1y *= cxv * dmp.fb[1][jj] * dmp.fc[2][kk];
       h1z *= cxv * dmp.fc[1][jj] * dmp.fb[2][kk];
     }
-    if (sr.sseg && sr.use_h2) {             // paged H-side source terms of step n+1 at column c-1
+    if (sr.sseg && sr.t->use_h2) {             // paged H-side source terms of step n+1 at column c-1
       const int blk = sr.sseg[((long long)kk * g.ny + jj) * ((g.nx + 255) >> 8) + ((c - 1) >> 8)];
       if (blk >= 0) {
         const long long qs = ((long long)blk * 3) * 256 + ((c - 1) & 255);
-        h1y = h1y + sr.h2[qs + 256];
-        h1z = h1z + sr.h2[qs + 512];
-        if (sr.h2b) { h1y = h1y + sr.h2b[qs + 256]; h1z = h1z + sr.h2b[qs + 512]; }
+        h1y = h1y + sr.t->h2[qs + 256];
+        h1z = h1z + sr.t->h2[qs + 512];
+        if (sr.t->h2b) { h1y = h1y + sr.t->h2b[qs + 256]; h1z = h1z + sr.t->h2b[qs + 512]; }
       }
     }
     hy = upd_h(h1y, ch, A(2, jj, kk + 1) - e1x, s.ipz[kk], A(6, jj, kk) - e1z, ipx);
@@ -1042,18 +1057,18 @@ __global__ __launch_bounds__(256) void seam_kernel(GridP g, FieldP b, StepP s, M
     ez_m = upd_e(A(4, j, k), qm.x, qm.y, hy_m - hy_mm, idx_m, hx_m - hxm_j, idy);
     ez_c = upd_e(A(6, j, k), qc.x, qc.y, hy_c - hy_m, idx_c, hx_c - hxc_j, idy);
   }
-  if (sr.sseg && sr.use_e2) {                // paged E-side source terms of step n+1 on these two columns
+  if (sr.sseg && sr.t->use_e2) {                // paged E-side source terms of step n+1 on these two columns
     const int nbxg = (g.nx + 255) >> 8;
     const int bl = sr.sseg[((long long)k * g.ny + j) * nbxg + ((c - 1) >> 8)], br = sr.sseg[((long long)k * g.ny + j) * nbxg + (cc >> 8)];
     if (bl >= 0) {
       const long long qs = ((long long)bl * 3) * 256 + ((c - 1) & 255);
-      ex_m = ex_m + sr.e2[qs]; ey_m = ey_m + sr.e2[qs + 256]; ez_m = ez_m + sr.e2[qs + 512];
-      if (sr.e2b) { ex_m = ex_m + sr.e2b[qs]; ey_m = ey_m + sr.e2b[qs + 256]; ez_m = ez_m + sr.e2b[qs + 512]; }
+      ex_m = ex_m + sr.t->e2[qs]; ey_m = ey_m + sr.t->e2[qs + 256]; ez_m = ez_m + sr.t->e2[qs + 512];
+      if (sr.t->e2b) { ex_m = ex_m + sr.t->e2b[qs]; ey_m = ey_m + sr.t->e2b[qs + 256]; ez_m = ez_m + sr.t->e2b[qs + 512]; }
     }
     if (br >= 0) {
       const long long qs = ((long long)br * 3) * 256 + (cc & 255);
-      ey_c = ey_c + sr.e2[qs + 256]; ez_c = ez_c + sr.e2[qs + 512];
-      if (sr.e2b) { ey_c = ey_c + sr.e2b[qs + 256]; ez_c = ez_c + sr.e2b[qs + 512]; }
+      ey_c = ey_c + sr.t->e2[qs + 256]; ez_c = ez_c + sr.t->e2[qs + 512];
+      if (sr.t->e2b) { ey_c = ey_c + sr.t->e2b[qs + 256]; ez_c = ez_c + sr.t->e2b[qs + 512]; }
     }
   }
   if (inj.val2 && inj.e2_in_sweep) {         // the E-side sources of step n+1 on these two columns (the plane's table rows in their order)

@@ -157,6 +157,8 @@ __global__ __launch_bounds__(512, (AXES == 7 ? 2 : 3)) void shell2_step_kernel(G
   zero<V>(pxe1); zero<V>(pxe2); zero<V>(pye1); zero<V>(pye2); zero<V>(pze1); zero<V>(pze2);
   float ipz_m = 0.f, idz_m = 0.f;          // 1 / steps of plane k-1
   [[maybe_unused]] uint32_t mwm[V] = {kBgWord, kBgWord, kBgWord, kBgWord};       // packed medium words of plane k-1 (S4)
+  int ss_m = -1;                           // block of the lane's row segment in the paged source terms, plane k-1 (S3, S4)
+  const bool box_src = sr.sseg && (sp.paged & 1), box_disp = dp.dseg && (sp.paged & 2);
   int sz_m = -1;                           // z membership of plane k-1 and its coefficients
   float4 czh_m = {0.f, 0.f, 0.f, 0.f}, cze_m = {0.f, 0.f, 0.f, 0.f};
   {
@@ -238,6 +240,7 @@ __global__ __launch_bounds__(512, (AXES == 7 ? 2 : 3)) void shell2_step_kernel(G
     float4 czh = {0.f, 0.f, 0.f, 0.f}, cze = {0.f, 0.f, 0.f, 0.f};
     if (sz >= 0) { czh = ldc_f4(AZ.ch4 + k); cze = ldc_f4(AZ.ce4 + k); }
     const bool mem_x = sx >= 0 && in_z, mem_y = sy >= 0 && in_z;
+    int ss = -1;                             // block of the lane's row segment in the paged source terms, this plane
     float exn[V], eyn[V], ezk[V], exj[V], ezj[V], hxn[V], hyn[V], hzn[V];
     ldf<V, true>(exn, uni(a.ex + pk + up), ob);
     ldf<V, true>(eyn, uni(a.ey + pk + up), ob);
@@ -397,16 +400,16 @@ __global__ __launch_bounds__(512, (AXES == 7 ? 2 : 3)) void shell2_step_kernel(G
       if (!row_ok) { zero<V>(e1xn); zero<V>(e1zn); }      // rows beyond the grid publish E = 0 (the wall)
       // paged source terms (round 6, fdtd_fused2.hpp SrcP: a mode plane / current sheet that runs through the layers while it injects):
       // the E-side terms of step n, behind the E-side recursions as launch_sources follows the sweep
-      if (sr.sseg && act && in_z) {
-        const int ss = sr.sseg[((long long)k * g.ny + j) * ((g.nx + 255) >> 8) + (i0 >> 8)];
+      if (box_src && act && in_z) {
+        ss = sr.sseg[((long long)k * g.ny + j) * ((g.nx + 255) >> 8) + (i0 >> 8)];
         if (ss >= 0) {
           const long long qs = ((long long)ss * 3) * 256 + (i0 & 255);
           float tx_[V], ty_[V], tz_[V];
-          ldv<V>(tx_, sr.e1 + qs); ldv<V>(ty_, sr.e1 + qs + 256); ldv<V>(tz_, sr.e1 + qs + 512);
+          ldv<V>(tx_, sr.t->e1 + qs); ldv<V>(ty_, sr.t->e1 + qs + 256); ldv<V>(tz_, sr.t->e1 + qs + 512);
 #pragma unroll
           for (int e = 0; e < V; ++e) { e1xn[e] = e1xn[e] + tx_[e]; e1yn[e] = e1yn[e] + ty_[e]; e1zn[e] = e1zn[e] + tz_[e]; }
-          if (sr.e1b) {
-            ldv<V>(tx_, sr.e1b + qs); ldv<V>(ty_, sr.e1b + qs + 256); ldv<V>(tz_, sr.e1b + qs + 512);
+          if (sr.t->e1b) {
+            ldv<V>(tx_, sr.t->e1b + qs); ldv<V>(ty_, sr.t->e1b + qs + 256); ldv<V>(tz_, sr.t->e1b + qs + 512);
 #pragma unroll
             for (int e = 0; e < V; ++e) { e1xn[e] = e1xn[e] + tx_[e]; e1yn[e] = e1yn[e] + ty_[e]; e1zn[e] = e1zn[e] + tz_[e]; }
           }
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(512, (AXES == 7 ? 2 : 3)) void shell2_step_kernel(G
       }
       // dispersive cells inside the shell (round 6, as fused2_step_kernel's OPT bit 5): E^{n+1} <- E^{n+1} - cc S(Q^n) from the paged
       // memory terms, last of all; the lane that owns the cells leaves E^{n+1} for ade2_kernel
-      if (dp.dseg && act && in_z) {
+      if (box_disp && act && in_z) {
         const int ds = dp.dseg[((long long)k * g.ny + j) * ((g.nx + 255) >> 8) + (i0 >> 8)];
         if (ds >= 0) {
           const long long qb = ((long long)ds * 3) * 256 + (i0 & 255);
@@ -459,16 +462,15 @@ __global__ __launch_bounds__(512, (AXES == 7 ? 2 : 3)) void shell2_step_kernel(G
       get(4 + (cur ^ 1) * 2 + 0, ma, exj1);
       get(4 + (cur ^ 1) * 2 + 1, ma, ezj1);
       // paged H-side source terms of step n+1 on H^{n+1/2}[k-1], in front of the H-side recursions (launch_sources precedes the sweep)
-      if (sr.sseg && sr.use_h2 && act && k > kA) {
-        const int ss = sr.sseg[((long long)(k - 1) * g.ny + j) * ((g.nx + 255) >> 8) + (i0 >> 8)];
-        if (ss >= 0) {
-          const long long qs = ((long long)ss * 3) * 256 + (i0 & 255);
+      if (box_src && k > kA) {
+        if (ss_m >= 0 && sr.t->use_h2) {
+          const long long qs = ((long long)ss_m * 3) * 256 + (i0 & 255);
           float tx_[V], ty_[V], tz_[V];
-          ldv<V>(tx_, sr.h2 + qs); ldv<V>(ty_, sr.h2 + qs + 256); ldv<V>(tz_, sr.h2 + qs + 512);
+          ldv<V>(tx_, sr.t->h2 + qs); ldv<V>(ty_, sr.t->h2 + qs + 256); ldv<V>(tz_, sr.t->h2 + qs + 512);
 #pragma unroll
           for (int e = 0; e < V; ++e) { h1x[e] = h1x[e] + tx_[e]; h1y[e] = h1y[e] + ty_[e]; h1z[e] = h1z[e] + tz_[e]; }
-          if (sr.h2b) {
-            ldv<V>(tx_, sr.h2b + qs); ldv<V>(ty_, sr.h2b + qs + 256); ldv<V>(tz_, sr.h2b + qs + 512);
+          if (sr.t->h2b) {
+            ldv<V>(tx_, sr.t->h2b + qs); ldv<V>(ty_, sr.t->h2b + qs + 256); ldv<V>(tz_, sr.t->h2b + qs + 512);
 #pragma unroll
             for (int e = 0; e < V; ++e) { h1x[e] = h1x[e] + tx_[e]; h1y[e] = h1y[e] + ty_[e]; h1z[e] = h1z[e] + tz_[e]; }
           }
@@ -586,16 +588,15 @@ __global__ __launch_bounds__(512, (AXES == 7 ? 2 : 3)) void shell2_step_kernel(G
           }
         }
       }
-      if (sr.sseg && sr.use_e2 && act) {        // paged E-side source terms of step n+1 on E^{n+2}[k-1]
-        const int ss = sr.sseg[((long long)(k - 1) * g.ny + j) * ((g.nx + 255) >> 8) + (i0 >> 8)];
-        if (ss >= 0) {
-          const long long qs = ((long long)ss * 3) * 256 + (i0 & 255);
+      if (box_src) {                            // paged E-side source terms of step n+1 on E^{n+2}[k-1]
+        if (ss_m >= 0 && sr.t->use_e2) {
+          const long long qs = ((long long)ss_m * 3) * 256 + (i0 & 255);
           float tx_[V], ty_[V], tz_[V];
-          ldv<V>(tx_, sr.e2 + qs); ldv<V>(ty_, sr.e2 + qs + 256); ldv<V>(tz_, sr.e2 + qs + 512);
+          ldv<V>(tx_, sr.t->e2 + qs); ldv<V>(ty_, sr.t->e2 + qs + 256); ldv<V>(tz_, sr.t->e2 + qs + 512);
 #pragma unroll
           for (int e = 0; e < V; ++e) { ex[e] = ex[e] + tx_[e]; ey[e] = ey[e] + ty_[e]; ez[e] = ez[e] + tz_[e]; }
-          if (sr.e2b) {
-            ldv<V>(tx_, sr.e2b + qs); ldv<V>(ty_, sr.e2b + qs + 256); ldv<V>(tz_, sr.e2b + qs + 512);
+          if (sr.t->e2b) {
+            ldv<V>(tx_, sr.t->e2b + qs); ldv<V>(ty_, sr.t->e2b + qs + 256); ldv<V>(tz_, sr.t->e2b + qs + 512);
 #pragma unroll
             for (int e = 0; e < V; ++e) { ex[e] = ex[e] + tx_[e]; ey[e] = ey[e] + ty_[e]; ez[e] = ez[e] + tz_[e]; }
           }
@@ -637,6 +638,7 @@ __global__ __launch_bounds__(512, (AXES == 7 ? 2 : 3)) void shell2_step_kernel(G
     }
     ipz_m = ipz; idz_m = idz;
     sz_m = sz; czh_m = czh; cze_m = cze;
+    ss_m = ss;
     if constexpr (MAT) {
 #pragma unroll
       for (int e = 0; e < V; ++e) mwm[e] = mw[e];

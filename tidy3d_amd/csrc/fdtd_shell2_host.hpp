@@ -12,6 +12,8 @@ struct Shell2P {
   int k0, k1;          // planes written
   int zchunk;          // planes per workgroup
   int nbx, nby, nbz;   // tiles
+  int paged;           // bit 0: a row segment the box visits (halo rows / planes / lanes included) holds a source node (SrcP), bit 1: a
+                       // dispersive cell (DispP) — boxes without look nothing up
 };
 
 // the middle step over the boxes of DFT monitors (as InjP's dump fields, fdtd_fused2.hpp): H^{n+1/2} for records at step n, E^{n+1} for
