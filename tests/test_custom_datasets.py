@@ -86,8 +86,8 @@ def test_custom_medium_with_many_permittivity_conductivity_pairs_takes_the_wide_
     rng = np.random.default_rng(0)
     n = 24
     x = np.linspace(-0.6, 0.6, n)
-    eps = 2.0 + 2.0 * rng.random((n, n, n))                       # 2 .. 4: 70 levels of 1 %
-    sig = 10.0 ** rng.uniform(-3, -2, (n, n, n))                  # a decade: 116 levels of 2 %
+    eps = 2.0 * 4.0 ** rng.random((n, n, n))                      # 2 .. 8: 140 levels of 1 %
+    sig = 10.0 ** rng.uniform(-3, -2, (n, n, n))                  # a decade on 50 levels (one coarsening step does not bring the pairs into 1022 slots)
     med = td.CustomMedium(permittivity=_spatial(eps, x, x, x), conductivity=_spatial(sig, x, x, x), interp_method="nearest")
     sim = td.Simulation(size=(1.2, 1.2, 1.2), grid_spec=td.GridSpec.uniform(dl=0.025), run_time=1e-14, subpixel=False,
                         structures=[td.Structure(geometry=td.Box(size=(1.0, 1.0, 1.0)), medium=med)],

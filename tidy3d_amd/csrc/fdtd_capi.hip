@@ -1508,7 +1508,6 @@ int shell2_boxes(const FdtdSolver* h, const ShellGeom& G, Shell2Box out[kShell2M
     if (!per_y && G.o1[1] < ny) out[n++] = {G.o0[0], G.o1[0], G.o1[1], ny, G.o0[2], G.o1[2], false, 7};
     return n;
   }
-  if (z_lo != 0 || z_hi != h->g.nz) { Shell2Box tmp[kShell2MaxBoxes]; (void)tmp; }
   return shell2_boxes_by_axes(h, G, out);
 }
 int shell2_boxes_by_axes(const FdtdSolver* h, const ShellGeom& G, Shell2Box out[kShell2MaxBoxes]) {
@@ -3709,7 +3708,8 @@ struct Run {
     // planes next to a cut take two single steps as a z hole and ship their planes after each (slab_shell2_pair)
     f2mc_ok = false;
     if (fused_multi && any_pml(h) && pml_in_m != 0 && pml_in_m == pml_in_sweep_mask(h) && !h->has_damp && h->shell_on != 0 &&
-        h->shell2_on != 0 && h->ade.empty() && !any_periodic(h) && (long long)h->g.sxy * 4 < (1LL << 32)) {
+        h->shell2_on != 0 && h->shell2_on != 2 && h->shell2_on != 3 &&      // (2 / 3: boxes cut by axes ignore the z range the cut planes' hole leaves them)
+        h->ade.empty() && !any_periodic(h) && (long long)h->g.sxy * 4 < (1LL << 32)) {
       int why = fused2_why_not(h, true, true);
       if (!why && !shell_geometry(h, &sgm)) why = FDTD_F2_OFF_PML;
       if (!why) {

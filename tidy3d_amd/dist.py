@@ -89,7 +89,12 @@ def make_engine(spec: SolverSpec, lib=None, device: Optional[int] = None, axis_s
     eng.slab_shift, eng.slab_user_z = shift, user_z     # gather_results renames the stitched boxes back
     if cpml_pairs_possible(spec, slabs):
         # CPML recursions inside the sweeps of EVERY rank (decided from the whole problem: the ranks then post the same messages):
-        # the state step pairs of CPML-carrying slab ranks start from and end in (fdtd_capi.hip, Run::slab_shell2_pair)
+        # the state step pairs of CPML-carrying slab ranks start from and end in (fdtd_capi.hip, Run::slab_shell2_pair).
+        # The exchange ships the top plane's psi_H when 64 * (rows + 1) <= 512 holds on a rank: FDTD_OPT_ROWS must be the SAME on every
+        # rank while this option is on (a rank with 8 or more rows per workgroup would post four messages fewer per cut and the run
+        # would hang) — nothing in this package sets it per rank.  A rank whose own monitors or sources keep it from pairs (a time
+        # monitor recording every step, a decay check every other step) pays the in-sweep recursions without them: 4 - 16 % on thin
+        # slabs (profiles/r04p); cpml_pairs_possible judges the whole problem only.
         from . import lib as L
         eng.set_option(L.OPT_PML_FUSED, 7)
     uid = [eng.unique_id() if rank == 0 else None]
