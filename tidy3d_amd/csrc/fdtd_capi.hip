@@ -3934,7 +3934,7 @@ struct Run {
       pair_spg = false;
       if (src_why != 0 && spg_ok && (src_why == FDTD_F2_OFF_TFSF || src_why == FDTD_F2_OFF_SOURCES || src_why == FDTD_F2_OFF_SEAM_SOURCE)) {
         const bool s2_form = s2_ok && zp_s2.ok && zp_s2.n == 1 && h->cfg.bc[2] != FDTD_BC_PERIODIC;
-        if (s2_form || (f2_ok && h->ade.empty())) { pair_spg = true; src_why = 0; src_alive = false; }
+        if (s2_form || f2_ok) { pair_spg = true; src_why = 0; src_alive = false; }
       }
       use_s2 = s2_ok && src_why == 0 && (!src_alive || s2_deep || pair_spg);
       if (use_s2) zp = &zp_s2;

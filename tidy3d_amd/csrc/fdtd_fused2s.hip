@@ -1,7 +1,7 @@
 // Translation unit of the instantiations of the two-steps-per-sweep kernel that add PAGED SOURCE TERMS (fdtd_kernels2.hpp, OPT bit 6;
 // round 6): step pairs while a TFSF box, a mode plane, a current sheet or any list of more than kMaxInj nodes injects.  Always with
 // non-temporal stores and the monitor table (bits 0 and 2); with / without materials; whole grid (with / without absorber layers)
-// or clipped to the bulk of a shell pair; the clipped materials one also with the dispersive cells' memory terms (bit 5).
+// or clipped to the bulk of a shell pair; the materials ones also with the dispersive cells' memory terms (bit 5).
 // Workgroups of up to 8 waves run under __launch_bounds__(512), larger ones under 1024.  Own unit: compiles beside the others.
 #include <hip/hip_runtime.h>
 #undef __global__
@@ -31,6 +31,7 @@ void launch_fused2_step_src(hipStream_t st, int waves, int opt, int grid_blocks,
       case 8: FDTD_F2_O(LBV, 77); break; case 10: FDTD_F2_O(LBV, 79); break;                                           \
       case 16: FDTD_F2_O(LBV, 85); break; case 18: FDTD_F2_O(LBV, 87); break;                                          \
       case 2 | 16 | 32: FDTD_F2_O(LBV, 119); break;                                                                    \
+      case 2 | 32: FDTD_F2_O(LBV, 103); break; case 2 | 8 | 32: FDTD_F2_O(LBV, 111); break;                            \
       default: break;       /* (fdtd_capi.hip asks for nothing else) */                                                \
     }                                                                                                                  \
   } while (0)
