@@ -1255,14 +1255,27 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
   if (use_disp) dp = DispP{h->disp.dseg, h->disp.cs, h->disp.e1};
   int opt = (h->mem_hints ? 1 : 0) | (h->mat4 ? 2 : 0) | ((tb->mons.empty() && (!tb->with_sources || h->src_h_nodes == 0) && !tb->dstart) ? 0 : 4) |
             (clip ? 16 : (h->has_damp ? 8 : 0)) | (use_disp ? 32 | 1 : 0);
-  if (h->whatif > 0 && opt == 1 && W == 16) opt |= h->whatif << 8;        // (measuring aid: the vacuum sweep with part of its work skipped)
+  if (h->whatif > 0 && h->whatif <= 8 && opt == 1 && W == 16) opt |= h->whatif << 8;        // (measuring aid: the vacuum sweep with part of its work skipped)
+  SrcP sr_used = sr;
+  if (h->whatif == 9 && !sr.sseg && !(opt & 8) && (!(opt & 32) || (opt & 16))) {
+    // measuring aid (scripts/probe_bodies.py): the instantiation that adds paged source terms over a map WITHOUT any source segment —
+    // every tile dispatches to the bodies the plain launch runs: what the larger kernel costs by itself (results unchanged)
+    SrcPaged& S = h->spg;
+    const size_t nseg = (size_t)g.nz * g.ny * ((g.nx + 255) / 256);
+    if (!S.sseg && S.state != 1) {
+      S.sseg_host.assign(nseg, -1);
+      SrcT tab{};
+      if (dev_upload(h, &S.sseg, (const int*)S.sseg_host.data(), nseg) || dev_upload(h, &S.tab, &tab, 1)) return -1;
+    }
+    if (S.sseg && S.state != 1) { sr_used.sseg = S.sseg; sr_used.t = S.tab; opt |= 64 | 4 | 1; }
+  }
   if (sr.sseg) { opt |= 64 | 4 | 1; *sources2_done = true; h->spg.pairs++; }
   const int blocks = remap ? ((total + 7) / 8) * 8 : total;
   // background-only tiles take the plain sweep inside the materials launch (fdtd_kernels2.hpp, tile classes)
-  const FdtdSolver::TileClasses* tc = tile_classes(h, W, zc, box, nbx, nby, nbz, use_disp, sr.sseg != nullptr);
-  const bool split = tc && (use_disp || sr.sseg || (tc->n_bg > 0 && (h->tile_split == 1 || 8 * tc->n_bg >= tc->n_all)));
+  const FdtdSolver::TileClasses* tc = tile_classes(h, W, zc, box, nbx, nby, nbz, use_disp, sr_used.sseg != nullptr);
+  const bool split = tc && (use_disp || sr_used.sseg || (tc->n_bg > 0 && (h->tile_split == 1 || 8 * tc->n_bg >= tc->n_all)));
   launch_fused2_step(st, W, opt, blocks, g, h->f, h->f2, sp, mp, zc, nbx, nby, nbz, remap, inj, h->seam_buf, dmp, box,
-                     TileClassP{split ? tc->dev : nullptr}, dp, sr);
+                     TileClassP{split ? tc->dev : nullptr}, dp, sr_used);
   if (n_seams > 0) launch_seams(st, g, h->f2, sp, mp, h->seam_buf, n_seams, dmp, box, inj, sr);
   time_end(h, st);
   if (use_disp) h->disp.pairs++;
@@ -4578,7 +4591,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
       h->spg_on = value < 0 ? -1 : (value != 0);
       if (h->spg.state == -1 && value != 0) h->spg.state = 0;
       return 0;
-    case FDTD_OPT_WHATIF: if (value < 0 || value > 8) break; h->whatif = value; return 0;
+    case FDTD_OPT_WHATIF: if (value < 0 || value > 9) break; h->whatif = value; return 0;
     case FDTD_OPT_DISP:
       if (h->disp.state == 1 && value == 0) break;       // (every ADE launch keeps the paged memory terms by now: set it before the first run)
       h->disp_on = value < 0 ? -1 : (value != 0);
