@@ -33,8 +33,8 @@ PY
       ;;
     stats)
       cd /tmp
-      for W in v0 v0s v2; do
-        case $W in v0) A="";; v0s) A="--opt OPT_TWOSTEP=0";; v2) A="--workload v2";; esac
+      for W in v0 v0s v2 v3; do
+        case $W in v0) A="";; v0s) A="--opt OPT_TWOSTEP=0";; *) A="--workload $W";; esac
         timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$W -o trace -- python $R/bench.py $A --steps 100 --warmup 10 --repeats 2 --no-cpu --no-workloads --no-single-steps --placement-tries 0 > $O/prof_${W}_bench.json 2> $O/prof_$W.err
         head -6 $O/prof_$W/trace_kernel_stats.csv | cut -c1-160
       done
@@ -42,7 +42,7 @@ PY
       cd $R;;
     pmc)
       cd /tmp
-      for W in v0 v0s v1 va v2; do
+      for W in v0 v0s v1 va v2 v3; do
         case $W in v0) A="";; v0s) A="--opt OPT_TWOSTEP=0";; *) A="--workload $W";; esac
         for C in FETCH_SIZE WRITE_SIZE; do
           timeout 240 rocprofv3 --pmc $C --output-format csv -d $O/pmc_$W/pmc_$C -o pmc -- python $R/bench.py $A --steps 6 --warmup 2 --repeats 1 --no-cpu --no-workloads --no-single-steps --placement-tries 0 > /dev/null 2> $O/pmc_${W}_$C.err
@@ -53,10 +53,10 @@ PY
       cd $R
       python - <<PY
 import json
-for w in ["v0", "v0s", "v1", "va", "v2"]:
+for w in ["v0", "v0s", "v1", "va", "v2", "v3"]:
     d = json.load(open("$O/pmc_%s_summary.json" % w))
     for k, v in d.items():
-        if "hbm_bytes_per_launch" in v and ("fused" in k or "seam" in k or "strip" in k or "shell2" in k):
+        if "hbm_bytes_per_launch" in v and ("fused" in k or "seam" in k or "strip" in k or "shell2" in k or "ade2" in k):
             print(w, k, round(v["hbm_bytes_per_launch"] / 1e9, 3), "GB  read", round(v["read_bytes_per_launch"] / 1e9, 3), "write", round(v["write_bytes_per_launch"] / 1e9, 3), "x", v.get("launches_FETCH_SIZE"))
 PY
       ;;

@@ -14,12 +14,15 @@ if sys.argv[1] == "--visit":
     # per PAIR (all launches of the pair together: the two-step sweep + the seam kernel, and for CPML grids the shell's launches)
     src, dst = sys.argv[2], sys.argv[3]
     rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-    S = {w: json.load(open(os.path.join(src, f"pmc_{w}_summary.json"))) for w in ("v0", "v0s", "v1", "va", "v2")}
+    S = {w: json.load(open(os.path.join(src, f"pmc_{w}_summary.json"))) for w in ("v0", "v0s", "v1", "va", "v2", "v3")
+         if os.path.exists(os.path.join(src, f"pmc_{w}_summary.json"))}
     k0 = [k for k in S["v0s"] if k.startswith("fused_step_kernel<false, 256, 0")]
     rec["fused_step_kernel"] = S["v0s"][k0[0]]["hbm_bytes_per_launch"]
     wl = {}
-    for w in ("v0", "v1", "va", "v2"):
-        ks = {k: v for k, v in S[w].items() if "hbm_bytes_per_launch" in v and any(t in k for t in ("fused", "seam_kernel", "strip_step", "shell2_step"))}
+    for w in ("v0", "v1", "va", "v2", "v3"):
+        if w not in S:
+            continue
+        ks = {k: v for k, v in S[w].items() if "hbm_bytes_per_launch" in v and any(t in k for t in ("fused", "seam_kernel", "strip_step", "shell2_step", "ade2_kernel"))}
         pairs = ks.get("fused2_step_kernel", {}).get("launches_FETCH_SIZE", 0)
         if pairs:
             tot = sum(v["hbm_bytes_per_launch"] * v["launches_FETCH_SIZE"] for v in ks.values())
