@@ -19,6 +19,26 @@ DEPS = SOURCES + [os.path.join(CSRC, "fdtd_kernels.hpp"), os.path.join(CSRC, "fd
                   os.path.join(HERE, "..", "include", "fdtd_hip.h"), os.path.abspath(__file__)]
 
 
+HOST_LIB = os.path.join(HERE, "libfdtd_host.so")
+HOST_SOURCE = os.path.join(CSRC, "host_raster.cpp")
+HOST_DEPS = [HOST_SOURCE, os.path.join(HERE, "..", "include", "fdtd_host.h")]
+
+
+def build_host(force: bool = False, verbose: bool = True) -> str:
+    """libfdtd_host.so (include/fdtd_host.h): the rasteriser's native host passes — plain C++ on threads, no HIP runtime.
+    -ffp-contract=off: the sample coordinates and inside tests are the NumPy statements' IEEE operations, one for one."""
+    if not force and os.path.exists(HOST_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB) for d in HOST_DEPS):
+        return HOST_LIB
+    cxx = shutil.which("g++") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    tmp = HOST_LIB + ".%d.tmp" % os.getpid()
+    cmd = [cxx, "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-Wall", HOST_SOURCE, "-o", tmp]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(tmp, HOST_LIB)
+    return HOST_LIB
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
@@ -27,6 +47,7 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    build_host(force, verbose)
     if not force and not needs_build():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

@@ -143,7 +143,38 @@ def surface_legs(spec: SolverSpec, mt, lo, hi, inc_e, inc_h):
         out_[:, 0] = key // N[1]
         return out_
 
+    # Membership in the total-field region factorises per axis: one small boolean table per (component, axis) over the indices
+    # -1 .. N (a shifted neighbour may lie one node outside the grid), looked up through contiguous index columns — the candidate
+    # set of a plane wave across a 1024 x 1024 period holds nine million nodes, and the six comparisons per axis and component on
+    # strided int64 columns, the copies of the shifted node lists and the Cb look-up of EVERY candidate were most of its set-up time.
+    tabs = {}
+
+    def table(comp):
+        if comp not in tabs:
+            t_ = []
+            for a_ in range(3):
+                i_ = np.arange(-1, N[a_] + 1)
+                t_.append((i_ >= lo[a_]) & (i_ <= (hi[a_] - 1 if _on_center(comp, a_) else hi[a_])))
+            tabs[comp] = t_
+        return tabs[comp]
+
+    def member(comp, cols, axis=None, shift=0):
+        t_ = table(comp)
+        m = None
+        for a_ in range(3):
+            v = t_[a_][cols[a_] + (1 + shift if a_ == axis else 1)]
+            m = v if m is None else m & v
+        return m
+
+    cols_cache = {}
+
+    def columns(nodes):
+        if "c" not in cols_cache:
+            cols_cache["c"] = [np.ascontiguousarray(nodes[:, a_]) for a_ in range(3)]
+        return cols_cache["c"]
+
     # ---- E-phase: E_c += Cb * sgn * (H_q[n] - H_q[n - e_a]) / dual_a for the term d_a H_q in (curl H)_c
+    from .spec import BC_PEC
     for c in range(3):
         for (a, f, sgn) in (((c + 1) % 3, (c + 2) % 3, 1.0), ((c + 2) % 3, (c + 1) % 3, -1.0)):
             if f not in inc_h:
@@ -151,24 +182,25 @@ def surface_legs(spec: SolverSpec, mt, lo, hi, inc_e, inc_h):
             nodes = candidates(c)
             if len(nodes) == 0:
                 continue
-            in_e = in_tf(c, nodes).astype(float)
-            cb = cb_at(spec, mt, c, nodes)
+            cols = columns(nodes)
+            in_e = member(c, cols)
             # wall nodes of E are forced to zero by the main kernels: never correct them
-            from .spec import BC_PEC
             wall = np.zeros(len(nodes), bool)
             for b in range(3):
                 if b != c and spec.bc[b][0] == BC_PEC:
-                    wall |= nodes[:, b] == 0
+                    wall |= cols[b] == 0
             for shift, leg_sign in ((0, 1.0), (-1, -1.0)):
-                nb = nodes.copy()
-                nb[:, a] += shift
-                valid = (nb[:, a] >= 0) & (nb[:, a] < N[a]) & ~wall
-                fac = (in_e - in_tf(3 + f, nb).astype(float)) * valid
-                sel = fac != 0
+                na = cols[a] + shift
+                sel = (in_e != member(3 + f, cols, a, shift)) & (na >= 0) & (na < N[a]) & ~wall
                 if not sel.any():
                     continue
-                w = cb[sel] * sgn * leg_sign * idl[a][nodes[sel, a]] * fac[sel]
-                out["e"].append((np.full(sel.sum(), c), nodes[sel], w, np.full(sel.sum(), 3 + f), nb[sel]))
+                rows = np.flatnonzero(sel)
+                here = nodes[rows]
+                nb = here.copy()
+                nb[:, a] += shift
+                fac = in_e[rows].astype(float) - in_tf(3 + f, nb).astype(float)
+                w = cb_at(spec, mt, c, here) * sgn * leg_sign * idl[a][here[:, a]] * fac
+                out["e"].append((np.full(rows.size, c), here, w, np.full(rows.size, 3 + f), nb))
     # ---- H-phase: H_c -= ch * sgn * (E_e[n + e_a] - E_e[n]) / primal_a for the term d_a E_e in (curl E)_c
     for c in range(3):
         for (a, f, sgn) in (((c + 1) % 3, (c + 2) % 3, 1.0), ((c + 2) % 3, (c + 1) % 3, -1.0)):
@@ -177,17 +209,20 @@ def surface_legs(spec: SolverSpec, mt, lo, hi, inc_e, inc_h):
             nodes = candidates(3 + c)
             if len(nodes) == 0:
                 continue
-            in_h = in_tf(3 + c, nodes).astype(float)
+            cols = columns(nodes)
+            in_h = member(3 + c, cols)
             for shift, leg_sign in ((1, 1.0), (0, -1.0)):
-                nb = nodes.copy()
-                nb[:, a] += shift
-                valid = (nb[:, a] >= 0) & (nb[:, a] < N[a])
-                fac = (in_h - in_tf(f, nb).astype(float)) * valid
-                sel = fac != 0
+                na = cols[a] + shift
+                sel = (in_h != member(f, cols, a, shift)) & (na >= 0) & (na < N[a])
                 if not sel.any():
                     continue
-                w = -ch * sgn * leg_sign * ip[a][nodes[sel, a]] * fac[sel]
-                out["h"].append((np.full(sel.sum(), 3 + c), nodes[sel], w, np.full(sel.sum(), f), nb[sel]))
+                rows = np.flatnonzero(sel)
+                here = nodes[rows]
+                nb = here.copy()
+                nb[:, a] += shift
+                fac = in_h[rows].astype(float) - in_tf(f, nb).astype(float)
+                w = -ch * sgn * leg_sign * ip[a][here[:, a]] * fac
+                out["h"].append((np.full(rows.size, 3 + c), here, w, np.full(rows.size, f), nb))
     res = {}
     for k in ("e", "h"):
         if out[k]:
