@@ -380,3 +380,32 @@ def test_background_only_tiles_on_the_plain_instantiation(bspec_name, w, zc, emu
             assert np.array_equal(got[0][c], outs[0][0][c]), c
         for k in outs[0][1]:
             assert np.array_equal(np.asarray(got[1][k]), np.asarray(outs[0][1][k])), k
+
+
+@pytest.mark.parametrize("name,zc,pf", [("one_tile", 32, 10), ("ragged_rows", 3, 10), ("two_x_tiles", 5, 10), ("three_x_tiles_tall", 4, 10),
+                                        ("ragged_rows", 3, 11), ("two_x_tiles", 32, 11), ("one_tile", 2, 12), ("three_x_tiles_tall", 5, 12),
+                                        ("one_tile", 32, 13), ("ragged_rows", 3, 13), ("two_x_tiles", 5, 13), ("three_x_tiles_tall", 4, 13),
+                                        ("one_tile", 32, 15), ("ragged_rows", 3, 15), ("two_x_tiles", 5, 15), ("three_x_tiles_tall", 4, 15),
+                                        ("ragged_rows", 3, 14)])
+def test_prefetch_instantiations_equal_single_steps(name, zc, pf, emu_lib):
+    """The PREFETCH instantiations of the vacuum sweep (FDTD_OPT_WHATIF = 10 ... 12: part of the next plane travels global memory ->
+    LDS by LDS-DMA while this one is computed; E1 exchanged through ONE buffer, published behind the second barrier): the same bits
+    as single steps — tile edges in x / y / z, chunk prologues, sources between the steps, runs of odd lengths.  13: E_x of the row
+    above handed down through a ninth exchange array instead of a second global load."""
+    N = SHAPES[name]
+    disc = discretize(_sim(N, monitors=False), n_steps=26)
+    disc.spec.decay_every = 0
+    ref_f, _, p0 = _run(disc.spec, emu_lib, 0)
+
+    def run_pf():
+        with HipEngine(disc.spec, lib=emu_lib, variant=L.VARIANT_FUSED, z_chunk=2) as e:
+            e.set_option(L.OPT_ROWS, 3)
+            e.set_option(L.OPT_TWOSTEP, 16 + 64 * zc)
+            e.set_option(L.OPT_WHATIF, pf)
+            pairs = sum(int(e.run(r).fused2_pairs) for r in (11, 15))
+            return [e.get_field(c) for c in range(6)], pairs
+    got_f, p1 = run_pf()
+    assert p0 == 0 and p1 == 5 + 7, p1
+    assert max(float(np.abs(f).max()) for f in ref_f) > 0
+    for c in range(6):
+        assert np.array_equal(got_f[c], ref_f[c]), c

@@ -1255,7 +1255,7 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
   if (use_disp) dp = DispP{h->disp.dseg, h->disp.cs, h->disp.e1};
   int opt = (h->mem_hints ? 1 : 0) | (h->mat4 ? 2 : 0) | ((tb->mons.empty() && (!tb->with_sources || h->src_h_nodes == 0) && !tb->dstart) ? 0 : 4) |
             (clip ? 16 : (h->has_damp ? 8 : 0)) | (use_disp ? 32 | 1 : 0);
-  if (h->whatif > 0 && h->whatif <= 8 && opt == 1 && W == 16) opt |= h->whatif << 8;        // (measuring aid: the vacuum sweep with part of its work skipped)
+  if (h->whatif > 0 && h->whatif <= 15 && h->whatif != 9 && opt == 1 && W == 16) opt |= h->whatif << 8;        // (measuring aid: the vacuum sweep with part of its work skipped)
   SrcP sr_used = sr;
   if (h->whatif == 9 && !sr.sseg && !(opt & 8) && (!(opt & 32) || (opt & 16))) {
     // measuring aid (scripts/probe_bodies.py): the instantiation that adds paged source terms over a map WITHOUT any source segment —
@@ -4591,7 +4591,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
       h->spg_on = value < 0 ? -1 : (value != 0);
       if (h->spg.state == -1 && value != 0) h->spg.state = 0;
       return 0;
-    case FDTD_OPT_WHATIF: if (value < 0 || value > 9) break; h->whatif = value; return 0;
+    case FDTD_OPT_WHATIF: if (value < 0 || value > 15) break; h->whatif = value; return 0;
     case FDTD_OPT_DISP:
       if (h->disp.state == 1 && value == 0) break;       // (every ADE launch keeps the paged memory terms by now: set it before the first run)
       h->disp_on = value < 0 ? -1 : (value != 0);

@@ -76,6 +76,12 @@ struct SrcP {
   const int* sseg = nullptr;               // [nz][ny][ceil(nx / 256)]: block of the row segment, -1 = no source node in it
   const SrcT* t = nullptr;
 };
+// exchange arrays of a workgroup of `waves` rows ([.][waves][64] float4 of dynamic LDS): H1_x H1_z | H2_x H2_z | E1_x E1_z twice, and — in
+// sixteen-wave workgroups (LB = 1024) — E_x of the next plane for the row below (fdtd_kernels2.hpp, EXJ)
+#if !defined(FDTD_NO_EXJ)
+#define FDTD_NO_EXJ 0       // (1: a build without it — the A/B of the other instantiations, variants/libfdtd_hip_noexj.so)
+#endif
+constexpr int fused2_xch_arrays(int waves) { return (waves > 12 && !FDTD_NO_EXJ) ? 9 : 8; }
 constexpr int kMaxCap = 1024;
 constexpr int kSeamArrays = 13;  // of step one: H1_y, H1_z, E1_x, E1_y, E1_z [c-1], E1_y, E1_z [c]; of step two: H2_x [c-1], H2_y, H2_z [c-2], H2_x, H2_y, H2_z [c]
                                  // (c = first column of the right tile)

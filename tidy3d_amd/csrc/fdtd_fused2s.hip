@@ -19,7 +19,7 @@ void launch_fused2_step_src(hipStream_t st, int waves, int opt, int grid_blocks,
                             int xcd_remap, const InjP& inj, float* seam, const DampT& dmp, const ClipP& clip, const TileClassP& tcl,
                             const DispP& dp, const SrcP& sr) {
   const dim3 grid(grid_blocks, 1, 1), block(64, waves, 1);
-  const size_t shmem = ((size_t)8 * waves * 64 + ((opt & 8) ? 2 * 64 : 0)) * sizeof(float4);
+  const size_t shmem = ((size_t)fused2_xch_arrays(waves) * waves * 64 + ((opt & 8) ? 2 * 64 : 0)) * sizeof(float4);
 #define FDTD_F2_O(LBV, OV)                                                                                             \
   hipLaunchKernelGGL((fused2_step_kernel<LBV, OV>), grid, block, shmem, st, g, a, b, s, m, zchunk, nbx, nby, nbz,     \
                      xcd_remap, inj, seam, dmp, clip, tcl, dp, sr)

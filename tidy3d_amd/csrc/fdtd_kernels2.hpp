@@ -35,6 +35,18 @@
 //   4  every plane load reads the same (cached) row: no HBM reads, same instructions    5  no field stores
 //   6  no barriers and no LDS exchange (own values instead of the neighbour rows')      7  loads + stores only (the copy floor of this tiling)
 //   8  no barriers, LDS traffic kept
+// PREFETCH instantiations (OPT bits 8 - 11 = 10 ... 12; CORRECT results, the same bits): part of plane k+1 travels global memory -> LDS
+// by LDS-DMA (global_load_lds_dwordx4) while plane k is computed — the one way to keep a second batch of loads in flight that costs
+// no registers (the sweep has 3 of 128 left).  The LDS for it comes from the E1 exchange arrays: published BEHIND the second barrier
+// (read behind the next first barrier) they need no second buffer, which leaves 6 exchange arrays + 3 prefetch arrays = 144 KB.
+//   10  H_x H_y H_z of the next plane       11  E_y H_y       12  E_x E_y (plane k+2) E_z (plane k+1)
+//   13  (no DMA) E_x of the row above comes from the wave above through a ninth exchange array instead of a second global load of the
+//       same line: published between the barriers of iteration k-1 (it is that wave's E_x[k], loaded a plane ahead), read in S1 of
+//       iteration k; the top row of the workgroup and the first iteration of a chunk load it as before.  Measured - 2.1 % and made the
+//       DEFAULT of every sixteen-wave instantiation (EXJ below);  14 = the sweep without it
+//   15  13 + E_z through LDS too: a wave requests E_z[k+1] of its row behind S1 of iteration k (into registers S1 has just freed),
+//       leaves it in a tenth... eighth array (E1 single-buffered as in 10 - 12) in front of the second barrier, and in S1 of iteration
+//       k+1 takes its own E_z[k+1] and the row above's from there: one global load of E_z per row and plane instead of two, half a plane ahead
 
 namespace fdtd {
 
@@ -133,6 +145,34 @@ __device__ __forceinline__ float lane_prev(float v) {
 #endif
 }
 
+// LDS-DMA: the wave's 64 lanes fetch 16 bytes each from base + off (off: the lane's byte offset) straight into LDS at
+// dst[lane] — no registers, and, issued through inline asm, absent from hipcc's s_waitcnt bookkeeping: nothing drains it at the
+// workgroup's barriers (a __builtin_amdgcn_global_load_lds in flight makes every __syncthreads wait for vmcnt(0)).  `dst` is the
+// wave's own 64-entry slice (wave-uniform); lds_dma_wait() in front of reading it.  On the CPU emulator: a plain copy.
+__device__ __forceinline__ void lds_dma16(const float* base, unsigned off, float4* dst, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dst);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(off), "s"(lds_addr), "s"(base) : "memory");
+#else
+  dst[lane] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + off);
+#endif
+}
+__device__ __forceinline__ void lds_dma_wait() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+// in front of re-using a slice: the wave's ds_reads of it have RETURNED (issued is not enough — with sixteen waves reading 3 KB each
+// the LDS queue is ~400 cycles deep, and a DMA that hits in L2 lands before that: seen on the device as wrong values spreading from a
+// seam column, where the neighbouring tile's edge loads had warmed the line; profiles/r6/r6u)
+__device__ __forceinline__ void lds_dma_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
+
 // A per-lane value the optimiser cannot see through.  Lane-constant predicates (first / last lane of a tile, cells beyond the row
 // end) are re-derived from it inside the march: hoisted out of the loop each of them is a 64-bit lane mask that lives in an
 // SGPR pair for the whole kernel — a dozen of them were a third of the SGPRs this kernel spills to VGPR lanes and reads back
@@ -170,6 +210,19 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
   // E^{n+2} and forms Q^{n+2} — ade_kernel's operations in its order, twice.
   constexpr bool DISP = (OPT & 32) != 0;
   constexpr int WHATIF = (OPT >> 8) & 15;
+  constexpr int PF = (WHATIF >= 10 && WHATIF <= 12) ? WHATIF : 0;            // prefetch instantiation (correct results)
+  // EXJ: E_x of the row above comes from the wave above through a ninth exchange array (fused2_xch_arrays) instead of a second global
+  // load of a line the workgroup has already fetched — 512^3 vacuum inside one engine 0.690 -> 0.675 ms per step (profiles/r6/r6u): the
+  // sweep is bound by requests between the CUs and L2 (11.6 B per cycle and CU), not by HBM alone.  Sixteen-wave workgroups only (one per
+  // CU whatever its LDS); WHATIF 14 = the sweep without it, for A/B inside one engine.  Whole bench lines of two builds, three rounds
+  // interleaved (profiles/r6/r6v): V1 + 3 %, V2 / V3 / V4 + 2 %, the absorber instantiation - 5 % (two more spilled registers) — left out there.
+  constexpr bool EZL = WHATIF == 15;                                         // E_z through LDS (variant 15)
+  constexpr bool EXJ = LB == 1024 && ((WHATIF == 0 && !FDTD_NO_EXJ && (OPT & 8) == 0) || WHATIF == 13 || EZL);
+  constexpr bool E1S = PF != 0 || EZL;                                       // E1 exchanged through ONE buffer (published behind the second barrier)
+  constexpr int XE = E1S ? 6 : 8, XZ = 7;                                    // exchange arrays of E_x[k+1] (EXJ) and E_z[k+1] (EZL)
+  [[maybe_unused]] constexpr int NPF = PF == 11 ? 2 : (PF ? 3 : 0);                           // arrays of the next plane that travel through LDS
+  constexpr int NXCH = E1S ? 6 : 8;                                           // exchange arrays (PF: E1 single-buffered)
+  static_assert((!PF && !EZL) || (OPT & 0xfe) == 0, "prefetch instantiations: the vacuum sweep only");
   constexpr bool DAMP = (OPT & 8) != 0;   // absorber layers: both fields of both steps are damped in registers (damp_kernel's factors)
   // CLIP: the launch covers the box `clip` only — the bulk of a grid whose shell (CPML slabs + a two-cell collar, the boundary
   // planes of a z-slab rank) is advanced by single steps beside it.  Tile rows and chunks start at the box's origin, nothing is
@@ -194,14 +247,14 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
   {
     const float4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < 8; ++q) xch[q * slot + me] = z4;     // rows beyond the grid publish E = 0, H = 0
+    for (int q = 0; q < NXCH; ++q) xch[q * slot + me] = z4;     // rows beyond the grid publish E = 0, H = 0
   }
   __shared__ float2 lut_s[MAT ? kMaxMedia : 1];
   if constexpr (MAT) {
     for (int q = me; q < m.n_media; q += slot) lut_s[q] = m.lut[q];
   }
   // absorber layers: the x factors of the tile's 256 cells (fb: cell boundaries, fc: cell centres; 1 outside the layers)
-  [[maybe_unused]] float4* xdm = xch + 8 * slot;             // [2][64]
+  [[maybe_unused]] float4* xdm = xch + (EXJ ? 9 : 8) * slot;             // [2][64]
   if constexpr (DAMP) {
     if (ty == 0) {
       const int ii = (tile_x * 64 + tx) * V;
@@ -313,6 +366,31 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
     float eyx_g, ezx_g;                                  // E^n_{y,z} of column i0 + 256 (last lane of a tile with a right neighbour)
     float exn_m, ez_mm, ey_mm, ex_jm, hy_o, hz_o;        // column i0 - 1 (first lane of a tile with a left neighbour)
   };
+  // PF: the arrays of plane k that travel through LDS, requested one plane ahead (behind S1 of plane k-1; the first one in front of the march)
+  [[maybe_unused]] float4* pfb = xch + NXCH * slot;           // [NPF][W][64]
+  [[maybe_unused]] auto pf_issue = [&](int k) __attribute__((always_inline)) {
+    if constexpr (PF != 0) {
+      const long long pb = (long long)k * g.sxy + rowb;
+      const long long up = (k < g.nz) ? g.sxy : 0;
+      lds_dma_fence();
+      if constexpr (PF == 10) {
+        lds_dma16(uni(a.hx + pb), ubc, pfb + 0 * slot + ty * 64, tx);
+        lds_dma16(uni(a.hy + pb), ubc, pfb + 1 * slot + ty * 64, tx);
+        lds_dma16(uni(a.hz + pb), ubc, pfb + 2 * slot + ty * 64, tx);
+      } else if constexpr (PF == 11) {
+        lds_dma16(uni(a.ey + pb + up), ubc, pfb + 0 * slot + ty * 64, tx);
+        lds_dma16(uni(a.hy + pb), ubc, pfb + 1 * slot + ty * 64, tx);
+      } else {
+        lds_dma16(uni(a.ex + pb + up), ubc, pfb + 0 * slot + ty * 64, tx);
+        lds_dma16(uni(a.ey + pb + up), ubc, pfb + 1 * slot + ty * 64, tx);
+        lds_dma16(uni(a.ez + pb), ubc, pfb + 2 * slot + ty * 64, tx);
+      }
+    }
+  };
+  [[maybe_unused]] auto pf_take = [&](int q, float (&o)[V]) __attribute__((always_inline)) {
+    const float4 t4 = pfb[q * slot + me];
+    o[0] = t4.x; o[1] = t4.y; o[2] = t4.z; o[3] = t4.w;
+  };
   auto issue = [&](int k, Ld& L) __attribute__((always_inline)) {
     if constexpr (WHATIF == 3) {      // (the three halo rows of a workgroup cost no loads — the upper bound of sharing them with the neighbouring workgroups)
       if (ty < 2 || ty == W - 1) {
@@ -330,20 +408,33 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
     const long long pb = WHATIF == 4 ? (long long)(k & 1) * g.sxy : (long long)k * g.sxy + rowb;
     const long long pjb = WHATIF == 4 ? (long long)(k & 1) * g.sxy + g.nx : (long long)k * g.sxy + rowpb;
     const long long up = WHATIF == 4 ? 0 : ((k < g.nz) ? g.sxy : 0);         // (iteration nz only needs E1_{x,y}[nz] = 0: it reads the ghost plane twice)
-    ldf<V, true>(L.exn, uni(a.ex + pb + up), ubc);
+    if constexpr (PF != 12) ldf<V, true>(L.exn, uni(a.ex + pb + up), ubc);
     if constexpr (WHATIF == 1) zero<V>(L.eyn);      // (E_y / H_y not loaded at all — the upper bound of prefetching them)
-    else ldf<V, true>(L.eyn, uni(a.ey + pb + up), ubc);
-    ldf<V, true>(L.ezk, uni(a.ez + pb), ubc);
+    else if constexpr (PF != 11 && PF != 12) ldf<V, true>(L.eyn, uni(a.ey + pb + up), ubc);
+    if constexpr (EZL) {
+      if (k == kA) ldf<V, true>(L.ezk, uni(a.ez + pb), ubc);
+      else { const float4 t4 = xch[XZ * slot + me]; L.ezk[0] = t4.x; L.ezk[1] = t4.y; L.ezk[2] = t4.z; L.ezk[3] = t4.w; }
+    } else if constexpr (PF != 12) ldf<V, true>(L.ezk, uni(a.ez + pb), ubc);
     if (use_jp) {
-      ldf<V, true>(L.exj, uni(a.ex + pjb), ubc);
-      ldf<V, true>(L.ezj, uni(a.ez + pjb), ubc);
+      if constexpr (EXJ) {
+        if (ty == W - 1 || k == kA) ldf<V, true>(L.exj, uni(a.ex + pjb), ubc);
+        else { const float4 t4 = xch[XE * slot + me + 64]; L.exj[0] = t4.x; L.exj[1] = t4.y; L.exj[2] = t4.z; L.exj[3] = t4.w; }
+      } else {
+        ldf<V, true>(L.exj, uni(a.ex + pjb), ubc);
+      }
+      if constexpr (EZL) {
+        if (ty == W - 1 || k == kA) ldf<V, true>(L.ezj, uni(a.ez + pjb), ubc);
+        else { const float4 t4 = xch[XZ * slot + me + 64]; L.ezj[0] = t4.x; L.ezj[1] = t4.y; L.ezj[2] = t4.z; L.ezj[3] = t4.w; }
+      } else {
+        ldf<V, true>(L.ezj, uni(a.ez + pjb), ubc);
+      }
     } else {
       zero<V>(L.exj); zero<V>(L.ezj);
     }
-    ldf<V, true>(L.hxn, uni(a.hx + pb), ubc);
+    if constexpr (PF != 10) ldf<V, true>(L.hxn, uni(a.hx + pb), ubc);
     if constexpr (WHATIF == 1) zero<V>(L.hyn);
-    else ldf<V, true>(L.hyn, uni(a.hy + pb), ubc);
-    ldf<V, true>(L.hzn, uni(a.hz + pb), ubc);
+    else if constexpr (PF != 10 && PF != 11) ldf<V, true>(L.hyn, uni(a.hy + pb), ubc);
+    if constexpr (PF != 10) ldf<V, true>(L.hzn, uni(a.hz + pb), ubc);
     L.eyx_g = 0.f; L.ezx_g = 0.f;
     if (act && txo == 63 && !last_x) { L.eyx_g = a.ey[pb + ux + V]; L.ezx_g = a.ez[pb + ux + V]; }
     if (per_x && act && last_x) { L.eyx_g = a.ey[pb]; L.ezx_g = a.ez[pb]; }        // (the row's first column)
@@ -354,6 +445,12 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
       L.ez_mm = a.ez[pm]; L.ey_mm = a.ey[pm];
       L.ex_jm = use_jp ? a.ex[pjb + im] : 0.f;
       L.hy_o = a.hy[pm]; L.hz_o = a.hz[pm];
+    }
+    if constexpr (PF != 0) {          // what came through LDS (requested a plane ago; every load of this plane is out by now)
+      lds_dma_wait();
+      if constexpr (PF == 10) { pf_take(0, L.hxn); pf_take(1, L.hyn); pf_take(2, L.hzn); }
+      else if constexpr (PF == 11) { pf_take(0, L.eyn); pf_take(1, L.hyn); }
+      else { pf_take(0, L.exn); pf_take(1, L.eyn); pf_take(2, L.ezk); }
     }
   };
   Ld LA, LB2;
@@ -443,6 +540,11 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
         hy_m = upd_h(L.hy_o, ch, L.exn_m - exk_m, ipz, ezk[0] - L.ez_mm, ipx_m);
         hz_m = upd_h(L.hz_o, ch, eyk[0] - L.ey_mm, ipx_m, L.ex_jm - exk_m, ipy);
       }
+    }
+    if constexpr (PF != 0) { if (k + 1 <= k1) pf_issue(k + 1); }      // (S1 has consumed this plane's slices)
+    [[maybe_unused]] float ezn_pre[V];
+    if constexpr (EZL) {                                                // E_z[k+1] of this row, for the next iteration (its own and the row below's)
+      if (k + 1 <= k1) ldf<V, true>(ezn_pre, uni(a.ez + pb + g.sxy), ubc);
     }
     if constexpr (WHATIF != 6) {
       float4 t4;
@@ -722,8 +824,8 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
       if constexpr (WHATIF == 6) {
         t0 = make_float4(e1x[0], e1x[1], e1x[2], e1x[3]); t1 = make_float4(e1z[0], e1z[1], e1z[2], e1z[3]);
       } else {
-        t0 = xch[(4 + (cur ^ 1) * 2 + 0) * slot + me + 64];
-        t1 = xch[(4 + (cur ^ 1) * 2 + 1) * slot + me + 64];
+        t0 = xch[(4 + (E1S ? 0 : (cur ^ 1) * 2) + 0) * slot + me + 64];
+        t1 = xch[(4 + (E1S ? 0 : (cur ^ 1) * 2) + 1) * slot + me + 64];
       }
       const float exj1[V] = {t0.x, t0.y, t0.z, t0.w}, ezj1[V] = {t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
@@ -752,16 +854,35 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
     }
     if constexpr (WHATIF != 6) {
       float4 t4;
-      t4.x = e1xn[0]; t4.y = e1xn[1]; t4.z = e1xn[2]; t4.w = e1xn[3];
-      xch[(4 + cur * 2 + 0) * slot + me] = t4;
-      t4.x = e1zn[0]; t4.y = e1zn[1]; t4.z = e1zn[2]; t4.w = e1zn[3];
-      xch[(4 + cur * 2 + 1) * slot + me] = t4;
+      if constexpr (!E1S) {
+        t4.x = e1xn[0]; t4.y = e1xn[1]; t4.z = e1xn[2]; t4.w = e1xn[3];
+        xch[(4 + cur * 2 + 0) * slot + me] = t4;
+        t4.x = e1zn[0]; t4.y = e1zn[1]; t4.z = e1zn[2]; t4.w = e1zn[3];
+        xch[(4 + cur * 2 + 1) * slot + me] = t4;
+      }
+      if constexpr (EXJ) {          // E_x[k+1] of this row for the wave below (its E_x of the row above in S1 of the next iteration)
+        t4.x = exn[0]; t4.y = exn[1]; t4.z = exn[2]; t4.w = exn[3];
+        xch[XE * slot + me] = t4;
+      }
+      if constexpr (EZL) {
+        if (k + 1 <= k1) {
+          t4.x = ezn_pre[0]; t4.y = ezn_pre[1]; t4.z = ezn_pre[2]; t4.w = ezn_pre[3];
+          xch[XZ * slot + me] = t4;
+        }
+      }
       t4.x = h2x[0]; t4.y = h2x[1]; t4.z = h2x[2]; t4.w = h2x[3];
       xch[2 * slot + me] = t4;
       t4.x = h2z[0]; t4.y = h2z[1]; t4.z = h2z[2]; t4.w = h2z[3];
       xch[3 * slot + me] = t4;
     }
     if constexpr (WHATIF != 2 && WHATIF != 6 && WHATIF != 8) __syncthreads();      // (2: no second barrier — the upper bound of a one-barrier pipeline)
+    if constexpr (E1S) {          // E1[k] for the row below: read in S3 of the NEXT iteration, behind its first barrier — one buffer
+      float4 t4;
+      t4.x = e1xn[0]; t4.y = e1xn[1]; t4.z = e1xn[2]; t4.w = e1xn[3];
+      xch[4 * slot + me] = t4;
+      t4.x = e1zn[0]; t4.y = e1zn[1]; t4.z = e1zn[2]; t4.w = e1zn[3];
+      xch[5 * slot + me] = t4;
+    }
     // ---- S4: E2[k-1] ----
     if (own && k > k0) {
       float hyx = lane_prev(h2y[V - 1]);
@@ -912,6 +1033,7 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
     cur ^= 1;
   };
   // two planes per trip: the carried values alternate between two register sets instead of being copied
+  if constexpr (PF != 0) pf_issue(kA);
   for (int k = kA; k <= k1; k += 2) {
     body(k, LA);
     if (k + 1 <= k1) body(k + 1, LB2);
