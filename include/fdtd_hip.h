@@ -96,6 +96,9 @@ typedef struct FdtdStats {
                                 sources (a TFSF box / mode plane while it injects ...); 0 = none (single steps then are record / decay-check /
                                 odd-count steps) */
   int32_t src_paged_pairs;   /* of fused2_pairs: pairs that carried paged source terms (FDTD_OPT_SRC_PAGED; round 6) */
+  double  seam_kernel_ms;    /* with FDTD_FLAG_TIME_KERNELS: summed durations of seam_kernel behind the two-step sweeps (until round 6 they
+                                were part of fused_kernel_ms, which now brackets the sweep alone — what rocprofv3 reports for the kernel) */
+  int64_t seam_kernel_launches;
 } FdtdStats;
 
 /* FdtdStats.fused2_off_reason: what keeps a run on single steps (the first reason found) */

@@ -33,6 +33,8 @@ def main():
     with HipEngine(spec, variant=L.VARIANT_FUSED) as e:
         for c in range(6):
             e.set_field(c, start[c])
+        if os.environ.get("PF_TWOSTEP"):             # W + 64 * planes per chunk
+            e.set_option(L.OPT_TWOSTEP, int(os.environ["PF_TWOSTEP"]))
         e.run(20)                                   # placement probe, tile shape
         ref = None
         for w in NAMES:

@@ -30,7 +30,7 @@ def test_product_library_exports_every_symbol():
 
 def test_struct_layouts():
     assert ctypes.sizeof(L.FdtdConfig) == 4 * (3 + 6 + 4) + 4 + 4 * 6
-    assert ctypes.sizeof(L.FdtdStats) == 8 + 4 + 4 + 8 * 4 + 8 * 3 + 8 * 2 + 4 * 6 + 4 * 4 + 8 + 4 * 2 + 8 + 8 + 8 + 8 * 3 + 8 + 4 * 2 + 8 + 4 * 2
+    assert ctypes.sizeof(L.FdtdStats) == 8 + 4 + 4 + 8 * 4 + 8 * 3 + 8 * 2 + 4 * 6 + 4 * 4 + 8 + 4 * 2 + 8 + 8 + 8 + 8 * 3 + 8 + 4 * 2 + 8 + 4 * 2 + 8 * 2
 
 
 def test_create_rejects_bad_config_without_touching_a_gpu(emu_lib):

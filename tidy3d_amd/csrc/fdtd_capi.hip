@@ -853,17 +853,27 @@ bool fused2_shape(const FdtdSolver* h, int* W, int* zc, const ClipP* box = nullp
         if (w == 16) w = h->twostep_w; else continue;
       }
       const int R = w - 3, nby = (nyb + R - 1) / R;
-      // (one round of one 16-wave workgroup per CU exposes every plane's latency: 64-plane slab 16 x 20 0.1436 ms per step against
-      //  8 x 30 0.1263, profiles/r4f — 10.5 us per plane iteration here, not the 8.2 of a five-round launch)
-      const double t8 = 6.0 + (h->mat4 ? 1.6 : 0.0), t16 = 10.5 + (h->mat4 ? 1.2 : 0.0);
-      const double slots = w <= 8 ? 512.0 : 256.0, t = w <= 8 ? t8 : (w >= 16 ? t16 : t8 + (t16 - t8) * (w - 8) / 8.0);
+      // Round 6 (profiles/r6/r6w_slab_shapes.jsonl: 512 x 512 slabs of 64 / 128 / 256 planes, forced shapes against the model of
+      // rounds 3 - 5, which took 8 waves everywhere): per plane iteration a 16-wave workgroup takes 6.6 us + 2.1 us x (how full the
+      // launch's rounds of 256 are) — 8.6 when two rounds are nearly full — and 1.4 x that when the launch is ONE round (every
+      // plane's latency exposed: 16 x 20 on the 60 planes of a 64-plane slab 278 us per pair); an 8-wave one 7.2 us (two per CU), not
+      // the 6.0 fitted to 256^3 grids; a chunk costs its two extra iterations and ~1.5 more (prologue, ramp).  64 planes: 8 x 30
+      // 253 us per pair, 16 x 10 234; 128 planes: 8 x 18 461, 16 x 21 400; 256 planes: 8 x 23 815, 16 x 42 752 — the shapes this picks.
+      // (a rank that carries CPML runs the shell's boxes and the cut planes' single steps beside the bulk: a single round is not left
+      //  alone on the machine — 64 planes with layers on x / y: 16 x 20 0.180 ms per step, 16 x 10 0.197, 8 x 30 0.256; 128 planes: 16 x 21
+      //  0.338, 16 x 42 0.343, r6x_slab_shapes_pml2)
+      const double one_round = any_pml(h) ? 1.1 : 1.4;
+      const double slots = w <= 8 ? 512.0 : 256.0;
       for (int nch = 1; nch <= std::max(1, nzb / 4); ++nch) {
         const int c = (nzb + nch - 1) / nch;
         if (c > 64) continue;
         const double wg = (double)nbx * nby * ((nzb + c - 1) / c);
         double rounds = wg / slots;
         if (rounds < 4.0) rounds = std::ceil(rounds);
-        const double cost = rounds * (c + 2) * t;
+        const double fill = wg / (std::ceil(wg / slots) * slots);
+        const double t8 = 7.2 + (h->mat4 ? 1.6 : 0.0), t16 = (6.6 + 2.1 * fill) * (rounds <= 1.0 ? one_round : 1.0) + (h->mat4 ? 1.2 : 0.0);
+        const double t = w <= 8 ? t8 : (w >= 16 ? t16 : t8 + (t16 - t8) * (w - 8) / 8.0);
+        const double cost = rounds * (c + 3.5) * t;
         if (!found || cost < best * 0.999) { best = cost; *W = w; *zc = c; found = true; }
       }
     }
@@ -1255,7 +1265,7 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
   if (use_disp) dp = DispP{h->disp.dseg, h->disp.cs, h->disp.e1};
   int opt = (h->mem_hints ? 1 : 0) | (h->mat4 ? 2 : 0) | ((tb->mons.empty() && (!tb->with_sources || h->src_h_nodes == 0) && !tb->dstart) ? 0 : 4) |
             (clip ? 16 : (h->has_damp ? 8 : 0)) | (use_disp ? 32 | 1 : 0);
-  if (h->whatif > 0 && h->whatif <= 15 && h->whatif != 9 && opt == 1 && W == 16) opt |= h->whatif << 8;        // (measuring aid: the vacuum sweep with part of its work skipped)
+  if (h->whatif > 0 && h->whatif <= 15 && h->whatif != 9 && opt == 1 && (W == 16 || h->whatif == 13 || h->whatif == 14)) opt |= h->whatif << 8;        // (measuring aid: the vacuum sweep with part of its work skipped)
   SrcP sr_used = sr;
   if (h->whatif == 9 && !sr.sseg && !(opt & 8) && (!(opt & 32) || (opt & 16))) {
     // measuring aid (scripts/probe_bodies.py): the instantiation that adds paged source terms over a map WITHOUT any source segment —
@@ -1276,8 +1286,12 @@ int launch_fused2(FdtdSolver* h, long long n, hipStream_t st, const F2Table* tb,
   const bool split = tc && (use_disp || sr_used.sseg || (tc->n_bg > 0 && (h->tile_split == 1 || 8 * tc->n_bg >= tc->n_all)));
   launch_fused2_step(st, W, opt, blocks, g, h->f, h->f2, sp, mp, zc, nbx, nby, nbz, remap, inj, h->seam_buf, dmp, box,
                      TileClassP{split ? tc->dev : nullptr}, dp, sr_used);
-  if (n_seams > 0) launch_seams(st, g, h->f2, sp, mp, h->seam_buf, n_seams, dmp, box, inj, sr);
   time_end(h, st);
+  if (n_seams > 0) {
+    time_begin(h, 4, st);
+    launch_seams(st, g, h->f2, sp, mp, h->seam_buf, n_seams, dmp, box, inj, sr);
+    time_end(h, st);
+  }
   if (use_disp) h->disp.pairs++;
   if (!clip) swap_sets(h);
   return 0;
@@ -1569,7 +1583,11 @@ void shell2_shape(const FdtdSolver* h, const Shell2Box& bx, int W, int zc_cap, S
   for (int q = 3; q <= kShell2MaxQ; ++q) {
     if (forced_q > 0 && q != std::max(3, std::min(forced_q, L))) continue;
     if (q > std::max(3, L)) break;
-    const int S = (64 / q) * W, R = S - 3;
+    const int S = (64 / q) * W;
+    // (a box that starts on the y-min wall — a wall, not a periodic wrap — and fits one tile row without the two halo slots below: jlo = 0)
+    const bool wall_lo = bx.j0 == 0 && h->cfg.bc[2] != FDTD_BC_PERIODIC && rows <= S - 1;
+    const int jlo = wall_lo ? 0 : 2;
+    const int R = S - 1 - jlo;
     if (R < 1) continue;
     // tiles overlap by two lanes: tile t holds lanes t (q - 2) ... t (q - 2) + q - 1 of the row; lv = the last lane that must come out right
     const int lv = halo_r ? L - 2 : L - 1, qv = halo_r ? q - 2 : q - 1;
@@ -1590,6 +1608,7 @@ void shell2_shape(const FdtdSolver* h, const Shell2Box& bx, int W, int zc_cap, S
       best_cost = cost;
       best.q = q; best.xorg = bx.i0 - 4 * halo_l;
       best.ci0 = bx.i0; best.ci1 = bx.i1; best.j0 = bx.j0; best.j1 = bx.j1; best.k0 = bx.k0; best.k1 = bx.k1;
+      best.jlo = jlo;
       best.zchunk = zc; best.nbx = nbx; best.nby = nby; best.nbz = nbz;
     }
   }
@@ -4287,14 +4306,15 @@ struct Run {
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->stats.run_ms = ms;
     h->stats.steps_done = h->step;
-    h->stats.h_kernel_ms = h->stats.e_kernel_ms = h->stats.fused_kernel_ms = h->stats.shell_kernel_ms = 0.0;
-    h->stats.h_kernel_launches = h->stats.e_kernel_launches = h->stats.fused_kernel_launches = h->stats.shell_kernel_launches = 0;
+    h->stats.h_kernel_ms = h->stats.e_kernel_ms = h->stats.fused_kernel_ms = h->stats.shell_kernel_ms = h->stats.seam_kernel_ms = 0.0;
+    h->stats.h_kernel_launches = h->stats.e_kernel_launches = h->stats.fused_kernel_launches = h->stats.shell_kernel_launches = h->stats.seam_kernel_launches = 0;
     for (size_t i = 0; i < h->kev_kind.size(); ++i) {
       float t = 0.f;
       if (hipEventElapsedTime(&t, h->kev[2 * i], h->kev[2 * i + 1]) != hipSuccess) continue;
       if (h->kev_kind[i] == 0) { h->stats.h_kernel_ms += t; h->stats.h_kernel_launches++; }
       else if (h->kev_kind[i] == 1) { h->stats.e_kernel_ms += t; h->stats.e_kernel_launches++; }
       else if (h->kev_kind[i] == 3) { h->stats.shell_kernel_ms += t; h->stats.shell_kernel_launches++; }
+      else if (h->kev_kind[i] == 4) { h->stats.seam_kernel_ms += t; h->stats.seam_kernel_launches++; }
       else { h->stats.fused_kernel_ms += t; h->stats.fused_kernel_launches++; }
     }
     return 0;

@@ -39,9 +39,8 @@ void launch_fused2_step(hipStream_t st, int waves, int opt, int grid_blocks, con
     return;
   }
   const dim3 grid(grid_blocks, 1, 1), block(64, waves, 1);
-  const size_t shmem = ((size_t)fused2_xch_arrays(waves) * waves * 64 + ((opt & 8) ? 2 * 64 : 0)) * sizeof(float4);
 #define FDTD_F2_O(LBV, OV)                                                                                             \
-  hipLaunchKernelGGL((fused2_step_kernel<LBV, OV>), grid, block, shmem, st, g, a, b, s, m, zchunk, nbx, nby, nbz,     \
+  hipLaunchKernelGGL((fused2_step_kernel<LBV, OV>), grid, block, fused2_lds_bytes(LBV, OV, waves), st, g, a, b, s, m, zchunk, nbx, nby, nbz,     \
                      xcd_remap, inj, seam, dmp, clip, tcl, dp, sr)
 #define FDTD_F2(LBV)                                                                                                   \
   do {                                                                                                                 \

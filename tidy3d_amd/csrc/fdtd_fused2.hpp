@@ -77,11 +77,17 @@ struct SrcP {
   const SrcT* t = nullptr;
 };
 // exchange arrays of a workgroup of `waves` rows ([.][waves][64] float4 of dynamic LDS): H1_x H1_z | H2_x H2_z | E1_x E1_z twice, and — in
-// sixteen-wave workgroups (LB = 1024) — E_x of the next plane for the row below (fdtd_kernels2.hpp, EXJ)
+// most instantiations (fused2_exj) — E_x of the next plane for the row below (fdtd_kernels2.hpp, EXJ)
 #if !defined(FDTD_NO_EXJ)
 #define FDTD_NO_EXJ 0       // (1: a build without it — the A/B of the other instantiations, variants/libfdtd_hip_noexj.so)
 #endif
-constexpr int fused2_xch_arrays(int waves) { return (waves > 12 && !FDTD_NO_EXJ) ? 9 : 8; }
+// (lb: the instantiation's launch bound, 512 / 768 / 1024 threads for <= 8 / <= 12 / <= 16 waves; opt: its OPT word)
+constexpr bool fused2_exj(int lb, int opt) { return !FDTD_NO_EXJ && (opt & 8) == 0 && !(lb == 512 && (opt & 2) != 0); }
+constexpr int fused2_xch_arrays(int lb, int opt) { return fused2_exj(lb, opt) ? 9 : 8; }
+// dynamic LDS of a launch of fused2_step_kernel<lb, opt> with `waves` rows per workgroup (+ the absorber layers' x factors, + the (Ca, Cb) table)
+constexpr size_t fused2_lds_bytes(int lb, int opt, int waves) {
+  return ((size_t)fused2_xch_arrays(lb, opt) * waves * 64 + ((opt & 8) ? 2 * 64 : 0)) * sizeof(float4) + ((opt & 2) ? (size_t)kMaxMedia * sizeof(float2) : 0);
+}
 constexpr int kMaxCap = 1024;
 constexpr int kSeamArrays = 13;  // of step one: H1_y, H1_z, E1_x, E1_y, E1_z [c-1], E1_y, E1_z [c]; of step two: H2_x [c-1], H2_y, H2_z [c-2], H2_x, H2_y, H2_z [c]
                                  // (c = first column of the right tile)

@@ -16,9 +16,8 @@ void launch_fused2_step_clip(hipStream_t st, int waves, int opt, int grid_blocks
                              const FieldP& b, const StepP& s, const MatP& m, int zchunk, int nbx, int nby, int nbz,
                              int xcd_remap, const InjP& inj, float* seam, const DampT& dmp, const ClipP& clip, const TileClassP& tcl) {
   const dim3 grid(grid_blocks, 1, 1), block(64, waves, 1);
-  const size_t shmem = ((size_t)fused2_xch_arrays(waves) * waves * 64) * sizeof(float4);
 #define FDTD_F2_O(LBV, OV)                                                                                             \
-  hipLaunchKernelGGL((fused2_step_kernel<LBV, OV>), grid, block, shmem, st, g, a, b, s, m, zchunk, nbx, nby, nbz,     \
+  hipLaunchKernelGGL((fused2_step_kernel<LBV, OV>), grid, block, fused2_lds_bytes(LBV, OV, waves), st, g, a, b, s, m, zchunk, nbx, nby, nbz,     \
                      xcd_remap, inj, seam, dmp, clip, tcl, DispP{nullptr, nullptr, nullptr}, SrcP{})
 #define FDTD_F2(LBV)                                                                                                   \
   do {                                                                                                                 \

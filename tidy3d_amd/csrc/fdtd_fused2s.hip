@@ -19,9 +19,8 @@ void launch_fused2_step_src(hipStream_t st, int waves, int opt, int grid_blocks,
                             int xcd_remap, const InjP& inj, float* seam, const DampT& dmp, const ClipP& clip, const TileClassP& tcl,
                             const DispP& dp, const SrcP& sr) {
   const dim3 grid(grid_blocks, 1, 1), block(64, waves, 1);
-  const size_t shmem = ((size_t)fused2_xch_arrays(waves) * waves * 64 + ((opt & 8) ? 2 * 64 : 0)) * sizeof(float4);
 #define FDTD_F2_O(LBV, OV)                                                                                             \
-  hipLaunchKernelGGL((fused2_step_kernel<LBV, OV>), grid, block, shmem, st, g, a, b, s, m, zchunk, nbx, nby, nbz,     \
+  hipLaunchKernelGGL((fused2_step_kernel<LBV, OV>), grid, block, fused2_lds_bytes(LBV, OV, waves), st, g, a, b, s, m, zchunk, nbx, nby, nbz,     \
                      xcd_remap, inj, seam, dmp, clip, tcl, dp, sr)
   // 64 + 4 + 1 = 69: source terms, monitor table, non-temporal stores; + 2: materials; + 8: absorber layers; + 16: clipped; + 32: memory terms
 #define FDTD_F2(LBV)                                                                                                   \

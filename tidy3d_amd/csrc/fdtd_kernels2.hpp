@@ -213,11 +213,12 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
   constexpr int PF = (WHATIF >= 10 && WHATIF <= 12) ? WHATIF : 0;            // prefetch instantiation (correct results)
   // EXJ: E_x of the row above comes from the wave above through a ninth exchange array (fused2_xch_arrays) instead of a second global
   // load of a line the workgroup has already fetched — 512^3 vacuum inside one engine 0.690 -> 0.675 ms per step (profiles/r6/r6u): the
-  // sweep is bound by requests between the CUs and L2 (11.6 B per cycle and CU), not by HBM alone.  Sixteen-wave workgroups only (one per
-  // CU whatever its LDS); WHATIF 14 = the sweep without it, for A/B inside one engine.  Whole bench lines of two builds, three rounds
+  // sweep is bound by requests between the CUs and L2 (11.6 B per cycle and CU), not by HBM alone; eight-wave workgroups: 256^3 - 1.5 %,
+  // 320^3 - 3.1 % (r6u_exj_8waves).  Not in the eight-wave materials instantiations (two workgroups per CU: 2 x (72 + 8) KB of LDS would
+  // leave one) nor with absorber layers (below); WHATIF 14 = the sweep without it, for A/B inside one engine.  Whole bench lines of two builds, three rounds
   // interleaved (profiles/r6/r6v): V1 + 3 %, V2 / V3 / V4 + 2 %, the absorber instantiation - 5 % (two more spilled registers) — left out there.
   constexpr bool EZL = WHATIF == 15;                                         // E_z through LDS (variant 15)
-  constexpr bool EXJ = LB == 1024 && ((WHATIF == 0 && !FDTD_NO_EXJ && (OPT & 8) == 0) || WHATIF == 13 || EZL);
+  constexpr bool EXJ = (WHATIF == 0 && (OPT & 4096) == 0) || WHATIF == 13 || EZL;      // (bit 12: the KERNEL's instantiation has no room for it — set by fused2_step_kernel, which sized the LDS)
   constexpr bool E1S = PF != 0 || EZL;                                       // E1 exchanged through ONE buffer (published behind the second barrier)
   constexpr int XE = E1S ? 6 : 8, XZ = 7;                                    // exchange arrays of E_x[k+1] (EXJ) and E_z[k+1] (EZL)
   [[maybe_unused]] constexpr int NPF = PF == 11 ? 2 : (PF ? 3 : 0);                           // arrays of the next plane that travel through LDS
@@ -249,12 +250,15 @@ __device__ __forceinline__ void fused2_step_tile(const GridP& g, const FieldP& a
 #pragma unroll
     for (int q = 0; q < NXCH; ++q) xch[q * slot + me] = z4;     // rows beyond the grid publish E = 0, H = 0
   }
-  __shared__ float2 lut_s[MAT ? kMaxMedia : 1];
+  // absorber layers: the x factors of the tile's 256 cells (fb: cell boundaries, fc: cell centres; 1 outside the layers)
+  [[maybe_unused]] float4* xdm = xch + (EXJ ? 9 : 8) * slot;             // [2][64]
+  // the (Ca, Cb) table: behind them in the DYNAMIC allocation (fused2_lds_bytes).  As a static array of this function it was allocated
+  // once per tile body of a kernel — three or four in the launches that dispatch by tile class, 24 - 32 KB beside 144 KB of exchange
+  // arrays: HSA_STATUS_ERROR_INVALID_ALLOCATION on the device (round 6, the random cases of tests/test_fuzz_round6.py)
+  [[maybe_unused]] float2* lut_s = reinterpret_cast<float2*>(xdm + (DAMP ? 2 * 64 : 0));
   if constexpr (MAT) {
     for (int q = me; q < m.n_media; q += slot) lut_s[q] = m.lut[q];
   }
-  // absorber layers: the x factors of the tile's 256 cells (fb: cell boundaries, fc: cell centres; 1 outside the layers)
-  [[maybe_unused]] float4* xdm = xch + (EXJ ? 9 : 8) * slot;             // [2][64]
   if constexpr (DAMP) {
     if (ty == 0) {
       const int ii = (tile_x * 64 + tx) * V;
@@ -1088,13 +1092,15 @@ __global__ __launch_bounds__(LB, (LB == 512 ? 4 : 1)) void fused2_step_kernel(Gr
   }
   // (bit 2 of a tile's class, launches that add paged source terms: a row segment of the tile holds a source node — the others run
   //  the instantiation without those lines: the mode plane of BASELINE config 3 crosses 1 tile row in 64, and the lines cost 8 %)
+  // (every tile body of this kernel shares the LDS the launcher sized from the kernel's own OPT word: fused2_xch_arrays)
+  constexpr int OPTK = OPT | (fused2_exj(LB, OPT) ? 0 : 4096);
   if constexpr ((OPT & 64) != 0) {
     if (tcl.cls && !(tcl.cls[t] & 4)) {
-      fused2_tile_by_class<LB, (OPT & ~64)>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t, dp, sr, tcl);
+      fused2_tile_by_class<LB, (OPTK & ~64)>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t, dp, sr, tcl);
       return;
     }
   }
-  fused2_tile_by_class<LB, OPT>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t, dp, sr, tcl);
+  fused2_tile_by_class<LB, OPTK>(g, a, b, s, m, zchunk, nbx, nby, nbz, inj, seam, dmp, clip, t, dp, sr, tcl);
 }
 
 // ---- the seams between x tiles -------------------------------------------------------------------------------------

@@ -22,7 +22,8 @@
 // fused2_step_kernel keeps per row in SGPRs is per lane here; all lanes load (idle ones from clamped addresses) and compute,
 // only the stores are predicated — every lane shift and barrier stays in uniform control flow.
 //   rows:    row slots 0 .. S-1 of a workgroup (S = (64 / Q) * waves) are rows j0 - 2 .. j0 + S - 3 of its tile; slots 2 .. S-2
-//            are written (two halo rows below, one above, recomputed — as in fused2_step_kernel).
+//            are written (two halo rows below, one above, recomputed — as in fused2_step_kernel).  A box on the y-min wall that fits one
+//            tile row starts with slot 0 on row 0 (Shell2P::jlo = 0): nothing lies below the wall.
 //   columns: x tiles OVERLAP by two lanes: lane 0 and lane Q-1 of a tile are halo lanes (what they hold after two steps is wrong
 //            two / one cells deep) unless they sit on an x wall — no seam scratch, no seam kernel, no edge-column loads.
 //   planes:  a chunk [k0, k1) runs iterations k0-1 .. k1; a prologue supplies H1_{x,y}[k0-2] from read-only psi.
@@ -70,8 +71,8 @@ __global__ __launch_bounds__(512, (AXES == 7 ? 2 : 3)) void shell2_step_kernel(G
   const int me = lane_on ? slot_i * Q + q : 0;             // compact index: the row below is me - Q, the row above me + Q (idle lanes publish nothing)
   const int mb = slot_i > 0 ? me - Q : me;               // (slot 0 / the top slot read their own entry: what they form from it is never used)
   const int ma = slot_i < S - 1 ? me + Q : me;
-  const int R = S - 3;
-  const int jr = sp.j0 + tile_y * R + slot_i - 2;        // the lane's row
+  const int R = S - 1 - sp.jlo;
+  const int jr = sp.j0 + tile_y * R + slot_i - sp.jlo;        // the lane's row
   const bool row_ok = lane_on && jr >= 0 && jr < g.ny;
   const int j = row_ok ? jr : 0;                         // (keeps every address inside the arrays)
   const int i0r = sp.xorg + (tile_x * (Q - 2) + q) * V;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(512, (AXES == 7 ? 2 : 3)) void shell2_step_kernel(G
   const bool act = row_ok && in_x;
   const bool last_x = !per_x && in_x && (i0 + V >= g.nx);
   const bool first_x = !per_x && in_x && (i0 == 0);
-  const bool own_row = slot_i >= 2 && slot_i <= S - 2 && row_ok && jr < sp.j1;
+  const bool own_row = slot_i >= sp.jlo && slot_i <= S - 2 && row_ok && jr < sp.j1;
   // a lane on a tile edge holds wrong values two / one cells deep after two steps (its neighbour lane belongs to the next tile) — unless it sits on a wall
   const bool own_col = act && i0r >= sp.ci0 && i0r < sp.ci1 && (q >= 1 || first_x) && (q <= Q - 2 || last_x);
   const bool st_lane = own_row && own_col;

@@ -9,6 +9,9 @@ struct Shell2P {
   int xorg;            // first column of lane 0 of x tile 0 (a multiple of 4, >= 0); tile t starts (q - 2) lanes further per t
   int ci0, ci1;        // columns written: [ci0, ci1), multiples of 4
   int j0, j1;          // rows written
+  int jlo;             // halo slots below a tile's first written row: 2 — or 0 for a box that starts on the y-min wall and fits ONE tile row
+                       // (nby == 1): its slot 0 is row 0, which needs nothing from below (round 6: the y-min slab of a 512^3 V2 grid, 14 rows,
+                       // took three tile rows of 8 slots, or two of 16, where 16 slots hold rows 0 .. 15)
   int k0, k1;          // planes written
   int zchunk;          // planes per workgroup
   int nbx, nby, nbz;   // tiles

@@ -76,7 +76,8 @@ class FdtdStats(C.Structure):
                 ("shell_pairs", C.c_int64), ("shell_kernel_ms", C.c_double), ("shell_kernel_launches", C.c_int64),
                 ("shell2_pairs", C.c_int64),
                 ("fused2_off_reason", C.c_int32), ("struct_bytes", C.c_int32), ("disp_pairs", C.c_int64),
-                ("single_step_reason", C.c_int32), ("src_paged_pairs", C.c_int32)]
+                ("single_step_reason", C.c_int32), ("src_paged_pairs", C.c_int32),
+                ("seam_kernel_ms", C.c_double), ("seam_kernel_launches", C.c_int64)]
 
 
 PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_int64, C.c_double, C.c_double, C.c_void_p)
