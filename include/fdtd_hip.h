@@ -274,7 +274,7 @@ enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_R
        FDTD_OPT_BND_PLANES = 7 /* planes per boundary chunk of the fused z-slab schedule, 0 = default (2) */,
        FDTD_OPT_AUTOTUNE = 8 /* 1: time a few tile shapes of the fused sweep on the first run of grids >= 2^20 cells (default 0) */,
        FDTD_OPT_PML_SPLIT = 9 /* CPML-carrying step as three launches over interior / edge tiles: -1 = by grid size (default), 0, 1 */,
-       FDTD_OPT_PLACEMENT_TRIES = 12, /* alternative placements of the field arrays the first large one-GPU run samples (0 ... 3, default 3; 0 = keep the first allocations): each costs four sweeps and, while it is timed, a second copy of the field memory */
+       FDTD_OPT_PLACEMENT_TRIES = 12, /* alternative placements of the field arrays the first large one-GPU run samples (0 ... 8, default 6; 0 = keep the first allocations): each costs six sweeps and a further copy of the field memory until the probe ends (candidates that lose are held so that the next one lands elsewhere) */
        FDTD_OPT_MEM_HINTS = 11, /* 1 (default): the measured store placement of the sweep (without CPML: non-temporal field stores, H ahead of the row exchange; with CPML: the H-side psi behind the E update); 0: plain stores, fields at the end of the plane, H-side psi in the H phase */
        FDTD_OPT_TBLOCK = 13, /* one-GPU fused runs without CPML / TFSF / periodic z: advance TWO time steps per pass over
                                 the grid, slab by slab (slab s+1 takes step n, then slab s takes step n+1 while the

@@ -238,9 +238,9 @@ struct FdtdSolver {
   // costs more (+0.41 ms / +3.0 ms) than the slab kernels it removes (0.22 ms / 0.45 ms) -> default 0.
   int pml_fused = -1;                // -1 = default
   // placement of the field arrays: how many alternative sets of allocations the first large run tries (probe_placement)
-  int placement_tries = 3;
+  int placement_tries = 6;
   bool placement_done = false;
-  float placement_ms[4] = {0.f, 0.f, 0.f, 0.f};      // time of the probe sweeps per candidate (the first is the original)
+  float placement_ms[9] = {};      // time of the probe sweeps per candidate (the first is the original)
   int placement_tried = 0, placement_kept = 0;        // candidates timed beyond the original / index of the one kept (0 = original)
   int mem_hints = 1;                 // FDTD_OPT_MEM_HINTS: 1 = non-temporal field stores in the sweep's instantiations without CPML
   int lds_pad = 0;                   // extra dynamic LDS per workgroup of the sweep (bytes): lowers its occupancy — a measuring aid
@@ -1818,7 +1818,10 @@ int probe_placement(FdtdSolver* h, hipStream_t st) {
     return 0;
   };
   int rc = 0;
-  for (int t = 0; t < h->placement_tries && t < 3 && !rc; ++t) {
+  // (round 6: candidates that lose are HELD until the probe ends — freed at once, their blocks came straight back as the next
+  //  candidate and the probe timed the same placement again; up to 8 tries)
+  std::vector<float*> held;
+  for (int t = 0; t < h->placement_tries && t < 8 && !rc; ++t) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + need / 4) break;
     float* cand[12] = {};
@@ -1830,7 +1833,7 @@ int probe_placement(FdtdSolver* h, hipStream_t st) {
       h->err.clear();
       break;
     }
-    auto drop_cand = [&]() { for (int c = 0; c < 12; ++c) release_buf(h, cand[c]); };
+    auto drop_cand = [&]() { for (int c = 0; c < 12; ++c) held.push_back(cand[c]); };
     // dev_alloc zero-fills on the NULL stream, which this engine's non-blocking stream does not wait for: without this the
     // memset of a candidate could land AFTER the copy below and the "restored" fields came back partly zero (caught by
     // tests/test_gpu_production_path.py on the first visit with this probe, profiles/r3l)
@@ -1860,7 +1863,7 @@ int probe_placement(FdtdSolver* h, hipStream_t st) {
       if (!rc) rc = copy6(cand + 6, cur + 6);
       if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail(h, "probe_placement: %s", hipGetErrorString(hipGetLastError()));
       if (rc) { drop_cand(); break; }
-      for (int c = 0; c < 12; ++c) { release_buf(h, cur[c]); cur[c] = cand[c]; }
+      for (int c = 0; c < 12; ++c) { held.push_back(cur[c]); cur[c] = cand[c]; }
       best = ms;
       h->placement_kept = t + 1;
     } else {
@@ -1870,6 +1873,13 @@ int probe_placement(FdtdSolver* h, hipStream_t st) {
   }
   for (int c = 0; c < 6; ++c) { h->fbase[c] = cur[c]; h->fbase2[c] = cur[6 + c]; }
   set_field_views(h);
+  if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = fail(h, "probe_placement: %s", hipGetErrorString(hipGetLastError()));
+  for (float* q : held) release_buf(h, q);
+  if (getenv("FDTD_PLACEMENT_LOG")) {
+    fprintf(stderr, "[placement] kept %d of 1 + %d:", h->placement_kept, h->placement_tried);
+    for (int t = 0; t <= h->placement_tried; ++t) fprintf(stderr, " %.3f", h->placement_ms[t]);
+    fprintf(stderr, " ms\n");
+  }
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   h->cfg.flags = flags;
@@ -4588,7 +4598,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
     case FDTD_OPT_BND_PLANES: h->bnd_planes = value > 0 ? value : 0; return 0;
     case FDTD_OPT_AUTOTUNE: h->autotune = value < 0 ? 0 : (value > 2 ? 1 : value); if (value) h->tuned = false; return 0;
     case FDTD_OPT_MEM_HINTS: h->mem_hints = value != 0; return 0;
-    case FDTD_OPT_PLACEMENT_TRIES: if (value < 0 || (value % 100) > 3) break; h->placement_tries = value; h->placement_done = false; return 0;
+    case FDTD_OPT_PLACEMENT_TRIES: if (value < 0 || (value % 100) > 8) break; h->placement_tries = value; h->placement_done = false; return 0;
     case FDTD_OPT_LDS_PAD: if (value < 0 || value > 120000) break; h->lds_pad = value; return 0;
     case FDTD_OPT_TBLOCK: h->tblock = value < 0 ? -1 : value; return 0;
     case FDTD_OPT_EDGE_ZCHUNK: h->edge_zchunk = value < 0 ? -1 : value; return 0;
