@@ -150,3 +150,21 @@ def test_lists_that_meet_on_nodes(emu_lib):
     got = run(disc.spec, emu_lib, 5 + 64 * 3, (11, 16))
     assert got[3] == 0, got[2:]
     same(ref, got)
+
+
+@pytest.mark.parametrize("N,w,zc", [((40, 30, 28), 5, 3), ((300, 26, 24), 16, 32)])
+def test_time_monitor_on_the_faces_of_a_tfsf_box(N, w, zc, emu_lib):
+    """point probes (stored as the 4 x 4 x 4 cells around them) on a corner and on a face of the TFSF box — they hold H nodes of the box's H-side corrections — recording
+    every step while the box injects inside pairs: the H-side terms of step n change H^{n-1/2} in front of the sweep, so the record of
+    step n takes its first H half-sample in front of THEM (as for magnetic dipoles).  Found by scripts/fuzz_round6.py on the device
+    (seed 11, case 47): the record came back half a term too large, fields identical."""
+    sx = (N[0] - 1e-6) * DL
+    cx = -0.5 * sx + 256 * DL if N[0] > 256 else 0.0
+    src = td.TFSF(center=(cx, 0, 0), size=(1.0, 0.7, 0.6), source_time=SHORT, injection_axis=2, direction="+")
+    mons = [td.FieldTimeMonitor(center=(cx + 0.5, 0.35, 0.3), size=(0, 0, 0), name="corner", interval=1, colocate=False),
+            td.FieldTimeMonitor(center=(cx - 0.5, 0.0, -0.3), size=(0, 0, 0), name="edge", interval=2, colocate=False,
+                                fields=["Hx", "Hy", "Ez"])]
+    disc = discretize(sim(N, PEC, [src], [], mons), n_steps=40)
+    disc.spec.decay_every = 0
+    got = check(disc.spec, emu_lib, w + 64 * zc, (11, 16, 13))
+    assert float(np.abs(np.asarray(got[1]["corner"])).max()) > 0

@@ -1585,7 +1585,7 @@ void shell2_shape(const FdtdSolver* h, const Shell2Box& bx, int W, int zc_cap, S
     if (q > std::max(3, L)) break;
     const int S = (64 / q) * W;
     // (a box that starts on the y-min wall — a wall, not a periodic wrap — and fits one tile row without the two halo slots below: jlo = 0)
-    const bool wall_lo = bx.j0 == 0 && h->cfg.bc[2] != FDTD_BC_PERIODIC && rows <= S - 1;
+    const bool wall_lo = bx.j0 == 0 && h->cfg.bc[2] != FDTD_BC_PERIODIC && rows <= S - 1 && !getenv("FDTD_NO_JLO");      // ($FDTD_NO_JLO: a debugging aid)
     const int jlo = wall_lo ? 0 : 2;
     const int R = S - 1 - jlo;
     if (R < 1) continue;
@@ -1703,6 +1703,16 @@ int shell2_why_not(const FdtdSolver* h, ShellGeom* G) {
   return 0;
 }
 
+// H-side source terms of step n act on H^{n-1/2} in place in FRONT of a pair's sweep: then the small time monitors of the pair take
+// E^n and their first H half-sample in front of those (record_monitors at the top of the step) and pair_record adds the rest.
+// Round 6: the H-side corrections of a TFSF box count too — since such boxes inject inside pairs (paged source terms) a probe on
+// one of their H nodes recorded half the term of step n too much (1e-12 of the field on the pulse's rising edge: one random device
+// case in 200, scripts/fuzz_round6.py seed 11 case 47).
+bool h_terms_in_front(const FdtdSolver* h) {
+  if (h->src_h_nodes > 0) return true;
+  for (const Tfsf& t : h->tfsf) if (t.h.n_targets) return true;
+  return false;
+}
 // behind the sweep of the pair (n, n + 1) (the sets are swapped: h->f2 = what it read, h->f = what it wrote): everything the
 // monitors of `tb` record of steps n and n + 1, in one launch
 void pair_record(FdtdSolver* h, const F2Table* tb, long long n, hipStream_t st) {
@@ -1724,7 +1734,7 @@ void pair_record(FdtdSolver* h, const F2Table* tb, long long n, hipStream_t st) 
   }
   if (tb->mons.empty()) return;
   PairRecP r{};
-  r.pre_done = h->src_h_nodes > 0;            // (then fdtd_run has not skipped them at the top of the step)
+  r.pre_done = h_terms_in_front(h);            // (then fdtd_run has not skipped them at the top of the step)
   long long max_cells = 0;
   for (size_t q = 0; q < tb->mons.size(); ++q) {
     Monitor& m = h->mons[(size_t)tb->mons[q]];
@@ -4002,7 +4012,7 @@ struct Run {
     pair_spg = pair_spg && pair && (use_s2 ? zp == &zp_s2 : (f2_ok && !f2s_ok));
     // (with H-side sources the monitors of a pair still take E^n and H^{n-1/2} here: those sources change H^{n-1/2} before the
     //  sweep, and pair_record reads the set afterwards)
-    if (rec) record_monitors(h, n, false, st, (pair && h->src_h_nodes == 0) ? &f2_plan : nullptr);
+    if (rec) record_monitors(h, n, false, st, (pair && !h_terms_in_front(h)) ? &f2_plan : nullptr);
     if (rec && multi) {
       // The record reads H^{n-1/2} of the top plane, which the comm stream is about to advance (its H-side corrections and
       // update of that plane wait for the E interior of the LAST step only): it must let the record finish first.  Found by
