@@ -49,6 +49,8 @@ with HipEngine(spec, device=0) as e:
              ("shell2_zc16", {**S2, L.OPT_SHELL2_SHAPE: sw(zcw=16, zcs=16)}),
              ("shell2_zc64", {**S2, L.OPT_SHELL2_SHAPE: sw(zcw=64, zcs=64)}),
              ("shell2_16x32", {**S2, L.OPT_TWOSTEP: 16 + 64 * 32}),
+             ("shell2_by_axes", {**P, L.OPT_SHELL2: 2}), ("shell2_by_axes_ws4", {**P, L.OPT_SHELL2: 2, L.OPT_SHELL2_SHAPE: sw(ws=4)}),
+             ("shell2_by_axes_ws8", {**P, L.OPT_SHELL2: 2, L.OPT_SHELL2_SHAPE: sw(ws=8)}), ("shell2_by_box", {**P, L.OPT_SHELL2: 3}),
              ("single", {L.OPT_TWOSTEP: 0}), ("shell2", S2)]
     if os.environ.get("PROBE_MODES"):
         keep = os.environ["PROBE_MODES"].split(",")
