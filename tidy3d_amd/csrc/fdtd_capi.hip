@@ -239,6 +239,7 @@ struct FdtdSolver {
   int pml_fused = -1;                // -1 = default
   // placement of the field arrays: how many alternative sets of allocations the first large run tries (probe_placement)
   int placement_tries = 6;
+  int slab_boxes_first = 1;          // FDTD_OPT_SLAB_BOXES_FIRST: the shell's boxes of a CPML slab-rank pair in front of the bulk sweep (1) or behind it (0)
   bool placement_done = false;
   float placement_ms[9] = {};      // time of the probe sweeps per candidate (the first is the original)
   int placement_tried = 0, placement_kept = 0;        // candidates timed beyond the original / index of the one kept (0 = original)
@@ -4042,6 +4043,13 @@ struct Run {
     HIPCHK(h, hipStreamWaitEvent(st, h->ev_e_bnd, 0));
     const ClipP clip{sgm.o0[0], sgm.o1[0], sgm.o0[1], sgm.o1[1], sgm.o0[2], sgm.o1[2]};
     bool s2done = false;
+    Shell2Box boxes[kShell2MaxBoxes];
+    const int nb = shell2_boxes(h, sgm, boxes, bl, nz - bh);
+    // Round 6: the boxes go out IN FRONT of the bulk on st (FDTD_OPT_SLAB_BOXES_FIRST, default).  Behind it (round 5) they ran alone
+    // on the machine for 87 us of a 362 us pair of a 64-plane slab while the hole's first step, beside the bulk's single round of
+    // one-per-CU workgroups, crawled for 160 us on the CUs the bulk left (kernel timeline profiles/r6/r6tr_timeline_p2.txt); in front,
+    // boxes and hole share the machine, then the bulk runs beside the exchanges and the hole's second step.
+    if (h->slab_boxes_first) launch_shell2_boxes(h, boxes, nb, h->pml_blk2[hp][ep], st, tb);
     if (launch_fused2(h, n, st, tb, &s2done, nullptr, &clip)) return -1;
     if (launch_fused_range(h, 0, bl ? bl + 1 : 0, cs, pml_in_m, bh ? nz - bh - 1 : nz, nz, -1, 0, 0, true, &s1)) return -1;
     HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
@@ -4053,11 +4061,9 @@ struct Run {
     if (bh) { launch_sources(h, true, n + 1, nz - bh, nz, cs, false, &B); launch_sources(h, false, n + 2, nz - bh, nz, cs, false, &B); }
     HIPCHK(h, hipEventRecord(h->ev_e_bnd, cs));
     if (exchange_fused_all(h, cs, psi_ghosts, &B, 2)) return -1;
-    Shell2Box boxes[kShell2MaxBoxes];
-    const int nb = shell2_boxes(h, sgm, boxes, bl, nz - bh);
-    // (the boxes behind the bulk on st: cs carries what the neighbours wait for — behind the hole's steps and the two exchanges the
-    //  boxes made cs the longer stream of a thin slab: 64 planes 0.232 -> 0.205 ms per step, 128 planes 0.500 -> 0.460, profiles/r5/r5zb)
-    launch_shell2_boxes(h, boxes, nb, h->pml_blk2[hp][ep], st, tb);
+    // (not on cs: it carries what the neighbours wait for — behind the hole's steps and the two exchanges the boxes made cs the longer
+    //  stream of a thin slab: 64 planes 0.232 -> 0.205 ms per step, 128 planes 0.500 -> 0.460, profiles/r5/r5zb)
+    if (!h->slab_boxes_first) launch_shell2_boxes(h, boxes, nb, h->pml_blk2[hp][ep], st, tb);
     swap_sets(h);                                                            // h->f = B: E^{n+2}, H^{n+3/2}
     swap_psi_h(h, 7);
     swap_psi_e(h);
@@ -4631,6 +4637,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
       h->spg_on = value < 0 ? -1 : (value != 0);
       if (h->spg.state == -1 && value != 0) h->spg.state = 0;
       return 0;
+    case FDTD_OPT_SLAB_BOXES_FIRST: if (value < 0 || value > 1) break; h->slab_boxes_first = value; return 0;
     case FDTD_OPT_WHATIF: if (value < 0 || value > 15) break; h->whatif = value; return 0;
     case FDTD_OPT_DISP:
       if (h->disp.state == 1 && value == 0) break;       // (every ADE launch keeps the paged memory terms by now: set it before the first run)

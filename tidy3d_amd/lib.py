@@ -45,7 +45,7 @@ BC_PEC, BC_PMC, BC_PERIODIC, BC_NEIGHBOR = 0, 1, 2, 3
 MON_TIME, MON_DFT = 0, 1
 VARIANT_AUTO, VARIANT_SIMPLE, VARIANT_ZMARCH, VARIANT_FUSED = 0, 1, 2, 3
 FLAG_TIME_KERNELS = 1
-OPT_FLAGS, OPT_VARIANT, OPT_ZCHUNK, OPT_ROWS, OPT_XCD_REMAP, OPT_FUSED_LB, OPT_PML_FUSED, OPT_BND_PLANES, OPT_AUTOTUNE, OPT_PML_SPLIT, OPT_LDS_PAD, OPT_MEM_HINTS, OPT_PLACEMENT_TRIES, OPT_TBLOCK, OPT_EDGE_ZCHUNK, OPT_GRAPH, OPT_TWOSTEP, OPT_SHELL_PAIRS, OPT_STRIP, OPT_SHELL2, OPT_SHELL2_SHAPE, OPT_DEBUG_SYNC, OPT_TILE_SPLIT, OPT_DISP, OPT_WHATIF, OPT_SRC_PAGED = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25
+OPT_FLAGS, OPT_VARIANT, OPT_ZCHUNK, OPT_ROWS, OPT_XCD_REMAP, OPT_FUSED_LB, OPT_PML_FUSED, OPT_BND_PLANES, OPT_AUTOTUNE, OPT_PML_SPLIT, OPT_LDS_PAD, OPT_MEM_HINTS, OPT_PLACEMENT_TRIES, OPT_TBLOCK, OPT_EDGE_ZCHUNK, OPT_GRAPH, OPT_TWOSTEP, OPT_SHELL_PAIRS, OPT_STRIP, OPT_SHELL2, OPT_SHELL2_SHAPE, OPT_DEBUG_SYNC, OPT_TILE_SPLIT, OPT_DISP, OPT_WHATIF, OPT_SRC_PAGED, OPT_SLAB_BOXES_FIRST = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26
 # FdtdStats.fused2_off_reason (include/fdtd_hip.h FDTD_F2_OFF_*)
 F2_OFF_REASONS = {0: "", 1: "switched off", 2: "grid too small", 3: "z-slab rank", 4: "CPML (shell pairs not possible)",
                   5: "dispersive media not confined to a few planes along z", 6: "TFSF box while it injects", 7: "Bloch / PMC-plus faces (or rows not a multiple of 4 cells)", 8: "magnetic sources with absorber layers",
