@@ -330,6 +330,36 @@ def test_two_steps_per_sweep_bit_identical_bench_v0(hip_lib, w, zc, n):
         assert np.array_equal(got[c], ref[c]), c
 
 
+@pytest.mark.parametrize("variant", [10, 11, 12, 13, 14])
+def test_prefetch_and_row_exchange_instantiations_on_the_device(hip_lib, variant):
+    """The measuring-aid instantiations of round 6 that give CORRECT results (FDTD_OPT_WHATIF = 10 ... 14, csrc/fdtd_kernels2.hpp): part of the
+    next plane through LDS by LDS-DMA (10 - 12), E_x of the row above from the wave above (13: the default's form), the sweep without it
+    (14).  The LDS-DMA ones raced on the device in their first form — a DMA that hit in L2 landed before the wave's queued ds_read of the
+    slice had returned; the emulator cannot see that — so they are held to the normal sweep here, three runs each, 320^3 bench V0."""
+    from bench import build_spec
+    n, steps = 320, 12
+    spec = build_spec(n, steps + 4, "v0")
+    init = _bench_init(n)
+    with HipEngine(spec, lib=hip_lib, axis_shift=0) as e:
+        e.set_option(L.OPT_TWOSTEP, 16 + 64 * 32)
+        e.set_option(L.OPT_PLACEMENT_TRIES, 0)
+
+        def run(whatif):
+            e.reset()
+            e.set_option(L.OPT_WHATIF, whatif)
+            for c in range(6):
+                e.set_field(c, init[c])
+            st = e.run(steps)
+            assert int(st.fused2_pairs) == steps // 2
+            return [e.get_field(c) for c in range(6)]
+        ref = run(0)
+        for _ in range(3):
+            got = run(variant)
+            for c in range(6):
+                assert np.array_equal(got[c], ref[c]), (variant, c)
+        e.set_option(L.OPT_WHATIF, 0)
+
+
 @pytest.mark.parametrize("w,zc,n", [(16, 32, 512), (8, 32, 512), (-1, 0, 256)])
 def test_two_steps_per_sweep_with_materials_bit_identical_bench_v1(hip_lib, w, zc, n):
     """bench.py's V1 workload (a sub-pixel-averaged dielectric sphere: 93 media; PEC walls, a dipole, random initial fields) on
