@@ -88,6 +88,11 @@ constexpr int fused2_xch_arrays(int lb, int opt) { return fused2_exj(lb, opt) ? 
 constexpr size_t fused2_lds_bytes(int lb, int opt, int waves) {
   return ((size_t)fused2_xch_arrays(lb, opt) * waves * 64 + ((opt & 8) ? 2 * 64 : 0)) * sizeof(float4) + ((opt & 2) ? (size_t)kMaxMedia * sizeof(float2) : 0);
 }
+// (everything a workgroup of the sweep keeps in LDS is in this one dynamic allocation — no static arrays in the tile bodies, which a
+//  kernel of several bodies would hold once per body — so the 160 KB of a gfx950 CU bound it here, at compile time)
+static_assert(fused2_lds_bytes(1024, 1 | 2 | 4 | 16 | 32 | 64, 16) <= 160 * 1024 && fused2_lds_bytes(1024, 2 | 8, 16) <= 160 * 1024 &&
+              2 * fused2_lds_bytes(512, 1, 8) <= 160 * 1024 && 2 * fused2_lds_bytes(512, 2 | 8, 8) <= 160 * 1024,
+              "fused2_step_kernel: LDS of a workgroup (two per CU for eight waves)");
 constexpr int kMaxCap = 1024;
 constexpr int kSeamArrays = 13;  // of step one: H1_y, H1_z, E1_x, E1_y, E1_z [c-1], E1_y, E1_z [c]; of step two: H2_x [c-1], H2_y, H2_z [c-2], H2_x, H2_y, H2_z [c]
                                  // (c = first column of the right tile)
