@@ -890,13 +890,18 @@ bool fused2_shape(const FdtdSolver* h, int* W, int* zc, const ClipP* box = nullp
     //  with 16 waves, 0.882 with 8 against 1.136 for single sweeps, profiles/r3zx)
     // (absorber layers damped in registers, 512^3 with 40 layers: 0.959 / 1.014 ms per step with 16 / 8 waves, 1.104 / 1.185 with
     //  materials too, profiles/r3zs)
-    const double t8 = 6.0 + (h->mat4 ? 1.6 : 0.0) + (h->has_damp ? 2.7 : 0.0), t16 = 8.2 + (h->mat4 ? 1.2 : 0.0) + (h->has_damp ? 3.0 : 0.0) + (h->mat4 && h->has_damp ? 0.5 : 0.0);
-    const double slots = w <= 8 ? 512.0 : 256.0, t = w <= 8 ? t8 : (w >= 16 ? t16 : t8 + (t16 - t8) * (w - 8) / 8.0);
+    // (round 6: 6.0 us per plane iteration of an 8-wave workgroup holds while the launch is ONE round — 256^3: 416 workgroups on 512
+    //  slots — launches of several rounds measure 7.2 - 7.7 (slab ranks, r6w) and 320^3 / 384^3 prefer 16 waves: 8 x 16 127 against
+    //  16 x 64 136 Gcells/s, 8 x 24 154 against 16 x 48 157, profiles/r6/r6sh_v0_shapes.jsonl)
+    const double t16 = 8.2 + (h->mat4 ? 1.2 : 0.0) + (h->has_damp ? 3.0 : 0.0) + (h->mat4 && h->has_damp ? 0.5 : 0.0);
+    const double slots = w <= 8 ? 512.0 : 256.0;
     for (int c : {64, 48, 32, 24, 16, 12, 8}) {
       if (c > std::max(8, g.nz)) continue;
       const double wg = (double)nbx * nby * ((g.nz + c - 1) / c);
       double rounds = wg / slots;
       if (rounds < 4.0) rounds = std::ceil(rounds);
+      const double t8 = (rounds <= 1.0 ? 6.0 : 6.8) + (h->mat4 ? 1.6 : 0.0) + (h->has_damp ? 2.7 : 0.0);
+      const double t = w <= 8 ? t8 : (w >= 16 ? t16 : t8 + (t16 - t8) * (w - 8) / 8.0);
       const double cost = rounds * (c + 2) * t;
       // (16 waves are tried first; 8 waves must be 8 % cheaper under the model to replace them: inside its error the measured
       //  times are equal or favour 16 waves — 512^3 0.703 / 0.709 ms, 1024^3 16 x 64 best, profiles/r3w, r3zw)
