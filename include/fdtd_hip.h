@@ -329,7 +329,7 @@ enum { FDTD_OPT_FLAGS = 0, FDTD_OPT_VARIANT = 1, FDTD_OPT_ZCHUNK = 2, FDTD_OPT_R
                                    two lists meet on a node), 0 = off: single steps (or the lists' planes as z holes) while they inject. */
        FDTD_OPT_WHATIF = 24, /* measuring aid (round 6): 1 ... 8 = a what-if instantiation of the vacuum two-step sweep that skips part of its work
                                 (csrc/fdtd_kernels2.hpp lists them) — WRONG results, meaningful times; 0 = off (default) */
-       FDTD_OPT_SLAB_BOXES_FIRST = 26, /* z-slab ranks that carry CPML, step pairs: the shell's boxes are launched in front of the bulk sweep (1, default) or behind it (0: round 5) */
+       FDTD_OPT_SLAB_BOXES_FIRST = 26, /* z-slab ranks that carry CPML, step pairs: the shell's boxes are launched in front of the bulk sweep (1), behind it (0: round 5), beside it on a third stream (2), or 2 for slabs of 96 planes and more, else 1 (3, default) */
        FDTD_OPT_LDS_PAD = 10 /* measuring aid: extra dynamic LDS per workgroup of the sweep in bytes (lowers its occupancy) */ };
 int fdtd_set_option(FdtdSolver* h, int key, int value);
 int fdtd_reset(FdtdSolver* h);      /* zero fields, auxiliaries, monitors and the step counter */

@@ -1,7 +1,7 @@
 """CPML slab-rank pairs on the device: random boxes with layers on x / y and a periodic z, run as ONE z-slab rank whose RCCL exchange
 is looped back to itself (HipEngine force_comm; FDTD_OPT_PML_FUSED = 7, step pairs forced) against the plain one-GPU run of the
 same problem in single steps — fields and records, bit for bit.
-    python scripts/fuzz_slab_cpml_device.py [n_cases] [seed]"""
+    python scripts/fuzz_slab_cpml_device.py [n_cases] [seed] [FDTD_OPT_SLAB_BOXES_FIRST value]"""
 import os
 import sys
 
@@ -54,6 +54,7 @@ def draw(rng):
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    boxes = int(sys.argv[3]) if len(sys.argv) > 3 else -1
     L.load_library()
     bad = in_pairs = 0
     for q in range(n_cases):
@@ -68,6 +69,8 @@ def main():
             e.comm_init(e.unique_id())
             e.set_option(L.OPT_PML_FUSED, 7)
             e.set_option(L.OPT_TWOSTEP, twostep)
+            if boxes >= 0:
+                e.set_option(L.OPT_SLAB_BOXES_FIRST, boxes)
             st = e.run()
             got, got_f = e.results(), [e.get_field(c) for c in range(6)]
         diff = [c for c in range(6) if not np.array_equal(got_f[c], ref_f[c])] + [k for k, v in ref.items() if not np.array_equal(np.asarray(got[k]), np.asarray(v))]

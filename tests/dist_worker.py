@@ -85,6 +85,9 @@ def main():
     if os.environ.get("TWOSTEP"):                           # step pairs on the slab ranks, whatever the grid size (tests)
         from tidy3d_amd import lib as L
         eng.set_option(L.OPT_TWOSTEP, int(os.environ["TWOSTEP"]))
+    if os.environ.get("SLAB_BOXES"):                        # where the shell's boxes of a CPML slab pair go (tests: 2 = a third stream)
+        from tidy3d_amd import lib as L
+        eng.set_option(L.OPT_SLAB_BOXES_FIRST, int(os.environ["SLAB_BOXES"]))
     if os.environ.get("PLACEMENT_TRIES"):                   # force the placement probe of the library on (tests)
         from tidy3d_amd import lib as L
         eng.set_option(L.OPT_PLACEMENT_TRIES, int(os.environ["PLACEMENT_TRIES"]))

@@ -15,8 +15,10 @@ from tidy3d_amd.engine import HipEngine, split_slabs
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def _launch(world, case, n_steps, out, port, slab_shift=None, placement_tries=None, pml_fused=None, twostep=None):
+def _launch(world, case, n_steps, out, port, slab_shift=None, placement_tries=None, pml_fused=None, twostep=None, slab_boxes=None):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if slab_boxes is not None:
+        env["SLAB_BOXES"] = str(slab_boxes)
     if twostep is not None:
         env["TWOSTEP"] = str(twostep)
     if slab_shift is not None:
@@ -136,15 +138,17 @@ CPML_PAIR_CASES = [(2, "slab_pairs_pml_box", 8 + 64 * 6), (2, "slab_pairs_pml_bo
                    (3, "slab_pairs_pml_box_near_cut", 8 + 64 * 4)]       # (the last one: a dipole next to a cut — its rank takes single steps beside ranks in pairs)
 
 
-@pytest.mark.parametrize("world,case,twostep", CPML_PAIR_CASES)
-def test_step_pairs_on_slab_ranks_that_carry_cpml(world, case, twostep, emu_lib, tmp_path):
+@pytest.mark.parametrize("world,case,twostep,boxes", [c + (None,) for c in CPML_PAIR_CASES] + [CPML_PAIR_CASES[0] + (2,), CPML_PAIR_CASES[2] + (0,)])
+def test_step_pairs_on_slab_ranks_that_carry_cpml(world, case, twostep, boxes, emu_lib, tmp_path):
     """Round 5: z-slab ranks with CPML (x / y layers on every rank, z layers on the end ranks) advance in shell2 pairs — bulk and boxes
     as on one GPU over the planes two or more away from a cut, the two planes next to a cut as a z hole that takes two single steps
     and ships its planes (and the H-side psi of the top plane) after each.  Same bits as the single-slab run, materials through the
-    cuts, monitor records ending pairs; every rank takes pairs."""
+    cuts, monitor records ending pairs; every rank takes pairs.  `boxes`: FDTD_OPT_SLAB_BOXES_FIRST — the shell's boxes behind the bulk
+    (0), in front of it (default) or on a third stream beside it (2: round 6)."""
     import cases
     out = str(tmp_path / "dist.npz")
-    _launch(world, case, 46, out, 29741 + CPML_PAIR_CASES.index((world, case, twostep)), twostep=twostep, pml_fused=7)
+    _launch(world, case, 46, out, 29741 + CPML_PAIR_CASES.index((world, case, twostep)) + (0 if boxes is None else 10 + boxes), twostep=twostep,
+            pml_fused=7, slab_boxes=boxes)
     got = np.load(out)
     if case == "slab_pairs_pml_box_near_cut":
         assert got["pairs"].max() >= 8 and got["pairs"].min() == 0, got["pairs"]

@@ -239,7 +239,10 @@ struct FdtdSolver {
   int pml_fused = -1;                // -1 = default
   // placement of the field arrays: how many alternative sets of allocations the first large run tries (probe_placement)
   int placement_tries = 6;
-  int slab_boxes_first = 1;          // FDTD_OPT_SLAB_BOXES_FIRST: the shell's boxes of a CPML slab-rank pair in front of the bulk sweep (1) or behind it (0)
+  int slab_boxes_first = 3;          // FDTD_OPT_SLAB_BOXES_FIRST: the shell's boxes of a CPML slab-rank pair in front of the bulk sweep (1), behind it (0),
+                                     // beside it on a stream of their own (2: box_stream), or 2 for slabs of 96 planes and more, else 1 (3, default)
+  hipStream_t box_stream = nullptr;  // (created at the first such pair)
+  hipEvent_t ev_box = nullptr;
   bool placement_done = false;
   float placement_ms[9] = {};      // time of the probe sweeps per candidate (the first is the original)
   int placement_tried = 0, placement_kept = 0;        // candidates timed beyond the original / index of the one kept (0 = original)
@@ -2800,6 +2803,8 @@ void fdtd_destroy(FdtdSolver* h) {
   if (h->ev_shell_b) hipEventDestroy(h->ev_shell_b);
   if (h->stream) hipStreamDestroy(h->stream);
   if (h->comm_stream && !h->streams_shared) hipStreamDestroy(h->comm_stream);
+  if (h->box_stream) hipStreamDestroy(h->box_stream);
+  if (h->ev_box) hipEventDestroy(h->ev_box);
   delete h;
 }
 
@@ -4054,7 +4059,23 @@ struct Run {
     // on the machine for 87 us of a 362 us pair of a 64-plane slab while the hole's first step, beside the bulk's single round of
     // one-per-CU workgroups, crawled for 160 us on the CUs the bulk left (kernel timeline profiles/r6/r6tr_timeline_p2.txt); in front,
     // boxes and hole share the machine, then the bulk runs beside the exchanges and the hole's second step.
-    if (h->slab_boxes_first) launch_shell2_boxes(h, boxes, nb, h->pml_blk2[hp][ep], st, tb);
+    // (2: on a third stream beside both — the boxes read set A and their own psi sets, write their own cells of set B: they wait for what
+    //  st and cs waited for, and st waits for them before it marks the pair's interior done)
+    // Measured (profiles/r6/r6b3_slab_boxes_third_stream.jsonl, 512 x 512 x nz with CPML on x / y, three rounds interleaved): 128 planes 0.3226 ->
+    // 0.3175 ms per step, 256 planes 0.571 -> 0.561 — but 64 planes 0.164 -> 0.213: beside a bulk of ONE round of one-per-CU workgroups the
+    // boxes and the hole's first step crawl on the CUs the bulk left, and st waits for the boxes.  Hence 3: by the slab's planes.
+    const bool third = (h->slab_boxes_first == 2 || (h->slab_boxes_first == 3 && nz >= 96)) && nb > 0 && !h->streams_shared && !h->debug_sync;
+    if (third) {
+      if (!h->box_stream) {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->box_stream, hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_box, hipEventDisableTiming));
+      }
+      HIPCHK(h, hipEventRecord(h->ev_box, st));                               // (everything st has issued: the last pair's interior)
+      HIPCHK(h, hipStreamWaitEvent(h->box_stream, h->ev_box, 0));
+      HIPCHK(h, hipStreamWaitEvent(h->box_stream, h->ev_e_bnd, 0));
+      launch_shell2_boxes(h, boxes, nb, h->pml_blk2[hp][ep], h->box_stream, tb);
+      HIPCHK(h, hipEventRecord(h->ev_box, h->box_stream));
+    } else if (h->slab_boxes_first) launch_shell2_boxes(h, boxes, nb, h->pml_blk2[hp][ep], st, tb);
     if (launch_fused2(h, n, st, tb, &s2done, nullptr, &clip)) return -1;
     if (launch_fused_range(h, 0, bl ? bl + 1 : 0, cs, pml_in_m, bh ? nz - bh - 1 : nz, nz, -1, 0, 0, true, &s1)) return -1;
     HIPCHK(h, hipEventRecord(h->ev_h_bnd, cs));
@@ -4069,6 +4090,7 @@ struct Run {
     // (not on cs: it carries what the neighbours wait for — behind the hole's steps and the two exchanges the boxes made cs the longer
     //  stream of a thin slab: 64 planes 0.232 -> 0.205 ms per step, 128 planes 0.500 -> 0.460, profiles/r5/r5zb)
     if (!h->slab_boxes_first) launch_shell2_boxes(h, boxes, nb, h->pml_blk2[hp][ep], st, tb);
+    if (third) HIPCHK(h, hipStreamWaitEvent(st, h->ev_box, 0));
     swap_sets(h);                                                            // h->f = B: E^{n+2}, H^{n+3/2}
     swap_psi_h(h, 7);
     swap_psi_e(h);
@@ -4642,7 +4664,7 @@ int fdtd_set_option(FdtdSolver* h, int key, int value) {
       h->spg_on = value < 0 ? -1 : (value != 0);
       if (h->spg.state == -1 && value != 0) h->spg.state = 0;
       return 0;
-    case FDTD_OPT_SLAB_BOXES_FIRST: if (value < 0 || value > 1) break; h->slab_boxes_first = value; return 0;
+    case FDTD_OPT_SLAB_BOXES_FIRST: if (value < 0 || value > 3) break; h->slab_boxes_first = value; return 0;
     case FDTD_OPT_WHATIF: if (value < 0 || value > 15) break; h->whatif = value; return 0;
     case FDTD_OPT_DISP:
       if (h->disp.state == 1 && value == 0) break;       // (every ADE launch keeps the paged memory terms by now: set it before the first run)
