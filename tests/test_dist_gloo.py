@@ -290,6 +290,36 @@ def test_balanced_slabs_follow_the_cost_model():
         cost[a:b].sum() for a, b in split_slabs(nz, 2))
 
 
+def test_balanced_slabs_price_planes_as_step_pairs_do_where_the_ranks_take_them():
+    """Round 6: ranks that advance in shell2 step pairs (dist.cpml_pairs_possible) pay 2.2 x a bulk plane for a plane inside the z layers,
+    not the 3.6 x of the single-step kernels — the end ranks get more planes than the single-step model hands them (measured on the
+    device: scripts/probe_end_rank.py, profiles/r6/r6er_end_rank_split_fresh_processes.jsonl), the partition stays contiguous, complete
+    and clear of the layers, and make_engine's gate still lets every rank take pairs."""
+    from tidy3d_amd.dist import cpml_pairs_possible
+    from tidy3d_amd.engine import balanced_slabs, plane_costs
+    import tidy3d_amd.schema as td
+    sim = td.Simulation(
+        size=(5.0, 5.0, 9.0), grid_spec=td.GridSpec.uniform(dl=0.05), run_time=1e-13,
+        structures=[td.Structure(geometry=td.Sphere(center=(0, 0, 0), radius=1.0), medium=td.Medium(permittivity=4.0))],
+        sources=[td.PointDipole(center=(0, 0, -1), source_time=td.GaussianPulse(freq0=3e14, fwidth=3e13), polarization="Ex")],
+        monitors=[], boundary_spec=td.BoundarySpec.all_sides(td.PML(num_layers=10)))
+    spec = discretize(sim, n_steps=2).spec
+    nz = spec.shape[2]
+    assert cpml_pairs_possible(spec)
+    single, pair = plane_costs(spec), plane_costs(spec, pairs=True)
+    assert 1.2 < pair[0] / pair[nz // 2] < 0.85 * single[0] / single[nz // 2]
+    assert (pair[:12] == pair[0]).all() and pair[12] == pair[nz // 2] and (pair[nz - 12:] == pair[0]).all()      # (10 layers + the two-cell collar)
+    for world in (2, 4, 8):
+        a, b = balanced_slabs(spec, world), balanced_slabs(spec, world, pairs=True)
+        assert b[0][0] == 0 and b[-1][1] == nz and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+        assert all(10 + 2 <= z0 <= nz - 10 - 2 for z0, _ in b[1:])
+        if world > 2:
+            assert b[0][1] - b[0][0] > a[0][1] - a[0][0] and b[-1][1] - b[-1][0] > a[-1][1] - a[-1][0]
+        cost = [pair[z0:z1].sum() for z0, z1 in b]
+        assert max(cost) <= max(pair[z0:z1].sum() for z0, z1 in a) + 1e-9
+        assert cpml_pairs_possible(spec, b) == (world == 2)           # (2^20 cells per rank: the library's threshold for pairs)
+
+
 @pytest.mark.parametrize("shift,world,case", [(1, 2, "media_mix"), (2, 3, "drude_in_pml")])
 def test_slab_axis_renaming_matches_single_slab(shift, world, case, emu_lib, tmp_path):
     """tidy3d_amd.dist.make_engine may rename the axes cyclically so that the slab axis is the one with the most

@@ -82,6 +82,12 @@ def make_engine(spec: SolverSpec, lib=None, device: Optional[int] = None, axis_s
     if nz < 2 * world:
         raise ValueError(f"{nz} planes cannot be split into {world} slabs of >= 2 planes")
     slabs = balanced_slabs(spec, world)       # equal modelled cost, not equal plane counts
+    if cpml_pairs_possible(spec):
+        # the ranks of this problem will advance in shell2 step pairs: price the planes as the pairs do (a z-layer plane 2.2 x a bulk
+        # plane, not 3.6 x) — where that split leaves every rank room for its pairs; else the single-step split stands
+        paired = balanced_slabs(spec, world, pairs=True)
+        if cpml_pairs_possible(spec, paired):
+            slabs = paired
     if device is None:
         device = env_ranks()[2]
     eng = HipEngine(spec, lib=lib, device=device, slab=slabs[rank], rank=rank, n_ranks=world,

@@ -46,11 +46,34 @@ def split_slabs(nz: int, n_ranks: int) -> List[Tuple[int, int]]:
     return out
 
 
-def plane_costs(spec: SolverSpec) -> np.ndarray:
+# per cell and step PAIR on MI355X (fdtd_capi.hip kShell2*Ps, profiles/r5/r5d, r5e): the clipped two-step sweep over the bulk (with
+# material words), a cell of the shell's wide boxes (y / z slabs), a cell of its x strips
+PAIR_BULK_PS, PAIR_BULK_MAT_PS, PAIR_WIDE_PS, PAIR_STRIP_PS = 11.3, 12.9, 27.0, 41.0
+
+
+def plane_costs(spec: SolverSpec, pairs: bool = False) -> np.ndarray:
     """Relative cost of one xy-plane per step, from the measured per-cell kernel times on MI355X
     (DESIGN.md section 5): fused sweep 9.3 ps/cell (+5 % with material words), CPML slab kernels
-    24 ps per cell and PML-axis membership, ADE 21 ps per dispersive cell and pole."""
+    24 ps per cell and PML-axis membership, ADE 21 ps per dispersive cell and pole.
+
+    ``pairs``: the ranks advance in shell2 step pairs (dist.cpml_pairs_possible) — a plane then costs what the pair's launches take
+    of it: the bulk's cells the clipped two-step sweep, the ring of x / y layers (+ the two-cell collar) the shell's strips and wide
+    boxes, and a plane inside the z layers is wide-box cells throughout: 2.2 x a bulk plane, where the single-step model says 3.6 x
+    (round 6: end ranks of a z-CPML problem were handed too few planes; scripts/probe_end_rank.py measures the split)."""
     nx, ny, nz = spec.shape
+    if pairs:
+        (xl, xh), (yl, yh), (zl, zh) = [(p[0].num_layers, p[1].num_layers) for p in spec.pml]
+        ox = nx - (xl + 2 if xl else 0) - (xh + 2 if xh else 0)
+        oy = ny - (yl + 2 if yl else 0) - (yh + 2 if yh else 0)
+        bulk = PAIR_BULK_MAT_PS if spec.mat_idx is not None else PAIR_BULK_PS
+        ring = (nx - ox) * ny * PAIR_STRIP_PS + ox * (ny - oy) * PAIR_WIDE_PS
+        cost = np.full(nz, 0.5 * (ox * oy * bulk + ring))
+        zpl = 0.5 * ((nx - ox) * ny * PAIR_STRIP_PS + ox * ny * PAIR_WIDE_PS)
+        if zl:
+            cost[:zl + 2] = zpl
+        if zh:
+            cost[nz - zh - 2:] = zpl
+        return cost
     cost = np.full(nz, nx * ny * 9.3 * (1.05 if spec.mat_idx is not None else 1.0))
     (xl, xh), (yl, yh), (zl, zh) = [(p[0].num_layers, p[1].num_layers) for p in spec.pml]
     cost += 24.0 * ((xl + xh) * ny + (yl + yh) * nx)
@@ -71,18 +94,18 @@ def plane_costs(spec: SolverSpec) -> np.ndarray:
     return cost
 
 
-def balanced_slabs(spec: SolverSpec, n_ranks: int, min_planes: int = 4) -> List[Tuple[int, int]]:
+def balanced_slabs(spec: SolverSpec, n_ranks: int, min_planes: int = 4, pairs: bool = False) -> List[Tuple[int, int]]:
     """Contiguous z-slabs of (nearly) equal modelled cost instead of equal plane counts: PML z-slabs
     and dispersive regions make some planes heavier (SURVEY.md section 8(e) "load balance").  Cuts
     are kept two planes clear of the z-PML so that the fused z-slab schedule stays available; falls
     back to ``split_slabs`` when the constraints cannot be met.  Deterministic: every rank derives
-    the same partition from the same spec."""
+    the same partition from the same spec.  ``pairs``: price the planes as shell2 step pairs do (plane_costs)."""
     nz = spec.shape[2]
     if n_ranks <= 1:
         return [(0, nz)]
     if nz < min_planes * n_ranks:
         return split_slabs(nz, n_ranks)
-    cum = np.concatenate(([0.0], np.cumsum(plane_costs(spec))))
+    cum = np.concatenate(([0.0], np.cumsum(plane_costs(spec, pairs))))
     zl, zh = spec.pml[2][0].num_layers, spec.pml[2][1].num_layers
     lo_ok = zl + 2 if zl else min_planes
     hi_ok = nz - zh - 2 if zh else nz - min_planes
