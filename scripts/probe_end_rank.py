@@ -3,9 +3,9 @@ One GPU cannot loop an END rank's exchange back to itself (its other z face carr
 problems on one GPU, in the step pairs a rank takes: the end rank = its planes with CPML on x / y / z-min and a PEC wall where the cut
 would be; a middle rank = its planes with CPML on x / y and PEC walls on z (beside it: the same planes as a real slab rank, periodic z
 with the RCCL exchange looped back — what the cut's hole and exchanges add).  Prints one JSON line per (ranks, cost model).
-Every slab is timed in a process of its own: engines created one after the other in ONE process get the blocks the last one freed,
-and where twelve arrays of 67 planes land inside blocks that held 70 planes cost 35 % (the first form of this script measured that,
-profiles/r6/r6er_end_rank_split_one_process_placement_artifact.jsonl).
+Every slab is timed in a process of its own: in the first form of this script (one process) every engine created after the first
+looped-back RCCL engine ran 18 - 35 % slower than the same slab in a fresh process (profiles/r6/r6er_end_rank_split_one_process_artifact.jsonl;
+cause not established).  A rank process holds one engine.
     python scripts/probe_end_rank.py [--ranks 8,4] [--steps 200]"""
 import argparse
 import json
