@@ -242,7 +242,7 @@ struct FdtdSolver {
   int slab_boxes_first = 3;          // FDTD_OPT_SLAB_BOXES_FIRST: the shell's boxes of a CPML slab-rank pair in front of the bulk sweep (1), behind it (0),
                                      // beside it on a stream of their own (2: box_stream), or 2 for slabs of 96 planes and more, else 1 (3, default)
   hipStream_t box_stream = nullptr;  // (created at the first such pair)
-  hipEvent_t ev_box = nullptr;
+  hipEvent_t ev_box = nullptr, ev_box_in = nullptr;      // the boxes done / what st had issued in front of them
   bool placement_done = false;
   float placement_ms[9] = {};      // time of the probe sweeps per candidate (the first is the original)
   int placement_tried = 0, placement_kept = 0;        // candidates timed beyond the original / index of the one kept (0 = original)
@@ -2805,6 +2805,7 @@ void fdtd_destroy(FdtdSolver* h) {
   if (h->comm_stream && !h->streams_shared) hipStreamDestroy(h->comm_stream);
   if (h->box_stream) hipStreamDestroy(h->box_stream);
   if (h->ev_box) hipEventDestroy(h->ev_box);
+  if (h->ev_box_in) hipEventDestroy(h->ev_box_in);
   delete h;
 }
 
@@ -4069,9 +4070,10 @@ struct Run {
       if (!h->box_stream) {
         HIPCHK(h, hipStreamCreateWithFlags(&h->box_stream, hipStreamNonBlocking));
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_box, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_box_in, hipEventDisableTiming));
       }
-      HIPCHK(h, hipEventRecord(h->ev_box, st));                               // (everything st has issued: the last pair's interior)
-      HIPCHK(h, hipStreamWaitEvent(h->box_stream, h->ev_box, 0));
+      HIPCHK(h, hipEventRecord(h->ev_box_in, st));                            // (everything st has issued: the last pair's interior)
+      HIPCHK(h, hipStreamWaitEvent(h->box_stream, h->ev_box_in, 0));
       HIPCHK(h, hipStreamWaitEvent(h->box_stream, h->ev_e_bnd, 0));
       launch_shell2_boxes(h, boxes, nb, h->pml_blk2[hp][ep], h->box_stream, tb);
       HIPCHK(h, hipEventRecord(h->ev_box, h->box_stream));
