@@ -1,0 +1,55 @@
+"""Does an engine run slower when an earlier engine of the same process held an RCCL communicator?  (scripts/probe_end_rank.py's first form
+and the `slab` stage of scripts/gpu_visit.sh time several looped-back slab ranks in ONE process; the later ones read 10 - 35 % slow.)
+One process per sequence; the LAST engine of a sequence is the one reported.
+    python scripts/probe_engine_order.py            (runs the sequences, a process each)
+    python scripts/probe_engine_order.py --seq c64,c128"""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEQS = ["c128", "c64,c128", "p64,c128", "v512,c128", "c64,c64,c64,c128", "p128", "c64,p128", "p64,p128"]
+
+
+def run_seq(names):
+    import numpy as np
+    import torch  # noqa: F401
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import probe_slab
+    from tidy3d_amd import lib as L
+    from tidy3d_amd.engine import HipEngine
+    out = None
+    for nm in names:
+        kind, nz = nm[0], int(nm[1:])                 # c: looped-back slab rank (periodic z, RCCL), p: the same slab without a communicator, v: 512^3-like cube
+        sp = probe_slab.spec_for(512, nz, 400, 0)
+        kw = dict(variant=L.VARIANT_FUSED)
+        if kind == "c":
+            kw["force_comm"] = True
+        with HipEngine(sp, **kw) as e:
+            if kind == "c":
+                e.comm_init(e.unique_id())
+            rng = np.random.default_rng(0)
+            for c in range(6):
+                e.set_field(c, rng.uniform(-1e-3, 1e-3, (nz, 512, 512)).astype(np.float32))
+            e.run(30)
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                st = e.run(100)
+                best = min(best, (time.perf_counter() - t0) / 100 * 1e3)
+            out = {"sequence": ",".join(names), "last": nm, "ms_per_step": best, "pairs": int(st.fused2_pairs), "stream_overlap": int(st.stream_overlap),
+                   "stream_retries": int(st.stream_retries), "placement": [int(st.placement) >> 8, int(st.placement) & 255]}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    if "--seq" in sys.argv:
+        run_seq(sys.argv[sys.argv.index("--seq") + 1].split(","))
+    else:
+        for s in SEQS:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--seq", s], capture_output=True, text=True, timeout=600)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            print(lines[-1] if lines else json.dumps({"sequence": s, "error": r.stderr[-400:]}), flush=True)
