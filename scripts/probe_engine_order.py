@@ -11,6 +11,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SEQS = ["c128", "c64,c128", "p64,c128", "v512,c128", "c64,c64,c64,c128", "p128", "c64,p128", "p64,p128"]
+SEQS_TORCH = ["v512", "t0,v512", "c64,v512", "t0,c128", "t0,p128", "c128", "p128"]       # t0: torch.distributed's own RCCL (world size 1) initialised first
 
 
 def run_seq(names):
@@ -23,8 +24,19 @@ def run_seq(names):
     from tidy3d_amd.engine import HipEngine
     out = None
     for nm in names:
+        if nm[0] == "t":
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29631")
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+            x = torch.ones(1024, device="cuda"); dist.all_reduce(x); dist.barrier(); torch.cuda.synchronize()
+            continue
         kind, nz = nm[0], int(nm[1:])                 # c: looped-back slab rank (periodic z, RCCL), p: the same slab without a communicator, v: 512^3-like cube
         sp = probe_slab.spec_for(512, nz, 400, 0)
+        if kind == "v":                                # the headline's walls
+            import dataclasses
+            from tidy3d_amd.spec import BC_PEC
+            sp = dataclasses.replace(sp, bc=(sp.bc[0], sp.bc[1], (BC_PEC, BC_PEC)))
         kw = dict(variant=L.VARIANT_FUSED)
         if kind == "c":
             kw["force_comm"] = True
@@ -49,7 +61,7 @@ if __name__ == "__main__":
     if "--seq" in sys.argv:
         run_seq(sys.argv[sys.argv.index("--seq") + 1].split(","))
     else:
-        for s in SEQS:
+        for s in (SEQS_TORCH if "--torch" in sys.argv else SEQS):
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--seq", s], capture_output=True, text=True, timeout=600)
             lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
             print(lines[-1] if lines else json.dumps({"sequence": s, "error": r.stderr[-400:]}), flush=True)
