@@ -241,7 +241,9 @@ struct FdtdSolver {
   int placement_tries = 6;
   int slab_boxes_first = 3;          // FDTD_OPT_SLAB_BOXES_FIRST: the shell's boxes of a CPML slab-rank pair in front of the bulk sweep (1), behind it (0),
                                      // beside it on a stream of their own (2: box_stream), or 2 for slabs of 96 planes and more, else 1 (3, default)
-  hipStream_t box_stream = nullptr;  // (created at the first such pair)
+  hipStream_t box_stream = nullptr;  // (made at the first such pair: make_box_stream)
+  bool box_stream_tried = false;
+  int box_stream_attempts = 0;
   hipEvent_t ev_box = nullptr, ev_box_in = nullptr;      // the boxes done / what st had issued in front of them
   bool placement_done = false;
   float placement_ms[9] = {};      // time of the probe sweeps per candidate (the first is the original)
@@ -1944,6 +1946,62 @@ int autotune_fused(FdtdSolver* h, hipStream_t st) {
   return 0;
 }
 
+// two spins of 200 us, one on each stream: 1 = they ran side by side, 0 = one after the other (one hardware queue), -1 = error
+int streams_run_side_by_side(FdtdSolver* h, hipStream_t a, hipStream_t b) {
+#if defined(__HIPCC__)
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device) != hipSuccess || khz <= 0) khz = 100000;
+  const long long ticks = (long long)khz / 5;
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess) return -1;
+  int res = -1;
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, 0LL);
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, 0LL);
+  if (hipStreamSynchronize(a) == hipSuccess && hipStreamSynchronize(b) == hipSuccess) {
+    hipEventRecord(e0, a);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, ticks);
+    hipEventRecord(e1, a);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, ticks);
+    hipEventRecord(e2, b);
+    if (hipEventSynchronize(e1) == hipSuccess && hipEventSynchronize(e2) == hipSuccess) {
+      float t1 = 0.f, t2 = 0.f;
+      hipEventElapsedTime(&t1, e0, e1);
+      hipEventElapsedTime(&t2, e0, e2);
+      res = std::max(t1, t2) < 0.32f ? 1 : 0;
+    }
+  }
+  hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
+  return res;
+#else
+  (void)h; (void)a; (void)b;
+  return 1;
+#endif
+}
+// the third stream of CPML slab-rank pairs (the shell's boxes beside the bulk and the cut planes' hole): one that shares a hardware queue
+// with neither of the engine's two streams — fresh streams are tried, the rejected ones held meanwhile (the runtime hands a new stream the
+// least-loaded queue); none found: box_stream stays null and the boxes keep their place in front of the bulk.  Called between runs' launches
+// only at the first such pair (it synchronises the two streams).
+int make_box_stream(FdtdSolver* h) {
+  h->box_stream_tried = true;
+  std::vector<hipStream_t> rejected;
+  hipStream_t found = nullptr;
+  for (int attempt = 0; attempt < 6 && !found; ++attempt) {
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+    const int a = streams_run_side_by_side(h, s, h->stream), b = a == 1 ? streams_run_side_by_side(h, s, h->comm_stream) : 0;
+    if (a == 1 && b == 1) found = s; else rejected.push_back(s);
+    if (a < 0 || b < 0) break;
+  }
+  for (hipStream_t r : rejected) hipStreamDestroy(r);
+  (void)hipGetLastError();
+  h->box_stream = found;
+  h->box_stream_attempts = (int)rejected.size() + (found ? 1 : 0);
+  if (found) {
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_box, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_box_in, hipEventDisableTiming));
+  }
+  return 0;
+}
 // Do the engine's two streams really run concurrently?  The HIP runtime multiplexes a process's streams onto
 // $GPU_MAX_HW_QUEUES hardware queues (default 4); two streams that land on ONE queue execute their launches one after
 // the other.  For this engine that is a silent 3x cliff: the boundary chunks and the interior sweep of a z-slab step
@@ -4065,13 +4123,10 @@ struct Run {
     // Measured (profiles/r6/r6b3_slab_boxes_third_stream.jsonl, 512 x 512 x nz with CPML on x / y, three rounds interleaved): 128 planes 0.3226 ->
     // 0.3175 ms per step, 256 planes 0.571 -> 0.561 — but 64 planes 0.164 -> 0.213: beside a bulk of ONE round of one-per-CU workgroups the
     // boxes and the hole's first step crawl on the CUs the bulk left, and st waits for the boxes.  Hence 3: by the slab's planes.
-    const bool third = (h->slab_boxes_first == 2 || (h->slab_boxes_first == 3 && nz >= 96)) && nb > 0 && !h->streams_shared && !h->debug_sync;
+    bool third = (h->slab_boxes_first == 2 || (h->slab_boxes_first == 3 && nz >= 96)) && nb > 0 && !h->streams_shared && !h->debug_sync;
+    if (third && !h->box_stream_tried && make_box_stream(h)) return -1;
+    third = third && h->box_stream != nullptr;
     if (third) {
-      if (!h->box_stream) {
-        HIPCHK(h, hipStreamCreateWithFlags(&h->box_stream, hipStreamNonBlocking));
-        HIPCHK(h, hipEventCreateWithFlags(&h->ev_box, hipEventDisableTiming));
-        HIPCHK(h, hipEventCreateWithFlags(&h->ev_box_in, hipEventDisableTiming));
-      }
       HIPCHK(h, hipEventRecord(h->ev_box_in, st));                            // (everything st has issued: the last pair's interior)
       HIPCHK(h, hipStreamWaitEvent(h->box_stream, h->ev_box_in, 0));
       HIPCHK(h, hipStreamWaitEvent(h->box_stream, h->ev_e_bnd, 0));
