@@ -187,7 +187,8 @@ def test_rccl_self_exchange_matches_ghost_copy(hip_lib):
 
 
 @pytest.mark.parametrize("schedule", ["cpml_three_launches", "shell_pairs_r4", "shell2_pairs", "slab_rank_fused", "slab_rank_fused_pml_in_sweep",
-                                      "slab_rank_pairs", "slab_rank_cpml_pairs", "slab_rank_two_pass"])
+                                      "slab_rank_pairs", "slab_rank_cpml_pairs", "slab_rank_cpml_pairs_boxes_behind", "slab_rank_cpml_pairs_boxes_in_front",
+                                      "slab_rank_cpml_pairs_boxes_third_stream", "slab_rank_two_pass"])
 def test_schedules_do_not_depend_on_stream_timing(schedule, hip_lib):
     """every schedule that splits a step between the two streams, run normally (three times: a race shows as
     run-to-run differences too) and with FDTD_OPT_DEBUG_SYNC — a device-wide synchronisation in front of and behind every launch
@@ -195,6 +196,11 @@ def test_schedules_do_not_depend_on_stream_timing(schedule, hip_lib):
     fuzz found were of that kind) gives different bits in the two modes; here: the same, fields and records."""
     from cases import pipelined_slab_case
     opts, comm = {}, False
+    # (round 6: where the shell's boxes of a CPML slab-rank pair go — FDTD_OPT_SLAB_BOXES_FIRST 0 / 1 / 2; the default takes the third stream
+    #  on this slab of 132 planes.  Under FDTD_OPT_DEBUG_SYNC the boxes stay on the main stream.)
+    boxes = {"slab_rank_cpml_pairs_boxes_behind": 0, "slab_rank_cpml_pairs_boxes_in_front": 1, "slab_rank_cpml_pairs_boxes_third_stream": 2}.get(schedule)
+    if boxes is not None:
+        schedule = "slab_rank_cpml_pairs"
     if schedule in ("cpml_three_launches", "shell_pairs_r4", "shell2_pairs"):
         N = (96, 72, 64)
         size = tuple(n * DL for n in N)
@@ -227,6 +233,8 @@ def test_schedules_do_not_depend_on_stream_timing(schedule, hip_lib):
         opts = {"slab_rank_fused": {}, "slab_rank_fused_pml_in_sweep": {L.OPT_PML_FUSED: 7, L.OPT_BND_PLANES: 3},
                 "slab_rank_pairs": {L.OPT_TWOSTEP: 8 + 64 * 8}, "slab_rank_cpml_pairs": {L.OPT_TWOSTEP: 8 + 64 * 8, L.OPT_PML_FUSED: 7},
                 "slab_rank_two_pass": {}}[schedule]
+        if boxes is not None:
+            opts[L.OPT_SLAB_BOXES_FIRST] = boxes
 
     def run(debug_sync):
         kw = dict(force_comm=True) if comm else dict(axis_shift=0)
