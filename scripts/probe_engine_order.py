@@ -31,21 +31,26 @@ def run_seq(names):
             dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
             x = torch.ones(1024, device="cuda"); dist.all_reduce(x); dist.barrier(); torch.cuda.synchronize()
             continue
-        kind, nz = nm[0], int(nm[1:])                 # c: looped-back slab rank (periodic z, RCCL), p: the same slab without a communicator, v: 512^3-like cube
-        sp = probe_slab.spec_for(512, nz, 400, 0)
+        kind, nz = nm[0], int(nm[1:])                 # c: looped-back slab rank (periodic z, RCCL), p: the same slab without a communicator, v: 512^3-like cube,
+        #                                               q: looped-back slab rank that carries CPML on x / y ($BOXES: FDTD_OPT_SLAB_BOXES_FIRST)
+        sp = probe_slab.spec_for(512, nz, 400, 2 if kind == "q" else 0)
         if kind == "v":                                # the headline's walls
             import dataclasses
             from tidy3d_amd.spec import BC_PEC
             sp = dataclasses.replace(sp, bc=(sp.bc[0], sp.bc[1], (BC_PEC, BC_PEC)))
         kw = dict(variant=L.VARIANT_FUSED)
-        if kind == "c":
+        if kind in "cq":
             kw["force_comm"] = True
         with HipEngine(sp, **kw) as e:
-            if kind == "c":
+            if kind in "cq":
                 e.comm_init(e.unique_id())
+            if kind == "q":
+                e.set_option(L.OPT_PML_FUSED, 7)
+                if os.environ.get("BOXES"):
+                    e.set_option(L.OPT_SLAB_BOXES_FIRST, int(os.environ["BOXES"]))
             rng = np.random.default_rng(0)
             for c in range(6):
-                e.set_field(c, rng.uniform(-1e-3, 1e-3, (nz, 512, 512)).astype(np.float32))
+                e.set_field(c, rng.uniform(-1e-3, 1e-3, tuple(reversed(sp.shape))).astype(np.float32))
             e.run(30)
             best = 1e9
             for _ in range(3):
@@ -53,7 +58,7 @@ def run_seq(names):
                 st = e.run(100)
                 best = min(best, (time.perf_counter() - t0) / 100 * 1e3)
             out = {"sequence": ",".join(names), "last": nm, "ms_per_step": best, "pairs": int(st.fused2_pairs), "stream_overlap": int(st.stream_overlap),
-                   "stream_retries": int(st.stream_retries), "placement": [int(st.placement) >> 8, int(st.placement) & 255]}
+                   "stream_retries": int(st.stream_retries), "boxes": os.environ.get("BOXES", ""), "shell2_pairs": int(st.shell2_pairs), "placement": [int(st.placement) >> 8, int(st.placement) & 255]}
     print(json.dumps(out), flush=True)
 
 
