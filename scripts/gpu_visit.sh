@@ -73,7 +73,7 @@ PY
     slab)
       # (a process per slab: engines created after an engine that held an RCCL communicator run 10 - 100 % slower, profiles/r6/r6ord_*)
       : > $O/slab.jsonl
-      for N in 8 4 2; do timeout 300 python scripts/probe_slab.py --slabs $N --modes comm_fused --twostep 0,-1 --ref512 $((N == 8)) >> $O/slab.jsonl 2>> $O/slab.err; done
+      for N in 8 4 2; do timeout 300 python scripts/probe_slab.py --slabs $N --modes comm_fused --twostep 0,-1 --ref512 $((N == 8)) 2>> $O/slab.err | grep "^{" >> $O/slab.jsonl; done
       cut -c1-200 $O/slab.jsonl;;
     mie)
       RUN_PERIODS=400 NFREQ=25 timeout 900 python scripts/probe_mie_refinement.py 20 30 40 > $O/mie_converged_25f.jsonl 2> $O/mie.err; cut -c1-160 $O/mie_converged_25f.jsonl;;
