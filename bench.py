@@ -544,6 +544,13 @@ def main():
     if eng is not None:
         eng.close()
     if rank == 0:
+        # (RCCL's version banner — the GPU boxes export NCCL_DEBUG=VERSION — sits in the C library's stdout buffer since the communicators
+        #  were made and would come out at exit, BEHIND the line: push it out first, so that the JSON line is the last one this rank prints)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
