@@ -188,8 +188,14 @@ void run_grid(dim3 grid, dim3 block, size_t shmem, std::function<void()> body) {
 struct hipemuStream { int id; };
 struct hipemuEvent { std::chrono::steady_clock::time_point t; };
 
+// $HIPEMU_POISON: device memory is handed out filled with that byte (0xFF: NaN floats, -1 indices) — a kernel that reads what nobody wrote
+// shows at once (on the device a fresh allocation is often zero, and a block recycled from an earlier engine of the process is not)
 hipError_t hipMalloc(void** p, size_t bytes) {
   *p = std::malloc(bytes ? bytes : 1);
+  if (*p) {
+    static const char* poison = std::getenv("HIPEMU_POISON");
+    if (poison) std::memset(*p, (int)std::strtol(poison, nullptr, 0), bytes ? bytes : 1);
+  }
   return *p ? hipSuccess : hipErrorOutOfMemory;
 }
 hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }

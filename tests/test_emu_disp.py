@@ -172,6 +172,27 @@ def test_dispersive_cells_deep_inside_the_bulk_of_shell2_pairs(N, w, zc, shell2,
     same(ref, got)
 
 
+@pytest.mark.parametrize("N,w,zc", [((48, 26, 24), 5, 3), ((300, 24, 22), 6, 4)])
+def test_dispersive_cells_on_the_first_planes_and_rows_of_the_bulk(N, w, zc, emu_lib):
+    """A Lorentz block whose lowest plane is the bulk's FIRST plane (and whose first row is the bulk's first row): the shell's z-min / y-min
+    boxes read the memory terms of that plane / row for their halo, so ade2_kernel — which rewrites the paged terms — must wait for the
+    boxes instead of running beside them.  Found on the device by scripts/fuzz_round6.py (seed 31, case 124; one run in a few there — the
+    emulator runs the streams in issue order and showed it every time: 14,000 cells off by 5e-6 after 26 steps)."""
+    sy, sz = (N[1] - 1e-6) * DL, (N[2] - 1e-6) * DL
+    z0, y0 = -0.5 * sz + 1.75 * DL, -0.5 * sy + 1.75 * DL             # (the collar is two cells: nodes of plane / row 2 of the domain inside, 1 outside)
+    structures = [td.Structure(geometry=td.Box(center=(-0.2, 0.1, 0.5 * (z0 + 0.1)), size=(0.5, 0.3, 0.1 - z0)), medium=LOR),
+                  td.Structure(geometry=td.Box(center=(0.3, 0.5 * (y0 + 0.05), 0.1), size=(0.3, 0.05 - y0, 0.2)), medium=DRU)]
+    disc = discretize(sim_for(N, bspec=PML, structures=structures, inner=0.5), n_steps=26)
+    disc.spec.decay_every = 0
+    pol = np.array([len(m.poles) for m in disc.spec.media])
+    where = np.argwhere((pol[np.asarray(disc.spec.mat_idx)] > 0).any(axis=0))
+    assert where[:, 0].min() == 3 + 2 and where[:, 1].min() == 3 + 2, (where[:, 0].min(), where[:, 1].min())      # (3 layers + the collar)
+    ref = run(disc.spec, emu_lib, 0, shell2=1, seed=5)
+    got = run(disc.spec, emu_lib, w + 64 * zc, shell2=1, seed=5)
+    assert ref[2] == 0 and got[2] == 12 and got[3] == 12 and got[4] == 12, got[2:]
+    same(ref, got)
+
+
 @pytest.mark.parametrize("N,w,zc,bspec", [((48, 26, 40), 5, 3, PML), ((300, 24, 22), 6, 4, PML), ((100, 23, 19), 8, 5, "periodic_x"),
                                           ((48, 26, 24), 16, 32, "odd")])
 def test_dispersive_cells_inside_the_layers(N, w, zc, bspec, emu_lib):

@@ -2349,7 +2349,7 @@ bool disp_inside(const FdtdSolver* h, const int lo[3], const int hi[3], int marg
   const Disp& D = h->disp;
   if (D.state != 1) return false;
   for (int a = 0; a < 3; ++a) {
-    const int m = a == 0 ? std::max(4, margin) : margin;
+    const int m = a == 0 ? std::max(margin ? 8 : 4, margin) : margin;       // (x: whole float4 lanes; the boxes' halo lanes reach 8 columns)
     if (D.lo[a] < lo[a] + m || D.hi[a] > hi[a] - m) return false;
   }
   return true;
@@ -3949,7 +3949,11 @@ struct Run {
     // beside the shell's boxes, once nothing else is due on E^{n+2} there — else at the end, behind the sources of step n + 1
     bool src_due = false;
     for (const PointSrc& sr : h->psrc) src_due = src_due || (sr.n_e && n + 1 < sr.n_steps);
-    const bool ade2_early = pair_disp && (s2 || !src_due) && disp_inside(h, sg.o0, sg.o1, 0);
+    // (clear of the bulk's faces by what the boxes read beyond their own cells — a plane, two rows, a halo lane: ade2_kernel REWRITES the
+    //  paged memory terms, and a box that has not yet read those of its halo plane would subtract the next pair's.  Found on the device by
+    //  scripts/fuzz_round6.py in the round's last hour (seed 31, case 124: a Lorentz body whose lowest plane is the bulk's first one — one run
+    //  in a few; the emulator, which runs the streams in issue order, shows it every time: tests/test_emu_disp.py).)
+    const bool ade2_early = pair_disp && (s2 || !src_due) && disp_inside(h, sg.o0, sg.o1, 2);
     if (ade2_early) launch_ade2(h, st, &B);
     launch_shell2_boxes(h, boxes, nb, h->pml_blk2[hp][ep], cs, tb, pair_disp, sr);
     if (holes || per_y) {
